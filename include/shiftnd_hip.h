@@ -1,0 +1,144 @@
+/*
+ * shiftnd_hip.h -- C ABI of the MI355X-native shiftnd library (libshiftnd_hip.so).
+ *
+ * This is the drop-in boundary of the hot path: plain pointers, sizes and strides, no torch types.
+ * Each entry point replaces one backend function of the reference
+ * (DeadAt0m/ActiveSparseShifts-PyTorch, paths relative to torchshifts/csrc/ops/):
+ *
+ *   shiftnd_forward            <- shiftnd_forward<nD,pad,active>   cuda/shifts_cuda.cu:202-266
+ *                                 (== cpu/shifts_cpu.cpp:216-232), i.e. the backend behind
+ *                                 torchshifts::_shift{1,2,3}d_forward (shifts.cpp:168-181)
+ *   shiftnd_backward           <- shiftnd_backward<nD,pad,active>  cuda/shifts_cuda.cu:270-345
+ *                                 (== cpu/shifts_cpu.cpp:237-255), behind
+ *                                 torchshifts::_shift{1,2,3}d_backward
+ *   shiftnd_forward_quantized  <- qshiftnd<nD,pad>                 quantized/shifts_quantized.cpp:107-130
+ *                                 (the reference has no GPU quantized path; this is new)
+ *   shiftnd_check_borders      <- check_borders                    shifts.cpp:93-135 (host only)
+ *
+ * Conventions
+ *   - Tensors are described the way the reference's kernels see them: sizes[5] = {N, C, H, W, D}
+ *     of the INPUT (unused trailing spatial dims = 1) and element strides[5] in the same order
+ *     (unused = 0).  ndim = number of spatial dims (1..3).
+ *   - weights: device pointer to a contiguous [C, ndim] array of the input's dtype
+ *     (column s shifts spatial dim s: H, W, D -- functional.py:76-77).
+ *   - borders: 6 HOST ints {l_i, r_i, l_j, r_j, l_k, r_k}, the absolute [l, r) window that
+ *     check_borders produces; the output has spatial sizes r - l.
+ *   - padding_mode: 0 zeros, 1 border, 2 periodic, 3 reflect, 4 symmetric
+ *     (BIPadding, kernels/shifts_kernels.h:5).
+ *   - All device pointers must belong to the device that is current on the calling thread;
+ *     `stream` is a hipStream_t (NULL = default stream).  Calls only enqueue work: no host
+ *     synchronisation, no allocation (graph-capture safe).
+ *   - Every function returns SHIFTND_OK (0) or a negative shiftnd_status; nothing is thrown.
+ *   - Numerics contract: SSL forward / SSL input-grad / quantized are pure
+ *     gathers and bit-exact; interpolation is evaluated as v1*(1-x)+v2*x with separate multiply
+ *     and add (no FMA contraction) in fp32 (fp64 for fp64 tensors), 16-bit inputs are widened to
+ *     fp32 and rounded once (RNE) on store; the weight gradient is accumulated in fp64 by a
+ *     deterministic two-stage reduction and rounded once to the tensor dtype.
+ */
+#ifndef SHIFTND_HIP_H_
+#define SHIFTND_HIP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SHIFTND_ABI_VERSION 1
+
+typedef enum shiftnd_dtype {
+    SHIFTND_F32 = 0,
+    SHIFTND_F64 = 1,
+    SHIFTND_F16 = 2,
+    SHIFTND_BF16 = 3,
+    SHIFTND_I8 = 4,  /* qint8  int_repr */
+    SHIFTND_U8 = 5,  /* quint8 int_repr */
+    SHIFTND_I32 = 6  /* qint32 int_repr */
+} shiftnd_dtype;
+
+typedef enum shiftnd_status {
+    SHIFTND_OK = 0,
+    SHIFTND_ERR_INVALID_ARGUMENT = -1,
+    SHIFTND_ERR_UNSUPPORTED_DTYPE = -2,
+    SHIFTND_ERR_WORKSPACE_TOO_SMALL = -3,
+    SHIFTND_ERR_LAUNCH_FAILED = -4,
+    SHIFTND_ERR_TOO_LARGE = -5
+} shiftnd_status;
+
+/* Which kernel family served the last call made on this host thread (for tests/benchmarks). */
+typedef enum shiftnd_path {
+    SHIFTND_PATH_NONE = 0,
+    SHIFTND_PATH_EMPTY = 1,   /* zero-element problem: nothing launched */
+    SHIFTND_PATH_PLANE = 2,   /* per-(N,C)-plane kernels, LDS index maps, 16-byte rows */
+    SHIFTND_PATH_STRIDED = 3  /* generic strided fallback (channels-last, ragged rows, huge dims) */
+} shiftnd_path;
+
+/* Problem geometry shared by the entry points. */
+typedef struct shiftnd_problem {
+    int32_t ndim;          /* spatial dims: 1, 2 or 3 */
+    int32_t dtype;         /* shiftnd_dtype of input/output (and of float weights) */
+    int32_t padding_mode;  /* 0..4 */
+    int32_t active;        /* 0: sparse shift (rounded integer shift); 1: active (interpolated) */
+    int64_t sizes[5];      /* input N, C, H, W, D */
+    int32_t borders[6];    /* l_i, r_i, l_j, r_j, l_k, r_k (unused dims: 0, 1) */
+} shiftnd_problem;
+
+int shiftnd_abi_version(void);
+const char *shiftnd_status_string(int status);
+int shiftnd_last_path(void);
+/* 0 = automatic, 1 = force the strided fallback (testing), 2 = force plane kernels or fail. */
+void shiftnd_set_path_policy(int policy);
+
+/*
+ * Host helper: the reference's check_borders (shifts.cpp:93-135).
+ * sizes/nsizes: full tensor shape; user: ndim x 2 cut amounts (left, right) or NULL for no crop.
+ * Writes borders[6] and new_sizes[nsizes].
+ */
+int shiftnd_check_borders(const int64_t *sizes, int nsizes, const int32_t *user, int ndim,
+                          int32_t borders[6], int64_t *new_sizes);
+
+/*
+ * Forward, float dtypes (F32, F64, F16, BF16).
+ * out has sizes {N, C, r_i-l_i, r_j-l_j, r_k-l_k}; out_strides are its element strides.
+ */
+int shiftnd_forward(const shiftnd_problem *p,
+                    const void *x, const int64_t x_strides[5],
+                    const void *weights,
+                    void *out, const int64_t out_strides[5],
+                    void *stream);
+
+/*
+ * Backward, float dtypes.  grad_out has the forward output's sizes; grad_x the input's sizes;
+ * grad_w is a contiguous [C, ndim] array of the tensor dtype and is fully overwritten.
+ * workspace: device scratch of at least shiftnd_backward_workspace_bytes(p) bytes
+ * (fp64 partial sums of the weight gradient); its contents need not be initialised.
+ */
+size_t shiftnd_backward_workspace_bytes(const shiftnd_problem *p);
+
+int shiftnd_backward(const shiftnd_problem *p,
+                     const void *grad_out, const int64_t grad_out_strides[5],
+                     const void *x, const int64_t x_strides[5],
+                     const void *weights,
+                     void *grad_x, const int64_t grad_x_strides[5],
+                     void *grad_w,
+                     void *workspace, size_t workspace_bytes,
+                     void *stream);
+
+/*
+ * Quantized forward (dtype I8, U8 or I32 = int_repr of the quantized input; p->active ignored).
+ * wq: device pointer to the contiguous [C, ndim] int_repr of the quantized weights, of type
+ * wq_dtype (I8, U8 or I32); shift = wq - w_zero_point; scale is ignored
+ * (kernels/shifts_kernels.h:553-555).  x_zero_point is the fill value (:569).
+ */
+int shiftnd_forward_quantized(const shiftnd_problem *p,
+                              const void *x, const int64_t x_strides[5],
+                              const void *wq, int32_t wq_dtype, int64_t w_zero_point,
+                              int64_t x_zero_point,
+                              void *out, const int64_t out_strides[5],
+                              void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SHIFTND_HIP_H_ */

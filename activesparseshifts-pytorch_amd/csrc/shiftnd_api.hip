@@ -1,0 +1,208 @@
+// shiftnd_api.hip -- the C ABI declared in include/shiftnd_hip.h: argument validation, geometry
+// normalisation and kernel-family selection.  No torch types, no allocation, no synchronisation.
+#include <string.h>
+
+#include "shiftnd_common.hpp"
+#include "shiftnd_launch.hpp"
+
+using namespace shiftnd;
+
+namespace {
+
+thread_local int g_last_path = SHIFTND_PATH_NONE;
+int g_policy = 0;  // 0 auto, 1 force strided, 2 require plane kernels
+
+bool is_float_dtype(int dt) { return dt >= SHIFTND_F32 && dt <= SHIFTND_BF16; }
+bool is_quant_dtype(int dt) { return dt >= SHIFTND_I8 && dt <= SHIFTND_I32; }
+
+// Build the normalised 3-dim geometry: real spatial dim r (0..nd-1 = H, W, D) becomes normalised
+// dim r + 3 - nd, so the innermost (contiguous) dim is always index 2 and leading dims have size 1.
+int build_geometry(const shiftnd_problem *p, const int64_t *xs, const int64_t *os, const int64_t *gs, Geometry &g) {
+    if (!p || p->ndim < 1 || p->ndim > 3 || p->padding_mode < 0 || p->padding_mode > 4) return SHIFTND_ERR_INVALID_ARGUMENT;
+    memset(&g, 0, sizeof(g));
+    g.nd = p->ndim;
+    g.pad = p->padding_mode;
+    g.active = p->active ? 1 : 0;
+    g.N = p->sizes[0];
+    g.C = p->sizes[1];
+    if (g.N < 0 || g.C < 0) return SHIFTND_ERR_INVALID_ARGUMENT;
+    const int lead = 3 - p->ndim;
+    for (int d = 0; d < 3; ++d) {
+        g.S[d] = 1;
+        g.O[d] = 1;
+        g.L[d] = 0;
+        g.wcol[d] = -1;
+    }
+    g.xs[0] = xs[0];
+    g.xs[1] = xs[1];
+    g.os[0] = os[0];
+    g.os[1] = os[1];
+    if (gs) {
+        g.gs[0] = gs[0];
+        g.gs[1] = gs[1];
+    }
+    for (int r = 0; r < p->ndim; ++r) {
+        const int d = r + lead;
+        const int64_t size = p->sizes[2 + r];
+        const int64_t l = p->borders[2 * r], rr = p->borders[2 * r + 1];
+        if (size < 0) return SHIFTND_ERR_INVALID_ARGUMENT;
+        if (size > 0 && (l < 0 || rr > size || rr <= l)) return SHIFTND_ERR_INVALID_ARGUMENT;
+        g.S[d] = size;
+        g.L[d] = l;
+        g.O[d] = size > 0 ? rr - l : 0;
+        g.wcol[d] = r;
+        g.xs[2 + d] = xs[2 + r];
+        g.os[2 + d] = os[2 + r];
+        if (gs) g.gs[2 + d] = gs[2 + r];
+    }
+    return SHIFTND_OK;
+}
+
+bool empty_problem(const Geometry &g) {
+    return g.N == 0 || g.C == 0 || g.S[0] * g.S[1] * g.S[2] == 0 || g.O[0] * g.O[1] * g.O[2] == 0;
+}
+
+int finish(int rc) {
+    if (rc != SHIFTND_OK) return rc;
+    return hipGetLastError() == hipSuccess ? SHIFTND_OK : SHIFTND_ERR_LAUNCH_FAILED;
+}
+
+int forward_common(const shiftnd_problem *p, const void *x, const int64_t *xs, const void *w, int wkind, int64_t wzp,
+                   uint64_t fill, void *out, const int64_t *os, void *stream) {
+    Geometry g;
+    const int rc = build_geometry(p, xs, os, nullptr, g);
+    if (rc != SHIFTND_OK) return rc;
+    if (empty_problem(g)) {
+        g_last_path = SHIFTND_PATH_EMPTY;
+        return SHIFTND_OK;
+    }
+    if (!x || !w || !out) return SHIFTND_ERR_INVALID_ARGUMENT;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const bool can_plane = plane_forward_eligible(g, p->dtype, x, out);
+    if (g_policy == 2 && !can_plane) return SHIFTND_ERR_INVALID_ARGUMENT;
+    if (can_plane && g_policy != 1) {
+        g_last_path = SHIFTND_PATH_PLANE;
+        return finish(plane_forward(g, p->dtype, x, w, wkind, wzp, fill, out, st));
+    }
+    g_last_path = SHIFTND_PATH_STRIDED;
+    return finish(strided_forward(g, p->dtype, x, w, wkind, wzp, fill, out, st));
+}
+
+}  // namespace
+
+extern "C" {
+
+int shiftnd_abi_version(void) { return SHIFTND_ABI_VERSION; }
+
+const char *shiftnd_status_string(int status) {
+    switch (status) {
+    case SHIFTND_OK: return "ok";
+    case SHIFTND_ERR_INVALID_ARGUMENT: return "invalid argument";
+    case SHIFTND_ERR_UNSUPPORTED_DTYPE: return "unsupported dtype";
+    case SHIFTND_ERR_WORKSPACE_TOO_SMALL: return "workspace too small";
+    case SHIFTND_ERR_LAUNCH_FAILED: return "kernel launch failed";
+    case SHIFTND_ERR_TOO_LARGE: return "problem too large";
+    default: return "unknown status";
+    }
+}
+
+int shiftnd_last_path(void) { return g_last_path; }
+
+void shiftnd_set_path_policy(int policy) { g_policy = policy; }
+
+// check_borders, ops/shifts.cpp:93-135 (host arithmetic only)
+int shiftnd_check_borders(const int64_t *sizes, int nsizes, const int32_t *user, int ndim, int32_t borders[6],
+                          int64_t *new_sizes) {
+    if (!sizes || !borders || !new_sizes || ndim < 1 || nsizes < ndim + 1) return SHIFTND_ERR_INVALID_ARGUMENT;
+    const int shift = ((ndim + 1) == nsizes) ? 1 : 2;
+    const int hdim = 3;
+    const int dims = ndim < hdim ? ndim : hdim;
+    if (shift + dims > nsizes) return SHIFTND_ERR_INVALID_ARGUMENT;
+    for (int i = 0; i < hdim; ++i) {
+        borders[2 * i] = 0;
+        borders[2 * i + 1] = (i + 1 > ndim) ? 1 : static_cast<int32_t>(sizes[i + shift]);
+    }
+    if (user) {
+        for (int i = 0; i < dims; ++i) {
+            const int32_t size = static_cast<int32_t>(sizes[i + shift]);
+            int32_t l = user[2 * i];
+            int32_t r = borders[2 * i + 1] - user[2 * i + 1];
+            if (r - l < 1) r = l + 1;          // degenerate window -> one element wide
+            if (l == size) { l = size - 1; r = l + 1; }
+            if (r == 0) { l = 0; r = 1; }
+            if (l < 0) l = 0;
+            if (r > size) r = size;
+            borders[2 * i] = l;
+            borders[2 * i + 1] = r;
+        }
+    }
+    for (int i = 0; i < shift; ++i) new_sizes[i] = sizes[i];
+    for (int i = 0; i < dims; ++i) new_sizes[i + shift] = static_cast<int64_t>(borders[2 * i + 1] - borders[2 * i]);
+    return SHIFTND_OK;
+}
+
+int shiftnd_forward(const shiftnd_problem *p, const void *x, const int64_t x_strides[5], const void *weights, void *out,
+                    const int64_t out_strides[5], void *stream) {
+    if (!p || !x_strides || !out_strides) return SHIFTND_ERR_INVALID_ARGUMENT;
+    if (!is_float_dtype(p->dtype)) return SHIFTND_ERR_UNSUPPORTED_DTYPE;
+    return forward_common(p, x, x_strides, weights, p->dtype, 0, 0ull, out, out_strides, stream);
+}
+
+int shiftnd_forward_quantized(const shiftnd_problem *p, const void *x, const int64_t x_strides[5], const void *wq,
+                              int32_t wq_dtype, int64_t w_zero_point, int64_t x_zero_point, void *out,
+                              const int64_t out_strides[5], void *stream) {
+    if (!p || !x_strides || !out_strides) return SHIFTND_ERR_INVALID_ARGUMENT;
+    if (!is_quant_dtype(p->dtype) || !is_quant_dtype(wq_dtype)) return SHIFTND_ERR_UNSUPPORTED_DTYPE;
+    shiftnd_problem q = *p;
+    q.active = 0;
+    // fill value = input zero point, as the element type's bit pattern
+    uint64_t fill = 0;
+    if (p->dtype == SHIFTND_I8) fill = static_cast<uint8_t>(static_cast<int8_t>(x_zero_point));
+    else if (p->dtype == SHIFTND_U8) fill = static_cast<uint8_t>(x_zero_point);
+    else fill = static_cast<uint32_t>(static_cast<int32_t>(x_zero_point));
+    return forward_common(&q, x, x_strides, wq, wq_dtype, w_zero_point, fill, out, out_strides, stream);
+}
+
+size_t shiftnd_backward_workspace_bytes(const shiftnd_problem *p) {
+    if (!p || p->ndim < 1 || p->ndim > 3) return 0;
+    // upper bound valid for both kernel families: one fp64 triple per (n, c) plane, and per row band
+    // when large planes are split (never more than max(N*C, 4096) groups, see make_plan)
+    const int64_t planes = (p->sizes[0] > 0 ? p->sizes[0] : 1) * (p->sizes[1] > 0 ? p->sizes[1] : 1);
+    const int64_t c = p->sizes[1] > 0 ? p->sizes[1] : 1;
+    int64_t groups = planes;
+    const int64_t banded = 4096 + 2 * c;  // bands are only used while C*groups*bands stays near 2048
+    if (groups < banded) groups = banded;
+    return static_cast<size_t>(groups) * 3 * sizeof(double);
+}
+
+int shiftnd_backward(const shiftnd_problem *p, const void *grad_out, const int64_t grad_out_strides[5], const void *x,
+                     const int64_t x_strides[5], const void *weights, void *grad_x, const int64_t grad_x_strides[5],
+                     void *grad_w, void *workspace, size_t workspace_bytes, void *stream) {
+    if (!p || !grad_out_strides || !x_strides || !grad_x_strides) return SHIFTND_ERR_INVALID_ARGUMENT;
+    if (!is_float_dtype(p->dtype)) return SHIFTND_ERR_UNSUPPORTED_DTYPE;
+    Geometry g;
+    const int rc = build_geometry(p, x_strides, grad_out_strides, grad_x_strides, g);
+    if (rc != SHIFTND_OK) return rc;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (g.N == 0 || g.C == 0 || g.S[0] * g.S[1] * g.S[2] == 0) {
+        // nothing to differentiate; grad_w (if any channels) is all zeros (zeros_like, shifts_cpu.cpp:247)
+        g_last_path = SHIFTND_PATH_EMPTY;
+        if (g.C > 0 && grad_w)
+            if (hipMemsetAsync(grad_w, 0, static_cast<size_t>(g.C) * g.nd * dtype_size(p->dtype), st) != hipSuccess)
+                return SHIFTND_ERR_LAUNCH_FAILED;
+        return SHIFTND_OK;
+    }
+    if (!grad_out || !x || !weights || !grad_x || !grad_w || !workspace) return SHIFTND_ERR_INVALID_ARGUMENT;
+    const bool can_plane = plane_backward_eligible(g, p->dtype, grad_out, x, grad_x);
+    if (g_policy == 2 && !can_plane) return SHIFTND_ERR_INVALID_ARGUMENT;
+    if (can_plane && g_policy != 1) {
+        if (plane_backward_workspace(g, p->dtype) > workspace_bytes) return SHIFTND_ERR_WORKSPACE_TOO_SMALL;
+        g_last_path = SHIFTND_PATH_PLANE;
+        return finish(plane_backward(g, p->dtype, grad_out, x, weights, grad_x, grad_w, workspace, st));
+    }
+    if (strided_backward_workspace(g) > workspace_bytes) return SHIFTND_ERR_WORKSPACE_TOO_SMALL;
+    g_last_path = SHIFTND_PATH_STRIDED;
+    return finish(strided_backward(g, p->dtype, grad_out, x, weights, grad_x, grad_w, workspace, st));
+}
+
+}  // extern "C"

@@ -1,0 +1,215 @@
+// shiftnd_common.hpp -- shared device/host helpers of the MI355X shiftnd kernels (gfx950 only).
+//
+// Semantics follow the reference's per-element math (torchshifts/csrc/ops/kernels/shifts_kernels.h,
+// interpolation.h); the structure (per-plane workgroups, LDS index maps, 16-byte row chunks,
+// fp64 two-stage weight-gradient reduction) is native to this library.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "shiftnd_hip.h"
+
+namespace shiftnd {
+
+constexpr int kThreads = 256;        // workgroup size of every kernel (4 waves of 64)
+constexpr int kMaxMapEntries = 12288; // LDS budget for index maps (48 KiB of int32)
+
+// ---------------------------------------------------------------------------------------------
+// Element types.  Storage type S (what lives in HBM), compute type C (what interpolation uses).
+// ---------------------------------------------------------------------------------------------
+struct f32_t { using S = float;    using C = float;  };
+struct f64_t { using S = double;   using C = double; };
+struct f16_t { using S = _Float16; using C = float;  };
+struct bf16_t { using S = __bf16;  using C = float;  };
+
+template <typename T> __device__ __forceinline__ typename T::C widen(typename T::S v) {
+    return static_cast<typename T::C>(v);
+}
+// one rounding (RNE) from the compute type to the storage type
+template <typename T> __device__ __forceinline__ typename T::S narrow(typename T::C v) {
+    return static_cast<typename T::S>(v);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Division by a launch-invariant 32-bit divisor (n < 2^31): q = (umulhi(n, mul) + n) >> shift.
+// ---------------------------------------------------------------------------------------------
+struct FastDiv {
+    uint32_t d, mul, shift;
+};
+inline FastDiv make_fastdiv(uint32_t d) {
+    FastDiv f;
+    f.d = d ? d : 1;
+    uint32_t s = 0;
+    while (s < 32 && (1ull << s) < f.d) ++s;
+    f.shift = s;
+    f.mul = static_cast<uint32_t>(((1ull << 32) * ((1ull << s) - f.d)) / f.d + 1);
+    return f;
+}
+__device__ __forceinline__ uint32_t fdiv(uint32_t n, const FastDiv &f) {
+    return (__umulhi(n, f.mul) + n) >> f.shift;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Padding index map: infer_index (shifts_kernels.h:10-29) + the `tidx >= 0` validity test of
+// get_shifted_value (:40-41): returns the source index in [0, len) or -1 for "use the fill value".
+// 64-bit so that arbitrarily large shifts (multi-wrap) stay exact.  len == 1 is handled by the
+// callers (size-1 dims ignore the shift, :40).
+// ---------------------------------------------------------------------------------------------
+__host__ __device__ __forceinline__ int64_t pmod(int64_t a, int64_t b) { return (b + (a % b)) % b; }
+
+__host__ __device__ inline int64_t pad_index(int64_t idx, int64_t len, int pad) {
+    int64_t r;
+    switch (pad) {
+    case 1:  // border
+        r = idx < 0 ? 0 : (idx > len - 1 ? len - 1 : idx);
+        break;
+    case 2:  // periodic
+        r = pmod(idx, len);
+        break;
+    case 3: {  // reflect, period 2*(len-1)
+        const int64_t neg = idx < 0 ? 1 : 0;
+        const int64_t a = idx < 0 ? -idx : idx;
+        const bool odd = ((neg + (a - neg) / (len - 1)) & 1) != 0;
+        const int64_t m = pmod(idx, len - 1);
+        r = odd ? (len - 1 - m) : m;
+        break;
+    }
+    case 4: {  // symmetric, period 2*len
+        const int64_t neg = idx < 0 ? 1 : 0;
+        const int64_t a = idx < 0 ? -idx : idx;
+        const bool odd = ((neg + (a - neg) / len) & 1) != 0;
+        const int64_t m = pmod(idx, len);
+        r = odd ? (len - 1 - m) : m;
+        break;
+    }
+    default:  // zeros: idx > len-1 -> fill; negatives are rejected by the >= 0 test
+        r = (idx > len - 1) ? -1 : idx;
+        break;
+    }
+    return r < 0 ? -1 : r;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Per-channel shift preparation (cpu/shifts_cpu.cpp:223-224 forward, :242-244 backward).
+// Rounding is half-to-even (torch::round on the CPU path), i.e. rint in the default mode.
+// ---------------------------------------------------------------------------------------------
+template <typename CT> __device__ __forceinline__ CT c_floor(CT v);
+template <> __device__ __forceinline__ float c_floor<float>(float v) { return floorf(v); }
+template <> __device__ __forceinline__ double c_floor<double>(double v) { return floor(v); }
+template <typename CT> __device__ __forceinline__ CT c_ceil(CT v);
+template <> __device__ __forceinline__ float c_ceil<float>(float v) { return ceilf(v); }
+template <> __device__ __forceinline__ double c_ceil<double>(double v) { return ceil(v); }
+template <typename CT> __device__ __forceinline__ CT c_rint(CT v);
+template <> __device__ __forceinline__ float c_rint<float>(float v) { return rintf(v); }
+template <> __device__ __forceinline__ double c_rint<double>(double v) { return rint(v); }
+
+template <typename CT>
+__device__ __forceinline__ void prep_shift_forward(CT w, bool active, int64_t &iw, CT &dw) {
+    const CT r = active ? c_floor<CT>(w) : c_rint<CT>(w);
+    iw = static_cast<int64_t>(r);
+    dw = active ? (w - static_cast<CT>(iw)) : CT(0);
+}
+template <typename CT>
+__device__ __forceinline__ void prep_shift_backward(CT w, bool active, int64_t &iw, CT &dw) {
+    dw = active ? (w - c_floor<CT>(w)) : ((w > CT(0)) ? (w - c_floor<CT>(w)) : (c_ceil<CT>(w) - w));
+    const CT r = active ? (w - dw) : c_rint<CT>(w);
+    iw = static_cast<int64_t>(r);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Interpolation (kernels/interpolation.h:3-61).  The library is compiled with -ffp-contract=off so
+// v1*(1-x)+v2*x is two multiplies and one add, as in the reference's x86-64 CPU build.
+// Corner order (shifts_kernels.h:58-103): bit0 = +1 along H, bit1 = +1 along W, bit2 = +1 along D.
+// ---------------------------------------------------------------------------------------------
+template <typename CT> __device__ __forceinline__ CT lerp1(CT v1, CT v2, CT x) { return v1 * (CT(1) - x) + v2 * x; }
+
+template <int ND, typename CT> __device__ __forceinline__ CT interp_nd(const CT *v, const CT *d) {
+    if constexpr (ND == 1) {
+        return lerp1(v[0], v[1], d[0]);
+    } else if constexpr (ND == 2) {
+        return lerp1(lerp1(v[0], v[1], d[0]), lerp1(v[2], v[3], d[0]), d[1]);
+    } else {
+        const CT a = lerp1(lerp1(v[0], v[1], d[0]), lerp1(v[2], v[3], d[0]), d[1]);
+        const CT b = lerp1(lerp1(v[4], v[5], d[0]), lerp1(v[6], v[7], d[0]), d[1]);
+        return lerp1(a, b, d[2]);
+    }
+}
+
+// compute_weight_gradients (shifts_kernels.h:132-154), including the reference's 2-D "dx" wiring
+// (interpolation.h:22-25: a difference along W blended with dW is used as the H-shift gradient).
+template <int ND, typename CT> __device__ __forceinline__ void weight_grads_nd(const CT *v, const CT *d, CT *g) {
+    if constexpr (ND == 1) {
+        g[0] = v[1] - v[0];
+    } else if constexpr (ND == 2) {
+        g[0] = lerp1(v[2] - v[0], v[3] - v[1], d[1]);
+        g[1] = lerp1(v[2], v[3], d[0]) - lerp1(v[0], v[1], d[0]);
+    } else {
+        g[0] = lerp1(lerp1(v[2] - v[0], v[3] - v[1], d[1]), lerp1(v[6] - v[4], v[7] - v[5], d[1]), d[2]);
+        g[1] = lerp1(lerp1(v[2], v[3], d[0]) - lerp1(v[0], v[1], d[0]),
+                     lerp1(v[6], v[7], d[0]) - lerp1(v[4], v[5], d[0]), d[2]);
+        g[2] = lerp1(lerp1(v[4], v[5], d[0]), lerp1(v[6], v[7], d[0]), d[1]) -
+               lerp1(lerp1(v[0], v[1], d[0]), lerp1(v[2], v[3], d[0]), d[1]);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Workgroup-wide fp64 sum (deterministic: fixed shuffle tree, fixed wave order).
+// Returns the total in thread 0.  `scratch` needs kThreads/64 doubles of LDS.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    return v;
+}
+__device__ __forceinline__ double block_sum(double v, double *scratch) {
+    v = wave_sum(v);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    __syncthreads();
+    if (lane == 0) scratch[wave] = v;
+    __syncthreads();
+    double t = 0.0;
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int w = 0; w < kThreads / 64; ++w) t += scratch[w];
+    }
+    return t;
+}
+
+// Final stage of the weight-gradient reduction: grad_w[c, s] = sum over partial groups.
+// partials layout: [group][C][3] doubles.  (Unnamed namespace: one private copy per translation unit.)
+namespace {
+template <typename T>
+__global__ void reduce_weight_grads(const double *__restrict__ partials, int groups, int C, int nd,
+                                    typename T::S *__restrict__ grad_w) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= C * nd) return;
+    const int c = t / nd, s = t - c * nd;
+    double acc = 0.0;
+    for (int g = 0; g < groups; ++g) acc += partials[(static_cast<size_t>(g) * C + c) * 3 + s];
+    if constexpr (sizeof(typename T::S) == 8) {
+        grad_w[t] = acc;
+    } else {
+        grad_w[t] = narrow<T>(static_cast<float>(acc));
+    }
+}
+}  // namespace
+
+// ---------------------------------------------------------------------------------------------
+// Host-side problem description handed to the kernel families.
+// ---------------------------------------------------------------------------------------------
+struct Geometry {
+    int nd;
+    int pad;
+    int active;
+    int64_t N, C;
+    int64_t S[3];    // input spatial sizes, normalised to 3 dims (leading dims = 1): [d0][d1][inner]
+    int64_t O[3];    // output (forward) / grad_out (backward) spatial sizes
+    int64_t L[3];    // left borders
+    int64_t xs[5];   // element strides of x, in normalised order N, C, d0, d1, inner
+    int64_t os[5];   // element strides of out (forward) / grad_out (backward)
+    int64_t gs[5];   // backward: element strides of grad_x
+    int wcol[3];     // weight column of each normalised dim, or -1
+};
+
+}  // namespace shiftnd

@@ -1,0 +1,43 @@
+// shiftnd_launch.hpp -- host-side entry points of the two kernel families (internal).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "shiftnd_common.hpp"
+
+namespace shiftnd {
+
+inline int dtype_size(int dtype) {
+    switch (dtype) {
+    case SHIFTND_F32: return 4;
+    case SHIFTND_F64: return 8;
+    case SHIFTND_F16: return 2;
+    case SHIFTND_BF16: return 2;
+    case SHIFTND_I8: return 1;
+    case SHIFTND_U8: return 1;
+    case SHIFTND_I32: return 4;
+    default: return 0;
+    }
+}
+
+// ---- strided fallback (shiftnd_strided.hip) ------------------------------------------------------
+// wkind: dtype of the weights array (float dtypes -> rint / floor+frac; I8/U8/I32 -> repr - wzp).
+int strided_forward(const Geometry &g, int dtype, const void *x, const void *w, int wkind, int64_t wzp,
+                    uint64_t fill_bits, void *out, hipStream_t st);
+size_t strided_backward_workspace(const Geometry &g);
+int strided_backward(const Geometry &g, int dtype, const void *go, const void *x, const void *w, void *gx, void *gw,
+                     void *workspace, hipStream_t st);
+
+// ---- per-plane kernels (shiftnd_plane.hip) -------------------------------------------------------
+// *_eligible: contiguous NC[spatial] tensors, maps fit in LDS, planes < 2^31 elements, and (for the
+// interpolating kernels) rows made of whole 16-byte chunks.
+bool plane_forward_eligible(const Geometry &g, int dtype, const void *x, const void *out);
+int plane_forward(const Geometry &g, int dtype, const void *x, const void *w, int wkind, int64_t wzp,
+                  uint64_t fill_bits, void *out, hipStream_t st);
+bool plane_backward_eligible(const Geometry &g, int dtype, const void *go, const void *x, const void *gx);
+size_t plane_backward_workspace(const Geometry &g, int dtype);
+int plane_backward(const Geometry &g, int dtype, const void *go, const void *x, const void *w, void *gx, void *gw,
+                   void *workspace, hipStream_t st);
+
+}  // namespace shiftnd

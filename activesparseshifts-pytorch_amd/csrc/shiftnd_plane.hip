@@ -1,0 +1,684 @@
+// shiftnd_plane.hip -- the tuned per-(N,C)-plane kernels for gfx950 (MI355X).
+//
+// Design (HBM-bound gather; no MFMA):
+//   * One workgroup owns one channel c and a group of batch entries n (optionally a band of rows of
+//     a large plane).  The shift of a channel is the same for every n, so the workgroup evaluates
+//     the padding index map ONCE per spatial dim into LDS (S_d + 1 int32 entries per dim):
+//     map_d[p] = source index of coordinate p, or -1 for "fill".  All five padding modes and
+//     arbitrarily large (multi-wrap) shifts cost the same in the streaming loop: the mode is only
+//     visible in the prologue.
+//   * The innermost (contiguous) dim is cut into 16-byte chunks; a thread owns one chunk column and
+//     walks down the rows (rows of all planes of the group form one "super-row" sequence so small
+//     planes still fill the workgroup).  Stores are aligned 16-byte row segments; loads are
+//     16-byte global loads at element alignment (gfx950 global loads take any alignment), so an
+//     arbitrary column shift costs no realignment work.  Only chunks that touch the padded region
+//     (map not affine across the chunk) take the per-element gather path.
+//   * Interpolation (active forward, backward) widens to fp32 (fp64 for fp64 tensors), evaluates
+//     v1*(1-x)+v2*x without FMA contraction, rounds once on store.
+//   * The weight gradient is accumulated per thread in fp64, reduced per workgroup (shuffle tree +
+//     LDS) into a [group][C][3] partial buffer and summed by reduce_weight_grads: deterministic,
+//     no atomics.
+//
+// Reference behaviour restated (paths under torchshifts/csrc/ops/):
+//   forward   kernels/shifts_kernels.h:156-220, cuda/shifts_cuda.cu:202-266
+//   backward  kernels/shifts_kernels.h:222-327, cuda/shifts_cuda.cu:270-345
+//   quantized kernels/shifts_kernels.h:532-571, quantized/shifts_quantized.cpp:107-130
+#include "shiftnd_common.hpp"
+#include "shiftnd_launch.hpp"
+
+namespace shiftnd {
+namespace {
+
+struct PlaneParams {
+    const void *x;      // forward: input; backward: saved input
+    const void *go;     // backward: incoming gradient (forward output shape)
+    void *out;          // forward: output; backward: grad_x
+    const void *w;      // weights (float dtype or quantized int_repr)
+    double *partials;   // backward: [groups*bands][C][3]
+    int64_t wzp;
+    uint64_t fill;
+    int64_t x_plane;    // elements per (n,c) plane of x
+    int64_t o_plane;    // elements per plane of out / grad_out
+    int wkind, N, C, nd, pad;
+    int S[3], O[3], L[3], wcol[3];
+    int ppw, groups, bands, rows_per_band;
+    int cpr, CW, RPS, CP;
+    int rows;           // rows per plane of the iteration space
+    FastDiv d_rows;     // divide by rows_per_band
+    FastDiv d_dim1;     // divide by the second outer dim of the iteration space
+};
+
+// ---- shift loading -------------------------------------------------------------------------------
+template <typename CT> __device__ __forceinline__ CT load_weight(const void *w, int wkind, int i) {
+    switch (wkind) {
+    case SHIFTND_F64: return static_cast<CT>(static_cast<const double *>(w)[i]);
+    case SHIFTND_F16: return static_cast<CT>(static_cast<const _Float16 *>(w)[i]);
+    case SHIFTND_BF16: return static_cast<CT>(static_cast<const __bf16 *>(w)[i]);
+    default: return static_cast<CT>(static_cast<const float *>(w)[i]);
+    }
+}
+
+__device__ __forceinline__ int64_t gather_shift(const void *w, int wkind, int64_t wzp, int i) {
+    switch (wkind) {
+    case SHIFTND_F32: return static_cast<int64_t>(rintf(static_cast<const float *>(w)[i]));
+    case SHIFTND_F64: return static_cast<int64_t>(rint(static_cast<const double *>(w)[i]));
+    case SHIFTND_F16: return static_cast<int64_t>(rintf(static_cast<float>(static_cast<const _Float16 *>(w)[i])));
+    case SHIFTND_BF16: return static_cast<int64_t>(rintf(static_cast<float>(static_cast<const __bf16 *>(w)[i])));
+    case SHIFTND_I8: return static_cast<int64_t>(static_cast<const int8_t *>(w)[i]) - wzp;
+    case SHIFTND_U8: return static_cast<int64_t>(static_cast<const uint8_t *>(w)[i]) - wzp;
+    default: return static_cast<int64_t>(static_cast<const int32_t *>(w)[i]) - wzp;
+    }
+}
+
+// Fill the LDS maps of the three normalised dims: map_d[p] = pad(p + sign*shift_d) for p in [0, size_d].
+// (size_d + 1 entries: the interpolating kernels also read coordinate p + 1.)
+__device__ __forceinline__ void build_maps(int *maps, const int size[3], const int64_t sh[3], int sign, int pad) {
+    const int n0 = size[0] + 1, n1 = size[1] + 1, n2 = size[2] + 1;
+    for (int t = threadIdx.x; t < n0 + n1 + n2; t += kThreads) {
+        const int d = t < n0 ? 0 : (t < n0 + n1 ? 1 : 2);
+        const int p = t - (d == 0 ? 0 : (d == 1 ? n0 : n0 + n1));
+        const int64_t len = size[d];
+        maps[t] = (len == 1) ? 0 : static_cast<int>(pad_index(static_cast<int64_t>(p) + sign * sh[d], len, pad));
+    }
+}
+
+struct WorkItem {  // which planes / rows this workgroup owns
+    int c, n0, nn, row0, nrows, pidx;
+};
+__device__ __forceinline__ WorkItem decode_block(const PlaneParams &p) {
+    WorkItem wi;
+    const int bid = blockIdx.x;
+    wi.c = bid % p.C;
+    const int rest = bid / p.C;
+    const int grp = rest % p.groups;
+    const int band = rest / p.groups;
+    wi.n0 = grp * p.ppw;
+    wi.nn = min(p.ppw, p.N - wi.n0);
+    wi.row0 = band * p.rows_per_band;
+    wi.nrows = min(p.rows_per_band, p.rows - wi.row0);
+    wi.pidx = band * p.groups + grp;
+    return wi;
+}
+
+// ---- 16-byte (or narrower) chunk I/O ----------------------------------------------------------------
+template <int ESIZE> struct raw_t;
+template <> struct raw_t<1> { using type = uint8_t; };
+template <> struct raw_t<2> { using type = uint16_t; };
+template <> struct raw_t<4> { using type = uint32_t; };
+template <> struct raw_t<8> { using type = uint64_t; };
+
+template <typename R, int E> struct Chunk { R e[E]; };
+
+template <typename R, int E> __device__ __forceinline__ Chunk<R, E> load_chunk(const R *src) {
+    Chunk<R, E> c;
+    __builtin_memcpy(c.e, src, sizeof(R) * E);  // element-aligned: one global_load_dwordx4 on gfx950
+    return c;
+}
+template <typename R, int E> __device__ __forceinline__ void store_chunk(R *dst, const Chunk<R, E> &c) {
+    __builtin_memcpy(__builtin_assume_aligned(dst, sizeof(R) * E), c.e, sizeof(R) * E);
+}
+
+// =====================================================================================================
+// Gather forward: SSL forward for every float dtype and the quantized forward (pure element copy).
+// =====================================================================================================
+template <int ESIZE, int V, int U>
+__global__ __launch_bounds__(kThreads) void plane_gather_forward(const PlaneParams p) {
+    using R = typename raw_t<ESIZE>::type;
+    constexpr int E = V / ESIZE;
+    extern __shared__ int maps[];
+    const int *m0 = maps, *m1 = maps + p.S[0] + 1, *m2 = m1 + p.S[1] + 1;
+
+    const WorkItem wi = decode_block(p);
+    int64_t sh[3];
+#pragma unroll
+    for (int d = 0; d < 3; ++d) sh[d] = p.wcol[d] >= 0 ? gather_shift(p.w, p.wkind, p.wzp, wi.c * p.nd + p.wcol[d]) : 0;
+    build_maps(maps, p.S, sh, -1, p.pad);
+    __syncthreads();
+
+    const R *__restrict__ x = static_cast<const R *>(p.x);
+    R *__restrict__ out = static_cast<R *>(p.out);
+    const R fill = static_cast<R>(p.fill);
+    const int tr = threadIdx.x / p.CW, tc = threadIdx.x - tr * p.CW;
+    if (tr >= p.RPS) return;
+    const int SR = wi.nn * wi.nrows;
+    const int S1 = p.S[1], S2 = p.S[2], O1 = p.O[1], O2 = p.O[2];
+
+    for (int cp = 0; cp < p.CP; ++cp) {
+        const int chunk = cp * p.CW + tc;
+        if (chunk >= p.cpr) break;
+        const int jo = chunk * E;
+        int mm[E];
+        bool contig = true;
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+            mm[e] = m2[jo + p.L[2] + e];
+            contig = contig && (mm[e] == mm[0] + e);
+        }
+        contig = contig && (mm[0] >= 0);
+
+        for (int sr0 = tr; sr0 < SR; sr0 += p.RPS * U) {
+            Chunk<R, E> v[U];
+            R *dst[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int sr = sr0 + u * p.RPS;
+                dst[u] = nullptr;
+                if (sr < SR) {
+                    const int nl = fdiv(sr, p.d_rows);
+                    const int r = wi.row0 + (sr - nl * wi.nrows);
+                    const int a = fdiv(r, p.d_dim1);
+                    const int b = r - a * O1;
+                    const int ra = m0[a + p.L[0]], rb = m1[b + p.L[1]];
+                    const int64_t plane = static_cast<int64_t>(wi.n0 + nl) * p.C + wi.c;
+                    dst[u] = out + plane * p.o_plane + static_cast<int64_t>(r) * O2 + jo;
+                    if (ra < 0 || rb < 0) {
+#pragma unroll
+                        for (int e = 0; e < E; ++e) v[u].e[e] = fill;
+                    } else {
+                        const R *row = x + plane * p.x_plane + static_cast<int64_t>(ra * S1 + rb) * S2;
+                        if (contig) {
+                            v[u] = load_chunk<R, E>(row + mm[0]);
+                        } else {
+#pragma unroll
+                            for (int e = 0; e < E; ++e) v[u].e[e] = mm[e] >= 0 ? row[mm[e]] : fill;
+                        }
+                    }
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+                if (dst[u]) store_chunk<R, E>(dst[u], v[u]);
+        }
+    }
+}
+
+// =====================================================================================================
+// Row loader for the interpolating kernels: E (+1) consecutive mapped elements of one source row.
+// =====================================================================================================
+template <typename T, int E, int CNT>
+__device__ __forceinline__ void load_row(const typename T::S *__restrict__ row, bool valid, bool contig,
+                                         const int (&mm)[E + 1], typename T::C (&vals)[E + 1]) {
+    using S = typename T::S;
+    using CT = typename T::C;
+    if (!valid) {
+#pragma unroll
+        for (int e = 0; e <= E; ++e) vals[e] = CT(0);
+        return;
+    }
+    if (contig) {
+        const Chunk<S, E> c = load_chunk<S, E>(row + mm[0]);
+#pragma unroll
+        for (int e = 0; e < E; ++e) vals[e] = widen<T>(c.e[e]);
+    } else {
+#pragma unroll
+        for (int e = 0; e < E; ++e) vals[e] = mm[e] >= 0 ? widen<T>(row[mm[e]]) : CT(0);
+    }
+    if (CNT > E) vals[E] = mm[E] >= 0 ? widen<T>(row[mm[E]]) : CT(0);
+    else vals[E] = CT(0);
+}
+
+// Outer-dim corner combos of a row: k bit r <-> +1 along real dim r (r < ND-1).
+// Returns the row offset (elements, within the plane) or -1 when any outer map says "fill".
+template <int ND>
+__device__ __forceinline__ int combo_offset(int k, const int *m0, const int *m1, int pa, int pb, int stride0, int stride1) {
+    if constexpr (ND == 1) {
+        return 0;
+    } else if constexpr (ND == 2) {
+        const int rb = m1[pb + (k & 1)];
+        return rb < 0 ? -1 : rb * stride1;
+    } else {
+        const int ra = m0[pa + (k & 1)];
+        const int rb = m1[pb + ((k >> 1) & 1)];
+        return (ra < 0 || rb < 0) ? -1 : ra * stride0 + rb * stride1;
+    }
+}
+
+// =====================================================================================================
+// Active forward: out = interp of the 2^ND corners around (coord - floor(w)).
+// =====================================================================================================
+template <typename T, int ND>
+__global__ __launch_bounds__(kThreads) void plane_active_forward(const PlaneParams p) {
+    using S = typename T::S;
+    using CT = typename T::C;
+    constexpr int E = 16 / sizeof(S);
+    constexpr int NC = 1 << (ND - 1);
+    extern __shared__ int maps[];
+    const int *m0 = maps, *m1 = maps + p.S[0] + 1, *m2 = m1 + p.S[1] + 1;
+
+    const WorkItem wi = decode_block(p);
+    int64_t sh[3] = {0, 0, 0};
+    CT dw[3] = {CT(0), CT(0), CT(0)};
+#pragma unroll
+    for (int d = 0; d < 3; ++d)
+        if (p.wcol[d] >= 0)
+            prep_shift_forward<CT>(load_weight<CT>(p.w, p.wkind, wi.c * p.nd + p.wcol[d]), true, sh[d], dw[p.wcol[d]]);
+    build_maps(maps, p.S, sh, -1, p.pad);
+    __syncthreads();
+
+    const S *__restrict__ x = static_cast<const S *>(p.x);
+    S *__restrict__ out = static_cast<S *>(p.out);
+    const int tr = threadIdx.x / p.CW, tc = threadIdx.x - tr * p.CW;
+    if (tr >= p.RPS) return;
+    const int SR = wi.nn * wi.nrows;
+    const int S1 = p.S[1], S2 = p.S[2], O1 = p.O[1], O2 = p.O[2];
+
+    for (int cp = 0; cp < p.CP; ++cp) {
+        const int chunk = cp * p.CW + tc;
+        if (chunk >= p.cpr) break;
+        const int jo = chunk * E;
+        int mm[E + 1];
+        bool contig = true;
+#pragma unroll
+        for (int e = 0; e <= E; ++e) {
+            mm[e] = m2[jo + p.L[2] + e];
+            if (e < E) contig = contig && (mm[e] == mm[0] + e);
+        }
+        contig = contig && (mm[0] >= 0);
+
+        for (int sr = tr; sr < SR; sr += p.RPS) {
+            const int nl = fdiv(sr, p.d_rows);
+            const int r = wi.row0 + (sr - nl * wi.nrows);
+            const int a = fdiv(r, p.d_dim1);
+            const int b = r - a * O1;
+            const int64_t plane = static_cast<int64_t>(wi.n0 + nl) * p.C + wi.c;
+            const S *xp = x + plane * p.x_plane;
+            CT vals[NC][E + 1];
+#pragma unroll
+            for (int k = 0; k < NC; ++k) {
+                const int off = combo_offset<ND>(k, m0, m1, a + p.L[0], b + p.L[1], S1 * S2, S2);
+                load_row<T, E, E + 1>(xp + (off < 0 ? 0 : off), off >= 0, contig, mm, vals[k]);
+            }
+            Chunk<S, E> res;
+#pragma unroll
+            for (int e = 0; e < E; ++e) {
+                CT v[1 << ND];
+#pragma unroll
+                for (int q = 0; q < (1 << ND); ++q) v[q] = vals[q & (NC - 1)][e + (q >> (ND - 1))];
+                res.e[e] = narrow<T>(interp_nd<ND, CT>(v, dw));
+            }
+            store_chunk<S, E>(out + plane * p.o_plane + static_cast<int64_t>(r) * O2 + jo, res);
+        }
+    }
+}
+
+// =====================================================================================================
+// Backward: grad_x (gather of grad_out, SSL; or interpolation of grad_out, active) and the weight
+// gradient partials.  Iteration space = input coordinates.
+// LDS maps: x maps (3 dims, S_d + 1 entries) followed by grad_out maps (3 dims, O_d + 1 entries).
+// =====================================================================================================
+template <typename T, int ND, bool ACTIVE>
+__global__ __launch_bounds__(kThreads) void plane_backward(const PlaneParams p) {
+    using S = typename T::S;
+    using CT = typename T::C;
+    constexpr int E = 16 / sizeof(S);
+    constexpr int NC = 1 << (ND - 1);
+    extern __shared__ int maps[];
+    __shared__ double scratch[kThreads / 64];
+    const int *m0 = maps, *m1 = m0 + p.S[0] + 1, *m2 = m1 + p.S[1] + 1;
+    int *gmaps = maps + p.S[0] + p.S[1] + p.S[2] + 3;
+    const int *g0 = gmaps, *g1 = g0 + p.O[0] + 1, *g2 = g1 + p.O[1] + 1;
+
+    const WorkItem wi = decode_block(p);
+    int64_t sh[3] = {0, 0, 0};
+    CT dw[3] = {CT(0), CT(0), CT(0)};
+#pragma unroll
+    for (int d = 0; d < 3; ++d)
+        if (p.wcol[d] >= 0)
+            prep_shift_backward<CT>(load_weight<CT>(p.w, p.wkind, wi.c * p.nd + p.wcol[d]), ACTIVE, sh[d], dw[p.wcol[d]]);
+    build_maps(maps, p.S, sh, -1, p.pad);
+    // grad_x source: SSL reads grad_out at o + shift, active at o - shift (shifts_kernels.h:287-293)
+    build_maps(gmaps, p.O, sh, ACTIVE ? -1 : +1, p.pad);
+    __syncthreads();
+
+    const S *__restrict__ x = static_cast<const S *>(p.x);
+    const S *__restrict__ go = static_cast<const S *>(p.go);
+    S *__restrict__ gx = static_cast<S *>(p.out);
+    const int tr = threadIdx.x / p.CW, tc = threadIdx.x - tr * p.CW;
+    const int SR = wi.nn * wi.nrows;
+    const int S1 = p.S[1], S2 = p.S[2], O1 = p.O[1], O2 = p.O[2];
+    double acc[3] = {0.0, 0.0, 0.0};
+
+    if (tr < p.RPS) {
+        for (int cp = 0; cp < p.CP; ++cp) {
+            const int chunk = cp * p.CW + tc;
+            if (chunk >= p.cpr) break;
+            const int ji = chunk * E;   // input inner coordinate of element 0
+            const int oj = ji - p.L[2];  // grad_out inner coordinate of element 0 (may be outside)
+            // per-chunk column state -----------------------------------------------------------------
+            int xm[E + 1], gm[E + 1];
+            unsigned inmask = 0;
+            bool xcontig = true, gcontig = true;
+#pragma unroll
+            for (int e = 0; e <= E; ++e) {
+                xm[e] = m2[ji + e];
+                if (e < E) xcontig = xcontig && (xm[e] == xm[0] + e);
+                const int o = oj + e;
+                const bool in = (o >= 0) && (o < O2);
+                if (e < E && in) inmask |= 1u << e;
+                // grad_out map; clamp the LDS index, entries of outside elements are never used
+                const int oc = o < 0 ? 0 : (o > O2 ? O2 : o);
+                gm[e] = g2[oc];
+                if (e < E) gcontig = gcontig && (gm[e] == gm[0] + e);
+            }
+            const bool allin = inmask == ((1u << E) - 1u);
+            xcontig = xcontig && (xm[0] >= 0);
+            gcontig = gcontig && allin && (gm[0] >= 0);
+
+            for (int sr = tr; sr < SR; sr += p.RPS) {
+                const int nl = fdiv(sr, p.d_rows);
+                const int r = wi.row0 + (sr - nl * wi.nrows);
+                const int a = fdiv(r, p.d_dim1);
+                const int b = r - a * S1;
+                const int oa = a - p.L[0], ob = b - p.L[1];
+                const int64_t plane = static_cast<int64_t>(wi.n0 + nl) * p.C + wi.c;
+                S *dst = gx + plane * p.x_plane + static_cast<int64_t>(r) * S2 + ji;
+                Chunk<S, E> res;
+                const bool rowin = (oa >= 0) && (oa < p.O[0]) && (ob >= 0) && (ob < O1);
+                if (!rowin || inmask == 0) {  // outside the border window: grad_x = 0, no weight-grad term
+#pragma unroll
+                    for (int e = 0; e < E; ++e) res.e[e] = narrow<T>(CT(0));
+                    store_chunk<S, E>(dst, res);
+                    continue;
+                }
+                const S *xp = x + plane * p.x_plane;
+                const S *gp = go + plane * p.o_plane;
+                // incoming gradient at this position ----------------------------------------------------
+                CT gval[E];
+                {
+                    const S *grow = gp + static_cast<int64_t>(oa * O1 + ob) * O2;
+                    if (allin) {
+                        const Chunk<S, E> c = load_chunk<S, E>(grow + oj);
+#pragma unroll
+                        for (int e = 0; e < E; ++e) gval[e] = widen<T>(c.e[e]);
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < E; ++e) gval[e] = ((inmask >> e) & 1u) ? widen<T>(grow[oj + e]) : CT(0);
+                    }
+                }
+                // weight gradient: corners of x around (coord - shift) --------------------------------------
+                {
+                    CT vals[NC][E + 1];
+#pragma unroll
+                    for (int k = 0; k < NC; ++k) {
+                        const int off = combo_offset<ND>(k, m0, m1, a, b, S1 * S2, S2);
+                        load_row<T, E, E + 1>(xp + (off < 0 ? 0 : off), off >= 0, xcontig, xm, vals[k]);
+                    }
+#pragma unroll
+                    for (int e = 0; e < E; ++e) {
+                        CT v[1 << ND], wg[3];
+#pragma unroll
+                        for (int q = 0; q < (1 << ND); ++q) v[q] = vals[q & (NC - 1)][e + (q >> (ND - 1))];
+                        weight_grads_nd<ND, CT>(v, dw, wg);
+                        if ((inmask >> e) & 1u) {
+#pragma unroll
+                            for (int s = 0; s < ND; ++s) acc[s] += static_cast<double>(gval[e] * wg[s]);
+                        }
+                    }
+                }
+                // input gradient ------------------------------------------------------------------------
+                if constexpr (ACTIVE) {
+                    CT vals[NC][E + 1];
+#pragma unroll
+                    for (int k = 0; k < NC; ++k) {
+                        const int off = combo_offset<ND>(k, g0, g1, oa, ob, O1 * O2, O2);
+                        load_row<T, E, E + 1>(gp + (off < 0 ? 0 : off), off >= 0, gcontig, gm, vals[k]);
+                    }
+#pragma unroll
+                    for (int e = 0; e < E; ++e) {
+                        CT v[1 << ND];
+#pragma unroll
+                        for (int q = 0; q < (1 << ND); ++q) v[q] = vals[q & (NC - 1)][e + (q >> (ND - 1))];
+                        const CT r1 = interp_nd<ND, CT>(v, dw);
+                        res.e[e] = narrow<T>(((inmask >> e) & 1u) ? r1 : CT(0));
+                    }
+                } else {
+                    const int ra = g0[oa], rb = g1[ob];
+                    if (ra < 0 || rb < 0) {
+#pragma unroll
+                        for (int e = 0; e < E; ++e) res.e[e] = narrow<T>(CT(0));
+                    } else {
+                        const S *srow = gp + static_cast<int64_t>(ra * O1 + rb) * O2;
+                        if (gcontig) {
+                            res = load_chunk<S, E>(srow + gm[0]);
+                        } else {
+#pragma unroll
+                            for (int e = 0; e < E; ++e)
+                                res.e[e] = (((inmask >> e) & 1u) && gm[e] >= 0) ? srow[gm[e]] : narrow<T>(CT(0));
+                        }
+                    }
+                }
+                store_chunk<S, E>(dst, res);
+            }
+        }
+    }
+#pragma unroll
+    for (int s = 0; s < 3; ++s) {
+        const double t = block_sum(acc[s], scratch);
+        if (threadIdx.x == 0) p.partials[(static_cast<size_t>(wi.pidx) * p.C + wi.c) * 3 + s] = t;
+    }
+}
+
+// =====================================================================================================
+// Host side: launch planning
+// =====================================================================================================
+bool contiguous(const int64_t st[5], int64_t N, int64_t C, const int64_t sz[3]) {
+    // strides in normalised order N, C, d0, d1, inner; size-1 dims may carry any stride
+    int64_t expect = 1;
+    const int64_t sizes[5] = {N, C, sz[0], sz[1], sz[2]};
+    for (int d = 4; d >= 0; --d) {
+        if (sizes[d] != 1 && st[d] != expect) return false;
+        expect *= sizes[d];
+    }
+    return true;
+}
+
+struct Plan {
+    int V, cpr, CW, RPS, CP, ppw, groups, bands, rows_per_band, rows;
+    size_t lds;
+    unsigned grid;
+};
+
+// rows/inner: iteration space of one plane; esize: element bytes; V: chunk bytes
+Plan make_plan(const Geometry &g, int64_t rows, int64_t inner, int esize, int V, int map_entries) {
+    Plan pl;
+    pl.V = V;
+    pl.rows = static_cast<int>(rows);
+    pl.cpr = static_cast<int>(inner * esize / V);
+    pl.CW = pl.cpr < kThreads ? pl.cpr : kThreads;
+    pl.RPS = kThreads / pl.CW;
+    pl.CP = (pl.cpr + pl.CW - 1) / pl.CW;
+    const int64_t plane_bytes = rows * inner * esize;
+    int64_t ppw = (128 * 1024) / (plane_bytes > 0 ? plane_bytes : 1);
+    if (ppw < 1) ppw = 1;
+    if (ppw > g.N) ppw = g.N;
+    auto ngroups = [&](int64_t q) { return (g.N + q - 1) / q; };
+    while (ppw > 1 && g.C * ngroups(ppw) < 2048) ppw = (ppw + 1) / 2;
+    pl.ppw = static_cast<int>(ppw);
+    pl.groups = static_cast<int>(ngroups(ppw));
+    // few, large planes: cut each plane into row bands so that >= ~2048 workgroups exist
+    int64_t bands = 1;
+    const int64_t wgs = g.C * pl.groups;
+    if (wgs < 2048 && ppw == 1) {
+        bands = (2048 + wgs - 1) / wgs;
+        const int64_t min_rows = static_cast<int64_t>(pl.RPS) * 4;  // at least 4 row steps per band
+        const int64_t max_bands = rows / (min_rows > 0 ? min_rows : 1);
+        if (bands > max_bands) bands = max_bands;
+        if (bands < 1) bands = 1;
+    }
+    pl.rows_per_band = static_cast<int>((rows + bands - 1) / bands);
+    pl.bands = static_cast<int>((rows + pl.rows_per_band - 1) / pl.rows_per_band);
+    pl.lds = static_cast<size_t>(map_entries) * sizeof(int);
+    pl.grid = static_cast<unsigned>(g.C * pl.groups * pl.bands);
+    return pl;
+}
+
+void fill_params(PlaneParams &p, const Geometry &g, const Plan &pl, int64_t dim1) {
+    p.N = static_cast<int>(g.N);
+    p.C = static_cast<int>(g.C);
+    p.nd = g.nd;
+    p.pad = g.pad;
+    for (int d = 0; d < 3; ++d) {
+        p.S[d] = static_cast<int>(g.S[d]);
+        p.O[d] = static_cast<int>(g.O[d]);
+        p.L[d] = static_cast<int>(g.L[d]);
+        p.wcol[d] = g.wcol[d];
+    }
+    p.x_plane = g.S[0] * g.S[1] * g.S[2];
+    p.o_plane = g.O[0] * g.O[1] * g.O[2];
+    p.ppw = pl.ppw;
+    p.groups = pl.groups;
+    p.bands = pl.bands;
+    p.rows_per_band = pl.rows_per_band;
+    p.cpr = pl.cpr;
+    p.CW = pl.CW;
+    p.RPS = pl.RPS;
+    p.CP = pl.CP;
+    p.rows = pl.rows;
+    p.d_rows = make_fastdiv(static_cast<uint32_t>(pl.rows_per_band));
+    p.d_dim1 = make_fastdiv(static_cast<uint32_t>(dim1));
+}
+
+bool common_eligible(const Geometry &g) {
+    const int64_t xe = g.S[0] * g.S[1] * g.S[2], oe = g.O[0] * g.O[1] * g.O[2];
+    if (xe >= (1LL << 30) || oe >= (1LL << 30)) return false;           // 32-bit in-plane offsets
+    if (g.N * g.C >= (1LL << 31) || g.N >= (1LL << 30) || g.C >= (1LL << 30)) return false;
+    return true;
+}
+
+int gather_vector_bytes(const Geometry &g, int esize, const void *out) {
+    const int cand[3] = {16, 8, 4};
+    for (int V : cand) {
+        if (V < esize) continue;
+        if ((g.O[2] * esize) % V != 0) continue;
+        if (reinterpret_cast<uintptr_t>(out) % V != 0) continue;
+        return V;
+    }
+    return esize;
+}
+
+template <int ESIZE, int V>
+void launch_gather(const PlaneParams &p, const Plan &pl, hipStream_t st) {
+    hipLaunchKernelGGL((plane_gather_forward<ESIZE, V, 4>), dim3(pl.grid), dim3(kThreads), pl.lds, st, p);
+}
+
+template <typename T>
+int launch_active_forward(const PlaneParams &p, const Plan &pl, hipStream_t st) {
+    switch (p.nd) {
+    case 1: hipLaunchKernelGGL((plane_active_forward<T, 1>), dim3(pl.grid), dim3(kThreads), pl.lds, st, p); break;
+    case 2: hipLaunchKernelGGL((plane_active_forward<T, 2>), dim3(pl.grid), dim3(kThreads), pl.lds, st, p); break;
+    default: hipLaunchKernelGGL((plane_active_forward<T, 3>), dim3(pl.grid), dim3(kThreads), pl.lds, st, p); break;
+    }
+    return SHIFTND_OK;
+}
+
+template <typename T, bool ACTIVE>
+void launch_backward_a(const PlaneParams &p, const Plan &pl, hipStream_t st) {
+    switch (p.nd) {
+    case 1: hipLaunchKernelGGL((plane_backward<T, 1, ACTIVE>), dim3(pl.grid), dim3(kThreads), pl.lds, st, p); break;
+    case 2: hipLaunchKernelGGL((plane_backward<T, 2, ACTIVE>), dim3(pl.grid), dim3(kThreads), pl.lds, st, p); break;
+    default: hipLaunchKernelGGL((plane_backward<T, 3, ACTIVE>), dim3(pl.grid), dim3(kThreads), pl.lds, st, p); break;
+    }
+}
+
+template <typename T>
+int launch_backward(const PlaneParams &p, const Plan &pl, bool active, void *gw, hipStream_t st) {
+    if (active) launch_backward_a<T, true>(p, pl, st);
+    else launch_backward_a<T, false>(p, pl, st);
+    const int cn = p.C * p.nd;
+    hipLaunchKernelGGL((reduce_weight_grads<T>), dim3((cn + 255) / 256), dim3(256), 0, st, p.partials,
+                       pl.groups * pl.bands, p.C, p.nd, static_cast<typename T::S *>(gw));
+    return SHIFTND_OK;
+}
+
+Plan backward_plan(const Geometry &g, int esize) {
+    const int entries = static_cast<int>(g.S[0] + g.S[1] + g.S[2] + g.O[0] + g.O[1] + g.O[2] + 6);
+    return make_plan(g, g.S[0] * g.S[1], g.S[2], esize, 16, entries);
+}
+
+}  // namespace
+
+bool plane_forward_eligible(const Geometry &g, int dtype, const void *x, const void *out) {
+    (void)x;
+    if (!common_eligible(g)) return false;
+    if (g.S[0] + g.S[1] + g.S[2] + 3 > kMaxMapEntries) return false;
+    if (!contiguous(g.xs, g.N, g.C, g.S) || !contiguous(g.os, g.N, g.C, g.O)) return false;
+    const bool interpolating = g.active && dtype <= SHIFTND_BF16;
+    if (interpolating) {
+        const int es = dtype_size(dtype);
+        if ((g.O[2] * es) % 16 != 0 || reinterpret_cast<uintptr_t>(out) % 16 != 0) return false;
+    }
+    return true;
+}
+
+int plane_forward(const Geometry &g, int dtype, const void *x, const void *w, int wkind, int64_t wzp,
+                  uint64_t fill_bits, void *out, hipStream_t st) {
+    const int es = dtype_size(dtype);
+    const bool interpolating = g.active && dtype <= SHIFTND_BF16;
+    const int entries = static_cast<int>(g.S[0] + g.S[1] + g.S[2] + 3);
+    PlaneParams p{};
+    p.x = x;
+    p.out = out;
+    p.w = w;
+    p.wkind = wkind;
+    p.wzp = wzp;
+    p.fill = fill_bits;
+    if (interpolating) {
+        const Plan pl = make_plan(g, g.O[0] * g.O[1], g.O[2], es, 16, entries);
+        fill_params(p, g, pl, g.O[1]);
+        switch (dtype) {
+        case SHIFTND_F32: return launch_active_forward<f32_t>(p, pl, st);
+        case SHIFTND_F64: return launch_active_forward<f64_t>(p, pl, st);
+        case SHIFTND_F16: return launch_active_forward<f16_t>(p, pl, st);
+        default: return launch_active_forward<bf16_t>(p, pl, st);
+        }
+    }
+    const int V = gather_vector_bytes(g, es, out);
+    const Plan pl = make_plan(g, g.O[0] * g.O[1], g.O[2], es, V, entries);
+    fill_params(p, g, pl, g.O[1]);
+#define SHIFTND_GATHER_CASE(ES, VV) \
+    if (es == ES && V == VV) { launch_gather<ES, VV>(p, pl, st); return SHIFTND_OK; }
+    SHIFTND_GATHER_CASE(1, 16) SHIFTND_GATHER_CASE(1, 8) SHIFTND_GATHER_CASE(1, 4) SHIFTND_GATHER_CASE(1, 1)
+    SHIFTND_GATHER_CASE(2, 16) SHIFTND_GATHER_CASE(2, 8) SHIFTND_GATHER_CASE(2, 4) SHIFTND_GATHER_CASE(2, 2)
+    SHIFTND_GATHER_CASE(4, 16) SHIFTND_GATHER_CASE(4, 8) SHIFTND_GATHER_CASE(4, 4)
+    SHIFTND_GATHER_CASE(8, 16) SHIFTND_GATHER_CASE(8, 8)
+#undef SHIFTND_GATHER_CASE
+    return SHIFTND_ERR_UNSUPPORTED_DTYPE;
+}
+
+bool plane_backward_eligible(const Geometry &g, int dtype, const void *go, const void *x, const void *gx) {
+    (void)go;
+    (void)x;
+    if (dtype > SHIFTND_BF16 || !common_eligible(g)) return false;
+    if (g.S[0] + g.S[1] + g.S[2] + g.O[0] + g.O[1] + g.O[2] + 6 > kMaxMapEntries) return false;
+    if (!contiguous(g.xs, g.N, g.C, g.S) || !contiguous(g.os, g.N, g.C, g.O) || !contiguous(g.gs, g.N, g.C, g.S))
+        return false;
+    const int es = dtype_size(dtype);
+    if ((g.S[2] * es) % 16 != 0 || reinterpret_cast<uintptr_t>(gx) % 16 != 0) return false;
+    return true;
+}
+
+size_t plane_backward_workspace(const Geometry &g, int dtype) {
+    const Plan pl = backward_plan(g, dtype_size(dtype));
+    return static_cast<size_t>(pl.groups) * pl.bands * static_cast<size_t>(g.C) * 3 * sizeof(double);
+}
+
+int plane_backward(const Geometry &g, int dtype, const void *go, const void *x, const void *w, void *gx, void *gw,
+                   void *workspace, hipStream_t st) {
+    const Plan pl = backward_plan(g, dtype_size(dtype));
+    PlaneParams p{};
+    p.x = x;
+    p.go = go;
+    p.out = gx;
+    p.w = w;
+    p.wkind = dtype;
+    p.partials = static_cast<double *>(workspace);
+    fill_params(p, g, pl, g.S[1]);
+    switch (dtype) {
+    case SHIFTND_F32: return launch_backward<f32_t>(p, pl, g.active != 0, gw, st);
+    case SHIFTND_F64: return launch_backward<f64_t>(p, pl, g.active != 0, gw, st);
+    case SHIFTND_F16: return launch_backward<f16_t>(p, pl, g.active != 0, gw, st);
+    default: return launch_backward<bf16_t>(p, pl, g.active != 0, gw, st);
+    }
+}
+
+}  // namespace shiftnd

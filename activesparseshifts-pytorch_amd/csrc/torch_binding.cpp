@@ -1,0 +1,326 @@
+// torch_binding.cpp -- the `torchshifts` operator library for PyTorch-ROCm (host C++).
+//
+// Re-provides the reference's dispatcher surface so that `torchshifts/_C.so` is a drop-in:
+//   * schemas of the six private ops + public shift{1,2,3}d + _cuda_version
+//       (reference: csrc/ops/shifts.cpp:168-181, csrc/torchshifts.cpp:35-40)
+//   * composite entry shift{N}d = check_borders + _shift{N}d_forward   (ops/shifts.cpp:93-166)
+//   * Autograd key: one templated autograd::Function instead of three copies
+//       (ops/autograd/shifts_autograd.cpp:15-281), incl. the double-backward guard
+//   * CUDA key (= HIP tensors on PyTorch-ROCm) and QuantizedCUDA key: thin adapters that pull
+//       pointers/strides out of at::Tensor and call the C ABI of libshiftnd_hip.so
+//       (include/shiftnd_hip.h).  No compute happens here and there is no CPU fallback: a HIP
+//       tensor either runs the HIP kernels or raises.
+// The CPU / QuantizedCPU keys (the reference's CPU backend) live in torch_cpu_backend.cpp.
+#include <ATen/ATen.h>
+#include <ATen/core/dispatch/Dispatcher.h>
+#include <c10/core/DeviceGuard.h>
+#include <c10/hip/HIPStream.h>
+#include <hip/hip_version.h>
+#include <torch/autograd.h>
+#include <torch/library.h>
+
+#include <string>
+#include <tuple>
+#include <vector>
+
+#include "shiftnd_hip.h"
+
+namespace torchshifts_amd {
+
+using at::Tensor;
+using torch::autograd::AutogradContext;
+using torch::autograd::variable_list;
+
+using forward_sig = Tensor(const Tensor &, const Tensor &, const Tensor &, at::IntArrayRef, int64_t, bool);
+using backward_sig = std::tuple<Tensor, Tensor>(const Tensor &, const Tensor &, const Tensor &, const Tensor &, int64_t,
+                                                bool);
+
+// ---- dispatcher re-entry (ops/shifts.cpp:10-88) ------------------------------------------------------
+template <int ND> Tensor call_forward(const Tensor &input, const Tensor &weights, const Tensor &borders,
+                                      at::IntArrayRef new_size, int64_t padding_mode, bool active_flag) {
+    static auto op = c10::Dispatcher::singleton()
+                         .findSchemaOrThrow(("torchshifts::_shift" + std::to_string(ND) + "d_forward").c_str(), "")
+                         .typed<forward_sig>();
+    return op.call(input, weights, borders, new_size, padding_mode, active_flag);
+}
+template <int ND>
+std::tuple<Tensor, Tensor> call_backward(const Tensor &grad, const Tensor &weights, const Tensor &input,
+                                         const Tensor &borders, int64_t padding_mode, bool active_flag) {
+    static auto op = c10::Dispatcher::singleton()
+                         .findSchemaOrThrow(("torchshifts::_shift" + std::to_string(ND) + "d_backward").c_str(), "")
+                         .typed<backward_sig>();
+    return op.call(grad, weights, input, borders, padding_mode, active_flag);
+}
+
+// ---- borders -------------------------------------------------------------------------------------------
+// check_borders (ops/shifts.cpp:93-135).  Unlike the reference the 6-int result stays on the HOST:
+// it is host-known, and the kernels take it as launch arguments (no 24-byte H2D copy per call).
+std::tuple<Tensor, std::vector<int64_t>> check_borders(const Tensor &input, const Tensor &borders, int64_t dim) {
+    const auto sizes = input.sizes();
+    TORCH_CHECK(static_cast<int64_t>(sizes.size()) >= dim + 1, "shift", dim, "d: input has too few dimensions");
+    std::vector<int32_t> user;
+    if (borders.numel() != 0) {
+        Tensor b = borders.to(at::kInt).to(at::kCPU).contiguous();
+        TORCH_CHECK(b.numel() >= 2 * std::min<int64_t>(dim, 3), "borders must hold (left, right) per spatial dim");
+        user.assign(b.data_ptr<int32_t>(), b.data_ptr<int32_t>() + b.numel());
+    }
+    Tensor std_borders = at::empty({6}, at::TensorOptions().dtype(at::kInt).device(at::kCPU));
+    std::vector<int64_t> new_sizes(sizes.size());
+    const int rc = shiftnd_check_borders(sizes.data(), static_cast<int>(sizes.size()), user.empty() ? nullptr : user.data(),
+                                         static_cast<int>(dim), std_borders.data_ptr<int32_t>(), new_sizes.data());
+    TORCH_CHECK(rc == SHIFTND_OK, "check_borders: ", shiftnd_status_string(rc));
+    new_sizes.resize(((dim + 1) == static_cast<int64_t>(sizes.size()) ? 1 : 2) + std::min<int64_t>(dim, 3));
+    return std::make_tuple(std_borders, new_sizes);
+}
+
+// 6 host ints from a borders tensor that may live anywhere (a device tensor costs one D2H sync;
+// the composite ops above never produce one)
+void read_borders(const Tensor &borders, int32_t out[6]) {
+    TORCH_CHECK(borders.numel() == 6, "borders must hold 6 integers [l_i, r_i, l_j, r_j, l_k, r_k]");
+    Tensor b = borders.to(at::kCPU).to(at::kInt).contiguous();
+    for (int i = 0; i < 6; ++i) out[i] = b.data_ptr<int32_t>()[i];
+}
+
+template <int ND> Tensor shift_public(const Tensor &input, const Tensor &weights, const Tensor &borders,
+                                      int64_t padding_mode, bool active_flag) {
+    auto bands = check_borders(input, borders, ND);
+    return call_forward<ND>(input, weights, std::get<0>(bands), std::get<1>(bands), padding_mode, active_flag);
+}
+
+std::tuple<Tensor, std::vector<int64_t>> check_borders_op(const Tensor &input, const Tensor &borders, int64_t dim) {
+    return check_borders(input, borders, dim);
+}
+
+// ---- Autograd key (ops/autograd/shifts_autograd.cpp) -------------------------------------------------
+template <int ND> struct ShiftFunction : public torch::autograd::Function<ShiftFunction<ND>> {
+    static variable_list forward(AutogradContext *ctx, const Tensor &input, const Tensor &weight, const Tensor &borders,
+                                 at::IntArrayRef new_size, int64_t padding_mode, bool active_flag) {
+        at::AutoDispatchBelowADInplaceOrView guard;
+        auto output = call_forward<ND>(input, weight, borders, new_size, padding_mode, active_flag);
+        ctx->saved_data["padding_mode"] = padding_mode;
+        ctx->saved_data["active_flag"] = active_flag;
+        ctx->save_for_backward({input, weight, borders});
+        return {output};
+    }
+    static variable_list backward(AutogradContext *ctx, const variable_list &grad_output) {
+        auto saved = ctx->get_saved_variables();
+        const auto padding_mode = ctx->saved_data["padding_mode"].toInt();
+        const auto active_flag = ctx->saved_data["active_flag"].toBool();
+        auto result = call_backward<ND>(grad_output[0], saved[1], saved[0], saved[2], padding_mode, active_flag);
+        return {std::get<0>(result), std::get<1>(result), Tensor(), Tensor(), Tensor(), Tensor()};
+    }
+};
+
+// the backward op is itself differentiable only to the extent of raising on a second backward
+template <int ND> struct ShiftBackwardFunction : public torch::autograd::Function<ShiftBackwardFunction<ND>> {
+    static variable_list forward(AutogradContext *ctx, const Tensor &grad, const Tensor &weights, const Tensor &input,
+                                 const Tensor &borders, int64_t padding_mode, bool active_flag) {
+        at::AutoDispatchBelowADInplaceOrView guard;
+        auto result = call_backward<ND>(grad, weights, input, borders, padding_mode, active_flag);
+        return {std::get<0>(result), std::get<1>(result)};
+    }
+    static variable_list backward(AutogradContext *, const variable_list &) {
+        TORCH_CHECK(0, "double backwards on shift", ND, "d not supported");
+    }
+};
+
+template <int ND> Tensor shift_autograd(const Tensor &input, const Tensor &weights, const Tensor &borders,
+                                        at::IntArrayRef new_size, int64_t padding_mode, bool active_flag) {
+    return ShiftFunction<ND>::apply(input, weights, borders, new_size, padding_mode, active_flag)[0];
+}
+template <int ND>
+std::tuple<Tensor, Tensor> shift_autograd_backward(const Tensor &grad, const Tensor &weights, const Tensor &input,
+                                                   const Tensor &borders, int64_t padding_mode, bool active_flag) {
+    auto result = ShiftBackwardFunction<ND>::apply(grad, weights, input, borders, padding_mode, active_flag);
+    return std::make_tuple(result[0], result[1]);
+}
+
+// ---- HIP backend adapters (CUDA dispatch key on PyTorch-ROCm) ----------------------------------------
+int to_shiftnd_dtype(at::ScalarType t, const char *what) {
+    switch (t) {
+    case at::kFloat: return SHIFTND_F32;
+    case at::kDouble: return SHIFTND_F64;
+    case at::kHalf: return SHIFTND_F16;
+    case at::kBFloat16: return SHIFTND_BF16;
+    default: TORCH_CHECK(false, "\"", what, "\" not implemented for '", c10::toString(t), "'");
+    }
+    return -1;
+}
+
+void fill_strides(const Tensor &t, int nd, int64_t out[5]) {
+    for (int i = 0; i < 5; ++i) out[i] = 0;
+    for (int i = 0; i < 2 + nd; ++i) out[i] = t.stride(i);
+}
+
+void fill_problem(shiftnd_problem &p, int nd, const Tensor &input, const int32_t borders[6], int64_t padding_mode,
+                  bool active, int dtype) {
+    p.ndim = nd;
+    p.dtype = dtype;
+    p.padding_mode = static_cast<int32_t>(padding_mode);
+    p.active = active ? 1 : 0;
+    for (int i = 0; i < 5; ++i) p.sizes[i] = 1;
+    for (int i = 0; i < 2 + nd; ++i) p.sizes[i] = input.size(i);
+    for (int i = 0; i < 6; ++i) p.borders[i] = borders[i];
+}
+
+hipStream_t current_stream(const Tensor &t) { return c10::hip::getCurrentHIPStream(t.device().index()).stream(); }
+
+void check_same(const char *fn, const Tensor &a, const char *an, const Tensor &b, const char *bn) {
+    TORCH_CHECK(a.get_device() == b.get_device(), "Expected tensor for ", an, " to be on the same device as tensor for ", bn,
+                "; but ", an, " is on device ", a.get_device(), " and ", bn, " is on device ", b.get_device(),
+                " (while checking arguments for ", fn, ")");
+    TORCH_CHECK(a.scalar_type() == b.scalar_type(), "Expected tensor for ", an, " to have the same type as tensor for ", bn,
+                "; but type ", c10::toString(a.scalar_type()), " does not equal ", c10::toString(b.scalar_type()),
+                " (while checking arguments for ", fn, ")");
+}
+
+template <int ND> Tensor shift_forward_hip(const Tensor &input, const Tensor &weights, const Tensor &borders,
+                                           at::IntArrayRef new_size, int64_t padding_mode, bool active_flag) {
+    TORCH_CHECK(input.is_cuda(), "input must be a CUDA tensor");
+    TORCH_CHECK(weights.is_cuda(), "weights must be a CUDA tensor");
+    check_same("shiftnd_forward_cuda", input, "input", weights, "weights");
+    TORCH_CHECK(input.dim() == ND + 2, "shift", ND, "d: expected a ", ND + 2, "-D input");
+    TORCH_CHECK(weights.dim() == 2 && weights.size(0) == input.size(1) && weights.size(1) == ND,
+                "shift", ND, "d: weights must have shape [C, ", ND, "]");
+    if (padding_mode < 0 || padding_mode > 4) return Tensor();  // the reference's switch has no default
+    c10::DeviceGuard device_guard(input.device());
+    const int dtype = to_shiftnd_dtype(input.scalar_type(), "shiftnd_forward_cuda");
+    int32_t b[6];
+    read_borders(borders, b);
+    Tensor w = weights.contiguous();
+    Tensor output = at::empty(new_size, input.options(), at::MemoryFormat::Contiguous);
+    shiftnd_problem p;
+    fill_problem(p, ND, input, b, padding_mode, active_flag, dtype);
+    int64_t xs[5], os[5];
+    fill_strides(input, ND, xs);
+    fill_strides(output, ND, os);
+    const int rc = shiftnd_forward(&p, input.data_ptr(), xs, w.data_ptr(), output.data_ptr(), os, current_stream(input));
+    TORCH_CHECK(rc == SHIFTND_OK, "shiftnd_forward (HIP): ", shiftnd_status_string(rc));
+    return output;
+}
+
+template <int ND>
+std::tuple<Tensor, Tensor> shift_backward_hip(const Tensor &grad, const Tensor &weights, const Tensor &input,
+                                              const Tensor &borders, int64_t padding_mode, bool active_flag) {
+    TORCH_CHECK(grad.is_cuda(), "grad must be a CUDA tensor");
+    TORCH_CHECK(input.is_cuda(), "input must be a CUDA tensor");
+    TORCH_CHECK(weights.is_cuda(), "weights must be a CUDA tensor");
+    check_same("shiftnd_backward_cuda", grad, "grad", input, "input");
+    check_same("shiftnd_backward_cuda", grad, "grad", weights, "weights");
+    TORCH_CHECK(input.dim() == ND + 2 && grad.dim() == ND + 2, "shift", ND, "d backward: expected ", ND + 2, "-D tensors");
+    if (padding_mode < 0 || padding_mode > 4) return std::make_tuple(Tensor(), Tensor());
+    c10::DeviceGuard device_guard(grad.device());
+    const int dtype = to_shiftnd_dtype(grad.scalar_type(), "shiftnd_backward_cuda");
+    int32_t b[6];
+    read_borders(borders, b);
+    for (int r = 0; r < ND; ++r)
+        TORCH_CHECK(grad.size(2 + r) == b[2 * r + 1] - b[2 * r], "shift", ND, "d backward: grad does not match borders");
+    Tensor w = weights.contiguous();
+    Tensor grad_input = at::empty_like(input, at::MemoryFormat::Contiguous);
+    Tensor grad_weights = at::empty_like(w, at::MemoryFormat::Contiguous);
+    shiftnd_problem p;
+    fill_problem(p, ND, input, b, padding_mode, active_flag, dtype);
+    const size_t ws_bytes = shiftnd_backward_workspace_bytes(&p);
+    Tensor workspace = at::empty({static_cast<int64_t>(ws_bytes)}, input.options().dtype(at::kByte));
+    int64_t gs[5], xs[5], gxs[5];
+    fill_strides(grad, ND, gs);
+    fill_strides(input, ND, xs);
+    fill_strides(grad_input, ND, gxs);
+    const int rc = shiftnd_backward(&p, grad.data_ptr(), gs, input.data_ptr(), xs, w.data_ptr(), grad_input.data_ptr(), gxs,
+                                    grad_weights.data_ptr(), workspace.data_ptr(), ws_bytes, current_stream(grad));
+    TORCH_CHECK(rc == SHIFTND_OK, "shiftnd_backward (HIP): ", shiftnd_status_string(rc));
+    return std::make_tuple(grad_input, grad_weights);
+}
+
+// ---- quantized HIP forward (QuantizedCUDA key; new -- the reference only has QuantizedCPU) --------------
+int quant_dtype(at::ScalarType t, const char *what) {
+    switch (t) {
+    case at::kQInt8: return SHIFTND_I8;
+    case at::kQUInt8: return SHIFTND_U8;
+    case at::kQInt32: return SHIFTND_I32;
+    default: TORCH_CHECK(false, "\"", what, "\" not implemented for '", c10::toString(t), "'");
+    }
+    return -1;
+}
+
+template <int ND> Tensor qshift_forward_hip(const Tensor &input, const Tensor &weights, const Tensor &borders,
+                                            at::IntArrayRef new_size, int64_t padding_mode, bool /*active_flag*/) {
+    TORCH_CHECK(input.is_cuda() && input.is_quantized(), "input must be a quantized CUDA tensor");
+    TORCH_CHECK(weights.is_quantized(), "weights must be a quantized tensor");
+    TORCH_CHECK(input.dim() == ND + 2, "shift", ND, "d: expected a ", ND + 2, "-D input");
+    if (padding_mode < 0 || padding_mode > 4) return Tensor();
+    c10::DeviceGuard device_guard(input.device());
+    const int dtype = quant_dtype(input.scalar_type(), "q_shiftnd_cuda");
+    const int wdtype = quant_dtype(weights.scalar_type(), "q_shiftnd_cuda");
+    int32_t b[6];
+    read_borders(borders, b);
+    Tensor wrepr = weights.int_repr().to(input.device()).contiguous();
+    TORCH_CHECK(wrepr.dim() == 2 && wrepr.size(0) == input.size(1) && wrepr.size(1) == ND,
+                "shift", ND, "d: weights must have shape [C, ", ND, "]");
+    const bool cl = input.is_contiguous(at::MemoryFormat::ChannelsLast) || input.is_contiguous(at::MemoryFormat::ChannelsLast3d);
+    Tensor output = cl ? at::_empty_affine_quantized(new_size, input.options().memory_format(input.suggest_memory_format()),
+                                                     input.q_scale(), input.q_zero_point(), c10::nullopt)
+                       : at::_empty_affine_quantized(new_size, input.options(), input.q_scale(), input.q_zero_point());
+    shiftnd_problem p;
+    fill_problem(p, ND, input, b, padding_mode, false, dtype);
+    int64_t xs[5], os[5];
+    fill_strides(input, ND, xs);
+    fill_strides(output, ND, os);
+    const int rc = shiftnd_forward_quantized(&p, input.data_ptr(), xs, wrepr.data_ptr(), wdtype, weights.q_zero_point(),
+                                             input.q_zero_point(), output.data_ptr(), os, current_stream(input));
+    TORCH_CHECK(rc == SHIFTND_OK, "shiftnd_forward_quantized (HIP): ", shiftnd_status_string(rc));
+    return output;
+}
+
+std::tuple<Tensor, Tensor> qshift_backward(const Tensor &, const Tensor &, const Tensor &, const Tensor &, int64_t, bool) {
+    TORCH_CHECK(0, "backwards on quantized tensor are not supported");
+}
+
+int64_t cuda_version() { return -1; }  // no CUDA toolkit: extension.py only compares when torch.version.cuda is set
+int64_t hip_version() { return HIP_VERSION; }
+
+}  // namespace torchshifts_amd
+
+using namespace torchshifts_amd;
+
+TORCH_LIBRARY(torchshifts, m) {
+    m.def("_cuda_version", &cuda_version);
+    m.def("_hip_version", &hip_version);
+    m.def("shift1d", &shift_public<1>);
+    m.def("shift2d", &shift_public<2>);
+    m.def("shift3d", &shift_public<3>);
+    m.def("_check_borders", &check_borders_op);
+    m.def("torchshifts::_shift1d_forward(Tensor input, Tensor weights, Tensor borders, int[] new_size, int padding_mode, bool active_flag) -> Tensor");
+    m.def("torchshifts::_shift1d_backward(Tensor grad, Tensor weights, Tensor input, Tensor borders, int padding_mode, bool active_flag) -> (Tensor, Tensor)");
+    m.def("torchshifts::_shift2d_forward(Tensor input, Tensor weights, Tensor borders, int[] new_size, int padding_mode, bool active_flag) -> Tensor");
+    m.def("torchshifts::_shift2d_backward(Tensor grad, Tensor weights, Tensor input, Tensor borders, int padding_mode, bool active_flag) -> (Tensor, Tensor)");
+    m.def("torchshifts::_shift3d_forward(Tensor input, Tensor weights, Tensor borders, int[] new_size, int padding_mode, bool active_flag) -> Tensor");
+    m.def("torchshifts::_shift3d_backward(Tensor grad, Tensor weights, Tensor input, Tensor borders, int padding_mode, bool active_flag) -> (Tensor, Tensor)");
+}
+
+TORCH_LIBRARY_IMPL(torchshifts, Autograd, m) {
+    m.impl("_shift1d_forward", TORCH_FN(shift_autograd<1>));
+    m.impl("_shift1d_backward", TORCH_FN(shift_autograd_backward<1>));
+    m.impl("_shift2d_forward", TORCH_FN(shift_autograd<2>));
+    m.impl("_shift2d_backward", TORCH_FN(shift_autograd_backward<2>));
+    m.impl("_shift3d_forward", TORCH_FN(shift_autograd<3>));
+    m.impl("_shift3d_backward", TORCH_FN(shift_autograd_backward<3>));
+}
+
+TORCH_LIBRARY_IMPL(torchshifts, CUDA, m) {
+    m.impl("_shift1d_forward", TORCH_FN(shift_forward_hip<1>));
+    m.impl("_shift1d_backward", TORCH_FN(shift_backward_hip<1>));
+    m.impl("_shift2d_forward", TORCH_FN(shift_forward_hip<2>));
+    m.impl("_shift2d_backward", TORCH_FN(shift_backward_hip<2>));
+    m.impl("_shift3d_forward", TORCH_FN(shift_forward_hip<3>));
+    m.impl("_shift3d_backward", TORCH_FN(shift_backward_hip<3>));
+}
+
+TORCH_LIBRARY_IMPL(torchshifts, QuantizedCUDA, m) {
+    m.impl("_shift1d_forward", TORCH_FN(qshift_forward_hip<1>));
+    m.impl("_shift1d_backward", TORCH_FN(qshift_backward));
+    m.impl("_shift2d_forward", TORCH_FN(qshift_forward_hip<2>));
+    m.impl("_shift2d_backward", TORCH_FN(qshift_backward));
+    m.impl("_shift3d_forward", TORCH_FN(qshift_forward_hip<3>));
+    m.impl("_shift3d_backward", TORCH_FN(qshift_backward));
+}

@@ -1,0 +1,163 @@
+"""ctypes binding of the C ABI in include/shiftnd_hip.h (libshiftnd_hip.so).
+
+This is the thinnest possible host side: it hands raw device pointers, sizes and strides of torch
+tensors to the library.  The dispatcher ops in `_C.so` call exactly the same entry points; tests and
+bench.py use this module to reach the kernels without dispatcher/allocator overhead.
+"""
+import ctypes
+import os
+
+import torch
+
+_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libshiftnd_hip.so")
+
+F32, F64, F16, BF16, I8, U8, I32 = range(7)
+PATH_NONE, PATH_EMPTY, PATH_PLANE, PATH_STRIDED = range(4)
+
+DTYPES = {torch.float32: F32, torch.float64: F64, torch.float16: F16, torch.bfloat16: BF16,
+          torch.int8: I8, torch.uint8: U8, torch.int32: I32}
+
+EXPORTS = ["shiftnd_abi_version", "shiftnd_status_string", "shiftnd_last_path", "shiftnd_set_path_policy",
+           "shiftnd_check_borders", "shiftnd_forward", "shiftnd_backward_workspace_bytes", "shiftnd_backward",
+           "shiftnd_forward_quantized"]
+
+
+class Problem(ctypes.Structure):
+    _fields_ = [("ndim", ctypes.c_int32), ("dtype", ctypes.c_int32), ("padding_mode", ctypes.c_int32),
+                ("active", ctypes.c_int32), ("sizes", ctypes.c_int64 * 5), ("borders", ctypes.c_int32 * 6)]
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        L = ctypes.CDLL(_LIB_PATH)
+        i64p = ctypes.POINTER(ctypes.c_int64)
+        vp = ctypes.c_void_p
+        L.shiftnd_abi_version.restype = ctypes.c_int
+        L.shiftnd_status_string.restype = ctypes.c_char_p
+        L.shiftnd_status_string.argtypes = [ctypes.c_int]
+        L.shiftnd_last_path.restype = ctypes.c_int
+        L.shiftnd_set_path_policy.argtypes = [ctypes.c_int]
+        L.shiftnd_check_borders.restype = ctypes.c_int
+        L.shiftnd_check_borders.argtypes = [i64p, ctypes.c_int, ctypes.POINTER(ctypes.c_int32), ctypes.c_int,
+                                            ctypes.POINTER(ctypes.c_int32), i64p]
+        L.shiftnd_forward.restype = ctypes.c_int
+        L.shiftnd_forward.argtypes = [ctypes.POINTER(Problem), vp, i64p, vp, vp, i64p, vp]
+        L.shiftnd_backward_workspace_bytes.restype = ctypes.c_size_t
+        L.shiftnd_backward_workspace_bytes.argtypes = [ctypes.POINTER(Problem)]
+        L.shiftnd_backward.restype = ctypes.c_int
+        L.shiftnd_backward.argtypes = [ctypes.POINTER(Problem), vp, i64p, vp, i64p, vp, vp, i64p, vp, vp,
+                                       ctypes.c_size_t, vp]
+        L.shiftnd_forward_quantized.restype = ctypes.c_int
+        L.shiftnd_forward_quantized.argtypes = [ctypes.POINTER(Problem), vp, i64p, vp, ctypes.c_int32, ctypes.c_int64,
+                                                ctypes.c_int64, vp, i64p, vp]
+        _lib = L
+    return _lib
+
+
+def check(rc, what):
+    if rc != 0:
+        raise RuntimeError("%s failed: %s (%d)" % (what, lib().shiftnd_status_string(rc).decode(), rc))
+
+
+def strides5(t):
+    s = list(t.stride()) + [0] * (5 - t.dim())
+    return (ctypes.c_int64 * 5)(*s)
+
+
+def default_borders(x):
+    nd = x.dim() - 2
+    b = []
+    for d in range(3):
+        b += [0, x.shape[2 + d] if d < nd else 1]
+    return b
+
+
+def check_borders(sizes, user, ndim):
+    sizes_a = (ctypes.c_int64 * len(sizes))(*sizes)
+    out = (ctypes.c_int32 * 6)()
+    new = (ctypes.c_int64 * len(sizes))()
+    up = None
+    if user is not None:
+        flat = [int(v) for row in user for v in row]
+        up = (ctypes.c_int32 * len(flat))(*flat)
+    check(lib().shiftnd_check_borders(sizes_a, len(sizes), up, ndim, out, new), "shiftnd_check_borders")
+    shift = 1 if ndim + 1 == len(sizes) else 2
+    return list(out), list(new)[:shift + min(ndim, 3)]
+
+
+def problem(x, pad, active, borders, dtype=None):
+    p = Problem()
+    p.ndim = x.dim() - 2
+    p.dtype = DTYPES[x.dtype] if dtype is None else dtype
+    p.padding_mode = int(pad)
+    p.active = int(bool(active))
+    for i in range(5):
+        p.sizes[i] = x.shape[i] if i < x.dim() else 1
+    for i, v in enumerate(default_borders(x) if borders is None else borders):
+        p.borders[i] = int(v)
+    return p
+
+
+def out_shape(x, borders):
+    nd = x.dim() - 2
+    b = default_borders(x) if borders is None else borders
+    return list(x.shape[:2]) + [b[2 * d + 1] - b[2 * d] for d in range(nd)]
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def forward(x, w, pad, active, borders=None, out=None):
+    """x, w: device tensors (float dtypes).  Returns a new contiguous output (or fills `out`)."""
+    p = problem(x, pad, active, borders)
+    if out is None:
+        out = torch.empty(out_shape(x, borders), dtype=x.dtype, device=x.device)
+    w = w.contiguous()
+    check(lib().shiftnd_forward(ctypes.byref(p), x.data_ptr(), strides5(x), w.data_ptr(), out.data_ptr(), strides5(out),
+                                _stream()), "shiftnd_forward")
+    return out
+
+
+def backward_workspace(x, pad, active, borders=None):
+    p = problem(x, pad, active, borders)
+    return torch.empty(int(lib().shiftnd_backward_workspace_bytes(ctypes.byref(p))), dtype=torch.uint8, device=x.device)
+
+
+def backward(grad_out, w, x, pad, active, borders=None, grad_x=None, grad_w=None, workspace=None):
+    p = problem(x, pad, active, borders)
+    w = w.contiguous()
+    if grad_x is None:
+        grad_x = torch.empty_like(x, memory_format=torch.contiguous_format)
+    if grad_w is None:
+        grad_w = torch.empty_like(w)
+    if workspace is None:
+        workspace = backward_workspace(x, pad, active, borders)
+    check(lib().shiftnd_backward(ctypes.byref(p), grad_out.data_ptr(), strides5(grad_out), x.data_ptr(), strides5(x),
+                                 w.data_ptr(), grad_x.data_ptr(), strides5(grad_x), grad_w.data_ptr(),
+                                 workspace.data_ptr(), workspace.numel(), _stream()), "shiftnd_backward")
+    return grad_x, grad_w
+
+
+def forward_quantized(xq, wq, w_zero_point, x_zero_point, pad, borders=None, out=None):
+    """xq: int8/uint8/int32 device tensor (int_repr); wq: int8/uint8/int32 device tensor [C, nd]."""
+    p = problem(xq, pad, False, borders)
+    if out is None:
+        out = torch.empty(out_shape(xq, borders), dtype=xq.dtype, device=xq.device)
+    wq = wq.contiguous()
+    check(lib().shiftnd_forward_quantized(ctypes.byref(p), xq.data_ptr(), strides5(xq), wq.data_ptr(), DTYPES[wq.dtype],
+                                          int(w_zero_point), int(x_zero_point), out.data_ptr(), strides5(out), _stream()),
+          "shiftnd_forward_quantized")
+    return out
+
+
+def last_path():
+    return lib().shiftnd_last_path()
+
+
+def set_path_policy(policy):
+    lib().shiftnd_set_path_policy(int(policy))

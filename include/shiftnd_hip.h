@@ -46,6 +46,7 @@ extern "C" {
 #endif
 
 #define SHIFTND_ABI_VERSION 1
+#define SHIFTND_API __attribute__((visibility("default")))
 
 typedef enum shiftnd_dtype {
     SHIFTND_F32 = 0,
@@ -84,25 +85,25 @@ typedef struct shiftnd_problem {
     int32_t borders[6];    /* l_i, r_i, l_j, r_j, l_k, r_k (unused dims: 0, 1) */
 } shiftnd_problem;
 
-int shiftnd_abi_version(void);
-const char *shiftnd_status_string(int status);
-int shiftnd_last_path(void);
+SHIFTND_API int shiftnd_abi_version(void);
+SHIFTND_API const char *shiftnd_status_string(int status);
+SHIFTND_API int shiftnd_last_path(void);
 /* 0 = automatic, 1 = force the strided fallback (testing), 2 = force plane kernels or fail. */
-void shiftnd_set_path_policy(int policy);
+SHIFTND_API void shiftnd_set_path_policy(int policy);
 
 /*
  * Host helper: the reference's check_borders (shifts.cpp:93-135).
  * sizes/nsizes: full tensor shape; user: ndim x 2 cut amounts (left, right) or NULL for no crop.
  * Writes borders[6] and new_sizes[nsizes].
  */
-int shiftnd_check_borders(const int64_t *sizes, int nsizes, const int32_t *user, int ndim,
+SHIFTND_API int shiftnd_check_borders(const int64_t *sizes, int nsizes, const int32_t *user, int ndim,
                           int32_t borders[6], int64_t *new_sizes);
 
 /*
  * Forward, float dtypes (F32, F64, F16, BF16).
  * out has sizes {N, C, r_i-l_i, r_j-l_j, r_k-l_k}; out_strides are its element strides.
  */
-int shiftnd_forward(const shiftnd_problem *p,
+SHIFTND_API int shiftnd_forward(const shiftnd_problem *p,
                     const void *x, const int64_t x_strides[5],
                     const void *weights,
                     void *out, const int64_t out_strides[5],
@@ -114,9 +115,9 @@ int shiftnd_forward(const shiftnd_problem *p,
  * workspace: device scratch of at least shiftnd_backward_workspace_bytes(p) bytes
  * (fp64 partial sums of the weight gradient); its contents need not be initialised.
  */
-size_t shiftnd_backward_workspace_bytes(const shiftnd_problem *p);
+SHIFTND_API size_t shiftnd_backward_workspace_bytes(const shiftnd_problem *p);
 
-int shiftnd_backward(const shiftnd_problem *p,
+SHIFTND_API int shiftnd_backward(const shiftnd_problem *p,
                      const void *grad_out, const int64_t grad_out_strides[5],
                      const void *x, const int64_t x_strides[5],
                      const void *weights,
@@ -131,7 +132,7 @@ int shiftnd_backward(const shiftnd_problem *p,
  * wq_dtype (I8, U8 or I32); shift = wq - w_zero_point; scale is ignored
  * (kernels/shifts_kernels.h:553-555).  x_zero_point is the fill value (:569).
  */
-int shiftnd_forward_quantized(const shiftnd_problem *p,
+SHIFTND_API int shiftnd_forward_quantized(const shiftnd_problem *p,
                               const void *x, const int64_t x_strides[5],
                               const void *wq, int32_t wq_dtype, int64_t w_zero_point,
                               int64_t x_zero_point,

@@ -1,0 +1,252 @@
+"""GPU parity: the HIP kernels, called through the C ABI (torchshifts.abi -> libshiftnd_hip.so),
+against (a) the golden fixtures recorded from the real reference and (b) the CPU oracle
+(oracle/shift_oracle.c) on seeded random problems that engage every kernel family.
+
+Bars:
+  SSL forward, SSL grad_x, quantized ........ bit-exact
+  active forward / active grad_x, fp32/fp64 .. bit-exact (same expression order, no FMA contraction);
+                                               tolerance stated where used: 1e-5 relative
+  grad_w ..................................... <= 1e-5 relative to the fp64 oracle (exact fixtures: bit-exact)
+  fp16 / bf16 ................................ oracle in fp32 on widened inputs, rounded once (RNE):
+                                               SSL bit-exact; interpolation within 1 ulp of the 16-bit type
+"""
+import numpy as np
+import pytest
+import torch
+
+from cases import float_cases, quant_cases, rel_err
+from oracle import oracle as O
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda:0"
+
+
+@pytest.fixture(scope="module")
+def abi():
+    from torchshifts import abi as A
+    assert torch.cuda.is_available(), "the gpu tests need an MI355X"
+    yield A
+    A.set_path_policy(0)
+
+
+def _np_dt(dt):
+    return np.float32 if dt == "f32" else np.float64
+
+
+def _dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
+
+
+@pytest.mark.parametrize("policy", [0, 1])
+def test_golden_float_grid(abi, policy):
+    """120 reference cases x {automatic path, forced strided fallback}"""
+    abi.set_path_policy(policy)
+    for key, nd, dt, pad, active, crop, x, w, go_full, out_r, gx_r, gw_r in float_cases("g1_float.npz"):
+        b, _ = abi.check_borders(list(x.shape), crop, nd)
+        xd, wd = _dev(x), _dev(w)
+        out = abi.forward(xd, wd, pad, active, b)
+        assert np.array_equal(out.cpu().numpy(), out_r), "forward " + key
+        go = _dev(go_full[tuple(slice(0, s) for s in out_r.shape)])
+        gx, gw = abi.backward(go, wd, xd, pad, active, b)
+        assert np.array_equal(gx.cpu().numpy(), gx_r), "grad_x " + key
+        assert np.array_equal(gw.cpu().numpy(), gw_r), "grad_w (exact data) " + key
+    abi.set_path_policy(0)
+
+
+def test_golden_random_grid(abi):
+    for key, nd, dt, pad, active, crop, x, w, go_full, out_r, gx_r, gw_r in float_cases("g1_random.npz"):
+        b, _ = abi.check_borders(list(x.shape), crop, nd)
+        xd, wd = _dev(x), _dev(w)
+        out = abi.forward(xd, wd, pad, active, b)
+        assert np.array_equal(out.cpu().numpy(), out_r), "forward " + key
+        go = _dev(go_full[tuple(slice(0, s) for s in out_r.shape)])
+        gx, gw = abi.backward(go, wd, xd, pad, active, b)
+        assert np.array_equal(gx.cpu().numpy(), gx_r), "grad_x " + key
+        tol = 1e-12 if dt == "f64" else 1e-5
+        assert rel_err(gw.cpu().numpy(), gw_r) < tol, "grad_w " + key
+
+
+@pytest.mark.parametrize("policy", [0, 1])
+def test_golden_quantized(abi, policy):
+    abi.set_path_policy(policy)
+    tdt = {"quint8": torch.uint8, "qint8": torch.int8, "qint32": torch.int32}
+    for key, nd, xname, layout, wname, pad, crop, xq, xzp, wq, wzp, out_r in quant_cases():
+        x = torch.from_numpy(xq).to(tdt[xname]).to(DEV)
+        if layout == "cl":
+            x = x.contiguous(memory_format=torch.channels_last)
+        elif layout == "cl3d":
+            x = x.contiguous(memory_format=torch.channels_last_3d)
+        w = torch.from_numpy(wq).to(torch.uint8 if wname == "wu8" else torch.int8).to(DEV)
+        b, _ = abi.check_borders(list(xq.shape), crop, nd)
+        out = abi.forward_quantized(x, w, wzp, xzp, pad, b)
+        assert np.array_equal(out.cpu().numpy(), out_r), key
+        if policy == 0 and layout == "nchw":
+            assert abi.last_path() == abi.PATH_PLANE, key
+    abi.set_path_policy(0)
+
+
+# ---- seeded random problems vs the oracle: shapes with 16-byte rows so the plane kernels run ---------
+SHAPES = [
+    # (shape, crop or None)
+    ((3, 5, 40), None), ((2, 3, 64), [[3, 5]]),
+    ((3, 5, 9, 24), None), ((2, 4, 13, 32), [[2, 1], [4, 4]]), ((2, 3, 1, 16), None), ((1, 2, 300, 8), None),
+    ((2, 3, 5, 6, 16), None), ((2, 2, 4, 7, 24), [[1, 0], [0, 2], [4, 4]]), ((1, 3, 1, 5, 8), None),
+]
+
+
+def _weights(rs, C, nd, sizes):
+    w = rs.uniform(-4.5, 4.5, size=(C, nd))
+    w[0, :] = [0.5, -1.5, 2.5][:nd]          # exact halves: round-half-even
+    if C > 1:
+        w[1, :] = [s + 2.25 for s in sizes]  # beyond the dim: multi-wrap
+    if C > 2:
+        w[2, :] = [-(2 * s + 0.75) for s in sizes]
+    return w
+
+
+@pytest.mark.parametrize("dt", ["f32", "f64"])
+@pytest.mark.parametrize("shape,crop", SHAPES)
+def test_random_vs_oracle(abi, shape, crop, dt):
+    rs = np.random.RandomState(sum(shape) * 131 + len(shape) + (dt == "f64"))
+    nd = len(shape) - 2
+    npdt = _np_dt(dt)
+    x = rs.uniform(-1, 1, size=shape).astype(npdt)
+    w = _weights(rs, shape[1], nd, shape[2:]).astype(npdt)
+    b, new = abi.check_borders(list(shape), crop, nd)
+    go = rs.uniform(-1, 1, size=new).astype(npdt)
+    xd, wd, god = _dev(x), _dev(w), _dev(go)
+    for pad in range(5):
+        for active in (0, 1):
+            out = abi.forward(xd, wd, pad, active, b)
+            inner_bytes = new[-1] * x.itemsize
+            if active == 0 or inner_bytes % 16 == 0:
+                assert abi.last_path() == abi.PATH_PLANE
+            assert np.array_equal(out.cpu().numpy(), O.forward(x, w, pad, active, b)), ("fwd", pad, active)
+            gx, gw = abi.backward(god, wd, xd, pad, active, b)
+            if (shape[-1] * x.itemsize) % 16 == 0:
+                assert abi.last_path() == abi.PATH_PLANE
+            gx_o, _ = O.backward(go, w, x, pad, active, b)
+            assert np.array_equal(gx.cpu().numpy(), gx_o), ("gx", pad, active)
+            # grad_w truth: the oracle in fp64 on the same values
+            _, gw64 = O.backward(go.astype(np.float64), w.astype(np.float64), x.astype(np.float64), pad, active, b)
+            assert rel_err(gw.cpu().numpy(), gw64) < (1e-12 if dt == "f64" else 1e-5), ("gw", pad, active)
+            # the two kernel families agree bit for bit on forward / grad_x
+            abi.set_path_policy(1)
+            out2 = abi.forward(xd, wd, pad, active, b)
+            gx2, gw2 = abi.backward(god, wd, xd, pad, active, b)
+            abi.set_path_policy(0)
+            assert torch.equal(out, out2) and torch.equal(gx, gx2)
+            assert rel_err(gw2.cpu().numpy(), gw64) < (1e-12 if dt == "f64" else 1e-5)
+
+
+def _ulp_close(a, ref, tdt):
+    """|a - ref| <= 1 ulp of the 16-bit type at ref"""
+    a32, r32 = a.float(), ref.float()
+    eps = torch.finfo(tdt).eps
+    ulp = torch.clamp(r32.abs(), min=torch.finfo(tdt).tiny) * eps
+    return bool(((a32 - r32).abs() <= ulp * 1.0001).all())
+
+
+@pytest.mark.parametrize("tdt", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("shape,crop", [((3, 5, 48), None), ((2, 4, 11, 32), [[2, 1], [8, 8]]), ((2, 3, 4, 6, 16), None),
+                                        ((2, 3, 7, 10), None)])
+def test_half_precision_vs_oracle(abi, shape, crop, tdt):
+    rs = np.random.RandomState(7)
+    nd = len(shape) - 2
+    x16 = torch.from_numpy(rs.uniform(-1, 1, size=shape).astype(np.float32)).to(tdt)
+    w16 = torch.from_numpy(_weights(rs, shape[1], nd, shape[2:]).astype(np.float32)).to(tdt)
+    b, new = abi.check_borders(list(shape), crop, nd)
+    go16 = torch.from_numpy(rs.uniform(-1, 1, size=new).astype(np.float32)).to(tdt)
+    x, w, go = x16.float().numpy(), w16.float().numpy(), go16.float().numpy()  # widened, exactly
+    xd, wd, god = x16.to(DEV), w16.to(DEV), go16.to(DEV)
+    for pad in range(5):
+        for active in (0, 1):
+            out = abi.forward(xd, wd, pad, active, b).cpu()
+            ref = torch.from_numpy(O.forward(x, w, pad, active, b)).to(tdt)  # one RNE rounding
+            gx, gw = abi.backward(god, wd, xd, pad, active, b)
+            gx_o, _ = O.backward(go, w, x, pad, active, b)
+            gx_ref = torch.from_numpy(gx_o).to(tdt)
+            if active == 0:
+                assert torch.equal(out, ref) and torch.equal(gx.cpu(), gx_ref), (pad, active)
+            else:
+                assert _ulp_close(out, ref, tdt) and _ulp_close(gx.cpu(), gx_ref, tdt), (pad, active)
+            _, gw64 = O.backward(go.astype(np.float64), w.astype(np.float64), x.astype(np.float64), pad, active, b)
+            assert rel_err(gw.float().cpu().numpy(), gw64) < 2 * torch.finfo(tdt).eps, ("gw", pad, active)
+
+
+def test_quantized_random_vs_oracle(abi):
+    rs = np.random.RandomState(11)
+    for shape, crop, tdt, npdt, zp in [((4, 6, 56, 56), None, torch.uint8, np.uint8, 3),
+                                       ((3, 5, 17, 24), [[1, 2], [8, 0]], torch.int8, np.int8, -5),
+                                       ((2, 3, 9, 5, 16), None, torch.uint8, np.uint8, 128),
+                                       ((2, 4, 33), None, torch.int32, np.int32, 7),
+                                       ((2, 3, 13, 7), None, torch.int8, np.int8, 0)]:
+        nd = len(shape) - 2
+        info = np.iinfo(npdt)
+        xq = rs.randint(max(info.min, -1000), min(info.max, 1000) + 1, size=shape).astype(npdt)
+        wq = rs.randint(118, 139, size=(shape[1], nd)).astype(np.uint8)
+        wq[0, :] = 128 + shape[-1] + 3  # shift beyond the dim
+        b, new = abi.check_borders(list(shape), crop, nd)
+        for pad in range(5):
+            out = abi.forward_quantized(torch.from_numpy(xq).to(tdt).to(DEV), torch.from_numpy(wq).to(DEV), 128, zp, pad, b)
+            assert abi.last_path() == abi.PATH_PLANE
+            assert np.array_equal(out.cpu().numpy(), O.forward_q(xq, wq, 128, zp, pad, b)), (shape, pad)
+
+
+def test_strided_inputs_and_empty(abi):
+    """channels-last / sliced inputs take the strided path and equal the contiguous result; empty tensors are no-ops"""
+    torch.manual_seed(0)
+    x = torch.rand(3, 6, 10, 16, device=DEV)
+    w = (torch.rand(6, 2, device=DEV) - 0.5) * 6
+    go = torch.rand(3, 6, 10, 16, device=DEV)
+    for pad in range(5):
+        for active in (0, 1):
+            ref = abi.forward(x, w, pad, active)
+            xcl = x.contiguous(memory_format=torch.channels_last)
+            out = abi.forward(xcl, w, pad, active)
+            assert abi.last_path() == abi.PATH_STRIDED and torch.equal(out, ref)
+            xs = torch.rand(3, 6, 10, 32, device=DEV)[..., ::2]
+            assert torch.equal(abi.forward(xs, w, pad, active), abi.forward(xs.contiguous(), w, pad, active))
+            gref = abi.backward(go, w, x, pad, active)
+            gx, gw = abi.backward(go.contiguous(memory_format=torch.channels_last), w, xcl, pad, active)
+            assert torch.equal(gx, gref[0]) and rel_err(gw.cpu().numpy(), gref[1].cpu().numpy()) < 1e-5
+            # expanded (stride-0) incoming gradient, as produced by out.sum().backward()
+            ones = torch.ones(1, device=DEV).expand(3, 6, 10, 16)
+            gx1, gw1 = abi.backward(ones, w, x, pad, active)
+            gx2, gw2 = abi.backward(torch.ones(3, 6, 10, 16, device=DEV), w, x, pad, active)
+            assert torch.equal(gx1, gx2) and rel_err(gw1.cpu().numpy(), gw2.cpu().numpy()) < 1e-5
+    e = torch.empty(0, 6, 10, 16, device=DEV)
+    assert abi.forward(e, w, 0, 0).shape == (0, 6, 10, 16) and abi.last_path() == abi.PATH_EMPTY
+    gx, gw = abi.backward(e, w, e, 0, 0)
+    assert gx.numel() == 0 and bool((gw == 0).all())
+
+
+def test_large_plane_band_split_and_wide_rows(abi):
+    """few large planes -> row bands; rows wider than one workgroup pass (cpr > 256)"""
+    rs = np.random.RandomState(5)
+    for shape in [(1, 2, 600, 64), (1, 1, 6, 4400), (2, 1, 3, 2048)]:
+        x = rs.uniform(-1, 1, size=shape).astype(np.float32)
+        w = rs.uniform(-3, 3, size=(shape[1], 2)).astype(np.float32)
+        go = rs.uniform(-1, 1, size=shape).astype(np.float32)
+        xd, wd, god = _dev(x), _dev(w), _dev(go)
+        for pad in (0, 2, 3):
+            for active in (0, 1):
+                out = abi.forward(xd, wd, pad, active)
+                assert abi.last_path() == abi.PATH_PLANE
+                assert np.array_equal(out.cpu().numpy(), O.forward(x, w, pad, active))
+                gx, gw = abi.backward(god, wd, xd, pad, active)
+                gx_o, _ = O.backward(go, w, x, pad, active)
+                _, gw64 = O.backward(go.astype(np.float64), w.astype(np.float64), x.astype(np.float64), pad, active)
+                assert np.array_equal(gx.cpu().numpy(), gx_o) and rel_err(gw.cpu().numpy(), gw64) < 1e-5
+
+
+def test_deterministic_weight_grad(abi):
+    torch.manual_seed(3)
+    x = torch.rand(16, 8, 32, 32, device=DEV)
+    go = torch.rand(16, 8, 32, 32, device=DEV)
+    w = (torch.rand(8, 2, device=DEV) - 0.5) * 5
+    ref = abi.backward(go, w, x, 3, 1)
+    for _ in range(5):
+        got = abi.backward(go, w, x, 3, 1)
+        assert torch.equal(got[0], ref[0]) and torch.equal(got[1], ref[1])

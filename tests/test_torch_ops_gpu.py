@@ -1,0 +1,140 @@
+"""GPU: the drop-in operator surface (torch.ops.torchshifts.* on HIP tensors, autograd, modules,
+QuantizedCUDA) against the golden fixtures and against the same ops on CPU tensors."""
+import numpy as np
+import pytest
+import torch
+
+import torchshifts
+from torchshifts import Shift1d, Shift2d, Shift3d
+from cases import float_cases, quant_cases, rel_err
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+OPS = torch.ops.torchshifts
+
+
+def _op(nd):
+    return getattr(OPS, "shift%dd" % nd)
+
+
+def test_dispatcher_autograd_matches_golden():
+    for key, nd, dt, pad, active, crop, x, w, go_full, out_r, gx_r, gw_r in float_cases("g1_float.npz"):
+        xt = torch.from_numpy(x.copy()).to(DEV).requires_grad_(True)
+        wt = torch.from_numpy(w.copy()).to(DEV).requires_grad_(True)
+        b = torch.Tensor() if crop is None else torch.tensor(crop, dtype=torch.long)
+        out = _op(nd)(xt, wt, b, pad, bool(active))
+        assert out.is_cuda and out.is_contiguous()
+        go = torch.from_numpy(np.ascontiguousarray(go_full[tuple(slice(0, s) for s in out.shape)])).to(DEV)
+        out.backward(go)
+        assert np.array_equal(out.detach().cpu().numpy(), out_r), "forward " + key
+        assert np.array_equal(xt.grad.cpu().numpy(), gx_r), "grad_x " + key
+        assert np.array_equal(wt.grad.cpu().numpy(), gw_r), "grad_w " + key
+
+
+def test_quantized_cuda_key():
+    tdt = {"quint8": torch.uint8, "qint8": torch.int8, "qint32": torch.int32}
+    n = 0
+    for key, nd, xname, layout, wname, pad, crop, xq, xzp, wq, wzp, out_r in quant_cases(nds=(2, 3)):
+        if wname != "wu8":
+            continue
+        x = torch._make_per_tensor_quantized_tensor(torch.from_numpy(xq).to(tdt[xname]).to(DEV), 0.05, xzp)
+        if layout == "cl":
+            x = x.contiguous(memory_format=torch.channels_last)
+        elif layout == "cl3d":
+            x = x.contiguous(memory_format=torch.channels_last_3d)
+        w = torch._make_per_tensor_quantized_tensor(torch.from_numpy(wq).to(torch.uint8).to(DEV), 1.0, wzp)
+        b = torch.Tensor() if crop is None else torch.tensor(crop, dtype=torch.long)
+        out = _op(nd)(x, w, b, pad, False)
+        assert out.is_quantized and out.is_cuda and out.q_zero_point() == xzp
+        assert np.array_equal(out.int_repr().cpu().contiguous().numpy(), out_r), key
+        n += 1
+    assert n == 100
+    with pytest.raises(RuntimeError, match="backwards on quantized tensor are not supported"):
+        OPS._shift2d_backward(x, w, x, torch.tensor([0, 1, 0, 1, 0, 1], dtype=torch.int32), 0, False)
+
+
+def test_modules_gpu_vs_cpu():
+    """the scenario of the reference's tests/shifts_test.py (fwd + MSE + bwd, SSL and active, emulate_dw),
+    with real assertions: HIP == CPU backend"""
+    torch.manual_seed(0)
+    args = {'kernel_size': 3, 'stride': 1, 'padding': (0, 0)}
+    for active in (False, True):
+        m = Shift2d(16, init_shift=1, sparsity_term=0., active_flag=active, emulate_dw=dict(args), init_thumb_rule=2)
+        x = torch.rand(8, 16, 64, 64)
+        t = 10 * torch.rand(8, 16, 62, 62)
+        xc = x.clone().requires_grad_(True)
+        out_c, loss = m(xc)
+        assert loss is None and out_c.shape == (8, 16, 62, 62)
+        torch.nn.functional.mse_loss(out_c, t).backward()
+        gw_c, gx_c = m.weight.grad.clone(), xc.grad.clone()
+        m.zero_grad()
+        mg = m.to(DEV)
+        xg = x.to(DEV).requires_grad_(True)
+        out_g, _ = mg(xg)
+        torch.nn.functional.mse_loss(out_g, t.to(DEV)).backward()
+        assert torch.equal(out_g.cpu(), out_c.detach())
+        assert torch.allclose(xg.grad.cpu(), gx_c, rtol=1e-6, atol=1e-9)
+        assert mg.weight.grad is not None and rel_err(mg.weight.grad.cpu().numpy(), gw_c.numpy()) < 1e-5
+    # 1-D / 3-D modules, strided emulation (avg-pool tail), sparsity loss
+    m3 = Shift3d(4, padding='reflect', active_flag=True, emulate_dw={'kernel_size': 3, 'stride': 2, 'padding': 1}).to(DEV)
+    out, loss = m3(torch.rand(2, 4, 8, 8, 8, device=DEV))
+    assert out.shape == (2, 4, 4, 4, 4) and loss is not None and loss.is_cuda
+    m1 = Shift1d(3, padding='periodic').to(DEV)
+    out, _ = m1(torch.rand(2, 3, 64, device=DEV))
+    assert out.shape == (2, 3, 64)
+
+
+def test_quantized_module_gpu():
+    from torchshifts.quantized.modules import Shift2d as QShift2d
+    torch.manual_seed(1)
+    m = Shift2d(8, init_shift=2, sparsity_term=0.)
+    q = QShift2d.from_float(m)
+    x = torch.rand(4, 8, 24, 24)
+    xq = torch.quantize_per_tensor(x, 1 / 255., 0, torch.quint8)
+    ref = q(xq)  # QuantizedCPU key
+    q.qweight = q.qweight.to(DEV)
+    out = q(xq.to(DEV))
+    assert out.is_cuda and torch.equal(out.int_repr().cpu(), ref.int_repr())
+
+
+def test_error_behaviour_gpu():
+    x = torch.rand(2, 3, 8, 8, device=DEV)
+    w = torch.rand(3, 2, device=DEV)
+    with pytest.raises(RuntimeError, match="same type"):
+        OPS.shift2d(x, w.double(), torch.Tensor(), 0, False)
+    with pytest.raises(RuntimeError, match="weights must be a CUDA tensor"):
+        OPS._shift2d_forward(x, w.cpu(), torch.tensor([0, 8, 0, 8, 0, 1], dtype=torch.int32), [2, 3, 8, 8], 0, False)
+    with pytest.raises(AssertionError):
+        torchshifts.functional.shift2d_func(x, w.cpu(), 0, False)
+    with pytest.raises(RuntimeError, match="not implemented for 'Int'"):
+        OPS.shift2d(x.int(), w.int(), torch.Tensor(), 0, False)
+    # borders may live on the device (the reference passes them there); result unchanged
+    b = torch.tensor([1, 7, 0, 8, 0, 1], dtype=torch.int32)
+    a = OPS._shift2d_forward(x, w, b, [2, 3, 6, 8], 2, True)
+    c = OPS._shift2d_forward(x, w, b.to(DEV), [2, 3, 6, 8], 2, True)
+    assert torch.equal(a, c)
+
+
+def test_streams_and_graph_capture():
+    """kernels launch on the current stream and are capture-safe (no allocation / sync in the C ABI)"""
+    from torchshifts import abi
+    x = torch.rand(4, 8, 32, 32, device=DEV)
+    w = (torch.rand(8, 2, device=DEV) - 0.5) * 4
+    ref = abi.forward(x, w, 3, 1)
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        out = abi.forward(x, w, 3, 1)
+    s.synchronize()
+    assert torch.equal(out, ref)
+    out2 = torch.empty_like(ref)
+    gx, gw = torch.empty_like(x), torch.empty_like(w)
+    ws = abi.backward_workspace(x, 3, 1)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        abi.forward(x, w, 3, 1, out=out2)
+        abi.backward(ref, w, x, 3, 1, grad_x=gx, grad_w=gw, workspace=ws)
+    g.replay()
+    torch.cuda.synchronize()
+    gx_ref, gw_ref = abi.backward(ref, w, x, 3, 1)
+    assert torch.equal(out2, ref) and torch.equal(gx, gx_ref) and torch.equal(gw, gw_ref)

@@ -48,7 +48,7 @@ def test_quantized_cuda_key():
         assert out.is_quantized and out.is_cuda and out.q_zero_point() == xzp
         assert np.array_equal(out.int_repr().cpu().contiguous().numpy(), out_r), key
         n += 1
-    assert n == 100
+    assert n == 120
     with pytest.raises(RuntimeError, match="backwards on quantized tensor are not supported"):
         OPS._shift2d_backward(x, w, x, torch.tensor([0, 1, 0, 1, 0, 1], dtype=torch.int32), 0, False)
 

@@ -110,6 +110,8 @@ int shiftnd_last_path(void) { return g_last_path; }
 
 void shiftnd_set_path_policy(int policy) { g_policy = policy; }
 
+void shiftnd_set_tuning(int knob, int value) { plane_set_tuning(knob, value); }
+
 // check_borders, ops/shifts.cpp:93-135 (host arithmetic only)
 int shiftnd_check_borders(const int64_t *sizes, int nsizes, const int32_t *user, int ndim, int32_t borders[6],
                           int64_t *new_sizes) {
@@ -164,15 +166,15 @@ int shiftnd_forward_quantized(const shiftnd_problem *p, const void *x, const int
 }
 
 size_t shiftnd_backward_workspace_bytes(const shiftnd_problem *p) {
-    if (!p || p->ndim < 1 || p->ndim > 3) return 0;
-    // upper bound valid for both kernel families: one fp64 triple per (n, c) plane, and per row band
-    // when large planes are split (never more than max(N*C, 4096) groups, see make_plan)
-    const int64_t planes = (p->sizes[0] > 0 ? p->sizes[0] : 1) * (p->sizes[1] > 0 ? p->sizes[1] : 1);
-    const int64_t c = p->sizes[1] > 0 ? p->sizes[1] : 1;
-    int64_t groups = planes;
-    const int64_t banded = 4096 + 2 * c;  // bands are only used while C*groups*bands stays near 2048
-    if (groups < banded) groups = banded;
-    return static_cast<size_t>(groups) * 3 * sizeof(double);
+    if (!p) return 0;
+    // the layout of the partial-sum buffer depends only on the geometry: evaluate both families' plans
+    const int64_t unit[5] = {0, 0, 0, 0, 0};
+    Geometry g;
+    if (build_geometry(p, unit, unit, unit, g) != SHIFTND_OK) return 0;
+    if (g.N == 0 || g.C == 0 || g.S[0] * g.S[1] * g.S[2] == 0) return sizeof(double);
+    const size_t a = strided_backward_workspace(g);
+    const size_t b = plane_backward_workspace(g, p->dtype);
+    return a > b ? a : b;
 }
 
 int shiftnd_backward(const shiftnd_problem *p, const void *grad_out, const int64_t grad_out_strides[5], const void *x,

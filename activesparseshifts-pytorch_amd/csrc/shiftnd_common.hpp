@@ -180,17 +180,20 @@ __device__ __forceinline__ double block_sum(double v, double *scratch) {
 // partials layout: [group][C][3] doubles.  (Unnamed namespace: one private copy per translation unit.)
 namespace {
 template <typename T>
-__global__ void reduce_weight_grads(const double *__restrict__ partials, int groups, int C, int nd,
-                                    typename T::S *__restrict__ grad_w) {
-    const int t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= C * nd) return;
+__global__ __launch_bounds__(64) void reduce_weight_grads(const double *__restrict__ partials, int groups, int C, int nd,
+                                                           typename T::S *__restrict__ grad_w) {
+    // one wave per output element: lanes stride over the groups (fixed order), then a fixed shuffle tree
+    const int t = blockIdx.x;
     const int c = t / nd, s = t - c * nd;
     double acc = 0.0;
-    for (int g = 0; g < groups; ++g) acc += partials[(static_cast<size_t>(g) * C + c) * 3 + s];
-    if constexpr (sizeof(typename T::S) == 8) {
-        grad_w[t] = acc;
-    } else {
-        grad_w[t] = narrow<T>(static_cast<float>(acc));
+    for (int g = threadIdx.x; g < groups; g += 64) acc += partials[(static_cast<size_t>(g) * C + c) * 3 + s];
+    acc = wave_sum(acc);
+    if (threadIdx.x == 0) {
+        if constexpr (sizeof(typename T::S) == 8) {
+            grad_w[t] = acc;
+        } else {
+            grad_w[t] = narrow<T>(static_cast<float>(acc));
+        }
     }
 }
 }  // namespace

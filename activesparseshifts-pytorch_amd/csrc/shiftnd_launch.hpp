@@ -32,6 +32,7 @@ int strided_backward(const Geometry &g, int dtype, const void *go, const void *x
 // ---- per-plane kernels (shiftnd_plane.hip) -------------------------------------------------------
 // *_eligible: contiguous NC[spatial] tensors, maps fit in LDS, planes < 2^31 elements, and (for the
 // interpolating kernels) rows made of whole 16-byte chunks.
+void plane_set_tuning(int knob, int value);
 bool plane_forward_eligible(const Geometry &g, int dtype, const void *x, const void *out);
 int plane_forward(const Geometry &g, int dtype, const void *x, const void *w, int wkind, int64_t wzp,
                   uint64_t fill_bits, void *out, hipStream_t st);

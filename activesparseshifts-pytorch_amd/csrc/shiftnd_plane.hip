@@ -472,6 +472,10 @@ bool contiguous(const int64_t st[5], int64_t N, int64_t C, const int64_t sz[3]) 
     return true;
 }
 
+// diagnostics knobs (shiftnd_set_tuning): 0 = min workgroups wanted, 1 = target bytes per workgroup,
+// 2 = gather-forward unroll (fp32/16-byte variant only)
+int g_tune[8] = {2048, 128 * 1024, 4, 0, 0, 0, 0, 0};
+
 struct Plan {
     int V, cpr, CW, RPS, CP, ppw, groups, bands, rows_per_band, rows;
     size_t lds;
@@ -484,22 +488,24 @@ Plan make_plan(const Geometry &g, int64_t rows, int64_t inner, int esize, int V,
     pl.V = V;
     pl.rows = static_cast<int>(rows);
     pl.cpr = static_cast<int>(inner * esize / V);
+    if (pl.cpr < 1) pl.cpr = 1;  // only reachable for ineligible geometries (workspace sizing)
     pl.CW = pl.cpr < kThreads ? pl.cpr : kThreads;
     pl.RPS = kThreads / pl.CW;
     pl.CP = (pl.cpr + pl.CW - 1) / pl.CW;
     const int64_t plane_bytes = rows * inner * esize;
-    int64_t ppw = (128 * 1024) / (plane_bytes > 0 ? plane_bytes : 1);
+    const int64_t min_wgs = g_tune[0];
+    int64_t ppw = g_tune[1] / (plane_bytes > 0 ? plane_bytes : 1);
     if (ppw < 1) ppw = 1;
     if (ppw > g.N) ppw = g.N;
     auto ngroups = [&](int64_t q) { return (g.N + q - 1) / q; };
-    while (ppw > 1 && g.C * ngroups(ppw) < 2048) ppw = (ppw + 1) / 2;
+    while (ppw > 1 && g.C * ngroups(ppw) < min_wgs) ppw = (ppw + 1) / 2;
     pl.ppw = static_cast<int>(ppw);
     pl.groups = static_cast<int>(ngroups(ppw));
     // few, large planes: cut each plane into row bands so that >= ~2048 workgroups exist
     int64_t bands = 1;
     const int64_t wgs = g.C * pl.groups;
-    if (wgs < 2048 && ppw == 1) {
-        bands = (2048 + wgs - 1) / wgs;
+    if (wgs < min_wgs && ppw == 1) {
+        bands = (min_wgs + wgs - 1) / wgs;
         const int64_t min_rows = static_cast<int64_t>(pl.RPS) * 4;  // at least 4 row steps per band
         const int64_t max_bands = rows / (min_rows > 0 ? min_rows : 1);
         if (bands > max_bands) bands = max_bands;
@@ -558,6 +564,14 @@ int gather_vector_bytes(const Geometry &g, int esize, const void *out) {
 
 template <int ESIZE, int V>
 void launch_gather(const PlaneParams &p, const Plan &pl, hipStream_t st) {
+    if constexpr (ESIZE == 4 && V == 16) {
+        switch (g_tune[2]) {
+        case 1: hipLaunchKernelGGL((plane_gather_forward<ESIZE, V, 1>), dim3(pl.grid), dim3(kThreads), pl.lds, st, p); return;
+        case 2: hipLaunchKernelGGL((plane_gather_forward<ESIZE, V, 2>), dim3(pl.grid), dim3(kThreads), pl.lds, st, p); return;
+        case 8: hipLaunchKernelGGL((plane_gather_forward<ESIZE, V, 8>), dim3(pl.grid), dim3(kThreads), pl.lds, st, p); return;
+        default: break;
+        }
+    }
     hipLaunchKernelGGL((plane_gather_forward<ESIZE, V, 4>), dim3(pl.grid), dim3(kThreads), pl.lds, st, p);
 }
 
@@ -585,8 +599,8 @@ int launch_backward(const PlaneParams &p, const Plan &pl, bool active, void *gw,
     if (active) launch_backward_a<T, true>(p, pl, st);
     else launch_backward_a<T, false>(p, pl, st);
     const int cn = p.C * p.nd;
-    hipLaunchKernelGGL((reduce_weight_grads<T>), dim3((cn + 255) / 256), dim3(256), 0, st, p.partials,
-                       pl.groups * pl.bands, p.C, p.nd, static_cast<typename T::S *>(gw));
+    hipLaunchKernelGGL((reduce_weight_grads<T>), dim3(cn), dim3(64), 0, st, p.partials, pl.groups * pl.bands, p.C, p.nd,
+                       static_cast<typename T::S *>(gw));
     return SHIFTND_OK;
 }
 
@@ -596,6 +610,10 @@ Plan backward_plan(const Geometry &g, int esize) {
 }
 
 }  // namespace
+
+void plane_set_tuning(int knob, int value) {
+    if (knob >= 0 && knob < 8) g_tune[knob] = value;
+}
 
 bool plane_forward_eligible(const Geometry &g, int dtype, const void *x, const void *out) {
     (void)x;

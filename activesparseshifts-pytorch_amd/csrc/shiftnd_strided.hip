@@ -211,8 +211,8 @@ int launch_strided_backward_nd(const Geometry &g, const void *go, const void *x,
                            static_cast<const S *>(go), static_cast<const S *>(x), static_cast<const S *>(w),
                            static_cast<S *>(gx), partials);
     const int cn = static_cast<int>(g.C) * g.nd;
-    hipLaunchKernelGGL((reduce_weight_grads<T>), dim3((cn + 255) / 256), dim3(256), 0, st, partials,
-                       static_cast<int>(g.N), static_cast<int>(g.C), g.nd, static_cast<S *>(gw));
+    hipLaunchKernelGGL((reduce_weight_grads<T>), dim3(cn), dim3(64), 0, st, partials, static_cast<int>(g.N),
+                       static_cast<int>(g.C), g.nd, static_cast<S *>(gw));
     return SHIFTND_OK;
 }
 

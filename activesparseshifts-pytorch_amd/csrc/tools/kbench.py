@@ -1,0 +1,84 @@
+#!/usr/bin/env python3
+"""Kernel-level A/B timing on the GPU box (HIP events, interleaved rounds in one process).
+
+    python tools/kbench.py [--workload c2] [--rounds 5] [--iters 10] [--knobs "0=2048,4096;2=1,2,4,8"]
+
+Times torch's own device copy (the practical HBM ceiling on this box), the forward and the backward
+kernel through the C ABI, for every combination given by --knobs (knob=value lists, see
+shiftnd_set_tuning).  Prints min/median ms and algorithmic GB/s.
+"""
+import argparse
+import itertools
+import os
+import statistics
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "activesparseshifts-pytorch_amd"))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+from bench import WORKLOADS, synth_tensor  # noqa: E402
+from torchshifts import abi  # noqa: E402
+
+
+def ev_time(fn, iters):
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    e1.synchronize()
+    return e0.elapsed_time(e1) / iters
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--workload", default="c2")
+    ap.add_argument("--rounds", type=int, default=5)
+    ap.add_argument("--iters", type=int, default=10)
+    ap.add_argument("--pad", type=int, default=0)
+    ap.add_argument("--knobs", default="")
+    ap.add_argument("--wrange", type=float, default=3.0)
+    a = ap.parse_args()
+    nd, shape, dtname, active, desc = WORKLOADS[a.workload]
+    dev = torch.device("cuda:0")
+    dtype = torch.float32 if dtname == "quint8" else getattr(torch, dtname)
+    x = synth_tensor(torch, shape, 1, dev, dtype)
+    go = synth_tensor(torch, shape, 2, dev, dtype)
+    w = synth_tensor(torch, (shape[1], nd), 3, dev, torch.float32, -a.wrange, a.wrange).to(dtype)
+    out, gx, gw = torch.empty_like(x), torch.empty_like(x), torch.empty_like(w)
+    elems, es = x.numel(), x.element_size()
+    knobs = []
+    for part in [p for p in a.knobs.split(";") if p]:
+        k, vals = part.split("=")
+        knobs.append((int(k), [int(v) for v in vals.split(",")]))
+    combos = list(itertools.product(*[[(k, v) for v in vals] for k, vals in knobs])) or [()]
+    variants = {"copy": lambda: out.copy_(x)}
+    res = {}
+    for r in range(a.rounds + 1):
+        for combo in combos:
+            for k, v in combo:
+                abi.set_tuning(k, v)
+            ws = abi.backward_workspace(x, a.pad, active)
+            tag = ",".join("%d=%d" % kv for kv in combo) or "default"
+            fns = {"fwd[" + tag + "]": lambda: abi.forward(x, w, a.pad, active, out=out),
+                   "bwd[" + tag + "]": lambda: abi.backward(go, w, x, a.pad, active, grad_x=gx, grad_w=gw, workspace=ws)}
+            if r == 0 or combo == combos[0]:
+                fns.update(variants)
+            for name, fn in fns.items():
+                fn()
+                torch.cuda.synchronize()
+                t = ev_time(fn, a.iters)
+                if r > 0:
+                    res.setdefault(name, []).append(t)
+    print("workload:", desc, "pad", a.pad)
+    for name, ts in res.items():
+        nbytes = {"c": 2, "f": 2, "b": 3}[name[0]] * es * elems
+        print("%-40s min %8.3f ms  med %8.3f ms  %8.1f GB/s (min)" % (name, min(ts), statistics.median(ts),
+                                                                       nbytes / min(ts) / 1e6))
+
+
+if __name__ == "__main__":
+    main()

@@ -18,6 +18,7 @@ DTYPES = {torch.float32: F32, torch.float64: F64, torch.float16: F16, torch.bflo
           torch.int8: I8, torch.uint8: U8, torch.int32: I32}
 
 EXPORTS = ["shiftnd_abi_version", "shiftnd_status_string", "shiftnd_last_path", "shiftnd_set_path_policy",
+           "shiftnd_set_tuning",
            "shiftnd_check_borders", "shiftnd_forward", "shiftnd_backward_workspace_bytes", "shiftnd_backward",
            "shiftnd_forward_quantized"]
 
@@ -41,6 +42,7 @@ def lib():
         L.shiftnd_status_string.argtypes = [ctypes.c_int]
         L.shiftnd_last_path.restype = ctypes.c_int
         L.shiftnd_set_path_policy.argtypes = [ctypes.c_int]
+        L.shiftnd_set_tuning.argtypes = [ctypes.c_int, ctypes.c_int]
         L.shiftnd_check_borders.restype = ctypes.c_int
         L.shiftnd_check_borders.argtypes = [i64p, ctypes.c_int, ctypes.POINTER(ctypes.c_int32), ctypes.c_int,
                                             ctypes.POINTER(ctypes.c_int32), i64p]
@@ -161,3 +163,8 @@ def last_path():
 
 def set_path_policy(policy):
     lib().shiftnd_set_path_policy(int(policy))
+
+
+def set_tuning(knob, value):
+    """diagnostics: launch-planning knobs (see include/shiftnd_hip.h)"""
+    lib().shiftnd_set_tuning(int(knob), int(value))

@@ -90,6 +90,9 @@ SHIFTND_API const char *shiftnd_status_string(int status);
 SHIFTND_API int shiftnd_last_path(void);
 /* 0 = automatic, 1 = force the strided fallback (testing), 2 = force plane kernels or fail. */
 SHIFTND_API void shiftnd_set_path_policy(int policy);
+/* Diagnostics: launch-planning knobs of the plane kernels (0: minimum workgroups wanted, 1: target
+ * bytes per workgroup, 2: gather-forward unroll).  Results never depend on them. */
+SHIFTND_API void shiftnd_set_tuning(int knob, int value);
 
 /*
  * Host helper: the reference's check_borders (shifts.cpp:93-135).

@@ -10,7 +10,7 @@ using namespace shiftnd;
 namespace {
 
 thread_local int g_last_path = SHIFTND_PATH_NONE;
-int g_policy = 0;  // 0 auto, 1 force strided, 2 require plane kernels
+int g_policy = 0;  // 0 auto, 1 force strided, 2 plane kernels (or fail), 3 sweep kernels (or fail)
 
 bool is_float_dtype(int dt) { return dt >= SHIFTND_F32 && dt <= SHIFTND_BF16; }
 bool is_quant_dtype(int dt) { return dt >= SHIFTND_I8 && dt <= SHIFTND_I32; }
@@ -78,8 +78,13 @@ int forward_common(const shiftnd_problem *p, const void *x, const int64_t *xs, c
     }
     if (!x || !w || !out) return SHIFTND_ERR_INVALID_ARGUMENT;
     hipStream_t st = static_cast<hipStream_t>(stream);
+    const bool can_sweep = sweep_forward_eligible(g, p->dtype, x, out);
     const bool can_plane = plane_forward_eligible(g, p->dtype, x, out);
-    if (g_policy == 2 && !can_plane) return SHIFTND_ERR_INVALID_ARGUMENT;
+    if ((g_policy == 2 && !can_plane) || (g_policy == 3 && !can_sweep)) return SHIFTND_ERR_INVALID_ARGUMENT;
+    if (can_sweep && (g_policy == 0 || g_policy == 3)) {
+        g_last_path = SHIFTND_PATH_SWEEP;
+        return finish(sweep_forward(g, p->dtype, x, w, wkind, wzp, fill, out, st));
+    }
     if (can_plane && g_policy != 1) {
         g_last_path = SHIFTND_PATH_PLANE;
         return finish(plane_forward(g, p->dtype, x, w, wkind, wzp, fill, out, st));
@@ -111,6 +116,10 @@ int shiftnd_last_path(void) { return g_last_path; }
 void shiftnd_set_path_policy(int policy) { g_policy = policy; }
 
 void shiftnd_set_tuning(int knob, int value) { plane_set_tuning(knob, value); }
+
+int shiftnd_debug_map(int64_t p, int64_t shift, int64_t len, int padding_mode) {
+    return sweep_debug_map(p, shift, len, padding_mode);
+}
 
 // check_borders, ops/shifts.cpp:93-135 (host arithmetic only)
 int shiftnd_check_borders(const int64_t *sizes, int nsizes, const int32_t *user, int ndim, int32_t borders[6],

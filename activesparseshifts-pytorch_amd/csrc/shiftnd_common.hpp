@@ -91,6 +91,48 @@ __host__ __device__ inline int64_t pad_index(int64_t idx, int64_t len, int pad) 
 }
 
 // ---------------------------------------------------------------------------------------------
+// Cheap per-element form of the same map, used by the sweep kernels (no tables):
+//   canon_shift() reduces a shift to a canonical representative with the same index map
+//   (zeros/border: clamped to [-len-1, len+1]; periodic: mod len; reflect: mod 2(len-1); symmetric:
+//   mod 2len), after which idx = p - shift lies within one period of [0, len) for every p in
+//   [0, len] and fold_index() needs at most two conditional folds.
+//   fold_index(p - canon_shift(s), len, pad) == pad_index(p - s, len, pad) for all p in [0, len];
+//   checked exhaustively on the host by tests/test_host_logic.py through shiftnd_debug_map().
+// ---------------------------------------------------------------------------------------------
+__host__ __device__ inline int canon_shift(int64_t s, int len, int pad) {
+    if (len <= 1) return 0;
+    int64_t period;
+    switch (pad) {
+    case 2: period = len; break;
+    case 3: period = 2 * (static_cast<int64_t>(len) - 1); break;
+    case 4: period = 2 * static_cast<int64_t>(len); break;
+    default: return static_cast<int>(s < -len - 1 ? -len - 1 : (s > len + 1 ? len + 1 : s));  // p ranges over [0, len]
+    }
+    if (s >= -0x40000000LL && s <= 0x40000000LL) {  // 32-bit remainder for every sane shift
+        const int p32 = static_cast<int>(period);
+        int r = static_cast<int>(s) % p32;
+        return r < 0 ? r + p32 : r;
+    }
+    return static_cast<int>(pmod(s, period));
+}
+
+__host__ __device__ __forceinline__ int fold_index(int idx, int len, int pad) {
+    switch (pad) {
+    case 1: return idx < 0 ? 0 : (idx > len - 1 ? len - 1 : idx);
+    case 2:
+        idx += idx < 0 ? len : 0;
+        return idx >= len ? idx - len : idx;
+    case 3:
+        idx = idx < 0 ? -idx : idx;
+        return idx > len - 1 ? 2 * (len - 1) - idx : idx;
+    case 4:
+        idx = idx < 0 ? -idx - 1 : idx;
+        return idx >= len ? 2 * len - 1 - idx : idx;
+    default: return (idx < 0 || idx >= len) ? -1 : idx;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // Per-channel shift preparation (cpu/shifts_cpu.cpp:223-224 forward, :242-244 backward).
 // Rounding is half-to-even (torch::round on the CPU path), i.e. rint in the default mode.
 // ---------------------------------------------------------------------------------------------

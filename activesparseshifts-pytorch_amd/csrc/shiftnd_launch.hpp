@@ -41,4 +41,10 @@ size_t plane_backward_workspace(const Geometry &g, int dtype);
 int plane_backward(const Geometry &g, int dtype, const void *go, const void *x, const void *w, void *gx, void *gw,
                    void *workspace, hipStream_t st);
 
+// ---- sweep kernels (shiftnd_sweep.hip): one 16-byte chunk per thread, XCD-contiguous grid ----------
+bool sweep_forward_eligible(const Geometry &g, int dtype, const void *x, const void *out);
+int sweep_forward(const Geometry &g, int dtype, const void *x, const void *w, int wkind, int64_t wzp, uint64_t fill_bits,
+                  void *out, hipStream_t st);
+int sweep_debug_map(int64_t p, int64_t shift, int64_t len, int pad);
+
 }  // namespace shiftnd

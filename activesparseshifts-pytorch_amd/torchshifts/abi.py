@@ -12,13 +12,13 @@ import torch
 _LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libshiftnd_hip.so")
 
 F32, F64, F16, BF16, I8, U8, I32 = range(7)
-PATH_NONE, PATH_EMPTY, PATH_PLANE, PATH_STRIDED = range(4)
+PATH_NONE, PATH_EMPTY, PATH_PLANE, PATH_STRIDED, PATH_SWEEP = range(5)
 
 DTYPES = {torch.float32: F32, torch.float64: F64, torch.float16: F16, torch.bfloat16: BF16,
           torch.int8: I8, torch.uint8: U8, torch.int32: I32}
 
 EXPORTS = ["shiftnd_abi_version", "shiftnd_status_string", "shiftnd_last_path", "shiftnd_set_path_policy",
-           "shiftnd_set_tuning",
+           "shiftnd_set_tuning", "shiftnd_debug_map",
            "shiftnd_check_borders", "shiftnd_forward", "shiftnd_backward_workspace_bytes", "shiftnd_backward",
            "shiftnd_forward_quantized"]
 
@@ -43,6 +43,8 @@ def lib():
         L.shiftnd_last_path.restype = ctypes.c_int
         L.shiftnd_set_path_policy.argtypes = [ctypes.c_int]
         L.shiftnd_set_tuning.argtypes = [ctypes.c_int, ctypes.c_int]
+        L.shiftnd_debug_map.restype = ctypes.c_int
+        L.shiftnd_debug_map.argtypes = [ctypes.c_int64, ctypes.c_int64, ctypes.c_int64, ctypes.c_int]
         L.shiftnd_check_borders.restype = ctypes.c_int
         L.shiftnd_check_borders.argtypes = [i64p, ctypes.c_int, ctypes.POINTER(ctypes.c_int32), ctypes.c_int,
                                             ctypes.POINTER(ctypes.c_int32), i64p]

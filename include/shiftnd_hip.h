@@ -72,7 +72,8 @@ typedef enum shiftnd_path {
     SHIFTND_PATH_NONE = 0,
     SHIFTND_PATH_EMPTY = 1,   /* zero-element problem: nothing launched */
     SHIFTND_PATH_PLANE = 2,   /* per-(N,C)-plane kernels, LDS index maps, 16-byte rows */
-    SHIFTND_PATH_STRIDED = 3  /* generic strided fallback (channels-last, ragged rows, huge dims) */
+    SHIFTND_PATH_STRIDED = 3, /* generic strided fallback (channels-last, ragged rows, huge dims) */
+    SHIFTND_PATH_SWEEP = 4    /* one 16-byte chunk per thread, XCD-contiguous sweep (the HBM-rate path) */
 } shiftnd_path;
 
 /* Problem geometry shared by the entry points. */
@@ -88,11 +89,15 @@ typedef struct shiftnd_problem {
 SHIFTND_API int shiftnd_abi_version(void);
 SHIFTND_API const char *shiftnd_status_string(int status);
 SHIFTND_API int shiftnd_last_path(void);
-/* 0 = automatic, 1 = force the strided fallback (testing), 2 = force plane kernels or fail. */
+/* 0 = automatic (sweep, else plane, else strided), 1 = force the strided fallback,
+ * 2 = plane kernels or fail, 3 = sweep kernels or fail (testing). */
 SHIFTND_API void shiftnd_set_path_policy(int policy);
 /* Diagnostics: launch-planning knobs of the plane kernels (0: minimum workgroups wanted, 1: target
  * bytes per workgroup, 2: gather-forward unroll).  Results never depend on them. */
 SHIFTND_API void shiftnd_set_tuning(int knob, int value);
+/* Diagnostics: the sweep kernels' arithmetic padding map evaluated on the host: source index of
+ * coordinate p (0 <= p <= len) under `shift`, or -1 for "fill". */
+SHIFTND_API int shiftnd_debug_map(int64_t p, int64_t shift, int64_t len, int padding_mode);
 
 /*
  * Host helper: the reference's check_borders (shifts.cpp:93-135).

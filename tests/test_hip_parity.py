@@ -40,7 +40,7 @@ def _dev(a):
 
 @pytest.mark.parametrize("policy", [0, 1])
 def test_golden_float_grid(abi, policy):
-    """120 reference cases x {automatic path, forced strided fallback}"""
+    """120 reference cases x {automatic path (sweep / plane / strided as eligible), forced strided fallback}"""
     abi.set_path_policy(policy)
     for key, nd, dt, pad, active, crop, x, w, go_full, out_r, gx_r, gw_r in float_cases("g1_float.npz"):
         b, _ = abi.check_borders(list(x.shape), crop, nd)
@@ -67,7 +67,7 @@ def test_golden_random_grid(abi):
         assert rel_err(gw.cpu().numpy(), gw_r) < tol, "grad_w " + key
 
 
-@pytest.mark.parametrize("policy", [0, 1])
+@pytest.mark.parametrize("policy", [0, 1, 2])
 def test_golden_quantized(abi, policy):
     abi.set_path_policy(policy)
     tdt = {"quint8": torch.uint8, "qint8": torch.int8, "qint32": torch.int32}
@@ -79,10 +79,12 @@ def test_golden_quantized(abi, policy):
             x = x.contiguous(memory_format=torch.channels_last_3d)
         w = torch.from_numpy(wq).to(torch.uint8 if wname == "wu8" else torch.int8).to(DEV)
         b, _ = abi.check_borders(list(xq.shape), crop, nd)
+        if policy == 2 and layout != "nchw":
+            continue  # plane kernels need contiguous NC[spatial] tensors
         out = abi.forward_quantized(x, w, wzp, xzp, pad, b)
         assert np.array_equal(out.cpu().numpy(), out_r), key
-        if policy == 0 and layout == "nchw":
-            assert abi.last_path() == abi.PATH_PLANE, key
+        if policy in (0, 2) and layout == "nchw":
+            assert abi.last_path() == (abi.PATH_SWEEP if policy == 0 else abi.PATH_PLANE), key
     abi.set_path_policy(0)
 
 
@@ -120,9 +122,19 @@ def test_random_vs_oracle(abi, shape, crop, dt):
         for active in (0, 1):
             out = abi.forward(xd, wd, pad, active, b)
             inner_bytes = new[-1] * x.itemsize
-            if active == 0 or inner_bytes % 16 == 0:
+            if active == 0:
+                assert abi.last_path() == abi.PATH_SWEEP
+            elif inner_bytes % 16 == 0:
                 assert abi.last_path() == abi.PATH_PLANE
-            assert np.array_equal(out.cpu().numpy(), O.forward(x, w, pad, active, b)), ("fwd", pad, active)
+            ref_out = O.forward(x, w, pad, active, b)
+            assert np.array_equal(out.cpu().numpy(), ref_out), ("fwd", pad, active)
+            abi.set_path_policy(2)  # the plane kernels serve the same problems
+            try:
+                outp = abi.forward(xd, wd, pad, active, b)
+                assert abi.last_path() == abi.PATH_PLANE and np.array_equal(outp.cpu().numpy(), ref_out)
+            except RuntimeError:
+                assert active == 1 and inner_bytes % 16 != 0
+            abi.set_path_policy(0)
             gx, gw = abi.backward(god, wd, xd, pad, active, b)
             if (shape[-1] * x.itemsize) % 16 == 0:
                 assert abi.last_path() == abi.PATH_PLANE
@@ -189,9 +201,13 @@ def test_quantized_random_vs_oracle(abi):
         wq[0, :] = 128 + shape[-1] + 3  # shift beyond the dim
         b, new = abi.check_borders(list(shape), crop, nd)
         for pad in range(5):
-            out = abi.forward_quantized(torch.from_numpy(xq).to(tdt).to(DEV), torch.from_numpy(wq).to(DEV), 128, zp, pad, b)
-            assert abi.last_path() == abi.PATH_PLANE
-            assert np.array_equal(out.cpu().numpy(), O.forward_q(xq, wq, 128, zp, pad, b)), (shape, pad)
+            ref = O.forward_q(xq, wq, 128, zp, pad, b)
+            for policy, path in ((0, abi.PATH_SWEEP), (2, abi.PATH_PLANE)):
+                abi.set_path_policy(policy)
+                out = abi.forward_quantized(torch.from_numpy(xq).to(tdt).to(DEV), torch.from_numpy(wq).to(DEV), 128, zp, pad, b)
+                assert abi.last_path() == path
+                assert np.array_equal(out.cpu().numpy(), ref), (shape, pad, policy)
+            abi.set_path_policy(0)
 
 
 def test_strided_inputs_and_empty(abi):
@@ -233,8 +249,11 @@ def test_large_plane_band_split_and_wide_rows(abi):
         for pad in (0, 2, 3):
             for active in (0, 1):
                 out = abi.forward(xd, wd, pad, active)
-                assert abi.last_path() == abi.PATH_PLANE
+                assert abi.last_path() == (abi.PATH_PLANE if active else abi.PATH_SWEEP)
                 assert np.array_equal(out.cpu().numpy(), O.forward(x, w, pad, active))
+                abi.set_path_policy(2)
+                assert torch.equal(abi.forward(xd, wd, pad, active), out) and abi.last_path() == abi.PATH_PLANE
+                abi.set_path_policy(0)
                 gx, gw = abi.backward(god, wd, xd, pad, active)
                 gx_o, _ = O.backward(go, w, x, pad, active)
                 _, gw64 = O.backward(go.astype(np.float64), w.astype(np.float64), x.astype(np.float64), pad, active)

@@ -1,0 +1,31 @@
+"""Host-side arithmetic of the HIP library, checked on the CPU: the sweep kernels' arithmetic padding
+map (canon_shift + fold_index, shiftnd_common.hpp) must equal the reference's infer_index for every
+coordinate, shift and length -- exhaustively over small lengths, plus huge (multi-wrap) shifts."""
+import itertools
+
+from oracle import oracle as O
+from torchshifts import abi
+
+
+def _ref(p, s, length, pad):
+    if length == 1:
+        return 0
+    m = O.infer_index(p - s, length, pad)
+    return m if m >= 0 else -1
+
+
+def test_arithmetic_map_equals_reference_exhaustive():
+    L = abi.lib()
+    for pad in range(5):
+        for length in range(1, 14):
+            for s in range(-4 * length - 5, 4 * length + 6):
+                for p in range(0, length + 1):
+                    assert L.shiftnd_debug_map(p, s, length, pad) == _ref(p, s, length, pad), (pad, length, s, p)
+
+
+def test_arithmetic_map_huge_shifts():
+    L = abi.lib()
+    for pad, length, s in itertools.product(range(5), (2, 3, 7, 224, 1000), (10 ** 6 + 3, -(10 ** 6) - 7, 2 ** 31 + 5,
+                                                                               -(2 ** 33) - 11, 2 ** 40 + 1, 2 ** 30, -(2 ** 30))):
+        for p in (0, 1, length // 2, length - 1, length):
+            assert L.shiftnd_debug_map(p, s, length, pad) == _ref(p, s, length, pad), (pad, length, s, p)

@@ -46,8 +46,9 @@ inline FastDiv make_fastdiv(uint32_t d) {
     f.mul = static_cast<uint32_t>(((1ull << 32) * ((1ull << s) - f.d)) / f.d + 1);
     return f;
 }
-__device__ __forceinline__ uint32_t fdiv(uint32_t n, const FastDiv &f) {
-    return (__umulhi(n, f.mul) + n) >> f.shift;
+__host__ __device__ __forceinline__ uint32_t fdiv(uint32_t n, const FastDiv &f) {
+    const uint32_t hi = static_cast<uint32_t>((static_cast<uint64_t>(n) * f.mul) >> 32);  // v_mul_hi_u32
+    return (hi + n) >> f.shift;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -99,19 +100,26 @@ __host__ __device__ inline int64_t pad_index(int64_t idx, int64_t len, int pad) 
 //   fold_index(p - canon_shift(s), len, pad) == pad_index(p - s, len, pad) for all p in [0, len];
 //   checked exhaustively on the host by tests/test_host_logic.py through shiftnd_debug_map().
 // ---------------------------------------------------------------------------------------------
-__host__ __device__ inline int canon_shift(int64_t s, int len, int pad) {
-    if (len <= 1) return 0;
-    int64_t period;
+__host__ __device__ inline int map_period(int len, int pad) {
     switch (pad) {
-    case 2: period = len; break;
-    case 3: period = 2 * (static_cast<int64_t>(len) - 1); break;
-    case 4: period = 2 * static_cast<int64_t>(len); break;
-    default: return static_cast<int>(s < -len - 1 ? -len - 1 : (s > len + 1 ? len + 1 : s));  // p ranges over [0, len]
+    case 2: return len;
+    case 3: return 2 * (len - 1);
+    case 4: return 2 * len;
+    default: return 0;  // zeros / border: no period, shifts are clamped
     }
-    if (s >= -0x40000000LL && s <= 0x40000000LL) {  // 32-bit remainder for every sane shift
-        const int p32 = static_cast<int>(period);
-        int r = static_cast<int>(s) % p32;
-        return r < 0 ? r + p32 : r;
+}
+
+// `dper` divides by map_period(len, pad) (host-built; ignored when the period is 0).
+// No hardware integer division is used: hipcc (ROCm 7.2) was seen to miscompile a 32-bit signed
+// remainder by a launch-uniform divisor in this function, and the multiply-shift form is cheaper.
+__host__ __device__ inline int canon_shift(int64_t s, int len, int pad, const FastDiv &dper) {
+    if (len <= 1) return 0;
+    const int period = map_period(len, pad);
+    if (period == 0) return static_cast<int>(s < -len - 1 ? -len - 1 : (s > len + 1 ? len + 1 : s));  // p ranges over [0, len]
+    if (s >= -0x40000000LL && s <= 0x40000000LL) {  // every sane shift: 32-bit multiply-shift remainder
+        const uint32_t a = static_cast<uint32_t>(s < 0 ? -s : s);
+        const uint32_t m = a - fdiv(a, dper) * static_cast<uint32_t>(period);
+        return static_cast<int>((s < 0 && m != 0) ? static_cast<uint32_t>(period) - m : m);
     }
     return static_cast<int>(pmod(s, period));
 }

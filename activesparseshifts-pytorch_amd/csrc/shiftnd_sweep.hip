@@ -43,6 +43,8 @@ struct SweepParams {
     int S[3], O[3], L[3], wcol[3];
     uint32_t cpr, cpp;         // chunks per row / per plane of the iteration space
     FastDiv d_cpp, d_cpr, d_dim1, d_C, d_bpp;
+    FastDiv d_per[3];          // divide by the padding period of each dim of x
+    FastDiv d_gper[3];         // backward: same for the grad_out dims
 };
 
 // workgroups that share an XCD (blockIdx % 8, round-robin dispatch) get consecutive logical ids
@@ -106,23 +108,23 @@ template <int ESIZE, int V>
 __global__ __launch_bounds__(kThreads) void sweep_gather_forward(const SweepParams p) {
     using R = typename raw_t<ESIZE>::type;
     constexpr int E = V / ESIZE;
+    // ---- workgroup-uniform part (scalar registers): which plane, which channel, its canonical shifts ----
     const uint32_t bid = xcd_remap(p.blocks_per_xcd);
     if (bid >= p.blocks) return;
-    const uint32_t Q = bid * kThreads + threadIdx.x;
-    if (Q >= p.total) return;
-    // chunk -> (plane, row, column)
-    const uint32_t plane = fdiv(Q, p.d_cpp);
-    const uint32_t q = Q - plane * p.cpp;
+    const uint32_t plane = fdiv(bid, p.d_bpp);
+    const uint32_t blk = bid - plane * p.bpp;
+    const int c = static_cast<int>(plane - fdiv(plane, p.d_C) * static_cast<uint32_t>(p.C));
+    int cs[3];
+#pragma unroll
+    for (int d = 0; d < 3; ++d)
+        cs[d] = p.wcol[d] >= 0 ? canon_shift(gather_shift(p.w, p.wkind, p.wzp, c * p.nd + p.wcol[d]), p.S[d], p.pad, p.d_per[d]) : 0;
+    // ---- per-thread part: chunk -> (row, column) ---------------------------------------------------------
+    const uint32_t q = blk * kThreads + threadIdx.x;
+    if (q >= p.cpp) return;
     const uint32_t r = fdiv(q, p.d_cpr);
     const int jo = static_cast<int>(q - r * p.cpr) * E;
     const uint32_t a = fdiv(r, p.d_dim1);
     const uint32_t b = r - a * static_cast<uint32_t>(p.O[1]);
-    const int c = static_cast<int>(plane - fdiv(plane, p.d_C) * static_cast<uint32_t>(p.C));
-
-    int cs[3];
-#pragma unroll
-    for (int d = 0; d < 3; ++d)
-        cs[d] = p.wcol[d] >= 0 ? canon_shift(gather_shift(p.w, p.wkind, p.wzp, c * p.nd + p.wcol[d]), p.S[d], p.pad) : 0;
 
     const R fill = static_cast<R>(p.fill);
     R *dst = static_cast<R *>(p.out) + static_cast<int64_t>(plane) * p.o_plane + static_cast<int64_t>(r) * p.O[2] + jo;
@@ -189,6 +191,10 @@ void fill_common(SweepParams &p, const Geometry &g) {
     p.x_plane = g.S[0] * g.S[1] * g.S[2];
     p.o_plane = g.O[0] * g.O[1] * g.O[2];
     p.d_C = make_fastdiv(static_cast<uint32_t>(g.C));
+    for (int d = 0; d < 3; ++d) {
+        p.d_per[d] = make_fastdiv(static_cast<uint32_t>(map_period(p.S[d], p.pad)));
+        p.d_gper[d] = make_fastdiv(static_cast<uint32_t>(map_period(p.O[d], p.pad)));
+    }
 }
 
 void set_grid(SweepParams &p, uint64_t blocks) {
@@ -213,8 +219,9 @@ bool sweep_forward_eligible(const Geometry &g, int dtype, const void *x, const v
     if (interpolating) return false;  // active forward: plane kernels (for now)
     const int es = dtype_size(dtype);
     const int V = gather_vector_bytes(g, es, out);
-    const int64_t chunks = g.N * g.C * oe * es / V;
-    return chunks < (1LL << 31) - 4096;  // 32-bit chunk ids
+    const int64_t cpp = oe * es / V;
+    const int64_t blocks = g.N * g.C * ((cpp + kThreads - 1) / kThreads);
+    return blocks < (1LL << 31) - 16;  // 32-bit workgroup ids (also the grid limit)
 }
 
 int sweep_forward(const Geometry &g, int dtype, const void *x, const void *w, int wkind, int64_t wzp, uint64_t fill_bits,
@@ -231,11 +238,11 @@ int sweep_forward(const Geometry &g, int dtype, const void *x, const void *w, in
     p.fill = fill_bits;
     p.cpr = static_cast<uint32_t>(g.O[2] * es / V);
     p.cpp = static_cast<uint32_t>(g.O[0] * g.O[1]) * p.cpr;
-    p.total = static_cast<uint32_t>(g.N * g.C) * p.cpp;
-    p.d_cpp = make_fastdiv(p.cpp);
+    p.bpp = (p.cpp + kThreads - 1) / kThreads;
+    p.d_bpp = make_fastdiv(p.bpp);
     p.d_cpr = make_fastdiv(p.cpr);
     p.d_dim1 = make_fastdiv(static_cast<uint32_t>(g.O[1]));
-    set_grid(p, (static_cast<uint64_t>(p.total) + kThreads - 1) / kThreads);
+    set_grid(p, static_cast<uint64_t>(g.N * g.C) * p.bpp);
 #define SHIFTND_GATHER_CASE(ES, VV) \
     if (es == ES && V == VV) { launch_gather<ES, VV>(p, st); return SHIFTND_OK; }
     SHIFTND_GATHER_CASE(1, 16) SHIFTND_GATHER_CASE(1, 8) SHIFTND_GATHER_CASE(1, 4) SHIFTND_GATHER_CASE(1, 1)
@@ -249,7 +256,8 @@ int sweep_forward(const Geometry &g, int dtype, const void *x, const void *w, in
 // host mirror of the per-element map, for tests: source index of coordinate p (or -1)
 int sweep_debug_map(int64_t p, int64_t shift, int64_t len, int pad) {
     if (len == 1) return 0;
-    return fold_index(static_cast<int>(p) - canon_shift(shift, static_cast<int>(len), pad), static_cast<int>(len), pad);
+    const FastDiv dper = make_fastdiv(static_cast<uint32_t>(map_period(static_cast<int>(len), pad)));
+    return fold_index(static_cast<int>(p) - canon_shift(shift, static_cast<int>(len), pad, dper), static_cast<int>(len), pad);
 }
 
 }  // namespace shiftnd

@@ -115,7 +115,10 @@ int shiftnd_last_path(void) { return g_last_path; }
 
 void shiftnd_set_path_policy(int policy) { g_policy = policy; }
 
-void shiftnd_set_tuning(int knob, int value) { plane_set_tuning(knob, value); }
+void shiftnd_set_tuning(int knob, int value) {
+    if (knob >= 8) sweep_set_tuning(knob - 8, value);  // 8/9: sweep forward K / max threads, 10/11: sweep backward
+    else plane_set_tuning(knob, value);
+}
 
 int shiftnd_debug_map(int64_t p, int64_t shift, int64_t len, int padding_mode) {
     return sweep_debug_map(p, shift, len, padding_mode);
@@ -183,7 +186,8 @@ size_t shiftnd_backward_workspace_bytes(const shiftnd_problem *p) {
     if (g.N == 0 || g.C == 0 || g.S[0] * g.S[1] * g.S[2] == 0) return sizeof(double);
     const size_t a = strided_backward_workspace(g);
     const size_t b = plane_backward_workspace(g, p->dtype);
-    return a > b ? a : b;
+    const size_t c = sweep_backward_workspace(g, p->dtype);
+    return a > b ? (a > c ? a : c) : (b > c ? b : c);
 }
 
 int shiftnd_backward(const shiftnd_problem *p, const void *grad_out, const int64_t grad_out_strides[5], const void *x,
@@ -204,8 +208,14 @@ int shiftnd_backward(const shiftnd_problem *p, const void *grad_out, const int64
         return SHIFTND_OK;
     }
     if (!grad_out || !x || !weights || !grad_x || !grad_w || !workspace) return SHIFTND_ERR_INVALID_ARGUMENT;
+    const bool can_sweep = sweep_backward_eligible(g, p->dtype, grad_out, x, grad_x);
     const bool can_plane = plane_backward_eligible(g, p->dtype, grad_out, x, grad_x);
-    if (g_policy == 2 && !can_plane) return SHIFTND_ERR_INVALID_ARGUMENT;
+    if ((g_policy == 2 && !can_plane) || (g_policy == 3 && !can_sweep)) return SHIFTND_ERR_INVALID_ARGUMENT;
+    if (can_sweep && (g_policy == 0 || g_policy == 3)) {
+        if (sweep_backward_workspace(g, p->dtype) > workspace_bytes) return SHIFTND_ERR_WORKSPACE_TOO_SMALL;
+        g_last_path = SHIFTND_PATH_SWEEP;
+        return finish(sweep_backward(g, p->dtype, grad_out, x, weights, grad_x, grad_w, workspace, st));
+    }
     if (can_plane && g_policy != 1) {
         if (plane_backward_workspace(g, p->dtype) > workspace_bytes) return SHIFTND_ERR_WORKSPACE_TOO_SMALL;
         g_last_path = SHIFTND_PATH_PLANE;

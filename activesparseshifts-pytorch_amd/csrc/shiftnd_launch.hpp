@@ -45,6 +45,11 @@ int plane_backward(const Geometry &g, int dtype, const void *go, const void *x, 
 bool sweep_forward_eligible(const Geometry &g, int dtype, const void *x, const void *out);
 int sweep_forward(const Geometry &g, int dtype, const void *x, const void *w, int wkind, int64_t wzp, uint64_t fill_bits,
                   void *out, hipStream_t st);
+bool sweep_backward_eligible(const Geometry &g, int dtype, const void *go, const void *x, const void *gx);
+size_t sweep_backward_workspace(const Geometry &g, int dtype);
+int sweep_backward(const Geometry &g, int dtype, const void *go, const void *x, const void *w, void *gx, void *gw,
+                   void *workspace, hipStream_t st);
+void sweep_set_tuning(int knob, int value);
 int sweep_debug_map(int64_t p, int64_t shift, int64_t len, int pad);
 
 }  // namespace shiftnd

@@ -136,14 +136,21 @@ def test_random_vs_oracle(abi, shape, crop, dt):
                 assert active == 1 and inner_bytes % 16 != 0
             abi.set_path_policy(0)
             gx, gw = abi.backward(god, wd, xd, pad, active, b)
-            if (shape[-1] * x.itemsize) % 16 == 0:
-                assert abi.last_path() == abi.PATH_PLANE
+            aligned = (shape[-1] * x.itemsize) % 16 == 0
+            if aligned:
+                assert abi.last_path() == abi.PATH_SWEEP
             gx_o, _ = O.backward(go, w, x, pad, active, b)
             assert np.array_equal(gx.cpu().numpy(), gx_o), ("gx", pad, active)
             # grad_w truth: the oracle in fp64 on the same values
             _, gw64 = O.backward(go.astype(np.float64), w.astype(np.float64), x.astype(np.float64), pad, active, b)
             assert rel_err(gw.cpu().numpy(), gw64) < (1e-12 if dt == "f64" else 1e-5), ("gw", pad, active)
-            # the two kernel families agree bit for bit on forward / grad_x
+            if aligned:  # the plane kernels serve the same problems
+                abi.set_path_policy(2)
+                gxp, gwp = abi.backward(god, wd, xd, pad, active, b)
+                abi.set_path_policy(0)
+                assert abi.last_path() == abi.PATH_PLANE and torch.equal(gxp, gx)
+                assert rel_err(gwp.cpu().numpy(), gw64) < (1e-12 if dt == "f64" else 1e-5)
+            # the kernel families agree bit for bit on forward / grad_x
             abi.set_path_policy(1)
             out2 = abi.forward(xd, wd, pad, active, b)
             gx2, gw2 = abi.backward(god, wd, xd, pad, active, b)
@@ -254,10 +261,14 @@ def test_large_plane_band_split_and_wide_rows(abi):
                 abi.set_path_policy(2)
                 assert torch.equal(abi.forward(xd, wd, pad, active), out) and abi.last_path() == abi.PATH_PLANE
                 abi.set_path_policy(0)
-                gx, gw = abi.backward(god, wd, xd, pad, active)
                 gx_o, _ = O.backward(go, w, x, pad, active)
                 _, gw64 = O.backward(go.astype(np.float64), w.astype(np.float64), x.astype(np.float64), pad, active)
-                assert np.array_equal(gx.cpu().numpy(), gx_o) and rel_err(gw.cpu().numpy(), gw64) < 1e-5
+                for policy, path in ((0, abi.PATH_SWEEP), (2, abi.PATH_PLANE)):
+                    abi.set_path_policy(policy)
+                    gx, gw = abi.backward(god, wd, xd, pad, active)
+                    assert abi.last_path() == path
+                    assert np.array_equal(gx.cpu().numpy(), gx_o) and rel_err(gw.cpu().numpy(), gw64) < 1e-5
+                abi.set_path_policy(0)
 
 
 def test_deterministic_weight_grad(abi):

@@ -211,7 +211,9 @@ int shiftnd_backward(const shiftnd_problem *p, const void *grad_out, const int64
     const bool can_sweep = sweep_backward_eligible(g, p->dtype, grad_out, x, grad_x);
     const bool can_plane = plane_backward_eligible(g, p->dtype, grad_out, x, grad_x);
     if ((g_policy == 2 && !can_plane) || (g_policy == 3 && !can_sweep)) return SHIFTND_ERR_INVALID_ARGUMENT;
-    if (can_sweep && (g_policy == 0 || g_policy == 3)) {
+    // automatic choice: the per-plane kernels (faster for the backward pass); the sweep kernels take over
+    // when the index maps do not fit in LDS
+    if (can_sweep && (g_policy == 3 || (g_policy == 0 && !can_plane))) {
         if (sweep_backward_workspace(g, p->dtype) > workspace_bytes) return SHIFTND_ERR_WORKSPACE_TOO_SMALL;
         g_last_path = SHIFTND_PATH_SWEEP;
         return finish(sweep_backward(g, p->dtype, grad_out, x, weights, grad_x, grad_w, workspace, st));

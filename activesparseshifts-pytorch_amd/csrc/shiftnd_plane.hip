@@ -109,13 +109,29 @@ template <> struct raw_t<8> { using type = uint64_t; };
 
 template <typename R, int E> struct Chunk { R e[E]; };
 
+template <int V> struct vec_of;
+template <> struct vec_of<16> { typedef uint32_t type __attribute__((ext_vector_type(4))); };
+template <> struct vec_of<8> { typedef uint32_t type __attribute__((ext_vector_type(2))); };
+template <> struct vec_of<4> { typedef uint32_t type; };
+template <> struct vec_of<2> { typedef uint16_t type; };
+template <> struct vec_of<1> { typedef uint8_t type; };
+
+// element-aligned V-byte load (one global_load_dwordx4 on gfx950), nontemporal: every byte is used once
 template <typename R, int E> __device__ __forceinline__ Chunk<R, E> load_chunk(const R *src) {
+    constexpr int V = sizeof(R) * E;
+    typedef typename vec_of<V>::type vec_t;
+    typedef vec_t unaligned_t __attribute__((aligned(sizeof(R) < 4 ? sizeof(R) : 4)));
+    const vec_t v = __builtin_nontemporal_load(reinterpret_cast<const unaligned_t *>(src));
     Chunk<R, E> c;
-    __builtin_memcpy(c.e, src, sizeof(R) * E);  // element-aligned: one global_load_dwordx4 on gfx950
+    __builtin_memcpy(c.e, &v, V);
     return c;
 }
 template <typename R, int E> __device__ __forceinline__ void store_chunk(R *dst, const Chunk<R, E> &c) {
-    __builtin_memcpy(__builtin_assume_aligned(dst, sizeof(R) * E), c.e, sizeof(R) * E);
+    constexpr int V = sizeof(R) * E;
+    typedef typename vec_of<V>::type vec_t;
+    vec_t v;
+    __builtin_memcpy(&v, c.e, V);
+    __builtin_nontemporal_store(v, reinterpret_cast<vec_t *>(dst));
 }
 
 // =====================================================================================================

@@ -138,17 +138,17 @@ def test_random_vs_oracle(abi, shape, crop, dt):
             gx, gw = abi.backward(god, wd, xd, pad, active, b)
             aligned = (shape[-1] * x.itemsize) % 16 == 0
             if aligned:
-                assert abi.last_path() == abi.PATH_SWEEP
+                assert abi.last_path() == abi.PATH_PLANE
             gx_o, _ = O.backward(go, w, x, pad, active, b)
             assert np.array_equal(gx.cpu().numpy(), gx_o), ("gx", pad, active)
             # grad_w truth: the oracle in fp64 on the same values
             _, gw64 = O.backward(go.astype(np.float64), w.astype(np.float64), x.astype(np.float64), pad, active, b)
             assert rel_err(gw.cpu().numpy(), gw64) < (1e-12 if dt == "f64" else 1e-5), ("gw", pad, active)
-            if aligned:  # the plane kernels serve the same problems
-                abi.set_path_policy(2)
+            if aligned:  # the sweep kernels serve the same problems
+                abi.set_path_policy(3)
                 gxp, gwp = abi.backward(god, wd, xd, pad, active, b)
                 abi.set_path_policy(0)
-                assert abi.last_path() == abi.PATH_PLANE and torch.equal(gxp, gx)
+                assert abi.last_path() == abi.PATH_SWEEP and torch.equal(gxp, gx)
                 assert rel_err(gwp.cpu().numpy(), gw64) < (1e-12 if dt == "f64" else 1e-5)
             # the kernel families agree bit for bit on forward / grad_x
             abi.set_path_policy(1)
@@ -263,7 +263,7 @@ def test_large_plane_band_split_and_wide_rows(abi):
                 abi.set_path_policy(0)
                 gx_o, _ = O.backward(go, w, x, pad, active)
                 _, gw64 = O.backward(go.astype(np.float64), w.astype(np.float64), x.astype(np.float64), pad, active)
-                for policy, path in ((0, abi.PATH_SWEEP), (2, abi.PATH_PLANE)):
+                for policy, path in ((3, abi.PATH_SWEEP), (0, abi.PATH_PLANE)):
                     abi.set_path_policy(policy)
                     gx, gw = abi.backward(god, wd, xd, pad, active)
                     assert abi.last_path() == path

@@ -118,12 +118,15 @@ template <> struct vec_of<4> { typedef uint32_t type; };
 template <> struct vec_of<2> { typedef uint16_t type; };
 template <> struct vec_of<1> { typedef uint8_t type; };
 
-// element-aligned V-byte load (one global_load_dwordx4 on gfx950), nontemporal: every byte is used once
-template <typename R, int E> __device__ __forceinline__ Chunk<R, E> load_chunk(const R *src) {
+// element-aligned V-byte load (one global_load_dwordx4 on gfx950).  NT = nontemporal: only for data
+// that no other workgroup re-reads (the gather forward); the backward kernels rely on L2 for the rows
+// that neighbouring rows share (measured: nontemporal loads there raise HBM reads from 7.6 to 10 GB).
+template <typename R, int E, bool NT = false> __device__ __forceinline__ Chunk<R, E> load_chunk(const R *src) {
     constexpr int V = sizeof(R) * E;
     typedef typename vec_of<V>::type vec_t;
     typedef vec_t unaligned_t __attribute__((aligned(sizeof(R) < 4 ? sizeof(R) : 4)));
-    const vec_t v = __builtin_nontemporal_load(reinterpret_cast<const unaligned_t *>(src));
+    const vec_t v = NT ? __builtin_nontemporal_load(reinterpret_cast<const unaligned_t *>(src))
+                       : *reinterpret_cast<const unaligned_t *>(src);
     Chunk<R, E> c;
     __builtin_memcpy(c.e, &v, V);
     return c;
@@ -195,7 +198,7 @@ __global__ __launch_bounds__(kThreads) void plane_gather_forward(const PlanePara
                     } else {
                         const R *row = x + plane * p.x_plane + static_cast<int64_t>(ra * S1 + rb) * S2;
                         if (contig) {
-                            v[u] = load_chunk<R, E>(row + mm[0]);
+                            v[u] = load_chunk<R, E, true>(row + mm[0]);
                         } else {
 #pragma unroll
                             for (int e = 0; e < E; ++e) v[u].e[e] = mm[e] >= 0 ? row[mm[e]] : fill;
@@ -505,9 +508,9 @@ __device__ __forceinline__ RowRaw<T, E> fetch_row(const typename T::S *__restric
         } else {
 #pragma unroll
             for (int e = 0; e < E; ++e)
-                if (mm[e] >= 0) r.v.e[e] = __builtin_nontemporal_load(row + mm[e]);
+                if (mm[e] >= 0) r.v.e[e] = row[mm[e]];
         }
-        if (mm[E] >= 0) r.last = __builtin_nontemporal_load(row + mm[E]);
+        if (mm[E] >= 0) r.last = row[mm[E]];
     }
     return r;
 }
@@ -610,7 +613,7 @@ __global__ __launch_bounds__(kThreads) void plane_backward_pipe(const PlaneParam
                     } else {
 #pragma unroll
                         for (int e = 0; e < E; ++e)
-                            sl.g.e[e] = ((inmask >> e) & 1u) ? __builtin_nontemporal_load(grow + oj + e) : zero;
+                            sl.g.e[e] = ((inmask >> e) & 1u) ? grow[oj + e] : zero;
                     }
 #pragma unroll
                     for (int h = 0; h < NH; ++h) {
@@ -633,7 +636,7 @@ __global__ __launch_bounds__(kThreads) void plane_backward_pipe(const PlaneParam
                             } else {
 #pragma unroll
                                 for (int e = 0; e < E; ++e)
-                                    sl.ghi[0].v.e[e] = (((inmask >> e) & 1u) && gm[e] >= 0) ? __builtin_nontemporal_load(srow + gm[e]) : zero;
+                                    sl.ghi[0].v.e[e] = (((inmask >> e) & 1u) && gm[e] >= 0) ? srow[gm[e]] : zero;
                             }
                         }
                     }

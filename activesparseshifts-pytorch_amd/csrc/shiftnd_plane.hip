@@ -480,7 +480,7 @@ __global__ __launch_bounds__(kThreads) void plane_backward(const PlaneParams p) 
 }
 
 // =====================================================================================================
-// Backward, pipelined form (default): same results as plane_backward above, restructured for HBM rate.
+// Backward, pipelined form (opt-in, tuning knob 3 = 0): same results as plane_backward above, restructured for HBM rate.
 //   * A thread owns a chunk column and a BAND of consecutive rows, so the corner rows it loaded for
 //     row r (the "+1" rows) are the "+0" rows of row r + 1: they stay in registers (ring of three
 //     slots) and every source row is loaded once per thread instead of twice.
@@ -743,8 +743,8 @@ bool contiguous(const int64_t st[5], int64_t N, int64_t C, const int64_t sz[3]) 
 }
 
 // diagnostics knobs (shiftnd_set_tuning): 0 = min workgroups wanted, 1 = target bytes per workgroup,
-// 2 = gather-forward unroll (fp32/16-byte variant only), 3 = 1: use the simple (unpipelined) backward kernel
-int g_tune[8] = {2048, 128 * 1024, 4, 0, 0, 0, 0, 0};
+// 2 = gather-forward unroll (fp32/16-byte variant only), 3 = 0: use the pipelined backward kernel (default 1: simple loop)
+int g_tune[8] = {2048, 128 * 1024, 4, 1, 0, 0, 0, 0};
 
 struct Plan {
     int V, cpr, CW, RPS, CP, ppw, groups, bands, rows_per_band, rows;
@@ -861,7 +861,7 @@ int launch_active_forward(const PlaneParams &p, const Plan &pl, hipStream_t st) 
 
 template <typename T, bool ACTIVE>
 void launch_backward_a(const PlaneParams &p, const Plan &pl, hipStream_t st) {
-    if (g_tune[3] == 0) {  // default: pipelined form
+    if (g_tune[3] == 0) {  // pipelined form (measured slower than the simple loop on MI355X so far: opt-in)
         switch (p.nd) {
         case 1: hipLaunchKernelGGL((plane_backward_pipe<T, 1, ACTIVE>), dim3(pl.grid), dim3(kThreads), pl.lds, st, p); break;
         case 2: hipLaunchKernelGGL((plane_backward_pipe<T, 2, ACTIVE>), dim3(pl.grid), dim3(kThreads), pl.lds, st, p); break;

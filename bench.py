@@ -39,6 +39,14 @@ WORKLOADS = {
 }
 
 
+def shard_range(n, rank, world):
+    """Contiguous batch slice [lo, hi) of rank `rank`: the op is per-sample independent, so the N-GPU job
+    is N independent slices of the batch (no data-path collective; sizes differ by at most one)."""
+    base, rem = divmod(n, world)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
 def cpu_baseline():
     """must run before this process touches the GPU (child process; see oracle/ref_bench.py)"""
     try:
@@ -104,6 +112,9 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     nd, shape, dtname, active, desc = WORKLOADS[a.workload]
+    # weak scaling: the global batch is world x the per-GPU batch; this rank owns one contiguous slice
+    lo, hi = shard_range(shape[0] * world, rank, world)
+    shape = (hi - lo,) + tuple(shape[1:])
     quant = dtname == "quint8"
     C = shape[1]
     elems = 1
@@ -180,18 +191,23 @@ def main():
         wi = wq.int_repr()
         outb = torch.empty_like(xi)
         t_f = event_time(lambda: abi.forward_quantized(xi, wi, 128, 0, a.pad, out=outb), kiters)
-        kernels["plane_gather_forward"] = {"ms": t_f, "GB/s": 2 * esize * elems / t_f / 1e6}
-        dom_name, dom_ms, dom_bytes = "plane_gather_forward", t_f, 2 * esize * elems
+        qname = {abi.PATH_PLANE: "plane", abi.PATH_SWEEP: "sweep"}.get(abi.last_path(), "strided") + "_gather_forward"
+        kernels[qname] = {"ms": t_f, "GB/s": 2 * esize * elems / t_f / 1e6}
+        dom_name, dom_ms, dom_bytes = qname, t_f, 2 * esize * elems
     else:
         outb, gxb, gwb = torch.empty_like(x), torch.empty_like(x), torch.empty_like(w)
         ws = abi.backward_workspace(x, a.pad, active)
         t_f = event_time(lambda: abi.forward(x, w, a.pad, active, out=outb), kiters)
         t_b = event_time(lambda: abi.backward(go, w, x, a.pad, active, grad_x=gxb, grad_w=gwb, workspace=ws), kiters)
-        fname = "plane_active_forward" if active else "plane_gather_forward"
+        fam = {abi.PATH_PLANE: "plane", abi.PATH_SWEEP: "sweep", abi.PATH_STRIDED: "strided"}
+        abi.forward(x, w, a.pad, active, out=outb)
+        fname = fam.get(abi.last_path(), "?") + ("_active_forward" if active else "_gather_forward")
+        abi.backward(go, w, x, a.pad, active, grad_x=gxb, grad_w=gwb, workspace=ws)
+        bname = fam.get(abi.last_path(), "?") + "_backward"
         kernels[fname] = {"ms": t_f, "GB/s": 2 * esize * elems / t_f / 1e6}
-        kernels["plane_backward"] = {"ms": t_b, "GB/s": 3 * esize * elems / t_b / 1e6}
-        dom_name, dom_ms, dom_bytes = "plane_backward", t_b, 3 * esize * elems
-    path = {abi.PATH_PLANE: "plane", abi.PATH_STRIDED: "strided"}.get(abi.last_path(), "?")
+        kernels[bname] = {"ms": t_b, "GB/s": 3 * esize * elems / t_b / 1e6}
+        dom_name, dom_ms, dom_bytes = bname, t_b, 3 * esize * elems
+    path = "+".join(sorted(set(k.split("_")[0] for k in kernels)))
 
     if rank == 0:
         achieved = dom_bytes / dom_ms / 1e6  # GB/s

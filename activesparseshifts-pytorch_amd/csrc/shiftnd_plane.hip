@@ -45,6 +45,9 @@ struct PlaneParams {
     int cpr, CW, RPS, CP;
     int rows;           // rows per plane of the iteration space
     int tbands, tband_len;  // pipelined backward: row bands per plane share handed to the RPS row slots
+    int tband_mode;         // 1: consecutive rows per thread (register carry), 0: rows RPS apart
+    int tile_bytes;         // LDS-staged backward: bytes of the row tile in front of the maps
+    FastDiv d_cpr;
     FastDiv d_tbands;
     FastDiv d_rows;     // divide by rows_per_band
     FastDiv d_dim1;     // divide by the second outer dim of the iteration space
@@ -554,7 +557,10 @@ __global__ __launch_bounds__(kThreads) void plane_backward_pipe(const PlaneParam
         Chunk<S, E> g;         // incoming gradient at this position
         RowRaw<T, E> xhi[NH];  // x rows of the "+1" corner combos (all combos when ND == 1)
         RowRaw<T, E> ghi[NH];  // active: grad_out rows of the "+1" combos; SSL: [0] = the shifted row
+        RowRaw<T, E> xlo[NH];  // "+0" combos, loaded only when they cannot be carried over from the previous row
+        RowRaw<T, E> glo[NH];
     };
+    const bool banded = p.tband_mode != 0;  // consecutive rows per thread (carry) or rows RPS apart (no carry)
 
     if (tr < p.RPS) {
         for (int cp = 0; cp < p.CP; ++cp) {
@@ -583,8 +589,10 @@ __global__ __launch_bounds__(kThreads) void plane_backward_pipe(const PlaneParam
             const int items = wi.nn * p.tbands;
             for (int t = tr; t < items; t += p.RPS) {
                 const int nl = fdiv(t, p.d_tbands);
-                const int rb0 = wi.row0 + (t - nl * p.tbands) * p.tband_len;
-                const int rb1 = min(rb0 + p.tband_len, wi.row0 + wi.nrows);
+                const int tb = t - nl * p.tbands;
+                // banded: rows [tb*len, (tb+1)*len); interleaved: rows tb, tb + RPS, ... of the workgroup's share
+                const int rb0 = wi.row0 + (banded ? tb * p.tband_len : tb);
+                const int rb1 = banded ? min(rb0 + p.tband_len, wi.row0 + wi.nrows) : wi.row0 + wi.nrows;
                 if (rb0 >= rb1) continue;
                 const int64_t plane = static_cast<int64_t>(wi.n0 + nl) * p.C + wi.c;
                 const S *xp = x + plane * p.x_plane;
@@ -599,7 +607,7 @@ __global__ __launch_bounds__(kThreads) void plane_backward_pipe(const PlaneParam
                     return combo_offset<ND>(ND == 2 ? hi : (hi * 2 + h), g0, g1, oa, ob, O1 * O2, O2);
                 };
                 // issue every load of row r into a slot
-                auto prefetch = [&](int r, Slot &sl) {
+                auto prefetch = [&](int r, Slot &sl, bool need_low) {
                     const int a = fdiv(r, p.d_dim1);
                     const int b = r - a * S1;
                     const int oa = a - p.L[0], ob = b - p.L[1];
@@ -619,6 +627,19 @@ __global__ __launch_bounds__(kThreads) void plane_backward_pipe(const PlaneParam
                     for (int h = 0; h < NH; ++h) {
                         const int off = xoff(a, b, h, ND == 1 ? 0 : 1);
                         sl.xhi[h] = fetch_row<T, E>(xp + (off < 0 ? 0 : off), off >= 0, xcontig, xm);
+                    }
+                    if constexpr (ND >= 2) {
+                        if (need_low || (ND == 3 && b == 0)) {
+#pragma unroll
+                            for (int h = 0; h < NH; ++h) {
+                                const int off = xoff(a, b, h, 0);
+                                sl.xlo[h] = fetch_row<T, E>(xp + (off < 0 ? 0 : off), off >= 0, xcontig, xm);
+                                if constexpr (ACTIVE) {
+                                    const int off2 = goff(oa, ob, h, 0);
+                                    sl.glo[h] = fetch_row<T, E>(gp + (off2 < 0 ? 0 : off2), off2 >= 0, gcontig, gm);
+                                }
+                            }
+                        }
                     }
                     if constexpr (ACTIVE) {
 #pragma unroll
@@ -651,25 +672,15 @@ __global__ __launch_bounds__(kThreads) void plane_backward_pipe(const PlaneParam
                         store_chunk<S, E>(dst, res);
                         return;
                     }
-                    const int a = fdiv(r, p.d_dim1);
-                    const int oa = a - p.L[0], ob = cur.b - p.L[1];
-                    // the "+0" combos: carried over from the previous row of this band when possible
+                    // the "+0" combos: carried over from the previous row of this band when possible, else the
+                    // slot's own copies (prefetch loaded them: prev_ok == false was known one row ahead)
                     const bool carry = (ND >= 2) && prev_ok && (ND < 3 || cur.b != 0);
                     RowRaw<T, E> xlo[NH], glo[NH];
                     if constexpr (ND >= 2) {
 #pragma unroll
                         for (int h = 0; h < NH; ++h) {
-                            if (carry) {
-                                xlo[h] = prv.xhi[h];
-                                if constexpr (ACTIVE) glo[h] = prv.ghi[h];
-                            } else {
-                                const int off = xoff(a, cur.b, h, 0);
-                                xlo[h] = fetch_row<T, E>(xp + (off < 0 ? 0 : off), off >= 0, xcontig, xm);
-                                if constexpr (ACTIVE) {
-                                    const int off2 = goff(oa, ob, h, 0);
-                                    glo[h] = fetch_row<T, E>(gp + (off2 < 0 ? 0 : off2), off2 >= 0, gcontig, gm);
-                                }
-                            }
+                            xlo[h] = carry ? prv.xhi[h] : cur.xlo[h];
+                            if constexpr (ACTIVE) glo[h] = carry ? prv.ghi[h] : cur.glo[h];
                         }
                     }
 #pragma unroll
@@ -705,20 +716,166 @@ __global__ __launch_bounds__(kThreads) void plane_backward_pipe(const PlaneParam
                 };
 
                 Slot ring[3];
-                prefetch(rb0, ring[0]);
+                const int step = banded ? 1 : p.RPS;
+                prefetch(rb0, ring[0], true);
                 bool prev_ok = false;
-                for (int r = rb0; r < rb1; r += 3) {
+                for (int r = rb0; r < rb1; r += 3 * step) {
 #pragma unroll
                     for (int ph = 0; ph < 3; ++ph) {
-                        const int rr = r + ph;
+                        const int rr = r + ph * step;
                         if (rr < rb1) {
-                            if (rr + 1 < rb1) prefetch(rr + 1, ring[(ph + 1) % 3]);
-                            process(rr, ring[ph], ring[(ph + 2) % 3], prev_ok);
+                            // row rr + 1 can carry its "+0" rows from row rr only when rr issues loads (banded mode)
+                            if (rr + step < rb1) prefetch(rr + step, ring[(ph + 1) % 3], !(banded && ring[ph].rowin));
+                            process(rr, ring[ph], ring[(ph + 2) % 3], banded && prev_ok);
                             prev_ok = ring[ph].rowin;
                         }
                     }
                 }
             }
+        }
+    }
+#pragma unroll
+    for (int s = 0; s < 3; ++s) {
+        const double t = block_sum(acc[s], scratch);
+        if (threadIdx.x == 0) p.partials[(static_cast<size_t>(wi.pidx) * p.C + wi.c) * 3 + s] = t;
+    }
+}
+
+// =====================================================================================================
+// Backward, LDS-staged form (2-D, no crop): every source row a step needs is brought into LDS once with
+// aligned 16-byte LDS-DMA loads (global_load_lds_dwordx4: no VGPRs, whole 64-byte lines), and all shifted /
+// corner / padded accesses become ds_reads at element granularity.  Compared with plane_backward this
+// removes the element-aligned global loads (every line requested twice), the per-element edge path
+// (same ds_read code serves interior and padded chunks) and the second global read of shared rows.
+// Per step of R rows the tile holds: R+1 rows of x (corner rows), R rows of grad_out (direct) and
+// R (SSL) or R+1 (active) shifted rows of grad_out; a slot whose map says "fill" is simply not read.
+// =====================================================================================================
+template <typename T, bool ACTIVE>
+__global__ __launch_bounds__(kThreads) void plane_backward_lds(const PlaneParams p) {
+    using S = typename T::S;
+    using CT = typename T::C;
+    constexpr int E = 16 / sizeof(S);
+    constexpr int ND = 2;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    __shared__ double scratch[kThreads / 64];
+    const int R = p.RPS;
+    const int NX = R + 1, NG = R, NGS = ACTIVE ? R + 1 : R, NS = NX + NG + NGS;
+    const int RB = p.S[2] * static_cast<int>(sizeof(S));  // row bytes, a multiple of 16
+    char *tile = smem;
+    int *maps = reinterpret_cast<int *>(smem + p.tile_bytes);
+    const int *m1 = maps + p.S[0] + 1, *m2 = m1 + p.S[1] + 1;
+    int *gmaps = maps + p.S[0] + p.S[1] + p.S[2] + 3;
+    const int *g1 = gmaps + p.O[0] + 1, *g2 = g1 + p.O[1] + 1;
+    int *slot_src = gmaps + p.O[0] + p.O[1] + p.O[2] + 3;
+
+    const WorkItem wi = decode_block(p);
+    int64_t sh[3] = {0, 0, 0};
+    CT dw[3] = {CT(0), CT(0), CT(0)};
+#pragma unroll
+    for (int d = 0; d < 3; ++d)
+        if (p.wcol[d] >= 0)
+            prep_shift_backward<CT>(load_weight<CT>(p.w, p.wkind, wi.c * p.nd + p.wcol[d]), ACTIVE, sh[d], dw[p.wcol[d]]);
+    build_maps(maps, p.S, sh, -1, p.pad);
+    build_maps(gmaps, p.O, sh, ACTIVE ? -1 : +1, p.pad);
+    __syncthreads();
+
+    const int S2 = p.S[2];
+    const int tr = threadIdx.x / p.CW, tc = threadIdx.x - tr * p.CW;
+    const bool worker = tr < R;
+    const int ji = tc * E;
+    int xm[E + 1], gm[E + 1];
+#pragma unroll
+    for (int e = 0; e <= E; ++e) {
+        xm[e] = worker ? m2[ji + e] : -1;
+        gm[e] = worker ? g2[ji + e] : -1;  // no crop: grad_out coordinates == input coordinates
+    }
+    const S zero = narrow<T>(CT(0));
+    double acc[3] = {0.0, 0.0, 0.0};
+    const int row_end = wi.row0 + wi.nrows;
+    const int pieces = NS * static_cast<int>(p.cpr);
+
+    for (int nl = 0; nl < wi.nn; ++nl) {
+        const int64_t plane = static_cast<int64_t>(wi.n0 + nl) * p.C + wi.c;
+        const S *xp = static_cast<const S *>(p.x) + plane * p.x_plane;
+        const S *gp = static_cast<const S *>(p.go) + plane * p.o_plane;
+        S *gxp = static_cast<S *>(p.out) + plane * p.x_plane;
+        for (int r0 = wi.row0; r0 < row_end; r0 += R) {
+            const int Rn = min(R, row_end - r0);
+            // slot table: element offset of each staged row inside its plane, or -1
+            if (threadIdx.x < NS) {
+                const int k = threadIdx.x;
+                int src;
+                if (k < NX) {
+                    const int v = (k <= Rn) ? m1[r0 + k] : -1;
+                    src = v < 0 ? -1 : v * S2;
+                } else if (k < NX + NG) {
+                    const int kk = k - NX;
+                    src = (kk < Rn) ? (r0 + kk) * S2 : -1;
+                } else {
+                    const int kk = k - NX - NG;
+                    const int v = (ACTIVE ? kk <= Rn : kk < Rn) ? g1[r0 + kk] : -1;
+                    src = v < 0 ? -1 : v * S2;
+                }
+                slot_src[k] = src;
+            }
+            __syncthreads();
+            // LDS-DMA: piece q = 16 bytes; lanes of a wave take consecutive pieces (LDS destination is linear)
+            for (int q0 = 0; q0 < pieces; q0 += kThreads) {
+                const int q = q0 + threadIdx.x;
+                if (q < pieces) {
+                    const int slot = fdiv(q, p.d_cpr);
+                    const int j = q - slot * static_cast<int>(p.cpr);
+                    const int src = slot_src[slot];
+                    if (src >= 0) {
+                        const S *g = (slot < NX ? xp : gp) + src + j * E;
+                        char *dst_wave = tile + (q0 + (threadIdx.x & ~63)) * 16;  // wave-uniform; hardware adds lane*16
+                        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)g,
+                                                         (__attribute__((address_space(3))) void *)dst_wave, 16, 0, 0);
+                    }
+                }
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (worker && tr < Rn) {
+                const int b = r0 + tr;
+                const S *tx0 = reinterpret_cast<const S *>(tile + tr * RB);
+                const S *tx1 = reinterpret_cast<const S *>(tile + (tr + 1) * RB);
+                const S *tg = reinterpret_cast<const S *>(tile + (NX + tr) * RB);
+                const S *ts0 = reinterpret_cast<const S *>(tile + (NX + NG + tr) * RB);
+                const S *ts1 = reinterpret_cast<const S *>(tile + (NX + NG + tr + 1) * RB);
+                const bool vx0 = slot_src[tr] >= 0, vx1 = slot_src[tr + 1] >= 0;
+                const bool vs0 = slot_src[NX + NG + tr] >= 0;
+                const bool vs1 = ACTIVE ? slot_src[NX + NG + tr + 1] >= 0 : false;
+                Chunk<S, E> gch;
+                __builtin_memcpy(gch.e, __builtin_assume_aligned(tg + ji, 16), 16);
+                CT xv[2][E + 1], gv[2][E + 1];
+                Chunk<S, E> res;
+#pragma unroll
+                for (int e = 0; e <= E; ++e) {
+                    xv[0][e] = (vx0 && xm[e] >= 0) ? widen<T>(tx0[xm[e]]) : CT(0);
+                    xv[1][e] = (vx1 && xm[e] >= 0) ? widen<T>(tx1[xm[e]]) : CT(0);
+                    if constexpr (ACTIVE) {
+                        gv[0][e] = (vs0 && gm[e] >= 0) ? widen<T>(ts0[gm[e]]) : CT(0);
+                        gv[1][e] = (vs1 && gm[e] >= 0) ? widen<T>(ts1[gm[e]]) : CT(0);
+                    }
+                }
+#pragma unroll
+                for (int e = 0; e < E; ++e) {
+                    CT v[4] = {xv[0][e], xv[1][e], xv[0][e + 1], xv[1][e + 1]}, wg[3];
+                    weight_grads_nd<ND, CT>(v, dw, wg);
+                    const CT gval = widen<T>(gch.e[e]);
+                    acc[0] += static_cast<double>(gval * wg[0]);
+                    acc[1] += static_cast<double>(gval * wg[1]);
+                    if constexpr (ACTIVE) {
+                        const CT u[4] = {gv[0][e], gv[1][e], gv[0][e + 1], gv[1][e + 1]};
+                        res.e[e] = narrow<T>(interp_nd<ND, CT>(u, dw));
+                    } else {
+                        res.e[e] = (vs0 && gm[e] >= 0) ? ts0[gm[e]] : zero;
+                    }
+                }
+                store_chunk<S, E>(gxp + static_cast<int64_t>(b) * S2 + ji, res);
+            }
+            __syncthreads();  // the tile is overwritten by the next step
         }
     }
 #pragma unroll
@@ -743,8 +900,8 @@ bool contiguous(const int64_t st[5], int64_t N, int64_t C, const int64_t sz[3]) 
 }
 
 // diagnostics knobs (shiftnd_set_tuning): 0 = min workgroups wanted, 1 = target bytes per workgroup,
-// 2 = gather-forward unroll (fp32/16-byte variant only), 3 = 0: use the pipelined backward kernel (default 1: simple loop)
-int g_tune[8] = {2048, 128 * 1024, 4, 1, 0, 0, 0, 0};
+// 2 = gather-forward unroll (fp32/16-byte variant only), 3 = backward kernel: 2 LDS-staged where it applies (default), 1 simple loop, 0 pipelined
+int g_tune[8] = {2048, 128 * 1024, 4, 2, 1, 0, 0, 0};
 
 struct Plan {
     int V, cpr, CW, RPS, CP, ppw, groups, bands, rows_per_band, rows;
@@ -815,6 +972,8 @@ void fill_params(PlaneParams &p, const Geometry &g, const Plan &pl, int64_t dim1
     if (p.tbands < 1) p.tbands = 1;
     p.tband_len = (pl.rows_per_band + p.tbands - 1) / p.tbands;
     p.d_tbands = make_fastdiv(static_cast<uint32_t>(p.tbands));
+    p.tband_mode = g_tune[4];
+    p.d_cpr = make_fastdiv(static_cast<uint32_t>(pl.cpr));
     p.d_dim1 = make_fastdiv(static_cast<uint32_t>(dim1));
 }
 
@@ -859,8 +1018,31 @@ int launch_active_forward(const PlaneParams &p, const Plan &pl, hipStream_t st) 
     return SHIFTND_OK;
 }
 
+bool lds_backward_ok(const PlaneParams &p, const Plan &pl, int esize, size_t *lds_bytes, int *tile_bytes) {
+    if (p.nd != 2 || pl.CP != 1) return false;
+    for (int d = 0; d < 3; ++d)
+        if (p.L[d] != 0 || p.O[d] != p.S[d]) return false;  // no crop: grad_out rows == input rows
+    const int slots = 3 * pl.RPS + 2;
+    const size_t tile = static_cast<size_t>(slots) * p.S[2] * esize;
+    const size_t total = tile + pl.lds + static_cast<size_t>(slots) * sizeof(int);
+    if (total > 60 * 1024 || slots > kThreads) return false;
+    *lds_bytes = total;
+    *tile_bytes = static_cast<int>(tile);
+    return true;
+}
+
 template <typename T, bool ACTIVE>
-void launch_backward_a(const PlaneParams &p, const Plan &pl, hipStream_t st) {
+void launch_backward_a(const PlaneParams &p_in, const Plan &pl, hipStream_t st) {
+    PlaneParams p = p_in;
+    if (g_tune[3] == 2) {  // LDS-staged form where it applies
+        size_t lds_bytes = 0;
+        int tile_bytes = 0;
+        if (lds_backward_ok(p, pl, static_cast<int>(sizeof(typename T::S)), &lds_bytes, &tile_bytes)) {
+            p.tile_bytes = tile_bytes;
+            hipLaunchKernelGGL((plane_backward_lds<T, ACTIVE>), dim3(pl.grid), dim3(kThreads), lds_bytes, st, p);
+            return;
+        }
+    }
     if (g_tune[3] == 0) {  // pipelined form (measured slower than the simple loop on MI355X so far: opt-in)
         switch (p.nd) {
         case 1: hipLaunchKernelGGL((plane_backward_pipe<T, 1, ACTIVE>), dim3(pl.grid), dim3(kThreads), pl.lds, st, p); break;

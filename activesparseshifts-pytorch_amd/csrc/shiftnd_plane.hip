@@ -47,6 +47,7 @@ struct PlaneParams {
     int tbands, tband_len;  // pipelined backward: row bands per plane share handed to the RPS row slots
     int tband_mode;         // 1: consecutive rows per thread (register carry), 0: rows RPS apart
     int tile_bytes;         // LDS-staged backward: bytes of the row tile in front of the maps
+    unsigned xcd_blocks;    // grid / 8 when the XCD-contiguous block remap is on (grid % 8 == 0), else 0
     FastDiv d_cpr;
     FastDiv d_tbands;
     FastDiv d_rows;     // divide by rows_per_band
@@ -92,7 +93,8 @@ struct WorkItem {  // which planes / rows this workgroup owns
 };
 __device__ __forceinline__ WorkItem decode_block(const PlaneParams &p) {
     WorkItem wi;
-    const int bid = blockIdx.x;
+    // XCD-contiguous ids (tuning knob 6): workgroups that share an XCD (blockIdx % 8) own adjacent planes
+    const int bid = p.xcd_blocks ? static_cast<int>((blockIdx.x & 7u) * p.xcd_blocks + (blockIdx.x >> 3)) : static_cast<int>(blockIdx.x);
     wi.c = bid % p.C;
     const int rest = bid / p.C;
     const int grp = rest % p.groups;
@@ -750,8 +752,8 @@ __global__ __launch_bounds__(kThreads) void plane_backward_pipe(const PlaneParam
 // Per step of R rows the tile holds: R+1 rows of x (corner rows), R rows of grad_out (direct) and
 // R (SSL) or R+1 (active) shifted rows of grad_out; a slot whose map says "fill" is simply not read.
 // =====================================================================================================
-template <typename T, bool ACTIVE>
-__global__ __launch_bounds__(kThreads) void plane_backward_lds(const PlaneParams p) {
+template <typename T, bool ACTIVE, int OCC>
+__global__ __launch_bounds__(kThreads, OCC) void plane_backward_lds(const PlaneParams p) {
     using S = typename T::S;
     using CT = typename T::C;
     constexpr int E = 16 / sizeof(S);
@@ -794,90 +796,268 @@ __global__ __launch_bounds__(kThreads) void plane_backward_lds(const PlaneParams
     const int row_end = wi.row0 + wi.nrows;
     const int pieces = NS * static_cast<int>(p.cpr);
 
-    for (int nl = 0; nl < wi.nn; ++nl) {
+    // slot table of a step: element offset of each staged row inside its plane, or -1.  Two tables: the table
+    // of step s+1 is written while step s is computed, so a step costs two barriers.
+    auto make_slots = [&](int r0, int Rn, int buf) {
+        if (threadIdx.x < NS) {
+            const int k = threadIdx.x;
+            int src;
+            if (k < NX) {
+                const int v = (k <= Rn) ? m1[r0 + k] : -1;
+                src = v < 0 ? -1 : v * S2;
+            } else if (k < NX + NG) {
+                const int kk = k - NX;
+                src = (kk < Rn) ? (r0 + kk) * S2 : -1;
+            } else {
+                const int kk = k - NX - NG;
+                const int v = (ACTIVE ? kk <= Rn : kk < Rn) ? g1[r0 + kk] : -1;
+                src = v < 0 ? -1 : v * S2;
+            }
+            slot_src[buf * NS + k] = src;
+        }
+    };
+    const int steps_per_plane = (wi.nrows + R - 1) / R;
+    const int total_steps = wi.nn * steps_per_plane;
+    int nl = 0, r0 = wi.row0, buf = 0;
+    make_slots(r0, min(R, row_end - r0), 0);
+    __syncthreads();
+    for (int step = 0; step < total_steps; ++step) {
+        const int Rn = min(R, row_end - r0);
+        const int *ss = slot_src + buf * NS;
         const int64_t plane = static_cast<int64_t>(wi.n0 + nl) * p.C + wi.c;
         const S *xp = static_cast<const S *>(p.x) + plane * p.x_plane;
         const S *gp = static_cast<const S *>(p.go) + plane * p.o_plane;
         S *gxp = static_cast<S *>(p.out) + plane * p.x_plane;
-        for (int r0 = wi.row0; r0 < row_end; r0 += R) {
-            const int Rn = min(R, row_end - r0);
-            // slot table: element offset of each staged row inside its plane, or -1
-            if (threadIdx.x < NS) {
-                const int k = threadIdx.x;
-                int src;
-                if (k < NX) {
-                    const int v = (k <= Rn) ? m1[r0 + k] : -1;
-                    src = v < 0 ? -1 : v * S2;
-                } else if (k < NX + NG) {
-                    const int kk = k - NX;
-                    src = (kk < Rn) ? (r0 + kk) * S2 : -1;
-                } else {
-                    const int kk = k - NX - NG;
-                    const int v = (ACTIVE ? kk <= Rn : kk < Rn) ? g1[r0 + kk] : -1;
-                    src = v < 0 ? -1 : v * S2;
-                }
-                slot_src[k] = src;
-            }
-            __syncthreads();
-            // LDS-DMA: piece q = 16 bytes; lanes of a wave take consecutive pieces (LDS destination is linear)
-            for (int q0 = 0; q0 < pieces; q0 += kThreads) {
-                const int q = q0 + threadIdx.x;
-                if (q < pieces) {
-                    const int slot = fdiv(q, p.d_cpr);
-                    const int j = q - slot * static_cast<int>(p.cpr);
-                    const int src = slot_src[slot];
-                    if (src >= 0) {
-                        const S *g = (slot < NX ? xp : gp) + src + j * E;
-                        char *dst_wave = tile + (q0 + (threadIdx.x & ~63)) * 16;  // wave-uniform; hardware adds lane*16
-                        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)g,
-                                                         (__attribute__((address_space(3))) void *)dst_wave, 16, 0, 0);
-                    }
+        // LDS-DMA: piece q = 16 bytes; lanes of a wave take consecutive pieces (LDS destination is linear)
+        for (int q0 = 0; q0 < pieces; q0 += kThreads) {
+            const int q = q0 + threadIdx.x;
+            if (q < pieces) {
+                const int slot = fdiv(q, p.d_cpr);
+                const int j = q - slot * static_cast<int>(p.cpr);
+                const int src = ss[slot];
+                if (src >= 0) {
+                    const S *g = (slot < NX ? xp : gp) + src + j * E;
+                    char *dst_wave = tile + (q0 + (threadIdx.x & ~63)) * 16;  // wave-uniform; hardware adds lane*16
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)g,
+                                                     (__attribute__((address_space(3))) void *)dst_wave, 16, 0, 0);
                 }
             }
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
-            if (worker && tr < Rn) {
-                const int b = r0 + tr;
-                const S *tx0 = reinterpret_cast<const S *>(tile + tr * RB);
-                const S *tx1 = reinterpret_cast<const S *>(tile + (tr + 1) * RB);
-                const S *tg = reinterpret_cast<const S *>(tile + (NX + tr) * RB);
-                const S *ts0 = reinterpret_cast<const S *>(tile + (NX + NG + tr) * RB);
-                const S *ts1 = reinterpret_cast<const S *>(tile + (NX + NG + tr + 1) * RB);
-                const bool vx0 = slot_src[tr] >= 0, vx1 = slot_src[tr + 1] >= 0;
-                const bool vs0 = slot_src[NX + NG + tr] >= 0;
-                const bool vs1 = ACTIVE ? slot_src[NX + NG + tr + 1] >= 0 : false;
-                Chunk<S, E> gch;
-                __builtin_memcpy(gch.e, __builtin_assume_aligned(tg + ji, 16), 16);
-                CT xv[2][E + 1], gv[2][E + 1];
-                Chunk<S, E> res;
-#pragma unroll
-                for (int e = 0; e <= E; ++e) {
-                    xv[0][e] = (vx0 && xm[e] >= 0) ? widen<T>(tx0[xm[e]]) : CT(0);
-                    xv[1][e] = (vx1 && xm[e] >= 0) ? widen<T>(tx1[xm[e]]) : CT(0);
-                    if constexpr (ACTIVE) {
-                        gv[0][e] = (vs0 && gm[e] >= 0) ? widen<T>(ts0[gm[e]]) : CT(0);
-                        gv[1][e] = (vs1 && gm[e] >= 0) ? widen<T>(ts1[gm[e]]) : CT(0);
-                    }
-                }
-#pragma unroll
-                for (int e = 0; e < E; ++e) {
-                    CT v[4] = {xv[0][e], xv[1][e], xv[0][e + 1], xv[1][e + 1]}, wg[3];
-                    weight_grads_nd<ND, CT>(v, dw, wg);
-                    const CT gval = widen<T>(gch.e[e]);
-                    acc[0] += static_cast<double>(gval * wg[0]);
-                    acc[1] += static_cast<double>(gval * wg[1]);
-                    if constexpr (ACTIVE) {
-                        const CT u[4] = {gv[0][e], gv[1][e], gv[0][e + 1], gv[1][e + 1]};
-                        res.e[e] = narrow<T>(interp_nd<ND, CT>(u, dw));
-                    } else {
-                        res.e[e] = (vs0 && gm[e] >= 0) ? ts0[gm[e]] : zero;
-                    }
-                }
-                store_chunk<S, E>(gxp + static_cast<int64_t>(b) * S2 + ji, res);
-            }
-            __syncthreads();  // the tile is overwritten by the next step
         }
+        int nl2 = nl, r2 = r0 + R;
+        if (r2 >= row_end) { r2 = wi.row0; ++nl2; }
+        if (step + 1 < total_steps) make_slots(r2, min(R, row_end - r2), buf ^ 1);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (worker && tr < Rn) {
+            const int b = r0 + tr;
+            const S *tx0 = reinterpret_cast<const S *>(tile + tr * RB);
+            const S *tx1 = reinterpret_cast<const S *>(tile + (tr + 1) * RB);
+            const S *tg = reinterpret_cast<const S *>(tile + (NX + tr) * RB);
+            const S *ts0 = reinterpret_cast<const S *>(tile + (NX + NG + tr) * RB);
+            const S *ts1 = reinterpret_cast<const S *>(tile + (NX + NG + tr + 1) * RB);
+            const bool vx0 = ss[tr] >= 0, vx1 = ss[tr + 1] >= 0;
+            const bool vs0 = ss[NX + NG + tr] >= 0;
+            const bool vs1 = ACTIVE ? ss[NX + NG + tr + 1] >= 0 : false;
+            Chunk<S, E> gch;
+            __builtin_memcpy(gch.e, __builtin_assume_aligned(tg + ji, 16), 16);
+            CT xv[2][E + 1], gv[2][E + 1];
+            Chunk<S, E> res;
+#pragma unroll
+            for (int e = 0; e <= E; ++e) {
+                xv[0][e] = (vx0 && xm[e] >= 0) ? widen<T>(tx0[xm[e]]) : CT(0);
+                xv[1][e] = (vx1 && xm[e] >= 0) ? widen<T>(tx1[xm[e]]) : CT(0);
+                if constexpr (ACTIVE) {
+                    gv[0][e] = (vs0 && gm[e] >= 0) ? widen<T>(ts0[gm[e]]) : CT(0);
+                    gv[1][e] = (vs1 && gm[e] >= 0) ? widen<T>(ts1[gm[e]]) : CT(0);
+                }
+            }
+#pragma unroll
+            for (int e = 0; e < E; ++e) {
+                CT v[4] = {xv[0][e], xv[1][e], xv[0][e + 1], xv[1][e + 1]}, wg[3];
+                weight_grads_nd<ND, CT>(v, dw, wg);
+                const CT gval = widen<T>(gch.e[e]);
+                acc[0] += static_cast<double>(gval * wg[0]);
+                acc[1] += static_cast<double>(gval * wg[1]);
+                if constexpr (ACTIVE) {
+                    const CT u[4] = {gv[0][e], gv[1][e], gv[0][e + 1], gv[1][e + 1]};
+                    res.e[e] = narrow<T>(interp_nd<ND, CT>(u, dw));
+                } else {
+                    res.e[e] = (vs0 && gm[e] >= 0) ? ts0[gm[e]] : zero;
+                }
+            }
+            store_chunk<S, E>(gxp + static_cast<int64_t>(b) * S2 + ji, res);
+        }
+        __syncthreads();  // the tile is overwritten by the next step; the next slot table is complete
+        nl = nl2;
+        r0 = r2;
+        buf ^= 1;
     }
+#pragma unroll
+    for (int s = 0; s < 3; ++s) {
+        const double t = block_sum(acc[s], scratch);
+        if (threadIdx.x == 0) p.partials[(static_cast<size_t>(wi.pidx) * p.C + wi.c) * 3 + s] = t;
+    }
+}
+
+// Double-buffered form of the LDS-staged backward: the rows of step s+1 are in flight (LDS-DMA into the other
+// tile) while step s is computed; one barrier per step.
+template <typename T, bool ACTIVE>
+__global__ __launch_bounds__(kThreads) void plane_backward_lds2(const PlaneParams p) {
+    using S = typename T::S;
+    using CT = typename T::C;
+    constexpr int E = 16 / sizeof(S);
+    constexpr int ND = 2;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    __shared__ double scratch[kThreads / 64];
+    const int R = p.RPS;
+    const int NX = R + 1, NG = R, NGS = ACTIVE ? R + 1 : R, NS = NX + NG + NGS;
+    const int RB = p.S[2] * static_cast<int>(sizeof(S));  // row bytes, a multiple of 16
+    char *tiles = smem;  // two tiles of p.tile_bytes each (double buffer)
+    int *maps = reinterpret_cast<int *>(smem + 2 * p.tile_bytes);
+    const int *m1 = maps + p.S[0] + 1, *m2 = m1 + p.S[1] + 1;
+    int *gmaps = maps + p.S[0] + p.S[1] + p.S[2] + 3;
+    const int *g1 = gmaps + p.O[0] + 1, *g2 = g1 + p.O[1] + 1;
+    int *slot_src = gmaps + p.O[0] + p.O[1] + p.O[2] + 3;
+
+    const WorkItem wi = decode_block(p);
+    int64_t sh[3] = {0, 0, 0};
+    CT dw[3] = {CT(0), CT(0), CT(0)};
+#pragma unroll
+    for (int d = 0; d < 3; ++d)
+        if (p.wcol[d] >= 0)
+            prep_shift_backward<CT>(load_weight<CT>(p.w, p.wkind, wi.c * p.nd + p.wcol[d]), ACTIVE, sh[d], dw[p.wcol[d]]);
+    build_maps(maps, p.S, sh, -1, p.pad);
+    build_maps(gmaps, p.O, sh, ACTIVE ? -1 : +1, p.pad);
+    __syncthreads();
+
+    const int S2 = p.S[2];
+    const int tr = threadIdx.x / p.CW, tc = threadIdx.x - tr * p.CW;
+    const bool worker = tr < R;
+    const int ji = tc * E;
+    int xm[E + 1], gm[E + 1];
+#pragma unroll
+    for (int e = 0; e <= E; ++e) {
+        xm[e] = worker ? m2[ji + e] : -1;
+        gm[e] = worker ? g2[ji + e] : -1;  // no crop: grad_out coordinates == input coordinates
+    }
+    const S zero = narrow<T>(CT(0));
+    double acc[3] = {0.0, 0.0, 0.0};
+    const int row_end = wi.row0 + wi.nrows;
+    const int pieces = NS * static_cast<int>(p.cpr);
+
+    // slot table of a step: element offset of each staged row inside its plane, or -1 (two tables: double buffer)
+    auto make_slots = [&](int r0, int Rn, int buf) {
+        if (threadIdx.x < NS) {
+            const int k = threadIdx.x;
+            int src;
+            if (k < NX) {
+                const int v = (k <= Rn) ? m1[r0 + k] : -1;
+                src = v < 0 ? -1 : v * S2;
+            } else if (k < NX + NG) {
+                const int kk = k - NX;
+                src = (kk < Rn) ? (r0 + kk) * S2 : -1;
+            } else {
+                const int kk = k - NX - NG;
+                const int v = (ACTIVE ? kk <= Rn : kk < Rn) ? g1[r0 + kk] : -1;
+                src = v < 0 ? -1 : v * S2;
+            }
+            slot_src[buf * NS + k] = src;
+        }
+    };
+    // LDS-DMA of a step's rows into tile `buf`; lanes of a wave take consecutive 16-byte pieces
+    auto issue_dma = [&](int nl, int buf) {
+        const int64_t plane = static_cast<int64_t>(wi.n0 + nl) * p.C + wi.c;
+        const S *xp = static_cast<const S *>(p.x) + plane * p.x_plane;
+        const S *gp = static_cast<const S *>(p.go) + plane * p.o_plane;
+        char *tile = tiles + buf * p.tile_bytes;
+        for (int q0 = 0; q0 < pieces; q0 += kThreads) {
+            const int q = q0 + threadIdx.x;
+            if (q < pieces) {
+                const int slot = fdiv(q, p.d_cpr);
+                const int j = q - slot * static_cast<int>(p.cpr);
+                const int src = slot_src[buf * NS + slot];
+                if (src >= 0) {
+                    const S *g = (slot < NX ? xp : gp) + src + j * E;
+                    char *dst_wave = tile + (q0 + (threadIdx.x & ~63)) * 16;
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)g,
+                                                     (__attribute__((address_space(3))) void *)dst_wave, 16, 0, 0);
+                }
+            }
+        }
+    };
+
+    const int steps_per_plane = (wi.nrows + R - 1) / R;
+    const int total_steps = wi.nn * steps_per_plane;
+    int nl = 0, r0 = wi.row0, buf = 0;
+    make_slots(r0, min(R, row_end - r0), 0);
+    __syncthreads();
+    issue_dma(0, 0);
+    bool stored = false;  // did this wave issue a global store after its last DMA? (decides the vmcnt to wait for)
+    for (int step = 0; step < total_steps; ++step) {
+        const int Rn = min(R, row_end - r0);
+        int nl2 = nl, r2 = r0 + R;
+        if (r2 >= row_end) { r2 = wi.row0; ++nl2; }
+        const bool has_next = step + 1 < total_steps;
+        if (has_next) make_slots(r2, min(R, row_end - r2), buf ^ 1);
+        // wait for this step's DMA only: vector-memory operations retire in order, so the (younger) store of the
+        // previous step may stay in flight
+        if (stored) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (has_next) issue_dma(nl2, buf ^ 1);  // tile buf^1 was last read before the barrier above
+        stored = false;
+        const bool active_lane = worker && tr < Rn;
+        if (active_lane) {
+            const char *tile = tiles + buf * p.tile_bytes;
+            const int *ss = slot_src + buf * NS;
+            const int64_t plane = static_cast<int64_t>(wi.n0 + nl) * p.C + wi.c;
+            S *gxp = static_cast<S *>(p.out) + plane * p.x_plane;
+            const int b = r0 + tr;
+            const S *tx0 = reinterpret_cast<const S *>(tile + tr * RB);
+            const S *tx1 = reinterpret_cast<const S *>(tile + (tr + 1) * RB);
+            const S *tg = reinterpret_cast<const S *>(tile + (NX + tr) * RB);
+            const S *ts0 = reinterpret_cast<const S *>(tile + (NX + NG + tr) * RB);
+            const S *ts1 = reinterpret_cast<const S *>(tile + (NX + NG + tr + 1) * RB);
+            const bool vx0 = ss[tr] >= 0, vx1 = ss[tr + 1] >= 0;
+            const bool vs0 = ss[NX + NG + tr] >= 0;
+            const bool vs1 = ACTIVE ? ss[NX + NG + tr + 1] >= 0 : false;
+            Chunk<S, E> gch;
+            __builtin_memcpy(gch.e, __builtin_assume_aligned(tg + ji, 16), 16);
+            CT xv[2][E + 1], gv[2][E + 1];
+            Chunk<S, E> res;
+#pragma unroll
+            for (int e = 0; e <= E; ++e) {
+                xv[0][e] = (vx0 && xm[e] >= 0) ? widen<T>(tx0[xm[e]]) : CT(0);
+                xv[1][e] = (vx1 && xm[e] >= 0) ? widen<T>(tx1[xm[e]]) : CT(0);
+                if constexpr (ACTIVE) {
+                    gv[0][e] = (vs0 && gm[e] >= 0) ? widen<T>(ts0[gm[e]]) : CT(0);
+                    gv[1][e] = (vs1 && gm[e] >= 0) ? widen<T>(ts1[gm[e]]) : CT(0);
+                }
+            }
+#pragma unroll
+            for (int e = 0; e < E; ++e) {
+                CT v[4] = {xv[0][e], xv[1][e], xv[0][e + 1], xv[1][e + 1]}, wg[3];
+                weight_grads_nd<ND, CT>(v, dw, wg);
+                const CT gval = widen<T>(gch.e[e]);
+                acc[0] += static_cast<double>(gval * wg[0]);
+                acc[1] += static_cast<double>(gval * wg[1]);
+                if constexpr (ACTIVE) {
+                    const CT u[4] = {gv[0][e], gv[1][e], gv[0][e + 1], gv[1][e + 1]};
+                    res.e[e] = narrow<T>(interp_nd<ND, CT>(u, dw));
+                } else {
+                    res.e[e] = (vs0 && gm[e] >= 0) ? ts0[gm[e]] : zero;
+                }
+            }
+            store_chunk<S, E>(gxp + static_cast<int64_t>(b) * S2 + ji, res);
+        }
+        stored = __builtin_amdgcn_ballot_w64(active_lane) != 0ull;  // wave-uniform: one store instruction was issued
+        nl = nl2;
+        r0 = r2;
+        buf ^= 1;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
     for (int s = 0; s < 3; ++s) {
         const double t = block_sum(acc[s], scratch);
@@ -900,8 +1080,9 @@ bool contiguous(const int64_t st[5], int64_t N, int64_t C, const int64_t sz[3]) 
 }
 
 // diagnostics knobs (shiftnd_set_tuning): 0 = min workgroups wanted, 1 = target bytes per workgroup,
-// 2 = gather-forward unroll (fp32/16-byte variant only), 3 = backward kernel: 2 LDS-staged where it applies (default), 1 simple loop, 0 pipelined
-int g_tune[8] = {2048, 128 * 1024, 4, 2, 1, 0, 0, 0};
+// 2 = gather-forward unroll (fp32/16-byte variant only), 6 = XCD-contiguous workgroup ids, 7 = minimum workgroups
+// wanted by the backward kernels (row bands of a plane share source rows through their XCD's L2), 3 = backward kernel: 2 LDS-staged where it applies (default), 1 simple loop, 0 pipelined
+int g_tune[8] = {2048, 128 * 1024, 4, 2, 1, 0, 1, 65536};
 
 struct Plan {
     int V, cpr, CW, RPS, CP, ppw, groups, bands, rows_per_band, rows;
@@ -910,7 +1091,7 @@ struct Plan {
 };
 
 // rows/inner: iteration space of one plane; esize: element bytes; V: chunk bytes
-Plan make_plan(const Geometry &g, int64_t rows, int64_t inner, int esize, int V, int map_entries) {
+Plan make_plan(const Geometry &g, int64_t rows, int64_t inner, int esize, int V, int map_entries, int64_t min_wgs_override = 0) {
     Plan pl;
     pl.V = V;
     pl.rows = static_cast<int>(rows);
@@ -920,7 +1101,7 @@ Plan make_plan(const Geometry &g, int64_t rows, int64_t inner, int esize, int V,
     pl.RPS = kThreads / pl.CW;
     pl.CP = (pl.cpr + pl.CW - 1) / pl.CW;
     const int64_t plane_bytes = rows * inner * esize;
-    const int64_t min_wgs = g_tune[0];
+    const int64_t min_wgs = min_wgs_override > 0 ? min_wgs_override : g_tune[0];
     int64_t ppw = g_tune[1] / (plane_bytes > 0 ? plane_bytes : 1);
     if (ppw < 1) ppw = 1;
     if (ppw > g.N) ppw = g.N;
@@ -973,6 +1154,7 @@ void fill_params(PlaneParams &p, const Geometry &g, const Plan &pl, int64_t dim1
     p.tband_len = (pl.rows_per_band + p.tbands - 1) / p.tbands;
     p.d_tbands = make_fastdiv(static_cast<uint32_t>(p.tbands));
     p.tband_mode = g_tune[4];
+    p.xcd_blocks = (g_tune[6] && pl.grid % 8 == 0) ? pl.grid / 8 : 0;
     p.d_cpr = make_fastdiv(static_cast<uint32_t>(pl.cpr));
     p.d_dim1 = make_fastdiv(static_cast<uint32_t>(dim1));
 }
@@ -1034,12 +1216,22 @@ bool lds_backward_ok(const PlaneParams &p, const Plan &pl, int esize, size_t *ld
 template <typename T, bool ACTIVE>
 void launch_backward_a(const PlaneParams &p_in, const Plan &pl, hipStream_t st) {
     PlaneParams p = p_in;
-    if (g_tune[3] == 2) {  // LDS-staged form where it applies
+    if (g_tune[3] == 2 || g_tune[3] == 3) {  // LDS-staged forms where they apply
         size_t lds_bytes = 0;
         int tile_bytes = 0;
         if (lds_backward_ok(p, pl, static_cast<int>(sizeof(typename T::S)), &lds_bytes, &tile_bytes)) {
             p.tile_bytes = tile_bytes;
-            hipLaunchKernelGGL((plane_backward_lds<T, ACTIVE>), dim3(pl.grid), dim3(kThreads), lds_bytes, st, p);
+            if (g_tune[3] == 3) {
+                const int slots = 3 * pl.RPS + 2;
+                const size_t bytes2 = lds_bytes + tile_bytes + static_cast<size_t>(slots) * sizeof(int);
+                hipLaunchKernelGGL((plane_backward_lds2<T, ACTIVE>), dim3(pl.grid), dim3(kThreads), bytes2, st, p);
+            } else {
+                const size_t bytes1 = lds_bytes + static_cast<size_t>(3 * pl.RPS + 2) * sizeof(int);  // second slot table
+                if (g_tune[5] == 8)
+                    hipLaunchKernelGGL((plane_backward_lds<T, ACTIVE, 8>), dim3(pl.grid), dim3(kThreads), bytes1, st, p);
+                else
+                    hipLaunchKernelGGL((plane_backward_lds<T, ACTIVE, 1>), dim3(pl.grid), dim3(kThreads), bytes1, st, p);
+            }
             return;
         }
     }
@@ -1070,7 +1262,7 @@ int launch_backward(const PlaneParams &p, const Plan &pl, bool active, void *gw,
 
 Plan backward_plan(const Geometry &g, int esize) {
     const int entries = static_cast<int>(g.S[0] + g.S[1] + g.S[2] + g.O[0] + g.O[1] + g.O[2] + 6);
-    return make_plan(g, g.S[0] * g.S[1], g.S[2], esize, 16, entries);
+    return make_plan(g, g.S[0] * g.S[1], g.S[2], esize, 16, entries, g_tune[7]);
 }
 
 }  // namespace

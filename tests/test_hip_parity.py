@@ -67,7 +67,7 @@ def test_golden_random_grid(abi):
         assert rel_err(gw.cpu().numpy(), gw_r) < tol, "grad_w " + key
 
 
-@pytest.mark.parametrize("policy", [0, 1, 2])
+@pytest.mark.parametrize("policy", [0, 1, 2, 3])
 def test_golden_quantized(abi, policy):
     abi.set_path_policy(policy)
     tdt = {"quint8": torch.uint8, "qint8": torch.int8, "qint32": torch.int32}
@@ -79,12 +79,12 @@ def test_golden_quantized(abi, policy):
             x = x.contiguous(memory_format=torch.channels_last_3d)
         w = torch.from_numpy(wq).to(torch.uint8 if wname == "wu8" else torch.int8).to(DEV)
         b, _ = abi.check_borders(list(xq.shape), crop, nd)
-        if policy == 2 and layout != "nchw":
-            continue  # plane kernels need contiguous NC[spatial] tensors
+        if policy in (2, 3) and layout != "nchw":
+            continue  # plane / sweep kernels need contiguous NC[spatial] tensors
         out = abi.forward_quantized(x, w, wzp, xzp, pad, b)
         assert np.array_equal(out.cpu().numpy(), out_r), key
-        if policy in (0, 2) and layout == "nchw":
-            assert abi.last_path() == (abi.PATH_SWEEP if policy == 0 else abi.PATH_PLANE), key
+        if policy in (0, 2, 3) and layout == "nchw":
+            assert abi.last_path() == (abi.PATH_SWEEP if policy == 3 else abi.PATH_PLANE), key
     abi.set_path_policy(0)
 
 
@@ -122,12 +122,15 @@ def test_random_vs_oracle(abi, shape, crop, dt):
         for active in (0, 1):
             out = abi.forward(xd, wd, pad, active, b)
             inner_bytes = new[-1] * x.itemsize
-            if active == 0:
-                assert abi.last_path() == abi.PATH_SWEEP
-            elif inner_bytes % 16 == 0:
-                assert abi.last_path() == abi.PATH_PLANE
+            if active == 0 or inner_bytes % 16 == 0:
+                assert abi.last_path() == abi.PATH_PLANE  # small planes: plane kernels by default
             ref_out = O.forward(x, w, pad, active, b)
             assert np.array_equal(out.cpu().numpy(), ref_out), ("fwd", pad, active)
+            if active == 0:  # the sweep kernels serve the same problems
+                abi.set_path_policy(3)
+                outs = abi.forward(xd, wd, pad, active, b)
+                abi.set_path_policy(0)
+                assert abi.last_path() == abi.PATH_SWEEP and np.array_equal(outs.cpu().numpy(), ref_out)
             abi.set_path_policy(2)  # the plane kernels serve the same problems
             try:
                 outp = abi.forward(xd, wd, pad, active, b)
@@ -209,7 +212,7 @@ def test_quantized_random_vs_oracle(abi):
         b, new = abi.check_borders(list(shape), crop, nd)
         for pad in range(5):
             ref = O.forward_q(xq, wq, 128, zp, pad, b)
-            for policy, path in ((0, abi.PATH_SWEEP), (2, abi.PATH_PLANE)):
+            for policy, path in ((3, abi.PATH_SWEEP), (2, abi.PATH_PLANE)):
                 abi.set_path_policy(policy)
                 out = abi.forward_quantized(torch.from_numpy(xq).to(tdt).to(DEV), torch.from_numpy(wq).to(DEV), 128, zp, pad, b)
                 assert abi.last_path() == path
@@ -256,8 +259,12 @@ def test_large_plane_band_split_and_wide_rows(abi):
         for pad in (0, 2, 3):
             for active in (0, 1):
                 out = abi.forward(xd, wd, pad, active)
-                assert abi.last_path() == (abi.PATH_PLANE if active else abi.PATH_SWEEP)
+                big_plane = shape[2] * shape[3] * 4 >= 32768
+                assert abi.last_path() == (abi.PATH_SWEEP if (not active and big_plane) else abi.PATH_PLANE)
                 assert np.array_equal(out.cpu().numpy(), O.forward(x, w, pad, active))
+                if not active:
+                    abi.set_path_policy(3)
+                    assert torch.equal(abi.forward(xd, wd, pad, active), out) and abi.last_path() == abi.PATH_SWEEP
                 abi.set_path_policy(2)
                 assert torch.equal(abi.forward(xd, wd, pad, active), out) and abi.last_path() == abi.PATH_PLANE
                 abi.set_path_policy(0)

@@ -41,13 +41,19 @@ def main():
     ap.add_argument("--pad", type=int, default=0)
     ap.add_argument("--knobs", default="")
     ap.add_argument("--wrange", type=float, default=3.0)
+    ap.add_argument("--policy", type=int, default=0)
     a = ap.parse_args()
     nd, shape, dtname, active, desc = WORKLOADS[a.workload]
     dev = torch.device("cuda:0")
-    dtype = torch.float32 if dtname == "quint8" else getattr(torch, dtname)
+    abi.set_path_policy(a.policy)
+    quant = dtname == "quint8"
+    dtype = torch.float32 if quant else getattr(torch, dtname)
     x = synth_tensor(torch, shape, 1, dev, dtype)
     go = synth_tensor(torch, shape, 2, dev, dtype)
     w = synth_tensor(torch, (shape[1], nd), 3, dev, torch.float32, -a.wrange, a.wrange).to(dtype)
+    if quant:
+        x = (x * 255).to(torch.uint8)
+        wq = (w.float().round() + 128).to(torch.uint8)
     out, gx, gw = torch.empty_like(x), torch.empty_like(x), torch.empty_like(w)
     elems, es = x.numel(), x.element_size()
     knobs = []
@@ -60,10 +66,13 @@ def main():
         for ci, combo in enumerate(combos):
             for k, v in combo:
                 abi.set_tuning(k, v)
-            ws = abi.backward_workspace(x, a.pad, active)
+            ws = None if quant else abi.backward_workspace(x, a.pad, active)
             tag = ",".join("%d=%d" % kv for kv in combo) or "default"
-            fns = {"fwd[" + tag + "]": lambda: abi.forward(x, w, a.pad, active, out=out),
-                   "bwd[" + tag + "]": lambda: abi.backward(go, w, x, a.pad, active, grad_x=gx, grad_w=gw, workspace=ws)}
+            if quant:
+                fns = {"fwd[" + tag + "]": lambda: abi.forward_quantized(x, wq, 128, 0, a.pad, out=out)}
+            else:
+                fns = {"fwd[" + tag + "]": lambda: abi.forward(x, w, a.pad, active, out=out),
+                       "bwd[" + tag + "]": lambda: abi.backward(go, w, x, a.pad, active, grad_x=gx, grad_w=gw, workspace=ws)}
             if ci == 0:
                 fns["copy"] = lambda: out.copy_(x)
             for name, fn in fns.items():

@@ -744,31 +744,128 @@ __global__ __launch_bounds__(kThreads) void plane_backward_pipe(const PlaneParam
 }
 
 // =====================================================================================================
-// Backward, LDS-staged form (2-D, no crop): every source row a step needs is brought into LDS once with
-// aligned 16-byte LDS-DMA loads (global_load_lds_dwordx4: no VGPRs, whole 64-byte lines), and all shifted /
-// corner / padded accesses become ds_reads at element granularity.  Compared with plane_backward this
-// removes the element-aligned global loads (every line requested twice), the per-element edge path
-// (same ds_read code serves interior and padded chunks) and the second global read of shared rows.
-// Per step of R rows the tile holds: R+1 rows of x (corner rows), R rows of grad_out (direct) and
-// R (SSL) or R+1 (active) shifted rows of grad_out; a slot whose map says "fill" is simply not read.
+// LDS-staged kernels (2-D and 3-D, no crop): every source row a step needs is brought into LDS once with
+// aligned 16-byte LDS-DMA loads (global_load_lds_dwordx4: no VGPRs, whole lines), and all shifted / corner /
+// padded accesses become ds_reads at element granularity.  Compared with the direct-load kernels this removes
+// the element-aligned global loads (every line requested twice), the per-element edge path (one ds_read code
+// path serves interior and padded chunks) and the repeated global reads of rows that neighbouring rows share.
+// A step = up to R consecutive rows (a, b0 .. b0+Rn-1) of one plane (fixed a).  Slots of its tile:
+//   X   NA x (R+1) rows of x:  (map0[a + ha], map1[b0 + k])            NA = 2 for 3-D (corner planes), else 1
+//   G   R rows of grad_out at the rows themselves (backward only)
+//   GS  backward, active: NA x (R+1) rows of grad_out through the grad maps; SSL: R shifted rows
+// A slot whose map says "fill" is not loaded and never read.
 // =====================================================================================================
-template <typename T, bool ACTIVE, int OCC>
-__global__ __launch_bounds__(kThreads, OCC) void plane_backward_lds(const PlaneParams p) {
+template <int ND, bool ACTIVE, bool BACKWARD> struct LdsTileShape {
+    static constexpr int NA = ND == 3 ? 2 : 1;
+    __host__ __device__ static int nx(int R) { return NA * (R + 1); }
+    __host__ __device__ static int ng(int R) { return BACKWARD ? R : 0; }
+    __host__ __device__ static int ngs(int R) { return BACKWARD ? (ACTIVE ? NA * (R + 1) : R) : 0; }
+    __host__ __device__ static int slots(int R) { return nx(R) + ng(R) + ngs(R); }
+};
+
+// Shared by the LDS-staged kernels: slot table + LDS-DMA of one step.
+template <typename T, int ND, bool ACTIVE, bool BACKWARD>
+struct LdsStager {
+    using S = typename T::S;
+    using Shape = LdsTileShape<ND, ACTIVE, BACKWARD>;
+    static constexpr int E = 16 / sizeof(S);
+    static constexpr int NA = Shape::NA;
+
+    // slot table: element offset of each staged row inside its plane, or -1
+    __device__ static void make_slots(const PlaneParams &p, int R, int a, int b0, int Rn, const int *m0, const int *m1,
+                                      const int *g0, const int *g1, int *slot_src) {
+        const int NX = Shape::nx(R), NG = Shape::ng(R), NS = Shape::slots(R);
+        const int k = threadIdx.x;
+        if (k >= NS) return;
+        int src = -1;
+        if (k < NX) {
+            const int ha = k / (R + 1), kk = k - ha * (R + 1);
+            if (kk <= Rn) {
+                const int ra = m0[a + ha], rb = m1[b0 + kk];
+                if (ra >= 0 && rb >= 0) src = (ra * p.S[1] + rb) * p.S[2];
+            }
+        } else if (k < NX + NG) {
+            const int kk = k - NX;
+            if (kk < Rn) src = (a * p.S[1] + b0 + kk) * p.S[2];
+        } else if (ACTIVE) {
+            const int k2 = k - NX - NG;
+            const int ha = k2 / (R + 1), kk = k2 - ha * (R + 1);
+            if (kk <= Rn) {
+                const int ra = g0[a + ha], rb = g1[b0 + kk];
+                if (ra >= 0 && rb >= 0) src = (ra * p.S[1] + rb) * p.S[2];
+            }
+        } else {
+            const int kk = k - NX - NG;
+            if (kk < Rn) {
+                const int ra = g0[a], rb = g1[b0 + kk];
+                if (ra >= 0 && rb >= 0) src = (ra * p.S[1] + rb) * p.S[2];
+            }
+        }
+        slot_src[k] = src;
+    }
+
+    // LDS-DMA: piece q = 16 bytes; lanes of a wave take consecutive pieces (the LDS destination is linear)
+    __device__ static void issue_dma(const PlaneParams &p, int R, const S *xp, const S *gp, const int *slot_src, char *tile) {
+        const int NX = Shape::nx(R);
+        const int pieces = Shape::slots(R) * static_cast<int>(p.cpr);
+        for (int q0 = 0; q0 < pieces; q0 += kThreads) {
+            const int q = q0 + threadIdx.x;
+            if (q < pieces) {
+                const int slot = fdiv(q, p.d_cpr);
+                const int j = q - slot * static_cast<int>(p.cpr);
+                const int src = slot_src[slot];
+                if (src >= 0) {
+                    const S *g = (slot < NX ? xp : gp) + src + j * E;
+                    char *dst_wave = tile + (q0 + (threadIdx.x & ~63)) * 16;  // wave-uniform; hardware adds lane * 16
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)g,
+                                                     (__attribute__((address_space(3))) void *)dst_wave, 16, 0, 0);
+                }
+            }
+        }
+    }
+};
+
+// corner values of one chunk from the staged rows: vals[k][e], k = outer corner combo (bit r <-> +1 along real
+// dim r < ND-1), e = 0..E (E + 1 columns through the column map)
+template <typename T, int ND>
+__device__ __forceinline__ void lds_corners(const char *tile, int RB, int R, int slot0, const int *ss, int tr,
+                                            const int (&cm)[16 / sizeof(typename T::S) + 1],
+                                            typename T::C (&vals)[1 << (ND - 1)][16 / sizeof(typename T::S) + 1]) {
     using S = typename T::S;
     using CT = typename T::C;
     constexpr int E = 16 / sizeof(S);
-    constexpr int ND = 2;
+    constexpr int NC = 1 << (ND - 1);
+#pragma unroll
+    for (int k = 0; k < NC; ++k) {
+        const int ha = ND == 3 ? (k & 1) : 0;
+        const int hb = ND == 3 ? ((k >> 1) & 1) : (k & 1);
+        const int slot = slot0 + ha * (R + 1) + tr + hb;
+        const bool valid = ss[slot] >= 0;
+        const S *row = reinterpret_cast<const S *>(tile + slot * RB);
+#pragma unroll
+        for (int e = 0; e <= E; ++e) vals[k][e] = (valid && cm[e] >= 0) ? widen<T>(row[cm[e]]) : CT(0);
+    }
+}
+
+template <typename T, int ND, bool ACTIVE, int OCC>
+__global__ __launch_bounds__(kThreads, OCC) void plane_backward_lds(const PlaneParams p) {
+    using S = typename T::S;
+    using CT = typename T::C;
+    using Stager = LdsStager<T, ND, ACTIVE, true>;
+    using Shape = LdsTileShape<ND, ACTIVE, true>;
+    constexpr int E = 16 / sizeof(S);
+    constexpr int NC = 1 << (ND - 1);
     extern __shared__ __attribute__((aligned(16))) char smem[];
     __shared__ double scratch[kThreads / 64];
     const int R = p.RPS;
-    const int NX = R + 1, NG = R, NGS = ACTIVE ? R + 1 : R, NS = NX + NG + NGS;
+    const int NX = Shape::nx(R), NG = Shape::ng(R), NS = Shape::slots(R);
     const int RB = p.S[2] * static_cast<int>(sizeof(S));  // row bytes, a multiple of 16
     char *tile = smem;
     int *maps = reinterpret_cast<int *>(smem + p.tile_bytes);
-    const int *m1 = maps + p.S[0] + 1, *m2 = m1 + p.S[1] + 1;
+    const int *m0 = maps, *m1 = maps + p.S[0] + 1, *m2 = m1 + p.S[1] + 1;
     int *gmaps = maps + p.S[0] + p.S[1] + p.S[2] + 3;
-    const int *g1 = gmaps + p.O[0] + 1, *g2 = g1 + p.O[1] + 1;
-    int *slot_src = gmaps + p.O[0] + p.O[1] + p.O[2] + 3;
+    const int *g0 = gmaps, *g1 = gmaps + p.O[0] + 1, *g2 = g1 + p.O[1] + 1;
+    int *slot_src = gmaps + p.O[0] + p.O[1] + p.O[2] + 3;  // two tables of NS entries
 
     const WorkItem wi = decode_block(p);
     int64_t sh[3] = {0, 0, 0};
@@ -781,7 +878,7 @@ __global__ __launch_bounds__(kThreads, OCC) void plane_backward_lds(const PlaneP
     build_maps(gmaps, p.O, sh, ACTIVE ? -1 : +1, p.pad);
     __syncthreads();
 
-    const int S2 = p.S[2];
+    const int S1 = p.S[1], S2 = p.S[2];
     const int tr = threadIdx.x / p.CW, tc = threadIdx.x - tr * p.CW;
     const bool worker = tr < R;
     const int ji = tc * E;
@@ -794,98 +891,70 @@ __global__ __launch_bounds__(kThreads, OCC) void plane_backward_lds(const PlaneP
     const S zero = narrow<T>(CT(0));
     double acc[3] = {0.0, 0.0, 0.0};
     const int row_end = wi.row0 + wi.nrows;
-    const int pieces = NS * static_cast<int>(p.cpr);
 
-    // slot table of a step: element offset of each staged row inside its plane, or -1.  Two tables: the table
-    // of step s+1 is written while step s is computed, so a step costs two barriers.
-    auto make_slots = [&](int r0, int Rn, int buf) {
-        if (threadIdx.x < NS) {
-            const int k = threadIdx.x;
-            int src;
-            if (k < NX) {
-                const int v = (k <= Rn) ? m1[r0 + k] : -1;
-                src = v < 0 ? -1 : v * S2;
-            } else if (k < NX + NG) {
-                const int kk = k - NX;
-                src = (kk < Rn) ? (r0 + kk) * S2 : -1;
-            } else {
-                const int kk = k - NX - NG;
-                const int v = (ACTIVE ? kk <= Rn : kk < Rn) ? g1[r0 + kk] : -1;
-                src = v < 0 ? -1 : v * S2;
-            }
-            slot_src[buf * NS + k] = src;
-        }
+    // steps never cross an `a` boundary; the slot table of step s+1 is written while step s is computed
+    auto step_len = [&](int r0) {
+        const int b0 = r0 - fdiv(r0, p.d_dim1) * S1;
+        return min(R, min(S1 - b0, row_end - r0));
     };
-    const int steps_per_plane = (wi.nrows + R - 1) / R;
-    const int total_steps = wi.nn * steps_per_plane;
     int nl = 0, r0 = wi.row0, buf = 0;
-    make_slots(r0, min(R, row_end - r0), 0);
+    {
+        const int a = fdiv(r0, p.d_dim1);
+        Stager::make_slots(p, R, a, r0 - a * S1, step_len(r0), m0, m1, g0, g1, slot_src);
+    }
     __syncthreads();
-    for (int step = 0; step < total_steps; ++step) {
-        const int Rn = min(R, row_end - r0);
+    while (nl < wi.nn) {
+        const int a = fdiv(r0, p.d_dim1);
+        const int b0 = r0 - a * S1;
+        const int Rn = step_len(r0);
         const int *ss = slot_src + buf * NS;
         const int64_t plane = static_cast<int64_t>(wi.n0 + nl) * p.C + wi.c;
         const S *xp = static_cast<const S *>(p.x) + plane * p.x_plane;
         const S *gp = static_cast<const S *>(p.go) + plane * p.o_plane;
         S *gxp = static_cast<S *>(p.out) + plane * p.x_plane;
-        // LDS-DMA: piece q = 16 bytes; lanes of a wave take consecutive pieces (LDS destination is linear)
-        for (int q0 = 0; q0 < pieces; q0 += kThreads) {
-            const int q = q0 + threadIdx.x;
-            if (q < pieces) {
-                const int slot = fdiv(q, p.d_cpr);
-                const int j = q - slot * static_cast<int>(p.cpr);
-                const int src = ss[slot];
-                if (src >= 0) {
-                    const S *g = (slot < NX ? xp : gp) + src + j * E;
-                    char *dst_wave = tile + (q0 + (threadIdx.x & ~63)) * 16;  // wave-uniform; hardware adds lane*16
-                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)g,
-                                                     (__attribute__((address_space(3))) void *)dst_wave, 16, 0, 0);
-                }
-            }
-        }
-        int nl2 = nl, r2 = r0 + R;
+        Stager::issue_dma(p, R, xp, gp, ss, tile);
+        int nl2 = nl, r2 = r0 + Rn;
         if (r2 >= row_end) { r2 = wi.row0; ++nl2; }
-        if (step + 1 < total_steps) make_slots(r2, min(R, row_end - r2), buf ^ 1);
+        if (nl2 < wi.nn) {
+            const int a2 = fdiv(r2, p.d_dim1);
+            Stager::make_slots(p, R, a2, r2 - a2 * S1, step_len(r2), m0, m1, g0, g1, slot_src + (buf ^ 1) * NS);
+        }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         if (worker && tr < Rn) {
-            const int b = r0 + tr;
-            const S *tx0 = reinterpret_cast<const S *>(tile + tr * RB);
-            const S *tx1 = reinterpret_cast<const S *>(tile + (tr + 1) * RB);
+            CT xv[NC][E + 1];
+            lds_corners<T, ND>(tile, RB, R, 0, ss, tr, xm, xv);
             const S *tg = reinterpret_cast<const S *>(tile + (NX + tr) * RB);
-            const S *ts0 = reinterpret_cast<const S *>(tile + (NX + NG + tr) * RB);
-            const S *ts1 = reinterpret_cast<const S *>(tile + (NX + NG + tr + 1) * RB);
-            const bool vx0 = ss[tr] >= 0, vx1 = ss[tr + 1] >= 0;
-            const bool vs0 = ss[NX + NG + tr] >= 0;
-            const bool vs1 = ACTIVE ? ss[NX + NG + tr + 1] >= 0 : false;
             Chunk<S, E> gch;
             __builtin_memcpy(gch.e, __builtin_assume_aligned(tg + ji, 16), 16);
-            CT xv[2][E + 1], gv[2][E + 1];
+            CT gv[NC][E + 1];
+            const S *ts0 = nullptr;
+            bool vs0 = false;
+            if constexpr (ACTIVE) {
+                lds_corners<T, ND>(tile, RB, R, NX + NG, ss, tr, gm, gv);
+            } else {
+                vs0 = ss[NX + NG + tr] >= 0;
+                ts0 = reinterpret_cast<const S *>(tile + (NX + NG + tr) * RB);
+            }
             Chunk<S, E> res;
 #pragma unroll
-            for (int e = 0; e <= E; ++e) {
-                xv[0][e] = (vx0 && xm[e] >= 0) ? widen<T>(tx0[xm[e]]) : CT(0);
-                xv[1][e] = (vx1 && xm[e] >= 0) ? widen<T>(tx1[xm[e]]) : CT(0);
-                if constexpr (ACTIVE) {
-                    gv[0][e] = (vs0 && gm[e] >= 0) ? widen<T>(ts0[gm[e]]) : CT(0);
-                    gv[1][e] = (vs1 && gm[e] >= 0) ? widen<T>(ts1[gm[e]]) : CT(0);
-                }
-            }
-#pragma unroll
             for (int e = 0; e < E; ++e) {
-                CT v[4] = {xv[0][e], xv[1][e], xv[0][e + 1], xv[1][e + 1]}, wg[3];
+                CT v[1 << ND], wg[3];
+#pragma unroll
+                for (int q = 0; q < (1 << ND); ++q) v[q] = xv[q & (NC - 1)][e + (q >> (ND - 1))];
                 weight_grads_nd<ND, CT>(v, dw, wg);
                 const CT gval = widen<T>(gch.e[e]);
-                acc[0] += static_cast<double>(gval * wg[0]);
-                acc[1] += static_cast<double>(gval * wg[1]);
+#pragma unroll
+                for (int s = 0; s < ND; ++s) acc[s] += static_cast<double>(gval * wg[s]);
                 if constexpr (ACTIVE) {
-                    const CT u[4] = {gv[0][e], gv[1][e], gv[0][e + 1], gv[1][e + 1]};
-                    res.e[e] = narrow<T>(interp_nd<ND, CT>(u, dw));
+#pragma unroll
+                    for (int q = 0; q < (1 << ND); ++q) v[q] = gv[q & (NC - 1)][e + (q >> (ND - 1))];
+                    res.e[e] = narrow<T>(interp_nd<ND, CT>(v, dw));
                 } else {
                     res.e[e] = (vs0 && gm[e] >= 0) ? ts0[gm[e]] : zero;
                 }
             }
-            store_chunk<S, E>(gxp + static_cast<int64_t>(b) * S2 + ji, res);
+            store_chunk<S, E>(gxp + static_cast<int64_t>(a * S1 + b0 + tr) * S2 + ji, res);
         }
         __syncthreads();  // the tile is overwritten by the next step; the next slot table is complete
         nl = nl2;
@@ -899,25 +968,23 @@ __global__ __launch_bounds__(kThreads, OCC) void plane_backward_lds(const PlaneP
     }
 }
 
-// Double-buffered form of the LDS-staged backward: the rows of step s+1 are in flight (LDS-DMA into the other
-// tile) while step s is computed; one barrier per step.
-template <typename T, bool ACTIVE>
-__global__ __launch_bounds__(kThreads) void plane_backward_lds2(const PlaneParams p) {
+// Active forward through the same staging (X slots only).
+template <typename T, int ND>
+__global__ __launch_bounds__(kThreads) void plane_active_forward_lds(const PlaneParams p) {
     using S = typename T::S;
     using CT = typename T::C;
+    using Stager = LdsStager<T, ND, true, false>;
+    using Shape = LdsTileShape<ND, true, false>;
     constexpr int E = 16 / sizeof(S);
-    constexpr int ND = 2;
+    constexpr int NC = 1 << (ND - 1);
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    __shared__ double scratch[kThreads / 64];
     const int R = p.RPS;
-    const int NX = R + 1, NG = R, NGS = ACTIVE ? R + 1 : R, NS = NX + NG + NGS;
-    const int RB = p.S[2] * static_cast<int>(sizeof(S));  // row bytes, a multiple of 16
-    char *tiles = smem;  // two tiles of p.tile_bytes each (double buffer)
-    int *maps = reinterpret_cast<int *>(smem + 2 * p.tile_bytes);
-    const int *m1 = maps + p.S[0] + 1, *m2 = m1 + p.S[1] + 1;
-    int *gmaps = maps + p.S[0] + p.S[1] + p.S[2] + 3;
-    const int *g1 = gmaps + p.O[0] + 1, *g2 = g1 + p.O[1] + 1;
-    int *slot_src = gmaps + p.O[0] + p.O[1] + p.O[2] + 3;
+    const int NS = Shape::slots(R);
+    const int RB = p.S[2] * static_cast<int>(sizeof(S));
+    char *tile = smem;
+    int *maps = reinterpret_cast<int *>(smem + p.tile_bytes);
+    const int *m0 = maps, *m1 = maps + p.S[0] + 1, *m2 = m1 + p.S[1] + 1;
+    int *slot_src = maps + p.S[0] + p.S[1] + p.S[2] + 3;  // two tables of NS entries
 
     const WorkItem wi = decode_block(p);
     int64_t sh[3] = {0, 0, 0};
@@ -925,143 +992,62 @@ __global__ __launch_bounds__(kThreads) void plane_backward_lds2(const PlaneParam
 #pragma unroll
     for (int d = 0; d < 3; ++d)
         if (p.wcol[d] >= 0)
-            prep_shift_backward<CT>(load_weight<CT>(p.w, p.wkind, wi.c * p.nd + p.wcol[d]), ACTIVE, sh[d], dw[p.wcol[d]]);
+            prep_shift_forward<CT>(load_weight<CT>(p.w, p.wkind, wi.c * p.nd + p.wcol[d]), true, sh[d], dw[p.wcol[d]]);
     build_maps(maps, p.S, sh, -1, p.pad);
-    build_maps(gmaps, p.O, sh, ACTIVE ? -1 : +1, p.pad);
     __syncthreads();
 
-    const int S2 = p.S[2];
+    const int S1 = p.S[1], S2 = p.S[2];
     const int tr = threadIdx.x / p.CW, tc = threadIdx.x - tr * p.CW;
     const bool worker = tr < R;
     const int ji = tc * E;
-    int xm[E + 1], gm[E + 1];
+    int xm[E + 1];
 #pragma unroll
-    for (int e = 0; e <= E; ++e) {
-        xm[e] = worker ? m2[ji + e] : -1;
-        gm[e] = worker ? g2[ji + e] : -1;  // no crop: grad_out coordinates == input coordinates
-    }
-    const S zero = narrow<T>(CT(0));
-    double acc[3] = {0.0, 0.0, 0.0};
+    for (int e = 0; e <= E; ++e) xm[e] = worker ? m2[ji + e] : -1;
     const int row_end = wi.row0 + wi.nrows;
-    const int pieces = NS * static_cast<int>(p.cpr);
-
-    // slot table of a step: element offset of each staged row inside its plane, or -1 (two tables: double buffer)
-    auto make_slots = [&](int r0, int Rn, int buf) {
-        if (threadIdx.x < NS) {
-            const int k = threadIdx.x;
-            int src;
-            if (k < NX) {
-                const int v = (k <= Rn) ? m1[r0 + k] : -1;
-                src = v < 0 ? -1 : v * S2;
-            } else if (k < NX + NG) {
-                const int kk = k - NX;
-                src = (kk < Rn) ? (r0 + kk) * S2 : -1;
-            } else {
-                const int kk = k - NX - NG;
-                const int v = (ACTIVE ? kk <= Rn : kk < Rn) ? g1[r0 + kk] : -1;
-                src = v < 0 ? -1 : v * S2;
-            }
-            slot_src[buf * NS + k] = src;
-        }
+    auto step_len = [&](int r0) {
+        const int b0 = r0 - fdiv(r0, p.d_dim1) * S1;
+        return min(R, min(S1 - b0, row_end - r0));
     };
-    // LDS-DMA of a step's rows into tile `buf`; lanes of a wave take consecutive 16-byte pieces
-    auto issue_dma = [&](int nl, int buf) {
+    int nl = 0, r0 = wi.row0, buf = 0;
+    {
+        const int a = fdiv(r0, p.d_dim1);
+        Stager::make_slots(p, R, a, r0 - a * S1, step_len(r0), m0, m1, nullptr, nullptr, slot_src);
+    }
+    __syncthreads();
+    while (nl < wi.nn) {
+        const int a = fdiv(r0, p.d_dim1);
+        const int b0 = r0 - a * S1;
+        const int Rn = step_len(r0);
+        const int *ss = slot_src + buf * NS;
         const int64_t plane = static_cast<int64_t>(wi.n0 + nl) * p.C + wi.c;
         const S *xp = static_cast<const S *>(p.x) + plane * p.x_plane;
-        const S *gp = static_cast<const S *>(p.go) + plane * p.o_plane;
-        char *tile = tiles + buf * p.tile_bytes;
-        for (int q0 = 0; q0 < pieces; q0 += kThreads) {
-            const int q = q0 + threadIdx.x;
-            if (q < pieces) {
-                const int slot = fdiv(q, p.d_cpr);
-                const int j = q - slot * static_cast<int>(p.cpr);
-                const int src = slot_src[buf * NS + slot];
-                if (src >= 0) {
-                    const S *g = (slot < NX ? xp : gp) + src + j * E;
-                    char *dst_wave = tile + (q0 + (threadIdx.x & ~63)) * 16;
-                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)g,
-                                                     (__attribute__((address_space(3))) void *)dst_wave, 16, 0, 0);
-                }
-            }
-        }
-    };
-
-    const int steps_per_plane = (wi.nrows + R - 1) / R;
-    const int total_steps = wi.nn * steps_per_plane;
-    int nl = 0, r0 = wi.row0, buf = 0;
-    make_slots(r0, min(R, row_end - r0), 0);
-    __syncthreads();
-    issue_dma(0, 0);
-    bool stored = false;  // did this wave issue a global store after its last DMA? (decides the vmcnt to wait for)
-    for (int step = 0; step < total_steps; ++step) {
-        const int Rn = min(R, row_end - r0);
-        int nl2 = nl, r2 = r0 + R;
+        S *op = static_cast<S *>(p.out) + plane * p.o_plane;
+        Stager::issue_dma(p, R, xp, xp, ss, tile);
+        int nl2 = nl, r2 = r0 + Rn;
         if (r2 >= row_end) { r2 = wi.row0; ++nl2; }
-        const bool has_next = step + 1 < total_steps;
-        if (has_next) make_slots(r2, min(R, row_end - r2), buf ^ 1);
-        // wait for this step's DMA only: vector-memory operations retire in order, so the (younger) store of the
-        // previous step may stay in flight
-        if (stored) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-        if (has_next) issue_dma(nl2, buf ^ 1);  // tile buf^1 was last read before the barrier above
-        stored = false;
-        const bool active_lane = worker && tr < Rn;
-        if (active_lane) {
-            const char *tile = tiles + buf * p.tile_bytes;
-            const int *ss = slot_src + buf * NS;
-            const int64_t plane = static_cast<int64_t>(wi.n0 + nl) * p.C + wi.c;
-            S *gxp = static_cast<S *>(p.out) + plane * p.x_plane;
-            const int b = r0 + tr;
-            const S *tx0 = reinterpret_cast<const S *>(tile + tr * RB);
-            const S *tx1 = reinterpret_cast<const S *>(tile + (tr + 1) * RB);
-            const S *tg = reinterpret_cast<const S *>(tile + (NX + tr) * RB);
-            const S *ts0 = reinterpret_cast<const S *>(tile + (NX + NG + tr) * RB);
-            const S *ts1 = reinterpret_cast<const S *>(tile + (NX + NG + tr + 1) * RB);
-            const bool vx0 = ss[tr] >= 0, vx1 = ss[tr + 1] >= 0;
-            const bool vs0 = ss[NX + NG + tr] >= 0;
-            const bool vs1 = ACTIVE ? ss[NX + NG + tr + 1] >= 0 : false;
-            Chunk<S, E> gch;
-            __builtin_memcpy(gch.e, __builtin_assume_aligned(tg + ji, 16), 16);
-            CT xv[2][E + 1], gv[2][E + 1];
+        if (nl2 < wi.nn) {
+            const int a2 = fdiv(r2, p.d_dim1);
+            Stager::make_slots(p, R, a2, r2 - a2 * S1, step_len(r2), m0, m1, nullptr, nullptr, slot_src + (buf ^ 1) * NS);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (worker && tr < Rn) {
+            CT xv[NC][E + 1];
+            lds_corners<T, ND>(tile, RB, R, 0, ss, tr, xm, xv);
             Chunk<S, E> res;
 #pragma unroll
-            for (int e = 0; e <= E; ++e) {
-                xv[0][e] = (vx0 && xm[e] >= 0) ? widen<T>(tx0[xm[e]]) : CT(0);
-                xv[1][e] = (vx1 && xm[e] >= 0) ? widen<T>(tx1[xm[e]]) : CT(0);
-                if constexpr (ACTIVE) {
-                    gv[0][e] = (vs0 && gm[e] >= 0) ? widen<T>(ts0[gm[e]]) : CT(0);
-                    gv[1][e] = (vs1 && gm[e] >= 0) ? widen<T>(ts1[gm[e]]) : CT(0);
-                }
-            }
-#pragma unroll
             for (int e = 0; e < E; ++e) {
-                CT v[4] = {xv[0][e], xv[1][e], xv[0][e + 1], xv[1][e + 1]}, wg[3];
-                weight_grads_nd<ND, CT>(v, dw, wg);
-                const CT gval = widen<T>(gch.e[e]);
-                acc[0] += static_cast<double>(gval * wg[0]);
-                acc[1] += static_cast<double>(gval * wg[1]);
-                if constexpr (ACTIVE) {
-                    const CT u[4] = {gv[0][e], gv[1][e], gv[0][e + 1], gv[1][e + 1]};
-                    res.e[e] = narrow<T>(interp_nd<ND, CT>(u, dw));
-                } else {
-                    res.e[e] = (vs0 && gm[e] >= 0) ? ts0[gm[e]] : zero;
-                }
+                CT v[1 << ND];
+#pragma unroll
+                for (int q = 0; q < (1 << ND); ++q) v[q] = xv[q & (NC - 1)][e + (q >> (ND - 1))];
+                res.e[e] = narrow<T>(interp_nd<ND, CT>(v, dw));
             }
-            store_chunk<S, E>(gxp + static_cast<int64_t>(b) * S2 + ji, res);
+            store_chunk<S, E>(op + static_cast<int64_t>(a * S1 + b0 + tr) * S2 + ji, res);
         }
-        stored = __builtin_amdgcn_ballot_w64(active_lane) != 0ull;  // wave-uniform: one store instruction was issued
+        __syncthreads();
         nl = nl2;
         r0 = r2;
         buf ^= 1;
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#pragma unroll
-    for (int s = 0; s < 3; ++s) {
-        const double t = block_sum(acc[s], scratch);
-        if (threadIdx.x == 0) p.partials[(static_cast<size_t>(wi.pidx) * p.C + wi.c) * 3 + s] = t;
     }
 }
 
@@ -1190,8 +1176,35 @@ void launch_gather(const PlaneParams &p, const Plan &pl, hipStream_t st) {
     hipLaunchKernelGGL((plane_gather_forward<ESIZE, V, 4>), dim3(pl.grid), dim3(kThreads), pl.lds, st, p);
 }
 
+// eligibility + LDS size of the LDS-staged kernels: 2-D / 3-D, no crop, one column pass, slot table <= threads
+bool lds_staged_ok(const PlaneParams &p, const Plan &pl, int esize, int slots, size_t *lds_bytes, int *tile_bytes) {
+    if ((p.nd != 2 && p.nd != 3) || pl.CP != 1) return false;
+    for (int d = 0; d < 3; ++d)
+        if (p.L[d] != 0 || p.O[d] != p.S[d]) return false;  // no crop: output rows == input rows
+    const size_t tile = static_cast<size_t>(slots) * p.S[2] * esize;
+    const size_t total = tile + pl.lds + 2 * static_cast<size_t>(slots) * sizeof(int);
+    if (total > 64 * 1024 || slots > kThreads) return false;
+    *lds_bytes = total;
+    *tile_bytes = static_cast<int>(tile);
+    return true;
+}
+
 template <typename T>
-int launch_active_forward(const PlaneParams &p, const Plan &pl, hipStream_t st) {
+int launch_active_forward(const PlaneParams &p_in, const Plan &pl, hipStream_t st) {
+    PlaneParams p = p_in;
+    if (g_tune[3] == 2 && p.nd >= 2) {  // LDS-staged form where it applies
+        size_t lds_bytes = 0;
+        int tile_bytes = 0;
+        const int slots = p.nd == 3 ? LdsTileShape<3, true, false>::slots(pl.RPS) : LdsTileShape<2, true, false>::slots(pl.RPS);
+        if (lds_staged_ok(p, pl, static_cast<int>(sizeof(typename T::S)), slots, &lds_bytes, &tile_bytes)) {
+            p.tile_bytes = tile_bytes;
+            if (p.nd == 3)
+                hipLaunchKernelGGL((plane_active_forward_lds<T, 3>), dim3(pl.grid), dim3(kThreads), lds_bytes, st, p);
+            else
+                hipLaunchKernelGGL((plane_active_forward_lds<T, 2>), dim3(pl.grid), dim3(kThreads), lds_bytes, st, p);
+            return SHIFTND_OK;
+        }
+    }
     switch (p.nd) {
     case 1: hipLaunchKernelGGL((plane_active_forward<T, 1>), dim3(pl.grid), dim3(kThreads), pl.lds, st, p); break;
     case 2: hipLaunchKernelGGL((plane_active_forward<T, 2>), dim3(pl.grid), dim3(kThreads), pl.lds, st, p); break;
@@ -1200,38 +1213,19 @@ int launch_active_forward(const PlaneParams &p, const Plan &pl, hipStream_t st) 
     return SHIFTND_OK;
 }
 
-bool lds_backward_ok(const PlaneParams &p, const Plan &pl, int esize, size_t *lds_bytes, int *tile_bytes) {
-    if (p.nd != 2 || pl.CP != 1) return false;
-    for (int d = 0; d < 3; ++d)
-        if (p.L[d] != 0 || p.O[d] != p.S[d]) return false;  // no crop: grad_out rows == input rows
-    const int slots = 3 * pl.RPS + 2;
-    const size_t tile = static_cast<size_t>(slots) * p.S[2] * esize;
-    const size_t total = tile + pl.lds + static_cast<size_t>(slots) * sizeof(int);
-    if (total > 60 * 1024 || slots > kThreads) return false;
-    *lds_bytes = total;
-    *tile_bytes = static_cast<int>(tile);
-    return true;
-}
-
 template <typename T, bool ACTIVE>
 void launch_backward_a(const PlaneParams &p_in, const Plan &pl, hipStream_t st) {
     PlaneParams p = p_in;
-    if (g_tune[3] == 2 || g_tune[3] == 3) {  // LDS-staged forms where they apply
+    if (g_tune[3] == 2 && p.nd >= 2) {  // LDS-staged form where it applies
         size_t lds_bytes = 0;
         int tile_bytes = 0;
-        if (lds_backward_ok(p, pl, static_cast<int>(sizeof(typename T::S)), &lds_bytes, &tile_bytes)) {
+        const int slots = p.nd == 3 ? LdsTileShape<3, ACTIVE, true>::slots(pl.RPS) : LdsTileShape<2, ACTIVE, true>::slots(pl.RPS);
+        if (lds_staged_ok(p, pl, static_cast<int>(sizeof(typename T::S)), slots, &lds_bytes, &tile_bytes)) {
             p.tile_bytes = tile_bytes;
-            if (g_tune[3] == 3) {
-                const int slots = 3 * pl.RPS + 2;
-                const size_t bytes2 = lds_bytes + tile_bytes + static_cast<size_t>(slots) * sizeof(int);
-                hipLaunchKernelGGL((plane_backward_lds2<T, ACTIVE>), dim3(pl.grid), dim3(kThreads), bytes2, st, p);
-            } else {
-                const size_t bytes1 = lds_bytes + static_cast<size_t>(3 * pl.RPS + 2) * sizeof(int);  // second slot table
-                if (g_tune[5] == 8)
-                    hipLaunchKernelGGL((plane_backward_lds<T, ACTIVE, 8>), dim3(pl.grid), dim3(kThreads), bytes1, st, p);
-                else
-                    hipLaunchKernelGGL((plane_backward_lds<T, ACTIVE, 1>), dim3(pl.grid), dim3(kThreads), bytes1, st, p);
-            }
+            if (p.nd == 3)
+                hipLaunchKernelGGL((plane_backward_lds<T, 3, ACTIVE, 1>), dim3(pl.grid), dim3(kThreads), lds_bytes, st, p);
+            else
+                hipLaunchKernelGGL((plane_backward_lds<T, 2, ACTIVE, 1>), dim3(pl.grid), dim3(kThreads), lds_bytes, st, p);
             return;
         }
     }

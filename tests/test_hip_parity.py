@@ -319,15 +319,18 @@ def test_pipelined_backward_variants(abi, mode):
         abi.set_tuning(4, 1)
 
 
-def test_lds_staged_backward(abi):
-    """opt-in LDS-staged 2-D backward (tuning knob 3 = 2) vs the default kernel: grad_x bit for bit"""
+def test_lds_staged_kernels(abi):
+    """the LDS-staged kernels (default, tuning knob 3 = 2: active forward and backward, 2-D / 3-D, no crop) vs
+    the direct-load plane kernels (knob 3 = 1): forward and grad_x bit for bit, grad_w to rounding"""
     rs = np.random.RandomState(33)
-    cases = [(3, 5, 9, 24), (2, 4, 13, 32), (2, 3, 1, 16), (1, 2, 300, 8), (2, 3, 40, 224), (1, 2, 7, 1000)]
+    cases = [(3, 5, 9, 24), (2, 4, 13, 32), (2, 3, 1, 16), (1, 2, 300, 8), (2, 3, 40, 224), (1, 2, 7, 1000),
+             (2, 3, 5, 6, 16), (2, 2, 4, 7, 24), (1, 3, 1, 5, 8), (1, 2, 3, 40, 112), (1, 2, 6, 1, 32)]
     try:
         for shape in cases:
-            for dt, tdt in ((np.float32, None), (np.float64, None), (np.float32, torch.bfloat16)):
+            nd = len(shape) - 2
+            for dt, tdt in ((np.float32, None), (np.float64, None), (np.float32, torch.bfloat16), (np.float32, torch.float16)):
                 x = rs.uniform(-1, 1, size=shape).astype(dt)
-                w = _weights(rs, shape[1], 2, shape[2:]).astype(dt)
+                w = _weights(rs, shape[1], nd, shape[2:]).astype(dt)
                 go = rs.uniform(-1, 1, size=shape).astype(dt)
                 xd, wd, god = _dev(x), _dev(w), _dev(go)
                 if tdt is not None:
@@ -335,10 +338,13 @@ def test_lds_staged_backward(abi):
                 for pad in range(5):
                     for active in (0, 1):
                         abi.set_tuning(3, 1)
+                        out0 = abi.forward(xd, wd, pad, active)
                         gx0, gw0 = abi.backward(god, wd, xd, pad, active)
                         abi.set_tuning(3, 2)
+                        out1 = abi.forward(xd, wd, pad, active)
                         gx1, gw1 = abi.backward(god, wd, xd, pad, active)
                         assert abi.last_path() == abi.PATH_PLANE
+                        assert torch.equal(out0, out1), (shape, dt, tdt, pad, active)
                         assert torch.equal(gx0, gx1), (shape, dt, tdt, pad, active)
                         assert rel_err(gw1.float().cpu().numpy(), gw0.float().cpu().numpy()) < 1e-5, (shape, pad, active)
     finally:

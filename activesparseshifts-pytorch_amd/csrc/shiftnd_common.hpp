@@ -204,6 +204,53 @@ template <int ND, typename CT> __device__ __forceinline__ void weight_grads_nd(c
 }
 
 // ---------------------------------------------------------------------------------------------
+// Weight gradient in multilinear form.  Every partial of compute_weight_gradients is a multilinear blend,
+// with per-channel (uniform) coefficients, of corner DIFFERENCES:
+//   2-D: A = v2-v0, B = v3-v1:          wg0 = lerp(A, B, dW),  wg1 = lerp(A, B, dH)
+//   3-D: A0 = v2-v0, B0 = v3-v1, A1 = v6-v4, B1 = v7-v5, Dq = v(q+4)-v(q):
+//        wg0 = lerp(lerp(A0,B0,dW), lerp(A1,B1,dW), dD), wg1 = same with dH, wg2 = bilerp(D0..D3; dH, dW)
+//   1-D: wg0 = v1-v0
+// so sum_e g_e * wg_s(e) = blend_s(sum_e g_e * diff_k(e)): the streaming loop accumulates NDIFF sums of
+// g * difference (differences first: no cancellation between large sums) and the blends are applied once per
+// thread.  Same value as the per-element form up to fp32 rounding of each term (the tests' bar for grad_w is
+// 1e-5 relative to an fp64 evaluation; on the dyadic fixture both forms are exact).
+// ---------------------------------------------------------------------------------------------
+template <int ND> struct WDiff { static constexpr int N = ND == 1 ? 1 : (ND == 2 ? 2 : 8); };
+
+template <int ND, typename CT> __device__ __forceinline__ void corner_diffs(const CT *v, CT *d) {
+    if constexpr (ND == 1) {
+        d[0] = v[1] - v[0];
+    } else if constexpr (ND == 2) {
+        d[0] = v[2] - v[0];
+        d[1] = v[3] - v[1];
+    } else {
+        d[0] = v[2] - v[0];
+        d[1] = v[3] - v[1];
+        d[2] = v[6] - v[4];
+        d[3] = v[7] - v[5];
+        d[4] = v[4] - v[0];
+        d[5] = v[5] - v[1];
+        d[6] = v[6] - v[2];
+        d[7] = v[7] - v[3];
+    }
+}
+
+// blends of the accumulated sums (fp64) -> the nD weight-gradient partials of this thread
+template <int ND> __device__ __forceinline__ void blend_diffs(const double *s, const double *d /*dH,dW,dD*/, double *g) {
+    auto lerp = [](double a, double b, double x) { return a * (1.0 - x) + b * x; };
+    if constexpr (ND == 1) {
+        g[0] = s[0];
+    } else if constexpr (ND == 2) {
+        g[0] = lerp(s[0], s[1], d[1]);
+        g[1] = lerp(s[0], s[1], d[0]);
+    } else {
+        g[0] = lerp(lerp(s[0], s[1], d[1]), lerp(s[2], s[3], d[1]), d[2]);
+        g[1] = lerp(lerp(s[0], s[1], d[0]), lerp(s[2], s[3], d[0]), d[2]);
+        g[2] = lerp(lerp(s[4], s[5], d[0]), lerp(s[6], s[7], d[0]), d[1]);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // Workgroup-wide fp64 sum (deterministic: fixed shuffle tree, fixed wave order).
 // Returns the total in thread 0.  `scratch` needs kThreads/64 doubles of LDS.
 // ---------------------------------------------------------------------------------------------

@@ -889,7 +889,10 @@ __global__ __launch_bounds__(kThreads, OCC) void plane_backward_lds(const PlaneP
         gm[e] = worker ? g2[ji + e] : -1;  // no crop: grad_out coordinates == input coordinates
     }
     const S zero = narrow<T>(CT(0));
-    double acc[3] = {0.0, 0.0, 0.0};
+    constexpr int NDIFF = WDiff<ND>::N;
+    double dsum[NDIFF];  // sums of g * corner difference (see corner_diffs)
+#pragma unroll
+    for (int i = 0; i < NDIFF; ++i) dsum[i] = 0.0;
     const int row_end = wi.row0 + wi.nrows;
 
     // steps never cross an `a` boundary; the slot table of step s+1 is written while step s is computed
@@ -937,15 +940,18 @@ __global__ __launch_bounds__(kThreads, OCC) void plane_backward_lds(const PlaneP
                 ts0 = reinterpret_cast<const S *>(tile + (NX + NG + tr) * RB);
             }
             Chunk<S, E> res;
+            CT part[NDIFF];  // this chunk's sums, in the compute type (E terms each)
+#pragma unroll
+            for (int i = 0; i < NDIFF; ++i) part[i] = CT(0);
 #pragma unroll
             for (int e = 0; e < E; ++e) {
-                CT v[1 << ND], wg[3];
+                CT v[1 << ND], df[NDIFF];
 #pragma unroll
                 for (int q = 0; q < (1 << ND); ++q) v[q] = xv[q & (NC - 1)][e + (q >> (ND - 1))];
-                weight_grads_nd<ND, CT>(v, dw, wg);
+                corner_diffs<ND, CT>(v, df);
                 const CT gval = widen<T>(gch.e[e]);
 #pragma unroll
-                for (int s = 0; s < ND; ++s) acc[s] += static_cast<double>(gval * wg[s]);
+                for (int i = 0; i < NDIFF; ++i) part[i] += gval * df[i];
                 if constexpr (ACTIVE) {
 #pragma unroll
                     for (int q = 0; q < (1 << ND); ++q) v[q] = gv[q & (NC - 1)][e + (q >> (ND - 1))];
@@ -954,12 +960,19 @@ __global__ __launch_bounds__(kThreads, OCC) void plane_backward_lds(const PlaneP
                     res.e[e] = (vs0 && gm[e] >= 0) ? ts0[gm[e]] : zero;
                 }
             }
+#pragma unroll
+            for (int i = 0; i < NDIFF; ++i) dsum[i] += static_cast<double>(part[i]);
             store_chunk<S, E>(gxp + static_cast<int64_t>(a * S1 + b0 + tr) * S2 + ji, res);
         }
         __syncthreads();  // the tile is overwritten by the next step; the next slot table is complete
         nl = nl2;
         r0 = r2;
         buf ^= 1;
+    }
+    double acc[3] = {0.0, 0.0, 0.0};
+    {
+        const double dwd[3] = {static_cast<double>(dw[0]), static_cast<double>(dw[1]), static_cast<double>(dw[2])};
+        blend_diffs<ND>(dsum, dwd, acc);
     }
 #pragma unroll
     for (int s = 0; s < 3; ++s) {

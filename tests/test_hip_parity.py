@@ -241,7 +241,9 @@ def test_strided_inputs_and_empty(abi):
             ones = torch.ones(1, device=DEV).expand(3, 6, 10, 16)
             gx1, gw1 = abi.backward(ones, w, x, pad, active)
             gx2, gw2 = abi.backward(torch.ones(3, 6, 10, 16, device=DEV), w, x, pad, active)
-            assert torch.equal(gx1, gx2) and rel_err(gw1.cpu().numpy(), gw2.cpu().numpy()) < 1e-5
+            # grad_out == 1: the weight gradient telescopes to ~0 for the wrapping paddings, so compare on the
+            # scale of the summed terms (480 per channel, each <= 1), not of the (cancelled) result
+            assert torch.equal(gx1, gx2) and float((gw1 - gw2).abs().max()) < 1e-5 * 480
     e = torch.empty(0, 6, 10, 16, device=DEV)
     assert abi.forward(e, w, 0, 0).shape == (0, 6, 10, 16) and abi.last_path() == abi.PATH_EMPTY
     gx, gw = abi.backward(e, w, e, 0, 0)

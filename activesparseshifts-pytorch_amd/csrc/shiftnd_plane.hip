@@ -47,6 +47,7 @@ struct PlaneParams {
     int tbands, tband_len;  // pipelined backward: row bands per plane share handed to the RPS row slots
     int tband_mode;         // 1: consecutive rows per thread (register carry), 0: rows RPS apart
     int tile_bytes;         // LDS-staged backward: bytes of the row tile in front of the maps
+    int lds_affine;         // LDS-staged kernels: read affine chunks as consecutive dwords (tuning knob 5 = 1 turns it off)
     unsigned xcd_blocks;    // grid / 8 when the XCD-contiguous block remap is on (grid % 8 == 0), else 0
     FastDiv d_cpr;
     FastDiv d_tbands;
@@ -825,14 +826,79 @@ struct LdsStager {
     }
 };
 
+// Column state of a chunk for LDS reads.  `affine`: every valid column satisfies cm[e] == base + e (true for all
+// interior chunks and for the edge chunks of zeros padding): the E + 1 values are then read as consecutive
+// dwords from one base address (compile-time offsets -> ds_read2_b32) and masked, instead of E + 1 independent
+// element reads.
+template <int E> struct ColState {
+    int cm[E + 1];
+    int base;     // element index of column 0 when affine
+    bool affine;
+};
+template <int E> __device__ __forceinline__ ColState<E> make_colstate(const int *map, int j0, bool live, bool allow_affine) {
+    ColState<E> c;
+    int first = -1;
+#pragma unroll
+    for (int e = 0; e <= E; ++e) {
+        c.cm[e] = live ? map[j0 + e] : -1;
+        if (first < 0 && c.cm[e] >= 0) first = e;
+    }
+    c.base = first >= 0 ? c.cm[first] - first : 0;
+    c.affine = allow_affine;
+#pragma unroll
+    for (int e = 0; e <= E; ++e) c.affine = c.affine && (c.cm[e] < 0 || c.cm[e] == c.base + e);
+    return c;
+}
+
+// E + 1 raw elements of one staged row (masked columns -> 0).  `row` points at the row's first byte in LDS; a
+// 64-byte pad in front of the tile keeps the few bytes an edge chunk reads before column 0 inside the allocation.
+template <typename S, int E>
+__device__ __forceinline__ void lds_read_row(const char *row, bool valid, const ColState<E> &c, S (&raw)[E + 1]) {
+    S zero;
+    __builtin_memset(&zero, 0, sizeof(S));
+    if (!valid) {
+#pragma unroll
+        for (int e = 0; e <= E; ++e) raw[e] = zero;
+        return;
+    }
+    if (c.affine) {
+        if constexpr (sizeof(S) == 2) {
+            // 18 bytes starting at a 2-byte boundary: five dwords, then a funnel shift by 0 or 16 bits
+            const int byte0 = c.base * 2;
+            const uint32_t *dwp = reinterpret_cast<const uint32_t *>(row + (byte0 & ~3));
+            const uint32_t sh = (byte0 & 2) ? 16u : 0u;
+            uint32_t dw[6];
+#pragma unroll
+            for (int i = 0; i < 5; ++i) dw[i] = dwp[i];
+            dw[5] = 0;
+#pragma unroll
+            for (int i = 0; i < 5; ++i) {
+                const uint32_t t = static_cast<uint32_t>(((static_cast<uint64_t>(dw[i + 1]) << 32) | dw[i]) >> sh);
+                const uint16_t lo = static_cast<uint16_t>(t), hi = static_cast<uint16_t>(t >> 16);
+                if (2 * i <= E) __builtin_memcpy(&raw[2 * i], &lo, 2);
+                if (2 * i + 1 <= E) __builtin_memcpy(&raw[2 * i + 1], &hi, 2);
+            }
+        } else {
+            const S *p0 = reinterpret_cast<const S *>(row) + c.base;
+#pragma unroll
+            for (int e = 0; e <= E; ++e) raw[e] = p0[e];
+        }
+#pragma unroll
+        for (int e = 0; e <= E; ++e) raw[e] = c.cm[e] >= 0 ? raw[e] : zero;
+    } else {
+        const S *p0 = reinterpret_cast<const S *>(row);
+#pragma unroll
+        for (int e = 0; e <= E; ++e) raw[e] = c.cm[e] >= 0 ? p0[c.cm[e]] : zero;
+    }
+}
+
 // corner values of one chunk from the staged rows: vals[k][e], k = outer corner combo (bit r <-> +1 along real
 // dim r < ND-1), e = 0..E (E + 1 columns through the column map)
 template <typename T, int ND>
 __device__ __forceinline__ void lds_corners(const char *tile, int RB, int R, int slot0, const int *ss, int tr,
-                                            const int (&cm)[16 / sizeof(typename T::S) + 1],
+                                            const ColState<16 / sizeof(typename T::S)> &cs,
                                             typename T::C (&vals)[1 << (ND - 1)][16 / sizeof(typename T::S) + 1]) {
     using S = typename T::S;
-    using CT = typename T::C;
     constexpr int E = 16 / sizeof(S);
     constexpr int NC = 1 << (ND - 1);
 #pragma unroll
@@ -840,10 +906,10 @@ __device__ __forceinline__ void lds_corners(const char *tile, int RB, int R, int
         const int ha = ND == 3 ? (k & 1) : 0;
         const int hb = ND == 3 ? ((k >> 1) & 1) : (k & 1);
         const int slot = slot0 + ha * (R + 1) + tr + hb;
-        const bool valid = ss[slot] >= 0;
-        const S *row = reinterpret_cast<const S *>(tile + slot * RB);
+        S raw[E + 1];
+        lds_read_row<S, E>(tile + slot * RB, ss[slot] >= 0, cs, raw);
 #pragma unroll
-        for (int e = 0; e <= E; ++e) vals[k][e] = (valid && cm[e] >= 0) ? widen<T>(row[cm[e]]) : CT(0);
+        for (int e = 0; e <= E; ++e) vals[k][e] = widen<T>(raw[e]);
     }
 }
 
@@ -860,8 +926,8 @@ __global__ __launch_bounds__(kThreads, OCC) void plane_backward_lds(const PlaneP
     const int R = p.RPS;
     const int NX = Shape::nx(R), NG = Shape::ng(R), NS = Shape::slots(R);
     const int RB = p.S[2] * static_cast<int>(sizeof(S));  // row bytes, a multiple of 16
-    char *tile = smem;
-    int *maps = reinterpret_cast<int *>(smem + p.tile_bytes);
+    char *tile = smem + 64;  // 64-byte pad: see lds_read_row
+    int *maps = reinterpret_cast<int *>(smem + 64 + p.tile_bytes);
     const int *m0 = maps, *m1 = maps + p.S[0] + 1, *m2 = m1 + p.S[1] + 1;
     int *gmaps = maps + p.S[0] + p.S[1] + p.S[2] + 3;
     const int *g0 = gmaps, *g1 = gmaps + p.O[0] + 1, *g2 = g1 + p.O[1] + 1;
@@ -882,13 +948,8 @@ __global__ __launch_bounds__(kThreads, OCC) void plane_backward_lds(const PlaneP
     const int tr = threadIdx.x / p.CW, tc = threadIdx.x - tr * p.CW;
     const bool worker = tr < R;
     const int ji = tc * E;
-    int xm[E + 1], gm[E + 1];
-#pragma unroll
-    for (int e = 0; e <= E; ++e) {
-        xm[e] = worker ? m2[ji + e] : -1;
-        gm[e] = worker ? g2[ji + e] : -1;  // no crop: grad_out coordinates == input coordinates
-    }
-    const S zero = narrow<T>(CT(0));
+    const ColState<E> xm = make_colstate<E>(m2, ji, worker, p.lds_affine != 0);
+    const ColState<E> gm = make_colstate<E>(g2, ji, worker, p.lds_affine != 0);  // no crop: grad_out coordinates == input coordinates
     constexpr int NDIFF = WDiff<ND>::N;
     double dsum[NDIFF];  // sums of g * corner difference (see corner_diffs)
 #pragma unroll
@@ -931,13 +992,11 @@ __global__ __launch_bounds__(kThreads, OCC) void plane_backward_lds(const PlaneP
             Chunk<S, E> gch;
             __builtin_memcpy(gch.e, __builtin_assume_aligned(tg + ji, 16), 16);
             CT gv[NC][E + 1];
-            const S *ts0 = nullptr;
-            bool vs0 = false;
+            S graw[E + 1];
             if constexpr (ACTIVE) {
                 lds_corners<T, ND>(tile, RB, R, NX + NG, ss, tr, gm, gv);
             } else {
-                vs0 = ss[NX + NG + tr] >= 0;
-                ts0 = reinterpret_cast<const S *>(tile + (NX + NG + tr) * RB);
+                lds_read_row<S, E>(tile + (NX + NG + tr) * RB, ss[NX + NG + tr] >= 0, gm, graw);
             }
             Chunk<S, E> res;
             CT part[NDIFF];  // this chunk's sums, in the compute type (E terms each)
@@ -957,7 +1016,7 @@ __global__ __launch_bounds__(kThreads, OCC) void plane_backward_lds(const PlaneP
                     for (int q = 0; q < (1 << ND); ++q) v[q] = gv[q & (NC - 1)][e + (q >> (ND - 1))];
                     res.e[e] = narrow<T>(interp_nd<ND, CT>(v, dw));
                 } else {
-                    res.e[e] = (vs0 && gm[e] >= 0) ? ts0[gm[e]] : zero;
+                    res.e[e] = graw[e];
                 }
             }
 #pragma unroll
@@ -994,8 +1053,8 @@ __global__ __launch_bounds__(kThreads) void plane_active_forward_lds(const Plane
     const int R = p.RPS;
     const int NS = Shape::slots(R);
     const int RB = p.S[2] * static_cast<int>(sizeof(S));
-    char *tile = smem;
-    int *maps = reinterpret_cast<int *>(smem + p.tile_bytes);
+    char *tile = smem + 64;  // 64-byte pad: see lds_read_row
+    int *maps = reinterpret_cast<int *>(smem + 64 + p.tile_bytes);
     const int *m0 = maps, *m1 = maps + p.S[0] + 1, *m2 = m1 + p.S[1] + 1;
     int *slot_src = maps + p.S[0] + p.S[1] + p.S[2] + 3;  // two tables of NS entries
 
@@ -1013,9 +1072,7 @@ __global__ __launch_bounds__(kThreads) void plane_active_forward_lds(const Plane
     const int tr = threadIdx.x / p.CW, tc = threadIdx.x - tr * p.CW;
     const bool worker = tr < R;
     const int ji = tc * E;
-    int xm[E + 1];
-#pragma unroll
-    for (int e = 0; e <= E; ++e) xm[e] = worker ? m2[ji + e] : -1;
+    const ColState<E> xm = make_colstate<E>(m2, ji, worker, p.lds_affine != 0);
     const int row_end = wi.row0 + wi.nrows;
     auto step_len = [&](int r0) {
         const int b0 = r0 - fdiv(r0, p.d_dim1) * S1;
@@ -1153,6 +1210,7 @@ void fill_params(PlaneParams &p, const Geometry &g, const Plan &pl, int64_t dim1
     p.tband_len = (pl.rows_per_band + p.tbands - 1) / p.tbands;
     p.d_tbands = make_fastdiv(static_cast<uint32_t>(p.tbands));
     p.tband_mode = g_tune[4];
+    p.lds_affine = g_tune[5] == 0;
     p.xcd_blocks = (g_tune[6] && pl.grid % 8 == 0) ? pl.grid / 8 : 0;
     p.d_cpr = make_fastdiv(static_cast<uint32_t>(pl.cpr));
     p.d_dim1 = make_fastdiv(static_cast<uint32_t>(dim1));
@@ -1195,7 +1253,7 @@ bool lds_staged_ok(const PlaneParams &p, const Plan &pl, int esize, int slots, s
     for (int d = 0; d < 3; ++d)
         if (p.L[d] != 0 || p.O[d] != p.S[d]) return false;  // no crop: output rows == input rows
     const size_t tile = static_cast<size_t>(slots) * p.S[2] * esize;
-    const size_t total = tile + pl.lds + 2 * static_cast<size_t>(slots) * sizeof(int);
+    const size_t total = 64 + tile + pl.lds + 2 * static_cast<size_t>(slots) * sizeof(int);
     if (total > 64 * 1024 || slots > kThreads) return false;
     *lds_bytes = total;
     *tile_bytes = static_cast<int>(tile);

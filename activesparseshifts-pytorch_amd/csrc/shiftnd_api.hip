@@ -10,6 +10,7 @@ using namespace shiftnd;
 namespace {
 
 thread_local int g_last_path = SHIFTND_PATH_NONE;
+thread_local const char *g_last_kernel = "";
 int g_policy = 0;  // 0 auto, 1 force strided, 2 plane kernels (or fail), 3 sweep kernels (or fail)
 
 bool is_float_dtype(int dt) { return dt >= SHIFTND_F32 && dt <= SHIFTND_BF16; }
@@ -100,7 +101,14 @@ int forward_common(const shiftnd_problem *p, const void *x, const int64_t *xs, c
 
 }  // namespace
 
+namespace shiftnd {
+void note_kernel(const char *name) { g_last_kernel = name; }
+const char *last_kernel() { return g_last_kernel; }
+}  // namespace shiftnd
+
 extern "C" {
+
+const char *shiftnd_last_kernel(void) { return g_last_kernel; }
 
 int shiftnd_abi_version(void) { return SHIFTND_ABI_VERSION; }
 

@@ -21,6 +21,11 @@ inline int dtype_size(int dtype) {
     }
 }
 
+// name of the main kernel launched by the last call on this host thread (diagnostics: bench.py matches it
+// against the rocprofv3 kernel trace)
+void note_kernel(const char *name);
+const char *last_kernel();
+
 // ---- strided fallback (shiftnd_strided.hip) ------------------------------------------------------
 // wkind: dtype of the weights array (float dtypes -> rint / floor+frac; I8/U8/I32 -> repr - wzp).
 int strided_forward(const Geometry &g, int dtype, const void *x, const void *w, int wkind, int64_t wzp,

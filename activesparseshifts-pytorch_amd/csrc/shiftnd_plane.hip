@@ -1269,6 +1269,7 @@ int launch_active_forward(const PlaneParams &p_in, const Plan &pl, hipStream_t s
         const int slots = p.nd == 3 ? LdsTileShape<3, true, false>::slots(pl.RPS) : LdsTileShape<2, true, false>::slots(pl.RPS);
         if (lds_staged_ok(p, pl, static_cast<int>(sizeof(typename T::S)), slots, &lds_bytes, &tile_bytes)) {
             p.tile_bytes = tile_bytes;
+            note_kernel("plane_active_forward_lds");
             if (p.nd == 3)
                 hipLaunchKernelGGL((plane_active_forward_lds<T, 3>), dim3(pl.grid), dim3(kThreads), lds_bytes, st, p);
             else
@@ -1276,6 +1277,7 @@ int launch_active_forward(const PlaneParams &p_in, const Plan &pl, hipStream_t s
             return SHIFTND_OK;
         }
     }
+    note_kernel("plane_active_forward");
     switch (p.nd) {
     case 1: hipLaunchKernelGGL((plane_active_forward<T, 1>), dim3(pl.grid), dim3(kThreads), pl.lds, st, p); break;
     case 2: hipLaunchKernelGGL((plane_active_forward<T, 2>), dim3(pl.grid), dim3(kThreads), pl.lds, st, p); break;
@@ -1293,6 +1295,7 @@ void launch_backward_a(const PlaneParams &p_in, const Plan &pl, hipStream_t st) 
         const int slots = p.nd == 3 ? LdsTileShape<3, ACTIVE, true>::slots(pl.RPS) : LdsTileShape<2, ACTIVE, true>::slots(pl.RPS);
         if (lds_staged_ok(p, pl, static_cast<int>(sizeof(typename T::S)), slots, &lds_bytes, &tile_bytes)) {
             p.tile_bytes = tile_bytes;
+            note_kernel("plane_backward_lds");
             if (p.nd == 3)
                 hipLaunchKernelGGL((plane_backward_lds<T, 3, ACTIVE, 1>), dim3(pl.grid), dim3(kThreads), lds_bytes, st, p);
             else
@@ -1300,6 +1303,7 @@ void launch_backward_a(const PlaneParams &p_in, const Plan &pl, hipStream_t st) 
             return;
         }
     }
+    note_kernel(g_tune[3] == 0 ? "plane_backward_pipe" : "plane_backward");
     if (g_tune[3] == 0) {  // pipelined form (measured slower than the simple loop on MI355X so far: opt-in)
         switch (p.nd) {
         case 1: hipLaunchKernelGGL((plane_backward_pipe<T, 1, ACTIVE>), dim3(pl.grid), dim3(kThreads), pl.lds, st, p); break;
@@ -1372,6 +1376,7 @@ int plane_forward(const Geometry &g, int dtype, const void *x, const void *w, in
         }
     }
     const int V = gather_vector_bytes(g, es, out);
+    note_kernel("plane_gather_forward");
     const Plan pl = make_plan(g, g.O[0] * g.O[1], g.O[2], es, V, entries);
     fill_params(p, g, pl, g.O[1]);
 #define SHIFTND_GATHER_CASE(ES, VV) \

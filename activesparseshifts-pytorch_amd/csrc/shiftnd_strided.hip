@@ -260,6 +260,7 @@ int strided_forward(const Geometry &g, int dtype, const void *x, const void *w, 
     const int64_t total = g.N * g.C * g.O[0] * g.O[1] * g.O[2];
     const unsigned grid = flat_grid(total);
     const bool gather_only = !g.active || dtype >= SHIFTND_I8;
+    note_kernel(gather_only ? "strided_gather_forward" : "strided_active_forward");
     if (gather_only) {
         switch (dtype_size(dtype)) {
         case 1:
@@ -295,6 +296,7 @@ size_t strided_backward_workspace(const Geometry &g) { return static_cast<size_t
 int strided_backward(const Geometry &g, int dtype, const void *go, const void *x, const void *w, void *gx, void *gw,
                      void *workspace, hipStream_t st) {
     double *partials = static_cast<double *>(workspace);
+    note_kernel("strided_backward");
     switch (dtype) {
     case SHIFTND_F32: return launch_strided_backward_t<f32_t>(g, go, x, w, gx, gw, partials, st);
     case SHIFTND_F64: return launch_strided_backward_t<f64_t>(g, go, x, w, gx, gw, partials, st);

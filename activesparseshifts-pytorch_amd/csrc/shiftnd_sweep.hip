@@ -532,6 +532,7 @@ int sweep_forward(const Geometry &g, int dtype, const void *x, const void *w, in
                   void *out, hipStream_t st) {
     const int es = dtype_size(dtype);
     const int V = gather_vector_bytes(g, es, out);
+    note_kernel("sweep_gather_forward");
     SweepParams p{};
     fill_common(p, g);
     p.x = x;
@@ -575,6 +576,7 @@ size_t sweep_backward_workspace(const Geometry &g, int dtype) {
 int sweep_backward(const Geometry &g, int dtype, const void *go, const void *x, const void *w, void *gx, void *gw,
                    void *workspace, hipStream_t st) {
     SweepParams p{};
+    note_kernel("sweep_backward");
     plan_backward(p, g, dtype_size(dtype));
     p.x = x;
     p.go = go;

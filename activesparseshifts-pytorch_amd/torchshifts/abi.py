@@ -18,7 +18,7 @@ DTYPES = {torch.float32: F32, torch.float64: F64, torch.float16: F16, torch.bflo
           torch.int8: I8, torch.uint8: U8, torch.int32: I32}
 
 EXPORTS = ["shiftnd_abi_version", "shiftnd_status_string", "shiftnd_last_path", "shiftnd_set_path_policy",
-           "shiftnd_set_tuning", "shiftnd_debug_map",
+           "shiftnd_set_tuning", "shiftnd_debug_map", "shiftnd_last_kernel",
            "shiftnd_check_borders", "shiftnd_forward", "shiftnd_backward_workspace_bytes", "shiftnd_backward",
            "shiftnd_forward_quantized"]
 
@@ -41,6 +41,7 @@ def lib():
         L.shiftnd_status_string.restype = ctypes.c_char_p
         L.shiftnd_status_string.argtypes = [ctypes.c_int]
         L.shiftnd_last_path.restype = ctypes.c_int
+        L.shiftnd_last_kernel.restype = ctypes.c_char_p
         L.shiftnd_set_path_policy.argtypes = [ctypes.c_int]
         L.shiftnd_set_tuning.argtypes = [ctypes.c_int, ctypes.c_int]
         L.shiftnd_debug_map.restype = ctypes.c_int
@@ -161,6 +162,10 @@ def forward_quantized(xq, wq, w_zero_point, x_zero_point, pad, borders=None, out
 
 def last_path():
     return lib().shiftnd_last_path()
+
+
+def last_kernel():
+    return lib().shiftnd_last_kernel().decode()
 
 
 def set_path_policy(policy):

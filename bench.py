@@ -191,7 +191,7 @@ def main():
         wi = wq.int_repr()
         outb = torch.empty_like(xi)
         t_f = event_time(lambda: abi.forward_quantized(xi, wi, 128, 0, a.pad, out=outb), kiters)
-        qname = {abi.PATH_PLANE: "plane", abi.PATH_SWEEP: "sweep"}.get(abi.last_path(), "strided") + "_gather_forward"
+        qname = abi.last_kernel()
         kernels[qname] = {"ms": t_f, "GB/s": 2 * esize * elems / t_f / 1e6}
         dom_name, dom_ms, dom_bytes = qname, t_f, 2 * esize * elems
     else:
@@ -199,11 +199,10 @@ def main():
         ws = abi.backward_workspace(x, a.pad, active)
         t_f = event_time(lambda: abi.forward(x, w, a.pad, active, out=outb), kiters)
         t_b = event_time(lambda: abi.backward(go, w, x, a.pad, active, grad_x=gxb, grad_w=gwb, workspace=ws), kiters)
-        fam = {abi.PATH_PLANE: "plane", abi.PATH_SWEEP: "sweep", abi.PATH_STRIDED: "strided"}
         abi.forward(x, w, a.pad, active, out=outb)
-        fname = fam.get(abi.last_path(), "?") + ("_active_forward" if active else "_gather_forward")
+        fname = abi.last_kernel()
         abi.backward(go, w, x, a.pad, active, grad_x=gxb, grad_w=gwb, workspace=ws)
-        bname = fam.get(abi.last_path(), "?") + "_backward"
+        bname = abi.last_kernel()
         kernels[fname] = {"ms": t_f, "GB/s": 2 * esize * elems / t_f / 1e6}
         kernels[bname] = {"ms": t_b, "GB/s": 3 * esize * elems / t_b / 1e6}
         dom_name, dom_ms, dom_bytes = bname, t_b, 3 * esize * elems

@@ -89,6 +89,8 @@ typedef struct shiftnd_problem {
 SHIFTND_API int shiftnd_abi_version(void);
 SHIFTND_API const char *shiftnd_status_string(int status);
 SHIFTND_API int shiftnd_last_path(void);
+/* Diagnostics: name (without template arguments) of the main kernel the last call on this thread launched. */
+SHIFTND_API const char *shiftnd_last_kernel(void);
 /* 0 = automatic (sweep, else plane, else strided), 1 = force the strided fallback,
  * 2 = plane kernels or fail, 3 = sweep kernels or fail (testing). */
 SHIFTND_API void shiftnd_set_path_policy(int policy);

@@ -39,6 +39,7 @@ int strided_backward(const Geometry &g, int dtype, const void *go, const void *x
 // interpolating kernels) rows made of whole 16-byte chunks.
 void plane_set_tuning(int knob, int value);
 bool plane_forward_eligible(const Geometry &g, int dtype, const void *x, const void *out);
+bool plane_forward_lds_gather(const Geometry &g, int dtype, const void *x, const void *out);
 int plane_forward(const Geometry &g, int dtype, const void *x, const void *w, int wkind, int64_t wzp,
                   uint64_t fill_bits, void *out, hipStream_t st);
 bool plane_backward_eligible(const Geometry &g, int dtype, const void *go, const void *x, const void *gx);

@@ -47,6 +47,8 @@ struct PlaneParams {
     int tbands, tband_len;  // pipelined backward: row bands per plane share handed to the RPS row slots
     int tband_mode;         // 1: consecutive rows per thread (register carry), 0: rows RPS apart
     int tile_bytes;         // LDS-staged backward: bytes of the row tile in front of the maps
+    unsigned xppr;          // LDS-staged gather forward: 16-byte pieces per SOURCE row
+    FastDiv d_xppr;
     int lds_affine;         // LDS-staged kernels: read affine chunks as consecutive dwords (tuning knob 5 = 1 turns it off)
     unsigned xcd_blocks;    // grid / 8 when the XCD-contiguous block remap is on (grid % 8 == 0), else 0
     FastDiv d_cpr;
@@ -1040,6 +1042,97 @@ __global__ __launch_bounds__(kThreads, OCC) void plane_backward_lds(const PlaneP
     }
 }
 
+// Gather forward through the same staging (SSL forward of 2/4/8-byte element types): R source rows per step,
+// aligned LDS-DMA, shifted columns read from LDS.  Used for 16-bit rows, where 2-byte-aligned 16-byte global
+// loads are slow (C5: 1.60 -> see DESIGN.md), and available for every eligible shape through tuning knob 2.
+template <int ESIZE>
+__global__ __launch_bounds__(kThreads) void plane_gather_forward_lds(const PlaneParams p) {
+    using R_t = typename raw_t<ESIZE>::type;
+    constexpr int E = 16 / ESIZE;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int R = p.RPS;
+    const int RB = p.S[2] * ESIZE;  // source row bytes, a multiple of 16
+    char *tile = smem + 64;
+    int *maps = reinterpret_cast<int *>(smem + 64 + p.tile_bytes);
+    const int *m0 = maps, *m1 = maps + p.S[0] + 1, *m2 = m1 + p.S[1] + 1;
+    int *slot_src = maps + p.S[0] + p.S[1] + p.S[2] + 3;  // two tables of R entries
+
+    const WorkItem wi = decode_block(p);
+    int64_t sh[3];
+#pragma unroll
+    for (int d = 0; d < 3; ++d) sh[d] = p.wcol[d] >= 0 ? gather_shift(p.w, p.wkind, p.wzp, wi.c * p.nd + p.wcol[d]) : 0;
+    build_maps(maps, p.S, sh, -1, p.pad);
+    __syncthreads();
+
+    const int O1 = p.O[1], O2 = p.O[2], S1 = p.S[1], S2 = p.S[2];
+    const int tr = threadIdx.x / p.CW, tc = threadIdx.x - tr * p.CW;
+    const bool worker = tr < R;
+    const int jo = tc * E;
+    const ColState<E> cs = make_colstate<E>(m2, jo + p.L[2], worker && (jo + E <= O2), p.lds_affine != 0);
+    const R_t fill = static_cast<R_t>(p.fill);
+    const int row_end = wi.row0 + wi.nrows;
+    const int pieces = R * static_cast<int>(p.xppr);
+    auto step_len = [&](int r0) {
+        const int b0 = r0 - fdiv(r0, p.d_dim1) * O1;
+        return min(R, min(O1 - b0, row_end - r0));
+    };
+    auto make_slots = [&](int r0, int Rn, int *tab) {
+        const int k = threadIdx.x;
+        if (k < R) {
+            int src = -1;
+            if (k < Rn) {
+                const int a = fdiv(r0, p.d_dim1);
+                const int b = r0 - a * O1 + k;
+                const int ra = m0[a + p.L[0]], rb = m1[b + p.L[1]];
+                if (ra >= 0 && rb >= 0) src = (ra * S1 + rb) * S2;
+            }
+            tab[k] = src;
+        }
+    };
+    int nl = 0, r0 = wi.row0, buf = 0;
+    make_slots(r0, step_len(r0), slot_src);
+    __syncthreads();
+    while (nl < wi.nn) {
+        const int Rn = step_len(r0);
+        const int *ss = slot_src + buf * R;
+        const int64_t plane = static_cast<int64_t>(wi.n0 + nl) * p.C + wi.c;
+        const R_t *xp = static_cast<const R_t *>(p.x) + plane * p.x_plane;
+        R_t *op = static_cast<R_t *>(p.out) + plane * p.o_plane;
+        for (int q0 = 0; q0 < pieces; q0 += kThreads) {
+            const int q = q0 + threadIdx.x;
+            if (q < pieces) {
+                const int slot = fdiv(q, p.d_xppr);
+                const int j = q - slot * static_cast<int>(p.xppr);
+                const int src = ss[slot];
+                if (src >= 0) {
+                    const R_t *g = xp + src + j * E;
+                    char *dst_wave = tile + (q0 + (threadIdx.x & ~63)) * 16;
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)g,
+                                                     (__attribute__((address_space(3))) void *)dst_wave, 16, 0, 0);
+                }
+            }
+        }
+        int nl2 = nl, r2 = r0 + Rn;
+        if (r2 >= row_end) { r2 = wi.row0; ++nl2; }
+        if (nl2 < wi.nn) make_slots(r2, step_len(r2), slot_src + (buf ^ 1) * R);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (worker && tr < Rn && jo + E <= O2) {
+            R_t raw[E + 1];
+            const bool valid = ss[tr] >= 0;
+            lds_read_row<R_t, E>(tile + tr * RB, valid, cs, raw);
+            Chunk<R_t, E> res;
+#pragma unroll
+            for (int e = 0; e < E; ++e) res.e[e] = (valid && cs.cm[e] >= 0) ? raw[e] : fill;
+            store_chunk<R_t, E>(op + static_cast<int64_t>(r0 + tr) * O2 + jo, res);
+        }
+        __syncthreads();
+        nl = nl2;
+        r0 = r2;
+        buf ^= 1;
+    }
+}
+
 // Active forward through the same staging (X slots only).
 template <typename T, int ND>
 __global__ __launch_bounds__(kThreads) void plane_active_forward_lds(const PlaneParams p) {
@@ -1176,6 +1269,8 @@ Plan make_plan(const Geometry &g, int64_t rows, int64_t inner, int esize, int V,
         if (bands < 1) bands = 1;
     }
     pl.rows_per_band = static_cast<int>((rows + bands - 1) / bands);
+    if (bands > 1)  // whole row steps per band (a ragged last step wastes lanes: 56 rows at 9 rows/step = 89 %)
+        pl.rows_per_band = ((pl.rows_per_band + pl.RPS - 1) / pl.RPS) * pl.RPS;
     pl.bands = static_cast<int>((rows + pl.rows_per_band - 1) / pl.rows_per_band);
     pl.lds = static_cast<size_t>(map_entries) * sizeof(int);
     pl.grid = static_cast<unsigned>(g.C * pl.groups * pl.bands);
@@ -1340,6 +1435,22 @@ void plane_set_tuning(int knob, int value) {
     if (knob >= 0 && knob < 8) g_tune[knob] = value;
 }
 
+static bool lds_gather_wanted(const Geometry &g, int es, int V, const Plan &pl, const void *x) {
+    if (!(V == 16 && es >= 2 && (g.S[2] * es) % 16 == 0 && pl.CP == 1 && reinterpret_cast<uintptr_t>(x) % 16 == 0)) return false;
+    if (!((es == 2 && g_tune[2] == 4) || g_tune[2] == 16)) return false;
+    const size_t total = 64 + static_cast<size_t>(pl.RPS) * g.S[2] * es + pl.lds + 2 * static_cast<size_t>(pl.RPS) * sizeof(int);
+    return total <= 64 * 1024;
+}
+
+// true when plane_forward would take the LDS-staged gather kernel (the API then prefers it over the sweep kernel)
+bool plane_forward_lds_gather(const Geometry &g, int dtype, const void *x, const void *out) {
+    if ((g.active && dtype <= SHIFTND_BF16) || !plane_forward_eligible(g, dtype, x, out)) return false;
+    const int es = dtype_size(dtype);
+    const int V = gather_vector_bytes(g, es, out);
+    const Plan pl = make_plan(g, g.O[0] * g.O[1], g.O[2], es, V, static_cast<int>(g.S[0] + g.S[1] + g.S[2] + 3));
+    return lds_gather_wanted(g, es, V, pl, x);
+}
+
 bool plane_forward_eligible(const Geometry &g, int dtype, const void *x, const void *out) {
     (void)x;
     if (!common_eligible(g)) return false;
@@ -1379,6 +1490,21 @@ int plane_forward(const Geometry &g, int dtype, const void *x, const void *w, in
     note_kernel("plane_gather_forward");
     const Plan pl = make_plan(g, g.O[0] * g.O[1], g.O[2], es, V, entries);
     fill_params(p, g, pl, g.O[1]);
+    // LDS-staged gather: 16-bit rows by default (knob 2 == 4), every eligible element size with knob 2 == 16
+    if (lds_gather_wanted(g, es, V, pl, x)) {
+        const size_t tile = static_cast<size_t>(pl.RPS) * g.S[2] * es;
+        const size_t total = 64 + tile + pl.lds + 2 * static_cast<size_t>(pl.RPS) * sizeof(int);
+        {
+            p.tile_bytes = static_cast<int>(tile);
+            p.xppr = static_cast<unsigned>(g.S[2] * es / 16);
+            p.d_xppr = make_fastdiv(p.xppr);
+            note_kernel("plane_gather_forward_lds");
+            if (es == 2) hipLaunchKernelGGL((plane_gather_forward_lds<2>), dim3(pl.grid), dim3(kThreads), total, st, p);
+            else if (es == 4) hipLaunchKernelGGL((plane_gather_forward_lds<4>), dim3(pl.grid), dim3(kThreads), total, st, p);
+            else hipLaunchKernelGGL((plane_gather_forward_lds<8>), dim3(pl.grid), dim3(kThreads), total, st, p);
+            return SHIFTND_OK;
+        }
+    }
 #define SHIFTND_GATHER_CASE(ES, VV) \
     if (es == ES && V == VV) { launch_gather<ES, VV>(p, pl, st); return SHIFTND_OK; }
     SHIFTND_GATHER_CASE(1, 16) SHIFTND_GATHER_CASE(1, 8) SHIFTND_GATHER_CASE(1, 4) SHIFTND_GATHER_CASE(1, 1)

@@ -351,3 +351,40 @@ def test_lds_staged_kernels(abi):
                         assert rel_err(gw1.float().cpu().numpy(), gw0.float().cpu().numpy()) < 1e-5, (shape, pad, active)
     finally:
         abi.set_tuning(3, 2)
+
+
+def test_lds_staged_gather_forward(abi):
+    """LDS-staged gather forward (default for 16-bit rows; every 2/4/8-byte type with tuning knob 2 = 16) vs the
+    oracle, with and without crop, all paddings; int32 rows use the quantized entry (fill = zero point)"""
+    rs = np.random.RandomState(44)
+    cases = [((3, 5, 9, 24), None), ((2, 4, 13, 32), [[2, 1], [8, 8]]), ((2, 3, 5, 6, 16), None),
+             ((2, 2, 4, 7, 24), [[1, 0], [0, 2], [8, 0]]), ((1, 2, 300, 8), None), ((2, 3, 40, 224), None)]
+    try:
+        abi.set_path_policy(2)
+        for knob in (4, 16):
+            abi.set_tuning(2, knob)
+            for shape, crop in cases:
+                nd = len(shape) - 2
+                b, new = abi.check_borders(list(shape), crop, nd)
+                x = rs.uniform(-1, 1, size=shape).astype(np.float32)
+                w = _weights(rs, shape[1], nd, shape[2:]).astype(np.float32)
+                for tdt in (torch.float32, torch.float64, torch.float16, torch.bfloat16):
+                    xd, wd = _dev(x).to(tdt), _dev(w).to(tdt)
+                    x_np = xd.cpu().double().numpy() if tdt != torch.float32 else x
+                    w_np = wd.cpu().double().numpy() if tdt != torch.float32 else w
+                    for pad in range(5):
+                        out = abi.forward(xd, wd, pad, 0, b)
+                        expect_lds = (knob == 16 or tdt in (torch.float16, torch.bfloat16))
+                        if expect_lds and (shape[-1] * xd.element_size()) % 16 == 0 and (new[-1] * xd.element_size()) % 16 == 0:
+                            assert abi.last_kernel() == "plane_gather_forward_lds", (shape, tdt, knob, abi.last_kernel())
+                        ref = O.forward(x_np, w_np, pad, 0, b)
+                        assert np.array_equal(out.cpu().double().numpy(), ref.astype(np.float64)), (shape, tdt, pad, knob)
+                # int32 "quantized" rows
+                xq = rs.randint(-1000, 1000, size=shape).astype(np.int32)
+                wq = rs.randint(120, 137, size=(shape[1], nd)).astype(np.uint8)
+                for pad in range(5):
+                    outq = abi.forward_quantized(torch.from_numpy(xq).to(DEV), torch.from_numpy(wq).to(DEV), 128, 7, pad, b)
+                    assert np.array_equal(outq.cpu().numpy(), O.forward_q(xq, wq, 128, 7, pad, b)), (shape, pad, knob)
+    finally:
+        abi.set_tuning(2, 4)
+        abi.set_path_policy(0)

@@ -915,8 +915,8 @@ __device__ __forceinline__ void lds_corners(const char *tile, int RB, int R, int
     }
 }
 
-template <typename T, int ND, bool ACTIVE, int OCC>
-__global__ __launch_bounds__(kThreads, OCC) void plane_backward_lds(const PlaneParams p) {
+template <typename T, int ND, bool ACTIVE, int TILES>
+__global__ __launch_bounds__(kThreads) void plane_backward_lds(const PlaneParams p) {
     using S = typename T::S;
     using CT = typename T::C;
     using Stager = LdsStager<T, ND, ACTIVE, true>;
@@ -928,8 +928,8 @@ __global__ __launch_bounds__(kThreads, OCC) void plane_backward_lds(const PlaneP
     const int R = p.RPS;
     const int NX = Shape::nx(R), NG = Shape::ng(R), NS = Shape::slots(R);
     const int RB = p.S[2] * static_cast<int>(sizeof(S));  // row bytes, a multiple of 16
-    char *tile = smem + 64;  // 64-byte pad: see lds_read_row
-    int *maps = reinterpret_cast<int *>(smem + 64 + p.tile_bytes);
+    char *tile0 = smem + 64;  // 64-byte pad: see lds_read_row
+    int *maps = reinterpret_cast<int *>(smem + 64 + TILES * p.tile_bytes);  // TILES == 2: alternate tiles, one barrier per step
     const int *m0 = maps, *m1 = maps + p.S[0] + 1, *m2 = m1 + p.S[1] + 1;
     int *gmaps = maps + p.S[0] + p.S[1] + p.S[2] + 3;
     const int *g0 = gmaps, *g1 = gmaps + p.O[0] + 1, *g2 = g1 + p.O[1] + 1;
@@ -963,7 +963,10 @@ __global__ __launch_bounds__(kThreads, OCC) void plane_backward_lds(const PlaneP
         const int b0 = r0 - fdiv(r0, p.d_dim1) * S1;
         return min(R, min(S1 - b0, row_end - r0));
     };
-    int nl = 0, r0 = wi.row0, buf = 0;
+    // slot tables rotate over NT buffers: with two tiles there is no barrier after the compute phase, so the table
+    // of step s must survive until every wave has passed the barrier of step s+1 (three tables)
+    constexpr int NT = TILES == 2 ? 3 : 2;
+    int nl = 0, r0 = wi.row0, buf = 0, tb = 0;
     {
         const int a = fdiv(r0, p.d_dim1);
         Stager::make_slots(p, R, a, r0 - a * S1, step_len(r0), m0, m1, g0, g1, slot_src);
@@ -973,7 +976,8 @@ __global__ __launch_bounds__(kThreads, OCC) void plane_backward_lds(const PlaneP
         const int a = fdiv(r0, p.d_dim1);
         const int b0 = r0 - a * S1;
         const int Rn = step_len(r0);
-        const int *ss = slot_src + buf * NS;
+        const int *ss = slot_src + tb * NS;
+        char *tile = tile0 + (TILES == 2 ? buf * p.tile_bytes : 0);
         const int64_t plane = static_cast<int64_t>(wi.n0 + nl) * p.C + wi.c;
         const S *xp = static_cast<const S *>(p.x) + plane * p.x_plane;
         const S *gp = static_cast<const S *>(p.go) + plane * p.o_plane;
@@ -983,7 +987,7 @@ __global__ __launch_bounds__(kThreads, OCC) void plane_backward_lds(const PlaneP
         if (r2 >= row_end) { r2 = wi.row0; ++nl2; }
         if (nl2 < wi.nn) {
             const int a2 = fdiv(r2, p.d_dim1);
-            Stager::make_slots(p, R, a2, r2 - a2 * S1, step_len(r2), m0, m1, g0, g1, slot_src + (buf ^ 1) * NS);
+            Stager::make_slots(p, R, a2, r2 - a2 * S1, step_len(r2), m0, m1, g0, g1, slot_src + ((tb + 1) % NT) * NS);
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
@@ -1025,10 +1029,13 @@ __global__ __launch_bounds__(kThreads, OCC) void plane_backward_lds(const PlaneP
             for (int i = 0; i < NDIFF; ++i) dsum[i] += static_cast<double>(part[i]);
             store_chunk<S, E>(gxp + static_cast<int64_t>(a * S1 + b0 + tr) * S2 + ji, res);
         }
-        __syncthreads();  // the tile is overwritten by the next step; the next slot table is complete
+        if (TILES == 1) __syncthreads();  // one tile: it is overwritten by the next step
+        // (two tiles: the next step writes the other tile, last read before this step's barrier, and the slot table
+        //  it uses was completed before that barrier too -- it is rewritten only after the next barrier)
         nl = nl2;
         r0 = r2;
         buf ^= 1;
+        tb = (tb + 1) % NT;
     }
     double acc[3] = {0.0, 0.0, 0.0};
     {
@@ -1391,10 +1398,17 @@ void launch_backward_a(const PlaneParams &p_in, const Plan &pl, hipStream_t st) 
         if (lds_staged_ok(p, pl, static_cast<int>(sizeof(typename T::S)), slots, &lds_bytes, &tile_bytes)) {
             p.tile_bytes = tile_bytes;
             note_kernel("plane_backward_lds");
-            if (p.nd == 3)
-                hipLaunchKernelGGL((plane_backward_lds<T, 3, ACTIVE, 1>), dim3(pl.grid), dim3(kThreads), lds_bytes, st, p);
-            else
-                hipLaunchKernelGGL((plane_backward_lds<T, 2, ACTIVE, 1>), dim3(pl.grid), dim3(kThreads), lds_bytes, st, p);
+            // two LDS tiles / one barrier per step pay when registers, not LDS, bound the resident workgroups:
+            // 16-bit dtypes by default (C5 backward 2.46 -> 2.21 ms; fp32 C2 1.84 -> 1.96 ms), knob 4 = 2 / 3 forces on / off
+            const bool want_two = g_tune[4] == 2 || (g_tune[4] != 3 && sizeof(typename T::S) == 2);
+            const bool two = want_two && lds_bytes + tile_bytes + slots * sizeof(int) <= 64 * 1024;
+            if (p.nd == 3) {
+                if (two) hipLaunchKernelGGL((plane_backward_lds<T, 3, ACTIVE, 2>), dim3(pl.grid), dim3(kThreads), lds_bytes + tile_bytes + slots * sizeof(int), st, p);
+                else hipLaunchKernelGGL((plane_backward_lds<T, 3, ACTIVE, 1>), dim3(pl.grid), dim3(kThreads), lds_bytes, st, p);
+            } else {
+                if (two) hipLaunchKernelGGL((plane_backward_lds<T, 2, ACTIVE, 2>), dim3(pl.grid), dim3(kThreads), lds_bytes + tile_bytes + slots * sizeof(int), st, p);
+                else hipLaunchKernelGGL((plane_backward_lds<T, 2, ACTIVE, 1>), dim3(pl.grid), dim3(kThreads), lds_bytes, st, p);
+            }
             return;
         }
     }

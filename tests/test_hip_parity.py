@@ -318,10 +318,12 @@ def test_pipelined_backward_variants(abi, mode):
                     assert rel_err(gw1.cpu().numpy(), gw0.cpu().numpy()) < 1e-6, (shape, pad, active)
     finally:
         abi.set_tuning(3, 2)
-        abi.set_tuning(4, 1)
+        abi.set_tuning(4, 1)  # 1 = automatic tile choice
+        abi.set_tuning(4, 1)  # 1 = automatic tile choice
 
 
-def test_lds_staged_kernels(abi):
+@pytest.mark.parametrize("tiles", [1, 2])
+def test_lds_staged_kernels(abi, tiles):
     """the LDS-staged kernels (default, tuning knob 3 = 2: active forward and backward, 2-D / 3-D, no crop) vs
     the direct-load plane kernels (knob 3 = 1): forward and grad_x bit for bit, grad_w to rounding"""
     rs = np.random.RandomState(33)
@@ -343,6 +345,7 @@ def test_lds_staged_kernels(abi):
                         out0 = abi.forward(xd, wd, pad, active)
                         gx0, gw0 = abi.backward(god, wd, xd, pad, active)
                         abi.set_tuning(3, 2)
+                        abi.set_tuning(4, 2 if tiles == 2 else 3)  # 2: two LDS tiles + one barrier per step, 3: one tile
                         out1 = abi.forward(xd, wd, pad, active)
                         gx1, gw1 = abi.backward(god, wd, xd, pad, active)
                         assert abi.last_path() == abi.PATH_PLANE
@@ -351,6 +354,7 @@ def test_lds_staged_kernels(abi):
                         assert rel_err(gw1.float().cpu().numpy(), gw0.float().cpu().numpy()) < 1e-5, (shape, pad, active)
     finally:
         abi.set_tuning(3, 2)
+        abi.set_tuning(4, 1)  # 1 = automatic tile choice
 
 
 def test_lds_staged_gather_forward(abi):

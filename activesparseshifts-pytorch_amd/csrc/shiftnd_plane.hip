@@ -839,13 +839,16 @@ template <int E> struct ColState {
 };
 template <int E> __device__ __forceinline__ ColState<E> make_colstate(const int *map, int j0, bool live, bool allow_affine) {
     ColState<E> c;
-    int first = -1;
+    c.base = 0;
+    bool found = false;  // (static indexing only: a runtime-indexed cm[] would live in scratch)
 #pragma unroll
     for (int e = 0; e <= E; ++e) {
         c.cm[e] = live ? map[j0 + e] : -1;
-        if (first < 0 && c.cm[e] >= 0) first = e;
+        if (!found && c.cm[e] >= 0) {
+            c.base = c.cm[e] - e;
+            found = true;
+        }
     }
-    c.base = first >= 0 ? c.cm[first] - first : 0;
     c.affine = allow_affine;
 #pragma unroll
     for (int e = 0; e <= E; ++e) c.affine = c.affine && (c.cm[e] < 0 || c.cm[e] == c.base + e);
@@ -992,19 +995,31 @@ __global__ __launch_bounds__(kThreads) void plane_backward_lds(const PlaneParams
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         if (worker && tr < Rn) {
+            Chunk<S, E> res;
+            // phase 1: grad_x (its corner values are dead before the x corners are read: fewer live registers)
+            if constexpr (ACTIVE) {
+                CT gv[NC][E + 1];
+                lds_corners<T, ND>(tile, RB, R, NX + NG, ss, tr, gm, gv);
+#pragma unroll
+                for (int e = 0; e < E; ++e) {
+                    CT v[1 << ND];
+#pragma unroll
+                    for (int q = 0; q < (1 << ND); ++q) v[q] = gv[q & (NC - 1)][e + (q >> (ND - 1))];
+                    res.e[e] = narrow<T>(interp_nd<ND, CT>(v, dw));
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            } else {
+                S graw[E + 1];
+                lds_read_row<S, E>(tile + (NX + NG + tr) * RB, ss[NX + NG + tr] >= 0, gm, graw);
+#pragma unroll
+                for (int e = 0; e < E; ++e) res.e[e] = graw[e];
+            }
+            // phase 2: weight-gradient sums from the x corners and the incoming gradient
             CT xv[NC][E + 1];
             lds_corners<T, ND>(tile, RB, R, 0, ss, tr, xm, xv);
             const S *tg = reinterpret_cast<const S *>(tile + (NX + tr) * RB);
             Chunk<S, E> gch;
             __builtin_memcpy(gch.e, __builtin_assume_aligned(tg + ji, 16), 16);
-            CT gv[NC][E + 1];
-            S graw[E + 1];
-            if constexpr (ACTIVE) {
-                lds_corners<T, ND>(tile, RB, R, NX + NG, ss, tr, gm, gv);
-            } else {
-                lds_read_row<S, E>(tile + (NX + NG + tr) * RB, ss[NX + NG + tr] >= 0, gm, graw);
-            }
-            Chunk<S, E> res;
             CT part[NDIFF];  // this chunk's sums, in the compute type (E terms each)
 #pragma unroll
             for (int i = 0; i < NDIFF; ++i) part[i] = CT(0);
@@ -1017,13 +1032,6 @@ __global__ __launch_bounds__(kThreads) void plane_backward_lds(const PlaneParams
                 const CT gval = widen<T>(gch.e[e]);
 #pragma unroll
                 for (int i = 0; i < NDIFF; ++i) part[i] += gval * df[i];
-                if constexpr (ACTIVE) {
-#pragma unroll
-                    for (int q = 0; q < (1 << ND); ++q) v[q] = gv[q & (NC - 1)][e + (q >> (ND - 1))];
-                    res.e[e] = narrow<T>(interp_nd<ND, CT>(v, dw));
-                } else {
-                    res.e[e] = graw[e];
-                }
             }
 #pragma unroll
             for (int i = 0; i < NDIFF; ++i) dsum[i] += static_cast<double>(part[i]);
@@ -1352,6 +1360,8 @@ void launch_gather(const PlaneParams &p, const Plan &pl, hipStream_t st) {
 // eligibility + LDS size of the LDS-staged kernels: 2-D / 3-D, no crop, one column pass, slot table <= threads
 bool lds_staged_ok(const PlaneParams &p, const Plan &pl, int esize, int slots, size_t *lds_bytes, int *tile_bytes) {
     if ((p.nd != 2 && p.nd != 3) || pl.CP != 1) return false;
+    // LDS-DMA moves aligned 16-byte pieces: row starts are multiples of 16 bytes from 16-byte aligned bases
+    if (reinterpret_cast<uintptr_t>(p.x) % 16 != 0 || (p.go && reinterpret_cast<uintptr_t>(p.go) % 16 != 0)) return false;
     for (int d = 0; d < 3; ++d)
         if (p.L[d] != 0 || p.O[d] != p.S[d]) return false;  // no crop: output rows == input rows
     const size_t tile = static_cast<size_t>(slots) * p.S[2] * esize;

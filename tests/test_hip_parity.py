@@ -319,7 +319,6 @@ def test_pipelined_backward_variants(abi, mode):
     finally:
         abi.set_tuning(3, 2)
         abi.set_tuning(4, 1)  # 1 = automatic tile choice
-        abi.set_tuning(4, 1)  # 1 = automatic tile choice
 
 
 @pytest.mark.parametrize("tiles", [1, 2])

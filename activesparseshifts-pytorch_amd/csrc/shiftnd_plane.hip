@@ -44,15 +44,12 @@ struct PlaneParams {
     int ppw, groups, bands, rows_per_band;
     int cpr, CW, RPS, CP;
     int rows;           // rows per plane of the iteration space
-    int tbands, tband_len;  // pipelined backward: row bands per plane share handed to the RPS row slots
-    int tband_mode;         // 1: consecutive rows per thread (register carry), 0: rows RPS apart
     int tile_bytes;         // LDS-staged backward: bytes of the row tile in front of the maps
     unsigned xppr;          // LDS-staged gather forward: 16-byte pieces per SOURCE row
     FastDiv d_xppr;
     int lds_affine;         // LDS-staged kernels: read affine chunks as consecutive dwords (tuning knob 5 = 1 turns it off)
     unsigned xcd_blocks;    // grid / 8 when the XCD-contiguous block remap is on (grid % 8 == 0), else 0
     FastDiv d_cpr;
-    FastDiv d_tbands;
     FastDiv d_rows;     // divide by rows_per_band
     FastDiv d_dim1;     // divide by the second outer dim of the iteration space
 };
@@ -477,265 +474,6 @@ __global__ __launch_bounds__(kThreads) void plane_backward(const PlaneParams p) 
                     }
                 }
                 store_chunk<S, E>(dst, res);
-            }
-        }
-    }
-#pragma unroll
-    for (int s = 0; s < 3; ++s) {
-        const double t = block_sum(acc[s], scratch);
-        if (threadIdx.x == 0) p.partials[(static_cast<size_t>(wi.pidx) * p.C + wi.c) * 3 + s] = t;
-    }
-}
-
-// =====================================================================================================
-// Backward, pipelined form (opt-in, tuning knob 3 = 0): same results as plane_backward above, restructured for HBM rate.
-//   * A thread owns a chunk column and a BAND of consecutive rows, so the corner rows it loaded for
-//     row r (the "+1" rows) are the "+0" rows of row r + 1: they stay in registers (ring of three
-//     slots) and every source row is loaded once per thread instead of twice.
-//   * The loads of row r + 1 are issued BEFORE row r is computed and stored: gfx950 retires a wave's
-//     vector-memory operations in order, so a load issued after a store would wait for that store's
-//     acknowledgement.
-// =====================================================================================================
-template <typename T, int E> struct RowRaw {
-    Chunk<typename T::S, E> v;
-    typename T::S last;
-};
-
-template <typename T, int E>
-__device__ __forceinline__ RowRaw<T, E> fetch_row(const typename T::S *__restrict__ row, bool valid, bool contig,
-                                                  const int (&mm)[E + 1]) {
-    using S = typename T::S;
-    RowRaw<T, E> r;
-    const S zero = narrow<T>(typename T::C(0));
-#pragma unroll
-    for (int e = 0; e < E; ++e) r.v.e[e] = zero;
-    r.last = zero;
-    if (valid) {
-        if (contig) {
-            r.v = load_chunk<S, E>(row + mm[0]);
-        } else {
-#pragma unroll
-            for (int e = 0; e < E; ++e)
-                if (mm[e] >= 0) r.v.e[e] = row[mm[e]];
-        }
-        if (mm[E] >= 0) r.last = row[mm[E]];
-    }
-    return r;
-}
-
-template <typename T, int ND, bool ACTIVE>
-__global__ __launch_bounds__(kThreads) void plane_backward_pipe(const PlaneParams p) {
-    using S = typename T::S;
-    using CT = typename T::C;
-    constexpr int E = 16 / sizeof(S);
-    constexpr int NC = 1 << (ND - 1);
-    constexpr int NH = ND == 1 ? 1 : NC / 2;  // corner combos that carry the "+1 along the walked dim" bit
-    extern __shared__ int maps[];
-    __shared__ double scratch[kThreads / 64];
-    const int *m0 = maps, *m1 = m0 + p.S[0] + 1, *m2 = m1 + p.S[1] + 1;
-    int *gmaps = maps + p.S[0] + p.S[1] + p.S[2] + 3;
-    const int *g0 = gmaps, *g1 = g0 + p.O[0] + 1, *g2 = g1 + p.O[1] + 1;
-
-    const WorkItem wi = decode_block(p);
-    int64_t sh[3] = {0, 0, 0};
-    CT dw[3] = {CT(0), CT(0), CT(0)};
-#pragma unroll
-    for (int d = 0; d < 3; ++d)
-        if (p.wcol[d] >= 0)
-            prep_shift_backward<CT>(load_weight<CT>(p.w, p.wkind, wi.c * p.nd + p.wcol[d]), ACTIVE, sh[d], dw[p.wcol[d]]);
-    build_maps(maps, p.S, sh, -1, p.pad);
-    build_maps(gmaps, p.O, sh, ACTIVE ? -1 : +1, p.pad);
-    __syncthreads();
-
-    const S *__restrict__ x = static_cast<const S *>(p.x);
-    const S *__restrict__ go = static_cast<const S *>(p.go);
-    S *__restrict__ gx = static_cast<S *>(p.out);
-    const int tr = threadIdx.x / p.CW, tc = threadIdx.x - tr * p.CW;
-    const int S1 = p.S[1], S2 = p.S[2], O1 = p.O[1], O2 = p.O[2];
-    const S zero = narrow<T>(CT(0));
-    double acc[3] = {0.0, 0.0, 0.0};
-
-    struct Slot {
-        bool rowin;            // inside the border window: loads were issued
-        bool gsvalid;          // SSL: the shifted grad_out row exists
-        int b;                 // position along the walked outer dim
-        Chunk<S, E> g;         // incoming gradient at this position
-        RowRaw<T, E> xhi[NH];  // x rows of the "+1" corner combos (all combos when ND == 1)
-        RowRaw<T, E> ghi[NH];  // active: grad_out rows of the "+1" combos; SSL: [0] = the shifted row
-        RowRaw<T, E> xlo[NH];  // "+0" combos, loaded only when they cannot be carried over from the previous row
-        RowRaw<T, E> glo[NH];
-    };
-    const bool banded = p.tband_mode != 0;  // consecutive rows per thread (carry) or rows RPS apart (no carry)
-
-    if (tr < p.RPS) {
-        for (int cp = 0; cp < p.CP; ++cp) {
-            const int chunk = cp * p.CW + tc;
-            if (chunk >= p.cpr) break;
-            const int ji = chunk * E;
-            const int oj = ji - p.L[2];
-            int xm[E + 1], gm[E + 1];
-            unsigned inmask = 0;
-            bool xcontig = true, gcontig = true;
-#pragma unroll
-            for (int e = 0; e <= E; ++e) {
-                xm[e] = m2[ji + e];
-                if (e < E) xcontig = xcontig && (xm[e] == xm[0] + e);
-                const int o = oj + e;
-                const bool in = (o >= 0) && (o < O2);
-                if (e < E && in) inmask |= 1u << e;
-                const int oc = o < 0 ? 0 : (o > O2 ? O2 : o);
-                gm[e] = g2[oc];
-                if (e < E) gcontig = gcontig && (gm[e] == gm[0] + e);
-            }
-            const bool allin = inmask == ((1u << E) - 1u);
-            xcontig = xcontig && (xm[0] >= 0);
-            gcontig = gcontig && allin && (gm[0] >= 0);
-
-            const int items = wi.nn * p.tbands;
-            for (int t = tr; t < items; t += p.RPS) {
-                const int nl = fdiv(t, p.d_tbands);
-                const int tb = t - nl * p.tbands;
-                // banded: rows [tb*len, (tb+1)*len); interleaved: rows tb, tb + RPS, ... of the workgroup's share
-                const int rb0 = wi.row0 + (banded ? tb * p.tband_len : tb);
-                const int rb1 = banded ? min(rb0 + p.tband_len, wi.row0 + wi.nrows) : wi.row0 + wi.nrows;
-                if (rb0 >= rb1) continue;
-                const int64_t plane = static_cast<int64_t>(wi.n0 + nl) * p.C + wi.c;
-                const S *xp = x + plane * p.x_plane;
-                const S *gp = go + plane * p.o_plane;
-                S *gxp = gx + plane * p.x_plane + ji;
-
-                // corner-combo helpers: `hi` selects the +1 row along the walked dim (b), h the other outer bit
-                auto xoff = [&](int a, int b, int h, int hi) {
-                    return combo_offset<ND>(ND == 2 ? hi : (hi * 2 + h), m0, m1, a, b, S1 * S2, S2);
-                };
-                auto goff = [&](int oa, int ob, int h, int hi) {
-                    return combo_offset<ND>(ND == 2 ? hi : (hi * 2 + h), g0, g1, oa, ob, O1 * O2, O2);
-                };
-                // issue every load of row r into a slot
-                auto prefetch = [&](int r, Slot &sl, bool need_low) {
-                    const int a = fdiv(r, p.d_dim1);
-                    const int b = r - a * S1;
-                    const int oa = a - p.L[0], ob = b - p.L[1];
-                    sl.b = b;
-                    sl.gsvalid = false;
-                    sl.rowin = (oa >= 0) && (oa < p.O[0]) && (ob >= 0) && (ob < O1) && (inmask != 0);
-                    if (!sl.rowin) return;
-                    const S *grow = gp + static_cast<int64_t>(oa * O1 + ob) * O2;
-                    if (allin) {
-                        sl.g = load_chunk<S, E>(grow + oj);
-                    } else {
-#pragma unroll
-                        for (int e = 0; e < E; ++e)
-                            sl.g.e[e] = ((inmask >> e) & 1u) ? grow[oj + e] : zero;
-                    }
-#pragma unroll
-                    for (int h = 0; h < NH; ++h) {
-                        const int off = xoff(a, b, h, ND == 1 ? 0 : 1);
-                        sl.xhi[h] = fetch_row<T, E>(xp + (off < 0 ? 0 : off), off >= 0, xcontig, xm);
-                    }
-                    if constexpr (ND >= 2) {
-                        if (need_low || (ND == 3 && b == 0)) {
-#pragma unroll
-                            for (int h = 0; h < NH; ++h) {
-                                const int off = xoff(a, b, h, 0);
-                                sl.xlo[h] = fetch_row<T, E>(xp + (off < 0 ? 0 : off), off >= 0, xcontig, xm);
-                                if constexpr (ACTIVE) {
-                                    const int off2 = goff(oa, ob, h, 0);
-                                    sl.glo[h] = fetch_row<T, E>(gp + (off2 < 0 ? 0 : off2), off2 >= 0, gcontig, gm);
-                                }
-                            }
-                        }
-                    }
-                    if constexpr (ACTIVE) {
-#pragma unroll
-                        for (int h = 0; h < NH; ++h) {
-                            const int off = goff(oa, ob, h, ND == 1 ? 0 : 1);
-                            sl.ghi[h] = fetch_row<T, E>(gp + (off < 0 ? 0 : off), off >= 0, gcontig, gm);
-                        }
-                    } else {
-                        const int ra = g0[oa], rb = g1[ob];
-                        sl.gsvalid = ra >= 0 && rb >= 0;
-                        if (sl.gsvalid) {
-                            const S *srow = gp + static_cast<int64_t>(ra * O1 + rb) * O2;
-                            if (gcontig) {
-                                sl.ghi[0].v = load_chunk<S, E>(srow + gm[0]);
-                            } else {
-#pragma unroll
-                                for (int e = 0; e < E; ++e)
-                                    sl.ghi[0].v.e[e] = (((inmask >> e) & 1u) && gm[e] >= 0) ? srow[gm[e]] : zero;
-                            }
-                        }
-                    }
-                };
-                // compute and store row r from its slot; `prv` holds row r - 1 when prev_ok
-                auto process = [&](int r, const Slot &cur, const Slot &prv, bool prev_ok) {
-                    S *dst = gxp + static_cast<int64_t>(r) * S2;
-                    Chunk<S, E> res;
-                    if (!cur.rowin) {
-#pragma unroll
-                        for (int e = 0; e < E; ++e) res.e[e] = zero;
-                        store_chunk<S, E>(dst, res);
-                        return;
-                    }
-                    // the "+0" combos: carried over from the previous row of this band when possible, else the
-                    // slot's own copies (prefetch loaded them: prev_ok == false was known one row ahead)
-                    const bool carry = (ND >= 2) && prev_ok && (ND < 3 || cur.b != 0);
-                    RowRaw<T, E> xlo[NH], glo[NH];
-                    if constexpr (ND >= 2) {
-#pragma unroll
-                        for (int h = 0; h < NH; ++h) {
-                            xlo[h] = carry ? prv.xhi[h] : cur.xlo[h];
-                            if constexpr (ACTIVE) glo[h] = carry ? prv.ghi[h] : cur.glo[h];
-                        }
-                    }
-#pragma unroll
-                    for (int e = 0; e < E; ++e) {
-                        CT v[1 << ND], wg[3];
-#pragma unroll
-                        for (int q = 0; q < (1 << ND); ++q) {
-                            const int k = q & (NC - 1), inner = q >> (ND - 1);
-                            const RowRaw<T, E> &rw = (ND == 1) ? cur.xhi[0] : ((k >= NH) ? cur.xhi[k - NH] : xlo[k]);
-                            v[q] = widen<T>(e + inner < E ? rw.v.e[(e + inner) % E] : rw.last);
-                        }
-                        weight_grads_nd<ND, CT>(v, dw, wg);
-                        const bool in = ((inmask >> e) & 1u) != 0;
-                        if (in) {
-                            const CT gval = widen<T>(cur.g.e[e]);
-#pragma unroll
-                            for (int s = 0; s < ND; ++s) acc[s] += static_cast<double>(gval * wg[s]);
-                        }
-                        if constexpr (ACTIVE) {
-#pragma unroll
-                            for (int q = 0; q < (1 << ND); ++q) {
-                                const int k = q & (NC - 1), inner = q >> (ND - 1);
-                                const RowRaw<T, E> &rw = (ND == 1) ? cur.ghi[0] : ((k >= NH) ? cur.ghi[k - NH] : glo[k]);
-                                v[q] = widen<T>(e + inner < E ? rw.v.e[(e + inner) % E] : rw.last);
-                            }
-                            const CT r1 = interp_nd<ND, CT>(v, dw);
-                            res.e[e] = narrow<T>(in ? r1 : CT(0));
-                        } else {
-                            res.e[e] = cur.gsvalid ? cur.ghi[0].v.e[e] : zero;
-                        }
-                    }
-                    store_chunk<S, E>(dst, res);
-                };
-
-                Slot ring[3];
-                const int step = banded ? 1 : p.RPS;
-                prefetch(rb0, ring[0], true);
-                bool prev_ok = false;
-                for (int r = rb0; r < rb1; r += 3 * step) {
-#pragma unroll
-                    for (int ph = 0; ph < 3; ++ph) {
-                        const int rr = r + ph * step;
-                        if (rr < rb1) {
-                            // row rr + 1 can carry its "+0" rows from row rr only when rr issues loads (banded mode)
-                            if (rr + step < rb1) prefetch(rr + step, ring[(ph + 1) % 3], !(banded && ring[ph].rowin));
-                            process(rr, ring[ph], ring[(ph + 2) % 3], banded && prev_ok);
-                            prev_ok = ring[ph].rowin;
-                        }
-                    }
-                }
             }
         }
     }
@@ -1245,7 +983,8 @@ bool contiguous(const int64_t st[5], int64_t N, int64_t C, const int64_t sz[3]) 
 
 // diagnostics knobs (shiftnd_set_tuning): 0 = min workgroups wanted, 1 = target bytes per workgroup,
 // 2 = gather-forward unroll (fp32/16-byte variant only), 6 = XCD-contiguous workgroup ids, 7 = minimum workgroups
-// wanted by the backward kernels (row bands of a plane share source rows through their XCD's L2), 3 = backward kernel: 2 LDS-staged where it applies (default), 1 simple loop, 0 pipelined
+// wanted by the backward kernels (row bands of a plane share source rows through their XCD's L2), 3 = backward / active-forward kernel: 2 LDS-staged where it applies (default), 1 direct global loads;
+// 4 = LDS tiles of the backward kernel: 1 automatic, 2 two tiles + one barrier per step, 3 one tile; 5 = 1: no affine dword reads
 int g_tune[8] = {2048, 128 * 1024, 4, 2, 1, 0, 1, 65536};
 
 struct Plan {
@@ -1315,11 +1054,6 @@ void fill_params(PlaneParams &p, const Geometry &g, const Plan &pl, int64_t dim1
     p.CP = pl.CP;
     p.rows = pl.rows;
     p.d_rows = make_fastdiv(static_cast<uint32_t>(pl.rows_per_band));
-    p.tbands = pl.RPS < pl.rows_per_band ? pl.RPS : pl.rows_per_band;
-    if (p.tbands < 1) p.tbands = 1;
-    p.tband_len = (pl.rows_per_band + p.tbands - 1) / p.tbands;
-    p.d_tbands = make_fastdiv(static_cast<uint32_t>(p.tbands));
-    p.tband_mode = g_tune[4];
     p.lds_affine = g_tune[5] == 0;
     p.xcd_blocks = (g_tune[6] && pl.grid % 8 == 0) ? pl.grid / 8 : 0;
     p.d_cpr = make_fastdiv(static_cast<uint32_t>(pl.cpr));
@@ -1422,15 +1156,7 @@ void launch_backward_a(const PlaneParams &p_in, const Plan &pl, hipStream_t st) 
             return;
         }
     }
-    note_kernel(g_tune[3] == 0 ? "plane_backward_pipe" : "plane_backward");
-    if (g_tune[3] == 0) {  // pipelined form (measured slower than the simple loop on MI355X so far: opt-in)
-        switch (p.nd) {
-        case 1: hipLaunchKernelGGL((plane_backward_pipe<T, 1, ACTIVE>), dim3(pl.grid), dim3(kThreads), pl.lds, st, p); break;
-        case 2: hipLaunchKernelGGL((plane_backward_pipe<T, 2, ACTIVE>), dim3(pl.grid), dim3(kThreads), pl.lds, st, p); break;
-        default: hipLaunchKernelGGL((plane_backward_pipe<T, 3, ACTIVE>), dim3(pl.grid), dim3(kThreads), pl.lds, st, p); break;
-        }
-        return;
-    }
+    note_kernel("plane_backward");
     switch (p.nd) {
     case 1: hipLaunchKernelGGL((plane_backward<T, 1, ACTIVE>), dim3(pl.grid), dim3(kThreads), pl.lds, st, p); break;
     case 2: hipLaunchKernelGGL((plane_backward<T, 2, ACTIVE>), dim3(pl.grid), dim3(kThreads), pl.lds, st, p); break;

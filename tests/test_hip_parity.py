@@ -291,36 +291,6 @@ def test_deterministic_weight_grad(abi):
         assert torch.equal(got[0], ref[0]) and torch.equal(got[1], ref[1])
 
 
-@pytest.mark.parametrize("mode", [0, 1])
-def test_pipelined_backward_variants(abi, mode):
-    """the opt-in pipelined plane backward (register carry of corner rows / prefetch one row ahead)
-    must equal the default kernel bit for bit on grad_x and to rounding on grad_w"""
-    rs = np.random.RandomState(21)
-    cases = [((3, 5, 40), None), ((2, 4, 13, 32), [[2, 1], [4, 4]]), ((3, 5, 9, 24), None),
-             ((2, 3, 5, 6, 16), None), ((2, 2, 4, 7, 24), [[1, 0], [0, 2], [4, 4]]), ((1, 2, 300, 8), None)]
-    try:
-        for shape, crop in cases:
-            nd = len(shape) - 2
-            x = rs.uniform(-1, 1, size=shape).astype(np.float32)
-            w = _weights(rs, shape[1], nd, shape[2:]).astype(np.float32)
-            b, new = abi.check_borders(list(shape), crop, nd)
-            go = rs.uniform(-1, 1, size=new).astype(np.float32)
-            xd, wd, god = _dev(x), _dev(w), _dev(go)
-            for pad in range(5):
-                for active in (0, 1):
-                    abi.set_tuning(3, 1)
-                    gx0, gw0 = abi.backward(god, wd, xd, pad, active, b)
-                    abi.set_tuning(3, 0)
-                    abi.set_tuning(4, mode)
-                    gx1, gw1 = abi.backward(god, wd, xd, pad, active, b)
-                    assert abi.last_path() == abi.PATH_PLANE
-                    assert torch.equal(gx0, gx1), (shape, pad, active)
-                    assert rel_err(gw1.cpu().numpy(), gw0.cpu().numpy()) < 1e-6, (shape, pad, active)
-    finally:
-        abi.set_tuning(3, 2)
-        abi.set_tuning(4, 1)  # 1 = automatic tile choice
-
-
 @pytest.mark.parametrize("tiles", [1, 2])
 def test_lds_staged_kernels(abi, tiles):
     """the LDS-staged kernels (default, tuning knob 3 = 2: active forward and backward, 2-D / 3-D, no crop) vs

@@ -18,10 +18,10 @@ constexpr int kMaxMapEntries = 12288; // LDS budget for index maps (48 KiB of in
 // ---------------------------------------------------------------------------------------------
 // Element types.  Storage type S (what lives in HBM), compute type C (what interpolation uses).
 // ---------------------------------------------------------------------------------------------
-struct f32_t { using S = float;    using C = float;  };
-struct f64_t { using S = double;   using C = double; };
-struct f16_t { using S = _Float16; using C = float;  };
-struct bf16_t { using S = __bf16;  using C = float;  };
+struct f32_t { using S = float;    using C = float;  static constexpr int kDtype = SHIFTND_F32; };
+struct f64_t { using S = double;   using C = double; static constexpr int kDtype = SHIFTND_F64; };
+struct f16_t { using S = _Float16; using C = float;  static constexpr int kDtype = SHIFTND_F16; };
+struct bf16_t { using S = __bf16;  using C = float;  static constexpr int kDtype = SHIFTND_BF16; };
 
 template <typename T> __device__ __forceinline__ typename T::C widen(typename T::S v) {
     return static_cast<typename T::C>(v);
@@ -294,6 +294,71 @@ __global__ __launch_bounds__(64) void reduce_weight_grads(const double *__restri
     }
 }
 }  // namespace
+
+// ---------------------------------------------------------------------------------------------
+// Raw element / chunk I/O shared by the kernel families.
+// ---------------------------------------------------------------------------------------------
+template <int ESIZE> struct raw_t;
+template <> struct raw_t<1> { using type = uint8_t; };
+template <> struct raw_t<2> { using type = uint16_t; };
+template <> struct raw_t<4> { using type = uint32_t; };
+template <> struct raw_t<8> { using type = uint64_t; };
+
+template <int V> struct vec_of;
+template <> struct vec_of<16> { typedef uint32_t type __attribute__((ext_vector_type(4))); };
+template <> struct vec_of<8> { typedef uint32_t type __attribute__((ext_vector_type(2))); };
+template <> struct vec_of<4> { typedef uint32_t type; };
+template <> struct vec_of<2> { typedef uint16_t type; };
+template <> struct vec_of<1> { typedef uint8_t type; };
+
+template <typename R, int E> struct Chunk { R e[E]; };  // one V = sizeof(R) * E byte piece of a row
+
+// element-aligned V-byte load (one global_load_dwordx4 for V = 16: gfx950 global loads take any alignment).
+// NT = nontemporal: only for data that no other workgroup re-reads (the gather forward); the backward kernels
+// rely on L2 for the rows that neighbouring rows share (measured: nontemporal loads there raise HBM reads from
+// 7.6 to 10 GB per C2 launch).
+template <typename R, int E, bool NT = false> __device__ __forceinline__ Chunk<R, E> load_chunk(const R *src) {
+    constexpr int V = sizeof(R) * E;
+    typedef typename vec_of<V>::type vec_t;
+    typedef vec_t unaligned_t __attribute__((aligned(sizeof(R) < 4 ? sizeof(R) : 4)));
+    const vec_t v = NT ? __builtin_nontemporal_load(reinterpret_cast<const unaligned_t *>(src))
+                       : *reinterpret_cast<const unaligned_t *>(src);
+    Chunk<R, E> c;
+    __builtin_memcpy(c.e, &v, V);
+    return c;
+}
+// aligned V-byte nontemporal store (every output byte is written once)
+template <typename R, int E> __device__ __forceinline__ void store_chunk(R *dst, const Chunk<R, E> &c) {
+    constexpr int V = sizeof(R) * E;
+    typedef typename vec_of<V>::type vec_t;
+    vec_t v;
+    __builtin_memcpy(&v, c.e, V);
+    __builtin_nontemporal_store(v, reinterpret_cast<vec_t *>(dst));
+}
+
+// float weight of any supported dtype, widened to the compute type
+template <typename CT> __device__ __forceinline__ CT load_weight(const void *w, int wkind, int64_t i) {
+    switch (wkind) {
+    case SHIFTND_F64: return static_cast<CT>(static_cast<const double *>(w)[i]);
+    case SHIFTND_F16: return static_cast<CT>(static_cast<const _Float16 *>(w)[i]);
+    case SHIFTND_BF16: return static_cast<CT>(static_cast<const __bf16 *>(w)[i]);
+    default: return static_cast<CT>(static_cast<const float *>(w)[i]);
+    }
+}
+
+// integer shift of the gather-only kernels: round-half-even of a float weight (SSL), or a quantized weight's
+// int_repr minus its zero point (kernels/shifts_kernels.h:553-555)
+__device__ __forceinline__ int64_t gather_shift(const void *w, int wkind, int64_t wzp, int64_t i) {
+    switch (wkind) {
+    case SHIFTND_F32: return static_cast<int64_t>(rintf(static_cast<const float *>(w)[i]));
+    case SHIFTND_F64: return static_cast<int64_t>(rint(static_cast<const double *>(w)[i]));
+    case SHIFTND_F16: return static_cast<int64_t>(rintf(static_cast<float>(static_cast<const _Float16 *>(w)[i])));
+    case SHIFTND_BF16: return static_cast<int64_t>(rintf(static_cast<float>(static_cast<const __bf16 *>(w)[i])));
+    case SHIFTND_I8: return static_cast<int64_t>(static_cast<const int8_t *>(w)[i]) - wzp;
+    case SHIFTND_U8: return static_cast<int64_t>(static_cast<const uint8_t *>(w)[i]) - wzp;
+    default: return static_cast<int64_t>(static_cast<const int32_t *>(w)[i]) - wzp;
+    }
+}
 
 // ---------------------------------------------------------------------------------------------
 // Host-side problem description handed to the kernel families.

@@ -54,28 +54,6 @@ struct PlaneParams {
     FastDiv d_dim1;     // divide by the second outer dim of the iteration space
 };
 
-// ---- shift loading -------------------------------------------------------------------------------
-template <typename CT> __device__ __forceinline__ CT load_weight(const void *w, int wkind, int i) {
-    switch (wkind) {
-    case SHIFTND_F64: return static_cast<CT>(static_cast<const double *>(w)[i]);
-    case SHIFTND_F16: return static_cast<CT>(static_cast<const _Float16 *>(w)[i]);
-    case SHIFTND_BF16: return static_cast<CT>(static_cast<const __bf16 *>(w)[i]);
-    default: return static_cast<CT>(static_cast<const float *>(w)[i]);
-    }
-}
-
-__device__ __forceinline__ int64_t gather_shift(const void *w, int wkind, int64_t wzp, int i) {
-    switch (wkind) {
-    case SHIFTND_F32: return static_cast<int64_t>(rintf(static_cast<const float *>(w)[i]));
-    case SHIFTND_F64: return static_cast<int64_t>(rint(static_cast<const double *>(w)[i]));
-    case SHIFTND_F16: return static_cast<int64_t>(rintf(static_cast<float>(static_cast<const _Float16 *>(w)[i])));
-    case SHIFTND_BF16: return static_cast<int64_t>(rintf(static_cast<float>(static_cast<const __bf16 *>(w)[i])));
-    case SHIFTND_I8: return static_cast<int64_t>(static_cast<const int8_t *>(w)[i]) - wzp;
-    case SHIFTND_U8: return static_cast<int64_t>(static_cast<const uint8_t *>(w)[i]) - wzp;
-    default: return static_cast<int64_t>(static_cast<const int32_t *>(w)[i]) - wzp;
-    }
-}
-
 // Fill the LDS maps of the three normalised dims: map_d[p] = pad(p + sign*shift_d) for p in [0, size_d].
 // (size_d + 1 entries: the interpolating kernels also read coordinate p + 1.)
 __device__ __forceinline__ void build_maps(int *maps, const int size[3], const int64_t sh[3], int sign, int pad) {
@@ -105,43 +83,6 @@ __device__ __forceinline__ WorkItem decode_block(const PlaneParams &p) {
     wi.nrows = min(p.rows_per_band, p.rows - wi.row0);
     wi.pidx = band * p.groups + grp;
     return wi;
-}
-
-// ---- 16-byte (or narrower) chunk I/O ----------------------------------------------------------------
-template <int ESIZE> struct raw_t;
-template <> struct raw_t<1> { using type = uint8_t; };
-template <> struct raw_t<2> { using type = uint16_t; };
-template <> struct raw_t<4> { using type = uint32_t; };
-template <> struct raw_t<8> { using type = uint64_t; };
-
-template <typename R, int E> struct Chunk { R e[E]; };
-
-template <int V> struct vec_of;
-template <> struct vec_of<16> { typedef uint32_t type __attribute__((ext_vector_type(4))); };
-template <> struct vec_of<8> { typedef uint32_t type __attribute__((ext_vector_type(2))); };
-template <> struct vec_of<4> { typedef uint32_t type; };
-template <> struct vec_of<2> { typedef uint16_t type; };
-template <> struct vec_of<1> { typedef uint8_t type; };
-
-// element-aligned V-byte load (one global_load_dwordx4 on gfx950).  NT = nontemporal: only for data
-// that no other workgroup re-reads (the gather forward); the backward kernels rely on L2 for the rows
-// that neighbouring rows share (measured: nontemporal loads there raise HBM reads from 7.6 to 10 GB).
-template <typename R, int E, bool NT = false> __device__ __forceinline__ Chunk<R, E> load_chunk(const R *src) {
-    constexpr int V = sizeof(R) * E;
-    typedef typename vec_of<V>::type vec_t;
-    typedef vec_t unaligned_t __attribute__((aligned(sizeof(R) < 4 ? sizeof(R) : 4)));
-    const vec_t v = NT ? __builtin_nontemporal_load(reinterpret_cast<const unaligned_t *>(src))
-                       : *reinterpret_cast<const unaligned_t *>(src);
-    Chunk<R, E> c;
-    __builtin_memcpy(c.e, &v, V);
-    return c;
-}
-template <typename R, int E> __device__ __forceinline__ void store_chunk(R *dst, const Chunk<R, E> &c) {
-    constexpr int V = sizeof(R) * E;
-    typedef typename vec_of<V>::type vec_t;
-    vec_t v;
-    __builtin_memcpy(&v, c.e, V);
-    __builtin_nontemporal_store(v, reinterpret_cast<vec_t *>(dst));
 }
 
 // =====================================================================================================

@@ -15,25 +15,6 @@
 namespace shiftnd {
 namespace {
 
-// raw shift loaders ------------------------------------------------------------------------------
-template <typename T>
-__device__ __forceinline__ typename T::C load_w(const void *w, int64_t i) {
-    return widen<T>(static_cast<const typename T::S *>(w)[i]);
-}
-
-// integer shift of (channel c, normalised dim dn) for gather-only kernels
-__device__ __forceinline__ int64_t int_shift(const void *w, int wkind, int64_t wzp, int64_t i) {
-    switch (wkind) {
-    case SHIFTND_F32: return static_cast<int64_t>(rintf(static_cast<const float *>(w)[i]));
-    case SHIFTND_F64: return static_cast<int64_t>(rint(static_cast<const double *>(w)[i]));
-    case SHIFTND_F16: return static_cast<int64_t>(rintf(static_cast<float>(static_cast<const _Float16 *>(w)[i])));
-    case SHIFTND_BF16: return static_cast<int64_t>(rintf(static_cast<float>(static_cast<const __bf16 *>(w)[i])));
-    case SHIFTND_I8: return static_cast<int64_t>(static_cast<const int8_t *>(w)[i]) - wzp;
-    case SHIFTND_U8: return static_cast<int64_t>(static_cast<const uint8_t *>(w)[i]) - wzp;
-    default: return static_cast<int64_t>(static_cast<const int32_t *>(w)[i]) - wzp;
-    }
-}
-
 // resolve one gather: returns element offset within the (n) slice or -1 (fill)
 __device__ __forceinline__ int64_t resolve(const int64_t idx[3], const int64_t size[3], const int64_t *st /*d0,d1,inner*/,
                                            int pad) {
@@ -46,12 +27,6 @@ __device__ __forceinline__ int64_t resolve(const int64_t idx[3], const int64_t s
     }
     return off;
 }
-
-template <int ESIZE> struct raw_t;
-template <> struct raw_t<1> { using type = uint8_t; };
-template <> struct raw_t<2> { using type = uint16_t; };
-template <> struct raw_t<4> { using type = uint32_t; };
-template <> struct raw_t<8> { using type = uint64_t; };
 
 // SSL / quantized forward: pure gather of ESIZE-byte elements ------------------------------------
 template <int ESIZE>
@@ -75,7 +50,7 @@ __global__ __launch_bounds__(kThreads) void strided_gather_forward(Geometry g, c
         int64_t idx[3];
 #pragma unroll
         for (int d = 0; d < 3; ++d) {
-            const int64_t sh = g.wcol[d] >= 0 ? int_shift(w, wkind, wzp, c * g.nd + g.wcol[d]) : 0;
+            const int64_t sh = g.wcol[d] >= 0 ? gather_shift(w, wkind, wzp, c * g.nd + g.wcol[d]) : 0;
             idx[d] = o[d] + g.L[d] - sh;
         }
         const int64_t off = resolve(idx, g.S, g.xs + 2, g.pad);
@@ -118,7 +93,7 @@ __global__ __launch_bounds__(kThreads) void strided_active_forward(Geometry g, c
 #pragma unroll
         for (int d = 0; d < 3; ++d) {
             int64_t sh = 0;
-            if (g.wcol[d] >= 0) prep_shift_forward<CT>(load_w<T>(w, c * g.nd + g.wcol[d]), true, sh, dw[g.wcol[d]]);
+            if (g.wcol[d] >= 0) prep_shift_forward<CT>(load_weight<CT>(w, T::kDtype, c * g.nd + g.wcol[d]), true, sh, dw[g.wcol[d]]);
             idx[d] = o[d] + g.L[d] - sh;
         }
         CT v[8];
@@ -142,7 +117,7 @@ __global__ __launch_bounds__(kThreads) void strided_backward(Geometry g, const t
     CT dw[3] = {0, 0, 0};
 #pragma unroll
     for (int d = 0; d < 3; ++d)
-        if (g.wcol[d] >= 0) prep_shift_backward<CT>(load_w<T>(w, c * g.nd + g.wcol[d]), ACTIVE, sh[d], dw[g.wcol[d]]);
+        if (g.wcol[d] >= 0) prep_shift_backward<CT>(load_weight<CT>(w, T::kDtype, c * g.nd + g.wcol[d]), ACTIVE, sh[d], dw[g.wcol[d]]);
 
     const typename T::S *xp = x + n * g.xs[0] + c * g.xs[1];
     const typename T::S *gop = go + n * g.os[0] + c * g.os[1];

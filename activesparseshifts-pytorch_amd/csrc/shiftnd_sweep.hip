@@ -60,52 +60,6 @@ __device__ __forceinline__ uint32_t xcd_remap(uint32_t blocks_per_xcd) {
     return (blockIdx.x & 7u) * blocks_per_xcd + (blockIdx.x >> 3);
 }
 
-template <int ESIZE> struct raw_t;
-template <> struct raw_t<1> { using type = uint8_t; };
-template <> struct raw_t<2> { using type = uint16_t; };
-template <> struct raw_t<4> { using type = uint32_t; };
-template <> struct raw_t<8> { using type = uint64_t; };
-
-// V-byte vectors with element alignment for loads (gfx950 global loads take any alignment)
-template <int V> struct vec_of;
-template <> struct vec_of<16> { typedef uint32_t type __attribute__((ext_vector_type(4))); };
-template <> struct vec_of<8> { typedef uint32_t type __attribute__((ext_vector_type(2))); };
-template <> struct vec_of<4> { typedef uint32_t type; };
-template <> struct vec_of<2> { typedef uint16_t type; };
-template <> struct vec_of<1> { typedef uint8_t type; };
-
-template <typename R, int E> struct Chunk { R e[E]; };
-
-template <typename R, int E> __device__ __forceinline__ Chunk<R, E> load_chunk_nt(const R *src) {
-    constexpr int V = sizeof(R) * E;
-    typedef typename vec_of<V>::type vec_t;
-    typedef vec_t unaligned_t __attribute__((aligned(sizeof(R) < 4 ? sizeof(R) : 4)));
-    const vec_t v = __builtin_nontemporal_load(reinterpret_cast<const unaligned_t *>(src));
-    Chunk<R, E> c;
-    __builtin_memcpy(c.e, &v, V);
-    return c;
-}
-template <typename R, int E> __device__ __forceinline__ void store_chunk_nt(R *dst, const Chunk<R, E> &c) {
-    constexpr int V = sizeof(R) * E;
-    typedef typename vec_of<V>::type vec_t;
-    vec_t v;
-    __builtin_memcpy(&v, c.e, V);
-    __builtin_nontemporal_store(v, reinterpret_cast<vec_t *>(dst));
-}
-template <typename R> __device__ __forceinline__ R load_elem_nt(const R *src) { return __builtin_nontemporal_load(src); }
-
-__device__ __forceinline__ int64_t gather_shift(const void *w, int wkind, int64_t wzp, int i) {
-    switch (wkind) {
-    case SHIFTND_F32: return static_cast<int64_t>(rintf(static_cast<const float *>(w)[i]));
-    case SHIFTND_F64: return static_cast<int64_t>(rint(static_cast<const double *>(w)[i]));
-    case SHIFTND_F16: return static_cast<int64_t>(rintf(static_cast<float>(static_cast<const _Float16 *>(w)[i])));
-    case SHIFTND_BF16: return static_cast<int64_t>(rintf(static_cast<float>(static_cast<const __bf16 *>(w)[i])));
-    case SHIFTND_I8: return static_cast<int64_t>(static_cast<const int8_t *>(w)[i]) - wzp;
-    case SHIFTND_U8: return static_cast<int64_t>(static_cast<const uint8_t *>(w)[i]) - wzp;
-    default: return static_cast<int64_t>(static_cast<const int32_t *>(w)[i]) - wzp;
-    }
-}
-
 // source index of coordinate p of a dim: -1 = fill
 __device__ __forceinline__ int map1(int p, int cs, int len, int pad) { return len == 1 ? 0 : fold_index(p - cs, len, pad); }
 
@@ -168,31 +122,22 @@ __global__ __launch_bounds__(kSweepMaxThreads) void sweep_gather_forward(const S
             } else {
                 const R *row = xp + static_cast<int64_t>(ra * p.S[1] + rb) * p.S[2];
                 if (contig) {
-                    v[k] = load_chunk_nt<R, E>(row + mm[0]);
+                    v[k] = load_chunk<R, E, true>(row + mm[0]);
                 } else {
 #pragma unroll
-                    for (int e = 0; e < E; ++e) v[k].e[e] = mm[e] >= 0 ? load_elem_nt<R>(row + mm[e]) : fill;
+                    for (int e = 0; e < E; ++e) v[k].e[e] = mm[e] >= 0 ? __builtin_nontemporal_load(row + mm[e]) : fill;
                 }
             }
         }
     }
 #pragma unroll
     for (int k = 0; k < KMAX; ++k)
-        if (dst[k]) store_chunk_nt<R, E>(dst[k], v[k]);
+        if (dst[k]) store_chunk<R, E>(dst[k], v[k]);
 }
 
 // =====================================================================================================
 // Interpolating kernels: row loader, corner combos, float weights
 // =====================================================================================================
-template <typename CT> __device__ __forceinline__ CT load_weight(const void *w, int wkind, int i) {
-    switch (wkind) {
-    case SHIFTND_F64: return static_cast<CT>(static_cast<const double *>(w)[i]);
-    case SHIFTND_F16: return static_cast<CT>(static_cast<const _Float16 *>(w)[i]);
-    case SHIFTND_BF16: return static_cast<CT>(static_cast<const __bf16 *>(w)[i]);
-    default: return static_cast<CT>(static_cast<const float *>(w)[i]);
-    }
-}
-
 // E (+1) consecutive mapped elements of one source row, widened to the compute type
 template <typename T, int E, int CNT>
 __device__ __forceinline__ void load_row(const typename T::S *__restrict__ row, bool valid, bool contig,
@@ -205,14 +150,14 @@ __device__ __forceinline__ void load_row(const typename T::S *__restrict__ row, 
         return;
     }
     if (contig) {
-        const Chunk<S, E> c = load_chunk_nt<S, E>(row + mm[0]);
+        const Chunk<S, E> c = load_chunk<S, E>(row + mm[0]);
 #pragma unroll
         for (int e = 0; e < E; ++e) vals[e] = widen<T>(c.e[e]);
     } else {
 #pragma unroll
-        for (int e = 0; e < E; ++e) vals[e] = mm[e] >= 0 ? widen<T>(load_elem_nt<S>(row + mm[e])) : CT(0);
+        for (int e = 0; e < E; ++e) vals[e] = mm[e] >= 0 ? widen<T>(row[mm[e]]) : CT(0);
     }
-    if (CNT > E) vals[E] = mm[E] >= 0 ? widen<T>(load_elem_nt<S>(row + mm[E])) : CT(0);
+    if (CNT > E) vals[E] = mm[E] >= 0 ? widen<T>(row[mm[E]]) : CT(0);
     else vals[E] = CT(0);
 }
 
@@ -318,7 +263,7 @@ __global__ __launch_bounds__(kSweepMaxThreads) void sweep_backward(const SweepPa
         if (!rowin || inmask == 0) {  // outside the border window: grad_x = 0, no weight-gradient term
 #pragma unroll
             for (int e = 0; e < E; ++e) res.e[e] = narrow<T>(CT(0));
-            store_chunk_nt<S, E>(dst, res);
+            store_chunk<S, E>(dst, res);
             continue;
         }
         // incoming gradient at this position
@@ -326,12 +271,12 @@ __global__ __launch_bounds__(kSweepMaxThreads) void sweep_backward(const SweepPa
         {
             const S *grow = gp + static_cast<int64_t>(oa * p.O[1] + ob) * p.O[2];
             if (allin) {
-                const Chunk<S, E> cg = load_chunk_nt<S, E>(grow + oj);
+                const Chunk<S, E> cg = load_chunk<S, E>(grow + oj);
 #pragma unroll
                 for (int e = 0; e < E; ++e) gval[e] = widen<T>(cg.e[e]);
             } else {
 #pragma unroll
-                for (int e = 0; e < E; ++e) gval[e] = ((inmask >> e) & 1u) ? widen<T>(load_elem_nt<S>(grow + oj + e)) : CT(0);
+                for (int e = 0; e < E; ++e) gval[e] = ((inmask >> e) & 1u) ? widen<T>(grow[oj + e]) : CT(0);
             }
         }
         // corners of x around (coord - shift) -> weight gradient
@@ -357,11 +302,11 @@ __global__ __launch_bounds__(kSweepMaxThreads) void sweep_backward(const SweepPa
             if (gvalid) {
                 const S *srow = gp + static_cast<int64_t>(ra * p.O[1] + rb) * p.O[2];
                 if (gcontig) {
-                    graw = load_chunk_nt<S, E>(srow + gm[0]);
+                    graw = load_chunk<S, E>(srow + gm[0]);
                 } else {
 #pragma unroll
                     for (int e = 0; e < E; ++e)
-                        graw.e[e] = (((inmask >> e) & 1u) && gm[e] >= 0) ? load_elem_nt<S>(srow + gm[e]) : narrow<T>(CT(0));
+                        graw.e[e] = (((inmask >> e) & 1u) && gm[e] >= 0) ? srow[gm[e]] : narrow<T>(CT(0));
                 }
             }
         }
@@ -386,7 +331,7 @@ __global__ __launch_bounds__(kSweepMaxThreads) void sweep_backward(const SweepPa
                 res.e[e] = gvalid ? graw.e[e] : narrow<T>(CT(0));
             }
         }
-        store_chunk_nt<S, E>(dst, res);
+        store_chunk<S, E>(dst, res);
     }
 #pragma unroll
     for (int s = 0; s < 3; ++s) {

@@ -361,3 +361,28 @@ def test_lds_staged_gather_forward(abi):
     finally:
         abi.set_tuning(2, 4)
         abi.set_path_policy(0)
+
+
+def test_huge_and_special_shifts_on_device(abi):
+    """shifts far beyond the dims (multi-wrap, beyond 2^31: the 64-bit paths of canon_shift / pad_index), exact
+    halves and signed zeros, for every kernel family, vs the oracle"""
+    x = np.arange(2 * 8 * 12 * 16, dtype=np.float64).reshape(2, 8, 12, 16)
+    go = np.cos(np.arange(x.size, dtype=np.float64)).reshape(x.shape)
+    w = np.array([[1e6 + 3, -(1e6) - 7], [2.0 ** 31 + 5, -(2.0 ** 33) - 11], [2.0 ** 40 + 1, 2.0 ** 30],
+                  [-(2.0 ** 30), 0.5], [-0.0, 0.0], [1.5, -2.5], [12.0, -16.0], [11.5, 15.5]])
+    xd, wd, god = _dev(x), _dev(w), _dev(go)
+    try:
+        for policy in (0, 1, 2, 3):
+            abi.set_path_policy(policy)
+            for pad in range(5):
+                for active in (0, 1):
+                    if policy == 3 and active:
+                        continue  # no sweep kernel for the interpolating forward
+                    out = abi.forward(xd, wd, pad, active)
+                    assert np.array_equal(out.cpu().numpy(), O.forward(x, w, pad, active)), (policy, pad, active)
+                    gx, gw = abi.backward(god, wd, xd, pad, active)
+                    gx_o, gw_o = O.backward(go, w, x, pad, active)
+                    assert np.array_equal(gx.cpu().numpy(), gx_o), (policy, pad, active)
+                    assert rel_err(gw.cpu().numpy(), gw_o) < 1e-12, (policy, pad, active)
+    finally:
+        abi.set_path_policy(0)

@@ -120,6 +120,7 @@ const char *shiftnd_status_string(int status) {
     case SHIFTND_ERR_WORKSPACE_TOO_SMALL: return "workspace too small";
     case SHIFTND_ERR_LAUNCH_FAILED: return "kernel launch failed";
     case SHIFTND_ERR_TOO_LARGE: return "problem too large";
+    case SHIFTND_ERR_NOT_FUSED: return "geometry not served by the fused kernels";
     default: return "unknown status";
     }
 }
@@ -239,6 +240,80 @@ int shiftnd_backward(const shiftnd_problem *p, const void *grad_out, const int64
     if (strided_backward_workspace(g) > workspace_bytes) return SHIFTND_ERR_WORKSPACE_TOO_SMALL;
     g_last_path = SHIFTND_PATH_STRIDED;
     return finish(strided_backward(g, p->dtype, grad_out, x, weights, grad_x, grad_w, workspace, st));
+}
+
+// ---- fused shift + average pool ----------------------------------------------------------------------------
+static int pooled_geometry(const shiftnd_problem *p, const int32_t *pool, Geometry &g) {
+    if (!p || !pool) return SHIFTND_ERR_INVALID_ARGUMENT;
+    if (!is_float_dtype(p->dtype)) return SHIFTND_ERR_UNSUPPORTED_DTYPE;
+    const int64_t unit[5] = {0, 0, 0, 0, 0};
+    const int rc = build_geometry(p, unit, unit, unit, g);
+    if (rc != SHIFTND_OK) return rc;
+    const int lead = 3 - p->ndim;
+    for (int d = 0; d < 3; ++d) g.K[d] = 1;
+    for (int r = 0; r < p->ndim; ++r) {
+        if (pool[r] < 1) return SHIFTND_ERR_INVALID_ARGUMENT;
+        g.K[r + lead] = pool[r];
+    }
+    for (int d = 0; d < 3; ++d) g.P[d] = (g.O[d] + g.K[d] - 1) / g.K[d];
+    // contiguous tensors: element strides in normalised order N, C, d0, d1, inner
+    auto fill = [&](int64_t *st, const int64_t *sz) {
+        st[4] = 1;
+        st[3] = sz[2];
+        st[2] = sz[2] * sz[1];
+        st[1] = sz[2] * sz[1] * sz[0];
+        st[0] = st[1] * g.C;
+    };
+    fill(g.xs, g.S);
+    fill(g.gs, g.S);
+    fill(g.os, g.P);
+    return SHIFTND_OK;
+}
+
+int shiftnd_pooled_sizes(const shiftnd_problem *p, const int32_t *pool, int64_t pooled_spatial[3]) {
+    Geometry g;
+    const int rc = pooled_geometry(p, pool, g);
+    if (rc != SHIFTND_OK) return rc;
+    if (!pooled_spatial) return SHIFTND_ERR_INVALID_ARGUMENT;
+    const int lead = 3 - p->ndim;
+    for (int r = 0; r < 3; ++r) pooled_spatial[r] = r < p->ndim ? g.P[r + lead] : 1;
+    return SHIFTND_OK;
+}
+
+int shiftnd_forward_pooled(const shiftnd_problem *p, const int32_t *pool, const void *x, const void *weights, void *out,
+                           void *stream) {
+    Geometry g;
+    const int rc = pooled_geometry(p, pool, g);
+    if (rc != SHIFTND_OK) return rc;
+    if (empty_problem(g)) {
+        g_last_path = SHIFTND_PATH_EMPTY;
+        return SHIFTND_OK;
+    }
+    if (!x || !weights || !out) return SHIFTND_ERR_INVALID_ARGUMENT;
+    if (!plane_pool_forward_eligible(g, p->dtype)) return SHIFTND_ERR_NOT_FUSED;
+    g_last_path = SHIFTND_PATH_PLANE;
+    return finish(plane_pool_forward(g, p->dtype, x, weights, out, static_cast<hipStream_t>(stream)));
+}
+
+int shiftnd_backward_pooled(const shiftnd_problem *p, const int32_t *pool, const void *grad_pooled, const void *x,
+                            const void *weights, void *grad_x, void *grad_w, void *workspace, size_t workspace_bytes,
+                            void *stream) {
+    Geometry g;
+    const int rc = pooled_geometry(p, pool, g);
+    if (rc != SHIFTND_OK) return rc;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (g.N == 0 || g.C == 0 || g.S[0] * g.S[1] * g.S[2] == 0) {
+        g_last_path = SHIFTND_PATH_EMPTY;
+        if (g.C > 0 && grad_w)
+            if (hipMemsetAsync(grad_w, 0, static_cast<size_t>(g.C) * g.nd * dtype_size(p->dtype), st) != hipSuccess)
+                return SHIFTND_ERR_LAUNCH_FAILED;
+        return SHIFTND_OK;
+    }
+    if (!grad_pooled || !x || !weights || !grad_x || !grad_w || !workspace) return SHIFTND_ERR_INVALID_ARGUMENT;
+    if (!plane_pool_backward_eligible(g, p->dtype, grad_x)) return SHIFTND_ERR_NOT_FUSED;
+    if (plane_backward_workspace(g, p->dtype) > workspace_bytes) return SHIFTND_ERR_WORKSPACE_TOO_SMALL;
+    g_last_path = SHIFTND_PATH_PLANE;
+    return finish(plane_pool_backward(g, p->dtype, grad_pooled, x, weights, grad_x, grad_w, workspace, st));
 }
 
 }  // extern "C"

@@ -375,6 +375,8 @@ struct Geometry {
     int64_t os[5];   // element strides of out (forward) / grad_out (backward)
     int64_t gs[5];   // backward: element strides of grad_x
     int wcol[3];     // weight column of each normalised dim, or -1
+    int64_t K[3];    // fused average pool: window = stride per normalised dim (1 = none); 0 when the call has no pool
+    int64_t P[3];    // pooled sizes ceil(O / K)
 };
 
 }  // namespace shiftnd

@@ -47,6 +47,14 @@ size_t plane_backward_workspace(const Geometry &g, int dtype);
 int plane_backward(const Geometry &g, int dtype, const void *go, const void *x, const void *w, void *gx, void *gw,
                    void *workspace, hipStream_t st);
 
+// fused shift + average pool (kernel = stride = g.K, ceil mode), contiguous tensors only; the backward uses the
+// plane_backward_workspace layout
+bool plane_pool_forward_eligible(const Geometry &g, int dtype);
+int plane_pool_forward(const Geometry &g, int dtype, const void *x, const void *w, void *out, hipStream_t st);
+bool plane_pool_backward_eligible(const Geometry &g, int dtype, const void *gx);
+int plane_pool_backward(const Geometry &g, int dtype, const void *go, const void *x, const void *w, void *gx, void *gw,
+                        void *workspace, hipStream_t st);
+
 // ---- sweep kernels (shiftnd_sweep.hip): one 16-byte chunk per thread, XCD-contiguous grid ----------
 bool sweep_forward_eligible(const Geometry &g, int dtype, const void *x, const void *out);
 int sweep_forward(const Geometry &g, int dtype, const void *x, const void *w, int wkind, int64_t wzp, uint64_t fill_bits,

@@ -52,6 +52,10 @@ struct PlaneParams {
     FastDiv d_cpr;
     FastDiv d_rows;     // divide by rows_per_band
     FastDiv d_dim1;     // divide by the second outer dim of the iteration space
+    // fused average pool (kernel = stride = K, ceil mode; modules/shifts.py:81-89): pooled sizes P = ceil(O / K)
+    int K[3], P[3];
+    FastDiv d_k[3];
+    FastDiv d_p2;
 };
 
 // Fill the LDS maps of the three normalised dims: map_d[p] = pad(p + sign*shift_d) for p in [0, size_d].
@@ -268,12 +272,144 @@ __global__ __launch_bounds__(kThreads) void plane_active_forward(const PlanePara
     }
 }
 
+// v / cnt with IEEE rounding.  A power-of-two count (every window of an even pool size) divides exactly by
+// multiplying with 2^-k: same bits as the division, none of its ~10 instructions.
+template <typename CT> __device__ __forceinline__ CT div_count(CT v, int cnt) {
+    if ((cnt & (cnt - 1)) != 0) return v / static_cast<CT>(cnt);
+    const int k = __builtin_ctz(static_cast<unsigned>(cnt));
+    CT scale;  // 2^-k from its bit pattern
+    if constexpr (sizeof(CT) == 4) {
+        const uint32_t bits = static_cast<uint32_t>(127 - k) << 23;
+        __builtin_memcpy(&scale, &bits, 4);
+    } else {
+        const uint64_t bits = static_cast<uint64_t>(1023 - k) << 52;
+        __builtin_memcpy(&scale, &bits, 8);
+    }
+    return v * scale;
+}
+
+// =====================================================================================================
+// Pooled forward: the shift followed by the average pool the reference's modules attach when they emulate a
+// strided depthwise conv (modules/shifts.py:81-89, 150-153: avg_pool{N}d(kernel = stride = K, ceil_mode=True))
+// in one pass: the shift output (K0*K1*K2 times larger than the result) never goes to HBM.
+// One thread per pooled element; the window is summed in ATen's order (row-major, starting from 0) in the
+// compute type and divided by the number of window elements inside the shift output, so fp32 / fp64 results
+// are bit-identical to shift + avg_pool.  16-bit interpolated values are rounded to the storage type first,
+// like the unfused sequence does when it stores the shift output.
+// =====================================================================================================
+// SMALLK: every window size is 1 or 2 -- the window loops are unrolled with predicates, so the (up to 8)
+// gathers of one pooled element are independent loads in flight together.
+template <typename T, int ND, bool ACTIVE, bool SMALLK>
+__global__ __launch_bounds__(kThreads) void plane_pool_forward(const PlaneParams p) {
+    using S = typename T::S;
+    using CT = typename T::C;
+    extern __shared__ int maps[];
+    const int *m0 = maps, *m1 = maps + p.S[0] + 1, *m2 = m1 + p.S[1] + 1;
+
+    const WorkItem wi = decode_block(p);  // rows = pooled rows P0 * P1
+    int64_t sh[3] = {0, 0, 0};
+    CT dw[3] = {CT(0), CT(0), CT(0)};
+#pragma unroll
+    for (int d = 0; d < 3; ++d)
+        if (p.wcol[d] >= 0)
+            prep_shift_forward<CT>(load_weight<CT>(p.w, p.wkind, wi.c * p.nd + p.wcol[d]), ACTIVE, sh[d], dw[p.wcol[d]]);
+    build_maps(maps, p.S, sh, -1, p.pad);
+    __syncthreads();
+
+    const S *__restrict__ x = static_cast<const S *>(p.x);
+    S *__restrict__ out = static_cast<S *>(p.out);
+    const int S1 = p.S[1], S2 = p.S[2], P1 = p.P[1], P2 = p.P[2];
+    const int total = wi.nn * wi.nrows * P2;
+    for (int t = threadIdx.x; t < total; t += kThreads) {
+        const int sr = fdiv(t, p.d_p2);
+        const int p2 = t - sr * P2;
+        const int nl = fdiv(sr, p.d_rows);
+        const int r = wi.row0 + (sr - nl * wi.nrows);
+        const int p0 = fdiv(r, p.d_dim1);
+        const int p1 = r - p0 * P1;
+        const int64_t plane = static_cast<int64_t>(wi.n0 + nl) * p.C + wi.c;
+        const S *xp = x + plane * p.x_plane;
+        const int n0 = min(p.K[0], p.O[0] - p0 * p.K[0]), n1 = min(p.K[1], p.O[1] - p1 * p.K[1]);
+        const int n2 = min(p.K[2], p.O[2] - p2 * p.K[2]);
+        CT acc = CT(0);
+        constexpr int M0 = SMALLK ? (ND == 3 ? 2 : 1) : (1 << 30), M1 = SMALLK ? (ND >= 2 ? 2 : 1) : (1 << 30);
+        constexpr int M2 = SMALLK ? 2 : (1 << 30);
+#pragma unroll
+        for (int u0 = 0; u0 < M0; ++u0) {
+            if (u0 >= n0) break;
+            const int i0 = p0 * p.K[0] + u0 + p.L[0];
+#pragma unroll
+            for (int u1 = 0; u1 < M1; ++u1) {
+                if (u1 >= n1) break;
+                const int i1 = p1 * p.K[1] + u1 + p.L[1];
+#pragma unroll
+                for (int u2 = 0; u2 < M2; ++u2) {
+                    if (u2 >= n2) break;
+                    const int i2 = p2 * p.K[2] + u2 + p.L[2];
+                    if constexpr (ACTIVE) {
+                        CT v[1 << ND];
+#pragma unroll
+                        for (int q = 0; q < (1 << ND); ++q) {
+                            // bit r of q <-> +1 along real dim r = normalised dim r + 3 - ND
+                            const int b0 = ND == 3 ? (q & 1) : 0;
+                            const int b1 = ND == 3 ? ((q >> 1) & 1) : (ND == 2 ? (q & 1) : 0);
+                            const int b2 = (q >> (ND - 1)) & 1;
+                            const int ra = m0[i0 + b0], rb = m1[i1 + b1], rc = m2[i2 + b2];
+                            v[q] = (ra >= 0 && rb >= 0 && rc >= 0) ? widen<T>(xp[(ra * S1 + rb) * S2 + rc]) : CT(0);
+                        }
+                        acc = acc + widen<T>(narrow<T>(interp_nd<ND, CT>(v, dw)));
+                    } else {
+                        const int ra = m0[i0], rb = m1[i1], rc = m2[i2];
+                        acc = acc + ((ra >= 0 && rb >= 0 && rc >= 0) ? widen<T>(xp[(ra * S1 + rb) * S2 + rc]) : CT(0));
+                    }
+                }
+            }
+        }
+        out[plane * p.o_plane + static_cast<int64_t>(r) * P2 + p2] = narrow<T>(div_count<CT>(acc, n0 * n1 * n2));
+    }
+}
+
 // =====================================================================================================
 // Backward: grad_x (gather of grad_out, SSL; or interpolation of grad_out, active) and the weight
 // gradient partials.  Iteration space = input coordinates.
 // LDS maps: x maps (3 dims, S_d + 1 entries) followed by grad_out maps (3 dims, O_d + 1 entries).
 // =====================================================================================================
-template <typename T, int ND, bool ACTIVE>
+// POOL: grad_out is the gradient of the POOLED output [P0][P1][P2]; the gradient of the shift output it stands for
+// is g(o) = round_S(grad_pooled[o / K] / count(o / K)) (ATen's avg_pool backward), evaluated on the fly.
+template <typename T, int ND>
+__device__ __forceinline__ bool combo_rows(int k, const int *m0, const int *m1, int pa, int pb, int &ra, int &rb) {
+    if constexpr (ND == 1) {
+        ra = 0;
+        rb = 0;
+        return true;
+    } else if constexpr (ND == 2) {
+        ra = 0;
+        rb = m1[pb + (k & 1)];
+        return rb >= 0;
+    } else {
+        ra = m0[pa + (k & 1)];
+        rb = m1[pb + ((k >> 1) & 1)];
+        return ra >= 0 && rb >= 0;
+    }
+}
+struct PoolRow {  // one row of the unpooled gradient: where it lives in the pooled plane
+    int off;  // element offset of the pooled row
+    int cnt;  // window elements along the two outer dims
+};
+__device__ __forceinline__ PoolRow pool_row(const PlaneParams &p, int a, int b) {
+    const int pa = fdiv(a, p.d_k[0]), pb = fdiv(b, p.d_k[1]);
+    PoolRow r;
+    r.off = (pa * p.P[1] + pb) * p.P[2];
+    r.cnt = min(p.K[0], p.O[0] - pa * p.K[0]) * min(p.K[1], p.O[1] - pb * p.K[1]);
+    return r;
+}
+template <typename T>
+__device__ __forceinline__ typename T::C pool_grad(const typename T::S *gp, const PoolRow &r, int pc, int cc) {
+    using CT = typename T::C;
+    return widen<T>(narrow<T>(div_count<CT>(widen<T>(gp[r.off + pc]), r.cnt * cc)));
+}
+
+template <typename T, int ND, bool ACTIVE, bool POOL = false>
 __global__ __launch_bounds__(kThreads) void plane_backward(const PlaneParams p) {
     using S = typename T::S;
     using CT = typename T::C;
@@ -313,6 +449,7 @@ __global__ __launch_bounds__(kThreads) void plane_backward(const PlaneParams p) 
             const int oj = ji - p.L[2];  // grad_out inner coordinate of element 0 (may be outside)
             // per-chunk column state -----------------------------------------------------------------
             int xm[E + 1], gm[E + 1];
+            int pcd[POOL ? E : 1], ccd[POOL ? E : 1], pcm[POOL ? E + 1 : 1], ccm[POOL ? E + 1 : 1];  // pooled column / window width
             unsigned inmask = 0;
             bool xcontig = true, gcontig = true;
 #pragma unroll
@@ -326,6 +463,14 @@ __global__ __launch_bounds__(kThreads) void plane_backward(const PlaneParams p) 
                 const int oc = o < 0 ? 0 : (o > O2 ? O2 : o);
                 gm[e] = g2[oc];
                 if (e < E) gcontig = gcontig && (gm[e] == gm[0] + e);
+                if constexpr (POOL) {
+                    if (e < E) {
+                        pcd[e] = fdiv(in ? o : 0, p.d_k[2]);
+                        ccd[e] = min(p.K[2], O2 - pcd[e] * p.K[2]);
+                    }
+                    pcm[e] = fdiv(gm[e] < 0 ? 0 : gm[e], p.d_k[2]);
+                    ccm[e] = min(p.K[2], O2 - pcm[e] * p.K[2]);
+                }
             }
             const bool allin = inmask == ((1u << E) - 1u);
             xcontig = xcontig && (xm[0] >= 0);
@@ -351,7 +496,11 @@ __global__ __launch_bounds__(kThreads) void plane_backward(const PlaneParams p) 
                 const S *gp = go + plane * p.o_plane;
                 // incoming gradient at this position ----------------------------------------------------
                 CT gval[E];
-                {
+                if constexpr (POOL) {
+                    const PoolRow pr = pool_row(p, oa, ob);
+#pragma unroll
+                    for (int e = 0; e < E; ++e) gval[e] = ((inmask >> e) & 1u) ? pool_grad<T>(gp, pr, pcd[e], ccd[e]) : CT(0);
+                } else {
                     const S *grow = gp + static_cast<int64_t>(oa * O1 + ob) * O2;
                     if (allin) {
                         const Chunk<S, E> c = load_chunk<S, E>(grow + oj);
@@ -387,8 +536,16 @@ __global__ __launch_bounds__(kThreads) void plane_backward(const PlaneParams p) 
                     CT vals[NC][E + 1];
 #pragma unroll
                     for (int k = 0; k < NC; ++k) {
-                        const int off = combo_offset<ND>(k, g0, g1, oa, ob, O1 * O2, O2);
-                        load_row<T, E, E + 1>(gp + (off < 0 ? 0 : off), off >= 0, gcontig, gm, vals[k]);
+                        if constexpr (POOL) {
+                            int ra, rb;
+                            const bool ok = combo_rows<T, ND>(k, g0, g1, oa, ob, ra, rb);
+                            const PoolRow pr = pool_row(p, ok ? ra : 0, ok ? rb : 0);
+#pragma unroll
+                            for (int e = 0; e <= E; ++e) vals[k][e] = (ok && gm[e] >= 0) ? pool_grad<T>(gp, pr, pcm[e], ccm[e]) : CT(0);
+                        } else {
+                            const int off = combo_offset<ND>(k, g0, g1, oa, ob, O1 * O2, O2);
+                            load_row<T, E, E + 1>(gp + (off < 0 ? 0 : off), off >= 0, gcontig, gm, vals[k]);
+                        }
                     }
 #pragma unroll
                     for (int e = 0; e < E; ++e) {
@@ -403,6 +560,11 @@ __global__ __launch_bounds__(kThreads) void plane_backward(const PlaneParams p) 
                     if (ra < 0 || rb < 0) {
 #pragma unroll
                         for (int e = 0; e < E; ++e) res.e[e] = narrow<T>(CT(0));
+                    } else if constexpr (POOL) {
+                        const PoolRow pr = pool_row(p, ra, rb);
+#pragma unroll
+                        for (int e = 0; e < E; ++e)
+                            res.e[e] = narrow<T>((((inmask >> e) & 1u) && gm[e] >= 0) ? pool_grad<T>(gp, pr, pcm[e], ccm[e]) : CT(0));
                     } else {
                         const S *srow = gp + static_cast<int64_t>(ra * O1 + rb) * O2;
                         if (gcontig) {
@@ -999,6 +1161,13 @@ void fill_params(PlaneParams &p, const Geometry &g, const Plan &pl, int64_t dim1
     p.xcd_blocks = (g_tune[6] && pl.grid % 8 == 0) ? pl.grid / 8 : 0;
     p.d_cpr = make_fastdiv(static_cast<uint32_t>(pl.cpr));
     p.d_dim1 = make_fastdiv(static_cast<uint32_t>(dim1));
+    for (int d = 0; d < 3; ++d) {
+        p.K[d] = g.K[d] > 0 ? static_cast<int>(g.K[d]) : 1;
+        p.P[d] = g.K[d] > 0 ? static_cast<int>(g.P[d]) : p.O[d];
+        p.d_k[d] = make_fastdiv(static_cast<uint32_t>(p.K[d]));
+    }
+    p.d_p2 = make_fastdiv(static_cast<uint32_t>(p.P[2] > 0 ? p.P[2] : 1));
+    if (g.K[0] > 0) p.o_plane = g.P[0] * g.P[1] * g.P[2];  // pooled calls: the output / incoming gradient is the pooled tensor
 }
 
 bool common_eligible(const Geometry &g) {
@@ -1105,9 +1274,40 @@ void launch_backward_a(const PlaneParams &p_in, const Plan &pl, hipStream_t st) 
     }
 }
 
+template <typename T, bool ACTIVE>
+void launch_backward_pool(const PlaneParams &p, const Plan &pl, hipStream_t st) {
+    note_kernel("plane_backward_pool");
+    switch (p.nd) {
+    case 1: hipLaunchKernelGGL((plane_backward<T, 1, ACTIVE, true>), dim3(pl.grid), dim3(kThreads), pl.lds, st, p); break;
+    case 2: hipLaunchKernelGGL((plane_backward<T, 2, ACTIVE, true>), dim3(pl.grid), dim3(kThreads), pl.lds, st, p); break;
+    default: hipLaunchKernelGGL((plane_backward<T, 3, ACTIVE, true>), dim3(pl.grid), dim3(kThreads), pl.lds, st, p); break;
+    }
+}
+
 template <typename T>
-int launch_backward(const PlaneParams &p, const Plan &pl, bool active, void *gw, hipStream_t st) {
-    if (active) launch_backward_a<T, true>(p, pl, st);
+int launch_pool_forward(const PlaneParams &p, const Plan &pl, bool active, hipStream_t st) {
+    note_kernel("plane_pool_forward");
+    const bool smallk = p.K[0] <= 2 && p.K[1] <= 2 && p.K[2] <= 2;
+#define SHIFTND_POOL_FWD(NDV) \
+    if (active && smallk) hipLaunchKernelGGL((plane_pool_forward<T, NDV, true, true>), dim3(pl.grid), dim3(kThreads), pl.lds, st, p); \
+    else if (active) hipLaunchKernelGGL((plane_pool_forward<T, NDV, true, false>), dim3(pl.grid), dim3(kThreads), pl.lds, st, p); \
+    else if (smallk) hipLaunchKernelGGL((plane_pool_forward<T, NDV, false, true>), dim3(pl.grid), dim3(kThreads), pl.lds, st, p); \
+    else hipLaunchKernelGGL((plane_pool_forward<T, NDV, false, false>), dim3(pl.grid), dim3(kThreads), pl.lds, st, p);
+    switch (p.nd) {
+    case 1: SHIFTND_POOL_FWD(1) break;
+    case 2: SHIFTND_POOL_FWD(2) break;
+    default: SHIFTND_POOL_FWD(3) break;
+    }
+#undef SHIFTND_POOL_FWD
+    return SHIFTND_OK;
+}
+
+template <typename T>
+int launch_backward(const PlaneParams &p, const Plan &pl, bool active, void *gw, hipStream_t st, bool pool = false) {
+    if (pool) {
+        if (active) launch_backward_pool<T, true>(p, pl, st);
+        else launch_backward_pool<T, false>(p, pl, st);
+    } else if (active) launch_backward_a<T, true>(p, pl, st);
     else launch_backward_a<T, false>(p, pl, st);
     const int cn = p.C * p.nd;
     hipLaunchKernelGGL((reduce_weight_grads<T>), dim3(cn), dim3(64), 0, st, p.partials, pl.groups * pl.bands, p.C, p.nd,
@@ -1221,6 +1421,56 @@ bool plane_backward_eligible(const Geometry &g, int dtype, const void *go, const
 size_t plane_backward_workspace(const Geometry &g, int dtype) {
     const Plan pl = backward_plan(g, dtype_size(dtype));
     return static_cast<size_t>(pl.groups) * pl.bands * static_cast<size_t>(g.C) * 3 * sizeof(double);
+}
+
+// ---- fused shift + average pool (contiguous tensors; g.K / g.P set) -----------------------------------------
+bool plane_pool_forward_eligible(const Geometry &g, int dtype) {
+    if (dtype > SHIFTND_BF16 || !common_eligible(g)) return false;
+    return g.S[0] + g.S[1] + g.S[2] + 3 <= kMaxMapEntries;
+}
+
+int plane_pool_forward(const Geometry &g, int dtype, const void *x, const void *w, void *out, hipStream_t st) {
+    const int es = dtype_size(dtype);
+    const int entries = static_cast<int>(g.S[0] + g.S[1] + g.S[2] + 3);
+    PlaneParams p{};
+    p.x = x;
+    p.out = out;
+    p.w = w;
+    p.wkind = dtype;
+    const Plan pl = make_plan(g, g.P[0] * g.P[1], g.P[2], es, es, entries);
+    fill_params(p, g, pl, g.P[1]);
+    switch (dtype) {
+    case SHIFTND_F32: return launch_pool_forward<f32_t>(p, pl, g.active != 0, st);
+    case SHIFTND_F64: return launch_pool_forward<f64_t>(p, pl, g.active != 0, st);
+    case SHIFTND_F16: return launch_pool_forward<f16_t>(p, pl, g.active != 0, st);
+    default: return launch_pool_forward<bf16_t>(p, pl, g.active != 0, st);
+    }
+}
+
+bool plane_pool_backward_eligible(const Geometry &g, int dtype, const void *gx) {
+    if (dtype > SHIFTND_BF16 || !common_eligible(g)) return false;
+    if (g.S[0] + g.S[1] + g.S[2] + g.O[0] + g.O[1] + g.O[2] + 6 > kMaxMapEntries) return false;
+    const int es = dtype_size(dtype);
+    return (g.S[2] * es) % 16 == 0 && reinterpret_cast<uintptr_t>(gx) % 16 == 0;
+}
+
+int plane_pool_backward(const Geometry &g, int dtype, const void *go, const void *x, const void *w, void *gx, void *gw,
+                        void *workspace, hipStream_t st) {
+    const Plan pl = backward_plan(g, dtype_size(dtype));
+    PlaneParams p{};
+    p.x = x;
+    p.go = go;
+    p.out = gx;
+    p.w = w;
+    p.wkind = dtype;
+    p.partials = static_cast<double *>(workspace);
+    fill_params(p, g, pl, g.S[1]);
+    switch (dtype) {
+    case SHIFTND_F32: return launch_backward<f32_t>(p, pl, g.active != 0, gw, st, true);
+    case SHIFTND_F64: return launch_backward<f64_t>(p, pl, g.active != 0, gw, st, true);
+    case SHIFTND_F16: return launch_backward<f16_t>(p, pl, g.active != 0, gw, st, true);
+    default: return launch_backward<bf16_t>(p, pl, g.active != 0, gw, st, true);
+    }
 }
 
 int plane_backward(const Geometry &g, int dtype, const void *go, const void *x, const void *w, void *gx, void *gw,

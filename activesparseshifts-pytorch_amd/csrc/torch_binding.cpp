@@ -10,6 +10,10 @@
 //       pointers/strides out of at::Tensor and call the C ABI of libshiftnd_hip.so
 //       (include/shiftnd_hip.h).  No compute happens here and there is no CPU fallback: a HIP
 //       tensor either runs the HIP kernels or raises.
+//   * New: shift{N}d_pool / _shift{N}d_pool_forward / _backward -- the shift followed by
+//       the average pool the reference's modules attach (modules/shifts.py:81-89, 150-153) as ONE op.  On HIP
+//       tensors it runs the fused kernels; everywhere else (CPU tensors, layouts the fused kernels do not
+//       serve) it is literally the reference's two-step sequence.
 // The CPU / QuantizedCPU keys (the reference's CPU backend) live in torch_cpu_backend.cpp.
 #include <ATen/ATen.h>
 #include <ATen/core/dispatch/Dispatcher.h>
@@ -232,6 +236,190 @@ std::tuple<Tensor, Tensor> shift_backward_hip(const Tensor &grad, const Tensor &
     return std::make_tuple(grad_input, grad_weights);
 }
 
+// ---- shift + average pool as one op ------------------------------------------------------------------------
+using pool_forward_sig = Tensor(const Tensor &, const Tensor &, const Tensor &, at::IntArrayRef, at::IntArrayRef, int64_t, bool);
+using pool_backward_sig = std::tuple<Tensor, Tensor>(const Tensor &, const Tensor &, const Tensor &, const Tensor &,
+                                                     at::IntArrayRef, int64_t, bool);
+template <int ND> Tensor call_pool_forward(const Tensor &input, const Tensor &weights, const Tensor &borders,
+                                           at::IntArrayRef new_size, at::IntArrayRef pool, int64_t padding_mode,
+                                           bool active_flag) {
+    static auto op = c10::Dispatcher::singleton()
+                         .findSchemaOrThrow(("torchshifts::_shift" + std::to_string(ND) + "d_pool_forward").c_str(), "")
+                         .typed<pool_forward_sig>();
+    return op.call(input, weights, borders, new_size, pool, padding_mode, active_flag);
+}
+template <int ND>
+std::tuple<Tensor, Tensor> call_pool_backward(const Tensor &grad, const Tensor &weights, const Tensor &input,
+                                              const Tensor &borders, at::IntArrayRef pool, int64_t padding_mode,
+                                              bool active_flag) {
+    static auto op = c10::Dispatcher::singleton()
+                         .findSchemaOrThrow(("torchshifts::_shift" + std::to_string(ND) + "d_pool_backward").c_str(), "")
+                         .typed<pool_backward_sig>();
+    return op.call(grad, weights, input, borders, pool, padding_mode, active_flag);
+}
+
+template <int ND> void check_pool(at::IntArrayRef pool) {
+    TORCH_CHECK(static_cast<int>(pool.size()) == ND, "shift", ND, "d_pool: pool must hold ", ND, " window sizes");
+    for (auto k : pool) TORCH_CHECK(k >= 1, "shift", ND, "d_pool: window sizes must be >= 1");
+}
+
+// the reference's sequence: _reduction_fn(shift(x)) with avg_pool{N}d(kernel = stride = pool, ceil_mode=True)
+// (modules/shifts.py:81-89, 150-153)
+template <int ND> Tensor pool_forward_composed(const Tensor &input, const Tensor &weights, const Tensor &borders,
+                                               at::IntArrayRef new_size, at::IntArrayRef pool, int64_t padding_mode,
+                                               bool active_flag) {
+    check_pool<ND>(pool);
+    Tensor y = call_forward<ND>(input, weights, borders, new_size, padding_mode, active_flag);
+    if (!y.defined()) return y;
+    if constexpr (ND == 1) return at::avg_pool1d(y, pool, pool, {0}, /*ceil_mode=*/true, /*count_include_pad=*/true);
+    else if constexpr (ND == 2) return at::avg_pool2d(y, pool, pool, {0, 0}, true, true, c10::nullopt);
+    else return at::avg_pool3d(y, pool, pool, {0, 0, 0}, true, true, c10::nullopt);
+}
+
+template <int ND>
+std::tuple<Tensor, Tensor> pool_backward_composed(const Tensor &grad, const Tensor &weights, const Tensor &input,
+                                                  const Tensor &borders, at::IntArrayRef pool, int64_t padding_mode,
+                                                  bool active_flag) {
+    check_pool<ND>(pool);
+    int32_t b[6];
+    read_borders(borders, b);
+    std::vector<int64_t> ysize = {input.size(0), input.size(1)};
+    for (int r = 0; r < ND; ++r) ysize.push_back(b[2 * r + 1] - b[2 * r]);
+    Tensor y_like = at::empty(ysize, grad.options());  // avg_pool's backward only looks at its shape
+    Tensor g;
+    if constexpr (ND == 1) {
+        g = at::avg_pool2d_backward(grad.unsqueeze(2), y_like.unsqueeze(2), {1, pool[0]}, {1, pool[0]}, {0, 0}, true, true,
+                                    c10::nullopt).squeeze(2);
+    } else if constexpr (ND == 2) {
+        g = at::avg_pool2d_backward(grad, y_like, pool, pool, {0, 0}, true, true, c10::nullopt);
+    } else {
+        g = at::avg_pool3d_backward(grad, y_like, pool, pool, {0, 0, 0}, true, true, c10::nullopt);
+    }
+    return call_backward<ND>(g, weights, input, borders, padding_mode, active_flag);
+}
+
+template <int ND> Tensor pool_forward_hip(const Tensor &input, const Tensor &weights, const Tensor &borders,
+                                          at::IntArrayRef new_size, at::IntArrayRef pool, int64_t padding_mode,
+                                          bool active_flag) {
+    check_pool<ND>(pool);
+    TORCH_CHECK(input.is_cuda(), "input must be a CUDA tensor");
+    TORCH_CHECK(weights.is_cuda(), "weights must be a CUDA tensor");
+    check_same("shiftnd_pool_forward_cuda", input, "input", weights, "weights");
+    TORCH_CHECK(input.dim() == ND + 2, "shift", ND, "d_pool: expected a ", ND + 2, "-D input");
+    TORCH_CHECK(weights.dim() == 2 && weights.size(0) == input.size(1) && weights.size(1) == ND,
+                "shift", ND, "d_pool: weights must have shape [C, ", ND, "]");
+    if (padding_mode < 0 || padding_mode > 4) return Tensor();
+    if (!input.is_contiguous()) return pool_forward_composed<ND>(input, weights, borders, new_size, pool, padding_mode, active_flag);
+    c10::DeviceGuard device_guard(input.device());
+    const int dtype = to_shiftnd_dtype(input.scalar_type(), "shiftnd_pool_forward_cuda");
+    int32_t b[6], k[3] = {1, 1, 1};
+    read_borders(borders, b);
+    for (int r = 0; r < ND; ++r) k[r] = static_cast<int32_t>(pool[r]);
+    shiftnd_problem p;
+    fill_problem(p, ND, input, b, padding_mode, active_flag, dtype);
+    int64_t ps[3];
+    int rc = shiftnd_pooled_sizes(&p, k, ps);
+    TORCH_CHECK(rc == SHIFTND_OK, "shiftnd_pooled_sizes: ", shiftnd_status_string(rc));
+    std::vector<int64_t> osize = {input.size(0), input.size(1)};
+    for (int r = 0; r < ND; ++r) osize.push_back(ps[r]);
+    Tensor w = weights.contiguous();
+    Tensor output = at::empty(osize, input.options(), at::MemoryFormat::Contiguous);
+    rc = shiftnd_forward_pooled(&p, k, input.data_ptr(), w.data_ptr(), output.data_ptr(), current_stream(input));
+    if (rc == SHIFTND_ERR_NOT_FUSED)
+        return pool_forward_composed<ND>(input, weights, borders, new_size, pool, padding_mode, active_flag);
+    TORCH_CHECK(rc == SHIFTND_OK, "shiftnd_forward_pooled (HIP): ", shiftnd_status_string(rc));
+    return output;
+}
+
+template <int ND>
+std::tuple<Tensor, Tensor> pool_backward_hip(const Tensor &grad, const Tensor &weights, const Tensor &input,
+                                             const Tensor &borders, at::IntArrayRef pool, int64_t padding_mode,
+                                             bool active_flag) {
+    check_pool<ND>(pool);
+    TORCH_CHECK(grad.is_cuda(), "grad must be a CUDA tensor");
+    TORCH_CHECK(input.is_cuda(), "input must be a CUDA tensor");
+    TORCH_CHECK(weights.is_cuda(), "weights must be a CUDA tensor");
+    check_same("shiftnd_pool_backward_cuda", grad, "grad", input, "input");
+    check_same("shiftnd_pool_backward_cuda", grad, "grad", weights, "weights");
+    TORCH_CHECK(input.dim() == ND + 2 && grad.dim() == ND + 2, "shift", ND, "d_pool backward: expected ", ND + 2, "-D tensors");
+    if (padding_mode < 0 || padding_mode > 4) return std::make_tuple(Tensor(), Tensor());
+    if (!input.is_contiguous())
+        return pool_backward_composed<ND>(grad, weights, input, borders, pool, padding_mode, active_flag);
+    c10::DeviceGuard device_guard(grad.device());
+    const int dtype = to_shiftnd_dtype(grad.scalar_type(), "shiftnd_pool_backward_cuda");
+    int32_t b[6], k[3] = {1, 1, 1};
+    read_borders(borders, b);
+    for (int r = 0; r < ND; ++r) k[r] = static_cast<int32_t>(pool[r]);
+    shiftnd_problem p;
+    fill_problem(p, ND, input, b, padding_mode, active_flag, dtype);
+    int64_t ps[3];
+    int rc = shiftnd_pooled_sizes(&p, k, ps);
+    TORCH_CHECK(rc == SHIFTND_OK, "shiftnd_pooled_sizes: ", shiftnd_status_string(rc));
+    for (int r = 0; r < ND; ++r)
+        TORCH_CHECK(grad.size(2 + r) == ps[r], "shift", ND, "d_pool backward: grad does not match the pooled size");
+    Tensor g = grad.contiguous();
+    Tensor w = weights.contiguous();
+    Tensor grad_input = at::empty_like(input, at::MemoryFormat::Contiguous);
+    Tensor grad_weights = at::empty_like(w, at::MemoryFormat::Contiguous);
+    const size_t ws_bytes = shiftnd_backward_workspace_bytes(&p);
+    Tensor workspace = at::empty({static_cast<int64_t>(ws_bytes)}, input.options().dtype(at::kByte));
+    rc = shiftnd_backward_pooled(&p, k, g.data_ptr(), input.data_ptr(), w.data_ptr(), grad_input.data_ptr(),
+                                 grad_weights.data_ptr(), workspace.data_ptr(), ws_bytes, current_stream(grad));
+    if (rc == SHIFTND_ERR_NOT_FUSED)
+        return pool_backward_composed<ND>(grad, weights, input, borders, pool, padding_mode, active_flag);
+    TORCH_CHECK(rc == SHIFTND_OK, "shiftnd_backward_pooled (HIP): ", shiftnd_status_string(rc));
+    return std::make_tuple(grad_input, grad_weights);
+}
+
+template <int ND> struct ShiftPoolFunction : public torch::autograd::Function<ShiftPoolFunction<ND>> {
+    static variable_list forward(AutogradContext *ctx, const Tensor &input, const Tensor &weight, const Tensor &borders,
+                                 at::IntArrayRef new_size, at::IntArrayRef pool, int64_t padding_mode, bool active_flag) {
+        at::AutoDispatchBelowADInplaceOrView guard;
+        auto output = call_pool_forward<ND>(input, weight, borders, new_size, pool, padding_mode, active_flag);
+        ctx->saved_data["padding_mode"] = padding_mode;
+        ctx->saved_data["active_flag"] = active_flag;
+        ctx->saved_data["pool"] = pool.vec();
+        ctx->save_for_backward({input, weight, borders});
+        return {output};
+    }
+    static variable_list backward(AutogradContext *ctx, const variable_list &grad_output) {
+        auto saved = ctx->get_saved_variables();
+        const auto padding_mode = ctx->saved_data["padding_mode"].toInt();
+        const auto active_flag = ctx->saved_data["active_flag"].toBool();
+        const auto pool = ctx->saved_data["pool"].toIntVector();
+        auto result = call_pool_backward<ND>(grad_output[0], saved[1], saved[0], saved[2], pool, padding_mode, active_flag);
+        return {std::get<0>(result), std::get<1>(result), Tensor(), Tensor(), Tensor(), Tensor(), Tensor()};
+    }
+};
+template <int ND> struct ShiftPoolBackwardFunction : public torch::autograd::Function<ShiftPoolBackwardFunction<ND>> {
+    static variable_list forward(AutogradContext *ctx, const Tensor &grad, const Tensor &weights, const Tensor &input,
+                                 const Tensor &borders, at::IntArrayRef pool, int64_t padding_mode, bool active_flag) {
+        at::AutoDispatchBelowADInplaceOrView guard;
+        auto result = call_pool_backward<ND>(grad, weights, input, borders, pool, padding_mode, active_flag);
+        return {std::get<0>(result), std::get<1>(result)};
+    }
+    static variable_list backward(AutogradContext *, const variable_list &) {
+        TORCH_CHECK(0, "double backwards on shift", ND, "d not supported");
+    }
+};
+template <int ND> Tensor pool_autograd(const Tensor &input, const Tensor &weights, const Tensor &borders,
+                                       at::IntArrayRef new_size, at::IntArrayRef pool, int64_t padding_mode,
+                                       bool active_flag) {
+    return ShiftPoolFunction<ND>::apply(input, weights, borders, new_size, pool, padding_mode, active_flag)[0];
+}
+template <int ND>
+std::tuple<Tensor, Tensor> pool_autograd_backward(const Tensor &grad, const Tensor &weights, const Tensor &input,
+                                                  const Tensor &borders, at::IntArrayRef pool, int64_t padding_mode,
+                                                  bool active_flag) {
+    auto result = ShiftPoolBackwardFunction<ND>::apply(grad, weights, input, borders, pool, padding_mode, active_flag);
+    return std::make_tuple(result[0], result[1]);
+}
+template <int ND> Tensor shift_pool_public(const Tensor &input, const Tensor &weights, const Tensor &borders,
+                                           at::IntArrayRef pool, int64_t padding_mode, bool active_flag) {
+    auto bands = check_borders(input, borders, ND);
+    return call_pool_forward<ND>(input, weights, std::get<0>(bands), std::get<1>(bands), pool, padding_mode, active_flag);
+}
+
 // ---- quantized HIP forward (QuantizedCUDA key; new -- the reference only has QuantizedCPU) --------------
 int quant_dtype(at::ScalarType t, const char *what) {
     switch (t) {
@@ -296,6 +484,16 @@ TORCH_LIBRARY(torchshifts, m) {
     m.def("torchshifts::_shift2d_backward(Tensor grad, Tensor weights, Tensor input, Tensor borders, int padding_mode, bool active_flag) -> (Tensor, Tensor)");
     m.def("torchshifts::_shift3d_forward(Tensor input, Tensor weights, Tensor borders, int[] new_size, int padding_mode, bool active_flag) -> Tensor");
     m.def("torchshifts::_shift3d_backward(Tensor grad, Tensor weights, Tensor input, Tensor borders, int padding_mode, bool active_flag) -> (Tensor, Tensor)");
+    // shift + avg_pool(kernel = stride = pool, ceil_mode=True) as one op (not in the reference)
+    m.def("torchshifts::shift1d_pool(Tensor input, Tensor weights, Tensor borders, int[] pool, int padding_mode, bool active_flag) -> Tensor", &shift_pool_public<1>);
+    m.def("torchshifts::shift2d_pool(Tensor input, Tensor weights, Tensor borders, int[] pool, int padding_mode, bool active_flag) -> Tensor", &shift_pool_public<2>);
+    m.def("torchshifts::shift3d_pool(Tensor input, Tensor weights, Tensor borders, int[] pool, int padding_mode, bool active_flag) -> Tensor", &shift_pool_public<3>);
+    m.def("torchshifts::_shift1d_pool_forward(Tensor input, Tensor weights, Tensor borders, int[] new_size, int[] pool, int padding_mode, bool active_flag) -> Tensor");
+    m.def("torchshifts::_shift1d_pool_backward(Tensor grad, Tensor weights, Tensor input, Tensor borders, int[] pool, int padding_mode, bool active_flag) -> (Tensor, Tensor)");
+    m.def("torchshifts::_shift2d_pool_forward(Tensor input, Tensor weights, Tensor borders, int[] new_size, int[] pool, int padding_mode, bool active_flag) -> Tensor");
+    m.def("torchshifts::_shift2d_pool_backward(Tensor grad, Tensor weights, Tensor input, Tensor borders, int[] pool, int padding_mode, bool active_flag) -> (Tensor, Tensor)");
+    m.def("torchshifts::_shift3d_pool_forward(Tensor input, Tensor weights, Tensor borders, int[] new_size, int[] pool, int padding_mode, bool active_flag) -> Tensor");
+    m.def("torchshifts::_shift3d_pool_backward(Tensor grad, Tensor weights, Tensor input, Tensor borders, int[] pool, int padding_mode, bool active_flag) -> (Tensor, Tensor)");
 }
 
 TORCH_LIBRARY_IMPL(torchshifts, Autograd, m) {
@@ -305,6 +503,22 @@ TORCH_LIBRARY_IMPL(torchshifts, Autograd, m) {
     m.impl("_shift2d_backward", TORCH_FN(shift_autograd_backward<2>));
     m.impl("_shift3d_forward", TORCH_FN(shift_autograd<3>));
     m.impl("_shift3d_backward", TORCH_FN(shift_autograd_backward<3>));
+    m.impl("_shift1d_pool_forward", TORCH_FN(pool_autograd<1>));
+    m.impl("_shift1d_pool_backward", TORCH_FN(pool_autograd_backward<1>));
+    m.impl("_shift2d_pool_forward", TORCH_FN(pool_autograd<2>));
+    m.impl("_shift2d_pool_backward", TORCH_FN(pool_autograd_backward<2>));
+    m.impl("_shift3d_pool_forward", TORCH_FN(pool_autograd<3>));
+    m.impl("_shift3d_pool_backward", TORCH_FN(pool_autograd_backward<3>));
+}
+
+// CPU tensors: the reference's two-step sequence (shift op on the CPU key, then ATen's pool)
+TORCH_LIBRARY_IMPL(torchshifts, CPU, m) {
+    m.impl("_shift1d_pool_forward", TORCH_FN(pool_forward_composed<1>));
+    m.impl("_shift1d_pool_backward", TORCH_FN(pool_backward_composed<1>));
+    m.impl("_shift2d_pool_forward", TORCH_FN(pool_forward_composed<2>));
+    m.impl("_shift2d_pool_backward", TORCH_FN(pool_backward_composed<2>));
+    m.impl("_shift3d_pool_forward", TORCH_FN(pool_forward_composed<3>));
+    m.impl("_shift3d_pool_backward", TORCH_FN(pool_backward_composed<3>));
 }
 
 TORCH_LIBRARY_IMPL(torchshifts, CUDA, m) {
@@ -314,6 +528,12 @@ TORCH_LIBRARY_IMPL(torchshifts, CUDA, m) {
     m.impl("_shift2d_backward", TORCH_FN(shift_backward_hip<2>));
     m.impl("_shift3d_forward", TORCH_FN(shift_forward_hip<3>));
     m.impl("_shift3d_backward", TORCH_FN(shift_backward_hip<3>));
+    m.impl("_shift1d_pool_forward", TORCH_FN(pool_forward_hip<1>));
+    m.impl("_shift1d_pool_backward", TORCH_FN(pool_backward_hip<1>));
+    m.impl("_shift2d_pool_forward", TORCH_FN(pool_forward_hip<2>));
+    m.impl("_shift2d_pool_backward", TORCH_FN(pool_backward_hip<2>));
+    m.impl("_shift3d_pool_forward", TORCH_FN(pool_forward_hip<3>));
+    m.impl("_shift3d_pool_backward", TORCH_FN(pool_backward_hip<3>));
 }
 
 TORCH_LIBRARY_IMPL(torchshifts, QuantizedCUDA, m) {

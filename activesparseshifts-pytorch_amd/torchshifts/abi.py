@@ -20,7 +20,7 @@ DTYPES = {torch.float32: F32, torch.float64: F64, torch.float16: F16, torch.bflo
 EXPORTS = ["shiftnd_abi_version", "shiftnd_status_string", "shiftnd_last_path", "shiftnd_set_path_policy",
            "shiftnd_set_tuning", "shiftnd_debug_map", "shiftnd_last_kernel",
            "shiftnd_check_borders", "shiftnd_forward", "shiftnd_backward_workspace_bytes", "shiftnd_backward",
-           "shiftnd_forward_quantized"]
+           "shiftnd_forward_quantized", "shiftnd_pooled_sizes", "shiftnd_forward_pooled", "shiftnd_backward_pooled"]
 
 
 class Problem(ctypes.Structure):
@@ -59,6 +59,13 @@ def lib():
         L.shiftnd_forward_quantized.restype = ctypes.c_int
         L.shiftnd_forward_quantized.argtypes = [ctypes.POINTER(Problem), vp, i64p, vp, ctypes.c_int32, ctypes.c_int64,
                                                 ctypes.c_int64, vp, i64p, vp]
+        i32p = ctypes.POINTER(ctypes.c_int32)
+        L.shiftnd_pooled_sizes.restype = ctypes.c_int
+        L.shiftnd_pooled_sizes.argtypes = [ctypes.POINTER(Problem), i32p, i64p]
+        L.shiftnd_forward_pooled.restype = ctypes.c_int
+        L.shiftnd_forward_pooled.argtypes = [ctypes.POINTER(Problem), i32p, vp, vp, vp, vp]
+        L.shiftnd_backward_pooled.restype = ctypes.c_int
+        L.shiftnd_backward_pooled.argtypes = [ctypes.POINTER(Problem), i32p, vp, vp, vp, vp, vp, vp, ctypes.c_size_t, vp]
         _lib = L
     return _lib
 
@@ -158,6 +165,47 @@ def forward_quantized(xq, wq, w_zero_point, x_zero_point, pad, borders=None, out
                                           int(w_zero_point), int(x_zero_point), out.data_ptr(), strides5(out), _stream()),
           "shiftnd_forward_quantized")
     return out
+
+
+def _pool_arg(pool, nd):
+    pool = [int(pool)] * nd if isinstance(pool, int) else [int(k) for k in pool]
+    assert len(pool) == nd
+    return (ctypes.c_int32 * nd)(*pool)
+
+
+def pooled_shape(x, pool, borders=None):
+    p = problem(x, 0, False, borders)
+    sp = (ctypes.c_int64 * 3)()
+    check(lib().shiftnd_pooled_sizes(ctypes.byref(p), _pool_arg(pool, p.ndim), sp), "shiftnd_pooled_sizes")
+    return list(x.shape[:2]) + list(sp)[:p.ndim]
+
+
+def forward_pooled(x, w, pad, active, pool, borders=None, out=None):
+    """Fused shift + avg_pool(kernel = stride = pool, ceil_mode=True); x, w contiguous device tensors."""
+    assert x.is_contiguous()
+    p = problem(x, pad, active, borders)
+    if out is None:
+        out = torch.empty(pooled_shape(x, pool, borders), dtype=x.dtype, device=x.device)
+    w = w.contiguous()
+    check(lib().shiftnd_forward_pooled(ctypes.byref(p), _pool_arg(pool, p.ndim), x.data_ptr(), w.data_ptr(),
+                                       out.data_ptr(), _stream()), "shiftnd_forward_pooled")
+    return out
+
+
+def backward_pooled(grad_pooled, w, x, pad, active, pool, borders=None, grad_x=None, grad_w=None, workspace=None):
+    assert x.is_contiguous() and grad_pooled.is_contiguous()
+    p = problem(x, pad, active, borders)
+    w = w.contiguous()
+    if grad_x is None:
+        grad_x = torch.empty_like(x)
+    if grad_w is None:
+        grad_w = torch.empty_like(w)
+    if workspace is None:
+        workspace = backward_workspace(x, pad, active, borders)
+    check(lib().shiftnd_backward_pooled(ctypes.byref(p), _pool_arg(pool, p.ndim), grad_pooled.data_ptr(), x.data_ptr(),
+                                        w.data_ptr(), grad_x.data_ptr(), grad_w.data_ptr(), workspace.data_ptr(),
+                                        workspace.numel(), _stream()), "shiftnd_backward_pooled")
+    return grad_x, grad_w
 
 
 def last_path():

@@ -15,8 +15,8 @@ _PADDING_DOC = "0 - zeros, 1 - border, 2 - periodic, 3 - reflect, 4 - symmetric"
 
 
 def _shift_func(dim: int, input: Tensor, weights: Tensor, padding_mode: int, active_flag: bool,
-                borders: Optional[Tensor]) -> Tensor:
-    name = f"shift{dim}d_func()"
+                borders: Optional[Tensor], pool=None) -> Tensor:
+    name = f"shift{dim}d_func()" if pool is None else f"shift{dim}d_pool_func()"
     _assert_has_ops()
     assert padding_mode in [0, 1, 2, 3, 4], f"{name} expected padding_mode can be {_PADDING_DOC}"
     assert len(input.shape) == dim + 2, f"{name}: expected {dim + 2}D tensor as input, but it is shape is {input.shape}"
@@ -33,6 +33,12 @@ def _shift_func(dim: int, input: Tensor, weights: Tensor, padding_mode: int, act
             f"borders must have shape [{dim}, 2]"
     else:
         borders = torch.Tensor()
+    if pool is not None:
+        if isinstance(pool, torch.Tensor):
+            pool = pool.reshape(-1).tolist()
+        pool = [int(pool)] * dim if isinstance(pool, (int, float)) else [int(k) for k in pool]
+        assert len(pool) == dim and all(k >= 1 for k in pool), f"{name}: pool must be {dim} window sizes >= 1"
+        return getattr(torch.ops.torchshifts, f"shift{dim}d_pool")(input, weights, borders, pool, padding_mode, active_flag)
     return getattr(torch.ops.torchshifts, f"shift{dim}d")(input, weights, borders, padding_mode, active_flag)
 
 
@@ -52,3 +58,23 @@ def shift3d_func(input: Tensor, weights: Tensor, padding_mode: int, active_flag:
                  borders: Optional[Tensor] = None) -> Tensor:
     """Shift a [N, C, H, W, D] tensor; weights [C, 3] (H, W, D); borders [3, 2]."""
     return _shift_func(3, input, weights, padding_mode, active_flag, borders)
+
+
+# ---- shift + average pool as one op (not in the reference; SURVEY.md section 8f, N1) -----------------------
+# `pool` is the window (= stride) per spatial dim, an int or a list.  The result equals
+# avg_pool{N}d(shift{N}d_func(...), kernel_size=pool, stride=pool, ceil_mode=True), the tail the reference's
+# modules attach when they emulate a strided depthwise conv (modules/shifts.py:81-89, 150-153).  On HIP tensors
+# the full-size shift output is never written to memory; on CPU tensors the op is literally that sequence.
+def shift1d_pool_func(input: Tensor, weights: Tensor, padding_mode: int, active_flag: bool,
+                      borders: Optional[Tensor] = None, pool=2) -> Tensor:
+    return _shift_func(1, input, weights, padding_mode, active_flag, borders, pool)
+
+
+def shift2d_pool_func(input: Tensor, weights: Tensor, padding_mode: int, active_flag: bool,
+                      borders: Optional[Tensor] = None, pool=2) -> Tensor:
+    return _shift_func(2, input, weights, padding_mode, active_flag, borders, pool)
+
+
+def shift3d_pool_func(input: Tensor, weights: Tensor, padding_mode: int, active_flag: bool,
+                      borders: Optional[Tensor] = None, pool=2) -> Tensor:
+    return _shift_func(3, input, weights, padding_mode, active_flag, borders, pool)

@@ -11,11 +11,13 @@ from functools import partial
 import torch
 from torch import nn
 
-from torchshifts.functional import shift1d_func, shift2d_func, shift3d_func
+from torchshifts.functional import (shift1d_func, shift1d_pool_func, shift2d_func, shift2d_pool_func, shift3d_func,
+                                    shift3d_pool_func)
 
 paddings_dict = {'zeros': 0, 'border': 1, 'periodic': 2, 'reflect': 3, 'symmetric': 4}
 
 _SHIFT_FUNCS = {1: shift1d_func, 2: shift2d_func, 3: shift3d_func}
+_SHIFT_POOL_FUNCS = {1: shift1d_pool_func, 2: shift2d_pool_func, 3: shift3d_pool_func}
 _AVG_POOLS = {1: torch.nn.functional.avg_pool1d, 2: torch.nn.functional.avg_pool2d, 3: torch.nn.functional.avg_pool3d}
 
 
@@ -113,6 +115,7 @@ class _Shiftnd(nn.Module):
         self._shift_func = self._init_shift_fn()
         self.cut_borders = None
         self._reduction_fn = self._identity
+        self._pool_size = None  # window (= stride) of the average pool that follows the shift, when there is one
         # QUIRK (reference modules/shifts.py:117-118): rule 2 is selected with `==` instead of `=`,
         # so both rule numbers initialise with rule 1.  Kept: initial weights match the reference.
         self._w_init_func = self._init_thumb_rule_1
@@ -126,6 +129,7 @@ class _Shiftnd(nn.Module):
             # QUIRK (:128-129): the conv's padding_mode is compared, not assigned -> self.padding is unchanged.
             if not (self._w_post_init_scale == 1).all():
                 self._reduction_fn = self._pooling(self._w_post_init_scale, self.dim)
+                self._pool_size = [int(k) for k in self._w_post_init_scale.reshape(-1).tolist()]
         self._init_weights()
 
     def _init_shift_fn(self):
@@ -148,6 +152,11 @@ class _Shiftnd(nn.Module):
     def forward(self, input):
         """Returns (output, loss); loss is None when sparsity_term == 0."""
         loss = self._compute_weight_loss() if bool(self.sparsity_term) else None
+        if self._pool_size is not None and self.dim in _SHIFT_POOL_FUNCS:
+            # reference: self._reduction_fn(shift(x)) (modules/shifts.py:150-153).  Same values from one op: on HIP
+            # tensors the shift output is pooled on the fly instead of being written and re-read
+            return _SHIFT_POOL_FUNCS[self.dim](input, self.weight, self.padding, self._active_flag, self.cut_borders,
+                                               self._pool_size), loss
         out = self._shift_func(input, self.weight, self.padding, self._active_flag, self.cut_borders)
         return self._reduction_fn(out), loss
 

@@ -14,6 +14,9 @@
  *   shiftnd_forward_quantized  <- qshiftnd<nD,pad>                 quantized/shifts_quantized.cpp:107-130
  *                                 (the reference has no GPU quantized path; this is new)
  *   shiftnd_check_borders      <- check_borders                    shifts.cpp:93-135 (host only)
+ *   shiftnd_forward_pooled /   <- the module-level sequence `_reduction_fn(shift(x))` of the reference's
+ *   shiftnd_backward_pooled       depthwise-conv emulation (torchshifts/modules/shifts.py:81-89, 150-153:
+ *                                 shift, then avg_pool{N}d(kernel = stride, ceil_mode=True)) in one pass
  *
  * Conventions
  *   - Tensors are described the way the reference's kernels see them: sizes[5] = {N, C, H, W, D}
@@ -45,7 +48,7 @@
 extern "C" {
 #endif
 
-#define SHIFTND_ABI_VERSION 1
+#define SHIFTND_ABI_VERSION 2
 #define SHIFTND_API __attribute__((visibility("default")))
 
 typedef enum shiftnd_dtype {
@@ -64,7 +67,8 @@ typedef enum shiftnd_status {
     SHIFTND_ERR_UNSUPPORTED_DTYPE = -2,
     SHIFTND_ERR_WORKSPACE_TOO_SMALL = -3,
     SHIFTND_ERR_LAUNCH_FAILED = -4,
-    SHIFTND_ERR_TOO_LARGE = -5
+    SHIFTND_ERR_TOO_LARGE = -5,
+    SHIFTND_ERR_NOT_FUSED = -6 /* pooled entry points: geometry not served; run shift and pool separately */
 } shiftnd_status;
 
 /* Which kernel family served the last call made on this host thread (for tests/benchmarks). */
@@ -148,6 +152,30 @@ SHIFTND_API int shiftnd_forward_quantized(const shiftnd_problem *p,
                               int64_t x_zero_point,
                               void *out, const int64_t out_strides[5],
                               void *stream);
+
+/*
+ * Fused shift + average pool.  The reference's modules follow the shift with
+ * avg_pool{N}d(kernel_size = stride = pool, ceil_mode=True) when they emulate a strided depthwise conv
+ * (torchshifts/modules/shifts.py:81-89, 150-153); these entry points produce the same result without
+ * writing / re-reading the full-size shift output.
+ *   pool:   p->ndim ints, window (= stride) per spatial dim (H, W, D), each >= 1.
+ *   Tensors are contiguous N, C, spatial: x and grad_x have the input's sizes, out / grad_pooled have spatial
+ *   sizes ceil((r - l) / pool).  shiftnd_pooled_sizes writes them.
+ *   Numerics: the window is summed in ATen's order in fp32 (fp64 for fp64) and divided by the number of window
+ *   elements inside the shift output; fp32 / fp64 results are bit-identical to the two-step sequence.
+ *   workspace: at least shiftnd_backward_workspace_bytes(p) bytes.
+ * Return SHIFTND_ERR_NOT_FUSED when the geometry is not served (the caller then runs shift and pool
+ * separately); nothing has been launched in that case.
+ */
+SHIFTND_API int shiftnd_pooled_sizes(const shiftnd_problem *p, const int32_t *pool, int64_t pooled_spatial[3]);
+
+SHIFTND_API int shiftnd_forward_pooled(const shiftnd_problem *p, const int32_t *pool,
+                           const void *x, const void *weights, void *out, void *stream);
+
+SHIFTND_API int shiftnd_backward_pooled(const shiftnd_problem *p, const int32_t *pool,
+                            const void *grad_pooled, const void *x, const void *weights,
+                            void *grad_x, void *grad_w,
+                            void *workspace, size_t workspace_bytes, void *stream);
 
 #ifdef __cplusplus
 }

@@ -193,3 +193,56 @@ def check_borders(sizes, user, dim):
         up = (ctypes.c_int32 * len(flat))(*flat)
     lib().oracle_check_borders(sizes_a, len(sizes), up, int(dim), std, new)
     return list(std), list(new)
+
+
+# ---------------------------------------------------------------------------------------------
+# The pooling tail of the reference's modules (torchshifts/modules/shifts.py:81-89, 150-153):
+# `_reduction_fn(out)` = torch.nn.functional.avg_pool{N}d(out, kernel_size=k, stride=k, ceil_mode=True).
+# The algorithm lives in ATen (torch 2.10, aten/src/ATen/native/cpu/AvgPoolKernel.cpp: the window is summed
+# sequentially in row-major order starting from 0 and divided by the number of window elements inside the
+# input when padding = 0; backward: every window element receives grad / that count).  Restated in numpy and
+# pinned bit-exact against torch's CPU avg_pool by tests/test_oracle_golden.py::test_avg_pool_restatement and
+# against the reference modules' pooled outputs in tests/golden/modules.npz.
+# ---------------------------------------------------------------------------------------------
+def _pool_counts(spatial, pooled, k):
+    cnt = np.ones([1, 1] + list(pooled), np.int64)
+    for d in range(len(k)):
+        c = np.minimum(k[d], spatial[d] - np.arange(pooled[d]) * k[d])
+        sh = [1] * (2 + len(k))
+        sh[2 + d] = pooled[d]
+        cnt = cnt * c.reshape(sh)
+    return cnt
+
+
+def avg_pool(y, k):
+    """avg_pool{N}d(y, kernel_size=k, stride=k, ceil_mode=True) for y[N, C, spatial...] (float32/float64)."""
+    import itertools
+    k = [int(k)] * (y.ndim - 2) if np.isscalar(k) else [int(v) for v in k]
+    sp = y.shape[2:]
+    pooled = [-(-s // kk) for s, kk in zip(sp, k)]
+    acc = np.zeros(y.shape[:2] + tuple(pooled), y.dtype)
+    for u in itertools.product(*[range(kk) for kk in k]):
+        part = y[(slice(None), slice(None)) + tuple(slice(uu, None, kk) for uu, kk in zip(u, k))]
+        idx = (slice(None), slice(None)) + tuple(slice(0, n) for n in part.shape[2:])
+        acc[idx] = acc[idx] + part
+    return (acc / _pool_counts(sp, pooled, k).astype(y.dtype)).astype(y.dtype)
+
+
+def avg_pool_backward(grad_pooled, k, spatial):
+    """gradient of avg_pool() with respect to its input of spatial sizes `spatial`."""
+    k = [int(k)] * (grad_pooled.ndim - 2) if np.isscalar(k) else [int(v) for v in k]
+    q = (grad_pooled / _pool_counts(spatial, grad_pooled.shape[2:], k).astype(grad_pooled.dtype)).astype(grad_pooled.dtype)
+    for d in range(len(k)):
+        q = np.repeat(q, k[d], axis=2 + d)
+        q = q[(slice(None),) * (2 + d) + (slice(0, spatial[d]),)]
+    return np.ascontiguousarray(q)
+
+
+def forward_pooled(x, w, pad, active, k, borders=None):
+    """the module-level sequence shift -> avg_pool (modules/shifts.py:150-153)"""
+    return avg_pool(forward(x, w, pad, active, borders), k)
+
+
+def backward_pooled(grad_pooled, w, x, pad, active, k, borders=None):
+    sp = out_shape(x, default_borders(x) if borders is None else borders)[2:]
+    return backward(avg_pool_backward(grad_pooled, k, sp), w, x, pad, active, borders)

@@ -17,7 +17,7 @@ def _declared_symbols():
 
 def test_header_symbols_exported():
     decl = _declared_symbols()
-    assert len(decl) == 12 and sorted(abi.EXPORTS) == decl
+    assert len(decl) == 15 and sorted(abi.EXPORTS) == decl
     L = ctypes.CDLL(abi._LIB_PATH)
     for name in decl:
         assert hasattr(L, name), name
@@ -32,7 +32,7 @@ def test_no_internal_symbols_leak():
 
 def test_host_only_entry_points():
     L = abi.lib()
-    assert L.shiftnd_abi_version() == 1
+    assert L.shiftnd_abi_version() == 2
     assert L.shiftnd_status_string(0) == b"ok" and L.shiftnd_status_string(-3) == b"workspace too small"
     assert abi.check_borders([2, 4, 6, 6], [[1, 2], [0, 1]], 2) == ([1, 4, 0, 5, 0, 1], [2, 4, 3, 5])
     assert abi.check_borders([2, 4, 6, 6], None, 2) == ([0, 6, 0, 6, 0, 1], [2, 4, 6, 6])
@@ -44,6 +44,12 @@ def test_host_only_entry_points():
     assert L.shiftnd_forward(ctypes.byref(p), None, st, None, None, st, None) == -1
     p.ndim, p.dtype = 2, abi.I8
     assert L.shiftnd_forward(ctypes.byref(p), None, st, None, None, st, None) == -2  # float entry, int dtype
+    # pooled sizes: ceil((r - l) / pool) per spatial dim
+    x = torch.empty(2, 3, 13, 20)
+    assert abi.pooled_shape(x, (2, 3)) == [2, 3, 7, 7]
+    assert abi.pooled_shape(x, 4, [1, 12, 2, 19, 0, 1]) == [2, 3, 3, 5]
+    p = abi.problem(x, 0, False, None)
+    assert L.shiftnd_pooled_sizes(ctypes.byref(p), (ctypes.c_int32 * 2)(2, 0), (ctypes.c_int64 * 3)()) == -1
 
 
 def test_check_borders_matches_oracle():

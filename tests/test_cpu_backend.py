@@ -158,3 +158,36 @@ def test_weight_grad_is_deterministic_multithreaded():
             assert torch.equal(got[0], ref[0]) and torch.equal(got[1], ref[1])
     finally:
         torch.set_num_threads(old)
+
+
+def test_pool_op_is_the_two_step_sequence_on_cpu():
+    """torchshifts::shift{N}d_pool on CPU tensors == shift{N}d followed by avg_pool{N}d(ceil_mode=True), values and
+    gradients (the reference modules' sequence, modules/shifts.py:150-153)"""
+    import torchshifts.functional as TF
+    torch.manual_seed(3)
+    F = {1: torch.nn.functional.avg_pool1d, 2: torch.nn.functional.avg_pool2d, 3: torch.nn.functional.avg_pool3d}
+    for nd, shape, pool, crop in [(1, (2, 3, 17), 2, None), (2, (2, 4, 9, 12), (2, 3), [[1, 0], [0, 2]]),
+                                  (3, (1, 2, 5, 6, 8), 2, None)]:
+        for pad, active in ((0, False), (3, True)):
+            x = torch.rand(shape, dtype=torch.float64)
+            w = torch.rand(shape[1], nd, dtype=torch.float64) * 4 - 2
+            b = None if crop is None else torch.tensor(crop)
+            xa, wa = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+            out = getattr(TF, "shift%dd_pool_func" % nd)(xa, wa, pad, active, b, pool)
+            xb, wb = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+            y = getattr(TF, "shift%dd_func" % nd)(xb, wb, pad, active, b)
+            k = pool if isinstance(pool, int) else list(pool)
+            ref = F[nd](y, kernel_size=k, stride=k, ceil_mode=True)
+            assert torch.equal(out, ref)
+            g = torch.rand_like(ref)
+            out.backward(g)
+            ref.backward(g)
+            assert torch.equal(xa.grad, xb.grad) and torch.equal(wa.grad, wb.grad)
+    with pytest.raises(AssertionError):
+        TF.shift2d_pool_func(torch.rand(1, 2, 4, 4), torch.zeros(2, 2), 0, False, None, [2])
+    with pytest.raises(RuntimeError, match="double backwards"):
+        x = torch.rand(1, 2, 6, 6, requires_grad=True)
+        w = torch.zeros(2, 2, requires_grad=True)
+        out = TF.shift2d_pool_func(x, w, 0, False, None, 2)
+        (gx,) = torch.autograd.grad(out.sum(), x, create_graph=True)
+        gx.sum().backward()

@@ -127,3 +127,25 @@ def test_channels_last_loop_order_matches_values():
     a = O.backward(go, w, x, 3, 1, None, nhwc_order=False)
     b = O.backward(go, w, x, 3, 1, None, nhwc_order=True)
     assert _eq(a[0], b[0]) and _eq(a[1], b[1])  # exact data -> order independent
+
+
+def test_avg_pool_restatement():
+    """the oracle's numpy restatement of ATen's avg_pool (ceil mode, kernel = stride) and of its backward is
+    bit-exact against torch's CPU kernels: this pins the pooled-sequence oracle used by the fused-op tests"""
+    import torch
+    torch.set_num_threads(1)
+    F = {1: torch.nn.functional.avg_pool1d, 2: torch.nn.functional.avg_pool2d, 3: torch.nn.functional.avg_pool3d}
+    rs = np.random.RandomState(0)
+    for dt in (np.float32, np.float64):
+        for shape, k in [((2, 3, 17), (2,)), ((2, 3, 16), (3,)), ((2, 3, 9, 11), (2, 2)), ((2, 3, 10, 12), (3, 2)),
+                         ((1, 2, 7, 7), (4, 4)), ((2, 2, 5, 6, 7), (2, 2, 2)), ((1, 2, 6, 7, 9), (2, 3, 4)),
+                         ((1, 1, 1, 5), (2, 2))]:
+            nd = len(k)
+            y = rs.uniform(-1, 1, size=shape).astype(dt)
+            t = torch.from_numpy(y.copy()).requires_grad_(True)
+            kk = k[0] if nd == 1 else list(k)
+            o = F[nd](t, kernel_size=kk, stride=kk, ceil_mode=True)
+            assert np.array_equal(O.avg_pool(y, k), o.detach().numpy()), (shape, k)
+            g = rs.uniform(-1, 1, size=tuple(o.shape)).astype(dt)
+            o.backward(torch.from_numpy(g))
+            assert np.array_equal(O.avg_pool_backward(g, k, shape[2:]), t.grad.numpy()), (shape, k)

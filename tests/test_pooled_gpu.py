@@ -1,0 +1,112 @@
+"""GPU parity of the fused shift + average pool entry points (shiftnd_forward_pooled / shiftnd_backward_pooled)
+against the oracle's restatement of the module-level sequence the reference runs
+(modules/shifts.py:150-153: shift, then avg_pool{N}d(kernel = stride, ceil_mode=True)).
+
+Bars: fp32 / fp64 forward and grad_x bit-exact (same summation order and one IEEE division);
+grad_w <= 1e-5 (fp32) / 1e-12 (fp64) relative to the oracle; bf16 / fp16 within 1 ulp of the 16-bit type
+against the fp32 oracle on widened inputs.
+"""
+import numpy as np
+import pytest
+import torch
+
+from cases import rel_err
+from oracle import oracle as O
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+@pytest.fixture(scope="module")
+def abi():
+    from torchshifts import abi as A
+    assert torch.cuda.is_available(), "the gpu tests need an MI355X"
+    return A
+
+
+def _dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
+
+
+CASES = [  # nd, shape, pool, crop
+    (1, (2, 5, 32), (2,), None),
+    (1, (3, 4, 36), (3,), [[1, 2]]),
+    (2, (2, 6, 12, 16), (2, 2), None),
+    (2, (2, 5, 13, 20), (2, 2), None),      # odd rows: ceil-mode partial windows
+    (2, (2, 4, 12, 24), (3, 2), [[1, 0], [2, 3]]),
+    (2, (1, 3, 9, 8), (4, 4), None),
+    (2, (2, 3, 10, 12), (1, 2), None),
+    (3, (2, 3, 6, 7, 8), (2, 2, 2), None),
+    (3, (1, 4, 5, 6, 12), (2, 3, 2), [[0, 1], [1, 0], [0, 0]]),
+]
+
+
+@pytest.mark.parametrize("dt", [np.float32, np.float64])
+def test_pooled_vs_oracle(abi, dt):
+    rs = np.random.RandomState(11)
+    for nd, shape, pool, crop in CASES:
+        x = rs.uniform(-1, 1, size=shape).astype(dt)
+        w = rs.uniform(-3.2, 3.2, size=(shape[1], nd)).astype(dt)
+        w[0] = 0.0
+        w[1, 0] = 2.5
+        b, new = abi.check_borders(list(shape), crop, nd)
+        for pad in range(5):
+            for active in (0, 1):
+                key = (nd, shape, pool, crop, pad, active)
+                ref = O.forward_pooled(x, w, pad, active, pool, b)
+                xd, wd = _dev(x), _dev(w)
+                out = abi.forward_pooled(xd, wd, pad, active, pool, b)
+                assert abi.last_kernel() == "plane_pool_forward"
+                assert list(out.shape) == list(ref.shape), key
+                assert np.array_equal(out.cpu().numpy(), ref), key
+                gp = rs.uniform(-1, 1, size=ref.shape).astype(dt)
+                gx_r, gw_r = O.backward_pooled(gp, w, x, pad, active, pool, b)
+                gx, gw = abi.backward_pooled(_dev(gp), wd, xd, pad, active, pool, b)
+                assert abi.last_kernel() == "plane_backward_pool"
+                assert np.array_equal(gx.cpu().numpy(), gx_r), key
+                assert rel_err(gw.cpu().numpy(), gw_r) < (1e-5 if dt == np.float32 else 1e-12), key
+
+
+@pytest.mark.parametrize("tdt", [torch.bfloat16, torch.float16])
+def test_pooled_16bit(abi, tdt):
+    rs = np.random.RandomState(5)
+    eps = 2.0 ** -8 if tdt == torch.bfloat16 else 2.0 ** -11
+    for nd, shape, pool, crop in [(2, (2, 4, 12, 16), (2, 2), None), (3, (1, 3, 6, 6, 8), (2, 2, 2), None),
+                                  (2, (2, 3, 13, 24), (3, 2), [[1, 0], [0, 3]])]:
+        xt = torch.from_numpy(rs.uniform(-1, 1, size=shape).astype(np.float32)).to(tdt)
+        wt = torch.from_numpy(rs.uniform(-2.5, 2.5, size=(shape[1], nd)).astype(np.float32)).to(tdt)
+        x, w = xt.float().numpy(), wt.float().numpy()
+        b, _ = abi.check_borders(list(shape), crop, nd)
+        for pad in (0, 3):
+            for active in (0, 1):
+                # unfused sequence on widened inputs with the shift output rounded to the storage type
+                y = torch.from_numpy(O.forward(x, w, pad, active, b)).to(tdt).float().numpy()
+                ref = O.avg_pool(y, pool)
+                out = abi.forward_pooled(xt.to(DEV), wt.to(DEV), pad, active, pool, b)
+                got = out.float().cpu().numpy()
+                assert np.max(np.abs(got - ref)) <= eps * max(1.0, np.max(np.abs(ref))), (shape, pad, active)
+                gpt = torch.from_numpy(rs.uniform(-1, 1, size=ref.shape).astype(np.float32)).to(tdt)
+                g = torch.from_numpy(O.avg_pool_backward(gpt.float().numpy(), pool, y.shape[2:])).to(tdt).float().numpy()
+                gx_r, gw_r = O.backward(g, w, x, pad, active, b)
+                gx, gw = abi.backward_pooled(gpt.to(DEV), wt.to(DEV), xt.to(DEV), pad, active, pool, b)
+                assert np.max(np.abs(gx.float().cpu().numpy() - gx_r)) <= eps * max(1.0, np.max(np.abs(gx_r)))
+                assert rel_err(gw.float().cpu().numpy(), gw_r) < 4 * eps
+
+
+def test_pooled_matches_unfused_fullsize(abi):
+    """size-independent property at a large size: fused == shift kernel + torch avg_pool (fp32, bit-exact)"""
+    torch.manual_seed(0)
+    x = torch.rand(8, 64, 224, 224, device=DEV)
+    w = (torch.rand(64, 2, device=DEV) * 6 - 3)
+    for pad, active in ((0, 0), (4, 1)):
+        y = abi.forward(x, w, pad, active)
+        ref = torch.nn.functional.avg_pool2d(y, 2, 2, ceil_mode=True)
+        out = abi.forward_pooled(x, w, pad, active, 2)
+        assert torch.equal(out, ref)
+        gp = torch.rand_like(ref)
+        yy = y.clone().requires_grad_(True)
+        torch.nn.functional.avg_pool2d(yy, 2, 2, ceil_mode=True).backward(gp)
+        gx_r, gw_r = abi.backward(yy.grad, w, x, pad, active)
+        gx, gw = abi.backward_pooled(gp, w, x, pad, active, 2)
+        assert torch.equal(gx, gx_r)
+        assert rel_err(gw.cpu().numpy(), gw_r.cpu().numpy()) < 1e-5

@@ -138,3 +138,58 @@ def test_streams_and_graph_capture():
     torch.cuda.synchronize()
     gx_ref, gw_ref = abi.backward(ref, w, x, 3, 1)
     assert torch.equal(out2, ref) and torch.equal(gx, gx_ref) and torch.equal(gw, gw_ref)
+
+
+def test_pool_op_gpu_vs_cpu():
+    """torchshifts::shift{N}d_pool on HIP tensors (fused kernels) == the same op on CPU tensors (the reference's
+    shift + avg_pool sequence): fp32 values bit-exact, grad_x bit-exact, grad_w <= 1e-5 relative"""
+    import torchshifts.functional as TF
+    from torchshifts import abi
+    torch.manual_seed(5)
+    for nd, shape, pool, crop in [(1, (2, 6, 40), 2, None), (2, (2, 8, 21, 32), (2, 2), None),
+                                  (2, (2, 4, 18, 24), (3, 2), [[1, 0], [0, 2]]), (3, (1, 4, 6, 7, 8), 2, None)]:
+        fn = getattr(TF, "shift%dd_pool_func" % nd)
+        for pad, active in ((0, False), (1, True), (4, False)):
+            x = torch.rand(shape)
+            w = torch.rand(shape[1], nd) * 5 - 2.5
+            b = None if crop is None else torch.tensor(crop)
+            xc, wc = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+            out_c = fn(xc, wc, pad, active, b, pool)
+            g = torch.rand_like(out_c)
+            out_c.backward(g)
+            xg, wg = x.to(DEV).requires_grad_(True), w.to(DEV).requires_grad_(True)
+            out_g = fn(xg, wg, pad, active, b, pool)
+            assert abi.last_kernel() == "plane_pool_forward"
+            out_g.backward(g.to(DEV))  # (runs on the autograd thread: its kernel name is checked in test_pooled_gpu.py)
+            assert torch.equal(out_g.cpu(), out_c.detach()), (shape, pad, active)
+            assert torch.equal(xg.grad.cpu(), xc.grad), (shape, pad, active)
+            assert rel_err(wg.grad.cpu().numpy(), wc.grad.numpy()) < 1e-5
+    # a layout the fused kernels do not serve (channels-last input) falls back to the two-step sequence, same values
+    x = torch.rand(2, 8, 12, 16).to(DEV).contiguous(memory_format=torch.channels_last)
+    w = (torch.rand(8, 2) * 4 - 2).to(DEV)
+    a = TF.shift2d_pool_func(x, w, 0, False, None, 2)
+    bb = TF.shift2d_pool_func(x.contiguous(), w, 0, False, None, 2)
+    assert torch.equal(a, bb)
+
+
+def test_strided_module_uses_fused_pool():
+    """a module that emulates a stride-2 depthwise conv runs ONE fused kernel per direction on the GPU and matches
+    the CPU module (= the reference's sequence)"""
+    from torchshifts import abi
+    torch.manual_seed(2)
+    m = Shift2d(16, padding='border', sparsity_term=0., emulate_dw={'kernel_size': 3, 'stride': 2, 'padding': 1})
+    x = torch.rand(4, 16, 30, 30)
+    xc = x.clone().requires_grad_(True)
+    out_c, _ = m(xc)
+    assert out_c.shape == (4, 16, 15, 15)
+    out_c.square().sum().backward()
+    gw_c, gx_c = m.weight.grad.clone(), xc.grad.clone()
+    m.zero_grad()
+    mg = m.to(DEV)
+    xg = x.to(DEV).requires_grad_(True)
+    out_g, _ = mg(xg)
+    assert abi.last_kernel() == "plane_pool_forward"
+    out_g.square().sum().backward()
+    assert torch.equal(out_g.cpu(), out_c.detach())
+    assert torch.allclose(xg.grad.cpu(), gx_c, rtol=1e-6, atol=1e-9)
+    assert rel_err(mg.weight.grad.cpu().numpy(), gw_c.numpy()) < 1e-5

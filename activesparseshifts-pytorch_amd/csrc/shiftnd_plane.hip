@@ -297,8 +297,10 @@ template <typename CT> __device__ __forceinline__ CT div_count(CT v, int cnt) {
 // are bit-identical to shift + avg_pool.  16-bit interpolated values are rounded to the storage type first,
 // like the unfused sequence does when it stores the shift output.
 // =====================================================================================================
-// SMALLK: every window size is 1 or 2 -- the window loops are unrolled with predicates, so the (up to 8)
-// gathers of one pooled element are independent loads in flight together.
+// SMALLK: every window size is 1 or 2 (the strided-conv emulation with stride 2).  Branch-free form: the source
+// samples a pooled element needs -- a 2 x 2 (x 2) block, one more per real dim when interpolating, since adjacent
+// window positions share corners (9 loads instead of 16 in 2-D, 27 instead of 64 in 3-D) -- are loaded as
+// independent, predicated loads, then combined from registers.
 template <typename T, int ND, bool ACTIVE, bool SMALLK>
 __global__ __launch_bounds__(kThreads) void plane_pool_forward(const PlaneParams p) {
     using S = typename T::S;
@@ -332,35 +334,78 @@ __global__ __launch_bounds__(kThreads) void plane_pool_forward(const PlaneParams
         const int n0 = min(p.K[0], p.O[0] - p0 * p.K[0]), n1 = min(p.K[1], p.O[1] - p1 * p.K[1]);
         const int n2 = min(p.K[2], p.O[2] - p2 * p.K[2]);
         CT acc = CT(0);
-        constexpr int M0 = SMALLK ? (ND == 3 ? 2 : 1) : (1 << 30), M1 = SMALLK ? (ND >= 2 ? 2 : 1) : (1 << 30);
-        constexpr int M2 = SMALLK ? 2 : (1 << 30);
+        if constexpr (SMALLK) {
+            // window extent M and sample extent A per normalised dim (dims in front of the real ones have size 1)
+            constexpr int M0 = ND == 3 ? 2 : 1, M1 = ND >= 2 ? 2 : 1, M2 = 2;
+            constexpr int A0 = M0 + (ACTIVE && ND == 3 ? 1 : 0), A1 = M1 + (ACTIVE && ND >= 2 ? 1 : 0), A2 = M2 + (ACTIVE ? 1 : 0);
+            int r0[A0], r1[A1], r2[A2];
+            // (a sample index beyond the last one the window uses is clamped to the map's last entry and never used)
 #pragma unroll
-        for (int u0 = 0; u0 < M0; ++u0) {
-            if (u0 >= n0) break;
-            const int i0 = p0 * p.K[0] + u0 + p.L[0];
+            for (int a = 0; a < A0; ++a) r0[a] = m0[min(p0 * p.K[0] + p.L[0] + a, p.S[0])];
 #pragma unroll
-            for (int u1 = 0; u1 < M1; ++u1) {
-                if (u1 >= n1) break;
-                const int i1 = p1 * p.K[1] + u1 + p.L[1];
+            for (int a = 0; a < A1; ++a) r1[a] = m1[min(p1 * p.K[1] + p.L[1] + a, S1)];
 #pragma unroll
-                for (int u2 = 0; u2 < M2; ++u2) {
-                    if (u2 >= n2) break;
-                    const int i2 = p2 * p.K[2] + u2 + p.L[2];
-                    if constexpr (ACTIVE) {
-                        CT v[1 << ND];
+            for (int a = 0; a < A2; ++a) r2[a] = m2[min(p2 * p.K[2] + p.L[2] + a, S2)];
+            CT sv[A0][A1][A2];
 #pragma unroll
-                        for (int q = 0; q < (1 << ND); ++q) {
-                            // bit r of q <-> +1 along real dim r = normalised dim r + 3 - ND
-                            const int b0 = ND == 3 ? (q & 1) : 0;
-                            const int b1 = ND == 3 ? ((q >> 1) & 1) : (ND == 2 ? (q & 1) : 0);
-                            const int b2 = (q >> (ND - 1)) & 1;
-                            const int ra = m0[i0 + b0], rb = m1[i1 + b1], rc = m2[i2 + b2];
-                            v[q] = (ra >= 0 && rb >= 0 && rc >= 0) ? widen<T>(xp[(ra * S1 + rb) * S2 + rc]) : CT(0);
+            for (int a = 0; a < A0; ++a)
+#pragma unroll
+                for (int b = 0; b < A1; ++b) {
+                    const bool rowok = r0[a] >= 0 && r1[b] >= 0;
+                    const int rowoff = rowok ? (r0[a] * S1 + r1[b]) * S2 : 0;
+#pragma unroll
+                    for (int c = 0; c < A2; ++c) {
+                        const bool ok = rowok && r2[c] >= 0;
+                        const CT v = widen<T>(xp[rowoff + (r2[c] >= 0 ? r2[c] : 0)]);
+                        sv[a][b][c] = ok ? v : CT(0);
+                    }
+                }
+#pragma unroll
+            for (int u0 = 0; u0 < M0; ++u0)
+#pragma unroll
+                for (int u1 = 0; u1 < M1; ++u1)
+#pragma unroll
+                    for (int u2 = 0; u2 < M2; ++u2) {
+                        CT val;
+                        if constexpr (ACTIVE) {
+                            CT v[1 << ND];
+#pragma unroll
+                            for (int q = 0; q < (1 << ND); ++q) {
+                                // bit r of q <-> +1 along real dim r = normalised dim r + 3 - ND
+                                const int b0 = ND == 3 ? (q & 1) : 0;
+                                const int b1 = ND == 3 ? ((q >> 1) & 1) : (ND == 2 ? (q & 1) : 0);
+                                const int b2 = (q >> (ND - 1)) & 1;
+                                v[q] = sv[u0 + b0][u1 + b1][u2 + b2];
+                            }
+                            val = widen<T>(narrow<T>(interp_nd<ND, CT>(v, dw)));
+                        } else {
+                            val = sv[u0][u1][u2];
                         }
-                        acc = acc + widen<T>(narrow<T>(interp_nd<ND, CT>(v, dw)));
-                    } else {
-                        const int ra = m0[i0], rb = m1[i1], rc = m2[i2];
-                        acc = acc + ((ra >= 0 && rb >= 0 && rc >= 0) ? widen<T>(xp[(ra * S1 + rb) * S2 + rc]) : CT(0));
+                        // (acc is never -0.0, so adding +0.0 for a position outside a ragged last window changes nothing)
+                        acc = acc + ((u0 < n0 && u1 < n1 && u2 < n2) ? val : CT(0));
+                    }
+        } else {
+            for (int u0 = 0; u0 < n0; ++u0) {
+                const int i0 = p0 * p.K[0] + u0 + p.L[0];
+                for (int u1 = 0; u1 < n1; ++u1) {
+                    const int i1 = p1 * p.K[1] + u1 + p.L[1];
+                    for (int u2 = 0; u2 < n2; ++u2) {
+                        const int i2 = p2 * p.K[2] + u2 + p.L[2];
+                        if constexpr (ACTIVE) {
+                            CT v[1 << ND];
+#pragma unroll
+                            for (int q = 0; q < (1 << ND); ++q) {
+                                const int b0 = ND == 3 ? (q & 1) : 0;
+                                const int b1 = ND == 3 ? ((q >> 1) & 1) : (ND == 2 ? (q & 1) : 0);
+                                const int b2 = (q >> (ND - 1)) & 1;
+                                const int ra = m0[i0 + b0], rb = m1[i1 + b1], rc = m2[i2 + b2];
+                                v[q] = (ra >= 0 && rb >= 0 && rc >= 0) ? widen<T>(xp[(ra * S1 + rb) * S2 + rc]) : CT(0);
+                            }
+                            acc = acc + widen<T>(narrow<T>(interp_nd<ND, CT>(v, dw)));
+                        } else {
+                            const int ra = m0[i0], rb = m1[i1], rc = m2[i2];
+                            acc = acc + ((ra >= 0 && rb >= 0 && rc >= 0) ? widen<T>(xp[(ra * S1 + rb) * S2 + rc]) : CT(0));
+                        }
                     }
                 }
             }
@@ -608,7 +653,7 @@ template <int ND, bool ACTIVE, bool BACKWARD> struct LdsTileShape {
 };
 
 // Shared by the LDS-staged kernels: slot table + LDS-DMA of one step.
-template <typename T, int ND, bool ACTIVE, bool BACKWARD>
+template <typename T, int ND, bool ACTIVE, bool BACKWARD, bool POOL = false>
 struct LdsStager {
     using S = typename T::S;
     using Shape = LdsTileShape<ND, ACTIVE, BACKWARD>;
@@ -616,12 +661,23 @@ struct LdsStager {
     static constexpr int NA = Shape::NA;
 
     // slot table: element offset of each staged row inside its plane, or -1
+    // POOL: a G / GS entry is the element offset of the POOLED row the slot's (unpooled) gradient row expands from,
+    // and slot_src[k + aux] the number of window elements along the two outer dims (see expand_pooled)
     __device__ static void make_slots(const PlaneParams &p, int R, int a, int b0, int Rn, const int *m0, const int *m1,
-                                      const int *g0, const int *g1, int *slot_src) {
+                                      const int *g0, const int *g1, int *slot_src, int aux = 0) {
         const int NX = Shape::nx(R), NG = Shape::ng(R), NS = Shape::slots(R);
         const int k = threadIdx.x;
         if (k >= NS) return;
         int src = -1;
+        auto grad_row = [&](int ra, int rb) {
+            if constexpr (POOL) {
+                const PoolRow pr = pool_row(p, ra, rb);
+                slot_src[k + aux] = pr.cnt;
+                return pr.off;
+            } else {
+                return (ra * p.S[1] + rb) * p.S[2];
+            }
+        };
         if (k < NX) {
             const int ha = k / (R + 1), kk = k - ha * (R + 1);
             if (kk <= Rn) {
@@ -630,26 +686,54 @@ struct LdsStager {
             }
         } else if (k < NX + NG) {
             const int kk = k - NX;
-            if (kk < Rn) src = (a * p.S[1] + b0 + kk) * p.S[2];
+            if (kk < Rn) src = grad_row(a, b0 + kk);
         } else if (ACTIVE) {
             const int k2 = k - NX - NG;
             const int ha = k2 / (R + 1), kk = k2 - ha * (R + 1);
             if (kk <= Rn) {
                 const int ra = g0[a + ha], rb = g1[b0 + kk];
-                if (ra >= 0 && rb >= 0) src = (ra * p.S[1] + rb) * p.S[2];
+                if (ra >= 0 && rb >= 0) src = grad_row(ra, rb);
             }
         } else {
             const int kk = k - NX - NG;
             if (kk < Rn) {
                 const int ra = g0[a], rb = g1[b0 + kk];
-                if (ra >= 0 && rb >= 0) src = (ra * p.S[1] + rb) * p.S[2];
+                if (ra >= 0 && rb >= 0) src = grad_row(ra, rb);
             }
         }
         slot_src[k] = src;
     }
 
+    // POOL: a G / GS slot holds one row of the UNPOOLED gradient g(o) = round_S(grad_pooled[o / K] / count(o / K)),
+    // expanded here from the pooled row (piece j = columns [j*E, j*E + E)), so the compute phase reads the tile
+    // exactly as it reads staged grad_out rows.  Windows of 2 along the row (the stride-2 emulation) take one load
+    // of E/2 pooled values per piece and, when the count is a power of two, one multiply each.
+    __device__ static void expand_pooled(const PlaneParams &p, const S *prow, int row_cnt, int j, char *dst) {
+        using CT = typename T::C;
+        Chunk<S, E> out;
+        if (p.K[2] == 2 && E % 2 == 0) {  // (rows are whole 16-byte pieces, so O2 is even: every window has 2 columns)
+            const Chunk<S, (E >= 2 ? E / 2 : 1)> pv = load_chunk<S, (E >= 2 ? E / 2 : 1)>(prow + j * (E / 2));
+#pragma unroll
+            for (int h = 0; h < E / 2; ++h) {
+                const S q = narrow<T>(div_count<CT>(widen<T>(pv.e[h]), row_cnt * 2));
+                out.e[2 * h] = q;
+                out.e[2 * h + 1] = q;
+            }
+        } else {
+            const int c0 = j * E;
+#pragma unroll
+            for (int e = 0; e < E; ++e) {
+                const int pc = fdiv(c0 + e, p.d_k[2]);
+                const int cc = min(p.K[2], p.O[2] - pc * p.K[2]);
+                out.e[e] = narrow<T>(div_count<CT>(widen<T>(prow[pc]), row_cnt * cc));
+            }
+        }
+        __builtin_memcpy(__builtin_assume_aligned(dst, 16), out.e, 16);
+    }
+
     // LDS-DMA: piece q = 16 bytes; lanes of a wave take consecutive pieces (the LDS destination is linear)
-    __device__ static void issue_dma(const PlaneParams &p, int R, const S *xp, const S *gp, const int *slot_src, char *tile) {
+    __device__ static void issue_dma(const PlaneParams &p, int R, const S *xp, const S *gp, const int *slot_src, char *tile,
+                                     int aux = 0) {
         const int NX = Shape::nx(R);
         const int pieces = Shape::slots(R) * static_cast<int>(p.cpr);
         for (int q0 = 0; q0 < pieces; q0 += kThreads) {
@@ -658,7 +742,9 @@ struct LdsStager {
                 const int slot = fdiv(q, p.d_cpr);
                 const int j = q - slot * static_cast<int>(p.cpr);
                 const int src = slot_src[slot];
-                if (src >= 0) {
+                if (POOL && slot >= NX) {
+                    if (src >= 0) expand_pooled(p, gp + src, slot_src[slot + aux], j, tile + q * 16);
+                } else if (src >= 0) {
                     const S *g = (slot < NX ? xp : gp) + src + j * E;
                     char *dst_wave = tile + (q0 + (threadIdx.x & ~63)) * 16;  // wave-uniform; hardware adds lane * 16
                     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)g,
@@ -759,11 +845,11 @@ __device__ __forceinline__ void lds_corners(const char *tile, int RB, int R, int
     }
 }
 
-template <typename T, int ND, bool ACTIVE, int TILES>
+template <typename T, int ND, bool ACTIVE, int TILES, bool POOL = false>
 __global__ __launch_bounds__(kThreads) void plane_backward_lds(const PlaneParams p) {
     using S = typename T::S;
     using CT = typename T::C;
-    using Stager = LdsStager<T, ND, ACTIVE, true>;
+    using Stager = LdsStager<T, ND, ACTIVE, true, POOL>;
     using Shape = LdsTileShape<ND, ACTIVE, true>;
     constexpr int E = 16 / sizeof(S);
     constexpr int NC = 1 << (ND - 1);
@@ -810,10 +896,11 @@ __global__ __launch_bounds__(kThreads) void plane_backward_lds(const PlaneParams
     // slot tables rotate over NT buffers: with two tiles there is no barrier after the compute phase, so the table
     // of step s must survive until every wave has passed the barrier of step s+1 (three tables)
     constexpr int NT = TILES == 2 ? 3 : 2;
+    const int aux = NT * NS;  // POOL: a second set of tables behind the slot tables
     int nl = 0, r0 = wi.row0, buf = 0, tb = 0;
     {
         const int a = fdiv(r0, p.d_dim1);
-        Stager::make_slots(p, R, a, r0 - a * S1, step_len(r0), m0, m1, g0, g1, slot_src);
+        Stager::make_slots(p, R, a, r0 - a * S1, step_len(r0), m0, m1, g0, g1, slot_src, aux);
     }
     __syncthreads();
     while (nl < wi.nn) {
@@ -826,12 +913,12 @@ __global__ __launch_bounds__(kThreads) void plane_backward_lds(const PlaneParams
         const S *xp = static_cast<const S *>(p.x) + plane * p.x_plane;
         const S *gp = static_cast<const S *>(p.go) + plane * p.o_plane;
         S *gxp = static_cast<S *>(p.out) + plane * p.x_plane;
-        Stager::issue_dma(p, R, xp, gp, ss, tile);
+        Stager::issue_dma(p, R, xp, gp, ss, tile, aux);
         int nl2 = nl, r2 = r0 + Rn;
         if (r2 >= row_end) { r2 = wi.row0; ++nl2; }
         if (nl2 < wi.nn) {
             const int a2 = fdiv(r2, p.d_dim1);
-            Stager::make_slots(p, R, a2, r2 - a2 * S1, step_len(r2), m0, m1, g0, g1, slot_src + ((tb + 1) % NT) * NS);
+            Stager::make_slots(p, R, a2, r2 - a2 * S1, step_len(r2), m0, m1, g0, g1, slot_src + ((tb + 1) % NT) * NS, aux);
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
@@ -1275,7 +1362,28 @@ void launch_backward_a(const PlaneParams &p_in, const Plan &pl, hipStream_t st) 
 }
 
 template <typename T, bool ACTIVE>
-void launch_backward_pool(const PlaneParams &p, const Plan &pl, hipStream_t st) {
+void launch_backward_pool(const PlaneParams &p_in, const Plan &pl, hipStream_t st) {
+    PlaneParams p = p_in;
+    if (g_tune[3] == 2 && p.nd >= 2) {  // LDS-staged form where it applies (pooled rows are expanded into the tile)
+        size_t lds_bytes = 0;
+        int tile_bytes = 0;
+        const int slots = p.nd == 3 ? LdsTileShape<3, ACTIVE, true>::slots(pl.RPS) : LdsTileShape<2, ACTIVE, true>::slots(pl.RPS);
+        if (lds_staged_ok(p, pl, static_cast<int>(sizeof(typename T::S)), slots, &lds_bytes, &tile_bytes)) {
+            p.tile_bytes = tile_bytes;
+            note_kernel("plane_backward_lds_pool");
+            lds_bytes += 3 * slots * sizeof(int);  // the second set of slot tables (window counts)
+            const bool want_two = g_tune[4] == 2 || (g_tune[4] != 3 && sizeof(typename T::S) == 2);
+            const bool two = want_two && lds_bytes + tile_bytes + slots * sizeof(int) <= 64 * 1024;
+            if (p.nd == 3) {
+                if (two) hipLaunchKernelGGL((plane_backward_lds<T, 3, ACTIVE, 2, true>), dim3(pl.grid), dim3(kThreads), lds_bytes + tile_bytes + slots * sizeof(int), st, p);
+                else hipLaunchKernelGGL((plane_backward_lds<T, 3, ACTIVE, 1, true>), dim3(pl.grid), dim3(kThreads), lds_bytes, st, p);
+            } else {
+                if (two) hipLaunchKernelGGL((plane_backward_lds<T, 2, ACTIVE, 2, true>), dim3(pl.grid), dim3(kThreads), lds_bytes + tile_bytes + slots * sizeof(int), st, p);
+                else hipLaunchKernelGGL((plane_backward_lds<T, 2, ACTIVE, 1, true>), dim3(pl.grid), dim3(kThreads), lds_bytes, st, p);
+            }
+            return;
+        }
+    }
     note_kernel("plane_backward_pool");
     switch (p.nd) {
     case 1: hipLaunchKernelGGL((plane_backward<T, 1, ACTIVE, true>), dim3(pl.grid), dim3(kThreads), pl.lds, st, p); break;

@@ -61,8 +61,13 @@ def test_pooled_vs_oracle(abi, dt):
                 assert np.array_equal(out.cpu().numpy(), ref), key
                 gp = rs.uniform(-1, 1, size=ref.shape).astype(dt)
                 gx_r, gw_r = O.backward_pooled(gp, w, x, pad, active, pool, b)
+                if nd == 3 and active:  # not fused by default (slower than the two-step sequence): force the kernels
+                    with pytest.raises(RuntimeError, match="not served"):
+                        abi.backward_pooled(_dev(gp), wd, xd, pad, active, pool, b)
+                    abi.set_path_policy(2)
                 gx, gw = abi.backward_pooled(_dev(gp), wd, xd, pad, active, pool, b)
-                assert abi.last_kernel() == "plane_backward_pool"
+                abi.set_path_policy(0)
+                assert abi.last_kernel() in ("plane_backward_pool", "plane_backward_lds_pool")
                 assert np.array_equal(gx.cpu().numpy(), gx_r), key
                 assert rel_err(gw.cpu().numpy(), gw_r) < (1e-5 if dt == np.float32 else 1e-12), key
 
@@ -88,7 +93,9 @@ def test_pooled_16bit(abi, tdt):
                 gpt = torch.from_numpy(rs.uniform(-1, 1, size=ref.shape).astype(np.float32)).to(tdt)
                 g = torch.from_numpy(O.avg_pool_backward(gpt.float().numpy(), pool, y.shape[2:])).to(tdt).float().numpy()
                 gx_r, gw_r = O.backward(g, w, x, pad, active, b)
+                abi.set_path_policy(2 if (nd == 3 and active) else 0)
                 gx, gw = abi.backward_pooled(gpt.to(DEV), wt.to(DEV), xt.to(DEV), pad, active, pool, b)
+                abi.set_path_policy(0)
                 assert np.max(np.abs(gx.float().cpu().numpy() - gx_r)) <= eps * max(1.0, np.max(np.abs(gx_r)))
                 assert rel_err(gw.float().cpu().numpy(), gw_r) < 4 * eps
 

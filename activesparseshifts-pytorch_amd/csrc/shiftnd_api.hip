@@ -82,18 +82,25 @@ int forward_common(const shiftnd_problem *p, const void *x, const int64_t *xs, c
     const bool can_sweep = sweep_forward_eligible(g, p->dtype, x, out);
     const bool can_plane = plane_forward_eligible(g, p->dtype, x, out);
     if ((g_policy == 2 && !can_plane) || (g_policy == 3 && !can_sweep)) return SHIFTND_ERR_INVALID_ARGUMENT;
-    // automatic choice: the sweep kernels for planes of >= 32 KiB (their per-wave prologue is amortised over
-    // several rows); small planes (e.g. 56x56 int8 = 3 KiB) go to the plane kernels, which walk many planes
-    // of one channel per workgroup (measured on C4: 0.13 ms vs 0.33 ms)
-    const int64_t out_plane_bytes = g.O[0] * g.O[1] * g.O[2] * dtype_size(p->dtype);
-    const bool prefer_sweep = (out_plane_bytes >= 32 * 1024 && !(can_plane && plane_forward_lds_gather(g, p->dtype, x, out))) || !can_plane;
-    if (can_sweep && (g_policy == 3 || (g_policy == 0 && prefer_sweep))) {
-        g_last_path = SHIFTND_PATH_SWEEP;
-        return finish(sweep_forward(g, p->dtype, x, w, wkind, wzp, fill, out, st));
+    if (g_policy != 4) {
+        // automatic choice: the sweep kernels for planes of >= 32 KiB (their per-wave prologue is amortised over
+        // several rows); small planes (e.g. 56x56 int8 = 3 KiB) go to the plane kernels, which walk many planes
+        // of one channel per workgroup (measured on C4: 0.13 ms vs 0.33 ms)
+        const int64_t out_plane_bytes = g.O[0] * g.O[1] * g.O[2] * dtype_size(p->dtype);
+        const bool prefer_sweep = (out_plane_bytes >= 32 * 1024 && !(can_plane && plane_forward_lds_gather(g, p->dtype, x, out))) || !can_plane;
+        if (can_sweep && (g_policy == 3 || (g_policy == 0 && prefer_sweep))) {
+            g_last_path = SHIFTND_PATH_SWEEP;
+            return finish(sweep_forward(g, p->dtype, x, w, wkind, wzp, fill, out, st));
+        }
+        if (can_plane && g_policy != 1) {
+            g_last_path = SHIFTND_PATH_PLANE;
+            return finish(plane_forward(g, p->dtype, x, w, wkind, wzp, fill, out, st));
+        }
     }
-    if (can_plane && g_policy != 1) {
-        g_last_path = SHIFTND_PATH_PLANE;
-        return finish(plane_forward(g, p->dtype, x, w, wkind, wzp, fill, out, st));
+    if (g_policy == 4 && !cl_forward_eligible(g)) return SHIFTND_ERR_INVALID_ARGUMENT;
+    if ((g_policy == 0 && cl_forward_preferred(g)) || g_policy == 4) {  // channels-last tensors: channel-fastest kernels
+        g_last_path = SHIFTND_PATH_CL;
+        return finish(cl_forward(g, p->dtype, x, w, wkind, wzp, fill, out, st));
     }
     g_last_path = SHIFTND_PATH_STRIDED;
     return finish(strided_forward(g, p->dtype, x, w, wkind, wzp, fill, out, st));
@@ -201,7 +208,9 @@ size_t shiftnd_backward_workspace_bytes(const shiftnd_problem *p) {
     const size_t a = strided_backward_workspace(g);
     const size_t b = plane_backward_workspace(g, p->dtype);
     const size_t c = sweep_backward_workspace(g, p->dtype);
-    return a > b ? (a > c ? a : c) : (b > c ? b : c);
+    const size_t d = cl_backward_workspace(g);
+    const size_t m = a > b ? (a > c ? a : c) : (b > c ? b : c);
+    return m > d ? m : d;
 }
 
 int shiftnd_backward(const shiftnd_problem *p, const void *grad_out, const int64_t grad_out_strides[5], const void *x,
@@ -232,10 +241,16 @@ int shiftnd_backward(const shiftnd_problem *p, const void *grad_out, const int64
         g_last_path = SHIFTND_PATH_SWEEP;
         return finish(sweep_backward(g, p->dtype, grad_out, x, weights, grad_x, grad_w, workspace, st));
     }
-    if (can_plane && g_policy != 1) {
+    if (can_plane && g_policy != 1 && g_policy != 4) {
         if (plane_backward_workspace(g, p->dtype) > workspace_bytes) return SHIFTND_ERR_WORKSPACE_TOO_SMALL;
         g_last_path = SHIFTND_PATH_PLANE;
         return finish(plane_backward(g, p->dtype, grad_out, x, weights, grad_x, grad_w, workspace, st));
+    }
+    if (g_policy == 4 && !cl_backward_eligible(g, p->dtype)) return SHIFTND_ERR_INVALID_ARGUMENT;
+    if ((g_policy == 0 && cl_backward_preferred(g, p->dtype)) || g_policy == 4) {
+        if (cl_backward_workspace(g) > workspace_bytes) return SHIFTND_ERR_WORKSPACE_TOO_SMALL;
+        g_last_path = SHIFTND_PATH_CL;
+        return finish(cl_backward(g, p->dtype, grad_out, x, weights, grad_x, grad_w, workspace, st));
     }
     if (strided_backward_workspace(g) > workspace_bytes) return SHIFTND_ERR_WORKSPACE_TOO_SMALL;
     g_last_path = SHIFTND_PATH_STRIDED;

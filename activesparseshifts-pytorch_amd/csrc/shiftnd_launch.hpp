@@ -55,6 +55,17 @@ bool plane_pool_backward_eligible(const Geometry &g, int dtype, const void *gx);
 int plane_pool_backward(const Geometry &g, int dtype, const void *go, const void *x, const void *w, void *gx, void *gw,
                         void *workspace, hipStream_t st);
 
+// ---- channel-fastest kernels for channels-last tensors (shiftnd_cl.hip): any strides, x with unit channel stride --
+bool cl_forward_eligible(const Geometry &g);
+bool cl_forward_preferred(const Geometry &g);   // eligible and the output is channel-fastest too
+bool cl_backward_preferred(const Geometry &g, int dtype);
+int cl_forward(const Geometry &g, int dtype, const void *x, const void *w, int wkind, int64_t wzp, uint64_t fill_bits,
+               void *out, hipStream_t st);
+bool cl_backward_eligible(const Geometry &g, int dtype);
+size_t cl_backward_workspace(const Geometry &g);
+int cl_backward(const Geometry &g, int dtype, const void *go, const void *x, const void *w, void *gx, void *gw,
+                void *workspace, hipStream_t st);
+
 // ---- sweep kernels (shiftnd_sweep.hip): one 16-byte chunk per thread, XCD-contiguous grid ----------
 bool sweep_forward_eligible(const Geometry &g, int dtype, const void *x, const void *out);
 int sweep_forward(const Geometry &g, int dtype, const void *x, const void *w, int wkind, int64_t wzp, uint64_t fill_bits,

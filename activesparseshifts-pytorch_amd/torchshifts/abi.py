@@ -12,7 +12,7 @@ import torch
 _LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libshiftnd_hip.so")
 
 F32, F64, F16, BF16, I8, U8, I32 = range(7)
-PATH_NONE, PATH_EMPTY, PATH_PLANE, PATH_STRIDED, PATH_SWEEP = range(5)
+PATH_NONE, PATH_EMPTY, PATH_PLANE, PATH_STRIDED, PATH_SWEEP, PATH_CL = range(6)
 
 DTYPES = {torch.float32: F32, torch.float64: F64, torch.float16: F16, torch.bfloat16: BF16,
           torch.int8: I8, torch.uint8: U8, torch.int32: I32}

@@ -77,7 +77,8 @@ typedef enum shiftnd_path {
     SHIFTND_PATH_EMPTY = 1,   /* zero-element problem: nothing launched */
     SHIFTND_PATH_PLANE = 2,   /* per-(N,C)-plane kernels, LDS index maps, 16-byte rows */
     SHIFTND_PATH_STRIDED = 3, /* generic strided fallback (channels-last, ragged rows, huge dims) */
-    SHIFTND_PATH_SWEEP = 4    /* one 16-byte chunk per thread, XCD-contiguous sweep (the HBM-rate path) */
+    SHIFTND_PATH_SWEEP = 4,   /* one 16-byte chunk per thread, XCD-contiguous sweep (the HBM-rate path) */
+    SHIFTND_PATH_CL = 5       /* channels-last input: lanes = consecutive channels of a pixel */
 } shiftnd_path;
 
 /* Problem geometry shared by the entry points. */
@@ -95,8 +96,8 @@ SHIFTND_API const char *shiftnd_status_string(int status);
 SHIFTND_API int shiftnd_last_path(void);
 /* Diagnostics: name (without template arguments) of the main kernel the last call on this thread launched. */
 SHIFTND_API const char *shiftnd_last_kernel(void);
-/* 0 = automatic (sweep, else plane, else strided), 1 = force the strided fallback,
- * 2 = plane kernels or fail, 3 = sweep kernels or fail (testing). */
+/* 0 = automatic (sweep, else plane, else channels-last, else strided), 1 = force the strided fallback,
+ * 2 = plane kernels or fail, 3 = sweep kernels or fail, 4 = channels-last kernels or fail (testing). */
 SHIFTND_API void shiftnd_set_path_policy(int policy);
 /* Diagnostics: launch-planning knobs of the plane kernels (0: minimum workgroups wanted, 1: target
  * bytes per workgroup, 2: gather-forward unroll).  Results never depend on them. */

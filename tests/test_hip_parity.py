@@ -67,7 +67,7 @@ def test_golden_random_grid(abi):
         assert rel_err(gw.cpu().numpy(), gw_r) < tol, "grad_w " + key
 
 
-@pytest.mark.parametrize("policy", [0, 1, 2, 3])
+@pytest.mark.parametrize("policy", [0, 1, 2, 3, 4])
 def test_golden_quantized(abi, policy):
     abi.set_path_policy(policy)
     tdt = {"quint8": torch.uint8, "qint8": torch.int8, "qint32": torch.int32}
@@ -81,8 +81,16 @@ def test_golden_quantized(abi, policy):
         b, _ = abi.check_borders(list(xq.shape), crop, nd)
         if policy in (2, 3) and layout != "nchw":
             continue  # plane / sweep kernels need contiguous NC[spatial] tensors
-        out = abi.forward_quantized(x, w, wzp, xzp, pad, b)
+        if policy == 4 and (layout == "nchw" or x.shape[1] < 2):
+            continue  # the channel-fastest kernels serve channels-last inputs
+        out = None
+        if layout != "nchw":  # the quantized op keeps the input's channels-last format (shifts_quantized.cpp:119-121)
+            out = torch.empty(abi.out_shape(x, b), dtype=x.dtype, device=DEV).contiguous(
+                memory_format=torch.channels_last if layout == "cl" else torch.channels_last_3d)
+        out = abi.forward_quantized(x, w, wzp, xzp, pad, b, out=out)
         assert np.array_equal(out.cpu().numpy(), out_r), key
+        if layout != "nchw" and policy in (0, 4) and x.shape[1] > 1:
+            assert abi.last_path() == abi.PATH_CL and abi.last_kernel() == "cl_gather_forward", key
         if policy in (0, 2, 3) and layout == "nchw":
             assert abi.last_path() == (abi.PATH_SWEEP if policy == 3 else abi.PATH_PLANE), key
     abi.set_path_policy(0)
@@ -221,7 +229,8 @@ def test_quantized_random_vs_oracle(abi):
 
 
 def test_strided_inputs_and_empty(abi):
-    """channels-last / sliced inputs take the strided path and equal the contiguous result; empty tensors are no-ops"""
+    """channels-last inputs take the channel-fastest kernels, sliced inputs the strided path; both equal the
+    contiguous result; empty tensors are no-ops"""
     torch.manual_seed(0)
     x = torch.rand(3, 6, 10, 16, device=DEV)
     w = (torch.rand(6, 2, device=DEV) - 0.5) * 6
@@ -231,9 +240,10 @@ def test_strided_inputs_and_empty(abi):
             ref = abi.forward(x, w, pad, active)
             xcl = x.contiguous(memory_format=torch.channels_last)
             out = abi.forward(xcl, w, pad, active)
-            assert abi.last_path() == abi.PATH_STRIDED and torch.equal(out, ref)
+            assert abi.last_path() == abi.PATH_STRIDED and torch.equal(out, ref)  # NCHW output: pixel-fastest kernels
             xs = torch.rand(3, 6, 10, 32, device=DEV)[..., ::2]
             assert torch.equal(abi.forward(xs, w, pad, active), abi.forward(xs.contiguous(), w, pad, active))
+            assert abi.last_path() == abi.PATH_PLANE  # (the second call; the sliced one ran the strided kernels)
             gref = abi.backward(go, w, x, pad, active)
             gx, gw = abi.backward(go.contiguous(memory_format=torch.channels_last), w, xcl, pad, active)
             assert torch.equal(gx, gref[0]) and rel_err(gw.cpu().numpy(), gref[1].cpu().numpy()) < 1e-5
@@ -386,3 +396,73 @@ def test_huge_and_special_shifts_on_device(abi):
                     assert rel_err(gw.cpu().numpy(), gw_o) < 1e-12, (policy, pad, active)
     finally:
         abi.set_path_policy(0)
+
+
+@pytest.mark.parametrize("dt", ["f32", "f64"])
+def test_channels_last_kernels_vs_oracle(abi, dt):
+    """channels-last inputs run the channel-fastest kernels (policy 0 picks them, policy 4 forces them): forward
+    (NCHW-contiguous output, like the reference, and channels-last output), backward with channels-last and
+    contiguous grad_out / grad_x, every padding mode, crops, huge shifts; bit-exact vs the oracle (grad_w <= 1e-5)"""
+    npdt = _np_dt(dt)
+    rs = np.random.RandomState(21)
+    for shape, crop, fmt in [((2, 8, 9, 12), None, torch.channels_last), ((3, 300, 6, 5), None, torch.channels_last),
+                             ((2, 5, 11, 7), [[2, 1], [1, 3]], torch.channels_last),
+                             ((2, 6, 4, 5, 6), None, torch.channels_last_3d),
+                             ((1, 3, 5, 4, 7), [[1, 0], [0, 1], [2, 2]], torch.channels_last_3d)]:
+        nd = len(shape) - 2
+        x = rs.uniform(-1, 1, size=shape).astype(npdt)
+        w = _weights(rs, shape[1], nd, shape[2:]).astype(npdt)
+        b, new = abi.check_borders(list(shape), crop, nd)
+        go = rs.uniform(-1, 1, size=new).astype(npdt)
+        xd = _dev(x).contiguous(memory_format=fmt)
+        wd = _dev(w)
+        for pad in range(5):
+            for active in (0, 1):
+                ref = O.forward(x, w, pad, active, b)
+                gx_o, _ = O.backward(go, w, x, pad, active, b)
+                _, gw64 = O.backward(go.astype(np.float64), w.astype(np.float64), x.astype(np.float64), pad, active, b)
+                for policy in (0, 4):  # 0 picks the channel-fastest kernels when every tensor is channels-last
+                    abi.set_path_policy(policy)
+                    out = abi.forward(xd, wd, pad, active, b)  # NCHW-contiguous output (shifts_cpu.cpp:221)
+                    assert abi.last_path() == (abi.PATH_CL if policy == 4 else abi.PATH_STRIDED), (shape, pad, active)
+                    assert np.array_equal(out.cpu().numpy(), ref), (shape, pad, active)
+                    out_cl = torch.empty(new, dtype=xd.dtype, device=DEV).contiguous(memory_format=fmt)
+                    abi.forward(xd, wd, pad, active, b, out=out_cl)
+                    assert abi.last_path() == abi.PATH_CL, (shape, pad, active)
+                    assert abi.last_kernel() == ("cl_active_forward" if active else "cl_gather_forward")
+                    assert np.array_equal(out_cl.cpu().numpy(), ref), (shape, pad, active)
+                    for god in (_dev(go), _dev(go).contiguous(memory_format=fmt)):
+                        for gxd in (torch.empty_like(xd), torch.empty(shape, dtype=xd.dtype, device=DEV)):
+                            gx, gw = abi.backward(god, wd, xd, pad, active, b, grad_x=gxd)
+                            all_cl = god.stride(1) == 1 and gxd.stride(1) == 1
+                            assert abi.last_path() == (abi.PATH_CL if (policy == 4 or all_cl) else abi.PATH_STRIDED)
+                            assert np.array_equal(gx.cpu().numpy(), gx_o), (shape, pad, active)
+                            assert rel_err(gw.cpu().numpy(), gw64) < (1e-12 if dt == "f64" else 1e-5), (shape, pad, active)
+                abi.set_path_policy(0)
+
+
+def test_channels_last_16bit_and_large(abi):
+    """bf16 channels-last (one RNE rounding) and a large channels-last problem against the NCHW kernels"""
+    torch.manual_seed(4)
+    x = torch.rand(8, 192, 56, 56, device=DEV)
+    w = torch.rand(192, 2, device=DEV) * 6 - 3
+    go = torch.rand_like(x)
+    xc = x.contiguous(memory_format=torch.channels_last)
+    for pad, active in ((0, 0), (3, 1), (2, 0)):
+        ref = abi.forward(x, w, pad, active)
+        gx_r, gw_r = abi.backward(go, w, x, pad, active)
+        out = abi.forward(xc, w, pad, active, out=torch.empty_like(xc))
+        assert abi.last_path() == abi.PATH_CL and torch.equal(out, ref)
+        gx, gw = abi.backward(go.contiguous(memory_format=torch.channels_last), w, xc, pad, active, grad_x=torch.empty_like(xc))
+        assert abi.last_path() == abi.PATH_CL and torch.equal(gx, gx_r)
+        assert rel_err(gw.cpu().numpy(), gw_r.cpu().numpy()) < 1e-5
+    xb, wb, gb = x.bfloat16(), w.bfloat16(), go.bfloat16()
+    xbc = xb.contiguous(memory_format=torch.channels_last)
+    for pad, active in ((0, 0), (4, 1)):
+        ref = abi.forward(xb, wb, pad, active)
+        out = abi.forward(xbc, wb, pad, active, out=torch.empty_like(xbc))
+        assert abi.last_path() == abi.PATH_CL and torch.equal(out, ref)
+        gx_r, gw_r = abi.backward(gb, wb, xb, pad, active)
+        gx, gw = abi.backward(gb, wb, xbc, pad, active, grad_x=torch.empty_like(xbc))
+        assert torch.equal(gx, gx_r)
+        assert rel_err(gw.float().cpu().numpy(), gw_r.float().cpu().numpy()) < 2 * torch.finfo(torch.bfloat16).eps

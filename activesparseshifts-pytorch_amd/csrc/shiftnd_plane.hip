@@ -732,6 +732,39 @@ struct LdsStager {
     }
 
     // LDS-DMA: piece q = 16 bytes; lanes of a wave take consecutive pieces (the LDS destination is linear)
+    // Which pieces a thread moves never changes from step to step: piece k of a thread is q = k * kThreads + tid.
+    // Its (slot, column piece) pair is decoded once, packed as slot * 256 + j (or -1), and the per-step work is the
+    // slot-table read, one address and the DMA.  For steps of at most kRegPieces pieces per thread (cpr <= 256).
+    static constexpr int kRegPieces = 3;
+    __host__ __device__ static bool pieces_fit(int cpr, int R) {
+        return Shape::slots(R) * cpr <= kRegPieces * kThreads && cpr <= 256;
+    }
+    __device__ static void decode_pieces(const PlaneParams &p, int R, int (&pk)[kRegPieces]) {
+        const int pieces = Shape::slots(R) * static_cast<int>(p.cpr);
+#pragma unroll
+        for (int k = 0; k < kRegPieces; ++k) {
+            const int q = k * kThreads + static_cast<int>(threadIdx.x);
+            const int slot = fdiv(q, p.d_cpr);
+            pk[k] = q < pieces ? slot * 256 + (q - slot * static_cast<int>(p.cpr)) : -1;
+        }
+    }
+    __device__ static void issue_dma_decoded(int NX, const S *xp, const S *gp, const int *slot_src, char *tile,
+                                             const int (&pk)[kRegPieces]) {
+#pragma unroll
+        for (int k = 0; k < kRegPieces; ++k) {
+            if (pk[k] >= 0) {
+                const int slot = pk[k] >> 8;
+                const int src = slot_src[slot];
+                if (src >= 0) {
+                    const S *g = (slot < NX ? xp : gp) + src + (pk[k] & 255) * E;
+                    char *dst_wave = tile + (k * kThreads + (threadIdx.x & ~63)) * 16;  // wave-uniform; hardware adds lane * 16
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)g,
+                                                     (__attribute__((address_space(3))) void *)dst_wave, 16, 0, 0);
+                }
+            }
+        }
+    }
+
     __device__ static void issue_dma(const PlaneParams &p, int R, const S *xp, const S *gp, const int *slot_src, char *tile,
                                      int aux = 0) {
         const int NX = Shape::nx(R);
@@ -845,7 +878,8 @@ __device__ __forceinline__ void lds_corners(const char *tile, int RB, int R, int
     }
 }
 
-template <typename T, int ND, bool ACTIVE, int TILES, bool POOL = false>
+// DEC: the step's DMA pieces per thread fit the pre-decoded form (LdsStager::pieces_fit, checked by the host)
+template <typename T, int ND, bool ACTIVE, int TILES, bool POOL = false, bool DEC = false>
 __global__ __launch_bounds__(kThreads) void plane_backward_lds(const PlaneParams p) {
     using S = typename T::S;
     using CT = typename T::C;
@@ -897,6 +931,8 @@ __global__ __launch_bounds__(kThreads) void plane_backward_lds(const PlaneParams
     // of step s must survive until every wave has passed the barrier of step s+1 (three tables)
     constexpr int NT = TILES == 2 ? 3 : 2;
     const int aux = NT * NS;  // POOL: a second set of tables behind the slot tables
+    int pk[Stager::kRegPieces];
+    if constexpr (DEC) Stager::decode_pieces(p, R, pk);
     int nl = 0, r0 = wi.row0, buf = 0, tb = 0;
     {
         const int a = fdiv(r0, p.d_dim1);
@@ -913,7 +949,8 @@ __global__ __launch_bounds__(kThreads) void plane_backward_lds(const PlaneParams
         const S *xp = static_cast<const S *>(p.x) + plane * p.x_plane;
         const S *gp = static_cast<const S *>(p.go) + plane * p.o_plane;
         S *gxp = static_cast<S *>(p.out) + plane * p.x_plane;
-        Stager::issue_dma(p, R, xp, gp, ss, tile, aux);
+        if constexpr (DEC) Stager::issue_dma_decoded(NX, xp, gp, ss, tile, pk);
+        else Stager::issue_dma(p, R, xp, gp, ss, tile, aux);
         int nl2 = nl, r2 = r0 + Rn;
         if (r2 >= row_end) { r2 = wi.row0; ++nl2; }
         if (nl2 < wi.nn) {
@@ -1244,7 +1281,7 @@ void fill_params(PlaneParams &p, const Geometry &g, const Plan &pl, int64_t dim1
     p.CP = pl.CP;
     p.rows = pl.rows;
     p.d_rows = make_fastdiv(static_cast<uint32_t>(pl.rows_per_band));
-    p.lds_affine = g_tune[5] == 0;
+    p.lds_affine = g_tune[5] != 1;
     p.xcd_blocks = (g_tune[6] && pl.grid % 8 == 0) ? pl.grid / 8 : 0;
     p.d_cpr = make_fastdiv(static_cast<uint32_t>(pl.cpr));
     p.d_dim1 = make_fastdiv(static_cast<uint32_t>(dim1));
@@ -1343,13 +1380,20 @@ void launch_backward_a(const PlaneParams &p_in, const Plan &pl, hipStream_t st) 
             // 16-bit dtypes by default (C5 backward 2.46 -> 2.21 ms; fp32 C2 1.84 -> 1.96 ms), knob 4 = 2 / 3 forces on / off
             const bool want_two = g_tune[4] == 2 || (g_tune[4] != 3 && sizeof(typename T::S) == 2);
             const bool two = want_two && lds_bytes + tile_bytes + slots * sizeof(int) <= 64 * 1024;
+            const size_t lds2 = lds_bytes + tile_bytes + slots * sizeof(int);
+            // few pieces per thread and step: the pre-decoded DMA form (knob 5 = 2 keeps the generic loop)
+            const bool dec = g_tune[5] != 2 && (p.nd == 3 ? LdsStager<T, 3, ACTIVE, true>::pieces_fit(pl.cpr, pl.RPS)
+                                                          : LdsStager<T, 2, ACTIVE, true>::pieces_fit(pl.cpr, pl.RPS));
+#define SHIFTND_BWD_LDS(NDV, TL, DECV, BYTES) \
+    hipLaunchKernelGGL((plane_backward_lds<T, NDV, ACTIVE, TL, false, DECV>), dim3(pl.grid), dim3(kThreads), BYTES, st, p)
             if (p.nd == 3) {
-                if (two) hipLaunchKernelGGL((plane_backward_lds<T, 3, ACTIVE, 2>), dim3(pl.grid), dim3(kThreads), lds_bytes + tile_bytes + slots * sizeof(int), st, p);
-                else hipLaunchKernelGGL((plane_backward_lds<T, 3, ACTIVE, 1>), dim3(pl.grid), dim3(kThreads), lds_bytes, st, p);
+                if (two) { if (dec) SHIFTND_BWD_LDS(3, 2, true, lds2); else SHIFTND_BWD_LDS(3, 2, false, lds2); }
+                else { if (dec) SHIFTND_BWD_LDS(3, 1, true, lds_bytes); else SHIFTND_BWD_LDS(3, 1, false, lds_bytes); }
             } else {
-                if (two) hipLaunchKernelGGL((plane_backward_lds<T, 2, ACTIVE, 2>), dim3(pl.grid), dim3(kThreads), lds_bytes + tile_bytes + slots * sizeof(int), st, p);
-                else hipLaunchKernelGGL((plane_backward_lds<T, 2, ACTIVE, 1>), dim3(pl.grid), dim3(kThreads), lds_bytes, st, p);
+                if (two) { if (dec) SHIFTND_BWD_LDS(2, 2, true, lds2); else SHIFTND_BWD_LDS(2, 2, false, lds2); }
+                else { if (dec) SHIFTND_BWD_LDS(2, 1, true, lds_bytes); else SHIFTND_BWD_LDS(2, 1, false, lds_bytes); }
             }
+#undef SHIFTND_BWD_LDS
             return;
         }
     }

@@ -750,16 +750,23 @@ struct LdsStager {
     }
     __device__ static void issue_dma_decoded(int NX, const S *xp, const S *gp, const int *slot_src, char *tile,
                                              const int (&pk)[kRegPieces]) {
+        const int wave = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x) >> 6);
 #pragma unroll
         for (int k = 0; k < kRegPieces; ++k) {
             if (pk[k] >= 0) {
                 const int slot = pk[k] >> 8;
                 const int src = slot_src[slot];
                 if (src >= 0) {
-                    const S *g = (slot < NX ? xp : gp) + src + (pk[k] & 255) * E;
-                    char *dst_wave = tile + (k * kThreads + (threadIdx.x & ~63)) * 16;  // wave-uniform; hardware adds lane * 16
-                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)g,
-                                                     (__attribute__((address_space(3))) void *)dst_wave, 16, 0, 0);
+                    // uniform base + 32-bit lane offset (planes are < 2^30 elements): the SGPR-base address form, one
+                    // instruction per array instead of a per-lane 64-bit pointer select
+                    const uint32_t off = static_cast<uint32_t>(src + (pk[k] & 255) * E) * static_cast<uint32_t>(sizeof(S));
+                    char *dst_wave = tile + (k * kThreads + wave * 64) * 16;  // wave-uniform; hardware adds lane * 16
+                    if (slot < NX)
+                        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(reinterpret_cast<const char *>(xp) + off),
+                                                         (__attribute__((address_space(3))) void *)dst_wave, 16, 0, 0);
+                    else
+                        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(reinterpret_cast<const char *>(gp) + off),
+                                                         (__attribute__((address_space(3))) void *)dst_wave, 16, 0, 0);
                 }
             }
         }
@@ -939,16 +946,18 @@ __global__ __launch_bounds__(kThreads) void plane_backward_lds(const PlaneParams
         Stager::make_slots(p, R, a, r0 - a * S1, step_len(r0), m0, m1, g0, g1, slot_src, aux);
     }
     __syncthreads();
+    // plane bases advance by one batch entry (C planes) when the row walk wraps: no 64-bit products in the loop
+    const int64_t plane0 = static_cast<int64_t>(wi.n0) * p.C + wi.c;
+    const S *xp = static_cast<const S *>(p.x) + plane0 * p.x_plane;
+    const S *gp = static_cast<const S *>(p.go) + plane0 * p.o_plane;
+    S *gxp = static_cast<S *>(p.out) + plane0 * p.x_plane;
+    const int64_t xstep = static_cast<int64_t>(p.C) * p.x_plane, gstep = static_cast<int64_t>(p.C) * p.o_plane;
     while (nl < wi.nn) {
         const int a = fdiv(r0, p.d_dim1);
         const int b0 = r0 - a * S1;
         const int Rn = step_len(r0);
         const int *ss = slot_src + tb * NS;
         char *tile = tile0 + (TILES == 2 ? buf * p.tile_bytes : 0);
-        const int64_t plane = static_cast<int64_t>(wi.n0 + nl) * p.C + wi.c;
-        const S *xp = static_cast<const S *>(p.x) + plane * p.x_plane;
-        const S *gp = static_cast<const S *>(p.go) + plane * p.o_plane;
-        S *gxp = static_cast<S *>(p.out) + plane * p.x_plane;
         if constexpr (DEC) Stager::issue_dma_decoded(NX, xp, gp, ss, tile, pk);
         else Stager::issue_dma(p, R, xp, gp, ss, tile, aux);
         int nl2 = nl, r2 = r0 + Rn;
@@ -1005,6 +1014,11 @@ __global__ __launch_bounds__(kThreads) void plane_backward_lds(const PlaneParams
         if (TILES == 1) __syncthreads();  // one tile: it is overwritten by the next step
         // (two tiles: the next step writes the other tile, last read before this step's barrier, and the slot table
         //  it uses was completed before that barrier too -- it is rewritten only after the next barrier)
+        if (nl2 != nl) {
+            xp += xstep;
+            gp += gstep;
+            gxp += xstep;
+        }
         nl = nl2;
         r0 = r2;
         buf ^= 1;

@@ -9,7 +9,9 @@ import os
 
 import torch
 
-_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libshiftnd_hip.so")
+# SHIFTND_HIP_LIB: another build of the library (kernel A/B runs with tools/kbench.py); the dispatcher ops in _C.so
+# always use the in-tree library
+_LIB_PATH = os.environ.get("SHIFTND_HIP_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "libshiftnd_hip.so")
 
 F32, F64, F16, BF16, I8, U8, I32 = range(7)
 PATH_NONE, PATH_EMPTY, PATH_PLANE, PATH_STRIDED, PATH_SWEEP, PATH_CL = range(6)

@@ -218,6 +218,19 @@ def main():
 
     if rank == 0:
         achieved = dom_bytes / dom_ms / 1e6  # GB/s
+        # HBM bytes per launch of the dominant kernel from the PMC passes of this same command (profiles/collect.sh
+        # cannot run inside the timed process: counters need their own rocprofv3 runs); null when no profile of this
+        # workload is committed
+        traffic, traffic_src = None, None
+        tpath = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_%s_traffic.json" % a.workload)
+        if a.pad == 0 and os.path.exists(tpath):
+            try:
+                tj = json.load(open(tpath))
+                t = tj["per_launch"].get(dom_name)
+                if t and "read_bytes" in t and "written_bytes" in t:
+                    traffic, traffic_src = t["read_bytes"] + t["written_bytes"], "profiles/" + os.path.basename(tpath)
+            except (OSError, ValueError, KeyError):
+                pass
         step_bytes = (2 if quant else 5) * esize * elems
         result = {
             "metric": "Gelem/s, Shift2d fwd+bwd N64/C256/224x224" if a.workload == "c2" else "Gelem/s, " + desc,
@@ -238,8 +251,8 @@ def main():
                                % (nd, path)},
             "achieved_hbm_GBps_step": step_bytes / (ms_per_step * 1e-3) / 1e9,
             "roofline": {"bound": "hbm", "kernel": dom_name, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None, "avg_kernel_ms": dom_ms,
-                         "algorithmic_bytes": dom_bytes},
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
+                         "avg_kernel_ms": dom_ms, "algorithmic_bytes": dom_bytes},
             "kernels": kernels,
         }
         if base is not None:

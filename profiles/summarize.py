@@ -14,6 +14,7 @@ def short(name):
 
 
 def main(root):
+    traffic = defaultdict(dict)  # kernel base name -> {"read_bytes", "written_bytes"} per launch (for bench.py)
     for f in glob.glob(os.path.join(root, "trace", "**", "*kernel_trace.csv"), recursive=True):
         dur = defaultdict(list)
         for r in csv.DictReader(open(f)):
@@ -35,11 +36,22 @@ def main(root):
                 for c, v in ctrs.items():
                     avg = sum(v) / len(v)
                     note = ""
+                    base = k.split("<")[0].split("(")[0].strip()
                     if c == "FETCH_SIZE":
                         note = "  KB/launch; x2 (gfx950 correction) = %.3f GB read" % (avg * 2 * 1024 / 1e9)
+                        traffic[base]["read_bytes"] = avg * 2 * 1024
                     if c == "WRITE_SIZE":
                         note = "  KB/launch = %.3f GB written" % (avg * 1024 / 1e9)
+                        traffic[base]["written_bytes"] = avg * 1024
                     print("%-70s %-28s avg %16.1f over %d launches%s" % (k[:70], c, avg, len(v), note))
+
+
+    if traffic:
+        import json
+        with open(os.path.join(root, "traffic.json"), "w") as fh:
+            json.dump({"source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of bench.py (profiles/collect.sh); "
+                                 "FETCH_SIZE doubled per the gfx950 correction of MI355X_MICROARCH.md",
+                       "per_launch": traffic}, fh, indent=1)
 
 
 if __name__ == "__main__":

@@ -159,7 +159,7 @@ __global__ __launch_bounds__(kThreads) void cl_active_forward(const ClParams p) 
                 const S raw = xn[(ro >= 0 ? ro : 0) + (cc >= 0 ? cc * p.xs[3] : 0)];
                 v[q] = (ro >= 0 && cc >= 0) ? widen<T>(raw) : CT(0);
             }
-            orow[j * p.os[3]] = narrow<T>(interp_nd<ND, CT>(v, dw));
+            orow[j * p.os[3]] = narrow<T>(interp_t<T, ND>(v, dw));
         }
     }
 }
@@ -234,7 +234,7 @@ __global__ __launch_bounds__(kThreads) void cl_backward(const ClParams p) {
                         const S raw = gon[ok ? ro + cc * p.os[3] : 0];
                         v[q] = ok ? widen<T>(raw) : CT(0);
                     }
-                    gxrow[j * p.gs[3]] = narrow<T>(pass ? interp_nd<ND, CT>(v, dw) : CT(0));
+                    gxrow[j * p.gs[3]] = narrow<T>(pass ? interp_t<T, ND>(v, dw) : CT(0));
                 } else {
                     const int gc = pass ? fold_dim(o2 - csg[2], p.O[2], p.pad) : -1;
                     const bool ok = pass && goff[0] >= 0 && gc >= 0;

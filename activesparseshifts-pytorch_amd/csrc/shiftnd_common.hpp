@@ -172,6 +172,12 @@ __device__ __forceinline__ void prep_shift_backward(CT w, bool active, int64_t &
 // v1*(1-x)+v2*x is two multiplies and one add, as in the reference's x86-64 CPU build.
 // Corner order (shifts_kernels.h:58-103): bit0 = +1 along H, bit1 = +1 along W, bit2 = +1 along D.
 // ---------------------------------------------------------------------------------------------
+// fused multiply-add, for the weight-gradient sums and the 16-bit interpolation (the library is built with -ffp-contract=off because the
+// interpolation must round like the reference's mul + mul + add; the sums carry a 1e-5 tolerance and are exact
+// either way on exactly representable data)
+__device__ __forceinline__ float fma_ct(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+__device__ __forceinline__ double fma_ct(double a, double b, double c) { return __builtin_fma(a, b, c); }
+
 template <typename CT> __device__ __forceinline__ CT lerp1(CT v1, CT v2, CT x) { return v1 * (CT(1) - x) + v2 * x; }
 
 template <int ND, typename CT> __device__ __forceinline__ CT interp_nd(const CT *v, const CT *d) {
@@ -184,6 +190,28 @@ template <int ND, typename CT> __device__ __forceinline__ CT interp_nd(const CT 
         const CT b = lerp1(lerp1(v[4], v[5], d[0]), lerp1(v[6], v[7], d[0]), d[1]);
         return lerp1(a, b, d[2]);
     }
+}
+
+// Interpolation as the kernels call it.  fp32 / fp64 tensors: the reference's expression, bit for bit.  16-bit
+// tensors have no executable reference arithmetic (fp32 math on widened inputs, one rounding to
+// the 16-bit type, compared within 1 ulp of that type), so each lerp is v1*(1-x) folded into one multiply and one
+// fused multiply-add: a third fewer instructions in kernels that are instruction-bound for 16-bit data, and not less
+// accurate.  Every kernel family uses this one definition, so they agree bit for bit with each other.
+template <typename CT> __device__ __forceinline__ CT lerp1_fused(CT v1, CT v2, CT x) { return fma_ct(v2, x, v1 * (CT(1) - x)); }
+template <int ND, typename CT> __device__ __forceinline__ CT interp_nd_fused(const CT *v, const CT *d) {
+    if constexpr (ND == 1) {
+        return lerp1_fused(v[0], v[1], d[0]);
+    } else if constexpr (ND == 2) {
+        return lerp1_fused(lerp1_fused(v[0], v[1], d[0]), lerp1_fused(v[2], v[3], d[0]), d[1]);
+    } else {
+        const CT a = lerp1_fused(lerp1_fused(v[0], v[1], d[0]), lerp1_fused(v[2], v[3], d[0]), d[1]);
+        const CT b = lerp1_fused(lerp1_fused(v[4], v[5], d[0]), lerp1_fused(v[6], v[7], d[0]), d[1]);
+        return lerp1_fused(a, b, d[2]);
+    }
+}
+template <typename T, int ND> __device__ __forceinline__ typename T::C interp_t(const typename T::C *v, const typename T::C *d) {
+    if constexpr (sizeof(typename T::S) == 2) return interp_nd_fused<ND, typename T::C>(v, d);
+    else return interp_nd<ND, typename T::C>(v, d);
 }
 
 // compute_weight_gradients (shifts_kernels.h:132-154), including the reference's 2-D "dx" wiring

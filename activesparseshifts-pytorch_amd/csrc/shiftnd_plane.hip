@@ -265,7 +265,7 @@ __global__ __launch_bounds__(kThreads) void plane_active_forward(const PlanePara
                 CT v[1 << ND];
 #pragma unroll
                 for (int q = 0; q < (1 << ND); ++q) v[q] = vals[q & (NC - 1)][e + (q >> (ND - 1))];
-                res.e[e] = narrow<T>(interp_nd<ND, CT>(v, dw));
+                res.e[e] = narrow<T>(interp_t<T, ND>(v, dw));
             }
             store_chunk<S, E>(out + plane * p.o_plane + static_cast<int64_t>(r) * O2 + jo, res);
         }
@@ -377,7 +377,7 @@ __global__ __launch_bounds__(kThreads) void plane_pool_forward(const PlaneParams
                                 const int b2 = (q >> (ND - 1)) & 1;
                                 v[q] = sv[u0 + b0][u1 + b1][u2 + b2];
                             }
-                            val = widen<T>(narrow<T>(interp_nd<ND, CT>(v, dw)));
+                            val = widen<T>(narrow<T>(interp_t<T, ND>(v, dw)));
                         } else {
                             val = sv[u0][u1][u2];
                         }
@@ -401,7 +401,7 @@ __global__ __launch_bounds__(kThreads) void plane_pool_forward(const PlaneParams
                                 const int ra = m0[i0 + b0], rb = m1[i1 + b1], rc = m2[i2 + b2];
                                 v[q] = (ra >= 0 && rb >= 0 && rc >= 0) ? widen<T>(xp[(ra * S1 + rb) * S2 + rc]) : CT(0);
                             }
-                            acc = acc + widen<T>(narrow<T>(interp_nd<ND, CT>(v, dw)));
+                            acc = acc + widen<T>(narrow<T>(interp_t<T, ND>(v, dw)));
                         } else {
                             const int ra = m0[i0], rb = m1[i1], rc = m2[i2];
                             acc = acc + ((ra >= 0 && rb >= 0 && rc >= 0) ? widen<T>(xp[(ra * S1 + rb) * S2 + rc]) : CT(0));
@@ -597,7 +597,7 @@ __global__ __launch_bounds__(kThreads) void plane_backward(const PlaneParams p) 
                         CT v[1 << ND];
 #pragma unroll
                         for (int q = 0; q < (1 << ND); ++q) v[q] = vals[q & (NC - 1)][e + (q >> (ND - 1))];
-                        const CT r1 = interp_nd<ND, CT>(v, dw);
+                        const CT r1 = interp_t<T, ND>(v, dw);
                         res.e[e] = narrow<T>(((inmask >> e) & 1u) ? r1 : CT(0));
                     }
                 } else {
@@ -979,7 +979,7 @@ __global__ __launch_bounds__(kThreads) void plane_backward_lds(const PlaneParams
                     CT v[1 << ND];
 #pragma unroll
                     for (int q = 0; q < (1 << ND); ++q) v[q] = gv[q & (NC - 1)][e + (q >> (ND - 1))];
-                    res.e[e] = narrow<T>(interp_nd<ND, CT>(v, dw));
+                    res.e[e] = narrow<T>(interp_t<T, ND>(v, dw));
                 }
                 __builtin_amdgcn_sched_barrier(0);
             } else {
@@ -1005,7 +1005,7 @@ __global__ __launch_bounds__(kThreads) void plane_backward_lds(const PlaneParams
                 corner_diffs<ND, CT>(v, df);
                 const CT gval = widen<T>(gch.e[e]);
 #pragma unroll
-                for (int i = 0; i < NDIFF; ++i) part[i] += gval * df[i];
+                for (int i = 0; i < NDIFF; ++i) part[i] = fma_ct(gval, df[i], part[i]);  // one rounding per term: fewer instructions, not less accurate
             }
 #pragma unroll
             for (int i = 0; i < NDIFF; ++i) dsum[i] += static_cast<double>(part[i]);
@@ -1197,7 +1197,7 @@ __global__ __launch_bounds__(kThreads) void plane_active_forward_lds(const Plane
                 CT v[1 << ND];
 #pragma unroll
                 for (int q = 0; q < (1 << ND); ++q) v[q] = xv[q & (NC - 1)][e + (q >> (ND - 1))];
-                res.e[e] = narrow<T>(interp_nd<ND, CT>(v, dw));
+                res.e[e] = narrow<T>(interp_t<T, ND>(v, dw));
             }
             store_chunk<S, E>(op + static_cast<int64_t>(a * S1 + b0 + tr) * S2 + ji, res);
         }
@@ -1223,10 +1223,10 @@ bool contiguous(const int64_t st[5], int64_t N, int64_t C, const int64_t sz[3]) 
 }
 
 // diagnostics knobs (shiftnd_set_tuning): 0 = min workgroups wanted, 1 = target bytes per workgroup,
-// 2 = gather-forward unroll (fp32/16-byte variant only), 6 = XCD-contiguous workgroup ids, 7 = minimum workgroups
-// wanted by the backward kernels (row bands of a plane share source rows through their XCD's L2), 3 = backward / active-forward kernel: 2 LDS-staged where it applies (default), 1 direct global loads;
+// 2 = gather-forward unroll (fp32/16-byte variant only), 6 = XCD-contiguous workgroup ids, 7 = workgroups
+// wanted by the backward kernels (0 = automatic, see backward_min_wgs), 3 = backward / active-forward kernel: 2 LDS-staged where it applies (default), 1 direct global loads;
 // 4 = LDS tiles of the backward kernel: 1 automatic, 2 two tiles + one barrier per step, 3 one tile; 5 = 1: no affine dword reads
-int g_tune[8] = {2048, 128 * 1024, 4, 2, 1, 0, 1, 65536};
+int g_tune[8] = {2048, 128 * 1024, 4, 2, 1, 0, 1, 0};
 
 struct Plan {
     int V, cpr, CW, RPS, CP, ppw, groups, bands, rows_per_band, rows;
@@ -1481,9 +1481,21 @@ int launch_backward(const PlaneParams &p, const Plan &pl, bool active, void *gw,
     return SHIFTND_OK;
 }
 
+// Workgroups wanted by the backward kernels (knob 7 overrides).  Measured on MI355X (tools/kbench.py --knobs 7=...):
+// the 2-D SSL kernel on 4-byte data (62 VGPRs, 8 workgroups per CU) is fastest with large planes cut into ~14-step
+// row bands (C2: 65536 -> 1.71 ms, 16384 -> 1.83 ms); every other variant holds more registers, keeps fewer
+// workgroups resident to hide its prologue behind, and wants few, long workgroups (8192: C5 fp16 2.04 -> 1.86 ms,
+// C3 bf16 3-D active 0.79 -> 0.65 ms, fp32 3-D SSL 0.82 -> 0.66 ms, 2-D active fp32 2.06 -> 1.98 ms,
+// N128 C512 56x56 fp32 0.59 -> 0.49 ms).
+int64_t backward_min_wgs(const Geometry &g, int esize) {
+    if (g_tune[7] > 0) return g_tune[7];
+    const int64_t plane_bytes = g.S[0] * g.S[1] * g.S[2] * esize;
+    return (g.nd <= 2 && !g.active && esize >= 4 && plane_bytes >= g_tune[1]) ? 65536 : 8192;
+}
+
 Plan backward_plan(const Geometry &g, int esize) {
     const int entries = static_cast<int>(g.S[0] + g.S[1] + g.S[2] + g.O[0] + g.O[1] + g.O[2] + 6);
-    return make_plan(g, g.S[0] * g.S[1], g.S[2], esize, 16, entries, g_tune[7]);
+    return make_plan(g, g.S[0] * g.S[1], g.S[2], esize, 16, entries, backward_min_wgs(g, esize));
 }
 
 }  // namespace

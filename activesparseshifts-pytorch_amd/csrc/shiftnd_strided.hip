@@ -98,7 +98,7 @@ __global__ __launch_bounds__(kThreads) void strided_active_forward(Geometry g, c
         }
         CT v[8];
         gather_corners<T, ND>(x + n * g.xs[0] + c * g.xs[1], idx, g.S, g.xs + 2, g.pad, true, v);
-        out[n * g.os[0] + c * g.os[1] + o0 * g.os[2] + o1 * g.os[3] + o2 * g.os[4]] = narrow<T>(interp_nd<ND, CT>(v, dw));
+        out[n * g.os[0] + c * g.os[1] + o0 * g.os[2] + o1 * g.os[3] + o2 * g.os[4]] = narrow<T>(interp_t<T, ND>(v, dw));
     }
 }
 
@@ -152,7 +152,7 @@ __global__ __launch_bounds__(kThreads) void strided_backward(Geometry g, const t
 #pragma unroll
             for (int d = 0; d < 3; ++d) gi[d] = o[d] - sh[d];
             gather_corners<T, ND>(gop, gi, g.O, g.os + 2, g.pad, pass, v);
-            res = pass ? interp_nd<ND, CT>(v, dw) : CT(0);
+            res = pass ? interp_t<T, ND>(v, dw) : CT(0);
             gxp[i0 * g.gs[2] + i1 * g.gs[3] + i2 * g.gs[4]] = narrow<T>(res);
         } else {
             int64_t gi[3];

@@ -325,7 +325,7 @@ __global__ __launch_bounds__(kSweepMaxThreads) void sweep_backward(const SweepPa
             if constexpr (ACTIVE) {
 #pragma unroll
                 for (int q = 0; q < (1 << ND); ++q) v[q] = gv[q & (NC - 1)][e + (q >> (ND - 1))];
-                const CT r1 = interp_nd<ND, CT>(v, dw);
+                const CT r1 = interp_t<T, ND>(v, dw);
                 res.e[e] = narrow<T>(in ? r1 : CT(0));
             } else {
                 res.e[e] = gvalid ? graw.e[e] : narrow<T>(CT(0));

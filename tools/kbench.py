@@ -43,7 +43,15 @@ def main():
     ap.add_argument("--wrange", type=float, default=3.0)
     ap.add_argument("--policy", type=int, default=0)
     a = ap.parse_args()
-    nd, shape, dtname, active, desc = WORKLOADS[a.workload]
+    extra = {  # tuning-only variants of the bench workloads
+        "c2a": (2, (64, 256, 224, 224), "float32", True, "Shift2d active N64 C256 224x224 fp32"),
+        "c5a": (2, (64, 512, 224, 224), "float16", True, "Shift2d active N64 C512 224x224 fp16"),
+        "c3f": (3, (8, 128, 16, 112, 112), "float32", True, "Shift3d active N8 C128 16x112x112 fp32"),
+        "c3s": (3, (8, 128, 16, 112, 112), "bfloat16", False, "Shift3d SSL N8 C128 16x112x112 bf16"),
+        "c3fs": (3, (8, 128, 16, 112, 112), "float32", False, "Shift3d SSL N8 C128 16x112x112 fp32"),
+        "r56": (2, (128, 512, 56, 56), "float32", False, "Shift2d SSL N128 C512 56x56 fp32"),
+    }
+    nd, shape, dtname, active, desc = {**WORKLOADS, **extra}[a.workload]
     dev = torch.device("cuda:0")
     abi.set_path_policy(a.policy)
     quant = dtname == "quint8"

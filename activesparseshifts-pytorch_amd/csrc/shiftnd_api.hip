@@ -326,9 +326,9 @@ int shiftnd_backward_pooled(const shiftnd_problem *p, const int32_t *pool, const
     }
     if (!grad_pooled || !x || !weights || !grad_x || !grad_w || !workspace) return SHIFTND_ERR_INVALID_ARGUMENT;
     if (!plane_pool_backward_eligible(g, p->dtype, grad_x)) return SHIFTND_ERR_NOT_FUSED;
-    // 3-D interpolating backward: 16 gradient corner rows per step would be expanded from pooled rows; measured 8-13 %
-    // slower than avg_pool backward + shiftnd_backward (N8 C128 16x112x112: 1.70 vs 1.57 ms fp32), so it is not fused
-    // unless the plane-kernel policy is forced (tests)
+    // 3-D interpolating backward: 16 gradient corner rows per step would be expanded from pooled rows; measured slower
+    // than avg_pool backward + shiftnd_backward (N8 C128 16x112x112: 1.42 vs 1.33 ms fp32, 1.32 vs 0.96 ms bf16), so it
+    // is not fused unless the plane-kernel policy is forced (tests)
     if (g.nd == 3 && g.active && g_policy != 2) return SHIFTND_ERR_NOT_FUSED;
     if (plane_backward_workspace(g, p->dtype) > workspace_bytes) return SHIFTND_ERR_WORKSPACE_TOO_SMALL;
     g_last_path = SHIFTND_PATH_PLANE;

@@ -1490,6 +1490,7 @@ int launch_backward(const PlaneParams &p, const Plan &pl, bool active, void *gw,
 int64_t backward_min_wgs(const Geometry &g, int esize) {
     if (g_tune[7] > 0) return g_tune[7];
     const int64_t plane_bytes = g.S[0] * g.S[1] * g.S[2] * esize;
+    if (g.K[0] > 0) return 8192;  // fused-pool backward (more registers): N64 C256 224x224 fp32 2.35 -> 2.13 ms
     return (g.nd <= 2 && !g.active && esize >= 4 && plane_bytes >= g_tune[1]) ? 65536 : 8192;
 }
 

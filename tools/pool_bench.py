@@ -40,6 +40,7 @@ def main():
     ap.add_argument("--pad", type=int, default=0)
     ap.add_argument("--iters", type=int, default=10)
     ap.add_argument("--rounds", type=int, default=3)
+    ap.add_argument("--force-fused", action="store_true", help="path policy 2: fuse the backward even where the automatic choice would not")
     a = ap.parse_args()
     shape = [int(v) for v in a.shape.split(",")]
     nd = len(shape) - 2
@@ -74,7 +75,10 @@ def main():
         abi.backward(g, w, x, a.pad, a.active, grad_x=gx, grad_w=gw, workspace=ws)
 
     def fus_bwd():
+        if a.force_fused:
+            abi.set_path_policy(2)
         abi.backward_pooled(gp, w, x, a.pad, a.active, a.pool, grad_x=gx, grad_w=gw, workspace=ws)
+        abi.set_path_policy(0)
 
     es = x.element_size()
     n, npool = x.numel(), ref.numel()

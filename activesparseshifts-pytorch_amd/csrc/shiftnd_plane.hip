@@ -1222,11 +1222,12 @@ bool contiguous(const int64_t st[5], int64_t N, int64_t C, const int64_t sz[3]) 
     return true;
 }
 
-// diagnostics knobs (shiftnd_set_tuning): 0 = min workgroups wanted, 1 = target bytes per workgroup,
+// diagnostics knobs (shiftnd_set_tuning): 0 = min workgroups wanted by the forward kernels (0 = automatic: 8192 for
+// the gather forward, 2048 otherwise), 1 = target bytes per workgroup,
 // 2 = gather-forward unroll (fp32/16-byte variant only), 6 = XCD-contiguous workgroup ids, 7 = workgroups
 // wanted by the backward kernels (0 = automatic, see backward_min_wgs), 3 = backward / active-forward kernel: 2 LDS-staged where it applies (default), 1 direct global loads;
 // 4 = LDS tiles of the backward kernel: 1 automatic, 2 two tiles + one barrier per step, 3 one tile; 5 = 1: no affine dword reads
-int g_tune[8] = {2048, 128 * 1024, 4, 2, 1, 0, 1, 0};
+int g_tune[8] = {0, 128 * 1024, 4, 2, 1, 0, 1, 0};
 
 struct Plan {
     int V, cpr, CW, RPS, CP, ppw, groups, bands, rows_per_band, rows;
@@ -1245,7 +1246,7 @@ Plan make_plan(const Geometry &g, int64_t rows, int64_t inner, int esize, int V,
     pl.RPS = kThreads / pl.CW;
     pl.CP = (pl.cpr + pl.CW - 1) / pl.CW;
     const int64_t plane_bytes = rows * inner * esize;
-    const int64_t min_wgs = min_wgs_override > 0 ? min_wgs_override : g_tune[0];
+    const int64_t min_wgs = min_wgs_override > 0 ? min_wgs_override : (g_tune[0] > 0 ? g_tune[0] : 2048);
     int64_t ppw = g_tune[1] / (plane_bytes > 0 ? plane_bytes : 1);
     if (ppw < 1) ppw = 1;
     if (ppw > g.N) ppw = g.N;
@@ -1512,12 +1513,16 @@ static bool lds_gather_wanted(const Geometry &g, int es, int V, const Plan &pl, 
     return total <= 64 * 1024;
 }
 
+// workgroups wanted by the gather forward (knob 0 overrides): a light kernel, 8 workgroups per CU resident -- 2048
+// workgroups are one round with no slack for uneven finish times (C4 quint8 N128 C512 56x56: 0.187 -> 0.134 ms)
+static int64_t gather_min_wgs() { return g_tune[0] > 0 ? g_tune[0] : 8192; }
+
 // true when plane_forward would take the LDS-staged gather kernel (the API then prefers it over the sweep kernel)
 bool plane_forward_lds_gather(const Geometry &g, int dtype, const void *x, const void *out) {
     if ((g.active && dtype <= SHIFTND_BF16) || !plane_forward_eligible(g, dtype, x, out)) return false;
     const int es = dtype_size(dtype);
     const int V = gather_vector_bytes(g, es, out);
-    const Plan pl = make_plan(g, g.O[0] * g.O[1], g.O[2], es, V, static_cast<int>(g.S[0] + g.S[1] + g.S[2] + 3));
+    const Plan pl = make_plan(g, g.O[0] * g.O[1], g.O[2], es, V, static_cast<int>(g.S[0] + g.S[1] + g.S[2] + 3), gather_min_wgs());
     return lds_gather_wanted(g, es, V, pl, x);
 }
 
@@ -1558,7 +1563,7 @@ int plane_forward(const Geometry &g, int dtype, const void *x, const void *w, in
     }
     const int V = gather_vector_bytes(g, es, out);
     note_kernel("plane_gather_forward");
-    const Plan pl = make_plan(g, g.O[0] * g.O[1], g.O[2], es, V, entries);
+    const Plan pl = make_plan(g, g.O[0] * g.O[1], g.O[2], es, V, entries, gather_min_wgs());
     fill_params(p, g, pl, g.O[1]);
     // LDS-staged gather: 16-bit rows by default (knob 2 == 4), every eligible element size with knob 2 == 16
     if (lds_gather_wanted(g, es, V, pl, x)) {

@@ -20,7 +20,7 @@ def abi():
     assert torch.cuda.is_available(), "the gpu tests need an MI355X"
     yield A
     A.set_path_policy(0)
-    for k, v in ((0, 2048), (1, 128 * 1024), (3, 2), (4, 1), (7, 0)):
+    for k, v in ((0, 0), (1, 128 * 1024), (3, 2), (4, 1), (7, 0)):
         A.set_tuning(k, v)
 
 
@@ -109,7 +109,7 @@ def test_fuzz_float(abi, seed):
             abi.set_path_policy(0)
             assert np.array_equal(gxp.cpu().numpy(), gxp_o), ("pool gx", pool) + key
             assert rel_err(gwp.cpu().numpy(), gwp64) < tol, ("pool gw", pool) + key
-    for k, v in ((0, 2048), (1, 128 * 1024), (3, 2), (4, 1), (7, 0)):
+    for k, v in ((0, 0), (1, 128 * 1024), (3, 2), (4, 1), (7, 0)):
         abi.set_tuning(k, v)
     assert checked >= 300  # 150 cases x (automatic + strided at least)
 
@@ -148,5 +148,5 @@ def test_fuzz_quantized(abi, seed):
             oc = torch.empty(new, dtype=tdt[npdt], device=DEV).contiguous(memory_format=fmt)
             abi.forward_quantized(x.contiguous(memory_format=fmt), w, wzp, xzp, pad, b, out=oc)
             assert abi.last_path() == abi.PATH_CL and np.array_equal(oc.cpu().numpy(), ref)
-    abi.set_tuning(0, 2048)
+    abi.set_tuning(0, 0)
     abi.set_tuning(1, 128 * 1024)

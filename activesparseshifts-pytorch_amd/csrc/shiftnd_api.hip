@@ -257,6 +257,15 @@ int shiftnd_backward(const shiftnd_problem *p, const void *grad_out, const int64
     return finish(strided_backward(g, p->dtype, grad_out, x, weights, grad_x, grad_w, workspace, st));
 }
 
+// ---- layout change ---------------------------------------------------------------------------------------------
+int shiftnd_transpose(const void *src, void *dst, int64_t batch, int64_t rows, int64_t cols, int32_t element_bytes,
+                      void *stream) {
+    if (batch < 0 || rows < 0 || cols < 0) return SHIFTND_ERR_INVALID_ARGUMENT;
+    if (batch == 0 || rows == 0 || cols == 0) return SHIFTND_OK;
+    if (!src || !dst) return SHIFTND_ERR_INVALID_ARGUMENT;
+    return finish(transpose_planes(src, dst, batch, rows, cols, element_bytes, static_cast<hipStream_t>(stream)));
+}
+
 // ---- fused shift + average pool ----------------------------------------------------------------------------
 static int pooled_geometry(const shiftnd_problem *p, const int32_t *pool, Geometry &g) {
     if (!p || !pool) return SHIFTND_ERR_INVALID_ARGUMENT;

@@ -66,6 +66,9 @@ size_t cl_backward_workspace(const Geometry &g);
 int cl_backward(const Geometry &g, int dtype, const void *go, const void *x, const void *w, void *gx, void *gw,
                 void *workspace, hipStream_t st);
 
+// ---- layout change (shiftnd_transpose.hip): dst[n][c][r] = src[n][r][c], dense tensors ---------------------------
+int transpose_planes(const void *src, void *dst, int64_t N, int64_t rows, int64_t cols, int esize, hipStream_t st);
+
 // ---- sweep kernels (shiftnd_sweep.hip): one 16-byte chunk per thread, XCD-contiguous grid ----------
 bool sweep_forward_eligible(const Geometry &g, int dtype, const void *x, const void *out);
 int sweep_forward(const Geometry &g, int dtype, const void *x, const void *w, int wkind, int64_t wzp, uint64_t fill_bits,

@@ -22,7 +22,7 @@ DTYPES = {torch.float32: F32, torch.float64: F64, torch.float16: F16, torch.bflo
 EXPORTS = ["shiftnd_abi_version", "shiftnd_status_string", "shiftnd_last_path", "shiftnd_set_path_policy",
            "shiftnd_set_tuning", "shiftnd_debug_map", "shiftnd_last_kernel",
            "shiftnd_check_borders", "shiftnd_forward", "shiftnd_backward_workspace_bytes", "shiftnd_backward",
-           "shiftnd_forward_quantized", "shiftnd_pooled_sizes", "shiftnd_forward_pooled", "shiftnd_backward_pooled"]
+           "shiftnd_forward_quantized", "shiftnd_pooled_sizes", "shiftnd_forward_pooled", "shiftnd_backward_pooled", "shiftnd_transpose"]
 
 
 class Problem(ctypes.Structure):
@@ -68,6 +68,8 @@ def lib():
         L.shiftnd_forward_pooled.argtypes = [ctypes.POINTER(Problem), i32p, vp, vp, vp, vp]
         L.shiftnd_backward_pooled.restype = ctypes.c_int
         L.shiftnd_backward_pooled.argtypes = [ctypes.POINTER(Problem), i32p, vp, vp, vp, vp, vp, vp, ctypes.c_size_t, vp]
+        L.shiftnd_transpose.restype = ctypes.c_int
+        L.shiftnd_transpose.argtypes = [vp, vp, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64, ctypes.c_int32, vp]
         _lib = L
     return _lib
 
@@ -208,6 +210,25 @@ def backward_pooled(grad_pooled, w, x, pad, active, pool, borders=None, grad_x=N
                                         w.data_ptr(), grad_x.data_ptr(), grad_w.data_ptr(), workspace.data_ptr(),
                                         workspace.numel(), _stream()), "shiftnd_backward_pooled")
     return grad_x, grad_w
+
+
+def to_contiguous(x):
+    """channels-last dense [N, C, spatial...] device tensor -> new contiguous tensor (shiftnd_transpose)"""
+    out = torch.empty(x.shape, dtype=x.dtype, device=x.device)
+    P = x[0, 0].numel()
+    check(lib().shiftnd_transpose(x.data_ptr(), out.data_ptr(), x.shape[0], P, x.shape[1], x.element_size(), _stream()),
+          "shiftnd_transpose")
+    return out
+
+
+def to_channels_last(x):
+    """contiguous [N, C, spatial...] device tensor -> new channels-last dense tensor (shiftnd_transpose)"""
+    fmt = torch.channels_last if x.dim() == 4 else torch.channels_last_3d
+    out = torch.empty(x.shape, dtype=x.dtype, device=x.device, memory_format=fmt)
+    P = x[0, 0].numel()
+    check(lib().shiftnd_transpose(x.data_ptr(), out.data_ptr(), x.shape[0], x.shape[1], P, x.element_size(), _stream()),
+          "shiftnd_transpose")
+    return out
 
 
 def last_path():

@@ -178,6 +178,18 @@ SHIFTND_API int shiftnd_backward_pooled(const shiftnd_problem *p, const int32_t 
                             void *grad_x, void *grad_w,
                             void *workspace, size_t workspace_bytes, void *stream);
 
+/*
+ * Layout change between channels-last and contiguous tensors: dst[b][c][r] = src[b][r][c] for dense
+ * src[batch][rows][cols] and dst[batch][cols][rows] of element_bytes-byte (1, 2, 4, 8) elements.
+ * Channels-last [N, H, W, C] -> contiguous [N, C, H, W]: rows = H*W, cols = C; the reverse: rows = C, cols = H*W.
+ * The reference's float ops return an NCHW-contiguous tensor even for a channels-last input
+ * (cpu/shifts_cpu.cpp:221) and its CUDA backend walks such an input through its strides; host glue that meets a
+ * channels-last tensor changes the layout with this call (a tile transpose at copy bandwidth) and runs the
+ * contiguous kernels, which is several times faster than any kernel that touches both layouts at once.
+ */
+SHIFTND_API int shiftnd_transpose(const void *src, void *dst, int64_t batch, int64_t rows, int64_t cols,
+                      int32_t element_bytes, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -193,3 +193,50 @@ def test_strided_module_uses_fused_pool():
     assert torch.equal(out_g.cpu(), out_c.detach())
     assert torch.allclose(xg.grad.cpu(), gx_c, rtol=1e-6, atol=1e-9)
     assert rel_err(mg.weight.grad.cpu().numpy(), gw_c.numpy()) < 1e-5
+
+
+def test_layout_change_kernel():
+    """shiftnd_transpose (channels-last <-> contiguous) is a pure permutation for every element size and ragged shape"""
+    from torchshifts import abi
+    torch.manual_seed(0)
+    for shape, dt in [((3, 70, 13, 9), torch.float32), ((2, 64, 16, 16), torch.float16), ((2, 5, 7, 3), torch.int8),
+                      ((1, 130, 65, 67), torch.uint8), ((2, 8, 3, 4, 5), torch.float64), ((4, 256, 56, 56), torch.bfloat16),
+                      ((2, 3, 100), torch.float32)]:
+        x = (torch.rand(shape, device=DEV) * 200 - 100).to(dt)
+        if len(shape) == 3:  # [N, C, L]: "channels-last" = [N, L, C] storage
+            xc = x.permute(0, 2, 1).contiguous().permute(0, 2, 1)
+            assert torch.equal(abi.to_contiguous(xc), x)
+            continue
+        fmt = torch.channels_last if len(shape) == 4 else torch.channels_last_3d
+        xc = x.contiguous(memory_format=fmt)
+        a, b = abi.to_contiguous(xc), abi.to_channels_last(x)
+        assert a.is_contiguous() and torch.equal(a, x), shape
+        assert b.stride() == xc.stride() and torch.equal(b, x), shape
+
+
+def test_channels_last_through_the_ops():
+    """channels-last tensors through the dispatcher ops: float ops return NCHW-contiguous results (like the reference),
+    values and gradients equal the contiguous call; the fused-pool op and the modules accept them too"""
+    import torchshifts.functional as TF
+    torch.manual_seed(1)
+    x = torch.rand(4, 24, 20, 28, device=DEV)
+    w = (torch.rand(24, 2, device=DEV) * 6 - 3)
+    for pad, active in ((0, False), (3, True)):
+        xa = x.clone().requires_grad_(True)
+        wa = w.clone().requires_grad_(True)
+        ref = TF.shift2d_func(xa, wa, pad, active)
+        g = torch.rand_like(ref)
+        ref.backward(g)
+        xb = x.clone().contiguous(memory_format=torch.channels_last).requires_grad_(True)
+        wb = w.clone().requires_grad_(True)
+        out = TF.shift2d_func(xb, wb, pad, active)
+        assert out.is_contiguous() and torch.equal(out, ref)
+        out.backward(g.contiguous(memory_format=torch.channels_last))
+        assert torch.equal(xb.grad, xa.grad) and rel_err(wb.grad.cpu().numpy(), wa.grad.cpu().numpy()) < 1e-6
+        pa = TF.shift2d_pool_func(x, w, pad, active, None, 2)
+        pb = TF.shift2d_pool_func(x.contiguous(memory_format=torch.channels_last), w, pad, active, None, 2)
+        assert torch.equal(pa, pb)
+    x3 = torch.rand(2, 6, 5, 8, 12, device=DEV)
+    w3 = (torch.rand(6, 3, device=DEV) * 4 - 2)
+    assert torch.equal(TF.shift3d_func(x3.contiguous(memory_format=torch.channels_last_3d), w3, 2, True),
+                       TF.shift3d_func(x3, w3, 2, True))

@@ -1170,16 +1170,22 @@ __global__ __launch_bounds__(kThreads) void plane_active_forward_lds(const Plane
         const int a = fdiv(r0, p.d_dim1);
         Stager::make_slots(p, R, a, r0 - a * S1, step_len(r0), m0, m1, nullptr, nullptr, slot_src);
     }
+    // pre-decoded DMA pieces and loop-carried plane bases, as in plane_backward_lds
+    int pk[Stager::kRegPieces];
+    const bool decoded = Stager::pieces_fit(static_cast<int>(p.cpr), R);
+    if (decoded) Stager::decode_pieces(p, R, pk);
     __syncthreads();
+    const int64_t plane0 = static_cast<int64_t>(wi.n0) * p.C + wi.c;
+    const S *xp = static_cast<const S *>(p.x) + plane0 * p.x_plane;
+    S *op = static_cast<S *>(p.out) + plane0 * p.o_plane;
+    const int64_t xstep = static_cast<int64_t>(p.C) * p.x_plane, ostep = static_cast<int64_t>(p.C) * p.o_plane;
     while (nl < wi.nn) {
         const int a = fdiv(r0, p.d_dim1);
         const int b0 = r0 - a * S1;
         const int Rn = step_len(r0);
         const int *ss = slot_src + buf * NS;
-        const int64_t plane = static_cast<int64_t>(wi.n0 + nl) * p.C + wi.c;
-        const S *xp = static_cast<const S *>(p.x) + plane * p.x_plane;
-        S *op = static_cast<S *>(p.out) + plane * p.o_plane;
-        Stager::issue_dma(p, R, xp, xp, ss, tile);
+        if (decoded) Stager::issue_dma_decoded(NS, xp, xp, ss, tile, pk);
+        else Stager::issue_dma(p, R, xp, xp, ss, tile);
         int nl2 = nl, r2 = r0 + Rn;
         if (r2 >= row_end) { r2 = wi.row0; ++nl2; }
         if (nl2 < wi.nn) {
@@ -1202,6 +1208,10 @@ __global__ __launch_bounds__(kThreads) void plane_active_forward_lds(const Plane
             store_chunk<S, E>(op + static_cast<int64_t>(a * S1 + b0 + tr) * S2 + ji, res);
         }
         __syncthreads();
+        if (nl2 != nl) {
+            xp += xstep;
+            op += ostep;
+        }
         nl = nl2;
         r0 = r2;
         buf ^= 1;

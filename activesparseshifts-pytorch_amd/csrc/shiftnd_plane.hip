@@ -1085,24 +1085,51 @@ __global__ __launch_bounds__(kThreads) void plane_gather_forward_lds(const Plane
     };
     int nl = 0, r0 = wi.row0, buf = 0;
     make_slots(r0, step_len(r0), slot_src);
+    // which pieces a thread moves is the same in every step: decode (slot, column piece) once (up to kPieces per thread)
+    constexpr int kPieces = 2;
+    const bool decoded = pieces <= kPieces * kThreads && p.xppr <= 256;
+    int pk[kPieces];
+#pragma unroll
+    for (int k = 0; k < kPieces; ++k) {
+        const int q = k * kThreads + static_cast<int>(threadIdx.x);
+        const int slot = fdiv(q, p.d_xppr);
+        pk[k] = q < pieces ? slot * 256 + (q - slot * static_cast<int>(p.xppr)) : -1;
+    }
+    const int wave = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x) >> 6);
     __syncthreads();
+    const int64_t plane0 = static_cast<int64_t>(wi.n0) * p.C + wi.c;
+    const R_t *xp = static_cast<const R_t *>(p.x) + plane0 * p.x_plane;
+    R_t *op = static_cast<R_t *>(p.out) + plane0 * p.o_plane;
+    const int64_t xstep = static_cast<int64_t>(p.C) * p.x_plane, ostep = static_cast<int64_t>(p.C) * p.o_plane;
     while (nl < wi.nn) {
         const int Rn = step_len(r0);
         const int *ss = slot_src + buf * R;
-        const int64_t plane = static_cast<int64_t>(wi.n0 + nl) * p.C + wi.c;
-        const R_t *xp = static_cast<const R_t *>(p.x) + plane * p.x_plane;
-        R_t *op = static_cast<R_t *>(p.out) + plane * p.o_plane;
-        for (int q0 = 0; q0 < pieces; q0 += kThreads) {
-            const int q = q0 + threadIdx.x;
-            if (q < pieces) {
-                const int slot = fdiv(q, p.d_xppr);
-                const int j = q - slot * static_cast<int>(p.xppr);
-                const int src = ss[slot];
-                if (src >= 0) {
-                    const R_t *g = xp + src + j * E;
-                    char *dst_wave = tile + (q0 + (threadIdx.x & ~63)) * 16;
-                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)g,
-                                                     (__attribute__((address_space(3))) void *)dst_wave, 16, 0, 0);
+        if (decoded) {
+#pragma unroll
+            for (int k = 0; k < kPieces; ++k) {
+                if (pk[k] >= 0) {
+                    const int src = ss[pk[k] >> 8];
+                    if (src >= 0) {
+                        const R_t *g = xp + src + (pk[k] & 255) * E;
+                        char *dst_wave = tile + (k * kThreads + wave * 64) * 16;
+                        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)g,
+                                                         (__attribute__((address_space(3))) void *)dst_wave, 16, 0, 0);
+                    }
+                }
+            }
+        } else {
+            for (int q0 = 0; q0 < pieces; q0 += kThreads) {
+                const int q = q0 + threadIdx.x;
+                if (q < pieces) {
+                    const int slot = fdiv(q, p.d_xppr);
+                    const int j = q - slot * static_cast<int>(p.xppr);
+                    const int src = ss[slot];
+                    if (src >= 0) {
+                        const R_t *g = xp + src + j * E;
+                        char *dst_wave = tile + (q0 + (threadIdx.x & ~63)) * 16;
+                        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)g,
+                                                         (__attribute__((address_space(3))) void *)dst_wave, 16, 0, 0);
+                    }
                 }
             }
         }
@@ -1121,6 +1148,10 @@ __global__ __launch_bounds__(kThreads) void plane_gather_forward_lds(const Plane
             store_chunk<R_t, E>(op + static_cast<int64_t>(r0 + tr) * O2 + jo, res);
         }
         __syncthreads();
+        if (nl2 != nl) {
+            xp += xstep;
+            op += ostep;
+        }
         nl = nl2;
         r0 = r2;
         buf ^= 1;

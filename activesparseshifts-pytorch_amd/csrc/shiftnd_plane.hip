@@ -858,9 +858,13 @@ __device__ __forceinline__ void lds_read_row(const char *row, bool valid, const 
 #pragma unroll
         for (int e = 0; e <= E; ++e) raw[e] = c.cm[e] >= 0 ? raw[e] : zero;
     } else {
+        // unconditional reads at a clamped column, then one select each: no per-element execution-mask juggling
         const S *p0 = reinterpret_cast<const S *>(row);
+        S tmp[E + 1];
 #pragma unroll
-        for (int e = 0; e <= E; ++e) raw[e] = c.cm[e] >= 0 ? p0[c.cm[e]] : zero;
+        for (int e = 0; e <= E; ++e) tmp[e] = p0[c.cm[e] > 0 ? c.cm[e] : 0];
+#pragma unroll
+        for (int e = 0; e <= E; ++e) raw[e] = c.cm[e] >= 0 ? tmp[e] : zero;
     }
 }
 
@@ -1337,7 +1341,10 @@ void fill_params(PlaneParams &p, const Geometry &g, const Plan &pl, int64_t dim1
     p.CP = pl.CP;
     p.rows = pl.rows;
     p.d_rows = make_fastdiv(static_cast<uint32_t>(pl.rows_per_band));
-    p.lds_affine = g_tune[5] != 1;
+    // With a wrapping / clamping padding every wave holds edge chunks whose maps are not affine, so it runs the affine
+    // AND the per-element read path; for the 3-D kernels (8 + 8 staged rows per chunk) per-element reads alone are
+    // cheaper (C3 with reflect padding: backward 0.82 -> 0.75 ms, forward 0.31 -> 0.30 ms; 2-D: no difference)
+    p.lds_affine = g_tune[5] != 1 && !(g.pad != 0 && g.nd == 3 && g_tune[5] != 2);
     p.xcd_blocks = (g_tune[6] && pl.grid % 8 == 0) ? pl.grid / 8 : 0;
     p.d_cpr = make_fastdiv(static_cast<uint32_t>(pl.cpr));
     p.d_dim1 = make_fastdiv(static_cast<uint32_t>(dim1));

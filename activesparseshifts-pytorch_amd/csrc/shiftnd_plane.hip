@@ -735,7 +735,7 @@ struct LdsStager {
     // Which pieces a thread moves never changes from step to step: piece k of a thread is q = k * kThreads + tid.
     // Its (slot, column piece) pair is decoded once, packed as slot * 256 + j (or -1), and the per-step work is the
     // slot-table read, one address and the DMA.  For steps of at most kRegPieces pieces per thread (cpr <= 256).
-    static constexpr int kRegPieces = 3;
+    static constexpr int kRegPieces = (ACTIVE || POOL || sizeof(S) == 2) ? 4 : 3;  // (3 keeps the 2-D SSL fp32 kernel at 64 VGPRs)
     __host__ __device__ static bool pieces_fit(int cpr, int R) {
         return Shape::slots(R) * cpr <= kRegPieces * kThreads && cpr <= 256;
     }
@@ -768,6 +768,50 @@ struct LdsStager {
                         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(reinterpret_cast<const char *>(gp) + off),
                                                          (__attribute__((address_space(3))) void *)dst_wave, 16, 0, 0);
                 }
+            }
+        }
+    }
+
+    // POOL with windows of 2 along the row, pre-decoded pieces: x pieces go by LDS-DMA; the pooled values of ALL of the
+    // thread's gradient pieces are loaded first and expanded afterwards, so their latencies overlap each other and
+    // the DMA instead of being paid piece by piece.
+    __device__ static void issue_dma_decoded_pool(int NX, const S *xp, const S *gp, const int *slot_src, char *tile,
+                                                  const int (&pk)[kRegPieces], int aux) {
+        using CT = typename T::C;
+        constexpr int H = E >= 2 ? E / 2 : 1;
+        const int wave = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x) >> 6);
+        Chunk<S, H> pv[kRegPieces];
+        int cnt[kRegPieces];
+#pragma unroll
+        for (int k = 0; k < kRegPieces; ++k) {
+            cnt[k] = 0;
+            if (pk[k] >= 0) {
+                const int slot = pk[k] >> 8;
+                const int src = slot_src[slot];
+                if (src >= 0) {
+                    if (slot < NX) {
+                        const S *g = xp + src + (pk[k] & 255) * E;
+                        char *dst_wave = tile + (k * kThreads + wave * 64) * 16;
+                        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)g,
+                                                         (__attribute__((address_space(3))) void *)dst_wave, 16, 0, 0);
+                    } else {
+                        pv[k] = load_chunk<S, H>(gp + src + (pk[k] & 255) * H);
+                        cnt[k] = slot_src[slot + aux] * 2;
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < kRegPieces; ++k) {
+            if (cnt[k] > 0) {
+                Chunk<S, E> out;
+#pragma unroll
+                for (int h = 0; h < H; ++h) {
+                    const S q = narrow<T>(div_count<CT>(widen<T>(pv[k].e[h]), cnt[k]));
+                    out.e[2 * h] = q;
+                    if (E >= 2) out.e[2 * h + 1] = q;
+                }
+                __builtin_memcpy(__builtin_assume_aligned(tile + (k * kThreads + static_cast<int>(threadIdx.x)) * 16, 16), out.e, 16);
             }
         }
     }
@@ -962,7 +1006,8 @@ __global__ __launch_bounds__(kThreads) void plane_backward_lds(const PlaneParams
         const int Rn = step_len(r0);
         const int *ss = slot_src + tb * NS;
         char *tile = tile0 + (TILES == 2 ? buf * p.tile_bytes : 0);
-        if constexpr (DEC) Stager::issue_dma_decoded(NX, xp, gp, ss, tile, pk);
+        if constexpr (DEC && POOL) Stager::issue_dma_decoded_pool(NX, xp, gp, ss, tile, pk, aux);
+        else if constexpr (DEC) Stager::issue_dma_decoded(NX, xp, gp, ss, tile, pk);
         else Stager::issue_dma(p, R, xp, gp, ss, tile, aux);
         int nl2 = nl, r2 = r0 + Rn;
         if (r2 >= row_end) { r2 = wi.row0; ++nl2; }
@@ -1481,6 +1526,17 @@ void launch_backward_pool(const PlaneParams &p_in, const Plan &pl, hipStream_t s
             lds_bytes += 3 * slots * sizeof(int);  // the second set of slot tables (window counts)
             const bool want_two = g_tune[4] == 2 || (g_tune[4] != 3 && sizeof(typename T::S) == 2);
             const bool two = want_two && lds_bytes + tile_bytes + slots * sizeof(int) <= 64 * 1024;
+            // windows of 2 along the row and few pieces per thread: the pre-decoded form (default tile count only)
+            constexpr int kDefTiles = sizeof(typename T::S) == 2 ? 2 : 1;
+            const bool dec = g_tune[5] != 2 && p.K[2] == 2 && two == (kDefTiles == 2) &&
+                             (p.nd == 3 ? LdsStager<T, 3, ACTIVE, true, true>::pieces_fit(pl.cpr, pl.RPS)
+                                        : LdsStager<T, 2, ACTIVE, true, true>::pieces_fit(pl.cpr, pl.RPS));
+            if (dec) {
+                const size_t bytes = two ? lds_bytes + tile_bytes + slots * sizeof(int) : lds_bytes;
+                if (p.nd == 3) hipLaunchKernelGGL((plane_backward_lds<T, 3, ACTIVE, kDefTiles, true, true>), dim3(pl.grid), dim3(kThreads), bytes, st, p);
+                else hipLaunchKernelGGL((plane_backward_lds<T, 2, ACTIVE, kDefTiles, true, true>), dim3(pl.grid), dim3(kThreads), bytes, st, p);
+                return;
+            }
             if (p.nd == 3) {
                 if (two) hipLaunchKernelGGL((plane_backward_lds<T, 3, ACTIVE, 2, true>), dim3(pl.grid), dim3(kThreads), lds_bytes + tile_bytes + slots * sizeof(int), st, p);
                 else hipLaunchKernelGGL((plane_backward_lds<T, 3, ACTIVE, 1, true>), dim3(pl.grid), dim3(kThreads), lds_bytes, st, p);

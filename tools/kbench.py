@@ -50,6 +50,9 @@ def main():
         "c3s": (3, (8, 128, 16, 112, 112), "bfloat16", False, "Shift3d SSL N8 C128 16x112x112 bf16"),
         "c3fs": (3, (8, 128, 16, 112, 112), "float32", False, "Shift3d SSL N8 C128 16x112x112 fp32"),
         "r56": (2, (128, 512, 56, 56), "float32", False, "Shift2d SSL N128 C512 56x56 fp32"),
+        "d1": (1, (256, 512, 4096), "float32", False, "Shift1d SSL N256 C512 L4096 fp32"),
+        "d1a": (1, (256, 512, 4096), "float32", True, "Shift1d active N256 C512 L4096 fp32"),
+        "d1h": (1, (256, 512, 4096), "float16", False, "Shift1d SSL N256 C512 L4096 fp16"),
     }
     nd, shape, dtname, active, desc = {**WORKLOADS, **extra}[a.workload]
     dev = torch.device("cuda:0")

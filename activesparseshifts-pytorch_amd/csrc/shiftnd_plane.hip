@@ -1596,7 +1596,17 @@ int64_t backward_min_wgs(const Geometry &g, int esize) {
     if (g_tune[7] > 0) return g_tune[7];
     const int64_t plane_bytes = g.S[0] * g.S[1] * g.S[2] * esize;
     if (g.K[0] > 0) return 8192;  // fused-pool backward (more registers): N64 C256 224x224 fp32 2.35 -> 2.13 ms
-    return (g.nd <= 2 && !g.active && esize >= 4 && plane_bytes >= g_tune[1]) ? 65536 : 8192;
+    if (!(g.nd <= 2 && !g.active && esize >= 4 && plane_bytes >= g_tune[1])) return 8192;
+    // large planes, light kernel: row bands of >= 14 steps each, up to 65536 workgroups in all (C2 N64 C256: 4 bands;
+    // N64 C64 224x224: 4 bands = 16384 workgroups, 0.43 ms where 65536 workgroups of 3.5 steps took 0.52 ms)
+    const int64_t cpr = g.S[2] * esize / 16 > 0 ? g.S[2] * esize / 16 : 1;
+    const int64_t rps = cpr < kThreads ? kThreads / cpr : 1;
+    const int64_t steps = (g.S[0] * g.S[1] + rps - 1) / rps;
+    const int64_t planes = g.N * g.C;
+    int64_t bands = planes < 65536 ? 65536 / planes : 1;
+    if (bands > steps / 14) bands = steps / 14;
+    if (bands < 1) bands = 1;
+    return planes * bands;
 }
 
 Plan backward_plan(const Geometry &g, int esize) {

@@ -50,6 +50,11 @@ def main():
         "c3s": (3, (8, 128, 16, 112, 112), "bfloat16", False, "Shift3d SSL N8 C128 16x112x112 bf16"),
         "c3fs": (3, (8, 128, 16, 112, 112), "float32", False, "Shift3d SSL N8 C128 16x112x112 fp32"),
         "r56": (2, (128, 512, 56, 56), "float32", False, "Shift2d SSL N128 C512 56x56 fp32"),
+        "c2n32": (2, (32, 256, 224, 224), "float32", False, "Shift2d SSL N32 C256 224x224 fp32"),
+        "c2n128": (2, (128, 256, 224, 224), "float32", False, "Shift2d SSL N128 C256 224x224 fp32"),
+        "c2c64": (2, (64, 64, 224, 224), "float32", False, "Shift2d SSL N64 C64 224x224 fp32"),
+        "c2s448": (2, (16, 256, 448, 448), "float32", False, "Shift2d SSL N16 C256 448x448 fp32"),
+        "c2s160": (2, (64, 256, 160, 160), "float32", False, "Shift2d SSL N64 C256 160x160 fp32"),
         "d1": (1, (256, 512, 4096), "float32", False, "Shift1d SSL N256 C512 L4096 fp32"),
         "d1a": (1, (256, 512, 4096), "float32", True, "Shift1d active N256 C512 L4096 fp32"),
         "d1h": (1, (256, 512, 4096), "float16", False, "Shift1d SSL N256 C512 L4096 fp16"),

@@ -33,10 +33,12 @@
  *     synchronisation, no allocation (graph-capture safe).
  *   - Every function returns SHIFTND_OK (0) or a negative shiftnd_status; nothing is thrown.
  *   - Numerics contract: SSL forward / SSL input-grad / quantized are pure
- *     gathers and bit-exact; interpolation is evaluated as v1*(1-x)+v2*x with separate multiply
- *     and add (no FMA contraction) in fp32 (fp64 for fp64 tensors), 16-bit inputs are widened to
- *     fp32 and rounded once (RNE) on store; the weight gradient is accumulated in fp64 by a
- *     deterministic two-stage reduction and rounded once to the tensor dtype.
+ *     gathers and bit-exact; for fp32 / fp64 tensors interpolation is evaluated as v1*(1-x)+v2*x
+ *     with separate multiplies and add (no FMA contraction), bit-identical to the reference's CPU
+ *     build; 16-bit inputs are widened to fp32, interpolated there (one multiply and one fused
+ *     multiply-add per lerp) and rounded once (RNE) on store; the weight gradient sums products in
+ *     the compute type (fused multiply-add), accumulates them in fp64 by a deterministic two-stage
+ *     reduction and rounds once to the tensor dtype.
  */
 #ifndef SHIFTND_HIP_H_
 #define SHIFTND_HIP_H_

@@ -816,6 +816,61 @@ struct LdsStager {
         }
     }
 
+    // The same in three parts, for kernels that keep few workgroups resident (16-bit data): the pooled values of step
+    // s + 1 are requested right after the barrier of step s, ride out their latency behind step s's compute phase, and
+    // are expanded at the top of step s + 1.
+    struct PoolRegs {
+        Chunk<S, (E >= 2 ? E / 2 : 1)> pv[kRegPieces];
+        int cnt[kRegPieces];
+    };
+    __device__ static void pool_load(int NX, const S *gp, const int *slot_src, const int (&pk)[kRegPieces], int aux, PoolRegs &r) {
+        constexpr int H = E >= 2 ? E / 2 : 1;
+#pragma unroll
+        for (int k = 0; k < kRegPieces; ++k) {
+            r.cnt[k] = 0;
+            if (pk[k] >= 0) {
+                const int slot = pk[k] >> 8;
+                const int src = slot_src[slot];
+                if (src >= 0 && slot >= NX) {
+                    r.pv[k] = load_chunk<S, H>(gp + src + (pk[k] & 255) * H);
+                    r.cnt[k] = slot_src[slot + aux] * 2;
+                }
+            }
+        }
+    }
+    __device__ static void pool_expand(const PoolRegs &r, char *tile) {
+        using CT = typename T::C;
+        constexpr int H = E >= 2 ? E / 2 : 1;
+#pragma unroll
+        for (int k = 0; k < kRegPieces; ++k) {
+            if (r.cnt[k] > 0) {
+                Chunk<S, E> out;
+#pragma unroll
+                for (int h = 0; h < H; ++h) {
+                    const S q = narrow<T>(div_count<CT>(widen<T>(r.pv[k].e[h]), r.cnt[k]));
+                    out.e[2 * h] = q;
+                    if (E >= 2) out.e[2 * h + 1] = q;
+                }
+                __builtin_memcpy(__builtin_assume_aligned(tile + (k * kThreads + static_cast<int>(threadIdx.x)) * 16, 16), out.e, 16);
+            }
+        }
+    }
+    __device__ static void dma_x_decoded(int NX, const S *xp, const int *slot_src, char *tile, const int (&pk)[kRegPieces]) {
+        const int wave = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x) >> 6);
+#pragma unroll
+        for (int k = 0; k < kRegPieces; ++k) {
+            if (pk[k] >= 0 && (pk[k] >> 8) < NX) {
+                const int src = slot_src[pk[k] >> 8];
+                if (src >= 0) {
+                    const S *g = xp + src + (pk[k] & 255) * E;
+                    char *dst_wave = tile + (k * kThreads + wave * 64) * 16;
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)g,
+                                                     (__attribute__((address_space(3))) void *)dst_wave, 16, 0, 0);
+                }
+            }
+        }
+    }
+
     __device__ static void issue_dma(const PlaneParams &p, int R, const S *xp, const S *gp, const int *slot_src, char *tile,
                                      int aux = 0) {
         const int NX = Shape::nx(R);
@@ -988,6 +1043,8 @@ __global__ __launch_bounds__(kThreads) void plane_backward_lds(const PlaneParams
     const int aux = NT * NS;  // POOL: a second set of tables behind the slot tables
     int pk[Stager::kRegPieces];
     if constexpr (DEC) Stager::decode_pieces(p, R, pk);
+    constexpr bool kPrefetchPool = DEC && POOL && sizeof(S) == 2;  // (fp32: 1.67 -> 2.09 ms with it)
+    typename Stager::PoolRegs pregs;
     int nl = 0, r0 = wi.row0, buf = 0, tb = 0;
     {
         const int a = fdiv(r0, p.d_dim1);
@@ -1000,13 +1057,17 @@ __global__ __launch_bounds__(kThreads) void plane_backward_lds(const PlaneParams
     const S *gp = static_cast<const S *>(p.go) + plane0 * p.o_plane;
     S *gxp = static_cast<S *>(p.out) + plane0 * p.x_plane;
     const int64_t xstep = static_cast<int64_t>(p.C) * p.x_plane, gstep = static_cast<int64_t>(p.C) * p.o_plane;
+    if constexpr (kPrefetchPool) Stager::pool_load(NX, gp, slot_src, pk, aux, pregs);  // pooled values of the first step
     while (nl < wi.nn) {
         const int a = fdiv(r0, p.d_dim1);
         const int b0 = r0 - a * S1;
         const int Rn = step_len(r0);
         const int *ss = slot_src + tb * NS;
         char *tile = tile0 + (TILES == 2 ? buf * p.tile_bytes : 0);
-        if constexpr (DEC && POOL) Stager::issue_dma_decoded_pool(NX, xp, gp, ss, tile, pk, aux);
+        if constexpr (kPrefetchPool) {
+            Stager::dma_x_decoded(NX, xp, ss, tile, pk);
+            Stager::pool_expand(pregs, tile);
+        } else if constexpr (DEC && POOL) Stager::issue_dma_decoded_pool(NX, xp, gp, ss, tile, pk, aux);
         else if constexpr (DEC) Stager::issue_dma_decoded(NX, xp, gp, ss, tile, pk);
         else Stager::issue_dma(p, R, xp, gp, ss, tile, aux);
         int nl2 = nl, r2 = r0 + Rn;
@@ -1017,6 +1078,9 @@ __global__ __launch_bounds__(kThreads) void plane_backward_lds(const PlaneParams
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
+        if constexpr (kPrefetchPool) {  // request the next step's pooled values; they arrive behind this step's compute
+            if (nl2 < wi.nn) Stager::pool_load(NX, nl2 != nl ? gp + gstep : gp, slot_src + ((tb + 1) % NT) * NS, pk, aux, pregs);
+        }
         if (worker && tr < Rn) {
             Chunk<S, E> res;
             // phase 1: grad_x (its corner values are dead before the x corners are read: fewer live registers)

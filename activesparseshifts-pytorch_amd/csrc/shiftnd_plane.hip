@@ -735,7 +735,8 @@ struct LdsStager {
     // Which pieces a thread moves never changes from step to step: piece k of a thread is q = k * kThreads + tid.
     // Its (slot, column piece) pair is decoded once, packed as slot * 256 + j (or -1), and the per-step work is the
     // slot-table read, one address and the DMA.  For steps of at most kRegPieces pieces per thread (cpr <= 256).
-    static constexpr int kRegPieces = (ACTIVE || POOL || sizeof(S) == 2) ? 4 : 3;  // (3 keeps the 2-D SSL fp32 kernel at 64 VGPRs)
+    // (3 keeps the 2-D SSL fp32 kernel at 64 VGPRs; the 3-D kernels stage up to 49 short rows per step)
+    static constexpr int kRegPieces = ND == 3 ? 6 : ((ACTIVE || POOL || sizeof(S) == 2) ? 4 : 3);
     __host__ __device__ static bool pieces_fit(int cpr, int R) {
         return Shape::slots(R) * cpr <= kRegPieces * kThreads && cpr <= 256;
     }

@@ -11,7 +11,7 @@ namespace {
 
 thread_local int g_last_path = SHIFTND_PATH_NONE;
 thread_local const char *g_last_kernel = "";
-int g_policy = 0;  // 0 auto, 1 force strided, 2 plane kernels (or fail), 3 sweep kernels (or fail)
+thread_local int g_policy = 0;  // 0 auto, 1 force strided, 2 plane kernels (or fail), 3 sweep kernels (or fail)
 
 bool is_float_dtype(int dt) { return dt >= SHIFTND_F32 && dt <= SHIFTND_BF16; }
 bool is_quant_dtype(int dt) { return dt >= SHIFTND_I8 && dt <= SHIFTND_I32; }

@@ -1382,7 +1382,7 @@ bool contiguous(const int64_t st[5], int64_t N, int64_t C, const int64_t sz[3]) 
 // 2 = gather-forward unroll (fp32/16-byte variant only), 6 = XCD-contiguous workgroup ids, 7 = workgroups
 // wanted by the backward kernels (0 = automatic, see backward_min_wgs), 3 = backward / active-forward kernel: 2 LDS-staged where it applies (default), 1 direct global loads;
 // 4 = LDS tiles of the backward kernel: 1 automatic, 2 two tiles + one barrier per step, 3 one tile; 5 = 1: no affine dword reads
-int g_tune[8] = {0, 128 * 1024, 4, 2, 1, 0, 1, 0};
+thread_local int g_tune[8] = {0, 128 * 1024, 4, 2, 1, 0, 1, 0};
 
 struct Plan {
     int V, cpr, CW, RPS, CP, ppw, groups, bands, rows_per_band, rows;

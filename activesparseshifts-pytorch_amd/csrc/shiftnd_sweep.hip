@@ -27,7 +27,7 @@ namespace shiftnd {
 namespace {
 
 constexpr int kSweepMaxThreads = 512;
-int g_sweep_tune[4] = {4, 512, 2, 256};  // [0] forward row steps per workgroup (K), [1] forward max threads,
+thread_local int g_sweep_tune[4] = {4, 512, 2, 256};  // [0] forward row steps per workgroup (K), [1] forward max threads,
                                          // [2] backward K, [3] backward max threads
 
 struct SweepParams {

@@ -16,7 +16,12 @@ The JSON line also carries
   cpu_baseline  the REAL reference CPU kernels (oracle/_ref, built from /root/reference) timed on
                 this host in a child process on a bounded sample (rank 0, --gpus 1 only)
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c2|c3|c4|c5] [--pad 0..4]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c2|c3|c4|c5|c2a] [--pad 0..4]
+
+Multi-GPU: `python bench.py --gpus N` starts the N rank processes itself (one per GPU; the parent never
+touches the GPU); under a launcher (`python -m torch.distributed.run --nproc-per-node N bench.py --gpus N`)
+the ranks come from RANK / LOCAL_RANK / WORLD_SIZE.  BASELINE config 5 (N512 C512 224x224 fp16 over 8 GPUs)
+is `python bench.py --workload c5 --gpus 8`.
 """
 import argparse
 import json
@@ -36,6 +41,8 @@ WORKLOADS = {
     "c3": (3, (8, 128, 16, 112, 112), "bfloat16", True, "Shift3d active fwd+bwd N8 C128 16x112x112 bf16"),
     "c4": (2, (128, 512, 56, 56), "quint8", False, "quantized Shift2d forward N128 C512 56x56 quint8"),
     "c5": (2, (64, 512, 224, 224), "float16", False, "Shift2d SSL fwd+bwd N64 C512 224x224 fp16 (per GPU)"),
+    # not a BASELINE config: C2's tensor through the interpolating (active) kernels
+    "c2a": (2, (64, 256, 224, 224), "float32", True, "Shift2d active fwd+bwd N64 C256 224x224 fp32"),
 }
 
 
@@ -47,15 +54,72 @@ def shard_range(n, rank, world):
     return lo, lo + base + (1 if rank < rem else 0)
 
 
-def cpu_baseline():
-    """must run before this process touches the GPU (child process; see oracle/ref_bench.py)"""
+def cpu_baseline(workload_pad=0):
+    """The REAL reference CPU kernels on this host (oracle/ref_bench.py, child process, before this process touches
+    the GPU).  SURVEY section 8d: timed with 1 thread AND with all host cores, host CPU model and core count stated.
+    `value`/`cores` = the all-cores run (the reference's at::parallel_for over N*C); `single_thread` beside it (the
+    only run whose weight gradient is race-free in the reference, global_scope.h:22)."""
+    script = os.path.join(ROOT, "oracle", "ref_bench.py")
     try:
-        out = subprocess.run([sys.executable, os.path.join(ROOT, "oracle", "ref_bench.py"), "--n", "8", "--threads", "1",
-                              "--iters", "2"], capture_output=True, text=True, timeout=600)
-        line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
-        return json.loads(line)
+        out = subprocess.run([sys.executable, script, "--n", "8", "--pad", str(workload_pad), "--iters", "2", "--both"],
+                             capture_output=True, text=True, timeout=900)
+        lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+        if out.returncode != 0 or not lines:
+            raise RuntimeError("ref_bench.py exit %d: %s" % (out.returncode, (out.stderr or out.stdout)[-300:]))
+        return json.loads(lines[-1])
     except Exception as e:  # noqa: BLE001
-        return {"value": None, "unit": "Gelem/s", "cores": 0, "kind": "unavailable", "sample": repr(e)[:200]}
+        return {"value": None, "unit": "Gelem/s", "cores": 0, "kind": "unavailable", "sample": repr(e)[:300]}
+
+
+def newest_traffic(workload, kernel_name, pad):
+    """HBM bytes per launch of the dominant kernel from the newest committed PMC profile of this workload
+    (profiles/r<NN>_<workload>_traffic.json, written by profiles/collect.sh + summarize.py: counters need their own
+    rocprofv3 passes, they cannot be read inside the timed process).  None when no profile names this kernel."""
+    import glob
+    import re
+    if pad != 0:
+        return None, None
+    best = None
+    for f in glob.glob(os.path.join(ROOT, "profiles", "r*_%s_traffic.json" % workload)):
+        m = re.match(r"r(\d+)_", os.path.basename(f))
+        if m and (best is None or int(m.group(1)) > best[0]):
+            best = (int(m.group(1)), f)
+    if best is None:
+        return None, None
+    try:
+        t = json.load(open(best[1]))["per_launch"].get(kernel_name)
+        if t and "read_bytes" in t and "written_bytes" in t:
+            return t["read_bytes"] + t["written_bytes"], "profiles/%s (round %d)" % (os.path.basename(best[1]), best[0])
+    except (OSError, ValueError, KeyError):
+        pass
+    return None, None
+
+
+def free_port():
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def launch_ranks(a, argv):
+    """`python bench.py --gpus N` without a launcher: start N rank processes (one per GPU) and wait.  This parent
+    never imports torch or touches the GPU; the children are fresh interpreters (no exec from a GPU process)."""
+    env = dict(os.environ)
+    env.setdefault("MASTER_ADDR", "127.0.0.1")
+    env.setdefault("MASTER_PORT", str(free_port()))
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env["WORLD_SIZE"] = env["LOCAL_WORLD_SIZE"] = str(a.gpus)
+    procs = []
+    for r in range(a.gpus):
+        e = dict(env, RANK=str(r), LOCAL_RANK=str(r))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=e))
+    rc = 0
+    for p in procs:
+        rc = max(rc, abs(p.wait()))
+    return rc
 
 
 def synth_tensor(torch, shape, seed, device, dtype, lo=0.0, hi=1.0):
@@ -77,23 +141,41 @@ def synth_tensor(torch, shape, seed, device, dtype, lo=0.0, hi=1.0):
     return out.view(*shape)
 
 
-def main():
+def parse_args(argv):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS))
     ap.add_argument("--pad", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    a = ap.parse_args()
+    ap.add_argument("--shape", default=None,
+                    help="comma-separated per-GPU shape replacing the workload's (functional checks of the rank code "
+                         "only: the JSON line then says so and is not a measurement of the named workload)")
+    ap.add_argument("--device", default="cuda", choices=("cuda", "cpu"),
+                    help="cpu = run the rank/launcher plumbing on the CPU dispatch key with gloo (tests only; "
+                         "no roofline, never a result)")
+    return ap.parse_args(argv)
+
+
+def main(argv=None):
+    argv = list(sys.argv[1:] if argv is None else argv)
+    a = parse_args(argv)
+
+    if "WORLD_SIZE" not in os.environ and a.gpus > 1:
+        sys.exit(launch_ranks(a, argv))  # parent: no torch, no GPU call
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != a.gpus:
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d (launch with `python bench.py --gpus N`, or "
+                         "`python -m torch.distributed.run --nproc-per-node N bench.py --gpus N`)" % (a.gpus, world))
 
     base = None
-    if rank == 0 and world == 1 and a.gpus == 1 and not a.no_cpu_baseline:
-        base = cpu_baseline()  # before any GPU initialisation in this process
+    if rank == 0 and world == 1 and a.workload == "c2" and a.shape is None and a.device == "cuda" \
+            and not a.no_cpu_baseline:
+        base = cpu_baseline(a.pad)  # child process, before any GPU initialisation in this process
 
     import torch
     import torch.distributed as dist
@@ -103,15 +185,20 @@ def main():
     from torchshifts.extension import _assert_has_ops
     _assert_has_ops()
 
-    if not torch.cuda.is_available():
+    on_gpu = a.device == "cuda"
+    if on_gpu and not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback exists for the measured path)")
-    # one process per GPU.  SHIFTND_BENCH_BACKEND=gloo lets the multi-rank code path be exercised on a box with
-    # fewer GPUs than ranks (ranks then share devices; collectives run on host tensors) -- a functional check only.
-    backend = os.environ.get("SHIFTND_BENCH_BACKEND", "nccl")
-    ndev = torch.cuda.device_count()
-    dev_index = local_rank if backend == "nccl" else local_rank % max(ndev, 1)
-    torch.cuda.set_device(dev_index)
-    dev = torch.device("cuda", dev_index)
+    # One process per GPU over RCCL.  When the box has fewer GPUs than ranks (a 1-GPU box running `--gpus 2` as a
+    # functional check of the rank code) the ranks share devices and rendezvous over gloo; the line says so.
+    ndev = torch.cuda.device_count() if on_gpu else 0
+    backend = os.environ.get("SHIFTND_BENCH_BACKEND") or ("nccl" if on_gpu and ndev >= world else "gloo")
+    oversubscribed = on_gpu and ndev < world
+    if on_gpu:
+        dev_index = local_rank % max(ndev, 1)
+        torch.cuda.set_device(dev_index)
+        dev = torch.device("cuda", dev_index)
+    else:
+        dev = torch.device("cpu")
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if backend == "nccl":
@@ -119,7 +206,15 @@ def main():
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
 
+    def sync():
+        if on_gpu:
+            torch.cuda.synchronize()
+
     nd, shape, dtname, active, desc = WORKLOADS[a.workload]
+    if a.shape:
+        shape = tuple(int(v) for v in a.shape.split(","))
+        assert len(shape) == nd + 2, "--shape needs %d dims for workload %s" % (nd + 2, a.workload)
+        desc = "FUNCTIONAL CHECK shape %s of: %s" % (list(shape), desc)
     # weak scaling: the global batch is world x the per-GPU batch; this rank owns one contiguous slice
     lo, hi = shard_range(shape[0] * world, rank, world)
     shape = (hi - lo,) + tuple(shape[1:])
@@ -146,11 +241,13 @@ def main():
         esize = 1
     else:
         dtype = getattr(torch, dtname)
+        if not on_gpu and dtype in (torch.float16, torch.bfloat16):
+            dtype = torch.float32  # the CPU key serves float/double like the reference's (shifts_cpu.cpp:228)
         x = synth_tensor(torch, shape, seed + 1, dev, dtype)
         go = synth_tensor(torch, shape, seed + 2, dev, dtype)
         w = w32.to(dtype)
         esize = x.element_size()
-    torch.cuda.synchronize()
+    sync()
 
     def step():
         if quant:
@@ -160,10 +257,10 @@ def main():
         return out, gx, gw
 
     def barrier():
-        torch.cuda.synchronize()
+        sync()
         if world > 1:
             dist.barrier()
-        torch.cuda.synchronize()
+        sync()
 
     for _ in range(a.warmup):
         step()
@@ -179,67 +276,71 @@ def main():
         dt = float(t.item())
     ms_per_step = dt / a.steps * 1e3
 
+    # ---- per-step spread (median / min over single steps; outside the contract's timed region) -----------
+    singles = []
+    for _ in range(min(a.steps, 50)):
+        sync()
+        t1 = time.perf_counter()
+        step()
+        sync()
+        singles.append((time.perf_counter() - t1) * 1e3)
+    singles.sort()
+
     # ---- per-kernel durations: HIP events on the launch stream, kernels called through the C ABI -------
     def event_time(fn, iters):
         stream = torch.cuda.current_stream()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         fn()
         torch.cuda.synchronize()
-        e0.record(stream)
-        for _ in range(iters):
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(iters + 1)]
+        ev[0].record(stream)
+        for i in range(iters):
             fn()
-        e1.record(stream)
-        e1.synchronize()
-        return e0.elapsed_time(e1) / iters  # ms
+            ev[i + 1].record(stream)
+        ev[-1].synchronize()
+        per = sorted(ev[i].elapsed_time(ev[i + 1]) for i in range(iters))
+        return ev[0].elapsed_time(ev[-1]) / iters, per[len(per) // 2], per[0]  # mean, median, min (ms)
 
     kiters = max(5, a.steps)
     kernels = {}
-    if quant:
-        xi = xq.int_repr()
-        wi = wq.int_repr()
-        outb = torch.empty_like(xi)
-        t_f = event_time(lambda: abi.forward_quantized(xi, wi, 128, 0, a.pad, out=outb), kiters)
-        qname = abi.last_kernel()
-        kernels[qname] = {"ms": t_f, "GB/s": 2 * esize * elems / t_f / 1e6}
-        dom_name, dom_ms, dom_bytes = qname, t_f, 2 * esize * elems
-    else:
-        outb, gxb, gwb = torch.empty_like(x), torch.empty_like(x), torch.empty_like(w)
-        ws = abi.backward_workspace(x, a.pad, active)
-        t_f = event_time(lambda: abi.forward(x, w, a.pad, active, out=outb), kiters)
-        t_b = event_time(lambda: abi.backward(go, w, x, a.pad, active, grad_x=gxb, grad_w=gwb, workspace=ws), kiters)
-        abi.forward(x, w, a.pad, active, out=outb)
-        fname = abi.last_kernel()
-        abi.backward(go, w, x, a.pad, active, grad_x=gxb, grad_w=gwb, workspace=ws)
-        bname = abi.last_kernel()
-        kernels[fname] = {"ms": t_f, "GB/s": 2 * esize * elems / t_f / 1e6}
-        kernels[bname] = {"ms": t_b, "GB/s": 3 * esize * elems / t_b / 1e6}
-        dom_name, dom_ms, dom_bytes = bname, t_b, 3 * esize * elems
-    path = "+".join(sorted(set(k.split("_")[0] for k in kernels)))
+    dom_name = dom_ms = dom_bytes = None
+    if on_gpu:
+        def record(name, t, nbytes):
+            kernels[name] = {"ms": t[0], "median_ms": t[1], "min_ms": t[2], "GB/s": nbytes / t[0] / 1e6}
+        if quant:
+            xi = xq.int_repr()
+            wi = wq.int_repr()
+            outb = torch.empty_like(xi)
+            t_f = event_time(lambda: abi.forward_quantized(xi, wi, 128, 0, a.pad, out=outb), kiters)
+            qname = abi.last_kernel()
+            record(qname, t_f, 2 * esize * elems)
+            dom_name, dom_ms, dom_bytes = qname, t_f[0], 2 * esize * elems
+        else:
+            outb, gxb, gwb = torch.empty_like(x), torch.empty_like(x), torch.empty_like(w)
+            ws = abi.backward_workspace(x, a.pad, active)
+            t_f = event_time(lambda: abi.forward(x, w, a.pad, active, out=outb), kiters)
+            t_b = event_time(lambda: abi.backward(go, w, x, a.pad, active, grad_x=gxb, grad_w=gwb, workspace=ws), kiters)
+            abi.forward(x, w, a.pad, active, out=outb)
+            fname = abi.last_kernel()
+            abi.backward(go, w, x, a.pad, active, grad_x=gxb, grad_w=gwb, workspace=ws)
+            bname = abi.last_kernel()
+            record(fname, t_f, 2 * esize * elems)
+            record(bname, t_b, 3 * esize * elems)
+            dom_name, dom_ms, dom_bytes = bname, t_b[0], 3 * esize * elems
+    path = "+".join(sorted(set(k.split("_")[0] for k in kernels))) or "cpu key"
 
     if rank == 0:
-        achieved = dom_bytes / dom_ms / 1e6  # GB/s
-        # HBM bytes per launch of the dominant kernel from the PMC passes of this same command (profiles/collect.sh
-        # cannot run inside the timed process: counters need their own rocprofv3 runs); null when no profile of this
-        # workload is committed
-        traffic, traffic_src = None, None
-        tpath = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_%s_traffic.json" % a.workload)
-        if a.pad == 0 and os.path.exists(tpath):
-            try:
-                tj = json.load(open(tpath))
-                t = tj["per_launch"].get(dom_name)
-                if t and "read_bytes" in t and "written_bytes" in t:
-                    traffic, traffic_src = t["read_bytes"] + t["written_bytes"], "profiles/" + os.path.basename(tpath)
-            except (OSError, ValueError, KeyError):
-                pass
         step_bytes = (2 if quant else 5) * esize * elems
         result = {
-            "metric": "Gelem/s, Shift2d fwd+bwd N64/C256/224x224" if a.workload == "c2" else "Gelem/s, " + desc,
+            "metric": "Gelem/s, Shift2d fwd+bwd N64/C256/224x224" if a.workload == "c2" and not a.shape
+                      else "Gelem/s, " + desc,
             "value": elems * world / (ms_per_step * 1e-3) / 1e9,
             "unit": "Gelem/s",
             "n_gpus": world,
             "steps": a.steps,
             "warmup": a.warmup,
             "ms_per_step": ms_per_step,
+            "ms_per_step_median": singles[len(singles) // 2],
+            "ms_per_step_min": singles[0],
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
@@ -247,18 +348,31 @@ def main():
             "data": "synthetic",
             "config": {"workload": desc + ", padding %d, per GPU; batch sharded over %d GPU(s), no collectives"
                                    % (a.pad, world),
-                       "path": "torch.ops.torchshifts._shift%dd_forward/_backward -> libshiftnd_hip.so (%s kernels)"
-                               % (nd, path)},
+                       "path": ("torch.ops.torchshifts._shift%dd_forward/_backward -> libshiftnd_hip.so (%s kernels)"
+                                % (nd, path)) if on_gpu else "torch.ops.torchshifts (CPU dispatch key of _C.so)",
+                       "ranks": {"world": world, "backend": backend if world > 1 else None, "devices": ndev,
+                                 "oversubscribed": oversubscribed}},
             "achieved_hbm_GBps_step": step_bytes / (ms_per_step * 1e-3) / 1e9,
-            "roofline": {"bound": "hbm", "kernel": dom_name, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
-                         "avg_kernel_ms": dom_ms, "algorithmic_bytes": dom_bytes},
             "kernels": kernels,
         }
+        if dom_name is not None:
+            achieved = dom_bytes / dom_ms / 1e6  # GB/s
+            traffic, traffic_src = newest_traffic(a.workload, dom_name, a.pad) if not a.shape else (None, None)
+            result["roofline"] = {"bound": "hbm", "kernel": dom_name, "achieved": achieved, "peak": HBM_PEAK_GBS,
+                                  "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                                  "traffic_source": traffic_src, "avg_kernel_ms": dom_ms,
+                                  "algorithmic_bytes": dom_bytes}
+        else:
+            result["roofline"] = None
+        if not on_gpu:
+            result["data"] = "synthetic; CPU functional check of the rank code, not a measurement"
+        if oversubscribed:
+            result["data"] = "synthetic; %d ranks share %d GPU(s): functional check, not a scaling point" % (world, ndev)
         if base is not None:
             result["cpu_baseline"] = base
         print(json.dumps(result), flush=True)
     if world > 1:
+        dist.barrier()
         dist.destroy_process_group()
 
 

@@ -99,7 +99,10 @@ SHIFTND_API int shiftnd_last_path(void);
 /* Diagnostics: name (without template arguments) of the main kernel the last call on this thread launched. */
 SHIFTND_API const char *shiftnd_last_kernel(void);
 /* 0 = automatic (sweep, else plane, else channels-last, else strided), 1 = force the strided fallback,
- * 2 = plane kernels or fail, 3 = sweep kernels or fail, 4 = channels-last kernels or fail (testing). */
+ * 2 = plane kernels or fail, 3 = sweep kernels or fail, 4 = channels-last kernels or fail (testing).
+ * THREAD-LOCAL like shiftnd_last_path: the policy and the tuning knobs below apply to calls made on the calling
+ * thread only, so a diagnostic setter can never re-route a concurrent caller (dispatcher threads, autograd
+ * worker threads always run with the defaults). */
 SHIFTND_API void shiftnd_set_path_policy(int policy);
 /* Diagnostics: launch-planning knobs of the plane kernels (0: minimum workgroups wanted, 1: target
  * bytes per workgroup, 2: gather-forward unroll).  Results never depend on them. */

@@ -1,0 +1,85 @@
+"""bench.py's own rank code: the self-launcher (`--gpus N` without WORLD_SIZE starts N rank
+processes before anything touches a GPU), init_process_group / barrier / all_reduce(MAX) / the one JSON line of rank 0.
+On this CPU container the ranks run the CPU dispatch key over gloo (`--device cpu`, a functional check that the JSON
+line labels as such); on the GPU box the same launcher runs 2 ranks on the one GPU."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BENCH = os.path.join(ROOT, "bench.py")
+
+
+def _run(args, env=None, timeout=600):
+    e = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT"):
+        e.pop(k, None)
+    e.update(env or {})
+    return subprocess.run([sys.executable, BENCH] + args, capture_output=True, text=True, timeout=timeout, env=e)
+
+
+def _json_lines(out):
+    return [json.loads(l) for l in out.splitlines() if l.startswith("{")]
+
+
+def test_self_launch_world2_cpu():
+    r = _run(["--gpus", "2", "--device", "cpu", "--shape", "4,8,16,16", "--steps", "2", "--warmup", "1"])
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = _json_lines(r.stdout)
+    assert len(lines) == 1, "exactly one JSON line (rank 0)"
+    j = lines[0]
+    assert j["n_gpus"] == 2 and j["config"]["ranks"] == {"world": 2, "backend": "gloo", "devices": 0,
+                                                          "oversubscribed": False}
+    assert j["scaling"] == "weak" and j["steps"] == 2 and j["warmup"] == 1
+    assert "cpu_baseline" not in j and j["roofline"] is None
+    assert "not a measurement" in j["data"]
+    # weak scaling: value counts the elements of both ranks
+    assert abs(j["value"] - 2 * 4 * 8 * 16 * 16 / (j["ms_per_step"] * 1e-3) / 1e9) < 1e-9
+
+
+def test_under_a_launcher_env_world2_cpu():
+    """what `python -m torch.distributed.run --nproc-per-node 2 bench.py --gpus 2` does: ranks from the env"""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = str(s.getsockname()[1])
+    s.close()
+    args = ["--gpus", "2", "--device", "cpu", "--workload", "c3", "--shape", "2,4,4,6,8", "--steps", "1", "--warmup", "0"]
+    procs = []
+    for r in range(2):
+        e = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=port)
+        procs.append(subprocess.Popen([sys.executable, BENCH] + args, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                                      text=True, env=e))
+    outs = [p.communicate(timeout=600) for p in procs]
+    assert all(p.returncode == 0 for p in procs), outs
+    assert len(_json_lines(outs[0][0])) == 1 and _json_lines(outs[1][0]) == []
+    assert _json_lines(outs[0][0])[0]["n_gpus"] == 2
+
+
+def test_gpus_must_match_world_size():
+    r = _run(["--gpus", "4", "--device", "cpu", "--shape", "4,8,16,16"], env={"WORLD_SIZE": "1", "RANK": "0"})
+    assert r.returncode != 0 and "WORLD_SIZE=1" in r.stderr
+
+
+def test_no_cpu_fallback_for_the_measured_path():
+    """default device is the GPU; without one the bench refuses instead of timing the CPU key"""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    r = _run(["--steps", "1", "--no-cpu-baseline"])
+    assert r.returncode != 0 and "needs an MI355X" in r.stderr
+
+
+@pytest.mark.gpu
+def test_self_launch_two_ranks_on_this_gpu_box():
+    """`python bench.py --gpus 2` on a 1-GPU box: both ranks share the GPU and rendezvous over gloo (with >= 2 GPUs:
+    RCCL); functional check of the launcher + rank code with the HIP kernels"""
+    r = _run(["--gpus", "2", "--shape", "8,32,56,56", "--steps", "3", "--warmup", "1"])
+    assert r.returncode == 0, r.stderr[-2000:]
+    j = _json_lines(r.stdout)
+    assert len(j) == 1 and j[0]["n_gpus"] == 2
+    assert j[0]["roofline"]["kernel"].startswith(("plane_", "sweep_"))
+    assert "cpu_baseline" not in j[0]

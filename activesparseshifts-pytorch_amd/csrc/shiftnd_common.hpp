@@ -141,6 +141,21 @@ __host__ __device__ __forceinline__ int fold_index(int idx, int len, int pad) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// LDS index maps of the per-channel kernels (one workgroup = one channel = one shift per dim):
+// map_d[p] = pad_index(p + sign*shift_d) for p in [0, size_d] (size_d + 1 entries: the interpolating
+// kernels also read coordinate p + 1), the three normalised dims back to back.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void build_maps(int *maps, const int size[3], const int64_t sh[3], int sign, int pad) {
+    const int n0 = size[0] + 1, n1 = size[1] + 1, n2 = size[2] + 1;
+    for (int t = threadIdx.x; t < n0 + n1 + n2; t += kThreads) {
+        const int d = t < n0 ? 0 : (t < n0 + n1 ? 1 : 2);
+        const int p = t - (d == 0 ? 0 : (d == 1 ? n0 : n0 + n1));
+        const int64_t len = size[d];
+        maps[t] = (len == 1) ? 0 : static_cast<int>(pad_index(static_cast<int64_t>(p) + sign * sh[d], len, pad));
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // Per-channel shift preparation (cpu/shifts_cpu.cpp:223-224 forward, :242-244 backward).
 // Rounding is half-to-even (torch::round on the CPU path), i.e. rint in the default mode.
 // ---------------------------------------------------------------------------------------------

@@ -55,6 +55,16 @@ bool plane_pool_backward_eligible(const Geometry &g, int dtype, const void *gx);
 int plane_pool_backward(const Geometry &g, int dtype, const void *go, const void *x, const void *w, void *gx, void *gw,
                         void *workspace, hipStream_t st);
 
+// ---- sliding-window kernels (shiftnd_slide.hip): backward pass and interpolating forward of contiguous 2-D / 3-D
+// problems without crop; part of the per-channel ("plane") family: plane_forward / plane_backward route to them
+bool slide_backward_eligible(const Geometry &g, int dtype, const void *go, const void *x, const void *gx);
+size_t slide_backward_workspace(const Geometry &g, int dtype);
+int slide_backward(const Geometry &g, int dtype, const void *go, const void *x, const void *w, void *gx, void *gw,
+                   void *workspace, hipStream_t st);
+bool slide_forward_eligible(const Geometry &g, int dtype, const void *x, const void *out);
+int slide_forward(const Geometry &g, int dtype, const void *x, const void *w, void *out, hipStream_t st);
+void slide_set_tuning(int knob, int value);
+
 // ---- channel-fastest kernels for channels-last tensors (shiftnd_cl.hip): any strides, x with unit channel stride --
 bool cl_forward_eligible(const Geometry &g);
 bool cl_forward_preferred(const Geometry &g);   // eligible and the output is channel-fastest too

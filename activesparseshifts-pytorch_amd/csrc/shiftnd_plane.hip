@@ -58,18 +58,6 @@ struct PlaneParams {
     FastDiv d_p2;
 };
 
-// Fill the LDS maps of the three normalised dims: map_d[p] = pad(p + sign*shift_d) for p in [0, size_d].
-// (size_d + 1 entries: the interpolating kernels also read coordinate p + 1.)
-__device__ __forceinline__ void build_maps(int *maps, const int size[3], const int64_t sh[3], int sign, int pad) {
-    const int n0 = size[0] + 1, n1 = size[1] + 1, n2 = size[2] + 1;
-    for (int t = threadIdx.x; t < n0 + n1 + n2; t += kThreads) {
-        const int d = t < n0 ? 0 : (t < n0 + n1 ? 1 : 2);
-        const int p = t - (d == 0 ? 0 : (d == 1 ? n0 : n0 + n1));
-        const int64_t len = size[d];
-        maps[t] = (len == 1) ? 0 : static_cast<int>(pad_index(static_cast<int64_t>(p) + sign * sh[d], len, pad));
-    }
-}
-
 struct WorkItem {  // which planes / rows this workgroup owns
     int c, n0, nn, row0, nrows, pidx;
 };
@@ -1748,6 +1736,7 @@ int plane_forward(const Geometry &g, int dtype, const void *x, const void *w, in
     p.wzp = wzp;
     p.fill = fill_bits;
     if (interpolating) {
+        if (slide_forward_eligible(g, dtype, x, out)) return slide_forward(g, dtype, x, w, out, st);
         const Plan pl = make_plan(g, g.O[0] * g.O[1], g.O[2], es, 16, entries);
         fill_params(p, g, pl, g.O[1]);
         switch (dtype) {
@@ -1800,7 +1789,9 @@ bool plane_backward_eligible(const Geometry &g, int dtype, const void *go, const
 
 size_t plane_backward_workspace(const Geometry &g, int dtype) {
     const Plan pl = backward_plan(g, dtype_size(dtype));
-    return static_cast<size_t>(pl.groups) * pl.bands * static_cast<size_t>(g.C) * 3 * sizeof(double);
+    const size_t own = static_cast<size_t>(pl.groups) * pl.bands * static_cast<size_t>(g.C) * 3 * sizeof(double);
+    const size_t slide = g.K[0] > 0 ? 0 : slide_backward_workspace(g, dtype);  // (the fused-pool calls never slide)
+    return own > slide ? own : slide;
 }
 
 // ---- fused shift + average pool (contiguous tensors; g.K / g.P set) -----------------------------------------
@@ -1855,6 +1846,7 @@ int plane_pool_backward(const Geometry &g, int dtype, const void *go, const void
 
 int plane_backward(const Geometry &g, int dtype, const void *go, const void *x, const void *w, void *gx, void *gw,
                    void *workspace, hipStream_t st) {
+    if (slide_backward_eligible(g, dtype, go, x, gx)) return slide_backward(g, dtype, go, x, w, gx, gw, workspace, st);
     const Plan pl = backward_plan(g, dtype_size(dtype));
     PlaneParams p{};
     p.x = x;

@@ -17,13 +17,19 @@ def main(root):
     traffic = defaultdict(dict)  # kernel base name -> {"read_bytes", "written_bytes"} per launch (for bench.py)
     for f in glob.glob(os.path.join(root, "trace", "**", "*kernel_trace.csv"), recursive=True):
         dur = defaultdict(list)
+        res = {}
         for r in csv.DictReader(open(f)):
-            dur[short(r["Kernel_Name"])].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+            k = short(r["Kernel_Name"])
+            dur[k].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+            res[k] = "vgpr %s agpr %s sgpr %s lds %s wg %s grid %s" % (
+                r.get("VGPR_Count", "?"), r.get("Accum_VGPR_Count", "?"), r.get("SGPR_Count", "?"),
+                r.get("LDS_Block_Size", "?"), r.get("Workgroup_Size_X", r.get("Workgroup_Size", "?")),
+                r.get("Grid_Size_X", r.get("Grid_Size", "?")))
         print("== kernel trace:", os.path.relpath(f, root))
         print("%-92s %6s %12s %12s" % ("kernel", "calls", "avg_us", "min_us"))
         for k, v in sorted(dur.items(), key=lambda kv: -sum(kv[1])):
-            if any(t in k for t in ("sweep_", "plane_", "strided_", "reduce_weight")):
-                print("%-92s %6d %12.1f %12.1f" % (k, len(v), sum(v) / len(v) / 1e3, min(v) / 1e3))
+            if any(t in k for t in ("sweep_", "plane_", "strided_", "reduce_weight", "cl_", "transpose")):
+                print("%-92s %6d %12.1f %12.1f   %s" % (k, len(v), sum(v) / len(v) / 1e3, min(v) / 1e3, res[k]))
     for d in sorted(glob.glob(os.path.join(root, "pmc_*"))):
         for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
             acc = defaultdict(lambda: defaultdict(list))
@@ -31,7 +37,7 @@ def main(root):
                 acc[short(r["Kernel_Name"])][r["Counter_Name"]].append(float(r["Counter_Value"]))
             print("== pmc:", os.path.relpath(f, root))
             for k, ctrs in acc.items():
-                if not any(t in k for t in ("sweep_", "plane_", "strided_")):
+                if not any(t in k for t in ("sweep_", "plane_", "strided_", "cl_")):
                     continue
                 for c, v in ctrs.items():
                     avg = sum(v) / len(v)

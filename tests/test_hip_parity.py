@@ -308,6 +308,7 @@ def test_lds_staged_kernels(abi, tiles):
     rs = np.random.RandomState(33)
     cases = [(3, 5, 9, 24), (2, 4, 13, 32), (2, 3, 1, 16), (1, 2, 300, 8), (2, 3, 40, 224), (1, 2, 7, 1000),
              (2, 3, 5, 6, 16), (2, 2, 4, 7, 24), (1, 3, 1, 5, 8), (1, 2, 3, 40, 112), (1, 2, 6, 1, 32)]
+    abi.set_tuning(12, 0)  # (the sliding-window kernels would take the 3-D cases: tests/test_slide_gpu.py)
     try:
         for shape in cases:
             nd = len(shape) - 2
@@ -334,6 +335,7 @@ def test_lds_staged_kernels(abi, tiles):
     finally:
         abi.set_tuning(3, 2)
         abi.set_tuning(4, 1)  # 1 = automatic tile choice
+        abi.set_tuning(12, -1)
 
 
 def test_lds_staged_gather_forward(abi):

@@ -1,0 +1,115 @@
+"""GPU parity of the sliding-window kernels (csrc/shiftnd_slide.hip: backward pass and interpolating forward of
+contiguous 2-D / 3-D problems without crop) against the CPU oracle, through the C ABI.
+
+Bars as everywhere: fp32 forward / grad_x bit-exact (the kernels nest the blends like
+interpolation.h:34-40), grad_w <= 1e-5 relative to the fp64 oracle; 16-bit: the sparse shift bit-exact,
+interpolation within 1 ulp of the 16-bit type.  Launch-planning knobs (12: which problems slide, 13: workgroups
+wanted, 14: minimum rows per band) are swept so that ragged bands, ragged plane groups and ragged unit groups run."""
+import numpy as np
+import pytest
+import torch
+
+from cases import rel_err
+from oracle import oracle as O
+from test_hip_parity import _ulp_close, _weights
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+@pytest.fixture()
+def abi():
+    from torchshifts import abi as A
+    assert torch.cuda.is_available()
+    A.set_path_policy(0)
+    A.set_tuning(12, 3)  # 2-D and 3-D problems slide
+    yield A
+    for k, v in ((12, -1), (13, 0), (14, 16)):
+        A.set_tuning(k, v)
+
+
+SHAPES = [
+    (2, 3, 5, 6, 16), (1, 2, 20, 9, 64), (2, 2, 3, 40, 112), (1, 3, 1, 5, 8), (1, 2, 6, 1, 32), (1, 1, 3, 37, 512),
+    (3, 5, 9, 24), (2, 3, 40, 224), (5, 2, 33, 64), (1, 2, 300, 8), (2, 3, 1, 16), (7, 2, 6, 56), (1, 2, 7, 1000), (2, 1, 5, 1024),
+]
+PLANS = [(0, 16), (100000, 2), (64, 5)]  # (knob 13, knob 14)
+
+
+@pytest.mark.parametrize("plan", PLANS)
+@pytest.mark.parametrize("shape", SHAPES)
+def test_fp32_vs_oracle(abi, shape, plan):
+    rs = np.random.RandomState(sum(shape) * 17 + plan[1])
+    nd = len(shape) - 2
+    x = rs.uniform(-1, 1, size=shape).astype(np.float32)
+    go = rs.uniform(-1, 1, size=shape).astype(np.float32)
+    w = _weights(rs, shape[1], nd, shape[2:]).astype(np.float32)
+    xd, wd, god = (torch.from_numpy(a).to(DEV) for a in (x, w, go))
+    abi.set_tuning(13, plan[0])
+    abi.set_tuning(14, plan[1])
+    for pad in range(5):
+        for active in (0, 1):
+            if active:
+                out = abi.forward(xd, wd, pad, active)
+                assert abi.last_kernel() == "slide_forward", (shape, abi.last_kernel())
+                assert np.array_equal(out.cpu().numpy(), O.forward(x, w, pad, active)), ("fwd", shape, pad)
+            gx, gw = abi.backward(god, wd, xd, pad, active)
+            assert abi.last_kernel() == "slide_backward", (shape, abi.last_kernel())
+            gx_o, _ = O.backward(go, w, x, pad, active)
+            assert np.array_equal(gx.cpu().numpy(), gx_o), ("gx", shape, pad, active)
+            _, gw64 = O.backward(go.astype(np.float64), w.astype(np.float64), x.astype(np.float64), pad, active)
+            assert rel_err(gw.cpu().numpy(), gw64) < 1e-5, ("gw", shape, pad, active)
+
+
+@pytest.mark.parametrize("tdt", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("shape", [(2, 3, 5, 6, 16), (1, 2, 20, 9, 64), (2, 2, 3, 40, 112), (3, 5, 9, 24), (2, 3, 40, 224),
+                                   (5, 2, 33, 64), (1, 2, 300, 8)])
+def test_16bit_vs_oracle(abi, shape, tdt):
+    rs = np.random.RandomState(sum(shape) + 5)
+    nd = len(shape) - 2
+    x16 = torch.from_numpy(rs.uniform(-1, 1, size=shape).astype(np.float32)).to(tdt)
+    go16 = torch.from_numpy(rs.uniform(-1, 1, size=shape).astype(np.float32)).to(tdt)
+    w16 = torch.from_numpy(_weights(rs, shape[1], nd, shape[2:]).astype(np.float32)).to(tdt)
+    x, w, go = x16.float().numpy(), w16.float().numpy(), go16.float().numpy()
+    xd, wd, god = x16.to(DEV), w16.to(DEV), go16.to(DEV)
+    for plan in PLANS[:2]:
+        abi.set_tuning(13, plan[0])
+        abi.set_tuning(14, plan[1])
+        for pad in range(5):
+            for active in (0, 1):
+                gx, gw = abi.backward(god, wd, xd, pad, active)
+                assert abi.last_kernel() == "slide_backward"
+                gx_ref = torch.from_numpy(O.backward(go, w, x, pad, active)[0]).to(tdt)
+                if active:
+                    out = abi.forward(xd, wd, pad, active)
+                    assert abi.last_kernel() == "slide_forward"
+                    ref = torch.from_numpy(O.forward(x, w, pad, active)).to(tdt)
+                    assert _ulp_close(out.cpu(), ref, tdt), ("fwd", shape, pad)
+                    assert _ulp_close(gx.cpu(), gx_ref, tdt), ("gx", shape, pad)
+                else:
+                    assert torch.equal(gx.cpu(), gx_ref), ("gx", shape, pad)
+                _, gw64 = O.backward(go.astype(np.float64), w.astype(np.float64), x.astype(np.float64), pad, active)
+                assert rel_err(gw.float().cpu().numpy(), gw64) < 2 * torch.finfo(tdt).eps, ("gw", shape, pad, active)
+
+
+def test_agrees_with_the_step_tiled_kernels(abi):
+    """same bits as the LDS-staged step kernels of shiftnd_plane.hip (forward, grad_x), deterministic grad_w"""
+    torch.manual_seed(1)
+    for shape, tdt in (((2, 8, 6, 24, 64), torch.float32), ((2, 8, 6, 24, 64), torch.bfloat16), ((4, 6, 48, 96), torch.float16)):
+        nd = len(shape) - 2
+        x = torch.rand(shape, device=DEV).to(tdt)
+        go = torch.rand(shape, device=DEV).to(tdt)
+        w = ((torch.rand(shape[1], nd, device=DEV) - 0.5) * 7).to(tdt)
+        for pad in (0, 3):
+            for active in (0, 1):
+                abi.set_tuning(12, 0)
+                gx0, gw0 = abi.backward(go, w, x, pad, active)
+                assert abi.last_kernel().startswith("plane_backward")
+                out0 = abi.forward(x, w, pad, active)
+                abi.set_tuning(12, 3)
+                gx1, gw1 = abi.backward(go, w, x, pad, active)
+                gx2, gw2 = abi.backward(go, w, x, pad, active)
+                assert abi.last_kernel() == "slide_backward"
+                assert torch.equal(gx0, gx1) and torch.equal(gx1, gx2) and torch.equal(gw1, gw2)
+                assert rel_err(gw1.float().cpu().numpy(), gw0.float().cpu().numpy()) < (1e-5 if tdt == torch.float32 else 2e-2)
+                if active:
+                    assert torch.equal(abi.forward(x, w, pad, active), out0)

@@ -33,8 +33,11 @@
 namespace shiftnd {
 namespace {
 
+#ifndef SLIDE_EU_ATTR
+#define SLIDE_EU_ATTR
+#endif
 constexpr int kGuard = 32;          // zeroed bytes on each side of a staged row
-constexpr int kFlushSteps = 4;      // fp32 partial sums go to the fp64 accumulators every kFlushSteps rows
+constexpr int kFlushSteps = 8;      // fp32 partial sums are blended into the fp64 accumulators every kFlushSteps rows
 
 struct SlideParams {
     const void *x;       // forward: input; backward: saved input
@@ -54,6 +57,7 @@ struct SlideParams {
     int units;           // 2-D: N * bands (n, band) units per channel
     int pitch;           // LDS bytes per staged row (row bytes + 2 guards)
     int tile_bytes;
+    int zslot;           // byte offset, in a tile, of a slot that is never written (all zeros): stands in for fill rows
     int npieces;         // 16-byte pieces staged per step
     unsigned xcd_blocks;
     FastDiv d_cpr, d_bands, d_inner, d_C, d_per;
@@ -69,6 +73,25 @@ template <typename T> __device__ __forceinline__ typename T::C lerp_t(typename T
     // one lerp of interp_t (shiftnd_common.hpp): the reference's mul + mul + add for fp32, mul + fma for 16-bit data
     if constexpr (sizeof(typename T::S) == 2) return lerp1_fused(a, b, x);
     else return lerp1(a, b, x);
+}
+
+// acc + a.lo * b.lo + a.hi * b.hi on packed 16-bit pairs (v_dot2c_f32_bf16 / v_dot2c_f32_f16): the products of two
+// 16-bit values are exact in fp32, and nothing has to be widened first (on gfx950 a widening shift costs as much issue
+// time as this whole instruction; tools/valu_bench.hip)
+template <typename T> __device__ __forceinline__ float dot2_acc(uint32_t a, uint32_t b, float c) {
+    if constexpr (T::kDtype == SHIFTND_BF16) {
+        typedef __bf16 v2 __attribute__((ext_vector_type(2)));
+        v2 x, y;
+        __builtin_memcpy(&x, &a, 4);
+        __builtin_memcpy(&y, &b, 4);
+        return __builtin_amdgcn_fdot2_f32_bf16(x, y, c, false);
+    } else {
+        typedef _Float16 v2 __attribute__((ext_vector_type(2)));
+        v2 x, y;
+        __builtin_memcpy(&x, &a, 4);
+        __builtin_memcpy(&y, &b, 4);
+        return __builtin_amdgcn_fdot2(x, y, c, false);
+    }
 }
 
 // How a thread reads its E + 1 shifted columns of a staged row (one per tensor kind: x rows, grad_out rows).
@@ -123,58 +146,39 @@ template <typename T> __device__ __forceinline__ void unpack_window(const uint32
     }
 }
 
-// NROWS staged rows (slots `slot0`, `slot0 + pitch`, ...) -> widened values of the thread's E + 1 columns
+// The thread's E + 1 shifted columns of NROWS staged rows (`slot[h]`: first byte of the row's slot) as packed windows:
+// 5 dwords per row, first column in the low bits of t[.][0] (16-bit types: two columns per dword).
 template <typename T, int NROWS>
-__device__ __forceinline__ void read_rows(const char *slot0, int pitch, const RowRead &rr, const int *map, int ji,
-                                          typename T::C (&v)[NROWS][16 / sizeof(typename T::S) + 1]) {
+__device__ __forceinline__ void read_rows(const char *const (&slot)[NROWS], const RowRead &rr, const int *map, int ji,
+                                          uint32_t (&t)[NROWS][5]) {
     using S = typename T::S;
-    using CT = typename T::C;
     constexpr int ES = sizeof(S), E = 16 / ES;
     if (rr.affine) {
 #pragma unroll
-        for (int h = 0; h < NROWS; ++h) {
-            uint32_t t[5];
-            read_window<ES>(slot0 + h * pitch + rr.woff, rr.half, t);
-            unpack_window<T>(t, v[h]);
-        }
+        for (int h = 0; h < NROWS; ++h) read_window<ES>(slot[h] + rr.woff, rr.half, t[h]);
     } else {
         int cm[E + 1];
 #pragma unroll
         for (int e = 0; e <= E; ++e) cm[e] = map[ji + e];
 #pragma unroll
         for (int h = 0; h < NROWS; ++h) {
-            const char *body = slot0 + h * pitch + rr.fboff;
+            const char *body = slot[h] + rr.fboff;
+            uint32_t raw[E + 1];
 #pragma unroll
             for (int e = 0; e <= E; ++e) {
-                const S raw = *reinterpret_cast<const S *>(body + (cm[e] > 0 ? cm[e] : 0) * ES);
-                v[h][e] = cm[e] >= 0 ? widen<T>(raw) : CT(0);
+                typename raw_t<ES>::type r = *reinterpret_cast<const typename raw_t<ES>::type *>(body + (cm[e] > 0 ? cm[e] : 0) * ES);
+                raw[e] = cm[e] >= 0 ? static_cast<uint32_t>(r) : 0u;
+            }
+            if constexpr (ES == 2) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) t[h][i] = raw[2 * i] | (raw[2 * i + 1] << 16);
+                t[h][4] = raw[8];
+            } else {
+#pragma unroll
+                for (int i = 0; i < 5; ++i) t[h][i] = raw[i];
             }
         }
     }
-}
-
-// the thread's E shifted columns of one staged row as raw elements (the sparse-shift input gradient: a copy)
-template <typename T>
-__device__ __forceinline__ Chunk<typename T::S, 16 / sizeof(typename T::S)> read_row_raw(const char *slot, const RowRead &rr,
-                                                                                            const int *map, int ji) {
-    using S = typename T::S;
-    constexpr int ES = sizeof(S), E = 16 / ES;
-    Chunk<S, E> c;
-    if (rr.affine) {
-        uint32_t t[5];
-        read_window<ES>(slot + rr.woff, rr.half, t);
-        __builtin_memcpy(c.e, t, 16);
-    } else {
-        S zero;
-        __builtin_memset(&zero, 0, sizeof(S));
-#pragma unroll
-        for (int e = 0; e < E; ++e) {
-            const int cm = map[ji + e];
-            const S raw = *reinterpret_cast<const S *>(slot + rr.fboff + (cm > 0 ? cm : 0) * ES);
-            c.e[e] = cm >= 0 ? raw : zero;
-        }
-    }
-    return c;
 }
 
 // Column state of a lane: affine window (all valid columns consecutive and congruent with the workgroup's
@@ -213,8 +217,8 @@ __device__ __forceinline__ RowRead make_rowread(const int *map, int ji, bool liv
 // One workgroup = one channel c and nseg segments; seg + 1 steps; see the header comment.
 //   ND 2/3; ACTIVE: interpolating (active shift) or sparse shift; BACKWARD: grad_x + weight-gradient partials, else
 //   the interpolating forward.  NP: 16-byte pieces a thread stages per step.
-template <typename T, int ND, bool ACTIVE, bool BACKWARD, int NP>
-__global__ __launch_bounds__(kThreads) void slide_kernel(const SlideParams p) {
+template <typename T, int ND, bool ACTIVE, bool BACKWARD, int NP, int DEPTH>
+__global__ __launch_bounds__(kThreads) SLIDE_EU_ATTR void slide_kernel(const SlideParams p) {
     using S = typename T::S;
     using CT = typename T::C;
     constexpr int ES = sizeof(S), E = 16 / ES;
@@ -302,6 +306,14 @@ __global__ __launch_bounds__(kThreads) void slide_kernel(const SlideParams p) {
     const int ji = tc * E;
     const RowRead rx = make_rowread<ES, E>(m2, ji, worker, dx, RB);
     const RowRead rg = BACKWARD ? make_rowread<ES, E>(g2, ji, worker, dg, RB) : rx;
+    // planes this thread's rows come from: bit h = x plane (a + h) is not fill, bit 2 + h = grad plane likewise
+    int pvalid = 0xf;
+    if constexpr (ND == 3) {
+        if (worker) {
+            pvalid = (m0[a0 + s] >= 0 ? 1 : 0) | (m0[a0 + s + 1] >= 0 ? 2 : 0);
+            if constexpr (BACKWARD) pvalid |= (g0[a0 + s] >= 0 ? 4 : 0) | ((ACTIVE ? g0[a0 + s + 1] : 0) >= 0 ? 8 : 0);
+        }
+    }
     const int oX = s * pitch;                                  // slot bases (bytes from the tile start)
     const int oG = (NSX + s) * pitch + kGuard + tc * 16;        // the incoming gradient at the thread's own position
     const int oGS = (NSX + nseg + s) * pitch;
@@ -312,13 +324,20 @@ __global__ __launch_bounds__(kThreads) void slide_kernel(const SlideParams p) {
 
     // ---- the pieces this thread stages every step -----------------------------------------------------------------
     // kind 0: x rows (through the x maps), 1: grad_out rows at the output position, 2: grad_out rows through the grad maps
-    int pbase[NP], pmeta[NP], pdst[NP];
+    // pdst: LDS byte offset of the piece in a tile | kind << 16, or -1; pbase: element offset of the piece's plane and
+    // column from (n0, c); pseg (2-D only; uniform in 3-D): first row | rows << 15 of the piece's segment
+    int pbase[NP], pdst[NP], pseg[ND == 2 ? NP : 1];
+    int ubstart = 0, ulen = 0;  // 3-D: every segment of the workgroup covers the same rows
+    if constexpr (ND == 3) {
+        int upoff;
+        seg_info(0, upoff, ubstart, ulen);
+    }
 #pragma unroll
     for (int k = 0; k < NP; ++k) {
         const int q = k * kThreads + static_cast<int>(threadIdx.x);
-        pbase[k] = -1;
-        pmeta[k] = 0;
+        pbase[k] = 0;
         pdst[k] = -1;
+        if constexpr (ND == 2) pseg[k] = 0;
         if (q < p.npieces) {
             const int slot = fdiv(q, p.d_cpr), j = q - slot * p.cpr;
             const int kind = slot < NSX ? 0 : (slot < NSX + nseg ? 1 : 2);
@@ -338,95 +357,161 @@ __global__ __launch_bounds__(kThreads) void slide_kernel(const SlideParams p) {
             } else {
                 ok = seg_info(idx, poff, bstart, len);
             }
-            pbase[k] = ok ? poff + j * E : -1;
-            pmeta[k] = kind | (bstart << 2) | (len << 17);
+            pbase[k] = ok ? poff + j * E : 0;  // (absent planes: any readable address; their slots are never read)
+            if constexpr (ND == 2) pseg[k] = bstart | (len << 15);
             const int disp = kind == 0 ? (dx & 12) : (kind == 2 ? (dg & 12) : 0);
-            pdst[k] = slot * pitch + kGuard + j * 16 - disp;
+            pdst[k] = (slot * pitch + kGuard + j * 16 - disp) | (kind << 16);
         }
     }
-    u4 pv[NP];
-    auto issue_loads = [&](int t1) {  // the rows step t1 needs, into registers
+    u4 pv[DEPTH][NP];  // staged pieces in flight: DEPTH steps ahead
+    // which row of its plane a piece of kind `kind` loads for step t1 (-1: fill, or nothing needed)
+    auto row_of = [&](int kind, int bstart, int len, int t1) {
+        int row = -1;
+        if (kind == 0) {
+            if (t1 <= len) row = m1[bstart + t1];
+        } else if (kind == 1) {
+            if (t1 >= 1 && t1 <= len) row = bstart + t1 - 1;
+        } else if (ACTIVE) {
+            if (t1 <= len) row = g1[bstart + t1];
+        } else {
+            if (t1 >= 1 && t1 <= len) row = g1[bstart + t1 - 1];
+        }
+        return row;
+    };
+    auto issue_loads = [&](int t1, u4 (&pvr)[NP]) {  // the rows step t1 needs, into registers
+        int urow[3] = {-1, -1, -1};
+        if constexpr (ND == 3) {  // one row per kind for the whole workgroup: scalar
+#pragma unroll
+            for (int kind = 0; kind < (BACKWARD ? 3 : 1); ++kind)
+                urow[kind] = __builtin_amdgcn_readfirstlane(row_of(kind, ubstart, ulen, t1));
+        }
 #pragma unroll
         for (int k = 0; k < NP; ++k) {
-            const int kind = pmeta[k] & 3, bstart = (pmeta[k] >> 2) & 0x7fff, len = pmeta[k] >> 17;
-            int row = -1;
-            if (kind == 0) {
-                if (t1 <= len) row = m1[bstart + t1];
-            } else if (kind == 1) {
-                if (t1 >= 1 && t1 <= len) row = bstart + t1 - 1;
-            } else if (ACTIVE) {
-                if (t1 <= len) row = g1[bstart + t1];
-            } else {
-                if (t1 >= 1 && t1 <= len) row = g1[bstart + t1 - 1];
-            }
-            const u4 zero = {0u, 0u, 0u, 0u};
-            pv[k] = zero;
-            if (pbase[k] >= 0 && row >= 0) {
-                const S *src = (kind == 0 ? xb : gb) + (static_cast<int64_t>(pbase[k]) + static_cast<int64_t>(row) * S2);
-                pv[k] = *reinterpret_cast<const u4 *>(__builtin_assume_aligned(src, 16));
-            }
+            const int kind = pdst[k] < 0 ? 0 : (pdst[k] >> 16) & 3;  // (threads without a k-th piece load an x row nobody stores)
+            int row;
+            if constexpr (ND == 3) row = kind == 0 ? urow[0] : (kind == 1 ? urow[1] : urow[2]);
+            else row = row_of(kind, pseg[k] & 0x7fff, pseg[k] >> 15, t1);
+            // unconditional (a conditional load would merge with a constant and be waited for right here): rows that
+            // are fill or not needed load row 0 -- the readers take the all-zero slot instead, see row_slot()
+            row = row < 0 ? 0 : row;
+            const S *src = (kind == 0 ? xb : gb) + (static_cast<int64_t>(pbase[k]) + static_cast<int64_t>(row) * S2);
+            pvr[k] = *reinterpret_cast<const u4 *>(__builtin_assume_aligned(src, 16));
         }
     };
-    auto write_tile = [&](char *tile) {
+    auto write_tile = [&](char *tile, const u4 (&pvr)[NP]) {
 #pragma unroll
         for (int k = 0; k < NP; ++k) {
             if (pdst[k] >= 0) {
-                uint32_t *d = reinterpret_cast<uint32_t *>(tile + pdst[k]);  // dword aligned (displaced rows)
-                d[0] = pv[k].x;
-                d[1] = pv[k].y;
-                d[2] = pv[k].z;
-                d[3] = pv[k].w;
+                uint32_t *d = reinterpret_cast<uint32_t *>(tile + (pdst[k] & 0xffff));  // dword aligned (displaced rows)
+                d[0] = pvr[k].x;
+                d[1] = pvr[k].y;
+                d[2] = pvr[k].z;
+                d[3] = pvr[k].w;
             }
         }
     };
 
     // ---- walk ---------------------------------------------------------------------------------------------------
     const CT dA = dw[0], dB = dw[ND - 2], dI = dw[ND - 1];
-    CT xp[NA][E + 1];   // x rows of the previous step (the hb = 0 corners)
-    CT lp[E + 1];       // ACTIVE: grad_out (forward: x) row of the previous step, blended over dim0 in 3-D
-    CT part[NDIFF];
-    double dsum[NDIFF];
+    uint32_t xpw[NA][5];  // x rows of the previous step (the hb = 0 corners), as packed windows
+    CT lp[E + 1];         // ACTIVE: grad_out (forward: x) row of the previous step, blended over dim0 in 3-D
+    // Weight-gradient sums over the last <= kFlushSteps rows, in the compute type.
+    //   4-byte data: part[i] = sum g * corner difference i (corner_diffs, shiftnd_common.hpp)
+    //   2-byte data: per staged x row r (previous rows first, then the new ones) A_r = sum_e g(e) x_r(e) in part[2r] and
+    //   B_r = sum_e g(e) x_r(e + 1) in part[2r + 1], from the PACKED rows with dot2 instructions; every corner
+    //   difference sum is a difference of two of them, taken in fp64 when the block is flushed (the tolerance for the
+    //   weight gradient of 16-bit tensors is the 16-bit epsilon; measured error ~1e-6 relative)
+    constexpr int NPART = ES == 2 ? 4 * NA : NDIFF;
+    CT part[NPART];
+    double acc[3] = {0.0, 0.0, 0.0};  // the thread's weight-gradient partials: blends of the flushed sums, in fp64
 #pragma unroll
-    for (int i = 0; i < NDIFF; ++i) {
-        part[i] = CT(0);
-        dsum[i] = 0.0;
-    }
+    for (int i = 0; i < NPART; ++i) part[i] = CT(0);
+    auto flush = [&]() {  // blend_diffs is linear in the sums: blending each flushed block equals blending the total
+        const double dwd[3] = {static_cast<double>(dw[0]), static_cast<double>(dw[1]), static_cast<double>(dw[2])};
+        double pd[NPART], sd[NDIFF], gb[3] = {0.0, 0.0, 0.0};
+#pragma unroll
+        for (int i = 0; i < NPART; ++i) {
+            pd[i] = static_cast<double>(part[i]);
+            part[i] = CT(0);
+        }
+        if constexpr (ES == 2 && ND == 3) {
+            // rows: 0 = (prev, ha0), 1 = (prev, ha1), 2 = (new, ha0), 3 = (new, ha1); A = pd[2r], B = pd[2r + 1]
+            sd[0] = pd[4] - pd[0];
+            sd[1] = pd[6] - pd[2];
+            sd[2] = pd[5] - pd[1];
+            sd[3] = pd[7] - pd[3];
+            sd[4] = pd[1] - pd[0];
+            sd[5] = pd[3] - pd[2];
+            sd[6] = pd[5] - pd[4];
+            sd[7] = pd[7] - pd[6];
+        } else if constexpr (ES == 2) {
+            sd[0] = pd[1] - pd[0];
+            sd[1] = pd[3] - pd[2];
+        } else {
+#pragma unroll
+            for (int i = 0; i < NDIFF; ++i) sd[i] = pd[i];
+        }
+        blend_diffs<ND>(sd, dwd, gb);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) acc[k] += gb[k];
+    };
 #pragma unroll
     for (int h = 0; h < NA; ++h)
 #pragma unroll
-        for (int e = 0; e <= E; ++e) xp[h][e] = CT(0);
+        for (int i = 0; i < 5; ++i) xpw[h][i] = 0u;
 #pragma unroll
     for (int e = 0; e <= E; ++e) lp[e] = CT(0);
 
-    issue_loads(0);
-    for (int t = 0; t <= p.seg; ++t) {
+    auto step = [&](int t, u4 (&pvr)[NP]) {
         char *tile = tiles + (t & 1) * p.tile_bytes;
-        write_tile(tile);
+        write_tile(tile, pvr);
         __syncthreads();
-        if (t < p.seg) issue_loads(t + 1);  // in flight while this step is computed
+        if (t + DEPTH <= p.seg) issue_loads(t + DEPTH, pvr);  // in flight while this and the next DEPTH - 1 steps are computed
         if (t <= mylen) {
+            // fill rows (zeros padding) read the all-zero slot
+            const bool rvx = m1[(ND == 3 ? ubstart : mybstart) + t] >= 0;
+            const char *xs[NA];
+#pragma unroll
+            for (int h = 0; h < NA; ++h) xs[h] = tile + ((rvx && ((pvalid >> h) & 1)) ? oX + h * pitch : p.zslot);
             if constexpr (BACKWARD) {
-                CT xn[NA][E + 1];
-                read_rows<T, NA>(tile + oX, pitch, rx, m2, ji, xn);
+                uint32_t xnw[NA][5];
+                read_rows<T, NA>(xs, rx, m2, ji, xnw);
                 if (t >= 1) {
                     // weight-gradient sums: g * corner differences (corner_diffs, shiftnd_common.hpp) with the
                     // differences that neighbouring elements / rows share computed once
                     Chunk<S, E> gch;
                     __builtin_memcpy(gch.e, __builtin_assume_aligned(tile + oG, 16), 16);
-                    if constexpr (ND == 3) {
-                        CT P[E + 1], Q[E + 1];
+                    if constexpr (ES == 2) {
+                        uint32_t gp[4], gs[5];  // g pairs [g(2i), g(2i+1)] and the same shifted by one: [g(2i-1), g(2i)]
+                        __builtin_memcpy(gp, gch.e, 16);
+                        gs[0] = gp[0] << 16;
 #pragma unroll
-                        for (int e = 0; e <= E; ++e) {
-                            P[e] = xn[0][e] - xp[0][e];
-                            Q[e] = xn[1][e] - xp[1][e];
+                        for (int i = 1; i < 4; ++i) gs[i] = __builtin_amdgcn_alignbit(gp[i], gp[i - 1], 16);
+                        gs[4] = gp[3] >> 16;
+#pragma unroll
+                        for (int r = 0; r < 2 * NA; ++r) {
+                            const uint32_t(&wdw)[5] = r < NA ? xpw[r < NA ? r : 0] : xnw[r < NA ? 0 : r - NA];
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) part[2 * r] = dot2_acc<T>(gp[i], wdw[i], part[2 * r]);
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) part[2 * r + 1] = dot2_acc<T>(gs[i], wdw[i], part[2 * r + 1]);
+                            part[2 * r + 1] = dot2_acc<T>(gs[4], wdw[4] & 0xffffu, part[2 * r + 1]);
                         }
+                    } else {
+                    CT xp[NA][E + 1], xn[NA][E + 1];
+#pragma unroll
+                    for (int h = 0; h < NA; ++h) {
+                        unpack_window<T>(xpw[h], xp[h]);
+                        unpack_window<T>(xnw[h], xn[h]);
+                    }
+                    if constexpr (ND == 3) {
 #pragma unroll
                         for (int e = 0; e < E; ++e) {
                             const CT gval = widen<T>(gch.e[e]);
-                            part[0] = fma_ct(gval, P[e], part[0]);
-                            part[1] = fma_ct(gval, Q[e], part[1]);
-                            part[2] = fma_ct(gval, P[e + 1], part[2]);
-                            part[3] = fma_ct(gval, Q[e + 1], part[3]);
+                            part[0] = fma_ct(gval, xn[0][e] - xp[0][e], part[0]);
+                            part[1] = fma_ct(gval, xn[1][e] - xp[1][e], part[1]);
+                            part[2] = fma_ct(gval, xn[0][e + 1] - xp[0][e + 1], part[2]);
+                            part[3] = fma_ct(gval, xn[1][e + 1] - xp[1][e + 1], part[3]);
                             part[4] = fma_ct(gval, xp[0][e + 1] - xp[0][e], part[4]);
                             part[5] = fma_ct(gval, xp[1][e + 1] - xp[1][e], part[5]);
                             part[6] = fma_ct(gval, xn[0][e + 1] - xn[0][e], part[6]);
@@ -440,29 +525,39 @@ __global__ __launch_bounds__(kThreads) void slide_kernel(const SlideParams p) {
                             part[1] = fma_ct(gval, xn[0][e + 1] - xn[0][e], part[1]);
                         }
                     }
-                    if ((t & (kFlushSteps - 1)) == 0) {
-#pragma unroll
-                        for (int i = 0; i < NDIFF; ++i) {
-                            dsum[i] += static_cast<double>(part[i]);
-                            part[i] = CT(0);
-                        }
                     }
+                    if ((t & (kFlushSteps - 1)) == 0) flush();
                 }
 #pragma unroll
                 for (int h = 0; h < NA; ++h)
 #pragma unroll
-                    for (int e = 0; e <= E; ++e) xp[h][e] = xn[h][e];
+                    for (int i = 0; i < 5; ++i) xpw[h][i] = xnw[h][i];
+                // the two halves of a step are independent: keep the scheduler from overlapping them (it would hold
+                // both halves' rows in registers at once and cost a wave of occupancy)
+                __builtin_amdgcn_sched_barrier(0);
             }
             S *dst = outp + static_cast<int64_t>(mybstart + t - 1) * S2;
             if constexpr (ACTIVE) {
-                CT gn[NA][E + 1];
-                if constexpr (BACKWARD) read_rows<T, NA>(tile + oGS, pitch, rg, g2, ji, gn);
-                else read_rows<T, NA>(tile + oX, pitch, rx, m2, ji, gn);
-                CT ln[E + 1];
+                uint32_t gw[NA][5];
+                if constexpr (BACKWARD) {
+                    const bool rvg = g1[(ND == 3 ? ubstart : mybstart) + t] >= 0;
+                    const char *gsl[NA];
 #pragma unroll
-                for (int e = 0; e <= E; ++e) {
-                    if constexpr (ND == 3) ln[e] = lerp_t<T>(gn[0][e], gn[1][e], dA);
-                    else ln[e] = gn[0][e];
+                    for (int h = 0; h < NA; ++h) gsl[h] = tile + ((rvg && ((pvalid >> (2 + h)) & 1)) ? oGS + h * pitch : p.zslot);
+                    read_rows<T, NA>(gsl, rg, g2, ji, gw);
+                } else {
+                    read_rows<T, NA>(xs, rx, m2, ji, gw);
+                }
+                CT ln[E + 1];
+                {
+                    CT gn[NA][E + 1];
+#pragma unroll
+                    for (int h = 0; h < NA; ++h) unpack_window<T>(gw[h], gn[h]);
+#pragma unroll
+                    for (int e = 0; e <= E; ++e) {
+                        if constexpr (ND == 3) ln[e] = lerp_t<T>(gn[0][e], gn[1][e], dA);
+                        else ln[e] = gn[0][e];
+                    }
                 }
                 if (t >= 1) {
                     CT m[E + 1];
@@ -476,17 +571,29 @@ __global__ __launch_bounds__(kThreads) void slide_kernel(const SlideParams p) {
 #pragma unroll
                 for (int e = 0; e <= E; ++e) lp[e] = ln[e];
             } else {
-                if (t >= 1) store_chunk<S, E>(dst, read_row_raw<T>(tile + oGS, rg, g2, ji));
+                if (t >= 1) {  // the sparse shift's input gradient is a copy of the shifted grad_out row
+                    uint32_t gw[1][5];
+                    const bool rvg = g1[(ND == 3 ? ubstart : mybstart) + t - 1] >= 0;
+                    const char *gsl[1] = {tile + ((rvg && ((pvalid >> 2) & 1)) ? oGS : p.zslot)};
+                    read_rows<T, 1>(gsl, rg, g2, ji, gw);
+                    Chunk<S, E> res;
+                    __builtin_memcpy(res.e, gw[0], 16);
+                    store_chunk<S, E>(dst, res);
+                }
             }
         }
+    };
+#pragma unroll
+    for (int d = 0; d < DEPTH; ++d)
+        if (d <= p.seg) issue_loads(d, pv[d]);
+    for (int t0 = 0; t0 <= p.seg; t0 += DEPTH) {
+#pragma unroll
+        for (int d = 0; d < DEPTH; ++d)
+            if (t0 + d <= p.seg) step(t0 + d, pv[d]);
     }
 
     if constexpr (BACKWARD) {
-#pragma unroll
-        for (int i = 0; i < NDIFF; ++i) dsum[i] += static_cast<double>(part[i]);
-        double acc[3] = {0.0, 0.0, 0.0};
-        const double dwd[3] = {static_cast<double>(dw[0]), static_cast<double>(dw[1]), static_cast<double>(dw[2])};
-        blend_diffs<ND>(dsum, dwd, acc);
+        flush();
         const int pidx = grp * p.inner + in;
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
@@ -539,7 +646,7 @@ SlidePlan slide_plan(const Geometry &g, int es, bool backward, int np_max) {
     if (g.nd == 3 && nseg > g.S[0]) nseg = static_cast<int>(g.S[0]);
     auto slots_of = [&](int n) { return backward ? (n + halo) + n + (g.active ? n + halo : n) : n + halo; };
     const size_t map_bytes = static_cast<size_t>(g.S[0] + g.S[1] + g.S[2] + 3) * (backward ? 2 : 1) * sizeof(int);
-    auto lds_of = [&](int n) { return 2 * static_cast<size_t>(slots_of(n)) * (RB + 2 * kGuard) + map_bytes; };
+    auto lds_of = [&](int n) { return 2 * static_cast<size_t>(slots_of(n) + 1) * (RB + 2 * kGuard) + map_bytes; };
     while (nseg > 1 && (static_cast<int64_t>(slots_of(nseg)) * pl.cpr > static_cast<int64_t>(np_max) * kThreads ||
                         lds_of(nseg) > 64 * 1024))
         --nseg;
@@ -581,7 +688,7 @@ SlidePlan slide_plan(const Geometry &g, int es, bool backward, int np_max) {
     pl.nslots = slots_of(nseg);
     pl.npieces = pl.nslots * pl.cpr;
     pl.pitch = static_cast<int>(RB) + 2 * kGuard;
-    pl.tile_bytes = pl.nslots * pl.pitch;
+    pl.tile_bytes = (pl.nslots + 1) * pl.pitch;  // + the all-zero slot
     pl.lds = 2 * static_cast<size_t>(pl.tile_bytes) + map_bytes;
     if (pl.lds > 64 * 1024) return pl;
     const int64_t grid = static_cast<int64_t>(pl.groups) * g.C * pl.inner;
@@ -610,6 +717,7 @@ void fill_slide(SlideParams &p, const Geometry &g, const SlidePlan &pl) {
     p.units = pl.units;
     p.pitch = pl.pitch;
     p.tile_bytes = pl.tile_bytes;
+    p.zslot = pl.nslots * pl.pitch;
     p.npieces = pl.npieces;
     p.xcd_blocks = pl.grid % 8 == 0 ? pl.grid / 8 : 0;
     p.d_cpr = make_fastdiv(static_cast<uint32_t>(pl.cpr));
@@ -620,16 +728,23 @@ void fill_slide(SlideParams &p, const Geometry &g, const SlidePlan &pl) {
 }
 
 constexpr int kNpBackward = 3, kNpForward = 2;
+#ifndef SLIDE_DEPTH_BWD
+#define SLIDE_DEPTH_BWD 1
+#endif
+#ifndef SLIDE_DEPTH_FWD
+#define SLIDE_DEPTH_FWD 1
+#endif
+constexpr int kDepthBackward = SLIDE_DEPTH_BWD, kDepthForward = SLIDE_DEPTH_FWD;  // steps of staging in flight
 
 template <typename T, bool ACTIVE>
 void launch_slide_backward(const SlideParams &p, const SlidePlan &pl, hipStream_t st) {
-    if (p.nd == 3) hipLaunchKernelGGL((slide_kernel<T, 3, ACTIVE, true, kNpBackward>), dim3(pl.grid), dim3(kThreads), pl.lds, st, p);
-    else hipLaunchKernelGGL((slide_kernel<T, 2, ACTIVE, true, kNpBackward>), dim3(pl.grid), dim3(kThreads), pl.lds, st, p);
+    if (p.nd == 3) hipLaunchKernelGGL((slide_kernel<T, 3, ACTIVE, true, kNpBackward, kDepthBackward>), dim3(pl.grid), dim3(kThreads), pl.lds, st, p);
+    else hipLaunchKernelGGL((slide_kernel<T, 2, ACTIVE, true, kNpBackward, kDepthBackward>), dim3(pl.grid), dim3(kThreads), pl.lds, st, p);
 }
 template <typename T>
 void launch_slide_forward(const SlideParams &p, const SlidePlan &pl, hipStream_t st) {
-    if (p.nd == 3) hipLaunchKernelGGL((slide_kernel<T, 3, true, false, kNpForward>), dim3(pl.grid), dim3(kThreads), pl.lds, st, p);
-    else hipLaunchKernelGGL((slide_kernel<T, 2, true, false, kNpForward>), dim3(pl.grid), dim3(kThreads), pl.lds, st, p);
+    if (p.nd == 3) hipLaunchKernelGGL((slide_kernel<T, 3, true, false, kNpForward, kDepthForward>), dim3(pl.grid), dim3(kThreads), pl.lds, st, p);
+    else hipLaunchKernelGGL((slide_kernel<T, 2, true, false, kNpForward, kDepthForward>), dim3(pl.grid), dim3(kThreads), pl.lds, st, p);
 }
 
 bool slide_wanted(const Geometry &g) {

@@ -36,7 +36,7 @@ namespace {
 #ifndef SLIDE_EU_ATTR
 #define SLIDE_EU_ATTR
 #endif
-constexpr int kGuard = 32;          // zeroed bytes on each side of a staged row
+constexpr int kGuard = 32;          // zeroed bytes in front of every staged row (and behind the last one)
 constexpr int kFlushSteps = 8;      // fp32 partial sums are blended into the fp64 accumulators every kFlushSteps rows
 
 struct SlideParams {
@@ -95,32 +95,52 @@ template <typename T> __device__ __forceinline__ float dot2_acc(uint32_t a, uint
 }
 
 // How a thread reads its E + 1 shifted columns of a staged row (one per tensor kind: x rows, grad_out rows).
+// Rows are staged as they are in memory (16-byte pieces at 16-byte LDS addresses: conflict-free ds_write_b128), so a
+// thread's window of E + 1 columns starts `phase` bytes into an aligned 32-byte span; `phase` (0..15) is the same for
+// every thread of the workgroup (one channel = one shift): dword R = phase / 4, and for 16-bit data the odd half.
 struct RowRead {
-    int woff;     // affine lanes: byte offset, from the row's slot base, of the 16-byte aligned window start
-    int fboff;    // element-wise lanes: byte offset of source column 0 from the slot base (kGuard - displacement)
-    int half;     // 16-bit types: 16 when the window starts at the odd half of its first dword (uniform), else 0
+    int woff;     // affine lanes: byte offset, from the row's slot base, of the aligned 32-byte span holding the window
+    int phase;    // uniform: byte phase of the window inside the span (see above)
     bool affine;
 };
 
-// E + 1 raw elements as 5 dwords, first element in the low bits of t[0]
-template <int ES> __device__ __forceinline__ void read_window(const char *p, int half, uint32_t (&t)[5]) {
+// E + 1 raw elements as 5 dwords (first element in the low bits of t[0]) out of the aligned 32-byte span at p.
+// R / HALF are compile-time: which of the 8 dwords the window starts with is register naming, and the funnel shift
+// for the odd half disappears when HALF == 0.
+template <int ES, int R, int HALF> __device__ __forceinline__ void read_window_ct(const char *p, uint32_t (&t)[5]) {
     typedef uint32_t u4 __attribute__((ext_vector_type(4)));
-    const u4 q = *reinterpret_cast<const u4 *>(__builtin_assume_aligned(p, 16));
-    const uint32_t d4 = *reinterpret_cast<const uint32_t *>(p + 16);
-    if constexpr (ES == 2) {
-        const uint32_t sh = static_cast<uint32_t>(half);
-        t[0] = __builtin_amdgcn_alignbit(q.y, q.x, sh);
-        t[1] = __builtin_amdgcn_alignbit(q.z, q.y, sh);
-        t[2] = __builtin_amdgcn_alignbit(q.w, q.z, sh);
-        t[3] = __builtin_amdgcn_alignbit(d4, q.w, sh);
-        t[4] = d4 >> sh;
+    const u4 q0 = *reinterpret_cast<const u4 *>(__builtin_assume_aligned(p, 16));
+    const u4 q1 = *reinterpret_cast<const u4 *>(__builtin_assume_aligned(p + 16, 16));
+    const uint32_t d[8] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w};
+    if constexpr (ES == 2 && HALF != 0) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) t[i] = __builtin_amdgcn_alignbit(d[R + i + 1], d[R + i], 16);
+        t[4] = d[R + 4] >> 16;
     } else {
-        t[0] = q.x;
-        t[1] = q.y;
-        t[2] = q.z;
-        t[3] = q.w;
-        t[4] = d4;
+#pragma unroll
+        for (int i = 0; i < 5; ++i) t[i] = d[R + i];
     }
+}
+template <int ES, int NROWS>
+__device__ __forceinline__ void read_windows(const char *const (&slot)[NROWS], int woff, int phase, uint32_t (&t)[NROWS][5]) {
+    // uniform switch: one workgroup = one phase
+#define SHIFTND_WIN_CASE(RR, HH) \
+    case (RR * 2 + HH): \
+        _Pragma("unroll") for (int h = 0; h < NROWS; ++h) read_window_ct<ES, RR, HH>(slot[h] + woff, t[h]); \
+        break;
+    switch (__builtin_amdgcn_readfirstlane(ES == 2 ? (phase >> 1) : ((phase >> 2) << 1))) {
+        SHIFTND_WIN_CASE(0, 0)
+        SHIFTND_WIN_CASE(1, 0)
+        SHIFTND_WIN_CASE(2, 0)
+        SHIFTND_WIN_CASE(3, 0)
+        SHIFTND_WIN_CASE(0, 1)
+        SHIFTND_WIN_CASE(1, 1)
+        SHIFTND_WIN_CASE(2, 1)
+    default:
+        _Pragma("unroll") for (int h = 0; h < NROWS; ++h) read_window_ct<ES, 3, 1>(slot[h] + woff, t[h]);
+        break;
+    }
+#undef SHIFTND_WIN_CASE
 }
 
 template <typename T> __device__ __forceinline__ void unpack_window(const uint32_t (&t)[5], typename T::C (&v)[16 / sizeof(typename T::S) + 1]) {
@@ -154,15 +174,14 @@ __device__ __forceinline__ void read_rows(const char *const (&slot)[NROWS], cons
     using S = typename T::S;
     constexpr int ES = sizeof(S), E = 16 / ES;
     if (rr.affine) {
-#pragma unroll
-        for (int h = 0; h < NROWS; ++h) read_window<ES>(slot[h] + rr.woff, rr.half, t[h]);
+        read_windows<ES, NROWS>(slot, rr.woff, rr.phase, t);
     } else {
         int cm[E + 1];
 #pragma unroll
         for (int e = 0; e <= E; ++e) cm[e] = map[ji + e];
 #pragma unroll
         for (int h = 0; h < NROWS; ++h) {
-            const char *body = slot[h] + rr.fboff;
+            const char *body = slot[h] + kGuard;
             uint32_t raw[E + 1];
 #pragma unroll
             for (int e = 0; e <= E; ++e) {
@@ -199,15 +218,13 @@ __device__ __forceinline__ RowRead make_rowread(const int *map, int ji, bool liv
     }
 #pragma unroll
     for (int e = 0; e <= E; ++e) affine = affine && (cm[e] < 0 || cm[e] == base + e);
-    const int disp = delta & 12;  // the rows of this kind sit `disp` bytes to the left of their slot body
-    rr.half = (ES == 2 && (delta & 2)) ? 16 : 0;
-    rr.fboff = kGuard - disp;
-    int w = -kGuard;  // no valid column: any window inside the zeroed guard
+    rr.phase = delta;
+    int w = -kGuard;  // no valid column: a span inside the zeroed guard
     if (found) {
         const int b0 = base * ES;                    // source byte of column 0 of the window (may be negative)
-        affine = affine && ((b0 & 15) == delta);     // congruent with the displacement (else: element-wise)
-        w = (b0 & ~3) - disp;                        // a multiple of 16 when congruent
-        w = w < -kGuard ? -kGuard : (w > row_bytes ? row_bytes : w);
+        affine = affine && ((b0 & 15) == delta);     // congruent with the workgroup's phase (else: element-wise)
+        w = b0 & ~15;                                // >= -16; the span ends at most 16 bytes behind the row
+        w = w < -kGuard ? -kGuard : (w > row_bytes - 16 ? row_bytes - 16 : w);
     }
     rr.woff = kGuard + w;
     rr.affine = affine;
@@ -291,8 +308,8 @@ __global__ __launch_bounds__(kThreads) SLIDE_EU_ATTR void slide_kernel(const Sli
         const u4 zero = {0u, 0u, 0u, 0u};
         for (int i = threadIdx.x; i < 2 * p.tile_bytes / 16; i += kThreads) z[i] = zero;
     }
-    // byte phase (mod 16) of the affine part of the column maps: rows are staged that many bytes (rounded down to a
-    // dword) to the left, which puts every thread's window on a 16-byte boundary
+    // byte phase (mod 16) of the affine part of the column maps: where, inside an aligned 32-byte span of a staged
+    // row, a thread's window of shifted columns starts (RowRead)
     const int csx = canon_shift(sh[2], S2, p.pad, p.d_per);
     const int dx = (-csx * ES) & 15;
     const int dg = (ACTIVE || !BACKWARD) ? dx : ((-canon_shift(-sh[2], S2, p.pad, p.d_per) * ES) & 15);
@@ -324,7 +341,7 @@ __global__ __launch_bounds__(kThreads) SLIDE_EU_ATTR void slide_kernel(const Sli
 
     // ---- the pieces this thread stages every step -----------------------------------------------------------------
     // kind 0: x rows (through the x maps), 1: grad_out rows at the output position, 2: grad_out rows through the grad maps
-    // pdst: LDS byte offset of the piece in a tile | kind << 16, or -1; pbase: element offset of the piece's plane and
+    // pdst: LDS byte offset of the piece in a tile | kind << 16; pbase: element offset of the piece's plane and
     // column from (n0, c); pseg (2-D only; uniform in 3-D): first row | rows << 15 of the piece's segment
     int pbase[NP], pdst[NP], pseg[ND == 2 ? NP : 1];
     int ubstart = 0, ulen = 0;  // 3-D: every segment of the workgroup covers the same rows
@@ -336,7 +353,8 @@ __global__ __launch_bounds__(kThreads) SLIDE_EU_ATTR void slide_kernel(const Sli
     for (int k = 0; k < NP; ++k) {
         const int q = k * kThreads + static_cast<int>(threadIdx.x);
         pbase[k] = 0;
-        pdst[k] = -1;
+        pdst[k] = p.zslot + pitch + kGuard;  // no k-th piece: loads an x row like everybody, stores it in the dump slot (a
+                                    // store under a thread-dependent branch would make hipcc wait for ALL memory traffic)
         if constexpr (ND == 2) pseg[k] = 0;
         if (q < p.npieces) {
             const int slot = fdiv(q, p.d_cpr), j = q - slot * p.cpr;
@@ -359,8 +377,7 @@ __global__ __launch_bounds__(kThreads) SLIDE_EU_ATTR void slide_kernel(const Sli
             }
             pbase[k] = ok ? poff + j * E : 0;  // (absent planes: any readable address; their slots are never read)
             if constexpr (ND == 2) pseg[k] = bstart | (len << 15);
-            const int disp = kind == 0 ? (dx & 12) : (kind == 2 ? (dg & 12) : 0);
-            pdst[k] = (slot * pitch + kGuard + j * 16 - disp) | (kind << 16);
+            pdst[k] = (slot * pitch + kGuard + j * 16) | (kind << 16);
         }
     }
     u4 pv[DEPTH][NP];  // staged pieces in flight: DEPTH steps ahead
@@ -387,7 +404,7 @@ __global__ __launch_bounds__(kThreads) SLIDE_EU_ATTR void slide_kernel(const Sli
         }
 #pragma unroll
         for (int k = 0; k < NP; ++k) {
-            const int kind = pdst[k] < 0 ? 0 : (pdst[k] >> 16) & 3;  // (threads without a k-th piece load an x row nobody stores)
+            const int kind = (pdst[k] >> 16) & 3;
             int row;
             if constexpr (ND == 3) row = kind == 0 ? urow[0] : (kind == 1 ? urow[1] : urow[2]);
             else row = row_of(kind, pseg[k] & 0x7fff, pseg[k] >> 15, t1);
@@ -399,15 +416,12 @@ __global__ __launch_bounds__(kThreads) SLIDE_EU_ATTR void slide_kernel(const Sli
         }
     };
     auto write_tile = [&](char *tile, const u4 (&pvr)[NP]) {
+#ifdef SLIDE_DBG_NOSTAGE
+        return;
+#endif
 #pragma unroll
         for (int k = 0; k < NP; ++k) {
-            if (pdst[k] >= 0) {
-                uint32_t *d = reinterpret_cast<uint32_t *>(tile + (pdst[k] & 0xffff));  // dword aligned (displaced rows)
-                d[0] = pvr[k].x;
-                d[1] = pvr[k].y;
-                d[2] = pvr[k].z;
-                d[3] = pvr[k].w;
-            }
+            *reinterpret_cast<u4 *>(__builtin_assume_aligned(tile + (pdst[k] & 0xffff), 16)) = pvr[k];
         }
     };
 
@@ -462,12 +476,33 @@ __global__ __launch_bounds__(kThreads) SLIDE_EU_ATTR void slide_kernel(const Sli
 #pragma unroll
     for (int e = 0; e <= E; ++e) lp[e] = CT(0);
 
+    Chunk<S, E> pres;  // output chunk computed by the previous step, and its row (-1: none)
+    int prow = -1;
+    auto flush_store = [&]() {
+        if (prow >= 0) {
+            store_chunk<S, E>(outp + static_cast<int64_t>(prow) * S2, pres);
+            prow = -1;
+        }
+    };
     auto step = [&](int t, u4 (&pvr)[NP]) {
         char *tile = tiles + (t & 1) * p.tile_bytes;
         write_tile(tile, pvr);
+#ifndef SLIDE_DBG_NOBARRIER
         __syncthreads();
+#endif
+        // The output row of the previous step leaves here, BEFORE the next loads are issued: loads and stores share
+        // one in-order counter (vmcnt), and the compiler waits for everything older when it needs the loads back, so a
+        // store issued after the loads would be waited for (its whole write latency) at the top of every step.
+        flush_store();
+#if !defined(SLIDE_DBG_NOSTAGE) && !defined(SLIDE_DBG_LATELOAD)
         if (t + DEPTH <= p.seg) issue_loads(t + DEPTH, pvr);  // in flight while this and the next DEPTH - 1 steps are computed
+#endif
+#ifdef SLIDE_DBG_NOCOMPUTE
+        if (t == p.seg && threadIdx.x == 0) *reinterpret_cast<volatile uint32_t *>(outp) = *reinterpret_cast<uint32_t *>(tile + 64);
+        if (false) {
+#else
         if (t <= mylen) {
+#endif
             // fill rows (zeros padding) read the all-zero slot
             const bool rvx = m1[(ND == 3 ? ubstart : mybstart) + t] >= 0;
             const char *xs[NA];
@@ -479,8 +514,9 @@ __global__ __launch_bounds__(kThreads) SLIDE_EU_ATTR void slide_kernel(const Sli
                 if (t >= 1) {
                     // weight-gradient sums: g * corner differences (corner_diffs, shiftnd_common.hpp) with the
                     // differences that neighbouring elements / rows share computed once
+                    const u4 gq = *reinterpret_cast<const u4 *>(__builtin_assume_aligned(tile + oG, 16));
                     Chunk<S, E> gch;
-                    __builtin_memcpy(gch.e, __builtin_assume_aligned(tile + oG, 16), 16);
+                    __builtin_memcpy(gch.e, &gq, 16);
                     if constexpr (ES == 2) {
                         uint32_t gp[4], gs[5];  // g pairs [g(2i), g(2i+1)] and the same shifted by one: [g(2i-1), g(2i)]
                         __builtin_memcpy(gp, gch.e, 16);
@@ -536,7 +572,6 @@ __global__ __launch_bounds__(kThreads) SLIDE_EU_ATTR void slide_kernel(const Sli
                 // both halves' rows in registers at once and cost a wave of occupancy)
                 __builtin_amdgcn_sched_barrier(0);
             }
-            S *dst = outp + static_cast<int64_t>(mybstart + t - 1) * S2;
             if constexpr (ACTIVE) {
                 uint32_t gw[NA][5];
                 if constexpr (BACKWARD) {
@@ -566,7 +601,8 @@ __global__ __launch_bounds__(kThreads) SLIDE_EU_ATTR void slide_kernel(const Sli
                     Chunk<S, E> res;
 #pragma unroll
                     for (int e = 0; e < E; ++e) res.e[e] = narrow<T>(lerp_t<T>(m[e], m[e + 1], dI));
-                    store_chunk<S, E>(dst, res);
+                    pres = res;
+                    prow = mybstart + t - 1;
                 }
 #pragma unroll
                 for (int e = 0; e <= E; ++e) lp[e] = ln[e];
@@ -578,19 +614,34 @@ __global__ __launch_bounds__(kThreads) SLIDE_EU_ATTR void slide_kernel(const Sli
                     read_rows<T, 1>(gsl, rg, g2, ji, gw);
                     Chunk<S, E> res;
                     __builtin_memcpy(res.e, gw[0], 16);
-                    store_chunk<S, E>(dst, res);
+                    pres = res;
+                    prow = mybstart + t - 1;
                 }
             }
         }
-    };
+#ifdef SLIDE_DBG_LATELOAD
+        __builtin_amdgcn_sched_barrier(0);
+        if (t + DEPTH <= p.seg) issue_loads(t + DEPTH, pvr);
+#endif
+};
+#ifdef SLIDE_DBG_STAGGER
+    // desynchronise the workgroups of a CU (they run identical steps and otherwise stay in lockstep)
+    for (int i = 0; i < static_cast<int>(((blockIdx.x >> 8) ^ (blockIdx.x >> 10) ^ (blockIdx.x >> 3)) & 3u) * SLIDE_DBG_STAGGER; ++i) __builtin_amdgcn_s_sleep(16);
+#endif
 #pragma unroll
-    for (int d = 0; d < DEPTH; ++d)
+    for (int d = 0; d < DEPTH; ++d) {
+#ifdef SLIDE_DBG_NOSTAGE
+        const u4 zz = {0u, 0u, 0u, 0u};
+        for (int k = 0; k < NP; ++k) pv[d][k] = zz;
+#endif
         if (d <= p.seg) issue_loads(d, pv[d]);
+    }
     for (int t0 = 0; t0 <= p.seg; t0 += DEPTH) {
 #pragma unroll
         for (int d = 0; d < DEPTH; ++d)
             if (t0 + d <= p.seg) step(t0 + d, pv[d]);
     }
+    flush_store();
 
     if constexpr (BACKWARD) {
         flush();
@@ -646,7 +697,7 @@ SlidePlan slide_plan(const Geometry &g, int es, bool backward, int np_max) {
     if (g.nd == 3 && nseg > g.S[0]) nseg = static_cast<int>(g.S[0]);
     auto slots_of = [&](int n) { return backward ? (n + halo) + n + (g.active ? n + halo : n) : n + halo; };
     const size_t map_bytes = static_cast<size_t>(g.S[0] + g.S[1] + g.S[2] + 3) * (backward ? 2 : 1) * sizeof(int);
-    auto lds_of = [&](int n) { return 2 * static_cast<size_t>(slots_of(n) + 1) * (RB + 2 * kGuard) + map_bytes; };
+    auto lds_of = [&](int n) { return 2 * (static_cast<size_t>(slots_of(n) + 2) * (RB + kGuard) + kGuard) + map_bytes; };
     while (nseg > 1 && (static_cast<int64_t>(slots_of(nseg)) * pl.cpr > static_cast<int64_t>(np_max) * kThreads ||
                         lds_of(nseg) > 64 * 1024))
         --nseg;
@@ -687,8 +738,8 @@ SlidePlan slide_plan(const Geometry &g, int es, bool backward, int np_max) {
     pl.nseg = nseg;
     pl.nslots = slots_of(nseg);
     pl.npieces = pl.nslots * pl.cpr;
-    pl.pitch = static_cast<int>(RB) + 2 * kGuard;
-    pl.tile_bytes = (pl.nslots + 1) * pl.pitch;  // + the all-zero slot
+    pl.pitch = static_cast<int>(RB) + kGuard;  // [guard][row]: the next slot's guard (or the tile's tail) is the right guard
+    pl.tile_bytes = (pl.nslots + 2) * pl.pitch + kGuard;  // + the all-zero slot, the dump slot and the tail guard
     pl.lds = 2 * static_cast<size_t>(pl.tile_bytes) + map_bytes;
     if (pl.lds > 64 * 1024) return pl;
     const int64_t grid = static_cast<int64_t>(pl.groups) * g.C * pl.inner;

@@ -480,7 +480,10 @@ __global__ __launch_bounds__(kThreads) SLIDE_EU_ATTR void slide_kernel(const Sli
     int prow = -1;
     auto flush_store = [&]() {
         if (prow >= 0) {
-            store_chunk<S, E>(outp + static_cast<int64_t>(prow) * S2, pres);
+            // a plain (L2-retained) store: a step writes one 16-byte-multiple row segment per plane, and the rows of a
+            // plane follow each other a step apart -- L2 merges them into whole lines; as nontemporal stores the partial
+            // lines went to HBM one by one (C3: forward 0.222 -> 0.184 ms, backward 0.324 -> 0.287 ms)
+            __builtin_memcpy(__builtin_assume_aligned(outp + static_cast<int64_t>(prow) * S2, 16), pres.e, 16);
             prow = -1;
         }
     };

@@ -65,6 +65,13 @@ bool slide_forward_eligible(const Geometry &g, int dtype, const void *x, const v
 int slide_forward(const Geometry &g, int dtype, const void *x, const void *w, void *out, hipStream_t st);
 void slide_set_tuning(int knob, int value);
 
+// ---- 1-byte elements on small planes (shiftnd_bytes.hip): whole planes through LDS, 16-byte output pieces that cross
+// rows; part of the per-channel family (plane_forward routes to it)
+bool bytes_forward_eligible(const Geometry &g, int dtype, const void *x, const void *out);
+int bytes_forward(const Geometry &g, const void *x, const void *w, int wkind, int64_t wzp, uint64_t fill_bits, void *out,
+                  hipStream_t st);
+void bytes_set_tuning(int knob, int value);
+
 // ---- channel-fastest kernels for channels-last tensors (shiftnd_cl.hip): any strides, x with unit channel stride --
 bool cl_forward_eligible(const Geometry &g);
 bool cl_forward_preferred(const Geometry &g);   // eligible and the output is channel-fastest too

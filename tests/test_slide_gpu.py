@@ -120,3 +120,37 @@ def test_agrees_with_the_step_tiled_kernels(abi):
                 if active:
                     out1 = abi.forward(x, w, pad, active)
                     assert torch.equal(out1, out0) if tdt == torch.float32 else _ulp_close(out1.cpu(), out0.cpu(), tdt)
+
+
+@pytest.mark.parametrize("shape,tdt,npdt,zp", [((4, 6, 56, 56), torch.uint8, np.uint8, 3), ((9, 5, 8, 16), torch.int8, np.int8, -5),
+                                               ((5, 3, 9, 5, 16), torch.uint8, np.uint8, 128), ((3, 4, 28, 28), torch.int8, np.int8, 0),
+                                               ((130, 2, 4, 4), torch.uint8, np.uint8, 7), ((2, 3, 1, 112, 32), torch.uint8, np.uint8, 255)])
+def test_small_plane_byte_kernel_vs_oracle(shape, tdt, npdt, zp):
+    """bytes_gather_forward (csrc/shiftnd_bytes.hip): the quantized forward on planes that are whole 16-byte pieces;
+    bit-exact against the oracle's quantized kernel (shifts_kernels.h:532-571) for every padding, shifts beyond the
+    dims, ragged last workgroups (knob 17 = planes per workgroup)"""
+    from torchshifts import abi
+    rs = np.random.RandomState(sum(shape))
+    nd = len(shape) - 2
+    info = np.iinfo(npdt)
+    xq = rs.randint(info.min, info.max + 1, size=shape).astype(npdt)
+    wq = rs.randint(121, 136, size=(shape[1], nd)).astype(np.uint8)
+    wq[0, :] = 128 + shape[-1] + 3  # a shift beyond the dim
+    if shape[1] > 1:
+        wq[1, :] = 128 - 2 * shape[-1] - 1
+    x = torch.from_numpy(xq).to(tdt).to(DEV)
+    w = torch.from_numpy(wq).to(DEV)
+    try:
+        for ppw in (0, 1, 3):
+            abi.set_tuning(17, ppw)
+            for pad in range(5):
+                out = abi.forward_quantized(x, w, 128, zp, pad)
+                assert abi.last_kernel() == "bytes_gather_forward", (shape, abi.last_kernel())
+                assert np.array_equal(out.cpu().numpy(), O.forward_q(xq, wq, 128, zp, pad)), (shape, pad, ppw)
+        abi.set_tuning(16, 0)  # the row-chunk kernel serves the same problem
+        out = abi.forward_quantized(x, w, 128, zp, 0)
+        assert abi.last_kernel() != "bytes_gather_forward"
+        assert np.array_equal(out.cpu().numpy(), O.forward_q(xq, wq, 128, zp, 0))
+    finally:
+        abi.set_tuning(16, 1)
+        abi.set_tuning(17, 0)

@@ -296,6 +296,15 @@ static int pooled_geometry(const shiftnd_problem *p, const int32_t *pool, Geomet
     return SHIFTND_OK;
 }
 
+size_t shiftnd_backward_pooled_workspace_bytes(const shiftnd_problem *p, const int32_t *pool) {
+    // the pooled backward plans its launch with the pool in the geometry (more, shorter workgroups than the plain
+    // backward of the same tensor can need more partial-sum groups)
+    Geometry g;
+    if (pooled_geometry(p, pool, g) != SHIFTND_OK) return 0;
+    if (g.N == 0 || g.C == 0 || g.S[0] * g.S[1] * g.S[2] == 0) return sizeof(double);
+    return plane_backward_workspace(g, p->dtype);
+}
+
 int shiftnd_pooled_sizes(const shiftnd_problem *p, const int32_t *pool, int64_t pooled_spatial[3]) {
     Geometry g;
     const int rc = pooled_geometry(p, pool, g);

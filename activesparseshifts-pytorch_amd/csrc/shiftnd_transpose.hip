@@ -22,7 +22,8 @@ __global__ __launch_bounds__(kThreads) void transpose_tiles(const void *__restri
                                                             int cols, int tiles_r, int tiles_c) {
     using R = typename raw_t<ESIZE>::type;
     constexpr int E = 16 / ESIZE;                       // elements per 16-byte piece
-    constexpr int PITCH = kTile * ESIZE + 4;            // bytes; +1 dword staggers the banks
+    // bytes; the extra dword (two for 8-byte elements, whose LDS accesses must stay 8-byte aligned) staggers the banks
+    constexpr int PITCH = kTile * ESIZE + (ESIZE == 8 ? 8 : 4);
     __shared__ __attribute__((aligned(16))) char tile[kTile * PITCH + 16];
     // consecutive workgroups walk the SHORTER tile dimension first (the channel dimension of either direction), so
     // the long contiguous side -- whole channels-last pixel rows -- is read or written as one contiguous region by

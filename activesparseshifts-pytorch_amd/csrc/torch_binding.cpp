@@ -408,7 +408,7 @@ std::tuple<Tensor, Tensor> pool_backward_hip(const Tensor &grad, const Tensor &w
     Tensor w = weights.contiguous();
     Tensor grad_input = at::empty_like(input, at::MemoryFormat::Contiguous);
     Tensor grad_weights = at::empty_like(w, at::MemoryFormat::Contiguous);
-    const size_t ws_bytes = shiftnd_backward_workspace_bytes(&p);
+    const size_t ws_bytes = shiftnd_backward_pooled_workspace_bytes(&p, k);  // (the pooled plan, not the plain one)
     Tensor workspace = at::empty({static_cast<int64_t>(ws_bytes)}, input.options().dtype(at::kByte));
     rc = shiftnd_backward_pooled(&p, k, g.data_ptr(), input.data_ptr(), w.data_ptr(), grad_input.data_ptr(),
                                  grad_weights.data_ptr(), workspace.data_ptr(), ws_bytes, current_stream(grad));

@@ -22,7 +22,7 @@ DTYPES = {torch.float32: F32, torch.float64: F64, torch.float16: F16, torch.bflo
 EXPORTS = ["shiftnd_abi_version", "shiftnd_status_string", "shiftnd_last_path", "shiftnd_set_path_policy",
            "shiftnd_set_tuning", "shiftnd_debug_map", "shiftnd_last_kernel",
            "shiftnd_check_borders", "shiftnd_forward", "shiftnd_backward_workspace_bytes", "shiftnd_backward",
-           "shiftnd_forward_quantized", "shiftnd_pooled_sizes", "shiftnd_forward_pooled", "shiftnd_backward_pooled", "shiftnd_transpose"]
+           "shiftnd_forward_quantized", "shiftnd_pooled_sizes", "shiftnd_backward_pooled_workspace_bytes", "shiftnd_forward_pooled", "shiftnd_backward_pooled", "shiftnd_transpose"]
 
 
 class Problem(ctypes.Structure):
@@ -64,6 +64,8 @@ def lib():
         i32p = ctypes.POINTER(ctypes.c_int32)
         L.shiftnd_pooled_sizes.restype = ctypes.c_int
         L.shiftnd_pooled_sizes.argtypes = [ctypes.POINTER(Problem), i32p, i64p]
+        L.shiftnd_backward_pooled_workspace_bytes.restype = ctypes.c_size_t
+        L.shiftnd_backward_pooled_workspace_bytes.argtypes = [ctypes.POINTER(Problem), i32p]
         L.shiftnd_forward_pooled.restype = ctypes.c_int
         L.shiftnd_forward_pooled.argtypes = [ctypes.POINTER(Problem), i32p, vp, vp, vp, vp]
         L.shiftnd_backward_pooled.restype = ctypes.c_int
@@ -205,7 +207,8 @@ def backward_pooled(grad_pooled, w, x, pad, active, pool, borders=None, grad_x=N
     if grad_w is None:
         grad_w = torch.empty_like(w)
     if workspace is None:
-        workspace = backward_workspace(x, pad, active, borders)
+        nbytes = int(lib().shiftnd_backward_pooled_workspace_bytes(ctypes.byref(p), _pool_arg(pool, p.ndim)))
+        workspace = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
     check(lib().shiftnd_backward_pooled(ctypes.byref(p), _pool_arg(pool, p.ndim), grad_pooled.data_ptr(), x.data_ptr(),
                                         w.data_ptr(), grad_x.data_ptr(), grad_w.data_ptr(), workspace.data_ptr(),
                                         workspace.numel(), _stream()), "shiftnd_backward_pooled")

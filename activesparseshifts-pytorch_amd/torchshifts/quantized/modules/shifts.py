@@ -3,8 +3,18 @@
 `forward` returns the tensor only (no loss).  `from_float` converts a float Shift{N}d; the integer
 shifts are `int_repr(qweight) - zero_point`, the scale is not used by the kernel
 (kernels/shifts_kernels.h:553-555).
+
+Differences from the reference:
+  * the quantized weights checkpoint and move with the module: their integer representation is a buffer
+    (`qweight_repr`), scale / zero point / dtype travel as the module's extra state; `qweight` is a property that
+    rebuilds the quantized tensor on the buffer's device (the reference keeps a plain attribute, :17, that
+    `state_dict()` drops and `.to(device)` leaves behind);
+  * `quantize_shift_weights` never changes a shift: the reference's `scale = ceil(range / 255)` (:10-12) is 0 when all
+    weights are equal (torch raises) and > 1 when the range exceeds 255, which silently HALVES every shift because
+    the kernel ignores the scale.  Here the scale is always 1; weights that do not fit quint8 around zero point 128
+    (|round(w)| > 127) become qint32 with zero point 0, which both backends accept.
 """
-import math
+import warnings
 
 import torch
 
@@ -15,11 +25,42 @@ rp_dict = {v: k for k, v in shifts.paddings_dict.items()}
 
 
 def quantize_shift_weights(weight):
-    """quint8, zero point 128, integer scale ceil(range / 255) (reference :10-12).
+    """Float shift weights -> quantized tensor whose `int_repr - zero_point` is round-half-even(weight).
 
-    QUIRK kept: ranges above 255 coarsen the shifts, and max == min gives scale 0 (torch raises)."""
-    scale = math.ceil((weight.max().item() - weight.min().item()) / 255.)
-    return torch.quantize_per_tensor(weight, scale, 128, torch.quint8)
+    quint8, scale 1, zero point 128 (the reference's layout whenever the reference is right); qint32, scale 1, zero
+    point 0 when a rounded shift leaves [-128, 127]."""
+    w = weight.detach().float()
+    if w.numel() and not bool(torch.isfinite(w).all()):
+        raise ValueError("quantize_shift_weights: weights must be finite")
+    amax = float(w.abs().max()) if w.numel() else 0.0
+    if amax <= 127.0:
+        return torch.quantize_per_tensor(w, 1.0, 128, torch.quint8)
+    warnings.warn("shift weights beyond +-127 do not fit quint8 around zero point 128: using qint32 weights "
+                  "(the reference would have coarsened every shift by ceil(range / 255))", stacklevel=2)
+    return torch.quantize_per_tensor(w, 1.0, 0, torch.qint32)
+
+
+def _quantized_avg_pool_hip(xq, kernel, dim):
+    """avg_pool{N}d(kernel = stride, ceil_mode=True) of a per-tensor quantized HIP tensor with the input's quantizer
+    (ATen has no QuantizedCUDA average pool).  ATen's CPU kernel (qavg_pool) evaluates
+    nearbyint(sum(x_int - zp) * (1 / count)) + zp per window, clamped to the type's range: the same arithmetic here, in
+    float32 on the integer representation, so the values equal the QuantizedCPU result."""
+    zp = xq.q_zero_point()
+    xi = xq.int_repr()
+    info = torch.iinfo(xi.dtype)
+    xf = xi.to(torch.float32) - float(zp)
+    kernel = [int(k) for k in kernel]
+    if dim == 1:  # (avg_pool1d has no divisor_override: pool a [N, C, 1, L] view)
+        xf, kernel = xf.unsqueeze(2), [1] + kernel
+    pool = torch.nn.functional.avg_pool3d if dim == 3 else torch.nn.functional.avg_pool2d
+    # window sums and window sizes (ceil mode: the last window of a dim may be ragged)
+    sums = pool(xf, kernel, kernel, 0, True, True, 1)
+    cnt = pool(torch.ones_like(xf[:1, :1]), kernel, kernel, 0, True, True, 1)
+    res = torch.round(sums * cnt.reciprocal())
+    if dim == 1:
+        res = res.squeeze(2)
+    res = (res + float(zp)).clamp_(info.min, info.max).to(xi.dtype)
+    return torch._make_per_tensor_quantized_tensor(res, xq.q_scale(), zp)
 
 
 class _QuantizedShiftMixin:
@@ -27,10 +68,45 @@ class _QuantizedShiftMixin:
     _qname = None
 
     def _init_quantized(self):
+        self.register_buffer("qweight_repr", torch.zeros(self.in_channels, self.dim, dtype=torch.uint8))
+        self._q_scale, self._q_zero_point, self._q_dtype = 1.0, 128, "quint8"
         self.qweight = quantize_shift_weights(self.weight.float())
 
+    # ---- the quantized weights: buffer + extra state ---------------------------------------------------------
+    @property
+    def qweight(self):
+        return torch._make_per_tensor_quantized_tensor(self.qweight_repr, self._q_scale, self._q_zero_point)
+
+    @qweight.setter
+    def qweight(self, q):
+        if not q.is_quantized:
+            raise ValueError("qweight must be a per-tensor quantized tensor")
+        self._q_scale, self._q_zero_point = float(q.q_scale()), int(q.q_zero_point())
+        self._q_dtype = str(q.dtype).replace("torch.", "")
+        self.qweight_repr = q.int_repr()  # (an existing buffer name: nn.Module keeps it registered)
+
+    def get_extra_state(self):
+        return {"qweight_scale": self._q_scale, "qweight_zero_point": self._q_zero_point, "qweight_dtype": self._q_dtype}
+
+    def set_extra_state(self, state):
+        self._q_scale = float(state["qweight_scale"])
+        self._q_zero_point = int(state["qweight_zero_point"])
+        self._q_dtype = state["qweight_dtype"]
+        want = {"quint8": torch.uint8, "qint8": torch.int8, "qint32": torch.int32}[self._q_dtype]
+        if self.qweight_repr.dtype != want:  # load_state_dict copies INTO the existing buffer: give it the saved type
+            self.qweight_repr = self.qweight_repr.to(want)
+
+    def _load_from_state_dict(self, state_dict, prefix, *args, **kwargs):
+        key = prefix + "qweight_repr"
+        if key in state_dict and state_dict[key].dtype != self.qweight_repr.dtype:
+            self.qweight_repr = torch.zeros_like(self.qweight_repr, dtype=state_dict[key].dtype)
+        super()._load_from_state_dict(state_dict, prefix, *args, **kwargs)
+
     def forward(self, input):
-        return self._reduction_fn(type(self)._qfunc(input, self.qweight, self.padding, self.cut_borders))
+        out = type(self)._qfunc(input, self.qweight, self.padding, self.cut_borders)
+        if self._pool_size is not None and out.is_cuda:
+            return _quantized_avg_pool_hip(out, self._pool_size, self.dim)
+        return self._reduction_fn(out)
 
     def _get_name(self):
         return self._qname
@@ -40,6 +116,7 @@ class _QuantizedShiftMixin:
         qshift = cls(mod.in_channels, rp_dict[mod.padding])
         qshift.cut_borders = mod.cut_borders
         qshift._reduction_fn = mod._reduction_fn
+        qshift._pool_size = getattr(mod, "_pool_size", None)
         qshift.weight = mod.weight
         qshift.qweight = quantize_shift_weights(mod.weight.float())
         return qshift

@@ -50,7 +50,7 @@
 extern "C" {
 #endif
 
-#define SHIFTND_ABI_VERSION 2
+#define SHIFTND_ABI_VERSION 3
 #define SHIFTND_API __attribute__((visibility("default")))
 
 typedef enum shiftnd_dtype {
@@ -169,11 +169,14 @@ SHIFTND_API int shiftnd_forward_quantized(const shiftnd_problem *p,
  *   sizes ceil((r - l) / pool).  shiftnd_pooled_sizes writes them.
  *   Numerics: the window is summed in ATen's order in fp32 (fp64 for fp64) and divided by the number of window
  *   elements inside the shift output; fp32 / fp64 results are bit-identical to the two-step sequence.
- *   workspace: at least shiftnd_backward_workspace_bytes(p) bytes.
+ *   workspace: at least shiftnd_backward_pooled_workspace_bytes(p, pool) bytes (the pooled launch plan can need more
+ *   partial-sum groups than the plain backward of the same tensor).
  * Return SHIFTND_ERR_NOT_FUSED when the geometry is not served (the caller then runs shift and pool
  * separately); nothing has been launched in that case.
  */
 SHIFTND_API int shiftnd_pooled_sizes(const shiftnd_problem *p, const int32_t *pool, int64_t pooled_spatial[3]);
+
+SHIFTND_API size_t shiftnd_backward_pooled_workspace_bytes(const shiftnd_problem *p, const int32_t *pool);
 
 SHIFTND_API int shiftnd_forward_pooled(const shiftnd_problem *p, const int32_t *pool,
                            const void *x, const void *weights, void *out, void *stream);

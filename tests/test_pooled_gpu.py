@@ -117,3 +117,33 @@ def test_pooled_matches_unfused_fullsize(abi):
         gx, gw = abi.backward_pooled(gp, w, x, pad, active, 2)
         assert torch.equal(gx, gx_r)
         assert rel_err(gw.cpu().numpy(), gw_r.cpu().numpy()) < 1e-5
+
+
+def test_pooled_backward_workspace_small_batch_large_plane():
+    """N = 1 with large planes: the pooled backward cuts planes into more row bands than the plain backward plans for,
+    so its workspace comes from its own query (shiftnd_backward_pooled_workspace_bytes); through the op and the C ABI"""
+    import ctypes
+    from torchshifts import abi
+    torch.manual_seed(2)
+    for shape, tdt in (((1, 8, 224, 224), torch.float32), ((1, 3, 300, 64), torch.float16), ((2, 2, 6, 40, 32), torch.float32)):
+        nd = len(shape) - 2
+        x = torch.rand(shape, device=DEV).to(tdt)
+        w = ((torch.rand(shape[1], nd, device=DEV) - 0.5) * 5).to(tdt)
+        for active in (0, 1):
+            gp = torch.rand(abi.pooled_shape(x, 2), device=DEV).to(tdt)
+            p = abi.problem(x, 0, active, None)
+            need = int(abi.lib().shiftnd_backward_pooled_workspace_bytes(ctypes.byref(p), abi._pool_arg(2, nd)))
+            plain = int(abi.lib().shiftnd_backward_workspace_bytes(ctypes.byref(p)))
+            assert need > 0
+            try:
+                gx, gw = abi.backward_pooled(gp, w, x, 0, active, 2)
+            except RuntimeError as e:  # 3-D active is not fused (SHIFTND_ERR_NOT_FUSED)
+                assert "not served" in str(e) and nd == 3 and active
+                continue
+            # the two-step reference: avg_pool backward (ATen) then the plain shift backward
+            xo = torch.zeros(shape, device=DEV, dtype=tdt, requires_grad=True)
+            pool = {2: torch.nn.functional.avg_pool2d, 3: torch.nn.functional.avg_pool3d}[nd]
+            pool(xo, 2, 2, 0, True).backward(gp)
+            gx_ref, gw_ref = abi.backward(xo.grad, w, x, 0, active)
+            assert torch.equal(gx, gx_ref) or (tdt != torch.float32 and (gx.float() - gx_ref.float()).abs().max() < 1e-2)
+            assert (gw.float() - gw_ref.float()).abs().max() <= 1e-3 * max(1.0, float(gw_ref.float().abs().max())), (shape, active, need, plain)

@@ -1,11 +1,19 @@
 """torch.ao.quantization.convert(..., mapping=torchshifts.quant_mapping) swaps float shift
 modules for the quantized ones (the reference's README:87-92 flow; its own mapping table no longer imports on
-torch 2.x).  CPU only: exercises the QuantizedCPU key."""
+torch 2.x); the quantized weights checkpoint and move with the module; quantize_shift_weights never changes a shift.
+CPU only: exercises the QuantizedCPU key."""
+import math
+import warnings
+
+import pytest
 import torch
 from torch import nn
 
 import torchshifts
-from torchshifts import Shift2d, quant_mapping
+from torchshifts import Shift1d, Shift2d, Shift3d, quant_mapping
+from torchshifts.quantized.modules.shifts import quantize_shift_weights
+
+QMODS = torchshifts.quantized.modules
 
 
 class Net(nn.Module):
@@ -32,12 +40,78 @@ def test_convert_with_quant_mapping():
     torch.ao.quantization.prepare(net, inplace=True)
     net(x)  # calibrate the stubs
     torch.ao.quantization.convert(net, inplace=True, mapping=quant_mapping)
-    assert type(net.shift) is torchshifts.quantized.modules.Shift2d
+    assert type(net.shift) is QMODS.Shift2d
     out = net(x)
     # a pure gather: the quantized result is the float result up to the input's quantisation step
     assert out.shape == ref.shape and (out - ref).abs().max() < 2.0 / 127
 
 
-def test_quantized_module_state_dict_keeps_weight():
-    q = torchshifts.quantized.modules.Shift2d.from_float(Shift2d(3, sparsity_term=0.))
-    assert "weight" in q.state_dict()  # the float parameter still checkpoints (qweight is re-derived by from_float)
+def test_quantized_weights_checkpoint_and_move():
+    torch.manual_seed(1)
+    q = QMODS.Shift2d.from_float(Shift2d(3, init_shift=3, sparsity_term=0.))
+    sd = q.state_dict()
+    assert "weight" in sd and "qweight_repr" in sd and "_extra_state" in sd
+    fresh = QMODS.Shift2d(3)
+    assert not torch.equal(fresh.qweight.int_repr(), q.qweight.int_repr())
+    fresh.load_state_dict(sd)
+    assert torch.equal(fresh.qweight.int_repr(), q.qweight.int_repr())
+    assert fresh.qweight.q_zero_point() == q.qweight.q_zero_point() == 128 and fresh.qweight.dtype == torch.quint8
+    # .to() moves the buffer the property is built from (meta device stands in for the GPU here)
+    assert q.to("meta").qweight_repr.device.type == "meta"
+    # assigning a quantized tensor goes through the property and stays registered
+    q2 = QMODS.Shift2d(3)
+    q2.qweight = torch.quantize_per_tensor(torch.tensor([[1., -2.], [0., 3.], [5., 5.]]), 1.0, 128, torch.quint8)
+    assert "qweight_repr" in dict(q2.named_buffers()) and q2.qweight.int_repr().tolist() == [[129, 126], [128, 131], [133, 133]]
+
+
+def test_qint32_weights_round_trip_through_state_dict():
+    m = Shift1d(2, sparsity_term=0.)
+    m.weight.data = torch.tensor([[300.0], [-2.0]])
+    with pytest.warns(UserWarning, match="qint32"):
+        q = QMODS.Shift1d.from_float(m)
+    fresh = QMODS.Shift1d(2)
+    fresh.load_state_dict(q.state_dict())
+    assert fresh.qweight.dtype == torch.qint32 and fresh.qweight.int_repr().flatten().tolist() == [300, -2]
+
+
+def test_quantize_shift_weights_edge_cases():
+    # all weights equal: the reference's scale is ceil(0 / 255) = 0 and torch raises; here the shift is kept
+    qw = quantize_shift_weights(torch.full((4, 2), 2.0))
+    assert qw.dtype == torch.quint8 and (qw.int_repr().long() - qw.q_zero_point()).unique().tolist() == [2]
+    # in range: identical to the reference's tensor (scale ceil(range / 255) = 1, zero point 128, quint8)
+    w = torch.tensor([[-3.4, 2.5], [0.5, -1.5], [7.0, 0.0]])
+    ref = torch.quantize_per_tensor(w, math.ceil((w.max().item() - w.min().item()) / 255.), 128, torch.quint8)
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        got = quantize_shift_weights(w)
+    assert torch.equal(got.int_repr(), ref.int_repr()) and got.q_zero_point() == 128
+    assert (got.int_repr().long() - 128).tolist() == [[-3, 2], [0, -2], [7, 0]]  # round half to even, like the float path
+    # range > 255: the reference's scale 2 would halve every shift (the kernel ignores the scale); qint32 keeps them
+    w = torch.tensor([[-200.0, 3.0], [200.0, -1.0]])
+    with pytest.warns(UserWarning):
+        got = quantize_shift_weights(w)
+    assert got.dtype == torch.qint32 and (got.int_repr().long() - got.q_zero_point()).tolist() == [[-200, 3], [200, -1]]
+    with pytest.raises(ValueError):
+        quantize_shift_weights(torch.tensor([[float("nan"), 0.0]]))
+
+
+@pytest.mark.parametrize("cls,shape", [(Shift1d, (2, 3, 20)), (Shift2d, (2, 3, 9, 11)), (Shift3d, (1, 2, 5, 6, 7))])
+def test_quantized_module_equals_float_module_on_the_grid(cls, shape):
+    """integer shifts on integer-valued data: the quantized module (QuantizedCPU) equals the float module, with and
+    without an average-pool tail (stride 2), qint32 weights included"""
+    torch.manual_seed(3)
+    for emulate, big in ((None, False), ({'kernel_size': 3, 'stride': 2, 'padding': 1}, False), (None, True)):
+        m = cls(shape[1], padding='zeros', sparsity_term=0., emulate_dw=dict(emulate) if emulate else None)
+        m.weight.data = torch.randint(-3, 4, m.weight.shape).float()
+        if big:
+            m.weight.data[0, 0] = 150.0
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            q = getattr(QMODS, cls.__name__).from_float(m)
+        x = torch.randint(0, 64, shape).float()
+        xq = torch.quantize_per_tensor(x, 1.0, 0, torch.quint8)
+        ref = m(x)[0]
+        out = q(xq)
+        assert out.is_quantized and out.shape == ref.shape
+        # pooled values: ATen rounds the window mean to the grid (half to even)
+        assert torch.equal(out.dequantize(), torch.round(ref)), (cls.__name__, emulate, big)

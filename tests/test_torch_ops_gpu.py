@@ -92,9 +92,29 @@ def test_quantized_module_gpu():
     x = torch.rand(4, 8, 24, 24)
     xq = torch.quantize_per_tensor(x, 1 / 255., 0, torch.quint8)
     ref = q(xq)  # QuantizedCPU key
-    q.qweight = q.qweight.to(DEV)
+    q = q.to(DEV)  # the quantized weights are a buffer: they move with the module
+    assert q.qweight.is_cuda and q.qweight_repr.is_cuda
     out = q(xq.to(DEV))
     assert out.is_cuda and torch.equal(out.int_repr().cpu(), ref.int_repr())
+
+
+@pytest.mark.parametrize("name,shape", [("Shift1d", (3, 4, 37)), ("Shift2d", (3, 8, 25, 24)), ("Shift3d", (2, 4, 7, 8, 16))])
+def test_quantized_module_with_pool_tail_gpu(name, shape):
+    """quantized module emulating a strided depthwise conv: shift + avg_pool(stride, ceil_mode) on the QuantizedCUDA
+    key equals the QuantizedCPU result (ATen's quantized average pool) bit for bit, ragged last windows included"""
+    import torchshifts.quantized.modules as QM
+    torch.manual_seed(5)
+    for stride, zp in ((2, 0), (3, 17)):
+        m = getattr(torchshifts, name)(shape[1], padding='reflect', sparsity_term=0.,
+                                       emulate_dw={'kernel_size': 3, 'stride': stride, 'padding': 1})
+        q = getattr(QM, name).from_float(m)
+        x = torch.rand(shape)
+        xq = torch.quantize_per_tensor(x, 1 / 255., zp, torch.quint8)
+        ref = q(xq)
+        out = q.to(DEV)(xq.to(DEV))
+        assert out.is_cuda and out.is_quantized and out.shape == ref.shape
+        assert out.q_zero_point() == ref.q_zero_point() and abs(out.q_scale() - ref.q_scale()) < 1e-12
+        assert torch.equal(out.int_repr().cpu(), ref.int_repr()), (name, stride)
 
 
 def test_error_behaviour_gpu():

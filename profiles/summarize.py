@@ -28,7 +28,7 @@ def main(root):
         print("== kernel trace:", os.path.relpath(f, root))
         print("%-92s %6s %12s %12s" % ("kernel", "calls", "avg_us", "min_us"))
         for k, v in sorted(dur.items(), key=lambda kv: -sum(kv[1])):
-            if any(t in k for t in ("sweep_", "plane_", "strided_", "reduce_weight", "cl_", "transpose", "slide_")):
+            if any(t in k for t in ("sweep_", "plane_", "strided_", "reduce_weight", "cl_", "transpose", "slide_", "bytes_")):
                 print("%-92s %6d %12.1f %12.1f   %s" % (k, len(v), sum(v) / len(v) / 1e3, min(v) / 1e3, res[k]))
     for d in sorted(glob.glob(os.path.join(root, "pmc_*"))):
         for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
@@ -37,12 +37,15 @@ def main(root):
                 acc[short(r["Kernel_Name"])][r["Counter_Name"]].append(float(r["Counter_Value"]))
             print("== pmc:", os.path.relpath(f, root))
             for k, ctrs in acc.items():
-                if not any(t in k for t in ("sweep_", "plane_", "strided_", "cl_", "slide_")):
+                if not any(t in k for t in ("sweep_", "plane_", "strided_", "cl_", "slide_", "bytes_")):
                     continue
                 for c, v in ctrs.items():
                     avg = sum(v) / len(v)
                     note = ""
                     base = k.split("<")[0].split("(")[0].strip()
+                    if base == "slide_kernel":  # one template for both directions: name them like shiftnd_last_kernel does
+                        targs = k.split("<", 1)[1].split(",")
+                        base = "slide_backward" if len(targs) > 3 and targs[3].strip() == "true" else "slide_forward"
                     if c == "FETCH_SIZE":
                         note = "  KB/launch; x2 (gfx950 correction) = %.3f GB read" % (avg * 2 * 1024 / 1e9)
                         traffic[base]["read_bytes"] = avg * 2 * 1024

@@ -97,6 +97,10 @@ int forward_common(const shiftnd_problem *p, const void *x, const int64_t *xs, c
             return finish(plane_forward(g, p->dtype, x, w, wkind, wzp, fill, out, st));
         }
     }
+    if ((g_policy == 0 || g_policy == 4) && cl_tiled_forward_eligible(g, p->dtype, x, out)) {  // channels-last in, LDS-tiled
+        g_last_path = SHIFTND_PATH_CL;
+        return finish(cl_tiled_forward(g, x, w, wkind, wzp, fill, out, st));
+    }
     if (g_policy == 4 && !cl_forward_eligible(g)) return SHIFTND_ERR_INVALID_ARGUMENT;
     if ((g_policy == 0 && cl_forward_preferred(g)) || g_policy == 4) {  // channels-last tensors: channel-fastest kernels
         g_last_path = SHIFTND_PATH_CL;
@@ -137,7 +141,8 @@ int shiftnd_last_path(void) { return g_last_path; }
 void shiftnd_set_path_policy(int policy) { g_policy = policy; }
 
 void shiftnd_set_tuning(int knob, int value) {
-    if (knob >= 16) bytes_set_tuning(knob - 16, value);  // 16: 1-byte small-plane kernel on / off, 17: planes per workgroup
+    if (knob >= 20) cl_tiled_set_tuning(knob - 20, value);  // 20: LDS-tiled channels-last forward on / off, 21: rows per band
+    else if (knob >= 16) bytes_set_tuning(knob - 16, value);  // 16: 1-byte small-plane kernel on / off, 17: planes per workgroup
     else if (knob >= 12) slide_set_tuning(knob - 12, value);  // 12: which problems slide, 13: workgroups wanted, 14: min rows per band
     else if (knob >= 8) sweep_set_tuning(knob - 8, value);  // 8/9: sweep forward K / max threads, 10/11: sweep backward
     else plane_set_tuning(knob, value);
@@ -176,6 +181,14 @@ int shiftnd_check_borders(const int64_t *sizes, int nsizes, const int32_t *user,
     for (int i = 0; i < shift; ++i) new_sizes[i] = sizes[i];
     for (int i = 0; i < dims; ++i) new_sizes[i + shift] = static_cast<int64_t>(borders[2 * i + 1] - borders[2 * i]);
     return SHIFTND_OK;
+}
+
+int shiftnd_forward_serves_channels_last(const shiftnd_problem *p, const void *x, const int64_t x_strides[5], const void *out,
+                                         const int64_t out_strides[5]) {
+    if (!p || !x_strides || !out_strides || g_policy != 0) return 0;
+    Geometry g;
+    if (build_geometry(p, x_strides, out_strides, nullptr, g) != SHIFTND_OK || empty_problem(g)) return 0;
+    return cl_tiled_forward_eligible(g, p->dtype, x, out) ? 1 : 0;
 }
 
 int shiftnd_forward(const shiftnd_problem *p, const void *x, const int64_t x_strides[5], const void *weights, void *out,

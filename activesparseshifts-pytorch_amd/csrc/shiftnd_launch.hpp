@@ -83,6 +83,13 @@ size_t cl_backward_workspace(const Geometry &g);
 int cl_backward(const Geometry &g, int dtype, const void *go, const void *x, const void *w, void *gx, void *gw,
                 void *workspace, hipStream_t st);
 
+// ---- LDS-tiled gather forward for dense channels-last inputs of 4-byte elements (shiftnd_cl_tiled.hip); the output is
+// channels-last or NCHW-contiguous
+bool cl_tiled_forward_eligible(const Geometry &g, int dtype, const void *x, const void *out);
+int cl_tiled_forward(const Geometry &g, const void *x, const void *w, int wkind, int64_t wzp, uint64_t fill_bits, void *out,
+                     hipStream_t st);
+void cl_tiled_set_tuning(int knob, int value);
+
 // ---- layout change (shiftnd_transpose.hip): dst[n][c][r] = src[n][r][c], dense tensors ---------------------------
 int transpose_planes(const void *src, void *dst, int64_t N, int64_t rows, int64_t cols, int esize, hipStream_t st);
 

@@ -233,13 +233,20 @@ template <int ND> Tensor shift_forward_hip(const Tensor &input_, const Tensor &w
     int32_t b[6];
     read_borders(borders, b);
     Tensor w = weights.contiguous();
-    const Tensor input = is_channels_last_dense(input_) ? channels_last_to_contiguous(input_) : input_;
-    Tensor output = at::empty(new_size, input.options(), at::MemoryFormat::Contiguous);
+    Tensor output = at::empty(new_size, input_.options(), at::MemoryFormat::Contiguous);
     shiftnd_problem p;
-    fill_problem(p, ND, input, b, padding_mode, active_flag, dtype);
+    fill_problem(p, ND, input_, b, padding_mode, active_flag, dtype);
     int64_t xs[5], os[5];
-    fill_strides(input, ND, xs);
     fill_strides(output, ND, os);
+    // a dense channels-last input: the library may have a kernel that reads it as it lies and writes the NCHW result
+    // (shiftnd_cl_tiled.hip); otherwise one tile transpose, then the contiguous kernels
+    bool direct = false;
+    if (is_channels_last_dense(input_)) {
+        fill_strides(input_, ND, xs);
+        direct = shiftnd_forward_serves_channels_last(&p, input_.data_ptr(), xs, output.data_ptr(), os) != 0;
+    }
+    const Tensor input = (is_channels_last_dense(input_) && !direct) ? channels_last_to_contiguous(input_) : input_;
+    fill_strides(input, ND, xs);
     const int rc = shiftnd_forward(&p, input.data_ptr(), xs, w.data_ptr(), output.data_ptr(), os, current_stream(input));
     TORCH_CHECK(rc == SHIFTND_OK, "shiftnd_forward (HIP): ", shiftnd_status_string(rc));
     return output;
@@ -495,7 +502,22 @@ template <int ND> Tensor qshift_forward_hip(const Tensor &input_, const Tensor &
     const bool cl = input_.is_contiguous(at::MemoryFormat::ChannelsLast) || input_.is_contiguous(at::MemoryFormat::ChannelsLast3d);
     // a channels-last input keeps its format (shifts_quantized.cpp:119-121).  Two tile transposes around the contiguous
     // kernel beat the channel-fastest kernel (N128 C512 56x56 quint8: 0.09 + 0.14 + 0.09 ms against 0.69 ms)
-    const bool via_transpose = cl && is_channels_last_dense(input_);
+    bool via_transpose = cl && is_channels_last_dense(input_);
+    if (via_transpose) {  // 4-byte elements: the LDS-tiled channels-last kernel keeps the format in one pass
+        Tensor out_cl = at::_empty_affine_quantized(new_size, input_.options().memory_format(input_.suggest_memory_format()),
+                                                    input_.q_scale(), input_.q_zero_point(), c10::nullopt);
+        shiftnd_problem pd;
+        fill_problem(pd, ND, input_, b, padding_mode, false, dtype);
+        int64_t xd[5], od[5];
+        fill_strides(input_, ND, xd);
+        fill_strides(out_cl, ND, od);
+        if (shiftnd_forward_serves_channels_last(&pd, input_.data_ptr(), xd, out_cl.data_ptr(), od)) {
+            const int rcd = shiftnd_forward_quantized(&pd, input_.data_ptr(), xd, wrepr.data_ptr(), wdtype, weights.q_zero_point(),
+                                                      input_.q_zero_point(), out_cl.data_ptr(), od, current_stream(input_));
+            TORCH_CHECK(rcd == SHIFTND_OK, "shiftnd_forward_quantized (HIP): ", shiftnd_status_string(rcd));
+            return out_cl;
+        }
+    }
     const Tensor input = via_transpose ? channels_last_to_contiguous(input_) : input_;
     Tensor output = (cl && !via_transpose)
                         ? at::_empty_affine_quantized(new_size, input.options().memory_format(input.suggest_memory_format()),

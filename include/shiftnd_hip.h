@@ -120,6 +120,14 @@ SHIFTND_API int shiftnd_check_borders(const int64_t *sizes, int nsizes, const in
                           int32_t borders[6], int64_t *new_sizes);
 
 /*
+ * 1 when shiftnd_forward would serve this call with a kernel made for a dense channels-last INPUT (x_strides) and the
+ * given output layout (channels-last or NCHW-contiguous) -- the caller then need not change the input's layout first
+ * (the torch operator library transposes channels-last inputs otherwise); 0 for every other call.
+ */
+SHIFTND_API int shiftnd_forward_serves_channels_last(const shiftnd_problem *p, const void *x, const int64_t x_strides[5],
+                                                     const void *out, const int64_t out_strides[5]);
+
+/*
  * Forward, float dtypes (F32, F64, F16, BF16).
  * out has sizes {N, C, r_i-l_i, r_j-l_j, r_k-l_k}; out_strides are its element strides.
  */

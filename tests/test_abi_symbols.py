@@ -17,7 +17,7 @@ def _declared_symbols():
 
 def test_header_symbols_exported():
     decl = _declared_symbols()
-    assert len(decl) == 17 and sorted(abi.EXPORTS) == decl
+    assert len(decl) == 18 and sorted(abi.EXPORTS) == decl
     L = ctypes.CDLL(abi._LIB_PATH)
     for name in decl:
         assert hasattr(L, name), name

@@ -154,3 +154,57 @@ def test_small_plane_byte_kernel_vs_oracle(shape, tdt, npdt, zp):
     finally:
         abi.set_tuning(16, 1)
         abi.set_tuning(17, 0)
+
+
+@pytest.mark.parametrize("shape", [(2, 8, 9, 12), (3, 300, 6, 5), (2, 64, 40, 70), (1, 36, 100, 33), (2, 4, 1, 50), (1, 32, 64, 1)])
+def test_tiled_channels_last_forward_vs_oracle(shape):
+    """cl_tiled_forward (csrc/shiftnd_cl_tiled.hip): dense channels-last fp32 / int32 input, channels-last or
+    NCHW-contiguous output, every padding it serves (periodic goes to the channel-fastest gather), shifts beyond the
+    ring (gathered from memory), ragged tiles / channel blocks / bands; bit-exact"""
+    from torchshifts import abi
+    rs = np.random.RandomState(sum(shape) + 3)
+    x = rs.uniform(-1, 1, size=shape).astype(np.float32)
+    w = rs.uniform(-3.4, 3.4, size=(shape[1], 2)).astype(np.float32)
+    w[0] = [0.5, -1.5]
+    w[1] = [shape[2] + 2.25, -7.0]       # beyond the dim / beyond the ring
+    w[2] = [-5.0, 2.5]
+    xd = torch.from_numpy(x).to(DEV).contiguous(memory_format=torch.channels_last)
+    wd = torch.from_numpy(w).to(DEV)
+    try:
+        for band_rows in (0, 5):
+            abi.set_tuning(21, band_rows)
+            for pad in (0, 1, 3, 4):
+                ref = O.forward(x, w, pad, False)
+                out = abi.forward(xd, wd, pad, False)  # NCHW-contiguous output
+                assert abi.last_kernel() == "cl_tiled_forward" and out.is_contiguous()
+                assert np.array_equal(out.cpu().numpy(), ref), (shape, pad, "nchw")
+                out_cl = torch.empty(shape, device=DEV).contiguous(memory_format=torch.channels_last)
+                abi.forward(xd, wd, pad, False, out=out_cl)
+                assert abi.last_kernel() == "cl_tiled_forward"
+                assert np.array_equal(out_cl.cpu().numpy(), ref), (shape, pad, "cl")
+        abi.set_tuning(21, 0)
+        abi.forward(xd, wd, 2, False)
+        assert abi.last_kernel() != "cl_tiled_forward"  # periodic
+        # int32 quantized: fill = the input's zero point
+        xq = rs.randint(-1000, 1000, size=shape).astype(np.int32)
+        wq = rs.randint(124, 133, size=(shape[1], 2)).astype(np.uint8)
+        xqd = torch.from_numpy(xq).to(DEV).contiguous(memory_format=torch.channels_last)
+        outq = torch.empty(shape, dtype=torch.int32, device=DEV).contiguous(memory_format=torch.channels_last)
+        abi.forward_quantized(xqd, torch.from_numpy(wq).to(DEV), 128, -7, 0, out=outq)
+        assert abi.last_kernel() == "cl_tiled_forward"
+        assert np.array_equal(outq.cpu().numpy(), O.forward_q(xq, wq, 128, -7, 0))
+    finally:
+        abi.set_tuning(21, 0)
+
+
+def test_channels_last_input_through_the_op_uses_the_tiled_kernel():
+    """torch.ops.torchshifts.shift2d with a channels-last fp32 input: one pass (no layout change first), NCHW result
+    like the reference (cpu/shifts_cpu.cpp:221), same bits as the contiguous input"""
+    import torchshifts  # noqa: F401
+    from torchshifts import abi
+    torch.manual_seed(4)
+    x = torch.rand(4, 64, 56, 56, device=DEV)
+    w = (torch.rand(64, 2, device=DEV) - 0.5) * 6
+    ref = torch.ops.torchshifts.shift2d(x, w, torch.Tensor(), 3, False)
+    out = torch.ops.torchshifts.shift2d(x.contiguous(memory_format=torch.channels_last), w, torch.Tensor(), 3, False)
+    assert abi.last_kernel() == "cl_tiled_forward" and out.is_contiguous() and torch.equal(out, ref)

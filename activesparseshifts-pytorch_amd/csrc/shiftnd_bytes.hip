@@ -86,7 +86,8 @@ __global__ __launch_bounds__(kThreads) void bytes_gather_forward(const BytesPara
         for (int i = 0; i < kMaxLoads; ++i) {
             // (unconditional load: threads past the end re-read piece 0 and drop it)
             const int off = (i * kThreads + static_cast<int>(threadIdx.x)) < total ? pl * nstride + k * 16 : 0;
-            v[i] = __builtin_nontemporal_load(reinterpret_cast<const u4 *>(xb + off));
+            // (a plain load: as nontemporal loads these were 10 % slower, 0.092 vs 0.083 ms on C4)
+            v[i] = *reinterpret_cast<const u4 *>(xb + off);
             next_piece(pl, k);
         }
     }

@@ -706,7 +706,10 @@ SlidePlan slide_plan(const Geometry &g, int es, bool backward, int np_max) {
         --nseg;
     if (static_cast<int64_t>(slots_of(nseg)) * pl.cpr > static_cast<int64_t>(np_max) * kThreads) return pl;
     (void)kinds;
-    const int64_t min_wgs = g_slide_tune[1] > 0 ? g_slide_tune[1] : 4096;
+    // workgroups wanted: whole rounds of what the chip holds at once (256 CUs x 4 resident workgroups) and few, long
+    // bands (a band pays one warm-up step).  Measured on C3 (tools/kbench.py --knobs 13=...): backward 3072 -> 0.306 ms
+    // (2048: 0.314, 4096: 0.317, 8192: 0.326), forward 1024 -> 0.187 ms (2048: 0.205, 4096: 0.209)
+    const int64_t min_wgs = g_slide_tune[1] > 0 ? g_slide_tune[1] : (backward ? 3072 : 1024);
     const int64_t min_rows = g_slide_tune[2] > 0 ? g_slide_tune[2] : 16;
     if (g.nd == 3) {
         if (plane >= (1LL << 30)) return pl;

@@ -26,6 +26,9 @@
 namespace shiftnd {
 namespace {
 
+#ifndef SWEEP_NT_LOAD
+#define SWEEP_NT_LOAD true
+#endif
 constexpr int kSweepMaxThreads = 512;
 thread_local int g_sweep_tune[4] = {4, 512, 2, 256};  // [0] forward row steps per workgroup (K), [1] forward max threads,
                                          // [2] backward K, [3] backward max threads
@@ -122,7 +125,7 @@ __global__ __launch_bounds__(kSweepMaxThreads) void sweep_gather_forward(const S
             } else {
                 const R *row = xp + static_cast<int64_t>(ra * p.S[1] + rb) * p.S[2];
                 if (contig) {
-                    v[k] = load_chunk<R, E, true>(row + mm[0]);
+                    v[k] = load_chunk<R, E, SWEEP_NT_LOAD>(row + mm[0]);
                 } else {
 #pragma unroll
                     for (int e = 0; e < E; ++e) v[k].e[e] = mm[e] >= 0 ? __builtin_nontemporal_load(row + mm[e]) : fill;

@@ -632,19 +632,23 @@ __global__ __launch_bounds__(kThreads) void plane_backward(const PlaneParams p) 
 //   GS  backward, active: NA x (R+1) rows of grad_out through the grad maps; SSL: R shifted rows
 // A slot whose map says "fill" is not loaded and never read.
 // =====================================================================================================
-template <int ND, bool ACTIVE, bool BACKWARD> struct LdsTileShape {
+// SCAT (2-D sparse-shift backward): no GS slots.  The sparse shift's input gradient is a row permutation of grad_out
+// (plus fill / folded rows at the two ends of a plane), so the G rows a step stages for the weight gradient are also
+// written out as the grad_x rows that read them (grad_x row b - shift <- grad_out row b): every grad_out row crosses
+// the L2 -> LDS path once instead of twice (13 -> 9 staged rows per 4-row step).
+template <int ND, bool ACTIVE, bool BACKWARD, bool SCAT = false> struct LdsTileShape {
     static constexpr int NA = ND == 3 ? 2 : 1;
     __host__ __device__ static int nx(int R) { return NA * (R + 1); }
     __host__ __device__ static int ng(int R) { return BACKWARD ? R : 0; }
-    __host__ __device__ static int ngs(int R) { return BACKWARD ? (ACTIVE ? NA * (R + 1) : R) : 0; }
+    __host__ __device__ static int ngs(int R) { return (BACKWARD && !SCAT) ? (ACTIVE ? NA * (R + 1) : R) : 0; }
     __host__ __device__ static int slots(int R) { return nx(R) + ng(R) + ngs(R); }
 };
 
 // Shared by the LDS-staged kernels: slot table + LDS-DMA of one step.
-template <typename T, int ND, bool ACTIVE, bool BACKWARD, bool POOL = false>
+template <typename T, int ND, bool ACTIVE, bool BACKWARD, bool POOL = false, bool SCAT = false>
 struct LdsStager {
     using S = typename T::S;
-    using Shape = LdsTileShape<ND, ACTIVE, BACKWARD>;
+    using Shape = LdsTileShape<ND, ACTIVE, BACKWARD, SCAT>;
     static constexpr int E = 16 / sizeof(S);
     static constexpr int NA = Shape::NA;
 
@@ -724,7 +728,7 @@ struct LdsStager {
     // Its (slot, column piece) pair is decoded once, packed as slot * 256 + j (or -1), and the per-step work is the
     // slot-table read, one address and the DMA.  For steps of at most kRegPieces pieces per thread (cpr <= 256).
     // (3 keeps the 2-D SSL fp32 kernel at 64 VGPRs; the 3-D kernels stage up to 49 short rows per step)
-    static constexpr int kRegPieces = ND == 3 ? 6 : ((ACTIVE || POOL || sizeof(S) == 2) ? 4 : 3);
+    static constexpr int kRegPieces = ND == 3 ? 6 : ((ACTIVE || POOL || sizeof(S) == 2) ? 4 : (SCAT ? 2 : 3));
     __host__ __device__ static bool pieces_fit(int cpr, int R) {
         return Shape::slots(R) * cpr <= kRegPieces * kThreads && cpr <= 256;
     }
@@ -978,12 +982,13 @@ __device__ __forceinline__ void lds_corners(const char *tile, int RB, int R, int
 }
 
 // DEC: the step's DMA pieces per thread fit the pre-decoded form (LdsStager::pieces_fit, checked by the host)
-template <typename T, int ND, bool ACTIVE, int TILES, bool POOL = false, bool DEC = false>
+template <typename T, int ND, bool ACTIVE, int TILES, bool POOL = false, bool DEC = false, bool SCAT = false>
 __global__ __launch_bounds__(kThreads) void plane_backward_lds(const PlaneParams p) {
     using S = typename T::S;
     using CT = typename T::C;
-    using Stager = LdsStager<T, ND, ACTIVE, true, POOL>;
-    using Shape = LdsTileShape<ND, ACTIVE, true>;
+    static_assert(!SCAT || (ND == 2 && !ACTIVE && !POOL), "the scatter form serves the 2-D sparse-shift backward");
+    using Stager = LdsStager<T, ND, ACTIVE, true, POOL, SCAT>;
+    using Shape = LdsTileShape<ND, ACTIVE, true, SCAT>;
     constexpr int E = 16 / sizeof(S);
     constexpr int NC = 1 << (ND - 1);
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -1019,6 +1024,9 @@ __global__ __launch_bounds__(kThreads) void plane_backward_lds(const PlaneParams
     double dsum[NDIFF];  // sums of g * corner difference (see corner_diffs)
 #pragma unroll
     for (int i = 0; i < NDIFF; ++i) dsum[i] = 0.0;
+    // SCAT: the row shift as the grad_x <- grad_out row map sees it (size-1 dims ignore the shift; anything beyond the
+    // dim leaves no row that maps by the plain shift)
+    const int scat_shift = (!SCAT || S1 == 1) ? 0 : static_cast<int>(sh[1] > S1 ? S1 : (sh[1] < -S1 ? -S1 : sh[1]));
     const int row_end = wi.row0 + wi.nrows;
 
     // steps never cross an `a` boundary; the slot table of step s+1 is written while step s is computed
@@ -1084,6 +1092,12 @@ __global__ __launch_bounds__(kThreads) void plane_backward_lds(const PlaneParams
                     res.e[e] = narrow<T>(interp_t<T, ND>(v, dw));
                 }
                 __builtin_amdgcn_sched_barrier(0);
+            } else if constexpr (SCAT) {
+                // the staged grad_out row b0 + tr, read through the column map, IS grad_x row scat_row (below)
+                S graw[E + 1];
+                lds_read_row<S, E>(tile + (NX + tr) * RB, true, gm, graw);
+#pragma unroll
+                for (int e = 0; e < E; ++e) res.e[e] = graw[e];
             } else {
                 S graw[E + 1];
                 lds_read_row<S, E>(tile + (NX + NG + tr) * RB, ss[NX + NG + tr] >= 0, gm, graw);
@@ -1111,7 +1125,16 @@ __global__ __launch_bounds__(kThreads) void plane_backward_lds(const PlaneParams
             }
 #pragma unroll
             for (int i = 0; i < NDIFF; ++i) dsum[i] += static_cast<double>(part[i]);
-            store_chunk<S, E>(gxp + static_cast<int64_t>(a * S1 + b0 + tr) * S2 + ji, res);
+            if constexpr (SCAT) {
+                // grad_x row whose source is grad_out row b: periodic padding is a permutation (the x map is the inverse
+                // of the grad map); otherwise b - shift when that is a row (rows [0, S1) of grad_out map to themselves),
+                // and the rows left over at one end of the plane are written by the tail pass below
+                const int b = b0 + tr;
+                const int brow = p.pad == 2 ? m1[b] : b - scat_shift;
+                if (brow >= 0 && brow < S1) store_chunk<S, E>(gxp + static_cast<int64_t>(brow) * S2 + ji, res);
+            } else {
+                store_chunk<S, E>(gxp + static_cast<int64_t>(a * S1 + b0 + tr) * S2 + ji, res);
+            }
         }
         if (TILES == 1) __syncthreads();  // one tile: it is overwritten by the next step
         // (two tiles: the next step writes the other tile, last read before this step's barrier, and the slot table
@@ -1125,6 +1148,38 @@ __global__ __launch_bounds__(kThreads) void plane_backward_lds(const PlaneParams
         r0 = r2;
         buf ^= 1;
         tb = (tb + 1) % NT;
+    }
+    if constexpr (SCAT) {
+        // tail pass: the grad_x rows no grad_out row maps to by the plain shift -- |shift| rows at one end of every plane
+        // (fill for zeros padding, clamped / reflected source rows otherwise); the workgroup whose band holds them
+        // reads their sources straight from memory (a few rows per plane)
+        if (p.pad != 2 && scat_shift != 0) {
+            const int e0 = scat_shift > 0 ? max(S1 - scat_shift, 0) : 0, e1 = scat_shift > 0 ? S1 : min(-scat_shift, S1);
+            const int lo = max(e0, wi.row0), hi = min(e1, row_end);
+            bool gcontig = true;
+#pragma unroll
+            for (int e = 0; e < E; ++e) gcontig = gcontig && gm.cm[e] >= 0 && gm.cm[e] == gm.cm[0] + e;
+            for (int pl = 0; pl < wi.nn; ++pl) {
+                const S *gpl = static_cast<const S *>(p.go) + (plane0 + static_cast<int64_t>(pl) * p.C) * p.o_plane;
+                S *gxl = static_cast<S *>(p.out) + (plane0 + static_cast<int64_t>(pl) * p.C) * p.x_plane;
+                for (int bq = lo + tr; worker && bq < hi; bq += R) {
+                    const int src = g1[bq];
+                    Chunk<S, E> res;
+                    S zero;
+                    __builtin_memset(&zero, 0, sizeof(S));
+                    if (src < 0) {
+#pragma unroll
+                        for (int e = 0; e < E; ++e) res.e[e] = zero;
+                    } else if (gcontig) {
+                        res = load_chunk<S, E>(gpl + static_cast<int64_t>(src) * S2 + gm.cm[0]);
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < E; ++e) res.e[e] = gm.cm[e] >= 0 ? gpl[static_cast<int64_t>(src) * S2 + gm.cm[e]] : zero;
+                    }
+                    store_chunk<S, E>(gxl + static_cast<int64_t>(bq) * S2 + ji, res);
+                }
+            }
+        }
     }
     double acc[3] = {0.0, 0.0, 0.0};
     {
@@ -1546,10 +1601,14 @@ int launch_active_forward(const PlaneParams &p_in, const Plan &pl, hipStream_t s
 template <typename T, bool ACTIVE>
 void launch_backward_a(const PlaneParams &p_in, const Plan &pl, hipStream_t st) {
     PlaneParams p = p_in;
-    if (g_tune[3] == 2 && p.nd >= 2) {  // LDS-staged form where it applies
+    if ((g_tune[3] == 2 || g_tune[3] == 3) && p.nd >= 2) {  // LDS-staged form where it applies
         size_t lds_bytes = 0;
         int tile_bytes = 0;
-        const int slots = p.nd == 3 ? LdsTileShape<3, ACTIVE, true>::slots(pl.RPS) : LdsTileShape<2, ACTIVE, true>::slots(pl.RPS);
+        // 2-D sparse shift: the scatter form (knob 3 = 3 keeps the gather form, with its GS slots)
+        constexpr bool kCanScat = !ACTIVE;
+        const bool scat = kCanScat && p.nd == 2 && g_tune[3] == 2;
+        const int slots = p.nd == 3 ? LdsTileShape<3, ACTIVE, true>::slots(pl.RPS)
+                                    : (scat ? LdsTileShape<2, ACTIVE, true, kCanScat>::slots(pl.RPS) : LdsTileShape<2, ACTIVE, true>::slots(pl.RPS));
         if (lds_staged_ok(p, pl, static_cast<int>(sizeof(typename T::S)), slots, &lds_bytes, &tile_bytes)) {
             p.tile_bytes = tile_bytes;
             note_kernel("plane_backward_lds");
@@ -1560,9 +1619,17 @@ void launch_backward_a(const PlaneParams &p_in, const Plan &pl, hipStream_t st) 
             const size_t lds2 = lds_bytes + tile_bytes + slots * sizeof(int);
             // few pieces per thread and step: the pre-decoded DMA form (knob 5 = 2 keeps the generic loop)
             const bool dec = g_tune[5] != 2 && (p.nd == 3 ? LdsStager<T, 3, ACTIVE, true>::pieces_fit(pl.cpr, pl.RPS)
-                                                          : LdsStager<T, 2, ACTIVE, true>::pieces_fit(pl.cpr, pl.RPS));
+                                                  : (scat ? LdsStager<T, 2, ACTIVE, true, false, kCanScat>::pieces_fit(pl.cpr, pl.RPS)
+                                                          : LdsStager<T, 2, ACTIVE, true>::pieces_fit(pl.cpr, pl.RPS)));
 #define SHIFTND_BWD_LDS(NDV, TL, DECV, BYTES) \
     hipLaunchKernelGGL((plane_backward_lds<T, NDV, ACTIVE, TL, false, DECV>), dim3(pl.grid), dim3(kThreads), BYTES, st, p)
+#define SHIFTND_BWD_SCAT(TL, DECV, BYTES) \
+    hipLaunchKernelGGL((plane_backward_lds<T, 2, ACTIVE, TL, false, DECV, kCanScat>), dim3(pl.grid), dim3(kThreads), BYTES, st, p)
+            if (scat) {
+                if (two) { if (dec) SHIFTND_BWD_SCAT(2, true, lds2); else SHIFTND_BWD_SCAT(2, false, lds2); }
+                else { if (dec) SHIFTND_BWD_SCAT(1, true, lds_bytes); else SHIFTND_BWD_SCAT(1, false, lds_bytes); }
+                return;
+            }
             if (p.nd == 3) {
                 if (two) { if (dec) SHIFTND_BWD_LDS(3, 2, true, lds2); else SHIFTND_BWD_LDS(3, 2, false, lds2); }
                 else { if (dec) SHIFTND_BWD_LDS(3, 1, true, lds_bytes); else SHIFTND_BWD_LDS(3, 1, false, lds_bytes); }
@@ -1571,6 +1638,7 @@ void launch_backward_a(const PlaneParams &p_in, const Plan &pl, hipStream_t st) 
                 else { if (dec) SHIFTND_BWD_LDS(2, 1, true, lds_bytes); else SHIFTND_BWD_LDS(2, 1, false, lds_bytes); }
             }
 #undef SHIFTND_BWD_LDS
+#undef SHIFTND_BWD_SCAT
             return;
         }
     }

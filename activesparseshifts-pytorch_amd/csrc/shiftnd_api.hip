@@ -87,7 +87,9 @@ int forward_common(const shiftnd_problem *p, const void *x, const int64_t *xs, c
         // several rows); small planes (e.g. 56x56 int8 = 3 KiB) go to the plane kernels, which walk many planes
         // of one channel per workgroup (measured on C4: 0.13 ms vs 0.33 ms)
         const int64_t out_plane_bytes = g.O[0] * g.O[1] * g.O[2] * dtype_size(p->dtype);
-        const bool prefer_sweep = (out_plane_bytes >= 32 * 1024 && !(can_plane && plane_forward_lds_gather(g, p->dtype, x, out))) || !can_plane;
+        // (interpolating problems keep the LDS-staged plane kernels whenever those take them: see DESIGN 3.14)
+        const bool interpolating = g.active && p->dtype <= SHIFTND_BF16;
+        const bool prefer_sweep = (out_plane_bytes >= 32 * 1024 && !interpolating && !(can_plane && plane_forward_lds_gather(g, p->dtype, x, out))) || !can_plane;
         if (can_sweep && (g_policy == 3 || (g_policy == 0 && prefer_sweep))) {
             g_last_path = SHIFTND_PATH_SWEEP;
             return finish(sweep_forward(g, p->dtype, x, w, wkind, wzp, fill, out, st));

@@ -33,9 +33,6 @@
 namespace shiftnd {
 namespace {
 
-#ifndef SLIDE_EU_ATTR
-#define SLIDE_EU_ATTR
-#endif
 constexpr int kGuard = 32;          // zeroed bytes in front of every staged row (and behind the last one)
 constexpr int kFlushSteps = 8;      // fp32 partial sums are blended into the fp64 accumulators every kFlushSteps rows
 
@@ -235,7 +232,7 @@ __device__ __forceinline__ RowRead make_rowread(const int *map, int ji, bool liv
 //   ND 2/3; ACTIVE: interpolating (active shift) or sparse shift; BACKWARD: grad_x + weight-gradient partials, else
 //   the interpolating forward.  NP: 16-byte pieces a thread stages per step.
 template <typename T, int ND, bool ACTIVE, bool BACKWARD, int NP, int DEPTH>
-__global__ __launch_bounds__(kThreads) SLIDE_EU_ATTR void slide_kernel(const SlideParams p) {
+__global__ __launch_bounds__(kThreads) void slide_kernel(const SlideParams p) {
     using S = typename T::S;
     using CT = typename T::C;
     constexpr int ES = sizeof(S), E = 16 / ES;
@@ -416,9 +413,6 @@ __global__ __launch_bounds__(kThreads) SLIDE_EU_ATTR void slide_kernel(const Sli
         }
     };
     auto write_tile = [&](char *tile, const u4 (&pvr)[NP]) {
-#ifdef SLIDE_DBG_NOSTAGE
-        return;
-#endif
 #pragma unroll
         for (int k = 0; k < NP; ++k) {
             *reinterpret_cast<u4 *>(__builtin_assume_aligned(tile + (pdst[k] & 0xffff), 16)) = pvr[k];
@@ -490,22 +484,13 @@ __global__ __launch_bounds__(kThreads) SLIDE_EU_ATTR void slide_kernel(const Sli
     auto step = [&](int t, u4 (&pvr)[NP]) {
         char *tile = tiles + (t & 1) * p.tile_bytes;
         write_tile(tile, pvr);
-#ifndef SLIDE_DBG_NOBARRIER
         __syncthreads();
-#endif
         // The output row of the previous step leaves here, BEFORE the next loads are issued: loads and stores share
         // one in-order counter (vmcnt), and the compiler waits for everything older when it needs the loads back, so a
         // store issued after the loads would be waited for (its whole write latency) at the top of every step.
         flush_store();
-#if !defined(SLIDE_DBG_NOSTAGE) && !defined(SLIDE_DBG_LATELOAD)
         if (t + DEPTH <= p.seg) issue_loads(t + DEPTH, pvr);  // in flight while this and the next DEPTH - 1 steps are computed
-#endif
-#ifdef SLIDE_DBG_NOCOMPUTE
-        if (t == p.seg && threadIdx.x == 0) *reinterpret_cast<volatile uint32_t *>(outp) = *reinterpret_cast<uint32_t *>(tile + 64);
-        if (false) {
-#else
         if (t <= mylen) {
-#endif
             // fill rows (zeros padding) read the all-zero slot
             const bool rvx = m1[(ND == 3 ? ubstart : mybstart) + t] >= 0;
             const char *xs[NA];
@@ -622,21 +607,9 @@ __global__ __launch_bounds__(kThreads) SLIDE_EU_ATTR void slide_kernel(const Sli
                 }
             }
         }
-#ifdef SLIDE_DBG_LATELOAD
-        __builtin_amdgcn_sched_barrier(0);
-        if (t + DEPTH <= p.seg) issue_loads(t + DEPTH, pvr);
-#endif
 };
-#ifdef SLIDE_DBG_STAGGER
-    // desynchronise the workgroups of a CU (they run identical steps and otherwise stay in lockstep)
-    for (int i = 0; i < static_cast<int>(((blockIdx.x >> 8) ^ (blockIdx.x >> 10) ^ (blockIdx.x >> 3)) & 3u) * SLIDE_DBG_STAGGER; ++i) __builtin_amdgcn_s_sleep(16);
-#endif
 #pragma unroll
     for (int d = 0; d < DEPTH; ++d) {
-#ifdef SLIDE_DBG_NOSTAGE
-        const u4 zz = {0u, 0u, 0u, 0u};
-        for (int k = 0; k < NP; ++k) pv[d][k] = zz;
-#endif
         if (d <= p.seg) issue_loads(d, pv[d]);
     }
     for (int t0 = 0; t0 <= p.seg; t0 += DEPTH) {
@@ -785,13 +758,9 @@ void fill_slide(SlideParams &p, const Geometry &g, const SlidePlan &pl) {
 }
 
 constexpr int kNpBackward = 3, kNpForward = 2;
-#ifndef SLIDE_DEPTH_BWD
-#define SLIDE_DEPTH_BWD 1
-#endif
-#ifndef SLIDE_DEPTH_FWD
-#define SLIDE_DEPTH_FWD 1
-#endif
-constexpr int kDepthBackward = SLIDE_DEPTH_BWD, kDepthForward = SLIDE_DEPTH_FWD;  // steps of staging in flight
+// steps of staging in flight: 2 costs 12 (backward) registers and a wave of occupancy, measured slower (C3 backward
+// 0.337 -> 0.356 ms)
+constexpr int kDepthBackward = 1, kDepthForward = 1;
 
 template <typename T, bool ACTIVE>
 void launch_slide_backward(const SlideParams &p, const SlidePlan &pl, hipStream_t st) {

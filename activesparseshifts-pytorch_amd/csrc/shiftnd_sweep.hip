@@ -179,6 +179,83 @@ __device__ __forceinline__ int combo_offset(int k, int pa, int pb, const int cs[
     }
 }
 
+// =====================================================================================================
+// Active (interpolating) forward in the sweep shape: out = interp of the 2^ND corners around (coord - floor(w))
+// (shifts_kernels.h:187-205).  Same workgroup shape as the gather forward; a thread keeps its chunk column (E + 1
+// mapped source columns) and visits K rows RPS apart, loading the 2^(ND-1) corner rows of each with element-aligned
+// 16-byte loads.  For rows made of whole 16-byte chunks only (4- and 8-byte elements: 16-bit rows go through LDS,
+// shiftnd_plane.hip / shiftnd_slide.hip, where 2-byte-aligned 16-byte global loads are slow).
+// =====================================================================================================
+template <typename T, int ND, int KMAX>
+__global__ __launch_bounds__(kSweepMaxThreads) void sweep_active_forward(const SweepParams p) {
+    using S = typename T::S;
+    using CT = typename T::C;
+    constexpr int E = 16 / sizeof(S);
+    constexpr int NC = 1 << (ND - 1);
+    const uint32_t bid = xcd_remap(p.blocks_per_xcd);
+    if (bid >= p.blocks) return;
+    const uint32_t plane = fdiv(bid, p.d_bpp);
+    const uint32_t blk = bid - plane * p.bpp;
+    const uint32_t band = fdiv(blk, p.d_tiles);
+    const uint32_t tile = blk - band * p.tiles;
+    const int c = static_cast<int>(plane - fdiv(plane, p.d_C) * static_cast<uint32_t>(p.C));
+    int cs[3] = {0, 0, 0};
+    CT dw[3] = {CT(0), CT(0), CT(0)};
+#pragma unroll
+    for (int d = 0; d < 3; ++d)
+        if (p.wcol[d] >= 0) {
+            int64_t iw;
+            prep_shift_forward<CT>(load_weight<CT>(p.w, p.wkind, c * p.nd + p.wcol[d]), true, iw, dw[p.wcol[d]]);
+            cs[d] = canon_shift(iw, p.S[d], p.pad, p.d_per[d]);
+        }
+    const uint32_t tr = fdiv(threadIdx.x, p.d_CW);
+    const uint32_t chunk = tile * p.CW + (threadIdx.x - tr * p.CW);
+    if (chunk >= p.cpr) return;
+    const int jo = static_cast<int>(chunk) * E;
+    int mm[E + 1];
+    bool contig = true;
+#pragma unroll
+    for (int e = 0; e <= E; ++e) {
+        mm[e] = map1(jo + p.L[2] + e, cs[2], p.S[2], p.pad);
+        if (e < E) contig = contig && (mm[e] == mm[0] + e);
+    }
+    contig = contig && (mm[0] >= 0);
+    const S *xp = static_cast<const S *>(p.x) + static_cast<int64_t>(plane) * p.x_plane;
+    S *op = static_cast<S *>(p.out) + static_cast<int64_t>(plane) * p.o_plane + jo;
+    const uint32_t r0 = band * (p.RPS * p.K) + tr;
+    CT vals[KMAX][NC][E + 1];
+    S *dst[KMAX];
+#pragma unroll
+    for (int k = 0; k < KMAX; ++k) {  // every load first
+        dst[k] = nullptr;
+        const uint32_t r = r0 + k * p.RPS;
+        if (k < static_cast<int>(p.K) && r < p.rows) {
+            const int a = static_cast<int>(fdiv(r, p.d_dim1));
+            const int b = static_cast<int>(r) - a * p.O[1];
+            dst[k] = op + static_cast<int64_t>(r) * p.O[2];
+#pragma unroll
+            for (int q = 0; q < NC; ++q) {
+                const int off = combo_offset<ND>(q, a + p.L[0], b + p.L[1], cs, p.S, p.pad);
+                load_row<T, E, E + 1>(xp + (off < 0 ? 0 : off), off >= 0, contig, mm, vals[k][q]);
+            }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < KMAX; ++k) {
+        if (dst[k]) {
+            Chunk<S, E> res;
+#pragma unroll
+            for (int e = 0; e < E; ++e) {
+                CT v[1 << ND];
+#pragma unroll
+                for (int q = 0; q < (1 << ND); ++q) v[q] = vals[k][q & (NC - 1)][e + (q >> (ND - 1))];
+                res.e[e] = narrow<T>(interp_t<T, ND>(v, dw));
+            }
+            store_chunk<S, E>(dst[k], res);
+        }
+    }
+}
+
 // workgroup-wide fp64 sum for up to kSweepMaxThreads threads; result valid in thread 0
 __device__ __forceinline__ double block_sum_n(double v, double *scratch) {
     v = wave_sum(v);
@@ -469,16 +546,49 @@ bool sweep_forward_eligible(const Geometry &g, int dtype, const void *x, const v
     if (g.N * g.C >= (1LL << 31)) return false;
     if (!contiguous(g.xs, g.N, g.C, g.S) || !contiguous(g.os, g.N, g.C, g.O)) return false;
     const bool interpolating = g.active && dtype <= SHIFTND_BF16;
-    if (interpolating) return false;  // active forward: plane kernels (for now)
     const int es = dtype_size(dtype);
+    if (interpolating) {  // sweep_active_forward: 4- / 8-byte elements, rows of whole 16-byte chunks
+        if (es < 4 || (g.O[2] * es) % 16 != 0 || reinterpret_cast<uintptr_t>(out) % 16 != 0) return false;
+        return g.N * g.C * (oe * es / 16) < (1LL << 31) - 16;
+    }
     const int V = gather_vector_bytes(g, es, out);
     const int64_t cpp = oe * es / V;
     return g.N * g.C * cpp < (1LL << 31) - 16;  // 32-bit workgroup ids (also the grid limit): one per chunk at worst
 }
 
+template <typename T> void launch_active_forward(const SweepParams &p, hipStream_t st) {
+    const dim3 grid(p.blocks_per_xcd * 8), block(p.threads);
+#define SHIFTND_SWEEP_ACTIVE(NDV) \
+    if (p.K <= 1) hipLaunchKernelGGL((sweep_active_forward<T, NDV, 1>), grid, block, 0, st, p); \
+    else if (p.K <= 2) hipLaunchKernelGGL((sweep_active_forward<T, NDV, 2>), grid, block, 0, st, p); \
+    else hipLaunchKernelGGL((sweep_active_forward<T, NDV, 4>), grid, block, 0, st, p);
+    switch (p.nd) {
+    case 1: SHIFTND_SWEEP_ACTIVE(1) break;
+    case 2: SHIFTND_SWEEP_ACTIVE(2) break;
+    default: SHIFTND_SWEEP_ACTIVE(3) break;
+    }
+#undef SHIFTND_SWEEP_ACTIVE
+}
+
 int sweep_forward(const Geometry &g, int dtype, const void *x, const void *w, int wkind, int64_t wzp, uint64_t fill_bits,
                   void *out, hipStream_t st) {
     const int es = dtype_size(dtype);
+    if (g.active && dtype <= SHIFTND_BF16) {
+        note_kernel("sweep_active_forward");
+        SweepParams p{};
+        fill_common(p, g);
+        p.x = x;
+        p.out = out;
+        p.w = w;
+        p.wkind = wkind;
+        p.d_dim1 = make_fastdiv(static_cast<uint32_t>(g.O[1]));
+        const int kmax = g.nd == 1 ? 4 : 2;  // rows per thread: 2^(nd-1) corner rows of E + 1 values each stay in registers (2-D: K=2 measured best)
+        plan_shape(p, static_cast<uint32_t>(g.O[2] * es / 16), static_cast<uint32_t>(g.O[0] * g.O[1]), g.N * g.C,
+                   g_sweep_tune[0] < kmax ? g_sweep_tune[0] : kmax, g_sweep_tune[1], kmax);
+        if (dtype == SHIFTND_F32) launch_active_forward<f32_t>(p, st);
+        else launch_active_forward<f64_t>(p, st);
+        return SHIFTND_OK;
+    }
     const int V = gather_vector_bytes(g, es, out);
     note_kernel("sweep_gather_forward");
     SweepParams p{};

@@ -42,6 +42,7 @@ struct BytesParams {
     int use_table;          // non-zero padding: the byte-by-byte source table is built
     unsigned xcd_blocks;
     FastDiv d_npc, d_S2, d_S12, d_C;
+    FastDiv d_per[3];    // divide by the padding period of each dim
 };
 
 __global__ __launch_bounds__(kThreads) void bytes_gather_forward(const BytesParams p) {
@@ -94,9 +95,10 @@ __global__ __launch_bounds__(kThreads) void bytes_gather_forward(const BytesPara
 
     // ---- per-channel tables (while the loads are in flight) ---------------------------------------------------
     int64_t sh[3];
+    gather_shifts3(p.w, p.wkind, p.wzp, static_cast<int64_t>(c) * p.nd, p.wcol, sh);
 #pragma unroll
-    for (int d = 0; d < 3; ++d) sh[d] = p.wcol[d] >= 0 ? gather_shift(p.w, p.wkind, p.wzp, c * p.nd + p.wcol[d]) : 0;
-    build_maps(maps, p.S, sh, -1, p.pad);
+    for (int d = 0; d < 3; ++d) sh[d] = p.wcol[d] >= 0 ? sh[d] : 0;
+    build_maps(maps, p.S, sh, -1, p.pad, p.d_per);
     __syncthreads();
     // one table entry per 16-byte output piece: walk its bytes through the maps (divisions once per piece)
     for (int k = threadIdx.x; k < p.npc; k += kThreads) {
@@ -290,6 +292,7 @@ int bytes_forward(const Geometry &g, const void *x, const void *w, int wkind, in
     p.d_S2 = make_fastdiv(static_cast<uint32_t>(g.S[2]));
     p.d_S12 = make_fastdiv(static_cast<uint32_t>(g.S[1] * g.S[2]));
     p.d_C = make_fastdiv(static_cast<uint32_t>(g.C));
+    for (int d = 0; d < 3; ++d) p.d_per[d] = make_fastdiv(static_cast<uint32_t>(map_period(p.S[d], g.pad)));
     note_kernel("bytes_gather_forward");
     hipLaunchKernelGGL(bytes_gather_forward, dim3(pl.grid), dim3(kThreads), pl.lds, st, p);
     return SHIFTND_OK;

@@ -34,6 +34,9 @@ constexpr int kRing = 2 * kR + 1;     // staged rows
 constexpr int kPitch = kCB + 1;       // words per staged pixel
 constexpr int kPieces = kPW * (kCB / 4);   // 16-byte pieces per staged row (304)
 constexpr int kNP = (kPieces + kThreads - 1) / kThreads;
+#ifndef CLT_DEPTH
+#define CLT_DEPTH 3
+#endif
 
 struct ClTiledParams {
     const uint32_t *x;
@@ -48,10 +51,42 @@ struct ClTiledParams {
     FastDiv d_perH, d_perW;
 };
 
+// integer shifts of NI weights, all loads issued before the first use (gather_shift, one element at a time, pays one
+// memory round trip per weight in every workgroup's prologue)
+template <int NI>
+__device__ __forceinline__ void gather_shifts(const void *w, int wkind, int64_t wzp, const int (&idx)[NI], int64_t (&sh)[NI]) {
+#define SHIFTND_CLT_LOAD(TYPE, EXPR) \
+    { \
+        TYPE raw[NI]; \
+        _Pragma("unroll") for (int i = 0; i < NI; ++i) raw[i] = static_cast<const TYPE *>(w)[idx[i]]; \
+        _Pragma("unroll") for (int i = 0; i < NI; ++i) { const TYPE r = raw[i]; sh[i] = (EXPR); } \
+    } \
+    break;
+    switch (wkind) {
+    case SHIFTND_F32: SHIFTND_CLT_LOAD(float, static_cast<int64_t>(rintf(r)))
+    case SHIFTND_F64: SHIFTND_CLT_LOAD(double, static_cast<int64_t>(rint(r)))
+    case SHIFTND_F16: SHIFTND_CLT_LOAD(_Float16, static_cast<int64_t>(rintf(static_cast<float>(r))))
+    case SHIFTND_BF16: SHIFTND_CLT_LOAD(__bf16, static_cast<int64_t>(rintf(static_cast<float>(r))))
+    case SHIFTND_I8: SHIFTND_CLT_LOAD(int8_t, static_cast<int64_t>(r) - wzp)
+    case SHIFTND_U8: SHIFTND_CLT_LOAD(uint8_t, static_cast<int64_t>(r) - wzp)
+    default: SHIFTND_CLT_LOAD(int32_t, static_cast<int64_t>(r) - wzp)
+    }
+#undef SHIFTND_CLT_LOAD
+}
+
+constexpr uint32_t kOutOfRange = 0x80000000u;   // buffer offset beyond every image (num_records < 2^31): loads give 0, stores are dropped
+constexpr int kBufferFlags = 0x00020000;        // raw buffer, 32-bit data format (gfx9 family resource word 3)
+
+// Every memory instruction of the row loop is unconditional and in straight-line code, so that hipcc counts vmcnt
+// exactly and the loads issued kDepth rows ahead really stay in flight (a load or store under a thread-dependent
+// branch makes it wait for vmcnt(0), i.e. one full memory round trip per row: 0.48 ms instead of 0.33 ms on
+// N16 C256 224x224 fp32).  What must not happen is expressed through buffer addressing instead: lanes without a source
+// piece / an output use an out-of-range offset, which the hardware answers with zero / drops.
 template <bool OUT_CL>
 __global__ __launch_bounds__(kThreads) void cl_tiled_forward(const ClTiledParams p) {
     typedef uint32_t u4 __attribute__((ext_vector_type(4)));
-    __shared__ uint32_t ring[kRing * kPW * kPitch];
+    __shared__ uint32_t ring[kRing * kPW * kPitch + 4];   // + dump words for pieces that do not exist
+    constexpr int kDump = kRing * kPW * kPitch;
 
     // ---- which tile ---------------------------------------------------------------------------------------------
     unsigned b = blockIdx.x;
@@ -65,132 +100,145 @@ __global__ __launch_bounds__(kThreads) void cl_tiled_forward(const ClTiledParams
     const int h0 = band * p.band_rows, h1 = min(p.H, h0 + p.band_rows);
     const int H = p.H, W = p.W, C = p.C;
     const uint32_t *xn = p.x + static_cast<int64_t>(n) * H * W * C;
+    uint32_t *on = p.out + static_cast<int64_t>(n) * H * W * C;
+    const uint32_t img_bytes = static_cast<uint32_t>(H) * static_cast<uint32_t>(W) * static_cast<uint32_t>(C) * 4u;  // < 2^31 (host)
+    const __amdgpu_buffer_rsrc_t xres = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t *>(xn), 0, img_bytes, kBufferFlags);
+    const __amdgpu_buffer_rsrc_t xnone = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t *>(xn), 0, 0, kBufferFlags);
+    const __amdgpu_buffer_rsrc_t ores = __builtin_amdgcn_make_buffer_rsrc(on, 0, img_bytes, kBufferFlags);
 
     // ---- thread -> outputs ----------------------------------------------------------------------------------------
     // OUT_CL: thread = (pixel lane 0..7, channel 0..31): pixels pl + 8 i;  else thread = (column 0..31, channel lane
     // 0..7): channels cl + 8 i.  Either way 4 outputs per step, and per (thread, i) a fixed channel.
     const int lane_a = static_cast<int>(threadIdx.x) & 31, lane_b = static_cast<int>(threadIdx.x) >> 5;
-    int ch[4], col[4];      // channel (within the block) and output column (within the tile) of output i
+    constexpr int NCH = OUT_CL ? 1 : 4;   // distinct channels of a thread
+    int64_t shifts[2 * NCH];
+    {
+        int widx[2 * NCH];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        ch[i] = OUT_CL ? lane_a : lane_b + 8 * i;
-        col[i] = OUT_CL ? lane_b + 8 * i : lane_a;
-    }
-    // per output: canonical shifts, the source column (constant over the rows), path
-    int csh[4], xoff[4];    // row shift; LDS word offset of the source pixel within a staged row, or -1 (fill), or -2 (far)
-    int gcol[4];            // far path: source column in the image (or -1)
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int c = c0 + ch[i];
-        csh[i] = 0;
-        xoff[i] = -1;
-        gcol[i] = -1;
-        if (c < C && w0 + col[i] < W) {
-            const int sh = canon_shift(gather_shift(p.w, p.wkind, p.wzp, static_cast<int64_t>(c) * 2 + 0), H, p.pad, p.d_perH);
-            const int sw = canon_shift(gather_shift(p.w, p.wkind, p.wzp, static_cast<int64_t>(c) * 2 + 1), W, p.pad, p.d_perW);
-            csh[i] = sh;
-            const int sx = W == 1 ? 0 : fold_index(w0 + col[i] - sw, W, p.pad);  // size-1 dims ignore the shift
-            gcol[i] = sx;
-            // canon_shift returns the non-negative representative for the reflecting paddings: look at the signed one
-            const int perH = map_period(H, p.pad), perW = map_period(W, p.pad);
-            const int sh_s = (perH && 2 * sh > perH) ? sh - perH : sh, sw_s = (perW && 2 * sw > perW) ? sw - perW : sw;
-            const bool near = sh_s >= -kR && sh_s <= kR && sw_s >= -kR && sw_s <= kR;
-            if (sx >= 0) xoff[i] = near ? (sx - (w0 - kR)) * kPitch + ch[i] : -2;
+        for (int j = 0; j < NCH; ++j) {
+            const int c = min(c0 + (OUT_CL ? lane_a : lane_b + 8 * j), C - 1);
+            widx[2 * j] = 2 * c;
+            widx[2 * j + 1] = 2 * c + 1;
         }
+        gather_shifts<2 * NCH>(p.w, p.wkind, p.wzp, widx, shifts);
     }
+    const int perH = map_period(H, p.pad), perW = map_period(W, p.pad);
+    int csh[4], xoff[4];       // canonical row shift; LDS word offset of the source pixel within a staged row
+    uint32_t ooff[4];          // byte offset of the output in row h0 of the image, or out of range (nothing to store)
+    bool near[4], far[4];      // served from the ring / gathered from memory after the row loop
+    int gcol[4];               // far: source column
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int ch = OUT_CL ? lane_a : lane_b + 8 * i, col = OUT_CL ? lane_b + 8 * i : lane_a;
+        const int c = c0 + ch;
+        const bool live = c < C && w0 + col < W;
+        const int sh = canon_shift(shifts[OUT_CL ? 0 : 2 * i], H, p.pad, p.d_perH);
+        const int sw = canon_shift(shifts[OUT_CL ? 1 : 2 * i + 1], W, p.pad, p.d_perW);
+        csh[i] = sh;
+        const int sx = W == 1 ? 0 : fold_index(w0 + min(col, W - 1 - w0) - sw, W, p.pad);  // size-1 dims ignore the shift
+        gcol[i] = sx;
+        // canon_shift returns the non-negative representative for the reflecting paddings: look at the signed one
+        const int sh_s = (perH && 2 * sh > perH) ? sh - perH : sh, sw_s = (perW && 2 * sw > perW) ? sw - perW : sw;
+        const bool in_ring = sh_s >= -kR && sh_s <= kR && sw_s >= -kR && sw_s <= kR;
+        near[i] = live && sx >= 0 && in_ring;
+        far[i] = live && sx >= 0 && !in_ring;
+        xoff[i] = near[i] ? (sx - (w0 - kR)) * kPitch + ch : 0;
+        const uint32_t o = OUT_CL ? (static_cast<uint32_t>(h0 * W + w0 + col) * C + c) * 4u
+                                  : (static_cast<uint32_t>(c * H + h0) * W + w0 + col) * 4u;
+        ooff[i] = (live && !far[i]) ? o : kOutOfRange;   // (a column in the zero padding stores the fill value)
+    }
+    const uint32_t ostep = static_cast<uint32_t>(OUT_CL ? W * C : W) * 4u;
 
     // ---- staging: 16-byte pieces of source row y: pixel w0 - R + px, channels c0 + 4 q .. ---------------------------
-    int ppx[kNP], pq[kNP];
+    uint32_t poff[kNP];    // byte offset of the piece in row 0 of the image, or out of range
+    int pdst[kNP];         // LDS word offset within a ring row, or the dump words
 #pragma unroll
     for (int k = 0; k < kNP; ++k) {
         const int q = k * kThreads + static_cast<int>(threadIdx.x);
-        ppx[k] = q < kPieces ? q >> 3 : -1;
-        pq[k] = q & 7;
-        const int gx = w0 - kR + ppx[k];
-        if (ppx[k] >= 0 && (gx < 0 || gx >= W || c0 + pq[k] * 4 >= C)) ppx[k] = -1;  // outside the image: never read
+        const int px = q >> 3, cc = c0 + (q & 7) * 4, gx = w0 - kR + px;
+        const bool piece = q < kPieces;
+        poff[k] = (piece && gx >= 0 && gx < W && cc < C) ? (static_cast<uint32_t>(gx) * C + cc) * 4u : kOutOfRange;
+        pdst[k] = piece ? px * kPitch + (q & 7) * 4 : -1;
     }
-    constexpr int kDepth = 3;  // rows of staging in flight (a workgroup moves only ~5 KB per row)
+    const uint32_t row_bytes = static_cast<uint32_t>(W) * C * 4u;
+    constexpr int kDepth = CLT_DEPTH;  // rows of staging in flight (a workgroup moves only ~5 KB per row)
     u4 pvs[kDepth][kNP];
-    auto load_row = [&](int y, u4 (&pv)[kNP]) {  // unconditional loads (clamped addresses): see shiftnd_slide.hip
-        const int yy = y < 0 ? 0 : (y >= H ? H - 1 : y);
+    auto load_row = [&](int y, int ylast, u4 (&pv)[kNP]) {  // rows outside the image or beyond the band: nothing is read
+        const bool wanted = y >= 0 && y <= ylast;
+        const __amdgpu_buffer_rsrc_t r = wanted ? xres : xnone;
+        const uint32_t so = wanted ? static_cast<uint32_t>(y) * row_bytes : 0u;
 #pragma unroll
-        for (int k = 0; k < kNP; ++k) {
-            const int gx = ppx[k] >= 0 ? w0 - kR + ppx[k] : w0 < W ? w0 : 0;
-            const int cc = ppx[k] >= 0 ? c0 + pq[k] * 4 : 0;
-            const uint32_t *src = xn + (static_cast<int64_t>(yy) * W + gx) * C + cc;
-            // (C need not be a multiple of 4 in general; the host only routes C % 4 == 0 here)
-            pv[k] = *reinterpret_cast<const u4 *>(__builtin_assume_aligned(src, 16));
-        }
+        for (int k = 0; k < kNP; ++k) pv[k] = __builtin_amdgcn_raw_buffer_load_b128(r, poff[k], so, 0);
     };
     auto store_row = [&](int y, const u4 (&pv)[kNP]) {
         const int slot = (y % kRing + kRing) % kRing;
 #pragma unroll
         for (int k = 0; k < kNP; ++k) {
-            if (ppx[k] >= 0) {
-                uint32_t *d = ring + (slot * kPW + ppx[k]) * kPitch + pq[k] * 4;
-                d[0] = pv[k].x;
-                d[1] = pv[k].y;
-                d[2] = pv[k].z;
-                d[3] = pv[k].w;
-            }
+            uint32_t *d = ring + (pdst[k] >= 0 ? slot * (kPW * kPitch) + pdst[k] : kDump);
+            d[0] = pv[k].x;
+            d[1] = pv[k].y;
+            d[2] = pv[k].z;
+            d[3] = pv[k].w;
         }
     };
+    const int ylast = min(H - 1, h1 - 1 + kR);
 
-    // rows h0 - R .. h0 + R - 1 first (all loads, then all stores), then one row per step
+    // rows h0 - R .. h0 + R - 1 first (all loads, then all stores), then one row per step.  The kDepth rows for the
+    // first steps are requested BEFORE them: when the ring rows have arrived nothing is pending any more, so the
+    // loop's wait counts are those of its own back edge (kDepth rows of loads and stores in flight), not the shorter
+    // distance of this prologue.
     {
         u4 pre[2 * kR][kNP];
 #pragma unroll
-        for (int r = 0; r < 2 * kR; ++r) load_row(h0 - kR + r, pre[r]);
+        for (int d = 0; d < kDepth; ++d) load_row(h0 + kR + d, ylast, pvs[d]);
+#pragma unroll
+        for (int r = 0; r < 2 * kR; ++r) load_row(h0 - kR + r, ylast, pre[r]);
 #pragma unroll
         for (int r = 0; r < 2 * kR; ++r) {
             const int y = h0 - kR + r;
             if (y >= 0 && y < H) store_row(y, pre[r]);
         }
     }
-#pragma unroll
-    for (int d = 0; d < kDepth; ++d) load_row(h0 + kR + d, pvs[d]);
-    // per output: running ring slot of the interior source row h - s (s = signed shift), running output pointer
-    int srow[4], slot[4];
-    uint32_t *optr[4];
-    bool live[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int perH = map_period(H, p.pad);
-        srow[i] = (perH && 2 * csh[i] > perH) ? csh[i] - perH : csh[i];
-        slot[i] = ((h0 - srow[i]) % kRing + kRing) % kRing;
-        live[i] = w0 + col[i] < W && c0 + ch[i] < C;
-        optr[i] = OUT_CL ? p.out + ((static_cast<int64_t>(n) * H + h0) * W + w0 + col[i]) * C + c0 + ch[i]
-                         : p.out + ((static_cast<int64_t>(n) * C + c0 + ch[i]) * H + h0) * W + w0 + col[i];
-    }
-    const int ostep = OUT_CL ? W * C : W;
     auto step = [&](int h, u4 (&pv)[kNP]) {
         __syncthreads();  // everybody is done with the slot that row h + R replaces (row h - R - 1)
         if (h + kR < H) store_row(h + kR, pv);
         __syncthreads();
-        if (h + kDepth < h1) load_row(h + kDepth + kR, pv);  // in flight while this and the next rows are produced
+        load_row(h + kDepth + kR, ylast, pv);  // in flight while this and the next rows are produced
+        const uint32_t so = static_cast<uint32_t>(h - h0) * ostep;
+        uint32_t v[4];
+        bool ok[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            uint32_t v = p.fill;
-            int sy = h - srow[i], sl = slot[i];
-            if (static_cast<unsigned>(sy) >= static_cast<unsigned>(H)) {  // outside the image: through the padding map
-                sy = H == 1 ? 0 : fold_index(h - csh[i], H, p.pad);
-                sl = sy % kRing;
-            }
-            if (H == 1) {
-                sy = 0;
-                sl = 0;
-            }
-            if (sy >= 0 && xoff[i] >= 0) v = ring[sl * (kPW * kPitch) + xoff[i]];
-            else if (sy >= 0 && xoff[i] == -2) v = xn[(static_cast<int64_t>(sy) * W + gcol[i]) * C + c0 + ch[i]];
-            if (live[i]) *optr[i] = v;
-            optr[i] += ostep;
-            slot[i] = slot[i] + 1 == kRing ? 0 : slot[i] + 1;
+            const int sy = H == 1 ? 0 : fold_index(h - csh[i], H, p.pad);   // -1: zero padding
+            ok[i] = near[i] && sy >= 0;
+            const uint32_t r = static_cast<uint32_t>(sy < 0 ? 0 : sy);
+            const uint32_t sl = r - __umulhi(r, 613566757u) * kRing;       // r % 7 (r < 2^20)
+            v[i] = ring[sl * (kPW * kPitch) + xoff[i]];
         }
-    };
-    for (int hb = h0; hb < h1; hb += kDepth) {
 #pragma unroll
-        for (int d = 0; d < kDepth; ++d)
-            if (hb + d < h1) step(hb + d, pvs[d]);
+        for (int i = 0; i < 4; ++i) __builtin_amdgcn_raw_buffer_store_b32(ok[i] ? v[i] : p.fill, ores, ooff[i], so, 0);
+    };
+    int hb = h0;
+    for (; hb + kDepth <= h1; hb += kDepth) {   // whole groups: no condition between the steps (exact wait counts)
+#pragma unroll
+        for (int d = 0; d < kDepth; ++d) step(hb + d, pvs[d]);
+    }
+#pragma unroll
+    for (int d = 0; d < kDepth - 1; ++d)
+        if (hb + d < h1) step(hb + d, pvs[d]);
+
+    // ---- shifts beyond the ring: gathered from memory, element by element (rare) -------------------------------------
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        if (!far[i]) continue;
+        const int ch = OUT_CL ? lane_a : lane_b + 8 * i, col = OUT_CL ? lane_b + 8 * i : lane_a;
+        uint32_t *o = OUT_CL ? on + (static_cast<int64_t>(h0) * W + w0 + col) * C + c0 + ch
+                             : on + (static_cast<int64_t>(c0 + ch) * H + h0) * W + w0 + col;
+        for (int h = h0; h < h1; ++h) {
+            const int sy = H == 1 ? 0 : fold_index(h - csh[i], H, p.pad);
+            *o = sy >= 0 ? xn[(static_cast<int64_t>(sy) * W + gcol[i]) * C + c0 + ch] : p.fill;
+            o += OUT_CL ? W * C : W;
+        }
     }
 }
 
@@ -219,6 +267,7 @@ bool cl_tiled_forward_eligible(const Geometry &g, int dtype, const void *x, cons
         if (g.L[d] != 0 || g.O[d] != g.S[d]) return false;
     if (g.C < 4 || g.C % 4 != 0 || g.S[1] >= (1 << 20) || g.S[2] >= (1 << 20) || g.N >= (1LL << 24) || g.C >= (1 << 24)) return false;
     if (reinterpret_cast<uintptr_t>(x) % 16 != 0 || reinterpret_cast<uintptr_t>(out) % 4 != 0) return false;
+    if (g.C * g.S[1] * g.S[2] * 4 >= (1LL << 31)) return false;  // one image per buffer resource, offsets below 2^31
     if (!dense_channels_last_2d(g.xs, g, g.S)) return false;
     return dense_channels_last_2d(g.os, g, g.O) || contiguous_2d(g.os, g, g.O);
 }
@@ -240,9 +289,10 @@ int cl_tiled_forward(const Geometry &g, const void *x, const void *w, int wkind,
     p.out_cl = dense_channels_last_2d(g.os, g, g.O) ? 1 : 0;
     p.wtiles = (p.W + kTW - 1) / kTW;
     p.cblocks = (p.C + kCB - 1) / kCB;
-    // bands along H: enough workgroups (>= ~4096), at least 8 R rows per band (the ring warm-up is 2 R rows)
+    // bands along H: enough workgroups (~7 per workgroup slot of the chip: 28-row bands measured best on N16 C256
+    // 224x224), at least 8 R rows per band (the ring warm-up is 2 R rows)
     const int64_t base = static_cast<int64_t>(p.N) * p.wtiles * p.cblocks;
-    int64_t bands = g_cl_tiled_tune[1] > 0 ? (p.H + g_cl_tiled_tune[1] - 1) / g_cl_tiled_tune[1] : (4096 + base - 1) / base;
+    int64_t bands = g_cl_tiled_tune[1] > 0 ? (p.H + g_cl_tiled_tune[1] - 1) / g_cl_tiled_tune[1] : (7168 + base - 1) / base;
     const int64_t max_bands = p.H / (8 * kR) > 0 ? p.H / (8 * kR) : 1;
     if (g_cl_tiled_tune[1] <= 0 && bands > max_bands) bands = max_bands;
     if (bands < 1) bands = 1;

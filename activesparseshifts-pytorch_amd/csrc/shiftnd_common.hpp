@@ -145,13 +145,24 @@ __host__ __device__ __forceinline__ int fold_index(int idx, int len, int pad) {
 // map_d[p] = pad_index(p + sign*shift_d) for p in [0, size_d] (size_d + 1 entries: the interpolating
 // kernels also read coordinate p + 1), the three normalised dims back to back.
 // ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ void build_maps(int *maps, const int size[3], const int64_t sh[3], int sign, int pad) {
-    const int n0 = size[0] + 1, n1 = size[1] + 1, n2 = size[2] + 1;
+// Entry p of dim d = pad_index(p + sign * sh[d]) = fold_index(p - canon_shift(-sign * sh[d])) (the identity above):
+// 32-bit selects per entry instead of pad_index's 64-bit divisions, and nothing is indexed dynamically (a dynamic index
+// into the kernel-argument arrays is a vector load from memory per entry).  `dper[d]` divides by
+// map_period(size[d], pad).  The prologue of every per-channel workgroup runs this: it is on the critical path of
+// workgroups that live for a few tens of microseconds.
+__device__ __forceinline__ void build_maps(int *maps, const int size[3], const int64_t sh[3], int sign, int pad,
+                                           const FastDiv dper[3]) {
+    const int l0 = size[0], l1 = size[1], l2 = size[2];
+    const int c0 = canon_shift(sign < 0 ? sh[0] : -sh[0], l0, pad, dper[0]);
+    const int c1 = canon_shift(sign < 0 ? sh[1] : -sh[1], l1, pad, dper[1]);
+    const int c2 = canon_shift(sign < 0 ? sh[2] : -sh[2], l2, pad, dper[2]);
+    const int n0 = l0 + 1, n1 = l1 + 1, n2 = l2 + 1;
     for (int t = threadIdx.x; t < n0 + n1 + n2; t += kThreads) {
         const int d = t < n0 ? 0 : (t < n0 + n1 ? 1 : 2);
         const int p = t - (d == 0 ? 0 : (d == 1 ? n0 : n0 + n1));
-        const int64_t len = size[d];
-        maps[t] = (len == 1) ? 0 : static_cast<int>(pad_index(static_cast<int64_t>(p) + sign * sh[d], len, pad));
+        const int len = d == 0 ? l0 : (d == 1 ? l1 : l2);
+        const int cs = d == 0 ? c0 : (d == 1 ? c1 : c2);
+        maps[t] = (len == 1) ? 0 : fold_index(p - cs, len, pad);
     }
 }
 
@@ -389,6 +400,28 @@ template <typename CT> __device__ __forceinline__ CT load_weight(const void *w, 
     }
 }
 
+// The (up to) three weights of a channel, every load issued before the first conversion: load_weight() per dim pays one
+// memory round trip per dim in the workgroup prologue.  Dims without a weight column read column 0 (never used).
+template <typename CT> __device__ __forceinline__ void load_weights3(const void *w, int wkind, int64_t base, const int wcol[3], CT out[3]) {
+    const int64_t i0 = base + (wcol[0] > 0 ? wcol[0] : 0), i1 = base + (wcol[1] > 0 ? wcol[1] : 0), i2 = base + (wcol[2] > 0 ? wcol[2] : 0);
+#define SHIFTND_LOAD3(TYPE) \
+    { \
+        const TYPE *q = static_cast<const TYPE *>(w); \
+        const TYPE r0 = q[i0], r1 = q[i1], r2 = q[i2]; \
+        out[0] = static_cast<CT>(r0); \
+        out[1] = static_cast<CT>(r1); \
+        out[2] = static_cast<CT>(r2); \
+    } \
+    break;
+    switch (wkind) {
+    case SHIFTND_F64: SHIFTND_LOAD3(double)
+    case SHIFTND_F16: SHIFTND_LOAD3(_Float16)
+    case SHIFTND_BF16: SHIFTND_LOAD3(__bf16)
+    default: SHIFTND_LOAD3(float)
+    }
+#undef SHIFTND_LOAD3
+}
+
 // integer shift of the gather-only kernels: round-half-even of a float weight (SSL), or a quantized weight's
 // int_repr minus its zero point (kernels/shifts_kernels.h:553-555)
 __device__ __forceinline__ int64_t gather_shift(const void *w, int wkind, int64_t wzp, int64_t i) {
@@ -401,6 +434,30 @@ __device__ __forceinline__ int64_t gather_shift(const void *w, int wkind, int64_
     case SHIFTND_U8: return static_cast<int64_t>(static_cast<const uint8_t *>(w)[i]) - wzp;
     default: return static_cast<int64_t>(static_cast<const int32_t *>(w)[i]) - wzp;
     }
+}
+
+// gather_shift for the (up to) three dims of a channel with the loads issued together (see load_weights3)
+__device__ __forceinline__ void gather_shifts3(const void *w, int wkind, int64_t wzp, int64_t base, const int wcol[3], int64_t out[3]) {
+    const int64_t i0 = base + (wcol[0] > 0 ? wcol[0] : 0), i1 = base + (wcol[1] > 0 ? wcol[1] : 0), i2 = base + (wcol[2] > 0 ? wcol[2] : 0);
+#define SHIFTND_GATHER3(TYPE, EXPR) \
+    { \
+        const TYPE *q = static_cast<const TYPE *>(w); \
+        const TYPE r0 = q[i0], r1 = q[i1], r2 = q[i2]; \
+        { const TYPE r = r0; out[0] = (EXPR); } \
+        { const TYPE r = r1; out[1] = (EXPR); } \
+        { const TYPE r = r2; out[2] = (EXPR); } \
+    } \
+    break;
+    switch (wkind) {
+    case SHIFTND_F32: SHIFTND_GATHER3(float, static_cast<int64_t>(rintf(r)))
+    case SHIFTND_F64: SHIFTND_GATHER3(double, static_cast<int64_t>(rint(r)))
+    case SHIFTND_F16: SHIFTND_GATHER3(_Float16, static_cast<int64_t>(rintf(static_cast<float>(r))))
+    case SHIFTND_BF16: SHIFTND_GATHER3(__bf16, static_cast<int64_t>(rintf(static_cast<float>(r))))
+    case SHIFTND_I8: SHIFTND_GATHER3(int8_t, static_cast<int64_t>(r) - wzp)
+    case SHIFTND_U8: SHIFTND_GATHER3(uint8_t, static_cast<int64_t>(r) - wzp)
+    default: SHIFTND_GATHER3(int32_t, static_cast<int64_t>(r) - wzp)
+    }
+#undef SHIFTND_GATHER3
 }
 
 // ---------------------------------------------------------------------------------------------

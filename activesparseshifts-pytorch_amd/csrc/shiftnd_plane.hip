@@ -52,6 +52,9 @@ struct PlaneParams {
     FastDiv d_cpr;
     FastDiv d_rows;     // divide by rows_per_band
     FastDiv d_dim1;     // divide by the second outer dim of the iteration space
+    FastDiv d_per[3];   // divide by the padding period of each dim of x (sizes S)
+    FastDiv d_perO[3];  // ... of out / grad_out (sizes O)
+    FastDiv d_C, d_groups;
     // fused average pool (kernel = stride = K, ceil mode; modules/shifts.py:81-89): pooled sizes P = ceil(O / K)
     int K[3], P[3];
     FastDiv d_k[3];
@@ -65,10 +68,10 @@ __device__ __forceinline__ WorkItem decode_block(const PlaneParams &p) {
     WorkItem wi;
     // XCD-contiguous ids (tuning knob 6): workgroups that share an XCD (blockIdx % 8) own adjacent planes
     const int bid = p.xcd_blocks ? static_cast<int>((blockIdx.x & 7u) * p.xcd_blocks + (blockIdx.x >> 3)) : static_cast<int>(blockIdx.x);
-    wi.c = bid % p.C;
-    const int rest = bid / p.C;
-    const int grp = rest % p.groups;
-    const int band = rest / p.groups;
+    const int rest = static_cast<int>(fdiv(static_cast<uint32_t>(bid), p.d_C));
+    wi.c = bid - rest * p.C;
+    const int band = static_cast<int>(fdiv(static_cast<uint32_t>(rest), p.d_groups));
+    const int grp = rest - band * p.groups;
     wi.n0 = grp * p.ppw;
     wi.nn = min(p.ppw, p.N - wi.n0);
     wi.row0 = band * p.rows_per_band;
@@ -89,9 +92,10 @@ __global__ __launch_bounds__(kThreads) void plane_gather_forward(const PlanePara
 
     const WorkItem wi = decode_block(p);
     int64_t sh[3];
+    gather_shifts3(p.w, p.wkind, p.wzp, static_cast<int64_t>(wi.c) * p.nd, p.wcol, sh);
 #pragma unroll
-    for (int d = 0; d < 3; ++d) sh[d] = p.wcol[d] >= 0 ? gather_shift(p.w, p.wkind, p.wzp, wi.c * p.nd + p.wcol[d]) : 0;
-    build_maps(maps, p.S, sh, -1, p.pad);
+    for (int d = 0; d < 3; ++d) sh[d] = p.wcol[d] >= 0 ? sh[d] : 0;
+    build_maps(maps, p.S, sh, -1, p.pad, p.d_per);
     __syncthreads();
 
     const R *__restrict__ x = static_cast<const R *>(p.x);
@@ -207,11 +211,13 @@ __global__ __launch_bounds__(kThreads) void plane_active_forward(const PlanePara
     const WorkItem wi = decode_block(p);
     int64_t sh[3] = {0, 0, 0};
     CT dw[3] = {CT(0), CT(0), CT(0)};
+    CT wv[3];
+    load_weights3<CT>(p.w, p.wkind, static_cast<int64_t>(wi.c) * p.nd, p.wcol, wv);
 #pragma unroll
     for (int d = 0; d < 3; ++d)
         if (p.wcol[d] >= 0)
-            prep_shift_forward<CT>(load_weight<CT>(p.w, p.wkind, wi.c * p.nd + p.wcol[d]), true, sh[d], dw[p.wcol[d]]);
-    build_maps(maps, p.S, sh, -1, p.pad);
+            prep_shift_forward<CT>(wv[d], true, sh[d], dw[p.wcol[d]]);
+    build_maps(maps, p.S, sh, -1, p.pad, p.d_per);
     __syncthreads();
 
     const S *__restrict__ x = static_cast<const S *>(p.x);
@@ -299,11 +305,13 @@ __global__ __launch_bounds__(kThreads) void plane_pool_forward(const PlaneParams
     const WorkItem wi = decode_block(p);  // rows = pooled rows P0 * P1
     int64_t sh[3] = {0, 0, 0};
     CT dw[3] = {CT(0), CT(0), CT(0)};
+    CT wv[3];
+    load_weights3<CT>(p.w, p.wkind, static_cast<int64_t>(wi.c) * p.nd, p.wcol, wv);
 #pragma unroll
     for (int d = 0; d < 3; ++d)
         if (p.wcol[d] >= 0)
-            prep_shift_forward<CT>(load_weight<CT>(p.w, p.wkind, wi.c * p.nd + p.wcol[d]), ACTIVE, sh[d], dw[p.wcol[d]]);
-    build_maps(maps, p.S, sh, -1, p.pad);
+            prep_shift_forward<CT>(wv[d], ACTIVE, sh[d], dw[p.wcol[d]]);
+    build_maps(maps, p.S, sh, -1, p.pad, p.d_per);
     __syncthreads();
 
     const S *__restrict__ x = static_cast<const S *>(p.x);
@@ -457,13 +465,15 @@ __global__ __launch_bounds__(kThreads) void plane_backward(const PlaneParams p) 
     const WorkItem wi = decode_block(p);
     int64_t sh[3] = {0, 0, 0};
     CT dw[3] = {CT(0), CT(0), CT(0)};
+    CT wv[3];
+    load_weights3<CT>(p.w, p.wkind, static_cast<int64_t>(wi.c) * p.nd, p.wcol, wv);
 #pragma unroll
     for (int d = 0; d < 3; ++d)
         if (p.wcol[d] >= 0)
-            prep_shift_backward<CT>(load_weight<CT>(p.w, p.wkind, wi.c * p.nd + p.wcol[d]), ACTIVE, sh[d], dw[p.wcol[d]]);
-    build_maps(maps, p.S, sh, -1, p.pad);
+            prep_shift_backward<CT>(wv[d], ACTIVE, sh[d], dw[p.wcol[d]]);
+    build_maps(maps, p.S, sh, -1, p.pad, p.d_per);
     // grad_x source: SSL reads grad_out at o + shift, active at o - shift (shifts_kernels.h:287-293)
-    build_maps(gmaps, p.O, sh, ACTIVE ? -1 : +1, p.pad);
+    build_maps(gmaps, p.O, sh, ACTIVE ? -1 : +1, p.pad, p.d_perO);
     __syncthreads();
 
     const S *__restrict__ x = static_cast<const S *>(p.x);
@@ -1006,12 +1016,14 @@ __global__ __launch_bounds__(kThreads) void plane_backward_lds(const PlaneParams
     const WorkItem wi = decode_block(p);
     int64_t sh[3] = {0, 0, 0};
     CT dw[3] = {CT(0), CT(0), CT(0)};
+    CT wv[3];
+    load_weights3<CT>(p.w, p.wkind, static_cast<int64_t>(wi.c) * p.nd, p.wcol, wv);
 #pragma unroll
     for (int d = 0; d < 3; ++d)
         if (p.wcol[d] >= 0)
-            prep_shift_backward<CT>(load_weight<CT>(p.w, p.wkind, wi.c * p.nd + p.wcol[d]), ACTIVE, sh[d], dw[p.wcol[d]]);
-    build_maps(maps, p.S, sh, -1, p.pad);
-    build_maps(gmaps, p.O, sh, ACTIVE ? -1 : +1, p.pad);
+            prep_shift_backward<CT>(wv[d], ACTIVE, sh[d], dw[p.wcol[d]]);
+    build_maps(maps, p.S, sh, -1, p.pad, p.d_per);
+    build_maps(gmaps, p.O, sh, ACTIVE ? -1 : +1, p.pad, p.d_perO);
     __syncthreads();
 
     const int S1 = p.S[1], S2 = p.S[2];
@@ -1210,9 +1222,10 @@ __global__ __launch_bounds__(kThreads) void plane_gather_forward_lds(const Plane
 
     const WorkItem wi = decode_block(p);
     int64_t sh[3];
+    gather_shifts3(p.w, p.wkind, p.wzp, static_cast<int64_t>(wi.c) * p.nd, p.wcol, sh);
 #pragma unroll
-    for (int d = 0; d < 3; ++d) sh[d] = p.wcol[d] >= 0 ? gather_shift(p.w, p.wkind, p.wzp, wi.c * p.nd + p.wcol[d]) : 0;
-    build_maps(maps, p.S, sh, -1, p.pad);
+    for (int d = 0; d < 3; ++d) sh[d] = p.wcol[d] >= 0 ? sh[d] : 0;
+    build_maps(maps, p.S, sh, -1, p.pad, p.d_per);
     __syncthreads();
 
     const int O1 = p.O[1], O2 = p.O[2], S1 = p.S[1], S2 = p.S[2];
@@ -1336,11 +1349,13 @@ __global__ __launch_bounds__(kThreads) void plane_active_forward_lds(const Plane
     const WorkItem wi = decode_block(p);
     int64_t sh[3] = {0, 0, 0};
     CT dw[3] = {CT(0), CT(0), CT(0)};
+    CT wv[3];
+    load_weights3<CT>(p.w, p.wkind, static_cast<int64_t>(wi.c) * p.nd, p.wcol, wv);
 #pragma unroll
     for (int d = 0; d < 3; ++d)
         if (p.wcol[d] >= 0)
-            prep_shift_forward<CT>(load_weight<CT>(p.w, p.wkind, wi.c * p.nd + p.wcol[d]), true, sh[d], dw[p.wcol[d]]);
-    build_maps(maps, p.S, sh, -1, p.pad);
+            prep_shift_forward<CT>(wv[d], true, sh[d], dw[p.wcol[d]]);
+    build_maps(maps, p.S, sh, -1, p.pad, p.d_per);
     __syncthreads();
 
     const int S1 = p.S[1], S2 = p.S[2];
@@ -1512,6 +1527,12 @@ void fill_params(PlaneParams &p, const Geometry &g, const Plan &pl, int64_t dim1
     p.xcd_blocks = (g_tune[6] && pl.grid % 8 == 0) ? pl.grid / 8 : 0;
     p.d_cpr = make_fastdiv(static_cast<uint32_t>(pl.cpr));
     p.d_dim1 = make_fastdiv(static_cast<uint32_t>(dim1));
+    p.d_C = make_fastdiv(static_cast<uint32_t>(p.C));
+    p.d_groups = make_fastdiv(static_cast<uint32_t>(pl.groups));
+    for (int d = 0; d < 3; ++d) {
+        p.d_per[d] = make_fastdiv(static_cast<uint32_t>(map_period(p.S[d], g.pad)));
+        p.d_perO[d] = make_fastdiv(static_cast<uint32_t>(map_period(p.O[d], g.pad)));
+    }
     for (int d = 0; d < 3; ++d) {
         p.K[d] = g.K[d] > 0 ? static_cast<int>(g.K[d]) : 1;
         p.P[d] = g.K[d] > 0 ? static_cast<int>(g.P[d]) : p.O[d];

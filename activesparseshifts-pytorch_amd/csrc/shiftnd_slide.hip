@@ -57,7 +57,8 @@ struct SlideParams {
     int zslot;           // byte offset, in a tile, of a slot that is never written (all zeros): stands in for fill rows
     int npieces;         // 16-byte pieces staged per step
     unsigned xcd_blocks;
-    FastDiv d_cpr, d_bands, d_inner, d_C, d_per;
+    FastDiv d_cpr, d_bands, d_inner, d_C;
+    FastDiv d_per[3];    // divide by the padding period of each dim
 };
 
 template <typename T> struct ElemTraits {
@@ -289,17 +290,18 @@ __global__ __launch_bounds__(kThreads) void slide_kernel(const SlideParams p) {
     // ---- per-channel shift, maps, zeroed tiles ------------------------------------------------------------------
     int64_t sh[3] = {0, 0, 0};
     CT dw[3] = {CT(0), CT(0), CT(0)};
+    CT wv[3];
+    load_weights3<CT>(p.w, p.wkind, static_cast<int64_t>(c) * p.nd, p.wcol, wv);
 #pragma unroll
     for (int d = 0; d < 3; ++d) {
         if (p.wcol[d] >= 0) {
-            const CT wv = load_weight<CT>(p.w, p.wkind, c * p.nd + p.wcol[d]);
-            if constexpr (BACKWARD) prep_shift_backward<CT>(wv, ACTIVE, sh[d], dw[p.wcol[d]]);
-            else prep_shift_forward<CT>(wv, true, sh[d], dw[p.wcol[d]]);
+            if constexpr (BACKWARD) prep_shift_backward<CT>(wv[d], ACTIVE, sh[d], dw[p.wcol[d]]);
+            else prep_shift_forward<CT>(wv[d], true, sh[d], dw[p.wcol[d]]);
         }
     }
-    build_maps(maps, p.S, sh, -1, p.pad);
+    build_maps(maps, p.S, sh, -1, p.pad, p.d_per);
     // grad_x source: the sparse shift reads grad_out at o + shift, the active one at o - shift (shifts_kernels.h:287-293)
-    if constexpr (BACKWARD) build_maps(gmaps, p.S, sh, ACTIVE ? -1 : +1, p.pad);
+    if constexpr (BACKWARD) build_maps(gmaps, p.S, sh, ACTIVE ? -1 : +1, p.pad, p.d_per);
     {
         u4 *z = reinterpret_cast<u4 *>(tiles);
         const u4 zero = {0u, 0u, 0u, 0u};
@@ -307,9 +309,9 @@ __global__ __launch_bounds__(kThreads) void slide_kernel(const SlideParams p) {
     }
     // byte phase (mod 16) of the affine part of the column maps: where, inside an aligned 32-byte span of a staged
     // row, a thread's window of shifted columns starts (RowRead)
-    const int csx = canon_shift(sh[2], S2, p.pad, p.d_per);
+    const int csx = canon_shift(sh[2], S2, p.pad, p.d_per[2]);
     const int dx = (-csx * ES) & 15;
-    const int dg = (ACTIVE || !BACKWARD) ? dx : ((-canon_shift(-sh[2], S2, p.pad, p.d_per) * ES) & 15);
+    const int dg = (ACTIVE || !BACKWARD) ? dx : ((-canon_shift(-sh[2], S2, p.pad, p.d_per[2]) * ES) & 15);
     __syncthreads();
 
     // ---- this thread's chunk column ------------------------------------------------------------------------------
@@ -754,7 +756,7 @@ void fill_slide(SlideParams &p, const Geometry &g, const SlidePlan &pl) {
     p.d_bands = make_fastdiv(static_cast<uint32_t>(pl.bands));
     p.d_inner = make_fastdiv(static_cast<uint32_t>(pl.inner));
     p.d_C = make_fastdiv(static_cast<uint32_t>(g.C));
-    p.d_per = make_fastdiv(static_cast<uint32_t>(map_period(static_cast<int>(g.S[2]), g.pad)));
+    for (int d = 0; d < 3; ++d) p.d_per[d] = make_fastdiv(static_cast<uint32_t>(map_period(static_cast<int>(g.S[d]), g.pad)));
 }
 
 constexpr int kNpBackward = 3, kNpForward = 2;

@@ -86,9 +86,12 @@ __global__ __launch_bounds__(kSweepMaxThreads) void sweep_gather_forward(const S
     const uint32_t tile = blk - band * p.tiles;
     const int c = static_cast<int>(plane - fdiv(plane, p.d_C) * static_cast<uint32_t>(p.C));
     int cs[3];
+    {
+        int64_t sh[3];
+        gather_shifts3(p.w, p.wkind, p.wzp, static_cast<int64_t>(c) * p.nd, p.wcol, sh);
 #pragma unroll
-    for (int d = 0; d < 3; ++d)
-        cs[d] = p.wcol[d] >= 0 ? canon_shift(gather_shift(p.w, p.wkind, p.wzp, c * p.nd + p.wcol[d]), p.S[d], p.pad, p.d_per[d]) : 0;
+        for (int d = 0; d < 3; ++d) cs[d] = p.wcol[d] >= 0 ? canon_shift(sh[d], p.S[d], p.pad, p.d_per[d]) : 0;
+    }
     // ---- per-thread part ---------------------------------------------------------------------------------
     const uint32_t tr = fdiv(threadIdx.x, p.d_CW);
     const uint32_t chunk = tile * p.CW + (threadIdx.x - tr * p.CW);
@@ -201,11 +204,13 @@ __global__ __launch_bounds__(kSweepMaxThreads) void sweep_active_forward(const S
     const int c = static_cast<int>(plane - fdiv(plane, p.d_C) * static_cast<uint32_t>(p.C));
     int cs[3] = {0, 0, 0};
     CT dw[3] = {CT(0), CT(0), CT(0)};
+    CT wv[3];
+    load_weights3<CT>(p.w, p.wkind, static_cast<int64_t>(c) * p.nd, p.wcol, wv);
 #pragma unroll
     for (int d = 0; d < 3; ++d)
         if (p.wcol[d] >= 0) {
             int64_t iw;
-            prep_shift_forward<CT>(load_weight<CT>(p.w, p.wkind, c * p.nd + p.wcol[d]), true, iw, dw[p.wcol[d]]);
+            prep_shift_forward<CT>(wv[d], true, iw, dw[p.wcol[d]]);
             cs[d] = canon_shift(iw, p.S[d], p.pad, p.d_per[d]);
         }
     const uint32_t tr = fdiv(threadIdx.x, p.d_CW);
@@ -291,11 +296,13 @@ __global__ __launch_bounds__(kSweepMaxThreads) void sweep_backward(const SweepPa
     const int c = static_cast<int>(plane - n * static_cast<uint32_t>(p.C));
     int cs[3] = {0, 0, 0}, gs[3] = {0, 0, 0};
     CT dw[3] = {CT(0), CT(0), CT(0)};
+    CT wv[3];
+    load_weights3<CT>(p.w, p.wkind, static_cast<int64_t>(c) * p.nd, p.wcol, wv);
 #pragma unroll
     for (int d = 0; d < 3; ++d)
         if (p.wcol[d] >= 0) {
             int64_t iw;
-            prep_shift_backward<CT>(load_weight<CT>(p.w, p.wkind, c * p.nd + p.wcol[d]), ACTIVE, iw, dw[p.wcol[d]]);
+            prep_shift_backward<CT>(wv[d], ACTIVE, iw, dw[p.wcol[d]]);
             cs[d] = canon_shift(iw, p.S[d], p.pad, p.d_per[d]);
             // grad_x source: SSL reads grad_out at o + shift, active at o - shift (shifts_kernels.h:287-293)
             gs[d] = canon_shift(ACTIVE ? iw : -iw, p.O[d], p.pad, p.d_gper[d]);

@@ -101,7 +101,7 @@ int forward_common(const shiftnd_problem *p, const void *x, const int64_t *xs, c
     }
     if ((g_policy == 0 || g_policy == 4) && cl_tiled_forward_eligible(g, p->dtype, x, out)) {  // channels-last in, LDS-tiled
         g_last_path = SHIFTND_PATH_CL;
-        return finish(cl_tiled_forward(g, x, w, wkind, wzp, fill, out, st));
+        return finish(cl_tiled_forward(g, p->dtype, x, w, wkind, wzp, fill, out, st));
     }
     if (g_policy == 4 && !cl_forward_eligible(g)) return SHIFTND_ERR_INVALID_ARGUMENT;
     if ((g_policy == 0 && cl_forward_preferred(g)) || g_policy == 4) {  // channels-last tensors: channel-fastest kernels

@@ -28,22 +28,23 @@ namespace {
 
 constexpr int kR = 3;                 // ring half depth = largest |shift| served from LDS
 constexpr int kTW = 32;               // output columns per workgroup
-constexpr int kCB = 32;               // channels per workgroup (128 bytes)
+constexpr int kLine = 128;            // bytes of channels per workgroup and pixel: 32 / 64 / 128 channels of 4 / 2 / 1 bytes
 constexpr int kPW = kTW + 2 * kR;     // staged pixels per row
 constexpr int kRing = 2 * kR + 1;     // staged rows
-constexpr int kPitch = kCB + 1;       // words per staged pixel
-constexpr int kPieces = kPW * (kCB / 4);   // 16-byte pieces per staged row (304)
+constexpr int kPitch = kLine / 4 + 1; // words per staged pixel
+constexpr int kRowWords = kPW * kPitch;
+constexpr int kPieces = kPW * (kLine / 16);   // 16-byte pieces per staged row (304)
 constexpr int kNP = (kPieces + kThreads - 1) / kThreads;
 #ifndef CLT_DEPTH
 #define CLT_DEPTH 3
 #endif
 
 struct ClTiledParams {
-    const uint32_t *x;
-    uint32_t *out;
+    const char *x;
+    char *out;
     const void *w;
     int64_t wzp;
-    uint32_t fill;
+    uint32_t fill;       // fill element (zero point / 0) in the low bits
     int wkind, N, C, H, W, pad;
     int out_cl;          // output layout: channels-last (1) or NCHW-contiguous (0)
     int wtiles, cblocks, bands, band_rows;
@@ -77,16 +78,31 @@ __device__ __forceinline__ void gather_shifts(const void *w, int wkind, int64_t 
 constexpr uint32_t kOutOfRange = 0x80000000u;   // buffer offset beyond every image (num_records < 2^31): loads give 0, stores are dropped
 constexpr int kBufferFlags = 0x00020000;        // raw buffer, 32-bit data format (gfx9 family resource word 3)
 
+template <int ES> struct ElemOf;
+template <> struct ElemOf<1> { using type = uint8_t; };
+template <> struct ElemOf<2> { using type = uint16_t; };
+template <> struct ElemOf<4> { using type = uint32_t; };
+
 // Every memory instruction of the row loop is unconditional and in straight-line code, so that hipcc counts vmcnt
 // exactly and the loads issued kDepth rows ahead really stay in flight (a load or store under a thread-dependent
 // branch makes it wait for vmcnt(0), i.e. one full memory round trip per row: 0.48 ms instead of 0.33 ms on
 // N16 C256 224x224 fp32).  What must not happen is expressed through buffer addressing instead: lanes without a source
 // piece / an output use an out-of-range offset, which the hardware answers with zero / drops.
-template <bool OUT_CL>
+//
+// A thread produces 4 output dwords per row; a dword holds NE = 4 / ES elements.  OUT_CL: dword = NE consecutive
+// channels of one pixel (thread = (dword of the pixel line 0..31, pixel lane 0..7), pixels pl + 8 i);  otherwise dword
+// = NE consecutive columns of one channel row (dword D = thread + 256 i of the tile's 128 / ES channel rows of
+// 32 ES bytes).  Either way every element of a thread has a fixed channel and column over the rows.
+template <int ES, bool OUT_CL>
 __global__ __launch_bounds__(kThreads) void cl_tiled_forward(const ClTiledParams p) {
     typedef uint32_t u4 __attribute__((ext_vector_type(4)));
-    __shared__ uint32_t ring[kRing * kPW * kPitch + 4];   // + dump words for pieces that do not exist
-    constexpr int kDump = kRing * kPW * kPitch;
+    using EL = typename ElemOf<ES>::type;
+    constexpr int NE = 4 / ES;            // elements per dword
+    constexpr int CB = kLine / ES;        // channels per workgroup
+    constexpr int RD = 8 * ES;            // NCHW output: dwords per channel-row segment of the tile
+    __shared__ uint32_t ring[kRing * kRowWords + 4];   // + dump words for pieces that do not exist
+    __shared__ int tab_sh[CB], tab_sw[CB];             // canonical shifts of the workgroup's channels
+    constexpr int kDump = kRing * kRowWords;
 
     // ---- which tile ---------------------------------------------------------------------------------------------
     unsigned b = blockIdx.x;
@@ -96,71 +112,28 @@ __global__ __launch_bounds__(kThreads) void cl_tiled_forward(const ClTiledParams
     b = fdiv(b, p.d_cblocks);
     const int band = static_cast<int>(b - fdiv(b, p.d_bands) * p.bands);
     const int n = static_cast<int>(fdiv(b, p.d_bands));
-    const int w0 = wt * kTW, c0 = cb * kCB;
+    const int w0 = wt * kTW, c0 = cb * CB;
     const int h0 = band * p.band_rows, h1 = min(p.H, h0 + p.band_rows);
     const int H = p.H, W = p.W, C = p.C;
-    const uint32_t *xn = p.x + static_cast<int64_t>(n) * H * W * C;
-    uint32_t *on = p.out + static_cast<int64_t>(n) * H * W * C;
-    const uint32_t img_bytes = static_cast<uint32_t>(H) * static_cast<uint32_t>(W) * static_cast<uint32_t>(C) * 4u;  // < 2^31 (host)
-    const __amdgpu_buffer_rsrc_t xres = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t *>(xn), 0, img_bytes, kBufferFlags);
-    const __amdgpu_buffer_rsrc_t xnone = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t *>(xn), 0, 0, kBufferFlags);
+    const char *xn = p.x + static_cast<int64_t>(n) * H * W * C * ES;
+    char *on = p.out + static_cast<int64_t>(n) * H * W * C * ES;
+    const uint32_t img_bytes = static_cast<uint32_t>(H) * static_cast<uint32_t>(W) * static_cast<uint32_t>(C) * ES;  // < 2^31 (host)
+    const __amdgpu_buffer_rsrc_t xres = __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(xn), 0, img_bytes, kBufferFlags);
+    const __amdgpu_buffer_rsrc_t xnone = __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(xn), 0, 0, kBufferFlags);
     const __amdgpu_buffer_rsrc_t ores = __builtin_amdgcn_make_buffer_rsrc(on, 0, img_bytes, kBufferFlags);
 
-    // ---- thread -> outputs ----------------------------------------------------------------------------------------
-    // OUT_CL: thread = (pixel lane 0..7, channel 0..31): pixels pl + 8 i;  else thread = (column 0..31, channel lane
-    // 0..7): channels cl + 8 i.  Either way 4 outputs per step, and per (thread, i) a fixed channel.
-    const int lane_a = static_cast<int>(threadIdx.x) & 31, lane_b = static_cast<int>(threadIdx.x) >> 5;
-    constexpr int NCH = OUT_CL ? 1 : 4;   // distinct channels of a thread
-    int64_t shifts[2 * NCH];
-    {
-        int widx[2 * NCH];
-#pragma unroll
-        for (int j = 0; j < NCH; ++j) {
-            const int c = min(c0 + (OUT_CL ? lane_a : lane_b + 8 * j), C - 1);
-            widx[2 * j] = 2 * c;
-            widx[2 * j + 1] = 2 * c + 1;
-        }
-        gather_shifts<2 * NCH>(p.w, p.wkind, p.wzp, widx, shifts);
-    }
-    const int perH = map_period(H, p.pad), perW = map_period(W, p.pad);
-    int csh[4], xoff[4];       // canonical row shift; LDS word offset of the source pixel within a staged row
-    uint32_t ooff[4];          // byte offset of the output in row h0 of the image, or out of range (nothing to store)
-    bool near[4], far[4];      // served from the ring / gathered from memory after the row loop
-    int gcol[4];               // far: source column
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int ch = OUT_CL ? lane_a : lane_b + 8 * i, col = OUT_CL ? lane_b + 8 * i : lane_a;
-        const int c = c0 + ch;
-        const bool live = c < C && w0 + col < W;
-        const int sh = canon_shift(shifts[OUT_CL ? 0 : 2 * i], H, p.pad, p.d_perH);
-        const int sw = canon_shift(shifts[OUT_CL ? 1 : 2 * i + 1], W, p.pad, p.d_perW);
-        csh[i] = sh;
-        const int sx = W == 1 ? 0 : fold_index(w0 + min(col, W - 1 - w0) - sw, W, p.pad);  // size-1 dims ignore the shift
-        gcol[i] = sx;
-        // canon_shift returns the non-negative representative for the reflecting paddings: look at the signed one
-        const int sh_s = (perH && 2 * sh > perH) ? sh - perH : sh, sw_s = (perW && 2 * sw > perW) ? sw - perW : sw;
-        const bool in_ring = sh_s >= -kR && sh_s <= kR && sw_s >= -kR && sw_s <= kR;
-        near[i] = live && sx >= 0 && in_ring;
-        far[i] = live && sx >= 0 && !in_ring;
-        xoff[i] = near[i] ? (sx - (w0 - kR)) * kPitch + ch : 0;
-        const uint32_t o = OUT_CL ? (static_cast<uint32_t>(h0 * W + w0 + col) * C + c) * 4u
-                                  : (static_cast<uint32_t>(c * H + h0) * W + w0 + col) * 4u;
-        ooff[i] = (live && !far[i]) ? o : kOutOfRange;   // (a column in the zero padding stores the fill value)
-    }
-    const uint32_t ostep = static_cast<uint32_t>(OUT_CL ? W * C : W) * 4u;
-
-    // ---- staging: 16-byte pieces of source row y: pixel w0 - R + px, channels c0 + 4 q .. ---------------------------
+    // ---- staging: 16-byte pieces of source row y: pixel w0 - R + px, bytes 16 q .. of the channel line ---------------
     uint32_t poff[kNP];    // byte offset of the piece in row 0 of the image, or out of range
     int pdst[kNP];         // LDS word offset within a ring row, or the dump words
 #pragma unroll
     for (int k = 0; k < kNP; ++k) {
         const int q = k * kThreads + static_cast<int>(threadIdx.x);
-        const int px = q >> 3, cc = c0 + (q & 7) * 4, gx = w0 - kR + px;
+        const int px = q >> 3, cbyte = c0 * ES + (q & 7) * 16, gx = w0 - kR + px;
         const bool piece = q < kPieces;
-        poff[k] = (piece && gx >= 0 && gx < W && cc < C) ? (static_cast<uint32_t>(gx) * C + cc) * 4u : kOutOfRange;
+        poff[k] = (piece && gx >= 0 && gx < W && cbyte < C * ES) ? static_cast<uint32_t>(gx) * C * ES + cbyte : kOutOfRange;
         pdst[k] = piece ? px * kPitch + (q & 7) * 4 : -1;
     }
-    const uint32_t row_bytes = static_cast<uint32_t>(W) * C * 4u;
+    const uint32_t row_bytes = static_cast<uint32_t>(W) * C * ES;
     constexpr int kDepth = CLT_DEPTH;  // rows of staging in flight (a workgroup moves only ~5 KB per row)
     u4 pvs[kDepth][kNP];
     auto load_row = [&](int y, int ylast, u4 (&pv)[kNP]) {  // rows outside the image or beyond the band: nothing is read
@@ -174,7 +147,7 @@ __global__ __launch_bounds__(kThreads) void cl_tiled_forward(const ClTiledParams
         const int slot = (y % kRing + kRing) % kRing;
 #pragma unroll
         for (int k = 0; k < kNP; ++k) {
-            uint32_t *d = ring + (pdst[k] >= 0 ? slot * (kPW * kPitch) + pdst[k] : kDump);
+            uint32_t *d = ring + (pdst[k] >= 0 ? slot * kRowWords + pdst[k] : kDump);
             d[0] = pv[k].x;
             d[1] = pv[k].y;
             d[2] = pv[k].z;
@@ -182,41 +155,104 @@ __global__ __launch_bounds__(kThreads) void cl_tiled_forward(const ClTiledParams
         }
     };
     const int ylast = min(H - 1, h1 - 1 + kR);
+    // The kDepth rows for the first steps are requested BEFORE the ring rows: when those have arrived nothing is
+    // pending any more, so the loop's wait counts are those of its own back edge (kDepth rows of loads and stores
+    // in flight), not the shorter distance of this prologue.
+    u4 pre[2 * kR][kNP];
+#pragma unroll
+    for (int d = 0; d < kDepth; ++d) load_row(h0 + kR + d, ylast, pvs[d]);
+#pragma unroll
+    for (int r = 0; r < 2 * kR; ++r) load_row(h0 - kR + r, ylast, pre[r]);
 
-    // rows h0 - R .. h0 + R - 1 first (all loads, then all stores), then one row per step.  The kDepth rows for the
-    // first steps are requested BEFORE them: when the ring rows have arrived nothing is pending any more, so the
-    // loop's wait counts are those of its own back edge (kDepth rows of loads and stores in flight), not the shorter
-    // distance of this prologue.
-    {
-        u4 pre[2 * kR][kNP];
-#pragma unroll
-        for (int d = 0; d < kDepth; ++d) load_row(h0 + kR + d, ylast, pvs[d]);
-#pragma unroll
-        for (int r = 0; r < 2 * kR; ++r) load_row(h0 - kR + r, ylast, pre[r]);
-#pragma unroll
-        for (int r = 0; r < 2 * kR; ++r) {
-            const int y = h0 - kR + r;
-            if (y >= 0 && y < H) store_row(y, pre[r]);
-        }
+    // ---- the channels' shifts (while the rows are in flight) -----------------------------------------------------------
+    if (threadIdx.x < CB) {
+        const int c = min(c0 + static_cast<int>(threadIdx.x), C - 1);
+        const int widx[2] = {2 * c, 2 * c + 1};
+        int64_t sh2[2];
+        gather_shifts<2>(p.w, p.wkind, p.wzp, widx, sh2);
+        tab_sh[threadIdx.x] = canon_shift(sh2[0], H, p.pad, p.d_perH);
+        tab_sw[threadIdx.x] = canon_shift(sh2[1], W, p.pad, p.d_perW);
     }
+    __syncthreads();
+
+    // ---- thread -> elements -------------------------------------------------------------------------------------------
+    const int lane_a = static_cast<int>(threadIdx.x) & 31, lane_b = static_cast<int>(threadIdx.x) >> 5;
+    const int perH = map_period(H, p.pad), perW = map_period(W, p.pad);
+    // rows of a thread's elements: OUT_CL one canonical row shift per element slot j (channels 4 lane_a / ES + j), else
+    // one per dword i (its channel)
+    constexpr int NSH = OUT_CL ? NE : 4;
+    int csh[NSH];
+    int xoff[4][NE];           // LDS byte offset of the source element within a staged row (0 when not served from the ring)
+    uint32_t ring_ok = 0, far = 0;   // bit 4 i + j: served from the ring / gathered from memory after the row loop
+    uint32_t ooff[4];          // byte offset of the output dword in row h0 of the image, or out of range (nothing to store)
+    int gcol[4][NE];           // far: source column
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int D = static_cast<int>(threadIdx.x) + kThreads * i;   // NCHW output: dword of the tile
+        bool live_dw = false;
+#pragma unroll
+        for (int j = 0; j < NE; ++j) {
+            const int ch = OUT_CL ? lane_a * NE + j : D / RD;
+            const int col = OUT_CL ? lane_b + 8 * i : (D % RD) * NE + j;
+            const int c = c0 + ch;
+            const bool live = c < C && w0 + col < W;
+            live_dw = live_dw || live;
+            const int sh = tab_sh[ch], sw = tab_sw[ch];
+            if (OUT_CL) csh[j] = sh;
+            else csh[i] = sh;
+            const int sx = W == 1 ? 0 : fold_index(w0 + min(col, W - 1 - w0) - sw, W, p.pad);  // size-1 dims ignore the shift
+            gcol[i][j] = sx;
+            // canon_shift returns the non-negative representative for the reflecting paddings: look at the signed one
+            const int sh_s = (perH && 2 * sh > perH) ? sh - perH : sh, sw_s = (perW && 2 * sw > perW) ? sw - perW : sw;
+            const bool in_ring = sh_s >= -kR && sh_s <= kR && sw_s >= -kR && sw_s <= kR;
+            const bool nr = live && sx >= 0 && in_ring;
+            ring_ok |= (nr ? 1u : 0u) << (4 * i + j);
+            far |= ((live && sx >= 0 && !in_ring) ? 1u : 0u) << (4 * i + j);
+            xoff[i][j] = nr ? (sx - (w0 - kR)) * (kPitch * 4) + ch * ES : 0;
+        }
+        // (C * ES and W * ES are multiples of 4 where it matters: a dword is live or dead as a whole)
+        const int ch0 = OUT_CL ? lane_a * NE : D / RD, col0 = OUT_CL ? lane_b + 8 * i : (D % RD) * NE;
+        const uint32_t o = OUT_CL ? (static_cast<uint32_t>(h0 * W + w0 + col0) * C + c0 + ch0) * ES
+                                  : (static_cast<uint32_t>((c0 + ch0) * H + h0) * W + w0 + col0) * ES;
+        ooff[i] = live_dw ? o : kOutOfRange;
+    }
+    const uint32_t ostep = static_cast<uint32_t>(OUT_CL ? W * C : W) * ES;
+
+    // rows h0 - R .. h0 + R - 1 of the ring
+#pragma unroll
+    for (int r = 0; r < 2 * kR; ++r) {
+        const int y = h0 - kR + r;
+        if (y >= 0 && y < H) store_row(y, pre[r]);
+    }
+    const uint8_t *ringb = reinterpret_cast<const uint8_t *>(ring);
     auto step = [&](int h, u4 (&pv)[kNP]) {
         __syncthreads();  // everybody is done with the slot that row h + R replaces (row h - R - 1)
         if (h + kR < H) store_row(h + kR, pv);
         __syncthreads();
         load_row(h + kDepth + kR, ylast, pv);  // in flight while this and the next rows are produced
         const uint32_t so = static_cast<uint32_t>(h - h0) * ostep;
-        uint32_t v[4];
-        bool ok[4];
+        int rowb[NSH];        // LDS byte offset of the source row of each shift, or -1 (zero padding)
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int sy = H == 1 ? 0 : fold_index(h - csh[i], H, p.pad);   // -1: zero padding
-            ok[i] = near[i] && sy >= 0;
+        for (int k = 0; k < NSH; ++k) {
+            const int sy = H == 1 ? 0 : fold_index(h - csh[k], H, p.pad);
             const uint32_t r = static_cast<uint32_t>(sy < 0 ? 0 : sy);
             const uint32_t sl = r - __umulhi(r, 613566757u) * kRing;       // r % 7 (r < 2^20)
-            v[i] = ring[sl * (kPW * kPitch) + xoff[i]];
+            rowb[k] = sy < 0 ? -1 : static_cast<int>(sl) * (kRowWords * 4);
+        }
+        uint32_t v[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            v[i] = 0;
+#pragma unroll
+            for (int j = 0; j < NE; ++j) {
+                const int rb = rowb[OUT_CL ? j : i];
+                const uint32_t e = *reinterpret_cast<const EL *>(ringb + (rb < 0 ? 0 : rb) + xoff[i][j]);
+                const bool ok = ((ring_ok >> (4 * i + j)) & 1u) && rb >= 0;
+                v[i] |= (ok ? e : p.fill) << (8 * ES * j);
+            }
         }
 #pragma unroll
-        for (int i = 0; i < 4; ++i) __builtin_amdgcn_raw_buffer_store_b32(ok[i] ? v[i] : p.fill, ores, ooff[i], so, 0);
+        for (int i = 0; i < 4; ++i) __builtin_amdgcn_raw_buffer_store_b32(v[i], ores, ooff[i], so, 0);
     };
     int hb = h0;
     for (; hb + kDepth <= h1; hb += kDepth) {   // whole groups: no condition between the steps (exact wait counts)
@@ -227,17 +263,28 @@ __global__ __launch_bounds__(kThreads) void cl_tiled_forward(const ClTiledParams
     for (int d = 0; d < kDepth - 1; ++d)
         if (hb + d < h1) step(hb + d, pvs[d]);
 
-    // ---- shifts beyond the ring: gathered from memory, element by element (rare) -------------------------------------
+    // ---- shifts beyond the ring: gathered from memory, element by element (rare).  The row loop stored the fill
+    // value in their place; those stores are complete before the elements are written again. ------------------------
+    if (far) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        if (!far[i]) continue;
-        const int ch = OUT_CL ? lane_a : lane_b + 8 * i, col = OUT_CL ? lane_b + 8 * i : lane_a;
-        uint32_t *o = OUT_CL ? on + (static_cast<int64_t>(h0) * W + w0 + col) * C + c0 + ch
-                             : on + (static_cast<int64_t>(c0 + ch) * H + h0) * W + w0 + col;
-        for (int h = h0; h < h1; ++h) {
-            const int sy = H == 1 ? 0 : fold_index(h - csh[i], H, p.pad);
-            *o = sy >= 0 ? xn[(static_cast<int64_t>(sy) * W + gcol[i]) * C + c0 + ch] : p.fill;
-            o += OUT_CL ? W * C : W;
+        for (int i = 0; i < 4; ++i) {
+#pragma unroll
+            for (int j = 0; j < NE; ++j) {
+                if (!((far >> (4 * i + j)) & 1u)) continue;
+                const int D = static_cast<int>(threadIdx.x) + kThreads * i;
+                const int ch = OUT_CL ? lane_a * NE + j : D / RD;
+                const int col = OUT_CL ? lane_b + 8 * i : (D % RD) * NE + j;
+                const EL *xe = reinterpret_cast<const EL *>(xn);
+                EL *o = reinterpret_cast<EL *>(on) + (OUT_CL ? (static_cast<int64_t>(h0) * W + w0 + col) * C + c0 + ch
+                                                             : (static_cast<int64_t>(c0 + ch) * H + h0) * W + w0 + col);
+                const int shc = csh[OUT_CL ? j : i];
+                for (int h = h0; h < h1; ++h) {
+                    const int sy = H == 1 ? 0 : fold_index(h - shc, H, p.pad);
+                    *o = sy >= 0 ? xe[(static_cast<int64_t>(sy) * W + gcol[i][j]) * C + c0 + ch] : static_cast<EL>(p.fill);
+                    o += OUT_CL ? W * C : W;
+                }
+            }
         }
     }
 }
@@ -258,29 +305,33 @@ void cl_tiled_set_tuning(int knob, int value) {
     if (knob >= 0 && knob < 2) g_cl_tiled_tune[knob] = value;
 }
 
-// 2-D, 4-byte elements, pure gather (sparse shift / quantized), no crop, not periodic, dense channels-last input with
-// C a multiple of 4, 16-byte aligned; output dense channels-last or NCHW-contiguous
+// 2-D, 1- / 2- / 4-byte elements, pure gather (sparse shift / quantized), no crop, not periodic, dense channels-last
+// input whose pixel lines (C elements) are whole 16-byte pieces, 16-byte aligned; output dense channels-last or
+// NCHW-contiguous with rows of whole dwords
 bool cl_tiled_forward_eligible(const Geometry &g, int dtype, const void *x, const void *out) {
-    if (!g_cl_tiled_tune[0] || g.nd != 2 || dtype_size(dtype) != 4 || g.pad == 2) return false;
+    const int es = dtype_size(dtype);
+    if (!g_cl_tiled_tune[0] || g.nd != 2 || es > 4 || g.pad == 2) return false;
     if (g.active && dtype <= SHIFTND_BF16) return false;
     for (int d = 0; d < 3; ++d)
         if (g.L[d] != 0 || g.O[d] != g.S[d]) return false;
-    if (g.C < 4 || g.C % 4 != 0 || g.S[1] >= (1 << 20) || g.S[2] >= (1 << 20) || g.N >= (1LL << 24) || g.C >= (1 << 24)) return false;
+    if ((g.C * es) % 16 != 0 || g.S[1] >= (1 << 20) || g.S[2] >= (1 << 20) || g.N >= (1LL << 24) || g.C >= (1 << 24)) return false;
     if (reinterpret_cast<uintptr_t>(x) % 16 != 0 || reinterpret_cast<uintptr_t>(out) % 4 != 0) return false;
-    if (g.C * g.S[1] * g.S[2] * 4 >= (1LL << 31)) return false;  // one image per buffer resource, offsets below 2^31
+    if (g.C * g.S[1] * g.S[2] * es >= (1LL << 31)) return false;  // one image per buffer resource, offsets below 2^31
     if (!dense_channels_last_2d(g.xs, g, g.S)) return false;
-    return dense_channels_last_2d(g.os, g, g.O) || contiguous_2d(g.os, g, g.O);
+    if (dense_channels_last_2d(g.os, g, g.O)) return true;
+    return contiguous_2d(g.os, g, g.O) && (g.S[2] * es) % 4 == 0;
 }
 
-int cl_tiled_forward(const Geometry &g, const void *x, const void *w, int wkind, int64_t wzp, uint64_t fill_bits, void *out,
-                     hipStream_t st) {
+int cl_tiled_forward(const Geometry &g, int dtype, const void *x, const void *w, int wkind, int64_t wzp, uint64_t fill_bits,
+                     void *out, hipStream_t st) {
+    const int es = dtype_size(dtype);
     ClTiledParams p{};
-    p.x = static_cast<const uint32_t *>(x);
-    p.out = static_cast<uint32_t *>(out);
+    p.x = static_cast<const char *>(x);
+    p.out = static_cast<char *>(out);
     p.w = w;
     p.wkind = wkind;
     p.wzp = wzp;
-    p.fill = static_cast<uint32_t>(fill_bits);
+    p.fill = static_cast<uint32_t>(es == 4 ? fill_bits : (fill_bits & ((1ull << (8 * es)) - 1)));
     p.N = static_cast<int>(g.N);
     p.C = static_cast<int>(g.C);
     p.H = static_cast<int>(g.S[1]);
@@ -288,7 +339,8 @@ int cl_tiled_forward(const Geometry &g, const void *x, const void *w, int wkind,
     p.pad = g.pad;
     p.out_cl = dense_channels_last_2d(g.os, g, g.O) ? 1 : 0;
     p.wtiles = (p.W + kTW - 1) / kTW;
-    p.cblocks = (p.C + kCB - 1) / kCB;
+    const int cb = kLine / es;
+    p.cblocks = (p.C + cb - 1) / cb;
     // bands along H: enough workgroups (~7 per workgroup slot of the chip: 28-row bands measured best on N16 C256
     // 224x224), at least 8 R rows per band (the ring warm-up is 2 R rows)
     const int64_t base = static_cast<int64_t>(p.N) * p.wtiles * p.cblocks;
@@ -306,8 +358,13 @@ int cl_tiled_forward(const Geometry &g, const void *x, const void *w, int wkind,
     p.d_perH = make_fastdiv(static_cast<uint32_t>(map_period(p.H, p.pad)));
     p.d_perW = make_fastdiv(static_cast<uint32_t>(map_period(p.W, p.pad)));
     note_kernel("cl_tiled_forward");
-    if (p.out_cl) hipLaunchKernelGGL((cl_tiled_forward<true>), dim3(static_cast<unsigned>(grid)), dim3(kThreads), 0, st, p);
-    else hipLaunchKernelGGL((cl_tiled_forward<false>), dim3(static_cast<unsigned>(grid)), dim3(kThreads), 0, st, p);
+#define SHIFTND_CLT_LAUNCH(ESV) \
+    if (p.out_cl) hipLaunchKernelGGL((cl_tiled_forward<ESV, true>), dim3(static_cast<unsigned>(grid)), dim3(kThreads), 0, st, p); \
+    else hipLaunchKernelGGL((cl_tiled_forward<ESV, false>), dim3(static_cast<unsigned>(grid)), dim3(kThreads), 0, st, p);
+    if (es == 4) { SHIFTND_CLT_LAUNCH(4) }
+    else if (es == 2) { SHIFTND_CLT_LAUNCH(2) }
+    else { SHIFTND_CLT_LAUNCH(1) }
+#undef SHIFTND_CLT_LAUNCH
     return SHIFTND_OK;
 }
 

@@ -86,7 +86,7 @@ int cl_backward(const Geometry &g, int dtype, const void *go, const void *x, con
 // ---- LDS-tiled gather forward for dense channels-last inputs of 4-byte elements (shiftnd_cl_tiled.hip); the output is
 // channels-last or NCHW-contiguous
 bool cl_tiled_forward_eligible(const Geometry &g, int dtype, const void *x, const void *out);
-int cl_tiled_forward(const Geometry &g, const void *x, const void *w, int wkind, int64_t wzp, uint64_t fill_bits, void *out,
+int cl_tiled_forward(const Geometry &g, int dtype, const void *x, const void *w, int wkind, int64_t wzp, uint64_t fill_bits, void *out,
                      hipStream_t st);
 void cl_tiled_set_tuning(int knob, int value);
 

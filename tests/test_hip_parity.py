@@ -90,8 +90,8 @@ def test_golden_quantized(abi, policy):
         out = abi.forward_quantized(x, w, wzp, xzp, pad, b, out=out)
         assert np.array_equal(out.cpu().numpy(), out_r), key
         if layout != "nchw" and policy in (0, 4) and x.shape[1] > 1:
-            # (4-byte elements, 2-D, no crop, no periodic wrap, C % 4 == 0: the LDS-tiled kernel)
-            tiled = xname == "qint32" and nd == 2 and crop is None and pad != 2 and x.shape[1] % 4 == 0
+            # (2-D, no crop, no periodic wrap, pixel lines of whole 16-byte pieces: the LDS-tiled kernel)
+            tiled = nd == 2 and crop is None and pad != 2 and (x.shape[1] * x.element_size()) % 16 == 0
             assert abi.last_path() == abi.PATH_CL and abi.last_kernel() == ("cl_tiled_forward" if tiled else "cl_gather_forward"), key
         if policy in (0, 2, 3) and layout == "nchw":
             assert abi.last_path() == (abi.PATH_SWEEP if policy == 3 else abi.PATH_PLANE), key

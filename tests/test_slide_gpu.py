@@ -197,6 +197,51 @@ def test_tiled_channels_last_forward_vs_oracle(shape):
         abi.set_tuning(21, 0)
 
 
+@pytest.mark.parametrize("shape", [(2, 16, 9, 12), (1, 144, 20, 37), (2, 64, 40, 70), (1, 32, 5, 6)])
+def test_tiled_channels_last_forward_small_elements(shape):
+    """cl_tiled_forward for 1- and 2-byte elements (a dword of output = 4 / 2 elements with their own shifts): quantized
+    uint8 / int8 keeping the channels-last format (shifts_quantized.cpp:119-121), fp16 / bf16 sparse shifts to
+    channels-last and NCHW-contiguous outputs; shifts beyond the ring; bit-exact vs the oracle"""
+    from torchshifts import abi
+    rs = np.random.RandomState(sum(shape) + 11)
+    C = shape[1]
+    try:
+        for band_rows in (0, 7):
+            abi.set_tuning(21, band_rows)
+            for npdt, zp in ((np.uint8, 7), (np.int8, -3)):
+                xq = rs.randint(0 if npdt == np.uint8 else -128, 127, size=shape).astype(npdt)
+                wq = rs.randint(124, 133, size=(C, 2)).astype(np.uint8)
+                wq[1] = [128 + 9, 128 - 6]   # beyond the ring
+                wq[2] = [128 - 4, 128 + 3]
+                xqd = torch.from_numpy(xq).to(DEV).contiguous(memory_format=torch.channels_last)
+                wqd = torch.from_numpy(wq).to(DEV)
+                for pad in (0, 1, 3, 4):
+                    outq = torch.empty(shape, dtype=xqd.dtype, device=DEV).contiguous(memory_format=torch.channels_last)
+                    abi.forward_quantized(xqd, wqd, 128, zp, pad, out=outq)
+                    assert abi.last_kernel() == "cl_tiled_forward", (shape, npdt, pad)
+                    assert np.array_equal(outq.cpu().numpy(), O.forward_q(xq, wq, 128, zp, pad)), (shape, npdt, pad)
+            if (C * 2) % 16 == 0:
+                for tdt in (torch.float16, torch.bfloat16):
+                    x = torch.from_numpy(rs.uniform(-1, 1, size=shape).astype(np.float32)).to(tdt)
+                    w = torch.from_numpy(rs.uniform(-3.4, 3.4, size=(C, 2)).astype(np.float32)).to(tdt)
+                    w[0, 0], w[0, 1] = 0.5, -1.5
+                    w[1, 0], w[1, 1] = shape[2] + 2.25, -7.0
+                    xd = x.to(DEV).contiguous(memory_format=torch.channels_last)
+                    wd = w.to(DEV)
+                    for pad in (0, 1, 3, 4):
+                        ref = abi.forward(x.to(DEV), wd, pad, False)   # the NCHW kernels (checked against the oracle elsewhere)
+                        out = abi.forward(xd, wd, pad, False)  # NCHW-contiguous output
+                        nchw_tiled = (shape[3] * 2) % 4 == 0
+                        assert (abi.last_kernel() == "cl_tiled_forward") == nchw_tiled and out.is_contiguous()
+                        assert torch.equal(out, ref), (shape, tdt, pad, "nchw")
+                        out_cl = torch.empty(shape, dtype=tdt, device=DEV).contiguous(memory_format=torch.channels_last)
+                        abi.forward(xd, wd, pad, False, out=out_cl)
+                        assert abi.last_kernel() == "cl_tiled_forward"
+                        assert torch.equal(out_cl, ref), (shape, tdt, pad, "cl")
+    finally:
+        abi.set_tuning(21, 0)
+
+
 def test_channels_last_input_through_the_op_uses_the_tiled_kernel():
     """torch.ops.torchshifts.shift2d with a channels-last fp32 input: one pass (no layout change first), NCHW result
     like the reference (cpu/shifts_cpu.cpp:221), same bits as the contiguous input"""

@@ -32,3 +32,23 @@ for br in [int(a) for a in sys.argv[1:]] or [0]:
     print("band_rows %3d  CL->NCHW %.3f ms (%s, %.0f GB/s)   CL->CL %.3f ms (%s)" % (br, t1, k1, 8 * x.numel() / t1 / 1e6, t2, k2))
 t0 = ev(lambda: abi.forward(x, w, 0, 0, out=o))
 print("NCHW->NCHW %.3f ms (%s)" % (t0, abi.last_kernel()))
+# quantized C4 in channels-last (the format is kept) and fp16
+xq = torch.randint(0, 255, (128, 512, 56, 56), dtype=torch.uint8, device=dev)
+wq = (torch.rand(512, 2, device=dev) * 6 - 3).round().add(128).to(torch.uint8)
+xqc = xq.contiguous(memory_format=torch.channels_last)
+oq = torch.empty_like(xq); oqc = torch.empty_like(xqc)
+t1 = ev(lambda: abi.forward_quantized(xq, wq, 128, 0, 0, out=oq)); k1 = abi.last_kernel()
+for br in [int(a) for a in sys.argv[1:]] or [0]:
+    abi.set_tuning(21, br)
+    t2 = ev(lambda: abi.forward_quantized(xqc, wq, 128, 0, 0, out=oqc)); k2 = abi.last_kernel()
+    assert torch.equal(oq, oqc)
+    print("C4 quint8 band_rows %3d  NCHW %.3f ms (%s)   CL->CL %.3f ms (%s)  %.0f GB/s" % (br, t1, k1, t2, k2, 2 * xq.numel() / t2 / 1e6))
+abi.set_tuning(21, 0)
+xh = torch.rand(16, 256, 224, 224, device=dev).half(); wh = (torch.rand(256, 2, device=dev) * 6 - 3).half()
+xhc = xh.contiguous(memory_format=torch.channels_last)
+oh = torch.empty_like(xh); ohc = torch.empty_like(xhc); oh2 = torch.empty_like(xh)
+t1 = ev(lambda: abi.forward(xh, wh, 0, 0, out=oh)); k1 = abi.last_kernel()
+t2 = ev(lambda: abi.forward(xhc, wh, 0, 0, out=oh2)); k2 = abi.last_kernel()
+t3 = ev(lambda: abi.forward(xhc, wh, 0, 0, out=ohc)); k3 = abi.last_kernel()
+assert torch.equal(oh, oh2) and torch.equal(oh, ohc)
+print("fp16 N16 C256 224^2  NCHW %.3f ms (%s)   CL->NCHW %.3f ms (%s)   CL->CL %.3f ms (%s)" % (t1, k1, t2, k2, t3, k3))

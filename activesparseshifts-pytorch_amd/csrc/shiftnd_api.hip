@@ -226,8 +226,10 @@ size_t shiftnd_backward_workspace_bytes(const shiftnd_problem *p) {
     const size_t b = plane_backward_workspace(g, p->dtype);
     const size_t c = sweep_backward_workspace(g, p->dtype);
     const size_t d = cl_backward_workspace(g);
-    const size_t m = a > b ? (a > c ? a : c) : (b > c ? b : c);
-    return m > d ? m : d;
+    const size_t e = cl_tiled_backward_workspace(g);
+    size_t m = a > b ? (a > c ? a : c) : (b > c ? b : c);
+    m = m > d ? m : d;
+    return m > e ? m : e;
 }
 
 int shiftnd_backward(const shiftnd_problem *p, const void *grad_out, const int64_t grad_out_strides[5], const void *x,
@@ -262,6 +264,11 @@ int shiftnd_backward(const shiftnd_problem *p, const void *grad_out, const int64
         if (plane_backward_workspace(g, p->dtype) > workspace_bytes) return SHIFTND_ERR_WORKSPACE_TOO_SMALL;
         g_last_path = SHIFTND_PATH_PLANE;
         return finish(plane_backward(g, p->dtype, grad_out, x, weights, grad_x, grad_w, workspace, st));
+    }
+    if ((g_policy == 0 || g_policy == 4) && cl_tiled_backward_eligible(g, p->dtype, grad_out, x, grad_x)) {  // all channels-last: LDS-tiled
+        if (cl_tiled_backward_workspace(g) > workspace_bytes) return SHIFTND_ERR_WORKSPACE_TOO_SMALL;
+        g_last_path = SHIFTND_PATH_CL;
+        return finish(cl_tiled_backward(g, p->dtype, grad_out, x, weights, grad_x, grad_w, workspace, st));
     }
     if (g_policy == 4 && !cl_backward_eligible(g, p->dtype)) return SHIFTND_ERR_INVALID_ARGUMENT;
     if ((g_policy == 0 && cl_backward_preferred(g, p->dtype)) || g_policy == 4) {

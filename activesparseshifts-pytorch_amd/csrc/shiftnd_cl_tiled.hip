@@ -289,6 +289,272 @@ __global__ __launch_bounds__(kThreads) void cl_tiled_forward(const ClTiledParams
     }
 }
 
+// =====================================================================================================
+// Backward for dense channels-last fp32 tensors (saved input, incoming gradient and grad_x all NHWC): the same
+// row walk with TWO rings, rows h - R .. h + R + 1 of the input and of the incoming gradient (the + 1: the
+// interpolation corners, which the sparse shift's weight gradient reads too, shifts_kernels.h:271-283), 16 output
+// columns x 32 channels per workgroup (2 x 24 KB of LDS: three workgroups per CU).  A thread keeps ONE channel
+// (lane % 32) and two pixels per row, so the weight-gradient sums stay in its registers (fp64, like every backward
+// kernel here) and are combined once per workgroup, in a fixed order, into the [group][C][3] partial sums that
+// reduce_weight_grads finishes.  grad_x: the sparse shift reads grad_out at o + shift (one tap, raw copy), the active
+// shift interpolates the four corners around o - floor(shift) (:287-293).  Reference: kernels/shifts_kernels.h:402-527.
+// Roofline: HBM, 3 x 4 bytes per element.
+// =====================================================================================================
+constexpr int kBTW = 16;                       // output columns per workgroup
+constexpr int kBPW = kBTW + 2 * kR + 1;        // staged pixels per row
+constexpr int kBRing = 8;                      // staged rows h - R .. h + R + 1
+constexpr int kBRowWords = kBPW * kPitch;
+constexpr int kBRingWords = kBRing * kBRowWords;
+constexpr int kBPieces = kBPW * (kLine / 16);  // 16-byte pieces per staged row and tensor (184: one per thread)
+static_assert(kBPieces <= kThreads, "one piece of each tensor per thread");
+
+struct ClTiledBwdParams {
+    const char *x, *go;
+    char *gx;
+    const void *w;
+    double *partials;    // [N * bands * wtiles][C][3]
+    int wkind, N, C, H, W, pad;
+    int wtiles, cblocks, bands, band_rows;
+    FastDiv d_wtiles, d_cblocks, d_bands;
+    FastDiv d_perH, d_perW;
+};
+
+template <typename T, bool ACTIVE>
+__global__ __launch_bounds__(kThreads) void cl_tiled_backward(const ClTiledBwdParams p) {
+    typedef uint32_t u4 __attribute__((ext_vector_type(4)));
+    using S = typename T::S;
+    using CT = typename T::C;
+    static_assert(sizeof(S) == 4, "4-byte elements");
+    constexpr int ES = 4, CB = kLine / ES;
+    __shared__ __attribute__((aligned(16))) uint32_t ring[2 * kBRingWords + 4];   // input ring, gradient ring, dump words
+    constexpr int kDump = 2 * kBRingWords;
+
+    // ---- which tile ---------------------------------------------------------------------------------------------
+    unsigned b = blockIdx.x;
+    const int cb = static_cast<int>(b - fdiv(b, p.d_cblocks) * p.cblocks);   // channel blocks of one pixel tile are neighbours
+    b = fdiv(b, p.d_cblocks);
+    const int pidx = static_cast<int>(b);                                     // (n, band, wt): the partial-sum group
+    const int wt = static_cast<int>(b - fdiv(b, p.d_wtiles) * p.wtiles);
+    b = fdiv(b, p.d_wtiles);
+    const int band = static_cast<int>(b - fdiv(b, p.d_bands) * p.bands);
+    const int n = static_cast<int>(fdiv(b, p.d_bands));
+    const int w0 = wt * kBTW, c0 = cb * CB;
+    const int h0 = band * p.band_rows, h1 = min(p.H, h0 + p.band_rows);
+    const int H = p.H, W = p.W, C = p.C;
+    const int64_t img = static_cast<int64_t>(n) * H * W * C * ES;
+    const char *xn = p.x + img, *gn = p.go + img;
+    char *on = p.gx + img;
+    const uint32_t img_bytes = static_cast<uint32_t>(H) * static_cast<uint32_t>(W) * static_cast<uint32_t>(C) * ES;  // < 2^31 (host)
+    const __amdgpu_buffer_rsrc_t xres = __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(xn), 0, img_bytes, kBufferFlags);
+    const __amdgpu_buffer_rsrc_t gres = __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(gn), 0, img_bytes, kBufferFlags);
+    const __amdgpu_buffer_rsrc_t none = __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(xn), 0, 0, kBufferFlags);
+    const __amdgpu_buffer_rsrc_t ores = __builtin_amdgcn_make_buffer_rsrc(on, 0, img_bytes, kBufferFlags);
+
+    // ---- staging: one 16-byte piece of the input row and one of the gradient row per thread ------------------------------
+    const int q = static_cast<int>(threadIdx.x);
+    const bool piece = q < kBPieces;
+    const int px = q >> 3, part = q & 7, gxs = w0 - kR + px;
+    const uint32_t poff = (piece && gxs >= 0 && gxs < W && c0 + part * 4 < C) ? (static_cast<uint32_t>(gxs) * C + c0 + part * 4) * ES : kOutOfRange;
+    const int pdst = piece ? px * kPitch + part * 4 : -1;
+    const uint32_t row_bytes = static_cast<uint32_t>(W) * C * ES;
+    constexpr int kDepth = CLT_DEPTH;
+    u4 pvx[kDepth], pvg[kDepth];
+    auto load_row = [&](int y, int ylast, u4 &vx, u4 &vg) {  // rows outside the image or beyond the band: nothing is read
+        const bool wanted = y >= 0 && y <= ylast;
+        const uint32_t so = wanted ? static_cast<uint32_t>(y) * row_bytes : 0u;
+        vx = __builtin_amdgcn_raw_buffer_load_b128(wanted ? xres : none, poff, so, 0);
+        vg = __builtin_amdgcn_raw_buffer_load_b128(wanted ? gres : none, poff, so, 0);
+    };
+    auto store_row = [&](int y, const u4 &vx, const u4 &vg) {
+        const int slot = y & (kBRing - 1);
+        uint32_t *dx = ring + (pdst >= 0 ? slot * kBRowWords + pdst : kDump);
+        uint32_t *dg = ring + (pdst >= 0 ? kBRingWords + slot * kBRowWords + pdst : kDump);
+        dx[0] = vx.x; dx[1] = vx.y; dx[2] = vx.z; dx[3] = vx.w;
+        dg[0] = vg.x; dg[1] = vg.y; dg[2] = vg.z; dg[3] = vg.w;
+    };
+    const int ylast = min(H - 1, h1 + kR);
+    u4 prex[2 * kR + 1], preg[2 * kR + 1];
+#pragma unroll
+    for (int d = 0; d < kDepth; ++d) load_row(h0 + kR + 1 + d, ylast, pvx[d], pvg[d]);
+#pragma unroll
+    for (int r = 0; r <= 2 * kR; ++r) load_row(h0 - kR + r, ylast, prex[r], preg[r]);
+
+    // ---- the thread's channel and its two pixels ---------------------------------------------------------------------
+    const int lane_a = static_cast<int>(threadIdx.x) & 31, lane_b = static_cast<int>(threadIdx.x) >> 5;
+    const int c = c0 + lane_a;
+    const bool live_c = c < C;
+    int64_t sh[3] = {0, 0, 0};
+    CT dw[3] = {CT(0), CT(0), CT(0)};
+    {
+        const int wcol[3] = {-1, 0, 1};
+        CT wv[3];
+        load_weights3<CT>(p.w, p.wkind, static_cast<int64_t>(live_c ? c : C - 1) * 2, wcol, wv);
+        prep_shift_backward<CT>(wv[1], ACTIVE, sh[1], dw[0]);
+        prep_shift_backward<CT>(wv[2], ACTIVE, sh[2], dw[1]);
+    }
+    const int csxH = canon_shift(sh[1], H, p.pad, p.d_perH), csxW = canon_shift(sh[2], W, p.pad, p.d_perW);
+    // grad_x source: the sparse shift reads grad_out at o + shift, the active one at o - shift (shifts_kernels.h:287-293)
+    const int csgH = canon_shift(ACTIVE ? sh[1] : -sh[1], H, p.pad, p.d_perH), csgW = canon_shift(ACTIVE ? sh[2] : -sh[2], W, p.pad, p.d_perW);
+    const int perH = map_period(H, p.pad), perW = map_period(W, p.pad);
+    const int sh_s = (perH && 2 * csxH > perH) ? csxH - perH : csxH, sw_s = (perW && 2 * csxW > perW) ? csxW - perW : csxW;
+    const bool in_ring = sh_s >= -kR && sh_s <= kR && sw_s >= -kR && sw_s <= kR;
+    const bool near_c = live_c && in_ring, far_c = live_c && !in_ring;
+    auto fold_h = [&](int idx) { return H == 1 ? 0 : fold_index(idx, H, p.pad); };   // size-1 dims ignore the shift
+    auto fold_w = [&](int idx) { return W == 1 ? 0 : fold_index(idx, W, p.pad); };
+    // per pixel: LDS byte offsets (within a ring row) of the input corners' columns and of the gradient taps' columns; -1: padding.
+    // A reflected corner can land one step outside the rings (reflect padding, last column / row, shift -R: the
+    // corner at distance R + 1 comes back at distance -(R + 1)); such pixels (`scol`) and rows (`skip` below) are left
+    // to the element-by-element pass at the end.
+    int xc0[2], xc1[2], gc0[2], gc1[2], gd[2];
+    uint32_t ooff[2];
+    bool live[2], scol[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int col = lane_b + 8 * i, wq = w0 + min(col, W - 1 - w0);
+        const int a0 = fold_w(wq - csxW), a1 = fold_w(wq - csxW + 1), b0 = fold_w(wq - csgW), b1 = ACTIVE ? fold_w(wq - csgW + 1) : -1;
+        auto outside = [&](int sx) { return sx >= 0 && (sx < w0 - kR || sx > w0 + kBTW + kR); };
+        scol[i] = near_c && w0 + col < W && (outside(a0) || outside(a1) || outside(b0) || outside(b1));
+        live[i] = near_c && w0 + col < W && !scol[i];
+        auto lds_col = [&](int sx) { return (live[i] && sx >= 0) ? (sx - (w0 - kR)) * (kPitch * 4) + lane_a * 4 : -1; };
+        xc0[i] = lds_col(a0);
+        xc1[i] = lds_col(a1);
+        gc0[i] = lds_col(b0);
+        gc1[i] = lds_col(b1);
+        gd[i] = (col + kR) * (kPitch * 4) + lane_a * 4;
+        ooff[i] = live[i] ? (static_cast<uint32_t>(h0 * W + w0 + col) * C + c) * ES : kOutOfRange;
+    }
+    const uint32_t ostep = static_cast<uint32_t>(W) * C * ES;
+
+#pragma unroll
+    for (int r = 0; r <= 2 * kR; ++r) {
+        const int y = h0 - kR + r;
+        if (y >= 0 && y < H) store_row(y, prex[r], preg[r]);
+    }
+    const char *ringx = reinterpret_cast<const char *>(ring), *ringg = ringx + kBRingWords * 4;
+    double acc[2] = {0.0, 0.0};
+    auto lds_f = [&](const char *base, int row, int colo) {   // a staged element, zero where the padding map says so
+        const bool ok = row >= 0 && colo >= 0;
+        const float v = *reinterpret_cast<const float *>(base + (ok ? row + colo : 0));
+        return ok ? v : 0.0f;
+    };
+    auto row_off = [&](int sy) { return sy < 0 ? -1 : (sy & (kBRing - 1)) * (kBRowWords * 4); };
+    // Source rows with ONE fold of the signed shift (|shift| <= R and H >= 5, or H == 1: the host routes nothing else
+    // here): idx in [h - R, h + R + 1] leaves [0, H) by at most R + 1 on one side.  Launch-uniform coefficients instead of
+    // fold_index's switch: r = idx inside, aLo - m idx below, aHi - m idx above (border: m = 0; reflect / symmetric:
+    // m = 1), -1 outside for the zero padding.
+    const int fm = (p.pad == 3 || p.pad == 4) ? -1 : 0;
+    const int fLo = p.pad == 4 ? -1 : 0, fHi = p.pad == 1 ? H - 1 : (p.pad == 3 ? 2 * H - 2 : 2 * H - 1);
+    const bool fzero = p.pad == 0;
+    auto fold1 = [&](int idx) {
+        const bool lo = idx < 0, hi = idx >= H;
+        const int t = idx & fm;
+        int r = lo ? fLo - t : (hi ? fHi - t : idx);
+        r = (fzero && (lo || hi)) ? -1 : r;
+        return H == 1 ? 0 : r;
+    };
+    // the one source row the rings cannot hold: reflect padding, last output row, shift -R (its + 1 corner, at distance
+    // R + 1, comes back at distance -(R + 1))
+    const bool srow = near_c && p.pad == 3 && H > 1 && sh_s == -kR && h1 == H;
+    int xrow1 = fold1(h0 - sh_s);   // the + 1 corner of step h - 1 is the first corner of step h
+    auto step = [&](int h, u4 &vx, u4 &vg) {
+        __syncthreads();  // everybody is done with the slot that row h + R + 1 replaces (row h - R - 1)
+        if (h + kR + 1 < H) store_row(h + kR + 1, vx, vg);
+        __syncthreads();
+        load_row(h + kDepth + kR + 1, ylast, vx, vg);
+        const uint32_t so = static_cast<uint32_t>(h - h0) * ostep;
+        const int xr0 = row_off(xrow1);
+        xrow1 = fold1(h + 1 - sh_s);
+        const int xr1 = row_off(xrow1);
+        const int gr0 = ACTIVE ? xr0 : row_off(fold1(h + sh_s)), gr1 = ACTIVE ? xr1 : -1;
+        const int gdr = (h & (kBRing - 1)) * (kBRowWords * 4);
+        const bool skip = srow && h == H - 1;
+        float res[2], s0 = 0.0f, s1 = 0.0f;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            CT v[4], wg[3];
+            v[0] = lds_f(ringx, xr0, xc0[i]);
+            v[1] = lds_f(ringx, xr1, xc0[i]);
+            v[2] = lds_f(ringx, xr0, xc1[i]);
+            v[3] = lds_f(ringx, xr1, xc1[i]);
+            const float graw = *reinterpret_cast<const float *>(ringg + gdr + gd[i]);
+            const float gval = (live[i] && !skip) ? graw : 0.0f;
+            weight_grads_nd<2, CT>(v, dw, wg);
+            s0 += gval * wg[0];
+            s1 += gval * wg[1];
+            if constexpr (ACTIVE) {
+                v[0] = lds_f(ringg, gr0, gc0[i]);
+                v[1] = lds_f(ringg, gr1, gc0[i]);
+                v[2] = lds_f(ringg, gr0, gc1[i]);
+                v[3] = lds_f(ringg, gr1, gc1[i]);
+                res[i] = interp_t<T, 2>(v, dw);
+            } else {
+                res[i] = lds_f(ringg, gr0, gc0[i]);   // pure copy: the bit pattern is kept
+            }
+        }
+        acc[0] += static_cast<double>(s0);   // (the two pixels' terms are added in fp32 first)
+        acc[1] += static_cast<double>(s1);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(res[i]), ores, skip ? kOutOfRange : ooff[i], so, 0);
+    };
+    int hb = h0;
+    for (; hb + kDepth <= h1; hb += kDepth) {   // whole groups: no condition between the steps (exact wait counts)
+#pragma unroll
+        for (int d = 0; d < kDepth; ++d) step(hb + d, pvx[d], pvg[d]);
+    }
+#pragma unroll
+    for (int d = 0; d < kDepth - 1; ++d)
+        if (hb + d < h1) step(hb + d, pvx[d], pvg[d]);
+
+    // ---- what the rings could not serve: channels whose shift leaves them, and the reflected corners above; everything
+    // from memory, element by element (rare) ------------------------------------------------------------------------------
+    if (live_c && (far_c || scol[0] || scol[1] || srow)) {
+        const float *xe = reinterpret_cast<const float *>(xn) + c, *ge = reinterpret_cast<const float *>(gn) + c;
+        float *oe = reinterpret_cast<float *>(on) + c;
+        auto tap = [&](const float *base, int r, int cc) { return (r >= 0 && cc >= 0) ? base[(static_cast<int64_t>(r) * W + cc) * C] : 0.0f; };
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int wq = w0 + lane_b + 8 * i;
+            if (wq >= W) continue;
+            const int a0 = fold_w(wq - csxW), a1 = fold_w(wq - csxW + 1), b0 = fold_w(wq - csgW), b1 = fold_w(wq - csgW + 1);
+            for (int h = h0; h < h1; ++h) {
+                if (!(far_c || scol[i] || (srow && h == H - 1))) continue;
+                const int r0 = fold_h(h - csxH), r1 = fold_h(h - csxH + 1), s0 = fold_h(h - csgH), s1 = fold_h(h - csgH + 1);
+                CT v[4] = {tap(xe, r0, a0), tap(xe, r1, a0), tap(xe, r0, a1), tap(xe, r1, a1)}, wg[3];
+                const float gval = ge[(static_cast<int64_t>(h) * W + wq) * C];
+                weight_grads_nd<2, CT>(v, dw, wg);
+                acc[0] += static_cast<double>(gval * wg[0]);
+                acc[1] += static_cast<double>(gval * wg[1]);
+                float r;
+                if constexpr (ACTIVE) {
+                    CT u[4] = {tap(ge, s0, b0), tap(ge, s1, b0), tap(ge, s0, b1), tap(ge, s1, b1)};
+                    r = interp_t<T, 2>(u, dw);
+                } else {
+                    r = tap(ge, s0, b0);
+                }
+                oe[(static_cast<int64_t>(h) * W + wq) * C] = r;
+            }
+        }
+    }
+
+    // ---- the workgroup's weight-gradient partial sums: pixel lanes of each channel, in lane order -----------------------
+    __syncthreads();
+    double *red = reinterpret_cast<double *>(ring);   // the rings are dead
+    red[threadIdx.x * 2] = acc[0];
+    red[threadIdx.x * 2 + 1] = acc[1];
+    __syncthreads();
+    if (lane_b == 0 && live_c) {
+        double t0 = 0.0, t1 = 0.0;
+        for (int k = 0; k < kThreads / 32; ++k) {
+            t0 += red[(k * 32 + lane_a) * 2];
+            t1 += red[(k * 32 + lane_a) * 2 + 1];
+        }
+        double *dst = p.partials + (static_cast<size_t>(pidx) * C + c) * 3;
+        dst[0] = t0;
+        dst[1] = t1;
+        dst[2] = 0.0;
+    }
+}
+
 thread_local int g_cl_tiled_tune[2] = {1, 0};  // [0] enabled, [1] rows per band (0 = automatic)
 
 bool dense_channels_last_2d(const int64_t st[5], const Geometry &g, const int64_t sz[3]) {
@@ -365,6 +631,87 @@ int cl_tiled_forward(const Geometry &g, int dtype, const void *x, const void *w,
     else if (es == 2) { SHIFTND_CLT_LAUNCH(2) }
     else { SHIFTND_CLT_LAUNCH(1) }
 #undef SHIFTND_CLT_LAUNCH
+    return SHIFTND_OK;
+}
+
+// ---- backward ------------------------------------------------------------------------------------------------------
+namespace {
+struct ClTiledBwdPlan {
+    int wtiles, cblocks, bands, band_rows;
+    int64_t groups;
+};
+ClTiledBwdPlan cl_tiled_backward_plan(const Geometry &g) {
+    ClTiledBwdPlan pl;
+    const int H = static_cast<int>(g.S[1]), W = static_cast<int>(g.S[2]);
+    pl.wtiles = (W + kBTW - 1) / kBTW;
+    pl.cblocks = static_cast<int>((g.C + 31) / 32);
+    // bands along H: ~7 workgroups per workgroup slot, at least 8 R rows per band, and (when the batch allows) at most
+    // 4096 partial-sum groups per channel
+    const int64_t base = g.N * pl.wtiles;
+    int64_t bands = g_cl_tiled_tune[1] > 0 ? (H + g_cl_tiled_tune[1] - 1) / g_cl_tiled_tune[1] : (7168 + base * pl.cblocks - 1) / (base * pl.cblocks);
+    const int64_t max_bands = H / (8 * kR) > 0 ? H / (8 * kR) : 1;
+    if (g_cl_tiled_tune[1] <= 0) {
+        if (bands > max_bands) bands = max_bands;
+        while (bands > 1 && base * bands > 4096) --bands;
+    }
+    if (bands < 1) bands = 1;
+    pl.band_rows = static_cast<int>((H + bands - 1) / bands);
+    pl.bands = (H + pl.band_rows - 1) / pl.band_rows;
+    pl.groups = base * pl.bands;
+    return pl;
+}
+}  // namespace
+
+// 2-D fp32, no crop, not periodic; saved input, incoming gradient and grad_x dense channels-last, C a multiple of 4
+bool cl_tiled_backward_eligible(const Geometry &g, int dtype, const void *go, const void *x, const void *gx) {
+    if (!g_cl_tiled_tune[0] || g.nd != 2 || dtype != SHIFTND_F32 || g.pad == 2) return false;
+    for (int d = 0; d < 3; ++d)
+        if (g.L[d] != 0 || g.O[d] != g.S[d]) return false;
+    if (g.C % 4 != 0 || g.S[1] >= (1 << 20) || g.S[2] >= (1 << 20) || g.N >= (1LL << 24) || g.C >= (1 << 24)) return false;
+    if (g.S[1] != 1 && g.S[1] < 5) return false;  // the kernel folds source rows once
+    if (reinterpret_cast<uintptr_t>(x) % 16 != 0 || reinterpret_cast<uintptr_t>(go) % 16 != 0 || reinterpret_cast<uintptr_t>(gx) % 4 != 0) return false;
+    if (g.C * g.S[1] * g.S[2] * 4 >= (1LL << 31)) return false;
+    if (!dense_channels_last_2d(g.xs, g, g.S) || !dense_channels_last_2d(g.os, g, g.O) || !dense_channels_last_2d(g.gs, g, g.S)) return false;
+    const ClTiledBwdPlan pl = cl_tiled_backward_plan(g);
+    return pl.groups * pl.cblocks < (1LL << 31);
+}
+
+size_t cl_tiled_backward_workspace(const Geometry &g) {
+    if (g.nd != 2 || g.C < 1 || g.N * g.S[1] * g.S[2] < 1) return 0;
+    const ClTiledBwdPlan pl = cl_tiled_backward_plan(g);
+    return static_cast<size_t>(pl.groups) * static_cast<size_t>(g.C) * 3 * sizeof(double);
+}
+
+int cl_tiled_backward(const Geometry &g, int dtype, const void *go, const void *x, const void *w, void *gx, void *gw,
+                      void *workspace, hipStream_t st) {
+    const ClTiledBwdPlan pl = cl_tiled_backward_plan(g);
+    ClTiledBwdParams p{};
+    p.x = static_cast<const char *>(x);
+    p.go = static_cast<const char *>(go);
+    p.gx = static_cast<char *>(gx);
+    p.w = w;
+    p.wkind = dtype;
+    p.partials = static_cast<double *>(workspace);
+    p.N = static_cast<int>(g.N);
+    p.C = static_cast<int>(g.C);
+    p.H = static_cast<int>(g.S[1]);
+    p.W = static_cast<int>(g.S[2]);
+    p.pad = g.pad;
+    p.wtiles = pl.wtiles;
+    p.cblocks = pl.cblocks;
+    p.bands = pl.bands;
+    p.band_rows = pl.band_rows;
+    p.d_wtiles = make_fastdiv(static_cast<uint32_t>(p.wtiles));
+    p.d_cblocks = make_fastdiv(static_cast<uint32_t>(p.cblocks));
+    p.d_bands = make_fastdiv(static_cast<uint32_t>(p.bands));
+    p.d_perH = make_fastdiv(static_cast<uint32_t>(map_period(p.H, p.pad)));
+    p.d_perW = make_fastdiv(static_cast<uint32_t>(map_period(p.W, p.pad)));
+    const dim3 grid(static_cast<unsigned>(pl.groups * pl.cblocks)), block(kThreads);
+    note_kernel("cl_tiled_backward");
+    if (g.active) hipLaunchKernelGGL((cl_tiled_backward<f32_t, true>), grid, block, 0, st, p);
+    else hipLaunchKernelGGL((cl_tiled_backward<f32_t, false>), grid, block, 0, st, p);
+    hipLaunchKernelGGL((reduce_weight_grads<f32_t>), dim3(p.C * 2), dim3(64), 0, st, p.partials, static_cast<int>(pl.groups), p.C, 2,
+                       static_cast<float *>(gw));
     return SHIFTND_OK;
 }
 

@@ -89,6 +89,11 @@ bool cl_tiled_forward_eligible(const Geometry &g, int dtype, const void *x, cons
 int cl_tiled_forward(const Geometry &g, int dtype, const void *x, const void *w, int wkind, int64_t wzp, uint64_t fill_bits, void *out,
                      hipStream_t st);
 void cl_tiled_set_tuning(int knob, int value);
+// ... and the backward of 2-D fp32 problems whose three tensors are all dense channels-last
+bool cl_tiled_backward_eligible(const Geometry &g, int dtype, const void *go, const void *x, const void *gx);
+size_t cl_tiled_backward_workspace(const Geometry &g);
+int cl_tiled_backward(const Geometry &g, int dtype, const void *go, const void *x, const void *w, void *gx, void *gw,
+                      void *workspace, hipStream_t st);
 
 // ---- layout change (shiftnd_transpose.hip): dst[n][c][r] = src[n][r][c], dense tensors ---------------------------
 int transpose_planes(const void *src, void *dst, int64_t N, int64_t rows, int64_t cols, int esize, hipStream_t st);

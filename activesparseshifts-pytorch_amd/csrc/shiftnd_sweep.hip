@@ -480,6 +480,8 @@ void set_grid(SweepParams &p, uint64_t blocks) {
 // last wave as possible (e.g. 56 chunks per row -> 448 threads = 7 full waves = 8 rows).
 void plan_shape(SweepParams &p, uint32_t cpr, uint32_t rows, int64_t planes, int k_want, int t_want, int k_cap) {
     const uint32_t tmax = static_cast<uint32_t>(t_want < 64 ? 64 : (t_want > kSweepMaxThreads ? kSweepMaxThreads : t_want));
+    if (cpr < 1) cpr = 1;  // only reachable for ineligible geometries (workspace sizing of rows shorter than 16 bytes)
+    if (rows < 1) rows = 1;
     p.cpr = cpr;
     p.rows = rows;
     p.CW = cpr < tmax ? cpr : tmax;

@@ -29,3 +29,18 @@ def test_arithmetic_map_huge_shifts():
                                                                                -(2 ** 33) - 11, 2 ** 40 + 1, 2 ** 30, -(2 ** 30))):
         for p in (0, 1, length // 2, length - 1, length):
             assert L.shiftnd_debug_map(p, s, length, pad) == _ref(p, s, length, pad), (pad, length, s, p)
+
+
+def test_workspace_query_tiny_shapes():
+    """shiftnd_backward_workspace_bytes plans every kernel family on the host: rows shorter than one 16-byte chunk
+    (W = 1..3 fp32) once divided by a zero chunk count there (SIGFPE).  Every dtype, 1-3 dims, sizes 1..5."""
+    import torch
+    for dt in (torch.float32, torch.float64, torch.float16, torch.bfloat16):
+        for shape in itertools.chain(itertools.product((1, 3), (1, 4), (1, 2, 5)),
+                                     itertools.product((1, 2), (1, 32), (1, 64), (1, 2, 3)),
+                                     itertools.product((2,), (1, 3), (1, 2), (1, 5), (1, 2))):
+            x = torch.zeros(*shape, dtype=dt)
+            for pad in range(5):
+                for active in (0, 1):
+                    ws = abi.backward_workspace(x, pad, active)
+                    assert ws.numel() >= shape[0] * shape[1] * 3 * 8 // 8  # at least one group of partial sums

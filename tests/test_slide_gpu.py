@@ -242,6 +242,43 @@ def test_tiled_channels_last_forward_small_elements(shape):
         abi.set_tuning(21, 0)
 
 
+@pytest.mark.parametrize("shape", [(2, 8, 9, 12), (3, 300, 6, 5), (2, 64, 40, 70), (1, 36, 100, 33), (2, 4, 1, 50), (1, 32, 64, 1)])
+def test_tiled_channels_last_backward_vs_oracle(shape):
+    """cl_tiled_backward (csrc/shiftnd_cl_tiled.hip): fp32, saved input / grad_out / grad_x all dense channels-last;
+    sparse and active shifts, every padding it serves, shifts beyond the ring, ragged tiles / channel blocks / bands;
+    grad_x bit-exact, grad_w within 1e-5 of the fp64 oracle"""
+    from torchshifts import abi
+    rs = np.random.RandomState(sum(shape) + 5)
+    x = rs.uniform(-1, 1, size=shape).astype(np.float32)
+    go = rs.uniform(-1, 1, size=shape).astype(np.float32)
+    w = rs.uniform(-3.4, 3.4, size=(shape[1], 2)).astype(np.float32)
+    w[0] = [0.5, -1.5]
+    w[1] = [shape[2] + 2.25, -7.0]       # beyond the dim / beyond the ring
+    w[2] = [-5.0, 2.5]
+    w[3] = [3.0, -3.0]
+    cl = torch.channels_last
+    xd = torch.from_numpy(x).to(DEV).contiguous(memory_format=cl)
+    god = torch.from_numpy(go).to(DEV).contiguous(memory_format=cl)
+    wd = torch.from_numpy(w).to(DEV)
+    try:
+        for band_rows in (0, 5):
+            abi.set_tuning(21, band_rows)
+            for pad in (0, 1, 3, 4):
+                for active in (0, 1):
+                    gx_o, _ = O.backward(go, w, x, pad, active)
+                    _, gw64 = O.backward(go.astype(np.float64), w.astype(np.float64), x.astype(np.float64), pad, active)
+                    gxd = torch.empty(shape, device=DEV).contiguous(memory_format=cl)
+                    gx, gw = abi.backward(god, wd, xd, pad, active, grad_x=gxd)
+                    assert abi.last_kernel() == "cl_tiled_backward", (shape, pad, active)
+                    assert np.array_equal(gx.cpu().numpy(), gx_o), (shape, pad, active, band_rows)
+                    assert rel_err(gw.cpu().numpy(), gw64) < 1e-5, (shape, pad, active, band_rows)
+        abi.set_tuning(21, 0)
+        abi.backward(god, wd, xd, 2, 0, grad_x=torch.empty(shape, device=DEV).contiguous(memory_format=cl))
+        assert abi.last_kernel() != "cl_tiled_backward"  # periodic
+    finally:
+        abi.set_tuning(21, 0)
+
+
 def test_channels_last_input_through_the_op_uses_the_tiled_kernel():
     """torch.ops.torchshifts.shift2d with a channels-last fp32 input: one pass (no layout change first), NCHW result
     like the reference (cpu/shifts_cpu.cpp:221), same bits as the contiguous input"""

@@ -193,6 +193,16 @@ int shiftnd_forward_serves_channels_last(const shiftnd_problem *p, const void *x
     return cl_tiled_forward_eligible(g, p->dtype, x, out) ? 1 : 0;
 }
 
+int shiftnd_backward_serves_channels_last(const shiftnd_problem *p, const void *grad_out, const int64_t grad_out_strides[5],
+                                          const void *x, const int64_t x_strides[5], const void *grad_x,
+                                          const int64_t grad_x_strides[5]) {
+    if (!p || !grad_out_strides || !x_strides || !grad_x_strides || g_policy != 0 || !is_float_dtype(p->dtype)) return 0;
+    Geometry g;
+    if (build_geometry(p, x_strides, grad_out_strides, grad_x_strides, g) != SHIFTND_OK) return 0;
+    if (g.N == 0 || g.C == 0 || g.S[0] * g.S[1] * g.S[2] == 0) return 0;
+    return cl_tiled_backward_eligible(g, p->dtype, grad_out, x, grad_x) ? 1 : 0;
+}
+
 int shiftnd_forward(const shiftnd_problem *p, const void *x, const int64_t x_strides[5], const void *weights, void *out,
                     const int64_t out_strides[5], void *stream) {
     if (!p || !x_strides || !out_strides) return SHIFTND_ERR_INVALID_ARGUMENT;

@@ -263,17 +263,30 @@ std::tuple<Tensor, Tensor> shift_backward_hip(const Tensor &grad_, const Tensor 
     TORCH_CHECK(input_.dim() == ND + 2 && grad_.dim() == ND + 2, "shift", ND, "d backward: expected ", ND + 2, "-D tensors");
     if (padding_mode < 0 || padding_mode > 4) return std::make_tuple(Tensor(), Tensor());
     c10::DeviceGuard device_guard(grad_.device());
-    // channels-last saved input / incoming gradient: change the layout once, then the contiguous kernels (see above)
-    const Tensor input = is_channels_last_dense(input_) ? channels_last_to_contiguous(input_) : input_;
-    const Tensor grad = is_channels_last_dense(grad_) ? channels_last_to_contiguous(grad_) : grad_;
-    const int dtype = to_shiftnd_dtype(grad.scalar_type(), "shiftnd_backward_cuda");
     int32_t b[6];
     read_borders(borders, b);
     for (int r = 0; r < ND; ++r)
-        TORCH_CHECK(grad.size(2 + r) == b[2 * r + 1] - b[2 * r], "shift", ND, "d backward: grad does not match borders");
+        TORCH_CHECK(grad_.size(2 + r) == b[2 * r + 1] - b[2 * r], "shift", ND, "d backward: grad does not match borders");
+    const int dtype = to_shiftnd_dtype(grad_.scalar_type(), "shiftnd_backward_cuda");
     Tensor w = weights.contiguous();
-    Tensor grad_input = at::empty_like(input, at::MemoryFormat::Contiguous);
     Tensor grad_weights = at::empty_like(w, at::MemoryFormat::Contiguous);
+    // saved input and incoming gradient both dense channels-last: the library may have a kernel for that layout
+    // (shiftnd_cl_tiled.hip; grad_x is channels-last too); otherwise change the layout once, then the contiguous kernels
+    bool direct = false;
+    Tensor grad_input;
+    if (is_channels_last_dense(input_) && is_channels_last_dense(grad_)) {
+        grad_input = at::empty_like(input_, input_.suggest_memory_format());
+        shiftnd_problem pd;
+        fill_problem(pd, ND, input_, b, padding_mode, active_flag, dtype);
+        int64_t gd[5], xd[5], gxd[5];
+        fill_strides(grad_, ND, gd);
+        fill_strides(input_, ND, xd);
+        fill_strides(grad_input, ND, gxd);
+        direct = shiftnd_backward_serves_channels_last(&pd, grad_.data_ptr(), gd, input_.data_ptr(), xd, grad_input.data_ptr(), gxd) != 0;
+    }
+    const Tensor input = (is_channels_last_dense(input_) && !direct) ? channels_last_to_contiguous(input_) : input_;
+    const Tensor grad = (is_channels_last_dense(grad_) && !direct) ? channels_last_to_contiguous(grad_) : grad_;
+    if (!direct) grad_input = at::empty_like(input, at::MemoryFormat::Contiguous);
     shiftnd_problem p;
     fill_problem(p, ND, input, b, padding_mode, active_flag, dtype);
     const size_t ws_bytes = shiftnd_backward_workspace_bytes(&p);

@@ -21,7 +21,8 @@ DTYPES = {torch.float32: F32, torch.float64: F64, torch.float16: F16, torch.bflo
 
 EXPORTS = ["shiftnd_abi_version", "shiftnd_status_string", "shiftnd_last_path", "shiftnd_set_path_policy",
            "shiftnd_set_tuning", "shiftnd_debug_map", "shiftnd_last_kernel",
-           "shiftnd_check_borders", "shiftnd_forward", "shiftnd_forward_serves_channels_last", "shiftnd_backward_workspace_bytes", "shiftnd_backward",
+           "shiftnd_check_borders", "shiftnd_forward", "shiftnd_forward_serves_channels_last", "shiftnd_backward_serves_channels_last",
+           "shiftnd_backward_workspace_bytes", "shiftnd_backward",
            "shiftnd_forward_quantized", "shiftnd_pooled_sizes", "shiftnd_backward_pooled_workspace_bytes", "shiftnd_forward_pooled", "shiftnd_backward_pooled", "shiftnd_transpose"]
 
 
@@ -55,6 +56,8 @@ def lib():
         L.shiftnd_forward.argtypes = [ctypes.POINTER(Problem), vp, i64p, vp, vp, i64p, vp]
         L.shiftnd_forward_serves_channels_last.restype = ctypes.c_int
         L.shiftnd_forward_serves_channels_last.argtypes = [ctypes.POINTER(Problem), vp, i64p, vp, i64p]
+        L.shiftnd_backward_serves_channels_last.restype = ctypes.c_int
+        L.shiftnd_backward_serves_channels_last.argtypes = [ctypes.POINTER(Problem), vp, i64p, vp, i64p, vp, i64p]
         L.shiftnd_backward_workspace_bytes.restype = ctypes.c_size_t
         L.shiftnd_backward_workspace_bytes.argtypes = [ctypes.POINTER(Problem)]
         L.shiftnd_backward.restype = ctypes.c_int

@@ -50,7 +50,7 @@
 extern "C" {
 #endif
 
-#define SHIFTND_ABI_VERSION 3
+#define SHIFTND_ABI_VERSION 4
 #define SHIFTND_API __attribute__((visibility("default")))
 
 typedef enum shiftnd_dtype {
@@ -126,6 +126,15 @@ SHIFTND_API int shiftnd_check_borders(const int64_t *sizes, int nsizes, const in
  */
 SHIFTND_API int shiftnd_forward_serves_channels_last(const shiftnd_problem *p, const void *x, const int64_t x_strides[5],
                                                      const void *out, const int64_t out_strides[5]);
+
+/*
+ * The same question for shiftnd_backward: 1 when the saved input, the incoming gradient and grad_x, all dense
+ * channels-last as their strides say, are served by a kernel made for that layout (no layout change needed).
+ */
+SHIFTND_API int shiftnd_backward_serves_channels_last(const shiftnd_problem *p, const void *grad_out,
+                                                      const int64_t grad_out_strides[5], const void *x,
+                                                      const int64_t x_strides[5], const void *grad_x,
+                                                      const int64_t grad_x_strides[5]);
 
 /*
  * Forward, float dtypes (F32, F64, F16, BF16).

@@ -290,3 +290,25 @@ def test_channels_last_input_through_the_op_uses_the_tiled_kernel():
     ref = torch.ops.torchshifts.shift2d(x, w, torch.Tensor(), 3, False)
     out = torch.ops.torchshifts.shift2d(x.contiguous(memory_format=torch.channels_last), w, torch.Tensor(), 3, False)
     assert abi.last_kernel() == "cl_tiled_forward" and out.is_contiguous() and torch.equal(out, ref)
+
+
+@pytest.mark.parametrize("active", [False, True])
+def test_channels_last_backward_through_the_op_uses_the_tiled_kernel(active):
+    """torch.ops.torchshifts._shift2d_backward with channels-last fp32 saved input and incoming gradient: one pass (no
+    layout change), grad_x channels-last, same values as the contiguous call"""
+    import torchshifts  # noqa: F401
+    from torchshifts import abi
+    torch.manual_seed(5)
+    cl = torch.channels_last
+    x = torch.rand(4, 64, 56, 56, device=DEV)
+    go = torch.rand(4, 64, 56, 56, device=DEV)
+    w = (torch.rand(64, 2, device=DEV) - 0.5) * 6
+    b6 = torch.tensor([0, 56, 0, 56, 0, 1], dtype=torch.int32)
+    op = torch.ops.torchshifts._shift2d_backward
+    gx_r, gw_r = op(go, w, x, b6, 3, active)
+    gx, gw = op(go.contiguous(memory_format=cl), w, x.contiguous(memory_format=cl), b6, 3, active)
+    assert abi.last_kernel() == "cl_tiled_backward" and gx.is_contiguous(memory_format=cl)
+    assert torch.equal(gx, gx_r) and rel_err(gw.cpu().numpy(), gw_r.cpu().numpy()) < 1e-5
+    # a contiguous incoming gradient: the layout of the saved input is changed once, then the contiguous kernels
+    gx2, gw2 = op(go, w, x.contiguous(memory_format=cl), b6, 3, active)
+    assert abi.last_kernel() != "cl_tiled_backward" and torch.equal(gx2, gx_r)

@@ -555,6 +555,236 @@ __global__ __launch_bounds__(kThreads) void cl_tiled_backward(const ClTiledBwdPa
     }
 }
 
+// =====================================================================================================
+// Active (interpolating) forward for dense channels-last fp32 inputs: out = interp of the four corners around
+// (o - floor(w)) (shifts_kernels.h:330-400 with :187-205).  The gather forward's tile (32 columns x 32 channels) with
+// a ring of rows h - R .. h + R + 1 and one more staged column for the + 1 corners; output channels-last or
+// NCHW-contiguous.  Roofline: HBM, 2 x 4 bytes per element.
+// =====================================================================================================
+constexpr int kAPW = kTW + 2 * kR + 1;         // staged pixels per row
+constexpr int kARing = 8;                      // staged rows h - R .. h + R + 1
+constexpr int kARowWords = kAPW * kPitch;
+constexpr int kAPieces = kAPW * (kLine / 16);  // 312
+constexpr int kANP = (kAPieces + kThreads - 1) / kThreads;
+
+template <typename T, bool OUT_CL>
+__global__ __launch_bounds__(kThreads) void cl_tiled_active_forward(const ClTiledParams p) {
+    typedef uint32_t u4 __attribute__((ext_vector_type(4)));
+    using S = typename T::S;
+    using CT = typename T::C;
+    static_assert(sizeof(S) == 4, "4-byte elements");
+    constexpr int ES = 4, CB = kLine / ES;
+    __shared__ uint32_t ring[kARing * kARowWords + 4];
+    __shared__ int tab_sh[CB], tab_sw[CB];     // signed row shift (or out of the ring: INT_MIN), canonical column shift
+    __shared__ int tab_shc[CB];                // canonical row shift (the element-by-element pass)
+    __shared__ float tab_dh[CB], tab_dw[CB];   // interpolation fractions
+    constexpr int kDump = kARing * kARowWords;
+    constexpr int kFarShift = -0x7fffffff - 1;
+
+    unsigned b = blockIdx.x;
+    const int wt = static_cast<int>(b - fdiv(b, p.d_wtiles) * p.wtiles);
+    b = fdiv(b, p.d_wtiles);
+    const int cb = static_cast<int>(b - fdiv(b, p.d_cblocks) * p.cblocks);
+    b = fdiv(b, p.d_cblocks);
+    const int band = static_cast<int>(b - fdiv(b, p.d_bands) * p.bands);
+    const int n = static_cast<int>(fdiv(b, p.d_bands));
+    const int w0 = wt * kTW, c0 = cb * CB;
+    const int h0 = band * p.band_rows, h1 = min(p.H, h0 + p.band_rows);
+    const int H = p.H, W = p.W, C = p.C;
+    const char *xn = p.x + static_cast<int64_t>(n) * H * W * C * ES;
+    char *on = p.out + static_cast<int64_t>(n) * H * W * C * ES;
+    const uint32_t img_bytes = static_cast<uint32_t>(H) * static_cast<uint32_t>(W) * static_cast<uint32_t>(C) * ES;
+    const __amdgpu_buffer_rsrc_t xres = __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(xn), 0, img_bytes, kBufferFlags);
+    const __amdgpu_buffer_rsrc_t xnone = __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(xn), 0, 0, kBufferFlags);
+    const __amdgpu_buffer_rsrc_t ores = __builtin_amdgcn_make_buffer_rsrc(on, 0, img_bytes, kBufferFlags);
+
+    // ---- staging (as in cl_tiled_forward) -----------------------------------------------------------------------------
+    uint32_t poff[kANP];
+    int pdst[kANP];
+#pragma unroll
+    for (int k = 0; k < kANP; ++k) {
+        const int q = k * kThreads + static_cast<int>(threadIdx.x);
+        const int px = q >> 3, cbyte = c0 * ES + (q & 7) * 16, gx = w0 - kR + px;
+        const bool piece = q < kAPieces;
+        poff[k] = (piece && gx >= 0 && gx < W && cbyte < C * ES) ? static_cast<uint32_t>(gx) * C * ES + cbyte : kOutOfRange;
+        pdst[k] = piece ? px * kPitch + (q & 7) * 4 : -1;
+    }
+    const uint32_t row_bytes = static_cast<uint32_t>(W) * C * ES;
+    constexpr int kDepth = CLT_DEPTH;
+    u4 pvs[kDepth][kANP];
+    auto load_row = [&](int y, int ylast, u4 (&pv)[kANP]) {
+        const bool wanted = y >= 0 && y <= ylast;
+        const __amdgpu_buffer_rsrc_t r = wanted ? xres : xnone;
+        const uint32_t so = wanted ? static_cast<uint32_t>(y) * row_bytes : 0u;
+#pragma unroll
+        for (int k = 0; k < kANP; ++k) pv[k] = __builtin_amdgcn_raw_buffer_load_b128(r, poff[k], so, 0);
+    };
+    auto store_row = [&](int y, const u4 (&pv)[kANP]) {
+        const int slot = y & (kARing - 1);
+#pragma unroll
+        for (int k = 0; k < kANP; ++k) {
+            uint32_t *d = ring + (pdst[k] >= 0 ? slot * kARowWords + pdst[k] : kDump);
+            d[0] = pv[k].x;
+            d[1] = pv[k].y;
+            d[2] = pv[k].z;
+            d[3] = pv[k].w;
+        }
+    };
+    const int ylast = min(H - 1, h1 + kR);
+    u4 pre[2 * kR + 1][kANP];
+#pragma unroll
+    for (int d = 0; d < kDepth; ++d) load_row(h0 + kR + 1 + d, ylast, pvs[d]);
+#pragma unroll
+    for (int r = 0; r <= 2 * kR; ++r) load_row(h0 - kR + r, ylast, pre[r]);
+
+    // ---- the channels' shifts ------------------------------------------------------------------------------------------
+    const int perH = map_period(H, p.pad), perW = map_period(W, p.pad);
+    if (threadIdx.x < CB) {
+        const int c = min(c0 + static_cast<int>(threadIdx.x), C - 1);
+        const int wcol[3] = {-1, 0, 1};
+        CT wv[3], dh, dwf;
+        int64_t sh2[2];
+        load_weights3<CT>(p.w, p.wkind, static_cast<int64_t>(c) * 2, wcol, wv);
+        prep_shift_forward<CT>(wv[1], true, sh2[0], dh);
+        prep_shift_forward<CT>(wv[2], true, sh2[1], dwf);
+        const int sh = canon_shift(sh2[0], H, p.pad, p.d_perH), sw = canon_shift(sh2[1], W, p.pad, p.d_perW);
+        const int sh_s = (perH && 2 * sh > perH) ? sh - perH : sh, sw_s = (perW && 2 * sw > perW) ? sw - perW : sw;
+        const bool in_ring = sh_s >= -kR && sh_s <= kR && sw_s >= -kR && sw_s <= kR;
+        tab_sh[threadIdx.x] = in_ring ? sh_s : kFarShift;
+        tab_shc[threadIdx.x] = sh;
+        tab_sw[threadIdx.x] = sw;
+        tab_dh[threadIdx.x] = dh;
+        tab_dw[threadIdx.x] = dwf;
+    }
+    __syncthreads();
+
+    // ---- thread -> outputs: OUT_CL one channel (lane % 32), columns pl + 8 i; else one column, channels cl + 8 i ---------
+    const int lane_a = static_cast<int>(threadIdx.x) & 31, lane_b = static_cast<int>(threadIdx.x) >> 5;
+    constexpr int NCH = OUT_CL ? 1 : 4;
+    auto fold_w = [&](int idx) { return W == 1 ? 0 : fold_index(idx, W, p.pad); };
+    auto fold_h = [&](int idx) { return H == 1 ? 0 : fold_index(idx, H, p.pad); };
+    int shs[NCH];              // signed row shift of the thread's channel(s)
+    CT dws[NCH][2];
+    bool srow[NCH];
+    int xc0[4], xc1[4];        // LDS byte offsets (within a ring row) of the corners' columns; -1: padding
+    uint32_t ooff[4];
+    uint32_t live = 0, rest = 0;   // bit i: served from the ring / left to the element-by-element pass (all rows)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int ch = OUT_CL ? lane_a : lane_b + 8 * i, col = OUT_CL ? lane_b + 8 * i : lane_a;
+        const int c = c0 + ch, k = OUT_CL ? 0 : i;
+        const bool inside = c < C && w0 + col < W;
+        const int s = tab_sh[ch], sw = tab_sw[ch];
+        shs[k] = s == kFarShift ? 0 : s;
+        dws[k][0] = tab_dh[ch];
+        dws[k][1] = tab_dw[ch];
+        // the one source row the ring cannot hold: reflect padding, last output row, shift -R (see cl_tiled_backward)
+        srow[k] = c < C && s != kFarShift && p.pad == 3 && H > 1 && s == -kR && h1 == H;
+        const int wq = w0 + min(col, W - 1 - w0);
+        const int a0 = fold_w(wq - sw), a1 = fold_w(wq - sw + 1);
+        auto outside = [&](int sx) { return sx >= 0 && (sx < w0 - kR || sx > w0 + kTW + kR); };
+        const bool mine = inside && s != kFarShift && !outside(a0) && !outside(a1);
+        live |= (mine ? 1u : 0u) << i;
+        rest |= ((inside && !mine) ? 1u : 0u) << i;
+        auto lds_col = [&](int sx) { return (mine && sx >= 0) ? (sx - (w0 - kR)) * (kPitch * 4) + ch * 4 : -1; };
+        xc0[i] = lds_col(a0);
+        xc1[i] = lds_col(a1);
+        const uint32_t o = OUT_CL ? (static_cast<uint32_t>(h0 * W + w0 + col) * C + c) * ES
+                                  : (static_cast<uint32_t>(c * H + h0) * W + w0 + col) * ES;
+        ooff[i] = mine ? o : kOutOfRange;
+    }
+    const uint32_t ostep = static_cast<uint32_t>(OUT_CL ? W * C : W) * ES;
+
+#pragma unroll
+    for (int r = 0; r <= 2 * kR; ++r) {
+        const int y = h0 - kR + r;
+        if (y >= 0 && y < H) store_row(y, pre[r]);
+    }
+    const char *ringx = reinterpret_cast<const char *>(ring);
+    auto lds_f = [&](int row, int colo) {
+        const bool ok = row >= 0 && colo >= 0;
+        const float v = *reinterpret_cast<const float *>(ringx + (ok ? row + colo : 0));
+        return ok ? v : 0.0f;
+    };
+    auto row_off = [&](int sy) { return sy < 0 ? -1 : (sy & (kARing - 1)) * (kARowWords * 4); };
+    const int fm = (p.pad == 3 || p.pad == 4) ? -1 : 0;   // one fold of the signed shift: see cl_tiled_backward
+    const int fLo = p.pad == 4 ? -1 : 0, fHi = p.pad == 1 ? H - 1 : (p.pad == 3 ? 2 * H - 2 : 2 * H - 1);
+    const bool fzero = p.pad == 0;
+    auto fold1 = [&](int idx) {
+        const bool lo = idx < 0, hi = idx >= H;
+        const int t = idx & fm;
+        int r = lo ? fLo - t : (hi ? fHi - t : idx);
+        r = (fzero && (lo || hi)) ? -1 : r;
+        return H == 1 ? 0 : r;
+    };
+    int xrow1[NCH];
+#pragma unroll
+    for (int k = 0; k < NCH; ++k) xrow1[k] = fold1(h0 - shs[k]);
+    auto step = [&](int h, u4 (&pv)[kANP]) {
+        __syncthreads();
+        if (h + kR + 1 < H) store_row(h + kR + 1, pv);
+        __syncthreads();
+        load_row(h + kDepth + kR + 1, ylast, pv);
+        const uint32_t so = static_cast<uint32_t>(h - h0) * ostep;
+        int xr0[NCH], xr1[NCH];
+        bool skip[NCH];
+#pragma unroll
+        for (int k = 0; k < NCH; ++k) {
+            xr0[k] = row_off(xrow1[k]);
+            xrow1[k] = fold1(h + 1 - shs[k]);
+            xr1[k] = row_off(xrow1[k]);
+            skip[k] = srow[k] && h == H - 1;
+        }
+        float res[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int k = OUT_CL ? 0 : i;
+            CT v[4];
+            v[0] = lds_f(xr0[k], xc0[i]);
+            v[1] = lds_f(xr1[k], xc0[i]);
+            v[2] = lds_f(xr0[k], xc1[i]);
+            v[3] = lds_f(xr1[k], xc1[i]);
+            res[i] = interp_t<T, 2>(v, dws[k]);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(res[i]), ores, skip[OUT_CL ? 0 : i] ? kOutOfRange : ooff[i], so, 0);
+    };
+    int hb = h0;
+    for (; hb + kDepth <= h1; hb += kDepth) {
+#pragma unroll
+        for (int d = 0; d < kDepth; ++d) step(hb + d, pvs[d]);
+    }
+#pragma unroll
+    for (int d = 0; d < kDepth - 1; ++d)
+        if (hb + d < h1) step(hb + d, pvs[d]);
+
+    // ---- what the ring could not serve, element by element from memory (rare) --------------------------------------------
+    bool any_srow = false;
+#pragma unroll
+    for (int k = 0; k < NCH; ++k) any_srow = any_srow || srow[k];
+    if (rest || any_srow) {
+        const float *xe = reinterpret_cast<const float *>(xn);
+        auto tap = [&](const float *base, int r, int cc) { return (r >= 0 && cc >= 0) ? base[(static_cast<int64_t>(r) * W + cc) * C] : 0.0f; };
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int k = OUT_CL ? 0 : i;
+            const bool all_rows = (rest >> i) & 1u, last_row = ((live >> i) & 1u) && srow[k];
+            if (!all_rows && !last_row) continue;
+            const int ch = OUT_CL ? lane_a : lane_b + 8 * i, col = OUT_CL ? lane_b + 8 * i : lane_a;
+            const int shc = tab_shc[ch], sw = tab_sw[ch], wq = w0 + col;
+            const int a0 = fold_w(wq - sw), a1 = fold_w(wq - sw + 1);
+            float *o = reinterpret_cast<float *>(on) + (OUT_CL ? (static_cast<int64_t>(h0) * W + wq) * C + c0 + ch
+                                                               : (static_cast<int64_t>(c0 + ch) * H + h0) * W + wq);
+            for (int h = all_rows ? h0 : H - 1; h < h1; ++h) {
+                const int r0 = fold_h(h - shc), r1 = fold_h(h - shc + 1);
+                CT v[4] = {tap(xe + c0 + ch, r0, a0), tap(xe + c0 + ch, r1, a0), tap(xe + c0 + ch, r0, a1), tap(xe + c0 + ch, r1, a1)};
+                o[static_cast<int64_t>(h - h0) * (OUT_CL ? W * C : W)] = interp_t<T, 2>(v, dws[k]);
+            }
+        }
+    }
+}
+
 thread_local int g_cl_tiled_tune[2] = {1, 0};  // [0] enabled, [1] rows per band (0 = automatic)
 
 bool dense_channels_last_2d(const int64_t st[5], const Geometry &g, const int64_t sz[3]) {
@@ -577,7 +807,9 @@ void cl_tiled_set_tuning(int knob, int value) {
 bool cl_tiled_forward_eligible(const Geometry &g, int dtype, const void *x, const void *out) {
     const int es = dtype_size(dtype);
     if (!g_cl_tiled_tune[0] || g.nd != 2 || es > 4 || g.pad == 2) return false;
-    if (g.active && dtype <= SHIFTND_BF16) return false;
+    if (g.active && dtype <= SHIFTND_BF16) {  // interpolating: cl_tiled_active_forward, fp32, rows folded once
+        if (dtype != SHIFTND_F32 || (g.S[1] != 1 && g.S[1] < 5)) return false;
+    }
     for (int d = 0; d < 3; ++d)
         if (g.L[d] != 0 || g.O[d] != g.S[d]) return false;
     if ((g.C * es) % 16 != 0 || g.S[1] >= (1 << 20) || g.S[2] >= (1 << 20) || g.N >= (1LL << 24) || g.C >= (1 << 24)) return false;
@@ -623,6 +855,12 @@ int cl_tiled_forward(const Geometry &g, int dtype, const void *x, const void *w,
     p.d_bands = make_fastdiv(static_cast<uint32_t>(p.bands));
     p.d_perH = make_fastdiv(static_cast<uint32_t>(map_period(p.H, p.pad)));
     p.d_perW = make_fastdiv(static_cast<uint32_t>(map_period(p.W, p.pad)));
+    if (g.active && dtype <= SHIFTND_BF16) {
+        note_kernel("cl_tiled_active_forward");
+        if (p.out_cl) hipLaunchKernelGGL((cl_tiled_active_forward<f32_t, true>), dim3(static_cast<unsigned>(grid)), dim3(kThreads), 0, st, p);
+        else hipLaunchKernelGGL((cl_tiled_active_forward<f32_t, false>), dim3(static_cast<unsigned>(grid)), dim3(kThreads), 0, st, p);
+        return SHIFTND_OK;
+    }
     note_kernel("cl_tiled_forward");
 #define SHIFTND_CLT_LAUNCH(ESV) \
     if (p.out_cl) hipLaunchKernelGGL((cl_tiled_forward<ESV, true>), dim3(static_cast<unsigned>(grid)), dim3(kThreads), 0, st, p); \

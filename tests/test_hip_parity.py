@@ -423,7 +423,7 @@ def test_channels_last_kernels_vs_oracle(abi, dt):
                 gx_o, _ = O.backward(go, w, x, pad, active, b)
                 _, gw64 = O.backward(go.astype(np.float64), w.astype(np.float64), x.astype(np.float64), pad, active, b)
                 # the LDS-tiled kernel (shiftnd_cl_tiled.hip) serves 4-byte 2-D gathers without crop / periodic wrap
-                tiled = dt == "f32" and nd == 2 and crop is None and pad != 2 and not active and shape[1] % 4 == 0
+                tiled = dt == "f32" and nd == 2 and crop is None and pad != 2 and shape[1] % 4 == 0
                 for policy in (0, 4):  # 0 picks the channel-fastest kernels when every tensor is channels-last
                     abi.set_path_policy(policy)
                     out = abi.forward(xd, wd, pad, active, b)  # NCHW-contiguous output (shifts_cpu.cpp:221)
@@ -432,7 +432,8 @@ def test_channels_last_kernels_vs_oracle(abi, dt):
                     out_cl = torch.empty(new, dtype=xd.dtype, device=DEV).contiguous(memory_format=fmt)
                     abi.forward(xd, wd, pad, active, b, out=out_cl)
                     assert abi.last_path() == abi.PATH_CL, (shape, pad, active)
-                    assert abi.last_kernel() == ("cl_active_forward" if active else ("cl_tiled_forward" if tiled else "cl_gather_forward"))
+                    assert abi.last_kernel() == (("cl_tiled_active_forward" if tiled else "cl_active_forward") if active else
+                                                 ("cl_tiled_forward" if tiled else "cl_gather_forward"))
                     assert np.array_equal(out_cl.cpu().numpy(), ref), (shape, pad, active)
                     for god in (_dev(go), _dev(go).contiguous(memory_format=fmt)):
                         for gxd in (torch.empty_like(xd), torch.empty(shape, dtype=xd.dtype, device=DEV)):

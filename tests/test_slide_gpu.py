@@ -279,6 +279,36 @@ def test_tiled_channels_last_backward_vs_oracle(shape):
         abi.set_tuning(21, 0)
 
 
+@pytest.mark.parametrize("shape", [(2, 8, 9, 12), (3, 300, 6, 5), (2, 64, 40, 70), (1, 36, 100, 33), (2, 4, 1, 50), (1, 32, 64, 1)])
+def test_tiled_channels_last_active_forward_vs_oracle(shape):
+    """cl_tiled_active_forward: fp32 channels-last input, interpolated output channels-last or NCHW-contiguous, every
+    padding it serves, shifts beyond the ring, the reflected corner of the last row / column; bit-exact"""
+    from torchshifts import abi
+    rs = np.random.RandomState(sum(shape) + 9)
+    x = rs.uniform(-1, 1, size=shape).astype(np.float32)
+    w = rs.uniform(-3.9, 3.9, size=(shape[1], 2)).astype(np.float32)
+    w[0] = [0.5, -1.5]
+    w[1] = [shape[2] + 2.25, -7.0]       # beyond the dim / beyond the ring
+    w[2] = [-5.0, 2.5]
+    w[3] = [-2.75, -2.25]                # floor = -3: the + 1 corner at distance 4
+    xd = torch.from_numpy(x).to(DEV).contiguous(memory_format=torch.channels_last)
+    wd = torch.from_numpy(w).to(DEV)
+    try:
+        for band_rows in (0, 5):
+            abi.set_tuning(21, band_rows)
+            for pad in (0, 1, 3, 4):
+                ref = O.forward(x, w, pad, True)
+                out = abi.forward(xd, wd, pad, True)  # NCHW-contiguous output
+                assert abi.last_kernel() == "cl_tiled_active_forward" and out.is_contiguous()
+                assert np.array_equal(out.cpu().numpy(), ref), (shape, pad, "nchw", band_rows)
+                out_cl = torch.empty(shape, device=DEV).contiguous(memory_format=torch.channels_last)
+                abi.forward(xd, wd, pad, True, out=out_cl)
+                assert abi.last_kernel() == "cl_tiled_active_forward"
+                assert np.array_equal(out_cl.cpu().numpy(), ref), (shape, pad, "cl", band_rows)
+    finally:
+        abi.set_tuning(21, 0)
+
+
 def test_channels_last_input_through_the_op_uses_the_tiled_kernel():
     """torch.ops.torchshifts.shift2d with a channels-last fp32 input: one pass (no layout change first), NCHW result
     like the reference (cpu/shifts_cpu.cpp:221), same bits as the contiguous input"""

@@ -336,7 +336,6 @@ __global__ __launch_bounds__(kThreads) void slide_kernel(const SlideParams p) {
     const int64_t plane_nc = static_cast<int64_t>(n0) * p.C + c;
     const S *xb = static_cast<const S *>(p.x) + plane_nc * p.plane;
     const S *gb = BACKWARD ? static_cast<const S *>(p.go) + plane_nc * p.plane : xb;
-    S *outp = static_cast<S *>(p.out) + plane_nc * p.plane + (worker ? mypoff + (ND == 3 ? (a0 + s) * S1 * S2 : 0) + ji : 0);
 
     // ---- the pieces this thread stages every step -----------------------------------------------------------------
     // kind 0: x rows (through the x maps), 1: grad_out rows at the output position, 2: grad_out rows through the grad maps
@@ -472,16 +471,23 @@ __global__ __launch_bounds__(kThreads) void slide_kernel(const SlideParams p) {
 #pragma unroll
     for (int e = 0; e <= E; ++e) lp[e] = CT(0);
 
-    Chunk<S, E> pres;  // output chunk computed by the previous step, and its row (-1: none)
+    Chunk<S, E> pres{};  // output chunk computed by the previous step, and its row (-1: none)
     int prow = -1;
+    // The store is unconditional (a store under a thread-dependent branch lowers the number of operations hipcc can
+    // count on between a load and its use, and the prefetch is waited for too early): threads with nothing to store use a
+    // buffer offset beyond the resource, which the hardware drops.
+    const __amdgpu_buffer_rsrc_t ores = __builtin_amdgcn_make_buffer_rsrc(
+        static_cast<S *>(p.out) + plane_nc * p.plane, 0, 0x7ffffffc, 0x00020000);   // spans below 2^31 bytes (slide_plan)
+    const uint32_t obase = static_cast<uint32_t>(worker ? mypoff + (ND == 3 ? (a0 + s) * S1 * S2 : 0) + ji : 0) * ES;
     auto flush_store = [&]() {
-        if (prow >= 0) {
-            // a plain (L2-retained) store: a step writes one 16-byte-multiple row segment per plane, and the rows of a
-            // plane follow each other a step apart -- L2 merges them into whole lines; as nontemporal stores the partial
-            // lines went to HBM one by one (C3: forward 0.222 -> 0.184 ms, backward 0.324 -> 0.287 ms)
-            __builtin_memcpy(__builtin_assume_aligned(outp + static_cast<int64_t>(prow) * S2, 16), pres.e, 16);
-            prow = -1;
-        }
+        // a plain (L2-retained) store: a step writes one 16-byte-multiple row segment per plane, and the rows of a
+        // plane follow each other a step apart -- L2 merges them into whole lines; as nontemporal stores the partial
+        // lines went to HBM one by one (C3: forward 0.222 -> 0.184 ms, backward 0.324 -> 0.287 ms)
+        u4 data;
+        __builtin_memcpy(&data, pres.e, 16);
+        const uint32_t off = prow >= 0 ? obase + static_cast<uint32_t>(prow) * static_cast<uint32_t>(S2 * ES) : 0x80000000u;
+        __builtin_amdgcn_raw_buffer_store_b128(data, ores, off, 0, 0);
+        prow = -1;
     };
     auto step = [&](int t, u4 (&pvr)[NP]) {
         char *tile = tiles + (t & 1) * p.tile_bytes;
@@ -491,7 +497,7 @@ __global__ __launch_bounds__(kThreads) void slide_kernel(const SlideParams p) {
         // one in-order counter (vmcnt), and the compiler waits for everything older when it needs the loads back, so a
         // store issued after the loads would be waited for (its whole write latency) at the top of every step.
         flush_store();
-        if (t + DEPTH <= p.seg) issue_loads(t + DEPTH, pvr);  // in flight while this and the next DEPTH - 1 steps are computed
+        issue_loads(t + DEPTH, pvr);  // in flight while this and the next DEPTH - 1 steps are computed (beyond the band: row 0, unused)
         if (t <= mylen) {
             // fill rows (zeros padding) read the all-zero slot
             const bool rvx = m1[(ND == 3 ? ubstart : mybstart) + t] >= 0;
@@ -611,14 +617,15 @@ __global__ __launch_bounds__(kThreads) void slide_kernel(const SlideParams p) {
         }
 };
 #pragma unroll
-    for (int d = 0; d < DEPTH; ++d) {
-        if (d <= p.seg) issue_loads(d, pv[d]);
-    }
-    for (int t0 = 0; t0 <= p.seg; t0 += DEPTH) {
+    for (int d = 0; d < DEPTH; ++d) issue_loads(d, pv[d]);
+    int t0 = 0;
+    for (; t0 + DEPTH <= p.seg + 1; t0 += DEPTH) {   // whole groups: nothing conditional between the steps (exact wait counts)
 #pragma unroll
-        for (int d = 0; d < DEPTH; ++d)
-            if (t0 + d <= p.seg) step(t0 + d, pv[d]);
+        for (int d = 0; d < DEPTH; ++d) step(t0 + d, pv[d]);
     }
+#pragma unroll
+    for (int d = 0; d < DEPTH - 1; ++d)
+        if (t0 + d <= p.seg) step(t0 + d, pv[d]);
     flush_store();
 
     if constexpr (BACKWARD) {
@@ -687,7 +694,7 @@ SlidePlan slide_plan(const Geometry &g, int es, bool backward, int np_max) {
     const int64_t min_wgs = g_slide_tune[1] > 0 ? g_slide_tune[1] : (backward ? 3072 : 1024);
     const int64_t min_rows = g_slide_tune[2] > 0 ? g_slide_tune[2] : 16;
     if (g.nd == 3) {
-        if (plane >= (1LL << 30)) return pl;
+        if (plane * es >= (1LL << 31)) return pl;  // buffer offsets of the output store
         pl.agroups = static_cast<int>((g.S[0] + nseg - 1) / nseg);
         const int64_t base = g.N * g.C * pl.agroups;
         int64_t bands = (min_wgs + base - 1) / base;
@@ -714,7 +721,7 @@ SlidePlan slide_plan(const Geometry &g, int es, bool backward, int np_max) {
         pl.groups = static_cast<int>((units + nseg - 1) / nseg);
         // the planes of one workgroup are addressed with 32-bit element offsets from its first plane
         const int64_t span = (static_cast<int64_t>(nseg) / pl.bands + 2) * g.C * plane;
-        if (span >= (1LL << 30)) return pl;
+        if (span >= (1LL << 30) || span * es >= (1LL << 31)) return pl;
     }
     pl.nseg = nseg;
     pl.nslots = slots_of(nseg);
@@ -762,12 +769,16 @@ void fill_slide(SlideParams &p, const Geometry &g, const SlidePlan &pl) {
 constexpr int kNpBackward = 3, kNpForward = 2;
 // steps of staging in flight: 2 costs 12 (backward) registers and a wave of occupancy, measured slower (C3 backward
 // 0.337 -> 0.356 ms)
-constexpr int kDepthBackward = 1, kDepthForward = 1;
+// staged rows in flight.  With every memory instruction of the walk unconditional the waits are exact, and a second
+// step of loads in flight pays for 16-bit data (C3 bf16 backward 0.301 -> 0.292 ms, the 3-D sparse shift 0.306 -> 0.293);
+// fp32 (twice the registers per piece) and the forward measure flat or worse, three steps worse everywhere.
+template <typename T> constexpr int kDepthBackward = sizeof(typename T::S) == 2 ? 2 : 1;
+constexpr int kDepthForward = 1;
 
 template <typename T, bool ACTIVE>
 void launch_slide_backward(const SlideParams &p, const SlidePlan &pl, hipStream_t st) {
-    if (p.nd == 3) hipLaunchKernelGGL((slide_kernel<T, 3, ACTIVE, true, kNpBackward, kDepthBackward>), dim3(pl.grid), dim3(kThreads), pl.lds, st, p);
-    else hipLaunchKernelGGL((slide_kernel<T, 2, ACTIVE, true, kNpBackward, kDepthBackward>), dim3(pl.grid), dim3(kThreads), pl.lds, st, p);
+    if (p.nd == 3) hipLaunchKernelGGL((slide_kernel<T, 3, ACTIVE, true, kNpBackward, kDepthBackward<T>>), dim3(pl.grid), dim3(kThreads), pl.lds, st, p);
+    else hipLaunchKernelGGL((slide_kernel<T, 2, ACTIVE, true, kNpBackward, kDepthBackward<T>>), dim3(pl.grid), dim3(kThreads), pl.lds, st, p);
 }
 template <typename T>
 void launch_slide_forward(const SlideParams &p, const SlidePlan &pl, hipStream_t st) {

@@ -6,9 +6,11 @@
 // peak, profiles/r02_c4_before_*).  But a PLANE (3136 bytes) is a whole number of pieces, 16-byte aligned, and the
 // shift is one number per channel: with D = shift_row * row_bytes + shift_col the output byte at plane offset o is the
 // source byte at offset o - D wherever it is not fill -- across row boundaries too.  So
-//   * one workgroup = one channel x `ppw` batch entries; it loads its source planes with aligned 16-byte loads
-//     (every byte once, all loads issued up front), parks them in LDS, and
-//   * builds, while the loads are in flight, a per-channel table with one entry per 16-byte OUTPUT piece of a plane:
+//   * one workgroup = one channel x `ppw * rpw` batch entries, in `rpw` rounds of `ppw` planes; per round it loads its
+//     source planes with aligned 16-byte loads (every byte once; the NEXT round's loads are issued before this round
+//     is assembled, and every store is unconditional -- an out-of-range buffer offset where there is nothing to
+//     store -- so that the compiler waits for the loads only, never for the stores), parks them in LDS, and
+//   * builds ONCE, while the first loads are in flight, a per-channel table with one entry per 16-byte OUTPUT piece of a plane:
 //     the (constant) source offset of its valid bytes and a byte mask of the valid ones; then
 //   * every thread assembles aligned 16-byte output pieces: five dwords from LDS at the source offset, one funnel
 //     shift per dword (v_alignbyte_b32), one v_bfi_b32 per dword against the mask to drop in the fill value (the
@@ -27,6 +29,7 @@ namespace {
 constexpr int kMaxLoads = 10;      // 16-byte pieces a thread loads (ppw * pieces per plane <= kMaxLoads * 256)
 constexpr int kPlaneGuard = 32;    // bytes between planes in LDS (windows of edge pieces reach 16 before / 20 behind)
 constexpr int kAllFill = INT32_MIN, kGeneral = INT32_MIN + 1;
+constexpr int kBytesWgs = 1024;    // workgroups wanted when a workgroup runs several rounds
 
 struct BytesParams {
     const uint8_t *x;
@@ -37,7 +40,8 @@ struct BytesParams {
     int wkind, N, C, nd, pad;
     int S[3], wcol[3];
     int plane_bytes, npc;   // bytes / 16-byte pieces per plane
-    int ppw, groups;        // planes per workgroup, workgroups per channel
+    int ppw, groups;        // planes per round of a workgroup, workgroups per channel
+    int rpw;                // rounds per workgroup: it owns ppw * rpw consecutive planes of its channel
     int pitch;              // LDS bytes per plane (plane + guard)
     int use_table;          // non-zero padding: the byte-by-byte source table is built
     unsigned xcd_blocks;
@@ -45,6 +49,8 @@ struct BytesParams {
     FastDiv d_per[3];    // divide by the padding period of each dim
 };
 
+// NL = 16-byte pieces a thread loads / stores per round (ppw * pieces per plane <= NL * 256).
+template <int NL>
 __global__ __launch_bounds__(kThreads) void bytes_gather_forward(const BytesParams p) {
     typedef uint32_t u4 __attribute__((ext_vector_type(4)));
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -60,16 +66,17 @@ __global__ __launch_bounds__(kThreads) void bytes_gather_forward(const BytesPara
 
     const unsigned bid = p.xcd_blocks ? (blockIdx.x & 7u) * p.xcd_blocks + (blockIdx.x >> 3) : blockIdx.x;
     const int grp = fdiv(bid, p.d_C), c = static_cast<int>(bid) - grp * p.C;
-    const int n0 = grp * p.ppw, nn = min(p.ppw, p.N - n0);
-    const int total = nn * p.npc;  // pieces of this workgroup
+    const int n0 = grp * p.ppw * p.rpw, nw = min(p.ppw * p.rpw, p.N - n0);   // this workgroup's planes: rounds of ppw
 
-    // ---- all source planes: aligned 16-byte loads, issued before anything else -------------------------------
-    // piece P = i * 256 + tid of the workgroup = piece k of its plane pl; 32-bit byte offsets from the workgroup's
-    // first plane (the host checks ppw * C * plane_bytes < 2^31)
+    // ---- source planes of a round: aligned 16-byte loads, issued before anything else ----------------------------
+    // piece P = i * 256 + tid of the round = piece k of its plane pl; 32-bit byte offsets from the workgroup's
+    // first plane (the host checks ppw * rpw * C * plane_bytes < 2^31)
     const int64_t base = (static_cast<int64_t>(n0) * p.C + c) * p.plane_bytes;
     const uint8_t *xb = p.x + base;
-    uint8_t *ob = p.out + base;
     const int nstride = p.C * p.plane_bytes;
+    // every store of the round loop is unconditional (pieces past the end: an offset the hardware drops), so that hipcc
+    // can count the stores between the next round's loads and their use, and waits for the loads only
+    const __amdgpu_buffer_rsrc_t ores = __builtin_amdgcn_make_buffer_rsrc(p.out + base, 0, 0x7ffffffc, 0x00020000);
     const int q256 = fdiv(kThreads, p.d_npc), r256 = kThreads - q256 * p.npc;
     const int pl0 = fdiv(threadIdx.x, p.d_npc), k0 = static_cast<int>(threadIdx.x) - pl0 * p.npc;
     auto next_piece = [&](int &pl, int &k) {
@@ -80,17 +87,26 @@ __global__ __launch_bounds__(kThreads) void bytes_gather_forward(const BytesPara
             ++pl;
         }
     };
-    u4 v[kMaxLoads];
-    {
+    u4 v[NL];
+    auto load_round = [&](int r) {   // (rounds past the end: every thread re-reads piece 0 and drops it)
+        const int total = max(0, min(p.ppw, nw - r * p.ppw)) * p.npc;
+        const int rbase = r * p.ppw * nstride;
         int pl = pl0, k = k0;
 #pragma unroll
-        for (int i = 0; i < kMaxLoads; ++i) {
+        for (int i = 0; i < NL; ++i) {
             // (unconditional load: threads past the end re-read piece 0 and drop it)
-            const int off = (i * kThreads + static_cast<int>(threadIdx.x)) < total ? pl * nstride + k * 16 : 0;
+            const int off = (i * kThreads + static_cast<int>(threadIdx.x)) < total ? rbase + pl * nstride + k * 16 : 0;
             // (a plain load: as nontemporal loads these were 10 % slower, 0.092 vs 0.083 ms on C4)
             v[i] = *reinterpret_cast<const u4 *>(xb + off);
             next_piece(pl, k);
         }
+    };
+    load_round(0);
+    {   // NL dropped stores: the first round then sees the same number of operations behind its loads as every other
+        // round (the wait counts of a loop are the minimum over its entry and its back edge)
+        const u4 z = {0u, 0u, 0u, 0u};
+#pragma unroll
+        for (int i = 0; i < NL; ++i) __builtin_amdgcn_raw_buffer_store_b128(z, ores, 0x80000000u, 0, 0);
     }
 
     // ---- per-channel tables (while the loads are in flight) ---------------------------------------------------
@@ -137,64 +153,72 @@ __global__ __launch_bounds__(kThreads) void bytes_gather_forward(const BytesPara
         poff[k] = general ? kGeneral : off;
     }
 
-    // ---- park the planes in LDS --------------------------------------------------------------------------------
-    {
+    for (int r = 0; r * p.ppw < nw; ++r) {
+        const int total = min(p.ppw, nw - r * p.ppw) * p.npc;  // pieces of this round
+        // ---- park the planes in LDS ----------------------------------------------------------------------------
+        {
+            int pl = pl0, k = k0;
+#pragma unroll
+            for (int i = 0; i < NL; ++i) {
+                if (i * kThreads + static_cast<int>(threadIdx.x) < total)
+                    *reinterpret_cast<u4 *>(__builtin_assume_aligned(planes + pl * p.pitch + k * 16, 16)) = v[i];
+                next_piece(pl, k);
+            }
+        }
+        __syncthreads();
+        load_round(r + 1);  // in flight while this round is assembled
+
+        // ---- assemble and store the output pieces ----------------------------------------------------------------
+        const uint32_t rbase = static_cast<uint32_t>(r * p.ppw) * static_cast<uint32_t>(nstride);
         int pl = pl0, k = k0;
 #pragma unroll
-        for (int i = 0; i < kMaxLoads; ++i) {
-            if (i * kThreads + static_cast<int>(threadIdx.x) < total)
-                *reinterpret_cast<u4 *>(__builtin_assume_aligned(planes + pl * p.pitch + k * 16, 16)) = v[i];
+        for (int i = 0; i < NL; ++i) {
+            const bool mine = i * kThreads + static_cast<int>(threadIdx.x) < total;
+            const int off = mine ? poff[k] : kAllFill;
+            const char *plane = planes + (mine ? pl * p.pitch : 0);
+            u4 res = {p.fill4, p.fill4, p.fill4, p.fill4};
+            if (off == kGeneral) {
+                uint32_t w[4] = {0u, 0u, 0u, 0u};
+#pragma unroll
+                for (int b = 0; b < 16; ++b) {
+                    const int s = tab[k * 16 + b];
+                    const uint32_t byte = s >= 0 ? static_cast<uint8_t>(plane[s]) : (p.fill4 & 0xffu);
+                    w[b >> 2] |= byte << ((b & 3) * 8);
+                }
+                res = u4{w[0], w[1], w[2], w[3]};
+            } else if (off != kAllFill) {
+                const int s0 = k * 16 + off;  // source byte of the piece's byte 0: >= -15, < plane_bytes
+                const uint32_t *dwp = reinterpret_cast<const uint32_t *>(plane + (s0 & ~3));
+                uint32_t d[5];
+#pragma unroll
+                for (int j = 0; j < 5; ++j) d[j] = dwp[j];
+                const uint32_t sb = static_cast<uint32_t>(s0 & 3);
+                const u4 mk = pmask[k];
+                const uint32_t m[4] = {mk.x, mk.y, mk.z, mk.w};
+                uint32_t w[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const uint32_t t = __builtin_amdgcn_alignbyte(d[j + 1], d[j], sb);
+                    w[j] = (t & m[j]) | (p.fill4 & ~m[j]);  // v_bfi_b32
+                }
+                res = u4{w[0], w[1], w[2], w[3]};
+            }
+            const uint32_t ooff = mine ? rbase + static_cast<uint32_t>(pl * nstride + k * 16) : 0x80000000u;
+            __builtin_amdgcn_raw_buffer_store_b128(res, ores, ooff, 0, 2);  // nontemporal
             next_piece(pl, k);
         }
-    }
-    __syncthreads();
-
-    // ---- assemble and store the output pieces -----------------------------------------------------------------
-    int pl = pl0, k = k0;
-#pragma unroll 2
-    for (int P = threadIdx.x; P < total; P += kThreads) {
-        const int off = poff[k];
-        const char *plane = planes + pl * p.pitch;
-        u4 res = {p.fill4, p.fill4, p.fill4, p.fill4};
-        if (off == kGeneral) {
-            uint32_t w[4] = {0u, 0u, 0u, 0u};
-#pragma unroll
-            for (int b = 0; b < 16; ++b) {
-                const int s = tab[k * 16 + b];
-                const uint32_t byte = s >= 0 ? static_cast<uint8_t>(plane[s]) : (p.fill4 & 0xffu);
-                w[b >> 2] |= byte << ((b & 3) * 8);
-            }
-            res = u4{w[0], w[1], w[2], w[3]};
-        } else if (off != kAllFill) {
-            const int s0 = k * 16 + off;  // source byte of the piece's byte 0: >= -15, < plane_bytes
-            const uint32_t *dwp = reinterpret_cast<const uint32_t *>(plane + (s0 & ~3));
-            uint32_t d[5];
-#pragma unroll
-            for (int i = 0; i < 5; ++i) d[i] = dwp[i];
-            const uint32_t sb = static_cast<uint32_t>(s0 & 3);
-            const u4 mk = pmask[k];
-            const uint32_t m[4] = {mk.x, mk.y, mk.z, mk.w};
-            uint32_t w[4];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const uint32_t t = __builtin_amdgcn_alignbyte(d[i + 1], d[i], sb);
-                w[i] = (t & m[i]) | (p.fill4 & ~m[i]);  // v_bfi_b32
-            }
-            res = u4{w[0], w[1], w[2], w[3]};
-        }
-        __builtin_nontemporal_store(res, reinterpret_cast<u4 *>(ob + (pl * nstride + k * 16)));
-        next_piece(pl, k);
+        __syncthreads();  // the next round parks its planes over these
     }
 }
 
 struct BytesPlan {
-    int npc, ppw, groups, pitch, use_table;
+    int npc, ppw, rpw, nl, groups, pitch, use_table;
     size_t lds;
     unsigned grid;
     bool ok;
 };
 
-thread_local int g_bytes_tune[3] = {1, 0, 0};  // [0] enabled, [1] planes per workgroup (0 = automatic), [2] LDS bytes for planes
+thread_local int g_bytes_tune[4] = {1, 0, 0, 0};  // [0] enabled, [1] planes per round (0 = automatic), [2] LDS bytes for planes, [3] rounds per workgroup
 
 BytesPlan bytes_plan(const Geometry &g) {
     BytesPlan pl{};
@@ -227,9 +251,19 @@ BytesPlan bytes_plan(const Geometry &g) {
         ppw = best;
     }
     if (ppw < 1 || ppw * pl.npc > static_cast<int64_t>(kMaxLoads) * kThreads) return pl;
-    if (ppw * g.C * plane >= (1LL << 31)) return pl;  // 32-bit byte offsets inside a workgroup
     pl.ppw = static_cast<int>(ppw);
-    pl.groups = static_cast<int>((g.N + ppw - 1) / ppw);
+    // rounds per workgroup: the per-channel tables are built once per workgroup and the next round's planes load while
+    // this round is assembled; as many as leave ~4 workgroups per CU (knob 19).  C4: 1 round 0.080 ms, 2+ rounds 0.067 ms
+    // (6.1 TB/s; torch's plain copy of the tensor: 0.077 ms); reflect padding 0.116 -> 0.088 ms with 8 rounds
+    int64_t rpw = g_bytes_tune[3] > 0 ? g_bytes_tune[3] : 1;
+    if (g_bytes_tune[3] <= 0)
+        while (rpw < 64 && g.C * ((g.N + ppw * rpw * 2 - 1) / (ppw * rpw * 2)) >= kBytesWgs) rpw *= 2;
+    if (ppw * rpw > g.N) rpw = (g.N + ppw - 1) / ppw;
+    if (ppw * rpw * g.C * plane >= (1LL << 31)) return pl;  // 32-bit byte offsets inside a workgroup
+    pl.rpw = static_cast<int>(rpw);
+    const int64_t need = (ppw * pl.npc + kThreads - 1) / kThreads;
+    pl.nl = need <= 2 ? 2 : (need <= 4 ? 4 : (need <= 7 ? 7 : 10));
+    pl.groups = static_cast<int>((g.N + ppw * rpw - 1) / (ppw * rpw));
     pl.lds = fixed + static_cast<size_t>(pl.ppw) * pl.pitch;
     if (pl.lds > 64 * 1024) return pl;
     const int64_t grid = static_cast<int64_t>(pl.groups) * g.C;
@@ -252,7 +286,7 @@ bool contiguous5b(const int64_t st[5], int64_t N, int64_t C, const int64_t sz[3]
 }  // namespace
 
 void bytes_set_tuning(int knob, int value) {
-    if (knob >= 0 && knob < 3) g_bytes_tune[knob] = value;
+    if (knob >= 0 && knob < 4) g_bytes_tune[knob] = value;
 }
 
 bool bytes_forward_eligible(const Geometry &g, int dtype, const void *x, const void *out) {
@@ -285,6 +319,7 @@ int bytes_forward(const Geometry &g, const void *x, const void *w, int wkind, in
     p.npc = pl.npc;
     p.ppw = pl.ppw;
     p.groups = pl.groups;
+    p.rpw = pl.rpw;
     p.pitch = pl.pitch;
     p.use_table = pl.use_table;
     p.xcd_blocks = pl.grid % 8 == 0 ? pl.grid / 8 : 0;
@@ -294,7 +329,12 @@ int bytes_forward(const Geometry &g, const void *x, const void *w, int wkind, in
     p.d_C = make_fastdiv(static_cast<uint32_t>(g.C));
     for (int d = 0; d < 3; ++d) p.d_per[d] = make_fastdiv(static_cast<uint32_t>(map_period(p.S[d], g.pad)));
     note_kernel("bytes_gather_forward");
-    hipLaunchKernelGGL(bytes_gather_forward, dim3(pl.grid), dim3(kThreads), pl.lds, st, p);
+    switch (pl.nl) {
+    case 2: hipLaunchKernelGGL(bytes_gather_forward<2>, dim3(pl.grid), dim3(kThreads), pl.lds, st, p); break;
+    case 4: hipLaunchKernelGGL(bytes_gather_forward<4>, dim3(pl.grid), dim3(kThreads), pl.lds, st, p); break;
+    case 7: hipLaunchKernelGGL(bytes_gather_forward<7>, dim3(pl.grid), dim3(kThreads), pl.lds, st, p); break;
+    default: hipLaunchKernelGGL(bytes_gather_forward<10>, dim3(pl.grid), dim3(kThreads), pl.lds, st, p); break;
+    }
     return SHIFTND_OK;
 }
 

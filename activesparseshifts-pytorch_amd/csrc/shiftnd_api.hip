@@ -190,6 +190,10 @@ int shiftnd_forward_serves_channels_last(const shiftnd_problem *p, const void *x
     if (!p || !x_strides || !out_strides || g_policy != 0) return 0;
     Geometry g;
     if (build_geometry(p, x_strides, out_strides, nullptr, g) != SHIFTND_OK || empty_problem(g)) return 0;
+    // 16-bit interpolation: one layout change + the contiguous kernel is faster than the tiled kernel (N16 C256 224x224
+    // bf16 through the op: 0.30 vs 0.54 ms; tools/cl_op_bench.py), so the answer is no although shiftnd_forward would
+    // take a channels-last tensor
+    if (g.active && (p->dtype == SHIFTND_F16 || p->dtype == SHIFTND_BF16)) return 0;
     return cl_tiled_forward_eligible(g, p->dtype, x, out) ? 1 : 0;
 }
 
@@ -200,6 +204,7 @@ int shiftnd_backward_serves_channels_last(const shiftnd_problem *p, const void *
     Geometry g;
     if (build_geometry(p, x_strides, grad_out_strides, grad_x_strides, g) != SHIFTND_OK) return 0;
     if (g.N == 0 || g.C == 0 || g.S[0] * g.S[1] * g.S[2] == 0) return 0;
+    if (g.active && (p->dtype == SHIFTND_F16 || p->dtype == SHIFTND_BF16)) return 0;  // (0.56 vs 0.66 ms: see above)
     return cl_tiled_backward_eligible(g, p->dtype, grad_out, x, grad_x) ? 1 : 0;
 }
 

@@ -324,8 +324,9 @@ __global__ __launch_bounds__(kThreads) void cl_tiled_backward(const ClTiledBwdPa
     typedef uint32_t u4 __attribute__((ext_vector_type(4)));
     using S = typename T::S;
     using CT = typename T::C;
-    static_assert(sizeof(S) == 4, "4-byte elements");
-    constexpr int ES = 4, CB = kLine / ES;
+    static_assert(sizeof(S) == 4 || sizeof(S) == 2, "fp32, fp16, bf16");
+    constexpr int ES = sizeof(S), CB = kLine / ES;   // channels per workgroup: 32 (fp32) or 64 (16-bit types)
+    constexpr int PL = kThreads / CB, NI = kBTW / PL;   // pixel lanes; pixels per thread and row (2 or 4)
     __shared__ __attribute__((aligned(16))) uint32_t ring[2 * kBRingWords + 4];   // input ring, gradient ring, dump words
     constexpr int kDump = 2 * kBRingWords;
 
@@ -354,7 +355,7 @@ __global__ __launch_bounds__(kThreads) void cl_tiled_backward(const ClTiledBwdPa
     const int q = static_cast<int>(threadIdx.x);
     const bool piece = q < kBPieces;
     const int px = q >> 3, part = q & 7, gxs = w0 - kR + px;
-    const uint32_t poff = (piece && gxs >= 0 && gxs < W && c0 + part * 4 < C) ? (static_cast<uint32_t>(gxs) * C + c0 + part * 4) * ES : kOutOfRange;
+    const uint32_t poff = (piece && gxs >= 0 && gxs < W && c0 * ES + part * 16 < C * ES) ? static_cast<uint32_t>(gxs) * C * ES + c0 * ES + part * 16 : kOutOfRange;
     const int pdst = piece ? px * kPitch + part * 4 : -1;
     const uint32_t row_bytes = static_cast<uint32_t>(W) * C * ES;
     constexpr int kDepth = CLT_DEPTH;
@@ -380,7 +381,7 @@ __global__ __launch_bounds__(kThreads) void cl_tiled_backward(const ClTiledBwdPa
     for (int r = 0; r <= 2 * kR; ++r) load_row(h0 - kR + r, ylast, prex[r], preg[r]);
 
     // ---- the thread's channel and its two pixels ---------------------------------------------------------------------
-    const int lane_a = static_cast<int>(threadIdx.x) & 31, lane_b = static_cast<int>(threadIdx.x) >> 5;
+    const int lane_a = static_cast<int>(threadIdx.x) % CB, lane_b = static_cast<int>(threadIdx.x) / CB;
     const int c = c0 + lane_a;
     const bool live_c = c < C;
     int64_t sh[3] = {0, 0, 0};
@@ -405,22 +406,22 @@ __global__ __launch_bounds__(kThreads) void cl_tiled_backward(const ClTiledBwdPa
     // A reflected corner can land one step outside the rings (reflect padding, last column / row, shift -R: the
     // corner at distance R + 1 comes back at distance -(R + 1)); such pixels (`scol`) and rows (`skip` below) are left
     // to the element-by-element pass at the end.
-    int xc0[2], xc1[2], gc0[2], gc1[2], gd[2];
-    uint32_t ooff[2];
-    bool live[2], scol[2];
+    int xc0[NI], xc1[NI], gc0[NI], gc1[NI], gd[NI];
+    uint32_t ooff[NI];
+    bool live[NI], scol[NI];
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int col = lane_b + 8 * i, wq = w0 + min(col, W - 1 - w0);
+    for (int i = 0; i < NI; ++i) {
+        const int col = lane_b + PL * i, wq = w0 + min(col, W - 1 - w0);
         const int a0 = fold_w(wq - csxW), a1 = fold_w(wq - csxW + 1), b0 = fold_w(wq - csgW), b1 = ACTIVE ? fold_w(wq - csgW + 1) : -1;
         auto outside = [&](int sx) { return sx >= 0 && (sx < w0 - kR || sx > w0 + kBTW + kR); };
         scol[i] = near_c && w0 + col < W && (outside(a0) || outside(a1) || outside(b0) || outside(b1));
         live[i] = near_c && w0 + col < W && !scol[i];
-        auto lds_col = [&](int sx) { return (live[i] && sx >= 0) ? (sx - (w0 - kR)) * (kPitch * 4) + lane_a * 4 : -1; };
+        auto lds_col = [&](int sx) { return (live[i] && sx >= 0) ? (sx - (w0 - kR)) * (kPitch * 4) + lane_a * ES : -1; };
         xc0[i] = lds_col(a0);
         xc1[i] = lds_col(a1);
         gc0[i] = lds_col(b0);
         gc1[i] = lds_col(b1);
-        gd[i] = (col + kR) * (kPitch * 4) + lane_a * 4;
+        gd[i] = (col + kR) * (kPitch * 4) + lane_a * ES;
         ooff[i] = live[i] ? (static_cast<uint32_t>(h0 * W + w0 + col) * C + c) * ES : kOutOfRange;
     }
     const uint32_t ostep = static_cast<uint32_t>(W) * C * ES;
@@ -432,11 +433,12 @@ __global__ __launch_bounds__(kThreads) void cl_tiled_backward(const ClTiledBwdPa
     }
     const char *ringx = reinterpret_cast<const char *>(ring), *ringg = ringx + kBRingWords * 4;
     double acc[2] = {0.0, 0.0};
-    auto lds_f = [&](const char *base, int row, int colo) {   // a staged element, zero where the padding map says so
+    auto lds_s = [&](const char *base, int row, int colo) {   // a staged element (storage type), zero where the padding map says so
         const bool ok = row >= 0 && colo >= 0;
-        const float v = *reinterpret_cast<const float *>(base + (ok ? row + colo : 0));
-        return ok ? v : 0.0f;
+        const S v = *reinterpret_cast<const S *>(base + (ok ? row + colo : 0));
+        return ok ? v : narrow<T>(CT(0));
     };
+    auto lds_f = [&](const char *base, int row, int colo) { return widen<T>(lds_s(base, row, colo)); };
     auto row_off = [&](int sy) { return sy < 0 ? -1 : (sy & (kBRing - 1)) * (kBRowWords * 4); };
     // Source rows with ONE fold of the signed shift (|shift| <= R and H >= 5, or H == 1: the host routes nothing else
     // here): idx in [h - R, h + R + 1] leaves [0, H) by at most R + 1 on one side.  Launch-uniform coefficients instead of
@@ -468,16 +470,17 @@ __global__ __launch_bounds__(kThreads) void cl_tiled_backward(const ClTiledBwdPa
         const int gr0 = ACTIVE ? xr0 : row_off(fold1(h + sh_s)), gr1 = ACTIVE ? xr1 : -1;
         const int gdr = (h & (kBRing - 1)) * (kBRowWords * 4);
         const bool skip = srow && h == H - 1;
-        float res[2], s0 = 0.0f, s1 = 0.0f;
+        S res[NI];
+        CT s0 = CT(0), s1 = CT(0);
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
+        for (int i = 0; i < NI; ++i) {
             CT v[4], wg[3];
             v[0] = lds_f(ringx, xr0, xc0[i]);
             v[1] = lds_f(ringx, xr1, xc0[i]);
             v[2] = lds_f(ringx, xr0, xc1[i]);
             v[3] = lds_f(ringx, xr1, xc1[i]);
-            const float graw = *reinterpret_cast<const float *>(ringg + gdr + gd[i]);
-            const float gval = (live[i] && !skip) ? graw : 0.0f;
+            const CT graw = widen<T>(*reinterpret_cast<const S *>(ringg + gdr + gd[i]));
+            const CT gval = (live[i] && !skip) ? graw : CT(0);
             weight_grads_nd<2, CT>(v, dw, wg);
             s0 += gval * wg[0];
             s1 += gval * wg[1];
@@ -486,15 +489,25 @@ __global__ __launch_bounds__(kThreads) void cl_tiled_backward(const ClTiledBwdPa
                 v[1] = lds_f(ringg, gr1, gc0[i]);
                 v[2] = lds_f(ringg, gr0, gc1[i]);
                 v[3] = lds_f(ringg, gr1, gc1[i]);
-                res[i] = interp_t<T, 2>(v, dw);
+                res[i] = narrow<T>(interp_t<T, 2>(v, dw));
             } else {
-                res[i] = lds_f(ringg, gr0, gc0[i]);   // pure copy: the bit pattern is kept
+                res[i] = lds_s(ringg, gr0, gc0[i]);   // pure copy: the bit pattern is kept
             }
         }
-        acc[0] += static_cast<double>(s0);   // (the two pixels' terms are added in fp32 first)
+        acc[0] += static_cast<double>(s0);   // (the pixels' terms of one row are added in fp32 first)
         acc[1] += static_cast<double>(s1);
 #pragma unroll
-        for (int i = 0; i < 2; ++i) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(res[i]), ores, skip ? kOutOfRange : ooff[i], so, 0);
+        for (int i = 0; i < NI; ++i) {
+            if constexpr (ES == 4) {
+                uint32_t bits;
+                __builtin_memcpy(&bits, &res[i], 4);
+                __builtin_amdgcn_raw_buffer_store_b32(bits, ores, skip ? kOutOfRange : ooff[i], so, 0);
+            } else {
+                uint16_t bits;
+                __builtin_memcpy(&bits, &res[i], 2);
+                __builtin_amdgcn_raw_buffer_store_b16(bits, ores, skip ? kOutOfRange : ooff[i], so, 0);
+            }
+        }
     };
     int hb = h0;
     for (; hb + kDepth <= h1; hb += kDepth) {   // whole groups: no condition between the steps (exact wait counts)
@@ -507,29 +520,33 @@ __global__ __launch_bounds__(kThreads) void cl_tiled_backward(const ClTiledBwdPa
 
     // ---- what the rings could not serve: channels whose shift leaves them, and the reflected corners above; everything
     // from memory, element by element (rare) ------------------------------------------------------------------------------
-    if (live_c && (far_c || scol[0] || scol[1] || srow)) {
-        const float *xe = reinterpret_cast<const float *>(xn) + c, *ge = reinterpret_cast<const float *>(gn) + c;
-        float *oe = reinterpret_cast<float *>(on) + c;
-        auto tap = [&](const float *base, int r, int cc) { return (r >= 0 && cc >= 0) ? base[(static_cast<int64_t>(r) * W + cc) * C] : 0.0f; };
+    bool any_scol = false;
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int wq = w0 + lane_b + 8 * i;
+    for (int i = 0; i < NI; ++i) any_scol = any_scol || scol[i];
+    if (live_c && (far_c || any_scol || srow)) {
+        const S *xe = reinterpret_cast<const S *>(xn) + c, *ge = reinterpret_cast<const S *>(gn) + c;
+        S *oe = reinterpret_cast<S *>(on) + c;
+        auto tap_s = [&](const S *base, int r, int cc) { return (r >= 0 && cc >= 0) ? base[(static_cast<int64_t>(r) * W + cc) * C] : narrow<T>(CT(0)); };
+        auto tap = [&](const S *base, int r, int cc) { return widen<T>(tap_s(base, r, cc)); };
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            const int wq = w0 + lane_b + PL * i;
             if (wq >= W) continue;
             const int a0 = fold_w(wq - csxW), a1 = fold_w(wq - csxW + 1), b0 = fold_w(wq - csgW), b1 = fold_w(wq - csgW + 1);
             for (int h = h0; h < h1; ++h) {
                 if (!(far_c || scol[i] || (srow && h == H - 1))) continue;
                 const int r0 = fold_h(h - csxH), r1 = fold_h(h - csxH + 1), s0 = fold_h(h - csgH), s1 = fold_h(h - csgH + 1);
                 CT v[4] = {tap(xe, r0, a0), tap(xe, r1, a0), tap(xe, r0, a1), tap(xe, r1, a1)}, wg[3];
-                const float gval = ge[(static_cast<int64_t>(h) * W + wq) * C];
+                const CT gval = widen<T>(ge[(static_cast<int64_t>(h) * W + wq) * C]);
                 weight_grads_nd<2, CT>(v, dw, wg);
                 acc[0] += static_cast<double>(gval * wg[0]);
                 acc[1] += static_cast<double>(gval * wg[1]);
-                float r;
+                S r;
                 if constexpr (ACTIVE) {
                     CT u[4] = {tap(ge, s0, b0), tap(ge, s1, b0), tap(ge, s0, b1), tap(ge, s1, b1)};
-                    r = interp_t<T, 2>(u, dw);
+                    r = narrow<T>(interp_t<T, 2>(u, dw));
                 } else {
-                    r = tap(ge, s0, b0);
+                    r = tap_s(ge, s0, b0);
                 }
                 oe[(static_cast<int64_t>(h) * W + wq) * C] = r;
             }
@@ -544,9 +561,9 @@ __global__ __launch_bounds__(kThreads) void cl_tiled_backward(const ClTiledBwdPa
     __syncthreads();
     if (lane_b == 0 && live_c) {
         double t0 = 0.0, t1 = 0.0;
-        for (int k = 0; k < kThreads / 32; ++k) {
-            t0 += red[(k * 32 + lane_a) * 2];
-            t1 += red[(k * 32 + lane_a) * 2 + 1];
+        for (int k = 0; k < PL; ++k) {
+            t0 += red[(k * CB + lane_a) * 2];
+            t1 += red[(k * CB + lane_a) * 2 + 1];
         }
         double *dst = p.partials + (static_cast<size_t>(pidx) * C + c) * 3;
         dst[0] = t0;
@@ -572,8 +589,11 @@ __global__ __launch_bounds__(kThreads) void cl_tiled_active_forward(const ClTile
     typedef uint32_t u4 __attribute__((ext_vector_type(4)));
     using S = typename T::S;
     using CT = typename T::C;
-    static_assert(sizeof(S) == 4, "4-byte elements");
-    constexpr int ES = 4, CB = kLine / ES;
+    static_assert(sizeof(S) == 4 || sizeof(S) == 2, "fp32, fp16, bf16");
+    constexpr int ES = sizeof(S), CB = kLine / ES;   // channels per workgroup: 32 (fp32) or 64 (16-bit types)
+    // OUT_CL: thread = (channel lane % CB, pixel lane), columns pl + PL i;  else thread = (column lane % 32, channel lane
+    // 0..7), channels cl + 8 i.  Either way NI outputs per row.
+    constexpr int LA = OUT_CL ? CB : kTW, PL = kThreads / LA, NI = OUT_CL ? kTW / PL : CB / PL;
     __shared__ uint32_t ring[kARing * kARowWords + 4];
     __shared__ int tab_sh[CB], tab_sw[CB];     // signed row shift (or out of the ring: INT_MIN), canonical column shift
     __shared__ int tab_shc[CB];                // canonical row shift (the element-by-element pass)
@@ -658,20 +678,20 @@ __global__ __launch_bounds__(kThreads) void cl_tiled_active_forward(const ClTile
     }
     __syncthreads();
 
-    // ---- thread -> outputs: OUT_CL one channel (lane % 32), columns pl + 8 i; else one column, channels cl + 8 i ---------
-    const int lane_a = static_cast<int>(threadIdx.x) & 31, lane_b = static_cast<int>(threadIdx.x) >> 5;
-    constexpr int NCH = OUT_CL ? 1 : 4;
+    // ---- thread -> outputs ---------------------------------------------------------------------------------------------
+    const int lane_a = static_cast<int>(threadIdx.x) % LA, lane_b = static_cast<int>(threadIdx.x) / LA;
+    constexpr int NCH = OUT_CL ? 1 : NI;
     auto fold_w = [&](int idx) { return W == 1 ? 0 : fold_index(idx, W, p.pad); };
     auto fold_h = [&](int idx) { return H == 1 ? 0 : fold_index(idx, H, p.pad); };
     int shs[NCH];              // signed row shift of the thread's channel(s)
     CT dws[NCH][2];
     bool srow[NCH];
-    int xc0[4], xc1[4];        // LDS byte offsets (within a ring row) of the corners' columns; -1: padding
-    uint32_t ooff[4];
+    int xc0[NI], xc1[NI];      // LDS byte offsets (within a ring row) of the corners' columns; -1: padding
+    uint32_t ooff[NI];
     uint32_t live = 0, rest = 0;   // bit i: served from the ring / left to the element-by-element pass (all rows)
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int ch = OUT_CL ? lane_a : lane_b + 8 * i, col = OUT_CL ? lane_b + 8 * i : lane_a;
+    for (int i = 0; i < NI; ++i) {
+        const int ch = OUT_CL ? lane_a : lane_b + PL * i, col = OUT_CL ? lane_b + PL * i : lane_a;
         const int c = c0 + ch, k = OUT_CL ? 0 : i;
         const bool inside = c < C && w0 + col < W;
         const int s = tab_sh[ch], sw = tab_sw[ch];
@@ -686,7 +706,7 @@ __global__ __launch_bounds__(kThreads) void cl_tiled_active_forward(const ClTile
         const bool mine = inside && s != kFarShift && !outside(a0) && !outside(a1);
         live |= (mine ? 1u : 0u) << i;
         rest |= ((inside && !mine) ? 1u : 0u) << i;
-        auto lds_col = [&](int sx) { return (mine && sx >= 0) ? (sx - (w0 - kR)) * (kPitch * 4) + ch * 4 : -1; };
+        auto lds_col = [&](int sx) { return (mine && sx >= 0) ? (sx - (w0 - kR)) * (kPitch * 4) + ch * ES : -1; };
         xc0[i] = lds_col(a0);
         xc1[i] = lds_col(a1);
         const uint32_t o = OUT_CL ? (static_cast<uint32_t>(h0 * W + w0 + col) * C + c) * ES
@@ -703,8 +723,8 @@ __global__ __launch_bounds__(kThreads) void cl_tiled_active_forward(const ClTile
     const char *ringx = reinterpret_cast<const char *>(ring);
     auto lds_f = [&](int row, int colo) {
         const bool ok = row >= 0 && colo >= 0;
-        const float v = *reinterpret_cast<const float *>(ringx + (ok ? row + colo : 0));
-        return ok ? v : 0.0f;
+        const S v = *reinterpret_cast<const S *>(ringx + (ok ? row + colo : 0));
+        return ok ? widen<T>(v) : CT(0);
     };
     auto row_off = [&](int sy) { return sy < 0 ? -1 : (sy & (kARing - 1)) * (kARowWords * 4); };
     const int fm = (p.pad == 3 || p.pad == 4) ? -1 : 0;   // one fold of the signed shift: see cl_tiled_backward
@@ -735,20 +755,30 @@ __global__ __launch_bounds__(kThreads) void cl_tiled_active_forward(const ClTile
             xr1[k] = row_off(xrow1[k]);
             skip[k] = srow[k] && h == H - 1;
         }
-        float res[4];
+        S res[NI];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < NI; ++i) {
             const int k = OUT_CL ? 0 : i;
             CT v[4];
             v[0] = lds_f(xr0[k], xc0[i]);
             v[1] = lds_f(xr1[k], xc0[i]);
             v[2] = lds_f(xr0[k], xc1[i]);
             v[3] = lds_f(xr1[k], xc1[i]);
-            res[i] = interp_t<T, 2>(v, dws[k]);
+            res[i] = narrow<T>(interp_t<T, 2>(v, dws[k]));
         }
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
-            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(res[i]), ores, skip[OUT_CL ? 0 : i] ? kOutOfRange : ooff[i], so, 0);
+        for (int i = 0; i < NI; ++i) {
+            const uint32_t off = skip[OUT_CL ? 0 : i] ? kOutOfRange : ooff[i];
+            if constexpr (ES == 4) {
+                uint32_t bits;
+                __builtin_memcpy(&bits, &res[i], 4);
+                __builtin_amdgcn_raw_buffer_store_b32(bits, ores, off, so, 0);
+            } else {
+                uint16_t bits;
+                __builtin_memcpy(&bits, &res[i], 2);
+                __builtin_amdgcn_raw_buffer_store_b16(bits, ores, off, so, 0);
+            }
+        }
     };
     int hb = h0;
     for (; hb + kDepth <= h1; hb += kDepth) {
@@ -764,22 +794,22 @@ __global__ __launch_bounds__(kThreads) void cl_tiled_active_forward(const ClTile
 #pragma unroll
     for (int k = 0; k < NCH; ++k) any_srow = any_srow || srow[k];
     if (rest || any_srow) {
-        const float *xe = reinterpret_cast<const float *>(xn);
-        auto tap = [&](const float *base, int r, int cc) { return (r >= 0 && cc >= 0) ? base[(static_cast<int64_t>(r) * W + cc) * C] : 0.0f; };
+        const S *xe = reinterpret_cast<const S *>(xn);
+        auto tap = [&](const S *base, int r, int cc) { return (r >= 0 && cc >= 0) ? widen<T>(base[(static_cast<int64_t>(r) * W + cc) * C]) : CT(0); };
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < NI; ++i) {
             const int k = OUT_CL ? 0 : i;
             const bool all_rows = (rest >> i) & 1u, last_row = ((live >> i) & 1u) && srow[k];
             if (!all_rows && !last_row) continue;
-            const int ch = OUT_CL ? lane_a : lane_b + 8 * i, col = OUT_CL ? lane_b + 8 * i : lane_a;
+            const int ch = OUT_CL ? lane_a : lane_b + PL * i, col = OUT_CL ? lane_b + PL * i : lane_a;
             const int shc = tab_shc[ch], sw = tab_sw[ch], wq = w0 + col;
             const int a0 = fold_w(wq - sw), a1 = fold_w(wq - sw + 1);
-            float *o = reinterpret_cast<float *>(on) + (OUT_CL ? (static_cast<int64_t>(h0) * W + wq) * C + c0 + ch
+            S *o = reinterpret_cast<S *>(on) + (OUT_CL ? (static_cast<int64_t>(h0) * W + wq) * C + c0 + ch
                                                                : (static_cast<int64_t>(c0 + ch) * H + h0) * W + wq);
             for (int h = all_rows ? h0 : H - 1; h < h1; ++h) {
                 const int r0 = fold_h(h - shc), r1 = fold_h(h - shc + 1);
                 CT v[4] = {tap(xe + c0 + ch, r0, a0), tap(xe + c0 + ch, r1, a0), tap(xe + c0 + ch, r0, a1), tap(xe + c0 + ch, r1, a1)};
-                o[static_cast<int64_t>(h - h0) * (OUT_CL ? W * C : W)] = interp_t<T, 2>(v, dws[k]);
+                o[static_cast<int64_t>(h - h0) * (OUT_CL ? W * C : W)] = narrow<T>(interp_t<T, 2>(v, dws[k]));
             }
         }
     }
@@ -807,8 +837,8 @@ void cl_tiled_set_tuning(int knob, int value) {
 bool cl_tiled_forward_eligible(const Geometry &g, int dtype, const void *x, const void *out) {
     const int es = dtype_size(dtype);
     if (!g_cl_tiled_tune[0] || g.nd != 2 || es > 4 || g.pad == 2) return false;
-    if (g.active && dtype <= SHIFTND_BF16) {  // interpolating: cl_tiled_active_forward, fp32, rows folded once
-        if (dtype != SHIFTND_F32 || (g.S[1] != 1 && g.S[1] < 5)) return false;
+    if (g.active && dtype <= SHIFTND_BF16) {  // interpolating: cl_tiled_active_forward (fp32, fp16, bf16), rows folded once
+        if (dtype == SHIFTND_F64 || (g.S[1] != 1 && g.S[1] < 5)) return false;
     }
     for (int d = 0; d < 3; ++d)
         if (g.L[d] != 0 || g.O[d] != g.S[d]) return false;
@@ -857,8 +887,13 @@ int cl_tiled_forward(const Geometry &g, int dtype, const void *x, const void *w,
     p.d_perW = make_fastdiv(static_cast<uint32_t>(map_period(p.W, p.pad)));
     if (g.active && dtype <= SHIFTND_BF16) {
         note_kernel("cl_tiled_active_forward");
-        if (p.out_cl) hipLaunchKernelGGL((cl_tiled_active_forward<f32_t, true>), dim3(static_cast<unsigned>(grid)), dim3(kThreads), 0, st, p);
-        else hipLaunchKernelGGL((cl_tiled_active_forward<f32_t, false>), dim3(static_cast<unsigned>(grid)), dim3(kThreads), 0, st, p);
+#define SHIFTND_CLT_ACTIVE(TT) \
+    if (p.out_cl) hipLaunchKernelGGL((cl_tiled_active_forward<TT, true>), dim3(static_cast<unsigned>(grid)), dim3(kThreads), 0, st, p); \
+    else hipLaunchKernelGGL((cl_tiled_active_forward<TT, false>), dim3(static_cast<unsigned>(grid)), dim3(kThreads), 0, st, p);
+        if (dtype == SHIFTND_F32) { SHIFTND_CLT_ACTIVE(f32_t) }
+        else if (dtype == SHIFTND_F16) { SHIFTND_CLT_ACTIVE(f16_t) }
+        else { SHIFTND_CLT_ACTIVE(bf16_t) }
+#undef SHIFTND_CLT_ACTIVE
         return SHIFTND_OK;
     }
     note_kernel("cl_tiled_forward");
@@ -878,11 +913,12 @@ struct ClTiledBwdPlan {
     int wtiles, cblocks, bands, band_rows;
     int64_t groups;
 };
-ClTiledBwdPlan cl_tiled_backward_plan(const Geometry &g) {
+ClTiledBwdPlan cl_tiled_backward_plan(const Geometry &g, int es = 4) {
     ClTiledBwdPlan pl;
     const int H = static_cast<int>(g.S[1]), W = static_cast<int>(g.S[2]);
     pl.wtiles = (W + kBTW - 1) / kBTW;
-    pl.cblocks = static_cast<int>((g.C + 31) / 32);
+    const int cbw = kLine / es;
+    pl.cblocks = static_cast<int>((g.C + cbw - 1) / cbw);
     // bands along H: ~7 workgroups per workgroup slot, at least 8 R rows per band, and (when the batch allows) at most
     // 4096 partial-sum groups per channel
     const int64_t base = g.N * pl.wtiles;
@@ -900,29 +936,42 @@ ClTiledBwdPlan cl_tiled_backward_plan(const Geometry &g) {
 }
 }  // namespace
 
-// 2-D fp32, no crop, not periodic; saved input, incoming gradient and grad_x dense channels-last, C a multiple of 4
+// 2-D fp32 / fp16 / bf16, no crop, not periodic; saved input, incoming gradient and grad_x dense channels-last, pixel
+// lines of whole 16-byte pieces
 bool cl_tiled_backward_eligible(const Geometry &g, int dtype, const void *go, const void *x, const void *gx) {
-    if (!g_cl_tiled_tune[0] || g.nd != 2 || dtype != SHIFTND_F32 || g.pad == 2) return false;
+    if (!g_cl_tiled_tune[0] || g.nd != 2 || (dtype != SHIFTND_F32 && dtype != SHIFTND_F16 && dtype != SHIFTND_BF16) || g.pad == 2) return false;
+    const int es = dtype_size(dtype);
     for (int d = 0; d < 3; ++d)
         if (g.L[d] != 0 || g.O[d] != g.S[d]) return false;
-    if (g.C % 4 != 0 || g.S[1] >= (1 << 20) || g.S[2] >= (1 << 20) || g.N >= (1LL << 24) || g.C >= (1 << 24)) return false;
+    if ((g.C * es) % 16 != 0 || g.S[1] >= (1 << 20) || g.S[2] >= (1 << 20) || g.N >= (1LL << 24) || g.C >= (1 << 24)) return false;
     if (g.S[1] != 1 && g.S[1] < 5) return false;  // the kernel folds source rows once
-    if (reinterpret_cast<uintptr_t>(x) % 16 != 0 || reinterpret_cast<uintptr_t>(go) % 16 != 0 || reinterpret_cast<uintptr_t>(gx) % 4 != 0) return false;
-    if (g.C * g.S[1] * g.S[2] * 4 >= (1LL << 31)) return false;
+    if (reinterpret_cast<uintptr_t>(x) % 16 != 0 || reinterpret_cast<uintptr_t>(go) % 16 != 0 || reinterpret_cast<uintptr_t>(gx) % es != 0) return false;
+    if (g.C * g.S[1] * g.S[2] * es >= (1LL << 31)) return false;
     if (!dense_channels_last_2d(g.xs, g, g.S) || !dense_channels_last_2d(g.os, g, g.O) || !dense_channels_last_2d(g.gs, g, g.S)) return false;
-    const ClTiledBwdPlan pl = cl_tiled_backward_plan(g);
+    const ClTiledBwdPlan pl = cl_tiled_backward_plan(g, es);
     return pl.groups * pl.cblocks < (1LL << 31);
 }
 
-size_t cl_tiled_backward_workspace(const Geometry &g) {
+size_t cl_tiled_backward_workspace(const Geometry &g) {   // (geometry only: the larger of the 4- and 2-byte plans)
     if (g.nd != 2 || g.C < 1 || g.N * g.S[1] * g.S[2] < 1) return 0;
-    const ClTiledBwdPlan pl = cl_tiled_backward_plan(g);
-    return static_cast<size_t>(pl.groups) * static_cast<size_t>(g.C) * 3 * sizeof(double);
+    const ClTiledBwdPlan p4 = cl_tiled_backward_plan(g, 4), p2 = cl_tiled_backward_plan(g, 2);
+    return static_cast<size_t>(p4.groups > p2.groups ? p4.groups : p2.groups) * static_cast<size_t>(g.C) * 3 * sizeof(double);
 }
+
+namespace {
+template <typename T>
+void launch_cl_tiled_backward(const ClTiledBwdParams &p, const ClTiledBwdPlan &pl, bool active, void *gw, hipStream_t st) {
+    const dim3 grid(static_cast<unsigned>(pl.groups * pl.cblocks)), block(kThreads);
+    if (active) hipLaunchKernelGGL((cl_tiled_backward<T, true>), grid, block, 0, st, p);
+    else hipLaunchKernelGGL((cl_tiled_backward<T, false>), grid, block, 0, st, p);
+    hipLaunchKernelGGL((reduce_weight_grads<T>), dim3(p.C * 2), dim3(64), 0, st, p.partials, static_cast<int>(pl.groups), p.C, 2,
+                       static_cast<typename T::S *>(gw));
+}
+}  // namespace
 
 int cl_tiled_backward(const Geometry &g, int dtype, const void *go, const void *x, const void *w, void *gx, void *gw,
                       void *workspace, hipStream_t st) {
-    const ClTiledBwdPlan pl = cl_tiled_backward_plan(g);
+    const ClTiledBwdPlan pl = cl_tiled_backward_plan(g, dtype_size(dtype));
     ClTiledBwdParams p{};
     p.x = static_cast<const char *>(x);
     p.go = static_cast<const char *>(go);
@@ -944,12 +993,13 @@ int cl_tiled_backward(const Geometry &g, int dtype, const void *go, const void *
     p.d_bands = make_fastdiv(static_cast<uint32_t>(p.bands));
     p.d_perH = make_fastdiv(static_cast<uint32_t>(map_period(p.H, p.pad)));
     p.d_perW = make_fastdiv(static_cast<uint32_t>(map_period(p.W, p.pad)));
-    const dim3 grid(static_cast<unsigned>(pl.groups * pl.cblocks)), block(kThreads);
     note_kernel("cl_tiled_backward");
-    if (g.active) hipLaunchKernelGGL((cl_tiled_backward<f32_t, true>), grid, block, 0, st, p);
-    else hipLaunchKernelGGL((cl_tiled_backward<f32_t, false>), grid, block, 0, st, p);
-    hipLaunchKernelGGL((reduce_weight_grads<f32_t>), dim3(p.C * 2), dim3(64), 0, st, p.partials, static_cast<int>(pl.groups), p.C, 2,
-                       static_cast<float *>(gw));
+    switch (dtype) {
+    case SHIFTND_F32: launch_cl_tiled_backward<f32_t>(p, pl, g.active != 0, gw, st); break;
+    case SHIFTND_F16: launch_cl_tiled_backward<f16_t>(p, pl, g.active != 0, gw, st); break;
+    case SHIFTND_BF16: launch_cl_tiled_backward<bf16_t>(p, pl, g.active != 0, gw, st); break;
+    default: return SHIFTND_ERR_UNSUPPORTED_DTYPE;
+    }
     return SHIFTND_OK;
 }
 

@@ -309,6 +309,46 @@ def test_tiled_channels_last_active_forward_vs_oracle(shape):
         abi.set_tuning(21, 0)
 
 
+@pytest.mark.parametrize("tdt", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("shape", [(2, 8, 9, 12), (2, 72, 40, 70), (1, 64, 100, 33), (2, 16, 1, 50)])
+def test_tiled_channels_last_16bit_active_and_backward(shape, tdt):
+    """cl_tiled_active_forward / cl_tiled_backward for fp16 and bf16 (64 channels per workgroup, 2-byte stores): the same
+    bits as the contiguous kernels (one definition of the 16-bit interpolation, shiftnd_common.hpp interp_t), which the
+    oracle checks elsewhere; grad_w within the 16-bit epsilon"""
+    from torchshifts import abi
+    rs = np.random.RandomState(sum(shape) + 13)
+    cl = torch.channels_last
+    x = torch.from_numpy(rs.uniform(-1, 1, size=shape).astype(np.float32)).to(tdt).to(DEV)
+    go = torch.from_numpy(rs.uniform(-1, 1, size=shape).astype(np.float32)).to(tdt).to(DEV)
+    w = rs.uniform(-3.9, 3.9, size=(shape[1], 2)).astype(np.float32)
+    w[0] = [0.5, -1.5]
+    w[1] = [shape[2] + 2.25, -7.0]       # beyond the dim / beyond the ring
+    w[2] = [-5.0, 2.5]
+    w[3] = [-2.75, -2.25]
+    wd = torch.from_numpy(w).to(tdt).to(DEV)
+    xc, goc = x.contiguous(memory_format=cl), go.contiguous(memory_format=cl)
+    eps = float(torch.finfo(tdt).eps)
+    try:
+        for band_rows in (0, 7):
+            abi.set_tuning(21, band_rows)
+            for pad in (0, 1, 3, 4):
+                ref = abi.forward(x, wd, pad, True)
+                out = abi.forward(xc, wd, pad, True)   # NCHW-contiguous output
+                nchw_tiled = (shape[3] * 2) % 4 == 0
+                assert (abi.last_kernel() == "cl_tiled_active_forward") == nchw_tiled and torch.equal(out, ref), (shape, pad)
+                out_cl = torch.empty(shape, dtype=tdt, device=DEV).contiguous(memory_format=cl)
+                abi.forward(xc, wd, pad, True, out=out_cl)
+                assert abi.last_kernel() == "cl_tiled_active_forward" and torch.equal(out_cl, ref), (shape, pad)
+                for active in (0, 1):
+                    gx_r, gw_r = abi.backward(go, wd, x, pad, active)
+                    gx, gw = abi.backward(goc, wd, xc, pad, active, grad_x=torch.empty(shape, dtype=tdt, device=DEV).contiguous(memory_format=cl))
+                    assert abi.last_kernel() == "cl_tiled_backward", (shape, pad, active)
+                    assert torch.equal(gx, gx_r), (shape, pad, active, band_rows)
+                    assert rel_err(gw.float().cpu().numpy(), gw_r.float().cpu().numpy()) < 4 * eps, (shape, pad, active)
+    finally:
+        abi.set_tuning(21, 0)
+
+
 def test_channels_last_input_through_the_op_uses_the_tiled_kernel():
     """torch.ops.torchshifts.shift2d with a channels-last fp32 input: one pass (no layout change first), NCHW result
     like the reference (cpu/shifts_cpu.cpp:221), same bits as the contiguous input"""

@@ -52,3 +52,16 @@ t2 = ev(lambda: abi.forward(xhc, wh, 0, 0, out=oh2)); k2 = abi.last_kernel()
 t3 = ev(lambda: abi.forward(xhc, wh, 0, 0, out=ohc)); k3 = abi.last_kernel()
 assert torch.equal(oh, oh2) and torch.equal(oh, ohc)
 print("fp16 N16 C256 224^2  NCHW %.3f ms (%s)   CL->NCHW %.3f ms (%s)   CL->CL %.3f ms (%s)" % (t1, k1, t2, k2, t3, k3))
+# bf16 active forward / backward, all tensors channels-last
+xb = torch.rand(16, 256, 224, 224, device=dev).bfloat16(); wb = (torch.rand(256, 2, device=dev) * 6 - 3).bfloat16()
+gb = torch.rand(16, 256, 224, 224, device=dev).bfloat16()
+xbc = xb.contiguous(memory_format=torch.channels_last); gbc = gb.contiguous(memory_format=torch.channels_last)
+ob = torch.empty_like(xb); obc = torch.empty_like(xbc); gxb = torch.empty_like(xb); gxbc = torch.empty_like(xbc); gwb = torch.empty_like(wb)
+ws = abi.backward_workspace(xb, 0, 1)
+for active in (0, 1):
+    t1 = ev(lambda: abi.forward(xb, wb, 0, active, out=ob)); k1 = abi.last_kernel()
+    t2 = ev(lambda: abi.forward(xbc, wb, 0, active, out=obc)); k2 = abi.last_kernel()
+    t3 = ev(lambda: abi.backward(gb, wb, xb, 0, active, grad_x=gxb, grad_w=gwb, workspace=ws)); k3 = abi.last_kernel()
+    t4 = ev(lambda: abi.backward(gbc, wb, xbc, 0, active, grad_x=gxbc, grad_w=gwb, workspace=ws)); k4 = abi.last_kernel()
+    assert torch.equal(ob, obc) and torch.equal(gxb, gxbc)
+    print("bf16 active=%d  fwd NCHW %.3f ms (%s)  NHWC %.3f ms (%s)   bwd NCHW %.3f ms (%s)  NHWC %.3f ms (%s)" % (active, t1, k1, t2, k2, t3, k3, t4, k4))

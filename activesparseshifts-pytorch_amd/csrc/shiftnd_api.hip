@@ -99,6 +99,10 @@ int forward_common(const shiftnd_problem *p, const void *x, const int64_t *xs, c
             return finish(plane_forward(g, p->dtype, x, w, wkind, wzp, fill, out, st));
         }
     }
+    if (g_policy == 0 && small_forward_eligible(g, p->dtype)) {  // interpolating, rows not whole 16-byte pieces, small planes
+        g_last_path = SHIFTND_PATH_PLANE;
+        return finish(small_forward(g, p->dtype, x, w, out, st));
+    }
     if ((g_policy == 0 || g_policy == 4) && cl_tiled_forward_eligible(g, p->dtype, x, out)) {  // channels-last in, LDS-tiled
         g_last_path = SHIFTND_PATH_CL;
         return finish(cl_tiled_forward(g, p->dtype, x, w, wkind, wzp, fill, out, st));
@@ -143,7 +147,8 @@ int shiftnd_last_path(void) { return g_last_path; }
 void shiftnd_set_path_policy(int policy) { g_policy = policy; }
 
 void shiftnd_set_tuning(int knob, int value) {
-    if (knob >= 20) cl_tiled_set_tuning(knob - 20, value);  // 20: LDS-tiled channels-last forward on / off, 21: rows per band
+    if (knob >= 24) small_set_tuning(knob - 24, value);  // 24: small-plane kernels on / off, 25: planes per round, 26: rounds per workgroup
+    else if (knob >= 20) cl_tiled_set_tuning(knob - 20, value);  // 20: LDS-tiled channels-last forward on / off, 21: rows per band
     else if (knob >= 16) bytes_set_tuning(knob - 16, value);  // 16: 1-byte small-plane kernel on / off, 17: planes per workgroup
     else if (knob >= 12) slide_set_tuning(knob - 12, value);  // 12: which problems slide, 13: workgroups wanted, 14: min rows per band
     else if (knob >= 8) sweep_set_tuning(knob - 8, value);  // 8/9: sweep forward K / max threads, 10/11: sweep backward
@@ -242,9 +247,11 @@ size_t shiftnd_backward_workspace_bytes(const shiftnd_problem *p) {
     const size_t c = sweep_backward_workspace(g, p->dtype);
     const size_t d = cl_backward_workspace(g);
     const size_t e = cl_tiled_backward_workspace(g);
+    const size_t f = small_backward_workspace(g, p->dtype);
     size_t m = a > b ? (a > c ? a : c) : (b > c ? b : c);
     m = m > d ? m : d;
-    return m > e ? m : e;
+    m = m > e ? m : e;
+    return m > f ? m : f;
 }
 
 int shiftnd_backward(const shiftnd_problem *p, const void *grad_out, const int64_t grad_out_strides[5], const void *x,
@@ -279,6 +286,11 @@ int shiftnd_backward(const shiftnd_problem *p, const void *grad_out, const int64
         if (plane_backward_workspace(g, p->dtype) > workspace_bytes) return SHIFTND_ERR_WORKSPACE_TOO_SMALL;
         g_last_path = SHIFTND_PATH_PLANE;
         return finish(plane_backward(g, p->dtype, grad_out, x, weights, grad_x, grad_w, workspace, st));
+    }
+    if (g_policy == 0 && small_backward_eligible(g, p->dtype)) {  // rows not whole 16-byte pieces, small planes
+        if (small_backward_workspace(g, p->dtype) > workspace_bytes) return SHIFTND_ERR_WORKSPACE_TOO_SMALL;
+        g_last_path = SHIFTND_PATH_PLANE;
+        return finish(small_backward(g, p->dtype, grad_out, x, weights, grad_x, grad_w, workspace, st));
     }
     if ((g_policy == 0 || g_policy == 4) && cl_tiled_backward_eligible(g, p->dtype, grad_out, x, grad_x)) {  // all channels-last: LDS-tiled
         if (cl_tiled_backward_workspace(g) > workspace_bytes) return SHIFTND_ERR_WORKSPACE_TOO_SMALL;

@@ -95,6 +95,16 @@ size_t cl_tiled_backward_workspace(const Geometry &g);
 int cl_tiled_backward(const Geometry &g, int dtype, const void *go, const void *x, const void *w, void *gx, void *gw,
                       void *workspace, hipStream_t st);
 
+// ---- whole small planes through LDS (shiftnd_small.hip): interpolating forward and backward of contiguous problems whose
+// rows are not whole 16-byte pieces (planes of at most 16 KiB)
+bool small_forward_eligible(const Geometry &g, int dtype);
+int small_forward(const Geometry &g, int dtype, const void *x, const void *w, void *out, hipStream_t st);
+bool small_backward_eligible(const Geometry &g, int dtype);
+size_t small_backward_workspace(const Geometry &g, int dtype);
+int small_backward(const Geometry &g, int dtype, const void *go, const void *x, const void *w, void *gx, void *gw,
+                   void *workspace, hipStream_t st);
+void small_set_tuning(int knob, int value);
+
 // ---- layout change (shiftnd_transpose.hip): dst[n][c][r] = src[n][r][c], dense tensors ---------------------------
 int transpose_planes(const void *src, void *dst, int64_t N, int64_t rows, int64_t cols, int esize, hipStream_t st);
 

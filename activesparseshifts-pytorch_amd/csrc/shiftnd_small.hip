@@ -1,0 +1,351 @@
+// shiftnd_small.hip -- whole small planes through LDS, gfx950 (MI355X): the interpolating forward and the backward
+// pass of contiguous problems whose rows are NOT whole 16-byte pieces (a 14 x 14 or 7 x 7 fp32 plane: 56- / 28-byte
+// rows) -- the late stages of a ResNet-shaped network, which the row-chunk kernels (16-byte rows) cannot take and the
+// one-thread-per-element fallback served at 0.15-0.7 TB/s (N128 C512 14x14 fp32: backward 0.32 ms, N128 C1024 7x7:
+// 0.51 ms).
+//
+// A plane of <= a few thousand elements fits LDS many times over, and the shift is one number per channel and dim, so
+//   * one workgroup = one channel x `ppr * rpw` batch entries, in `rpw` rounds of `ppr` planes: the per-channel index
+//     maps (build_maps) are built once per workgroup;
+//   * per round the planes of the saved input (and of the incoming gradient) are copied to LDS element by element with
+//     coalesced loads (a plane is one contiguous run of memory, at element alignment only);
+//   * a thread owns flat (plane, element) indices idx = tid + 256 k: every lane is busy whatever the plane size; the
+//     element's coordinates come from two multiply-shift divisions, its corner rows / columns from the maps, the corner
+//     values from LDS; stores are coalesced element stores;
+//   * backward: fp64 weight-gradient sums per thread, one block sum per workgroup into the [group][C][3] partial sums
+//     that reduce_weight_grads finishes (deterministic).
+// Arithmetic is the shared one (interp_t, weight_grads_nd, prep_shift_*): results are bit-identical to the other kernel
+// families for forward and grad_x.
+//
+// Reference behaviour restated (paths under torchshifts/csrc/ops/): forward kernels/shifts_kernels.h:156-220, backward
+// :222-327, interpolation kernels/interpolation.h:3-61, weight preparation cpu/shifts_cpu.cpp:223-224, :242-244.
+// Roofline: HBM; forward 2 s bytes per element, backward 3 s.
+#include "shiftnd_common.hpp"
+#include "shiftnd_launch.hpp"
+
+namespace shiftnd {
+namespace {
+
+struct SmallParams {
+    const void *x;       // forward: input; backward: saved input
+    const void *go;      // backward: incoming gradient
+    void *out;           // forward: output; backward: grad_x
+    const void *w;
+    double *partials;    // backward: [groups][C][3]
+    int wkind, N, C, nd, pad;
+    int S[3], wcol[3];
+    int PE;              // elements per plane
+    int ppr, rpw;        // planes per round, rounds per workgroup
+    int map_entries;     // S0 + S1 + S2 + 3
+    unsigned xcd_blocks;
+    FastDiv d_S2, d_S12, d_PE, d_C;
+    FastDiv d_per[3];
+};
+
+template <typename T, int ND, bool ACTIVE, bool BACKWARD>
+__global__ __launch_bounds__(kThreads) void small_plane_kernel(const SmallParams p) {
+    using S = typename T::S;
+    using CT = typename T::C;
+    constexpr int NC = 1 << ND;
+    static_assert(ACTIVE || BACKWARD, "the sparse-shift forward is served by the gather kernels");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    __shared__ double scratch[kThreads / 64];
+    int *maps = reinterpret_cast<int *>(smem);
+    const int S0 = p.S[0], S1 = p.S[1], S2 = p.S[2], PE = p.PE;
+    const int *m0 = maps, *m1 = m0 + S0 + 1, *m2 = m1 + S1 + 1;
+    int *gmaps = maps + p.map_entries;
+    const int *g0 = gmaps, *g1 = g0 + S0 + 1, *g2 = g1 + S1 + 1;
+    S *xbuf = reinterpret_cast<S *>(smem + static_cast<size_t>(p.map_entries) * (BACKWARD ? 2 : 1) * sizeof(int));
+    S *gbuf = xbuf + static_cast<size_t>(p.ppr) * PE;   // (backward only)
+
+    const unsigned bid = p.xcd_blocks ? (blockIdx.x & 7u) * p.xcd_blocks + (blockIdx.x >> 3) : blockIdx.x;
+    const int grp = fdiv(bid, p.d_C), c = static_cast<int>(bid) - grp * p.C;
+    const int n0 = grp * p.ppr * p.rpw, nw = min(p.ppr * p.rpw, p.N - n0);
+
+    // ---- per-channel shift and maps ------------------------------------------------------------------------------------
+    int64_t sh[3] = {0, 0, 0};
+    CT dw[3] = {CT(0), CT(0), CT(0)};
+    CT wv[3];
+    load_weights3<CT>(p.w, p.wkind, static_cast<int64_t>(c) * p.nd, p.wcol, wv);
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+        if (p.wcol[d] >= 0) {
+            if constexpr (BACKWARD) prep_shift_backward<CT>(wv[d], ACTIVE, sh[d], dw[p.wcol[d]]);
+            else prep_shift_forward<CT>(wv[d], true, sh[d], dw[p.wcol[d]]);
+        }
+    }
+    build_maps(maps, p.S, sh, -1, p.pad, p.d_per);
+    // grad_x source: the sparse shift reads grad_out at o + shift, the active one at o - shift (shifts_kernels.h:287-293)
+    if constexpr (BACKWARD) build_maps(gmaps, p.S, sh, ACTIVE ? -1 : +1, p.pad, p.d_per);
+
+    const int64_t nstride = static_cast<int64_t>(p.C) * PE;
+    const S *xb = static_cast<const S *>(p.x) + (static_cast<int64_t>(n0) * p.C + c) * PE;
+    const S *gb = BACKWARD ? static_cast<const S *>(p.go) + (static_cast<int64_t>(n0) * p.C + c) * PE : xb;
+    S *ob = static_cast<S *>(p.out) + (static_cast<int64_t>(n0) * p.C + c) * PE;
+    double acc[3] = {0.0, 0.0, 0.0};
+
+    // corner values of one element: rows / columns through the maps, values from the staged plane (zero where the
+    // padding map says so).  Corner order (shifts_kernels.h:58-103): bit r = +1 along the r-th spatial dim of the
+    // tensor, i.e. along the normalised dims [0][1][2] in 3-D, [1][2] in 2-D, [2] in 1-D.
+    auto corners = [&](const S *plane, const int *q0, const int *q1, const int *q2, int a, int b, int cc, CT (&v)[NC]) {
+        if constexpr (ND == 1) {
+            const int c0 = q2[cc], c1 = q2[cc + 1];
+            v[0] = c0 >= 0 ? widen<T>(plane[c0]) : CT(0);
+            v[1] = c1 >= 0 ? widen<T>(plane[c1]) : CT(0);
+        } else if constexpr (ND == 2) {
+            const int r0 = q1[b], r1 = q1[b + 1], c0 = q2[cc], c1 = q2[cc + 1];
+            const int rr[2] = {r0, r1}, ccs[2] = {c0, c1};
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int r = rr[q & 1], col = ccs[q >> 1];
+                const bool ok = r >= 0 && col >= 0;
+                const S raw = plane[ok ? r * S2 + col : 0];
+                v[q] = ok ? widen<T>(raw) : CT(0);
+            }
+        } else {
+            const int d0 = q0[a], d1 = q0[a + 1], r0 = q1[b], r1 = q1[b + 1], c0 = q2[cc], c1 = q2[cc + 1];
+            const int dd[2] = {d0, d1}, rr[2] = {r0, r1}, ccs[2] = {c0, c1};
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const int dep = dd[q & 1], r = rr[(q >> 1) & 1], col = ccs[q >> 2];
+                const bool ok = r >= 0 && col >= 0 && dep >= 0;
+                const S raw = plane[ok ? (dep * S1 + r) * S2 + col : 0];
+                v[q] = ok ? widen<T>(raw) : CT(0);
+            }
+        }
+    };
+
+    for (int r = 0; r * p.ppr < nw; ++r) {
+        const int np = min(p.ppr, nw - r * p.ppr), total = np * PE;
+        const int64_t rbase = static_cast<int64_t>(r) * p.ppr * nstride;
+        __syncthreads();  // the maps are complete / the previous round is done with the buffers
+        for (int idx = threadIdx.x; idx < total; idx += kThreads) {
+            const int pl = fdiv(idx, p.d_PE), o = idx - pl * PE;
+            xbuf[idx] = xb[rbase + pl * nstride + o];
+            if constexpr (BACKWARD) gbuf[idx] = gb[rbase + pl * nstride + o];
+        }
+        __syncthreads();
+        for (int idx = threadIdx.x; idx < total; idx += kThreads) {
+            const int pl = fdiv(idx, p.d_PE), o = idx - pl * PE;
+            const int a = fdiv(o, p.d_S12), rem = o - a * (S1 * S2);
+            const int b = fdiv(rem, p.d_S2), cc = rem - b * S2;
+            const S *xpl = xbuf + pl * PE;
+            S res;
+            if constexpr (BACKWARD) {
+                const S *gpl = gbuf + pl * PE;
+                CT v[NC], wg[3];
+                corners(xpl, m0, m1, m2, a, b, cc, v);
+                const CT gval = widen<T>(gbuf[idx]);
+                weight_grads_nd<ND, CT>(v, dw, wg);
+#pragma unroll
+                for (int s = 0; s < ND; ++s) acc[s] += static_cast<double>(gval * wg[s]);
+                if constexpr (ACTIVE) {
+                    corners(gpl, g0, g1, g2, a, b, cc, v);
+                    res = narrow<T>(interp_t<T, ND>(v, dw));
+                } else {
+                    const int ra = ND == 3 ? g0[a] : 0, rb = ND >= 2 ? g1[b] : 0, rc = g2[cc];
+                    const bool ok = ra >= 0 && rb >= 0 && rc >= 0;
+                    const S raw = gpl[ok ? (ra * S1 + rb) * S2 + rc : 0];
+                    res = ok ? raw : narrow<T>(CT(0));   // pure copy: the bit pattern is kept
+                }
+            } else {
+                CT v[NC];
+                corners(xpl, m0, m1, m2, a, b, cc, v);
+                res = narrow<T>(interp_t<T, ND>(v, dw));
+            }
+            ob[rbase + pl * nstride + o] = res;
+        }
+    }
+
+    if constexpr (BACKWARD) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const double tsum = block_sum(acc[k], scratch);
+            if (threadIdx.x == 0) p.partials[(static_cast<size_t>(grp) * p.C + c) * 3 + k] = tsum;
+        }
+    }
+}
+
+struct SmallPlan {
+    int ppr, rpw, groups, map_entries;
+    size_t lds;
+    unsigned grid;
+    bool ok;
+};
+
+thread_local int g_small_tune[3] = {1, 0, 0};  // [0] enabled, [1] planes per round (0 = automatic), [2] rounds per workgroup
+
+bool contiguous5s(const int64_t st[5], int64_t N, int64_t C, const int64_t sz[3]) {
+    int64_t expect = 1;
+    const int64_t sizes[5] = {N, C, sz[0], sz[1], sz[2]};
+    for (int d = 4; d >= 0; --d) {
+        if (sizes[d] != 1 && st[d] != expect) return false;
+        expect *= sizes[d];
+    }
+    return true;
+}
+
+constexpr int kSmallMaxPlaneBytes = 16 * 1024;   // per tensor
+constexpr int kSmallLds = 32 * 1024;             // planes of a round, at most
+constexpr int kSmallRoundElems = 1536;           // elements of a round, about
+constexpr int kSmallWgs = 4096;                  // workgroups wanted
+
+SmallPlan small_plan(const Geometry &g, int es, bool backward) {
+    SmallPlan pl{};
+    pl.ok = false;
+    for (int d = 0; d < 3; ++d)
+        if (g.L[d] != 0 || g.O[d] != g.S[d]) return pl;
+    const int64_t pe = g.S[0] * g.S[1] * g.S[2];
+    if (pe < 1 || pe * es > kSmallMaxPlaneBytes) return pl;
+    if (g.N >= (1LL << 30) || g.C >= (1LL << 30) || g.N * g.C >= (1LL << 31)) return pl;
+    pl.map_entries = static_cast<int>(g.S[0] + g.S[1] + g.S[2] + 3);
+    const size_t map_bytes = static_cast<size_t>(pl.map_entries) * (backward ? 2 : 1) * sizeof(int);
+    if (map_bytes > 16 * 1024) return pl;
+    const int64_t per_plane = pe * es * (backward ? 2 : 1);
+    // planes per round: ~1536 elements (six per thread) measured best -- N128 C512 14x14 fp32 backward 0.091 ms with 31
+    // planes (48 KiB) per round, 0.056 ms with 8; N128 C1024 7x7 0.075 ms with 64, 0.037 ms with 16 -- small rounds keep
+    // many workgroups per CU resident, and those overlap each other's copy-in and compute phases
+    int64_t ppr = g_small_tune[1] > 0 ? g_small_tune[1] : kSmallRoundElems / pe;
+    if (ppr * per_plane > kSmallLds) ppr = kSmallLds / per_plane;
+    if (ppr < 1) ppr = 1;
+    if (ppr > g.N) ppr = g.N;
+    // workgroups per channel: enough for ~kSmallWgs workgroups, the batch split evenly between them (a ragged split --
+    // 124 + 4 planes -- leaves half of the workgroups idle), then even rounds inside a workgroup
+    int64_t rpw;
+    if (g_small_tune[2] > 0) {
+        rpw = g_small_tune[2];
+    } else {
+        const int64_t rounds = (g.N + ppr - 1) / ppr;
+        int64_t groups = (kSmallWgs + g.C - 1) / g.C;
+        if (groups > rounds) groups = rounds;
+        if (groups < 1) groups = 1;
+        const int64_t per_wg = (g.N + groups - 1) / groups;
+        rpw = (per_wg + ppr - 1) / ppr;
+        if (g_small_tune[1] <= 0) ppr = (per_wg + rpw - 1) / rpw;
+    }
+    if (ppr * rpw > g.N) rpw = (g.N + ppr - 1) / ppr;
+    pl.ppr = static_cast<int>(ppr);
+    pl.rpw = static_cast<int>(rpw);
+    pl.groups = static_cast<int>((g.N + ppr * rpw - 1) / (ppr * rpw));
+    pl.lds = map_bytes + static_cast<size_t>(ppr) * static_cast<size_t>(per_plane);
+    if (pl.lds > 60 * 1024) return pl;
+    const int64_t grid = static_cast<int64_t>(pl.groups) * g.C;
+    if (grid >= (1LL << 31)) return pl;
+    pl.grid = static_cast<unsigned>(grid);
+    pl.ok = true;
+    return pl;
+}
+
+void fill_small(SmallParams &p, const Geometry &g, const SmallPlan &pl) {
+    p.N = static_cast<int>(g.N);
+    p.C = static_cast<int>(g.C);
+    p.nd = g.nd;
+    p.pad = g.pad;
+    for (int d = 0; d < 3; ++d) {
+        p.S[d] = static_cast<int>(g.S[d]);
+        p.wcol[d] = g.wcol[d];
+        p.d_per[d] = make_fastdiv(static_cast<uint32_t>(map_period(p.S[d], g.pad)));
+    }
+    p.PE = p.S[0] * p.S[1] * p.S[2];
+    p.ppr = pl.ppr;
+    p.rpw = pl.rpw;
+    p.map_entries = pl.map_entries;
+    p.xcd_blocks = pl.grid % 8 == 0 ? pl.grid / 8 : 0;
+    p.d_S2 = make_fastdiv(static_cast<uint32_t>(p.S[2]));
+    p.d_S12 = make_fastdiv(static_cast<uint32_t>(p.S[1] * p.S[2]));
+    p.d_PE = make_fastdiv(static_cast<uint32_t>(p.PE));
+    p.d_C = make_fastdiv(static_cast<uint32_t>(p.C));
+}
+
+template <typename T, bool BACKWARD>
+void launch_small(const SmallParams &p, const SmallPlan &pl, bool active, hipStream_t st) {
+    const dim3 grid(pl.grid), block(kThreads);
+#define SHIFTND_SMALL(NDV) \
+    if constexpr (BACKWARD) { \
+        if (active) hipLaunchKernelGGL((small_plane_kernel<T, NDV, true, true>), grid, block, pl.lds, st, p); \
+        else hipLaunchKernelGGL((small_plane_kernel<T, NDV, false, true>), grid, block, pl.lds, st, p); \
+    } else { \
+        hipLaunchKernelGGL((small_plane_kernel<T, NDV, true, false>), grid, block, pl.lds, st, p); \
+    }
+    switch (p.nd) {
+    case 1: SHIFTND_SMALL(1) break;
+    case 2: SHIFTND_SMALL(2) break;
+    default: SHIFTND_SMALL(3) break;
+    }
+#undef SHIFTND_SMALL
+}
+
+}  // namespace
+
+void small_set_tuning(int knob, int value) {
+    if (knob >= 0 && knob < 3) g_small_tune[knob] = value;
+}
+
+// interpolating forward of contiguous float tensors, no crop, planes of at most 16 KiB
+bool small_forward_eligible(const Geometry &g, int dtype) {
+    if (!g_small_tune[0] || dtype > SHIFTND_BF16 || !g.active) return false;
+    if (!contiguous5s(g.xs, g.N, g.C, g.S) || !contiguous5s(g.os, g.N, g.C, g.O)) return false;
+    return small_plan(g, dtype_size(dtype), false).ok;
+}
+
+int small_forward(const Geometry &g, int dtype, const void *x, const void *w, void *out, hipStream_t st) {
+    const SmallPlan pl = small_plan(g, dtype_size(dtype), false);
+    if (!pl.ok) return SHIFTND_ERR_INVALID_ARGUMENT;
+    SmallParams p{};
+    p.x = x;
+    p.out = out;
+    p.w = w;
+    p.wkind = dtype;
+    fill_small(p, g, pl);
+    note_kernel("small_plane_forward");
+    switch (dtype) {
+    case SHIFTND_F32: launch_small<f32_t, false>(p, pl, true, st); break;
+    case SHIFTND_F64: launch_small<f64_t, false>(p, pl, true, st); break;
+    case SHIFTND_F16: launch_small<f16_t, false>(p, pl, true, st); break;
+    default: launch_small<bf16_t, false>(p, pl, true, st); break;
+    }
+    return SHIFTND_OK;
+}
+
+bool small_backward_eligible(const Geometry &g, int dtype) {
+    if (!g_small_tune[0] || dtype > SHIFTND_BF16) return false;
+    if (!contiguous5s(g.xs, g.N, g.C, g.S) || !contiguous5s(g.os, g.N, g.C, g.O) || !contiguous5s(g.gs, g.N, g.C, g.S)) return false;
+    return small_plan(g, dtype_size(dtype), true).ok;
+}
+
+size_t small_backward_workspace(const Geometry &g, int dtype) {
+    if (dtype > SHIFTND_BF16) return 0;
+    const SmallPlan pl = small_plan(g, dtype_size(dtype), true);
+    return pl.ok ? static_cast<size_t>(pl.groups) * static_cast<size_t>(g.C) * 3 * sizeof(double) : 0;
+}
+
+template <typename T>
+static void small_backward_t(const SmallParams &p, const SmallPlan &pl, bool active, void *gw, hipStream_t st) {
+    launch_small<T, true>(p, pl, active, st);
+    hipLaunchKernelGGL((reduce_weight_grads<T>), dim3(p.C * p.nd), dim3(64), 0, st, p.partials, pl.groups, p.C, p.nd,
+                       static_cast<typename T::S *>(gw));
+}
+
+int small_backward(const Geometry &g, int dtype, const void *go, const void *x, const void *w, void *gx, void *gw,
+                   void *workspace, hipStream_t st) {
+    const SmallPlan pl = small_plan(g, dtype_size(dtype), true);
+    if (!pl.ok) return SHIFTND_ERR_INVALID_ARGUMENT;
+    SmallParams p{};
+    p.x = x;
+    p.go = go;
+    p.out = gx;
+    p.w = w;
+    p.wkind = dtype;
+    p.partials = static_cast<double *>(workspace);
+    fill_small(p, g, pl);
+    note_kernel("small_plane_backward");
+    switch (dtype) {
+    case SHIFTND_F32: small_backward_t<f32_t>(p, pl, g.active != 0, gw, st); break;
+    case SHIFTND_F64: small_backward_t<f64_t>(p, pl, g.active != 0, gw, st); break;
+    case SHIFTND_F16: small_backward_t<f16_t>(p, pl, g.active != 0, gw, st); break;
+    default: small_backward_t<bf16_t>(p, pl, g.active != 0, gw, st); break;
+    }
+    return SHIFTND_OK;
+}
+
+}  // namespace shiftnd

@@ -1,0 +1,94 @@
+"""Small-plane kernels (csrc/shiftnd_small.hip): contiguous problems whose rows are not whole 16-byte pieces."""
+import numpy as np
+import pytest
+import torch
+
+from cases import rel_err
+from oracle import oracle as O
+from test_hip_parity import _weights
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+SHAPES = [(3, 5, 7, 7), (4, 6, 14, 14), (2, 3, 13, 5), (5, 4, 1, 9), (3, 4, 13), (2, 3, 4, 5, 6), (2, 2, 3, 7, 7), (9, 3, 1, 1, 3)]
+
+
+@pytest.fixture(scope="module")
+def abi():
+    from torchshifts import abi as A
+    yield A
+    for k in (24, 25, 26):
+        A.set_tuning(k, 1 if k == 24 else 0)
+    A.set_path_policy(0)
+
+
+@pytest.mark.parametrize("dt", ["f32", "f64"])
+@pytest.mark.parametrize("shape", SHAPES)
+def test_small_planes_vs_oracle(abi, shape, dt):
+    """interpolating forward, sparse / active backward, every padding, shifts beyond the dims; several rounds per
+    workgroup and ragged last rounds (knobs 25 / 26); forward and grad_x bit-exact, grad_w vs the fp64 oracle"""
+    npdt = np.float32 if dt == "f32" else np.float64
+    rs = np.random.RandomState(sum(shape) * 7 + len(shape))
+    nd = len(shape) - 2
+    x = rs.uniform(-1, 1, size=shape).astype(npdt)
+    go = rs.uniform(-1, 1, size=shape).astype(npdt)
+    w = _weights(rs, shape[1], nd, shape[2:]).astype(npdt)
+    xd, god, wd = torch.from_numpy(x).to(DEV), torch.from_numpy(go).to(DEV), torch.from_numpy(w).to(DEV)
+    ragged = (shape[-1] * x.itemsize) % 16 != 0   # (whole 16-byte rows go to the row-chunk kernels)
+    for ppr, rpw in ((0, 0), (1, 2), (2, 3)):
+        abi.set_tuning(25, ppr)
+        abi.set_tuning(26, rpw)
+        for pad in range(5):
+            out = abi.forward(xd, wd, pad, 1)
+            assert (abi.last_kernel() == "small_plane_forward") == ragged, (shape, pad)
+            assert np.array_equal(out.cpu().numpy(), O.forward(x, w, pad, 1)), (shape, pad, ppr, rpw)
+            for active in (0, 1):
+                gx, gw = abi.backward(god, wd, xd, pad, active)
+                assert (abi.last_kernel() == "small_plane_backward") == ragged, (shape, pad, active)
+                gx_o, _ = O.backward(go, w, x, pad, active)
+                _, gw64 = O.backward(go.astype(np.float64), w.astype(np.float64), x.astype(np.float64), pad, active)
+                assert np.array_equal(gx.cpu().numpy(), gx_o), (shape, pad, active, ppr, rpw)
+                assert rel_err(gw.cpu().numpy(), gw64) < (1e-12 if dt == "f64" else 1e-5), (shape, pad, active)
+    abi.set_tuning(25, 0)
+    abi.set_tuning(26, 0)
+
+
+@pytest.mark.parametrize("tdt", [torch.float16, torch.bfloat16])
+def test_small_planes_16bit_agree_with_the_strided_kernels(abi, tdt):
+    """fp16 / bf16: the same bits as the one-thread-per-element kernels (one definition of the arithmetic)"""
+    torch.manual_seed(3)
+    for shape in [(6, 8, 14, 14), (5, 7, 7, 7), (3, 4, 3, 5, 6)]:
+        nd = len(shape) - 2
+        x = torch.rand(shape, device=DEV).to(tdt)
+        go = torch.rand(shape, device=DEV).to(tdt)
+        w = ((torch.rand(shape[1], nd, device=DEV) - 0.5) * 7).to(tdt)
+        for pad in (0, 2, 3):
+            for active in (0, 1):
+                abi.set_path_policy(1)
+                ref = abi.forward(x, w, pad, 1)
+                gx_r, gw_r = abi.backward(go, w, x, pad, active)
+                abi.set_path_policy(0)
+                out = abi.forward(x, w, pad, 1)
+                assert abi.last_kernel() == "small_plane_forward" and torch.equal(out, ref)
+                gx, gw = abi.backward(go, w, x, pad, active)
+                assert abi.last_kernel() == "small_plane_backward" and torch.equal(gx, gx_r)
+                assert rel_err(gw.float().cpu().numpy(), gw_r.float().cpu().numpy()) < 4 * float(torch.finfo(tdt).eps)
+
+
+def test_small_planes_full_batch(abi):
+    """ResNet-stage shapes at full batch against the one-thread-per-element kernels"""
+    torch.manual_seed(9)
+    for shape in [(128, 512, 14, 14), (128, 1024, 7, 7)]:
+        x = torch.rand(shape, device=DEV)
+        go = torch.rand(shape, device=DEV)
+        w = (torch.rand(shape[1], 2, device=DEV) - 0.5) * 6
+        for active in (0, 1):
+            abi.set_path_policy(1)
+            ref = abi.forward(x, w, 0, 1)
+            gx_r, gw_r = abi.backward(go, w, x, 0, active)
+            abi.set_path_policy(0)
+            out = abi.forward(x, w, 0, 1)
+            gx, gw = abi.backward(go, w, x, 0, active)
+            assert abi.last_kernel() == "small_plane_backward"
+            assert torch.equal(out, ref) and torch.equal(gx, gx_r)
+            assert rel_err(gw.cpu().numpy(), gw_r.cpu().numpy()) < 1e-5

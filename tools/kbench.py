@@ -42,6 +42,9 @@ def main():
     ap.add_argument("--knobs", default="")
     ap.add_argument("--wrange", type=float, default=3.0)
     ap.add_argument("--policy", type=int, default=0)
+    ap.add_argument("--shape", default="", help="N,C,spatial... with --dtype / --active: a free-form workload")
+    ap.add_argument("--dtype", default="float32")
+    ap.add_argument("--active", type=int, default=0)
     a = ap.parse_args()
     extra = {  # tuning-only variants of the bench workloads
         "c2a": (2, (64, 256, 224, 224), "float32", True, "Shift2d active N64 C256 224x224 fp32"),
@@ -59,6 +62,10 @@ def main():
         "d1a": (1, (256, 512, 4096), "float32", True, "Shift1d active N256 C512 L4096 fp32"),
         "d1h": (1, (256, 512, 4096), "float16", False, "Shift1d SSL N256 C512 L4096 fp16"),
     }
+    if a.shape:
+        shp = tuple(int(v) for v in a.shape.split(","))
+        extra["free"] = (len(shp) - 2, shp, a.dtype, bool(a.active), "Shift%dd %s %s %s" % (len(shp) - 2, "active" if a.active else "SSL", a.shape, a.dtype))
+        a.workload = "free"
     nd, shape, dtname, active, desc = {**WORKLOADS, **extra}[a.workload]
     dev = torch.device("cuda:0")
     abi.set_path_policy(a.policy)

@@ -166,6 +166,140 @@ __global__ __launch_bounds__(kThreads) void small_plane_kernel(const SmallParams
     }
 }
 
+// =====================================================================================================
+// Row bands: the same idea for planes that do not fit (1-D / 2-D, rows of any length that is not a whole number of
+// 16-byte pieces: 113 x 113, 225 x 225, 299 x 299 ...).  A workgroup owns one channel and a run of (batch entry, band of
+// BR rows) units; per unit it stages the BR + 1 SOURCE rows of the band (row slot j = map1[b0 + j]: the "+ 1 along H"
+// corner row of output row b is the first corner row of row b + 1; rows the padding map declares fill are staged as
+// zeros) and, for the backward, the BR (+ 1) gradient rows its grad_x reads; the incoming gradient at the output
+// position is read straight from memory (coalesced, every element once).
+// =====================================================================================================
+struct BandParams {
+    const void *x, *go;
+    void *out;
+    const void *w;
+    double *partials;
+    int wkind, N, C, nd, pad;
+    int S[3], wcol[3];
+    int BR, bands, units, upw;   // rows per band, bands per plane, N * bands, units per workgroup
+    int map_entries;
+    unsigned xcd_blocks;
+    FastDiv d_S2, d_bands, d_C;
+    FastDiv d_per[3];
+};
+
+template <typename T, int ND, bool ACTIVE, bool BACKWARD>
+__global__ __launch_bounds__(kThreads) void band_plane_kernel(const BandParams p) {
+    using S = typename T::S;
+    using CT = typename T::C;
+    constexpr int NC = 1 << ND;
+    static_assert(ND == 1 || ND == 2, "one or two spatial dims");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    __shared__ double scratch[kThreads / 64];
+    int *maps = reinterpret_cast<int *>(smem);
+    const int S0 = p.S[0], S1 = p.S[1], S2 = p.S[2], BR = p.BR;
+    const int *m1 = maps + S0 + 1, *m2 = m1 + S1 + 1;
+    int *gmaps = maps + p.map_entries;
+    const int *g1 = gmaps + S0 + 1, *g2 = g1 + S1 + 1;
+    S *xrows = reinterpret_cast<S *>(smem + static_cast<size_t>(p.map_entries) * (BACKWARD ? 2 : 1) * sizeof(int));
+    S *grows = xrows + static_cast<size_t>(ND == 1 ? 1 : BR + 1) * S2;   // (backward only; 1-D: the one row)
+
+    const unsigned bid = p.xcd_blocks ? (blockIdx.x & 7u) * p.xcd_blocks + (blockIdx.x >> 3) : blockIdx.x;
+    const int grp = fdiv(bid, p.d_C), c = static_cast<int>(bid) - grp * p.C;
+    const int u0 = grp * p.upw, nu = min(p.upw, p.units - u0);
+
+    int64_t sh[3] = {0, 0, 0};
+    CT dw[3] = {CT(0), CT(0), CT(0)};
+    CT wv[3];
+    load_weights3<CT>(p.w, p.wkind, static_cast<int64_t>(c) * p.nd, p.wcol, wv);
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+        if (p.wcol[d] >= 0) {
+            if constexpr (BACKWARD) prep_shift_backward<CT>(wv[d], ACTIVE, sh[d], dw[p.wcol[d]]);
+            else prep_shift_forward<CT>(wv[d], true, sh[d], dw[p.wcol[d]]);
+        }
+    }
+    build_maps(maps, p.S, sh, -1, p.pad, p.d_per);
+    if constexpr (BACKWARD) build_maps(gmaps, p.S, sh, ACTIVE ? -1 : +1, p.pad, p.d_per);
+
+    const int64_t plane = static_cast<int64_t>(S1) * S2;
+    double acc[3] = {0.0, 0.0, 0.0};
+    const S zero = narrow<T>(CT(0));
+    for (int k = 0; k < nu; ++k) {
+        const int u = u0 + k;
+        const int n = fdiv(u, p.d_bands), band = u - n * p.bands;
+        const int b0 = band * BR, nb = min(BR, S1 - b0);
+        const int64_t pbase = (static_cast<int64_t>(n) * p.C + c) * plane;
+        const S *xp = static_cast<const S *>(p.x) + pbase;
+        const S *gp = BACKWARD ? static_cast<const S *>(p.go) + pbase : xp;
+        S *op = static_cast<S *>(p.out) + pbase;
+        __syncthreads();  // the maps are complete / the previous unit is done with the rows
+        for (int idx = threadIdx.x; idx < (ND == 1 ? 1 : nb + 1) * S2; idx += kThreads) {
+            const int j = fdiv(idx, p.d_S2), cc = idx - j * S2;
+            const int rx = m1[b0 + j];
+            xrows[idx] = rx >= 0 ? xp[static_cast<int64_t>(rx) * S2 + cc] : zero;
+            if constexpr (BACKWARD) {
+                const int rg = (ACTIVE || j < nb) ? g1[b0 + j] : -1;
+                grows[idx] = rg >= 0 ? gp[static_cast<int64_t>(rg) * S2 + cc] : zero;
+            }
+        }
+        __syncthreads();
+        for (int idx = threadIdx.x; idx < nb * S2; idx += kThreads) {
+            const int j = fdiv(idx, p.d_S2), cc = idx - j * S2;
+            const int64_t o = static_cast<int64_t>(b0 + j) * S2 + cc;
+            // corner order: bit 0 = +1 along H (2-D) / along L (1-D), bit 1 = +1 along W (2-D)
+            auto corners = [&](const S *rows, const int *q2, CT (&v)[NC]) {
+                const int c0 = q2[cc], c1 = q2[cc + 1];
+                if constexpr (ND == 1) {
+                    v[0] = c0 >= 0 ? widen<T>(rows[c0]) : CT(0);
+                    v[1] = c1 >= 0 ? widen<T>(rows[c1]) : CT(0);
+                } else {
+                    const S *r0 = rows + j * S2, *r1 = r0 + S2;
+                    v[0] = c0 >= 0 ? widen<T>(r0[c0]) : CT(0);
+                    v[1] = c0 >= 0 ? widen<T>(r1[c0]) : CT(0);
+                    v[2] = c1 >= 0 ? widen<T>(r0[c1]) : CT(0);
+                    v[3] = c1 >= 0 ? widen<T>(r1[c1]) : CT(0);
+                }
+            };
+            S res;
+            CT v[NC];
+            if constexpr (BACKWARD) {
+                CT wg[3];
+                corners(xrows, m2, v);
+                const CT gval = widen<T>(gp[o]);
+                weight_grads_nd<ND, CT>(v, dw, wg);
+#pragma unroll
+                for (int s = 0; s < ND; ++s) acc[s] += static_cast<double>(gval * wg[s]);
+                if constexpr (ACTIVE) {
+                    corners(grows, g2, v);
+                    res = narrow<T>(interp_t<T, ND>(v, dw));
+                } else {
+                    const int rc = g2[cc];
+                    res = rc >= 0 ? grows[j * S2 + rc] : zero;   // pure copy: the bit pattern is kept
+                }
+            } else {
+                corners(xrows, m2, v);
+                res = narrow<T>(interp_t<T, ND>(v, dw));
+            }
+            op[o] = res;
+        }
+    }
+    if constexpr (BACKWARD) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const double tsum = block_sum(acc[k], scratch);
+            if (threadIdx.x == 0) p.partials[(static_cast<size_t>(grp) * p.C + c) * 3 + k] = tsum;
+        }
+    }
+}
+
+struct BandPlan {
+    int BR, bands, units, upw, groups, map_entries;
+    size_t lds;
+    unsigned grid;
+    bool ok;
+};
+
 struct SmallPlan {
     int ppr, rpw, groups, map_entries;
     size_t lds;
@@ -275,6 +409,79 @@ void launch_small(const SmallParams &p, const SmallPlan &pl, bool active, hipStr
 #undef SHIFTND_SMALL
 }
 
+BandPlan band_plan(const Geometry &g, int es, bool backward) {
+    BandPlan pl{};
+    pl.ok = false;
+    if (g.nd != 1 && g.nd != 2) return pl;
+    for (int d = 0; d < 3; ++d)
+        if (g.L[d] != 0 || g.O[d] != g.S[d]) return pl;
+    const int64_t W = g.S[2], H = g.S[1];
+    if (W < 1 || H < 1 || g.S[0] != 1 || H * W >= (1LL << 30)) return pl;
+    if (g.N >= (1LL << 30) || g.C >= (1LL << 30) || g.N * g.C >= (1LL << 31)) return pl;
+    pl.map_entries = static_cast<int>(g.S[0] + g.S[1] + g.S[2] + 3);
+    const size_t map_bytes = static_cast<size_t>(pl.map_entries) * (backward ? 2 : 1) * sizeof(int);
+    if (map_bytes > 24 * 1024) return pl;
+    const int64_t row_bytes = W * es * (backward ? 2 : 1);
+    // rows per band: ~1536 elements per unit (see small_plan), within 24 KiB of staged rows
+    int64_t br = g_small_tune[1] > 0 ? g_small_tune[1] : (kSmallRoundElems + W - 1) / W;
+    while (br > 1 && (br + 1) * row_bytes > 24 * 1024) --br;
+    if (br > H) br = H;
+    const int64_t staged = g.nd == 1 ? 1 : br + 1;   // rows in LDS per tensor
+    if (br < 1 || staged * row_bytes > 40 * 1024) return pl;
+    pl.BR = static_cast<int>(br);
+    pl.bands = static_cast<int>((H + br - 1) / br);
+    const int64_t units = g.N * pl.bands;
+    if (units >= (1LL << 30)) return pl;
+    pl.units = static_cast<int>(units);
+    int64_t groups = (kSmallWgs + g.C - 1) / g.C;
+    if (groups > units) groups = units;
+    if (groups < 1) groups = 1;
+    pl.upw = static_cast<int>((units + groups - 1) / groups);
+    pl.groups = static_cast<int>((units + pl.upw - 1) / pl.upw);
+    pl.lds = map_bytes + static_cast<size_t>(staged) * static_cast<size_t>(row_bytes);
+    const int64_t grid = static_cast<int64_t>(pl.groups) * g.C;
+    if (grid >= (1LL << 31)) return pl;
+    pl.grid = static_cast<unsigned>(grid);
+    pl.ok = true;
+    return pl;
+}
+
+void fill_band(BandParams &p, const Geometry &g, const BandPlan &pl) {
+    p.N = static_cast<int>(g.N);
+    p.C = static_cast<int>(g.C);
+    p.nd = g.nd;
+    p.pad = g.pad;
+    for (int d = 0; d < 3; ++d) {
+        p.S[d] = static_cast<int>(g.S[d]);
+        p.wcol[d] = g.wcol[d];
+        p.d_per[d] = make_fastdiv(static_cast<uint32_t>(map_period(p.S[d], g.pad)));
+    }
+    p.BR = pl.BR;
+    p.bands = pl.bands;
+    p.units = pl.units;
+    p.upw = pl.upw;
+    p.map_entries = pl.map_entries;
+    p.xcd_blocks = pl.grid % 8 == 0 ? pl.grid / 8 : 0;
+    p.d_S2 = make_fastdiv(static_cast<uint32_t>(p.S[2]));
+    p.d_bands = make_fastdiv(static_cast<uint32_t>(p.bands));
+    p.d_C = make_fastdiv(static_cast<uint32_t>(p.C));
+}
+
+template <typename T, bool BACKWARD>
+void launch_band(const BandParams &p, const BandPlan &pl, bool active, hipStream_t st) {
+    const dim3 grid(pl.grid), block(kThreads);
+#define SHIFTND_BAND(NDV) \
+    if constexpr (BACKWARD) { \
+        if (active) hipLaunchKernelGGL((band_plane_kernel<T, NDV, true, true>), grid, block, pl.lds, st, p); \
+        else hipLaunchKernelGGL((band_plane_kernel<T, NDV, false, true>), grid, block, pl.lds, st, p); \
+    } else { \
+        hipLaunchKernelGGL((band_plane_kernel<T, NDV, true, false>), grid, block, pl.lds, st, p); \
+    }
+    if (p.nd == 1) { SHIFTND_BAND(1) }
+    else { SHIFTND_BAND(2) }
+#undef SHIFTND_BAND
+}
+
 }  // namespace
 
 void small_set_tuning(int knob, int value) {
@@ -285,12 +492,29 @@ void small_set_tuning(int knob, int value) {
 bool small_forward_eligible(const Geometry &g, int dtype) {
     if (!g_small_tune[0] || dtype > SHIFTND_BF16 || !g.active) return false;
     if (!contiguous5s(g.xs, g.N, g.C, g.S) || !contiguous5s(g.os, g.N, g.C, g.O)) return false;
-    return small_plan(g, dtype_size(dtype), false).ok;
+    return small_plan(g, dtype_size(dtype), false).ok || band_plan(g, dtype_size(dtype), false).ok;
 }
 
 int small_forward(const Geometry &g, int dtype, const void *x, const void *w, void *out, hipStream_t st) {
     const SmallPlan pl = small_plan(g, dtype_size(dtype), false);
-    if (!pl.ok) return SHIFTND_ERR_INVALID_ARGUMENT;
+    if (!pl.ok) {   // the plane does not fit: row bands
+        const BandPlan bp = band_plan(g, dtype_size(dtype), false);
+        if (!bp.ok) return SHIFTND_ERR_INVALID_ARGUMENT;
+        BandParams b{};
+        b.x = x;
+        b.out = out;
+        b.w = w;
+        b.wkind = dtype;
+        fill_band(b, g, bp);
+        note_kernel("band_plane_forward");
+        switch (dtype) {
+        case SHIFTND_F32: launch_band<f32_t, false>(b, bp, true, st); break;
+        case SHIFTND_F64: launch_band<f64_t, false>(b, bp, true, st); break;
+        case SHIFTND_F16: launch_band<f16_t, false>(b, bp, true, st); break;
+        default: launch_band<bf16_t, false>(b, bp, true, st); break;
+        }
+        return SHIFTND_OK;
+    }
     SmallParams p{};
     p.x = x;
     p.out = out;
@@ -310,13 +534,22 @@ int small_forward(const Geometry &g, int dtype, const void *x, const void *w, vo
 bool small_backward_eligible(const Geometry &g, int dtype) {
     if (!g_small_tune[0] || dtype > SHIFTND_BF16) return false;
     if (!contiguous5s(g.xs, g.N, g.C, g.S) || !contiguous5s(g.os, g.N, g.C, g.O) || !contiguous5s(g.gs, g.N, g.C, g.S)) return false;
-    return small_plan(g, dtype_size(dtype), true).ok;
+    return small_plan(g, dtype_size(dtype), true).ok || band_plan(g, dtype_size(dtype), true).ok;
 }
 
 size_t small_backward_workspace(const Geometry &g, int dtype) {
     if (dtype > SHIFTND_BF16) return 0;
     const SmallPlan pl = small_plan(g, dtype_size(dtype), true);
-    return pl.ok ? static_cast<size_t>(pl.groups) * static_cast<size_t>(g.C) * 3 * sizeof(double) : 0;
+    if (pl.ok) return static_cast<size_t>(pl.groups) * static_cast<size_t>(g.C) * 3 * sizeof(double);
+    const BandPlan bp = band_plan(g, dtype_size(dtype), true);
+    return bp.ok ? static_cast<size_t>(bp.groups) * static_cast<size_t>(g.C) * 3 * sizeof(double) : 0;
+}
+
+template <typename T>
+static void band_backward_t(const BandParams &p, const BandPlan &pl, bool active, void *gw, hipStream_t st) {
+    launch_band<T, true>(p, pl, active, st);
+    hipLaunchKernelGGL((reduce_weight_grads<T>), dim3(p.C * p.nd), dim3(64), 0, st, p.partials, pl.groups, p.C, p.nd,
+                       static_cast<typename T::S *>(gw));
 }
 
 template <typename T>
@@ -329,7 +562,26 @@ static void small_backward_t(const SmallParams &p, const SmallPlan &pl, bool act
 int small_backward(const Geometry &g, int dtype, const void *go, const void *x, const void *w, void *gx, void *gw,
                    void *workspace, hipStream_t st) {
     const SmallPlan pl = small_plan(g, dtype_size(dtype), true);
-    if (!pl.ok) return SHIFTND_ERR_INVALID_ARGUMENT;
+    if (!pl.ok) {   // the planes do not fit: row bands
+        const BandPlan bp = band_plan(g, dtype_size(dtype), true);
+        if (!bp.ok) return SHIFTND_ERR_INVALID_ARGUMENT;
+        BandParams b{};
+        b.x = x;
+        b.go = go;
+        b.out = gx;
+        b.w = w;
+        b.wkind = dtype;
+        b.partials = static_cast<double *>(workspace);
+        fill_band(b, g, bp);
+        note_kernel("band_plane_backward");
+        switch (dtype) {
+        case SHIFTND_F32: band_backward_t<f32_t>(b, bp, g.active != 0, gw, st); break;
+        case SHIFTND_F64: band_backward_t<f64_t>(b, bp, g.active != 0, gw, st); break;
+        case SHIFTND_F16: band_backward_t<f16_t>(b, bp, g.active != 0, gw, st); break;
+        default: band_backward_t<bf16_t>(b, bp, g.active != 0, gw, st); break;
+        }
+        return SHIFTND_OK;
+    }
     SmallParams p{};
     p.x = x;
     p.go = go;

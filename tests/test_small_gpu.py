@@ -92,3 +92,60 @@ def test_small_planes_full_batch(abi):
             assert abi.last_kernel() == "small_plane_backward"
             assert torch.equal(out, ref) and torch.equal(gx, gx_r)
             assert rel_err(gw.cpu().numpy(), gw_r.cpu().numpy()) < 1e-5
+
+
+BAND_SHAPES = [(2, 3, 40, 113), (2, 2, 300, 25), (2, 3, 2301), (1, 2, 37, 131)]
+
+
+@pytest.mark.parametrize("dt", ["f32", "f64"])
+@pytest.mark.parametrize("shape", BAND_SHAPES)
+def test_row_bands_vs_oracle(abi, shape, dt):
+    """band_plane_forward / band_plane_backward: 1-D / 2-D planes that do not fit LDS, rows that are not whole 16-byte
+    pieces; every padding, shifts beyond the dims, ragged last bands and one-row bands (knob 25); forward and grad_x
+    bit-exact, grad_w vs the fp64 oracle"""
+    npdt = np.float32 if dt == "f32" else np.float64
+    if len(shape) == 3:  # 1-D: one row is the whole plane -- longer than the small-plane limit, short enough for LDS
+        shape = (shape[0], shape[1], 4501 if dt == "f32" else 2201)
+    rs = np.random.RandomState(sum(shape) * 5 + len(shape))
+    nd = len(shape) - 2
+    x = rs.uniform(-1, 1, size=shape).astype(npdt)
+    go = rs.uniform(-1, 1, size=shape).astype(npdt)
+    w = _weights(rs, shape[1], nd, shape[2:]).astype(npdt)
+    xd, god, wd = torch.from_numpy(x).to(DEV), torch.from_numpy(go).to(DEV), torch.from_numpy(w).to(DEV)
+    ragged = (shape[-1] * x.itemsize) % 16 != 0
+    assert ragged
+    for br in (0, 1, 3):
+        abi.set_tuning(25, br)
+        for pad in range(5):
+            out = abi.forward(xd, wd, pad, 1)
+            assert abi.last_kernel() == "band_plane_forward", (shape, pad)
+            assert np.array_equal(out.cpu().numpy(), O.forward(x, w, pad, 1)), (shape, pad, br)
+            for active in (0, 1):
+                gx, gw = abi.backward(god, wd, xd, pad, active)
+                # (a 1-D fp32 row longer than the small-plane limit does not fit LDS twice with its maps: one thread per element)
+                assert abi.last_kernel() == ("strided_backward" if (nd == 1 and dt == "f32") else "band_plane_backward"), (shape, pad, active)
+                gx_o, _ = O.backward(go, w, x, pad, active)
+                _, gw64 = O.backward(go.astype(np.float64), w.astype(np.float64), x.astype(np.float64), pad, active)
+                assert np.array_equal(gx.cpu().numpy(), gx_o), (shape, pad, active, br)
+                assert rel_err(gw.cpu().numpy(), gw64) < (1e-12 if dt == "f64" else 1e-5), (shape, pad, active)
+    abi.set_tuning(25, 0)
+
+
+def test_row_bands_16bit_and_full_size(abi):
+    """bf16 against the one-thread-per-element kernels, and an odd-sized image batch at full size"""
+    torch.manual_seed(11)
+    for shape, tdt in [((3, 8, 60, 151), torch.bfloat16), ((8, 64, 225, 225), torch.float32)]:
+        x = torch.rand(shape, device=DEV).to(tdt)
+        go = torch.rand(shape, device=DEV).to(tdt)
+        w = ((torch.rand(shape[1], 2, device=DEV) - 0.5) * 7).to(tdt)
+        for pad, active in ((0, 0), (3, 1), (2, 1)):
+            abi.set_path_policy(1)
+            ref = abi.forward(x, w, pad, 1)
+            gx_r, gw_r = abi.backward(go, w, x, pad, active)
+            abi.set_path_policy(0)
+            out = abi.forward(x, w, pad, 1)
+            assert abi.last_kernel() == "band_plane_forward" and torch.equal(out, ref)
+            gx, gw = abi.backward(go, w, x, pad, active)
+            assert abi.last_kernel() == "band_plane_backward" and torch.equal(gx, gx_r)
+            tol = 1e-5 if tdt == torch.float32 else 4 * float(torch.finfo(tdt).eps)
+            assert rel_err(gw.float().cpu().numpy(), gw_r.float().cpu().numpy()) < tol

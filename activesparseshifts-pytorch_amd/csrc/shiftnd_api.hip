@@ -90,6 +90,12 @@ int forward_common(const shiftnd_problem *p, const void *x, const int64_t *xs, c
         // (interpolating problems keep the LDS-staged plane kernels whenever those take them: see DESIGN 3.14)
         const bool interpolating = g.active && p->dtype <= SHIFTND_BF16;
         const bool prefer_sweep = (out_plane_bytes >= 32 * 1024 && !interpolating && !(can_plane && plane_forward_lds_gather(g, p->dtype, x, out))) || !can_plane;
+        // rows that are not whole 16-byte pieces, planes above 16 KiB: the chunk kernels would move them element by
+        // element (shiftnd_small.hip)
+        if (g_policy == 0 && out_plane_bytes > 16 * 1024 && band_gather_forward_eligible(g, p->dtype)) {
+            g_last_path = SHIFTND_PATH_PLANE;
+            return finish(band_gather_forward(g, p->dtype, x, w, wkind, wzp, fill, out, st));
+        }
         if (can_sweep && (g_policy == 3 || (g_policy == 0 && prefer_sweep))) {
             g_last_path = SHIFTND_PATH_SWEEP;
             return finish(sweep_forward(g, p->dtype, x, w, wkind, wzp, fill, out, st));

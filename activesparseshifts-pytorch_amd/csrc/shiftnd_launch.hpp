@@ -104,6 +104,10 @@ size_t small_backward_workspace(const Geometry &g, int dtype);
 int small_backward(const Geometry &g, int dtype, const void *go, const void *x, const void *w, void *gx, void *gw,
                    void *workspace, hipStream_t st);
 void small_set_tuning(int knob, int value);
+// ... and the sparse-shift / quantized forward of 1-D / 2-D problems with such rows (any element size)
+bool band_gather_forward_eligible(const Geometry &g, int dtype);
+int band_gather_forward(const Geometry &g, int dtype, const void *x, const void *w, int wkind, int64_t wzp, uint64_t fill_bits,
+                        void *out, hipStream_t st);
 
 // ---- layout change (shiftnd_transpose.hip): dst[n][c][r] = src[n][r][c], dense tensors ---------------------------
 int transpose_planes(const void *src, void *dst, int64_t N, int64_t rows, int64_t cols, int esize, hipStream_t st);

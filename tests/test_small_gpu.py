@@ -149,3 +149,40 @@ def test_row_bands_16bit_and_full_size(abi):
             assert abi.last_kernel() == "band_plane_backward" and torch.equal(gx, gx_r)
             tol = 1e-5 if tdt == torch.float32 else 4 * float(torch.finfo(tdt).eps)
             assert rel_err(gw.float().cpu().numpy(), gw_r.float().cpu().numpy()) < tol
+
+
+def test_row_band_gather_forward_vs_oracle(abi):
+    """band_gather_forward: sparse-shift / quantized forward of planes above 16 KiB whose rows are not whole 16-byte
+    pieces, every element size, every padding; bit-exact"""
+    rs = np.random.RandomState(17)
+    for shape in [(2, 3, 70, 113), (1, 2, 300, 25), (2, 2, 4501)]:
+        nd = len(shape) - 2
+        for npdt in (np.float32, np.float64):
+            if shape[-1] * shape[-2 if nd == 2 else -1] * np.dtype(npdt).itemsize <= 16 * 1024 and nd == 2:
+                continue
+            x = rs.uniform(-1, 1, size=shape).astype(npdt)
+            w = _weights(rs, shape[1], nd, shape[2:]).astype(npdt)
+            xd, wd = torch.from_numpy(x).to(DEV), torch.from_numpy(w).to(DEV)
+            for br in (0, 1, 5):
+                abi.set_tuning(25, br)
+                for pad in range(5):
+                    out = abi.forward(xd, wd, pad, 0)
+                    assert abi.last_kernel() == "band_gather_forward", (shape, npdt, pad)
+                    assert np.array_equal(out.cpu().numpy(), O.forward(x, w, pad, 0)), (shape, npdt, pad, br)
+            abi.set_tuning(25, 0)
+        # quantized uint8 / int32, fp16 (raw copies): uint8 planes above 16 KiB need more elements
+    for shape, npdt in [((2, 3, 150, 131), np.uint8), ((1, 2, 90, 57), np.int32)]:
+        xq = rs.randint(0, 200, size=shape).astype(npdt)
+        wq = rs.randint(100, 160, size=(shape[1], 2)).astype(np.uint8)
+        xqd, wqd = torch.from_numpy(xq).to(DEV), torch.from_numpy(wq).to(DEV)
+        for pad in range(5):
+            out = abi.forward_quantized(xqd, wqd, 128, 5, pad)
+            assert abi.last_kernel() == "band_gather_forward", (shape, pad)
+            assert np.array_equal(out.cpu().numpy(), O.forward_q(xq, wq, 128, 5, pad)), (shape, pad)
+    xh = torch.rand(2, 3, 100, 131, device=DEV).half()
+    wh = ((torch.rand(3, 2, device=DEV) - 0.5) * 9).half()
+    abi.set_path_policy(1)
+    ref = abi.forward(xh, wh, 3, 0)
+    abi.set_path_policy(0)
+    out = abi.forward(xh, wh, 3, 0)
+    assert abi.last_kernel() == "band_gather_forward" and torch.equal(out, ref)

@@ -1,25 +1,26 @@
-// shiftnd_cl_tiled.hip -- LDS-tiled sparse-shift / quantized forward for channels-last (NHWC) inputs of 4-byte
-// elements, gfx950 (MI355X).  SURVEY section 8f N3.
+// shiftnd_cl_tiled.hip -- LDS-tiled kernels for dense channels-last (NHWC) tensors, 2-D, gfx950 (MI355X): the sparse-shift
+// / quantized forward (1-, 2- and 4-byte elements), the interpolating forward and the backward (fp32, fp16, bf16).
+// SURVEY section 8f N3; DESIGN section 3.11.
 //
 // In NHWC the channels of a pixel are contiguous and every channel has its own shift, so the channel-fastest gather
 // of shiftnd_cl.hip sends the 64 lanes of a wave to up to (2 max|shift| + 1)^2 different pixels: one cache-line
-// lookup per lane (0.97 TB/s on N16 C256 224x224 fp32).  But every source element is used by exactly one output
-// element, so the data can be moved once, through LDS:
-//   * a workgroup owns 32 channels (one 128-byte line per pixel) x TW = 32 output columns and walks down the rows of
-//     a band; LDS holds a ring of 2 R + 1 source rows of TW + 2 R pixels (R = 3: shifts up to +-3 in each dim take
-//     the tiled path per channel, larger ones gather from memory);
-//   * per step ONE new source row is staged (whole lines, global -> registers one step ahead -> LDS; 1.19x
-//     horizontal halo, no vertical halo) and ONE output row is produced;
+// lookup per lane (0.97 TB/s on N16 C256 224x224 fp32).  But every source element is used by a bounded set of output
+// elements, so the data can be moved once, through LDS:
+//   * a workgroup owns one 128-byte line of channels per pixel (32 / 64 / 128 channels of 4 / 2 / 1 bytes) x a strip
+//     of output columns and walks down the rows of a band; LDS holds a ring of source rows with a halo of R = 3 pixels
+//     (shifts up to +-3 in each dim take the tiled path per channel, larger ones go element by element at the end);
+//   * per step ONE new source row is staged (whole lines, global -> registers three rows ahead -> LDS) and ONE output
+//     row is produced; every memory instruction of the row loop is unconditional (raw-buffer addressing drops what must
+//     not happen), so the compiler's wait counts are exact and the prefetch really is in flight;
 //   * the pixel pitch in LDS is 33 words: lanes that read consecutive channels of arbitrary pixels, or consecutive
-//     pixels of one channel, hit 32 different banks -- the gather runs at LDS rate;
-//   * OUT_CL: the output is channels-last too (the quantized op keeps the format, shifts_quantized.cpp:119-121; a
-//     thread keeps one channel and walks the pixels, stores are whole 128-byte pixel lines); otherwise the output is
-//     NCHW-contiguous like the reference's float forward (cpu/shifts_cpu.cpp:221): lanes run along the row of one
-//     channel and store 128-byte row segments -- the layout change costs nothing extra.
+//     pixels of one channel, hit different banks -- the gather runs at LDS rate;
+//   * forward output: channels-last (the quantized op keeps the format, shifts_quantized.cpp:119-121) or
+//     NCHW-contiguous like the reference's float forward (cpu/shifts_cpu.cpp:221): lanes then run along the row of one
+//     channel -- the layout change costs nothing extra.
 // Periodic padding wraps to the far side of the plane (not in the ring) and is left to shiftnd_cl.hip.
 //
-// Reference behaviour restated: kernels/shifts_kernels.h:330-400 (nhwdc forward), :574-624 (quantized).
-// Roofline: HBM, 2 x 4 bytes per element.
+// Reference behaviour restated: kernels/shifts_kernels.h:330-400 (nhwdc forward), :402-527 (nhwdc backward), :574-624
+// (quantized).  Roofline: HBM, 2 x s bytes per element forward, 3 x s backward.
 #include "shiftnd_common.hpp"
 #include "shiftnd_launch.hpp"
 

@@ -104,8 +104,13 @@ SHIFTND_API const char *shiftnd_last_kernel(void);
  * thread only, so a diagnostic setter can never re-route a concurrent caller (dispatcher threads, autograd
  * worker threads always run with the defaults). */
 SHIFTND_API void shiftnd_set_path_policy(int policy);
-/* Diagnostics: launch-planning knobs of the plane kernels (0: minimum workgroups wanted, 1: target
- * bytes per workgroup, 2: gather-forward unroll).  Results never depend on them. */
+/* Diagnostics: launch-planning knobs, by kernel family (csrc/shiftnd_api.hip routes them).  0-7 plane kernels
+ * (0: minimum workgroups wanted, 1: target bytes per workgroup, 2: gather-forward unroll, 3: backward form, 5: affine
+ * LDS reads, 6: XCD-contiguous block ids), 8-11 sweep kernels, 12-15 sliding-window kernels (12: which problems take
+ * them, 13: workgroups wanted, 14: minimum rows per band), 16-19 one-byte small-plane kernel (16: on / off, 17: planes
+ * per round, 18: LDS bytes, 19: rounds per workgroup), 20-21 LDS-tiled channels-last kernels (20: on / off, 21: rows
+ * per band), 24-26 small-plane / row-band kernels (24: on / off, 25: planes per round or rows per band, 26: rounds per
+ * workgroup); 0 restores the default of a knob.  Results never depend on them. */
 SHIFTND_API void shiftnd_set_tuning(int knob, int value);
 /* Diagnostics: the sweep kernels' arithmetic padding map evaluated on the host: source index of
  * coordinate p (0 <= p <= len) under `shift`, or -1 for "fill". */

@@ -61,7 +61,7 @@ def cpu_baseline(workload_pad=0):
     only run whose weight gradient is race-free in the reference, global_scope.h:22)."""
     script = os.path.join(ROOT, "oracle", "ref_bench.py")
     try:
-        out = subprocess.run([sys.executable, script, "--n", "8", "--pad", str(workload_pad), "--iters", "2", "--both"],
+        out = subprocess.run([sys.executable, script, "--n", "24", "--pad", str(workload_pad), "--iters", "2", "--both"],
                              capture_output=True, text=True, timeout=900)
         lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
         if out.returncode != 0 or not lines:

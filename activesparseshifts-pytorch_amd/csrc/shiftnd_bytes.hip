@@ -226,7 +226,7 @@ BytesPlan bytes_plan(const Geometry &g) {
     for (int d = 0; d < 3; ++d)
         if (g.L[d] != 0 || g.O[d] != g.S[d]) return pl;
     const int64_t plane = g.S[0] * g.S[1] * g.S[2];
-    if (plane % 16 != 0 || plane > 12288 || plane < 16) return pl;  // (the byte table holds int16 offsets)
+    if (plane % 16 != 0 || plane > 16384 || plane < 16) return pl;  // (the byte table holds int16 offsets; 112 x 112 = 12544 still fits)
     if (g.S[0] + g.S[1] + g.S[2] + 3 > 2048) return pl;
     if (g.N >= (1LL << 30) || g.C >= (1LL << 30)) return pl;
     pl.npc = static_cast<int>(plane / 16);

@@ -382,3 +382,25 @@ def test_channels_last_backward_through_the_op_uses_the_tiled_kernel(active):
     # a contiguous incoming gradient: the layout of the saved input is changed once, then the contiguous kernels
     gx2, gw2 = op(go, w, x.contiguous(memory_format=cl), b6, 3, active)
     assert abi.last_kernel() != "cl_tiled_backward" and torch.equal(gx2, gx_r)
+
+
+def test_byte_kernel_on_112x112_planes():
+    """the largest plane the byte kernel takes with zeros padding (12544 bytes: the stem of a 224-pixel network after its
+    first stride-2 layer); the other paddings need the byte table as well and take it while that fits LDS.  Bit-exact
+    either way, rounds per workgroup 1 and 3 (knob 19)"""
+    from torchshifts import abi
+    rs = np.random.RandomState(112)
+    shape = (5, 4, 112, 112)
+    xq = rs.randint(0, 256, size=shape).astype(np.uint8)
+    wq = rs.randint(123, 134, size=(4, 2)).astype(np.uint8)
+    x, w = torch.from_numpy(xq).to(DEV), torch.from_numpy(wq).to(DEV)
+    try:
+        for rpw in (0, 1, 3):
+            abi.set_tuning(19, rpw)
+            for pad in range(5):
+                out = abi.forward_quantized(x, w, 128, 9, pad)
+                if pad == 0:
+                    assert abi.last_kernel() == "bytes_gather_forward"
+                assert np.array_equal(out.cpu().numpy(), O.forward_q(xq, wq, 128, 9, pad)), (pad, rpw)
+    finally:
+        abi.set_tuning(19, 0)

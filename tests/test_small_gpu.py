@@ -5,7 +5,7 @@ import torch
 
 from cases import rel_err
 from oracle import oracle as O
-from test_hip_parity import _weights
+from test_hip_parity import _ulp_close, _weights
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
@@ -68,10 +68,13 @@ def test_small_planes_16bit_agree_with_the_strided_kernels(abi, tdt):
                 ref = abi.forward(x, w, pad, 1)
                 gx_r, gw_r = abi.backward(go, w, x, pad, active)
                 abi.set_path_policy(0)
+                # (16-bit interpolation: the kernel families agree to 1 ulp of the 16-bit type -- the compiler may fuse
+                # a widening into one family's multiply-add -- the sparse shift's grad_x is a raw copy: equal)
                 out = abi.forward(x, w, pad, 1)
-                assert abi.last_kernel() == "small_plane_forward" and torch.equal(out, ref)
+                assert abi.last_kernel() == "small_plane_forward" and _ulp_close(out.cpu(), ref.cpu(), tdt)
                 gx, gw = abi.backward(go, w, x, pad, active)
-                assert abi.last_kernel() == "small_plane_backward" and torch.equal(gx, gx_r)
+                assert abi.last_kernel() == "small_plane_backward"
+                assert _ulp_close(gx.cpu(), gx_r.cpu(), tdt) if active else torch.equal(gx, gx_r)
                 assert rel_err(gw.float().cpu().numpy(), gw_r.float().cpu().numpy()) < 4 * float(torch.finfo(tdt).eps)
 
 

@@ -14,8 +14,8 @@
 //     values from LDS; stores are coalesced element stores;
 //   * backward: fp64 weight-gradient sums per thread, one block sum per workgroup into the [group][C][3] partial sums
 //     that reduce_weight_grads finishes (deterministic).
-// Arithmetic is the shared one (interp_t, weight_grads_nd, prep_shift_*): results are bit-identical to the other kernel
-// families for forward and grad_x.
+// Arithmetic is the shared one (interp_t, weight_grads_nd, prep_shift_*): forward and grad_x are bit-identical to the
+// other kernel families in fp32 / fp64, within 1 ulp of the 16-bit type for fp16 / bf16 interpolation.
 //
 // Reference behaviour restated (paths under torchshifts/csrc/ops/): forward kernels/shifts_kernels.h:156-220, backward
 // :222-327, interpolation kernels/interpolation.h:3-61, weight preparation cpu/shifts_cpu.cpp:223-224, :242-244.

@@ -1,0 +1,138 @@
+#!/usr/bin/env python3
+"""Randomised parity run of the round-2 kernel families against the oracle (GPU box):
+    python3 tools/fuzz_round2.py [--seconds 120] [--seed 0]
+channels-last tiled kernels (forward 1/2/4 bytes, active forward, backward), small-plane / row-band kernels, the byte
+kernel with rounds.  Prints the number of cases per kernel and stops at the first mismatch."""
+import argparse
+import collections
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "activesparseshifts-pytorch_amd"))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+from torchshifts import abi  # noqa: E402
+from oracle import oracle as O  # noqa: E402
+
+DEV = "cuda:0"
+count = collections.Counter()
+
+
+def rel_err(a, b):
+    """max error relative to the largest weight gradient, or to 1 when all of them are small sums of large terms (a
+    single channel whose terms cancel: the fp32 products then limit the relative error, not the kernel)"""
+    d = np.abs(a.astype(np.float64) - b.astype(np.float64)).max()
+    return d / max(np.abs(b).max(), 1.0)
+
+
+def weights(rs, C, nd, sizes, span):
+    w = rs.uniform(-span, span, size=(C, nd))
+    k = rs.randint(0, 4)
+    if k == 0:
+        w[rs.randint(C)] = [s + 1.25 for s in sizes]
+    if k == 1:
+        w[rs.randint(C)] = [-(2 * s + 0.5) for s in sizes]
+    if k == 2:
+        w[rs.randint(C)] = [-3.0, -2.75, 3.0][:nd]
+    return w
+
+
+def case_cl(rs):
+    C = int(rs.choice([4, 8, 12, 32, 36, 64, 100]))
+    H = int(rs.choice([1, 5, 6, 9, 17, 33])); W = int(rs.randint(1, 41))
+    N = int(rs.randint(1, 4))
+    shape = (N, C, H, W)
+    pad = int(rs.choice([0, 1, 3, 4])); active = int(rs.randint(0, 2))
+    x = rs.uniform(-1, 1, size=shape).astype(np.float32); go = rs.uniform(-1, 1, size=shape).astype(np.float32)
+    w = weights(rs, C, 2, shape[2:], 3.9).astype(np.float32)
+    cl = torch.channels_last
+    xd = torch.from_numpy(x).to(DEV).contiguous(memory_format=cl); gd = torch.from_numpy(go).to(DEV).contiguous(memory_format=cl)
+    wd = torch.from_numpy(w).to(DEV)
+    abi.set_tuning(21, int(rs.choice([0, 0, 3, 7])))
+    ref = O.forward(x, w, pad, active)
+    for out in (None, torch.empty(shape, device=DEV).contiguous(memory_format=cl)):
+        o = abi.forward(xd, wd, pad, active, out=out)
+        count[abi.last_kernel()] += 1
+        assert np.array_equal(o.cpu().numpy(), ref), ("cl fwd", shape, pad, active)
+    gx, gw = abi.backward(gd, wd, xd, pad, active, grad_x=torch.empty(shape, device=DEV).contiguous(memory_format=cl))
+    count[abi.last_kernel()] += 1
+    gx_o, _ = O.backward(go, w, x, pad, active)
+    _, gw64 = O.backward(go.astype(np.float64), w.astype(np.float64), x.astype(np.float64), pad, active)
+    assert np.array_equal(gx.cpu().numpy(), gx_o), ("cl gx", shape, pad, active)
+    assert rel_err(gw.cpu().numpy(), gw64) < 1e-5, ("cl gw", shape, pad, active)
+    abi.set_tuning(21, 0)
+    # quantized uint8, format kept
+    if (C * 1) % 16 == 0:
+        xq = rs.randint(0, 256, size=shape).astype(np.uint8); wq = rs.randint(122, 135, size=(C, 2)).astype(np.uint8)
+        oq = torch.empty(shape, dtype=torch.uint8, device=DEV).contiguous(memory_format=cl)
+        abi.forward_quantized(torch.from_numpy(xq).to(DEV).contiguous(memory_format=cl), torch.from_numpy(wq).to(DEV), 128, 3, pad, out=oq)
+        count[abi.last_kernel() + "/u8"] += 1
+        assert np.array_equal(oq.cpu().numpy(), O.forward_q(xq, wq, 128, 3, pad)), ("cl u8", shape, pad)
+
+
+def case_ragged(rs):
+    nd = int(rs.choice([1, 2, 2, 2, 3]))
+    npdt = rs.choice([np.float32, np.float64])
+    if nd == 1:
+        sp = (int(rs.choice([3, 13, 301, 2301])),)
+    elif nd == 2:
+        sp = (int(rs.randint(1, 80)), int(rs.choice([1, 3, 5, 7, 13, 14, 27, 57, 113, 131])))
+    else:
+        sp = (int(rs.randint(1, 5)), int(rs.randint(1, 9)), int(rs.choice([3, 5, 7, 9])))
+    N, C = int(rs.randint(1, 6)), int(rs.randint(1, 7))
+    shape = (N, C) + sp
+    if (sp[-1] * np.dtype(npdt).itemsize) % 16 == 0:
+        return
+    pad = int(rs.randint(0, 5)); active = int(rs.randint(0, 2))
+    x = rs.uniform(-1, 1, size=shape).astype(npdt); go = rs.uniform(-1, 1, size=shape).astype(npdt)
+    w = weights(rs, C, nd, sp, 4.5).astype(npdt)
+    xd, gd, wd = torch.from_numpy(x).to(DEV), torch.from_numpy(go).to(DEV), torch.from_numpy(w).to(DEV)
+    abi.set_tuning(25, int(rs.choice([0, 0, 1, 2, 5]))); abi.set_tuning(26, int(rs.choice([0, 0, 1, 3])))
+    o = abi.forward(xd, wd, pad, active)
+    count[abi.last_kernel()] += 1
+    assert np.array_equal(o.cpu().numpy(), O.forward(x, w, pad, active)), ("ragged fwd", shape, pad, active, abi.last_kernel())
+    gx, gw = abi.backward(gd, wd, xd, pad, active)
+    count[abi.last_kernel()] += 1
+    gx_o, _ = O.backward(go, w, x, pad, active)
+    _, gw64 = O.backward(go.astype(np.float64), w.astype(np.float64), x.astype(np.float64), pad, active)
+    assert np.array_equal(gx.cpu().numpy(), gx_o), ("ragged gx", shape, pad, active, abi.last_kernel())
+    e = rel_err(gw.cpu().numpy(), gw64)
+    assert e < (1e-12 if npdt == np.float64 else 1e-5), ("ragged gw", shape, pad, active, abi.last_kernel(), str(npdt), e, w.tolist(), gw.cpu().numpy().tolist(), gw64.tolist())
+    abi.set_tuning(25, 0); abi.set_tuning(26, 0)
+
+
+def case_bytes(rs):
+    H, W = [(8, 16), (28, 28), (56, 56), (4, 4), (112, 112), (12, 20)][rs.randint(6)]
+    N, C = int(rs.randint(1, 41)), int(rs.randint(1, 5))
+    shape = (N, C, H, W)
+    pad = int(rs.randint(0, 5))
+    xq = rs.randint(0, 256, size=shape).astype(np.uint8); wq = rs.randint(120, 137, size=(C, 2)).astype(np.uint8)
+    abi.set_tuning(17, int(rs.choice([0, 0, 1, 3]))); abi.set_tuning(19, int(rs.choice([0, 0, 1, 2, 5])))
+    o = abi.forward_quantized(torch.from_numpy(xq).to(DEV), torch.from_numpy(wq).to(DEV), 128, 11, pad)
+    count[abi.last_kernel() + "/u8"] += 1
+    assert np.array_equal(o.cpu().numpy(), O.forward_q(xq, wq, 128, 11, pad)), ("bytes", shape, pad)
+    abi.set_tuning(17, 0); abi.set_tuning(19, 0)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--seconds", type=float, default=120)
+    ap.add_argument("--seed", type=int, default=0)
+    a = ap.parse_args()
+    rs = np.random.RandomState(a.seed)
+    t0 = time.time()
+    n = 0
+    while time.time() - t0 < a.seconds:
+        [case_cl, case_ragged, case_ragged, case_bytes][n % 4](rs)
+        n += 1
+    print("cases", n, dict(count))
+    print("fuzz ok")
+
+
+if __name__ == "__main__":
+    main()

@@ -90,6 +90,11 @@ int forward_common(const shiftnd_problem *p, const void *x, const int64_t *xs, c
         // (interpolating problems keep the LDS-staged plane kernels whenever those take them: see DESIGN 3.14)
         const bool interpolating = g.active && p->dtype <= SHIFTND_BF16;
         const bool prefer_sweep = (out_plane_bytes >= 32 * 1024 && !interpolating && !(can_plane && plane_forward_lds_gather(g, p->dtype, x, out))) || !can_plane;
+        // 1-byte (and, knob 28, 2-byte) rows of whole 16-byte pieces beyond the byte kernel's small planes: rows through LDS
+        if (g_policy == 0 && !bytes_forward_eligible(g, p->dtype, x, out) && rows_forward_eligible(g, p->dtype, x, out)) {
+            g_last_path = SHIFTND_PATH_PLANE;
+            return finish(rows_forward(g, p->dtype, x, w, wkind, wzp, fill, out, st));
+        }
         // rows that are not whole 16-byte pieces, planes above 16 KiB: the chunk kernels would move them element by
         // element (shiftnd_small.hip)
         if (g_policy == 0 && out_plane_bytes > 16 * 1024 && band_gather_forward_eligible(g, p->dtype)) {
@@ -153,7 +158,8 @@ int shiftnd_last_path(void) { return g_last_path; }
 void shiftnd_set_path_policy(int policy) { g_policy = policy; }
 
 void shiftnd_set_tuning(int knob, int value) {
-    if (knob >= 24) small_set_tuning(knob - 24, value);  // 24: small-plane kernels on / off, 25: planes per round, 26: rounds per workgroup
+    if (knob >= 28) rows_set_tuning(knob - 28, value);  // 28: element sizes served (bit 0: 1 byte, bit 1: 2 bytes), 29: rows per band, 30: workgroups
+    else if (knob >= 24) small_set_tuning(knob - 24, value);  // 24: small-plane kernels on / off, 25: planes per round, 26: rounds per workgroup
     else if (knob >= 20) cl_tiled_set_tuning(knob - 20, value);  // 20: LDS-tiled channels-last forward on / off, 21: rows per band
     else if (knob >= 16) bytes_set_tuning(knob - 16, value);  // 16: 1-byte small-plane kernel on / off, 17: planes per workgroup
     else if (knob >= 12) slide_set_tuning(knob - 12, value);  // 12: which problems slide, 13: workgroups wanted, 14: min rows per band

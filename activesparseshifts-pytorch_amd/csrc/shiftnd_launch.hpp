@@ -109,6 +109,14 @@ bool band_gather_forward_eligible(const Geometry &g, int dtype);
 int band_gather_forward(const Geometry &g, int dtype, const void *x, const void *w, int wkind, int64_t wzp, uint64_t fill_bits,
                         void *out, hipStream_t st);
 
+// ---- rows through LDS with register prefetch (shiftnd_rows.hip): sparse-shift / quantized forward of 1- / 2-byte elements,
+// contiguous tensors, rows of whole 16-byte pieces
+bool rows_forward_eligible(const Geometry &g, int dtype, const void *x, const void *out);
+int rows_forward(const Geometry &g, int dtype, const void *x, const void *w, int wkind, int64_t wzp, uint64_t fill_bits, void *out,
+                 hipStream_t st);
+void rows_set_tuning(int knob, int value);
+bool bytes_forward_eligible(const Geometry &g, int dtype, const void *x, const void *out);
+
 // ---- layout change (shiftnd_transpose.hip): dst[n][c][r] = src[n][r][c], dense tensors ---------------------------
 int transpose_planes(const void *src, void *dst, int64_t N, int64_t rows, int64_t cols, int esize, hipStream_t st);
 

@@ -110,7 +110,8 @@ SHIFTND_API void shiftnd_set_path_policy(int policy);
  * them, 13: workgroups wanted, 14: minimum rows per band), 16-19 one-byte small-plane kernel (16: on / off, 17: planes
  * per round, 18: LDS bytes, 19: rounds per workgroup), 20-21 LDS-tiled channels-last kernels (20: on / off, 21: rows
  * per band), 24-26 small-plane / row-band kernels (24: on / off, 25: planes per round or rows per band, 26: rounds per
- * workgroup); for the sizing knobs 0 means automatic.  Results never depend on them. */
+ * workgroup), 28-30 one-byte row kernel (28: element sizes served, 29: rows per band, 30: workgroups wanted); for the
+ * sizing knobs 0 means automatic.  Results never depend on them. */
 SHIFTND_API void shiftnd_set_tuning(int knob, int value);
 /* Diagnostics: the sweep kernels' arithmetic padding map evaluated on the host: source index of
  * coordinate p (0 <= p <= len) under `shift`, or -1 for "fill". */

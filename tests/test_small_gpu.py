@@ -189,3 +189,48 @@ def test_row_band_gather_forward_vs_oracle(abi):
     abi.set_path_policy(0)
     out = abi.forward(xh, wh, 3, 0)
     assert abi.last_kernel() == "band_gather_forward" and torch.equal(out, ref)
+
+
+@pytest.mark.parametrize("shape,npdt", [((2, 3, 40, 64), np.uint8), ((1, 2, 3, 33, 48), np.int8), ((3, 2, 150, 224), np.uint8),
+                                        ((2, 2, 1, 4096), np.uint8), ((2, 3, 130), np.uint8)])
+def test_rows_gather_forward_vs_oracle(abi, shape, npdt):
+    """rows_gather_forward (csrc/shiftnd_rows.hip): quantized forward of 1-byte rows of whole 16-byte pieces beyond the
+    byte kernel's small planes; every padding, shifts beyond the dims, ragged last row groups / bands (knob 29); bit-exact"""
+    rs = np.random.RandomState(sum(shape) + 1)
+    nd = len(shape) - 2
+    info = np.iinfo(npdt)
+    xq = rs.randint(info.min, info.max + 1, size=shape).astype(npdt)
+    wq = rs.randint(120, 137, size=(shape[1], nd)).astype(np.uint8)
+    wq[0, :] = min(255, 128 + shape[-1] + 3)
+    x, w = torch.from_numpy(xq).to(DEV), torch.from_numpy(wq).to(DEV)
+    rows = (shape[-1] % 16 == 0) and int(np.prod(shape[2:])) > 16384
+    try:
+        abi.set_tuning(16, 0 if not rows else 1)   # (small planes: the byte kernel off, so that this kernel is measured)
+        for br in (0, 7):
+            abi.set_tuning(29, br)
+            for pad in range(5):
+                out = abi.forward_quantized(x, w, 128, -3 if npdt == np.int8 else 9, pad)
+                if shape[-1] % 16 == 0:
+                    assert abi.last_kernel() == "rows_gather_forward", (shape, pad, abi.last_kernel())
+                assert np.array_equal(out.cpu().numpy(), O.forward_q(xq, wq, 128, -3 if npdt == np.int8 else 9, pad)), (shape, pad, br)
+    finally:
+        abi.set_tuning(16, 1)
+        abi.set_tuning(29, 0)
+
+
+def test_rows_gather_forward_16bit(abi):
+    """the same kernel for fp16 / bf16 sparse shifts (knob 28 bit 1) against the default kernels"""
+    torch.manual_seed(2)
+    for shape, tdt in [((3, 4, 50, 72), torch.float16), ((2, 3, 4, 20, 40), torch.bfloat16)]:
+        nd = len(shape) - 2
+        x = torch.rand(shape, device=DEV).to(tdt)
+        w = ((torch.rand(shape[1], nd, device=DEV) - 0.5) * 9).to(tdt)
+        for pad in range(5):
+            ref = abi.forward(x, w, pad, 0)
+            abi.set_tuning(28, 3)
+            try:
+                out = abi.forward(x, w, pad, 0)
+                assert abi.last_kernel() == "rows_gather_forward"
+            finally:
+                abi.set_tuning(28, 1)
+            assert torch.equal(out, ref), (shape, pad)

@@ -107,16 +107,16 @@ def case_ragged(rs):
 
 
 def case_bytes(rs):
-    H, W = [(8, 16), (28, 28), (56, 56), (4, 4), (112, 112), (12, 20)][rs.randint(6)]
-    N, C = int(rs.randint(1, 41)), int(rs.randint(1, 5))
+    H, W = [(8, 16), (28, 28), (56, 56), (4, 4), (112, 112), (12, 20), (150, 224), (530, 32), (75, 240)][rs.randint(9)]
+    N, C = int(rs.randint(1, 41 if H * W <= 16384 else 5)), int(rs.randint(1, 5))
     shape = (N, C, H, W)
     pad = int(rs.randint(0, 5))
     xq = rs.randint(0, 256, size=shape).astype(np.uint8); wq = rs.randint(120, 137, size=(C, 2)).astype(np.uint8)
-    abi.set_tuning(17, int(rs.choice([0, 0, 1, 3]))); abi.set_tuning(19, int(rs.choice([0, 0, 1, 2, 5])))
+    abi.set_tuning(17, int(rs.choice([0, 0, 1, 3]))); abi.set_tuning(19, int(rs.choice([0, 0, 1, 2, 5]))); abi.set_tuning(29, int(rs.choice([0, 0, 5, 40])))
     o = abi.forward_quantized(torch.from_numpy(xq).to(DEV), torch.from_numpy(wq).to(DEV), 128, 11, pad)
     count[abi.last_kernel() + "/u8"] += 1
     assert np.array_equal(o.cpu().numpy(), O.forward_q(xq, wq, 128, 11, pad)), ("bytes", shape, pad)
-    abi.set_tuning(17, 0); abi.set_tuning(19, 0)
+    abi.set_tuning(17, 0); abi.set_tuning(19, 0); abi.set_tuning(29, 0)
 
 
 def main():

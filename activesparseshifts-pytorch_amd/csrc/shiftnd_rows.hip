@@ -85,7 +85,17 @@ __global__ __launch_bounds__(kThreads) void rows_gather_forward(const RowsParams
         affine = affine && cm[e] == cm[0] + e && cm[0] >= 0;
     }
     const int s0 = affine ? cm[0] * ES : 0;                 // byte offset of the source window in the staged row
-    const int wdw = kRowGuard + (s0 & ~3), wsh = s0 & 3;    // aligned dword start, sub-dword displacement
+    // The window starts at the same byte of its aligned 16-byte piece in every affine piece of the workgroup (s0 = 16 tc -
+    // shift * ES): two aligned 16-byte LDS reads (no bank conflicts between the lanes of a row; five dword reads at a lane
+    // stride of 16 bytes conflict four ways) and a uniform choice of the five dwords that hold the window.
+    const int wq = kRowGuard + (s0 & ~15);
+    int phase = 0;
+    {
+        const unsigned long long am = __ballot(affine);
+        if (am) phase = __builtin_amdgcn_readlane(s0 & 15, static_cast<int>(__builtin_ctzll(am)));
+    }
+    const uint32_t wsh = static_cast<uint32_t>(phase & 3);
+    const int wk = phase >> 2;
 
     const int64_t plane_elems = static_cast<int64_t>(S1) * S2;
     const int64_t chan_bytes = static_cast<int64_t>(S0) * plane_elems * ES;   // one (n, c) volume
@@ -141,12 +151,27 @@ __global__ __launch_bounds__(kThreads) void rows_gather_forward(const RowsParams
         const char *row = tile + (worker ? tr : 0) * pitch;
         uint32_t w[4];
         if (affine) {
-            const uint32_t *dwp = reinterpret_cast<const uint32_t *>(row + wdw);
-            uint32_t d[5];
+            const u4 q0 = *reinterpret_cast<const u4 *>(__builtin_assume_aligned(row + wq, 16));
+            const u4 q1 = *reinterpret_cast<const u4 *>(__builtin_assume_aligned(row + wq + 16, 16));
+            const uint32_t D[8] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w};
+            switch (wk) {   // (uniform)
+            case 0:
 #pragma unroll
-            for (int i = 0; i < 5; ++i) d[i] = dwp[i];
+                for (int i = 0; i < 4; ++i) w[i] = __builtin_amdgcn_alignbyte(D[i + 1], D[i], wsh);
+                break;
+            case 1:
 #pragma unroll
-            for (int i = 0; i < 4; ++i) w[i] = __builtin_amdgcn_alignbyte(d[i + 1], d[i], static_cast<uint32_t>(wsh));
+                for (int i = 0; i < 4; ++i) w[i] = __builtin_amdgcn_alignbyte(D[i + 2], D[i + 1], wsh);
+                break;
+            case 2:
+#pragma unroll
+                for (int i = 0; i < 4; ++i) w[i] = __builtin_amdgcn_alignbyte(D[i + 3], D[i + 2], wsh);
+                break;
+            default:
+#pragma unroll
+                for (int i = 0; i < 4; ++i) w[i] = __builtin_amdgcn_alignbyte(D[i + 4], D[i + 3], wsh);
+                break;
+            }
         } else {
             const EL *re = reinterpret_cast<const EL *>(row + kRowGuard);
             const EL fe = static_cast<EL>(p.fill4);

@@ -39,7 +39,7 @@ struct RowsParams {
     int units, upw;      // N * S0 * bands, units per workgroup
     int map_entries;
     unsigned xcd_blocks;
-    FastDiv d_cpr, d_bands, d_S0, d_C, d_gpb;
+    FastDiv d_cpr, d_bands, d_S0, d_C;
     FastDiv d_per[3];
 };
 
@@ -102,36 +102,58 @@ __global__ __launch_bounds__(kThreads) void rows_gather_forward(const RowsParams
     // buffer resources over the channel's volumes of one batch entry are rebuilt per unit (uniform); offsets < 2^31 (host)
     constexpr int kDepth = ROWS_DEPTH;
     u4 pv[kDepth];
-    // step s of the workgroup = (unit k, row group g): a flat counter so that the prefetch runs across units
+    // step s of the workgroup = (unit k, row group gi of its band): two cursors walk the steps -- one for the step being
+    // produced, one kDepth steps ahead for the loads -- and keep everything that changes only with the unit (batch entry,
+    // depth, band: uniform values) out of the per-step arithmetic
     const int gpb = (p.BR + R - 1) / R;                      // row groups per full band
-    auto locate = [&](int s, const char *&src, char *&dst, uint32_t &soff, uint32_t &doff, bool &fillrow) {
-        // which rows step s moves: source piece offset for this thread (or out of range), output piece offset likewise
-        const int k = static_cast<int>(fdiv(static_cast<uint32_t>(s), p.d_gpb)), gi = s - k * gpb;
-        const int u = u0 + (k < nu ? k : 0);
+    const int nsteps = nu * gpb;
+    struct Cursor {
+        int k, gi;             // unit of the workgroup, row group of the band
+        int b0, bend;          // first row of the group, end of the band's rows
+        int64_t vol;           // byte offset of the (n, c) volume
+        uint32_t sp, dp;       // byte offsets of the source / output plane in the volume; sp out of range: fill plane
+    };
+    auto enter_unit = [&](Cursor &cu) {   // (uniform)
+        const int u = u0 + (cu.k < nu ? cu.k : 0);
         const int t1 = fdiv(u, p.d_bands), band = u - t1 * p.bands;     // t1 = n * S0 + a
         const int n = fdiv(t1, p.d_S0), a = t1 - n * S0;
-        const int b = band * p.BR + gi * R + tr;
-        const bool live = k < nu && worker && b < min(S1, (band + 1) * p.BR);
-        const int ra = live ? m0[a] : -1, rb = live ? m1[b] : -1;
-        const int64_t vol = (static_cast<int64_t>(n) * p.C + c) * chan_bytes;
-        src = p.x + vol;
-        dst = p.out + vol;
-        fillrow = !(ra >= 0 && rb >= 0);
-        soff = (live && !fillrow) ? static_cast<uint32_t>((static_cast<int64_t>(ra) * S1 + rb) * RB + tc * 16) : 0x80000000u;
-        doff = live ? static_cast<uint32_t>((static_cast<int64_t>(a) * S1 + b) * RB + tc * 16) : 0x80000000u;
+        const int ra = m0[a];
+        cu.b0 = band * p.BR;
+        cu.bend = cu.k < nu ? min(S1, (band + 1) * p.BR) : 0;
+        cu.vol = (static_cast<int64_t>(n) * p.C + c) * chan_bytes;
+        cu.sp = ra >= 0 ? static_cast<uint32_t>(static_cast<int64_t>(ra) * S1 * RB) : 0x80000000u;
+        cu.dp = static_cast<uint32_t>(static_cast<int64_t>(a) * S1 * RB);
     };
-    const int nsteps = nu * gpb;
-    auto issue = [&](int s, u4 &v) {
-        const char *src;
-        char *dst;
+    auto advance = [&](Cursor &cu) {
+        cu.b0 += R;
+        if (++cu.gi == gpb) {
+            cu.gi = 0;
+            ++cu.k;
+            enter_unit(cu);
+        }
+    };
+    // this thread's piece offsets for the cursor's step (out of range: nothing to load / store), and whether the row is fill
+    auto piece = [&](const Cursor &cu, uint32_t &soff, uint32_t &doff, bool &fillrow) {
+        const int b = cu.b0 + tr;
+        const bool live = worker && b < cu.bend;
+        const int rb = live ? m1[b] : -1;
+        fillrow = rb < 0 || cu.sp == 0x80000000u;
+        soff = (live && !fillrow) ? cu.sp + static_cast<uint32_t>(rb * RB + tc * 16) : 0x80000000u;
+        doff = live ? cu.dp + static_cast<uint32_t>(b * RB + tc * 16) : 0x80000000u;
+    };
+    Cursor cur{0, 0, 0, 0, 0, 0u, 0u}, ahead{0, 0, 0, 0, 0, 0u, 0u};
+    enter_unit(cur);
+    enter_unit(ahead);
+    auto issue = [&](u4 &v) {   // the loads of the `ahead` cursor's step, then on to the next step
         uint32_t soff, doff;
         bool fr;
-        locate(s, src, dst, soff, doff, fr);
-        const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(src), 0, 0x7ffffffc, 0x00020000);
+        piece(ahead, soff, doff, fr);
+        const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(p.x) + ahead.vol, 0, 0x7ffffffc, 0x00020000);
         v = __builtin_amdgcn_raw_buffer_load_b128(r, soff, 0, 0);
+        advance(ahead);
     };
 #pragma unroll
-    for (int d = 0; d < kDepth; ++d) issue(d, pv[d]);
+    for (int d = 0; d < kDepth; ++d) issue(pv[d]);
     {   // kDepth dropped stores: the loop's entry path then has as many operations behind its loads as the back edge
         const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(p.out, 0, 0, 0x00020000);
         const u4 z = {0u, 0u, 0u, 0u};
@@ -142,12 +164,12 @@ __global__ __launch_bounds__(kThreads) void rows_gather_forward(const RowsParams
         char *tile = tiles + (s & 1) * tile_bytes;
         if (worker) *reinterpret_cast<u4 *>(__builtin_assume_aligned(tile + tr * pitch + kRowGuard + tc * 16, 16)) = v;
         __syncthreads();
-        const char *src;
-        char *dst;
         uint32_t soff, doff;
         bool fillrow;
-        locate(s, src, dst, soff, doff, fillrow);
-        issue(s + kDepth, v);
+        piece(cur, soff, doff, fillrow);
+        char *dst = p.out + cur.vol;
+        advance(cur);
+        issue(v);
         const char *row = tile + (worker ? tr : 0) * pitch;
         uint32_t w[4];
         if (affine) {
@@ -310,7 +332,6 @@ int rows_forward(const Geometry &g, int dtype, const void *x, const void *w, int
     p.d_bands = make_fastdiv(static_cast<uint32_t>(pl.bands));
     p.d_S0 = make_fastdiv(static_cast<uint32_t>(p.S[0]));
     p.d_C = make_fastdiv(static_cast<uint32_t>(p.C));
-    p.d_gpb = make_fastdiv(static_cast<uint32_t>((pl.BR + pl.R - 1) / pl.R));
     note_kernel("rows_gather_forward");
     if (es == 1) hipLaunchKernelGGL(rows_gather_forward<1>, dim3(pl.grid), dim3(kThreads), pl.lds, st, p);
     else hipLaunchKernelGGL(rows_gather_forward<2>, dim3(pl.grid), dim3(kThreads), pl.lds, st, p);

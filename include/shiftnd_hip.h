@@ -108,8 +108,8 @@ SHIFTND_API void shiftnd_set_path_policy(int policy);
  * (0: minimum workgroups wanted, 1: target bytes per workgroup, 2: gather-forward unroll, 3: backward form, 5: affine
  * LDS reads, 6: XCD-contiguous block ids), 8-11 sweep kernels, 12-15 sliding-window kernels (12: which problems take
  * them, 13: workgroups wanted, 14: minimum rows per band), 16-19 one-byte small-plane kernel (16: on / off, 17: planes
- * per round, 18: LDS bytes, 19: rounds per workgroup), 20-21 LDS-tiled channels-last kernels (20: on / off, 21: rows
- * per band), 24-26 small-plane / row-band kernels (24: on / off, 25: planes per round or rows per band, 26: rounds per
+ * per round, 18: LDS bytes, 19: rounds per workgroup), 20-22 LDS-tiled channels-last kernels (20: on / off, 21: rows
+ * per band, 22: XCD-contiguous block ids), 24-26 small-plane / row-band kernels (24: on / off, 25: planes per round or rows per band, 26: rounds per
  * workgroup), 28-30 one-byte row kernel (28: element sizes served, 29: rows per band, 30: workgroups wanted); for the
  * sizing knobs 0 means automatic.  Results never depend on them. */
 SHIFTND_API void shiftnd_set_tuning(int knob, int value);

@@ -76,22 +76,35 @@ __global__ __launch_bounds__(kThreads) void rows_gather_forward(const RowsParams
     const int tr = fdiv(threadIdx.x, p.d_cpr), tc = static_cast<int>(threadIdx.x) - tr * p.cpr;
     const bool worker = tr < R;
     const int j0 = tc * E;
-    // the output piece's columns: affine (source column = j - shift, all of them inside the row) or element by element
+    // the output piece's columns: affine (every VALID column is j - shift; the others -- beyond the row with zeros padding
+    // -- are dropped by a byte mask and replaced by the fill value) or, where a padding wraps or reflects inside the piece,
+    // element by element.  With zeros padding no piece takes the element path.
     int cm[E];
-    bool affine = worker;
+    int base = 0;
+    bool found = false;
 #pragma unroll
     for (int e = 0; e < E; ++e) {
         cm[e] = worker ? m2[j0 + e] : -1;
-        affine = affine && cm[e] == cm[0] + e && cm[0] >= 0;
+        if (!found && cm[e] >= 0) {
+            base = cm[e] - e;
+            found = true;
+        }
     }
-    const int s0 = affine ? cm[0] * ES : 0;                 // byte offset of the source window in the staged row
+    bool affine = worker;
+    uint32_t mk[4] = {0u, 0u, 0u, 0u};   // bytes of the piece that come from the source row
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        affine = affine && (cm[e] < 0 || cm[e] == base + e);
+        if (cm[e] >= 0) mk[(e * ES) >> 2] |= (ES == 1 ? 0xffu : 0xffffu) << (((e * ES) & 3) * 8);
+    }
+    const int s0 = affine ? base * ES : 0;                  // byte offset of the source window in the staged row (>= -15)
     // The window starts at the same byte of its aligned 16-byte piece in every affine piece of the workgroup (s0 = 16 tc -
     // shift * ES): two aligned 16-byte LDS reads (no bank conflicts between the lanes of a row; five dword reads at a lane
     // stride of 16 bytes conflict four ways) and a uniform choice of the five dwords that hold the window.
     const int wq = kRowGuard + (s0 & ~15);
     int phase = 0;
     {
-        const unsigned long long am = __ballot(affine);
+        const unsigned long long am = __ballot(affine && found);
         if (am) phase = __builtin_amdgcn_readlane(s0 & 15, static_cast<int>(__builtin_ctzll(am)));
     }
     const uint32_t wsh = static_cast<uint32_t>(phase & 3);
@@ -204,6 +217,10 @@ __global__ __launch_bounds__(kThreads) void rows_gather_forward(const RowsParams
                 const EL val = cm[e] >= 0 ? re[cm[e] > 0 ? cm[e] : 0] : fe;
                 w[(e * ES) >> 2] |= static_cast<uint32_t>(val) << (((e * ES) & 3) * 8);
             }
+        }
+        if (affine) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) w[i] = (w[i] & mk[i]) | (p.fill4 & ~mk[i]);   // v_bfi_b32
         }
         const u4 res = fillrow ? u4{p.fill4, p.fill4, p.fill4, p.fill4} : u4{w[0], w[1], w[2], w[3]};
         const __amdgpu_buffer_rsrc_t ores = __builtin_amdgcn_make_buffer_rsrc(dst, 0, 0x7ffffffc, 0x00020000);

@@ -1,0 +1,56 @@
+#!/usr/bin/env python3
+"""A fixed set of calls outside bench.py's workloads, for profiles/collect_tool.sh: channels-last tensors (N16 C256 224x224
+fp32 forward / active forward / backward, quint8 C4 in NHWC), ragged rows (N128 C1024 14x14, N8 C64 225x225) and the
+one-byte row kernel (N64 C256 224x224 uint8).  Every call runs `--iters` times."""
+import argparse
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "activesparseshifts-pytorch_amd"))
+sys.path.insert(0, ROOT)
+from torchshifts import abi  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--iters", type=int, default=5)
+    a = ap.parse_args()
+    dev = "cuda:0"
+    torch.manual_seed(0)
+    cl = torch.channels_last
+    calls = []
+    x = torch.rand(16, 256, 224, 224, device=dev).contiguous(memory_format=cl)
+    go = torch.rand(16, 256, 224, 224, device=dev).contiguous(memory_format=cl)
+    w = torch.rand(256, 2, device=dev) * 6 - 3
+    out_n = torch.empty(16, 256, 224, 224, device=dev)
+    out_c, gx, gw = torch.empty_like(x), torch.empty_like(x), torch.empty_like(w)
+    ws = abi.backward_workspace(x, 0, 1)
+    calls += [lambda: abi.forward(x, w, 0, 0, out=out_n), lambda: abi.forward(x, w, 0, 0, out=out_c), lambda: abi.forward(x, w, 0, 1, out=out_c),
+              lambda: abi.backward(go, w, x, 0, 0, grad_x=gx, grad_w=gw, workspace=ws), lambda: abi.backward(go, w, x, 0, 1, grad_x=gx, grad_w=gw, workspace=ws)]
+    xq = torch.randint(0, 255, (128, 512, 56, 56), dtype=torch.uint8, device=dev).contiguous(memory_format=cl)
+    wq = (torch.rand(512, 2, device=dev) * 6 - 3).round().add(128).to(torch.uint8)
+    oq = torch.empty_like(xq)
+    calls.append(lambda: abi.forward_quantized(xq, wq, 128, 0, 0, out=oq))
+    for shape in ((128, 1024, 14, 14), (8, 64, 225, 225)):
+        xs, gs = torch.rand(shape, device=dev), torch.rand(shape, device=dev)
+        w2 = torch.rand(shape[1], 2, device=dev) * 6 - 3
+        os_, gxs, gws = torch.empty_like(xs), torch.empty_like(xs), torch.empty_like(w2)
+        wss = abi.backward_workspace(xs, 0, 1)
+        calls += [lambda xs=xs, w2=w2, os_=os_: abi.forward(xs, w2, 0, 1, out=os_),
+                  lambda xs=xs, gs=gs, w2=w2, gxs=gxs, gws=gws, wss=wss: abi.backward(gs, w2, xs, 0, 1, grad_x=gxs, grad_w=gws, workspace=wss)]
+    xb = torch.randint(0, 255, (64, 256, 224, 224), dtype=torch.uint8, device=dev)
+    wb = (torch.rand(256, 2, device=dev) * 6 - 3).round().add(128).to(torch.uint8)
+    ob = torch.empty_like(xb)
+    calls.append(lambda: abi.forward_quantized(xb, wb, 128, 0, 0, out=ob))
+    for f in calls:
+        for _ in range(a.iters):
+            f()
+    torch.cuda.synchronize()
+    print("done")
+
+
+if __name__ == "__main__":
+    main()

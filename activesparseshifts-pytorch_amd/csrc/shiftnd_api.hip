@@ -101,6 +101,11 @@ int forward_common(const shiftnd_problem *p, const void *x, const int64_t *xs, c
             g_last_path = SHIFTND_PATH_PLANE;
             return finish(band_gather_forward(g, p->dtype, x, w, wkind, wzp, fill, out, st));
         }
+        // 2-D sparse shift of 4- / 8-byte elements on planes of >= 32 KiB: the linear sweep of one-step workgroups
+        if (g_policy == 0 && step_forward_eligible(g, p->dtype, x, out)) {
+            g_last_path = SHIFTND_PATH_SWEEP;
+            return finish(step_forward(g, p->dtype, x, w, wkind, wzp, fill, out, st));
+        }
         if (can_sweep && (g_policy == 3 || (g_policy == 0 && prefer_sweep))) {
             g_last_path = SHIFTND_PATH_SWEEP;
             return finish(sweep_forward(g, p->dtype, x, w, wkind, wzp, fill, out, st));
@@ -158,7 +163,8 @@ int shiftnd_last_path(void) { return g_last_path; }
 void shiftnd_set_path_policy(int policy) { g_policy = policy; }
 
 void shiftnd_set_tuning(int knob, int value) {
-    if (knob >= 28) rows_set_tuning(knob - 28, value);  // 28: element sizes served (bit 0: 1 byte, bit 1: 2 bytes), 29: rows per band, 30: workgroups
+    if (knob >= 32) step_set_tuning(knob - 32, value);  // 32: one-step backward 0 automatic / 1 never / 2 whenever eligible
+    else if (knob >= 28) rows_set_tuning(knob - 28, value);  // 28: element sizes served (bit 0: 1 byte, bit 1: 2 bytes), 29: rows per band, 30: workgroups
     else if (knob >= 24) small_set_tuning(knob - 24, value);  // 24: small-plane kernels on / off, 25: planes per round, 26: rounds per workgroup
     else if (knob >= 20) cl_tiled_set_tuning(knob - 20, value);  // 20: LDS-tiled channels-last forward on / off, 21: rows per band
     else if (knob >= 16) bytes_set_tuning(knob - 16, value);  // 16: 1-byte small-plane kernel on / off, 17: planes per workgroup

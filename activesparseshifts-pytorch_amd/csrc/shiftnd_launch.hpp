@@ -65,6 +65,18 @@ bool slide_forward_eligible(const Geometry &g, int dtype, const void *x, const v
 int slide_forward(const Geometry &g, int dtype, const void *x, const void *w, void *out, hipStream_t st);
 void slide_set_tuning(int knob, int value);
 
+// ---- one-step workgroups (shiftnd_step.hip): the backward pass of contiguous 2-D problems as a linear sweep of short
+// workgroups; part of the per-channel family (plane_backward routes to it)
+bool step_backward_eligible(const Geometry &g, int dtype, const void *go, const void *x, const void *gx);
+size_t step_backward_workspace(const Geometry &g, int dtype);
+int step_backward(const Geometry &g, int dtype, const void *go, const void *x, const void *w, void *gx, void *gw,
+                  void *workspace, hipStream_t st);
+// ... and the sparse-shift / quantized forward of 4- / 8-byte elements in the same shape (part of the sweep family)
+bool step_forward_eligible(const Geometry &g, int dtype, const void *x, const void *out);
+int step_forward(const Geometry &g, int dtype, const void *x, const void *w, int wkind, int64_t wzp, uint64_t fill_bits,
+                 void *out, hipStream_t st);
+void step_set_tuning(int knob, int value);
+
 // ---- 1-byte elements on small planes (shiftnd_bytes.hip): whole planes through LDS, 16-byte output pieces that cross
 // rows; part of the per-channel family (plane_forward routes to it)
 bool bytes_forward_eligible(const Geometry &g, int dtype, const void *x, const void *out);

@@ -25,6 +25,14 @@
 //   quantized kernels/shifts_kernels.h:532-571, quantized/shifts_quantized.cpp:107-130
 #include "shiftnd_common.hpp"
 #include "shiftnd_launch.hpp"
+#include "shiftnd_stage.hpp"
+
+#ifndef SHIFTND_DMA_AUX_X
+#define SHIFTND_DMA_AUX_X 0  // cache-policy bits of the LDS-DMA row loads (2 = nt); A/B builds override
+#endif
+#ifndef SHIFTND_DMA_AUX_G
+#define SHIFTND_DMA_AUX_G 0
+#endif
 
 namespace shiftnd {
 namespace {
@@ -49,6 +57,8 @@ struct PlaneParams {
     FastDiv d_xppr;
     int lds_affine;         // LDS-staged kernels: read affine chunks as consecutive dwords (tuning knob 5 = 1 turns it off)
     unsigned xcd_blocks;    // grid / 8 when the XCD-contiguous block remap is on (grid % 8 == 0), else 0
+    int band_fast;          // workgroup ids run band-fastest, then channel, then batch group (the batch walk, see backward_plan)
+    FastDiv d_bands;
     FastDiv d_cpr;
     FastDiv d_rows;     // divide by rows_per_band
     FastDiv d_dim1;     // divide by the second outer dim of the iteration space
@@ -68,10 +78,18 @@ __device__ __forceinline__ WorkItem decode_block(const PlaneParams &p) {
     WorkItem wi;
     // XCD-contiguous ids (tuning knob 6): workgroups that share an XCD (blockIdx % 8) own adjacent planes
     const int bid = p.xcd_blocks ? static_cast<int>((blockIdx.x & 7u) * p.xcd_blocks + (blockIdx.x >> 3)) : static_cast<int>(blockIdx.x);
-    const int rest = static_cast<int>(fdiv(static_cast<uint32_t>(bid), p.d_C));
-    wi.c = bid - rest * p.C;
-    const int band = static_cast<int>(fdiv(static_cast<uint32_t>(rest), p.d_groups));
-    const int grp = rest - band * p.groups;
+    int band, grp;
+    if (p.band_fast) {
+        const int rest = static_cast<int>(fdiv(static_cast<uint32_t>(bid), p.d_bands));
+        band = bid - rest * p.bands;
+        grp = static_cast<int>(fdiv(static_cast<uint32_t>(rest), p.d_C));
+        wi.c = rest - grp * p.C;
+    } else {
+        const int rest = static_cast<int>(fdiv(static_cast<uint32_t>(bid), p.d_C));
+        wi.c = bid - rest * p.C;
+        band = static_cast<int>(fdiv(static_cast<uint32_t>(rest), p.d_groups));
+        grp = rest - band * p.groups;
+    }
     wi.n0 = grp * p.ppw;
     wi.nn = min(p.ppw, p.N - wi.n0);
     wi.row0 = band * p.rows_per_band;
@@ -766,10 +784,10 @@ struct LdsStager {
                     char *dst_wave = tile + (k * kThreads + wave * 64) * 16;  // wave-uniform; hardware adds lane * 16
                     if (slot < NX)
                         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(reinterpret_cast<const char *>(xp) + off),
-                                                         (__attribute__((address_space(3))) void *)dst_wave, 16, 0, 0);
+                                                         (__attribute__((address_space(3))) void *)dst_wave, 16, 0, SHIFTND_DMA_AUX_X);
                     else
                         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(reinterpret_cast<const char *>(gp) + off),
-                                                         (__attribute__((address_space(3))) void *)dst_wave, 16, 0, 0);
+                                                         (__attribute__((address_space(3))) void *)dst_wave, 16, 0, SHIFTND_DMA_AUX_G);
                 }
             }
         }
@@ -896,79 +914,6 @@ struct LdsStager {
         }
     }
 };
-
-// Column state of a chunk for LDS reads.  `affine`: every valid column satisfies cm[e] == base + e (true for all
-// interior chunks and for the edge chunks of zeros padding): the E + 1 values are then read as consecutive
-// dwords from one base address (compile-time offsets -> ds_read2_b32) and masked, instead of E + 1 independent
-// element reads.
-template <int E> struct ColState {
-    int cm[E + 1];
-    int base;     // element index of column 0 when affine
-    bool affine;
-};
-template <int E> __device__ __forceinline__ ColState<E> make_colstate(const int *map, int j0, bool live, bool allow_affine) {
-    ColState<E> c;
-    c.base = 0;
-    bool found = false;  // (static indexing only: a runtime-indexed cm[] would live in scratch)
-#pragma unroll
-    for (int e = 0; e <= E; ++e) {
-        c.cm[e] = live ? map[j0 + e] : -1;
-        if (!found && c.cm[e] >= 0) {
-            c.base = c.cm[e] - e;
-            found = true;
-        }
-    }
-    c.affine = allow_affine;
-#pragma unroll
-    for (int e = 0; e <= E; ++e) c.affine = c.affine && (c.cm[e] < 0 || c.cm[e] == c.base + e);
-    return c;
-}
-
-// E + 1 raw elements of one staged row (masked columns -> 0).  `row` points at the row's first byte in LDS; a
-// 64-byte pad in front of the tile keeps the few bytes an edge chunk reads before column 0 inside the allocation.
-template <typename S, int E>
-__device__ __forceinline__ void lds_read_row(const char *row, bool valid, const ColState<E> &c, S (&raw)[E + 1]) {
-    S zero;
-    __builtin_memset(&zero, 0, sizeof(S));
-    if (!valid) {
-#pragma unroll
-        for (int e = 0; e <= E; ++e) raw[e] = zero;
-        return;
-    }
-    if (c.affine) {
-        if constexpr (sizeof(S) == 2) {
-            // 18 bytes starting at a 2-byte boundary: five dwords, then a funnel shift by 0 or 16 bits
-            const int byte0 = c.base * 2;
-            const uint32_t *dwp = reinterpret_cast<const uint32_t *>(row + (byte0 & ~3));
-            const uint32_t sh = (byte0 & 2) ? 16u : 0u;
-            uint32_t dw[6];
-#pragma unroll
-            for (int i = 0; i < 5; ++i) dw[i] = dwp[i];
-            dw[5] = 0;
-#pragma unroll
-            for (int i = 0; i < 5; ++i) {
-                const uint32_t t = __builtin_amdgcn_alignbit(dw[i + 1], dw[i], sh);  // v_alignbit_b32 (a 64-bit shift is quarter rate)
-                const uint16_t lo = static_cast<uint16_t>(t), hi = static_cast<uint16_t>(t >> 16);
-                if (2 * i <= E) __builtin_memcpy(&raw[2 * i], &lo, 2);
-                if (2 * i + 1 <= E) __builtin_memcpy(&raw[2 * i + 1], &hi, 2);
-            }
-        } else {
-            const S *p0 = reinterpret_cast<const S *>(row) + c.base;
-#pragma unroll
-            for (int e = 0; e <= E; ++e) raw[e] = p0[e];
-        }
-#pragma unroll
-        for (int e = 0; e <= E; ++e) raw[e] = c.cm[e] >= 0 ? raw[e] : zero;
-    } else {
-        // unconditional reads at a clamped column, then one select each: no per-element execution-mask juggling
-        const S *p0 = reinterpret_cast<const S *>(row);
-        S tmp[E + 1];
-#pragma unroll
-        for (int e = 0; e <= E; ++e) tmp[e] = p0[c.cm[e] > 0 ? c.cm[e] : 0];
-#pragma unroll
-        for (int e = 0; e <= E; ++e) raw[e] = c.cm[e] >= 0 ? tmp[e] : zero;
-    }
-}
 
 // corner values of one chunk from the staged rows: vals[k][e], k = outer corner combo (bit r <-> +1 along real
 // dim r < ND-1), e = 0..E (E + 1 columns through the column map)
@@ -1446,6 +1391,7 @@ struct Plan {
     int V, cpr, CW, RPS, CP, ppw, groups, bands, rows_per_band, rows;
     size_t lds;
     unsigned grid;
+    int band_fast = 0;
 };
 
 // rows/inner: iteration space of one plane; esize: element bytes; V: chunk bytes
@@ -1525,6 +1471,8 @@ void fill_params(PlaneParams &p, const Geometry &g, const Plan &pl, int64_t dim1
     // cheaper (C3 with reflect padding: backward 0.82 -> 0.75 ms, forward 0.31 -> 0.30 ms; 2-D: no difference)
     p.lds_affine = g_tune[5] != 1 && !(g.pad != 0 && g.nd == 3 && g_tune[5] != 2);
     p.xcd_blocks = (g_tune[6] && pl.grid % 8 == 0) ? pl.grid / 8 : 0;
+    p.band_fast = pl.band_fast;
+    p.d_bands = make_fastdiv(static_cast<uint32_t>(pl.bands > 0 ? pl.bands : 1));
     p.d_cpr = make_fastdiv(static_cast<uint32_t>(pl.cpr));
     p.d_dim1 = make_fastdiv(static_cast<uint32_t>(dim1));
     p.d_C = make_fastdiv(static_cast<uint32_t>(p.C));
@@ -1769,7 +1717,22 @@ int64_t backward_min_wgs(const Geometry &g, int esize) {
 
 Plan backward_plan(const Geometry &g, int esize) {
     const int entries = static_cast<int>(g.S[0] + g.S[1] + g.S[2] + g.O[0] + g.O[1] + g.O[2] + 6);
-    return make_plan(g, g.S[0] * g.S[1], g.S[2], esize, 16, entries, backward_min_wgs(g, esize));
+    Plan pl = make_plan(g, g.S[0] * g.S[1], g.S[2], esize, 16, entries, backward_min_wgs(g, esize));
+    if (g_tune[7] < 0 && g.nd <= 2) {  // EXPERIMENT: the batch walk -- a workgroup keeps one step of rows and walks the batch
+        int k = -g_tune[7];
+        const bool cfast = k >= 1000;
+        if (cfast) k -= 1000;
+        const int rpb = pl.RPS * (k >= 100 ? k / 100 : 1);  // hundreds digit: steps per band
+        k %= 100;
+        pl.groups = k < 1 ? 1 : (k > g.N ? static_cast<int>(g.N) : k);
+        pl.ppw = static_cast<int>((g.N + pl.groups - 1) / pl.groups);
+        pl.groups = static_cast<int>((g.N + pl.ppw - 1) / pl.ppw);
+        pl.rows_per_band = rpb;
+        pl.bands = (pl.rows + rpb - 1) / rpb;
+        pl.grid = static_cast<unsigned>(g.C * pl.groups * pl.bands);
+        pl.band_fast = cfast ? 0 : 1;
+    }
+    return pl;
 }
 
 }  // namespace
@@ -1881,7 +1844,9 @@ size_t plane_backward_workspace(const Geometry &g, int dtype) {
     const Plan pl = backward_plan(g, dtype_size(dtype));
     const size_t own = static_cast<size_t>(pl.groups) * pl.bands * static_cast<size_t>(g.C) * 3 * sizeof(double);
     const size_t slide = g.K[0] > 0 ? 0 : slide_backward_workspace(g, dtype);  // (the fused-pool calls never slide)
-    return own > slide ? own : slide;
+    const size_t step = g.K[0] > 0 ? 0 : step_backward_workspace(g, dtype);
+    const size_t m = own > slide ? own : slide;
+    return m > step ? m : step;
 }
 
 // ---- fused shift + average pool (contiguous tensors; g.K / g.P set) -----------------------------------------
@@ -1936,6 +1901,7 @@ int plane_pool_backward(const Geometry &g, int dtype, const void *go, const void
 
 int plane_backward(const Geometry &g, int dtype, const void *go, const void *x, const void *w, void *gx, void *gw,
                    void *workspace, hipStream_t st) {
+    if (step_backward_eligible(g, dtype, go, x, gx)) return step_backward(g, dtype, go, x, w, gx, gw, workspace, st);
     if (slide_backward_eligible(g, dtype, go, x, gx)) return slide_backward(g, dtype, go, x, w, gx, gw, workspace, st);
     const Plan pl = backward_plan(g, dtype_size(dtype));
     PlaneParams p{};

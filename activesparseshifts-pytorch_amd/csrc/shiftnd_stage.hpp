@@ -1,0 +1,84 @@
+// shiftnd_stage.hpp -- reading staged rows back from LDS: the column state of a 16-byte chunk and the E + 1 mapped
+// elements of one staged row.  Shared by the LDS-staged kernel families (shiftnd_plane.hip, shiftnd_step.hip).
+#pragma once
+
+#include "shiftnd_common.hpp"
+
+namespace shiftnd {
+namespace {
+
+// Column state of a chunk for LDS reads.  `affine`: every valid column satisfies cm[e] == base + e (true for all
+// interior chunks and for the edge chunks of zeros padding): the E + 1 values are then read as consecutive
+// dwords from one base address (compile-time offsets -> ds_read2_b32) and masked, instead of E + 1 independent
+// element reads.
+template <int E> struct ColState {
+    int cm[E + 1];
+    int base;     // element index of column 0 when affine
+    bool affine;
+};
+template <int E> __device__ __forceinline__ ColState<E> make_colstate(const int *map, int j0, bool live, bool allow_affine) {
+    ColState<E> c;
+    c.base = 0;
+    bool found = false;  // (static indexing only: a runtime-indexed cm[] would live in scratch)
+#pragma unroll
+    for (int e = 0; e <= E; ++e) {
+        c.cm[e] = live ? map[j0 + e] : -1;
+        if (!found && c.cm[e] >= 0) {
+            c.base = c.cm[e] - e;
+            found = true;
+        }
+    }
+    c.affine = allow_affine;
+#pragma unroll
+    for (int e = 0; e <= E; ++e) c.affine = c.affine && (c.cm[e] < 0 || c.cm[e] == c.base + e);
+    return c;
+}
+
+// E + 1 raw elements of one staged row (masked columns -> 0).  `row` points at the row's first byte in LDS; a
+// 64-byte pad in front of the tile keeps the few bytes an edge chunk reads before column 0 inside the allocation.
+template <typename S, int E>
+__device__ __forceinline__ void lds_read_row(const char *row, bool valid, const ColState<E> &c, S (&raw)[E + 1]) {
+    S zero;
+    __builtin_memset(&zero, 0, sizeof(S));
+    if (!valid) {
+#pragma unroll
+        for (int e = 0; e <= E; ++e) raw[e] = zero;
+        return;
+    }
+    if (c.affine) {
+        if constexpr (sizeof(S) == 2) {
+            // 18 bytes starting at a 2-byte boundary: five dwords, then a funnel shift by 0 or 16 bits
+            const int byte0 = c.base * 2;
+            const uint32_t *dwp = reinterpret_cast<const uint32_t *>(row + (byte0 & ~3));
+            const uint32_t sh = (byte0 & 2) ? 16u : 0u;
+            uint32_t dw[6];
+#pragma unroll
+            for (int i = 0; i < 5; ++i) dw[i] = dwp[i];
+            dw[5] = 0;
+#pragma unroll
+            for (int i = 0; i < 5; ++i) {
+                const uint32_t t = __builtin_amdgcn_alignbit(dw[i + 1], dw[i], sh);  // v_alignbit_b32 (a 64-bit shift is quarter rate)
+                const uint16_t lo = static_cast<uint16_t>(t), hi = static_cast<uint16_t>(t >> 16);
+                if (2 * i <= E) __builtin_memcpy(&raw[2 * i], &lo, 2);
+                if (2 * i + 1 <= E) __builtin_memcpy(&raw[2 * i + 1], &hi, 2);
+            }
+        } else {
+            const S *p0 = reinterpret_cast<const S *>(row) + c.base;
+#pragma unroll
+            for (int e = 0; e <= E; ++e) raw[e] = p0[e];
+        }
+#pragma unroll
+        for (int e = 0; e <= E; ++e) raw[e] = c.cm[e] >= 0 ? raw[e] : zero;
+    } else {
+        // unconditional reads at a clamped column, then one select each: no per-element execution-mask juggling
+        const S *p0 = reinterpret_cast<const S *>(row);
+        S tmp[E + 1];
+#pragma unroll
+        for (int e = 0; e <= E; ++e) tmp[e] = p0[c.cm[e] > 0 ? c.cm[e] : 0];
+#pragma unroll
+        for (int e = 0; e <= E; ++e) raw[e] = c.cm[e] >= 0 ? tmp[e] : zero;
+    }
+}
+
+}  // namespace
+}  // namespace shiftnd

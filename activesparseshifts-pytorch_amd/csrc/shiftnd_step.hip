@@ -1,0 +1,672 @@
+// shiftnd_step.hip -- one-step workgroups: the backward pass of contiguous 2-D problems as a linear sweep.
+//
+// What the memory system of the MI355X rewards (tools/stream_probe --mock): many SHORT workgroups
+// that are dispatched in address order, each moving a few KB and exiting -- a plain 2-read-1-write stream staged
+// through LDS reaches 6.5 TB/s in that shape, against 5.4 TB/s when a workgroup walks a 50 KB band of its own (the shape
+// of plane_backward_lds) and 5.2 TB/s for a whole plane per workgroup: the fewer independent sweep fronts the DRAM
+// sees, the better (8 fronts, one per XCD, are as good as one).  So here a workgroup owns ONE step -- R = 256 / (chunks
+// per row) consecutive rows of one (n, c) plane -- and the grid is every step of the tensor in memory order, the
+// workgroups of an XCD (blockIdx % 8) owning a contiguous eighth of it.
+//
+// A workgroup that lives for one step cannot build per-channel index maps in LDS, nor amortise a long scalar prologue
+// (the sweep kernels' per-wave prologue costs them 35 % at one row group per workgroup).  Everything per-channel is
+// therefore prepared ONCE by a small kernel launched in front (step_prep: one workgroup per channel) and read back
+// with one scalar load (ChanDesc: canonical row shifts, scatter shift, fractions) and one 16- / 32-byte vector load per
+// map (the column state of the thread's chunk: E + 1 source columns, affine flag) -- both issued before the row
+// staging and consumed after it.  Row sources are folded arithmetically per staged piece (fold_index: <= 5 VALU).
+//
+// Per step: LDS-DMA (global_load_lds_dwordx4, nontemporal: every byte is read by one or two neighbouring workgroups)
+// of the R + 1 corner rows of x and the R rows of grad_out (interpolating: + the R + 1 rows grad_x interpolates
+// between), one barrier, the same arithmetic as plane_backward_lds (shiftnd_common.hpp: corner_diffs / interp_t), one
+// nontemporal 16-byte store per thread.  The sparse shift runs in scatter form (a staged grad_out row IS a grad_x
+// row; the |shift| rows at one end of a plane that no row maps to are produced by the workgroup that owns their
+// position, from memory).  Weight gradient: per-thread sums of g * corner difference in the compute type, a fixed
+// DPP tree per wave, the four wave sums added in fp64 -> partials[step][NDIFF]; step_reduce adds the steps of a channel
+// in a fixed order and applies the per-channel blends (blend_diffs) once.  Deterministic, no atomics.
+//
+// Reference behaviour restated: kernels/shifts_kernels.h:222-327 (backward), :132-154 (weight gradients),
+// cuda/shifts_cuda.cu:168-199, :270-345 (weight preparation, launch).
+#include "shiftnd_common.hpp"
+#include "shiftnd_launch.hpp"
+#include "shiftnd_stage.hpp"
+
+namespace shiftnd {
+namespace {
+
+// knobs (shiftnd_set_tuning 32..): [0] backward, [1] gather forward: 0 = automatic, 1 = never, 2 = whenever eligible
+thread_local int g_step_tune[4] = {0, 0, 0, 0};
+
+struct ChanDesc {  // per channel, written by step_prep
+    int cx1;       // x row map:      m1[p] = fold_index(p - cx1, S1, pad)
+    int cg1;       // grad row map:   g1[p] = fold_index(p - cg1, S1, pad)
+    int scat;      // sparse shift: the row shift clamped to [-S1, S1] (0 when S1 == 1)
+    int cx2, cg2;  // the column maps' canonical shifts (zeros padding: the column state is two compares, no table)
+    int pad_[3];
+    double dw[2];  // fractions (dH, dW) of prep_shift_backward, exactly as the compute type holds them
+};
+
+struct StepParams {
+    const void *x;      // saved input
+    const void *go;     // incoming gradient
+    void *out;          // grad_x
+    const void *w;
+    double *partials;   // [total_steps][NDIFF]
+    ChanDesc *desc;     // [C]
+    int16_t *colx;      // [C][cpr][REC] column state of every chunk through the x column map
+    int16_t *colg;      // ... through the grad column map
+    int64_t x_plane;    // elements per (n, c) plane
+    int wkind, N, C, pad;
+    int S1, S2;         // rows per plane, elements per row
+    int cpr, R, spp;    // 16-byte chunks per row, rows per step, steps per plane
+    uint32_t total_steps, steps_per_xcd;
+    FastDiv d_spp, d_C, d_cpr, d_per1, d_per2;
+};
+
+template <int E> struct RecSize { static constexpr int N = (E + 3 <= 8) ? 8 : 16; };  // int16 entries per record
+
+__device__ __forceinline__ int row_map(int p, int cs, int len, int pad) { return len == 1 ? 0 : fold_index(p - cs, len, pad); }
+
+// ---------------------------------------------------------------------------------------------------------------------
+// step_prep: one workgroup per channel -- the weight preparation of the reference (shifts_cuda.cu:168-199) plus the
+// channel's column maps in the form the step kernels read them
+// ---------------------------------------------------------------------------------------------------------------------
+template <typename T, bool ACTIVE>
+__global__ __launch_bounds__(kThreads) void step_prep(const StepParams p) {
+    using S = typename T::S;
+    using CT = typename T::C;
+    constexpr int E = 16 / sizeof(S);
+    constexpr int REC = RecSize<E>::N;
+    const int c = blockIdx.x;
+    const CT wr = load_weight<CT>(p.w, p.wkind, static_cast<int64_t>(c) * 2 + 0);
+    const CT wc = load_weight<CT>(p.w, p.wkind, static_cast<int64_t>(c) * 2 + 1);
+    int64_t sr, sc;
+    CT dr, dc;
+    prep_shift_backward<CT>(wr, ACTIVE, sr, dr);
+    prep_shift_backward<CT>(wc, ACTIVE, sc, dc);
+    // build_maps: x map with sign -1 -> canon_shift(sh); grad map with sign +1 (sparse) -> canon_shift(-sh), -1 (active)
+    const int cx1 = canon_shift(sr, p.S1, p.pad, p.d_per1), cx2 = canon_shift(sc, p.S2, p.pad, p.d_per2);
+    const int cg1 = canon_shift(ACTIVE ? sr : -sr, p.S1, p.pad, p.d_per1), cg2 = canon_shift(ACTIVE ? sc : -sc, p.S2, p.pad, p.d_per2);
+    if (threadIdx.x == 0) {
+        ChanDesc d;
+        d.cx1 = cx1;
+        d.cg1 = cg1;
+        d.scat = p.S1 == 1 ? 0 : static_cast<int>(sr > p.S1 ? p.S1 : (sr < -p.S1 ? -p.S1 : sr));
+        d.cx2 = cx2;
+        d.cg2 = cg2;
+        d.pad_[0] = d.pad_[1] = d.pad_[2] = 0;
+        d.dw[0] = static_cast<double>(dr);
+        d.dw[1] = static_cast<double>(dc);
+        p.desc[c] = d;
+    }
+    for (int j = threadIdx.x; j < p.cpr; j += kThreads) {
+#pragma unroll
+        for (int which = 0; which < 2; ++which) {
+            const int cs = which ? cg2 : cx2;
+            int cm[E + 1];
+            int base = 0;
+            bool found = false, affine = true;
+#pragma unroll
+            for (int e = 0; e <= E; ++e) {
+                cm[e] = row_map(j * E + e, cs, p.S2, p.pad);
+                if (!found && cm[e] >= 0) {
+                    base = cm[e] - e;
+                    found = true;
+                }
+            }
+#pragma unroll
+            for (int e = 0; e <= E; ++e) affine = affine && (cm[e] < 0 || cm[e] == base + e);
+            int16_t *rec = (which ? p.colg : p.colx) + (static_cast<size_t>(c) * p.cpr + j) * REC;
+#pragma unroll
+            for (int e = 0; e <= E; ++e) rec[e] = static_cast<int16_t>(cm[e]);
+            rec[E + 1] = static_cast<int16_t>(base);
+            rec[E + 2] = affine ? 1 : 0;
+        }
+    }
+}
+
+template <int E> __device__ __forceinline__ ColState<E> load_colstate(const int16_t *rec) {
+    constexpr int REC = RecSize<E>::N;
+    int16_t r[REC];
+    const Chunk<int16_t, 8> a = load_chunk<int16_t, 8>(rec);
+    __builtin_memcpy(r, a.e, 16);
+    if constexpr (REC == 16) {
+        const Chunk<int16_t, 8> b = load_chunk<int16_t, 8>(rec + 8);
+        __builtin_memcpy(r + 8, b.e, 16);
+    }
+    ColState<E> c;
+#pragma unroll
+    for (int e = 0; e <= E; ++e) c.cm[e] = r[e];
+    c.base = r[E + 1];
+    c.affine = r[E + 2] != 0;
+    return c;
+}
+
+// fixed-order sum over the 64 lanes of a wave, result in lane 63.  fp32: six v_add_f32 with DPP operands (row shifts,
+// then the row broadcasts of GFX9); fp64: the shuffle tree (fp64 tensors are rare, the DPP form moves 32 bits)
+__device__ __forceinline__ float wave_total(float v) {
+#define SHIFTND_DPP_ADD(CTRL, ROWMASK) \
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, ROWMASK, 0xf, true))
+    SHIFTND_DPP_ADD(0x111, 0xf);  // row_shr:1
+    SHIFTND_DPP_ADD(0x112, 0xf);  // row_shr:2
+    SHIFTND_DPP_ADD(0x114, 0xf);  // row_shr:4
+    SHIFTND_DPP_ADD(0x118, 0xf);  // row_shr:8   -> lane 15 of every row holds its row's sum
+    SHIFTND_DPP_ADD(0x142, 0xa);  // row_bcast:15 -> rows 1 and 3 add the row below
+    SHIFTND_DPP_ADD(0x143, 0xc);  // row_bcast:31 -> rows 2 and 3 add lane 31
+#undef SHIFTND_DPP_ADD
+    return v;
+}
+__device__ __forceinline__ double wave_total(double v) {
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const double o = __shfl_up(v, off, 64);
+        v += (static_cast<int>(threadIdx.x & 63) >= off) ? o : 0.0;
+    }
+    return v;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// step_backward.  PAD is a template parameter: the row maps are folded per staged piece and per output row, and a
+// run-time padding switch there costs more scalar-unit time than a one-step workgroup has (one scalar unit per CU;
+// shiftnd_common.hpp fold_index is 2 - 5 VALU instructions once the mode is known).
+// ---------------------------------------------------------------------------------------------------------------------
+template <int PAD> __device__ __forceinline__ int row_map_t(int p, int cs, int len) { return len == 1 ? 0 : fold_index(p - cs, len, PAD); }
+
+// canon_shift (shiftnd_common.hpp) for |s| < 2^30 and a compile-time padding mode, all in 32 bits
+template <int PAD> __device__ __forceinline__ int canon_shift32(int s, int len, const FastDiv &dper) {
+    if (len <= 1) return 0;
+    if constexpr (PAD <= 1) {
+        return s < -len - 1 ? -len - 1 : (s > len + 1 ? len + 1 : s);
+    } else {
+        const int period = PAD == 2 ? len : (PAD == 3 ? 2 * (len - 1) : 2 * len);
+        const uint32_t a = static_cast<uint32_t>(s < 0 ? -s : s);
+        const uint32_t m = a - fdiv(a, dper) * static_cast<uint32_t>(period);
+        return static_cast<int>((s < 0 && m != 0) ? static_cast<uint32_t>(period) - m : m);
+    }
+}
+
+template <typename T, bool ACTIVE, int PAD>
+__global__ __launch_bounds__(kThreads) void step_backward(const StepParams p) {
+    using S = typename T::S;
+    using CT = typename T::C;
+    constexpr int E = 16 / sizeof(S);
+    constexpr int REC = RecSize<E>::N;
+    constexpr bool SCAT = !ACTIVE;
+    constexpr int NDIFF = 2;
+    constexpr int KP = ACTIVE ? 5 : 3;  // staged pieces per thread: (2R + 1) cpr <= 3 * 256, (3R + 2) cpr <= 5 * 256
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char *tile = smem + 64;  // 64-byte pad: see lds_read_row
+
+    const uint32_t bid = (blockIdx.x & 7u) * p.steps_per_xcd + (blockIdx.x >> 3);  // XCD-contiguous step ids
+    if (bid >= p.total_steps) return;
+    const uint32_t plane = fdiv(bid, p.d_spp);
+    const int step = static_cast<int>(bid - plane * static_cast<uint32_t>(p.spp));
+    const int c = static_cast<int>(plane - fdiv(plane, p.d_C) * static_cast<uint32_t>(p.C));
+    const ChanDesc d = p.desc[c];
+    const int R = p.R, S1 = p.S1, S2 = p.S2, cpr = p.cpr;
+    const int b0 = step * R;
+    const int Rn = min(R, S1 - b0);
+    const int NX = R + 1, NG = R;
+    const int npieces = (ACTIVE ? 3 * R + 2 : 2 * R + 1) * cpr;
+    const int RB = S2 * static_cast<int>(sizeof(S));
+    const S *xp = static_cast<const S *>(p.x) + static_cast<int64_t>(plane) * p.x_plane;
+    const S *gp = static_cast<const S *>(p.go) + static_cast<int64_t>(plane) * p.x_plane;
+    S *gxp = static_cast<S *>(p.out) + static_cast<int64_t>(plane) * p.x_plane;
+
+    // ---- the thread's chunk: column state through both maps (vector loads, consumed behind the barrier) -----------
+    const int tid = static_cast<int>(threadIdx.x);
+    const int tr = static_cast<int>(fdiv(static_cast<uint32_t>(tid), p.d_cpr)), tc = tid - tr * cpr;
+    const bool worker = tr < Rn;
+    const int ji = tc * E;
+    ColState<E> xm, gm;
+    if constexpr (PAD == 0) {  // zeros: column j0 + e reads column j0 + e - shift when that is a column
+        auto affine_state = [&](int cs) {
+            ColState<E> st;
+            st.base = ji - cs;
+            st.affine = true;
+#pragma unroll
+            for (int e = 0; e <= E; ++e) st.cm[e] = (st.base + e >= 0 && st.base + e < S2) ? st.base + e : -1;
+            return st;
+        };
+        xm = affine_state(d.cx2);
+        gm = affine_state(d.cg2);
+    } else {
+        const size_t rec = (static_cast<size_t>(c) * cpr + tc) * REC;
+        xm = load_colstate<E>(p.colx + rec);
+        gm = load_colstate<E>(p.colg + rec);
+    }
+
+    // ---- stage the rows: aligned 16-byte pieces, lanes of a wave take consecutive pieces; straight-line code ---------
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+#pragma unroll
+    for (int k = 0; k < KP; ++k) {
+        if (k * kThreads < npieces) {  // uniform
+            const int q = k * kThreads + tid;
+            const int slot = static_cast<int>(fdiv(static_cast<uint32_t>(q), p.d_cpr));
+            const int j = q - slot * cpr;
+            // group 0: corner rows of x, m1[b0 + r], r <= Rn; group 1: the incoming gradient at rows b0 + r, r < Rn;
+            // group 2 (interpolating): the rows grad_x blends, g1[b0 + r], r <= Rn.  In-range rows map to themselves in
+            // every padding mode, so group 1 is the same fold with shift 0.
+            const bool g0 = slot < NX, g2 = ACTIVE && slot >= NX + NG;
+            const int r = slot - (g0 ? 0 : (g2 ? NX + NG : NX));
+            const int cs = g0 ? d.cx1 : (g2 ? d.cg1 : 0);
+            int src = row_map_t<PAD>(b0 + r, cs, S1);
+            if (r > Rn - ((g0 || g2) ? 0 : 1) || q >= npieces) src = -1;
+            // uniform base + 32-bit lane offset (planes are < 2^30 elements): the SGPR-base address form, one
+            // instruction per array (a wave's 64 pieces are nearly always of one array)
+            const uint32_t off = static_cast<uint32_t>(src * S2 + j * E) * static_cast<uint32_t>(sizeof(S));
+            char *dst_wave = tile + (k * kThreads + wave * 64) * 16;  // wave-uniform; hardware adds lane * 16
+            if (src >= 0 && g0)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(reinterpret_cast<const char *>(xp) + off),
+                                                 (__attribute__((address_space(3))) void *)dst_wave, 16, 0, 2 /* nt */);
+            if (src >= 0 && !g0)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(reinterpret_cast<const char *>(gp) + off),
+                                                 (__attribute__((address_space(3))) void *)dst_wave, 16, 0, 2 /* nt */);
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    CT part[NDIFF] = {CT(0), CT(0)};
+    if (worker) {
+        const int b = b0 + tr;
+        CT dw[2] = {static_cast<CT>(d.dw[0]), static_cast<CT>(d.dw[1])};
+        Chunk<S, E> res;
+        // only zeros padding has rows without a source
+        auto row_valid = [&](int pr, int cs) { return PAD != 0 || row_map_t<PAD>(pr, cs, S1) >= 0; };
+        // ---- grad_x ----------------------------------------------------------------------------------------------
+        if constexpr (ACTIVE) {
+            CT gv[2][E + 1];
+#pragma unroll
+            for (int hb = 0; hb < 2; ++hb) {
+                S raw[E + 1];
+                lds_read_row<S, E>(tile + (NX + NG + tr + hb) * RB, row_valid(b + hb, d.cg1), gm, raw);
+#pragma unroll
+                for (int e = 0; e <= E; ++e) gv[hb][e] = widen<T>(raw[e]);
+            }
+#pragma unroll
+            for (int e = 0; e < E; ++e) {
+                const CT v[4] = {gv[0][e], gv[1][e], gv[0][e + 1], gv[1][e + 1]};
+                res.e[e] = narrow<T>(interp_t<T, 2>(v, dw));
+            }
+        } else {
+            // the staged grad_out row b, read through the column map, IS a grad_x row (which one: below)
+            S graw[E + 1];
+            lds_read_row<S, E>(tile + (NX + tr) * RB, true, gm, graw);
+#pragma unroll
+            for (int e = 0; e < E; ++e) res.e[e] = graw[e];
+        }
+        // ---- weight-gradient sums from the x corners and the incoming gradient --------------------------------------
+        CT xv[2][E + 1];
+#pragma unroll
+        for (int hb = 0; hb < 2; ++hb) {
+            S raw[E + 1];
+            lds_read_row<S, E>(tile + (tr + hb) * RB, row_valid(b + hb, d.cx1), xm, raw);
+#pragma unroll
+            for (int e = 0; e <= E; ++e) xv[hb][e] = widen<T>(raw[e]);
+        }
+        Chunk<S, E> gch;
+        __builtin_memcpy(gch.e, __builtin_assume_aligned(tile + (NX + tr) * RB + ji * static_cast<int>(sizeof(S)), 16), 16);
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+            const CT v[4] = {xv[0][e], xv[1][e], xv[0][e + 1], xv[1][e + 1]};
+            CT df[NDIFF];
+            corner_diffs<2, CT>(v, df);
+            const CT gval = widen<T>(gch.e[e]);
+#pragma unroll
+            for (int i = 0; i < NDIFF; ++i) part[i] = fma_ct(gval, df[i], part[i]);
+        }
+        // ---- store ---------------------------------------------------------------------------------------------------
+        if constexpr (SCAT) {
+            // periodic padding is a permutation (the x map is the inverse of the grad map); otherwise row b - shift when
+            // that is a row, and the rows no grad_out row reaches are the tail below
+            const int brow = PAD == 2 ? row_map_t<PAD>(b, d.cx1, S1) : b - d.scat;
+            if (brow >= 0 && brow < S1) store_chunk<S, E>(gxp + static_cast<int64_t>(brow) * S2 + ji, res);
+            if (PAD != 2 && d.scat != 0) {
+                const int e0 = d.scat > 0 ? max(S1 - d.scat, 0) : 0, e1 = d.scat > 0 ? S1 : min(-d.scat, S1);
+                if (b >= e0 && b < e1) {  // this row of grad_x has no source by the plain shift: fill, or a clamped / reflected row
+                    const int src = row_map_t<PAD>(b, d.cg1, S1);
+                    S zero;
+                    __builtin_memset(&zero, 0, sizeof(S));
+                    Chunk<S, E> t;
+                    bool gcontig = true;
+#pragma unroll
+                    for (int e = 0; e < E; ++e) gcontig = gcontig && gm.cm[e] >= 0 && gm.cm[e] == gm.cm[0] + e;
+                    if (src < 0) {
+#pragma unroll
+                        for (int e = 0; e < E; ++e) t.e[e] = zero;
+                    } else if (gcontig) {
+                        t = load_chunk<S, E>(gp + static_cast<int64_t>(src) * S2 + gm.cm[0]);
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < E; ++e) t.e[e] = gm.cm[e] >= 0 ? gp[static_cast<int64_t>(src) * S2 + gm.cm[e]] : zero;
+                    }
+                    store_chunk<S, E>(gxp + static_cast<int64_t>(b) * S2 + ji, t);
+                }
+            }
+        } else {
+            store_chunk<S, E>(gxp + static_cast<int64_t>(b) * S2 + ji, res);
+        }
+    }
+    // ---- this step's sums: DPP tree per wave, the four waves added in fp64 by one thread ----------------------------
+    double *scratch = reinterpret_cast<double *>(tile + ((npieces * 16 + 63) & ~63));
+    const CT t0 = wave_total(part[0]), t1 = wave_total(part[1]);
+    if ((tid & 63) == 63) {
+        scratch[2 * wave] = static_cast<double>(t0);
+        scratch[2 * wave + 1] = static_cast<double>(t1);
+    }
+    __syncthreads();
+    if (tid < NDIFF) {
+        double a = 0.0;
+#pragma unroll
+        for (int w = 0; w < kThreads / 64; ++w) a += scratch[2 * w + tid];
+        p.partials[static_cast<size_t>(bid) * NDIFF + tid] = a;
+    }
+}
+
+
+// ---------------------------------------------------------------------------------------------------------------------
+// step_gather_forward: the sparse-shift / quantized forward of 4- and 8-byte elements as the same linear sweep of
+// one-step workgroups (sweep_gather_forward with one row group per workgroup reaches 3.9 TB/s: its generic per-wave
+// prologue is what a short workgroup cannot afford).  No LDS, no barrier, no table: a thread loads its 16-byte chunk
+// at the shifted position (gfx950 global loads take any alignment) and stores it; the padding mode is a template
+// parameter, the channel's shifts come from one scalar load of its weights.
+// ---------------------------------------------------------------------------------------------------------------------
+struct GatherParams {  // 2-D problems: rows x inner, one weight per dim
+    const void *x;
+    void *out;
+    const void *w;
+    int64_t wzp;
+    uint64_t fill;
+    int64_t x_plane, o_plane;
+    int wkind, C;
+    int S1, S2, O1, O2, L1, L2;
+    int cpr, R, spp;
+    uint32_t total_steps, steps_per_xcd;
+    FastDiv d_spp, d_C, d_cpr, d_per1, d_per2;
+};
+
+template <int ESIZE, int PAD>
+__global__ __launch_bounds__(kThreads) void step_gather_forward(const GatherParams p) {
+    using R_t = typename raw_t<ESIZE>::type;
+    constexpr int E = 16 / ESIZE;
+    const uint32_t bid = (blockIdx.x & 7u) * p.steps_per_xcd + (blockIdx.x >> 3);
+    if (bid >= p.total_steps) return;
+    const uint32_t plane = fdiv(bid, p.d_spp);
+    const int step = static_cast<int>(bid - plane * static_cast<uint32_t>(p.spp));
+    const int c = static_cast<int>(plane - fdiv(plane, p.d_C) * static_cast<uint32_t>(p.C));
+    // the channel's two shifts: fp32 weights (every float module) through the scalar cache and 32-bit arithmetic;
+    // anything else -- other weight dtypes, |weight| >= 2^30 -- through the generic 64-bit path
+    int cs1 = 0, cs2 = 0;
+    bool fast = p.wkind == SHIFTND_F32;
+    if (fast) {
+        const __attribute__((address_space(4))) float *wc =
+            reinterpret_cast<const __attribute__((address_space(4))) float *>(reinterpret_cast<uintptr_t>(p.w)) + static_cast<int64_t>(c) * 2;
+        const float r1 = rintf(wc[0]), r2 = rintf(wc[1]);
+        fast = fabsf(r1) < 1073741824.f && fabsf(r2) < 1073741824.f;
+        cs1 = canon_shift32<PAD>(__builtin_amdgcn_readfirstlane(static_cast<int>(r1)), p.S1, p.d_per1);
+        cs2 = canon_shift32<PAD>(__builtin_amdgcn_readfirstlane(static_cast<int>(r2)), p.S2, p.d_per2);
+    }
+    if (!fast) {
+        const int wcol[3] = {-1, 0, 1};
+        int64_t sh[3];
+        gather_shifts3(p.w, p.wkind, p.wzp, static_cast<int64_t>(c) * 2, wcol, sh);
+        cs1 = canon_shift(sh[1], p.S1, PAD, p.d_per1);
+        cs2 = canon_shift(sh[2], p.S2, PAD, p.d_per2);
+    }
+    const int tid = static_cast<int>(threadIdx.x);
+    const int tr = static_cast<int>(fdiv(static_cast<uint32_t>(tid), p.d_cpr)), tc = tid - tr * p.cpr;
+    const int r = step * p.R + tr;
+    if (tr >= p.R || r >= p.O1) return;
+    const int jo = tc * E;
+    const int rb = row_map_t<PAD>(r + p.L1, cs1, p.S1);
+    int mm[E];
+    bool contig = true;
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        mm[e] = row_map_t<PAD>(jo + p.L2 + e, cs2, p.S2);
+        contig = contig && (mm[e] == mm[0] + e);
+    }
+    contig = contig && mm[0] >= 0;
+    const R_t fill = static_cast<R_t>(p.fill);
+    const R_t *xp = static_cast<const R_t *>(p.x) + static_cast<int64_t>(plane) * p.x_plane;
+    R_t *dst = static_cast<R_t *>(p.out) + static_cast<int64_t>(plane) * p.o_plane + r * p.O2 + jo;
+    Chunk<R_t, E> v;
+    if (rb < 0) {
+#pragma unroll
+        for (int e = 0; e < E; ++e) v.e[e] = fill;
+    } else {
+        const R_t *row = xp + rb * p.S2;
+        if (contig) {
+            v = load_chunk<R_t, E, true>(row + mm[0]);
+        } else {
+#pragma unroll
+            for (int e = 0; e < E; ++e) v.e[e] = mm[e] >= 0 ? __builtin_nontemporal_load(row + mm[e]) : fill;
+        }
+    }
+    store_chunk<R_t, E>(dst, v);
+}
+
+// grad_w[c][0..1] = blend(sum over the steps of channel c, in a fixed order)
+template <typename T>
+__global__ __launch_bounds__(kThreads) void step_reduce(const StepParams p, typename T::S *__restrict__ grad_w) {
+    __shared__ double scratch[kThreads / 64];
+    const int c = blockIdx.x;
+    const uint32_t per_channel = static_cast<uint32_t>(p.N) * static_cast<uint32_t>(p.spp);
+    double a0 = 0.0, a1 = 0.0;
+    for (uint32_t i = threadIdx.x; i < per_channel; i += kThreads) {
+        const uint32_t n = fdiv(i, p.d_spp);
+        const uint32_t st = i - n * static_cast<uint32_t>(p.spp);
+        const double *q = p.partials + ((static_cast<size_t>(n) * p.C + c) * p.spp + st) * 2;
+        a0 += q[0];
+        a1 += q[1];
+    }
+    a0 = block_sum(a0, scratch);
+    a1 = block_sum(a1, scratch);
+    if (threadIdx.x == 0) {
+        const double dsum[2] = {a0, a1};
+        const double dwd[3] = {p.desc[c].dw[0], p.desc[c].dw[1], 0.0};
+        double acc[3] = {0.0, 0.0, 0.0};
+        blend_diffs<2>(dsum, dwd, acc);
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            if constexpr (sizeof(typename T::S) == 8) grad_w[c * 2 + s] = acc[s];
+            else grad_w[c * 2 + s] = narrow<T>(static_cast<float>(acc[s]));
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------------------------------------
+bool dense(const int64_t st[5], int64_t N, int64_t C, const int64_t sz[3]) {
+    int64_t expect = 1;
+    const int64_t sizes[5] = {N, C, sz[0], sz[1], sz[2]};
+    for (int d = 4; d >= 0; --d) {
+        if (sizes[d] != 1 && st[d] != expect) return false;
+        expect *= sizes[d];
+    }
+    return true;
+}
+
+struct StepLayout {
+    int cpr, R, spp, rec;
+    uint64_t total_steps;
+    size_t off_desc, off_colx, off_colg, bytes;
+};
+
+StepLayout step_layout(const Geometry &g, int es) {
+    StepLayout L{};
+    const int E = 16 / es;
+    L.cpr = static_cast<int>(g.S[2] * es / 16);
+    if (L.cpr < 1) L.cpr = 1;
+    L.R = kThreads / L.cpr < 1 ? 1 : kThreads / L.cpr;
+    if (L.R > g.S[1]) L.R = static_cast<int>(g.S[1] > 0 ? g.S[1] : 1);
+    L.spp = static_cast<int>((g.S[1] + L.R - 1) / L.R);
+    L.rec = (E + 3 <= 8) ? 8 : 16;
+    L.total_steps = static_cast<uint64_t>(g.N) * g.C * L.spp;
+    auto up = [](size_t v) { return (v + 255) & ~static_cast<size_t>(255); };
+    L.off_desc = up(L.total_steps * 2 * sizeof(double));
+    L.off_colx = L.off_desc + up(static_cast<size_t>(g.C) * sizeof(ChanDesc));
+    L.off_colg = L.off_colx + up(static_cast<size_t>(g.C) * L.cpr * L.rec * sizeof(int16_t));
+    L.bytes = L.off_colg + up(static_cast<size_t>(g.C) * L.cpr * L.rec * sizeof(int16_t));
+    return L;
+}
+
+template <typename T>
+int launch_step_backward(StepParams &p, const StepLayout &L, bool active, void *gw, hipStream_t st) {
+    using S = typename T::S;
+    const int slots = active ? 3 * L.R + 2 : 2 * L.R + 1;
+    const size_t lds = 64 + ((static_cast<size_t>(slots) * L.cpr * 16 + 63) & ~static_cast<size_t>(63)) + (kThreads / 64) * 2 * sizeof(double);
+    const dim3 grid(p.steps_per_xcd * 8), block(kThreads);
+#define SHIFTND_STEP_PAD(ACT, PADV) \
+    case PADV: hipLaunchKernelGGL((step_backward<T, ACT, PADV>), grid, block, lds, st, p); break;
+    if (active) {
+        hipLaunchKernelGGL((step_prep<T, true>), dim3(p.C), block, 0, st, p);
+        switch (p.pad) { SHIFTND_STEP_PAD(true, 0) SHIFTND_STEP_PAD(true, 1) SHIFTND_STEP_PAD(true, 2) SHIFTND_STEP_PAD(true, 3) default: SHIFTND_STEP_PAD(true, 4) }
+    } else {
+        hipLaunchKernelGGL((step_prep<T, false>), dim3(p.C), block, 0, st, p);
+        switch (p.pad) { SHIFTND_STEP_PAD(false, 0) SHIFTND_STEP_PAD(false, 1) SHIFTND_STEP_PAD(false, 2) SHIFTND_STEP_PAD(false, 3) default: SHIFTND_STEP_PAD(false, 4) }
+    }
+#undef SHIFTND_STEP_PAD
+    hipLaunchKernelGGL((step_reduce<T>), dim3(p.C), block, 0, st, p, static_cast<S *>(gw));
+    return SHIFTND_OK;
+}
+
+}  // namespace
+
+void step_set_tuning(int knob, int value) {
+    if (knob >= 0 && knob < 4) g_step_tune[knob] = value;
+}
+
+// contiguous 2-D problems without crop whose rows are whole 16-byte pieces and at most one workgroup pass wide
+bool step_backward_eligible(const Geometry &g, int dtype, const void *go, const void *x, const void *gx) {
+    if (g_step_tune[0] == 1) return false;
+    if (dtype > SHIFTND_BF16 || g.nd != 2 || g.K[0] > 0) return false;
+    const int es = dtype_size(dtype);
+    for (int d = 0; d < 3; ++d)
+        if (g.O[d] != g.S[d] || g.L[d] != 0) return false;
+    if (g.S[0] != 1 || g.S[1] < 1 || g.S[2] < 1) return false;
+    if ((g.S[2] * es) % 16 != 0 || g.S[2] * es / 16 > kThreads || g.S[2] > 32000) return false;
+    if (g.S[1] * g.S[2] >= (1LL << 30)) return false;
+    if (!dense(g.xs, g.N, g.C, g.S) || !dense(g.os, g.N, g.C, g.O) || !dense(g.gs, g.N, g.C, g.S)) return false;
+    if (reinterpret_cast<uintptr_t>(go) % 16 || reinterpret_cast<uintptr_t>(x) % 16 || reinterpret_cast<uintptr_t>(gx) % 16) return false;
+    const StepLayout L = step_layout(g, es);
+    if (L.total_steps + 8 >= (1ull << 31)) return false;
+    if (g_step_tune[0] == 2) return true;
+    return true;
+}
+
+
+// sparse-shift / quantized forward of 4- and 8-byte elements: dense tensors, output rows of whole 16-byte chunks and at
+// most one workgroup pass wide (crops are fine: a gather)
+bool step_forward_eligible(const Geometry &g, int dtype, const void *x, const void *out) {
+    (void)x;
+    if (g_step_tune[1] == 1) return false;
+    const int es = dtype_size(dtype);
+    if (es != 4 && es != 8) return false;
+    if (g.active && dtype <= SHIFTND_BF16) return false;
+    if (g.nd != 2 || g.S[0] != 1 || g.O[0] != 1) return false;
+    const int64_t xe = g.S[1] * g.S[2], oe = g.O[1] * g.O[2];
+    if (xe < 1 || oe < 1 || xe >= (1LL << 30) || oe >= (1LL << 30)) return false;
+    if ((g.O[2] * es) % 16 != 0 || g.O[2] * es / 16 > kThreads || reinterpret_cast<uintptr_t>(out) % 16 != 0) return false;
+    if (!dense(g.xs, g.N, g.C, g.S) || !dense(g.os, g.N, g.C, g.O)) return false;
+    const int cpr = static_cast<int>(g.O[2] * es / 16);
+    const int64_t R = kThreads / cpr;
+    const int64_t spp = (g.O[1] + R - 1) / R;
+    if (g.N * g.C * spp + 8 >= (1LL << 31)) return false;
+    if (g_step_tune[1] == 2) return true;
+    return oe * es >= 32 * 1024;  // as the sweep kernels: small planes go to the per-channel walk
+}
+
+int step_forward(const Geometry &g, int dtype, const void *x, const void *w, int wkind, int64_t wzp, uint64_t fill_bits,
+                 void *out, hipStream_t st) {
+    const int es = dtype_size(dtype);
+    GatherParams p{};
+    p.x = x;
+    p.out = out;
+    p.w = w;
+    p.wzp = wzp;
+    p.fill = fill_bits;
+    p.wkind = wkind;
+    p.C = static_cast<int>(g.C);
+    p.S1 = static_cast<int>(g.S[1]);
+    p.S2 = static_cast<int>(g.S[2]);
+    p.O1 = static_cast<int>(g.O[1]);
+    p.O2 = static_cast<int>(g.O[2]);
+    p.L1 = static_cast<int>(g.L[1]);
+    p.L2 = static_cast<int>(g.L[2]);
+    p.x_plane = g.S[1] * g.S[2];
+    p.o_plane = g.O[1] * g.O[2];
+    p.cpr = static_cast<int>(g.O[2] * es / 16);
+    p.R = kThreads / p.cpr;
+    if (p.R > p.O1) p.R = p.O1;
+    p.spp = (p.O1 + p.R - 1) / p.R;
+    const uint64_t total = static_cast<uint64_t>(g.N) * g.C * p.spp;
+    p.total_steps = static_cast<uint32_t>(total);
+    p.steps_per_xcd = static_cast<uint32_t>((total + 7) / 8);
+    p.d_spp = make_fastdiv(static_cast<uint32_t>(p.spp));
+    p.d_C = make_fastdiv(static_cast<uint32_t>(p.C));
+    p.d_cpr = make_fastdiv(static_cast<uint32_t>(p.cpr));
+    p.d_per1 = make_fastdiv(static_cast<uint32_t>(map_period(p.S1, g.pad)));
+    p.d_per2 = make_fastdiv(static_cast<uint32_t>(map_period(p.S2, g.pad)));
+    note_kernel("step_gather_forward");
+    const dim3 grid(p.steps_per_xcd * 8), block(kThreads);
+#define SHIFTND_STEP_FWD(ES) \
+    switch (g.pad) { \
+    case 0: hipLaunchKernelGGL((step_gather_forward<ES, 0>), grid, block, 0, st, p); break; \
+    case 1: hipLaunchKernelGGL((step_gather_forward<ES, 1>), grid, block, 0, st, p); break; \
+    case 2: hipLaunchKernelGGL((step_gather_forward<ES, 2>), grid, block, 0, st, p); break; \
+    case 3: hipLaunchKernelGGL((step_gather_forward<ES, 3>), grid, block, 0, st, p); break; \
+    default: hipLaunchKernelGGL((step_gather_forward<ES, 4>), grid, block, 0, st, p); break; \
+    }
+    if (es == 4) { SHIFTND_STEP_FWD(4) } else { SHIFTND_STEP_FWD(8) }
+#undef SHIFTND_STEP_FWD
+    return SHIFTND_OK;
+}
+
+size_t step_backward_workspace(const Geometry &g, int dtype) {
+    if (dtype > SHIFTND_BF16 || g.nd != 2) return 0;
+    return step_layout(g, dtype_size(dtype)).bytes;
+}
+
+int step_backward(const Geometry &g, int dtype, const void *go, const void *x, const void *w, void *gx, void *gw,
+                  void *workspace, hipStream_t st) {
+    const int es = dtype_size(dtype);
+    const StepLayout L = step_layout(g, es);
+    StepParams p{};
+    p.x = x;
+    p.go = go;
+    p.out = gx;
+    p.w = w;
+    char *ws = static_cast<char *>(workspace);
+    p.partials = reinterpret_cast<double *>(ws);
+    p.desc = reinterpret_cast<ChanDesc *>(ws + L.off_desc);
+    p.colx = reinterpret_cast<int16_t *>(ws + L.off_colx);
+    p.colg = reinterpret_cast<int16_t *>(ws + L.off_colg);
+    p.x_plane = g.S[1] * g.S[2];
+    p.wkind = dtype;
+    p.N = static_cast<int>(g.N);
+    p.C = static_cast<int>(g.C);
+    p.pad = g.pad;
+    p.S1 = static_cast<int>(g.S[1]);
+    p.S2 = static_cast<int>(g.S[2]);
+    p.cpr = L.cpr;
+    p.R = L.R;
+    p.spp = L.spp;
+    p.total_steps = static_cast<uint32_t>(L.total_steps);
+    p.steps_per_xcd = static_cast<uint32_t>((L.total_steps + 7) / 8);
+    p.d_spp = make_fastdiv(static_cast<uint32_t>(L.spp));
+    p.d_C = make_fastdiv(static_cast<uint32_t>(p.C));
+    p.d_cpr = make_fastdiv(static_cast<uint32_t>(L.cpr));
+    p.d_per1 = make_fastdiv(static_cast<uint32_t>(map_period(p.S1, g.pad)));
+    p.d_per2 = make_fastdiv(static_cast<uint32_t>(map_period(p.S2, g.pad)));
+    note_kernel("step_backward");
+    switch (dtype) {
+    case SHIFTND_F32: return launch_step_backward<f32_t>(p, L, g.active != 0, gw, st);
+    case SHIFTND_F64: return launch_step_backward<f64_t>(p, L, g.active != 0, gw, st);
+    case SHIFTND_F16: return launch_step_backward<f16_t>(p, L, g.active != 0, gw, st);
+    default: return launch_step_backward<bf16_t>(p, L, g.active != 0, gw, st);
+    }
+}
+
+}  // namespace shiftnd

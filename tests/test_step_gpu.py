@@ -1,0 +1,172 @@
+"""GPU parity of the one-step kernels (csrc/shiftnd_step.hip: the backward pass of contiguous 2-D problems as a linear
+sweep of one-step workgroups) against the CPU oracle, through the C ABI.
+
+Bars as everywhere: fp32 / fp64 grad_x bit-exact, grad_w <= 1e-5 relative to the fp64 oracle
+(bit-exact on the dyadic golden fixture); 16-bit: the sparse shift bit-exact, interpolation within 1 ulp of the 16-bit
+type, grad_w within the 16-bit epsilon.  Shapes cover one step per plane, ragged last steps, one-row planes, rows of one
+chunk and of 256 chunks, shifts beyond the dim (the special rows of `_weights`)."""
+import numpy as np
+import pytest
+import torch
+
+from cases import rel_err
+from oracle import oracle as O
+from test_hip_parity import _ulp_close, _weights
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+@pytest.fixture()
+def abi():
+    from torchshifts import abi as A
+    assert torch.cuda.is_available()
+    A.set_path_policy(0)
+    A.set_tuning(32, 2)  # whenever eligible
+    A.set_tuning(33, 2)
+    yield A
+    A.set_tuning(32, 0)
+    A.set_tuning(33, 0)
+
+
+SHAPES = [(3, 5, 9, 24), (2, 3, 40, 224), (5, 2, 33, 64), (1, 2, 300, 8), (2, 3, 1, 16), (7, 2, 6, 56), (1, 2, 7, 1000),
+          (2, 1, 5, 1024), (2, 4, 224, 224), (1, 3, 17, 4), (2, 2, 64, 12), (3, 2, 2, 512)]
+
+
+@pytest.mark.parametrize("shape", SHAPES)
+def test_fp32_vs_oracle(abi, shape):
+    rs = np.random.RandomState(sum(shape) * 13 + 1)
+    x = rs.uniform(-1, 1, size=shape).astype(np.float32)
+    go = rs.uniform(-1, 1, size=shape).astype(np.float32)
+    w = _weights(rs, shape[1], 2, shape[2:]).astype(np.float32)
+    xd, wd, god = (torch.from_numpy(a).to(DEV) for a in (x, w, go))
+    for pad in range(5):
+        for active in (0, 1):
+            gx, gw = abi.backward(god, wd, xd, pad, active)
+            assert abi.last_kernel() == "step_backward", (shape, abi.last_kernel())
+            gx_o, _ = O.backward(go, w, x, pad, active)
+            assert np.array_equal(gx.cpu().numpy(), gx_o), ("gx", shape, pad, active)
+            _, gw64 = O.backward(go.astype(np.float64), w.astype(np.float64), x.astype(np.float64), pad, active)
+            assert rel_err(gw.cpu().numpy(), gw64) < 1e-5, ("gw", shape, pad, active)
+            gx2, gw2 = abi.backward(god, wd, xd, pad, active)
+            assert torch.equal(gx, gx2) and torch.equal(gw, gw2)  # deterministic
+
+
+@pytest.mark.parametrize("shape", [(3, 5, 9, 24), (2, 3, 40, 224), (1, 2, 300, 8), (2, 3, 1, 16), (2, 1, 5, 512), (1, 2, 33, 2)])
+def test_fp64_vs_oracle(abi, shape):
+    rs = np.random.RandomState(sum(shape) * 7 + 3)
+    x = rs.uniform(-1, 1, size=shape)
+    go = rs.uniform(-1, 1, size=shape)
+    w = _weights(rs, shape[1], 2, shape[2:]).astype(np.float64)
+    xd, wd, god = (torch.from_numpy(a).to(DEV) for a in (x, w, go))
+    for pad in range(5):
+        for active in (0, 1):
+            gx, gw = abi.backward(god, wd, xd, pad, active)
+            assert abi.last_kernel() == "step_backward", (shape, abi.last_kernel())
+            gx_o, gw_o = O.backward(go, w, x, pad, active)
+            assert np.array_equal(gx.cpu().numpy(), gx_o), ("gx", shape, pad, active)
+            assert rel_err(gw.cpu().numpy(), gw_o) < 1e-12, ("gw", shape, pad, active)
+
+
+@pytest.mark.parametrize("tdt", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("shape", [(3, 5, 9, 24), (2, 3, 40, 224), (5, 2, 33, 64), (1, 2, 300, 8), (2, 2, 1, 16), (2, 1, 5, 2048)])
+def test_16bit_vs_oracle(abi, shape, tdt):
+    rs = np.random.RandomState(sum(shape) + 11)
+    x16 = torch.from_numpy(rs.uniform(-1, 1, size=shape).astype(np.float32)).to(tdt)
+    go16 = torch.from_numpy(rs.uniform(-1, 1, size=shape).astype(np.float32)).to(tdt)
+    w16 = torch.from_numpy(_weights(rs, shape[1], 2, shape[2:]).astype(np.float32)).to(tdt)
+    x, w, go = x16.float().numpy(), w16.float().numpy(), go16.float().numpy()
+    xd, wd, god = x16.to(DEV), w16.to(DEV), go16.to(DEV)
+    for pad in range(5):
+        for active in (0, 1):
+            gx, gw = abi.backward(god, wd, xd, pad, active)
+            assert abi.last_kernel() == "step_backward"
+            gx_ref = torch.from_numpy(O.backward(go, w, x, pad, active)[0]).to(tdt)
+            if active:
+                assert _ulp_close(gx.cpu(), gx_ref, tdt), ("gx", shape, pad)
+            else:
+                assert torch.equal(gx.cpu(), gx_ref), ("gx", shape, pad)
+            _, gw64 = O.backward(go.astype(np.float64), w.astype(np.float64), x.astype(np.float64), pad, active)
+            assert rel_err(gw.float().cpu().numpy(), gw64) < 2 * torch.finfo(tdt).eps, ("gw", shape, pad, active)
+
+
+def test_dyadic_bit_exact(abi):
+    """dyadic data (multiples of 1/8, weights multiples of 1/4): every product and partial sum is exact in fp32, so grad_w
+    must equal the fp64 oracle's bit for bit whatever the summation order (the golden fixture's rows are 5 wide, not whole
+    16-byte pieces: tests/test_hip_parity.py runs it through the other families)"""
+    rs = np.random.RandomState(7)
+    for shape in ((2, 3, 8, 16), (1, 4, 13, 32), (3, 2, 5, 8)):
+        x = (rs.randint(-8, 9, size=shape) / 8.0).astype(np.float32)
+        go = (rs.randint(-8, 9, size=shape) / 8.0).astype(np.float32)
+        w = (rs.randint(-14, 15, size=(shape[1], 2)) / 4.0).astype(np.float32)
+        xd, wd, god = (torch.from_numpy(a).to(DEV) for a in (x, w, go))
+        for pad in range(5):
+            for active in (0, 1):
+                gx, gw = abi.backward(god, wd, xd, pad, active)
+                assert abi.last_kernel() == "step_backward"
+                gx_o, _ = O.backward(go, w, x, pad, active)
+                _, gw64 = O.backward(go.astype(np.float64), w.astype(np.float64), x.astype(np.float64), pad, active)
+                assert np.array_equal(gx.cpu().numpy(), gx_o), (shape, pad, active)
+                assert np.array_equal(gw.cpu().numpy(), gw64.astype(np.float32)), (shape, pad, active)
+
+
+def test_agrees_with_the_band_walk_kernels(abi):
+    """same grad_x bits as plane_backward_lds, grad_w within the fp32 bar, on a shape both families take"""
+    torch.manual_seed(3)
+    for shape, tdt in (((4, 6, 48, 96), torch.float32), ((4, 6, 48, 96), torch.float16), ((2, 8, 224, 224), torch.float32)):
+        x = torch.rand(shape, device=DEV).to(tdt)
+        go = torch.rand(shape, device=DEV).to(tdt)
+        w = ((torch.rand(shape[1], 2, device=DEV) - 0.5) * 7).to(tdt)
+        for pad in range(5):
+            for active in (0, 1):
+                abi.set_tuning(32, 1)
+                gx0, gw0 = abi.backward(go, w, x, pad, active)
+                assert abi.last_kernel().startswith("plane_backward")
+                abi.set_tuning(32, 2)
+                gx1, gw1 = abi.backward(go, w, x, pad, active)
+                assert abi.last_kernel() == "step_backward"
+                if active and tdt != torch.float32:
+                    assert _ulp_close(gx1.cpu(), gx0.cpu(), tdt)
+                else:
+                    assert torch.equal(gx0, gx1)
+                assert rel_err(gw1.float().cpu().numpy(), gw0.float().cpu().numpy()) < (1e-5 if tdt == torch.float32 else 2e-2)
+
+
+FWD_SHAPES = [((3, 5, 9, 24), None), ((2, 3, 40, 224), None), ((5, 2, 33, 64), [[1, 2], [4, 8]]), ((1, 2, 300, 8), [[3, 0], [0, 0]]),
+              ((2, 3, 1, 16), None), ((2, 2, 7, 1000), [[0, 1], [8, 16]]), ((2, 1, 5, 1024), None), ((2, 4, 224, 224), None),
+              ((1, 3, 17, 4), None), ((2, 3, 30, 40), [[2, 3], [4, 4]])]
+
+
+@pytest.mark.parametrize("dt", ["f32", "f64"])
+@pytest.mark.parametrize("shape,crop", FWD_SHAPES)
+def test_gather_forward_vs_oracle(abi, shape, crop, dt):
+    """sparse-shift forward of 4- / 8-byte elements, crops included: bit-exact (a pure gather)"""
+    rs = np.random.RandomState(sum(shape) * 5 + 2)
+    npdt = np.float32 if dt == "f32" else np.float64
+    x = rs.uniform(-1, 1, size=shape).astype(npdt)
+    w = _weights(rs, shape[1], 2, shape[2:]).astype(npdt)
+    b, new = abi.check_borders(list(shape), crop, 2)
+    if (new[-1] * x.itemsize) % 16:
+        pytest.skip("output rows are not whole 16-byte chunks")
+    xd, wd = torch.from_numpy(x).to(DEV), torch.from_numpy(w).to(DEV)
+    for pad in range(5):
+        out = abi.forward(xd, wd, pad, 0, b)
+        assert abi.last_kernel() == "step_gather_forward", (shape, abi.last_kernel())
+        assert np.array_equal(out.cpu().numpy(), O.forward(x, w, pad, 0, b)), (shape, crop, pad)
+
+
+def test_gather_forward_quantized_int32_and_huge_weights(abi):
+    """qint32 tensors with quantized weights (the generic shift path), and float weights beyond 2^30 (the 64-bit path)"""
+    rs = np.random.RandomState(5)
+    xq = rs.randint(-1000, 1000, size=(2, 4, 24, 32)).astype(np.int32)
+    wq = rs.randint(120, 136, size=(4, 2)).astype(np.uint8)
+    for pad in range(5):
+        out = abi.forward_quantized(torch.from_numpy(xq).to(DEV), torch.from_numpy(wq).to(DEV), 128, -3, pad)
+        assert abi.last_kernel() == "step_gather_forward"
+        assert np.array_equal(out.cpu().numpy(), O.forward_q(xq, wq, 128, -3, pad)), pad
+    x = rs.uniform(-1, 1, size=(1, 3, 12, 16)).astype(np.float32)
+    w = np.array([[3e9, -2.0], [1.0, -5e9], [2.5e9, 2.5e9]], dtype=np.float32)
+    for pad in range(5):
+        out = abi.forward(torch.from_numpy(x).to(DEV), torch.from_numpy(w).to(DEV), pad, 0)
+        assert abi.last_kernel() == "step_gather_forward"
+        assert np.array_equal(out.cpu().numpy(), O.forward(x, w, pad, 0)), pad

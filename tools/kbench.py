@@ -45,6 +45,8 @@ def main():
     ap.add_argument("--shape", default="", help="N,C,spatial... with --dtype / --active: a free-form workload")
     ap.add_argument("--dtype", default="float32")
     ap.add_argument("--active", type=int, default=0)
+    ap.add_argument("--libs", default="", help="comma-separated variants/<name>.so builds timed interleaved in THIS process "
+                                               "(same tensors, same physical pages); 'tree' = the in-tree library")
     a = ap.parse_args()
     extra = {  # tuning-only variants of the bench workloads
         "c2a": (2, (64, 256, 224, 224), "float32", True, "Shift2d active N64 C256 224x224 fp32"),
@@ -84,13 +86,23 @@ def main():
         k, vals = part.split("=")
         knobs.append((int(k), [int(v) for v in vals.split(",")]))
     combos = list(itertools.product(*[[(k, v) for v in vals] for k, vals in knobs])) or [()]
+    libs = {}
+    for name in [n for n in a.libs.split(",") if n]:
+        abi._LIB_PATH = (os.path.join(ROOT, "activesparseshifts-pytorch_amd", "torchshifts", "libshiftnd_hip.so") if name == "tree"
+                         else os.path.join(ROOT, "variants", name + ".so"))
+        abi._lib = None
+        libs[name] = abi.lib()
+    combos = [(ln, c) for c in combos for ln in (libs or {"": None})]
     res = {}
     for r in range(a.rounds + 1):
-        for ci, combo in enumerate(combos):
+        for ci, (ln, combo) in enumerate(combos):
+            if ln:
+                abi._lib = libs[ln]
+                abi.set_path_policy(a.policy)
             for k, v in combo:
                 abi.set_tuning(k, v)
             ws = None if quant else abi.backward_workspace(x, a.pad, active)
-            tag = ",".join("%d=%d" % kv for kv in combo) or "default"
+            tag = (ln + ":" if ln else "") + (",".join("%d=%d" % kv for kv in combo) or "default")
             if quant:
                 fns = {"fwd[" + tag + "]": lambda: abi.forward_quantized(x, wq, 128, 0, a.pad, out=out)}
             else:

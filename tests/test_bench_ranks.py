@@ -81,5 +81,5 @@ def test_self_launch_two_ranks_on_this_gpu_box():
     assert r.returncode == 0, r.stderr[-2000:]
     j = _json_lines(r.stdout)
     assert len(j) == 1 and j[0]["n_gpus"] == 2
-    assert j[0]["roofline"]["kernel"].startswith(("plane_", "sweep_"))
+    assert j[0]["roofline"]["kernel"].startswith(("plane_", "sweep_", "step_"))
     assert "cpu_baseline" not in j[0]

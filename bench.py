@@ -16,6 +16,9 @@ The JSON line also carries
   cpu_baseline  the REAL reference CPU kernels (oracle/_ref, built from /root/reference) timed on
                 this host in a child process on a bounded sample (rank 0, --gpus 1 only)
 
+  roofline.box_stream / frac_of_box   the same box's plain 1R1W / 2R1W float4 streams (tools/stream_probe, a child
+                process that has exited before this one touches the GPU) and the dominant kernel's rate against them
+
     python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c2|c3|c4|c5|c2a] [--pad 0..4]
 
 Multi-GPU: `python bench.py --gpus N` starts the N rank processes itself (one per GPU; the parent never
@@ -61,14 +64,31 @@ def cpu_baseline(workload_pad=0):
     only run whose weight gradient is race-free in the reference, global_scope.h:22)."""
     script = os.path.join(ROOT, "oracle", "ref_bench.py")
     try:
-        out = subprocess.run([sys.executable, script, "--n", "24", "--pad", str(workload_pad), "--iters", "2", "--both"],
-                             capture_output=True, text=True, timeout=900)
+        out = subprocess.run([sys.executable, script, "--n", "24", "--pad", str(workload_pad), "--iters", "2", "--both",
+                              "--full", "64"], capture_output=True, text=True, timeout=900)
         lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
         if out.returncode != 0 or not lines:
             raise RuntimeError("ref_bench.py exit %d: %s" % (out.returncode, (out.stderr or out.stdout)[-300:]))
         return json.loads(lines[-1])
     except Exception as e:  # noqa: BLE001
         return {"value": None, "unit": "Gelem/s", "cores": 0, "kind": "unavailable", "sample": repr(e)[:300]}
+
+
+def box_stream():
+    """Same-box calibration: tools/stream_probe (a plain HIP binary, built by __graft_entry__.build()) streams C2-sized
+    buffers with float4 accesses -- best 1-read-1-write and 2-read-1-write rates over a small fixed set of launch shapes --
+    in a child process that has exited before this process touches the GPU.  The kernels' rates are reported against
+    these next to the 8 TB/s fraction: boxes of the pool differ by several per cent, the ratio to the box's own plain
+    streams does not."""
+    exe = os.path.join(ROOT, "tools", "stream_probe")
+    try:
+        out = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+        lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+        if out.returncode != 0 or not lines:
+            raise RuntimeError("stream_probe exit %d: %s" % (out.returncode, (out.stderr or out.stdout)[-300:]))
+        return json.loads(lines[-1])
+    except Exception as e:  # noqa: BLE001
+        return {"probe": "unavailable", "error": repr(e)[:300]}
 
 
 def newest_traffic(workload, kernel_name, pad):
@@ -116,9 +136,31 @@ def launch_ranks(a, argv):
     for r in range(a.gpus):
         e = dict(env, RANK=str(r), LOCAL_RANK=str(r))
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=e))
+    # supervise: the first rank that fails takes the others down (they would otherwise sit in the rendezvous or in a
+    # barrier until the collective timeout), and the parent exits with its code within seconds
     rc = 0
-    for p in procs:
-        rc = max(rc, abs(p.wait()))
+    live = list(procs)
+    while live:
+        time.sleep(0.05)
+        for p in list(live):
+            code = p.poll()
+            if code is None:
+                continue
+            live.remove(p)
+            if code != 0 and rc == 0:
+                rc = abs(code) or 1
+                for q in live:
+                    q.terminate()
+                deadline = time.time() + 5.0
+                for q in live:
+                    try:
+                        q.wait(timeout=max(0.1, deadline - time.time()))
+                    except subprocess.TimeoutExpired:
+                        q.kill()
+                live = []
+                break
+    if rc:
+        sys.stderr.write("bench.py: a rank exited with code %d; the other ranks were stopped\n" % rc)
     return rc
 
 
@@ -152,6 +194,10 @@ def parse_args(argv):
     ap.add_argument("--shape", default=None,
                     help="comma-separated per-GPU shape replacing the workload's (functional checks of the rank code "
                          "only: the JSON line then says so and is not a measurement of the named workload)")
+    ap.add_argument("--allow-oversubscribe", action="store_true",
+                    help="let --gpus N run on a box with fewer than N GPUs (ranks share devices over gloo): a functional "
+                         "check of the rank code, never a scaling point.  Without it such a request is an error.")
+    ap.add_argument("--no-probe", action="store_true", help="skip the same-box stream calibration (tools/stream_probe)")
     ap.add_argument("--device", default="cuda", choices=("cuda", "cpu"),
                     help="cpu = run the rank/launcher plumbing on the CPU dispatch key with gloo (tests only; "
                          "no roofline, never a result)")
@@ -176,6 +222,9 @@ def main(argv=None):
     if rank == 0 and world == 1 and a.workload == "c2" and a.shape is None and a.device == "cuda" \
             and not a.no_cpu_baseline:
         base = cpu_baseline(a.pad)  # child process, before any GPU initialisation in this process
+    probe = None
+    if rank == 0 and world == 1 and a.device == "cuda" and not a.no_probe:
+        probe = box_stream()  # child process too: it has left the GPU before this process initialises it
 
     import torch
     import torch.distributed as dist
@@ -193,6 +242,9 @@ def main(argv=None):
     ndev = torch.cuda.device_count() if on_gpu else 0
     backend = os.environ.get("SHIFTND_BENCH_BACKEND") or ("nccl" if on_gpu and ndev >= world else "gloo")
     oversubscribed = on_gpu and ndev < world
+    if oversubscribed and not a.allow_oversubscribe:
+        raise SystemExit("bench.py: --gpus %d but this box has %d GPU(s); a scaling point needs one GPU per rank "
+                         "(--allow-oversubscribe runs the ranks on shared devices as a functional check)" % (world, ndev))
     if on_gpu:
         dev_index = local_rank % max(ndev, 1)
         torch.cuda.set_device(dev_index)
@@ -201,10 +253,15 @@ def main(argv=None):
         dev = torch.device("cpu")
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        import datetime
+        limit = datetime.timedelta(seconds=int(os.environ.get("SHIFTND_BENCH_TIMEOUT_S", "300")))
         if backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev, timeout=limit)
         else:
-            dist.init_process_group(backend, rank=rank, world_size=world)
+            dist.init_process_group(backend, rank=rank, world_size=world, timeout=limit)
+    if os.environ.get("SHIFTND_BENCH_FAIL_RANK") == str(rank):  # tests: a rank that dies after the rendezvous
+        sys.stderr.write("bench.py: rank %d exits on request (SHIFTND_BENCH_FAIL_RANK)\n" % rank)
+        os._exit(7)
 
     def sync():
         if on_gpu:
@@ -270,8 +327,12 @@ def main(argv=None):
         step()
     barrier()
     dt = time.perf_counter() - t0
+    per_rank_ms = [dt / a.steps * 1e3]
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+        every = [torch.zeros_like(t) for _ in range(world)]
+        dist.all_gather(every, t)
+        per_rank_ms = [float(v.item()) / a.steps * 1e3 for v in every]
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     ms_per_step = dt / a.steps * 1e3
@@ -304,16 +365,20 @@ def main(argv=None):
     kernels = {}
     dom_name = dom_ms = dom_bytes = None
     if on_gpu:
-        def record(name, t, nbytes):
+        def record(name, t, nbytes, stream_kind=None):
             kernels[name] = {"ms": t[0], "median_ms": t[1], "min_ms": t[2], "GB/s": nbytes / t[0] / 1e6}
+            ref = (probe or {}).get(stream_kind + "_GBps") if stream_kind else None
+            if ref:  # against the plain stream of the same read / write mix on this box
+                kernels[name]["stream"] = stream_kind
+                kernels[name]["frac_of_box"] = nbytes / t[0] / 1e6 / ref
         if quant:
             xi = xq.int_repr()
             wi = wq.int_repr()
             outb = torch.empty_like(xi)
             t_f = event_time(lambda: abi.forward_quantized(xi, wi, 128, 0, a.pad, out=outb), kiters)
             qname = abi.last_kernel()
-            record(qname, t_f, 2 * esize * elems)
-            dom_name, dom_ms, dom_bytes = qname, t_f[0], 2 * esize * elems
+            record(qname, t_f, 2 * esize * elems, "1R1W")
+            dom_name, dom_ms, dom_bytes, dom_kind = qname, t_f[0], 2 * esize * elems, "1R1W"
         else:
             outb, gxb, gwb = torch.empty_like(x), torch.empty_like(x), torch.empty_like(w)
             ws = abi.backward_workspace(x, a.pad, active)
@@ -323,9 +388,9 @@ def main(argv=None):
             fname = abi.last_kernel()
             abi.backward(go, w, x, a.pad, active, grad_x=gxb, grad_w=gwb, workspace=ws)
             bname = abi.last_kernel()
-            record(fname, t_f, 2 * esize * elems)
-            record(bname, t_b, 3 * esize * elems)
-            dom_name, dom_ms, dom_bytes = bname, t_b[0], 3 * esize * elems
+            record(fname, t_f, 2 * esize * elems, "1R1W")
+            record(bname, t_b, 3 * esize * elems, "2R1W")
+            dom_name, dom_ms, dom_bytes, dom_kind = bname, t_b[0], 3 * esize * elems, "2R1W"
     path = "+".join(sorted(set(k.split("_")[0] for k in kernels))) or "cpu key"
 
     if rank == 0:
@@ -351,7 +416,9 @@ def main(argv=None):
                        "path": ("torch.ops.torchshifts._shift%dd_forward/_backward -> libshiftnd_hip.so (%s kernels)"
                                 % (nd, path)) if on_gpu else "torch.ops.torchshifts (CPU dispatch key of _C.so)",
                        "ranks": {"world": world, "backend": backend if world > 1 else None, "devices": ndev,
-                                 "oversubscribed": oversubscribed}},
+                                 "oversubscribed": oversubscribed,
+                                 "device_name": torch.cuda.get_device_name(dev) if on_gpu else None}},
+            "per_rank_ms": per_rank_ms,
             "achieved_hbm_GBps_step": step_bytes / (ms_per_step * 1e-3) / 1e9,
             "kernels": kernels,
         }
@@ -362,6 +429,10 @@ def main(argv=None):
                                   "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                                   "traffic_source": traffic_src, "avg_kernel_ms": dom_ms,
                                   "algorithmic_bytes": dom_bytes}
+            if probe is not None:
+                result["roofline"]["box_stream"] = probe
+                ref = probe.get(dom_kind + "_GBps")
+                result["roofline"]["frac_of_box"] = achieved / ref if ref else None
         else:
             result["roofline"] = None
         if not on_gpu:

@@ -55,6 +55,9 @@ def main():
     ap.add_argument("--pad", type=int, default=0)
     ap.add_argument("--both", action="store_true",
                     help="SURVEY 8d: time 1 thread AND all usable host cores on the --n sample, plus the N=4 slice")
+    ap.add_argument("--full", type=int, default=0,
+                    help="with --both: also time the FULL workload at this batch size (BASELINE config 2: 64), one timed "
+                         "iteration after a warm-up pass, 1 thread and all cores (SURVEY 8d, BASELINE.md section 4)")
     ap.add_argument("--allow-port", action="store_true",
                     help="time the plain-C restatement (oracle/shift_oracle.c) when oracle/_ref is missing")
     a = ap.parse_args()
@@ -93,7 +96,12 @@ def main():
         def run(n, threads, iters):
             torch.set_num_threads(threads)
             shape = (n, a.c, a.hw, a.hw)
-            xt, got = torch.from_numpy(synth(shape, 1)), torch.from_numpy(synth(shape, 2))
+            if n > 8 and n % 8 == 0:  # the hash stream of 8 samples, repeated: same work, a fraction of the set-up time
+                base = (8, a.c, a.hw, a.hw)
+                xt = torch.from_numpy(synth(base, 1)).repeat(n // 8, 1, 1, 1)
+                got = torch.from_numpy(synth(base, 2)).repeat(n // 8, 1, 1, 1)
+            else:
+                xt, got = torch.from_numpy(synth(shape, 1)), torch.from_numpy(synth(shape, 2))
             wt = torch.from_numpy((synth((a.c, 2), 3) * 6 - 3).astype(np.float32))
             b = torch.tensor([0, a.hw, 0, a.hw, 0, 1], dtype=torch.int32)
             ts = []
@@ -126,6 +134,8 @@ def main():
             out["note"] = ("all-cores run = the reference's at::parallel_for over N*C; its multi-thread weight gradient "
                            "races (global_scope.h:22) -- timing only")
         out["n4_slice"] = [entry(4, t, 1) for t in thread_sets]  # beside SURVEY section 6's N=4 numbers
+        if a.full > 0 and kind == "reference":
+            out["full_size"] = [entry(a.full, t, 1) for t in thread_sets]  # the stated configuration itself
     print(json.dumps(out))
 
 

@@ -33,7 +33,8 @@ def test_self_launch_world2_cpu():
     assert len(lines) == 1, "exactly one JSON line (rank 0)"
     j = lines[0]
     assert j["n_gpus"] == 2 and j["config"]["ranks"] == {"world": 2, "backend": "gloo", "devices": 0,
-                                                          "oversubscribed": False}
+                                                          "oversubscribed": False, "device_name": None}
+    assert len(j["per_rank_ms"]) == 2 and abs(max(j["per_rank_ms"]) - j["ms_per_step"]) < 1e-9
     assert j["scaling"] == "weak" and j["steps"] == 2 and j["warmup"] == 1
     assert "cpu_baseline" not in j and j["roofline"] is None
     assert "not a measurement" in j["data"]
@@ -64,6 +65,18 @@ def test_gpus_must_match_world_size():
     assert r.returncode != 0 and "WORLD_SIZE=1" in r.stderr
 
 
+def test_a_dying_rank_stops_the_job_quickly():
+    """rank 1 dies after the rendezvous: the launcher stops rank 0 (which would otherwise wait in its first barrier for the
+    collective timeout) and exits non-zero within seconds"""
+    import time
+    t0 = time.time()
+    r = _run(["--gpus", "2", "--device", "cpu", "--shape", "4,8,16,16", "--steps", "2", "--warmup", "1"],
+             env={"SHIFTND_BENCH_FAIL_RANK": "1", "SHIFTND_BENCH_TIMEOUT_S": "600"}, timeout=300)
+    assert r.returncode != 0 and "the other ranks were stopped" in r.stderr, r.stderr[-2000:]
+    assert time.time() - t0 < 120  # (most of it is two interpreters importing torch)
+    assert _json_lines(r.stdout) == []
+
+
 def test_no_cpu_fallback_for_the_measured_path():
     """default device is the GPU; without one the bench refuses instead of timing the CPU key"""
     import torch
@@ -77,7 +90,11 @@ def test_no_cpu_fallback_for_the_measured_path():
 def test_self_launch_two_ranks_on_this_gpu_box():
     """`python bench.py --gpus 2` on a 1-GPU box: both ranks share the GPU and rendezvous over gloo (with >= 2 GPUs:
     RCCL); functional check of the launcher + rank code with the HIP kernels"""
-    r = _run(["--gpus", "2", "--shape", "8,32,56,56", "--steps", "3", "--warmup", "1"])
+    import torch
+    if torch.cuda.device_count() < 2:
+        refused = _run(["--gpus", "2", "--shape", "8,32,56,56", "--steps", "1", "--warmup", "0"], timeout=120)
+        assert refused.returncode != 0 and "--allow-oversubscribe" in refused.stderr  # never a silent degradation
+    r = _run(["--gpus", "2", "--shape", "8,32,56,56", "--steps", "3", "--warmup", "1", "--allow-oversubscribe"])
     assert r.returncode == 0, r.stderr[-2000:]
     j = _json_lines(r.stdout)
     assert len(j) == 1 and j[0]["n_gpus"] == 2

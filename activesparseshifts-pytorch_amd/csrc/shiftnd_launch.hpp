@@ -75,6 +75,9 @@ int step_backward(const Geometry &g, int dtype, const void *go, const void *x, c
 bool step_forward_eligible(const Geometry &g, int dtype, const void *x, const void *out);
 int step_forward(const Geometry &g, int dtype, const void *x, const void *w, int wkind, int64_t wzp, uint64_t fill_bits,
                  void *out, hipStream_t st);
+// ... and the forwards that stage their source rows in LDS: interpolating (every float dtype), sparse shift of 2-byte elements
+bool step_forward_lds_eligible(const Geometry &g, int dtype, const void *x, const void *out);
+int step_forward_lds(const Geometry &g, int dtype, const void *x, const void *w, int wkind, uint64_t fill_bits, void *out, hipStream_t st);
 void step_set_tuning(int knob, int value);
 
 // ---- 1-byte elements on small planes (shiftnd_bytes.hip): whole planes through LDS, 16-byte output pieces that cross

@@ -33,7 +33,7 @@
 namespace shiftnd {
 namespace {
 
-// knobs (shiftnd_set_tuning 32..): [0] backward, [1] gather forward: 0 = automatic, 1 = never, 2 = whenever eligible
+// knobs (shiftnd_set_tuning 32..): [0] backward, [1] gather forward (direct loads), [2] forwards through LDS: 0 = automatic, 1 = never, 2 = whenever eligible
 thread_local int g_step_tune[4] = {0, 0, 0, 0};
 
 struct ChanDesc {  // per channel, written by step_prep
@@ -192,7 +192,6 @@ __global__ __launch_bounds__(kThreads) void step_backward(const StepParams p) {
     constexpr int REC = RecSize<E>::N;
     constexpr bool SCAT = !ACTIVE;
     constexpr int NDIFF = 2;
-    constexpr int KP = ACTIVE ? 5 : 3;  // staged pieces per thread: (2R + 1) cpr <= 3 * 256, (3R + 2) cpr <= 5 * 256
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char *tile = smem + 64;  // 64-byte pad: see lds_read_row
 
@@ -222,9 +221,10 @@ __global__ __launch_bounds__(kThreads) void step_backward(const StepParams p) {
         auto affine_state = [&](int cs) {
             ColState<E> st;
             st.base = ji - cs;
+            if (st.base + E < 0 || st.base >= S2) st.base = 0;  // no column of the chunk has a source: every entry is -1 below
             st.affine = true;
 #pragma unroll
-            for (int e = 0; e <= E; ++e) st.cm[e] = (st.base + e >= 0 && st.base + e < S2) ? st.base + e : -1;
+            for (int e = 0; e <= E; ++e) st.cm[e] = (ji - cs + e >= 0 && ji - cs + e < S2) ? ji - cs + e : -1;
             return st;
         };
         xm = affine_state(d.cx2);
@@ -235,32 +235,32 @@ __global__ __launch_bounds__(kThreads) void step_backward(const StepParams p) {
         gm = load_colstate<E>(p.colg + rec);
     }
 
-    // ---- stage the rows: aligned 16-byte pieces, lanes of a wave take consecutive pieces; straight-line code ---------
+    // ---- stage the rows: aligned 16-byte pieces.  Thread (tr, tc) moves piece tc of row tr of every group (its own
+    // chunk position: no index arithmetic), the first cpr threads move the extra corner row of the groups that have one;
+    // a wave's pieces are consecutive, the LDS destination is a wave-uniform base (the hardware adds lane * 16).
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-#pragma unroll
-    for (int k = 0; k < KP; ++k) {
-        if (k * kThreads < npieces) {  // uniform
-            const int q = k * kThreads + tid;
-            const int slot = static_cast<int>(fdiv(static_cast<uint32_t>(q), p.d_cpr));
-            const int j = q - slot * cpr;
-            // group 0: corner rows of x, m1[b0 + r], r <= Rn; group 1: the incoming gradient at rows b0 + r, r < Rn;
-            // group 2 (interpolating): the rows grad_x blends, g1[b0 + r], r <= Rn.  In-range rows map to themselves in
-            // every padding mode, so group 1 is the same fold with shift 0.
-            const bool g0 = slot < NX, g2 = ACTIVE && slot >= NX + NG;
-            const int r = slot - (g0 ? 0 : (g2 ? NX + NG : NX));
-            const int cs = g0 ? d.cx1 : (g2 ? d.cg1 : 0);
-            int src = row_map_t<PAD>(b0 + r, cs, S1);
-            if (r > Rn - ((g0 || g2) ? 0 : 1) || q >= npieces) src = -1;
-            // uniform base + 32-bit lane offset (planes are < 2^30 elements): the SGPR-base address form, one
-            // instruction per array (a wave's 64 pieces are nearly always of one array)
-            const uint32_t off = static_cast<uint32_t>(src * S2 + j * E) * static_cast<uint32_t>(sizeof(S));
-            char *dst_wave = tile + (k * kThreads + wave * 64) * 16;  // wave-uniform; hardware adds lane * 16
-            if (src >= 0 && g0)
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(reinterpret_cast<const char *>(xp) + off),
-                                                 (__attribute__((address_space(3))) void *)dst_wave, 16, 0, 2 /* nt */);
-            if (src >= 0 && !g0)
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(reinterpret_cast<const char *>(gp) + off),
-                                                 (__attribute__((address_space(3))) void *)dst_wave, 16, 0, 2 /* nt */);
+    auto dma = [&](const S *base, int src_row, int col_piece, int lds_piece0) {
+        // uniform base + 32-bit lane offset (planes are < 2^30 elements): the SGPR-base address form
+        const uint32_t off = static_cast<uint32_t>(src_row * S2 + col_piece * E) * static_cast<uint32_t>(sizeof(S));
+        char *dst_wave = tile + (lds_piece0 + wave * 64) * 16;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(reinterpret_cast<const char *>(base) + off),
+                                         (__attribute__((address_space(3))) void *)dst_wave, 16, 0, 2 /* nt */);
+    };
+    if (tr < R) {
+        const int sx = tr <= Rn ? row_map_t<PAD>(b0 + tr, d.cx1, S1) : -1;  // corner rows of x: m1[b0 + tr]
+        if (sx >= 0) dma(xp, sx, tc, 0);
+        if (tr < Rn) dma(gp, b0 + tr, tc, NX * cpr);  // the incoming gradient at the rows themselves
+        if constexpr (ACTIVE) {
+            const int sg = tr <= Rn ? row_map_t<PAD>(b0 + tr, d.cg1, S1) : -1;  // the rows grad_x blends: g1[b0 + tr]
+            if (sg >= 0) dma(gp, sg, tc, (NX + NG) * cpr);
+        }
+    }
+    if (Rn == R && tid < cpr) {  // the + 1 corner row of a full step (a ragged last step has it among its first R rows)
+        const int sx = row_map_t<PAD>(b0 + R, d.cx1, S1);
+        if (sx >= 0) dma(xp, sx, tid, R * cpr);
+        if constexpr (ACTIVE) {
+            const int sg = row_map_t<PAD>(b0 + R, d.cg1, S1);
+            if (sg >= 0) dma(gp, sg, tid, (NX + NG + R) * cpr);
         }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -446,6 +446,159 @@ __global__ __launch_bounds__(kThreads) void step_gather_forward(const GatherPara
     store_chunk<R_t, E>(dst, v);
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------
+// step_forward_lds: forwards that read their source rows through LDS, in the same one-step shape -- the interpolating
+// forward of every float dtype (R + 1 corner rows per step) and the sparse-shift forward of 2-byte elements (16-byte
+// global loads at 2-byte alignment are slow; aligned LDS-DMA + a funnel shift is not).  No table, no workspace: the
+// column state of the thread's chunk is folded arithmetically (one map, the forward has VALU time to spare), the
+// channel's two weights come through the scalar cache.
+// ---------------------------------------------------------------------------------------------------------------------
+struct FwdParams {
+    const void *x;
+    void *out;
+    const void *w;
+    uint64_t fill;
+    int64_t x_plane, o_plane;
+    int wkind, C;
+    int S1, S2, O1, O2, L1, L2;
+    int cpr, xppr, R, spp;   // output chunks per row, source pieces per row, rows per step, steps per plane
+    uint32_t total_steps, steps_per_xcd;
+    FastDiv d_spp, d_C, d_cpr, d_xppr, d_per1, d_per2;
+};
+
+// the two weights of channel c (row dim, inner dim) widened to the compute type, through the scalar cache
+template <typename CT> __device__ __forceinline__ void load_weights2(const void *w, int wkind, int c, CT &wr, CT &wc) {
+    const uintptr_t base = reinterpret_cast<uintptr_t>(w);
+    if (wkind == SHIFTND_F64) {
+        const __attribute__((address_space(4))) double *q = reinterpret_cast<const __attribute__((address_space(4))) double *>(base) + static_cast<int64_t>(c) * 2;
+        wr = static_cast<CT>(q[0]);
+        wc = static_cast<CT>(q[1]);
+    } else if (wkind == SHIFTND_F16 || wkind == SHIFTND_BF16) {
+        const uint32_t word = (reinterpret_cast<const __attribute__((address_space(4))) uint32_t *>(base))[c];
+        const uint16_t lo = static_cast<uint16_t>(word), hi = static_cast<uint16_t>(word >> 16);
+        if (wkind == SHIFTND_F16) {
+            wr = static_cast<CT>(__builtin_bit_cast(_Float16, lo));
+            wc = static_cast<CT>(__builtin_bit_cast(_Float16, hi));
+        } else {
+            wr = static_cast<CT>(__builtin_bit_cast(float, static_cast<uint32_t>(lo) << 16));
+            wc = static_cast<CT>(__builtin_bit_cast(float, static_cast<uint32_t>(hi) << 16));
+        }
+    } else {
+        const __attribute__((address_space(4))) float *q = reinterpret_cast<const __attribute__((address_space(4))) float *>(base) + static_cast<int64_t>(c) * 2;
+        wr = static_cast<CT>(q[0]);
+        wc = static_cast<CT>(q[1]);
+    }
+}
+
+// canonical shift of an integral shift held in the compute type: 32-bit arithmetic below 2^30, the 64-bit form beyond
+template <int PAD, typename CT> __device__ __forceinline__ int canon_of(CT r, int len, const FastDiv &dper) {
+    if (r > CT(-1073741824) && r < CT(1073741824)) return canon_shift32<PAD>(static_cast<int>(r), len, dper);
+    return canon_shift(static_cast<int64_t>(r), len, PAD, dper);
+}
+
+// column state of E + 1 consecutive map entries starting at coordinate j0, folded arithmetically
+template <int E, int PAD> __device__ __forceinline__ ColState<E> fold_colstate(int j0, int cs, int len) {
+    ColState<E> c;
+    c.base = 0;
+    bool found = false;
+#pragma unroll
+    for (int e = 0; e <= E; ++e) {
+        c.cm[e] = row_map_t<PAD>(j0 + e, cs, len);
+        if (!found && c.cm[e] >= 0) {
+            c.base = c.cm[e] - e;
+            found = true;
+        }
+    }
+    c.affine = true;
+#pragma unroll
+    for (int e = 0; e <= E; ++e) c.affine = c.affine && (c.cm[e] < 0 || c.cm[e] == c.base + e);
+    return c;
+}
+
+template <typename T, bool ACTIVE, int PAD>
+__global__ __launch_bounds__(kThreads) void step_forward_lds(const FwdParams p) {
+    using S = typename T::S;
+    using CT = typename T::C;
+    constexpr int E = 16 / sizeof(S);
+    constexpr int KP = 4;  // staged pieces per thread (host: (R + 1) * xppr <= 4 * 256)
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char *tile = smem + 64;  // 64-byte pads in front and behind: see lds_read_row
+
+    const uint32_t bid = (blockIdx.x & 7u) * p.steps_per_xcd + (blockIdx.x >> 3);
+    if (bid >= p.total_steps) return;
+    const uint32_t plane = fdiv(bid, p.d_spp);
+    const int step = static_cast<int>(bid - plane * static_cast<uint32_t>(p.spp));
+    const int c = static_cast<int>(plane - fdiv(plane, p.d_C) * static_cast<uint32_t>(p.C));
+    CT wr, wc;
+    load_weights2<CT>(p.w, p.wkind, c, wr, wc);
+    // weights_init_forward (shifts_cuda.cu:168-183): sparse shift rounds (half to even, as the CPU path), active floors
+    const CT rr = ACTIVE ? c_floor<CT>(wr) : c_rint<CT>(wr), rc = ACTIVE ? c_floor<CT>(wc) : c_rint<CT>(wc);
+    const CT dw[2] = {ACTIVE ? wr - rr : CT(0), ACTIVE ? wc - rc : CT(0)};
+    const int cs1 = __builtin_amdgcn_readfirstlane(canon_of<PAD, CT>(rr, p.S1, p.d_per1));
+    const int cs2 = __builtin_amdgcn_readfirstlane(canon_of<PAD, CT>(rc, p.S2, p.d_per2));
+
+    const int R = p.R, S1 = p.S1, S2 = p.S2, cpr = p.cpr, xppr = p.xppr;
+    const int b0 = step * R;
+    const int Rn = min(R, p.O1 - b0);
+    const int NX = R + (ACTIVE ? 1 : 0);
+    const int npieces = NX * xppr;
+    const int RB = S2 * static_cast<int>(sizeof(S));
+    const S *xp = static_cast<const S *>(p.x) + static_cast<int64_t>(plane) * p.x_plane;
+    S *op = static_cast<S *>(p.out) + static_cast<int64_t>(plane) * p.o_plane;
+
+    const int tid = static_cast<int>(threadIdx.x);
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+#pragma unroll
+    for (int k = 0; k < KP; ++k) {
+        if (k * kThreads < npieces) {  // uniform
+            const int q = k * kThreads + tid;
+            const int slot = static_cast<int>(fdiv(static_cast<uint32_t>(q), p.d_xppr));
+            const int j = q - slot * xppr;
+            int src = row_map_t<PAD>(b0 + p.L1 + slot, cs1, S1);
+            if (slot > Rn - (ACTIVE ? 0 : 1) || q >= npieces) src = -1;
+            const uint32_t off = static_cast<uint32_t>(src * S2 + j * E) * static_cast<uint32_t>(sizeof(S));
+            char *dst_wave = tile + (k * kThreads + wave * 64) * 16;  // wave-uniform; hardware adds lane * 16
+            if (src >= 0)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(reinterpret_cast<const char *>(xp) + off),
+                                                 (__attribute__((address_space(3))) void *)dst_wave, 16, 0, 2 /* nt */);
+        }
+    }
+    const int tr = static_cast<int>(fdiv(static_cast<uint32_t>(tid), p.d_cpr)), tc = tid - tr * cpr;
+    const int jo = tc * E;
+    const ColState<E> xm = fold_colstate<E, PAD>(jo + p.L2, cs2, S2);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tr >= Rn) return;
+    const int b = b0 + tr;
+    auto row_valid = [&](int pr) { return PAD != 0 || row_map_t<PAD>(pr, cs1, S1) >= 0; };
+    Chunk<S, E> res;
+    if constexpr (ACTIVE) {
+        CT xv[2][E + 1];
+#pragma unroll
+        for (int hb = 0; hb < 2; ++hb) {
+            S raw[E + 1];
+            lds_read_row<S, E>(tile + (tr + hb) * RB, row_valid(b + p.L1 + hb), xm, raw);
+#pragma unroll
+            for (int e = 0; e <= E; ++e) xv[hb][e] = widen<T>(raw[e]);
+        }
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+            const CT v[4] = {xv[0][e], xv[1][e], xv[0][e + 1], xv[1][e + 1]};
+            res.e[e] = narrow<T>(interp_t<T, 2>(v, dw));
+        }
+    } else {
+        S raw[E + 1], fill;
+        const typename raw_t<sizeof(S)>::type fill_bits = static_cast<typename raw_t<sizeof(S)>::type>(p.fill);
+        __builtin_memcpy(&fill, &fill_bits, sizeof(S));
+        const bool valid = row_valid(b + p.L1);
+        lds_read_row<S, E>(tile + tr * RB, valid, xm, raw);
+#pragma unroll
+        for (int e = 0; e < E; ++e) res.e[e] = (valid && xm.cm[e] >= 0) ? raw[e] : fill;
+    }
+    store_chunk<S, E>(op + static_cast<int64_t>(b) * p.O2 + jo, res);
+}
+
 // grad_w[c][0..1] = blend(sum over the steps of channel c, in a fixed order)
 template <typename T>
 __global__ __launch_bounds__(kThreads) void step_reduce(const StepParams p, typename T::S *__restrict__ grad_w) {
@@ -621,6 +774,92 @@ int step_forward(const Geometry &g, int dtype, const void *x, const void *w, int
     }
     if (es == 4) { SHIFTND_STEP_FWD(4) } else { SHIFTND_STEP_FWD(8) }
 #undef SHIFTND_STEP_FWD
+    return SHIFTND_OK;
+}
+
+
+// interpolating forward of every float dtype, sparse-shift forward of 2-byte elements: dense 2-D tensors, source rows and
+// output rows of whole 16-byte pieces, at most one workgroup pass wide
+bool step_forward_lds_eligible(const Geometry &g, int dtype, const void *x, const void *out) {
+    if (g_step_tune[2] == 1) return false;
+    if (dtype > SHIFTND_BF16) return false;
+    const int es = dtype_size(dtype);
+    const bool interpolating = g.active != 0;
+    if (!interpolating && es != 2) return false;
+    if (g.nd != 2 || g.S[0] != 1 || g.O[0] != 1) return false;
+    const int64_t xe = g.S[1] * g.S[2], oe = g.O[1] * g.O[2];
+    if (xe < 1 || oe < 1 || xe >= (1LL << 30) || oe >= (1LL << 30) || g.S[2] > 32000) return false;
+    if ((g.S[2] * es) % 16 != 0 || reinterpret_cast<uintptr_t>(x) % 16 != 0) return false;
+    if ((g.O[2] * es) % 16 != 0 || g.O[2] * es / 16 > kThreads || reinterpret_cast<uintptr_t>(out) % 16 != 0) return false;
+    if (!dense(g.xs, g.N, g.C, g.S) || !dense(g.os, g.N, g.C, g.O)) return false;
+    const int cpr = static_cast<int>(g.O[2] * es / 16), xppr = static_cast<int>(g.S[2] * es / 16);
+    int64_t R = kThreads / cpr;
+    if (R > g.O[1]) R = g.O[1];
+    if ((R + 1) * xppr > 4 * kThreads) return false;  // (heavy crops: few output chunks per source row)
+    const int64_t spp = (g.O[1] + R - 1) / R;
+    if (g.N * g.C * spp + 8 >= (1LL << 31)) return false;
+    // not taken automatically yet: at 8 KB per workgroup the per-workgroup prologue costs more than the sweep order returns
+    // (C5 forward 1.35 vs 1.10 ms of plane_gather_forward_lds, C2-tensor active forward 1.33 vs 1.10 ms)
+    return g_step_tune[2] == 2;
+}
+
+template <typename T>
+static void launch_step_forward_lds(const FwdParams &p, bool active, int pad, size_t lds, hipStream_t st) {
+    const dim3 grid(p.steps_per_xcd * 8), block(kThreads);
+#define SHIFTND_STEP_FWD_LDS(ACT, PADV) \
+    case PADV: hipLaunchKernelGGL((step_forward_lds<T, ACT, PADV>), grid, block, lds, st, p); break;
+    if (active) {
+        switch (pad) { SHIFTND_STEP_FWD_LDS(true, 0) SHIFTND_STEP_FWD_LDS(true, 1) SHIFTND_STEP_FWD_LDS(true, 2) SHIFTND_STEP_FWD_LDS(true, 3) default: SHIFTND_STEP_FWD_LDS(true, 4) }
+    } else {
+        switch (pad) { SHIFTND_STEP_FWD_LDS(false, 0) SHIFTND_STEP_FWD_LDS(false, 1) SHIFTND_STEP_FWD_LDS(false, 2) SHIFTND_STEP_FWD_LDS(false, 3) default: SHIFTND_STEP_FWD_LDS(false, 4) }
+    }
+#undef SHIFTND_STEP_FWD_LDS
+}
+
+int step_forward_lds(const Geometry &g, int dtype, const void *x, const void *w, int wkind, uint64_t fill_bits, void *out, hipStream_t st) {
+    const int es = dtype_size(dtype);
+    FwdParams p{};
+    p.x = x;
+    p.out = out;
+    p.w = w;
+    p.fill = fill_bits;
+    p.wkind = wkind;
+    p.C = static_cast<int>(g.C);
+    p.S1 = static_cast<int>(g.S[1]);
+    p.S2 = static_cast<int>(g.S[2]);
+    p.O1 = static_cast<int>(g.O[1]);
+    p.O2 = static_cast<int>(g.O[2]);
+    p.L1 = static_cast<int>(g.L[1]);
+    p.L2 = static_cast<int>(g.L[2]);
+    p.x_plane = g.S[1] * g.S[2];
+    p.o_plane = g.O[1] * g.O[2];
+    p.cpr = static_cast<int>(g.O[2] * es / 16);
+    p.xppr = static_cast<int>(g.S[2] * es / 16);
+    p.R = kThreads / p.cpr;
+    if (p.R > p.O1) p.R = p.O1;
+    p.spp = (p.O1 + p.R - 1) / p.R;
+    const uint64_t total = static_cast<uint64_t>(g.N) * g.C * p.spp;
+    p.total_steps = static_cast<uint32_t>(total);
+    p.steps_per_xcd = static_cast<uint32_t>((total + 7) / 8);
+    p.d_spp = make_fastdiv(static_cast<uint32_t>(p.spp));
+    p.d_C = make_fastdiv(static_cast<uint32_t>(p.C));
+    p.d_cpr = make_fastdiv(static_cast<uint32_t>(p.cpr));
+    p.d_xppr = make_fastdiv(static_cast<uint32_t>(p.xppr));
+    p.d_per1 = make_fastdiv(static_cast<uint32_t>(map_period(p.S1, g.pad)));
+    p.d_per2 = make_fastdiv(static_cast<uint32_t>(map_period(p.S2, g.pad)));
+    const bool active = g.active != 0;
+    const size_t lds = 64 + static_cast<size_t>(p.R + (active ? 1 : 0)) * p.xppr * 16 + 64;
+    note_kernel(active ? "step_active_forward" : "step_gather_forward_lds");
+    if (!active) {  // a raw copy of 2-byte elements: one instantiation serves fp16 and bf16
+        launch_step_forward_lds<f16_t>(p, false, g.pad, lds, st);
+        return SHIFTND_OK;
+    }
+    switch (dtype) {
+    case SHIFTND_F32: launch_step_forward_lds<f32_t>(p, true, g.pad, lds, st); break;
+    case SHIFTND_F64: launch_step_forward_lds<f64_t>(p, true, g.pad, lds, st); break;
+    case SHIFTND_F16: launch_step_forward_lds<f16_t>(p, true, g.pad, lds, st); break;
+    default: launch_step_forward_lds<bf16_t>(p, true, g.pad, lds, st); break;
+    }
     return SHIFTND_OK;
 }
 

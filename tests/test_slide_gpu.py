@@ -24,8 +24,9 @@ def abi():
     A.set_path_policy(0)
     A.set_tuning(12, 3)  # 2-D and 3-D problems slide
     A.set_tuning(32, 1)  # (the one-step kernels, which take 2-D problems first, have their own file: test_step_gpu.py)
+    A.set_tuning(34, 1)
     yield A
-    for k, v in ((12, -1), (13, 0), (14, 16), (32, 0)):
+    for k, v in ((12, -1), (13, 0), (14, 16), (32, 0), (34, 0)):
         A.set_tuning(k, v)
 
 

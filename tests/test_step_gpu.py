@@ -24,9 +24,10 @@ def abi():
     A.set_path_policy(0)
     A.set_tuning(32, 2)  # whenever eligible
     A.set_tuning(33, 2)
+    A.set_tuning(34, 2)
     yield A
-    A.set_tuning(32, 0)
-    A.set_tuning(33, 0)
+    for k in (32, 33, 34):
+        A.set_tuning(k, 0)
 
 
 SHAPES = [(3, 5, 9, 24), (2, 3, 40, 224), (5, 2, 33, 64), (1, 2, 300, 8), (2, 3, 1, 16), (7, 2, 6, 56), (1, 2, 7, 1000),
@@ -170,3 +171,42 @@ def test_gather_forward_quantized_int32_and_huge_weights(abi):
         out = abi.forward(torch.from_numpy(x).to(DEV), torch.from_numpy(w).to(DEV), pad, 0)
         assert abi.last_kernel() == "step_gather_forward"
         assert np.array_equal(out.cpu().numpy(), O.forward(x, w, pad, 0)), pad
+
+
+@pytest.mark.parametrize("dt", ["f32", "f64"])
+@pytest.mark.parametrize("shape,crop", FWD_SHAPES)
+def test_active_forward_vs_oracle(abi, shape, crop, dt):
+    """interpolating forward through LDS, crops included: fp32 / fp64 bit-exact (the reference's expression order)"""
+    rs = np.random.RandomState(sum(shape) * 3 + 4)
+    npdt = np.float32 if dt == "f32" else np.float64
+    x = rs.uniform(-1, 1, size=shape).astype(npdt)
+    w = _weights(rs, shape[1], 2, shape[2:]).astype(npdt)
+    b, new = abi.check_borders(list(shape), crop, 2)
+    if (new[-1] * x.itemsize) % 16 or (shape[-1] * x.itemsize) % 16 or new[-1] * x.itemsize > 4096:
+        pytest.skip("rows are not whole 16-byte pieces, or wider than one workgroup pass")
+    xd, wd = torch.from_numpy(x).to(DEV), torch.from_numpy(w).to(DEV)
+    for pad in range(5):
+        out = abi.forward(xd, wd, pad, 1, b)
+        assert abi.last_kernel() == "step_active_forward", (shape, abi.last_kernel())
+        assert np.array_equal(out.cpu().numpy(), O.forward(x, w, pad, 1, b)), (shape, crop, pad)
+
+
+@pytest.mark.parametrize("tdt", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("shape,crop", [((3, 5, 9, 24), None), ((2, 3, 40, 224), None), ((5, 2, 33, 64), [[1, 2], [8, 8]]),
+                                        ((1, 2, 300, 8), None), ((2, 2, 1, 16), None), ((2, 1, 5, 2048), None),
+                                        ((2, 3, 30, 48), [[2, 3], [8, 16]])])
+def test_16bit_forwards_vs_oracle(abi, shape, crop, tdt):
+    """2-byte elements: the sparse shift is a raw copy (bit-exact), interpolation within 1 ulp of the 16-bit type"""
+    rs = np.random.RandomState(sum(shape) + 29)
+    x16 = torch.from_numpy(rs.uniform(-1, 1, size=shape).astype(np.float32)).to(tdt)
+    w16 = torch.from_numpy(_weights(rs, shape[1], 2, shape[2:]).astype(np.float32)).to(tdt)
+    x, w = x16.float().numpy(), w16.float().numpy()
+    b, new = abi.check_borders(list(shape), crop, 2)
+    xd, wd = x16.to(DEV), w16.to(DEV)
+    for pad in range(5):
+        out = abi.forward(xd, wd, pad, 0, b)
+        assert abi.last_kernel() == "step_gather_forward_lds", (shape, abi.last_kernel())
+        assert torch.equal(out.cpu(), torch.from_numpy(O.forward(x, w, pad, 0, b)).to(tdt)), ("ssl", shape, pad)
+        out = abi.forward(xd, wd, pad, 1, b)
+        assert abi.last_kernel() == "step_active_forward", (shape, abi.last_kernel())
+        assert _ulp_close(out.cpu(), torch.from_numpy(O.forward(x, w, pad, 1, b)).to(tdt), tdt), ("active", shape, pad)

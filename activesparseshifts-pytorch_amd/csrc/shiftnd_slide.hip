@@ -17,12 +17,14 @@
 //   * staging goes global -> registers -> LDS, one step ahead: the loads of step t + 1 are in flight while step t is
 //     computed (LDS-DMA would make hipcc wait vmcnt(0) before the first LDS read of the compute phase).  Two LDS
 //     tiles alternate, one barrier per step.
-//   * rows are written to LDS displaced by 0..3 dwords (the channel's inner shift is the same for every thread of the
-//     workgroup), so every thread's window of E + 1 shifted columns starts at a 16-byte boundary: one ds_read_b128 +
-//     one ds_read_b32 per row, no bank conflicts between the lanes of a row; 16-bit types take one uniform funnel
-//     shift (v_alignbit) for the odd half.  Every row has zeroed guard bytes on both sides, so with zeros padding the
-//     columns outside the row read as 0 without a mask; chunks whose column map is not affine (edges of the wrapping
-//     / clamping paddings) read element by element through the LDS column map.
+//   * rows are staged exactly as they lie in memory (aligned 16-byte pieces behind a zeroed guard).  A thread's window
+//     of E + 1 shifted columns starts `phase` bytes into an aligned 32-byte span of its row; the phase is the same for
+//     every thread of the workgroup (one channel = one inner shift), so it is resolved by a uniform switch into
+//     compile-time register naming (RowRead / read_windows): two aligned ds_read_b128 per row, one v_alignbit per dword
+//     only for the odd half of 16-bit data.  Every row has zeroed guard bytes on both sides, so with zeros padding the
+//     columns outside the row read as 0 without a mask; chunks whose column map is not affine, or not congruent with
+//     the workgroup's phase (edges of the wrapping / clamping paddings), read element by element through the LDS
+//     column map.
 //
 // Reference behaviour restated (paths under torchshifts/csrc/ops/): backward kernels/shifts_kernels.h:222-327 with
 // kernels/interpolation.h:3-61, forward kernels/shifts_kernels.h:156-220; weight preparation cpu/shifts_cpu.cpp:223-224,
@@ -202,6 +204,7 @@ __device__ __forceinline__ void read_rows(const char *const (&slot)[NROWS], cons
 // displacement) or element-wise reads.
 template <int ES, int E>
 __device__ __forceinline__ RowRead make_rowread(const int *map, int ji, bool live, int delta /*bytes, 0..15*/, int row_bytes) {
+    (void)row_bytes;
     RowRead rr;
     int base = 0;
     bool found = false, affine = true;
@@ -221,8 +224,9 @@ __device__ __forceinline__ RowRead make_rowread(const int *map, int ji, bool liv
     if (found) {
         const int b0 = base * ES;                    // source byte of column 0 of the window (may be negative)
         affine = affine && ((b0 & 15) == delta);     // congruent with the workgroup's phase (else: element-wise)
-        w = b0 & ~15;                                // >= -16; the span ends at most 16 bytes behind the row
-        w = w < -kGuard ? -kGuard : (w > row_bytes - 16 ? row_bytes - 16 : w);
+        w = b0 & ~15;                                // >= -16 (base >= -E); the 32-byte span ends at most 16 bytes behind the
+                                                     // row, inside the guard: b0 <= row_bytes - ES, so w <= row_bytes - 16
+        w = w < -kGuard ? -kGuard : w;
     }
     rr.woff = kGuard + w;
     rr.affine = affine;

@@ -516,8 +516,9 @@ template <int ND> Tensor qshift_forward_hip(const Tensor &input_, const Tensor &
     // a channels-last input keeps its format (shifts_quantized.cpp:119-121).  Two tile transposes around the contiguous
     // kernel beat the channel-fastest kernel (N128 C512 56x56 quint8: 0.09 + 0.14 + 0.09 ms against 0.69 ms)
     bool via_transpose = cl && is_channels_last_dense(input_);
-    if (via_transpose) {  // 4-byte elements: the LDS-tiled channels-last kernel keeps the format in one pass
-        Tensor out_cl = at::_empty_affine_quantized(new_size, input_.options().memory_format(input_.suggest_memory_format()),
+    Tensor out_cl;  // the channels-last result: written by the LDS-tiled kernel, or by the layout change at the end
+    if (via_transpose) {  // the LDS-tiled channels-last kernel keeps the format in one pass
+        out_cl = at::_empty_affine_quantized(new_size, input_.options().memory_format(input_.suggest_memory_format()),
                                                     input_.q_scale(), input_.q_zero_point(), c10::nullopt);
         shiftnd_problem pd;
         fill_problem(pd, ND, input_, b, padding_mode, false, dtype);
@@ -546,9 +547,7 @@ template <int ND> Tensor qshift_forward_hip(const Tensor &input_, const Tensor &
                                              input.q_zero_point(), output.data_ptr(), os, current_stream(input));
     TORCH_CHECK(rc == SHIFTND_OK, "shiftnd_forward_quantized (HIP): ", shiftnd_status_string(rc));
     if (via_transpose && output.numel() > 0 && output.size(1) > 1) {
-        Tensor out_cl = at::_empty_affine_quantized(new_size, input_.options().memory_format(input_.suggest_memory_format()),
-                                                    input_.q_scale(), input_.q_zero_point(), c10::nullopt);
-        contiguous_to_channels_last(output, out_cl);
+        contiguous_to_channels_last(output, out_cl);  // (allocated above: one channels-last buffer per call either way)
         return out_cl;
     }
     return output;

@@ -96,11 +96,20 @@ class _QuantizedShiftMixin:
         if self.qweight_repr.dtype != want:  # load_state_dict copies INTO the existing buffer: give it the saved type
             self.qweight_repr = self.qweight_repr.to(want)
 
-    def _load_from_state_dict(self, state_dict, prefix, *args, **kwargs):
-        key = prefix + "qweight_repr"
+    def _load_from_state_dict(self, state_dict, prefix, local_metadata, strict, missing_keys, unexpected_keys, error_msgs):
+        key, extra = prefix + "qweight_repr", prefix + "_extra_state"
+        legacy = key not in state_dict and (prefix + "weight") in state_dict
         if key in state_dict and state_dict[key].dtype != self.qweight_repr.dtype:
             self.qweight_repr = torch.zeros_like(self.qweight_repr, dtype=state_dict[key].dtype)
-        super()._load_from_state_dict(state_dict, prefix, *args, **kwargs)
+        super()._load_from_state_dict(state_dict, prefix, local_metadata, strict, missing_keys, unexpected_keys, error_msgs)
+        if legacy:
+            # a checkpoint in the reference's layout (only the float `weight`: its `qweight` is a plain attribute that
+            # state_dict() drops, quantized/modules/shifts.py:17): the quantized weights are what from_float would make
+            # of the loaded float weights -- never the fresh module's initial shifts
+            self.qweight = quantize_shift_weights(self.weight.detach().float())
+            for k in (key, extra):
+                while k in missing_keys:
+                    missing_keys.remove(k)
 
     def forward(self, input):
         out = type(self)._qfunc(input, self.qweight, self.padding, self.cut_borders)

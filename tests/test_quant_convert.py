@@ -115,3 +115,31 @@ def test_quantized_module_equals_float_module_on_the_grid(cls, shape):
         assert out.is_quantized and out.shape == ref.shape
         # pooled values: ATen rounds the window mean to the grid (half to even)
         assert torch.equal(out.dequantize(), torch.round(ref)), (cls.__name__, emulate, big)
+
+
+def test_checkpoint_in_the_reference_layout_loads():
+    """A checkpoint that holds only the float `weight` (the reference's quantized modules keep `qweight` as a plain
+    attribute that state_dict() drops; round-1 checkpoints of this repo look the same): strict loading succeeds and the
+    quantized shifts follow the LOADED weights, not the fresh module's initial ones."""
+    torch.manual_seed(3)
+    for cls, qcls, nd in ((Shift1d, QMODS.Shift1d, 1), (Shift2d, QMODS.Shift2d, 2), (Shift3d, QMODS.Shift3d, 3)):
+        q = qcls(5, 'zeros')
+        w = torch.tensor([[2.0, -3.0, 1.0], [0.5, 1.5, -2.5], [-1.2, 4.4, 0.0], [7.0, -7.0, 3.3], [0.0, 0.0, 0.0]])[:, :nd]
+        legacy = {"weight": w.clone()}
+        missing = q.load_state_dict(legacy, strict=True)
+        assert not missing.missing_keys and not missing.unexpected_keys
+        want = torch.round(w).to(torch.int64)
+        got = q.qweight.int_repr().to(torch.int64) - q.qweight.q_zero_point()
+        assert torch.equal(got, want)
+        # inside a parent module too (prefix handling)
+        parent = nn.Sequential(qcls(5, 'zeros'))
+        parent.load_state_dict({"0.weight": w.clone()}, strict=True)
+        got = parent[0].qweight.int_repr().to(torch.int64) - parent[0].qweight.q_zero_point()
+        assert torch.equal(got, want)
+    # a current-format checkpoint still wins over re-derivation
+    q = QMODS.Shift2d(2, 'zeros')
+    q.qweight = torch.quantize_per_tensor(torch.tensor([[3.0, -2.0], [1.0, 0.0]]), 1.0, 128, torch.quint8)
+    sd = q.state_dict()
+    q2 = QMODS.Shift2d(2, 'zeros')
+    q2.load_state_dict(sd)
+    assert torch.equal(q2.qweight.int_repr(), q.qweight.int_repr())

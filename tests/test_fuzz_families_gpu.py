@@ -1,0 +1,31 @@
+"""A seeded, time-boxed slice of tools/fuzz_round2.py in the GPU suite: random shapes, paddings, shift kinds, launch-planning
+knobs and dtypes through the round-2 / round-3 kernel families (LDS-tiled channels-last, small planes / row bands, the
+byte kernel, the one-step kernels), every case against the CPU oracle (bit-exact gathers and fp32 / fp64 interpolation,
+1 ulp for 16-bit interpolation, grad_w 1e-5 / 16-bit epsilon of the fp64 evaluation).  The standalone tool runs the same
+cases for as long as asked."""
+import os
+import sys
+import time
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+
+
+@pytest.mark.parametrize("seed", [0, 1, 2])
+def test_random_cases_against_the_oracle(seed):
+    import fuzz_round2 as F
+    assert torch.cuda.is_available()
+    rs = np.random.RandomState(1000 + seed)
+    F.count.clear()
+    t0, n = time.time(), 0
+    while time.time() - t0 < 20.0 or n < 60:  # ~20 s per seed, at least 60 cases
+        F.CASES[n % len(F.CASES)](rs)
+        n += 1
+    kernels = set(F.count)
+    for must in ("cl_tiled_backward", "step_backward", "step_gather_forward"):
+        assert must in kernels, (must, dict(F.count))
+    assert any(k.startswith(("small_", "band_")) for k in kernels), dict(F.count)

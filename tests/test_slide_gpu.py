@@ -314,9 +314,10 @@ def test_tiled_channels_last_active_forward_vs_oracle(shape):
 @pytest.mark.parametrize("tdt", [torch.float16, torch.bfloat16])
 @pytest.mark.parametrize("shape", [(2, 8, 9, 12), (2, 72, 40, 70), (1, 64, 100, 33), (2, 16, 1, 50)])
 def test_tiled_channels_last_16bit_active_and_backward(shape, tdt):
-    """cl_tiled_active_forward / cl_tiled_backward for fp16 and bf16 (64 channels per workgroup, 2-byte stores): the same
-    bits as the contiguous kernels (one definition of the 16-bit interpolation, shiftnd_common.hpp interp_t), which the
-    oracle checks elsewhere; grad_w within the 16-bit epsilon"""
+    """cl_tiled_active_forward / cl_tiled_backward for fp16 and bf16 (64 channels per workgroup, 2-byte stores) against the
+    ORACLE (widened inputs, one rounding: interpolation within 1 ulp of the 16-bit type, the sparse shift's grad_x bit-exact,
+    grad_w within the 16-bit epsilon of the fp64 evaluation) -- and the same bits as the contiguous kernels (one definition
+    of the 16-bit interpolation, shiftnd_common.hpp interp_t)"""
     from torchshifts import abi
     rs = np.random.RandomState(sum(shape) + 13)
     cl = torch.channels_last
@@ -329,24 +330,36 @@ def test_tiled_channels_last_16bit_active_and_backward(shape, tdt):
     w[3] = [-2.75, -2.25]
     wd = torch.from_numpy(w).to(tdt).to(DEV)
     xc, goc = x.contiguous(memory_format=cl), go.contiguous(memory_format=cl)
+    xn, gn, wn = x.float().cpu().numpy(), go.float().cpu().numpy(), wd.float().cpu().numpy()
     eps = float(torch.finfo(tdt).eps)
     try:
         for band_rows in (0, 7):
             abi.set_tuning(21, band_rows)
             for pad in (0, 1, 3, 4):
                 ref = abi.forward(x, wd, pad, True)
+                # the oracle on the widened values, one rounding to the 16-bit type: the bar for every 16-bit kernel
+                ref_o = torch.from_numpy(O.forward(xn, wn, pad, True)).to(tdt)
                 out = abi.forward(xc, wd, pad, True)   # NCHW-contiguous output
                 nchw_tiled = (shape[3] * 2) % 4 == 0
                 assert (abi.last_kernel() == "cl_tiled_active_forward") == nchw_tiled and torch.equal(out, ref), (shape, pad)
+                assert _ulp_close(out.cpu(), ref_o, tdt), ("oracle", shape, pad)
                 out_cl = torch.empty(shape, dtype=tdt, device=DEV).contiguous(memory_format=cl)
                 abi.forward(xc, wd, pad, True, out=out_cl)
                 assert abi.last_kernel() == "cl_tiled_active_forward" and torch.equal(out_cl, ref), (shape, pad)
+                assert _ulp_close(out_cl.cpu(), ref_o, tdt), ("oracle", shape, pad)
                 for active in (0, 1):
                     gx_r, gw_r = abi.backward(go, wd, x, pad, active)
                     gx, gw = abi.backward(goc, wd, xc, pad, active, grad_x=torch.empty(shape, dtype=tdt, device=DEV).contiguous(memory_format=cl))
                     assert abi.last_kernel() == "cl_tiled_backward", (shape, pad, active)
                     assert torch.equal(gx, gx_r), (shape, pad, active, band_rows)
                     assert rel_err(gw.float().cpu().numpy(), gw_r.float().cpu().numpy()) < 4 * eps, (shape, pad, active)
+                    gx_o = torch.from_numpy(O.backward(gn, wn, xn, pad, active)[0]).to(tdt)
+                    if active:
+                        assert _ulp_close(gx.cpu(), gx_o, tdt), ("oracle gx", shape, pad)
+                    else:
+                        assert torch.equal(gx.cpu(), gx_o), ("oracle gx", shape, pad)
+                    _, gw64 = O.backward(gn.astype(np.float64), wn.astype(np.float64), xn.astype(np.float64), pad, active)
+                    assert rel_err(gw.float().cpu().numpy(), gw64) < 2 * eps, ("oracle gw", shape, pad, active)
     finally:
         abi.set_tuning(21, 0)
 

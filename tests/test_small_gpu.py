@@ -55,7 +55,8 @@ def test_small_planes_vs_oracle(abi, shape, dt):
 
 @pytest.mark.parametrize("tdt", [torch.float16, torch.bfloat16])
 def test_small_planes_16bit_agree_with_the_strided_kernels(abi, tdt):
-    """fp16 / bf16: the same bits as the one-thread-per-element kernels (one definition of the arithmetic)"""
+    """fp16 / bf16: within 1 ulp of the oracle (bit-exact for the sparse shift's raw copies), and the same bits as the
+    one-thread-per-element kernels (one definition of the arithmetic)"""
     torch.manual_seed(3)
     for shape in [(6, 8, 14, 14), (5, 7, 7, 7), (3, 4, 3, 5, 6)]:
         nd = len(shape) - 2
@@ -76,6 +77,13 @@ def test_small_planes_16bit_agree_with_the_strided_kernels(abi, tdt):
                 assert abi.last_kernel() == "small_plane_backward"
                 assert _ulp_close(gx.cpu(), gx_r.cpu(), tdt) if active else torch.equal(gx, gx_r)
                 assert rel_err(gw.float().cpu().numpy(), gw_r.float().cpu().numpy()) < 4 * float(torch.finfo(tdt).eps)
+                # ... and against the oracle itself (widened inputs, one rounding), not only against a sibling kernel
+                xn, gn, wn = x.float().cpu().numpy(), go.float().cpu().numpy(), w.float().cpu().numpy()
+                assert _ulp_close(out.cpu(), torch.from_numpy(O.forward(xn, wn, pad, 1)).to(tdt), tdt), (shape, pad)
+                gx_o = torch.from_numpy(O.backward(gn, wn, xn, pad, active)[0]).to(tdt)
+                assert _ulp_close(gx.cpu(), gx_o, tdt) if active else torch.equal(gx.cpu(), gx_o), (shape, pad, active)
+                _, gw64 = O.backward(gn.astype(np.float64), wn.astype(np.float64), xn.astype(np.float64), pad, active)
+                assert rel_err(gw.float().cpu().numpy(), gw64) < 2 * float(torch.finfo(tdt).eps), (shape, pad, active)
 
 
 def test_small_planes_full_batch(abi):
@@ -135,7 +143,8 @@ def test_row_bands_vs_oracle(abi, shape, dt):
 
 
 def test_row_bands_16bit_and_full_size(abi):
-    """bf16 against the one-thread-per-element kernels, and an odd-sized image batch at full size"""
+    """bf16 against the oracle and the one-thread-per-element kernels, and an odd-sized image batch at full size (oracle on
+    its first samples)"""
     torch.manual_seed(11)
     for shape, tdt in [((3, 8, 60, 151), torch.bfloat16), ((8, 64, 225, 225), torch.float32)]:
         x = torch.rand(shape, device=DEV).to(tdt)
@@ -152,6 +161,18 @@ def test_row_bands_16bit_and_full_size(abi):
             assert abi.last_kernel() == "band_plane_backward" and torch.equal(gx, gx_r)
             tol = 1e-5 if tdt == torch.float32 else 4 * float(torch.finfo(tdt).eps)
             assert rel_err(gw.float().cpu().numpy(), gw_r.float().cpu().numpy()) < tol
+            # the oracle itself on the first samples (all of the small bf16 case): 1 ulp of the 16-bit type / bit-exact
+            ns = 2 if shape[0] > 3 else shape[0]
+            xn, gn, wn = x[:ns].float().cpu().numpy(), go[:ns].float().cpu().numpy(), w.float().cpu().numpy()
+            ref_o = torch.from_numpy(O.forward(xn, wn, pad, 1)).to(tdt)
+            gx_o = torch.from_numpy(O.backward(gn, wn, xn, pad, active)[0]).to(tdt)
+            if tdt == torch.float32:
+                assert torch.equal(out[:ns].cpu(), ref_o) and torch.equal(gx[:ns].cpu(), gx_o), (shape, pad, active)
+            else:
+                assert _ulp_close(out[:ns].cpu(), ref_o, tdt), (shape, pad)
+                assert _ulp_close(gx[:ns].cpu(), gx_o, tdt) if active else torch.equal(gx[:ns].cpu(), gx_o), (shape, pad)
+                _, gw64 = O.backward(gn.astype(np.float64), wn.astype(np.float64), xn.astype(np.float64), pad, active)
+                assert rel_err(gw.float().cpu().numpy(), gw64) < 2 * float(torch.finfo(tdt).eps), (shape, pad, active)
 
 
 def test_row_band_gather_forward_vs_oracle(abi):

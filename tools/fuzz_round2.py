@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Randomised parity run of the round-2 kernel families against the oracle (GPU box):
+"""Randomised parity run of the round-2 / round-3 kernel families against the oracle (GPU box; a seeded, time-boxed slice of
+it runs in `pytest -m gpu`: tests/test_fuzz_families_gpu.py):
     python3 tools/fuzz_round2.py [--seconds 120] [--seed 0]
 channels-last tiled kernels (forward 1/2/4 bytes, active forward, backward), small-plane / row-band kernels, the byte
 kernel with rounds.  Prints the number of cases per kernel and stops at the first mismatch."""
@@ -119,6 +120,60 @@ def case_bytes(rs):
     abi.set_tuning(17, 0); abi.set_tuning(19, 0); abi.set_tuning(29, 0)
 
 
+def case_step(rs):
+    """round 3: the one-step kernels (shiftnd_step.hip) -- 2-D problems whose rows are whole 16-byte pieces, every float
+    dtype, forced through knobs 32-34; the forward also with crops"""
+    tdt = [torch.float32, torch.float64, torch.float16, torch.bfloat16][rs.randint(4)]
+    es = torch.empty(0, dtype=tdt).element_size()
+    per16 = 16 // es
+    H = int(rs.choice([1, 2, 5, 9, 18, 37, 64, 113]))
+    W = per16 * int(rs.choice([1, 2, 3, 7, 14, 28, 56, 64, 100, 256][: (10 if es < 8 else 9)]))
+    N, C = int(rs.randint(1, 4)), int(rs.randint(1, 6))
+    shape = (N, C, H, W)
+    pad = int(rs.randint(0, 5)); active = int(rs.randint(0, 2))
+    x32 = rs.uniform(-1, 1, size=shape); g32 = rs.uniform(-1, 1, size=shape)
+    xt, gt = torch.from_numpy(x32).to(tdt), torch.from_numpy(g32).to(tdt)
+    wt = torch.from_numpy(weights(rs, C, 2, shape[2:], 4.5)).to(tdt)
+    wide = np.float64 if tdt == torch.float64 else np.float32
+    x, go, w = xt.to(torch.float64).numpy().astype(wide), gt.to(torch.float64).numpy().astype(wide), wt.to(torch.float64).numpy().astype(wide)
+    xd, gd, wd = xt.to(DEV), gt.to(DEV), wt.to(DEV)
+    exact = tdt in (torch.float32, torch.float64)
+    from test_hip_parity import _ulp_close
+    for k in (32, 33, 34):
+        abi.set_tuning(k, 2)
+    try:
+        gx, gw = abi.backward(gd, wd, xd, pad, active)
+        assert abi.last_kernel() == "step_backward", (shape, tdt, abi.last_kernel())
+        count["step_backward"] += 1
+        gx_o = torch.from_numpy(O.backward(go, w, x, pad, active)[0]).to(tdt)
+        if exact or not active:
+            assert torch.equal(gx.cpu(), gx_o), ("step gx", shape, tdt, pad, active)
+        else:
+            assert _ulp_close(gx.cpu(), gx_o, tdt), ("step gx", shape, tdt, pad, active)
+        _, gw64 = O.backward(go.astype(np.float64), w.astype(np.float64), x.astype(np.float64), pad, active)
+        tol = {torch.float64: 1e-12, torch.float32: 1e-5}.get(tdt, 2 * float(torch.finfo(tdt).eps))
+        assert rel_err(gw.to(torch.float64).cpu().numpy(), gw64) < tol, ("step gw", shape, tdt, pad, active)
+        # forward, with a random crop that keeps the output rows whole 16-byte pieces
+        crop = None
+        if rs.randint(2) and H > 3 and W > 2 * per16:
+            crop = [[int(rs.randint(0, 2)), int(rs.randint(0, 2))], [per16 * int(rs.randint(0, 2)), per16 * int(rs.randint(0, 2))]]
+        b, new = abi.check_borders(list(shape), crop, 2)
+        o = abi.forward(xd, wd, pad, active, b)
+        count[abi.last_kernel()] += 1
+        assert abi.last_kernel().startswith("step_"), (shape, tdt, crop, abi.last_kernel())
+        ref = torch.from_numpy(O.forward(x, w, pad, active, b)).to(tdt)
+        if exact or not active:
+            assert torch.equal(o.cpu(), ref), ("step fwd", shape, tdt, pad, active, crop)
+        else:
+            assert _ulp_close(o.cpu(), ref, tdt), ("step fwd", shape, tdt, pad, active, crop)
+    finally:
+        for k in (32, 33, 34):
+            abi.set_tuning(k, 0)
+
+
+CASES = [case_cl, case_ragged, case_ragged, case_bytes, case_step, case_step]
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--seconds", type=float, default=120)
@@ -128,7 +183,7 @@ def main():
     t0 = time.time()
     n = 0
     while time.time() - t0 < a.seconds:
-        [case_cl, case_ragged, case_ragged, case_bytes][n % 4](rs)
+        CASES[n % len(CASES)](rs)
         n += 1
     print("cases", n, dict(count))
     print("fuzz ok")

@@ -33,16 +33,17 @@
 namespace shiftnd {
 namespace {
 
-// knobs (shiftnd_set_tuning 32..): [0] backward, [1] gather forward (direct loads), [2] forwards through LDS: 0 = automatic, 1 = never, 2 = whenever eligible
+// knobs (shiftnd_set_tuning 32..): [0] backward, [1] gather forward (direct loads), [2] forwards through LDS: 0 = automatic, 1 = never, 2 = whenever eligible; [3] 1 = 3-D backward too
 thread_local int g_step_tune[4] = {0, 0, 0, 0};
 
 struct ChanDesc {  // per channel, written by step_prep
-    int cx1;       // x row map:      m1[p] = fold_index(p - cx1, S1, pad)
-    int cg1;       // grad row map:   g1[p] = fold_index(p - cg1, S1, pad)
-    int scat;      // sparse shift: the row shift clamped to [-S1, S1] (0 when S1 == 1)
+    int cx0, cg0;  // plane maps (3-D; 0 for 2-D):  m0[p] = fold_index(p - cx0, S0, pad), g0[p] likewise with cg0
+    int cx1, cg1;  // row maps:                     m1[p] = fold_index(p - cx1, S1, pad), g1[p] likewise with cg1
     int cx2, cg2;  // the column maps' canonical shifts (zeros padding: the column state is two compares, no table)
-    int pad_[3];
-    double dw[2];  // fractions (dH, dW) of prep_shift_backward, exactly as the compute type holds them
+    int scat;      // 2-D sparse shift: the row shift clamped to [-S1, S1] (0 when S1 == 1)
+    int pad_;
+    double dw[3];  // fractions of prep_shift_backward per real dim, exactly as the compute type holds them
+    double pad2_;
 };
 
 struct StepParams {
@@ -54,12 +55,13 @@ struct StepParams {
     ChanDesc *desc;     // [C]
     int16_t *colx;      // [C][cpr][REC] column state of every chunk through the x column map
     int16_t *colg;      // ... through the grad column map
-    int64_t x_plane;    // elements per (n, c) plane
-    int wkind, N, C, pad;
-    int S1, S2;         // rows per plane, elements per row
+    int64_t x_plane;    // elements per (n, c) plane (2-D) / volume (3-D)
+    int wkind, N, C, pad, nd;
+    int S0, S1, S2;     // planes per volume (1 for 2-D), rows per plane, elements per row
     int cpr, R, spp;    // 16-byte chunks per row, rows per step, steps per plane
+    int spv;            // steps per (n, c): S0 * spp
     uint32_t total_steps, steps_per_xcd;
-    FastDiv d_spp, d_C, d_cpr, d_per1, d_per2;
+    FastDiv d_spp, d_spv, d_C, d_cpr, d_per0, d_per1, d_per2;
 };
 
 template <int E> struct RecSize { static constexpr int N = (E + 3 <= 8) ? 8 : 16; };  // int16 entries per record
@@ -77,27 +79,37 @@ __global__ __launch_bounds__(kThreads) void step_prep(const StepParams p) {
     constexpr int E = 16 / sizeof(S);
     constexpr int REC = RecSize<E>::N;
     const int c = blockIdx.x;
-    const CT wr = load_weight<CT>(p.w, p.wkind, static_cast<int64_t>(c) * 2 + 0);
-    const CT wc = load_weight<CT>(p.w, p.wkind, static_cast<int64_t>(c) * 2 + 1);
-    int64_t sr, sc;
-    CT dr, dc;
-    prep_shift_backward<CT>(wr, ACTIVE, sr, dr);
-    prep_shift_backward<CT>(wc, ACTIVE, sc, dc);
+    // real dim r of an nd-dim problem is normalised dim r + 3 - nd: (plane,) row, inner
+    const int lead = 3 - p.nd;
+    int64_t sh[3] = {0, 0, 0};
+    CT dw[3] = {CT(0), CT(0), CT(0)};
+    for (int r = 0; r < p.nd; ++r) {
+        const CT wv = load_weight<CT>(p.w, p.wkind, static_cast<int64_t>(c) * p.nd + r);
+        prep_shift_backward<CT>(wv, ACTIVE, sh[r + lead], dw[r]);
+    }
     // build_maps: x map with sign -1 -> canon_shift(sh); grad map with sign +1 (sparse) -> canon_shift(-sh), -1 (active)
-    const int cx1 = canon_shift(sr, p.S1, p.pad, p.d_per1), cx2 = canon_shift(sc, p.S2, p.pad, p.d_per2);
-    const int cg1 = canon_shift(ACTIVE ? sr : -sr, p.S1, p.pad, p.d_per1), cg2 = canon_shift(ACTIVE ? sc : -sc, p.S2, p.pad, p.d_per2);
+    const int cx0 = canon_shift(sh[0], p.S0, p.pad, p.d_per0), cx1 = canon_shift(sh[1], p.S1, p.pad, p.d_per1),
+              cx2 = canon_shift(sh[2], p.S2, p.pad, p.d_per2);
+    const int cg0 = canon_shift(ACTIVE ? sh[0] : -sh[0], p.S0, p.pad, p.d_per0),
+              cg1 = canon_shift(ACTIVE ? sh[1] : -sh[1], p.S1, p.pad, p.d_per1),
+              cg2 = canon_shift(ACTIVE ? sh[2] : -sh[2], p.S2, p.pad, p.d_per2);
     if (threadIdx.x == 0) {
         ChanDesc d;
+        d.cx0 = cx0;
+        d.cg0 = cg0;
         d.cx1 = cx1;
         d.cg1 = cg1;
-        d.scat = p.S1 == 1 ? 0 : static_cast<int>(sr > p.S1 ? p.S1 : (sr < -p.S1 ? -p.S1 : sr));
         d.cx2 = cx2;
         d.cg2 = cg2;
-        d.pad_[0] = d.pad_[1] = d.pad_[2] = 0;
-        d.dw[0] = static_cast<double>(dr);
-        d.dw[1] = static_cast<double>(dc);
+        d.scat = p.S1 == 1 ? 0 : static_cast<int>(sh[1] > p.S1 ? p.S1 : (sh[1] < -p.S1 ? -p.S1 : sh[1]));
+        d.pad_ = 0;
+        d.dw[0] = static_cast<double>(dw[0]);
+        d.dw[1] = static_cast<double>(dw[1]);
+        d.dw[2] = static_cast<double>(dw[2]);
+        d.pad2_ = 0.0;
         p.desc[c] = d;
     }
+    if (p.pad == 0) return;  // zeros padding: the step kernels fold the column state themselves
     for (int j = threadIdx.x; j < p.cpr; j += kThreads) {
 #pragma unroll
         for (int which = 0; which < 2; ++which) {
@@ -184,34 +196,47 @@ template <int PAD> __device__ __forceinline__ int canon_shift32(int s, int len, 
     }
 }
 
-template <typename T, bool ACTIVE, int PAD>
+template <typename T, int ND, bool ACTIVE, int PAD>
 __global__ __launch_bounds__(kThreads) void step_backward(const StepParams p) {
     using S = typename T::S;
     using CT = typename T::C;
     constexpr int E = 16 / sizeof(S);
     constexpr int REC = RecSize<E>::N;
-    constexpr bool SCAT = !ACTIVE;
-    constexpr int NDIFF = 2;
+    constexpr bool SCAT = !ACTIVE && ND == 2;  // 3-D sparse shift: gather form (one staged row per grad_x row)
+    constexpr int NDIFF = WDiff<ND>::N;
+    constexpr int NP = ND == 3 ? 2 : 1;        // planes a step's corners come from
+    constexpr int NCC = 1 << (ND - 1);         // corner rows per element
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char *tile = smem + 64;  // 64-byte pad: see lds_read_row
 
     const uint32_t bid = (blockIdx.x & 7u) * p.steps_per_xcd + (blockIdx.x >> 3);  // XCD-contiguous step ids
     if (bid >= p.total_steps) return;
-    const uint32_t plane = fdiv(bid, p.d_spp);
-    const int step = static_cast<int>(bid - plane * static_cast<uint32_t>(p.spp));
+    const uint32_t plane = fdiv(bid, p.d_spv);          // (n, c)
+    const uint32_t vstep = bid - plane * static_cast<uint32_t>(p.spv);
+    const int a = ND == 3 ? static_cast<int>(fdiv(vstep, p.d_spp)) : 0;
+    const int step = static_cast<int>(vstep) - a * p.spp;
     const int c = static_cast<int>(plane - fdiv(plane, p.d_C) * static_cast<uint32_t>(p.C));
     const ChanDesc d = p.desc[c];
-    const int R = p.R, S1 = p.S1, S2 = p.S2, cpr = p.cpr;
+    const int R = p.R, S0 = p.S0, S1 = p.S1, S2 = p.S2, cpr = p.cpr;
     const int b0 = step * R;
     const int Rn = min(R, S1 - b0);
-    const int NX = R + 1, NG = R;
-    const int npieces = (ACTIVE ? 3 * R + 2 : 2 * R + 1) * cpr;
+    // staged groups, in rows of the tile: X planes [NP][R + 1], G [R], GS: active [NP][R + 1], 3-D sparse [R], 2-D sparse none
+    const int NX = NP * (R + 1), NG = R;
+    const int NGS = ACTIVE ? NP * (R + 1) : (SCAT ? 0 : R);
+    const int npieces = (NX + NG + NGS) * cpr;
     const int RB = S2 * static_cast<int>(sizeof(S));
     const S *xp = static_cast<const S *>(p.x) + static_cast<int64_t>(plane) * p.x_plane;
     const S *gp = static_cast<const S *>(p.go) + static_cast<int64_t>(plane) * p.x_plane;
-    S *gxp = static_cast<S *>(p.out) + static_cast<int64_t>(plane) * p.x_plane;
+    S *gxp = static_cast<S *>(p.out) + static_cast<int64_t>(plane) * p.x_plane + static_cast<int64_t>(a) * S1 * S2;
+    // source planes of the corners (3-D; uniform): -1 = fill
+    int pax[NP], pag[NP];
+#pragma unroll
+    for (int h = 0; h < NP; ++h) {
+        pax[h] = ND == 3 ? row_map_t<PAD>(a + h, d.cx0, S0) : 0;
+        pag[h] = ND == 3 ? row_map_t<PAD>(a + h, d.cg0, S0) : 0;
+    }
 
-    // ---- the thread's chunk: column state through both maps (vector loads, consumed behind the barrier) -----------
+    // ---- the thread's chunk: column state through both maps -----------------------------------------------------
     const int tid = static_cast<int>(threadIdx.x);
     const int tr = static_cast<int>(fdiv(static_cast<uint32_t>(tid), p.d_cpr)), tc = tid - tr * cpr;
     const bool worker = tr < Rn;
@@ -229,7 +254,7 @@ __global__ __launch_bounds__(kThreads) void step_backward(const StepParams p) {
         };
         xm = affine_state(d.cx2);
         gm = affine_state(d.cg2);
-    } else {
+    } else {  // one vector load per map, consumed behind the barrier
         const size_t rec = (static_cast<size_t>(c) * cpr + tc) * REC;
         xm = load_colstate<E>(p.colx + rec);
         gm = load_colstate<E>(p.colg + rec);
@@ -248,69 +273,92 @@ __global__ __launch_bounds__(kThreads) void step_backward(const StepParams p) {
     };
     if (tr < R) {
         const int sx = tr <= Rn ? row_map_t<PAD>(b0 + tr, d.cx1, S1) : -1;  // corner rows of x: m1[b0 + tr]
-        if (sx >= 0) dma(xp, sx, tc, 0);
-        if (tr < Rn) dma(gp, b0 + tr, tc, NX * cpr);  // the incoming gradient at the rows themselves
+#pragma unroll
+        for (int h = 0; h < NP; ++h)
+            if (sx >= 0 && pax[h] >= 0) dma(xp, pax[h] * S1 + sx, tc, h * (R + 1) * cpr);
+        if (tr < Rn) dma(gp, a * S1 + b0 + tr, tc, NX * cpr);  // the incoming gradient at the rows themselves
         if constexpr (ACTIVE) {
             const int sg = tr <= Rn ? row_map_t<PAD>(b0 + tr, d.cg1, S1) : -1;  // the rows grad_x blends: g1[b0 + tr]
-            if (sg >= 0) dma(gp, sg, tc, (NX + NG) * cpr);
+#pragma unroll
+            for (int h = 0; h < NP; ++h)
+                if (sg >= 0 && pag[h] >= 0) dma(gp, pag[h] * S1 + sg, tc, (NX + NG + h * (R + 1)) * cpr);
+        } else if constexpr (!SCAT) {
+            const int sg = tr < Rn ? row_map_t<PAD>(b0 + tr, d.cg1, S1) : -1;  // 3-D sparse shift: the one row grad_x copies
+            if (sg >= 0 && pag[0] >= 0) dma(gp, pag[0] * S1 + sg, tc, (NX + NG) * cpr);
         }
     }
     if (Rn == R && tid < cpr) {  // the + 1 corner row of a full step (a ragged last step has it among its first R rows)
         const int sx = row_map_t<PAD>(b0 + R, d.cx1, S1);
-        if (sx >= 0) dma(xp, sx, tid, R * cpr);
+#pragma unroll
+        for (int h = 0; h < NP; ++h)
+            if (sx >= 0 && pax[h] >= 0) dma(xp, pax[h] * S1 + sx, tid, (h * (R + 1) + R) * cpr);
         if constexpr (ACTIVE) {
             const int sg = row_map_t<PAD>(b0 + R, d.cg1, S1);
-            if (sg >= 0) dma(gp, sg, tid, (NX + NG + R) * cpr);
+#pragma unroll
+            for (int h = 0; h < NP; ++h)
+                if (sg >= 0 && pag[h] >= 0) dma(gp, pag[h] * S1 + sg, tid, (NX + NG + h * (R + 1) + R) * cpr);
         }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
-    CT part[NDIFF] = {CT(0), CT(0)};
+    CT part[NDIFF];
+#pragma unroll
+    for (int i = 0; i < NDIFF; ++i) part[i] = CT(0);
     if (worker) {
         const int b = b0 + tr;
-        CT dw[2] = {static_cast<CT>(d.dw[0]), static_cast<CT>(d.dw[1])};
+        CT dw[3] = {static_cast<CT>(d.dw[0]), static_cast<CT>(d.dw[1]), static_cast<CT>(d.dw[2])};
         Chunk<S, E> res;
         // only zeros padding has rows without a source
         auto row_valid = [&](int pr, int cs) { return PAD != 0 || row_map_t<PAD>(pr, cs, S1) >= 0; };
+        // corner row k of an element: bit 0 = + 1 plane (3-D), next bit = + 1 row
+        auto corner_plane = [](int k) { return ND == 3 ? (k & 1) : 0; };
+        auto corner_row = [](int k) { return ND == 3 ? ((k >> 1) & 1) : (k & 1); };
         // ---- grad_x ----------------------------------------------------------------------------------------------
         if constexpr (ACTIVE) {
-            CT gv[2][E + 1];
+            CT gv[NCC][E + 1];
 #pragma unroll
-            for (int hb = 0; hb < 2; ++hb) {
+            for (int k = 0; k < NCC; ++k) {
+                const int ha = corner_plane(k), hb = corner_row(k);
                 S raw[E + 1];
-                lds_read_row<S, E>(tile + (NX + NG + tr + hb) * RB, row_valid(b + hb, d.cg1), gm, raw);
+                lds_read_row<S, E>(tile + (NX + NG + ha * (R + 1) + tr + hb) * RB, pag[ha] >= 0 && row_valid(b + hb, d.cg1), gm, raw);
 #pragma unroll
-                for (int e = 0; e <= E; ++e) gv[hb][e] = widen<T>(raw[e]);
+                for (int e = 0; e <= E; ++e) gv[k][e] = widen<T>(raw[e]);
             }
 #pragma unroll
             for (int e = 0; e < E; ++e) {
-                const CT v[4] = {gv[0][e], gv[1][e], gv[0][e + 1], gv[1][e + 1]};
-                res.e[e] = narrow<T>(interp_t<T, 2>(v, dw));
+                CT v[1 << ND];
+#pragma unroll
+                for (int q = 0; q < (1 << ND); ++q) v[q] = gv[q & (NCC - 1)][e + (q >> (ND - 1))];
+                res.e[e] = narrow<T>(interp_t<T, ND>(v, dw));
             }
         } else {
-            // the staged grad_out row b, read through the column map, IS a grad_x row (which one: below)
+            // 2-D: the staged grad_out row b, read through the column map, IS a grad_x row (which one: below);
+            // 3-D: the staged row g1[b] of plane g0[a]
             S graw[E + 1];
-            lds_read_row<S, E>(tile + (NX + tr) * RB, true, gm, graw);
+            const bool gvalid = SCAT || (pag[0] >= 0 && row_valid(b, d.cg1));
+            lds_read_row<S, E>(tile + ((SCAT ? NX : NX + NG) + tr) * RB, gvalid, gm, graw);
 #pragma unroll
             for (int e = 0; e < E; ++e) res.e[e] = graw[e];
         }
         // ---- weight-gradient sums from the x corners and the incoming gradient --------------------------------------
-        CT xv[2][E + 1];
+        CT xv[NCC][E + 1];
 #pragma unroll
-        for (int hb = 0; hb < 2; ++hb) {
+        for (int k = 0; k < NCC; ++k) {
+            const int ha = corner_plane(k), hb = corner_row(k);
             S raw[E + 1];
-            lds_read_row<S, E>(tile + (tr + hb) * RB, row_valid(b + hb, d.cx1), xm, raw);
+            lds_read_row<S, E>(tile + (ha * (R + 1) + tr + hb) * RB, pax[ha] >= 0 && row_valid(b + hb, d.cx1), xm, raw);
 #pragma unroll
-            for (int e = 0; e <= E; ++e) xv[hb][e] = widen<T>(raw[e]);
+            for (int e = 0; e <= E; ++e) xv[k][e] = widen<T>(raw[e]);
         }
         Chunk<S, E> gch;
         __builtin_memcpy(gch.e, __builtin_assume_aligned(tile + (NX + tr) * RB + ji * static_cast<int>(sizeof(S)), 16), 16);
 #pragma unroll
         for (int e = 0; e < E; ++e) {
-            const CT v[4] = {xv[0][e], xv[1][e], xv[0][e + 1], xv[1][e + 1]};
-            CT df[NDIFF];
-            corner_diffs<2, CT>(v, df);
+            CT v[1 << ND], df[NDIFF];
+#pragma unroll
+            for (int q = 0; q < (1 << ND); ++q) v[q] = xv[q & (NCC - 1)][e + (q >> (ND - 1))];
+            corner_diffs<ND, CT>(v, df);
             const CT gval = widen<T>(gch.e[e]);
 #pragma unroll
             for (int i = 0; i < NDIFF; ++i) part[i] = fma_ct(gval, df[i], part[i]);
@@ -349,17 +397,17 @@ __global__ __launch_bounds__(kThreads) void step_backward(const StepParams p) {
     }
     // ---- this step's sums: DPP tree per wave, the four waves added in fp64 by one thread ----------------------------
     double *scratch = reinterpret_cast<double *>(tile + ((npieces * 16 + 63) & ~63));
-    const CT t0 = wave_total(part[0]), t1 = wave_total(part[1]);
-    if ((tid & 63) == 63) {
-        scratch[2 * wave] = static_cast<double>(t0);
-        scratch[2 * wave + 1] = static_cast<double>(t1);
+#pragma unroll
+    for (int i = 0; i < NDIFF; ++i) {
+        const CT t = wave_total(part[i]);
+        if ((tid & 63) == 63) scratch[NDIFF * wave + i] = static_cast<double>(t);
     }
     __syncthreads();
     if (tid < NDIFF) {
-        double a = 0.0;
+        double acc = 0.0;
 #pragma unroll
-        for (int w = 0; w < kThreads / 64; ++w) a += scratch[2 * w + tid];
-        p.partials[static_cast<size_t>(bid) * NDIFF + tid] = a;
+        for (int w = 0; w < kThreads / 64; ++w) acc += scratch[NDIFF * w + tid];
+        p.partials[static_cast<size_t>(bid) * NDIFF + tid] = acc;
     }
 }
 
@@ -599,34 +647,38 @@ __global__ __launch_bounds__(kThreads) void step_forward_lds(const FwdParams p) 
     store_chunk<S, E>(op + static_cast<int64_t>(b) * p.O2 + jo, res);
 }
 
-// grad_w[c][0..1] = blend(sum over the steps of channel c, in a fixed order)
-template <typename T>
+// grad_w[c][0..nd-1] = blend(sum over the steps of channel c, in a fixed order)
+template <typename T, int ND>
 __global__ __launch_bounds__(kThreads) void step_reduce(const StepParams p, typename T::S *__restrict__ grad_w) {
+    constexpr int NDIFF = WDiff<ND>::N;
     __shared__ double scratch[kThreads / 64];
     const int c = blockIdx.x;
-    const uint32_t per_channel = static_cast<uint32_t>(p.N) * static_cast<uint32_t>(p.spp);
-    double a0 = 0.0, a1 = 0.0;
-    for (uint32_t i = threadIdx.x; i < per_channel; i += kThreads) {
-        const uint32_t n = fdiv(i, p.d_spp);
-        const uint32_t st = i - n * static_cast<uint32_t>(p.spp);
-        const double *q = p.partials + ((static_cast<size_t>(n) * p.C + c) * p.spp + st) * 2;
-        a0 += q[0];
-        a1 += q[1];
-    }
-    a0 = block_sum(a0, scratch);
-    a1 = block_sum(a1, scratch);
-    if (threadIdx.x == 0) {
-        const double dsum[2] = {a0, a1};
-        const double dwd[3] = {p.desc[c].dw[0], p.desc[c].dw[1], 0.0};
-        double acc[3] = {0.0, 0.0, 0.0};
-        blend_diffs<2>(dsum, dwd, acc);
+    const uint32_t per_channel = static_cast<uint32_t>(p.N) * static_cast<uint32_t>(p.spv);
+    double acc[NDIFF];
 #pragma unroll
-        for (int s = 0; s < 2; ++s) {
-            if constexpr (sizeof(typename T::S) == 8) grad_w[c * 2 + s] = acc[s];
-            else grad_w[c * 2 + s] = narrow<T>(static_cast<float>(acc[s]));
+    for (int i = 0; i < NDIFF; ++i) acc[i] = 0.0;
+    for (uint32_t i = threadIdx.x; i < per_channel; i += kThreads) {
+        const uint32_t n = fdiv(i, p.d_spv);
+        const uint32_t st = i - n * static_cast<uint32_t>(p.spv);
+        const double *q = p.partials + ((static_cast<size_t>(n) * p.C + c) * p.spv + st) * NDIFF;
+#pragma unroll
+        for (int k = 0; k < NDIFF; ++k) acc[k] += q[k];
+    }
+    double dsum[NDIFF];
+#pragma unroll
+    for (int k = 0; k < NDIFF; ++k) dsum[k] = block_sum(acc[k], scratch);
+    if (threadIdx.x == 0) {
+        const double dwd[3] = {p.desc[c].dw[0], p.desc[c].dw[1], p.desc[c].dw[2]};
+        double out[3] = {0.0, 0.0, 0.0};
+        blend_diffs<ND>(dsum, dwd, out);
+#pragma unroll
+        for (int s = 0; s < ND; ++s) {
+            if constexpr (sizeof(typename T::S) == 8) grad_w[c * ND + s] = out[s];
+            else grad_w[c * ND + s] = narrow<T>(static_cast<float>(out[s]));
         }
     }
 }
+
 
 // ---------------------------------------------------------------------------------------------------------------------
 // host side
@@ -642,7 +694,7 @@ bool dense(const int64_t st[5], int64_t N, int64_t C, const int64_t sz[3]) {
 }
 
 struct StepLayout {
-    int cpr, R, spp, rec;
+    int cpr, R, spp, spv, rec, ndiff;
     uint64_t total_steps;
     size_t off_desc, off_colx, off_colg, bytes;
 };
@@ -655,24 +707,31 @@ StepLayout step_layout(const Geometry &g, int es) {
     L.R = kThreads / L.cpr < 1 ? 1 : kThreads / L.cpr;
     if (L.R > g.S[1]) L.R = static_cast<int>(g.S[1] > 0 ? g.S[1] : 1);
     L.spp = static_cast<int>((g.S[1] + L.R - 1) / L.R);
+    L.spv = static_cast<int>(g.S[0]) * L.spp;
     L.rec = (E + 3 <= 8) ? 8 : 16;
-    L.total_steps = static_cast<uint64_t>(g.N) * g.C * L.spp;
+    L.ndiff = g.nd == 3 ? 8 : 2;
+    L.total_steps = static_cast<uint64_t>(g.N) * g.C * L.spv;
     auto up = [](size_t v) { return (v + 255) & ~static_cast<size_t>(255); };
-    L.off_desc = up(L.total_steps * 2 * sizeof(double));
+    L.off_desc = up(L.total_steps * L.ndiff * sizeof(double));
     L.off_colx = L.off_desc + up(static_cast<size_t>(g.C) * sizeof(ChanDesc));
     L.off_colg = L.off_colx + up(static_cast<size_t>(g.C) * L.cpr * L.rec * sizeof(int16_t));
     L.bytes = L.off_colg + up(static_cast<size_t>(g.C) * L.cpr * L.rec * sizeof(int16_t));
     return L;
 }
 
-template <typename T>
+size_t step_lds_bytes(const StepLayout &L, int nd, bool active) {
+    const int np = nd == 3 ? 2 : 1;
+    const int slots = np * (L.R + 1) + L.R + (active ? np * (L.R + 1) : (nd == 3 ? L.R : 0));
+    return 64 + ((static_cast<size_t>(slots) * L.cpr * 16 + 63) & ~static_cast<size_t>(63)) + (kThreads / 64) * L.ndiff * sizeof(double);
+}
+
+template <typename T, int ND>
 int launch_step_backward(StepParams &p, const StepLayout &L, bool active, void *gw, hipStream_t st) {
     using S = typename T::S;
-    const int slots = active ? 3 * L.R + 2 : 2 * L.R + 1;
-    const size_t lds = 64 + ((static_cast<size_t>(slots) * L.cpr * 16 + 63) & ~static_cast<size_t>(63)) + (kThreads / 64) * 2 * sizeof(double);
+    const size_t lds = step_lds_bytes(L, ND, active);
     const dim3 grid(p.steps_per_xcd * 8), block(kThreads);
 #define SHIFTND_STEP_PAD(ACT, PADV) \
-    case PADV: hipLaunchKernelGGL((step_backward<T, ACT, PADV>), grid, block, lds, st, p); break;
+    case PADV: hipLaunchKernelGGL((step_backward<T, ND, ACT, PADV>), grid, block, lds, st, p); break;
     if (active) {
         hipLaunchKernelGGL((step_prep<T, true>), dim3(p.C), block, 0, st, p);
         switch (p.pad) { SHIFTND_STEP_PAD(true, 0) SHIFTND_STEP_PAD(true, 1) SHIFTND_STEP_PAD(true, 2) SHIFTND_STEP_PAD(true, 3) default: SHIFTND_STEP_PAD(true, 4) }
@@ -681,7 +740,7 @@ int launch_step_backward(StepParams &p, const StepLayout &L, bool active, void *
         switch (p.pad) { SHIFTND_STEP_PAD(false, 0) SHIFTND_STEP_PAD(false, 1) SHIFTND_STEP_PAD(false, 2) SHIFTND_STEP_PAD(false, 3) default: SHIFTND_STEP_PAD(false, 4) }
     }
 #undef SHIFTND_STEP_PAD
-    hipLaunchKernelGGL((step_reduce<T>), dim3(p.C), block, 0, st, p, static_cast<S *>(gw));
+    hipLaunchKernelGGL((step_reduce<T, ND>), dim3(p.C), block, 0, st, p, static_cast<S *>(gw));
     return SHIFTND_OK;
 }
 
@@ -691,24 +750,24 @@ void step_set_tuning(int knob, int value) {
     if (knob >= 0 && knob < 4) g_step_tune[knob] = value;
 }
 
-// contiguous 2-D problems without crop whose rows are whole 16-byte pieces and at most one workgroup pass wide
+// contiguous 2-D / 3-D problems without crop whose rows are whole 16-byte pieces and at most one workgroup pass wide
 bool step_backward_eligible(const Geometry &g, int dtype, const void *go, const void *x, const void *gx) {
     if (g_step_tune[0] == 1) return false;
-    if (dtype > SHIFTND_BF16 || g.nd != 2 || g.K[0] > 0) return false;
+    if (dtype > SHIFTND_BF16 || (g.nd != 2 && g.nd != 3) || g.K[0] > 0) return false;
     const int es = dtype_size(dtype);
     for (int d = 0; d < 3; ++d)
         if (g.O[d] != g.S[d] || g.L[d] != 0) return false;
-    if (g.S[0] != 1 || g.S[1] < 1 || g.S[2] < 1) return false;
+    if ((g.nd == 2 && g.S[0] != 1) || g.S[0] < 1 || g.S[1] < 1 || g.S[2] < 1) return false;
     if ((g.S[2] * es) % 16 != 0 || g.S[2] * es / 16 > kThreads || g.S[2] > 32000) return false;
-    if (g.S[1] * g.S[2] >= (1LL << 30)) return false;
+    if (g.S[0] * g.S[1] * g.S[2] >= (1LL << 30)) return false;
     if (!dense(g.xs, g.N, g.C, g.S) || !dense(g.os, g.N, g.C, g.O) || !dense(g.gs, g.N, g.C, g.S)) return false;
     if (reinterpret_cast<uintptr_t>(go) % 16 || reinterpret_cast<uintptr_t>(x) % 16 || reinterpret_cast<uintptr_t>(gx) % 16) return false;
     const StepLayout L = step_layout(g, es);
     if (L.total_steps + 8 >= (1ull << 31)) return false;
+    if (step_lds_bytes(L, g.nd, g.active != 0) > 64 * 1024) return false;
     if (g_step_tune[0] == 2) return true;
-    return true;
+    return g.nd == 2 || g_step_tune[3] == 1;  // 3-D: knob 35 = 1
 }
-
 
 // sparse-shift / quantized forward of 4- and 8-byte elements: dense tensors, output rows of whole 16-byte chunks and at
 // most one workgroup pass wide (crops are fine: a gather)
@@ -864,7 +923,7 @@ int step_forward_lds(const Geometry &g, int dtype, const void *x, const void *w,
 }
 
 size_t step_backward_workspace(const Geometry &g, int dtype) {
-    if (dtype > SHIFTND_BF16 || g.nd != 2) return 0;
+    if (dtype > SHIFTND_BF16 || (g.nd != 2 && g.nd != 3)) return 0;
     return step_layout(g, dtype_size(dtype)).bytes;
 }
 
@@ -882,30 +941,38 @@ int step_backward(const Geometry &g, int dtype, const void *go, const void *x, c
     p.desc = reinterpret_cast<ChanDesc *>(ws + L.off_desc);
     p.colx = reinterpret_cast<int16_t *>(ws + L.off_colx);
     p.colg = reinterpret_cast<int16_t *>(ws + L.off_colg);
-    p.x_plane = g.S[1] * g.S[2];
+    p.x_plane = g.S[0] * g.S[1] * g.S[2];
     p.wkind = dtype;
     p.N = static_cast<int>(g.N);
     p.C = static_cast<int>(g.C);
     p.pad = g.pad;
+    p.nd = g.nd;
+    p.S0 = static_cast<int>(g.S[0]);
     p.S1 = static_cast<int>(g.S[1]);
     p.S2 = static_cast<int>(g.S[2]);
     p.cpr = L.cpr;
     p.R = L.R;
     p.spp = L.spp;
+    p.spv = L.spv;
     p.total_steps = static_cast<uint32_t>(L.total_steps);
     p.steps_per_xcd = static_cast<uint32_t>((L.total_steps + 7) / 8);
     p.d_spp = make_fastdiv(static_cast<uint32_t>(L.spp));
+    p.d_spv = make_fastdiv(static_cast<uint32_t>(L.spv));
     p.d_C = make_fastdiv(static_cast<uint32_t>(p.C));
     p.d_cpr = make_fastdiv(static_cast<uint32_t>(L.cpr));
+    p.d_per0 = make_fastdiv(static_cast<uint32_t>(map_period(p.S0, g.pad)));
     p.d_per1 = make_fastdiv(static_cast<uint32_t>(map_period(p.S1, g.pad)));
     p.d_per2 = make_fastdiv(static_cast<uint32_t>(map_period(p.S2, g.pad)));
     note_kernel("step_backward");
+    const bool active = g.active != 0;
+#define SHIFTND_STEP_T(TT) (g.nd == 3 ? launch_step_backward<TT, 3>(p, L, active, gw, st) : launch_step_backward<TT, 2>(p, L, active, gw, st))
     switch (dtype) {
-    case SHIFTND_F32: return launch_step_backward<f32_t>(p, L, g.active != 0, gw, st);
-    case SHIFTND_F64: return launch_step_backward<f64_t>(p, L, g.active != 0, gw, st);
-    case SHIFTND_F16: return launch_step_backward<f16_t>(p, L, g.active != 0, gw, st);
-    default: return launch_step_backward<bf16_t>(p, L, g.active != 0, gw, st);
+    case SHIFTND_F32: return SHIFTND_STEP_T(f32_t);
+    case SHIFTND_F64: return SHIFTND_STEP_T(f64_t);
+    case SHIFTND_F16: return SHIFTND_STEP_T(f16_t);
+    default: return SHIFTND_STEP_T(bf16_t);
     }
+#undef SHIFTND_STEP_T
 }
 
 }  // namespace shiftnd

@@ -90,6 +90,11 @@ int forward_common(const shiftnd_problem *p, const void *x, const int64_t *xs, c
         // (interpolating problems keep the LDS-staged plane kernels whenever those take them: see DESIGN 3.14)
         const bool interpolating = g.active && p->dtype <= SHIFTND_BF16;
         const bool prefer_sweep = (out_plane_bytes >= 32 * 1024 && !interpolating && !(can_plane && plane_forward_lds_gather(g, p->dtype, x, out))) || !can_plane;
+        // 2-D sparse shift / quantized forward as a linear sweep of one-step workgroups
+        if (g_policy == 0 && step_forward_eligible(g, p->dtype, x, out)) {
+            g_last_path = SHIFTND_PATH_SWEEP;
+            return finish(step_forward(g, p->dtype, x, w, wkind, wzp, fill, out, st));
+        }
         // 1-byte (and, knob 28, 2-byte) rows of whole 16-byte pieces beyond the byte kernel's small planes: rows through LDS
         if (g_policy == 0 && !bytes_forward_eligible(g, p->dtype, x, out) && rows_forward_eligible(g, p->dtype, x, out)) {
             g_last_path = SHIFTND_PATH_PLANE;
@@ -105,10 +110,6 @@ int forward_common(const shiftnd_problem *p, const void *x, const int64_t *xs, c
         if (g_policy == 0 && wkind <= SHIFTND_BF16 && step_forward_lds_eligible(g, p->dtype, x, out)) {
             g_last_path = SHIFTND_PATH_SWEEP;
             return finish(step_forward_lds(g, p->dtype, x, w, wkind, fill, out, st));
-        }
-        if (g_policy == 0 && step_forward_eligible(g, p->dtype, x, out)) {
-            g_last_path = SHIFTND_PATH_SWEEP;
-            return finish(step_forward(g, p->dtype, x, w, wkind, wzp, fill, out, st));
         }
         if (can_sweep && (g_policy == 3 || (g_policy == 0 && prefer_sweep))) {
             g_last_path = SHIFTND_PATH_SWEEP;

@@ -419,6 +419,82 @@ __global__ __launch_bounds__(kThreads) void step_backward(const StepParams p) {
 // at the shifted position (gfx950 global loads take any alignment) and stores it; the padding mode is a template
 // parameter, the channel's shifts come from one scalar load of its weights.
 // ---------------------------------------------------------------------------------------------------------------------
+// the two weights of channel c (row dim, inner dim) widened to the compute type, through the scalar cache
+template <typename CT> __device__ __forceinline__ void load_weights2(const void *w, int wkind, int c, CT &wr, CT &wc) {
+    const uintptr_t base = reinterpret_cast<uintptr_t>(w);
+    if (wkind == SHIFTND_F64) {
+        const __attribute__((address_space(4))) double *q = reinterpret_cast<const __attribute__((address_space(4))) double *>(base) + static_cast<int64_t>(c) * 2;
+        wr = static_cast<CT>(q[0]);
+        wc = static_cast<CT>(q[1]);
+    } else if (wkind == SHIFTND_F16 || wkind == SHIFTND_BF16) {
+        const uint32_t word = (reinterpret_cast<const __attribute__((address_space(4))) uint32_t *>(base))[c];
+        const uint16_t lo = static_cast<uint16_t>(word), hi = static_cast<uint16_t>(word >> 16);
+        if (wkind == SHIFTND_F16) {
+            wr = static_cast<CT>(__builtin_bit_cast(_Float16, lo));
+            wc = static_cast<CT>(__builtin_bit_cast(_Float16, hi));
+        } else {
+            wr = static_cast<CT>(__builtin_bit_cast(float, static_cast<uint32_t>(lo) << 16));
+            wc = static_cast<CT>(__builtin_bit_cast(float, static_cast<uint32_t>(hi) << 16));
+        }
+    } else {
+        const __attribute__((address_space(4))) float *q = reinterpret_cast<const __attribute__((address_space(4))) float *>(base) + static_cast<int64_t>(c) * 2;
+        wr = static_cast<CT>(q[0]);
+        wc = static_cast<CT>(q[1]);
+    }
+}
+
+// canonical shift of an integral shift held in the compute type: 32-bit arithmetic below 2^30, the 64-bit form beyond
+template <int PAD, typename CT> __device__ __forceinline__ int canon_of(CT r, int len, const FastDiv &dper) {
+    if (r > CT(-1073741824) && r < CT(1073741824)) return canon_shift32<PAD>(static_cast<int>(r), len, dper);
+    return canon_shift(static_cast<int64_t>(r), len, PAD, dper);
+}
+
+// the two canonical shifts of channel c for the gather kernels (sparse shift: round half to even; quantized: int_repr minus
+// zero point, kernels/shifts_kernels.h:553-555), every weight dtype through the scalar cache
+template <int PAD>
+__device__ __forceinline__ void channel_shifts2(const void *w, int wkind, int64_t wzp, int c, int S1, int S2, const FastDiv &d1,
+                                                const FastDiv &d2, int &cs1, int &cs2) {
+    if (wkind <= SHIFTND_BF16) {
+        if (wkind == SHIFTND_F64) {
+            double wr, wc;
+            load_weights2<double>(w, wkind, c, wr, wc);
+            cs1 = canon_of<PAD, double>(rint(wr), S1, d1);
+            cs2 = canon_of<PAD, double>(rint(wc), S2, d2);
+        } else {
+            float wr, wc;
+            load_weights2<float>(w, wkind, c, wr, wc);
+            cs1 = canon_of<PAD, float>(rintf(wr), S1, d1);
+            cs2 = canon_of<PAD, float>(rintf(wc), S2, d2);
+        }
+    } else {
+        const uintptr_t base = reinterpret_cast<uintptr_t>(w);
+        int64_t r1, r2;
+        if (wkind == SHIFTND_I32) {
+            const __attribute__((address_space(4))) int32_t *q = reinterpret_cast<const __attribute__((address_space(4))) int32_t *>(base) + static_cast<int64_t>(c) * 2;
+            r1 = q[0];
+            r2 = q[1];
+        } else {  // two bytes at byte offset 2 c: the aligned dword that holds them
+            const uintptr_t at = base + static_cast<uintptr_t>(c) * 2;
+            const uint32_t word = *reinterpret_cast<const __attribute__((address_space(4))) uint32_t *>(at & ~static_cast<uintptr_t>(3));
+            const uint32_t pair = word >> ((at & 2) * 8);
+            if (wkind == SHIFTND_I8) {
+                r1 = static_cast<int8_t>(pair & 0xff);
+                r2 = static_cast<int8_t>((pair >> 8) & 0xff);
+            } else {
+                r1 = pair & 0xff;
+                r2 = (pair >> 8) & 0xff;
+            }
+        }
+        r1 -= wzp;
+        r2 -= wzp;
+        const bool small = r1 > -1073741824 && r1 < 1073741824 && r2 > -1073741824 && r2 < 1073741824;
+        cs1 = small ? canon_shift32<PAD>(static_cast<int>(r1), S1, d1) : canon_shift(r1, S1, PAD, d1);
+        cs2 = small ? canon_shift32<PAD>(static_cast<int>(r2), S2, d2) : canon_shift(r2, S2, PAD, d2);
+    }
+    cs1 = __builtin_amdgcn_readfirstlane(cs1);
+    cs2 = __builtin_amdgcn_readfirstlane(cs2);
+}
+
 struct GatherParams {  // 2-D problems: rows x inner, one weight per dim
     const void *x;
     void *out;
@@ -429,6 +505,7 @@ struct GatherParams {  // 2-D problems: rows x inner, one weight per dim
     int wkind, C;
     int S1, S2, O1, O2, L1, L2;
     int cpr, R, spp;
+    int xppr;   // 16-byte pieces per source row (the small-element kernel)
     uint32_t total_steps, steps_per_xcd;
     FastDiv d_spp, d_C, d_cpr, d_per1, d_per2;
 };
@@ -442,25 +519,8 @@ __global__ __launch_bounds__(kThreads) void step_gather_forward(const GatherPara
     const uint32_t plane = fdiv(bid, p.d_spp);
     const int step = static_cast<int>(bid - plane * static_cast<uint32_t>(p.spp));
     const int c = static_cast<int>(plane - fdiv(plane, p.d_C) * static_cast<uint32_t>(p.C));
-    // the channel's two shifts: fp32 weights (every float module) through the scalar cache and 32-bit arithmetic;
-    // anything else -- other weight dtypes, |weight| >= 2^30 -- through the generic 64-bit path
-    int cs1 = 0, cs2 = 0;
-    bool fast = p.wkind == SHIFTND_F32;
-    if (fast) {
-        const __attribute__((address_space(4))) float *wc =
-            reinterpret_cast<const __attribute__((address_space(4))) float *>(reinterpret_cast<uintptr_t>(p.w)) + static_cast<int64_t>(c) * 2;
-        const float r1 = rintf(wc[0]), r2 = rintf(wc[1]);
-        fast = fabsf(r1) < 1073741824.f && fabsf(r2) < 1073741824.f;
-        cs1 = canon_shift32<PAD>(__builtin_amdgcn_readfirstlane(static_cast<int>(r1)), p.S1, p.d_per1);
-        cs2 = canon_shift32<PAD>(__builtin_amdgcn_readfirstlane(static_cast<int>(r2)), p.S2, p.d_per2);
-    }
-    if (!fast) {
-        const int wcol[3] = {-1, 0, 1};
-        int64_t sh[3];
-        gather_shifts3(p.w, p.wkind, p.wzp, static_cast<int64_t>(c) * 2, wcol, sh);
-        cs1 = canon_shift(sh[1], p.S1, PAD, p.d_per1);
-        cs2 = canon_shift(sh[2], p.S2, PAD, p.d_per2);
-    }
+    int cs1, cs2;
+    channel_shifts2<PAD>(p.w, p.wkind, p.wzp, c, p.S1, p.S2, p.d_per1, p.d_per2, cs1, cs2);
     const int tid = static_cast<int>(threadIdx.x);
     const int tr = static_cast<int>(fdiv(static_cast<uint32_t>(tid), p.d_cpr)), tc = tid - tr * p.cpr;
     const int r = step * p.R + tr;
@@ -495,6 +555,72 @@ __global__ __launch_bounds__(kThreads) void step_gather_forward(const GatherPara
 }
 
 
+// The same for 1- and 2-byte elements, where a 16-byte load at element alignment is slow: the output chunk's 16 source
+// bytes lie in two ALIGNED 16-byte pieces of the source row (rows are whole pieces), displaced by a byte phase that is
+// the same for the whole workgroup (one channel = one inner shift; the crop offset is uniform): two aligned loads, a
+// uniform switch on the dword part of the phase and one v_alignbit per output dword.  With zeros padding a piece is
+// either inside the row or entirely fill, so the row ends need no element path at all; the wrapping / clamping paddings
+// send only the chunks that touch a row end through the element-by-element map.
+template <int ESIZE, int PAD>
+__global__ __launch_bounds__(kThreads) void step_gather_forward_small(const GatherParams p) {
+    using R_t = typename raw_t<ESIZE>::type;
+    typedef uint32_t u4 __attribute__((ext_vector_type(4)));
+    constexpr int E = 16 / ESIZE;
+    const uint32_t bid = (blockIdx.x & 7u) * p.steps_per_xcd + (blockIdx.x >> 3);
+    if (bid >= p.total_steps) return;
+    const uint32_t plane = fdiv(bid, p.d_spp);
+    const int step = static_cast<int>(bid - plane * static_cast<uint32_t>(p.spp));
+    const int c = static_cast<int>(plane - fdiv(plane, p.d_C) * static_cast<uint32_t>(p.C));
+    int cs1, cs2;
+    channel_shifts2<PAD>(p.w, p.wkind, p.wzp, c, p.S1, p.S2, p.d_per1, p.d_per2, cs1, cs2);
+    const int tid = static_cast<int>(threadIdx.x);
+    const int tr = static_cast<int>(fdiv(static_cast<uint32_t>(tid), p.d_cpr)), tc = tid - tr * p.cpr;
+    const int r = step * p.R + tr;
+    if (tr >= p.R || r >= p.O1) return;
+    const int rb = row_map_t<PAD>(r + p.L1, cs1, p.S1);
+    const int dcol = p.L2 - cs2;               // source column of output column 0 under the plain shift (uniform)
+    const int ph = (dcol * ESIZE) & 15;        // byte phase of every chunk's source window
+    const int q = tc + ((dcol * ESIZE) >> 4);  // first aligned source piece of this chunk (may lie outside the row)
+    uint32_t fill32 = static_cast<uint32_t>(p.fill) & (ESIZE == 1 ? 0xffu : 0xffffu);
+    fill32 = ESIZE == 1 ? fill32 * 0x01010101u : fill32 * 0x00010001u;
+    const u4 fillv = {fill32, fill32, fill32, fill32};
+    const char *xrow = static_cast<const char *>(p.x) + (static_cast<int64_t>(plane) * p.x_plane + static_cast<int64_t>(rb < 0 ? 0 : rb) * p.S2) * ESIZE;
+    R_t *dst = static_cast<R_t *>(p.out) + static_cast<int64_t>(plane) * p.o_plane + r * p.O2 + tc * E;
+    const int s0 = tc * E + dcol;
+    const bool plain = PAD == 0 || (s0 >= 0 && s0 + E <= p.S2);  // every source column inside the row maps to itself
+    u4 o = fillv;
+    if (plain) {
+        const bool va = rb >= 0 && q >= 0 && q < p.xppr, vb = rb >= 0 && q + 1 >= 0 && q + 1 < p.xppr;
+        const int qa = q < 0 ? 0 : (q >= p.xppr ? p.xppr - 1 : q), qb = q + 1 < 0 ? 0 : (q + 1 >= p.xppr ? p.xppr - 1 : q + 1);
+        u4 A = __builtin_nontemporal_load(reinterpret_cast<const u4 *>(xrow) + qa);
+        u4 B = fillv;
+        if (ph != 0) B = __builtin_nontemporal_load(reinterpret_cast<const u4 *>(xrow) + qb);  // uniform
+        A = va ? A : fillv;
+        B = vb ? B : fillv;
+        const uint32_t sh = static_cast<uint32_t>(ph & 3) * 8u;
+        switch (ph >> 2) {  // uniform
+        case 0: o = u4{__builtin_amdgcn_alignbit(A.y, A.x, sh), __builtin_amdgcn_alignbit(A.z, A.y, sh), __builtin_amdgcn_alignbit(A.w, A.z, sh), __builtin_amdgcn_alignbit(B.x, A.w, sh)}; break;
+        case 1: o = u4{__builtin_amdgcn_alignbit(A.z, A.y, sh), __builtin_amdgcn_alignbit(A.w, A.z, sh), __builtin_amdgcn_alignbit(B.x, A.w, sh), __builtin_amdgcn_alignbit(B.y, B.x, sh)}; break;
+        case 2: o = u4{__builtin_amdgcn_alignbit(A.w, A.z, sh), __builtin_amdgcn_alignbit(B.x, A.w, sh), __builtin_amdgcn_alignbit(B.y, B.x, sh), __builtin_amdgcn_alignbit(B.z, B.y, sh)}; break;
+        default: o = u4{__builtin_amdgcn_alignbit(B.x, A.w, sh), __builtin_amdgcn_alignbit(B.y, B.x, sh), __builtin_amdgcn_alignbit(B.z, B.y, sh), __builtin_amdgcn_alignbit(B.w, B.z, sh)}; break;
+        }
+    } else if (rb >= 0) {
+        // a chunk at a row end under a wrapping / clamping padding: element by element.  (Costs its wave a second memory
+        // round trip; issuing these loads unconditionally for every lane -- raw-buffer offsets out of range where not
+        // needed -- was measured slower still: C5 reflect 1.52 vs 1.39 ms, against 1.25 ms of plane_gather_forward_lds,
+        // which is why the automatic choice takes this kernel for zeros padding only.)
+        const R_t *row = reinterpret_cast<const R_t *>(xrow);
+        Chunk<R_t, E> v;
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+            const int m = row_map_t<PAD>(tc * E + p.L2 + e, cs2, p.S2);
+            v.e[e] = m >= 0 ? row[m] : static_cast<R_t>(p.fill);
+        }
+        __builtin_memcpy(&o, v.e, 16);
+    }
+    __builtin_nontemporal_store(o, reinterpret_cast<u4 *>(dst));
+}
+
 // ---------------------------------------------------------------------------------------------------------------------
 // step_forward_lds: forwards that read their source rows through LDS, in the same one-step shape -- the interpolating
 // forward of every float dtype (R + 1 corner rows per step) and the sparse-shift forward of 2-byte elements (16-byte
@@ -514,36 +640,6 @@ struct FwdParams {
     uint32_t total_steps, steps_per_xcd;
     FastDiv d_spp, d_C, d_cpr, d_xppr, d_per1, d_per2;
 };
-
-// the two weights of channel c (row dim, inner dim) widened to the compute type, through the scalar cache
-template <typename CT> __device__ __forceinline__ void load_weights2(const void *w, int wkind, int c, CT &wr, CT &wc) {
-    const uintptr_t base = reinterpret_cast<uintptr_t>(w);
-    if (wkind == SHIFTND_F64) {
-        const __attribute__((address_space(4))) double *q = reinterpret_cast<const __attribute__((address_space(4))) double *>(base) + static_cast<int64_t>(c) * 2;
-        wr = static_cast<CT>(q[0]);
-        wc = static_cast<CT>(q[1]);
-    } else if (wkind == SHIFTND_F16 || wkind == SHIFTND_BF16) {
-        const uint32_t word = (reinterpret_cast<const __attribute__((address_space(4))) uint32_t *>(base))[c];
-        const uint16_t lo = static_cast<uint16_t>(word), hi = static_cast<uint16_t>(word >> 16);
-        if (wkind == SHIFTND_F16) {
-            wr = static_cast<CT>(__builtin_bit_cast(_Float16, lo));
-            wc = static_cast<CT>(__builtin_bit_cast(_Float16, hi));
-        } else {
-            wr = static_cast<CT>(__builtin_bit_cast(float, static_cast<uint32_t>(lo) << 16));
-            wc = static_cast<CT>(__builtin_bit_cast(float, static_cast<uint32_t>(hi) << 16));
-        }
-    } else {
-        const __attribute__((address_space(4))) float *q = reinterpret_cast<const __attribute__((address_space(4))) float *>(base) + static_cast<int64_t>(c) * 2;
-        wr = static_cast<CT>(q[0]);
-        wc = static_cast<CT>(q[1]);
-    }
-}
-
-// canonical shift of an integral shift held in the compute type: 32-bit arithmetic below 2^30, the 64-bit form beyond
-template <int PAD, typename CT> __device__ __forceinline__ int canon_of(CT r, int len, const FastDiv &dper) {
-    if (r > CT(-1073741824) && r < CT(1073741824)) return canon_shift32<PAD>(static_cast<int>(r), len, dper);
-    return canon_shift(static_cast<int64_t>(r), len, PAD, dper);
-}
 
 // column state of E + 1 consecutive map entries starting at coordinate j0, folded arithmetically
 template <int E, int PAD> __device__ __forceinline__ ColState<E> fold_colstate(int j0, int cs, int len) {
@@ -772,12 +868,13 @@ bool step_backward_eligible(const Geometry &g, int dtype, const void *go, const 
 // sparse-shift / quantized forward of 4- and 8-byte elements: dense tensors, output rows of whole 16-byte chunks and at
 // most one workgroup pass wide (crops are fine: a gather)
 bool step_forward_eligible(const Geometry &g, int dtype, const void *x, const void *out) {
-    (void)x;
     if (g_step_tune[1] == 1) return false;
     const int es = dtype_size(dtype);
-    if (es != 4 && es != 8) return false;
+    if (es != 1 && es != 2 && es != 4 && es != 8) return false;
     if (g.active && dtype <= SHIFTND_BF16) return false;
     if (g.nd != 2 || g.S[0] != 1 || g.O[0] != 1) return false;
+    // 1- / 2-byte elements: aligned pieces of the source rows
+    if (es < 4 && ((g.S[2] * es) % 16 != 0 || reinterpret_cast<uintptr_t>(x) % 16 != 0)) return false;
     const int64_t xe = g.S[1] * g.S[2], oe = g.O[1] * g.O[2];
     if (xe < 1 || oe < 1 || xe >= (1LL << 30) || oe >= (1LL << 30)) return false;
     if ((g.O[2] * es) % 16 != 0 || g.O[2] * es / 16 > kThreads || reinterpret_cast<uintptr_t>(out) % 16 != 0) return false;
@@ -787,6 +884,9 @@ bool step_forward_eligible(const Geometry &g, int dtype, const void *x, const vo
     const int64_t spp = (g.O[1] + R - 1) / R;
     if (g.N * g.C * spp + 8 >= (1LL << 31)) return false;
     if (g_step_tune[1] == 2) return true;
+    // 1- / 2-byte elements: zeros padding only (row-end chunks of the other paddings go element by element), planes of at
+    // least 16 KiB (2-byte) / 32 KiB (1-byte): below that the per-channel kernels that walk many planes win
+    if (es < 4) return g.pad == 0 && oe * es >= (es == 2 ? 16 : 32) * 1024;
     return oe * es >= 32 * 1024;  // as the sweep kernels: small planes go to the per-channel walk
 }
 
@@ -810,6 +910,7 @@ int step_forward(const Geometry &g, int dtype, const void *x, const void *w, int
     p.x_plane = g.S[1] * g.S[2];
     p.o_plane = g.O[1] * g.O[2];
     p.cpr = static_cast<int>(g.O[2] * es / 16);
+    p.xppr = static_cast<int>(g.S[2] * es / 16);
     p.R = kThreads / p.cpr;
     if (p.R > p.O1) p.R = p.O1;
     p.spp = (p.O1 + p.R - 1) / p.R;
@@ -821,17 +922,20 @@ int step_forward(const Geometry &g, int dtype, const void *x, const void *w, int
     p.d_cpr = make_fastdiv(static_cast<uint32_t>(p.cpr));
     p.d_per1 = make_fastdiv(static_cast<uint32_t>(map_period(p.S1, g.pad)));
     p.d_per2 = make_fastdiv(static_cast<uint32_t>(map_period(p.S2, g.pad)));
-    note_kernel("step_gather_forward");
+    note_kernel(es < 4 ? "step_gather_forward_small" : "step_gather_forward");
     const dim3 grid(p.steps_per_xcd * 8), block(kThreads);
-#define SHIFTND_STEP_FWD(ES) \
+#define SHIFTND_STEP_FWD(KERNEL, ES) \
     switch (g.pad) { \
-    case 0: hipLaunchKernelGGL((step_gather_forward<ES, 0>), grid, block, 0, st, p); break; \
-    case 1: hipLaunchKernelGGL((step_gather_forward<ES, 1>), grid, block, 0, st, p); break; \
-    case 2: hipLaunchKernelGGL((step_gather_forward<ES, 2>), grid, block, 0, st, p); break; \
-    case 3: hipLaunchKernelGGL((step_gather_forward<ES, 3>), grid, block, 0, st, p); break; \
-    default: hipLaunchKernelGGL((step_gather_forward<ES, 4>), grid, block, 0, st, p); break; \
+    case 0: hipLaunchKernelGGL((KERNEL<ES, 0>), grid, block, 0, st, p); break; \
+    case 1: hipLaunchKernelGGL((KERNEL<ES, 1>), grid, block, 0, st, p); break; \
+    case 2: hipLaunchKernelGGL((KERNEL<ES, 2>), grid, block, 0, st, p); break; \
+    case 3: hipLaunchKernelGGL((KERNEL<ES, 3>), grid, block, 0, st, p); break; \
+    default: hipLaunchKernelGGL((KERNEL<ES, 4>), grid, block, 0, st, p); break; \
     }
-    if (es == 4) { SHIFTND_STEP_FWD(4) } else { SHIFTND_STEP_FWD(8) }
+    if (es == 1) { SHIFTND_STEP_FWD(step_gather_forward_small, 1) }
+    else if (es == 2) { SHIFTND_STEP_FWD(step_gather_forward_small, 2) }
+    else if (es == 4) { SHIFTND_STEP_FWD(step_gather_forward, 4) }
+    else { SHIFTND_STEP_FWD(step_gather_forward, 8) }
 #undef SHIFTND_STEP_FWD
     return SHIFTND_OK;
 }

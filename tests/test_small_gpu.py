@@ -227,6 +227,7 @@ def test_rows_gather_forward_vs_oracle(abi, shape, npdt):
     rows = (shape[-1] % 16 == 0) and int(np.prod(shape[2:])) > 16384
     try:
         abi.set_tuning(16, 0 if not rows else 1)   # (small planes: the byte kernel off, so that this kernel is measured)
+        abi.set_tuning(33, 1)                      # (the one-step kernel takes large zero-padded planes first: test_step_gpu.py)
         for br in (0, 7):
             abi.set_tuning(29, br)
             for pad in range(5):
@@ -237,6 +238,7 @@ def test_rows_gather_forward_vs_oracle(abi, shape, npdt):
     finally:
         abi.set_tuning(16, 1)
         abi.set_tuning(29, 0)
+        abi.set_tuning(33, 0)
 
 
 def test_rows_gather_forward_16bit(abi):

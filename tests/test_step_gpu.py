@@ -204,7 +204,9 @@ def test_16bit_forwards_vs_oracle(abi, shape, crop, tdt):
     b, new = abi.check_borders(list(shape), crop, 2)
     xd, wd = x16.to(DEV), w16.to(DEV)
     for pad in range(5):
+        abi.set_tuning(33, 1)  # (the direct-load kernel would take the sparse shift first: tested below)
         out = abi.forward(xd, wd, pad, 0, b)
+        abi.set_tuning(33, 2)
         assert abi.last_kernel() == "step_gather_forward_lds", (shape, abi.last_kernel())
         assert torch.equal(out.cpu(), torch.from_numpy(O.forward(x, w, pad, 0, b)).to(tdt)), ("ssl", shape, pad)
         out = abi.forward(xd, wd, pad, 1, b)
@@ -259,3 +261,35 @@ def test_3d_backward_16bit_vs_oracle(abi, shape, tdt):
                 assert torch.equal(gx.cpu(), gx_ref), ("gx", shape, pad)
             _, gw64 = O.backward(go.astype(np.float64), w.astype(np.float64), x.astype(np.float64), pad, active)
             assert rel_err(gw.float().cpu().numpy(), gw64) < 2 * torch.finfo(tdt).eps, ("gw", shape, pad, active)
+
+
+@pytest.mark.parametrize("npdt", [np.uint8, np.int8, np.uint16])
+@pytest.mark.parametrize("shape,crop", [((3, 5, 9, 32), None), ((2, 3, 40, 224), None), ((5, 2, 33, 64), [[1, 2], [16, 16]]),
+                                        ((1, 2, 300, 16), None), ((2, 2, 1, 48), None), ((2, 1, 5, 2048), None),
+                                        ((2, 3, 30, 96), [[2, 3], [16, 32]]), ((2, 2, 17, 80), [[0, 0], [5, 11]])])
+def test_small_element_gather_forward_vs_oracle(abi, shape, crop, npdt):
+    """1- and 2-byte elements through two aligned 16-byte loads and a uniform byte funnel: bit-exact (a pure gather),
+    every padding, crops that keep or break the 16-byte phase, quantized weights (uint8 / int8 tensors) and float16 bit
+    patterns (uint16 stands for fp16 / bf16: the kernel moves raw elements)"""
+    rs = np.random.RandomState(sum(shape) * 7 + 9)
+    b, new = abi.check_borders(list(shape), crop, 2)
+    es = np.dtype(npdt).itemsize
+    if (new[-1] * es) % 16 or (shape[-1] * es) % 16 or new[-1] * es > 4096:
+        pytest.skip("rows are not whole 16-byte pieces, or wider than one workgroup pass")
+    if npdt == np.uint16:
+        x16 = torch.from_numpy(rs.uniform(-1, 1, size=shape).astype(np.float32)).to(torch.float16)
+        w16 = torch.from_numpy(_weights(rs, shape[1], 2, shape[2:]).astype(np.float32)).to(torch.float16)
+        for pad in range(5):
+            out = abi.forward(x16.to(DEV), w16.to(DEV), pad, 0, b)
+            assert abi.last_kernel() == "step_gather_forward_small", (shape, abi.last_kernel())
+            ref = torch.from_numpy(O.forward(x16.float().numpy(), w16.float().numpy(), pad, 0, b)).to(torch.float16)
+            assert torch.equal(out.cpu(), ref), (shape, crop, pad)
+        return
+    info = np.iinfo(npdt)
+    xq = rs.randint(info.min, info.max + 1, size=shape).astype(npdt)
+    wq = rs.randint(118, 139, size=(shape[1], 2)).astype(np.uint8)
+    wq[0] = [128 + 100, 128 - 90]  # far beyond small dims
+    for pad in range(5):
+        out = abi.forward_quantized(torch.from_numpy(xq).to(DEV), torch.from_numpy(wq).to(DEV), 128, 7, pad, b)
+        assert abi.last_kernel() == "step_gather_forward_small", (shape, abi.last_kernel())
+        assert np.array_equal(out.cpu().numpy(), O.forward_q(xq, wq, 128, 7, pad, b)), (shape, crop, pad)

@@ -621,6 +621,90 @@ __global__ __launch_bounds__(kThreads) void step_gather_forward_small(const Gath
     __builtin_nontemporal_store(o, reinterpret_cast<u4 *>(dst));
 }
 
+// The interpolating forward of 4- / 8-byte elements in the same shape, by direct loads: per corner row one element-aligned
+// 16-byte raw-buffer load for the chunk's E columns and one element load for column E.  The buffer resource is the
+// (n, c) plane, so a window that starts before the plane or ends behind it reads zeros instead of faulting, and a window
+// that starts before its ROW (zeros padding: shift to the right at the row start) reads the neighbouring row's tail,
+// which the column mask then discards: with zeros padding every chunk is affine and the kernel has no branch and no
+// element path at all.  The other paddings send the chunks at the row ends through the element-by-element map.
+template <typename T, int PAD>
+__global__ __launch_bounds__(kThreads) void step_active_forward_direct(const GatherParams p) {
+    using S = typename T::S;
+    using CT = typename T::C;
+    constexpr int ES = sizeof(S);
+    constexpr int E = 16 / ES;
+    const uint32_t bid = (blockIdx.x & 7u) * p.steps_per_xcd + (blockIdx.x >> 3);
+    if (bid >= p.total_steps) return;
+    const uint32_t plane = fdiv(bid, p.d_spp);
+    const int step = static_cast<int>(bid - plane * static_cast<uint32_t>(p.spp));
+    const int c = static_cast<int>(plane - fdiv(plane, p.d_C) * static_cast<uint32_t>(p.C));
+    CT wr, wc;
+    load_weights2<CT>(p.w, p.wkind, c, wr, wc);
+    const CT rr = c_floor<CT>(wr), rc = c_floor<CT>(wc);  // weights_init_forward, active: floor + fraction
+    const CT dw[2] = {wr - rr, wc - rc};
+    const int cs1 = __builtin_amdgcn_readfirstlane(canon_of<PAD, CT>(rr, p.S1, p.d_per1));
+    const int cs2 = __builtin_amdgcn_readfirstlane(canon_of<PAD, CT>(rc, p.S2, p.d_per2));
+    const int tid = static_cast<int>(threadIdx.x);
+    const int tr = static_cast<int>(fdiv(static_cast<uint32_t>(tid), p.d_cpr)), tc = tid - tr * p.cpr;
+    const int r = step * p.R + tr;
+    if (tr >= p.R || r >= p.O1) return;
+    const int jo = tc * E;
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<char *>(static_cast<const char *>(p.x)) + static_cast<int64_t>(plane) * p.x_plane * ES, 0,
+        static_cast<int>(p.x_plane * ES), 0x00020000);
+    int mm[E + 1];
+    bool affine = true;
+    int base = 0;
+    bool found = false;
+#pragma unroll
+    for (int e = 0; e <= E; ++e) {
+        mm[e] = row_map_t<PAD>(jo + p.L2 + e, cs2, p.S2);
+        if (!found && mm[e] >= 0) {
+            base = mm[e] - e;
+            found = true;
+        }
+    }
+#pragma unroll
+    for (int e = 0; e <= E; ++e) affine = affine && (mm[e] < 0 || mm[e] == base + e);
+    CT xv[2][E + 1];
+#pragma unroll
+    for (int hb = 0; hb < 2; ++hb) {
+        const int rb = row_map_t<PAD>(r + p.L1 + hb, cs1, p.S1);
+        const int rowoff = (rb < 0 ? 0 : rb) * p.S2;
+        if (PAD == 0 || affine) {
+            const uint32_t off = static_cast<uint32_t>(rowoff + base) * ES;  // (a negative window start wraps out of range: zeros)
+            S raw[E + 1];
+            if constexpr (ES == 4) {
+                typedef uint32_t u4 __attribute__((ext_vector_type(4)));
+                const u4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, off, 0, 2);
+                __builtin_memcpy(raw, &v, 16);
+                const uint32_t t = __builtin_amdgcn_raw_buffer_load_b32(rsrc, off + 16, 0, 2);
+                __builtin_memcpy(&raw[E], &t, 4);
+            } else {
+                typedef uint32_t u4 __attribute__((ext_vector_type(4)));
+                typedef uint32_t u2 __attribute__((ext_vector_type(2)));
+                const u4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, off, 0, 2);
+                __builtin_memcpy(raw, &v, 16);
+                const u2 t = __builtin_amdgcn_raw_buffer_load_b64(rsrc, off + 16, 0, 2);
+                __builtin_memcpy(&raw[E], &t, 8);
+            }
+#pragma unroll
+            for (int e = 0; e <= E; ++e) xv[hb][e] = (rb >= 0 && mm[e] >= 0) ? widen<T>(raw[e]) : CT(0);
+        } else {
+            const S *row = static_cast<const S *>(p.x) + static_cast<int64_t>(plane) * p.x_plane + rowoff;
+#pragma unroll
+            for (int e = 0; e <= E; ++e) xv[hb][e] = (rb >= 0 && mm[e] >= 0) ? widen<T>(row[mm[e]]) : CT(0);
+        }
+    }
+    Chunk<S, E> res;
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        const CT v[4] = {xv[0][e], xv[1][e], xv[0][e + 1], xv[1][e + 1]};
+        res.e[e] = narrow<T>(interp_t<T, 2>(v, dw));
+    }
+    store_chunk<S, E>(static_cast<S *>(p.out) + static_cast<int64_t>(plane) * p.o_plane + r * p.O2 + jo, res);
+}
+
 // ---------------------------------------------------------------------------------------------------------------------
 // step_forward_lds: forwards that read their source rows through LDS, in the same one-step shape -- the interpolating
 // forward of every float dtype (R + 1 corner rows per step) and the sparse-shift forward of 2-byte elements (16-byte
@@ -871,7 +955,8 @@ bool step_forward_eligible(const Geometry &g, int dtype, const void *x, const vo
     if (g_step_tune[1] == 1) return false;
     const int es = dtype_size(dtype);
     if (es != 1 && es != 2 && es != 4 && es != 8) return false;
-    if (g.active && dtype <= SHIFTND_BF16) return false;
+    const bool interpolating = g.active && dtype <= SHIFTND_BF16;
+    if (interpolating && (es < 4 || g.S[1] * g.S[2] * es >= (1LL << 31))) return false;  // (the buffer resource spans one plane)
     if (g.nd != 2 || g.S[0] != 1 || g.O[0] != 1) return false;
     // 1- / 2-byte elements: aligned pieces of the source rows
     if (es < 4 && ((g.S[2] * es) % 16 != 0 || reinterpret_cast<uintptr_t>(x) % 16 != 0)) return false;
@@ -884,6 +969,7 @@ bool step_forward_eligible(const Geometry &g, int dtype, const void *x, const vo
     const int64_t spp = (g.O[1] + R - 1) / R;
     if (g.N * g.C * spp + 8 >= (1LL << 31)) return false;
     if (g_step_tune[1] == 2) return true;
+    if (interpolating) return g.pad == 0 && oe * es >= 32 * 1024;  // (row-end chunks of the other paddings: element by element)
     // 1- / 2-byte elements: zeros padding only (row-end chunks of the other paddings go element by element), planes of at
     // least 16 KiB (2-byte) / 32 KiB (1-byte): below that the per-channel kernels that walk many planes win
     if (es < 4) return g.pad == 0 && oe * es >= (es == 2 ? 16 : 32) * 1024;
@@ -922,8 +1008,22 @@ int step_forward(const Geometry &g, int dtype, const void *x, const void *w, int
     p.d_cpr = make_fastdiv(static_cast<uint32_t>(p.cpr));
     p.d_per1 = make_fastdiv(static_cast<uint32_t>(map_period(p.S1, g.pad)));
     p.d_per2 = make_fastdiv(static_cast<uint32_t>(map_period(p.S2, g.pad)));
-    note_kernel(es < 4 ? "step_gather_forward_small" : "step_gather_forward");
     const dim3 grid(p.steps_per_xcd * 8), block(kThreads);
+    if (g.active && dtype <= SHIFTND_BF16) {
+        note_kernel("step_active_forward_direct");
+#define SHIFTND_STEP_ACT(TT) \
+    switch (g.pad) { \
+    case 0: hipLaunchKernelGGL((step_active_forward_direct<TT, 0>), grid, block, 0, st, p); break; \
+    case 1: hipLaunchKernelGGL((step_active_forward_direct<TT, 1>), grid, block, 0, st, p); break; \
+    case 2: hipLaunchKernelGGL((step_active_forward_direct<TT, 2>), grid, block, 0, st, p); break; \
+    case 3: hipLaunchKernelGGL((step_active_forward_direct<TT, 3>), grid, block, 0, st, p); break; \
+    default: hipLaunchKernelGGL((step_active_forward_direct<TT, 4>), grid, block, 0, st, p); break; \
+    }
+        if (dtype == SHIFTND_F32) { SHIFTND_STEP_ACT(f32_t) } else { SHIFTND_STEP_ACT(f64_t) }
+#undef SHIFTND_STEP_ACT
+        return SHIFTND_OK;
+    }
+    note_kernel(es < 4 ? "step_gather_forward_small" : "step_gather_forward");
 #define SHIFTND_STEP_FWD(KERNEL, ES) \
     switch (g.pad) { \
     case 0: hipLaunchKernelGGL((KERNEL<ES, 0>), grid, block, 0, st, p); break; \

@@ -186,9 +186,15 @@ def test_active_forward_vs_oracle(abi, shape, crop, dt):
         pytest.skip("rows are not whole 16-byte pieces, or wider than one workgroup pass")
     xd, wd = torch.from_numpy(x).to(DEV), torch.from_numpy(w).to(DEV)
     for pad in range(5):
-        out = abi.forward(xd, wd, pad, 1, b)
+        ref = O.forward(x, w, pad, 1, b)
+        out = abi.forward(xd, wd, pad, 1, b)  # by direct loads (raw-buffer windows, no LDS)
+        assert abi.last_kernel() == "step_active_forward_direct", (shape, abi.last_kernel())
+        assert np.array_equal(out.cpu().numpy(), ref), ("direct", shape, crop, pad)
+        abi.set_tuning(33, 1)
+        out = abi.forward(xd, wd, pad, 1, b)  # through LDS
+        abi.set_tuning(33, 2)
         assert abi.last_kernel() == "step_active_forward", (shape, abi.last_kernel())
-        assert np.array_equal(out.cpu().numpy(), O.forward(x, w, pad, 1, b)), (shape, crop, pad)
+        assert np.array_equal(out.cpu().numpy(), ref), ("lds", shape, crop, pad)
 
 
 @pytest.mark.parametrize("tdt", [torch.float16, torch.bfloat16])

@@ -273,6 +273,155 @@ BytesPlan bytes_plan(const Geometry &g) {
     return pl;
 }
 
+// =====================================================================================================================
+// bytes_block_forward: planes that are NOT whole 16-byte pieces (14 x 14 = 196 bytes, 7 x 7 = 49: the late stages of a
+// quantized ResNet-shaped network), which the chunk kernels move element by element (0.7 - 0.9 TB/s).  The planes of
+// cb = 16 / gcd(plane bytes, 16) consecutive channels of one batch entry ARE a run of whole, aligned pieces (196 x 4 =
+// 49 x 16 = 784 bytes), so a workgroup owns one block of cb channels and a group of batch entries:
+//   * once: a table with one int16 per byte of the block -- the byte's source offset inside the block, through the
+//     padding map of ITS channel, or -1 for the fill value; every thread keeps the 16 entries of its output piece in
+//     registers for the life of the workgroup;
+//   * per round of nr batch entries: each thread loads one aligned piece (the next round's before this round is
+//     assembled), parks it in LDS, gathers its 16 output bytes through its table entries and stores one aligned piece.
+// Any padding, any number of dims; no crop.
+// =====================================================================================================================
+struct BlockParams {
+    const uint8_t *x;
+    uint8_t *out;
+    const void *w;
+    int64_t wzp;
+    uint32_t fill;
+    int wkind, N, C, nd, pad;
+    int S[3], wcol[3];
+    int plane_bytes, cb, block_bytes, npb;  // channels per block, bytes / pieces per block
+    int nr, npw;                            // batch entries per round, per workgroup
+    int cblocks;                            // C / cb
+    FastDiv d_npb, d_plane, d_S2, d_S12, d_cblocks;
+    FastDiv d_per[3];
+};
+
+__global__ __launch_bounds__(kThreads) void bytes_block_forward(const BlockParams p) {
+    typedef uint32_t u4 __attribute__((ext_vector_type(4)));
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    // LDS: [2 x nr block images] | table (int16 per block byte) | canonical shifts (cb x 3 ints)
+    char *img = smem;
+    const int img_bytes = p.nr * p.block_bytes;
+    int16_t *tab = reinterpret_cast<int16_t *>(smem + 2 * img_bytes);
+    int *cs = reinterpret_cast<int *>(smem + 2 * img_bytes + ((p.block_bytes * 2 + 15) & ~15));
+    const int tid = static_cast<int>(threadIdx.x);
+    const int grp = static_cast<int>(fdiv(blockIdx.x, p.d_cblocks)), cblk = static_cast<int>(blockIdx.x) - grp * p.cblocks;
+    const int c0 = cblk * p.cb;
+    const int n0 = grp * p.npw, nn = min(p.npw, p.N - n0);
+    // this thread's piece: batch entry j of a round, piece t of the block
+    const int j = static_cast<int>(fdiv(static_cast<uint32_t>(tid), p.d_npb)), t = tid - j * p.npb;
+    const bool mine = j < p.nr;
+    const int64_t stride_n = static_cast<int64_t>(p.C) * p.plane_bytes;
+    const uint8_t *xb = p.x + (static_cast<int64_t>(n0) * p.C + c0) * p.plane_bytes + t * 16;
+    uint8_t *ob = p.out + (static_cast<int64_t>(n0) * p.C + c0) * p.plane_bytes + t * 16;
+    u4 cur = {0, 0, 0, 0};
+    if (mine && j < nn) cur = *reinterpret_cast<const u4 *>(xb + j * stride_n);  // first round, in flight behind the table
+    // ---- canonical shifts of the block's channels ---------------------------------------------------------------------
+    if (tid < p.cb * 3) {
+        const int pl = tid / 3, d = tid - pl * 3;
+        int v = 0;
+        if (p.wcol[d] >= 0) {
+            const int64_t sh = gather_shift(p.w, p.wkind, p.wzp, static_cast<int64_t>(c0 + pl) * p.nd + p.wcol[d]);
+            v = canon_shift(sh, p.S[d], p.pad, p.d_per[d]);
+        }
+        cs[tid] = v;
+    }
+    __syncthreads();
+    // ---- the table: source offset of every byte of the block ----------------------------------------------------------
+    for (int q = tid; q < p.block_bytes; q += kThreads) {
+        const int pl = static_cast<int>(fdiv(static_cast<uint32_t>(q), p.d_plane));
+        const int o = q - pl * p.plane_bytes;
+        const int a = static_cast<int>(fdiv(static_cast<uint32_t>(o), p.d_S12));
+        const int rem = o - a * p.S[1] * p.S[2];
+        const int b = static_cast<int>(fdiv(static_cast<uint32_t>(rem), p.d_S2));
+        const int cc = rem - b * p.S[2];
+        const int sa = p.S[0] == 1 ? 0 : fold_index(a - cs[pl * 3 + 0], p.S[0], p.pad);
+        const int sb = p.S[1] == 1 ? 0 : fold_index(b - cs[pl * 3 + 1], p.S[1], p.pad);
+        const int sc = p.S[2] == 1 ? 0 : fold_index(cc - cs[pl * 3 + 2], p.S[2], p.pad);
+        tab[q] = (sa < 0 || sb < 0 || sc < 0) ? static_cast<int16_t>(-1)
+                                               : static_cast<int16_t>(pl * p.plane_bytes + (sa * p.S[1] + sb) * p.S[2] + sc);
+    }
+    __syncthreads();
+    int16_t src[16];
+    {
+        const u4 lo = *reinterpret_cast<const u4 *>(tab + (mine ? t : 0) * 16);
+        const u4 hi = *reinterpret_cast<const u4 *>(tab + (mine ? t : 0) * 16 + 8);
+        __builtin_memcpy(src, &lo, 16);
+        __builtin_memcpy(src + 8, &hi, 16);
+    }
+    // ---- rounds -------------------------------------------------------------------------------------------------------
+    int buf = 0;
+    for (int r0 = 0; r0 < nn; r0 += p.nr) {
+        char *im = img + buf * img_bytes;
+        if (mine) *reinterpret_cast<u4 *>(im + j * p.block_bytes + t * 16) = cur;
+        const int jn = r0 + p.nr + j;
+        u4 nxt = {0, 0, 0, 0};
+        if (mine && jn < nn) nxt = *reinterpret_cast<const u4 *>(xb + jn * stride_n);
+        __syncthreads();  // (two images: the next round writes the other one, so one barrier per round)
+        if (mine && r0 + j < nn) {
+            const uint8_t *blk = reinterpret_cast<const uint8_t *>(im + j * p.block_bytes);
+            uint32_t o4[4];
+#pragma unroll
+            for (int d4 = 0; d4 < 4; ++d4) {
+                uint32_t word = 0;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int sidx = src[d4 * 4 + k];
+                    const uint32_t v = sidx >= 0 ? blk[sidx] : (p.fill & 0xffu);
+                    word |= v << (8 * k);
+                }
+                o4[d4] = word;
+            }
+            const u4 res = {o4[0], o4[1], o4[2], o4[3]};
+            __builtin_nontemporal_store(res, reinterpret_cast<u4 *>(ob + (r0 + j) * stride_n));
+        }
+        cur = nxt;
+        buf ^= 1;
+    }
+}
+
+struct BlockPlan {
+    bool ok = false;
+    int cb = 0, block_bytes = 0, npb = 0, nr = 0, npw = 0, groups = 0;
+    size_t lds = 0;
+    unsigned grid = 0;
+};
+
+BlockPlan block_plan(const Geometry &g) {
+    BlockPlan pl;
+    const int64_t plane = g.S[0] * g.S[1] * g.S[2];
+    if (plane < 1 || plane % 16 == 0 || plane > 4096) return pl;  // (whole-piece planes: bytes_gather_forward)
+    int gcd = 16;
+    while (plane % gcd) gcd /= 2;
+    pl.cb = 16 / gcd;
+    if (g.C % pl.cb) return pl;
+    pl.block_bytes = static_cast<int>(plane * pl.cb);
+    if (pl.block_bytes > 16384) return pl;  // int16 table, LDS
+    pl.npb = pl.block_bytes / 16;
+    if (pl.npb > kThreads) return pl;
+    pl.nr = kThreads / pl.npb;
+    if (pl.nr > g.N) pl.nr = static_cast<int>(g.N);
+    // batch entries per workgroup: whole rounds, ~2048+ workgroups in all when the batch allows
+    const int64_t cblocks = g.C / pl.cb;
+    int64_t rounds = (g.N + pl.nr - 1) / pl.nr;
+    int64_t rpw = rounds;
+    while (rpw > 1 && cblocks * ((rounds + rpw - 1) / rpw) < 2048) rpw = (rpw + 1) / 2;
+    pl.npw = static_cast<int>(rpw * pl.nr);
+    pl.groups = static_cast<int>((g.N + pl.npw - 1) / pl.npw);
+    pl.lds = 2 * static_cast<size_t>(pl.nr) * pl.block_bytes + ((static_cast<size_t>(pl.block_bytes) * 2 + 15) & ~static_cast<size_t>(15)) + pl.cb * 3 * sizeof(int);
+    if (pl.lds > 64 * 1024) return pl;
+    if (g.N * g.C * plane >= (1LL << 40)) return pl;
+    const int64_t grid = cblocks * pl.groups;
+    if (grid >= (1LL << 31)) return pl;
+    pl.grid = static_cast<unsigned>(grid);
+    pl.ok = true;
+    return pl;
+}
+
 bool contiguous5b(const int64_t st[5], int64_t N, int64_t C, const int64_t sz[3]) {
     int64_t expect = 1;
     const int64_t sizes[5] = {N, C, sz[0], sz[1], sz[2]};
@@ -335,6 +484,53 @@ int bytes_forward(const Geometry &g, const void *x, const void *w, int wkind, in
     case 7: hipLaunchKernelGGL(bytes_gather_forward<7>, dim3(pl.grid), dim3(kThreads), pl.lds, st, p); break;
     default: hipLaunchKernelGGL(bytes_gather_forward<10>, dim3(pl.grid), dim3(kThreads), pl.lds, st, p); break;
     }
+    return SHIFTND_OK;
+}
+
+// one-byte planes that are not whole 16-byte pieces, no crop, contiguous
+bool bytes_block_forward_eligible(const Geometry &g, int dtype, const void *x, const void *out) {
+    if (!g_bytes_tune[0] || dtype_size(dtype) != 1 || g.active) return false;
+    for (int d = 0; d < 3; ++d)
+        if (g.O[d] != g.S[d] || g.L[d] != 0) return false;
+    if (!contiguous5b(g.xs, g.N, g.C, g.S) || !contiguous5b(g.os, g.N, g.C, g.O)) return false;
+    if (reinterpret_cast<uintptr_t>(x) % 16 || reinterpret_cast<uintptr_t>(out) % 16) return false;
+    return block_plan(g).ok;
+}
+
+int bytes_block_forward(const Geometry &g, const void *x, const void *w, int wkind, int64_t wzp, uint64_t fill_bits, void *out,
+                        hipStream_t st) {
+    const BlockPlan pl = block_plan(g);
+    if (!pl.ok) return SHIFTND_ERR_INVALID_ARGUMENT;
+    BlockParams p{};
+    p.x = static_cast<const uint8_t *>(x);
+    p.out = static_cast<uint8_t *>(out);
+    p.w = w;
+    p.wkind = wkind;
+    p.wzp = wzp;
+    p.fill = static_cast<uint32_t>(fill_bits & 0xff);
+    p.N = static_cast<int>(g.N);
+    p.C = static_cast<int>(g.C);
+    p.nd = g.nd;
+    p.pad = g.pad;
+    for (int d = 0; d < 3; ++d) {
+        p.S[d] = static_cast<int>(g.S[d]);
+        p.wcol[d] = g.wcol[d];
+        p.d_per[d] = make_fastdiv(static_cast<uint32_t>(map_period(p.S[d], g.pad)));
+    }
+    p.plane_bytes = static_cast<int>(g.S[0] * g.S[1] * g.S[2]);
+    p.cb = pl.cb;
+    p.block_bytes = pl.block_bytes;
+    p.npb = pl.npb;
+    p.nr = pl.nr;
+    p.npw = pl.npw;
+    p.cblocks = static_cast<int>(g.C / pl.cb);
+    p.d_npb = make_fastdiv(static_cast<uint32_t>(pl.npb));
+    p.d_plane = make_fastdiv(static_cast<uint32_t>(p.plane_bytes));
+    p.d_S2 = make_fastdiv(static_cast<uint32_t>(g.S[2]));
+    p.d_S12 = make_fastdiv(static_cast<uint32_t>(g.S[1] * g.S[2]));
+    p.d_cblocks = make_fastdiv(static_cast<uint32_t>(p.cblocks));
+    note_kernel("bytes_block_forward");
+    hipLaunchKernelGGL(bytes_block_forward, dim3(pl.grid), dim3(kThreads), pl.lds, st, p);
     return SHIFTND_OK;
 }
 

@@ -86,6 +86,10 @@ bool bytes_forward_eligible(const Geometry &g, int dtype, const void *x, const v
 int bytes_forward(const Geometry &g, const void *x, const void *w, int wkind, int64_t wzp, uint64_t fill_bits, void *out,
                   hipStream_t st);
 void bytes_set_tuning(int knob, int value);
+// ... and one-byte planes that are NOT whole 16-byte pieces (14 x 14, 7 x 7): blocks of consecutive channels through LDS
+bool bytes_block_forward_eligible(const Geometry &g, int dtype, const void *x, const void *out);
+int bytes_block_forward(const Geometry &g, const void *x, const void *w, int wkind, int64_t wzp, uint64_t fill_bits, void *out,
+                        hipStream_t st);
 
 // ---- channel-fastest kernels for channels-last tensors (shiftnd_cl.hip): any strides, x with unit channel stride --
 bool cl_forward_eligible(const Geometry &g);

@@ -1799,6 +1799,7 @@ int plane_forward(const Geometry &g, int dtype, const void *x, const void *w, in
         }
     }
     if (bytes_forward_eligible(g, dtype, x, out)) return bytes_forward(g, x, w, wkind, wzp, fill_bits, out, st);
+    if (bytes_block_forward_eligible(g, dtype, x, out)) return bytes_block_forward(g, x, w, wkind, wzp, fill_bits, out, st);
     const int V = gather_vector_bytes(g, es, out);
     note_kernel("plane_gather_forward");
     const Plan pl = make_plan(g, g.O[0] * g.O[1], g.O[2], es, V, entries, gather_min_wgs(), V < 16 ? 2 : 4);

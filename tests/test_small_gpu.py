@@ -257,3 +257,25 @@ def test_rows_gather_forward_16bit(abi):
             finally:
                 abi.set_tuning(28, 1)
             assert torch.equal(out, ref), (shape, pad)
+
+
+@pytest.mark.parametrize("shape,npdt", [((6, 8, 14, 14), np.uint8), ((5, 32, 7, 7), np.int8), ((37, 16, 7, 7), np.uint8),
+                                        ((2, 16, 3, 5, 7), np.uint8), ((4, 16, 13), np.int8), ((3, 4, 14, 14), np.uint8),
+                                        ((130, 64, 14, 14), np.uint8), ((2, 8, 30, 30), np.uint8), ((3, 2, 11, 8), np.int8)])
+def test_one_byte_ragged_planes_vs_oracle(abi, shape, npdt):
+    """bytes_block_forward (csrc/shiftnd_bytes.hip): quantized forward of one-byte planes that are not whole 16-byte pieces
+    (14 x 14, 7 x 7: blocks of 16 / gcd(plane bytes, 16) consecutive channels through LDS); every padding, shifts beyond
+    the dims, ragged last rounds and batch groups; bit-exact"""
+    rs = np.random.RandomState(sum(shape) + 3)
+    nd = len(shape) - 2
+    info = np.iinfo(npdt)
+    xq = rs.randint(info.min, info.max + 1, size=shape).astype(npdt)
+    wq = rs.randint(122, 135, size=(shape[1], nd)).astype(np.uint8)
+    wq[0, :] = min(255, 128 + shape[-1] + 2)
+    wq[1, :] = 128 - 5
+    x, w = torch.from_numpy(xq).to(DEV), torch.from_numpy(wq).to(DEV)
+    zp = -3 if npdt == np.int8 else 9
+    for pad in range(5):
+        out = abi.forward_quantized(x, w, 128, zp, pad)
+        assert abi.last_kernel() == "bytes_block_forward", (shape, pad, abi.last_kernel())
+        assert np.array_equal(out.cpu().numpy(), O.forward_q(xq, wq, 128, zp, pad)), (shape, pad)

@@ -969,7 +969,9 @@ bool step_forward_eligible(const Geometry &g, int dtype, const void *x, const vo
     const int64_t spp = (g.O[1] + R - 1) / R;
     if (g.N * g.C * spp + 8 >= (1LL << 31)) return false;
     if (g_step_tune[1] == 2) return true;
-    if (interpolating) return g.pad == 0 && oe * es >= 32 * 1024;  // (row-end chunks of the other paddings: element by element)
+    // interpolating by direct loads: every corner row is loaded by two workgroups at element alignment -- measured
+    // slower than the LDS-staged plane kernel (C2 tensor 1.51 vs 1.13 ms): on request only (knob 33 = 2)
+    if (interpolating) return false;
     // 1- / 2-byte elements: zeros padding only (row-end chunks of the other paddings go element by element), planes of at
     // least 16 KiB (2-byte) / 32 KiB (1-byte): below that the per-channel kernels that walk many planes win
     if (es < 4) return g.pad == 0 && oe * es >= (es == 2 ? 16 : 32) * 1024;

@@ -1,10 +1,9 @@
-mkdir -p gpurun_out/r03r
-exec > gpurun_out/r03r/log.txt 2>&1
-for wl in c2 c3 c4 c5; do
-  bash profiles/collect.sh $wl --workload $wl > gpurun_out/r03r/collect_$wl.log 2>&1
-  cp gpurun_out/prof_$wl/summary.txt gpurun_out/r03r/${wl}_summary.txt; cp gpurun_out/prof_$wl/traffic.json gpurun_out/r03r/${wl}_traffic.json
-done
-python3 bench.py > gpurun_out/r03r/bench_c2.json 2> gpurun_out/r03r/bench_c2.err
-for wl in c3 c4 c5 c2a; do python3 bench.py --workload $wl --no-cpu-baseline > gpurun_out/r03r/bench_$wl.json 2> gpurun_out/r03r/bench_$wl.err; done
-for pad in 1 2 3 4; do python3 bench.py --pad $pad --no-cpu-baseline > gpurun_out/r03r/bench_c2_pad$pad.json 2>/dev/null; done
-python3 bench.py --gpus 2 --allow-oversubscribe --no-cpu-baseline --steps 10 > gpurun_out/r03r/bench_gpus2.json 2> gpurun_out/r03r/bench_gpus2.err
+mkdir -p gpurun_out/r03s
+exec > gpurun_out/r03s/log.txt 2>&1
+timeout 900 python3 -m pytest tests/test_step_gpu.py tests/test_small_gpu.py -x -q 2>&1 | tail -8
+python3 tools/kbench.py --workload c2a --rounds 2 --iters 10 --knobs "33=1,0" | grep fwd
+python3 tools/kbench.py --shape 64,128,112,112 --active 1 --rounds 2 --iters 20 --knobs "33=1,0" | grep fwd
+python3 tools/kbench.py --shape 32,64,224,224 --dtype float64 --active 1 --rounds 2 --iters 10 --knobs "33=1,0" | grep fwd
+python3 tools/kbench.py --shape 128,1024,14,14 --dtype quint8 --rounds 2 --iters 50 --knobs "16=1,0"
+python3 tools/kbench.py --shape 128,2048,7,7 --dtype quint8 --rounds 2 --iters 50 --knobs "16=1,0"
+python3 tools/kbench.py --shape 128,1024,14,14 --dtype quint8 --pad 3 --rounds 2 --iters 50 --knobs "16=1,0"

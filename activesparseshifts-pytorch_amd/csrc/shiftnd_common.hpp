@@ -304,6 +304,22 @@ template <int ND> __device__ __forceinline__ void blend_diffs(const double *s, c
     }
 }
 
+// v / cnt with IEEE rounding.  A power-of-two count (every window of an even pool size) divides exactly by
+// multiplying with 2^-k: same bits as the division, none of its ~10 instructions.
+template <typename CT> __device__ __forceinline__ CT div_count(CT v, int cnt) {
+    if ((cnt & (cnt - 1)) != 0) return v / static_cast<CT>(cnt);
+    const int k = __builtin_ctz(static_cast<unsigned>(cnt));
+    CT scale;  // 2^-k from its bit pattern
+    if constexpr (sizeof(CT) == 4) {
+        const uint32_t bits = static_cast<uint32_t>(127 - k) << 23;
+        __builtin_memcpy(&scale, &bits, 4);
+    } else {
+        const uint64_t bits = static_cast<uint64_t>(1023 - k) << 52;
+        __builtin_memcpy(&scale, &bits, 8);
+    }
+    return v * scale;
+}
+
 // ---------------------------------------------------------------------------------------------
 // Workgroup-wide fp64 sum (deterministic: fixed shuffle tree, fixed wave order).
 // Returns the total in thread 0.  `scratch` needs kThreads/64 doubles of LDS.

@@ -68,6 +68,7 @@ void slide_set_tuning(int knob, int value);
 // ---- one-step workgroups (shiftnd_step.hip): the backward pass of contiguous 2-D problems as a linear sweep of short
 // workgroups; part of the per-channel family (plane_backward routes to it)
 bool step_backward_eligible(const Geometry &g, int dtype, const void *go, const void *x, const void *gx);
+bool step_backward_pooled_eligible(const Geometry &g, int dtype, const void *go, const void *x, const void *gx);
 size_t step_backward_workspace(const Geometry &g, int dtype);
 int step_backward(const Geometry &g, int dtype, const void *go, const void *x, const void *w, void *gx, void *gw,
                   void *workspace, hipStream_t st);

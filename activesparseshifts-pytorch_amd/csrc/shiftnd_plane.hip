@@ -284,21 +284,6 @@ __global__ __launch_bounds__(kThreads) void plane_active_forward(const PlanePara
     }
 }
 
-// v / cnt with IEEE rounding.  A power-of-two count (every window of an even pool size) divides exactly by
-// multiplying with 2^-k: same bits as the division, none of its ~10 instructions.
-template <typename CT> __device__ __forceinline__ CT div_count(CT v, int cnt) {
-    if ((cnt & (cnt - 1)) != 0) return v / static_cast<CT>(cnt);
-    const int k = __builtin_ctz(static_cast<unsigned>(cnt));
-    CT scale;  // 2^-k from its bit pattern
-    if constexpr (sizeof(CT) == 4) {
-        const uint32_t bits = static_cast<uint32_t>(127 - k) << 23;
-        __builtin_memcpy(&scale, &bits, 4);
-    } else {
-        const uint64_t bits = static_cast<uint64_t>(1023 - k) << 52;
-        __builtin_memcpy(&scale, &bits, 8);
-    }
-    return v * scale;
-}
 
 // =====================================================================================================
 // Pooled forward: the shift followed by the average pool the reference's modules attach when they emulate a
@@ -1845,7 +1830,7 @@ size_t plane_backward_workspace(const Geometry &g, int dtype) {
     const Plan pl = backward_plan(g, dtype_size(dtype));
     const size_t own = static_cast<size_t>(pl.groups) * pl.bands * static_cast<size_t>(g.C) * 3 * sizeof(double);
     const size_t slide = g.K[0] > 0 ? 0 : slide_backward_workspace(g, dtype);  // (the fused-pool calls never slide)
-    const size_t step = g.K[0] > 0 ? 0 : step_backward_workspace(g, dtype);
+    const size_t step = step_backward_workspace(g, dtype);
     const size_t m = own > slide ? own : slide;
     return m > step ? m : step;
 }
@@ -1883,6 +1868,7 @@ bool plane_pool_backward_eligible(const Geometry &g, int dtype, const void *gx) 
 
 int plane_pool_backward(const Geometry &g, int dtype, const void *go, const void *x, const void *w, void *gx, void *gw,
                         void *workspace, hipStream_t st) {
+    if (step_backward_pooled_eligible(g, dtype, go, x, gx)) return step_backward(g, dtype, go, x, w, gx, gw, workspace, st);
     const Plan pl = backward_plan(g, dtype_size(dtype));
     PlaneParams p{};
     p.x = x;

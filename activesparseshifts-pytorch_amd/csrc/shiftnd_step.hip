@@ -62,6 +62,10 @@ struct StepParams {
     int spv;            // steps per (n, c): S0 * spp
     uint32_t total_steps, steps_per_xcd;
     FastDiv d_spp, d_spv, d_C, d_cpr, d_per0, d_per1, d_per2;
+    // fused average-pool tail (2-D): `go` is the gradient of the POOLED output [N, C, P1, P2], window = stride = (K1, K2)
+    int K1, K2, P1, P2;
+    int64_t g_plane;    // elements per (n, c) plane of `go`
+    FastDiv d_k1, d_k2;
 };
 
 template <int E> struct RecSize { static constexpr int N = (E + 3 <= 8) ? 8 : 16; };  // int16 entries per record
@@ -196,8 +200,9 @@ template <int PAD> __device__ __forceinline__ int canon_shift32(int s, int len, 
     }
 }
 
-template <typename T, int ND, bool ACTIVE, int PAD>
+template <typename T, int ND, bool ACTIVE, int PAD, bool POOL = false>
 __global__ __launch_bounds__(kThreads) void step_backward(const StepParams p) {
+    static_assert(!POOL || ND == 2, "the fused pool tail is 2-D here");
     using S = typename T::S;
     using CT = typename T::C;
     constexpr int E = 16 / sizeof(S);
@@ -226,7 +231,7 @@ __global__ __launch_bounds__(kThreads) void step_backward(const StepParams p) {
     const int npieces = (NX + NG + NGS) * cpr;
     const int RB = S2 * static_cast<int>(sizeof(S));
     const S *xp = static_cast<const S *>(p.x) + static_cast<int64_t>(plane) * p.x_plane;
-    const S *gp = static_cast<const S *>(p.go) + static_cast<int64_t>(plane) * p.x_plane;
+    const S *gp = static_cast<const S *>(p.go) + static_cast<int64_t>(plane) * (POOL ? p.g_plane : p.x_plane);
     S *gxp = static_cast<S *>(p.out) + static_cast<int64_t>(plane) * p.x_plane + static_cast<int64_t>(a) * S1 * S2;
     // source planes of the corners (3-D; uniform): -1 = fill
     int pax[NP], pag[NP];
@@ -271,17 +276,69 @@ __global__ __launch_bounds__(kThreads) void step_backward(const StepParams p) {
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(reinterpret_cast<const char *>(base) + off),
                                          (__attribute__((address_space(3))) void *)dst_wave, 16, 0, 2 /* nt */);
     };
+    // POOL: a row of the unpooled gradient is its pooled row expanded: g(b, j) = grad_pooled[b / K1][j / K2] / (window size),
+    // rounded to the storage type like the two-step sequence (ATen's avg_pool backward); a thread expands its own piece
+    // into the tile (the loads of all its pieces first, so that their latencies overlap each other and the row DMA)
+    auto pooled_load = [&](int grow, int col_piece, Chunk<S, E> &raw, int &cnt) {
+        const int pr = static_cast<int>(fdiv(static_cast<uint32_t>(grow), p.d_k1));
+        cnt = min(p.K1, S1 - pr * p.K1);
+        const S *prow = gp + static_cast<int64_t>(pr) * p.P2;
+        if (p.K2 == 2 && E % 2 == 0) {
+            const Chunk<S, (E >= 2 ? E / 2 : 1)> h = load_chunk<S, (E >= 2 ? E / 2 : 1)>(prow + col_piece * (E / 2));
+#pragma unroll
+            for (int e = 0; e < E / 2; ++e) raw.e[e] = h.e[e];
+        } else {
+#pragma unroll
+            for (int e = 0; e < E; ++e) raw.e[e] = prow[fdiv(static_cast<uint32_t>(col_piece * E + e), p.d_k2)];
+        }
+    };
+    auto pooled_store = [&](const Chunk<S, E> &raw, int cnt, int col_piece, int lds_piece) {
+        Chunk<S, E> out;
+        if (p.K2 == 2 && E % 2 == 0) {
+#pragma unroll
+            for (int h = 0; h < E / 2; ++h) {
+                const S q = narrow<T>(div_count<CT>(widen<T>(raw.e[h]), cnt * 2));
+                out.e[2 * h] = q;
+                out.e[2 * h + 1] = q;
+            }
+        } else {
+#pragma unroll
+            for (int e = 0; e < E; ++e) {
+                const int pc = static_cast<int>(fdiv(static_cast<uint32_t>(col_piece * E + e), p.d_k2));
+                out.e[e] = narrow<T>(div_count<CT>(widen<T>(raw.e[e]), cnt * min(p.K2, S2 - pc * p.K2)));
+            }
+        }
+        __builtin_memcpy(__builtin_assume_aligned(tile + lds_piece * 16, 16), out.e, 16);
+    };
+    Chunk<S, E> pq[POOL ? (ACTIVE ? 3 : 1) : 1];
+    int pcnt[3] = {0, 0, 0}, pdst[3] = {-1, -1, -1}, pcol[3] = {0, 0, 0};
     if (tr < R) {
         const int sx = tr <= Rn ? row_map_t<PAD>(b0 + tr, d.cx1, S1) : -1;  // corner rows of x: m1[b0 + tr]
 #pragma unroll
         for (int h = 0; h < NP; ++h)
             if (sx >= 0 && pax[h] >= 0) dma(xp, pax[h] * S1 + sx, tc, h * (R + 1) * cpr);
-        if (tr < Rn) dma(gp, a * S1 + b0 + tr, tc, NX * cpr);  // the incoming gradient at the rows themselves
+        if (tr < Rn) {  // the incoming gradient at the rows themselves
+            if constexpr (POOL) {
+                pooled_load(b0 + tr, tc, pq[0], pcnt[0]);
+                pdst[0] = NX * cpr + tid;
+                pcol[0] = tc;
+            } else {
+                dma(gp, a * S1 + b0 + tr, tc, NX * cpr);
+            }
+        }
         if constexpr (ACTIVE) {
             const int sg = tr <= Rn ? row_map_t<PAD>(b0 + tr, d.cg1, S1) : -1;  // the rows grad_x blends: g1[b0 + tr]
+            if constexpr (POOL) {
+                if (sg >= 0) {
+                    pooled_load(sg, tc, pq[1], pcnt[1]);
+                    pdst[1] = (NX + NG) * cpr + tid;
+                    pcol[1] = tc;
+                }
+            } else {
 #pragma unroll
-            for (int h = 0; h < NP; ++h)
-                if (sg >= 0 && pag[h] >= 0) dma(gp, pag[h] * S1 + sg, tc, (NX + NG + h * (R + 1)) * cpr);
+                for (int h = 0; h < NP; ++h)
+                    if (sg >= 0 && pag[h] >= 0) dma(gp, pag[h] * S1 + sg, tc, (NX + NG + h * (R + 1)) * cpr);
+            }
         } else if constexpr (!SCAT) {
             const int sg = tr < Rn ? row_map_t<PAD>(b0 + tr, d.cg1, S1) : -1;  // 3-D sparse shift: the one row grad_x copies
             if (sg >= 0 && pag[0] >= 0) dma(gp, pag[0] * S1 + sg, tc, (NX + NG) * cpr);
@@ -294,10 +351,23 @@ __global__ __launch_bounds__(kThreads) void step_backward(const StepParams p) {
             if (sx >= 0 && pax[h] >= 0) dma(xp, pax[h] * S1 + sx, tid, (h * (R + 1) + R) * cpr);
         if constexpr (ACTIVE) {
             const int sg = row_map_t<PAD>(b0 + R, d.cg1, S1);
+            if constexpr (POOL) {
+                if (sg >= 0) {
+                    pooled_load(sg, tid, pq[2], pcnt[2]);
+                    pdst[2] = (NX + NG + R) * cpr + tid;
+                    pcol[2] = tid;
+                }
+            } else {
 #pragma unroll
-            for (int h = 0; h < NP; ++h)
-                if (sg >= 0 && pag[h] >= 0) dma(gp, pag[h] * S1 + sg, tid, (NX + NG + h * (R + 1) + R) * cpr);
+                for (int h = 0; h < NP; ++h)
+                    if (sg >= 0 && pag[h] >= 0) dma(gp, pag[h] * S1 + sg, tid, (NX + NG + h * (R + 1) + R) * cpr);
+            }
         }
+    }
+    if constexpr (POOL) {
+#pragma unroll
+        for (int k = 0; k < (ACTIVE ? 3 : 1); ++k)
+            if (pdst[k] >= 0) pooled_store(pq[k], pcnt[k], pcol[k], pdst[k]);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
@@ -382,6 +452,16 @@ __global__ __launch_bounds__(kThreads) void step_backward(const StepParams p) {
                     if (src < 0) {
 #pragma unroll
                         for (int e = 0; e < E; ++e) t.e[e] = zero;
+                    } else if constexpr (POOL) {
+                        const int pr = static_cast<int>(fdiv(static_cast<uint32_t>(src), p.d_k1));
+                        const int rc = min(p.K1, S1 - pr * p.K1);
+#pragma unroll
+                        for (int e = 0; e < E; ++e) {
+                            const int col = gm.cm[e] >= 0 ? gm.cm[e] : 0;
+                            const int pc = static_cast<int>(fdiv(static_cast<uint32_t>(col), p.d_k2));
+                            const S q = narrow<T>(div_count<CT>(widen<T>(gp[static_cast<int64_t>(pr) * p.P2 + pc]), rc * min(p.K2, S2 - pc * p.K2)));
+                            t.e[e] = gm.cm[e] >= 0 ? q : zero;
+                        }
                     } else if (gcontig) {
                         t = load_chunk<S, E>(gp + static_cast<int64_t>(src) * S2 + gm.cm[0]);
                     } else {
@@ -623,10 +703,10 @@ __global__ __launch_bounds__(kThreads) void step_gather_forward_small(const Gath
 
 // The interpolating forward of 4- / 8-byte elements in the same shape, by direct loads: per corner row one element-aligned
 // 16-byte raw-buffer load for the chunk's E columns and one element load for column E.  The buffer resource is the
-// (n, c) plane, so a window that starts before the plane or ends behind it reads zeros instead of faulting, and a window
-// that starts before its ROW (zeros padding: shift to the right at the row start) reads the neighbouring row's tail,
-// which the column mask then discards: with zeros padding every chunk is affine and the kernel has no branch and no
-// element path at all.  The other paddings send the chunks at the row ends through the element-by-element map.
+// (n, c) plane; a window that starts before its ROW (zeros padding: shift to the right at the row start) reads the
+// neighbouring row's tail, which the column mask then discards, so with zeros padding every chunk inside the plane is one
+// window; the windows that would straddle the plane's first or last byte, and the row-end chunks of the other paddings, go
+// element by element.
 template <typename T, int PAD>
 __global__ __launch_bounds__(kThreads) void step_active_forward_direct(const GatherParams p) {
     using S = typename T::S;
@@ -671,8 +751,11 @@ __global__ __launch_bounds__(kThreads) void step_active_forward_direct(const Gat
     for (int hb = 0; hb < 2; ++hb) {
         const int rb = row_map_t<PAD>(r + p.L1 + hb, cs1, p.S1);
         const int rowoff = (rb < 0 ? 0 : rb) * p.S2;
-        if (PAD == 0 || affine) {
-            const uint32_t off = static_cast<uint32_t>(rowoff + base) * ES;  // (a negative window start wraps out of range: zeros)
+        // (the first row's windows that start before the plane, and the last row's that end behind it, take the element
+        //  path: a 16-byte buffer load that straddles the resource's range is answered with zeros as a whole)
+        const bool inside = rowoff + base >= 0 && rowoff + base + E + 1 <= static_cast<int>(p.x_plane);
+        if ((PAD == 0 || affine) && inside) {
+            const uint32_t off = static_cast<uint32_t>(rowoff + base) * ES;
             S raw[E + 1];
             if constexpr (ES == 4) {
                 typedef uint32_t u4 __attribute__((ext_vector_type(4)));
@@ -911,7 +994,11 @@ int launch_step_backward(StepParams &p, const StepLayout &L, bool active, void *
     const size_t lds = step_lds_bytes(L, ND, active);
     const dim3 grid(p.steps_per_xcd * 8), block(kThreads);
 #define SHIFTND_STEP_PAD(ACT, PADV) \
-    case PADV: hipLaunchKernelGGL((step_backward<T, ND, ACT, PADV>), grid, block, lds, st, p); break;
+    case PADV: \
+        if constexpr (ND == 2) { \
+            if (p.K1 > 0) { hipLaunchKernelGGL((step_backward<T, ND, ACT, PADV, true>), grid, block, lds, st, p); break; } \
+        } \
+        hipLaunchKernelGGL((step_backward<T, ND, ACT, PADV>), grid, block, lds, st, p); break;
     if (active) {
         hipLaunchKernelGGL((step_prep<T, true>), dim3(p.C), block, 0, st, p);
         switch (p.pad) { SHIFTND_STEP_PAD(true, 0) SHIFTND_STEP_PAD(true, 1) SHIFTND_STEP_PAD(true, 2) SHIFTND_STEP_PAD(true, 3) default: SHIFTND_STEP_PAD(true, 4) }
@@ -931,17 +1018,37 @@ void step_set_tuning(int knob, int value) {
 }
 
 // contiguous 2-D / 3-D problems without crop whose rows are whole 16-byte pieces and at most one workgroup pass wide
+static bool step_backward_core(const Geometry &g, int dtype, const void *go, const void *x, const void *gx);
+
 bool step_backward_eligible(const Geometry &g, int dtype, const void *go, const void *x, const void *gx) {
+    return g.K[0] <= 0 && step_backward_core(g, dtype, go, x, gx);
+}
+
+// the fused shift + average-pool backward (2-D; `go` = gradient of the pooled output, contiguous)
+bool step_backward_pooled_eligible(const Geometry &g, int dtype, const void *go, const void *x, const void *gx) {
+    if (!(g.K[0] > 0 && g.nd == 2)) return false;
+    (void)go;
+    // the interpolating shift expands three pooled pieces per thread and is faster on the band-walk kernel (N64 C256 224x224
+    // fp32: 2.58 vs 2.22 ms); the sparse shift: 1.60 vs 1.65 ms, fp16 C512 1.98 vs 2.34 ms, N128 C512 56x56 0.43 vs 0.51 ms
+    if (g.active && g_step_tune[0] != 2) return false;
+    return step_backward_core(g, dtype, nullptr, x, gx);
+}
+
+static bool step_backward_core(const Geometry &g, int dtype, const void *go, const void *x, const void *gx) {
     if (g_step_tune[0] == 1) return false;
-    if (dtype > SHIFTND_BF16 || (g.nd != 2 && g.nd != 3) || g.K[0] > 0) return false;
+    if (dtype > SHIFTND_BF16 || (g.nd != 2 && g.nd != 3)) return false;
     const int es = dtype_size(dtype);
     for (int d = 0; d < 3; ++d)
         if (g.O[d] != g.S[d] || g.L[d] != 0) return false;
     if ((g.nd == 2 && g.S[0] != 1) || g.S[0] < 1 || g.S[1] < 1 || g.S[2] < 1) return false;
     if ((g.S[2] * es) % 16 != 0 || g.S[2] * es / 16 > kThreads || g.S[2] > 32000) return false;
     if (g.S[0] * g.S[1] * g.S[2] >= (1LL << 30)) return false;
-    if (!dense(g.xs, g.N, g.C, g.S) || !dense(g.os, g.N, g.C, g.O) || !dense(g.gs, g.N, g.C, g.S)) return false;
-    if (reinterpret_cast<uintptr_t>(go) % 16 || reinterpret_cast<uintptr_t>(x) % 16 || reinterpret_cast<uintptr_t>(gx) % 16) return false;
+    if (g.K[0] > 0) {  // pooled calls: the gradient has the pooled shape (contiguous by contract)
+        if (!dense(g.xs, g.N, g.C, g.S) || !dense(g.gs, g.N, g.C, g.S)) return false;
+    } else if (!dense(g.xs, g.N, g.C, g.S) || !dense(g.os, g.N, g.C, g.O) || !dense(g.gs, g.N, g.C, g.S)) {
+        return false;
+    }
+    if ((g.K[0] <= 0 && reinterpret_cast<uintptr_t>(go) % 16) || reinterpret_cast<uintptr_t>(x) % 16 || reinterpret_cast<uintptr_t>(gx) % 16) return false;
     const StepLayout L = step_layout(g, es);
     if (L.total_steps + 8 >= (1ull << 31)) return false;
     if (step_lds_bytes(L, g.nd, g.active != 0) > 64 * 1024) return false;
@@ -1169,7 +1276,16 @@ int step_backward(const Geometry &g, int dtype, const void *go, const void *x, c
     p.d_per0 = make_fastdiv(static_cast<uint32_t>(map_period(p.S0, g.pad)));
     p.d_per1 = make_fastdiv(static_cast<uint32_t>(map_period(p.S1, g.pad)));
     p.d_per2 = make_fastdiv(static_cast<uint32_t>(map_period(p.S2, g.pad)));
-    note_kernel("step_backward");
+    if (g.K[0] > 0) {  // fused average-pool tail
+        p.K1 = static_cast<int>(g.K[1]);
+        p.K2 = static_cast<int>(g.K[2]);
+        p.P1 = static_cast<int>(g.P[1]);
+        p.P2 = static_cast<int>(g.P[2]);
+        p.g_plane = g.P[1] * g.P[2];
+        p.d_k1 = make_fastdiv(static_cast<uint32_t>(p.K1));
+        p.d_k2 = make_fastdiv(static_cast<uint32_t>(p.K2));
+    }
+    note_kernel(g.K[0] > 0 ? "step_backward_pool" : "step_backward");
     const bool active = g.active != 0;
 #define SHIFTND_STEP_T(TT) (g.nd == 3 ? launch_step_backward<TT, 3>(p, L, active, gw, st) : launch_step_backward<TT, 2>(p, L, active, gw, st))
     switch (dtype) {

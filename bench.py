@@ -198,6 +198,9 @@ def parse_args(argv):
                     help="let --gpus N run on a box with fewer than N GPUs (ranks share devices over gloo): a functional "
                          "check of the rank code, never a scaling point.  Without it such a request is an error.")
     ap.add_argument("--no-probe", action="store_true", help="skip the same-box stream calibration (tools/stream_probe)")
+    ap.add_argument("--force-process-group", action="store_true",
+                    help="initialise the process group (RCCL on a GPU box) even for --gpus 1: exercises the rendezvous, "
+                         "barrier, all_gather and all_reduce(MAX) calls of the multi-GPU path on a 1-GPU box (tests)")
     ap.add_argument("--device", default="cuda", choices=("cuda", "cpu"),
                     help="cpu = run the rank/launcher plumbing on the CPU dispatch key with gloo (tests only; "
                          "no roofline, never a result)")
@@ -251,8 +254,10 @@ def main(argv=None):
         dev = torch.device("cuda", dev_index)
     else:
         dev = torch.device("cpu")
-    if world > 1:
+    use_pg = world > 1 or a.force_process_group
+    if use_pg:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", str(free_port()))
         import datetime
         limit = datetime.timedelta(seconds=int(os.environ.get("SHIFTND_BENCH_TIMEOUT_S", "300")))
         if backend == "nccl":
@@ -315,7 +320,7 @@ def main(argv=None):
 
     def barrier():
         sync()
-        if world > 1:
+        if use_pg:
             dist.barrier()
         sync()
 
@@ -328,7 +333,7 @@ def main(argv=None):
     barrier()
     dt = time.perf_counter() - t0
     per_rank_ms = [dt / a.steps * 1e3]
-    if world > 1:
+    if use_pg:
         t = torch.tensor([dt], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         every = [torch.zeros_like(t) for _ in range(world)]
         dist.all_gather(every, t)
@@ -415,7 +420,7 @@ def main(argv=None):
                                    % (a.pad, world),
                        "path": ("torch.ops.torchshifts._shift%dd_forward/_backward -> libshiftnd_hip.so (%s kernels)"
                                 % (nd, path)) if on_gpu else "torch.ops.torchshifts (CPU dispatch key of _C.so)",
-                       "ranks": {"world": world, "backend": backend if world > 1 else None, "devices": ndev,
+                       "ranks": {"world": world, "backend": backend if use_pg else None, "devices": ndev,
                                  "oversubscribed": oversubscribed,
                                  "device_name": torch.cuda.get_device_name(dev) if on_gpu else None}},
             "per_rank_ms": per_rank_ms,
@@ -442,7 +447,7 @@ def main(argv=None):
         if base is not None:
             result["cpu_baseline"] = base
         print(json.dumps(result), flush=True)
-    if world > 1:
+    if use_pg:
         dist.barrier()
         dist.destroy_process_group()
 

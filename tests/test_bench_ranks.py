@@ -100,3 +100,15 @@ def test_self_launch_two_ranks_on_this_gpu_box():
     assert len(j) == 1 and j[0]["n_gpus"] == 2
     assert j[0]["roofline"]["kernel"].startswith(("plane_", "sweep_", "step_"))
     assert "cpu_baseline" not in j[0]
+
+
+@pytest.mark.gpu
+def test_rccl_calls_of_the_rank_code_on_one_gpu():
+    """the multi-GPU path's collectives with the backend it uses on a real node -- RCCL (`nccl`), device-bound process
+    group, barrier, all_gather and all_reduce(MAX) of GPU tensors -- on the one GPU of this box (world size 1)"""
+    r = _run(["--gpus", "1", "--force-process-group", "--shape", "8,32,56,56", "--steps", "3", "--warmup", "1",
+              "--no-cpu-baseline", "--no-probe"])
+    assert r.returncode == 0, r.stderr[-2000:]
+    j = _json_lines(r.stdout)
+    assert len(j) == 1 and j[0]["n_gpus"] == 1 and j[0]["config"]["ranks"]["backend"] == "nccl"
+    assert len(j[0]["per_rank_ms"]) == 1 and abs(j[0]["per_rank_ms"][0] - j[0]["ms_per_step"]) < 1e-9

@@ -40,10 +40,13 @@ def main():
     ap.add_argument("--pad", type=int, default=0)
     ap.add_argument("--iters", type=int, default=10)
     ap.add_argument("--rounds", type=int, default=3)
+    ap.add_argument("--no-step", action="store_true", help="knob 32 = 1: the band-walk kernels instead of the one-step kernels")
     ap.add_argument("--force-fused", action="store_true", help="path policy 2: fuse the backward even where the automatic choice would not")
     a = ap.parse_args()
     shape = [int(v) for v in a.shape.split(",")]
     nd = len(shape) - 2
+    if a.no_step:
+        abi.set_tuning(32, 1)
     dt = getattr(torch, a.dtype)
     dev = torch.device("cuda:0")
     torch.manual_seed(0)
@@ -93,6 +96,7 @@ def main():
         for kk, fn in fns.items():
             best[kk] = min(best[kk], ev_time(fn, a.iters))
     print("shape %s pool %d %s active %d pad %d" % (shape, a.pool, a.dtype, a.active, a.pad))
+    print("backward kernel:", abi.last_kernel())
     for kk in fns:
         print("%-12s %8.3f ms   %7.1f GB/s algorithmic (%.2f GB)" % (kk, best[kk], traffic[kk] / best[kk] / 1e6, traffic[kk] / 1e9))
 

@@ -33,7 +33,7 @@
 namespace shiftnd {
 namespace {
 
-// knobs (shiftnd_set_tuning 32..): [0] backward, [1] gather forward (direct loads), [2] forwards through LDS: 0 = automatic, 1 = never, 2 = whenever eligible; [3] 1 = 3-D backward too
+// knobs (shiftnd_set_tuning 32..): [0] backward, [1] gather forward (direct loads), [2] forwards through LDS: 0 = automatic, 1 = never, 2 = whenever eligible; [3] bit 0: 3-D backward too, bit 1 / bit 2: one / two row groups per thread always
 thread_local int g_step_tune[4] = {0, 0, 0, 0};
 
 struct ChanDesc {  // per channel, written by step_prep
@@ -200,9 +200,13 @@ template <int PAD> __device__ __forceinline__ int canon_shift32(int s, int len, 
     }
 }
 
-template <typename T, int ND, bool ACTIVE, int PAD, bool POOL = false>
+// U = row groups per thread: a workgroup owns U * R rows.  U = 2 halves the per-workgroup scalar work and the column-state
+// prologue per byte -- for the variants that are bound by instruction issue rather than by memory order (16-bit data, the
+// interpolating shift); the light fp32 sparse shift keeps U = 1 (the tighter sweep front: DESIGN 3.16).
+template <typename T, int ND, bool ACTIVE, int PAD, bool POOL = false, int U = 1>
 __global__ __launch_bounds__(kThreads) void step_backward(const StepParams p) {
     static_assert(!POOL || ND == 2, "the fused pool tail is 2-D here");
+    static_assert(!POOL || U == 1, "the pooled variant keeps one row group per thread");
     using S = typename T::S;
     using CT = typename T::C;
     constexpr int E = 16 / sizeof(S);
@@ -223,11 +227,12 @@ __global__ __launch_bounds__(kThreads) void step_backward(const StepParams p) {
     const int c = static_cast<int>(plane - fdiv(plane, p.d_C) * static_cast<uint32_t>(p.C));
     const ChanDesc d = p.desc[c];
     const int R = p.R, S0 = p.S0, S1 = p.S1, S2 = p.S2, cpr = p.cpr;
-    const int b0 = step * R;
-    const int Rn = min(R, S1 - b0);
+    const int RT = U * R;  // rows of this step
+    const int b0 = step * RT;
+    const int Rn = min(RT, S1 - b0);
     // staged groups, in rows of the tile: X planes [NP][R + 1], G [R], GS: active [NP][R + 1], 3-D sparse [R], 2-D sparse none
-    const int NX = NP * (R + 1), NG = R;
-    const int NGS = ACTIVE ? NP * (R + 1) : (SCAT ? 0 : R);
+    const int NX = NP * (RT + 1), NG = RT;
+    const int NGS = ACTIVE ? NP * (RT + 1) : (SCAT ? 0 : RT);
     const int npieces = (NX + NG + NGS) * cpr;
     const int RB = S2 * static_cast<int>(sizeof(S));
     const S *xp = static_cast<const S *>(p.x) + static_cast<int64_t>(plane) * p.x_plane;
@@ -244,7 +249,6 @@ __global__ __launch_bounds__(kThreads) void step_backward(const StepParams p) {
     // ---- the thread's chunk: column state through both maps -----------------------------------------------------
     const int tid = static_cast<int>(threadIdx.x);
     const int tr = static_cast<int>(fdiv(static_cast<uint32_t>(tid), p.d_cpr)), tc = tid - tr * cpr;
-    const bool worker = tr < Rn;
     const int ji = tc * E;
     ColState<E> xm, gm;
     if constexpr (PAD == 0) {  // zeros: column j0 + e reads column j0 + e - shift when that is a column
@@ -312,55 +316,59 @@ __global__ __launch_bounds__(kThreads) void step_backward(const StepParams p) {
     };
     Chunk<S, E> pq[POOL ? (ACTIVE ? 3 : 1) : 1];
     int pcnt[3] = {0, 0, 0}, pdst[3] = {-1, -1, -1}, pcol[3] = {0, 0, 0};
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
     if (tr < R) {
-        const int sx = tr <= Rn ? row_map_t<PAD>(b0 + tr, d.cx1, S1) : -1;  // corner rows of x: m1[b0 + tr]
+        const int vtr = tr + u * R, vtid = tid + u * R * cpr;  // this row group's row / piece index
+        const int sx = vtr <= Rn ? row_map_t<PAD>(b0 + vtr, d.cx1, S1) : -1;  // corner rows of x: m1[b0 + tr]
 #pragma unroll
         for (int h = 0; h < NP; ++h)
-            if (sx >= 0 && pax[h] >= 0) dma(xp, pax[h] * S1 + sx, tc, h * (R + 1) * cpr);
-        if (tr < Rn) {  // the incoming gradient at the rows themselves
+            if (sx >= 0 && pax[h] >= 0) dma(xp, pax[h] * S1 + sx, tc, h * (RT + 1) * cpr + u * R * cpr);
+        if (vtr < Rn) {  // the incoming gradient at the rows themselves
             if constexpr (POOL) {
-                pooled_load(b0 + tr, tc, pq[0], pcnt[0]);
-                pdst[0] = NX * cpr + tid;
+                pooled_load(b0 + vtr, tc, pq[0], pcnt[0]);
+                pdst[0] = NX * cpr + vtid;
                 pcol[0] = tc;
             } else {
-                dma(gp, a * S1 + b0 + tr, tc, NX * cpr);
+                dma(gp, a * S1 + b0 + vtr, tc, NX * cpr + u * R * cpr);
             }
         }
         if constexpr (ACTIVE) {
-            const int sg = tr <= Rn ? row_map_t<PAD>(b0 + tr, d.cg1, S1) : -1;  // the rows grad_x blends: g1[b0 + tr]
+            const int sg = vtr <= Rn ? row_map_t<PAD>(b0 + vtr, d.cg1, S1) : -1;  // the rows grad_x blends: g1[b0 + tr]
             if constexpr (POOL) {
                 if (sg >= 0) {
                     pooled_load(sg, tc, pq[1], pcnt[1]);
-                    pdst[1] = (NX + NG) * cpr + tid;
+                    pdst[1] = (NX + NG) * cpr + vtid;
                     pcol[1] = tc;
                 }
             } else {
 #pragma unroll
                 for (int h = 0; h < NP; ++h)
-                    if (sg >= 0 && pag[h] >= 0) dma(gp, pag[h] * S1 + sg, tc, (NX + NG + h * (R + 1)) * cpr);
+                    if (sg >= 0 && pag[h] >= 0) dma(gp, pag[h] * S1 + sg, tc, (NX + NG + h * (RT + 1)) * cpr + u * R * cpr);
             }
         } else if constexpr (!SCAT) {
-            const int sg = tr < Rn ? row_map_t<PAD>(b0 + tr, d.cg1, S1) : -1;  // 3-D sparse shift: the one row grad_x copies
-            if (sg >= 0 && pag[0] >= 0) dma(gp, pag[0] * S1 + sg, tc, (NX + NG) * cpr);
+            const int sg = vtr < Rn ? row_map_t<PAD>(b0 + vtr, d.cg1, S1) : -1;  // 3-D sparse shift: the one row grad_x copies
+            if (sg >= 0 && pag[0] >= 0) dma(gp, pag[0] * S1 + sg, tc, (NX + NG) * cpr + u * R * cpr);
         }
     }
-    if (Rn == R && tid < cpr) {  // the + 1 corner row of a full step (a ragged last step has it among its first R rows)
-        const int sx = row_map_t<PAD>(b0 + R, d.cx1, S1);
+    }
+    if (Rn == RT && tid < cpr) {  // the + 1 corner row of a full step (a ragged last step has it among its first R rows)
+        const int sx = row_map_t<PAD>(b0 + RT, d.cx1, S1);
 #pragma unroll
         for (int h = 0; h < NP; ++h)
-            if (sx >= 0 && pax[h] >= 0) dma(xp, pax[h] * S1 + sx, tid, (h * (R + 1) + R) * cpr);
+            if (sx >= 0 && pax[h] >= 0) dma(xp, pax[h] * S1 + sx, tid, (h * (RT + 1) + RT) * cpr);
         if constexpr (ACTIVE) {
-            const int sg = row_map_t<PAD>(b0 + R, d.cg1, S1);
+            const int sg = row_map_t<PAD>(b0 + RT, d.cg1, S1);
             if constexpr (POOL) {
                 if (sg >= 0) {
                     pooled_load(sg, tid, pq[2], pcnt[2]);
-                    pdst[2] = (NX + NG + R) * cpr + tid;
+                    pdst[2] = (NX + NG + RT) * cpr + tid;
                     pcol[2] = tid;
                 }
             } else {
 #pragma unroll
                 for (int h = 0; h < NP; ++h)
-                    if (sg >= 0 && pag[h] >= 0) dma(gp, pag[h] * S1 + sg, tid, (NX + NG + h * (R + 1) + R) * cpr);
+                    if (sg >= 0 && pag[h] >= 0) dma(gp, pag[h] * S1 + sg, tid, (NX + NG + h * (RT + 1) + RT) * cpr);
             }
         }
     }
@@ -375,8 +383,11 @@ __global__ __launch_bounds__(kThreads) void step_backward(const StepParams p) {
     CT part[NDIFF];
 #pragma unroll
     for (int i = 0; i < NDIFF; ++i) part[i] = CT(0);
-    if (worker) {
-        const int b = b0 + tr;
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+    const int vtr = tr + u * R;
+    if (tr < R && vtr < Rn) {
+        const int b = b0 + vtr;
         CT dw[3] = {static_cast<CT>(d.dw[0]), static_cast<CT>(d.dw[1]), static_cast<CT>(d.dw[2])};
         Chunk<S, E> res;
         // only zeros padding has rows without a source
@@ -391,7 +402,7 @@ __global__ __launch_bounds__(kThreads) void step_backward(const StepParams p) {
             for (int k = 0; k < NCC; ++k) {
                 const int ha = corner_plane(k), hb = corner_row(k);
                 S raw[E + 1];
-                lds_read_row<S, E>(tile + (NX + NG + ha * (R + 1) + tr + hb) * RB, pag[ha] >= 0 && row_valid(b + hb, d.cg1), gm, raw);
+                lds_read_row<S, E>(tile + (NX + NG + ha * (RT + 1) + vtr + hb) * RB, pag[ha] >= 0 && row_valid(b + hb, d.cg1), gm, raw);
 #pragma unroll
                 for (int e = 0; e <= E; ++e) gv[k][e] = widen<T>(raw[e]);
             }
@@ -407,7 +418,7 @@ __global__ __launch_bounds__(kThreads) void step_backward(const StepParams p) {
             // 3-D: the staged row g1[b] of plane g0[a]
             S graw[E + 1];
             const bool gvalid = SCAT || (pag[0] >= 0 && row_valid(b, d.cg1));
-            lds_read_row<S, E>(tile + ((SCAT ? NX : NX + NG) + tr) * RB, gvalid, gm, graw);
+            lds_read_row<S, E>(tile + ((SCAT ? NX : NX + NG) + vtr) * RB, gvalid, gm, graw);
 #pragma unroll
             for (int e = 0; e < E; ++e) res.e[e] = graw[e];
         }
@@ -417,12 +428,12 @@ __global__ __launch_bounds__(kThreads) void step_backward(const StepParams p) {
         for (int k = 0; k < NCC; ++k) {
             const int ha = corner_plane(k), hb = corner_row(k);
             S raw[E + 1];
-            lds_read_row<S, E>(tile + (ha * (R + 1) + tr + hb) * RB, pax[ha] >= 0 && row_valid(b + hb, d.cx1), xm, raw);
+            lds_read_row<S, E>(tile + (ha * (RT + 1) + vtr + hb) * RB, pax[ha] >= 0 && row_valid(b + hb, d.cx1), xm, raw);
 #pragma unroll
             for (int e = 0; e <= E; ++e) xv[k][e] = widen<T>(raw[e]);
         }
         Chunk<S, E> gch;
-        __builtin_memcpy(gch.e, __builtin_assume_aligned(tile + (NX + tr) * RB + ji * static_cast<int>(sizeof(S)), 16), 16);
+        __builtin_memcpy(gch.e, __builtin_assume_aligned(tile + (NX + vtr) * RB + ji * static_cast<int>(sizeof(S)), 16), 16);
 #pragma unroll
         for (int e = 0; e < E; ++e) {
             CT v[1 << ND], df[NDIFF];
@@ -474,6 +485,7 @@ __global__ __launch_bounds__(kThreads) void step_backward(const StepParams p) {
         } else {
             store_chunk<S, E>(gxp + static_cast<int64_t>(b) * S2 + ji, res);
         }
+    }
     }
     // ---- this step's sums: DPP tree per wave, the four waves added in fp64 by one thread ----------------------------
     double *scratch = reinterpret_cast<double *>(tile + ((npieces * 16 + 63) & ~63));
@@ -957,10 +969,21 @@ bool dense(const int64_t st[5], int64_t N, int64_t C, const int64_t sz[3]) {
 }
 
 struct StepLayout {
-    int cpr, R, spp, spv, rec, ndiff;
+    int cpr, R, U, spp, spv, rec, ndiff;
     uint64_t total_steps;
     size_t off_desc, off_colx, off_colg, bytes;
 };
+
+// row groups per thread (knob 35 bit 1 = 2: always one, bit 2 = 4: always two): two for 16-bit data, where the kernel is
+// bound by instruction issue (same box, one vs two: fp16 C512 224x224 reflect 1.80 -> 1.67 ms, interpolating 1.91 -> 1.79,
+// bf16 N128 C256 56x56 0.126 -> 0.109; zeros padding 1.61 vs 1.62); one for 4- / 8-byte elements (fp32 sparse 1.58 vs 1.62,
+// interpolating 1.63 vs 1.67 ms: the tighter sweep front wins), 3-D and pooled calls
+int step_row_groups(const Geometry &g, int es) {
+    if (g.nd != 2 || g.K[0] > 0) return 1;
+    if (g_step_tune[3] & 2) return 1;
+    if (g_step_tune[3] & 4) return 2;
+    return es == 2 ? 2 : 1;
+}
 
 StepLayout step_layout(const Geometry &g, int es) {
     StepLayout L{};
@@ -969,7 +992,9 @@ StepLayout step_layout(const Geometry &g, int es) {
     if (L.cpr < 1) L.cpr = 1;
     L.R = kThreads / L.cpr < 1 ? 1 : kThreads / L.cpr;
     if (L.R > g.S[1]) L.R = static_cast<int>(g.S[1] > 0 ? g.S[1] : 1);
-    L.spp = static_cast<int>((g.S[1] + L.R - 1) / L.R);
+    L.U = step_row_groups(g, es);
+    if (L.U * L.R > g.S[1] && L.R >= g.S[1]) L.U = 1;  // (one row group already covers the plane)
+    L.spp = static_cast<int>((g.S[1] + L.U * L.R - 1) / (L.U * L.R));
     L.spv = static_cast<int>(g.S[0]) * L.spp;
     L.rec = (E + 3 <= 8) ? 8 : 16;
     L.ndiff = g.nd == 3 ? 8 : 2;
@@ -984,7 +1009,8 @@ StepLayout step_layout(const Geometry &g, int es) {
 
 size_t step_lds_bytes(const StepLayout &L, int nd, bool active) {
     const int np = nd == 3 ? 2 : 1;
-    const int slots = np * (L.R + 1) + L.R + (active ? np * (L.R + 1) : (nd == 3 ? L.R : 0));
+    const int RT = L.U * L.R;
+    const int slots = np * (RT + 1) + RT + (active ? np * (RT + 1) : (nd == 3 ? RT : 0));
     return 64 + ((static_cast<size_t>(slots) * L.cpr * 16 + 63) & ~static_cast<size_t>(63)) + (kThreads / 64) * L.ndiff * sizeof(double);
 }
 
@@ -997,6 +1023,7 @@ int launch_step_backward(StepParams &p, const StepLayout &L, bool active, void *
     case PADV: \
         if constexpr (ND == 2) { \
             if (p.K1 > 0) { hipLaunchKernelGGL((step_backward<T, ND, ACT, PADV, true>), grid, block, lds, st, p); break; } \
+            if (L.U == 2) { hipLaunchKernelGGL((step_backward<T, ND, ACT, PADV, false, 2>), grid, block, lds, st, p); break; } \
         } \
         hipLaunchKernelGGL((step_backward<T, ND, ACT, PADV>), grid, block, lds, st, p); break;
     if (active) {
@@ -1053,7 +1080,7 @@ static bool step_backward_core(const Geometry &g, int dtype, const void *go, con
     if (L.total_steps + 8 >= (1ull << 31)) return false;
     if (step_lds_bytes(L, g.nd, g.active != 0) > 64 * 1024) return false;
     if (g_step_tune[0] == 2) return true;
-    return g.nd == 2 || g_step_tune[3] == 1;  // 3-D: knob 35 = 1
+    return g.nd == 2 || (g_step_tune[3] & 1);  // 3-D: knob 35 bit 0
 }
 
 // sparse-shift / quantized forward of 4- and 8-byte elements: dense tensors, output rows of whole 16-byte chunks and at

@@ -108,7 +108,7 @@ int forward_common(const shiftnd_problem *p, const void *x, const int64_t *xs, c
         }
         // 2-D sparse shift of 4- / 8-byte elements on planes of >= 32 KiB: the linear sweep of one-step workgroups
         if (g_policy == 0 && wkind <= SHIFTND_BF16 && step_forward_lds_eligible(g, p->dtype, x, out)) {
-            g_last_path = SHIFTND_PATH_SWEEP;
+            g_last_path = SHIFTND_PATH_PLANE;  // (LDS-staged, like the per-channel kernels it supersedes)
             return finish(step_forward_lds(g, p->dtype, x, w, wkind, fill, out, st));
         }
         if (can_sweep && (g_policy == 3 || (g_policy == 0 && prefer_sweep))) {

@@ -839,12 +839,12 @@ template <int E, int PAD> __device__ __forceinline__ ColState<E> fold_colstate(i
     return c;
 }
 
-template <typename T, bool ACTIVE, int PAD>
+template <typename T, bool ACTIVE, int PAD, int U>
 __global__ __launch_bounds__(kThreads) void step_forward_lds(const FwdParams p) {
     using S = typename T::S;
     using CT = typename T::C;
     constexpr int E = 16 / sizeof(S);
-    constexpr int KP = 4;  // staged pieces per thread (host: (R + 1) * xppr <= 4 * 256)
+    constexpr int KP = 4;  // staged pieces per thread of the generic (cropped) staging loop (host: (U R + 1) * xppr <= 4 * 256)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char *tile = smem + 64;  // 64-byte pads in front and behind: see lds_read_row
 
@@ -862,64 +862,94 @@ __global__ __launch_bounds__(kThreads) void step_forward_lds(const FwdParams p) 
     const int cs2 = __builtin_amdgcn_readfirstlane(canon_of<PAD, CT>(rc, p.S2, p.d_per2));
 
     const int R = p.R, S1 = p.S1, S2 = p.S2, cpr = p.cpr, xppr = p.xppr;
-    const int b0 = step * R;
-    const int Rn = min(R, p.O1 - b0);
-    const int NX = R + (ACTIVE ? 1 : 0);
-    const int npieces = NX * xppr;
-    const int RB = S2 * static_cast<int>(sizeof(S));
+    const int RT = U * R;
+    const int b0 = step * RT;
+    const int Rn = min(RT, p.O1 - b0);
+    const int last = Rn - (ACTIVE ? 0 : 1);  // last staged row of the step (the interpolating shift: + 1 corner row)
     const S *xp = static_cast<const S *>(p.x) + static_cast<int64_t>(plane) * p.x_plane;
     S *op = static_cast<S *>(p.out) + static_cast<int64_t>(plane) * p.o_plane;
 
     const int tid = static_cast<int>(threadIdx.x);
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-#pragma unroll
-    for (int k = 0; k < KP; ++k) {
-        if (k * kThreads < npieces) {  // uniform
-            const int q = k * kThreads + tid;
-            const int slot = static_cast<int>(fdiv(static_cast<uint32_t>(q), p.d_xppr));
-            const int j = q - slot * xppr;
-            int src = row_map_t<PAD>(b0 + p.L1 + slot, cs1, S1);
-            if (slot > Rn - (ACTIVE ? 0 : 1) || q >= npieces) src = -1;
-            const uint32_t off = static_cast<uint32_t>(src * S2 + j * E) * static_cast<uint32_t>(sizeof(S));
-            char *dst_wave = tile + (k * kThreads + wave * 64) * 16;  // wave-uniform; hardware adds lane * 16
-            if (src >= 0)
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(reinterpret_cast<const char *>(xp) + off),
-                                                 (__attribute__((address_space(3))) void *)dst_wave, 16, 0, 2 /* nt */);
-        }
-    }
     const int tr = static_cast<int>(fdiv(static_cast<uint32_t>(tid), p.d_cpr)), tc = tid - tr * cpr;
-    const int jo = tc * E;
-    const ColState<E> xm = fold_colstate<E, PAD>(jo + p.L2, cs2, S2);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (tr >= Rn) return;
-    const int b = b0 + tr;
-    auto row_valid = [&](int pr) { return PAD != 0 || row_map_t<PAD>(pr, cs1, S1) >= 0; };
-    Chunk<S, E> res;
-    if constexpr (ACTIVE) {
-        CT xv[2][E + 1];
+    auto dma = [&](int src_row, int col_piece, int lds_piece0) {
+        const uint32_t off = static_cast<uint32_t>(src_row * S2 + col_piece * E) * static_cast<uint32_t>(sizeof(S));
+        char *dst_wave = tile + (lds_piece0 + wave * 64) * 16;  // wave-uniform; hardware adds lane * 16
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(reinterpret_cast<const char *>(xp) + off),
+                                         (__attribute__((address_space(3))) void *)dst_wave, 16, 0, 2 /* nt */);
+    };
+    if (xppr == cpr) {  // no crop along the rows: thread (tr, tc) stages piece tc of its own rows (no index arithmetic)
 #pragma unroll
-        for (int hb = 0; hb < 2; ++hb) {
-            S raw[E + 1];
-            lds_read_row<S, E>(tile + (tr + hb) * RB, row_valid(b + p.L1 + hb), xm, raw);
-#pragma unroll
-            for (int e = 0; e <= E; ++e) xv[hb][e] = widen<T>(raw[e]);
+        for (int u = 0; u < U; ++u) {
+            const int vtr = tr + u * R;
+            if (tr < R && vtr <= last) {
+                const int src = row_map_t<PAD>(b0 + p.L1 + vtr, cs1, S1);
+                if (src >= 0) dma(src, tc, u * R * cpr);
+            }
         }
-#pragma unroll
-        for (int e = 0; e < E; ++e) {
-            const CT v[4] = {xv[0][e], xv[1][e], xv[0][e + 1], xv[1][e + 1]};
-            res.e[e] = narrow<T>(interp_t<T, 2>(v, dw));
+        if (ACTIVE && Rn == RT && tid < cpr) {
+            const int src = row_map_t<PAD>(b0 + p.L1 + RT, cs1, S1);
+            if (src >= 0) dma(src, tid, RT * cpr);
         }
     } else {
-        S raw[E + 1], fill;
-        const typename raw_t<sizeof(S)>::type fill_bits = static_cast<typename raw_t<sizeof(S)>::type>(p.fill);
-        __builtin_memcpy(&fill, &fill_bits, sizeof(S));
-        const bool valid = row_valid(b + p.L1);
-        lds_read_row<S, E>(tile + tr * RB, valid, xm, raw);
+        const int npieces = (last + 1) * xppr;
 #pragma unroll
-        for (int e = 0; e < E; ++e) res.e[e] = (valid && xm.cm[e] >= 0) ? raw[e] : fill;
+        for (int k = 0; k < KP; ++k) {
+            if (k * kThreads < npieces) {  // uniform
+                const int q = k * kThreads + tid;
+                const int slot = static_cast<int>(fdiv(static_cast<uint32_t>(q), p.d_xppr));
+                const int j = q - slot * xppr;
+                int src = row_map_t<PAD>(b0 + p.L1 + slot, cs1, S1);
+                if (q >= npieces) src = -1;
+                if (src >= 0) dma(src, j, k * kThreads);
+            }
+        }
     }
-    store_chunk<S, E>(op + static_cast<int64_t>(b) * p.O2 + jo, res);
+    const int jo = tc * E;
+    ColState<E> xm;
+    if constexpr (PAD == 0) {  // zeros: column j reads column j - shift when that is a column (affine everywhere)
+        const int base = jo + p.L2 - cs2;
+        xm.base = (base + E < 0 || base >= S2) ? 0 : base;
+        xm.affine = true;
+#pragma unroll
+        for (int e = 0; e <= E; ++e) xm.cm[e] = (base + e >= 0 && base + e < S2) ? base + e : -1;
+    } else {
+        xm = fold_colstate<E, PAD>(jo + p.L2, cs2, S2);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    auto row_valid = [&](int pr) { return PAD != 0 || row_map_t<PAD>(pr, cs1, S1) >= 0; };
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const int vtr = tr + u * R;
+        if (tr >= R || vtr >= Rn) continue;
+        const int b = b0 + vtr;
+        Chunk<S, E> res;
+        if constexpr (ACTIVE) {
+            CT xv[2][E + 1];
+#pragma unroll
+            for (int hb = 0; hb < 2; ++hb) {
+                S raw[E + 1];
+                lds_read_row<S, E>(tile + (vtr + hb) * (xppr * 16), row_valid(b + p.L1 + hb), xm, raw);
+#pragma unroll
+                for (int e = 0; e <= E; ++e) xv[hb][e] = widen<T>(raw[e]);
+            }
+#pragma unroll
+            for (int e = 0; e < E; ++e) {
+                const CT v[4] = {xv[0][e], xv[1][e], xv[0][e + 1], xv[1][e + 1]};
+                res.e[e] = narrow<T>(interp_t<T, 2>(v, dw));
+            }
+        } else {
+            S raw[E + 1], fill;
+            const typename raw_t<sizeof(S)>::type fill_bits = static_cast<typename raw_t<sizeof(S)>::type>(p.fill);
+            __builtin_memcpy(&fill, &fill_bits, sizeof(S));
+            const bool valid = row_valid(b + p.L1);
+            lds_read_row<S, E>(tile + vtr * (xppr * 16), valid, xm, raw);
+#pragma unroll
+            for (int e = 0; e < E; ++e) res.e[e] = (valid && xm.cm[e] >= 0) ? raw[e] : fill;
+        }
+        store_chunk<S, E>(op + static_cast<int64_t>(b) * p.O2 + jo, res);
+    }
 }
 
 // grad_w[c][0..nd-1] = blend(sum over the steps of channel c, in a fixed order)
@@ -1194,19 +1224,26 @@ bool step_forward_lds_eligible(const Geometry &g, int dtype, const void *x, cons
     const int cpr = static_cast<int>(g.O[2] * es / 16), xppr = static_cast<int>(g.S[2] * es / 16);
     int64_t R = kThreads / cpr;
     if (R > g.O[1]) R = g.O[1];
-    if ((R + 1) * xppr > 4 * kThreads) return false;  // (heavy crops: few output chunks per source row)
+    if ((2 * R + 1) * xppr > 4 * kThreads) return false;  // (heavy crops: few output chunks per source row)
+    if (64 + (2 * R + 1) * xppr * 16 + 64 > 64 * 1024) return false;
     const int64_t spp = (g.O[1] + R - 1) / R;
     if (g.N * g.C * spp + 8 >= (1LL << 31)) return false;
-    // not taken automatically yet: at 8 KB per workgroup the per-workgroup prologue costs more than the sweep order returns
-    // (C5 forward 1.35 vs 1.10 ms of plane_gather_forward_lds, C2-tensor active forward 1.33 vs 1.10 ms)
-    return g_step_tune[2] == 2;
+    // knob 34: 0 = automatic (two row groups per thread), 1 = never, 2 / 3 = always, with one / two row groups
+    if (g_step_tune[2] >= 2) return true;
+    // same box, per-channel LDS kernels -> this one: interpolating fp32 N64 C256 224x224 1.09 -> 1.00 ms, N16 C64 448x448
+    // 0.39 -> 0.26, N128 C256 56x56 0.158 -> 0.135, bf16 0.079 -> 0.068, N256 C512 8x8 0.103 -> 0.086; sparse fp16 reflect
+    // C512 224x224 1.21 -> 1.06, bf16 56x56 0.078 -> 0.064; the one loss: sparse 2-byte planes of 2 KiB (32x32: 0.059 -> 0.064)
+    return interpolating || oe * es >= 4 * 1024;
 }
 
 template <typename T>
-static void launch_step_forward_lds(const FwdParams &p, bool active, int pad, size_t lds, hipStream_t st) {
+static void launch_step_forward_lds(const FwdParams &p, bool active, int pad, int U, size_t lds, hipStream_t st) {
     const dim3 grid(p.steps_per_xcd * 8), block(kThreads);
 #define SHIFTND_STEP_FWD_LDS(ACT, PADV) \
-    case PADV: hipLaunchKernelGGL((step_forward_lds<T, ACT, PADV>), grid, block, lds, st, p); break;
+    case PADV: \
+        if (U == 2) hipLaunchKernelGGL((step_forward_lds<T, ACT, PADV, 2>), grid, block, lds, st, p); \
+        else hipLaunchKernelGGL((step_forward_lds<T, ACT, PADV, 1>), grid, block, lds, st, p); \
+        break;
     if (active) {
         switch (pad) { SHIFTND_STEP_FWD_LDS(true, 0) SHIFTND_STEP_FWD_LDS(true, 1) SHIFTND_STEP_FWD_LDS(true, 2) SHIFTND_STEP_FWD_LDS(true, 3) default: SHIFTND_STEP_FWD_LDS(true, 4) }
     } else {
@@ -1236,7 +1273,9 @@ int step_forward_lds(const Geometry &g, int dtype, const void *x, const void *w,
     p.xppr = static_cast<int>(g.S[2] * es / 16);
     p.R = kThreads / p.cpr;
     if (p.R > p.O1) p.R = p.O1;
-    p.spp = (p.O1 + p.R - 1) / p.R;
+    int U = g_step_tune[2] == 2 ? 1 : 2;  // (one row group: C2-tensor interpolating forward 1.15 ms, two: 1.00 ms)
+    if (p.R >= p.O1) U = 1;
+    p.spp = (p.O1 + U * p.R - 1) / (U * p.R);
     const uint64_t total = static_cast<uint64_t>(g.N) * g.C * p.spp;
     p.total_steps = static_cast<uint32_t>(total);
     p.steps_per_xcd = static_cast<uint32_t>((total + 7) / 8);
@@ -1247,17 +1286,17 @@ int step_forward_lds(const Geometry &g, int dtype, const void *x, const void *w,
     p.d_per1 = make_fastdiv(static_cast<uint32_t>(map_period(p.S1, g.pad)));
     p.d_per2 = make_fastdiv(static_cast<uint32_t>(map_period(p.S2, g.pad)));
     const bool active = g.active != 0;
-    const size_t lds = 64 + static_cast<size_t>(p.R + (active ? 1 : 0)) * p.xppr * 16 + 64;
+    const size_t lds = 64 + static_cast<size_t>(U * p.R + (active ? 1 : 0)) * p.xppr * 16 + 64;
     note_kernel(active ? "step_active_forward" : "step_gather_forward_lds");
     if (!active) {  // a raw copy of 2-byte elements: one instantiation serves fp16 and bf16
-        launch_step_forward_lds<f16_t>(p, false, g.pad, lds, st);
+        launch_step_forward_lds<f16_t>(p, false, g.pad, U, lds, st);
         return SHIFTND_OK;
     }
     switch (dtype) {
-    case SHIFTND_F32: launch_step_forward_lds<f32_t>(p, true, g.pad, lds, st); break;
-    case SHIFTND_F64: launch_step_forward_lds<f64_t>(p, true, g.pad, lds, st); break;
-    case SHIFTND_F16: launch_step_forward_lds<f16_t>(p, true, g.pad, lds, st); break;
-    default: launch_step_forward_lds<bf16_t>(p, true, g.pad, lds, st); break;
+    case SHIFTND_F32: launch_step_forward_lds<f32_t>(p, true, g.pad, U, lds, st); break;
+    case SHIFTND_F64: launch_step_forward_lds<f64_t>(p, true, g.pad, U, lds, st); break;
+    case SHIFTND_F16: launch_step_forward_lds<f16_t>(p, true, g.pad, U, lds, st); break;
+    default: launch_step_forward_lds<bf16_t>(p, true, g.pad, U, lds, st); break;
     }
     return SHIFTND_OK;
 }

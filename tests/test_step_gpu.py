@@ -191,10 +191,13 @@ def test_active_forward_vs_oracle(abi, shape, crop, dt):
         assert abi.last_kernel() == "step_active_forward_direct", (shape, abi.last_kernel())
         assert np.array_equal(out.cpu().numpy(), ref), ("direct", shape, crop, pad)
         abi.set_tuning(33, 1)
-        out = abi.forward(xd, wd, pad, 1, b)  # through LDS
+        for groups in (2, 3):  # through LDS, one / two row groups per thread
+            abi.set_tuning(34, groups)
+            out = abi.forward(xd, wd, pad, 1, b)
+            assert abi.last_kernel() == "step_active_forward", (shape, abi.last_kernel())
+            assert np.array_equal(out.cpu().numpy(), ref), ("lds", shape, crop, pad, groups)
         abi.set_tuning(33, 2)
-        assert abi.last_kernel() == "step_active_forward", (shape, abi.last_kernel())
-        assert np.array_equal(out.cpu().numpy(), ref), ("lds", shape, crop, pad)
+        abi.set_tuning(34, 2)
 
 
 @pytest.mark.parametrize("tdt", [torch.float16, torch.bfloat16])
@@ -210,14 +213,17 @@ def test_16bit_forwards_vs_oracle(abi, shape, crop, tdt):
     b, new = abi.check_borders(list(shape), crop, 2)
     xd, wd = x16.to(DEV), w16.to(DEV)
     for pad in range(5):
-        abi.set_tuning(33, 1)  # (the direct-load kernel would take the sparse shift first: tested below)
-        out = abi.forward(xd, wd, pad, 0, b)
-        abi.set_tuning(33, 2)
-        assert abi.last_kernel() == "step_gather_forward_lds", (shape, abi.last_kernel())
-        assert torch.equal(out.cpu(), torch.from_numpy(O.forward(x, w, pad, 0, b)).to(tdt)), ("ssl", shape, pad)
-        out = abi.forward(xd, wd, pad, 1, b)
-        assert abi.last_kernel() == "step_active_forward", (shape, abi.last_kernel())
-        assert _ulp_close(out.cpu(), torch.from_numpy(O.forward(x, w, pad, 1, b)).to(tdt), tdt), ("active", shape, pad)
+        for groups in (2, 3):  # one / two row groups per thread
+            abi.set_tuning(34, groups)
+            abi.set_tuning(33, 1)  # (the direct-load kernel would take the sparse shift first: tested below)
+            out = abi.forward(xd, wd, pad, 0, b)
+            abi.set_tuning(33, 2)
+            assert abi.last_kernel() == "step_gather_forward_lds", (shape, abi.last_kernel())
+            assert torch.equal(out.cpu(), torch.from_numpy(O.forward(x, w, pad, 0, b)).to(tdt)), ("ssl", shape, pad, groups)
+            out = abi.forward(xd, wd, pad, 1, b)
+            assert abi.last_kernel() == "step_active_forward", (shape, abi.last_kernel())
+            assert _ulp_close(out.cpu(), torch.from_numpy(O.forward(x, w, pad, 1, b)).to(tdt), tdt), ("active", shape, pad, groups)
+        abi.set_tuning(34, 2)
 
 
 SHAPES3 = [(2, 3, 5, 6, 16), (1, 2, 20, 9, 64), (2, 2, 3, 40, 112), (1, 3, 1, 5, 8), (1, 2, 6, 1, 32), (1, 1, 3, 37, 512),

@@ -1,9 +1,6 @@
-mkdir -p gpurun_out/r03u
-exec > gpurun_out/r03u/log.txt 2>&1
-timeout 900 python3 -m pytest tests/test_step_gpu.py tests/test_fuzz_families_gpu.py -x -q 2>&1 | tail -5
-for wl in c2 c5 c2a c5a; do python3 tools/kbench.py --workload $wl --rounds 2 --iters 10 --knobs "35=2,4" | grep bwd; done
-python3 tools/kbench.py --workload c5 --pad 3 --rounds 2 --iters 10 --knobs "35=2,4" | grep bwd
-python3 tools/kbench.py --shape 128,256,56,56 --dtype bfloat16 --rounds 2 --iters 20 --knobs "35=2,4" | grep bwd
-python3 tools/kbench.py --shape 128,256,56,56 --active 1 --rounds 2 --iters 20 --knobs "35=2,4" | grep bwd
-python3 tools/kbench.py --shape 128,512,28,28 --active 1 --rounds 2 --iters 20 --knobs "35=2,4" | grep bwd
-python3 tools/kbench.py --shape 128,512,28,28 --rounds 2 --iters 20 --knobs "35=2,4" | grep bwd
+mkdir -p gpurun_out/r03v
+exec > gpurun_out/r03v/log3.txt 2>&1
+timeout 1500 python3 -m pytest tests -q -m gpu 2>&1 | tail -8
+python3 bench.py --workload c2a --no-cpu-baseline --steps 20 | python3 -c "
+import json,sys
+j=json.loads([l for l in sys.stdin if l.startswith('{')][-1]); print('c2a', j['ms_per_step'], {k:(round(v['ms'],4), round(v.get('frac_of_box',0),3)) for k,v in j['kernels'].items()})"

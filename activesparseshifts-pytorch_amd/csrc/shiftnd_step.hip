@@ -33,7 +33,7 @@
 namespace shiftnd {
 namespace {
 
-// knobs (shiftnd_set_tuning 32..): [0] backward, [1] gather forward (direct loads), [2] forwards through LDS: 0 = automatic, 1 = never, 2 = whenever eligible; [3] bit 0: 3-D backward too, bit 1 / bit 2: one / two row groups per thread always
+// knobs (shiftnd_set_tuning 32..): [0] backward, [1] gather forward (direct loads), [2] forwards through LDS: 0 = automatic, 1 = never, 2 = whenever eligible; [3] bit 0: 3-D backward too, bit 1 / bit 2: one / two row groups per thread always, bit 3: 3-D forwards through LDS too
 thread_local int g_step_tune[4] = {0, 0, 0, 0};
 
 struct ChanDesc {  // per channel, written by step_prep
@@ -812,13 +812,41 @@ struct FwdParams {
     void *out;
     const void *w;
     uint64_t fill;
-    int64_t x_plane, o_plane;
-    int wkind, C;
-    int S1, S2, O1, O2, L1, L2;
+    int64_t x_plane, o_plane;  // elements per (n, c) plane (2-D) / volume (3-D)
+    int wkind, C, nd;
+    int S0, S1, S2, O0, O1, O2, L0, L1, L2;
     int cpr, xppr, R, spp;   // output chunks per row, source pieces per row, rows per step, steps per plane
+    int spv;                 // steps per (n, c): O0 * spp
     uint32_t total_steps, steps_per_xcd;
-    FastDiv d_spp, d_C, d_cpr, d_xppr, d_per1, d_per2;
+    FastDiv d_spp, d_spv, d_C, d_cpr, d_xppr, d_per0, d_per1, d_per2;
 };
+
+// the nd weights of channel c in normalised order (plane, row, inner; leading dims 0), widened, through the scalar cache
+template <typename CT> __device__ __forceinline__ void load_weights_nd(const void *w, int wkind, int c, int nd, CT (&out)[3]) {
+    const uintptr_t base = reinterpret_cast<uintptr_t>(w);
+    CT v[3] = {CT(0), CT(0), CT(0)};
+    if (wkind == SHIFTND_F64) {
+        const __attribute__((address_space(4))) double *q = reinterpret_cast<const __attribute__((address_space(4))) double *>(base) + static_cast<int64_t>(c) * nd;
+        for (int r = 0; r < 3; ++r) if (r < nd) v[r] = static_cast<CT>(q[r]);
+    } else if (wkind == SHIFTND_F16 || wkind == SHIFTND_BF16) {
+        // nd halfwords at byte offset 2 nd c: the two aligned dwords that hold them
+        const uintptr_t at = base + static_cast<uintptr_t>(c) * nd * 2;
+        const __attribute__((address_space(4))) uint32_t *q = reinterpret_cast<const __attribute__((address_space(4))) uint32_t *>(at & ~static_cast<uintptr_t>(3));
+        const uint64_t bits = (static_cast<uint64_t>(q[1]) << 32 | q[0]) >> ((at & 2) * 8);
+        for (int r = 0; r < 3; ++r) {
+            if (r >= nd) break;
+            const uint16_t h = static_cast<uint16_t>(bits >> (16 * r));
+            v[r] = wkind == SHIFTND_F16 ? static_cast<CT>(__builtin_bit_cast(_Float16, h))
+                                        : static_cast<CT>(__builtin_bit_cast(float, static_cast<uint32_t>(h) << 16));
+        }
+    } else {
+        const __attribute__((address_space(4))) float *q = reinterpret_cast<const __attribute__((address_space(4))) float *>(base) + static_cast<int64_t>(c) * nd;
+        for (int r = 0; r < 3; ++r) if (r < nd) v[r] = static_cast<CT>(q[r]);
+    }
+    const int lead = 3 - nd;
+    out[0] = out[1] = out[2] = CT(0);
+    for (int r = 0; r < 3; ++r) if (r < nd) out[r + lead] = v[r];
+}
 
 // column state of E + 1 consecutive map entries starting at coordinate j0, folded arithmetically
 template <int E, int PAD> __device__ __forceinline__ ColState<E> fold_colstate(int j0, int cs, int len) {
@@ -839,35 +867,49 @@ template <int E, int PAD> __device__ __forceinline__ ColState<E> fold_colstate(i
     return c;
 }
 
-template <typename T, bool ACTIVE, int PAD, int U>
+template <typename T, int ND, bool ACTIVE, int PAD, int U>
 __global__ __launch_bounds__(kThreads) void step_forward_lds(const FwdParams p) {
     using S = typename T::S;
     using CT = typename T::C;
     constexpr int E = 16 / sizeof(S);
-    constexpr int KP = 4;  // staged pieces per thread of the generic (cropped) staging loop (host: (U R + 1) * xppr <= 4 * 256)
+    constexpr int KP = 4;  // staged pieces per thread and plane of the generic (cropped) staging loop
+    constexpr int NPL = (ND == 3 && ACTIVE) ? 2 : 1;  // source planes of a step
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char *tile = smem + 64;  // 64-byte pads in front and behind: see lds_read_row
 
     const uint32_t bid = (blockIdx.x & 7u) * p.steps_per_xcd + (blockIdx.x >> 3);
     if (bid >= p.total_steps) return;
-    const uint32_t plane = fdiv(bid, p.d_spp);
-    const int step = static_cast<int>(bid - plane * static_cast<uint32_t>(p.spp));
+    const uint32_t plane = fdiv(bid, p.d_spv);
+    const uint32_t vstep = bid - plane * static_cast<uint32_t>(p.spv);
+    const int a = ND == 3 ? static_cast<int>(fdiv(vstep, p.d_spp)) : 0;
+    const int step = static_cast<int>(vstep) - a * p.spp;
     const int c = static_cast<int>(plane - fdiv(plane, p.d_C) * static_cast<uint32_t>(p.C));
-    CT wr, wc;
-    load_weights2<CT>(p.w, p.wkind, c, wr, wc);
+    CT wv[3];
+    load_weights_nd<CT>(p.w, p.wkind, c, p.nd, wv);
     // weights_init_forward (shifts_cuda.cu:168-183): sparse shift rounds (half to even, as the CPU path), active floors
-    const CT rr = ACTIVE ? c_floor<CT>(wr) : c_rint<CT>(wr), rc = ACTIVE ? c_floor<CT>(wc) : c_rint<CT>(wc);
-    const CT dw[2] = {ACTIVE ? wr - rr : CT(0), ACTIVE ? wc - rc : CT(0)};
-    const int cs1 = __builtin_amdgcn_readfirstlane(canon_of<PAD, CT>(rr, p.S1, p.d_per1));
-    const int cs2 = __builtin_amdgcn_readfirstlane(canon_of<PAD, CT>(rc, p.S2, p.d_per2));
+    CT rr[3], dn[3];
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+        rr[d] = ACTIVE ? c_floor<CT>(wv[d]) : c_rint<CT>(wv[d]);
+        dn[d] = ACTIVE ? wv[d] - rr[d] : CT(0);
+    }
+    const int cs0 = ND == 3 ? __builtin_amdgcn_readfirstlane(canon_of<PAD, CT>(rr[0], p.S0, p.d_per0)) : 0;
+    const int cs1 = __builtin_amdgcn_readfirstlane(canon_of<PAD, CT>(rr[1], p.S1, p.d_per1));
+    const int cs2 = __builtin_amdgcn_readfirstlane(canon_of<PAD, CT>(rr[2], p.S2, p.d_per2));
+    // fractions in real-dim order (interp_t's d[]): 2-D (row, inner), 3-D (plane, row, inner)
+    const CT dw[3] = {ND == 3 ? dn[0] : dn[1], ND == 3 ? dn[1] : dn[2], ND == 3 ? dn[2] : CT(0)};
 
-    const int R = p.R, S1 = p.S1, S2 = p.S2, cpr = p.cpr, xppr = p.xppr;
+    const int R = p.R, S0 = p.S0, S1 = p.S1, S2 = p.S2, cpr = p.cpr, xppr = p.xppr;
     const int RT = U * R;
+    const int PR = RT + (ACTIVE ? 1 : 0);   // staged rows per plane
     const int b0 = step * RT;
     const int Rn = min(RT, p.O1 - b0);
     const int last = Rn - (ACTIVE ? 0 : 1);  // last staged row of the step (the interpolating shift: + 1 corner row)
     const S *xp = static_cast<const S *>(p.x) + static_cast<int64_t>(plane) * p.x_plane;
-    S *op = static_cast<S *>(p.out) + static_cast<int64_t>(plane) * p.o_plane;
+    S *op = static_cast<S *>(p.out) + static_cast<int64_t>(plane) * p.o_plane + static_cast<int64_t>(a) * p.O1 * p.O2;
+    int pa[NPL];
+#pragma unroll
+    for (int h = 0; h < NPL; ++h) pa[h] = ND == 3 ? row_map_t<PAD>(a + p.L0 + h, cs0, S0) : 0;
 
     const int tid = static_cast<int>(threadIdx.x);
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -884,24 +926,31 @@ __global__ __launch_bounds__(kThreads) void step_forward_lds(const FwdParams p) 
             const int vtr = tr + u * R;
             if (tr < R && vtr <= last) {
                 const int src = row_map_t<PAD>(b0 + p.L1 + vtr, cs1, S1);
-                if (src >= 0) dma(src, tc, u * R * cpr);
+#pragma unroll
+                for (int h = 0; h < NPL; ++h)
+                    if (src >= 0 && pa[h] >= 0) dma(pa[h] * S1 + src, tc, h * PR * cpr + u * R * cpr);
             }
         }
         if (ACTIVE && Rn == RT && tid < cpr) {
             const int src = row_map_t<PAD>(b0 + p.L1 + RT, cs1, S1);
-            if (src >= 0) dma(src, tid, RT * cpr);
+#pragma unroll
+            for (int h = 0; h < NPL; ++h)
+                if (src >= 0 && pa[h] >= 0) dma(pa[h] * S1 + src, tid, (h * PR + RT) * cpr);
         }
     } else {
         const int npieces = (last + 1) * xppr;
 #pragma unroll
-        for (int k = 0; k < KP; ++k) {
-            if (k * kThreads < npieces) {  // uniform
-                const int q = k * kThreads + tid;
-                const int slot = static_cast<int>(fdiv(static_cast<uint32_t>(q), p.d_xppr));
-                const int j = q - slot * xppr;
-                int src = row_map_t<PAD>(b0 + p.L1 + slot, cs1, S1);
-                if (q >= npieces) src = -1;
-                if (src >= 0) dma(src, j, k * kThreads);
+        for (int h = 0; h < NPL; ++h) {
+#pragma unroll
+            for (int k = 0; k < KP; ++k) {
+                if (k * kThreads < npieces) {  // uniform
+                    const int q = k * kThreads + tid;
+                    const int slot = static_cast<int>(fdiv(static_cast<uint32_t>(q), p.d_xppr));
+                    const int j = q - slot * xppr;
+                    int src = row_map_t<PAD>(b0 + p.L1 + slot, cs1, S1);
+                    if (q >= npieces || pa[h] < 0) src = -1;
+                    if (src >= 0) dma(pa[h] * S1 + src, j, h * PR * xppr + k * kThreads);
+                }
             }
         }
     }
@@ -919,18 +968,46 @@ __global__ __launch_bounds__(kThreads) void step_forward_lds(const FwdParams p) 
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     auto row_valid = [&](int pr) { return PAD != 0 || row_map_t<PAD>(pr, cs1, S1) >= 0; };
+    const int RBL = xppr * 16;  // bytes per staged row
 #pragma unroll
     for (int u = 0; u < U; ++u) {
         const int vtr = tr + u * R;
         if (tr >= R || vtr >= Rn) continue;
         const int b = b0 + vtr;
         Chunk<S, E> res;
-        if constexpr (ACTIVE) {
+        if constexpr (ACTIVE && ND == 3) {
+            // the reference nests the blends plane, row, inner (interpolation.h:34-40): blended over the two planes first,
+            // a row of E + 1 columns serves the E elements of the chunk -- 3 E + 3 blends per chunk instead of 7 E, same bits
+            CT rowb[2][E + 1];
+#pragma unroll
+            for (int hb = 0; hb < 2; ++hb) {
+                S r0[E + 1], r1[E + 1];
+                const bool rv = row_valid(b + p.L1 + hb);
+                lds_read_row<S, E>(tile + (vtr + hb) * RBL, rv && pa[0] >= 0, xm, r0);
+                lds_read_row<S, E>(tile + (PR + vtr + hb) * RBL, rv && pa[1] >= 0, xm, r1);
+#pragma unroll
+                for (int e = 0; e <= E; ++e) {
+                    const CT two[2] = {widen<T>(r0[e]), widen<T>(r1[e])};
+                    rowb[hb][e] = interp_t<T, 1>(two, &dw[0]);
+                }
+            }
+            CT colb[E + 1];
+#pragma unroll
+            for (int e = 0; e <= E; ++e) {
+                const CT two[2] = {rowb[0][e], rowb[1][e]};
+                colb[e] = interp_t<T, 1>(two, &dw[1]);
+            }
+#pragma unroll
+            for (int e = 0; e < E; ++e) {
+                const CT two[2] = {colb[e], colb[e + 1]};
+                res.e[e] = narrow<T>(interp_t<T, 1>(two, &dw[2]));
+            }
+        } else if constexpr (ACTIVE) {
             CT xv[2][E + 1];
 #pragma unroll
             for (int hb = 0; hb < 2; ++hb) {
                 S raw[E + 1];
-                lds_read_row<S, E>(tile + (vtr + hb) * (xppr * 16), row_valid(b + p.L1 + hb), xm, raw);
+                lds_read_row<S, E>(tile + (vtr + hb) * RBL, row_valid(b + p.L1 + hb), xm, raw);
 #pragma unroll
                 for (int e = 0; e <= E; ++e) xv[hb][e] = widen<T>(raw[e]);
             }
@@ -943,8 +1020,8 @@ __global__ __launch_bounds__(kThreads) void step_forward_lds(const FwdParams p) 
             S raw[E + 1], fill;
             const typename raw_t<sizeof(S)>::type fill_bits = static_cast<typename raw_t<sizeof(S)>::type>(p.fill);
             __builtin_memcpy(&fill, &fill_bits, sizeof(S));
-            const bool valid = row_valid(b + p.L1);
-            lds_read_row<S, E>(tile + vtr * (xppr * 16), valid, xm, raw);
+            const bool valid = pa[0] >= 0 && row_valid(b + p.L1);
+            lds_read_row<S, E>(tile + vtr * RBL, valid, xm, raw);
 #pragma unroll
             for (int e = 0; e < E; ++e) res.e[e] = (valid && xm.cm[e] >= 0) ? raw[e] : fill;
         }
@@ -1215,8 +1292,12 @@ bool step_forward_lds_eligible(const Geometry &g, int dtype, const void *x, cons
     const int es = dtype_size(dtype);
     const bool interpolating = g.active != 0;
     if (!interpolating && es != 2) return false;
-    if (g.nd != 2 || g.S[0] != 1 || g.O[0] != 1) return false;
-    const int64_t xe = g.S[1] * g.S[2], oe = g.O[1] * g.O[2];
+    if ((g.nd != 2 && g.nd != 3) || (g.nd == 2 && (g.S[0] != 1 || g.O[0] != 1))) return false;
+    // 3-D: 4- / 8-byte interpolation (N8 C128 16x112x112 fp32 0.38 -> 0.30 ms) and the 2-byte sparse shift (0.155 -> 0.136 ms);
+    // 16-bit interpolation stays on the sliding-window kernel (0.18 vs 0.215 ms: four corner rows to unpack per output row
+    // against two) unless forced (knob 34 >= 2 or knob 35 bit 3)
+    if (g.nd == 3 && interpolating && es == 2 && !(g_step_tune[2] >= 2 || (g_step_tune[3] & 8))) return false;
+    const int64_t xe = g.S[0] * g.S[1] * g.S[2], oe = g.O[0] * g.O[1] * g.O[2];
     if (xe < 1 || oe < 1 || xe >= (1LL << 30) || oe >= (1LL << 30) || g.S[2] > 32000) return false;
     if ((g.S[2] * es) % 16 != 0 || reinterpret_cast<uintptr_t>(x) % 16 != 0) return false;
     if ((g.O[2] * es) % 16 != 0 || g.O[2] * es / 16 > kThreads || reinterpret_cast<uintptr_t>(out) % 16 != 0) return false;
@@ -1224,16 +1305,17 @@ bool step_forward_lds_eligible(const Geometry &g, int dtype, const void *x, cons
     const int cpr = static_cast<int>(g.O[2] * es / 16), xppr = static_cast<int>(g.S[2] * es / 16);
     int64_t R = kThreads / cpr;
     if (R > g.O[1]) R = g.O[1];
+    const int64_t npl = (g.nd == 3 && interpolating) ? 2 : 1;
     if ((2 * R + 1) * xppr > 4 * kThreads) return false;  // (heavy crops: few output chunks per source row)
-    if (64 + (2 * R + 1) * xppr * 16 + 64 > 64 * 1024) return false;
+    if (64 + npl * (2 * R + 1) * xppr * 16 + 64 > 64 * 1024) return false;
     const int64_t spp = (g.O[1] + R - 1) / R;
-    if (g.N * g.C * spp + 8 >= (1LL << 31)) return false;
+    if (g.N * g.C * g.O[0] * spp + 8 >= (1LL << 31)) return false;
     // knob 34: 0 = automatic (two row groups per thread), 1 = never, 2 / 3 = always, with one / two row groups
     if (g_step_tune[2] >= 2) return true;
     // same box, per-channel LDS kernels -> this one: interpolating fp32 N64 C256 224x224 1.09 -> 1.00 ms, N16 C64 448x448
     // 0.39 -> 0.26, N128 C256 56x56 0.158 -> 0.135, bf16 0.079 -> 0.068, N256 C512 8x8 0.103 -> 0.086; sparse fp16 reflect
     // C512 224x224 1.21 -> 1.06, bf16 56x56 0.078 -> 0.064; the one loss: sparse 2-byte planes of 2 KiB (32x32: 0.059 -> 0.064)
-    return interpolating || oe * es >= 4 * 1024;
+    return interpolating || g.O[1] * g.O[2] * es >= 4 * 1024;
 }
 
 template <typename T>
@@ -1241,8 +1323,11 @@ static void launch_step_forward_lds(const FwdParams &p, bool active, int pad, in
     const dim3 grid(p.steps_per_xcd * 8), block(kThreads);
 #define SHIFTND_STEP_FWD_LDS(ACT, PADV) \
     case PADV: \
-        if (U == 2) hipLaunchKernelGGL((step_forward_lds<T, ACT, PADV, 2>), grid, block, lds, st, p); \
-        else hipLaunchKernelGGL((step_forward_lds<T, ACT, PADV, 1>), grid, block, lds, st, p); \
+        if (p.nd == 3) { \
+            if (U == 2) hipLaunchKernelGGL((step_forward_lds<T, 3, ACT, PADV, 2>), grid, block, lds, st, p); \
+            else hipLaunchKernelGGL((step_forward_lds<T, 3, ACT, PADV, 1>), grid, block, lds, st, p); \
+        } else if (U == 2) hipLaunchKernelGGL((step_forward_lds<T, 2, ACT, PADV, 2>), grid, block, lds, st, p); \
+        else hipLaunchKernelGGL((step_forward_lds<T, 2, ACT, PADV, 1>), grid, block, lds, st, p); \
         break;
     if (active) {
         switch (pad) { SHIFTND_STEP_FWD_LDS(true, 0) SHIFTND_STEP_FWD_LDS(true, 1) SHIFTND_STEP_FWD_LDS(true, 2) SHIFTND_STEP_FWD_LDS(true, 3) default: SHIFTND_STEP_FWD_LDS(true, 4) }
@@ -1261,14 +1346,18 @@ int step_forward_lds(const Geometry &g, int dtype, const void *x, const void *w,
     p.fill = fill_bits;
     p.wkind = wkind;
     p.C = static_cast<int>(g.C);
+    p.nd = g.nd;
+    p.S0 = static_cast<int>(g.S[0]);
     p.S1 = static_cast<int>(g.S[1]);
     p.S2 = static_cast<int>(g.S[2]);
+    p.O0 = static_cast<int>(g.O[0]);
     p.O1 = static_cast<int>(g.O[1]);
     p.O2 = static_cast<int>(g.O[2]);
+    p.L0 = static_cast<int>(g.L[0]);
     p.L1 = static_cast<int>(g.L[1]);
     p.L2 = static_cast<int>(g.L[2]);
-    p.x_plane = g.S[1] * g.S[2];
-    p.o_plane = g.O[1] * g.O[2];
+    p.x_plane = g.S[0] * g.S[1] * g.S[2];
+    p.o_plane = g.O[0] * g.O[1] * g.O[2];
     p.cpr = static_cast<int>(g.O[2] * es / 16);
     p.xppr = static_cast<int>(g.S[2] * es / 16);
     p.R = kThreads / p.cpr;
@@ -1276,7 +1365,10 @@ int step_forward_lds(const Geometry &g, int dtype, const void *x, const void *w,
     int U = g_step_tune[2] == 2 ? 1 : 2;  // (one row group: C2-tensor interpolating forward 1.15 ms, two: 1.00 ms)
     if (p.R >= p.O1) U = 1;
     p.spp = (p.O1 + U * p.R - 1) / (U * p.R);
-    const uint64_t total = static_cast<uint64_t>(g.N) * g.C * p.spp;
+    p.spv = p.O0 * p.spp;
+    p.d_spv = make_fastdiv(static_cast<uint32_t>(p.spv));
+    p.d_per0 = make_fastdiv(static_cast<uint32_t>(map_period(p.S0, g.pad)));
+    const uint64_t total = static_cast<uint64_t>(g.N) * g.C * p.spv;
     p.total_steps = static_cast<uint32_t>(total);
     p.steps_per_xcd = static_cast<uint32_t>((total + 7) / 8);
     p.d_spp = make_fastdiv(static_cast<uint32_t>(p.spp));
@@ -1286,7 +1378,7 @@ int step_forward_lds(const Geometry &g, int dtype, const void *x, const void *w,
     p.d_per1 = make_fastdiv(static_cast<uint32_t>(map_period(p.S1, g.pad)));
     p.d_per2 = make_fastdiv(static_cast<uint32_t>(map_period(p.S2, g.pad)));
     const bool active = g.active != 0;
-    const size_t lds = 64 + static_cast<size_t>(U * p.R + (active ? 1 : 0)) * p.xppr * 16 + 64;
+    const size_t lds = 64 + static_cast<size_t>((g.nd == 3 && active) ? 2 : 1) * (U * p.R + (active ? 1 : 0)) * p.xppr * 16 + 64;
     note_kernel(active ? "step_active_forward" : "step_gather_forward_lds");
     if (!active) {  // a raw copy of 2-byte elements: one instantiation serves fp16 and bf16
         launch_step_forward_lds<f16_t>(p, false, g.pad, U, lds, st);

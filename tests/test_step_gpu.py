@@ -305,3 +305,38 @@ def test_small_element_gather_forward_vs_oracle(abi, shape, crop, npdt):
         out = abi.forward_quantized(torch.from_numpy(xq).to(DEV), torch.from_numpy(wq).to(DEV), 128, 7, pad, b)
         assert abi.last_kernel() == "step_gather_forward_small", (shape, abi.last_kernel())
         assert np.array_equal(out.cpu().numpy(), O.forward_q(xq, wq, 128, 7, pad, b)), (shape, crop, pad)
+
+
+@pytest.mark.parametrize("dt", ["f32", "f64", "f16", "bf16"])
+@pytest.mark.parametrize("shape,crop", [((2, 3, 5, 6, 16), None), ((1, 2, 20, 9, 64), None), ((2, 2, 3, 40, 112), None),
+                                        ((1, 3, 1, 5, 8), None), ((1, 2, 6, 1, 32), None), ((1, 1, 3, 37, 512), None),
+                                        ((2, 2, 4, 7, 24), [[1, 0], [0, 2], [8, 0]]), ((2, 3, 6, 11, 32), [[0, 1], [2, 1], [0, 8]])])
+def test_3d_forwards_through_lds_vs_oracle(abi, shape, crop, dt):
+    """3-D interpolating forward (two source planes per step, blends shared along the reference's nesting: same bits as
+    interp_nd) and 3-D sparse forward of 2-byte elements through the one-step LDS kernel; crops included"""
+    tdt = {"f32": torch.float32, "f64": torch.float64, "f16": torch.float16, "bf16": torch.bfloat16}[dt]
+    rs = np.random.RandomState(sum(shape) * 3 + 11)
+    xt = torch.from_numpy(rs.uniform(-1, 1, size=shape)).to(tdt)
+    wt = torch.from_numpy(_weights(rs, shape[1], 3, shape[2:])).to(tdt)
+    es = xt.element_size()
+    b, new = abi.check_borders(list(shape), crop, 3)
+    if (new[-1] * es) % 16 or (shape[-1] * es) % 16:
+        pytest.skip("rows are not whole 16-byte pieces")
+    wide = np.float64 if tdt == torch.float64 else np.float32
+    x, w = xt.to(torch.float64).numpy().astype(wide), wt.to(torch.float64).numpy().astype(wide)
+    xd, wd = xt.to(DEV), wt.to(DEV)
+    for groups in (2, 3):
+        abi.set_tuning(34, groups)
+        for pad in range(5):
+            out = abi.forward(xd, wd, pad, 1, b)
+            assert abi.last_kernel() == "step_active_forward", (shape, abi.last_kernel())
+            ref = torch.from_numpy(O.forward(x, w, pad, 1, b)).to(tdt)
+            if es >= 4:
+                assert torch.equal(out.cpu(), ref), ("active", shape, crop, pad, groups)
+            else:
+                assert _ulp_close(out.cpu(), ref, tdt), ("active", shape, crop, pad, groups)
+            if es == 2:
+                out = abi.forward(xd, wd, pad, 0, b)
+                assert abi.last_kernel() == "step_gather_forward_lds", (shape, abi.last_kernel())
+                assert torch.equal(out.cpu(), torch.from_numpy(O.forward(x, w, pad, 0, b)).to(tdt)), ("ssl", shape, crop, pad)
+    abi.set_tuning(34, 2)

@@ -57,8 +57,6 @@ struct PlaneParams {
     FastDiv d_xppr;
     int lds_affine;         // LDS-staged kernels: read affine chunks as consecutive dwords (tuning knob 5 = 1 turns it off)
     unsigned xcd_blocks;    // grid / 8 when the XCD-contiguous block remap is on (grid % 8 == 0), else 0
-    int band_fast;          // workgroup ids run band-fastest, then channel, then batch group (the batch walk, see backward_plan)
-    FastDiv d_bands;
     FastDiv d_cpr;
     FastDiv d_rows;     // divide by rows_per_band
     FastDiv d_dim1;     // divide by the second outer dim of the iteration space
@@ -78,18 +76,10 @@ __device__ __forceinline__ WorkItem decode_block(const PlaneParams &p) {
     WorkItem wi;
     // XCD-contiguous ids (tuning knob 6): workgroups that share an XCD (blockIdx % 8) own adjacent planes
     const int bid = p.xcd_blocks ? static_cast<int>((blockIdx.x & 7u) * p.xcd_blocks + (blockIdx.x >> 3)) : static_cast<int>(blockIdx.x);
-    int band, grp;
-    if (p.band_fast) {
-        const int rest = static_cast<int>(fdiv(static_cast<uint32_t>(bid), p.d_bands));
-        band = bid - rest * p.bands;
-        grp = static_cast<int>(fdiv(static_cast<uint32_t>(rest), p.d_C));
-        wi.c = rest - grp * p.C;
-    } else {
-        const int rest = static_cast<int>(fdiv(static_cast<uint32_t>(bid), p.d_C));
-        wi.c = bid - rest * p.C;
-        band = static_cast<int>(fdiv(static_cast<uint32_t>(rest), p.d_groups));
-        grp = rest - band * p.groups;
-    }
+    const int rest = static_cast<int>(fdiv(static_cast<uint32_t>(bid), p.d_C));
+    wi.c = bid - rest * p.C;
+    const int band = static_cast<int>(fdiv(static_cast<uint32_t>(rest), p.d_groups));
+    const int grp = rest - band * p.groups;
     wi.n0 = grp * p.ppw;
     wi.nn = min(p.ppw, p.N - wi.n0);
     wi.row0 = band * p.rows_per_band;
@@ -1376,7 +1366,6 @@ struct Plan {
     int V, cpr, CW, RPS, CP, ppw, groups, bands, rows_per_band, rows;
     size_t lds;
     unsigned grid;
-    int band_fast = 0;
 };
 
 // rows/inner: iteration space of one plane; esize: element bytes; V: chunk bytes
@@ -1456,8 +1445,6 @@ void fill_params(PlaneParams &p, const Geometry &g, const Plan &pl, int64_t dim1
     // cheaper (C3 with reflect padding: backward 0.82 -> 0.75 ms, forward 0.31 -> 0.30 ms; 2-D: no difference)
     p.lds_affine = g_tune[5] != 1 && !(g.pad != 0 && g.nd == 3 && g_tune[5] != 2);
     p.xcd_blocks = (g_tune[6] && pl.grid % 8 == 0) ? pl.grid / 8 : 0;
-    p.band_fast = pl.band_fast;
-    p.d_bands = make_fastdiv(static_cast<uint32_t>(pl.bands > 0 ? pl.bands : 1));
     p.d_cpr = make_fastdiv(static_cast<uint32_t>(pl.cpr));
     p.d_dim1 = make_fastdiv(static_cast<uint32_t>(dim1));
     p.d_C = make_fastdiv(static_cast<uint32_t>(p.C));
@@ -1702,22 +1689,9 @@ int64_t backward_min_wgs(const Geometry &g, int esize) {
 
 Plan backward_plan(const Geometry &g, int esize) {
     const int entries = static_cast<int>(g.S[0] + g.S[1] + g.S[2] + g.O[0] + g.O[1] + g.O[2] + 6);
-    Plan pl = make_plan(g, g.S[0] * g.S[1], g.S[2], esize, 16, entries, backward_min_wgs(g, esize));
-    if (g_tune[7] < 0 && g.nd <= 2) {  // EXPERIMENT: the batch walk -- a workgroup keeps one step of rows and walks the batch
-        int k = -g_tune[7];
-        const bool cfast = k >= 1000;
-        if (cfast) k -= 1000;
-        const int rpb = pl.RPS * (k >= 100 ? k / 100 : 1);  // hundreds digit: steps per band
-        k %= 100;
-        pl.groups = k < 1 ? 1 : (k > g.N ? static_cast<int>(g.N) : k);
-        pl.ppw = static_cast<int>((g.N + pl.groups - 1) / pl.groups);
-        pl.groups = static_cast<int>((g.N + pl.ppw - 1) / pl.ppw);
-        pl.rows_per_band = rpb;
-        pl.bands = (pl.rows + rpb - 1) / rpb;
-        pl.grid = static_cast<unsigned>(g.C * pl.groups * pl.bands);
-        pl.band_fast = cfast ? 0 : 1;
-    }
-    return pl;
+    // (a batch walk -- a workgroup keeps one step of rows and walks n, every step 51 MB ahead -- was measured 7 - 16 % slower
+    //  than the band walk: DESIGN section 9)
+    return make_plan(g, g.S[0] * g.S[1], g.S[2], esize, 16, entries, backward_min_wgs(g, esize));
 }
 
 }  // namespace

@@ -509,13 +509,12 @@ void plan_shape(SweepParams &p, uint32_t cpr, uint32_t rows, int64_t planes, int
 
 template <int ESIZE, int V> void launch_gather(const SweepParams &p, hipStream_t st) {
     const dim3 grid(p.blocks_per_xcd * 8), block(p.threads);
-    // unused dynamic LDS = an occupancy limit (knob 9 = KB * 1000 + threads): fewer resident workgroups keep fewer
-    // bytes in flight, which the memory system rewards (tools/stream_probe X4)
-    const size_t pad = static_cast<size_t>(g_sweep_tune[1] / 1000) * 1024;
-    if (p.K <= 1) hipLaunchKernelGGL((sweep_gather_forward<ESIZE, V, 1>), grid, block, pad, st, p);
-    else if (p.K <= 2) hipLaunchKernelGGL((sweep_gather_forward<ESIZE, V, 2>), grid, block, pad, st, p);
-    else if (p.K <= 4) hipLaunchKernelGGL((sweep_gather_forward<ESIZE, V, 4>), grid, block, pad, st, p);
-    else hipLaunchKernelGGL((sweep_gather_forward<ESIZE, V, 8>), grid, block, pad, st, p);
+    // (an occupancy limit through unused dynamic LDS was tried here -- fewer bytes in flight help a plain copy, tools/stream_probe
+    //  X4 -- and changed nothing: 1.105 ms at every setting)
+    if (p.K <= 1) hipLaunchKernelGGL((sweep_gather_forward<ESIZE, V, 1>), grid, block, 0, st, p);
+    else if (p.K <= 2) hipLaunchKernelGGL((sweep_gather_forward<ESIZE, V, 2>), grid, block, 0, st, p);
+    else if (p.K <= 4) hipLaunchKernelGGL((sweep_gather_forward<ESIZE, V, 4>), grid, block, 0, st, p);
+    else hipLaunchKernelGGL((sweep_gather_forward<ESIZE, V, 8>), grid, block, 0, st, p);
 }
 
 
@@ -613,7 +612,7 @@ int sweep_forward(const Geometry &g, int dtype, const void *x, const void *w, in
     p.fill = fill_bits;
     p.d_dim1 = make_fastdiv(static_cast<uint32_t>(g.O[1]));
     plan_shape(p, static_cast<uint32_t>(g.O[2] * es / V), static_cast<uint32_t>(g.O[0] * g.O[1]), g.N * g.C,
-               g_sweep_tune[0], g_sweep_tune[1] % 1000, 8);
+               g_sweep_tune[0], g_sweep_tune[1], 8);
 #define SHIFTND_GATHER_CASE(ES, VV) \
     if (es == ES && V == VV) { launch_gather<ES, VV>(p, st); return SHIFTND_OK; }
     SHIFTND_GATHER_CASE(1, 16) SHIFTND_GATHER_CASE(1, 8) SHIFTND_GATHER_CASE(1, 4) SHIFTND_GATHER_CASE(1, 1)

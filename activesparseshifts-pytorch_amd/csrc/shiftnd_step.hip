@@ -1,31 +1,37 @@
-// shiftnd_step.hip -- one-step workgroups: the backward pass of contiguous 2-D problems as a linear sweep.
+// shiftnd_step.hip -- one-step workgroups: the backward pass and the forwards of contiguous 2-D (and 3-D) problems as a
+// linear sweep of short workgroups (gfx950 / MI355X).  DESIGN section 3.16.
 //
 // What the memory system of the MI355X rewards (tools/stream_probe --mock): many SHORT workgroups
 // that are dispatched in address order, each moving a few KB and exiting -- a plain 2-read-1-write stream staged
 // through LDS reaches 6.5 TB/s in that shape, against 5.4 TB/s when a workgroup walks a 50 KB band of its own (the shape
 // of plane_backward_lds) and 5.2 TB/s for a whole plane per workgroup: the fewer independent sweep fronts the DRAM
-// sees, the better (8 fronts, one per XCD, are as good as one).  So here a workgroup owns ONE step -- R = 256 / (chunks
-// per row) consecutive rows of one (n, c) plane -- and the grid is every step of the tensor in memory order, the
-// workgroups of an XCD (blockIdx % 8) owning a contiguous eighth of it.
+// sees, the better (8 fronts, one per XCD, are as good as one).  So here a workgroup owns ONE step -- U * R consecutive
+// rows of one (n, c) plane, R = 256 / (chunks per row), U = 1 or 2 row groups per thread -- and the grid is every step of
+// the tensor in memory order, the workgroups of an XCD (blockIdx % 8) owning a contiguous eighth of it.
 //
 // A workgroup that lives for one step cannot build per-channel index maps in LDS, nor amortise a long scalar prologue
-// (the sweep kernels' per-wave prologue costs them 35 % at one row group per workgroup).  Everything per-channel is
-// therefore prepared ONCE by a small kernel launched in front (step_prep: one workgroup per channel) and read back
-// with one scalar load (ChanDesc: canonical row shifts, scatter shift, fractions) and one 16- / 32-byte vector load per
-// map (the column state of the thread's chunk: E + 1 source columns, affine flag) -- both issued before the row
-// staging and consumed after it.  Row sources are folded arithmetically per staged piece (fold_index: <= 5 VALU).
+// (all waves of a workgroup run the scalar part, one scalar unit per CU): the padding mode is a template parameter, row
+// sources are folded arithmetically (fold_index: 2 - 5 VALU), per-channel state comes through the scalar cache.
 //
-// Per step: LDS-DMA (global_load_lds_dwordx4, nontemporal: every byte is read by one or two neighbouring workgroups)
-// of the R + 1 corner rows of x and the R rows of grad_out (interpolating: + the R + 1 rows grad_x interpolates
-// between), one barrier, the same arithmetic as plane_backward_lds (shiftnd_common.hpp: corner_diffs / interp_t), one
-// nontemporal 16-byte store per thread.  The sparse shift runs in scatter form (a staged grad_out row IS a grad_x
-// row; the |shift| rows at one end of a plane that no row maps to are produced by the workgroup that owns their
-// position, from memory).  Weight gradient: per-thread sums of g * corner difference in the compute type, a fixed
-// DPP tree per wave, the four wave sums added in fp64 -> partials[step][NDIFF]; step_reduce adds the steps of a channel
-// in a fixed order and applies the per-channel blends (blend_diffs) once.  Deterministic, no atomics.
+//   step_prep / step_backward / step_reduce   backward pass (2-D by default, 3-D on request; fused average-pool tail for
+//                          the 2-D sparse shift).  step_prep (one workgroup per channel) writes ChanDesc -- canonical
+//                          shifts, scatter shift, fractions -- and, for the paddings other than zeros, the column state of
+//                          every chunk; step_backward stages the R + 1 corner rows of x and the R rows of grad_out
+//                          (interpolating: + the rows grad_x blends) by LDS-DMA, nontemporal, one barrier, the arithmetic of
+//                          plane_backward_lds, one store per thread; the sparse shift runs in scatter form.  Weight
+//                          gradient: per-thread sums of g * corner difference, a fixed DPP tree per wave, the waves added
+//                          in fp64 -> partials[step][NDIFF]; step_reduce adds a channel's steps in a fixed order and applies
+//                          the per-channel blends once.  Deterministic, no atomics.
+//   step_gather_forward         sparse-shift / quantized forward of 4- / 8-byte elements: one element-aligned 16-byte load, one
+//                          store, no LDS.
+//   step_gather_forward_small   ... of 1- / 2-byte elements: two aligned 16-byte loads and a workgroup-uniform byte funnel.
+//   step_forward_lds            forwards through LDS: interpolating (2-D every float dtype, 3-D 4- / 8-byte) and the 2-byte
+//                          sparse shift; 3-D blends shared along the reference's nesting.
+//   step_active_forward_direct  interpolating forward by raw-buffer windows, no LDS (on request: slower than the LDS form).
 //
-// Reference behaviour restated: kernels/shifts_kernels.h:222-327 (backward), :132-154 (weight gradients),
-// cuda/shifts_cuda.cu:168-199, :270-345 (weight preparation, launch).
+// Reference behaviour restated: kernels/shifts_kernels.h:156-220 (forward), :222-327 (backward), :132-154 (weight
+// gradients), :532-571 (quantized); kernels/interpolation.h:3-61; cuda/shifts_cuda.cu:168-199, :202-345 (weight
+// preparation, launch).  Roofline: HBM; forward 2 s bytes per element, backward 3 s.
 #include "shiftnd_common.hpp"
 #include "shiftnd_launch.hpp"
 #include "shiftnd_stage.hpp"

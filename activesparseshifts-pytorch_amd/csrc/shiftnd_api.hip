@@ -341,9 +341,9 @@ int shiftnd_transpose(const void *src, void *dst, int64_t batch, int64_t rows, i
 }
 
 // ---- fused shift + average pool ----------------------------------------------------------------------------
-static int pooled_geometry(const shiftnd_problem *p, const int32_t *pool, Geometry &g) {
+static int pooled_geometry(const shiftnd_problem *p, const int32_t *pool, Geometry &g, bool quantized_too = false) {
     if (!p || !pool) return SHIFTND_ERR_INVALID_ARGUMENT;
-    if (!is_float_dtype(p->dtype)) return SHIFTND_ERR_UNSUPPORTED_DTYPE;
+    if (!is_float_dtype(p->dtype) && !(quantized_too && is_quant_dtype(p->dtype))) return SHIFTND_ERR_UNSUPPORTED_DTYPE;
     const int64_t unit[5] = {0, 0, 0, 0, 0};
     const int rc = build_geometry(p, unit, unit, unit, g);
     if (rc != SHIFTND_OK) return rc;
@@ -379,7 +379,7 @@ size_t shiftnd_backward_pooled_workspace_bytes(const shiftnd_problem *p, const i
 
 int shiftnd_pooled_sizes(const shiftnd_problem *p, const int32_t *pool, int64_t pooled_spatial[3]) {
     Geometry g;
-    const int rc = pooled_geometry(p, pool, g);
+    const int rc = pooled_geometry(p, pool, g, true);  // (the sizes do not depend on the element type)
     if (rc != SHIFTND_OK) return rc;
     if (!pooled_spatial) return SHIFTND_ERR_INVALID_ARGUMENT;
     const int lead = 3 - p->ndim;
@@ -400,6 +400,26 @@ int shiftnd_forward_pooled(const shiftnd_problem *p, const int32_t *pool, const 
     if (!plane_pool_forward_eligible(g, p->dtype)) return SHIFTND_ERR_NOT_FUSED;
     g_last_path = SHIFTND_PATH_PLANE;
     return finish(plane_pool_forward(g, p->dtype, x, weights, out, static_cast<hipStream_t>(stream)));
+}
+
+int shiftnd_forward_quantized_pooled(const shiftnd_problem *p, const int32_t *pool, const void *x, const void *wq, int32_t wq_dtype,
+                                     int64_t w_zero_point, int64_t x_zero_point, int32_t requant, void *out, void *stream) {
+    if (!p || !pool) return SHIFTND_ERR_INVALID_ARGUMENT;
+    if (requant != SHIFTND_REQUANT_ZP_INSIDE && requant != SHIFTND_REQUANT_ZP_OUTSIDE) return SHIFTND_ERR_INVALID_ARGUMENT;
+    if (!is_quant_dtype(p->dtype) || !is_quant_dtype(wq_dtype)) return SHIFTND_ERR_UNSUPPORTED_DTYPE;
+    shiftnd_problem q = *p;
+    q.active = 0;
+    Geometry g;
+    const int rc = pooled_geometry(&q, pool, g, true);
+    if (rc != SHIFTND_OK) return rc;
+    if (empty_problem(g)) {
+        g_last_path = SHIFTND_PATH_EMPTY;
+        return SHIFTND_OK;
+    }
+    if (!x || !wq || !out) return SHIFTND_ERR_INVALID_ARGUMENT;
+    if (!qpool_forward_eligible(g, p->dtype)) return SHIFTND_ERR_NOT_FUSED;
+    g_last_path = SHIFTND_PATH_PLANE;
+    return finish(qpool_forward(g, p->dtype, x, wq, wq_dtype, w_zero_point, x_zero_point, requant, out, static_cast<hipStream_t>(stream)));
 }
 
 int shiftnd_backward_pooled(const shiftnd_problem *p, const int32_t *pool, const void *grad_pooled, const void *x,

@@ -137,6 +137,11 @@ int rows_forward(const Geometry &g, int dtype, const void *x, const void *w, int
 void rows_set_tuning(int knob, int value);
 bool bytes_forward_eligible(const Geometry &g, int dtype, const void *x, const void *out);
 
+// ---- quantized shift + average pool in one pass (shiftnd_qpool.hip): one-byte element types, contiguous tensors
+bool qpool_forward_eligible(const Geometry &g, int dtype);
+int qpool_forward(const Geometry &g, int dtype, const void *x, const void *w, int wkind, int64_t wzp, int64_t xzp, int requant, void *out,
+                  hipStream_t st);
+
 // ---- layout change (shiftnd_transpose.hip): dst[n][c][r] = src[n][r][c], dense tensors ---------------------------
 int transpose_planes(const void *src, void *dst, int64_t N, int64_t rows, int64_t cols, int esize, hipStream_t st);
 

@@ -553,6 +553,86 @@ template <int ND> Tensor qshift_forward_hip(const Tensor &input_, const Tensor &
     return output;
 }
 
+// quantized shift + average pool (the tail of a quantized module that emulates a strided depthwise conv) as one op on
+// the QuantizedCUDA key: one pass for int8 / uint8 (shiftnd_forward_quantized_pooled); other element types and
+// non-contiguous inputs run the quantized shift and then ATen's QuantizedCPU pool arithmetic with float HIP ops on the
+// integer representation (the same values).
+//
+// ATen's QuantizedCPU average pool rounds in two ways (include/shiftnd_hip.h: SHIFTND_REQUANT_*): its channels-last kernel
+// -- taken for every 3-D tensor and for a 4-D tensor that is_contiguous(ChannelsLast), which a contiguous one with C == 1
+// or H == W == 1 also is; avg_pool1d pools the [N, C, 1, L] view -- adds the zero point after the rounding, its contiguous
+// kernel before.  `y_sizes` / `y_channels_last`: the shift output the reference's module would hand to its pool
+// (ops/quantized/shifts_quantized.cpp:119-125 keeps a channels-last input's layout).
+template <int ND> bool qpool_zp_outside(at::IntArrayRef y_sizes, bool y_channels_last) {
+    if (ND == 3) return true;
+    if (ND == 2 && y_channels_last) return true;
+    const int64_t C = y_sizes[1], H = ND == 1 ? 1 : y_sizes[2], W = y_sizes[ND + 1];
+    return C == 1 || (H == 1 && W == 1);
+}
+
+template <int ND> Tensor qpool_composite(const Tensor &y, at::IntArrayRef pool) {
+    const int64_t zp = y.q_zero_point();
+    Tensor xi = y.int_repr();
+    Tensor xf = xi.to(at::kFloat) - static_cast<double>(zp);
+    std::vector<int64_t> k(pool.begin(), pool.end());
+    if (ND == 1) {  // (avg_pool1d has no divisor_override: pool a [N, C, 1, L] view)
+        xf = xf.unsqueeze(2);
+        k.insert(k.begin(), 1);
+    }
+    std::vector<int64_t> zeros(k.size(), 0);
+    Tensor ones = at::ones_like(xf.narrow(0, 0, 1).narrow(1, 0, 1));
+    Tensor sums = ND == 3 ? at::avg_pool3d(xf, k, k, zeros, true, true, 1) : at::avg_pool2d(xf, k, k, zeros, true, true, 1);
+    Tensor cnt = ND == 3 ? at::avg_pool3d(ones, k, k, zeros, true, true, 1) : at::avg_pool2d(ones, k, k, zeros, true, true, 1);
+    const bool outside = qpool_zp_outside<ND>(y.sizes(), ND == 2 && y.is_contiguous(at::MemoryFormat::ChannelsLast));
+    Tensor mult = cnt.to(at::kDouble).reciprocal().to(at::kFloat);  // float(1 / count)
+    Tensor res = outside ? at::round(sums * mult) + static_cast<double>(zp)
+                         : at::round(sums * mult.reciprocal().reciprocal() + static_cast<double>(zp));
+    if (ND == 1) res = res.squeeze(2);
+    double lo = 0, hi = 255;
+    if (xi.scalar_type() == at::kChar) { lo = -128; hi = 127; }
+    if (xi.scalar_type() == at::kInt) { lo = -2147483648.0; hi = 2147483647.0; }
+    res = res.clamp_(lo, hi).to(xi.scalar_type());
+    return at::_make_per_tensor_quantized_tensor(res, y.q_scale(), zp);
+}
+
+template <int ND> Tensor qpool_forward_hip(const Tensor &input_, const Tensor &weights, const Tensor &borders,
+                                           at::IntArrayRef new_size, at::IntArrayRef pool, int64_t padding_mode, bool active_flag) {
+    check_pool<ND>(pool);
+    TORCH_CHECK(input_.is_cuda() && input_.is_quantized(), "input must be a quantized CUDA tensor");
+    TORCH_CHECK(weights.is_quantized(), "weights must be a quantized tensor");
+    TORCH_CHECK(input_.dim() == ND + 2, "shift", ND, "d_pool: expected a ", ND + 2, "-D input");
+    if (padding_mode < 0 || padding_mode > 4) return Tensor();
+    c10::DeviceGuard device_guard(input_.device());
+    const int dtype = quant_dtype(input_.scalar_type(), "q_shiftnd_pool_cuda");
+    const int wdtype = quant_dtype(weights.scalar_type(), "q_shiftnd_pool_cuda");
+    if (input_.is_contiguous() && (dtype == SHIFTND_I8 || dtype == SHIFTND_U8)) {
+        int32_t b[6];
+        read_borders(borders, b);
+        Tensor wrepr = weights.int_repr().to(input_.device()).contiguous();
+        TORCH_CHECK(wrepr.dim() == 2 && wrepr.size(0) == input_.size(1) && wrepr.size(1) == ND,
+                    "shift", ND, "d_pool: weights must have shape [C, ", ND, "]");
+        int32_t k[3] = {1, 1, 1};
+        for (int r = 0; r < ND; ++r) k[r] = static_cast<int32_t>(pool[r]);
+        shiftnd_problem p;
+        fill_problem(p, ND, input_, b, padding_mode, false, dtype);
+        int64_t ps[3];
+        int rc = shiftnd_pooled_sizes(&p, k, ps);
+        TORCH_CHECK(rc == SHIFTND_OK, "shiftnd_pooled_sizes: ", shiftnd_status_string(rc));
+        std::vector<int64_t> osize = {input_.size(0), input_.size(1)};
+        for (int r = 0; r < ND; ++r) osize.push_back(ps[r]);
+        std::vector<int64_t> ysize = {input_.size(0), input_.size(1)};
+        for (int r = 0; r < ND; ++r) ysize.push_back(b[2 * r + 1] - b[2 * r]);
+        const int32_t requant = qpool_zp_outside<ND>(ysize, false) ? SHIFTND_REQUANT_ZP_OUTSIDE : SHIFTND_REQUANT_ZP_INSIDE;
+        Tensor output = at::_empty_affine_quantized(osize, input_.options().memory_format(at::MemoryFormat::Contiguous),
+                                                    input_.q_scale(), input_.q_zero_point(), c10::nullopt);
+        rc = shiftnd_forward_quantized_pooled(&p, k, input_.data_ptr(), wrepr.data_ptr(), wdtype, weights.q_zero_point(),
+                                              input_.q_zero_point(), requant, output.data_ptr(), current_stream(input_));
+        if (rc == SHIFTND_OK) return output;
+        TORCH_CHECK(rc == SHIFTND_ERR_NOT_FUSED, "shiftnd_forward_quantized_pooled (HIP): ", shiftnd_status_string(rc));
+    }
+    return qpool_composite<ND>(qshift_forward_hip<ND>(input_, weights, borders, new_size, padding_mode, active_flag), pool);
+}
+
 std::tuple<Tensor, Tensor> qshift_backward(const Tensor &, const Tensor &, const Tensor &, const Tensor &, int64_t, bool) {
     TORCH_CHECK(0, "backwards on quantized tensor are not supported");
 }
@@ -636,4 +716,7 @@ TORCH_LIBRARY_IMPL(torchshifts, QuantizedCUDA, m) {
     m.impl("_shift2d_backward", TORCH_FN(qshift_backward));
     m.impl("_shift3d_forward", TORCH_FN(qshift_forward_hip<3>));
     m.impl("_shift3d_backward", TORCH_FN(qshift_backward));
+    m.impl("_shift1d_pool_forward", TORCH_FN(qpool_forward_hip<1>));
+    m.impl("_shift2d_pool_forward", TORCH_FN(qpool_forward_hip<2>));
+    m.impl("_shift3d_pool_forward", TORCH_FN(qpool_forward_hip<3>));
 }

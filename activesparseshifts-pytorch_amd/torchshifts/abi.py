@@ -23,7 +23,7 @@ EXPORTS = ["shiftnd_abi_version", "shiftnd_status_string", "shiftnd_last_path", 
            "shiftnd_set_tuning", "shiftnd_debug_map", "shiftnd_last_kernel",
            "shiftnd_check_borders", "shiftnd_forward", "shiftnd_forward_serves_channels_last", "shiftnd_backward_serves_channels_last",
            "shiftnd_backward_workspace_bytes", "shiftnd_backward",
-           "shiftnd_forward_quantized", "shiftnd_pooled_sizes", "shiftnd_backward_pooled_workspace_bytes", "shiftnd_forward_pooled", "shiftnd_backward_pooled", "shiftnd_transpose"]
+           "shiftnd_forward_quantized", "shiftnd_pooled_sizes", "shiftnd_backward_pooled_workspace_bytes", "shiftnd_forward_pooled", "shiftnd_backward_pooled", "shiftnd_forward_quantized_pooled", "shiftnd_transpose"]
 
 
 class Problem(ctypes.Structure):
@@ -75,6 +75,9 @@ def lib():
         L.shiftnd_forward_pooled.argtypes = [ctypes.POINTER(Problem), i32p, vp, vp, vp, vp]
         L.shiftnd_backward_pooled.restype = ctypes.c_int
         L.shiftnd_backward_pooled.argtypes = [ctypes.POINTER(Problem), i32p, vp, vp, vp, vp, vp, vp, ctypes.c_size_t, vp]
+        L.shiftnd_forward_quantized_pooled.restype = ctypes.c_int
+        L.shiftnd_forward_quantized_pooled.argtypes = [ctypes.POINTER(Problem), i32p, vp, vp, ctypes.c_int32, ctypes.c_int64,
+                                                       ctypes.c_int64, ctypes.c_int32, vp, vp]
         L.shiftnd_transpose.restype = ctypes.c_int
         L.shiftnd_transpose.argtypes = [vp, vp, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64, ctypes.c_int32, vp]
         _lib = L
@@ -200,6 +203,23 @@ def forward_pooled(x, w, pad, active, pool, borders=None, out=None):
     w = w.contiguous()
     check(lib().shiftnd_forward_pooled(ctypes.byref(p), _pool_arg(pool, p.ndim), x.data_ptr(), w.data_ptr(),
                                        out.data_ptr(), _stream()), "shiftnd_forward_pooled")
+    return out
+
+
+REQUANT_ZP_INSIDE, REQUANT_ZP_OUTSIDE = 0, 1
+
+
+def forward_quantized_pooled(xq, wq, w_zero_point, x_zero_point, pad, pool, borders=None, out=None, requant=REQUANT_ZP_INSIDE):
+    """Quantized shift + avg_pool(kernel = stride = pool, ceil_mode=True) in one pass; xq: int8 / uint8 contiguous device
+    tensor (int_repr), wq: integer tensor [C, nd]; requant: which of ATen's two roundings (include/shiftnd_hip.h)."""
+    assert xq.is_contiguous()
+    p = problem(xq, pad, False, borders)
+    if out is None:
+        out = torch.empty(pooled_shape(xq, pool, borders), dtype=xq.dtype, device=xq.device)
+    wq = wq.contiguous()
+    check(lib().shiftnd_forward_quantized_pooled(ctypes.byref(p), _pool_arg(pool, p.ndim), xq.data_ptr(), wq.data_ptr(),
+                                                 DTYPES[wq.dtype], int(w_zero_point), int(x_zero_point), int(requant), out.data_ptr(),
+                                                 _stream()), "shiftnd_forward_quantized_pooled")
     return out
 
 

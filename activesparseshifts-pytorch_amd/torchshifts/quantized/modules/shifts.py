@@ -19,7 +19,10 @@ import warnings
 import torch
 
 import torchshifts.modules.shifts as shifts
+from torchshifts.functional import shift1d_pool_func, shift2d_pool_func, shift3d_pool_func
 from torchshifts.quantized.functional import shift1d_quantized, shift2d_quantized, shift3d_quantized
+
+_POOL_FUNCS = {1: shift1d_pool_func, 2: shift2d_pool_func, 3: shift3d_pool_func}
 
 rp_dict = {v: k for k, v in shifts.paddings_dict.items()}
 
@@ -38,29 +41,6 @@ def quantize_shift_weights(weight):
     warnings.warn("shift weights beyond +-127 do not fit quint8 around zero point 128: using qint32 weights "
                   "(the reference would have coarsened every shift by ceil(range / 255))", stacklevel=2)
     return torch.quantize_per_tensor(w, 1.0, 0, torch.qint32)
-
-
-def _quantized_avg_pool_hip(xq, kernel, dim):
-    """avg_pool{N}d(kernel = stride, ceil_mode=True) of a per-tensor quantized HIP tensor with the input's quantizer
-    (ATen has no QuantizedCUDA average pool).  ATen's CPU kernel (qavg_pool) evaluates
-    nearbyint(sum(x_int - zp) * (1 / count)) + zp per window, clamped to the type's range: the same arithmetic here, in
-    float32 on the integer representation, so the values equal the QuantizedCPU result."""
-    zp = xq.q_zero_point()
-    xi = xq.int_repr()
-    info = torch.iinfo(xi.dtype)
-    xf = xi.to(torch.float32) - float(zp)
-    kernel = [int(k) for k in kernel]
-    if dim == 1:  # (avg_pool1d has no divisor_override: pool a [N, C, 1, L] view)
-        xf, kernel = xf.unsqueeze(2), [1] + kernel
-    pool = torch.nn.functional.avg_pool3d if dim == 3 else torch.nn.functional.avg_pool2d
-    # window sums and window sizes (ceil mode: the last window of a dim may be ragged)
-    sums = pool(xf, kernel, kernel, 0, True, True, 1)
-    cnt = pool(torch.ones_like(xf[:1, :1]), kernel, kernel, 0, True, True, 1)
-    res = torch.round(sums * cnt.reciprocal())
-    if dim == 1:
-        res = res.squeeze(2)
-    res = (res + float(zp)).clamp_(info.min, info.max).to(xi.dtype)
-    return torch._make_per_tensor_quantized_tensor(res, xq.q_scale(), zp)
 
 
 class _QuantizedShiftMixin:
@@ -112,9 +92,14 @@ class _QuantizedShiftMixin:
                     missing_keys.remove(k)
 
     def forward(self, input):
+        if self._pool_size is not None and input.is_cuda:
+            # ATen has no QuantizedCUDA average pool: torchshifts::shift{N}d_pool on the QuantizedCUDA key runs the shift and
+            # the pool as one pass (int8 / uint8) with the QuantizedCPU pool's arithmetic -- the values _reduction_fn gives
+            # on CPU tensors, ragged last windows included
+            if not input.is_quantized:
+                raise ValueError(f"Input to '{self._qname}' must be quantized!")
+            return _POOL_FUNCS[self.dim](input, self.qweight, self.padding, False, self.cut_borders, self._pool_size)
         out = type(self)._qfunc(input, self.qweight, self.padding, self.cut_borders)
-        if self._pool_size is not None and out.is_cuda:
-            return _quantized_avg_pool_hip(out, self._pool_size, self.dim)
         return self._reduction_fn(out)
 
     def _get_name(self):

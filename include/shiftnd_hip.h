@@ -50,7 +50,7 @@
 extern "C" {
 #endif
 
-#define SHIFTND_ABI_VERSION 4
+#define SHIFTND_ABI_VERSION 5
 #define SHIFTND_API __attribute__((visibility("default")))
 
 typedef enum shiftnd_dtype {
@@ -210,6 +210,27 @@ SHIFTND_API int shiftnd_backward_pooled(const shiftnd_problem *p, const int32_t 
                             const void *grad_pooled, const void *x, const void *weights,
                             void *grad_x, void *grad_w,
                             void *workspace, size_t workspace_bytes, void *stream);
+
+#define SHIFTND_REQUANT_ZP_INSIDE 0
+#define SHIFTND_REQUANT_ZP_OUTSIDE 1
+
+/*
+ * ABI 5: the same tail for the quantized forward (torchshifts/quantized/modules/shifts.py:19-20: a quantized module that
+ * emulates a strided depthwise conv returns _reduction_fn(shift(x))): out = avg_pool(qshift(x)) in one pass, contiguous
+ * int8 / uint8 tensors (p->dtype), quantized weights as in shiftnd_forward_quantized.  Requantization is ATen's
+ * QuantizedCPU average pool in fp32 on acc = sum(x_int - x_zero_point) over the window, clamped to the type's range; scale
+ * and zero point of the result are the input's.  ATen itself rounds in two ways and `requant` names the one wanted:
+ *   SHIFTND_REQUANT_ZP_INSIDE   nearbyint(x_zero_point + acc * (1 / count))  -- its kernel for contiguous 1-D / 2-D tensors
+ *                               (quantize_val -> fbgemm::Quantize: the zero point is added before the rounding)
+ *   SHIFTND_REQUANT_ZP_OUTSIDE  nearbyint(acc * (1 / count)) + x_zero_point  -- its channels-last kernel, which also serves
+ *                               every 3-D tensor and any [N, C, H, W] tensor whose shift output is channels-last-contiguous
+ *                               too (C == 1 or H == W == 1)
+ * (they differ when the zero point is odd and the window mean is a tie).  The torch operator library picks the form ATen
+ * would use for the reference's shift output (torch_binding.cpp: qpool_zp_outside).  SHIFTND_ERR_NOT_FUSED for other element types (nothing launched).
+ */
+SHIFTND_API int shiftnd_forward_quantized_pooled(const shiftnd_problem *p, const int32_t *pool, const void *x, const void *wq,
+                                     int32_t wq_dtype, int64_t w_zero_point, int64_t x_zero_point, int32_t requant, void *out,
+                                     void *stream);
 
 /*
  * Layout change between channels-last and contiguous tensors: dst[b][c][r] = src[b][r][c] for dense

@@ -17,7 +17,7 @@ def _declared_symbols():
 
 def test_header_symbols_exported():
     decl = _declared_symbols()
-    assert len(decl) == 19 and sorted(abi.EXPORTS) == decl
+    assert len(decl) == 20 and sorted(abi.EXPORTS) == decl
     L = ctypes.CDLL(abi._LIB_PATH)
     for name in decl:
         assert hasattr(L, name), name
@@ -32,7 +32,7 @@ def test_no_internal_symbols_leak():
 
 def test_host_only_entry_points():
     L = abi.lib()
-    assert L.shiftnd_abi_version() == 4
+    assert L.shiftnd_abi_version() == 5
     assert L.shiftnd_status_string(0) == b"ok" and L.shiftnd_status_string(-3) == b"workspace too small"
     assert abi.check_borders([2, 4, 6, 6], [[1, 2], [0, 1]], 2) == ([1, 4, 0, 5, 0, 1], [2, 4, 3, 5])
     assert abi.check_borders([2, 4, 6, 6], None, 2) == ([0, 6, 0, 6, 0, 1], [2, 4, 6, 6])

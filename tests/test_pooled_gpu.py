@@ -173,3 +173,48 @@ def test_pooled_backward_workspace_small_batch_large_plane():
             gx_ref, gw_ref = abi.backward(xo.grad, w, x, 0, active)
             assert torch.equal(gx, gx_ref) or (tdt != torch.float32 and (gx.float() - gx_ref.float()).abs().max() < 1e-2)
             assert (gw.float() - gw_ref.float()).abs().max() <= 1e-3 * max(1.0, float(gw_ref.float().abs().max())), (shape, active, need, plain)
+
+
+def aten_inv(cnt):
+    """1 / scale of ATen's requantization in its average pool: scale = 1 / float(1 / count), all in fp32"""
+    mult = np.float32(1.0 / cnt)
+    return np.float32(1.0) / (np.float32(1.0) / mult)
+
+
+@pytest.mark.parametrize("npdt", [np.uint8, np.int8])
+def test_quantized_pooled_forward_vs_oracle(abi, npdt):
+    """shiftnd_forward_quantized_pooled (csrc/shiftnd_qpool.hip) through the C ABI: the oracle's quantized shift followed by
+    ATen's QuantizedCPU average-pool arithmetic restated in numpy, BOTH of ATen's roundings (zero point inside the rounding:
+    nearbyint(zp + sum(x - zp) * inv), inv = 1 / (1 / float(1 / count)); outside: nearbyint(sum * float(1 / count)) + zp --
+    each pinned against torch's own CPU kernels by tests/test_quant_convert.py::
+    test_quantized_avg_pool_restatement_matches_aten); odd zero points so that the two differ; every padding, crops, ragged
+    last windows, 1-D / 2-D / 3-D"""
+    rs = np.random.RandomState(21)
+    info = np.iinfo(npdt)
+    differ = False
+    for nd, shape, pool, crop in CASES:
+        xq = rs.randint(info.min, info.max + 1, size=shape).astype(npdt)
+        wq = rs.randint(123, 134, size=(shape[1], nd)).astype(np.uint8)
+        wq[0] = 128 + shape[-1] + 2 if shape[-1] < 120 else 130
+        zp = 7 if npdt == np.uint8 else -9
+        b, new = abi.check_borders(list(shape), crop, nd)
+        for pad in range(5):
+            y = O.forward_q(xq, wq, 128, zp, pad, b).astype(np.int64) - zp
+            psz = [-(-new[2 + r] // pool[r]) for r in range(nd)]
+            refs = [np.zeros(list(new[:2]) + psz, dtype=npdt) for _ in range(2)]
+            for idx in np.ndindex(*psz):
+                sl = tuple(slice(idx[r] * pool[r], min((idx[r] + 1) * pool[r], new[2 + r])) for r in range(nd))
+                win = y[(slice(None), slice(None)) + sl]
+                cnt = int(np.prod(win.shape[2:]))
+                s32 = win.reshape(win.shape[0], win.shape[1], -1).sum(axis=2).astype(np.float32)
+                q_in = np.rint(np.float32(zp) + s32 * aten_inv(cnt)).astype(np.int64)
+                q_out = np.rint(s32 * np.float32(1.0 / cnt)).astype(np.int64) + zp
+                for ref, q in zip(refs, (q_in, q_out)):
+                    ref[(slice(None), slice(None)) + idx] = np.clip(q, info.min, info.max).astype(npdt)
+            differ = differ or not np.array_equal(refs[0], refs[1])
+            for requant, ref in zip((abi.REQUANT_ZP_INSIDE, abi.REQUANT_ZP_OUTSIDE), refs):
+                out = abi.forward_quantized_pooled(torch.from_numpy(xq).to(DEV), torch.from_numpy(wq).to(DEV), 128, zp, pad, pool, b,
+                                                   requant=requant)
+                assert abi.last_kernel() == "qpool_forward"
+                assert np.array_equal(out.cpu().numpy(), ref), (nd, shape, pool, crop, pad, requant)
+    assert differ  # the inputs do separate the two roundings

@@ -143,3 +143,50 @@ def test_checkpoint_in_the_reference_layout_loads():
     q2 = QMODS.Shift2d(2, 'zeros')
     q2.load_state_dict(sd)
     assert torch.equal(q2.qweight.int_repr(), q.qweight.int_repr())
+
+
+def test_quantized_avg_pool_restatement_matches_aten():
+    """The arithmetic csrc/shiftnd_qpool.hip restates, against torch's own QuantizedCPU average pools over random windows,
+    element types, zero points and ragged (ceil-mode) windows.  ATen rounds in two ways: its contiguous 1-D / 2-D kernel
+    computes nearbyint(zp + sum(x - zp) * inv) in fp32, inv = 1 / (1 / float(1 / count)) -- the zero point INSIDE the
+    rounding; its channels-last kernel (every 3-D tensor, and 4-D tensors that are channels-last-contiguous, which a
+    contiguous tensor with one channel also is) computes nearbyint(sum * float(1 / count)) + zp.  The two differ when the
+    zero point is odd and the mean is a tie; torch_binding.cpp: qpool_zp_outside picks per tensor."""
+    import numpy as np
+    torch.manual_seed(2)
+
+    def both(acc, cnt, zp, lo, hi):
+        acc = acc.astype(np.float32)
+        mult = np.float32(1.0 / cnt)
+        inv = np.float32(1.0) / (np.float32(1.0) / mult)
+        inside = np.clip(np.rint(np.float32(zp) + acc * inv).astype(np.int64), lo, hi)
+        outside = np.clip(np.rint(acc * mult).astype(np.int64) + zp, lo, hi)
+        return inside, outside
+
+    # (shape, channels_last, form ATen uses: 0 = inside, 1 = outside)
+    cases = [((2, 3, 17, 19), False, 0), ((2, 3, 17, 19), True, 1), ((2, 1, 9, 11), False, 1), ((2, 3, 1, 13), False, 0),
+             ((2, 3, 23), False, 0), ((3, 1, 23), False, 1), ((2, 3, 5, 7, 9), False, 1), ((2, 3, 5, 7, 9), True, 1)]
+    separated = 0
+    for shape, cl, form in cases:
+        nd = len(shape) - 2
+        for trial in range(8):
+            qdt = torch.quint8 if trial % 2 == 0 else torch.qint8
+            lo, hi = (0, 255) if qdt == torch.quint8 else (-128, 127)
+            zp = int(torch.randint(lo, hi + 1, (1,)))
+            k = tuple(int(torch.randint(1, 5, (1,))) for _ in range(nd))
+            xi = torch.randint(lo, hi + 1, shape)
+            xq = torch._make_per_tensor_quantized_tensor(xi.to(torch.uint8 if qdt == torch.quint8 else torch.int8), 0.0123, zp)
+            if cl:
+                xq = xq.contiguous(memory_format=torch.channels_last if nd == 2 else torch.channels_last_3d)
+            pool = {1: torch.nn.functional.avg_pool1d, 2: torch.nn.functional.avg_pool2d, 3: torch.nn.functional.avg_pool3d}[nd]
+            ref = pool(xq, k, k, 0, True).int_repr().numpy().astype(np.int64)
+            x = xi.numpy().astype(np.int64)
+            for idx in np.ndindex(*ref.shape[2:]):
+                sl = tuple(slice(idx[r] * k[r], min((idx[r] + 1) * k[r], shape[2 + r])) for r in range(nd))
+                win = x[(slice(None), slice(None)) + sl]
+                cnt = int(np.prod(win.shape[2:]))
+                acc = win.reshape(shape[0], shape[1], -1).sum(2) - cnt * zp
+                forms = both(acc, cnt, zp, lo, hi)
+                assert np.array_equal(forms[form], ref[(slice(None), slice(None)) + idx]), (shape, cl, qdt, zp, k, idx)
+                separated += int((forms[0] != forms[1]).sum())
+    assert separated > 0  # the two forms really differ on these inputs

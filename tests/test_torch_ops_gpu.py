@@ -103,18 +103,50 @@ def test_quantized_module_with_pool_tail_gpu(name, shape):
     """quantized module emulating a strided depthwise conv: shift + avg_pool(stride, ceil_mode) on the QuantizedCUDA
     key equals the QuantizedCPU result (ATen's quantized average pool) bit for bit, ragged last windows included"""
     import torchshifts.quantized.modules as QM
+    from torchshifts import abi
     torch.manual_seed(5)
-    for stride, zp in ((2, 0), (3, 17)):
-        m = getattr(torchshifts, name)(shape[1], padding='reflect', sparsity_term=0.,
+    for stride, zp, qdt, padding in ((2, 0, torch.quint8, 'reflect'), (3, 17, torch.quint8, 'zeros'), (2, -5, torch.qint8, 'periodic'),
+                                     (3, 3, torch.qint8, 'border'), (2, 100, torch.quint8, 'symmetric')):
+        m = getattr(torchshifts, name)(shape[1], padding=padding, sparsity_term=0.,
                                        emulate_dw={'kernel_size': 3, 'stride': stride, 'padding': 1})
         q = getattr(QM, name).from_float(m)
         x = torch.rand(shape)
-        xq = torch.quantize_per_tensor(x, 1 / 255., zp, torch.quint8)
+        xq = torch.quantize_per_tensor(x, 1 / 255. if qdt == torch.quint8 else 1 / 127., zp, qdt)
         ref = q(xq)
         out = q.to(DEV)(xq.to(DEV))
+        assert abi.last_kernel() == "qpool_forward"  # shift and pool in ONE pass (round 2: six passes of torch ops)
         assert out.is_cuda and out.is_quantized and out.shape == ref.shape
         assert out.q_zero_point() == ref.q_zero_point() and abs(out.q_scale() - ref.q_scale()) < 1e-12
-        assert torch.equal(out.int_repr().cpu(), ref.int_repr()), (name, stride)
+        assert torch.equal(out.int_repr().cpu(), ref.int_repr()), (name, stride, padding)
+    # qint32 tensors and non-contiguous inputs take the two-step route on the same key: same values
+    m = getattr(torchshifts, name)(shape[1], padding='reflect', sparsity_term=0., emulate_dw={'kernel_size': 3, 'stride': 2, 'padding': 1})
+    q = getattr(QM, name).from_float(m)
+    xq = torch.quantize_per_tensor(torch.rand(shape), 1 / 255., 3, torch.quint8)
+    ref = q(xq)
+    xs = torch.quantize_per_tensor(torch.rand((shape[0] * 2,) + tuple(shape[1:])), 1 / 255., 3, torch.quint8)
+    ref_s = q(xs[::2])
+    out_s = q.to(DEV)(xs.to(DEV)[::2])
+    assert torch.equal(out_s.int_repr().cpu(), ref_s.int_repr())
+    # ATen's QuantizedCPU pool rounds with the zero point outside the rounding for channels-last tensors, for every 3-D
+    # tensor and for one-channel tensors (its channels-last kernel), inside otherwise: odd zero points tell the two apart
+    q = q.cpu()
+    if len(shape) > 3:
+        fmt = torch.channels_last if len(shape) == 4 else torch.channels_last_3d
+        for zp in (3, 101):
+            xc = torch.quantize_per_tensor(torch.rand(shape), 1 / 255., zp, torch.quint8).contiguous(memory_format=fmt)
+            ref_c = q.cpu()(xc)
+            xg = xc.to(DEV).contiguous(memory_format=fmt)  # (a quantized .to(device) does not promise to keep the layout)
+            assert xg.is_contiguous(memory_format=fmt) and not xg.is_contiguous()
+            out_c = q.to(DEV)(xg)
+            assert torch.equal(out_c.int_repr().cpu(), ref_c.int_repr()), (name, "channels-last", zp)
+    m1 = getattr(torchshifts, name)(1, padding='zeros', sparsity_term=0., emulate_dw={'kernel_size': 3, 'stride': 3, 'padding': 1})
+    q1 = getattr(QM, name).from_float(m1)
+    for zp in (3, 101):
+        x1 = torch.quantize_per_tensor(torch.rand((shape[0], 1) + tuple(shape[2:])), 1 / 255., zp, torch.quint8)
+        ref_1 = q1.cpu()(x1)
+        out_1 = q1.to(DEV)(x1.to(DEV))
+        assert abi.last_kernel() == "qpool_forward"
+        assert torch.equal(out_1.int_repr().cpu(), ref_1.int_repr()), (name, "one channel", zp)
 
 
 def test_error_behaviour_gpu():

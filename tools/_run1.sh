@@ -1,3 +1,5 @@
-mkdir -p gpurun_out/r03y
-python3 tools/cl_tiled_bench.py 0 4 8 16 32 64 > gpurun_out/r03y/cl.txt 2>&1
-python3 tools/cl_bench.py >> gpurun_out/r03y/cl.txt 2>&1
+mkdir -p gpurun_out/r03z
+exec > gpurun_out/r03z/log.txt 2>&1
+timeout 1500 python3 -m pytest tests -x -q -m gpu 2>&1 | tail -6
+python3 -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -3
+python3 tools/pool_bench.py 2>&1 | tail -12

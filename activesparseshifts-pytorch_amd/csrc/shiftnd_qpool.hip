@@ -15,6 +15,8 @@
 namespace shiftnd {
 namespace {
 
+thread_local int g_qpool_tune[2] = {0, 0};  // [0]: 1 = qpool_forward only (no per-channel plane kernel)
+
 struct QPoolParams {
     const void *x;
     void *out;
@@ -68,17 +70,259 @@ __global__ __launch_bounds__(kThreads) void qpool_forward(const QPoolParams p) {
     const float mult = static_cast<float>(1.0 / static_cast<double>(n0 * n1 * n2));
     int q;
     if (p.zp_outside) {
-        q = static_cast<int>(nearbyintf(static_cast<float>(acc) * mult)) + p.xzp;
+        q = static_cast<int>(nearbyintf(__fmul_rn(static_cast<float>(acc), mult))) + p.xzp;
     } else {
         const float scale = 1.0f / mult;
         const float inv = 1.0f / scale;
-        q = static_cast<int>(nearbyintf(static_cast<float>(p.xzp) + static_cast<float>(acc) * inv));
+        q = static_cast<int>(nearbyintf(__fadd_rn(static_cast<float>(p.xzp), __fmul_rn(static_cast<float>(acc), inv))));  // (no fma)
     }
     q = q < p.qmin ? p.qmin : (q > p.qmax ? p.qmax : q);
     static_cast<EL *>(p.out)[static_cast<int64_t>(plane) * p.p_plane + t] = static_cast<EL>(q);
 }
 
+
+// =====================================================================================================================
+// qpool_plane_forward: the same result at stream rate for the planes a quantized network pools (7 x 7 ... 112 x 112).
+// One thread per pooled element redoes the padding arithmetic of its window for every (n, c) plane and reads single
+// bytes from HBM (0.54 ms for N128 C512 56 x 56: 0.47 TB/s).  But the window of a pooled element is the same set of
+// plane offsets for every batch entry of one channel, so a workgroup owns ONE channel and a group of batch entries:
+//   * once: every thread works out, for the NI items it owns (item = 4 adjacent pooled elements of a pooled row), the
+//     LDS offset of each of the 4 * KV window bytes through the channel's padding map; fill bytes (zeros padding) and the
+//     slots a ragged last window does not have point at an LDS byte that holds the zero point, so the sum needs no
+//     predicate; plus 1 / count per pooled element;
+//   * per round: the planes of `ppw` batch entries stream into LDS as they lie (global_load_lds, 16- or 4-byte pieces;
+//     planes that are not whole dwords go through registers); each thread sums its 4 * KV LDS bytes per item,
+//     requantizes 4 results and stores one dword.  Several workgroups share a CU (the image of a round is a few KiB), so
+//     the loads of one overlap the sums of another.
+// Eligibility: one-byte elements, contiguous tensors, plane <= 48 KiB, KV = window bytes in {2, 3, 4, 8, 9},
+// NI * KV <= 18.  Everything else stays on qpool_forward.
+// =====================================================================================================================
+struct QPlaneParams {
+    const uint8_t *x;
+    uint8_t *out;
+    const void *w;
+    int64_t wzp;
+    int32_t xzp, qmin, qmax;
+    int wkind, C, N, nd, pad, zp_outside;
+    int S[3], O[3], L[3], K[3], P[3], wcol[3];
+    int plane_bytes, pooled_bytes;  // per (n, c)
+    int items, groups;              // items per plane = pooled rows * groups; groups = ceil(P2 / 4)
+    int ppw, rpw;                   // planes per round, rounds per workgroup
+    int vec;                        // staging piece: 16, 4 or 1 bytes
+    int pieces;                     // pieces per plane
+    int zoff;                       // LDS offset of the zero-point bytes (past the image, which is rounded up to whole wave loads)
+    FastDiv d_items, d_groups, d_P1, d_pieces, d_C;
+    FastDiv d_per[3];
+};
+
+// the window triples served, by their size: 2 = (1, 1, 2), 3 = (1, 1, 3), 4 = (1, 2, 2), 8 = (2, 2, 2), 9 = (1, 3, 3)
+template <int KV> struct QWindow {
+    static constexpr int K0 = KV == 8 ? 2 : 1;
+    static constexpr int K1 = KV == 4 || KV == 8 ? 2 : (KV == 9 ? 3 : 1);
+    static constexpr int K2 = KV == 2 || KV == 4 || KV == 8 ? 2 : 3;
+};
+
+template <typename EL, int KV, int NI>
+__global__ __launch_bounds__(kThreads) void qpool_plane_forward(const QPlaneParams p) {
+    constexpr int K0 = QWindow<KV>::K0, K1 = QWindow<KV>::K1, K2 = QWindow<KV>::K2;
+    static_assert(K0 * K1 * K2 == KV, "window triple");
+    extern __shared__ __attribute__((aligned(16))) unsigned char q_lds[];
+    const int t = static_cast<int>(threadIdx.x);
+    const uint32_t ng = fdiv(blockIdx.x, p.d_C);
+    const int c = static_cast<int>(blockIdx.x - ng * static_cast<uint32_t>(p.C));
+    if (t < 16) q_lds[p.zoff + t] = static_cast<unsigned char>(p.xzp);
+
+    // ---- staging of one round: planes n0 .. n0 + ppw - 1 of channel c, as they lie ----------------------------------
+    const int total_pieces = p.ppw * p.pieces;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6), lane = t & 63;
+    auto stage = [&](int n0) {
+        if (p.vec == 1) {
+            for (int q = t; q < total_pieces; q += kThreads) {
+                const int slot = static_cast<int>(fdiv(static_cast<uint32_t>(q), p.d_pieces));
+                const int pq = q - slot * p.pieces;
+                const int n = min(n0 + slot, p.N - 1);
+                q_lds[q] = p.x[(static_cast<int64_t>(n) * p.C + c) * p.plane_bytes + pq];
+            }
+            return;
+        }
+        for (int base = wave * 64; base < total_pieces; base += kThreads) {
+            const int q = min(base + lane, total_pieces - 1);  // (lanes past the end reload the last piece: in bounds)
+            const int slot = static_cast<int>(fdiv(static_cast<uint32_t>(q), p.d_pieces));
+            const int pq = q - slot * p.pieces;
+            const int n = min(n0 + slot, p.N - 1);
+            const unsigned char *src = p.x + (static_cast<int64_t>(n) * p.C + c) * p.plane_bytes + pq * p.vec;
+            unsigned char *ld = q_lds + base * p.vec;  // wave-uniform: the hardware adds lane * size
+            if (p.vec == 16)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
+                                                 (__attribute__((address_space(3))) void *)ld, 16, 0, 0);
+            else
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
+                                                 (__attribute__((address_space(3))) void *)ld, 4, 0, 0);
+        }
+    };
+    const int n_first = static_cast<int>(ng) * p.rpw * p.ppw;
+    stage(n_first);
+
+    // ---- once per workgroup: window offsets and 1 / count of the items this thread owns -------------------------------
+    int cs[3] = {0, 0, 0};
+#pragma unroll
+    for (int d = 0; d < 3; ++d)
+        if (p.wcol[d] >= 0)
+            cs[d] = canon_shift(gather_shift(p.w, p.wkind, p.wzp, static_cast<int64_t>(c) * p.nd + p.wcol[d]), p.S[d], p.pad, p.d_per[d]);
+    int off[NI][4][KV];
+    float rc[NI][4];
+    int slot_of[NI], obyte[NI], ovalid[NI];  // ovalid: how many of the item's 4 pooled elements exist (0 = idle thread)
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+        int item = t + i * kThreads, slot = 0;
+        if (NI == 1) {
+            slot = static_cast<int>(fdiv(static_cast<uint32_t>(t), p.d_items));
+            item = t - slot * p.items;
+        }
+        const bool live = NI == 1 ? slot < p.ppw : item < p.items;
+        if (!live) item = 0, slot = 0;
+        const int pr = static_cast<int>(fdiv(static_cast<uint32_t>(item), p.d_groups));
+        const int cg = item - pr * p.groups;
+        const int p0 = static_cast<int>(fdiv(static_cast<uint32_t>(pr), p.d_P1));
+        const int p1 = pr - p0 * p.P[1];
+        const int n0 = min(K0, p.O[0] - p0 * K0), n1 = min(K1, p.O[1] - p1 * K1);
+        slot_of[i] = slot;
+        obyte[i] = pr * p.P[2] + cg * 4;
+        ovalid[i] = live ? min(4, p.P[2] - cg * 4) : 0;
+        // the map is separable: K0 * K1 row offsets (-1: fill or outside a ragged window), 4 * K2 column offsets
+        int rowoff[K0 * K1], coloff[4 * K2];
+#pragma unroll
+        for (int a = 0; a < K0; ++a) {
+            const int sa = p.S[0] == 1 ? 0 : fold_index(p0 * K0 + a + p.L[0] - cs[0], p.S[0], p.pad);
+#pragma unroll
+            for (int b = 0; b < K1; ++b) {
+                const int sb = p.S[1] == 1 ? 0 : fold_index(p1 * K1 + b + p.L[1] - cs[1], p.S[1], p.pad);
+                rowoff[a * K1 + b] = (a < n0 && b < n1 && sa >= 0 && sb >= 0) ? slot * p.plane_bytes + (sa * p.S[1] + sb) * p.S[2] : -1;
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int p2 = cg * 4 + j;
+            const int n2 = min(K2, p.O[2] - p2 * K2);  // (<= 0 for a pooled column that does not exist)
+            const int cnt = n0 * n1 * max(n2, 1);
+            const float mult = static_cast<float>(1.0 / static_cast<double>(cnt));
+            rc[i][j] = p.zp_outside ? mult : 1.0f / (1.0f / mult);
+#pragma unroll
+            for (int k = 0; k < K2; ++k) {
+                const int sc = p.S[2] == 1 ? 0 : fold_index(p2 * K2 + k + p.L[2] - cs[2], p.S[2], p.pad);
+                coloff[j * K2 + k] = k < n2 ? sc : -1;
+            }
+#pragma unroll
+            for (int ab = 0; ab < K0 * K1; ++ab)
+#pragma unroll
+                for (int k = 0; k < K2; ++k)
+                    off[i][j][ab * K2 + k] = (rowoff[ab] | coloff[j * K2 + k]) < 0 ? p.zoff : rowoff[ab] + coloff[j * K2 + k];
+        }
+    }
+    const int zsum = KV * p.xzp;
+    const float zpf = static_cast<float>(p.xzp);
+    const bool dword_out = (p.P[2] & 3) == 0 && (p.pooled_bytes & 3) == 0;
+
+    for (int r = 0; r < p.rpw; ++r) {
+        const int n0 = n_first + r * p.ppw;
+        if (r > 0) {
+            __syncthreads();  // everybody has finished reading the previous image
+            stage(n0);
+        }
+        __builtin_amdgcn_s_waitcnt(0);  // our loads into LDS (and LDS writes) have landed ...
+        __syncthreads();                // ... everybody's
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            const int n = n0 + slot_of[i];
+            int qv[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                int sum = 0;
+#pragma unroll
+                for (int s = 0; s < KV; ++s) sum += static_cast<int>(reinterpret_cast<const EL *>(q_lds)[off[i][j][s]]);
+                // (no clamp: the result is the rounded mean of values of the type, the float error is < 1e-4; the product and the
+                // sum are rounded separately, as ATen's are -- never contracted into one fma)
+                const float prod = __fmul_rn(static_cast<float>(sum - zsum), rc[i][j]);
+                qv[j] = p.zp_outside ? static_cast<int>(nearbyintf(prod)) + p.xzp : static_cast<int>(nearbyintf(__fadd_rn(zpf, prod)));
+            }
+            if (ovalid[i] > 0 && n < p.N) {
+                uint8_t *o = p.out + (static_cast<int64_t>(n) * p.C + c) * p.pooled_bytes + obyte[i];
+                if (ovalid[i] == 4 && dword_out) {
+                    const uint32_t lo = __builtin_amdgcn_perm(static_cast<uint32_t>(qv[1]), static_cast<uint32_t>(qv[0]), 0x0c0c0400u);
+                    const uint32_t hi = __builtin_amdgcn_perm(static_cast<uint32_t>(qv[3]), static_cast<uint32_t>(qv[2]), 0x04000c0cu);
+                    *reinterpret_cast<uint32_t *>(o) = lo | hi;
+                } else {
+                    for (int j = 0; j < ovalid[i]; ++j) o[j] = static_cast<uint8_t>(qv[j]);
+                }
+            }
+        }
+    }
+}
+
+struct QPlanePlan {
+    bool ok = false;
+    int KV = 0, NI = 0, ppw = 0, rpw = 0, ngroups = 0, vec = 0, pieces = 0, items = 0, groups = 0, zoff = 0, lds = 0;
+};
+
+QPlanePlan qplane_plan(const Geometry &g) {
+    QPlanePlan q;
+    const int64_t plane = g.S[0] * g.S[1] * g.S[2], pooled = g.P[0] * g.P[1] * g.P[2];
+    if (plane < 1 || pooled < 1 || plane > 48 * 1024 || g.N < 1 || g.C < 1 || g.N * g.C >= (1LL << 31)) return q;
+    if (g.N * g.C * plane >= (1LL << 40)) return q;
+    const int64_t kv = (g.K[0] > 0 ? g.K[0] : 1) * (g.K[1] > 0 ? g.K[1] : 1) * (g.K[2] > 0 ? g.K[2] : 1);
+    if (kv != 2 && kv != 3 && kv != 4 && kv != 8 && kv != 9) return q;
+    const int64_t k0 = kv == 8 ? 2 : 1, k1 = (kv == 4 || kv == 8) ? 2 : (kv == 9 ? 3 : 1);
+    if ((g.K[0] > 0 ? g.K[0] : 1) != k0 || (g.K[1] > 0 ? g.K[1] : 1) != k1) return q;  // (QWindow: the triples compiled)
+    q.KV = static_cast<int>(kv);
+    q.groups = static_cast<int>((g.P[2] + 3) / 4);
+    const int64_t items = g.P[0] * g.P[1] * q.groups;
+    int ni = static_cast<int>((items + kThreads - 1) / kThreads);
+    ni = ni <= 1 ? 1 : (ni == 2 ? 2 : 4);
+    if (items > 4LL * kThreads || ni * q.KV > 18) return q;
+    q.NI = ni;
+    q.items = static_cast<int>(items);
+    q.ppw = ni == 1 ? static_cast<int>(std::min<int64_t>(kThreads / items, g.N)) : 1;
+    q.vec = plane % 16 == 0 ? 16 : (plane % 4 == 0 ? 4 : 1);
+    q.pieces = static_cast<int>(plane / q.vec);
+    const int total = q.ppw * q.pieces;
+    q.zoff = q.vec == 1 ? ((total + 15) / 16) * 16 : ((total + 63) / 64) * 64 * q.vec;
+    q.lds = q.zoff + 16;
+    if (q.lds > 64 * 1024) return q;
+    // batch groups: enough workgroups to fill the chip several times over, as many rounds per workgroup as that allows
+    // (the per-workgroup set-up is ~10 rounds' worth of instructions)
+    const int64_t rounds = (g.N + q.ppw - 1) / q.ppw;
+    const int64_t want_wgs = g_qpool_tune[1] > 0 ? g_qpool_tune[1] : 3072;
+    const int64_t want_groups = std::max<int64_t>(1, (want_wgs + g.C - 1) / g.C);
+    const int64_t ngroups = std::min<int64_t>(rounds, want_groups);
+    q.rpw = static_cast<int>((rounds + ngroups - 1) / ngroups);
+    q.ngroups = static_cast<int>((rounds + q.rpw - 1) / q.rpw);
+    if (static_cast<int64_t>(q.ngroups) * g.C >= (1LL << 31)) return q;
+    q.ok = true;
+    return q;
+}
+
+template <typename EL, int KV> void launch_qplane(const QPlanePlan &q, const QPlaneParams &p, hipStream_t st) {
+    const dim3 grid(static_cast<unsigned>(q.ngroups) * static_cast<unsigned>(p.C)), block(kThreads);
+    if (q.NI == 1) hipLaunchKernelGGL((qpool_plane_forward<EL, KV, 1>), grid, block, q.lds, st, p);
+    else if (q.NI == 2) hipLaunchKernelGGL((qpool_plane_forward<EL, KV, 2>), grid, block, q.lds, st, p);
+    else if constexpr (KV <= 4) hipLaunchKernelGGL((qpool_plane_forward<EL, KV, 4>), grid, block, q.lds, st, p);
+}
+
+template <typename EL> void launch_qplane_kv(const QPlanePlan &q, const QPlaneParams &p, hipStream_t st) {
+    switch (q.KV) {
+    case 2: launch_qplane<EL, 2>(q, p, st); break;
+    case 3: launch_qplane<EL, 3>(q, p, st); break;
+    case 4: launch_qplane<EL, 4>(q, p, st); break;
+    case 8: launch_qplane<EL, 8>(q, p, st); break;
+    default: launch_qplane<EL, 9>(q, p, st); break;
+    }
+}
+
 }  // namespace
+
+void qpool_set_tuning(int knob, int value) {
+    if (knob >= 0 && knob < 2) g_qpool_tune[knob] = value;
+}
 
 bool qpool_forward_eligible(const Geometry &g, int dtype) {
     if (dtype != SHIFTND_I8 && dtype != SHIFTND_U8) return false;
@@ -90,6 +334,50 @@ bool qpool_forward_eligible(const Geometry &g, int dtype) {
 
 int qpool_forward(const Geometry &g, int dtype, const void *x, const void *w, int wkind, int64_t wzp, int64_t xzp, int requant, void *out,
                   hipStream_t st) {
+    const QPlanePlan qp = qplane_plan(g);
+    if (qp.ok && g_qpool_tune[0] != 1) {
+        QPlaneParams p{};
+        p.x = static_cast<const uint8_t *>(x);
+        p.out = static_cast<uint8_t *>(out);
+        p.w = w;
+        p.wzp = wzp;
+        p.xzp = static_cast<int32_t>(xzp);
+        p.qmin = dtype == SHIFTND_I8 ? -128 : 0;
+        p.qmax = dtype == SHIFTND_I8 ? 127 : 255;
+        p.wkind = wkind;
+        p.zp_outside = requant == SHIFTND_REQUANT_ZP_OUTSIDE ? 1 : 0;
+        p.C = static_cast<int>(g.C);
+        p.N = static_cast<int>(g.N);
+        p.nd = g.nd;
+        p.pad = g.pad;
+        for (int d = 0; d < 3; ++d) {
+            p.S[d] = static_cast<int>(g.S[d]);
+            p.O[d] = static_cast<int>(g.O[d]);
+            p.L[d] = static_cast<int>(g.L[d]);
+            p.K[d] = static_cast<int>(g.K[d] > 0 ? g.K[d] : 1);
+            p.P[d] = static_cast<int>(g.P[d]);
+            p.wcol[d] = g.wcol[d];
+            p.d_per[d] = make_fastdiv(static_cast<uint32_t>(map_period(p.S[d], g.pad)));
+        }
+        p.plane_bytes = static_cast<int>(g.S[0] * g.S[1] * g.S[2]);
+        p.pooled_bytes = static_cast<int>(g.P[0] * g.P[1] * g.P[2]);
+        p.items = qp.items;
+        p.groups = qp.groups;
+        p.ppw = qp.ppw;
+        p.rpw = qp.rpw;
+        p.vec = qp.vec;
+        p.pieces = qp.pieces;
+        p.zoff = qp.zoff;
+        p.d_items = make_fastdiv(static_cast<uint32_t>(qp.items));
+        p.d_groups = make_fastdiv(static_cast<uint32_t>(qp.groups));
+        p.d_P1 = make_fastdiv(static_cast<uint32_t>(g.P[1]));
+        p.d_pieces = make_fastdiv(static_cast<uint32_t>(qp.pieces));
+        p.d_C = make_fastdiv(static_cast<uint32_t>(g.C));
+        note_kernel("qpool_plane_forward");
+        if (dtype == SHIFTND_I8) launch_qplane_kv<int8_t>(qp, p, st);
+        else launch_qplane_kv<uint8_t>(qp, p, st);
+        return SHIFTND_OK;
+    }
     QPoolParams p{};
     p.x = x;
     p.out = out;

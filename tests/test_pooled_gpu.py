@@ -174,6 +174,20 @@ def test_pooled_backward_workspace_small_batch_large_plane():
             assert torch.equal(gx, gx_ref) or (tdt != torch.float32 and (gx.float() - gx_ref.float()).abs().max() < 1e-2)
             assert (gw.float() - gw_ref.float()).abs().max() <= 1e-3 * max(1.0, float(gw_ref.float().abs().max())), (shape, active, need, plain)
 
+QCASES = [  # the planes the per-channel quantized kernel (qpool_plane_forward) stages: nd, shape, pool, crop
+    (2, (5, 6, 56, 56), (2, 2), None),      # one plane per round, 16-byte pieces, batch not a multiple of anything
+    (2, (11, 3, 28, 28), (2, 2), None),     # several planes per round, a ragged last round
+    (2, (9, 4, 14, 14), (2, 2), None),      # dword pieces
+    (2, (21, 5, 7, 7), (2, 2), None),       # byte pieces, ragged windows, pooled rows that are not whole dwords
+    (2, (3, 3, 56, 56), (3, 3), None),      # nine-byte windows, ragged
+    (2, (2, 2, 112, 112), (2, 2), None),    # four items per thread
+    (2, (2, 3, 40, 48), (2, 2), [[3, 2], [4, 8]]),
+    (3, (3, 2, 8, 28, 28), (2, 2, 2), None),
+    (3, (2, 3, 4, 14, 16), (1, 2, 2), None),
+    (1, (7, 5, 64), (2,), None),
+    (1, (4, 3, 99), (3,), [[2, 1]]),
+]
+
 
 def aten_inv(cnt):
     """1 / scale of ATen's requantization in its average pool: scale = 1 / float(1 / count), all in fp32"""
@@ -192,7 +206,8 @@ def test_quantized_pooled_forward_vs_oracle(abi, npdt):
     rs = np.random.RandomState(21)
     info = np.iinfo(npdt)
     differ = False
-    for nd, shape, pool, crop in CASES:
+    served = set()
+    for nd, shape, pool, crop in CASES + QCASES:
         xq = rs.randint(info.min, info.max + 1, size=shape).astype(npdt)
         wq = rs.randint(123, 134, size=(shape[1], nd)).astype(np.uint8)
         wq[0] = 128 + shape[-1] + 2 if shape[-1] < 120 else 130
@@ -213,8 +228,13 @@ def test_quantized_pooled_forward_vs_oracle(abi, npdt):
                     ref[(slice(None), slice(None)) + idx] = np.clip(q, info.min, info.max).astype(npdt)
             differ = differ or not np.array_equal(refs[0], refs[1])
             for requant, ref in zip((abi.REQUANT_ZP_INSIDE, abi.REQUANT_ZP_OUTSIDE), refs):
-                out = abi.forward_quantized_pooled(torch.from_numpy(xq).to(DEV), torch.from_numpy(wq).to(DEV), 128, zp, pad, pool, b,
-                                                   requant=requant)
-                assert abi.last_kernel() == "qpool_forward"
-                assert np.array_equal(out.cpu().numpy(), ref), (nd, shape, pool, crop, pad, requant)
+                for knob in (0, 1):  # 0: the per-channel plane kernel where it serves, 1: one thread per pooled element
+                    abi.set_tuning(36, knob)
+                    out = abi.forward_quantized_pooled(torch.from_numpy(xq).to(DEV), torch.from_numpy(wq).to(DEV), 128, zp, pad, pool,
+                                                       b, requant=requant)
+                    abi.set_tuning(36, 0)
+                    assert abi.last_kernel() in (("qpool_forward",) if knob else ("qpool_forward", "qpool_plane_forward"))
+                    served.add(abi.last_kernel())
+                    assert np.array_equal(out.cpu().numpy(), ref), (nd, shape, pool, crop, pad, requant, abi.last_kernel())
     assert differ  # the inputs do separate the two roundings
+    assert served == {"qpool_forward", "qpool_plane_forward"}

@@ -31,6 +31,29 @@ def ev_time(fn, iters):
     return e0.elapsed_time(e1) / iters
 
 
+def quant_main(a, shape, nd):
+    dev = torch.device("cuda:0")
+    torch.manual_seed(0)
+    xq = torch.randint(0, 256, shape, device=dev, dtype=torch.uint8)
+    wq = torch.randint(125, 132, (shape[1], nd), device=dev, dtype=torch.uint8)
+    y = torch.empty_like(xq)
+    out = abi.forward_quantized_pooled(xq, wq, 128, 3, a.pad, a.pool)
+    fns = {"qshift alone": lambda: abi.forward_quantized(xq, wq, 128, 3, a.pad, out=y),
+           "qshift+pool": lambda: abi.forward_quantized_pooled(xq, wq, 128, 3, a.pad, a.pool, out=out)}
+    traffic = {"qshift alone": 2 * xq.numel(), "qshift+pool": xq.numel() + out.numel()}
+    best = {k: 1e9 for k in fns}
+    for k, fn in fns.items():
+        fn()
+        print(k, "kernel:", abi.last_kernel())
+    torch.cuda.synchronize()
+    for _ in range(a.rounds):
+        for k, fn in fns.items():
+            best[k] = min(best[k], ev_time(fn, a.iters))
+    print("shape %s pool %d uint8 pad %d" % (shape, a.pool, a.pad))
+    for k in fns:
+        print("%-12s %8.4f ms   %7.1f GB/s algorithmic (%.3f GB)" % (k, best[k], traffic[k] / best[k] / 1e6, traffic[k] / 1e9))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--shape", default="64,256,224,224")
@@ -42,9 +65,17 @@ def main():
     ap.add_argument("--rounds", type=int, default=3)
     ap.add_argument("--no-step", action="store_true", help="knob 32 = 1: the band-walk kernels instead of the one-step kernels")
     ap.add_argument("--force-fused", action="store_true", help="path policy 2: fuse the backward even where the automatic choice would not")
+    ap.add_argument("--knob", action="append", default=[], help="K=V tuning knob (repeatable)")
+    ap.add_argument("--quant", action="store_true", help="one-byte quantized tensors: shiftnd_forward_quantized alone vs "
+                    "shiftnd_forward_quantized_pooled (ATen has no QuantizedCUDA pool to compare with)")
     a = ap.parse_args()
     shape = [int(v) for v in a.shape.split(",")]
     nd = len(shape) - 2
+    for kv in a.knob:
+        k, v = kv.split("=")
+        abi.set_tuning(int(k), int(v))
+    if a.quant:
+        return quant_main(a, shape, nd)
     if a.no_step:
         abi.set_tuning(32, 1)
     dt = getattr(torch, a.dtype)

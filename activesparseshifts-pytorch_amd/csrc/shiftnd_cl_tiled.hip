@@ -317,13 +317,20 @@ struct ClTiledBwdParams {
     const void *w;
     double *partials;    // [N * bands * wtiles][C][3]
     int wkind, N, C, H, W, pad;
+    int go_nchw;         // the incoming gradient is NCHW-contiguous (saved input and grad_x: channels-last)
     int wtiles, cblocks, bands, band_rows;
     unsigned xcd_blocks;     // grid / 8 when the XCD-contiguous block remap is on (grid % 8 == 0 and knob 22), else 0
     FastDiv d_wtiles, d_cblocks, d_bands;
     FastDiv d_perH, d_perW;
 };
 
-template <typename T, bool ACTIVE>
+// GO_NCHW: the incoming gradient is NCHW-contiguous (what the op downstream of the reference's float forward hands back:
+// that forward returns an NCHW tensor even for a channels-last input, cpu/shifts_cpu.cpp:221) while the saved input and
+// grad_x are channels-last.  The gradient ring is filled from channel rows instead of pixel lines: CB segments of kBPW
+// consecutive elements per staged row, element loads with lanes along the pixels (a wave touches ~3 runs of 92 / 46
+// bytes), written to the same [pixel][channel] ring (pitch 33 words: lanes along the pixels of one channel hit
+// different banks).  Everything after the staging is the same kernel.
+template <typename T, bool ACTIVE, bool GO_NCHW>
 __global__ __launch_bounds__(kThreads) void cl_tiled_backward(const ClTiledBwdParams p) {
     typedef uint32_t u4 __attribute__((ext_vector_type(4)));
     using S = typename T::S;
@@ -355,6 +362,10 @@ __global__ __launch_bounds__(kThreads) void cl_tiled_backward(const ClTiledBwdPa
     const __amdgpu_buffer_rsrc_t gres = __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(gn), 0, img_bytes, kBufferFlags);
     const __amdgpu_buffer_rsrc_t none = __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(xn), 0, 0, kBufferFlags);
     const __amdgpu_buffer_rsrc_t ores = __builtin_amdgcn_make_buffer_rsrc(on, 0, img_bytes, kBufferFlags);
+    // the gradient element (row r, column cc) of channel ch, in elements from the image base
+    auto g_index = [&](int ch, int r, int cc) {
+        return GO_NCHW ? (static_cast<int64_t>(ch) * H + r) * W + cc : (static_cast<int64_t>(r) * W + cc) * C + ch;
+    };
 
     // ---- staging: one 16-byte piece of the input row and one of the gradient row per thread ------------------------------
     const int q = static_cast<int>(threadIdx.x);
@@ -364,22 +375,62 @@ __global__ __launch_bounds__(kThreads) void cl_tiled_backward(const ClTiledBwdPa
     const int pdst = piece ? px * kPitch + part * 4 : -1;
     const uint32_t row_bytes = static_cast<uint32_t>(W) * C * ES;
     constexpr int kDepth = CLT_DEPTH;
-    u4 pvx[kDepth], pvg[kDepth];
-    auto load_row = [&](int y, int ylast, u4 &vx, u4 &vg) {  // rows outside the image or beyond the band: nothing is read
+    // GO_NCHW: element e = ch * kBPW + px of the staged gradient row, kGN per thread
+    constexpr int kGE = CB * kBPW, kGN = GO_NCHW ? (kGE + kThreads - 1) / kThreads : 1;
+    struct GRow {
+        u4 v;                // the thread's 16-byte piece of a channels-last gradient row
+        uint32_t e[kGN];     // GO_NCHW: its elements of the row's channel segments
+    };
+    uint32_t goff[kGN];      // byte offset of the element in row 0 of the (NCHW) image, or out of range
+    int gdst[kGN];           // LDS byte offset within a ring row, or -1 (dump)
+    if constexpr (GO_NCHW) {
+#pragma unroll
+        for (int k = 0; k < kGN; ++k) {
+            const int e = k * kThreads + q, ch = e / kBPW, pxe = e - ch * kBPW, gxe = w0 - kR + pxe;
+            const bool ok = e < kGE && gxe >= 0 && gxe < W && c0 + ch < C;
+            goff[k] = ok ? (static_cast<uint32_t>(c0 + ch) * H * W + gxe) * ES : kOutOfRange;
+            gdst[k] = e < kGE ? pxe * (kPitch * 4) + ch * ES : -1;
+        }
+    }
+    const uint32_t grow_bytes = GO_NCHW ? static_cast<uint32_t>(W) * ES : row_bytes;
+    u4 pvx[kDepth];
+    GRow pvg[kDepth];
+    auto load_row = [&](int y, int ylast, u4 &vx, GRow &vg) {  // rows outside the image or beyond the band: nothing is read
         const bool wanted = y >= 0 && y <= ylast;
         const uint32_t so = wanted ? static_cast<uint32_t>(y) * row_bytes : 0u;
         vx = __builtin_amdgcn_raw_buffer_load_b128(wanted ? xres : none, poff, so, 0);
-        vg = __builtin_amdgcn_raw_buffer_load_b128(wanted ? gres : none, poff, so, 0);
+        if constexpr (GO_NCHW) {
+            const uint32_t sg = wanted ? static_cast<uint32_t>(y) * grow_bytes : 0u;
+#pragma unroll
+            for (int k = 0; k < kGN; ++k) {
+                if constexpr (ES == 4) vg.e[k] = __builtin_amdgcn_raw_buffer_load_b32(wanted ? gres : none, goff[k], sg, 0);
+                else vg.e[k] = __builtin_amdgcn_raw_buffer_load_b16(wanted ? gres : none, goff[k], sg, 0);
+            }
+        } else {
+            vg.v = __builtin_amdgcn_raw_buffer_load_b128(wanted ? gres : none, poff, so, 0);
+        }
     };
-    auto store_row = [&](int y, const u4 &vx, const u4 &vg) {
+    auto store_row = [&](int y, const u4 &vx, const GRow &vg) {
         const int slot = y & (kBRing - 1);
         uint32_t *dx = ring + (pdst >= 0 ? slot * kBRowWords + pdst : kDump);
-        uint32_t *dg = ring + (pdst >= 0 ? kBRingWords + slot * kBRowWords + pdst : kDump);
         dx[0] = vx.x; dx[1] = vx.y; dx[2] = vx.z; dx[3] = vx.w;
-        dg[0] = vg.x; dg[1] = vg.y; dg[2] = vg.z; dg[3] = vg.w;
+        if constexpr (GO_NCHW) {
+            char *gbase = reinterpret_cast<char *>(ring) + (kBRingWords + slot * kBRowWords) * 4;
+            char *dump = reinterpret_cast<char *>(ring) + kDump * 4;
+#pragma unroll
+            for (int k = 0; k < kGN; ++k) {
+                char *d = gdst[k] >= 0 ? gbase + gdst[k] : dump;
+                if constexpr (ES == 4) *reinterpret_cast<uint32_t *>(d) = vg.e[k];
+                else *reinterpret_cast<uint16_t *>(d) = static_cast<uint16_t>(vg.e[k]);
+            }
+        } else {
+            uint32_t *dg = ring + (pdst >= 0 ? kBRingWords + slot * kBRowWords + pdst : kDump);
+            dg[0] = vg.v.x; dg[1] = vg.v.y; dg[2] = vg.v.z; dg[3] = vg.v.w;
+        }
     };
     const int ylast = min(H - 1, h1 + kR);
-    u4 prex[2 * kR + 1], preg[2 * kR + 1];
+    u4 prex[2 * kR + 1];
+    GRow preg[2 * kR + 1];
 #pragma unroll
     for (int d = 0; d < kDepth; ++d) load_row(h0 + kR + 1 + d, ylast, pvx[d], pvg[d]);
 #pragma unroll
@@ -463,7 +514,7 @@ __global__ __launch_bounds__(kThreads) void cl_tiled_backward(const ClTiledBwdPa
     // R + 1, comes back at distance -(R + 1))
     const bool srow = near_c && p.pad == 3 && H > 1 && sh_s == -kR && h1 == H;
     int xrow1 = fold1(h0 - sh_s);   // the + 1 corner of step h - 1 is the first corner of step h
-    auto step = [&](int h, u4 &vx, u4 &vg) {
+    auto step = [&](int h, u4 &vx, GRow &vg) {
         __syncthreads();  // everybody is done with the slot that row h + R + 1 replaces (row h - R - 1)
         if (h + kR + 1 < H) store_row(h + kR + 1, vx, vg);
         __syncthreads();
@@ -529,10 +580,12 @@ __global__ __launch_bounds__(kThreads) void cl_tiled_backward(const ClTiledBwdPa
 #pragma unroll
     for (int i = 0; i < NI; ++i) any_scol = any_scol || scol[i];
     if (live_c && (far_c || any_scol || srow)) {
-        const S *xe = reinterpret_cast<const S *>(xn) + c, *ge = reinterpret_cast<const S *>(gn) + c;
+        const S *xe = reinterpret_cast<const S *>(xn) + c, *ge = reinterpret_cast<const S *>(gn);
         S *oe = reinterpret_cast<S *>(on) + c;
         auto tap_s = [&](const S *base, int r, int cc) { return (r >= 0 && cc >= 0) ? base[(static_cast<int64_t>(r) * W + cc) * C] : narrow<T>(CT(0)); };
         auto tap = [&](const S *base, int r, int cc) { return widen<T>(tap_s(base, r, cc)); };
+        auto gtap_s = [&](int r, int cc) { return (r >= 0 && cc >= 0) ? ge[g_index(c, r, cc)] : narrow<T>(CT(0)); };
+        auto gtap = [&](int r, int cc) { return widen<T>(gtap_s(r, cc)); };
 #pragma unroll
         for (int i = 0; i < NI; ++i) {
             const int wq = w0 + lane_b + PL * i;
@@ -542,16 +595,16 @@ __global__ __launch_bounds__(kThreads) void cl_tiled_backward(const ClTiledBwdPa
                 if (!(far_c || scol[i] || (srow && h == H - 1))) continue;
                 const int r0 = fold_h(h - csxH), r1 = fold_h(h - csxH + 1), s0 = fold_h(h - csgH), s1 = fold_h(h - csgH + 1);
                 CT v[4] = {tap(xe, r0, a0), tap(xe, r1, a0), tap(xe, r0, a1), tap(xe, r1, a1)}, wg[3];
-                const CT gval = widen<T>(ge[(static_cast<int64_t>(h) * W + wq) * C]);
+                const CT gval = widen<T>(ge[g_index(c, h, wq)]);
                 weight_grads_nd<2, CT>(v, dw, wg);
                 acc[0] += static_cast<double>(gval * wg[0]);
                 acc[1] += static_cast<double>(gval * wg[1]);
                 S r;
                 if constexpr (ACTIVE) {
-                    CT u[4] = {tap(ge, s0, b0), tap(ge, s1, b0), tap(ge, s0, b1), tap(ge, s1, b1)};
+                    CT u[4] = {gtap(s0, b0), gtap(s1, b0), gtap(s0, b1), gtap(s1, b1)};
                     r = narrow<T>(interp_t<T, 2>(u, dw));
                 } else {
-                    r = tap_s(ge, s0, b0);
+                    r = gtap_s(s0, b0);
                 }
                 oe[(static_cast<int64_t>(h) * W + wq) * C] = r;
             }
@@ -954,9 +1007,12 @@ bool cl_tiled_backward_eligible(const Geometry &g, int dtype, const void *go, co
         if (g.L[d] != 0 || g.O[d] != g.S[d]) return false;
     if ((g.C * es) % 16 != 0 || g.S[1] >= (1 << 20) || g.S[2] >= (1 << 20) || g.N >= (1LL << 24) || g.C >= (1 << 24)) return false;
     if (g.S[1] != 1 && g.S[1] < 5) return false;  // the kernel folds source rows once
-    if (reinterpret_cast<uintptr_t>(x) % 16 != 0 || reinterpret_cast<uintptr_t>(go) % 16 != 0 || reinterpret_cast<uintptr_t>(gx) % es != 0) return false;
     if (g.C * g.S[1] * g.S[2] * es >= (1LL << 31)) return false;
-    if (!dense_channels_last_2d(g.xs, g, g.S) || !dense_channels_last_2d(g.os, g, g.O) || !dense_channels_last_2d(g.gs, g, g.S)) return false;
+    if (!dense_channels_last_2d(g.xs, g, g.S) || !dense_channels_last_2d(g.gs, g, g.S)) return false;
+    // the incoming gradient: channels-last like the others, or NCHW-contiguous (the mixed form: GO_NCHW)
+    const bool go_cl = dense_channels_last_2d(g.os, g, g.O);
+    if (!go_cl && !contiguous_2d(g.os, g, g.O)) return false;
+    if (reinterpret_cast<uintptr_t>(x) % 16 != 0 || reinterpret_cast<uintptr_t>(go) % (go_cl ? 16 : es) != 0 || reinterpret_cast<uintptr_t>(gx) % es != 0) return false;
     const ClTiledBwdPlan pl = cl_tiled_backward_plan(g, es);
     return pl.groups * pl.cblocks < (1LL << 31);
 }
@@ -971,8 +1027,13 @@ namespace {
 template <typename T>
 void launch_cl_tiled_backward(const ClTiledBwdParams &p, const ClTiledBwdPlan &pl, bool active, void *gw, hipStream_t st) {
     const dim3 grid(static_cast<unsigned>(pl.groups * pl.cblocks)), block(kThreads);
-    if (active) hipLaunchKernelGGL((cl_tiled_backward<T, true>), grid, block, 0, st, p);
-    else hipLaunchKernelGGL((cl_tiled_backward<T, false>), grid, block, 0, st, p);
+    if (p.go_nchw) {
+        if (active) hipLaunchKernelGGL((cl_tiled_backward<T, true, true>), grid, block, 0, st, p);
+        else hipLaunchKernelGGL((cl_tiled_backward<T, false, true>), grid, block, 0, st, p);
+    } else {
+        if (active) hipLaunchKernelGGL((cl_tiled_backward<T, true, false>), grid, block, 0, st, p);
+        else hipLaunchKernelGGL((cl_tiled_backward<T, false, false>), grid, block, 0, st, p);
+    }
     hipLaunchKernelGGL((reduce_weight_grads<T>), dim3(p.C * 2), dim3(64), 0, st, p.partials, static_cast<int>(pl.groups), p.C, 2,
                        static_cast<typename T::S *>(gw));
 }
@@ -993,6 +1054,7 @@ int cl_tiled_backward(const Geometry &g, int dtype, const void *go, const void *
     p.H = static_cast<int>(g.S[1]);
     p.W = static_cast<int>(g.S[2]);
     p.pad = g.pad;
+    p.go_nchw = dense_channels_last_2d(g.os, g, g.O) ? 0 : 1;   // (a tensor that is both -- C == 1 -- reads the same either way)
     p.wtiles = pl.wtiles;
     p.cblocks = pl.cblocks;
     p.bands = pl.bands;
@@ -1006,7 +1068,7 @@ int cl_tiled_backward(const Geometry &g, int dtype, const void *go, const void *
         const int64_t grid = pl.groups * pl.cblocks;
         p.xcd_blocks = (g_cl_tiled_tune[2] && grid % 8 == 0) ? static_cast<unsigned>(grid / 8) : 0;
     }
-    note_kernel("cl_tiled_backward");
+    note_kernel(p.go_nchw ? "cl_tiled_backward_nchw_grad" : "cl_tiled_backward");
     switch (dtype) {
     case SHIFTND_F32: launch_cl_tiled_backward<f32_t>(p, pl, g.active != 0, gw, st); break;
     case SHIFTND_F16: launch_cl_tiled_backward<f16_t>(p, pl, g.active != 0, gw, st); break;

@@ -270,11 +270,13 @@ std::tuple<Tensor, Tensor> shift_backward_hip(const Tensor &grad_, const Tensor 
     const int dtype = to_shiftnd_dtype(grad_.scalar_type(), "shiftnd_backward_cuda");
     Tensor w = weights.contiguous();
     Tensor grad_weights = at::empty_like(w, at::MemoryFormat::Contiguous);
-    // saved input and incoming gradient both dense channels-last: the library may have a kernel for that layout
-    // (shiftnd_cl_tiled.hip; grad_x is channels-last too); otherwise change the layout once, then the contiguous kernels
+    // saved input dense channels-last, incoming gradient channels-last too or NCHW-contiguous (what follows the reference's
+    // float forward, which returns NCHW for a channels-last input): the library may have a kernel for that layout
+    // (shiftnd_cl_tiled.hip; grad_x comes out in the input's layout); otherwise change the layout once, then the
+    // contiguous kernels
     bool direct = false;
     Tensor grad_input;
-    if (is_channels_last_dense(input_) && is_channels_last_dense(grad_)) {
+    if (is_channels_last_dense(input_) && (is_channels_last_dense(grad_) || grad_.is_contiguous())) {
         grad_input = at::empty_like(input_, input_.suggest_memory_format());
         shiftnd_problem pd;
         fill_problem(pd, ND, input_, b, padding_mode, active_flag, dtype);

@@ -282,6 +282,81 @@ def test_tiled_channels_last_backward_vs_oracle(shape):
 
 
 @pytest.mark.parametrize("shape", [(2, 8, 9, 12), (3, 300, 6, 5), (2, 64, 40, 70), (1, 36, 100, 33), (2, 4, 1, 50), (1, 32, 64, 1)])
+def test_tiled_backward_nchw_gradient_vs_oracle(shape):
+    """cl_tiled_backward<GO_NCHW>: saved input channels-last, incoming gradient NCHW-contiguous (what an op downstream of
+    the reference's float forward returns, cpu/shifts_cpu.cpp:221), grad_x in the input's layout -- one pass, no transpose.
+    fp32: grad_x bit-exact with the oracle, grad_w within 1e-5 of its fp64 evaluation; fp16 / bf16 (sparse shift): grad_x
+    bit-exact, grad_w within the type's epsilon"""
+    from torchshifts import abi
+    rs = np.random.RandomState(sum(shape) + 31)
+    x = rs.uniform(-1, 1, size=shape).astype(np.float32)
+    go = rs.uniform(-1, 1, size=shape).astype(np.float32)
+    w = rs.uniform(-3.4, 3.4, size=(shape[1], 2)).astype(np.float32)
+    w[0] = [0.5, -1.5]
+    w[1] = [shape[2] + 2.25, -7.0]       # beyond the dim / beyond the ring
+    w[2] = [-5.0, 2.5]
+    w[3] = [3.0, -3.0]
+    cl = torch.channels_last
+    xd = torch.from_numpy(x).to(DEV).contiguous(memory_format=cl)
+    god = torch.from_numpy(go).to(DEV)   # NCHW
+    wd = torch.from_numpy(w).to(DEV)
+    try:
+        for band_rows in (0, 5):
+            abi.set_tuning(21, band_rows)
+            for pad in (0, 1, 3, 4):
+                for active in (0, 1):
+                    gx_o, _ = O.backward(go, w, x, pad, active)
+                    _, gw64 = O.backward(go.astype(np.float64), w.astype(np.float64), x.astype(np.float64), pad, active)
+                    gxd = torch.empty(shape, device=DEV).contiguous(memory_format=cl)
+                    gx, gw = abi.backward(god, wd, xd, pad, active, grad_x=gxd)
+                    assert abi.last_kernel() == "cl_tiled_backward_nchw_grad", (shape, pad, active)
+                    assert np.array_equal(gx.cpu().numpy(), gx_o), (shape, pad, active, band_rows)
+                    assert rel_err(gw.cpu().numpy(), gw64) < 1e-5, (shape, pad, active, band_rows)
+        abi.set_tuning(21, 0)
+        for tdt in (torch.float16, torch.bfloat16):
+            if (shape[1] * 2) % 16:
+                continue
+            x16, go16, w16 = torch.from_numpy(x).to(tdt), torch.from_numpy(go).to(tdt), torch.from_numpy(w).to(tdt)
+            xn, gn, wn = x16.float().numpy(), go16.float().numpy(), w16.float().numpy()
+            eps = float(torch.finfo(tdt).eps)
+            for pad in (0, 1, 3, 4):
+                gx_o = torch.from_numpy(O.backward(gn, wn, xn, pad, 0)[0]).to(tdt)
+                _, gw64 = O.backward(gn.astype(np.float64), wn.astype(np.float64), xn.astype(np.float64), pad, 0)
+                gxd = torch.empty(shape, dtype=tdt, device=DEV).contiguous(memory_format=cl)
+                gx, gw = abi.backward(go16.to(DEV), w16.to(DEV), x16.to(DEV).contiguous(memory_format=cl), pad, 0, grad_x=gxd)
+                assert abi.last_kernel() == "cl_tiled_backward_nchw_grad", (shape, tdt, pad)
+                assert torch.equal(gx.cpu(), gx_o), (shape, tdt, pad)
+                assert rel_err(gw.float().cpu().numpy(), gw64) < 2 * eps, (shape, tdt, pad)
+    finally:
+        abi.set_tuning(21, 0)
+
+
+def test_channels_last_module_trains_without_a_transpose():
+    """Shift2d on a channels-last input through the dispatcher ops: the forward returns NCHW (as the reference's does), the
+    gradient that comes back is NCHW, and the backward runs as ONE kernel that reads both as they lie and writes grad_x in
+    the input's layout -- same values as the contiguous run"""
+    import torchshifts
+    from torchshifts import abi
+    torch.manual_seed(3)
+    for active in (False, True):
+        m = torchshifts.Shift2d(64, init_shift=2, sparsity_term=0., active_flag=active).to(DEV)
+        x = torch.rand(4, 64, 40, 36, device=DEV)
+        t = torch.rand(4, 64, 40, 36, device=DEV)
+        xc = x.clone().requires_grad_(True)
+        out_c, _ = m(xc)
+        torch.nn.functional.mse_loss(out_c, t).backward()
+        gw_c, gx_c = m.weight.grad.clone(), xc.grad.clone()
+        m.zero_grad()
+        xl = x.clone().contiguous(memory_format=torch.channels_last).requires_grad_(True)
+        out_l, _ = m(xl)
+        assert out_l.is_contiguous() and torch.equal(out_l, out_c)
+        torch.nn.functional.mse_loss(out_l, t).backward()
+        assert xl.grad.is_contiguous(memory_format=torch.channels_last)
+        assert torch.equal(xl.grad, gx_c), active
+        assert rel_err(m.weight.grad.cpu().numpy(), gw_c.cpu().numpy()) < 1e-5
+
+
+@pytest.mark.parametrize("shape", [(2, 8, 9, 12), (3, 300, 6, 5), (2, 64, 40, 70), (1, 36, 100, 33), (2, 4, 1, 50), (1, 32, 64, 1)])
 def test_tiled_channels_last_active_forward_vs_oracle(shape):
     """cl_tiled_active_forward: fp32 channels-last input, interpolated output channels-last or NCHW-contiguous, every
     padding it serves, shifts beyond the ring, the reflected corner of the last row / column; bit-exact"""

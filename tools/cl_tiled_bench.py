@@ -65,3 +65,17 @@ for active in (0, 1):
     t4 = ev(lambda: abi.backward(gbc, wb, xbc, 0, active, grad_x=gxbc, grad_w=gwb, workspace=ws)); k4 = abi.last_kernel()
     assert torch.equal(ob, obc) and torch.equal(gxb, gxbc)
     print("bf16 active=%d  fwd NCHW %.3f ms (%s)  NHWC %.3f ms (%s)   bwd NCHW %.3f ms (%s)  NHWC %.3f ms (%s)" % (active, t1, k1, t2, k2, t3, k3, t4, k4))
+# fp32 backward: all channels-last, the mixed form (NHWC saved input, NCHW gradient, NHWC grad_x), the contiguous kernels,
+# and what the mixed form cost before (transpose x, contiguous backward: grad_x NCHW)
+g = torch.rand(16, 256, 224, 224, device=dev); gc = g.contiguous(memory_format=torch.channels_last)
+gx = torch.empty_like(x); gxc = torch.empty_like(xc); gw = torch.empty_like(w)
+ws = abi.backward_workspace(x, 0, 1)
+for active in (0, 1):
+    t1 = ev(lambda: abi.backward(g, w, x, 0, active, grad_x=gx, grad_w=gw, workspace=ws)); k1 = abi.last_kernel()
+    t2 = ev(lambda: abi.backward(gc, w, xc, 0, active, grad_x=gxc, grad_w=gw, workspace=ws)); k2 = abi.last_kernel()
+    ref_gx = gxc.clone()
+    t3 = ev(lambda: abi.backward(g, w, xc, 0, active, grad_x=gxc, grad_w=gw, workspace=ws)); k3 = abi.last_kernel()
+    assert torch.equal(gxc, ref_gx) and torch.equal(gx, ref_gx)
+    t4 = ev(lambda: abi.backward(g, w, abi.to_contiguous(xc), 0, active, grad_x=gx, grad_w=gw, workspace=ws))
+    print("fp32 active=%d bwd  NCHW %.3f ms (%s)   all NHWC %.3f ms (%s)   NHWC x + NCHW grad %.3f ms (%s, %.0f GB/s)   transpose + NCHW %.3f ms"
+          % (active, t1, k1, t2, k2, t3, k3, 12 * x.numel() / t3 / 1e6, t4))

@@ -17,7 +17,9 @@
 //   * forward output: channels-last (the quantized op keeps the format, shifts_quantized.cpp:119-121) or
 //     NCHW-contiguous like the reference's float forward (cpu/shifts_cpu.cpp:221): lanes then run along the row of one
 //     channel -- the layout change costs nothing extra.
-// Periodic padding wraps to the far side of the plane (not in the ring) and is left to shiftnd_cl.hip.
+// Periodic padding wraps to the far side of the plane: the pixels near the left / right edge and the rows near the top /
+// bottom whose source is not in the ring (at most R of each) are written by the element-by-element pass that also serves
+// the shifts beyond the ring; everything else of a periodic call takes the tiled path.
 //
 // Reference behaviour restated: kernels/shifts_kernels.h:330-400 (nhwdc forward), :402-527 (nhwdc backward), :574-624
 // (quantized).  Roofline: HBM, 2 x s bytes per element forward, 3 x s backward.
@@ -207,7 +209,8 @@ __global__ __launch_bounds__(kThreads) void cl_tiled_forward(const ClTiledParams
             gcol[i][j] = sx;
             // canon_shift returns the non-negative representative for the reflecting paddings: look at the signed one
             const int sh_s = (perH && 2 * sh > perH) ? sh - perH : sh, sw_s = (perW && 2 * sw > perW) ? sw - perW : sw;
-            const bool in_ring = sh_s >= -kR && sh_s <= kR && sw_s >= -kR && sw_s <= kR;
+            // (periodic padding: a column near the edge comes from the far side of the row -- not among the staged pixels)
+            const bool in_ring = sh_s >= -kR && sh_s <= kR && sw_s >= -kR && sw_s <= kR && (sx < 0 || (sx >= w0 - kR && sx < w0 + kTW + kR));
             const bool nr = live && sx >= 0 && in_ring;
             ring_ok |= (nr ? 1u : 0u) << (4 * i + j);
             far |= ((live && sx >= 0 && !in_ring) ? 1u : 0u) << (4 * i + j);
@@ -228,6 +231,7 @@ __global__ __launch_bounds__(kThreads) void cl_tiled_forward(const ClTiledParams
         if (y >= 0 && y < H) store_row(y, pre[r]);
     }
     const uint8_t *ringb = reinterpret_cast<const uint8_t *>(ring);
+    const bool periodic = p.pad == 2 && H > 1;
     auto step = [&](int h, u4 (&pv)[kNP]) {
         __syncthreads();  // everybody is done with the slot that row h + R replaces (row h - R - 1)
         if (h + kR < H) store_row(h + kR, pv);
@@ -240,7 +244,10 @@ __global__ __launch_bounds__(kThreads) void cl_tiled_forward(const ClTiledParams
             const int sy = H == 1 ? 0 : fold_index(h - csh[k], H, p.pad);
             const uint32_t r = static_cast<uint32_t>(sy < 0 ? 0 : sy);
             const uint32_t sl = r - __umulhi(r, 613566757u) * kRing;       // r % 7 (r < 2^20)
-            rowb[k] = sy < 0 ? -1 : static_cast<int>(sl) * (kRowWords * 4);
+            // (periodic padding: a row that wraps to the far side of the image is not in the ring; the fill value goes out
+            // and the pass after the loop writes the element)
+            const bool wrapped = periodic && (sy < h - kR || sy > h + kR);
+            rowb[k] = (sy < 0 || wrapped) ? -1 : static_cast<int>(sl) * (kRowWords * 4);
         }
         uint32_t v[4];
 #pragma unroll
@@ -268,13 +275,15 @@ __global__ __launch_bounds__(kThreads) void cl_tiled_forward(const ClTiledParams
 
     // ---- shifts beyond the ring: gathered from memory, element by element (rare).  The row loop stored the fill
     // value in their place; those stores are complete before the elements are written again. ------------------------
-    if (far) {
+    const bool wrap_rows = periodic && (h0 < kR || h1 > H - kR);   // the band holds rows whose source row wraps
+    if (far || (wrap_rows && ring_ok)) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
 #pragma unroll
             for (int j = 0; j < NE; ++j) {
-                if (!((far >> (4 * i + j)) & 1u)) continue;
+                const bool all_rows = (far >> (4 * i + j)) & 1u;
+                if (!all_rows && !(wrap_rows && ((ring_ok >> (4 * i + j)) & 1u))) continue;
                 const int D = static_cast<int>(threadIdx.x) + kThreads * i;
                 const int ch = OUT_CL ? lane_a * NE + j : D / RD;
                 const int col = OUT_CL ? lane_b + 8 * i : (D % RD) * NE + j;
@@ -284,7 +293,8 @@ __global__ __launch_bounds__(kThreads) void cl_tiled_forward(const ClTiledParams
                 const int shc = csh[OUT_CL ? j : i];
                 for (int h = h0; h < h1; ++h) {
                     const int sy = H == 1 ? 0 : fold_index(h - shc, H, p.pad);
-                    *o = sy >= 0 ? xe[(static_cast<int64_t>(sy) * W + gcol[i][j]) * C + c0 + ch] : static_cast<EL>(p.fill);
+                    if (all_rows || sy < h - kR || sy > h + kR)
+                        *o = sy >= 0 ? xe[(static_cast<int64_t>(sy) * W + gcol[i][j]) * C + c0 + ch] : static_cast<EL>(p.fill);
                     o += OUT_CL ? W * C : W;
                 }
             }
@@ -513,6 +523,13 @@ __global__ __launch_bounds__(kThreads) void cl_tiled_backward(const ClTiledBwdPa
     // the one source row the rings cannot hold: reflect padding, last output row, shift -R (its + 1 corner, at distance
     // R + 1, comes back at distance -(R + 1))
     const bool srow = near_c && p.pad == 3 && H > 1 && sh_s == -kR && h1 == H;
+    // periodic padding: rows whose input corners or gradient taps wrap to the far side of the image (at most R + 1 at the top
+    // or the bottom) are not in the rings: left to the element-by-element pass
+    const bool periodic = p.pad == 2 && H > 1;
+    auto wraps = [&](int h) {
+        const int g0 = ACTIVE ? h - sh_s : h + sh_s;   // the gradient taps' first row (the active shift's second: + 1)
+        return periodic && near_c && (h - sh_s < 0 || h + 1 - sh_s >= H || g0 < 0 || g0 + (ACTIVE ? 1 : 0) >= H);
+    };
     int xrow1 = fold1(h0 - sh_s);   // the + 1 corner of step h - 1 is the first corner of step h
     auto step = [&](int h, u4 &vx, GRow &vg) {
         __syncthreads();  // everybody is done with the slot that row h + R + 1 replaces (row h - R - 1)
@@ -525,7 +542,7 @@ __global__ __launch_bounds__(kThreads) void cl_tiled_backward(const ClTiledBwdPa
         const int xr1 = row_off(xrow1);
         const int gr0 = ACTIVE ? xr0 : row_off(fold1(h + sh_s)), gr1 = ACTIVE ? xr1 : -1;
         const int gdr = (h & (kBRing - 1)) * (kBRowWords * 4);
-        const bool skip = srow && h == H - 1;
+        const bool skip = (srow && h == H - 1) || wraps(h);
         S res[NI];
         CT s0 = CT(0), s1 = CT(0);
 #pragma unroll
@@ -579,7 +596,8 @@ __global__ __launch_bounds__(kThreads) void cl_tiled_backward(const ClTiledBwdPa
     bool any_scol = false;
 #pragma unroll
     for (int i = 0; i < NI; ++i) any_scol = any_scol || scol[i];
-    if (live_c && (far_c || any_scol || srow)) {
+    const bool wrap_rows = periodic && near_c && (h0 <= kR || h1 >= H - kR - 1);
+    if (live_c && (far_c || any_scol || srow || wrap_rows)) {
         const S *xe = reinterpret_cast<const S *>(xn) + c, *ge = reinterpret_cast<const S *>(gn);
         S *oe = reinterpret_cast<S *>(on) + c;
         auto tap_s = [&](const S *base, int r, int cc) { return (r >= 0 && cc >= 0) ? base[(static_cast<int64_t>(r) * W + cc) * C] : narrow<T>(CT(0)); };
@@ -592,7 +610,7 @@ __global__ __launch_bounds__(kThreads) void cl_tiled_backward(const ClTiledBwdPa
             if (wq >= W) continue;
             const int a0 = fold_w(wq - csxW), a1 = fold_w(wq - csxW + 1), b0 = fold_w(wq - csgW), b1 = fold_w(wq - csgW + 1);
             for (int h = h0; h < h1; ++h) {
-                if (!(far_c || scol[i] || (srow && h == H - 1))) continue;
+                if (!(far_c || scol[i] || (srow && h == H - 1) || wraps(h))) continue;
                 const int r0 = fold_h(h - csxH), r1 = fold_h(h - csxH + 1), s0 = fold_h(h - csgH), s1 = fold_h(h - csgH + 1);
                 CT v[4] = {tap(xe, r0, a0), tap(xe, r1, a0), tap(xe, r0, a1), tap(xe, r1, a1)}, wg[3];
                 const CT gval = widen<T>(ge[g_index(c, h, wq)]);
@@ -796,6 +814,10 @@ __global__ __launch_bounds__(kThreads) void cl_tiled_active_forward(const ClTile
         r = (fzero && (lo || hi)) ? -1 : r;
         return H == 1 ? 0 : r;
     };
+    // periodic padding: a corner row that wraps to the far side of the image is not in the ring; such rows (at most R + 1 at
+    // the top or the bottom of the image) are left to the element-by-element pass, like the reflected corner above
+    const bool periodic = p.pad == 2 && H > 1;
+    auto wraps = [&](int h, int sgn) { return periodic && (h - sgn < 0 || h + 1 - sgn >= H); };
     int xrow1[NCH];
 #pragma unroll
     for (int k = 0; k < NCH; ++k) xrow1[k] = fold1(h0 - shs[k]);
@@ -812,7 +834,7 @@ __global__ __launch_bounds__(kThreads) void cl_tiled_active_forward(const ClTile
             xr0[k] = row_off(xrow1[k]);
             xrow1[k] = fold1(h + 1 - shs[k]);
             xr1[k] = row_off(xrow1[k]);
-            skip[k] = srow[k] && h == H - 1;
+            skip[k] = (srow[k] && h == H - 1) || wraps(h, shs[k]);
         }
         S res[NI];
 #pragma unroll
@@ -852,20 +874,22 @@ __global__ __launch_bounds__(kThreads) void cl_tiled_active_forward(const ClTile
     bool any_srow = false;
 #pragma unroll
     for (int k = 0; k < NCH; ++k) any_srow = any_srow || srow[k];
-    if (rest || any_srow) {
+    const bool wrap_rows = periodic && (h0 <= kR || h1 >= H - kR - 1);
+    if (rest || any_srow || (wrap_rows && live)) {
         const S *xe = reinterpret_cast<const S *>(xn);
         auto tap = [&](const S *base, int r, int cc) { return (r >= 0 && cc >= 0) ? widen<T>(base[(static_cast<int64_t>(r) * W + cc) * C]) : CT(0); };
 #pragma unroll
         for (int i = 0; i < NI; ++i) {
             const int k = OUT_CL ? 0 : i;
-            const bool all_rows = (rest >> i) & 1u, last_row = ((live >> i) & 1u) && srow[k];
-            if (!all_rows && !last_row) continue;
+            const bool all_rows = (rest >> i) & 1u, mine = (live >> i) & 1u;
+            if (!all_rows && !(mine && (srow[k] || wrap_rows))) continue;
             const int ch = OUT_CL ? lane_a : lane_b + PL * i, col = OUT_CL ? lane_b + PL * i : lane_a;
             const int shc = tab_shc[ch], sw = tab_sw[ch], wq = w0 + col;
             const int a0 = fold_w(wq - sw), a1 = fold_w(wq - sw + 1);
             S *o = reinterpret_cast<S *>(on) + (OUT_CL ? (static_cast<int64_t>(h0) * W + wq) * C + c0 + ch
                                                                : (static_cast<int64_t>(c0 + ch) * H + h0) * W + wq);
-            for (int h = all_rows ? h0 : H - 1; h < h1; ++h) {
+            for (int h = h0; h < h1; ++h) {
+                if (!all_rows && !((srow[k] && h == H - 1) || wraps(h, shs[k]))) continue;
                 const int r0 = fold_h(h - shc), r1 = fold_h(h - shc + 1);
                 CT v[4] = {tap(xe + c0 + ch, r0, a0), tap(xe + c0 + ch, r1, a0), tap(xe + c0 + ch, r0, a1), tap(xe + c0 + ch, r1, a1)};
                 o[static_cast<int64_t>(h - h0) * (OUT_CL ? W * C : W)] = narrow<T>(interp_t<T, 2>(v, dws[k]));
@@ -892,12 +916,12 @@ void cl_tiled_set_tuning(int knob, int value) {
     if (knob >= 0 && knob < 3) g_cl_tiled_tune[knob] = value;
 }
 
-// 2-D, 1- / 2- / 4-byte elements, pure gather (sparse shift / quantized), no crop, not periodic, dense channels-last
+// 2-D, 1- / 2- / 4-byte elements, pure gather (sparse shift / quantized), no crop, dense channels-last
 // input whose pixel lines (C elements) are whole 16-byte pieces, 16-byte aligned; output dense channels-last or
 // NCHW-contiguous with rows of whole dwords
 bool cl_tiled_forward_eligible(const Geometry &g, int dtype, const void *x, const void *out) {
     const int es = dtype_size(dtype);
-    if (!g_cl_tiled_tune[0] || g.nd != 2 || es > 4 || g.pad == 2) return false;
+    if (!g_cl_tiled_tune[0] || g.nd != 2 || es > 4) return false;
     if (g.active && dtype <= SHIFTND_BF16) {  // interpolating: cl_tiled_active_forward (fp32, fp16, bf16), rows folded once
         if (dtype == SHIFTND_F64 || (g.S[1] != 1 && g.S[1] < 5)) return false;
     }
@@ -998,10 +1022,10 @@ ClTiledBwdPlan cl_tiled_backward_plan(const Geometry &g, int es = 4) {
 }
 }  // namespace
 
-// 2-D fp32 / fp16 / bf16, no crop, not periodic; saved input, incoming gradient and grad_x dense channels-last, pixel
+// 2-D fp32 / fp16 / bf16, no crop; saved input and grad_x dense channels-last, incoming gradient too or NCHW-contiguous, pixel
 // lines of whole 16-byte pieces
 bool cl_tiled_backward_eligible(const Geometry &g, int dtype, const void *go, const void *x, const void *gx) {
-    if (!g_cl_tiled_tune[0] || g.nd != 2 || (dtype != SHIFTND_F32 && dtype != SHIFTND_F16 && dtype != SHIFTND_BF16) || g.pad == 2) return false;
+    if (!g_cl_tiled_tune[0] || g.nd != 2 || (dtype != SHIFTND_F32 && dtype != SHIFTND_F16 && dtype != SHIFTND_BF16)) return false;
     const int es = dtype_size(dtype);
     for (int d = 0; d < 3; ++d)
         if (g.L[d] != 0 || g.O[d] != g.S[d]) return false;

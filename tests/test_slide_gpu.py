@@ -161,7 +161,7 @@ def test_small_plane_byte_kernel_vs_oracle(shape, tdt, npdt, zp):
 @pytest.mark.parametrize("shape", [(2, 8, 9, 12), (3, 300, 6, 5), (2, 64, 40, 70), (1, 36, 100, 33), (2, 4, 1, 50), (1, 32, 64, 1)])
 def test_tiled_channels_last_forward_vs_oracle(shape):
     """cl_tiled_forward (csrc/shiftnd_cl_tiled.hip): dense channels-last fp32 / int32 input, channels-last or
-    NCHW-contiguous output, every padding it serves (periodic goes to the channel-fastest gather), shifts beyond the
+    NCHW-contiguous output, every padding (periodic: the wrapped edge pixels / rows through the element pass), shifts beyond the
     ring (gathered from memory), ragged tiles / channel blocks / bands; bit-exact"""
     from torchshifts import abi
     rs = np.random.RandomState(sum(shape) + 3)
@@ -175,7 +175,7 @@ def test_tiled_channels_last_forward_vs_oracle(shape):
     try:
         for band_rows in (0, 5):
             abi.set_tuning(21, band_rows)
-            for pad in (0, 1, 3, 4):
+            for pad in (0, 1, 2, 3, 4):
                 ref = O.forward(x, w, pad, False)
                 out = abi.forward(xd, wd, pad, False)  # NCHW-contiguous output
                 assert abi.last_kernel() == "cl_tiled_forward" and out.is_contiguous()
@@ -185,8 +185,6 @@ def test_tiled_channels_last_forward_vs_oracle(shape):
                 assert abi.last_kernel() == "cl_tiled_forward"
                 assert np.array_equal(out_cl.cpu().numpy(), ref), (shape, pad, "cl")
         abi.set_tuning(21, 0)
-        abi.forward(xd, wd, 2, False)
-        assert abi.last_kernel() != "cl_tiled_forward"  # periodic
         # int32 quantized: fill = the input's zero point
         xq = rs.randint(-1000, 1000, size=shape).astype(np.int32)
         wq = rs.randint(124, 133, size=(shape[1], 2)).astype(np.uint8)
@@ -217,7 +215,7 @@ def test_tiled_channels_last_forward_small_elements(shape):
                 wq[2] = [128 - 4, 128 + 3]
                 xqd = torch.from_numpy(xq).to(DEV).contiguous(memory_format=torch.channels_last)
                 wqd = torch.from_numpy(wq).to(DEV)
-                for pad in (0, 1, 3, 4):
+                for pad in (0, 1, 2, 3, 4):
                     outq = torch.empty(shape, dtype=xqd.dtype, device=DEV).contiguous(memory_format=torch.channels_last)
                     abi.forward_quantized(xqd, wqd, 128, zp, pad, out=outq)
                     assert abi.last_kernel() == "cl_tiled_forward", (shape, npdt, pad)
@@ -230,7 +228,7 @@ def test_tiled_channels_last_forward_small_elements(shape):
                     w[1, 0], w[1, 1] = shape[2] + 2.25, -7.0
                     xd = x.to(DEV).contiguous(memory_format=torch.channels_last)
                     wd = w.to(DEV)
-                    for pad in (0, 1, 3, 4):
+                    for pad in (0, 1, 2, 3, 4):
                         ref = abi.forward(x.to(DEV), wd, pad, False)   # the NCHW kernels (checked against the oracle elsewhere)
                         out = abi.forward(xd, wd, pad, False)  # NCHW-contiguous output
                         nchw_tiled = (shape[3] * 2) % 4 == 0
@@ -265,7 +263,7 @@ def test_tiled_channels_last_backward_vs_oracle(shape):
     try:
         for band_rows in (0, 5):
             abi.set_tuning(21, band_rows)
-            for pad in (0, 1, 3, 4):
+            for pad in (0, 1, 2, 3, 4):
                 for active in (0, 1):
                     gx_o, _ = O.backward(go, w, x, pad, active)
                     _, gw64 = O.backward(go.astype(np.float64), w.astype(np.float64), x.astype(np.float64), pad, active)
@@ -275,8 +273,6 @@ def test_tiled_channels_last_backward_vs_oracle(shape):
                     assert np.array_equal(gx.cpu().numpy(), gx_o), (shape, pad, active, band_rows)
                     assert rel_err(gw.cpu().numpy(), gw64) < 1e-5, (shape, pad, active, band_rows)
         abi.set_tuning(21, 0)
-        abi.backward(god, wd, xd, 2, 0, grad_x=torch.empty(shape, device=DEV).contiguous(memory_format=cl))
-        assert abi.last_kernel() != "cl_tiled_backward"  # periodic
     finally:
         abi.set_tuning(21, 0)
 
@@ -303,7 +299,7 @@ def test_tiled_backward_nchw_gradient_vs_oracle(shape):
     try:
         for band_rows in (0, 5):
             abi.set_tuning(21, band_rows)
-            for pad in (0, 1, 3, 4):
+            for pad in (0, 1, 2, 3, 4):
                 for active in (0, 1):
                     gx_o, _ = O.backward(go, w, x, pad, active)
                     _, gw64 = O.backward(go.astype(np.float64), w.astype(np.float64), x.astype(np.float64), pad, active)
@@ -319,7 +315,7 @@ def test_tiled_backward_nchw_gradient_vs_oracle(shape):
             x16, go16, w16 = torch.from_numpy(x).to(tdt), torch.from_numpy(go).to(tdt), torch.from_numpy(w).to(tdt)
             xn, gn, wn = x16.float().numpy(), go16.float().numpy(), w16.float().numpy()
             eps = float(torch.finfo(tdt).eps)
-            for pad in (0, 1, 3, 4):
+            for pad in (0, 1, 2, 3, 4):
                 gx_o = torch.from_numpy(O.backward(gn, wn, xn, pad, 0)[0]).to(tdt)
                 _, gw64 = O.backward(gn.astype(np.float64), wn.astype(np.float64), xn.astype(np.float64), pad, 0)
                 gxd = torch.empty(shape, dtype=tdt, device=DEV).contiguous(memory_format=cl)
@@ -373,7 +369,7 @@ def test_tiled_channels_last_active_forward_vs_oracle(shape):
     try:
         for band_rows in (0, 5):
             abi.set_tuning(21, band_rows)
-            for pad in (0, 1, 3, 4):
+            for pad in (0, 1, 2, 3, 4):
                 ref = O.forward(x, w, pad, True)
                 out = abi.forward(xd, wd, pad, True)  # NCHW-contiguous output
                 assert abi.last_kernel() == "cl_tiled_active_forward" and out.is_contiguous()
@@ -410,7 +406,7 @@ def test_tiled_channels_last_16bit_active_and_backward(shape, tdt):
     try:
         for band_rows in (0, 7):
             abi.set_tuning(21, band_rows)
-            for pad in (0, 1, 3, 4):
+            for pad in (0, 1, 2, 3, 4):
                 ref = abi.forward(x, wd, pad, True)
                 # the oracle on the widened values, one rounding to the 16-bit type: the bar for every 16-bit kernel
                 ref_o = torch.from_numpy(O.forward(xn, wn, pad, True)).to(tdt)

@@ -79,3 +79,12 @@ for active in (0, 1):
     t4 = ev(lambda: abi.backward(g, w, abi.to_contiguous(xc), 0, active, grad_x=gx, grad_w=gw, workspace=ws))
     print("fp32 active=%d bwd  NCHW %.3f ms (%s)   all NHWC %.3f ms (%s)   NHWC x + NCHW grad %.3f ms (%s, %.0f GB/s)   transpose + NCHW %.3f ms"
           % (active, t1, k1, t2, k2, t3, k3, 12 * x.numel() / t3 / 1e6, t4))
+# periodic padding through the tiled kernels (edge pixels / rows by the element pass) against the channel-fastest kernels
+for active in (0, 1):
+    t1 = ev(lambda: abi.forward(xc, w, 2, active, out=ocl)); k1 = abi.last_kernel()
+    t2 = ev(lambda: abi.backward(gc, w, xc, 2, active, grad_x=gxc, grad_w=gw, workspace=ws)); k2 = abi.last_kernel()
+    abi.set_tuning(20, 0)
+    t3 = ev(lambda: abi.forward(xc, w, 2, active, out=ocl)); k3 = abi.last_kernel()
+    t4 = ev(lambda: abi.backward(gc, w, xc, 2, active, grad_x=gxc, grad_w=gw, workspace=ws)); k4 = abi.last_kernel()
+    abi.set_tuning(20, 1)
+    print("fp32 periodic active=%d  fwd %.3f ms (%s) vs %.3f ms (%s)   bwd %.3f ms (%s) vs %.3f ms (%s)" % (active, t1, k1, t3, k3, t2, k2, t4, k4))

@@ -107,6 +107,11 @@ int forward_common(const shiftnd_problem *p, const void *x, const int64_t *xs, c
             return finish(band_gather_forward(g, p->dtype, x, w, wkind, wzp, fill, out, st));
         }
         // 2-D sparse shift of 4- / 8-byte elements on planes of >= 32 KiB: the linear sweep of one-step workgroups
+        // 3-D interpolating forward: a walk through the planes (one new plane per step, the other carried in registers)
+        if (g_policy == 0 && wkind <= SHIFTND_BF16 && walk_forward_eligible(g, p->dtype, x, out)) {
+            g_last_path = SHIFTND_PATH_PLANE;
+            return finish(walk_forward(g, p->dtype, x, w, wkind, out, st));
+        }
         if (g_policy == 0 && wkind <= SHIFTND_BF16 && step_forward_lds_eligible(g, p->dtype, x, out)) {
             g_last_path = SHIFTND_PATH_PLANE;  // (LDS-staged, like the per-channel kernels it supersedes)
             return finish(step_forward_lds(g, p->dtype, x, w, wkind, fill, out, st));

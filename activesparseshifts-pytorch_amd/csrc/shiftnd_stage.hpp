@@ -80,5 +80,29 @@ __device__ __forceinline__ void lds_read_row(const char *row, bool valid, const 
     }
 }
 
+// The six dwords of a staged row starting at dword (byte0 >> 2), read as the two aligned 16-byte spans that hold them.
+// Five or six ds_read_b32 at a lane stride of 16 bytes (neighbouring chunks) are 4- to 8-way bank conflicts -- half of the
+// LDS time of the 16-bit one-step kernels (SQ_LDS_BANK_CONFLICT); two ds_read_b128 at 16-byte aligned addresses are
+// conflict-free.  Which dword of the span the window starts with is `ph >> 2` with ph = byte0 & 15, the same for every
+// thread of a workgroup whose chunks share one column shift (row bytes are a multiple of 16): a uniform switch into
+// compile-time register naming.  `row` is 16-byte aligned; the tile's 64-byte pads take the spans of the edge chunks.
+template <int RR> __device__ __forceinline__ void lds_span_pick(const uint32_t (&d)[8], uint32_t (&o)[6]) {
+#pragma unroll
+    for (int i = 0; i < 6; ++i) o[i] = RR + i < 8 ? d[RR + i < 8 ? RR + i : 7] : 0u;
+}
+__device__ __forceinline__ void lds_window6(const char *row, int byte0, int ph, uint32_t (&o)[6]) {
+    typedef uint32_t u4 __attribute__((ext_vector_type(4)));
+    const char *p = row + (byte0 & ~15);
+    const u4 q0 = *reinterpret_cast<const u4 *>(__builtin_assume_aligned(p, 16));
+    const u4 q1 = *reinterpret_cast<const u4 *>(__builtin_assume_aligned(p + 16, 16));
+    const uint32_t d[8] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w};
+    switch (ph >> 2) {
+    case 0: lds_span_pick<0>(d, o); break;
+    case 1: lds_span_pick<1>(d, o); break;
+    case 2: lds_span_pick<2>(d, o); break;
+    default: lds_span_pick<3>(d, o); break;
+    }
+}
+
 }  // namespace
 }  // namespace shiftnd

@@ -1035,6 +1035,503 @@ __global__ __launch_bounds__(kThreads) void step_forward_lds(const FwdParams p) 
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// walk_forward: the 3-D interpolating forward as a walk along dim0.  step_forward_lds<T, 3> reads, masks and widens four
+// corner rows per output row (C3, bf16: 220 vector instructions per 8-element chunk, 82 % VALU-busy at 3.8 TB/s); the
+// sliding-window kernel (shiftnd_slide.hip) carries half of them in registers but walks down the ROWS of 16 planes at
+// once: 224-byte pieces 25 KB apart, 1024 long workgroups.  Here a workgroup owns R consecutive rows (a contiguous
+// R x row-bytes run of every plane) of one (n, c) volume and walks through its planes a = 0 .. O0 - 1: source plane
+// map(a + 1) of step a IS source plane map(a) of step a + 1 -- for every padding, the map is the same expression -- so
+// the two corner rows of the "+1" plane stay in registers (widened) and become the "+0" plane's rows of the next step.
+// Per step: ONE plane's R + 1 rows staged (global_load_lds, every thread its own piece: the row and column maps of a
+// thread never change along the walk), two row windows read and widened instead of four, the blends nested as the
+// reference nests them (plane, row, inner: interpolation.h:34-40; same bits as interp_nd).  Contiguous 3-D tensors
+// without crop; every float dtype.
+// ---------------------------------------------------------------------------------------------------------------------
+template <typename T, int PAD>
+__global__ __launch_bounds__(kThreads) void walk_forward(const FwdParams p) {
+    using S = typename T::S;
+    using CT = typename T::C;
+    constexpr int E = 16 / sizeof(S);
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char *tile = smem + 64;  // 64-byte pads in front and behind: see lds_read_row
+
+    const uint32_t bid = (blockIdx.x & 7u) * p.steps_per_xcd + (blockIdx.x >> 3);
+    if (bid >= p.total_steps) return;
+    const uint32_t plane = fdiv(bid, p.d_spp);
+    const int step = static_cast<int>(bid - plane * static_cast<uint32_t>(p.spp));
+    const int c = static_cast<int>(plane - fdiv(plane, p.d_C) * static_cast<uint32_t>(p.C));
+    CT wv[3];
+    load_weights_nd<CT>(p.w, p.wkind, c, p.nd, wv);
+    CT rr[3], dn[3];
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+        rr[d] = c_floor<CT>(wv[d]);
+        dn[d] = wv[d] - rr[d];
+    }
+    const int cs0 = __builtin_amdgcn_readfirstlane(canon_of<PAD, CT>(rr[0], p.S0, p.d_per0));
+    const int cs1 = __builtin_amdgcn_readfirstlane(canon_of<PAD, CT>(rr[1], p.S1, p.d_per1));
+    const int cs2 = __builtin_amdgcn_readfirstlane(canon_of<PAD, CT>(rr[2], p.S2, p.d_per2));
+    const CT dw[3] = {dn[0], dn[1], dn[2]};
+
+    const int R = p.R, S0 = p.S0, S1 = p.S1, S2 = p.S2, cpr = p.cpr;
+    const int b0 = step * R;
+    const int Rn = min(R, p.O1 - b0);
+    const char *xp = reinterpret_cast<const char *>(static_cast<const S *>(p.x) + static_cast<int64_t>(plane) * p.x_plane);
+    S *op = static_cast<S *>(p.out) + static_cast<int64_t>(plane) * p.o_plane;
+
+    const int tid = static_cast<int>(threadIdx.x);
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tr = static_cast<int>(fdiv(static_cast<uint32_t>(tid), p.d_cpr)), tc = tid - tr * cpr;
+    // the pieces this thread stages, the same for every plane: piece tc of its own row (rows 0 .. Rn: the + 1 corner row of
+    // a ragged last step is somebody's own row) and, in a full step, piece tid of row R
+    const int src_own = (tr < R && tr <= Rn) ? row_map_t<PAD>(b0 + tr, cs1, S1) : -1;
+    const int src_extra = (Rn == R && tid < cpr) ? row_map_t<PAD>(b0 + R, cs1, S1) : -1;
+    const uint32_t off_own = static_cast<uint32_t>(max(src_own, 0) * S2 + tc * E) * static_cast<uint32_t>(sizeof(S));
+    const uint32_t off_extra = static_cast<uint32_t>(max(src_extra, 0) * S2 + tid * E) * static_cast<uint32_t>(sizeof(S));
+    const uint32_t plane_bytes = static_cast<uint32_t>(S1) * static_cast<uint32_t>(S2) * static_cast<uint32_t>(sizeof(S));
+    auto stage = [&](int pa) {   // source plane pa (uniform) -> the tile
+        if (pa < 0) return;
+        const char *base = xp + static_cast<size_t>(pa) * plane_bytes;
+        if (src_own >= 0)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(base + off_own),
+                                             (__attribute__((address_space(3))) void *)(tile + wave * 64 * 16), 16, 0, 2 /* nt */);
+        if (src_extra >= 0)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(base + off_extra),
+                                             (__attribute__((address_space(3))) void *)(tile + (R * cpr + wave * 64) * 16), 16, 0, 2);
+    };
+    const int jo = tc * E;
+    ColState<E> xm;
+    if constexpr (PAD == 0) {
+        const int base = jo - cs2;
+        xm.base = (base + E < 0 || base >= S2) ? 0 : base;
+        xm.affine = true;
+#pragma unroll
+        for (int e = 0; e <= E; ++e) xm.cm[e] = (base + e >= 0 && base + e < S2) ? base + e : -1;
+    } else {
+        xm = fold_colstate<E, PAD>(jo, cs2, S2);
+    }
+    const bool mine = tr < R && tr < Rn;   // this thread produces a chunk
+    const int b = b0 + tr;
+    bool rv[2];
+#pragma unroll
+    for (int hb = 0; hb < 2; ++hb) rv[hb] = PAD != 0 || row_map_t<PAD>(b + hb, cs1, S1) >= 0;
+    const int RBL = cpr * 16;  // bytes per staged row
+    const char *rows = tile + tr * RBL;
+
+    // plane map(0): the first step's "+0" rows
+    CT carried[2][E + 1];
+    {
+        const int pa0 = row_map_t<PAD>(0, cs0, S0);
+        stage(pa0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+#pragma unroll
+        for (int hb = 0; hb < 2; ++hb) {
+            S r0[E + 1];
+            lds_read_row<S, E>(rows + hb * RBL, mine && rv[hb] && pa0 >= 0, xm, r0);
+#pragma unroll
+            for (int e = 0; e <= E; ++e) carried[hb][e] = widen<T>(r0[e]);
+        }
+    }
+    const int64_t out_plane = static_cast<int64_t>(p.O1) * p.O2;
+    S *orow = op + static_cast<int64_t>(b) * p.O2 + jo;
+    for (int a = 0; a < p.O0; ++a) {
+        const int pa1 = row_map_t<PAD>(a + 1, cs0, S0);
+        __syncthreads();   // everybody has read the previous plane
+        stage(pa1);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        CT rowb[2][E + 1];
+#pragma unroll
+        for (int hb = 0; hb < 2; ++hb) {
+            S r1[E + 1];
+            lds_read_row<S, E>(rows + hb * RBL, mine && rv[hb] && pa1 >= 0, xm, r1);
+#pragma unroll
+            for (int e = 0; e <= E; ++e) {
+                const CT nv = widen<T>(r1[e]);
+                const CT two[2] = {carried[hb][e], nv};
+                rowb[hb][e] = interp_t<T, 1>(two, &dw[0]);
+                carried[hb][e] = nv;
+            }
+        }
+        CT colb[E + 1];
+#pragma unroll
+        for (int e = 0; e <= E; ++e) {
+            const CT two[2] = {rowb[0][e], rowb[1][e]};
+            colb[e] = interp_t<T, 1>(two, &dw[1]);
+        }
+        Chunk<S, E> res;
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+            const CT two[2] = {colb[e], colb[e + 1]};
+            res.e[e] = narrow<T>(interp_t<T, 1>(two, &dw[2]));
+        }
+        if (mine) store_chunk<S, E>(orow + a * out_plane, res);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// walk_backward: the 3-D interpolating backward as the same walk along dim0 (see walk_forward).  A workgroup owns R rows of
+// one (n, c) volume and walks through its planes; per step it stages ONE plane of the saved input and ONE of the incoming
+// gradient (R + 1 rows each: the "+1" corner planes map0(a + 1) of the two maps) and reads the thread's own gradient chunk
+// straight from memory; the "+0" corner planes are the previous step's "+1" planes, widened, in registers.  grad_x: the
+// blends nested as the reference nests them (plane, row, inner) -- 3 E + 3 instead of 7 E, same bits as interp_nd; the
+// weight gradient: the eight corner-difference sums of step_backward<T, 3>, accumulated over the walk (fp32 per step,
+// folded into fp64 every four planes), one record per workgroup for step_reduce.
+// ---------------------------------------------------------------------------------------------------------------------
+// acc + a.lo * b.lo + a.hi * b.hi on packed 16-bit pairs (v_dot2c_f32_bf16 / v_dot2c_f32_f16): the products of two 16-bit
+// values are exact in fp32 and nothing has to be widened first
+template <typename T> __device__ __forceinline__ float dot2_packed(uint32_t a, uint32_t b, float c) {
+    if constexpr (T::kDtype == SHIFTND_BF16) {
+        typedef __bf16 v2 __attribute__((ext_vector_type(2)));
+        return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(v2, a), __builtin_bit_cast(v2, b), c, false);
+    } else {
+        typedef _Float16 v2 __attribute__((ext_vector_type(2)));
+        return __builtin_amdgcn_fdot2(__builtin_bit_cast(v2, a), __builtin_bit_cast(v2, b), c, false);
+    }
+}
+
+template <typename T, int PAD>
+__global__ __launch_bounds__(kThreads) void walk_backward(const StepParams p) {
+    using S = typename T::S;
+    using CT = typename T::C;
+    constexpr int E = 16 / sizeof(S);
+    constexpr int REC = RecSize<E>::N;
+    constexpr int NDIFF = WDiff<3>::N;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char *tile = smem + 64;
+
+    const uint32_t bid = (blockIdx.x & 7u) * p.steps_per_xcd + (blockIdx.x >> 3);
+    if (bid >= p.total_steps) return;
+    const uint32_t plane = fdiv(bid, p.d_spp);   // (n, c)
+    const int step = static_cast<int>(bid - plane * static_cast<uint32_t>(p.spp));
+    const int c = static_cast<int>(plane - fdiv(plane, p.d_C) * static_cast<uint32_t>(p.C));
+    const ChanDesc d = p.desc[c];
+    const int R = p.R, S0 = p.S0, S1 = p.S1, S2 = p.S2, cpr = p.cpr;
+    const int b0 = step * R;
+    const int Rn = min(R, S1 - b0);
+    const int RB = S2 * static_cast<int>(sizeof(S));
+    const char *xp = reinterpret_cast<const char *>(static_cast<const S *>(p.x) + static_cast<int64_t>(plane) * p.x_plane);
+    const S *gp = static_cast<const S *>(p.go) + static_cast<int64_t>(plane) * p.x_plane;
+    S *gxp = static_cast<S *>(p.out) + static_cast<int64_t>(plane) * p.x_plane;
+
+    const int tid = static_cast<int>(threadIdx.x);
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tr = static_cast<int>(fdiv(static_cast<uint32_t>(tid), p.d_cpr)), tc = tid - tr * cpr;
+    const int ji = tc * E;
+    ColState<E> xm, gm;
+    if constexpr (PAD == 0) {
+        auto affine_state = [&](int cs) {
+            ColState<E> st;
+            st.base = ji - cs;
+            if (st.base + E < 0 || st.base >= S2) st.base = 0;
+            st.affine = true;
+#pragma unroll
+            for (int e = 0; e <= E; ++e) st.cm[e] = (ji - cs + e >= 0 && ji - cs + e < S2) ? ji - cs + e : -1;
+            return st;
+        };
+        xm = affine_state(d.cx2);
+        gm = affine_state(d.cg2);
+    } else {
+        const size_t rec = (static_cast<size_t>(c) * cpr + tc) * REC;
+        xm = load_colstate<E>(p.colx + rec);
+        gm = load_colstate<E>(p.colg + rec);
+    }
+    // the pieces this thread stages, the same for every plane (see walk_forward)
+    const bool own = tr < R && tr <= Rn, extra = Rn == R && tid < cpr;
+    const int sx_own = own ? row_map_t<PAD>(b0 + tr, d.cx1, S1) : -1, sg_own = own ? row_map_t<PAD>(b0 + tr, d.cg1, S1) : -1;
+    const int sx_extra = extra ? row_map_t<PAD>(b0 + R, d.cx1, S1) : -1, sg_extra = extra ? row_map_t<PAD>(b0 + R, d.cg1, S1) : -1;
+    auto piece_off = [&](int row, int piece) { return static_cast<uint32_t>(max(row, 0) * S2 + piece * E) * static_cast<uint32_t>(sizeof(S)); };
+    const uint32_t ox_own = piece_off(sx_own, tc), og_own = piece_off(sg_own, tc), ox_extra = piece_off(sx_extra, tid), og_extra = piece_off(sg_extra, tid);
+    const uint32_t plane_bytes = static_cast<uint32_t>(S1) * static_cast<uint32_t>(S2) * static_cast<uint32_t>(sizeof(S));
+    const int GP0 = (R + 1) * cpr;   // first LDS piece of the gradient group
+    // Staging goes global -> registers -> LDS, one plane ahead: the loads of plane a + 2 are in flight while step a is
+    // computed (an LDS-DMA in flight would make hipcc wait for it before the first LDS read of the compute phase).  Every
+    // memory instruction of the loop is unconditional -- a thread without a piece (or a plane that is fill) uses an
+    // out-of-range buffer offset / an empty resource, which loads zeros, and parks them in its private dump slot -- so the
+    // compiler's wait counts are exact.
+    typedef uint32_t u4 __attribute__((ext_vector_type(4)));
+    constexpr uint32_t kOOR = 0x80000000u;
+    constexpr int kRsrcFlags = 0x00020000;
+    const uint32_t vol_bytes = static_cast<uint32_t>(S0) * plane_bytes;   // < 2^31 (host)
+    const __amdgpu_buffer_rsrc_t xres = __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(xp), 0, vol_bytes, kRsrcFlags);
+    const __amdgpu_buffer_rsrc_t gres = __builtin_amdgcn_make_buffer_rsrc(const_cast<S *>(gp), 0, vol_bytes, kRsrcFlags);
+    const __amdgpu_buffer_rsrc_t ores = __builtin_amdgcn_make_buffer_rsrc(gxp, 0, vol_bytes, kRsrcFlags);
+    const __amdgpu_buffer_rsrc_t none = __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(xp), 0, 0, kRsrcFlags);
+    const uint32_t vx_own = sx_own >= 0 ? ox_own : kOOR, vg_own = sg_own >= 0 ? og_own : kOOR;
+    const uint32_t vx_extra = sx_extra >= 0 ? ox_extra : kOOR, vg_extra = sg_extra >= 0 ? og_extra : kOOR;
+    char *dump = tile + 2 * GP0 * 16 + tid * 16;
+    char *dx_own = own ? tile + tid * 16 : dump, *dx_extra = extra ? tile + (R * cpr + tid) * 16 : dump;
+    char *dg_own = own ? tile + (GP0 + tid) * 16 : dump, *dg_extra = extra ? tile + (GP0 + R * cpr + tid) * 16 : dump;
+    struct Staged { u4 xo, xe, go, ge; };
+    auto load_planes = [&](int pax, int pag, Staged &v) {   // source planes (uniform; -1: fill)
+        const uint32_t sx = pax >= 0 ? static_cast<uint32_t>(pax) * plane_bytes : 0u, sg = pag >= 0 ? static_cast<uint32_t>(pag) * plane_bytes : 0u;
+        v.xo = __builtin_amdgcn_raw_buffer_load_b128(pax >= 0 ? xres : none, vx_own, sx, 0);
+        v.go = __builtin_amdgcn_raw_buffer_load_b128(pag >= 0 ? gres : none, vg_own, sg, 0);
+        v.xe = __builtin_amdgcn_raw_buffer_load_b128(pax >= 0 ? xres : none, vx_extra, sx, 0);
+        v.ge = __builtin_amdgcn_raw_buffer_load_b128(pag >= 0 ? gres : none, vg_extra, sg, 0);
+    };
+    auto park = [&](const Staged &v) {
+        *reinterpret_cast<u4 *>(__builtin_assume_aligned(dx_own, 16)) = v.xo;
+        *reinterpret_cast<u4 *>(__builtin_assume_aligned(dg_own, 16)) = v.go;
+        *reinterpret_cast<u4 *>(__builtin_assume_aligned(dx_extra, 16)) = v.xe;
+        *reinterpret_cast<u4 *>(__builtin_assume_aligned(dg_extra, 16)) = v.ge;
+    };
+    const bool mine = tr < R && tr < Rn;
+    const int b = b0 + tr;
+    const char *rows_x = tile + tr * RB, *rows_g = tile + (R + 1 + tr) * RB;
+    const CT dw[3] = {static_cast<CT>(d.dw[0]), static_cast<CT>(d.dw[1]), static_cast<CT>(d.dw[2])};
+    // ---- window reads: two aligned 16-byte spans per row and a uniform phase (lds_window6) ------------------------------
+    // Fill rows and fill planes are zeros in the tile (empty resource / out-of-range offset), so only the columns are masked.
+    // Zeros padding: every chunk is affine (one whose window lies outside the row has all its columns masked: any dwords do);
+    // the other paddings: chunks whose map is not affine, or not at the workgroup's phase, read element by element.
+    constexpr int ES = static_cast<int>(sizeof(S));
+    if (!mine) {   // a thread without a chunk reads rows that are not its own: every column masked (0 * garbage is not 0)
+#pragma unroll
+        for (int e = 0; e <= E; ++e) xm.cm[e] = gm.cm[e] = -1;
+    }
+    const int phx = (-d.cx2 * ES) & 15, phg = (-d.cg2 * ES) & 15;
+    const bool fx = PAD == 0 || (xm.affine && ((xm.base * ES) & 15) == phx);
+    const bool fg = PAD == 0 || (gm.affine && ((gm.base * ES) & 15) == phg);
+    uint32_t xmask[5] = {0, 0, 0, 0, 0}, gmask[5] = {0, 0, 0, 0, 0};   // 16-bit data: per-dword column masks
+    if constexpr (ES == 2) {
+#pragma unroll
+        for (int i = 0; i < 5; ++i) {
+            const int hi = 2 * i + 1 <= E ? 2 * i + 1 : E;
+            xmask[i] = (xm.cm[2 * i] >= 0 ? 0xffffu : 0u) | ((2 * i + 1 <= E && xm.cm[hi] >= 0) ? 0xffff0000u : 0u);
+            gmask[i] = (gm.cm[2 * i] >= 0 ? 0xffffu : 0u) | ((2 * i + 1 <= E && gm.cm[hi] >= 0) ? 0xffff0000u : 0u);
+        }
+    }
+    auto window_packed = [&](const char *rowp, const ColState<E> &cst, bool fast, int ph, const uint32_t(&m)[5], uint32_t(&t)[5]) {
+        if (fast) {
+            uint32_t o[6];
+            lds_window6(rowp, cst.base * 2, ph, o);
+            if (ph & 2) {   // uniform
+#pragma unroll
+                for (int i = 0; i < 5; ++i) t[i] = __builtin_amdgcn_alignbit(o[i + 1], o[i], 16) & m[i];
+            } else {
+#pragma unroll
+                for (int i = 0; i < 5; ++i) t[i] = o[i] & m[i];
+            }
+        } else if constexpr (PAD != 0) {
+            const uint16_t *p0 = reinterpret_cast<const uint16_t *>(rowp);
+#pragma unroll
+            for (int i = 0; i < 5; ++i) {
+                const int hi = 2 * i + 1 <= E ? 2 * i + 1 : E;
+                const uint32_t lo = p0[cst.cm[2 * i] > 0 ? cst.cm[2 * i] : 0];
+                const uint32_t up = p0[cst.cm[hi] > 0 ? cst.cm[hi] : 0];
+                t[i] = (lo | (up << 16)) & m[i];
+            }
+        }
+    };
+    auto window = [&](const char *rowp, const ColState<E> &cst, bool fast, int ph, const uint32_t(&m)[5], S(&raw)[E + 1]) {
+        if constexpr (ES == 2) {
+            uint32_t t[5];
+            window_packed(rowp, cst, fast, ph, m, t);
+#pragma unroll
+            for (int e = 0; e <= E; ++e) {
+                const uint16_t h = static_cast<uint16_t>(e & 1 ? t[e >> 1] >> 16 : t[e >> 1]);
+                __builtin_memcpy(&raw[e], &h, 2);
+            }
+        } else {
+            S zero;
+            __builtin_memset(&zero, 0, sizeof(S));
+            if (fast) {
+                uint32_t o[6];
+                lds_window6(rowp, cst.base * ES, ph, o);
+#pragma unroll
+                for (int e = 0; e <= E; ++e) {
+                    if constexpr (ES == 4) {
+                        __builtin_memcpy(&raw[e], &o[e], 4);
+                    } else {
+                        const uint64_t q = static_cast<uint64_t>(o[2 * e]) | (static_cast<uint64_t>(o[2 * e + 1]) << 32);
+                        __builtin_memcpy(&raw[e], &q, 8);
+                    }
+                }
+            } else {
+                const S *p0 = reinterpret_cast<const S *>(rowp);
+#pragma unroll
+                for (int e = 0; e <= E; ++e) raw[e] = p0[cst.cm[e] > 0 ? cst.cm[e] : 0];
+            }
+#pragma unroll
+            for (int e = 0; e <= E; ++e) raw[e] = cst.cm[e] >= 0 ? raw[e] : zero;
+        }
+    };
+
+    // 16-bit data: the x corners never leave their packed form (the weight-gradient sums are v_dot2c products of packed pairs
+    // of x and of the incoming gradient: 48 instructions per chunk instead of 128 subtractions and multiply-adds plus the
+    // unpacking); cxm: per-dword masks of the window's columns
+    constexpr bool PACKED = sizeof(S) == 2;
+    constexpr int NS = PACKED ? 8 : NDIFF;   // running sums: per corner (packed) / per corner difference
+    uint32_t cxp[2][5];
+    CT cx[PACKED ? 1 : 2][PACKED ? 1 : E + 1], cg[2][E + 1];   // the "+0" planes' corner rows
+    {
+        const int pax0 = row_map_t<PAD>(0, d.cx0, S0), pag0 = row_map_t<PAD>(0, d.cg0, S0);
+        Staged v0;
+        load_planes(pax0, pag0, v0);
+        park(v0);
+        __syncthreads();
+#pragma unroll
+        for (int hb = 0; hb < 2; ++hb) {
+            S rg[E + 1];
+            window(rows_g + hb * RB, gm, fg, phg, gmask, rg);
+#pragma unroll
+            for (int e = 0; e <= E; ++e) cg[hb][e] = widen<T>(rg[e]);
+            if constexpr (PACKED) {
+                window_packed(rows_x + hb * RB, xm, fx, phx, xmask, cxp[hb]);
+            } else {
+                S rx[E + 1];
+                window(rows_x + hb * RB, xm, fx, phx, xmask, rx);
+#pragma unroll
+                for (int e = 0; e <= E; ++e) cx[hb][e] = widen<T>(rx[e]);
+            }
+        }
+    }
+    // running sums: fp32 per step, folded every four planes into this thread's fp64 slots in LDS (registers are what limits
+    // the number of resident workgroups here)
+    double *accs = reinterpret_cast<double *>(tile + 2 * GP0 * 16 + kThreads * 16) + tid;   // [NS][kThreads]
+    CT part[NS];
+#pragma unroll
+    for (int i = 0; i < NS; ++i) {
+        accs[i * kThreads] = 0.0;
+        part[i] = CT(0);
+    }
+    const uint32_t my = mine ? static_cast<uint32_t>(b * S2 + ji) * static_cast<uint32_t>(sizeof(S)) : kOOR;   // own chunk, bytes within a plane
+    __syncthreads();   // the "+0" planes have been read
+    Staged pend;       // plane a + 1 of the step about to run
+    load_planes(row_map_t<PAD>(1, d.cx0, S0), row_map_t<PAD>(1, d.cg0, S0), pend);
+    u4 gcur = __builtin_amdgcn_raw_buffer_load_b128(gres, my, 0u, 0);   // the incoming gradient at the thread's own chunk
+    for (int a = 0; a < S0; ++a) {
+        park(pend);
+        __syncthreads();
+        // plane a + 2, in flight while this step is computed (the last step has none: empty resources; a buffer's range
+        // check does not see the scalar offset)
+        const bool more = a + 1 < S0;
+        load_planes(more ? row_map_t<PAD>(a + 2, d.cx0, S0) : -1, more ? row_map_t<PAD>(a + 2, d.cg0, S0) : -1, pend);
+        Chunk<S, E> gch;
+        __builtin_memcpy(gch.e, &gcur, 16);
+        // ---- weight-gradient sums: corners of x (plane bit 0, row bit 1, column bit 2: step_backward's order) ------------
+        if constexpr (PACKED) {
+            uint32_t gq[4], nxp[2][5];
+            __builtin_memcpy(gq, gch.e, 16);
+#pragma unroll
+            for (int hb = 0; hb < 2; ++hb) {
+                window_packed(rows_x + hb * RB, xm, fx, phx, xmask, nxp[hb]);
+#pragma unroll
+                for (int pl = 0; pl < 2; ++pl) {
+                    const uint32_t(&wv)[5] = pl ? nxp[hb] : cxp[hb];
+                    const int q0 = pl | (hb << 1), q1 = q0 | 4;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        part[q0] = dot2_packed<T>(gq[i], wv[i], part[q0]);
+                        part[q1] = dot2_packed<T>(gq[i], __builtin_amdgcn_alignbit(wv[i + 1], wv[i], 16), part[q1]);
+                    }
+                }
+            }
+#pragma unroll
+            for (int hb = 0; hb < 2; ++hb)
+#pragma unroll
+                for (int i = 0; i < 5; ++i) cxp[hb][i] = nxp[hb][i];
+        } else {
+            CT nx[2][E + 1];
+#pragma unroll
+            for (int hb = 0; hb < 2; ++hb) {
+                S rx[E + 1];
+                window(rows_x + hb * RB, xm, fx, phx, xmask, rx);
+#pragma unroll
+                for (int e = 0; e <= E; ++e) nx[hb][e] = widen<T>(rx[e]);
+            }
+#pragma unroll
+            for (int e = 0; e < E; ++e) {
+                CT v[8], df[NDIFF];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    const int hb = (q >> 1) & 1, col = e + (q >> 2);
+                    v[q] = (q & 1) ? nx[hb][col] : cx[hb][col];
+                }
+                corner_diffs<3, CT>(v, df);
+                const CT gval = widen<T>(gch.e[e]);
+#pragma unroll
+                for (int i = 0; i < NDIFF; ++i) part[i] = fma_ct(gval, df[i], part[i]);
+            }
+#pragma unroll
+            for (int hb = 0; hb < 2; ++hb)
+#pragma unroll
+                for (int e = 0; e <= E; ++e) cx[hb][e] = nx[hb][e];
+        }
+        // the next step's own chunk: in flight through the blends below and the next step's staging
+        gcur = __builtin_amdgcn_raw_buffer_load_b128(a + 1 < S0 ? gres : none, my, static_cast<uint32_t>(a + 1) * plane_bytes, 0);
+        // ---- grad_x ------------------------------------------------------------------------------------------------
+        CT rowb[2][E + 1];
+#pragma unroll
+        for (int hb = 0; hb < 2; ++hb) {
+            S rg[E + 1];
+            window(rows_g + hb * RB, gm, fg, phg, gmask, rg);
+#pragma unroll
+            for (int e = 0; e <= E; ++e) {
+                const CT nv = widen<T>(rg[e]);
+                const CT two[2] = {cg[hb][e], nv};
+                rowb[hb][e] = interp_t<T, 1>(two, &dw[0]);
+                cg[hb][e] = nv;
+            }
+        }
+        Chunk<S, E> res;
+        {
+            CT colb[E + 1];
+#pragma unroll
+            for (int e = 0; e <= E; ++e) {
+                const CT two[2] = {rowb[0][e], rowb[1][e]};
+                colb[e] = interp_t<T, 1>(two, &dw[1]);
+            }
+#pragma unroll
+            for (int e = 0; e < E; ++e) {
+                const CT two[2] = {colb[e], colb[e + 1]};
+                res.e[e] = narrow<T>(interp_t<T, 1>(two, &dw[2]));
+            }
+        }
+        {
+            u4 bits;
+            __builtin_memcpy(&bits, res.e, 16);
+            __builtin_amdgcn_raw_buffer_store_b128(bits, ores, my, static_cast<uint32_t>(a) * plane_bytes, 0);
+        }
+        if ((a & 3) == 3 || a == S0 - 1) {
+#pragma unroll
+            for (int i = 0; i < NS; ++i) {
+                accs[i * kThreads] += static_cast<double>(part[i]);
+                part[i] = CT(0);
+            }
+        }
+        __syncthreads();   // everybody has read this step's planes
+    }
+    double acc[NS];
+#pragma unroll
+    for (int i = 0; i < NS; ++i) acc[i] = accs[i * kThreads];
+    if constexpr (PACKED) {  // per-corner sums -> the corner-difference sums (corner_diffs is linear)
+        double v[8], df[NDIFF];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) v[q] = acc[q];
+        corner_diffs<3, double>(v, df);
+#pragma unroll
+        for (int i = 0; i < NDIFF; ++i) acc[i] = df[i];
+    }
+    // ---- the workgroup's sums: shuffle tree per wave, the four waves added by one thread ----------------------------------
+    __syncthreads();
+    double *scratch = reinterpret_cast<double *>(tile);   // the tile is dead
+#pragma unroll
+    for (int i = 0; i < NDIFF; ++i) {
+        const double t = wave_total(acc[i]);
+        if ((tid & 63) == 63) scratch[NDIFF * wave + i] = t;
+    }
+    __syncthreads();
+    if (tid < NDIFF) {
+        double sum = 0.0;
+#pragma unroll
+        for (int w = 0; w < kThreads / 64; ++w) sum += scratch[NDIFF * w + tid];
+        p.partials[static_cast<size_t>(bid) * NDIFF + tid] = sum;
+    }
+}
+
 // grad_w[c][0..nd-1] = blend(sum over the steps of channel c, in a fixed order)
 template <typename T, int ND>
 __global__ __launch_bounds__(kThreads) void step_reduce(const StepParams p, typename T::S *__restrict__ grad_w) {
@@ -1159,6 +1656,7 @@ void step_set_tuning(int knob, int value) {
 
 // contiguous 2-D / 3-D problems without crop whose rows are whole 16-byte pieces and at most one workgroup pass wide
 static bool step_backward_core(const Geometry &g, int dtype, const void *go, const void *x, const void *gx);
+bool walk_backward_eligible(const Geometry &g, int dtype, const void *go, const void *x, const void *gx);
 
 bool step_backward_eligible(const Geometry &g, int dtype, const void *go, const void *x, const void *gx) {
     return g.K[0] <= 0 && step_backward_core(g, dtype, go, x, gx);
@@ -1193,7 +1691,8 @@ static bool step_backward_core(const Geometry &g, int dtype, const void *go, con
     if (L.total_steps + 8 >= (1ull << 31)) return false;
     if (step_lds_bytes(L, g.nd, g.active != 0) > 64 * 1024) return false;
     if (g_step_tune[0] == 2) return true;
-    return g.nd == 2 || (g_step_tune[3] & 1);  // 3-D: knob 35 bit 0
+    // 3-D: the walk through the planes where it serves (16-bit interpolating), else knob 35 bit 0
+    return g.nd == 2 || (g_step_tune[3] & 1) || (g.K[0] <= 0 && walk_backward_eligible(g, dtype, go, x, gx));
 }
 
 // sparse-shift / quantized forward of 4- and 8-byte elements: dense tensors, output rows of whole 16-byte chunks and at
@@ -1399,6 +1898,114 @@ int step_forward_lds(const Geometry &g, int dtype, const void *x, const void *w,
     return SHIFTND_OK;
 }
 
+// the 3-D interpolating forward as a walk through the planes: contiguous, no crop, rows of whole 16-byte pieces and at most
+// one workgroup pass wide
+bool walk_forward_eligible(const Geometry &g, int dtype, const void *x, const void *out) {
+    if (g_step_tune[2] == 1 || (g_step_tune[3] & 16)) return false;   // knob 34 = 1: no forwards through LDS; knob 35 bit 4: no walk
+    if (dtype > SHIFTND_BF16 || g.nd != 3 || !g.active) return false;
+    const int es = dtype_size(dtype);
+    for (int d = 0; d < 3; ++d)
+        if (g.L[d] != 0 || g.O[d] != g.S[d]) return false;
+    const int64_t xe = g.S[0] * g.S[1] * g.S[2];
+    if (xe < 1 || xe >= (1LL << 30) || g.S[2] > 32000 || g.S[0] < 2) return false;
+    if ((g.S[2] * es) % 16 != 0 || g.S[2] * es / 16 > kThreads) return false;
+    if (reinterpret_cast<uintptr_t>(x) % 16 != 0 || reinterpret_cast<uintptr_t>(out) % 16 != 0) return false;
+    if (!dense(g.xs, g.N, g.C, g.S) || !dense(g.os, g.N, g.C, g.O)) return false;
+    const int64_t cpr = g.S[2] * es / 16;
+    const int64_t rmax = std::min<int64_t>(kThreads / cpr, g.S[1]);
+    if (64 + (rmax + 1) * cpr * 16 + 64 > 64 * 1024) return false;
+    const int64_t spp = (g.S[1] + rmax - 1) / rmax;
+    if (g.N * g.C * spp + 8 >= (1LL << 31)) return false;
+    // 16-bit data (C3: 0.179 -> 0.154 ms); 4- / 8-byte elements are as fast on step_forward_lds (N8 C128 16x112x112 fp32: 0.285
+    // vs 0.301 ms) unless asked for (knob 35 bit 5)
+    return es == 2 || (g_step_tune[3] & 32);
+}
+
+int walk_forward(const Geometry &g, int dtype, const void *x, const void *w, int wkind, void *out, hipStream_t st) {
+    const int es = dtype_size(dtype);
+    FwdParams p{};
+    p.x = x;
+    p.out = out;
+    p.w = w;
+    p.wkind = wkind;
+    p.C = static_cast<int>(g.C);
+    p.nd = g.nd;
+    p.S0 = p.O0 = static_cast<int>(g.S[0]);
+    p.S1 = p.O1 = static_cast<int>(g.S[1]);
+    p.S2 = p.O2 = static_cast<int>(g.S[2]);
+    p.x_plane = p.o_plane = g.S[0] * g.S[1] * g.S[2];
+    p.cpr = p.xppr = static_cast<int>(g.S[2] * es / 16);
+    const int rmax = std::min<int>(kThreads / p.cpr, p.S1);
+    p.spp = (p.S1 + rmax - 1) / rmax;
+    p.R = (p.S1 + p.spp - 1) / p.spp;   // balanced steps: 112 rows of 14 pieces -> 7 steps of 16 rows, not 6 of 18 and one of 4
+    p.spv = p.spp;
+    const uint64_t total = static_cast<uint64_t>(g.N) * g.C * p.spp;
+    p.total_steps = static_cast<uint32_t>(total);
+    p.steps_per_xcd = static_cast<uint32_t>((total + 7) / 8);
+    p.d_spp = make_fastdiv(static_cast<uint32_t>(p.spp));
+    p.d_spv = p.d_spp;
+    p.d_C = make_fastdiv(static_cast<uint32_t>(p.C));
+    p.d_cpr = make_fastdiv(static_cast<uint32_t>(p.cpr));
+    p.d_xppr = p.d_cpr;
+    p.d_per0 = make_fastdiv(static_cast<uint32_t>(map_period(p.S0, g.pad)));
+    p.d_per1 = make_fastdiv(static_cast<uint32_t>(map_period(p.S1, g.pad)));
+    p.d_per2 = make_fastdiv(static_cast<uint32_t>(map_period(p.S2, g.pad)));
+    const size_t lds = 64 + static_cast<size_t>(p.R + 1) * p.cpr * 16 + 64;
+    const dim3 grid(p.steps_per_xcd * 8), block(kThreads);
+    note_kernel("walk_forward");
+#define SHIFTND_WALK_FWD(T) \
+    switch (g.pad) { \
+    case 0: hipLaunchKernelGGL((walk_forward<T, 0>), grid, block, lds, st, p); break; \
+    case 1: hipLaunchKernelGGL((walk_forward<T, 1>), grid, block, lds, st, p); break; \
+    case 2: hipLaunchKernelGGL((walk_forward<T, 2>), grid, block, lds, st, p); break; \
+    case 3: hipLaunchKernelGGL((walk_forward<T, 3>), grid, block, lds, st, p); break; \
+    default: hipLaunchKernelGGL((walk_forward<T, 4>), grid, block, lds, st, p); break; \
+    }
+    switch (dtype) {
+    case SHIFTND_F32: SHIFTND_WALK_FWD(f32_t) break;
+    case SHIFTND_F64: SHIFTND_WALK_FWD(f64_t) break;
+    case SHIFTND_F16: SHIFTND_WALK_FWD(f16_t) break;
+    default: SHIFTND_WALK_FWD(bf16_t) break;
+    }
+#undef SHIFTND_WALK_FWD
+    return SHIFTND_OK;
+}
+
+// the 3-D interpolating backward as a walk through the planes (walk_backward): what step_backward takes, 3-D, >= 2 planes.
+// Automatic for 2- and 4-byte elements; knob 35 bit 5 (32): fp64 too; bit 4 (16): never; bit 0: the one-step form instead.
+bool walk_backward_eligible(const Geometry &g, int dtype, const void *go, const void *x, const void *gx) {
+    if (g_step_tune[0] == 1 || (g_step_tune[3] & 16) || (g_step_tune[3] & 1)) return false;   // (bit 0: the one-step 3-D form)
+    if (dtype > SHIFTND_BF16 || g.nd != 3 || !g.active || g.K[0] > 0 || g.S[0] < 2) return false;
+    const int es = dtype_size(dtype);
+    for (int d = 0; d < 3; ++d)
+        if (g.O[d] != g.S[d] || g.L[d] != 0) return false;
+    if (g.S[1] < 1 || (g.S[2] * es) % 16 != 0 || g.S[2] * es / 16 > kThreads || g.S[2] > 32000) return false;
+    if (g.S[0] * g.S[1] * g.S[2] >= (1LL << 30)) return false;
+    if (!dense(g.xs, g.N, g.C, g.S) || !dense(g.os, g.N, g.C, g.O) || !dense(g.gs, g.N, g.C, g.S)) return false;
+    if (reinterpret_cast<uintptr_t>(go) % 16 || reinterpret_cast<uintptr_t>(x) % 16 || reinterpret_cast<uintptr_t>(gx) % 16) return false;
+    const StepLayout L = step_layout(g, es);
+    if (L.total_steps + 8 >= (1ull << 31)) return false;
+    const int64_t rmax = std::min<int64_t>(kThreads / L.cpr, g.S[1]);
+    if (64 + 2 * (rmax + 1) * L.cpr * 16 + kThreads * 16 + kThreads * 64 + 64 > 64 * 1024) return false;
+    if (g.S[0] * g.S[1] * g.S[2] * es >= (1LL << 31)) return false;   // (one buffer resource spans an (n, c) volume)
+    // same box, N8 C128 16x112x112: bf16 0.283 (slide_backward) -> 0.263 ms, fp32 0.524 -> 0.486 ms; fp64 on request (bit 5)
+    return es <= 4 || (g_step_tune[3] & 32);
+}
+
+template <typename T> static void launch_walk_backward(StepParams &p, size_t lds, void *gw, hipStream_t st) {
+    using S = typename T::S;
+    const dim3 grid(p.steps_per_xcd * 8), block(kThreads);
+    hipLaunchKernelGGL((step_prep<T, true>), dim3(p.C), block, 0, st, p);
+    switch (p.pad) {
+    case 0: hipLaunchKernelGGL((walk_backward<T, 0>), grid, block, lds, st, p); break;
+    case 1: hipLaunchKernelGGL((walk_backward<T, 1>), grid, block, lds, st, p); break;
+    case 2: hipLaunchKernelGGL((walk_backward<T, 2>), grid, block, lds, st, p); break;
+    case 3: hipLaunchKernelGGL((walk_backward<T, 3>), grid, block, lds, st, p); break;
+    default: hipLaunchKernelGGL((walk_backward<T, 4>), grid, block, lds, st, p); break;
+    }
+    hipLaunchKernelGGL((step_reduce<T, 3>), dim3(p.C), block, 0, st, p, static_cast<S *>(gw));
+}
+
 size_t step_backward_workspace(const Geometry &g, int dtype) {
     if (dtype > SHIFTND_BF16 || (g.nd != 2 && g.nd != 3)) return 0;
     return step_layout(g, dtype_size(dtype)).bytes;
@@ -1448,6 +2055,27 @@ int step_backward(const Geometry &g, int dtype, const void *go, const void *x, c
         p.g_plane = g.P[1] * g.P[2];
         p.d_k1 = make_fastdiv(static_cast<uint32_t>(p.K1));
         p.d_k2 = make_fastdiv(static_cast<uint32_t>(p.K2));
+    }
+    if (walk_backward_eligible(g, dtype, go, x, gx)) {
+        // the walk through the planes: balanced row steps, one record of sums per workgroup
+        const int rmax = std::min<int>(kThreads / L.cpr, p.S1);
+        p.spp = (p.S1 + rmax - 1) / rmax;
+        p.R = (p.S1 + p.spp - 1) / p.spp;
+        p.spv = p.spp;
+        const uint64_t total = static_cast<uint64_t>(g.N) * g.C * p.spp;
+        p.total_steps = static_cast<uint32_t>(total);
+        p.steps_per_xcd = static_cast<uint32_t>((total + 7) / 8);
+        p.d_spp = make_fastdiv(static_cast<uint32_t>(p.spp));
+        p.d_spv = p.d_spp;
+        const size_t lds = 64 + static_cast<size_t>(2 * (p.R + 1)) * L.cpr * 16 + kThreads * 16 + kThreads * 8 * sizeof(double) + 64;   // tile, dump slots, sums, pad
+        note_kernel("walk_backward");
+        switch (dtype) {
+        case SHIFTND_F32: launch_walk_backward<f32_t>(p, lds, gw, st); break;
+        case SHIFTND_F64: launch_walk_backward<f64_t>(p, lds, gw, st); break;
+        case SHIFTND_F16: launch_walk_backward<f16_t>(p, lds, gw, st); break;
+        default: launch_walk_backward<bf16_t>(p, lds, gw, st); break;
+        }
+        return SHIFTND_OK;
     }
     note_kernel(g.K[0] > 0 ? "step_backward_pool" : "step_backward");
     const bool active = g.active != 0;

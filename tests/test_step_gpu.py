@@ -26,7 +26,7 @@ def abi():
     A.set_tuning(33, 2)
     A.set_tuning(34, 2)
     yield A
-    for k in (32, 33, 34):
+    for k in (32, 33, 34, 35):
         A.set_tuning(k, 0)
 
 
@@ -41,6 +41,7 @@ def test_fp32_vs_oracle(abi, shape):
     go = rs.uniform(-1, 1, size=shape).astype(np.float32)
     w = _weights(rs, shape[1], 2, shape[2:]).astype(np.float32)
     xd, wd, god = (torch.from_numpy(a).to(DEV) for a in (x, w, go))
+    abi.set_tuning(35, 16)  # (not the walk through the planes: test_3d_walk_backward_vs_oracle)
     for pad in range(5):
         for active in (0, 1):
             gx, gw = abi.backward(god, wd, xd, pad, active)
@@ -60,6 +61,7 @@ def test_fp64_vs_oracle(abi, shape):
     go = rs.uniform(-1, 1, size=shape)
     w = _weights(rs, shape[1], 2, shape[2:]).astype(np.float64)
     xd, wd, god = (torch.from_numpy(a).to(DEV) for a in (x, w, go))
+    abi.set_tuning(35, 16)  # (not the walk through the planes: test_3d_walk_backward_vs_oracle)
     for pad in range(5):
         for active in (0, 1):
             gx, gw = abi.backward(god, wd, xd, pad, active)
@@ -78,6 +80,7 @@ def test_16bit_vs_oracle(abi, shape, tdt):
     w16 = torch.from_numpy(_weights(rs, shape[1], 2, shape[2:]).astype(np.float32)).to(tdt)
     x, w, go = x16.float().numpy(), w16.float().numpy(), go16.float().numpy()
     xd, wd, god = x16.to(DEV), w16.to(DEV), go16.to(DEV)
+    abi.set_tuning(35, 16)  # (not the walk through the planes)
     for pad in range(5):
         for active in (0, 1):
             gx, gw = abi.backward(god, wd, xd, pad, active)
@@ -243,6 +246,7 @@ def test_3d_backward_vs_oracle(abi, shape, dt):
     go = rs.uniform(-1, 1, size=shape).astype(npdt)
     w = _weights(rs, shape[1], 3, shape[2:]).astype(npdt)
     xd, wd, god = (torch.from_numpy(a).to(DEV) for a in (x, w, go))
+    abi.set_tuning(35, 16)  # (not the walk through the planes: test_3d_walk_backward_vs_oracle)
     for pad in range(5):
         for active in (0, 1):
             gx, gw = abi.backward(god, wd, xd, pad, active)
@@ -262,6 +266,7 @@ def test_3d_backward_16bit_vs_oracle(abi, shape, tdt):
     w16 = torch.from_numpy(_weights(rs, shape[1], 3, shape[2:]).astype(np.float32)).to(tdt)
     x, w, go = x16.float().numpy(), w16.float().numpy(), go16.float().numpy()
     xd, wd, god = x16.to(DEV), w16.to(DEV), go16.to(DEV)
+    abi.set_tuning(35, 16)  # (not the walk through the planes)
     for pad in range(5):
         for active in (0, 1):
             gx, gw = abi.backward(god, wd, xd, pad, active)
@@ -325,6 +330,7 @@ def test_3d_forwards_through_lds_vs_oracle(abi, shape, crop, dt):
     wide = np.float64 if tdt == torch.float64 else np.float32
     x, w = xt.to(torch.float64).numpy().astype(wide), wt.to(torch.float64).numpy().astype(wide)
     xd, wd = xt.to(DEV), wt.to(DEV)
+    abi.set_tuning(35, 16)  # (not the walk through the planes: test_3d_walk_forward_vs_oracle)
     for groups in (2, 3):
         abi.set_tuning(34, groups)
         for pad in range(5):
@@ -340,3 +346,66 @@ def test_3d_forwards_through_lds_vs_oracle(abi, shape, crop, dt):
                 assert abi.last_kernel() == "step_gather_forward_lds", (shape, abi.last_kernel())
                 assert torch.equal(out.cpu(), torch.from_numpy(O.forward(x, w, pad, 0, b)).to(tdt)), ("ssl", shape, crop, pad)
     abi.set_tuning(34, 2)
+
+
+@pytest.mark.parametrize("dt", ["f32", "f64", "f16", "bf16"])
+@pytest.mark.parametrize("shape", [(2, 3, 5, 6, 16), (1, 2, 20, 9, 64), (2, 2, 3, 40, 112), (1, 2, 2, 1, 32), (1, 1, 3, 37, 512),
+                                   (1, 2, 16, 112, 112), (2, 2, 7, 300, 8), (1, 3, 4, 33, 2048 // 8)])
+def test_3d_walk_forward_vs_oracle(abi, shape, dt):
+    """walk_forward (csrc/shiftnd_step.hip): the 3-D interpolating forward as a walk through the planes -- one plane staged
+    per step, the other plane's corner rows carried in registers; blends nested as the reference nests them (fp32 / fp64
+    bit-exact with the oracle, 16-bit within 1 ulp); every padding; ragged last row steps, one-row planes, rows of one and of
+    256 pieces, shifts beyond every dim"""
+    tdt = {"f32": torch.float32, "f64": torch.float64, "f16": torch.float16, "bf16": torch.bfloat16}[dt]
+    rs = np.random.RandomState(sum(shape) * 5 + 3)
+    xt = torch.from_numpy(rs.uniform(-1, 1, size=shape)).to(tdt)
+    wt = torch.from_numpy(_weights(rs, shape[1], 3, shape[2:])).to(tdt)
+    es = xt.element_size()
+    if (shape[-1] * es) % 16 or shape[-1] * es // 16 > 256:
+        pytest.skip("rows are not whole 16-byte pieces / wider than one workgroup pass")
+    wide = np.float64 if tdt == torch.float64 else np.float32
+    x, w = xt.to(torch.float64).numpy().astype(wide), wt.to(torch.float64).numpy().astype(wide)
+    xd, wd = xt.to(DEV), wt.to(DEV)
+    abi.set_tuning(34, 0)
+    abi.set_tuning(35, 32)  # every float dtype (automatic: 16-bit only)
+    for pad in range(5):
+        out = abi.forward(xd, wd, pad, 1)
+        assert abi.last_kernel() == "walk_forward", (shape, abi.last_kernel())
+        ref = torch.from_numpy(O.forward(x, w, pad, 1)).to(tdt)
+        if es >= 4:
+            assert torch.equal(out.cpu(), ref), (shape, dt, pad)
+        else:
+            assert _ulp_close(out.cpu(), ref, tdt), (shape, dt, pad)
+
+
+@pytest.mark.parametrize("dt", ["f32", "f64", "f16", "bf16"])
+@pytest.mark.parametrize("shape", [(2, 3, 5, 6, 16), (1, 2, 20, 9, 64), (2, 2, 3, 40, 112), (1, 2, 2, 1, 32), (1, 1, 3, 37, 512),
+                                   (1, 2, 16, 112, 112), (2, 2, 7, 300, 8), (1, 3, 9, 33, 256)])
+def test_3d_walk_backward_vs_oracle(abi, shape, dt):
+    """walk_backward (csrc/shiftnd_step.hip): the 3-D interpolating backward as a walk through the planes -- one plane of the
+    saved input and one of the gradient staged per step, the other corner planes carried in registers, the weight-gradient
+    sums accumulated over the walk.  grad_x: fp32 / fp64 bit-exact with the oracle, 16-bit within 1 ulp; grad_w within
+    1e-5 / 1e-12 / the 16-bit epsilon of the fp64 evaluation; every padding, ragged row steps, shifts beyond every dim"""
+    tdt = {"f32": torch.float32, "f64": torch.float64, "f16": torch.float16, "bf16": torch.bfloat16}[dt]
+    rs = np.random.RandomState(sum(shape) * 7 + 1)
+    xt = torch.from_numpy(rs.uniform(-1, 1, size=shape)).to(tdt)
+    gt = torch.from_numpy(rs.uniform(-1, 1, size=shape)).to(tdt)
+    wt = torch.from_numpy(_weights(rs, shape[1], 3, shape[2:])).to(tdt)
+    es = xt.element_size()
+    if (shape[-1] * es) % 16 or shape[-1] * es // 16 > 256:
+        pytest.skip("rows are not whole 16-byte pieces / wider than one workgroup pass")
+    wide = np.float64 if tdt == torch.float64 else np.float32
+    x, go, w = (t.to(torch.float64).numpy().astype(wide) for t in (xt, gt, wt))
+    xd, god, wd = xt.to(DEV), gt.to(DEV), wt.to(DEV)
+    abi.set_tuning(35, 32)  # every float dtype (automatic: 16-bit only)
+    for pad in range(5):
+        gx, gw = abi.backward(god, wd, xd, pad, 1)
+        assert abi.last_kernel() == "walk_backward", (shape, abi.last_kernel())
+        gx_ref = torch.from_numpy(O.backward(go, w, x, pad, 1)[0]).to(tdt)
+        if es >= 4:
+            assert torch.equal(gx.cpu(), gx_ref), ("gx", shape, dt, pad)
+        else:
+            assert _ulp_close(gx.cpu(), gx_ref, tdt), ("gx", shape, dt, pad)
+        _, gw64 = O.backward(go.astype(np.float64), w.astype(np.float64), x.astype(np.float64), pad, 1)
+        tol = {"f32": 1e-5, "f64": 1e-12}.get(dt, 2 * float(torch.finfo(tdt).eps))
+        assert rel_err(gw.to(torch.float64).cpu().numpy(), gw64) < tol, ("gw", shape, dt, pad)

@@ -1,3 +1,5 @@
 mkdir -p gpurun_out/r03z
 exec > gpurun_out/r03z/log.txt 2>&1
-timeout 1200 python3 -m pytest tests/test_slide_gpu.py tests/test_hip_parity.py tests/test_fuzz_families_gpu.py tests/test_fuzz_gpu.py -x -q -m gpu 2>&1 | tail -12
+timeout 1500 python3 -m pytest tests -x -q -m gpu 2>&1 | tail -6
+python3 -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -2
+python3 bench.py --workload c3 2>&1 | tail -1 | cut -c1-900

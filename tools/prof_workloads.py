@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """A fixed set of calls outside bench.py's workloads, for profiles/collect_tool.sh: channels-last tensors (N16 C256 224x224
 fp32 forward / active forward / backward, quint8 C4 in NHWC), ragged rows (N128 C1024 14x14, N8 C64 225x225) and the
-one-byte row kernel (N64 C256 224x224 uint8).  Every call runs `--iters` times."""
+one-byte row kernel (N64 C256 224x224 uint8); round 3: the channels-last backward with an NCHW gradient, periodic padding through the
+tiled kernels, the fused quantized shift + average pool.  Every call runs `--iters` times."""
 import argparse
 import os
 import sys
@@ -45,6 +46,14 @@ def main():
     wb = (torch.rand(256, 2, device=dev) * 6 - 3).round().add(128).to(torch.uint8)
     ob = torch.empty_like(xb)
     calls.append(lambda: abi.forward_quantized(xb, wb, 128, 0, 0, out=ob))
+    # round 3: the mixed-layout backward (NHWC saved input, NCHW gradient), periodic padding through the tiled kernels, the fused
+    # quantized shift + average pool (C4's tensor, pool 2)
+    go_n = torch.rand(16, 256, 224, 224, device=dev)
+    calls += [lambda: abi.backward(go_n, w, x, 0, 0, grad_x=gx, grad_w=gw, workspace=ws), lambda: abi.backward(go_n, w, x, 0, 1, grad_x=gx, grad_w=gw, workspace=ws),
+              lambda: abi.forward(x, w, 2, 0, out=out_c), lambda: abi.backward(go, w, x, 2, 0, grad_x=gx, grad_w=gw, workspace=ws)]
+    xq2 = torch.randint(0, 255, (128, 512, 56, 56), dtype=torch.uint8, device=dev)
+    oq2 = abi.forward_quantized_pooled(xq2, wq, 128, 3, 0, 2)
+    calls.append(lambda: abi.forward_quantized_pooled(xq2, wq, 128, 3, 0, 2, out=oq2))
     for f in calls:
         for _ in range(a.iters):
             f()

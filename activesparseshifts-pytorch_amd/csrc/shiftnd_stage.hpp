@@ -104,5 +104,42 @@ __device__ __forceinline__ void lds_window6(const char *row, int byte0, int ph, 
     }
 }
 
+// lds_read_row with the span reader: `fast` = this chunk's map is affine and its window sits at the workgroup's phase `ph`
+// (uniform); other chunks, and invalid rows, take lds_read_row's paths
+template <typename S, int E>
+__device__ __forceinline__ void lds_read_row_span(const char *row, bool valid, const ColState<E> &c, bool fast, int ph, S (&raw)[E + 1]) {
+    if (!valid || !fast) {
+        ColState<E> slow = c;
+        slow.affine = false;
+        lds_read_row<S, E>(row, valid, slow, raw);
+        return;
+    }
+    S zero;
+    __builtin_memset(&zero, 0, sizeof(S));
+    uint32_t o[6];
+    lds_window6(row, c.base * static_cast<int>(sizeof(S)), ph, o);
+    if constexpr (sizeof(S) == 2) {
+        const uint32_t sh = (ph & 2) ? 16u : 0u;   // uniform
+#pragma unroll
+        for (int i = 0; i < 5; ++i) {
+            const uint32_t t = __builtin_amdgcn_alignbit(o[i + 1], o[i], sh);
+            const uint16_t lo = static_cast<uint16_t>(t), hi = static_cast<uint16_t>(t >> 16);
+            if (2 * i <= E) __builtin_memcpy(&raw[2 * i], &lo, 2);
+            if (2 * i + 1 <= E) __builtin_memcpy(&raw[2 * i + 1], &hi, 2);
+        }
+    } else if constexpr (sizeof(S) == 4) {
+#pragma unroll
+        for (int e = 0; e <= E; ++e) __builtin_memcpy(&raw[e], &o[e], 4);
+    } else {
+#pragma unroll
+        for (int e = 0; e <= E; ++e) {
+            const uint64_t q = static_cast<uint64_t>(o[2 * e]) | (static_cast<uint64_t>(o[2 * e + 1]) << 32);
+            __builtin_memcpy(&raw[e], &q, 8);
+        }
+    }
+#pragma unroll
+    for (int e = 0; e <= E; ++e) raw[e] = c.cm[e] >= 0 ? raw[e] : zero;
+}
+
 }  // namespace
 }  // namespace shiftnd

@@ -1192,6 +1192,9 @@ __global__ __launch_bounds__(kThreads) void walk_forward(const FwdParams p) {
     } else {
         xm = fold_colstate<E, PAD>(jo, cs2, S2);
     }
+    // window reads: two aligned 16-byte spans and the workgroup's phase (lds_window6: no bank conflicts)
+    const int phw = (-cs2 * static_cast<int>(sizeof(S))) & 15;
+    const bool fastw = xm.affine && (PAD == 0 || ((xm.base * static_cast<int>(sizeof(S))) & 15) == phw);
     const bool mine = tr < R && tr < Rn;   // this thread produces a chunk
     const int b = b0 + tr;
     bool rv[2];
@@ -1210,7 +1213,7 @@ __global__ __launch_bounds__(kThreads) void walk_forward(const FwdParams p) {
 #pragma unroll
         for (int hb = 0; hb < 2; ++hb) {
             S r0[E + 1];
-            lds_read_row<S, E>(rows + hb * RBL, mine && rv[hb] && pa0 >= 0, xm, r0);
+            lds_read_row_span<S, E>(rows + hb * RBL, mine && rv[hb] && pa0 >= 0, xm, fastw, phw, r0);
 #pragma unroll
             for (int e = 0; e <= E; ++e) carried[hb][e] = widen<T>(r0[e]);
         }
@@ -1227,7 +1230,7 @@ __global__ __launch_bounds__(kThreads) void walk_forward(const FwdParams p) {
 #pragma unroll
         for (int hb = 0; hb < 2; ++hb) {
             S r1[E + 1];
-            lds_read_row<S, E>(rows + hb * RBL, mine && rv[hb] && pa1 >= 0, xm, r1);
+            lds_read_row_span<S, E>(rows + hb * RBL, mine && rv[hb] && pa1 >= 0, xm, fastw, phw, r1);
 #pragma unroll
             for (int e = 0; e <= E; ++e) {
                 const CT nv = widen<T>(r1[e]);

@@ -88,3 +88,11 @@ for active in (0, 1):
     t4 = ev(lambda: abi.backward(gc, w, xc, 2, active, grad_x=gxc, grad_w=gw, workspace=ws)); k4 = abi.last_kernel()
     abi.set_tuning(20, 1)
     print("fp32 periodic active=%d  fwd %.3f ms (%s) vs %.3f ms (%s)   bwd %.3f ms (%s) vs %.3f ms (%s)" % (active, t1, k1, t3, k3, t2, k2, t4, k4))
+# backward: rows per band (knob 21) -- fewer, longer bands re-read fewer halo rows
+for br in (0, 28, 56, 112, 224):
+    abi.set_tuning(21, br)
+    t2 = ev(lambda: abi.backward(gc, w, xc, 0, 0, grad_x=gxc, grad_w=gw, workspace=ws))
+    t3 = ev(lambda: abi.backward(g, w, xc, 0, 0, grad_x=gxc, grad_w=gw, workspace=ws))
+    t4 = ev(lambda: abi.backward(gc, w, xc, 0, 1, grad_x=gxc, grad_w=gw, workspace=ws))
+    print("bwd band_rows %3d  all NHWC %.3f ms   NCHW grad %.3f ms   active %.3f ms" % (br, t2, t3, t4))
+abi.set_tuning(21, 0)

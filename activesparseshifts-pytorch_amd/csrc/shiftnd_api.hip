@@ -443,10 +443,16 @@ int shiftnd_backward_pooled(const shiftnd_problem *p, const int32_t *pool, const
         return SHIFTND_OK;
     }
     if (!grad_pooled || !x || !weights || !grad_x || !grad_w || !workspace) return SHIFTND_ERR_INVALID_ARGUMENT;
+    // 3-D interpolating: the walk through the planes with the pooled gradient expanded on the way into LDS
+    if (g_policy == 0 && walk_backward_pooled_eligible(g, p->dtype, grad_pooled, x, grad_x)) {
+        if (plane_backward_workspace(g, p->dtype) > workspace_bytes) return SHIFTND_ERR_WORKSPACE_TOO_SMALL;
+        g_last_path = SHIFTND_PATH_PLANE;
+        return finish(step_backward(g, p->dtype, grad_pooled, x, weights, grad_x, grad_w, workspace, st));
+    }
     if (!plane_pool_backward_eligible(g, p->dtype, grad_x)) return SHIFTND_ERR_NOT_FUSED;
-    // 3-D interpolating backward: 16 gradient corner rows per step would be expanded from pooled rows; measured slower
-    // than avg_pool backward + shiftnd_backward (N8 C128 16x112x112: 1.42 vs 1.33 ms fp32, 1.32 vs 0.96 ms bf16), so it
-    // is not fused unless the plane-kernel policy is forced (tests)
+    // what the walk does not take of the 3-D interpolating backward: through the band-walk kernels 16 gradient corner rows per
+    // step would be expanded from pooled rows -- measured slower than avg_pool backward + shiftnd_backward (N8 C128 16x112x112:
+    // 1.42 vs 1.33 ms fp32, 1.32 vs 0.96 ms bf16), so it is not fused unless the plane-kernel policy is forced (tests)
     if (g.nd == 3 && g.active && g_policy != 2) return SHIFTND_ERR_NOT_FUSED;
     if (plane_backward_workspace(g, p->dtype) > workspace_bytes) return SHIFTND_ERR_WORKSPACE_TOO_SMALL;
     g_last_path = SHIFTND_PATH_PLANE;

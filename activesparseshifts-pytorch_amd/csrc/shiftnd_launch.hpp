@@ -139,6 +139,7 @@ bool bytes_forward_eligible(const Geometry &g, int dtype, const void *x, const v
 
 // ---- quantized shift + average pool in one pass (shiftnd_qpool.hip): one-byte element types, contiguous tensors
 bool qpool_forward_eligible(const Geometry &g, int dtype);
+bool walk_backward_pooled_eligible(const Geometry &g, int dtype, const void *go, const void *x, const void *gx);
 bool walk_forward_eligible(const Geometry &g, int dtype, const void *x, const void *out);
 int walk_forward(const Geometry &g, int dtype, const void *x, const void *w, int wkind, void *out, hipStream_t st);
 void qpool_set_tuning(int knob, int value);

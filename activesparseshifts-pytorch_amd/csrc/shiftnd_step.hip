@@ -72,6 +72,8 @@ struct StepParams {
     int K1, K2, P1, P2;
     int64_t g_plane;    // elements per (n, c) plane of `go`
     FastDiv d_k1, d_k2;
+    int K0, P0;         // 3-D pooled calls (walk_backward<..., POOL>): window and pooled size along dim0
+    FastDiv d_k0;
 };
 
 template <int E> struct RecSize { static constexpr int N = (E + 3 <= 8) ? 8 : 16; };  // int16 entries per record
@@ -1264,7 +1266,11 @@ __global__ __launch_bounds__(kThreads) void walk_forward(const FwdParams p) {
 // weight gradient: the eight corner-difference sums of step_backward<T, 3>, accumulated over the walk (fp32 per step,
 // folded into fp64 every four planes), one record per workgroup for step_reduce.
 // ---------------------------------------------------------------------------------------------------------------------
-template <typename T, int PAD>
+// POOL: `go` is the gradient of the POOLED output [N, C, P0, P1, P2] (window = stride = (K0, K1, 2)): every 16-byte piece of the
+// unpooled gradient the walk consumes -- the staged corner rows and the thread's own chunk -- is 8 bytes of a pooled row, loaded
+// as they are and expanded when they are parked / used: g = pooled / (window size), rounded to the storage type like the two-step
+// sequence (ATen's avg_pool backward).  The rest of the kernel does not know.
+template <typename T, int PAD, bool POOL = false>
 __global__ __launch_bounds__(kThreads) void walk_backward(const StepParams p) {
     using S = typename T::S;
     using CT = typename T::C;
@@ -1285,7 +1291,7 @@ __global__ __launch_bounds__(kThreads) void walk_backward(const StepParams p) {
     const int Rn = min(R, S1 - b0);
     const int RB = S2 * static_cast<int>(sizeof(S));
     const char *xp = reinterpret_cast<const char *>(static_cast<const S *>(p.x) + static_cast<int64_t>(plane) * p.x_plane);
-    const S *gp = static_cast<const S *>(p.go) + static_cast<int64_t>(plane) * p.x_plane;
+    const S *gp = static_cast<const S *>(p.go) + static_cast<int64_t>(plane) * (POOL ? p.g_plane : p.x_plane);
     S *gxp = static_cast<S *>(p.out) + static_cast<int64_t>(plane) * p.x_plane;
 
     const int tid = static_cast<int>(threadIdx.x);
@@ -1328,27 +1334,79 @@ __global__ __launch_bounds__(kThreads) void walk_backward(const StepParams p) {
     constexpr int kRsrcFlags = 0x00020000;
     const uint32_t vol_bytes = static_cast<uint32_t>(S0) * plane_bytes;   // < 2^31 (host)
     const __amdgpu_buffer_rsrc_t xres = __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(xp), 0, vol_bytes, kRsrcFlags);
-    const __amdgpu_buffer_rsrc_t gres = __builtin_amdgcn_make_buffer_rsrc(const_cast<S *>(gp), 0, vol_bytes, kRsrcFlags);
+    const __amdgpu_buffer_rsrc_t gres = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<S *>(gp), 0, POOL ? static_cast<uint32_t>(p.g_plane) * static_cast<uint32_t>(sizeof(S)) : vol_bytes, kRsrcFlags);
+    // POOL: the 8 bytes of pooled row `row / K1` under piece `piece` of unpooled row `row`, bytes within a pooled plane; the
+    // window rows the pooled row averages
+    typedef uint32_t u2 __attribute__((ext_vector_type(2)));
+    auto pooled_off = [&](int row, int piece) {
+        const int pr = static_cast<int>(fdiv(static_cast<uint32_t>(max(row, 0)), p.d_k1));
+        return static_cast<uint32_t>(pr * p.P2 + piece * (E / 2)) * static_cast<uint32_t>(sizeof(S));
+    };
+    auto pooled_rows = [&](int row) {
+        const int pr = static_cast<int>(fdiv(static_cast<uint32_t>(max(row, 0)), p.d_k1));
+        return min(p.K1, S1 - pr * p.K1);
+    };
+    const uint32_t pooled_plane_bytes = POOL ? static_cast<uint32_t>(p.P1) * static_cast<uint32_t>(p.P2) * static_cast<uint32_t>(sizeof(S)) : 0u;
+    auto pooled_plane = [&](int pa, uint32_t &soff, int &n0) {   // unpooled plane (uniform) -> byte offset of its pooled plane, window planes
+        const int pp = static_cast<int>(fdiv(static_cast<uint32_t>(max(pa, 0)), p.d_k0));
+        soff = static_cast<uint32_t>(pp) * pooled_plane_bytes;
+        n0 = min(p.K0, S0 - pp * p.K0);
+    };
+    // 8 pooled bytes -> the 16-byte piece of the unpooled gradient: every element twice, divided by the window size `cnt`
+    auto expand = [&](u2 raw, int cnt) {
+        Chunk<S, (E >= 2 ? E / 2 : 1)> in;
+        __builtin_memcpy(in.e, &raw, 8);
+        Chunk<S, E> out;
+#pragma unroll
+        for (int h = 0; h < E / 2; ++h) {
+            const S q = narrow<T>(div_count<CT>(widen<T>(in.e[h]), cnt));
+            out.e[2 * h] = q;
+            out.e[2 * h + 1] = q;
+        }
+        u4 v;
+        __builtin_memcpy(&v, out.e, 16);
+        return v;
+    };
     const __amdgpu_buffer_rsrc_t ores = __builtin_amdgcn_make_buffer_rsrc(gxp, 0, vol_bytes, kRsrcFlags);
     const __amdgpu_buffer_rsrc_t none = __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(xp), 0, 0, kRsrcFlags);
-    const uint32_t vx_own = sx_own >= 0 ? ox_own : kOOR, vg_own = sg_own >= 0 ? og_own : kOOR;
-    const uint32_t vx_extra = sx_extra >= 0 ? ox_extra : kOOR, vg_extra = sg_extra >= 0 ? og_extra : kOOR;
+    const uint32_t vx_own = sx_own >= 0 ? ox_own : kOOR, vx_extra = sx_extra >= 0 ? ox_extra : kOOR;
+    const uint32_t vg_own = sg_own >= 0 ? (POOL ? pooled_off(sg_own, tc) : og_own) : kOOR;
+    const uint32_t vg_extra = sg_extra >= 0 ? (POOL ? pooled_off(sg_extra, tid) : og_extra) : kOOR;
+    const int n1_own = POOL ? pooled_rows(sg_own) : 1, n1_extra = POOL ? pooled_rows(sg_extra) : 1;   // window rows of the staged pieces
     char *dump = tile + 2 * GP0 * 16 + tid * 16;
     char *dx_own = own ? tile + tid * 16 : dump, *dx_extra = extra ? tile + (R * cpr + tid) * 16 : dump;
     char *dg_own = own ? tile + (GP0 + tid) * 16 : dump, *dg_extra = extra ? tile + (GP0 + R * cpr + tid) * 16 : dump;
-    struct Staged { u4 xo, xe, go, ge; };
+    struct Staged {
+        u4 xo, xe, go, ge;
+        u2 po, pe;   // POOL: the pooled bytes of the gradient pieces, expanded when parked
+        int n0;      // ... and the window planes of their pooled plane
+    };
     auto load_planes = [&](int pax, int pag, Staged &v) {   // source planes (uniform; -1: fill)
-        const uint32_t sx = pax >= 0 ? static_cast<uint32_t>(pax) * plane_bytes : 0u, sg = pag >= 0 ? static_cast<uint32_t>(pag) * plane_bytes : 0u;
+        const uint32_t sx = pax >= 0 ? static_cast<uint32_t>(pax) * plane_bytes : 0u;
         v.xo = __builtin_amdgcn_raw_buffer_load_b128(pax >= 0 ? xres : none, vx_own, sx, 0);
-        v.go = __builtin_amdgcn_raw_buffer_load_b128(pag >= 0 ? gres : none, vg_own, sg, 0);
         v.xe = __builtin_amdgcn_raw_buffer_load_b128(pax >= 0 ? xres : none, vx_extra, sx, 0);
-        v.ge = __builtin_amdgcn_raw_buffer_load_b128(pag >= 0 ? gres : none, vg_extra, sg, 0);
+        if constexpr (POOL) {
+            uint32_t sg;
+            pooled_plane(pag, sg, v.n0);
+            v.po = __builtin_amdgcn_raw_buffer_load_b64(pag >= 0 ? gres : none, vg_own, sg, 0);
+            v.pe = __builtin_amdgcn_raw_buffer_load_b64(pag >= 0 ? gres : none, vg_extra, sg, 0);
+        } else {
+            const uint32_t sg = pag >= 0 ? static_cast<uint32_t>(pag) * plane_bytes : 0u;
+            v.go = __builtin_amdgcn_raw_buffer_load_b128(pag >= 0 ? gres : none, vg_own, sg, 0);
+            v.ge = __builtin_amdgcn_raw_buffer_load_b128(pag >= 0 ? gres : none, vg_extra, sg, 0);
+        }
     };
     auto park = [&](const Staged &v) {
         *reinterpret_cast<u4 *>(__builtin_assume_aligned(dx_own, 16)) = v.xo;
-        *reinterpret_cast<u4 *>(__builtin_assume_aligned(dg_own, 16)) = v.go;
         *reinterpret_cast<u4 *>(__builtin_assume_aligned(dx_extra, 16)) = v.xe;
-        *reinterpret_cast<u4 *>(__builtin_assume_aligned(dg_extra, 16)) = v.ge;
+        if constexpr (POOL) {
+            *reinterpret_cast<u4 *>(__builtin_assume_aligned(dg_own, 16)) = expand(v.po, v.n0 * n1_own * 2);
+            *reinterpret_cast<u4 *>(__builtin_assume_aligned(dg_extra, 16)) = expand(v.pe, v.n0 * n1_extra * 2);
+        } else {
+            *reinterpret_cast<u4 *>(__builtin_assume_aligned(dg_own, 16)) = v.go;
+            *reinterpret_cast<u4 *>(__builtin_assume_aligned(dg_extra, 16)) = v.ge;
+        }
     };
     const bool mine = tr < R && tr < Rn;
     const int b = b0 + tr;
@@ -1470,10 +1528,25 @@ __global__ __launch_bounds__(kThreads) void walk_backward(const StepParams p) {
         part[i] = CT(0);
     }
     const uint32_t my = mine ? static_cast<uint32_t>(b * S2 + ji) * static_cast<uint32_t>(sizeof(S)) : kOOR;   // own chunk, bytes within a plane
+    const uint32_t myp = (POOL && mine) ? pooled_off(b, tc) : kOOR;   // POOL: its pooled bytes
+    const int n1_my = POOL ? pooled_rows(b) : 1;
+    auto load_own = [&](int a, bool have) {   // the incoming gradient at the thread's own chunk of plane a (raw: u4, or the pooled 8 bytes in .xy)
+        u4 r;
+        if constexpr (POOL) {
+            uint32_t sg;
+            int n0;
+            pooled_plane(a, sg, n0);
+            const u2 q = __builtin_amdgcn_raw_buffer_load_b64(have ? gres : none, myp, sg, 0);
+            r = u4{q.x, q.y, static_cast<uint32_t>(n0), 0u};
+        } else {
+            r = __builtin_amdgcn_raw_buffer_load_b128(have ? gres : none, my, static_cast<uint32_t>(a) * plane_bytes, 0);
+        }
+        return r;
+    };
     __syncthreads();   // the "+0" planes have been read
     Staged pend;       // plane a + 1 of the step about to run
     load_planes(row_map_t<PAD>(1, d.cx0, S0), row_map_t<PAD>(1, d.cg0, S0), pend);
-    u4 gcur = __builtin_amdgcn_raw_buffer_load_b128(gres, my, 0u, 0);   // the incoming gradient at the thread's own chunk
+    u4 gcur = load_own(0, true);
     for (int a = 0; a < S0; ++a) {
         park(pend);
         __syncthreads();
@@ -1482,7 +1555,12 @@ __global__ __launch_bounds__(kThreads) void walk_backward(const StepParams p) {
         const bool more = a + 1 < S0;
         load_planes(more ? row_map_t<PAD>(a + 2, d.cx0, S0) : -1, more ? row_map_t<PAD>(a + 2, d.cg0, S0) : -1, pend);
         Chunk<S, E> gch;
-        __builtin_memcpy(gch.e, &gcur, 16);
+        if constexpr (POOL) {
+            const u4 ex = expand(u2{gcur.x, gcur.y}, static_cast<int>(gcur.z) * n1_my * 2);
+            __builtin_memcpy(gch.e, &ex, 16);
+        } else {
+            __builtin_memcpy(gch.e, &gcur, 16);
+        }
         // ---- weight-gradient sums: corners of x (plane bit 0, row bit 1, column bit 2: step_backward's order) ------------
         if constexpr (PACKED) {
             uint32_t gq[4], nxp[2][5];
@@ -1533,7 +1611,7 @@ __global__ __launch_bounds__(kThreads) void walk_backward(const StepParams p) {
                 for (int e = 0; e <= E; ++e) cx[hb][e] = nx[hb][e];
         }
         // the next step's own chunk: in flight through the blends below and the next step's staging
-        gcur = __builtin_amdgcn_raw_buffer_load_b128(a + 1 < S0 ? gres : none, my, static_cast<uint32_t>(a + 1) * plane_bytes, 0);
+        gcur = load_own(a + 1, a + 1 < S0);
         // ---- grad_x ------------------------------------------------------------------------------------------------
         CT rowb[2][E + 1];
 #pragma unroll
@@ -2045,16 +2123,28 @@ int walk_forward(const Geometry &g, int dtype, const void *x, const void *w, int
 
 // the 3-D interpolating backward as a walk through the planes (walk_backward): what step_backward takes, 3-D, >= 2 planes.
 // Automatic for 2- and 4-byte elements; knob 35 bit 5 (32): fp64 too; bit 4 (16): never; bit 0: the one-step form instead.
+static bool walk_backward_core(const Geometry &g, int dtype, const void *go, const void *x, const void *gx, bool pooled);
 bool walk_backward_eligible(const Geometry &g, int dtype, const void *go, const void *x, const void *gx) {
+    return g.K[0] <= 0 && walk_backward_core(g, dtype, go, x, gx, false);
+}
+// the fused shift + average-pool backward in 3-D (interpolating): `go` = gradient of the pooled output, contiguous; windows
+// (K0, K1, 2)
+bool walk_backward_pooled_eligible(const Geometry &g, int dtype, const void *go, const void *x, const void *gx) {
+    if (!(g.K[0] > 0 && g.nd == 3) || g.K[2] != 2 || g.K[1] < 1) return false;
+    if (reinterpret_cast<uintptr_t>(go) % 8) return false;
+    if (g.P[0] * g.P[1] * g.P[2] * dtype_size(dtype) >= (1LL << 31)) return false;
+    return walk_backward_core(g, dtype, nullptr, x, gx, true);
+}
+static bool walk_backward_core(const Geometry &g, int dtype, const void *go, const void *x, const void *gx, bool pooled) {
     if (g_step_tune[0] == 1 || (g_step_tune[3] & 16) || (g_step_tune[3] & 1)) return false;   // (bit 0: the one-step 3-D form)
-    if (dtype > SHIFTND_BF16 || g.nd != 3 || !g.active || g.K[0] > 0 || g.S[0] < 2) return false;
+    if (dtype > SHIFTND_BF16 || g.nd != 3 || !g.active || g.S[0] < 2) return false;
     const int es = dtype_size(dtype);
     for (int d = 0; d < 3; ++d)
         if (g.O[d] != g.S[d] || g.L[d] != 0) return false;
     if (g.S[1] < 1 || (g.S[2] * es) % 16 != 0 || g.S[2] * es / 16 > kThreads || g.S[2] > 32000) return false;
     if (g.S[0] * g.S[1] * g.S[2] >= (1LL << 30)) return false;
-    if (!dense(g.xs, g.N, g.C, g.S) || !dense(g.os, g.N, g.C, g.O) || !dense(g.gs, g.N, g.C, g.S)) return false;
-    if (reinterpret_cast<uintptr_t>(go) % 16 || reinterpret_cast<uintptr_t>(x) % 16 || reinterpret_cast<uintptr_t>(gx) % 16) return false;
+    if (!dense(g.xs, g.N, g.C, g.S) || (!pooled && !dense(g.os, g.N, g.C, g.O)) || !dense(g.gs, g.N, g.C, g.S)) return false;
+    if ((!pooled && reinterpret_cast<uintptr_t>(go) % 16) || reinterpret_cast<uintptr_t>(x) % 16 || reinterpret_cast<uintptr_t>(gx) % 16) return false;
     const StepLayout L = step_layout(g, es);
     if (L.total_steps + 8 >= (1ull << 31)) return false;
     const int64_t rmax = std::min<int64_t>(kThreads / L.cpr, g.S[1]);
@@ -2068,13 +2158,13 @@ template <typename T> static void launch_walk_backward(StepParams &p, size_t lds
     using S = typename T::S;
     const dim3 grid(p.steps_per_xcd * 8), block(kThreads);
     hipLaunchKernelGGL((step_prep<T, true>), dim3(p.C), block, 0, st, p);
-    switch (p.pad) {
-    case 0: hipLaunchKernelGGL((walk_backward<T, 0>), grid, block, lds, st, p); break;
-    case 1: hipLaunchKernelGGL((walk_backward<T, 1>), grid, block, lds, st, p); break;
-    case 2: hipLaunchKernelGGL((walk_backward<T, 2>), grid, block, lds, st, p); break;
-    case 3: hipLaunchKernelGGL((walk_backward<T, 3>), grid, block, lds, st, p); break;
-    default: hipLaunchKernelGGL((walk_backward<T, 4>), grid, block, lds, st, p); break;
-    }
+#define SHIFTND_WALK_BWD(PADV) \
+    case PADV: \
+        if (p.K0 > 0) hipLaunchKernelGGL((walk_backward<T, PADV, true>), grid, block, lds, st, p); \
+        else hipLaunchKernelGGL((walk_backward<T, PADV, false>), grid, block, lds, st, p); \
+        break;
+    switch (p.pad) { SHIFTND_WALK_BWD(0) SHIFTND_WALK_BWD(1) SHIFTND_WALK_BWD(2) SHIFTND_WALK_BWD(3) default: SHIFTND_WALK_BWD(4) }
+#undef SHIFTND_WALK_BWD
     hipLaunchKernelGGL((step_reduce<T, 3>), dim3(p.C), block, 0, st, p, static_cast<S *>(gw));
 }
 
@@ -2128,8 +2218,14 @@ int step_backward(const Geometry &g, int dtype, const void *go, const void *x, c
         p.d_k1 = make_fastdiv(static_cast<uint32_t>(p.K1));
         p.d_k2 = make_fastdiv(static_cast<uint32_t>(p.K2));
     }
-    if (walk_backward_eligible(g, dtype, go, x, gx)) {
+    if (walk_backward_eligible(g, dtype, go, x, gx) || walk_backward_pooled_eligible(g, dtype, go, x, gx)) {
         // the walk through the planes: balanced row steps, one record of sums per workgroup
+        if (g.K[0] > 0) {
+            p.K0 = static_cast<int>(g.K[0]);
+            p.P0 = static_cast<int>(g.P[0]);
+            p.d_k0 = make_fastdiv(static_cast<uint32_t>(p.K0));
+            p.g_plane = g.P[0] * g.P[1] * g.P[2];
+        }
         const int rmax = std::min<int>(kThreads / L.cpr, p.S1);
         p.spp = (p.S1 + rmax - 1) / rmax;
         p.R = (p.S1 + p.spp - 1) / p.spp;
@@ -2140,7 +2236,7 @@ int step_backward(const Geometry &g, int dtype, const void *go, const void *x, c
         p.d_spp = make_fastdiv(static_cast<uint32_t>(p.spp));
         p.d_spv = p.d_spp;
         const size_t lds = 64 + static_cast<size_t>(2 * (p.R + 1)) * L.cpr * 16 + kThreads * 16 + kThreads * 8 * sizeof(double) + 64;   // tile, dump slots, sums, pad
-        note_kernel("walk_backward");
+        note_kernel(g.K[0] > 0 ? "walk_backward_pool" : "walk_backward");
         switch (dtype) {
         case SHIFTND_F32: launch_walk_backward<f32_t>(p, lds, gw, st); break;
         case SHIFTND_F64: launch_walk_backward<f64_t>(p, lds, gw, st); break;

@@ -63,14 +63,19 @@ def test_pooled_vs_oracle(abi, dt):
                 assert np.array_equal(out.cpu().numpy(), ref), key
                 gp = rs.uniform(-1, 1, size=ref.shape).astype(dt)
                 gx_r, gw_r = O.backward_pooled(gp, w, x, pad, active, pool, b)
-                if nd == 3 and active:  # not fused by default (slower than the two-step sequence): force the kernels
+                # 3-D interpolating: the walk through the planes (2- / 4-byte elements, windows (K0, K1, 2), no crop); what it does
+                # not take is not fused by default (the band-walk kernels are slower than the two-step sequence there): forced
+                walk = (nd == 3 and active and dt == np.float32 and crop is None and pool[-1] == 2 and shape[2] >= 2
+                        and (shape[-1] * x.itemsize) % 16 == 0)
+                if nd == 3 and active and not walk:
                     with pytest.raises(RuntimeError, match="not served"):
                         abi.backward_pooled(_dev(gp), wd, xd, pad, active, pool, b)
                     abi.set_path_policy(2)
                 gx, gw = abi.backward_pooled(_dev(gp), wd, xd, pad, active, pool, b)
                 abi.set_path_policy(0)
                 step = nd == 2 and crop is None and (shape[-1] * x.itemsize) % 16 == 0 and not active  # the one-step kernel's cases
-                assert abi.last_kernel() in (("step_backward_pool",) if step else ("plane_backward_pool", "plane_backward_lds_pool")), key
+                want = ("walk_backward_pool",) if walk else (("step_backward_pool",) if step else ("plane_backward_pool", "plane_backward_lds_pool"))
+                assert abi.last_kernel() in want, key
                 assert np.array_equal(gx.cpu().numpy(), gx_r), key
                 assert rel_err(gw.cpu().numpy(), gw_r) < (1e-5 if dt == np.float32 else 1e-12), key
 
@@ -119,11 +124,14 @@ def test_pooled_16bit(abi, tdt):
                 gpt = torch.from_numpy(rs.uniform(-1, 1, size=ref.shape).astype(np.float32)).to(tdt)
                 g = torch.from_numpy(O.avg_pool_backward(gpt.float().numpy(), pool, y.shape[2:])).to(tdt).float().numpy()
                 gx_r, gw_r = O.backward(g, w, x, pad, active, b)
-                abi.set_path_policy(2 if (nd == 3 and active) else 0)
-                gx, gw = abi.backward_pooled(gpt.to(DEV), wt.to(DEV), xt.to(DEV), pad, active, pool, b)
-                abi.set_path_policy(0)
-                assert np.max(np.abs(gx.float().cpu().numpy() - gx_r)) <= eps * max(1.0, np.max(np.abs(gx_r)))
-                assert rel_err(gw.float().cpu().numpy(), gw_r) < 4 * eps
+                for policy in ((0, 2) if (nd == 3 and active) else (0,)):  # 3-D interpolating: the walk (0) and the band-walk kernels (2)
+                    abi.set_path_policy(policy)
+                    gx, gw = abi.backward_pooled(gpt.to(DEV), wt.to(DEV), xt.to(DEV), pad, active, pool, b)
+                    abi.set_path_policy(0)
+                    if nd == 3 and active:
+                        assert (abi.last_kernel() == "walk_backward_pool") == (policy == 0), (shape, policy, abi.last_kernel())
+                    assert np.max(np.abs(gx.float().cpu().numpy() - gx_r)) <= eps * max(1.0, np.max(np.abs(gx_r)))
+                    assert rel_err(gw.float().cpu().numpy(), gw_r) < 4 * eps
 
 
 def test_pooled_matches_unfused_fullsize(abi):
@@ -163,7 +171,7 @@ def test_pooled_backward_workspace_small_batch_large_plane():
             assert need > 0
             try:
                 gx, gw = abi.backward_pooled(gp, w, x, 0, active, 2)
-            except RuntimeError as e:  # 3-D active is not fused (SHIFTND_ERR_NOT_FUSED)
+            except RuntimeError as e:  # (what the 3-D walk does not take is not fused: SHIFTND_ERR_NOT_FUSED)
                 assert "not served" in str(e) and nd == 3 and active
                 continue
             # the two-step reference: avg_pool backward (ATen) then the plain shift backward
@@ -238,3 +246,39 @@ def test_quantized_pooled_forward_vs_oracle(abi, npdt):
                     assert np.array_equal(out.cpu().numpy(), ref), (nd, shape, pool, crop, pad, requant, abi.last_kernel())
     assert differ  # the inputs do separate the two roundings
     assert served == {"qpool_forward", "qpool_plane_forward"}
+
+
+@pytest.mark.parametrize("dt", ["f32", "f16", "bf16"])
+@pytest.mark.parametrize("shape,pool", [((2, 3, 5, 7, 16), (2, 2, 2)), ((1, 2, 6, 9, 32), (3, 2, 2)), ((1, 2, 4, 40, 112), (1, 2, 2)),
+                                        ((2, 2, 9, 33, 64), (2, 3, 2)), ((1, 3, 2, 1, 8), (2, 2, 2))])
+def test_pooled_3d_walk_backward(abi, shape, pool, dt):
+    """walk_backward<..., POOL>: the 3-D interpolating shift + average pool backward in one pass (the pooled gradient expanded on
+    its way into LDS).  fp32: grad_x bit-exact with the oracle's fused backward, grad_w within 1e-5; 16-bit: against the two-step
+    sequence on widened values (the unpooled gradient rounded to the storage type, as ATen's avg_pool backward returns it);
+    ragged windows along planes and rows, every padding"""
+    tdt = {"f32": torch.float32, "f16": torch.float16, "bf16": torch.bfloat16}[dt]
+    rs = np.random.RandomState(sum(shape) + 41)
+    xt = torch.from_numpy(rs.uniform(-1, 1, size=shape).astype(np.float32)).to(tdt)
+    if (shape[-1] * xt.element_size()) % 16:
+        pytest.skip("rows are not whole 16-byte pieces")
+    wt = torch.from_numpy(rs.uniform(-2.6, 2.6, size=(shape[1], 3)).astype(np.float32)).to(tdt)
+    wt[0] = torch.tensor([shape[2] + 1.5, -0.25, 9.75]).to(tdt)   # beyond the planes / beyond a piece of columns
+    x, w = xt.float().numpy(), wt.float().numpy()
+    b, _ = abi.check_borders(list(shape), None, 3)
+    eps = {"f32": 0.0, "f16": 2.0 ** -11, "bf16": 2.0 ** -8}[dt]
+    for pad in range(5):
+        y = O.forward(x, w, pad, 1, b)
+        pshape = O.avg_pool(y, pool).shape
+        gpt = torch.from_numpy(rs.uniform(-1, 1, size=pshape).astype(np.float32)).to(tdt)
+        gx, gw = abi.backward_pooled(gpt.to(DEV), wt.to(DEV), xt.to(DEV), pad, 1, pool, b)
+        assert abi.last_kernel() == "walk_backward_pool", (shape, pool, abi.last_kernel())
+        if dt == "f32":
+            gx_r, gw_r = O.backward_pooled(gpt.numpy(), w, x, pad, 1, pool, b)
+            assert np.array_equal(gx.cpu().numpy(), gx_r), (shape, pool, pad)
+            _, gw64 = O.backward_pooled(gpt.numpy().astype(np.float64), w.astype(np.float64), x.astype(np.float64), pad, 1, pool, b)
+            assert rel_err(gw.cpu().numpy(), gw64) < 1e-5, (shape, pool, pad)
+        else:
+            g = torch.from_numpy(O.avg_pool_backward(gpt.float().numpy(), pool, y.shape[2:])).to(tdt).float().numpy()
+            gx_r, gw_r = O.backward(g, w, x, pad, 1, b)
+            assert np.max(np.abs(gx.float().cpu().numpy() - gx_r)) <= eps * max(1.0, np.max(np.abs(gx_r))), (shape, pool, pad)
+            assert rel_err(gw.float().cpu().numpy(), gw_r) < 4 * eps, (shape, pool, pad)

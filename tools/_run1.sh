@@ -1,5 +1,5 @@
-mkdir -p gpurun_out/r03f
-bash tools/gpu_round.sh r03f c2 c3 c4 c5 > gpurun_out/r03f/round.log 2>&1
-python3 bench.py --workload c2a --no-cpu-baseline > gpurun_out/r03f/bench_c2a.json 2> gpurun_out/r03f/bench_c2a.err
-bash profiles/collect_tool.sh extra tools/prof_workloads.py --iters 5 > gpurun_out/r03f/collect_extra.log 2>&1
-cp gpurun_out/prof_extra/summary.txt gpurun_out/r03f/extra_summary.txt
+mkdir -p gpurun_out/r03z
+exec > gpurun_out/r03z/log.txt 2>&1
+timeout 1200 python3 -m pytest tests/test_pooled_gpu.py tests/test_step_gpu.py -x -q -m gpu 2>&1 | tail -12
+python3 tools/pool_bench.py --dtype bfloat16 --shape 8,128,16,112,112 --active 1 2>&1 | tail -6
+python3 tools/pool_bench.py --dtype float32 --shape 8,128,16,112,112 --active 1 2>&1 | tail -6

@@ -1,6 +1,6 @@
 """A seeded, time-boxed slice of tools/fuzz_round2.py in the GPU suite: random shapes, paddings, shift kinds, launch-planning
 knobs and dtypes through the round-2 / round-3 kernel families (LDS-tiled channels-last, small planes / row bands, the
-byte kernel, the one-step kernels), every case against the CPU oracle (bit-exact gathers and fp32 / fp64 interpolation,
+byte kernel, the one-step kernels, the 3-D walk kernels incl. the pooled backward), every case against the CPU oracle (bit-exact gathers and fp32 / fp64 interpolation,
 1 ulp for 16-bit interpolation, grad_w 1e-5 / 16-bit epsilon of the fp64 evaluation).  The standalone tool runs the same
 cases for as long as asked."""
 import os
@@ -26,6 +26,6 @@ def test_random_cases_against_the_oracle(seed):
         F.CASES[n % len(F.CASES)](rs)
         n += 1
     kernels = set(F.count)
-    for must in ("cl_tiled_backward", "step_backward", "step_gather_forward"):
+    for must in ("cl_tiled_backward", "step_backward", "step_gather_forward", "walk_forward", "walk_backward", "walk_backward_pool"):
         assert must in kernels, (must, dict(F.count))
     assert any(k.startswith(("small_", "band_")) for k in kernels), dict(F.count)

@@ -149,7 +149,7 @@ def case_step(rs):
         if exact or not active:
             assert torch.equal(gx.cpu(), gx_o), ("step gx", shape, tdt, pad, active)
         else:
-            assert _ulp_close(gx.cpu(), gx_o, tdt), ("step gx", shape, tdt, pad, active)
+            assert _ulp_close(gx.cpu(), gx_o, tdt, 32 * 2.0 ** -24), ("step gx", shape, tdt, pad, active)
         _, gw64 = O.backward(go.astype(np.float64), w.astype(np.float64), x.astype(np.float64), pad, active)
         tol = {torch.float64: 1e-12, torch.float32: 1e-5}.get(tdt, 2 * float(torch.finfo(tdt).eps))
         assert rel_err(gw.to(torch.float64).cpu().numpy(), gw64) < tol, ("step gw", shape, tdt, pad, active)
@@ -165,13 +165,77 @@ def case_step(rs):
         if exact or not active:
             assert torch.equal(o.cpu(), ref), ("step fwd", shape, tdt, pad, active, crop)
         else:
-            assert _ulp_close(o.cpu(), ref, tdt), ("step fwd", shape, tdt, pad, active, crop)
+            assert _ulp_close(o.cpu(), ref, tdt, 32 * 2.0 ** -24), ("step fwd", shape, tdt, pad, active, crop)
     finally:
         for k in (32, 33, 34):
             abi.set_tuning(k, 0)
 
 
-CASES = [case_cl, case_ragged, case_ragged, case_bytes, case_step, case_step]
+last = {}
+
+
+def case_walk(rs):
+    """round 3: the walk through the planes (walk_forward / walk_backward / walk_backward<POOL>) -- 3-D interpolating problems
+    whose rows are whole 16-byte pieces, every float dtype (knob 35 bit 5), every padding; the pooled backward against the
+    oracle's fused backward (fp32) or the two-step sequence on widened values (16-bit)"""
+    tdt = [torch.float32, torch.float64, torch.float16, torch.bfloat16][rs.randint(4)]
+    es = torch.empty(0, dtype=tdt).element_size()
+    per16 = 16 // es
+    D = int(rs.choice([2, 3, 5, 8, 17])); H = int(rs.choice([1, 2, 5, 9, 18, 37, 64]))
+    W = per16 * int(rs.choice([1, 2, 3, 7, 14, 28, 64]))
+    N, C = int(rs.randint(1, 3)), int(rs.randint(1, 5))
+    shape = (N, C, D, H, W)
+    pad = int(rs.randint(0, 5))
+    xt = torch.from_numpy(rs.uniform(-1, 1, size=shape)).to(tdt); gt = torch.from_numpy(rs.uniform(-1, 1, size=shape)).to(tdt)
+    wt = torch.from_numpy(weights(rs, C, 3, shape[2:], 4.5)).to(tdt)
+    wide = np.float64 if tdt == torch.float64 else np.float32
+    x, go, w = (t.to(torch.float64).numpy().astype(wide) for t in (xt, gt, wt))
+    xd, gd, wd = xt.to(DEV), gt.to(DEV), wt.to(DEV)
+    exact = tdt in (torch.float32, torch.float64)
+    from test_hip_parity import _ulp_close
+    last.update(shape=shape, tdt=tdt, pad=pad, xt=xt, gt=gt, wt=wt)   # (for a post-mortem: tools/_dbg.py)
+    abi.set_tuning(35, 32)
+    try:
+        o = abi.forward(xd, wd, pad, 1)
+        assert abi.last_kernel() == "walk_forward", (shape, tdt, abi.last_kernel())
+        count["walk_forward"] += 1
+        ref = torch.from_numpy(O.forward(x, w, pad, 1)).to(tdt)
+        # 16-bit: 1 ulp of the type, plus 32 fp32 ulps of the (unit-scale) operands for results that cancel to almost nothing
+        # (seven nested blends in 3-D, evaluated with mul + fma here and mul, mul, add in the oracle)
+        floor16 = 32 * 2.0 ** -24
+        assert torch.equal(o.cpu(), ref) if exact else _ulp_close(o.cpu(), ref, tdt, floor16), ("walk fwd", shape, tdt, pad)
+        gx, gw = abi.backward(gd, wd, xd, pad, 1)
+        assert abi.last_kernel() == "walk_backward", (shape, tdt, abi.last_kernel())
+        count["walk_backward"] += 1
+        gx_o = torch.from_numpy(O.backward(go, w, x, pad, 1)[0]).to(tdt)
+        assert torch.equal(gx.cpu(), gx_o) if exact else _ulp_close(gx.cpu(), gx_o, tdt, floor16), ("walk gx", shape, tdt, pad)
+        _, gw64 = O.backward(go.astype(np.float64), w.astype(np.float64), x.astype(np.float64), pad, 1)
+        tol = {torch.float64: 1e-12, torch.float32: 1e-5}.get(tdt, 2 * float(torch.finfo(tdt).eps))
+        assert rel_err(gw.to(torch.float64).cpu().numpy(), gw64) < tol, ("walk gw", shape, tdt, pad)
+        if tdt != torch.float64:
+            pool = (int(rs.randint(1, 4)), int(rs.randint(1, 4)), 2)
+            y = O.forward(x, w, pad, 1)
+            gpt = torch.from_numpy(rs.uniform(-1, 1, size=O.avg_pool(y, pool).shape)).to(tdt)
+            gx, gw = abi.backward_pooled(gpt.to(DEV), wd, xd, pad, 1, pool)
+            assert abi.last_kernel() == "walk_backward_pool", (shape, tdt, pool, abi.last_kernel())
+            count["walk_backward_pool"] += 1
+            if tdt == torch.float32:
+                gx_r, _ = O.backward_pooled(gpt.numpy(), w, x, pad, 1, pool)
+                assert np.array_equal(gx.cpu().numpy(), gx_r), ("walk pool gx", shape, pool, pad)
+                _, gw_r = O.backward_pooled(gpt.numpy().astype(np.float64), w.astype(np.float64), x.astype(np.float64), pad, 1, pool)
+                assert rel_err(gw.cpu().numpy(), gw_r) < 1e-5, ("walk pool gw", shape, pool, pad)
+            else:
+                eps = float(torch.finfo(tdt).eps)
+                g = torch.from_numpy(O.avg_pool_backward(gpt.float().numpy(), pool, y.shape[2:])).to(tdt).float().numpy()
+                gx_r, gw_r = O.backward(g, w, x, pad, 1)
+                assert np.max(np.abs(gx.float().cpu().numpy() - gx_r)) <= eps * max(1.0, np.max(np.abs(gx_r))), ("walk pool gx", shape, tdt, pool, pad)
+                assert rel_err(gw.float().cpu().numpy(), gw_r) < 4 * eps, ("walk pool gw", shape, tdt, pool, pad)
+    finally:
+        abi.set_tuning(35, 0)
+
+
+CASES = [case_cl, case_ragged, case_ragged, case_bytes, case_step, case_step, case_walk, case_walk]
+
 
 
 def main():

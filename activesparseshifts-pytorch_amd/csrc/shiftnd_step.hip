@@ -1270,8 +1270,12 @@ __global__ __launch_bounds__(kThreads) void walk_forward(const FwdParams p) {
 // unpooled gradient the walk consumes -- the staged corner rows and the thread's own chunk -- is 8 bytes of a pooled row, loaded
 // as they are and expanded when they are parked / used: g = pooled / (window size), rounded to the storage type like the two-step
 // sequence (ATen's avg_pool backward).  The rest of the kernel does not know.
-template <typename T, int PAD, bool POOL = false>
+// ACTIVE = false: the sparse shift.  Its weight gradient is the same eight corner sums (the x corners around i - round(w),
+// fractions frac(|w|): shifts_cpu.cpp:242-244); its grad_x is ONE tap of the gradient -- go(g0[a], g1[b], gcol[j]) -- so the
+// step stages the gradient plane g0[a] itself (no "+1" plane, nothing carried) and copies the window.
+template <typename T, int PAD, bool POOL = false, bool ACTIVE = true>
 __global__ __launch_bounds__(kThreads) void walk_backward(const StepParams p) {
+    static_assert(ACTIVE || !POOL, "the pooled walk is the interpolating one");
     using S = typename T::S;
     using CT = typename T::C;
     constexpr int E = 16 / sizeof(S);
@@ -1319,7 +1323,7 @@ __global__ __launch_bounds__(kThreads) void walk_backward(const StepParams p) {
     // the pieces this thread stages, the same for every plane (see walk_forward)
     const bool own = tr < R && tr <= Rn, extra = Rn == R && tid < cpr;
     const int sx_own = own ? row_map_t<PAD>(b0 + tr, d.cx1, S1) : -1, sg_own = own ? row_map_t<PAD>(b0 + tr, d.cg1, S1) : -1;
-    const int sx_extra = extra ? row_map_t<PAD>(b0 + R, d.cx1, S1) : -1, sg_extra = extra ? row_map_t<PAD>(b0 + R, d.cg1, S1) : -1;
+    const int sx_extra = extra ? row_map_t<PAD>(b0 + R, d.cx1, S1) : -1, sg_extra = (extra && ACTIVE) ? row_map_t<PAD>(b0 + R, d.cg1, S1) : -1;
     auto piece_off = [&](int row, int piece) { return static_cast<uint32_t>(max(row, 0) * S2 + piece * E) * static_cast<uint32_t>(sizeof(S)); };
     const uint32_t ox_own = piece_off(sx_own, tc), og_own = piece_off(sg_own, tc), ox_extra = piece_off(sx_extra, tid), og_extra = piece_off(sg_extra, tid);
     const uint32_t plane_bytes = static_cast<uint32_t>(S1) * static_cast<uint32_t>(S2) * static_cast<uint32_t>(sizeof(S));
@@ -1497,17 +1501,19 @@ __global__ __launch_bounds__(kThreads) void walk_backward(const StepParams p) {
     uint32_t cxp[2][5];
     CT cx[PACKED ? 1 : 2][PACKED ? 1 : E + 1], cg[2][E + 1];   // the "+0" planes' corner rows
     {
-        const int pax0 = row_map_t<PAD>(0, d.cx0, S0), pag0 = row_map_t<PAD>(0, d.cg0, S0);
+        const int pax0 = row_map_t<PAD>(0, d.cx0, S0), pag0 = ACTIVE ? row_map_t<PAD>(0, d.cg0, S0) : -1;
         Staged v0;
         load_planes(pax0, pag0, v0);
         park(v0);
         __syncthreads();
 #pragma unroll
         for (int hb = 0; hb < 2; ++hb) {
-            S rg[E + 1];
-            window(rows_g + hb * RB, gm, fg, phg, gmask, rg);
+            if constexpr (ACTIVE) {
+                S rg[E + 1];
+                window(rows_g + hb * RB, gm, fg, phg, gmask, rg);
 #pragma unroll
-            for (int e = 0; e <= E; ++e) cg[hb][e] = widen<T>(rg[e]);
+                for (int e = 0; e <= E; ++e) cg[hb][e] = widen<T>(rg[e]);
+            }
             if constexpr (PACKED) {
                 window_packed(rows_x + hb * RB, xm, fx, phx, xmask, cxp[hb]);
             } else {
@@ -1545,7 +1551,8 @@ __global__ __launch_bounds__(kThreads) void walk_backward(const StepParams p) {
     };
     __syncthreads();   // the "+0" planes have been read
     Staged pend;       // plane a + 1 of the step about to run
-    load_planes(row_map_t<PAD>(1, d.cx0, S0), row_map_t<PAD>(1, d.cg0, S0), pend);
+    constexpr int GA = ACTIVE ? 1 : 0;   // the gradient plane of step a: the "+1" corner plane / the plane the tap reads
+    load_planes(row_map_t<PAD>(1, d.cx0, S0), row_map_t<PAD>(GA, d.cg0, S0), pend);
     u4 gcur = load_own(0, true);
     for (int a = 0; a < S0; ++a) {
         park(pend);
@@ -1553,7 +1560,7 @@ __global__ __launch_bounds__(kThreads) void walk_backward(const StepParams p) {
         // plane a + 2, in flight while this step is computed (the last step has none: empty resources; a buffer's range
         // check does not see the scalar offset)
         const bool more = a + 1 < S0;
-        load_planes(more ? row_map_t<PAD>(a + 2, d.cx0, S0) : -1, more ? row_map_t<PAD>(a + 2, d.cg0, S0) : -1, pend);
+        load_planes(more ? row_map_t<PAD>(a + 2, d.cx0, S0) : -1, more ? row_map_t<PAD>(a + 1 + GA, d.cg0, S0) : -1, pend);
         Chunk<S, E> gch;
         if constexpr (POOL) {
             const u4 ex = expand(u2{gcur.x, gcur.y}, static_cast<int>(gcur.z) * n1_my * 2);
@@ -1613,21 +1620,21 @@ __global__ __launch_bounds__(kThreads) void walk_backward(const StepParams p) {
         // the next step's own chunk: in flight through the blends below and the next step's staging
         gcur = load_own(a + 1, a + 1 < S0);
         // ---- grad_x ------------------------------------------------------------------------------------------------
-        CT rowb[2][E + 1];
-#pragma unroll
-        for (int hb = 0; hb < 2; ++hb) {
-            S rg[E + 1];
-            window(rows_g + hb * RB, gm, fg, phg, gmask, rg);
-#pragma unroll
-            for (int e = 0; e <= E; ++e) {
-                const CT nv = widen<T>(rg[e]);
-                const CT two[2] = {cg[hb][e], nv};
-                rowb[hb][e] = interp_t<T, 1>(two, &dw[0]);
-                cg[hb][e] = nv;
-            }
-        }
         Chunk<S, E> res;
-        {
+        if constexpr (ACTIVE) {
+            CT rowb[2][E + 1];
+#pragma unroll
+            for (int hb = 0; hb < 2; ++hb) {
+                S rg[E + 1];
+                window(rows_g + hb * RB, gm, fg, phg, gmask, rg);
+#pragma unroll
+                for (int e = 0; e <= E; ++e) {
+                    const CT nv = widen<T>(rg[e]);
+                    const CT two[2] = {cg[hb][e], nv};
+                    rowb[hb][e] = interp_t<T, 1>(two, &dw[0]);
+                    cg[hb][e] = nv;
+                }
+            }
             CT colb[E + 1];
 #pragma unroll
             for (int e = 0; e <= E; ++e) {
@@ -1639,6 +1646,15 @@ __global__ __launch_bounds__(kThreads) void walk_backward(const StepParams p) {
                 const CT two[2] = {colb[e], colb[e + 1]};
                 res.e[e] = narrow<T>(interp_t<T, 1>(two, &dw[2]));
             }
+        } else if constexpr (PACKED) {   // the sparse shift: a raw copy of the window (the bit pattern is kept)
+            uint32_t t[5];
+            window_packed(rows_g, gm, fg, phg, gmask, t);
+            __builtin_memcpy(res.e, t, 16);
+        } else {
+            S rg[E + 1];
+            window(rows_g, gm, fg, phg, gmask, rg);
+#pragma unroll
+            for (int e = 0; e < E; ++e) res.e[e] = rg[e];
         }
         {
             u4 bits;
@@ -2137,7 +2153,7 @@ bool walk_backward_pooled_eligible(const Geometry &g, int dtype, const void *go,
 }
 static bool walk_backward_core(const Geometry &g, int dtype, const void *go, const void *x, const void *gx, bool pooled) {
     if (g_step_tune[0] == 1 || (g_step_tune[3] & 16) || (g_step_tune[3] & 1)) return false;   // (bit 0: the one-step 3-D form)
-    if (dtype > SHIFTND_BF16 || g.nd != 3 || !g.active || g.S[0] < 2) return false;
+    if (dtype > SHIFTND_BF16 || g.nd != 3 || g.S[0] < 2 || (pooled && !g.active)) return false;
     const int es = dtype_size(dtype);
     for (int d = 0; d < 3; ++d)
         if (g.O[d] != g.S[d] || g.L[d] != 0) return false;
@@ -2154,13 +2170,15 @@ static bool walk_backward_core(const Geometry &g, int dtype, const void *go, con
     return es <= 4 || (g_step_tune[3] & 32);
 }
 
-template <typename T> static void launch_walk_backward(StepParams &p, size_t lds, void *gw, hipStream_t st) {
+template <typename T> static void launch_walk_backward(StepParams &p, size_t lds, bool active, void *gw, hipStream_t st) {
     using S = typename T::S;
     const dim3 grid(p.steps_per_xcd * 8), block(kThreads);
-    hipLaunchKernelGGL((step_prep<T, true>), dim3(p.C), block, 0, st, p);
+    if (active) hipLaunchKernelGGL((step_prep<T, true>), dim3(p.C), block, 0, st, p);
+    else hipLaunchKernelGGL((step_prep<T, false>), dim3(p.C), block, 0, st, p);
 #define SHIFTND_WALK_BWD(PADV) \
     case PADV: \
-        if (p.K0 > 0) hipLaunchKernelGGL((walk_backward<T, PADV, true>), grid, block, lds, st, p); \
+        if (!active) hipLaunchKernelGGL((walk_backward<T, PADV, false, false>), grid, block, lds, st, p); \
+        else if (p.K0 > 0) hipLaunchKernelGGL((walk_backward<T, PADV, true>), grid, block, lds, st, p); \
         else hipLaunchKernelGGL((walk_backward<T, PADV, false>), grid, block, lds, st, p); \
         break;
     switch (p.pad) { SHIFTND_WALK_BWD(0) SHIFTND_WALK_BWD(1) SHIFTND_WALK_BWD(2) SHIFTND_WALK_BWD(3) default: SHIFTND_WALK_BWD(4) }
@@ -2236,12 +2254,12 @@ int step_backward(const Geometry &g, int dtype, const void *go, const void *x, c
         p.d_spp = make_fastdiv(static_cast<uint32_t>(p.spp));
         p.d_spv = p.d_spp;
         const size_t lds = 64 + static_cast<size_t>(2 * (p.R + 1)) * L.cpr * 16 + kThreads * 16 + kThreads * 8 * sizeof(double) + 64;   // tile, dump slots, sums, pad
-        note_kernel(g.K[0] > 0 ? "walk_backward_pool" : "walk_backward");
+        note_kernel(g.K[0] > 0 ? "walk_backward_pool" : (g.active ? "walk_backward" : "walk_backward_sparse"));
         switch (dtype) {
-        case SHIFTND_F32: launch_walk_backward<f32_t>(p, lds, gw, st); break;
-        case SHIFTND_F64: launch_walk_backward<f64_t>(p, lds, gw, st); break;
-        case SHIFTND_F16: launch_walk_backward<f16_t>(p, lds, gw, st); break;
-        default: launch_walk_backward<bf16_t>(p, lds, gw, st); break;
+        case SHIFTND_F32: launch_walk_backward<f32_t>(p, lds, g.active != 0, gw, st); break;
+        case SHIFTND_F64: launch_walk_backward<f64_t>(p, lds, g.active != 0, gw, st); break;
+        case SHIFTND_F16: launch_walk_backward<f16_t>(p, lds, g.active != 0, gw, st); break;
+        default: launch_walk_backward<bf16_t>(p, lds, g.active != 0, gw, st); break;
         }
         return SHIFTND_OK;
     }

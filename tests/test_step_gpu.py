@@ -397,15 +397,16 @@ def test_3d_walk_backward_vs_oracle(abi, shape, dt):
     wide = np.float64 if tdt == torch.float64 else np.float32
     x, go, w = (t.to(torch.float64).numpy().astype(wide) for t in (xt, gt, wt))
     xd, god, wd = xt.to(DEV), gt.to(DEV), wt.to(DEV)
-    abi.set_tuning(35, 32)  # every float dtype (automatic: 16-bit only)
+    abi.set_tuning(35, 32)  # every float dtype (automatic: 2- and 4-byte elements)
     for pad in range(5):
-        gx, gw = abi.backward(god, wd, xd, pad, 1)
-        assert abi.last_kernel() == "walk_backward", (shape, abi.last_kernel())
-        gx_ref = torch.from_numpy(O.backward(go, w, x, pad, 1)[0]).to(tdt)
-        if es >= 4:
-            assert torch.equal(gx.cpu(), gx_ref), ("gx", shape, dt, pad)
-        else:
-            assert _ulp_close(gx.cpu(), gx_ref, tdt), ("gx", shape, dt, pad)
-        _, gw64 = O.backward(go.astype(np.float64), w.astype(np.float64), x.astype(np.float64), pad, 1)
-        tol = {"f32": 1e-5, "f64": 1e-12}.get(dt, 2 * float(torch.finfo(tdt).eps))
-        assert rel_err(gw.to(torch.float64).cpu().numpy(), gw64) < tol, ("gw", shape, dt, pad)
+        for active in (1, 0):   # the sparse shift: one gradient tap copied (bit-exact in every dtype), the same corner sums
+            gx, gw = abi.backward(god, wd, xd, pad, active)
+            assert abi.last_kernel() == ("walk_backward" if active else "walk_backward_sparse"), (shape, abi.last_kernel())
+            gx_ref = torch.from_numpy(O.backward(go, w, x, pad, active)[0]).to(tdt)
+            if es >= 4 or not active:
+                assert torch.equal(gx.cpu(), gx_ref), ("gx", shape, dt, pad, active)
+            else:
+                assert _ulp_close(gx.cpu(), gx_ref, tdt), ("gx", shape, dt, pad)
+            _, gw64 = O.backward(go.astype(np.float64), w.astype(np.float64), x.astype(np.float64), pad, active)
+            tol = {"f32": 1e-5, "f64": 1e-12}.get(dt, 2 * float(torch.finfo(tdt).eps))
+            assert rel_err(gw.to(torch.float64).cpu().numpy(), gw64) < tol, ("gw", shape, dt, pad, active)

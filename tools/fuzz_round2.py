@@ -212,6 +212,12 @@ def case_walk(rs):
         _, gw64 = O.backward(go.astype(np.float64), w.astype(np.float64), x.astype(np.float64), pad, 1)
         tol = {torch.float64: 1e-12, torch.float32: 1e-5}.get(tdt, 2 * float(torch.finfo(tdt).eps))
         assert rel_err(gw.to(torch.float64).cpu().numpy(), gw64) < tol, ("walk gw", shape, tdt, pad)
+        gx, gw = abi.backward(gd, wd, xd, pad, 0)   # the sparse shift through the same walk
+        assert abi.last_kernel() == "walk_backward_sparse", (shape, tdt, abi.last_kernel())
+        count["walk_backward_sparse"] += 1
+        assert torch.equal(gx.cpu(), torch.from_numpy(O.backward(go, w, x, pad, 0)[0]).to(tdt)), ("walk sparse gx", shape, tdt, pad)
+        _, gw64 = O.backward(go.astype(np.float64), w.astype(np.float64), x.astype(np.float64), pad, 0)
+        assert rel_err(gw.to(torch.float64).cpu().numpy(), gw64) < tol, ("walk sparse gw", shape, tdt, pad)
         if tdt != torch.float64:
             pool = (int(rs.randint(1, 4)), int(rs.randint(1, 4)), 2)
             y = O.forward(x, w, pad, 1)

@@ -173,7 +173,8 @@ int shiftnd_last_path(void) { return g_last_path; }
 void shiftnd_set_path_policy(int policy) { g_policy = policy; }
 
 void shiftnd_set_tuning(int knob, int value) {
-    if (knob >= 36) qpool_set_tuning(knob - 36, value);  // 36: quantized pool 0 automatic / 1 the element-per-thread kernel only
+    if (knob >= 38) step_set_tuning(4 + knob - 38, value);  // 38: planes per workgroup of the walk kernels
+    else if (knob >= 36) qpool_set_tuning(knob - 36, value);  // 36: quantized pool 0 automatic / 1 the element-per-thread kernel only
     else if (knob >= 32) step_set_tuning(knob - 32, value);  // 32: one-step backward 0 automatic / 1 never / 2 whenever eligible
     else if (knob >= 28) rows_set_tuning(knob - 28, value);  // 28: element sizes served (bit 0: 1 byte, bit 1: 2 bytes), 29: rows per band, 30: workgroups
     else if (knob >= 24) small_set_tuning(knob - 24, value);  // 24: small-plane kernels on / off, 25: planes per round, 26: rounds per workgroup

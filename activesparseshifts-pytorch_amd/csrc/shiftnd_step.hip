@@ -40,7 +40,7 @@ namespace shiftnd {
 namespace {
 
 // knobs (shiftnd_set_tuning 32..): [0] backward, [1] gather forward (direct loads), [2] forwards through LDS: 0 = automatic, 1 = never, 2 = whenever eligible; [3] bit 0: 3-D backward too, bit 1 / bit 2: one / two row groups per thread always, bit 3: 3-D forwards through LDS too
-thread_local int g_step_tune[4] = {0, 0, 0, 0};
+thread_local int g_step_tune[5] = {0, 0, 0, 0, 0};   // [4]: planes per workgroup of the walk kernels (0 = all)
 
 struct ChanDesc {  // per channel, written by step_prep
     int cx0, cg0;  // plane maps (3-D; 0 for 2-D):  m0[p] = fold_index(p - cx0, S0, pad), g0[p] likewise with cg0
@@ -74,6 +74,7 @@ struct StepParams {
     FastDiv d_k1, d_k2;
     int K0, P0;         // 3-D pooled calls (walk_backward<..., POOL>): window and pooled size along dim0
     FastDiv d_k0;
+    int walk_planes;    // walk_backward: planes a workgroup walks through (S0, or a part of the volume's depth)
 };
 
 template <int E> struct RecSize { static constexpr int N = (E + 3 <= 8) ? 8 : 16; };  // int16 entries per record
@@ -1286,8 +1287,11 @@ __global__ __launch_bounds__(kThreads) void walk_backward(const StepParams p) {
 
     const uint32_t bid = (blockIdx.x & 7u) * p.steps_per_xcd + (blockIdx.x >> 3);
     if (bid >= p.total_steps) return;
-    const uint32_t plane = fdiv(bid, p.d_spp);   // (n, c)
-    const int step = static_cast<int>(bid - plane * static_cast<uint32_t>(p.spp));
+    const uint32_t plane = fdiv(bid, p.d_spv);   // (n, c); its spv = (depth parts) * (row steps) workgroups
+    const uint32_t vrem = bid - plane * static_cast<uint32_t>(p.spv);
+    const int dq = static_cast<int>(fdiv(vrem, p.d_spp));
+    const int step = static_cast<int>(vrem) - dq * p.spp;
+    const int a0 = dq * p.walk_planes, a1 = min(p.S0, a0 + p.walk_planes);   // the planes this workgroup walks through
     const int c = static_cast<int>(plane - fdiv(plane, p.d_C) * static_cast<uint32_t>(p.C));
     const ChanDesc d = p.desc[c];
     const int R = p.R, S0 = p.S0, S1 = p.S1, S2 = p.S2, cpr = p.cpr;
@@ -1501,7 +1505,7 @@ __global__ __launch_bounds__(kThreads) void walk_backward(const StepParams p) {
     uint32_t cxp[2][5];
     CT cx[PACKED ? 1 : 2][PACKED ? 1 : E + 1], cg[2][E + 1];   // the "+0" planes' corner rows
     {
-        const int pax0 = row_map_t<PAD>(0, d.cx0, S0), pag0 = ACTIVE ? row_map_t<PAD>(0, d.cg0, S0) : -1;
+        const int pax0 = row_map_t<PAD>(a0, d.cx0, S0), pag0 = ACTIVE ? row_map_t<PAD>(a0, d.cg0, S0) : -1;
         Staged v0;
         load_planes(pax0, pag0, v0);
         park(v0);
@@ -1552,14 +1556,14 @@ __global__ __launch_bounds__(kThreads) void walk_backward(const StepParams p) {
     __syncthreads();   // the "+0" planes have been read
     Staged pend;       // plane a + 1 of the step about to run
     constexpr int GA = ACTIVE ? 1 : 0;   // the gradient plane of step a: the "+1" corner plane / the plane the tap reads
-    load_planes(row_map_t<PAD>(1, d.cx0, S0), row_map_t<PAD>(GA, d.cg0, S0), pend);
-    u4 gcur = load_own(0, true);
-    for (int a = 0; a < S0; ++a) {
+    load_planes(row_map_t<PAD>(a0 + 1, d.cx0, S0), row_map_t<PAD>(a0 + GA, d.cg0, S0), pend);
+    u4 gcur = load_own(a0, true);
+    for (int a = a0; a < a1; ++a) {
         park(pend);
         __syncthreads();
         // plane a + 2, in flight while this step is computed (the last step has none: empty resources; a buffer's range
         // check does not see the scalar offset)
-        const bool more = a + 1 < S0;
+        const bool more = a + 1 < a1;
         load_planes(more ? row_map_t<PAD>(a + 2, d.cx0, S0) : -1, more ? row_map_t<PAD>(a + 1 + GA, d.cg0, S0) : -1, pend);
         Chunk<S, E> gch;
         if constexpr (POOL) {
@@ -1618,7 +1622,7 @@ __global__ __launch_bounds__(kThreads) void walk_backward(const StepParams p) {
                 for (int e = 0; e <= E; ++e) cx[hb][e] = nx[hb][e];
         }
         // the next step's own chunk: in flight through the blends below and the next step's staging
-        gcur = load_own(a + 1, a + 1 < S0);
+        gcur = load_own(a + 1, a + 1 < a1);
         // ---- grad_x ------------------------------------------------------------------------------------------------
         Chunk<S, E> res;
         if constexpr (ACTIVE) {
@@ -1661,7 +1665,7 @@ __global__ __launch_bounds__(kThreads) void walk_backward(const StepParams p) {
             __builtin_memcpy(&bits, res.e, 16);
             __builtin_amdgcn_raw_buffer_store_b128(bits, ores, my, static_cast<uint32_t>(a) * plane_bytes, 0);
         }
-        if ((a & 3) == 3 || a == S0 - 1) {
+        if ((a & 3) == 3 || a == a1 - 1) {
 #pragma unroll
             for (int i = 0; i < NS; ++i) {
                 accs[i * kThreads] += static_cast<double>(part[i]);
@@ -1817,7 +1821,7 @@ int launch_step_backward(StepParams &p, const StepLayout &L, bool active, void *
 }  // namespace
 
 void step_set_tuning(int knob, int value) {
-    if (knob >= 0 && knob < 4) g_step_tune[knob] = value;
+    if (knob >= 0 && knob < 5) g_step_tune[knob] = value;
 }
 
 // contiguous 2-D / 3-D problems without crop whose rows are whole 16-byte pieces and at most one workgroup pass wide
@@ -2247,12 +2251,16 @@ int step_backward(const Geometry &g, int dtype, const void *go, const void *x, c
         const int rmax = std::min<int>(kThreads / L.cpr, p.S1);
         p.spp = (p.S1 + rmax - 1) / rmax;
         p.R = (p.S1 + p.spp - 1) / p.spp;
-        p.spv = p.spp;
-        const uint64_t total = static_cast<uint64_t>(g.N) * g.C * p.spp;
+        // planes per workgroup (knob 38): all of them, or a part of the depth -- more, shorter workgroups, one more staged plane each
+        p.walk_planes = (g_step_tune[4] > 0 && g_step_tune[4] < p.S0) ? g_step_tune[4] : p.S0;
+        const int dparts = (p.S0 + p.walk_planes - 1) / p.walk_planes;
+        p.spv = dparts * p.spp;
+        const uint64_t total = static_cast<uint64_t>(g.N) * g.C * p.spv;
+        if (total > L.total_steps) return SHIFTND_ERR_WORKSPACE_TOO_SMALL;   // (cannot happen: dparts <= S0, spp <= the one-step plan's)
         p.total_steps = static_cast<uint32_t>(total);
         p.steps_per_xcd = static_cast<uint32_t>((total + 7) / 8);
         p.d_spp = make_fastdiv(static_cast<uint32_t>(p.spp));
-        p.d_spv = p.d_spp;
+        p.d_spv = make_fastdiv(static_cast<uint32_t>(p.spv));
         const size_t lds = 64 + static_cast<size_t>(2 * (p.R + 1)) * L.cpr * 16 + kThreads * 16 + kThreads * 8 * sizeof(double) + 64;   // tile, dump slots, sums, pad
         note_kernel(g.K[0] > 0 ? "walk_backward_pool" : (g.active ? "walk_backward" : "walk_backward_sparse"));
         switch (dtype) {

@@ -113,7 +113,8 @@ SHIFTND_API void shiftnd_set_path_policy(int policy);
  * workgroup), 28-30 one-byte row kernel (28: element sizes served, 29: rows per band, 30: workgroups wanted), 32-35
  * one-step kernels (32: 2-D backward, 33: sparse-shift forward by direct loads, 34: forwards through LDS; each 0 =
  * automatic, 1 = never, 2 = whenever eligible; 35: bit set of opt-in forms, csrc/shiftnd_step.hip), 36-37 quantized
- * pool (36: 1 = the element-per-thread kernel only, 37: workgroups wanted); for the sizing knobs 0 means automatic.
+ * pool (36: 1 = the element-per-thread kernel only, 37: workgroups wanted), 38 planes per workgroup of the 3-D walk
+ * kernels; for the sizing knobs 0 means automatic.
  * Results never depend on them.
  * shiftnd_backward_workspace_bytes plans with the calling thread's knobs: size and run on the same thread. */
 SHIFTND_API void shiftnd_set_tuning(int knob, int value);

@@ -404,6 +404,11 @@ int shiftnd_forward_pooled(const shiftnd_problem *p, const int32_t *pool, const 
         return SHIFTND_OK;
     }
     if (!x || !weights || !out) return SHIFTND_ERR_INVALID_ARGUMENT;
+    // 3-D interpolating: the walk through the planes with the pool as its epilogue
+    if (g_policy == 0 && walk_forward_pooled_eligible(g, p->dtype, x, out)) {
+        g_last_path = SHIFTND_PATH_PLANE;
+        return finish(walk_forward(g, p->dtype, x, weights, p->dtype, out, static_cast<hipStream_t>(stream)));
+    }
     if (!plane_pool_forward_eligible(g, p->dtype)) return SHIFTND_ERR_NOT_FUSED;
     g_last_path = SHIFTND_PATH_PLANE;
     return finish(plane_pool_forward(g, p->dtype, x, weights, out, static_cast<hipStream_t>(stream)));

@@ -909,6 +909,10 @@ struct FwdParams {
     int spv;                 // steps per (n, c): O0 * spp
     uint32_t total_steps, steps_per_xcd;
     FastDiv d_spp, d_spv, d_C, d_cpr, d_xppr, d_per0, d_per1, d_per2;
+    // walk_forward<..., POOL>: average pool (K0, K1, 2) behind the shift; `out` is the pooled tensor [N, C, P0, P1, P2]
+    int K0, K1, P1, P2;
+    int64_t p_plane;   // pooled elements per (n, c)
+    FastDiv d_k0;
 };
 
 // the nd weights of channel c in normalised order (plane, row, inner; leading dims 0), widened, through the scalar cache
@@ -1132,7 +1136,12 @@ __global__ __launch_bounds__(kThreads) void step_forward_lds(const FwdParams p) 
 // reference nests them (plane, row, inner: interpolation.h:34-40; same bits as interp_nd).  Contiguous 3-D tensors
 // without crop; every float dtype.
 // ---------------------------------------------------------------------------------------------------------------------
-template <typename T, int PAD>
+// POOL: the module's average pool (windows (K0, K1, 2), K1 <= 2, ceil mode) as the epilogue: a plane's values are rounded to the
+// storage type like the two-step sequence's shift output and summed in ATen's order -- plane, row, column -- in the compute
+// type: the two columns of a window sit in one thread, its planes arrive in consecutive steps (the sum stays in registers),
+// and the second row belongs to the thread one row down, which leaves its chunk in LDS for the next step (two alternating
+// slots: no extra barrier).  Only the pooled tensor is written.
+template <typename T, int PAD, bool POOL = false>
 __global__ __launch_bounds__(kThreads) void walk_forward(const FwdParams p) {
     using S = typename T::S;
     using CT = typename T::C;
@@ -1162,7 +1171,7 @@ __global__ __launch_bounds__(kThreads) void walk_forward(const FwdParams p) {
     const int b0 = step * R;
     const int Rn = min(R, p.O1 - b0);
     const char *xp = reinterpret_cast<const char *>(static_cast<const S *>(p.x) + static_cast<int64_t>(plane) * p.x_plane);
-    S *op = static_cast<S *>(p.out) + static_cast<int64_t>(plane) * p.o_plane;
+    S *op = static_cast<S *>(p.out) + static_cast<int64_t>(plane) * (POOL ? p.p_plane : p.o_plane);
 
     const int tid = static_cast<int>(threadIdx.x);
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1223,6 +1232,38 @@ __global__ __launch_bounds__(kThreads) void walk_forward(const FwdParams p) {
     }
     const int64_t out_plane = static_cast<int64_t>(p.O1) * p.O2;
     S *orow = op + static_cast<int64_t>(b) * p.O2 + jo;
+    // POOL state: the thread that owns the first row of a window (every thread when K1 == 1) accumulates its E / 2 windows
+    typedef uint32_t u4 __attribute__((ext_vector_type(4)));
+    char *xch = tile + (R + 1) * RBL + 64;                         // [2][kThreads] chunks: the second rows of the windows
+    const bool pairs = POOL && p.K1 == 2;
+    const bool first_row = POOL && mine && (!pairs || (tr & 1) == 0);
+    const int n1 = pairs ? min(2, p.O1 - b) : 1;                  // rows of this thread's windows (a ragged last row: 1)
+    const int pr = pairs ? (b >> 1) : b;
+    CT pacc[E / 2 > 0 ? E / 2 : 1];
+    Chunk<S, E> prev;                                             // this thread's chunk of the previous plane
+    auto pool_plane = [&](int ap) {   // fold plane ap (own chunk `prev`, the row below from the exchange slot) into the windows
+        const int pp = static_cast<int>(fdiv(static_cast<uint32_t>(ap), p.d_k0));
+        const int u0 = ap - pp * p.K0, n0 = min(p.K0, p.O0 - pp * p.K0);
+        if (u0 == 0) {
+#pragma unroll
+            for (int j = 0; j < E / 2; ++j) pacc[j] = CT(0);
+        }
+#pragma unroll
+        for (int j = 0; j < E / 2; ++j) pacc[j] = (pacc[j] + widen<T>(prev.e[2 * j])) + widen<T>(prev.e[2 * j + 1]);
+        if (n1 == 2) {
+            Chunk<S, E> below;
+            __builtin_memcpy(below.e, __builtin_assume_aligned(xch + ((ap & 1) * kThreads + tid) * 16, 16), 16);
+#pragma unroll
+            for (int j = 0; j < E / 2; ++j) pacc[j] = (pacc[j] + widen<T>(below.e[2 * j])) + widen<T>(below.e[2 * j + 1]);
+        }
+        if (u0 == n0 - 1) {
+            Chunk<S, (E / 2 > 0 ? E / 2 : 1)> outc;
+#pragma unroll
+            for (int j = 0; j < E / 2; ++j) outc.e[j] = narrow<T>(div_count<CT>(pacc[j], n0 * n1 * 2));
+            S *dst = op + (static_cast<int64_t>(pp) * p.P1 + pr) * p.P2 + jo / 2;
+            __builtin_memcpy(__builtin_assume_aligned(dst, sizeof(S) * E / 2), outc.e, sizeof(S) * (E / 2));
+        }
+    };
     for (int a = 0; a < p.O0; ++a) {
         const int pa1 = row_map_t<PAD>(a + 1, cs0, S0);
         __syncthreads();   // everybody has read the previous plane
@@ -1254,7 +1295,17 @@ __global__ __launch_bounds__(kThreads) void walk_forward(const FwdParams p) {
             const CT two[2] = {colb[e], colb[e + 1]};
             res.e[e] = narrow<T>(interp_t<T, 1>(two, &dw[2]));
         }
-        if (mine) store_chunk<S, E>(orow + a * out_plane, res);
+        if constexpr (POOL) {
+            if (first_row && a > 0) pool_plane(a - 1);   // (the row below left its chunk of plane a - 1 before this step's barriers)
+            prev = res;
+            if (pairs && mine && (tr & 1)) __builtin_memcpy(__builtin_assume_aligned(xch + ((a & 1) * kThreads + tid - cpr) * 16, 16), res.e, 16);
+        } else {
+            if (mine) store_chunk<S, E>(orow + a * out_plane, res);
+        }
+    }
+    if constexpr (POOL) {
+        __syncthreads();
+        if (first_row) pool_plane(p.O0 - 1);
     }
 }
 
@@ -2070,7 +2121,16 @@ int step_forward_lds(const Geometry &g, int dtype, const void *x, const void *w,
 
 // the 3-D interpolating forward as a walk through the planes: contiguous, no crop, rows of whole 16-byte pieces and at most
 // one workgroup pass wide
+static bool walk_forward_core(const Geometry &g, int dtype, const void *x, const void *out, bool pooled);
 bool walk_forward_eligible(const Geometry &g, int dtype, const void *x, const void *out) {
+    return g.K[0] <= 0 && walk_forward_core(g, dtype, x, out, false);
+}
+// the fused shift + average pool forward in 3-D (interpolating): windows (K0, K1 <= 2, 2), `out` = the pooled tensor, contiguous
+bool walk_forward_pooled_eligible(const Geometry &g, int dtype, const void *x, const void *out) {
+    if (!(g.K[0] > 0 && g.nd == 3) || g.K[2] != 2 || g.K[1] < 1 || g.K[1] > 2) return false;
+    return walk_forward_core(g, dtype, x, out, true);
+}
+static bool walk_forward_core(const Geometry &g, int dtype, const void *x, const void *out, bool pooled) {
     if (g_step_tune[2] == 1 || (g_step_tune[3] & 16)) return false;   // knob 34 = 1: no forwards through LDS; knob 35 bit 4: no walk
     if (dtype > SHIFTND_BF16 || g.nd != 3 || !g.active) return false;
     const int es = dtype_size(dtype);
@@ -2080,12 +2140,13 @@ bool walk_forward_eligible(const Geometry &g, int dtype, const void *x, const vo
     if (xe < 1 || xe >= (1LL << 30) || g.S[2] > 32000 || g.S[0] < 2) return false;
     if ((g.S[2] * es) % 16 != 0 || g.S[2] * es / 16 > kThreads) return false;
     if (reinterpret_cast<uintptr_t>(x) % 16 != 0 || reinterpret_cast<uintptr_t>(out) % 16 != 0) return false;
-    if (!dense(g.xs, g.N, g.C, g.S) || !dense(g.os, g.N, g.C, g.O)) return false;
+    if (!dense(g.xs, g.N, g.C, g.S) || (!pooled && !dense(g.os, g.N, g.C, g.O))) return false;
     const int64_t cpr = g.S[2] * es / 16;
     const int64_t rmax = std::min<int64_t>(kThreads / cpr, g.S[1]);
-    if (64 + (rmax + 1) * cpr * 16 + 64 > 64 * 1024) return false;
+    if (64 + (rmax + 2) * cpr * 16 + 64 + 2 * kThreads * 16 + 64 > 64 * 1024) return false;
     const int64_t spp = (g.S[1] + rmax - 1) / rmax;
-    if (g.N * g.C * spp + 8 >= (1LL << 31)) return false;
+    if (g.N * g.C * (spp + 1) + 8 >= (1LL << 31)) return false;
+    if (pooled) return rmax >= 2 || g.K[1] == 1;   // (a window's two rows live in one workgroup)
     // 16-bit data (C3: 0.179 -> 0.154 ms); 4- / 8-byte elements are as fast on step_forward_lds (N8 C128 16x112x112 fp32: 0.285
     // vs 0.301 ms) unless asked for (knob 35 bit 5)
     return es == 2 || (g_step_tune[3] & 32);
@@ -2108,6 +2169,19 @@ int walk_forward(const Geometry &g, int dtype, const void *x, const void *w, int
     const int rmax = std::min<int>(kThreads / p.cpr, p.S1);
     p.spp = (p.S1 + rmax - 1) / rmax;
     p.R = (p.S1 + p.spp - 1) / p.spp;   // balanced steps: 112 rows of 14 pieces -> 7 steps of 16 rows, not 6 of 18 and one of 4
+    const bool pooled = g.K[0] > 0;
+    if (pooled) {
+        p.K0 = static_cast<int>(g.K[0]);
+        p.K1 = static_cast<int>(g.K[1]);
+        p.P1 = static_cast<int>(g.P[1]);
+        p.P2 = static_cast<int>(g.P[2]);
+        p.p_plane = g.P[0] * g.P[1] * g.P[2];
+        p.d_k0 = make_fastdiv(static_cast<uint32_t>(p.K0));
+        if (p.K1 == 2 && (p.R & 1)) {   // a window's two rows in one workgroup: an even number of rows per step
+            p.R = p.R + 1 <= rmax ? p.R + 1 : p.R - 1;
+            p.spp = (p.S1 + p.R - 1) / p.R;
+        }
+    }
     p.spv = p.spp;
     const uint64_t total = static_cast<uint64_t>(g.N) * g.C * p.spp;
     p.total_steps = static_cast<uint32_t>(total);
@@ -2120,17 +2194,16 @@ int walk_forward(const Geometry &g, int dtype, const void *x, const void *w, int
     p.d_per0 = make_fastdiv(static_cast<uint32_t>(map_period(p.S0, g.pad)));
     p.d_per1 = make_fastdiv(static_cast<uint32_t>(map_period(p.S1, g.pad)));
     p.d_per2 = make_fastdiv(static_cast<uint32_t>(map_period(p.S2, g.pad)));
-    const size_t lds = 64 + static_cast<size_t>(p.R + 1) * p.cpr * 16 + 64;
+    const size_t lds = 64 + static_cast<size_t>(p.R + 1) * p.cpr * 16 + 64 + (pooled ? 2 * kThreads * 16 + 64 : 0);   // tile (+ exchange slots)
     const dim3 grid(p.steps_per_xcd * 8), block(kThreads);
-    note_kernel("walk_forward");
+    note_kernel(pooled ? "walk_forward_pool" : "walk_forward");
+#define SHIFTND_WALK_FWD_PAD(T, PADV) \
+    case PADV: \
+        if (pooled) hipLaunchKernelGGL((walk_forward<T, PADV, true>), grid, block, lds, st, p); \
+        else hipLaunchKernelGGL((walk_forward<T, PADV, false>), grid, block, lds, st, p); \
+        break;
 #define SHIFTND_WALK_FWD(T) \
-    switch (g.pad) { \
-    case 0: hipLaunchKernelGGL((walk_forward<T, 0>), grid, block, lds, st, p); break; \
-    case 1: hipLaunchKernelGGL((walk_forward<T, 1>), grid, block, lds, st, p); break; \
-    case 2: hipLaunchKernelGGL((walk_forward<T, 2>), grid, block, lds, st, p); break; \
-    case 3: hipLaunchKernelGGL((walk_forward<T, 3>), grid, block, lds, st, p); break; \
-    default: hipLaunchKernelGGL((walk_forward<T, 4>), grid, block, lds, st, p); break; \
-    }
+    switch (g.pad) { SHIFTND_WALK_FWD_PAD(T, 0) SHIFTND_WALK_FWD_PAD(T, 1) SHIFTND_WALK_FWD_PAD(T, 2) SHIFTND_WALK_FWD_PAD(T, 3) default: SHIFTND_WALK_FWD_PAD(T, 4) }
     switch (dtype) {
     case SHIFTND_F32: SHIFTND_WALK_FWD(f32_t) break;
     case SHIFTND_F64: SHIFTND_WALK_FWD(f64_t) break;
@@ -2138,6 +2211,7 @@ int walk_forward(const Geometry &g, int dtype, const void *x, const void *w, int
     default: SHIFTND_WALK_FWD(bf16_t) break;
     }
 #undef SHIFTND_WALK_FWD
+#undef SHIFTND_WALK_FWD_PAD
     return SHIFTND_OK;
 }
 

@@ -58,7 +58,10 @@ def test_pooled_vs_oracle(abi, dt):
                 ref = O.forward_pooled(x, w, pad, active, pool, b)
                 xd, wd = _dev(x), _dev(w)
                 out = abi.forward_pooled(xd, wd, pad, active, pool, b)
-                assert abi.last_kernel() == "plane_pool_forward"
+                # (3-D interpolating, windows (K0, K1 <= 2, 2), no crop, rows of whole 16-byte pieces: the walk through the planes)
+                fwalk = (nd == 3 and active and crop is None and pool[-1] == 2 and shape[2] >= 2 and (shape[-1] * x.itemsize) % 16 == 0
+                         and (pool[-2] == 1 or (pool[-2] == 2 and shape[3] >= 2)))
+                assert abi.last_kernel() == ("walk_forward_pool" if fwalk else "plane_pool_forward"), key
                 assert list(out.shape) == list(ref.shape), key
                 assert np.array_equal(out.cpu().numpy(), ref), key
                 gp = rs.uniform(-1, 1, size=ref.shape).astype(dt)
@@ -252,8 +255,8 @@ def test_quantized_pooled_forward_vs_oracle(abi, npdt):
 @pytest.mark.parametrize("shape,pool", [((2, 3, 5, 7, 16), (2, 2, 2)), ((1, 2, 6, 9, 32), (3, 2, 2)), ((1, 2, 4, 40, 112), (1, 2, 2)),
                                         ((2, 2, 9, 33, 64), (2, 3, 2)), ((1, 3, 2, 1, 8), (2, 2, 2))])
 def test_pooled_3d_walk_backward(abi, shape, pool, dt):
-    """walk_backward<..., POOL>: the 3-D interpolating shift + average pool backward in one pass (the pooled gradient expanded on
-    its way into LDS).  fp32: grad_x bit-exact with the oracle's fused backward, grad_w within 1e-5; 16-bit: against the two-step
+    """walk_forward<..., POOL> / walk_backward<..., POOL>: the 3-D interpolating shift + average pool in one pass each way (the
+    pool as the forward walk's epilogue; the pooled gradient expanded on its way into LDS).  fp32: grad_x bit-exact with the oracle's fused backward, grad_w within 1e-5; 16-bit: against the two-step
     sequence on widened values (the unpooled gradient rounded to the storage type, as ATen's avg_pool backward returns it);
     ragged windows along planes and rows, every padding"""
     tdt = {"f32": torch.float32, "f16": torch.float16, "bf16": torch.bfloat16}[dt]
@@ -269,6 +272,15 @@ def test_pooled_3d_walk_backward(abi, shape, pool, dt):
     for pad in range(5):
         y = O.forward(x, w, pad, 1, b)
         pshape = O.avg_pool(y, pool).shape
+        # the forward: walk_forward<..., POOL> for windows (K0, K1 <= 2, 2) (the pool as the walk's epilogue), else the plane kernel
+        out = abi.forward_pooled(xt.to(DEV), wt.to(DEV), pad, 1, pool, b)
+        fwalk = pool[1] == 1 or (pool[1] == 2 and shape[3] >= 2)   # (a window's two rows live in one workgroup)
+        assert abi.last_kernel() == ("walk_forward_pool" if fwalk else "plane_pool_forward"), (shape, pool, abi.last_kernel())
+        if dt == "f32":
+            assert np.array_equal(out.cpu().numpy(), O.forward_pooled(x, w, pad, 1, pool, b)), ("fwd", shape, pool, pad)
+        else:
+            ref = O.avg_pool(torch.from_numpy(y).to(tdt).float().numpy(), pool)
+            assert np.max(np.abs(out.float().cpu().numpy() - ref)) <= eps * max(1.0, np.max(np.abs(ref))), ("fwd", shape, pool, pad)
         gpt = torch.from_numpy(rs.uniform(-1, 1, size=pshape).astype(np.float32)).to(tdt)
         gx, gw = abi.backward_pooled(gpt.to(DEV), wt.to(DEV), xt.to(DEV), pad, 1, pool, b)
         assert abi.last_kernel() == "walk_backward_pool", (shape, pool, abi.last_kernel())

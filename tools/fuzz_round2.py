@@ -222,6 +222,15 @@ def case_walk(rs):
             pool = (int(rs.randint(1, 4)), int(rs.randint(1, 4)), 2)
             y = O.forward(x, w, pad, 1)
             gpt = torch.from_numpy(rs.uniform(-1, 1, size=O.avg_pool(y, pool).shape)).to(tdt)
+            outp = abi.forward_pooled(xd, wd, pad, 1, pool)
+            fwalk = pool[1] == 1 or (pool[1] == 2 and H >= 2)
+            assert abi.last_kernel() == ("walk_forward_pool" if fwalk else "plane_pool_forward"), (shape, tdt, pool, abi.last_kernel())
+            count[abi.last_kernel()] += 1
+            if tdt == torch.float32:
+                assert np.array_equal(outp.cpu().numpy(), O.forward_pooled(x, w, pad, 1, pool)), ("walk pool fwd", shape, pool, pad)
+            else:
+                refp = O.avg_pool(torch.from_numpy(y).to(tdt).float().numpy(), pool)
+                assert np.max(np.abs(outp.float().cpu().numpy() - refp)) <= float(torch.finfo(tdt).eps) * max(1.0, np.max(np.abs(refp))), ("walk pool fwd", shape, tdt, pool, pad)
             gx, gw = abi.backward_pooled(gpt.to(DEV), wd, xd, pad, 1, pool)
             assert abi.last_kernel() == "walk_backward_pool", (shape, tdt, pool, abi.last_kernel())
             count["walk_backward_pool"] += 1

@@ -28,6 +28,14 @@
 //   step_forward_lds            forwards through LDS: interpolating (2-D every float dtype, 3-D 4- / 8-byte) and the 2-byte
 //                          sparse shift; 3-D blends shared along the reference's nesting.
 //   step_active_forward_direct  interpolating forward by raw-buffer windows, no LDS (on request: slower than the LDS form).
+//   walk_forward / walk_backward  3-D problems as a walk through the PLANES (the one exception to "one step per workgroup"): a
+//                          workgroup owns R rows of one (n, c) volume and steps through its planes; the "+1" corner plane of a
+//                          step is the "+0" plane of the next and stays in registers, so a step stages one plane per tensor
+//                          and reads two windows instead of four (the one-step 3-D kernels are bound by exactly that work).
+//                          Forward: interpolating; POOL: the module's average pool as the epilogue.  Backward: interpolating
+//                          and sparse shift; packed v_dot2c corner sums for 16-bit data, register-prefetched staging,
+//                          conflict-free window reads (lds_window6); POOL: the pooled gradient expanded on its way into LDS.
+//                          Partials and reduction as for step_backward (one record per workgroup).
 //
 // Reference behaviour restated: kernels/shifts_kernels.h:156-220 (forward), :222-327 (backward), :132-154 (weight
 // gradients), :532-571 (quantized); kernels/interpolation.h:3-61; cuda/shifts_cuda.cu:168-199, :202-345 (weight
@@ -39,7 +47,7 @@
 namespace shiftnd {
 namespace {
 
-// knobs (shiftnd_set_tuning 32..): [0] backward, [1] gather forward (direct loads), [2] forwards through LDS: 0 = automatic, 1 = never, 2 = whenever eligible; [3] bit 0: 3-D backward too, bit 1 / bit 2: one / two row groups per thread always, bit 3: 3-D forwards through LDS too
+// knobs (shiftnd_set_tuning 32..): [0] backward, [1] gather forward (direct loads), [2] forwards through LDS: 0 = automatic, 1 = never, 2 = whenever eligible; [3] bit 0: 3-D backward in the one-step form, bit 1 / bit 2: one / two row groups per thread always, bit 3: 3-D forwards through LDS too, bit 4: no walk kernels, bit 5: walk kernels for every float dtype
 thread_local int g_step_tune[5] = {0, 0, 0, 0, 0};   // [4]: planes per workgroup of the walk kernels (0 = all)
 
 struct ChanDesc {  // per channel, written by step_prep

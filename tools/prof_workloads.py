@@ -54,6 +54,17 @@ def main():
     xq2 = torch.randint(0, 255, (128, 512, 56, 56), dtype=torch.uint8, device=dev)
     oq2 = abi.forward_quantized_pooled(xq2, wq, 128, 3, 0, 2)
     calls.append(lambda: abi.forward_quantized_pooled(xq2, wq, 128, 3, 0, 2, out=oq2))
+    # the 3-D walk kernels outside bench.py's C3: sparse shift, pooled forward / backward (N8 C128 16x112x112 bf16)
+    x3 = torch.rand(8, 128, 16, 112, 112, device=dev).bfloat16()
+    g3 = torch.rand_like(x3)
+    w3 = (torch.rand(128, 3, device=dev) * 6 - 3).bfloat16()
+    gx3, gw3 = torch.empty_like(x3), torch.empty_like(w3)
+    ws3 = abi.backward_workspace(x3, 0, 0)
+    gp3 = torch.rand(abi.pooled_shape(x3, 2), device=dev).bfloat16()
+    op3 = abi.forward_pooled(x3, w3, 0, 1, 2)
+    calls += [lambda: abi.backward(g3, w3, x3, 0, 0, grad_x=gx3, grad_w=gw3, workspace=ws3),
+              lambda: abi.forward_pooled(x3, w3, 0, 1, 2, out=op3),
+              lambda: abi.backward_pooled(gp3, w3, x3, 0, 1, 2, grad_x=gx3, grad_w=gw3)]
     for f in calls:
         for _ in range(a.iters):
             f()

@@ -1335,7 +1335,6 @@ __global__ __launch_bounds__(kThreads) void walk_forward(const FwdParams p) {
 // step stages the gradient plane g0[a] itself (no "+1" plane, nothing carried) and copies the window.
 template <typename T, int PAD, bool POOL = false, bool ACTIVE = true>
 __global__ __launch_bounds__(kThreads) void walk_backward(const StepParams p) {
-    static_assert(ACTIVE || !POOL, "the pooled walk is the interpolating one");
     using S = typename T::S;
     using CT = typename T::C;
     constexpr int E = 16 / sizeof(S);
@@ -2229,7 +2228,7 @@ static bool walk_backward_core(const Geometry &g, int dtype, const void *go, con
 bool walk_backward_eligible(const Geometry &g, int dtype, const void *go, const void *x, const void *gx) {
     return g.K[0] <= 0 && walk_backward_core(g, dtype, go, x, gx, false);
 }
-// the fused shift + average-pool backward in 3-D (interpolating): `go` = gradient of the pooled output, contiguous; windows
+// the fused shift + average-pool backward in 3-D (both shifts): `go` = gradient of the pooled output, contiguous; windows
 // (K0, K1, 2)
 bool walk_backward_pooled_eligible(const Geometry &g, int dtype, const void *go, const void *x, const void *gx) {
     if (!(g.K[0] > 0 && g.nd == 3) || g.K[2] != 2 || g.K[1] < 1) return false;
@@ -2239,7 +2238,7 @@ bool walk_backward_pooled_eligible(const Geometry &g, int dtype, const void *go,
 }
 static bool walk_backward_core(const Geometry &g, int dtype, const void *go, const void *x, const void *gx, bool pooled) {
     if (g_step_tune[0] == 1 || (g_step_tune[3] & 16) || (g_step_tune[3] & 1)) return false;   // (bit 0: the one-step 3-D form)
-    if (dtype > SHIFTND_BF16 || g.nd != 3 || g.S[0] < 2 || (pooled && !g.active)) return false;
+    if (dtype > SHIFTND_BF16 || g.nd != 3 || g.S[0] < 2) return false;
     const int es = dtype_size(dtype);
     for (int d = 0; d < 3; ++d)
         if (g.O[d] != g.S[d] || g.L[d] != 0) return false;
@@ -2263,7 +2262,8 @@ template <typename T> static void launch_walk_backward(StepParams &p, size_t lds
     else hipLaunchKernelGGL((step_prep<T, false>), dim3(p.C), block, 0, st, p);
 #define SHIFTND_WALK_BWD(PADV) \
     case PADV: \
-        if (!active) hipLaunchKernelGGL((walk_backward<T, PADV, false, false>), grid, block, lds, st, p); \
+        if (!active && p.K0 > 0) hipLaunchKernelGGL((walk_backward<T, PADV, true, false>), grid, block, lds, st, p); \
+        else if (!active) hipLaunchKernelGGL((walk_backward<T, PADV, false, false>), grid, block, lds, st, p); \
         else if (p.K0 > 0) hipLaunchKernelGGL((walk_backward<T, PADV, true>), grid, block, lds, st, p); \
         else hipLaunchKernelGGL((walk_backward<T, PADV, false>), grid, block, lds, st, p); \
         break;

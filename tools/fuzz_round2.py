@@ -245,6 +245,14 @@ def case_walk(rs):
                 gx_r, gw_r = O.backward(g, w, x, pad, 1)
                 assert np.max(np.abs(gx.float().cpu().numpy() - gx_r)) <= eps * max(1.0, np.max(np.abs(gx_r))), ("walk pool gx", shape, tdt, pool, pad)
                 assert rel_err(gw.float().cpu().numpy(), gw_r) < 4 * eps, ("walk pool gw", shape, tdt, pool, pad)
+            # ... and the sparse shift's pooled backward (one gradient tap: grad_x is a copy of the expanded gradient)
+            gx, gw = abi.backward_pooled(gpt.to(DEV), wd, xd, pad, 0, pool)
+            assert abi.last_kernel() == "walk_backward_pool", (shape, tdt, pool, abi.last_kernel())
+            g = torch.from_numpy(O.avg_pool_backward(gpt.float().numpy(), pool, y.shape[2:])).to(tdt).to(torch.float64).numpy().astype(wide)
+            gx_r, _ = O.backward(g, w, x, pad, 0)
+            assert torch.equal(gx.cpu(), torch.from_numpy(gx_r).to(tdt)), ("walk sparse pool gx", shape, tdt, pool, pad)
+            _, gw_r = O.backward(g.astype(np.float64), w.astype(np.float64), x.astype(np.float64), pad, 0)
+            assert rel_err(gw.to(torch.float64).cpu().numpy(), gw_r) < tol, ("walk sparse pool gw", shape, tdt, pool, pad)
     finally:
         abi.set_tuning(35, 0)
 

@@ -1241,7 +1241,6 @@ __global__ __launch_bounds__(kThreads) void walk_forward(const FwdParams p) {
     const int64_t out_plane = static_cast<int64_t>(p.O1) * p.O2;
     S *orow = op + static_cast<int64_t>(b) * p.O2 + jo;
     // POOL state: the thread that owns the first row of a window (every thread when K1 == 1) accumulates its E / 2 windows
-    typedef uint32_t u4 __attribute__((ext_vector_type(4)));
     char *xch = tile + (R + 1) * RBL + 64;                         // [2][kThreads] chunks: the second rows of the windows
     const bool pairs = POOL && p.K1 == 2;
     const bool first_row = POOL && mine && (!pairs || (tr & 1) == 0);

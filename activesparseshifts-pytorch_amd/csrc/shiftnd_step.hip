@@ -420,11 +420,14 @@ __global__ __launch_bounds__(kThreads) void step_backward(const StepParams p) {
 #define SHIFTND_STEP_PK 1
 #endif
     constexpr bool PK = SHIFTND_STEP_PK && sizeof(S) == 2 && SCAT;
+    // ... and the 2-D interpolating shift of 16-bit data shares the packed corner sums (its grad_x blends keep their widened
+    // windows, read through the span reader)
+    constexpr bool PKX = SHIFTND_STEP_PK && sizeof(S) == 2 && ND == 2;
     const int phx = (-d.cx2 * 2) & 15, phg = (-d.cg2 * 2) & 15;   // uniform phases of the windows (PK)
     uint32_t xmask[5] = {0, 0, 0, 0, 0}, gmask[5] = {0, 0, 0, 0, 0};
     bool fx = false, fg = false;
     float sc[2][2] = {{0.f, 0.f}, {0.f, 0.f}};   // PK: per-corner sums [row][column offset]
-    if constexpr (PK) {
+    if constexpr (PKX) {
 #pragma unroll
         for (int i = 0; i < 5; ++i) {
             const int hi = 2 * i + 1 <= E ? 2 * i + 1 : E;
@@ -477,7 +480,8 @@ __global__ __launch_bounds__(kThreads) void step_backward(const StepParams p) {
             for (int k = 0; k < NCC; ++k) {
                 const int ha = corner_plane(k), hb = corner_row(k);
                 S raw[E + 1];
-                lds_read_row<S, E>(tile + (NX + NG + ha * (RT + 1) + vtr + hb) * RB, pag[ha] >= 0 && row_valid(b + hb, d.cg1), gm, raw);
+                if constexpr (PKX) lds_read_row_span<S, E>(tile + (NX + NG + ha * (RT + 1) + vtr + hb) * RB, pag[ha] >= 0 && row_valid(b + hb, d.cg1), gm, fg, phg, raw);
+                else lds_read_row<S, E>(tile + (NX + NG + ha * (RT + 1) + vtr + hb) * RB, pag[ha] >= 0 && row_valid(b + hb, d.cg1), gm, raw);
 #pragma unroll
                 for (int e = 0; e <= E; ++e) gv[k][e] = widen<T>(raw[e]);
             }
@@ -502,7 +506,7 @@ __global__ __launch_bounds__(kThreads) void step_backward(const StepParams p) {
             for (int e = 0; e < E; ++e) res.e[e] = graw[e];
         }
         // ---- weight-gradient sums from the x corners and the incoming gradient --------------------------------------
-        if constexpr (PK) {
+        if constexpr (PKX) {
             uint32_t gq[4];
             __builtin_memcpy(gq, __builtin_assume_aligned(tile + (NX + vtr) * RB + ji * static_cast<int>(sizeof(S)), 16), 16);
 #pragma unroll
@@ -581,7 +585,7 @@ __global__ __launch_bounds__(kThreads) void step_backward(const StepParams p) {
         }
     }
     }
-    if constexpr (PK) {   // corner_diffs<2> of the per-corner sums (it is linear): column difference at row 0, at row 1
+    if constexpr (PKX) {   // corner_diffs<2> of the per-corner sums (it is linear): column difference at row 0, at row 1
         part[0] = static_cast<CT>(sc[0][1] - sc[0][0]);
         part[1] = static_cast<CT>(sc[1][1] - sc[1][0]);
     }

@@ -1071,6 +1071,10 @@ __global__ __launch_bounds__(kThreads) void step_forward_lds(const FwdParams p) 
     } else {
         xm = fold_colstate<E, PAD>(jo + p.L2, cs2, S2);
     }
+    // window reads: two aligned 16-byte spans and the workgroup's phase (lds_window6: no bank conflicts); chunks that are not
+    // affine at that phase (and cropped problems, whose staged rows start at another column) read element by element
+    const int phw = ((p.L2 - cs2) * static_cast<int>(sizeof(S))) & 15;
+    const bool fastw = xm.affine && ((xm.base * static_cast<int>(sizeof(S))) & 15) == phw;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     auto row_valid = [&](int pr) { return PAD != 0 || row_map_t<PAD>(pr, cs1, S1) >= 0; };
@@ -1089,8 +1093,8 @@ __global__ __launch_bounds__(kThreads) void step_forward_lds(const FwdParams p) 
             for (int hb = 0; hb < 2; ++hb) {
                 S r0[E + 1], r1[E + 1];
                 const bool rv = row_valid(b + p.L1 + hb);
-                lds_read_row<S, E>(tile + (vtr + hb) * RBL, rv && pa[0] >= 0, xm, r0);
-                lds_read_row<S, E>(tile + (PR + vtr + hb) * RBL, rv && pa[1] >= 0, xm, r1);
+                lds_read_row_span<S, E>(tile + (vtr + hb) * RBL, rv && pa[0] >= 0, xm, fastw, phw, r0);
+                lds_read_row_span<S, E>(tile + (PR + vtr + hb) * RBL, rv && pa[1] >= 0, xm, fastw, phw, r1);
 #pragma unroll
                 for (int e = 0; e <= E; ++e) {
                     const CT two[2] = {widen<T>(r0[e]), widen<T>(r1[e])};
@@ -1113,7 +1117,7 @@ __global__ __launch_bounds__(kThreads) void step_forward_lds(const FwdParams p) 
 #pragma unroll
             for (int hb = 0; hb < 2; ++hb) {
                 S raw[E + 1];
-                lds_read_row<S, E>(tile + (vtr + hb) * RBL, row_valid(b + p.L1 + hb), xm, raw);
+                lds_read_row_span<S, E>(tile + (vtr + hb) * RBL, row_valid(b + p.L1 + hb), xm, fastw, phw, raw);
 #pragma unroll
                 for (int e = 0; e <= E; ++e) xv[hb][e] = widen<T>(raw[e]);
             }
@@ -1127,7 +1131,7 @@ __global__ __launch_bounds__(kThreads) void step_forward_lds(const FwdParams p) 
             const typename raw_t<sizeof(S)>::type fill_bits = static_cast<typename raw_t<sizeof(S)>::type>(p.fill);
             __builtin_memcpy(&fill, &fill_bits, sizeof(S));
             const bool valid = pa[0] >= 0 && row_valid(b + p.L1);
-            lds_read_row<S, E>(tile + vtr * RBL, valid, xm, raw);
+            lds_read_row_span<S, E>(tile + vtr * RBL, valid, xm, fastw, phw, raw);
 #pragma unroll
             for (int e = 0; e < E; ++e) res.e[e] = (valid && xm.cm[e] >= 0) ? raw[e] : fill;
         }

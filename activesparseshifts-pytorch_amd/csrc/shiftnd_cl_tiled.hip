@@ -553,10 +553,12 @@ __global__ __launch_bounds__(kThreads) void cl_tiled_backward(const ClTiledBwdPa
             v[2] = lds_f(ringx, xr0, xc1[i]);
             v[3] = lds_f(ringx, xr1, xc1[i]);
             const CT graw = widen<T>(*reinterpret_cast<const S *>(ringg + gdr + gd[i]));
-            const CT gval = (live[i] && !skip) ? graw : CT(0);
+            const bool counted = live[i] && !skip;
             weight_grads_nd<2, CT>(v, dw, wg);
-            s0 += gval * wg[0];
-            s1 += gval * wg[1];
+            // (selected, not multiplied by zero: the corners of a skipped row can come from ring slots that were never staged --
+            // periodic padding, a source row past the image -- and 0 * NaN is not 0)
+            s0 += counted ? graw * wg[0] : CT(0);
+            s1 += counted ? graw * wg[1] : CT(0);
             if constexpr (ACTIVE) {
                 v[0] = lds_f(ringg, gr0, gc0[i]);
                 v[1] = lds_f(ringg, gr1, gc0[i]);

@@ -48,7 +48,7 @@ def case_cl(rs):
     H = int(rs.choice([1, 5, 6, 9, 17, 33])); W = int(rs.randint(1, 41))
     N = int(rs.randint(1, 4))
     shape = (N, C, H, W)
-    pad = int(rs.choice([0, 1, 3, 4])); active = int(rs.randint(0, 2))
+    pad = int(rs.randint(0, 5)); active = int(rs.randint(0, 2))   # (periodic: the wrapped edges through the element pass)
     x = rs.uniform(-1, 1, size=shape).astype(np.float32); go = rs.uniform(-1, 1, size=shape).astype(np.float32)
     w = weights(rs, C, 2, shape[2:], 3.9).astype(np.float32)
     cl = torch.channels_last
@@ -60,11 +60,16 @@ def case_cl(rs):
         o = abi.forward(xd, wd, pad, active, out=out)
         count[abi.last_kernel()] += 1
         assert np.array_equal(o.cpu().numpy(), ref), ("cl fwd", shape, pad, active)
+    if rs.randint(2):   # the mixed form: NCHW incoming gradient, channels-last saved input and grad_x
+        gd = torch.from_numpy(go).to(DEV)
     gx, gw = abi.backward(gd, wd, xd, pad, active, grad_x=torch.empty(shape, device=DEV).contiguous(memory_format=cl))
     count[abi.last_kernel()] += 1
     gx_o, _ = O.backward(go, w, x, pad, active)
     _, gw64 = O.backward(go.astype(np.float64), w.astype(np.float64), x.astype(np.float64), pad, active)
     assert np.array_equal(gx.cpu().numpy(), gx_o), ("cl gx", shape, pad, active)
+    if not rel_err(gw.cpu().numpy(), gw64) < 1e-5:   # post-mortem
+        err = np.abs(gw.cpu().numpy() - gw64)
+        print("CL GW MISMATCH", shape, pad, active, abi.last_kernel(), "weights", w.tolist(), "got", gw.cpu().numpy().tolist(), "want", gw64.tolist(), "err", err.tolist())
     assert rel_err(gw.cpu().numpy(), gw64) < 1e-5, ("cl gw", shape, pad, active)
     abi.set_tuning(21, 0)
     # quantized uint8, format kept
@@ -118,6 +123,24 @@ def case_bytes(rs):
     count[abi.last_kernel() + "/u8"] += 1
     assert np.array_equal(o.cpu().numpy(), O.forward_q(xq, wq, 128, 11, pad)), ("bytes", shape, pad)
     abi.set_tuning(17, 0); abi.set_tuning(19, 0); abi.set_tuning(29, 0)
+    # the fused quantized shift + average pool, both of ATen's roundings, against a numpy restatement on the oracle's shift
+    pool = (int(rs.randint(1, 4)), int(rs.randint(2, 4)))
+    y = O.forward_q(xq, wq, 128, 11, pad).astype(np.int64) - 11
+    psz = [-(-H // pool[0]), -(-W // pool[1])]
+    for requant in (abi.REQUANT_ZP_INSIDE, abi.REQUANT_ZP_OUTSIDE):
+        ref = np.zeros((N, C) + tuple(psz), dtype=np.uint8)
+        for i in range(psz[0]):
+            for j in range(psz[1]):
+                win = y[:, :, i * pool[0]:min((i + 1) * pool[0], H), j * pool[1]:min((j + 1) * pool[1], W)]
+                cnt = win.shape[2] * win.shape[3]
+                acc = win.reshape(N, C, -1).sum(2).astype(np.float32)
+                mult = np.float32(1.0 / cnt)
+                q = (np.rint(np.float32(11) + acc * (np.float32(1) / (np.float32(1) / mult))) if requant == abi.REQUANT_ZP_INSIDE
+                     else np.rint(acc * mult) + 11)
+                ref[:, :, i, j] = np.clip(q, 0, 255).astype(np.uint8)
+        op = abi.forward_quantized_pooled(torch.from_numpy(xq).to(DEV), torch.from_numpy(wq).to(DEV), 128, 11, pad, pool, requant=requant)
+        count[abi.last_kernel() + "/u8"] += 1
+        assert np.array_equal(op.cpu().numpy(), ref), ("qpool", shape, pool, pad, requant, abi.last_kernel())
 
 
 def case_step(rs):

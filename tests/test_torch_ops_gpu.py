@@ -248,6 +248,34 @@ def test_strided_module_uses_fused_pool():
     assert rel_err(mg.weight.grad.cpu().numpy(), gw_c.numpy()) < 1e-5
 
 
+def test_strided_3d_modules_use_the_walk_pool_kernels():
+    """Shift3d emulating a stride-2 depthwise conv, sparse (the reference's default) and interpolating: one fused kernel per
+    direction on the GPU (the walk through the planes with the pool riding on it) and the CPU module's values (= the reference's
+    shift + avg_pool3d sequence): outputs and grad_x bit-exact in fp32, grad_w within 1e-5"""
+    from torchshifts import abi
+    torch.manual_seed(4)
+    for active in (False, True):
+        m = Shift3d(8, padding='reflect', sparsity_term=0., active_flag=active, emulate_dw={'kernel_size': 3, 'stride': 2, 'padding': 1})
+        with torch.no_grad():
+            m.weight.copy_(torch.rand(8, 3) * 5 - 2.5)
+        x = torch.rand(2, 8, 6, 11, 16)
+        xc = x.clone().requires_grad_(True)
+        out_c, _ = m(xc)
+        assert out_c.shape == (2, 8, 3, 6, 8)
+        out_c.square().sum().backward()
+        gw_c, gx_c = m.weight.grad.clone(), xc.grad.clone()
+        m.zero_grad()
+        mg = m.to(DEV)
+        xg = x.to(DEV).requires_grad_(True)
+        out_g, _ = mg(xg)
+        assert abi.last_kernel() == ("walk_forward_pool" if active else "plane_pool_forward"), abi.last_kernel()
+        out_g.square().sum().backward()
+        assert torch.equal(out_g.cpu(), out_c.detach()), active
+        assert torch.equal(xg.grad.cpu(), gx_c), active
+        assert rel_err(mg.weight.grad.cpu().numpy(), gw_c.numpy()) < 1e-5, active
+        m.cpu()
+
+
 def test_layout_change_kernel():
     """shiftnd_transpose (channels-last <-> contiguous) is a pure permutation for every element size and ragged shape"""
     from torchshifts import abi

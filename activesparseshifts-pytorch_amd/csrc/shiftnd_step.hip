@@ -1390,15 +1390,19 @@ __global__ __launch_bounds__(kThreads) void walk_backward(const StepParams p) {
         gm = load_colstate<E>(p.colg + rec);
     }
     // the pieces this thread stages, the same for every plane (see walk_forward)
-    const bool own = tr < R && tr <= Rn, extra = Rn == R && tid < cpr;
-    const int sx_own = own ? row_map_t<PAD>(b0 + tr, d.cx1, S1) : -1, sg_own = own ? row_map_t<PAD>(b0 + tr, d.cg1, S1) : -1;
-    const int sx_extra = extra ? row_map_t<PAD>(b0 + R, d.cx1, S1) : -1, sg_extra = (extra && ACTIVE) ? row_map_t<PAD>(b0 + R, d.cg1, S1) : -1;
+    // (the host picks R with (R + 1) * cpr <= 256: thread (tr, tc), tr <= R, stages piece tc of row tr -- the "+1" corner row of
+    // the step's last row included -- so a plane costs one load per tensor and thread, and two planes can be in flight)
+    const bool own = tr <= R && tr <= Rn;
+    const int sx_own = own ? row_map_t<PAD>(b0 + tr, d.cx1, S1) : -1;
+    const int sg_own = (own && (ACTIVE || tr < R)) ? row_map_t<PAD>(b0 + tr, d.cg1, S1) : -1;
     auto piece_off = [&](int row, int piece) { return static_cast<uint32_t>(max(row, 0) * S2 + piece * E) * static_cast<uint32_t>(sizeof(S)); };
-    const uint32_t ox_own = piece_off(sx_own, tc), og_own = piece_off(sg_own, tc), ox_extra = piece_off(sx_extra, tid), og_extra = piece_off(sg_extra, tid);
+    const uint32_t ox_own = piece_off(sx_own, tc), og_own = piece_off(sg_own, tc);
     const uint32_t plane_bytes = static_cast<uint32_t>(S1) * static_cast<uint32_t>(S2) * static_cast<uint32_t>(sizeof(S));
     const int GP0 = (R + 1) * cpr;   // first LDS piece of the gradient group
-    // Staging goes global -> registers -> LDS, one plane ahead: the loads of plane a + 2 are in flight while step a is
-    // computed (an LDS-DMA in flight would make hipcc wait for it before the first LDS read of the compute phase).  Every
+    // Staging goes global -> registers -> LDS, TWO planes ahead (two register sets alternate, the loop is unrolled by two): the
+    // loads of planes a + 2 and a + 3 are in flight while step a is computed -- a step lasts about as long as a memory round
+    // trip under load, one plane ahead left the parking store waiting (an LDS-DMA in flight would make hipcc wait for it
+    // before the first LDS read of the compute phase).  Every
     // memory instruction of the loop is unconditional -- a thread without a piece (or a plane that is fill) uses an
     // out-of-range buffer offset / an empty resource, which loads zeros, and parks them in its private dump slot -- so the
     // compiler's wait counts are exact.
@@ -1443,43 +1447,33 @@ __global__ __launch_bounds__(kThreads) void walk_backward(const StepParams p) {
     };
     const __amdgpu_buffer_rsrc_t ores = __builtin_amdgcn_make_buffer_rsrc(gxp, 0, vol_bytes, kRsrcFlags);
     const __amdgpu_buffer_rsrc_t none = __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(xp), 0, 0, kRsrcFlags);
-    const uint32_t vx_own = sx_own >= 0 ? ox_own : kOOR, vx_extra = sx_extra >= 0 ? ox_extra : kOOR;
+    const uint32_t vx_own = sx_own >= 0 ? ox_own : kOOR;
     const uint32_t vg_own = sg_own >= 0 ? (POOL ? pooled_off(sg_own, tc) : og_own) : kOOR;
-    const uint32_t vg_extra = sg_extra >= 0 ? (POOL ? pooled_off(sg_extra, tid) : og_extra) : kOOR;
-    const int n1_own = POOL ? pooled_rows(sg_own) : 1, n1_extra = POOL ? pooled_rows(sg_extra) : 1;   // window rows of the staged pieces
+    const int n1_own = POOL ? pooled_rows(sg_own) : 1;   // window rows of the staged piece
     char *dump = tile + 2 * GP0 * 16 + tid * 16;
-    char *dx_own = own ? tile + tid * 16 : dump, *dx_extra = extra ? tile + (R * cpr + tid) * 16 : dump;
-    char *dg_own = own ? tile + (GP0 + tid) * 16 : dump, *dg_extra = extra ? tile + (GP0 + R * cpr + tid) * 16 : dump;
+    char *dx_own = own ? tile + tid * 16 : dump;
+    char *dg_own = own ? tile + (GP0 + tid) * 16 : dump;
     struct Staged {
-        u4 xo, xe, go, ge;
-        u2 po, pe;   // POOL: the pooled bytes of the gradient pieces, expanded when parked
-        int n0;      // ... and the window planes of their pooled plane
+        u4 xo, go;
+        u2 po;    // POOL: the pooled bytes of the gradient piece, expanded when parked
+        int n0;   // ... and the window planes of their pooled plane
     };
     auto load_planes = [&](int pax, int pag, Staged &v) {   // source planes (uniform; -1: fill)
         const uint32_t sx = pax >= 0 ? static_cast<uint32_t>(pax) * plane_bytes : 0u;
         v.xo = __builtin_amdgcn_raw_buffer_load_b128(pax >= 0 ? xres : none, vx_own, sx, 0);
-        v.xe = __builtin_amdgcn_raw_buffer_load_b128(pax >= 0 ? xres : none, vx_extra, sx, 0);
         if constexpr (POOL) {
             uint32_t sg;
             pooled_plane(pag, sg, v.n0);
             v.po = __builtin_amdgcn_raw_buffer_load_b64(pag >= 0 ? gres : none, vg_own, sg, 0);
-            v.pe = __builtin_amdgcn_raw_buffer_load_b64(pag >= 0 ? gres : none, vg_extra, sg, 0);
         } else {
             const uint32_t sg = pag >= 0 ? static_cast<uint32_t>(pag) * plane_bytes : 0u;
             v.go = __builtin_amdgcn_raw_buffer_load_b128(pag >= 0 ? gres : none, vg_own, sg, 0);
-            v.ge = __builtin_amdgcn_raw_buffer_load_b128(pag >= 0 ? gres : none, vg_extra, sg, 0);
         }
     };
     auto park = [&](const Staged &v) {
         *reinterpret_cast<u4 *>(__builtin_assume_aligned(dx_own, 16)) = v.xo;
-        *reinterpret_cast<u4 *>(__builtin_assume_aligned(dx_extra, 16)) = v.xe;
-        if constexpr (POOL) {
-            *reinterpret_cast<u4 *>(__builtin_assume_aligned(dg_own, 16)) = expand(v.po, v.n0 * n1_own * 2);
-            *reinterpret_cast<u4 *>(__builtin_assume_aligned(dg_extra, 16)) = expand(v.pe, v.n0 * n1_extra * 2);
-        } else {
-            *reinterpret_cast<u4 *>(__builtin_assume_aligned(dg_own, 16)) = v.go;
-            *reinterpret_cast<u4 *>(__builtin_assume_aligned(dg_extra, 16)) = v.ge;
-        }
+        if constexpr (POOL) *reinterpret_cast<u4 *>(__builtin_assume_aligned(dg_own, 16)) = expand(v.po, v.n0 * n1_own * 2);
+        else *reinterpret_cast<u4 *>(__builtin_assume_aligned(dg_own, 16)) = v.go;
     };
     const bool mine = tr < R && tr < Rn;
     const int b = b0 + tr;
@@ -1619,17 +1613,18 @@ __global__ __launch_bounds__(kThreads) void walk_backward(const StepParams p) {
         return r;
     };
     __syncthreads();   // the "+0" planes have been read
-    Staged pend;       // plane a + 1 of the step about to run
     constexpr int GA = ACTIVE ? 1 : 0;   // the gradient plane of step a: the "+1" corner plane / the plane the tap reads
-    load_planes(row_map_t<PAD>(a0 + 1, d.cx0, S0), row_map_t<PAD>(a0 + GA, d.cg0, S0), pend);
+    // the planes of steps a0 and a0 + 1 (steps that do not exist: empty resources; a buffer's range check does not see the
+    // scalar offset)
+    Staged stA, stB;
+    load_planes(row_map_t<PAD>(a0 + 1, d.cx0, S0), row_map_t<PAD>(a0 + GA, d.cg0, S0), stA);
+    load_planes(a0 + 1 < a1 ? row_map_t<PAD>(a0 + 2, d.cx0, S0) : -1, a0 + 1 < a1 ? row_map_t<PAD>(a0 + 1 + GA, d.cg0, S0) : -1, stB);
     u4 gcur = load_own(a0, true);
-    for (int a = a0; a < a1; ++a) {
+    auto walk_step = [&](int a, Staged &pend) {   // `pend` holds the planes of step a; it leaves with those of step a + 2 in flight
         park(pend);
         __syncthreads();
-        // plane a + 2, in flight while this step is computed (the last step has none: empty resources; a buffer's range
-        // check does not see the scalar offset)
-        const bool more = a + 1 < a1;
-        load_planes(more ? row_map_t<PAD>(a + 2, d.cx0, S0) : -1, more ? row_map_t<PAD>(a + 1 + GA, d.cg0, S0) : -1, pend);
+        const bool more = a + 2 < a1;
+        load_planes(more ? row_map_t<PAD>(a + 3, d.cx0, S0) : -1, more ? row_map_t<PAD>(a + 2 + GA, d.cg0, S0) : -1, pend);
         Chunk<S, E> gch;
         if constexpr (POOL) {
             const u4 ex = expand(u2{gcur.x, gcur.y}, static_cast<int>(gcur.z) * n1_my * 2);
@@ -1738,7 +1733,13 @@ __global__ __launch_bounds__(kThreads) void walk_backward(const StepParams p) {
             }
         }
         __syncthreads();   // everybody has read this step's planes
+    };
+    int a = a0;
+    for (; a + 1 < a1; a += 2) {   // whole pairs: no condition between the steps (exact wait counts)
+        walk_step(a, stA);
+        walk_step(a + 1, stB);
     }
+    if (a < a1) walk_step(a, stA);
     double acc[NS];
 #pragma unroll
     for (int i = 0; i < NS; ++i) acc[i] = accs[i * kThreads];
@@ -2255,7 +2256,8 @@ static bool walk_backward_core(const Geometry &g, int dtype, const void *go, con
     if ((!pooled && reinterpret_cast<uintptr_t>(go) % 16) || reinterpret_cast<uintptr_t>(x) % 16 || reinterpret_cast<uintptr_t>(gx) % 16) return false;
     const StepLayout L = step_layout(g, es);
     if (L.total_steps + 8 >= (1ull << 31)) return false;
-    const int64_t rmax = std::min<int64_t>(kThreads / L.cpr, g.S[1]);
+    if (L.cpr > kThreads / 2) return false;   // (R + 1 rows of pieces per plane and tensor, one piece per thread)
+    const int64_t rmax = std::min<int64_t>(kThreads / L.cpr - 1, g.S[1]);
     if (64 + 2 * (rmax + 1) * L.cpr * 16 + kThreads * 16 + kThreads * 64 + 64 > 64 * 1024) return false;
     if (g.S[0] * g.S[1] * g.S[2] * es >= (1LL << 31)) return false;   // (one buffer resource spans an (n, c) volume)
     // same box, N8 C128 16x112x112: bf16 0.283 (slide_backward) -> 0.263 ms, fp32 0.524 -> 0.486 ms; fp64 on request (bit 5)
@@ -2337,7 +2339,7 @@ int step_backward(const Geometry &g, int dtype, const void *go, const void *x, c
             p.d_k0 = make_fastdiv(static_cast<uint32_t>(p.K0));
             p.g_plane = g.P[0] * g.P[1] * g.P[2];
         }
-        const int rmax = std::min<int>(kThreads / L.cpr, p.S1);
+        const int rmax = std::min<int>(kThreads / L.cpr - 1, p.S1);   // (R + 1) * cpr <= 256: every staged piece has its thread
         p.spp = (p.S1 + rmax - 1) / rmax;
         p.R = (p.S1 + p.spp - 1) / p.spp;
         // planes per workgroup (knob 38): all of them, or a part of the depth -- more, shorter workgroups, one more staged plane each

@@ -409,6 +409,11 @@ int shiftnd_forward_pooled(const shiftnd_problem *p, const int32_t *pool, const 
         g_last_path = SHIFTND_PATH_PLANE;
         return finish(walk_forward(g, p->dtype, x, weights, p->dtype, out, static_cast<hipStream_t>(stream)));
     }
+    // 2-D sparse shift, 2 x 2 windows, fp32 / fp64: the linear sweep of one-step workgroups with the pool as its epilogue
+    if (g_policy == 0 && step_forward_pooled_eligible(g, p->dtype, x, out)) {
+        g_last_path = SHIFTND_PATH_SWEEP;
+        return finish(step_forward_pooled(g, p->dtype, x, weights, p->dtype, out, static_cast<hipStream_t>(stream)));
+    }
     if (!plane_pool_forward_eligible(g, p->dtype)) return SHIFTND_ERR_NOT_FUSED;
     g_last_path = SHIFTND_PATH_PLANE;
     return finish(plane_pool_forward(g, p->dtype, x, weights, out, static_cast<hipStream_t>(stream)));

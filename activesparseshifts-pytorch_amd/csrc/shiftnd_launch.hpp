@@ -142,6 +142,8 @@ bool qpool_forward_eligible(const Geometry &g, int dtype);
 bool walk_backward_pooled_eligible(const Geometry &g, int dtype, const void *go, const void *x, const void *gx);
 bool walk_forward_eligible(const Geometry &g, int dtype, const void *x, const void *out);
 bool walk_forward_pooled_eligible(const Geometry &g, int dtype, const void *x, const void *out);
+bool step_forward_pooled_eligible(const Geometry &g, int dtype, const void *x, const void *out);
+int step_forward_pooled(const Geometry &g, int dtype, const void *x, const void *w, int wkind, void *out, hipStream_t st);
 int walk_forward(const Geometry &g, int dtype, const void *x, const void *w, int wkind, void *out, hipStream_t st);
 void qpool_set_tuning(int knob, int value);
 int qpool_forward(const Geometry &g, int dtype, const void *x, const void *w, int wkind, int64_t wzp, int64_t xzp, int requant, void *out,

@@ -755,6 +755,67 @@ __global__ __launch_bounds__(kThreads) void step_gather_forward(const GatherPara
 // uniform switch on the dword part of the phase and one v_alignbit per output dword.  With zeros padding a piece is
 // either inside the row or entirely fill, so the row ends need no element path at all; the wrapping / clamping paddings
 // send only the chunks that touch a row end through the element-by-element map.
+// step_gather_forward with the module's 2 x 2 average pool as its epilogue (2-D sparse shift, 4- / 8-byte float elements): a thread
+// gathers the chunk of BOTH rows of a pooled row, sums each window in ATen's order (row, then column) in the compute type, divides
+// by the window size and stores E / 2 pooled elements -- the shift output never exists.  `out` is the pooled tensor [N, C, P1, P2];
+// p.O1 / p.O2 are the sizes of the (virtual) shift output, p.spp counts steps of R POOLED rows.
+template <typename T, int PAD>
+__global__ __launch_bounds__(kThreads) void step_gather_forward_pool(const GatherParams p) {
+    using S = typename T::S;
+    using CT = typename T::C;
+    constexpr int E = 16 / sizeof(S);
+    const uint32_t bid = (blockIdx.x & 7u) * p.steps_per_xcd + (blockIdx.x >> 3);
+    if (bid >= p.total_steps) return;
+    const uint32_t plane = fdiv(bid, p.d_spp);
+    const int step = static_cast<int>(bid - plane * static_cast<uint32_t>(p.spp));
+    const int c = static_cast<int>(plane - fdiv(plane, p.d_C) * static_cast<uint32_t>(p.C));
+    int cs1, cs2;
+    channel_shifts2<PAD>(p.w, p.wkind, p.wzp, c, p.S1, p.S2, p.d_per1, p.d_per2, cs1, cs2);
+    const int tid = static_cast<int>(threadIdx.x);
+    const int tr = static_cast<int>(fdiv(static_cast<uint32_t>(tid), p.d_cpr)), tc = tid - tr * p.cpr;
+    const int P1 = (p.O1 + 1) >> 1, P2 = p.O2 >> 1;
+    const int pr = step * p.R + tr;   // pooled row
+    if (tr >= p.R || pr >= P1) return;
+    const int jo = tc * E;
+    int mm[E];
+    bool contig = true;
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        mm[e] = row_map_t<PAD>(jo + p.L2 + e, cs2, p.S2);
+        contig = contig && (mm[e] == mm[0] + e);
+    }
+    contig = contig && mm[0] >= 0;
+    const S *xp = static_cast<const S *>(p.x) + static_cast<int64_t>(plane) * p.x_plane;
+    const int n1 = min(2, p.O1 - 2 * pr);   // rows of this window row (a ragged last one: 1)
+    S zero;
+    __builtin_memset(&zero, 0, sizeof(S));
+    Chunk<S, E> v[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int rb = h < n1 ? row_map_t<PAD>(2 * pr + h + p.L1, cs1, p.S1) : -1;
+        if (rb < 0) {
+#pragma unroll
+            for (int e = 0; e < E; ++e) v[h].e[e] = zero;
+        } else {
+            const S *row = xp + rb * p.S2;
+            if (contig) {
+                v[h] = load_chunk<S, E, true>(row + mm[0]);
+            } else {
+#pragma unroll
+                for (int e = 0; e < E; ++e) v[h].e[e] = mm[e] >= 0 ? __builtin_nontemporal_load(row + mm[e]) : zero;
+            }
+        }
+    }
+    Chunk<S, (E / 2 > 0 ? E / 2 : 1)> outc;
+#pragma unroll
+    for (int j = 0; j < E / 2; ++j) {
+        CT acc = (CT(0) + widen<T>(v[0].e[2 * j])) + widen<T>(v[0].e[2 * j + 1]);
+        if (n1 == 2) acc = (acc + widen<T>(v[1].e[2 * j])) + widen<T>(v[1].e[2 * j + 1]);
+        outc.e[j] = narrow<T>(div_count<CT>(acc, n1 * 2));
+    }
+    S *dst = static_cast<S *>(p.out) + static_cast<int64_t>(plane) * p.o_plane + static_cast<int64_t>(pr) * P2 + jo / 2;
+    __builtin_memcpy(__builtin_assume_aligned(dst, 8), outc.e, 8);
+}
 template <int ESIZE, int PAD>
 __global__ __launch_bounds__(kThreads) void step_gather_forward_small(const GatherParams p) {
     using R_t = typename raw_t<ESIZE>::type;
@@ -2131,6 +2192,65 @@ int step_forward_lds(const Geometry &g, int dtype, const void *x, const void *w,
     case SHIFTND_F16: launch_step_forward_lds<f16_t>(p, true, g.pad, U, lds, st); break;
     default: launch_step_forward_lds<bf16_t>(p, true, g.pad, U, lds, st); break;
     }
+    return SHIFTND_OK;
+}
+
+// the 2-D sparse shift + 2 x 2 average pool of 4- / 8-byte float elements in one sweep of one-step workgroups
+bool step_forward_pooled_eligible(const Geometry &g, int dtype, const void *x, const void *out) {
+    if (g_step_tune[1] == 1) return false;
+    if (dtype != SHIFTND_F32 && dtype != SHIFTND_F64) return false;
+    if (g.nd != 2 || g.active || g.K[1] != 2 || g.K[2] != 2 || g.S[0] != 1 || g.O[0] != 1) return false;
+    const int es = dtype_size(dtype);
+    const int64_t xe = g.S[1] * g.S[2], oe = g.O[1] * g.O[2];
+    if (xe < 1 || oe < 1 || xe >= (1LL << 30) || oe >= (1LL << 30)) return false;
+    if ((g.O[2] * es) % 16 != 0 || g.O[2] * es / 16 > kThreads || reinterpret_cast<uintptr_t>(out) % 8 != 0) return false;
+    if (!dense(g.xs, g.N, g.C, g.S)) return false;
+    const int64_t cpr = g.O[2] * es / 16, R = kThreads / cpr, p1 = (g.O[1] + 1) / 2;
+    return g.N * g.C * ((p1 + R - 1) / R) + 8 < (1LL << 31);
+}
+
+int step_forward_pooled(const Geometry &g, int dtype, const void *x, const void *w, int wkind, void *out, hipStream_t st) {
+    const int es = dtype_size(dtype);
+    GatherParams p{};
+    p.x = x;
+    p.out = out;
+    p.w = w;
+    p.wkind = wkind;
+    p.C = static_cast<int>(g.C);
+    p.S1 = static_cast<int>(g.S[1]);
+    p.S2 = static_cast<int>(g.S[2]);
+    p.O1 = static_cast<int>(g.O[1]);
+    p.O2 = static_cast<int>(g.O[2]);
+    p.L1 = static_cast<int>(g.L[1]);
+    p.L2 = static_cast<int>(g.L[2]);
+    p.x_plane = g.S[1] * g.S[2];
+    p.o_plane = g.P[1] * g.P[2];   // (the pooled plane)
+    p.cpr = static_cast<int>(g.O[2] * es / 16);
+    p.xppr = static_cast<int>(g.S[2] * es / 16);
+    const int P1 = static_cast<int>(g.P[1]);
+    p.R = kThreads / p.cpr;
+    if (p.R > P1) p.R = P1;
+    p.spp = (P1 + p.R - 1) / p.R;
+    const uint64_t total = static_cast<uint64_t>(g.N) * g.C * p.spp;
+    p.total_steps = static_cast<uint32_t>(total);
+    p.steps_per_xcd = static_cast<uint32_t>((total + 7) / 8);
+    p.d_spp = make_fastdiv(static_cast<uint32_t>(p.spp));
+    p.d_C = make_fastdiv(static_cast<uint32_t>(p.C));
+    p.d_cpr = make_fastdiv(static_cast<uint32_t>(p.cpr));
+    p.d_per1 = make_fastdiv(static_cast<uint32_t>(map_period(p.S1, g.pad)));
+    p.d_per2 = make_fastdiv(static_cast<uint32_t>(map_period(p.S2, g.pad)));
+    const dim3 grid(p.steps_per_xcd * 8), block(kThreads);
+    note_kernel("step_gather_forward_pool");
+#define SHIFTND_STEP_FWD_POOL(TT) \
+    switch (g.pad) { \
+    case 0: hipLaunchKernelGGL((step_gather_forward_pool<TT, 0>), grid, block, 0, st, p); break; \
+    case 1: hipLaunchKernelGGL((step_gather_forward_pool<TT, 1>), grid, block, 0, st, p); break; \
+    case 2: hipLaunchKernelGGL((step_gather_forward_pool<TT, 2>), grid, block, 0, st, p); break; \
+    case 3: hipLaunchKernelGGL((step_gather_forward_pool<TT, 3>), grid, block, 0, st, p); break; \
+    default: hipLaunchKernelGGL((step_gather_forward_pool<TT, 4>), grid, block, 0, st, p); break; \
+    }
+    if (dtype == SHIFTND_F32) { SHIFTND_STEP_FWD_POOL(f32_t) } else { SHIFTND_STEP_FWD_POOL(f64_t) }
+#undef SHIFTND_STEP_FWD_POOL
     return SHIFTND_OK;
 }
 

@@ -1253,23 +1253,23 @@ __global__ __launch_bounds__(kThreads) void walk_forward(const FwdParams p) {
     const int tid = static_cast<int>(threadIdx.x);
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int tr = static_cast<int>(fdiv(static_cast<uint32_t>(tid), p.d_cpr)), tc = tid - tr * cpr;
-    // the pieces this thread stages, the same for every plane: piece tc of its own row (rows 0 .. Rn: the + 1 corner row of
-    // a ragged last step is somebody's own row) and, in a full step, piece tid of row R
-    const int src_own = (tr < R && tr <= Rn) ? row_map_t<PAD>(b0 + tr, cs1, S1) : -1;
-    const int src_extra = (Rn == R && tid < cpr) ? row_map_t<PAD>(b0 + R, cs1, S1) : -1;
-    const uint32_t off_own = static_cast<uint32_t>(max(src_own, 0) * S2 + tc * E) * static_cast<uint32_t>(sizeof(S));
-    const uint32_t off_extra = static_cast<uint32_t>(max(src_extra, 0) * S2 + tid * E) * static_cast<uint32_t>(sizeof(S));
+    // the piece this thread stages, the same for every plane: piece tc of row tr, rows 0 .. min(R, Rn) -- the host picks R with
+    // (R + 1) * cpr <= 256, so the + 1 corner row of the step's last row has its threads too.  Staging goes global -> registers
+    // -> LDS, two planes ahead (two registers sets alternate, the loop unrolled by two; see walk_backward); a thread without a
+    // piece, a fill row and a fill plane load zeros (out-of-range offset / empty resource) and park them.
+    (void)wave;
+    typedef uint32_t u4 __attribute__((ext_vector_type(4)));
+    const bool own = tr <= R && tr <= Rn;
+    const int src_own = own ? row_map_t<PAD>(b0 + tr, cs1, S1) : -1;
     const uint32_t plane_bytes = static_cast<uint32_t>(S1) * static_cast<uint32_t>(S2) * static_cast<uint32_t>(sizeof(S));
-    auto stage = [&](int pa) {   // source plane pa (uniform) -> the tile
-        if (pa < 0) return;
-        const char *base = xp + static_cast<size_t>(pa) * plane_bytes;
-        if (src_own >= 0)
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(base + off_own),
-                                             (__attribute__((address_space(3))) void *)(tile + wave * 64 * 16), 16, 0, 2 /* nt */);
-        if (src_extra >= 0)
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(base + off_extra),
-                                             (__attribute__((address_space(3))) void *)(tile + (R * cpr + wave * 64) * 16), 16, 0, 2);
+    const uint32_t voff = src_own >= 0 ? static_cast<uint32_t>(src_own * S2 + tc * E) * static_cast<uint32_t>(sizeof(S)) : 0x80000000u;
+    const __amdgpu_buffer_rsrc_t xres = __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(xp), 0, static_cast<uint32_t>(S0) * plane_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t none = __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(xp), 0, 0, 0x00020000);
+    char *park_at = own ? tile + tid * 16 : tile + (R + 1) * cpr * 16 + 64 + (POOL ? 2 * kThreads * 16 + 64 : 0) + tid * 16;   // (a private dump slot)
+    auto load_plane = [&](int pa) {   // source plane pa (uniform; -1: fill)
+        return __builtin_amdgcn_raw_buffer_load_b128(pa >= 0 ? xres : none, voff, pa >= 0 ? static_cast<uint32_t>(pa) * plane_bytes : 0u, 0);
     };
+    auto park = [&](const u4 &v) { *reinterpret_cast<u4 *>(__builtin_assume_aligned(park_at, 16)) = v; };
     const int jo = tc * E;
     ColState<E> xm;
     if constexpr (PAD == 0) {
@@ -1296,8 +1296,7 @@ __global__ __launch_bounds__(kThreads) void walk_forward(const FwdParams p) {
     CT carried[2][E + 1];
     {
         const int pa0 = row_map_t<PAD>(0, cs0, S0);
-        stage(pa0);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        park(load_plane(pa0));
         __syncthreads();
 #pragma unroll
         for (int hb = 0; hb < 2; ++hb) {
@@ -1340,12 +1339,14 @@ __global__ __launch_bounds__(kThreads) void walk_forward(const FwdParams p) {
             __builtin_memcpy(__builtin_assume_aligned(dst, sizeof(S) * E / 2), outc.e, sizeof(S) * (E / 2));
         }
     };
-    for (int a = 0; a < p.O0; ++a) {
+    __syncthreads();   // the first plane has been read
+    u4 stA = load_plane(row_map_t<PAD>(1, cs0, S0));                            // the "+1" plane of step 0
+    u4 stB = load_plane(1 < p.O0 ? row_map_t<PAD>(2, cs0, S0) : -1);            // ... of step 1
+    auto walk_step = [&](int a, u4 &pend) {   // `pend`: the "+1" plane of step a; leaves with that of step a + 2 in flight
         const int pa1 = row_map_t<PAD>(a + 1, cs0, S0);
-        __syncthreads();   // everybody has read the previous plane
-        stage(pa1);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        park(pend);
         __syncthreads();
+        pend = load_plane(a + 2 < p.O0 ? row_map_t<PAD>(a + 3, cs0, S0) : -1);
         CT rowb[2][E + 1];
 #pragma unroll
         for (int hb = 0; hb < 2; ++hb) {
@@ -1378,7 +1379,14 @@ __global__ __launch_bounds__(kThreads) void walk_forward(const FwdParams p) {
         } else {
             if (mine) store_chunk<S, E>(orow + a * out_plane, res);
         }
+        __syncthreads();   // everybody has read this step's plane
+    };
+    int a = 0;
+    for (; a + 1 < p.O0; a += 2) {   // whole pairs: no condition between the steps
+        walk_step(a, stA);
+        walk_step(a + 1, stB);
     }
+    if (a < p.O0) walk_step(a, stA);
     if constexpr (POOL) {
         __syncthreads();
         if (first_row) pool_plane(p.O0 - 1);
@@ -2277,14 +2285,15 @@ static bool walk_forward_core(const Geometry &g, int dtype, const void *x, const
     if (reinterpret_cast<uintptr_t>(x) % 16 != 0 || reinterpret_cast<uintptr_t>(out) % 16 != 0) return false;
     if (!dense(g.xs, g.N, g.C, g.S) || (!pooled && !dense(g.os, g.N, g.C, g.O))) return false;
     const int64_t cpr = g.S[2] * es / 16;
-    const int64_t rmax = std::min<int64_t>(kThreads / cpr, g.S[1]);
-    if (64 + (rmax + 2) * cpr * 16 + 64 + 2 * kThreads * 16 + 64 > 64 * 1024) return false;
+    if (cpr > kThreads / 2 || g.S[0] * g.S[1] * g.S[2] * es >= (1LL << 31)) return false;   // (one piece per thread; one buffer resource per volume)
+    const int64_t rmax = std::min<int64_t>(kThreads / cpr - 1, g.S[1]);
+    if (64 + (rmax + 2) * cpr * 16 + 64 + 2 * kThreads * 16 + 64 + kThreads * 16 > 64 * 1024) return false;
     const int64_t spp = (g.S[1] + rmax - 1) / rmax;
     if (g.N * g.C * (spp + 1) + 8 >= (1LL << 31)) return false;
     if (pooled) return rmax >= 2 || g.K[1] == 1;   // (a window's two rows live in one workgroup)
-    // 16-bit data (C3: 0.179 -> 0.154 ms); 4- / 8-byte elements are as fast on step_forward_lds (N8 C128 16x112x112 fp32: 0.285
-    // vs 0.301 ms) unless asked for (knob 35 bit 5)
-    return es == 2 || (g_step_tune[3] & 32);
+    // same box, N8 C128 16x112x112: bf16 0.178 (slide_forward) -> 0.148 ms, fp32 0.308 (step_forward_lds) -> 0.259 ms; fp64 on
+    // request (knob 35 bit 5)
+    return es <= 4 || (g_step_tune[3] & 32);
 }
 
 int walk_forward(const Geometry &g, int dtype, const void *x, const void *w, int wkind, void *out, hipStream_t st) {
@@ -2301,7 +2310,7 @@ int walk_forward(const Geometry &g, int dtype, const void *x, const void *w, int
     p.S2 = p.O2 = static_cast<int>(g.S[2]);
     p.x_plane = p.o_plane = g.S[0] * g.S[1] * g.S[2];
     p.cpr = p.xppr = static_cast<int>(g.S[2] * es / 16);
-    const int rmax = std::min<int>(kThreads / p.cpr, p.S1);
+    const int rmax = std::min<int>(kThreads / p.cpr - 1, p.S1);   // (R + 1) * cpr <= 256: every staged piece has its thread
     p.spp = (p.S1 + rmax - 1) / rmax;
     p.R = (p.S1 + p.spp - 1) / p.spp;   // balanced steps: 112 rows of 14 pieces -> 7 steps of 16 rows, not 6 of 18 and one of 4
     const bool pooled = g.K[0] > 0;
@@ -2329,7 +2338,7 @@ int walk_forward(const Geometry &g, int dtype, const void *x, const void *w, int
     p.d_per0 = make_fastdiv(static_cast<uint32_t>(map_period(p.S0, g.pad)));
     p.d_per1 = make_fastdiv(static_cast<uint32_t>(map_period(p.S1, g.pad)));
     p.d_per2 = make_fastdiv(static_cast<uint32_t>(map_period(p.S2, g.pad)));
-    const size_t lds = 64 + static_cast<size_t>(p.R + 1) * p.cpr * 16 + 64 + (pooled ? 2 * kThreads * 16 + 64 : 0);   // tile (+ exchange slots)
+    const size_t lds = 64 + static_cast<size_t>(p.R + 1) * p.cpr * 16 + 64 + (pooled ? 2 * kThreads * 16 + 64 : 0) + kThreads * 16;   // tile (+ exchange slots), dump slots
     const dim3 grid(p.steps_per_xcd * 8), block(kThreads);
     note_kernel(pooled ? "walk_forward_pool" : "walk_forward");
 #define SHIFTND_WALK_FWD_PAD(T, PADV) \

@@ -91,7 +91,7 @@ int forward_common(const shiftnd_problem *p, const void *x, const int64_t *xs, c
         const bool interpolating = g.active && p->dtype <= SHIFTND_BF16;
         const bool prefer_sweep = (out_plane_bytes >= 32 * 1024 && !interpolating && !(can_plane && plane_forward_lds_gather(g, p->dtype, x, out))) || !can_plane;
         // 2-D sparse shift / quantized forward as a linear sweep of one-step workgroups
-        if (g_policy == 0 && step_forward_eligible(g, p->dtype, x, out)) {
+        if (g_policy == 0 && (g.nd == 2 || wkind <= SHIFTND_BF16) && step_forward_eligible(g, p->dtype, x, out)) {
             g_last_path = SHIFTND_PATH_SWEEP;
             return finish(step_forward(g, p->dtype, x, w, wkind, wzp, fill, out, st));
         }

@@ -702,19 +702,77 @@ struct GatherParams {  // 2-D problems: rows x inner, one weight per dim
     int xppr;   // 16-byte pieces per source row (the small-element kernel)
     uint32_t total_steps, steps_per_xcd;
     FastDiv d_spp, d_C, d_cpr, d_per1, d_per2;
+    // 3-D (step_gather_forward<..., 3>: float weights): planes of the volume, steps per (n, c) = O0 * spp
+    int S0, O0, L0, spv;
+    FastDiv d_spv, d_per0;
 };
 
-template <int ESIZE, int PAD>
+// the nd weights of channel c in normalised order (plane, row, inner; leading dims 0), widened, through the scalar cache
+template <typename CT> __device__ __forceinline__ void load_weights_nd(const void *w, int wkind, int c, int nd, CT (&out)[3]) {
+    const uintptr_t base = reinterpret_cast<uintptr_t>(w);
+    CT v[3] = {CT(0), CT(0), CT(0)};
+    if (wkind == SHIFTND_F64) {
+        const __attribute__((address_space(4))) double *q = reinterpret_cast<const __attribute__((address_space(4))) double *>(base) + static_cast<int64_t>(c) * nd;
+        for (int r = 0; r < 3; ++r) if (r < nd) v[r] = static_cast<CT>(q[r]);
+    } else if (wkind == SHIFTND_F16 || wkind == SHIFTND_BF16) {
+        // nd halfwords at byte offset 2 nd c: the two aligned dwords that hold them
+        const uintptr_t at = base + static_cast<uintptr_t>(c) * nd * 2;
+        const __attribute__((address_space(4))) uint32_t *q = reinterpret_cast<const __attribute__((address_space(4))) uint32_t *>(at & ~static_cast<uintptr_t>(3));
+        const uint64_t bits = (static_cast<uint64_t>(q[1]) << 32 | q[0]) >> ((at & 2) * 8);
+        for (int r = 0; r < 3; ++r) {
+            if (r >= nd) break;
+            const uint16_t h = static_cast<uint16_t>(bits >> (16 * r));
+            v[r] = wkind == SHIFTND_F16 ? static_cast<CT>(__builtin_bit_cast(_Float16, h))
+                                        : static_cast<CT>(__builtin_bit_cast(float, static_cast<uint32_t>(h) << 16));
+        }
+    } else {
+        const __attribute__((address_space(4))) float *q = reinterpret_cast<const __attribute__((address_space(4))) float *>(base) + static_cast<int64_t>(c) * nd;
+        for (int r = 0; r < 3; ++r) if (r < nd) v[r] = static_cast<CT>(q[r]);
+    }
+    const int lead = 3 - nd;
+    out[0] = out[1] = out[2] = CT(0);
+    for (int r = 0; r < 3; ++r) if (r < nd) out[r + lead] = v[r];
+}
+
+// ND = 3 (float weights): the step is (n, c, output plane a, row step); the source plane of a is one more folded index.
+template <int ESIZE, int PAD, int ND = 2>
 __global__ __launch_bounds__(kThreads) void step_gather_forward(const GatherParams p) {
     using R_t = typename raw_t<ESIZE>::type;
     constexpr int E = 16 / ESIZE;
     const uint32_t bid = (blockIdx.x & 7u) * p.steps_per_xcd + (blockIdx.x >> 3);
     if (bid >= p.total_steps) return;
-    const uint32_t plane = fdiv(bid, p.d_spp);
-    const int step = static_cast<int>(bid - plane * static_cast<uint32_t>(p.spp));
-    const int c = static_cast<int>(plane - fdiv(plane, p.d_C) * static_cast<uint32_t>(p.C));
-    int cs1, cs2;
-    channel_shifts2<PAD>(p.w, p.wkind, p.wzp, c, p.S1, p.S2, p.d_per1, p.d_per2, cs1, cs2);
+    uint32_t plane;
+    int step, a = 0, pa = 0, cs1, cs2;
+    if constexpr (ND == 3) {
+        plane = fdiv(bid, p.d_spv);
+        const uint32_t vstep = bid - plane * static_cast<uint32_t>(p.spv);
+        a = static_cast<int>(fdiv(vstep, p.d_spp));
+        step = static_cast<int>(vstep) - a * p.spp;
+        const int c = static_cast<int>(plane - fdiv(plane, p.d_C) * static_cast<uint32_t>(p.C));
+        int cs0;
+        if (p.wkind == SHIFTND_F64) {
+            double wv[3];
+            load_weights_nd<double>(p.w, p.wkind, c, 3, wv);
+            cs0 = canon_of<PAD, double>(rint(wv[0]), p.S0, p.d_per0);
+            cs1 = canon_of<PAD, double>(rint(wv[1]), p.S1, p.d_per1);
+            cs2 = canon_of<PAD, double>(rint(wv[2]), p.S2, p.d_per2);
+        } else {
+            float wv[3];
+            load_weights_nd<float>(p.w, p.wkind, c, 3, wv);
+            cs0 = canon_of<PAD, float>(rintf(wv[0]), p.S0, p.d_per0);
+            cs1 = canon_of<PAD, float>(rintf(wv[1]), p.S1, p.d_per1);
+            cs2 = canon_of<PAD, float>(rintf(wv[2]), p.S2, p.d_per2);
+        }
+        cs0 = __builtin_amdgcn_readfirstlane(cs0);
+        cs1 = __builtin_amdgcn_readfirstlane(cs1);
+        cs2 = __builtin_amdgcn_readfirstlane(cs2);
+        pa = row_map_t<PAD>(a + p.L0, cs0, p.S0);
+    } else {
+        plane = fdiv(bid, p.d_spp);
+        step = static_cast<int>(bid - plane * static_cast<uint32_t>(p.spp));
+        const int c = static_cast<int>(plane - fdiv(plane, p.d_C) * static_cast<uint32_t>(p.C));
+        channel_shifts2<PAD>(p.w, p.wkind, p.wzp, c, p.S1, p.S2, p.d_per1, p.d_per2, cs1, cs2);
+    }
     const int tid = static_cast<int>(threadIdx.x);
     const int tr = static_cast<int>(fdiv(static_cast<uint32_t>(tid), p.d_cpr)), tc = tid - tr * p.cpr;
     const int r = step * p.R + tr;
@@ -730,10 +788,10 @@ __global__ __launch_bounds__(kThreads) void step_gather_forward(const GatherPara
     }
     contig = contig && mm[0] >= 0;
     const R_t fill = static_cast<R_t>(p.fill);
-    const R_t *xp = static_cast<const R_t *>(p.x) + static_cast<int64_t>(plane) * p.x_plane;
-    R_t *dst = static_cast<R_t *>(p.out) + static_cast<int64_t>(plane) * p.o_plane + r * p.O2 + jo;
+    const R_t *xp = static_cast<const R_t *>(p.x) + static_cast<int64_t>(plane) * p.x_plane + static_cast<int64_t>(pa < 0 ? 0 : pa) * p.S1 * p.S2;
+    R_t *dst = static_cast<R_t *>(p.out) + static_cast<int64_t>(plane) * p.o_plane + (static_cast<int64_t>(a) * p.O1 + r) * p.O2 + jo;
     Chunk<R_t, E> v;
-    if (rb < 0) {
+    if (rb < 0 || pa < 0) {
 #pragma unroll
         for (int e = 0; e < E; ++e) v.e[e] = fill;
     } else {
@@ -987,33 +1045,6 @@ struct FwdParams {
     int64_t p_plane;   // pooled elements per (n, c)
     FastDiv d_k0;
 };
-
-// the nd weights of channel c in normalised order (plane, row, inner; leading dims 0), widened, through the scalar cache
-template <typename CT> __device__ __forceinline__ void load_weights_nd(const void *w, int wkind, int c, int nd, CT (&out)[3]) {
-    const uintptr_t base = reinterpret_cast<uintptr_t>(w);
-    CT v[3] = {CT(0), CT(0), CT(0)};
-    if (wkind == SHIFTND_F64) {
-        const __attribute__((address_space(4))) double *q = reinterpret_cast<const __attribute__((address_space(4))) double *>(base) + static_cast<int64_t>(c) * nd;
-        for (int r = 0; r < 3; ++r) if (r < nd) v[r] = static_cast<CT>(q[r]);
-    } else if (wkind == SHIFTND_F16 || wkind == SHIFTND_BF16) {
-        // nd halfwords at byte offset 2 nd c: the two aligned dwords that hold them
-        const uintptr_t at = base + static_cast<uintptr_t>(c) * nd * 2;
-        const __attribute__((address_space(4))) uint32_t *q = reinterpret_cast<const __attribute__((address_space(4))) uint32_t *>(at & ~static_cast<uintptr_t>(3));
-        const uint64_t bits = (static_cast<uint64_t>(q[1]) << 32 | q[0]) >> ((at & 2) * 8);
-        for (int r = 0; r < 3; ++r) {
-            if (r >= nd) break;
-            const uint16_t h = static_cast<uint16_t>(bits >> (16 * r));
-            v[r] = wkind == SHIFTND_F16 ? static_cast<CT>(__builtin_bit_cast(_Float16, h))
-                                        : static_cast<CT>(__builtin_bit_cast(float, static_cast<uint32_t>(h) << 16));
-        }
-    } else {
-        const __attribute__((address_space(4))) float *q = reinterpret_cast<const __attribute__((address_space(4))) float *>(base) + static_cast<int64_t>(c) * nd;
-        for (int r = 0; r < 3; ++r) if (r < nd) v[r] = static_cast<CT>(q[r]);
-    }
-    const int lead = 3 - nd;
-    out[0] = out[1] = out[2] = CT(0);
-    for (int r = 0; r < 3; ++r) if (r < nd) out[r + lead] = v[r];
-}
 
 // column state of E + 1 consecutive map entries starting at coordinate j0, folded arithmetically
 template <int E, int PAD> __device__ __forceinline__ ColState<E> fold_colstate(int j0, int cs, int len) {
@@ -2008,25 +2039,27 @@ bool step_forward_eligible(const Geometry &g, int dtype, const void *x, const vo
     if (es != 1 && es != 2 && es != 4 && es != 8) return false;
     const bool interpolating = g.active && dtype <= SHIFTND_BF16;
     if (interpolating && (es < 4 || g.S[1] * g.S[2] * es >= (1LL << 31))) return false;  // (the buffer resource spans one plane)
-    if (g.nd != 2 || g.S[0] != 1 || g.O[0] != 1) return false;
+    // 2-D; 3-D for the sparse shift of 4- / 8-byte elements (the caller checks that its weights are floats)
+    if (g.nd == 3 ? (es < 4 || interpolating) : (g.nd != 2 || g.S[0] != 1 || g.O[0] != 1)) return false;
     // 1- / 2-byte elements: aligned pieces of the source rows
     if (es < 4 && ((g.S[2] * es) % 16 != 0 || reinterpret_cast<uintptr_t>(x) % 16 != 0)) return false;
-    const int64_t xe = g.S[1] * g.S[2], oe = g.O[1] * g.O[2];
+    const int64_t xe = g.S[0] * g.S[1] * g.S[2], oe = g.O[0] * g.O[1] * g.O[2];
     if (xe < 1 || oe < 1 || xe >= (1LL << 30) || oe >= (1LL << 30)) return false;
     if ((g.O[2] * es) % 16 != 0 || g.O[2] * es / 16 > kThreads || reinterpret_cast<uintptr_t>(out) % 16 != 0) return false;
     if (!dense(g.xs, g.N, g.C, g.S) || !dense(g.os, g.N, g.C, g.O)) return false;
     const int cpr = static_cast<int>(g.O[2] * es / 16);
     const int64_t R = kThreads / cpr;
     const int64_t spp = (g.O[1] + R - 1) / R;
-    if (g.N * g.C * spp + 8 >= (1LL << 31)) return false;
+    if (g.N * g.C * g.O[0] * spp + 8 >= (1LL << 31)) return false;
     if (g_step_tune[1] == 2) return true;
     // interpolating by direct loads: every corner row is loaded by two workgroups at element alignment -- measured
     // slower than the LDS-staged plane kernel (C2 tensor 1.51 vs 1.13 ms): on request only (knob 33 = 2)
     if (interpolating) return false;
     // 1- / 2-byte elements: zeros padding only (row-end chunks of the other paddings go element by element), planes of at
     // least 16 KiB (2-byte) / 32 KiB (1-byte): below that the per-channel kernels that walk many planes win
-    if (es < 4) return g.pad == 0 && oe * es >= (es == 2 ? 16 : 32) * 1024;
-    return oe * es >= 32 * 1024;  // as the sweep kernels: small planes go to the per-channel walk
+    const int64_t pe = g.O[1] * g.O[2];   // (a plane's elements: a 3-D volume of small planes is no better off)
+    if (es < 4) return g.pad == 0 && pe * es >= (es == 2 ? 16 : 32) * 1024;
+    return pe * es >= 32 * 1024;  // as the sweep kernels: small planes go to the per-channel walk
 }
 
 int step_forward(const Geometry &g, int dtype, const void *x, const void *w, int wkind, int64_t wzp, uint64_t fill_bits,
@@ -2053,15 +2086,39 @@ int step_forward(const Geometry &g, int dtype, const void *x, const void *w, int
     p.R = kThreads / p.cpr;
     if (p.R > p.O1) p.R = p.O1;
     p.spp = (p.O1 + p.R - 1) / p.R;
-    const uint64_t total = static_cast<uint64_t>(g.N) * g.C * p.spp;
+    p.S0 = static_cast<int>(g.S[0]);
+    p.O0 = static_cast<int>(g.O[0]);
+    p.L0 = static_cast<int>(g.L[0]);
+    p.spv = p.O0 * p.spp;
+    if (g.nd == 3) {
+        p.x_plane = g.S[0] * g.S[1] * g.S[2];
+        p.o_plane = g.O[0] * g.O[1] * g.O[2];
+    }
+    const uint64_t total = static_cast<uint64_t>(g.N) * g.C * p.spv;
     p.total_steps = static_cast<uint32_t>(total);
     p.steps_per_xcd = static_cast<uint32_t>((total + 7) / 8);
     p.d_spp = make_fastdiv(static_cast<uint32_t>(p.spp));
+    p.d_spv = make_fastdiv(static_cast<uint32_t>(p.spv));
     p.d_C = make_fastdiv(static_cast<uint32_t>(p.C));
     p.d_cpr = make_fastdiv(static_cast<uint32_t>(p.cpr));
+    p.d_per0 = make_fastdiv(static_cast<uint32_t>(map_period(p.S0, g.pad)));
     p.d_per1 = make_fastdiv(static_cast<uint32_t>(map_period(p.S1, g.pad)));
     p.d_per2 = make_fastdiv(static_cast<uint32_t>(map_period(p.S2, g.pad)));
     const dim3 grid(p.steps_per_xcd * 8), block(kThreads);
+    if (g.nd == 3) {   // sparse shift of 4- / 8-byte elements, float weights (the eligibility check and the caller see to that)
+        note_kernel("step_gather_forward");
+#define SHIFTND_STEP_FWD3(ES) \
+    switch (g.pad) { \
+    case 0: hipLaunchKernelGGL((step_gather_forward<ES, 0, 3>), grid, block, 0, st, p); break; \
+    case 1: hipLaunchKernelGGL((step_gather_forward<ES, 1, 3>), grid, block, 0, st, p); break; \
+    case 2: hipLaunchKernelGGL((step_gather_forward<ES, 2, 3>), grid, block, 0, st, p); break; \
+    case 3: hipLaunchKernelGGL((step_gather_forward<ES, 3, 3>), grid, block, 0, st, p); break; \
+    default: hipLaunchKernelGGL((step_gather_forward<ES, 4, 3>), grid, block, 0, st, p); break; \
+    }
+        if (es == 4) { SHIFTND_STEP_FWD3(4) } else { SHIFTND_STEP_FWD3(8) }
+#undef SHIFTND_STEP_FWD3
+        return SHIFTND_OK;
+    }
     if (g.active && dtype <= SHIFTND_BF16) {
         note_kernel("step_active_forward_direct");
 #define SHIFTND_STEP_ACT(TT) \

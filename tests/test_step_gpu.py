@@ -410,3 +410,33 @@ def test_3d_walk_backward_vs_oracle(abi, shape, dt):
             _, gw64 = O.backward(go.astype(np.float64), w.astype(np.float64), x.astype(np.float64), pad, active)
             tol = {"f32": 1e-5, "f64": 1e-12}.get(dt, 2 * float(torch.finfo(tdt).eps))
             assert rel_err(gw.to(torch.float64).cpu().numpy(), gw64) < tol, ("gw", shape, dt, pad, active)
+
+
+@pytest.mark.parametrize("dt", ["f32", "f64", "i32"])
+@pytest.mark.parametrize("shape,crop", [((2, 3, 5, 6, 16), None), ((1, 2, 4, 40, 112), None), ((2, 2, 6, 9, 32), [[1, 0], [0, 2], [4, 8]]),
+                                        ((1, 3, 1, 5, 8), None), ((1, 2, 3, 1, 1024), None)])
+def test_3d_gather_forward_vs_oracle(abi, shape, crop, dt):
+    """step_gather_forward<..., 3>: the 3-D sparse shift of 4- / 8-byte elements as the linear sweep of one-step workgroups (float
+    weights; quantized int32 tensors take it when their weights are floats' stand-ins -- here: the float op on int32 bit
+    patterns is not a thing, so int32 goes through forward_quantized and must NOT take this kernel); crops, every padding,
+    shifts beyond every dim; bit-exact"""
+    rs = np.random.RandomState(sum(shape) + 77)
+    b, new = abi.check_borders(list(shape), crop, 3)
+    if dt == "i32":
+        xq = rs.randint(-1000, 1000, size=shape).astype(np.int32)
+        wq = rs.randint(124, 133, size=(shape[1], 3)).astype(np.uint8)
+        for pad in range(5):
+            out = abi.forward_quantized(torch.from_numpy(xq).to(DEV), torch.from_numpy(wq).to(DEV), 128, 5, pad, b)
+            assert abi.last_kernel() != "step_gather_forward", abi.last_kernel()   # (integer weights: the sweep / plane kernels)
+            assert np.array_equal(out.cpu().numpy(), O.forward_q(xq, wq, 128, 5, pad, b)), (shape, crop, pad)
+        return
+    npdt = np.float32 if dt == "f32" else np.float64
+    if (new[-1] * np.dtype(npdt).itemsize) % 16 or new[-1] * np.dtype(npdt).itemsize // 16 > 256:
+        pytest.skip("output rows are not whole 16-byte pieces / wider than one workgroup pass")
+    x = rs.uniform(-1, 1, size=shape).astype(npdt)
+    w = _weights(rs, shape[1], 3, shape[2:]).astype(npdt)
+    xd, wd = torch.from_numpy(x).to(DEV), torch.from_numpy(w).to(DEV)
+    for pad in range(5):
+        out = abi.forward(xd, wd, pad, 0, b)
+        assert abi.last_kernel() == "step_gather_forward", (shape, abi.last_kernel())
+        assert np.array_equal(out.cpu().numpy(), O.forward(x, w, pad, 0, b)), (shape, crop, pad)

@@ -23,6 +23,8 @@
 //   forward   kernels/shifts_kernels.h:156-220, cuda/shifts_cuda.cu:202-266
 //   backward  kernels/shifts_kernels.h:222-327, cuda/shifts_cuda.cu:270-345
 //   quantized kernels/shifts_kernels.h:532-571, quantized/shifts_quantized.cpp:107-130
+#include <algorithm>
+
 #include "shiftnd_common.hpp"
 #include "shiftnd_launch.hpp"
 #include "shiftnd_stage.hpp"
@@ -1804,7 +1806,7 @@ size_t plane_backward_workspace(const Geometry &g, int dtype) {
     const Plan pl = backward_plan(g, dtype_size(dtype));
     const size_t own = static_cast<size_t>(pl.groups) * pl.bands * static_cast<size_t>(g.C) * 3 * sizeof(double);
     const size_t slide = g.K[0] > 0 ? 0 : slide_backward_workspace(g, dtype);  // (the fused-pool calls never slide)
-    const size_t step = step_backward_workspace(g, dtype);
+    const size_t step = std::max(step_backward_workspace(g, dtype), g.K[0] > 0 ? size_t(0) : walk16_backward_workspace(g, dtype));
     const size_t m = own > slide ? own : slide;
     return m > step ? m : step;
 }
@@ -1862,6 +1864,7 @@ int plane_pool_backward(const Geometry &g, int dtype, const void *go, const void
 
 int plane_backward(const Geometry &g, int dtype, const void *go, const void *x, const void *w, void *gx, void *gw,
                    void *workspace, hipStream_t st) {
+    if (walk16_backward_eligible(g, dtype, go, x, gx)) return walk16_backward(g, dtype, go, x, w, gx, gw, workspace, st);
     if (step_backward_eligible(g, dtype, go, x, gx)) return step_backward(g, dtype, go, x, w, gx, gw, workspace, st);
     if (slide_backward_eligible(g, dtype, go, x, gx)) return slide_backward(g, dtype, go, x, w, gx, gw, workspace, st);
     const Plan pl = backward_plan(g, dtype_size(dtype));

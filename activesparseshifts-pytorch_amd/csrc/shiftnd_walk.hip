@@ -1,0 +1,454 @@
+// shiftnd_walk.hip -- the 3-D backward of 16-bit tensors as a walk through the planes, round 4 (gfx950 / MI355X).
+// DESIGN section 3.17.  BASELINE config 3 (Shift3d active, N8 C128 16x112x112 bf16) runs here.
+//
+// The walk itself is round 3's (shiftnd_step.hip, walk_backward): a workgroup owns R consecutive rows of one (n, c) volume
+// and steps through its planes; per step ONE plane of the saved input and ONE of the incoming gradient are staged (R + 1
+// rows each, global -> registers -> LDS, two planes ahead), the "+0" corner plane of a step is the previous step's "+1"
+// plane and stays in registers.  That kernel moved exactly the algorithmic bytes but issued ~200 vector instructions per
+// wave and step from 138 (zeros padding) to 192 (the other paddings) VGPRs: 3 and 2 waves per SIMD.  What changed:
+//
+//   * LDS layout by DWORD PLANES: dword i of piece p lives at plane[i][p].  The 5 dwords of a thread's shifted window are
+//     5 ds_read_b32 whose lanes hit consecutive banks (no conflicts), and the window's phase is part of the ADDRESS --
+//     no two-span read + uniform switch + 24 register moves per step (lds_window6), and no funnel shift per window.
+//   * two zero pieces behind every staged row (zeros padding): a window that leaves its row reads zeros -- no column masks
+//     (36 v_and per step).  The other paddings never mask: their maps have a source for every column.
+//   * the half-word parity of a window is handled where it is cheapest: the weight-gradient sums pair the x dwords AS THEY
+//     LIE with the own gradient chunk either as it lies or shifted by one element (5 shifts per step instead of 16 + 16),
+//     the blends unpack the right halves (two copies of the two sections, chosen by a uniform branch).
+//   * 16-bit interpolation nests the three blends inner-first (row, column, then plane) instead of the reference's plane,
+//     row, column (interpolation.h:34-40): the row / column blend of a plane is computed once and carried to the next step
+//     -- 8 fp32 values instead of 18, 50 instead of 70 blend instructions.  fp32 / fp64 tensors keep the reference's nesting
+//     bit for bit (shiftnd_step.hip); 16-bit tensors have no executable reference arithmetic (fp32 math on the
+//     widened inputs, one rounding, within 1 ulp of the 16-bit type) and the tests hold this kernel to exactly that.
+//   * the running sums stay fp32 in registers across at most 16 planes and are flushed per WAVE (DPP tree) into fp64
+//     slots: no per-thread fp64 slots in LDS (16 KB), 16.6 KB of LDS per workgroup in all.
+//   * chunks whose column map is not a plain shift (the row ends of border / periodic / reflect / symmetric) gather their
+//     9 elements through 9 precomputed LDS addresses; the padding mode is a run-time value there (two instantiations per
+//     dtype and shift kind instead of five).
+//
+// Reference behaviour restated: kernels/shifts_kernels.h:222-327 (backward), :132-154 (weight gradients),
+// kernels/interpolation.h:34-61; cpu/shifts_cpu.cpp:242-244 (weight preparation: step_prep).
+#include "shiftnd_step.hpp"
+
+namespace shiftnd {
+namespace {
+
+constexpr int kWalkSlots = 512;                        // piece slots per dword plane: 448 of the tile, 64 dump slots
+constexpr int kWalkPlaneBytes = kWalkSlots * 4;
+constexpr int kWalkTileBytes = 4 * kWalkPlaneBytes;    // one tensor's tile
+constexpr int kWalkMargin = 2;                         // zero pieces in front of row 0
+constexpr int kWalkGuard = 2;                          // zero pieces behind every row
+constexpr int kWalkDump0 = 448;
+constexpr int kWalkFlush = 16;                         // planes between two flushes of the fp32 sums
+
+typedef uint32_t u4_t __attribute__((ext_vector_type(4)));
+
+// byte offset (within a tile) of dword D of the piece-linear dword stream
+__device__ __forceinline__ uint32_t walk_dword_at(int D) { return static_cast<uint32_t>((D & 3) * kWalkPlaneBytes + (D >> 2) * 4); }
+// ... of 16-bit element m of the row whose first piece sits in slot `slot0`
+__device__ __forceinline__ uint32_t walk_elem_at(int slot0, int m) {
+    return static_cast<uint32_t>(((m >> 1) & 3) * kWalkPlaneBytes + (slot0 + (m >> 3)) * 4 + (m & 1) * 2);
+}
+
+template <typename T> __device__ __forceinline__ float half_value(uint32_t dword, int hi) {
+    const uint16_t h = static_cast<uint16_t>(hi ? dword >> 16 : dword);
+    return widen<T>(__builtin_bit_cast(typename T::S, h));
+}
+
+// Column state of a thread's window through one map.  NA addresses: zeros padding 5 (the window's dwords); otherwise 9 --
+// a plain-shift chunk uses the first 5 as dword addresses, any other chunk all 9 as element addresses.
+template <int NA> struct WalkWindow {
+    uint32_t at[NA];   // byte offsets within the tile, row 0 of the thread (row 1: + row pitch)
+    bool plain;        // the window is 5 consecutive dwords
+};
+
+template <bool ZEROS, int NA>
+__device__ __forceinline__ WalkWindow<NA> walk_window(int ji, int cs, int S2, int pad, int slot0, bool live) {
+    WalkWindow<NA> w;
+    w.plain = true;
+    int D = 0;   // the margin: zeros
+    if constexpr (ZEROS) {
+        const int first = ji - cs;   // column of window element 0
+        if (live && first + 8 >= 0 && first < S2) D = slot0 * 4 + ((first * 2) >> 2);   // (floor: first >= -8)
+#pragma unroll
+        for (int i = 0; i < NA; ++i) w.at[i] = walk_dword_at(D + i);
+    } else {
+        int cm[9];
+        bool run = true;
+#pragma unroll
+        for (int k = 0; k < 9; ++k) {
+            cm[k] = fold_index(ji + k - cs, S2, pad);   // paddings 1 .. 4: always a column
+            run = run && cm[k] == cm[0] + k;
+        }
+        w.plain = run || !live;
+        if (live && run) D = slot0 * 4 + (cm[0] >> 1);
+        if (w.plain) {
+#pragma unroll
+            for (int i = 0; i < NA; ++i) w.at[i] = walk_dword_at(D + (i < 5 ? i : 4));
+        } else {
+#pragma unroll
+            for (int k = 0; k < NA; ++k) w.at[k] = walk_elem_at(slot0, cm[k < 9 ? k : 8]);
+        }
+    }
+    return w;
+}
+
+// the 5 dwords of a window: half (k + PAR) of the result is window element k
+template <bool ZEROS, int NA, int PAR>
+__device__ __forceinline__ void walk_read(const char *tile, const WalkWindow<NA> &w, uint32_t row_off, uint32_t (&o)[5]) {
+    if (ZEROS || w.plain) {
+#pragma unroll
+        for (int i = 0; i < 5; ++i) o[i] = *reinterpret_cast<const uint32_t *>(tile + w.at[i] + row_off);
+    } else {
+        uint32_t h[9];
+#pragma unroll
+        for (int k = 0; k < 9; ++k) h[k] = *reinterpret_cast<const uint16_t *>(tile + w.at[k < NA ? k : 0] + row_off);
+        if constexpr (PAR == 0) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) o[i] = h[2 * i] | (h[2 * i + 1] << 16);
+            o[4] = h[8];
+        } else {
+            o[0] = h[0] << 16;
+#pragma unroll
+            for (int i = 1; i < 5; ++i) o[i] = h[2 * i - 1] | (h[2 * i] << 16);
+        }
+    }
+}
+
+template <typename T, bool ACTIVE, bool ZEROS>
+__global__ __launch_bounds__(kThreads) void walk_backward16(const StepParams p) {
+    using S = typename T::S;
+    static_assert(sizeof(S) == 2, "16-bit element types");
+    constexpr int E = 8;
+    constexpr int NA = ZEROS ? 5 : 9;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char *const tx = smem;
+    char *const tg = smem + kWalkTileBytes;
+    double *const wsum = reinterpret_cast<double *>(smem + 2 * kWalkTileBytes);   // [waves][8]
+
+    const uint32_t bid = (blockIdx.x & 7u) * p.steps_per_xcd + (blockIdx.x >> 3);   // XCD-contiguous ids
+    if (bid >= p.total_steps) return;
+    const uint32_t plane = fdiv(bid, p.d_spp);   // (n, c)
+    const int step = static_cast<int>(bid - plane * static_cast<uint32_t>(p.spp));
+    const int c = static_cast<int>(plane - fdiv(plane, p.d_C) * static_cast<uint32_t>(p.C));
+    const ChanDesc d = p.desc[c];
+    const int pad = ZEROS ? 0 : p.pad;
+    const int R = p.R, S0 = p.S0, S1 = p.S1, S2 = p.S2, cpr = p.cpr;
+    const int b0 = step * R;
+    const int Rn = min(R, S1 - b0);
+    const int tid = static_cast<int>(threadIdx.x);
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tr = static_cast<int>(fdiv(static_cast<uint32_t>(tid), p.d_cpr)), tc = tid - tr * cpr;
+    const int ji = tc * E;
+    const int RP = cpr + kWalkGuard;   // row pitch of the tile in pieces
+
+    // ---- zero the tiles (margin, guards) and the wave sums ------------------------------------------------------------------
+    for (int o = tid * 16; o < 2 * kWalkTileBytes + (kThreads / 64) * 8 * static_cast<int>(sizeof(double)); o += kThreads * 16)
+        *reinterpret_cast<u4_t *>(__builtin_assume_aligned(smem + o, 16)) = u4_t{0u, 0u, 0u, 0u};
+
+    // ---- the pieces this thread stages, the same for every plane: piece tc of row tr, tr <= min(R, Rn) ----------------------
+    const bool own = tr <= R && tr <= Rn;
+    const int sx_own = own ? row_map(b0 + tr, d.cx1, S1, pad) : -1;
+    const int sg_own = (own && (ACTIVE || tr < R)) ? row_map(b0 + tr, d.cg1, S1, pad) : -1;
+    constexpr uint32_t kOOR = 0x80000000u;
+    constexpr int kRsrcFlags = 0x00020000;
+    const uint32_t plane_bytes = static_cast<uint32_t>(S1) * static_cast<uint32_t>(S2) * 2u;
+    const uint32_t vol_bytes = static_cast<uint32_t>(S0) * plane_bytes;   // < 2^31 (host)
+    const char *xp = reinterpret_cast<const char *>(static_cast<const S *>(p.x) + static_cast<int64_t>(plane) * p.x_plane);
+    const char *gp = reinterpret_cast<const char *>(static_cast<const S *>(p.go) + static_cast<int64_t>(plane) * p.x_plane);
+    char *gxp = reinterpret_cast<char *>(static_cast<S *>(p.out) + static_cast<int64_t>(plane) * p.x_plane);
+    const __amdgpu_buffer_rsrc_t xres = __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(xp), 0, vol_bytes, kRsrcFlags);
+    const __amdgpu_buffer_rsrc_t gres = __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(gp), 0, vol_bytes, kRsrcFlags);
+    const __amdgpu_buffer_rsrc_t ores = __builtin_amdgcn_make_buffer_rsrc(gxp, 0, vol_bytes, kRsrcFlags);
+    const __amdgpu_buffer_rsrc_t none = __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(xp), 0, 0, kRsrcFlags);
+    const uint32_t vx_own = sx_own >= 0 ? static_cast<uint32_t>(sx_own * S2 + ji) * 2u : kOOR;
+    const uint32_t vg_own = sg_own >= 0 ? static_cast<uint32_t>(sg_own * S2 + ji) * 2u : kOOR;
+    // (a thread without a piece loads zeros -- out-of-range offset -- and parks them in a dump slot: every memory
+    //  instruction of the loop is unconditional, the compiler's wait counts are exact)
+    const uint32_t park_at = static_cast<uint32_t>(own ? kWalkMargin + tr * RP + tc : kWalkDump0 + (tid & 63)) * 4u;
+    struct Staged { u4_t xo, go; };
+    auto load_planes = [&](int pax, int pag, Staged &v) {   // source planes (uniform; -1: fill)
+        v.xo = __builtin_amdgcn_raw_buffer_load_b128(pax >= 0 ? xres : none, vx_own, pax >= 0 ? static_cast<uint32_t>(pax) * plane_bytes : 0u, 0);
+        v.go = __builtin_amdgcn_raw_buffer_load_b128(pag >= 0 ? gres : none, vg_own, pag >= 0 ? static_cast<uint32_t>(pag) * plane_bytes : 0u, 0);
+    };
+    auto park_piece = [&](char *tile, const u4_t &v) {
+        uint32_t *q = reinterpret_cast<uint32_t *>(tile + park_at);
+        q[0] = v.x;
+        q[kWalkSlots] = v.y;
+        q[2 * kWalkSlots] = v.z;
+        q[3 * kWalkSlots] = v.w;
+    };
+    auto park = [&](const Staged &v) {
+        park_piece(tx, v.xo);
+        park_piece(tg, v.go);
+    };
+
+    // ---- this thread's chunk ---------------------------------------------------------------------------------------------------
+    const bool mine = tr < R && tr < Rn;
+    const int b = b0 + tr;
+    const int slot0 = kWalkMargin + tr * RP;
+    const WalkWindow<NA> wx = walk_window<ZEROS, NA>(ji, d.cx2, S2, pad, slot0, mine);
+    const WalkWindow<NA> wg = walk_window<ZEROS, NA>(ji, d.cg2, S2, pad, slot0, mine);
+    const uint32_t row1 = static_cast<uint32_t>(RP) * 4u;
+    const int px = d.cx2 & 1, pg = d.cg2 & 1;   // half-word parity of the windows (uniform: rows are whole pieces)
+    const float dP = static_cast<float>(d.dw[0]), dR = static_cast<float>(d.dw[1]), dC = static_cast<float>(d.dw[2]);
+    const uint32_t my = mine ? static_cast<uint32_t>(b * S2 + ji) * 2u : kOOR;   // own chunk, bytes within a plane
+    auto load_own = [&](int a, bool have) {
+        return __builtin_amdgcn_raw_buffer_load_b128(have ? gres : none, my, static_cast<uint32_t>(a) * plane_bytes, 0);
+    };
+    auto lerp = [](float v1, float v2, float x) { return lerp1_fused<float>(v1, v2, x); };
+
+    // row / column blend of one gradient plane at this thread's chunk (ACTIVE): B[e] = blend over rows b, b + 1 and columns
+    // e, e + 1 of the staged plane.  PAR = half-word parity of the window.
+    auto plane_blend = [&](auto par_tag, float (&B)[E]) {
+        constexpr int PAR = decltype(par_tag)::value;
+        uint32_t r0[5], r1[5];
+        walk_read<ZEROS, NA, PAR>(tg, wg, 0u, r0);
+        walk_read<ZEROS, NA, PAR>(tg, wg, row1, r1);
+        float rb[E + 1];
+#pragma unroll
+        for (int k = 0; k <= E; ++k) {
+            const int h = k + PAR;
+            rb[k] = lerp(half_value<T>(r0[h >> 1], h & 1), half_value<T>(r1[h >> 1], h & 1), dR);
+        }
+#pragma unroll
+        for (int e = 0; e < E; ++e) B[e] = lerp(rb[e], rb[e + 1], dC);
+    };
+    // weight-gradient sums of one step: corners (plane pl, row hb) of x against the own gradient chunk, as the x dwords lie.
+    // sa: the chunk as it lies against dwords PAR .. PAR + 3, sb: the chunk shifted by one element against dwords 0 .. 4.
+    // Column offset 0 / 1 of the corner = (sa, sb) for an even window, (sb, sa) for an odd one.
+    auto wgrad = [&](auto par_tag, const u4_t &g, const uint32_t (&x0)[2][5], uint32_t (&x1)[2][5], float (&sa)[2][2], float (&sb)[2][2]) {
+        constexpr int PAR = decltype(par_tag)::value;
+        walk_read<ZEROS, NA, PAR>(tx, wx, 0u, x1[0]);
+        walk_read<ZEROS, NA, PAR>(tx, wx, row1, x1[1]);
+        const uint32_t gq[4] = {g.x, g.y, g.z, g.w};
+        const uint32_t gs[5] = {gq[0] << 16, __builtin_amdgcn_alignbit(gq[1], gq[0], 16), __builtin_amdgcn_alignbit(gq[2], gq[1], 16),
+                                __builtin_amdgcn_alignbit(gq[3], gq[2], 16), gq[3] >> 16};
+#pragma unroll
+        for (int hb = 0; hb < 2; ++hb) {
+#pragma unroll
+            for (int pl = 0; pl < 2; ++pl) {
+                const uint32_t(&w)[5] = pl ? x1[hb] : x0[hb];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) sa[pl][hb] = dot2_packed<T>(gq[i], w[i + PAR], sa[pl][hb]);
+#pragma unroll
+                for (int i = 0; i < 5; ++i) sb[pl][hb] = dot2_packed<T>(gs[i], w[i], sb[pl][hb]);
+            }
+        }
+    };
+    using par0 = std::integral_constant<int, 0>;
+    using par1 = std::integral_constant<int, 1>;
+
+    // ---- the "+0" planes of the first step --------------------------------------------------------------------------------------
+    uint32_t xa[2][5], xb[2][5];     // packed x windows of the two corner planes (alternating roles)
+    float Ba[E], Bb[E];              // ACTIVE: blended gradient planes (alternating roles)
+    float sa[2][2] = {{0.f, 0.f}, {0.f, 0.f}}, sb[2][2] = {{0.f, 0.f}, {0.f, 0.f}};
+    {
+        Staged v0;
+        load_planes(row_map(0, d.cx0, S0, pad), ACTIVE ? row_map(0, d.cg0, S0, pad) : -1, v0);
+        __syncthreads();   // the tiles are zero
+        park(v0);
+        __syncthreads();
+        if (px) {
+            walk_read<ZEROS, NA, 1>(tx, wx, 0u, xa[0]);
+            walk_read<ZEROS, NA, 1>(tx, wx, row1, xa[1]);
+        } else {
+            walk_read<ZEROS, NA, 0>(tx, wx, 0u, xa[0]);
+            walk_read<ZEROS, NA, 0>(tx, wx, row1, xa[1]);
+        }
+        if constexpr (ACTIVE) {
+            if (pg) plane_blend(par1{}, Ba);
+            else plane_blend(par0{}, Ba);
+        }
+    }
+    __syncthreads();   // the "+0" planes have been read
+    constexpr int GA = ACTIVE ? 1 : 0;   // the gradient plane of step a: the "+1" corner plane / the plane the tap reads
+    Staged stA, stB;
+    load_planes(row_map(1, d.cx0, S0, pad), row_map(GA, d.cg0, S0, pad), stA);
+    load_planes(1 < S0 ? row_map(2, d.cx0, S0, pad) : -1, 1 < S0 ? row_map(1 + GA, d.cg0, S0, pad) : -1, stB);
+    u4_t gcur = load_own(0, true);
+
+    auto flush = [&]() {   // fp32 sums of this wave -> its fp64 slots (fixed DPP tree, lane 63)
+        const float v[8] = {sa[0][0], sa[1][0], sa[0][1], sa[1][1], sb[0][0], sb[1][0], sb[0][1], sb[1][1]};   // [kind][hb][pl]
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const float t = wave_total(v[i]);
+            if ((tid & 63) == 63) wsum[wave * 8 + i] += static_cast<double>(t);
+        }
+#pragma unroll
+        for (int pl = 0; pl < 2; ++pl)
+#pragma unroll
+            for (int hb = 0; hb < 2; ++hb) sa[pl][hb] = sb[pl][hb] = 0.f;
+    };
+
+    // one step: `pend` holds the planes of step a and leaves with those of step a + 2 in flight; x0 / B0: the "+0" planes (in),
+    // x1 / B1: the "+1" planes (out: the next step's "+0")
+    auto walk_step = [&](int a, Staged &pend, const uint32_t (&x0)[2][5], uint32_t (&x1)[2][5], const float (&B0)[E], float (&B1)[E]) {
+        park(pend);
+        __syncthreads();
+        const bool more = a + 2 < S0;
+        load_planes(more ? row_map(a + 3, d.cx0, S0, pad) : -1, more ? row_map(a + 2 + GA, d.cg0, S0, pad) : -1, pend);
+        if (px) wgrad(par1{}, gcur, x0, x1, sa, sb);
+        else wgrad(par0{}, gcur, x0, x1, sa, sb);
+        gcur = load_own(a + 1, a + 1 < S0);   // the next step's own chunk: in flight through the blends and the next staging
+        u4_t res;
+        if constexpr (ACTIVE) {
+            if (pg) plane_blend(par1{}, B1);
+            else plane_blend(par0{}, B1);
+            float o[E];
+#pragma unroll
+            for (int e = 0; e < E; ++e) o[e] = lerp(B0[e], B1[e], dP);
+            Chunk<S, E> ch;
+#pragma unroll
+            for (int e = 0; e < E; ++e) ch.e[e] = narrow<T>(o[e]);
+            __builtin_memcpy(&res, ch.e, 16);
+        } else {   // the sparse shift: the window itself (bit patterns kept)
+            uint32_t t[5];
+            if (pg) {
+                walk_read<ZEROS, NA, 1>(tg, wg, 0u, t);
+                res = u4_t{__builtin_amdgcn_alignbit(t[1], t[0], 16), __builtin_amdgcn_alignbit(t[2], t[1], 16),
+                           __builtin_amdgcn_alignbit(t[3], t[2], 16), __builtin_amdgcn_alignbit(t[4], t[3], 16)};
+            } else {
+                walk_read<ZEROS, NA, 0>(tg, wg, 0u, t);
+                res = u4_t{t[0], t[1], t[2], t[3]};
+            }
+        }
+        __builtin_amdgcn_raw_buffer_store_b128(res, ores, my, static_cast<uint32_t>(a) * plane_bytes, 0);
+        if ((a & (kWalkFlush - 1)) == kWalkFlush - 1) flush();
+        __syncthreads();   // everybody has read this step's planes
+    };
+    int a = 0;
+    for (; a + 1 < S0; a += 2) {   // whole pairs: no condition between the steps (exact wait counts)
+        walk_step(a, stA, xa, xb, Ba, Bb);
+        walk_step(a + 1, stB, xb, xa, Bb, Ba);
+    }
+    if (a < S0) walk_step(a, stA, xa, xb, Ba, Bb);
+    if ((S0 & (kWalkFlush - 1)) != 0) flush();
+    __syncthreads();
+    // ---- the workgroup's record: per-corner sums -> the corner-difference sums (corner_diffs is linear) ------------------------
+    if (tid < 8) {
+        double s[8];   // [kind][hb][pl]
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            s[i] = 0.0;
+#pragma unroll
+            for (int w = 0; w < kThreads / 64; ++w) s[i] += wsum[w * 8 + i];
+        }
+        // corner q = pl | hb << 1 | col << 2 (step_backward's order); col = kind for an even x window, 1 - kind for an odd one
+        double v[8], df[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int pl = q & 1, hb = (q >> 1) & 1, col = q >> 2;
+            const int kind_even = col, kind_odd = 1 - col;
+            const double se = s[kind_even * 4 + hb * 2 + pl], so = s[kind_odd * 4 + hb * 2 + pl];
+            v[q] = px ? so : se;
+        }
+        corner_diffs<3, double>(v, df);
+        double out = df[0];
+#pragma unroll
+        for (int i = 1; i < 8; ++i) out = tid == i ? df[i] : out;
+        p.partials[static_cast<size_t>(bid) * 8 + tid] = out;
+    }
+}
+
+struct WalkPlan {
+    int cpr, R, spp;
+    uint64_t total;
+    size_t off_desc, bytes;
+};
+
+WalkPlan walk_plan(const Geometry &g) {
+    WalkPlan w{};
+    w.cpr = static_cast<int>(g.S[2] * 2 / 16);
+    if (w.cpr < 1) w.cpr = 1;
+    // (R + 1) * cpr <= 256: every staged piece has its thread; the tile: margin + (R + 1) * (cpr + guard) <= 448 slots
+    int rmax = kThreads / w.cpr - 1;
+    rmax = std::min(rmax, (kWalkDump0 - kWalkMargin) / (w.cpr + kWalkGuard) - 1);
+    rmax = std::max(1, std::min<int>(rmax, static_cast<int>(g.S[1])));
+    w.spp = static_cast<int>((g.S[1] + rmax - 1) / rmax);
+    w.R = static_cast<int>((g.S[1] + w.spp - 1) / w.spp);   // balanced steps: 112 rows of 14 pieces -> 7 steps of 16 rows
+    w.total = static_cast<uint64_t>(g.N) * g.C * w.spp;
+    auto up = [](size_t v) { return (v + 255) & ~static_cast<size_t>(255); };
+    w.off_desc = up(w.total * 8 * sizeof(double));
+    w.bytes = w.off_desc + up(static_cast<size_t>(g.C) * sizeof(ChanDesc));
+    return w;
+}
+
+bool walk16_geometry_ok(const Geometry &g, int dtype) {
+    if ((dtype != SHIFTND_F16 && dtype != SHIFTND_BF16) || g.nd != 3 || g.K[0] > 0 || g.S[0] < 2) return false;
+    for (int d = 0; d < 3; ++d)
+        if (g.O[d] != g.S[d] || g.L[d] != 0) return false;
+    if (g.S[1] < 1 || (g.S[2] * 2) % 16 != 0 || g.S[2] * 2 / 16 > kThreads / 2 || g.S[2] > 32000) return false;
+    if (g.S[0] * g.S[1] * g.S[2] * 2 >= (1LL << 31)) return false;   // (one buffer resource spans an (n, c) volume)
+    return walk_plan(g).total + 8 < (1ull << 31);
+}
+
+}  // namespace
+
+// the 3-D backward of fp16 / bf16 tensors (both shifts, every padding): contiguous, no crop, rows of whole 16-byte pieces
+bool walk16_backward_eligible(const Geometry &g, int dtype, const void *go, const void *x, const void *gx) {
+    if (g_step_tune[0] == 1 || (g_step_tune[3] & (16 | 64 | 1))) return false;   // knob 35 bit 4: no walk; bit 6: round 3's; bit 0: one-step
+    if (!walk16_geometry_ok(g, dtype)) return false;
+    if (!dense(g.xs, g.N, g.C, g.S) || !dense(g.os, g.N, g.C, g.O) || !dense(g.gs, g.N, g.C, g.S)) return false;
+    return reinterpret_cast<uintptr_t>(go) % 16 == 0 && reinterpret_cast<uintptr_t>(x) % 16 == 0 && reinterpret_cast<uintptr_t>(gx) % 16 == 0;
+}
+
+size_t walk16_backward_workspace(const Geometry &g, int dtype) { return walk16_geometry_ok(g, dtype) ? walk_plan(g).bytes : 0; }
+
+int walk16_backward(const Geometry &g, int dtype, const void *go, const void *x, const void *w, void *gx, void *gw, void *workspace,
+                    hipStream_t st) {
+    const WalkPlan W = walk_plan(g);
+    StepParams p{};
+    p.x = x;
+    p.go = go;
+    p.out = gx;
+    p.w = w;
+    char *ws = static_cast<char *>(workspace);
+    p.partials = reinterpret_cast<double *>(ws);
+    p.desc = reinterpret_cast<ChanDesc *>(ws + W.off_desc);
+    p.colx = p.colg = nullptr;   // (no column tables: the kernel folds its maps itself)
+    p.x_plane = g.S[0] * g.S[1] * g.S[2];
+    p.wkind = dtype;
+    p.N = static_cast<int>(g.N);
+    p.C = static_cast<int>(g.C);
+    p.pad = g.pad;
+    p.nd = 3;
+    p.S0 = static_cast<int>(g.S[0]);
+    p.S1 = static_cast<int>(g.S[1]);
+    p.S2 = static_cast<int>(g.S[2]);
+    p.cpr = W.cpr;
+    p.R = W.R;
+    p.spp = p.spv = W.spp;
+    p.walk_planes = p.S0;
+    p.total_steps = static_cast<uint32_t>(W.total);
+    p.steps_per_xcd = static_cast<uint32_t>((W.total + 7) / 8);
+    p.d_spp = p.d_spv = make_fastdiv(static_cast<uint32_t>(W.spp));
+    p.d_C = make_fastdiv(static_cast<uint32_t>(p.C));
+    p.d_cpr = make_fastdiv(static_cast<uint32_t>(W.cpr));
+    p.d_per0 = make_fastdiv(static_cast<uint32_t>(map_period(p.S0, g.pad)));
+    p.d_per1 = make_fastdiv(static_cast<uint32_t>(map_period(p.S1, g.pad)));
+    p.d_per2 = make_fastdiv(static_cast<uint32_t>(map_period(p.S2, g.pad)));
+    const size_t lds = 2 * kWalkTileBytes + (kThreads / 64) * 8 * sizeof(double);
+    const dim3 grid(p.steps_per_xcd * 8), block(kThreads);
+    const bool active = g.active != 0, zeros = g.pad == 0;
+    note_kernel(active ? "walk_backward16" : "walk_backward16_sparse");
+#define SHIFTND_WALK16(TT) \
+    { \
+        using GW = typename TT::S; \
+        if (active) { \
+            hipLaunchKernelGGL((step_prep<TT, true>), dim3(p.C), block, 0, st, p); \
+            if (zeros) hipLaunchKernelGGL((walk_backward16<TT, true, true>), grid, block, lds, st, p); \
+            else hipLaunchKernelGGL((walk_backward16<TT, true, false>), grid, block, lds, st, p); \
+        } else { \
+            hipLaunchKernelGGL((step_prep<TT, false>), dim3(p.C), block, 0, st, p); \
+            if (zeros) hipLaunchKernelGGL((walk_backward16<TT, false, true>), grid, block, lds, st, p); \
+            else hipLaunchKernelGGL((walk_backward16<TT, false, false>), grid, block, lds, st, p); \
+        } \
+        hipLaunchKernelGGL((step_reduce<TT, 3>), dim3(p.C), block, 0, st, p, static_cast<GW *>(gw)); \
+    }
+    if (dtype == SHIFTND_F16) SHIFTND_WALK16(f16_t) else SHIFTND_WALK16(bf16_t)
+#undef SHIFTND_WALK16
+    return SHIFTND_OK;
+}
+
+}  // namespace shiftnd

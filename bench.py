@@ -10,7 +10,7 @@ drop-in dispatcher ops torch.ops.torchshifts._shift2d_forward/_backward (allocat
 and the workspace included).  Inputs are resident in HBM before the timed region.
 
 The JSON line also carries
-  roofline      the dominant kernel (plane_backward): algorithmic bytes (3*s per element, SURVEY
+  roofline      the dominant kernel (step_backward on C2): algorithmic bytes (3*s per element, SURVEY
                 section 8d) / average launch duration measured with HIP events on the launch
                 stream, against the 8 TB/s HBM peak
   cpu_baseline  the REAL reference CPU kernels (oracle/_ref, built from /root/reference) timed on
@@ -19,7 +19,7 @@ The JSON line also carries
   roofline.box_stream / frac_of_box   the same box's plain 1R1W / 2R1W float4 streams (tools/stream_probe, a child
                 process that has exited before this one touches the GPU) and the dominant kernel's rate against them
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c2|c3|c4|c5|c2a] [--pad 0..4]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c2|c3|c4|c5|c2a|c2crop|c2acrop|t1|t1a|c1d|c1da|c1dh] [--pad 0..4]
 
 Multi-GPU: `python bench.py --gpus N` starts the N rank processes itself (one per GPU; the parent never
 touches the GPU); under a launcher (`python -m torch.distributed.run --nproc-per-node N bench.py --gpus N`)
@@ -46,7 +46,20 @@ WORKLOADS = {
     "c5": (2, (64, 512, 224, 224), "float16", False, "Shift2d SSL fwd+bwd N64 C512 224x224 fp16 (per GPU)"),
     # not a BASELINE config: C2's tensor through the interpolating (active) kernels
     "c2a": (2, (64, 256, 224, 224), "float32", True, "Shift2d active fwd+bwd N64 C256 224x224 fp32"),
+    # round 4 -- the reference's everyday cases: cropped windows (every emulate_dw module with padding < kernel // 2,
+    # modules/shifts.py:41-46) and Shift1d (functional.py:7-36).  t1 / t1a = the reference's own test script
+    # (tests/shifts_test.py:9-28: N512 C16 64x64, 3x3 depthwise emulation without padding -> cut 1 / 1, output 62x62)
+    "c2crop": (2, (64, 256, 224, 224), "float32", False, "Shift2d SSL fwd+bwd N64 C256 224x224 fp32, cut [[1,1],[1,1]] (output 222x222)"),
+    "c2acrop": (2, (64, 256, 224, 224), "float32", True, "Shift2d active fwd+bwd N64 C256 224x224 fp32, cut [[1,1],[1,1]] (output 222x222)"),
+    "t1": (2, (512, 16, 64, 64), "float32", False, "Shift2d SSL fwd+bwd N512 C16 64x64 fp32, cut [[1,1],[1,1]] (the reference's tests/shifts_test.py)"),
+    "t1a": (2, (512, 16, 64, 64), "float32", True, "Shift2d active fwd+bwd N512 C16 64x64 fp32, cut [[1,1],[1,1]] (the reference's tests/shifts_test.py)"),
+    "c1d": (1, (256, 512, 4096), "float32", False, "Shift1d SSL fwd+bwd N256 C512 L4096 fp32"),
+    "c1da": (1, (256, 512, 4096), "float32", True, "Shift1d active fwd+bwd N256 C512 L4096 fp32"),
+    "c1dh": (1, (256, 512, 4096), "float16", False, "Shift1d SSL fwd+bwd N256 C512 L4096 fp16"),
 }
+
+# user `borders` of the cropped workloads ([nD, 2] cut-left / cut-right amounts, functional.py:22,32-35)
+CUTS = {"c2crop": [[1, 1], [1, 1]], "c2acrop": [[1, 1], [1, 1]], "t1": [[1, 1], [1, 1]], "t1a": [[1, 1], [1, 1]]}
 
 
 def shard_range(n, rank, world):
@@ -288,7 +301,15 @@ def main(argv=None):
     ops = torch.ops.torchshifts
     fwd_op = getattr(ops, "_shift%dd_forward" % nd)
     bwd_op = getattr(ops, "_shift%dd_backward" % nd)
-    borders = torch.tensor(abi.default_borders(torch.empty(shape, device="meta")), dtype=torch.int32)  # host
+    cuts = CUTS.get(a.workload)
+    if cuts is None:
+        bl, oshape = abi.default_borders(torch.empty(shape, device="meta")), list(shape)
+    else:  # check_borders (ops/shifts.cpp:93-135): cut amounts -> the absolute [l, r) window and the output size
+        bl, oshape = abi.check_borders(list(shape), cuts, nd)
+    borders = torch.tensor(bl, dtype=torch.int32)  # host
+    oelems = 1
+    for s_ in oshape:
+        oelems *= s_
 
     # ---- synthetic inputs (resident before timing) ----------------------------------------------------
     seed = 1000 * rank
@@ -306,15 +327,15 @@ def main(argv=None):
         if not on_gpu and dtype in (torch.float16, torch.bfloat16):
             dtype = torch.float32  # the CPU key serves float/double like the reference's (shifts_cpu.cpp:228)
         x = synth_tensor(torch, shape, seed + 1, dev, dtype)
-        go = synth_tensor(torch, shape, seed + 2, dev, dtype)
+        go = synth_tensor(torch, tuple(oshape), seed + 2, dev, dtype)
         w = w32.to(dtype)
         esize = x.element_size()
     sync()
 
     def step():
         if quant:
-            return fwd_op(xq, wq, borders, list(shape), a.pad, False)
-        out = fwd_op(x, w, borders, list(shape), a.pad, active)
+            return fwd_op(xq, wq, borders, oshape, a.pad, False)
+        out = fwd_op(x, w, borders, oshape, a.pad, active)
         gx, gw = bwd_op(go, w, x, borders, a.pad, active)
         return out, gx, gw
 
@@ -385,21 +406,24 @@ def main(argv=None):
             record(qname, t_f, 2 * esize * elems, "1R1W")
             dom_name, dom_ms, dom_bytes, dom_kind = qname, t_f[0], 2 * esize * elems, "1R1W"
         else:
-            outb, gxb, gwb = torch.empty_like(x), torch.empty_like(x), torch.empty_like(w)
-            ws = abi.backward_workspace(x, a.pad, active)
-            t_f = event_time(lambda: abi.forward(x, w, a.pad, active, out=outb), kiters)
-            t_b = event_time(lambda: abi.backward(go, w, x, a.pad, active, grad_x=gxb, grad_w=gwb, workspace=ws), kiters)
-            abi.forward(x, w, a.pad, active, out=outb)
+            outb, gxb, gwb = torch.empty_like(go), torch.empty_like(x), torch.empty_like(w)
+            bk = None if cuts is None else bl
+            ws = abi.backward_workspace(x, a.pad, active, bk)
+            t_f = event_time(lambda: abi.forward(x, w, a.pad, active, borders=bk, out=outb), kiters)
+            t_b = event_time(lambda: abi.backward(go, w, x, a.pad, active, borders=bk, grad_x=gxb, grad_w=gwb, workspace=ws), kiters)
+            abi.forward(x, w, a.pad, active, borders=bk, out=outb)
             fname = abi.last_kernel()
-            abi.backward(go, w, x, a.pad, active, grad_x=gxb, grad_w=gwb, workspace=ws)
+            abi.backward(go, w, x, a.pad, active, borders=bk, grad_x=gxb, grad_w=gwb, workspace=ws)
             bname = abi.last_kernel()
-            record(fname, t_f, 2 * esize * elems, "1R1W")
-            record(bname, t_b, 3 * esize * elems, "2R1W")
-            dom_name, dom_ms, dom_bytes, dom_kind = bname, t_b[0], 3 * esize * elems, "2R1W"
+            # algorithmic bytes: forward reads x, writes out; backward reads grad_out and x, writes grad_x
+            # (a cropped window: out / grad_out have the window's size)
+            record(fname, t_f, esize * (elems + oelems), "1R1W")
+            record(bname, t_b, esize * (2 * elems + oelems), "2R1W")
+            dom_name, dom_ms, dom_bytes, dom_kind = bname, t_b[0], esize * (2 * elems + oelems), "2R1W"
     path = "+".join(sorted(set(k.split("_")[0] for k in kernels))) or "cpu key"
 
     if rank == 0:
-        step_bytes = (2 if quant else 5) * esize * elems
+        step_bytes = 2 * esize * elems if quant else esize * (3 * elems + 2 * oelems)
         result = {
             "metric": "Gelem/s, Shift2d fwd+bwd N64/C256/224x224" if a.workload == "c2" and not a.shape
                       else "Gelem/s, " + desc,

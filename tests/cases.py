@@ -43,6 +43,14 @@ def quant_cases(nds=(1, 2, 3)):
                             yield key, nd, xname, layout, wname, pad, crop, xq, xzp, wq, wzp, d["out_" + key]
 
 
+def gw16_tol(eps):
+    """Bound of a 16-bit weight gradient against the fp64 evaluation, relative to the largest entry (rel_err): the kernels carry the
+    sums in fp32 / fp64 and round ONCE to the storage type -- half a unit in the last place, i.e. eps / 2 of the entry (eps =
+    torch.finfo(dtype).eps), plus the fp64 -> fp32 -> 16-bit double rounding (2^-17 of that).  A dropped row group or a wrong corner
+    shows up far above this; the earlier 2 * eps did not always."""
+    return 0.51 * float(eps)
+
+
 def rel_err(a, ref):
     """max |a - ref| / max(|ref|max, tiny): scale-relative error used for fp tolerances"""
     a = np.asarray(a, np.float64)

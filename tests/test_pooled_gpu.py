@@ -136,7 +136,7 @@ def test_pooled_16bit(abi, tdt):
                     if nd == 3:
                         assert (abi.last_kernel() == "walk_backward_pool") == (policy == 0), (shape, policy, abi.last_kernel())
                     assert np.max(np.abs(gx.float().cpu().numpy() - gx_r)) <= eps * max(1.0, np.max(np.abs(gx_r)))
-                    assert rel_err(gw.float().cpu().numpy(), gw_r) < 4 * eps
+                    assert rel_err(gw.float().cpu().numpy(), gw_r) < 1.02 * eps + 1e-5   # one rounding (eps = half a unit) + the fp32 oracle's own error
 
 
 def test_pooled_matches_unfused_fullsize(abi):
@@ -296,4 +296,4 @@ def test_pooled_3d_walk_backward(abi, shape, pool, dt):
                 g = torch.from_numpy(O.avg_pool_backward(gpt.float().numpy(), pool, y.shape[2:])).to(tdt).float().numpy()
                 gx_r, gw_r = O.backward(g, w, x, pad, active, b)
                 assert np.max(np.abs(gx.float().cpu().numpy() - gx_r)) <= (eps if active else 0.0) * max(1.0, np.max(np.abs(gx_r))), (shape, pool, pad, active)
-                assert rel_err(gw.float().cpu().numpy(), gw_r) < 4 * eps, (shape, pool, pad, active)
+                assert rel_err(gw.float().cpu().numpy(), gw_r) < 1.02 * eps + 1e-5, (shape, pool, pad, active)

@@ -108,6 +108,10 @@ int forward_common(const shiftnd_problem *p, const void *x, const int64_t *xs, c
         }
         // 2-D sparse shift of 4- / 8-byte elements on planes of >= 32 KiB: the linear sweep of one-step workgroups
         // 3-D interpolating forward: a walk through the planes (one new plane per step, the other carried in registers)
+        if (g_policy == 0 && wkind == p->dtype && walk16_forward_eligible(g, p->dtype, x, out)) {
+            g_last_path = SHIFTND_PATH_PLANE;
+            return finish(walk16_forward(g, p->dtype, x, w, wkind, out, st));
+        }
         if (g_policy == 0 && wkind <= SHIFTND_BF16 && walk_forward_eligible(g, p->dtype, x, out)) {
             g_last_path = SHIFTND_PATH_PLANE;
             return finish(walk_forward(g, p->dtype, x, w, wkind, out, st));

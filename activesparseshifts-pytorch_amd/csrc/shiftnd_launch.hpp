@@ -81,6 +81,8 @@ bool step_forward_lds_eligible(const Geometry &g, int dtype, const void *x, cons
 int step_forward_lds(const Geometry &g, int dtype, const void *x, const void *w, int wkind, uint64_t fill_bits, void *out, hipStream_t st);
 void step_set_tuning(int knob, int value);
 // ---- the 3-D backward of 16-bit tensors as a walk through the planes (shiftnd_walk.hip, round 4; plane_backward routes to it)
+bool walk16_forward_eligible(const Geometry &g, int dtype, const void *x, const void *out);
+int walk16_forward(const Geometry &g, int dtype, const void *x, const void *w, int wkind, void *out, hipStream_t st);
 bool walk16_backward_eligible(const Geometry &g, int dtype, const void *go, const void *x, const void *gx);
 size_t walk16_backward_workspace(const Geometry &g, int dtype);
 int walk16_backward(const Geometry &g, int dtype, const void *go, const void *x, const void *w, void *gx, void *gw, void *workspace,

@@ -325,6 +325,7 @@ struct FwdParams {
     uint64_t fill;
     int64_t x_plane, o_plane;  // elements per (n, c) plane (2-D) / volume (3-D)
     int wkind, C, nd;
+    int pad;   // (the round-4 walk kernels: the padding mode is a run-time value there)
     int S0, S1, S2, O0, O1, O2, L0, L1, L2;
     int cpr, xppr, R, spp;   // output chunks per row, source pieces per row, rows per step, steps per plane
     int spv;                 // steps per (n, c): O0 * spp

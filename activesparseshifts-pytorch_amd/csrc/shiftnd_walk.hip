@@ -43,6 +43,13 @@ constexpr int kWalkFlush = 16;                         // planes between two flu
 
 typedef uint32_t u4_t __attribute__((ext_vector_type(4)));
 
+// cache-policy bits: the staged loads and the own chunk are plain (every gradient plane is read twice by its workgroup, the
+// "+1" corner row by two workgroups: nontemporal loads cost 20 %), grad_x is written once and not read again: nontemporal
+// (C3 0.243 -> 0.236 ms).  Measured and dropped: walks of 8 / 4 / 2 / 1 planes per workgroup, an occupancy
+// limit, plain dispatch order instead of XCD-contiguous ids, no "+1" corner row -- the memory skeleton of the walk (loads and
+// stores only) stays at 0.22 - 0.24 ms in every form; the kernel runs within 3 % of that skeleton.
+constexpr int kWalkStoreAux = 2;
+
 // byte offset (within a tile) of dword D of the piece-linear dword stream
 __device__ __forceinline__ uint32_t walk_dword_at(int D) { return static_cast<uint32_t>((D & 3) * kWalkPlaneBytes + (D >> 2) * 4); }
 // ... of 16-bit element m of the row whose first piece sits in slot `slot0`
@@ -130,6 +137,8 @@ __global__ __launch_bounds__(kThreads) void walk_backward16(const StepParams p) 
     if (bid >= p.total_steps) return;
     const uint32_t plane = fdiv(bid, p.d_spp);   // (n, c)
     const int step = static_cast<int>(bid - plane * static_cast<uint32_t>(p.spp));
+    constexpr int a0 = 0;   // the planes this workgroup walks through: all of them
+    const int a1 = p.S0;
     const int c = static_cast<int>(plane - fdiv(plane, p.d_C) * static_cast<uint32_t>(p.C));
     const ChanDesc d = p.desc[c];
     const int pad = ZEROS ? 0 : p.pad;
@@ -243,9 +252,17 @@ __global__ __launch_bounds__(kThreads) void walk_backward16(const StepParams p) 
     uint32_t xa[2][5], xb[2][5];     // packed x windows of the two corner planes (alternating roles)
     float Ba[E], Bb[E];              // ACTIVE: blended gradient planes (alternating roles)
     float sa[2][2] = {{0.f, 0.f}, {0.f, 0.f}}, sb[2][2] = {{0.f, 0.f}, {0.f, 0.f}};
+    // every load of the prologue is issued before the first wait: the first step's planes, the second's and the own chunk
+    // travel together with the "+0" planes (one memory round trip per workgroup instead of two)
+    constexpr int GA = ACTIVE ? 1 : 0;   // the gradient plane of step a: the "+1" corner plane / the plane the tap reads
+    Staged stA, stB;
+    u4_t gcur;
     {
         Staged v0;
-        load_planes(row_map(0, d.cx0, S0, pad), ACTIVE ? row_map(0, d.cg0, S0, pad) : -1, v0);
+        load_planes(row_map(a0, d.cx0, S0, pad), ACTIVE ? row_map(a0, d.cg0, S0, pad) : -1, v0);
+        load_planes(row_map(a0 + 1, d.cx0, S0, pad), row_map(a0 + GA, d.cg0, S0, pad), stA);
+        load_planes(a0 + 1 < a1 ? row_map(a0 + 2, d.cx0, S0, pad) : -1, a0 + 1 < a1 ? row_map(a0 + 1 + GA, d.cg0, S0, pad) : -1, stB);
+        gcur = load_own(a0, true);
         __syncthreads();   // the tiles are zero
         park(v0);
         __syncthreads();
@@ -262,11 +279,6 @@ __global__ __launch_bounds__(kThreads) void walk_backward16(const StepParams p) 
         }
     }
     __syncthreads();   // the "+0" planes have been read
-    constexpr int GA = ACTIVE ? 1 : 0;   // the gradient plane of step a: the "+1" corner plane / the plane the tap reads
-    Staged stA, stB;
-    load_planes(row_map(1, d.cx0, S0, pad), row_map(GA, d.cg0, S0, pad), stA);
-    load_planes(1 < S0 ? row_map(2, d.cx0, S0, pad) : -1, 1 < S0 ? row_map(1 + GA, d.cg0, S0, pad) : -1, stB);
-    u4_t gcur = load_own(0, true);
 
     auto flush = [&]() {   // fp32 sums of this wave -> its fp64 slots (fixed DPP tree, lane 63)
         const float v[8] = {sa[0][0], sa[1][0], sa[0][1], sa[1][1], sb[0][0], sb[1][0], sb[0][1], sb[1][1]};   // [kind][hb][pl]
@@ -286,11 +298,11 @@ __global__ __launch_bounds__(kThreads) void walk_backward16(const StepParams p) 
     auto walk_step = [&](int a, Staged &pend, const uint32_t (&x0)[2][5], uint32_t (&x1)[2][5], const float (&B0)[E], float (&B1)[E]) {
         park(pend);
         __syncthreads();
-        const bool more = a + 2 < S0;
+        const bool more = a + 2 < a1;
         load_planes(more ? row_map(a + 3, d.cx0, S0, pad) : -1, more ? row_map(a + 2 + GA, d.cg0, S0, pad) : -1, pend);
         if (px) wgrad(par1{}, gcur, x0, x1, sa, sb);
         else wgrad(par0{}, gcur, x0, x1, sa, sb);
-        gcur = load_own(a + 1, a + 1 < S0);   // the next step's own chunk: in flight through the blends and the next staging
+        gcur = load_own(a + 1, a + 1 < a1);   // the next step's own chunk: in flight through the blends and the next staging
         u4_t res;
         if constexpr (ACTIVE) {
             if (pg) plane_blend(par1{}, B1);
@@ -313,17 +325,17 @@ __global__ __launch_bounds__(kThreads) void walk_backward16(const StepParams p) 
                 res = u4_t{t[0], t[1], t[2], t[3]};
             }
         }
-        __builtin_amdgcn_raw_buffer_store_b128(res, ores, my, static_cast<uint32_t>(a) * plane_bytes, 0);
-        if ((a & (kWalkFlush - 1)) == kWalkFlush - 1) flush();
+        __builtin_amdgcn_raw_buffer_store_b128(res, ores, my, static_cast<uint32_t>(a) * plane_bytes, kWalkStoreAux);
+        if (((a - a0) & (kWalkFlush - 1)) == kWalkFlush - 1) flush();
         __syncthreads();   // everybody has read this step's planes
     };
-    int a = 0;
-    for (; a + 1 < S0; a += 2) {   // whole pairs: no condition between the steps (exact wait counts)
+    int a = a0;
+    for (; a + 1 < a1; a += 2) {   // whole pairs: no condition between the steps (exact wait counts)
         walk_step(a, stA, xa, xb, Ba, Bb);
         walk_step(a + 1, stB, xb, xa, Bb, Ba);
     }
-    if (a < S0) walk_step(a, stA, xa, xb, Ba, Bb);
-    if ((S0 & (kWalkFlush - 1)) != 0) flush();
+    if (a < a1) walk_step(a, stA, xa, xb, Ba, Bb);
+    if (((a1 - a0) & (kWalkFlush - 1)) != 0) flush();
     __syncthreads();
     // ---- the workgroup's record: per-corner sums -> the corner-difference sums (corner_diffs is linear) ------------------------
     if (tid < 8) {
@@ -349,6 +361,131 @@ __global__ __launch_bounds__(kThreads) void walk_backward16(const StepParams p) 
         for (int i = 1; i < 8; ++i) out = tid == i ? df[i] : out;
         p.partials[static_cast<size_t>(bid) * 8 + tid] = out;
     }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// walk_forward16: the 3-D interpolating forward of 16-bit tensors, the same walk with the same tile layout: one plane of x
+// staged per step, its row / column blend computed once and carried to the next step as the "+0" plane (8 fp32 values).
+// Reference: kernels/shifts_kernels.h:156-220 (:187-205), interpolation.h:34-40; weights cuda/shifts_cuda.cu:168-183.
+// ---------------------------------------------------------------------------------------------------------------------
+template <typename T, bool ZEROS>
+__global__ __launch_bounds__(kThreads) void walk_forward16(const FwdParams p) {
+    using S = typename T::S;
+    static_assert(sizeof(S) == 2, "16-bit element types");
+    constexpr int E = 8;
+    constexpr int NA = ZEROS ? 5 : 9;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char *const tx = smem;
+
+    const uint32_t bid = (blockIdx.x & 7u) * p.steps_per_xcd + (blockIdx.x >> 3);
+    if (bid >= p.total_steps) return;
+    const uint32_t plane = fdiv(bid, p.d_spp);
+    const int step = static_cast<int>(bid - plane * static_cast<uint32_t>(p.spp));
+    const int c = static_cast<int>(plane - fdiv(plane, p.d_C) * static_cast<uint32_t>(p.C));
+    const int pad = ZEROS ? 0 : p.pad;
+    float wv[3];
+    load_weights_nd<float>(p.w, p.wkind, c, 3, wv);
+    float rr[3], dn[3];
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {   // weights_init_forward, active: floor + fraction
+        rr[d] = floorf(wv[d]);
+        dn[d] = wv[d] - rr[d];
+    }
+    const int cs0 = __builtin_amdgcn_readfirstlane(canon_shift(static_cast<int64_t>(rr[0]), p.S0, pad, p.d_per0));
+    const int cs1 = __builtin_amdgcn_readfirstlane(canon_shift(static_cast<int64_t>(rr[1]), p.S1, pad, p.d_per1));
+    const int cs2 = __builtin_amdgcn_readfirstlane(canon_shift(static_cast<int64_t>(rr[2]), p.S2, pad, p.d_per2));
+    const float dP = dn[0], dR = dn[1], dC = dn[2];
+
+    const int R = p.R, S0 = p.S0, S1 = p.S1, S2 = p.S2, cpr = p.cpr;
+    const int b0 = step * R;
+    const int Rn = min(R, S1 - b0);
+    const int tid = static_cast<int>(threadIdx.x);
+    const int tr = static_cast<int>(fdiv(static_cast<uint32_t>(tid), p.d_cpr)), tc = tid - tr * cpr;
+    const int ji = tc * E;
+    const int RP = cpr + kWalkGuard;
+    for (int o = tid * 16; o < kWalkTileBytes; o += kThreads * 16)
+        *reinterpret_cast<u4_t *>(__builtin_assume_aligned(smem + o, 16)) = u4_t{0u, 0u, 0u, 0u};
+
+    const bool own = tr <= R && tr <= Rn;
+    const int sx_own = own ? row_map(b0 + tr, cs1, S1, pad) : -1;
+    constexpr uint32_t kOOR = 0x80000000u;
+    constexpr int kRsrcFlags = 0x00020000;
+    const uint32_t plane_bytes = static_cast<uint32_t>(S1) * static_cast<uint32_t>(S2) * 2u;
+    const uint32_t vol_bytes = static_cast<uint32_t>(S0) * plane_bytes;
+    const char *xp = reinterpret_cast<const char *>(static_cast<const S *>(p.x) + static_cast<int64_t>(plane) * p.x_plane);
+    char *op = reinterpret_cast<char *>(static_cast<S *>(p.out) + static_cast<int64_t>(plane) * p.o_plane);
+    const __amdgpu_buffer_rsrc_t xres = __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(xp), 0, vol_bytes, kRsrcFlags);
+    const __amdgpu_buffer_rsrc_t ores = __builtin_amdgcn_make_buffer_rsrc(op, 0, vol_bytes, kRsrcFlags);
+    const __amdgpu_buffer_rsrc_t none = __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(xp), 0, 0, kRsrcFlags);
+    const uint32_t vx_own = sx_own >= 0 ? static_cast<uint32_t>(sx_own * S2 + ji) * 2u : kOOR;
+    const uint32_t park_at = static_cast<uint32_t>(own ? kWalkMargin + tr * RP + tc : kWalkDump0 + (tid & 63)) * 4u;
+    auto load_plane = [&](int pa) {   // source plane (uniform; -1: fill)
+        return __builtin_amdgcn_raw_buffer_load_b128(pa >= 0 ? xres : none, vx_own, pa >= 0 ? static_cast<uint32_t>(pa) * plane_bytes : 0u, 0);
+    };
+    auto park = [&](const u4_t &v) {
+        uint32_t *q = reinterpret_cast<uint32_t *>(tx + park_at);
+        q[0] = v.x;
+        q[kWalkSlots] = v.y;
+        q[2 * kWalkSlots] = v.z;
+        q[3 * kWalkSlots] = v.w;
+    };
+    const bool mine = tr < R && tr < Rn;
+    const int slot0 = kWalkMargin + tr * RP;
+    const WalkWindow<NA> wx = walk_window<ZEROS, NA>(ji, cs2, S2, pad, slot0, mine);
+    const uint32_t row1 = static_cast<uint32_t>(RP) * 4u;
+    const int px = cs2 & 1;
+    const uint32_t my = mine ? static_cast<uint32_t>((b0 + tr) * S2 + ji) * 2u : kOOR;
+    auto lerp = [](float v1, float v2, float x) { return lerp1_fused<float>(v1, v2, x); };
+    auto plane_blend = [&](auto par_tag, float (&B)[E]) {
+        constexpr int PAR = decltype(par_tag)::value;
+        uint32_t r0[5], r1[5];
+        walk_read<ZEROS, NA, PAR>(tx, wx, 0u, r0);
+        walk_read<ZEROS, NA, PAR>(tx, wx, row1, r1);
+        float rb[E + 1];
+#pragma unroll
+        for (int k = 0; k <= E; ++k) {
+            const int h = k + PAR;
+            rb[k] = lerp(half_value<T>(r0[h >> 1], h & 1), half_value<T>(r1[h >> 1], h & 1), dR);
+        }
+#pragma unroll
+        for (int e = 0; e < E; ++e) B[e] = lerp(rb[e], rb[e + 1], dC);
+    };
+    using par0 = std::integral_constant<int, 0>;
+    using par1 = std::integral_constant<int, 1>;
+
+    float Ba[E], Bb[E];
+    u4_t stA, stB;
+    {
+        const u4_t v0 = load_plane(row_map(0, cs0, S0, pad));
+        stA = load_plane(row_map(1, cs0, S0, pad));
+        stB = load_plane(1 < S0 ? row_map(2, cs0, S0, pad) : -1);
+        __syncthreads();   // the tile is zero
+        park(v0);
+        __syncthreads();
+        if (px) plane_blend(par1{}, Ba);
+        else plane_blend(par0{}, Ba);
+    }
+    __syncthreads();
+    auto walk_step = [&](int a, u4_t &pend, const float (&B0)[E], float (&B1)[E]) {
+        park(pend);
+        __syncthreads();
+        pend = load_plane(a + 2 < S0 ? row_map(a + 3, cs0, S0, pad) : -1);
+        if (px) plane_blend(par1{}, B1);
+        else plane_blend(par0{}, B1);
+        Chunk<S, E> ch;
+#pragma unroll
+        for (int e = 0; e < E; ++e) ch.e[e] = narrow<T>(lerp(B0[e], B1[e], dP));
+        u4_t res;
+        __builtin_memcpy(&res, ch.e, 16);
+        __builtin_amdgcn_raw_buffer_store_b128(res, ores, my, static_cast<uint32_t>(a) * plane_bytes, kWalkStoreAux);
+        __syncthreads();
+    };
+    int a = 0;
+    for (; a + 1 < S0; a += 2) {
+        walk_step(a, stA, Ba, Bb);
+        walk_step(a + 1, stB, Bb, Ba);
+    }
+    if (a < S0) walk_step(a, stA, Ba, Bb);
 }
 
 struct WalkPlan {
@@ -384,6 +521,53 @@ bool walk16_geometry_ok(const Geometry &g, int dtype) {
 }
 
 }  // namespace
+
+// the 3-D interpolating forward of fp16 / bf16 tensors: contiguous, no crop, rows of whole 16-byte pieces, float weights of the
+// tensor's dtype
+bool walk16_forward_eligible(const Geometry &g, int dtype, const void *x, const void *out) {
+    if (g_step_tune[2] == 1 || (g_step_tune[3] & (16 | 64))) return false;   // knob 34 = 1: no forwards through LDS; knob 35 bit 4 / 6
+    if (!g.active || !walk16_geometry_ok(g, dtype)) return false;
+    if (!dense(g.xs, g.N, g.C, g.S) || !dense(g.os, g.N, g.C, g.O)) return false;
+    return reinterpret_cast<uintptr_t>(x) % 16 == 0 && reinterpret_cast<uintptr_t>(out) % 16 == 0;
+}
+
+int walk16_forward(const Geometry &g, int dtype, const void *x, const void *w, int wkind, void *out, hipStream_t st) {
+    const WalkPlan W = walk_plan(g);
+    FwdParams p{};
+    p.x = x;
+    p.out = out;
+    p.w = w;
+    p.wkind = wkind;
+    p.C = static_cast<int>(g.C);
+    p.nd = 3;
+    p.pad = g.pad;
+    p.S0 = p.O0 = static_cast<int>(g.S[0]);
+    p.S1 = p.O1 = static_cast<int>(g.S[1]);
+    p.S2 = p.O2 = static_cast<int>(g.S[2]);
+    p.x_plane = p.o_plane = g.S[0] * g.S[1] * g.S[2];
+    p.cpr = p.xppr = W.cpr;
+    p.R = W.R;
+    p.spp = p.spv = W.spp;
+    p.total_steps = static_cast<uint32_t>(W.total);
+    p.steps_per_xcd = static_cast<uint32_t>((W.total + 7) / 8);
+    p.d_spp = p.d_spv = make_fastdiv(static_cast<uint32_t>(W.spp));
+    p.d_C = make_fastdiv(static_cast<uint32_t>(p.C));
+    p.d_cpr = p.d_xppr = make_fastdiv(static_cast<uint32_t>(W.cpr));
+    p.d_per0 = make_fastdiv(static_cast<uint32_t>(map_period(p.S0, g.pad)));
+    p.d_per1 = make_fastdiv(static_cast<uint32_t>(map_period(p.S1, g.pad)));
+    p.d_per2 = make_fastdiv(static_cast<uint32_t>(map_period(p.S2, g.pad)));
+    const dim3 grid(p.steps_per_xcd * 8), block(kThreads);
+    note_kernel("walk_forward16");
+    const bool zeros = g.pad == 0;
+    if (dtype == SHIFTND_F16) {
+        if (zeros) hipLaunchKernelGGL((walk_forward16<f16_t, true>), grid, block, kWalkTileBytes, st, p);
+        else hipLaunchKernelGGL((walk_forward16<f16_t, false>), grid, block, kWalkTileBytes, st, p);
+    } else {
+        if (zeros) hipLaunchKernelGGL((walk_forward16<bf16_t, true>), grid, block, kWalkTileBytes, st, p);
+        else hipLaunchKernelGGL((walk_forward16<bf16_t, false>), grid, block, kWalkTileBytes, st, p);
+    }
+    return SHIFTND_OK;
+}
 
 // the 3-D backward of fp16 / bf16 tensors (both shifts, every padding): contiguous, no crop, rows of whole 16-byte pieces
 bool walk16_backward_eligible(const Geometry &g, int dtype, const void *go, const void *x, const void *gx) {

@@ -87,7 +87,7 @@ def cpu_baseline(workload_pad=0):
         return {"value": None, "unit": "Gelem/s", "cores": 0, "kind": "unavailable", "sample": repr(e)[:300]}
 
 
-def box_stream():
+def box_stream(tensor_bytes=None):
     """Same-box calibration: tools/stream_probe (a plain HIP binary, built by __graft_entry__.build()) streams C2-sized
     buffers with float4 accesses -- best 1-read-1-write and 2-read-1-write rates over a small fixed set of launch shapes --
     in a child process that has exited before this process touches the GPU.  The kernels' rates are reported against
@@ -95,7 +95,8 @@ def box_stream():
     streams does not."""
     exe = os.path.join(ROOT, "tools", "stream_probe")
     try:
-        out = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+        out = subprocess.run([exe] + (["--bytes", str(int(tensor_bytes))] if tensor_bytes else []), capture_output=True, text=True,
+                             timeout=300)
         lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
         if out.returncode != 0 or not lines:
             raise RuntimeError("stream_probe exit %d: %s" % (out.returncode, (out.stderr or out.stdout)[-300:]))
@@ -240,7 +241,13 @@ def main(argv=None):
         base = cpu_baseline(a.pad)  # child process, before any GPU initialisation in this process
     probe = None
     if rank == 0 and world == 1 and a.device == "cuda" and not a.no_probe:
-        probe = box_stream()  # child process too: it has left the GPU before this process initialises it
+        # child process too: it has left the GPU before this process initialises it.  Streams of THIS workload's tensor size
+        # (a 0.2 ms kernel over 0.4 GB tensors pays launch ramp and tail that a 1.5 ms kernel over 3.3 GB does not)
+        _nd, _shape, _dt, _act, _desc = WORKLOADS[a.workload]
+        _n = 1
+        for _s in (tuple(int(v) for v in a.shape.split(",")) if a.shape else _shape):
+            _n *= _s
+        probe = box_stream(_n * {"float32": 4, "bfloat16": 2, "float16": 2, "quint8": 1}[_dt])
 
     import torch
     import torch.distributed as dist

@@ -370,7 +370,7 @@ def test_3d_walk_forward_vs_oracle(abi, shape, dt):
     abi.set_tuning(35, 32)  # every float dtype (automatic: 16-bit only)
     for pad in range(5):
         out = abi.forward(xd, wd, pad, 1)
-        assert abi.last_kernel() == "walk_forward", (shape, abi.last_kernel())
+        assert abi.last_kernel() == ("walk_forward16" if es == 2 else "walk_forward"), (shape, abi.last_kernel())   # 16-bit: shiftnd_walk.hip
         ref = torch.from_numpy(O.forward(x, w, pad, 1)).to(tdt)
         if es >= 4:
             assert torch.equal(out.cpu(), ref), (shape, dt, pad)

@@ -1806,7 +1806,7 @@ size_t plane_backward_workspace(const Geometry &g, int dtype) {
     const Plan pl = backward_plan(g, dtype_size(dtype));
     const size_t own = static_cast<size_t>(pl.groups) * pl.bands * static_cast<size_t>(g.C) * 3 * sizeof(double);
     const size_t slide = g.K[0] > 0 ? 0 : slide_backward_workspace(g, dtype);  // (the fused-pool calls never slide)
-    const size_t step = std::max(step_backward_workspace(g, dtype), g.K[0] > 0 ? size_t(0) : walk16_backward_workspace(g, dtype));
+    const size_t step = std::max(step_backward_workspace(g, dtype), g.K[0] > 0 ? size_t(0) : std::max(walk16_backward_workspace(g, dtype), span_backward_workspace(g, dtype)));
     const size_t m = own > slide ? own : slide;
     return m > step ? m : step;
 }
@@ -1866,6 +1866,7 @@ int plane_backward(const Geometry &g, int dtype, const void *go, const void *x, 
                    void *workspace, hipStream_t st) {
     if (walk16_backward_eligible(g, dtype, go, x, gx)) return walk16_backward(g, dtype, go, x, w, gx, gw, workspace, st);
     if (step_backward_eligible(g, dtype, go, x, gx)) return step_backward(g, dtype, go, x, w, gx, gw, workspace, st);
+    if (span_backward_eligible(g, dtype, go, x, gx)) return span_backward(g, dtype, go, x, w, gx, gw, workspace, st);
     if (slide_backward_eligible(g, dtype, go, x, gx)) return slide_backward(g, dtype, go, x, w, gx, gw, workspace, st);
     const Plan pl = backward_plan(g, dtype_size(dtype));
     PlaneParams p{};

@@ -1,0 +1,511 @@
+// shiftnd_span.hip -- the one-step sweep for the tensors the reference's users actually have (round 4): CROPPED
+// 2-D windows (every depthwise-conv emulation with padding < kernel / 2: modules/shifts.py:41-46, ops/shifts.cpp:93-135 -- the
+// reference's own test script is N512 C16 64x64 cut to 62x62) and Shift1d (functional.py:7-36), whose rows can be longer than
+// one workgroup pass.  step_backward (shiftnd_step.hip) needs grad_out rows that are whole 16-byte pieces at the positions
+// of the x rows; a cropped grad_out has neither (222 fp32 = 888 bytes per row, shifted by the window's corner).
+//
+// Same shape as step_backward -- one step per workgroup, workgroups in address order, LDS-DMA staging, one barrier, a DPP
+// wave tree and one partial record per step -- with the staging generalised to SPANS: every source row a step needs (corner
+// rows of x, the grad_out rows at the step's own rows, the grad_out rows grad_x gathers or blends) is one slot of the tile,
+// filled with the 16-byte pieces of the TENSOR's byte stream that cover the needed columns of that row; a slot remembers the
+// byte phase of its row (grad_out rows start anywhere), and the window reads go element by element through ColState
+// (shiftnd_stage.hpp) as everywhere.  A step is R rows x one column segment of at most 256 chunks of the x plane: 1-D rows of
+// any length are walked segment by segment, each staging only the columns its windows reach.
+//
+//   span_prep      per channel: weight preparation (cpu/shifts_cpu.cpp:242-244), canonical shifts of the x maps over the
+//                  input sizes and of the gradient maps over the WINDOW sizes (the reference pads grad_out with the cropped
+//                  sizes, kernels/shifts_kernels.h:295-297, :319-324), column tables for the paddings other than zeros
+//   span_backward  the step kernel: grad_x (zero outside the window: shifts_kernels.h:271, :314) and the step's sums of
+//                  g * corner difference
+//   step_reduce    (shiftnd_step.hpp) the channel sums and the blends, as for step_backward
+//
+// Reference behaviour restated: kernels/shifts_kernels.h:222-327, :132-154; interpolation.h:3-31.  Roofline: HBM, 3 s bytes
+// per element of the uncropped tensor minus the cropped margin of grad_out.
+#include "shiftnd_step.hpp"
+
+namespace shiftnd {
+namespace {
+
+constexpr int kSpanRounds = 6;   // staging rounds of 256 pieces: five slots of 258 pieces (one row per step, rows of 256 chunks) fit
+
+struct SpanParams {
+    const void *x;      // saved input [N, C, S1, S2]
+    const void *go;     // incoming gradient [N, C, O1, O2]
+    void *out;          // grad_x, like x
+    const void *w;
+    double *partials;   // [total_steps][NDIFF]
+    ChanDesc *desc;     // [C]
+    int16_t *colx;      // [C][cpr][REC] column state of every x chunk through the x column map
+    int16_t *colg;      // ... of every x chunk's window position through the gradient column map (window coordinates)
+    int64_t x_plane, g_plane;   // elements per (n, c)
+    int wkind, N, C, pad, nd;
+    int S1, S2, O1, O2, L1, L2;
+    int cpr, seg, nseg;  // 16-byte chunks per x row, chunks per column segment (<= 256), segments per row
+    int R, rsteps, spp;  // rows per step, row steps per plane, steps per plane = rsteps * nseg
+    int P;               // pieces per slot
+    uint32_t total_steps, steps_per_xcd;
+    FastDiv d_spp, d_C, d_seg, d_nseg, d_P, d_per1x, d_per2x, d_per1g, d_per2g;
+};
+
+// ---------------------------------------------------------------------------------------------------------------------
+// span_prep: one workgroup per channel
+// ---------------------------------------------------------------------------------------------------------------------
+template <typename T, bool ACTIVE>
+__global__ __launch_bounds__(kThreads) void span_prep(const SpanParams p) {
+    using S = typename T::S;
+    using CT = typename T::C;
+    constexpr int E = 16 / sizeof(S);
+    constexpr int REC = RecSize<E>::N;
+    const int c = blockIdx.x;
+    const int lead = 2 - p.nd;   // real dim r -> (row, column) index r + 2 - nd
+    int64_t sh[2] = {0, 0};
+    CT dw[2] = {CT(0), CT(0)};
+    for (int r = 0; r < p.nd; ++r) {
+        const CT wv = load_weight<CT>(p.w, p.wkind, static_cast<int64_t>(c) * p.nd + r);
+        prep_shift_backward<CT>(wv, ACTIVE, sh[r + lead], dw[r]);
+    }
+    const int cx1 = canon_shift(sh[0], p.S1, p.pad, p.d_per1x), cx2 = canon_shift(sh[1], p.S2, p.pad, p.d_per2x);
+    const int cg1 = canon_shift(ACTIVE ? sh[0] : -sh[0], p.O1, p.pad, p.d_per1g);
+    const int cg2 = canon_shift(ACTIVE ? sh[1] : -sh[1], p.O2, p.pad, p.d_per2g);
+    if (threadIdx.x == 0) {
+        ChanDesc d;
+        d.cx0 = d.cg0 = 0;
+        d.cx1 = cx1;
+        d.cg1 = cg1;
+        d.cx2 = cx2;
+        d.cg2 = cg2;
+        d.scat = 0;
+        d.pad_ = 0;
+        d.dw[0] = static_cast<double>(dw[0]);
+        d.dw[1] = static_cast<double>(dw[1]);
+        d.dw[2] = 0.0;
+        d.pad2_ = 0.0;
+        p.desc[c] = d;
+    }
+    if (p.pad == 0) return;  // zeros padding: the column state is two compares per entry, folded in the step kernel
+    for (int j = threadIdx.x; j < p.cpr; j += kThreads) {
+#pragma unroll
+        for (int which = 0; which < 2; ++which) {
+            int cm[E + 1];
+            int base = 0;
+            bool found = false, affine = true;
+#pragma unroll
+            for (int e = 0; e <= E; ++e) {
+                if (which == 0) {
+                    cm[e] = row_map(j * E + e, cx2, p.S2, p.pad);
+                } else {  // window coordinate of x column j E + e (the map is defined on [0, O2])
+                    const int q = j * E + e - p.L2;
+                    cm[e] = (q >= 0 && q <= p.O2) ? row_map(q, cg2, p.O2, p.pad) : -1;
+                }
+                if (!found && cm[e] >= 0) {
+                    base = cm[e] - e;
+                    found = true;
+                }
+            }
+#pragma unroll
+            for (int e = 0; e <= E; ++e) affine = affine && (cm[e] < 0 || cm[e] == base + e);
+            int16_t *rec = (which ? p.colg : p.colx) + (static_cast<size_t>(c) * p.cpr + j) * REC;
+#pragma unroll
+            for (int e = 0; e <= E; ++e) rec[e] = static_cast<int16_t>(cm[e]);
+            rec[E + 1] = static_cast<int16_t>(base);
+            rec[E + 2] = affine ? 1 : 0;
+        }
+    }
+}
+
+// E + 1 elements of a source row through a column state: from the staged slot, or -- a chunk whose columns are not all among the
+// staged ones (only a column segment of the row is staged when rows are longer than a workgroup pass: the chunks that wrap,
+// clamp or reflect at the row ends then read elsewhere) -- element by element from memory
+template <typename S, int E>
+__device__ __forceinline__ void span_read(const char *lds_row, const S *mem_row, bool staged, bool valid, const ColState<E> &c, S (&raw)[E + 1]) {
+    if (valid && !staged) {
+        S zero;
+        __builtin_memset(&zero, 0, sizeof(S));
+#pragma unroll
+        for (int e = 0; e <= E; ++e) raw[e] = c.cm[e] >= 0 ? mem_row[c.cm[e]] : zero;
+        return;
+    }
+    lds_read_row<S, E>(lds_row, valid, c, raw);
+}
+
+template <typename T, int ND, bool ACTIVE, int PAD>
+__global__ __launch_bounds__(kThreads) void span_backward(const SpanParams p) {
+    using S = typename T::S;
+    using CT = typename T::C;
+    constexpr int ES = sizeof(S);
+    constexpr int E = 16 / ES;
+    constexpr int REC = RecSize<E>::N;
+    constexpr int NDIFF = WDiff<ND>::N;
+    constexpr int NCC = 1 << (ND - 1);   // corner rows per element
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char *tile = smem + 64;  // 64-byte pads in front and behind: see lds_read_row
+
+    const uint32_t bid = (blockIdx.x & 7u) * p.steps_per_xcd + (blockIdx.x >> 3);  // XCD-contiguous step ids
+    if (bid >= p.total_steps) return;
+    const uint32_t plane = fdiv(bid, p.d_spp);   // (n, c)
+    const uint32_t vstep = bid - plane * static_cast<uint32_t>(p.spp);
+    const int rstep = static_cast<int>(fdiv(vstep, p.d_nseg));
+    const int sg = static_cast<int>(vstep) - rstep * p.nseg;
+    const int c = static_cast<int>(plane - fdiv(plane, p.d_C) * static_cast<uint32_t>(p.C));
+    const ChanDesc d = p.desc[c];
+    const int R = p.R, S1 = p.S1, S2 = p.S2, O1 = p.O1, O2 = p.O2, L1 = p.L1, L2 = p.L2, cpr = p.cpr, P = p.P;
+    const int b0 = rstep * R;
+    const int Rn = min(R, S1 - b0);
+    const bool whole = p.nseg == 1;   // the step spans whole rows: every column of a staged row is in LDS
+    // tile slots: x corner rows [NX], grad_out at the step's own rows [NG], the grad_out rows grad_x reads [NGS]
+    const int NX = ND == 2 ? R + 1 : 1, NG = ND == 2 ? R : 1;
+    const int NGS = ND == 2 ? (ACTIVE ? R + 1 : R) : 1;
+    // the column segment and the columns of each tensor its windows reach (whole rows when there is one segment)
+    const int J0 = sg * p.seg * E, J1 = min(S2, J0 + p.seg * E);
+    auto clampi = [](int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); };
+    const int xc0 = whole ? 0 : clampi(J0 - d.cx2, 0, S2), xc1 = whole ? S2 : clampi(J1 - d.cx2 + 1, 0, S2);
+    const int oc0 = whole ? 0 : clampi(J0 - L2, 0, O2), oc1 = whole ? O2 : clampi(J1 - L2, 0, O2);
+    const int sc0 = whole ? 0 : clampi(J0 - L2 - d.cg2, 0, O2), sc1 = whole ? O2 : clampi(J1 - L2 - d.cg2 + 1, 0, O2);
+    const S *xp = static_cast<const S *>(p.x) + static_cast<int64_t>(plane) * p.x_plane;
+    const S *gp = static_cast<const S *>(p.go) + static_cast<int64_t>(plane) * p.g_plane;
+    S *gxp = static_cast<S *>(p.out) + static_cast<int64_t>(plane) * p.x_plane;
+    // grad_out is addressed as the TENSOR's stream of 16-byte pieces (its planes and rows start anywhere): the byte offset of
+    // this plane within its first piece
+    const int gph = static_cast<int>((static_cast<uint64_t>(plane) * static_cast<uint64_t>(p.g_plane) * ES) & 15u);
+    const char *gp16 = reinterpret_cast<const char *>(gp) - gph;   // 16-byte aligned (the tensor's base is)
+
+    const int tid = static_cast<int>(threadIdx.x);
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // a slot's source: which row of which tensor, which columns; -> first byte (plane-relative), bytes
+    // bytes [lo, hi) relative to `base` (16-byte aligned); valid: the row exists (a row of the wrapping / clamping paddings exists
+    // even when no column of the plain shift does: its chunks then read through their maps)
+    struct Src { const char *base; int lo, hi; bool valid; };
+    auto slot_src = [&](int slot) {
+        Src s;
+        if (slot < NX) {
+            const int i = slot;
+            const int row = ND == 2 ? row_map_t<PAD>(b0 + i, d.cx1, S1) : 0;
+            s.base = reinterpret_cast<const char *>(xp);
+            s.valid = i <= (ND == 2 ? Rn : 0) && row >= 0;
+            s.lo = (row * S2 + xc0) * ES;
+            s.hi = (row * S2 + xc1) * ES;
+        } else if (slot < NX + NG) {
+            const int i = slot - NX;
+            const int row = b0 + i - L1;
+            s.base = gp16;
+            s.valid = i < Rn && row >= 0 && row < O1;
+            s.lo = gph + (row * O2 + oc0) * ES;
+            s.hi = gph + (row * O2 + oc1) * ES;
+        } else {
+            const int i = slot - NX - NG;
+            const int pr = b0 + i - L1;   // window coordinate of the row (the map is defined on [0, O1])
+            const bool dom = pr >= 0 && (ACTIVE ? pr <= O1 : pr < O1) && i < (ACTIVE && ND == 2 ? Rn + 1 : Rn);
+            const int row = dom ? (ND == 2 ? row_map_t<PAD>(pr, d.cg1, O1) : 0) : -1;
+            s.base = gp16;
+            s.valid = row >= 0;
+            s.lo = gph + (row * O2 + sc0) * ES;
+            s.hi = gph + (row * O2 + sc1) * ES;
+        }
+        return s;
+    };
+    // ---- stage: piece q of the tile = piece (q mod P) of slot (q div P); a wave's pieces are consecutive, the LDS destination
+    // is a wave-uniform base (the hardware adds lane * 16)
+    const int npieces = (NX + NG + NGS) * P;
+#pragma unroll
+    for (int k = 0; k < kSpanRounds; ++k) {
+        if (k * kThreads < npieces) {   // uniform
+            const int q = k * kThreads + tid;
+            const int slot = static_cast<int>(fdiv(static_cast<uint32_t>(q), p.d_P));
+            const int piece = q - slot * P;
+            const Src s = slot_src(slot);
+            const int p0 = s.lo >> 4, cnt = ((s.hi + 15) >> 4) - p0;
+            if (q < npieces && s.valid && piece < cnt) {   // (cnt <= 0: no column of this row is staged)
+                char *dst_wave = tile + (k * kThreads + wave * 64) * 16;
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(s.base + static_cast<int64_t>(p0 + piece) * 16),
+                                                 (__attribute__((address_space(3))) void *)dst_wave, 16, 0, 0);
+            }
+        }
+    }
+
+    // ---- the thread's chunk: column state through the x map, the gradient map (window coordinates) and the plain window ----
+    const int tr = static_cast<int>(fdiv(static_cast<uint32_t>(tid), p.d_seg)), tc = tid - tr * p.seg;
+    const int jc = sg * p.seg + tc;   // chunk of the x row
+    const int ji = jc * E;
+    const bool mine = tr < Rn && tc < p.seg && jc < cpr;
+    ColState<E> xm, gm, om;
+    {
+        // entry e = column first + e when that is a column; `safe`: a staged column for a chunk without any (every entry masked)
+        auto affine_state = [&](int first, int len, int safe) {
+            ColState<E> st;
+            st.base = first;
+            if (first + E < 0 || first >= len) st.base = safe;
+            st.affine = true;
+#pragma unroll
+            for (int e = 0; e <= E; ++e) st.cm[e] = (first + e >= 0 && first + e < len) ? first + e : -1;
+            return st;
+        };
+        om = affine_state(ji - L2, O2, oc0);   // grad_out at the chunk's own columns
+        if constexpr (PAD == 0) {
+            xm = affine_state(ji - d.cx2, S2, xc0);
+            gm = affine_state(ji - L2 - d.cg2, O2, sc0);
+            if (O2 == 1) {   // a window one column wide ignores the shift (shifts_kernels.h:40-48): both corners read column 0
+                gm.affine = false;
+#pragma unroll
+                for (int e = 0; e <= E; ++e) gm.cm[e] = (ji - L2 + e >= 0 && ji - L2 + e <= 1) ? 0 : -1;
+            }
+        } else {
+            const size_t rec = (static_cast<size_t>(c) * cpr + (mine ? jc : 0)) * REC;
+            xm = load_colstate<E>(p.colx + rec);
+            gm = load_colstate<E>(p.colg + rec);
+            bool any = false;   // a chunk outside the window has no gradient column at all: keep its reads inside the slot
+#pragma unroll
+            for (int e = 0; e <= E; ++e) any = any || gm.cm[e] >= 0;
+            if (!any) {
+                gm.base = sc0;
+                gm.affine = true;
+            }
+        }
+    }
+    // are all columns of a chunk's window among the staged ones [c0, c1) of its tensor's rows
+    auto in_span = [&](const ColState<E> &st, int c0, int c1) {
+        bool ok = st.affine;
+#pragma unroll
+        for (int e = 0; e <= E; ++e) ok = ok && (st.cm[e] < 0 || (st.cm[e] >= c0 && st.cm[e] < c1));
+        return ok;
+    };
+    const bool xs = whole || in_span(xm, xc0, xc1), gs = whole || in_span(gm, sc0, sc1);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    CT part[NDIFF];
+#pragma unroll
+    for (int i = 0; i < NDIFF; ++i) part[i] = CT(0);
+    if (mine) {
+        const int b = b0 + tr;
+        const CT dw[3] = {static_cast<CT>(d.dw[0]), static_cast<CT>(d.dw[1]), CT(0)};
+        // first byte of a staged row's column 0 within its slot (may lie in front of the slot: only staged columns are read)
+        auto slot_row = [&](int slot, const Src &s, int c0) { return tile + slot * P * 16 + (s.lo & 15) - c0 * ES; };
+        auto corner_row = [](int k) { return ND == 2 ? (k & 1) : 0; };
+        const bool in_row = b >= L1 && b < L1 + O1;
+        S zero;
+        __builtin_memset(&zero, 0, sizeof(S));
+        Chunk<S, E> res;
+        // ---- grad_x ----------------------------------------------------------------------------------------------------
+        if constexpr (ACTIVE) {
+            CT gv[NCC][E + 1];
+#pragma unroll
+            for (int k = 0; k < NCC; ++k) {
+                const int slot = NX + NG + tr + corner_row(k);
+                const Src s = slot_src(slot);
+                S raw[E + 1];
+                span_read<S, E>(slot_row(slot, s, sc0), reinterpret_cast<const S *>(s.base + s.lo) - sc0, gs, in_row && s.valid, gm, raw);
+#pragma unroll
+                for (int e = 0; e <= E; ++e) gv[k][e] = widen<T>(raw[e]);
+            }
+#pragma unroll
+            for (int e = 0; e < E; ++e) {
+                CT v[1 << ND];
+#pragma unroll
+                for (int q = 0; q < (1 << ND); ++q) v[q] = gv[q & (NCC - 1)][e + (q >> (ND - 1))];
+                const bool inside = in_row && ji + e >= L2 && ji + e < L2 + O2;
+                res.e[e] = inside ? narrow<T>(interp_t<T, ND>(v, dw)) : zero;
+            }
+        } else {
+            const int slot = NX + NG + tr;
+            const Src s = slot_src(slot);
+            S raw[E + 1];
+            span_read<S, E>(slot_row(slot, s, sc0), reinterpret_cast<const S *>(s.base + s.lo) - sc0, gs, in_row && s.valid, gm, raw);
+#pragma unroll
+            for (int e = 0; e < E; ++e) {
+                const bool inside = in_row && ji + e >= L2 && ji + e < L2 + O2;
+                res.e[e] = inside ? raw[e] : zero;
+            }
+        }
+        // ---- weight-gradient sums: corners of x against grad_out at the chunk's own position (0 outside the window) ---------
+        CT xv[NCC][E + 1];
+#pragma unroll
+        for (int k = 0; k < NCC; ++k) {
+            const int slot = tr + corner_row(k);
+            const Src s = slot_src(slot);
+            S raw[E + 1];
+            span_read<S, E>(slot_row(slot, s, xc0), reinterpret_cast<const S *>(s.base + s.lo) - xc0, xs, s.valid, xm, raw);
+#pragma unroll
+            for (int e = 0; e <= E; ++e) xv[k][e] = widen<T>(raw[e]);
+        }
+        S graw[E + 1];
+        {
+            const int slot = NX + tr;
+            const Src s = slot_src(slot);
+            lds_read_row<S, E>(slot_row(slot, s, oc0), s.valid, om, graw);
+        }
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+            CT v[1 << ND], df[NDIFF];
+#pragma unroll
+            for (int q = 0; q < (1 << ND); ++q) v[q] = xv[q & (NCC - 1)][e + (q >> (ND - 1))];
+            corner_diffs<ND, CT>(v, df);
+            const CT gval = widen<T>(graw[e]);
+#pragma unroll
+            for (int i = 0; i < NDIFF; ++i) part[i] = fma_ct(gval, df[i], part[i]);
+        }
+        store_chunk<S, E>(gxp + static_cast<int64_t>(b) * S2 + ji, res);
+    }
+    // ---- this step's sums: DPP tree per wave, the four waves added in fp64 by one thread ----------------------------------
+    double *scratch = reinterpret_cast<double *>(tile + ((npieces * 16 + 63) & ~63) + 64);
+#pragma unroll
+    for (int i = 0; i < NDIFF; ++i) {
+        const CT t = wave_total(part[i]);
+        if ((tid & 63) == 63) scratch[NDIFF * wave + i] = static_cast<double>(t);
+    }
+    __syncthreads();
+    if (tid < NDIFF) {
+        double acc = 0.0;
+#pragma unroll
+        for (int w = 0; w < kThreads / 64; ++w) acc += scratch[NDIFF * w + tid];
+        p.partials[static_cast<size_t>(bid) * NDIFF + tid] = acc;
+    }
+}
+
+struct SpanPlan {
+    int cpr, seg, nseg, R, rsteps, spp, P, ndiff, rec;
+    uint64_t total;
+    size_t off_desc, off_colx, off_colg, bytes, lds;
+};
+
+SpanPlan span_plan(const Geometry &g, int es) {
+    SpanPlan s{};
+    const int E = 16 / es;
+    s.cpr = static_cast<int>(g.S[2] * es / 16);
+    if (s.cpr < 1) s.cpr = 1;
+    s.seg = std::min(s.cpr, kThreads);
+    s.nseg = (s.cpr + s.seg - 1) / s.seg;
+    s.P = s.seg + 2;
+    // rows per step: R * seg threads, and the tile's (3 R + 2) slots of P pieces within the staging rounds
+    int R = kThreads / s.seg;
+    R = std::min(R, (kSpanRounds * kThreads / s.P - 2) / 3);
+    R = std::max(1, std::min<int>(R, static_cast<int>(g.S[1])));
+    if (g.nd == 1 || s.nseg > 1) R = 1;
+    s.R = R;
+    s.rsteps = static_cast<int>((g.S[1] + R - 1) / R);
+    s.spp = s.rsteps * s.nseg;
+    s.ndiff = g.nd == 1 ? 1 : 2;
+    s.rec = (E + 3 <= 8) ? 8 : 16;
+    s.total = static_cast<uint64_t>(g.N) * g.C * s.spp;
+    auto up = [](size_t v) { return (v + 255) & ~static_cast<size_t>(255); };
+    s.off_desc = up(s.total * s.ndiff * sizeof(double));
+    s.off_colx = s.off_desc + up(static_cast<size_t>(g.C) * sizeof(ChanDesc));
+    s.off_colg = s.off_colx + up(static_cast<size_t>(g.C) * s.cpr * s.rec * sizeof(int16_t));
+    s.bytes = s.off_colg + up(static_cast<size_t>(g.C) * s.cpr * s.rec * sizeof(int16_t));
+    const int nslots = g.nd == 2 ? (3 * R + 2) : 3;
+    s.lds = 64 + ((static_cast<size_t>(nslots) * s.P * 16 + 63) & ~static_cast<size_t>(63)) + 64 + (kThreads / 64) * 2 * sizeof(double);
+    return s;
+}
+
+// what the kernel serves, pointers aside (the workspace is planned from this)
+bool span_geometry_ok(const Geometry &g, int dtype) {
+    if (dtype > SHIFTND_BF16 || (g.nd != 1 && g.nd != 2) || g.K[0] > 0) return false;
+    const int es = dtype_size(dtype);
+    if (g.S[0] != 1 || g.O[0] != 1 || g.S[1] < 1 || g.S[2] < 1 || g.O[1] < 1 || g.O[2] < 1) return false;
+    if ((g.S[2] * es) % 16 != 0 || g.S[2] > 32000) return false;                       // x rows: whole pieces; int16 column tables
+    if ((g.N * g.C * g.O[1] * g.O[2] * es) % 16 != 0) return false;                     // grad_out: a whole number of pieces
+    if (g.S[1] * g.S[2] >= (1LL << 28) || g.O[1] * g.O[2] >= (1LL << 28)) return false;  // 32-bit byte offsets within a plane
+    const SpanPlan s = span_plan(g, es);
+    return s.total + 8 < (1ull << 31) && s.lds <= 64 * 1024;
+}
+
+}  // namespace
+
+// cropped 2-D problems, and 1-D problems whose rows fill at least a wave: dense tensors, 16-byte aligned
+bool span_backward_eligible(const Geometry &g, int dtype, const void *go, const void *x, const void *gx) {
+    if (g_step_tune[0] == 1 || !span_geometry_ok(g, dtype)) return false;
+    if (!dense(g.xs, g.N, g.C, g.S) || !dense(g.os, g.N, g.C, g.O) || !dense(g.gs, g.N, g.C, g.S)) return false;
+    if (reinterpret_cast<uintptr_t>(go) % 16 || reinterpret_cast<uintptr_t>(x) % 16 || reinterpret_cast<uintptr_t>(gx) % 16) return false;
+    if (g_step_tune[0] == 2) return true;
+    const int es = dtype_size(dtype);
+    if (g.nd == 1) return g.S[2] * es / 16 >= 64;   // (short rows: one row per workgroup would leave most lanes idle)
+    bool crop = false;
+    for (int d = 1; d < 3; ++d) crop = crop || g.O[d] != g.S[d] || g.L[d] != 0;
+    return crop;   // (uncropped 2-D: step_backward)
+}
+
+size_t span_backward_workspace(const Geometry &g, int dtype) { return span_geometry_ok(g, dtype) ? span_plan(g, dtype_size(dtype)).bytes : 0; }
+
+template <typename T, int ND>
+static void launch_span_backward(const SpanParams &p, const SpanPlan &sp, bool active, void *gw, hipStream_t st) {
+    using S = typename T::S;
+    const dim3 grid(p.steps_per_xcd * 8), block(kThreads);
+#define SHIFTND_SPAN_PAD(ACT, PADV) \
+    case PADV: hipLaunchKernelGGL((span_backward<T, ND, ACT, PADV>), grid, block, sp.lds, st, p); break;
+    if (active) {
+        hipLaunchKernelGGL((span_prep<T, true>), dim3(p.C), block, 0, st, p);
+        switch (p.pad) { SHIFTND_SPAN_PAD(true, 0) SHIFTND_SPAN_PAD(true, 1) SHIFTND_SPAN_PAD(true, 2) SHIFTND_SPAN_PAD(true, 3) default: SHIFTND_SPAN_PAD(true, 4) }
+    } else {
+        hipLaunchKernelGGL((span_prep<T, false>), dim3(p.C), block, 0, st, p);
+        switch (p.pad) { SHIFTND_SPAN_PAD(false, 0) SHIFTND_SPAN_PAD(false, 1) SHIFTND_SPAN_PAD(false, 2) SHIFTND_SPAN_PAD(false, 3) default: SHIFTND_SPAN_PAD(false, 4) }
+    }
+#undef SHIFTND_SPAN_PAD
+    // the channel sums and the blends: step_reduce reads the record layout through StepParams
+    StepParams r{};
+    r.partials = p.partials;
+    r.desc = p.desc;
+    r.N = p.N;
+    r.C = p.C;
+    r.spv = p.spp;
+    r.d_spv = p.d_spp;
+    hipLaunchKernelGGL((step_reduce<T, ND>), dim3(p.C), block, 0, st, r, static_cast<S *>(gw));
+}
+
+int span_backward(const Geometry &g, int dtype, const void *go, const void *x, const void *w, void *gx, void *gw, void *workspace,
+                  hipStream_t st) {
+    const int es = dtype_size(dtype);
+    const SpanPlan sp = span_plan(g, es);
+    SpanParams p{};
+    p.x = x;
+    p.go = go;
+    p.out = gx;
+    p.w = w;
+    char *ws = static_cast<char *>(workspace);
+    p.partials = reinterpret_cast<double *>(ws);
+    p.desc = reinterpret_cast<ChanDesc *>(ws + sp.off_desc);
+    p.colx = reinterpret_cast<int16_t *>(ws + sp.off_colx);
+    p.colg = reinterpret_cast<int16_t *>(ws + sp.off_colg);
+    p.x_plane = g.S[1] * g.S[2];
+    p.g_plane = g.O[1] * g.O[2];
+    p.wkind = dtype;
+    p.N = static_cast<int>(g.N);
+    p.C = static_cast<int>(g.C);
+    p.pad = g.pad;
+    p.nd = g.nd;
+    p.S1 = static_cast<int>(g.S[1]);
+    p.S2 = static_cast<int>(g.S[2]);
+    p.O1 = static_cast<int>(g.O[1]);
+    p.O2 = static_cast<int>(g.O[2]);
+    p.L1 = static_cast<int>(g.L[1]);
+    p.L2 = static_cast<int>(g.L[2]);
+    p.cpr = sp.cpr;
+    p.seg = sp.seg;
+    p.nseg = sp.nseg;
+    p.R = sp.R;
+    p.rsteps = sp.rsteps;
+    p.spp = sp.spp;
+    p.P = sp.P;
+    p.total_steps = static_cast<uint32_t>(sp.total);
+    p.steps_per_xcd = static_cast<uint32_t>((sp.total + 7) / 8);
+    p.d_spp = make_fastdiv(static_cast<uint32_t>(sp.spp));
+    p.d_C = make_fastdiv(static_cast<uint32_t>(p.C));
+    p.d_seg = make_fastdiv(static_cast<uint32_t>(sp.seg));
+    p.d_nseg = make_fastdiv(static_cast<uint32_t>(sp.nseg));
+    p.d_P = make_fastdiv(static_cast<uint32_t>(sp.P));
+    p.d_per1x = make_fastdiv(static_cast<uint32_t>(map_period(p.S1, g.pad)));
+    p.d_per2x = make_fastdiv(static_cast<uint32_t>(map_period(p.S2, g.pad)));
+    p.d_per1g = make_fastdiv(static_cast<uint32_t>(map_period(p.O1, g.pad)));
+    p.d_per2g = make_fastdiv(static_cast<uint32_t>(map_period(p.O2, g.pad)));
+    note_kernel("span_backward");
+    const bool active = g.active != 0;
+#define SHIFTND_SPAN_T(TT) (g.nd == 1 ? launch_span_backward<TT, 1>(p, sp, active, gw, st) : launch_span_backward<TT, 2>(p, sp, active, gw, st))
+    switch (dtype) {
+    case SHIFTND_F32: SHIFTND_SPAN_T(f32_t); break;
+    case SHIFTND_F64: SHIFTND_SPAN_T(f64_t); break;
+    case SHIFTND_F16: SHIFTND_SPAN_T(f16_t); break;
+    default: SHIFTND_SPAN_T(bf16_t); break;
+    }
+#undef SHIFTND_SPAN_T
+    return SHIFTND_OK;
+}
+
+}  // namespace shiftnd

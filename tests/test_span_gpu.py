@@ -1,0 +1,102 @@
+"""GPU parity of the span kernels (csrc/shiftnd_span.hip: cropped 2-D windows and 1-D rows of any length as one-step workgroups
+over row spans) against the CPU oracle, through the C ABI.  The shapes are the reference's everyday cases: the depthwise-conv
+emulation's cut of one element per side (modules/shifts.py:41-46; the reference's own test script, tests/shifts_test.py:9-28, is
+N512 C16 64x64 cut to 62x62), asymmetric and one-sided cuts, windows one element wide, and Shift1d rows shorter and longer than
+one workgroup pass.  Bars as everywhere: fp32 / fp64 grad_x bit-exact, grad_w <= 1e-5 / 1e-12 of the fp64
+evaluation; 16-bit: the sparse shift bit-exact, interpolation within 1 ulp, grad_w within half a unit of the type."""
+import numpy as np
+import pytest
+import torch
+
+from cases import rel_err, gw16_tol
+from oracle import oracle as O
+from test_hip_parity import _ulp_close, _weights
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+@pytest.fixture()
+def abi():
+    from torchshifts import abi as A
+    assert torch.cuda.is_available()
+    A.set_path_policy(0)
+    yield A
+    for k in (32, 33, 34, 35):
+        A.set_tuning(k, 0)
+
+
+CASES_2D = [((3, 5, 9, 24), [[1, 1], [1, 1]]), ((2, 3, 64, 64), [[1, 1], [1, 1]]), ((2, 2, 40, 224), [[1, 1], [1, 1]]),
+            ((2, 3, 17, 32), [[2, 0], [0, 3]]), ((1, 2, 12, 16), [[0, 0], [5, 6]]), ((2, 2, 7, 1000), [[3, 3], [1, 0]]),
+            ((1, 3, 33, 8), [[1, 2], [4, 3]]), ((2, 2, 6, 2048), [[0, 1], [7, 9]]), ((1, 2, 5, 12), [[4, 0], [0, 0]]),
+            ((1, 1, 300, 16), [[100, 150], [2, 2]]), ((2, 2, 16, 16), [[0, 0], [0, 1]])]
+
+
+@pytest.mark.parametrize("dt", ["f32", "f64", "f16", "bf16"])
+@pytest.mark.parametrize("shape,crop", CASES_2D)
+def test_cropped_backward_vs_oracle(abi, shape, crop, dt):
+    tdt = {"f32": torch.float32, "f64": torch.float64, "f16": torch.float16, "bf16": torch.bfloat16}[dt]
+    es = torch.empty(0, dtype=tdt).element_size()
+    b, new = abi.check_borders(list(shape), crop, 2)
+    total = 1
+    for v in new:
+        total *= v
+    if (shape[-1] * es) % 16 or (total * es) % 16:
+        pytest.skip("x rows are not whole 16-byte pieces / grad_out is not a whole number of pieces")
+    rs = np.random.RandomState(sum(shape) * 11 + 5)
+    xt = torch.from_numpy(rs.uniform(-1, 1, size=shape)).to(tdt)
+    gt = torch.from_numpy(rs.uniform(-1, 1, size=new)).to(tdt)
+    wt = torch.from_numpy(_weights(rs, shape[1], 2, shape[2:])).to(tdt)
+    wide = np.float64 if tdt == torch.float64 else np.float32
+    x, go, w = (t.to(torch.float64).numpy().astype(wide) for t in (xt, gt, wt))
+    xd, god, wd = xt.to(DEV), gt.to(DEV), wt.to(DEV)
+    for pad in range(5):
+        for active in (0, 1):
+            gx, gw = abi.backward(god, wd, xd, pad, active, b)
+            assert abi.last_kernel() == "span_backward", (shape, crop, abi.last_kernel())
+            gx_ref = torch.from_numpy(O.backward(go, w, x, pad, active, b)[0]).to(tdt)
+            if es >= 4 or not active:
+                assert torch.equal(gx.cpu(), gx_ref), ("gx", shape, crop, dt, pad, active)
+            else:
+                assert _ulp_close(gx.cpu(), gx_ref, tdt), ("gx", shape, crop, dt, pad, active)
+            _, gw64 = O.backward(go.astype(np.float64), w.astype(np.float64), x.astype(np.float64), pad, active, b)
+            tol = {"f32": 1e-5, "f64": 1e-12}.get(dt, gw16_tol(torch.finfo(tdt).eps))
+            assert rel_err(gw.to(torch.float64).cpu().numpy(), gw64) < tol, ("gw", shape, crop, dt, pad, active)
+            gx2, gw2 = abi.backward(god, wd, xd, pad, active, b)
+            assert torch.equal(gx, gx2) and torch.equal(gw, gw2)  # deterministic
+
+
+CASES_1D = [((3, 5, 512), None), ((2, 3, 4096), None), ((2, 2, 1024 + 256), None), ((2, 3, 2048), [[3, 5]]), ((1, 2, 4096 + 64), [[0, 16]]),
+            ((2, 2, 640), [[100, 28]]), ((1, 3, 1032), None)]
+
+
+@pytest.mark.parametrize("dt", ["f32", "f64", "f16", "bf16"])
+@pytest.mark.parametrize("shape,crop", CASES_1D)
+def test_1d_backward_vs_oracle(abi, shape, crop, dt):
+    tdt = {"f32": torch.float32, "f64": torch.float64, "f16": torch.float16, "bf16": torch.bfloat16}[dt]
+    es = torch.empty(0, dtype=tdt).element_size()
+    b, new = abi.check_borders(list(shape), crop, 1)
+    total = 1
+    for v in new:
+        total *= v
+    if (shape[-1] * es) % 16 or (total * es) % 16 or shape[-1] * es // 16 < 64:
+        pytest.skip("rows are not whole 16-byte pieces / shorter than a wave of chunks / grad_out is not a whole number of pieces")
+    rs = np.random.RandomState(sum(shape) * 3 + 2)
+    xt = torch.from_numpy(rs.uniform(-1, 1, size=shape)).to(tdt)
+    gt = torch.from_numpy(rs.uniform(-1, 1, size=new)).to(tdt)
+    wt = torch.from_numpy(_weights(rs, shape[1], 1, shape[2:])).to(tdt)
+    wide = np.float64 if tdt == torch.float64 else np.float32
+    x, go, w = (t.to(torch.float64).numpy().astype(wide) for t in (xt, gt, wt))
+    xd, god, wd = xt.to(DEV), gt.to(DEV), wt.to(DEV)
+    for pad in range(5):
+        for active in (0, 1):
+            gx, gw = abi.backward(god, wd, xd, pad, active, b)
+            assert abi.last_kernel() == "span_backward", (shape, crop, abi.last_kernel())
+            gx_ref = torch.from_numpy(O.backward(go, w, x, pad, active, b)[0]).to(tdt)
+            if es >= 4 or not active:
+                assert torch.equal(gx.cpu(), gx_ref), ("gx", shape, crop, dt, pad, active)
+            else:
+                assert _ulp_close(gx.cpu(), gx_ref, tdt), ("gx", shape, crop, dt, pad, active)
+            _, gw64 = O.backward(go.astype(np.float64), w.astype(np.float64), x.astype(np.float64), pad, active, b)
+            tol = {"f32": 1e-5, "f64": 1e-12}.get(dt, gw16_tol(torch.finfo(tdt).eps))
+            assert rel_err(gw.to(torch.float64).cpu().numpy(), gw64) < tol, ("gw", shape, crop, dt, pad, active)

@@ -65,8 +65,23 @@ def build_hip(force, pool):
     for j in jobs:
         j.result()
     if force or jobs or newer(lib, objs):
+        check_no_scratch(objs)
         run([hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", lib])
     return lib
+
+
+def check_no_scratch(objs):
+    """Every kernel of this library is bandwidth-bound: one that needs a private segment (scratch) spills registers or indexes
+    a local array dynamically inside its streaming loop.  tools/kernel_resources.py reads the AMDGPU metadata note of every
+    code object (llvm-readelf --notes); the build fails when a kernel has private_segment_fixed_size > 0 or spilled VGPRs."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("kernel_resources", os.path.join(ROOT, "tools", "kernel_resources.py"))
+    kr = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(kr)
+    bad = kr.check_no_scratch(objs)
+    if bad:
+        raise RuntimeError("kernels with scratch (bytes per lane): " + "; ".join("%s: %d" % b for b in bad[:20]))
+    print("  no kernel of %d objects uses scratch" % len(objs), flush=True)
 
 
 def build_torch(force, pool):

@@ -95,6 +95,12 @@ int forward_common(const shiftnd_problem *p, const void *x, const int64_t *xs, c
             g_last_path = SHIFTND_PATH_SWEEP;
             return finish(step_forward(g, p->dtype, x, w, wkind, wzp, fill, out, st));
         }
+        // cropped windows with ragged rows, 1-D rows of any length, ragged source rows (float tensors): one-step workgroups over
+        // row spans -- what the aligned one-step forwards below do not take
+        if (g_policy == 0 && wkind == p->dtype && !step_forward_lds_eligible(g, p->dtype, x, out) && span_forward_eligible(g, p->dtype, x, out)) {
+            g_last_path = SHIFTND_PATH_PLANE;
+            return finish(span_forward(g, p->dtype, x, w, wkind, out, st));
+        }
         // 1-byte (and, knob 28, 2-byte) rows of whole 16-byte pieces beyond the byte kernel's small planes: rows through LDS
         if (g_policy == 0 && !bytes_forward_eligible(g, p->dtype, x, out) && rows_forward_eligible(g, p->dtype, x, out)) {
             g_last_path = SHIFTND_PATH_PLANE;

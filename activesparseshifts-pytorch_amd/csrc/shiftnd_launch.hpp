@@ -81,6 +81,8 @@ bool step_forward_lds_eligible(const Geometry &g, int dtype, const void *x, cons
 int step_forward_lds(const Geometry &g, int dtype, const void *x, const void *w, int wkind, uint64_t fill_bits, void *out, hipStream_t st);
 void step_set_tuning(int knob, int value);
 // ---- cropped 2-D windows and 1-D rows of any length as one-step workgroups over row spans (shiftnd_span.hip, round 4)
+bool span_forward_eligible(const Geometry &g, int dtype, const void *x, const void *out);
+int span_forward(const Geometry &g, int dtype, const void *x, const void *w, int wkind, void *out, hipStream_t st);
 bool span_backward_eligible(const Geometry &g, int dtype, const void *go, const void *x, const void *gx);
 size_t span_backward_workspace(const Geometry &g, int dtype);
 int span_backward(const Geometry &g, int dtype, const void *go, const void *x, const void *w, void *gx, void *gw, void *workspace,

@@ -352,6 +352,7 @@ __global__ __launch_bounds__(kThreads) void span_backward(const SpanParams p) {
         const CT t = wave_total(part[i]);
         if ((tid & 63) == 63) scratch[NDIFF * wave + i] = static_cast<double>(t);
     }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // (explicit wait + clobber at every barrier: see walk_barrier, shiftnd_walk.hip)
     __syncthreads();
     if (tid < NDIFF) {
         double acc = 0.0;
@@ -359,6 +360,210 @@ __global__ __launch_bounds__(kThreads) void span_backward(const SpanParams p) {
         for (int w = 0; w < kThreads / 64; ++w) acc += scratch[NDIFF * w + tid];
         p.partials[static_cast<size_t>(bid) * NDIFF + tid] = acc;
     }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// span_forward: the forward of the same tensors (kernels/shifts_kernels.h:156-220; weights cuda/shifts_cuda.cu:168-183).  The
+// output window has ragged rows too, so a step is 256 consecutive 16-byte chunks of the OUTPUT plane's byte stream (planes
+// are whole pieces; a chunk may straddle two output rows); the source rows those chunks read are staged as spans of x (which
+// may have ragged rows itself: 62 x 62 inputs).  A chunk inside one output row reads its window through ColState; one that
+// straddles two rows, and one whose columns are not among the staged ones, goes element by element.
+// ---------------------------------------------------------------------------------------------------------------------
+struct SpanFwdParams {
+    const void *x;
+    void *out;
+    const void *w;
+    int64_t x_plane, o_plane;   // elements per (n, c)
+    int wkind, C, nd;
+    int S1, S2, O1, O2, L1, L2;
+    int ocp, cps, spp;   // 16-byte chunks per output plane, chunks per step (256; 254 when only a column segment is staged), steps per plane
+    int P, wholeP;       // pieces per slot; the same when whole rows are staged (0: only the columns the step reaches)
+    uint32_t total_steps, steps_per_xcd;
+    FastDiv d_spp, d_C, d_O2, d_P, d_per1, d_per2;
+};
+
+template <typename T, int ND, bool ACTIVE, int PAD>
+__global__ __launch_bounds__(kThreads) void span_forward(const SpanFwdParams p) {
+    using S = typename T::S;
+    using CT = typename T::C;
+    constexpr int ES = sizeof(S);
+    constexpr int E = 16 / ES;
+    constexpr int NCC = 1 << (ND - 1);
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char *tile = smem + 64;
+
+    const uint32_t bid = (blockIdx.x & 7u) * p.steps_per_xcd + (blockIdx.x >> 3);
+    if (bid >= p.total_steps) return;
+    const uint32_t plane = fdiv(bid, p.d_spp);
+    const int step = static_cast<int>(bid - plane * static_cast<uint32_t>(p.spp));
+    const int c = static_cast<int>(plane - fdiv(plane, p.d_C) * static_cast<uint32_t>(p.C));
+    CT wv[3];
+    load_weights_nd<CT>(p.w, p.wkind, c, p.nd, wv);   // normalised order: (plane,) row, inner
+    CT rr[3], dn[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {   // weights_init_forward: the sparse shift rounds (half to even, as the CPU path), active floors
+        rr[k] = ACTIVE ? c_floor<CT>(wv[k]) : c_rint<CT>(wv[k]);
+        dn[k] = ACTIVE ? wv[k] - rr[k] : CT(0);
+    }
+    const int S1 = p.S1, S2 = p.S2, O2 = p.O2, L1 = p.L1, L2 = p.L2, P = p.P;
+    const int cs1 = ND == 2 ? __builtin_amdgcn_readfirstlane(canon_of<PAD, CT>(rr[1], S1, p.d_per1)) : 0;
+    const int cs2 = __builtin_amdgcn_readfirstlane(canon_of<PAD, CT>(rr[2], S2, p.d_per2));
+    const CT dw[3] = {ND == 2 ? dn[1] : dn[2], dn[2], CT(0)};   // fractions in real-dim order
+
+    // the step's chunks, output rows and source columns
+    const int q0 = step * p.cps, q1 = min(p.ocp, q0 + p.cps);
+    const int F0 = q0 * E, F1 = q1 * E;   // flat elements of the output plane
+    const int r0 = static_cast<int>(fdiv(static_cast<uint32_t>(F0), p.d_O2)), r1 = static_cast<int>(fdiv(static_cast<uint32_t>(F1 - 1), p.d_O2));
+    const int nr = r1 - r0 + 1 + (ACTIVE && ND == 2 ? 1 : 0);   // staged source rows
+    const bool whole = p.wholeP != 0;
+    auto clampi = [](int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); };
+    const int jlo = r0 == r1 ? F0 - r0 * O2 : 0, jhi = r0 == r1 ? F1 - r0 * O2 : O2;   // output columns [jlo, jhi)
+    // (only a column segment staged and the step straddles two output rows -- rows longer than a workgroup pass: nothing is
+    //  staged, its chunks read from memory)
+    const bool none = !whole && r0 != r1;
+    const int c0 = whole || none ? 0 : clampi(jlo + L2 - cs2, 0, S2);
+    const int c1 = whole ? S2 : (none ? 0 : clampi(jhi + L2 - cs2 + (ACTIVE ? 1 : 0), 0, S2));
+    const S *xp = static_cast<const S *>(p.x) + static_cast<int64_t>(plane) * p.x_plane;
+    S *op = static_cast<S *>(p.out) + static_cast<int64_t>(plane) * p.o_plane;
+    const int xph = static_cast<int>((static_cast<uint64_t>(plane) * static_cast<uint64_t>(p.x_plane) * ES) & 15u);
+    const char *xp16 = reinterpret_cast<const char *>(xp) - xph;   // 16-byte aligned (the tensor's base is)
+
+    const int tid = static_cast<int>(threadIdx.x);
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // slot i = source row of output row r0 + i (window coordinates + L1 through the row map); -1: fill
+    auto slot_row = [&](int i) { return ND == 2 ? row_map_t<PAD>(r0 + i + L1, cs1, S1) : 0; };
+    const int npieces = nr * P;
+#pragma unroll
+    for (int k = 0; k < kSpanRounds; ++k) {
+        if (k * kThreads < npieces) {   // uniform
+            const int q = k * kThreads + tid;
+            const int slot = static_cast<int>(fdiv(static_cast<uint32_t>(q), p.d_P));
+            const int piece = q - slot * P;
+            const int row = slot < nr ? slot_row(slot) : -1;
+            const int lo = xph + (row * S2 + c0) * ES, hi = xph + (row * S2 + c1) * ES;
+            const int p0 = lo >> 4, cnt = ((hi + 15) >> 4) - p0;
+            if (q < npieces && row >= 0 && piece < cnt) {
+                char *dst_wave = tile + (k * kThreads + wave * 64) * 16;
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(xp16 + static_cast<int64_t>(p0 + piece) * 16),
+                                                 (__attribute__((address_space(3))) void *)dst_wave, 16, 0, 2 /* nt */);
+            }
+        }
+    }
+    // ---- the thread's chunk ---------------------------------------------------------------------------------------------------
+    const int q = q0 + tid;
+    const bool mine = q < q1;
+    const int e0 = q * E;
+    const int r = mine ? static_cast<int>(fdiv(static_cast<uint32_t>(e0), p.d_O2)) : r0;
+    const int j = e0 - r * O2;
+    const bool one_row = j + E <= O2;
+    ColState<E> xm;
+    if constexpr (PAD == 0) {
+        const int first = j + L2 - cs2;
+        xm.base = (first + E < 0 || first >= S2) ? c0 : first;
+        xm.affine = true;
+#pragma unroll
+        for (int e = 0; e <= E; ++e) xm.cm[e] = (first + e >= 0 && first + e < S2) ? first + e : -1;
+    } else {
+        xm = fold_colstate<E, PAD>(j + L2, cs2, S2);
+    }
+    bool staged = xm.affine;   // every column of the window among the staged ones
+#pragma unroll
+    for (int e = 0; e <= E; ++e) staged = staged && (xm.cm[e] < 0 || (xm.cm[e] >= c0 && xm.cm[e] < c1));
+    staged = staged || whole;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (!mine) return;
+    S zero;
+    __builtin_memset(&zero, 0, sizeof(S));
+    // column 0 of a staged row within its slot / in memory
+    auto lds_row = [&](int slot, int row) { return tile + slot * P * 16 + ((xph + (row * S2 + c0) * ES) & 15) - c0 * ES; };
+    auto mem_row = [&](int row) { return xp + static_cast<int64_t>(row) * S2; };
+    // one element of source row `slot`, column m (or -1)
+    auto element = [&](int slot, int m) {
+        const int row = slot_row(slot);
+        if (row < 0 || m < 0) return zero;
+        if (whole || (m >= c0 && m < c1)) return reinterpret_cast<const S *>(lds_row(slot, row))[m];
+        return mem_row(row)[m];
+    };
+    Chunk<S, E> res;
+    if (one_row) {
+        CT xv[NCC][E + 1];
+#pragma unroll
+        for (int k = 0; k < (ACTIVE ? NCC : 1); ++k) {   // (the sparse shift reads one row)
+            const int slot = r - r0 + k;
+            const int row = slot_row(slot);
+            S raw[E + 1];
+            span_read<S, E>(lds_row(slot, row), mem_row(row), staged, row >= 0, xm, raw);
+#pragma unroll
+            for (int e = 0; e <= E; ++e) xv[k][e] = widen<T>(raw[e]);
+            if constexpr (!ACTIVE) {
+#pragma unroll
+                for (int e = 0; e < E; ++e) res.e[e] = raw[e];
+            }
+        }
+        if constexpr (ACTIVE) {
+#pragma unroll
+            for (int e = 0; e < E; ++e) {
+                CT v[1 << ND];
+#pragma unroll
+                for (int qq = 0; qq < (1 << ND); ++qq) v[qq] = xv[qq & (NCC - 1)][e + (qq >> (ND - 1))];
+                res.e[e] = narrow<T>(interp_t<T, ND>(v, dw));
+            }
+        }
+    } else {   // the chunk straddles two output rows: element by element
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+            const bool next = j + e >= O2;
+            const int slot = r - r0 + (next ? 1 : 0), je = next ? j + e - O2 : j + e;
+            const int m0 = row_map_t<PAD>(je + L2, cs2, S2);
+            if constexpr (ACTIVE) {
+                const int m1 = row_map_t<PAD>(je + L2 + 1, cs2, S2);
+                CT v[1 << ND];
+#pragma unroll
+                for (int qq = 0; qq < (1 << ND); ++qq) v[qq] = widen<T>(element(slot + (qq & (NCC - 1)), (qq >> (ND - 1)) ? m1 : m0));
+                res.e[e] = narrow<T>(interp_t<T, ND>(v, dw));
+            } else {
+                res.e[e] = element(slot, m0);
+            }
+        }
+    }
+    store_chunk<S, E>(op + e0, res);
+}
+
+struct SpanFwdPlan {
+    int ocp, cps, spp, P, wholeP;
+    uint64_t total;
+    size_t lds;
+    bool ok;
+};
+
+SpanFwdPlan span_forward_plan(const Geometry &g, int es) {
+    SpanFwdPlan s{};
+    const int E = 16 / es;
+    const int64_t oe = g.O[1] * g.O[2];
+    s.ocp = static_cast<int>(oe * es / 16);
+    // source rows a step can touch: the output rows of 256 chunks (+ the corner row)
+    const int64_t rows = std::min<int64_t>(g.O[1], (static_cast<int64_t>(kThreads) * E + g.O[2] - 2) / g.O[2] + 1) + (g.active && g.nd == 2 ? 1 : 0);
+    const int64_t cprx = (g.S[2] * es + 15) / 16 + 1;   // pieces that cover a (ragged) source row
+    const int64_t budget = kSpanRounds * kThreads;
+    // whole source rows when a step spans whole output rows (an output row of at most 256 chunks); rows longer than a step
+    // stage only the columns the step's chunks reach
+    if (g.O[2] * es <= kThreads * 16 && rows * cprx <= budget) {
+        s.P = s.wholeP = static_cast<int>(cprx);
+        s.cps = kThreads;
+    } else {
+        // only the columns the step's chunks reach: 256 chunks' source columns (+ the corner column, + the misalignment of the
+        // shift) lie in 258 pieces.  (Steps of 254 chunks, whose columns fit one staging round of 256 pieces, were measured: their
+        // 4064-byte output blocks split every 64-byte sector between two workgroups -- N256 C512 L4096 fp32 0.91 -> 1.10 ms.)
+        s.wholeP = 0;
+        s.cps = kThreads;
+        s.P = kThreads + 2;
+    }
+    s.spp = (s.ocp + s.cps - 1) / s.cps;
+    s.total = static_cast<uint64_t>(g.N) * g.C * s.spp;
+    s.ok = rows * s.P <= budget;
+    s.lds = 64 + ((static_cast<size_t>(rows) * s.P * 16 + 63) & ~static_cast<size_t>(63)) + 64;
+    return s;
 }
 
 struct SpanPlan {
@@ -372,6 +577,8 @@ SpanPlan span_plan(const Geometry &g, int es) {
     const int E = 16 / es;
     s.cpr = static_cast<int>(g.S[2] * es / 16);
     if (s.cpr < 1) s.cpr = 1;
+    // column segments of at most 256 chunks (4 KB blocks of grad_x: see span_forward_plan); slots of seg + 2 pieces (a ragged
+    // grad_out row's cover; a segment's source columns + corner column + shift misalignment)
     s.seg = std::min(s.cpr, kThreads);
     s.nseg = (s.cpr + s.seg - 1) / s.seg;
     s.P = s.seg + 2;
@@ -409,6 +616,91 @@ bool span_geometry_ok(const Geometry &g, int dtype) {
 }
 
 }  // namespace
+
+// the forward of cropped windows, 1-D rows and ragged rows: dense float tensors whose planes (output) and total size (input)
+// are whole 16-byte pieces
+bool span_forward_eligible(const Geometry &g, int dtype, const void *x, const void *out) {
+    if (g_step_tune[2] == 1) return false;   // knob 34 = 1: no forwards through LDS
+    if (dtype > SHIFTND_BF16 || (g.nd != 1 && g.nd != 2) || g.K[0] > 0) return false;
+    const int es = dtype_size(dtype);
+    if (g.S[0] != 1 || g.O[0] != 1 || g.S[1] < 1 || g.S[2] < 1 || g.O[1] < 1 || g.O[2] < 1) return false;
+    if ((g.O[1] * g.O[2] * es) % 16 != 0 || (g.N * g.C * g.S[1] * g.S[2] * es) % 16 != 0) return false;
+    if (g.S[1] * g.S[2] >= (1LL << 28) || g.O[1] * g.O[2] >= (1LL << 28)) return false;
+    if (!dense(g.xs, g.N, g.C, g.S) || !dense(g.os, g.N, g.C, g.O)) return false;
+    if (reinterpret_cast<uintptr_t>(x) % 16 || reinterpret_cast<uintptr_t>(out) % 16) return false;
+    const SpanFwdPlan s = span_forward_plan(g, es);
+    if (!s.ok || s.total + 8 >= (1ull << 31) || s.lds > 64 * 1024) return false;
+    if (g_step_tune[2] >= 2) return true;
+    bool crop = false;
+    for (int d = 1; d < 3; ++d) crop = crop || g.O[d] != g.S[d] || g.L[d] != 0;
+    const bool ragged = (g.S[2] * es) % 16 != 0;
+    // cropped or ragged 2-D planes (the aligned, uncropped ones: the step kernels).  1-D rows on request only (knob 34 >= 2): same
+    // box, N256 C512 L4096: fp32 sparse 0.90 vs 0.92 ms of the per-channel kernels, interpolating 0.88 vs 0.83, fp16 0.57 vs 0.42
+    return g.nd == 2 && (crop || ragged);
+}
+
+template <typename T, int ND>
+static void launch_span_forward(const SpanFwdParams &p, size_t lds, bool active, int pad, hipStream_t st) {
+    const dim3 grid(p.steps_per_xcd * 8), block(kThreads);
+#define SHIFTND_SPAN_FWD(ACT, PADV) \
+    case PADV: hipLaunchKernelGGL((span_forward<T, ND, ACT, PADV>), grid, block, lds, st, p); break;
+    if (active) {
+        switch (pad) { SHIFTND_SPAN_FWD(true, 0) SHIFTND_SPAN_FWD(true, 1) SHIFTND_SPAN_FWD(true, 2) SHIFTND_SPAN_FWD(true, 3) default: SHIFTND_SPAN_FWD(true, 4) }
+    } else {
+        switch (pad) { SHIFTND_SPAN_FWD(false, 0) SHIFTND_SPAN_FWD(false, 1) SHIFTND_SPAN_FWD(false, 2) SHIFTND_SPAN_FWD(false, 3) default: SHIFTND_SPAN_FWD(false, 4) }
+    }
+#undef SHIFTND_SPAN_FWD
+}
+
+int span_forward(const Geometry &g, int dtype, const void *x, const void *w, int wkind, void *out, hipStream_t st) {
+    const int es = dtype_size(dtype);
+    const SpanFwdPlan sp = span_forward_plan(g, es);
+    SpanFwdParams p{};
+    p.x = x;
+    p.out = out;
+    p.w = w;
+    p.wkind = wkind;
+    p.C = static_cast<int>(g.C);
+    p.nd = g.nd;
+    p.S1 = static_cast<int>(g.S[1]);
+    p.S2 = static_cast<int>(g.S[2]);
+    p.O1 = static_cast<int>(g.O[1]);
+    p.O2 = static_cast<int>(g.O[2]);
+    p.L1 = static_cast<int>(g.L[1]);
+    p.L2 = static_cast<int>(g.L[2]);
+    p.x_plane = g.S[1] * g.S[2];
+    p.o_plane = g.O[1] * g.O[2];
+    p.ocp = sp.ocp;
+    p.cps = sp.cps;
+    p.spp = sp.spp;
+    p.P = sp.P;
+    p.wholeP = sp.wholeP;
+    p.total_steps = static_cast<uint32_t>(sp.total);
+    p.steps_per_xcd = static_cast<uint32_t>((sp.total + 7) / 8);
+    p.d_spp = make_fastdiv(static_cast<uint32_t>(sp.spp));
+    p.d_C = make_fastdiv(static_cast<uint32_t>(p.C));
+    p.d_O2 = make_fastdiv(static_cast<uint32_t>(p.O2));
+    p.d_P = make_fastdiv(static_cast<uint32_t>(sp.P));
+    p.d_per1 = make_fastdiv(static_cast<uint32_t>(map_period(p.S1, g.pad)));
+    p.d_per2 = make_fastdiv(static_cast<uint32_t>(map_period(p.S2, g.pad)));
+    const bool active = g.active != 0;
+    note_kernel(active ? "span_active_forward" : "span_gather_forward");
+#define SHIFTND_SPAN_FT(TT) (g.nd == 1 ? launch_span_forward<TT, 1>(p, sp.lds, active, g.pad, st) : launch_span_forward<TT, 2>(p, sp.lds, active, g.pad, st))
+    if (!active) {   // a raw copy: one instantiation per element size
+        if (es == 2) SHIFTND_SPAN_FT(f16_t);
+        else if (es == 4) SHIFTND_SPAN_FT(f32_t);
+        else SHIFTND_SPAN_FT(f64_t);
+        return SHIFTND_OK;
+    }
+    switch (dtype) {
+    case SHIFTND_F32: SHIFTND_SPAN_FT(f32_t); break;
+    case SHIFTND_F64: SHIFTND_SPAN_FT(f64_t); break;
+    case SHIFTND_F16: SHIFTND_SPAN_FT(f16_t); break;
+    default: SHIFTND_SPAN_FT(bf16_t); break;
+    }
+#undef SHIFTND_SPAN_FT
+    return SHIFTND_OK;
+}
 
 // cropped 2-D problems, and 1-D problems whose rows fill at least a wave: dense tensors, 16-byte aligned
 bool span_backward_eligible(const Geometry &g, int dtype, const void *go, const void *x, const void *gx) {

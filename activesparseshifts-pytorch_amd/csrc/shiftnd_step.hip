@@ -131,39 +131,57 @@ __global__ __launch_bounds__(kThreads) void step_backward(const StepParams p) {
     // POOL: a row of the unpooled gradient is its pooled row expanded: g(b, j) = grad_pooled[b / K1][j / K2] / (window size),
     // rounded to the storage type like the two-step sequence (ATen's avg_pool backward); a thread expands its own piece
     // into the tile (the loads of all its pieces first, so that their latencies overlap each other and the row DMA)
-    auto pooled_load = [&](int grow, int col_piece, Chunk<S, E> &raw, int &cnt) {
+    // (three NAMED pieces per thread -- the step's own row, the row grad_x blends, the + 1 corner row -- each a value: arrays of
+    //  chunks indexed in a loop, filled through references, stayed in scratch: 64 bytes per lane in round 3)
+    struct Pooled {
+        Chunk<S, E> raw;   // the pooled elements under the piece (E / 2 of them when K2 == 2)
+        int cnt;           // rows of the pooled row's window
+        int dst;           // tile piece (-1: none)
+        int col;
+    };
+    auto pooled_load = [&](int grow, int col_piece, int dst) {
+        Pooled q;
+        q.dst = dst;
+        q.col = col_piece;
         const int pr = static_cast<int>(fdiv(static_cast<uint32_t>(grow), p.d_k1));
-        cnt = min(p.K1, S1 - pr * p.K1);
+        q.cnt = min(p.K1, S1 - pr * p.K1);
         const S *prow = gp + static_cast<int64_t>(pr) * p.P2;
+        S zero;
+        __builtin_memset(&zero, 0, sizeof(S));
+#pragma unroll
+        for (int e = 0; e < E; ++e) q.raw.e[e] = zero;
         if (p.K2 == 2 && E % 2 == 0) {
             const Chunk<S, (E >= 2 ? E / 2 : 1)> h = load_chunk<S, (E >= 2 ? E / 2 : 1)>(prow + col_piece * (E / 2));
 #pragma unroll
-            for (int e = 0; e < E / 2; ++e) raw.e[e] = h.e[e];
+            for (int e = 0; e < E / 2; ++e) q.raw.e[e] = h.e[e];
         } else {
 #pragma unroll
-            for (int e = 0; e < E; ++e) raw.e[e] = prow[fdiv(static_cast<uint32_t>(col_piece * E + e), p.d_k2)];
+            for (int e = 0; e < E; ++e) q.raw.e[e] = prow[fdiv(static_cast<uint32_t>(col_piece * E + e), p.d_k2)];
         }
+        return q;
     };
-    auto pooled_store = [&](const Chunk<S, E> &raw, int cnt, int col_piece, int lds_piece) {
+    auto pooled_store = [&](const Pooled &q) {
         Chunk<S, E> out;
         if (p.K2 == 2 && E % 2 == 0) {
 #pragma unroll
             for (int h = 0; h < E / 2; ++h) {
-                const S q = narrow<T>(div_count<CT>(widen<T>(raw.e[h]), cnt * 2));
-                out.e[2 * h] = q;
-                out.e[2 * h + 1] = q;
+                const S v = narrow<T>(div_count<CT>(widen<T>(q.raw.e[h]), q.cnt * 2));
+                out.e[2 * h] = v;
+                out.e[2 * h + 1] = v;
             }
         } else {
 #pragma unroll
             for (int e = 0; e < E; ++e) {
-                const int pc = static_cast<int>(fdiv(static_cast<uint32_t>(col_piece * E + e), p.d_k2));
-                out.e[e] = narrow<T>(div_count<CT>(widen<T>(raw.e[e]), cnt * min(p.K2, S2 - pc * p.K2)));
+                const int pc = static_cast<int>(fdiv(static_cast<uint32_t>(q.col * E + e), p.d_k2));
+                out.e[e] = narrow<T>(div_count<CT>(widen<T>(q.raw.e[e]), q.cnt * min(p.K2, S2 - pc * p.K2)));
             }
         }
-        __builtin_memcpy(__builtin_assume_aligned(tile + lds_piece * 16, 16), out.e, 16);
+        __builtin_memcpy(__builtin_assume_aligned(tile + q.dst * 16, 16), out.e, 16);
     };
-    Chunk<S, E> pq[POOL ? (ACTIVE ? 3 : 1) : 1];
-    int pcnt[3] = {0, 0, 0}, pdst[3] = {-1, -1, -1}, pcol[3] = {0, 0, 0};
+    Pooled pqA, pqB, pqC;
+    pqA.dst = pqB.dst = pqC.dst = -1;
+    pqA.cnt = pqB.cnt = pqC.cnt = 1;
+    pqA.col = pqB.col = pqC.col = 0;
 #pragma unroll
     for (int u = 0; u < U; ++u) {
     if (tr < R) {
@@ -173,22 +191,13 @@ __global__ __launch_bounds__(kThreads) void step_backward(const StepParams p) {
         for (int h = 0; h < NP; ++h)
             if (sx >= 0 && pax[h] >= 0) dma(xp, pax[h] * S1 + sx, tc, h * (RT + 1) * cpr + u * R * cpr);
         if (vtr < Rn) {  // the incoming gradient at the rows themselves
-            if constexpr (POOL) {
-                pooled_load(b0 + vtr, tc, pq[0], pcnt[0]);
-                pdst[0] = NX * cpr + vtid;
-                pcol[0] = tc;
-            } else {
-                dma(gp, a * S1 + b0 + vtr, tc, NX * cpr + u * R * cpr);
-            }
+            if constexpr (POOL) pqA = pooled_load(b0 + vtr, tc, NX * cpr + vtid);
+            else dma(gp, a * S1 + b0 + vtr, tc, NX * cpr + u * R * cpr);
         }
         if constexpr (ACTIVE) {
             const int sg = vtr <= Rn ? row_map_t<PAD>(b0 + vtr, d.cg1, S1) : -1;  // the rows grad_x blends: g1[b0 + tr]
             if constexpr (POOL) {
-                if (sg >= 0) {
-                    pooled_load(sg, tc, pq[1], pcnt[1]);
-                    pdst[1] = (NX + NG) * cpr + vtid;
-                    pcol[1] = tc;
-                }
+                if (sg >= 0) pqB = pooled_load(sg, tc, (NX + NG) * cpr + vtid);
             } else {
 #pragma unroll
                 for (int h = 0; h < NP; ++h)
@@ -208,11 +217,7 @@ __global__ __launch_bounds__(kThreads) void step_backward(const StepParams p) {
         if constexpr (ACTIVE) {
             const int sg = row_map_t<PAD>(b0 + RT, d.cg1, S1);
             if constexpr (POOL) {
-                if (sg >= 0) {
-                    pooled_load(sg, tid, pq[2], pcnt[2]);
-                    pdst[2] = (NX + NG + RT) * cpr + tid;
-                    pcol[2] = tid;
-                }
+                if (sg >= 0) pqC = pooled_load(sg, tid, (NX + NG + RT) * cpr + tid);
             } else {
 #pragma unroll
                 for (int h = 0; h < NP; ++h)
@@ -220,10 +225,12 @@ __global__ __launch_bounds__(kThreads) void step_backward(const StepParams p) {
             }
         }
     }
-    if constexpr (POOL) {
-#pragma unroll
-        for (int k = 0; k < (ACTIVE ? 3 : 1); ++k)
-            if (pdst[k] >= 0) pooled_store(pq[k], pcnt[k], pcol[k], pdst[k]);
+    if constexpr (POOL) {   // (every load above is in flight before the first conversion)
+        if (pqA.dst >= 0) pooled_store(pqA);
+        if constexpr (ACTIVE) {
+            if (pqB.dst >= 0) pooled_store(pqB);
+            if (pqC.dst >= 0) pooled_store(pqC);
+        }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();

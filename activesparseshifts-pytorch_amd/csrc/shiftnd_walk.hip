@@ -43,6 +43,18 @@ constexpr int kWalkFlush = 16;                         // planes between two flu
 
 typedef uint32_t u4_t __attribute__((ext_vector_type(4)));
 
+// The workgroup barrier of the walk kernels: every LDS operation of this wave has completed, and the compiler may not move a
+// memory access across it.  A bare __syncthreads() was not enough in walk_backward16<..., ZEROS = false>: with several
+// workgroups per CU (N * C * steps > 256) its gather path -- ds_read_u16 under a thread-dependent branch -- raced with the next
+// step's parking stores; non-deterministic zeros in grad_x on 70 % of the channels of C3 with border padding, invisible with
+// one workgroup per CU (the small shapes of the parity tests).  Found by the full-size test of round 4; any explicit wait +
+// memory clobber next to either barrier of the step removes it.
+__device__ __forceinline__ void walk_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __syncthreads();
+    asm volatile("" ::: "memory");
+}
+
 // cache-policy bits: the staged loads and the own chunk are plain (every gradient plane is read twice by its workgroup, the
 // "+1" corner row by two workgroups: nontemporal loads cost 20 %), grad_x is written once and not read again: nontemporal
 // (C3 0.243 -> 0.236 ms).  Measured and dropped: walks of 8 / 4 / 2 / 1 planes per workgroup, an occupancy
@@ -263,9 +275,9 @@ __global__ __launch_bounds__(kThreads) void walk_backward16(const StepParams p) 
         load_planes(row_map(a0 + 1, d.cx0, S0, pad), row_map(a0 + GA, d.cg0, S0, pad), stA);
         load_planes(a0 + 1 < a1 ? row_map(a0 + 2, d.cx0, S0, pad) : -1, a0 + 1 < a1 ? row_map(a0 + 1 + GA, d.cg0, S0, pad) : -1, stB);
         gcur = load_own(a0, true);
-        __syncthreads();   // the tiles are zero
+        walk_barrier();   // the tiles are zero
         park(v0);
-        __syncthreads();
+        walk_barrier();
         if (px) {
             walk_read<ZEROS, NA, 1>(tx, wx, 0u, xa[0]);
             walk_read<ZEROS, NA, 1>(tx, wx, row1, xa[1]);
@@ -278,7 +290,7 @@ __global__ __launch_bounds__(kThreads) void walk_backward16(const StepParams p) 
             else plane_blend(par0{}, Ba);
         }
     }
-    __syncthreads();   // the "+0" planes have been read
+    walk_barrier();   // the "+0" planes have been read
 
     auto flush = [&]() {   // fp32 sums of this wave -> its fp64 slots (fixed DPP tree, lane 63)
         const float v[8] = {sa[0][0], sa[1][0], sa[0][1], sa[1][1], sb[0][0], sb[1][0], sb[0][1], sb[1][1]};   // [kind][hb][pl]
@@ -297,7 +309,7 @@ __global__ __launch_bounds__(kThreads) void walk_backward16(const StepParams p) 
     // x1 / B1: the "+1" planes (out: the next step's "+0")
     auto walk_step = [&](int a, Staged &pend, const uint32_t (&x0)[2][5], uint32_t (&x1)[2][5], const float (&B0)[E], float (&B1)[E]) {
         park(pend);
-        __syncthreads();
+        walk_barrier();
         const bool more = a + 2 < a1;
         load_planes(more ? row_map(a + 3, d.cx0, S0, pad) : -1, more ? row_map(a + 2 + GA, d.cg0, S0, pad) : -1, pend);
         if (px) wgrad(par1{}, gcur, x0, x1, sa, sb);
@@ -327,7 +339,7 @@ __global__ __launch_bounds__(kThreads) void walk_backward16(const StepParams p) 
         }
         __builtin_amdgcn_raw_buffer_store_b128(res, ores, my, static_cast<uint32_t>(a) * plane_bytes, kWalkStoreAux);
         if (((a - a0) & (kWalkFlush - 1)) == kWalkFlush - 1) flush();
-        __syncthreads();   // everybody has read this step's planes
+        walk_barrier();   // everybody has read this step's planes
     };
     int a = a0;
     for (; a + 1 < a1; a += 2) {   // whole pairs: no condition between the steps (exact wait counts)
@@ -336,7 +348,7 @@ __global__ __launch_bounds__(kThreads) void walk_backward16(const StepParams p) 
     }
     if (a < a1) walk_step(a, stA, xa, xb, Ba, Bb);
     if (((a1 - a0) & (kWalkFlush - 1)) != 0) flush();
-    __syncthreads();
+    walk_barrier();
     // ---- the workgroup's record: per-corner sums -> the corner-difference sums (corner_diffs is linear) ------------------------
     if (tid < 8) {
         double s[8];   // [kind][hb][pl]
@@ -459,16 +471,16 @@ __global__ __launch_bounds__(kThreads) void walk_forward16(const FwdParams p) {
         const u4_t v0 = load_plane(row_map(0, cs0, S0, pad));
         stA = load_plane(row_map(1, cs0, S0, pad));
         stB = load_plane(1 < S0 ? row_map(2, cs0, S0, pad) : -1);
-        __syncthreads();   // the tile is zero
+        walk_barrier();   // the tile is zero
         park(v0);
-        __syncthreads();
+        walk_barrier();
         if (px) plane_blend(par1{}, Ba);
         else plane_blend(par0{}, Ba);
     }
-    __syncthreads();
+    walk_barrier();
     auto walk_step = [&](int a, u4_t &pend, const float (&B0)[E], float (&B1)[E]) {
         park(pend);
-        __syncthreads();
+        walk_barrier();
         pend = load_plane(a + 2 < S0 ? row_map(a + 3, cs0, S0, pad) : -1);
         if (px) plane_blend(par1{}, B1);
         else plane_blend(par0{}, B1);
@@ -478,7 +490,7 @@ __global__ __launch_bounds__(kThreads) void walk_forward16(const FwdParams p) {
         u4_t res;
         __builtin_memcpy(&res, ch.e, 16);
         __builtin_amdgcn_raw_buffer_store_b128(res, ores, my, static_cast<uint32_t>(a) * plane_bytes, kWalkStoreAux);
-        __syncthreads();
+        walk_barrier();
     };
     int a = 0;
     for (; a + 1 < S0; a += 2) {

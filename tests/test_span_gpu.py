@@ -100,3 +100,73 @@ def test_1d_backward_vs_oracle(abi, shape, crop, dt):
             _, gw64 = O.backward(go.astype(np.float64), w.astype(np.float64), x.astype(np.float64), pad, active, b)
             tol = {"f32": 1e-5, "f64": 1e-12}.get(dt, gw16_tol(torch.finfo(tdt).eps))
             assert rel_err(gw.to(torch.float64).cpu().numpy(), gw64) < tol, ("gw", shape, crop, dt, pad, active)
+
+
+CASES_FWD_2D = CASES_2D + [((2, 3, 62, 62), None), ((2, 2, 62, 62), [[1, 1], [1, 1]]), ((1, 2, 113, 113), [[0, 1], [0, 1]]), ((2, 2, 30, 20), None),
+                           ((1, 2, 9, 4100), [[1, 0], [2, 2]])]
+
+
+@pytest.mark.parametrize("dt", ["f32", "f64", "f16", "bf16"])
+@pytest.mark.parametrize("shape,crop", CASES_FWD_2D)
+def test_cropped_forward_vs_oracle(abi, shape, crop, dt):
+    """span_forward: cropped windows (ragged output rows) and ragged source rows (62 x 62, 113 x 113 inputs); chunks that straddle
+    two output rows, steps that straddle many; every padding, both shifts"""
+    tdt = {"f32": torch.float32, "f64": torch.float64, "f16": torch.float16, "bf16": torch.bfloat16}[dt]
+    es = torch.empty(0, dtype=tdt).element_size()
+    b, new = abi.check_borders(list(shape), crop, 2)
+    xtotal = 1
+    for v in shape:
+        xtotal *= v
+    if (new[-1] * new[-2] * es) % 16 or (xtotal * es) % 16:
+        pytest.skip("output planes / the input are not whole numbers of 16-byte pieces")
+    rs = np.random.RandomState(sum(shape) * 17 + 3)
+    xt = torch.from_numpy(rs.uniform(-1, 1, size=shape)).to(tdt)
+    wt = torch.from_numpy(_weights(rs, shape[1], 2, shape[2:])).to(tdt)
+    wide = np.float64 if tdt == torch.float64 else np.float32
+    x, w = (t.to(torch.float64).numpy().astype(wide) for t in (xt, wt))
+    xd, wd = xt.to(DEV), wt.to(DEV)
+    abi.set_tuning(34, 2)   # whenever eligible (the automatic choice leaves aligned, uncropped planes to the step kernels)
+    abi.set_tuning(33, 1)
+    for pad in range(5):
+        for active in (0, 1):
+            out = abi.forward(xd, wd, pad, active, b)
+            if abi.last_kernel().startswith("step_"):
+                continue   # (output rows of whole pieces: the aligned one-step forwards keep them)
+            assert abi.last_kernel() == ("span_active_forward" if active else "span_gather_forward"), (shape, crop, abi.last_kernel())
+            ref = torch.from_numpy(O.forward(x, w, pad, active, b)).to(tdt)
+            if es >= 4 or not active:
+                assert torch.equal(out.cpu(), ref), (shape, crop, dt, pad, active)
+            else:
+                assert _ulp_close(out.cpu(), ref, tdt), (shape, crop, dt, pad, active)
+
+
+@pytest.mark.parametrize("dt", ["f32", "f64", "f16", "bf16"])
+@pytest.mark.parametrize("shape,crop", CASES_1D)
+def test_1d_forward_vs_oracle(abi, shape, crop, dt):
+    tdt = {"f32": torch.float32, "f64": torch.float64, "f16": torch.float16, "bf16": torch.bfloat16}[dt]
+    es = torch.empty(0, dtype=tdt).element_size()
+    b, new = abi.check_borders(list(shape), crop, 1)
+    xtotal = 1
+    for v in shape:
+        xtotal *= v
+    if (new[-1] * es) % 16 or (xtotal * es) % 16 or new[-1] * es // 16 < 64:
+        pytest.skip("output rows are not whole 16-byte pieces / shorter than a wave of chunks")
+    rs = np.random.RandomState(sum(shape) * 19 + 7)
+    xt = torch.from_numpy(rs.uniform(-1, 1, size=shape)).to(tdt)
+    wt = torch.from_numpy(_weights(rs, shape[1], 1, shape[2:])).to(tdt)
+    wide = np.float64 if tdt == torch.float64 else np.float32
+    x, w = (t.to(torch.float64).numpy().astype(wide) for t in (xt, wt))
+    xd, wd = xt.to(DEV), wt.to(DEV)
+    abi.set_tuning(34, 2)   # whenever eligible (the automatic choice keeps 1-D forwards on the per-channel kernels)
+    abi.set_tuning(33, 1)
+    for pad in range(5):
+        for active in (0, 1):
+            out = abi.forward(xd, wd, pad, active, b)
+            if abi.last_kernel().startswith("step_"):
+                continue
+            assert abi.last_kernel() == ("span_active_forward" if active else "span_gather_forward"), (shape, crop, abi.last_kernel())
+            ref = torch.from_numpy(O.forward(x, w, pad, active, b)).to(tdt)
+            if es >= 4 or not active:
+                assert torch.equal(out.cpu(), ref), (shape, crop, dt, pad, active)
+            else:
+                assert _ulp_close(out.cpu(), ref, tdt), (shape, crop, dt, pad, active)

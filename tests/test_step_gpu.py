@@ -16,6 +16,13 @@ from test_hip_parity import _ulp_close, _weights
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
 
+# 16-bit 3-D interpolation (the walk kernels): 1 ulp of the 16-bit type at the result, plus 8 fp32 ulps of the OPERANDS' scale
+# (|x|, |grad| <= 1 in these tests) for results that cancel to almost nothing.  Seven nested blends, evaluated here inner-first
+# with mul + fma and by the oracle plane-first with mul, mul, add (the reference's nesting): each blend rounds once at the
+# magnitude of its operands, so the two fp32 evaluations differ by a few 2^-24 of the operand scale whatever the result is --
+# more than one 16-bit ulp of a result below 2^-16 of that scale.  Among millions of outputs a few are that small.
+FLOOR16 = 8 * 2.0 ** -24
+
 
 @pytest.fixture()
 def abi():
@@ -350,7 +357,7 @@ def test_3d_forwards_through_lds_vs_oracle(abi, shape, crop, dt):
 
 @pytest.mark.parametrize("dt", ["f32", "f64", "f16", "bf16"])
 @pytest.mark.parametrize("shape", [(2, 3, 5, 6, 16), (1, 2, 20, 9, 64), (2, 2, 3, 40, 112), (1, 2, 2, 1, 32), (1, 1, 3, 37, 512),
-                                   (1, 2, 16, 112, 112), (2, 2, 7, 300, 8), (1, 3, 4, 33, 2048 // 8)])
+                                   (1, 2, 16, 112, 112), (2, 2, 7, 300, 8), (1, 3, 4, 33, 2048 // 8), (2, 160, 5, 48, 112)])
 def test_3d_walk_forward_vs_oracle(abi, shape, dt):
     """walk_forward (csrc/shiftnd_step.hip): the 3-D interpolating forward as a walk through the planes -- one plane staged
     per step, the other plane's corner rows carried in registers; blends nested as the reference nests them (fp32 / fp64
@@ -375,12 +382,13 @@ def test_3d_walk_forward_vs_oracle(abi, shape, dt):
         if es >= 4:
             assert torch.equal(out.cpu(), ref), (shape, dt, pad)
         else:
-            assert _ulp_close(out.cpu(), ref, tdt), (shape, dt, pad)
+            assert _ulp_close(out.cpu(), ref, tdt, FLOOR16), (shape, dt, pad)
 
 
 @pytest.mark.parametrize("dt", ["f32", "f64", "f16", "bf16"])
 @pytest.mark.parametrize("shape", [(2, 3, 5, 6, 16), (1, 2, 20, 9, 64), (2, 2, 3, 40, 112), (1, 2, 2, 1, 32), (1, 1, 3, 37, 512),
-                                   (1, 2, 16, 112, 112), (2, 2, 7, 300, 8), (1, 3, 9, 33, 256)])
+                                   (1, 2, 16, 112, 112), (2, 2, 7, 300, 8), (1, 3, 9, 33, 256),
+                                   (2, 160, 5, 48, 112)])   # 960 workgroups: several per CU (the race of walk_barrier, shiftnd_walk.hip)
 def test_3d_walk_backward_vs_oracle(abi, shape, dt):
     """walk_backward (csrc/shiftnd_step.hip): the 3-D interpolating backward as a walk through the planes -- one plane of the
     saved input and one of the gradient staged per step, the other corner planes carried in registers, the weight-gradient
@@ -407,7 +415,7 @@ def test_3d_walk_backward_vs_oracle(abi, shape, dt):
             if es >= 4 or not active:
                 assert torch.equal(gx.cpu(), gx_ref), ("gx", shape, dt, pad, active)
             else:
-                assert _ulp_close(gx.cpu(), gx_ref, tdt), ("gx", shape, dt, pad)
+                assert _ulp_close(gx.cpu(), gx_ref, tdt, FLOOR16), ("gx", shape, dt, pad)
             _, gw64 = O.backward(go.astype(np.float64), w.astype(np.float64), x.astype(np.float64), pad, active)
             tol = {"f32": 1e-5, "f64": 1e-12}.get(dt, gw16_tol(torch.finfo(tdt).eps))
             assert rel_err(gw.to(torch.float64).cpu().numpy(), gw64) < tol, ("gw", shape, dt, pad, active)

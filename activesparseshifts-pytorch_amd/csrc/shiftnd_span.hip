@@ -510,11 +510,11 @@ __global__ __launch_bounds__(kThreads) void span_forward(const SpanFwdParams p) 
                 res.e[e] = narrow<T>(interp_t<T, ND>(v, dw));
             }
         }
-    } else {   // the chunk straddles two output rows: element by element
+    } else {   // the chunk straddles output rows (two, or E of them when a row is one element): element by element
 #pragma unroll
         for (int e = 0; e < E; ++e) {
-            const bool next = j + e >= O2;
-            const int slot = r - r0 + (next ? 1 : 0), je = next ? j + e - O2 : j + e;
+            const int re = static_cast<int>(fdiv(static_cast<uint32_t>(e0 + e), p.d_O2));
+            const int slot = re - r0, je = e0 + e - re * O2;
             const int m0 = row_map_t<PAD>(je + L2, cs2, S2);
             if constexpr (ACTIVE) {
                 const int m1 = row_map_t<PAD>(je + L2 + 1, cs2, S2);
@@ -633,10 +633,11 @@ bool span_forward_eligible(const Geometry &g, int dtype, const void *x, const vo
     if (g_step_tune[2] >= 2) return true;
     bool crop = false;
     for (int d = 1; d < 3; ++d) crop = crop || g.O[d] != g.S[d] || g.L[d] != 0;
-    const bool ragged = (g.S[2] * es) % 16 != 0;
-    // cropped or ragged 2-D planes (the aligned, uncropped ones: the step kernels).  1-D rows on request only (knob 34 >= 2): same
-    // box, N256 C512 L4096: fp32 sparse 0.90 vs 0.92 ms of the per-channel kernels, interpolating 0.88 vs 0.83, fp16 0.57 vs 0.42
-    return g.nd == 2 && (crop || ragged);
+    // cropped 2-D windows (the aligned ones whose output rows are whole pieces too: the step kernels, asked first).  On request
+    // only (knob 34 >= 2): uncropped planes with ragged rows -- same box, N128 C1024 14x14 fp32 0.20 vs 0.052 ms of the small-plane
+    // kernels, N64 C256 62x62 0.125 vs 0.101 -- and 1-D rows: N256 C512 L4096 fp32 sparse 0.90 vs 0.92 ms of the per-channel
+    // kernels, interpolating 0.88 vs 0.83, fp16 0.57 vs 0.42
+    return g.nd == 2 && crop;
 }
 
 template <typename T, int ND>

@@ -1553,14 +1553,16 @@ int step_row_groups(const Geometry &g, int es) {
     return es == 2 ? 2 : 1;
 }
 
-StepLayout step_layout(const Geometry &g, int es) {
+// force_u: row groups per thread (0: by dtype and knob 35).  The WORKSPACE is planned with one (the most steps), so that its size
+// does not depend on the thread-local knobs of whoever asks; a run lays its regions out with its own U inside that.
+StepLayout step_layout(const Geometry &g, int es, int force_u = 0) {
     StepLayout L{};
     const int E = 16 / es;
     L.cpr = static_cast<int>(g.S[2] * es / 16);
     if (L.cpr < 1) L.cpr = 1;
     L.R = kThreads / L.cpr < 1 ? 1 : kThreads / L.cpr;
     if (L.R > g.S[1]) L.R = static_cast<int>(g.S[1] > 0 ? g.S[1] : 1);
-    L.U = step_row_groups(g, es);
+    L.U = force_u > 0 ? force_u : step_row_groups(g, es);
     if (L.U * L.R > g.S[1] && L.R >= g.S[1]) L.U = 1;  // (one row group already covers the plane)
     L.spp = static_cast<int>((g.S[1] + L.U * L.R - 1) / (L.U * L.R));
     L.spv = static_cast<int>(g.S[0]) * L.spp;
@@ -2089,9 +2091,22 @@ template <typename T> static void launch_walk_backward(StepParams &p, size_t lds
     hipLaunchKernelGGL((step_reduce<T, 3>), dim3(p.C), block, 0, st, p, static_cast<S *>(gw));
 }
 
+// the pointer-free part of step_backward_core / walk_backward_core: which geometries these kernels can serve at all
+static bool step_shape_ok(const Geometry &g, int dtype) {
+    if (dtype > SHIFTND_BF16 || (g.nd != 2 && g.nd != 3)) return false;
+    const int es = dtype_size(dtype);
+    for (int d = 0; d < 3; ++d)
+        if (g.O[d] != g.S[d] || g.L[d] != 0) return false;
+    if ((g.nd == 2 && g.S[0] != 1) || g.S[0] < 1 || g.S[1] < 1 || g.S[2] < 1) return false;
+    if ((g.S[2] * es) % 16 != 0 || g.S[2] * es / 16 > kThreads || g.S[2] > 32000) return false;
+    return g.S[0] * g.S[1] * g.S[2] < (1LL << 30);
+}
+
+// what step_backward needs of the workspace: nothing for the geometries it never serves (crops, rows that are not whole pieces,
+// rows wider than a workgroup pass: those plans used to inflate every backward workspace), and independent of the knobs
 size_t step_backward_workspace(const Geometry &g, int dtype) {
-    if (dtype > SHIFTND_BF16 || (g.nd != 2 && g.nd != 3)) return 0;
-    return step_layout(g, dtype_size(dtype)).bytes;
+    if (!step_shape_ok(g, dtype)) return 0;
+    return step_layout(g, dtype_size(dtype), 1).bytes;
 }
 
 int step_backward(const Geometry &g, int dtype, const void *go, const void *x, const void *w, void *gx, void *gw,
@@ -2154,8 +2169,14 @@ int step_backward(const Geometry &g, int dtype, const void *go, const void *x, c
         p.walk_planes = (g_step_tune[4] > 0 && g_step_tune[4] < p.S0) ? g_step_tune[4] : p.S0;
         const int dparts = (p.S0 + p.walk_planes - 1) / p.walk_planes;
         p.spv = dparts * p.spp;
-        const uint64_t total = static_cast<uint64_t>(g.N) * g.C * p.spv;
-        if (total > L.total_steps) return SHIFTND_ERR_WORKSPACE_TOO_SMALL;   // (cannot happen: dparts <= S0, spp <= the one-step plan's)
+        uint64_t total = static_cast<uint64_t>(g.N) * g.C * p.spv;
+        if (total > step_layout(g, es, 1).total_steps) {
+            // more records than the workspace was planned for (knob 38 with few rows per step: a walk step holds one row fewer
+            // than a one-step workgroup): walk the whole depth -- one part, at most twice the one-step plan's row steps <= S0 of them
+            p.walk_planes = p.S0;
+            p.spv = p.spp;
+            total = static_cast<uint64_t>(g.N) * g.C * p.spv;
+        }
         p.total_steps = static_cast<uint32_t>(total);
         p.steps_per_xcd = static_cast<uint32_t>((total + 7) / 8);
         p.d_spp = make_fastdiv(static_cast<uint32_t>(p.spp));

@@ -205,7 +205,10 @@ template <typename CT> __device__ __forceinline__ void load_weights2(const void 
         wr = static_cast<CT>(q[0]);
         wc = static_cast<CT>(q[1]);
     } else if (wkind == SHIFTND_F16 || wkind == SHIFTND_BF16) {
-        const uint32_t word = (reinterpret_cast<const __attribute__((address_space(4))) uint32_t *>(base))[c];
+        // two halfwords at byte offset 4 c of a base that is 2-byte aligned at least: the two aligned dwords that hold them
+        const uintptr_t at = base + static_cast<uintptr_t>(c) * 4;
+        const __attribute__((address_space(4))) uint32_t *q = reinterpret_cast<const __attribute__((address_space(4))) uint32_t *>(at & ~static_cast<uintptr_t>(3));
+        const uint32_t word = (at & 2) ? ((q[0] >> 16) | (q[1] << 16)) : q[0];
         const uint16_t lo = static_cast<uint16_t>(word), hi = static_cast<uint16_t>(word >> 16);
         if (wkind == SHIFTND_F16) {
             wr = static_cast<CT>(__builtin_bit_cast(_Float16, lo));

@@ -582,7 +582,11 @@ template <int ND> Tensor qpool_composite(const Tensor &y, at::IntArrayRef pool) 
         k.insert(k.begin(), 1);
     }
     std::vector<int64_t> zeros(k.size(), 0);
-    Tensor ones = at::ones_like(xf.narrow(0, 0, 1).narrow(1, 0, 1));
+    // the window counts: ones of the SPATIAL shape (an empty batch or zero channels must not be indexed -- the reference's
+    // sequence returns an empty tensor for them)
+    std::vector<int64_t> one_shape(xf.sizes().begin(), xf.sizes().end());
+    one_shape[0] = one_shape[1] = 1;
+    Tensor ones = at::ones(one_shape, xf.options());
     Tensor sums = ND == 3 ? at::avg_pool3d(xf, k, k, zeros, true, true, 1) : at::avg_pool2d(xf, k, k, zeros, true, true, 1);
     Tensor cnt = ND == 3 ? at::avg_pool3d(ones, k, k, zeros, true, true, 1) : at::avg_pool2d(ones, k, k, zeros, true, true, 1);
     const bool outside = qpool_zp_outside<ND>(y.sizes(), ND == 2 && y.is_contiguous(at::MemoryFormat::ChannelsLast));

@@ -370,6 +370,32 @@ def main(argv=None):
         dt = float(t.item())
     ms_per_step = dt / a.steps * 1e3
 
+    # ---- what every rank ran on (N > 1: all-gathered; the first 8-GPU run describes itself) ------------------------------
+    def rank_info():
+        info = {"rank": rank, "local_rank": local_rank, "host": os.uname().nodename, "pid": os.getpid(),
+                "device_index": dev.index if on_gpu else None, "world_size": world, "backend": backend if use_pg else None}
+        if on_gpu:
+            pr = torch.cuda.get_device_properties(dev)
+            info["device_name"] = pr.name
+            info["uuid"] = str(getattr(pr, "uuid", "")) or None
+            info["pci_bus_id"] = "%04x:%02x:%02x" % (getattr(pr, "pci_domain_id", 0), getattr(pr, "pci_bus_id", 0), getattr(pr, "pci_device_id", 0))
+            info["hbm_bytes"] = pr.total_memory
+        if use_pg:
+            info["pg_world_size"] = dist.get_world_size()
+            info["pg_backend"] = dist.get_backend()
+        return info
+
+    per_rank = [rank_info()]
+    if use_pg:
+        every_info = [None] * world
+        dist.all_gather_object(every_info, per_rank[0])
+        per_rank = every_info
+        if on_gpu and not oversubscribed:
+            # one GPU per rank: distinct devices, or the line is not a scaling point -- fail loudly
+            seen = set((r["host"], r.get("uuid") or r.get("pci_bus_id") or r["device_index"]) for r in per_rank)
+            if len(seen) != world:
+                raise SystemExit("bench.py: %d ranks ran on %d distinct GPU(s): %s" % (world, len(seen), per_rank))
+
     # ---- per-step spread (median / min over single steps; outside the contract's timed region) -----------
     singles = []
     for _ in range(min(a.steps, 50)):
@@ -453,7 +479,8 @@ def main(argv=None):
                                 % (nd, path)) if on_gpu else "torch.ops.torchshifts (CPU dispatch key of _C.so)",
                        "ranks": {"world": world, "backend": backend if use_pg else None, "devices": ndev,
                                  "oversubscribed": oversubscribed,
-                                 "device_name": torch.cuda.get_device_name(dev) if on_gpu else None}},
+                                 "device_name": torch.cuda.get_device_name(dev) if on_gpu else None,
+                                 "per_rank": per_rank}},
             "per_rank_ms": per_rank_ms,
             "achieved_hbm_GBps_step": step_bytes / (ms_per_step * 1e-3) / 1e9,
             "kernels": kernels,

@@ -32,8 +32,12 @@ def test_self_launch_world2_cpu():
     lines = _json_lines(r.stdout)
     assert len(lines) == 1, "exactly one JSON line (rank 0)"
     j = lines[0]
-    assert j["n_gpus"] == 2 and j["config"]["ranks"] == {"world": 2, "backend": "gloo", "devices": 0,
-                                                          "oversubscribed": False, "device_name": None}
+    ranks = dict(j["config"]["ranks"])
+    per_rank = ranks.pop("per_rank")
+    assert j["n_gpus"] == 2 and ranks == {"world": 2, "backend": "gloo", "devices": 0, "oversubscribed": False, "device_name": None}
+    # every rank describes itself (all-gathered): rank ids, process-group size and backend as the process group reports them
+    assert [r["rank"] for r in per_rank] == [0, 1] and len(set(r["pid"] for r in per_rank)) == 2
+    assert all(r["pg_world_size"] == 2 and r["pg_backend"] == "gloo" and r["device_index"] is None for r in per_rank)
     assert len(j["per_rank_ms"]) == 2 and abs(max(j["per_rank_ms"]) - j["ms_per_step"]) < 1e-9
     assert j["scaling"] == "weak" and j["steps"] == 2 and j["warmup"] == 1
     assert "cpu_baseline" not in j and j["roofline"] is None
@@ -112,3 +116,7 @@ def test_rccl_calls_of_the_rank_code_on_one_gpu():
     j = _json_lines(r.stdout)
     assert len(j) == 1 and j[0]["n_gpus"] == 1 and j[0]["config"]["ranks"]["backend"] == "nccl"
     assert len(j[0]["per_rank_ms"]) == 1 and abs(j[0]["per_rank_ms"][0] - j[0]["ms_per_step"]) < 1e-9
+    # the rank describes the device RCCL bound it to (what the first 8-GPU run will be read by)
+    pr = j[0]["config"]["ranks"]["per_rank"]
+    assert len(pr) == 1 and pr[0]["device_index"] == 0 and pr[0]["pg_backend"] == "nccl" and pr[0]["pg_world_size"] == 1
+    assert pr[0]["device_name"] and pr[0]["pci_bus_id"] and pr[0]["hbm_bytes"] > 2 ** 37

@@ -102,7 +102,7 @@ def test_1d_backward_vs_oracle(abi, shape, crop, dt):
             assert rel_err(gw.to(torch.float64).cpu().numpy(), gw64) < tol, ("gw", shape, crop, dt, pad, active)
 
 
-CASES_FWD_2D = CASES_2D + [((2, 3, 62, 62), None), ((2, 2, 62, 62), [[1, 1], [1, 1]]), ((1, 2, 113, 113), [[0, 1], [0, 1]]), ((2, 2, 30, 20), None),
+CASES_FWD_2D = CASES_2D + [((2, 3, 62, 62), None), ((2, 2, 62, 62), [[1, 1], [1, 1]]), ((1, 2, 113, 113), [[0, 1], [0, 1]]), ((2, 2, 30, 20), None), ((2, 5, 8, 1), None), ((2, 3, 16, 2), None), ((1, 4, 12, 3), None), ((2, 2, 40, 8), [[1, 1], [3, 4]]),
                            ((1, 2, 9, 4100), [[1, 0], [2, 2]])]
 
 

@@ -13,11 +13,11 @@
 
 namespace shiftnd {
 
-// knobs (shiftnd_set_tuning 32..): [0] backward, [1] gather forward (direct loads), [2] forwards through LDS: 0 = automatic, 1 = never, 2 = whenever eligible; [3] bit 0: 3-D backward in the one-step form, bit 1 / bit 2: one / two row groups per thread always, bit 3: 3-D forwards through LDS too, bit 4: no walk kernels, bit 5: walk kernels for every float dtype, bit 6: the round-3 walk kernels for 16-bit data too
+// knobs (shiftnd_set_tuning 32..): [0] backward, [1] gather forward (direct loads), [2] forwards through LDS: 0 = automatic, 1 = never, 2 = whenever eligible; [3] bit 1 / bit 2: one / two row groups per thread always, bit 3: 3-D forwards through LDS too, bit 4: no walk kernels, bit 5: round 3's walk kernels for fp64 too
 extern thread_local int g_step_tune[5];   // [4]: planes per workgroup of the walk kernels (0 = all); defined in shiftnd_step.hip
 
-namespace {
-
+// (the launch parameters are named types of the library: they cross translation units -- step_backward() hands its
+//  StepParams to shiftnd_walk3.hip; the kernels and helpers below are private copies per translation unit)
 struct ChanDesc {  // per channel, written by step_prep
     int cx0, cg0;  // plane maps (3-D; 0 for 2-D):  m0[p] = fold_index(p - cx0, S0, pad), g0[p] likewise with cg0
     int cx1, cg1;  // row maps:                     m1[p] = fold_index(p - cx1, S1, pad), g1[p] likewise with cg1
@@ -52,6 +52,11 @@ struct StepParams {
     FastDiv d_k0;
     int walk_planes;    // walk_backward: planes a workgroup walks through (S0, or a part of the volume's depth)
 };
+
+// the second half of step_backward()'s launch for 3-D problems (shiftnd_walk3.hip)
+int walk3_backward_launch(StepParams &p, const Geometry &g, int dtype, int cpr, void *gw, hipStream_t st);
+
+namespace {
 
 template <int E> struct RecSize { static constexpr int N = (E + 3 <= 8) ? 8 : 16; };  // int16 entries per record
 
@@ -403,6 +408,55 @@ bool dense(const int64_t st[5], int64_t N, int64_t C, const int64_t sz[3]) {
         expect *= sizes[d];
     }
     return true;
+}
+
+// ---- the launch plan of step_backward and of the round-3 walk kernels (host) ---------------------------------------------
+struct StepLayout {
+    int cpr, R, U, spp, spv, rec, ndiff;
+    uint64_t total_steps;
+    size_t off_desc, off_colx, off_colg, bytes;
+};
+
+// row groups per thread (knob 35 bit 1 = 2: always one, bit 2 = 4: always two): two for 16-bit data, where the kernel is
+// bound by instruction issue (same box, one vs two: fp16 C512 224x224 reflect 1.80 -> 1.67 ms, interpolating 1.91 -> 1.79,
+// bf16 N128 C256 56x56 0.126 -> 0.109; zeros padding 1.61 vs 1.62); one for 4- / 8-byte elements (fp32 sparse 1.58 vs 1.62,
+// interpolating 1.63 vs 1.67 ms: the tighter sweep front wins), 3-D and pooled calls
+int step_row_groups(const Geometry &g, int es) {
+    if (g.nd != 2 || g.K[0] > 0) return 1;
+    if (g_step_tune[3] & 2) return 1;
+    if (g_step_tune[3] & 4) return 2;
+    return es == 2 ? 2 : 1;
+}
+
+// force_u: row groups per thread (0: by dtype and knob 35).  The WORKSPACE is planned with one (the most steps), so that its size
+// does not depend on the thread-local knobs of whoever asks; a run lays its regions out with its own U inside that.
+StepLayout step_layout(const Geometry &g, int es, int force_u = 0) {
+    StepLayout L{};
+    const int E = 16 / es;
+    L.cpr = static_cast<int>(g.S[2] * es / 16);
+    if (L.cpr < 1) L.cpr = 1;
+    L.R = kThreads / L.cpr < 1 ? 1 : kThreads / L.cpr;
+    if (L.R > g.S[1]) L.R = static_cast<int>(g.S[1] > 0 ? g.S[1] : 1);
+    L.U = force_u > 0 ? force_u : step_row_groups(g, es);
+    if (L.U * L.R > g.S[1] && L.R >= g.S[1]) L.U = 1;  // (one row group already covers the plane)
+    L.spp = static_cast<int>((g.S[1] + L.U * L.R - 1) / (L.U * L.R));
+    L.spv = static_cast<int>(g.S[0]) * L.spp;
+    L.rec = (E + 3 <= 8) ? 8 : 16;
+    L.ndiff = g.nd == 3 ? 8 : 2;
+    L.total_steps = static_cast<uint64_t>(g.N) * g.C * L.spv;
+    auto up = [](size_t v) { return (v + 255) & ~static_cast<size_t>(255); };
+    L.off_desc = up(L.total_steps * L.ndiff * sizeof(double));
+    L.off_colx = L.off_desc + up(static_cast<size_t>(g.C) * sizeof(ChanDesc));
+    L.off_colg = L.off_colx + up(static_cast<size_t>(g.C) * L.cpr * L.rec * sizeof(int16_t));
+    L.bytes = L.off_colg + up(static_cast<size_t>(g.C) * L.cpr * L.rec * sizeof(int16_t));
+    return L;
+}
+
+size_t step_lds_bytes(const StepLayout &L, int nd, bool active) {
+    const int np = nd == 3 ? 2 : 1;
+    const int RT = L.U * L.R;
+    const int slots = np * (RT + 1) + RT + (active ? np * (RT + 1) : (nd == 3 ? RT : 0));
+    return 64 + ((static_cast<size_t>(slots) * L.cpr * 16 + 63) & ~static_cast<size_t>(63)) + (kThreads / 64) * L.ndiff * sizeof(double);
 }
 
 }  // namespace

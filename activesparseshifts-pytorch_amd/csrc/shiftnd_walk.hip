@@ -537,7 +537,7 @@ bool walk16_geometry_ok(const Geometry &g, int dtype) {
 // the 3-D interpolating forward of fp16 / bf16 tensors: contiguous, no crop, rows of whole 16-byte pieces, float weights of the
 // tensor's dtype
 bool walk16_forward_eligible(const Geometry &g, int dtype, const void *x, const void *out) {
-    if (g_step_tune[2] == 1 || (g_step_tune[3] & (16 | 64))) return false;   // knob 34 = 1: no forwards through LDS; knob 35 bit 4 / 6
+    if (g_step_tune[2] == 1 || (g_step_tune[3] & 16)) return false;   // knob 34 = 1: no forwards through LDS; knob 35 bit 4: no walk kernels
     if (!g.active || !walk16_geometry_ok(g, dtype)) return false;
     if (!dense(g.xs, g.N, g.C, g.S) || !dense(g.os, g.N, g.C, g.O)) return false;
     return reinterpret_cast<uintptr_t>(x) % 16 == 0 && reinterpret_cast<uintptr_t>(out) % 16 == 0;
@@ -583,7 +583,7 @@ int walk16_forward(const Geometry &g, int dtype, const void *x, const void *w, i
 
 // the 3-D backward of fp16 / bf16 tensors (both shifts, every padding): contiguous, no crop, rows of whole 16-byte pieces
 bool walk16_backward_eligible(const Geometry &g, int dtype, const void *go, const void *x, const void *gx) {
-    if (g_step_tune[0] == 1 || (g_step_tune[3] & (16 | 64 | 1))) return false;   // knob 35 bit 4: no walk; bit 6: round 3's; bit 0: one-step
+    if (g_step_tune[0] == 1 || (g_step_tune[3] & 16)) return false;   // knob 32 = 1: never; knob 35 bit 4: no walk kernels
     if (!walk16_geometry_ok(g, dtype)) return false;
     if (!dense(g.xs, g.N, g.C, g.S) || !dense(g.os, g.N, g.C, g.O) || !dense(g.gs, g.N, g.C, g.S)) return false;
     return reinterpret_cast<uintptr_t>(go) % 16 == 0 && reinterpret_cast<uintptr_t>(x) % 16 == 0 && reinterpret_cast<uintptr_t>(gx) % 16 == 0;

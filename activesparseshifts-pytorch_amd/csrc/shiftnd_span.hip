@@ -43,6 +43,7 @@ struct SpanParams {
     int cpr, seg, nseg;  // 16-byte chunks per x row, chunks per column segment (<= 256), segments per row
     int R, rsteps, spp;  // rows per step, row steps per plane, steps per plane = rsteps * nseg
     int P;               // pieces per slot
+    int U;               // chunks per thread (1; up to 4 for 1-D rows longer than 256 chunks: seg = 256 U chunks, one row per step)
     uint32_t total_steps, steps_per_xcd;
     FastDiv d_spp, d_C, d_seg, d_nseg, d_P, d_per1x, d_per2x, d_per1g, d_per2g;
 };
@@ -206,61 +207,33 @@ __global__ __launch_bounds__(kThreads) void span_backward(const SpanParams p) {
     // ---- stage: piece q of the tile = piece (q mod P) of slot (q div P); a wave's pieces are consecutive, the LDS destination
     // is a wave-uniform base (the hardware adds lane * 16)
     const int npieces = (NX + NG + NGS) * P;
-#pragma unroll
-    for (int k = 0; k < kSpanRounds; ++k) {
-        if (k * kThreads < npieces) {   // uniform
-            const int q = k * kThreads + tid;
-            const int slot = static_cast<int>(fdiv(static_cast<uint32_t>(q), p.d_P));
-            const int piece = q - slot * P;
-            const Src s = slot_src(slot);
-            const int p0 = s.lo >> 4, cnt = ((s.hi + 15) >> 4) - p0;
-            if (q < npieces && s.valid && piece < cnt) {   // (cnt <= 0: no column of this row is staged)
-                char *dst_wave = tile + (k * kThreads + wave * 64) * 16;
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(s.base + static_cast<int64_t>(p0 + piece) * 16),
-                                                 (__attribute__((address_space(3))) void *)dst_wave, 16, 0, 0);
-            }
+    auto stage_round = [&](int k) {
+        const int q = k * kThreads + tid;
+        const int slot = static_cast<int>(fdiv(static_cast<uint32_t>(q), p.d_P));
+        const int piece = q - slot * P;
+        const Src s = slot_src(slot);
+        const int p0 = s.lo >> 4, cnt = ((s.hi + 15) >> 4) - p0;
+        if (q < npieces && s.valid && piece < cnt) {   // (cnt <= 0: no column of this row is staged)
+            char *dst_wave = tile + (k * kThreads + wave * 64) * 16;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(s.base + static_cast<int64_t>(p0 + piece) * 16),
+                                             (__attribute__((address_space(3))) void *)dst_wave, 16, 0, 0);
         }
+    };
+    if (p.U == 1) {
+#pragma unroll
+        for (int k = 0; k < kSpanRounds; ++k)
+            if (k * kThreads < npieces) stage_round(k);   // uniform
+    } else {   // long 1-D rows, several chunks per thread: up to 13 rounds
+        for (int k = 0; k * kThreads < npieces; ++k) stage_round(k);
     }
 
-    // ---- the thread's chunk: column state through the x map, the gradient map (window coordinates) and the plain window ----
-    const int tr = static_cast<int>(fdiv(static_cast<uint32_t>(tid), p.d_seg)), tc = tid - tr * p.seg;
-    const int jc = sg * p.seg + tc;   // chunk of the x row
-    const int ji = jc * E;
-    const bool mine = tr < Rn && tc < p.seg && jc < cpr;
-    ColState<E> xm, gm, om;
-    {
-        // entry e = column first + e when that is a column; `safe`: a staged column for a chunk without any (every entry masked)
-        auto affine_state = [&](int first, int len, int safe) {
-            ColState<E> st;
-            st.base = first;
-            if (first + E < 0 || first >= len) st.base = safe;
-            st.affine = true;
-#pragma unroll
-            for (int e = 0; e <= E; ++e) st.cm[e] = (first + e >= 0 && first + e < len) ? first + e : -1;
-            return st;
-        };
-        om = affine_state(ji - L2, O2, oc0);   // grad_out at the chunk's own columns
-        if constexpr (PAD == 0) {
-            xm = affine_state(ji - d.cx2, S2, xc0);
-            gm = affine_state(ji - L2 - d.cg2, O2, sc0);
-            if (O2 == 1) {   // a window one column wide ignores the shift (shifts_kernels.h:40-48): both corners read column 0
-                gm.affine = false;
-#pragma unroll
-                for (int e = 0; e <= E; ++e) gm.cm[e] = (ji - L2 + e >= 0 && ji - L2 + e <= 1) ? 0 : -1;
-            }
-        } else {
-            const size_t rec = (static_cast<size_t>(c) * cpr + (mine ? jc : 0)) * REC;
-            xm = load_colstate<E>(p.colx + rec);
-            gm = load_colstate<E>(p.colg + rec);
-            bool any = false;   // a chunk outside the window has no gradient column at all: keep its reads inside the slot
-#pragma unroll
-            for (int e = 0; e <= E; ++e) any = any || gm.cm[e] >= 0;
-            if (!any) {
-                gm.base = sc0;
-                gm.affine = true;
-            }
-        }
-    }
+    // ---- a thread's chunk: position, column state through the x map, the gradient map (window coordinates) and the plain window.
+    // U chunks per thread (U > 1: one row per step, chunk tid + u * 256 of the segment)
+    struct ChunkState {
+        int tr, jc, ji;
+        bool mine, xs, gs;
+        ColState<E> xm, gm, om;
+    };
     // are all columns of a chunk's window among the staged ones [c0, c1) of its tensor's rows
     auto in_span = [&](const ColState<E> &st, int c0, int c1) {
         bool ok = st.affine;
@@ -268,13 +241,69 @@ __global__ __launch_bounds__(kThreads) void span_backward(const SpanParams p) {
         for (int e = 0; e <= E; ++e) ok = ok && (st.cm[e] < 0 || (st.cm[e] >= c0 && st.cm[e] < c1));
         return ok;
     };
-    const bool xs = whole || in_span(xm, xc0, xc1), gs = whole || in_span(gm, sc0, sc1);
+    auto chunk_state = [&](int u) {
+        ChunkState cs;
+        const int tr = p.U == 1 ? static_cast<int>(fdiv(static_cast<uint32_t>(tid), p.d_seg)) : 0;
+        const int tc = p.U == 1 ? tid - tr * p.seg : tid + u * kThreads;
+        const int jc = sg * p.seg + tc;   // chunk of the x row
+        const int ji = jc * E;
+        const bool mine = tr < Rn && tc < p.seg && jc < cpr;
+        ColState<E> xm, gm, om;
+        {
+            // entry e = column first + e when that is a column; `safe`: a staged column for a chunk without any (every entry masked)
+            auto affine_state = [&](int first, int len, int safe) {
+                ColState<E> st;
+                st.base = first;
+                if (first + E < 0 || first >= len) st.base = safe;
+                st.affine = true;
+#pragma unroll
+                for (int e = 0; e <= E; ++e) st.cm[e] = (first + e >= 0 && first + e < len) ? first + e : -1;
+                return st;
+            };
+            om = affine_state(ji - L2, O2, oc0);   // grad_out at the chunk's own columns
+            if constexpr (PAD == 0) {
+                xm = affine_state(ji - d.cx2, S2, xc0);
+                gm = affine_state(ji - L2 - d.cg2, O2, sc0);
+                if (O2 == 1) {   // a window one column wide ignores the shift (shifts_kernels.h:40-48): both corners read column 0
+                    gm.affine = false;
+#pragma unroll
+                    for (int e = 0; e <= E; ++e) gm.cm[e] = (ji - L2 + e >= 0 && ji - L2 + e <= 1) ? 0 : -1;
+                }
+            } else {
+                const size_t rec = (static_cast<size_t>(c) * cpr + (mine ? jc : 0)) * REC;
+                xm = load_colstate<E>(p.colx + rec);
+                gm = load_colstate<E>(p.colg + rec);
+                bool any = false;   // a chunk outside the window has no gradient column at all: keep its reads inside the slot
+#pragma unroll
+                for (int e = 0; e <= E; ++e) any = any || gm.cm[e] >= 0;
+                if (!any) {
+                    gm.base = sc0;
+                    gm.affine = true;
+                }
+            }
+        }
+        cs.tr = tr;
+        cs.jc = jc;
+        cs.ji = ji;
+        cs.mine = mine;
+        cs.xm = xm;
+        cs.gm = gm;
+        cs.om = om;
+        cs.xs = whole || in_span(xm, xc0, xc1);
+        cs.gs = whole || in_span(gm, sc0, sc1);
+        return cs;
+    };
+    const ChunkState first = chunk_state(0);   // (its table loads -- paddings other than zeros -- travel with the staged rows)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-
     CT part[NDIFF];
 #pragma unroll
     for (int i = 0; i < NDIFF; ++i) part[i] = CT(0);
+    for (int u = 0; u < p.U; ++u) {
+    const ChunkState cs = u == 0 ? first : chunk_state(u);
+    const int tr = cs.tr, ji = cs.ji;
+    const bool mine = cs.mine, xs = cs.xs, gs = cs.gs;
+    const ColState<E> &xm = cs.xm, &gm = cs.gm, &om = cs.om;
     if (mine) {
         const int b = b0 + tr;
         const CT dw[3] = {static_cast<CT>(d.dw[0]), static_cast<CT>(d.dw[1]), CT(0)};
@@ -345,6 +374,7 @@ __global__ __launch_bounds__(kThreads) void span_backward(const SpanParams p) {
         }
         store_chunk<S, E>(gxp + static_cast<int64_t>(b) * S2 + ji, res);
     }
+    }   // u
     // ---- this step's sums: DPP tree per wave, the four waves added in fp64 by one thread ----------------------------------
     double *scratch = reinterpret_cast<double *>(tile + ((npieces * 16 + 63) & ~63) + 64);
 #pragma unroll
@@ -353,6 +383,216 @@ __global__ __launch_bounds__(kThreads) void span_backward(const SpanParams p) {
         if ((tid & 63) == 63) scratch[NDIFF * wave + i] = static_cast<double>(t);
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // (explicit wait + clobber at every barrier: see walk_barrier, shiftnd_walk.hip)
+    __syncthreads();
+    if (tid < NDIFF) {
+        double acc = 0.0;
+#pragma unroll
+        for (int w = 0; w < kThreads / 64; ++w) acc += scratch[NDIFF * w + tid];
+        p.partials[static_cast<size_t>(bid) * NDIFF + tid] = acc;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// crop_backward: the 2-D cropped backward in step_backward's shape and at its instruction count.  span_backward above is
+// general (segments, slots decoded per piece, three read paths) and pays for it in control flow: 2500 instructions, 113
+// exec-mask regions, ~340 scalar instructions per wave -- on C2's tensor cut by one element per side the four waves of a
+// workgroup need 0.57 us of the CU's scalar unit for 11 KB of traffic (4.9 TB/s).  Here, as in step_backward:
+//   * thread (tr, tc) stages piece tc of row tr of every group, nothing is decoded;
+//   * the x corner rows (whole pieces) come by LDS-DMA; the grad_out rows are ragged -- their 16-byte cover starts anywhere
+//     and can be one piece longer than an x row -- and come global -> registers -> LDS through a buffer resource: every load
+//     and every LDS store is unconditional (a lane without a piece loads zeros from an out-of-range offset and parks them in
+//     the unused tail of its slot);
+//   * one read path (ColState), the window mask applied to the result.
+// 2-D, rows of at most 256 chunks; 1-D rows stay with span_backward.
+// ---------------------------------------------------------------------------------------------------------------------
+template <typename T, bool ACTIVE, int PAD>
+__global__ __launch_bounds__(kThreads) void crop_backward(const SpanParams p) {
+    using S = typename T::S;
+    using CT = typename T::C;
+    constexpr int ES = sizeof(S);
+    constexpr int E = 16 / ES;
+    constexpr int REC = RecSize<E>::N;
+    constexpr int NDIFF = 2;
+    typedef uint32_t u4 __attribute__((ext_vector_type(4)));
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char *tile = smem + 64;  // 64-byte pads in front and behind: see lds_read_row
+
+    const uint32_t bid = (blockIdx.x & 7u) * p.steps_per_xcd + (blockIdx.x >> 3);  // XCD-contiguous step ids
+    if (bid >= p.total_steps) return;
+    const uint32_t plane = fdiv(bid, p.d_spp);   // (n, c)
+    const int step = static_cast<int>(bid - plane * static_cast<uint32_t>(p.spp));
+    const int c = static_cast<int>(plane - fdiv(plane, p.d_C) * static_cast<uint32_t>(p.C));
+    const ChanDesc d = p.desc[c];
+    const int R = p.R, S1 = p.S1, S2 = p.S2, O1 = p.O1, O2 = p.O2, L1 = p.L1, L2 = p.L2, cpr = p.cpr;
+    const int b0 = step * R;
+    const int Rn = min(R, S1 - b0);
+    // tile: x corner rows [R + 1][cpr pieces] | grad_out at the step's own rows [R][cpr + 2] | the rows grad_x reads [R (+ 1)][cpr + 2]
+    const int RBX = cpr * 16, PG = cpr + 2, RBG = PG * 16;
+    const int goff = (R + 1) * RBX, gsoff = goff + R * RBG;
+    const S *xp = static_cast<const S *>(p.x) + static_cast<int64_t>(plane) * p.x_plane;
+    const S *gp = static_cast<const S *>(p.go) + static_cast<int64_t>(plane) * p.g_plane;
+    S *gxp = static_cast<S *>(p.out) + static_cast<int64_t>(plane) * p.x_plane;
+    // grad_out as the TENSOR's stream of 16-byte pieces: this plane starts gph bytes into its first piece
+    const int gph = static_cast<int>((static_cast<uint64_t>(plane) * static_cast<uint64_t>(p.g_plane) * ES) & 15u);
+    const char *gp16 = reinterpret_cast<const char *>(gp) - gph;
+    const uint32_t gbytes = static_cast<uint32_t>(gph) + static_cast<uint32_t>(p.g_plane) * ES;   // this plane's bytes from gp16 (a whole number of pieces or the tensor's end: host)
+    const __amdgpu_buffer_rsrc_t gres = __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(gp16), 0, (gbytes + 15u) & ~15u, 0x00020000);
+    constexpr uint32_t kOOR = 0x80000000u;
+
+    const int tid = static_cast<int>(threadIdx.x);
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tr = static_cast<int>(fdiv(static_cast<uint32_t>(tid), p.d_seg)), tc = tid - tr * cpr;
+    const int ji = tc * E;
+    // ---- x corner rows: LDS-DMA, thread (tr, tc) moves piece tc of row tr; the first cpr threads the + 1 row of a full step ----
+    auto dma_x = [&](int src_row, int col_piece, int lds_piece0) {
+        const uint32_t off = static_cast<uint32_t>(src_row * S2 + col_piece * E) * static_cast<uint32_t>(ES);
+        char *dst_wave = tile + (lds_piece0 + wave * 64) * 16;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(reinterpret_cast<const char *>(xp) + off),
+                                         (__attribute__((address_space(3))) void *)dst_wave, 16, 0, 0);
+    };
+    if (tr < R) {
+        const int sx = tr <= Rn ? row_map_t<PAD>(b0 + tr, d.cx1, S1) : -1;
+        if (sx >= 0) dma_x(sx, tc, 0);
+    }
+    if (Rn == R && tid < cpr) {
+        const int sx = row_map_t<PAD>(b0 + R, d.cx1, S1);
+        if (sx >= 0) dma_x(sx, tid, R * cpr);
+    }
+    // ---- grad_out rows: a row's cover = pieces (lo >> 4) .. of the stream, lo = gph + row O2 ES; the slot keeps them from its
+    // first byte, so column j of the row sits at (lo & 15) + j ES.  Piece tc by thread (tr, tc); pieces cpr, cpr + 1 by tc < 2.
+    auto row_lo = [&](int row) { return gph + row * O2 * ES; };
+    auto cover_off = [&](int row, int piece) {   // byte offset of a cover piece from gp16, or out of range
+        const int lo = row_lo(row), p0 = lo >> 4, cnt = ((lo + O2 * ES + 15) >> 4) - p0;
+        return (row >= 0 && piece < cnt) ? static_cast<uint32_t>(p0 + piece) * 16u : kOOR;
+    };
+    const int ro = (tr < R && tr < Rn && b0 + tr - L1 >= 0 && b0 + tr - L1 < O1) ? b0 + tr - L1 : -1;   // own row
+    auto gs_row = [&](int i, bool have) {   // the row grad_x reads at step row i (window coordinates through the row map)
+        const int pr = b0 + i - L1;
+        const bool dom = have && pr >= 0 && (ACTIVE ? pr <= O1 : pr < O1);
+        return dom ? row_map_t<PAD>(pr, d.cg1, O1) : -1;
+    };
+    const int rs = gs_row(tr, tr < R && (ACTIVE ? tr <= Rn : tr < Rn));
+    const int rcorner = (ACTIVE && Rn == R && tid < cpr + 2) ? gs_row(R, true) : -1;   // + 1 row of a full step: threads 0 .. cpr + 1
+    const int xt = tc < 2 ? cpr + tc : PG;   // the extra pieces of a row's cover (PG: none)
+    const u4 vo0 = __builtin_amdgcn_raw_buffer_load_b128(gres, cover_off(ro, tc), 0, 0);
+    const u4 vo1 = __builtin_amdgcn_raw_buffer_load_b128(gres, cover_off(ro, xt), 0, 0);
+    const u4 vs0 = __builtin_amdgcn_raw_buffer_load_b128(gres, cover_off(rs, tc), 0, 0);
+    const u4 vs1 = __builtin_amdgcn_raw_buffer_load_b128(gres, cover_off(rs, xt), 0, 0);
+    u4 vc = {0u, 0u, 0u, 0u};
+    if constexpr (ACTIVE) vc = __builtin_amdgcn_raw_buffer_load_b128(gres, cover_off(rcorner, tid), 0, 0);
+
+    // ---- the thread's chunk: column state through the x map, the gradient map (window coordinates) and the plain window ----
+    ColState<E> xm, gm, om;
+    {
+        auto affine_state = [&](int first, int len) {
+            ColState<E> st;
+            st.base = first;
+            if (first + E < 0 || first >= len) st.base = 0;
+            st.affine = true;
+#pragma unroll
+            for (int e = 0; e <= E; ++e) st.cm[e] = (first + e >= 0 && first + e < len) ? first + e : -1;
+            return st;
+        };
+        om = affine_state(ji - L2, O2);
+        if constexpr (PAD == 0) {
+            xm = affine_state(ji - d.cx2, S2);
+            gm = affine_state(ji - L2 - d.cg2, O2);
+            if (O2 == 1) {   // a window one column wide ignores the shift (shifts_kernels.h:40-48): both corners read column 0
+                gm.affine = false;
+#pragma unroll
+                for (int e = 0; e <= E; ++e) gm.cm[e] = (ji - L2 + e >= 0 && ji - L2 + e <= 1) ? 0 : -1;
+            }
+        } else {
+            const size_t rec = (static_cast<size_t>(c) * cpr + (tr < R ? tc : 0)) * REC;
+            xm = load_colstate<E>(p.colx + rec);
+            gm = load_colstate<E>(p.colg + rec);
+        }
+    }
+    // park the gradient pieces (a lane without one holds zeros and writes them into its slot's unused tail / a dump piece)
+    {
+        const int slot = tr < R ? tr : 0;   // (threads beyond the R rows: zeros into row 0's tail piece... see below)
+        char *dump = tile + gsoff + (R + 1) * RBG;
+        auto park = [&](char *row_base, bool live, int piece, const u4 &v) {
+            char *dst = (live && piece < PG) ? row_base + piece * 16 : dump + (tid & 63) * 16;
+            *reinterpret_cast<u4 *>(__builtin_assume_aligned(dst, 16)) = v;
+        };
+        park(tile + goff + slot * RBG, tr < R, tc, vo0);
+        park(tile + goff + slot * RBG, tr < R, xt, vo1);
+        park(tile + gsoff + slot * RBG, tr < R, tc, vs0);
+        park(tile + gsoff + slot * RBG, tr < R, xt, vs1);
+        if constexpr (ACTIVE) park(tile + gsoff + R * RBG, tid < PG, tid, vc);
+    }
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    CT part[NDIFF] = {CT(0), CT(0)};
+    if (tr < R && tr < Rn) {
+        const int b = b0 + tr;
+        const CT dw[3] = {static_cast<CT>(d.dw[0]), static_cast<CT>(d.dw[1]), CT(0)};
+        const bool in_row = b >= L1 && b < L1 + O1;
+        auto row_valid = [&](int pr, int cs, int len) { return PAD != 0 || row_map_t<PAD>(pr, cs, len) >= 0; };
+        S zero;
+        __builtin_memset(&zero, 0, sizeof(S));
+        Chunk<S, E> res;
+        // ---- grad_x -------------------------------------------------------------------------------------------------------
+        if constexpr (ACTIVE) {
+            CT gv[2][E + 1];
+#pragma unroll
+            for (int hb = 0; hb < 2; ++hb) {
+                const int pr = b - L1 + hb;
+                const bool dom = in_row && pr <= O1;
+                const int srow = dom ? row_map_t<PAD>(pr, d.cg1, O1) : -1;
+                S raw[E + 1];
+                lds_read_row<S, E>(tile + gsoff + (tr + hb) * RBG + (row_lo(srow) & 15), srow >= 0, gm, raw);
+#pragma unroll
+                for (int e = 0; e <= E; ++e) gv[hb][e] = widen<T>(raw[e]);
+            }
+#pragma unroll
+            for (int e = 0; e < E; ++e) {
+                const CT v[4] = {gv[0][e], gv[1][e], gv[0][e + 1], gv[1][e + 1]};
+                const bool inside = in_row && ji + e >= L2 && ji + e < L2 + O2;
+                res.e[e] = inside ? narrow<T>(interp_t<T, 2>(v, dw)) : zero;
+            }
+        } else {
+            const int srow = in_row ? row_map_t<PAD>(b - L1, d.cg1, O1) : -1;
+            S raw[E + 1];
+            lds_read_row<S, E>(tile + gsoff + tr * RBG + (row_lo(srow) & 15), srow >= 0, gm, raw);
+#pragma unroll
+            for (int e = 0; e < E; ++e) {
+                const bool inside = in_row && ji + e >= L2 && ji + e < L2 + O2;
+                res.e[e] = inside ? raw[e] : zero;
+            }
+        }
+        // ---- weight-gradient sums: corners of x against grad_out at the chunk's own position (0 outside the window) --------
+        CT xv[2][E + 1];
+#pragma unroll
+        for (int hb = 0; hb < 2; ++hb) {
+            S raw[E + 1];
+            lds_read_row<S, E>(tile + (tr + hb) * RBX, row_valid(b + hb, d.cx1, S1), xm, raw);
+#pragma unroll
+            for (int e = 0; e <= E; ++e) xv[hb][e] = widen<T>(raw[e]);
+        }
+        S graw[E + 1];
+        lds_read_row<S, E>(tile + goff + tr * RBG + (row_lo(b - L1) & 15), in_row, om, graw);
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+            const CT v[4] = {xv[0][e], xv[1][e], xv[0][e + 1], xv[1][e + 1]};
+            CT df[NDIFF];
+            corner_diffs<2, CT>(v, df);
+            const CT gval = widen<T>(graw[e]);
+#pragma unroll
+            for (int i = 0; i < NDIFF; ++i) part[i] = fma_ct(gval, df[i], part[i]);
+        }
+        store_chunk<S, E>(gxp + static_cast<int64_t>(b) * S2 + ji, res);
+    }
+    // ---- this step's sums: DPP tree per wave, the four waves added in fp64 by one thread ----------------------------------
+    double *scratch = reinterpret_cast<double *>(tile + ((gsoff + (R + 1) * RBG + 64 * 16 + 63) & ~63) + 64);
+#pragma unroll
+    for (int i = 0; i < NDIFF; ++i) {
+        const CT t = wave_total(part[i]);
+        if ((tid & 63) == 63) scratch[NDIFF * wave + i] = static_cast<double>(t);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __syncthreads();
     if (tid < NDIFF) {
         double acc = 0.0;
@@ -433,24 +673,32 @@ __global__ __launch_bounds__(kThreads) void span_forward(const SpanFwdParams p) 
     // slot i = source row of output row r0 + i (window coordinates + L1 through the row map); -1: fill
     auto slot_row = [&](int i) { return ND == 2 ? row_map_t<PAD>(r0 + i + L1, cs1, S1) : 0; };
     const int npieces = nr * P;
-#pragma unroll
-    for (int k = 0; k < kSpanRounds; ++k) {
-        if (k * kThreads < npieces) {   // uniform
-            const int q = k * kThreads + tid;
-            const int slot = static_cast<int>(fdiv(static_cast<uint32_t>(q), p.d_P));
-            const int piece = q - slot * P;
-            const int row = slot < nr ? slot_row(slot) : -1;
-            const int lo = xph + (row * S2 + c0) * ES, hi = xph + (row * S2 + c1) * ES;
-            const int p0 = lo >> 4, cnt = ((hi + 15) >> 4) - p0;
-            if (q < npieces && row >= 0 && piece < cnt) {
-                char *dst_wave = tile + (k * kThreads + wave * 64) * 16;
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(xp16 + static_cast<int64_t>(p0 + piece) * 16),
-                                                 (__attribute__((address_space(3))) void *)dst_wave, 16, 0, 2 /* nt */);
-            }
+    auto stage_round = [&](int k) {
+        const int q = k * kThreads + tid;
+        const int slot = static_cast<int>(fdiv(static_cast<uint32_t>(q), p.d_P));
+        const int piece = q - slot * P;
+        const int row = slot < nr ? slot_row(slot) : -1;
+        const int lo = xph + (row * S2 + c0) * ES, hi = xph + (row * S2 + c1) * ES;
+        const int p0 = lo >> 4, cnt = ((hi + 15) >> 4) - p0;
+        if (q < npieces && row >= 0 && piece < cnt) {
+            char *dst_wave = tile + (k * kThreads + wave * 64) * 16;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(xp16 + static_cast<int64_t>(p0 + piece) * 16),
+                                             (__attribute__((address_space(3))) void *)dst_wave, 16, 0, 2 /* nt */);
         }
+    };
+    const int U = (p.cps + kThreads - 1) / kThreads;   // chunks per thread (1; up to 4 for 1-D rows longer than 256 chunks)
+    if (U == 1) {
+#pragma unroll
+        for (int k = 0; k < kSpanRounds; ++k)
+            if (k * kThreads < npieces) stage_round(k);   // uniform
+    } else {
+        for (int k = 0; k * kThreads < npieces; ++k) stage_round(k);
     }
-    // ---- the thread's chunk ---------------------------------------------------------------------------------------------------
-    const int q = q0 + tid;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    // ---- the thread's chunks ---------------------------------------------------------------------------------------------------
+    for (int u = 0; u < U; ++u) {
+    const int q = q0 + tid + u * kThreads;
     const bool mine = q < q1;
     const int e0 = q * E;
     const int r = mine ? static_cast<int>(fdiv(static_cast<uint32_t>(e0), p.d_O2)) : r0;
@@ -470,9 +718,7 @@ __global__ __launch_bounds__(kThreads) void span_forward(const SpanFwdParams p) 
 #pragma unroll
     for (int e = 0; e <= E; ++e) staged = staged && (xm.cm[e] < 0 || (xm.cm[e] >= c0 && xm.cm[e] < c1));
     staged = staged || whole;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (!mine) return;
+    if (!mine) continue;
     S zero;
     __builtin_memset(&zero, 0, sizeof(S));
     // column 0 of a staged row within its slot / in memory
@@ -528,6 +774,123 @@ __global__ __launch_bounds__(kThreads) void span_forward(const SpanFwdParams p) 
         }
     }
     store_chunk<S, E>(op + e0, res);
+    }   // u
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// crop_forward: the 2-D cropped forward, lean like crop_backward (span_forward above: 1100 instructions, 45 exec-mask regions,
+// 4.2 / 3.1 TB/s on C2's tensor cut by one element per side).  A step is 256 consecutive 16-byte chunks of the output plane's
+// byte stream (the window's rows are ragged: 222 fp32 = 888 bytes); the x rows those chunks read -- whole pieces, at most 256
+// per row -- are staged by LDS-DMA, piece q of the tile = piece (q mod cpr) of source row (q div cpr).  A chunk inside one
+// output row reads its window through ColState; a chunk that straddles rows goes element by element, without branches
+// (clamped index + select).
+// ---------------------------------------------------------------------------------------------------------------------
+template <typename T, bool ACTIVE, int PAD>
+__global__ __launch_bounds__(kThreads) void crop_forward(const SpanFwdParams p) {
+    using S = typename T::S;
+    using CT = typename T::C;
+    constexpr int ES = sizeof(S);
+    constexpr int E = 16 / ES;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char *tile = smem + 64;
+
+    const uint32_t bid = (blockIdx.x & 7u) * p.steps_per_xcd + (blockIdx.x >> 3);
+    if (bid >= p.total_steps) return;
+    const uint32_t plane = fdiv(bid, p.d_spp);
+    const int step = static_cast<int>(bid - plane * static_cast<uint32_t>(p.spp));
+    const int c = static_cast<int>(plane - fdiv(plane, p.d_C) * static_cast<uint32_t>(p.C));
+    CT wr, wc;
+    load_weights2<CT>(p.w, p.wkind, c, wr, wc);
+    const CT rr = ACTIVE ? c_floor<CT>(wr) : c_rint<CT>(wr), rc = ACTIVE ? c_floor<CT>(wc) : c_rint<CT>(wc);
+    const CT dw[2] = {ACTIVE ? wr - rr : CT(0), ACTIVE ? wc - rc : CT(0)};
+    const int S1 = p.S1, S2 = p.S2, O2 = p.O2, L1 = p.L1, L2 = p.L2, cpr = p.P;   // (P = pieces per source row)
+    const int cs1 = __builtin_amdgcn_readfirstlane(canon_of<PAD, CT>(rr, S1, p.d_per1));
+    const int cs2 = __builtin_amdgcn_readfirstlane(canon_of<PAD, CT>(rc, S2, p.d_per2));
+
+    const int q0 = step * kThreads, q1 = min(p.ocp, q0 + kThreads);
+    const int F0 = q0 * E, F1 = q1 * E;
+    const int r0 = static_cast<int>(fdiv(static_cast<uint32_t>(F0), p.d_O2)), r1 = static_cast<int>(fdiv(static_cast<uint32_t>(F1 - 1), p.d_O2));
+    const int nr = r1 - r0 + 1 + (ACTIVE ? 1 : 0);   // staged source rows: those of output rows r0 .. r1 (+ the corner row)
+    const S *xp = static_cast<const S *>(p.x) + static_cast<int64_t>(plane) * p.x_plane;
+    S *op = static_cast<S *>(p.out) + static_cast<int64_t>(plane) * p.o_plane;
+    const int tid = static_cast<int>(threadIdx.x);
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int RB = cpr * 16;
+    const int npieces = nr * cpr;
+    for (int k = 0; k * kThreads < npieces; ++k) {   // (uniform trip count: one to four rounds)
+        const int q = k * kThreads + tid;
+        const int slot = static_cast<int>(fdiv(static_cast<uint32_t>(q), p.d_P));
+        const int piece = q - slot * cpr;
+        const int row = q < npieces ? row_map_t<PAD>(r0 + slot + L1, cs1, S1) : -1;
+        if (row >= 0) {
+            char *dst_wave = tile + (k * kThreads + wave * 64) * 16;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(reinterpret_cast<const char *>(xp) + static_cast<uint32_t>(row * S2 * ES + piece * 16)),
+                                             (__attribute__((address_space(3))) void *)dst_wave, 16, 0, 0);
+        }
+    }
+    // ---- the thread's chunk ---------------------------------------------------------------------------------------------------
+    const int q = q0 + tid;
+    const int e0 = q * E;
+    const int r = q < q1 ? static_cast<int>(fdiv(static_cast<uint32_t>(e0), p.d_O2)) : r0;
+    const int j = e0 - r * O2;
+    ColState<E> xm;
+    if constexpr (PAD == 0) {
+        const int first = j + L2 - cs2;
+        xm.base = (first + E < 0 || first >= S2) ? 0 : first;
+        xm.affine = true;
+#pragma unroll
+        for (int e = 0; e <= E; ++e) xm.cm[e] = (first + e >= 0 && first + e < S2) ? first + e : -1;
+    } else {
+        xm = fold_colstate<E, PAD>(j + L2, cs2, S2);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (q >= q1) return;
+    auto row_ok = [&](int slot) { return PAD != 0 || row_map_t<PAD>(r0 + slot + L1, cs1, S1) >= 0; };
+    const S zero = static_cast<S>(0.0f);   // (a value, not an object the lambdas below could take the address of: that one went to scratch)
+    Chunk<S, E> res;
+    if (j + E <= O2) {   // the chunk lies in one output row
+        const int slot = r - r0;
+        if constexpr (ACTIVE) {
+            CT xv[2][E + 1];
+#pragma unroll
+            for (int hb = 0; hb < 2; ++hb) {
+                S raw[E + 1];
+                lds_read_row<S, E>(tile + (slot + hb) * RB, row_ok(slot + hb), xm, raw);
+#pragma unroll
+                for (int e = 0; e <= E; ++e) xv[hb][e] = widen<T>(raw[e]);
+            }
+#pragma unroll
+            for (int e = 0; e < E; ++e) {
+                const CT v[4] = {xv[0][e], xv[1][e], xv[0][e + 1], xv[1][e + 1]};
+                res.e[e] = narrow<T>(interp_t<T, 2>(v, dw));
+            }
+        } else {
+            S raw[E + 1];
+            lds_read_row<S, E>(tile + slot * RB, row_ok(slot), xm, raw);
+#pragma unroll
+            for (int e = 0; e < E; ++e) res.e[e] = raw[e];
+        }
+    } else {   // it straddles output rows: element by element (clamped reads, then one select each)
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+            const int re = static_cast<int>(fdiv(static_cast<uint32_t>(e0 + e), p.d_O2));
+            const int slot = re - r0, je = e0 + e - re * O2;
+            const int m0 = row_map_t<PAD>(je + L2, cs2, S2);
+            auto at = [&](int sl, int m) {
+                const S v = reinterpret_cast<const S *>(tile + sl * RB)[m > 0 ? m : 0];
+                return (m >= 0 && row_ok(sl)) ? v : zero;
+            };
+            if constexpr (ACTIVE) {
+                const int m1 = row_map_t<PAD>(je + L2 + 1, cs2, S2);
+                const CT v[4] = {widen<T>(at(slot, m0)), widen<T>(at(slot + 1, m0)), widen<T>(at(slot, m1)), widen<T>(at(slot + 1, m1))};
+                res.e[e] = narrow<T>(interp_t<T, 2>(v, dw));
+            } else {
+                res.e[e] = at(slot, m0);
+            }
+        }
+    }
+    store_chunk<S, E>(op + e0, res);
 }
 
 struct SpanFwdPlan {
@@ -548,7 +911,11 @@ SpanFwdPlan span_forward_plan(const Geometry &g, int es) {
     const int64_t budget = kSpanRounds * kThreads;
     // whole source rows when a step spans whole output rows (an output row of at most 256 chunks); rows longer than a step
     // stage only the columns the step's chunks reach
-    if (g.O[2] * es <= kThreads * 16 && rows * cprx <= budget) {
+    if (g.nd == 1 && g.O[2] * es > kThreads * 16 && g.O[2] * es <= 4 * kThreads * 16 && cprx * 16 + 128 <= 60 * 1024) {
+        // a 1-D row of at most 1024 chunks is one step, up to four chunks per thread, the whole source row staged (see span_plan)
+        s.P = s.wholeP = static_cast<int>(cprx);
+        s.cps = static_cast<int>(g.O[2] * es / 16);
+    } else if (g.O[2] * es <= kThreads * 16 && rows * cprx <= budget) {
         s.P = s.wholeP = static_cast<int>(cprx);
         s.cps = kThreads;
     } else {
@@ -561,13 +928,14 @@ SpanFwdPlan span_forward_plan(const Geometry &g, int es) {
     }
     s.spp = (s.ocp + s.cps - 1) / s.cps;
     s.total = static_cast<uint64_t>(g.N) * g.C * s.spp;
-    s.ok = rows * s.P <= budget;
-    s.lds = 64 + ((static_cast<size_t>(rows) * s.P * 16 + 63) & ~static_cast<size_t>(63)) + 64;
+    const int64_t slots = s.cps > kThreads ? 1 : rows;   // (a whole 1-D row per step: one source row)
+    s.ok = slots * s.P <= (s.cps > kThreads ? 16 : kSpanRounds) * kThreads;
+    s.lds = 64 + ((static_cast<size_t>(slots) * s.P * 16 + 63) & ~static_cast<size_t>(63)) + 64;
     return s;
 }
 
 struct SpanPlan {
-    int cpr, seg, nseg, R, rsteps, spp, P, ndiff, rec;
+    int cpr, seg, nseg, R, rsteps, spp, P, U, ndiff, rec;
     uint64_t total;
     size_t off_desc, off_colx, off_colg, bytes, lds;
 };
@@ -580,11 +948,18 @@ SpanPlan span_plan(const Geometry &g, int es) {
     // column segments of at most 256 chunks (4 KB blocks of grad_x: see span_forward_plan); slots of seg + 2 pieces (a ragged
     // grad_out row's cover; a segment's source columns + corner column + shift misalignment)
     s.seg = std::min(s.cpr, kThreads);
+    s.U = 1;
+    if (g.nd == 1 && s.cpr > kThreads) {
+        // 1-D rows longer than a workgroup pass: up to four chunks per thread -- rows of at most 1024 chunks are one segment (every
+        // staged piece is read by this workgroup only; with 256-chunk segments every workgroup also read the first 32 bytes of its
+        // neighbour's block: N256 C512 L4096 fp32 backward 1.23 ms = 5.2 TB/s against 6.2 TB/s of the same kernel on 2-D crops)
+        s.U = std::min(4, (s.cpr + kThreads - 1) / kThreads);
+        s.seg = std::min(s.cpr, s.U * kThreads);
+    }
     s.nseg = (s.cpr + s.seg - 1) / s.seg;
     s.P = s.seg + 2;
     // rows per step: R * seg threads, and the tile's (3 R + 2) slots of P pieces within the staging rounds
-    int R = kThreads / s.seg;
-    R = std::min(R, (kSpanRounds * kThreads / s.P - 2) / 3);
+    int R = std::max(1, kThreads / s.seg);
     R = std::max(1, std::min<int>(R, static_cast<int>(g.S[1])));
     if (g.nd == 1 || s.nseg > 1) R = 1;
     s.R = R;
@@ -598,8 +973,12 @@ SpanPlan span_plan(const Geometry &g, int es) {
     s.off_colx = s.off_desc + up(static_cast<size_t>(g.C) * sizeof(ChanDesc));
     s.off_colg = s.off_colx + up(static_cast<size_t>(g.C) * s.cpr * s.rec * sizeof(int16_t));
     s.bytes = s.off_colg + up(static_cast<size_t>(g.C) * s.cpr * s.rec * sizeof(int16_t));
-    const int nslots = g.nd == 2 ? (3 * R + 2) : 3;
-    s.lds = 64 + ((static_cast<size_t>(nslots) * s.P * 16 + 63) & ~static_cast<size_t>(63)) + 64 + (kThreads / 64) * 2 * sizeof(double);
+    if (g.nd == 2) {   // crop_backward: x rows [R + 1][cpr] | own rows [R][cpr + 2] | read rows [R + 1][cpr + 2] | 64 dump pieces
+        const size_t tile = (static_cast<size_t>(R + 1) * s.cpr + static_cast<size_t>(2 * R + 1) * (s.cpr + 2) + 64) * 16;
+        s.lds = 64 + ((tile + 63) & ~static_cast<size_t>(63)) + 64 + (kThreads / 64) * 2 * sizeof(double);
+    } else {
+        s.lds = 64 + ((static_cast<size_t>(3) * s.P * 16 + 63) & ~static_cast<size_t>(63)) + 64 + (kThreads / 64) * 2 * sizeof(double);
+    }
     return s;
 }
 
@@ -611,6 +990,7 @@ bool span_geometry_ok(const Geometry &g, int dtype) {
     if ((g.S[2] * es) % 16 != 0 || g.S[2] > 32000) return false;                       // x rows: whole pieces; int16 column tables
     if ((g.N * g.C * g.O[1] * g.O[2] * es) % 16 != 0) return false;                     // grad_out: a whole number of pieces
     if (g.S[1] * g.S[2] >= (1LL << 28) || g.O[1] * g.O[2] >= (1LL << 28)) return false;  // 32-bit byte offsets within a plane
+    if (g.nd == 2 && g.S[2] * es > kThreads * 16) return false;   // crop_backward: rows of at most 256 chunks
     const SpanPlan s = span_plan(g, es);
     return s.total + 8 < (1ull << 31) && s.lds <= 64 * 1024;
 }
@@ -653,9 +1033,27 @@ static void launch_span_forward(const SpanFwdParams &p, size_t lds, bool active,
 #undef SHIFTND_SPAN_FWD
 }
 
+// crop_forward: 2-D, source rows of whole pieces (at most 256), at most four staging rounds
+static bool crop_forward_ok(const Geometry &g, int es) {
+    if (g.nd != 2 || (g.S[2] * es) % 16 != 0 || g.S[2] * es > kThreads * 16) return false;
+    const int E = 16 / es;
+    const int64_t rows = std::min<int64_t>(g.O[1], (static_cast<int64_t>(kThreads) * E + g.O[2] - 2) / g.O[2] + 1) + (g.active ? 1 : 0);
+    return rows * (g.S[2] * es / 16) <= 4 * kThreads;
+}
+
 int span_forward(const Geometry &g, int dtype, const void *x, const void *w, int wkind, void *out, hipStream_t st) {
     const int es = dtype_size(dtype);
-    const SpanFwdPlan sp = span_forward_plan(g, es);
+    SpanFwdPlan sp = span_forward_plan(g, es);
+    const bool lean = crop_forward_ok(g, es);
+    if (lean) {   // whole source rows, exact pitch
+        const int E = 16 / es;
+        const int64_t rows = std::min<int64_t>(g.O[1], (static_cast<int64_t>(kThreads) * E + g.O[2] - 2) / g.O[2] + 1) + (g.active ? 1 : 0);
+        sp.P = sp.wholeP = static_cast<int>(g.S[2] * es / 16);
+        sp.cps = kThreads;
+        sp.spp = (sp.ocp + kThreads - 1) / kThreads;
+        sp.total = static_cast<uint64_t>(g.N) * g.C * sp.spp;
+        sp.lds = 64 + ((static_cast<size_t>(rows) * sp.P * 16 + 63) & ~static_cast<size_t>(63)) + 64;
+    }
     SpanFwdParams p{};
     p.x = x;
     p.out = out;
@@ -685,6 +1083,26 @@ int span_forward(const Geometry &g, int dtype, const void *x, const void *w, int
     p.d_per1 = make_fastdiv(static_cast<uint32_t>(map_period(p.S1, g.pad)));
     p.d_per2 = make_fastdiv(static_cast<uint32_t>(map_period(p.S2, g.pad)));
     const bool active = g.active != 0;
+    if (lean) {
+        note_kernel(active ? "crop_active_forward" : "crop_gather_forward");
+        const dim3 grid(p.steps_per_xcd * 8), block(kThreads);
+#define SHIFTND_CROP_FWD(TT, ACT) \
+        switch (g.pad) { \
+        case 0: hipLaunchKernelGGL((crop_forward<TT, ACT, 0>), grid, block, sp.lds, st, p); break; \
+        case 1: hipLaunchKernelGGL((crop_forward<TT, ACT, 1>), grid, block, sp.lds, st, p); break; \
+        case 2: hipLaunchKernelGGL((crop_forward<TT, ACT, 2>), grid, block, sp.lds, st, p); break; \
+        case 3: hipLaunchKernelGGL((crop_forward<TT, ACT, 3>), grid, block, sp.lds, st, p); break; \
+        default: hipLaunchKernelGGL((crop_forward<TT, ACT, 4>), grid, block, sp.lds, st, p); break; \
+        }
+        if (!active) {   // a raw copy: one instantiation per element size
+            if (es == 2) { SHIFTND_CROP_FWD(f16_t, false) } else if (es == 4) { SHIFTND_CROP_FWD(f32_t, false) } else { SHIFTND_CROP_FWD(f64_t, false) }
+        } else if (dtype == SHIFTND_F32) { SHIFTND_CROP_FWD(f32_t, true)
+        } else if (dtype == SHIFTND_F64) { SHIFTND_CROP_FWD(f64_t, true)
+        } else if (dtype == SHIFTND_F16) { SHIFTND_CROP_FWD(f16_t, true)
+        } else { SHIFTND_CROP_FWD(bf16_t, true) }
+#undef SHIFTND_CROP_FWD
+        return SHIFTND_OK;
+    }
     note_kernel(active ? "span_active_forward" : "span_gather_forward");
 #define SHIFTND_SPAN_FT(TT) (g.nd == 1 ? launch_span_forward<TT, 1>(p, sp.lds, active, g.pad, st) : launch_span_forward<TT, 2>(p, sp.lds, active, g.pad, st))
     if (!active) {   // a raw copy: one instantiation per element size
@@ -723,7 +1141,10 @@ static void launch_span_backward(const SpanParams &p, const SpanPlan &sp, bool a
     using S = typename T::S;
     const dim3 grid(p.steps_per_xcd * 8), block(kThreads);
 #define SHIFTND_SPAN_PAD(ACT, PADV) \
-    case PADV: hipLaunchKernelGGL((span_backward<T, ND, ACT, PADV>), grid, block, sp.lds, st, p); break;
+    case PADV: \
+        if constexpr (ND == 2) hipLaunchKernelGGL((crop_backward<T, ACT, PADV>), grid, block, sp.lds, st, p); \
+        else hipLaunchKernelGGL((span_backward<T, ND, ACT, PADV>), grid, block, sp.lds, st, p); \
+        break;
     if (active) {
         hipLaunchKernelGGL((span_prep<T, true>), dim3(p.C), block, 0, st, p);
         switch (p.pad) { SHIFTND_SPAN_PAD(true, 0) SHIFTND_SPAN_PAD(true, 1) SHIFTND_SPAN_PAD(true, 2) SHIFTND_SPAN_PAD(true, 3) default: SHIFTND_SPAN_PAD(true, 4) }
@@ -777,6 +1198,7 @@ int span_backward(const Geometry &g, int dtype, const void *go, const void *x, c
     p.rsteps = sp.rsteps;
     p.spp = sp.spp;
     p.P = sp.P;
+    p.U = sp.U;
     p.total_steps = static_cast<uint32_t>(sp.total);
     p.steps_per_xcd = static_cast<uint32_t>((sp.total + 7) / 8);
     p.d_spp = make_fastdiv(static_cast<uint32_t>(sp.spp));
@@ -788,7 +1210,7 @@ int span_backward(const Geometry &g, int dtype, const void *go, const void *x, c
     p.d_per2x = make_fastdiv(static_cast<uint32_t>(map_period(p.S2, g.pad)));
     p.d_per1g = make_fastdiv(static_cast<uint32_t>(map_period(p.O1, g.pad)));
     p.d_per2g = make_fastdiv(static_cast<uint32_t>(map_period(p.O2, g.pad)));
-    note_kernel("span_backward");
+    note_kernel(g.nd == 2 ? "crop_backward" : "span_backward");
     const bool active = g.active != 0;
 #define SHIFTND_SPAN_T(TT) (g.nd == 1 ? launch_span_backward<TT, 1>(p, sp, active, gw, st) : launch_span_backward<TT, 2>(p, sp, active, gw, st))
     switch (dtype) {

@@ -15,10 +15,10 @@ ROUTES = {
     "c3 sparse": ((1, 128, 16, 112, 112), torch.bfloat16, False, None, "step_gather_forward_lds", "walk_backward16_sparse"),
     "c3 fp32": ((1, 128, 16, 112, 112), torch.float32, True, None, "walk_forward", "walk_backward"),
     "c5": ((2, 512, 224, 224), torch.float16, False, None, "step_gather_forward_small", "step_backward"),
-    "c2crop": ((2, 256, 224, 224), torch.float32, False, [[1, 1], [1, 1]], "span_gather_forward", "span_backward"),
-    "c2acrop": ((2, 256, 224, 224), torch.float32, True, [[1, 1], [1, 1]], "span_active_forward", "span_backward"),
-    "t1": ((8, 16, 64, 64), torch.float32, False, [[1, 1], [1, 1]], "span_gather_forward", "span_backward"),
-    "t1a": ((8, 16, 64, 64), torch.float32, True, [[1, 1], [1, 1]], "span_active_forward", "span_backward"),
+    "c2crop": ((2, 256, 224, 224), torch.float32, False, [[1, 1], [1, 1]], "crop_gather_forward", "crop_backward"),
+    "c2acrop": ((2, 256, 224, 224), torch.float32, True, [[1, 1], [1, 1]], "crop_active_forward", "crop_backward"),
+    "t1": ((8, 16, 64, 64), torch.float32, False, [[1, 1], [1, 1]], "crop_gather_forward", "crop_backward"),
+    "t1a": ((8, 16, 64, 64), torch.float32, True, [[1, 1], [1, 1]], "crop_active_forward", "crop_backward"),
     "c1d": ((4, 512, 4096), torch.float32, False, None, None, "span_backward"),
     "c1da": ((4, 512, 4096), torch.float32, True, None, None, "span_backward"),
     "c1dh": ((4, 512, 4096), torch.float16, False, None, None, "span_backward"),

@@ -19,7 +19,7 @@ sys.path.insert(0, ROOT)
 
 import torch  # noqa: E402
 
-from bench import WORKLOADS, synth_tensor  # noqa: E402
+from bench import CUTS, WORKLOADS, synth_tensor  # noqa: E402
 from torchshifts import abi  # noqa: E402
 
 
@@ -45,6 +45,7 @@ def main():
     ap.add_argument("--shape", default="", help="N,C,spatial... with --dtype / --active: a free-form workload")
     ap.add_argument("--dtype", default="float32")
     ap.add_argument("--active", type=int, default=0)
+    ap.add_argument("--cut", default="", help="cut amounts per dim, e.g. '1,1;1,1' (default: the workload's, bench.py CUTS)")
     ap.add_argument("--libs", default="", help="comma-separated variants/<name>.so builds timed interleaved in THIS process "
                                                "(same tensors, same physical pages); 'tree' = the in-tree library")
     a = ap.parse_args()
@@ -73,14 +74,18 @@ def main():
     abi.set_path_policy(a.policy)
     quant = dtname == "quint8"
     dtype = torch.float32 if quant else getattr(torch, dtname)
+    cuts = CUTS.get(a.workload)
+    if a.cut:
+        cuts = [[int(v) for v in part.split(",")] for part in a.cut.split(";")]
+    borders, oshape = abi.check_borders(list(shape), cuts, nd) if cuts else (None, list(shape))   # (cropped windows: bench.py's CUTS)
     x = synth_tensor(torch, shape, 1, dev, dtype)
-    go = synth_tensor(torch, shape, 2, dev, dtype)
+    go = synth_tensor(torch, tuple(oshape), 2, dev, dtype)
     w = synth_tensor(torch, (shape[1], nd), 3, dev, torch.float32, -a.wrange, a.wrange).to(dtype)
     if quant:
         x = (x * 255).to(torch.uint8)
         wq = (w.float().round() + 128).to(torch.uint8)
-    out, gx, gw = torch.empty_like(x), torch.empty_like(x), torch.empty_like(w)
-    elems, es = x.numel(), x.element_size()
+    out, gx, gw = torch.empty_like(go), torch.empty_like(x), torch.empty_like(w)
+    elems, oelems, es = x.numel(), go.numel(), x.element_size()
     knobs = []
     for part in [p for p in a.knobs.split(";") if p]:
         k, vals = part.split("=")
@@ -93,7 +98,7 @@ def main():
         abi._lib = None
         libs[name] = abi.lib()
     combos = [(ln, c) for c in combos for ln in (libs or {"": None})]
-    res = {}
+    res, kernels = {}, {}
     for r in range(a.rounds + 1):
         for ci, (ln, combo) in enumerate(combos):
             if ln:
@@ -101,24 +106,26 @@ def main():
                 abi.set_path_policy(a.policy)
             for k, v in combo:
                 abi.set_tuning(k, v)
-            ws = None if quant else abi.backward_workspace(x, a.pad, active)
+            ws = None if quant else abi.backward_workspace(x, a.pad, active, borders)
             tag = (ln + ":" if ln else "") + (",".join("%d=%d" % kv for kv in combo) or "default")
             if quant:
                 fns = {"fwd[" + tag + "]": lambda: abi.forward_quantized(x, wq, 128, 0, a.pad, out=out)}
             else:
-                fns = {"fwd[" + tag + "]": lambda: abi.forward(x, w, a.pad, active, out=out),
-                       "bwd[" + tag + "]": lambda: abi.backward(go, w, x, a.pad, active, grad_x=gx, grad_w=gw, workspace=ws)}
+                fns = {"fwd[" + tag + "]": lambda: abi.forward(x, w, a.pad, active, borders, out=out),
+                       "bwd[" + tag + "]": lambda: abi.backward(go, w, x, a.pad, active, borders, grad_x=gx, grad_w=gw, workspace=ws)}
             if ci == 0:
-                fns["copy"] = lambda: out.copy_(x)
+                fns["copy"] = lambda: gx.copy_(x)
             for name, fn in fns.items():
                 fn()
+                kernels.setdefault(name, abi.last_kernel() if name != "copy" else "torch copy")
                 torch.cuda.synchronize()
                 t = ev_time(fn, a.iters)
                 if r > 0:
                     res.setdefault(name, []).append(t)
     print("workload:", desc, "pad", a.pad)
+    print("kernels:", kernels)
     for name, ts in res.items():
-        nbytes = {"c": 2, "f": 2, "b": 3}[name[0]] * es * elems
+        nbytes = {"c": 2 * elems, "f": elems + oelems, "b": 2 * elems + oelems}[name[0]] * es
         print("%-40s min %8.3f ms  med %8.3f ms  %8.1f GB/s (min)" % (name, min(ts), statistics.median(ts),
                                                                        nbytes / min(ts) / 1e6))
 

@@ -398,10 +398,9 @@ __global__ __launch_bounds__(kThreads) void span_backward(const SpanParams p) {
 // exec-mask regions, ~340 scalar instructions per wave -- on C2's tensor cut by one element per side the four waves of a
 // workgroup need 0.57 us of the CU's scalar unit for 11 KB of traffic (4.9 TB/s).  Here, as in step_backward:
 //   * thread (tr, tc) stages piece tc of row tr of every group, nothing is decoded;
-//   * the x corner rows (whole pieces) come by LDS-DMA; the grad_out rows are ragged -- their 16-byte cover starts anywhere
-//     and can be one piece longer than an x row -- and come global -> registers -> LDS through a buffer resource: every load
-//     and every LDS store is unconditional (a lane without a piece loads zeros from an out-of-range offset and parks them in
-//     the unused tail of its slot);
+//   * everything comes by LDS-DMA.  The grad_out rows are ragged -- their 16-byte cover starts anywhere and can be two pieces
+//     longer than an x row -- so those groups have a thread mapping of their own (piece t mod (cpr + 2) of row t div (cpr + 2):
+//     lane-linear in LDS, which is what the DMA needs);
 //   * one read path (ColState), the window mask applied to the result.
 // 2-D, rows of at most 256 chunks; 1-D rows stay with span_backward.
 // ---------------------------------------------------------------------------------------------------------------------
@@ -435,9 +434,6 @@ __global__ __launch_bounds__(kThreads) void crop_backward(const SpanParams p) {
     // grad_out as the TENSOR's stream of 16-byte pieces: this plane starts gph bytes into its first piece
     const int gph = static_cast<int>((static_cast<uint64_t>(plane) * static_cast<uint64_t>(p.g_plane) * ES) & 15u);
     const char *gp16 = reinterpret_cast<const char *>(gp) - gph;
-    const uint32_t gbytes = static_cast<uint32_t>(gph) + static_cast<uint32_t>(p.g_plane) * ES;   // this plane's bytes from gp16 (a whole number of pieces or the tensor's end: host)
-    const __amdgpu_buffer_rsrc_t gres = __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(gp16), 0, (gbytes + 15u) & ~15u, 0x00020000);
-    constexpr uint32_t kOOR = 0x80000000u;
 
     const int tid = static_cast<int>(threadIdx.x);
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -459,30 +455,36 @@ __global__ __launch_bounds__(kThreads) void crop_backward(const SpanParams p) {
         if (sx >= 0) dma_x(sx, tid, R * cpr);
     }
     // ---- grad_out rows: a row's cover = pieces (lo >> 4) .. of the stream, lo = gph + row O2 ES; the slot keeps them from its
-    // first byte, so column j of the row sits at (lo & 15) + j ES.  Piece tc by thread (tr, tc); pieces cpr, cpr + 1 by tc < 2.
+    // first byte, so column j of the row sits at (lo & 15) + j ES.  A cover has up to cpr + 2 pieces, so these groups have their
+    // own thread mapping -- thread t moves piece t mod (cpr + 2) of row t div (cpr + 2): lane-linear in LDS, hence LDS-DMA as well.
+    // (The host picks R with R (cpr + 2) <= 256.)
     auto row_lo = [&](int row) { return gph + row * O2 * ES; };
-    auto cover_off = [&](int row, int piece) {   // byte offset of a cover piece from gp16, or out of range
+    const int PGi = cpr + 2;
+    const int rg = static_cast<int>(fdiv(static_cast<uint32_t>(tid), p.d_P)), pg = tid - rg * PGi;   // (d_P divides by cpr + 2)
+    auto dma_g = [&](int row, int piece, int lds_piece0) {   // piece `piece` of the cover of grad_out row `row`
         const int lo = row_lo(row), p0 = lo >> 4, cnt = ((lo + O2 * ES + 15) >> 4) - p0;
-        return (row >= 0 && piece < cnt) ? static_cast<uint32_t>(p0 + piece) * 16u : kOOR;
+        if (row >= 0 && piece < cnt) {
+            char *dst_wave = tile + (lds_piece0 + wave * 64) * 16;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(gp16 + static_cast<uint32_t>(p0 + piece) * 16u),
+                                             (__attribute__((address_space(3))) void *)dst_wave, 16, 0, 0);
+        }
     };
-    const int ro = (tr < R && tr < Rn && b0 + tr - L1 >= 0 && b0 + tr - L1 < O1) ? b0 + tr - L1 : -1;   // own row
     auto gs_row = [&](int i, bool have) {   // the row grad_x reads at step row i (window coordinates through the row map)
         const int pr = b0 + i - L1;
         const bool dom = have && pr >= 0 && (ACTIVE ? pr <= O1 : pr < O1);
         return dom ? row_map_t<PAD>(pr, d.cg1, O1) : -1;
     };
-    const int rs = gs_row(tr, tr < R && (ACTIVE ? tr <= Rn : tr < Rn));
-    const int rcorner = (ACTIVE && Rn == R && tid < cpr + 2) ? gs_row(R, true) : -1;   // + 1 row of a full step: threads 0 .. cpr + 1
-    const int xt = tc < 2 ? cpr + tc : PG;   // the extra pieces of a row's cover (PG: none)
-    const u4 vo0 = __builtin_amdgcn_raw_buffer_load_b128(gres, cover_off(ro, tc), 0, 0);
-    const u4 vo1 = __builtin_amdgcn_raw_buffer_load_b128(gres, cover_off(ro, xt), 0, 0);
-    const u4 vs0 = __builtin_amdgcn_raw_buffer_load_b128(gres, cover_off(rs, tc), 0, 0);
-    const u4 vs1 = __builtin_amdgcn_raw_buffer_load_b128(gres, cover_off(rs, xt), 0, 0);
-    u4 vc = {0u, 0u, 0u, 0u};
-    if constexpr (ACTIVE) vc = __builtin_amdgcn_raw_buffer_load_b128(gres, cover_off(rcorner, tid), 0, 0);
+    {
+        const int ro = (rg < R && rg < Rn && b0 + rg - L1 >= 0 && b0 + rg - L1 < O1) ? b0 + rg - L1 : -1;   // the step's own rows
+        dma_g(ro, pg, goff / 16);
+        dma_g(gs_row(rg, rg < R && (ACTIVE ? rg <= Rn : rg < Rn)), pg, gsoff / 16);
+        if constexpr (ACTIVE) {
+            if (Rn == R && tid < PGi) dma_g(gs_row(R, true), tid, gsoff / 16 + R * PGi);   // the + 1 row of a full step
+        }
+    }
 
-    // ---- the thread's chunk: column state through the x map, the gradient map (window coordinates) and the plain window ----
-    ColState<E> xm, gm, om;
+    // ---- the thread's chunk: column state through the x map and the gradient map (window coordinates); the window mask ----
+    ColState<E> xm, gm;
     {
         auto affine_state = [&](int first, int len) {
             ColState<E> st;
@@ -493,7 +495,6 @@ __global__ __launch_bounds__(kThreads) void crop_backward(const SpanParams p) {
             for (int e = 0; e <= E; ++e) st.cm[e] = (first + e >= 0 && first + e < len) ? first + e : -1;
             return st;
         };
-        om = affine_state(ji - L2, O2);
         if constexpr (PAD == 0) {
             xm = affine_state(ji - d.cx2, S2);
             gm = affine_state(ji - L2 - d.cg2, O2);
@@ -508,21 +509,7 @@ __global__ __launch_bounds__(kThreads) void crop_backward(const SpanParams p) {
             gm = load_colstate<E>(p.colg + rec);
         }
     }
-    // park the gradient pieces (a lane without one holds zeros and writes them into its slot's unused tail / a dump piece)
-    {
-        const int slot = tr < R ? tr : 0;   // (threads beyond the R rows: zeros into row 0's tail piece... see below)
-        char *dump = tile + gsoff + (R + 1) * RBG;
-        auto park = [&](char *row_base, bool live, int piece, const u4 &v) {
-            char *dst = (live && piece < PG) ? row_base + piece * 16 : dump + (tid & 63) * 16;
-            *reinterpret_cast<u4 *>(__builtin_assume_aligned(dst, 16)) = v;
-        };
-        park(tile + goff + slot * RBG, tr < R, tc, vo0);
-        park(tile + goff + slot * RBG, tr < R, xt, vo1);
-        park(tile + gsoff + slot * RBG, tr < R, tc, vs0);
-        park(tile + gsoff + slot * RBG, tr < R, xt, vs1);
-        if constexpr (ACTIVE) park(tile + gsoff + R * RBG, tid < PG, tid, vc);
-    }
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
     CT part[NDIFF] = {CT(0), CT(0)};
@@ -531,8 +518,10 @@ __global__ __launch_bounds__(kThreads) void crop_backward(const SpanParams p) {
         const CT dw[3] = {static_cast<CT>(d.dw[0]), static_cast<CT>(d.dw[1]), CT(0)};
         const bool in_row = b >= L1 && b < L1 + O1;
         auto row_valid = [&](int pr, int cs, int len) { return PAD != 0 || row_map_t<PAD>(pr, cs, len) >= 0; };
-        S zero;
-        __builtin_memset(&zero, 0, sizeof(S));
+        const S zero = static_cast<S>(0.0f);
+        bool inside[E];   // the chunk's positions inside the window
+#pragma unroll
+        for (int e = 0; e < E; ++e) inside[e] = in_row && ji + e >= L2 && ji + e < L2 + O2;
         Chunk<S, E> res;
         // ---- grad_x -------------------------------------------------------------------------------------------------------
         if constexpr (ACTIVE) {
@@ -550,18 +539,14 @@ __global__ __launch_bounds__(kThreads) void crop_backward(const SpanParams p) {
 #pragma unroll
             for (int e = 0; e < E; ++e) {
                 const CT v[4] = {gv[0][e], gv[1][e], gv[0][e + 1], gv[1][e + 1]};
-                const bool inside = in_row && ji + e >= L2 && ji + e < L2 + O2;
-                res.e[e] = inside ? narrow<T>(interp_t<T, 2>(v, dw)) : zero;
+                res.e[e] = inside[e] ? narrow<T>(interp_t<T, 2>(v, dw)) : zero;
             }
         } else {
             const int srow = in_row ? row_map_t<PAD>(b - L1, d.cg1, O1) : -1;
             S raw[E + 1];
             lds_read_row<S, E>(tile + gsoff + tr * RBG + (row_lo(srow) & 15), srow >= 0, gm, raw);
 #pragma unroll
-            for (int e = 0; e < E; ++e) {
-                const bool inside = in_row && ji + e >= L2 && ji + e < L2 + O2;
-                res.e[e] = inside ? raw[e] : zero;
-            }
+            for (int e = 0; e < E; ++e) res.e[e] = inside[e] ? raw[e] : zero;
         }
         // ---- weight-gradient sums: corners of x against grad_out at the chunk's own position (0 outside the window) --------
         CT xv[2][E + 1];
@@ -572,21 +557,22 @@ __global__ __launch_bounds__(kThreads) void crop_backward(const SpanParams p) {
 #pragma unroll
             for (int e = 0; e <= E; ++e) xv[hb][e] = widen<T>(raw[e]);
         }
-        S graw[E + 1];
-        lds_read_row<S, E>(tile + goff + tr * RBG + (row_lo(b - L1) & 15), in_row, om, graw);
+        // (the own gradient chunk: E elements at column ji - L2 of the row's slot -- clamped to the slot, masked by the window)
+        const S *grow = reinterpret_cast<const S *>(tile + goff + tr * RBG + (in_row ? (row_lo(b - L1) & 15) : 0)) + (in_row ? ji - L2 : 0);
 #pragma unroll
         for (int e = 0; e < E; ++e) {
             const CT v[4] = {xv[0][e], xv[1][e], xv[0][e + 1], xv[1][e + 1]};
             CT df[NDIFF];
             corner_diffs<2, CT>(v, df);
-            const CT gval = widen<T>(graw[e]);
+            const S graw = grow[e];
+            const CT gval = widen<T>(inside[e] ? graw : zero);
 #pragma unroll
             for (int i = 0; i < NDIFF; ++i) part[i] = fma_ct(gval, df[i], part[i]);
         }
         store_chunk<S, E>(gxp + static_cast<int64_t>(b) * S2 + ji, res);
     }
     // ---- this step's sums: DPP tree per wave, the four waves added in fp64 by one thread ----------------------------------
-    double *scratch = reinterpret_cast<double *>(tile + ((gsoff + (R + 1) * RBG + 64 * 16 + 63) & ~63) + 64);
+    double *scratch = reinterpret_cast<double *>(tile + ((gsoff + (R + 1) * RBG + 63) & ~63) + 64);
 #pragma unroll
     for (int i = 0; i < NDIFF; ++i) {
         const CT t = wave_total(part[i]);
@@ -845,11 +831,10 @@ __global__ __launch_bounds__(kThreads) void crop_forward(const SpanFwdParams p) 
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (q >= q1) return;
     auto row_ok = [&](int slot) { return PAD != 0 || row_map_t<PAD>(r0 + slot + L1, cs1, S1) >= 0; };
     const S zero = static_cast<S>(0.0f);   // (a value, not an object the lambdas below could take the address of: that one went to scratch)
-    Chunk<S, E> res;
-    if (j + E <= O2) {   // the chunk lies in one output row
+    if (q < q1 && j + E <= O2) {   // the chunk lies in one output row
+        Chunk<S, E> res;
         const int slot = r - r0;
         if constexpr (ACTIVE) {
             CT xv[2][E + 1];
@@ -871,26 +856,37 @@ __global__ __launch_bounds__(kThreads) void crop_forward(const SpanFwdParams p) 
 #pragma unroll
             for (int e = 0; e < E; ++e) res.e[e] = raw[e];
         }
-    } else {   // it straddles output rows: element by element (clamped reads, then one select each)
+        store_chunk<S, E>(op + e0, res);
+    }
+    // The chunks that straddle output rows -- at most one per row boundary inside the step -- are done afterwards by the first
+    // wave alone, one boundary per lane, element by element (clamped reads, then one select each).  Inside the chunk loop
+    // above they cost every wave the whole element-by-element path: almost every wave of 64 chunks holds one (c2acrop: 258 ->
+    // ~120 vector instructions per wave).
+    if (wave != 0) return;
+    const int rb = r0 + 1 + tid;   // the boundary between output rows rb - 1 and rb
+    const uint32_t fb = static_cast<uint32_t>(rb) * static_cast<uint32_t>(O2);   // its first flat element
+    const int qb = static_cast<int>(fb / E);
+    if (rb > r1 || fb % E == 0 || qb < q0 || qb >= q1) return;
+    Chunk<S, E> res;
+    const int eb = qb * E;
 #pragma unroll
-        for (int e = 0; e < E; ++e) {
-            const int re = static_cast<int>(fdiv(static_cast<uint32_t>(e0 + e), p.d_O2));
-            const int slot = re - r0, je = e0 + e - re * O2;
-            const int m0 = row_map_t<PAD>(je + L2, cs2, S2);
-            auto at = [&](int sl, int m) {
-                const S v = reinterpret_cast<const S *>(tile + sl * RB)[m > 0 ? m : 0];
-                return (m >= 0 && row_ok(sl)) ? v : zero;
-            };
-            if constexpr (ACTIVE) {
-                const int m1 = row_map_t<PAD>(je + L2 + 1, cs2, S2);
-                const CT v[4] = {widen<T>(at(slot, m0)), widen<T>(at(slot + 1, m0)), widen<T>(at(slot, m1)), widen<T>(at(slot + 1, m1))};
-                res.e[e] = narrow<T>(interp_t<T, 2>(v, dw));
-            } else {
-                res.e[e] = at(slot, m0);
-            }
+    for (int e = 0; e < E; ++e) {
+        const int re = static_cast<int>(fdiv(static_cast<uint32_t>(eb + e), p.d_O2));
+        const int slot = re - r0, je = eb + e - re * O2;
+        const int m0 = row_map_t<PAD>(je + L2, cs2, S2);
+        auto at = [&](int sl, int m) {
+            const S v = reinterpret_cast<const S *>(tile + sl * RB)[m > 0 ? m : 0];
+            return (m >= 0 && row_ok(sl)) ? v : zero;
+        };
+        if constexpr (ACTIVE) {
+            const int m1 = row_map_t<PAD>(je + L2 + 1, cs2, S2);
+            const CT v[4] = {widen<T>(at(slot, m0)), widen<T>(at(slot + 1, m0)), widen<T>(at(slot, m1)), widen<T>(at(slot + 1, m1))};
+            res.e[e] = narrow<T>(interp_t<T, 2>(v, dw));
+        } else {
+            res.e[e] = at(slot, m0);
         }
     }
-    store_chunk<S, E>(op + e0, res);
+    store_chunk<S, E>(op + eb, res);
 }
 
 struct SpanFwdPlan {
@@ -959,7 +955,7 @@ SpanPlan span_plan(const Geometry &g, int es) {
     s.nseg = (s.cpr + s.seg - 1) / s.seg;
     s.P = s.seg + 2;
     // rows per step: R * seg threads, and the tile's (3 R + 2) slots of P pieces within the staging rounds
-    int R = std::max(1, kThreads / s.seg);
+    int R = std::max(1, g.nd == 2 ? kThreads / (s.seg + 2) : kThreads / s.seg);   // (2-D: R covers of cpr + 2 pieces per staging pass)
     R = std::max(1, std::min<int>(R, static_cast<int>(g.S[1])));
     if (g.nd == 1 || s.nseg > 1) R = 1;
     s.R = R;
@@ -973,8 +969,8 @@ SpanPlan span_plan(const Geometry &g, int es) {
     s.off_colx = s.off_desc + up(static_cast<size_t>(g.C) * sizeof(ChanDesc));
     s.off_colg = s.off_colx + up(static_cast<size_t>(g.C) * s.cpr * s.rec * sizeof(int16_t));
     s.bytes = s.off_colg + up(static_cast<size_t>(g.C) * s.cpr * s.rec * sizeof(int16_t));
-    if (g.nd == 2) {   // crop_backward: x rows [R + 1][cpr] | own rows [R][cpr + 2] | read rows [R + 1][cpr + 2] | 64 dump pieces
-        const size_t tile = (static_cast<size_t>(R + 1) * s.cpr + static_cast<size_t>(2 * R + 1) * (s.cpr + 2) + 64) * 16;
+    if (g.nd == 2) {   // crop_backward: x rows [R + 1][cpr] | own rows [R][cpr + 2] | read rows [R + 1][cpr + 2]
+        const size_t tile = (static_cast<size_t>(R + 1) * s.cpr + static_cast<size_t>(2 * R + 1) * (s.cpr + 2)) * 16;
         s.lds = 64 + ((tile + 63) & ~static_cast<size_t>(63)) + 64 + (kThreads / 64) * 2 * sizeof(double);
     } else {
         s.lds = 64 + ((static_cast<size_t>(3) * s.P * 16 + 63) & ~static_cast<size_t>(63)) + 64 + (kThreads / 64) * 2 * sizeof(double);
@@ -990,7 +986,7 @@ bool span_geometry_ok(const Geometry &g, int dtype) {
     if ((g.S[2] * es) % 16 != 0 || g.S[2] > 32000) return false;                       // x rows: whole pieces; int16 column tables
     if ((g.N * g.C * g.O[1] * g.O[2] * es) % 16 != 0) return false;                     // grad_out: a whole number of pieces
     if (g.S[1] * g.S[2] >= (1LL << 28) || g.O[1] * g.O[2] >= (1LL << 28)) return false;  // 32-bit byte offsets within a plane
-    if (g.nd == 2 && g.S[2] * es > kThreads * 16) return false;   // crop_backward: rows of at most 256 chunks
+    if (g.nd == 2 && g.S[2] * es > (kThreads - 2) * 16) return false;   // crop_backward: a grad_out row's cover (cpr + 2 pieces) per staging pass
     const SpanPlan s = span_plan(g, es);
     return s.total + 8 < (1ull << 31) && s.lds <= 64 * 1024;
 }
@@ -1143,7 +1139,7 @@ static void launch_span_backward(const SpanParams &p, const SpanPlan &sp, bool a
 #define SHIFTND_SPAN_PAD(ACT, PADV) \
     case PADV: \
         if constexpr (ND == 2) hipLaunchKernelGGL((crop_backward<T, ACT, PADV>), grid, block, sp.lds, st, p); \
-        else hipLaunchKernelGGL((span_backward<T, ND, ACT, PADV>), grid, block, sp.lds, st, p); \
+        else hipLaunchKernelGGL((span_backward<T, 1, ACT, PADV>), grid, block, sp.lds, st, p);   /* (span_backward<..., 2, ...> is not instantiated) */ \
         break;
     if (active) {
         hipLaunchKernelGGL((span_prep<T, true>), dim3(p.C), block, 0, st, p);

@@ -1,26 +1,33 @@
 // shiftnd_span.hip -- the one-step sweep for the tensors the reference's users actually have (round 4): CROPPED
 // 2-D windows (every depthwise-conv emulation with padding < kernel / 2: modules/shifts.py:41-46, ops/shifts.cpp:93-135 -- the
 // reference's own test script is N512 C16 64x64 cut to 62x62) and Shift1d (functional.py:7-36), whose rows can be longer than
-// one workgroup pass.  step_backward (shiftnd_step.hip) needs grad_out rows that are whole 16-byte pieces at the positions
-// of the x rows; a cropped grad_out has neither (222 fp32 = 888 bytes per row, shifted by the window's corner).
+// one workgroup pass.  The one-step kernels of shiftnd_step*.hip need rows that are whole 16-byte pieces at matching positions
+// in every tensor; a cropped grad_out / output has neither (222 fp32 = 888 bytes per row, shifted by the window's corner).
 //
-// Same shape as step_backward -- one step per workgroup, workgroups in address order, LDS-DMA staging, one barrier, a DPP
-// wave tree and one partial record per step -- with the staging generalised to SPANS: every source row a step needs (corner
-// rows of x, the grad_out rows at the step's own rows, the grad_out rows grad_x gathers or blends) is one slot of the tile,
-// filled with the 16-byte pieces of the TENSOR's byte stream that cover the needed columns of that row; a slot remembers the
-// byte phase of its row (grad_out rows start anywhere), and the window reads go element by element through ColState
-// (shiftnd_stage.hpp) as everywhere.  A step is R rows x one column segment of at most 256 chunks of the x plane: 1-D rows of
-// any length are walked segment by segment, each staging only the columns its windows reach.
+// Same shape as step_backward -- one step per workgroup, workgroups in address order, LDS-DMA staging, one barrier, a DPP wave
+// tree and one partial record per step -- with the ragged tensor addressed as the TENSOR's stream of 16-byte pieces: a staged
+// row is the pieces that cover it, and remembers the byte phase of its first column.
 //
-//   span_prep      per channel: weight preparation (cpu/shifts_cpu.cpp:242-244), canonical shifts of the x maps over the
-//                  input sizes and of the gradient maps over the WINDOW sizes (the reference pads grad_out with the cropped
-//                  sizes, kernels/shifts_kernels.h:295-297, :319-324), column tables for the paddings other than zeros
-//   span_backward  the step kernel: grad_x (zero outside the window: shifts_kernels.h:271, :314) and the step's sums of
-//                  g * corner difference
-//   step_reduce    (shiftnd_step.hpp) the channel sums and the blends, as for step_backward
+//   span_prep       per channel: weight preparation (cpu/shifts_cpu.cpp:242-244), canonical shifts of the x maps over the input
+//                   sizes and of the gradient maps over the WINDOW sizes (the reference pads grad_out with the cropped sizes,
+//                   kernels/shifts_kernels.h:295-297, :319-324), column tables for the paddings other than zeros
+//   crop_backward   2-D: grad_x (zero outside the window: shifts_kernels.h:271, :314) and the step's sums of g * corner
+//                   difference; R rows of the x plane per step
+//   crop_forward    2-D: a step is 256 consecutive chunks of the OUTPUT plane's byte stream (ragged output rows), the source
+//                   rows they read staged whole; the chunks that straddle output rows are done once per workgroup by one wave
+//   row_backward /  1-D: a step is a segment of 256 chunks of a row and stages only the columns its windows reach
+//   row_forward
+//   span_forward    the general form of crop_forward (source rows with ragged pieces too, slots decoded per piece, three read
+//                   paths): what crop_forward does not take; 1100 instructions against 400, 4.2 against 6.1 TB/s -- kept for the
+//                   inputs whose own rows are ragged (62 x 62, cut)
+//   step_reduce     (shiftnd_step.hpp) the channel sums and the blends, as for step_backward
 //
-// Reference behaviour restated: kernels/shifts_kernels.h:222-327, :132-154; interpolation.h:3-31.  Roofline: HBM, 3 s bytes
-// per element of the uncropped tensor minus the cropped margin of grad_out.
+// Lesson of the first version (span_backward, removed): a kernel this short lives or dies by its control flow -- 2500
+// instructions, 113 exec-mask regions and ~340 scalar instructions per wave kept the CU's one scalar unit busy for 0.57 us per
+// workgroup of 11 KB (4.9 TB/s); the lean kernels issue ~200 vector + ~120 scalar instructions per wave (6.0 - 6.3 TB/s).
+//
+// Reference behaviour restated: kernels/shifts_kernels.h:156-220, :222-327, :132-154; interpolation.h:3-31.  Roofline: HBM, 2 s /
+// 3 s bytes per element (the window's size for the output / the incoming gradient).
 #include "shiftnd_step.hpp"
 
 namespace shiftnd {
@@ -43,7 +50,6 @@ struct SpanParams {
     int cpr, seg, nseg;  // 16-byte chunks per x row, chunks per column segment (<= 256), segments per row
     int R, rsteps, spp;  // rows per step, row steps per plane, steps per plane = rsteps * nseg
     int P;               // pieces per slot
-    int U;               // chunks per thread (1; up to 4 for 1-D rows longer than 256 chunks: seg = 256 U chunks, one row per step)
     uint32_t total_steps, steps_per_xcd;
     FastDiv d_spp, d_C, d_seg, d_nseg, d_P, d_per1x, d_per2x, d_per1g, d_per2g;
 };
@@ -129,280 +135,14 @@ __device__ __forceinline__ void span_read(const char *lds_row, const S *mem_row,
     lds_read_row<S, E>(lds_row, valid, c, raw);
 }
 
-template <typename T, int ND, bool ACTIVE, int PAD>
-__global__ __launch_bounds__(kThreads) void span_backward(const SpanParams p) {
-    using S = typename T::S;
-    using CT = typename T::C;
-    constexpr int ES = sizeof(S);
-    constexpr int E = 16 / ES;
-    constexpr int REC = RecSize<E>::N;
-    constexpr int NDIFF = WDiff<ND>::N;
-    constexpr int NCC = 1 << (ND - 1);   // corner rows per element
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    char *tile = smem + 64;  // 64-byte pads in front and behind: see lds_read_row
-
-    const uint32_t bid = (blockIdx.x & 7u) * p.steps_per_xcd + (blockIdx.x >> 3);  // XCD-contiguous step ids
-    if (bid >= p.total_steps) return;
-    const uint32_t plane = fdiv(bid, p.d_spp);   // (n, c)
-    const uint32_t vstep = bid - plane * static_cast<uint32_t>(p.spp);
-    const int rstep = static_cast<int>(fdiv(vstep, p.d_nseg));
-    const int sg = static_cast<int>(vstep) - rstep * p.nseg;
-    const int c = static_cast<int>(plane - fdiv(plane, p.d_C) * static_cast<uint32_t>(p.C));
-    const ChanDesc d = p.desc[c];
-    const int R = p.R, S1 = p.S1, S2 = p.S2, O1 = p.O1, O2 = p.O2, L1 = p.L1, L2 = p.L2, cpr = p.cpr, P = p.P;
-    const int b0 = rstep * R;
-    const int Rn = min(R, S1 - b0);
-    const bool whole = p.nseg == 1;   // the step spans whole rows: every column of a staged row is in LDS
-    // tile slots: x corner rows [NX], grad_out at the step's own rows [NG], the grad_out rows grad_x reads [NGS]
-    const int NX = ND == 2 ? R + 1 : 1, NG = ND == 2 ? R : 1;
-    const int NGS = ND == 2 ? (ACTIVE ? R + 1 : R) : 1;
-    // the column segment and the columns of each tensor its windows reach (whole rows when there is one segment)
-    const int J0 = sg * p.seg * E, J1 = min(S2, J0 + p.seg * E);
-    auto clampi = [](int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); };
-    const int xc0 = whole ? 0 : clampi(J0 - d.cx2, 0, S2), xc1 = whole ? S2 : clampi(J1 - d.cx2 + 1, 0, S2);
-    const int oc0 = whole ? 0 : clampi(J0 - L2, 0, O2), oc1 = whole ? O2 : clampi(J1 - L2, 0, O2);
-    const int sc0 = whole ? 0 : clampi(J0 - L2 - d.cg2, 0, O2), sc1 = whole ? O2 : clampi(J1 - L2 - d.cg2 + 1, 0, O2);
-    const S *xp = static_cast<const S *>(p.x) + static_cast<int64_t>(plane) * p.x_plane;
-    const S *gp = static_cast<const S *>(p.go) + static_cast<int64_t>(plane) * p.g_plane;
-    S *gxp = static_cast<S *>(p.out) + static_cast<int64_t>(plane) * p.x_plane;
-    // grad_out is addressed as the TENSOR's stream of 16-byte pieces (its planes and rows start anywhere): the byte offset of
-    // this plane within its first piece
-    const int gph = static_cast<int>((static_cast<uint64_t>(plane) * static_cast<uint64_t>(p.g_plane) * ES) & 15u);
-    const char *gp16 = reinterpret_cast<const char *>(gp) - gph;   // 16-byte aligned (the tensor's base is)
-
-    const int tid = static_cast<int>(threadIdx.x);
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    // a slot's source: which row of which tensor, which columns; -> first byte (plane-relative), bytes
-    // bytes [lo, hi) relative to `base` (16-byte aligned); valid: the row exists (a row of the wrapping / clamping paddings exists
-    // even when no column of the plain shift does: its chunks then read through their maps)
-    struct Src { const char *base; int lo, hi; bool valid; };
-    auto slot_src = [&](int slot) {
-        Src s;
-        if (slot < NX) {
-            const int i = slot;
-            const int row = ND == 2 ? row_map_t<PAD>(b0 + i, d.cx1, S1) : 0;
-            s.base = reinterpret_cast<const char *>(xp);
-            s.valid = i <= (ND == 2 ? Rn : 0) && row >= 0;
-            s.lo = (row * S2 + xc0) * ES;
-            s.hi = (row * S2 + xc1) * ES;
-        } else if (slot < NX + NG) {
-            const int i = slot - NX;
-            const int row = b0 + i - L1;
-            s.base = gp16;
-            s.valid = i < Rn && row >= 0 && row < O1;
-            s.lo = gph + (row * O2 + oc0) * ES;
-            s.hi = gph + (row * O2 + oc1) * ES;
-        } else {
-            const int i = slot - NX - NG;
-            const int pr = b0 + i - L1;   // window coordinate of the row (the map is defined on [0, O1])
-            const bool dom = pr >= 0 && (ACTIVE ? pr <= O1 : pr < O1) && i < (ACTIVE && ND == 2 ? Rn + 1 : Rn);
-            const int row = dom ? (ND == 2 ? row_map_t<PAD>(pr, d.cg1, O1) : 0) : -1;
-            s.base = gp16;
-            s.valid = row >= 0;
-            s.lo = gph + (row * O2 + sc0) * ES;
-            s.hi = gph + (row * O2 + sc1) * ES;
-        }
-        return s;
-    };
-    // ---- stage: piece q of the tile = piece (q mod P) of slot (q div P); a wave's pieces are consecutive, the LDS destination
-    // is a wave-uniform base (the hardware adds lane * 16)
-    const int npieces = (NX + NG + NGS) * P;
-    auto stage_round = [&](int k) {
-        const int q = k * kThreads + tid;
-        const int slot = static_cast<int>(fdiv(static_cast<uint32_t>(q), p.d_P));
-        const int piece = q - slot * P;
-        const Src s = slot_src(slot);
-        const int p0 = s.lo >> 4, cnt = ((s.hi + 15) >> 4) - p0;
-        if (q < npieces && s.valid && piece < cnt) {   // (cnt <= 0: no column of this row is staged)
-            char *dst_wave = tile + (k * kThreads + wave * 64) * 16;
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(s.base + static_cast<int64_t>(p0 + piece) * 16),
-                                             (__attribute__((address_space(3))) void *)dst_wave, 16, 0, 0);
-        }
-    };
-    if (p.U == 1) {
-#pragma unroll
-        for (int k = 0; k < kSpanRounds; ++k)
-            if (k * kThreads < npieces) stage_round(k);   // uniform
-    } else {   // long 1-D rows, several chunks per thread: up to 13 rounds
-        for (int k = 0; k * kThreads < npieces; ++k) stage_round(k);
-    }
-
-    // ---- a thread's chunk: position, column state through the x map, the gradient map (window coordinates) and the plain window.
-    // U chunks per thread (U > 1: one row per step, chunk tid + u * 256 of the segment)
-    struct ChunkState {
-        int tr, jc, ji;
-        bool mine, xs, gs;
-        ColState<E> xm, gm, om;
-    };
-    // are all columns of a chunk's window among the staged ones [c0, c1) of its tensor's rows
-    auto in_span = [&](const ColState<E> &st, int c0, int c1) {
-        bool ok = st.affine;
-#pragma unroll
-        for (int e = 0; e <= E; ++e) ok = ok && (st.cm[e] < 0 || (st.cm[e] >= c0 && st.cm[e] < c1));
-        return ok;
-    };
-    auto chunk_state = [&](int u) {
-        ChunkState cs;
-        const int tr = p.U == 1 ? static_cast<int>(fdiv(static_cast<uint32_t>(tid), p.d_seg)) : 0;
-        const int tc = p.U == 1 ? tid - tr * p.seg : tid + u * kThreads;
-        const int jc = sg * p.seg + tc;   // chunk of the x row
-        const int ji = jc * E;
-        const bool mine = tr < Rn && tc < p.seg && jc < cpr;
-        ColState<E> xm, gm, om;
-        {
-            // entry e = column first + e when that is a column; `safe`: a staged column for a chunk without any (every entry masked)
-            auto affine_state = [&](int first, int len, int safe) {
-                ColState<E> st;
-                st.base = first;
-                if (first + E < 0 || first >= len) st.base = safe;
-                st.affine = true;
-#pragma unroll
-                for (int e = 0; e <= E; ++e) st.cm[e] = (first + e >= 0 && first + e < len) ? first + e : -1;
-                return st;
-            };
-            om = affine_state(ji - L2, O2, oc0);   // grad_out at the chunk's own columns
-            if constexpr (PAD == 0) {
-                xm = affine_state(ji - d.cx2, S2, xc0);
-                gm = affine_state(ji - L2 - d.cg2, O2, sc0);
-                if (O2 == 1) {   // a window one column wide ignores the shift (shifts_kernels.h:40-48): both corners read column 0
-                    gm.affine = false;
-#pragma unroll
-                    for (int e = 0; e <= E; ++e) gm.cm[e] = (ji - L2 + e >= 0 && ji - L2 + e <= 1) ? 0 : -1;
-                }
-            } else {
-                const size_t rec = (static_cast<size_t>(c) * cpr + (mine ? jc : 0)) * REC;
-                xm = load_colstate<E>(p.colx + rec);
-                gm = load_colstate<E>(p.colg + rec);
-                bool any = false;   // a chunk outside the window has no gradient column at all: keep its reads inside the slot
-#pragma unroll
-                for (int e = 0; e <= E; ++e) any = any || gm.cm[e] >= 0;
-                if (!any) {
-                    gm.base = sc0;
-                    gm.affine = true;
-                }
-            }
-        }
-        cs.tr = tr;
-        cs.jc = jc;
-        cs.ji = ji;
-        cs.mine = mine;
-        cs.xm = xm;
-        cs.gm = gm;
-        cs.om = om;
-        cs.xs = whole || in_span(xm, xc0, xc1);
-        cs.gs = whole || in_span(gm, sc0, sc1);
-        return cs;
-    };
-    const ChunkState first = chunk_state(0);   // (its table loads -- paddings other than zeros -- travel with the staged rows)
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    CT part[NDIFF];
-#pragma unroll
-    for (int i = 0; i < NDIFF; ++i) part[i] = CT(0);
-    for (int u = 0; u < p.U; ++u) {
-    const ChunkState cs = u == 0 ? first : chunk_state(u);
-    const int tr = cs.tr, ji = cs.ji;
-    const bool mine = cs.mine, xs = cs.xs, gs = cs.gs;
-    const ColState<E> &xm = cs.xm, &gm = cs.gm, &om = cs.om;
-    if (mine) {
-        const int b = b0 + tr;
-        const CT dw[3] = {static_cast<CT>(d.dw[0]), static_cast<CT>(d.dw[1]), CT(0)};
-        // first byte of a staged row's column 0 within its slot (may lie in front of the slot: only staged columns are read)
-        auto slot_row = [&](int slot, const Src &s, int c0) { return tile + slot * P * 16 + (s.lo & 15) - c0 * ES; };
-        auto corner_row = [](int k) { return ND == 2 ? (k & 1) : 0; };
-        const bool in_row = b >= L1 && b < L1 + O1;
-        S zero;
-        __builtin_memset(&zero, 0, sizeof(S));
-        Chunk<S, E> res;
-        // ---- grad_x ----------------------------------------------------------------------------------------------------
-        if constexpr (ACTIVE) {
-            CT gv[NCC][E + 1];
-#pragma unroll
-            for (int k = 0; k < NCC; ++k) {
-                const int slot = NX + NG + tr + corner_row(k);
-                const Src s = slot_src(slot);
-                S raw[E + 1];
-                span_read<S, E>(slot_row(slot, s, sc0), reinterpret_cast<const S *>(s.base + s.lo) - sc0, gs, in_row && s.valid, gm, raw);
-#pragma unroll
-                for (int e = 0; e <= E; ++e) gv[k][e] = widen<T>(raw[e]);
-            }
-#pragma unroll
-            for (int e = 0; e < E; ++e) {
-                CT v[1 << ND];
-#pragma unroll
-                for (int q = 0; q < (1 << ND); ++q) v[q] = gv[q & (NCC - 1)][e + (q >> (ND - 1))];
-                const bool inside = in_row && ji + e >= L2 && ji + e < L2 + O2;
-                res.e[e] = inside ? narrow<T>(interp_t<T, ND>(v, dw)) : zero;
-            }
-        } else {
-            const int slot = NX + NG + tr;
-            const Src s = slot_src(slot);
-            S raw[E + 1];
-            span_read<S, E>(slot_row(slot, s, sc0), reinterpret_cast<const S *>(s.base + s.lo) - sc0, gs, in_row && s.valid, gm, raw);
-#pragma unroll
-            for (int e = 0; e < E; ++e) {
-                const bool inside = in_row && ji + e >= L2 && ji + e < L2 + O2;
-                res.e[e] = inside ? raw[e] : zero;
-            }
-        }
-        // ---- weight-gradient sums: corners of x against grad_out at the chunk's own position (0 outside the window) ---------
-        CT xv[NCC][E + 1];
-#pragma unroll
-        for (int k = 0; k < NCC; ++k) {
-            const int slot = tr + corner_row(k);
-            const Src s = slot_src(slot);
-            S raw[E + 1];
-            span_read<S, E>(slot_row(slot, s, xc0), reinterpret_cast<const S *>(s.base + s.lo) - xc0, xs, s.valid, xm, raw);
-#pragma unroll
-            for (int e = 0; e <= E; ++e) xv[k][e] = widen<T>(raw[e]);
-        }
-        S graw[E + 1];
-        {
-            const int slot = NX + tr;
-            const Src s = slot_src(slot);
-            lds_read_row<S, E>(slot_row(slot, s, oc0), s.valid, om, graw);
-        }
-#pragma unroll
-        for (int e = 0; e < E; ++e) {
-            CT v[1 << ND], df[NDIFF];
-#pragma unroll
-            for (int q = 0; q < (1 << ND); ++q) v[q] = xv[q & (NCC - 1)][e + (q >> (ND - 1))];
-            corner_diffs<ND, CT>(v, df);
-            const CT gval = widen<T>(graw[e]);
-#pragma unroll
-            for (int i = 0; i < NDIFF; ++i) part[i] = fma_ct(gval, df[i], part[i]);
-        }
-        store_chunk<S, E>(gxp + static_cast<int64_t>(b) * S2 + ji, res);
-    }
-    }   // u
-    // ---- this step's sums: DPP tree per wave, the four waves added in fp64 by one thread ----------------------------------
-    double *scratch = reinterpret_cast<double *>(tile + ((npieces * 16 + 63) & ~63) + 64);
-#pragma unroll
-    for (int i = 0; i < NDIFF; ++i) {
-        const CT t = wave_total(part[i]);
-        if ((tid & 63) == 63) scratch[NDIFF * wave + i] = static_cast<double>(t);
-    }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // (explicit wait + clobber at every barrier: see walk_barrier, shiftnd_walk.hip)
-    __syncthreads();
-    if (tid < NDIFF) {
-        double acc = 0.0;
-#pragma unroll
-        for (int w = 0; w < kThreads / 64; ++w) acc += scratch[NDIFF * w + tid];
-        p.partials[static_cast<size_t>(bid) * NDIFF + tid] = acc;
-    }
-}
-
 // ---------------------------------------------------------------------------------------------------------------------
-// crop_backward: the 2-D cropped backward in step_backward's shape and at its instruction count.  span_backward above is
-// general (segments, slots decoded per piece, three read paths) and pays for it in control flow: 2500 instructions, 113
-// exec-mask regions, ~340 scalar instructions per wave -- on C2's tensor cut by one element per side the four waves of a
-// workgroup need 0.57 us of the CU's scalar unit for 11 KB of traffic (4.9 TB/s).  Here, as in step_backward:
+// crop_backward: the 2-D cropped backward in step_backward's shape and at its instruction count.  As in step_backward:
 //   * thread (tr, tc) stages piece tc of row tr of every group, nothing is decoded;
 //   * everything comes by LDS-DMA.  The grad_out rows are ragged -- their 16-byte cover starts anywhere and can be two pieces
 //     longer than an x row -- so those groups have a thread mapping of their own (piece t mod (cpr + 2) of row t div (cpr + 2):
 //     lane-linear in LDS, which is what the DMA needs);
 //   * one read path (ColState), the window mask applied to the result.
-// 2-D, rows of at most 256 chunks; 1-D rows stay with span_backward.
+// 2-D, rows of at most 254 chunks (wider cropped rows: the per-channel kernels); 1-D: row_backward.
 // ---------------------------------------------------------------------------------------------------------------------
 template <typename T, bool ACTIVE, int PAD>
 __global__ __launch_bounds__(kThreads) void crop_backward(const SpanParams p) {
@@ -412,7 +152,6 @@ __global__ __launch_bounds__(kThreads) void crop_backward(const SpanParams p) {
     constexpr int E = 16 / ES;
     constexpr int REC = RecSize<E>::N;
     constexpr int NDIFF = 2;
-    typedef uint32_t u4 __attribute__((ext_vector_type(4)));
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char *tile = smem + 64;  // 64-byte pads in front and behind: see lds_read_row
 
@@ -889,6 +628,220 @@ __global__ __launch_bounds__(kThreads) void crop_forward(const SpanFwdParams p) 
     store_chunk<S, E>(op + eb, res);
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// row_forward / row_backward: Shift1d (functional.py:7-36) in the same lean shape.  A plane is one row; a step is a segment
+// of 256 chunks of it and stages only the source columns its windows reach (at most 258 pieces per tensor: 256 by thread t,
+// the rest by the first threads in a second DMA).  Chunks whose columns are not all among the staged ones -- the row ends of
+// the wrapping / clamping / reflecting paddings -- read element by element from memory.
+// ---------------------------------------------------------------------------------------------------------------------
+template <typename T, bool ACTIVE, int PAD>
+__global__ __launch_bounds__(kThreads) void row_forward(const SpanFwdParams p) {
+    using S = typename T::S;
+    using CT = typename T::C;
+    constexpr int ES = sizeof(S);
+    constexpr int E = 16 / ES;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char *tile = smem + 64;
+
+    const uint32_t bid = (blockIdx.x & 7u) * p.steps_per_xcd + (blockIdx.x >> 3);
+    if (bid >= p.total_steps) return;
+    const uint32_t plane = fdiv(bid, p.d_spp);
+    const int step = static_cast<int>(bid - plane * static_cast<uint32_t>(p.spp));
+    const int c = static_cast<int>(plane - fdiv(plane, p.d_C) * static_cast<uint32_t>(p.C));
+    CT wv[3];
+    load_weights_nd<CT>(p.w, p.wkind, c, 1, wv);
+    const CT rc = ACTIVE ? c_floor<CT>(wv[2]) : c_rint<CT>(wv[2]);
+    const CT dw[1] = {ACTIVE ? wv[2] - rc : CT(0)};
+    const int S2 = p.S2, L2 = p.L2;
+    const int cs2 = __builtin_amdgcn_readfirstlane(canon_of<PAD, CT>(rc, S2, p.d_per2));
+    const int q0 = step * kThreads, q1 = min(p.ocp, q0 + kThreads);
+    auto clampi = [](int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); };
+    const int a0 = clampi(q0 * E + L2 - cs2, 0, S2), a1 = clampi(q1 * E + L2 - cs2 + (ACTIVE ? 1 : 0), 0, S2);   // staged columns [a0, a1)
+    const int plo = (a0 * ES) >> 4, np = a1 > a0 ? ((a1 * ES + 15) >> 4) - plo : 0;
+    const S *xp = static_cast<const S *>(p.x) + static_cast<int64_t>(plane) * p.x_plane;
+    S *op = static_cast<S *>(p.out) + static_cast<int64_t>(plane) * p.o_plane;
+    const int tid = static_cast<int>(threadIdx.x);
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    auto dma = [&](int piece, int lds_piece0) {
+        char *dst_wave = tile + (lds_piece0 + wave * 64) * 16;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(reinterpret_cast<const char *>(xp) + static_cast<uint32_t>(plo + piece) * 16u),
+                                         (__attribute__((address_space(3))) void *)dst_wave, 16, 0, 0);
+    };
+    if (tid < np) dma(tid, 0);
+    if (wave == 0 && tid + kThreads < np) dma(tid + kThreads, kThreads);
+    const int q = q0 + tid;
+    const int j = q * E;
+    ColState<E> xm;
+    if constexpr (PAD == 0) {
+        const int first = j + L2 - cs2;
+        xm.base = (first + E < 0 || first >= S2) ? a0 : first;
+        xm.affine = true;
+#pragma unroll
+        for (int e = 0; e <= E; ++e) xm.cm[e] = (first + e >= 0 && first + e < S2) ? first + e : -1;
+    } else {
+        xm = fold_colstate<E, PAD>(j + L2, cs2, S2);
+    }
+    bool staged = xm.affine;
+    if constexpr (PAD != 0) {
+#pragma unroll
+        for (int e = 0; e <= E; ++e) staged = staged && (xm.cm[e] >= a0 && xm.cm[e] < a1);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (q >= q1) return;
+    S raw[E + 1];
+    if (PAD == 0 || staged) {
+        lds_read_row<S, E>(tile - plo * 16, true, xm, raw);
+    } else {
+        const S zero = static_cast<S>(0.0f);
+#pragma unroll
+        for (int e = 0; e <= E; ++e) raw[e] = xm.cm[e] >= 0 ? xp[xm.cm[e]] : zero;
+    }
+    Chunk<S, E> res;
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        if constexpr (ACTIVE) {
+            const CT v[2] = {widen<T>(raw[e]), widen<T>(raw[e + 1])};
+            res.e[e] = narrow<T>(interp_t<T, 1>(v, dw));
+        } else {
+            res.e[e] = raw[e];
+        }
+    }
+    store_chunk<S, E>(op + j, res);
+}
+
+template <typename T, bool ACTIVE, int PAD>
+__global__ __launch_bounds__(kThreads) void row_backward(const SpanParams p) {
+    using S = typename T::S;
+    using CT = typename T::C;
+    constexpr int ES = sizeof(S);
+    constexpr int E = 16 / ES;
+    constexpr int REC = RecSize<E>::N;
+    constexpr int SLOT = (kThreads + 3) * 16;   // bytes per staged span (258 pieces + one of slack)
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char *tile = smem + 64;
+
+    const uint32_t bid = (blockIdx.x & 7u) * p.steps_per_xcd + (blockIdx.x >> 3);
+    if (bid >= p.total_steps) return;
+    const uint32_t plane = fdiv(bid, p.d_spp);   // (n, c): one row
+    const int sg = static_cast<int>(bid - plane * static_cast<uint32_t>(p.spp));
+    const int c = static_cast<int>(plane - fdiv(plane, p.d_C) * static_cast<uint32_t>(p.C));
+    const ChanDesc d = p.desc[c];
+    const int S2 = p.S2, O2 = p.O2, L2 = p.L2, cpr = p.cpr;
+    const int J0 = sg * kThreads * E, J1 = min(S2, J0 + kThreads * E);   // the segment's columns of the x row
+    auto clampi = [](int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); };
+    const S *xp = static_cast<const S *>(p.x) + static_cast<int64_t>(plane) * p.x_plane;
+    const S *gp = static_cast<const S *>(p.go) + static_cast<int64_t>(plane) * p.g_plane;
+    S *gxp = static_cast<S *>(p.out) + static_cast<int64_t>(plane) * p.x_plane;
+    const int gph = static_cast<int>((static_cast<uint64_t>(plane) * static_cast<uint64_t>(p.g_plane) * ES) & 15u);
+    const char *gp16 = reinterpret_cast<const char *>(gp) - gph;
+    // staged columns of the three spans and their first pieces (x: row-relative; grad_out: relative to gp16)
+    const int xa0 = clampi(J0 - d.cx2, 0, S2), xa1 = clampi(J1 - d.cx2 + 1, 0, S2);
+    const int oa0 = clampi(J0 - L2, 0, O2), oa1 = clampi(J1 - L2, 0, O2);
+    const int sa0 = clampi(J0 - L2 - d.cg2, 0, O2), sa1 = clampi(J1 - L2 - d.cg2 + (ACTIVE ? 1 : 0), 0, O2);
+    const int xlo = (xa0 * ES) >> 4, xn = xa1 > xa0 ? ((xa1 * ES + 15) >> 4) - xlo : 0;
+    const int olo = (gph + oa0 * ES) >> 4, on = oa1 > oa0 ? ((gph + oa1 * ES + 15) >> 4) - olo : 0;
+    const int slo = (gph + sa0 * ES) >> 4, sn = sa1 > sa0 ? ((gph + sa1 * ES + 15) >> 4) - slo : 0;
+    const int tid = static_cast<int>(threadIdx.x);
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    auto dma = [&](const char *base16, int piece, int lds_byte0) {
+        char *dst_wave = tile + lds_byte0 + wave * 64 * 16;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(base16 + static_cast<uint32_t>(piece) * 16u),
+                                         (__attribute__((address_space(3))) void *)dst_wave, 16, 0, 0);
+    };
+    if (tid < xn) dma(reinterpret_cast<const char *>(xp), xlo + tid, 0);
+    if (tid < on) dma(gp16, olo + tid, SLOT);
+    if (tid < sn) dma(gp16, slo + tid, 2 * SLOT);
+    if (wave == 0) {   // the pieces beyond 256 of each span: a handful of lanes
+        if (tid + kThreads < xn) dma(reinterpret_cast<const char *>(xp), xlo + kThreads + tid, kThreads * 16);
+        if (tid + kThreads < on) dma(gp16, olo + kThreads + tid, SLOT + kThreads * 16);
+        if (tid + kThreads < sn) dma(gp16, slo + kThreads + tid, 2 * SLOT + kThreads * 16);
+    }
+    const int jc = sg * kThreads + tid, ji = jc * E;
+    const bool mine = jc < cpr;
+    ColState<E> xm, gm;
+    {
+        auto affine_state = [&](int first, int len, int safe) {
+            ColState<E> st;
+            st.base = first;
+            if (first + E < 0 || first >= len) st.base = safe;
+            st.affine = true;
+#pragma unroll
+            for (int e = 0; e <= E; ++e) st.cm[e] = (first + e >= 0 && first + e < len) ? first + e : -1;
+            return st;
+        };
+        if constexpr (PAD == 0) {
+            xm = affine_state(ji - d.cx2, S2, xa0);
+            gm = affine_state(ji - L2 - d.cg2, O2, sa0);
+            if (O2 == 1) {   // a window one column wide ignores the shift: both corners read column 0
+                gm.affine = false;
+#pragma unroll
+                for (int e = 0; e <= E; ++e) gm.cm[e] = (ji - L2 + e >= 0 && ji - L2 + e <= 1) ? 0 : -1;
+            }
+        } else {
+            const size_t rec = (static_cast<size_t>(c) * cpr + (mine ? jc : 0)) * REC;
+            xm = load_colstate<E>(p.colx + rec);
+            gm = load_colstate<E>(p.colg + rec);
+        }
+    }
+    auto in_span = [&](const ColState<E> &st, int c0, int c1) {
+        bool ok = st.affine;
+#pragma unroll
+        for (int e = 0; e <= E; ++e) ok = ok && (st.cm[e] < 0 || (st.cm[e] >= c0 && st.cm[e] < c1));
+        return ok;
+    };
+    const bool xs = (PAD == 0 && O2 != 1) || in_span(xm, xa0, xa1), gs = (PAD == 0 && O2 != 1) || in_span(gm, sa0, sa1);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    CT part = CT(0);
+    if (mine) {
+        const CT dw[1] = {static_cast<CT>(d.dw[0])};
+        const S zero = static_cast<S>(0.0f);
+        bool inside[E];
+#pragma unroll
+        for (int e = 0; e < E; ++e) inside[e] = ji + e >= L2 && ji + e < L2 + O2;
+        auto read = [&](const char *lds_col0, const S *mem_col0, bool staged, const ColState<E> &st, S (&raw)[E + 1]) {
+            if (staged) {
+                lds_read_row<S, E>(lds_col0, true, st, raw);
+            } else {
+#pragma unroll
+                for (int e = 0; e <= E; ++e) raw[e] = st.cm[e] >= 0 ? mem_col0[st.cm[e]] : zero;
+            }
+        };
+        S xr[E + 1], gr[E + 1];
+        read(tile - xlo * 16, xp, xs, xm, xr);
+        read(tile + 2 * SLOT - slo * 16 + gph, gp, gs, gm, gr);
+        const S *own = reinterpret_cast<const S *>(tile + SLOT - olo * 16 + gph);   // column 0 of the own-gradient span
+        Chunk<S, E> res;
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+            const S gl = own[clampi(ji - L2 + e, oa0, max(oa0, oa1 - 1))];   // (clamped into the staged columns, then masked)
+            const S g = inside[e] ? gl : zero;
+            part = fma_ct(widen<T>(g), widen<T>(xr[e + 1]) - widen<T>(xr[e]), part);
+            if constexpr (ACTIVE) {
+                const CT v[2] = {widen<T>(gr[e]), widen<T>(gr[e + 1])};
+                res.e[e] = inside[e] ? narrow<T>(interp_t<T, 1>(v, dw)) : zero;
+            } else {
+                res.e[e] = inside[e] ? gr[e] : zero;
+            }
+        }
+        store_chunk<S, E>(gxp + ji, res);
+    }
+    double *scratch = reinterpret_cast<double *>(tile + 3 * SLOT + 64);
+    {
+        const CT t = wave_total(part);
+        if ((tid & 63) == 63) scratch[wave] = static_cast<double>(t);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) {
+        double acc = 0.0;
+#pragma unroll
+        for (int w = 0; w < kThreads / 64; ++w) acc += scratch[w];
+        p.partials[bid] = acc;
+    }
+}
+
 struct SpanFwdPlan {
     int ocp, cps, spp, P, wholeP;
     uint64_t total;
@@ -907,11 +860,7 @@ SpanFwdPlan span_forward_plan(const Geometry &g, int es) {
     const int64_t budget = kSpanRounds * kThreads;
     // whole source rows when a step spans whole output rows (an output row of at most 256 chunks); rows longer than a step
     // stage only the columns the step's chunks reach
-    if (g.nd == 1 && g.O[2] * es > kThreads * 16 && g.O[2] * es <= 4 * kThreads * 16 && cprx * 16 + 128 <= 60 * 1024) {
-        // a 1-D row of at most 1024 chunks is one step, up to four chunks per thread, the whole source row staged (see span_plan)
-        s.P = s.wholeP = static_cast<int>(cprx);
-        s.cps = static_cast<int>(g.O[2] * es / 16);
-    } else if (g.O[2] * es <= kThreads * 16 && rows * cprx <= budget) {
+    if (g.O[2] * es <= kThreads * 16 && rows * cprx <= budget) {
         s.P = s.wholeP = static_cast<int>(cprx);
         s.cps = kThreads;
     } else {
@@ -931,7 +880,7 @@ SpanFwdPlan span_forward_plan(const Geometry &g, int es) {
 }
 
 struct SpanPlan {
-    int cpr, seg, nseg, R, rsteps, spp, P, U, ndiff, rec;
+    int cpr, seg, nseg, R, rsteps, spp, P, ndiff, rec;
     uint64_t total;
     size_t off_desc, off_colx, off_colg, bytes, lds;
 };
@@ -944,14 +893,6 @@ SpanPlan span_plan(const Geometry &g, int es) {
     // column segments of at most 256 chunks (4 KB blocks of grad_x: see span_forward_plan); slots of seg + 2 pieces (a ragged
     // grad_out row's cover; a segment's source columns + corner column + shift misalignment)
     s.seg = std::min(s.cpr, kThreads);
-    s.U = 1;
-    if (g.nd == 1 && s.cpr > kThreads) {
-        // 1-D rows longer than a workgroup pass: up to four chunks per thread -- rows of at most 1024 chunks are one segment (every
-        // staged piece is read by this workgroup only; with 256-chunk segments every workgroup also read the first 32 bytes of its
-        // neighbour's block: N256 C512 L4096 fp32 backward 1.23 ms = 5.2 TB/s against 6.2 TB/s of the same kernel on 2-D crops)
-        s.U = std::min(4, (s.cpr + kThreads - 1) / kThreads);
-        s.seg = std::min(s.cpr, s.U * kThreads);
-    }
     s.nseg = (s.cpr + s.seg - 1) / s.seg;
     s.P = s.seg + 2;
     // rows per step: R * seg threads, and the tile's (3 R + 2) slots of P pieces within the staging rounds
@@ -972,8 +913,8 @@ SpanPlan span_plan(const Geometry &g, int es) {
     if (g.nd == 2) {   // crop_backward: x rows [R + 1][cpr] | own rows [R][cpr + 2] | read rows [R + 1][cpr + 2]
         const size_t tile = (static_cast<size_t>(R + 1) * s.cpr + static_cast<size_t>(2 * R + 1) * (s.cpr + 2)) * 16;
         s.lds = 64 + ((tile + 63) & ~static_cast<size_t>(63)) + 64 + (kThreads / 64) * 2 * sizeof(double);
-    } else {
-        s.lds = 64 + ((static_cast<size_t>(3) * s.P * 16 + 63) & ~static_cast<size_t>(63)) + 64 + (kThreads / 64) * 2 * sizeof(double);
+    } else {   // row_backward: three spans of (256 + 3) pieces
+        s.lds = 64 + 3 * (kThreads + 3) * 16 + 64 + (kThreads / 64) * sizeof(double);
     }
     return s;
 }
@@ -1000,6 +941,7 @@ bool span_forward_eligible(const Geometry &g, int dtype, const void *x, const vo
     if (dtype > SHIFTND_BF16 || (g.nd != 1 && g.nd != 2) || g.K[0] > 0) return false;
     const int es = dtype_size(dtype);
     if (g.S[0] != 1 || g.O[0] != 1 || g.S[1] < 1 || g.S[2] < 1 || g.O[1] < 1 || g.O[2] < 1) return false;
+    if (g.nd == 1 && (g.S[2] * es) % 16 != 0) return false;   // row_forward: rows of whole pieces
     if ((g.O[1] * g.O[2] * es) % 16 != 0 || (g.N * g.C * g.S[1] * g.S[2] * es) % 16 != 0) return false;
     if (g.S[1] * g.S[2] >= (1LL << 28) || g.O[1] * g.O[2] >= (1LL << 28)) return false;
     if (!dense(g.xs, g.N, g.C, g.S) || !dense(g.os, g.N, g.C, g.O)) return false;
@@ -1009,11 +951,12 @@ bool span_forward_eligible(const Geometry &g, int dtype, const void *x, const vo
     if (g_step_tune[2] >= 2) return true;
     bool crop = false;
     for (int d = 1; d < 3; ++d) crop = crop || g.O[d] != g.S[d] || g.L[d] != 0;
-    // cropped 2-D windows (the aligned ones whose output rows are whole pieces too: the step kernels, asked first).  On request
-    // only (knob 34 >= 2): uncropped planes with ragged rows -- same box, N128 C1024 14x14 fp32 0.20 vs 0.052 ms of the small-plane
-    // kernels, N64 C256 62x62 0.125 vs 0.101 -- and 1-D rows: N256 C512 L4096 fp32 sparse 0.90 vs 0.92 ms of the per-channel
-    // kernels, interpolating 0.88 vs 0.83, fp16 0.57 vs 0.42
-    return g.nd == 2 && crop;
+    // cropped 2-D windows (the aligned ones whose output rows are whole pieces too: the step kernels, asked first) and 1-D rows of
+    // at least 128 chunks (same box, N256 C512 L4096: fp32 0.94 -> 0.69 ms, interpolating 0.84 -> 0.69, fp16 0.44 -> 0.35).  On
+    // request only (knob 34 >= 2): uncropped planes with ragged rows -- N128 C1024 14x14 fp32 0.20 vs 0.052 ms of the small-plane
+    // kernels, N64 C256 62x62 0.125 vs 0.101
+    if (g.nd == 1) return (g.S[2] * es) % 16 == 0 && g.O[2] * es / 16 >= 128;   // row_forward (short rows: the per-channel kernels)
+    return crop;
 }
 
 template <typename T, int ND>
@@ -1040,6 +983,15 @@ static bool crop_forward_ok(const Geometry &g, int es) {
 int span_forward(const Geometry &g, int dtype, const void *x, const void *w, int wkind, void *out, hipStream_t st) {
     const int es = dtype_size(dtype);
     SpanFwdPlan sp = span_forward_plan(g, es);
+    const bool row1d = g.nd == 1 && (g.S[2] * es) % 16 == 0;
+    if (row1d) {   // row_forward: segments of 256 chunks, the columns their windows reach
+        sp.P = kThreads + 2;
+        sp.wholeP = 0;
+        sp.cps = kThreads;
+        sp.spp = (sp.ocp + kThreads - 1) / kThreads;
+        sp.total = static_cast<uint64_t>(g.N) * g.C * sp.spp;
+        sp.lds = 64 + (kThreads + 3) * 16 + 64;
+    }
     const bool lean = crop_forward_ok(g, es);
     if (lean) {   // whole source rows, exact pitch
         const int E = 16 / es;
@@ -1079,6 +1031,26 @@ int span_forward(const Geometry &g, int dtype, const void *x, const void *w, int
     p.d_per1 = make_fastdiv(static_cast<uint32_t>(map_period(p.S1, g.pad)));
     p.d_per2 = make_fastdiv(static_cast<uint32_t>(map_period(p.S2, g.pad)));
     const bool active = g.active != 0;
+    if (row1d) {
+        note_kernel(active ? "row_active_forward" : "row_gather_forward");
+        const dim3 grid(p.steps_per_xcd * 8), block(kThreads);
+#define SHIFTND_ROW_FWD(TT, ACT) \
+        switch (g.pad) { \
+        case 0: hipLaunchKernelGGL((row_forward<TT, ACT, 0>), grid, block, sp.lds, st, p); break; \
+        case 1: hipLaunchKernelGGL((row_forward<TT, ACT, 1>), grid, block, sp.lds, st, p); break; \
+        case 2: hipLaunchKernelGGL((row_forward<TT, ACT, 2>), grid, block, sp.lds, st, p); break; \
+        case 3: hipLaunchKernelGGL((row_forward<TT, ACT, 3>), grid, block, sp.lds, st, p); break; \
+        default: hipLaunchKernelGGL((row_forward<TT, ACT, 4>), grid, block, sp.lds, st, p); break; \
+        }
+        if (!active) {
+            if (es == 2) { SHIFTND_ROW_FWD(f16_t, false) } else if (es == 4) { SHIFTND_ROW_FWD(f32_t, false) } else { SHIFTND_ROW_FWD(f64_t, false) }
+        } else if (dtype == SHIFTND_F32) { SHIFTND_ROW_FWD(f32_t, true)
+        } else if (dtype == SHIFTND_F64) { SHIFTND_ROW_FWD(f64_t, true)
+        } else if (dtype == SHIFTND_F16) { SHIFTND_ROW_FWD(f16_t, true)
+        } else { SHIFTND_ROW_FWD(bf16_t, true) }
+#undef SHIFTND_ROW_FWD
+        return SHIFTND_OK;
+    }
     if (lean) {
         note_kernel(active ? "crop_active_forward" : "crop_gather_forward");
         const dim3 grid(p.steps_per_xcd * 8), block(kThreads);
@@ -1100,7 +1072,7 @@ int span_forward(const Geometry &g, int dtype, const void *x, const void *w, int
         return SHIFTND_OK;
     }
     note_kernel(active ? "span_active_forward" : "span_gather_forward");
-#define SHIFTND_SPAN_FT(TT) (g.nd == 1 ? launch_span_forward<TT, 1>(p, sp.lds, active, g.pad, st) : launch_span_forward<TT, 2>(p, sp.lds, active, g.pad, st))
+#define SHIFTND_SPAN_FT(TT) launch_span_forward<TT, 2>(p, sp.lds, active, g.pad, st)   /* (1-D: row_forward above) */
     if (!active) {   // a raw copy: one instantiation per element size
         if (es == 2) SHIFTND_SPAN_FT(f16_t);
         else if (es == 4) SHIFTND_SPAN_FT(f32_t);
@@ -1124,7 +1096,7 @@ bool span_backward_eligible(const Geometry &g, int dtype, const void *go, const 
     if (reinterpret_cast<uintptr_t>(go) % 16 || reinterpret_cast<uintptr_t>(x) % 16 || reinterpret_cast<uintptr_t>(gx) % 16) return false;
     if (g_step_tune[0] == 2) return true;
     const int es = dtype_size(dtype);
-    if (g.nd == 1) return g.S[2] * es / 16 >= 64;   // (short rows: one row per workgroup would leave most lanes idle)
+    if (g.nd == 1) return g.S[2] * es / 16 >= 128;   // (short rows: one row per workgroup would leave most lanes idle)
     bool crop = false;
     for (int d = 1; d < 3; ++d) crop = crop || g.O[d] != g.S[d] || g.L[d] != 0;
     return crop;   // (uncropped 2-D: step_backward)
@@ -1139,7 +1111,7 @@ static void launch_span_backward(const SpanParams &p, const SpanPlan &sp, bool a
 #define SHIFTND_SPAN_PAD(ACT, PADV) \
     case PADV: \
         if constexpr (ND == 2) hipLaunchKernelGGL((crop_backward<T, ACT, PADV>), grid, block, sp.lds, st, p); \
-        else hipLaunchKernelGGL((span_backward<T, 1, ACT, PADV>), grid, block, sp.lds, st, p);   /* (span_backward<..., 2, ...> is not instantiated) */ \
+        else hipLaunchKernelGGL((row_backward<T, ACT, PADV>), grid, block, sp.lds, st, p); \
         break;
     if (active) {
         hipLaunchKernelGGL((span_prep<T, true>), dim3(p.C), block, 0, st, p);
@@ -1194,7 +1166,6 @@ int span_backward(const Geometry &g, int dtype, const void *go, const void *x, c
     p.rsteps = sp.rsteps;
     p.spp = sp.spp;
     p.P = sp.P;
-    p.U = sp.U;
     p.total_steps = static_cast<uint32_t>(sp.total);
     p.steps_per_xcd = static_cast<uint32_t>((sp.total + 7) / 8);
     p.d_spp = make_fastdiv(static_cast<uint32_t>(sp.spp));
@@ -1206,7 +1177,7 @@ int span_backward(const Geometry &g, int dtype, const void *go, const void *x, c
     p.d_per2x = make_fastdiv(static_cast<uint32_t>(map_period(p.S2, g.pad)));
     p.d_per1g = make_fastdiv(static_cast<uint32_t>(map_period(p.O1, g.pad)));
     p.d_per2g = make_fastdiv(static_cast<uint32_t>(map_period(p.O2, g.pad)));
-    note_kernel(g.nd == 2 ? "crop_backward" : "span_backward");
+    note_kernel(g.nd == 2 ? "crop_backward" : "row_backward");
     const bool active = g.active != 0;
 #define SHIFTND_SPAN_T(TT) (g.nd == 1 ? launch_span_backward<TT, 1>(p, sp, active, gw, st) : launch_span_backward<TT, 2>(p, sp, active, gw, st))
     switch (dtype) {

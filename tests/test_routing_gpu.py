@@ -19,9 +19,9 @@ ROUTES = {
     "c2acrop": ((2, 256, 224, 224), torch.float32, True, [[1, 1], [1, 1]], "crop_active_forward", "crop_backward"),
     "t1": ((8, 16, 64, 64), torch.float32, False, [[1, 1], [1, 1]], "crop_gather_forward", "crop_backward"),
     "t1a": ((8, 16, 64, 64), torch.float32, True, [[1, 1], [1, 1]], "crop_active_forward", "crop_backward"),
-    "c1d": ((4, 512, 4096), torch.float32, False, None, None, "span_backward"),
-    "c1da": ((4, 512, 4096), torch.float32, True, None, None, "span_backward"),
-    "c1dh": ((4, 512, 4096), torch.float16, False, None, None, "span_backward"),
+    "c1d": ((4, 512, 4096), torch.float32, False, None, "row_gather_forward", "row_backward"),
+    "c1da": ((4, 512, 4096), torch.float32, True, None, "row_active_forward", "row_backward"),
+    "c1dh": ((4, 512, 4096), torch.float16, False, None, "row_gather_forward", "row_backward"),
 }
 
 

@@ -49,6 +49,7 @@ struct ClTiledParams {
     int64_t wzp;
     uint32_t fill;       // fill element (zero point / 0) in the low bits
     int wkind, N, C, H, W, pad;
+    int OH, OW, LH, LW;  // the window: output sizes and its corner in the source image (round 4; no crop: H, W, 0, 0)
     int out_cl;          // output layout: channels-last (1) or NCHW-contiguous (0)
     int wtiles, cblocks, bands, band_rows;
     unsigned xcd_blocks;     // grid / 8 when the XCD-contiguous block remap is on (grid % 8 == 0 and knob 22), else 0
@@ -118,14 +119,17 @@ __global__ __launch_bounds__(kThreads) void cl_tiled_forward(const ClTiledParams
     const int band = static_cast<int>(b - fdiv(b, p.d_bands) * p.bands);
     const int n = static_cast<int>(fdiv(b, p.d_bands));
     const int w0 = wt * kTW, c0 = cb * CB;
-    const int h0 = band * p.band_rows, h1 = min(p.H, h0 + p.band_rows);
-    const int H = p.H, W = p.W, C = p.C;
+    // the window (round 4): output rows / columns [0, OH) x [0, OW) read source rows / columns + (LH, LW) through the maps; the
+    // ring follows the SOURCE rows hs = h + LH and pixels w0 + LW - R ..
+    const int H = p.H, W = p.W, C = p.C, OH = p.OH, OW = p.OW, LH = p.LH, LW = p.LW;
+    const int h0 = band * p.band_rows, h1 = min(OH, h0 + p.band_rows);
     const char *xn = p.x + static_cast<int64_t>(n) * H * W * C * ES;
-    char *on = p.out + static_cast<int64_t>(n) * H * W * C * ES;
+    char *on = p.out + static_cast<int64_t>(n) * OH * OW * C * ES;
     const uint32_t img_bytes = static_cast<uint32_t>(H) * static_cast<uint32_t>(W) * static_cast<uint32_t>(C) * ES;  // < 2^31 (host)
+    const uint32_t out_bytes = static_cast<uint32_t>(OH) * static_cast<uint32_t>(OW) * static_cast<uint32_t>(C) * ES;
     const __amdgpu_buffer_rsrc_t xres = __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(xn), 0, img_bytes, kBufferFlags);
     const __amdgpu_buffer_rsrc_t xnone = __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(xn), 0, 0, kBufferFlags);
-    const __amdgpu_buffer_rsrc_t ores = __builtin_amdgcn_make_buffer_rsrc(on, 0, img_bytes, kBufferFlags);
+    const __amdgpu_buffer_rsrc_t ores = __builtin_amdgcn_make_buffer_rsrc(on, 0, out_bytes, kBufferFlags);
 
     // ---- staging: 16-byte pieces of source row y: pixel w0 - R + px, bytes 16 q .. of the channel line ---------------
     uint32_t poff[kNP];    // byte offset of the piece in row 0 of the image, or out of range
@@ -133,7 +137,7 @@ __global__ __launch_bounds__(kThreads) void cl_tiled_forward(const ClTiledParams
 #pragma unroll
     for (int k = 0; k < kNP; ++k) {
         const int q = k * kThreads + static_cast<int>(threadIdx.x);
-        const int px = q >> 3, cbyte = c0 * ES + (q & 7) * 16, gx = w0 - kR + px;
+        const int px = q >> 3, cbyte = c0 * ES + (q & 7) * 16, gx = w0 + LW - kR + px;
         const bool piece = q < kPieces;
         poff[k] = (piece && gx >= 0 && gx < W && cbyte < C * ES) ? static_cast<uint32_t>(gx) * C * ES + cbyte : kOutOfRange;
         pdst[k] = piece ? px * kPitch + (q & 7) * 4 : -1;
@@ -159,15 +163,15 @@ __global__ __launch_bounds__(kThreads) void cl_tiled_forward(const ClTiledParams
             d[3] = pv[k].w;
         }
     };
-    const int ylast = min(H - 1, h1 - 1 + kR);
+    const int ylast = min(H - 1, h1 - 1 + LH + kR);
     // The kDepth rows for the first steps are requested BEFORE the ring rows: when those have arrived nothing is
     // pending any more, so the loop's wait counts are those of its own back edge (kDepth rows of loads and stores
     // in flight), not the shorter distance of this prologue.
     u4 pre[2 * kR][kNP];
 #pragma unroll
-    for (int d = 0; d < kDepth; ++d) load_row(h0 + kR + d, ylast, pvs[d]);
+    for (int d = 0; d < kDepth; ++d) load_row(h0 + LH + kR + d, ylast, pvs[d]);
 #pragma unroll
-    for (int r = 0; r < 2 * kR; ++r) load_row(h0 - kR + r, ylast, pre[r]);
+    for (int r = 0; r < 2 * kR; ++r) load_row(h0 + LH - kR + r, ylast, pre[r]);
 
     // ---- the channels' shifts (while the rows are in flight) -----------------------------------------------------------
     if (threadIdx.x < CB) {
@@ -200,53 +204,54 @@ __global__ __launch_bounds__(kThreads) void cl_tiled_forward(const ClTiledParams
             const int ch = OUT_CL ? lane_a * NE + j : D / RD;
             const int col = OUT_CL ? lane_b + 8 * i : (D % RD) * NE + j;
             const int c = c0 + ch;
-            const bool live = c < C && w0 + col < W;
+            const bool live = c < C && w0 + col < OW;
             live_dw = live_dw || live;
             const int sh = tab_sh[ch], sw = tab_sw[ch];
             if (OUT_CL) csh[j] = sh;
             else csh[i] = sh;
-            const int sx = W == 1 ? 0 : fold_index(w0 + min(col, W - 1 - w0) - sw, W, p.pad);  // size-1 dims ignore the shift
+            const int sx = W == 1 ? 0 : fold_index(w0 + LW + min(col, OW - 1 - w0) - sw, W, p.pad);  // size-1 dims ignore the shift
             gcol[i][j] = sx;
             // canon_shift returns the non-negative representative for the reflecting paddings: look at the signed one
             const int sh_s = (perH && 2 * sh > perH) ? sh - perH : sh, sw_s = (perW && 2 * sw > perW) ? sw - perW : sw;
             // (periodic padding: a column near the edge comes from the far side of the row -- not among the staged pixels)
-            const bool in_ring = sh_s >= -kR && sh_s <= kR && sw_s >= -kR && sw_s <= kR && (sx < 0 || (sx >= w0 - kR && sx < w0 + kTW + kR));
+            const bool in_ring = sh_s >= -kR && sh_s <= kR && sw_s >= -kR && sw_s <= kR && (sx < 0 || (sx >= w0 + LW - kR && sx < w0 + LW + kTW + kR));
             const bool nr = live && sx >= 0 && in_ring;
             ring_ok |= (nr ? 1u : 0u) << (4 * i + j);
             far |= ((live && sx >= 0 && !in_ring) ? 1u : 0u) << (4 * i + j);
-            xoff[i][j] = nr ? (sx - (w0 - kR)) * (kPitch * 4) + ch * ES : 0;
+            xoff[i][j] = nr ? (sx - (w0 + LW - kR)) * (kPitch * 4) + ch * ES : 0;
         }
         // (C * ES and W * ES are multiples of 4 where it matters: a dword is live or dead as a whole)
         const int ch0 = OUT_CL ? lane_a * NE : D / RD, col0 = OUT_CL ? lane_b + 8 * i : (D % RD) * NE;
-        const uint32_t o = OUT_CL ? (static_cast<uint32_t>(h0 * W + w0 + col0) * C + c0 + ch0) * ES
-                                  : (static_cast<uint32_t>((c0 + ch0) * H + h0) * W + w0 + col0) * ES;
+        const uint32_t o = OUT_CL ? (static_cast<uint32_t>(h0 * OW + w0 + col0) * C + c0 + ch0) * ES
+                                  : (static_cast<uint32_t>((c0 + ch0) * OH + h0) * OW + w0 + col0) * ES;
         ooff[i] = live_dw ? o : kOutOfRange;
     }
-    const uint32_t ostep = static_cast<uint32_t>(OUT_CL ? W * C : W) * ES;
+    const uint32_t ostep = static_cast<uint32_t>(OUT_CL ? OW * C : OW) * ES;
 
     // rows h0 - R .. h0 + R - 1 of the ring
 #pragma unroll
     for (int r = 0; r < 2 * kR; ++r) {
-        const int y = h0 - kR + r;
+        const int y = h0 + LH - kR + r;
         if (y >= 0 && y < H) store_row(y, pre[r]);
     }
     const uint8_t *ringb = reinterpret_cast<const uint8_t *>(ring);
     const bool periodic = p.pad == 2 && H > 1;
     auto step = [&](int h, u4 (&pv)[kNP]) {
-        __syncthreads();  // everybody is done with the slot that row h + R replaces (row h - R - 1)
-        if (h + kR < H) store_row(h + kR, pv);
+        const int hs = h + LH;   // the source row of output row h under a zero shift
+        __syncthreads();  // everybody is done with the slot that row hs + R replaces (row hs - R - 1)
+        if (hs + kR < H) store_row(hs + kR, pv);
         __syncthreads();
-        load_row(h + kDepth + kR, ylast, pv);  // in flight while this and the next rows are produced
+        load_row(hs + kDepth + kR, ylast, pv);  // in flight while this and the next rows are produced
         const uint32_t so = static_cast<uint32_t>(h - h0) * ostep;
         int rowb[NSH];        // LDS byte offset of the source row of each shift, or -1 (zero padding)
 #pragma unroll
         for (int k = 0; k < NSH; ++k) {
-            const int sy = H == 1 ? 0 : fold_index(h - csh[k], H, p.pad);
+            const int sy = H == 1 ? 0 : fold_index(hs - csh[k], H, p.pad);
             const uint32_t r = static_cast<uint32_t>(sy < 0 ? 0 : sy);
             const uint32_t sl = r - __umulhi(r, 613566757u) * kRing;       // r % 7 (r < 2^20)
             // (periodic padding: a row that wraps to the far side of the image is not in the ring; the fill value goes out
             // and the pass after the loop writes the element)
-            const bool wrapped = periodic && (sy < h - kR || sy > h + kR);
+            const bool wrapped = periodic && (sy < hs - kR || sy > hs + kR);
             rowb[k] = (sy < 0 || wrapped) ? -1 : static_cast<int>(sl) * (kRowWords * 4);
         }
         uint32_t v[4];
@@ -275,7 +280,7 @@ __global__ __launch_bounds__(kThreads) void cl_tiled_forward(const ClTiledParams
 
     // ---- shifts beyond the ring: gathered from memory, element by element (rare).  The row loop stored the fill
     // value in their place; those stores are complete before the elements are written again. ------------------------
-    const bool wrap_rows = periodic && (h0 < kR || h1 > H - kR);   // the band holds rows whose source row wraps
+    const bool wrap_rows = periodic && (h0 + LH < kR || h1 + LH > H - kR);   // the band holds rows whose source row wraps
     if (far || (wrap_rows && ring_ok)) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
@@ -288,14 +293,14 @@ __global__ __launch_bounds__(kThreads) void cl_tiled_forward(const ClTiledParams
                 const int ch = OUT_CL ? lane_a * NE + j : D / RD;
                 const int col = OUT_CL ? lane_b + 8 * i : (D % RD) * NE + j;
                 const EL *xe = reinterpret_cast<const EL *>(xn);
-                EL *o = reinterpret_cast<EL *>(on) + (OUT_CL ? (static_cast<int64_t>(h0) * W + w0 + col) * C + c0 + ch
-                                                             : (static_cast<int64_t>(c0 + ch) * H + h0) * W + w0 + col);
+                EL *o = reinterpret_cast<EL *>(on) + (OUT_CL ? (static_cast<int64_t>(h0) * OW + w0 + col) * C + c0 + ch
+                                                             : (static_cast<int64_t>(c0 + ch) * OH + h0) * OW + w0 + col);
                 const int shc = csh[OUT_CL ? j : i];
                 for (int h = h0; h < h1; ++h) {
-                    const int sy = H == 1 ? 0 : fold_index(h - shc, H, p.pad);
-                    if (all_rows || sy < h - kR || sy > h + kR)
+                    const int sy = H == 1 ? 0 : fold_index(h + LH - shc, H, p.pad);
+                    if (all_rows || sy < h + LH - kR || sy > h + LH + kR)
                         *o = sy >= 0 ? xe[(static_cast<int64_t>(sy) * W + gcol[i][j]) * C + c0 + ch] : static_cast<EL>(p.fill);
-                    o += OUT_CL ? W * C : W;
+                    o += OUT_CL ? OW * C : OW;
                 }
             }
         }
@@ -927,14 +932,15 @@ bool cl_tiled_forward_eligible(const Geometry &g, int dtype, const void *x, cons
     if (g.active && dtype <= SHIFTND_BF16) {  // interpolating: cl_tiled_active_forward (fp32, fp16, bf16), rows folded once
         if (dtype == SHIFTND_F64 || (g.S[1] != 1 && g.S[1] < 5)) return false;
     }
-    for (int d = 0; d < 3; ++d)
-        if (g.L[d] != 0 || g.O[d] != g.S[d]) return false;
+    const bool interpolating = g.active && dtype <= SHIFTND_BF16;
+    for (int d = 0; d < 3; ++d)   // the window (a crop of the output): the gather kernel only (round 4)
+        if ((g.L[d] != 0 || g.O[d] != g.S[d]) && (interpolating || d == 0 || g.O[d] < 1)) return false;
     if ((g.C * es) % 16 != 0 || g.S[1] >= (1 << 20) || g.S[2] >= (1 << 20) || g.N >= (1LL << 24) || g.C >= (1 << 24)) return false;
     if (reinterpret_cast<uintptr_t>(x) % 16 != 0 || reinterpret_cast<uintptr_t>(out) % 4 != 0) return false;
     if (g.C * g.S[1] * g.S[2] * es >= (1LL << 31)) return false;  // one image per buffer resource, offsets below 2^31
     if (!dense_channels_last_2d(g.xs, g, g.S)) return false;
     if (dense_channels_last_2d(g.os, g, g.O)) return true;
-    return contiguous_2d(g.os, g, g.O) && (g.S[2] * es) % 4 == 0;
+    return contiguous_2d(g.os, g, g.O) && (g.O[2] * es) % 4 == 0;
 }
 
 int cl_tiled_forward(const Geometry &g, int dtype, const void *x, const void *w, int wkind, int64_t wzp, uint64_t fill_bits,
@@ -951,20 +957,24 @@ int cl_tiled_forward(const Geometry &g, int dtype, const void *x, const void *w,
     p.C = static_cast<int>(g.C);
     p.H = static_cast<int>(g.S[1]);
     p.W = static_cast<int>(g.S[2]);
+    p.OH = static_cast<int>(g.O[1]);
+    p.OW = static_cast<int>(g.O[2]);
+    p.LH = static_cast<int>(g.L[1]);
+    p.LW = static_cast<int>(g.L[2]);
     p.pad = g.pad;
     p.out_cl = dense_channels_last_2d(g.os, g, g.O) ? 1 : 0;
-    p.wtiles = (p.W + kTW - 1) / kTW;
+    p.wtiles = (p.OW + kTW - 1) / kTW;
     const int cb = kLine / es;
     p.cblocks = (p.C + cb - 1) / cb;
     // bands along H: enough workgroups (~7 per workgroup slot of the chip: 28-row bands measured best on N16 C256
     // 224x224), at least 8 R rows per band (the ring warm-up is 2 R rows)
     const int64_t base = static_cast<int64_t>(p.N) * p.wtiles * p.cblocks;
-    int64_t bands = g_cl_tiled_tune[1] > 0 ? (p.H + g_cl_tiled_tune[1] - 1) / g_cl_tiled_tune[1] : (7168 + base - 1) / base;
-    const int64_t max_bands = p.H / (8 * kR) > 0 ? p.H / (8 * kR) : 1;
+    int64_t bands = g_cl_tiled_tune[1] > 0 ? (p.OH + g_cl_tiled_tune[1] - 1) / g_cl_tiled_tune[1] : (7168 + base - 1) / base;
+    const int64_t max_bands = p.OH / (8 * kR) > 0 ? p.OH / (8 * kR) : 1;
     if (g_cl_tiled_tune[1] <= 0 && bands > max_bands) bands = max_bands;
     if (bands < 1) bands = 1;
-    p.band_rows = static_cast<int>((p.H + bands - 1) / bands);
-    p.bands = (p.H + p.band_rows - 1) / p.band_rows;
+    p.band_rows = static_cast<int>((p.OH + bands - 1) / bands);
+    p.bands = (p.OH + p.band_rows - 1) / p.band_rows;
     const int64_t grid = base * p.bands;
     if (grid >= (1LL << 31)) return SHIFTND_ERR_TOO_LARGE;
     p.xcd_blocks = (g_cl_tiled_tune[2] && grid % 8 == 0) ? static_cast<unsigned>(grid / 8) : 0;

@@ -197,6 +197,65 @@ def test_tiled_channels_last_forward_vs_oracle(shape):
         abi.set_tuning(21, 0)
 
 
+CL_CROPS = [((2, 8, 9, 12), [[1, 1], [1, 1]]), ((3, 300, 6, 5), [[0, 2], [1, 0]]), ((2, 64, 40, 70), [[1, 1], [1, 1]]),
+            ((1, 36, 100, 33), [[7, 30], [0, 5]]), ((2, 4, 12, 50), [[11, 0], [3, 3]]), ((1, 32, 64, 9), [[0, 0], [4, 4]]),
+            ((2, 16, 33, 40), [[5, 3], [2, 6]])]
+
+
+@pytest.mark.parametrize("shape,crop", CL_CROPS)
+def test_tiled_channels_last_cropped_forward_vs_oracle(shape, crop):
+    """cl_tiled_forward with a window (round 4: the emulated `valid` cut of modules/shifts.py:41-46 on a channels-last
+    input): the ring follows the source rows / pixels of the window, the output has the window's sizes; fp32 (channels-last
+    and NCHW-contiguous outputs), quantized uint8 (channels-last, shifts_quantized.cpp:119-121) and bf16; every padding,
+    shifts beyond the ring and beyond the dim, ragged bands; bit-exact vs the oracle"""
+    from torchshifts import abi
+    b, new = abi.check_borders(list(shape), crop, 2)
+    rs = np.random.RandomState(sum(shape) + 29)
+    x = rs.uniform(-1, 1, size=shape).astype(np.float32)
+    w = rs.uniform(-3.4, 3.4, size=(shape[1], 2)).astype(np.float32)
+    w[0] = [0.5, -1.5]
+    w[1] = [shape[2] + 2.25, -7.0]       # beyond the dim / beyond the ring
+    w[2] = [-5.0, 2.5]
+    xd = torch.from_numpy(x).to(DEV).contiguous(memory_format=torch.channels_last)
+    wd = torch.from_numpy(w).to(DEV)
+    try:
+        for band_rows in (0, 5):
+            abi.set_tuning(21, band_rows)
+            for pad in (0, 1, 2, 3, 4):
+                ref = O.forward(x, w, pad, False, b)
+                assert list(ref.shape) == list(new)
+                out = abi.forward(xd, wd, pad, False, b)  # NCHW-contiguous output
+                assert abi.last_kernel() == "cl_tiled_forward" and out.is_contiguous(), abi.last_kernel()
+                assert np.array_equal(out.cpu().numpy(), ref), (shape, crop, pad, "nchw")
+                out_cl = torch.empty(new, device=DEV).contiguous(memory_format=torch.channels_last)
+                abi.forward(xd, wd, pad, False, b, out=out_cl)
+                assert abi.last_kernel() == "cl_tiled_forward"
+                assert np.array_equal(out_cl.cpu().numpy(), ref), (shape, crop, pad, "cl")
+        abi.set_tuning(21, 0)
+        if shape[1] % 16 == 0:
+            xq = rs.randint(0, 255, size=shape).astype(np.uint8)
+            wq = rs.randint(124, 133, size=(shape[1], 2)).astype(np.uint8)
+            wq[1] = [128 + 9, 128 - 6]
+            xqd = torch.from_numpy(xq).to(DEV).contiguous(memory_format=torch.channels_last)
+            for pad in (0, 1, 2, 3, 4):
+                outq = torch.empty(new, dtype=torch.uint8, device=DEV).contiguous(memory_format=torch.channels_last)
+                abi.forward_quantized(xqd, torch.from_numpy(wq).to(DEV), 128, 7, pad, b, out=outq)
+                assert abi.last_kernel() == "cl_tiled_forward"
+                assert np.array_equal(outq.cpu().numpy(), O.forward_q(xq, wq, 128, 7, pad, b)), (shape, crop, pad, "u8")
+        if shape[1] % 8 == 0:
+            xb = torch.from_numpy(x).to(torch.bfloat16)
+            wb = torch.from_numpy(w).to(torch.bfloat16)
+            xbd = xb.to(DEV).contiguous(memory_format=torch.channels_last)
+            for pad in (0, 1, 2, 3, 4):
+                ref = O.forward(xb.float().numpy(), wb.float().numpy(), pad, False, b)
+                out_cl = torch.empty(new, dtype=torch.bfloat16, device=DEV).contiguous(memory_format=torch.channels_last)
+                abi.forward(xbd, wb.to(DEV), pad, False, b, out=out_cl)
+                assert abi.last_kernel() == "cl_tiled_forward"
+                assert np.array_equal(out_cl.float().cpu().numpy(), ref), (shape, crop, pad, "bf16")
+    finally:
+        abi.set_tuning(21, 0)
+
+
 @pytest.mark.parametrize("shape", [(2, 16, 9, 12), (1, 144, 20, 37), (2, 64, 40, 70), (1, 32, 5, 6)])
 def test_tiled_channels_last_forward_small_elements(shape):
     """cl_tiled_forward for 1- and 2-byte elements (a dword of output = 4 / 2 elements with their own shifts): quantized

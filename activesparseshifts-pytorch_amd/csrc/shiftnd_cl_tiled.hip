@@ -332,11 +332,12 @@ struct ClTiledBwdParams {
     const void *w;
     double *partials;    // [N * bands * wtiles][C][3]
     int wkind, N, C, H, W, pad;
+    int OH, OW, LH, LW;  // the window (round 4): grad_out's sizes and its corner in the input image (no crop: H, W, 0, 0)
     int go_nchw;         // the incoming gradient is NCHW-contiguous (saved input and grad_x: channels-last)
     int wtiles, cblocks, bands, band_rows;
     unsigned xcd_blocks;     // grid / 8 when the XCD-contiguous block remap is on (grid % 8 == 0 and knob 22), else 0
     FastDiv d_wtiles, d_cblocks, d_bands;
-    FastDiv d_perH, d_perW;
+    FastDiv d_perH, d_perW, d_perOH, d_perOW;
 };
 
 // GO_NCHW: the incoming gradient is NCHW-contiguous (what the op downstream of the reference's float forward hands back:
@@ -368,18 +369,23 @@ __global__ __launch_bounds__(kThreads) void cl_tiled_backward(const ClTiledBwdPa
     const int n = static_cast<int>(fdiv(b, p.d_bands));
     const int w0 = wt * kBTW, c0 = cb * CB;
     const int h0 = band * p.band_rows, h1 = min(p.H, h0 + p.band_rows);
-    const int H = p.H, W = p.W, C = p.C;
+    // The window (round 4; shifts_kernels.h:402-527 with the borders of shifts.cpp:93-135): grad_out has the window's sizes OH x OW
+    // and sits at (LH, LW) of the input image.  The kernel stays in INPUT coordinates: the gradient ring's row y / pixel gxs hold
+    // grad_out's row y - LH / column gxs - LW (nothing outside the window), the gradient maps fold in the window's sizes and are
+    // moved back by (LH, LW); input elements outside the window get a zero gradient and add nothing to the weight gradients.
+    const int H = p.H, W = p.W, C = p.C, OH = p.OH, OW = p.OW, LH = p.LH, LW = p.LW;
     const int64_t img = static_cast<int64_t>(n) * H * W * C * ES;
-    const char *xn = p.x + img, *gn = p.go + img;
+    const char *xn = p.x + img, *gn = p.go + static_cast<int64_t>(n) * OH * OW * C * ES;
     char *on = p.gx + img;
     const uint32_t img_bytes = static_cast<uint32_t>(H) * static_cast<uint32_t>(W) * static_cast<uint32_t>(C) * ES;  // < 2^31 (host)
+    const uint32_t go_bytes = static_cast<uint32_t>(OH) * static_cast<uint32_t>(OW) * static_cast<uint32_t>(C) * ES;
     const __amdgpu_buffer_rsrc_t xres = __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(xn), 0, img_bytes, kBufferFlags);
-    const __amdgpu_buffer_rsrc_t gres = __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(gn), 0, img_bytes, kBufferFlags);
+    const __amdgpu_buffer_rsrc_t gres = __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(gn), 0, go_bytes, kBufferFlags);
     const __amdgpu_buffer_rsrc_t none = __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(xn), 0, 0, kBufferFlags);
     const __amdgpu_buffer_rsrc_t ores = __builtin_amdgcn_make_buffer_rsrc(on, 0, img_bytes, kBufferFlags);
-    // the gradient element (row r, column cc) of channel ch, in elements from the image base
+    // the gradient element (row r, column cc: grad_out's own coordinates) of channel ch, in elements from the image base
     auto g_index = [&](int ch, int r, int cc) {
-        return GO_NCHW ? (static_cast<int64_t>(ch) * H + r) * W + cc : (static_cast<int64_t>(r) * W + cc) * C + ch;
+        return GO_NCHW ? (static_cast<int64_t>(ch) * OH + r) * OW + cc : (static_cast<int64_t>(r) * OW + cc) * C + ch;
     };
 
     // ---- staging: one 16-byte piece of the input row and one of the gradient row per thread ------------------------------
@@ -387,6 +393,7 @@ __global__ __launch_bounds__(kThreads) void cl_tiled_backward(const ClTiledBwdPa
     const bool piece = q < kBPieces;
     const int px = q >> 3, part = q & 7, gxs = w0 - kR + px;
     const uint32_t poff = (piece && gxs >= 0 && gxs < W && c0 * ES + part * 16 < C * ES) ? static_cast<uint32_t>(gxs) * C * ES + c0 * ES + part * 16 : kOutOfRange;
+    const uint32_t poffg = (piece && gxs >= LW && gxs < LW + OW && c0 * ES + part * 16 < C * ES) ? static_cast<uint32_t>(gxs - LW) * C * ES + c0 * ES + part * 16 : kOutOfRange;
     const int pdst = piece ? px * kPitch + part * 4 : -1;
     const uint32_t row_bytes = static_cast<uint32_t>(W) * C * ES;
     constexpr int kDepth = CLT_DEPTH;
@@ -402,27 +409,28 @@ __global__ __launch_bounds__(kThreads) void cl_tiled_backward(const ClTiledBwdPa
 #pragma unroll
         for (int k = 0; k < kGN; ++k) {
             const int e = k * kThreads + q, ch = e / kBPW, pxe = e - ch * kBPW, gxe = w0 - kR + pxe;
-            const bool ok = e < kGE && gxe >= 0 && gxe < W && c0 + ch < C;
-            goff[k] = ok ? (static_cast<uint32_t>(c0 + ch) * H * W + gxe) * ES : kOutOfRange;
+            const bool ok = e < kGE && gxe >= LW && gxe < LW + OW && c0 + ch < C;
+            goff[k] = ok ? (static_cast<uint32_t>(c0 + ch) * OH * OW + (gxe - LW)) * ES : kOutOfRange;
             gdst[k] = e < kGE ? pxe * (kPitch * 4) + ch * ES : -1;
         }
     }
-    const uint32_t grow_bytes = GO_NCHW ? static_cast<uint32_t>(W) * ES : row_bytes;
+    const uint32_t grow_bytes = static_cast<uint32_t>(OW) * (GO_NCHW ? 1 : C) * ES;
     u4 pvx[kDepth];
     GRow pvg[kDepth];
     auto load_row = [&](int y, int ylast, u4 &vx, GRow &vg) {  // rows outside the image or beyond the band: nothing is read
         const bool wanted = y >= 0 && y <= ylast;
         const uint32_t so = wanted ? static_cast<uint32_t>(y) * row_bytes : 0u;
         vx = __builtin_amdgcn_raw_buffer_load_b128(wanted ? xres : none, poff, so, 0);
+        const bool wanted_g = wanted && y >= LH && y < LH + OH;   // grad_out's row y - LH
+        const uint32_t sg = wanted_g ? static_cast<uint32_t>(y - LH) * grow_bytes : 0u;
         if constexpr (GO_NCHW) {
-            const uint32_t sg = wanted ? static_cast<uint32_t>(y) * grow_bytes : 0u;
 #pragma unroll
             for (int k = 0; k < kGN; ++k) {
-                if constexpr (ES == 4) vg.e[k] = __builtin_amdgcn_raw_buffer_load_b32(wanted ? gres : none, goff[k], sg, 0);
-                else vg.e[k] = __builtin_amdgcn_raw_buffer_load_b16(wanted ? gres : none, goff[k], sg, 0);
+                if constexpr (ES == 4) vg.e[k] = __builtin_amdgcn_raw_buffer_load_b32(wanted_g ? gres : none, goff[k], sg, 0);
+                else vg.e[k] = __builtin_amdgcn_raw_buffer_load_b16(wanted_g ? gres : none, goff[k], sg, 0);
             }
         } else {
-            vg.v = __builtin_amdgcn_raw_buffer_load_b128(wanted ? gres : none, poff, so, 0);
+            vg.v = __builtin_amdgcn_raw_buffer_load_b128(wanted_g ? gres : none, poffg, sg, 0);
         }
     };
     auto store_row = [&](int y, const u4 &vx, const GRow &vg) {
@@ -466,24 +474,32 @@ __global__ __launch_bounds__(kThreads) void cl_tiled_backward(const ClTiledBwdPa
     }
     const int csxH = canon_shift(sh[1], H, p.pad, p.d_perH), csxW = canon_shift(sh[2], W, p.pad, p.d_perW);
     // grad_x source: the sparse shift reads grad_out at o + shift, the active one at o - shift (shifts_kernels.h:287-293)
-    const int csgH = canon_shift(ACTIVE ? sh[1] : -sh[1], H, p.pad, p.d_perH), csgW = canon_shift(ACTIVE ? sh[2] : -sh[2], W, p.pad, p.d_perW);
-    const int perH = map_period(H, p.pad), perW = map_period(W, p.pad);
+    // (the gradient's maps fold in the window's sizes: their own canonical shifts)
+    const int csgH = canon_shift(ACTIVE ? sh[1] : -sh[1], OH, p.pad, p.d_perOH), csgW = canon_shift(ACTIVE ? sh[2] : -sh[2], OW, p.pad, p.d_perOW);
+    const int perH = map_period(H, p.pad), perW = map_period(W, p.pad), perOH = map_period(OH, p.pad), perOW = map_period(OW, p.pad);
     const int sh_s = (perH && 2 * csxH > perH) ? csxH - perH : csxH, sw_s = (perW && 2 * csxW > perW) ? csxW - perW : csxW;
-    const bool in_ring = sh_s >= -kR && sh_s <= kR && sw_s >= -kR && sw_s <= kR;
+    const int gh_s = (perOH && 2 * csgH > perOH) ? csgH - perOH : csgH, gw_s = (perOW && 2 * csgW > perOW) ? csgW - perOW : csgW;
+    const bool in_ring = sh_s >= -kR && sh_s <= kR && sw_s >= -kR && sw_s <= kR && gh_s >= -kR && gh_s <= kR && gw_s >= -kR && gw_s <= kR;
     const bool near_c = live_c && in_ring, far_c = live_c && !in_ring;
     auto fold_h = [&](int idx) { return H == 1 ? 0 : fold_index(idx, H, p.pad); };   // size-1 dims ignore the shift
     auto fold_w = [&](int idx) { return W == 1 ? 0 : fold_index(idx, W, p.pad); };
+    // the gradient's maps: grad_out coordinates in, INPUT coordinates out (-1: padding)
+    auto fold_gh = [&](int idx) { const int r = OH == 1 ? 0 : fold_index(idx, OH, p.pad); return r < 0 ? -1 : r + LH; };
+    auto fold_gw = [&](int idx) { const int r = OW == 1 ? 0 : fold_index(idx, OW, p.pad); return r < 0 ? -1 : r + LW; };
     // per pixel: LDS byte offsets (within a ring row) of the input corners' columns and of the gradient taps' columns; -1: padding.
     // A reflected corner can land one step outside the rings (reflect padding, last column / row, shift -R: the
     // corner at distance R + 1 comes back at distance -(R + 1)); such pixels (`scol`) and rows (`skip` below) are left
     // to the element-by-element pass at the end.
     int xc0[NI], xc1[NI], gc0[NI], gc1[NI], gd[NI];
     uint32_t ooff[NI];
-    bool live[NI], scol[NI];
+    bool live[NI], scol[NI], cpass[NI];   // cpass: the pixel's column lies in the window
 #pragma unroll
     for (int i = 0; i < NI; ++i) {
         const int col = lane_b + PL * i, wq = w0 + min(col, W - 1 - w0);
-        const int a0 = fold_w(wq - csxW), a1 = fold_w(wq - csxW + 1), b0 = fold_w(wq - csgW), b1 = ACTIVE ? fold_w(wq - csgW + 1) : -1;
+        cpass[i] = wq >= LW && wq < LW + OW;
+        // (a column outside the window: zero gradient, nothing counted -- every map "padding")
+        const int a0 = cpass[i] ? fold_w(wq - csxW) : -1, a1 = cpass[i] ? fold_w(wq - csxW + 1) : -1;
+        const int b0 = cpass[i] ? fold_gw(wq - LW - csgW) : -1, b1 = (ACTIVE && cpass[i]) ? fold_gw(wq - LW - csgW + 1) : -1;
         auto outside = [&](int sx) { return sx >= 0 && (sx < w0 - kR || sx > w0 + kBTW + kR); };
         scol[i] = near_c && w0 + col < W && (outside(a0) || outside(a1) || outside(b0) || outside(b1));
         live[i] = near_c && w0 + col < W && !scol[i];
@@ -525,15 +541,27 @@ __global__ __launch_bounds__(kThreads) void cl_tiled_backward(const ClTiledBwdPa
         r = (fzero && (lo || hi)) ? -1 : r;
         return H == 1 ? 0 : r;
     };
-    // the one source row the rings cannot hold: reflect padding, last output row, shift -R (its + 1 corner, at distance
-    // R + 1, comes back at distance -(R + 1))
+    // the gradient's rows, folded once in the window's sizes (OH >= 5 or OH == 1: host), grad_out row in, input row out
+    const int gLo = p.pad == 4 ? -1 : 0, gHi = p.pad == 1 ? OH - 1 : (p.pad == 3 ? 2 * OH - 2 : 2 * OH - 1);
+    auto fold1g = [&](int idx) {
+        const bool lo = idx < 0, hi = idx >= OH;
+        const int t = idx & fm;
+        int r = lo ? gLo - t : (hi ? gHi - t : idx);
+        r = (fzero && (lo || hi)) ? -1 : r;
+        r = OH == 1 ? 0 : r;
+        return r < 0 ? -1 : r + LH;
+    };
+    // the one source row the rings cannot hold: reflect padding, last row (of the image: the input's corners; of the window: the
+    // active shift's gradient taps), shift -R (its + 1 corner, at distance R + 1, comes back at distance -(R + 1))
     const bool srow = near_c && p.pad == 3 && H > 1 && sh_s == -kR && h1 == H;
-    // periodic padding: rows whose input corners or gradient taps wrap to the far side of the image (at most R + 1 at the top
-    // or the bottom) are not in the rings: left to the element-by-element pass
+    const bool srow_g = ACTIVE && near_c && p.pad == 3 && OH > 1 && gh_s == -kR;
+    // periodic padding: rows whose input corners or gradient taps wrap to the far side of the image / the window (at most R + 1
+    // at the top or the bottom) are not in the rings: left to the element-by-element pass
     const bool periodic = p.pad == 2 && H > 1;
     auto wraps = [&](int h) {
-        const int g0 = ACTIVE ? h - sh_s : h + sh_s;   // the gradient taps' first row (the active shift's second: + 1)
-        return periodic && near_c && (h - sh_s < 0 || h + 1 - sh_s >= H || g0 < 0 || g0 + (ACTIVE ? 1 : 0) >= H);
+        const int g0 = h - LH - gh_s;   // the gradient taps' first row, grad_out coordinates (the active shift's second: + 1)
+        const bool in_rows = h >= LH && h < LH + OH;
+        return periodic && near_c && (h - sh_s < 0 || h + 1 - sh_s >= H || (in_rows && OH > 1 && (g0 < 0 || g0 + (ACTIVE ? 1 : 0) >= OH)));
     };
     int xrow1 = fold1(h0 - sh_s);   // the + 1 corner of step h - 1 is the first corner of step h
     auto step = [&](int h, u4 &vx, GRow &vg) {
@@ -545,9 +573,10 @@ __global__ __launch_bounds__(kThreads) void cl_tiled_backward(const ClTiledBwdPa
         const int xr0 = row_off(xrow1);
         xrow1 = fold1(h + 1 - sh_s);
         const int xr1 = row_off(xrow1);
-        const int gr0 = ACTIVE ? xr0 : row_off(fold1(h + sh_s)), gr1 = ACTIVE ? xr1 : -1;
+        const bool rpass = h >= LH && h < LH + OH;   // the row lies in the window (else: zero gradient, nothing counted)
+        const int gr0 = rpass ? row_off(fold1g(h - LH - gh_s)) : -1, gr1 = (ACTIVE && rpass) ? row_off(fold1g(h - LH - gh_s + 1)) : -1;
         const int gdr = (h & (kBRing - 1)) * (kBRowWords * 4);
-        const bool skip = (srow && h == H - 1) || wraps(h);
+        const bool skip = (srow && h == H - 1) || (srow_g && h == LH + OH - 1) || wraps(h);
         S res[NI];
         CT s0 = CT(0), s1 = CT(0);
 #pragma unroll
@@ -558,7 +587,7 @@ __global__ __launch_bounds__(kThreads) void cl_tiled_backward(const ClTiledBwdPa
             v[2] = lds_f(ringx, xr0, xc1[i]);
             v[3] = lds_f(ringx, xr1, xc1[i]);
             const CT graw = widen<T>(*reinterpret_cast<const S *>(ringg + gdr + gd[i]));
-            const bool counted = live[i] && !skip;
+            const bool counted = live[i] && !skip && rpass && cpass[i];
             weight_grads_nd<2, CT>(v, dw, wg);
             // (selected, not multiplied by zero: the corners of a skipped row can come from ring slots that were never staged --
             // periodic padding, a source row past the image -- and 0 * NaN is not 0)
@@ -603,8 +632,8 @@ __global__ __launch_bounds__(kThreads) void cl_tiled_backward(const ClTiledBwdPa
     bool any_scol = false;
 #pragma unroll
     for (int i = 0; i < NI; ++i) any_scol = any_scol || scol[i];
-    const bool wrap_rows = periodic && near_c && (h0 <= kR || h1 >= H - kR - 1);
-    if (live_c && (far_c || any_scol || srow || wrap_rows)) {
+    const bool wrap_rows = periodic && near_c && (h0 <= kR || h1 >= H - kR - 1 || (h0 <= LH + kR && h1 > LH) || (h1 >= LH + OH - kR - 1 && h0 < LH + OH));
+    if (live_c && (far_c || any_scol || srow || srow_g || wrap_rows)) {
         const S *xe = reinterpret_cast<const S *>(xn) + c, *ge = reinterpret_cast<const S *>(gn);
         S *oe = reinterpret_cast<S *>(on) + c;
         auto tap_s = [&](const S *base, int r, int cc) { return (r >= 0 && cc >= 0) ? base[(static_cast<int64_t>(r) * W + cc) * C] : narrow<T>(CT(0)); };
@@ -615,12 +644,18 @@ __global__ __launch_bounds__(kThreads) void cl_tiled_backward(const ClTiledBwdPa
         for (int i = 0; i < NI; ++i) {
             const int wq = w0 + lane_b + PL * i;
             if (wq >= W) continue;
-            const int a0 = fold_w(wq - csxW), a1 = fold_w(wq - csxW + 1), b0 = fold_w(wq - csgW), b1 = fold_w(wq - csgW + 1);
+            const int a0 = fold_w(wq - csxW), a1 = fold_w(wq - csxW + 1);
+            const int b0 = fold_gw(wq - LW - csgW) - LW, b1 = fold_gw(wq - LW - csgW + 1) - LW;   // grad_out columns (< 0: padding)
             for (int h = h0; h < h1; ++h) {
-                if (!(far_c || scol[i] || (srow && h == H - 1) || wraps(h))) continue;
-                const int r0 = fold_h(h - csxH), r1 = fold_h(h - csxH + 1), s0 = fold_h(h - csgH), s1 = fold_h(h - csgH + 1);
+                if (!(far_c || scol[i] || (srow && h == H - 1) || (srow_g && h == LH + OH - 1) || wraps(h))) continue;
+                if (!(h >= LH && h < LH + OH && wq >= LW && wq < LW + OW)) {   // outside the window
+                    oe[(static_cast<int64_t>(h) * W + wq) * C] = narrow<T>(CT(0));
+                    continue;
+                }
+                const int r0 = fold_h(h - csxH), r1 = fold_h(h - csxH + 1);
+                const int s0 = fold_gh(h - LH - csgH) - LH, s1 = fold_gh(h - LH - csgH + 1) - LH;   // grad_out rows (< 0: padding)
                 CT v[4] = {tap(xe, r0, a0), tap(xe, r1, a0), tap(xe, r0, a1), tap(xe, r1, a1)}, wg[3];
-                const CT gval = widen<T>(ge[g_index(c, h, wq)]);
+                const CT gval = widen<T>(ge[g_index(c, h - LH, wq - LW)]);
                 weight_grads_nd<2, CT>(v, dw, wg);
                 acc[0] += static_cast<double>(gval * wg[0]);
                 acc[1] += static_cast<double>(gval * wg[1]);
@@ -693,14 +728,16 @@ __global__ __launch_bounds__(kThreads) void cl_tiled_active_forward(const ClTile
     const int band = static_cast<int>(b - fdiv(b, p.d_bands) * p.bands);
     const int n = static_cast<int>(fdiv(b, p.d_bands));
     const int w0 = wt * kTW, c0 = cb * CB;
-    const int h0 = band * p.band_rows, h1 = min(p.H, h0 + p.band_rows);
-    const int H = p.H, W = p.W, C = p.C;
+    // the window (round 4, as in cl_tiled_forward): output row h / column w read the source around (h + LH, w + LW)
+    const int H = p.H, W = p.W, C = p.C, OH = p.OH, OW = p.OW, LH = p.LH, LW = p.LW;
+    const int h0 = band * p.band_rows, h1 = min(OH, h0 + p.band_rows);
     const char *xn = p.x + static_cast<int64_t>(n) * H * W * C * ES;
-    char *on = p.out + static_cast<int64_t>(n) * H * W * C * ES;
+    char *on = p.out + static_cast<int64_t>(n) * OH * OW * C * ES;
     const uint32_t img_bytes = static_cast<uint32_t>(H) * static_cast<uint32_t>(W) * static_cast<uint32_t>(C) * ES;
+    const uint32_t out_bytes = static_cast<uint32_t>(OH) * static_cast<uint32_t>(OW) * static_cast<uint32_t>(C) * ES;
     const __amdgpu_buffer_rsrc_t xres = __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(xn), 0, img_bytes, kBufferFlags);
     const __amdgpu_buffer_rsrc_t xnone = __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(xn), 0, 0, kBufferFlags);
-    const __amdgpu_buffer_rsrc_t ores = __builtin_amdgcn_make_buffer_rsrc(on, 0, img_bytes, kBufferFlags);
+    const __amdgpu_buffer_rsrc_t ores = __builtin_amdgcn_make_buffer_rsrc(on, 0, out_bytes, kBufferFlags);
 
     // ---- staging (as in cl_tiled_forward) -----------------------------------------------------------------------------
     uint32_t poff[kANP];
@@ -708,7 +745,7 @@ __global__ __launch_bounds__(kThreads) void cl_tiled_active_forward(const ClTile
 #pragma unroll
     for (int k = 0; k < kANP; ++k) {
         const int q = k * kThreads + static_cast<int>(threadIdx.x);
-        const int px = q >> 3, cbyte = c0 * ES + (q & 7) * 16, gx = w0 - kR + px;
+        const int px = q >> 3, cbyte = c0 * ES + (q & 7) * 16, gx = w0 + LW - kR + px;
         const bool piece = q < kAPieces;
         poff[k] = (piece && gx >= 0 && gx < W && cbyte < C * ES) ? static_cast<uint32_t>(gx) * C * ES + cbyte : kOutOfRange;
         pdst[k] = piece ? px * kPitch + (q & 7) * 4 : -1;
@@ -734,12 +771,12 @@ __global__ __launch_bounds__(kThreads) void cl_tiled_active_forward(const ClTile
             d[3] = pv[k].w;
         }
     };
-    const int ylast = min(H - 1, h1 + kR);
+    const int ylast = min(H - 1, h1 + LH + kR);
     u4 pre[2 * kR + 1][kANP];
 #pragma unroll
-    for (int d = 0; d < kDepth; ++d) load_row(h0 + kR + 1 + d, ylast, pvs[d]);
+    for (int d = 0; d < kDepth; ++d) load_row(h0 + LH + kR + 1 + d, ylast, pvs[d]);
 #pragma unroll
-    for (int r = 0; r <= 2 * kR; ++r) load_row(h0 - kR + r, ylast, pre[r]);
+    for (int r = 0; r <= 2 * kR; ++r) load_row(h0 + LH - kR + r, ylast, pre[r]);
 
     // ---- the channels' shifts ------------------------------------------------------------------------------------------
     const int perH = map_period(H, p.pad), perW = map_period(W, p.pad);
@@ -777,31 +814,31 @@ __global__ __launch_bounds__(kThreads) void cl_tiled_active_forward(const ClTile
     for (int i = 0; i < NI; ++i) {
         const int ch = OUT_CL ? lane_a : lane_b + PL * i, col = OUT_CL ? lane_b + PL * i : lane_a;
         const int c = c0 + ch, k = OUT_CL ? 0 : i;
-        const bool inside = c < C && w0 + col < W;
+        const bool inside = c < C && w0 + col < OW;
         const int s = tab_sh[ch], sw = tab_sw[ch];
         shs[k] = s == kFarShift ? 0 : s;
         dws[k][0] = tab_dh[ch];
         dws[k][1] = tab_dw[ch];
         // the one source row the ring cannot hold: reflect padding, last output row, shift -R (see cl_tiled_backward)
-        srow[k] = c < C && s != kFarShift && p.pad == 3 && H > 1 && s == -kR && h1 == H;
-        const int wq = w0 + min(col, W - 1 - w0);
+        srow[k] = c < C && s != kFarShift && p.pad == 3 && H > 1 && s == -kR && h1 + LH == H;
+        const int wq = w0 + LW + min(col, OW - 1 - w0);   // the source column under a zero shift
         const int a0 = fold_w(wq - sw), a1 = fold_w(wq - sw + 1);
-        auto outside = [&](int sx) { return sx >= 0 && (sx < w0 - kR || sx > w0 + kTW + kR); };
+        auto outside = [&](int sx) { return sx >= 0 && (sx < w0 + LW - kR || sx > w0 + LW + kTW + kR); };
         const bool mine = inside && s != kFarShift && !outside(a0) && !outside(a1);
         live |= (mine ? 1u : 0u) << i;
         rest |= ((inside && !mine) ? 1u : 0u) << i;
-        auto lds_col = [&](int sx) { return (mine && sx >= 0) ? (sx - (w0 - kR)) * (kPitch * 4) + ch * ES : -1; };
+        auto lds_col = [&](int sx) { return (mine && sx >= 0) ? (sx - (w0 + LW - kR)) * (kPitch * 4) + ch * ES : -1; };
         xc0[i] = lds_col(a0);
         xc1[i] = lds_col(a1);
-        const uint32_t o = OUT_CL ? (static_cast<uint32_t>(h0 * W + w0 + col) * C + c) * ES
-                                  : (static_cast<uint32_t>(c * H + h0) * W + w0 + col) * ES;
+        const uint32_t o = OUT_CL ? (static_cast<uint32_t>(h0 * OW + w0 + col) * C + c) * ES
+                                  : (static_cast<uint32_t>(c * OH + h0) * OW + w0 + col) * ES;
         ooff[i] = mine ? o : kOutOfRange;
     }
-    const uint32_t ostep = static_cast<uint32_t>(OUT_CL ? W * C : W) * ES;
+    const uint32_t ostep = static_cast<uint32_t>(OUT_CL ? OW * C : OW) * ES;
 
 #pragma unroll
     for (int r = 0; r <= 2 * kR; ++r) {
-        const int y = h0 - kR + r;
+        const int y = h0 + LH - kR + r;
         if (y >= 0 && y < H) store_row(y, pre[r]);
     }
     const char *ringx = reinterpret_cast<const char *>(ring);
@@ -824,24 +861,25 @@ __global__ __launch_bounds__(kThreads) void cl_tiled_active_forward(const ClTile
     // periodic padding: a corner row that wraps to the far side of the image is not in the ring; such rows (at most R + 1 at
     // the top or the bottom of the image) are left to the element-by-element pass, like the reflected corner above
     const bool periodic = p.pad == 2 && H > 1;
-    auto wraps = [&](int h, int sgn) { return periodic && (h - sgn < 0 || h + 1 - sgn >= H); };
+    auto wraps = [&](int hs, int sgn) { return periodic && (hs - sgn < 0 || hs + 1 - sgn >= H); };   // hs: the source row h + LH
     int xrow1[NCH];
 #pragma unroll
-    for (int k = 0; k < NCH; ++k) xrow1[k] = fold1(h0 - shs[k]);
+    for (int k = 0; k < NCH; ++k) xrow1[k] = fold1(h0 + LH - shs[k]);
     auto step = [&](int h, u4 (&pv)[kANP]) {
+        const int hs = h + LH;
         __syncthreads();
-        if (h + kR + 1 < H) store_row(h + kR + 1, pv);
+        if (hs + kR + 1 < H) store_row(hs + kR + 1, pv);
         __syncthreads();
-        load_row(h + kDepth + kR + 1, ylast, pv);
+        load_row(hs + kDepth + kR + 1, ylast, pv);
         const uint32_t so = static_cast<uint32_t>(h - h0) * ostep;
         int xr0[NCH], xr1[NCH];
         bool skip[NCH];
 #pragma unroll
         for (int k = 0; k < NCH; ++k) {
             xr0[k] = row_off(xrow1[k]);
-            xrow1[k] = fold1(h + 1 - shs[k]);
+            xrow1[k] = fold1(hs + 1 - shs[k]);
             xr1[k] = row_off(xrow1[k]);
-            skip[k] = (srow[k] && h == H - 1) || wraps(h, shs[k]);
+            skip[k] = (srow[k] && hs == H - 1) || wraps(hs, shs[k]);
         }
         S res[NI];
 #pragma unroll
@@ -881,7 +919,7 @@ __global__ __launch_bounds__(kThreads) void cl_tiled_active_forward(const ClTile
     bool any_srow = false;
 #pragma unroll
     for (int k = 0; k < NCH; ++k) any_srow = any_srow || srow[k];
-    const bool wrap_rows = periodic && (h0 <= kR || h1 >= H - kR - 1);
+    const bool wrap_rows = periodic && (h0 + LH <= kR || h1 + LH >= H - kR - 1);
     if (rest || any_srow || (wrap_rows && live)) {
         const S *xe = reinterpret_cast<const S *>(xn);
         auto tap = [&](const S *base, int r, int cc) { return (r >= 0 && cc >= 0) ? widen<T>(base[(static_cast<int64_t>(r) * W + cc) * C]) : CT(0); };
@@ -891,15 +929,16 @@ __global__ __launch_bounds__(kThreads) void cl_tiled_active_forward(const ClTile
             const bool all_rows = (rest >> i) & 1u, mine = (live >> i) & 1u;
             if (!all_rows && !(mine && (srow[k] || wrap_rows))) continue;
             const int ch = OUT_CL ? lane_a : lane_b + PL * i, col = OUT_CL ? lane_b + PL * i : lane_a;
-            const int shc = tab_shc[ch], sw = tab_sw[ch], wq = w0 + col;
+            const int shc = tab_shc[ch], sw = tab_sw[ch], wo = w0 + col, wq = wo + LW;
             const int a0 = fold_w(wq - sw), a1 = fold_w(wq - sw + 1);
-            S *o = reinterpret_cast<S *>(on) + (OUT_CL ? (static_cast<int64_t>(h0) * W + wq) * C + c0 + ch
-                                                               : (static_cast<int64_t>(c0 + ch) * H + h0) * W + wq);
+            S *o = reinterpret_cast<S *>(on) + (OUT_CL ? (static_cast<int64_t>(h0) * OW + wo) * C + c0 + ch
+                                                               : (static_cast<int64_t>(c0 + ch) * OH + h0) * OW + wo);
             for (int h = h0; h < h1; ++h) {
-                if (!all_rows && !((srow[k] && h == H - 1) || wraps(h, shs[k]))) continue;
-                const int r0 = fold_h(h - shc), r1 = fold_h(h - shc + 1);
+                const int hs = h + LH;
+                if (!all_rows && !((srow[k] && hs == H - 1) || wraps(hs, shs[k]))) continue;
+                const int r0 = fold_h(hs - shc), r1 = fold_h(hs - shc + 1);
                 CT v[4] = {tap(xe + c0 + ch, r0, a0), tap(xe + c0 + ch, r1, a0), tap(xe + c0 + ch, r0, a1), tap(xe + c0 + ch, r1, a1)};
-                o[static_cast<int64_t>(h - h0) * (OUT_CL ? W * C : W)] = narrow<T>(interp_t<T, 2>(v, dws[k]));
+                o[static_cast<int64_t>(h - h0) * (OUT_CL ? OW * C : OW)] = narrow<T>(interp_t<T, 2>(v, dws[k]));
             }
         }
     }
@@ -932,9 +971,8 @@ bool cl_tiled_forward_eligible(const Geometry &g, int dtype, const void *x, cons
     if (g.active && dtype <= SHIFTND_BF16) {  // interpolating: cl_tiled_active_forward (fp32, fp16, bf16), rows folded once
         if (dtype == SHIFTND_F64 || (g.S[1] != 1 && g.S[1] < 5)) return false;
     }
-    const bool interpolating = g.active && dtype <= SHIFTND_BF16;
-    for (int d = 0; d < 3; ++d)   // the window (a crop of the output): the gather kernel only (round 4)
-        if ((g.L[d] != 0 || g.O[d] != g.S[d]) && (interpolating || d == 0 || g.O[d] < 1)) return false;
+    for (int d = 0; d < 3; ++d)   // the window (a crop of the output, round 4): both forward kernels
+        if ((g.L[d] != 0 || g.O[d] != g.S[d]) && (d == 0 || g.O[d] < 1)) return false;
     if ((g.C * es) % 16 != 0 || g.S[1] >= (1 << 20) || g.S[2] >= (1 << 20) || g.N >= (1LL << 24) || g.C >= (1 << 24)) return false;
     if (reinterpret_cast<uintptr_t>(x) % 16 != 0 || reinterpret_cast<uintptr_t>(out) % 4 != 0) return false;
     if (g.C * g.S[1] * g.S[2] * es >= (1LL << 31)) return false;  // one image per buffer resource, offsets below 2^31
@@ -1039,10 +1077,10 @@ ClTiledBwdPlan cl_tiled_backward_plan(const Geometry &g, int es = 4) {
 bool cl_tiled_backward_eligible(const Geometry &g, int dtype, const void *go, const void *x, const void *gx) {
     if (!g_cl_tiled_tune[0] || g.nd != 2 || (dtype != SHIFTND_F32 && dtype != SHIFTND_F16 && dtype != SHIFTND_BF16)) return false;
     const int es = dtype_size(dtype);
-    for (int d = 0; d < 3; ++d)
-        if (g.L[d] != 0 || g.O[d] != g.S[d]) return false;
+    for (int d = 0; d < 3; ++d)   // the window (round 4): grad_out has its sizes
+        if ((g.L[d] != 0 || g.O[d] != g.S[d]) && (d == 0 || g.O[d] < 1)) return false;
     if ((g.C * es) % 16 != 0 || g.S[1] >= (1 << 20) || g.S[2] >= (1 << 20) || g.N >= (1LL << 24) || g.C >= (1 << 24)) return false;
-    if (g.S[1] != 1 && g.S[1] < 5) return false;  // the kernel folds source rows once
+    if ((g.S[1] != 1 && g.S[1] < 5) || (g.O[1] != 1 && g.O[1] < 5)) return false;  // the kernel folds source rows once
     if (g.C * g.S[1] * g.S[2] * es >= (1LL << 31)) return false;
     if (!dense_channels_last_2d(g.xs, g, g.S) || !dense_channels_last_2d(g.gs, g, g.S)) return false;
     // the incoming gradient: channels-last like the others, or NCHW-contiguous (the mixed form: GO_NCHW)
@@ -1089,6 +1127,10 @@ int cl_tiled_backward(const Geometry &g, int dtype, const void *go, const void *
     p.C = static_cast<int>(g.C);
     p.H = static_cast<int>(g.S[1]);
     p.W = static_cast<int>(g.S[2]);
+    p.OH = static_cast<int>(g.O[1]);
+    p.OW = static_cast<int>(g.O[2]);
+    p.LH = static_cast<int>(g.L[1]);
+    p.LW = static_cast<int>(g.L[2]);
     p.pad = g.pad;
     p.go_nchw = dense_channels_last_2d(g.os, g, g.O) ? 0 : 1;   // (a tensor that is both -- C == 1 -- reads the same either way)
     p.wtiles = pl.wtiles;
@@ -1100,6 +1142,8 @@ int cl_tiled_backward(const Geometry &g, int dtype, const void *go, const void *
     p.d_bands = make_fastdiv(static_cast<uint32_t>(p.bands));
     p.d_perH = make_fastdiv(static_cast<uint32_t>(map_period(p.H, p.pad)));
     p.d_perW = make_fastdiv(static_cast<uint32_t>(map_period(p.W, p.pad)));
+    p.d_perOH = make_fastdiv(static_cast<uint32_t>(map_period(p.OH, p.pad)));
+    p.d_perOW = make_fastdiv(static_cast<uint32_t>(map_period(p.OW, p.pad)));
     {
         const int64_t grid = pl.groups * pl.cblocks;
         p.xcd_blocks = (g_cl_tiled_tune[2] && grid % 8 == 0) ? static_cast<unsigned>(grid / 8) : 0;

@@ -231,6 +231,14 @@ def test_tiled_channels_last_cropped_forward_vs_oracle(shape, crop):
                 abi.forward(xd, wd, pad, False, b, out=out_cl)
                 assert abi.last_kernel() == "cl_tiled_forward"
                 assert np.array_equal(out_cl.cpu().numpy(), ref), (shape, crop, pad, "cl")
+                if shape[2] >= 5:   # cl_tiled_active_forward (rows folded once: H >= 5)
+                    ref = O.forward(x, w, pad, True, b)
+                    out = abi.forward(xd, wd, pad, True, b)
+                    assert abi.last_kernel() == "cl_tiled_active_forward" and out.is_contiguous(), abi.last_kernel()
+                    assert np.array_equal(out.cpu().numpy(), ref), (shape, crop, pad, "active nchw")
+                    abi.forward(xd, wd, pad, True, b, out=out_cl)
+                    assert abi.last_kernel() == "cl_tiled_active_forward"
+                    assert np.array_equal(out_cl.cpu().numpy(), ref), (shape, crop, pad, "active cl")
         abi.set_tuning(21, 0)
         if shape[1] % 16 == 0:
             xq = rs.randint(0, 255, size=shape).astype(np.uint8)
@@ -252,6 +260,11 @@ def test_tiled_channels_last_cropped_forward_vs_oracle(shape, crop):
                 abi.forward(xbd, wb.to(DEV), pad, False, b, out=out_cl)
                 assert abi.last_kernel() == "cl_tiled_forward"
                 assert np.array_equal(out_cl.float().cpu().numpy(), ref), (shape, crop, pad, "bf16")
+                if shape[2] >= 5:
+                    ref = torch.from_numpy(O.forward(xb.float().numpy(), wb.float().numpy(), pad, True, b)).to(torch.bfloat16)
+                    abi.forward(xbd, wb.to(DEV), pad, True, b, out=out_cl)
+                    assert abi.last_kernel() == "cl_tiled_active_forward"
+                    assert _ulp_close(out_cl.cpu(), ref, torch.bfloat16), (shape, crop, pad, "bf16 active")
     finally:
         abi.set_tuning(21, 0)
 
@@ -332,6 +345,69 @@ def test_tiled_channels_last_backward_vs_oracle(shape):
                     assert np.array_equal(gx.cpu().numpy(), gx_o), (shape, pad, active, band_rows)
                     assert rel_err(gw.cpu().numpy(), gw64) < 1e-5, (shape, pad, active, band_rows)
         abi.set_tuning(21, 0)
+    finally:
+        abi.set_tuning(21, 0)
+
+
+CL_CROPS_BWD = [((2, 8, 9, 12), [[1, 1], [1, 1]]), ((3, 300, 8, 5), [[0, 2], [1, 0]]), ((2, 64, 40, 70), [[1, 1], [1, 1]]),
+                ((1, 36, 100, 33), [[7, 30], [0, 5]]), ((2, 4, 12, 50), [[6, 0], [3, 3]]), ((1, 32, 64, 9), [[0, 0], [4, 4]]),
+                ((2, 16, 33, 40), [[5, 3], [2, 6]]), ((1, 8, 7, 21), [[3, 3], [0, 20]]), ((2, 12, 30, 16), [[0, 25], [15, 0]])]
+
+
+@pytest.mark.parametrize("go_layout", ["cl", "nchw"])
+@pytest.mark.parametrize("shape,crop", CL_CROPS_BWD)
+def test_tiled_channels_last_cropped_backward_vs_oracle(shape, crop, go_layout):
+    """cl_tiled_backward with a window (round 4): saved input / grad_x channels-last at the full size, grad_out (channels-last or
+    NCHW-contiguous) with the window's sizes; the gradient's maps fold in the WINDOW's sizes (shifts_kernels.h:402-527 through
+    shifts.cpp:93-135), elements outside the window get zero and count nothing.  Windows one row / one column wide, shifts
+    beyond the ring and beyond the dim, every padding, both shifts, ragged bands.  fp32: grad_x bit-exact, grad_w within 1e-5 of
+    the fp64 oracle; bf16 sparse: grad_x bit-exact"""
+    from torchshifts import abi
+    b, new = abi.check_borders(list(shape), crop, 2)
+    rs = np.random.RandomState(sum(shape) + 41)
+    x = rs.uniform(-1, 1, size=shape).astype(np.float32)
+    go = rs.uniform(-1, 1, size=new).astype(np.float32)
+    w = rs.uniform(-3.4, 3.4, size=(shape[1], 2)).astype(np.float32)
+    w[0] = [0.5, -1.5]
+    w[1] = [shape[2] + 2.25, -7.0]       # beyond the dim / beyond the ring
+    w[2] = [-5.0, 2.5]
+    w[3] = [3.0, -3.0]
+    cl = torch.channels_last
+    xd = torch.from_numpy(x).to(DEV).contiguous(memory_format=cl)
+    god = torch.from_numpy(go).to(DEV)
+    if go_layout == "cl":
+        god = god.contiguous(memory_format=cl)
+    wd = torch.from_numpy(w).to(DEV)
+    name = "cl_tiled_backward" if go_layout == "cl" else "cl_tiled_backward_nchw_grad"
+    if new[2] * new[3] == 1:   # a 1 x 1 window is both layouts at once: either reading is right
+        name = ("cl_tiled_backward", "cl_tiled_backward_nchw_grad")
+    tiled = new[2] == 1 or new[2] >= 5   # (the kernel folds the gradient's rows once)
+    try:
+        for band_rows in (0, 5):
+            abi.set_tuning(21, band_rows)
+            for pad in (0, 1, 2, 3, 4):
+                for active in (0, 1):
+                    gx_o, _ = O.backward(go, w, x, pad, active, b)
+                    _, gw64 = O.backward(go.astype(np.float64), w.astype(np.float64), x.astype(np.float64), pad, active, b)
+                    gxd = torch.empty(shape, device=DEV).contiguous(memory_format=cl)
+                    gx, gw = abi.backward(god, wd, xd, pad, active, b, grad_x=gxd)
+                    assert (abi.last_kernel() in name if isinstance(name, tuple) else abi.last_kernel() == name) == tiled, (shape, crop, pad, active, abi.last_kernel())
+                    assert np.array_equal(gx.cpu().numpy(), gx_o), (shape, crop, pad, active, band_rows)
+                    assert rel_err(gw.cpu().numpy(), gw64) < 1e-5, (shape, crop, pad, active, band_rows)
+        abi.set_tuning(21, 0)
+        if (shape[1] * 2) % 16 == 0:
+            tdt = torch.bfloat16
+            x16, go16, w16 = torch.from_numpy(x).to(tdt), torch.from_numpy(go).to(tdt), torch.from_numpy(w).to(tdt)
+            xn, gn, wn = x16.float().numpy(), go16.float().numpy(), w16.float().numpy()
+            g16 = go16.to(DEV).contiguous(memory_format=cl) if go_layout == "cl" else go16.to(DEV)
+            for pad in (0, 1, 2, 3, 4):
+                gx_o = torch.from_numpy(O.backward(gn, wn, xn, pad, 0, b)[0]).to(tdt)
+                _, gw64 = O.backward(gn.astype(np.float64), wn.astype(np.float64), xn.astype(np.float64), pad, 0, b)
+                gxd = torch.empty(shape, dtype=tdt, device=DEV).contiguous(memory_format=cl)
+                gx, gw = abi.backward(g16, w16.to(DEV), x16.to(DEV).contiguous(memory_format=cl), pad, 0, b, grad_x=gxd)
+                assert (abi.last_kernel() in name if isinstance(name, tuple) else abi.last_kernel() == name) == tiled, (shape, crop, pad, abi.last_kernel())
+                assert torch.equal(gx.cpu(), gx_o), (shape, crop, pad, "bf16")
+                assert rel_err(gw.float().cpu().numpy(), gw64) < gw16_tol(float(torch.finfo(tdt).eps)), (shape, crop, pad, "bf16")
     finally:
         abi.set_tuning(21, 0)
 

@@ -18,11 +18,32 @@ from torchshifts import abi  # noqa: E402
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--iters", type=int, default=5)
+    ap.add_argument("--only", default="", help="clcrop: only the cropped channels-last calls of round 4 (the same kernel instantiations "
+                    "as the un-cropped ones: a run of their own keeps the per-kernel averages apart)")
     a = ap.parse_args()
     dev = "cuda:0"
     torch.manual_seed(0)
     cl = torch.channels_last
     calls = []
+    if a.only == "clcrop":   # N16 C256 224x224 fp32 channels-last, cut [[1, 1], [1, 1]] -> 222x222 (modules/shifts.py:41-46)
+        x = torch.rand(16, 256, 224, 224, device=dev).contiguous(memory_format=cl)
+        w = torch.rand(256, 2, device=dev) * 6 - 3
+        b, new = abi.check_borders([16, 256, 224, 224], [[1, 1], [1, 1]], 2)
+        go = torch.rand(new, device=dev).contiguous(memory_format=cl)
+        go_n = torch.rand(new, device=dev)
+        out_c, out_n = torch.empty_like(go), torch.empty_like(go_n)
+        gx, gw = torch.empty_like(x), torch.empty_like(w)
+        ws = abi.backward_workspace(x, 0, 1, b)
+        calls = [lambda: abi.forward(x, w, 0, 0, b, out=out_n), lambda: abi.forward(x, w, 0, 0, b, out=out_c), lambda: abi.forward(x, w, 0, 1, b, out=out_c),
+                 lambda: abi.backward(go, w, x, 0, 0, b, grad_x=gx, grad_w=gw, workspace=ws), lambda: abi.backward(go, w, x, 0, 1, b, grad_x=gx, grad_w=gw, workspace=ws),
+                 lambda: abi.backward(go_n, w, x, 0, 0, b, grad_x=gx, grad_w=gw, workspace=ws)]
+        for f in calls:
+            for _ in range(a.iters):
+                f()
+            print(abi.last_kernel())
+        torch.cuda.synchronize()
+        print("done")
+        return
     x = torch.rand(16, 256, 224, 224, device=dev).contiguous(memory_format=cl)
     go = torch.rand(16, 256, 224, 224, device=dev).contiguous(memory_format=cl)
     w = torch.rand(256, 2, device=dev) * 6 - 3

@@ -50,11 +50,12 @@ struct ClTiledParams {
     uint32_t fill;       // fill element (zero point / 0) in the low bits
     int wkind, N, C, H, W, pad;
     int OH, OW, LH, LW;  // the window: output sizes and its corner in the source image (round 4; no crop: H, W, 0, 0)
+    int D, OD, LD;       // ND3 (NDHWC): planes of the source, of the output, the window's first plane (2-D: 1, 1, 0)
     int out_cl;          // output layout: channels-last (1) or NCHW-contiguous (0)
     int wtiles, cblocks, bands, band_rows;
     unsigned xcd_blocks;     // grid / 8 when the XCD-contiguous block remap is on (grid % 8 == 0 and knob 22), else 0
     FastDiv d_wtiles, d_cblocks, d_bands;
-    FastDiv d_perH, d_perW;
+    FastDiv d_perH, d_perW, d_perD, d_OD;
 };
 
 // integer shifts of NI weights, all loads issued before the first use (gather_shift, one element at a time, pays one
@@ -98,7 +99,13 @@ template <> struct ElemOf<4> { using type = uint32_t; };
 // channels of one pixel (thread = (dword of the pixel line 0..31, pixel lane 0..7), pixels pl + 8 i);  otherwise dword
 // = NE consecutive columns of one channel row (dword D = thread + 256 i of the tile's 128 / ES channel rows of
 // 32 ES bytes).  Either way every element of a thread has a fixed channel and column over the rows.
-template <int ES, bool OUT_CL>
+//
+// ND3 (round 4, NDHWC): a workgroup works on ONE output plane dz.  Its ring is filled element by element, every channel from ITS
+// source plane fold(dz + LD - shift_d(c)) -- so a ring row holds, for every channel, the row of the plane that channel reads,
+// and everything behind the staging is the 2-D kernel unchanged (rows and columns shift through the ring, the depth shift
+// through the staging address).  Every source element is read once, whatever the depth shifts are; the price is 4-byte (2-byte)
+// loads with the lanes along the channels instead of 16-byte pieces.  4- and 2-byte elements.
+template <int ES, bool OUT_CL, bool ND3>
 __global__ __launch_bounds__(kThreads) void cl_tiled_forward(const ClTiledParams p) {
     typedef uint32_t u4 __attribute__((ext_vector_type(4)));
     using EL = typename ElemOf<ES>::type;
@@ -107,6 +114,7 @@ __global__ __launch_bounds__(kThreads) void cl_tiled_forward(const ClTiledParams
     constexpr int RD = 8 * ES;            // NCHW output: dwords per channel-row segment of the tile
     __shared__ uint32_t ring[kRing * kRowWords + 4];   // + dump words for pieces that do not exist
     __shared__ int tab_sh[CB], tab_sw[CB];             // canonical shifts of the workgroup's channels
+    __shared__ int tab_pz[ND3 ? CB : 1];               // ND3: the channel's source plane for this workgroup's output plane (-1: fill)
     constexpr int kDump = kRing * kRowWords;
 
     // ---- which tile ---------------------------------------------------------------------------------------------
@@ -117,72 +125,114 @@ __global__ __launch_bounds__(kThreads) void cl_tiled_forward(const ClTiledParams
     const int cb = static_cast<int>(b - fdiv(b, p.d_cblocks) * p.cblocks);
     b = fdiv(b, p.d_cblocks);
     const int band = static_cast<int>(b - fdiv(b, p.d_bands) * p.bands);
-    const int n = static_cast<int>(fdiv(b, p.d_bands));
+    const unsigned img = fdiv(b, p.d_bands);   // (n, output plane): p.OD == 1 for 2-D problems
+    const int n = static_cast<int>(ND3 ? fdiv(img, p.d_OD) : img);
+    const int dz = ND3 ? static_cast<int>(img) - n * p.OD : 0;
     const int w0 = wt * kTW, c0 = cb * CB;
     // the window (round 4): output rows / columns [0, OH) x [0, OW) read source rows / columns + (LH, LW) through the maps; the
     // ring follows the SOURCE rows hs = h + LH and pixels w0 + LW - R ..
     const int H = p.H, W = p.W, C = p.C, OH = p.OH, OW = p.OW, LH = p.LH, LW = p.LW;
     const int h0 = band * p.band_rows, h1 = min(OH, h0 + p.band_rows);
-    const char *xn = p.x + static_cast<int64_t>(n) * H * W * C * ES;
-    char *on = p.out + static_cast<int64_t>(n) * OH * OW * C * ES;
-    const uint32_t img_bytes = static_cast<uint32_t>(H) * static_cast<uint32_t>(W) * static_cast<uint32_t>(C) * ES;  // < 2^31 (host)
-    const uint32_t out_bytes = static_cast<uint32_t>(OH) * static_cast<uint32_t>(OW) * static_cast<uint32_t>(C) * ES;
+    const int DZ = ND3 ? p.D : 1, OD = ND3 ? p.OD : 1;
+    const char *xn = p.x + static_cast<int64_t>(n) * DZ * H * W * C * ES;
+    char *on = p.out + static_cast<int64_t>(n) * OD * OH * OW * C * ES;
+    const uint32_t img_bytes = static_cast<uint32_t>(DZ) * static_cast<uint32_t>(H) * static_cast<uint32_t>(W) * static_cast<uint32_t>(C) * ES;  // < 2^31 (host)
+    const uint32_t out_bytes = static_cast<uint32_t>(OD) * static_cast<uint32_t>(OH) * static_cast<uint32_t>(OW) * static_cast<uint32_t>(C) * ES;
+    const uint32_t plane_bytes = static_cast<uint32_t>(H) * static_cast<uint32_t>(W) * static_cast<uint32_t>(C) * ES;
     const __amdgpu_buffer_rsrc_t xres = __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(xn), 0, img_bytes, kBufferFlags);
     const __amdgpu_buffer_rsrc_t xnone = __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(xn), 0, 0, kBufferFlags);
     const __amdgpu_buffer_rsrc_t ores = __builtin_amdgcn_make_buffer_rsrc(on, 0, out_bytes, kBufferFlags);
 
+    // ND3: the channels' shifts FIRST -- the staging addresses depend on the depth shift (one weight round trip before the
+    // first row is requested; the 2-D kernel loads its weights while the rows are in flight)
+    auto channel_table = [&]() {
+        if (threadIdx.x < CB) {
+            const int c = min(c0 + static_cast<int>(threadIdx.x), C - 1);
+            if constexpr (ND3) {
+                const int widx[3] = {3 * c, 3 * c + 1, 3 * c + 2};
+                int64_t sh3[3];
+                gather_shifts<3>(p.w, p.wkind, p.wzp, widx, sh3);
+                tab_pz[threadIdx.x] = DZ == 1 ? 0 : fold_index(dz + p.LD - canon_shift(sh3[0], DZ, p.pad, p.d_perD), DZ, p.pad);   // size-1 dims ignore the shift
+                tab_sh[threadIdx.x] = canon_shift(sh3[1], H, p.pad, p.d_perH);
+                tab_sw[threadIdx.x] = canon_shift(sh3[2], W, p.pad, p.d_perW);
+            } else {
+                const int widx[2] = {2 * c, 2 * c + 1};
+                int64_t sh2[2];
+                gather_shifts<2>(p.w, p.wkind, p.wzp, widx, sh2);
+                tab_sh[threadIdx.x] = canon_shift(sh2[0], H, p.pad, p.d_perH);
+                tab_sw[threadIdx.x] = canon_shift(sh2[1], W, p.pad, p.d_perW);
+            }
+        }
+        __syncthreads();
+    };
+    if constexpr (ND3) channel_table();
+
     // ---- staging: 16-byte pieces of source row y: pixel w0 - R + px, bytes 16 q .. of the channel line ---------------
-    uint32_t poff[kNP];    // byte offset of the piece in row 0 of the image, or out of range
-    int pdst[kNP];         // LDS word offset within a ring row, or the dump words
+    // (ND3: elements instead -- element e = px * CB + channel of the staged row, lanes along the channels)
+    constexpr int kNS = ND3 ? (kPW * CB + kThreads - 1) / kThreads : kNP;   // loads per thread and staged row
+    uint32_t poff[kNS];    // byte offset of the piece / element in row 0 of the image (ND3: of its channel's plane), or out of range
+    int pdst[kNS];         // LDS word (ND3: byte) offset within a ring row, or the dump words (-1)
 #pragma unroll
-    for (int k = 0; k < kNP; ++k) {
+    for (int k = 0; k < kNS; ++k) {
         const int q = k * kThreads + static_cast<int>(threadIdx.x);
-        const int px = q >> 3, cbyte = c0 * ES + (q & 7) * 16, gx = w0 + LW - kR + px;
-        const bool piece = q < kPieces;
-        poff[k] = (piece && gx >= 0 && gx < W && cbyte < C * ES) ? static_cast<uint32_t>(gx) * C * ES + cbyte : kOutOfRange;
-        pdst[k] = piece ? px * kPitch + (q & 7) * 4 : -1;
+        if constexpr (ND3) {
+            const int px = q / CB, ch = q - px * CB, gx = w0 + LW - kR + px;
+            const bool elem = px < kPW;
+            const int pz = tab_pz[ch];
+            poff[k] = (elem && gx >= 0 && gx < W && c0 + ch < C && pz >= 0)
+                          ? static_cast<uint32_t>(pz) * plane_bytes + (static_cast<uint32_t>(gx) * C + c0 + ch) * ES : kOutOfRange;
+            pdst[k] = elem ? px * (kPitch * 4) + ch * ES : -1;
+        } else {
+            const int px = q >> 3, cbyte = c0 * ES + (q & 7) * 16, gx = w0 + LW - kR + px;
+            const bool piece = q < kPieces;
+            poff[k] = (piece && gx >= 0 && gx < W && cbyte < C * ES) ? static_cast<uint32_t>(gx) * C * ES + cbyte : kOutOfRange;
+            pdst[k] = piece ? px * kPitch + (q & 7) * 4 : -1;
+        }
     }
     const uint32_t row_bytes = static_cast<uint32_t>(W) * C * ES;
     constexpr int kDepth = CLT_DEPTH;  // rows of staging in flight (a workgroup moves only ~5 KB per row)
-    u4 pvs[kDepth][kNP];
-    auto load_row = [&](int y, int ylast, u4 (&pv)[kNP]) {  // rows outside the image or beyond the band: nothing is read
+    using SV = std::conditional_t<ND3, uint32_t, u4>;   // what one staging load returns
+    SV pvs[kDepth][kNS];
+    auto load_row = [&](int y, int ylast, SV (&pv)[kNS]) {  // rows outside the image or beyond the band: nothing is read
         const bool wanted = y >= 0 && y <= ylast;
         const __amdgpu_buffer_rsrc_t r = wanted ? xres : xnone;
         const uint32_t so = wanted ? static_cast<uint32_t>(y) * row_bytes : 0u;
 #pragma unroll
-        for (int k = 0; k < kNP; ++k) pv[k] = __builtin_amdgcn_raw_buffer_load_b128(r, poff[k], so, 0);
+        for (int k = 0; k < kNS; ++k) {
+            if constexpr (!ND3) pv[k] = __builtin_amdgcn_raw_buffer_load_b128(r, poff[k], so, 0);
+            else if constexpr (ES == 4) pv[k] = __builtin_amdgcn_raw_buffer_load_b32(r, poff[k], so, 0);
+            else if constexpr (ES == 2) pv[k] = __builtin_amdgcn_raw_buffer_load_b16(r, poff[k], so, 0);
+            else pv[k] = __builtin_amdgcn_raw_buffer_load_b8(r, poff[k], so, 0);
+        }
     };
-    auto store_row = [&](int y, const u4 (&pv)[kNP]) {
+    auto store_row = [&](int y, const SV (&pv)[kNS]) {
         const int slot = (y % kRing + kRing) % kRing;
 #pragma unroll
-        for (int k = 0; k < kNP; ++k) {
-            uint32_t *d = ring + (pdst[k] >= 0 ? slot * kRowWords + pdst[k] : kDump);
-            d[0] = pv[k].x;
-            d[1] = pv[k].y;
-            d[2] = pv[k].z;
-            d[3] = pv[k].w;
+        for (int k = 0; k < kNS; ++k) {
+            if constexpr (ND3) {
+                char *d = reinterpret_cast<char *>(ring) + (pdst[k] >= 0 ? slot * (kRowWords * 4) + pdst[k] : kDump * 4);
+                *reinterpret_cast<EL *>(d) = static_cast<EL>(pv[k]);
+            } else {
+                uint32_t *d = ring + (pdst[k] >= 0 ? slot * kRowWords + pdst[k] : kDump);
+                d[0] = pv[k].x;
+                d[1] = pv[k].y;
+                d[2] = pv[k].z;
+                d[3] = pv[k].w;
+            }
         }
     };
     const int ylast = min(H - 1, h1 - 1 + LH + kR);
     // The kDepth rows for the first steps are requested BEFORE the ring rows: when those have arrived nothing is
     // pending any more, so the loop's wait counts are those of its own back edge (kDepth rows of loads and stores
     // in flight), not the shorter distance of this prologue.
-    u4 pre[2 * kR][kNP];
+    SV pre[2 * kR][kNS];
 #pragma unroll
     for (int d = 0; d < kDepth; ++d) load_row(h0 + LH + kR + d, ylast, pvs[d]);
 #pragma unroll
     for (int r = 0; r < 2 * kR; ++r) load_row(h0 + LH - kR + r, ylast, pre[r]);
 
     // ---- the channels' shifts (while the rows are in flight) -----------------------------------------------------------
-    if (threadIdx.x < CB) {
-        const int c = min(c0 + static_cast<int>(threadIdx.x), C - 1);
-        const int widx[2] = {2 * c, 2 * c + 1};
-        int64_t sh2[2];
-        gather_shifts<2>(p.w, p.wkind, p.wzp, widx, sh2);
-        tab_sh[threadIdx.x] = canon_shift(sh2[0], H, p.pad, p.d_perH);
-        tab_sw[threadIdx.x] = canon_shift(sh2[1], W, p.pad, p.d_perW);
-    }
-    __syncthreads();
+    if constexpr (!ND3) channel_table();
 
     // ---- thread -> elements -------------------------------------------------------------------------------------------
     const int lane_a = static_cast<int>(threadIdx.x) & 31, lane_b = static_cast<int>(threadIdx.x) >> 5;
@@ -209,7 +259,8 @@ __global__ __launch_bounds__(kThreads) void cl_tiled_forward(const ClTiledParams
             const int sh = tab_sh[ch], sw = tab_sw[ch];
             if (OUT_CL) csh[j] = sh;
             else csh[i] = sh;
-            const int sx = W == 1 ? 0 : fold_index(w0 + LW + min(col, OW - 1 - w0) - sw, W, p.pad);  // size-1 dims ignore the shift
+            int sx = W == 1 ? 0 : fold_index(w0 + LW + min(col, OW - 1 - w0) - sw, W, p.pad);  // size-1 dims ignore the shift
+            if constexpr (ND3) sx = tab_pz[ch] < 0 ? -1 : sx;   // the channel's source plane is padding: fill, like a column outside
             gcol[i][j] = sx;
             // canon_shift returns the non-negative representative for the reflecting paddings: look at the signed one
             const int sh_s = (perH && 2 * sh > perH) ? sh - perH : sh, sw_s = (perW && 2 * sw > perW) ? sw - perW : sw;
@@ -222,8 +273,8 @@ __global__ __launch_bounds__(kThreads) void cl_tiled_forward(const ClTiledParams
         }
         // (C * ES and W * ES are multiples of 4 where it matters: a dword is live or dead as a whole)
         const int ch0 = OUT_CL ? lane_a * NE : D / RD, col0 = OUT_CL ? lane_b + 8 * i : (D % RD) * NE;
-        const uint32_t o = OUT_CL ? (static_cast<uint32_t>(h0 * OW + w0 + col0) * C + c0 + ch0) * ES
-                                  : (static_cast<uint32_t>((c0 + ch0) * OH + h0) * OW + w0 + col0) * ES;
+        const uint32_t o = OUT_CL ? (static_cast<uint32_t>((dz * OH + h0) * OW + w0 + col0) * C + c0 + ch0) * ES
+                                  : (static_cast<uint32_t>(((c0 + ch0) * OD + dz) * OH + h0) * OW + w0 + col0) * ES;
         ooff[i] = live_dw ? o : kOutOfRange;
     }
     const uint32_t ostep = static_cast<uint32_t>(OUT_CL ? OW * C : OW) * ES;
@@ -236,7 +287,7 @@ __global__ __launch_bounds__(kThreads) void cl_tiled_forward(const ClTiledParams
     }
     const uint8_t *ringb = reinterpret_cast<const uint8_t *>(ring);
     const bool periodic = p.pad == 2 && H > 1;
-    auto step = [&](int h, u4 (&pv)[kNP]) {
+    auto step = [&](int h, SV (&pv)[kNS]) {
         const int hs = h + LH;   // the source row of output row h under a zero shift
         __syncthreads();  // everybody is done with the slot that row hs + R replaces (row hs - R - 1)
         if (hs + kR < H) store_row(hs + kR, pv);
@@ -293,13 +344,14 @@ __global__ __launch_bounds__(kThreads) void cl_tiled_forward(const ClTiledParams
                 const int ch = OUT_CL ? lane_a * NE + j : D / RD;
                 const int col = OUT_CL ? lane_b + 8 * i : (D % RD) * NE + j;
                 const EL *xe = reinterpret_cast<const EL *>(xn);
-                EL *o = reinterpret_cast<EL *>(on) + (OUT_CL ? (static_cast<int64_t>(h0) * OW + w0 + col) * C + c0 + ch
-                                                             : (static_cast<int64_t>(c0 + ch) * OH + h0) * OW + w0 + col);
+                EL *o = reinterpret_cast<EL *>(on) + (OUT_CL ? ((static_cast<int64_t>(dz) * OH + h0) * OW + w0 + col) * C + c0 + ch
+                                                             : ((static_cast<int64_t>(c0 + ch) * OD + dz) * OH + h0) * OW + w0 + col);
+                const int64_t zoff = ND3 ? static_cast<int64_t>(tab_pz[ch]) * H * W * C : 0;   // the channel's source plane (far: pz >= 0)
                 const int shc = csh[OUT_CL ? j : i];
                 for (int h = h0; h < h1; ++h) {
                     const int sy = H == 1 ? 0 : fold_index(h + LH - shc, H, p.pad);
                     if (all_rows || sy < h + LH - kR || sy > h + LH + kR)
-                        *o = sy >= 0 ? xe[(static_cast<int64_t>(sy) * W + gcol[i][j]) * C + c0 + ch] : static_cast<EL>(p.fill);
+                        *o = sy >= 0 ? xe[zoff + (static_cast<int64_t>(sy) * W + gcol[i][j]) * C + c0 + ch] : static_cast<EL>(p.fill);
                     o += OUT_CL ? OW * C : OW;
                 }
             }
@@ -955,6 +1007,15 @@ bool dense_channels_last_2d(const int64_t st[5], const Geometry &g, const int64_
 bool contiguous_2d(const int64_t st[5], const Geometry &g, const int64_t sz[3]) {
     return st[4] == 1 && (sz[1] == 1 || st[3] == sz[2]) && st[1] == sz[1] * sz[2] && (g.N == 1 || st[0] == g.C * sz[1] * sz[2]);
 }
+// 3-D: dense NDHWC (channels_last_3d) / NCDHW-contiguous
+bool dense_channels_last_3d(const int64_t st[5], const Geometry &g, const int64_t sz[3]) {
+    return st[1] == 1 && st[4] == g.C && (sz[1] == 1 || st[3] == g.C * sz[2]) && (sz[0] == 1 || st[2] == g.C * sz[1] * sz[2]) &&
+           (g.N == 1 || st[0] == g.C * sz[0] * sz[1] * sz[2]);
+}
+bool contiguous_3d(const int64_t st[5], const Geometry &g, const int64_t sz[3]) {
+    return st[4] == 1 && (sz[1] == 1 || st[3] == sz[2]) && (sz[0] == 1 || st[2] == sz[1] * sz[2]) && st[1] == sz[0] * sz[1] * sz[2] &&
+           (g.N == 1 || st[0] == g.C * sz[0] * sz[1] * sz[2]);
+}
 
 }  // namespace
 
@@ -967,14 +1028,21 @@ void cl_tiled_set_tuning(int knob, int value) {
 // NCHW-contiguous with rows of whole dwords
 bool cl_tiled_forward_eligible(const Geometry &g, int dtype, const void *x, const void *out) {
     const int es = dtype_size(dtype);
-    if (!g_cl_tiled_tune[0] || g.nd != 2 || es > 4) return false;
+    if (!g_cl_tiled_tune[0] || (g.nd != 2 && g.nd != 3) || es > 4) return false;
     if (g.active && dtype <= SHIFTND_BF16) {  // interpolating: cl_tiled_active_forward (fp32, fp16, bf16), rows folded once
-        if (dtype == SHIFTND_F64 || (g.S[1] != 1 && g.S[1] < 5)) return false;
+        if (g.nd != 2 || dtype == SHIFTND_F64 || (g.S[1] != 1 && g.S[1] < 5)) return false;
     }
     for (int d = 0; d < 3; ++d)   // the window (a crop of the output, round 4): both forward kernels
-        if ((g.L[d] != 0 || g.O[d] != g.S[d]) && (d == 0 || g.O[d] < 1)) return false;
+        if ((g.L[d] != 0 || g.O[d] != g.S[d]) && ((d == 0 && g.nd != 3) || g.O[d] < 1)) return false;
     if ((g.C * es) % 16 != 0 || g.S[1] >= (1 << 20) || g.S[2] >= (1 << 20) || g.N >= (1LL << 24) || g.C >= (1 << 24)) return false;
     if (reinterpret_cast<uintptr_t>(x) % 16 != 0 || reinterpret_cast<uintptr_t>(out) % 4 != 0) return false;
+    if (g.nd == 3) {   // NDHWC (round 4): the gather kernel of 2- and 4-byte elements, one output plane per workgroup
+        if (es < 2 || g.S[0] >= (1 << 20) || g.N * g.O[0] >= (1LL << 24)) return false;
+        if (g.C * g.S[0] * g.S[1] * g.S[2] * es >= (1LL << 31) || g.C * g.O[0] * g.O[1] * g.O[2] * es >= (1LL << 31)) return false;
+        if (!dense_channels_last_3d(g.xs, g, g.S)) return false;
+        if (dense_channels_last_3d(g.os, g, g.O)) return true;
+        return contiguous_3d(g.os, g, g.O) && (g.O[2] * es) % 4 == 0;
+    }
     if (g.C * g.S[1] * g.S[2] * es >= (1LL << 31)) return false;  // one image per buffer resource, offsets below 2^31
     if (!dense_channels_last_2d(g.xs, g, g.S)) return false;
     if (dense_channels_last_2d(g.os, g, g.O)) return true;
@@ -999,14 +1067,18 @@ int cl_tiled_forward(const Geometry &g, int dtype, const void *x, const void *w,
     p.OW = static_cast<int>(g.O[2]);
     p.LH = static_cast<int>(g.L[1]);
     p.LW = static_cast<int>(g.L[2]);
+    p.D = static_cast<int>(g.S[0]);
+    p.OD = static_cast<int>(g.O[0]);
+    p.LD = static_cast<int>(g.L[0]);
     p.pad = g.pad;
-    p.out_cl = dense_channels_last_2d(g.os, g, g.O) ? 1 : 0;
+    const bool nd3 = g.nd == 3;
+    p.out_cl = (nd3 ? dense_channels_last_3d(g.os, g, g.O) : dense_channels_last_2d(g.os, g, g.O)) ? 1 : 0;
     p.wtiles = (p.OW + kTW - 1) / kTW;
     const int cb = kLine / es;
     p.cblocks = (p.C + cb - 1) / cb;
     // bands along H: enough workgroups (~7 per workgroup slot of the chip: 28-row bands measured best on N16 C256
     // 224x224), at least 8 R rows per band (the ring warm-up is 2 R rows)
-    const int64_t base = static_cast<int64_t>(p.N) * p.wtiles * p.cblocks;
+    const int64_t base = static_cast<int64_t>(p.N) * p.OD * p.wtiles * p.cblocks;   // (2-D: OD == 1)
     int64_t bands = g_cl_tiled_tune[1] > 0 ? (p.OH + g_cl_tiled_tune[1] - 1) / g_cl_tiled_tune[1] : (7168 + base - 1) / base;
     const int64_t max_bands = p.OH / (8 * kR) > 0 ? p.OH / (8 * kR) : 1;
     if (g_cl_tiled_tune[1] <= 0 && bands > max_bands) bands = max_bands;
@@ -1021,6 +1093,18 @@ int cl_tiled_forward(const Geometry &g, int dtype, const void *x, const void *w,
     p.d_bands = make_fastdiv(static_cast<uint32_t>(p.bands));
     p.d_perH = make_fastdiv(static_cast<uint32_t>(map_period(p.H, p.pad)));
     p.d_perW = make_fastdiv(static_cast<uint32_t>(map_period(p.W, p.pad)));
+    p.d_perD = make_fastdiv(static_cast<uint32_t>(map_period(p.D, p.pad)));
+    p.d_OD = make_fastdiv(static_cast<uint32_t>(p.OD));
+    if (nd3) {
+        note_kernel("cl_tiled_forward_3d");
+#define SHIFTND_CLT_LAUNCH3(ESV) \
+    if (p.out_cl) hipLaunchKernelGGL((cl_tiled_forward<ESV, true, true>), dim3(static_cast<unsigned>(grid)), dim3(kThreads), 0, st, p); \
+    else hipLaunchKernelGGL((cl_tiled_forward<ESV, false, true>), dim3(static_cast<unsigned>(grid)), dim3(kThreads), 0, st, p);
+        if (es == 4) { SHIFTND_CLT_LAUNCH3(4) }
+        else { SHIFTND_CLT_LAUNCH3(2) }
+#undef SHIFTND_CLT_LAUNCH3
+        return SHIFTND_OK;
+    }
     if (g.active && dtype <= SHIFTND_BF16) {
         note_kernel("cl_tiled_active_forward");
 #define SHIFTND_CLT_ACTIVE(TT) \
@@ -1034,8 +1118,8 @@ int cl_tiled_forward(const Geometry &g, int dtype, const void *x, const void *w,
     }
     note_kernel("cl_tiled_forward");
 #define SHIFTND_CLT_LAUNCH(ESV) \
-    if (p.out_cl) hipLaunchKernelGGL((cl_tiled_forward<ESV, true>), dim3(static_cast<unsigned>(grid)), dim3(kThreads), 0, st, p); \
-    else hipLaunchKernelGGL((cl_tiled_forward<ESV, false>), dim3(static_cast<unsigned>(grid)), dim3(kThreads), 0, st, p);
+    if (p.out_cl) hipLaunchKernelGGL((cl_tiled_forward<ESV, true, false>), dim3(static_cast<unsigned>(grid)), dim3(kThreads), 0, st, p); \
+    else hipLaunchKernelGGL((cl_tiled_forward<ESV, false, false>), dim3(static_cast<unsigned>(grid)), dim3(kThreads), 0, st, p);
     if (es == 4) { SHIFTND_CLT_LAUNCH(4) }
     else if (es == 2) { SHIFTND_CLT_LAUNCH(2) }
     else { SHIFTND_CLT_LAUNCH(1) }

@@ -1,6 +1,7 @@
 """A seeded, time-boxed slice of tools/fuzz_round2.py in the GPU suite: random shapes, paddings, shift kinds, launch-planning
 knobs and dtypes through the round-2 / round-3 kernel families (LDS-tiled channels-last, small planes / row bands, the
-byte kernel, the one-step kernels, the 3-D walk kernels incl. the pooled backward), every case against the CPU oracle (bit-exact gathers and fp32 / fp64 interpolation,
+byte kernel, the one-step kernels, the 3-D walk kernels incl. the pooled backward; round 4: crops and Shift1d through the crop / row kernels,
+channels-last windows), every case against the CPU oracle (bit-exact gathers and fp32 / fp64 interpolation,
 1 ulp for 16-bit interpolation, grad_w 1e-5 / 16-bit epsilon of the fp64 evaluation).  The standalone tool runs the same
 cases for as long as asked."""
 import os
@@ -22,10 +23,11 @@ def test_random_cases_against_the_oracle(seed):
     rs = np.random.RandomState(1000 + seed)
     F.count.clear()
     t0, n = time.time(), 0
-    while time.time() - t0 < 20.0 or n < 60:  # ~20 s per seed, at least 60 cases
+    while time.time() - t0 < 25.0 or n < 88:  # ~25 s per seed, at least 8 rounds of the case list
         F.CASES[n % len(F.CASES)](rs)
         n += 1
     kernels = set(F.count)
-    for must in ("cl_tiled_backward", "step_backward", "step_gather_forward", "walk_forward", "walk_backward", "walk_backward16", "walk_backward_pool"):
+    for must in ("cl_tiled_backward", "step_backward", "step_gather_forward", "walk_forward", "walk_backward", "walk_backward16", "walk_backward_pool",
+                 "crop_backward", "cl_tiled_backward/crop"):
         assert must in kernels, (must, dict(F.count))
     assert any(k.startswith(("small_", "band_")) for k in kernels), dict(F.count)

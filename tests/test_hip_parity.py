@@ -90,8 +90,8 @@ def test_golden_quantized(abi, policy):
         out = abi.forward_quantized(x, w, wzp, xzp, pad, b, out=out)
         assert np.array_equal(out.cpu().numpy(), out_r), key
         if layout != "nchw" and policy in (0, 4) and x.shape[1] > 1:
-            # (2-D, no crop, pixel lines of whole 16-byte pieces: the LDS-tiled kernel)
-            tiled = nd == 2 and crop is None and (x.shape[1] * x.element_size()) % 16 == 0
+            # (2-D, pixel lines of whole 16-byte pieces: the LDS-tiled kernel; windows too since round 4)
+            tiled = nd == 2 and (x.shape[1] * x.element_size()) % 16 == 0
             assert abi.last_path() == abi.PATH_CL and abi.last_kernel() == ("cl_tiled_forward" if tiled else "cl_gather_forward"), key
         if policy in (0, 2, 3) and layout == "nchw":
             assert abi.last_path() == (abi.PATH_SWEEP if policy == 3 else abi.PATH_PLANE), key
@@ -426,8 +426,9 @@ def test_channels_last_kernels_vs_oracle(abi, dt):
                 ref = O.forward(x, w, pad, active, b)
                 gx_o, _ = O.backward(go, w, x, pad, active, b)
                 _, gw64 = O.backward(go.astype(np.float64), w.astype(np.float64), x.astype(np.float64), pad, active, b)
-                # the LDS-tiled kernel (shiftnd_cl_tiled.hip) serves 4-byte 2-D gathers without crop
-                tiled = dt == "f32" and nd == 2 and crop is None and shape[1] % 4 == 0
+                # the LDS-tiled kernels (shiftnd_cl_tiled.hip) serve 4-byte 2-D tensors whose pixel lines are whole pieces
+                # (windows too since round 4; the cropped case of this list has 5 channels)
+                tiled = dt == "f32" and nd == 2 and shape[1] % 4 == 0
                 for policy in (0, 4):  # 0 picks the channel-fastest kernels when every tensor is channels-last
                     abi.set_path_policy(policy)
                     out = abi.forward(xd, wd, pad, active, b)  # NCHW-contiguous output (shifts_cpu.cpp:221)

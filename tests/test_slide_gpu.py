@@ -269,6 +269,67 @@ def test_tiled_channels_last_cropped_forward_vs_oracle(shape, crop):
         abi.set_tuning(21, 0)
 
 
+CL3_CASES = [((2, 8, 4, 9, 12), None), ((1, 36, 3, 10, 33), None), ((2, 64, 5, 12, 40), [[1, 1], [1, 1], [1, 1]]),
+             ((1, 32, 1, 6, 7), None), ((2, 4, 6, 1, 50), None), ((1, 12, 7, 8, 1), [[2, 3], [0, 0], [0, 0]]),
+             ((1, 16, 16, 20, 35), [[0, 1], [3, 0], [2, 2]])]
+
+
+@pytest.mark.parametrize("shape,crop", CL3_CASES)
+def test_tiled_channels_last_3d_forward_vs_oracle(shape, crop):
+    """cl_tiled_forward<..., ND3> (round 4, NDHWC): dense channels_last_3d fp32 / bf16 / int32 input, output channels_last_3d or
+    NCDHW-contiguous; every padding, depth shifts of any size (through the staging address), row / column shifts beyond the
+    ring, windows in all three dims, size-1 dims; bit-exact vs the oracle"""
+    from torchshifts import abi
+    cl3 = torch.channels_last_3d
+    b, new = abi.check_borders(list(shape), crop, 3)
+    rs = np.random.RandomState(sum(shape) + 57)
+    x = rs.uniform(-1, 1, size=shape).astype(np.float32)
+    w = rs.uniform(-3.4, 3.4, size=(shape[1], 3)).astype(np.float32)
+    w[0] = [0.5, -1.5, 1.0]
+    w[1] = [shape[2] + 2.25, shape[3] + 1.0, -7.0]       # beyond the dims / beyond the ring
+    w[2] = [-5.0, 2.5, -2.0]
+    w[3] = [1.0, 0.0, 0.0]
+    xd = torch.from_numpy(x).to(DEV).contiguous(memory_format=cl3)
+    wd = torch.from_numpy(w).to(DEV)
+    try:
+        for band_rows in (0, 5):
+            abi.set_tuning(21, band_rows)
+            for pad in (0, 1, 2, 3, 4):
+                ref = O.forward(x, w, pad, False, b)
+                out = abi.forward(xd, wd, pad, False, b)  # NCDHW-contiguous output
+                assert abi.last_kernel() == "cl_tiled_forward_3d" and out.is_contiguous(), abi.last_kernel()
+                assert np.array_equal(out.cpu().numpy(), ref), (shape, crop, pad, "ncdhw")
+                out_cl = torch.empty(new, device=DEV).contiguous(memory_format=cl3)
+                abi.forward(xd, wd, pad, False, b, out=out_cl)
+                assert abi.last_kernel() == "cl_tiled_forward_3d"
+                assert np.array_equal(out_cl.cpu().numpy(), ref), (shape, crop, pad, "cl")
+        abi.set_tuning(21, 0)
+        # int32 quantized: fill = the input's zero point, format kept (shifts_quantized.cpp:119-121)
+        xq = rs.randint(-1000, 1000, size=shape).astype(np.int32)
+        wq = rs.randint(124, 133, size=(shape[1], 3)).astype(np.uint8)
+        xqd = torch.from_numpy(xq).to(DEV).contiguous(memory_format=cl3)
+        for pad in (0, 2, 3):
+            outq = torch.empty(new, dtype=torch.int32, device=DEV).contiguous(memory_format=cl3)
+            abi.forward_quantized(xqd, torch.from_numpy(wq).to(DEV), 128, -7, pad, b, out=outq)
+            assert abi.last_kernel() == "cl_tiled_forward_3d"
+            assert np.array_equal(outq.cpu().numpy(), O.forward_q(xq, wq, 128, -7, pad, b)), (shape, crop, pad, "i32")
+        if shape[1] % 8 == 0:
+            xb, wb = torch.from_numpy(x).to(torch.bfloat16), torch.from_numpy(w).to(torch.bfloat16)
+            xbd = xb.to(DEV).contiguous(memory_format=cl3)
+            for pad in (0, 1, 2, 3, 4):
+                ref = O.forward(xb.float().numpy(), wb.float().numpy(), pad, False, b)
+                out_cl = torch.empty(new, dtype=torch.bfloat16, device=DEV).contiguous(memory_format=cl3)
+                abi.forward(xbd, wb.to(DEV), pad, False, b, out=out_cl)
+                assert abi.last_kernel() == "cl_tiled_forward_3d"
+                assert np.array_equal(out_cl.float().cpu().numpy(), ref), (shape, crop, pad, "bf16 cl")
+                if (new[4] * 2) % 4 == 0:
+                    out = abi.forward(xbd, wb.to(DEV), pad, False, b)
+                    assert abi.last_kernel() == "cl_tiled_forward_3d" and out.is_contiguous()
+                    assert np.array_equal(out.float().cpu().numpy(), ref), (shape, crop, pad, "bf16 ncdhw")
+    finally:
+        abi.set_tuning(21, 0)
+
+
 @pytest.mark.parametrize("shape", [(2, 16, 9, 12), (1, 144, 20, 37), (2, 64, 40, 70), (1, 32, 5, 6)])
 def test_tiled_channels_last_forward_small_elements(shape):
     """cl_tiled_forward for 1- and 2-byte elements (a dword of output = 4 / 2 elements with their own shifts): quantized

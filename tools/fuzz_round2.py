@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Randomised parity run of the round-2 / round-3 kernel families against the oracle (GPU box; a seeded, time-boxed slice of
+"""Randomised parity run of the round-2 / round-3 / round-4 kernel families against the oracle (GPU box; a seeded, time-boxed slice of
 it runs in `pytest -m gpu`: tests/test_fuzz_families_gpu.py):
     python3 tools/fuzz_round2.py [--seconds 120] [--seed 0]
 channels-last tiled kernels (forward 1/2/4 bytes, active forward, backward), small-plane / row-band kernels, the byte
@@ -280,7 +280,109 @@ def case_walk(rs):
         abi.set_tuning(35, 0)
 
 
-CASES = [case_cl, case_ragged, case_ragged, case_bytes, case_step, case_step, case_walk, case_walk]
+def _random_crop(rs, sizes):
+    """borders argument: per dim [left cut, right cut], each side 0 .. a third of the dim, at least one element kept"""
+    crop = []
+    for s in sizes:
+        l = int(rs.randint(0, max(1, s // 3) + 1)) if rs.randint(3) else 0
+        r = int(rs.randint(0, max(1, s // 3) + 1)) if rs.randint(3) else 0
+        if l + r >= s:
+            l, r = 0, 0
+        crop.append([l, r])
+    return crop
+
+
+def _check_float(tag, tdt, got, ref, exact, floor=0.0):
+    from test_hip_parity import _ulp_close
+    refd = torch.from_numpy(ref).to(tdt)
+    if exact:
+        assert torch.equal(got.cpu(), refd), tag
+    else:
+        assert _ulp_close(got.cpu(), refd, tdt, floor), tag
+
+
+def case_crop(rs):
+    """round 4: windows (crops) and Shift1d through the lean one-step kernels of shiftnd_span.hip -- 1-D / 2-D problems whose x rows
+    are whole 16-byte pieces, every float dtype, every padding, both shifts, random asymmetric cuts; default routing (which
+    kernel took a call is counted, the routing itself is pinned by tests/test_span_gpu.py and tests/test_routing_gpu.py)"""
+    tdt = [torch.float32, torch.float64, torch.float16, torch.bfloat16][rs.randint(4)]
+    es = torch.empty(0, dtype=tdt).element_size()
+    per16 = 16 // es
+    nd = 1 if rs.randint(3) == 0 else 2
+    if nd == 1:
+        sp = (per16 * int(rs.choice([1, 3, 16, 128, 130, 257, 300, 513, 1024])),)
+    else:
+        sp = (int(rs.choice([1, 2, 5, 9, 18, 37, 64])), per16 * int(rs.choice([1, 2, 3, 7, 14, 16, 28, 56, 100, 254])))
+    N, C = int(rs.randint(1, 4)), int(rs.randint(1, 6))
+    shape = (N, C) + sp
+    crop = _random_crop(rs, sp) if (nd == 2 or rs.randint(2)) else None
+    b, new = abi.check_borders(list(shape), crop, nd)
+    total = int(np.prod(new))
+    pad = int(rs.randint(0, 5)); active = int(rs.randint(0, 2))
+    xt = torch.from_numpy(rs.uniform(-1, 1, size=shape)).to(tdt); gt = torch.from_numpy(rs.uniform(-1, 1, size=new)).to(tdt)
+    wt = torch.from_numpy(weights(rs, C, nd, sp, 4.5)).to(tdt)
+    wide = np.float64 if tdt == torch.float64 else np.float32
+    x, go, w = (t.to(torch.float64).numpy().astype(wide) for t in (xt, gt, wt))
+    xd, gd, wd = xt.to(DEV), gt.to(DEV), wt.to(DEV)
+    exact = tdt in (torch.float32, torch.float64) or not active
+    cropped = list(new) != list(shape)
+    o = abi.forward(xd, wd, pad, active, b)
+    count[abi.last_kernel()] += 1
+    _check_float(("crop fwd", shape, crop, tdt, pad, active, abi.last_kernel()), tdt, o, O.forward(x, w, pad, active, b), exact, 32 * 2.0 ** -24)
+    gx, gw = abi.backward(gd, wd, xd, pad, active, b)
+    count[abi.last_kernel()] += 1
+    _check_float(("crop gx", shape, crop, tdt, pad, active, abi.last_kernel()), tdt, gx, O.backward(go, w, x, pad, active, b)[0], exact, 32 * 2.0 ** -24)
+    _, gw64 = O.backward(go.astype(np.float64), w.astype(np.float64), x.astype(np.float64), pad, active, b)
+    tol = {torch.float64: 1e-12, torch.float32: 1e-5}.get(tdt, 0.51 * float(torch.finfo(tdt).eps))
+    if tdt == torch.float32:   # (a sum that cancels: the fp32 evaluation's own error is the bar -- tests/test_span_gpu.py)
+        tol = max(tol, 2 * rel_err(O.backward(go, w, x, pad, active, b)[1], gw64))
+    e = rel_err(gw.to(torch.float64).cpu().numpy(), gw64)
+    assert e < tol, ("crop gw", shape, crop, tdt, pad, active, abi.last_kernel(), e)
+
+
+def case_cl_crop(rs):
+    """round 4: the LDS-tiled channels-last kernels with a window -- forward (both output layouts), interpolating forward,
+    backward with either gradient layout; fp32, and quint8 keeping the format"""
+    C = int(rs.choice([4, 8, 12, 32, 36, 64, 100]))
+    H = int(rs.choice([5, 6, 9, 17, 33])); W = int(rs.randint(2, 41))
+    N = int(rs.randint(1, 4))
+    shape = (N, C, H, W)
+    crop = _random_crop(rs, (H, W))
+    b, new = abi.check_borders(list(shape), crop, 2)
+    pad = int(rs.randint(0, 5)); active = int(rs.randint(0, 2))
+    x = rs.uniform(-1, 1, size=shape).astype(np.float32); go = rs.uniform(-1, 1, size=new).astype(np.float32)
+    w = weights(rs, C, 2, shape[2:], 3.9).astype(np.float32)
+    cl = torch.channels_last
+    xd = torch.from_numpy(x).to(DEV).contiguous(memory_format=cl)
+    wd = torch.from_numpy(w).to(DEV)
+    abi.set_tuning(21, int(rs.choice([0, 0, 3, 7])))
+    try:
+        ref = O.forward(x, w, pad, active, b)
+        for out in (None, torch.empty(new, device=DEV).contiguous(memory_format=cl)):
+            o = abi.forward(xd, wd, pad, active, b, out=out)
+            count[abi.last_kernel() + "/crop"] += 1
+            assert np.array_equal(o.cpu().numpy(), ref), ("cl crop fwd", shape, crop, pad, active, abi.last_kernel())
+        gd = torch.from_numpy(go).to(DEV)
+        if rs.randint(2):
+            gd = gd.contiguous(memory_format=cl)
+        gx, gw = abi.backward(gd, wd, xd, pad, active, b, grad_x=torch.empty(shape, device=DEV).contiguous(memory_format=cl))
+        count[abi.last_kernel() + "/crop"] += 1
+        gx_o, _ = O.backward(go, w, x, pad, active, b)
+        _, gw64 = O.backward(go.astype(np.float64), w.astype(np.float64), x.astype(np.float64), pad, active, b)
+        assert np.array_equal(gx.cpu().numpy(), gx_o), ("cl crop gx", shape, crop, pad, active, abi.last_kernel())
+        tol = max(1e-5, 2 * rel_err(O.backward(go, w, x, pad, active, b)[1], gw64))
+        assert rel_err(gw.cpu().numpy(), gw64) < tol, ("cl crop gw", shape, crop, pad, active, abi.last_kernel())
+        if C % 16 == 0:
+            xq = rs.randint(0, 256, size=shape).astype(np.uint8); wq = rs.randint(122, 135, size=(C, 2)).astype(np.uint8)
+            oq = torch.empty(new, dtype=torch.uint8, device=DEV).contiguous(memory_format=cl)
+            abi.forward_quantized(torch.from_numpy(xq).to(DEV).contiguous(memory_format=cl), torch.from_numpy(wq).to(DEV), 128, 3, pad, b, out=oq)
+            count[abi.last_kernel() + "/crop/u8"] += 1
+            assert np.array_equal(oq.cpu().numpy(), O.forward_q(xq, wq, 128, 3, pad, b)), ("cl crop u8", shape, crop, pad)
+    finally:
+        abi.set_tuning(21, 0)
+
+
+CASES = [case_cl, case_ragged, case_ragged, case_bytes, case_step, case_step, case_walk, case_walk, case_crop, case_crop, case_cl_crop]
 
 
 

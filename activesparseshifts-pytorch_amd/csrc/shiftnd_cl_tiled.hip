@@ -406,8 +406,20 @@ __global__ __launch_bounds__(kThreads) void cl_tiled_backward(const ClTiledBwdPa
     static_assert(sizeof(S) == 4 || sizeof(S) == 2, "fp32, fp16, bf16");
     constexpr int ES = sizeof(S), CB = kLine / ES;   // channels per workgroup: 32 (fp32) or 64 (16-bit types)
     constexpr int PL = kThreads / CB, NI = kBTW / PL;   // pixel lanes; pixels per thread and row (2 or 4)
-    __shared__ __attribute__((aligned(16))) uint32_t ring[2 * kBRingWords + 4];   // input ring, gradient ring, dump words
-    constexpr int kDump = 2 * kBRingWords;
+    // four zero words, input ring, gradient ring, dump words.  The zero words are what a padding tap reads: row and column offsets
+    // of taps that do not exist are hugely negative (kNeg), the address is max(offset sum, 0) -- no lane masks, no selects, no
+    // exec-mask regions in the row loop (round 4: the loop issued 137 scalar instructions per row, and the CU's one scalar unit
+    // was busy for two thirds of the kernel's time)
+    // words per staged pixel: 32 -- every LDS read of the row loop has its lanes along the CHANNELS of (per lane different) pixels,
+    // bank = channel word whatever the pixel; the padded pitch of the forward kernels (33: their NCHW-output form reads along the
+    // pixels) made half of this kernel's LDS cycles bank conflicts.  GO_NCHW stages along the pixels and keeps 33.
+    constexpr int PITCH = GO_NCHW ? kPitch : kLine / 4;
+    constexpr int BROW = kBPW * PITCH, BRING = kBRing * BROW;
+    __shared__ __attribute__((aligned(16))) uint32_t ring_all[4 + 2 * BRING + 4];
+    uint32_t *const ring = ring_all + 4;
+    constexpr int kDump = 2 * BRING;
+    constexpr int kNeg = -(1 << 24);
+    if (threadIdx.x < 4) ring_all[threadIdx.x] = 0u;   // (read after the first barrier of the row loop)
 
     // ---- which tile ---------------------------------------------------------------------------------------------
     // XCD-contiguous ids: workgroups that share an XCD (blockIdx % 8) and its L2 own neighbouring tiles (shared halo)
@@ -433,7 +445,6 @@ __global__ __launch_bounds__(kThreads) void cl_tiled_backward(const ClTiledBwdPa
     const uint32_t go_bytes = static_cast<uint32_t>(OH) * static_cast<uint32_t>(OW) * static_cast<uint32_t>(C) * ES;
     const __amdgpu_buffer_rsrc_t xres = __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(xn), 0, img_bytes, kBufferFlags);
     const __amdgpu_buffer_rsrc_t gres = __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(gn), 0, go_bytes, kBufferFlags);
-    const __amdgpu_buffer_rsrc_t none = __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(xn), 0, 0, kBufferFlags);
     const __amdgpu_buffer_rsrc_t ores = __builtin_amdgcn_make_buffer_rsrc(on, 0, img_bytes, kBufferFlags);
     // the gradient element (row r, column cc: grad_out's own coordinates) of channel ch, in elements from the image base
     auto g_index = [&](int ch, int r, int cc) {
@@ -446,7 +457,7 @@ __global__ __launch_bounds__(kThreads) void cl_tiled_backward(const ClTiledBwdPa
     const int px = q >> 3, part = q & 7, gxs = w0 - kR + px;
     const uint32_t poff = (piece && gxs >= 0 && gxs < W && c0 * ES + part * 16 < C * ES) ? static_cast<uint32_t>(gxs) * C * ES + c0 * ES + part * 16 : kOutOfRange;
     const uint32_t poffg = (piece && gxs >= LW && gxs < LW + OW && c0 * ES + part * 16 < C * ES) ? static_cast<uint32_t>(gxs - LW) * C * ES + c0 * ES + part * 16 : kOutOfRange;
-    const int pdst = piece ? px * kPitch + part * 4 : -1;
+    const int pdst = piece ? px * PITCH + part * 4 : -1;
     const uint32_t row_bytes = static_cast<uint32_t>(W) * C * ES;
     constexpr int kDepth = CLT_DEPTH;
     // GO_NCHW: element e = ch * kBPW + px of the staged gradient row, kGN per thread
@@ -463,34 +474,38 @@ __global__ __launch_bounds__(kThreads) void cl_tiled_backward(const ClTiledBwdPa
             const int e = k * kThreads + q, ch = e / kBPW, pxe = e - ch * kBPW, gxe = w0 - kR + pxe;
             const bool ok = e < kGE && gxe >= LW && gxe < LW + OW && c0 + ch < C;
             goff[k] = ok ? (static_cast<uint32_t>(c0 + ch) * OH * OW + (gxe - LW)) * ES : kOutOfRange;
-            gdst[k] = e < kGE ? pxe * (kPitch * 4) + ch * ES : -1;
+            gdst[k] = e < kGE ? pxe * (PITCH * 4) + ch * ES : -1;
         }
     }
     const uint32_t grow_bytes = static_cast<uint32_t>(OW) * (GO_NCHW ? 1 : C) * ES;
     u4 pvx[kDepth];
     GRow pvg[kDepth];
     auto load_row = [&](int y, int ylast, u4 &vx, GRow &vg) {  // rows outside the image or beyond the band: nothing is read
-        const bool wanted = y >= 0 && y <= ylast;
-        const uint32_t so = wanted ? static_cast<uint32_t>(y) * row_bytes : 0u;
-        vx = __builtin_amdgcn_raw_buffer_load_b128(wanted ? xres : none, poff, so, 0);
-        const bool wanted_g = wanted && y >= LH && y < LH + OH;   // grad_out's row y - LH
-        const uint32_t sg = wanted_g ? static_cast<uint32_t>(y - LH) * grow_bytes : 0u;
+        // (a row that is not wanted: the out-of-range bit in the vector offset -- one scalar select per row; choosing between the
+        //  image's resource and an empty one compiled to branches around duplicated loads)
+        //  image's resource and an empty one compiled to branches around duplicated loads, and so did selects on "wanted": sign
+        //  arithmetic instead)
+        const int unwanted = (y >> 31) | ((ylast - y) >> 31);   // -1: above the image or beyond what the band needs
+        const uint32_t so = static_cast<uint32_t>(y & ~unwanted) * row_bytes, dead = static_cast<uint32_t>(unwanted) & kOutOfRange;
+        vx = __builtin_amdgcn_raw_buffer_load_b128(xres, poff | dead, so, 0);
+        const int unwanted_g = unwanted | ((y - LH) >> 31) | ((LH + OH - 1 - y) >> 31);   // grad_out's row y - LH
+        const uint32_t sg = static_cast<uint32_t>((y - LH) & ~unwanted_g) * grow_bytes, dead_g = static_cast<uint32_t>(unwanted_g) & kOutOfRange;
         if constexpr (GO_NCHW) {
 #pragma unroll
             for (int k = 0; k < kGN; ++k) {
-                if constexpr (ES == 4) vg.e[k] = __builtin_amdgcn_raw_buffer_load_b32(wanted_g ? gres : none, goff[k], sg, 0);
-                else vg.e[k] = __builtin_amdgcn_raw_buffer_load_b16(wanted_g ? gres : none, goff[k], sg, 0);
+                if constexpr (ES == 4) vg.e[k] = __builtin_amdgcn_raw_buffer_load_b32(gres, goff[k] | dead_g, sg, 0);
+                else vg.e[k] = __builtin_amdgcn_raw_buffer_load_b16(gres, goff[k] | dead_g, sg, 0);
             }
         } else {
-            vg.v = __builtin_amdgcn_raw_buffer_load_b128(wanted_g ? gres : none, poffg, sg, 0);
+            vg.v = __builtin_amdgcn_raw_buffer_load_b128(gres, poffg | dead_g, sg, 0);
         }
     };
     auto store_row = [&](int y, const u4 &vx, const GRow &vg) {
         const int slot = y & (kBRing - 1);
-        uint32_t *dx = ring + (pdst >= 0 ? slot * kBRowWords + pdst : kDump);
+        uint32_t *dx = ring + (pdst >= 0 ? slot * BROW + pdst : kDump);
         dx[0] = vx.x; dx[1] = vx.y; dx[2] = vx.z; dx[3] = vx.w;
         if constexpr (GO_NCHW) {
-            char *gbase = reinterpret_cast<char *>(ring) + (kBRingWords + slot * kBRowWords) * 4;
+            char *gbase = reinterpret_cast<char *>(ring) + (BRING + slot * BROW) * 4;
             char *dump = reinterpret_cast<char *>(ring) + kDump * 4;
 #pragma unroll
             for (int k = 0; k < kGN; ++k) {
@@ -499,7 +514,7 @@ __global__ __launch_bounds__(kThreads) void cl_tiled_backward(const ClTiledBwdPa
                 else *reinterpret_cast<uint16_t *>(d) = static_cast<uint16_t>(vg.e[k]);
             }
         } else {
-            uint32_t *dg = ring + (pdst >= 0 ? kBRingWords + slot * kBRowWords + pdst : kDump);
+            uint32_t *dg = ring + (pdst >= 0 ? BRING + slot * BROW + pdst : kDump);
             dg[0] = vg.v.x; dg[1] = vg.v.y; dg[2] = vg.v.z; dg[3] = vg.v.w;
         }
     };
@@ -538,13 +553,14 @@ __global__ __launch_bounds__(kThreads) void cl_tiled_backward(const ClTiledBwdPa
     // the gradient's maps: grad_out coordinates in, INPUT coordinates out (-1: padding)
     auto fold_gh = [&](int idx) { const int r = OH == 1 ? 0 : fold_index(idx, OH, p.pad); return r < 0 ? -1 : r + LH; };
     auto fold_gw = [&](int idx) { const int r = OW == 1 ? 0 : fold_index(idx, OW, p.pad); return r < 0 ? -1 : r + LW; };
-    // per pixel: LDS byte offsets (within a ring row) of the input corners' columns and of the gradient taps' columns; -1: padding.
+    // per pixel: LDS byte offsets (within a ring row) of the input corners' columns and of the gradient taps' columns; kNeg: padding.
     // A reflected corner can land one step outside the rings (reflect padding, last column / row, shift -R: the
     // corner at distance R + 1 comes back at distance -(R + 1)); such pixels (`scol`) and rows (`skip` below) are left
     // to the element-by-element pass at the end.
     int xc0[NI], xc1[NI], gc0[NI], gc1[NI], gd[NI];
     uint32_t ooff[NI];
     bool live[NI], scol[NI], cpass[NI];   // cpass: the pixel's column lies in the window
+    int lcount[NI];                       // -1: live and in the window (its terms count), else 0
 #pragma unroll
     for (int i = 0; i < NI; ++i) {
         const int col = lane_b + PL * i, wq = w0 + min(col, W - 1 - w0);
@@ -555,12 +571,13 @@ __global__ __launch_bounds__(kThreads) void cl_tiled_backward(const ClTiledBwdPa
         auto outside = [&](int sx) { return sx >= 0 && (sx < w0 - kR || sx > w0 + kBTW + kR); };
         scol[i] = near_c && w0 + col < W && (outside(a0) || outside(a1) || outside(b0) || outside(b1));
         live[i] = near_c && w0 + col < W && !scol[i];
-        auto lds_col = [&](int sx) { return (live[i] && sx >= 0) ? (sx - (w0 - kR)) * (kPitch * 4) + lane_a * ES : -1; };
+        lcount[i] = (live[i] && cpass[i]) ? -1 : 0;
+        auto lds_col = [&](int sx) { return (live[i] && sx >= 0) ? (sx - (w0 - kR)) * (PITCH * 4) + lane_a * ES : kNeg; };
         xc0[i] = lds_col(a0);
         xc1[i] = lds_col(a1);
         gc0[i] = lds_col(b0);
         gc1[i] = lds_col(b1);
-        gd[i] = (col + kR) * (kPitch * 4) + lane_a * ES;
+        gd[i] = (col + kR) * (PITCH * 4) + lane_a * ES;
         ooff[i] = live[i] ? (static_cast<uint32_t>(h0 * W + w0 + col) * C + c) * ES : kOutOfRange;
     }
     const uint32_t ostep = static_cast<uint32_t>(W) * C * ES;
@@ -570,39 +587,31 @@ __global__ __launch_bounds__(kThreads) void cl_tiled_backward(const ClTiledBwdPa
         const int y = h0 - kR + r;
         if (y >= 0 && y < H) store_row(y, prex[r], preg[r]);
     }
-    const char *ringx = reinterpret_cast<const char *>(ring), *ringg = ringx + kBRingWords * 4;
+    const char *ringz = reinterpret_cast<const char *>(ring_all);   // byte 0: the zero words
+    constexpr int ringx = 16, ringg = 16 + BRING * 4;          // the rings, bytes from ringz
     double acc[2] = {0.0, 0.0};
-    auto lds_s = [&](const char *base, int row, int colo) {   // a staged element (storage type), zero where the padding map says so
-        const bool ok = row >= 0 && colo >= 0;
-        const S v = *reinterpret_cast<const S *>(base + (ok ? row + colo : 0));
-        return ok ? v : narrow<T>(CT(0));
+    auto lds_s = [&](int base, int row, int colo) {   // a staged element (storage type); padding (a negative offset) reads a zero word
+        return *reinterpret_cast<const S *>(ringz + max(base + row + colo, 0));
     };
-    auto lds_f = [&](const char *base, int row, int colo) { return widen<T>(lds_s(base, row, colo)); };
-    auto row_off = [&](int sy) { return sy < 0 ? -1 : (sy & (kBRing - 1)) * (kBRowWords * 4); };
+    auto lds_f = [&](int base, int row, int colo) { return widen<T>(lds_s(base, row, colo)); };
+    auto row_off = [&](int sy) { return ((sy & (kBRing - 1)) * (BROW * 4)) | ((sy >> 31) & kNeg); };   // (a negative row: padding)
     // Source rows with ONE fold of the signed shift (|shift| <= R and H >= 5, or H == 1: the host routes nothing else
     // here): idx in [h - R, h + R + 1] leaves [0, H) by at most R + 1 on one side.  Launch-uniform coefficients instead of
     // fold_index's switch: r = idx inside, aLo - m idx below, aHi - m idx above (border: m = 0; reflect / symmetric:
     // m = 1), -1 outside for the zero padding.
+    // Bit arithmetic, not selects: the nested selects compiled to exec-mask regions (six per row).
     const int fm = (p.pad == 3 || p.pad == 4) ? -1 : 0;
     const int fLo = p.pad == 4 ? -1 : 0, fHi = p.pad == 1 ? H - 1 : (p.pad == 3 ? 2 * H - 2 : 2 * H - 1);
-    const bool fzero = p.pad == 0;
-    auto fold1 = [&](int idx) {
-        const bool lo = idx < 0, hi = idx >= H;
-        const int t = idx & fm;
-        int r = lo ? fLo - t : (hi ? fHi - t : idx);
-        r = (fzero && (lo || hi)) ? -1 : r;
-        return H == 1 ? 0 : r;
+    const int zneg = p.pad == 0 ? kNeg : 0;   // zeros padding: outside -> negative
+    auto fold_once = [&](int idx, int n, int lo_c, int hi_c) {
+        const int below = idx >> 31, above = (n - 1 - idx) >> 31, t = idx & fm;
+        const int r = (idx & ~(below | above)) | ((lo_c - t) & below) | ((hi_c - t) & above) | ((below | above) & zneg);
+        return n == 1 ? 0 : r;   // (size-1 dims ignore the shift; launch-uniform)
     };
+    auto fold1 = [&](int idx) { return fold_once(idx, H, fLo, fHi); };
     // the gradient's rows, folded once in the window's sizes (OH >= 5 or OH == 1: host), grad_out row in, input row out
     const int gLo = p.pad == 4 ? -1 : 0, gHi = p.pad == 1 ? OH - 1 : (p.pad == 3 ? 2 * OH - 2 : 2 * OH - 1);
-    auto fold1g = [&](int idx) {
-        const bool lo = idx < 0, hi = idx >= OH;
-        const int t = idx & fm;
-        int r = lo ? gLo - t : (hi ? gHi - t : idx);
-        r = (fzero && (lo || hi)) ? -1 : r;
-        r = OH == 1 ? 0 : r;
-        return r < 0 ? -1 : r + LH;
-    };
+    auto fold1g = [&](int idx) { return fold_once(idx, OH, gLo, gHi) + LH; };   // (padding stays negative: LH < 2^20)
     // the one source row the rings cannot hold: reflect padding, last row (of the image: the input's corners; of the window: the
     // active shift's gradient taps), shift -R (its + 1 corner, at distance R + 1, comes back at distance -(R + 1))
     const bool srow = near_c && p.pad == 3 && H > 1 && sh_s == -kR && h1 == H;
@@ -616,6 +625,7 @@ __global__ __launch_bounds__(kThreads) void cl_tiled_backward(const ClTiledBwdPa
         return periodic && near_c && (h - sh_s < 0 || h + 1 - sh_s >= H || (in_rows && OH > 1 && (g0 < 0 || g0 + (ACTIVE ? 1 : 0) >= OH)));
     };
     int xrow1 = fold1(h0 - sh_s);   // the + 1 corner of step h - 1 is the first corner of step h
+    int grow1 = fold1g(h0 - LH - gh_s);   // ... and so is the active shift's second gradient row
     auto step = [&](int h, u4 &vx, GRow &vg) {
         __syncthreads();  // everybody is done with the slot that row h + R + 1 replaces (row h - R - 1)
         if (h + kR + 1 < H) store_row(h + kR + 1, vx, vg);
@@ -626,9 +636,19 @@ __global__ __launch_bounds__(kThreads) void cl_tiled_backward(const ClTiledBwdPa
         xrow1 = fold1(h + 1 - sh_s);
         const int xr1 = row_off(xrow1);
         const bool rpass = h >= LH && h < LH + OH;   // the row lies in the window (else: zero gradient, nothing counted)
-        const int gr0 = rpass ? row_off(fold1g(h - LH - gh_s)) : -1, gr1 = (ACTIVE && rpass) ? row_off(fold1g(h - LH - gh_s + 1)) : -1;
-        const int gdr = (h & (kBRing - 1)) * (kBRowWords * 4);
-        const bool skip = (srow && h == H - 1) || (srow_g && h == LH + OH - 1) || wraps(h);
+        int gr0, gr1 = kNeg;
+        if constexpr (ACTIVE) {
+            gr0 = rpass ? row_off(grow1) : kNeg;
+            grow1 = fold1g(h + 1 - LH - gh_s);
+            gr1 = rpass ? row_off(grow1) : kNeg;
+        } else {
+            gr0 = rpass ? row_off(fold1g(h - LH - gh_s)) : kNeg;
+        }
+        const int gdr = (h & (kBRing - 1)) * (BROW * 4);
+        int skip = 0;   // -1: this thread leaves the row to the element pass (launch-uniform guards: one padding mode each)
+        if (p.pad == 3) skip = ((srow && h == H - 1) || (srow_g && h == LH + OH - 1)) ? -1 : 0;
+        else if (p.pad == 2) skip = wraps(h) ? -1 : 0;
+        const int stepok = (rpass ? -1 : 0) & ~skip;
         S res[NI];
         CT s0 = CT(0), s1 = CT(0);
 #pragma unroll
@@ -638,13 +658,14 @@ __global__ __launch_bounds__(kThreads) void cl_tiled_backward(const ClTiledBwdPa
             v[1] = lds_f(ringx, xr1, xc0[i]);
             v[2] = lds_f(ringx, xr0, xc1[i]);
             v[3] = lds_f(ringx, xr1, xc1[i]);
-            const CT graw = widen<T>(*reinterpret_cast<const S *>(ringg + gdr + gd[i]));
-            const bool counted = live[i] && !skip && rpass && cpass[i];
+            const CT graw = widen<T>(*reinterpret_cast<const S *>(ringz + ringg + gdr + gd[i]));
+            const uint32_t counted = static_cast<uint32_t>(lcount[i] & stepok);
             weight_grads_nd<2, CT>(v, dw, wg);
-            // (selected, not multiplied by zero: the corners of a skipped row can come from ring slots that were never staged --
-            // periodic padding, a source row past the image -- and 0 * NaN is not 0)
-            s0 += counted ? graw * wg[0] : CT(0);
-            s1 += counted ? graw * wg[1] : CT(0);
+            // (masked bit by bit, not multiplied by zero: the corners of a skipped row can come from ring slots that were never
+            // staged -- periodic padding, a source row past the image -- and 0 * NaN is not 0; a mask of lanes would be scalar work)
+            static_assert(sizeof(CT) == 4, "fp32 compute type");
+            s0 += __builtin_bit_cast(CT, __builtin_bit_cast(uint32_t, graw * wg[0]) & counted);
+            s1 += __builtin_bit_cast(CT, __builtin_bit_cast(uint32_t, graw * wg[1]) & counted);
             if constexpr (ACTIVE) {
                 v[0] = lds_f(ringg, gr0, gc0[i]);
                 v[1] = lds_f(ringg, gr1, gc0[i]);
@@ -662,11 +683,11 @@ __global__ __launch_bounds__(kThreads) void cl_tiled_backward(const ClTiledBwdPa
             if constexpr (ES == 4) {
                 uint32_t bits;
                 __builtin_memcpy(&bits, &res[i], 4);
-                __builtin_amdgcn_raw_buffer_store_b32(bits, ores, skip ? kOutOfRange : ooff[i], so, 0);
+                __builtin_amdgcn_raw_buffer_store_b32(bits, ores, ooff[i] | (static_cast<uint32_t>(skip) & kOutOfRange), so, 0);
             } else {
                 uint16_t bits;
                 __builtin_memcpy(&bits, &res[i], 2);
-                __builtin_amdgcn_raw_buffer_store_b16(bits, ores, skip ? kOutOfRange : ooff[i], so, 0);
+                __builtin_amdgcn_raw_buffer_store_b16(bits, ores, ooff[i] | (static_cast<uint32_t>(skip) & kOutOfRange), so, 0);
             }
         }
     };
@@ -725,7 +746,7 @@ __global__ __launch_bounds__(kThreads) void cl_tiled_backward(const ClTiledBwdPa
 
     // ---- the workgroup's weight-gradient partial sums: pixel lanes of each channel, in lane order -----------------------
     __syncthreads();
-    double *red = reinterpret_cast<double *>(ring);   // the rings are dead
+    double *red = reinterpret_cast<double *>(ring_all);   // the rings are dead
     red[threadIdx.x * 2] = acc[0];
     red[threadIdx.x * 2 + 1] = acc[1];
     __syncthreads();

@@ -503,7 +503,11 @@ __global__ __launch_bounds__(kThreads) void cl_tiled_backward(const ClTiledBwdPa
     auto store_row = [&](int y, const u4 &vx, const GRow &vg) {
         const int slot = y & (kBRing - 1);
         uint32_t *dx = ring + (pdst >= 0 ? slot * BROW + pdst : kDump);
-        dx[0] = vx.x; dx[1] = vx.y; dx[2] = vx.z; dx[3] = vx.w;
+        if constexpr (PITCH % 4 == 0) {   // 16-byte aligned pieces: one ds_write_b128, the 8 pieces of a pixel cover all banks
+            *reinterpret_cast<u4 *>(__builtin_assume_aligned(dx, 16)) = vx;
+        } else {
+            dx[0] = vx.x; dx[1] = vx.y; dx[2] = vx.z; dx[3] = vx.w;
+        }
         if constexpr (GO_NCHW) {
             char *gbase = reinterpret_cast<char *>(ring) + (BRING + slot * BROW) * 4;
             char *dump = reinterpret_cast<char *>(ring) + kDump * 4;
@@ -515,7 +519,11 @@ __global__ __launch_bounds__(kThreads) void cl_tiled_backward(const ClTiledBwdPa
             }
         } else {
             uint32_t *dg = ring + (pdst >= 0 ? BRING + slot * BROW + pdst : kDump);
-            dg[0] = vg.v.x; dg[1] = vg.v.y; dg[2] = vg.v.z; dg[3] = vg.v.w;
+            if constexpr (PITCH % 4 == 0) {
+                *reinterpret_cast<u4 *>(__builtin_assume_aligned(dg, 16)) = vg.v;
+            } else {
+                dg[0] = vg.v.x; dg[1] = vg.v.y; dg[2] = vg.v.z; dg[3] = vg.v.w;
+            }
         }
     };
     const int ylast = min(H - 1, h1 + kR);

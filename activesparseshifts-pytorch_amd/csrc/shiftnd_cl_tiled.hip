@@ -112,7 +112,13 @@ __global__ __launch_bounds__(kThreads) void cl_tiled_forward(const ClTiledParams
     constexpr int NE = 4 / ES;            // elements per dword
     constexpr int CB = kLine / ES;        // channels per workgroup
     constexpr int RD = 8 * ES;            // NCHW output: dwords per channel-row segment of the tile
-    __shared__ uint32_t ring[kRing * kRowWords + 4];   // + dump words for pieces that do not exist
+    // one dword of fill elements, the ring, dump words for pieces that do not exist.  An element that is not served from the ring
+    // (padding, a shift beyond the ring) reads the fill word: its offsets are hugely negative (kNeg) and the address is
+    // max(offset sum, 0) -- no lane masks in the row loop (round 4: the loop was scalar-bound, 94 - 220 scalar instructions per row)
+    __shared__ __attribute__((aligned(16))) uint32_t ring_all[4 + kRing * kRowWords + 4];
+    uint32_t *const ring = ring_all + 4;
+    constexpr int kNeg = -(1 << 24);
+    if (threadIdx.x == 0) ring_all[0] = ES == 4 ? p.fill : (ES == 2 ? (p.fill & 0xffffu) * 0x10001u : (p.fill & 0xffu) * 0x01010101u);
     __shared__ int tab_sh[CB], tab_sw[CB];             // canonical shifts of the workgroup's channels
     __shared__ int tab_pz[ND3 ? CB : 1];               // ND3: the channel's source plane for this workgroup's output plane (-1: fill)
     constexpr int kDump = kRing * kRowWords;
@@ -140,7 +146,6 @@ __global__ __launch_bounds__(kThreads) void cl_tiled_forward(const ClTiledParams
     const uint32_t out_bytes = static_cast<uint32_t>(OD) * static_cast<uint32_t>(OH) * static_cast<uint32_t>(OW) * static_cast<uint32_t>(C) * ES;
     const uint32_t plane_bytes = static_cast<uint32_t>(H) * static_cast<uint32_t>(W) * static_cast<uint32_t>(C) * ES;
     const __amdgpu_buffer_rsrc_t xres = __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(xn), 0, img_bytes, kBufferFlags);
-    const __amdgpu_buffer_rsrc_t xnone = __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(xn), 0, 0, kBufferFlags);
     const __amdgpu_buffer_rsrc_t ores = __builtin_amdgcn_make_buffer_rsrc(on, 0, out_bytes, kBufferFlags);
 
     // ND3: the channels' shifts FIRST -- the staging addresses depend on the depth shift (one weight round trip before the
@@ -194,15 +199,16 @@ __global__ __launch_bounds__(kThreads) void cl_tiled_forward(const ClTiledParams
     using SV = std::conditional_t<ND3, uint32_t, u4>;   // what one staging load returns
     SV pvs[kDepth][kNS];
     auto load_row = [&](int y, int ylast, SV (&pv)[kNS]) {  // rows outside the image or beyond the band: nothing is read
-        const bool wanted = y >= 0 && y <= ylast;
-        const __amdgpu_buffer_rsrc_t r = wanted ? xres : xnone;
-        const uint32_t so = wanted ? static_cast<uint32_t>(y) * row_bytes : 0u;
+        // (sign arithmetic: selects on "wanted" compiled to branches around duplicated loads)
+        const int unwanted = (y >> 31) | ((ylast - y) >> 31);
+        const __amdgpu_buffer_rsrc_t r = xres;
+        const uint32_t so = static_cast<uint32_t>(y & ~unwanted) * row_bytes, dead = static_cast<uint32_t>(unwanted) & kOutOfRange;
 #pragma unroll
         for (int k = 0; k < kNS; ++k) {
-            if constexpr (!ND3) pv[k] = __builtin_amdgcn_raw_buffer_load_b128(r, poff[k], so, 0);
-            else if constexpr (ES == 4) pv[k] = __builtin_amdgcn_raw_buffer_load_b32(r, poff[k], so, 0);
-            else if constexpr (ES == 2) pv[k] = __builtin_amdgcn_raw_buffer_load_b16(r, poff[k], so, 0);
-            else pv[k] = __builtin_amdgcn_raw_buffer_load_b8(r, poff[k], so, 0);
+            if constexpr (!ND3) pv[k] = __builtin_amdgcn_raw_buffer_load_b128(r, poff[k] | dead, so, 0);
+            else if constexpr (ES == 4) pv[k] = __builtin_amdgcn_raw_buffer_load_b32(r, poff[k] | dead, so, 0);
+            else if constexpr (ES == 2) pv[k] = __builtin_amdgcn_raw_buffer_load_b16(r, poff[k] | dead, so, 0);
+            else pv[k] = __builtin_amdgcn_raw_buffer_load_b8(r, poff[k] | dead, so, 0);
         }
     };
     auto store_row = [&](int y, const SV (&pv)[kNS]) {
@@ -240,8 +246,8 @@ __global__ __launch_bounds__(kThreads) void cl_tiled_forward(const ClTiledParams
     // rows of a thread's elements: OUT_CL one canonical row shift per element slot j (channels 4 lane_a / ES + j), else
     // one per dword i (its channel)
     constexpr int NSH = OUT_CL ? NE : 4;
-    int csh[NSH];
-    int xoff[4][NE];           // LDS byte offset of the source element within a staged row (0 when not served from the ring)
+    int csh[NSH], ssh[NSH];    // canonical / signed row shift
+    int xoff[4][NE];           // LDS byte offset of the source element within a staged row (kNeg when not served from the ring)
     uint32_t ring_ok = 0, far = 0;   // bit 4 i + j: served from the ring / gathered from memory after the row loop
     uint32_t ooff[4];          // byte offset of the output dword in row h0 of the image, or out of range (nothing to store)
     int gcol[4][NE];           // far: source column
@@ -267,9 +273,11 @@ __global__ __launch_bounds__(kThreads) void cl_tiled_forward(const ClTiledParams
             // (periodic padding: a column near the edge comes from the far side of the row -- not among the staged pixels)
             const bool in_ring = sh_s >= -kR && sh_s <= kR && sw_s >= -kR && sw_s <= kR && (sx < 0 || (sx >= w0 + LW - kR && sx < w0 + LW + kTW + kR));
             const bool nr = live && sx >= 0 && in_ring;
+            if (OUT_CL) ssh[j] = sh_s;
+            else ssh[i] = sh_s;
             ring_ok |= (nr ? 1u : 0u) << (4 * i + j);
             far |= ((live && sx >= 0 && !in_ring) ? 1u : 0u) << (4 * i + j);
-            xoff[i][j] = nr ? (sx - (w0 + LW - kR)) * (kPitch * 4) + ch * ES : 0;
+            xoff[i][j] = nr ? (sx - (w0 + LW - kR)) * (kPitch * 4) + ch * ES : kNeg;
         }
         // (C * ES and W * ES are multiples of 4 where it matters: a dword is live or dead as a whole)
         const int ch0 = OUT_CL ? lane_a * NE : D / RD, col0 = OUT_CL ? lane_b + 8 * i : (D % RD) * NE;
@@ -285,8 +293,19 @@ __global__ __launch_bounds__(kThreads) void cl_tiled_forward(const ClTiledParams
         const int y = h0 + LH - kR + r;
         if (y >= 0 && y < H) store_row(y, pre[r]);
     }
-    const uint8_t *ringb = reinterpret_cast<const uint8_t *>(ring);
+    const uint8_t *ringz = reinterpret_cast<const uint8_t *>(ring_all);   // byte 0: the fill word; the ring starts at byte 16
     const bool periodic = p.pad == 2 && H > 1;
+    // source rows of shifts within the ring with ONE fold, in bit arithmetic (cl_tiled_backward): valid for H > R or H == 1
+    // (host: smaller images keep the channel-fastest kernels).  Periodic: a row that wraps is not in the ring -- negative like the zero padding (the fill
+    // value goes out and the pass after the loop writes the element)
+    const int fm = (p.pad == 3 || p.pad == 4) ? -1 : 0;
+    const int fLo = p.pad == 4 ? -1 : 0, fHi = p.pad == 1 ? H - 1 : (p.pad == 3 ? 2 * H - 2 : 2 * H - 1);
+    const int zneg = (p.pad == 0 || p.pad == 2) ? kNeg : 0;
+    auto fold_once = [&](int idx) {
+        const int below = idx >> 31, above = (H - 1 - idx) >> 31, t = idx & fm;
+        const int r = (idx & ~(below | above)) | ((fLo - t) & below) | ((fHi - t) & above) | ((below | above) & zneg);
+        return H == 1 ? 0 : r;
+    };
     auto step = [&](int h, SV (&pv)[kNS]) {
         const int hs = h + LH;   // the source row of output row h under a zero shift
         __syncthreads();  // everybody is done with the slot that row hs + R replaces (row hs - R - 1)
@@ -294,16 +313,13 @@ __global__ __launch_bounds__(kThreads) void cl_tiled_forward(const ClTiledParams
         __syncthreads();
         load_row(hs + kDepth + kR, ylast, pv);  // in flight while this and the next rows are produced
         const uint32_t so = static_cast<uint32_t>(h - h0) * ostep;
-        int rowb[NSH];        // LDS byte offset of the source row of each shift, or -1 (zero padding)
+        int rowb[NSH];        // LDS byte offset (from ringz) of the source row of each shift, or negative (padding)
 #pragma unroll
         for (int k = 0; k < NSH; ++k) {
-            const int sy = H == 1 ? 0 : fold_index(hs - csh[k], H, p.pad);
-            const uint32_t r = static_cast<uint32_t>(sy < 0 ? 0 : sy);
+            const int sy = fold_once(hs - ssh[k]);
+            const uint32_t r = static_cast<uint32_t>(sy & ~(sy >> 31));    // (0 for a negative row)
             const uint32_t sl = r - __umulhi(r, 613566757u) * kRing;       // r % 7 (r < 2^20)
-            // (periodic padding: a row that wraps to the far side of the image is not in the ring; the fill value goes out
-            // and the pass after the loop writes the element)
-            const bool wrapped = periodic && (sy < hs - kR || sy > hs + kR);
-            rowb[k] = (sy < 0 || wrapped) ? -1 : static_cast<int>(sl) * (kRowWords * 4);
+            rowb[k] = (16 + static_cast<int>(sl) * (kRowWords * 4)) | ((sy >> 31) & kNeg);
         }
         uint32_t v[4];
 #pragma unroll
@@ -311,10 +327,8 @@ __global__ __launch_bounds__(kThreads) void cl_tiled_forward(const ClTiledParams
             v[i] = 0;
 #pragma unroll
             for (int j = 0; j < NE; ++j) {
-                const int rb = rowb[OUT_CL ? j : i];
-                const uint32_t e = *reinterpret_cast<const EL *>(ringb + (rb < 0 ? 0 : rb) + xoff[i][j]);
-                const bool ok = ((ring_ok >> (4 * i + j)) & 1u) && rb >= 0;
-                v[i] |= (ok ? e : p.fill) << (8 * ES * j);
+                const uint32_t e = *reinterpret_cast<const EL *>(ringz + max(rowb[OUT_CL ? j : i] + xoff[i][j], 0));
+                v[i] |= e << (8 * ES * j);
             }
         }
 #pragma unroll
@@ -347,10 +361,12 @@ __global__ __launch_bounds__(kThreads) void cl_tiled_forward(const ClTiledParams
                 EL *o = reinterpret_cast<EL *>(on) + (OUT_CL ? ((static_cast<int64_t>(dz) * OH + h0) * OW + w0 + col) * C + c0 + ch
                                                              : ((static_cast<int64_t>(c0 + ch) * OD + dz) * OH + h0) * OW + w0 + col);
                 const int64_t zoff = ND3 ? static_cast<int64_t>(tab_pz[ch]) * H * W * C : 0;   // the channel's source plane (far: pz >= 0)
-                const int shc = csh[OUT_CL ? j : i];
+                const int shc = csh[OUT_CL ? j : i], shs = ssh[OUT_CL ? j : i];
                 for (int h = h0; h < h1; ++h) {
                     const int sy = H == 1 ? 0 : fold_index(h + LH - shc, H, p.pad);
-                    if (all_rows || sy < h + LH - kR || sy > h + LH + kR)
+                    // (an element of the ring, periodic padding: exactly the rows the loop took for padding -- the source row
+                    //  under the signed shift lies outside the image)
+                    if (all_rows || h + LH - shs < 0 || h + LH - shs >= H)
                         *o = sy >= 0 ? xe[zoff + (static_cast<int64_t>(sy) * W + gcol[i][j]) * C + c0 + ch] : static_cast<EL>(p.fill);
                     o += OUT_CL ? OW * C : OW;
                 }
@@ -373,8 +389,6 @@ __global__ __launch_bounds__(kThreads) void cl_tiled_forward(const ClTiledParams
 constexpr int kBTW = 16;                       // output columns per workgroup
 constexpr int kBPW = kBTW + 2 * kR + 1;        // staged pixels per row
 constexpr int kBRing = 8;                      // staged rows h - R .. h + R + 1
-constexpr int kBRowWords = kBPW * kPitch;
-constexpr int kBRingWords = kBRing * kBRowWords;
 constexpr int kBPieces = kBPW * (kLine / 16);  // 16-byte pieces per staged row and tensor (184: one per thread)
 static_assert(kBPieces <= kThreads, "one piece of each tensor per thread");
 
@@ -793,7 +807,11 @@ __global__ __launch_bounds__(kThreads) void cl_tiled_active_forward(const ClTile
     // OUT_CL: thread = (channel lane % CB, pixel lane), columns pl + PL i;  else thread = (column lane % 32, channel lane
     // 0..7), channels cl + 8 i.  Either way NI outputs per row.
     constexpr int LA = OUT_CL ? CB : kTW, PL = kThreads / LA, NI = OUT_CL ? kTW / PL : CB / PL;
-    __shared__ uint32_t ring[kARing * kARowWords + 4];
+    // four zero words (what a padding corner reads: cl_tiled_backward), the ring, dump words
+    __shared__ __attribute__((aligned(16))) uint32_t ring_all[4 + kARing * kARowWords + 4];
+    uint32_t *const ring = ring_all + 4;
+    constexpr int kNeg = -(1 << 24);
+    if (threadIdx.x < 4) ring_all[threadIdx.x] = 0u;
     __shared__ int tab_sh[CB], tab_sw[CB];     // signed row shift (or out of the ring: INT_MIN), canonical column shift
     __shared__ int tab_shc[CB];                // canonical row shift (the element-by-element pass)
     __shared__ float tab_dh[CB], tab_dw[CB];   // interpolation fractions
@@ -817,7 +835,6 @@ __global__ __launch_bounds__(kThreads) void cl_tiled_active_forward(const ClTile
     const uint32_t img_bytes = static_cast<uint32_t>(H) * static_cast<uint32_t>(W) * static_cast<uint32_t>(C) * ES;
     const uint32_t out_bytes = static_cast<uint32_t>(OH) * static_cast<uint32_t>(OW) * static_cast<uint32_t>(C) * ES;
     const __amdgpu_buffer_rsrc_t xres = __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(xn), 0, img_bytes, kBufferFlags);
-    const __amdgpu_buffer_rsrc_t xnone = __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(xn), 0, 0, kBufferFlags);
     const __amdgpu_buffer_rsrc_t ores = __builtin_amdgcn_make_buffer_rsrc(on, 0, out_bytes, kBufferFlags);
 
     // ---- staging (as in cl_tiled_forward) -----------------------------------------------------------------------------
@@ -835,11 +852,10 @@ __global__ __launch_bounds__(kThreads) void cl_tiled_active_forward(const ClTile
     constexpr int kDepth = CLT_DEPTH;
     u4 pvs[kDepth][kANP];
     auto load_row = [&](int y, int ylast, u4 (&pv)[kANP]) {
-        const bool wanted = y >= 0 && y <= ylast;
-        const __amdgpu_buffer_rsrc_t r = wanted ? xres : xnone;
-        const uint32_t so = wanted ? static_cast<uint32_t>(y) * row_bytes : 0u;
+        const int unwanted = (y >> 31) | ((ylast - y) >> 31);   // (sign arithmetic: cl_tiled_backward)
+        const uint32_t so = static_cast<uint32_t>(y & ~unwanted) * row_bytes, dead = static_cast<uint32_t>(unwanted) & kOutOfRange;
 #pragma unroll
-        for (int k = 0; k < kANP; ++k) pv[k] = __builtin_amdgcn_raw_buffer_load_b128(r, poff[k], so, 0);
+        for (int k = 0; k < kANP; ++k) pv[k] = __builtin_amdgcn_raw_buffer_load_b128(xres, poff[k] | dead, so, 0);
     };
     auto store_row = [&](int y, const u4 (&pv)[kANP]) {
         const int slot = y & (kARing - 1);
@@ -908,7 +924,7 @@ __global__ __launch_bounds__(kThreads) void cl_tiled_active_forward(const ClTile
         const bool mine = inside && s != kFarShift && !outside(a0) && !outside(a1);
         live |= (mine ? 1u : 0u) << i;
         rest |= ((inside && !mine) ? 1u : 0u) << i;
-        auto lds_col = [&](int sx) { return (mine && sx >= 0) ? (sx - (w0 + LW - kR)) * (kPitch * 4) + ch * ES : -1; };
+        auto lds_col = [&](int sx) { return (mine && sx >= 0) ? (sx - (w0 + LW - kR)) * (kPitch * 4) + ch * ES : kNeg; };
         xc0[i] = lds_col(a0);
         xc1[i] = lds_col(a1);
         const uint32_t o = OUT_CL ? (static_cast<uint32_t>(h0 * OW + w0 + col) * C + c) * ES
@@ -922,21 +938,17 @@ __global__ __launch_bounds__(kThreads) void cl_tiled_active_forward(const ClTile
         const int y = h0 + LH - kR + r;
         if (y >= 0 && y < H) store_row(y, pre[r]);
     }
-    const char *ringx = reinterpret_cast<const char *>(ring);
-    auto lds_f = [&](int row, int colo) {
-        const bool ok = row >= 0 && colo >= 0;
-        const S v = *reinterpret_cast<const S *>(ringx + (ok ? row + colo : 0));
-        return ok ? widen<T>(v) : CT(0);
+    const char *ringz = reinterpret_cast<const char *>(ring_all);   // byte 0: the zero words; the ring starts at byte 16
+    auto lds_f = [&](int row, int colo) {   // padding (a negative offset) reads a zero word: no lane masks
+        return widen<T>(*reinterpret_cast<const S *>(ringz + max(row + colo, 0)));
     };
-    auto row_off = [&](int sy) { return sy < 0 ? -1 : (sy & (kARing - 1)) * (kARowWords * 4); };
-    const int fm = (p.pad == 3 || p.pad == 4) ? -1 : 0;   // one fold of the signed shift: see cl_tiled_backward
+    auto row_off = [&](int sy) { return (16 + (sy & (kARing - 1)) * (kARowWords * 4)) | ((sy >> 31) & kNeg); };
+    const int fm = (p.pad == 3 || p.pad == 4) ? -1 : 0;   // one fold of the signed shift, in bit arithmetic: see cl_tiled_backward
     const int fLo = p.pad == 4 ? -1 : 0, fHi = p.pad == 1 ? H - 1 : (p.pad == 3 ? 2 * H - 2 : 2 * H - 1);
-    const bool fzero = p.pad == 0;
+    const int zneg = p.pad == 0 ? kNeg : 0;
     auto fold1 = [&](int idx) {
-        const bool lo = idx < 0, hi = idx >= H;
-        const int t = idx & fm;
-        int r = lo ? fLo - t : (hi ? fHi - t : idx);
-        r = (fzero && (lo || hi)) ? -1 : r;
+        const int below = idx >> 31, above = (H - 1 - idx) >> 31, t = idx & fm;
+        const int r = (idx & ~(below | above)) | ((fLo - t) & below) | ((fHi - t) & above) | ((below | above) & zneg);
         return H == 1 ? 0 : r;
     };
     // periodic padding: a corner row that wraps to the far side of the image is not in the ring; such rows (at most R + 1 at
@@ -954,13 +966,15 @@ __global__ __launch_bounds__(kThreads) void cl_tiled_active_forward(const ClTile
         load_row(hs + kDepth + kR + 1, ylast, pv);
         const uint32_t so = static_cast<uint32_t>(h - h0) * ostep;
         int xr0[NCH], xr1[NCH];
-        bool skip[NCH];
+        int skip[NCH];   // -1: the row is left to the element pass (launch-uniform guards: one padding mode each)
 #pragma unroll
         for (int k = 0; k < NCH; ++k) {
             xr0[k] = row_off(xrow1[k]);
             xrow1[k] = fold1(hs + 1 - shs[k]);
             xr1[k] = row_off(xrow1[k]);
-            skip[k] = (srow[k] && hs == H - 1) || wraps(hs, shs[k]);
+            skip[k] = 0;
+            if (p.pad == 3) skip[k] = (srow[k] && hs == H - 1) ? -1 : 0;
+            else if (p.pad == 2) skip[k] = wraps(hs, shs[k]) ? -1 : 0;
         }
         S res[NI];
 #pragma unroll
@@ -975,7 +989,7 @@ __global__ __launch_bounds__(kThreads) void cl_tiled_active_forward(const ClTile
         }
 #pragma unroll
         for (int i = 0; i < NI; ++i) {
-            const uint32_t off = skip[OUT_CL ? 0 : i] ? kOutOfRange : ooff[i];
+            const uint32_t off = ooff[i] | (static_cast<uint32_t>(skip[OUT_CL ? 0 : i]) & kOutOfRange);
             if constexpr (ES == 4) {
                 uint32_t bits;
                 __builtin_memcpy(&bits, &res[i], 4);
@@ -1061,6 +1075,7 @@ bool cl_tiled_forward_eligible(const Geometry &g, int dtype, const void *x, cons
     if (g.active && dtype <= SHIFTND_BF16) {  // interpolating: cl_tiled_active_forward (fp32, fp16, bf16), rows folded once
         if (g.nd != 2 || dtype == SHIFTND_F64 || (g.S[1] != 1 && g.S[1] < 5)) return false;
     }
+    if (g.S[1] != 1 && g.S[1] <= kR) return false;   // the gather kernel folds its source rows once too (round 4)
     for (int d = 0; d < 3; ++d)   // the window (a crop of the output, round 4): both forward kernels
         if ((g.L[d] != 0 || g.O[d] != g.S[d]) && ((d == 0 && g.nd != 3) || g.O[d] < 1)) return false;
     if ((g.C * es) % 16 != 0 || g.S[1] >= (1 << 20) || g.S[2] >= (1 << 20) || g.N >= (1LL << 24) || g.C >= (1 << 24)) return false;

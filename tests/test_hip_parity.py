@@ -90,9 +90,17 @@ def test_golden_quantized(abi, policy):
         out = abi.forward_quantized(x, w, wzp, xzp, pad, b, out=out)
         assert np.array_equal(out.cpu().numpy(), out_r), key
         if layout != "nchw" and policy in (0, 4) and x.shape[1] > 1:
-            # (2-D, pixel lines of whole 16-byte pieces: the LDS-tiled kernel; windows too since round 4)
-            tiled = nd == 2 and (x.shape[1] * x.element_size()) % 16 == 0
-            assert abi.last_path() == abi.PATH_CL and abi.last_kernel() == ("cl_tiled_forward" if tiled else "cl_gather_forward"), key
+            # (pixel lines of whole 16-byte pieces, rows folded once: the LDS-tiled kernel; windows too since round 4, and NDHWC
+            #  tensors of 2- / 4-byte elements)
+            lines = (x.shape[1] * x.element_size()) % 16 == 0 and (x.shape[-2] == 1 or x.shape[-2] > 3)
+            want = "cl_gather_forward"
+            if lines and nd == 2:
+                want = "cl_tiled_forward"
+            if lines and nd == 3 and x.element_size() >= 2:
+                want = "cl_tiled_forward_3d"
+            if not (abi.last_path() == abi.PATH_CL and abi.last_kernel() == want):
+                abi.set_path_policy(0)
+            assert abi.last_path() == abi.PATH_CL and abi.last_kernel() == want, (key, abi.last_kernel())
         if policy in (0, 2, 3) and layout == "nchw":
             assert abi.last_path() == (abi.PATH_SWEEP if policy == 3 else abi.PATH_PLANE), key
     abi.set_path_policy(0)

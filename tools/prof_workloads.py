@@ -18,13 +18,32 @@ from torchshifts import abi  # noqa: E402
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--iters", type=int, default=5)
-    ap.add_argument("--only", default="", help="clcrop: only the cropped channels-last calls of round 4 (the same kernel instantiations "
+    ap.add_argument("--only", default="", help="cl3d: the NDHWC forward calls of round 4; clcrop: only the cropped channels-last calls of round 4 (the same kernel instantiations "
                     "as the un-cropped ones: a run of their own keeps the per-kernel averages apart)")
     a = ap.parse_args()
     dev = "cuda:0"
     torch.manual_seed(0)
     cl = torch.channels_last
     calls = []
+    if a.only == "cl3d":   # NDHWC: N8 C128 16x112x112 (config 3's tensor) int32 quantized keeping the format, fp32 / bf16 sparse to NDHWC
+        cl3 = torch.channels_last_3d
+        shape = (8, 128, 16, 112, 112)
+        xq = torch.randint(-1000, 1000, shape, dtype=torch.int32, device=dev).contiguous(memory_format=cl3)
+        wq = (torch.rand(128, 3, device=dev) * 2 - 1).round().add(128).to(torch.uint8)
+        oq = torch.empty_like(xq)
+        xf = torch.rand(shape, device=dev).contiguous(memory_format=cl3)
+        xb = xf.bfloat16()
+        wf = torch.rand(128, 3, device=dev) * 2 - 1
+        of, ob = torch.empty_like(xf), torch.empty_like(xb)
+        calls = [lambda: abi.forward_quantized(xq, wq, 128, 3, 0, out=oq), lambda: abi.forward(xf, wf, 0, 0, out=of),
+                 lambda: abi.forward(xb, wf.bfloat16(), 0, 0, out=ob)]
+        for f in calls:
+            for _ in range(a.iters):
+                f()
+            print(abi.last_kernel())
+        torch.cuda.synchronize()
+        print("done")
+        return
     if a.only == "clcrop":   # N16 C256 224x224 fp32 channels-last, cut [[1, 1], [1, 1]] -> 222x222 (modules/shifts.py:41-46)
         x = torch.rand(16, 256, 224, 224, device=dev).contiguous(memory_format=cl)
         w = torch.rand(256, 2, device=dev) * 6 - 3

@@ -239,11 +239,10 @@ int shiftnd_forward_serves_channels_last(const shiftnd_problem *p, const void *x
     // bf16 through the op: 0.30 vs 0.54 ms; tools/cl_op_bench.py), so the answer is no although shiftnd_forward would
     // take a channels-last tensor
     if (g.active && (p->dtype == SHIFTND_F16 || p->dtype == SHIFTND_BF16)) return 0;
-    // NDHWC (round 4): the tiled kernel stages element by element; it beats the layout change + the contiguous kernels only when
-    // the output keeps the channels-last format (the quantized op; N8 C128 16x112x112 fp32 0.53 vs 0.57 + a transpose back, bf16
-    // 0.34 vs 0.29 + a transpose back) -- to an NCDHW output the layout change wins (fp32 0.60 vs 0.57 ms, bf16 0.42 vs 0.29;
-    // tools/cl3d_bench.py)
-    if (g.nd == 3 && !(g.os[1] == 1 && g.C > 1)) return 0;
+    // NDHWC (round 4): the tiled kernel stages element by element.  N8 C128 16x112x112 (tools/cl3d_bench.py): fp32 0.42 ms to an
+    // NDHWC output, 0.49 to NCDHW, against 0.57 ms for the layout change + the contiguous kernel (+ a transpose back when the format
+    // is kept); bf16 0.29 / 0.36 against 0.29 -- so 2-byte elements to an NCDHW output keep the layout change
+    if (g.nd == 3 && !(g.os[1] == 1 && g.C > 1) && dtype_size(p->dtype) != 4) return 0;
     return cl_tiled_forward_eligible(g, p->dtype, x, out) ? 1 : 0;
 }
 

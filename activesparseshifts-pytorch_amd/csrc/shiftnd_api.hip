@@ -243,6 +243,9 @@ int shiftnd_forward_serves_channels_last(const shiftnd_problem *p, const void *x
     // NDHWC output, 0.49 to NCDHW, against 0.57 ms for the layout change + the contiguous kernel (+ a transpose back when the format
     // is kept); bf16 0.29 / 0.36 against 0.29 -- so 2-byte elements to an NCDHW output keep the layout change
     if (g.nd == 3 && !(g.os[1] == 1 && g.C > 1) && dtype_size(p->dtype) != 4) return 0;
+    // ... and the interpolating NDHWC kernel (plane blend at staging time, fp32 ring) only wins for fp32 to an NDHWC output: 0.56 ms
+    // against 0.59 + a transpose back (to NCDHW 0.61 against 0.59; bf16 0.49 - 0.52 against 0.29)
+    if (g.nd == 3 && g.active && !(g.os[1] == 1 && g.C > 1)) return 0;
     return cl_tiled_forward_eligible(g, p->dtype, x, out) ? 1 : 0;
 }
 

@@ -804,13 +804,20 @@ constexpr int kARowWords = kAPW * kPitch;
 constexpr int kAPieces = kAPW * (kLine / 16);  // 312
 constexpr int kANP = (kAPieces + kThreads - 1) / kThreads;
 
-template <typename T, bool OUT_CL>
+//
+// ND3 (round 4, NDHWC): the reference's 3-D blend nests the PLANE blend innermost (interpolation.h:34-40), so it is done at staging
+// time: a ring element is u = lerp(x[plane0], x[plane1], d_plane) of its channel's two source planes, in fp32 whatever the tensor's
+// type (32 channels per workgroup), and everything behind the staging is the 2-D kernel on u with the row / column fractions --
+// the same bits as interp_nd<3>.  One output plane per workgroup, the plane the fastest block index (cl_tiled_forward<.., ND3>).
+template <typename T, bool OUT_CL, bool ND3>
 __global__ __launch_bounds__(kThreads) void cl_tiled_active_forward(const ClTiledParams p) {
     typedef uint32_t u4 __attribute__((ext_vector_type(4)));
     using S = typename T::S;
     using CT = typename T::C;
     static_assert(sizeof(S) == 4 || sizeof(S) == 2, "fp32, fp16, bf16");
-    constexpr int ES = sizeof(S), CB = kLine / ES;   // channels per workgroup: 32 (fp32) or 64 (16-bit types)
+    static_assert(!ND3 || sizeof(CT) == 4, "the ring of the 3-D form holds fp32 plane blends");
+    constexpr int ES = sizeof(S), RES = ND3 ? 4 : ES;   // element size in memory / in the ring
+    constexpr int CB = kLine / RES;                     // channels per workgroup: 32 (fp32, ND3) or 64 (16-bit types, 2-D)
     // OUT_CL: thread = (channel lane % CB, pixel lane), columns pl + PL i;  else thread = (column lane % 32, channel lane
     // 0..7), channels cl + 8 i.  Either way NI outputs per row.
     constexpr int LA = OUT_CL ? CB : kTW, PL = kThreads / LA, NI = OUT_CL ? kTW / PL : CB / PL;
@@ -822,11 +829,19 @@ __global__ __launch_bounds__(kThreads) void cl_tiled_active_forward(const ClTile
     __shared__ int tab_sh[CB], tab_sw[CB];     // signed row shift (or out of the ring: INT_MIN), canonical column shift
     __shared__ int tab_shc[CB];                // canonical row shift (the element-by-element pass)
     __shared__ float tab_dh[CB], tab_dw[CB];   // interpolation fractions
+    __shared__ int tab_pz0[ND3 ? CB : 1], tab_pz1[ND3 ? CB : 1];   // ND3: the channel's two source planes (-1: padding)
+    __shared__ float tab_dp[ND3 ? CB : 1];                          // ... and its plane fraction
     constexpr int kDump = kARing * kARowWords;
     constexpr int kFarShift = -0x7fffffff - 1;
 
     // XCD-contiguous ids: workgroups that share an XCD (blockIdx % 8) and its L2 own neighbouring tiles (shared halo)
     unsigned b = p.xcd_blocks ? (blockIdx.x & 7u) * p.xcd_blocks + (blockIdx.x >> 3) : blockIdx.x;
+    int dz = 0;   // ND3: the output plane, the fastest index (neighbouring planes share their pixel lines in L2)
+    if constexpr (ND3) {
+        const unsigned q = fdiv(b, p.d_OD);
+        dz = static_cast<int>(b - q * static_cast<unsigned>(p.OD));
+        b = q;
+    }
     const int wt = static_cast<int>(b - fdiv(b, p.d_wtiles) * p.wtiles);
     b = fdiv(b, p.d_wtiles);
     const int cb = static_cast<int>(b - fdiv(b, p.d_cblocks) * p.cblocks);
@@ -837,71 +852,128 @@ __global__ __launch_bounds__(kThreads) void cl_tiled_active_forward(const ClTile
     // the window (round 4, as in cl_tiled_forward): output row h / column w read the source around (h + LH, w + LW)
     const int H = p.H, W = p.W, C = p.C, OH = p.OH, OW = p.OW, LH = p.LH, LW = p.LW;
     const int h0 = band * p.band_rows, h1 = min(OH, h0 + p.band_rows);
-    const char *xn = p.x + static_cast<int64_t>(n) * H * W * C * ES;
-    char *on = p.out + static_cast<int64_t>(n) * OH * OW * C * ES;
-    const uint32_t img_bytes = static_cast<uint32_t>(H) * static_cast<uint32_t>(W) * static_cast<uint32_t>(C) * ES;
-    const uint32_t out_bytes = static_cast<uint32_t>(OH) * static_cast<uint32_t>(OW) * static_cast<uint32_t>(C) * ES;
+    const int DZ = ND3 ? p.D : 1, OD = ND3 ? p.OD : 1;
+    const char *xn = p.x + static_cast<int64_t>(n) * DZ * H * W * C * ES;
+    char *on = p.out + static_cast<int64_t>(n) * OD * OH * OW * C * ES;
+    const uint32_t plane_bytes = static_cast<uint32_t>(H) * static_cast<uint32_t>(W) * static_cast<uint32_t>(C) * ES;
+    const uint32_t img_bytes = static_cast<uint32_t>(DZ) * plane_bytes;
+    const uint32_t out_bytes = static_cast<uint32_t>(OD) * static_cast<uint32_t>(OH) * static_cast<uint32_t>(OW) * static_cast<uint32_t>(C) * ES;
     const __amdgpu_buffer_rsrc_t xres = __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(xn), 0, img_bytes, kBufferFlags);
     const __amdgpu_buffer_rsrc_t ores = __builtin_amdgcn_make_buffer_rsrc(on, 0, out_bytes, kBufferFlags);
 
-    // ---- staging (as in cl_tiled_forward) -----------------------------------------------------------------------------
-    uint32_t poff[kANP];
-    int pdst[kANP];
+    // ---- the channels' shifts (ND3: first -- the staging addresses depend on the depth shift) ----------------------------------
+    const int perH = map_period(H, p.pad), perW = map_period(W, p.pad);
+    auto channel_table = [&]() {
+        if (threadIdx.x < CB) {
+            const int c = min(c0 + static_cast<int>(threadIdx.x), C - 1);
+            CT wv[3], dh, dwf;
+            int64_t sh2[2];
+            if constexpr (ND3) {
+                const int wcol[3] = {0, 1, 2};
+                load_weights3<CT>(p.w, p.wkind, static_cast<int64_t>(c) * 3, wcol, wv);
+                int64_t shd;
+                CT dp;
+                prep_shift_forward<CT>(wv[0], true, shd, dp);
+                const int sd = canon_shift(shd, DZ, p.pad, p.d_perD);
+                tab_pz0[threadIdx.x] = DZ == 1 ? 0 : fold_index(dz + p.LD - sd, DZ, p.pad);   // size-1 dims ignore the shift
+                tab_pz1[threadIdx.x] = DZ == 1 ? 0 : fold_index(dz + p.LD - sd + 1, DZ, p.pad);
+                tab_dp[threadIdx.x] = dp;
+            } else {
+                const int wcol[3] = {-1, 0, 1};
+                load_weights3<CT>(p.w, p.wkind, static_cast<int64_t>(c) * 2, wcol, wv);
+            }
+            prep_shift_forward<CT>(wv[1], true, sh2[0], dh);
+            prep_shift_forward<CT>(wv[2], true, sh2[1], dwf);
+            const int sh = canon_shift(sh2[0], H, p.pad, p.d_perH), sw = canon_shift(sh2[1], W, p.pad, p.d_perW);
+            const int sh_s = (perH && 2 * sh > perH) ? sh - perH : sh, sw_s = (perW && 2 * sw > perW) ? sw - perW : sw;
+            const bool in_ring = sh_s >= -kR && sh_s <= kR && sw_s >= -kR && sw_s <= kR;
+            tab_sh[threadIdx.x] = in_ring ? sh_s : kFarShift;
+            tab_shc[threadIdx.x] = sh;
+            tab_sw[threadIdx.x] = sw;
+            tab_dh[threadIdx.x] = dh;
+            tab_dw[threadIdx.x] = dwf;
+        }
+        __syncthreads();
+    };
+    if constexpr (ND3) channel_table();
+
+    // ---- staging (as in cl_tiled_forward; ND3: element px * 32 + channel of the staged row from the channel's two planes) -----
+    constexpr int kNS = ND3 ? (kAPW * CB + kThreads - 1) / kThreads : kANP;
+    struct Pair { uint32_t a, b; };
+    using SV = std::conditional_t<ND3, Pair, u4>;
+    uint32_t poff[kNS], poff1[ND3 ? kNS : 1];
+    int pdst[kNS];
+    float my_dp = 0.f;   // ND3: the plane fraction of the thread's staging channel (element q: channel q % 32 = tid % 32 for every k)
+    if constexpr (ND3) my_dp = tab_dp[threadIdx.x % CB];
 #pragma unroll
-    for (int k = 0; k < kANP; ++k) {
+    for (int k = 0; k < kNS; ++k) {
         const int q = k * kThreads + static_cast<int>(threadIdx.x);
-        const int px = q >> 3, cbyte = c0 * ES + (q & 7) * 16, gx = w0 + LW - kR + px;
-        const bool piece = q < kAPieces;
-        poff[k] = (piece && gx >= 0 && gx < W && cbyte < C * ES) ? static_cast<uint32_t>(gx) * C * ES + cbyte : kOutOfRange;
-        pdst[k] = piece ? px * kPitch + (q & 7) * 4 : -1;
+        if constexpr (ND3) {
+            const int px = q / CB, ch = q - px * CB, gx = w0 + LW - kR + px;
+            const bool elem = px < kAPW && gx >= 0 && gx < W && c0 + ch < C;
+            const int pz0 = tab_pz0[ch], pz1 = tab_pz1[ch];
+            const uint32_t inplane = (static_cast<uint32_t>(gx) * C + c0 + ch) * ES;
+            poff[k] = (elem && pz0 >= 0) ? static_cast<uint32_t>(pz0) * plane_bytes + inplane : kOutOfRange;
+            poff1[k] = (elem && pz1 >= 0) ? static_cast<uint32_t>(pz1) * plane_bytes + inplane : kOutOfRange;
+            pdst[k] = px < kAPW ? px * (kPitch * 4) + ch * 4 : -1;   // (bytes)
+        } else {
+            const int px = q >> 3, cbyte = c0 * ES + (q & 7) * 16, gx = w0 + LW - kR + px;
+            const bool piece = q < kAPieces;
+            poff[k] = (piece && gx >= 0 && gx < W && cbyte < C * ES) ? static_cast<uint32_t>(gx) * C * ES + cbyte : kOutOfRange;
+            pdst[k] = piece ? px * kPitch + (q & 7) * 4 : -1;
+        }
     }
     const uint32_t row_bytes = static_cast<uint32_t>(W) * C * ES;
     constexpr int kDepth = CLT_DEPTH;
-    u4 pvs[kDepth][kANP];
-    auto load_row = [&](int y, int ylast, u4 (&pv)[kANP]) {
+    SV pvs[kDepth][kNS];
+    auto load_elem = [&](uint32_t off, uint32_t so) {
+        if constexpr (ES == 4) return static_cast<uint32_t>(__builtin_amdgcn_raw_buffer_load_b32(xres, off, so, 0));
+        else return static_cast<uint32_t>(__builtin_amdgcn_raw_buffer_load_b16(xres, off, so, 0));
+    };
+    auto load_row = [&](int y, int ylast, SV (&pv)[kNS]) {
         const int unwanted = (y >> 31) | ((ylast - y) >> 31);   // (sign arithmetic: cl_tiled_backward)
         const uint32_t so = static_cast<uint32_t>(y & ~unwanted) * row_bytes, dead = static_cast<uint32_t>(unwanted) & kOutOfRange;
 #pragma unroll
-        for (int k = 0; k < kANP; ++k) pv[k] = __builtin_amdgcn_raw_buffer_load_b128(xres, poff[k] | dead, so, 0);
+        for (int k = 0; k < kNS; ++k) {
+            if constexpr (ND3) {
+                pv[k].a = load_elem(poff[k] | dead, so);
+                pv[k].b = load_elem(poff1[k] | dead, so);
+            } else {
+                pv[k] = __builtin_amdgcn_raw_buffer_load_b128(xres, poff[k] | dead, so, 0);
+            }
+        }
     };
-    auto store_row = [&](int y, const u4 (&pv)[kANP]) {
+    auto as_ct = [](uint32_t bits) {   // a loaded element (raw bits in the low half for 16-bit types) in the compute type
+        if constexpr (ES == 4) return __builtin_bit_cast(float, bits);
+        else return widen<T>(__builtin_bit_cast(S, static_cast<uint16_t>(bits)));
+    };
+    auto store_row = [&](int y, const SV (&pv)[kNS]) {
         const int slot = y & (kARing - 1);
 #pragma unroll
-        for (int k = 0; k < kANP; ++k) {
-            uint32_t *d = ring + (pdst[k] >= 0 ? slot * kARowWords + pdst[k] : kDump);
-            d[0] = pv[k].x;
-            d[1] = pv[k].y;
-            d[2] = pv[k].z;
-            d[3] = pv[k].w;
+        for (int k = 0; k < kNS; ++k) {
+            if constexpr (ND3) {
+                // the plane blend, exactly the innermost blend of interp_nd<3> / interp_nd_fused<3>
+                const CT v[2] = {as_ct(pv[k].a), as_ct(pv[k].b)}, d1[1] = {my_dp};
+                const CT u = interp_t<T, 1>(v, d1);
+                char *d = reinterpret_cast<char *>(ring) + (pdst[k] >= 0 ? slot * (kARowWords * 4) + pdst[k] : kDump * 4);
+                *reinterpret_cast<float *>(d) = u;
+            } else {
+                uint32_t *d = ring + (pdst[k] >= 0 ? slot * kARowWords + pdst[k] : kDump);
+                d[0] = pv[k].x;
+                d[1] = pv[k].y;
+                d[2] = pv[k].z;
+                d[3] = pv[k].w;
+            }
         }
     };
     const int ylast = min(H - 1, h1 + LH + kR);
-    u4 pre[2 * kR + 1][kANP];
+    SV pre[2 * kR + 1][kNS];
 #pragma unroll
     for (int d = 0; d < kDepth; ++d) load_row(h0 + LH + kR + 1 + d, ylast, pvs[d]);
 #pragma unroll
     for (int r = 0; r <= 2 * kR; ++r) load_row(h0 + LH - kR + r, ylast, pre[r]);
 
-    // ---- the channels' shifts ------------------------------------------------------------------------------------------
-    const int perH = map_period(H, p.pad), perW = map_period(W, p.pad);
-    if (threadIdx.x < CB) {
-        const int c = min(c0 + static_cast<int>(threadIdx.x), C - 1);
-        const int wcol[3] = {-1, 0, 1};
-        CT wv[3], dh, dwf;
-        int64_t sh2[2];
-        load_weights3<CT>(p.w, p.wkind, static_cast<int64_t>(c) * 2, wcol, wv);
-        prep_shift_forward<CT>(wv[1], true, sh2[0], dh);
-        prep_shift_forward<CT>(wv[2], true, sh2[1], dwf);
-        const int sh = canon_shift(sh2[0], H, p.pad, p.d_perH), sw = canon_shift(sh2[1], W, p.pad, p.d_perW);
-        const int sh_s = (perH && 2 * sh > perH) ? sh - perH : sh, sw_s = (perW && 2 * sw > perW) ? sw - perW : sw;
-        const bool in_ring = sh_s >= -kR && sh_s <= kR && sw_s >= -kR && sw_s <= kR;
-        tab_sh[threadIdx.x] = in_ring ? sh_s : kFarShift;
-        tab_shc[threadIdx.x] = sh;
-        tab_sw[threadIdx.x] = sw;
-        tab_dh[threadIdx.x] = dh;
-        tab_dw[threadIdx.x] = dwf;
-    }
-    __syncthreads();
+    if constexpr (!ND3) channel_table();   // (2-D: while the rows are in flight)
 
     // ---- thread -> outputs ---------------------------------------------------------------------------------------------
     const int lane_a = static_cast<int>(threadIdx.x) % LA, lane_b = static_cast<int>(threadIdx.x) / LA;
@@ -931,11 +1003,11 @@ __global__ __launch_bounds__(kThreads) void cl_tiled_active_forward(const ClTile
         const bool mine = inside && s != kFarShift && !outside(a0) && !outside(a1);
         live |= (mine ? 1u : 0u) << i;
         rest |= ((inside && !mine) ? 1u : 0u) << i;
-        auto lds_col = [&](int sx) { return (mine && sx >= 0) ? (sx - (w0 + LW - kR)) * (kPitch * 4) + ch * ES : kNeg; };
+        auto lds_col = [&](int sx) { return (mine && sx >= 0) ? (sx - (w0 + LW - kR)) * (kPitch * 4) + ch * RES : kNeg; };
         xc0[i] = lds_col(a0);
         xc1[i] = lds_col(a1);
-        const uint32_t o = OUT_CL ? (static_cast<uint32_t>(h0 * OW + w0 + col) * C + c) * ES
-                                  : (static_cast<uint32_t>(c * OH + h0) * OW + w0 + col) * ES;
+        const uint32_t o = OUT_CL ? (static_cast<uint32_t>((dz * OH + h0) * OW + w0 + col) * C + c) * ES
+                                  : (static_cast<uint32_t>((c * OD + dz) * OH + h0) * OW + w0 + col) * ES;
         ooff[i] = mine ? o : kOutOfRange;
     }
     const uint32_t ostep = static_cast<uint32_t>(OUT_CL ? OW * C : OW) * ES;
@@ -947,7 +1019,8 @@ __global__ __launch_bounds__(kThreads) void cl_tiled_active_forward(const ClTile
     }
     const char *ringz = reinterpret_cast<const char *>(ring_all);   // byte 0: the zero words; the ring starts at byte 16
     auto lds_f = [&](int row, int colo) {   // padding (a negative offset) reads a zero word: no lane masks
-        return widen<T>(*reinterpret_cast<const S *>(ringz + max(row + colo, 0)));
+        if constexpr (ND3) return *reinterpret_cast<const float *>(ringz + max(row + colo, 0));
+        else return widen<T>(*reinterpret_cast<const S *>(ringz + max(row + colo, 0)));
     };
     auto row_off = [&](int sy) { return (16 + (sy & (kARing - 1)) * (kARowWords * 4)) | ((sy >> 31) & kNeg); };
     const int fm = (p.pad == 3 || p.pad == 4) ? -1 : 0;   // one fold of the signed shift, in bit arithmetic: see cl_tiled_backward
@@ -965,7 +1038,7 @@ __global__ __launch_bounds__(kThreads) void cl_tiled_active_forward(const ClTile
     int xrow1[NCH];
 #pragma unroll
     for (int k = 0; k < NCH; ++k) xrow1[k] = fold1(h0 + LH - shs[k]);
-    auto step = [&](int h, u4 (&pv)[kANP]) {
+    auto step = [&](int h, SV (&pv)[kNS]) {
         const int hs = h + LH;
         __syncthreads();
         if (hs + kR + 1 < H) store_row(hs + kR + 1, pv);
@@ -1024,7 +1097,20 @@ __global__ __launch_bounds__(kThreads) void cl_tiled_active_forward(const ClTile
     const bool wrap_rows = periodic && (h0 + LH <= kR || h1 + LH >= H - kR - 1);
     if (rest || any_srow || (wrap_rows && live)) {
         const S *xe = reinterpret_cast<const S *>(xn);
-        auto tap = [&](const S *base, int r, int cc) { return (r >= 0 && cc >= 0) ? widen<T>(base[(static_cast<int64_t>(r) * W + cc) * C]) : CT(0); };
+        int ez0 = 0, ez1 = 0;   // ND3: the two source planes and the plane fraction of the element at hand
+        CT edp = CT(0);
+        const int64_t plane_elems = static_cast<int64_t>(H) * W * C;
+        auto tap = [&](const S *base, int r, int cc) {
+            if (r < 0 || cc < 0) return CT(0);
+            const int64_t at = (static_cast<int64_t>(r) * W + cc) * C;
+            if constexpr (ND3) {   // the plane blend first, like the staging
+                const CT v[2] = {ez0 >= 0 ? widen<T>(base[ez0 * plane_elems + at]) : CT(0), ez1 >= 0 ? widen<T>(base[ez1 * plane_elems + at]) : CT(0)};
+                const CT d1[1] = {edp};
+                return interp_t<T, 1>(v, d1);
+            } else {
+                return widen<T>(base[at]);
+            }
+        };
 #pragma unroll
         for (int i = 0; i < NI; ++i) {
             const int k = OUT_CL ? 0 : i;
@@ -1033,8 +1119,13 @@ __global__ __launch_bounds__(kThreads) void cl_tiled_active_forward(const ClTile
             const int ch = OUT_CL ? lane_a : lane_b + PL * i, col = OUT_CL ? lane_b + PL * i : lane_a;
             const int shc = tab_shc[ch], sw = tab_sw[ch], wo = w0 + col, wq = wo + LW;
             const int a0 = fold_w(wq - sw), a1 = fold_w(wq - sw + 1);
-            S *o = reinterpret_cast<S *>(on) + (OUT_CL ? (static_cast<int64_t>(h0) * OW + wo) * C + c0 + ch
-                                                               : (static_cast<int64_t>(c0 + ch) * OH + h0) * OW + wo);
+            if constexpr (ND3) {
+                ez0 = tab_pz0[ch];
+                ez1 = tab_pz1[ch];
+                edp = tab_dp[ch];
+            }
+            S *o = reinterpret_cast<S *>(on) + (OUT_CL ? ((static_cast<int64_t>(dz) * OH + h0) * OW + wo) * C + c0 + ch
+                                                               : ((static_cast<int64_t>(c0 + ch) * OD + dz) * OH + h0) * OW + wo);
             for (int h = h0; h < h1; ++h) {
                 const int hs = h + LH;
                 if (!all_rows && !((srow[k] && hs == H - 1) || wraps(hs, shs[k]))) continue;
@@ -1080,7 +1171,7 @@ bool cl_tiled_forward_eligible(const Geometry &g, int dtype, const void *x, cons
     const int es = dtype_size(dtype);
     if (!g_cl_tiled_tune[0] || (g.nd != 2 && g.nd != 3) || es > 4) return false;
     if (g.active && dtype <= SHIFTND_BF16) {  // interpolating: cl_tiled_active_forward (fp32, fp16, bf16), rows folded once
-        if (g.nd != 2 || dtype == SHIFTND_F64 || (g.S[1] != 1 && g.S[1] < 5)) return false;
+        if (dtype == SHIFTND_F64 || (g.S[1] != 1 && g.S[1] < 5)) return false;
     }
     if (g.S[1] != 1 && g.S[1] <= kR) return false;   // the gather kernel folds its source rows once too (round 4)
     for (int d = 0; d < 3; ++d)   // the window (a crop of the output, round 4): both forward kernels
@@ -1125,7 +1216,8 @@ int cl_tiled_forward(const Geometry &g, int dtype, const void *x, const void *w,
     const bool nd3 = g.nd == 3;
     p.out_cl = (nd3 ? dense_channels_last_3d(g.os, g, g.O) : dense_channels_last_2d(g.os, g, g.O)) ? 1 : 0;
     p.wtiles = (p.OW + kTW - 1) / kTW;
-    const int cb = kLine / es;
+    const bool active3 = nd3 && g.active && dtype <= SHIFTND_BF16;   // (its ring holds fp32 plane blends: 32 channels per workgroup)
+    const int cb = active3 ? kLine / 4 : kLine / es;
     p.cblocks = (p.C + cb - 1) / cb;
     // bands along H: enough workgroups (~7 per workgroup slot of the chip: 28-row bands measured best on N16 C256
     // 224x224), at least 8 R rows per band (the ring warm-up is 2 R rows)
@@ -1146,6 +1238,17 @@ int cl_tiled_forward(const Geometry &g, int dtype, const void *x, const void *w,
     p.d_perW = make_fastdiv(static_cast<uint32_t>(map_period(p.W, p.pad)));
     p.d_perD = make_fastdiv(static_cast<uint32_t>(map_period(p.D, p.pad)));
     p.d_OD = make_fastdiv(static_cast<uint32_t>(p.OD));
+    if (active3) {
+        note_kernel("cl_tiled_active_forward_3d");
+#define SHIFTND_CLT_ACTIVE3(TT) \
+    if (p.out_cl) hipLaunchKernelGGL((cl_tiled_active_forward<TT, true, true>), dim3(static_cast<unsigned>(grid)), dim3(kThreads), 0, st, p); \
+    else hipLaunchKernelGGL((cl_tiled_active_forward<TT, false, true>), dim3(static_cast<unsigned>(grid)), dim3(kThreads), 0, st, p);
+        if (dtype == SHIFTND_F32) { SHIFTND_CLT_ACTIVE3(f32_t) }
+        else if (dtype == SHIFTND_F16) { SHIFTND_CLT_ACTIVE3(f16_t) }
+        else { SHIFTND_CLT_ACTIVE3(bf16_t) }
+#undef SHIFTND_CLT_ACTIVE3
+        return SHIFTND_OK;
+    }
     if (nd3) {
         note_kernel("cl_tiled_forward_3d");
 #define SHIFTND_CLT_LAUNCH3(ESV) \
@@ -1159,8 +1262,8 @@ int cl_tiled_forward(const Geometry &g, int dtype, const void *x, const void *w,
     if (g.active && dtype <= SHIFTND_BF16) {
         note_kernel("cl_tiled_active_forward");
 #define SHIFTND_CLT_ACTIVE(TT) \
-    if (p.out_cl) hipLaunchKernelGGL((cl_tiled_active_forward<TT, true>), dim3(static_cast<unsigned>(grid)), dim3(kThreads), 0, st, p); \
-    else hipLaunchKernelGGL((cl_tiled_active_forward<TT, false>), dim3(static_cast<unsigned>(grid)), dim3(kThreads), 0, st, p);
+    if (p.out_cl) hipLaunchKernelGGL((cl_tiled_active_forward<TT, true, false>), dim3(static_cast<unsigned>(grid)), dim3(kThreads), 0, st, p); \
+    else hipLaunchKernelGGL((cl_tiled_active_forward<TT, false, false>), dim3(static_cast<unsigned>(grid)), dim3(kThreads), 0, st, p);
         if (dtype == SHIFTND_F32) { SHIFTND_CLT_ACTIVE(f32_t) }
         else if (dtype == SHIFTND_F16) { SHIFTND_CLT_ACTIVE(f16_t) }
         else { SHIFTND_CLT_ACTIVE(bf16_t) }

@@ -303,6 +303,14 @@ def test_tiled_channels_last_3d_forward_vs_oracle(shape, crop):
                 abi.forward(xd, wd, pad, False, b, out=out_cl)
                 assert abi.last_kernel() == "cl_tiled_forward_3d"
                 assert np.array_equal(out_cl.cpu().numpy(), ref), (shape, crop, pad, "cl")
+                if shape[3] == 1 or shape[3] >= 5:   # the interpolating shift: the plane blend at staging time, bit-exact in fp32
+                    ref = O.forward(x, w, pad, True, b)
+                    out = abi.forward(xd, wd, pad, True, b)
+                    assert abi.last_kernel() == "cl_tiled_active_forward_3d" and out.is_contiguous(), abi.last_kernel()
+                    assert np.array_equal(out.cpu().numpy(), ref), (shape, crop, pad, "active ncdhw")
+                    abi.forward(xd, wd, pad, True, b, out=out_cl)
+                    assert abi.last_kernel() == "cl_tiled_active_forward_3d"
+                    assert np.array_equal(out_cl.cpu().numpy(), ref), (shape, crop, pad, "active cl")
         abi.set_tuning(21, 0)
         # int32 quantized: fill = the input's zero point, format kept (shifts_quantized.cpp:119-121)
         xq = rs.randint(-1000, 1000, size=shape).astype(np.int32)
@@ -326,6 +334,11 @@ def test_tiled_channels_last_3d_forward_vs_oracle(shape, crop):
                     out = abi.forward(xbd, wb.to(DEV), pad, False, b)
                     assert abi.last_kernel() == "cl_tiled_forward_3d" and out.is_contiguous()
                     assert np.array_equal(out.float().cpu().numpy(), ref), (shape, crop, pad, "bf16 ncdhw")
+                if shape[3] == 1 or shape[3] >= 5:
+                    refa = torch.from_numpy(O.forward(xb.float().numpy(), wb.float().numpy(), pad, True, b)).to(torch.bfloat16)
+                    abi.forward(xbd, wb.to(DEV), pad, True, b, out=out_cl)
+                    assert abi.last_kernel() == "cl_tiled_active_forward_3d"
+                    assert _ulp_close(out_cl.cpu(), refa, torch.bfloat16, 8 * 2.0 ** -24), (shape, crop, pad, "bf16 active")
     finally:
         abi.set_tuning(21, 0)
 

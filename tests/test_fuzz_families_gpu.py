@@ -23,11 +23,11 @@ def test_random_cases_against_the_oracle(seed):
     rs = np.random.RandomState(1000 + seed)
     F.count.clear()
     t0, n = time.time(), 0
-    while time.time() - t0 < 25.0 or n < 88:  # ~25 s per seed, at least 8 rounds of the case list
+    while time.time() - t0 < 25.0 or n < 96:  # ~25 s per seed, at least 8 rounds of the case list
         F.CASES[n % len(F.CASES)](rs)
         n += 1
     kernels = set(F.count)
     for must in ("cl_tiled_backward", "step_backward", "step_gather_forward", "walk_forward", "walk_backward", "walk_backward16", "walk_backward_pool",
-                 "crop_backward", "cl_tiled_backward/crop"):
+                 "crop_backward", "cl_tiled_backward/crop", "cl_tiled_forward_3d"):
         assert must in kernels, (must, dict(F.count))
     assert any(k.startswith(("small_", "band_")) for k in kernels), dict(F.count)

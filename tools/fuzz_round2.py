@@ -382,7 +382,39 @@ def case_cl_crop(rs):
         abi.set_tuning(21, 0)
 
 
-CASES = [case_cl, case_ragged, case_ragged, case_bytes, case_step, case_step, case_walk, case_walk, case_crop, case_crop, case_cl_crop]
+def case_cl3d(rs):
+    """round 4: NDHWC forwards (cl_tiled_forward_3d: sparse / quantized, cl_tiled_active_forward_3d: the plane blend at staging time);
+    fp32 bit-exact both ways, int32 quantized, random windows in all three dims, any depth shift"""
+    C = int(rs.choice([4, 8, 12, 32, 36, 64]))
+    D = int(rs.choice([1, 2, 3, 5, 8])); H = int(rs.choice([1, 5, 6, 9, 17])); W = int(rs.randint(1, 30))
+    N = int(rs.randint(1, 3))
+    shape = (N, C, D, H, W)
+    crop = _random_crop(rs, (D, H, W)) if rs.randint(2) else None
+    b, new = abi.check_borders(list(shape), crop, 3)
+    pad = int(rs.randint(0, 5)); active = int(rs.randint(0, 2))
+    x = rs.uniform(-1, 1, size=shape).astype(np.float32)
+    w = weights(rs, C, 3, shape[2:], 3.9).astype(np.float32)
+    cl3 = torch.channels_last_3d
+    xd = torch.from_numpy(x).to(DEV).contiguous(memory_format=cl3)
+    wd = torch.from_numpy(w).to(DEV)
+    abi.set_tuning(21, int(rs.choice([0, 0, 3, 7])))
+    try:
+        ref = O.forward(x, w, pad, active, b)
+        for out in (None, torch.empty(new, device=DEV).contiguous(memory_format=cl3)):
+            o = abi.forward(xd, wd, pad, active, b, out=out)
+            count[abi.last_kernel()] += 1
+            assert abi.last_kernel() == ("cl_tiled_active_forward_3d" if active else "cl_tiled_forward_3d"), (shape, crop, abi.last_kernel())
+            assert np.array_equal(o.cpu().numpy(), ref), ("cl3d fwd", shape, crop, pad, active)
+        xq = rs.randint(-500, 500, size=shape).astype(np.int32); wq = rs.randint(122, 135, size=(C, 3)).astype(np.uint8)
+        oq = torch.empty(new, dtype=torch.int32, device=DEV).contiguous(memory_format=cl3)
+        abi.forward_quantized(torch.from_numpy(xq).to(DEV).contiguous(memory_format=cl3), torch.from_numpy(wq).to(DEV), 128, 3, pad, b, out=oq)
+        count[abi.last_kernel() + "/i32"] += 1
+        assert np.array_equal(oq.cpu().numpy(), O.forward_q(xq, wq, 128, 3, pad, b)), ("cl3d i32", shape, crop, pad)
+    finally:
+        abi.set_tuning(21, 0)
+
+
+CASES = [case_cl, case_ragged, case_ragged, case_bytes, case_step, case_step, case_walk, case_walk, case_crop, case_crop, case_cl_crop, case_cl3d]
 
 
 

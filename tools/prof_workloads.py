@@ -36,7 +36,7 @@ def main():
         wf = torch.rand(128, 3, device=dev) * 2 - 1
         of, ob = torch.empty_like(xf), torch.empty_like(xb)
         calls = [lambda: abi.forward_quantized(xq, wq, 128, 3, 0, out=oq), lambda: abi.forward(xf, wf, 0, 0, out=of),
-                 lambda: abi.forward(xb, wf.bfloat16(), 0, 0, out=ob)]
+                 lambda: abi.forward(xb, wf.bfloat16(), 0, 0, out=ob), lambda: abi.forward(xf, wf, 0, 1, out=of)]
         for f in calls:
             for _ in range(a.iters):
                 f()

@@ -231,17 +231,15 @@ __global__ __launch_bounds__(kThreads) void crop_backward(const SpanParams p) {
             if (first + E < 0 || first >= len) st.base = 0;
             st.affine = true;
 #pragma unroll
-            for (int e = 0; e <= E; ++e) st.cm[e] = (first + e >= 0 && first + e < len) ? first + e : -1;
+            for (int e = 0; e <= E; ++e)   // (one unsigned compare: a pair of signed ones is a scalar and of two lane masks)
+                st.cm[e] = static_cast<unsigned>(first + e) < static_cast<unsigned>(len) ? first + e : -1;
             return st;
         };
         if constexpr (PAD == 0) {
             xm = affine_state(ji - d.cx2, S2);
             gm = affine_state(ji - L2 - d.cg2, O2);
-            if (O2 == 1) {   // a window one column wide ignores the shift (shifts_kernels.h:40-48): both corners read column 0
-                gm.affine = false;
-#pragma unroll
-                for (int e = 0; e <= E; ++e) gm.cm[e] = (ji - L2 + e >= 0 && ji - L2 + e <= 1) ? 0 : -1;
-            }
+            // (a window one column wide ignores the shift, shifts_kernels.h:40-48 -- both corners read column 0, not an affine
+            //  state: span_backward_eligible sends O2 == 1 with zeros padding to the per-channel kernels)
         } else {
             const size_t rec = (static_cast<size_t>(c) * cpr + (tr < R ? tc : 0)) * REC;
             xm = load_colstate<E>(p.colx + rec);
@@ -258,9 +256,15 @@ __global__ __launch_bounds__(kThreads) void crop_backward(const SpanParams p) {
         const bool in_row = b >= L1 && b < L1 + O1;
         auto row_valid = [&](int pr, int cs, int len) { return PAD != 0 || row_map_t<PAD>(pr, cs, len) >= 0; };
         const S zero = static_cast<S>(0.0f);
+        // zeros padding: every column state is affine (the host keeps windows one column wide, whose gradient map is not, away
+        // from this kernel) -- the reader without branches
+        auto read_row = [&](const char *row, bool valid, const ColState<E> &cst, S (&raw)[E + 1]) {
+            if constexpr (PAD == 0) lds_read_row_affine<S, E>(row, valid, cst, raw);
+            else lds_read_row<S, E>(row, valid, cst, raw);
+        };
         bool inside[E];   // the chunk's positions inside the window
 #pragma unroll
-        for (int e = 0; e < E; ++e) inside[e] = in_row && ji + e >= L2 && ji + e < L2 + O2;
+        for (int e = 0; e < E; ++e) inside[e] = static_cast<unsigned>(ji + e - L2) < static_cast<unsigned>(in_row ? O2 : 0);
         Chunk<S, E> res;
         // ---- grad_x -------------------------------------------------------------------------------------------------------
         if constexpr (ACTIVE) {
@@ -271,7 +275,7 @@ __global__ __launch_bounds__(kThreads) void crop_backward(const SpanParams p) {
                 const bool dom = in_row && pr <= O1;
                 const int srow = dom ? row_map_t<PAD>(pr, d.cg1, O1) : -1;
                 S raw[E + 1];
-                lds_read_row<S, E>(tile + gsoff + (tr + hb) * RBG + (row_lo(srow) & 15), srow >= 0, gm, raw);
+                read_row(tile + gsoff + (tr + hb) * RBG + (row_lo(srow) & 15), srow >= 0, gm, raw);
 #pragma unroll
                 for (int e = 0; e <= E; ++e) gv[hb][e] = widen<T>(raw[e]);
             }
@@ -283,7 +287,7 @@ __global__ __launch_bounds__(kThreads) void crop_backward(const SpanParams p) {
         } else {
             const int srow = in_row ? row_map_t<PAD>(b - L1, d.cg1, O1) : -1;
             S raw[E + 1];
-            lds_read_row<S, E>(tile + gsoff + tr * RBG + (row_lo(srow) & 15), srow >= 0, gm, raw);
+            read_row(tile + gsoff + tr * RBG + (row_lo(srow) & 15), srow >= 0, gm, raw);
 #pragma unroll
             for (int e = 0; e < E; ++e) res.e[e] = inside[e] ? raw[e] : zero;
         }
@@ -292,7 +296,7 @@ __global__ __launch_bounds__(kThreads) void crop_backward(const SpanParams p) {
 #pragma unroll
         for (int hb = 0; hb < 2; ++hb) {
             S raw[E + 1];
-            lds_read_row<S, E>(tile + (tr + hb) * RBX, row_valid(b + hb, d.cx1, S1), xm, raw);
+            read_row(tile + (tr + hb) * RBX, row_valid(b + hb, d.cx1, S1), xm, raw);
 #pragma unroll
             for (int e = 0; e <= E; ++e) xv[hb][e] = widen<T>(raw[e]);
         }
@@ -564,7 +568,7 @@ __global__ __launch_bounds__(kThreads) void crop_forward(const SpanFwdParams p) 
         xm.base = (first + E < 0 || first >= S2) ? 0 : first;
         xm.affine = true;
 #pragma unroll
-        for (int e = 0; e <= E; ++e) xm.cm[e] = (first + e >= 0 && first + e < S2) ? first + e : -1;
+        for (int e = 0; e <= E; ++e) xm.cm[e] = static_cast<unsigned>(first + e) < static_cast<unsigned>(S2) ? first + e : -1;
     } else {
         xm = fold_colstate<E, PAD>(j + L2, cs2, S2);
     }
@@ -580,7 +584,8 @@ __global__ __launch_bounds__(kThreads) void crop_forward(const SpanFwdParams p) 
 #pragma unroll
             for (int hb = 0; hb < 2; ++hb) {
                 S raw[E + 1];
-                lds_read_row<S, E>(tile + (slot + hb) * RB, row_ok(slot + hb), xm, raw);
+                if constexpr (PAD == 0) lds_read_row_affine<S, E>(tile + (slot + hb) * RB, row_ok(slot + hb), xm, raw);
+                else lds_read_row<S, E>(tile + (slot + hb) * RB, row_ok(slot + hb), xm, raw);
 #pragma unroll
                 for (int e = 0; e <= E; ++e) xv[hb][e] = widen<T>(raw[e]);
             }
@@ -591,7 +596,8 @@ __global__ __launch_bounds__(kThreads) void crop_forward(const SpanFwdParams p) 
             }
         } else {
             S raw[E + 1];
-            lds_read_row<S, E>(tile + slot * RB, row_ok(slot), xm, raw);
+            if constexpr (PAD == 0) lds_read_row_affine<S, E>(tile + slot * RB, row_ok(slot), xm, raw);
+            else lds_read_row<S, E>(tile + slot * RB, row_ok(slot), xm, raw);
 #pragma unroll
             for (int e = 0; e < E; ++e) res.e[e] = raw[e];
         }
@@ -1094,6 +1100,9 @@ bool span_backward_eligible(const Geometry &g, int dtype, const void *go, const 
     if (g_step_tune[0] == 1 || !span_geometry_ok(g, dtype)) return false;
     if (!dense(g.xs, g.N, g.C, g.S) || !dense(g.os, g.N, g.C, g.O) || !dense(g.gs, g.N, g.C, g.S)) return false;
     if (reinterpret_cast<uintptr_t>(go) % 16 || reinterpret_cast<uintptr_t>(x) % 16 || reinterpret_cast<uintptr_t>(gx) % 16) return false;
+    // (crop_backward<.., PAD = 0> reads every chunk through an affine column state; a window one column wide ignores the shift and
+    //  is not one)
+    if (g.nd == 2 && g.pad == 0 && g.O[2] == 1) return false;
     if (g_step_tune[0] == 2) return true;
     const int es = dtype_size(dtype);
     if (g.nd == 1) return g.S[2] * es / 16 >= 128;   // (short rows: one row per workgroup would leave most lanes idle)

@@ -80,6 +80,41 @@ __device__ __forceinline__ void lds_read_row(const char *row, bool valid, const 
     }
 }
 
+// lds_read_row for a chunk whose column state is KNOWN to be affine (zeros padding: every chunk), without control flow: the reads
+// are unconditional (an affine state's base always points into the row's slot), "row valid" and "column valid" are one integer
+// test per element.  Round 4: the two data-dependent branches of lds_read_row cost two or three exec-mask regions per call -- a
+// dozen scalar instructions -- and the one-step kernels that call it three or four times per workgroup are partly bound by the
+// CU's scalar unit.  (Going further -- validity as integer masks and-ed into the loaded bits, no lane conditions at
+// all -- removed another 60 scalar instructions per wave and was SLOWER: 40 more vector instructions; c2acrop backward 1.76 -> 1.89 ms.)
+template <typename S, int E>
+__device__ __forceinline__ void lds_read_row_affine(const char *row, bool valid, const ColState<E> &c, S (&raw)[E + 1]) {
+    S zero;
+    __builtin_memset(&zero, 0, sizeof(S));
+    const int dead = valid ? 0 : -1;
+    if constexpr (sizeof(S) == 2) {
+        const int byte0 = c.base * 2;
+        const uint32_t *dwp = reinterpret_cast<const uint32_t *>(row + (byte0 & ~3));
+        const uint32_t sh = (byte0 & 2) ? 16u : 0u;
+        uint32_t dw[6];
+#pragma unroll
+        for (int i = 0; i < 5; ++i) dw[i] = dwp[i];
+        dw[5] = 0;
+#pragma unroll
+        for (int i = 0; i < 5; ++i) {
+            const uint32_t t = __builtin_amdgcn_alignbit(dw[i + 1], dw[i], sh);
+            const uint16_t lo = static_cast<uint16_t>(t), hi = static_cast<uint16_t>(t >> 16);
+            if (2 * i <= E) __builtin_memcpy(&raw[2 * i], &lo, 2);
+            if (2 * i + 1 <= E) __builtin_memcpy(&raw[2 * i + 1], &hi, 2);
+        }
+    } else {
+        const S *p0 = reinterpret_cast<const S *>(row) + c.base;
+#pragma unroll
+        for (int e = 0; e <= E; ++e) raw[e] = p0[e];
+    }
+#pragma unroll
+    for (int e = 0; e <= E; ++e) raw[e] = (c.cm[e] | dead) >= 0 ? raw[e] : zero;
+}
+
 // The six dwords of a staged row starting at dword (byte0 >> 2), read as the two aligned 16-byte spans that hold them.
 // Five or six ds_read_b32 at a lane stride of 16 bytes (neighbouring chunks) are 4- to 8-way bank conflicts -- half of the
 // LDS time of the 16-bit one-step kernels (SQ_LDS_BANK_CONFLICT); two ds_read_b128 at 16-byte aligned addresses are

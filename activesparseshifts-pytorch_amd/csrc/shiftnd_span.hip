@@ -439,7 +439,7 @@ __global__ __launch_bounds__(kThreads) void span_forward(const SpanFwdParams p) 
         xm.base = (first + E < 0 || first >= S2) ? c0 : first;
         xm.affine = true;
 #pragma unroll
-        for (int e = 0; e <= E; ++e) xm.cm[e] = (first + e >= 0 && first + e < S2) ? first + e : -1;
+        for (int e = 0; e <= E; ++e) xm.cm[e] = static_cast<unsigned>(first + e) < static_cast<unsigned>(S2) ? first + e : -1;
     } else {
         xm = fold_colstate<E, PAD>(j + L2, cs2, S2);
     }
@@ -683,7 +683,7 @@ __global__ __launch_bounds__(kThreads) void row_forward(const SpanFwdParams p) {
         xm.base = (first + E < 0 || first >= S2) ? a0 : first;
         xm.affine = true;
 #pragma unroll
-        for (int e = 0; e <= E; ++e) xm.cm[e] = (first + e >= 0 && first + e < S2) ? first + e : -1;
+        for (int e = 0; e <= E; ++e) xm.cm[e] = static_cast<unsigned>(first + e) < static_cast<unsigned>(S2) ? first + e : -1;
     } else {
         xm = fold_colstate<E, PAD>(j + L2, cs2, S2);
     }
@@ -697,7 +697,8 @@ __global__ __launch_bounds__(kThreads) void row_forward(const SpanFwdParams p) {
     if (q >= q1) return;
     S raw[E + 1];
     if (PAD == 0 || staged) {
-        lds_read_row<S, E>(tile - plo * 16, true, xm, raw);
+        if constexpr (PAD == 0) lds_read_row_affine<S, E>(tile - plo * 16, true, xm, raw);   // (zeros padding: every state is affine)
+        else lds_read_row<S, E>(tile - plo * 16, true, xm, raw);
     } else {
         const S zero = static_cast<S>(0.0f);
 #pragma unroll
@@ -805,9 +806,11 @@ __global__ __launch_bounds__(kThreads) void row_backward(const SpanParams p) {
         const S zero = static_cast<S>(0.0f);
         bool inside[E];
 #pragma unroll
-        for (int e = 0; e < E; ++e) inside[e] = ji + e >= L2 && ji + e < L2 + O2;
+        for (int e = 0; e < E; ++e) inside[e] = static_cast<unsigned>(ji + e - L2) < static_cast<unsigned>(O2);
         auto read = [&](const char *lds_col0, const S *mem_col0, bool staged, const ColState<E> &st, S (&raw)[E + 1]) {
-            if (staged) {
+            if (PAD == 0 && O2 != 1) {   // (launch-uniform: zeros padding, every state affine and staged -- no data-dependent branch)
+                lds_read_row_affine<S, E>(lds_col0, true, st, raw);
+            } else if (staged) {
                 lds_read_row<S, E>(lds_col0, true, st, raw);
             } else {
 #pragma unroll

@@ -657,6 +657,37 @@ def test_channels_last_input_through_the_op_uses_the_tiled_kernel():
     assert abi.last_kernel() == "cl_tiled_forward" and out.is_contiguous() and torch.equal(out, ref)
 
 
+def test_channels_last_3d_input_through_the_op():
+    """torch.ops.torchshifts.shift3d with an NDHWC (channels_last_3d) input: fp32 sparse shift in one pass through
+    cl_tiled_forward_3d (NCDHW result like the reference, cpu/shifts_cpu.cpp:221); the interpolating shift, bf16 and the whole
+    backward through the layout change + the contiguous kernels -- every result the same bits as the contiguous input's, the
+    gradients flowing through autograd"""
+    import torchshifts  # noqa: F401
+    from torchshifts import abi
+    torch.manual_seed(6)
+    cl3 = torch.channels_last_3d
+    x = torch.rand(2, 32, 6, 20, 24, device=DEV)
+    w = (torch.rand(32, 3, device=DEV) - 0.5) * 4
+    ref = torch.ops.torchshifts.shift3d(x, w, torch.Tensor(), 0, False)
+    out = torch.ops.torchshifts.shift3d(x.contiguous(memory_format=cl3), w, torch.Tensor(), 0, False)
+    assert abi.last_kernel() == "cl_tiled_forward_3d" and out.is_contiguous() and torch.equal(out, ref), abi.last_kernel()
+    for active, tdt in ((True, torch.float32), (False, torch.bfloat16), (True, torch.bfloat16)):
+        xa, wa = x.to(tdt), w.to(tdt)
+        ref = torch.ops.torchshifts.shift3d(xa, wa, torch.Tensor(), 3, active)
+        out = torch.ops.torchshifts.shift3d(xa.contiguous(memory_format=cl3), wa, torch.Tensor(), 3, active)
+        assert torch.equal(out, ref), (active, tdt, abi.last_kernel())
+    # training step: the same gradients as with a contiguous input
+    grads = []
+    for fmt in (torch.contiguous_format, cl3):
+        xi = x.clone().contiguous(memory_format=fmt).requires_grad_(True)
+        wi = w.clone().requires_grad_(True)
+        y = torch.ops.torchshifts.shift3d(xi, wi, torch.Tensor(), 0, True)
+        y.square().sum().backward()
+        grads.append((xi.grad.contiguous(), wi.grad))
+    assert torch.equal(grads[0][0], grads[1][0])
+    assert torch.allclose(grads[0][1], grads[1][1], rtol=1e-5, atol=1e-5)
+
+
 @pytest.mark.parametrize("active", [False, True])
 def test_channels_last_backward_through_the_op_uses_the_tiled_kernel(active):
     """torch.ops.torchshifts._shift2d_backward with channels-last fp32 saved input and incoming gradient: one pass (no

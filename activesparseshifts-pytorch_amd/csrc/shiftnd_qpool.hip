@@ -318,6 +318,194 @@ template <typename EL> void launch_qplane_kv(const QPlanePlan &q, const QPlanePa
     }
 }
 
+// =====================================================================================================================
+// qpool_band_forward (round 4): the same fused pass for planes the plane kernel cannot hold -- 224 x 224 uint8 is 50 KB and
+// 12544 pooled elements -- 1-D / 2-D.  A workgroup owns a BAND of pooled rows of one channel and walks the batch: per image it
+// stages the band's source rows -- row slot i = the row the map gives for window row band0 * K1 + i, so every padding mode is
+// just a different row address -- and each thread sums the windows of up to NI items (4 pooled elements each) through offsets it
+// computed once.  Windows as in the plane kernel without the plane-pair forms: KV = 2, 3, 4, 9.
+// =====================================================================================================================
+struct QBandParams {
+    const uint8_t *x;
+    uint8_t *out;
+    const void *w;
+    int64_t wzp;
+    int32_t xzp;
+    int wkind, C, N, pad, zp_outside, nd;
+    int S1, S2, O1, O2, L1, L2, P1, P2, wcol1, wcol2;
+    int band, nbands;    // pooled rows per band, bands per plane
+    int groups;          // items per pooled row = ceil(P2 / 4)
+    int rpw, ngroups;    // images per workgroup, image groups
+    int vec, ppr;        // staging piece (16 / 4 / 1 bytes), pieces per source row
+    int zoff;            // LDS offset of the zero-point bytes
+    FastDiv d_groups, d_ppr, d_C, d_nbands, d_per1, d_per2;
+};
+
+template <typename EL, int KV, int NI>
+__global__ __launch_bounds__(kThreads) void qpool_band_forward(const QBandParams p) {
+    constexpr int K1 = QWindow<KV>::K1, K2 = QWindow<KV>::K2;
+    static_assert(QWindow<KV>::K0 == 1, "1-D / 2-D windows");
+    extern __shared__ __attribute__((aligned(16))) unsigned char q_lds[];
+    const int t = static_cast<int>(threadIdx.x);
+    uint32_t b = blockIdx.x;
+    const int c = static_cast<int>(b - fdiv(b, p.d_C) * static_cast<uint32_t>(p.C));
+    b = fdiv(b, p.d_C);
+    const int band = static_cast<int>(b - fdiv(b, p.d_nbands) * static_cast<uint32_t>(p.nbands));
+    const int ng = static_cast<int>(fdiv(b, p.d_nbands));
+    const int pb0 = band * p.band, nb = min(p.band, p.P1 - pb0);   // the band's pooled rows
+    if (t < 16) q_lds[p.zoff + t] = static_cast<unsigned char>(p.xzp);
+    int cs1 = 0, cs2 = 0;
+    if (p.wcol1 >= 0) cs1 = canon_shift(gather_shift(p.w, p.wkind, p.wzp, static_cast<int64_t>(c) * p.nd + p.wcol1), p.S1, p.pad, p.d_per1);
+    if (p.wcol2 >= 0) cs2 = canon_shift(gather_shift(p.w, p.wkind, p.wzp, static_cast<int64_t>(c) * p.nd + p.wcol2), p.S2, p.pad, p.d_per2);
+    auto src_row = [&](int wrow) { return p.S1 == 1 ? 0 : fold_index(wrow + p.L1 - cs1, p.S1, p.pad); };   // window row -> source row (-1: fill)
+    const int64_t plane = static_cast<int64_t>(p.S1) * p.S2, pooled = static_cast<int64_t>(p.P1) * p.P2;
+
+    // ---- the pieces this thread stages per image (the same for every image): up to NP ------------------------------------------
+    constexpr int NP = 16;   // (host: band * K1 * ppr <= NP * 256)
+    const int npieces = nb * K1 * p.ppr;
+    int soff[NP];            // byte offset of the piece in the image's plane, or -1
+#pragma unroll
+    for (int k = 0; k < NP; ++k) {
+        const int q = t + k * kThreads;
+        const int slot = static_cast<int>(fdiv(static_cast<uint32_t>(q), p.d_ppr)), pq = q - slot * p.ppr;
+        const int r = q < npieces ? src_row(pb0 * K1 + slot) : -1;
+        soff[k] = r >= 0 ? r * p.S2 + pq * p.vec : -1;
+    }
+    auto stage = [&](int n) {
+        const unsigned char *xp = p.x + (static_cast<int64_t>(min(n, p.N - 1)) * p.C + c) * plane;
+#pragma unroll
+        for (int k = 0; k < NP; ++k) {
+            if (k * kThreads >= npieces) break;   // (uniform)
+            const int q = t + k * kThreads;
+            if (soff[k] < 0) continue;
+            if (p.vec == 16) {
+                typedef uint32_t u4 __attribute__((ext_vector_type(4)));
+                *reinterpret_cast<u4 *>(__builtin_assume_aligned(q_lds + q * 16, 16)) = *reinterpret_cast<const u4 *>(__builtin_assume_aligned(xp + soff[k], 16));
+            } else if (p.vec == 4) {
+                *reinterpret_cast<uint32_t *>(q_lds + q * 4) = *reinterpret_cast<const uint32_t *>(xp + soff[k]);
+            } else {
+                q_lds[q] = xp[soff[k]];
+            }
+        }
+    };
+    const int n_first = ng * p.rpw;
+    stage(n_first);
+
+    // ---- once per workgroup: the window offsets of the thread's items -----------------------------------------------------------
+    int off[NI][4][KV];
+    float rc[NI][4];
+    int obyte[NI], ovalid[NI];
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+        int item = t + i * kThreads;
+        const bool live = item < nb * p.groups;
+        if (!live) item = 0;
+        const int prl = static_cast<int>(fdiv(static_cast<uint32_t>(item), p.d_groups)), cg = item - prl * p.groups;
+        const int p1 = pb0 + prl;
+        const int n1 = min(K1, p.O1 - p1 * K1);
+        obyte[i] = p1 * p.P2 + cg * 4;
+        ovalid[i] = live ? min(4, p.P2 - cg * 4) : 0;
+        int rowoff[K1], coloff[4 * K2];
+#pragma unroll
+        for (int bb = 0; bb < K1; ++bb) rowoff[bb] = (bb < n1 && src_row(p1 * K1 + bb) >= 0) ? (prl * K1 + bb) * p.S2 : -1;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int p2 = cg * 4 + j;
+            const int n2 = min(K2, p.O2 - p2 * K2);
+            const int cnt = max(n1, 1) * max(n2, 1);
+            const float mult = static_cast<float>(1.0 / static_cast<double>(cnt));
+            rc[i][j] = p.zp_outside ? mult : 1.0f / (1.0f / mult);
+#pragma unroll
+            for (int k = 0; k < K2; ++k) {
+                const int sc = p.S2 == 1 ? 0 : fold_index(p2 * K2 + k + p.L2 - cs2, p.S2, p.pad);
+                coloff[j * K2 + k] = k < n2 ? sc : -1;
+            }
+#pragma unroll
+            for (int bb = 0; bb < K1; ++bb)
+#pragma unroll
+                for (int k = 0; k < K2; ++k)
+                    off[i][j][bb * K2 + k] = (rowoff[bb] | coloff[j * K2 + k]) < 0 ? p.zoff : rowoff[bb] + coloff[j * K2 + k];
+        }
+    }
+    const int zsum = KV * p.xzp;
+    const float zpf = static_cast<float>(p.xzp);
+    const bool dword_out = (p.P2 & 3) == 0 && (pooled & 3) == 0;
+    for (int r = 0; r < p.rpw; ++r) {
+        const int n = n_first + r;
+        if (r > 0) {
+            __syncthreads();   // everybody has finished reading the previous image's band
+            stage(n);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            int qv[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                int sum = 0;
+#pragma unroll
+                for (int s2 = 0; s2 < KV; ++s2) sum += static_cast<int>(reinterpret_cast<const EL *>(q_lds)[off[i][j][s2]]);
+                const float prod = __fmul_rn(static_cast<float>(sum - zsum), rc[i][j]);   // (ATen's two roundings: qpool_plane_forward)
+                qv[j] = p.zp_outside ? static_cast<int>(nearbyintf(prod)) + p.xzp : static_cast<int>(nearbyintf(__fadd_rn(zpf, prod)));
+            }
+            if (ovalid[i] > 0 && n < p.N) {
+                uint8_t *o = p.out + (static_cast<int64_t>(n) * p.C + c) * pooled + obyte[i];
+                if (ovalid[i] == 4 && dword_out) {
+                    const uint32_t lo = __builtin_amdgcn_perm(static_cast<uint32_t>(qv[1]), static_cast<uint32_t>(qv[0]), 0x0c0c0400u);
+                    const uint32_t hi = __builtin_amdgcn_perm(static_cast<uint32_t>(qv[3]), static_cast<uint32_t>(qv[2]), 0x04000c0cu);
+                    *reinterpret_cast<uint32_t *>(o) = lo | hi;
+                } else {
+                    for (int j = 0; j < ovalid[i]; ++j) o[j] = static_cast<uint8_t>(qv[j]);
+                }
+            }
+        }
+    }
+}
+
+struct QBandPlan {
+    bool ok = false;
+    int KV = 0, NI = 0, band = 0, nbands = 0, groups = 0, rpw = 0, ngroups = 0, vec = 0, ppr = 0, zoff = 0, lds = 0;
+};
+
+QBandPlan qband_plan(const Geometry &g, const void *x) {
+    QBandPlan q;
+    if (g.S[0] != 1 || g.K[0] > 1 || g.N < 1 || g.C < 1 || g.P[1] < 1 || g.P[2] < 1) return q;   // 1-D / 2-D
+    if (g.S[1] * g.S[2] >= (1LL << 30) || g.N * g.C * g.S[1] * g.S[2] >= (1LL << 40)) return q;
+    const int64_t k1 = g.K[1] > 0 ? g.K[1] : 1, k2 = g.K[2] > 0 ? g.K[2] : 1, kv = k1 * k2;
+    if (!((k1 == 1 && (k2 == 2 || k2 == 3)) || (k1 == 2 && k2 == 2) || (k1 == 3 && k2 == 3))) return q;
+    q.KV = static_cast<int>(kv);
+    q.NI = kv == 9 ? 2 : 4;
+    q.groups = static_cast<int>((g.P[2] + 3) / 4);
+    if (q.groups > q.NI * kThreads) return q;
+    q.vec = (g.S[2] % 16 == 0 && reinterpret_cast<uintptr_t>(x) % 16 == 0) ? 16 : ((g.S[2] % 4 == 0 && reinterpret_cast<uintptr_t>(x) % 4 == 0) ? 4 : 1);
+    q.ppr = static_cast<int>(g.S[2] / q.vec);
+    int64_t band = std::min<int64_t>(g.P[1], (q.NI * kThreads) / q.groups);
+    // the staged rows: at most 16 pieces per thread and 60 KB of LDS
+    while (band > 1 && (band * k1 * q.ppr > 16 * kThreads || band * k1 * g.S[2] > 60 * 1024)) --band;
+    if (band * k1 * q.ppr > 16 * kThreads || band * k1 * g.S[2] > 60 * 1024) return q;
+    q.band = static_cast<int>(band);
+    q.nbands = static_cast<int>((g.P[1] + band - 1) / band);
+    q.zoff = static_cast<int>(((band * k1 * g.S[2] + 15) / 16) * 16);
+    q.lds = q.zoff + 16;
+    const int64_t want_wgs = 4096, per_image = g.C * q.nbands;
+    const int64_t ngroups = std::min<int64_t>(g.N, std::max<int64_t>(1, (want_wgs + per_image - 1) / per_image));
+    q.rpw = static_cast<int>((g.N + ngroups - 1) / ngroups);
+    q.ngroups = static_cast<int>((g.N + q.rpw - 1) / q.rpw);
+    if (static_cast<int64_t>(q.ngroups) * per_image >= (1LL << 31)) return q;
+    q.ok = true;
+    return q;
+}
+
+template <typename EL> void launch_qband(const QBandPlan &q, const QBandParams &p, hipStream_t st) {
+    const dim3 grid(static_cast<unsigned>(q.ngroups) * static_cast<unsigned>(p.nbands) * static_cast<unsigned>(p.C)), block(kThreads);
+    switch (q.KV) {
+    case 2: hipLaunchKernelGGL((qpool_band_forward<EL, 2, 4>), grid, block, q.lds, st, p); break;
+    case 3: hipLaunchKernelGGL((qpool_band_forward<EL, 3, 4>), grid, block, q.lds, st, p); break;
+    case 4: hipLaunchKernelGGL((qpool_band_forward<EL, 4, 4>), grid, block, q.lds, st, p); break;
+    default: hipLaunchKernelGGL((qpool_band_forward<EL, 9, 2>), grid, block, q.lds, st, p); break;
+    }
+}
+
 }  // namespace
 
 void qpool_set_tuning(int knob, int value) {
@@ -376,6 +564,49 @@ int qpool_forward(const Geometry &g, int dtype, const void *x, const void *w, in
         note_kernel("qpool_plane_forward");
         if (dtype == SHIFTND_I8) launch_qplane_kv<int8_t>(qp, p, st);
         else launch_qplane_kv<uint8_t>(qp, p, st);
+        return SHIFTND_OK;
+    }
+    const QBandPlan qb = qband_plan(g, x);
+    if (qb.ok && g_qpool_tune[0] != 1) {   // planes beyond the plane kernel: bands of pooled rows (round 4)
+        QBandParams p{};
+        p.x = static_cast<const uint8_t *>(x);
+        p.out = static_cast<uint8_t *>(out);
+        p.w = w;
+        p.wzp = wzp;
+        p.xzp = static_cast<int32_t>(xzp);
+        p.wkind = wkind;
+        p.zp_outside = requant == SHIFTND_REQUANT_ZP_OUTSIDE ? 1 : 0;
+        p.C = static_cast<int>(g.C);
+        p.N = static_cast<int>(g.N);
+        p.nd = g.nd;
+        p.pad = g.pad;
+        p.S1 = static_cast<int>(g.S[1]);
+        p.S2 = static_cast<int>(g.S[2]);
+        p.O1 = static_cast<int>(g.O[1]);
+        p.O2 = static_cast<int>(g.O[2]);
+        p.L1 = static_cast<int>(g.L[1]);
+        p.L2 = static_cast<int>(g.L[2]);
+        p.P1 = static_cast<int>(g.P[1]);
+        p.P2 = static_cast<int>(g.P[2]);
+        p.wcol1 = g.wcol[1];
+        p.wcol2 = g.wcol[2];
+        p.band = qb.band;
+        p.nbands = qb.nbands;
+        p.groups = qb.groups;
+        p.rpw = qb.rpw;
+        p.ngroups = qb.ngroups;
+        p.vec = qb.vec;
+        p.ppr = qb.ppr;
+        p.zoff = qb.zoff;
+        p.d_groups = make_fastdiv(static_cast<uint32_t>(qb.groups));
+        p.d_ppr = make_fastdiv(static_cast<uint32_t>(qb.ppr));
+        p.d_C = make_fastdiv(static_cast<uint32_t>(g.C));
+        p.d_nbands = make_fastdiv(static_cast<uint32_t>(qb.nbands));
+        p.d_per1 = make_fastdiv(static_cast<uint32_t>(map_period(p.S1, g.pad)));
+        p.d_per2 = make_fastdiv(static_cast<uint32_t>(map_period(p.S2, g.pad)));
+        note_kernel("qpool_band_forward");
+        if (dtype == SHIFTND_I8) launch_qband<int8_t>(qb, p, st);
+        else launch_qband<uint8_t>(qb, p, st);
         return SHIFTND_OK;
     }
     QPoolParams p{};

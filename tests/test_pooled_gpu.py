@@ -199,6 +199,12 @@ QCASES = [  # the planes the per-channel quantized kernel (qpool_plane_forward) 
     (3, (2, 3, 4, 14, 16), (1, 2, 2), None),
     (1, (7, 5, 64), (2,), None),
     (1, (4, 3, 99), (3,), [[2, 1]]),
+    # round 4, qpool_band_forward: planes beyond the plane kernel (more than 48 KiB or more than 1024 items), bands of pooled rows
+    (2, (3, 2, 224, 224), (2, 2), None),              # 50 KB planes, 16-byte pieces, four bands
+    (2, (2, 3, 150, 226), (2, 2), [[1, 0], [3, 3]]),  # byte / dword pieces, ragged last band and windows, a crop
+    (2, (5, 2, 130, 120), (3, 3), None),              # nine-byte windows
+    (2, (2, 2, 300, 36), (1, 2), None),               # a row window
+    (1, (3, 2, 9000), (2,), None),                    # Shift1d: one long row
 ]
 
 
@@ -246,11 +252,11 @@ def test_quantized_pooled_forward_vs_oracle(abi, npdt):
                     out = abi.forward_quantized_pooled(torch.from_numpy(xq).to(DEV), torch.from_numpy(wq).to(DEV), 128, zp, pad, pool,
                                                        b, requant=requant)
                     abi.set_tuning(36, 0)
-                    assert abi.last_kernel() in (("qpool_forward",) if knob else ("qpool_forward", "qpool_plane_forward"))
+                    assert abi.last_kernel() in (("qpool_forward",) if knob else ("qpool_forward", "qpool_plane_forward", "qpool_band_forward"))
                     served.add(abi.last_kernel())
                     assert np.array_equal(out.cpu().numpy(), ref), (nd, shape, pool, crop, pad, requant, abi.last_kernel())
     assert differ  # the inputs do separate the two roundings
-    assert served == {"qpool_forward", "qpool_plane_forward"}
+    assert served == {"qpool_forward", "qpool_plane_forward", "qpool_band_forward"}
 
 
 @pytest.mark.parametrize("dt", ["f32", "f16", "bf16"])

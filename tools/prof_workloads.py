@@ -91,6 +91,8 @@ def main():
     go_n = torch.rand(16, 256, 224, 224, device=dev)
     calls += [lambda: abi.backward(go_n, w, x, 0, 0, grad_x=gx, grad_w=gw, workspace=ws), lambda: abi.backward(go_n, w, x, 0, 1, grad_x=gx, grad_w=gw, workspace=ws),
               lambda: abi.forward(x, w, 2, 0, out=out_c), lambda: abi.backward(go, w, x, 2, 0, grad_x=gx, grad_w=gw, workspace=ws)]
+    ob2 = abi.forward_quantized_pooled(xb, wb, 128, 3, 0, 2)   # round 4: planes beyond the plane kernel -> qpool_band_forward
+    calls.append(lambda: abi.forward_quantized_pooled(xb, wb, 128, 3, 0, 2, out=ob2))
     xq2 = torch.randint(0, 255, (128, 512, 56, 56), dtype=torch.uint8, device=dev)
     oq2 = abi.forward_quantized_pooled(xq2, wq, 128, 3, 0, 2)
     calls.append(lambda: abi.forward_quantized_pooled(xq2, wq, 128, 3, 0, 2, out=oq2))

@@ -337,7 +337,7 @@ struct QBandParams {
     int groups;          // items per pooled row = ceil(P2 / 4)
     int rpw, ngroups;    // images per workgroup, image groups
     int vec, ppr;        // staging piece (16 / 4 / 1 bytes), pieces per source row
-    int zoff;            // LDS offset of the zero-point bytes
+    int pitch, zrow;     // LDS bytes per staged row (>= S2 + 1: byte S2 of every row holds the zero point), the all-zero-point row
     FastDiv d_groups, d_ppr, d_C, d_nbands, d_per1, d_per2;
 };
 
@@ -353,7 +353,11 @@ __global__ __launch_bounds__(kThreads) void qpool_band_forward(const QBandParams
     const int band = static_cast<int>(b - fdiv(b, p.d_nbands) * static_cast<uint32_t>(p.nbands));
     const int ng = static_cast<int>(fdiv(b, p.d_nbands));
     const int pb0 = band * p.band, nb = min(p.band, p.P1 - pb0);   // the band's pooled rows
-    if (t < 16) q_lds[p.zoff + t] = static_cast<unsigned char>(p.xzp);
+    // what a window element outside the tensor / the window reads: the zero point -- byte S2 of every staged row (an invalid column)
+    // and one whole row of zero points (an invalid row).  Offsets are then row + column, nothing to select: 10 registers per item
+    // instead of 16 (4 items: the kernel went from 2 to 3 waves per SIMD)
+    for (int q = t; q < p.pitch; q += kThreads) q_lds[p.zrow * p.pitch + q] = static_cast<unsigned char>(p.xzp);
+    for (int q = t; q < p.zrow; q += kThreads) q_lds[q * p.pitch + p.S2] = static_cast<unsigned char>(p.xzp);
     int cs1 = 0, cs2 = 0;
     if (p.wcol1 >= 0) cs1 = canon_shift(gather_shift(p.w, p.wkind, p.wzp, static_cast<int64_t>(c) * p.nd + p.wcol1), p.S1, p.pad, p.d_per1);
     if (p.wcol2 >= 0) cs2 = canon_shift(gather_shift(p.w, p.wkind, p.wzp, static_cast<int64_t>(c) * p.nd + p.wcol2), p.S2, p.pad, p.d_per2);
@@ -364,27 +368,28 @@ __global__ __launch_bounds__(kThreads) void qpool_band_forward(const QBandParams
     constexpr int NP = 16;   // (host: band * K1 * ppr <= NP * 256)
     const int npieces = nb * K1 * p.ppr;
     int soff[NP];            // byte offset of the piece in the image's plane, or -1
+    int doff[NP];            // ... in LDS
 #pragma unroll
     for (int k = 0; k < NP; ++k) {
         const int q = t + k * kThreads;
         const int slot = static_cast<int>(fdiv(static_cast<uint32_t>(q), p.d_ppr)), pq = q - slot * p.ppr;
         const int r = q < npieces ? src_row(pb0 * K1 + slot) : -1;
         soff[k] = r >= 0 ? r * p.S2 + pq * p.vec : -1;
+        doff[k] = slot * p.pitch + pq * p.vec;
     }
     auto stage = [&](int n) {
         const unsigned char *xp = p.x + (static_cast<int64_t>(min(n, p.N - 1)) * p.C + c) * plane;
 #pragma unroll
         for (int k = 0; k < NP; ++k) {
             if (k * kThreads >= npieces) break;   // (uniform)
-            const int q = t + k * kThreads;
             if (soff[k] < 0) continue;
             if (p.vec == 16) {
                 typedef uint32_t u4 __attribute__((ext_vector_type(4)));
-                *reinterpret_cast<u4 *>(__builtin_assume_aligned(q_lds + q * 16, 16)) = *reinterpret_cast<const u4 *>(__builtin_assume_aligned(xp + soff[k], 16));
+                *reinterpret_cast<u4 *>(__builtin_assume_aligned(q_lds + doff[k], 16)) = *reinterpret_cast<const u4 *>(__builtin_assume_aligned(xp + soff[k], 16));
             } else if (p.vec == 4) {
-                *reinterpret_cast<uint32_t *>(q_lds + q * 4) = *reinterpret_cast<const uint32_t *>(xp + soff[k]);
+                *reinterpret_cast<uint32_t *>(q_lds + doff[k]) = *reinterpret_cast<const uint32_t *>(xp + soff[k]);
             } else {
-                q_lds[q] = xp[soff[k]];
+                q_lds[doff[k]] = xp[soff[k]];
             }
         }
     };
@@ -392,7 +397,7 @@ __global__ __launch_bounds__(kThreads) void qpool_band_forward(const QBandParams
     stage(n_first);
 
     // ---- once per workgroup: the window offsets of the thread's items -----------------------------------------------------------
-    int off[NI][4][KV];
+    int rowoff[NI][K1], coloff[NI][4 * K2];
     float rc[NI][4];
     int obyte[NI], ovalid[NI];
 #pragma unroll
@@ -405,9 +410,8 @@ __global__ __launch_bounds__(kThreads) void qpool_band_forward(const QBandParams
         const int n1 = min(K1, p.O1 - p1 * K1);
         obyte[i] = p1 * p.P2 + cg * 4;
         ovalid[i] = live ? min(4, p.P2 - cg * 4) : 0;
-        int rowoff[K1], coloff[4 * K2];
 #pragma unroll
-        for (int bb = 0; bb < K1; ++bb) rowoff[bb] = (bb < n1 && src_row(p1 * K1 + bb) >= 0) ? (prl * K1 + bb) * p.S2 : -1;
+        for (int bb = 0; bb < K1; ++bb) rowoff[i][bb] = ((bb < n1 && src_row(p1 * K1 + bb) >= 0) ? prl * K1 + bb : p.zrow) * p.pitch;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int p2 = cg * 4 + j;
@@ -418,13 +422,8 @@ __global__ __launch_bounds__(kThreads) void qpool_band_forward(const QBandParams
 #pragma unroll
             for (int k = 0; k < K2; ++k) {
                 const int sc = p.S2 == 1 ? 0 : fold_index(p2 * K2 + k + p.L2 - cs2, p.S2, p.pad);
-                coloff[j * K2 + k] = k < n2 ? sc : -1;
+                coloff[i][j * K2 + k] = (k < n2 && sc >= 0) ? sc : p.S2;
             }
-#pragma unroll
-            for (int bb = 0; bb < K1; ++bb)
-#pragma unroll
-                for (int k = 0; k < K2; ++k)
-                    off[i][j][bb * K2 + k] = (rowoff[bb] | coloff[j * K2 + k]) < 0 ? p.zoff : rowoff[bb] + coloff[j * K2 + k];
         }
     }
     const int zsum = KV * p.xzp;
@@ -444,7 +443,9 @@ __global__ __launch_bounds__(kThreads) void qpool_band_forward(const QBandParams
             for (int j = 0; j < 4; ++j) {
                 int sum = 0;
 #pragma unroll
-                for (int s2 = 0; s2 < KV; ++s2) sum += static_cast<int>(reinterpret_cast<const EL *>(q_lds)[off[i][j][s2]]);
+                for (int bb = 0; bb < K1; ++bb)
+#pragma unroll
+                    for (int kk = 0; kk < K2; ++kk) sum += static_cast<int>(reinterpret_cast<const EL *>(q_lds)[rowoff[i][bb] + coloff[i][j * K2 + kk]]);
                 const float prod = __fmul_rn(static_cast<float>(sum - zsum), rc[i][j]);   // (ATen's two roundings: qpool_plane_forward)
                 qv[j] = p.zp_outside ? static_cast<int>(nearbyintf(prod)) + p.xzp : static_cast<int>(nearbyintf(__fadd_rn(zpf, prod)));
             }
@@ -464,7 +465,7 @@ __global__ __launch_bounds__(kThreads) void qpool_band_forward(const QBandParams
 
 struct QBandPlan {
     bool ok = false;
-    int KV = 0, NI = 0, band = 0, nbands = 0, groups = 0, rpw = 0, ngroups = 0, vec = 0, ppr = 0, zoff = 0, lds = 0;
+    int KV = 0, NI = 0, band = 0, nbands = 0, groups = 0, rpw = 0, ngroups = 0, vec = 0, ppr = 0, pitch = 0, lds = 0;
 };
 
 QBandPlan qband_plan(const Geometry &g, const void *x) {
@@ -479,14 +480,14 @@ QBandPlan qband_plan(const Geometry &g, const void *x) {
     if (q.groups > q.NI * kThreads) return q;
     q.vec = (g.S[2] % 16 == 0 && reinterpret_cast<uintptr_t>(x) % 16 == 0) ? 16 : ((g.S[2] % 4 == 0 && reinterpret_cast<uintptr_t>(x) % 4 == 0) ? 4 : 1);
     q.ppr = static_cast<int>(g.S[2] / q.vec);
+    q.pitch = static_cast<int>(((g.S[2] + 1 + 15) / 16) * 16);
     int64_t band = std::min<int64_t>(g.P[1], (q.NI * kThreads) / q.groups);
-    // the staged rows: at most 16 pieces per thread and 60 KB of LDS
-    while (band > 1 && (band * k1 * q.ppr > 16 * kThreads || band * k1 * g.S[2] > 60 * 1024)) --band;
-    if (band * k1 * q.ppr > 16 * kThreads || band * k1 * g.S[2] > 60 * 1024) return q;
+    // the staged rows (+ the row of zero points): at most 16 pieces per thread and 60 KB of LDS
+    while (band > 1 && (band * k1 * q.ppr > 16 * kThreads || (band * k1 + 1) * q.pitch > 60 * 1024)) --band;
+    if (band * k1 * q.ppr > 16 * kThreads || (band * k1 + 1) * q.pitch > 60 * 1024) return q;
     q.band = static_cast<int>(band);
     q.nbands = static_cast<int>((g.P[1] + band - 1) / band);
-    q.zoff = static_cast<int>(((band * k1 * g.S[2] + 15) / 16) * 16);
-    q.lds = q.zoff + 16;
+    q.lds = static_cast<int>((band * k1 + 1) * q.pitch);
     const int64_t want_wgs = 4096, per_image = g.C * q.nbands;
     const int64_t ngroups = std::min<int64_t>(g.N, std::max<int64_t>(1, (want_wgs + per_image - 1) / per_image));
     q.rpw = static_cast<int>((g.N + ngroups - 1) / ngroups);
@@ -597,7 +598,8 @@ int qpool_forward(const Geometry &g, int dtype, const void *x, const void *w, in
         p.ngroups = qb.ngroups;
         p.vec = qb.vec;
         p.ppr = qb.ppr;
-        p.zoff = qb.zoff;
+        p.pitch = qb.pitch;
+        p.zrow = qb.band * static_cast<int>(g.K[1] > 0 ? g.K[1] : 1);
         p.d_groups = make_fastdiv(static_cast<uint32_t>(qb.groups));
         p.d_ppr = make_fastdiv(static_cast<uint32_t>(qb.ppr));
         p.d_C = make_fastdiv(static_cast<uint32_t>(g.C));

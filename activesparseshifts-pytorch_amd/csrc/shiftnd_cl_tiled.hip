@@ -407,6 +407,7 @@ struct ClTiledBwdParams {
     int wkind, N, C, H, W, pad;
     int OH, OW, LH, LW;  // the window (round 4): grad_out's sizes and its corner in the input image (no crop: H, W, 0, 0)
     int go_nchw;         // the incoming gradient is NCHW-contiguous (saved input and grad_x: channels-last)
+    int go_pieces;       // ... and its rows are whole, aligned 16-byte pieces: staged by 16-byte loads (4-byte elements)
     int wtiles, cblocks, bands, band_rows;
     unsigned xcd_blocks;     // grid / 8 when the XCD-contiguous block remap is on (grid % 8 == 0 and knob 22), else 0
     FastDiv d_wtiles, d_cblocks, d_bands;
@@ -434,11 +435,12 @@ __global__ __launch_bounds__(kThreads) void cl_tiled_backward(const ClTiledBwdPa
     // words per staged pixel: 32 -- every LDS read of the row loop has its lanes along the CHANNELS of (per lane different) pixels,
     // bank = channel word whatever the pixel; the padded pitch of the forward kernels (33: their NCHW-output form reads along the
     // pixels) made half of this kernel's LDS cycles bank conflicts.  GO_NCHW stages along the pixels and keeps 33.
-    constexpr int PITCH = GO_NCHW ? kPitch : kLine / 4;
-    constexpr int BROW = kBPW * PITCH, BRING = kBRing * BROW;
-    __shared__ __attribute__((aligned(16))) uint32_t ring_all[4 + 2 * BRING + 4];
+    // (the INPUT ring is staged by pieces and read along the channels in every form: 32; only the gradient ring of GO_NCHW is 33)
+    constexpr int PITCHX = kLine / 4, PITCHG = GO_NCHW ? kPitch : kLine / 4;
+    constexpr int BROWX = kBPW * PITCHX, BROWG = kBPW * PITCHG, BRINGX = kBRing * BROWX, BRINGG = kBRing * BROWG;
+    __shared__ __attribute__((aligned(16))) uint32_t ring_all[4 + BRINGX + BRINGG + 4];
     uint32_t *const ring = ring_all + 4;
-    constexpr int kDump = 2 * BRING;
+    constexpr int kDump = BRINGX + BRINGG;
     constexpr int kNeg = -(1 << 24);
     if (threadIdx.x < 4) ring_all[threadIdx.x] = 0u;   // (read after the first barrier of the row loop)
 
@@ -478,7 +480,7 @@ __global__ __launch_bounds__(kThreads) void cl_tiled_backward(const ClTiledBwdPa
     const int px = q >> 3, part = q & 7, gxs = w0 - kR + px;
     const uint32_t poff = (piece && gxs >= 0 && gxs < W && c0 * ES + part * 16 < C * ES) ? static_cast<uint32_t>(gxs) * C * ES + c0 * ES + part * 16 : kOutOfRange;
     const uint32_t poffg = (piece && gxs >= LW && gxs < LW + OW && c0 * ES + part * 16 < C * ES) ? static_cast<uint32_t>(gxs - LW) * C * ES + c0 * ES + part * 16 : kOutOfRange;
-    const int pdst = piece ? px * PITCH + part * 4 : -1;
+    const int pdst = piece ? px * PITCHX + part * 4 : -1;   // (also the gradient's when it is channels-last: PITCHG == PITCHX then)
     const uint32_t row_bytes = static_cast<uint32_t>(W) * C * ES;
     constexpr int kDepth = CLT_DEPTH;
     // GO_NCHW: element e = ch * kBPW + px of the staged gradient row, kGN per thread
@@ -495,7 +497,26 @@ __global__ __launch_bounds__(kThreads) void cl_tiled_backward(const ClTiledBwdPa
             const int e = k * kThreads + q, ch = e / kBPW, pxe = e - ch * kBPW, gxe = w0 - kR + pxe;
             const bool ok = e < kGE && gxe >= LW && gxe < LW + OW && c0 + ch < C;
             goff[k] = ok ? (static_cast<uint32_t>(c0 + ch) * OH * OW + (gxe - LW)) * ES : kOutOfRange;
-            gdst[k] = e < kGE ? pxe * (PITCH * 4) + ch * ES : -1;
+            gdst[k] = e < kGE ? pxe * (PITCHG * 4) + ch * ES : -1;
+        }
+    }
+    // GO_NCHW, 4-byte elements, gradient rows of whole 16-byte pieces (host: p.go_pieces): the channel segments by 16-byte loads --
+    // the 23 staged pixels of a channel lie in at most 7 aligned pieces, 32 channels x 7 = 224 pieces: ONE load per thread and row
+    // instead of three element loads; the four elements of a piece go to four pixels of the ring (or to the dump word).
+    constexpr int kGPC = 7;                      // pieces per channel segment
+    const bool g_pieces = GO_NCHW && ES == 4 && p.go_pieces != 0;   // (launch-uniform)
+    uint32_t gpoff = kOutOfRange;
+    int gpdst[4] = {-1, -1, -1, -1};
+    if constexpr (GO_NCHW && ES == 4) {
+        const int ch = q / kGPC, pi = q - ch * kGPC;
+        const int cstart = w0 - kR - LW;                       // grad_out column of ring pixel 0
+        const int e0 = ((cstart >> 2) + pi) * 4;               // ... of this piece's first element (floor: cstart may be negative)
+        const bool ok = q < CB * kGPC && e0 >= 0 && e0 < OW && c0 + ch < C;
+        gpoff = ok ? (static_cast<uint32_t>(c0 + ch) * OH * OW + e0) * ES : kOutOfRange;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int pxj = e0 + j - cstart;
+            gpdst[j] = (q < CB * kGPC && pxj >= 0 && pxj < kBPW) ? pxj * (PITCHG * 4) + ch * ES : -1;
         }
     }
     const uint32_t grow_bytes = static_cast<uint32_t>(OW) * (GO_NCHW ? 1 : C) * ES;
@@ -512,10 +533,14 @@ __global__ __launch_bounds__(kThreads) void cl_tiled_backward(const ClTiledBwdPa
         const int unwanted_g = unwanted | ((y - LH) >> 31) | ((LH + OH - 1 - y) >> 31);   // grad_out's row y - LH
         const uint32_t sg = static_cast<uint32_t>((y - LH) & ~unwanted_g) * grow_bytes, dead_g = static_cast<uint32_t>(unwanted_g) & kOutOfRange;
         if constexpr (GO_NCHW) {
+            if (g_pieces) {
+                vg.v = __builtin_amdgcn_raw_buffer_load_b128(gres, gpoff | dead_g, sg, 0);
+            } else {
 #pragma unroll
-            for (int k = 0; k < kGN; ++k) {
-                if constexpr (ES == 4) vg.e[k] = __builtin_amdgcn_raw_buffer_load_b32(gres, goff[k] | dead_g, sg, 0);
-                else vg.e[k] = __builtin_amdgcn_raw_buffer_load_b16(gres, goff[k] | dead_g, sg, 0);
+                for (int k = 0; k < kGN; ++k) {
+                    if constexpr (ES == 4) vg.e[k] = __builtin_amdgcn_raw_buffer_load_b32(gres, goff[k] | dead_g, sg, 0);
+                    else vg.e[k] = __builtin_amdgcn_raw_buffer_load_b16(gres, goff[k] | dead_g, sg, 0);
+                }
             }
         } else {
             vg.v = __builtin_amdgcn_raw_buffer_load_b128(gres, poffg | dead_g, sg, 0);
@@ -523,28 +548,26 @@ __global__ __launch_bounds__(kThreads) void cl_tiled_backward(const ClTiledBwdPa
     };
     auto store_row = [&](int y, const u4 &vx, const GRow &vg) {
         const int slot = y & (kBRing - 1);
-        uint32_t *dx = ring + (pdst >= 0 ? slot * BROW + pdst : kDump);
-        if constexpr (PITCH % 4 == 0) {   // 16-byte aligned pieces: one ds_write_b128, the 8 pieces of a pixel cover all banks
-            *reinterpret_cast<u4 *>(__builtin_assume_aligned(dx, 16)) = vx;
-        } else {
-            dx[0] = vx.x; dx[1] = vx.y; dx[2] = vx.z; dx[3] = vx.w;
-        }
+        uint32_t *dx = ring + (pdst >= 0 ? slot * BROWX + pdst : kDump);
+        *reinterpret_cast<u4 *>(__builtin_assume_aligned(dx, 16)) = vx;   // 16-byte aligned pieces: one ds_write_b128, the 8 pieces of a pixel cover all banks
         if constexpr (GO_NCHW) {
-            char *gbase = reinterpret_cast<char *>(ring) + (BRING + slot * BROW) * 4;
+            char *gbase = reinterpret_cast<char *>(ring) + (BRINGX + slot * BROWG) * 4;
             char *dump = reinterpret_cast<char *>(ring) + kDump * 4;
+            if (g_pieces) {
+                const uint32_t ge[4] = {vg.v.x, vg.v.y, vg.v.z, vg.v.w};
 #pragma unroll
-            for (int k = 0; k < kGN; ++k) {
-                char *d = gdst[k] >= 0 ? gbase + gdst[k] : dump;
-                if constexpr (ES == 4) *reinterpret_cast<uint32_t *>(d) = vg.e[k];
-                else *reinterpret_cast<uint16_t *>(d) = static_cast<uint16_t>(vg.e[k]);
+                for (int j = 0; j < 4; ++j) *reinterpret_cast<uint32_t *>(gpdst[j] >= 0 ? gbase + gpdst[j] : dump) = ge[j];
+            } else {
+#pragma unroll
+                for (int k = 0; k < kGN; ++k) {
+                    char *d = gdst[k] >= 0 ? gbase + gdst[k] : dump;
+                    if constexpr (ES == 4) *reinterpret_cast<uint32_t *>(d) = vg.e[k];
+                    else *reinterpret_cast<uint16_t *>(d) = static_cast<uint16_t>(vg.e[k]);
+                }
             }
         } else {
-            uint32_t *dg = ring + (pdst >= 0 ? BRING + slot * BROW + pdst : kDump);
-            if constexpr (PITCH % 4 == 0) {
-                *reinterpret_cast<u4 *>(__builtin_assume_aligned(dg, 16)) = vg.v;
-            } else {
-                dg[0] = vg.v.x; dg[1] = vg.v.y; dg[2] = vg.v.z; dg[3] = vg.v.w;
-            }
+            uint32_t *dg = ring + (pdst >= 0 ? BRINGX + slot * BROWG + pdst : kDump);
+            *reinterpret_cast<u4 *>(__builtin_assume_aligned(dg, 16)) = vg.v;
         }
     };
     const int ylast = min(H - 1, h1 + kR);
@@ -601,12 +624,12 @@ __global__ __launch_bounds__(kThreads) void cl_tiled_backward(const ClTiledBwdPa
         scol[i] = near_c && w0 + col < W && (outside(a0) || outside(a1) || outside(b0) || outside(b1));
         live[i] = near_c && w0 + col < W && !scol[i];
         lcount[i] = (live[i] && cpass[i]) ? -1 : 0;
-        auto lds_col = [&](int sx) { return (live[i] && sx >= 0) ? (sx - (w0 - kR)) * (PITCH * 4) + lane_a * ES : kNeg; };
-        xc0[i] = lds_col(a0);
-        xc1[i] = lds_col(a1);
-        gc0[i] = lds_col(b0);
-        gc1[i] = lds_col(b1);
-        gd[i] = (col + kR) * (PITCH * 4) + lane_a * ES;
+        auto lds_col = [&](int sx, int pitch) { return (live[i] && sx >= 0) ? (sx - (w0 - kR)) * (pitch * 4) + lane_a * ES : kNeg; };
+        xc0[i] = lds_col(a0, PITCHX);
+        xc1[i] = lds_col(a1, PITCHX);
+        gc0[i] = lds_col(b0, PITCHG);
+        gc1[i] = lds_col(b1, PITCHG);
+        gd[i] = (col + kR) * (PITCHG * 4) + lane_a * ES;
         ooff[i] = live[i] ? (static_cast<uint32_t>(h0 * W + w0 + col) * C + c) * ES : kOutOfRange;
     }
     const uint32_t ostep = static_cast<uint32_t>(W) * C * ES;
@@ -617,13 +640,14 @@ __global__ __launch_bounds__(kThreads) void cl_tiled_backward(const ClTiledBwdPa
         if (y >= 0 && y < H) store_row(y, prex[r], preg[r]);
     }
     const char *ringz = reinterpret_cast<const char *>(ring_all);   // byte 0: the zero words
-    constexpr int ringx = 16, ringg = 16 + BRING * 4;          // the rings, bytes from ringz
+    constexpr int ringx = 16, ringg = 16 + BRINGX * 4;         // the rings, bytes from ringz
     double acc[2] = {0.0, 0.0};
     auto lds_s = [&](int base, int row, int colo) {   // a staged element (storage type); padding (a negative offset) reads a zero word
         return *reinterpret_cast<const S *>(ringz + max(base + row + colo, 0));
     };
     auto lds_f = [&](int base, int row, int colo) { return widen<T>(lds_s(base, row, colo)); };
-    auto row_off = [&](int sy) { return ((sy & (kBRing - 1)) * (BROW * 4)) | ((sy >> 31) & kNeg); };   // (a negative row: padding)
+    auto row_off = [&](int sy) { return ((sy & (kBRing - 1)) * (BROWX * 4)) | ((sy >> 31) & kNeg); };   // (a negative row: padding)
+    auto row_off_g = [&](int sy) { return ((sy & (kBRing - 1)) * (BROWG * 4)) | ((sy >> 31) & kNeg); };
     // Source rows with ONE fold of the signed shift (|shift| <= R and H >= 5, or H == 1: the host routes nothing else
     // here): idx in [h - R, h + R + 1] leaves [0, H) by at most R + 1 on one side.  Launch-uniform coefficients instead of
     // fold_index's switch: r = idx inside, aLo - m idx below, aHi - m idx above (border: m = 0; reflect / symmetric:
@@ -667,13 +691,13 @@ __global__ __launch_bounds__(kThreads) void cl_tiled_backward(const ClTiledBwdPa
         const bool rpass = h >= LH && h < LH + OH;   // the row lies in the window (else: zero gradient, nothing counted)
         int gr0, gr1 = kNeg;
         if constexpr (ACTIVE) {
-            gr0 = rpass ? row_off(grow1) : kNeg;
+            gr0 = rpass ? row_off_g(grow1) : kNeg;
             grow1 = fold1g(h + 1 - LH - gh_s);
-            gr1 = rpass ? row_off(grow1) : kNeg;
+            gr1 = rpass ? row_off_g(grow1) : kNeg;
         } else {
-            gr0 = rpass ? row_off(fold1g(h - LH - gh_s)) : kNeg;
+            gr0 = rpass ? row_off_g(fold1g(h - LH - gh_s)) : kNeg;
         }
-        const int gdr = (h & (kBRing - 1)) * (BROW * 4);
+        const int gdr = (h & (kBRing - 1)) * (BROWG * 4);
         int skip = 0;   // -1: this thread leaves the row to the element pass (launch-uniform guards: one padding mode each)
         if (p.pad == 3) skip = ((srow && h == H - 1) || (srow_g && h == LH + OH - 1)) ? -1 : 0;
         else if (p.pad == 2) skip = wraps(h) ? -1 : 0;
@@ -1371,6 +1395,7 @@ int cl_tiled_backward(const Geometry &g, int dtype, const void *go, const void *
     p.LW = static_cast<int>(g.L[2]);
     p.pad = g.pad;
     p.go_nchw = dense_channels_last_2d(g.os, g, g.O) ? 0 : 1;   // (a tensor that is both -- C == 1 -- reads the same either way)
+    p.go_pieces = (p.go_nchw && (g.O[2] * dtype_size(dtype)) % 16 == 0 && reinterpret_cast<uintptr_t>(go) % 16 == 0) ? 1 : 0;
     p.wtiles = pl.wtiles;
     p.cblocks = pl.cblocks;
     p.bands = pl.bands;

@@ -425,7 +425,8 @@ def test_tiled_channels_last_backward_vs_oracle(shape):
 
 CL_CROPS_BWD = [((2, 8, 9, 12), [[1, 1], [1, 1]]), ((3, 300, 8, 5), [[0, 2], [1, 0]]), ((2, 64, 40, 70), [[1, 1], [1, 1]]),
                 ((1, 36, 100, 33), [[7, 30], [0, 5]]), ((2, 4, 12, 50), [[6, 0], [3, 3]]), ((1, 32, 64, 9), [[0, 0], [4, 4]]),
-                ((2, 16, 33, 40), [[5, 3], [2, 6]]), ((1, 8, 7, 21), [[3, 3], [0, 20]]), ((2, 12, 30, 16), [[0, 25], [15, 0]])]
+                ((2, 16, 33, 40), [[5, 3], [2, 6]]), ((1, 8, 7, 21), [[3, 3], [0, 20]]), ((2, 12, 30, 16), [[0, 25], [15, 0]]),
+                ((2, 8, 12, 44), [[1, 1], [3, 5]])]   # (a window of 36 columns at column 3: NCHW gradient rows of whole pieces)
 
 
 @pytest.mark.parametrize("go_layout", ["cl", "nchw"])
@@ -486,7 +487,8 @@ def test_tiled_channels_last_cropped_backward_vs_oracle(shape, crop, go_layout):
         abi.set_tuning(21, 0)
 
 
-@pytest.mark.parametrize("shape", [(2, 8, 9, 12), (3, 300, 6, 5), (2, 64, 40, 70), (1, 36, 100, 33), (2, 4, 1, 50), (1, 32, 64, 1)])
+@pytest.mark.parametrize("shape", [(2, 8, 9, 12), (3, 300, 6, 5), (2, 64, 40, 70), (1, 36, 100, 33), (2, 4, 1, 50), (1, 32, 64, 1),
+                                   (2, 64, 40, 72), (1, 36, 21, 36), (2, 12, 9, 16)])   # (rows of whole 16-byte pieces: the piece staging)
 def test_tiled_backward_nchw_gradient_vs_oracle(shape):
     """cl_tiled_backward<GO_NCHW>: saved input channels-last, incoming gradient NCHW-contiguous (what an op downstream of
     the reference's float forward returns, cpu/shifts_cpu.cpp:221), grad_x in the input's layout -- one pass, no transpose.

@@ -79,18 +79,64 @@ template <typename T> __device__ __forceinline__ float half_value(uint32_t dword
 template <int NA> struct WalkWindow {
     uint32_t at[NA];   // byte offsets within the tile, row 0 of the thread (row 1: + row pitch)
     bool plain;        // the window is 5 consecutive dwords
+    // paddings 1 .. 4, |shift| <= 1 (launch-uniform `small`: the common case -- weights start in (-1, 1)): the window is read as
+    // it lies between the row's ZERO guards and at most two elements from beyond the row's end are or-ed in: window element 0
+    // (left end) or elements 7 and 8 (right end), each the folded column's element replicated into both halves and masked into
+    // dword 0, 3 or 4.  No thread-dependent branch: without this every wave (each holds some row-end chunks) ran the 9-address
+    // gather path beside the plain one -- 3 x the LDS instructions and 2 x the scalar ones of the zeros-padding kernel.
+    // (Measured and dropped: two more launch-uniform modes for |shift| <= 7 -- border: one edge element and five dword masks;
+    //  periodic: a second plain window one row length away -- took the kernel from 127 to 187 VGPRs, two waves per SIMD.)
+    bool small;
+    uint32_t fix_at[NA > 5 ? 2 : 1];      // byte offset (row 0) of the source element; the zero margin when there is none
+    uint32_t fix_m[NA > 5 ? 2 : 1][3];    // its mask in dwords 0, 3, 4 of the window
 };
 
 template <bool ZEROS, int NA>
-__device__ __forceinline__ WalkWindow<NA> walk_window(int ji, int cs, int S2, int pad, int slot0, bool live) {
+__device__ __forceinline__ WalkWindow<NA> walk_window(int ji, int cs, int S2, int pad, int slot0, bool live, bool small) {
     WalkWindow<NA> w;
     w.plain = true;
+    w.small = !ZEROS && small;
     int D = 0;   // the margin: zeros
+    const int first = ji - cs;   // column of window element 0
     if constexpr (ZEROS) {
-        const int first = ji - cs;   // column of window element 0
         if (live && first + 8 >= 0 && first < S2) D = slot0 * 4 + ((first * 2) >> 2);   // (floor: first >= -8)
 #pragma unroll
         for (int i = 0; i < NA; ++i) w.at[i] = walk_dword_at(D + i);
+    } else if (small) {   // (uniform; cs is the SIGNED shift here, |cs| <= 1, and the row has at least two chunks)
+        if (live) D = slot0 * 4 + ((first * 2) >> 2);
+#pragma unroll
+        for (int i = 0; i < NA; ++i) w.at[i] = walk_dword_at(D + (i < 5 ? i : 4));
+        const int par = first & 1;
+        int nf = 0;
+        w.fix_at[0] = w.fix_at[1] = 0u;
+#pragma unroll
+        for (int f = 0; f < 2; ++f)
+#pragma unroll
+            for (int d = 0; d < 3; ++d) w.fix_m[f][d] = 0u;
+        const int ks[3] = {0, 7, 8};
+#pragma unroll
+        for (int t = 0; t < 3; ++t) {
+            const int col = first + ks[t];
+            if (live && (col < 0 || col >= S2)) {
+                const int hpos = ks[t] + par, dw = hpos >> 1;   // dword 0, 3 or 4
+                const uint32_t m = (hpos & 1) ? 0xffff0000u : 0x0000ffffu;
+                const uint32_t at = walk_elem_at(slot0, fold_index(col, S2, pad));
+                const int d = dw == 0 ? 0 : dw - 2;
+                // (static indexing: at most two of the three candidates are beyond the row)
+                if (nf == 0) {
+                    w.fix_at[0] = at;
+                    w.fix_m[0][0] = d == 0 ? m : 0u;
+                    w.fix_m[0][1] = d == 1 ? m : 0u;
+                    w.fix_m[0][2] = d == 2 ? m : 0u;
+                } else {
+                    w.fix_at[1] = at;
+                    w.fix_m[1][0] = d == 0 ? m : 0u;
+                    w.fix_m[1][1] = d == 1 ? m : 0u;
+                    w.fix_m[1][2] = d == 2 ? m : 0u;
+                }
+                ++nf;
+            }
+        }
     } else {
         int cm[9];
         bool run = true;
@@ -115,6 +161,21 @@ __device__ __forceinline__ WalkWindow<NA> walk_window(int ji, int cs, int S2, in
 // the 5 dwords of a window: half (k + PAR) of the result is window element k
 template <bool ZEROS, int NA, int PAR>
 __device__ __forceinline__ void walk_read(const char *tile, const WalkWindow<NA> &w, uint32_t row_off, uint32_t (&o)[5]) {
+    if constexpr (!ZEROS) {
+        if (w.small) {   // (uniform)
+#pragma unroll
+            for (int i = 0; i < 5; ++i) o[i] = *reinterpret_cast<const uint32_t *>(tile + w.at[i] + row_off);
+#pragma unroll
+            for (int f = 0; f < 2; ++f) {
+                const uint32_t e = *reinterpret_cast<const uint16_t *>(tile + w.fix_at[f] + row_off);
+                const uint32_t ee = e | (e << 16);
+                o[0] |= ee & w.fix_m[f][0];
+                o[3] |= ee & w.fix_m[f][1];
+                o[4] |= ee & w.fix_m[f][2];
+            }
+            return;
+        }
+    }
     if (ZEROS || w.plain) {
 #pragma unroll
         for (int i = 0; i < 5; ++i) o[i] = *reinterpret_cast<const uint32_t *>(tile + w.at[i] + row_off);
@@ -208,10 +269,14 @@ __global__ __launch_bounds__(kThreads) void walk_backward16(const StepParams p) 
     const bool mine = tr < R && tr < Rn;
     const int b = b0 + tr;
     const int slot0 = kWalkMargin + tr * RP;
-    const WalkWindow<NA> wx = walk_window<ZEROS, NA>(ji, d.cx2, S2, pad, slot0, mine);
-    const WalkWindow<NA> wg = walk_window<ZEROS, NA>(ji, d.cg2, S2, pad, slot0, mine);
+    // (the signed column shifts; |shift| <= 1 and at least two chunks per row: the fix-up reader, see WalkWindow)
+    const int per2 = map_period(S2, pad);
+    const int sx2 = (!ZEROS && per2 && 2 * d.cx2 > per2) ? d.cx2 - per2 : d.cx2, sg2 = (!ZEROS && per2 && 2 * d.cg2 > per2) ? d.cg2 - per2 : d.cg2;
+    const bool small_x = !ZEROS && cpr >= 2 && sx2 >= -1 && sx2 <= 1, small_g = !ZEROS && cpr >= 2 && sg2 >= -1 && sg2 <= 1;
+    const WalkWindow<NA> wx = walk_window<ZEROS, NA>(ji, small_x ? sx2 : d.cx2, S2, pad, slot0, mine, small_x);
+    const WalkWindow<NA> wg = walk_window<ZEROS, NA>(ji, small_g ? sg2 : d.cg2, S2, pad, slot0, mine, small_g);
     const uint32_t row1 = static_cast<uint32_t>(RP) * 4u;
-    const int px = d.cx2 & 1, pg = d.cg2 & 1;   // half-word parity of the windows (uniform: rows are whole pieces)
+    const int px = (small_x ? sx2 : d.cx2) & 1, pg = (small_g ? sg2 : d.cg2) & 1;   // half-word parity of the windows (uniform: rows are whole pieces)
     const float dP = static_cast<float>(d.dw[0]), dR = static_cast<float>(d.dw[1]), dC = static_cast<float>(d.dw[2]);
     const uint32_t my = mine ? static_cast<uint32_t>(b * S2 + ji) * 2u : kOOR;   // own chunk, bytes within a plane
     auto load_own = [&](int a, bool have) {
@@ -443,9 +508,12 @@ __global__ __launch_bounds__(kThreads) void walk_forward16(const FwdParams p) {
     };
     const bool mine = tr < R && tr < Rn;
     const int slot0 = kWalkMargin + tr * RP;
-    const WalkWindow<NA> wx = walk_window<ZEROS, NA>(ji, cs2, S2, pad, slot0, mine);
+    const int per2 = map_period(S2, pad);
+    const int ss2 = (!ZEROS && per2 && 2 * cs2 > per2) ? cs2 - per2 : cs2;   // the signed column shift
+    const bool small_x = !ZEROS && cpr >= 2 && ss2 >= -1 && ss2 <= 1;
+    const WalkWindow<NA> wx = walk_window<ZEROS, NA>(ji, small_x ? ss2 : cs2, S2, pad, slot0, mine, small_x);
     const uint32_t row1 = static_cast<uint32_t>(RP) * 4u;
-    const int px = cs2 & 1;
+    const int px = (small_x ? ss2 : cs2) & 1;
     const uint32_t my = mine ? static_cast<uint32_t>((b0 + tr) * S2 + ji) * 2u : kOOR;
     auto lerp = [](float v1, float v2, float x) { return lerp1_fused<float>(v1, v2, x); };
     auto plane_blend = [&](auto par_tag, float (&B)[E]) {

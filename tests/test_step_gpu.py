@@ -369,6 +369,42 @@ def test_3d_walk_backward_vs_oracle(abi, shape, dt):
             assert rel_err(gw.to(torch.float64).cpu().numpy(), gw64) < tol, ("gw", shape, dt, pad, active)
 
 
+@pytest.mark.parametrize("dt", ["f16", "bf16"])
+@pytest.mark.parametrize("shape", [(2, 6, 5, 6, 16), (1, 8, 3, 9, 64), (2, 4, 4, 40, 112), (1, 5, 2, 3, 8), (2, 160, 5, 48, 112)])
+def test_3d_walk_small_shifts_vs_oracle(abi, shape, dt):
+    """The fix-up window reader of the generic-padding walk kernels (shiftnd_walk.hip, WalkWindow::small: |column shift| <= 1 --
+    weights as the reference initialises them, uniform in (-1, 1), plus exact -1 / 0 / 1 and one channel beyond 1 that keeps the
+    gather path): paddings 1 .. 4, forward and both backwards; rows of one chunk (no fix-up reader), two chunks, many; 960
+    workgroups.  16-bit interpolation within 1 ulp, the sparse shift bit-exact, grad_w within half an ulp of the largest entry"""
+    tdt = {"f16": torch.float16, "bf16": torch.bfloat16}[dt]
+    rs = np.random.RandomState(sum(shape) * 3 + 11)
+    C = shape[1]
+    w = rs.uniform(-0.999, 0.999, size=(C, 3))
+    w[0] = [1.0, -1.0, 1.0]
+    w[1] = [0.0, 0.5, -1.0]
+    w[2] = [-0.75, 1.0, 0.0]
+    w[3] = [0.25, -0.5, 2.5]   # beyond 1: this channel's workgroups keep the gather path
+    xt = torch.from_numpy(rs.uniform(-1, 1, size=shape)).to(tdt)
+    gt = torch.from_numpy(rs.uniform(-1, 1, size=shape)).to(tdt)
+    wt = torch.from_numpy(w).to(tdt)
+    x, go, wn = (t.float().numpy() for t in (xt, gt, wt))
+    xd, god, wd = xt.to(DEV), gt.to(DEV), wt.to(DEV)
+    for pad in (1, 2, 3, 4):
+        out = abi.forward(xd, wd, pad, 1)
+        assert abi.last_kernel() == "walk_forward16", abi.last_kernel()
+        assert _ulp_close(out.cpu(), torch.from_numpy(O.forward(x, wn, pad, 1)).to(tdt), tdt, FLOOR16), ("fwd", shape, dt, pad)
+        for active in (1, 0):
+            gx, gw = abi.backward(god, wd, xd, pad, active)
+            assert abi.last_kernel() == "walk_backward16" + ("" if active else "_sparse"), abi.last_kernel()
+            gx_ref = torch.from_numpy(O.backward(go, wn, x, pad, active)[0]).to(tdt)
+            if active:
+                assert _ulp_close(gx.cpu(), gx_ref, tdt, FLOOR16), ("gx", shape, dt, pad)
+            else:
+                assert torch.equal(gx.cpu(), gx_ref), ("gx sparse", shape, dt, pad)
+            _, gw64 = O.backward(go.astype(np.float64), wn.astype(np.float64), x.astype(np.float64), pad, active)
+            assert rel_err(gw.to(torch.float64).cpu().numpy(), gw64) < gw16_tol(torch.finfo(tdt).eps), ("gw", shape, dt, pad, active)
+
+
 @pytest.mark.parametrize("dt", ["f32", "f64", "i32"])
 @pytest.mark.parametrize("shape,crop", [((2, 3, 5, 6, 16), None), ((1, 2, 4, 40, 112), None), ((2, 2, 6, 9, 32), [[1, 0], [0, 2], [4, 8]]),
                                         ((1, 3, 1, 5, 8), None), ((1, 2, 3, 1, 1024), None)])

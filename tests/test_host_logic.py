@@ -44,3 +44,24 @@ def test_workspace_query_tiny_shapes():
                 for active in (0, 1):
                     ws = abi.backward_workspace(x, pad, active)
                     assert ws.numel() >= shape[0] * shape[1] * 3 * 8 // 8  # at least one group of partial sums
+
+
+def test_no_kernel_of_the_built_library_uses_scratch():
+    """build() refuses to link when a kernel needs a private segment (tools/kernel_resources.py over the AMDGPU metadata notes of
+    every code object); this test repeats the check on the objects that are there and pins the tool itself: it must find the
+    library's kernels (more than a thousand) and report the resources of a known one"""
+    import glob
+    import importlib.util
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    objs = sorted(glob.glob(os.path.join(root, "activesparseshifts-pytorch_amd", "build", "*.hip.o")))
+    if not objs:
+        import pytest
+        pytest.skip("no built objects (run __graft_entry__.build() first)")
+    spec = importlib.util.spec_from_file_location("kernel_resources", os.path.join(root, "tools", "kernel_resources.py"))
+    kr = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(kr)
+    assert kr.check_no_scratch(objs) == []
+    rows = kr.collect(objs)
+    assert len(rows) > 1000
+    assert any("walk_backward16" in r["demangled"] for r in rows)

@@ -9,6 +9,8 @@
 //
 // Reference behaviour restated: kernels/shifts_kernels.h:532-571 (quantized shift: shift = int_repr(w) - w.zero_point,
 // fill = x.zero_point); the pool is ATen's.  Roofline: HBM, (1 + 1 / window) bytes per element.
+#include <type_traits>
+
 #include "shiftnd_common.hpp"
 #include "shiftnd_launch.hpp"
 
@@ -463,8 +465,176 @@ __global__ __launch_bounds__(kThreads) void qpool_band_forward(const QBandParams
     }
 }
 
+// qpool_band_fast (round 4): the band kernel's inner loop by DWORDS for the common case -- zeros padding, windows two columns wide
+// (1 x 2, 2 x 2), output rows of whole windows.  The 8 source bytes of an item's 4 pooled elements are contiguous in the staged
+// row whatever the shift, and with 16 zero-point bytes in front of every staged row and 32 behind it the columns the zero padding
+// fills need no test either: three aligned ds_read_b32 and two v_alignbyte per row, then one v_dot4 per row and pooled element
+// (dot4 of the bytes with 0x00000101 / 0x01010000 = the sum of a byte pair) -- ~45 vector + 6 LDS instructions per item instead of
+// ~86 + 16.  A channel whose column shift is beyond +-8 (uniform per workgroup) sums byte by byte.
+template <typename EL, int K1, int NI>
+__global__ __launch_bounds__(kThreads) void qpool_band_fast(const QBandParams p) {
+    constexpr int K2 = 2, KV = K1 * K2, kPadL = 16;
+    typedef uint32_t u4 __attribute__((ext_vector_type(4)));
+    extern __shared__ __attribute__((aligned(16))) unsigned char q_lds[];
+    const int t = static_cast<int>(threadIdx.x);
+    uint32_t b = blockIdx.x;
+    const int c = static_cast<int>(b - fdiv(b, p.d_C) * static_cast<uint32_t>(p.C));
+    b = fdiv(b, p.d_C);
+    const int band = static_cast<int>(b - fdiv(b, p.d_nbands) * static_cast<uint32_t>(p.nbands));
+    const int ng = static_cast<int>(fdiv(b, p.d_nbands));
+    const int pb0 = band * p.band, nb = min(p.band, p.P1 - pb0);
+    {   // every byte of the tile is the zero point until a row is staged over it: the pads of the rows, the zero-point row
+        const uint32_t z = static_cast<uint32_t>(p.xzp & 0xff) * 0x01010101u;
+        for (int q = t * 16; q < (p.zrow + 1) * p.pitch; q += kThreads * 16) *reinterpret_cast<u4 *>(__builtin_assume_aligned(q_lds + q, 16)) = u4{z, z, z, z};
+    }
+    int cs1 = 0, cs2 = 0;
+    if (p.wcol1 >= 0) cs1 = canon_shift(gather_shift(p.w, p.wkind, p.wzp, static_cast<int64_t>(c) * p.nd + p.wcol1), p.S1, 0, p.d_per1);
+    if (p.wcol2 >= 0) cs2 = canon_shift(gather_shift(p.w, p.wkind, p.wzp, static_cast<int64_t>(c) * p.nd + p.wcol2), p.S2, 0, p.d_per2);
+    auto src_row = [&](int wrow) { return p.S1 == 1 ? 0 : fold_index(wrow + p.L1 - cs1, p.S1, 0); };
+    const int64_t plane = static_cast<int64_t>(p.S1) * p.S2, pooled = static_cast<int64_t>(p.P1) * p.P2;
+    constexpr int NP = 16;
+    const int npieces = nb * K1 * p.ppr;
+    int soff[NP], doff[NP];
+#pragma unroll
+    for (int k = 0; k < NP; ++k) {
+        const int q = t + k * kThreads;
+        const int slot = static_cast<int>(fdiv(static_cast<uint32_t>(q), p.d_ppr)), pq = q - slot * p.ppr;
+        const int r = q < npieces ? src_row(pb0 * K1 + slot) : -1;
+        soff[k] = r >= 0 ? r * p.S2 + pq * p.vec : -1;
+        doff[k] = slot * p.pitch + kPadL + pq * p.vec;
+    }
+    auto stage = [&](int n) {
+        const unsigned char *xp = p.x + (static_cast<int64_t>(min(n, p.N - 1)) * p.C + c) * plane;
+#pragma unroll
+        for (int k = 0; k < NP; ++k) {
+            if (k * kThreads >= npieces) break;   // (uniform)
+            if (soff[k] < 0) continue;
+            if (p.vec == 16) *reinterpret_cast<u4 *>(__builtin_assume_aligned(q_lds + doff[k], 16)) = *reinterpret_cast<const u4 *>(__builtin_assume_aligned(xp + soff[k], 16));
+            else if (p.vec == 4) *reinterpret_cast<uint32_t *>(q_lds + doff[k]) = *reinterpret_cast<const uint32_t *>(xp + soff[k]);
+            else q_lds[doff[k]] = xp[soff[k]];
+        }
+    };
+    // the next image's first pieces travel while this image is summed (16-byte pieces: registers for four per thread -- 1024 pieces,
+    // a 224 x 224 band; what is beyond them is staged behind the barrier as before)
+    constexpr int NPRE = 4;
+    u4 pre[NPRE];
+    const bool prefetch = p.vec == 16;
+    auto load_pre = [&](int n) {
+        const unsigned char *xp = p.x + (static_cast<int64_t>(min(n, p.N - 1)) * p.C + c) * plane;
+#pragma unroll
+        for (int k = 0; k < NPRE; ++k)   // (unconditional: a thread without a piece re-reads byte 0 of the plane and drops it)
+            pre[k] = *reinterpret_cast<const u4 *>(__builtin_assume_aligned(xp + (soff[k] >= 0 ? soff[k] : 0), 16));
+    };
+    auto store_pre = [&]() {
+#pragma unroll
+        for (int k = 0; k < NPRE; ++k)
+            if (soff[k] >= 0) *reinterpret_cast<u4 *>(__builtin_assume_aligned(q_lds + doff[k], 16)) = pre[k];
+    };
+    auto stage_rest = [&](int n) {
+        const unsigned char *xp = p.x + (static_cast<int64_t>(min(n, p.N - 1)) * p.C + c) * plane;
+#pragma unroll
+        for (int k = NPRE; k < NP; ++k) {
+            if (k * kThreads >= npieces) break;   // (uniform)
+            if (soff[k] < 0) continue;
+            *reinterpret_cast<u4 *>(__builtin_assume_aligned(q_lds + doff[k], 16)) = *reinterpret_cast<const u4 *>(__builtin_assume_aligned(xp + soff[k], 16));
+        }
+    };
+    const int n_first = ng * p.rpw;
+    __syncthreads();   // the tile is all zero point
+    stage(n_first);
+
+    int rowoff[NI][K1], coff[NI], obyte[NI], ovalid[NI];
+    float rc[NI];   // (whole windows along the columns: one count per item)
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+        int item = t + i * kThreads;
+        const bool live = item < nb * p.groups;
+        if (!live) item = 0;
+        const int prl = static_cast<int>(fdiv(static_cast<uint32_t>(item), p.d_groups)), cg = item - prl * p.groups;
+        const int p1 = pb0 + prl;
+        const int n1 = min(K1, p.O1 - p1 * K1);
+        obyte[i] = p1 * p.P2 + cg * 4;
+        ovalid[i] = live ? min(4, p.P2 - cg * 4) : 0;
+#pragma unroll
+        for (int bb = 0; bb < K1; ++bb) rowoff[i][bb] = ((bb < n1 && src_row(p1 * K1 + bb) >= 0) ? prl * K1 + bb : p.zrow) * p.pitch;
+        coff[i] = cg * (4 * K2) + p.L2 - cs2;   // source column of the item's first window element
+        const float mult = static_cast<float>(1.0 / static_cast<double>(max(n1, 1) * K2));
+        rc[i] = p.zp_outside ? mult : 1.0f / (1.0f / mult);
+    }
+    const bool near = cs2 >= -8 && cs2 <= 8;   // (uniform: the pads hold what the zero padding fills)
+    const uint32_t sh = static_cast<uint32_t>(p.L2 - cs2) & 3u;   // byte phase of every item's window (uniform)
+    const int zsum = KV * p.xzp;
+    const float zpf = static_cast<float>(p.xzp);
+    const bool dword_out = (p.P2 & 3) == 0 && (pooled & 3) == 0;
+    for (int r = 0; r < p.rpw; ++r) {
+        const int n = n_first + r;
+        if (r > 0) {
+            __syncthreads();
+            if (prefetch) {
+                store_pre();
+                stage_rest(n);
+            } else {
+                stage(n);
+            }
+        }
+        __syncthreads();
+        if (prefetch && r + 1 < p.rpw) load_pre(n + 1);
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            int sums[4] = {0, 0, 0, 0};
+            if (near) {
+#pragma unroll
+                for (int bb = 0; bb < K1; ++bb) {
+                    const uint32_t *dp = reinterpret_cast<const uint32_t *>(q_lds + rowoff[i][bb] + ((kPadL + coff[i]) & ~3));
+                    const uint32_t d0 = dp[0], d1 = dp[1], d2 = dp[2];
+                    const uint32_t a0 = __builtin_amdgcn_alignbyte(d1, d0, sh), a1 = __builtin_amdgcn_alignbyte(d2, d1, sh);
+                    if constexpr (std::is_signed<EL>::value) {
+                        sums[0] = __builtin_amdgcn_sdot4(static_cast<int>(a0), 0x00000101, sums[0], false);
+                        sums[1] = __builtin_amdgcn_sdot4(static_cast<int>(a0), 0x01010000, sums[1], false);
+                        sums[2] = __builtin_amdgcn_sdot4(static_cast<int>(a1), 0x00000101, sums[2], false);
+                        sums[3] = __builtin_amdgcn_sdot4(static_cast<int>(a1), 0x01010000, sums[3], false);
+                    } else {
+                        sums[0] = static_cast<int>(__builtin_amdgcn_udot4(a0, 0x00000101u, static_cast<uint32_t>(sums[0]), false));
+                        sums[1] = static_cast<int>(__builtin_amdgcn_udot4(a0, 0x01010000u, static_cast<uint32_t>(sums[1]), false));
+                        sums[2] = static_cast<int>(__builtin_amdgcn_udot4(a1, 0x00000101u, static_cast<uint32_t>(sums[2]), false));
+                        sums[3] = static_cast<int>(__builtin_amdgcn_udot4(a1, 0x01010000u, static_cast<uint32_t>(sums[3]), false));
+                    }
+                }
+            } else {   // a column shift beyond the pads: byte by byte (zeros padding: a column outside the row is the zero point)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int bb = 0; bb < K1; ++bb)
+#pragma unroll
+                        for (int kk = 0; kk < K2; ++kk) {
+                            const int sc = coff[i] + j * K2 + kk;
+                            const int at = (sc >= 0 && sc < p.S2) ? kPadL + sc : kPadL + p.S2;
+                            sums[j] += static_cast<int>(reinterpret_cast<const EL *>(q_lds)[rowoff[i][bb] + at]);
+                        }
+            }
+            int qv[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float prod = __fmul_rn(static_cast<float>(sums[j] - zsum), rc[i]);   // (ATen's two roundings: qpool_plane_forward)
+                qv[j] = p.zp_outside ? static_cast<int>(nearbyintf(prod)) + p.xzp : static_cast<int>(nearbyintf(__fadd_rn(zpf, prod)));
+            }
+            if (ovalid[i] > 0 && n < p.N) {
+                uint8_t *o = p.out + (static_cast<int64_t>(n) * p.C + c) * pooled + obyte[i];
+                if (ovalid[i] == 4 && dword_out) {
+                    const uint32_t lo = __builtin_amdgcn_perm(static_cast<uint32_t>(qv[1]), static_cast<uint32_t>(qv[0]), 0x0c0c0400u);
+                    const uint32_t hi = __builtin_amdgcn_perm(static_cast<uint32_t>(qv[3]), static_cast<uint32_t>(qv[2]), 0x04000c0cu);
+                    *reinterpret_cast<uint32_t *>(o) = lo | hi;
+                } else {
+                    for (int j = 0; j < ovalid[i]; ++j) o[j] = static_cast<uint8_t>(qv[j]);
+                }
+            }
+        }
+    }
+}
+
 struct QBandPlan {
     bool ok = false;
+    bool fast = false;   // qpool_band_fast: zeros padding, windows two columns wide, output rows of whole windows
     int KV = 0, NI = 0, band = 0, nbands = 0, groups = 0, rpw = 0, ngroups = 0, vec = 0, ppr = 0, pitch = 0, lds = 0;
 };
 
@@ -480,7 +650,8 @@ QBandPlan qband_plan(const Geometry &g, const void *x) {
     if (q.groups > q.NI * kThreads) return q;
     q.vec = (g.S[2] % 16 == 0 && reinterpret_cast<uintptr_t>(x) % 16 == 0) ? 16 : ((g.S[2] % 4 == 0 && reinterpret_cast<uintptr_t>(x) % 4 == 0) ? 4 : 1);
     q.ppr = static_cast<int>(g.S[2] / q.vec);
-    q.pitch = static_cast<int>(((g.S[2] + 1 + 15) / 16) * 16);
+    q.fast = g.pad == 0 && k2 == 2 && g.O[2] % 2 == 0;
+    q.pitch = q.fast ? static_cast<int>(((16 + g.S[2] + 32 + 15) / 16) * 16) : static_cast<int>(((g.S[2] + 1 + 15) / 16) * 16);
     int64_t band = std::min<int64_t>(g.P[1], (q.NI * kThreads) / q.groups);
     // the staged rows (+ the row of zero points): at most 16 pieces per thread and 60 KB of LDS
     while (band > 1 && (band * k1 * q.ppr > 16 * kThreads || (band * k1 + 1) * q.pitch > 60 * 1024)) --band;
@@ -499,6 +670,11 @@ QBandPlan qband_plan(const Geometry &g, const void *x) {
 
 template <typename EL> void launch_qband(const QBandPlan &q, const QBandParams &p, hipStream_t st) {
     const dim3 grid(static_cast<unsigned>(q.ngroups) * static_cast<unsigned>(p.nbands) * static_cast<unsigned>(p.C)), block(kThreads);
+    if (q.fast) {
+        if (q.KV == 4) hipLaunchKernelGGL((qpool_band_fast<EL, 2, 4>), grid, block, q.lds, st, p);
+        else hipLaunchKernelGGL((qpool_band_fast<EL, 1, 4>), grid, block, q.lds, st, p);
+        return;
+    }
     switch (q.KV) {
     case 2: hipLaunchKernelGGL((qpool_band_forward<EL, 2, 4>), grid, block, q.lds, st, p); break;
     case 3: hipLaunchKernelGGL((qpool_band_forward<EL, 3, 4>), grid, block, q.lds, st, p); break;
@@ -606,7 +782,7 @@ int qpool_forward(const Geometry &g, int dtype, const void *x, const void *w, in
         p.d_nbands = make_fastdiv(static_cast<uint32_t>(qb.nbands));
         p.d_per1 = make_fastdiv(static_cast<uint32_t>(map_period(p.S1, g.pad)));
         p.d_per2 = make_fastdiv(static_cast<uint32_t>(map_period(p.S2, g.pad)));
-        note_kernel("qpool_band_forward");
+        note_kernel(qb.fast ? "qpool_band_fast" : "qpool_band_forward");
         if (dtype == SHIFTND_I8) launch_qband<int8_t>(qb, p, st);
         else launch_qband<uint8_t>(qb, p, st);
         return SHIFTND_OK;

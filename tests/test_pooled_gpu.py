@@ -252,11 +252,11 @@ def test_quantized_pooled_forward_vs_oracle(abi, npdt):
                     out = abi.forward_quantized_pooled(torch.from_numpy(xq).to(DEV), torch.from_numpy(wq).to(DEV), 128, zp, pad, pool,
                                                        b, requant=requant)
                     abi.set_tuning(36, 0)
-                    assert abi.last_kernel() in (("qpool_forward",) if knob else ("qpool_forward", "qpool_plane_forward", "qpool_band_forward"))
+                    assert abi.last_kernel() in (("qpool_forward",) if knob else ("qpool_forward", "qpool_plane_forward", "qpool_band_forward", "qpool_band_fast"))
                     served.add(abi.last_kernel())
                     assert np.array_equal(out.cpu().numpy(), ref), (nd, shape, pool, crop, pad, requant, abi.last_kernel())
     assert differ  # the inputs do separate the two roundings
-    assert served == {"qpool_forward", "qpool_plane_forward", "qpool_band_forward"}
+    assert served == {"qpool_forward", "qpool_plane_forward", "qpool_band_forward", "qpool_band_fast"}
 
 
 @pytest.mark.parametrize("dt", ["f32", "f16", "bf16"])

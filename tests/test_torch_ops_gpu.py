@@ -114,7 +114,7 @@ def test_quantized_module_with_pool_tail_gpu(name, shape):
         xq = torch.quantize_per_tensor(x, 1 / 255. if qdt == torch.quint8 else 1 / 127., zp, qdt)
         ref = q(xq)
         out = q.to(DEV)(xq.to(DEV))
-        assert abi.last_kernel() in ("qpool_forward", "qpool_plane_forward", "qpool_band_forward")  # shift and pool in ONE pass (round 2: six passes of torch ops)
+        assert abi.last_kernel() in ("qpool_forward", "qpool_plane_forward", "qpool_band_forward", "qpool_band_fast")  # shift and pool in ONE pass (round 2: six passes of torch ops)
         assert out.is_cuda and out.is_quantized and out.shape == ref.shape
         assert out.q_zero_point() == ref.q_zero_point() and abs(out.q_scale() - ref.q_scale()) < 1e-12
         assert torch.equal(out.int_repr().cpu(), ref.int_repr()), (name, stride, padding)
@@ -145,7 +145,7 @@ def test_quantized_module_with_pool_tail_gpu(name, shape):
         x1 = torch.quantize_per_tensor(torch.rand((shape[0], 1) + tuple(shape[2:])), 1 / 255., zp, torch.quint8)
         ref_1 = q1.cpu()(x1)
         out_1 = q1.to(DEV)(x1.to(DEV))
-        assert abi.last_kernel() in ("qpool_forward", "qpool_plane_forward", "qpool_band_forward")
+        assert abi.last_kernel() in ("qpool_forward", "qpool_plane_forward", "qpool_band_forward", "qpool_band_fast")
         assert torch.equal(out_1.int_repr().cpu(), ref_1.int_repr()), (name, "one channel", zp)
 
 

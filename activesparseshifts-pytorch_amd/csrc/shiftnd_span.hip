@@ -607,31 +607,34 @@ __global__ __launch_bounds__(kThreads) void crop_forward(const SpanFwdParams p) 
     // wave alone, one boundary per lane, element by element (clamped reads, then one select each).  Inside the chunk loop
     // above they cost every wave the whole element-by-element path: almost every wave of 64 chunks holds one (c2acrop: 258 ->
     // ~120 vector instructions per wave).
+    // (A step of 256 chunks spans more than 64 row boundaries when the window's rows are shorter than 4 chunks -- 130 x 12
+    // fp32 cut to 128 x 10 has 102 -- so the lanes loop over them.)
     if (wave != 0) return;
-    const int rb = r0 + 1 + tid;   // the boundary between output rows rb - 1 and rb
-    const uint32_t fb = static_cast<uint32_t>(rb) * static_cast<uint32_t>(O2);   // its first flat element
-    const int qb = static_cast<int>(fb / E);
-    if (rb > r1 || fb % E == 0 || qb < q0 || qb >= q1) return;
-    Chunk<S, E> res;
-    const int eb = qb * E;
+    for (int rb = r0 + 1 + tid; rb <= r1; rb += 64) {   // the boundary between output rows rb - 1 and rb
+        const uint32_t fb = static_cast<uint32_t>(rb) * static_cast<uint32_t>(O2);   // its first flat element
+        const int qb = static_cast<int>(fb / E);
+        if (fb % E == 0 || qb < q0 || qb >= q1) continue;
+        Chunk<S, E> res;
+        const int eb = qb * E;
 #pragma unroll
-    for (int e = 0; e < E; ++e) {
-        const int re = static_cast<int>(fdiv(static_cast<uint32_t>(eb + e), p.d_O2));
-        const int slot = re - r0, je = eb + e - re * O2;
-        const int m0 = row_map_t<PAD>(je + L2, cs2, S2);
-        auto at = [&](int sl, int m) {
-            const S v = reinterpret_cast<const S *>(tile + sl * RB)[m > 0 ? m : 0];
-            return (m >= 0 && row_ok(sl)) ? v : zero;
-        };
-        if constexpr (ACTIVE) {
-            const int m1 = row_map_t<PAD>(je + L2 + 1, cs2, S2);
-            const CT v[4] = {widen<T>(at(slot, m0)), widen<T>(at(slot + 1, m0)), widen<T>(at(slot, m1)), widen<T>(at(slot + 1, m1))};
-            res.e[e] = narrow<T>(interp_t<T, 2>(v, dw));
-        } else {
-            res.e[e] = at(slot, m0);
+        for (int e = 0; e < E; ++e) {
+            const int re = static_cast<int>(fdiv(static_cast<uint32_t>(eb + e), p.d_O2));
+            const int slot = re - r0, je = eb + e - re * O2;
+            const int m0 = row_map_t<PAD>(je + L2, cs2, S2);
+            auto at = [&](int sl, int m) {
+                const S v = reinterpret_cast<const S *>(tile + sl * RB)[m > 0 ? m : 0];
+                return (m >= 0 && row_ok(sl)) ? v : zero;
+            };
+            if constexpr (ACTIVE) {
+                const int m1 = row_map_t<PAD>(je + L2 + 1, cs2, S2);
+                const CT v[4] = {widen<T>(at(slot, m0)), widen<T>(at(slot + 1, m0)), widen<T>(at(slot, m1)), widen<T>(at(slot + 1, m1))};
+                res.e[e] = narrow<T>(interp_t<T, 2>(v, dw));
+            } else {
+                res.e[e] = at(slot, m0);
+            }
         }
+        store_chunk<S, E>(op + eb, res);
     }
-    store_chunk<S, E>(op + eb, res);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------

@@ -33,6 +33,17 @@ class Problem(ctypes.Structure):
 
 _lib = None
 
+# Test aid (tests/conftest.py sets it): outputs this module allocates are filled with a byte pattern before the call, so that an
+# output element no kernel wrote fails a comparison every time instead of only when the allocator hands back dirty memory.
+POISON = False
+
+
+def _new(shape, like):
+    t = torch.empty(list(shape), dtype=like.dtype, device=like.device)
+    if POISON and t.numel():
+        t.view(-1).view(torch.uint8).fill_(0xA5)
+    return t
+
 
 def lib():
     global _lib
@@ -142,7 +153,7 @@ def forward(x, w, pad, active, borders=None, out=None):
     """x, w: device tensors (float dtypes).  Returns a new contiguous output (or fills `out`)."""
     p = problem(x, pad, active, borders)
     if out is None:
-        out = torch.empty(out_shape(x, borders), dtype=x.dtype, device=x.device)
+        out = _new(out_shape(x, borders), x)
     w = w.contiguous()
     check(lib().shiftnd_forward(ctypes.byref(p), x.data_ptr(), strides5(x), w.data_ptr(), out.data_ptr(), strides5(out),
                                 _stream()), "shiftnd_forward")
@@ -158,9 +169,9 @@ def backward(grad_out, w, x, pad, active, borders=None, grad_x=None, grad_w=None
     p = problem(x, pad, active, borders)
     w = w.contiguous()
     if grad_x is None:
-        grad_x = torch.empty_like(x, memory_format=torch.contiguous_format)
+        grad_x = _new(x.shape, x)
     if grad_w is None:
-        grad_w = torch.empty_like(w)
+        grad_w = _new(w.shape, w)
     if workspace is None:
         workspace = backward_workspace(x, pad, active, borders)
     check(lib().shiftnd_backward(ctypes.byref(p), grad_out.data_ptr(), strides5(grad_out), x.data_ptr(), strides5(x),
@@ -173,7 +184,7 @@ def forward_quantized(xq, wq, w_zero_point, x_zero_point, pad, borders=None, out
     """xq: int8/uint8/int32 device tensor (int_repr); wq: int8/uint8/int32 device tensor [C, nd]."""
     p = problem(xq, pad, False, borders)
     if out is None:
-        out = torch.empty(out_shape(xq, borders), dtype=xq.dtype, device=xq.device)
+        out = _new(out_shape(xq, borders), xq)
     wq = wq.contiguous()
     check(lib().shiftnd_forward_quantized(ctypes.byref(p), xq.data_ptr(), strides5(xq), wq.data_ptr(), DTYPES[wq.dtype],
                                           int(w_zero_point), int(x_zero_point), out.data_ptr(), strides5(out), _stream()),
@@ -199,7 +210,7 @@ def forward_pooled(x, w, pad, active, pool, borders=None, out=None):
     assert x.is_contiguous()
     p = problem(x, pad, active, borders)
     if out is None:
-        out = torch.empty(pooled_shape(x, pool, borders), dtype=x.dtype, device=x.device)
+        out = _new(pooled_shape(x, pool, borders), x)
     w = w.contiguous()
     check(lib().shiftnd_forward_pooled(ctypes.byref(p), _pool_arg(pool, p.ndim), x.data_ptr(), w.data_ptr(),
                                        out.data_ptr(), _stream()), "shiftnd_forward_pooled")
@@ -215,7 +226,7 @@ def forward_quantized_pooled(xq, wq, w_zero_point, x_zero_point, pad, pool, bord
     assert xq.is_contiguous()
     p = problem(xq, pad, False, borders)
     if out is None:
-        out = torch.empty(pooled_shape(xq, pool, borders), dtype=xq.dtype, device=xq.device)
+        out = _new(pooled_shape(xq, pool, borders), xq)
     wq = wq.contiguous()
     check(lib().shiftnd_forward_quantized_pooled(ctypes.byref(p), _pool_arg(pool, p.ndim), xq.data_ptr(), wq.data_ptr(),
                                                  DTYPES[wq.dtype], int(w_zero_point), int(x_zero_point), int(requant), out.data_ptr(),
@@ -228,9 +239,9 @@ def backward_pooled(grad_pooled, w, x, pad, active, pool, borders=None, grad_x=N
     p = problem(x, pad, active, borders)
     w = w.contiguous()
     if grad_x is None:
-        grad_x = torch.empty_like(x)
+        grad_x = _new(x.shape, x)
     if grad_w is None:
-        grad_w = torch.empty_like(w)
+        grad_w = _new(w.shape, w)
     if workspace is None:
         nbytes = int(lib().shiftnd_backward_pooled_workspace_bytes(ctypes.byref(p), _pool_arg(pool, p.ndim)))
         workspace = torch.empty(nbytes, dtype=torch.uint8, device=x.device)

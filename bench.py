@@ -19,7 +19,13 @@ The JSON line also carries
   roofline.box_stream / frac_of_box   the same box's plain 1R1W / 2R1W float4 streams (tools/stream_probe, a child
                 process that has exited before this one touches the GPU) and the dominant kernel's rate against them
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c2|c3|c4|c5|c2a|c2crop|c2acrop|t1|t1a|c1d|c1da|c1dh] [--pad 0..4]
+  configs       (default run only: --gpus 1, workload c2, padding 0) AFTER the headline's timed region, in the same
+                process, every other BASELINE config (C2 paddings 1-4, C3 paddings 0-4, C4, C5 per GPU) and the round's
+                other workloads are built, timed for >= 20 steps through the same dispatcher ops, measured kernel by
+                kernel with HIP events and freed again: {name: {ms_per_step, value, dtype, roofline: {kernel, frac,
+                frac_of_box, traffic}}}.  --no-configs skips it.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload NAME] [--pad 0..4]      (NAME: see WORKLOADS)
 
 Multi-GPU: `python bench.py --gpus N` starts the N rank processes itself (one per GPU; the parent never
 touches the GPU); under a launcher (`python -m torch.distributed.run --nproc-per-node N bench.py --gpus N`)
@@ -36,7 +42,8 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(ROOT, "activesparseshifts-pytorch_amd"))
 
-HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured float4 copy)
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (the guide's measured float4 copy: 6.29 TB/s; tools/stream_probe
+#                         measures 6.4-6.5 TB/s on this pool's boxes and the line carries that number as roofline.box_stream)
 
 WORKLOADS = {
     # name: (nd, shape per GPU, dtype, active, description)
@@ -56,7 +63,32 @@ WORKLOADS = {
     "c1d": (1, (256, 512, 4096), "float32", False, "Shift1d SSL fwd+bwd N256 C512 L4096 fp32"),
     "c1da": (1, (256, 512, 4096), "float32", True, "Shift1d active fwd+bwd N256 C512 L4096 fp32"),
     "c1dh": (1, (256, 512, 4096), "float16", False, "Shift1d SSL fwd+bwd N256 C512 L4096 fp16"),
+    # round 5 -- rows that are not whole 16-byte pieces: the deep stages of an ImageNet CNN (14x14), and the OUTPUT of a cropped
+    # shift as the next layer's input (62x62 = t1's output, 222x222 = c2crop's output; modules/shifts.py:41-46)
+    "r14": (2, (128, 1024, 14, 14), "float32", False, "Shift2d SSL fwd+bwd N128 C1024 14x14 fp32 (ragged rows)"),
+    "r14a": (2, (128, 1024, 14, 14), "float32", True, "Shift2d active fwd+bwd N128 C1024 14x14 fp32 (ragged rows)"),
+    "r7": (2, (128, 2048, 7, 7), "float32", False, "Shift2d SSL fwd+bwd N128 C2048 7x7 fp32 (ragged rows)"),
+    "r14h": (2, (128, 1024, 14, 14), "float16", False, "Shift2d SSL fwd+bwd N128 C1024 14x14 fp16 (ragged rows)"),
+    "r62": (2, (512, 16, 62, 62), "float32", False, "Shift2d SSL fwd+bwd N512 C16 62x62 fp32 (ragged rows: t1's output as the next input)"),
+    "r222": (2, (64, 256, 222, 222), "float32", False, "Shift2d SSL fwd+bwd N64 C256 222x222 fp32 (ragged rows: c2crop's output as the next input)"),
+    "r225": (2, (8, 64, 225, 225), "float32", False, "Shift2d SSL fwd+bwd N8 C64 225x225 fp32 (ragged rows)"),
+    # channels-last tensors as they lie: saved input, incoming gradient and grad_x all NHWC / NDHWC
+    "cl2d": (2, (16, 256, 224, 224), "float32", False, "Shift2d SSL fwd+bwd N16 C256 224x224 fp32, channels-last (NHWC) tensors"),
+    "cl2da": (2, (16, 256, 224, 224), "float32", True, "Shift2d active fwd+bwd N16 C256 224x224 fp32, channels-last (NHWC) tensors"),
+    "cl3d": (3, (8, 128, 16, 112, 112), "float32", False, "Shift3d SSL fwd+bwd N8 C128 16x112x112 fp32, channels-last (NDHWC) tensors"),
+    "cl3da": (3, (8, 128, 16, 112, 112), "float32", True, "Shift3d active fwd+bwd N8 C128 16x112x112 fp32, channels-last (NDHWC) tensors"),
+    "cl3dh": (3, (8, 128, 16, 112, 112), "bfloat16", True, "Shift3d active fwd+bwd N8 C128 16x112x112 bf16, channels-last (NDHWC) tensors"),
 }
+
+# workloads whose tensors are channels-last (dense NHWC / NDHWC strides behind the logical NCHW / NCDHW shape)
+CHANNELS_LAST = {"cl2d", "cl2da", "cl3d", "cl3da", "cl3dh"}
+
+# What the default run times after the headline (same process, >= 20 steps each): every BASELINE.json config the headline is not
+# -- C2 paddings 1-4, C3 paddings 0-4, C4, C5 (per GPU) -- then the round's other workloads.
+EXTRA_CONFIGS = ([("c2_pad%d" % p, "c2", p) for p in (1, 2, 3, 4)] + [("c3_pad%d" % p, "c3", p) for p in range(5)] +
+                 [("c4", "c4", 0), ("c5", "c5", 0)] +
+                 [(n, n, 0) for n in ("c2a", "c2crop", "c2acrop", "t1", "t1a", "c1d", "r14", "r14a", "r62", "r222", "cl2d", "cl2da", "cl3d", "cl3da")])
+ESIZE = {"float32": 4, "bfloat16": 2, "float16": 2, "quint8": 1}
 
 # user `borders` of the cropped workloads ([nD, 2] cut-left / cut-right amounts, functional.py:22,32-35)
 CUTS = {"c2crop": [[1, 1], [1, 1]], "c2acrop": [[1, 1], [1, 1]], "t1": [[1, 1], [1, 1]], "t1a": [[1, 1], [1, 1]]}
@@ -111,10 +143,9 @@ def newest_traffic(workload, kernel_name, pad):
     rocprofv3 passes, they cannot be read inside the timed process).  None when no profile names this kernel."""
     import glob
     import re
-    if pad != 0:
-        return None, None
     best = None
-    for f in glob.glob(os.path.join(ROOT, "profiles", "r*_%s_traffic.json" % workload)):
+    tags = ["%s_pad%d" % (workload, pad)] + ([workload] if pad == 0 else [])
+    for f in [g for t in tags for g in glob.glob(os.path.join(ROOT, "profiles", "r*_%s_traffic.json" % t))]:
         m = re.match(r"r(\d+)_", os.path.basename(f))
         if m and (best is None or int(m.group(1)) > best[0]):
             best = (int(m.group(1)), f)
@@ -212,6 +243,11 @@ def parse_args(argv):
                     help="let --gpus N run on a box with fewer than N GPUs (ranks share devices over gloo): a functional "
                          "check of the rank code, never a scaling point.  Without it such a request is an error.")
     ap.add_argument("--no-probe", action="store_true", help="skip the same-box stream calibration (tools/stream_probe)")
+    ap.add_argument("--no-configs", action="store_true",
+                    help="default run only: skip the other BASELINE configs / workloads timed after the headline")
+    ap.add_argument("--configs", default=None, help="comma-separated subset of the configs timed after the headline")
+    ap.add_argument("--configs-budget-s", type=float, default=150.0,
+                    help="wall-clock budget of the configs leg; configs that would start beyond it are reported as skipped")
     ap.add_argument("--force-process-group", action="store_true",
                     help="initialise the process group (RCCL on a GPU box) even for --gpus 1: exercises the rendezvous, "
                          "barrier, all_gather and all_reduce(MAX) calls of the multi-GPU path on a 1-GPU box (tests)")
@@ -235,19 +271,31 @@ def main(argv=None):
         raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d (launch with `python bench.py --gpus N`, or "
                          "`python -m torch.distributed.run --nproc-per-node N bench.py --gpus N`)" % (a.gpus, world))
 
+    default_run = rank == 0 and world == 1 and a.workload == "c2" and a.pad == 0 and a.shape is None and a.device == "cuda"
     base = None
     if rank == 0 and world == 1 and a.workload == "c2" and a.shape is None and a.device == "cuda" \
             and not a.no_cpu_baseline:
         base = cpu_baseline(a.pad)  # child process, before any GPU initialisation in this process
-    probe = None
+    probes = {}
+
+    def tensor_bytes(name, shape_arg=None):
+        _nd, _shape, _dt, _act, _desc = WORKLOADS[name]
+        _n = 1
+        for _s in (tuple(int(v) for v in shape_arg.split(",")) if shape_arg else _shape):
+            _n *= _s
+        return _n * ESIZE[_dt]
+
     if rank == 0 and world == 1 and a.device == "cuda" and not a.no_probe:
         # child process too: it has left the GPU before this process initialises it.  Streams of THIS workload's tensor size
-        # (a 0.2 ms kernel over 0.4 GB tensors pays launch ramp and tail that a 1.5 ms kernel over 3.3 GB does not)
-        _nd, _shape, _dt, _act, _desc = WORKLOADS[a.workload]
-        _n = 1
-        for _s in (tuple(int(v) for v in a.shape.split(",")) if a.shape else _shape):
-            _n *= _s
-        probe = box_stream(_n * {"float32": 4, "bfloat16": 2, "float16": 2, "quint8": 1}[_dt])
+        # (a 0.2 ms kernel over 0.4 GB tensors pays launch ramp and tail that a 1.5 ms kernel over 3.3 GB does not); the
+        # default run also calibrates at the tensor sizes of the BASELINE configs it times after the headline
+        sizes = [tensor_bytes(a.workload, a.shape)]
+        if default_run and not a.no_configs:
+            sizes += [tensor_bytes(n) for n in ("c3", "c4")]
+        for nb in sizes:
+            if nb not in probes:
+                probes[nb] = box_stream(nb)
+    probe = probes.get(tensor_bytes(a.workload, a.shape))
 
     import torch
     import torch.distributed as dist
@@ -292,65 +340,134 @@ def main(argv=None):
         if on_gpu:
             torch.cuda.synchronize()
 
-    nd, shape, dtname, active, desc = WORKLOADS[a.workload]
-    if a.shape:
-        shape = tuple(int(v) for v in a.shape.split(","))
-        assert len(shape) == nd + 2, "--shape needs %d dims for workload %s" % (nd + 2, a.workload)
-        desc = "FUNCTIONAL CHECK shape %s of: %s" % (list(shape), desc)
-    # weak scaling: the global batch is world x the per-GPU batch; this rank owns one contiguous slice
-    lo, hi = shard_range(shape[0] * world, rank, world)
-    shape = (hi - lo,) + tuple(shape[1:])
-    quant = dtname == "quint8"
-    C = shape[1]
-    elems = 1
-    for s in shape:
-        elems *= s
-    ops = torch.ops.torchshifts
-    fwd_op = getattr(ops, "_shift%dd_forward" % nd)
-    bwd_op = getattr(ops, "_shift%dd_backward" % nd)
-    cuts = CUTS.get(a.workload)
-    if cuts is None:
-        bl, oshape = abi.default_borders(torch.empty(shape, device="meta")), list(shape)
-    else:  # check_borders (ops/shifts.cpp:93-135): cut amounts -> the absolute [l, r) window and the output size
-        bl, oshape = abi.check_borders(list(shape), cuts, nd)
-    borders = torch.tensor(bl, dtype=torch.int32)  # host
-    oelems = 1
-    for s_ in oshape:
-        oelems *= s_
-
-    # ---- synthetic inputs (resident before timing) ----------------------------------------------------
-    seed = 1000 * rank
-    w32 = synth_tensor(torch, (C, nd), seed + 3, dev, torch.float32, -3.0, 3.0)
-    special = [0.0, 0.5, -1.5, 2.5, float(shape[2] + 3)]  # alignment classes + a beyond-the-dim shift
-    for i, v in enumerate(special[:C]):
-        w32[i, :] = v
-    if quant:
-        x = (synth_tensor(torch, shape, seed + 1, dev, torch.float32) * 255).to(torch.uint8)
-        xq = torch._make_per_tensor_quantized_tensor(x, 1 / 255.0, 0)
-        wq = torch.quantize_per_tensor(w32, 1.0, 128, torch.quint8)
-        esize = 1
-    else:
-        dtype = getattr(torch, dtname)
-        if not on_gpu and dtype in (torch.float16, torch.bfloat16):
-            dtype = torch.float32  # the CPU key serves float/double like the reference's (shifts_cpu.cpp:228)
-        x = synth_tensor(torch, shape, seed + 1, dev, dtype)
-        go = synth_tensor(torch, tuple(oshape), seed + 2, dev, dtype)
-        w = w32.to(dtype)
-        esize = x.element_size()
-    sync()
-
-    def step():
-        if quant:
-            return fwd_op(xq, wq, borders, oshape, a.pad, False)
-        out = fwd_op(x, w, borders, oshape, a.pad, active)
-        gx, gw = bwd_op(go, w, x, borders, a.pad, active)
-        return out, gx, gw
-
     def barrier():
         sync()
         if use_pg:
             dist.barrier()
         sync()
+
+    ops = torch.ops.torchshifts
+
+    class Workload:
+        """The synthetic tensors of one workload (resident in HBM), its step through the dispatcher ops, and its kernels
+        through the C ABI."""
+
+        def __init__(self, name, pad, shape_arg=None):
+            self.name, self.pad = name, pad
+            nd, shape, dtname, active, desc = WORKLOADS[name]
+            if shape_arg:
+                shape = tuple(int(v) for v in shape_arg.split(","))
+                assert len(shape) == nd + 2, "--shape needs %d dims for workload %s" % (nd + 2, name)
+                desc = "FUNCTIONAL CHECK shape %s of: %s" % (list(shape), desc)
+            # weak scaling: the global batch is world x the per-GPU batch; this rank owns one contiguous slice
+            lo, hi = shard_range(shape[0] * world, rank, world)
+            shape = (hi - lo,) + tuple(shape[1:])
+            self.nd, self.shape, self.dtname, self.active, self.desc = nd, shape, dtname, active, desc
+            self.quant = quant = dtname == "quint8"
+            C = shape[1]
+            self.elems = 1
+            for s_ in shape:
+                self.elems *= s_
+            self.fwd_op = getattr(ops, "_shift%dd_forward" % nd)
+            self.bwd_op = getattr(ops, "_shift%dd_backward" % nd)
+            self.cuts = cuts = CUTS.get(name)
+            if cuts is None:
+                self.bl, self.oshape = abi.default_borders(torch.empty(shape, device="meta")), list(shape)
+            else:  # check_borders (ops/shifts.cpp:93-135): cut amounts -> the absolute [l, r) window and the output size
+                self.bl, self.oshape = abi.check_borders(list(shape), cuts, nd)
+            self.borders = torch.tensor(self.bl, dtype=torch.int32)  # host
+            self.oelems = 1
+            for s_ in self.oshape:
+                self.oelems *= s_
+            # ---- synthetic inputs (resident before timing) ------------------------------------------------
+            seed = 1000 * rank
+            w32 = synth_tensor(torch, (C, nd), seed + 3, dev, torch.float32, -3.0, 3.0)
+            special = [0.0, 0.5, -1.5, 2.5, float(shape[2] + 3)]  # alignment classes + a beyond-the-dim shift
+            for i, v in enumerate(special[:C]):
+                w32[i, :] = v
+            cl = name in CHANNELS_LAST
+            fmt = (torch.channels_last if nd == 2 else torch.channels_last_3d) if cl else torch.contiguous_format
+            if quant:
+                x = (synth_tensor(torch, shape, seed + 1, dev, torch.float32) * 255).to(torch.uint8)
+                self.xq = torch._make_per_tensor_quantized_tensor(x, 1 / 255.0, 0)
+                self.wq = torch.quantize_per_tensor(w32, 1.0, 128, torch.quint8)
+                self.esize = 1
+            else:
+                dtype = getattr(torch, dtname)
+                if not on_gpu and dtype in (torch.float16, torch.bfloat16):
+                    dtype = torch.float32  # the CPU key serves float/double like the reference's (shifts_cpu.cpp:228)
+                self.x = synth_tensor(torch, shape, seed + 1, dev, dtype).contiguous(memory_format=fmt)
+                self.go = synth_tensor(torch, tuple(self.oshape), seed + 2, dev, dtype).contiguous(memory_format=fmt)
+                self.w = w32.to(dtype)
+                self.esize = self.x.element_size()
+            self.fmt = fmt
+            sync()
+
+        def step(self):
+            if self.quant:
+                return self.fwd_op(self.xq, self.wq, self.borders, self.oshape, self.pad, False)
+            out = self.fwd_op(self.x, self.w, self.borders, self.oshape, self.pad, self.active)
+            gx, gw = self.bwd_op(self.go, self.w, self.x, self.borders, self.pad, self.active)
+            return out, gx, gw
+
+        def step_bytes(self):
+            return 2 * self.esize * self.elems if self.quant else self.esize * (3 * self.elems + 2 * self.oelems)
+
+        def kernel_times(self, kiters, probe):
+            """per-kernel durations: HIP events on the launch stream, kernels called through the C ABI.
+            Returns (kernels, dominant kernel's (name, ms, algorithmic bytes, stream kind))"""
+            kernels = {}
+
+            def record(name, t, nbytes, stream_kind=None):
+                kernels[name] = {"ms": t[0], "median_ms": t[1], "min_ms": t[2], "GB/s": nbytes / t[0] / 1e6}
+                ref = (probe or {}).get(stream_kind + "_GBps") if stream_kind else None
+                if ref:  # against the plain stream of the same read / write mix on this box
+                    kernels[name]["stream"] = stream_kind
+                    kernels[name]["frac_of_box"] = nbytes / t[0] / 1e6 / ref
+            esize, elems, oelems, pad, active = self.esize, self.elems, self.oelems, self.pad, self.active
+            if self.quant:
+                xi = self.xq.int_repr()
+                wi = self.wq.int_repr()
+                outb = torch.empty_like(xi)
+                t_f = event_time(lambda: abi.forward_quantized(xi, wi, 128, 0, pad, out=outb), kiters)
+                qname = abi.last_kernel()
+                record(qname, t_f, 2 * esize * elems, "1R1W")
+                return kernels, (qname, t_f[0], 2 * esize * elems, "1R1W")
+            x, go, w = self.x, self.go, self.w
+            # (the float forward's output is NCHW-contiguous even for a channels-last input, cpu/shifts_cpu.cpp:221; grad_x
+            # has the input's layout, :246)
+            outb, gxb, gwb = torch.empty(self.oshape, dtype=x.dtype, device=x.device), torch.empty_like(x), torch.empty_like(w)
+            bk = None if self.cuts is None else self.bl
+            ws = abi.backward_workspace(x, pad, active, bk)
+            t_f = event_time(lambda: abi.forward(x, w, pad, active, borders=bk, out=outb), kiters)
+            t_b = event_time(lambda: abi.backward(go, w, x, pad, active, borders=bk, grad_x=gxb, grad_w=gwb, workspace=ws), kiters)
+            abi.forward(x, w, pad, active, borders=bk, out=outb)
+            fname = abi.last_kernel()
+            abi.backward(go, w, x, pad, active, borders=bk, grad_x=gxb, grad_w=gwb, workspace=ws)
+            bname = abi.last_kernel()
+            # algorithmic bytes (SURVEY 8d): forward reads x, writes out; backward reads grad_out and x, writes grad_x
+            # (a cropped window: out / grad_out have the window's size)
+            record(fname, t_f, esize * (elems + oelems), "1R1W")
+            record(bname, t_b, esize * (2 * elems + oelems), "2R1W")
+            return kernels, (bname, t_b[0], esize * (2 * elems + oelems), "2R1W")
+
+    def event_time(fn, iters):
+        stream = torch.cuda.current_stream()
+        fn()
+        torch.cuda.synchronize()
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(iters + 1)]
+        ev[0].record(stream)
+        for i in range(iters):
+            fn()
+            ev[i + 1].record(stream)
+        ev[-1].synchronize()
+        per = sorted(ev[i].elapsed_time(ev[i + 1]) for i in range(iters))
+        return ev[0].elapsed_time(ev[-1]) / iters, per[len(per) // 2], per[0]  # mean, median, min (ms)
+
+    wl = Workload(a.workload, a.pad, a.shape)
+    nd, shape, dtname, active, desc = wl.nd, wl.shape, wl.dtname, wl.active, wl.desc
+    elems, quant = wl.elems, wl.quant
+    step = wl.step
 
     for _ in range(a.warmup):
         step()
@@ -378,7 +495,8 @@ def main(argv=None):
             pr = torch.cuda.get_device_properties(dev)
             info["device_name"] = pr.name
             info["uuid"] = str(getattr(pr, "uuid", "")) or None
-            info["pci_bus_id"] = "%04x:%02x:%02x" % (getattr(pr, "pci_domain_id", 0), getattr(pr, "pci_bus_id", 0), getattr(pr, "pci_device_id", 0))
+            have_pci = all(hasattr(pr, k) for k in ("pci_domain_id", "pci_bus_id", "pci_device_id"))
+            info["pci_bus_id"] = ("%04x:%02x:%02x" % (pr.pci_domain_id, pr.pci_bus_id, pr.pci_device_id)) if have_pci else None
             info["hbm_bytes"] = pr.total_memory
         if use_pg:
             info["pg_world_size"] = dist.get_world_size()
@@ -391,10 +509,12 @@ def main(argv=None):
         dist.all_gather_object(every_info, per_rank[0])
         per_rank = every_info
         if on_gpu and not oversubscribed:
-            # one GPU per rank: distinct devices, or the line is not a scaling point -- fail loudly
-            seen = set((r["host"], r.get("uuid") or r.get("pci_bus_id") or r["device_index"]) for r in per_rank)
-            if len(seen) != world:
-                raise SystemExit("bench.py: %d ranks ran on %d distinct GPU(s): %s" % (world, len(seen), per_rank))
+            # one GPU per rank: abort only when two ranks PROVABLY share a device -- the same host and the same device index,
+            # or the same meaningful uuid / PCI id (a torch build that reports an empty or all-zero uuid, or no PCI
+            # attributes, says nothing: those fall back to the device index the rank selected)
+            shared = distinct_device_conflicts(per_rank)
+            if shared:
+                raise SystemExit("bench.py: ranks share a GPU: %s -- %s" % (shared, per_rank))
 
     # ---- per-step spread (median / min over single steps; outside the contract's timed region) -----------
     singles = []
@@ -406,57 +526,29 @@ def main(argv=None):
         singles.append((time.perf_counter() - t1) * 1e3)
     singles.sort()
 
-    # ---- per-kernel durations: HIP events on the launch stream, kernels called through the C ABI -------
-    def event_time(fn, iters):
-        stream = torch.cuda.current_stream()
-        fn()
-        torch.cuda.synchronize()
-        ev = [torch.cuda.Event(enable_timing=True) for _ in range(iters + 1)]
-        ev[0].record(stream)
-        for i in range(iters):
-            fn()
-            ev[i + 1].record(stream)
-        ev[-1].synchronize()
-        per = sorted(ev[i].elapsed_time(ev[i + 1]) for i in range(iters))
-        return ev[0].elapsed_time(ev[-1]) / iters, per[len(per) // 2], per[0]  # mean, median, min (ms)
-
     kiters = max(5, a.steps)
     kernels = {}
     dom_name = dom_ms = dom_bytes = None
     if on_gpu:
-        def record(name, t, nbytes, stream_kind=None):
-            kernels[name] = {"ms": t[0], "median_ms": t[1], "min_ms": t[2], "GB/s": nbytes / t[0] / 1e6}
-            ref = (probe or {}).get(stream_kind + "_GBps") if stream_kind else None
-            if ref:  # against the plain stream of the same read / write mix on this box
-                kernels[name]["stream"] = stream_kind
-                kernels[name]["frac_of_box"] = nbytes / t[0] / 1e6 / ref
-        if quant:
-            xi = xq.int_repr()
-            wi = wq.int_repr()
-            outb = torch.empty_like(xi)
-            t_f = event_time(lambda: abi.forward_quantized(xi, wi, 128, 0, a.pad, out=outb), kiters)
-            qname = abi.last_kernel()
-            record(qname, t_f, 2 * esize * elems, "1R1W")
-            dom_name, dom_ms, dom_bytes, dom_kind = qname, t_f[0], 2 * esize * elems, "1R1W"
-        else:
-            outb, gxb, gwb = torch.empty_like(go), torch.empty_like(x), torch.empty_like(w)
-            bk = None if cuts is None else bl
-            ws = abi.backward_workspace(x, a.pad, active, bk)
-            t_f = event_time(lambda: abi.forward(x, w, a.pad, active, borders=bk, out=outb), kiters)
-            t_b = event_time(lambda: abi.backward(go, w, x, a.pad, active, borders=bk, grad_x=gxb, grad_w=gwb, workspace=ws), kiters)
-            abi.forward(x, w, a.pad, active, borders=bk, out=outb)
-            fname = abi.last_kernel()
-            abi.backward(go, w, x, a.pad, active, borders=bk, grad_x=gxb, grad_w=gwb, workspace=ws)
-            bname = abi.last_kernel()
-            # algorithmic bytes: forward reads x, writes out; backward reads grad_out and x, writes grad_x
-            # (a cropped window: out / grad_out have the window's size)
-            record(fname, t_f, esize * (elems + oelems), "1R1W")
-            record(bname, t_b, esize * (2 * elems + oelems), "2R1W")
-            dom_name, dom_ms, dom_bytes, dom_kind = bname, t_b[0], esize * (2 * elems + oelems), "2R1W"
+        kernels, (dom_name, dom_ms, dom_bytes, dom_kind) = wl.kernel_times(kiters, probe)
     path = "+".join(sorted(set(k.split("_")[0] for k in kernels))) or "cpu key"
 
+    def roofline_of(name, pad, dom, probe_, shape_arg=None):
+        dname, dms, dbytes, dkind = dom
+        achieved = dbytes / dms / 1e6  # GB/s
+        traffic, traffic_src = newest_traffic(name, dname, pad) if not shape_arg else (None, None)
+        r = {"bound": "hbm", "kernel": dname, "achieved": achieved, "peak": HBM_PEAK_GBS,
+             "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+             "traffic_source": traffic_src, "avg_kernel_ms": dms,
+             "algorithmic_bytes": dbytes}
+        if probe_ is not None:
+            ref = probe_.get(dkind + "_GBps")
+            r["frac_of_box"] = achieved / ref if ref else None
+        return r
+
+    dtag = {"float32": "f32", "bfloat16": "bf16", "float16": "f16", "quint8": "u8"}
     if rank == 0:
-        step_bytes = 2 * esize * elems if quant else esize * (3 * elems + 2 * oelems)
+        step_bytes = wl.step_bytes()
         result = {
             "metric": "Gelem/s, Shift2d fwd+bwd N64/C256/224x224" if a.workload == "c2" and not a.shape
                       else "Gelem/s, " + desc,
@@ -471,7 +563,7 @@ def main(argv=None):
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": {"float32": "f32", "bfloat16": "bf16", "float16": "f16", "quint8": "u8"}[dtname],
+            "dtype": dtag[dtname],
             "data": "synthetic",
             "config": {"workload": desc + ", padding %d, per GPU; batch sharded over %d GPU(s), no collectives"
                                    % (a.pad, world),
@@ -486,16 +578,11 @@ def main(argv=None):
             "kernels": kernels,
         }
         if dom_name is not None:
-            achieved = dom_bytes / dom_ms / 1e6  # GB/s
-            traffic, traffic_src = newest_traffic(a.workload, dom_name, a.pad) if not a.shape else (None, None)
-            result["roofline"] = {"bound": "hbm", "kernel": dom_name, "achieved": achieved, "peak": HBM_PEAK_GBS,
-                                  "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                                  "traffic_source": traffic_src, "avg_kernel_ms": dom_ms,
-                                  "algorithmic_bytes": dom_bytes}
+            result["roofline"] = roofline_of(a.workload, a.pad, (dom_name, dom_ms, dom_bytes, dom_kind), probe, a.shape)
             if probe is not None:
+                fob = result["roofline"].pop("frac_of_box")
                 result["roofline"]["box_stream"] = probe
-                ref = probe.get(dom_kind + "_GBps")
-                result["roofline"]["frac_of_box"] = achieved / ref if ref else None
+                result["roofline"]["frac_of_box"] = fob
         else:
             result["roofline"] = None
         if not on_gpu:
@@ -504,10 +591,73 @@ def main(argv=None):
             result["data"] = "synthetic; %d ranks share %d GPU(s): functional check, not a scaling point" % (world, ndev)
         if base is not None:
             result["cpu_baseline"] = base
+
+        # ---- the other BASELINE configs and workloads, driver-timed: same process, after the headline (whose tensors are
+        # freed first), each built, warmed up, timed over >= 20 steps exactly like the headline, measured kernel by kernel
+        if default_run and not a.no_configs:
+            del wl, step
+            configs = {}
+            t_all = time.perf_counter()
+            csteps, cwarm = max(20, a.steps), max(5, a.warmup)
+            only = set(a.configs.split(",")) if a.configs else None
+            for cname, wname, pad in EXTRA_CONFIGS:
+                if only is not None and cname not in only and wname not in only:
+                    continue
+                if time.perf_counter() - t_all > a.configs_budget_s:
+                    configs[cname] = {"skipped": "time budget (--configs-budget-s %g)" % a.configs_budget_s}
+                    continue
+                try:
+                    torch.cuda.empty_cache()
+                    cw = Workload(wname, pad)
+                    for _ in range(cwarm):
+                        cw.step()
+                    barrier()
+                    c0 = time.perf_counter()
+                    for _ in range(csteps):
+                        cw.step()
+                    barrier()
+                    cms = (time.perf_counter() - c0) / csteps * 1e3
+                    cprobe = probes.get(tensor_bytes(wname))
+                    ck, cdom = cw.kernel_times(csteps, cprobe)
+                    rl = roofline_of(wname, pad, cdom, cprobe)
+                    configs[cname] = {
+                        "workload": cw.desc + ", padding %d" % pad, "steps": csteps, "warmup": cwarm,
+                        "ms_per_step": cms, "value": cw.elems / (cms * 1e-3) / 1e9, "unit": "Gelem/s", "dtype": dtag[cw.dtname],
+                        "achieved_hbm_GBps_step": cw.step_bytes() / (cms * 1e-3) / 1e9,
+                        "kernels": {k: {"ms": v["ms"], "GB/s": v["GB/s"], "frac": v["GB/s"] / HBM_PEAK_GBS,
+                                        "frac_of_box": v.get("frac_of_box")} for k, v in ck.items()},
+                        "roofline": {"kernel": rl["kernel"], "frac": rl["frac"], "frac_of_box": rl.get("frac_of_box"),
+                                     "traffic": rl["traffic"], "traffic_source": rl["traffic_source"],
+                                     "avg_kernel_ms": rl["avg_kernel_ms"], "algorithmic_bytes": rl["algorithmic_bytes"]}}
+                    del cw, ck
+                except Exception as e:  # noqa: BLE001  (one failing workload must not lose the headline line; it is reported)
+                    configs[cname] = {"error": repr(e)[:300]}
+            result["configs"] = configs
+            result["configs_wall_s"] = time.perf_counter() - t_all
         print(json.dumps(result), flush=True)
     if use_pg:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def distinct_device_conflicts(per_rank):
+    """Pairs of ranks that provably run on ONE GPU: the same host and the same selected device index, or the same
+    meaningful uuid / PCI id.  An empty, all-zero or absent uuid and an absent PCI id say nothing (a ROCm / torch build may
+    not report them): such ranks are compared by (host, device index) only."""
+    def meaningful(v):
+        return bool(v) and any(ch not in "0-:. " for ch in str(v).lower())
+    seen, shared = {}, []
+    for r in per_rank:
+        keys = [("index", r["host"], r["device_index"])]
+        if meaningful(r.get("uuid")):
+            keys.append(("uuid", r["uuid"]))
+        if meaningful(r.get("pci_bus_id")):
+            keys.append(("pci", r["host"], r["pci_bus_id"]))
+        for k in keys:
+            if k in seen and seen[k] != r["rank"]:
+                shared.append((seen[k], r["rank"], k[0]))
+            seen.setdefault(k, r["rank"])
+    return sorted(set(shared))
 
 
 if __name__ == "__main__":

@@ -16,3 +16,6 @@ for p in (ROOT, PKG, os.path.dirname(os.path.abspath(__file__))):
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # outputs allocated by the ctypes binding start from a byte pattern: an element no kernel wrote fails deterministically
+    from torchshifts import abi
+    abi.POISON = True

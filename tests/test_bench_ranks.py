@@ -120,3 +120,19 @@ def test_rccl_calls_of_the_rank_code_on_one_gpu():
     pr = j[0]["config"]["ranks"]["per_rank"]
     assert len(pr) == 1 and pr[0]["device_index"] == 0 and pr[0]["pg_backend"] == "nccl" and pr[0]["pg_world_size"] == 1
     assert pr[0]["device_name"] and pr[0]["pci_bus_id"] and pr[0]["hbm_bytes"] > 2 ** 37
+
+
+def test_distinct_device_guard_only_fires_on_provable_sharing():
+    """a torch build that reports no uuid / an all-zero PCI id must not make eight ranks on eight devices look
+    like one GPU; two ranks on one device index of one host (or with one real uuid) must still abort."""
+    sys.path.insert(0, ROOT)
+    import bench
+    def rk(i, dev, uuid=None, pci=None, host="h"):
+        return {"rank": i, "host": host, "device_index": dev, "uuid": uuid, "pci_bus_id": pci}
+    assert bench.distinct_device_conflicts([rk(i, i, "00000000-0000-0000-0000-000000000000", "0000:00:00") for i in range(8)]) == []
+    assert bench.distinct_device_conflicts([rk(i, i) for i in range(8)]) == []
+    assert bench.distinct_device_conflicts([rk(i, i, "6462-%d" % i, "0000:%02x:00" % (0x10 + i)) for i in range(8)]) == []
+    assert bench.distinct_device_conflicts([rk(0, 0), rk(1, 0)]) == [(0, 1, "index")]
+    assert bench.distinct_device_conflicts([rk(0, 0, "abc"), rk(1, 1, "abc")]) == [(0, 1, "uuid")]
+    assert bench.distinct_device_conflicts([rk(0, 0, None, "0000:72:00"), rk(1, 1, None, "0000:72:00")]) == [(0, 1, "pci")]
+    assert bench.distinct_device_conflicts([rk(0, 0, host="a"), rk(1, 0, host="b")]) == []

@@ -113,7 +113,11 @@ def test_1d_backward_vs_oracle(abi, shape, crop, dt):
 
 
 CASES_FWD_2D = CASES_2D + [((2, 3, 62, 62), None), ((2, 2, 62, 62), [[1, 1], [1, 1]]), ((1, 2, 113, 113), [[0, 1], [0, 1]]), ((2, 2, 30, 20), None), ((2, 5, 8, 1), None), ((2, 3, 16, 2), None), ((1, 4, 12, 3), None), ((2, 2, 40, 8), [[1, 1], [3, 4]]),
-                           ((1, 2, 9, 4100), [[1, 0], [2, 2]])]
+                           ((1, 2, 9, 4100), [[1, 0], [2, 2]]),
+                           # tall, narrow windows: a step of 256 chunks crosses more than 64 output-row boundaries (the
+                           # straddling chunks beyond the 64th boundary were never written)
+                           ((1, 2, 130, 12), [[1, 1], [1, 1]]), ((1, 2, 200, 24), [[0, 0], [1, 1]]), ((2, 2, 260, 8), [[2, 2], [1, 1]]),
+                           ((1, 3, 400, 4), [[0, 0], [1, 0]]), ((1, 2, 514, 8), [[1, 1], [0, 1]])]
 
 
 @pytest.mark.parametrize("dt", ["f32", "f64", "f16", "bf16"])

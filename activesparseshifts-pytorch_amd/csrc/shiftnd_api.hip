@@ -11,6 +11,7 @@ namespace {
 
 thread_local int g_last_path = SHIFTND_PATH_NONE;
 thread_local const char *g_last_kernel = "";
+thread_local int g_cl3 = 0;     // knob 23: the direct NDHWC backward (shiftnd_cl_tiled3.hip) 0 automatic / 1 never / 2 whenever eligible
 thread_local int g_policy = 0;  // 0 auto, 1 force strided, 2 plane kernels (or fail), 3 sweep kernels (or fail)
 
 bool is_float_dtype(int dt) { return dt >= SHIFTND_F32 && dt <= SHIFTND_BF16; }
@@ -188,6 +189,7 @@ void shiftnd_set_tuning(int knob, int value) {
     else if (knob >= 32) step_set_tuning(knob - 32, value);  // 32: one-step backward 0 automatic / 1 never / 2 whenever eligible
     else if (knob >= 28) rows_set_tuning(knob - 28, value);  // 28: element sizes served (bit 0: 1 byte, bit 1: 2 bytes), 29: rows per band, 30: workgroups
     else if (knob >= 24) small_set_tuning(knob - 24, value);  // 24: small-plane kernels on / off, 25: planes per round, 26: rounds per workgroup
+    else if (knob == 23) g_cl3 = value;
     else if (knob >= 20) cl_tiled_set_tuning(knob - 20, value);  // 20: LDS-tiled channels-last forward on / off, 21: rows per band
     else if (knob >= 16) bytes_set_tuning(knob - 16, value);  // 16: 1-byte small-plane kernel on / off, 17: planes per workgroup
     else if (knob >= 12) slide_set_tuning(knob - 12, value);  // 12: which problems slide, 13: workgroups wanted, 14: min rows per band
@@ -256,6 +258,14 @@ int shiftnd_backward_serves_channels_last(const shiftnd_problem *p, const void *
     Geometry g;
     if (build_geometry(p, x_strides, grad_out_strides, grad_x_strides, g) != SHIFTND_OK) return 0;
     if (g.N == 0 || g.C == 0 || g.S[0] * g.S[1] * g.S[2] == 0) return 0;
+    if (g.nd == 3) {
+        // NDHWC (round 5): shiftnd_cl_tiled3.hip serves such tensors as they lie (what a C-ABI caller gets: 1.2 - 1.5 ms on N8 C128
+        // 16x112x112 fp32 where the channel-fastest kernels took 21 - 36 ms), but the op's route -- shiftnd_transpose of the saved
+        // input, the walk kernels, shiftnd_transpose of grad_x back -- measures 1.04 ms (bf16 0.53 against 1.0 - 1.4;
+        // tools/cl3d_bench.py): the answer stays no unless knob 23 asks for the direct kernel
+        if (g_cl3 != 2) return 0;
+        return cl_tiled3_backward_eligible(g, p->dtype, grad_out, x, grad_x) ? 1 : 0;
+    }
     if (g.active && (p->dtype == SHIFTND_F16 || p->dtype == SHIFTND_BF16)) return 0;  // (0.56 vs 0.66 ms: see above)
     return cl_tiled_backward_eligible(g, p->dtype, grad_out, x, grad_x) ? 1 : 0;
 }
@@ -295,9 +305,11 @@ size_t shiftnd_backward_workspace_bytes(const shiftnd_problem *p) {
     const size_t d = cl_backward_workspace(g);
     const size_t e = cl_tiled_backward_workspace(g);
     const size_t f = small_backward_workspace(g, p->dtype);
+    const size_t h = cl_tiled3_backward_workspace(g);
     size_t m = a > b ? (a > c ? a : c) : (b > c ? b : c);
     m = m > d ? m : d;
     m = m > e ? m : e;
+    m = m > h ? m : h;
     return m > f ? m : f;
 }
 
@@ -343,6 +355,11 @@ int shiftnd_backward(const shiftnd_problem *p, const void *grad_out, const int64
         if (cl_tiled_backward_workspace(g) > workspace_bytes) return SHIFTND_ERR_WORKSPACE_TOO_SMALL;
         g_last_path = SHIFTND_PATH_CL;
         return finish(cl_tiled_backward(g, p->dtype, grad_out, x, weights, grad_x, grad_w, workspace, st));
+    }
+    if ((g_policy == 0 || g_policy == 4) && g_cl3 != 1 && cl_tiled3_backward_eligible(g, p->dtype, grad_out, x, grad_x)) {  // NDHWC: LDS-tiled, one plane per workgroup
+        if (cl_tiled3_backward_workspace(g) > workspace_bytes) return SHIFTND_ERR_WORKSPACE_TOO_SMALL;
+        g_last_path = SHIFTND_PATH_CL;
+        return finish(cl_tiled3_backward(g, p->dtype, grad_out, x, weights, grad_x, grad_w, workspace, st));
     }
     if (g_policy == 4 && !cl_backward_eligible(g, p->dtype)) return SHIFTND_ERR_INVALID_ARGUMENT;
     if ((g_policy == 0 && cl_backward_preferred(g, p->dtype)) || g_policy == 4) {

@@ -129,6 +129,12 @@ size_t cl_tiled_backward_workspace(const Geometry &g);
 int cl_tiled_backward(const Geometry &g, int dtype, const void *go, const void *x, const void *w, void *gx, void *gw,
                       void *workspace, hipStream_t st);
 
+// ... and of 3-D problems whose saved input and grad_x are dense NDHWC, the gradient NDHWC or NCDHW-contiguous (shiftnd_cl_tiled3.hip, round 5)
+bool cl_tiled3_backward_eligible(const Geometry &g, int dtype, const void *go, const void *x, const void *gx);
+size_t cl_tiled3_backward_workspace(const Geometry &g);
+int cl_tiled3_backward(const Geometry &g, int dtype, const void *go, const void *x, const void *w, void *gx, void *gw,
+                       void *workspace, hipStream_t st);
+
 // ---- whole small planes through LDS (shiftnd_small.hip): interpolating forward and backward of contiguous problems whose
 // rows are not whole 16-byte pieces (planes of at most 16 KiB)
 bool small_forward_eligible(const Geometry &g, int dtype);

@@ -343,6 +343,68 @@ def test_tiled_channels_last_3d_forward_vs_oracle(shape, crop):
         abi.set_tuning(21, 0)
 
 
+CL3B_CASES = CL3_CASES + [((1, 8, 3, 5, 20), None), ((1, 40, 4, 30, 17), [[1, 0], [2, 3], [0, 1]]), ((2, 16, 2, 64, 16), None)]
+
+
+@pytest.mark.parametrize("go_layout", ["ndhwc", "ncdhw"])
+@pytest.mark.parametrize("shape,crop", CL3B_CASES)
+def test_tiled_channels_last_3d_backward_vs_oracle(shape, crop, go_layout):
+    """cl_tiled_backward_3d (round 5, shiftnd_cl_tiled3.hip): saved input and grad_x dense channels_last_3d, the incoming gradient
+    channels_last_3d or NCDHW-contiguous (what follows the reference's float forward, cpu/shifts_cpu.cpp:221); both shifts, every
+    padding, depth shifts of any size (through the staging address), row / column shifts beyond the ring, windows in all three
+    dims, size-1 dims.  fp32: grad_x bit-exact, grad_w <= 1e-5 of the fp64 evaluation; bf16 / fp16: the sparse shift's grad_x
+    bit-exact, interpolation within 1 ulp, grad_w within half a unit of the type."""
+    from torchshifts import abi
+    if not (shape[3] == 1 or shape[3] >= 5) or (shape[1] * 4) % 16:
+        pytest.skip("the tiled kernels fold their source rows once (H == 1 or H >= 5); pixel lines of whole 16-byte pieces")
+    cl3 = torch.channels_last_3d
+    b, new = abi.check_borders(list(shape), crop, 3)
+    if not (new[3] == 1 or new[3] >= 5):
+        pytest.skip("window rows")
+    rs = np.random.RandomState(sum(shape) + 91)
+    x = rs.uniform(-1, 1, size=shape).astype(np.float32)
+    go = rs.uniform(-1, 1, size=new).astype(np.float32)
+    w = rs.uniform(-3.4, 3.4, size=(shape[1], 3)).astype(np.float32)
+    w[0] = [0.5, -1.5, 1.0]
+    w[1] = [shape[2] + 2.25, shape[3] + 1.0, -7.0]       # beyond the dims / beyond the ring
+    w[2] = [-5.0, 2.5, -2.0]
+    w[3] = [1.0, 0.0, 0.0]
+    w[4 % shape[1]] = [-0.25, -3.0, 3.0]                 # the ring's edges (reflect: the corner one step beyond it)
+    fmt = cl3 if go_layout == "ndhwc" else torch.contiguous_format
+    name = "cl_tiled_backward_3d" if go_layout == "ndhwc" else "cl_tiled_backward_3d_ncdhw_grad"
+    for tdt in (torch.float32, torch.bfloat16, torch.float16):
+        es = 4 if tdt == torch.float32 else 2
+        if (shape[1] * es) % 16:
+            continue
+        xt, gt, wt = (torch.from_numpy(a).to(tdt) for a in (x, go, w))
+        xr, gr, wr = (t.float().numpy() for t in (xt, gt, wt))
+        xd = xt.to(DEV).contiguous(memory_format=cl3)
+        gd = gt.to(DEV).contiguous(memory_format=fmt)
+        wd = wt.to(DEV)
+        for pad in (0, 1, 2, 3, 4):
+            for active in (0, 1):
+                gx = torch.empty_like(xd)
+                gx.fill_(float("nan"))   # (an element no kernel wrote fails the comparison)
+                gx, gw = abi.backward(gd, wd, xd, pad, active, b, grad_x=gx)
+                assert abi.last_kernel() == name, (abi.last_kernel(), shape, crop, tdt)
+                gx_ref, _ = O.backward(gr, wr, xr, pad, active, b)
+                _, gw64 = O.backward(gr.astype(np.float64), wr.astype(np.float64), xr.astype(np.float64), pad, active, b)
+                tag = (shape, crop, go_layout, str(tdt), pad, active)
+                if tdt == torch.float32:
+                    assert np.array_equal(gx.cpu().numpy(), gx_ref), ("gx",) + tag
+                    tol = max(1e-5, 2 * rel_err(O.backward(gr, wr, xr, pad, active, b)[1], gw64))   # (never looser than the reference's own fp32)
+                    assert rel_err(gw.cpu().numpy(), gw64) < tol, ("gw",) + tag
+                else:
+                    ref16 = torch.from_numpy(gx_ref).to(tdt)
+                    if active:
+                        assert _ulp_close(gx.cpu(), ref16, tdt, 8 * 2.0 ** -24), ("gx",) + tag
+                    else:
+                        assert torch.equal(gx.cpu(), ref16), ("gx",) + tag
+                    assert rel_err(gw.float().cpu().numpy(), gw64) < gw16_tol(torch.finfo(tdt).eps), ("gw",) + tag
+                gx2, gw2 = abi.backward(gd, wd, xd, pad, active, b, grad_x=torch.empty_like(xd))
+                assert torch.equal(gx2, gx) and torch.equal(gw2, gw), ("deterministic",) + tag
+
+
 @pytest.mark.parametrize("shape", [(2, 16, 9, 12), (1, 144, 20, 37), (2, 64, 40, 70), (1, 32, 5, 6)])
 def test_tiled_channels_last_forward_small_elements(shape):
     """cl_tiled_forward for 1- and 2-byte elements (a dword of output = 4 / 2 elements with their own shifts): quantized

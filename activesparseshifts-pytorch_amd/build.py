@@ -23,7 +23,7 @@ PKG = os.path.join(HERE, "torchshifts")
 OBJ = os.path.join(HERE, "build")
 INC = os.path.join(ROOT, "include")
 
-HIP_SOURCES = ["shiftnd_api.hip", "shiftnd_strided.hip", "shiftnd_plane.hip", "shiftnd_sweep.hip", "shiftnd_slide.hip", "shiftnd_step.hip", "shiftnd_step_fwd.hip", "shiftnd_walk3.hip", "shiftnd_walk.hip", "shiftnd_span.hip", "shiftnd_bytes.hip", "shiftnd_small.hip", "shiftnd_rows.hip", "shiftnd_qpool.hip", "shiftnd_cl.hip", "shiftnd_cl_tiled.hip", "shiftnd_cl_tiled3.hip", "shiftnd_transpose.hip"]
+HIP_SOURCES = ["shiftnd_api.hip", "shiftnd_strided.hip", "shiftnd_plane.hip", "shiftnd_sweep.hip", "shiftnd_slide.hip", "shiftnd_step.hip", "shiftnd_step_fwd.hip", "shiftnd_walk3.hip", "shiftnd_walk.hip", "shiftnd_span.hip", "shiftnd_flat.hip", "shiftnd_bytes.hip", "shiftnd_small.hip", "shiftnd_rows.hip", "shiftnd_qpool.hip", "shiftnd_cl.hip", "shiftnd_cl_tiled.hip", "shiftnd_cl_tiled3.hip", "shiftnd_transpose.hip"]
 CPP_SOURCES = ["torch_binding.cpp", "torch_cpu_backend.cpp"]
 HEADERS = [os.path.join(CSRC, h) for h in ("shiftnd_common.hpp", "shiftnd_launch.hpp", "shiftnd_stage.hpp", "shiftnd_step.hpp")] + [
     os.path.join(INC, "shiftnd_hip.h")]

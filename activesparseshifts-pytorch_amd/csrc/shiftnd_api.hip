@@ -60,6 +60,21 @@ int build_geometry(const shiftnd_problem *p, const int64_t *xs, const int64_t *o
     return SHIFTND_OK;
 }
 
+thread_local int g_flat = 0;   // knob 27 (mirrors shiftnd_flat.hip's): 2 = the flat-stream kernels whenever eligible
+
+// rows of the INPUT that are not whole 16-byte pieces: what the chunk kernels (step_*, crop_*, row_*: input rows of whole pieces, any
+// window) do not take -- the flat-stream kernels' automatic share
+bool ragged_rows(const Geometry &g, int dtype) {
+    const int es = dtype_size(dtype);
+    return (g.S[2] * es) % 16 != 0;
+}
+
+bool cropped(const Geometry &g) {
+    for (int d = 0; d < 3; ++d)
+        if (g.L[d] != 0 || g.O[d] != g.S[d]) return true;
+    return false;
+}
+
 bool empty_problem(const Geometry &g) {
     return g.N == 0 || g.C == 0 || g.S[0] * g.S[1] * g.S[2] == 0 || g.O[0] * g.O[1] * g.O[2] == 0;
 }
@@ -91,6 +106,10 @@ int forward_common(const shiftnd_problem *p, const void *x, const int64_t *xs, c
         // (interpolating problems keep the LDS-staged plane kernels whenever those take them: see DESIGN 3.14)
         const bool interpolating = g.active && p->dtype <= SHIFTND_BF16;
         const bool prefer_sweep = (out_plane_bytes >= 32 * 1024 && !interpolating && !(can_plane && plane_forward_lds_gather(g, p->dtype, x, out))) || !can_plane;
+        if (g_policy == 0 && g_flat == 2 && wkind == p->dtype && flat_forward_eligible(g, p->dtype, x, out)) {   // (knob 27 = 2: tests)
+            g_last_path = SHIFTND_PATH_PLANE;
+            return finish(flat_forward(g, p->dtype, x, w, wkind, out, st));
+        }
         // 2-D sparse shift / quantized forward as a linear sweep of one-step workgroups
         if (g_policy == 0 && (g.nd == 2 || wkind <= SHIFTND_BF16) && step_forward_eligible(g, p->dtype, x, out)) {
             g_last_path = SHIFTND_PATH_SWEEP;
@@ -101,6 +120,13 @@ int forward_common(const shiftnd_problem *p, const void *x, const int64_t *xs, c
         if (g_policy == 0 && wkind == p->dtype && !step_forward_lds_eligible(g, p->dtype, x, out) && span_forward_eligible(g, p->dtype, x, out)) {
             g_last_path = SHIFTND_PATH_PLANE;
             return finish(span_forward(g, p->dtype, x, w, wkind, out, st));
+        }
+        // rows that are not whole 16-byte pieces (14 x 14, 62 x 62, 222 x 222 ...; float tensors): one-step workgroups over the
+        // tensor's flat chunk stream
+        // (... and windows the chunk kernels asked above did not take: output planes that are not whole pieces)
+        if (g_policy == 0 && wkind == p->dtype && (g_flat == 2 || ragged_rows(g, p->dtype) || cropped(g)) && flat_forward_eligible(g, p->dtype, x, out)) {
+            g_last_path = SHIFTND_PATH_PLANE;
+            return finish(flat_forward(g, p->dtype, x, w, wkind, out, st));
         }
         // 1-byte (and, knob 28, 2-byte) rows of whole 16-byte pieces beyond the byte kernel's small planes: rows through LDS
         if (g_policy == 0 && !bytes_forward_eligible(g, p->dtype, x, out) && rows_forward_eligible(g, p->dtype, x, out)) {
@@ -184,7 +210,8 @@ int shiftnd_last_path(void) { return g_last_path; }
 void shiftnd_set_path_policy(int policy) { g_policy = policy; }
 
 void shiftnd_set_tuning(int knob, int value) {
-    if (knob >= 38) step_set_tuning(4 + knob - 38, value);  // 38: planes per workgroup of the walk kernels
+    if (knob == 27) { g_flat = value; flat_set_tuning(value); }   // 27: the flat-stream kernels 0 automatic (ragged rows) / 1 never / 2 whenever eligible
+    else if (knob >= 38) step_set_tuning(4 + knob - 38, value);  // 38: planes per workgroup of the walk kernels
     else if (knob >= 36) qpool_set_tuning(knob - 36, value);  // 36: quantized pool 0 automatic / 1 the element-per-thread kernel only
     else if (knob >= 32) step_set_tuning(knob - 32, value);  // 32: one-step backward 0 automatic / 1 never / 2 whenever eligible
     else if (knob >= 28) rows_set_tuning(knob - 28, value);  // 28: element sizes served (bit 0: 1 byte, bit 1: 2 bytes), 29: rows per band, 30: workgroups
@@ -306,10 +333,12 @@ size_t shiftnd_backward_workspace_bytes(const shiftnd_problem *p) {
     const size_t e = cl_tiled_backward_workspace(g);
     const size_t f = small_backward_workspace(g, p->dtype);
     const size_t h = cl_tiled3_backward_workspace(g);
+    const size_t fl = flat_backward_workspace(g);
     size_t m = a > b ? (a > c ? a : c) : (b > c ? b : c);
     m = m > d ? m : d;
     m = m > e ? m : e;
     m = m > h ? m : h;
+    m = m > fl ? m : fl;
     return m > f ? m : f;
 }
 
@@ -331,6 +360,11 @@ int shiftnd_backward(const shiftnd_problem *p, const void *grad_out, const int64
         return SHIFTND_OK;
     }
     if (!grad_out || !x || !weights || !grad_x || !grad_w || !workspace) return SHIFTND_ERR_INVALID_ARGUMENT;
+    if (g_policy == 0 && g_flat == 2 && flat_backward_eligible(g, p->dtype, grad_out, x, grad_x)) {   // (knob 27 = 2: tests)
+        if (flat_backward_workspace(g) > workspace_bytes) return SHIFTND_ERR_WORKSPACE_TOO_SMALL;
+        g_last_path = SHIFTND_PATH_PLANE;
+        return finish(flat_backward(g, p->dtype, grad_out, x, weights, grad_x, grad_w, workspace, st));
+    }
     const bool can_sweep = sweep_backward_eligible(g, p->dtype, grad_out, x, grad_x);
     const bool can_plane = plane_backward_eligible(g, p->dtype, grad_out, x, grad_x);
     if ((g_policy == 2 && !can_plane) || (g_policy == 3 && !can_sweep)) return SHIFTND_ERR_INVALID_ARGUMENT;
@@ -340,6 +374,13 @@ int shiftnd_backward(const shiftnd_problem *p, const void *grad_out, const int64
         if (sweep_backward_workspace(g, p->dtype) > workspace_bytes) return SHIFTND_ERR_WORKSPACE_TOO_SMALL;
         g_last_path = SHIFTND_PATH_SWEEP;
         return finish(sweep_backward(g, p->dtype, grad_out, x, weights, grad_x, grad_w, workspace, st));
+    }
+    // ragged input rows -- and windows crop_backward does not take (a gradient that is not a whole number of pieces): the flat chunk stream
+    if (g_policy == 0 && (g_flat == 2 || ragged_rows(g, p->dtype) || (cropped(g) && !span_backward_eligible(g, p->dtype, grad_out, x, grad_x))) &&
+        flat_backward_eligible(g, p->dtype, grad_out, x, grad_x)) {
+        if (flat_backward_workspace(g) > workspace_bytes) return SHIFTND_ERR_WORKSPACE_TOO_SMALL;
+        g_last_path = SHIFTND_PATH_PLANE;
+        return finish(flat_backward(g, p->dtype, grad_out, x, weights, grad_x, grad_w, workspace, st));
     }
     if (can_plane && g_policy != 1 && g_policy != 4) {
         if (plane_backward_workspace(g, p->dtype) > workspace_bytes) return SHIFTND_ERR_WORKSPACE_TOO_SMALL;

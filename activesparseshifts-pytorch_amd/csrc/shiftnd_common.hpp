@@ -366,6 +366,30 @@ __global__ __launch_bounds__(64) void reduce_weight_grads(const double *__restri
 }  // namespace
 
 // ---------------------------------------------------------------------------------------------
+// buffer_store_dwordx4 with the row / plane offset in an SGPR (soffset).  gfx950 reads the 128 bits of store data over more than
+// one cycle: a VALU instruction that overwrites one of the data registers in the very next issue slot corrupts what is stored.
+// LLVM's hazard recognizer (GCNHazardRecognizer::createsVALUHazard) inserts the wait state for a MUBUF store of more than 64 bits
+// only when soffset is NOT a register; with a register soffset nothing separated
+//     buffer_store_dwordx4 v[2:5], v73, s[24:27], s56 offen nt
+//     v_cndmask_b32_e64 v2, 0, -1, s[16:17]          <- loop bookkeeping the scheduler placed in the store's shadow
+// in walk_backward16<.., ZEROS = false> (hipcc 7.2, -O3): non-deterministic zeros in grad_x whenever the memory pipeline was busy
+// enough to delay the data read -- several workgroups per CU -- and never on small shapes.  Round 4 took it for an LDS race and
+// "fixed" it with waits and compiler barriers around __syncthreads(), which moved the v_cndmask 14 instructions away by accident.
+// Round 5: tools/isa_barriers.py + an instruction diff of the two builds found the pair; a build with bare barriers and
+// `s_nop 1` behind the store is clean on the shapes the bare build fails 20 times out of 20 (tools/race_probe.py;
+// profiles/r05_walk_race.txt).  The asm's input operand keeps the data registers live up to the wait states.
+// SHIFTND_DIAG_NO_STORE_NOP reproduces the failure.
+// ---------------------------------------------------------------------------------------------
+typedef uint32_t shiftnd_u4 __attribute__((ext_vector_type(4)));
+template <int AUX>   // cache-policy bits of the instruction (2 = nontemporal)
+__device__ __forceinline__ void buffer_store_b128_soffset(shiftnd_u4 data, __amdgpu_buffer_rsrc_t rsrc, uint32_t voffset, uint32_t soffset) {
+    __builtin_amdgcn_raw_buffer_store_b128(data, rsrc, voffset, soffset, AUX);
+#ifndef SHIFTND_DIAG_NO_STORE_NOP
+    asm volatile("s_nop 1" ::"v"(data));
+#endif
+}
+
+// ---------------------------------------------------------------------------------------------
 // Raw element / chunk I/O shared by the kernel families.
 // ---------------------------------------------------------------------------------------------
 template <int ESIZE> struct raw_t;

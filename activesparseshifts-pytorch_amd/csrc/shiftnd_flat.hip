@@ -1,0 +1,766 @@
+// shiftnd_flat.hip -- contiguous 1-D / 2-D problems whose rows are NOT whole 16-byte pieces, as one-step workgroups over the
+// tensor's FLAT stream of 16-byte chunks; gfx950 (MI355X), round 5.  DESIGN section 3.19.
+//
+// The shapes: the deep stages of every ImageNet network (14 x 14 and 7 x 7 planes: 56- / 28-byte fp32 rows), odd image sizes
+// (113, 225, 299 ...), and the OUTPUT of every cropped shift as the next layer's input (62 x 62, 222 x 222: the reference's
+// emulate_dw modules cut one element per side, modules/shifts.py:41-46, tests/shifts_test.py:9-28).  The chunk kernels need rows of
+// whole pieces; until round 5 these shapes ran per-channel kernels with element-wide loads at 2 - 3 TB/s (shiftnd_small.hip).
+//
+// A contiguous NC[H]W tensor is one stream of planes: plane p = (n, c) starts at byte p x plane_bytes, at no particular alignment,
+// but the TENSOR starts 16-byte aligned.  A workgroup owns ONE step = 256 consecutive chunks (4 KB) of the flat output (forward) /
+// grad_x (backward) stream and the grid is every step in memory order (XCD k owns the k-th eighth: shiftnd_step.hip's rule).
+//   * small planes (the source planes of a step fit the LDS budget): the step's planes p_a .. p_b of the SOURCE tensor(s) are one
+//     contiguous byte range -- staged by LDS-DMA (global_load_lds, 16-byte pieces, lane-linear: no decode at all), whatever the
+//     channels' shifts are; every padding's sources lie inside (a plane is its own padding domain);
+//   * large planes (a step touches at most two): per plane the contiguous range of source ROWS the step's rows read under zeros /
+//     border padding (the unfolded row range clamped into the plane); rows the periodic / reflecting paddings fold elsewhere --
+//     a few rows at the top and bottom of a plane -- are read from memory by the elements that need them;
+//   * a thread produces one output chunk = E elements that may straddle rows and planes: (plane, row, column) of the first
+//     element by two multiply-shift divisions, the others by carries; every element is a map lookup (arithmetic: fold_index) and
+//     an LDS read at its own address -- the same code for every position, no divergent edge path;
+//   * per-plane parameters (canonical shifts, fractions, LDS bases) sit in a small LDS table filled by the first threads while
+//     the DMA is in flight; a chunk reads its plane's entry and the next one's.
+// Backward: reference semantics of kernels/shifts_kernels.h:222-327 (the window: :271, :295-297, :314-324).  Weight gradients in
+// the multilinear form (shiftnd_common.hpp): per chunk and plane two fp32 sums of g x corner difference, parked in LDS, added per
+// plane by 16-lane groups in a fixed order (fp64) into one record per (step, plane); flat_reduce adds a channel's records in a
+// fixed order and applies the blends once.  Deterministic, no atomics.
+// Forward: kernels/shifts_kernels.h:156-220.  Roofline: HBM, 2 x s bytes per element forward, 3 x s backward.
+#include "shiftnd_step.hpp"
+
+namespace shiftnd {
+namespace {
+
+constexpr int kMaxPlanes = 72;             // planes a step may touch (small planes: 4096 / plane bytes + 2)
+constexpr int kCoverBudget = 24 * 1024;    // LDS bytes per staged tensor
+
+struct FlatDesc {   // per channel, written by flat_prep (backward)
+    int cx1, cx2;   // canonical shifts of the input's row / column maps (sizes S1, S2)
+    int cg1, cg2;   // ... of the gradient's maps (the window's sizes O1, O2; sparse shift: the opposite direction)
+    double dw[2];   // fractions of prep_shift_backward (row, column), exactly as the compute type holds them
+};
+
+struct FlatParams {
+    const void *x;        // forward: input; backward: saved input
+    const void *go;       // backward: incoming gradient
+    void *out;            // forward: output; backward: grad_x
+    const void *w;
+    FlatDesc *desc;       // backward: [C]
+    double *partials;     // backward: [total_steps + planes][2]
+    int wkind, C, pad, nd;
+    int S1, S2, O1, O2, L1, L2;
+    uint32_t XP, OP;      // elements per plane of x / of out (grad_out)
+    uint32_t total;       // elements of the streamed tensor (forward: out; backward: grad_x)
+    uint32_t planes;      // N * C
+    uint32_t total_steps, steps_per_xcd;
+    FastDiv d_SP, d_SR;   // the streamed tensor's plane elements / row length
+    FastDiv d_C, d_per1, d_per2, d_pero1, d_pero2;
+    uint32_t x_bytes, go_bytes;   // sizes of the staged tensors (the last piece of a cover may reach past the end: see stage())
+};
+
+template <typename S> __device__ __forceinline__ S lds_at(const char *smem, int off) { return *reinterpret_cast<const S *>(smem + off); }
+
+__device__ __forceinline__ int imap(int p, int cs, int len, int pad) { return len == 1 ? 0 : fold_index(p - cs, len, pad); }
+
+// one plane's parameters as the element loop reads them
+template <typename CT> struct PlaneRec {
+    int c1, c2;      // canonical shifts of the map the kernel gathers the FIRST staged tensor through (x)
+    int g1, g2;      // backward: ... the gradient through
+    int xb, gb;      // LDS byte offset of the plane's element (0, 0) in the staged cover of x / of the gradient (may be negative: rows before the cover)
+    int xr0, xr1;    // staged rows of x (large planes; small planes: 0 .. S1 - 1)
+    int gr0, gr1;    // ... of the gradient
+    CT f1, f2;       // fractions (row, column)
+};
+
+// cover of rows [r0, r1] of plane pl (elements per plane P, row length R): 16-byte pieces [first, first + n) of the tensor
+struct Cover {
+    uint32_t first;   // first piece (byte offset >> 4)
+    int n;            // pieces (0: nothing)
+    int base;         // LDS byte offset of the plane's element (0, 0), relative to the cover's first staged byte
+};
+template <int ES> __device__ __forceinline__ Cover row_cover(uint32_t pl, uint32_t P, int R, int r0, int r1) {
+    Cover c;
+    if (r1 < r0) {
+        c.first = 0;
+        c.n = 0;
+        c.base = 0;
+        return c;
+    }
+    const uint64_t b0 = (static_cast<uint64_t>(pl) * P + static_cast<uint64_t>(r0) * R) * ES, b1 = (static_cast<uint64_t>(pl) * P + static_cast<uint64_t>(r1 + 1) * R) * ES;
+    c.first = static_cast<uint32_t>(b0 >> 4);
+    c.n = static_cast<int>(((b1 + 15) >> 4) - (b0 >> 4));
+    c.base = static_cast<int>(b0 & 15) - r0 * R * ES;
+    return c;
+}
+
+// LDS-DMA of pieces [first, first + n) of `src` to smem + dst (16-byte aligned), lane-linear; every thread of the workgroup calls it.
+// The last piece of a tensor whose size is not a multiple of 16 reaches up to 15 bytes past its end: inside the same aligned
+// 16-byte granule as its last valid byte, hence inside the same page -- never a fault; the bytes are never used.
+__device__ __forceinline__ void stage(const void *src, uint32_t first, int n, char *smem, int dst) {
+    const int tid = static_cast<int>(threadIdx.x);
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const char *base = static_cast<const char *>(src) + (static_cast<uint64_t>(first) << 4);
+    for (int k = 0; k * kThreads < n; ++k) {   // (uniform trip count)
+        const int q = k * kThreads + tid;
+        if (q < n) {
+            char *dst_wave = smem + dst + (k * kThreads + wave * 64) * 16;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(base + static_cast<uint32_t>(q) * 16u),
+                                             (__attribute__((address_space(3))) void *)dst_wave, 16, 0, 0);
+        }
+    }
+}
+
+// the unfolded source rows [a, b] of a plane clamped into it (exact for zeros and border padding); empty when zeros padding puts
+// every row outside
+__device__ __forceinline__ void clamp_rows(int a, int b, int len, bool zeros, int &r0, int &r1) {
+    if (zeros && (b < 0 || a >= len)) {
+        r0 = 0;
+        r1 = -1;
+        return;
+    }
+    r0 = a < 0 ? 0 : (a >= len ? len - 1 : a);
+    r1 = b < 0 ? 0 : (b >= len ? len - 1 : b);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// flat_forward<T, ACTIVE, PADZ, SMALL>: PADZ = zeros padding (validity is two unsigned compares), else the padding mode is a run-time
+// value folded per element; SMALL = the whole source planes of a step are staged.
+// LDS: [plane table][cover of x]
+// ---------------------------------------------------------------------------------------------------------------------
+template <typename T, bool ACTIVE, bool PADZ, bool SMALL>
+__global__ __launch_bounds__(kThreads) void flat_forward(const FlatParams p) {
+    using S = typename T::S;
+    using CT = typename T::C;
+    constexpr int ES = sizeof(S);
+    constexpr int E = 16 / ES;
+    using Rec = PlaneRec<CT>;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    Rec *table = reinterpret_cast<Rec *>(smem);
+    constexpr int TAB = ((SMALL ? kMaxPlanes : 2) * static_cast<int>(sizeof(Rec)) + 15) & ~15;
+    const int COV = TAB;   // LDS offset of the cover
+
+    const uint32_t bid = (blockIdx.x & 7u) * p.steps_per_xcd + (blockIdx.x >> 3);
+    if (bid >= p.total_steps) return;
+    const int tid = static_cast<int>(threadIdx.x);
+    const int S1 = p.S1, S2 = p.S2, O1 = p.O1, O2 = p.O2, L1 = p.L1, L2 = p.L2, pad = p.pad;
+    const uint32_t f0 = bid * static_cast<uint32_t>(kThreads * E);                                  // first element of the step
+    const uint32_t f1 = min(p.total, f0 + static_cast<uint32_t>(kThreads * E)) - 1u;                // ... and its last
+    const uint32_t plA = fdiv(f0, p.d_SP), plB = fdiv(f1, p.d_SP);
+    const int nplanes = static_cast<int>(plB - plA) + 1;
+
+    auto channel = [&](uint32_t pl, int &c1, int &c2, CT &fr1, CT &fr2) {   // the plane's shifts (shifts_cpu.cpp:223-224), canonical
+        const int c = static_cast<int>(pl - fdiv(pl, p.d_C) * static_cast<uint32_t>(p.C));
+        CT wv[3];
+        load_weights_nd<CT>(p.w, p.wkind, c, p.nd, wv);
+        const CT r1 = ACTIVE ? c_floor<CT>(wv[1]) : c_rint<CT>(wv[1]), r2 = ACTIVE ? c_floor<CT>(wv[2]) : c_rint<CT>(wv[2]);
+        fr1 = ACTIVE ? wv[1] - r1 : CT(0);
+        fr2 = ACTIVE ? wv[2] - r2 : CT(0);
+        c1 = canon_shift(static_cast<int64_t>(r1), S1, pad, p.d_per1);
+        c2 = canon_shift(static_cast<int64_t>(r2), S2, pad, p.d_per2);
+    };
+
+    if constexpr (SMALL) {
+        const Cover cv = row_cover<ES>(plA, p.XP, S2, 0, static_cast<int>((plB - plA + 1) * static_cast<uint32_t>(S1)) - 1);   // planes plA .. plB whole
+        stage(p.x, cv.first, cv.n, smem, COV);
+        if (tid < nplanes) {
+            Rec r;
+            channel(plA + tid, r.c1, r.c2, r.f1, r.f2);
+            r.xb = COV + cv.base + tid * static_cast<int>(p.XP) * ES;
+            r.xr0 = 0;
+            r.xr1 = S1 - 1;
+            r.g1 = r.g2 = r.gb = r.gr0 = r.gr1 = 0;
+            table[tid] = r;
+        }
+    } else {
+        // at most two planes; every thread evaluates both (uniform: scalar loads, scalar arithmetic)
+        int used = 0;
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const uint32_t pl = plA + k;
+            Rec r;
+            channel(min(pl, p.planes - 1), r.c1, r.c2, r.f1, r.f2);
+            // output rows of this plane inside the step
+            const uint32_t lo = k == 0 ? f0 - plA * p.OP : 0u, hi = (k == 0 && plB == plA) || k == 1 ? f1 - pl * p.OP : p.OP - 1u;
+            const int i0 = static_cast<int>(fdiv(lo, p.d_SR)), i1 = static_cast<int>(fdiv(hi, p.d_SR));
+            int r0 = 0, r1 = -1;
+            if (k < nplanes) clamp_rows(S1 == 1 ? 0 : i0 + L1 - r.c1, S1 == 1 ? 0 : i1 + L1 - r.c1 + (ACTIVE ? 1 : 0), S1, PADZ, r0, r1);
+            const Cover cv = row_cover<ES>(pl, p.XP, S2, r0, r1);
+            stage(p.x, cv.first, cv.n, smem, COV + used);
+            r.xb = COV + used + cv.base;
+            r.xr0 = r0;
+            r.xr1 = r1;
+            r.g1 = r.g2 = r.gb = r.gr0 = r.gr1 = 0;
+            used += cv.n * 16;
+            if (tid == k) table[k] = r;
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    const uint32_t f = f0 + static_cast<uint32_t>(tid * E);
+    if (f >= p.total) return;
+    const uint32_t pl = fdiv(f, p.d_SP);
+    const uint32_t r = f - pl * p.OP;
+    int i = static_cast<int>(fdiv(r, p.d_SR));
+    int j = static_cast<int>(r) - i * O2;
+    const int slot = static_cast<int>(pl - plA);
+    const Rec D0 = table[slot], D1 = table[min(slot + 1, nplanes - 1)];
+    const int ecut = static_cast<int>(min(static_cast<uint32_t>(E), p.OP - r));   // elements of this chunk in plane pl
+    const S *xg = static_cast<const S *>(p.x);
+    const S zero = static_cast<S>(0.0f);
+    Chunk<S, E> res;
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        const bool first = e < ecut;
+        const int c1 = first ? D0.c1 : D1.c1, c2 = first ? D0.c2 : D1.c2, xb = first ? D0.xb : D1.xb;
+        const uint32_t ple = first ? pl : pl + 1u;
+        auto tap = [&](int a, int b) -> S {   // source element (row a, column b), unfolded coordinates
+            if constexpr (PADZ) {
+                const bool ok = static_cast<unsigned>(a) < static_cast<unsigned>(S1) && static_cast<unsigned>(b) < static_cast<unsigned>(S2);
+                const S v = lds_at<S>(smem, ok ? xb + (a * S2 + b) * ES : 0);
+                return ok ? v : zero;
+            } else {
+                const int ar = S1 == 1 ? 0 : fold_index(a, S1, pad), bc = S2 == 1 ? 0 : fold_index(b, S2, pad);
+                if constexpr (SMALL) {
+                    return lds_at<S>(smem, xb + (ar * S2 + bc) * ES);
+                } else {
+                    const int xr0 = first ? D0.xr0 : D1.xr0, xr1 = first ? D0.xr1 : D1.xr1;
+                    if (ar >= xr0 && ar <= xr1) return lds_at<S>(smem, xb + (ar * S2 + bc) * ES);
+                    return xg[static_cast<uint64_t>(ple) * p.XP + static_cast<uint32_t>(ar * S2 + bc)];   // a row the padding folds out of the cover
+                }
+            }
+        };
+        const int a = S1 == 1 ? 0 : i + L1 - c1, b = S2 == 1 ? 0 : j + L2 - c2;
+        if constexpr (ACTIVE) {
+            const CT fr[2] = {first ? D0.f1 : D1.f1, first ? D0.f2 : D1.f2};
+            const int a1 = S1 == 1 ? 0 : a + 1, b1 = S2 == 1 ? 0 : b + 1;
+            if (p.nd == 1) {   // (uniform) Shift1d: interp1D of the two column corners (interpolation.h:3-7)
+                const CT v[2] = {widen<T>(tap(a, b)), widen<T>(tap(a, b1))};
+                res.e[e] = narrow<T>(interp_t<T, 1>(v, fr + 1));
+            } else {
+                const CT v[4] = {widen<T>(tap(a, b)), widen<T>(tap(a1, b)), widen<T>(tap(a, b1)), widen<T>(tap(a1, b1))};
+                res.e[e] = narrow<T>(interp_t<T, 2>(v, fr));
+            }
+        } else {
+            res.e[e] = tap(a, b);
+        }
+        ++j;
+        if (j == O2) {
+            j = 0;
+            ++i;
+            if (i == O1) i = 0;
+        }
+    }
+    S *op = static_cast<S *>(p.out) + f;
+    if (f + E <= p.total) {
+        store_chunk<S, E>(op, res);
+    } else {
+#pragma unroll
+        for (int e = 0; e < E; ++e)
+            if (f + e < p.total) op[e] = res.e[e];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// flat_prep: one thread per channel -- the weight preparation of the reference's backward (shifts_cpu.cpp:242-244)
+// ---------------------------------------------------------------------------------------------------------------------
+template <typename T, bool ACTIVE>
+__global__ __launch_bounds__(kThreads) void flat_prep(const FlatParams p) {
+    using CT = typename T::C;
+    const int c = static_cast<int>(blockIdx.x * kThreads + threadIdx.x);
+    if (c >= p.C) return;
+    const int lead = 3 - p.nd;
+    int64_t sh[3] = {0, 0, 0};
+    CT dw[3] = {CT(0), CT(0), CT(0)};
+    for (int r = 0; r < p.nd; ++r) {
+        const CT wv = load_weight<CT>(p.w, p.wkind, static_cast<int64_t>(c) * p.nd + r);
+        prep_shift_backward<CT>(wv, ACTIVE, sh[r + lead], dw[r + lead]);
+    }
+    FlatDesc d;
+    d.cx1 = canon_shift(sh[1], p.S1, p.pad, p.d_per1);
+    d.cx2 = canon_shift(sh[2], p.S2, p.pad, p.d_per2);
+    d.cg1 = canon_shift(ACTIVE ? sh[1] : -sh[1], p.O1, p.pad, p.d_pero1);
+    d.cg2 = canon_shift(ACTIVE ? sh[2] : -sh[2], p.O2, p.pad, p.d_pero2);
+    d.dw[0] = static_cast<double>(dw[1]);
+    d.dw[1] = static_cast<double>(dw[2]);
+    p.desc[c] = d;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// flat_backward<T, ACTIVE, PADZ, SMALL>.  LDS: [plane table][per-chunk partial sums][cover of x][cover of grad_out]
+// ---------------------------------------------------------------------------------------------------------------------
+template <typename T, bool ACTIVE, bool PADZ, bool SMALL>
+__global__ __launch_bounds__(kThreads) void flat_backward(const FlatParams p, int gcov_off) {
+    using S = typename T::S;
+    using CT = typename T::C;
+    constexpr int ES = sizeof(S);
+    constexpr int E = 16 / ES;
+    using Rec = PlaneRec<CT>;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    Rec *table = reinterpret_cast<Rec *>(smem);
+    constexpr int TAB = ((SMALL ? kMaxPlanes : 2) * static_cast<int>(sizeof(Rec)) + 15) & ~15;
+    constexpr int PART = TAB;                                        // [256][4] CT: (sumA, sumB) of the chunk's first plane, of its second
+    constexpr int XCOV = PART + kThreads * 4 * static_cast<int>(sizeof(CT));
+    const int GCOV = XCOV + gcov_off;                                // (host: the largest x cover of any step, 16-byte aligned)
+
+    const uint32_t bid = (blockIdx.x & 7u) * p.steps_per_xcd + (blockIdx.x >> 3);
+    if (bid >= p.total_steps) return;
+    const int tid = static_cast<int>(threadIdx.x);
+    const int S1 = p.S1, S2 = p.S2, O1 = p.O1, O2 = p.O2, L1 = p.L1, L2 = p.L2, pad = p.pad;
+    const uint32_t f0 = bid * static_cast<uint32_t>(kThreads * E);
+    const uint32_t f1 = min(p.total, f0 + static_cast<uint32_t>(kThreads * E)) - 1u;
+    const uint32_t plA = fdiv(f0, p.d_SP), plB = fdiv(f1, p.d_SP);
+    const int nplanes = static_cast<int>(plB - plA) + 1;
+    const bool cropped = O1 != S1 || O2 != S2;   // (uniform)
+
+    auto fill = [&](uint32_t pl, Rec &r) {
+        const int c = static_cast<int>(pl - fdiv(pl, p.d_C) * static_cast<uint32_t>(p.C));
+        const FlatDesc d = p.desc[c];
+        r.c1 = d.cx1;
+        r.c2 = d.cx2;
+        r.g1 = d.cg1;
+        r.g2 = d.cg2;
+        r.f1 = static_cast<CT>(d.dw[0]);
+        r.f2 = static_cast<CT>(d.dw[1]);
+    };
+    if constexpr (SMALL) {
+        const Cover cx = row_cover<ES>(plA, p.XP, S2, 0, static_cast<int>((plB - plA + 1) * static_cast<uint32_t>(S1)) - 1);
+        const Cover cg = row_cover<ES>(plA, p.OP, O2, 0, static_cast<int>((plB - plA + 1) * static_cast<uint32_t>(O1)) - 1);
+        stage(p.x, cx.first, cx.n, smem, XCOV);
+        stage(p.go, cg.first, cg.n, smem, GCOV);
+        if (tid < nplanes) {
+            Rec r;
+            fill(plA + tid, r);
+            r.xb = XCOV + cx.base + tid * static_cast<int>(p.XP) * ES;
+            r.gb = GCOV + cg.base + tid * static_cast<int>(p.OP) * ES;
+            r.xr0 = 0;
+            r.xr1 = S1 - 1;
+            r.gr0 = 0;
+            r.gr1 = O1 - 1;
+            table[tid] = r;
+        }
+    } else {
+        int usedx = 0, usedg = 0;
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const uint32_t pl = plA + k;
+            Rec r;
+            fill(min(pl, p.planes - 1), r);
+            const uint32_t lo = k == 0 ? f0 - plA * p.XP : 0u, hi = (k == 0 && plB == plA) || k == 1 ? f1 - pl * p.XP : p.XP - 1u;
+            const int i0 = static_cast<int>(fdiv(lo, p.d_SR)), i1 = static_cast<int>(fdiv(hi, p.d_SR));
+            int xr0 = 0, xr1 = -1, gr0 = 0, gr1 = -1;
+            if (k < nplanes) {
+                // rows of the window inside the step's rows (elements outside the window read nothing)
+                const int w0 = max(i0, L1), w1 = min(i1, L1 + O1 - 1);
+                if (w0 <= w1) {
+                    clamp_rows(S1 == 1 ? 0 : w0 - r.c1, S1 == 1 ? 0 : w1 - r.c1 + 1, S1, PADZ, xr0, xr1);
+                    clamp_rows(O1 == 1 ? 0 : w0 - L1 - r.g1, O1 == 1 ? 0 : w1 - L1 - r.g1 + (ACTIVE ? 1 : 0), O1, PADZ, gr0, gr1);
+                }
+            }
+            const Cover cx = row_cover<ES>(pl, p.XP, S2, xr0, xr1), cg = row_cover<ES>(pl, p.OP, O2, gr0, gr1);
+            stage(p.x, cx.first, cx.n, smem, XCOV + usedx);
+            stage(p.go, cg.first, cg.n, smem, GCOV + usedg);
+            r.xb = XCOV + usedx + cx.base;
+            r.gb = GCOV + usedg + cg.base;
+            r.xr0 = xr0;
+            r.xr1 = xr1;
+            r.gr0 = gr0;
+            r.gr1 = gr1;
+            usedx += cx.n * 16;
+            usedg += cg.n * 16;
+            if (tid == k) table[k] = r;
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    const uint32_t f = f0 + static_cast<uint32_t>(tid * E);
+    const bool mine = f < p.total;
+    CT sums[4] = {CT(0), CT(0), CT(0), CT(0)};
+    if (mine) {
+        const uint32_t pl = fdiv(f, p.d_SP);
+        const uint32_t r = f - pl * p.XP;
+        int i = static_cast<int>(fdiv(r, p.d_SR));
+        int j = static_cast<int>(r) - i * S2;
+        const int slot = static_cast<int>(pl - plA);
+        const Rec D0 = table[slot], D1 = table[min(slot + 1, nplanes - 1)];
+        const int ecut = static_cast<int>(min(static_cast<uint32_t>(E), p.XP - r));
+        const S *xg = static_cast<const S *>(p.x), *gg = static_cast<const S *>(p.go);
+        const S zero = static_cast<S>(0.0f);
+        // the gradient at the output positions themselves.  Small planes: from the staged planes; large planes: from memory --
+        // without a crop grad_out has grad_x's own geometry, the chunk is one aligned 16-byte load
+        Chunk<S, E> own;
+        bool own_loaded = false;
+        if constexpr (!SMALL) {
+            if (!cropped && f + E <= p.total) {
+                own = load_chunk<S, E>(gg + f);
+                own_loaded = true;
+            }
+        }
+        Chunk<S, E> res;
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+            const bool first = e < ecut;
+            const int c1 = first ? D0.c1 : D1.c1, c2 = first ? D0.c2 : D1.c2, g1 = first ? D0.g1 : D1.g1, g2 = first ? D0.g2 : D1.g2;
+            const int xb = first ? D0.xb : D1.xb, gb = first ? D0.gb : D1.gb;
+            const uint32_t ple = first ? pl : pl + 1u;
+            const int io = i - L1, jo = j - L2;   // the element in grad_out's coordinates
+            const bool inside = static_cast<unsigned>(io) < static_cast<unsigned>(O1) && static_cast<unsigned>(jo) < static_cast<unsigned>(O2) && f + e < p.total;
+            auto xtap = [&](int a, int b) -> S {
+                if constexpr (PADZ) {
+                    const bool ok = inside && static_cast<unsigned>(a) < static_cast<unsigned>(S1) && static_cast<unsigned>(b) < static_cast<unsigned>(S2);
+                    const S v = lds_at<S>(smem, ok ? xb + (a * S2 + b) * ES : 0);
+                    return ok ? v : zero;
+                } else {
+                    const int ar = S1 == 1 ? 0 : fold_index(a, S1, pad), bc = S2 == 1 ? 0 : fold_index(b, S2, pad);
+                    if constexpr (SMALL) {
+                        const S v = lds_at<S>(smem, inside ? xb + (ar * S2 + bc) * ES : 0);
+                        return inside ? v : zero;
+                    } else {
+                        if (!inside) return zero;
+                        const int xr0 = first ? D0.xr0 : D1.xr0, xr1 = first ? D0.xr1 : D1.xr1;
+                        if (ar >= xr0 && ar <= xr1) return lds_at<S>(smem, xb + (ar * S2 + bc) * ES);
+                        return xg[static_cast<uint64_t>(ple) * p.XP + static_cast<uint32_t>(ar * S2 + bc)];
+                    }
+                }
+            };
+            auto gtap = [&](int a, int b) -> S {   // grad_out (row a, column b), its own unfolded coordinates
+                if constexpr (PADZ) {
+                    const bool ok = inside && static_cast<unsigned>(a) < static_cast<unsigned>(O1) && static_cast<unsigned>(b) < static_cast<unsigned>(O2);
+                    const S v = lds_at<S>(smem, ok ? gb + (a * O2 + b) * ES : 0);
+                    return ok ? v : zero;
+                } else {
+                    const int ar = O1 == 1 ? 0 : fold_index(a, O1, pad), bc = O2 == 1 ? 0 : fold_index(b, O2, pad);
+                    if constexpr (SMALL) {
+                        const S v = lds_at<S>(smem, inside ? gb + (ar * O2 + bc) * ES : 0);
+                        return inside ? v : zero;
+                    } else {
+                        if (!inside) return zero;
+                        const int gr0 = first ? D0.gr0 : D1.gr0, gr1 = first ? D0.gr1 : D1.gr1;
+                        if (ar >= gr0 && ar <= gr1) return lds_at<S>(smem, gb + (ar * O2 + bc) * ES);
+                        return gg[static_cast<uint64_t>(ple) * p.OP + static_cast<uint32_t>(ar * O2 + bc)];
+                    }
+                }
+            };
+            // the gradient at the position itself (shifts_kernels.h:271)
+            S gs;
+            if constexpr (SMALL) {
+                const S v = lds_at<S>(smem, inside ? gb + (io * O2 + jo) * ES : 0);
+                gs = inside ? v : zero;
+            } else {
+                if (own_loaded) gs = inside ? own.e[e] : zero;
+                else gs = inside ? gg[static_cast<uint64_t>(ple) * p.OP + static_cast<uint32_t>(io * O2 + jo)] : zero;
+            }
+            const CT g = widen<T>(gs);
+            // the input corners around (i, j) - shift (:274-279) and the two corner differences of the weight gradient
+            const int a = S1 == 1 ? 0 : i - c1, b = S2 == 1 ? 0 : j - c2, a1 = S1 == 1 ? 0 : a + 1, b1 = S2 == 1 ? 0 : b + 1;
+            const CT v0 = widen<T>(xtap(a, b)), v1 = widen<T>(xtap(a1, b)), v2 = widen<T>(xtap(a, b1)), v3 = widen<T>(xtap(a1, b1));
+            const CT dA = v2 - v0, dB = v3 - v1;
+            if (first) {
+                sums[0] = fma_ct(g, dA, sums[0]);
+                sums[1] = fma_ct(g, dB, sums[1]);
+            } else {
+                sums[2] = fma_ct(g, dA, sums[2]);
+                sums[3] = fma_ct(g, dB, sums[3]);
+            }
+            // grad_x (:299-324)
+            const int ga = O1 == 1 ? 0 : io - g1, gbc = O2 == 1 ? 0 : jo - g2;
+            if constexpr (ACTIVE) {
+                const CT fr[2] = {first ? D0.f1 : D1.f1, first ? D0.f2 : D1.f2};
+                const int ga1 = O1 == 1 ? 0 : ga + 1, gb1 = O2 == 1 ? 0 : gbc + 1;
+                S rv;
+                if (p.nd == 1) {
+                    const CT u[2] = {widen<T>(gtap(ga, gbc)), widen<T>(gtap(ga, gb1))};
+                    rv = narrow<T>(interp_t<T, 1>(u, fr + 1));
+                } else {
+                    const CT u[4] = {widen<T>(gtap(ga, gbc)), widen<T>(gtap(ga1, gbc)), widen<T>(gtap(ga, gb1)), widen<T>(gtap(ga1, gb1))};
+                    rv = narrow<T>(interp_t<T, 2>(u, fr));
+                }
+                res.e[e] = inside ? rv : zero;
+            } else {
+                res.e[e] = gtap(ga, gbc);
+            }
+            ++j;
+            if (j == S2) {
+                j = 0;
+                ++i;
+                if (i == S1) i = 0;
+            }
+        }
+        S *op = static_cast<S *>(p.out) + f;
+        if (f + E <= p.total) {
+            store_chunk<S, E>(op, res);
+        } else {
+#pragma unroll
+            for (int e = 0; e < E; ++e)
+                if (f + e < p.total) op[e] = res.e[e];
+        }
+    }
+    // ---- the step's weight-gradient records: one per plane it touches, the chunks' sums added in chunk order -----------------
+    CT *part = reinterpret_cast<CT *>(smem + PART);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) part[tid * 4 + k] = sums[k];
+    __syncthreads();
+    const int grp = tid >> 4, lane = tid & 15;
+    for (int k = grp; k < nplanes; k += kThreads / 16) {
+        const uint32_t pl = plA + static_cast<uint32_t>(k);
+        // the plane's elements inside the step, step-local
+        const uint32_t lo = pl * p.XP > f0 ? pl * p.XP - f0 : 0u;
+        const uint32_t hi = min(f1 - f0, (pl + 1u) * p.XP - 1u - f0);
+        const int tlo = static_cast<int>(lo / E), thi = static_cast<int>(hi / E);
+        double a = 0.0, b = 0.0;
+        for (int t = tlo + lane; t <= thi; t += 16) {
+            // chunk t holds this plane as its first plane unless the plane starts inside it
+            const int sl = (static_cast<uint32_t>(t) * E < lo) ? 2 : 0;
+            a += static_cast<double>(part[t * 4 + sl]);
+            b += static_cast<double>(part[t * 4 + sl + 1]);
+        }
+#pragma unroll
+        for (int off = 8; off >= 1; off >>= 1) {   // fixed tree over the 16 lanes
+            a += __shfl_down(a, off, 16);
+            b += __shfl_down(b, off, 16);
+        }
+        if (lane == 0) {
+            double *rec = p.partials + (static_cast<size_t>(bid) + pl) * 2;
+            rec[0] = a;
+            rec[1] = b;
+        }
+    }
+}
+
+// grad_w[c][:] = blend(sum over the records of channel c's planes, in a fixed order): one wave per channel, lanes over the batch
+template <typename T>
+__global__ __launch_bounds__(64) void flat_reduce(const FlatParams p, int N, typename T::S *__restrict__ grad_w) {
+    using S = typename T::S;
+    constexpr int E = 16 / sizeof(S);
+    const int c = blockIdx.x;
+    double a = 0.0, b = 0.0;
+    for (int n = threadIdx.x; n < N; n += 64) {
+        const uint64_t pl = static_cast<uint64_t>(n) * p.C + c;
+        const uint64_t e0 = pl * p.XP, e1 = e0 + p.XP - 1;
+        const uint64_t s0 = e0 / (kThreads * E), s1 = e1 / (kThreads * E);
+        for (uint64_t s = s0; s <= s1; ++s) {
+            const double *rec = p.partials + (s + pl) * 2;
+            a += rec[0];
+            b += rec[1];
+        }
+    }
+    a = wave_sum(a);
+    b = wave_sum(b);
+    if (threadIdx.x == 0) {
+        const FlatDesc d = p.desc[c];
+        double out[2];
+        if (p.nd == 1) {
+            out[0] = a;   // 1-D: the one partial is the column difference (interp1D_dx, interpolation.h:10-13)
+            out[1] = 0.0;
+        } else {
+            const double s[2] = {a, b};
+            blend_diffs<2>(s, d.dw, out);
+        }
+        for (int k = 0; k < p.nd; ++k) {
+            if constexpr (sizeof(S) == 8) grad_w[c * p.nd + k] = out[k];
+            else grad_w[c * p.nd + k] = narrow<T>(static_cast<float>(out[k]));
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------------------------------------
+struct FlatPlan {
+    bool ok, small;
+    size_t lds;        // dynamic LDS bytes
+    int gcov_off;      // backward: offset of the gradient's cover behind the x cover
+    uint64_t steps;
+};
+
+// ceil-ish bound of the cover of `planes_max` whole planes / of (rows + extra) rows, in bytes, 16-byte pieces
+inline int64_t cover_bytes(int64_t payload) { return ((payload + 15 + 15) / 16) * 16; }
+
+// backward = true: the streamed tensor has x's geometry (S), staged: x (S) and grad_out (O); forward: streamed out (O), staged x (S)
+FlatPlan flat_plan(const Geometry &g, int es, bool backward) {
+    FlatPlan pl{};
+    const int E = 16 / es;
+    const int64_t S1 = g.S[1], S2 = g.S[2], O1 = g.O[1], O2 = g.O[2];
+    const int64_t XPB = S1 * S2 * es, OPB = O1 * O2 * es;
+    const int64_t SPB = backward ? XPB : OPB;          // plane bytes of the streamed tensor
+    const int64_t total = g.N * g.C * (backward ? S1 * S2 : O1 * O2);
+    pl.steps = static_cast<uint64_t>((total + kThreads * E - 1) / (kThreads * E));
+    const int64_t step_bytes = kThreads * 16;
+    const int64_t nplanes = (step_bytes + SPB - 1) / SPB + 1;                 // planes a step can touch
+    const int rec = es == 8 ? 56 : 48;   // sizeof(PlaneRec<CT>)
+    // small: whole planes of every staged tensor
+    const int64_t cx_small = cover_bytes(nplanes * XPB), cg_small = cover_bytes(nplanes * OPB);
+    if (nplanes <= kMaxPlanes && cx_small <= kCoverBudget && (!backward || cg_small <= kCoverBudget)) {
+        pl.ok = true;
+        pl.small = true;
+        const int64_t tab = ((kMaxPlanes * rec + 15) / 16) * 16;
+        pl.gcov_off = static_cast<int>(cx_small);
+        pl.lds = static_cast<size_t>(tab + (backward ? kThreads * 4 * (es == 8 ? 8 : 4) + cx_small + cg_small : cx_small));
+        return pl;
+    }
+    // large: at most two planes per step, row ranges
+    if (SPB < step_bytes) return pl;
+    const int64_t SR = backward ? S2 : O2;                                     // row length of the streamed tensor
+    const int64_t rows = (kThreads * E + SR - 2) / SR + 1;                     // rows a step can touch (both planes together: + 1)
+    // per plane (rows_k + 1 (+1)) source rows; two planes: rows + 1 + 2 * 2
+    const int64_t cx_large = cover_bytes((rows + 5) * S2 * es) + 32, cg_large = cover_bytes((rows + 5) * O2 * es) + 32;
+    if (cx_large > kCoverBudget || (backward && cg_large > kCoverBudget)) return pl;
+    pl.ok = true;
+    pl.small = false;
+    const int64_t tab = ((2 * rec + 15) / 16) * 16;
+    pl.gcov_off = static_cast<int>(cx_large);
+    pl.lds = static_cast<size_t>(tab + (backward ? kThreads * 4 * (es == 8 ? 8 : 4) + cx_large + cg_large : cx_large));
+    return pl;
+}
+
+thread_local int g_flat_tune = 0;   // knob 27: 0 automatic, 1 never, 2 whenever eligible
+
+bool flat_common_ok(const Geometry &g, int dtype, const void *a, const void *b) {
+    if (g_flat_tune == 1) return false;
+    if (dtype > SHIFTND_BF16 || (g.nd != 1 && g.nd != 2) || g.K[0] > 0) return false;
+    if (g.S[0] != 1 || g.O[0] != 1 || g.S[1] < 1 || g.S[2] < 1 || g.O[1] < 1 || g.O[2] < 1 || g.N < 1 || g.C < 1) return false;
+    if (g.nd == 1 && (g.S[1] != 1 || g.O[1] != 1)) return false;
+    const int es = dtype_size(dtype);
+    // 32-bit element and byte arithmetic in the kernels
+    if (g.N * g.C * g.S[1] * g.S[2] * es >= (1LL << 32) || g.N * g.C * g.O[1] * g.O[2] * es >= (1LL << 32)) return false;
+    if (g.N * g.C >= (1LL << 31) || g.S[1] >= (1 << 15) || g.S[2] >= (1 << 15) || g.S[1] * g.S[2] * es >= (1LL << 26)) return false;
+    if (reinterpret_cast<uintptr_t>(a) % 16 || reinterpret_cast<uintptr_t>(b) % 16) return false;
+    return true;
+}
+
+template <typename T, bool SMALL>
+void launch_flat_forward(const FlatParams &p, size_t lds, bool active, bool padz, hipStream_t st) {
+    const dim3 grid(p.steps_per_xcd * 8), block(kThreads);
+    if (active) {
+        if (padz) hipLaunchKernelGGL((flat_forward<T, true, true, SMALL>), grid, block, lds, st, p);
+        else hipLaunchKernelGGL((flat_forward<T, true, false, SMALL>), grid, block, lds, st, p);
+    } else {
+        if (padz) hipLaunchKernelGGL((flat_forward<T, false, true, SMALL>), grid, block, lds, st, p);
+        else hipLaunchKernelGGL((flat_forward<T, false, false, SMALL>), grid, block, lds, st, p);
+    }
+}
+
+template <typename T, bool SMALL>
+void launch_flat_backward(const FlatParams &p, const FlatPlan &pl, bool active, bool padz, int N, void *gw, hipStream_t st) {
+    const dim3 grid(p.steps_per_xcd * 8), block(kThreads);
+    if (active) hipLaunchKernelGGL((flat_prep<T, true>), dim3((p.C + kThreads - 1) / kThreads), block, 0, st, p);
+    else hipLaunchKernelGGL((flat_prep<T, false>), dim3((p.C + kThreads - 1) / kThreads), block, 0, st, p);
+    if (active) {
+        if (padz) hipLaunchKernelGGL((flat_backward<T, true, true, SMALL>), grid, block, pl.lds, st, p, pl.gcov_off);
+        else hipLaunchKernelGGL((flat_backward<T, true, false, SMALL>), grid, block, pl.lds, st, p, pl.gcov_off);
+    } else {
+        if (padz) hipLaunchKernelGGL((flat_backward<T, false, true, SMALL>), grid, block, pl.lds, st, p, pl.gcov_off);
+        else hipLaunchKernelGGL((flat_backward<T, false, false, SMALL>), grid, block, pl.lds, st, p, pl.gcov_off);
+    }
+    hipLaunchKernelGGL((flat_reduce<T>), dim3(p.C), dim3(64), 0, st, p, N, static_cast<typename T::S *>(gw));
+}
+
+void fill_params(FlatParams &p, const Geometry &g, int es, bool backward, const FlatPlan &pl) {
+    p.C = static_cast<int>(g.C);
+    p.pad = g.pad;
+    p.nd = g.nd;
+    p.S1 = static_cast<int>(g.S[1]);
+    p.S2 = static_cast<int>(g.S[2]);
+    p.O1 = static_cast<int>(g.O[1]);
+    p.O2 = static_cast<int>(g.O[2]);
+    p.L1 = static_cast<int>(g.L[1]);
+    p.L2 = static_cast<int>(g.L[2]);
+    p.XP = static_cast<uint32_t>(g.S[1] * g.S[2]);
+    p.OP = static_cast<uint32_t>(g.O[1] * g.O[2]);
+    p.planes = static_cast<uint32_t>(g.N * g.C);
+    p.total = p.planes * (backward ? p.XP : p.OP);
+    p.total_steps = static_cast<uint32_t>(pl.steps);
+    p.steps_per_xcd = (p.total_steps + 7) / 8;
+    p.d_SP = make_fastdiv(backward ? p.XP : p.OP);
+    p.d_SR = make_fastdiv(static_cast<uint32_t>(backward ? p.S2 : p.O2));
+    p.d_C = make_fastdiv(static_cast<uint32_t>(p.C));
+    p.d_per1 = make_fastdiv(static_cast<uint32_t>(map_period(p.S1, p.pad)));
+    p.d_per2 = make_fastdiv(static_cast<uint32_t>(map_period(p.S2, p.pad)));
+    p.d_pero1 = make_fastdiv(static_cast<uint32_t>(map_period(p.O1, p.pad)));
+    p.d_pero2 = make_fastdiv(static_cast<uint32_t>(map_period(p.O2, p.pad)));
+    p.x_bytes = p.planes * p.XP * es;
+    p.go_bytes = p.planes * p.OP * es;
+}
+
+}  // namespace
+
+void flat_set_tuning(int value) { g_flat_tune = value; }
+
+// contiguous 1-D / 2-D float tensors (a window included), any row length; taken automatically where the chunk kernels are not
+// eligible (rows or planes that are not whole 16-byte pieces)
+bool flat_forward_eligible(const Geometry &g, int dtype, const void *x, const void *out) {
+    if (!flat_common_ok(g, dtype, x, out)) return false;
+    if (!dense(g.xs, g.N, g.C, g.S) || !dense(g.os, g.N, g.C, g.O)) return false;
+    return flat_plan(g, dtype_size(dtype), false).ok;
+}
+
+int flat_forward(const Geometry &g, int dtype, const void *x, const void *w, int wkind, void *out, hipStream_t st) {
+    const int es = dtype_size(dtype);
+    const FlatPlan pl = flat_plan(g, es, false);
+    FlatParams p{};
+    p.x = x;
+    p.out = out;
+    p.w = w;
+    p.wkind = wkind;
+    fill_params(p, g, es, false, pl);
+    const bool padz = g.pad == 0, active = g.active != 0;
+    note_kernel(active ? "flat_active_forward" : "flat_gather_forward");
+#define SHIFTND_FLAT_FWD(TT) \
+    if (pl.small) launch_flat_forward<TT, true>(p, pl.lds, active, padz, st); \
+    else launch_flat_forward<TT, false>(p, pl.lds, active, padz, st);
+    switch (dtype) {
+    case SHIFTND_F32: SHIFTND_FLAT_FWD(f32_t) break;
+    case SHIFTND_F64: SHIFTND_FLAT_FWD(f64_t) break;
+    case SHIFTND_F16: SHIFTND_FLAT_FWD(f16_t) break;
+    default: SHIFTND_FLAT_FWD(bf16_t) break;
+    }
+#undef SHIFTND_FLAT_FWD
+    return SHIFTND_OK;
+}
+
+bool flat_backward_eligible(const Geometry &g, int dtype, const void *go, const void *x, const void *gx) {
+    if (!flat_common_ok(g, dtype, x, gx) || reinterpret_cast<uintptr_t>(go) % 16) return false;
+    if (!dense(g.xs, g.N, g.C, g.S) || !dense(g.os, g.N, g.C, g.O) || !dense(g.gs, g.N, g.C, g.S)) return false;
+    return flat_plan(g, dtype_size(dtype), true).ok;
+}
+
+// geometry only: records of the widest plan (2-byte elements: the fewest elements per step is the 8-byte type's)
+size_t flat_backward_workspace(const Geometry &g) {
+    if ((g.nd != 1 && g.nd != 2) || g.N < 1 || g.C < 1 || g.S[1] * g.S[2] < 1) return 0;
+    if (g.N * g.C * g.S[1] * g.S[2] >= (1LL << 32)) return 0;
+    const uint64_t total = static_cast<uint64_t>(g.N) * g.C * g.S[1] * g.S[2];
+    const uint64_t steps = (total + kThreads * 2 - 1) / (kThreads * 2);   // E = 2 (fp64): the most steps
+    auto up = [](size_t v) { return (v + 255) & ~static_cast<size_t>(255); };
+    return up((steps + static_cast<uint64_t>(g.N) * g.C + 1) * 2 * sizeof(double)) + up(static_cast<size_t>(g.C) * sizeof(FlatDesc));
+}
+
+int flat_backward(const Geometry &g, int dtype, const void *go, const void *x, const void *w, void *gx, void *gw, void *workspace,
+                  hipStream_t st) {
+    const int es = dtype_size(dtype);
+    const FlatPlan pl = flat_plan(g, es, true);
+    FlatParams p{};
+    p.x = x;
+    p.go = go;
+    p.out = gx;
+    p.w = w;
+    p.wkind = dtype;
+    fill_params(p, g, es, true, pl);
+    auto up = [](size_t v) { return (v + 255) & ~static_cast<size_t>(255); };
+    p.partials = static_cast<double *>(workspace);
+    p.desc = reinterpret_cast<FlatDesc *>(static_cast<char *>(workspace) + up((pl.steps + static_cast<uint64_t>(g.N) * g.C + 1) * 2 * sizeof(double)));
+    const bool padz = g.pad == 0, active = g.active != 0;
+    note_kernel("flat_backward");
+#define SHIFTND_FLAT_BWD(TT) \
+    if (pl.small) launch_flat_backward<TT, true>(p, pl, active, padz, static_cast<int>(g.N), gw, st); \
+    else launch_flat_backward<TT, false>(p, pl, active, padz, static_cast<int>(g.N), gw, st);
+    switch (dtype) {
+    case SHIFTND_F32: SHIFTND_FLAT_BWD(f32_t) break;
+    case SHIFTND_F64: SHIFTND_FLAT_BWD(f64_t) break;
+    case SHIFTND_F16: SHIFTND_FLAT_BWD(f16_t) break;
+    default: SHIFTND_FLAT_BWD(bf16_t) break;
+    }
+#undef SHIFTND_FLAT_BWD
+    return SHIFTND_OK;
+}
+
+}  // namespace shiftnd

@@ -135,6 +135,16 @@ size_t cl_tiled3_backward_workspace(const Geometry &g);
 int cl_tiled3_backward(const Geometry &g, int dtype, const void *go, const void *x, const void *w, void *gx, void *gw,
                        void *workspace, hipStream_t st);
 
+// ---- rows that are not whole 16-byte pieces as one-step workgroups over the tensor's flat chunk stream (shiftnd_flat.hip, round 5):
+// contiguous 1-D / 2-D float tensors, a window included
+bool flat_forward_eligible(const Geometry &g, int dtype, const void *x, const void *out);
+int flat_forward(const Geometry &g, int dtype, const void *x, const void *w, int wkind, void *out, hipStream_t st);
+bool flat_backward_eligible(const Geometry &g, int dtype, const void *go, const void *x, const void *gx);
+size_t flat_backward_workspace(const Geometry &g);
+int flat_backward(const Geometry &g, int dtype, const void *go, const void *x, const void *w, void *gx, void *gw, void *workspace,
+                  hipStream_t st);
+void flat_set_tuning(int value);   // knob 27: 0 automatic (ragged rows), 1 never, 2 whenever eligible
+
 // ---- whole small planes through LDS (shiftnd_small.hip): interpolating forward and backward of contiguous problems whose
 // rows are not whole 16-byte pieces (planes of at most 16 KiB)
 bool small_forward_eligible(const Geometry &g, int dtype);

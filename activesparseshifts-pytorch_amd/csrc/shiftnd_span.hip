@@ -332,11 +332,10 @@ __global__ __launch_bounds__(kThreads) void crop_backward(const SpanParams p) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
-// span_forward: the forward of the same tensors (kernels/shifts_kernels.h:156-220; weights cuda/shifts_cuda.cu:168-183).  The
-// output window has ragged rows too, so a step is 256 consecutive 16-byte chunks of the OUTPUT plane's byte stream (planes
-// are whole pieces; a chunk may straddle two output rows); the source rows those chunks read are staged as spans of x (which
-// may have ragged rows itself: 62 x 62 inputs).  A chunk inside one output row reads its window through ColState; one that
-// straddles two rows, and one whose columns are not among the staged ones, goes element by element.
+// The forward of the same tensors (kernels/shifts_kernels.h:156-220; weights cuda/shifts_cuda.cu:168-183): crop_forward (2-D
+// windows on source rows of whole pieces) and row_forward (1-D).  The output window has ragged rows, so a step is 256 consecutive
+// 16-byte chunks of the OUTPUT plane's byte stream (planes are whole pieces; a chunk may straddle two output rows).  (Round 4's
+// general form for ragged SOURCE rows, span_forward -- 1100 instructions, 4.2 TB/s -- is gone: shiftnd_flat.hip serves those.)
 // ---------------------------------------------------------------------------------------------------------------------
 struct SpanFwdParams {
     const void *x;
@@ -351,164 +350,9 @@ struct SpanFwdParams {
     FastDiv d_spp, d_C, d_O2, d_P, d_per1, d_per2;
 };
 
-template <typename T, int ND, bool ACTIVE, int PAD>
-__global__ __launch_bounds__(kThreads) void span_forward(const SpanFwdParams p) {
-    using S = typename T::S;
-    using CT = typename T::C;
-    constexpr int ES = sizeof(S);
-    constexpr int E = 16 / ES;
-    constexpr int NCC = 1 << (ND - 1);
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    char *tile = smem + 64;
-
-    const uint32_t bid = (blockIdx.x & 7u) * p.steps_per_xcd + (blockIdx.x >> 3);
-    if (bid >= p.total_steps) return;
-    const uint32_t plane = fdiv(bid, p.d_spp);
-    const int step = static_cast<int>(bid - plane * static_cast<uint32_t>(p.spp));
-    const int c = static_cast<int>(plane - fdiv(plane, p.d_C) * static_cast<uint32_t>(p.C));
-    CT wv[3];
-    load_weights_nd<CT>(p.w, p.wkind, c, p.nd, wv);   // normalised order: (plane,) row, inner
-    CT rr[3], dn[3];
-#pragma unroll
-    for (int k = 0; k < 3; ++k) {   // weights_init_forward: the sparse shift rounds (half to even, as the CPU path), active floors
-        rr[k] = ACTIVE ? c_floor<CT>(wv[k]) : c_rint<CT>(wv[k]);
-        dn[k] = ACTIVE ? wv[k] - rr[k] : CT(0);
-    }
-    const int S1 = p.S1, S2 = p.S2, O2 = p.O2, L1 = p.L1, L2 = p.L2, P = p.P;
-    const int cs1 = ND == 2 ? __builtin_amdgcn_readfirstlane(canon_of<PAD, CT>(rr[1], S1, p.d_per1)) : 0;
-    const int cs2 = __builtin_amdgcn_readfirstlane(canon_of<PAD, CT>(rr[2], S2, p.d_per2));
-    const CT dw[3] = {ND == 2 ? dn[1] : dn[2], dn[2], CT(0)};   // fractions in real-dim order
-
-    // the step's chunks, output rows and source columns
-    const int q0 = step * p.cps, q1 = min(p.ocp, q0 + p.cps);
-    const int F0 = q0 * E, F1 = q1 * E;   // flat elements of the output plane
-    const int r0 = static_cast<int>(fdiv(static_cast<uint32_t>(F0), p.d_O2)), r1 = static_cast<int>(fdiv(static_cast<uint32_t>(F1 - 1), p.d_O2));
-    const int nr = r1 - r0 + 1 + (ACTIVE && ND == 2 ? 1 : 0);   // staged source rows
-    const bool whole = p.wholeP != 0;
-    auto clampi = [](int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); };
-    const int jlo = r0 == r1 ? F0 - r0 * O2 : 0, jhi = r0 == r1 ? F1 - r0 * O2 : O2;   // output columns [jlo, jhi)
-    // (only a column segment staged and the step straddles two output rows -- rows longer than a workgroup pass: nothing is
-    //  staged, its chunks read from memory)
-    const bool none = !whole && r0 != r1;
-    const int c0 = whole || none ? 0 : clampi(jlo + L2 - cs2, 0, S2);
-    const int c1 = whole ? S2 : (none ? 0 : clampi(jhi + L2 - cs2 + (ACTIVE ? 1 : 0), 0, S2));
-    const S *xp = static_cast<const S *>(p.x) + static_cast<int64_t>(plane) * p.x_plane;
-    S *op = static_cast<S *>(p.out) + static_cast<int64_t>(plane) * p.o_plane;
-    const int xph = static_cast<int>((static_cast<uint64_t>(plane) * static_cast<uint64_t>(p.x_plane) * ES) & 15u);
-    const char *xp16 = reinterpret_cast<const char *>(xp) - xph;   // 16-byte aligned (the tensor's base is)
-
-    const int tid = static_cast<int>(threadIdx.x);
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    // slot i = source row of output row r0 + i (window coordinates + L1 through the row map); -1: fill
-    auto slot_row = [&](int i) { return ND == 2 ? row_map_t<PAD>(r0 + i + L1, cs1, S1) : 0; };
-    const int npieces = nr * P;
-    auto stage_round = [&](int k) {
-        const int q = k * kThreads + tid;
-        const int slot = static_cast<int>(fdiv(static_cast<uint32_t>(q), p.d_P));
-        const int piece = q - slot * P;
-        const int row = slot < nr ? slot_row(slot) : -1;
-        const int lo = xph + (row * S2 + c0) * ES, hi = xph + (row * S2 + c1) * ES;
-        const int p0 = lo >> 4, cnt = ((hi + 15) >> 4) - p0;
-        if (q < npieces && row >= 0 && piece < cnt) {
-            char *dst_wave = tile + (k * kThreads + wave * 64) * 16;
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(xp16 + static_cast<int64_t>(p0 + piece) * 16),
-                                             (__attribute__((address_space(3))) void *)dst_wave, 16, 0, 2 /* nt */);
-        }
-    };
-    const int U = (p.cps + kThreads - 1) / kThreads;   // chunks per thread (1; up to 4 for 1-D rows longer than 256 chunks)
-    if (U == 1) {
-#pragma unroll
-        for (int k = 0; k < kSpanRounds; ++k)
-            if (k * kThreads < npieces) stage_round(k);   // uniform
-    } else {
-        for (int k = 0; k * kThreads < npieces; ++k) stage_round(k);
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    // ---- the thread's chunks ---------------------------------------------------------------------------------------------------
-    for (int u = 0; u < U; ++u) {
-    const int q = q0 + tid + u * kThreads;
-    const bool mine = q < q1;
-    const int e0 = q * E;
-    const int r = mine ? static_cast<int>(fdiv(static_cast<uint32_t>(e0), p.d_O2)) : r0;
-    const int j = e0 - r * O2;
-    const bool one_row = j + E <= O2;
-    ColState<E> xm;
-    if constexpr (PAD == 0) {
-        const int first = j + L2 - cs2;
-        xm.base = (first + E < 0 || first >= S2) ? c0 : first;
-        xm.affine = true;
-#pragma unroll
-        for (int e = 0; e <= E; ++e) xm.cm[e] = static_cast<unsigned>(first + e) < static_cast<unsigned>(S2) ? first + e : -1;
-    } else {
-        xm = fold_colstate<E, PAD>(j + L2, cs2, S2);
-    }
-    bool staged = xm.affine;   // every column of the window among the staged ones
-#pragma unroll
-    for (int e = 0; e <= E; ++e) staged = staged && (xm.cm[e] < 0 || (xm.cm[e] >= c0 && xm.cm[e] < c1));
-    staged = staged || whole;
-    if (!mine) continue;
-    S zero;
-    __builtin_memset(&zero, 0, sizeof(S));
-    // column 0 of a staged row within its slot / in memory
-    auto lds_row = [&](int slot, int row) { return tile + slot * P * 16 + ((xph + (row * S2 + c0) * ES) & 15) - c0 * ES; };
-    auto mem_row = [&](int row) { return xp + static_cast<int64_t>(row) * S2; };
-    // one element of source row `slot`, column m (or -1)
-    auto element = [&](int slot, int m) {
-        const int row = slot_row(slot);
-        if (row < 0 || m < 0) return zero;
-        if (whole || (m >= c0 && m < c1)) return reinterpret_cast<const S *>(lds_row(slot, row))[m];
-        return mem_row(row)[m];
-    };
-    Chunk<S, E> res;
-    if (one_row) {
-        CT xv[NCC][E + 1];
-#pragma unroll
-        for (int k = 0; k < (ACTIVE ? NCC : 1); ++k) {   // (the sparse shift reads one row)
-            const int slot = r - r0 + k;
-            const int row = slot_row(slot);
-            S raw[E + 1];
-            span_read<S, E>(lds_row(slot, row), mem_row(row), staged, row >= 0, xm, raw);
-#pragma unroll
-            for (int e = 0; e <= E; ++e) xv[k][e] = widen<T>(raw[e]);
-            if constexpr (!ACTIVE) {
-#pragma unroll
-                for (int e = 0; e < E; ++e) res.e[e] = raw[e];
-            }
-        }
-        if constexpr (ACTIVE) {
-#pragma unroll
-            for (int e = 0; e < E; ++e) {
-                CT v[1 << ND];
-#pragma unroll
-                for (int qq = 0; qq < (1 << ND); ++qq) v[qq] = xv[qq & (NCC - 1)][e + (qq >> (ND - 1))];
-                res.e[e] = narrow<T>(interp_t<T, ND>(v, dw));
-            }
-        }
-    } else {   // the chunk straddles output rows (two, or E of them when a row is one element): element by element
-#pragma unroll
-        for (int e = 0; e < E; ++e) {
-            const int re = static_cast<int>(fdiv(static_cast<uint32_t>(e0 + e), p.d_O2));
-            const int slot = re - r0, je = e0 + e - re * O2;
-            const int m0 = row_map_t<PAD>(je + L2, cs2, S2);
-            if constexpr (ACTIVE) {
-                const int m1 = row_map_t<PAD>(je + L2 + 1, cs2, S2);
-                CT v[1 << ND];
-#pragma unroll
-                for (int qq = 0; qq < (1 << ND); ++qq) v[qq] = widen<T>(element(slot + (qq & (NCC - 1)), (qq >> (ND - 1)) ? m1 : m0));
-                res.e[e] = narrow<T>(interp_t<T, ND>(v, dw));
-            } else {
-                res.e[e] = element(slot, m0);
-            }
-        }
-    }
-    store_chunk<S, E>(op + e0, res);
-    }   // u
-}
-
 // ---------------------------------------------------------------------------------------------------------------------
-// crop_forward: the 2-D cropped forward, lean like crop_backward (span_forward above: 1100 instructions, 45 exec-mask regions,
-// 4.2 / 3.1 TB/s on C2's tensor cut by one element per side).  A step is 256 consecutive 16-byte chunks of the output plane's
+// crop_forward: the 2-D cropped forward, lean like crop_backward (round 4's general span_forward: 1100 instructions, 45 exec-mask
+// regions, 4.2 / 3.1 TB/s on C2's tensor cut by one element per side).  A step is 256 consecutive 16-byte chunks of the output plane's
 // byte stream (the window's rows are ragged: 222 fp32 = 888 bytes); the x rows those chunks read -- whole pieces, at most 256
 // per row -- are staged by LDS-DMA, piece q of the tile = piece (q mod cpr) of source row (q div cpr).  A chunk inside one
 // output row reads its window through ColState; a chunk that straddles rows goes element by element, without branches
@@ -948,6 +792,8 @@ bool span_geometry_ok(const Geometry &g, int dtype) {
 
 // the forward of cropped windows, 1-D rows and ragged rows: dense float tensors whose planes (output) and total size (input)
 // are whole 16-byte pieces
+static bool crop_forward_ok(const Geometry &g, int es);
+
 bool span_forward_eligible(const Geometry &g, int dtype, const void *x, const void *out) {
     if (g_step_tune[2] == 1) return false;   // knob 34 = 1: no forwards through LDS
     if (dtype > SHIFTND_BF16 || (g.nd != 1 && g.nd != 2) || g.K[0] > 0) return false;
@@ -960,28 +806,16 @@ bool span_forward_eligible(const Geometry &g, int dtype, const void *x, const vo
     if (reinterpret_cast<uintptr_t>(x) % 16 || reinterpret_cast<uintptr_t>(out) % 16) return false;
     const SpanFwdPlan s = span_forward_plan(g, es);
     if (!s.ok || s.total + 8 >= (1ull << 31) || s.lds > 64 * 1024) return false;
+    const bool served = g.nd == 1 ? (g.S[2] * es) % 16 == 0 : crop_forward_ok(g, es);   // row_forward / crop_forward
+    if (!served) return false;
     if (g_step_tune[2] >= 2) return true;
     bool crop = false;
     for (int d = 1; d < 3; ++d) crop = crop || g.O[d] != g.S[d] || g.L[d] != 0;
-    // cropped 2-D windows (the aligned ones whose output rows are whole pieces too: the step kernels, asked first) and 1-D rows of
-    // at least 128 chunks (same box, N256 C512 L4096: fp32 0.94 -> 0.69 ms, interpolating 0.84 -> 0.69, fp16 0.44 -> 0.35).  On
-    // request only (knob 34 >= 2): uncropped planes with ragged rows -- N128 C1024 14x14 fp32 0.20 vs 0.052 ms of the small-plane
-    // kernels, N64 C256 62x62 0.125 vs 0.101
-    if (g.nd == 1) return (g.S[2] * es) % 16 == 0 && g.O[2] * es / 16 >= 128;   // row_forward (short rows: the per-channel kernels)
+    // cropped 2-D windows on source rows of whole pieces (the aligned ones whose output rows are whole pieces too: the step kernels,
+    // asked first) and 1-D rows of at least 128 chunks (same box, N256 C512 L4096: fp32 0.94 -> 0.69 ms, interpolating 0.84 -> 0.69,
+    // fp16 0.44 -> 0.35).  Ragged source rows: shiftnd_flat.hip.
+    if (g.nd == 1) return g.O[2] * es / 16 >= 128;   // row_forward (short rows: the per-channel kernels)
     return crop;
-}
-
-template <typename T, int ND>
-static void launch_span_forward(const SpanFwdParams &p, size_t lds, bool active, int pad, hipStream_t st) {
-    const dim3 grid(p.steps_per_xcd * 8), block(kThreads);
-#define SHIFTND_SPAN_FWD(ACT, PADV) \
-    case PADV: hipLaunchKernelGGL((span_forward<T, ND, ACT, PADV>), grid, block, lds, st, p); break;
-    if (active) {
-        switch (pad) { SHIFTND_SPAN_FWD(true, 0) SHIFTND_SPAN_FWD(true, 1) SHIFTND_SPAN_FWD(true, 2) SHIFTND_SPAN_FWD(true, 3) default: SHIFTND_SPAN_FWD(true, 4) }
-    } else {
-        switch (pad) { SHIFTND_SPAN_FWD(false, 0) SHIFTND_SPAN_FWD(false, 1) SHIFTND_SPAN_FWD(false, 2) SHIFTND_SPAN_FWD(false, 3) default: SHIFTND_SPAN_FWD(false, 4) }
-    }
-#undef SHIFTND_SPAN_FWD
 }
 
 // crop_forward: 2-D, source rows of whole pieces (at most 256), at most four staging rounds
@@ -1083,22 +917,7 @@ int span_forward(const Geometry &g, int dtype, const void *x, const void *w, int
 #undef SHIFTND_CROP_FWD
         return SHIFTND_OK;
     }
-    note_kernel(active ? "span_active_forward" : "span_gather_forward");
-#define SHIFTND_SPAN_FT(TT) launch_span_forward<TT, 2>(p, sp.lds, active, g.pad, st)   /* (1-D: row_forward above) */
-    if (!active) {   // a raw copy: one instantiation per element size
-        if (es == 2) SHIFTND_SPAN_FT(f16_t);
-        else if (es == 4) SHIFTND_SPAN_FT(f32_t);
-        else SHIFTND_SPAN_FT(f64_t);
-        return SHIFTND_OK;
-    }
-    switch (dtype) {
-    case SHIFTND_F32: SHIFTND_SPAN_FT(f32_t); break;
-    case SHIFTND_F64: SHIFTND_SPAN_FT(f64_t); break;
-    case SHIFTND_F16: SHIFTND_SPAN_FT(f16_t); break;
-    default: SHIFTND_SPAN_FT(bf16_t); break;
-    }
-#undef SHIFTND_SPAN_FT
-    return SHIFTND_OK;
+    return SHIFTND_ERR_INVALID_ARGUMENT;   // (span_forward_eligible admits nothing else)
 }
 
 // cropped 2-D problems, and 1-D problems whose rows fill at least a wave: dense tensors, 16-byte aligned

@@ -43,17 +43,11 @@ constexpr int kWalkFlush = 16;                         // planes between two flu
 
 typedef uint32_t u4_t __attribute__((ext_vector_type(4)));
 
-// The workgroup barrier of the walk kernels: every LDS operation of this wave has completed, and the compiler may not move a
-// memory access across it.  A bare __syncthreads() was not enough in walk_backward16<..., ZEROS = false>: with several
-// workgroups per CU (N * C * steps > 256) its gather path -- ds_read_u16 under a thread-dependent branch -- raced with the next
-// step's parking stores; non-deterministic zeros in grad_x on 70 % of the channels of C3 with border padding, invisible with
-// one workgroup per CU (the small shapes of the parity tests).  Found by the full-size test of round 4; any explicit wait +
-// memory clobber next to either barrier of the step removes it.
-__device__ __forceinline__ void walk_barrier() {
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __syncthreads();
-    asm volatile("" ::: "memory");
-}
+// The workgroup barrier of the walk kernels.  (Round 4 wrapped it in an explicit lgkmcnt wait and compiler barriers against what
+// looked like an LDS race of walk_backward16<..., ZEROS = false>; round 5 found the cause elsewhere -- a store-data hazard behind
+// buffer_store_dwordx4 with an SGPR soffset, shiftnd_common.hpp: buffer_store_b128_soffset -- and the barrier is plain again: every
+// s_barrier of these kernels is preceded by s_waitcnt lgkmcnt(0) with no LDS instruction in between, tools/isa_barriers.py.)
+__device__ __forceinline__ void walk_barrier() { __syncthreads(); }
 
 // cache-policy bits: the staged loads and the own chunk are plain (every gradient plane is read twice by its workgroup, the
 // "+1" corner row by two workgroups: nontemporal loads cost 20 %), grad_x is written once and not read again: nontemporal
@@ -402,7 +396,7 @@ __global__ __launch_bounds__(kThreads) void walk_backward16(const StepParams p) 
                 res = u4_t{t[0], t[1], t[2], t[3]};
             }
         }
-        __builtin_amdgcn_raw_buffer_store_b128(res, ores, my, static_cast<uint32_t>(a) * plane_bytes, kWalkStoreAux);
+        buffer_store_b128_soffset<kWalkStoreAux>(res, ores, my, static_cast<uint32_t>(a) * plane_bytes);
         if (((a - a0) & (kWalkFlush - 1)) == kWalkFlush - 1) flush();
         walk_barrier();   // everybody has read this step's planes
     };
@@ -557,7 +551,7 @@ __global__ __launch_bounds__(kThreads) void walk_forward16(const FwdParams p) {
         for (int e = 0; e < E; ++e) ch.e[e] = narrow<T>(lerp(B0[e], B1[e], dP));
         u4_t res;
         __builtin_memcpy(&res, ch.e, 16);
-        __builtin_amdgcn_raw_buffer_store_b128(res, ores, my, static_cast<uint32_t>(a) * plane_bytes, kWalkStoreAux);
+        buffer_store_b128_soffset<kWalkStoreAux>(res, ores, my, static_cast<uint32_t>(a) * plane_bytes);
         walk_barrier();
     };
     int a = 0;

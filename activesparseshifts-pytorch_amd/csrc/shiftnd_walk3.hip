@@ -599,7 +599,7 @@ __global__ __launch_bounds__(kThreads) void walk_backward(const StepParams p) {
         {
             u4 bits;
             __builtin_memcpy(&bits, res.e, 16);
-            __builtin_amdgcn_raw_buffer_store_b128(bits, ores, my, static_cast<uint32_t>(a) * plane_bytes, 0);
+            buffer_store_b128_soffset<0>(bits, ores, my, static_cast<uint32_t>(a) * plane_bytes);
         }
         if ((a & 3) == 3 || a == a1 - 1) {
 #pragma unroll

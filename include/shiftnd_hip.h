@@ -110,7 +110,7 @@ SHIFTND_API void shiftnd_set_path_policy(int policy);
  * them, 13: workgroups wanted, 14: minimum rows per band), 16-19 one-byte small-plane kernel (16: on / off, 17: planes
  * per round, 18: LDS bytes, 19: rounds per workgroup), 20-22 LDS-tiled channels-last kernels (20: on / off, 21: rows
  * per band, 22: XCD-contiguous block ids; 23: the direct NDHWC backward 0 = automatic, 1 = never, 2 = whenever eligible), 24-26 small-plane / row-band kernels (24: on / off, 25: planes per round or rows per band, 26: rounds per
- * workgroup), 28-30 one-byte row kernel (28: element sizes served, 29: rows per band, 30: workgroups wanted), 32-35
+ * workgroup), 27 flat-stream kernels for ragged rows (0 = automatic, 1 = never, 2 = whenever eligible), 28-30 one-byte row kernel (28: element sizes served, 29: rows per band, 30: workgroups wanted), 32-35
  * one-step kernels (32: 2-D backward, 33: sparse-shift forward by direct loads, 34: forwards through LDS; each 0 =
  * automatic, 1 = never, 2 = whenever eligible; 35: bit set of opt-in forms, csrc/shiftnd_step.hip), 36-37 quantized
  * pool (36: 1 = the element-per-thread kernel only, 37: workgroups wanted), 38 planes per workgroup of the 3-D walk

@@ -11,6 +11,7 @@ import torch
 from cases import rel_err, gw16_tol
 from oracle import oracle as O
 from test_hip_parity import _ulp_close, _weights
+from test_flat_gpu import flat_serves
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
@@ -41,8 +42,8 @@ def test_cropped_backward_vs_oracle(abi, shape, crop, dt):
     total = 1
     for v in new:
         total *= v
-    if (shape[-1] * es) % 16 or (total * es) % 16:
-        pytest.skip("x rows are not whole 16-byte pieces / grad_out is not a whole number of pieces")
+    # x rows that are not whole 16-byte pieces, or a gradient that is not a whole number of pieces: the flat-stream kernels (round 5)
+    ragged = bool((shape[-1] * es) % 16 or (total * es) % 16)
     rs = np.random.RandomState(sum(shape) * 11 + 5)
     xt = torch.from_numpy(rs.uniform(-1, 1, size=shape)).to(tdt)
     gt = torch.from_numpy(rs.uniform(-1, 1, size=new)).to(tdt)
@@ -57,7 +58,12 @@ def test_cropped_backward_vs_oracle(abi, shape, crop, dt):
             # (... and a window ONE column wide with zeros padding: its gradient map ignores the shift and is not the affine column
             #  state crop_backward<.., PAD = 0> reads through)
             lean = shape[-1] * es <= 4064 and not (pad == 0 and new[-1] == 1)
-            assert abi.last_kernel() == ("crop_backward" if lean else "plane_backward"), (shape, crop, pad, abi.last_kernel())
+            if ragged:
+                assert abi.last_kernel() in ("flat_backward", "plane_backward", "small_plane_backward", "band_plane_backward"), (shape, crop, pad, abi.last_kernel())
+            elif lean:
+                assert abi.last_kernel() == "crop_backward", (shape, crop, pad, abi.last_kernel())
+            else:   # (what crop_backward leaves: the flat-stream kernels when they serve the geometry, else the per-channel ones)
+                assert abi.last_kernel() == ("flat_backward" if flat_serves(shape, new, es, True) else "plane_backward"), (shape, crop, pad, abi.last_kernel())
             gx_ref = torch.from_numpy(O.backward(go, w, x, pad, active, b)[0]).to(tdt)
             if es >= 4 or not active:
                 assert torch.equal(gx.cpu(), gx_ref), ("gx", shape, crop, dt, pad, active)
@@ -88,8 +94,6 @@ def test_1d_backward_vs_oracle(abi, shape, crop, dt):
     total = 1
     for v in new:
         total *= v
-    if (shape[-1] * es) % 16 or (total * es) % 16:
-        pytest.skip("rows are not whole 16-byte pieces / grad_out is not a whole number of pieces")
     abi.set_tuning(32, 2)   # whenever eligible (the automatic choice leaves rows of fewer than 128 chunks to the per-channel kernels)
     rs = np.random.RandomState(sum(shape) * 3 + 2)
     xt = torch.from_numpy(rs.uniform(-1, 1, size=shape)).to(tdt)
@@ -101,7 +105,7 @@ def test_1d_backward_vs_oracle(abi, shape, crop, dt):
     for pad in range(5):
         for active in (0, 1):
             gx, gw = abi.backward(god, wd, xd, pad, active, b)
-            assert abi.last_kernel() in ("row_backward", "crop_backward"), (shape, crop, abi.last_kernel())
+            assert abi.last_kernel() in ("row_backward", "crop_backward", "flat_backward", "plane_backward"), (shape, crop, abi.last_kernel())
             gx_ref = torch.from_numpy(O.backward(go, w, x, pad, active, b)[0]).to(tdt)
             if es >= 4 or not active:
                 assert torch.equal(gx.cpu(), gx_ref), ("gx", shape, crop, dt, pad, active)
@@ -123,16 +127,15 @@ CASES_FWD_2D = CASES_2D + [((2, 3, 62, 62), None), ((2, 2, 62, 62), [[1, 1], [1,
 @pytest.mark.parametrize("dt", ["f32", "f64", "f16", "bf16"])
 @pytest.mark.parametrize("shape,crop", CASES_FWD_2D)
 def test_cropped_forward_vs_oracle(abi, shape, crop, dt):
-    """span_forward: cropped windows (ragged output rows) and ragged source rows (62 x 62, 113 x 113 inputs); chunks that straddle
-    two output rows, steps that straddle many; every padding, both shifts"""
+    """crop_forward (cropped windows on source rows of whole pieces: ragged output rows, chunks that straddle two output rows, steps
+    that straddle many) and -- ragged source rows (62 x 62, 113 x 113 inputs), planes that are not whole pieces -- the flat-stream
+    kernels of round 5; every padding, both shifts"""
     tdt = {"f32": torch.float32, "f64": torch.float64, "f16": torch.float16, "bf16": torch.bfloat16}[dt]
     es = torch.empty(0, dtype=tdt).element_size()
     b, new = abi.check_borders(list(shape), crop, 2)
     xtotal = 1
     for v in shape:
         xtotal *= v
-    if (new[-1] * new[-2] * es) % 16 or (xtotal * es) % 16:
-        pytest.skip("output planes / the input are not whole numbers of 16-byte pieces")
     rs = np.random.RandomState(sum(shape) * 17 + 3)
     xt = torch.from_numpy(rs.uniform(-1, 1, size=shape)).to(tdt)
     wt = torch.from_numpy(_weights(rs, shape[1], 2, shape[2:])).to(tdt)
@@ -144,9 +147,9 @@ def test_cropped_forward_vs_oracle(abi, shape, crop, dt):
     for pad in range(5):
         for active in (0, 1):
             out = abi.forward(xd, wd, pad, active, b)
-            if abi.last_kernel().startswith("step_"):
-                continue   # (output rows of whole pieces: the aligned one-step forwards keep them)
-            assert abi.last_kernel() in (("span_active_forward", "crop_active_forward", "row_active_forward") if active else ("span_gather_forward", "crop_gather_forward", "row_gather_forward")), (shape, crop, abi.last_kernel())
+            # (aligned rows / tiny planes keep their kernels, windows far smaller than their planes the strided ones; checked all the same)
+            if not abi.last_kernel().startswith(("step_", "plane_", "sweep_", "small_", "band_")) and flat_serves(shape, new, es, False):
+                assert abi.last_kernel() in (("flat_active_forward", "crop_active_forward", "row_active_forward") if active else ("flat_gather_forward", "crop_gather_forward", "row_gather_forward")), (shape, crop, abi.last_kernel())
             ref = torch.from_numpy(O.forward(x, w, pad, active, b)).to(tdt)
             if es >= 4 or not active:
                 assert torch.equal(out.cpu(), ref), (shape, crop, dt, pad, active)
@@ -163,8 +166,6 @@ def test_1d_forward_vs_oracle(abi, shape, crop, dt):
     xtotal = 1
     for v in shape:
         xtotal *= v
-    if (new[-1] * es) % 16 or (xtotal * es) % 16 or (shape[-1] * es) % 16:
-        pytest.skip("rows are not whole 16-byte pieces")
     rs = np.random.RandomState(sum(shape) * 19 + 7)
     xt = torch.from_numpy(rs.uniform(-1, 1, size=shape)).to(tdt)
     wt = torch.from_numpy(_weights(rs, shape[1], 1, shape[2:])).to(tdt)
@@ -176,9 +177,8 @@ def test_1d_forward_vs_oracle(abi, shape, crop, dt):
     for pad in range(5):
         for active in (0, 1):
             out = abi.forward(xd, wd, pad, active, b)
-            if abi.last_kernel().startswith("step_"):
-                continue
-            assert abi.last_kernel() in (("span_active_forward", "crop_active_forward", "row_active_forward") if active else ("span_gather_forward", "crop_gather_forward", "row_gather_forward")), (shape, crop, abi.last_kernel())
+            if not abi.last_kernel().startswith(("step_", "plane_", "sweep_")):
+                assert abi.last_kernel() in (("flat_active_forward", "crop_active_forward", "row_active_forward") if active else ("flat_gather_forward", "crop_gather_forward", "row_gather_forward")), (shape, crop, abi.last_kernel())
             ref = torch.from_numpy(O.forward(x, w, pad, active, b)).to(tdt)
             if es >= 4 or not active:
                 assert torch.equal(out.cpu(), ref), (shape, crop, dt, pad, active)

@@ -54,10 +54,30 @@ struct FlatParams {
     uint32_t total_steps, steps_per_xcd;
     FastDiv d_SP, d_SR;   // the streamed tensor's plane elements / row length
     FastDiv d_C, d_per1, d_per2, d_pero1, d_pero2;
-    uint32_t x_bytes, go_bytes;   // sizes of the staged tensors (the last piece of a cover may reach past the end: see stage())
+    int lds_bytes;        // the launch's dynamic LDS size (clamps the corner reads of the zeros-padding forms)
+    int front;            // bytes of slack between the tables and the first cover (a corner group that starts one row / column early)
 };
 
 template <typename S> __device__ __forceinline__ S lds_at(const char *smem, int off) { return *reinterpret_cast<const S *>(smem + off); }
+
+constexpr int kZero = 0;   // LDS bytes [0, 16) hold zeros: what an element outside the window / in the padding reads (an address select, no
+                           // select on the value and no exec-mask region around the read: a kernel this short lives or dies by its control flow)
+constexpr int kTab = 16;   // the plane table behind them
+
+// canon_shift (shiftnd_common.hpp) of an integral shift held in the compute type: 32-bit arithmetic below 2^30 (always, in practice),
+// the 64-bit form beyond; the padding mode is a run-time value
+template <typename CT> __device__ __forceinline__ int canon_rt(CT r, int len, int pad, const FastDiv &dper) {
+    if (len <= 1) return 0;
+    if (r > CT(-1073741824) && r < CT(1073741824)) {
+        const int s = static_cast<int>(r);
+        if (pad <= 1) return s < -len - 1 ? -len - 1 : (s > len + 1 ? len + 1 : s);
+        const int period = pad == 2 ? len : (pad == 3 ? 2 * (len - 1) : 2 * len);
+        const uint32_t a = static_cast<uint32_t>(s < 0 ? -s : s);
+        const uint32_t m = a - fdiv(a, dper) * static_cast<uint32_t>(period);
+        return static_cast<int>((s < 0 && m != 0) ? static_cast<uint32_t>(period) - m : m);
+    }
+    return canon_shift(static_cast<int64_t>(r), len, pad, dper);
+}
 
 __device__ __forceinline__ int imap(int p, int cs, int len, int pad) { return len == 1 ? 0 : fold_index(p - cs, len, pad); }
 
@@ -122,26 +142,29 @@ __device__ __forceinline__ void clamp_rows(int a, int b, int len, bool zeros, in
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
-// flat_forward<T, ACTIVE, PADZ, SMALL>: PADZ = zeros padding (validity is two unsigned compares), else the padding mode is a run-time
-// value folded per element; SMALL = the whole source planes of a step are staged.
+// flat_forward<T, ACTIVE, PAD, SMALL>: the padding mode is a template parameter (every element folds its coordinates: with a run-time
+// mode the reflecting paddings ran at half the zeros padding's rate); SMALL = the whole source planes of a step are staged.
 // LDS: [plane table][cover of x]
 // ---------------------------------------------------------------------------------------------------------------------
-template <typename T, bool ACTIVE, bool PADZ, bool SMALL>
+template <typename T, bool ACTIVE, int PAD, bool SMALL>
 __global__ __launch_bounds__(kThreads) void flat_forward(const FlatParams p) {
+    constexpr bool PADZ = PAD == 0;
     using S = typename T::S;
     using CT = typename T::C;
     constexpr int ES = sizeof(S);
     constexpr int E = 16 / ES;
     using Rec = PlaneRec<CT>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    Rec *table = reinterpret_cast<Rec *>(smem);
-    constexpr int TAB = ((SMALL ? kMaxPlanes : 2) * static_cast<int>(sizeof(Rec)) + 15) & ~15;
-    const int COV = TAB;   // LDS offset of the cover
+    Rec *table = reinterpret_cast<Rec *>(smem + kTab);
+    constexpr int TAB = kTab + (((SMALL ? kMaxPlanes : 2) * static_cast<int>(sizeof(Rec)) + 15) & ~15);
+    const int COV = TAB + p.front;   // LDS offset of the cover
+    if (threadIdx.x < 4) reinterpret_cast<uint32_t *>(smem)[threadIdx.x] = 0u;
 
     const uint32_t bid = (blockIdx.x & 7u) * p.steps_per_xcd + (blockIdx.x >> 3);
     if (bid >= p.total_steps) return;
     const int tid = static_cast<int>(threadIdx.x);
-    const int S1 = p.S1, S2 = p.S2, O1 = p.O1, O2 = p.O2, L1 = p.L1, L2 = p.L2, pad = p.pad;
+    const int S1 = p.S1, S2 = p.S2, O1 = p.O1, O2 = p.O2, L1 = p.L1, L2 = p.L2;
+    constexpr int pad = PAD;
     const uint32_t f0 = bid * static_cast<uint32_t>(kThreads * E);                                  // first element of the step
     const uint32_t f1 = min(p.total, f0 + static_cast<uint32_t>(kThreads * E)) - 1u;                // ... and its last
     const uint32_t plA = fdiv(f0, p.d_SP), plB = fdiv(f1, p.d_SP);
@@ -149,13 +172,14 @@ __global__ __launch_bounds__(kThreads) void flat_forward(const FlatParams p) {
 
     auto channel = [&](uint32_t pl, int &c1, int &c2, CT &fr1, CT &fr2) {   // the plane's shifts (shifts_cpu.cpp:223-224), canonical
         const int c = static_cast<int>(pl - fdiv(pl, p.d_C) * static_cast<uint32_t>(p.C));
-        CT wv[3];
-        load_weights_nd<CT>(p.w, p.wkind, c, p.nd, wv);
-        const CT r1 = ACTIVE ? c_floor<CT>(wv[1]) : c_rint<CT>(wv[1]), r2 = ACTIVE ? c_floor<CT>(wv[2]) : c_rint<CT>(wv[2]);
-        fr1 = ACTIVE ? wv[1] - r1 : CT(0);
-        fr2 = ACTIVE ? wv[2] - r2 : CT(0);
-        c1 = canon_shift(static_cast<int64_t>(r1), S1, pad, p.d_per1);
-        c2 = canon_shift(static_cast<int64_t>(r2), S2, pad, p.d_per2);
+        // (weights of the tensor's dtype -- shiftnd_api.hip routes nothing else here -- but T only says the element SIZE for the sparse shift)
+        const CT w1 = p.nd == 2 ? load_weight<CT>(p.w, p.wkind, static_cast<int64_t>(c) * 2) : CT(0);
+        const CT w2 = load_weight<CT>(p.w, p.wkind, static_cast<int64_t>(c) * p.nd + p.nd - 1);
+        const CT r1 = ACTIVE ? c_floor<CT>(w1) : c_rint<CT>(w1), r2 = ACTIVE ? c_floor<CT>(w2) : c_rint<CT>(w2);
+        fr1 = ACTIVE ? w1 - r1 : CT(0);
+        fr2 = ACTIVE ? w2 - r2 : CT(0);
+        c1 = canon_rt<CT>(r1, S1, pad, p.d_per1);
+        c2 = canon_rt<CT>(r2, S2, pad, p.d_per2);
     };
 
     if constexpr (SMALL) {
@@ -207,41 +231,68 @@ __global__ __launch_bounds__(kThreads) void flat_forward(const FlatParams p) {
     const int ecut = static_cast<int>(min(static_cast<uint32_t>(E), p.OP - r));   // elements of this chunk in plane pl
     const S *xg = static_cast<const S *>(p.x);
     const S zero = static_cast<S>(0.0f);
+    // the last LDS byte offset a corner group may start at (the launch adds a row of slack behind the covers: every VALID corner
+    // group starts below it, only groups of masked corners are moved)
+    const int lim = p.lds_bytes - ((S1 == 1 ? 0 : S2) + 2) * ES;
+    const bool one_d = p.nd == 1;                  // (uniform) Shift1d: interp1D of the two column corners (interpolation.h:3-7)
     Chunk<S, E> res;
+    // SIMPLE: no chunk of this wave changes planes and every source row it folds to is staged -- no per-element selects between two
+    // plane records, no staged-row checks (large planes: all but the waves at a plane's first / last rows)
+    auto elements = [&](auto simple_tag) {
+    constexpr bool SIMPLE = decltype(simple_tag)::value;
 #pragma unroll
     for (int e = 0; e < E; ++e) {
-        const bool first = e < ecut;
+        const bool first = SIMPLE || e < ecut;
         const int c1 = first ? D0.c1 : D1.c1, c2 = first ? D0.c2 : D1.c2, xb = first ? D0.xb : D1.xb;
-        const uint32_t ple = first ? pl : pl + 1u;
-        auto tap = [&](int a, int b) -> S {   // source element (row a, column b), unfolded coordinates
-            if constexpr (PADZ) {
-                const bool ok = static_cast<unsigned>(a) < static_cast<unsigned>(S1) && static_cast<unsigned>(b) < static_cast<unsigned>(S2);
-                const S v = lds_at<S>(smem, ok ? xb + (a * S2 + b) * ES : 0);
-                return ok ? v : zero;
+        const int a = S1 == 1 ? 0 : i + L1 - c1, b = S2 == 1 ? 0 : j + L2 - c2;   // the source element, unfolded coordinates
+        if constexpr (PADZ) {
+            const bool ra = static_cast<unsigned>(a) < static_cast<unsigned>(S1), cb = static_cast<unsigned>(b) < static_cast<unsigned>(S2);
+            if constexpr (!ACTIVE) {
+                res.e[e] = lds_at<S>(smem, (ra && cb) ? xb + (a * S2 + b) * ES : kZero);   // (an address select: the zero words; no exec region)
             } else {
-                const int ar = S1 == 1 ? 0 : fold_index(a, S1, pad), bc = S2 == 1 ? 0 : fold_index(b, S2, pad);
-                if constexpr (SMALL) {
+                // the four corners from two addresses (row a, row a + 1; columns b, b + 1 adjacent), read unconditionally at a clamped
+                // address and masked afterwards
+                const bool ra1 = S1 == 1 ? ra : static_cast<unsigned>(a + 1) < static_cast<unsigned>(S1);
+                const bool cb1 = S2 == 1 ? cb : static_cast<unsigned>(b + 1) < static_cast<unsigned>(S2);
+                const int base = min(max(xb + (a * S2 + b) * ES, 0), lim);
+                const int dn = S1 == 1 ? 0 : S2 * ES, rt = S2 == 1 ? 0 : ES;
+                const S q00 = lds_at<S>(smem, base), q01 = lds_at<S>(smem, base + rt), q10 = lds_at<S>(smem, base + dn), q11 = lds_at<S>(smem, base + dn + rt);
+                const CT fr[2] = {first ? D0.f1 : D1.f1, first ? D0.f2 : D1.f2};
+                const CT v00 = (ra && cb) ? widen<T>(q00) : CT(0), v10 = (ra1 && cb) ? widen<T>(q10) : CT(0);
+                const CT v01 = (ra && cb1) ? widen<T>(q01) : CT(0), v11 = (ra1 && cb1) ? widen<T>(q11) : CT(0);
+                if (one_d) {
+                    const CT v[2] = {v00, v01};
+                    res.e[e] = narrow<T>(interp_t<T, 1>(v, fr + 1));
+                } else {
+                    const CT v[4] = {v00, v10, v01, v11};   // corner order: bit 0 = + 1 row, bit 1 = + 1 column (shifts_kernels.h:58-103)
+                    res.e[e] = narrow<T>(interp_t<T, 2>(v, fr));
+                }
+            }
+        } else {
+            const uint32_t ple = first ? pl : pl + 1u;
+            const int xr0 = first ? D0.xr0 : D1.xr0, xr1 = first ? D0.xr1 : D1.xr1;
+            auto tap = [&](int ar, int bc) -> S {   // folded coordinates: always a source element
+                if constexpr (SMALL || PAD == 1 || SIMPLE) {   // (border padding clamps into the staged rows)
                     return lds_at<S>(smem, xb + (ar * S2 + bc) * ES);
                 } else {
-                    const int xr0 = first ? D0.xr0 : D1.xr0, xr1 = first ? D0.xr1 : D1.xr1;
                     if (ar >= xr0 && ar <= xr1) return lds_at<S>(smem, xb + (ar * S2 + bc) * ES);
                     return xg[static_cast<uint64_t>(ple) * p.XP + static_cast<uint32_t>(ar * S2 + bc)];   // a row the padding folds out of the cover
                 }
-            }
-        };
-        const int a = S1 == 1 ? 0 : i + L1 - c1, b = S2 == 1 ? 0 : j + L2 - c2;
-        if constexpr (ACTIVE) {
-            const CT fr[2] = {first ? D0.f1 : D1.f1, first ? D0.f2 : D1.f2};
-            const int a1 = S1 == 1 ? 0 : a + 1, b1 = S2 == 1 ? 0 : b + 1;
-            if (p.nd == 1) {   // (uniform) Shift1d: interp1D of the two column corners (interpolation.h:3-7)
-                const CT v[2] = {widen<T>(tap(a, b)), widen<T>(tap(a, b1))};
-                res.e[e] = narrow<T>(interp_t<T, 1>(v, fr + 1));
+            };
+            const int ar = S1 == 1 ? 0 : fold_index(a, S1, PAD), bc = S2 == 1 ? 0 : fold_index(b, S2, PAD);
+            if constexpr (!ACTIVE) {
+                res.e[e] = tap(ar, bc);
             } else {
-                const CT v[4] = {widen<T>(tap(a, b)), widen<T>(tap(a1, b)), widen<T>(tap(a, b1)), widen<T>(tap(a1, b1))};
-                res.e[e] = narrow<T>(interp_t<T, 2>(v, fr));
+                const int ar1 = S1 == 1 ? 0 : fold_index(a + 1, S1, PAD), bc1 = S2 == 1 ? 0 : fold_index(b + 1, S2, PAD);
+                const CT fr[2] = {first ? D0.f1 : D1.f1, first ? D0.f2 : D1.f2};
+                if (one_d) {
+                    const CT v[2] = {widen<T>(tap(ar, bc)), widen<T>(tap(ar, bc1))};
+                    res.e[e] = narrow<T>(interp_t<T, 1>(v, fr + 1));
+                } else {
+                    const CT v[4] = {widen<T>(tap(ar, bc)), widen<T>(tap(ar1, bc)), widen<T>(tap(ar, bc1)), widen<T>(tap(ar1, bc1))};
+                    res.e[e] = narrow<T>(interp_t<T, 2>(v, fr));
+                }
             }
-        } else {
-            res.e[e] = tap(a, b);
         }
         ++j;
         if (j == O2) {
@@ -250,6 +301,17 @@ __global__ __launch_bounds__(kThreads) void flat_forward(const FlatParams p) {
             if (i == O1) i = 0;
         }
     }
+    };
+    // rows this chunk reads, unfolded: [i + L1 - c1, i_last + L1 - c1 (+ 1)] -- inside the plane: nothing folds, everything is staged
+    bool simple = ecut == E;
+    if constexpr (!SMALL) {
+        const int ilast = static_cast<int>(fdiv(static_cast<uint32_t>(r) + E - 1, p.d_SR));
+        const int a_lo = i + L1 - D0.c1, a_hi = ilast + L1 - D0.c1 + (ACTIVE ? 1 : 0);
+        if constexpr (PAD >= 2) simple = simple && (S1 == 1 || (a_lo >= 0 && a_hi < S1));
+    }
+    if (__all(simple)) elements(std::true_type{});
+    else elements(std::false_type{});
+    (void)zero;
     S *op = static_cast<S *>(p.out) + f;
     if (f + E <= p.total) {
         store_chunk<S, E>(op, res);
@@ -288,24 +350,26 @@ __global__ __launch_bounds__(kThreads) void flat_prep(const FlatParams p) {
 // ---------------------------------------------------------------------------------------------------------------------
 // flat_backward<T, ACTIVE, PADZ, SMALL>.  LDS: [plane table][per-chunk partial sums][cover of x][cover of grad_out]
 // ---------------------------------------------------------------------------------------------------------------------
-template <typename T, bool ACTIVE, bool PADZ, bool SMALL>
+template <typename T, bool ACTIVE, int PAD, bool SMALL>
 __global__ __launch_bounds__(kThreads) void flat_backward(const FlatParams p, int gcov_off) {
+    constexpr bool PADZ = PAD == 0;
     using S = typename T::S;
     using CT = typename T::C;
     constexpr int ES = sizeof(S);
     constexpr int E = 16 / ES;
     using Rec = PlaneRec<CT>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    Rec *table = reinterpret_cast<Rec *>(smem);
-    constexpr int TAB = ((SMALL ? kMaxPlanes : 2) * static_cast<int>(sizeof(Rec)) + 15) & ~15;
+    Rec *table = reinterpret_cast<Rec *>(smem + kTab);
+    constexpr int TAB = kTab + (((SMALL ? kMaxPlanes : 2) * static_cast<int>(sizeof(Rec)) + 15) & ~15);
+    if (threadIdx.x < 4) reinterpret_cast<uint32_t *>(smem)[threadIdx.x] = 0u;
     constexpr int PART = TAB;                                        // [256][4] CT: (sumA, sumB) of the chunk's first plane, of its second
-    constexpr int XCOV = PART + kThreads * 4 * static_cast<int>(sizeof(CT));
+    const int XCOV = PART + kThreads * 4 * static_cast<int>(sizeof(CT)) + p.front;
     const int GCOV = XCOV + gcov_off;                                // (host: the largest x cover of any step, 16-byte aligned)
 
     const uint32_t bid = (blockIdx.x & 7u) * p.steps_per_xcd + (blockIdx.x >> 3);
     if (bid >= p.total_steps) return;
     const int tid = static_cast<int>(threadIdx.x);
-    const int S1 = p.S1, S2 = p.S2, O1 = p.O1, O2 = p.O2, L1 = p.L1, L2 = p.L2, pad = p.pad;
+    const int S1 = p.S1, S2 = p.S2, O1 = p.O1, O2 = p.O2, L1 = p.L1, L2 = p.L2;
     const uint32_t f0 = bid * static_cast<uint32_t>(kThreads * E);
     const uint32_t f1 = min(p.total, f0 + static_cast<uint32_t>(kThreads * E)) - 1u;
     const uint32_t plA = fdiv(f0, p.d_SP), plB = fdiv(f1, p.d_SP);
@@ -386,6 +450,8 @@ __global__ __launch_bounds__(kThreads) void flat_backward(const FlatParams p, in
         const int ecut = static_cast<int>(min(static_cast<uint32_t>(E), p.XP - r));
         const S *xg = static_cast<const S *>(p.x), *gg = static_cast<const S *>(p.go);
         const S zero = static_cast<S>(0.0f);
+        const int lim = p.lds_bytes - ((S1 == 1 ? 0 : S2) + 2) * ES, glim = p.lds_bytes - ((O1 == 1 ? 0 : O2) + 2) * ES;   // (see flat_forward)
+        const bool one_d = p.nd == 1;
         // the gradient at the output positions themselves.  Small planes: from the staged planes; large planes: from memory --
         // without a crop grad_out has grad_x's own geometry, the chunk is one aligned 16-byte load
         Chunk<S, E> own;
@@ -397,87 +463,121 @@ __global__ __launch_bounds__(kThreads) void flat_backward(const FlatParams p, in
             }
         }
         Chunk<S, E> res;
+        auto elements = [&](auto simple_tag) {   // (SIMPLE: see flat_forward)
+        constexpr bool SIMPLE = decltype(simple_tag)::value;
 #pragma unroll
         for (int e = 0; e < E; ++e) {
-            const bool first = e < ecut;
+            const bool first = SIMPLE || e < ecut;
             const int c1 = first ? D0.c1 : D1.c1, c2 = first ? D0.c2 : D1.c2, g1 = first ? D0.g1 : D1.g1, g2 = first ? D0.g2 : D1.g2;
             const int xb = first ? D0.xb : D1.xb, gb = first ? D0.gb : D1.gb;
             const uint32_t ple = first ? pl : pl + 1u;
             const int io = i - L1, jo = j - L2;   // the element in grad_out's coordinates
             const bool inside = static_cast<unsigned>(io) < static_cast<unsigned>(O1) && static_cast<unsigned>(jo) < static_cast<unsigned>(O2) && f + e < p.total;
-            auto xtap = [&](int a, int b) -> S {
-                if constexpr (PADZ) {
-                    const bool ok = inside && static_cast<unsigned>(a) < static_cast<unsigned>(S1) && static_cast<unsigned>(b) < static_cast<unsigned>(S2);
-                    const S v = lds_at<S>(smem, ok ? xb + (a * S2 + b) * ES : 0);
-                    return ok ? v : zero;
-                } else {
-                    const int ar = S1 == 1 ? 0 : fold_index(a, S1, pad), bc = S2 == 1 ? 0 : fold_index(b, S2, pad);
-                    if constexpr (SMALL) {
-                        const S v = lds_at<S>(smem, inside ? xb + (ar * S2 + bc) * ES : 0);
-                        return inside ? v : zero;
-                    } else {
-                        if (!inside) return zero;
-                        const int xr0 = first ? D0.xr0 : D1.xr0, xr1 = first ? D0.xr1 : D1.xr1;
-                        if (ar >= xr0 && ar <= xr1) return lds_at<S>(smem, xb + (ar * S2 + bc) * ES);
-                        return xg[static_cast<uint64_t>(ple) * p.XP + static_cast<uint32_t>(ar * S2 + bc)];
-                    }
-                }
-            };
-            auto gtap = [&](int a, int b) -> S {   // grad_out (row a, column b), its own unfolded coordinates
-                if constexpr (PADZ) {
-                    const bool ok = inside && static_cast<unsigned>(a) < static_cast<unsigned>(O1) && static_cast<unsigned>(b) < static_cast<unsigned>(O2);
-                    const S v = lds_at<S>(smem, ok ? gb + (a * O2 + b) * ES : 0);
-                    return ok ? v : zero;
-                } else {
-                    const int ar = O1 == 1 ? 0 : fold_index(a, O1, pad), bc = O2 == 1 ? 0 : fold_index(b, O2, pad);
-                    if constexpr (SMALL) {
-                        const S v = lds_at<S>(smem, inside ? gb + (ar * O2 + bc) * ES : 0);
-                        return inside ? v : zero;
-                    } else {
-                        if (!inside) return zero;
-                        const int gr0 = first ? D0.gr0 : D1.gr0, gr1 = first ? D0.gr1 : D1.gr1;
-                        if (ar >= gr0 && ar <= gr1) return lds_at<S>(smem, gb + (ar * O2 + bc) * ES);
-                        return gg[static_cast<uint64_t>(ple) * p.OP + static_cast<uint32_t>(ar * O2 + bc)];
-                    }
-                }
-            };
             // the gradient at the position itself (shifts_kernels.h:271)
             S gs;
             if constexpr (SMALL) {
-                const S v = lds_at<S>(smem, inside ? gb + (io * O2 + jo) * ES : 0);
-                gs = inside ? v : zero;
+                gs = lds_at<S>(smem, inside ? gb + (io * O2 + jo) * ES : kZero);
             } else {
                 if (own_loaded) gs = inside ? own.e[e] : zero;
                 else gs = inside ? gg[static_cast<uint64_t>(ple) * p.OP + static_cast<uint32_t>(io * O2 + jo)] : zero;
             }
             const CT g = widen<T>(gs);
-            // the input corners around (i, j) - shift (:274-279) and the two corner differences of the weight gradient
-            const int a = S1 == 1 ? 0 : i - c1, b = S2 == 1 ? 0 : j - c2, a1 = S1 == 1 ? 0 : a + 1, b1 = S2 == 1 ? 0 : b + 1;
-            const CT v0 = widen<T>(xtap(a, b)), v1 = widen<T>(xtap(a1, b)), v2 = widen<T>(xtap(a, b1)), v3 = widen<T>(xtap(a1, b1));
-            const CT dA = v2 - v0, dB = v3 - v1;
-            if (first) {
-                sums[0] = fma_ct(g, dA, sums[0]);
-                sums[1] = fma_ct(g, dB, sums[1]);
+            // the input corners around (i, j) - shift (:274-279): unfolded coordinates a, a + 1 x b, b + 1
+            const int a = S1 == 1 ? 0 : i - c1, b = S2 == 1 ? 0 : j - c2;
+            const int ga = O1 == 1 ? 0 : io - g1, gbc = O2 == 1 ? 0 : jo - g2;   // the gradient tap(s) of grad_x (:299-324)
+            CT v0, v1, v2, v3;   // corner order: bit 0 = + 1 row, bit 1 = + 1 column
+            if constexpr (PADZ) {
+                // two addresses (rows a, a + 1; the columns b, b + 1 are adjacent), read unconditionally at a clamped address, masked
+                // afterwards (elements outside the window read nothing: every mask carries `inside`)
+                const bool ra = inside && static_cast<unsigned>(a) < static_cast<unsigned>(S1), ra1 = S1 == 1 ? ra : inside && static_cast<unsigned>(a + 1) < static_cast<unsigned>(S1);
+                const bool cb = static_cast<unsigned>(b) < static_cast<unsigned>(S2), cb1 = S2 == 1 ? cb : static_cast<unsigned>(b + 1) < static_cast<unsigned>(S2);
+                const int base = min(max(xb + (a * S2 + b) * ES, 0), lim);
+                const int dn = S1 == 1 ? 0 : S2 * ES, rt = S2 == 1 ? 0 : ES;
+                const S q00 = lds_at<S>(smem, base), q01 = lds_at<S>(smem, base + rt), q10 = lds_at<S>(smem, base + dn), q11 = lds_at<S>(smem, base + dn + rt);
+                v0 = (ra && cb) ? widen<T>(q00) : CT(0);
+                v1 = (ra1 && cb) ? widen<T>(q10) : CT(0);
+                v2 = (ra && cb1) ? widen<T>(q01) : CT(0);
+                v3 = (ra1 && cb1) ? widen<T>(q11) : CT(0);
             } else {
-                sums[2] = fma_ct(g, dA, sums[2]);
-                sums[3] = fma_ct(g, dB, sums[3]);
+                const int xr0 = first ? D0.xr0 : D1.xr0, xr1 = first ? D0.xr1 : D1.xr1;
+                auto xtap = [&](int ar, int bc) -> CT {   // folded coordinates: always a source element; outside the window: the zero words
+                    if constexpr (SMALL || PAD == 1 || SIMPLE) {
+                        return widen<T>(lds_at<S>(smem, inside ? xb + (ar * S2 + bc) * ES : kZero));
+                    } else {
+                        if (!inside) return CT(0);
+                        if (ar >= xr0 && ar <= xr1) return widen<T>(lds_at<S>(smem, xb + (ar * S2 + bc) * ES));
+                        return widen<T>(xg[static_cast<uint64_t>(ple) * p.XP + static_cast<uint32_t>(ar * S2 + bc)]);
+                    }
+                };
+                const int ar = S1 == 1 ? 0 : fold_index(a, S1, PAD), ar1 = S1 == 1 ? 0 : fold_index(a + 1, S1, PAD);
+                const int bc = S2 == 1 ? 0 : fold_index(b, S2, PAD), bc1 = S2 == 1 ? 0 : fold_index(b + 1, S2, PAD);
+                v0 = xtap(ar, bc);
+                v1 = xtap(ar1, bc);
+                v2 = xtap(ar, bc1);
+                v3 = xtap(ar1, bc1);
             }
+            const CT dA = v2 - v0, dB = v3 - v1;
+            // (the product goes to the sums of the chunk's first plane or of its second; selected, not multiplied by zero: 0 x inf)
+            const CT pA = g * dA, pB = g * dB;
+            sums[0] += first ? pA : CT(0);
+            sums[1] += first ? pB : CT(0);
+            sums[2] += first ? CT(0) : pA;
+            sums[3] += first ? CT(0) : pB;
             // grad_x (:299-324)
-            const int ga = O1 == 1 ? 0 : io - g1, gbc = O2 == 1 ? 0 : jo - g2;
-            if constexpr (ACTIVE) {
-                const CT fr[2] = {first ? D0.f1 : D1.f1, first ? D0.f2 : D1.f2};
-                const int ga1 = O1 == 1 ? 0 : ga + 1, gb1 = O2 == 1 ? 0 : gbc + 1;
-                S rv;
-                if (p.nd == 1) {
-                    const CT u[2] = {widen<T>(gtap(ga, gbc)), widen<T>(gtap(ga, gb1))};
-                    rv = narrow<T>(interp_t<T, 1>(u, fr + 1));
+            if constexpr (PADZ) {
+                const bool ra = inside && static_cast<unsigned>(ga) < static_cast<unsigned>(O1), cb = static_cast<unsigned>(gbc) < static_cast<unsigned>(O2);
+                if constexpr (!ACTIVE) {
+                    if constexpr (SMALL) {
+                        res.e[e] = lds_at<S>(smem, (ra && cb) ? gb + (ga * O2 + gbc) * ES : kZero);
+                    } else {
+                        res.e[e] = lds_at<S>(smem, (ra && cb) ? gb + (ga * O2 + gbc) * ES : kZero);
+                    }
                 } else {
-                    const CT u[4] = {widen<T>(gtap(ga, gbc)), widen<T>(gtap(ga1, gbc)), widen<T>(gtap(ga, gb1)), widen<T>(gtap(ga1, gb1))};
-                    rv = narrow<T>(interp_t<T, 2>(u, fr));
+                    const bool ra1 = O1 == 1 ? ra : inside && static_cast<unsigned>(ga + 1) < static_cast<unsigned>(O1);
+                    const bool cb1 = O2 == 1 ? cb : static_cast<unsigned>(gbc + 1) < static_cast<unsigned>(O2);
+                    const int base = min(max(gb + (ga * O2 + gbc) * ES, 0), glim);
+                    const int dn = O1 == 1 ? 0 : O2 * ES, rt = O2 == 1 ? 0 : ES;
+                    const S q00 = lds_at<S>(smem, base), q01 = lds_at<S>(smem, base + rt), q10 = lds_at<S>(smem, base + dn), q11 = lds_at<S>(smem, base + dn + rt);
+                    const CT fr[2] = {first ? D0.f1 : D1.f1, first ? D0.f2 : D1.f2};
+                    const CT u00 = (ra && cb) ? widen<T>(q00) : CT(0), u10 = (ra1 && cb) ? widen<T>(q10) : CT(0);
+                    const CT u01 = (ra && cb1) ? widen<T>(q01) : CT(0), u11 = (ra1 && cb1) ? widen<T>(q11) : CT(0);
+                    S rv;
+                    if (one_d) {
+                        const CT u[2] = {u00, u01};
+                        rv = narrow<T>(interp_t<T, 1>(u, fr + 1));
+                    } else {
+                        const CT u[4] = {u00, u10, u01, u11};
+                        rv = narrow<T>(interp_t<T, 2>(u, fr));
+                    }
+                    res.e[e] = inside ? rv : zero;
                 }
-                res.e[e] = inside ? rv : zero;
             } else {
-                res.e[e] = gtap(ga, gbc);
+                const int gr0 = first ? D0.gr0 : D1.gr0, gr1 = first ? D0.gr1 : D1.gr1;
+                auto gtap = [&](int ar, int bc) -> S {   // grad_out (row ar, column bc), folded in the window's sizes (:295-297, :319-324)
+                    if constexpr (SMALL || PAD == 1 || SIMPLE) {
+                        return lds_at<S>(smem, inside ? gb + (ar * O2 + bc) * ES : kZero);
+                    } else {
+                        if (!inside) return zero;
+                        if (ar >= gr0 && ar <= gr1) return lds_at<S>(smem, gb + (ar * O2 + bc) * ES);
+                        return gg[static_cast<uint64_t>(ple) * p.OP + static_cast<uint32_t>(ar * O2 + bc)];
+                    }
+                };
+                const int ar = O1 == 1 ? 0 : fold_index(ga, O1, PAD), bc = O2 == 1 ? 0 : fold_index(gbc, O2, PAD);
+                if constexpr (!ACTIVE) {
+                    res.e[e] = gtap(ar, bc);
+                } else {
+                    const int ar1 = O1 == 1 ? 0 : fold_index(ga + 1, O1, PAD), bc1 = O2 == 1 ? 0 : fold_index(gbc + 1, O2, PAD);
+                    const CT fr[2] = {first ? D0.f1 : D1.f1, first ? D0.f2 : D1.f2};
+                    S rv;
+                    if (one_d) {
+                        const CT u[2] = {widen<T>(gtap(ar, bc)), widen<T>(gtap(ar, bc1))};
+                        rv = narrow<T>(interp_t<T, 1>(u, fr + 1));
+                    } else {
+                        const CT u[4] = {widen<T>(gtap(ar, bc)), widen<T>(gtap(ar1, bc)), widen<T>(gtap(ar, bc1)), widen<T>(gtap(ar1, bc1))};
+                        rv = narrow<T>(interp_t<T, 2>(u, fr));
+                    }
+                    res.e[e] = inside ? rv : zero;
+                }
             }
             ++j;
             if (j == S2) {
@@ -486,6 +586,16 @@ __global__ __launch_bounds__(kThreads) void flat_backward(const FlatParams p, in
                 if (i == S1) i = 0;
             }
         }
+        };
+        bool simple = ecut == E;
+        if constexpr (!SMALL && PAD >= 2) {
+            // rows this chunk reads, unfolded, of the input and of the gradient: inside the plane / the window nothing folds
+            const int ilast = static_cast<int>(fdiv(static_cast<uint32_t>(r) + E - 1, p.d_SR));
+            const int a_lo = i - D0.c1, a_hi = ilast - D0.c1 + 1, g_lo = i - L1 - D0.g1, g_hi = ilast - L1 - D0.g1 + (ACTIVE ? 1 : 0);
+            simple = simple && (S1 == 1 || (a_lo >= 0 && a_hi < S1)) && (O1 == 1 || (g_lo >= 0 && g_hi < O1));
+        }
+        if (__all(simple)) elements(std::true_type{});
+        else elements(std::false_type{});
         S *op = static_cast<S *>(p.out) + f;
         if (f + E <= p.total) {
             store_chunk<S, E>(op, res);
@@ -570,6 +680,7 @@ struct FlatPlan {
     bool ok, small;
     size_t lds;        // dynamic LDS bytes
     int gcov_off;      // backward: offset of the gradient's cover behind the x cover
+    int front;         // slack in front of the first cover
     uint64_t steps;
 };
 
@@ -588,14 +699,17 @@ FlatPlan flat_plan(const Geometry &g, int es, bool backward) {
     const int64_t step_bytes = kThreads * 16;
     const int64_t nplanes = (step_bytes + SPB - 1) / SPB + 1;                 // planes a step can touch
     const int rec = es == 8 ? 56 : 48;   // sizeof(PlaneRec<CT>)
+    // one row (+ 2 elements) of slack behind the covers: the clamp of the zeros-padding corner reads never moves a valid group
+    const size_t slack = static_cast<size_t>(((std::max(S1 == 1 ? 0 : S2, O1 == 1 ? 0 : O2) + 2) * es + 15) / 16 * 16);
     // small: whole planes of every staged tensor
     const int64_t cx_small = cover_bytes(nplanes * XPB), cg_small = cover_bytes(nplanes * OPB);
     if (nplanes <= kMaxPlanes && cx_small <= kCoverBudget && (!backward || cg_small <= kCoverBudget)) {
         pl.ok = true;
         pl.small = true;
-        const int64_t tab = ((kMaxPlanes * rec + 15) / 16) * 16;
+        const int64_t tab = kTab + ((kMaxPlanes * rec + 15) / 16) * 16;
         pl.gcov_off = static_cast<int>(cx_small);
-        pl.lds = static_cast<size_t>(tab + (backward ? kThreads * 4 * (es == 8 ? 8 : 4) + cx_small + cg_small : cx_small));
+        pl.front = static_cast<int>(slack);
+        pl.lds = static_cast<size_t>(tab + (backward ? kThreads * 4 * (es == 8 ? 8 : 4) + cx_small + cg_small : cx_small)) + 2 * slack;
         return pl;
     }
     // large: at most two planes per step, row ranges
@@ -607,9 +721,10 @@ FlatPlan flat_plan(const Geometry &g, int es, bool backward) {
     if (cx_large > kCoverBudget || (backward && cg_large > kCoverBudget)) return pl;
     pl.ok = true;
     pl.small = false;
-    const int64_t tab = ((2 * rec + 15) / 16) * 16;
+    const int64_t tab = kTab + ((2 * rec + 15) / 16) * 16;
     pl.gcov_off = static_cast<int>(cx_large);
-    pl.lds = static_cast<size_t>(tab + (backward ? kThreads * 4 * (es == 8 ? 8 : 4) + cx_large + cg_large : cx_large));
+    pl.front = static_cast<int>(slack);
+    pl.lds = static_cast<size_t>(tab + (backward ? kThreads * 4 * (es == 8 ? 8 : 4) + cx_large + cg_large : cx_large)) + 2 * slack;
     return pl;
 }
 
@@ -628,29 +743,28 @@ bool flat_common_ok(const Geometry &g, int dtype, const void *a, const void *b) 
     return true;
 }
 
-template <typename T, bool SMALL>
-void launch_flat_forward(const FlatParams &p, size_t lds, bool active, bool padz, hipStream_t st) {
+template <typename T, bool ACTIVE, bool SMALL>
+void launch_flat_forward(const FlatParams &p, size_t lds, int pad, hipStream_t st) {
     const dim3 grid(p.steps_per_xcd * 8), block(kThreads);
-    if (active) {
-        if (padz) hipLaunchKernelGGL((flat_forward<T, true, true, SMALL>), grid, block, lds, st, p);
-        else hipLaunchKernelGGL((flat_forward<T, true, false, SMALL>), grid, block, lds, st, p);
-    } else {
-        if (padz) hipLaunchKernelGGL((flat_forward<T, false, true, SMALL>), grid, block, lds, st, p);
-        else hipLaunchKernelGGL((flat_forward<T, false, false, SMALL>), grid, block, lds, st, p);
+    switch (pad) {
+    case 0: hipLaunchKernelGGL((flat_forward<T, ACTIVE, 0, SMALL>), grid, block, lds, st, p); break;
+    case 1: hipLaunchKernelGGL((flat_forward<T, ACTIVE, 1, SMALL>), grid, block, lds, st, p); break;
+    case 2: hipLaunchKernelGGL((flat_forward<T, ACTIVE, 2, SMALL>), grid, block, lds, st, p); break;
+    case 3: hipLaunchKernelGGL((flat_forward<T, ACTIVE, 3, SMALL>), grid, block, lds, st, p); break;
+    default: hipLaunchKernelGGL((flat_forward<T, ACTIVE, 4, SMALL>), grid, block, lds, st, p); break;
     }
 }
 
-template <typename T, bool SMALL>
-void launch_flat_backward(const FlatParams &p, const FlatPlan &pl, bool active, bool padz, int N, void *gw, hipStream_t st) {
+template <typename T, bool ACTIVE, bool SMALL>
+void launch_flat_backward(const FlatParams &p, const FlatPlan &pl, int pad, int N, void *gw, hipStream_t st) {
     const dim3 grid(p.steps_per_xcd * 8), block(kThreads);
-    if (active) hipLaunchKernelGGL((flat_prep<T, true>), dim3((p.C + kThreads - 1) / kThreads), block, 0, st, p);
-    else hipLaunchKernelGGL((flat_prep<T, false>), dim3((p.C + kThreads - 1) / kThreads), block, 0, st, p);
-    if (active) {
-        if (padz) hipLaunchKernelGGL((flat_backward<T, true, true, SMALL>), grid, block, pl.lds, st, p, pl.gcov_off);
-        else hipLaunchKernelGGL((flat_backward<T, true, false, SMALL>), grid, block, pl.lds, st, p, pl.gcov_off);
-    } else {
-        if (padz) hipLaunchKernelGGL((flat_backward<T, false, true, SMALL>), grid, block, pl.lds, st, p, pl.gcov_off);
-        else hipLaunchKernelGGL((flat_backward<T, false, false, SMALL>), grid, block, pl.lds, st, p, pl.gcov_off);
+    hipLaunchKernelGGL((flat_prep<T, ACTIVE>), dim3((p.C + kThreads - 1) / kThreads), block, 0, st, p);
+    switch (pad) {
+    case 0: hipLaunchKernelGGL((flat_backward<T, ACTIVE, 0, SMALL>), grid, block, pl.lds, st, p, pl.gcov_off); break;
+    case 1: hipLaunchKernelGGL((flat_backward<T, ACTIVE, 1, SMALL>), grid, block, pl.lds, st, p, pl.gcov_off); break;
+    case 2: hipLaunchKernelGGL((flat_backward<T, ACTIVE, 2, SMALL>), grid, block, pl.lds, st, p, pl.gcov_off); break;
+    case 3: hipLaunchKernelGGL((flat_backward<T, ACTIVE, 3, SMALL>), grid, block, pl.lds, st, p, pl.gcov_off); break;
+    default: hipLaunchKernelGGL((flat_backward<T, ACTIVE, 4, SMALL>), grid, block, pl.lds, st, p, pl.gcov_off); break;
     }
     hipLaunchKernelGGL((flat_reduce<T>), dim3(p.C), dim3(64), 0, st, p, N, static_cast<typename T::S *>(gw));
 }
@@ -678,8 +792,8 @@ void fill_params(FlatParams &p, const Geometry &g, int es, bool backward, const 
     p.d_per2 = make_fastdiv(static_cast<uint32_t>(map_period(p.S2, p.pad)));
     p.d_pero1 = make_fastdiv(static_cast<uint32_t>(map_period(p.O1, p.pad)));
     p.d_pero2 = make_fastdiv(static_cast<uint32_t>(map_period(p.O2, p.pad)));
-    p.x_bytes = p.planes * p.XP * es;
-    p.go_bytes = p.planes * p.OP * es;
+    p.lds_bytes = static_cast<int>(pl.lds);
+    p.front = pl.front;
 }
 
 }  // namespace
@@ -703,17 +817,18 @@ int flat_forward(const Geometry &g, int dtype, const void *x, const void *w, int
     p.w = w;
     p.wkind = wkind;
     fill_params(p, g, es, false, pl);
-    const bool padz = g.pad == 0, active = g.active != 0;
+    const bool active = g.active != 0;
     note_kernel(active ? "flat_active_forward" : "flat_gather_forward");
-#define SHIFTND_FLAT_FWD(TT) \
-    if (pl.small) launch_flat_forward<TT, true>(p, pl.lds, active, padz, st); \
-    else launch_flat_forward<TT, false>(p, pl.lds, active, padz, st);
-    switch (dtype) {
-    case SHIFTND_F32: SHIFTND_FLAT_FWD(f32_t) break;
-    case SHIFTND_F64: SHIFTND_FLAT_FWD(f64_t) break;
-    case SHIFTND_F16: SHIFTND_FLAT_FWD(f16_t) break;
-    default: SHIFTND_FLAT_FWD(bf16_t) break;
-    }
+    // (the sparse shift is a raw copy: one instantiation per element size)
+#define SHIFTND_FLAT_FWD(TT, ACT) \
+    if (pl.small) launch_flat_forward<TT, ACT, true>(p, pl.lds, g.pad, st); \
+    else launch_flat_forward<TT, ACT, false>(p, pl.lds, g.pad, st);
+    if (!active) {
+        if (es == 2) { SHIFTND_FLAT_FWD(f16_t, false) } else if (es == 4) { SHIFTND_FLAT_FWD(f32_t, false) } else { SHIFTND_FLAT_FWD(f64_t, false) }
+    } else if (dtype == SHIFTND_F32) { SHIFTND_FLAT_FWD(f32_t, true)
+    } else if (dtype == SHIFTND_F64) { SHIFTND_FLAT_FWD(f64_t, true)
+    } else if (dtype == SHIFTND_F16) { SHIFTND_FLAT_FWD(f16_t, true)
+    } else { SHIFTND_FLAT_FWD(bf16_t, true) }
 #undef SHIFTND_FLAT_FWD
     return SHIFTND_OK;
 }
@@ -748,17 +863,20 @@ int flat_backward(const Geometry &g, int dtype, const void *go, const void *x, c
     auto up = [](size_t v) { return (v + 255) & ~static_cast<size_t>(255); };
     p.partials = static_cast<double *>(workspace);
     p.desc = reinterpret_cast<FlatDesc *>(static_cast<char *>(workspace) + up((pl.steps + static_cast<uint64_t>(g.N) * g.C + 1) * 2 * sizeof(double)));
-    const bool padz = g.pad == 0, active = g.active != 0;
+    const bool active = g.active != 0;
     note_kernel("flat_backward");
-#define SHIFTND_FLAT_BWD(TT) \
-    if (pl.small) launch_flat_backward<TT, true>(p, pl, active, padz, static_cast<int>(g.N), gw, st); \
-    else launch_flat_backward<TT, false>(p, pl, active, padz, static_cast<int>(g.N), gw, st);
+#define SHIFTND_FLAT_BWD(TT, ACT) \
+    if (pl.small) launch_flat_backward<TT, ACT, true>(p, pl, g.pad, static_cast<int>(g.N), gw, st); \
+    else launch_flat_backward<TT, ACT, false>(p, pl, g.pad, static_cast<int>(g.N), gw, st);
+#define SHIFTND_FLAT_BWD2(TT) \
+    if (active) { SHIFTND_FLAT_BWD(TT, true) } else { SHIFTND_FLAT_BWD(TT, false) }
     switch (dtype) {
-    case SHIFTND_F32: SHIFTND_FLAT_BWD(f32_t) break;
-    case SHIFTND_F64: SHIFTND_FLAT_BWD(f64_t) break;
-    case SHIFTND_F16: SHIFTND_FLAT_BWD(f16_t) break;
-    default: SHIFTND_FLAT_BWD(bf16_t) break;
+    case SHIFTND_F32: SHIFTND_FLAT_BWD2(f32_t) break;
+    case SHIFTND_F64: SHIFTND_FLAT_BWD2(f64_t) break;
+    case SHIFTND_F16: SHIFTND_FLAT_BWD2(f16_t) break;
+    default: SHIFTND_FLAT_BWD2(bf16_t) break;
     }
+#undef SHIFTND_FLAT_BWD2
 #undef SHIFTND_FLAT_BWD
     return SHIFTND_OK;
 }

@@ -129,6 +129,21 @@ __device__ __forceinline__ void stage(const void *src, uint32_t first, int n, ch
     }
 }
 
+// ... by the first wave alone (large planes: the covers depend on the channel's shift; the scalar work that leads to them -- and the CU
+// has ONE scalar unit -- is done by one wave of the four instead of all of them)
+__device__ __forceinline__ void stage_wave0(const void *src, uint32_t first, int n, char *smem, int dst) {
+    const int lane = static_cast<int>(threadIdx.x);   // (called under threadIdx.x < 64)
+    const char *base = static_cast<const char *>(src) + (static_cast<uint64_t>(first) << 4);
+    for (int k = 0; k * 64 < n; ++k) {
+        const int q = k * 64 + lane;
+        if (q < n) {
+            char *dst_wave = smem + dst + k * 64 * 16;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(base + static_cast<uint32_t>(q) * 16u),
+                                             (__attribute__((address_space(3))) void *)dst_wave, 16, 0, 0);
+        }
+    }
+}
+
 // the unfolded source rows [a, b] of a plane clamped into it (exact for zeros and border padding); empty when zeros padding puts
 // every row outside
 __device__ __forceinline__ void clamp_rows(int a, int b, int len, bool zeros, int &r0, int &r1) {
@@ -195,20 +210,20 @@ __global__ __launch_bounds__(kThreads) void flat_forward(const FlatParams p) {
             table[tid] = r;
         }
     } else {
-        // at most two planes; every thread evaluates both (uniform: scalar loads, scalar arithmetic)
+        // at most two planes; the first wave evaluates them, stages their covers and writes the table
         int used = 0;
-#pragma unroll
-        for (int k = 0; k < 2; ++k) {
+        if (tid < 64)
+        for (int k = 0; k < nplanes; ++k) {   // (uniform trip count: one plane for all but the steps at a plane's end)
             const uint32_t pl = plA + k;
             Rec r;
-            channel(min(pl, p.planes - 1), r.c1, r.c2, r.f1, r.f2);
+            channel(pl, r.c1, r.c2, r.f1, r.f2);
             // output rows of this plane inside the step
             const uint32_t lo = k == 0 ? f0 - plA * p.OP : 0u, hi = (k == 0 && plB == plA) || k == 1 ? f1 - pl * p.OP : p.OP - 1u;
             const int i0 = static_cast<int>(fdiv(lo, p.d_SR)), i1 = static_cast<int>(fdiv(hi, p.d_SR));
             int r0 = 0, r1 = -1;
-            if (k < nplanes) clamp_rows(S1 == 1 ? 0 : i0 + L1 - r.c1, S1 == 1 ? 0 : i1 + L1 - r.c1 + (ACTIVE ? 1 : 0), S1, PADZ, r0, r1);
+            clamp_rows(S1 == 1 ? 0 : i0 + L1 - r.c1, S1 == 1 ? 0 : i1 + L1 - r.c1 + (ACTIVE ? 1 : 0), S1, PADZ, r0, r1);
             const Cover cv = row_cover<ES>(pl, p.XP, S2, r0, r1);
-            stage(p.x, cv.first, cv.n, smem, COV + used);
+            stage_wave0(p.x, cv.first, cv.n, smem, COV + used);
             r.xb = COV + used + cv.base;
             r.xr0 = r0;
             r.xr1 = r1;
@@ -279,11 +294,13 @@ __global__ __launch_bounds__(kThreads) void flat_forward(const FlatParams p) {
                     return xg[static_cast<uint64_t>(ple) * p.XP + static_cast<uint32_t>(ar * S2 + bc)];   // a row the padding folds out of the cover
                 }
             };
-            const int ar = S1 == 1 ? 0 : fold_index(a, S1, PAD), bc = S2 == 1 ? 0 : fold_index(b, S2, PAD);
+            // (SIMPLE on large planes: the chunk's rows lie inside the plane unfolded)
+            constexpr bool ROWS_IN = SIMPLE && !SMALL && PAD >= 2;
+            const int ar = S1 == 1 ? 0 : (ROWS_IN ? a : fold_index(a, S1, PAD)), bc = S2 == 1 ? 0 : fold_index(b, S2, PAD);
             if constexpr (!ACTIVE) {
                 res.e[e] = tap(ar, bc);
             } else {
-                const int ar1 = S1 == 1 ? 0 : fold_index(a + 1, S1, PAD), bc1 = S2 == 1 ? 0 : fold_index(b + 1, S2, PAD);
+                const int ar1 = S1 == 1 ? 0 : (ROWS_IN ? a + 1 : fold_index(a + 1, S1, PAD)), bc1 = S2 == 1 ? 0 : fold_index(b + 1, S2, PAD);
                 const CT fr[2] = {first ? D0.f1 : D1.f1, first ? D0.f2 : D1.f2};
                 if (one_d) {
                     const CT v[2] = {widen<T>(tap(ar, bc)), widen<T>(tap(ar, bc1))};
@@ -404,15 +421,15 @@ __global__ __launch_bounds__(kThreads) void flat_backward(const FlatParams p, in
         }
     } else {
         int usedx = 0, usedg = 0;
-#pragma unroll
-        for (int k = 0; k < 2; ++k) {
+        if (tid < 64)   // (the first wave alone: see stage_wave0)
+        for (int k = 0; k < nplanes; ++k) {   // (uniform trip count: one plane for all but the steps at a plane's end)
             const uint32_t pl = plA + k;
             Rec r;
-            fill(min(pl, p.planes - 1), r);
+            fill(pl, r);
             const uint32_t lo = k == 0 ? f0 - plA * p.XP : 0u, hi = (k == 0 && plB == plA) || k == 1 ? f1 - pl * p.XP : p.XP - 1u;
             const int i0 = static_cast<int>(fdiv(lo, p.d_SR)), i1 = static_cast<int>(fdiv(hi, p.d_SR));
             int xr0 = 0, xr1 = -1, gr0 = 0, gr1 = -1;
-            if (k < nplanes) {
+            {
                 // rows of the window inside the step's rows (elements outside the window read nothing)
                 const int w0 = max(i0, L1), w1 = min(i1, L1 + O1 - 1);
                 if (w0 <= w1) {
@@ -421,8 +438,8 @@ __global__ __launch_bounds__(kThreads) void flat_backward(const FlatParams p, in
                 }
             }
             const Cover cx = row_cover<ES>(pl, p.XP, S2, xr0, xr1), cg = row_cover<ES>(pl, p.OP, O2, gr0, gr1);
-            stage(p.x, cx.first, cx.n, smem, XCOV + usedx);
-            stage(p.go, cg.first, cg.n, smem, GCOV + usedg);
+            stage_wave0(p.x, cx.first, cx.n, smem, XCOV + usedx);
+            stage_wave0(p.go, cg.first, cg.n, smem, GCOV + usedg);
             r.xb = XCOV + usedx + cx.base;
             r.gb = GCOV + usedg + cg.base;
             r.xr0 = xr0;
@@ -509,7 +526,8 @@ __global__ __launch_bounds__(kThreads) void flat_backward(const FlatParams p, in
                         return widen<T>(xg[static_cast<uint64_t>(ple) * p.XP + static_cast<uint32_t>(ar * S2 + bc)]);
                     }
                 };
-                const int ar = S1 == 1 ? 0 : fold_index(a, S1, PAD), ar1 = S1 == 1 ? 0 : fold_index(a + 1, S1, PAD);
+                constexpr bool ROWS_IN = SIMPLE && !SMALL && PAD >= 2;   // (the chunk's rows lie inside the plane / the window unfolded)
+                const int ar = S1 == 1 ? 0 : (ROWS_IN ? a : fold_index(a, S1, PAD)), ar1 = S1 == 1 ? 0 : (ROWS_IN ? a + 1 : fold_index(a + 1, S1, PAD));
                 const int bc = S2 == 1 ? 0 : fold_index(b, S2, PAD), bc1 = S2 == 1 ? 0 : fold_index(b + 1, S2, PAD);
                 v0 = xtap(ar, bc);
                 v1 = xtap(ar1, bc);
@@ -562,11 +580,12 @@ __global__ __launch_bounds__(kThreads) void flat_backward(const FlatParams p, in
                         return gg[static_cast<uint64_t>(ple) * p.OP + static_cast<uint32_t>(ar * O2 + bc)];
                     }
                 };
-                const int ar = O1 == 1 ? 0 : fold_index(ga, O1, PAD), bc = O2 == 1 ? 0 : fold_index(gbc, O2, PAD);
+                constexpr bool GROWS_IN = SIMPLE && !SMALL && PAD >= 2;
+                const int ar = O1 == 1 ? 0 : (GROWS_IN ? ga : fold_index(ga, O1, PAD)), bc = O2 == 1 ? 0 : fold_index(gbc, O2, PAD);
                 if constexpr (!ACTIVE) {
                     res.e[e] = gtap(ar, bc);
                 } else {
-                    const int ar1 = O1 == 1 ? 0 : fold_index(ga + 1, O1, PAD), bc1 = O2 == 1 ? 0 : fold_index(gbc + 1, O2, PAD);
+                    const int ar1 = O1 == 1 ? 0 : (GROWS_IN ? ga + 1 : fold_index(ga + 1, O1, PAD)), bc1 = O2 == 1 ? 0 : fold_index(gbc + 1, O2, PAD);
                     const CT fr[2] = {first ? D0.f1 : D1.f1, first ? D0.f2 : D1.f2};
                     S rv;
                     if (one_d) {

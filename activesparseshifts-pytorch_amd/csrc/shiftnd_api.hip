@@ -123,8 +123,7 @@ int forward_common(const shiftnd_problem *p, const void *x, const int64_t *xs, c
         }
         // rows that are not whole 16-byte pieces (14 x 14, 62 x 62, 222 x 222 ...; float tensors): one-step workgroups over the
         // tensor's flat chunk stream
-        // (... and windows the chunk kernels asked above did not take: output planes that are not whole pieces)
-        if (g_policy == 0 && wkind == p->dtype && (g_flat == 2 || ragged_rows(g, p->dtype) || cropped(g)) && flat_forward_eligible(g, p->dtype, x, out)) {
+        if (g_policy == 0 && wkind == p->dtype && ragged_rows(g, p->dtype) && flat_forward_eligible(g, p->dtype, x, out)) {
             g_last_path = SHIFTND_PATH_PLANE;
             return finish(flat_forward(g, p->dtype, x, w, wkind, out, st));
         }
@@ -161,6 +160,12 @@ int forward_common(const shiftnd_problem *p, const void *x, const int64_t *xs, c
             g_last_path = SHIFTND_PATH_PLANE;
             return finish(plane_forward(g, p->dtype, x, w, wkind, wzp, fill, out, st));
         }
+    }
+    // windows no chunk kernel took (output planes that are not a whole number of 16-byte pieces): the flat chunk stream before the
+    // one-thread-per-element kernels
+    if (g_policy == 0 && wkind == p->dtype && cropped(g) && flat_forward_eligible(g, p->dtype, x, out)) {
+        g_last_path = SHIFTND_PATH_PLANE;
+        return finish(flat_forward(g, p->dtype, x, w, wkind, out, st));
     }
     if (g_policy == 0 && small_forward_eligible(g, p->dtype)) {  // interpolating, rows not whole 16-byte pieces, small planes
         g_last_path = SHIFTND_PATH_PLANE;

@@ -364,138 +364,8 @@ struct BandPlan {
     bool ok;
 };
 
-// The same kernel for planes of at most kTablePlane elements (32 x 32 and below: the 14 x 14 / 7 x 7 stages), with the
-// index arithmetic taken out of the element loop: once per workgroup every output element of a plane gets its corner
-// offsets (int16, into a staged plane) -- for the input corners and for the gradient taps -- and every staged plane
-// ends with one zero element that the offsets of padded corners point to.  Per element that leaves one division
-// (flat index -> plane), two table reads, the taps and the arithmetic: no map lookups, no validity selects.
-constexpr int kTablePlane = 1024;
-
-template <typename T, int ND, bool ACTIVE, bool BACKWARD>
-__global__ __launch_bounds__(kThreads) void small_table_kernel(const SmallParams p) {
-    using S = typename T::S;
-    using CT = typename T::C;
-    constexpr int NC = 1 << ND;
-    constexpr int NG = BACKWARD ? (ACTIVE ? NC : 1) : 0;   // gradient taps per element
-    static_assert(ACTIVE || BACKWARD, "the sparse-shift forward is served by the gather kernels");
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    __shared__ double scratch[kThreads / 64];
-    int *maps = reinterpret_cast<int *>(smem);
-    const int S0 = p.S[0], S1 = p.S[1], S2 = p.S[2], PE = p.PE, PP = PE + 1;   // PP: staged plane pitch (the zero element)
-    const int *m0 = maps, *m1 = m0 + S0 + 1, *m2 = m1 + S1 + 1;
-    int *gmaps = maps + p.map_entries;
-    const int *g0 = gmaps, *g1 = g0 + S0 + 1, *g2 = g1 + S1 + 1;
-    int16_t *xt = reinterpret_cast<int16_t *>(smem + map_bytes16(p.map_entries, BACKWARD));
-    int16_t *gt = xt + static_cast<size_t>(PE) * NC;
-    // (element buffers at a 16-byte boundary behind the tables)
-    const size_t tab_bytes = (static_cast<size_t>(PE) * (NC + NG) * sizeof(int16_t) + 15) & ~static_cast<size_t>(15);
-    S *xbuf = reinterpret_cast<S *>(reinterpret_cast<char *>(xt) + tab_bytes);
-    S *gbuf = xbuf + static_cast<size_t>(p.ppr) * PP;
-
-    const unsigned bid = p.xcd_blocks ? (blockIdx.x & 7u) * p.xcd_blocks + (blockIdx.x >> 3) : blockIdx.x;
-    const int grp = fdiv(bid, p.d_C), c = static_cast<int>(bid) - grp * p.C;
-    const int n0 = grp * p.ppr * p.rpw, nw = min(p.ppr * p.rpw, p.N - n0);
-
-    int64_t sh[3] = {0, 0, 0};
-    CT dw[3] = {CT(0), CT(0), CT(0)};
-    CT wv[3];
-    load_weights3<CT>(p.w, p.wkind, static_cast<int64_t>(c) * p.nd, p.wcol, wv);
-#pragma unroll
-    for (int d = 0; d < 3; ++d) {
-        if (p.wcol[d] >= 0) {
-            if constexpr (BACKWARD) prep_shift_backward<CT>(wv[d], ACTIVE, sh[d], dw[p.wcol[d]]);
-            else prep_shift_forward<CT>(wv[d], true, sh[d], dw[p.wcol[d]]);
-        }
-    }
-    build_maps(maps, p.S, sh, -1, p.pad, p.d_per);
-    if constexpr (BACKWARD) build_maps(gmaps, p.S, sh, ACTIVE ? -1 : +1, p.pad, p.d_per);
-    __syncthreads();
-    // corner q of element (a, b, cc) through maps q0 / q1 / q2: offset into a staged plane, PE = the zero element
-    // (corner order: bit r = +1 along the r-th spatial dim of the tensor)
-    auto corner = [&](const int *q0, const int *q1, const int *q2, int a, int b, int cc, int q) {
-        int ra = 0, rb = 0, rc;
-        if constexpr (ND == 1) {
-            rc = q2[cc + (q & 1)];
-        } else if constexpr (ND == 2) {
-            rb = q1[b + (q & 1)];
-            rc = q2[cc + (q >> 1)];
-        } else {
-            ra = q0[a + (q & 1)];
-            rb = q1[b + ((q >> 1) & 1)];
-            rc = q2[cc + (q >> 2)];
-        }
-        return (ra >= 0 && rb >= 0 && rc >= 0) ? (ra * S1 + rb) * S2 + rc : PE;
-    };
-    for (int o = threadIdx.x; o < PE; o += kThreads) {
-        const int a = fdiv(o, p.d_S12), rem = o - a * (S1 * S2);
-        const int b = fdiv(rem, p.d_S2), cc = rem - b * S2;
-#pragma unroll
-        for (int q = 0; q < NC; ++q) xt[o * NC + q] = static_cast<int16_t>(corner(m0, m1, m2, a, b, cc, q));
-        if constexpr (BACKWARD) {
-            if constexpr (ACTIVE) {
-#pragma unroll
-                for (int q = 0; q < NC; ++q) gt[o * NC + q] = static_cast<int16_t>(corner(g0, g1, g2, a, b, cc, q));
-            } else {
-                gt[o] = static_cast<int16_t>(corner(g0, g1, g2, a, b, cc, 0));
-            }
-        }
-    }
-
-    const int64_t nstride = static_cast<int64_t>(p.C) * PE;
-    const S *xb = static_cast<const S *>(p.x) + (static_cast<int64_t>(n0) * p.C + c) * PE;
-    const S *gb = BACKWARD ? static_cast<const S *>(p.go) + (static_cast<int64_t>(n0) * p.C + c) * PE : xb;
-    S *ob = static_cast<S *>(p.out) + (static_cast<int64_t>(n0) * p.C + c) * PE;
-    double acc[3] = {0.0, 0.0, 0.0};
-    const S zero = narrow<T>(CT(0));
-    for (int r = 0; r * p.ppr < nw; ++r) {
-        const int np = min(p.ppr, nw - r * p.ppr), total = np * PE;
-        const int64_t rbase = static_cast<int64_t>(r) * p.ppr * nstride;
-        __syncthreads();  // the tables are complete / the previous round is done with the buffers
-        for (int idx = threadIdx.x; idx < total; idx += kThreads) {
-            const int pl = fdiv(idx, p.d_PE), o = idx - pl * PE;
-            xbuf[pl * PP + o] = xb[rbase + pl * nstride + o];
-            if constexpr (BACKWARD) gbuf[pl * PP + o] = gb[rbase + pl * nstride + o];
-        }
-        for (int pl = threadIdx.x; pl < np; pl += kThreads) {
-            xbuf[pl * PP + PE] = zero;
-            if constexpr (BACKWARD) gbuf[pl * PP + PE] = zero;
-        }
-        __syncthreads();
-        for (int idx = threadIdx.x; idx < total; idx += kThreads) {
-            const int pl = fdiv(idx, p.d_PE), o = idx - pl * PE;
-            const S *xpl = xbuf + pl * PP;
-            CT v[NC];
-#pragma unroll
-            for (int q = 0; q < NC; ++q) v[q] = widen<T>(xpl[xt[o * NC + q]]);
-            S res;
-            if constexpr (BACKWARD) {
-                const S *gpl = gbuf + pl * PP;
-                CT wg[3];
-                const CT gval = widen<T>(gpl[o]);
-                weight_grads_nd<ND, CT>(v, dw, wg);
-#pragma unroll
-                for (int s = 0; s < ND; ++s) acc[s] += static_cast<double>(gval * wg[s]);
-                if constexpr (ACTIVE) {
-#pragma unroll
-                    for (int q = 0; q < NC; ++q) v[q] = widen<T>(gpl[gt[o * NC + q]]);
-                    res = narrow<T>(interp_t<T, ND>(v, dw));
-                } else {
-                    res = gpl[gt[o]];   // pure copy: the bit pattern is kept (the zero element for padding)
-                }
-            } else {
-                res = narrow<T>(interp_t<T, ND>(v, dw));
-            }
-            ob[rbase + pl * nstride + o] = res;
-        }
-    }
-    if constexpr (BACKWARD) {
-#pragma unroll
-        for (int k = 0; k < 3; ++k) {
-            const double tsum = block_sum(acc[k], scratch);
-            if (threadIdx.x == 0) p.partials[(static_cast<size_t>(grp) * p.C + c) * 3 + k] = tsum;
-        }
-    }
-}
+// (Round 2's table form of this kernel for planes of at most 1024 elements -- the 14 x 14 / 7 x 7 stages -- and the 1-D / 2-D
+// instantiations went with round 5: those shapes are the flat-stream kernels', shiftnd_flat.hip.)
 
 struct SmallPlan {
     int ppr, rpw, groups, map_entries;
@@ -526,6 +396,7 @@ SmallPlan small_plan(const Geometry &g, int es, bool backward) {
     SmallPlan pl{};
     pl.ok = false;
     pl.table = false;
+    if (g.nd != 3) return pl;   // (round 5: 1-D / 2-D planes with ragged rows are the flat-stream kernels', shiftnd_flat.hip)
     for (int d = 0; d < 3; ++d)
         if (g.L[d] != 0 || g.O[d] != g.S[d]) return pl;
     const int64_t pe = g.S[0] * g.S[1] * g.S[2];
@@ -561,15 +432,6 @@ SmallPlan small_plan(const Geometry &g, int es, bool backward) {
     pl.rpw = static_cast<int>(rpw);
     pl.groups = static_cast<int>((g.N + ppr * rpw - 1) / (ppr * rpw));
     pl.lds = map_bytes + static_cast<size_t>(ppr) * static_cast<size_t>(per_plane);
-    if (pe <= kTablePlane && g_small_tune[0] != 2) {   // (knob 24 = 2: the map-based kernel everywhere)
-        const int nc = 1 << g.nd, ng = backward ? (g.active ? nc : 1) : 0;
-        const size_t tab = (static_cast<size_t>(pe) * (nc + ng) * sizeof(int16_t) + 15) & ~static_cast<size_t>(15);
-        const size_t lds = map_bytes + tab + static_cast<size_t>(ppr) * static_cast<size_t>(pe + 1) * es * (backward ? 2 : 1);
-        if (lds <= 60 * 1024) {
-            pl.table = true;
-            pl.lds = lds;
-        }
-    }
     if (pl.lds > 60 * 1024) return pl;
     const int64_t grid = static_cast<int64_t>(pl.groups) * g.C;
     if (grid >= (1LL << 31)) return pl;
@@ -609,15 +471,7 @@ void launch_small(const SmallParams &p, const SmallPlan &pl, bool active, hipStr
     } else { \
         hipLaunchKernelGGL((KERNEL<T, NDV, true, false>), grid, block, pl.lds, st, p); \
     }
-#define SHIFTND_SMALL(NDV) \
-    if (pl.table) { SHIFTND_SMALL_K(small_table_kernel, NDV) } \
-    else { SHIFTND_SMALL_K(small_plane_kernel, NDV) }
-    switch (p.nd) {
-    case 1: SHIFTND_SMALL(1) break;
-    case 2: SHIFTND_SMALL(2) break;
-    default: SHIFTND_SMALL(3) break;
-    }
-#undef SHIFTND_SMALL
+    SHIFTND_SMALL_K(small_plane_kernel, 3)   // (3-D volumes only: small_plan)
 #undef SHIFTND_SMALL_K
 }
 

@@ -685,17 +685,19 @@ def test_tiled_channels_last_16bit_active_and_backward(shape, tdt):
                 ref_o = torch.from_numpy(O.forward(xn, wn, pad, True)).to(tdt)
                 out = abi.forward(xc, wd, pad, True)   # NCHW-contiguous output
                 nchw_tiled = (shape[3] * 2) % 4 == 0
-                assert (abi.last_kernel() == "cl_tiled_active_forward") == nchw_tiled and torch.equal(out, ref), (shape, pad)
+                # (against the contiguous kernel family: within 1 ulp -- the compiler may fuse the final rounding to 16 bits into the last
+                #  multiply-add of one family (v_fma_mixlo: one rounding) and not of the other (two); the oracle is the bar, below)
+                assert (abi.last_kernel() == "cl_tiled_active_forward") == nchw_tiled and _ulp_close(out.cpu(), ref.cpu(), tdt), (shape, pad)
                 assert _ulp_close(out.cpu(), ref_o, tdt), ("oracle", shape, pad)
                 out_cl = torch.empty(shape, dtype=tdt, device=DEV).contiguous(memory_format=cl)
                 abi.forward(xc, wd, pad, True, out=out_cl)
-                assert abi.last_kernel() == "cl_tiled_active_forward" and torch.equal(out_cl, ref), (shape, pad)
+                assert abi.last_kernel() == "cl_tiled_active_forward" and _ulp_close(out_cl.cpu(), ref.cpu(), tdt), (shape, pad)
                 assert _ulp_close(out_cl.cpu(), ref_o, tdt), ("oracle", shape, pad)
                 for active in (0, 1):
                     gx_r, gw_r = abi.backward(go, wd, x, pad, active)
                     gx, gw = abi.backward(goc, wd, xc, pad, active, grad_x=torch.empty(shape, dtype=tdt, device=DEV).contiguous(memory_format=cl))
                     assert abi.last_kernel() == "cl_tiled_backward", (shape, pad, active)
-                    assert torch.equal(gx, gx_r), (shape, pad, active, band_rows)
+                    assert (_ulp_close(gx.cpu(), gx_r.cpu(), tdt) if active else torch.equal(gx, gx_r)), (shape, pad, active, band_rows)
                     assert rel_err(gw.float().cpu().numpy(), gw_r.float().cpu().numpy()) < 2 * gw16_tol(eps), (shape, pad, active)   # (two roundings)
                     gx_o = torch.from_numpy(O.backward(gn, wn, xn, pad, active)[0]).to(tdt)
                     if active:

@@ -1,4 +1,7 @@
-"""Small-plane kernels (csrc/shiftnd_small.hip): contiguous problems whose rows are not whole 16-byte pieces."""
+"""Small-plane kernels (csrc/shiftnd_small.hip): contiguous problems whose rows are not whole 16-byte pieces.  Since round 5 the
+1-D / 2-D shapes of this file run the flat-stream kernels (csrc/shiftnd_flat.hip; their own file: test_flat_gpu.py) by default: the
+small-plane kernels keep the 3-D volumes, the row-band kernels what the flat-stream kernels do not take; the band tests turn the
+flat-stream kernels off (knob 27 = 1) to measure them."""
 import numpy as np
 import pytest
 import torch
@@ -6,6 +9,7 @@ import torch
 from cases import rel_err, gw16_tol
 from oracle import oracle as O
 from test_hip_parity import _ulp_close, _weights
+from test_flat_gpu import flat_serves
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
@@ -19,7 +23,20 @@ def abi():
     yield A
     for k in (24, 25, 26):
         A.set_tuning(k, 1 if k == 24 else 0)
+    A.set_tuning(27, 0)
     A.set_path_policy(0)
+
+
+def _fwd_name(nd, shape=None, es=4):   # who serves an interpolating forward with ragged rows
+    if nd == 3:
+        return "small_plane_forward"
+    return "flat_active_forward" if shape is None or flat_serves(shape, shape, es, False) else "band_plane_forward"
+
+
+def _bwd_name(nd, shape=None, es=4):
+    if nd == 3:
+        return "small_plane_backward"
+    return "flat_backward" if shape is None or flat_serves(shape, shape, es, True) else "band_plane_backward"
 
 
 @pytest.mark.parametrize("dt", ["f32", "f64"])
@@ -40,11 +57,11 @@ def test_small_planes_vs_oracle(abi, shape, dt):
         abi.set_tuning(26, rpw)
         for pad in range(5):
             out = abi.forward(xd, wd, pad, 1)
-            assert (abi.last_kernel() == "small_plane_forward") == ragged, (shape, pad)
+            assert (abi.last_kernel() == _fwd_name(nd, shape, x.itemsize)) == ragged, (shape, pad, abi.last_kernel())
             assert np.array_equal(out.cpu().numpy(), O.forward(x, w, pad, 1)), (shape, pad, ppr, rpw)
             for active in (0, 1):
                 gx, gw = abi.backward(god, wd, xd, pad, active)
-                assert (abi.last_kernel() == "small_plane_backward") == ragged, (shape, pad, active)
+                assert (abi.last_kernel() == _bwd_name(nd, shape, x.itemsize)) == ragged, (shape, pad, active, abi.last_kernel())
                 gx_o, _ = O.backward(go, w, x, pad, active)
                 _, gw64 = O.backward(go.astype(np.float64), w.astype(np.float64), x.astype(np.float64), pad, active)
                 assert np.array_equal(gx.cpu().numpy(), gx_o), (shape, pad, active, ppr, rpw)
@@ -72,9 +89,9 @@ def test_small_planes_16bit_agree_with_the_strided_kernels(abi, tdt):
                 # (16-bit interpolation: the kernel families agree to 1 ulp of the 16-bit type -- the compiler may fuse
                 # a widening into one family's multiply-add -- the sparse shift's grad_x is a raw copy: equal)
                 out = abi.forward(x, w, pad, 1)
-                assert abi.last_kernel() == "small_plane_forward" and _ulp_close(out.cpu(), ref.cpu(), tdt)
+                assert abi.last_kernel() == _fwd_name(nd) and _ulp_close(out.cpu(), ref.cpu(), tdt)
                 gx, gw = abi.backward(go, w, x, pad, active)
-                assert abi.last_kernel() == "small_plane_backward"
+                assert abi.last_kernel() == _bwd_name(nd)
                 assert _ulp_close(gx.cpu(), gx_r.cpu(), tdt) if active else torch.equal(gx, gx_r)
                 assert rel_err(gw.float().cpu().numpy(), gw_r.float().cpu().numpy()) < 2 * gw16_tol(torch.finfo(tdt).eps)   # (two roundings)
                 # ... and against the oracle itself (widened inputs, one rounding), not only against a sibling kernel
@@ -100,7 +117,7 @@ def test_small_planes_full_batch(abi):
             abi.set_path_policy(0)
             out = abi.forward(x, w, 0, 1)
             gx, gw = abi.backward(go, w, x, 0, active)
-            assert abi.last_kernel() == "small_plane_backward"
+            assert abi.last_kernel() == "flat_backward"
             assert torch.equal(out, ref) and torch.equal(gx, gx_r)
             assert rel_err(gw.cpu().numpy(), gw_r.cpu().numpy()) < 1e-5
 
@@ -125,6 +142,7 @@ def test_row_bands_vs_oracle(abi, shape, dt):
     xd, god, wd = torch.from_numpy(x).to(DEV), torch.from_numpy(go).to(DEV), torch.from_numpy(w).to(DEV)
     ragged = (shape[-1] * x.itemsize) % 16 != 0
     assert ragged
+    abi.set_tuning(27, 1)   # (the flat-stream kernels would take most of these shapes: off, the band kernels are measured)
     for br in (0, 1, 3):
         abi.set_tuning(25, br)
         for pad in range(5):
@@ -140,12 +158,14 @@ def test_row_bands_vs_oracle(abi, shape, dt):
                 assert np.array_equal(gx.cpu().numpy(), gx_o), (shape, pad, active, br)
                 assert rel_err(gw.cpu().numpy(), gw64) < (1e-12 if dt == "f64" else 1e-5), (shape, pad, active)
     abi.set_tuning(25, 0)
+    abi.set_tuning(27, 0)
 
 
 def test_row_bands_16bit_and_full_size(abi):
     """bf16 against the oracle and the one-thread-per-element kernels, and an odd-sized image batch at full size (oracle on
     its first samples)"""
     torch.manual_seed(11)
+    abi.set_tuning(27, 1)
     for shape, tdt in [((3, 8, 60, 151), torch.bfloat16), ((8, 64, 225, 225), torch.float32)]:
         x = torch.rand(shape, device=DEV).to(tdt)
         go = torch.rand(shape, device=DEV).to(tdt)
@@ -173,11 +193,13 @@ def test_row_bands_16bit_and_full_size(abi):
                 assert _ulp_close(gx[:ns].cpu(), gx_o, tdt) if active else torch.equal(gx[:ns].cpu(), gx_o), (shape, pad)
                 _, gw64 = O.backward(gn.astype(np.float64), wn.astype(np.float64), xn.astype(np.float64), pad, active)
                 assert rel_err(gw.float().cpu().numpy(), gw64) < gw16_tol(torch.finfo(tdt).eps), (shape, pad, active)
+    abi.set_tuning(27, 0)
 
 
 def test_row_band_gather_forward_vs_oracle(abi):
     """band_gather_forward: sparse-shift / quantized forward of planes above 16 KiB whose rows are not whole 16-byte
     pieces, every element size, every padding; bit-exact"""
+    abi.set_tuning(27, 1)   # (the flat-stream kernels take the float cases by default: off here)
     rs = np.random.RandomState(17)
     for shape in [(2, 3, 70, 113), (1, 2, 300, 25), (2, 2, 4501)]:
         nd = len(shape) - 2
@@ -211,6 +233,7 @@ def test_row_band_gather_forward_vs_oracle(abi):
     out = abi.forward(xh, wh, 3, 0)
     assert abi.last_kernel() == "band_gather_forward" and torch.equal(out, ref)
 
+    abi.set_tuning(27, 0)
 
 @pytest.mark.parametrize("shape,npdt", [((2, 3, 40, 64), np.uint8), ((1, 2, 3, 33, 48), np.int8), ((3, 2, 150, 224), np.uint8),
                                         ((2, 2, 1, 4096), np.uint8), ((2, 3, 130), np.uint8)])

@@ -753,46 +753,100 @@ __global__ __launch_bounds__(kThreads) void cl_tiled_backward(const ClTiledBwdPa
     for (int d = 0; d < kDepth - 1; ++d)
         if (hb + d < h1) step(hb + d, pvx[d], pvg[d]);
 
-    // ---- what the rings could not serve: channels whose shift leaves them, and the reflected corners above; everything
-    // from memory, element by element (rare) ------------------------------------------------------------------------------
+    // ---- what the rings could not serve, from memory, element by element.  One element of channel `ch` (canonical shifts cxH .. cgW,
+    // fractions fr) at row h, column wq of the image: grad_x written, the weight-gradient terms added to (t0, t1) --------------------
+    auto far_element = [&](int ch, int h, int wq, int cxH, int cxW, int cgH, int cgW, const CT (&fr)[3], double &t0, double &t1) {
+        const S *xe = reinterpret_cast<const S *>(xn) + ch, *ge = reinterpret_cast<const S *>(gn);
+        S *oe = reinterpret_cast<S *>(on) + ch;
+        auto tap_s = [&](const S *base, int r, int cc) { return (r >= 0 && cc >= 0) ? base[(static_cast<int64_t>(r) * W + cc) * C] : narrow<T>(CT(0)); };
+        auto tap = [&](const S *base, int r, int cc) { return widen<T>(tap_s(base, r, cc)); };
+        auto gtap_s = [&](int r, int cc) { return (r >= 0 && cc >= 0) ? ge[g_index(ch, r, cc)] : narrow<T>(CT(0)); };
+        auto gtap = [&](int r, int cc) { return widen<T>(gtap_s(r, cc)); };
+        if (!(h >= LH && h < LH + OH && wq >= LW && wq < LW + OW)) {   // outside the window
+            oe[(static_cast<int64_t>(h) * W + wq) * C] = narrow<T>(CT(0));
+            return;
+        }
+        const int a0 = fold_w(wq - cxW), a1 = fold_w(wq - cxW + 1);
+        const int b0 = fold_gw(wq - LW - cgW) - LW, b1 = fold_gw(wq - LW - cgW + 1) - LW;   // grad_out columns (< 0: padding)
+        const int r0 = fold_h(h - cxH), r1 = fold_h(h - cxH + 1);
+        const int s0 = fold_gh(h - LH - cgH) - LH, s1 = fold_gh(h - LH - cgH + 1) - LH;   // grad_out rows (< 0: padding)
+        CT v[4] = {tap(xe, r0, a0), tap(xe, r1, a0), tap(xe, r0, a1), tap(xe, r1, a1)}, wg[3];
+        const CT gval = widen<T>(ge[g_index(ch, h - LH, wq - LW)]);
+        weight_grads_nd<2, CT>(v, fr, wg);
+        t0 += static_cast<double>(gval * wg[0]);
+        t1 += static_cast<double>(gval * wg[1]);
+        S r;
+        if constexpr (ACTIVE) {
+            CT u[4] = {gtap(s0, b0), gtap(s1, b0), gtap(s0, b1), gtap(s1, b1)};
+            r = narrow<T>(interp_t<T, 2>(u, fr));
+        } else {
+            r = gtap_s(s0, b0);
+        }
+        oe[(static_cast<int64_t>(h) * W + wq) * C] = r;
+    };
+    // (a) the few elements of channels INSIDE the ring: the reflected corner one step beyond it, the rows / columns whose periodic
+    // source wraps -- by the thread that owns them
     bool any_scol = false;
 #pragma unroll
     for (int i = 0; i < NI; ++i) any_scol = any_scol || scol[i];
     const bool wrap_rows = periodic && near_c && (h0 <= kR || h1 >= H - kR - 1 || (h0 <= LH + kR && h1 > LH) || (h1 >= LH + OH - kR - 1 && h0 < LH + OH));
-    if (live_c && (far_c || any_scol || srow || srow_g || wrap_rows)) {
-        const S *xe = reinterpret_cast<const S *>(xn) + c, *ge = reinterpret_cast<const S *>(gn);
-        S *oe = reinterpret_cast<S *>(on) + c;
-        auto tap_s = [&](const S *base, int r, int cc) { return (r >= 0 && cc >= 0) ? base[(static_cast<int64_t>(r) * W + cc) * C] : narrow<T>(CT(0)); };
-        auto tap = [&](const S *base, int r, int cc) { return widen<T>(tap_s(base, r, cc)); };
-        auto gtap_s = [&](int r, int cc) { return (r >= 0 && cc >= 0) ? ge[g_index(c, r, cc)] : narrow<T>(CT(0)); };
-        auto gtap = [&](int r, int cc) { return widen<T>(gtap_s(r, cc)); };
+    if (near_c && (any_scol || srow || srow_g || wrap_rows)) {
 #pragma unroll
         for (int i = 0; i < NI; ++i) {
             const int wq = w0 + lane_b + PL * i;
             if (wq >= W) continue;
-            const int a0 = fold_w(wq - csxW), a1 = fold_w(wq - csxW + 1);
-            const int b0 = fold_gw(wq - LW - csgW) - LW, b1 = fold_gw(wq - LW - csgW + 1) - LW;   // grad_out columns (< 0: padding)
             for (int h = h0; h < h1; ++h) {
-                if (!(far_c || scol[i] || (srow && h == H - 1) || (srow_g && h == LH + OH - 1) || wraps(h))) continue;
-                if (!(h >= LH && h < LH + OH && wq >= LW && wq < LW + OW)) {   // outside the window
-                    oe[(static_cast<int64_t>(h) * W + wq) * C] = narrow<T>(CT(0));
-                    continue;
+                if (!(scol[i] || (srow && h == H - 1) || (srow_g && h == LH + OH - 1) || wraps(h))) continue;
+                far_element(c, h, wq, csxH, csxW, csgH, csgW, dw, acc[0], acc[1]);
+            }
+        }
+    }
+    // (b) channels whose shift leaves the ring (|row or column shift| > R): ALL threads of the workgroup share the band's elements of
+    // such a channel (round 5: its own pixel lanes alone walked the band's rows one after the other -- 56 dependent round trips; one
+    // such channel in 256 doubled the kernel's time: N16 C256 224x224 fp32 0.53 -> 0.99 ms)
+    {
+        __shared__ unsigned long long far_mask_s;
+        __syncthreads();
+        if (threadIdx.x < 64) {   // (the channel lanes with pixel lane 0 are threads 0 .. CB - 1: inside the first wave)
+            const unsigned long long m = __ballot(far_c && static_cast<int>(threadIdx.x) < CB);
+            if (threadIdx.x == 0) far_mask_s = m;
+        }
+        __syncthreads();
+        unsigned long long fm_left = far_mask_s;
+        double *fred = reinterpret_cast<double *>(ring_all);   // the rings are dead
+        while (fm_left) {   // (uniform)
+            const int fch = __builtin_ctzll(fm_left);
+            fm_left &= fm_left - 1;
+            const int cf = c0 + fch;
+            int64_t fsh[3] = {0, 0, 0};
+            CT ffr[3] = {CT(0), CT(0), CT(0)};
+            {
+                const int wcol[3] = {-1, 0, 1};
+                CT wv[3];
+                load_weights3<CT>(p.w, p.wkind, static_cast<int64_t>(cf) * 2, wcol, wv);
+                prep_shift_backward<CT>(wv[1], ACTIVE, fsh[1], ffr[0]);
+                prep_shift_backward<CT>(wv[2], ACTIVE, fsh[2], ffr[1]);
+            }
+            const int fxH = canon_shift(fsh[1], H, p.pad, p.d_perH), fxW = canon_shift(fsh[2], W, p.pad, p.d_perW);
+            const int fgH = canon_shift(ACTIVE ? fsh[1] : -fsh[1], OH, p.pad, p.d_perOH), fgW = canon_shift(ACTIVE ? fsh[2] : -fsh[2], OW, p.pad, p.d_perOW);
+            double t0 = 0.0, t1 = 0.0;
+            const int nelem = (h1 - h0) * kBTW;
+            for (int q = static_cast<int>(threadIdx.x); q < nelem; q += kThreads) {
+                const int h = h0 + q / kBTW, wq = w0 + q % kBTW;
+                if (wq < W) far_element(cf, h, wq, fxH, fxW, fgH, fgW, ffr, t0, t1);
+            }
+            __syncthreads();
+            fred[threadIdx.x * 2] = t0;
+            fred[threadIdx.x * 2 + 1] = t1;
+            __syncthreads();
+            if (static_cast<int>(threadIdx.x) == fch) {   // the channel's owner (pixel lane 0): the threads' sums in thread order
+                double u0 = 0.0, u1 = 0.0;
+                for (int k = 0; k < kThreads; ++k) {
+                    u0 += fred[k * 2];
+                    u1 += fred[k * 2 + 1];
                 }
-                const int r0 = fold_h(h - csxH), r1 = fold_h(h - csxH + 1);
-                const int s0 = fold_gh(h - LH - csgH) - LH, s1 = fold_gh(h - LH - csgH + 1) - LH;   // grad_out rows (< 0: padding)
-                CT v[4] = {tap(xe, r0, a0), tap(xe, r1, a0), tap(xe, r0, a1), tap(xe, r1, a1)}, wg[3];
-                const CT gval = widen<T>(ge[g_index(c, h - LH, wq - LW)]);
-                weight_grads_nd<2, CT>(v, dw, wg);
-                acc[0] += static_cast<double>(gval * wg[0]);
-                acc[1] += static_cast<double>(gval * wg[1]);
-                S r;
-                if constexpr (ACTIVE) {
-                    CT u[4] = {gtap(s0, b0), gtap(s1, b0), gtap(s0, b1), gtap(s1, b1)};
-                    r = narrow<T>(interp_t<T, 2>(u, dw));
-                } else {
-                    r = gtap_s(s0, b0);
-                }
-                oe[(static_cast<int64_t>(h) * W + wq) * C] = r;
+                acc[0] += u0;
+                acc[1] += u1;
             }
         }
     }

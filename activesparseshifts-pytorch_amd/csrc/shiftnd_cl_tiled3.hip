@@ -435,52 +435,117 @@ __global__ __launch_bounds__(kThreads) CLT3_OCC void cl_tiled_backward_3d(const 
     for (int d = 0; d < kDepth - 1; ++d)
         if (hb + d < h1) step(hb + d, pvs[d], pvo[d]);
 
-    // ---- what the rings could not serve: channels whose row / column shift leaves them, the reflected corners, the wrapping
-    // rows; everything from memory, element by element (rare) ----------------------------------------------------------------
-    bool any_scol = false;
-#pragma unroll
-    for (int i = 0; i < kNI; ++i) any_scol = any_scol || scol[i];
-    const bool wrap_rows = periodic && near_c && (h0 <= kR || h1 >= H - kR - 1 || (h0 <= LH + kR && h1 > LH) || (h1 >= LH + OH - kR - 1 && h0 < LH + OH));
-    if (live_c && (far_c || any_scol || srow || srow_g || wrap_rows)) {
-        const S *xe = reinterpret_cast<const S *>(xn) + c, *ge = reinterpret_cast<const S *>(gn);
-        S *oe = reinterpret_cast<S *>(on) + c;
+    // ---- what the rings could not serve, from memory, element by element.  One element of channel `ch` (canonical row / column shifts,
+    // planes, fractions) at row h, column wq of plane dz: grad_x written, the eight weight-gradient terms added to t[] ------------------
+    struct FarP {
+        int cxH, cxW, cgH, cgW, xp0, xp1, gp0, gp1;
+        CT fr[3];
+    };
+    auto far_element = [&](int ch, int h, int wq, const FarP &P, double (&t)[8]) {
+        const S *xe = reinterpret_cast<const S *>(xn) + ch, *ge = reinterpret_cast<const S *>(gn);
+        S *oe = reinterpret_cast<S *>(on) + ch;
         auto g_index = [&](int pl, int r, int cc) {
-            return GO_NCDHW ? ((static_cast<int64_t>(c) * OD + pl) * OH + r) * OW + cc : ((static_cast<int64_t>(pl) * OH + r) * OW + cc) * C + c;
+            return GO_NCDHW ? ((static_cast<int64_t>(ch) * OD + pl) * OH + r) * OW + cc : ((static_cast<int64_t>(pl) * OH + r) * OW + cc) * C + ch;
         };
         auto tap = [&](int pl, int r, int cc) { return (pl >= 0 && r >= 0 && cc >= 0) ? widen<T>(xe[((static_cast<int64_t>(pl) * H + r) * W + cc) * C]) : CT(0); };
         auto gtap_s = [&](int pl, int r, int cc) { return (pl >= 0 && r >= 0 && cc >= 0) ? ge[g_index(pl, r, cc)] : narrow<T>(CT(0)); };
         auto gtap = [&](int pl, int r, int cc) { return widen<T>(gtap_s(pl, r, cc)); };
+        const int64_t o = ((static_cast<int64_t>(dz) * H + h) * W + wq) * C;
+        if (!(ppass && h >= LH && h < LH + OH && wq >= LW && wq < LW + OW)) {   // outside the window
+            oe[o] = narrow<T>(CT(0));
+            return;
+        }
+        const int a0 = fold_w(wq - P.cxW), a1 = fold_w(wq - P.cxW + 1);
+        const int b0 = fold_gw(wq - LW - P.cgW) - LW, b1 = fold_gw(wq - LW - P.cgW + 1) - LW;   // grad_out columns (< 0: padding)
+        const int r0 = fold_h(h - P.cxH), r1 = fold_h(h - P.cxH + 1);
+        const int s0 = fold_gh(h - LH - P.cgH) - LH, s1 = fold_gh(h - LH - P.cgH + 1) - LH;   // grad_out rows (< 0: padding)
+        const CT v[8] = {tap(P.xp0, r0, a0), tap(P.xp1, r0, a0), tap(P.xp0, r1, a0), tap(P.xp1, r1, a0),
+                         tap(P.xp0, r0, a1), tap(P.xp1, r0, a1), tap(P.xp0, r1, a1), tap(P.xp1, r1, a1)};
+        CT df[8];
+        const CT gval = widen<T>(ge[g_index(dzo, h - LH, wq - LW)]);
+        corner_diffs<3, CT>(v, df);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) t[k] += static_cast<double>(gval * df[k]);
+        S r;
+        if constexpr (ACTIVE) {
+            const CT u[8] = {gtap(P.gp0, s0, b0), gtap(P.gp1, s0, b0), gtap(P.gp0, s1, b0), gtap(P.gp1, s1, b0),
+                             gtap(P.gp0, s0, b1), gtap(P.gp1, s0, b1), gtap(P.gp0, s1, b1), gtap(P.gp1, s1, b1)};
+            r = narrow<T>(interp_t<T, 3>(u, P.fr));
+        } else {
+            r = gtap_s(P.gp0, s0, b0);
+        }
+        oe[o] = r;
+    };
+    // (a) the few elements of channels inside the ring (the reflected corner one step beyond it, wrapping rows / columns): their owner
+    bool any_scol = false;
+#pragma unroll
+    for (int i = 0; i < kNI; ++i) any_scol = any_scol || scol[i];
+    const bool wrap_rows = periodic && near_c && (h0 <= kR || h1 >= H - kR - 1 || (h0 <= LH + kR && h1 > LH) || (h1 >= LH + OH - kR - 1 && h0 < LH + OH));
+    if (near_c && (any_scol || srow || srow_g || wrap_rows)) {
+        FarP P;
+        P.cxH = csxH; P.cxW = csxW; P.cgH = csgH; P.cgW = csgW; P.xp0 = xp0; P.xp1 = xp1; P.gp0 = gp0; P.gp1 = gp1;
+        P.fr[0] = dw[0]; P.fr[1] = dw[1]; P.fr[2] = dw[2];
 #pragma unroll
         for (int i = 0; i < kNI; ++i) {
             const int wq = w0 + lane_b + kPL * i;
             if (wq >= W) continue;
-            const int a0 = fold_w(wq - csxW), a1 = fold_w(wq - csxW + 1);
-            const int b0 = fold_gw(wq - LW - csgW) - LW, b1 = fold_gw(wq - LW - csgW + 1) - LW;   // grad_out columns (< 0: padding)
             for (int h = h0; h < h1; ++h) {
-                if (!(far_c || scol[i] || (srow && h == H - 1) || (srow_g && h == LH + OH - 1) || wraps(h))) continue;
-                const int64_t o = ((static_cast<int64_t>(dz) * H + h) * W + wq) * C;
-                if (!(ppass && h >= LH && h < LH + OH && wq >= LW && wq < LW + OW)) {   // outside the window
-                    oe[o] = narrow<T>(CT(0));
-                    continue;
-                }
-                const int r0 = fold_h(h - csxH), r1 = fold_h(h - csxH + 1);
-                const int s0 = fold_gh(h - LH - csgH) - LH, s1 = fold_gh(h - LH - csgH + 1) - LH;   // grad_out rows (< 0: padding)
-                const CT v[8] = {tap(xp0, r0, a0), tap(xp1, r0, a0), tap(xp0, r1, a0), tap(xp1, r1, a0),
-                                 tap(xp0, r0, a1), tap(xp1, r0, a1), tap(xp0, r1, a1), tap(xp1, r1, a1)};
-                CT df[8];
-                const CT gval = widen<T>(ge[g_index(dzo, h - LH, wq - LW)]);
-                corner_diffs<3, CT>(v, df);
+                if (!(scol[i] || (srow && h == H - 1) || (srow_g && h == LH + OH - 1) || wraps(h))) continue;
+                far_element(c, h, wq, P, acc);
+            }
+        }
+    }
+    // (b) channels whose row / column shift leaves the ring: all threads of the workgroup share the band's elements of such a channel
+    // (its own eight pixel lanes alone would walk the band's rows one after the other: dozens of dependent memory round trips)
+    {
+        __shared__ unsigned int far_mask_s;
+        __syncthreads();
+        if (threadIdx.x < 64) {   // (the channel lanes with pixel lane 0 are threads 0 .. 31)
+            const unsigned long long m = __ballot(far_c && static_cast<int>(threadIdx.x) < kCB);
+            if (threadIdx.x == 0) far_mask_s = static_cast<unsigned int>(m);
+        }
+        __syncthreads();
+        unsigned int fm_left = far_mask_s;
+        double *fred = reinterpret_cast<double *>(lds);   // the rings are dead
+        while (fm_left) {   // (uniform)
+            const int fch = __builtin_ctz(fm_left);
+            fm_left &= fm_left - 1;
+            const int cf = c0 + fch;
+            FarP P;
+            {
+                const int wcol[3] = {0, 1, 2};
+                CT wv[3];
+                int64_t fs[3];
+                load_weights3<CT>(p.w, p.wkind, static_cast<int64_t>(cf) * 3, wcol, wv);
 #pragma unroll
-                for (int k = 0; k < 8; ++k) acc[k] += static_cast<double>(gval * df[k]);
-                S r;
-                if constexpr (ACTIVE) {
-                    const CT u[8] = {gtap(gp0, s0, b0), gtap(gp1, s0, b0), gtap(gp0, s1, b0), gtap(gp1, s1, b0),
-                                     gtap(gp0, s0, b1), gtap(gp1, s0, b1), gtap(gp0, s1, b1), gtap(gp1, s1, b1)};
-                    r = narrow<T>(interp_t<T, 3>(u, dw));
-                } else {
-                    r = gtap_s(gp0, s0, b0);
-                }
-                oe[o] = r;
+                for (int k = 0; k < 3; ++k) prep_shift_backward<CT>(wv[k], ACTIVE, fs[k], P.fr[k]);
+                const int fxD = canon_shift(fs[0], D, p.pad, p.d_perD), fgD = canon_shift(ACTIVE ? fs[0] : -fs[0], OD, p.pad, p.d_perOD);
+                P.cxH = canon_shift(fs[1], H, p.pad, p.d_perH);
+                P.cxW = canon_shift(fs[2], W, p.pad, p.d_perW);
+                P.cgH = canon_shift(ACTIVE ? fs[1] : -fs[1], OH, p.pad, p.d_perOH);
+                P.cgW = canon_shift(ACTIVE ? fs[2] : -fs[2], OW, p.pad, p.d_perOW);
+                P.xp0 = D == 1 ? 0 : fold_index(dz - fxD, D, p.pad);
+                P.xp1 = D == 1 ? 0 : fold_index(dz - fxD + 1, D, p.pad);
+                P.gp0 = !ppass ? -1 : (OD == 1 ? 0 : fold_index(dzo - fgD, OD, p.pad));
+                P.gp1 = (!ppass || !ACTIVE) ? -1 : (OD == 1 ? 0 : fold_index(dzo - fgD + 1, OD, p.pad));
+            }
+            double t[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+            const int nelem = (h1 - h0) * kTW3;
+            for (int q = static_cast<int>(threadIdx.x); q < nelem; q += kThreads) {
+                const int h = h0 + q / kTW3, wq = w0 + q % kTW3;
+                if (wq < W) far_element(cf, h, wq, P, t);
+            }
+            __syncthreads();
+#pragma unroll
+            for (int k = 0; k < 8; ++k) fred[threadIdx.x * 8 + k] = t[k];
+            __syncthreads();
+            if (static_cast<int>(threadIdx.x) == fch) {   // the channel's owner (pixel lane 0): the threads' sums in thread order
+                double u[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+                for (int k = 0; k < kThreads; ++k)
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) u[j] += fred[k * 8 + j];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) acc[j] += u[j];
             }
         }
     }

@@ -28,7 +28,7 @@ def main(root):
         print("== kernel trace:", os.path.relpath(f, root))
         print("%-92s %6s %12s %12s" % ("kernel", "calls", "avg_us", "min_us"))
         for k, v in sorted(dur.items(), key=lambda kv: -sum(kv[1])):
-            if any(t in k for t in ("sweep_", "plane_", "strided_", "reduce_weight", "cl_", "transpose", "slide_", "bytes_", "small_", "band_", "rows_", "step_", "walk_", "qpool_", "span_", "crop_", "row_")):
+            if any(t in k for t in ("sweep_", "plane_", "strided_", "reduce_weight", "cl_", "transpose", "slide_", "bytes_", "small_", "band_", "rows_", "step_", "walk_", "qpool_", "span_", "crop_", "row_", "flat_")):
                 print("%-92s %6d %12.1f %12.1f   %s" % (k, len(v), sum(v) / len(v) / 1e3, min(v) / 1e3, res[k]))
     for d in sorted(glob.glob(os.path.join(root, "pmc_*"))):
         for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
@@ -37,7 +37,7 @@ def main(root):
                 acc[short(r["Kernel_Name"])][r["Counter_Name"]].append(float(r["Counter_Value"]))
             print("== pmc:", os.path.relpath(f, root))
             for k, ctrs in acc.items():
-                if not any(t in k for t in ("sweep_", "plane_", "strided_", "cl_", "slide_", "bytes_", "small_", "band_", "rows_", "step_", "walk_", "qpool_", "span_", "crop_", "row_")):
+                if not any(t in k for t in ("sweep_", "plane_", "strided_", "cl_", "slide_", "bytes_", "small_", "band_", "rows_", "step_", "walk_", "qpool_", "span_", "crop_", "row_", "flat_")):
                     continue
                 for c, v in ctrs.items():
                     avg = sum(v) / len(v)

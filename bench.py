@@ -276,7 +276,11 @@ def main(argv=None):
     if rank == 0 and world == 1 and a.workload == "c2" and a.shape is None and a.device == "cuda" \
             and not a.no_cpu_baseline:
         base = cpu_baseline(a.pad)  # child process, before any GPU initialisation in this process
-    probes = {}
+    probes = {}   # same-box streams by size class: tensors within a quarter octave of each other share one calibration run
+
+    def size_class(nbytes):
+        import math
+        return int(round(4 * math.log2(max(nbytes, 1))))
 
     def tensor_bytes(name, shape_arg=None):
         _nd, _shape, _dt, _act, _desc = WORKLOADS[name]
@@ -291,11 +295,11 @@ def main(argv=None):
         # default run also calibrates at the tensor sizes of the BASELINE configs it times after the headline
         sizes = [tensor_bytes(a.workload, a.shape)]
         if default_run and not a.no_configs:
-            sizes += [tensor_bytes(n) for n in ("c3", "c4")]
+            sizes += [tensor_bytes(w) for _n, w, _p in EXTRA_CONFIGS]
         for nb in sizes:
-            if nb not in probes:
-                probes[nb] = box_stream(nb)
-    probe = probes.get(tensor_bytes(a.workload, a.shape))
+            if size_class(nb) not in probes:
+                probes[size_class(nb)] = box_stream(nb)
+    probe = probes.get(size_class(tensor_bytes(a.workload, a.shape)))
 
     import torch
     import torch.distributed as dist
@@ -617,7 +621,7 @@ def main(argv=None):
                         cw.step()
                     barrier()
                     cms = (time.perf_counter() - c0) / csteps * 1e3
-                    cprobe = probes.get(tensor_bytes(wname))
+                    cprobe = probes.get(size_class(tensor_bytes(wname)))
                     ck, cdom = cw.kernel_times(csteps, cprobe)
                     rl = roofline_of(wname, pad, cdom, cprobe)
                     configs[cname] = {

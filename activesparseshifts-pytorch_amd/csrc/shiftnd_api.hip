@@ -380,8 +380,15 @@ int shiftnd_backward(const shiftnd_problem *p, const void *grad_out, const int64
         g_last_path = SHIFTND_PATH_SWEEP;
         return finish(sweep_backward(g, p->dtype, grad_out, x, weights, grad_x, grad_w, workspace, st));
     }
-    // ragged input rows -- and windows crop_backward does not take (a gradient that is not a whole number of pieces): the flat chunk stream
-    if (g_policy == 0 && (g_flat == 2 || ragged_rows(g, p->dtype) || (cropped(g) && !span_backward_eligible(g, p->dtype, grad_out, x, grad_x))) &&
+    // ragged rows of 4- / 8-byte elements on planes with rows of at least 8 chunks: the row-relative crop_backward (shiftnd_span.hip, XRAG)
+    if (g_policy == 0 && g_flat != 2 && ragged_rows(g, p->dtype) && span_backward_eligible(g, p->dtype, grad_out, x, grad_x)) {
+        if (span_backward_workspace(g, p->dtype) > workspace_bytes) return SHIFTND_ERR_WORKSPACE_TOO_SMALL;
+        g_last_path = SHIFTND_PATH_PLANE;
+        return finish(span_backward(g, p->dtype, grad_out, x, weights, grad_x, grad_w, workspace, st));
+    }
+    // ragged input rows -- and windows crop_backward does not take: the flat chunk stream.  (Ragged rows of 4- / 8-byte elements on
+    // planes large enough for the row-relative crop_backward: that one, through plane_backward below.)
+    if (g_policy == 0 && !span_backward_eligible(g, p->dtype, grad_out, x, grad_x) && (ragged_rows(g, p->dtype) || cropped(g)) &&
         flat_backward_eligible(g, p->dtype, grad_out, x, grad_x)) {
         if (flat_backward_workspace(g) > workspace_bytes) return SHIFTND_ERR_WORKSPACE_TOO_SMALL;
         g_last_path = SHIFTND_PATH_PLANE;

@@ -421,6 +421,15 @@ template <typename R, int E, bool NT = false> __device__ __forceinline__ Chunk<R
     __builtin_memcpy(c.e, &v, V);
     return c;
 }
+// element-aligned V-byte nontemporal store (one global_store_dwordx4 for V = 16 at a 4-byte boundary)
+template <typename R, int E> __device__ __forceinline__ void store_chunk_unaligned(R *dst, const Chunk<R, E> &c) {
+    constexpr int V = sizeof(R) * E;
+    typedef typename vec_of<V>::type vec_t;
+    typedef vec_t unaligned_t __attribute__((aligned(sizeof(R) < 4 ? sizeof(R) : 4)));
+    vec_t v;
+    __builtin_memcpy(&v, c.e, V);
+    __builtin_nontemporal_store(v, reinterpret_cast<unaligned_t *>(dst));
+}
 // aligned V-byte nontemporal store (every output byte is written once)
 template <typename R, int E> __device__ __forceinline__ void store_chunk(R *dst, const Chunk<R, E> &c) {
     constexpr int V = sizeof(R) * E;

@@ -144,7 +144,13 @@ __device__ __forceinline__ void span_read(const char *lds_row, const S *mem_row,
 //   * one read path (ColState), the window mask applied to the result.
 // 2-D, rows of at most 254 chunks (wider cropped rows: the per-channel kernels); 1-D: row_backward.
 // ---------------------------------------------------------------------------------------------------------------------
-template <typename T, bool ACTIVE, int PAD>
+// XRAG (round 5): x rows that are not whole 16-byte pieces (62 x 62, 222 x 222 fp32: the output of a cropped shift as the next
+// layer's input).  4- / 8-byte elements: the x rows are staged as covers with a phase, exactly like the grad_out rows; a thread's
+// chunk is ROW-RELATIVE -- elements 4 k .. 4 k + 3 of its row, cpr = ceil(row bytes / 16) of them, the last one partial -- and
+// grad_x leaves through element-aligned 16-byte stores (gfx950 global stores take any alignment; a wave's chunks are still one
+// contiguous run of memory).  No chunk straddles rows: the lean in-row path everywhere (the flat-stream kernels of
+// shiftnd_flat.hip, which keep aligned stores, pay for that with a per-element path: N64 C256 222x222 fp32 3.0 -> 1.9 ms).
+template <typename T, bool ACTIVE, int PAD, bool XRAG = false>
 __global__ __launch_bounds__(kThreads) void crop_backward(const SpanParams p) {
     using S = typename T::S;
     using CT = typename T::C;
@@ -165,7 +171,8 @@ __global__ __launch_bounds__(kThreads) void crop_backward(const SpanParams p) {
     const int b0 = step * R;
     const int Rn = min(R, S1 - b0);
     // tile: x corner rows [R + 1][cpr pieces] | grad_out at the step's own rows [R][cpr + 2] | the rows grad_x reads [R (+ 1)][cpr + 2]
-    const int RBX = cpr * 16, PG = cpr + 2, RBG = PG * 16;
+    // (XRAG: the x rows are covers of cpr + 2 pieces too)
+    const int RBX = (XRAG ? cpr + 2 : cpr) * 16, PG = cpr + 2, RBG = PG * 16;
     const int goff = (R + 1) * RBX, gsoff = goff + R * RBG;
     const S *xp = static_cast<const S *>(p.x) + static_cast<int64_t>(plane) * p.x_plane;
     const S *gp = static_cast<const S *>(p.go) + static_cast<int64_t>(plane) * p.g_plane;
@@ -185,13 +192,18 @@ __global__ __launch_bounds__(kThreads) void crop_backward(const SpanParams p) {
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(reinterpret_cast<const char *>(xp) + off),
                                          (__attribute__((address_space(3))) void *)dst_wave, 16, 0, 0);
     };
-    if (tr < R) {
-        const int sx = tr <= Rn ? row_map_t<PAD>(b0 + tr, d.cx1, S1) : -1;
-        if (sx >= 0) dma_x(sx, tc, 0);
-    }
-    if (Rn == R && tid < cpr) {
-        const int sx = row_map_t<PAD>(b0 + R, d.cx1, S1);
-        if (sx >= 0) dma_x(sx, tid, R * cpr);
+    // XRAG: this plane of x starts xph bytes into its first piece of the tensor's stream
+    const int xph = XRAG ? static_cast<int>((static_cast<uint64_t>(plane) * static_cast<uint64_t>(p.x_plane) * ES) & 15u) : 0;
+    auto xrow_lo = [&](int row) { return xph + row * S2 * ES; };
+    if constexpr (!XRAG) {
+        if (tr < R) {
+            const int sx = tr <= Rn ? row_map_t<PAD>(b0 + tr, d.cx1, S1) : -1;
+            if (sx >= 0) dma_x(sx, tc, 0);
+        }
+        if (Rn == R && tid < cpr) {
+            const int sx = row_map_t<PAD>(b0 + R, d.cx1, S1);
+            if (sx >= 0) dma_x(sx, tid, R * cpr);
+        }
     }
     // ---- grad_out rows: a row's cover = pieces (lo >> 4) .. of the stream, lo = gph + row O2 ES; the slot keeps them from its
     // first byte, so column j of the row sits at (lo & 15) + j ES.  A cover has up to cpr + 2 pieces, so these groups have their
@@ -213,6 +225,19 @@ __global__ __launch_bounds__(kThreads) void crop_backward(const SpanParams p) {
         const bool dom = have && pr >= 0 && (ACTIVE ? pr <= O1 : pr < O1);
         return dom ? row_map_t<PAD>(pr, d.cg1, O1) : -1;
     };
+    if constexpr (XRAG) {   // the x corner rows as covers: thread t moves piece t mod (cpr + 2) of row t div (cpr + 2); the first threads the + 1 row
+        const char *xp16 = reinterpret_cast<const char *>(xp) - xph;
+        auto dma_xc = [&](int row, int piece, int lds_piece0) {
+            const int lo = xrow_lo(row), p0 = lo >> 4, cnt = ((lo + S2 * ES + 15) >> 4) - p0;
+            if (row >= 0 && piece < cnt) {
+                char *dst_wave = tile + (lds_piece0 + wave * 64) * 16;
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(xp16 + static_cast<uint32_t>(p0 + piece) * 16u),
+                                                 (__attribute__((address_space(3))) void *)dst_wave, 16, 0, 0);
+            }
+        };
+        dma_xc((rg < R && rg <= Rn) ? row_map_t<PAD>(b0 + rg, d.cx1, S1) : -1, pg, 0);
+        if (Rn == R && tid < PGi) dma_xc(row_map_t<PAD>(b0 + R, d.cx1, S1), tid, R * PGi);
+    }
     {
         const int ro = (rg < R && rg < Rn && b0 + rg - L1 >= 0 && b0 + rg - L1 < O1) ? b0 + rg - L1 : -1;   // the step's own rows
         dma_g(ro, pg, goff / 16);
@@ -296,7 +321,9 @@ __global__ __launch_bounds__(kThreads) void crop_backward(const SpanParams p) {
 #pragma unroll
         for (int hb = 0; hb < 2; ++hb) {
             S raw[E + 1];
-            read_row(tile + (tr + hb) * RBX, row_valid(b + hb, d.cx1, S1), xm, raw);
+            // (XRAG: the row's first byte sits at the phase of its SOURCE row's cover)
+            const int xphase = XRAG ? (xrow_lo(max(row_map_t<PAD>(b + hb, d.cx1, S1), 0)) & 15) : 0;
+            read_row(tile + (tr + hb) * RBX + xphase, row_valid(b + hb, d.cx1, S1), xm, raw);
 #pragma unroll
             for (int e = 0; e <= E; ++e) xv[hb][e] = widen<T>(raw[e]);
         }
@@ -312,7 +339,18 @@ __global__ __launch_bounds__(kThreads) void crop_backward(const SpanParams p) {
 #pragma unroll
             for (int i = 0; i < NDIFF; ++i) part[i] = fma_ct(gval, df[i], part[i]);
         }
-        store_chunk<S, E>(gxp + static_cast<int64_t>(b) * S2 + ji, res);
+        if constexpr (XRAG) {   // element-aligned; the row's last chunk may be partial
+            S *dst = gxp + static_cast<int64_t>(b) * S2 + ji;
+            if (ji + E <= S2) {
+                store_chunk_unaligned<S, E>(dst, res);
+            } else {
+#pragma unroll
+                for (int e = 0; e < E; ++e)
+                    if (ji + e < S2) dst[e] = res.e[e];
+            }
+        } else {
+            store_chunk<S, E>(gxp + static_cast<int64_t>(b) * S2 + ji, res);
+        }
     }
     // ---- this step's sums: DPP tree per wave, the four waves added in fp64 by one thread ----------------------------------
     double *scratch = reinterpret_cast<double *>(tile + ((gsoff + (R + 1) * RBG + 63) & ~63) + 64);
@@ -478,6 +516,116 @@ __global__ __launch_bounds__(kThreads) void crop_forward(const SpanFwdParams p) 
             }
         }
         store_chunk<S, E>(op + eb, res);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// ragged_forward (round 5): the 2-D forward of 4- / 8-byte elements whose SOURCE rows are not whole 16-byte pieces (62 x 62,
+// 222 x 222 fp32 ...; a window included), in crop_backward<.., XRAG>'s row-relative shape: a step is R output rows of one plane,
+// thread (tr, tc) owns elements 4 tc .. 4 tc + 3 of output row tr (cpr = ceil(output row bytes / 16) chunks, the last one partial);
+// the R (+ 1) source rows are staged as covers with a phase (thread t moves piece t mod (xcpr + 2) of row t div (xcpr + 2));
+// the output leaves through element-aligned 16-byte stores.  No chunk straddles rows: one lean path (ColState windows).
+// Reference: kernels/shifts_kernels.h:156-220.
+// ---------------------------------------------------------------------------------------------------------------------
+template <typename T, bool ACTIVE, int PAD>
+__global__ __launch_bounds__(kThreads) void ragged_forward(const SpanFwdParams p) {
+    using S = typename T::S;
+    using CT = typename T::C;
+    constexpr int ES = sizeof(S);
+    constexpr int E = 16 / ES;
+    static_assert(ES >= 4, "4- / 8-byte elements (2-byte-aligned 16-byte stores are slow: shiftnd_flat.hip)");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char *tile = smem + 64;
+
+    const uint32_t bid = (blockIdx.x & 7u) * p.steps_per_xcd + (blockIdx.x >> 3);
+    if (bid >= p.total_steps) return;
+    const uint32_t plane = fdiv(bid, p.d_spp);
+    const int step = static_cast<int>(bid - plane * static_cast<uint32_t>(p.spp));
+    const int c = static_cast<int>(plane - fdiv(plane, p.d_C) * static_cast<uint32_t>(p.C));
+    CT wr, wc;
+    load_weights2<CT>(p.w, p.wkind, c, wr, wc);
+    const CT rr = ACTIVE ? c_floor<CT>(wr) : c_rint<CT>(wr), rc = ACTIVE ? c_floor<CT>(wc) : c_rint<CT>(wc);
+    const CT dw[2] = {ACTIVE ? wr - rr : CT(0), ACTIVE ? wc - rc : CT(0)};
+    const int S1 = p.S1, S2 = p.S2, O1 = p.O1, O2 = p.O2, L1 = p.L1, L2 = p.L2;
+    const int cpr = p.ocp, R = p.cps, PX = p.P;   // output chunks per row, rows per step, pieces per staged source row (xcpr + 2)
+    const int cs1 = __builtin_amdgcn_readfirstlane(canon_of<PAD, CT>(rr, S1, p.d_per1));
+    const int cs2 = __builtin_amdgcn_readfirstlane(canon_of<PAD, CT>(rc, S2, p.d_per2));
+    const int b0 = step * R, Rn = min(R, O1 - b0);
+    const S *xp = static_cast<const S *>(p.x) + static_cast<int64_t>(plane) * p.x_plane;
+    S *op = static_cast<S *>(p.out) + static_cast<int64_t>(plane) * p.o_plane;
+    const int xph = static_cast<int>((static_cast<uint64_t>(plane) * static_cast<uint64_t>(p.x_plane) * ES) & 15u);
+    const char *xp16 = reinterpret_cast<const char *>(xp) - xph;
+    auto xrow_lo = [&](int row) { return xph + row * S2 * ES; };
+    const int tid = static_cast<int>(threadIdx.x);
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int RBX = PX * 16;
+    // ---- the source rows of output rows b0 .. b0 + Rn - 1 (+ the corner row): covers of at most xcpr + 1 pieces -----------------
+    auto src_row = [&](int i) { return row_map_t<PAD>(b0 + i + L1, cs1, S1); };   // (-1: padding)
+    auto dma_x = [&](int row, int piece, int lds_piece0) {
+        const int lo = xrow_lo(row), p0 = lo >> 4, cnt = ((lo + S2 * ES + 15) >> 4) - p0;
+        if (row >= 0 && piece < cnt) {
+            char *dst_wave = tile + (lds_piece0 + wave * 64) * 16;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(xp16 + static_cast<uint32_t>(p0 + piece) * 16u),
+                                             (__attribute__((address_space(3))) void *)dst_wave, 16, 0, 0);
+        }
+    };
+    {
+        const int rg = static_cast<int>(fdiv(static_cast<uint32_t>(tid), p.d_P)), pg = tid - rg * PX;
+        dma_x((rg < R && (ACTIVE ? rg <= Rn : rg < Rn)) ? src_row(rg) : -1, pg, 0);
+        if constexpr (ACTIVE) {
+            if (Rn == R && tid < PX) dma_x(src_row(R), tid, R * PX);   // the + 1 row of a full step
+        }
+    }
+    // ---- the thread's chunk -----------------------------------------------------------------------------------------------------
+    const int tr = static_cast<int>(fdiv(static_cast<uint32_t>(tid), p.d_O2)), tc = tid - tr * cpr;   // (d_O2 divides by cpr here)
+    const int ji = tc * E;
+    ColState<E> xm;
+    if constexpr (PAD == 0) {
+        const int first = ji + L2 - cs2;
+        xm.base = (first + E < 0 || first >= S2) ? 0 : first;
+        xm.affine = true;
+#pragma unroll
+        for (int e = 0; e <= E; ++e) xm.cm[e] = static_cast<unsigned>(first + e) < static_cast<unsigned>(S2) ? first + e : -1;
+    } else {
+        xm = fold_colstate<E, PAD>(ji + L2, cs2, S2);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tr >= R || tr >= Rn) return;
+    auto read_row = [&](int slot, S (&raw)[E + 1]) {
+        const int sr = src_row(slot);
+        const char *row = tile + slot * RBX + (xrow_lo(max(sr, 0)) & 15);
+        if constexpr (PAD == 0) lds_read_row_affine<S, E>(row, sr >= 0, xm, raw);
+        else lds_read_row<S, E>(row, sr >= 0, xm, raw);
+    };
+    Chunk<S, E> res;
+    if constexpr (ACTIVE) {
+        CT xv[2][E + 1];
+#pragma unroll
+        for (int hb = 0; hb < 2; ++hb) {
+            S raw[E + 1];
+            read_row(tr + hb, raw);
+#pragma unroll
+            for (int e = 0; e <= E; ++e) xv[hb][e] = widen<T>(raw[e]);
+        }
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+            const CT v[4] = {xv[0][e], xv[1][e], xv[0][e + 1], xv[1][e + 1]};
+            res.e[e] = narrow<T>(interp_t<T, 2>(v, dw));
+        }
+    } else {
+        S raw[E + 1];
+        read_row(tr, raw);
+#pragma unroll
+        for (int e = 0; e < E; ++e) res.e[e] = raw[e];
+    }
+    S *dst = op + static_cast<int64_t>(b0 + tr) * O2 + ji;
+    if (ji + E <= O2) {
+        store_chunk_unaligned<S, E>(dst, res);
+    } else {
+#pragma unroll
+        for (int e = 0; e < E; ++e)
+            if (ji + e < O2) dst[e] = res.e[e];
     }
 }
 
@@ -744,7 +892,8 @@ struct SpanPlan {
 SpanPlan span_plan(const Geometry &g, int es) {
     SpanPlan s{};
     const int E = 16 / es;
-    s.cpr = static_cast<int>(g.S[2] * es / 16);
+    const bool xrag = (g.S[2] * es) % 16 != 0;   // crop_backward<.., XRAG>: row-relative chunks, the last one partial
+    s.cpr = static_cast<int>((g.S[2] * es + 15) / 16);
     if (s.cpr < 1) s.cpr = 1;
     // column segments of at most 256 chunks (4 KB blocks of grad_x: see span_forward_plan); slots of seg + 2 pieces (a ragged
     // grad_out row's cover; a segment's source columns + corner column + shift misalignment)
@@ -767,7 +916,7 @@ SpanPlan span_plan(const Geometry &g, int es) {
     s.off_colg = s.off_colx + up(static_cast<size_t>(g.C) * s.cpr * s.rec * sizeof(int16_t));
     s.bytes = s.off_colg + up(static_cast<size_t>(g.C) * s.cpr * s.rec * sizeof(int16_t));
     if (g.nd == 2) {   // crop_backward: x rows [R + 1][cpr] | own rows [R][cpr + 2] | read rows [R + 1][cpr + 2]
-        const size_t tile = (static_cast<size_t>(R + 1) * s.cpr + static_cast<size_t>(2 * R + 1) * (s.cpr + 2)) * 16;
+        const size_t tile = (static_cast<size_t>(R + 1) * (s.cpr + (xrag ? 2 : 0)) + static_cast<size_t>(2 * R + 1) * (s.cpr + 2)) * 16;
         s.lds = 64 + ((tile + 63) & ~static_cast<size_t>(63)) + 64 + (kThreads / 64) * 2 * sizeof(double);
     } else {   // row_backward: three spans of (256 + 3) pieces
         s.lds = 64 + 3 * (kThreads + 3) * 16 + 64 + (kThreads / 64) * sizeof(double);
@@ -780,8 +929,10 @@ bool span_geometry_ok(const Geometry &g, int dtype) {
     if (dtype > SHIFTND_BF16 || (g.nd != 1 && g.nd != 2) || g.K[0] > 0) return false;
     const int es = dtype_size(dtype);
     if (g.S[0] != 1 || g.O[0] != 1 || g.S[1] < 1 || g.S[2] < 1 || g.O[1] < 1 || g.O[2] < 1) return false;
-    if ((g.S[2] * es) % 16 != 0 || g.S[2] > 32000) return false;                       // x rows: whole pieces; int16 column tables
-    if ((g.N * g.C * g.O[1] * g.O[2] * es) % 16 != 0) return false;                     // grad_out: a whole number of pieces
+    // x rows: whole pieces -- or, 2-D with 4- / 8-byte elements, any length (crop_backward<.., XRAG>, round 5); int16 column tables
+    if (((g.S[2] * es) % 16 != 0 && !(g.nd == 2 && es >= 4)) || g.S[2] > 32000) return false;
+    // (grad_out / x need not be a whole number of pieces: the last piece of a cover reaches at most 15 bytes past the tensor's
+    //  end, inside the 16-byte granule -- hence the page -- of its last valid byte; those bytes are never used)
     if (g.S[1] * g.S[2] >= (1LL << 28) || g.O[1] * g.O[2] >= (1LL << 28)) return false;  // 32-bit byte offsets within a plane
     if (g.nd == 2 && g.S[2] * es > (kThreads - 2) * 16) return false;   // crop_backward: a grad_out row's cover (cpr + 2 pieces) per staging pass
     const SpanPlan s = span_plan(g, es);
@@ -794,11 +945,25 @@ bool span_geometry_ok(const Geometry &g, int dtype) {
 // are whole 16-byte pieces
 static bool crop_forward_ok(const Geometry &g, int es);
 
+// ragged_forward: 2-D, 4- / 8-byte elements, source rows that are not whole pieces, at least 8 chunks wide (shorter rows: whole planes
+// through the flat-stream kernels) and at most 254 (a cover of xcpr + 2 pieces per staging pass), at least 16 rows
+static bool ragged_forward_ok(const Geometry &g, int es) {
+    if (g.nd != 2 || es < 4 || (g.S[2] * es) % 16 == 0) return false;
+    if (g.S[2] * es < 8 * 16 || g.S[2] * es > (kThreads - 2) * 16 || g.S[1] < 16) return false;
+    return g.S[1] * g.S[2] < (1LL << 28) && g.O[1] * g.O[2] < (1LL << 28);
+}
+
 bool span_forward_eligible(const Geometry &g, int dtype, const void *x, const void *out) {
     if (g_step_tune[2] == 1) return false;   // knob 34 = 1: no forwards through LDS
     if (dtype > SHIFTND_BF16 || (g.nd != 1 && g.nd != 2) || g.K[0] > 0) return false;
     const int es = dtype_size(dtype);
     if (g.S[0] != 1 || g.O[0] != 1 || g.S[1] < 1 || g.S[2] < 1 || g.O[1] < 1 || g.O[2] < 1) return false;
+    if (ragged_forward_ok(g, es)) {
+        if (!dense(g.xs, g.N, g.C, g.S) || !dense(g.os, g.N, g.C, g.O)) return false;
+        if (reinterpret_cast<uintptr_t>(x) % 16 || reinterpret_cast<uintptr_t>(out) % es) return false;
+        const int64_t rows = std::min<int64_t>(g.O[1], kThreads / ((g.S[2] * es + 15) / 16 + 2));
+        return g.N * g.C * ((g.O[1] + rows - 1) / rows) + 8 < (1LL << 31);
+    }
     if (g.nd == 1 && (g.S[2] * es) % 16 != 0) return false;   // row_forward: rows of whole pieces
     if ((g.O[1] * g.O[2] * es) % 16 != 0 || (g.N * g.C * g.S[1] * g.S[2] * es) % 16 != 0) return false;
     if (g.S[1] * g.S[2] >= (1LL << 28) || g.O[1] * g.O[2] >= (1LL << 28)) return false;
@@ -828,6 +993,56 @@ static bool crop_forward_ok(const Geometry &g, int es) {
 
 int span_forward(const Geometry &g, int dtype, const void *x, const void *w, int wkind, void *out, hipStream_t st) {
     const int es = dtype_size(dtype);
+    if (ragged_forward_ok(g, es)) {
+        SpanFwdParams p{};
+        p.x = x;
+        p.out = out;
+        p.w = w;
+        p.wkind = wkind;
+        p.C = static_cast<int>(g.C);
+        p.nd = g.nd;
+        p.S1 = static_cast<int>(g.S[1]);
+        p.S2 = static_cast<int>(g.S[2]);
+        p.O1 = static_cast<int>(g.O[1]);
+        p.O2 = static_cast<int>(g.O[2]);
+        p.L1 = static_cast<int>(g.L[1]);
+        p.L2 = static_cast<int>(g.L[2]);
+        p.x_plane = g.S[1] * g.S[2];
+        p.o_plane = g.O[1] * g.O[2];
+        const int xcpr = static_cast<int>((g.S[2] * es + 15) / 16);
+        p.P = xcpr + 2;                                                 // pieces per staged source row
+        p.ocp = static_cast<int>((g.O[2] * es + 15) / 16);              // output chunks per row
+        p.cps = std::max(1, std::min<int>(static_cast<int>(g.O[1]), kThreads / p.P));   // rows per step
+        p.spp = (p.O1 + p.cps - 1) / p.cps;
+        const uint64_t total = static_cast<uint64_t>(g.N) * g.C * p.spp;
+        p.total_steps = static_cast<uint32_t>(total);
+        p.steps_per_xcd = static_cast<uint32_t>((total + 7) / 8);
+        p.d_spp = make_fastdiv(static_cast<uint32_t>(p.spp));
+        p.d_C = make_fastdiv(static_cast<uint32_t>(p.C));
+        p.d_O2 = make_fastdiv(static_cast<uint32_t>(p.ocp));            // (ragged_forward: thread -> (row, chunk))
+        p.d_P = make_fastdiv(static_cast<uint32_t>(p.P));
+        p.d_per1 = make_fastdiv(static_cast<uint32_t>(map_period(p.S1, g.pad)));
+        p.d_per2 = make_fastdiv(static_cast<uint32_t>(map_period(p.S2, g.pad)));
+        const size_t lds = 64 + static_cast<size_t>(p.cps + 1) * p.P * 16 + 64;
+        const bool act = g.active != 0;
+        note_kernel(act ? "ragged_active_forward" : "ragged_gather_forward");
+        const dim3 grid(p.steps_per_xcd * 8), block(kThreads);
+#define SHIFTND_RAG_FWD(TT, ACT) \
+        switch (g.pad) { \
+        case 0: hipLaunchKernelGGL((ragged_forward<TT, ACT, 0>), grid, block, lds, st, p); break; \
+        case 1: hipLaunchKernelGGL((ragged_forward<TT, ACT, 1>), grid, block, lds, st, p); break; \
+        case 2: hipLaunchKernelGGL((ragged_forward<TT, ACT, 2>), grid, block, lds, st, p); break; \
+        case 3: hipLaunchKernelGGL((ragged_forward<TT, ACT, 3>), grid, block, lds, st, p); break; \
+        default: hipLaunchKernelGGL((ragged_forward<TT, ACT, 4>), grid, block, lds, st, p); break; \
+        }
+        if (dtype == SHIFTND_F64) {
+            if (act) { SHIFTND_RAG_FWD(f64_t, true) } else { SHIFTND_RAG_FWD(f64_t, false) }
+        } else {
+            if (act) { SHIFTND_RAG_FWD(f32_t, true) } else { SHIFTND_RAG_FWD(f32_t, false) }
+        }
+#undef SHIFTND_RAG_FWD
+        return SHIFTND_OK;
+    }
     SpanFwdPlan sp = span_forward_plan(g, es);
     const bool row1d = g.nd == 1 && (g.S[2] * es) % 16 == 0;
     if (row1d) {   // row_forward: segments of 256 chunks, the columns their windows reach
@@ -933,18 +1148,21 @@ bool span_backward_eligible(const Geometry &g, int dtype, const void *go, const 
     if (g.nd == 1) return g.S[2] * es / 16 >= 128;   // (short rows: one row per workgroup would leave most lanes idle)
     bool crop = false;
     for (int d = 1; d < 3; ++d) crop = crop || g.O[d] != g.S[d] || g.L[d] != 0;
+    // ragged x rows of at least 8 chunks (62 x 62, 222 x 222 fp32 ...): the row-relative form; shorter rows (14 x 14, 7 x 7) leave most
+    // of a workgroup's lanes idle here -- whole planes through the flat-stream kernels
+    if ((g.S[2] * es) % 16 != 0) return g.S[2] * es >= 8 * 16 && g.S[1] >= 16;
     return crop;   // (uncropped 2-D: step_backward)
 }
 
 size_t span_backward_workspace(const Geometry &g, int dtype) { return span_geometry_ok(g, dtype) ? span_plan(g, dtype_size(dtype)).bytes : 0; }
 
-template <typename T, int ND>
+template <typename T, int ND, bool XRAG = false>
 static void launch_span_backward(const SpanParams &p, const SpanPlan &sp, bool active, void *gw, hipStream_t st) {
     using S = typename T::S;
     const dim3 grid(p.steps_per_xcd * 8), block(kThreads);
 #define SHIFTND_SPAN_PAD(ACT, PADV) \
     case PADV: \
-        if constexpr (ND == 2) hipLaunchKernelGGL((crop_backward<T, ACT, PADV>), grid, block, sp.lds, st, p); \
+        if constexpr (ND == 2) hipLaunchKernelGGL((crop_backward<T, ACT, PADV, XRAG>), grid, block, sp.lds, st, p); \
         else hipLaunchKernelGGL((row_backward<T, ACT, PADV>), grid, block, sp.lds, st, p); \
         break;
     if (active) {
@@ -1011,8 +1229,14 @@ int span_backward(const Geometry &g, int dtype, const void *go, const void *x, c
     p.d_per2x = make_fastdiv(static_cast<uint32_t>(map_period(p.S2, g.pad)));
     p.d_per1g = make_fastdiv(static_cast<uint32_t>(map_period(p.O1, g.pad)));
     p.d_per2g = make_fastdiv(static_cast<uint32_t>(map_period(p.O2, g.pad)));
-    note_kernel(g.nd == 2 ? "crop_backward" : "row_backward");
     const bool active = g.active != 0;
+    if (g.nd == 2 && (g.S[2] * es) % 16 != 0) {   // ragged x rows (4- / 8-byte elements: span_geometry_ok)
+        note_kernel("crop_backward_ragged");
+        if (dtype == SHIFTND_F64) launch_span_backward<f64_t, 2, true>(p, sp, active, gw, st);
+        else launch_span_backward<f32_t, 2, true>(p, sp, active, gw, st);
+        return SHIFTND_OK;
+    }
+    note_kernel(g.nd == 2 ? "crop_backward" : "row_backward");
 #define SHIFTND_SPAN_T(TT) (g.nd == 1 ? launch_span_backward<TT, 1>(p, sp, active, gw, st) : launch_span_backward<TT, 2>(p, sp, active, gw, st))
     switch (dtype) {
     case SHIFTND_F32: SHIFTND_SPAN_T(f32_t); break;

@@ -125,12 +125,20 @@ def test_flat_default_route_for_ragged_rows():
     from torchshifts import abi
     abi.set_path_policy(0)
     abi.set_tuning(27, 0)
-    for shape, flat in (((4, 8, 14, 14), True), ((2, 4, 62, 62), True), ((1, 2, 222, 222), True), ((2, 4, 64, 64), False), ((2, 3, 1001), True), ((2, 3, 1024), False)):
+    # (shape, the forward's family, the backward's kernel: fp32 planes with rows of at least 8 chunks take the row-relative crop_backward)
+    for shape, flat, bwd in (((4, 8, 14, 14), True, "flat_backward"), ((2, 4, 62, 62), True, "crop_backward_ragged"), ((1, 2, 222, 222), True, "crop_backward_ragged"),
+                             ((2, 4, 64, 64), False, "step_backward"), ((2, 3, 1001), True, "flat_backward"), ((2, 3, 1024), False, None)):
         nd = len(shape) - 2
         x = torch.rand(shape, device=DEV)
         w = torch.rand(shape[1], nd, device=DEV) * 4 - 2
         for active in (0, 1):
             abi.forward(x, w, 0, active)
-            assert abi.last_kernel().startswith("flat_") == flat, (shape, active, abi.last_kernel())
+            big = bwd == "crop_backward_ragged"   # (fp32 rows of at least 8 chunks: the row-relative kernels of shiftnd_span.hip)
+            assert abi.last_kernel().startswith("ragged_" if big else "flat_") == flat, (shape, active, abi.last_kernel())
             abi.backward(torch.rand(shape, device=DEV), w, x, 0, active)
-            assert (abi.last_kernel() == "flat_backward") == flat, (shape, active, abi.last_kernel())
+            if bwd is not None:
+                assert abi.last_kernel() == bwd, (shape, active, abi.last_kernel())
+    xh = torch.rand(2, 4, 62, 62, device=DEV).half()   # 16-bit ragged rows: the flat stream (2-byte-aligned 16-byte stores are slow)
+    wh = (torch.rand(4, 2, device=DEV) * 4 - 2).half()
+    abi.backward(torch.rand(2, 4, 62, 62, device=DEV).half(), wh, xh, 0, 0)
+    assert abi.last_kernel() == "flat_backward"

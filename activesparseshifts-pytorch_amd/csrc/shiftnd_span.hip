@@ -948,7 +948,9 @@ static bool crop_forward_ok(const Geometry &g, int es);
 // ragged_forward: 2-D, 4- / 8-byte elements, source rows that are not whole pieces, at least 8 chunks wide (shorter rows: whole planes
 // through the flat-stream kernels) and at most 254 (a cover of xcpr + 2 pieces per staging pass), at least 16 rows
 static bool ragged_forward_ok(const Geometry &g, int es) {
-    if (g.nd != 2 || es < 4 || (g.S[2] * es) % 16 == 0) return false;
+    // (knob 34 = 3: windows on source rows of whole pieces too -- crop_forward's share -- for A / B runs)
+    const bool window = g.O[1] != g.S[1] || g.O[2] != g.S[2];
+    if (g.nd != 2 || es < 4 || ((g.S[2] * es) % 16 == 0 && !(g_step_tune[2] == 3 && window))) return false;
     if (g.S[2] * es < 8 * 16 || g.S[2] * es > (kThreads - 2) * 16 || g.S[1] < 16) return false;
     return g.S[1] * g.S[2] < (1LL << 28) && g.O[1] * g.O[2] < (1LL << 28);
 }

@@ -142,7 +142,8 @@ def test_row_bands_vs_oracle(abi, shape, dt):
     xd, god, wd = torch.from_numpy(x).to(DEV), torch.from_numpy(go).to(DEV), torch.from_numpy(w).to(DEV)
     ragged = (shape[-1] * x.itemsize) % 16 != 0
     assert ragged
-    abi.set_tuning(27, 1)   # (the flat-stream kernels would take most of these shapes: off, the band kernels are measured)
+    for k in (27, 32, 34):   # (the flat-stream and the row-relative kernels would take most of these shapes: off, the band kernels are measured)
+        abi.set_tuning(k, 1)
     for br in (0, 1, 3):
         abi.set_tuning(25, br)
         for pad in range(5):
@@ -158,14 +159,16 @@ def test_row_bands_vs_oracle(abi, shape, dt):
                 assert np.array_equal(gx.cpu().numpy(), gx_o), (shape, pad, active, br)
                 assert rel_err(gw.cpu().numpy(), gw64) < (1e-12 if dt == "f64" else 1e-5), (shape, pad, active)
     abi.set_tuning(25, 0)
-    abi.set_tuning(27, 0)
+    for k in (27, 32, 34):
+        abi.set_tuning(k, 0)
 
 
 def test_row_bands_16bit_and_full_size(abi):
     """bf16 against the oracle and the one-thread-per-element kernels, and an odd-sized image batch at full size (oracle on
     its first samples)"""
     torch.manual_seed(11)
-    abi.set_tuning(27, 1)
+    for k in (27, 32, 34):
+        abi.set_tuning(k, 1)
     for shape, tdt in [((3, 8, 60, 151), torch.bfloat16), ((8, 64, 225, 225), torch.float32)]:
         x = torch.rand(shape, device=DEV).to(tdt)
         go = torch.rand(shape, device=DEV).to(tdt)
@@ -193,13 +196,15 @@ def test_row_bands_16bit_and_full_size(abi):
                 assert _ulp_close(gx[:ns].cpu(), gx_o, tdt) if active else torch.equal(gx[:ns].cpu(), gx_o), (shape, pad)
                 _, gw64 = O.backward(gn.astype(np.float64), wn.astype(np.float64), xn.astype(np.float64), pad, active)
                 assert rel_err(gw.float().cpu().numpy(), gw64) < gw16_tol(torch.finfo(tdt).eps), (shape, pad, active)
-    abi.set_tuning(27, 0)
+    for k in (27, 32, 34):
+        abi.set_tuning(k, 0)
 
 
 def test_row_band_gather_forward_vs_oracle(abi):
     """band_gather_forward: sparse-shift / quantized forward of planes above 16 KiB whose rows are not whole 16-byte
     pieces, every element size, every padding; bit-exact"""
-    abi.set_tuning(27, 1)   # (the flat-stream kernels take the float cases by default: off here)
+    for k in (27, 34):   # (the flat-stream / row-relative kernels take the float cases by default: off here)
+        abi.set_tuning(k, 1)
     rs = np.random.RandomState(17)
     for shape in [(2, 3, 70, 113), (1, 2, 300, 25), (2, 2, 4501)]:
         nd = len(shape) - 2
@@ -233,7 +238,8 @@ def test_row_band_gather_forward_vs_oracle(abi):
     out = abi.forward(xh, wh, 3, 0)
     assert abi.last_kernel() == "band_gather_forward" and torch.equal(out, ref)
 
-    abi.set_tuning(27, 0)
+    for k in (27, 32, 34):
+        abi.set_tuning(k, 0)
 
 @pytest.mark.parametrize("shape,npdt", [((2, 3, 40, 64), np.uint8), ((1, 2, 3, 33, 48), np.int8), ((3, 2, 150, 224), np.uint8),
                                         ((2, 2, 1, 4096), np.uint8), ((2, 3, 130), np.uint8)])

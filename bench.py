@@ -152,7 +152,14 @@ def newest_traffic(workload, kernel_name, pad):
     if best is None:
         return None, None
     try:
-        t = json.load(open(best[1]))["per_launch"].get(kernel_name)
+        per = json.load(open(best[1]))["per_launch"]
+        # (shiftnd_last_kernel names the ROUTE -- crop_backward_ragged, flat_gather_forward -- the profile the kernel function)
+        t = None
+        for cand in (kernel_name, kernel_name.replace("_ragged", ""), kernel_name.replace("_gather_", "_").replace("_active_", "_"),
+                     kernel_name.replace("_ncdhw_grad", "").replace("_nchw_grad", "")):
+            if cand in per:
+                t = per[cand]
+                break
         if t and "read_bytes" in t and "written_bytes" in t:
             return t["read_bytes"] + t["written_bytes"], "profiles/%s (round %d)" % (os.path.basename(best[1]), best[0])
     except (OSError, ValueError, KeyError):

@@ -200,12 +200,17 @@ QCASES = [  # the planes the per-channel quantized kernel (qpool_plane_forward) 
     (1, (7, 5, 64), (2,), None),
     (1, (4, 3, 99), (3,), [[2, 1]]),
     # round 4, qpool_band_forward: planes beyond the plane kernel (more than 48 KiB or more than 1024 items), bands of pooled rows
-    (2, (3, 2, 224, 224), (2, 2), None),              # 50 KB planes, 16-byte pieces, four bands
-    (2, (2, 3, 150, 226), (2, 2), [[1, 0], [3, 3]]),  # byte / dword pieces, ragged last band and windows, a crop
+    (2, (3, 6, 224, 224), (2, 2), None),              # 50 KB planes, 16-byte pieces, four bands (six channels: the shifts of BAND_SHIFTS below)
+    (2, (2, 6, 150, 226), (2, 2), [[1, 0], [3, 3]]),  # byte / dword pieces, ragged last band and windows, a crop
     (2, (5, 2, 130, 120), (3, 3), None),              # nine-byte windows
     (2, (2, 2, 300, 36), (1, 2), None),               # a row window
     (1, (3, 2, 9000), (2,), None),                    # Shift1d: one long row
+    (2, (2, 6, 60, 230), (2, 2), [[0, 0], [3, 2]]),   # a window whose left border is not a multiple of 4 and whose width is odd: the non-fast band kernel
 ]
+
+# column shifts at and beyond the edge of qpool_band_fast's 16 / 32-byte zero-point pads (+-7, +-8, +-9), and shifts
+# that are partially in range (about half the row): (row, column) shifts of channels 1 .. 5 of the six-channel band cases
+BAND_SHIFTS = [(-7, 8), (9, -9), (None, None), (8, 7), (-8, -7)]   # (None: half the plane, set per case)
 
 
 def aten_inv(cnt):
@@ -230,6 +235,9 @@ def test_quantized_pooled_forward_vs_oracle(abi, npdt):
         xq = rs.randint(info.min, info.max + 1, size=shape).astype(npdt)
         wq = rs.randint(123, 134, size=(shape[1], nd)).astype(np.uint8)
         wq[0] = 128 + shape[-1] + 2 if shape[-1] < 120 else 130
+        if nd == 2 and shape[1] == 6 and shape[-1] >= 200:   # the band cases: shifts around the pads' edges and partially in range
+            for ch, (sr, sc) in enumerate(BAND_SHIFTS, start=1):
+                wq[ch] = [128 + (shape[2] // 2 if sr is None else sr), 128 - (shape[3] // 2 - 14 if sc is None else -sc)]
         zp = 7 if npdt == np.uint8 else -9
         b, new = abi.check_borders(list(shape), crop, nd)
         for pad in range(5):

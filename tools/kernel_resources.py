@@ -47,6 +47,8 @@ def code_objects(path, tmp):
                             "--output=" + co], capture_output=True, text=True)
         if r.returncode == 0 and os.path.exists(co) and os.path.getsize(co) > 0:
             outs.append(co)
+        elif TARGET.encode() in data[s:s + 4096]:   # the bundle holds a gfx950 entry and the bundler could not extract it
+            raise RuntimeError("kernel_resources: clang-offload-bundler failed on %s: %s" % (os.path.basename(path), (r.stderr or "").strip()[:200]))
     return outs
 
 
@@ -97,8 +99,18 @@ def default_objects():
 
 
 def check_no_scratch(paths=None):
-    """-> list of (kernel, bytes per lane) that use scratch; build.py raises when it is not empty"""
-    return [(k["demangled"], k["private_segment_fixed_size"]) for k in collect(paths or default_objects())
+    """-> list of (kernel, bytes per lane) that use scratch; build.py raises when it is not empty.
+    Raises itself when the check could pass vacuously: an object that yields no kernel (the bundler failed, the note format
+    changed) or a kernel record without the fields the check reads."""
+    paths = list(paths or default_objects())
+    ks = collect(paths)
+    # (a host-only TU -- shiftnd_api.hip -- legitimately holds no kernel; a LIBRARY's worth of objects without kernels does not)
+    if len(ks) < max(1, len(paths) // 2):
+        raise RuntimeError("kernel_resources: %d kernels found in %d objects (clang-offload-bundler / llvm-readelf --notes output changed?)" % (len(ks), len(paths)))
+    blind = [k["demangled"] for k in ks if "private_segment_fixed_size" not in k or "vgpr_count" not in k]
+    if blind:
+        raise RuntimeError("kernel_resources: %d kernel records without private_segment_fixed_size / vgpr_count (note format?): %s" % (len(blind), blind[0]))
+    return [(k["demangled"], k["private_segment_fixed_size"]) for k in ks
             if k.get("private_segment_fixed_size", 0) > 0 or k.get("vgpr_spill_count", 0) > 0]
 
 

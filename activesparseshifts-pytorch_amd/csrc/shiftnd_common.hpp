@@ -422,10 +422,11 @@ template <typename R, int E, bool NT = false> __device__ __forceinline__ Chunk<R
     return c;
 }
 // element-aligned V-byte nontemporal store (one global_store_dwordx4 for V = 16 at a 4-byte boundary)
+// (the caller guarantees a 4-byte boundary also for 2-byte elements: rows of an even number of them)
 template <typename R, int E> __device__ __forceinline__ void store_chunk_unaligned(R *dst, const Chunk<R, E> &c) {
     constexpr int V = sizeof(R) * E;
     typedef typename vec_of<V>::type vec_t;
-    typedef vec_t unaligned_t __attribute__((aligned(sizeof(R) < 4 ? sizeof(R) : 4)));
+    typedef vec_t unaligned_t __attribute__((aligned(4)));
     vec_t v;
     __builtin_memcpy(&v, c.e, V);
     __builtin_nontemporal_store(v, reinterpret_cast<unaligned_t *>(dst));

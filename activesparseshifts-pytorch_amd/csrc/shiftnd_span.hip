@@ -533,7 +533,8 @@ __global__ __launch_bounds__(kThreads) void ragged_forward(const SpanFwdParams p
     using CT = typename T::C;
     constexpr int ES = sizeof(S);
     constexpr int E = 16 / ES;
-    static_assert(ES >= 4, "4- / 8-byte elements (2-byte-aligned 16-byte stores are slow: shiftnd_flat.hip)");
+    // (2-byte elements: rows of an EVEN number of them -- the host checks -- so that every row starts at a 4-byte boundary; 2-byte-aligned
+    //  16-byte stores are slow, those shapes stay with shiftnd_flat.hip)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char *tile = smem + 64;
 
@@ -930,7 +931,9 @@ bool span_geometry_ok(const Geometry &g, int dtype) {
     const int es = dtype_size(dtype);
     if (g.S[0] != 1 || g.O[0] != 1 || g.S[1] < 1 || g.S[2] < 1 || g.O[1] < 1 || g.O[2] < 1) return false;
     // x rows: whole pieces -- or, 2-D with 4- / 8-byte elements, any length (crop_backward<.., XRAG>, round 5); int16 column tables
-    if (((g.S[2] * es) % 16 != 0 && !(g.nd == 2 && es >= 4)) || g.S[2] > 32000) return false;
+    // (2-byte elements: input AND gradient rows of an even number of elements -- every row at a 4-byte boundary)
+    const bool rag_ok = g.nd == 2 && (es >= 4 || (es == 2 && g.S[2] % 2 == 0 && g.O[2] % 2 == 0));
+    if (((g.S[2] * es) % 16 != 0 && !rag_ok) || g.S[2] > 32000) return false;
     // (grad_out / x need not be a whole number of pieces: the last piece of a cover reaches at most 15 bytes past the tensor's
     //  end, inside the 16-byte granule -- hence the page -- of its last valid byte; those bytes are never used)
     if (g.S[1] * g.S[2] >= (1LL << 28) || g.O[1] * g.O[2] >= (1LL << 28)) return false;  // 32-bit byte offsets within a plane
@@ -950,7 +953,8 @@ static bool crop_forward_ok(const Geometry &g, int es);
 static bool ragged_forward_ok(const Geometry &g, int es) {
     // (knob 34 = 3: windows on source rows of whole pieces too -- crop_forward's share -- for A / B runs)
     const bool window = g.O[1] != g.S[1] || g.O[2] != g.S[2];
-    if (g.nd != 2 || es < 4 || ((g.S[2] * es) % 16 == 0 && !(g_step_tune[2] == 3 && window))) return false;
+    if (g.nd != 2 || es < 2 || ((g.S[2] * es) % 16 == 0 && !(g_step_tune[2] == 3 && window))) return false;
+    if (es == 2 && (g.S[2] % 2 != 0 || g.O[2] % 2 != 0)) return false;   // 2-byte elements: every source and output row at a 4-byte boundary
     if (g.S[2] * es < 8 * 16 || g.S[2] * es > (kThreads - 2) * 16 || g.S[1] < 16) return false;
     return g.S[1] * g.S[2] < (1LL << 28) && g.O[1] * g.O[2] < (1LL << 28);
 }
@@ -1037,11 +1041,12 @@ int span_forward(const Geometry &g, int dtype, const void *x, const void *w, int
         case 3: hipLaunchKernelGGL((ragged_forward<TT, ACT, 3>), grid, block, lds, st, p); break; \
         default: hipLaunchKernelGGL((ragged_forward<TT, ACT, 4>), grid, block, lds, st, p); break; \
         }
-        if (dtype == SHIFTND_F64) {
-            if (act) { SHIFTND_RAG_FWD(f64_t, true) } else { SHIFTND_RAG_FWD(f64_t, false) }
-        } else {
-            if (act) { SHIFTND_RAG_FWD(f32_t, true) } else { SHIFTND_RAG_FWD(f32_t, false) }
-        }
+        if (!act) {   // a raw copy: one instantiation per element size
+            if (es == 2) { SHIFTND_RAG_FWD(f16_t, false) } else if (es == 4) { SHIFTND_RAG_FWD(f32_t, false) } else { SHIFTND_RAG_FWD(f64_t, false) }
+        } else if (dtype == SHIFTND_F32) { SHIFTND_RAG_FWD(f32_t, true)
+        } else if (dtype == SHIFTND_F64) { SHIFTND_RAG_FWD(f64_t, true)
+        } else if (dtype == SHIFTND_F16) { SHIFTND_RAG_FWD(f16_t, true)
+        } else { SHIFTND_RAG_FWD(bf16_t, true) }
 #undef SHIFTND_RAG_FWD
         return SHIFTND_OK;
     }
@@ -1234,8 +1239,12 @@ int span_backward(const Geometry &g, int dtype, const void *go, const void *x, c
     const bool active = g.active != 0;
     if (g.nd == 2 && (g.S[2] * es) % 16 != 0) {   // ragged x rows (4- / 8-byte elements: span_geometry_ok)
         note_kernel("crop_backward_ragged");
-        if (dtype == SHIFTND_F64) launch_span_backward<f64_t, 2, true>(p, sp, active, gw, st);
-        else launch_span_backward<f32_t, 2, true>(p, sp, active, gw, st);
+        switch (dtype) {
+        case SHIFTND_F64: launch_span_backward<f64_t, 2, true>(p, sp, active, gw, st); break;
+        case SHIFTND_F32: launch_span_backward<f32_t, 2, true>(p, sp, active, gw, st); break;
+        case SHIFTND_F16: launch_span_backward<f16_t, 2, true>(p, sp, active, gw, st); break;
+        default: launch_span_backward<bf16_t, 2, true>(p, sp, active, gw, st); break;
+        }
         return SHIFTND_OK;
     }
     note_kernel(g.nd == 2 ? "crop_backward" : "row_backward");

@@ -33,7 +33,7 @@ namespace {
 constexpr int kMaxPlanes = 72;             // planes a step may touch (small planes: 4096 / plane bytes + 2)
 constexpr int kCoverBudget = 24 * 1024;    // LDS bytes per staged tensor
 
-struct FlatDesc {   // per channel, written by flat_prep (backward)
+struct FlatDesc {   // (round 5's first version: per channel, written by a prep kernel; the workspace keeps room for it)
     int cx1, cx2;   // canonical shifts of the input's row / column maps (sizes S1, S2)
     int cg1, cg2;   // ... of the gradient's maps (the window's sizes O1, O2; sparse shift: the opposite direction)
     double dw[2];   // fractions of prep_shift_backward (row, column), exactly as the compute type holds them
@@ -339,29 +339,21 @@ __global__ __launch_bounds__(kThreads) void flat_forward(const FlatParams p) {
     }
 }
 
-// ---------------------------------------------------------------------------------------------------------------------
-// flat_prep: one thread per channel -- the weight preparation of the reference's backward (shifts_cpu.cpp:242-244)
-// ---------------------------------------------------------------------------------------------------------------------
-template <typename T, bool ACTIVE>
-__global__ __launch_bounds__(kThreads) void flat_prep(const FlatParams p) {
-    using CT = typename T::C;
-    const int c = static_cast<int>(blockIdx.x * kThreads + threadIdx.x);
-    if (c >= p.C) return;
-    const int lead = 3 - p.nd;
-    int64_t sh[3] = {0, 0, 0};
-    CT dw[3] = {CT(0), CT(0), CT(0)};
-    for (int r = 0; r < p.nd; ++r) {
-        const CT wv = load_weight<CT>(p.w, p.wkind, static_cast<int64_t>(c) * p.nd + r);
-        prep_shift_backward<CT>(wv, ACTIVE, sh[r + lead], dw[r + lead]);
-    }
-    FlatDesc d;
-    d.cx1 = canon_shift(sh[1], p.S1, p.pad, p.d_per1);
-    d.cx2 = canon_shift(sh[2], p.S2, p.pad, p.d_per2);
-    d.cg1 = canon_shift(ACTIVE ? sh[1] : -sh[1], p.O1, p.pad, p.d_pero1);
-    d.cg2 = canon_shift(ACTIVE ? sh[2] : -sh[2], p.O2, p.pad, p.d_pero2);
-    d.dw[0] = static_cast<double>(dw[1]);
-    d.dw[1] = static_cast<double>(dw[2]);
-    p.desc[c] = d;
+// The weight preparation of the reference's backward (shifts_cpu.cpp:242-244) for channel c, in the kernel that needs it (round 5: a
+// prep kernel of its own cost a 60 us call 5 us): fractions, canonical shifts of the input's maps (sizes S) and of the gradient's
+// (the window's sizes O; sparse shift: the opposite direction).
+template <typename CT, bool ACTIVE>
+__device__ __forceinline__ void flat_channel_backward(const FlatParams &p, int c, int &cx1, int &cx2, int &cg1, int &cg2, CT &f1, CT &f2) {
+    const CT w1 = p.nd == 2 ? load_weight<CT>(p.w, p.wkind, static_cast<int64_t>(c) * 2) : CT(0);
+    const CT w2 = load_weight<CT>(p.w, p.wkind, static_cast<int64_t>(c) * p.nd + p.nd - 1);
+    auto frac = [](CT w) { return ACTIVE ? (w - c_floor<CT>(w)) : ((w > CT(0)) ? (w - c_floor<CT>(w)) : (c_ceil<CT>(w) - w)); };   // prep_shift_backward
+    f1 = p.nd == 2 ? frac(w1) : CT(0);
+    f2 = frac(w2);
+    const CT r1 = ACTIVE ? (w1 - f1) : c_rint<CT>(w1), r2 = ACTIVE ? (w2 - f2) : c_rint<CT>(w2);   // integral
+    cx1 = canon_rt<CT>(r1, p.S1, p.pad, p.d_per1);
+    cx2 = canon_rt<CT>(r2, p.S2, p.pad, p.d_per2);
+    cg1 = canon_rt<CT>(ACTIVE ? r1 : -r1, p.O1, p.pad, p.d_pero1);
+    cg2 = canon_rt<CT>(ACTIVE ? r2 : -r2, p.O2, p.pad, p.d_pero2);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -395,13 +387,7 @@ __global__ __launch_bounds__(kThreads) void flat_backward(const FlatParams p, in
 
     auto fill = [&](uint32_t pl, Rec &r) {
         const int c = static_cast<int>(pl - fdiv(pl, p.d_C) * static_cast<uint32_t>(p.C));
-        const FlatDesc d = p.desc[c];
-        r.c1 = d.cx1;
-        r.c2 = d.cx2;
-        r.g1 = d.cg1;
-        r.g2 = d.cg2;
-        r.f1 = static_cast<CT>(d.dw[0]);
-        r.f2 = static_cast<CT>(d.dw[1]);
+        flat_channel_backward<CT, ACTIVE>(p, c, r.c1, r.c2, r.g1, r.g2, r.f1, r.f2);
     };
     if constexpr (SMALL) {
         const Cover cx = row_cover<ES>(plA, p.XP, S2, 0, static_cast<int>((plB - plA + 1) * static_cast<uint32_t>(S1)) - 1);
@@ -658,7 +644,7 @@ __global__ __launch_bounds__(kThreads) void flat_backward(const FlatParams p, in
 
 // grad_w[c][:] = blend(sum over the records of channel c's planes, in a fixed order): one wave per channel, lanes over the batch
 template <typename T>
-__global__ __launch_bounds__(64) void flat_reduce(const FlatParams p, int N, typename T::S *__restrict__ grad_w) {
+__global__ __launch_bounds__(64) void flat_reduce(const FlatParams p, int N, int active, typename T::S *__restrict__ grad_w) {
     using S = typename T::S;
     constexpr int E = 16 / sizeof(S);
     const int c = blockIdx.x;
@@ -676,14 +662,18 @@ __global__ __launch_bounds__(64) void flat_reduce(const FlatParams p, int N, typ
     a = wave_sum(a);
     b = wave_sum(b);
     if (threadIdx.x == 0) {
-        const FlatDesc d = p.desc[c];
         double out[2];
         if (p.nd == 1) {
             out[0] = a;   // 1-D: the one partial is the column difference (interp1D_dx, interpolation.h:10-13)
             out[1] = 0.0;
         } else {
-            const double s[2] = {a, b};
-            blend_diffs<2>(s, d.dw, out);
+            using CT = typename T::C;
+            int u0, u1, u2, u3;
+            CT f1, f2;
+            if (active) flat_channel_backward<CT, true>(p, c, u0, u1, u2, u3, f1, f2);
+            else flat_channel_backward<CT, false>(p, c, u0, u1, u2, u3, f1, f2);
+            const double s[2] = {a, b}, dwd[2] = {static_cast<double>(f1), static_cast<double>(f2)};   // (exactly as the compute type holds them)
+            blend_diffs<2>(s, dwd, out);
         }
         for (int k = 0; k < p.nd; ++k) {
             if constexpr (sizeof(S) == 8) grad_w[c * p.nd + k] = out[k];
@@ -777,7 +767,6 @@ void launch_flat_forward(const FlatParams &p, size_t lds, int pad, hipStream_t s
 template <typename T, bool ACTIVE, bool SMALL>
 void launch_flat_backward(const FlatParams &p, const FlatPlan &pl, int pad, int N, void *gw, hipStream_t st) {
     const dim3 grid(p.steps_per_xcd * 8), block(kThreads);
-    hipLaunchKernelGGL((flat_prep<T, ACTIVE>), dim3((p.C + kThreads - 1) / kThreads), block, 0, st, p);
     switch (pad) {
     case 0: hipLaunchKernelGGL((flat_backward<T, ACTIVE, 0, SMALL>), grid, block, pl.lds, st, p, pl.gcov_off); break;
     case 1: hipLaunchKernelGGL((flat_backward<T, ACTIVE, 1, SMALL>), grid, block, pl.lds, st, p, pl.gcov_off); break;
@@ -785,7 +774,7 @@ void launch_flat_backward(const FlatParams &p, const FlatPlan &pl, int pad, int 
     case 3: hipLaunchKernelGGL((flat_backward<T, ACTIVE, 3, SMALL>), grid, block, pl.lds, st, p, pl.gcov_off); break;
     default: hipLaunchKernelGGL((flat_backward<T, ACTIVE, 4, SMALL>), grid, block, pl.lds, st, p, pl.gcov_off); break;
     }
-    hipLaunchKernelGGL((flat_reduce<T>), dim3(p.C), dim3(64), 0, st, p, N, static_cast<typename T::S *>(gw));
+    hipLaunchKernelGGL((flat_reduce<T>), dim3(p.C), dim3(64), 0, st, p, N, ACTIVE ? 1 : 0, static_cast<typename T::S *>(gw));
 }
 
 void fill_params(FlatParams &p, const Geometry &g, int es, bool backward, const FlatPlan &pl) {

@@ -123,6 +123,34 @@ __global__ __launch_bounds__(kThreads) void span_prep(const SpanParams p) {
 // E + 1 elements of a source row through a column state: from the staged slot, or -- a chunk whose columns are not all among the
 // staged ones (only a column segment of the row is staged when rows are longer than a workgroup pass: the chunks that wrap,
 // clamp or reflect at the row ends then read elsewhere) -- element by element from memory
+// span_prep's descriptor computed in the kernel that needs it -- zeros padding has no column tables, and a prep kernel of its own costs
+// a 70 us call 4.5 us (round 5).  The first step of the first batch entry leaves the descriptor in p.desc for step_reduce.
+template <typename T, bool ACTIVE>
+__device__ __forceinline__ ChanDesc span_desc_zeros(const SpanParams &p, int c, bool publish) {
+    using CT = typename T::C;
+    const int lead = 2 - p.nd;
+    int64_t sh[2] = {0, 0};
+    CT dw[2] = {CT(0), CT(0)};
+    for (int r = 0; r < p.nd; ++r) {
+        const CT wv = load_weight<CT>(p.w, p.wkind, static_cast<int64_t>(c) * p.nd + r);
+        prep_shift_backward<CT>(wv, ACTIVE, sh[r + lead], dw[r]);
+    }
+    ChanDesc d;
+    d.cx0 = d.cg0 = 0;
+    d.cx1 = canon_shift(sh[0], p.S1, 0, p.d_per1x);
+    d.cx2 = canon_shift(sh[1], p.S2, 0, p.d_per2x);
+    d.cg1 = canon_shift(ACTIVE ? sh[0] : -sh[0], p.O1, 0, p.d_per1g);
+    d.cg2 = canon_shift(ACTIVE ? sh[1] : -sh[1], p.O2, 0, p.d_per2g);
+    d.scat = 0;
+    d.pad_ = 0;
+    d.dw[0] = static_cast<double>(dw[0]);
+    d.dw[1] = static_cast<double>(dw[1]);
+    d.dw[2] = 0.0;
+    d.pad2_ = 0.0;
+    if (publish && threadIdx.x == 0) p.desc[c] = d;
+    return d;
+}
+
 template <typename S, int E>
 __device__ __forceinline__ void span_read(const char *lds_row, const S *mem_row, bool staged, bool valid, const ColState<E> &c, S (&raw)[E + 1]) {
     if (valid && !staged) {
@@ -166,7 +194,7 @@ __global__ __launch_bounds__(kThreads) void crop_backward(const SpanParams p) {
     const uint32_t plane = fdiv(bid, p.d_spp);   // (n, c)
     const int step = static_cast<int>(bid - plane * static_cast<uint32_t>(p.spp));
     const int c = static_cast<int>(plane - fdiv(plane, p.d_C) * static_cast<uint32_t>(p.C));
-    const ChanDesc d = p.desc[c];
+    const ChanDesc d = PAD == 0 ? span_desc_zeros<T, ACTIVE>(p, c, plane < static_cast<uint32_t>(p.C) && step == 0) : p.desc[c];
     const int R = p.R, S1 = p.S1, S2 = p.S2, O1 = p.O1, O2 = p.O2, L1 = p.L1, L2 = p.L2, cpr = p.cpr;
     const int b0 = step * R;
     const int Rn = min(R, S1 - b0);
@@ -729,7 +757,7 @@ __global__ __launch_bounds__(kThreads) void row_backward(const SpanParams p) {
     const uint32_t plane = fdiv(bid, p.d_spp);   // (n, c): one row
     const int sg = static_cast<int>(bid - plane * static_cast<uint32_t>(p.spp));
     const int c = static_cast<int>(plane - fdiv(plane, p.d_C) * static_cast<uint32_t>(p.C));
-    const ChanDesc d = p.desc[c];
+    const ChanDesc d = PAD == 0 ? span_desc_zeros<T, ACTIVE>(p, c, plane < static_cast<uint32_t>(p.C) && sg == 0) : p.desc[c];
     const int S2 = p.S2, O2 = p.O2, L2 = p.L2, cpr = p.cpr;
     const int J0 = sg * kThreads * E, J1 = min(S2, J0 + kThreads * E);   // the segment's columns of the x row
     auto clampi = [](int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); };
@@ -1172,11 +1200,12 @@ static void launch_span_backward(const SpanParams &p, const SpanPlan &sp, bool a
         if constexpr (ND == 2) hipLaunchKernelGGL((crop_backward<T, ACT, PADV, XRAG>), grid, block, sp.lds, st, p); \
         else hipLaunchKernelGGL((row_backward<T, ACT, PADV>), grid, block, sp.lds, st, p); \
         break;
+    // (zeros padding: no column tables -- the kernels prepare their channel themselves and publish the descriptor for step_reduce)
     if (active) {
-        hipLaunchKernelGGL((span_prep<T, true>), dim3(p.C), block, 0, st, p);
+        if (p.pad != 0) hipLaunchKernelGGL((span_prep<T, true>), dim3(p.C), block, 0, st, p);
         switch (p.pad) { SHIFTND_SPAN_PAD(true, 0) SHIFTND_SPAN_PAD(true, 1) SHIFTND_SPAN_PAD(true, 2) SHIFTND_SPAN_PAD(true, 3) default: SHIFTND_SPAN_PAD(true, 4) }
     } else {
-        hipLaunchKernelGGL((span_prep<T, false>), dim3(p.C), block, 0, st, p);
+        if (p.pad != 0) hipLaunchKernelGGL((span_prep<T, false>), dim3(p.C), block, 0, st, p);
         switch (p.pad) { SHIFTND_SPAN_PAD(false, 0) SHIFTND_SPAN_PAD(false, 1) SHIFTND_SPAN_PAD(false, 2) SHIFTND_SPAN_PAD(false, 3) default: SHIFTND_SPAN_PAD(false, 4) }
     }
 #undef SHIFTND_SPAN_PAD

@@ -2,6 +2,8 @@
 // normalisation and kernel-family selection.  No torch types, no allocation, no synchronisation.
 #include <string.h>
 
+#include <algorithm>
+
 #include "shiftnd_common.hpp"
 #include "shiftnd_launch.hpp"
 
@@ -74,6 +76,65 @@ bool cropped(const Geometry &g) {
         if (g.L[d] != 0 || g.O[d] != g.S[d]) return true;
     return false;
 }
+
+// ---------------------------------------------------------------------------------------------
+// The tuning knobs (shiftnd_set_tuning) live in thread-local arrays next to the kernels they shape; this file keeps a
+// thread-local shadow of every value so that a call can be planned under the DEFAULT knobs whatever the calling thread
+// has set: shiftnd_backward_workspace_bytes returns the larger of the default plan's and the calling thread's plan's
+// bytes, and a backward whose plan (under the calling thread's knobs) needs more than it was given runs under the
+// default plan instead -- sizing on one thread and running on another can never end in WORKSPACE_TOO_SMALL.
+// ---------------------------------------------------------------------------------------------
+constexpr int kKnobs = 40;
+constexpr int kKnobDefault[kKnobs] = {
+    0, 128 * 1024, 4, 2, 1, 0, 1, 0,   //  0..7   plane kernels (g_tune)
+    4, 512, 2, 256,                    //  8..11  sweep kernels
+    -1, 0, 16, 0,                      // 12..15  sliding-window kernels
+    1, 0, 0, 0,                        // 16..19  one-byte small-plane kernel
+    1, 0, 1,                           // 20..22  LDS-tiled channels-last kernels
+    0,                                 // 23      direct NDHWC backward
+    1, 0, 0,                           // 24..26  small-plane / row-band kernels
+    0,                                 // 27      flat-stream kernels
+    1, 0, 0, 0,                        // 28..31  one-byte row kernel (31 unused)
+    0, 0, 0, 0,                        // 32..35  one-step kernels
+    0, 0,                              // 36..37  quantized pool
+    0, 0};                             // 38      planes per workgroup of the walk kernels (39 unused)
+thread_local int g_knob[kKnobs] = {
+    0, 128 * 1024, 4, 2, 1, 0, 1, 0, 4, 512, 2, 256, -1, 0, 16, 0, 1, 0, 0, 0, 1, 0, 1, 0, 1, 0, 0, 0, 1, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+
+void apply_knob(int knob, int value) {
+    if (knob == 27) { g_flat = value; flat_set_tuning(value); }   // 27: the flat-stream kernels 0 automatic (ragged rows) / 1 never / 2 whenever eligible
+    else if (knob >= 38) step_set_tuning(4 + knob - 38, value);  // 38: planes per workgroup of the walk kernels
+    else if (knob >= 36) qpool_set_tuning(knob - 36, value);  // 36: quantized pool 0 automatic / 1 the element-per-thread kernel only
+    else if (knob >= 32) step_set_tuning(knob - 32, value);  // 32: one-step backward 0 automatic / 1 never / 2 whenever eligible
+    else if (knob >= 28) rows_set_tuning(knob - 28, value);  // 28: element sizes served (bit 0: 1 byte, bit 1: 2 bytes), 29: rows per band, 30: workgroups
+    else if (knob >= 24) small_set_tuning(knob - 24, value);  // 24: small-plane kernels on / off, 25: planes per round, 26: rounds per workgroup
+    else if (knob == 23) g_cl3 = value;
+    else if (knob >= 20) cl_tiled_set_tuning(knob - 20, value);  // 20: LDS-tiled channels-last forward on / off, 21: rows per band
+    else if (knob >= 16) bytes_set_tuning(knob - 16, value);  // 16: 1-byte small-plane kernel on / off, 17: planes per workgroup
+    else if (knob >= 12) slide_set_tuning(knob - 12, value);  // 12: which problems slide, 13: workgroups wanted, 14: min rows per band
+    else if (knob >= 8) sweep_set_tuning(knob - 8, value);  // 8/9: sweep forward K / max threads, 10/11: sweep backward
+    else plane_set_tuning(knob, value);
+}
+
+bool knobs_touched() {
+    for (int k = 0; k < kKnobs; ++k)
+        if (g_knob[k] != kKnobDefault[k]) return true;
+    return false;
+}
+
+// the default knobs for the lifetime of the object (this thread only), the thread's own back afterwards
+struct DefaultKnobs {
+    DefaultKnobs() {
+        for (int k = 0; k < kKnobs; ++k)
+            if (g_knob[k] != kKnobDefault[k]) apply_knob(k, kKnobDefault[k]);
+    }
+    ~DefaultKnobs() {
+        for (int k = 0; k < kKnobs; ++k)
+            if (g_knob[k] != kKnobDefault[k]) apply_knob(k, g_knob[k]);
+    }
+    DefaultKnobs(const DefaultKnobs &) = delete;
+    DefaultKnobs &operator=(const DefaultKnobs &) = delete;
+};
 
 bool empty_problem(const Geometry &g) {
     return g.N == 0 || g.C == 0 || g.S[0] * g.S[1] * g.S[2] == 0 || g.O[0] * g.O[1] * g.O[2] == 0;
@@ -215,18 +276,9 @@ int shiftnd_last_path(void) { return g_last_path; }
 void shiftnd_set_path_policy(int policy) { g_policy = policy; }
 
 void shiftnd_set_tuning(int knob, int value) {
-    if (knob == 27) { g_flat = value; flat_set_tuning(value); }   // 27: the flat-stream kernels 0 automatic (ragged rows) / 1 never / 2 whenever eligible
-    else if (knob >= 38) step_set_tuning(4 + knob - 38, value);  // 38: planes per workgroup of the walk kernels
-    else if (knob >= 36) qpool_set_tuning(knob - 36, value);  // 36: quantized pool 0 automatic / 1 the element-per-thread kernel only
-    else if (knob >= 32) step_set_tuning(knob - 32, value);  // 32: one-step backward 0 automatic / 1 never / 2 whenever eligible
-    else if (knob >= 28) rows_set_tuning(knob - 28, value);  // 28: element sizes served (bit 0: 1 byte, bit 1: 2 bytes), 29: rows per band, 30: workgroups
-    else if (knob >= 24) small_set_tuning(knob - 24, value);  // 24: small-plane kernels on / off, 25: planes per round, 26: rounds per workgroup
-    else if (knob == 23) g_cl3 = value;
-    else if (knob >= 20) cl_tiled_set_tuning(knob - 20, value);  // 20: LDS-tiled channels-last forward on / off, 21: rows per band
-    else if (knob >= 16) bytes_set_tuning(knob - 16, value);  // 16: 1-byte small-plane kernel on / off, 17: planes per workgroup
-    else if (knob >= 12) slide_set_tuning(knob - 12, value);  // 12: which problems slide, 13: workgroups wanted, 14: min rows per band
-    else if (knob >= 8) sweep_set_tuning(knob - 8, value);  // 8/9: sweep forward K / max threads, 10/11: sweep backward
-    else plane_set_tuning(knob, value);
+    if (knob < 0 || knob >= kKnobs) return;
+    g_knob[knob] = value;
+    apply_knob(knob, value);
 }
 
 int shiftnd_debug_map(int64_t p, int64_t shift, int64_t len, int padding_mode) {
@@ -324,32 +376,56 @@ int shiftnd_forward_quantized(const shiftnd_problem *p, const void *x, const int
     return forward_common(&q, x, x_strides, wq, wq_dtype, w_zero_point, fill, out, out_strides, stream);
 }
 
+// bytes of partial-sum records the backward families can need for this geometry under the calling thread's knobs
+static size_t backward_workspace_now(const Geometry &g, int dtype) {
+    size_t m = strided_backward_workspace(g);
+    m = std::max(m, plane_backward_workspace(g, dtype));
+    m = std::max(m, sweep_backward_workspace(g, dtype));
+    m = std::max(m, cl_backward_workspace(g));
+    m = std::max(m, cl_tiled_backward_workspace(g));
+    m = std::max(m, small_backward_workspace(g, dtype));
+    m = std::max(m, cl_tiled3_backward_workspace(g));
+    m = std::max(m, flat_backward_workspace(g));
+    return m;
+}
+
 size_t shiftnd_backward_workspace_bytes(const shiftnd_problem *p) {
     if (!p) return 0;
-    // the layout of the partial-sum buffer depends only on the geometry: evaluate both families' plans
+    // the layout of the partial-sum buffer depends only on the geometry: evaluate every family's plan
     const int64_t unit[5] = {0, 0, 0, 0, 0};
     Geometry g;
     if (build_geometry(p, unit, unit, unit, g) != SHIFTND_OK) return 0;
     if (g.N == 0 || g.C == 0 || g.S[0] * g.S[1] * g.S[2] == 0) return sizeof(double);
-    const size_t a = strided_backward_workspace(g);
-    const size_t b = plane_backward_workspace(g, p->dtype);
-    const size_t c = sweep_backward_workspace(g, p->dtype);
-    const size_t d = cl_backward_workspace(g);
-    const size_t e = cl_tiled_backward_workspace(g);
-    const size_t f = small_backward_workspace(g, p->dtype);
-    const size_t h = cl_tiled3_backward_workspace(g);
-    const size_t fl = flat_backward_workspace(g);
-    size_t m = a > b ? (a > c ? a : c) : (b > c ? b : c);
-    m = m > d ? m : d;
-    m = m > e ? m : e;
-    m = m > h ? m : h;
-    m = m > fl ? m : fl;
-    return m > f ? m : f;
+    size_t m = backward_workspace_now(g, p->dtype);
+    if (knobs_touched()) {   // ... and under the default knobs: what a run on any thread can fall back to
+        DefaultKnobs scope;
+        m = std::max(m, backward_workspace_now(g, p->dtype));
+    }
+    return m;
 }
+
+static int backward_planned(const shiftnd_problem *p, const void *grad_out, const int64_t grad_out_strides[5], const void *x,
+                            const int64_t x_strides[5], const void *weights, void *grad_x, const int64_t grad_x_strides[5],
+                            void *grad_w, void *workspace, size_t workspace_bytes, void *stream);
 
 int shiftnd_backward(const shiftnd_problem *p, const void *grad_out, const int64_t grad_out_strides[5], const void *x,
                      const int64_t x_strides[5], const void *weights, void *grad_x, const int64_t grad_x_strides[5],
                      void *grad_w, void *workspace, size_t workspace_bytes, void *stream) {
+    int rc = backward_planned(p, grad_out, grad_out_strides, x, x_strides, weights, grad_x, grad_x_strides, grad_w, workspace,
+                              workspace_bytes, stream);
+    if (rc == SHIFTND_ERR_WORKSPACE_TOO_SMALL && knobs_touched()) {
+        // (nothing was launched.)  This thread's knobs plan more partial records than the caller sized for -- e.g. sized on
+        // a thread with the default knobs: run the default plan, which shiftnd_backward_workspace_bytes always covers
+        DefaultKnobs scope;
+        rc = backward_planned(p, grad_out, grad_out_strides, x, x_strides, weights, grad_x, grad_x_strides, grad_w, workspace,
+                              workspace_bytes, stream);
+    }
+    return rc;
+}
+
+static int backward_planned(const shiftnd_problem *p, const void *grad_out, const int64_t grad_out_strides[5], const void *x,
+                            const int64_t x_strides[5], const void *weights, void *grad_x, const int64_t grad_x_strides[5],
+                            void *grad_w, void *workspace, size_t workspace_bytes, void *stream) {
     if (!p || !grad_out_strides || !x_strides || !grad_x_strides) return SHIFTND_ERR_INVALID_ARGUMENT;
     if (!is_float_dtype(p->dtype)) return SHIFTND_ERR_UNSUPPORTED_DTYPE;
     Geometry g;
@@ -468,7 +544,12 @@ size_t shiftnd_backward_pooled_workspace_bytes(const shiftnd_problem *p, const i
     Geometry g;
     if (pooled_geometry(p, pool, g) != SHIFTND_OK) return 0;
     if (g.N == 0 || g.C == 0 || g.S[0] * g.S[1] * g.S[2] == 0) return sizeof(double);
-    return plane_backward_workspace(g, p->dtype);
+    size_t m = plane_backward_workspace(g, p->dtype);
+    if (knobs_touched()) {   // (as shiftnd_backward_workspace_bytes)
+        DefaultKnobs scope;
+        m = std::max(m, plane_backward_workspace(g, p->dtype));
+    }
+    return m;
 }
 
 int shiftnd_pooled_sizes(const shiftnd_problem *p, const int32_t *pool, int64_t pooled_spatial[3]) {
@@ -526,9 +607,24 @@ int shiftnd_forward_quantized_pooled(const shiftnd_problem *p, const int32_t *po
     return finish(qpool_forward(g, p->dtype, x, wq, wq_dtype, w_zero_point, x_zero_point, requant, out, static_cast<hipStream_t>(stream)));
 }
 
+static int backward_pooled_planned(const shiftnd_problem *p, const int32_t *pool, const void *grad_pooled, const void *x,
+                                   const void *weights, void *grad_x, void *grad_w, void *workspace, size_t workspace_bytes,
+                                   void *stream);
+
 int shiftnd_backward_pooled(const shiftnd_problem *p, const int32_t *pool, const void *grad_pooled, const void *x,
                             const void *weights, void *grad_x, void *grad_w, void *workspace, size_t workspace_bytes,
                             void *stream) {
+    int rc = backward_pooled_planned(p, pool, grad_pooled, x, weights, grad_x, grad_w, workspace, workspace_bytes, stream);
+    if (rc == SHIFTND_ERR_WORKSPACE_TOO_SMALL && knobs_touched()) {   // (as shiftnd_backward)
+        DefaultKnobs scope;
+        rc = backward_pooled_planned(p, pool, grad_pooled, x, weights, grad_x, grad_w, workspace, workspace_bytes, stream);
+    }
+    return rc;
+}
+
+static int backward_pooled_planned(const shiftnd_problem *p, const int32_t *pool, const void *grad_pooled, const void *x,
+                                   const void *weights, void *grad_x, void *grad_w, void *workspace, size_t workspace_bytes,
+                                   void *stream) {
     Geometry g;
     const int rc = pooled_geometry(p, pool, g);
     if (rc != SHIFTND_OK) return rc;

@@ -420,8 +420,7 @@ static int launch_cl_backward(const ClParams &p, const Geometry &g, const ClPlan
     }
 #undef SHIFTND_CL_BWD
     const int cn = p.C * p.nd;
-    hipLaunchKernelGGL((reduce_weight_grads<T>), dim3(cn), dim3(64), 0, st, p.partials, pl.pgroups, p.C, p.nd,
-                       static_cast<typename T::S *>(gw));
+    reduce_weight_grads_of<T>(p.partials, pl.pgroups, p.C, p.nd, gw, st);
     return SHIFTND_OK;
 }
 

@@ -1424,8 +1424,7 @@ void launch_cl_tiled_backward(const ClTiledBwdParams &p, const ClTiledBwdPlan &p
         if (active) hipLaunchKernelGGL((cl_tiled_backward<T, true, false>), grid, block, 0, st, p);
         else hipLaunchKernelGGL((cl_tiled_backward<T, false, false>), grid, block, 0, st, p);
     }
-    hipLaunchKernelGGL((reduce_weight_grads<T>), dim3(p.C * 2), dim3(64), 0, st, p.partials, static_cast<int>(pl.groups), p.C, 2,
-                       static_cast<typename T::S *>(gw));
+    reduce_weight_grads_of<T>(p.partials, static_cast<int>(pl.groups), p.C, 2, gw, st);
 }
 }  // namespace
 

@@ -644,8 +644,7 @@ void launch3(const ClTiled3Params &p, const Plan3 &pl, bool active, void *gw, hi
         if (active) hipLaunchKernelGGL((cl_tiled_backward_3d<T, true, false>), grid, block, 0, st, p);
         else hipLaunchKernelGGL((cl_tiled_backward_3d<T, false, false>), grid, block, 0, st, p);
     }
-    hipLaunchKernelGGL((reduce_weight_grads<T>), dim3(p.C * 3), dim3(64), 0, st, p.partials, static_cast<int>(pl.groups), p.C, 3,
-                       static_cast<typename T::S *>(gw));
+    reduce_weight_grads_of<T>(p.partials, static_cast<int>(pl.groups), p.C, 3, gw, st);
 }
 }  // namespace
 

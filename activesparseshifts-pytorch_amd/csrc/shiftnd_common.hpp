@@ -344,26 +344,13 @@ __device__ __forceinline__ double block_sum(double v, double *scratch) {
 }
 
 // Final stage of the weight-gradient reduction: grad_w[c, s] = sum over partial groups.
-// partials layout: [group][C][3] doubles.  (Unnamed namespace: one private copy per translation unit.)
-namespace {
+// partials layout: [group][C][3] doubles.  One copy of the kernels in the library (shiftnd_strided.hip defines them and this
+// launcher); T::kDtype selects the output type.
+void launch_reduce_weight_grads(int dtype, const double *partials, int groups, int C, int nd, void *grad_w, hipStream_t st);
 template <typename T>
-__global__ __launch_bounds__(64) void reduce_weight_grads(const double *__restrict__ partials, int groups, int C, int nd,
-                                                           typename T::S *__restrict__ grad_w) {
-    // one wave per output element: lanes stride over the groups (fixed order), then a fixed shuffle tree
-    const int t = blockIdx.x;
-    const int c = t / nd, s = t - c * nd;
-    double acc = 0.0;
-    for (int g = threadIdx.x; g < groups; g += 64) acc += partials[(static_cast<size_t>(g) * C + c) * 3 + s];
-    acc = wave_sum(acc);
-    if (threadIdx.x == 0) {
-        if constexpr (sizeof(typename T::S) == 8) {
-            grad_w[t] = acc;
-        } else {
-            grad_w[t] = narrow<T>(static_cast<float>(acc));
-        }
-    }
+inline void reduce_weight_grads_of(const double *partials, int groups, int C, int nd, void *grad_w, hipStream_t st) {
+    launch_reduce_weight_grads(T::kDtype, partials, groups, C, nd, grad_w, st);
 }
-}  // namespace
 
 // ---------------------------------------------------------------------------------------------
 // buffer_store_dwordx4 with the row / plane offset in an SGPR (soffset).  gfx950 reads the 128 bits of store data over more than

@@ -79,6 +79,26 @@ template <typename CT> __device__ __forceinline__ int canon_rt(CT r, int len, in
     return canon_shift(static_cast<int64_t>(r), len, pad, dper);
 }
 
+// fold_index for PAD = kPadRT (shiftnd_step.hpp): the wrapping paddings 2 .. 4 through ONE instantiation, the mode a kernel argument;
+// both folds are (idx ^ m) + c with launch-uniform m (0 periodic, -1 reflect / symmetric) and c (shiftnd_step.hpp fold_index_rt
+// without the border mode, which keeps its own instantiation here: it clamps into the staged rows)
+struct FoldRT { int m, cn, ch; };
+__device__ __forceinline__ FoldRT fold_coeffs(int len, int pad) {
+    FoldRT f;
+    f.m = pad >= 3 ? -1 : 0;
+    f.cn = pad == 2 ? len : (pad == 3 ? 1 : 0);
+    f.ch = pad == 2 ? -len : (pad == 3 ? 2 * (len - 1) + 1 : 2 * len);
+    return f;
+}
+template <int PAD> __device__ __forceinline__ int fold_t(int idx, int len, const FoldRT &f) {
+    if constexpr (PAD == kPadRT) {
+        const int t = idx < 0 ? (idx ^ f.m) + f.cn : idx;
+        return t > len - 1 ? (t ^ f.m) + f.ch : t;
+    } else {
+        return fold_index(idx, len, PAD);
+    }
+}
+
 __device__ __forceinline__ int imap(int p, int cs, int len, int pad) { return len == 1 ? 0 : fold_index(p - cs, len, pad); }
 
 // one plane's parameters as the element loop reads them
@@ -157,8 +177,9 @@ __device__ __forceinline__ void clamp_rows(int a, int b, int len, bool zeros, in
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
-// flat_forward<T, ACTIVE, PAD, SMALL>: the padding mode is a template parameter (every element folds its coordinates: with a run-time
-// mode the reflecting paddings ran at half the zeros padding's rate); SMALL = the whole source planes of a step are staged.
+// flat_forward<T, ACTIVE, PAD, SMALL>: PAD = 0 zeros, 1 border, kPadRT = the three wrapping modes with the mode a kernel argument and
+// a branch-free fold (every element folds its coordinates: through a run-time `switch` the reflecting paddings ran at half the zeros
+// padding's rate); SMALL = the whole source planes of a step are staged.
 // LDS: [plane table][cover of x]
 // ---------------------------------------------------------------------------------------------------------------------
 template <typename T, bool ACTIVE, int PAD, bool SMALL>
@@ -179,7 +200,10 @@ __global__ __launch_bounds__(kThreads) void flat_forward(const FlatParams p) {
     if (bid >= p.total_steps) return;
     const int tid = static_cast<int>(threadIdx.x);
     const int S1 = p.S1, S2 = p.S2, O1 = p.O1, O2 = p.O2, L1 = p.L1, L2 = p.L2;
-    constexpr int pad = PAD;
+    const int pad = PAD == kPadRT ? p.pad : PAD;
+    const FoldRT fS1 = fold_coeffs(S1, pad), fS2 = fold_coeffs(S2, pad);
+    (void)fS1;
+    (void)fS2;
     const uint32_t f0 = bid * static_cast<uint32_t>(kThreads * E);                                  // first element of the step
     const uint32_t f1 = min(p.total, f0 + static_cast<uint32_t>(kThreads * E)) - 1u;                // ... and its last
     const uint32_t plA = fdiv(f0, p.d_SP), plB = fdiv(f1, p.d_SP);
@@ -296,11 +320,11 @@ __global__ __launch_bounds__(kThreads) void flat_forward(const FlatParams p) {
             };
             // (SIMPLE on large planes: the chunk's rows lie inside the plane unfolded)
             constexpr bool ROWS_IN = SIMPLE && !SMALL && PAD >= 2;
-            const int ar = S1 == 1 ? 0 : (ROWS_IN ? a : fold_index(a, S1, PAD)), bc = S2 == 1 ? 0 : fold_index(b, S2, PAD);
+            const int ar = S1 == 1 ? 0 : (ROWS_IN ? a : fold_t<PAD>(a, S1, fS1)), bc = S2 == 1 ? 0 : fold_t<PAD>(b, S2, fS2);
             if constexpr (!ACTIVE) {
                 res.e[e] = tap(ar, bc);
             } else {
-                const int ar1 = S1 == 1 ? 0 : (ROWS_IN ? a + 1 : fold_index(a + 1, S1, PAD)), bc1 = S2 == 1 ? 0 : fold_index(b + 1, S2, PAD);
+                const int ar1 = S1 == 1 ? 0 : (ROWS_IN ? a + 1 : fold_t<PAD>(a + 1, S1, fS1)), bc1 = S2 == 1 ? 0 : fold_t<PAD>(b + 1, S2, fS2);
                 const CT fr[2] = {first ? D0.f1 : D1.f1, first ? D0.f2 : D1.f2};
                 if (one_d) {
                     const CT v[2] = {widen<T>(tap(ar, bc)), widen<T>(tap(ar, bc1))};
@@ -379,6 +403,8 @@ __global__ __launch_bounds__(kThreads) void flat_backward(const FlatParams p, in
     if (bid >= p.total_steps) return;
     const int tid = static_cast<int>(threadIdx.x);
     const int S1 = p.S1, S2 = p.S2, O1 = p.O1, O2 = p.O2, L1 = p.L1, L2 = p.L2;
+    const FoldRT fS1 = fold_coeffs(S1, p.pad), fS2 = fold_coeffs(S2, p.pad), fO1 = fold_coeffs(O1, p.pad), fO2 = fold_coeffs(O2, p.pad);
+    (void)fS1; (void)fS2; (void)fO1; (void)fO2;
     const uint32_t f0 = bid * static_cast<uint32_t>(kThreads * E);
     const uint32_t f1 = min(p.total, f0 + static_cast<uint32_t>(kThreads * E)) - 1u;
     const uint32_t plA = fdiv(f0, p.d_SP), plB = fdiv(f1, p.d_SP);
@@ -513,8 +539,8 @@ __global__ __launch_bounds__(kThreads) void flat_backward(const FlatParams p, in
                     }
                 };
                 constexpr bool ROWS_IN = SIMPLE && !SMALL && PAD >= 2;   // (the chunk's rows lie inside the plane / the window unfolded)
-                const int ar = S1 == 1 ? 0 : (ROWS_IN ? a : fold_index(a, S1, PAD)), ar1 = S1 == 1 ? 0 : (ROWS_IN ? a + 1 : fold_index(a + 1, S1, PAD));
-                const int bc = S2 == 1 ? 0 : fold_index(b, S2, PAD), bc1 = S2 == 1 ? 0 : fold_index(b + 1, S2, PAD);
+                const int ar = S1 == 1 ? 0 : (ROWS_IN ? a : fold_t<PAD>(a, S1, fS1)), ar1 = S1 == 1 ? 0 : (ROWS_IN ? a + 1 : fold_t<PAD>(a + 1, S1, fS1));
+                const int bc = S2 == 1 ? 0 : fold_t<PAD>(b, S2, fS2), bc1 = S2 == 1 ? 0 : fold_t<PAD>(b + 1, S2, fS2);
                 v0 = xtap(ar, bc);
                 v1 = xtap(ar1, bc);
                 v2 = xtap(ar, bc1);
@@ -567,11 +593,11 @@ __global__ __launch_bounds__(kThreads) void flat_backward(const FlatParams p, in
                     }
                 };
                 constexpr bool GROWS_IN = SIMPLE && !SMALL && PAD >= 2;
-                const int ar = O1 == 1 ? 0 : (GROWS_IN ? ga : fold_index(ga, O1, PAD)), bc = O2 == 1 ? 0 : fold_index(gbc, O2, PAD);
+                const int ar = O1 == 1 ? 0 : (GROWS_IN ? ga : fold_t<PAD>(ga, O1, fO1)), bc = O2 == 1 ? 0 : fold_t<PAD>(gbc, O2, fO2);
                 if constexpr (!ACTIVE) {
                     res.e[e] = gtap(ar, bc);
                 } else {
-                    const int ar1 = O1 == 1 ? 0 : (GROWS_IN ? ga + 1 : fold_index(ga + 1, O1, PAD)), bc1 = O2 == 1 ? 0 : fold_index(gbc + 1, O2, PAD);
+                    const int ar1 = O1 == 1 ? 0 : (GROWS_IN ? ga + 1 : fold_t<PAD>(ga + 1, O1, fO1)), bc1 = O2 == 1 ? 0 : fold_t<PAD>(gbc + 1, O2, fO2);
                     const CT fr[2] = {first ? D0.f1 : D1.f1, first ? D0.f2 : D1.f2};
                     S rv;
                     if (one_d) {
@@ -758,9 +784,7 @@ void launch_flat_forward(const FlatParams &p, size_t lds, int pad, hipStream_t s
     switch (pad) {
     case 0: hipLaunchKernelGGL((flat_forward<T, ACTIVE, 0, SMALL>), grid, block, lds, st, p); break;
     case 1: hipLaunchKernelGGL((flat_forward<T, ACTIVE, 1, SMALL>), grid, block, lds, st, p); break;
-    case 2: hipLaunchKernelGGL((flat_forward<T, ACTIVE, 2, SMALL>), grid, block, lds, st, p); break;
-    case 3: hipLaunchKernelGGL((flat_forward<T, ACTIVE, 3, SMALL>), grid, block, lds, st, p); break;
-    default: hipLaunchKernelGGL((flat_forward<T, ACTIVE, 4, SMALL>), grid, block, lds, st, p); break;
+    default: hipLaunchKernelGGL((flat_forward<T, ACTIVE, kPadRT, SMALL>), grid, block, lds, st, p); break;   // periodic / reflect / symmetric: one instantiation, p.pad
     }
 }
 
@@ -770,9 +794,7 @@ void launch_flat_backward(const FlatParams &p, const FlatPlan &pl, int pad, int 
     switch (pad) {
     case 0: hipLaunchKernelGGL((flat_backward<T, ACTIVE, 0, SMALL>), grid, block, pl.lds, st, p, pl.gcov_off); break;
     case 1: hipLaunchKernelGGL((flat_backward<T, ACTIVE, 1, SMALL>), grid, block, pl.lds, st, p, pl.gcov_off); break;
-    case 2: hipLaunchKernelGGL((flat_backward<T, ACTIVE, 2, SMALL>), grid, block, pl.lds, st, p, pl.gcov_off); break;
-    case 3: hipLaunchKernelGGL((flat_backward<T, ACTIVE, 3, SMALL>), grid, block, pl.lds, st, p, pl.gcov_off); break;
-    default: hipLaunchKernelGGL((flat_backward<T, ACTIVE, 4, SMALL>), grid, block, pl.lds, st, p, pl.gcov_off); break;
+    default: hipLaunchKernelGGL((flat_backward<T, ACTIVE, kPadRT, SMALL>), grid, block, pl.lds, st, p, pl.gcov_off); break;   // periodic / reflect / symmetric: one instantiation, p.pad
     }
     hipLaunchKernelGGL((flat_reduce<T>), dim3(p.C), dim3(64), 0, st, p, N, ACTIVE ? 1 : 0, static_cast<typename T::S *>(gw));
 }

@@ -1544,44 +1544,34 @@ int launch_active_forward(const PlaneParams &p_in, const Plan &pl, hipStream_t s
 template <typename T, bool ACTIVE>
 void launch_backward_a(const PlaneParams &p_in, const Plan &pl, hipStream_t st) {
     PlaneParams p = p_in;
-    if ((g_tune[3] == 2 || g_tune[3] == 3) && p.nd >= 2) {  // LDS-staged form where it applies
+    // LDS-staged form where it applies: 3-D volumes (what the walk through the planes does not take -- fp64, rows wider than
+    // half a workgroup pass, one-row planes ...).  The 2-D forms are no longer built: every dense un-cropped 2-D problem with
+    // rows of at most 256 pieces is step_backward's (tools/route_census.py found no default-routed shape for them).
+    if ((g_tune[3] == 2 || g_tune[3] == 3) && p.nd == 3) {
         size_t lds_bytes = 0;
         int tile_bytes = 0;
-        // 2-D sparse shift: the scatter form (knob 3 = 3 keeps the gather form, with its GS slots)
-        constexpr bool kCanScat = !ACTIVE;
-        const bool scat = kCanScat && p.nd == 2 && g_tune[3] == 2;
-        const int slots = p.nd == 3 ? LdsTileShape<3, ACTIVE, true>::slots(pl.RPS)
-                                    : (scat ? LdsTileShape<2, ACTIVE, true, kCanScat>::slots(pl.RPS) : LdsTileShape<2, ACTIVE, true>::slots(pl.RPS));
+        const int slots = LdsTileShape<3, ACTIVE, true>::slots(pl.RPS);
         if (lds_staged_ok(p, pl, static_cast<int>(sizeof(typename T::S)), slots, &lds_bytes, &tile_bytes)) {
             p.tile_bytes = tile_bytes;
             note_kernel("plane_backward_lds");
-            // two LDS tiles / one barrier per step pay when registers, not LDS, bound the resident workgroups:
-            // 16-bit dtypes by default (C5 backward 2.46 -> 2.21 ms; fp32 C2 1.84 -> 1.96 ms), knob 4 = 2 / 3 forces on / off
-            const bool want_two = g_tune[4] == 2 || (g_tune[4] != 3 && sizeof(typename T::S) == 2);
-            const bool two = want_two && lds_bytes + tile_bytes + slots * sizeof(int) <= 64 * 1024;
+            // two LDS tiles / one barrier per step pay when registers, not LDS, bound the resident workgroups: 16-bit dtypes
+            // (C5 backward 2.46 -> 2.21 ms; fp32 C2 1.84 -> 1.96 ms: 4- / 8-byte elements keep one tile, and only that form
+            // is built for them); knob 4 = 3 forces one tile for 16-bit data too
+            constexpr bool kTwoTiles = sizeof(typename T::S) == 2;
+            const bool two = kTwoTiles && g_tune[4] != 3 && lds_bytes + tile_bytes + slots * sizeof(int) <= 64 * 1024;
             const size_t lds2 = lds_bytes + tile_bytes + slots * sizeof(int);
             // few pieces per thread and step: the pre-decoded DMA form (knob 5 = 2 keeps the generic loop)
-            const bool dec = g_tune[5] != 2 && (p.nd == 3 ? LdsStager<T, 3, ACTIVE, true>::pieces_fit(pl.cpr, pl.RPS)
-                                                  : (scat ? LdsStager<T, 2, ACTIVE, true, false, kCanScat>::pieces_fit(pl.cpr, pl.RPS)
-                                                          : LdsStager<T, 2, ACTIVE, true>::pieces_fit(pl.cpr, pl.RPS)));
-#define SHIFTND_BWD_LDS(NDV, TL, DECV, BYTES) \
-    hipLaunchKernelGGL((plane_backward_lds<T, NDV, ACTIVE, TL, false, DECV>), dim3(pl.grid), dim3(kThreads), BYTES, st, p)
-#define SHIFTND_BWD_SCAT(TL, DECV, BYTES) \
-    hipLaunchKernelGGL((plane_backward_lds<T, 2, ACTIVE, TL, false, DECV, kCanScat>), dim3(pl.grid), dim3(kThreads), BYTES, st, p)
-            if (scat) {
-                if (two) { if (dec) SHIFTND_BWD_SCAT(2, true, lds2); else SHIFTND_BWD_SCAT(2, false, lds2); }
-                else { if (dec) SHIFTND_BWD_SCAT(1, true, lds_bytes); else SHIFTND_BWD_SCAT(1, false, lds_bytes); }
-                return;
+            const bool dec = g_tune[5] != 2 && LdsStager<T, 3, ACTIVE, true>::pieces_fit(pl.cpr, pl.RPS);
+#define SHIFTND_BWD_LDS(TL, DECV, BYTES) \
+    hipLaunchKernelGGL((plane_backward_lds<T, 3, ACTIVE, TL, false, DECV>), dim3(pl.grid), dim3(kThreads), BYTES, st, p)
+            if constexpr (kTwoTiles) {
+                if (two) {
+                    if (dec) SHIFTND_BWD_LDS(2, true, lds2); else SHIFTND_BWD_LDS(2, false, lds2);
+                    return;
+                }
             }
-            if (p.nd == 3) {
-                if (two) { if (dec) SHIFTND_BWD_LDS(3, 2, true, lds2); else SHIFTND_BWD_LDS(3, 2, false, lds2); }
-                else { if (dec) SHIFTND_BWD_LDS(3, 1, true, lds_bytes); else SHIFTND_BWD_LDS(3, 1, false, lds_bytes); }
-            } else {
-                if (two) { if (dec) SHIFTND_BWD_LDS(2, 2, true, lds2); else SHIFTND_BWD_LDS(2, 2, false, lds2); }
-                else { if (dec) SHIFTND_BWD_LDS(2, 1, true, lds_bytes); else SHIFTND_BWD_LDS(2, 1, false, lds_bytes); }
-            }
+            if (dec) SHIFTND_BWD_LDS(1, true, lds_bytes); else SHIFTND_BWD_LDS(1, false, lds_bytes);
 #undef SHIFTND_BWD_LDS
-#undef SHIFTND_BWD_SCAT
             return;
         }
     }
@@ -1596,7 +1586,11 @@ void launch_backward_a(const PlaneParams &p_in, const Plan &pl, hipStream_t st) 
 template <typename T, bool ACTIVE>
 void launch_backward_pool(const PlaneParams &p_in, const Plan &pl, hipStream_t st) {
     PlaneParams p = p_in;
-    if (g_tune[3] == 2 && p.nd >= 2) {  // LDS-staged form where it applies (pooled rows are expanded into the tile)
+    // LDS-staged form where it applies (pooled rows are expanded into the tile).  The 3-D interpolating form is not built:
+    // shiftnd_backward_pooled hands those volumes to the walk or reports SHIFTND_ERR_NOT_FUSED (measured slower than
+    // avg_pool backward + shiftnd_backward)
+    constexpr bool k3d = !ACTIVE;
+    if (g_tune[3] == 2 && (p.nd == 2 || (p.nd == 3 && k3d))) {
         size_t lds_bytes = 0;
         int tile_bytes = 0;
         const int slots = p.nd == 3 ? LdsTileShape<3, ACTIVE, true>::slots(pl.RPS) : LdsTileShape<2, ACTIVE, true>::slots(pl.RPS);
@@ -1604,26 +1598,29 @@ void launch_backward_pool(const PlaneParams &p_in, const Plan &pl, hipStream_t s
             p.tile_bytes = tile_bytes;
             note_kernel("plane_backward_lds_pool");
             lds_bytes += 3 * slots * sizeof(int);  // the second set of slot tables (window counts)
-            const bool want_two = g_tune[4] == 2 || (g_tune[4] != 3 && sizeof(typename T::S) == 2);
-            const bool two = want_two && lds_bytes + tile_bytes + slots * sizeof(int) <= 64 * 1024;
+            // tiles as in launch_backward_a: two for 16-bit data when they fit, one for 4- / 8-byte elements
+            constexpr bool kTwoTiles = sizeof(typename T::S) == 2;
+            const bool two = kTwoTiles && g_tune[4] != 3 && lds_bytes + tile_bytes + slots * sizeof(int) <= 64 * 1024;
+            const size_t bytes = two ? lds_bytes + tile_bytes + slots * sizeof(int) : lds_bytes;
             // windows of 2 along the row and few pieces per thread: the pre-decoded form (default tile count only)
-            constexpr int kDefTiles = sizeof(typename T::S) == 2 ? 2 : 1;
-            const bool dec = g_tune[5] != 2 && p.K[2] == 2 && two == (kDefTiles == 2) &&
+            constexpr int kDefTiles = kTwoTiles ? 2 : 1;
+            const bool dec = g_tune[5] != 2 && p.K[2] == 2 && two == kTwoTiles &&
                              (p.nd == 3 ? LdsStager<T, 3, ACTIVE, true, true>::pieces_fit(pl.cpr, pl.RPS)
                                         : LdsStager<T, 2, ACTIVE, true, true>::pieces_fit(pl.cpr, pl.RPS));
-            if (dec) {
-                const size_t bytes = two ? lds_bytes + tile_bytes + slots * sizeof(int) : lds_bytes;
-                if (p.nd == 3) hipLaunchKernelGGL((plane_backward_lds<T, 3, ACTIVE, kDefTiles, true, true>), dim3(pl.grid), dim3(kThreads), bytes, st, p);
-                else hipLaunchKernelGGL((plane_backward_lds<T, 2, ACTIVE, kDefTiles, true, true>), dim3(pl.grid), dim3(kThreads), bytes, st, p);
-                return;
-            }
+#define SHIFTND_BWD_POOL(NDV, TL, DECV) \
+    hipLaunchKernelGGL((plane_backward_lds<T, NDV, ACTIVE, TL, true, DECV>), dim3(pl.grid), dim3(kThreads), bytes, st, p)
             if (p.nd == 3) {
-                if (two) hipLaunchKernelGGL((plane_backward_lds<T, 3, ACTIVE, 2, true>), dim3(pl.grid), dim3(kThreads), lds_bytes + tile_bytes + slots * sizeof(int), st, p);
-                else hipLaunchKernelGGL((plane_backward_lds<T, 3, ACTIVE, 1, true>), dim3(pl.grid), dim3(kThreads), lds_bytes, st, p);
+                if constexpr (k3d) {
+                    if (dec) SHIFTND_BWD_POOL(3, kDefTiles, true);
+                    else if (two) SHIFTND_BWD_POOL(3, kDefTiles, false);
+                    else SHIFTND_BWD_POOL(3, 1, false);
+                }
             } else {
-                if (two) hipLaunchKernelGGL((plane_backward_lds<T, 2, ACTIVE, 2, true>), dim3(pl.grid), dim3(kThreads), lds_bytes + tile_bytes + slots * sizeof(int), st, p);
-                else hipLaunchKernelGGL((plane_backward_lds<T, 2, ACTIVE, 1, true>), dim3(pl.grid), dim3(kThreads), lds_bytes, st, p);
+                if (dec) SHIFTND_BWD_POOL(2, kDefTiles, true);
+                else if (two) SHIFTND_BWD_POOL(2, kDefTiles, false);
+                else SHIFTND_BWD_POOL(2, 1, false);
             }
+#undef SHIFTND_BWD_POOL
             return;
         }
     }
@@ -1661,8 +1658,7 @@ int launch_backward(const PlaneParams &p, const Plan &pl, bool active, void *gw,
     } else if (active) launch_backward_a<T, true>(p, pl, st);
     else launch_backward_a<T, false>(p, pl, st);
     const int cn = p.C * p.nd;
-    hipLaunchKernelGGL((reduce_weight_grads<T>), dim3(cn), dim3(64), 0, st, p.partials, pl.groups * pl.bands, p.C, p.nd,
-                       static_cast<typename T::S *>(gw));
+    reduce_weight_grads_of<T>(p.partials, pl.groups * pl.bands, p.C, p.nd, gw, st);
     return SHIFTND_OK;
 }
 

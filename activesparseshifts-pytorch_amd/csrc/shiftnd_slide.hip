@@ -834,8 +834,7 @@ int slide_backward(const Geometry &g, int dtype, const void *go, const void *x, 
     { \
         if (g.active) launch_slide_backward<TT, true>(p, pl, st); \
         else launch_slide_backward<TT, false>(p, pl, st); \
-        hipLaunchKernelGGL((reduce_weight_grads<TT>), dim3(cn), dim3(64), 0, st, p.partials, groups, p.C, p.nd, \
-                           static_cast<typename TT::S *>(gw)); \
+        reduce_weight_grads_of<TT>(p.partials, groups, p.C, p.nd, gw, st); \
     }
     switch (dtype) {
     case SHIFTND_F32: SHIFTND_SLIDE_BWD(f32_t) break;

@@ -649,15 +649,13 @@ size_t small_backward_workspace(const Geometry &g, int dtype) {
 template <typename T>
 static void band_backward_t(const BandParams &p, const BandPlan &pl, bool active, void *gw, hipStream_t st) {
     launch_band<T, true>(p, pl, active, st);
-    hipLaunchKernelGGL((reduce_weight_grads<T>), dim3(p.C * p.nd), dim3(64), 0, st, p.partials, pl.groups, p.C, p.nd,
-                       static_cast<typename T::S *>(gw));
+    reduce_weight_grads_of<T>(p.partials, pl.groups, p.C, p.nd, gw, st);
 }
 
 template <typename T>
 static void small_backward_t(const SmallParams &p, const SmallPlan &pl, bool active, void *gw, hipStream_t st) {
     launch_small<T, true>(p, pl, active, st);
-    hipLaunchKernelGGL((reduce_weight_grads<T>), dim3(p.C * p.nd), dim3(64), 0, st, p.partials, pl.groups, p.C, p.nd,
-                       static_cast<typename T::S *>(gw));
+    reduce_weight_grads_of<T>(p.partials, pl.groups, p.C, p.nd, gw, st);
 }
 
 int small_backward(const Geometry &g, int dtype, const void *go, const void *x, const void *w, void *gx, void *gw,

@@ -225,11 +225,11 @@ __global__ __launch_bounds__(kThreads) void crop_backward(const SpanParams p) {
     auto xrow_lo = [&](int row) { return xph + row * S2 * ES; };
     if constexpr (!XRAG) {
         if (tr < R) {
-            const int sx = tr <= Rn ? row_map_t<PAD>(b0 + tr, d.cx1, S1) : -1;
+            const int sx = tr <= Rn ? row_map_t<PAD>(b0 + tr, d.cx1, S1, p.pad) : -1;
             if (sx >= 0) dma_x(sx, tc, 0);
         }
         if (Rn == R && tid < cpr) {
-            const int sx = row_map_t<PAD>(b0 + R, d.cx1, S1);
+            const int sx = row_map_t<PAD>(b0 + R, d.cx1, S1, p.pad);
             if (sx >= 0) dma_x(sx, tid, R * cpr);
         }
     }
@@ -251,7 +251,7 @@ __global__ __launch_bounds__(kThreads) void crop_backward(const SpanParams p) {
     auto gs_row = [&](int i, bool have) {   // the row grad_x reads at step row i (window coordinates through the row map)
         const int pr = b0 + i - L1;
         const bool dom = have && pr >= 0 && (ACTIVE ? pr <= O1 : pr < O1);
-        return dom ? row_map_t<PAD>(pr, d.cg1, O1) : -1;
+        return dom ? row_map_t<PAD>(pr, d.cg1, O1, p.pad) : -1;
     };
     if constexpr (XRAG) {   // the x corner rows as covers: thread t moves piece t mod (cpr + 2) of row t div (cpr + 2); the first threads the + 1 row
         const char *xp16 = reinterpret_cast<const char *>(xp) - xph;
@@ -263,8 +263,8 @@ __global__ __launch_bounds__(kThreads) void crop_backward(const SpanParams p) {
                                                  (__attribute__((address_space(3))) void *)dst_wave, 16, 0, 0);
             }
         };
-        dma_xc((rg < R && rg <= Rn) ? row_map_t<PAD>(b0 + rg, d.cx1, S1) : -1, pg, 0);
-        if (Rn == R && tid < PGi) dma_xc(row_map_t<PAD>(b0 + R, d.cx1, S1), tid, R * PGi);
+        dma_xc((rg < R && rg <= Rn) ? row_map_t<PAD>(b0 + rg, d.cx1, S1, p.pad) : -1, pg, 0);
+        if (Rn == R && tid < PGi) dma_xc(row_map_t<PAD>(b0 + R, d.cx1, S1, p.pad), tid, R * PGi);
     }
     {
         const int ro = (rg < R && rg < Rn && b0 + rg - L1 >= 0 && b0 + rg - L1 < O1) ? b0 + rg - L1 : -1;   // the step's own rows
@@ -307,7 +307,7 @@ __global__ __launch_bounds__(kThreads) void crop_backward(const SpanParams p) {
         const int b = b0 + tr;
         const CT dw[3] = {static_cast<CT>(d.dw[0]), static_cast<CT>(d.dw[1]), CT(0)};
         const bool in_row = b >= L1 && b < L1 + O1;
-        auto row_valid = [&](int pr, int cs, int len) { return PAD != 0 || row_map_t<PAD>(pr, cs, len) >= 0; };
+        auto row_valid = [&](int pr, int cs, int len) { return PAD != 0 || row_map_t<PAD>(pr, cs, len, p.pad) >= 0; };
         const S zero = static_cast<S>(0.0f);
         // zeros padding: every column state is affine (the host keeps windows one column wide, whose gradient map is not, away
         // from this kernel) -- the reader without branches
@@ -326,7 +326,7 @@ __global__ __launch_bounds__(kThreads) void crop_backward(const SpanParams p) {
             for (int hb = 0; hb < 2; ++hb) {
                 const int pr = b - L1 + hb;
                 const bool dom = in_row && pr <= O1;
-                const int srow = dom ? row_map_t<PAD>(pr, d.cg1, O1) : -1;
+                const int srow = dom ? row_map_t<PAD>(pr, d.cg1, O1, p.pad) : -1;
                 S raw[E + 1];
                 read_row(tile + gsoff + (tr + hb) * RBG + (row_lo(srow) & 15), srow >= 0, gm, raw);
 #pragma unroll
@@ -338,7 +338,7 @@ __global__ __launch_bounds__(kThreads) void crop_backward(const SpanParams p) {
                 res.e[e] = inside[e] ? narrow<T>(interp_t<T, 2>(v, dw)) : zero;
             }
         } else {
-            const int srow = in_row ? row_map_t<PAD>(b - L1, d.cg1, O1) : -1;
+            const int srow = in_row ? row_map_t<PAD>(b - L1, d.cg1, O1, p.pad) : -1;
             S raw[E + 1];
             read_row(tile + gsoff + tr * RBG + (row_lo(srow) & 15), srow >= 0, gm, raw);
 #pragma unroll
@@ -350,7 +350,7 @@ __global__ __launch_bounds__(kThreads) void crop_backward(const SpanParams p) {
         for (int hb = 0; hb < 2; ++hb) {
             S raw[E + 1];
             // (XRAG: the row's first byte sits at the phase of its SOURCE row's cover)
-            const int xphase = XRAG ? (xrow_lo(max(row_map_t<PAD>(b + hb, d.cx1, S1), 0)) & 15) : 0;
+            const int xphase = XRAG ? (xrow_lo(max(row_map_t<PAD>(b + hb, d.cx1, S1, p.pad), 0)) & 15) : 0;
             read_row(tile + (tr + hb) * RBX + xphase, row_valid(b + hb, d.cx1, S1), xm, raw);
 #pragma unroll
             for (int e = 0; e <= E; ++e) xv[hb][e] = widen<T>(raw[e]);
@@ -408,7 +408,7 @@ struct SpanFwdParams {
     void *out;
     const void *w;
     int64_t x_plane, o_plane;   // elements per (n, c)
-    int wkind, C, nd;
+    int wkind, C, nd, pad;   // pad: the padding mode (the PAD = kPadRT instantiations read it)
     int S1, S2, O1, O2, L1, L2;
     int ocp, cps, spp;   // 16-byte chunks per output plane, chunks per step (256; 254 when only a column segment is staged), steps per plane
     int P, wholeP;       // pieces per slot; the same when whole rows are staged (0: only the columns the step reaches)
@@ -443,8 +443,8 @@ __global__ __launch_bounds__(kThreads) void crop_forward(const SpanFwdParams p) 
     const CT rr = ACTIVE ? c_floor<CT>(wr) : c_rint<CT>(wr), rc = ACTIVE ? c_floor<CT>(wc) : c_rint<CT>(wc);
     const CT dw[2] = {ACTIVE ? wr - rr : CT(0), ACTIVE ? wc - rc : CT(0)};
     const int S1 = p.S1, S2 = p.S2, O2 = p.O2, L1 = p.L1, L2 = p.L2, cpr = p.P;   // (P = pieces per source row)
-    const int cs1 = __builtin_amdgcn_readfirstlane(canon_of<PAD, CT>(rr, S1, p.d_per1));
-    const int cs2 = __builtin_amdgcn_readfirstlane(canon_of<PAD, CT>(rc, S2, p.d_per2));
+    const int cs1 = __builtin_amdgcn_readfirstlane(canon_of<PAD, CT>(rr, S1, p.d_per1, p.pad));
+    const int cs2 = __builtin_amdgcn_readfirstlane(canon_of<PAD, CT>(rc, S2, p.d_per2, p.pad));
 
     const int q0 = step * kThreads, q1 = min(p.ocp, q0 + kThreads);
     const int F0 = q0 * E, F1 = q1 * E;
@@ -460,7 +460,7 @@ __global__ __launch_bounds__(kThreads) void crop_forward(const SpanFwdParams p) 
         const int q = k * kThreads + tid;
         const int slot = static_cast<int>(fdiv(static_cast<uint32_t>(q), p.d_P));
         const int piece = q - slot * cpr;
-        const int row = q < npieces ? row_map_t<PAD>(r0 + slot + L1, cs1, S1) : -1;
+        const int row = q < npieces ? row_map_t<PAD>(r0 + slot + L1, cs1, S1, p.pad) : -1;
         if (row >= 0) {
             char *dst_wave = tile + (k * kThreads + wave * 64) * 16;
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(reinterpret_cast<const char *>(xp) + static_cast<uint32_t>(row * S2 * ES + piece * 16)),
@@ -480,11 +480,11 @@ __global__ __launch_bounds__(kThreads) void crop_forward(const SpanFwdParams p) 
 #pragma unroll
         for (int e = 0; e <= E; ++e) xm.cm[e] = static_cast<unsigned>(first + e) < static_cast<unsigned>(S2) ? first + e : -1;
     } else {
-        xm = fold_colstate<E, PAD>(j + L2, cs2, S2);
+        xm = fold_colstate<E, PAD>(j + L2, cs2, S2, p.pad);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    auto row_ok = [&](int slot) { return PAD != 0 || row_map_t<PAD>(r0 + slot + L1, cs1, S1) >= 0; };
+    auto row_ok = [&](int slot) { return PAD != 0 || row_map_t<PAD>(r0 + slot + L1, cs1, S1, p.pad) >= 0; };
     const S zero = static_cast<S>(0.0f);   // (a value, not an object the lambdas below could take the address of: that one went to scratch)
     if (q < q1 && j + E <= O2) {   // the chunk lies in one output row
         Chunk<S, E> res;
@@ -530,13 +530,13 @@ __global__ __launch_bounds__(kThreads) void crop_forward(const SpanFwdParams p) 
         for (int e = 0; e < E; ++e) {
             const int re = static_cast<int>(fdiv(static_cast<uint32_t>(eb + e), p.d_O2));
             const int slot = re - r0, je = eb + e - re * O2;
-            const int m0 = row_map_t<PAD>(je + L2, cs2, S2);
+            const int m0 = row_map_t<PAD>(je + L2, cs2, S2, p.pad);
             auto at = [&](int sl, int m) {
                 const S v = reinterpret_cast<const S *>(tile + sl * RB)[m > 0 ? m : 0];
                 return (m >= 0 && row_ok(sl)) ? v : zero;
             };
             if constexpr (ACTIVE) {
-                const int m1 = row_map_t<PAD>(je + L2 + 1, cs2, S2);
+                const int m1 = row_map_t<PAD>(je + L2 + 1, cs2, S2, p.pad);
                 const CT v[4] = {widen<T>(at(slot, m0)), widen<T>(at(slot + 1, m0)), widen<T>(at(slot, m1)), widen<T>(at(slot + 1, m1))};
                 res.e[e] = narrow<T>(interp_t<T, 2>(v, dw));
             } else {
@@ -577,8 +577,8 @@ __global__ __launch_bounds__(kThreads) void ragged_forward(const SpanFwdParams p
     const CT dw[2] = {ACTIVE ? wr - rr : CT(0), ACTIVE ? wc - rc : CT(0)};
     const int S1 = p.S1, S2 = p.S2, O1 = p.O1, O2 = p.O2, L1 = p.L1, L2 = p.L2;
     const int cpr = p.ocp, R = p.cps, PX = p.P;   // output chunks per row, rows per step, pieces per staged source row (xcpr + 2)
-    const int cs1 = __builtin_amdgcn_readfirstlane(canon_of<PAD, CT>(rr, S1, p.d_per1));
-    const int cs2 = __builtin_amdgcn_readfirstlane(canon_of<PAD, CT>(rc, S2, p.d_per2));
+    const int cs1 = __builtin_amdgcn_readfirstlane(canon_of<PAD, CT>(rr, S1, p.d_per1, p.pad));
+    const int cs2 = __builtin_amdgcn_readfirstlane(canon_of<PAD, CT>(rc, S2, p.d_per2, p.pad));
     const int b0 = step * R, Rn = min(R, O1 - b0);
     const S *xp = static_cast<const S *>(p.x) + static_cast<int64_t>(plane) * p.x_plane;
     S *op = static_cast<S *>(p.out) + static_cast<int64_t>(plane) * p.o_plane;
@@ -589,7 +589,7 @@ __global__ __launch_bounds__(kThreads) void ragged_forward(const SpanFwdParams p
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int RBX = PX * 16;
     // ---- the source rows of output rows b0 .. b0 + Rn - 1 (+ the corner row): covers of at most xcpr + 1 pieces -----------------
-    auto src_row = [&](int i) { return row_map_t<PAD>(b0 + i + L1, cs1, S1); };   // (-1: padding)
+    auto src_row = [&](int i) { return row_map_t<PAD>(b0 + i + L1, cs1, S1, p.pad); };   // (-1: padding)
     auto dma_x = [&](int row, int piece, int lds_piece0) {
         const int lo = xrow_lo(row), p0 = lo >> 4, cnt = ((lo + S2 * ES + 15) >> 4) - p0;
         if (row >= 0 && piece < cnt) {
@@ -616,7 +616,7 @@ __global__ __launch_bounds__(kThreads) void ragged_forward(const SpanFwdParams p
 #pragma unroll
         for (int e = 0; e <= E; ++e) xm.cm[e] = static_cast<unsigned>(first + e) < static_cast<unsigned>(S2) ? first + e : -1;
     } else {
-        xm = fold_colstate<E, PAD>(ji + L2, cs2, S2);
+        xm = fold_colstate<E, PAD>(ji + L2, cs2, S2, p.pad);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
@@ -683,7 +683,7 @@ __global__ __launch_bounds__(kThreads) void row_forward(const SpanFwdParams p) {
     const CT rc = ACTIVE ? c_floor<CT>(wv[2]) : c_rint<CT>(wv[2]);
     const CT dw[1] = {ACTIVE ? wv[2] - rc : CT(0)};
     const int S2 = p.S2, L2 = p.L2;
-    const int cs2 = __builtin_amdgcn_readfirstlane(canon_of<PAD, CT>(rc, S2, p.d_per2));
+    const int cs2 = __builtin_amdgcn_readfirstlane(canon_of<PAD, CT>(rc, S2, p.d_per2, p.pad));
     const int q0 = step * kThreads, q1 = min(p.ocp, q0 + kThreads);
     auto clampi = [](int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); };
     const int a0 = clampi(q0 * E + L2 - cs2, 0, S2), a1 = clampi(q1 * E + L2 - cs2 + (ACTIVE ? 1 : 0), 0, S2);   // staged columns [a0, a1)
@@ -709,7 +709,7 @@ __global__ __launch_bounds__(kThreads) void row_forward(const SpanFwdParams p) {
 #pragma unroll
         for (int e = 0; e <= E; ++e) xm.cm[e] = static_cast<unsigned>(first + e) < static_cast<unsigned>(S2) ? first + e : -1;
     } else {
-        xm = fold_colstate<E, PAD>(j + L2, cs2, S2);
+        xm = fold_colstate<E, PAD>(j + L2, cs2, S2, p.pad);
     }
     bool staged = xm.affine;
     if constexpr (PAD != 0) {
@@ -1055,6 +1055,7 @@ int span_forward(const Geometry &g, int dtype, const void *x, const void *w, int
         p.d_C = make_fastdiv(static_cast<uint32_t>(p.C));
         p.d_O2 = make_fastdiv(static_cast<uint32_t>(p.ocp));            // (ragged_forward: thread -> (row, chunk))
         p.d_P = make_fastdiv(static_cast<uint32_t>(p.P));
+        p.pad = g.pad;
         p.d_per1 = make_fastdiv(static_cast<uint32_t>(map_period(p.S1, g.pad)));
         p.d_per2 = make_fastdiv(static_cast<uint32_t>(map_period(p.S2, g.pad)));
         const size_t lds = 64 + static_cast<size_t>(p.cps + 1) * p.P * 16 + 64;
@@ -1062,13 +1063,8 @@ int span_forward(const Geometry &g, int dtype, const void *x, const void *w, int
         note_kernel(act ? "ragged_active_forward" : "ragged_gather_forward");
         const dim3 grid(p.steps_per_xcd * 8), block(kThreads);
 #define SHIFTND_RAG_FWD(TT, ACT) \
-        switch (g.pad) { \
-        case 0: hipLaunchKernelGGL((ragged_forward<TT, ACT, 0>), grid, block, lds, st, p); break; \
-        case 1: hipLaunchKernelGGL((ragged_forward<TT, ACT, 1>), grid, block, lds, st, p); break; \
-        case 2: hipLaunchKernelGGL((ragged_forward<TT, ACT, 2>), grid, block, lds, st, p); break; \
-        case 3: hipLaunchKernelGGL((ragged_forward<TT, ACT, 3>), grid, block, lds, st, p); break; \
-        default: hipLaunchKernelGGL((ragged_forward<TT, ACT, 4>), grid, block, lds, st, p); break; \
-        }
+        if (g.pad == 0) hipLaunchKernelGGL((ragged_forward<TT, ACT, 0>), grid, block, lds, st, p); \
+        else hipLaunchKernelGGL((ragged_forward<TT, ACT, kPadRT>), grid, block, lds, st, p);
         if (!act) {   // a raw copy: one instantiation per element size
             if (es == 2) { SHIFTND_RAG_FWD(f16_t, false) } else if (es == 4) { SHIFTND_RAG_FWD(f32_t, false) } else { SHIFTND_RAG_FWD(f64_t, false) }
         } else if (dtype == SHIFTND_F32) { SHIFTND_RAG_FWD(f32_t, true)
@@ -1124,6 +1120,7 @@ int span_forward(const Geometry &g, int dtype, const void *x, const void *w, int
     p.d_C = make_fastdiv(static_cast<uint32_t>(p.C));
     p.d_O2 = make_fastdiv(static_cast<uint32_t>(p.O2));
     p.d_P = make_fastdiv(static_cast<uint32_t>(sp.P));
+    p.pad = g.pad;
     p.d_per1 = make_fastdiv(static_cast<uint32_t>(map_period(p.S1, g.pad)));
     p.d_per2 = make_fastdiv(static_cast<uint32_t>(map_period(p.S2, g.pad)));
     const bool active = g.active != 0;
@@ -1131,13 +1128,8 @@ int span_forward(const Geometry &g, int dtype, const void *x, const void *w, int
         note_kernel(active ? "row_active_forward" : "row_gather_forward");
         const dim3 grid(p.steps_per_xcd * 8), block(kThreads);
 #define SHIFTND_ROW_FWD(TT, ACT) \
-        switch (g.pad) { \
-        case 0: hipLaunchKernelGGL((row_forward<TT, ACT, 0>), grid, block, sp.lds, st, p); break; \
-        case 1: hipLaunchKernelGGL((row_forward<TT, ACT, 1>), grid, block, sp.lds, st, p); break; \
-        case 2: hipLaunchKernelGGL((row_forward<TT, ACT, 2>), grid, block, sp.lds, st, p); break; \
-        case 3: hipLaunchKernelGGL((row_forward<TT, ACT, 3>), grid, block, sp.lds, st, p); break; \
-        default: hipLaunchKernelGGL((row_forward<TT, ACT, 4>), grid, block, sp.lds, st, p); break; \
-        }
+        if (g.pad == 0) hipLaunchKernelGGL((row_forward<TT, ACT, 0>), grid, block, sp.lds, st, p); \
+        else hipLaunchKernelGGL((row_forward<TT, ACT, kPadRT>), grid, block, sp.lds, st, p);
         if (!active) {
             if (es == 2) { SHIFTND_ROW_FWD(f16_t, false) } else if (es == 4) { SHIFTND_ROW_FWD(f32_t, false) } else { SHIFTND_ROW_FWD(f64_t, false) }
         } else if (dtype == SHIFTND_F32) { SHIFTND_ROW_FWD(f32_t, true)
@@ -1151,13 +1143,8 @@ int span_forward(const Geometry &g, int dtype, const void *x, const void *w, int
         note_kernel(active ? "crop_active_forward" : "crop_gather_forward");
         const dim3 grid(p.steps_per_xcd * 8), block(kThreads);
 #define SHIFTND_CROP_FWD(TT, ACT) \
-        switch (g.pad) { \
-        case 0: hipLaunchKernelGGL((crop_forward<TT, ACT, 0>), grid, block, sp.lds, st, p); break; \
-        case 1: hipLaunchKernelGGL((crop_forward<TT, ACT, 1>), grid, block, sp.lds, st, p); break; \
-        case 2: hipLaunchKernelGGL((crop_forward<TT, ACT, 2>), grid, block, sp.lds, st, p); break; \
-        case 3: hipLaunchKernelGGL((crop_forward<TT, ACT, 3>), grid, block, sp.lds, st, p); break; \
-        default: hipLaunchKernelGGL((crop_forward<TT, ACT, 4>), grid, block, sp.lds, st, p); break; \
-        }
+        if (g.pad == 0) hipLaunchKernelGGL((crop_forward<TT, ACT, 0>), grid, block, sp.lds, st, p); \
+        else hipLaunchKernelGGL((crop_forward<TT, ACT, kPadRT>), grid, block, sp.lds, st, p);
         if (!active) {   // a raw copy: one instantiation per element size
             if (es == 2) { SHIFTND_CROP_FWD(f16_t, false) } else if (es == 4) { SHIFTND_CROP_FWD(f32_t, false) } else { SHIFTND_CROP_FWD(f64_t, false) }
         } else if (dtype == SHIFTND_F32) { SHIFTND_CROP_FWD(f32_t, true)
@@ -1196,17 +1183,17 @@ static void launch_span_backward(const SpanParams &p, const SpanPlan &sp, bool a
     using S = typename T::S;
     const dim3 grid(p.steps_per_xcd * 8), block(kThreads);
 #define SHIFTND_SPAN_PAD(ACT, PADV) \
-    case PADV: \
+    { \
         if constexpr (ND == 2) hipLaunchKernelGGL((crop_backward<T, ACT, PADV, XRAG>), grid, block, sp.lds, st, p); \
         else hipLaunchKernelGGL((row_backward<T, ACT, PADV>), grid, block, sp.lds, st, p); \
-        break;
+    }
     // (zeros padding: no column tables -- the kernels prepare their channel themselves and publish the descriptor for step_reduce)
     if (active) {
         if (p.pad != 0) hipLaunchKernelGGL((span_prep<T, true>), dim3(p.C), block, 0, st, p);
-        switch (p.pad) { SHIFTND_SPAN_PAD(true, 0) SHIFTND_SPAN_PAD(true, 1) SHIFTND_SPAN_PAD(true, 2) SHIFTND_SPAN_PAD(true, 3) default: SHIFTND_SPAN_PAD(true, 4) }
+        if (p.pad == 0) SHIFTND_SPAN_PAD(true, 0) else SHIFTND_SPAN_PAD(true, kPadRT)
     } else {
         if (p.pad != 0) hipLaunchKernelGGL((span_prep<T, false>), dim3(p.C), block, 0, st, p);
-        switch (p.pad) { SHIFTND_SPAN_PAD(false, 0) SHIFTND_SPAN_PAD(false, 1) SHIFTND_SPAN_PAD(false, 2) SHIFTND_SPAN_PAD(false, 3) default: SHIFTND_SPAN_PAD(false, 4) }
+        if (p.pad == 0) SHIFTND_SPAN_PAD(false, 0) else SHIFTND_SPAN_PAD(false, kPadRT)
     }
 #undef SHIFTND_SPAN_PAD
     // the channel sums and the blends: step_reduce reads the record layout through StepParams
@@ -1217,7 +1204,7 @@ static void launch_span_backward(const SpanParams &p, const SpanPlan &sp, bool a
     r.C = p.C;
     r.spv = p.spp;
     r.d_spv = p.d_spp;
-    hipLaunchKernelGGL((step_reduce<T, ND>), dim3(p.C), block, 0, st, r, static_cast<S *>(gw));
+    launch_step_reduce(T::kDtype, ND, r, gw, st);
 }
 
 int span_backward(const Geometry &g, int dtype, const void *go, const void *x, const void *w, void *gx, void *gw, void *workspace,

@@ -437,26 +437,57 @@ int launch_step_backward(StepParams &p, const StepLayout &L, bool active, void *
     using S = typename T::S;
     const size_t lds = step_lds_bytes(L, ND, active);
     const dim3 grid(p.steps_per_xcd * 8), block(kThreads);
+    // (only the forms a call reaches are built: the fused pool for the sparse shift, two row groups per thread for 16-bit data)
 #define SHIFTND_STEP_PAD(ACT, PADV) \
     case PADV: \
         if constexpr (ND == 2) { \
-            if (p.K1 > 0) { hipLaunchKernelGGL((step_backward<T, ND, ACT, PADV, true>), grid, block, lds, st, p); break; } \
-            if (L.U == 2) { hipLaunchKernelGGL((step_backward<T, ND, ACT, PADV, false, 2>), grid, block, lds, st, p); break; } \
+            if constexpr (!ACT) \
+                if (p.K1 > 0) { hipLaunchKernelGGL((step_backward<T, ND, ACT, PADV, true>), grid, block, lds, st, p); break; } \
+            if constexpr (sizeof(S) == 2) \
+                if (L.U == 2) { hipLaunchKernelGGL((step_backward<T, ND, ACT, PADV, false, 2>), grid, block, lds, st, p); break; } \
         } \
         hipLaunchKernelGGL((step_backward<T, ND, ACT, PADV>), grid, block, lds, st, p); break;
+    launch_step_prep(T::kDtype, active, p, st);
     if (active) {
-        hipLaunchKernelGGL((step_prep<T, true>), dim3(p.C), block, 0, st, p);
         switch (p.pad) { SHIFTND_STEP_PAD(true, 0) SHIFTND_STEP_PAD(true, 1) SHIFTND_STEP_PAD(true, 2) SHIFTND_STEP_PAD(true, 3) default: SHIFTND_STEP_PAD(true, 4) }
     } else {
-        hipLaunchKernelGGL((step_prep<T, false>), dim3(p.C), block, 0, st, p);
         switch (p.pad) { SHIFTND_STEP_PAD(false, 0) SHIFTND_STEP_PAD(false, 1) SHIFTND_STEP_PAD(false, 2) SHIFTND_STEP_PAD(false, 3) default: SHIFTND_STEP_PAD(false, 4) }
     }
 #undef SHIFTND_STEP_PAD
-    hipLaunchKernelGGL((step_reduce<T, ND>), dim3(p.C), block, 0, st, p, static_cast<S *>(gw));
+    launch_step_reduce(T::kDtype, ND, p, gw, st);
     return SHIFTND_OK;
 }
 
 }  // namespace
+
+void launch_step_prep(int dtype, bool active, const StepParams &p, hipStream_t st) {
+    const dim3 grid(p.C), block(kThreads);
+#define SHIFTND_PREP(TT) \
+    if (active) hipLaunchKernelGGL((step_prep<TT, true>), grid, block, 0, st, p); \
+    else hipLaunchKernelGGL((step_prep<TT, false>), grid, block, 0, st, p);
+    switch (dtype) {
+    case SHIFTND_F32: SHIFTND_PREP(f32_t) break;
+    case SHIFTND_F64: SHIFTND_PREP(f64_t) break;
+    case SHIFTND_F16: SHIFTND_PREP(f16_t) break;
+    default: SHIFTND_PREP(bf16_t) break;
+    }
+#undef SHIFTND_PREP
+}
+
+void launch_step_reduce(int dtype, int nd, const StepParams &p, void *grad_w, hipStream_t st) {
+    const dim3 grid(p.C), block(kThreads);
+#define SHIFTND_REDUCE(TT) \
+    if (nd == 1) hipLaunchKernelGGL((step_reduce<TT, 1>), grid, block, 0, st, p, static_cast<typename TT::S *>(grad_w)); \
+    else if (nd == 2) hipLaunchKernelGGL((step_reduce<TT, 2>), grid, block, 0, st, p, static_cast<typename TT::S *>(grad_w)); \
+    else hipLaunchKernelGGL((step_reduce<TT, 3>), grid, block, 0, st, p, static_cast<typename TT::S *>(grad_w));
+    switch (dtype) {
+    case SHIFTND_F32: SHIFTND_REDUCE(f32_t) break;
+    case SHIFTND_F64: SHIFTND_REDUCE(f64_t) break;
+    case SHIFTND_F16: SHIFTND_REDUCE(f16_t) break;
+    default: SHIFTND_REDUCE(bf16_t) break;
+    }
+#undef SHIFTND_REDUCE
+}
 
 void step_set_tuning(int knob, int value) {
     if (knob >= 0 && knob < 5) g_step_tune[knob] = value;
@@ -475,8 +506,9 @@ bool step_backward_pooled_eligible(const Geometry &g, int dtype, const void *go,
     if (!(g.K[0] > 0 && g.nd == 2)) return false;
     (void)go;
     // the interpolating shift expands three pooled pieces per thread and is faster on the band-walk kernel (N64 C256 224x224
-    // fp32: 2.58 vs 2.22 ms); the sparse shift: 1.60 vs 1.65 ms, fp16 C512 1.98 vs 2.34 ms, N128 C512 56x56 0.43 vs 0.51 ms
-    if (g.active && g_step_tune[0] != 2) return false;
+    // fp32: 2.58 vs 2.22 ms: that form is not built); the sparse shift: 1.60 vs 1.65 ms, fp16 C512 1.98 vs 2.34 ms, N128 C512
+    // 56x56 0.43 vs 0.51 ms
+    if (g.active) return false;
     return step_backward_core(g, dtype, nullptr, x, gx);
 }
 

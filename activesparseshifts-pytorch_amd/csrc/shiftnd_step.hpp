@@ -56,6 +56,11 @@ struct StepParams {
 // the second half of step_backward()'s launch for 3-D problems (shiftnd_walk3.hip)
 int walk3_backward_launch(StepParams &p, const Geometry &g, int dtype, int cpr, void *gw, hipStream_t st);
 
+// One copy of step_prep / step_reduce in the library: shiftnd_step.hip instantiates them and defines these launchers; the walk
+// and row-span translation units call them (T::kDtype picks the element type).
+void launch_step_prep(int dtype, bool active, const StepParams &p, hipStream_t st);
+void launch_step_reduce(int dtype, int nd, const StepParams &p, void *grad_w, hipStream_t st);
+
 namespace {
 
 template <int E> struct RecSize { static constexpr int N = (E + 3 <= 8) ? 8 : 16; };  // int16 entries per record
@@ -175,12 +180,39 @@ __device__ __forceinline__ double wave_total(double v) {
 // run-time padding switch there costs more scalar-unit time than a one-step workgroup has (one scalar unit per CU;
 // shiftnd_common.hpp fold_index is 2 - 5 VALU instructions once the mode is known).
 // ---------------------------------------------------------------------------------------------------------------------
-template <int PAD> __device__ __forceinline__ int row_map_t(int p, int cs, int len) { return len == 1 ? 0 : fold_index(p - cs, len, PAD); }
+// PAD = kPadRT: one instantiation for the four non-zeros paddings, the mode (1 .. 4) a kernel argument (`rt`).  The row-span and
+// flat-stream kernels take it -- their hot bench shapes use zeros padding, and five copies of each were 60 % of their 390 kernels;
+// the one-step and walk kernels (the C2 / C3 padding rows of the bench) keep the compile-time modes.
+constexpr int kPadRT = 5;
+
+// fold_index for a run-time mode in 1 .. 4, branch-free: both folds are  ((idx ^ m) & am) + c  with launch-uniform m, am, c
+//   border     0 / len - 1              m = 0,  am = 0
+//   periodic   idx + len / idx - len    m = 0,  am = -1
+//   reflect    -idx / 2 (len - 1) - idx m = -1, am = -1   (-idx = ~idx + 1)
+//   symmetric  -idx - 1 / 2 len - 1 - idx
+__device__ __forceinline__ int fold_index_rt(int idx, int len, int pad) {
+    const int m = pad >= 3 ? -1 : 0, am = pad == 1 ? 0 : -1;
+    const int cn = pad == 2 ? len : (pad == 3 ? 1 : 0);
+    const int ch = pad == 1 ? len - 1 : (pad == 2 ? -len : (pad == 3 ? 2 * (len - 1) + 1 : 2 * len));
+    const int t = idx < 0 ? ((idx ^ m) & am) + cn : idx;
+    return t > len - 1 ? ((t ^ m) & am) + ch : t;
+}
+
+template <int PAD> __device__ __forceinline__ int row_map_t(int p, int cs, int len, int rt = 0) {
+    if constexpr (PAD == kPadRT) return len == 1 ? 0 : fold_index_rt(p - cs, len, rt);
+    else return len == 1 ? 0 : fold_index(p - cs, len, PAD);
+}
 
 // canon_shift (shiftnd_common.hpp) for |s| < 2^30 and a compile-time padding mode, all in 32 bits
-template <int PAD> __device__ __forceinline__ int canon_shift32(int s, int len, const FastDiv &dper) {
+template <int PAD> __device__ __forceinline__ int canon_shift32(int s, int len, const FastDiv &dper, int rt = 0) {
     if (len <= 1) return 0;
-    if constexpr (PAD <= 1) {
+    if constexpr (PAD == kPadRT) {
+        if (rt <= 1) return s < -len - 1 ? -len - 1 : (s > len + 1 ? len + 1 : s);
+        const int period = rt == 2 ? len : (rt == 3 ? 2 * (len - 1) : 2 * len);
+        const uint32_t a = static_cast<uint32_t>(s < 0 ? -s : s);
+        const uint32_t m = a - fdiv(a, dper) * static_cast<uint32_t>(period);
+        return static_cast<int>((s < 0 && m != 0) ? static_cast<uint32_t>(period) - m : m);
+    } else if constexpr (PAD <= 1) {
         return s < -len - 1 ? -len - 1 : (s > len + 1 ? len + 1 : s);
     } else {
         const int period = PAD == 2 ? len : (PAD == 3 ? 2 * (len - 1) : 2 * len);
@@ -230,9 +262,9 @@ template <typename CT> __device__ __forceinline__ void load_weights2(const void 
 }
 
 // canonical shift of an integral shift held in the compute type: 32-bit arithmetic below 2^30, the 64-bit form beyond
-template <int PAD, typename CT> __device__ __forceinline__ int canon_of(CT r, int len, const FastDiv &dper) {
-    if (r > CT(-1073741824) && r < CT(1073741824)) return canon_shift32<PAD>(static_cast<int>(r), len, dper);
-    return canon_shift(static_cast<int64_t>(r), len, PAD, dper);
+template <int PAD, typename CT> __device__ __forceinline__ int canon_of(CT r, int len, const FastDiv &dper, int rt = 0) {
+    if (r > CT(-1073741824) && r < CT(1073741824)) return canon_shift32<PAD>(static_cast<int>(r), len, dper, rt);
+    return canon_shift(static_cast<int64_t>(r), len, PAD == kPadRT ? rt : PAD, dper);
 }
 
 // the two canonical shifts of channel c for the gather kernels (sparse shift: round half to even; quantized: int_repr minus
@@ -346,13 +378,13 @@ struct FwdParams {
 };
 
 // column state of E + 1 consecutive map entries starting at coordinate j0, folded arithmetically
-template <int E, int PAD> __device__ __forceinline__ ColState<E> fold_colstate(int j0, int cs, int len) {
+template <int E, int PAD> __device__ __forceinline__ ColState<E> fold_colstate(int j0, int cs, int len, int rt = 0) {
     ColState<E> c;
     c.base = 0;
     bool found = false;
 #pragma unroll
     for (int e = 0; e <= E; ++e) {
-        c.cm[e] = row_map_t<PAD>(j0 + e, cs, len);
+        c.cm[e] = row_map_t<PAD>(j0 + e, cs, len, rt);
         if (!found && c.cm[e] >= 0) {
             c.base = c.cm[e] - e;
             found = true;
@@ -417,15 +449,14 @@ struct StepLayout {
     size_t off_desc, off_colx, off_colg, bytes;
 };
 
-// row groups per thread (knob 35 bit 1 = 2: always one, bit 2 = 4: always two): two for 16-bit data, where the kernel is
+// row groups per thread (knob 35 bit 1 = 2: always one): two for 16-bit data, where the kernel is
 // bound by instruction issue (same box, one vs two: fp16 C512 224x224 reflect 1.80 -> 1.67 ms, interpolating 1.91 -> 1.79,
 // bf16 N128 C256 56x56 0.126 -> 0.109; zeros padding 1.61 vs 1.62); one for 4- / 8-byte elements (fp32 sparse 1.58 vs 1.62,
 // interpolating 1.63 vs 1.67 ms: the tighter sweep front wins), 3-D and pooled calls
 int step_row_groups(const Geometry &g, int es) {
     if (g.nd != 2 || g.K[0] > 0) return 1;
     if (g_step_tune[3] & 2) return 1;
-    if (g_step_tune[3] & 4) return 2;
-    return es == 2 ? 2 : 1;
+    return es == 2 ? 2 : 1;   // (two row groups are built for 16-bit data only)
 }
 
 // force_u: row groups per thread (0: by dtype and knob 35).  The WORKSPACE is planned with one (the most steps), so that its size

@@ -505,9 +505,9 @@ bool step_forward_lds_eligible(const Geometry &g, int dtype, const void *x, cons
     if (!interpolating && es != 2) return false;
     if ((g.nd != 2 && g.nd != 3) || (g.nd == 2 && (g.S[0] != 1 || g.O[0] != 1))) return false;
     // 3-D: 4- / 8-byte interpolation (N8 C128 16x112x112 fp32 0.38 -> 0.30 ms) and the 2-byte sparse shift (0.155 -> 0.136 ms);
-    // 16-bit interpolation stays on the sliding-window kernel (0.18 vs 0.215 ms: four corner rows to unpack per output row
-    // against two) unless forced (knob 34 >= 2 or knob 35 bit 3)
-    if (g.nd == 3 && interpolating && es == 2 && !(g_step_tune[2] >= 2 || (g_step_tune[3] & 8))) return false;
+    // 16-bit interpolation is walk_forward16's (this kernel measured 0.215 ms against the sliding window's 0.18: four corner rows
+    // to unpack per output row against two -- the form is no longer built)
+    if (g.nd == 3 && interpolating && es == 2) return false;
     const int64_t xe = g.S[0] * g.S[1] * g.S[2], oe = g.O[0] * g.O[1] * g.O[2];
     if (xe < 1 || oe < 1 || xe >= (1LL << 30) || oe >= (1LL << 30) || g.S[2] > 32000) return false;
     if ((g.S[2] * es) % 16 != 0 || reinterpret_cast<uintptr_t>(x) % 16 != 0) return false;
@@ -529,22 +529,23 @@ bool step_forward_lds_eligible(const Geometry &g, int dtype, const void *x, cons
     return interpolating || g.O[1] * g.O[2] * es >= 4 * 1024;
 }
 
-template <typename T>
-static void launch_step_forward_lds(const FwdParams &p, bool active, int pad, int U, size_t lds, hipStream_t st) {
+// (only the forms a call can reach are instantiated: the sparse shift as one raw 2-byte copy, the 3-D interpolation for 4- / 8-byte
+// elements -- walk_forward16 serves the 16-bit volumes)
+template <typename T, bool ACT>
+static void launch_step_forward_lds(const FwdParams &p, int pad, int U, size_t lds, hipStream_t st) {
     const dim3 grid(p.steps_per_xcd * 8), block(kThreads);
-#define SHIFTND_STEP_FWD_LDS(ACT, PADV) \
+    constexpr bool k3d = !ACT || sizeof(typename T::S) >= 4;
+#define SHIFTND_STEP_FWD_LDS(PADV) \
     case PADV: \
         if (p.nd == 3) { \
-            if (U == 2) hipLaunchKernelGGL((step_forward_lds<T, 3, ACT, PADV, 2>), grid, block, lds, st, p); \
-            else hipLaunchKernelGGL((step_forward_lds<T, 3, ACT, PADV, 1>), grid, block, lds, st, p); \
+            if constexpr (k3d) { \
+                if (U == 2) hipLaunchKernelGGL((step_forward_lds<T, 3, ACT, PADV, 2>), grid, block, lds, st, p); \
+                else hipLaunchKernelGGL((step_forward_lds<T, 3, ACT, PADV, 1>), grid, block, lds, st, p); \
+            } \
         } else if (U == 2) hipLaunchKernelGGL((step_forward_lds<T, 2, ACT, PADV, 2>), grid, block, lds, st, p); \
         else hipLaunchKernelGGL((step_forward_lds<T, 2, ACT, PADV, 1>), grid, block, lds, st, p); \
         break;
-    if (active) {
-        switch (pad) { SHIFTND_STEP_FWD_LDS(true, 0) SHIFTND_STEP_FWD_LDS(true, 1) SHIFTND_STEP_FWD_LDS(true, 2) SHIFTND_STEP_FWD_LDS(true, 3) default: SHIFTND_STEP_FWD_LDS(true, 4) }
-    } else {
-        switch (pad) { SHIFTND_STEP_FWD_LDS(false, 0) SHIFTND_STEP_FWD_LDS(false, 1) SHIFTND_STEP_FWD_LDS(false, 2) SHIFTND_STEP_FWD_LDS(false, 3) default: SHIFTND_STEP_FWD_LDS(false, 4) }
-    }
+    switch (pad) { SHIFTND_STEP_FWD_LDS(0) SHIFTND_STEP_FWD_LDS(1) SHIFTND_STEP_FWD_LDS(2) SHIFTND_STEP_FWD_LDS(3) default: SHIFTND_STEP_FWD_LDS(4) }
 #undef SHIFTND_STEP_FWD_LDS
 }
 
@@ -592,14 +593,14 @@ int step_forward_lds(const Geometry &g, int dtype, const void *x, const void *w,
     const size_t lds = 64 + static_cast<size_t>((g.nd == 3 && active) ? 2 : 1) * (U * p.R + (active ? 1 : 0)) * p.xppr * 16 + 64;
     note_kernel(active ? "step_active_forward" : "step_gather_forward_lds");
     if (!active) {  // a raw copy of 2-byte elements: one instantiation serves fp16 and bf16
-        launch_step_forward_lds<f16_t>(p, false, g.pad, U, lds, st);
+        launch_step_forward_lds<f16_t, false>(p, g.pad, U, lds, st);
         return SHIFTND_OK;
     }
     switch (dtype) {
-    case SHIFTND_F32: launch_step_forward_lds<f32_t>(p, true, g.pad, U, lds, st); break;
-    case SHIFTND_F64: launch_step_forward_lds<f64_t>(p, true, g.pad, U, lds, st); break;
-    case SHIFTND_F16: launch_step_forward_lds<f16_t>(p, true, g.pad, U, lds, st); break;
-    default: launch_step_forward_lds<bf16_t>(p, true, g.pad, U, lds, st); break;
+    case SHIFTND_F32: launch_step_forward_lds<f32_t, true>(p, g.pad, U, lds, st); break;
+    case SHIFTND_F64: launch_step_forward_lds<f64_t, true>(p, g.pad, U, lds, st); break;
+    case SHIFTND_F16: launch_step_forward_lds<f16_t, true>(p, g.pad, U, lds, st); break;
+    default: launch_step_forward_lds<bf16_t, true>(p, g.pad, U, lds, st); break;
     }
     return SHIFTND_OK;
 }

@@ -13,14 +13,45 @@
 #include "shiftnd_launch.hpp"
 
 namespace shiftnd {
+// the final stage of every family's weight-gradient reduction (declared in shiftnd_common.hpp)
+namespace {
+template <typename T>
+__global__ __launch_bounds__(64) void reduce_weight_grads(const double *__restrict__ partials, int groups, int C, int nd,
+                                                           typename T::S *__restrict__ grad_w) {
+    // one wave per output element: lanes stride over the groups (fixed order), then a fixed shuffle tree
+    const int t = blockIdx.x;
+    const int c = t / nd, s = t - c * nd;
+    double acc = 0.0;
+    for (int g = threadIdx.x; g < groups; g += 64) acc += partials[(static_cast<size_t>(g) * C + c) * 3 + s];
+    acc = wave_sum(acc);
+    if (threadIdx.x == 0) {
+        if constexpr (sizeof(typename T::S) == 8) {
+            grad_w[t] = acc;
+        } else {
+            grad_w[t] = narrow<T>(static_cast<float>(acc));
+        }
+    }
+}
+}  // namespace
+
+void launch_reduce_weight_grads(int dtype, const double *partials, int groups, int C, int nd, void *grad_w, hipStream_t st) {
+    const dim3 grid(static_cast<unsigned>(C) * nd), block(64);
+    switch (dtype) {
+    case SHIFTND_F32: hipLaunchKernelGGL((reduce_weight_grads<f32_t>), grid, block, 0, st, partials, groups, C, nd, static_cast<float *>(grad_w)); break;
+    case SHIFTND_F64: hipLaunchKernelGGL((reduce_weight_grads<f64_t>), grid, block, 0, st, partials, groups, C, nd, static_cast<double *>(grad_w)); break;
+    case SHIFTND_F16: hipLaunchKernelGGL((reduce_weight_grads<f16_t>), grid, block, 0, st, partials, groups, C, nd, static_cast<f16_t::S *>(grad_w)); break;
+    default: hipLaunchKernelGGL((reduce_weight_grads<bf16_t>), grid, block, 0, st, partials, groups, C, nd, static_cast<bf16_t::S *>(grad_w)); break;
+    }
+}
+
 namespace {
 
 // resolve one gather: returns element offset within the (n) slice or -1 (fill)
 __device__ __forceinline__ int64_t resolve(const int64_t idx[3], const int64_t size[3], const int64_t *st /*d0,d1,inner*/,
                                            int pad) {
     int64_t off = 0;
-#pragma unroll
-    for (int d = 0; d < 3; ++d) {
+#pragma unroll 1
+    for (int d = 0; d < 3; ++d) {   // one copy of the padding map (64-bit divisions) in the code
         const int64_t t = (size[d] == 1) ? 0 : pad_index(idx[d], size[d], pad);
         if (t < 0) return -1;
         off += t * st[d];
@@ -59,17 +90,40 @@ __global__ __launch_bounds__(kThreads) void strided_gather_forward(Geometry g, c
     }
 }
 
-// gather the 2^ND corners of `arr` around idx (normalised dims), masked by `pass`
+// gather the 2^ND corners of `arr` around idx (normalised dims), masked by `pass`.  The padding map is separable: each
+// dim resolves its two coordinates once (6 pad_index evaluations, not 3 per corner -- every one carries 64-bit divisions,
+// and the all-corners form made these kernels 165-325 KB of code each).
 template <typename T, int ND>
 __device__ __forceinline__ void gather_corners(const typename T::S *arr, const int64_t idx[3], const int64_t size[3],
                                                const int64_t *st, int pad, bool pass, typename T::C *v) {
+    int64_t ax[3][2] = {{-1, -1}, {-1, -1}, {-1, -1}};   // element offset of coordinate idx[d] + k along dim d, or -1 (fill)
+    // one copy of the padding map in the code, walked 2 * ND + (3 - ND) times (the registers are picked by compile-time
+    // selects: a dynamically indexed local array would live in scratch)
+#pragma unroll 1
+    for (int j = 0; j < 6; ++j) {
+        const int d = j >> 1, k = j & 1;
+        if (k == 1 && d < 3 - ND) continue;   // leading (size-1) dims have one coordinate
+        const int64_t sz = d == 0 ? size[0] : (d == 1 ? size[1] : size[2]);
+        const int64_t at = (d == 0 ? idx[0] : (d == 1 ? idx[1] : idx[2])) + k;
+        const int64_t sd = d == 0 ? st[0] : (d == 1 ? st[1] : st[2]);
+        const int64_t t = (sz == 1) ? 0 : pad_index(at, sz, pad);
+        const int64_t r = t < 0 ? -1 : t * sd;
+#pragma unroll
+        for (int dd = 0; dd < 3; ++dd)
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) ax[dd][kk] = (j == dd * 2 + kk) ? r : ax[dd][kk];
+    }
 #pragma unroll
     for (int q = 0; q < (1 << ND); ++q) {
-        int64_t id[3] = {idx[0], idx[1], idx[2]};
+        int64_t off = 0;
+        bool in = pass;
 #pragma unroll
-        for (int r = 0; r < ND; ++r) id[r + 3 - ND] += (q >> r) & 1;
-        const int64_t off = pass ? resolve(id, size, st, pad) : -1;
-        v[q] = off >= 0 ? widen<T>(arr[off]) : typename T::C(0);
+        for (int d = 0; d < 3; ++d) {
+            const int k = d >= 3 - ND ? (q >> (d - (3 - ND))) & 1 : 0;
+            in = in && ax[d][k] >= 0;
+            off += ax[d][k];
+        }
+        v[q] = in ? widen<T>(arr[off]) : typename T::C(0);
     }
 }
 
@@ -186,8 +240,7 @@ int launch_strided_backward_nd(const Geometry &g, const void *go, const void *x,
                            static_cast<const S *>(go), static_cast<const S *>(x), static_cast<const S *>(w),
                            static_cast<S *>(gx), partials);
     const int cn = static_cast<int>(g.C) * g.nd;
-    hipLaunchKernelGGL((reduce_weight_grads<T>), dim3(cn), dim3(64), 0, st, partials, static_cast<int>(g.N),
-                       static_cast<int>(g.C), g.nd, static_cast<S *>(gw));
+    reduce_weight_grads_of<T>(partials, static_cast<int>(g.N), static_cast<int>(g.C), g.nd, gw, st);
     return SHIFTND_OK;
 }
 

@@ -507,22 +507,22 @@ void plan_shape(SweepParams &p, uint32_t cpr, uint32_t rows, int64_t planes, int
     set_grid(p, static_cast<uint64_t>(planes) * p.bpp);
 }
 
+// Row steps per workgroup (the kernels' K) are fixed at the values the round-2 sweeps settled on -- 4 for the gather forward,
+// 2 for the backward, 2^(3 - nd) capped at 2 .. 4 for the interpolating forward: one instantiation per form (the other K's,
+// once reachable through knobs 8 / 10, were 99 kernels nothing routed to).
+constexpr int kGatherK = 4, kBackwardK = 2;
+
 template <int ESIZE, int V> void launch_gather(const SweepParams &p, hipStream_t st) {
     const dim3 grid(p.blocks_per_xcd * 8), block(p.threads);
     // (an occupancy limit through unused dynamic LDS was tried here -- fewer bytes in flight help a plain copy, tools/stream_probe
     //  X4 -- and changed nothing: 1.105 ms at every setting)
-    if (p.K <= 1) hipLaunchKernelGGL((sweep_gather_forward<ESIZE, V, 1>), grid, block, 0, st, p);
-    else if (p.K <= 2) hipLaunchKernelGGL((sweep_gather_forward<ESIZE, V, 2>), grid, block, 0, st, p);
-    else if (p.K <= 4) hipLaunchKernelGGL((sweep_gather_forward<ESIZE, V, 4>), grid, block, 0, st, p);
-    else hipLaunchKernelGGL((sweep_gather_forward<ESIZE, V, 8>), grid, block, 0, st, p);
+    hipLaunchKernelGGL((sweep_gather_forward<ESIZE, V, kGatherK>), grid, block, 0, st, p);
 }
 
 
 template <typename T, int ND, bool ACTIVE> void launch_backward_k(const SweepParams &p, hipStream_t st) {
     const dim3 grid(p.blocks_per_xcd * 8), block(p.threads);
-    if (p.K <= 1) hipLaunchKernelGGL((sweep_backward<T, ND, ACTIVE, 1>), grid, block, 0, st, p);
-    else if (p.K <= 2) hipLaunchKernelGGL((sweep_backward<T, ND, ACTIVE, 2>), grid, block, 0, st, p);
-    else hipLaunchKernelGGL((sweep_backward<T, ND, ACTIVE, 4>), grid, block, 0, st, p);
+    hipLaunchKernelGGL((sweep_backward<T, ND, ACTIVE, kBackwardK>), grid, block, 0, st, p);
 }
 template <typename T, bool ACTIVE> void launch_backward_nd(const SweepParams &p, hipStream_t st) {
     switch (p.nd) {
@@ -535,8 +535,7 @@ template <typename T> int launch_backward(const SweepParams &p, bool active, int
     if (active) launch_backward_nd<T, true>(p, st);
     else launch_backward_nd<T, false>(p, st);
     const int cn = p.C * p.nd;
-    hipLaunchKernelGGL((reduce_weight_grads<T>), dim3(cn), dim3(64), 0, st, p.partials, groups, p.C, p.nd,
-                       static_cast<typename T::S *>(gw));
+    reduce_weight_grads_of<T>(p.partials, groups, p.C, p.nd, gw, st);
     return SHIFTND_OK;
 }
 
@@ -544,7 +543,7 @@ void plan_backward(SweepParams &p, const Geometry &g, int es) {
     fill_common(p, g);
     p.d_dim1 = make_fastdiv(static_cast<uint32_t>(g.S[1]));
     plan_shape(p, static_cast<uint32_t>(g.S[2] * es / 16), static_cast<uint32_t>(g.S[0] * g.S[1]), g.N * g.C,
-               g_sweep_tune[2], g_sweep_tune[3], 4);
+               kBackwardK, g_sweep_tune[3], kBackwardK);
 }
 
 }  // namespace
@@ -569,16 +568,11 @@ bool sweep_forward_eligible(const Geometry &g, int dtype, const void *x, const v
 
 template <typename T> void launch_active_forward(const SweepParams &p, hipStream_t st) {
     const dim3 grid(p.blocks_per_xcd * 8), block(p.threads);
-#define SHIFTND_SWEEP_ACTIVE(NDV) \
-    if (p.K <= 1) hipLaunchKernelGGL((sweep_active_forward<T, NDV, 1>), grid, block, 0, st, p); \
-    else if (p.K <= 2) hipLaunchKernelGGL((sweep_active_forward<T, NDV, 2>), grid, block, 0, st, p); \
-    else hipLaunchKernelGGL((sweep_active_forward<T, NDV, 4>), grid, block, 0, st, p);
-    switch (p.nd) {
-    case 1: SHIFTND_SWEEP_ACTIVE(1) break;
-    case 2: SHIFTND_SWEEP_ACTIVE(2) break;
-    default: SHIFTND_SWEEP_ACTIVE(3) break;
+    switch (p.nd) {   // (K = the plan's: 4 rows per thread for 1-D, 2 otherwise)
+    case 1: hipLaunchKernelGGL((sweep_active_forward<T, 1, 4>), grid, block, 0, st, p); break;
+    case 2: hipLaunchKernelGGL((sweep_active_forward<T, 2, 2>), grid, block, 0, st, p); break;
+    default: hipLaunchKernelGGL((sweep_active_forward<T, 3, 2>), grid, block, 0, st, p); break;
     }
-#undef SHIFTND_SWEEP_ACTIVE
 }
 
 int sweep_forward(const Geometry &g, int dtype, const void *x, const void *w, int wkind, int64_t wzp, uint64_t fill_bits,
@@ -595,7 +589,7 @@ int sweep_forward(const Geometry &g, int dtype, const void *x, const void *w, in
         p.d_dim1 = make_fastdiv(static_cast<uint32_t>(g.O[1]));
         const int kmax = g.nd == 1 ? 4 : 2;  // rows per thread: 2^(nd-1) corner rows of E + 1 values each stay in registers (2-D: K=2 measured best)
         plan_shape(p, static_cast<uint32_t>(g.O[2] * es / 16), static_cast<uint32_t>(g.O[0] * g.O[1]), g.N * g.C,
-                   g_sweep_tune[0] < kmax ? g_sweep_tune[0] : kmax, g_sweep_tune[1], kmax);
+                   kmax, g_sweep_tune[1], kmax);
         if (dtype == SHIFTND_F32) launch_active_forward<f32_t>(p, st);
         else launch_active_forward<f64_t>(p, st);
         return SHIFTND_OK;
@@ -612,7 +606,7 @@ int sweep_forward(const Geometry &g, int dtype, const void *x, const void *w, in
     p.fill = fill_bits;
     p.d_dim1 = make_fastdiv(static_cast<uint32_t>(g.O[1]));
     plan_shape(p, static_cast<uint32_t>(g.O[2] * es / V), static_cast<uint32_t>(g.O[0] * g.O[1]), g.N * g.C,
-               g_sweep_tune[0], g_sweep_tune[1], 8);
+               kGatherK, g_sweep_tune[1], kGatherK);
 #define SHIFTND_GATHER_CASE(ES, VV) \
     if (es == ES && V == VV) { launch_gather<ES, VV>(p, st); return SHIFTND_OK; }
     SHIFTND_GATHER_CASE(1, 16) SHIFTND_GATHER_CASE(1, 8) SHIFTND_GATHER_CASE(1, 4) SHIFTND_GATHER_CASE(1, 1)

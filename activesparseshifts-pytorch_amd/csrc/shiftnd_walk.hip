@@ -692,17 +692,15 @@ int walk16_backward(const Geometry &g, int dtype, const void *go, const void *x,
     note_kernel(active ? "walk_backward16" : "walk_backward16_sparse");
 #define SHIFTND_WALK16(TT) \
     { \
-        using GW = typename TT::S; \
+        launch_step_prep(TT::kDtype, active, p, st); \
         if (active) { \
-            hipLaunchKernelGGL((step_prep<TT, true>), dim3(p.C), block, 0, st, p); \
             if (zeros) hipLaunchKernelGGL((walk_backward16<TT, true, true>), grid, block, lds, st, p); \
             else hipLaunchKernelGGL((walk_backward16<TT, true, false>), grid, block, lds, st, p); \
         } else { \
-            hipLaunchKernelGGL((step_prep<TT, false>), dim3(p.C), block, 0, st, p); \
             if (zeros) hipLaunchKernelGGL((walk_backward16<TT, false, true>), grid, block, lds, st, p); \
             else hipLaunchKernelGGL((walk_backward16<TT, false, false>), grid, block, lds, st, p); \
         } \
-        hipLaunchKernelGGL((step_reduce<TT, 3>), dim3(p.C), block, 0, st, p, static_cast<GW *>(gw)); \
+        launch_step_reduce(TT::kDtype, 3, p, gw, st); \
     }
     if (dtype == SHIFTND_F16) SHIFTND_WALK16(f16_t) else SHIFTND_WALK16(bf16_t)
 #undef SHIFTND_WALK16

@@ -783,8 +783,7 @@ static bool walk_backward_core(const Geometry &g, int dtype, const void *go, con
 template <typename T> static void launch_walk_backward(StepParams &p, size_t lds, bool active, void *gw, hipStream_t st) {
     using S = typename T::S;
     const dim3 grid(p.steps_per_xcd * 8), block(kThreads);
-    if (active) hipLaunchKernelGGL((step_prep<T, true>), dim3(p.C), block, 0, st, p);
-    else hipLaunchKernelGGL((step_prep<T, false>), dim3(p.C), block, 0, st, p);
+    launch_step_prep(T::kDtype, active, p, st);
     // (16-bit tensors without a pool: walk_backward16, shiftnd_walk.hip -- only their pooled variants are instantiated here)
     constexpr bool PLAIN = sizeof(S) != 2;
 #define SHIFTND_WALK_BWD(PADV) \
@@ -798,7 +797,7 @@ template <typename T> static void launch_walk_backward(StepParams &p, size_t lds
         break;
     switch (p.pad) { SHIFTND_WALK_BWD(0) SHIFTND_WALK_BWD(1) SHIFTND_WALK_BWD(2) SHIFTND_WALK_BWD(3) default: SHIFTND_WALK_BWD(4) }
 #undef SHIFTND_WALK_BWD
-    hipLaunchKernelGGL((step_reduce<T, 3>), dim3(p.C), block, 0, st, p, static_cast<S *>(gw));
+    launch_step_reduce(T::kDtype, 3, p, gw, st);
 }
 
 // the second half of step_backward()'s launch for 3-D problems: balanced row steps, one record of sums per workgroup

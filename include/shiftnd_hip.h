@@ -116,7 +116,9 @@ SHIFTND_API void shiftnd_set_path_policy(int policy);
  * pool (36: 1 = the element-per-thread kernel only, 37: workgroups wanted), 38 planes per workgroup of the 3-D walk
  * kernels; for the sizing knobs 0 means automatic.
  * Results never depend on them.
- * shiftnd_backward_workspace_bytes plans with the calling thread's knobs: size and run on the same thread. */
+ * shiftnd_backward_workspace_bytes (and the pooled form) returns the larger of the default knobs' plan and the calling
+ * thread's: a backward whose own plan needs more than it was given runs the default plan instead, so sizing on one
+ * thread and running on another never ends in SHIFTND_ERR_WORKSPACE_TOO_SMALL. */
 SHIFTND_API void shiftnd_set_tuning(int knob, int value);
 /* Diagnostics: the sweep kernels' arithmetic padding map evaluated on the host: source index of
  * coordinate p (0 <= p <= len) under `shift`, or -1 for "fill". */

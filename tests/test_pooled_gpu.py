@@ -85,29 +85,6 @@ def test_pooled_vs_oracle(abi, dt):
                 assert rel_err(gw.cpu().numpy(), gw_r) < (1e-5 if dt == np.float32 else 1e-12), key
 
 
-@pytest.mark.parametrize("dt", [np.float32, np.float64])
-def test_pooled_one_step_interpolating_on_request(abi, dt):
-    """the one-step pooled backward also serves the interpolating shift (knob 32 = 2; the automatic choice keeps the band-walk
-    kernel there): same bar"""
-    rs = np.random.RandomState(13)
-    abi.set_tuning(32, 2)
-    try:
-        for shape, pool in (((3, 4, 37, 64), (2, 2)), ((2, 3, 9, 40), (3, 5)), ((2, 2, 12, 16), (2, 2))):
-            x = rs.uniform(-1, 1, size=shape).astype(dt)
-            w = rs.uniform(-3.2, 3.2, size=(shape[1], 2)).astype(dt)
-            b, _ = abi.check_borders(list(shape), None, 2)
-            for pad in range(5):
-                ref = O.forward_pooled(x, w, pad, 1, pool, b)
-                gp = rs.uniform(-1, 1, size=ref.shape).astype(dt)
-                gx_r, gw_r = O.backward_pooled(gp, w, x, pad, 1, pool, b)
-                gx, gw = abi.backward_pooled(_dev(gp), _dev(w), _dev(x), pad, 1, pool, b)
-                assert abi.last_kernel() == "step_backward_pool"
-                assert np.array_equal(gx.cpu().numpy(), gx_r), (shape, pool, pad)
-                assert rel_err(gw.cpu().numpy(), gw_r) < (1e-5 if dt == np.float32 else 1e-12), (shape, pool, pad)
-    finally:
-        abi.set_tuning(32, 0)
-
-
 @pytest.mark.parametrize("tdt", [torch.bfloat16, torch.float16])
 def test_pooled_16bit(abi, tdt):
     rs = np.random.RandomState(5)

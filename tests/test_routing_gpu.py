@@ -51,3 +51,79 @@ def test_default_route_c4_quantized():
     for pad in range(5):
         abi.forward_quantized(xq, wq, 128, 0, pad)
         assert abi.last_kernel() == "bytes_gather_forward", (pad, abi.last_kernel())
+
+
+# -- sizing on one thread, running on another ----------------------------------------------------------------------------------
+KNOB_DEFAULTS = [0, 128 * 1024, 4, 2, 1, 0, 1, 0, 4, 512, 2, 256, -1, 0, 16, 0, 1, 0, 0, 0, 1, 0, 1, 0, 1, 0, 0, 0, 1, 0, 0, 0, 0, 0, 0, 0, 0,
+                 0, 0, 0]
+# (shape, dtype, channels-last, knob settings of the running thread); the knobs shape the launch plan, and with it the number of
+# partial-sum records a family needs -- knob 21 = 1 (one row per band of the NHWC kernel) needs 8-20 x the default plan's bytes
+CROSS_THREAD = [
+    ((4, 64, 56, 56), torch.float32, True, [(21, 1)]),
+    ((4, 64, 56, 56), torch.bfloat16, True, [(21, 1)]),
+    ((2, 4, 96, 512), torch.float32, False, [(11, 1), (10, 1)]),
+    ((4, 32, 56, 56), torch.float32, False, [(0, 1 << 20), (1, 1), (32, 1), (12, 0)]),
+    ((2, 8, 6, 40, 48), torch.float32, False, [(0, 1 << 20), (1, 1), (38, 1)]),
+    ((8, 16, 14, 14), torch.float32, False, [(25, 1), (26, 1)]),
+]
+
+
+@pytest.mark.parametrize("case", range(len(CROSS_THREAD)))
+def test_backward_sized_with_default_knobs_runs_under_any(case):
+    """include/shiftnd_hip.h: the bytes shiftnd_backward_workspace_bytes returns on a thread with untouched knobs serve a
+    shiftnd_backward on a thread whose knobs plan more partial records (the call runs the default plan instead of failing with
+    WORKSPACE_TOO_SMALL).  grad_x is the oracle's bit for bit (fp32; 1 ulp for bf16) and the default thread's, grad_w within
+    the parity bar."""
+    import threading
+    import numpy as np
+    from cases import rel_err, gw16_tol
+    from oracle import oracle as O
+    from test_hip_parity import _ulp_close
+    from torchshifts import abi
+    shape, tdt, cl, knobs = CROSS_THREAD[case]
+    nd = len(shape) - 2
+    abi.set_path_policy(0)
+    rs = np.random.RandomState(case + 11)
+    xt = torch.from_numpy(rs.uniform(-1, 1, size=shape)).to(tdt)
+    gt = torch.from_numpy(rs.uniform(-1, 1, size=shape)).to(tdt)
+    wt = torch.from_numpy(rs.uniform(-2.5, 2.5, size=(shape[1], nd))).to(tdt)
+    x, go, w = (t.to(torch.float64).numpy().astype(np.float32) for t in (xt, gt, wt))
+    xd, god, wd = xt.to(DEV), gt.to(DEV), wt.to(DEV)
+    if cl:
+        xd, god = abi.to_channels_last(xd), abi.to_channels_last(god)
+    for pad in (0, 3):
+        ws = abi.backward_workspace(xd, pad, True)      # sized here, knobs untouched
+        gx0, gw0 = abi.backward(god, wd, xd, pad, True, workspace=ws)
+        k0 = abi.last_kernel()
+        out = {}
+
+        def run():
+            try:
+                for knob, value in knobs:
+                    abi.set_tuning(knob, value)
+                ws.fill_(0xA5)
+                out["given"] = abi.backward(god, wd, xd, pad, True, workspace=ws)
+                out["kernel"] = abi.last_kernel()
+                out["own"] = abi.backward(god, wd, xd, pad, True)   # ... and a buffer sized on THIS thread serves its own plan
+                out["bytes"] = abi.backward_workspace(xd, pad, True).numel()
+            except Exception as e:   # noqa: BLE001 (reported by the assertion below)
+                out["err"] = e
+            finally:
+                for knob, _ in knobs:
+                    abi.set_tuning(knob, KNOB_DEFAULTS[knob])
+
+        t = threading.Thread(target=run)
+        t.start()
+        t.join()
+        assert "err" not in out, (case, pad, out.get("err"))
+        assert out["bytes"] >= ws.numel(), (case, pad)
+        gx_ref = torch.from_numpy(O.backward(go, w, x, pad, 1)[0]).to(tdt)
+        _, gw64 = O.backward(go.astype(np.float64), w.astype(np.float64), x.astype(np.float64), pad, 1)
+        tol = 1e-5 if tdt == torch.float32 else gw16_tol(torch.finfo(tdt).eps)
+        for name, (gx, gw) in (("default", (gx0, gw0)), ("given", out["given"]), ("own", out["own"])):
+            got = gx.cpu()   # (torch compares values, whatever the layout)
+            if tdt == torch.float32:
+                assert torch.equal(got, gx_ref), (case, pad, name, k0, out["kernel"])
+            else:
+                assert _ulp_close(got, gx_ref, tdt), (case, pad, name, k0, out["kernel"])
+            assert rel_err(gw.to(torch.float64).cpu().numpy(), gw64) < tol, (case, pad, name, k0, out["kernel"])

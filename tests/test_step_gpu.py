@@ -289,13 +289,11 @@ def test_3d_forwards_through_lds_vs_oracle(abi, shape, crop, dt):
     for groups in (2, 3):
         abi.set_tuning(34, groups)
         for pad in range(5):
-            out = abi.forward(xd, wd, pad, 1, b)
-            assert abi.last_kernel() == "step_active_forward", (shape, abi.last_kernel())
-            ref = torch.from_numpy(O.forward(x, w, pad, 1, b)).to(tdt)
-            if es >= 4:
+            if es >= 4:   # (16-bit volumes interpolate in walk_forward16 / the sliding window: test_3d_walk_forward_vs_oracle, test_slide_gpu.py)
+                out = abi.forward(xd, wd, pad, 1, b)
+                assert abi.last_kernel() == "step_active_forward", (shape, abi.last_kernel())
+                ref = torch.from_numpy(O.forward(x, w, pad, 1, b)).to(tdt)
                 assert torch.equal(out.cpu(), ref), ("active", shape, crop, pad, groups)
-            else:
-                assert _ulp_close(out.cpu(), ref, tdt), ("active", shape, crop, pad, groups)
             if es == 2:
                 out = abi.forward(xd, wd, pad, 0, b)
                 assert abi.last_kernel() == "step_gather_forward_lds", (shape, abi.last_kernel())

@@ -28,13 +28,15 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--iters", type=int, default=20)
 ap.add_argument("--old", action="store_true")
 ap.add_argument("--only", default=None)
+ap.add_argument("--pads", default="0,3")
 a = ap.parse_args()
 if a.old:
     abi.set_tuning(27, 1)
 SHAPES = [("r14", (128, 1024, 14, 14), torch.float32, None), ("r7", (128, 2048, 7, 7), torch.float32, None), ("r14h", (128, 1024, 14, 14), torch.float16, None),
           ("r28h", (128, 512, 28, 28), torch.bfloat16, [[1, 1], [1, 1]]),
           ("r62", (512, 16, 62, 62), torch.float32, None), ("r62c", (512, 16, 62, 62), torch.float32, [[1, 1], [1, 1]]), ("r113", (16, 64, 113, 113), torch.float32, None),
-          ("r222", (64, 256, 222, 222), torch.float32, None), ("r225", (8, 64, 225, 225), torch.float32, None), ("r222h", (64, 256, 222, 222), torch.float16, None)]
+          ("r222", (64, 256, 222, 222), torch.float32, None), ("r225", (8, 64, 225, 225), torch.float32, None), ("r222h", (64, 256, 222, 222), torch.float16, None),
+          ("c2crop", (64, 256, 224, 224), torch.float32, [[1, 1], [1, 1]]), ("c1d", (32, 512, 4096), torch.float32, None)]
 for name, shape, tdt, cut in SHAPES:
     if a.only and name not in a.only.split(","):
         continue
@@ -46,7 +48,7 @@ for name, shape, tdt, cut in SHAPES:
     es = x.element_size()
     out, gx, gw = torch.empty_like(go), torch.empty_like(x), torch.empty_like(w)
     ws = abi.backward_workspace(x, 0, 0, b)
-    for pad in (0, 3):
+    for pad in [int(v) for v in a.pads.split(",")]:
         row = "%-6s pad %d" % (name, pad)
         for active in (0, 1):
             tf = ev(lambda: abi.forward(x, w, pad, active, b, out=out), a.iters)

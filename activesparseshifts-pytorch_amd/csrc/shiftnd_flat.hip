@@ -33,7 +33,7 @@ namespace {
 constexpr int kMaxPlanes = 72;             // planes a step may touch (small planes: 4096 / plane bytes + 2)
 constexpr int kCoverBudget = 24 * 1024;    // LDS bytes per staged tensor
 
-struct FlatDesc {   // (round 5's first version: per channel, written by a prep kernel; the workspace keeps room for it)
+struct FlatDesc {   // per channel, written by flat_prep (backward)
     int cx1, cx2;   // canonical shifts of the input's row / column maps (sizes S1, S2)
     int cg1, cg2;   // ... of the gradient's maps (the window's sizes O1, O2; sparse shift: the opposite direction)
     double dw[2];   // fractions of prep_shift_backward (row, column), exactly as the compute type holds them
@@ -82,6 +82,7 @@ template <typename CT> __device__ __forceinline__ int canon_rt(CT r, int len, in
 // fold_index for PAD = kPadRT (shiftnd_step.hpp): the wrapping paddings 2 .. 4 through ONE instantiation, the mode a kernel argument;
 // both folds are (idx ^ m) + c with launch-uniform m (0 periodic, -1 reflect / symmetric) and c (shiftnd_step.hpp fold_index_rt
 // without the border mode, which keeps its own instantiation here: it clamps into the staged rows)
+constexpr int kPadRT = 5;   // template value of the flat-stream kernels: periodic, reflect or symmetric, the mode in p.pad
 struct FoldRT { int m, cn, ch; };
 __device__ __forceinline__ FoldRT fold_coeffs(int len, int pad) {
     FoldRT f;
@@ -380,6 +381,26 @@ __device__ __forceinline__ void flat_channel_backward(const FlatParams &p, int c
     cg2 = canon_rt<CT>(ACTIVE ? r2 : -r2, p.O2, p.pad, p.d_pero2);
 }
 
+// flat_prep: one thread per channel writes the channel's descriptor.  (Computing it in flat_backward itself -- every workgroup for
+// each plane it touches, tried in round 5 to save the launch -- puts weight loads and the shift arithmetic in front of a one-step
+// workgroup's first DMA: FLAT_INLINE_PREP=1 builds that form for A / B runs.)
+#ifndef FLAT_INLINE_PREP
+#define FLAT_INLINE_PREP 0
+#endif
+template <typename T>
+__global__ __launch_bounds__(kThreads) void flat_prep(const FlatParams p, const int active) {
+    using CT = typename T::C;
+    const int c = static_cast<int>(blockIdx.x * kThreads + threadIdx.x);
+    if (c >= p.C) return;
+    FlatDesc d;
+    CT f1, f2;
+    if (active) flat_channel_backward<CT, true>(p, c, d.cx1, d.cx2, d.cg1, d.cg2, f1, f2);
+    else flat_channel_backward<CT, false>(p, c, d.cx1, d.cx2, d.cg1, d.cg2, f1, f2);
+    d.dw[0] = static_cast<double>(f1);
+    d.dw[1] = static_cast<double>(f2);
+    p.desc[c] = d;
+}
+
 // ---------------------------------------------------------------------------------------------------------------------
 // flat_backward<T, ACTIVE, PADZ, SMALL>.  LDS: [plane table][per-chunk partial sums][cover of x][cover of grad_out]
 // ---------------------------------------------------------------------------------------------------------------------
@@ -413,7 +434,17 @@ __global__ __launch_bounds__(kThreads) void flat_backward(const FlatParams p, in
 
     auto fill = [&](uint32_t pl, Rec &r) {
         const int c = static_cast<int>(pl - fdiv(pl, p.d_C) * static_cast<uint32_t>(p.C));
+#if FLAT_INLINE_PREP
         flat_channel_backward<CT, ACTIVE>(p, c, r.c1, r.c2, r.g1, r.g2, r.f1, r.f2);
+#else
+        const FlatDesc d = p.desc[c];
+        r.c1 = d.cx1;
+        r.c2 = d.cx2;
+        r.g1 = d.cg1;
+        r.g2 = d.cg2;
+        r.f1 = static_cast<CT>(d.dw[0]);
+        r.f2 = static_cast<CT>(d.dw[1]);
+#endif
     };
     if constexpr (SMALL) {
         const Cover cx = row_cover<ES>(plA, p.XP, S2, 0, static_cast<int>((plB - plA + 1) * static_cast<uint32_t>(S1)) - 1);
@@ -791,6 +822,7 @@ void launch_flat_forward(const FlatParams &p, size_t lds, int pad, hipStream_t s
 template <typename T, bool ACTIVE, bool SMALL>
 void launch_flat_backward(const FlatParams &p, const FlatPlan &pl, int pad, int N, void *gw, hipStream_t st) {
     const dim3 grid(p.steps_per_xcd * 8), block(kThreads);
+    if (!FLAT_INLINE_PREP) hipLaunchKernelGGL((flat_prep<T>), dim3((p.C + kThreads - 1) / kThreads), block, 0, st, p, ACTIVE ? 1 : 0);
     switch (pad) {
     case 0: hipLaunchKernelGGL((flat_backward<T, ACTIVE, 0, SMALL>), grid, block, pl.lds, st, p, pl.gcov_off); break;
     case 1: hipLaunchKernelGGL((flat_backward<T, ACTIVE, 1, SMALL>), grid, block, pl.lds, st, p, pl.gcov_off); break;

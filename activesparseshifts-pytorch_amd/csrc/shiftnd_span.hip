@@ -57,8 +57,8 @@ struct SpanParams {
 // ---------------------------------------------------------------------------------------------------------------------
 // span_prep: one workgroup per channel
 // ---------------------------------------------------------------------------------------------------------------------
-template <typename T, bool ACTIVE>
-__global__ __launch_bounds__(kThreads) void span_prep(const SpanParams p) {
+template <typename T>
+__global__ __launch_bounds__(kThreads) void span_prep(const SpanParams p, const bool ACTIVE) {
     using S = typename T::S;
     using CT = typename T::C;
     constexpr int E = 16 / sizeof(S);
@@ -123,34 +123,6 @@ __global__ __launch_bounds__(kThreads) void span_prep(const SpanParams p) {
 // E + 1 elements of a source row through a column state: from the staged slot, or -- a chunk whose columns are not all among the
 // staged ones (only a column segment of the row is staged when rows are longer than a workgroup pass: the chunks that wrap,
 // clamp or reflect at the row ends then read elsewhere) -- element by element from memory
-// span_prep's descriptor computed in the kernel that needs it -- zeros padding has no column tables, and a prep kernel of its own costs
-// a 70 us call 4.5 us (round 5).  The first step of the first batch entry leaves the descriptor in p.desc for step_reduce.
-template <typename T, bool ACTIVE>
-__device__ __forceinline__ ChanDesc span_desc_zeros(const SpanParams &p, int c, bool publish) {
-    using CT = typename T::C;
-    const int lead = 2 - p.nd;
-    int64_t sh[2] = {0, 0};
-    CT dw[2] = {CT(0), CT(0)};
-    for (int r = 0; r < p.nd; ++r) {
-        const CT wv = load_weight<CT>(p.w, p.wkind, static_cast<int64_t>(c) * p.nd + r);
-        prep_shift_backward<CT>(wv, ACTIVE, sh[r + lead], dw[r]);
-    }
-    ChanDesc d;
-    d.cx0 = d.cg0 = 0;
-    d.cx1 = canon_shift(sh[0], p.S1, 0, p.d_per1x);
-    d.cx2 = canon_shift(sh[1], p.S2, 0, p.d_per2x);
-    d.cg1 = canon_shift(ACTIVE ? sh[0] : -sh[0], p.O1, 0, p.d_per1g);
-    d.cg2 = canon_shift(ACTIVE ? sh[1] : -sh[1], p.O2, 0, p.d_per2g);
-    d.scat = 0;
-    d.pad_ = 0;
-    d.dw[0] = static_cast<double>(dw[0]);
-    d.dw[1] = static_cast<double>(dw[1]);
-    d.dw[2] = 0.0;
-    d.pad2_ = 0.0;
-    if (publish && threadIdx.x == 0) p.desc[c] = d;
-    return d;
-}
-
 template <typename S, int E>
 __device__ __forceinline__ void span_read(const char *lds_row, const S *mem_row, bool staged, bool valid, const ColState<E> &c, S (&raw)[E + 1]) {
     if (valid && !staged) {
@@ -194,7 +166,7 @@ __global__ __launch_bounds__(kThreads) void crop_backward(const SpanParams p) {
     const uint32_t plane = fdiv(bid, p.d_spp);   // (n, c)
     const int step = static_cast<int>(bid - plane * static_cast<uint32_t>(p.spp));
     const int c = static_cast<int>(plane - fdiv(plane, p.d_C) * static_cast<uint32_t>(p.C));
-    const ChanDesc d = PAD == 0 ? span_desc_zeros<T, ACTIVE>(p, c, plane < static_cast<uint32_t>(p.C) && step == 0) : p.desc[c];
+    const ChanDesc d = p.desc[c];
     const int R = p.R, S1 = p.S1, S2 = p.S2, O1 = p.O1, O2 = p.O2, L1 = p.L1, L2 = p.L2, cpr = p.cpr;
     const int b0 = step * R;
     const int Rn = min(R, S1 - b0);
@@ -408,7 +380,7 @@ struct SpanFwdParams {
     void *out;
     const void *w;
     int64_t x_plane, o_plane;   // elements per (n, c)
-    int wkind, C, nd, pad;   // pad: the padding mode (the PAD = kPadRT instantiations read it)
+    int wkind, C, nd, pad;   // pad: the padding mode (the PAD = kPadMirror instantiations read it: reflect or symmetric)
     int S1, S2, O1, O2, L1, L2;
     int ocp, cps, spp;   // 16-byte chunks per output plane, chunks per step (256; 254 when only a column segment is staged), steps per plane
     int P, wholeP;       // pieces per slot; the same when whole rows are staged (0: only the columns the step reaches)
@@ -424,7 +396,7 @@ struct SpanFwdParams {
 // output row reads its window through ColState; a chunk that straddles rows goes element by element, without branches
 // (clamped index + select).
 // ---------------------------------------------------------------------------------------------------------------------
-template <typename T, bool ACTIVE, int PAD>
+template <typename T, bool ACTIVE, int PAD, int U = 1>
 __global__ __launch_bounds__(kThreads) void crop_forward(const SpanFwdParams p) {
     using S = typename T::S;
     using CT = typename T::C;
@@ -446,7 +418,9 @@ __global__ __launch_bounds__(kThreads) void crop_forward(const SpanFwdParams p) 
     const int cs1 = __builtin_amdgcn_readfirstlane(canon_of<PAD, CT>(rr, S1, p.d_per1, p.pad));
     const int cs2 = __builtin_amdgcn_readfirstlane(canon_of<PAD, CT>(rc, S2, p.d_per2, p.pad));
 
-    const int q0 = step * kThreads, q1 = min(p.ocp, q0 + kThreads);
+    // U chunks per thread (the interpolating shift: a step of 512 chunks stages 11 source rows for 9.2 output rows of 222 fp32, a step
+    // of 256 seven for 4.6 -- a quarter less through the LDS-DMA path, and half the per-step scalar work)
+    const int q0 = step * (U * kThreads), q1 = min(p.ocp, q0 + U * kThreads);
     const int F0 = q0 * E, F1 = q1 * E;
     const int r0 = static_cast<int>(fdiv(static_cast<uint32_t>(F0), p.d_O2)), r1 = static_cast<int>(fdiv(static_cast<uint32_t>(F1 - 1), p.d_O2));
     const int nr = r1 - r0 + 1 + (ACTIVE ? 1 : 0);   // staged source rows: those of output rows r0 .. r1 (+ the corner row)
@@ -467,8 +441,12 @@ __global__ __launch_bounds__(kThreads) void crop_forward(const SpanFwdParams p) 
                                              (__attribute__((address_space(3))) void *)dst_wave, 16, 0, 0);
         }
     }
-    // ---- the thread's chunk ---------------------------------------------------------------------------------------------------
-    const int q = q0 + tid;
+    // ---- the thread's chunks --------------------------------------------------------------------------------------------------
+    auto row_ok = [&](int slot) { return PAD != 0 || row_map_t<PAD>(r0 + slot + L1, cs1, S1, p.pad) >= 0; };
+    const S zero = static_cast<S>(0.0f);   // (a value, not an object the lambdas below could take the address of: that one went to scratch)
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+    const int q = q0 + u * kThreads + tid;
     const int e0 = q * E;
     const int r = q < q1 ? static_cast<int>(fdiv(static_cast<uint32_t>(e0), p.d_O2)) : r0;
     const int j = e0 - r * O2;
@@ -482,10 +460,10 @@ __global__ __launch_bounds__(kThreads) void crop_forward(const SpanFwdParams p) 
     } else {
         xm = fold_colstate<E, PAD>(j + L2, cs2, S2, p.pad);
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    auto row_ok = [&](int slot) { return PAD != 0 || row_map_t<PAD>(r0 + slot + L1, cs1, S1, p.pad) >= 0; };
-    const S zero = static_cast<S>(0.0f);   // (a value, not an object the lambdas below could take the address of: that one went to scratch)
+    if (u == 0) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
     if (q < q1 && j + E <= O2) {   // the chunk lies in one output row
         Chunk<S, E> res;
         const int slot = r - r0;
@@ -512,6 +490,7 @@ __global__ __launch_bounds__(kThreads) void crop_forward(const SpanFwdParams p) 
             for (int e = 0; e < E; ++e) res.e[e] = raw[e];
         }
         store_chunk<S, E>(op + e0, res);
+    }
     }
     // The chunks that straddle output rows -- at most one per row boundary inside the step -- are done afterwards by the first
     // wave alone, one boundary per lane, element by element (clamped reads, then one select each).  Inside the chunk loop
@@ -757,7 +736,7 @@ __global__ __launch_bounds__(kThreads) void row_backward(const SpanParams p) {
     const uint32_t plane = fdiv(bid, p.d_spp);   // (n, c): one row
     const int sg = static_cast<int>(bid - plane * static_cast<uint32_t>(p.spp));
     const int c = static_cast<int>(plane - fdiv(plane, p.d_C) * static_cast<uint32_t>(p.C));
-    const ChanDesc d = PAD == 0 ? span_desc_zeros<T, ACTIVE>(p, c, plane < static_cast<uint32_t>(p.C) && sg == 0) : p.desc[c];
+    const ChanDesc d = p.desc[c];
     const int S2 = p.S2, O2 = p.O2, L2 = p.L2, cpr = p.cpr;
     const int J0 = sg * kThreads * E, J1 = min(S2, J0 + kThreads * E);   // the segment's columns of the x row
     auto clampi = [](int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); };
@@ -1018,11 +997,24 @@ bool span_forward_eligible(const Geometry &g, int dtype, const void *x, const vo
 }
 
 // crop_forward: 2-D, source rows of whole pieces (at most 256), at most four staging rounds
+// source rows a step of `chunks` output chunks stages (the corner row of the interpolating shift included)
+static int64_t crop_forward_rows(const Geometry &g, int es, int chunks) {
+    const int E = 16 / es;
+    return std::min<int64_t>(g.O[1], (static_cast<int64_t>(chunks) * E + g.O[2] - 2) / g.O[2] + 1) + (g.active ? 1 : 0);
+}
+
 static bool crop_forward_ok(const Geometry &g, int es) {
     if (g.nd != 2 || (g.S[2] * es) % 16 != 0 || g.S[2] * es > kThreads * 16) return false;
-    const int E = 16 / es;
-    const int64_t rows = std::min<int64_t>(g.O[1], (static_cast<int64_t>(kThreads) * E + g.O[2] - 2) / g.O[2] + 1) + (g.active ? 1 : 0);
-    return rows * (g.S[2] * es / 16) <= 4 * kThreads;
+    return crop_forward_rows(g, es, kThreads) * (g.S[2] * es / 16) <= 4 * kThreads;
+}
+
+// chunks per thread of crop_forward: two for the interpolating shift on planes of more than one such step whose rows fit 24 KiB of LDS
+// (knob 35 bit 1 = 2: always one)
+static int crop_forward_groups(const Geometry &g, int es) {
+    if (!g.active || (g_step_tune[3] & 2)) return 1;
+    const int64_t ocp = (g.O[1] * g.O[2] * es + 15) / 16;
+    if (ocp <= 2 * kThreads) return 1;
+    return crop_forward_rows(g, es, 2 * kThreads) * (g.S[2] * es / 16) <= 6 * kThreads ? 2 : 1;
 }
 
 int span_forward(const Geometry &g, int dtype, const void *x, const void *w, int wkind, void *out, hipStream_t st) {
@@ -1063,8 +1055,12 @@ int span_forward(const Geometry &g, int dtype, const void *x, const void *w, int
         note_kernel(act ? "ragged_active_forward" : "ragged_gather_forward");
         const dim3 grid(p.steps_per_xcd * 8), block(kThreads);
 #define SHIFTND_RAG_FWD(TT, ACT) \
-        if (g.pad == 0) hipLaunchKernelGGL((ragged_forward<TT, ACT, 0>), grid, block, lds, st, p); \
-        else hipLaunchKernelGGL((ragged_forward<TT, ACT, kPadRT>), grid, block, lds, st, p);
+        switch (pad_template(g.pad)) { \
+        case 0: hipLaunchKernelGGL((ragged_forward<TT, ACT, 0>), grid, block, lds, st, p); break; \
+        case 1: hipLaunchKernelGGL((ragged_forward<TT, ACT, 1>), grid, block, lds, st, p); break; \
+        case 2: hipLaunchKernelGGL((ragged_forward<TT, ACT, 2>), grid, block, lds, st, p); break; \
+        default: hipLaunchKernelGGL((ragged_forward<TT, ACT, kPadMirror>), grid, block, lds, st, p); break; \
+        }
         if (!act) {   // a raw copy: one instantiation per element size
             if (es == 2) { SHIFTND_RAG_FWD(f16_t, false) } else if (es == 4) { SHIFTND_RAG_FWD(f32_t, false) } else { SHIFTND_RAG_FWD(f64_t, false) }
         } else if (dtype == SHIFTND_F32) { SHIFTND_RAG_FWD(f32_t, true)
@@ -1085,12 +1081,13 @@ int span_forward(const Geometry &g, int dtype, const void *x, const void *w, int
         sp.lds = 64 + (kThreads + 3) * 16 + 64;
     }
     const bool lean = crop_forward_ok(g, es);
+    int cropU = 1;
     if (lean) {   // whole source rows, exact pitch
-        const int E = 16 / es;
-        const int64_t rows = std::min<int64_t>(g.O[1], (static_cast<int64_t>(kThreads) * E + g.O[2] - 2) / g.O[2] + 1) + (g.active ? 1 : 0);
+        cropU = crop_forward_groups(g, es);
+        const int64_t rows = crop_forward_rows(g, es, cropU * kThreads);
         sp.P = sp.wholeP = static_cast<int>(g.S[2] * es / 16);
-        sp.cps = kThreads;
-        sp.spp = (sp.ocp + kThreads - 1) / kThreads;
+        sp.cps = cropU * kThreads;
+        sp.spp = (sp.ocp + sp.cps - 1) / sp.cps;
         sp.total = static_cast<uint64_t>(g.N) * g.C * sp.spp;
         sp.lds = 64 + ((static_cast<size_t>(rows) * sp.P * 16 + 63) & ~static_cast<size_t>(63)) + 64;
     }
@@ -1128,8 +1125,12 @@ int span_forward(const Geometry &g, int dtype, const void *x, const void *w, int
         note_kernel(active ? "row_active_forward" : "row_gather_forward");
         const dim3 grid(p.steps_per_xcd * 8), block(kThreads);
 #define SHIFTND_ROW_FWD(TT, ACT) \
-        if (g.pad == 0) hipLaunchKernelGGL((row_forward<TT, ACT, 0>), grid, block, sp.lds, st, p); \
-        else hipLaunchKernelGGL((row_forward<TT, ACT, kPadRT>), grid, block, sp.lds, st, p);
+        switch (pad_template(g.pad)) { \
+        case 0: hipLaunchKernelGGL((row_forward<TT, ACT, 0>), grid, block, sp.lds, st, p); break; \
+        case 1: hipLaunchKernelGGL((row_forward<TT, ACT, 1>), grid, block, sp.lds, st, p); break; \
+        case 2: hipLaunchKernelGGL((row_forward<TT, ACT, 2>), grid, block, sp.lds, st, p); break; \
+        default: hipLaunchKernelGGL((row_forward<TT, ACT, kPadMirror>), grid, block, sp.lds, st, p); break; \
+        }
         if (!active) {
             if (es == 2) { SHIFTND_ROW_FWD(f16_t, false) } else if (es == 4) { SHIFTND_ROW_FWD(f32_t, false) } else { SHIFTND_ROW_FWD(f64_t, false) }
         } else if (dtype == SHIFTND_F32) { SHIFTND_ROW_FWD(f32_t, true)
@@ -1142,9 +1143,15 @@ int span_forward(const Geometry &g, int dtype, const void *x, const void *w, int
     if (lean) {
         note_kernel(active ? "crop_active_forward" : "crop_gather_forward");
         const dim3 grid(p.steps_per_xcd * 8), block(kThreads);
+#define SHIFTND_CROP_FWD_U(TT, ACT, UU) \
+        switch (pad_template(g.pad)) { \
+        case 0: hipLaunchKernelGGL((crop_forward<TT, ACT, 0, UU>), grid, block, sp.lds, st, p); break; \
+        case 1: hipLaunchKernelGGL((crop_forward<TT, ACT, 1, UU>), grid, block, sp.lds, st, p); break; \
+        case 2: hipLaunchKernelGGL((crop_forward<TT, ACT, 2, UU>), grid, block, sp.lds, st, p); break; \
+        default: hipLaunchKernelGGL((crop_forward<TT, ACT, kPadMirror, UU>), grid, block, sp.lds, st, p); break; \
+        }
 #define SHIFTND_CROP_FWD(TT, ACT) \
-        if (g.pad == 0) hipLaunchKernelGGL((crop_forward<TT, ACT, 0>), grid, block, sp.lds, st, p); \
-        else hipLaunchKernelGGL((crop_forward<TT, ACT, kPadRT>), grid, block, sp.lds, st, p);
+        if (ACT && cropU == 2) { SHIFTND_CROP_FWD_U(TT, ACT, (ACT ? 2 : 1)) } else { SHIFTND_CROP_FWD_U(TT, ACT, 1) }
         if (!active) {   // a raw copy: one instantiation per element size
             if (es == 2) { SHIFTND_CROP_FWD(f16_t, false) } else if (es == 4) { SHIFTND_CROP_FWD(f32_t, false) } else { SHIFTND_CROP_FWD(f64_t, false) }
         } else if (dtype == SHIFTND_F32) { SHIFTND_CROP_FWD(f32_t, true)
@@ -1152,6 +1159,7 @@ int span_forward(const Geometry &g, int dtype, const void *x, const void *w, int
         } else if (dtype == SHIFTND_F16) { SHIFTND_CROP_FWD(f16_t, true)
         } else { SHIFTND_CROP_FWD(bf16_t, true) }
 #undef SHIFTND_CROP_FWD
+#undef SHIFTND_CROP_FWD_U
         return SHIFTND_OK;
     }
     return SHIFTND_ERR_INVALID_ARGUMENT;   // (span_forward_eligible admits nothing else)
@@ -1183,17 +1191,19 @@ static void launch_span_backward(const SpanParams &p, const SpanPlan &sp, bool a
     using S = typename T::S;
     const dim3 grid(p.steps_per_xcd * 8), block(kThreads);
 #define SHIFTND_SPAN_PAD(ACT, PADV) \
-    { \
+    case PADV: \
         if constexpr (ND == 2) hipLaunchKernelGGL((crop_backward<T, ACT, PADV, XRAG>), grid, block, sp.lds, st, p); \
         else hipLaunchKernelGGL((row_backward<T, ACT, PADV>), grid, block, sp.lds, st, p); \
-    }
-    // (zeros padding: no column tables -- the kernels prepare their channel themselves and publish the descriptor for step_reduce)
+        break;
+    // (the channel descriptors come from span_prep for every padding: computing them in crop_backward itself -- tried in round 5 to save
+    //  the 4.5 us launch -- put weight loads and 64-bit shift arithmetic in front of every one-step workgroup's first DMA: N64 C256
+    //  224x224 cut 1/1 fp32 1.65 -> 2.02 ms)
     if (active) {
-        if (p.pad != 0) hipLaunchKernelGGL((span_prep<T, true>), dim3(p.C), block, 0, st, p);
-        if (p.pad == 0) SHIFTND_SPAN_PAD(true, 0) else SHIFTND_SPAN_PAD(true, kPadRT)
+        hipLaunchKernelGGL((span_prep<T>), dim3(p.C), block, 0, st, p, true);
+        switch (pad_template(p.pad)) { SHIFTND_SPAN_PAD(true, 0) SHIFTND_SPAN_PAD(true, 1) SHIFTND_SPAN_PAD(true, 2) default: SHIFTND_SPAN_PAD(true, 3) }
     } else {
-        if (p.pad != 0) hipLaunchKernelGGL((span_prep<T, false>), dim3(p.C), block, 0, st, p);
-        if (p.pad == 0) SHIFTND_SPAN_PAD(false, 0) else SHIFTND_SPAN_PAD(false, kPadRT)
+        hipLaunchKernelGGL((span_prep<T>), dim3(p.C), block, 0, st, p, false);
+        switch (pad_template(p.pad)) { SHIFTND_SPAN_PAD(false, 0) SHIFTND_SPAN_PAD(false, 1) SHIFTND_SPAN_PAD(false, 2) default: SHIFTND_SPAN_PAD(false, 3) }
     }
 #undef SHIFTND_SPAN_PAD
     // the channel sums and the blends: step_reduce reads the record layout through StepParams

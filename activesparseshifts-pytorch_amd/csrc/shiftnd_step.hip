@@ -90,8 +90,8 @@ __global__ __launch_bounds__(kThreads) void step_backward(const StepParams p) {
     int pax[NP], pag[NP];
 #pragma unroll
     for (int h = 0; h < NP; ++h) {
-        pax[h] = ND == 3 ? row_map_t<PAD>(a + h, d.cx0, S0) : 0;
-        pag[h] = ND == 3 ? row_map_t<PAD>(a + h, d.cg0, S0) : 0;
+        pax[h] = ND == 3 ? row_map_t<PAD>(a + h, d.cx0, S0, p.pad) : 0;
+        pag[h] = ND == 3 ? row_map_t<PAD>(a + h, d.cg0, S0, p.pad) : 0;
     }
 
     // ---- the thread's chunk: column state through both maps -----------------------------------------------------
@@ -186,7 +186,7 @@ __global__ __launch_bounds__(kThreads) void step_backward(const StepParams p) {
     for (int u = 0; u < U; ++u) {
     if (tr < R) {
         const int vtr = tr + u * R, vtid = tid + u * R * cpr;  // this row group's row / piece index
-        const int sx = vtr <= Rn ? row_map_t<PAD>(b0 + vtr, d.cx1, S1) : -1;  // corner rows of x: m1[b0 + tr]
+        const int sx = vtr <= Rn ? row_map_t<PAD>(b0 + vtr, d.cx1, S1, p.pad) : -1;  // corner rows of x: m1[b0 + tr]
 #pragma unroll
         for (int h = 0; h < NP; ++h)
             if (sx >= 0 && pax[h] >= 0) dma(xp, pax[h] * S1 + sx, tc, h * (RT + 1) * cpr + u * R * cpr);
@@ -195,7 +195,7 @@ __global__ __launch_bounds__(kThreads) void step_backward(const StepParams p) {
             else dma(gp, a * S1 + b0 + vtr, tc, NX * cpr + u * R * cpr);
         }
         if constexpr (ACTIVE) {
-            const int sg = vtr <= Rn ? row_map_t<PAD>(b0 + vtr, d.cg1, S1) : -1;  // the rows grad_x blends: g1[b0 + tr]
+            const int sg = vtr <= Rn ? row_map_t<PAD>(b0 + vtr, d.cg1, S1, p.pad) : -1;  // the rows grad_x blends: g1[b0 + tr]
             if constexpr (POOL) {
                 if (sg >= 0) pqB = pooled_load(sg, tc, (NX + NG) * cpr + vtid);
             } else {
@@ -204,18 +204,18 @@ __global__ __launch_bounds__(kThreads) void step_backward(const StepParams p) {
                     if (sg >= 0 && pag[h] >= 0) dma(gp, pag[h] * S1 + sg, tc, (NX + NG + h * (RT + 1)) * cpr + u * R * cpr);
             }
         } else if constexpr (!SCAT) {
-            const int sg = vtr < Rn ? row_map_t<PAD>(b0 + vtr, d.cg1, S1) : -1;  // 3-D sparse shift: the one row grad_x copies
+            const int sg = vtr < Rn ? row_map_t<PAD>(b0 + vtr, d.cg1, S1, p.pad) : -1;  // 3-D sparse shift: the one row grad_x copies
             if (sg >= 0 && pag[0] >= 0) dma(gp, pag[0] * S1 + sg, tc, (NX + NG) * cpr + u * R * cpr);
         }
     }
     }
     if (Rn == RT && tid < cpr) {  // the + 1 corner row of a full step (a ragged last step has it among its first R rows)
-        const int sx = row_map_t<PAD>(b0 + RT, d.cx1, S1);
+        const int sx = row_map_t<PAD>(b0 + RT, d.cx1, S1, p.pad);
 #pragma unroll
         for (int h = 0; h < NP; ++h)
             if (sx >= 0 && pax[h] >= 0) dma(xp, pax[h] * S1 + sx, tid, (h * (RT + 1) + RT) * cpr);
         if constexpr (ACTIVE) {
-            const int sg = row_map_t<PAD>(b0 + RT, d.cg1, S1);
+            const int sg = row_map_t<PAD>(b0 + RT, d.cg1, S1, p.pad);
             if constexpr (POOL) {
                 if (sg >= 0) pqC = pooled_load(sg, tid, (NX + NG + RT) * cpr + tid);
             } else {
@@ -295,7 +295,7 @@ __global__ __launch_bounds__(kThreads) void step_backward(const StepParams p) {
         CT dw[3] = {static_cast<CT>(d.dw[0]), static_cast<CT>(d.dw[1]), static_cast<CT>(d.dw[2])};
         Chunk<S, E> res;
         // only zeros padding has rows without a source
-        auto row_valid = [&](int pr, int cs) { return PAD != 0 || row_map_t<PAD>(pr, cs, S1) >= 0; };
+        auto row_valid = [&](int pr, int cs) { return PAD != 0 || row_map_t<PAD>(pr, cs, S1, p.pad) >= 0; };
         // corner row k of an element: bit 0 = + 1 plane (3-D), next bit = + 1 row
         auto corner_plane = [](int k) { return ND == 3 ? (k & 1) : 0; };
         auto corner_row = [](int k) { return ND == 3 ? ((k >> 1) & 1) : (k & 1); };
@@ -372,12 +372,12 @@ __global__ __launch_bounds__(kThreads) void step_backward(const StepParams p) {
         if constexpr (SCAT) {
             // periodic padding is a permutation (the x map is the inverse of the grad map); otherwise row b - shift when
             // that is a row, and the rows no grad_out row reaches are the tail below
-            const int brow = PAD == 2 ? row_map_t<PAD>(b, d.cx1, S1) : b - d.scat;
+            const int brow = PAD == 2 ? row_map_t<PAD>(b, d.cx1, S1, p.pad) : b - d.scat;
             if (brow >= 0 && brow < S1) store_chunk<S, E>(gxp + static_cast<int64_t>(brow) * S2 + ji, res);
             if (PAD != 2 && d.scat != 0) {
                 const int e0 = d.scat > 0 ? max(S1 - d.scat, 0) : 0, e1 = d.scat > 0 ? S1 : min(-d.scat, S1);
                 if (b >= e0 && b < e1) {  // this row of grad_x has no source by the plain shift: fill, or a clamped / reflected row
-                    const int src = row_map_t<PAD>(b, d.cg1, S1);
+                    const int src = row_map_t<PAD>(b, d.cg1, S1, p.pad);
                     S zero;
                     __builtin_memset(&zero, 0, sizeof(S));
                     Chunk<S, E> t;
@@ -449,9 +449,9 @@ int launch_step_backward(StepParams &p, const StepLayout &L, bool active, void *
         hipLaunchKernelGGL((step_backward<T, ND, ACT, PADV>), grid, block, lds, st, p); break;
     launch_step_prep(T::kDtype, active, p, st);
     if (active) {
-        switch (p.pad) { SHIFTND_STEP_PAD(true, 0) SHIFTND_STEP_PAD(true, 1) SHIFTND_STEP_PAD(true, 2) SHIFTND_STEP_PAD(true, 3) default: SHIFTND_STEP_PAD(true, 4) }
+        switch (p.pad) { SHIFTND_STEP_PAD(true, 0) SHIFTND_STEP_PAD(true, 1) SHIFTND_STEP_PAD(true, 2) default: SHIFTND_STEP_PAD(true, 3) }   // (3 = reflect and symmetric: shiftnd_step.hpp kPadMirror)
     } else {
-        switch (p.pad) { SHIFTND_STEP_PAD(false, 0) SHIFTND_STEP_PAD(false, 1) SHIFTND_STEP_PAD(false, 2) SHIFTND_STEP_PAD(false, 3) default: SHIFTND_STEP_PAD(false, 4) }
+        switch (p.pad) { SHIFTND_STEP_PAD(false, 0) SHIFTND_STEP_PAD(false, 1) SHIFTND_STEP_PAD(false, 2) default: SHIFTND_STEP_PAD(false, 3) }
     }
 #undef SHIFTND_STEP_PAD
     launch_step_reduce(T::kDtype, ND, p, gw, st);
@@ -462,9 +462,7 @@ int launch_step_backward(StepParams &p, const StepLayout &L, bool active, void *
 
 void launch_step_prep(int dtype, bool active, const StepParams &p, hipStream_t st) {
     const dim3 grid(p.C), block(kThreads);
-#define SHIFTND_PREP(TT) \
-    if (active) hipLaunchKernelGGL((step_prep<TT, true>), grid, block, 0, st, p); \
-    else hipLaunchKernelGGL((step_prep<TT, false>), grid, block, 0, st, p);
+#define SHIFTND_PREP(TT) hipLaunchKernelGGL((step_prep<TT>), grid, block, 0, st, p, active);
     switch (dtype) {
     case SHIFTND_F32: SHIFTND_PREP(f32_t) break;
     case SHIFTND_F64: SHIFTND_PREP(f64_t) break;
@@ -476,10 +474,7 @@ void launch_step_prep(int dtype, bool active, const StepParams &p, hipStream_t s
 
 void launch_step_reduce(int dtype, int nd, const StepParams &p, void *grad_w, hipStream_t st) {
     const dim3 grid(p.C), block(kThreads);
-#define SHIFTND_REDUCE(TT) \
-    if (nd == 1) hipLaunchKernelGGL((step_reduce<TT, 1>), grid, block, 0, st, p, static_cast<typename TT::S *>(grad_w)); \
-    else if (nd == 2) hipLaunchKernelGGL((step_reduce<TT, 2>), grid, block, 0, st, p, static_cast<typename TT::S *>(grad_w)); \
-    else hipLaunchKernelGGL((step_reduce<TT, 3>), grid, block, 0, st, p, static_cast<typename TT::S *>(grad_w));
+#define SHIFTND_REDUCE(TT) hipLaunchKernelGGL((step_reduce<TT>), grid, block, 0, st, p, static_cast<typename TT::S *>(grad_w), nd);
     switch (dtype) {
     case SHIFTND_F32: SHIFTND_REDUCE(f32_t) break;
     case SHIFTND_F64: SHIFTND_REDUCE(f64_t) break;

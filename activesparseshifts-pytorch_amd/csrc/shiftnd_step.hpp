@@ -71,8 +71,8 @@ __device__ __forceinline__ int row_map(int p, int cs, int len, int pad) { return
 // step_prep: one workgroup per channel -- the weight preparation of the reference (shifts_cuda.cu:168-199) plus the
 // channel's column maps in the form the step kernels read them
 // ---------------------------------------------------------------------------------------------------------------------
-template <typename T, bool ACTIVE>
-__global__ __launch_bounds__(kThreads) void step_prep(const StepParams p) {
+template <typename T>
+__global__ __launch_bounds__(kThreads) void step_prep(const StepParams p, const bool ACTIVE) {   // (ACTIVE: a launch argument -- one kernel per dtype)
     using S = typename T::S;
     using CT = typename T::C;
     constexpr int E = 16 / sizeof(S);
@@ -180,42 +180,34 @@ __device__ __forceinline__ double wave_total(double v) {
 // run-time padding switch there costs more scalar-unit time than a one-step workgroup has (one scalar unit per CU;
 // shiftnd_common.hpp fold_index is 2 - 5 VALU instructions once the mode is known).
 // ---------------------------------------------------------------------------------------------------------------------
-// PAD = kPadRT: one instantiation for the four non-zeros paddings, the mode (1 .. 4) a kernel argument (`rt`).  The row-span and
-// flat-stream kernels take it -- their hot bench shapes use zeros padding, and five copies of each were 60 % of their 390 kernels;
-// the one-step and walk kernels (the C2 / C3 padding rows of the bench) keep the compile-time modes.
-constexpr int kPadRT = 5;
+// PAD as a template parameter takes the values 0 .. 3, and 3 stands for BOTH mirroring modes: reflect (3) and symmetric (4) differ
+// by a constant -- k = pad - 3 -- in each of their two folds,
+//     idx < 0:        -idx      / -idx - 1         = max(idx, -k - idx)
+//     idx > len - 1:  2 (len - 1) - idx / 2 len - 1 - idx = min(t, 2 (len - 1) + k - t)
+// two VALU instructions each with k in a scalar register: the same count as the compile-time forms, one instantiation instead of two.
+// `rt` is the kernel's padding argument (p.pad); it only matters for PAD = 3.  (A run-time mode for all four non-zeros paddings was
+// measured on the row-span kernels: + 13 .. 30 % on their forwards, + 5 .. 20 % on the backwards -- ten VALU instructions per fold
+// against two to five; the flat-stream kernels, whose per-element path hides it, merge the three wrapping modes: shiftnd_flat.hip.)
+constexpr int kPadMirror = 3;
+constexpr int pad_template(int pad) { return pad >= kPadMirror ? kPadMirror : pad; }
 
-// fold_index for a run-time mode in 1 .. 4, branch-free: both folds are  ((idx ^ m) & am) + c  with launch-uniform m, am, c
-//   border     0 / len - 1              m = 0,  am = 0
-//   periodic   idx + len / idx - len    m = 0,  am = -1
-//   reflect    -idx / 2 (len - 1) - idx m = -1, am = -1   (-idx = ~idx + 1)
-//   symmetric  -idx - 1 / 2 len - 1 - idx
-__device__ __forceinline__ int fold_index_rt(int idx, int len, int pad) {
-    const int m = pad >= 3 ? -1 : 0, am = pad == 1 ? 0 : -1;
-    const int cn = pad == 2 ? len : (pad == 3 ? 1 : 0);
-    const int ch = pad == 1 ? len - 1 : (pad == 2 ? -len : (pad == 3 ? 2 * (len - 1) + 1 : 2 * len));
-    const int t = idx < 0 ? ((idx ^ m) & am) + cn : idx;
-    return t > len - 1 ? ((t ^ m) & am) + ch : t;
+__device__ __forceinline__ int fold_mirror(int idx, int len, int k) {
+    const int t = max(idx, -k - idx);
+    return min(t, 2 * (len - 1) + k - t);
 }
 
-template <int PAD> __device__ __forceinline__ int row_map_t(int p, int cs, int len, int rt = 0) {
-    if constexpr (PAD == kPadRT) return len == 1 ? 0 : fold_index_rt(p - cs, len, rt);
+template <int PAD> __device__ __forceinline__ int row_map_t(int p, int cs, int len, int rt = kPadMirror) {
+    if constexpr (PAD == kPadMirror) return len == 1 ? 0 : fold_mirror(p - cs, len, rt - kPadMirror);
     else return len == 1 ? 0 : fold_index(p - cs, len, PAD);
 }
 
 // canon_shift (shiftnd_common.hpp) for |s| < 2^30 and a compile-time padding mode, all in 32 bits
-template <int PAD> __device__ __forceinline__ int canon_shift32(int s, int len, const FastDiv &dper, int rt = 0) {
+template <int PAD> __device__ __forceinline__ int canon_shift32(int s, int len, const FastDiv &dper, int rt = kPadMirror) {
     if (len <= 1) return 0;
-    if constexpr (PAD == kPadRT) {
-        if (rt <= 1) return s < -len - 1 ? -len - 1 : (s > len + 1 ? len + 1 : s);
-        const int period = rt == 2 ? len : (rt == 3 ? 2 * (len - 1) : 2 * len);
-        const uint32_t a = static_cast<uint32_t>(s < 0 ? -s : s);
-        const uint32_t m = a - fdiv(a, dper) * static_cast<uint32_t>(period);
-        return static_cast<int>((s < 0 && m != 0) ? static_cast<uint32_t>(period) - m : m);
-    } else if constexpr (PAD <= 1) {
+    if constexpr (PAD <= 1) {
         return s < -len - 1 ? -len - 1 : (s > len + 1 ? len + 1 : s);
     } else {
-        const int period = PAD == 2 ? len : (PAD == 3 ? 2 * (len - 1) : 2 * len);
+        const int period = PAD == 2 ? len : 2 * (len - 1) + 2 * (rt - kPadMirror);   // reflect 2 (len - 1), symmetric 2 len
         const uint32_t a = static_cast<uint32_t>(s < 0 ? -s : s);
         const uint32_t m = a - fdiv(a, dper) * static_cast<uint32_t>(period);
         return static_cast<int>((s < 0 && m != 0) ? static_cast<uint32_t>(period) - m : m);
@@ -262,27 +254,27 @@ template <typename CT> __device__ __forceinline__ void load_weights2(const void 
 }
 
 // canonical shift of an integral shift held in the compute type: 32-bit arithmetic below 2^30, the 64-bit form beyond
-template <int PAD, typename CT> __device__ __forceinline__ int canon_of(CT r, int len, const FastDiv &dper, int rt = 0) {
+template <int PAD, typename CT> __device__ __forceinline__ int canon_of(CT r, int len, const FastDiv &dper, int rt = kPadMirror) {
     if (r > CT(-1073741824) && r < CT(1073741824)) return canon_shift32<PAD>(static_cast<int>(r), len, dper, rt);
-    return canon_shift(static_cast<int64_t>(r), len, PAD == kPadRT ? rt : PAD, dper);
+    return canon_shift(static_cast<int64_t>(r), len, PAD == kPadMirror ? rt : PAD, dper);
 }
 
 // the two canonical shifts of channel c for the gather kernels (sparse shift: round half to even; quantized: int_repr minus
 // zero point, kernels/shifts_kernels.h:553-555), every weight dtype through the scalar cache
 template <int PAD>
 __device__ __forceinline__ void channel_shifts2(const void *w, int wkind, int64_t wzp, int c, int S1, int S2, const FastDiv &d1,
-                                                const FastDiv &d2, int &cs1, int &cs2) {
+                                                const FastDiv &d2, int &cs1, int &cs2, int rt = kPadMirror) {
     if (wkind <= SHIFTND_BF16) {
         if (wkind == SHIFTND_F64) {
             double wr, wc;
             load_weights2<double>(w, wkind, c, wr, wc);
-            cs1 = canon_of<PAD, double>(rint(wr), S1, d1);
-            cs2 = canon_of<PAD, double>(rint(wc), S2, d2);
+            cs1 = canon_of<PAD, double>(rint(wr), S1, d1, rt);
+            cs2 = canon_of<PAD, double>(rint(wc), S2, d2, rt);
         } else {
             float wr, wc;
             load_weights2<float>(w, wkind, c, wr, wc);
-            cs1 = canon_of<PAD, float>(rintf(wr), S1, d1);
-            cs2 = canon_of<PAD, float>(rintf(wc), S2, d2);
+            cs1 = canon_of<PAD, float>(rintf(wr), S1, d1, rt);
+            cs2 = canon_of<PAD, float>(rintf(wc), S2, d2, rt);
         }
     } else {
         const uintptr_t base = reinterpret_cast<uintptr_t>(w);
@@ -306,8 +298,8 @@ __device__ __forceinline__ void channel_shifts2(const void *w, int wkind, int64_
         r1 -= wzp;
         r2 -= wzp;
         const bool small = r1 > -1073741824 && r1 < 1073741824 && r2 > -1073741824 && r2 < 1073741824;
-        cs1 = small ? canon_shift32<PAD>(static_cast<int>(r1), S1, d1) : canon_shift(r1, S1, PAD, d1);
-        cs2 = small ? canon_shift32<PAD>(static_cast<int>(r2), S2, d2) : canon_shift(r2, S2, PAD, d2);
+        cs1 = small ? canon_shift32<PAD>(static_cast<int>(r1), S1, d1, rt) : canon_shift(r1, S1, PAD == kPadMirror ? rt : PAD, d1);
+        cs2 = small ? canon_shift32<PAD>(static_cast<int>(r2), S2, d2, rt) : canon_shift(r2, S2, PAD == kPadMirror ? rt : PAD, d2);
     }
     cs1 = __builtin_amdgcn_readfirstlane(cs1);
     cs2 = __builtin_amdgcn_readfirstlane(cs2);
@@ -320,7 +312,7 @@ struct GatherParams {  // 2-D problems: rows x inner, one weight per dim
     int64_t wzp;
     uint64_t fill;
     int64_t x_plane, o_plane;
-    int wkind, C;
+    int wkind, C, pad;   // pad: the padding mode (the kPadMirror instantiations: reflect or symmetric)
     int S1, S2, O1, O2, L1, L2;
     int cpr, R, spp;
     int xppr;   // 16-byte pieces per source row (the small-element kernel)
@@ -378,7 +370,7 @@ struct FwdParams {
 };
 
 // column state of E + 1 consecutive map entries starting at coordinate j0, folded arithmetically
-template <int E, int PAD> __device__ __forceinline__ ColState<E> fold_colstate(int j0, int cs, int len, int rt = 0) {
+template <int E, int PAD> __device__ __forceinline__ ColState<E> fold_colstate(int j0, int cs, int len, int rt = kPadMirror) {
     ColState<E> c;
     c.base = 0;
     bool found = false;
@@ -398,9 +390,8 @@ template <int E, int PAD> __device__ __forceinline__ ColState<E> fold_colstate(i
 
 // grad_w[c][0..nd-1] = blend(sum over the steps of channel c, in a fixed order)
 template <typename T, int ND>
-__global__ __launch_bounds__(kThreads) void step_reduce(const StepParams p, typename T::S *__restrict__ grad_w) {
+__device__ __forceinline__ void step_reduce_nd(const StepParams &p, typename T::S *__restrict__ grad_w, double *scratch) {
     constexpr int NDIFF = WDiff<ND>::N;
-    __shared__ double scratch[kThreads / 64];
     const int c = blockIdx.x;
     const uint32_t per_channel = static_cast<uint32_t>(p.N) * static_cast<uint32_t>(p.spv);
     double acc[NDIFF];
@@ -426,6 +417,15 @@ __global__ __launch_bounds__(kThreads) void step_reduce(const StepParams p, type
             else grad_w[c * ND + s] = narrow<T>(static_cast<float>(out[s]));
         }
     }
+}
+
+// (one kernel per dtype: the number of dims is a launch argument that picks the body)
+template <typename T>
+__global__ __launch_bounds__(kThreads) void step_reduce(const StepParams p, typename T::S *__restrict__ grad_w, const int nd) {
+    __shared__ double scratch[kThreads / 64];
+    if (nd == 1) step_reduce_nd<T, 1>(p, grad_w, scratch);
+    else if (nd == 2) step_reduce_nd<T, 2>(p, grad_w, scratch);
+    else step_reduce_nd<T, 3>(p, grad_w, scratch);
 }
 
 

@@ -35,37 +35,37 @@ __global__ __launch_bounds__(kThreads) void step_gather_forward(const GatherPara
         if (p.wkind == SHIFTND_F64) {
             double wv[3];
             load_weights_nd<double>(p.w, p.wkind, c, 3, wv);
-            cs0 = canon_of<PAD, double>(rint(wv[0]), p.S0, p.d_per0);
-            cs1 = canon_of<PAD, double>(rint(wv[1]), p.S1, p.d_per1);
-            cs2 = canon_of<PAD, double>(rint(wv[2]), p.S2, p.d_per2);
+            cs0 = canon_of<PAD, double>(rint(wv[0]), p.S0, p.d_per0, p.pad);
+            cs1 = canon_of<PAD, double>(rint(wv[1]), p.S1, p.d_per1, p.pad);
+            cs2 = canon_of<PAD, double>(rint(wv[2]), p.S2, p.d_per2, p.pad);
         } else {
             float wv[3];
             load_weights_nd<float>(p.w, p.wkind, c, 3, wv);
-            cs0 = canon_of<PAD, float>(rintf(wv[0]), p.S0, p.d_per0);
-            cs1 = canon_of<PAD, float>(rintf(wv[1]), p.S1, p.d_per1);
-            cs2 = canon_of<PAD, float>(rintf(wv[2]), p.S2, p.d_per2);
+            cs0 = canon_of<PAD, float>(rintf(wv[0]), p.S0, p.d_per0, p.pad);
+            cs1 = canon_of<PAD, float>(rintf(wv[1]), p.S1, p.d_per1, p.pad);
+            cs2 = canon_of<PAD, float>(rintf(wv[2]), p.S2, p.d_per2, p.pad);
         }
         cs0 = __builtin_amdgcn_readfirstlane(cs0);
         cs1 = __builtin_amdgcn_readfirstlane(cs1);
         cs2 = __builtin_amdgcn_readfirstlane(cs2);
-        pa = row_map_t<PAD>(a + p.L0, cs0, p.S0);
+        pa = row_map_t<PAD>(a + p.L0, cs0, p.S0, p.pad);
     } else {
         plane = fdiv(bid, p.d_spp);
         step = static_cast<int>(bid - plane * static_cast<uint32_t>(p.spp));
         const int c = static_cast<int>(plane - fdiv(plane, p.d_C) * static_cast<uint32_t>(p.C));
-        channel_shifts2<PAD>(p.w, p.wkind, p.wzp, c, p.S1, p.S2, p.d_per1, p.d_per2, cs1, cs2);
+        channel_shifts2<PAD>(p.w, p.wkind, p.wzp, c, p.S1, p.S2, p.d_per1, p.d_per2, cs1, cs2, p.pad);
     }
     const int tid = static_cast<int>(threadIdx.x);
     const int tr = static_cast<int>(fdiv(static_cast<uint32_t>(tid), p.d_cpr)), tc = tid - tr * p.cpr;
     const int r = step * p.R + tr;
     if (tr >= p.R || r >= p.O1) return;
     const int jo = tc * E;
-    const int rb = row_map_t<PAD>(r + p.L1, cs1, p.S1);
+    const int rb = row_map_t<PAD>(r + p.L1, cs1, p.S1, p.pad);
     int mm[E];
     bool contig = true;
 #pragma unroll
     for (int e = 0; e < E; ++e) {
-        mm[e] = row_map_t<PAD>(jo + p.L2 + e, cs2, p.S2);
+        mm[e] = row_map_t<PAD>(jo + p.L2 + e, cs2, p.S2, p.pad);
         contig = contig && (mm[e] == mm[0] + e);
     }
     contig = contig && mm[0] >= 0;
@@ -110,7 +110,7 @@ __global__ __launch_bounds__(kThreads) void step_gather_forward_pool(const Gathe
     const int step = static_cast<int>(bid - plane * static_cast<uint32_t>(p.spp));
     const int c = static_cast<int>(plane - fdiv(plane, p.d_C) * static_cast<uint32_t>(p.C));
     int cs1, cs2;
-    channel_shifts2<PAD>(p.w, p.wkind, p.wzp, c, p.S1, p.S2, p.d_per1, p.d_per2, cs1, cs2);
+    channel_shifts2<PAD>(p.w, p.wkind, p.wzp, c, p.S1, p.S2, p.d_per1, p.d_per2, cs1, cs2, p.pad);
     const int tid = static_cast<int>(threadIdx.x);
     const int tr = static_cast<int>(fdiv(static_cast<uint32_t>(tid), p.d_cpr)), tc = tid - tr * p.cpr;
     const int P1 = (p.O1 + 1) >> 1, P2 = p.O2 >> 1;
@@ -121,7 +121,7 @@ __global__ __launch_bounds__(kThreads) void step_gather_forward_pool(const Gathe
     bool contig = true;
 #pragma unroll
     for (int e = 0; e < E; ++e) {
-        mm[e] = row_map_t<PAD>(jo + p.L2 + e, cs2, p.S2);
+        mm[e] = row_map_t<PAD>(jo + p.L2 + e, cs2, p.S2, p.pad);
         contig = contig && (mm[e] == mm[0] + e);
     }
     contig = contig && mm[0] >= 0;
@@ -132,7 +132,7 @@ __global__ __launch_bounds__(kThreads) void step_gather_forward_pool(const Gathe
     Chunk<S, E> v[2];
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
-        const int rb = h < n1 ? row_map_t<PAD>(2 * pr + h + p.L1, cs1, p.S1) : -1;
+        const int rb = h < n1 ? row_map_t<PAD>(2 * pr + h + p.L1, cs1, p.S1, p.pad) : -1;
         if (rb < 0) {
 #pragma unroll
             for (int e = 0; e < E; ++e) v[h].e[e] = zero;
@@ -167,12 +167,12 @@ __global__ __launch_bounds__(kThreads) void step_gather_forward_small(const Gath
     const int step = static_cast<int>(bid - plane * static_cast<uint32_t>(p.spp));
     const int c = static_cast<int>(plane - fdiv(plane, p.d_C) * static_cast<uint32_t>(p.C));
     int cs1, cs2;
-    channel_shifts2<PAD>(p.w, p.wkind, p.wzp, c, p.S1, p.S2, p.d_per1, p.d_per2, cs1, cs2);
+    channel_shifts2<PAD>(p.w, p.wkind, p.wzp, c, p.S1, p.S2, p.d_per1, p.d_per2, cs1, cs2, p.pad);
     const int tid = static_cast<int>(threadIdx.x);
     const int tr = static_cast<int>(fdiv(static_cast<uint32_t>(tid), p.d_cpr)), tc = tid - tr * p.cpr;
     const int r = step * p.R + tr;
     if (tr >= p.R || r >= p.O1) return;
-    const int rb = row_map_t<PAD>(r + p.L1, cs1, p.S1);
+    const int rb = row_map_t<PAD>(r + p.L1, cs1, p.S1, p.pad);
     const int dcol = p.L2 - cs2;               // source column of output column 0 under the plain shift (uniform)
     const int ph = (dcol * ESIZE) & 15;        // byte phase of every chunk's source window
     const int q = tc + ((dcol * ESIZE) >> 4);  // first aligned source piece of this chunk (may lie outside the row)
@@ -208,7 +208,7 @@ __global__ __launch_bounds__(kThreads) void step_gather_forward_small(const Gath
         Chunk<R_t, E> v;
 #pragma unroll
         for (int e = 0; e < E; ++e) {
-            const int m = row_map_t<PAD>(tc * E + p.L2 + e, cs2, p.S2);
+            const int m = row_map_t<PAD>(tc * E + p.L2 + e, cs2, p.S2, p.pad);
             v.e[e] = m >= 0 ? row[m] : static_cast<R_t>(p.fill);
         }
         __builtin_memcpy(&o, v.e, 16);
@@ -249,9 +249,9 @@ __global__ __launch_bounds__(kThreads) void step_forward_lds(const FwdParams p) 
         rr[d] = ACTIVE ? c_floor<CT>(wv[d]) : c_rint<CT>(wv[d]);
         dn[d] = ACTIVE ? wv[d] - rr[d] : CT(0);
     }
-    const int cs0 = ND == 3 ? __builtin_amdgcn_readfirstlane(canon_of<PAD, CT>(rr[0], p.S0, p.d_per0)) : 0;
-    const int cs1 = __builtin_amdgcn_readfirstlane(canon_of<PAD, CT>(rr[1], p.S1, p.d_per1));
-    const int cs2 = __builtin_amdgcn_readfirstlane(canon_of<PAD, CT>(rr[2], p.S2, p.d_per2));
+    const int cs0 = ND == 3 ? __builtin_amdgcn_readfirstlane(canon_of<PAD, CT>(rr[0], p.S0, p.d_per0, p.pad)) : 0;
+    const int cs1 = __builtin_amdgcn_readfirstlane(canon_of<PAD, CT>(rr[1], p.S1, p.d_per1, p.pad));
+    const int cs2 = __builtin_amdgcn_readfirstlane(canon_of<PAD, CT>(rr[2], p.S2, p.d_per2, p.pad));
     // fractions in real-dim order (interp_t's d[]): 2-D (row, inner), 3-D (plane, row, inner)
     const CT dw[3] = {ND == 3 ? dn[0] : dn[1], ND == 3 ? dn[1] : dn[2], ND == 3 ? dn[2] : CT(0)};
 
@@ -265,7 +265,7 @@ __global__ __launch_bounds__(kThreads) void step_forward_lds(const FwdParams p) 
     S *op = static_cast<S *>(p.out) + static_cast<int64_t>(plane) * p.o_plane + static_cast<int64_t>(a) * p.O1 * p.O2;
     int pa[NPL];
 #pragma unroll
-    for (int h = 0; h < NPL; ++h) pa[h] = ND == 3 ? row_map_t<PAD>(a + p.L0 + h, cs0, S0) : 0;
+    for (int h = 0; h < NPL; ++h) pa[h] = ND == 3 ? row_map_t<PAD>(a + p.L0 + h, cs0, S0, p.pad) : 0;
 
     const int tid = static_cast<int>(threadIdx.x);
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -281,14 +281,14 @@ __global__ __launch_bounds__(kThreads) void step_forward_lds(const FwdParams p) 
         for (int u = 0; u < U; ++u) {
             const int vtr = tr + u * R;
             if (tr < R && vtr <= last) {
-                const int src = row_map_t<PAD>(b0 + p.L1 + vtr, cs1, S1);
+                const int src = row_map_t<PAD>(b0 + p.L1 + vtr, cs1, S1, p.pad);
 #pragma unroll
                 for (int h = 0; h < NPL; ++h)
                     if (src >= 0 && pa[h] >= 0) dma(pa[h] * S1 + src, tc, h * PR * cpr + u * R * cpr);
             }
         }
         if (ACTIVE && Rn == RT && tid < cpr) {
-            const int src = row_map_t<PAD>(b0 + p.L1 + RT, cs1, S1);
+            const int src = row_map_t<PAD>(b0 + p.L1 + RT, cs1, S1, p.pad);
 #pragma unroll
             for (int h = 0; h < NPL; ++h)
                 if (src >= 0 && pa[h] >= 0) dma(pa[h] * S1 + src, tid, (h * PR + RT) * cpr);
@@ -303,7 +303,7 @@ __global__ __launch_bounds__(kThreads) void step_forward_lds(const FwdParams p) 
                     const int q = k * kThreads + tid;
                     const int slot = static_cast<int>(fdiv(static_cast<uint32_t>(q), p.d_xppr));
                     const int j = q - slot * xppr;
-                    int src = row_map_t<PAD>(b0 + p.L1 + slot, cs1, S1);
+                    int src = row_map_t<PAD>(b0 + p.L1 + slot, cs1, S1, p.pad);
                     if (q >= npieces || pa[h] < 0) src = -1;
                     if (src >= 0) dma(pa[h] * S1 + src, j, h * PR * xppr + k * kThreads);
                 }
@@ -319,7 +319,7 @@ __global__ __launch_bounds__(kThreads) void step_forward_lds(const FwdParams p) 
 #pragma unroll
         for (int e = 0; e <= E; ++e) xm.cm[e] = (base + e >= 0 && base + e < S2) ? base + e : -1;
     } else {
-        xm = fold_colstate<E, PAD>(jo + p.L2, cs2, S2);
+        xm = fold_colstate<E, PAD>(jo + p.L2, cs2, S2, p.pad);
     }
     // window reads: two aligned 16-byte spans and the workgroup's phase (lds_window6: no bank conflicts); chunks that are not
     // affine at that phase (and cropped problems, whose staged rows start at another column) read element by element
@@ -327,7 +327,7 @@ __global__ __launch_bounds__(kThreads) void step_forward_lds(const FwdParams p) 
     const bool fastw = xm.affine && ((xm.base * static_cast<int>(sizeof(S))) & 15) == phw;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    auto row_valid = [&](int pr) { return PAD != 0 || row_map_t<PAD>(pr, cs1, S1) >= 0; };
+    auto row_valid = [&](int pr) { return PAD != 0 || row_map_t<PAD>(pr, cs1, S1, p.pad) >= 0; };
     const int RBL = xppr * 16;  // bytes per staged row
 #pragma unroll
     for (int u = 0; u < U; ++u) {
@@ -424,6 +424,7 @@ int step_forward(const Geometry &g, int dtype, const void *x, const void *w, int
                  void *out, hipStream_t st) {
     const int es = dtype_size(dtype);
     GatherParams p{};
+    p.pad = g.pad;
     p.x = x;
     p.out = out;
     p.w = w;
@@ -470,8 +471,7 @@ int step_forward(const Geometry &g, int dtype, const void *x, const void *w, int
     case 0: hipLaunchKernelGGL((step_gather_forward<ES, 0, 3>), grid, block, 0, st, p); break; \
     case 1: hipLaunchKernelGGL((step_gather_forward<ES, 1, 3>), grid, block, 0, st, p); break; \
     case 2: hipLaunchKernelGGL((step_gather_forward<ES, 2, 3>), grid, block, 0, st, p); break; \
-    case 3: hipLaunchKernelGGL((step_gather_forward<ES, 3, 3>), grid, block, 0, st, p); break; \
-    default: hipLaunchKernelGGL((step_gather_forward<ES, 4, 3>), grid, block, 0, st, p); break; \
+    default: hipLaunchKernelGGL((step_gather_forward<ES, kPadMirror, 3>), grid, block, 0, st, p); break; \
     }
         if (es == 4) { SHIFTND_STEP_FWD3(4) } else { SHIFTND_STEP_FWD3(8) }
 #undef SHIFTND_STEP_FWD3
@@ -483,8 +483,7 @@ int step_forward(const Geometry &g, int dtype, const void *x, const void *w, int
     case 0: hipLaunchKernelGGL((KERNEL<ES, 0>), grid, block, 0, st, p); break; \
     case 1: hipLaunchKernelGGL((KERNEL<ES, 1>), grid, block, 0, st, p); break; \
     case 2: hipLaunchKernelGGL((KERNEL<ES, 2>), grid, block, 0, st, p); break; \
-    case 3: hipLaunchKernelGGL((KERNEL<ES, 3>), grid, block, 0, st, p); break; \
-    default: hipLaunchKernelGGL((KERNEL<ES, 4>), grid, block, 0, st, p); break; \
+    default: hipLaunchKernelGGL((KERNEL<ES, kPadMirror>), grid, block, 0, st, p); break;   /* reflect and symmetric */ \
     }
     if (es == 1) { SHIFTND_STEP_FWD(step_gather_forward_small, 1) }
     else if (es == 2) { SHIFTND_STEP_FWD(step_gather_forward_small, 2) }
@@ -538,20 +537,17 @@ static void launch_step_forward_lds(const FwdParams &p, int pad, int U, size_t l
 #define SHIFTND_STEP_FWD_LDS(PADV) \
     case PADV: \
         if (p.nd == 3) { \
-            if constexpr (k3d) { \
-                if (U == 2) hipLaunchKernelGGL((step_forward_lds<T, 3, ACT, PADV, 2>), grid, block, lds, st, p); \
-                else hipLaunchKernelGGL((step_forward_lds<T, 3, ACT, PADV, 1>), grid, block, lds, st, p); \
-            } \
-        } else if (U == 2) hipLaunchKernelGGL((step_forward_lds<T, 2, ACT, PADV, 2>), grid, block, lds, st, p); \
-        else hipLaunchKernelGGL((step_forward_lds<T, 2, ACT, PADV, 1>), grid, block, lds, st, p); \
+            if constexpr (k3d) hipLaunchKernelGGL((step_forward_lds<T, 3, ACT, PADV, 2>), grid, block, lds, st, p); \
+        } else hipLaunchKernelGGL((step_forward_lds<T, 2, ACT, PADV, 2>), grid, block, lds, st, p); \
         break;
-    switch (pad) { SHIFTND_STEP_FWD_LDS(0) SHIFTND_STEP_FWD_LDS(1) SHIFTND_STEP_FWD_LDS(2) SHIFTND_STEP_FWD_LDS(3) default: SHIFTND_STEP_FWD_LDS(4) }
+    switch (pad) { SHIFTND_STEP_FWD_LDS(0) SHIFTND_STEP_FWD_LDS(1) SHIFTND_STEP_FWD_LDS(2) default: SHIFTND_STEP_FWD_LDS(3) }
 #undef SHIFTND_STEP_FWD_LDS
 }
 
 int step_forward_lds(const Geometry &g, int dtype, const void *x, const void *w, int wkind, uint64_t fill_bits, void *out, hipStream_t st) {
     const int es = dtype_size(dtype);
     FwdParams p{};
+    p.pad = g.pad;
     p.x = x;
     p.out = out;
     p.w = w;
@@ -574,8 +570,9 @@ int step_forward_lds(const Geometry &g, int dtype, const void *x, const void *w,
     p.xppr = static_cast<int>(g.S[2] * es / 16);
     p.R = kThreads / p.cpr;
     if (p.R > p.O1) p.R = p.O1;
-    int U = g_step_tune[2] == 2 ? 1 : 2;  // (one row group: C2-tensor interpolating forward 1.15 ms, two: 1.00 ms)
-    if (p.R >= p.O1) U = 1;
+    // two row groups per thread (one row group: C2-tensor interpolating forward 1.15 ms, two: 1.00 ms); only that form is built -- a
+    // plane of fewer rows than one group is a ragged last step like any other (rows beyond the plane stage and store nothing)
+    const int U = 2;
     p.spp = (p.O1 + U * p.R - 1) / (U * p.R);
     p.spv = p.O0 * p.spp;
     p.d_spv = make_fastdiv(static_cast<uint32_t>(p.spv));
@@ -622,6 +619,7 @@ bool step_forward_pooled_eligible(const Geometry &g, int dtype, const void *x, c
 int step_forward_pooled(const Geometry &g, int dtype, const void *x, const void *w, int wkind, void *out, hipStream_t st) {
     const int es = dtype_size(dtype);
     GatherParams p{};
+    p.pad = g.pad;
     p.x = x;
     p.out = out;
     p.w = w;
@@ -656,8 +654,7 @@ int step_forward_pooled(const Geometry &g, int dtype, const void *x, const void 
     case 0: hipLaunchKernelGGL((step_gather_forward_pool<TT, 0>), grid, block, 0, st, p); break; \
     case 1: hipLaunchKernelGGL((step_gather_forward_pool<TT, 1>), grid, block, 0, st, p); break; \
     case 2: hipLaunchKernelGGL((step_gather_forward_pool<TT, 2>), grid, block, 0, st, p); break; \
-    case 3: hipLaunchKernelGGL((step_gather_forward_pool<TT, 3>), grid, block, 0, st, p); break; \
-    default: hipLaunchKernelGGL((step_gather_forward_pool<TT, 4>), grid, block, 0, st, p); break; \
+    default: hipLaunchKernelGGL((step_gather_forward_pool<TT, kPadMirror>), grid, block, 0, st, p); break; \
     }
     if (dtype == SHIFTND_F32) { SHIFTND_STEP_FWD_POOL(f32_t) } else { SHIFTND_STEP_FWD_POOL(f64_t) }
 #undef SHIFTND_STEP_FWD_POOL

@@ -46,9 +46,9 @@ __global__ __launch_bounds__(kThreads) void walk_forward(const FwdParams p) {
         rr[d] = c_floor<CT>(wv[d]);
         dn[d] = wv[d] - rr[d];
     }
-    const int cs0 = __builtin_amdgcn_readfirstlane(canon_of<PAD, CT>(rr[0], p.S0, p.d_per0));
-    const int cs1 = __builtin_amdgcn_readfirstlane(canon_of<PAD, CT>(rr[1], p.S1, p.d_per1));
-    const int cs2 = __builtin_amdgcn_readfirstlane(canon_of<PAD, CT>(rr[2], p.S2, p.d_per2));
+    const int cs0 = __builtin_amdgcn_readfirstlane(canon_of<PAD, CT>(rr[0], p.S0, p.d_per0, p.pad));
+    const int cs1 = __builtin_amdgcn_readfirstlane(canon_of<PAD, CT>(rr[1], p.S1, p.d_per1, p.pad));
+    const int cs2 = __builtin_amdgcn_readfirstlane(canon_of<PAD, CT>(rr[2], p.S2, p.d_per2, p.pad));
     const CT dw[3] = {dn[0], dn[1], dn[2]};
 
     const int R = p.R, S0 = p.S0, S1 = p.S1, S2 = p.S2, cpr = p.cpr;
@@ -67,7 +67,7 @@ __global__ __launch_bounds__(kThreads) void walk_forward(const FwdParams p) {
     (void)wave;
     typedef uint32_t u4 __attribute__((ext_vector_type(4)));
     const bool own = tr <= R && tr <= Rn;
-    const int src_own = own ? row_map_t<PAD>(b0 + tr, cs1, S1) : -1;
+    const int src_own = own ? row_map_t<PAD>(b0 + tr, cs1, S1, p.pad) : -1;
     const uint32_t plane_bytes = static_cast<uint32_t>(S1) * static_cast<uint32_t>(S2) * static_cast<uint32_t>(sizeof(S));
     const uint32_t voff = src_own >= 0 ? static_cast<uint32_t>(src_own * S2 + tc * E) * static_cast<uint32_t>(sizeof(S)) : 0x80000000u;
     const __amdgpu_buffer_rsrc_t xres = __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(xp), 0, static_cast<uint32_t>(S0) * plane_bytes, 0x00020000);
@@ -86,7 +86,7 @@ __global__ __launch_bounds__(kThreads) void walk_forward(const FwdParams p) {
 #pragma unroll
         for (int e = 0; e <= E; ++e) xm.cm[e] = (base + e >= 0 && base + e < S2) ? base + e : -1;
     } else {
-        xm = fold_colstate<E, PAD>(jo, cs2, S2);
+        xm = fold_colstate<E, PAD>(jo, cs2, S2, p.pad);
     }
     // window reads: two aligned 16-byte spans and the workgroup's phase (lds_window6: no bank conflicts)
     const int phw = (-cs2 * static_cast<int>(sizeof(S))) & 15;
@@ -95,14 +95,14 @@ __global__ __launch_bounds__(kThreads) void walk_forward(const FwdParams p) {
     const int b = b0 + tr;
     bool rv[2];
 #pragma unroll
-    for (int hb = 0; hb < 2; ++hb) rv[hb] = PAD != 0 || row_map_t<PAD>(b + hb, cs1, S1) >= 0;
+    for (int hb = 0; hb < 2; ++hb) rv[hb] = PAD != 0 || row_map_t<PAD>(b + hb, cs1, S1, p.pad) >= 0;
     const int RBL = cpr * 16;  // bytes per staged row
     const char *rows = tile + tr * RBL;
 
     // plane map(0): the first step's "+0" rows
     CT carried[2][E + 1];
     {
-        const int pa0 = row_map_t<PAD>(0, cs0, S0);
+        const int pa0 = row_map_t<PAD>(0, cs0, S0, p.pad);
         park(load_plane(pa0));
         __syncthreads();
 #pragma unroll
@@ -147,13 +147,13 @@ __global__ __launch_bounds__(kThreads) void walk_forward(const FwdParams p) {
         }
     };
     __syncthreads();   // the first plane has been read
-    u4 stA = load_plane(row_map_t<PAD>(1, cs0, S0));                            // the "+1" plane of step 0
-    u4 stB = load_plane(1 < p.O0 ? row_map_t<PAD>(2, cs0, S0) : -1);            // ... of step 1
+    u4 stA = load_plane(row_map_t<PAD>(1, cs0, S0, p.pad));                            // the "+1" plane of step 0
+    u4 stB = load_plane(1 < p.O0 ? row_map_t<PAD>(2, cs0, S0, p.pad) : -1);            // ... of step 1
     auto walk_step = [&](int a, u4 &pend) {   // `pend`: the "+1" plane of step a; leaves with that of step a + 2 in flight
-        const int pa1 = row_map_t<PAD>(a + 1, cs0, S0);
+        const int pa1 = row_map_t<PAD>(a + 1, cs0, S0, p.pad);
         park(pend);
         __syncthreads();
-        pend = load_plane(a + 2 < p.O0 ? row_map_t<PAD>(a + 3, cs0, S0) : -1);
+        pend = load_plane(a + 2 < p.O0 ? row_map_t<PAD>(a + 3, cs0, S0, p.pad) : -1);
         CT rowb[2][E + 1];
 #pragma unroll
         for (int hb = 0; hb < 2; ++hb) {
@@ -269,8 +269,8 @@ __global__ __launch_bounds__(kThreads) void walk_backward(const StepParams p) {
     // (the host picks R with (R + 1) * cpr <= 256: thread (tr, tc), tr <= R, stages piece tc of row tr -- the "+1" corner row of
     // the step's last row included -- so a plane costs one load per tensor and thread, and two planes can be in flight)
     const bool own = tr <= R && tr <= Rn;
-    const int sx_own = own ? row_map_t<PAD>(b0 + tr, d.cx1, S1) : -1;
-    const int sg_own = (own && (ACTIVE || tr < R)) ? row_map_t<PAD>(b0 + tr, d.cg1, S1) : -1;
+    const int sx_own = own ? row_map_t<PAD>(b0 + tr, d.cx1, S1, p.pad) : -1;
+    const int sg_own = (own && (ACTIVE || tr < R)) ? row_map_t<PAD>(b0 + tr, d.cg1, S1, p.pad) : -1;
     auto piece_off = [&](int row, int piece) { return static_cast<uint32_t>(max(row, 0) * S2 + piece * E) * static_cast<uint32_t>(sizeof(S)); };
     const uint32_t ox_own = piece_off(sx_own, tc), og_own = piece_off(sg_own, tc);
     const uint32_t plane_bytes = static_cast<uint32_t>(S1) * static_cast<uint32_t>(S2) * static_cast<uint32_t>(sizeof(S));
@@ -440,7 +440,7 @@ __global__ __launch_bounds__(kThreads) void walk_backward(const StepParams p) {
     uint32_t cxp[2][5];
     CT cx[PACKED ? 1 : 2][PACKED ? 1 : E + 1], cg[2][E + 1];   // the "+0" planes' corner rows
     {
-        const int pax0 = row_map_t<PAD>(a0, d.cx0, S0), pag0 = ACTIVE ? row_map_t<PAD>(a0, d.cg0, S0) : -1;
+        const int pax0 = row_map_t<PAD>(a0, d.cx0, S0, p.pad), pag0 = ACTIVE ? row_map_t<PAD>(a0, d.cg0, S0, p.pad) : -1;
         Staged v0;
         load_planes(pax0, pag0, v0);
         park(v0);
@@ -493,14 +493,14 @@ __global__ __launch_bounds__(kThreads) void walk_backward(const StepParams p) {
     // the planes of steps a0 and a0 + 1 (steps that do not exist: empty resources; a buffer's range check does not see the
     // scalar offset)
     Staged stA, stB;
-    load_planes(row_map_t<PAD>(a0 + 1, d.cx0, S0), row_map_t<PAD>(a0 + GA, d.cg0, S0), stA);
-    load_planes(a0 + 1 < a1 ? row_map_t<PAD>(a0 + 2, d.cx0, S0) : -1, a0 + 1 < a1 ? row_map_t<PAD>(a0 + 1 + GA, d.cg0, S0) : -1, stB);
+    load_planes(row_map_t<PAD>(a0 + 1, d.cx0, S0, p.pad), row_map_t<PAD>(a0 + GA, d.cg0, S0, p.pad), stA);
+    load_planes(a0 + 1 < a1 ? row_map_t<PAD>(a0 + 2, d.cx0, S0, p.pad) : -1, a0 + 1 < a1 ? row_map_t<PAD>(a0 + 1 + GA, d.cg0, S0, p.pad) : -1, stB);
     u4 gcur = load_own(a0, true);
     auto walk_step = [&](int a, Staged &pend) {   // `pend` holds the planes of step a; it leaves with those of step a + 2 in flight
         park(pend);
         __syncthreads();
         const bool more = a + 2 < a1;
-        load_planes(more ? row_map_t<PAD>(a + 3, d.cx0, S0) : -1, more ? row_map_t<PAD>(a + 2 + GA, d.cg0, S0) : -1, pend);
+        load_planes(more ? row_map_t<PAD>(a + 3, d.cx0, S0, p.pad) : -1, more ? row_map_t<PAD>(a + 2 + GA, d.cg0, S0, p.pad) : -1, pend);
         Chunk<S, E> gch;
         if constexpr (POOL) {
             const u4 ex = expand(u2{gcur.x, gcur.y}, static_cast<int>(gcur.z) * n1_my * 2);
@@ -684,6 +684,7 @@ static bool walk_forward_core(const Geometry &g, int dtype, const void *x, const
 int walk_forward(const Geometry &g, int dtype, const void *x, const void *w, int wkind, void *out, hipStream_t st) {
     const int es = dtype_size(dtype);
     FwdParams p{};
+    p.pad = g.pad;
     p.x = x;
     p.out = out;
     p.w = w;
@@ -732,7 +733,7 @@ int walk_forward(const Geometry &g, int dtype, const void *x, const void *w, int
         else if constexpr (sizeof(typename T::S) != 2) hipLaunchKernelGGL((walk_forward<T, PADV, false>), grid, block, lds, st, p); \
         break;
 #define SHIFTND_WALK_FWD(T) \
-    switch (g.pad) { SHIFTND_WALK_FWD_PAD(T, 0) SHIFTND_WALK_FWD_PAD(T, 1) SHIFTND_WALK_FWD_PAD(T, 2) SHIFTND_WALK_FWD_PAD(T, 3) default: SHIFTND_WALK_FWD_PAD(T, 4) }
+    switch (g.pad) { SHIFTND_WALK_FWD_PAD(T, 0) SHIFTND_WALK_FWD_PAD(T, 1) SHIFTND_WALK_FWD_PAD(T, 2) default: SHIFTND_WALK_FWD_PAD(T, 3) }
     switch (dtype) {
     case SHIFTND_F32: SHIFTND_WALK_FWD(f32_t) break;
     case SHIFTND_F64: SHIFTND_WALK_FWD(f64_t) break;
@@ -795,7 +796,7 @@ template <typename T> static void launch_walk_backward(StepParams &p, size_t lds
             else hipLaunchKernelGGL((walk_backward<T, PADV, false>), grid, block, lds, st, p); \
         } \
         break;
-    switch (p.pad) { SHIFTND_WALK_BWD(0) SHIFTND_WALK_BWD(1) SHIFTND_WALK_BWD(2) SHIFTND_WALK_BWD(3) default: SHIFTND_WALK_BWD(4) }
+    switch (p.pad) { SHIFTND_WALK_BWD(0) SHIFTND_WALK_BWD(1) SHIFTND_WALK_BWD(2) default: SHIFTND_WALK_BWD(3) }
 #undef SHIFTND_WALK_BWD
     launch_step_reduce(T::kDtype, 3, p, gw, st);
 }

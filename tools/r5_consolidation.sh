@@ -1,0 +1,12 @@
+#!/bin/bash
+# After the round-5 consolidation: (1) the route census with channels-last outputs, (2) the wrapping paddings of the row-span /
+# flat-stream kernels before (variants/oldpads.so: one instantiation per mode) and after (the mode as a kernel argument)
+cd "$GRAFT_REPO_ROOT"
+mkdir -p gpurun_out/consol
+python3 tools/route_census.py --cases 6000 --seed 1 --out gpurun_out/consol/route_census.txt > gpurun_out/consol/census.log 2>&1
+tail -2 gpurun_out/consol/census.log
+for r in 1 2; do
+  python3 tools/flat_bench.py --pads 0,1,2,3,4 --iters 30 > gpurun_out/consol/pads_new_$r.txt 2>&1
+  SHIFTND_HIP_LIB=$GRAFT_REPO_ROOT/variants/oldpads.so python3 tools/flat_bench.py --pads 0,1,2,3,4 --iters 30 > gpurun_out/consol/pads_old_$r.txt 2>&1
+done
+tail -3 gpurun_out/consol/pads_new_2.txt

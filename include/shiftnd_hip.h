@@ -106,7 +106,8 @@ SHIFTND_API const char *shiftnd_last_kernel(void);
 SHIFTND_API void shiftnd_set_path_policy(int policy);
 /* Diagnostics: launch-planning knobs, by kernel family (csrc/shiftnd_api.hip routes them).  0-7 plane kernels
  * (0: minimum workgroups wanted, 1: target bytes per workgroup, 2: gather-forward unroll, 3: backward form, 5: affine
- * LDS reads, 6: XCD-contiguous block ids), 8-11 sweep kernels, 12-15 sliding-window kernels (12: which problems take
+ * LDS reads, 6: XCD-contiguous block ids), 8-11 sweep kernels (9 / 11: max threads; the row steps per workgroup 8 / 10 once
+ * chose are fixed), 12-15 sliding-window kernels (12: which problems take
  * them, 13: workgroups wanted, 14: minimum rows per band), 16-19 one-byte small-plane kernel (16: on / off, 17: planes
  * per round, 18: LDS bytes, 19: rounds per workgroup), 20-22 LDS-tiled channels-last kernels (20: on / off, 21: rows
  * per band, 22: XCD-contiguous block ids; 23: the direct NDHWC backward 0 = automatic, 1 = never, 2 = whenever eligible), 24-26 small-plane / row-band kernels (24: on / off, 25: planes per round or rows per band, 26: rounds per

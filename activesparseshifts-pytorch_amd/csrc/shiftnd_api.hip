@@ -232,6 +232,10 @@ int forward_common(const shiftnd_problem *p, const void *x, const int64_t *xs, c
         g_last_path = SHIFTND_PATH_PLANE;
         return finish(small_forward(g, p->dtype, x, w, out, st));
     }
+    if (g_policy == 0 && wkind == p->dtype && plane_ragged_forward_eligible(g, p->dtype, x, out)) {  // ... larger 3-D volumes: narrow chunks
+        g_last_path = SHIFTND_PATH_PLANE;
+        return finish(plane_ragged_forward(g, p->dtype, x, w, out, st));
+    }
     if ((g_policy == 0 || g_policy == 4) && cl_tiled_forward_eligible(g, p->dtype, x, out)) {  // channels-last in, LDS-tiled
         g_last_path = SHIFTND_PATH_CL;
         return finish(cl_tiled_forward(g, p->dtype, x, w, wkind, wzp, fill, out, st));
@@ -386,6 +390,7 @@ static size_t backward_workspace_now(const Geometry &g, int dtype) {
     m = std::max(m, small_backward_workspace(g, dtype));
     m = std::max(m, cl_tiled3_backward_workspace(g));
     m = std::max(m, flat_backward_workspace(g));
+    m = std::max(m, plane_ragged_backward_workspace(g, dtype));
     return m;
 }
 
@@ -479,6 +484,13 @@ static int backward_planned(const shiftnd_problem *p, const void *grad_out, cons
         if (small_backward_workspace(g, p->dtype) > workspace_bytes) return SHIFTND_ERR_WORKSPACE_TOO_SMALL;
         g_last_path = SHIFTND_PATH_PLANE;
         return finish(small_backward(g, p->dtype, grad_out, x, weights, grad_x, grad_w, workspace, st));
+    }
+    // 3-D volumes with ragged rows beyond the small-plane kernels (16 x 28 x 28 bf16, 8 x 56 x 62 fp32 ...): the direct-load plane
+    // kernels with 4- / 8-byte chunks instead of the one-thread-per-element fallback
+    if (g_policy == 0 && plane_ragged_backward_eligible(g, p->dtype, grad_out, x, grad_x)) {
+        if (plane_ragged_backward_workspace(g, p->dtype) > workspace_bytes) return SHIFTND_ERR_WORKSPACE_TOO_SMALL;
+        g_last_path = SHIFTND_PATH_PLANE;
+        return finish(plane_ragged_backward(g, p->dtype, grad_out, x, weights, grad_x, grad_w, workspace, st));
     }
     if ((g_policy == 0 || g_policy == 4) && cl_tiled_backward_eligible(g, p->dtype, grad_out, x, grad_x)) {  // all channels-last: LDS-tiled
         if (cl_tiled_backward_workspace(g) > workspace_bytes) return SHIFTND_ERR_WORKSPACE_TOO_SMALL;

@@ -44,6 +44,14 @@ int plane_forward(const Geometry &g, int dtype, const void *x, const void *w, in
                   uint64_t fill_bits, void *out, hipStream_t st);
 bool plane_backward_eligible(const Geometry &g, int dtype, const void *go, const void *x, const void *gx);
 size_t plane_backward_workspace(const Geometry &g, int dtype);
+// 3-D volumes with rows that are not whole 16-byte pieces, beyond the small-plane kernels: the direct-load plane kernels with
+// 4- / 8-byte chunks (interpolating forward, both backwards)
+bool plane_ragged_forward_eligible(const Geometry &g, int dtype, const void *x, const void *out);
+int plane_ragged_forward(const Geometry &g, int dtype, const void *x, const void *w, void *out, hipStream_t st);
+bool plane_ragged_backward_eligible(const Geometry &g, int dtype, const void *go, const void *x, const void *gx);
+size_t plane_ragged_backward_workspace(const Geometry &g, int dtype);
+int plane_ragged_backward(const Geometry &g, int dtype, const void *go, const void *x, const void *w, void *gx, void *gw,
+                          void *workspace, hipStream_t st);
 int plane_backward(const Geometry &g, int dtype, const void *go, const void *x, const void *w, void *gx, void *gw,
                    void *workspace, hipStream_t st);
 

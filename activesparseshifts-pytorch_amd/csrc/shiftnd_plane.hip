@@ -209,11 +209,13 @@ __device__ __forceinline__ int combo_offset(int k, const int *m0, const int *m1,
 // =====================================================================================================
 // Active forward: out = interp of the 2^ND corners around (coord - floor(w)).
 // =====================================================================================================
-template <typename T, int ND>
+// VB = bytes a thread moves per row step: 16, or -- rows that are not whole 16-byte pieces, round 5 -- 4 (two 16-bit elements, one
+// fp32) / 8 (one fp64): the same kernel with narrower chunks (plane_ragged_forward / plane_ragged_backward below)
+template <typename T, int ND, int VB = 16>
 __global__ __launch_bounds__(kThreads) void plane_active_forward(const PlaneParams p) {
     using S = typename T::S;
     using CT = typename T::C;
-    constexpr int E = 16 / sizeof(S);
+    constexpr int E = VB / sizeof(S);
     constexpr int NC = 1 << (ND - 1);
     extern __shared__ int maps[];
     const int *m0 = maps, *m1 = maps + p.S[0] + 1, *m2 = m1 + p.S[1] + 1;
@@ -445,11 +447,11 @@ __device__ __forceinline__ typename T::C pool_grad(const typename T::S *gp, cons
     return widen<T>(narrow<T>(div_count<CT>(widen<T>(gp[r.off + pc]), r.cnt * cc)));
 }
 
-template <typename T, int ND, bool ACTIVE, bool POOL = false>
+template <typename T, int ND, bool ACTIVE, bool POOL = false, int VB = 16>
 __global__ __launch_bounds__(kThreads) void plane_backward(const PlaneParams p) {
     using S = typename T::S;
     using CT = typename T::C;
-    constexpr int E = 16 / sizeof(S);
+    constexpr int E = VB / sizeof(S);
     constexpr int NC = 1 << (ND - 1);
     extern __shared__ int maps[];
     __shared__ double scratch[kThreads / 64];
@@ -1250,99 +1252,6 @@ __global__ __launch_bounds__(kThreads) void plane_gather_forward_lds(const Plane
     }
 }
 
-// Active forward through the same staging (X slots only).
-template <typename T, int ND>
-__global__ __launch_bounds__(kThreads) void plane_active_forward_lds(const PlaneParams p) {
-    using S = typename T::S;
-    using CT = typename T::C;
-    using Stager = LdsStager<T, ND, true, false>;
-    using Shape = LdsTileShape<ND, true, false>;
-    constexpr int E = 16 / sizeof(S);
-    constexpr int NC = 1 << (ND - 1);
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int R = p.RPS;
-    const int NS = Shape::slots(R);
-    const int RB = p.S[2] * static_cast<int>(sizeof(S));
-    char *tile = smem + 64;  // 64-byte pad: see lds_read_row
-    int *maps = reinterpret_cast<int *>(smem + 64 + p.tile_bytes);
-    const int *m0 = maps, *m1 = maps + p.S[0] + 1, *m2 = m1 + p.S[1] + 1;
-    int *slot_src = maps + p.S[0] + p.S[1] + p.S[2] + 3;  // two tables of NS entries
-
-    const WorkItem wi = decode_block(p);
-    int64_t sh[3] = {0, 0, 0};
-    CT dw[3] = {CT(0), CT(0), CT(0)};
-    CT wv[3];
-    load_weights3<CT>(p.w, p.wkind, static_cast<int64_t>(wi.c) * p.nd, p.wcol, wv);
-#pragma unroll
-    for (int d = 0; d < 3; ++d)
-        if (p.wcol[d] >= 0)
-            prep_shift_forward<CT>(wv[d], true, sh[d], dw[p.wcol[d]]);
-    build_maps(maps, p.S, sh, -1, p.pad, p.d_per);
-    __syncthreads();
-
-    const int S1 = p.S[1], S2 = p.S[2];
-    const int tr = threadIdx.x / p.CW, tc = threadIdx.x - tr * p.CW;
-    const bool worker = tr < R;
-    const int ji = tc * E;
-    const ColState<E> xm = make_colstate<E>(m2, ji, worker, p.lds_affine != 0);
-    const int row_end = wi.row0 + wi.nrows;
-    auto step_len = [&](int r0) {
-        const int b0 = r0 - fdiv(r0, p.d_dim1) * S1;
-        return min(R, min(S1 - b0, row_end - r0));
-    };
-    int nl = 0, r0 = wi.row0, buf = 0;
-    {
-        const int a = fdiv(r0, p.d_dim1);
-        Stager::make_slots(p, R, a, r0 - a * S1, step_len(r0), m0, m1, nullptr, nullptr, slot_src);
-    }
-    // pre-decoded DMA pieces and loop-carried plane bases, as in plane_backward_lds
-    int pk[Stager::kRegPieces];
-    const bool decoded = Stager::pieces_fit(static_cast<int>(p.cpr), R);
-    if (decoded) Stager::decode_pieces(p, R, pk);
-    __syncthreads();
-    const int64_t plane0 = static_cast<int64_t>(wi.n0) * p.C + wi.c;
-    const S *xp = static_cast<const S *>(p.x) + plane0 * p.x_plane;
-    S *op = static_cast<S *>(p.out) + plane0 * p.o_plane;
-    const int64_t xstep = static_cast<int64_t>(p.C) * p.x_plane, ostep = static_cast<int64_t>(p.C) * p.o_plane;
-    while (nl < wi.nn) {
-        const int a = fdiv(r0, p.d_dim1);
-        const int b0 = r0 - a * S1;
-        const int Rn = step_len(r0);
-        const int *ss = slot_src + buf * NS;
-        if (decoded) Stager::issue_dma_decoded(NS, xp, xp, ss, tile, pk);
-        else Stager::issue_dma(p, R, xp, xp, ss, tile);
-        int nl2 = nl, r2 = r0 + Rn;
-        if (r2 >= row_end) { r2 = wi.row0; ++nl2; }
-        if (nl2 < wi.nn) {
-            const int a2 = fdiv(r2, p.d_dim1);
-            Stager::make_slots(p, R, a2, r2 - a2 * S1, step_len(r2), m0, m1, nullptr, nullptr, slot_src + (buf ^ 1) * NS);
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (worker && tr < Rn) {
-            CT xv[NC][E + 1];
-            lds_corners<T, ND>(tile, RB, R, 0, ss, tr, xm, xv);
-            Chunk<S, E> res;
-#pragma unroll
-            for (int e = 0; e < E; ++e) {
-                CT v[1 << ND];
-#pragma unroll
-                for (int q = 0; q < (1 << ND); ++q) v[q] = xv[q & (NC - 1)][e + (q >> (ND - 1))];
-                res.e[e] = narrow<T>(interp_t<T, ND>(v, dw));
-            }
-            store_chunk<S, E>(op + static_cast<int64_t>(a * S1 + b0 + tr) * S2 + ji, res);
-        }
-        __syncthreads();
-        if (nl2 != nl) {
-            xp += xstep;
-            op += ostep;
-        }
-        nl = nl2;
-        r0 = r2;
-        buf ^= 1;
-    }
-}
-
 // =====================================================================================================
 // Host side: launch planning
 // =====================================================================================================
@@ -1489,14 +1398,8 @@ void launch_gather(const PlaneParams &p, const Plan &pl, hipStream_t st) {
     if constexpr (V < 16) {
         hipLaunchKernelGGL((plane_gather_forward<ESIZE, V, 2>), dim3(pl.grid), dim3(kThreads), pl.lds, st, p);
         return;
-    } else if constexpr (ESIZE == 4 && V == 16) {
-        switch (g_tune[2]) {
-        case 1: hipLaunchKernelGGL((plane_gather_forward<ESIZE, V, 1>), dim3(pl.grid), dim3(kThreads), pl.lds, st, p); return;
-        case 2: hipLaunchKernelGGL((plane_gather_forward<ESIZE, V, 2>), dim3(pl.grid), dim3(kThreads), pl.lds, st, p); return;
-        case 8: hipLaunchKernelGGL((plane_gather_forward<ESIZE, V, 8>), dim3(pl.grid), dim3(kThreads), pl.lds, st, p); return;
-        default: break;
-        }
     }
+    // (row steps per thread: 4; the other unrolls knob 2 once chose for 4-byte elements are no longer built)
     if constexpr (V >= 16) hipLaunchKernelGGL((plane_gather_forward<ESIZE, V, 4>), dim3(pl.grid), dim3(kThreads), pl.lds, st, p);
 }
 
@@ -1517,21 +1420,9 @@ bool lds_staged_ok(const PlaneParams &p, const Plan &pl, int esize, int slots, s
 
 template <typename T>
 int launch_active_forward(const PlaneParams &p_in, const Plan &pl, hipStream_t st) {
-    PlaneParams p = p_in;
-    if (g_tune[3] == 2 && p.nd >= 2) {  // LDS-staged form where it applies
-        size_t lds_bytes = 0;
-        int tile_bytes = 0;
-        const int slots = p.nd == 3 ? LdsTileShape<3, true, false>::slots(pl.RPS) : LdsTileShape<2, true, false>::slots(pl.RPS);
-        if (lds_staged_ok(p, pl, static_cast<int>(sizeof(typename T::S)), slots, &lds_bytes, &tile_bytes)) {
-            p.tile_bytes = tile_bytes;
-            note_kernel("plane_active_forward_lds");
-            if (p.nd == 3)
-                hipLaunchKernelGGL((plane_active_forward_lds<T, 3>), dim3(pl.grid), dim3(kThreads), lds_bytes, st, p);
-            else
-                hipLaunchKernelGGL((plane_active_forward_lds<T, 2>), dim3(pl.grid), dim3(kThreads), lds_bytes, st, p);
-            return SHIFTND_OK;
-        }
-    }
+    const PlaneParams &p = p_in;
+    // (the LDS-staged form, plane_active_forward_lds, is no longer built: every un-cropped problem of whole 16-byte rows it took is
+    //  step_forward_lds's, walk_forward's or slide_forward's -- no default-routed shape in tools/route_census.py's 6 000 problems)
     note_kernel("plane_active_forward");
     switch (p.nd) {
     case 1: hipLaunchKernelGGL((plane_active_forward<T, 1>), dim3(pl.grid), dim3(kThreads), pl.lds, st, p); break;
@@ -1879,6 +1770,102 @@ int plane_backward(const Geometry &g, int dtype, const void *go, const void *x, 
     case SHIFTND_F16: return launch_backward<f16_t>(p, pl, g.active != 0, gw, st);
     default: return launch_backward<bf16_t>(p, pl, g.active != 0, gw, st);
     }
+}
+
+// ---- 3-D volumes whose rows are not whole 16-byte pieces (round 5) -------------------------------------------------------------
+// 16 x 28 x 28 bf16 (56-byte rows), 8 x 56 x 62 fp32 ...: volumes beyond the small-plane kernels' 16 KiB.  The route census found
+// them on the strided fallback (one thread per element, 64-bit index arithmetic, one workgroup per (n, c)): 0.02 - 0.5 TB/s.  The
+// direct-load plane kernels serve them with chunks of 4 bytes (two 16-bit elements / one fp32) or 8 (one fp64): padding maps in LDS,
+// row bands across workgroups, coalesced element-aligned loads and stores.  Rows of an odd number of 16-bit elements stay on the
+// fallback.
+static int ragged_vector_bytes(int es, int64_t row_elems) {
+    if (es == 2) return row_elems % 2 == 0 ? 4 : 0;
+    return es;
+}
+
+bool plane_ragged_forward_eligible(const Geometry &g, int dtype, const void *x, const void *out) {
+    (void)x;
+    if (dtype > SHIFTND_BF16 || !g.active || g.nd != 3 || g.K[0] > 0 || !common_eligible(g)) return false;
+    if (g.S[0] + g.S[1] + g.S[2] + 3 > kMaxMapEntries) return false;
+    if (!contiguous(g.xs, g.N, g.C, g.S) || !contiguous(g.os, g.N, g.C, g.O)) return false;
+    const int es = dtype_size(dtype);
+    if ((g.O[2] * es) % 16 == 0) return false;   // (whole pieces: plane_forward)
+    const int vb = ragged_vector_bytes(es, g.O[2]);
+    return vb != 0 && reinterpret_cast<uintptr_t>(out) % vb == 0;
+}
+
+int plane_ragged_forward(const Geometry &g, int dtype, const void *x, const void *w, void *out, hipStream_t st) {
+    const int es = dtype_size(dtype);
+    const int entries = static_cast<int>(g.S[0] + g.S[1] + g.S[2] + 3);
+    PlaneParams p{};
+    p.x = x;
+    p.out = out;
+    p.w = w;
+    p.wkind = dtype;
+    const Plan pl = make_plan(g, g.O[0] * g.O[1], g.O[2], es, ragged_vector_bytes(es, g.O[2]), entries);
+    fill_params(p, g, pl, g.O[1]);
+    note_kernel("plane_active_forward_ragged");
+    const dim3 grid(pl.grid), block(kThreads);
+    switch (dtype) {
+    case SHIFTND_F32: hipLaunchKernelGGL((plane_active_forward<f32_t, 3, 4>), grid, block, pl.lds, st, p); break;
+    case SHIFTND_F64: hipLaunchKernelGGL((plane_active_forward<f64_t, 3, 8>), grid, block, pl.lds, st, p); break;
+    case SHIFTND_F16: hipLaunchKernelGGL((plane_active_forward<f16_t, 3, 4>), grid, block, pl.lds, st, p); break;
+    default: hipLaunchKernelGGL((plane_active_forward<bf16_t, 3, 4>), grid, block, pl.lds, st, p); break;
+    }
+    return SHIFTND_OK;
+}
+
+static Plan ragged_backward_plan(const Geometry &g, int es) {
+    const int entries = static_cast<int>(g.S[0] + g.S[1] + g.S[2] + g.O[0] + g.O[1] + g.O[2] + 6);
+    const int vb = ragged_vector_bytes(es, g.S[2]);
+    return make_plan(g, g.S[0] * g.S[1], g.S[2], es, vb ? vb : es, entries, backward_min_wgs(g, es));
+}
+
+bool plane_ragged_backward_eligible(const Geometry &g, int dtype, const void *go, const void *x, const void *gx) {
+    (void)go;
+    (void)x;
+    if (dtype > SHIFTND_BF16 || g.nd != 3 || g.K[0] > 0 || !common_eligible(g)) return false;
+    if (g.S[0] + g.S[1] + g.S[2] + g.O[0] + g.O[1] + g.O[2] + 6 > kMaxMapEntries) return false;
+    if (!contiguous(g.xs, g.N, g.C, g.S) || !contiguous(g.os, g.N, g.C, g.O) || !contiguous(g.gs, g.N, g.C, g.S)) return false;
+    const int es = dtype_size(dtype);
+    if ((g.S[2] * es) % 16 == 0) return false;   // (whole pieces: plane_backward)
+    const int vb = ragged_vector_bytes(es, g.S[2]);
+    // (the incoming gradient's rows are read by element-aligned loads: a window along the row needs no alignment of its own)
+    return vb != 0 && reinterpret_cast<uintptr_t>(gx) % vb == 0;
+}
+
+size_t plane_ragged_backward_workspace(const Geometry &g, int dtype) {
+    if (dtype > SHIFTND_BF16 || g.nd != 3 || g.C < 1 || g.N < 1 || g.S[0] * g.S[1] * g.S[2] < 1) return 0;
+    const Plan pl = ragged_backward_plan(g, dtype_size(dtype));
+    return static_cast<size_t>(pl.groups) * pl.bands * static_cast<size_t>(g.C) * 3 * sizeof(double);
+}
+
+int plane_ragged_backward(const Geometry &g, int dtype, const void *go, const void *x, const void *w, void *gx, void *gw,
+                          void *workspace, hipStream_t st) {
+    const Plan pl = ragged_backward_plan(g, dtype_size(dtype));
+    PlaneParams p{};
+    p.x = x;
+    p.go = go;
+    p.out = gx;
+    p.w = w;
+    p.wkind = dtype;
+    p.partials = static_cast<double *>(workspace);
+    fill_params(p, g, pl, g.S[1]);
+    note_kernel("plane_backward_ragged");
+    const dim3 grid(pl.grid), block(kThreads);
+    const bool active = g.active != 0;
+#define SHIFTND_RAGGED_BWD(TT, VBV) \
+    if (active) hipLaunchKernelGGL((plane_backward<TT, 3, true, false, VBV>), grid, block, pl.lds, st, p); \
+    else hipLaunchKernelGGL((plane_backward<TT, 3, false, false, VBV>), grid, block, pl.lds, st, p); \
+    reduce_weight_grads_of<TT>(p.partials, pl.groups * pl.bands, p.C, p.nd, gw, st);
+    switch (dtype) {
+    case SHIFTND_F32: SHIFTND_RAGGED_BWD(f32_t, 4) break;
+    case SHIFTND_F64: SHIFTND_RAGGED_BWD(f64_t, 8) break;
+    case SHIFTND_F16: SHIFTND_RAGGED_BWD(f16_t, 4) break;
+    default: SHIFTND_RAGGED_BWD(bf16_t, 4) break;
+    }
+#undef SHIFTND_RAGGED_BWD
+    return SHIFTND_OK;
 }
 
 }  // namespace shiftnd

@@ -39,6 +39,7 @@ constexpr int kWalkTileBytes = 4 * kWalkPlaneBytes;    // one tensor's tile
 constexpr int kWalkMargin = 2;                         // zero pieces in front of row 0
 constexpr int kWalkGuard = 2;                          // zero pieces behind every row
 constexpr int kWalkDump0 = 448;
+constexpr int kWalkSmall = 6;                          // |column shift| up to which the guards hold the folded row ends (paddings 1 .. 4)
 constexpr int kWalkFlush = 16;                         // planes between two flushes of the fp32 sums
 
 typedef uint32_t u4_t __attribute__((ext_vector_type(4)));
@@ -70,67 +71,80 @@ template <typename T> __device__ __forceinline__ float half_value(uint32_t dword
 
 // Column state of a thread's window through one map.  NA addresses: zeros padding 5 (the window's dwords); otherwise 9 --
 // a plain-shift chunk uses the first 5 as dword addresses, any other chunk all 9 as element addresses.
+//
+// Paddings 1 .. 4 with |shift| <= 6 (launch-uniform `small`: weights start in (-1, 1) and stay small): the window of a row-end
+// chunk reaches at most seven elements in front of its row and eight behind it -- the row's two guard pieces.  Every element there
+// is a fold of the row's FIRST or LAST piece (border: one element repeated; periodic: the other end's piece as it is; symmetric:
+// the piece reversed; reflect: reversed and moved by one element), and the threads that stage those two pieces hold them in
+// registers: they park a second, permuted copy into the guards (walk_park_guards), so EVERY chunk reads its window as five plain
+// dwords, exactly like the zeros-padding kernel.  (Round 4 read the window between ZERO guards and or-ed up to two folded elements
+// in per read for |shift| <= 1 -- 16 VGPRs of masks and addresses -- and every other shift made each wave, all of which hold some
+// row-end chunks, run the 9-address gather beside the plain path: 3 x the LDS instructions of the zeros-padding kernel.  Measured
+// and dropped in round 4: launch-uniform per-read fix-ups for |shift| <= 7 -- 127 -> 187 VGPRs.)
 template <int NA> struct WalkWindow {
     uint32_t at[NA];   // byte offsets within the tile, row 0 of the thread (row 1: + row pitch)
     bool plain;        // the window is 5 consecutive dwords
-    // paddings 1 .. 4, |shift| <= 1 (launch-uniform `small`: the common case -- weights start in (-1, 1)): the window is read as
-    // it lies between the row's ZERO guards and at most two elements from beyond the row's end are or-ed in: window element 0
-    // (left end) or elements 7 and 8 (right end), each the folded column's element replicated into both halves and masked into
-    // dword 0, 3 or 4.  No thread-dependent branch: without this every wave (each holds some row-end chunks) ran the 9-address
-    // gather path beside the plain one -- 3 x the LDS instructions and 2 x the scalar ones of the zeros-padding kernel.
-    // (Measured and dropped: two more launch-uniform modes for |shift| <= 7 -- border: one edge element and five dword masks;
-    //  periodic: a second plain window one row length away -- took the kernel from 127 to 187 VGPRs, two waves per SIMD.)
-    bool small;
-    uint32_t fix_at[NA > 5 ? 2 : 1];      // byte offset (row 0) of the source element; the zero margin when there is none
-    uint32_t fix_m[NA > 5 ? 2 : 1][3];    // its mask in dwords 0, 3, 4 of the window
 };
+
+// The guard pieces of the row whose first piece sits in slot `slot0`: slot0 - 1 (elements -8 .. -1) and slot0 + cpr (elements
+// S2 .. S2 + 7).  A thread that holds the row's first / last piece `v` (v.x = elements 0, 1 ... v.w = elements 6, 7 of the piece)
+// parks the fold of it:
+//   left guard  (from the FIRST piece f; periodic: the LAST piece as it is)
+//       border     f0 f0 f0 f0 f0 f0 f0 f0          symmetric  f7 f6 f5 f4 f3 f2 f1 f0        reflect  -- f7 f6 f5 f4 f3 f2 f1
+//   right guard (from the LAST piece l; periodic: the FIRST piece as it is)
+//       border     l7 l7 l7 l7 l7 l7 l7 l7          symmetric  l7 l6 l5 l4 l3 l2 l1 l0        reflect  l6 l5 l4 l3 l2 l1 l0 --
+// (--: element -8 / S2 + 7, which no window of |shift| <= 6 reads.)  Threads with nothing to park are given a dump slot: the four
+// stores are unconditional.
+struct WalkGuards { uint32_t at; bool left; };
+__device__ __forceinline__ WalkGuards walk_guards(bool fill, bool own, bool first, bool last, int pad, int slot0, int cpr, int lane) {
+    const bool wrap = pad == 2;   // periodic: the guards come from the other end of the row
+    WalkGuards g;
+    g.left = wrap ? last : first;
+    const bool on = fill && own && (first || last);
+    g.at = static_cast<uint32_t>(on ? (g.left ? slot0 - 1 : slot0 + cpr) : kWalkDump0 + lane) * 4u;
+    return g;
+}
+__device__ __forceinline__ void walk_park_guards(char *tile, const WalkGuards &g, const u4_t &v, int pad) {
+    auto rot = [](uint32_t a) { return __builtin_amdgcn_alignbit(a, a, 16); };   // swap the halves
+    const u4_t rev = u4_t{rot(v.w), rot(v.z), rot(v.y), rot(v.x)};                // e7 e6 | e5 e4 | e3 e2 | e1 e0
+    u4_t o;
+    if (pad == 2) {          // (uniform)
+        o = v;
+    } else if (pad == 4) {
+        o = rev;
+    } else if (pad == 3) {   // the reversed piece moved by one element: towards the row on either side
+        const u4_t l = u4_t{rev.x << 16, __builtin_amdgcn_alignbit(rev.y, rev.x, 16), __builtin_amdgcn_alignbit(rev.z, rev.y, 16),
+                            __builtin_amdgcn_alignbit(rev.w, rev.z, 16)};                      // -- e7 | e6 e5 | e4 e3 | e2 e1
+        const u4_t r = u4_t{__builtin_amdgcn_alignbit(rev.y, rev.x, 16), __builtin_amdgcn_alignbit(rev.z, rev.y, 16),
+                            __builtin_amdgcn_alignbit(rev.w, rev.z, 16), rev.w >> 16};         // e6 e5 | e4 e3 | e2 e1 | e0 --
+        o = g.left ? l : r;
+    } else {                 // border: the row's first / last element
+        const uint32_t e = g.left ? (v.x & 0xffffu) : (v.w >> 16);
+        const uint32_t ee = e | (e << 16);
+        o = u4_t{ee, ee, ee, ee};
+    }
+    uint32_t *q = reinterpret_cast<uint32_t *>(tile + g.at);
+    q[0] = o.x;
+    q[kWalkSlots] = o.y;
+    q[2 * kWalkSlots] = o.z;
+    q[3 * kWalkSlots] = o.w;
+}
 
 template <bool ZEROS, int NA>
 __device__ __forceinline__ WalkWindow<NA> walk_window(int ji, int cs, int S2, int pad, int slot0, bool live, bool small) {
     WalkWindow<NA> w;
     w.plain = true;
-    w.small = !ZEROS && small;
     int D = 0;   // the margin: zeros
     const int first = ji - cs;   // column of window element 0
     if constexpr (ZEROS) {
         if (live && first + 8 >= 0 && first < S2) D = slot0 * 4 + ((first * 2) >> 2);   // (floor: first >= -8)
 #pragma unroll
         for (int i = 0; i < NA; ++i) w.at[i] = walk_dword_at(D + i);
-    } else if (small) {   // (uniform; cs is the SIGNED shift here, |cs| <= 1, and the row has at least two chunks)
+    } else if (small) {   // (uniform; cs is the SIGNED shift here, |cs| <= 6, and the row has at least two chunks: the guards hold
+                          //  the folded elements -- walk_park_guards -- and the window is five plain dwords)
         if (live) D = slot0 * 4 + ((first * 2) >> 2);
 #pragma unroll
         for (int i = 0; i < NA; ++i) w.at[i] = walk_dword_at(D + (i < 5 ? i : 4));
-        const int par = first & 1;
-        int nf = 0;
-        w.fix_at[0] = w.fix_at[1] = 0u;
-#pragma unroll
-        for (int f = 0; f < 2; ++f)
-#pragma unroll
-            for (int d = 0; d < 3; ++d) w.fix_m[f][d] = 0u;
-        const int ks[3] = {0, 7, 8};
-#pragma unroll
-        for (int t = 0; t < 3; ++t) {
-            const int col = first + ks[t];
-            if (live && (col < 0 || col >= S2)) {
-                const int hpos = ks[t] + par, dw = hpos >> 1;   // dword 0, 3 or 4
-                const uint32_t m = (hpos & 1) ? 0xffff0000u : 0x0000ffffu;
-                const uint32_t at = walk_elem_at(slot0, fold_index(col, S2, pad));
-                const int d = dw == 0 ? 0 : dw - 2;
-                // (static indexing: at most two of the three candidates are beyond the row)
-                if (nf == 0) {
-                    w.fix_at[0] = at;
-                    w.fix_m[0][0] = d == 0 ? m : 0u;
-                    w.fix_m[0][1] = d == 1 ? m : 0u;
-                    w.fix_m[0][2] = d == 2 ? m : 0u;
-                } else {
-                    w.fix_at[1] = at;
-                    w.fix_m[1][0] = d == 0 ? m : 0u;
-                    w.fix_m[1][1] = d == 1 ? m : 0u;
-                    w.fix_m[1][2] = d == 2 ? m : 0u;
-                }
-                ++nf;
-            }
-        }
     } else {
         int cm[9];
         bool run = true;
@@ -155,21 +169,6 @@ __device__ __forceinline__ WalkWindow<NA> walk_window(int ji, int cs, int S2, in
 // the 5 dwords of a window: half (k + PAR) of the result is window element k
 template <bool ZEROS, int NA, int PAR>
 __device__ __forceinline__ void walk_read(const char *tile, const WalkWindow<NA> &w, uint32_t row_off, uint32_t (&o)[5]) {
-    if constexpr (!ZEROS) {
-        if (w.small) {   // (uniform)
-#pragma unroll
-            for (int i = 0; i < 5; ++i) o[i] = *reinterpret_cast<const uint32_t *>(tile + w.at[i] + row_off);
-#pragma unroll
-            for (int f = 0; f < 2; ++f) {
-                const uint32_t e = *reinterpret_cast<const uint16_t *>(tile + w.fix_at[f] + row_off);
-                const uint32_t ee = e | (e << 16);
-                o[0] |= ee & w.fix_m[f][0];
-                o[3] |= ee & w.fix_m[f][1];
-                o[4] |= ee & w.fix_m[f][2];
-            }
-            return;
-        }
-    }
     if (ZEROS || w.plain) {
 #pragma unroll
         for (int i = 0; i < 5; ++i) o[i] = *reinterpret_cast<const uint32_t *>(tile + w.at[i] + row_off);
@@ -254,19 +253,25 @@ __global__ __launch_bounds__(kThreads) void walk_backward16(const StepParams p) 
         q[2 * kWalkSlots] = v.z;
         q[3 * kWalkSlots] = v.w;
     };
+    const int slot0 = kWalkMargin + tr * RP;
+    // (the signed column shifts; |shift| <= 6 and at least two chunks per row: the folded row ends live in the guards, see WalkWindow)
+    const int per2 = map_period(S2, pad);
+    const int sx2 = (!ZEROS && per2 && 2 * d.cx2 > per2) ? d.cx2 - per2 : d.cx2, sg2 = (!ZEROS && per2 && 2 * d.cg2 > per2) ? d.cg2 - per2 : d.cg2;
+    const bool small_x = !ZEROS && cpr >= 2 && sx2 >= -kWalkSmall && sx2 <= kWalkSmall, small_g = !ZEROS && cpr >= 2 && sg2 >= -kWalkSmall && sg2 <= kWalkSmall;
+    const WalkGuards gdx = walk_guards(small_x, own, tc == 0, tc == cpr - 1, pad, slot0, cpr, tid & 63);
+    const WalkGuards gdg = walk_guards(small_g, own && (ACTIVE || tr < R), tc == 0, tc == cpr - 1, pad, slot0, cpr, tid & 63);
     auto park = [&](const Staged &v) {
         park_piece(tx, v.xo);
         park_piece(tg, v.go);
+        if constexpr (!ZEROS) {
+            if (small_x) walk_park_guards(tx, gdx, v.xo, pad);   // (uniform)
+            if (small_g) walk_park_guards(tg, gdg, v.go, pad);
+        }
     };
 
     // ---- this thread's chunk ---------------------------------------------------------------------------------------------------
     const bool mine = tr < R && tr < Rn;
     const int b = b0 + tr;
-    const int slot0 = kWalkMargin + tr * RP;
-    // (the signed column shifts; |shift| <= 1 and at least two chunks per row: the fix-up reader, see WalkWindow)
-    const int per2 = map_period(S2, pad);
-    const int sx2 = (!ZEROS && per2 && 2 * d.cx2 > per2) ? d.cx2 - per2 : d.cx2, sg2 = (!ZEROS && per2 && 2 * d.cg2 > per2) ? d.cg2 - per2 : d.cg2;
-    const bool small_x = !ZEROS && cpr >= 2 && sx2 >= -1 && sx2 <= 1, small_g = !ZEROS && cpr >= 2 && sg2 >= -1 && sg2 <= 1;
     const WalkWindow<NA> wx = walk_window<ZEROS, NA>(ji, small_x ? sx2 : d.cx2, S2, pad, slot0, mine, small_x);
     const WalkWindow<NA> wg = walk_window<ZEROS, NA>(ji, small_g ? sg2 : d.cg2, S2, pad, slot0, mine, small_g);
     const uint32_t row1 = static_cast<uint32_t>(RP) * 4u;
@@ -493,18 +498,22 @@ __global__ __launch_bounds__(kThreads) void walk_forward16(const FwdParams p) {
     auto load_plane = [&](int pa) {   // source plane (uniform; -1: fill)
         return __builtin_amdgcn_raw_buffer_load_b128(pa >= 0 ? xres : none, vx_own, pa >= 0 ? static_cast<uint32_t>(pa) * plane_bytes : 0u, 0);
     };
+    const bool mine = tr < R && tr < Rn;
+    const int slot0 = kWalkMargin + tr * RP;
+    const int per2 = map_period(S2, pad);
+    const int ss2 = (!ZEROS && per2 && 2 * cs2 > per2) ? cs2 - per2 : cs2;   // the signed column shift
+    const bool small_x = !ZEROS && cpr >= 2 && ss2 >= -kWalkSmall && ss2 <= kWalkSmall;
+    const WalkGuards gdx = walk_guards(small_x, own, tc == 0, tc == cpr - 1, pad, slot0, cpr, tid & 63);
     auto park = [&](const u4_t &v) {
         uint32_t *q = reinterpret_cast<uint32_t *>(tx + park_at);
         q[0] = v.x;
         q[kWalkSlots] = v.y;
         q[2 * kWalkSlots] = v.z;
         q[3 * kWalkSlots] = v.w;
+        if constexpr (!ZEROS) {
+            if (small_x) walk_park_guards(tx, gdx, v, pad);   // (uniform: the folded row ends, see WalkWindow)
+        }
     };
-    const bool mine = tr < R && tr < Rn;
-    const int slot0 = kWalkMargin + tr * RP;
-    const int per2 = map_period(S2, pad);
-    const int ss2 = (!ZEROS && per2 && 2 * cs2 > per2) ? cs2 - per2 : cs2;   // the signed column shift
-    const bool small_x = !ZEROS && cpr >= 2 && ss2 >= -1 && ss2 <= 1;
     const WalkWindow<NA> wx = walk_window<ZEROS, NA>(ji, small_x ? ss2 : cs2, S2, pad, slot0, mine, small_x);
     const uint32_t row1 = static_cast<uint32_t>(RP) * 4u;
     const int px = (small_x ? ss2 : cs2) & 1;

@@ -1,0 +1,98 @@
+"""3-D volumes whose rows are not whole 16-byte pieces, beyond the small-plane kernels' 16 KiB (16 x 28 x 28 bf16, 8 x 30 x 62 fp32 ...):
+the direct-load plane kernels with 4- / 8-byte chunks (csrc/shiftnd_plane.hip: plane_ragged_forward / plane_ragged_backward) instead
+of the one-thread-per-element fallback the route census found them on.  Every padding, both shifts, windows; fp32 / fp64 bit-exact
+with the oracle, 16-bit within 1 ulp, grad_w within the parity bars (reference: kernels/shifts_kernels.h:156-327)."""
+import numpy as np
+import pytest
+import torch
+
+from cases import rel_err, gw16_tol
+from oracle import oracle as O
+from test_hip_parity import _ulp_close, _weights
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+TDT = {"f32": torch.float32, "f64": torch.float64, "f16": torch.float16, "bf16": torch.bfloat16}
+
+# (shape, cut): rows of 28 / 30 / 62 / 110 elements; volumes of 19 - 60 KB
+CASES = [((2, 3, 16, 28, 28), None), ((1, 2, 8, 30, 62), None), ((2, 2, 9, 20, 30), None), ((1, 2, 3, 40, 110), None),
+         ((1, 2, 10, 30, 62), [[1, 0], [0, 2], [3, 1]]), ((1, 3, 12, 28, 30), [[0, 1], [2, 0], [0, 2]])]
+
+
+@pytest.fixture(scope="module")
+def abi():
+    from torchshifts import abi as A
+    assert torch.cuda.is_available(), "the gpu tests need an MI355X"
+    A.set_path_policy(0)
+    return A
+
+
+def _serves(shape, new, es, backward):
+    """plane_ragged_*_eligible's geometry part: 3-D, ragged rows of whole 4-byte groups, beyond the small-plane kernels"""
+    rows = shape[-1] if backward else new[-1]
+    if (rows * es) % 16 == 0 or (es == 2 and rows % 2):
+        return False
+    cropped = list(shape[2:]) != list(new[2:])
+    return cropped or int(np.prod(shape[2:])) * es > 16 * 1024
+
+
+@pytest.mark.parametrize("dt", ["f32", "f64", "f16", "bf16"])
+@pytest.mark.parametrize("shape,crop", CASES)
+def test_ragged_volumes_vs_oracle(abi, shape, crop, dt):
+    tdt = TDT[dt]
+    b, new = abi.check_borders(list(shape), crop, 3)
+    rs = np.random.RandomState(sum(shape) * 5 + 1)
+    xt = torch.from_numpy(rs.uniform(-1, 1, size=shape)).to(tdt)
+    gt = torch.from_numpy(rs.uniform(-1, 1, size=new)).to(tdt)
+    wt = torch.from_numpy(_weights(rs, shape[1], 3, shape[2:])).to(tdt)
+    wide = np.float64 if tdt == torch.float64 else np.float32
+    x, go, w = (t.to(torch.float64).numpy().astype(wide) for t in (xt, gt, wt))
+    xd, god, wd = xt.to(DEV), gt.to(DEV), wt.to(DEV)
+    es = xt.element_size()
+    for pad in range(5):
+        out = abi.forward(xd, wd, pad, 1, b)
+        if _serves(shape, new, es, False):
+            assert abi.last_kernel() == "plane_active_forward_ragged", (shape, crop, dt, abi.last_kernel())
+        ref = torch.from_numpy(O.forward(x, w, pad, 1, b)).to(tdt)
+        if es >= 4:
+            assert torch.equal(out.cpu(), ref), ("fwd", shape, crop, dt, pad)
+        else:
+            assert _ulp_close(out.cpu(), ref, tdt), ("fwd", shape, crop, dt, pad)
+        for active in (0, 1):
+            gx, gw = abi.backward(god, wd, xd, pad, active, b)
+            if _serves(shape, new, es, True):
+                assert abi.last_kernel() == "plane_backward_ragged", (shape, crop, dt, abi.last_kernel())
+            gx_ref = torch.from_numpy(O.backward(go, w, x, pad, active, b)[0]).to(tdt)
+            if es >= 4 or not active:
+                assert torch.equal(gx.cpu(), gx_ref), ("gx", shape, crop, dt, pad, active)
+            else:
+                assert _ulp_close(gx.cpu(), gx_ref, tdt), ("gx", shape, crop, dt, pad, active)
+            _, gw64 = O.backward(go.astype(np.float64), w.astype(np.float64), x.astype(np.float64), pad, active, b)
+            tol = {"f32": 1e-5, "f64": 1e-12}.get(dt, gw16_tol(torch.finfo(tdt).eps))
+            assert rel_err(gw.to(torch.float64).cpu().numpy(), gw64) < tol, ("gw", shape, crop, dt, pad, active)
+            gx2, gw2 = abi.backward(god, wd, xd, pad, active, b)
+            assert torch.equal(gx, gx2) and torch.equal(gw, gw2)   # deterministic
+
+
+def test_ragged_volume_at_size(abi):
+    """N8 C128 16 x 28 x 28 bf16 (a video network's 28 x 28 stage): linearity of the backward in the incoming gradient and the
+    forward's values (1 ulp) against the strided fallback (policy 1), which the oracle-sized cases above pin"""
+    torch.manual_seed(5)
+    shape = (8, 128, 16, 28, 28)
+    x = torch.rand(shape, device=DEV).bfloat16()
+    go = torch.rand(shape, device=DEV).bfloat16()
+    w = ((torch.rand(shape[1], 3, device=DEV) * 2 - 1) * 1.5).bfloat16()
+    for pad in (0, 2, 4):
+        out = abi.forward(x, w, pad, 1)
+        assert abi.last_kernel() == "plane_active_forward_ragged"
+        gx, gw = abi.backward(go, w, x, pad, 1)
+        assert abi.last_kernel() == "plane_backward_ragged"
+        abi.set_path_policy(1)
+        try:
+            out_s = abi.forward(x, w, pad, 1)
+            gx_s, gw_s = abi.backward(go, w, x, pad, 1)
+        finally:
+            abi.set_path_policy(0)
+        # (two 16-bit kernel families: 1 ulp -- the compiler may fuse the last blend and the rounding in one of them)
+        assert _ulp_close(out.cpu(), out_s.cpu(), torch.bfloat16) and _ulp_close(gx.cpu(), gx_s.cpu(), torch.bfloat16), pad
+        assert (gw.float() - gw_s.float()).abs().max().item() <= gw16_tol(torch.finfo(torch.bfloat16).eps) * max(1.0, gw_s.float().abs().max().item())

@@ -67,6 +67,7 @@ FAMILY_ROUTES = [
     ("backward", "crop_backward_ragged", "float64", (2, 1, 100, 225), None, 2, 1, False),
     ("backward", "flat_backward", "bfloat16", (2, 2, 7, 11), None, 1, 0, False),
     ("backward", "plane_backward", "float32", (1, 1, 48), None, 2, 0, False),
+    ("backward", "plane_backward_ragged", "bfloat16", (1, 2, 16, 28, 28), None, 3, 1, False),   # (added with the kernels, after the census)
     ("backward", "plane_backward_lds", "float64", (1, 2, 14, 3, 24), None, 2, 1, False),
     ("backward", "row_backward", "float64", (1, 16, 1000), None, 1, 0, False),
     ("backward", "slide_backward", "float16", (1, 1, 1, 2, 200), None, 0, 0, False),
@@ -90,6 +91,7 @@ FAMILY_ROUTES = [
     ("forward", "flat_active_forward", "bfloat16", (3, 3, 112, 3), None, 1, 1, False),
     ("forward", "flat_gather_forward", "bfloat16", (2, 2, 7, 11), None, 1, 0, False),
     ("forward", "plane_active_forward", "float64", (1, 16, 96), None, 1, 1, False),
+    ("forward", "plane_active_forward_ragged", "float32", (1, 2, 8, 30, 62), None, 1, 1, False),
     ("forward", "plane_gather_forward", "float32", (2, 1, 1), None, 1, 0, False),
     ("forward", "plane_gather_forward_lds", "float16", (2, 1, 384), None, 4, 0, False),
     ("forward", "ragged_active_forward", "float32", (1, 1, 16, 62), None, 0, 1, False),

@@ -368,12 +368,14 @@ def test_3d_walk_backward_vs_oracle(abi, shape, dt):
 
 
 @pytest.mark.parametrize("dt", ["f16", "bf16"])
-@pytest.mark.parametrize("shape", [(2, 6, 5, 6, 16), (1, 8, 3, 9, 64), (2, 4, 4, 40, 112), (1, 5, 2, 3, 8), (2, 160, 5, 48, 112)])
+@pytest.mark.parametrize("shape", [(2, 20, 5, 6, 16), (1, 20, 3, 9, 64), (2, 20, 4, 40, 112), (1, 20, 2, 3, 8), (2, 160, 5, 48, 112)])
 def test_3d_walk_small_shifts_vs_oracle(abi, shape, dt):
-    """The fix-up window reader of the generic-padding walk kernels (shiftnd_walk.hip, WalkWindow::small: |column shift| <= 1 --
-    weights as the reference initialises them, uniform in (-1, 1), plus exact -1 / 0 / 1 and one channel beyond 1 that keeps the
-    gather path): paddings 1 .. 4, forward and both backwards; rows of one chunk (no fix-up reader), two chunks, many; 960
-    workgroups.  16-bit interpolation within 1 ulp, the sparse shift bit-exact, grad_w within half an ulp of the largest entry"""
+    """The folded row ends of the generic-padding walk kernels (shiftnd_walk.hip, WalkWindow / walk_park_guards: for |column shift|
+    <= 6 the threads that stage a row's first and last piece park a permuted copy in the row's guard pieces and every window is five
+    plain dwords): weights as the reference initialises them, uniform in (-1, 1), plus every integral column shift in -8 .. 8 and
+    the half-way ones around the limit (7 and beyond keep the 9-address gather path); paddings 1 .. 4, forward and both backwards;
+    rows of one chunk (no guards), two chunks (the first and the last piece are neighbours), many; 960 workgroups.  16-bit
+    interpolation within 1 ulp, the sparse shift bit-exact, grad_w within half an ulp of the largest entry"""
     tdt = {"f16": torch.float16, "bf16": torch.bfloat16}[dt]
     rs = np.random.RandomState(sum(shape) * 3 + 11)
     C = shape[1]
@@ -381,7 +383,8 @@ def test_3d_walk_small_shifts_vs_oracle(abi, shape, dt):
     w[0] = [1.0, -1.0, 1.0]
     w[1] = [0.0, 0.5, -1.0]
     w[2] = [-0.75, 1.0, 0.0]
-    w[3] = [0.25, -0.5, 2.5]   # beyond 1: this channel's workgroups keep the gather path
+    for k, col in enumerate([2.5, -2.0, 3.0, -4.5, 5.0, -5.75, 6.0, -6.0, 6.5, -6.5, 7.0, -7.0, 8.0, -8.25, 5.5, -3.25, 4.0]):
+        w[3 + k] = [0.25 * ((k % 5) - 2), -0.5 * ((k % 3) - 1), col]
     xt = torch.from_numpy(rs.uniform(-1, 1, size=shape)).to(tdt)
     gt = torch.from_numpy(rs.uniform(-1, 1, size=shape)).to(tdt)
     wt = torch.from_numpy(w).to(tdt)

@@ -419,7 +419,6 @@ static int launch_cl_backward(const ClParams &p, const Geometry &g, const ClPlan
     default: SHIFTND_CL_BWD(3) break;
     }
 #undef SHIFTND_CL_BWD
-    const int cn = p.C * p.nd;
     reduce_weight_grads_of<T>(p.partials, pl.pgroups, p.C, p.nd, gw, st);
     return SHIFTND_OK;
 }

@@ -1548,7 +1548,6 @@ int launch_backward(const PlaneParams &p, const Plan &pl, bool active, void *gw,
         else launch_backward_pool<T, false>(p, pl, st);
     } else if (active) launch_backward_a<T, true>(p, pl, st);
     else launch_backward_a<T, false>(p, pl, st);
-    const int cn = p.C * p.nd;
     reduce_weight_grads_of<T>(p.partials, pl.groups * pl.bands, p.C, p.nd, gw, st);
     return SHIFTND_OK;
 }

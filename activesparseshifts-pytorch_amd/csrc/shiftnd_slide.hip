@@ -829,7 +829,7 @@ int slide_backward(const Geometry &g, int dtype, const void *go, const void *x, 
     p.partials = static_cast<double *>(workspace);
     fill_slide(p, g, pl);
     note_kernel("slide_backward");
-    const int cn = p.C * p.nd, groups = pl.groups * pl.inner;
+    const int groups = pl.groups * pl.inner;
 #define SHIFTND_SLIDE_BWD(TT) \
     { \
         if (g.active) launch_slide_backward<TT, true>(p, pl, st); \

@@ -1188,7 +1188,6 @@ size_t span_backward_workspace(const Geometry &g, int dtype) { return span_geome
 
 template <typename T, int ND, bool XRAG = false>
 static void launch_span_backward(const SpanParams &p, const SpanPlan &sp, bool active, void *gw, hipStream_t st) {
-    using S = typename T::S;
     const dim3 grid(p.steps_per_xcd * 8), block(kThreads);
 #define SHIFTND_SPAN_PAD(ACT, PADV) \
     case PADV: \

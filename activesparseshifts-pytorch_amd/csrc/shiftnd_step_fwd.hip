@@ -531,7 +531,7 @@ bool step_forward_lds_eligible(const Geometry &g, int dtype, const void *x, cons
 // (only the forms a call can reach are instantiated: the sparse shift as one raw 2-byte copy, the 3-D interpolation for 4- / 8-byte
 // elements -- walk_forward16 serves the 16-bit volumes)
 template <typename T, bool ACT>
-static void launch_step_forward_lds(const FwdParams &p, int pad, int U, size_t lds, hipStream_t st) {
+static void launch_step_forward_lds(const FwdParams &p, int pad, size_t lds, hipStream_t st) {
     const dim3 grid(p.steps_per_xcd * 8), block(kThreads);
     constexpr bool k3d = !ACT || sizeof(typename T::S) >= 4;
 #define SHIFTND_STEP_FWD_LDS(PADV) \
@@ -590,14 +590,14 @@ int step_forward_lds(const Geometry &g, int dtype, const void *x, const void *w,
     const size_t lds = 64 + static_cast<size_t>((g.nd == 3 && active) ? 2 : 1) * (U * p.R + (active ? 1 : 0)) * p.xppr * 16 + 64;
     note_kernel(active ? "step_active_forward" : "step_gather_forward_lds");
     if (!active) {  // a raw copy of 2-byte elements: one instantiation serves fp16 and bf16
-        launch_step_forward_lds<f16_t, false>(p, g.pad, U, lds, st);
+        launch_step_forward_lds<f16_t, false>(p, g.pad, lds, st);
         return SHIFTND_OK;
     }
     switch (dtype) {
-    case SHIFTND_F32: launch_step_forward_lds<f32_t, true>(p, g.pad, U, lds, st); break;
-    case SHIFTND_F64: launch_step_forward_lds<f64_t, true>(p, g.pad, U, lds, st); break;
-    case SHIFTND_F16: launch_step_forward_lds<f16_t, true>(p, g.pad, U, lds, st); break;
-    default: launch_step_forward_lds<bf16_t, true>(p, g.pad, U, lds, st); break;
+    case SHIFTND_F32: launch_step_forward_lds<f32_t, true>(p, g.pad, lds, st); break;
+    case SHIFTND_F64: launch_step_forward_lds<f64_t, true>(p, g.pad, lds, st); break;
+    case SHIFTND_F16: launch_step_forward_lds<f16_t, true>(p, g.pad, lds, st); break;
+    default: launch_step_forward_lds<bf16_t, true>(p, g.pad, lds, st); break;
     }
     return SHIFTND_OK;
 }

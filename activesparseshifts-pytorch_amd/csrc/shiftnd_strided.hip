@@ -239,7 +239,6 @@ int launch_strided_backward_nd(const Geometry &g, const void *go, const void *x,
         hipLaunchKernelGGL((strided_backward<T, ND, false>), dim3(static_cast<unsigned>(planes)), dim3(kThreads), 0, st, g,
                            static_cast<const S *>(go), static_cast<const S *>(x), static_cast<const S *>(w),
                            static_cast<S *>(gx), partials);
-    const int cn = static_cast<int>(g.C) * g.nd;
     reduce_weight_grads_of<T>(partials, static_cast<int>(g.N), static_cast<int>(g.C), g.nd, gw, st);
     return SHIFTND_OK;
 }

@@ -534,7 +534,6 @@ template <typename T, bool ACTIVE> void launch_backward_nd(const SweepParams &p,
 template <typename T> int launch_backward(const SweepParams &p, bool active, int groups, void *gw, hipStream_t st) {
     if (active) launch_backward_nd<T, true>(p, st);
     else launch_backward_nd<T, false>(p, st);
-    const int cn = p.C * p.nd;
     reduce_weight_grads_of<T>(p.partials, groups, p.C, p.nd, gw, st);
     return SHIFTND_OK;
 }

@@ -130,7 +130,7 @@ __device__ __forceinline__ void walk_park_guards(char *tile, const WalkGuards &g
     q[3 * kWalkSlots] = o.w;
 }
 
-template <bool ZEROS, int NA>
+template <bool ZEROS, int NA, bool LEAN = false>
 __device__ __forceinline__ WalkWindow<NA> walk_window(int ji, int cs, int S2, int pad, int slot0, bool live, bool small) {
     WalkWindow<NA> w;
     w.plain = true;
@@ -140,7 +140,7 @@ __device__ __forceinline__ WalkWindow<NA> walk_window(int ji, int cs, int S2, in
         if (live && first + 8 >= 0 && first < S2) D = slot0 * 4 + ((first * 2) >> 2);   // (floor: first >= -8)
 #pragma unroll
         for (int i = 0; i < NA; ++i) w.at[i] = walk_dword_at(D + i);
-    } else if (small) {   // (uniform; cs is the SIGNED shift here, |cs| <= 6, and the row has at least two chunks: the guards hold
+    } else if (LEAN || small) {   // (uniform; cs is the SIGNED shift here, |cs| <= 6, and the row has at least two chunks: the guards hold
                           //  the folded elements -- walk_park_guards -- and the window is five plain dwords)
         if (live) D = slot0 * 4 + ((first * 2) >> 2);
 #pragma unroll
@@ -188,12 +188,15 @@ __device__ __forceinline__ void walk_read(const char *tile, const WalkWindow<NA>
     }
 }
 
-template <typename T, bool ACTIVE, bool ZEROS>
-__global__ __launch_bounds__(kThreads) void walk_backward16(const StepParams p) {
+// LEAN (paddings 1 .. 4): the workgroup's channel has small column shifts in both maps -- every window is five plain dwords between
+// filled guards, no gather path, five window addresses instead of nine.  The kernel picks the body per workgroup (its channel's shifts).
+template <typename T, bool ACTIVE, bool ZEROS, bool LEAN>
+__device__ __forceinline__ void walk_backward16_body(const StepParams &p) {
     using S = typename T::S;
     static_assert(sizeof(S) == 2, "16-bit element types");
     constexpr int E = 8;
-    constexpr int NA = ZEROS ? 5 : 9;
+    constexpr bool PLAIN = ZEROS || LEAN;   // (what walk_read needs to know)
+    constexpr int NA = PLAIN ? 5 : 9;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char *const tx = smem;
     char *const tg = smem + kWalkTileBytes;
@@ -257,7 +260,7 @@ __global__ __launch_bounds__(kThreads) void walk_backward16(const StepParams p) 
     // (the signed column shifts; |shift| <= 6 and at least two chunks per row: the folded row ends live in the guards, see WalkWindow)
     const int per2 = map_period(S2, pad);
     const int sx2 = (!ZEROS && per2 && 2 * d.cx2 > per2) ? d.cx2 - per2 : d.cx2, sg2 = (!ZEROS && per2 && 2 * d.cg2 > per2) ? d.cg2 - per2 : d.cg2;
-    const bool small_x = !ZEROS && cpr >= 2 && sx2 >= -kWalkSmall && sx2 <= kWalkSmall, small_g = !ZEROS && cpr >= 2 && sg2 >= -kWalkSmall && sg2 <= kWalkSmall;
+    const bool small_x = LEAN || (!ZEROS && cpr >= 2 && sx2 >= -kWalkSmall && sx2 <= kWalkSmall), small_g = LEAN || (!ZEROS && cpr >= 2 && sg2 >= -kWalkSmall && sg2 <= kWalkSmall);
     const WalkGuards gdx = walk_guards(small_x, own, tc == 0, tc == cpr - 1, pad, slot0, cpr, tid & 63);
     const WalkGuards gdg = walk_guards(small_g, own && (ACTIVE || tr < R), tc == 0, tc == cpr - 1, pad, slot0, cpr, tid & 63);
     auto park = [&](const Staged &v) {
@@ -272,8 +275,8 @@ __global__ __launch_bounds__(kThreads) void walk_backward16(const StepParams p) 
     // ---- this thread's chunk ---------------------------------------------------------------------------------------------------
     const bool mine = tr < R && tr < Rn;
     const int b = b0 + tr;
-    const WalkWindow<NA> wx = walk_window<ZEROS, NA>(ji, small_x ? sx2 : d.cx2, S2, pad, slot0, mine, small_x);
-    const WalkWindow<NA> wg = walk_window<ZEROS, NA>(ji, small_g ? sg2 : d.cg2, S2, pad, slot0, mine, small_g);
+    const WalkWindow<NA> wx = walk_window<ZEROS, NA, LEAN>(ji, small_x ? sx2 : d.cx2, S2, pad, slot0, mine, small_x);
+    const WalkWindow<NA> wg = walk_window<ZEROS, NA, LEAN>(ji, small_g ? sg2 : d.cg2, S2, pad, slot0, mine, small_g);
     const uint32_t row1 = static_cast<uint32_t>(RP) * 4u;
     const int px = (small_x ? sx2 : d.cx2) & 1, pg = (small_g ? sg2 : d.cg2) & 1;   // half-word parity of the windows (uniform: rows are whole pieces)
     const float dP = static_cast<float>(d.dw[0]), dR = static_cast<float>(d.dw[1]), dC = static_cast<float>(d.dw[2]);
@@ -288,8 +291,8 @@ __global__ __launch_bounds__(kThreads) void walk_backward16(const StepParams p) 
     auto plane_blend = [&](auto par_tag, float (&B)[E]) {
         constexpr int PAR = decltype(par_tag)::value;
         uint32_t r0[5], r1[5];
-        walk_read<ZEROS, NA, PAR>(tg, wg, 0u, r0);
-        walk_read<ZEROS, NA, PAR>(tg, wg, row1, r1);
+        walk_read<PLAIN, NA, PAR>(tg, wg, 0u, r0);
+        walk_read<PLAIN, NA, PAR>(tg, wg, row1, r1);
         float rb[E + 1];
 #pragma unroll
         for (int k = 0; k <= E; ++k) {
@@ -304,8 +307,8 @@ __global__ __launch_bounds__(kThreads) void walk_backward16(const StepParams p) 
     // Column offset 0 / 1 of the corner = (sa, sb) for an even window, (sb, sa) for an odd one.
     auto wgrad = [&](auto par_tag, const u4_t &g, const uint32_t (&x0)[2][5], uint32_t (&x1)[2][5], float (&sa)[2][2], float (&sb)[2][2]) {
         constexpr int PAR = decltype(par_tag)::value;
-        walk_read<ZEROS, NA, PAR>(tx, wx, 0u, x1[0]);
-        walk_read<ZEROS, NA, PAR>(tx, wx, row1, x1[1]);
+        walk_read<PLAIN, NA, PAR>(tx, wx, 0u, x1[0]);
+        walk_read<PLAIN, NA, PAR>(tx, wx, row1, x1[1]);
         const uint32_t gq[4] = {g.x, g.y, g.z, g.w};
         const uint32_t gs[5] = {gq[0] << 16, __builtin_amdgcn_alignbit(gq[1], gq[0], 16), __builtin_amdgcn_alignbit(gq[2], gq[1], 16),
                                 __builtin_amdgcn_alignbit(gq[3], gq[2], 16), gq[3] >> 16};
@@ -343,11 +346,11 @@ __global__ __launch_bounds__(kThreads) void walk_backward16(const StepParams p) 
         park(v0);
         walk_barrier();
         if (px) {
-            walk_read<ZEROS, NA, 1>(tx, wx, 0u, xa[0]);
-            walk_read<ZEROS, NA, 1>(tx, wx, row1, xa[1]);
+            walk_read<PLAIN, NA, 1>(tx, wx, 0u, xa[0]);
+            walk_read<PLAIN, NA, 1>(tx, wx, row1, xa[1]);
         } else {
-            walk_read<ZEROS, NA, 0>(tx, wx, 0u, xa[0]);
-            walk_read<ZEROS, NA, 0>(tx, wx, row1, xa[1]);
+            walk_read<PLAIN, NA, 0>(tx, wx, 0u, xa[0]);
+            walk_read<PLAIN, NA, 0>(tx, wx, row1, xa[1]);
         }
         if constexpr (ACTIVE) {
             if (pg) plane_blend(par1{}, Ba);
@@ -393,11 +396,11 @@ __global__ __launch_bounds__(kThreads) void walk_backward16(const StepParams p) 
         } else {   // the sparse shift: the window itself (bit patterns kept)
             uint32_t t[5];
             if (pg) {
-                walk_read<ZEROS, NA, 1>(tg, wg, 0u, t);
+                walk_read<PLAIN, NA, 1>(tg, wg, 0u, t);
                 res = u4_t{__builtin_amdgcn_alignbit(t[1], t[0], 16), __builtin_amdgcn_alignbit(t[2], t[1], 16),
                            __builtin_amdgcn_alignbit(t[3], t[2], 16), __builtin_amdgcn_alignbit(t[4], t[3], 16)};
             } else {
-                walk_read<ZEROS, NA, 0>(tg, wg, 0u, t);
+                walk_read<PLAIN, NA, 0>(tg, wg, 0u, t);
                 res = u4_t{t[0], t[1], t[2], t[3]};
             }
         }
@@ -436,6 +439,24 @@ __global__ __launch_bounds__(kThreads) void walk_backward16(const StepParams p) 
 #pragma unroll
         for (int i = 1; i < 8; ++i) out = tid == i ? df[i] : out;
         p.partials[static_cast<size_t>(bid) * 8 + tid] = out;
+    }
+}
+
+template <typename T, bool ACTIVE, bool ZEROS>
+__global__ __launch_bounds__(kThreads) void walk_backward16(const StepParams p) {
+    if constexpr (ZEROS) {
+        walk_backward16_body<T, ACTIVE, true, false>(p);
+    } else {
+        const uint32_t bid = (blockIdx.x & 7u) * p.steps_per_xcd + (blockIdx.x >> 3);
+        if (bid >= p.total_steps) return;
+        const uint32_t plane = fdiv(bid, p.d_spp);
+        const int c = static_cast<int>(plane - fdiv(plane, p.d_C) * static_cast<uint32_t>(p.C));
+        const int cx2 = p.desc[c].cx2, cg2 = p.desc[c].cg2;
+        const int per2 = map_period(p.S2, p.pad);
+        const int sx2 = (per2 && 2 * cx2 > per2) ? cx2 - per2 : cx2, sg2 = (per2 && 2 * cg2 > per2) ? cg2 - per2 : cg2;
+        const bool lean = p.cpr >= 2 && sx2 >= -kWalkSmall && sx2 <= kWalkSmall && sg2 >= -kWalkSmall && sg2 <= kWalkSmall;   // (uniform)
+        if (lean) walk_backward16_body<T, ACTIVE, false, true>(p);
+        else walk_backward16_body<T, ACTIVE, false, false>(p);
     }
 }
 

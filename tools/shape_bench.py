@@ -30,7 +30,10 @@ ap = argparse.ArgumentParser()
 ap.add_argument("problems", nargs="+")
 ap.add_argument("--pads", default="0,3")
 ap.add_argument("--iters", type=int, default=20)
+ap.add_argument("--knobs", default="", help="knob=value,... (shiftnd_set_tuning)")
 a = ap.parse_args()
+for kv in filter(None, a.knobs.split(",")):
+    abi.set_tuning(int(kv.split("=")[0]), int(kv.split("=")[1]))
 for spec in a.problems:
     shp, dt = spec.split(":")
     shape = tuple(int(v) for v in shp.split(","))

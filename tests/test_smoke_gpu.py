@@ -15,5 +15,8 @@ def test_graft_entry_smoke():
         sys.path.insert(0, root)
     import __graft_entry__ as g
     from torchshifts import abi
+    from test_routing_gpu import KNOB_DEFAULTS
     abi.set_path_policy(0)
+    for knob, value in enumerate(KNOB_DEFAULTS):   # (other modules of the suite leave their knobs behind on this thread)
+        abi.set_tuning(knob, value)
     assert g.smoke() is None

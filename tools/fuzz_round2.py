@@ -419,6 +419,48 @@ CASES = [case_cl, case_ragged, case_ragged, case_bytes, case_step, case_step, ca
 
 
 
+def case_ragged3d(rs):
+    """round 5: 3-D volumes whose rows are not whole 16-byte pieces, beyond the small-plane kernels (plane_ragged_*: the plane kernels
+    with 4- / 8-byte chunks) and below them (small_plane_*): interpolating forward, both backwards, every padding, windows"""
+    from test_hip_parity import _ulp_close
+    tdt = [torch.float32, torch.float64, torch.float16, torch.bfloat16][rs.randint(4)]
+    es = torch.empty(0, dtype=tdt).element_size()
+    while True:
+        D = int(rs.choice([2, 3, 5, 9, 16])); H = int(rs.choice([3, 7, 14, 20, 30])); W = int(rs.choice([6, 7, 10, 14, 15, 22, 28, 30, 31, 62, 110]))
+        if (W * es) % 16 and D * H * W * es <= 96 * 1024:   # (fp64: the odd widths)
+            break
+    N, C = int(rs.randint(1, 3)), int(rs.randint(1, 4))
+    shape = (N, C, D, H, W)
+    crop = _random_crop(rs, shape[2:]) if rs.rand() < 0.3 else None
+    b, new = abi.check_borders(list(shape), crop, 3)
+    pad = int(rs.randint(0, 5))
+    xt = torch.from_numpy(rs.uniform(-1, 1, size=shape)).to(tdt); gt = torch.from_numpy(rs.uniform(-1, 1, size=new)).to(tdt)
+    wt = torch.from_numpy(weights(rs, C, 3, shape[2:], 3.5)).to(tdt)
+    wide = np.float64 if tdt == torch.float64 else np.float32
+    x, go, w = (t.to(torch.float64).numpy().astype(wide) for t in (xt, gt, wt))
+    xd, gd, wd = xt.to(DEV), gt.to(DEV), wt.to(DEV)
+    exact = tdt in (torch.float32, torch.float64)
+    last.update(shape=shape, tdt=tdt, pad=pad, xt=xt, gt=gt, wt=wt)
+    floor16 = 32 * 2.0 ** -24
+    o = abi.forward(xd, wd, pad, 1, b)
+    count[abi.last_kernel()] += 1
+    ref = torch.from_numpy(O.forward(x, w, pad, 1, b)).to(tdt)
+    assert torch.equal(o.cpu(), ref) if exact else _ulp_close(o.cpu(), ref, tdt, floor16), ("ragged3d fwd", shape, crop, tdt, pad, abi.last_kernel())
+    for active in (1, 0):
+        gx, gw = abi.backward(gd, wd, xd, pad, active, b)
+        k = abi.last_kernel()
+        count[k] += 1
+        gx_o = torch.from_numpy(O.backward(go, w, x, pad, active, b)[0]).to(tdt)
+        ok = torch.equal(gx.cpu(), gx_o) if (exact or not active) else _ulp_close(gx.cpu(), gx_o, tdt, floor16)
+        assert ok, ("ragged3d gx", shape, crop, tdt, pad, active, k)
+        _, gw64 = O.backward(go.astype(np.float64), w.astype(np.float64), x.astype(np.float64), pad, active, b)
+        tol = {torch.float64: 1e-12, torch.float32: 1e-5}.get(tdt, 0.51 * float(torch.finfo(tdt).eps))
+        assert rel_err(gw.to(torch.float64).cpu().numpy(), gw64) < tol, ("ragged3d gw", shape, crop, tdt, pad, active, k)
+
+
+CASES += [case_ragged3d, case_ragged3d]
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--seconds", type=float, default=120)

@@ -75,7 +75,10 @@ def test_cropped_backward_vs_oracle(abi, shape, crop, dt):
                 # a window of a few hundred elements can cancel to a small sum (case 9: 600 terms of ~0.3 add up to 0.14): there the
                 # reference's own fp32 CPU evaluation is 1.2e-5 .. 2e-5 from the fp64 one.  The bar stays 1e-5, or twice the fp32
                 # oracle's own distance where that is larger -- never looser than the reference's fp32 path on the same data.
-                tol = max(tol, 2 * rel_err(O.backward(go, w, x, pad, active, b)[1], gw64))
+                own = 2 * rel_err(O.backward(go, w, x, pad, active, b)[1], gw64)
+                if own > tol:   # (logged: `pytest -rP` / -s shows which cases used the wider bar)
+                    print("relaxed grad_w bar", shape, crop, pad, active, "%.3g" % own)
+                    tol = own
             assert rel_err(gw.to(torch.float64).cpu().numpy(), gw64) < tol, ("gw", shape, crop, dt, pad, active)
             gx2, gw2 = abi.backward(god, wd, xd, pad, active, b)
             assert torch.equal(gx, gx2) and torch.equal(gw, gw2)  # deterministic
@@ -225,7 +228,10 @@ def test_ragged_rows_backward_vs_oracle(abi, shape, crop, dt):
             _, gw64 = O.backward(go.astype(np.float64), w.astype(np.float64), x.astype(np.float64), pad, active, b)
             tol = {"f32": 1e-5, "f64": 1e-12}.get(dt, gw16_tol(torch.finfo(tdt).eps))
             if dt == "f32":
-                tol = max(tol, 2 * rel_err(O.backward(go, w, x, pad, active, b)[1], gw64))
+                own = 2 * rel_err(O.backward(go, w, x, pad, active, b)[1], gw64)
+                if own > tol:   # (logged: `pytest -rP` / -s shows which cases used the wider bar)
+                    print("relaxed grad_w bar", shape, crop, pad, active, "%.3g" % own)
+                    tol = own
             assert rel_err(gw.to(torch.float64).cpu().numpy(), gw64) < tol, ("gw", shape, crop, dt, pad, active)
             gx2, gw2 = abi.backward(god, wd, xd, pad, active, b)
             assert torch.equal(gx, gx2) and torch.equal(gw, gw2)  # deterministic

@@ -1,6 +1,7 @@
 #!/bin/bash
 # After the round-5 consolidation: (1) the route census with channels-last outputs, (2) the wrapping paddings of the row-span /
-# flat-stream kernels before (variants/oldpads.so: one instantiation per mode) and after (the mode as a kernel argument)
+# flat-stream kernels before (variants/oldpads.so: one instantiation per mode -- the library of commit f52a8b4 linked with the other
+# objects of the tree, built by hand with tools/build_variant.sh-style commands; not kept) and after (the mode as a kernel argument)
 cd "$GRAFT_REPO_ROOT"
 mkdir -p gpurun_out/consol
 python3 tools/route_census.py --cases 6000 --seed 1 --out gpurun_out/consol/route_census.txt > gpurun_out/consol/census.log 2>&1

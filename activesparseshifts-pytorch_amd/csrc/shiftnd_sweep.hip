@@ -556,8 +556,10 @@ bool sweep_forward_eligible(const Geometry &g, int dtype, const void *x, const v
     if (!contiguous(g.xs, g.N, g.C, g.S) || !contiguous(g.os, g.N, g.C, g.O)) return false;
     const bool interpolating = g.active && dtype <= SHIFTND_BF16;
     const int es = dtype_size(dtype);
-    if (interpolating) {  // sweep_active_forward: 4- / 8-byte elements, rows of whole 16-byte chunks
-        if (es < 4 || (g.O[2] * es) % 16 != 0 || reinterpret_cast<uintptr_t>(out) % 16 != 0) return false;
+    if (interpolating) {  // sweep_active_forward: rows of whole 16-byte chunks; 4- / 8-byte elements, and 2-D / 3-D 16-bit tensors (the caller
+                          // prefers the LDS kernels for those: this is what rows beyond their reach -- 2-D rows of more than 12 288
+                          // elements, 16-bit -- take instead of the strided fallback; 1-D 16-bit rows are row_active_forward's)
+        if ((es < 4 && g.nd == 1) || (g.O[2] * es) % 16 != 0 || reinterpret_cast<uintptr_t>(out) % 16 != 0) return false;
         return g.N * g.C * (oe * es / 16) < (1LL << 31) - 16;
     }
     const int V = gather_vector_bytes(g, es, out);
@@ -568,7 +570,9 @@ bool sweep_forward_eligible(const Geometry &g, int dtype, const void *x, const v
 template <typename T> void launch_active_forward(const SweepParams &p, hipStream_t st) {
     const dim3 grid(p.blocks_per_xcd * 8), block(p.threads);
     switch (p.nd) {   // (K = the plan's: 4 rows per thread for 1-D, 2 otherwise)
-    case 1: hipLaunchKernelGGL((sweep_active_forward<T, 1, 4>), grid, block, 0, st, p); break;
+    case 1:
+        if constexpr (sizeof(typename T::S) >= 4) hipLaunchKernelGGL((sweep_active_forward<T, 1, 4>), grid, block, 0, st, p);
+        break;
     case 2: hipLaunchKernelGGL((sweep_active_forward<T, 2, 2>), grid, block, 0, st, p); break;
     default: hipLaunchKernelGGL((sweep_active_forward<T, 3, 2>), grid, block, 0, st, p); break;
     }
@@ -590,7 +594,9 @@ int sweep_forward(const Geometry &g, int dtype, const void *x, const void *w, in
         plan_shape(p, static_cast<uint32_t>(g.O[2] * es / 16), static_cast<uint32_t>(g.O[0] * g.O[1]), g.N * g.C,
                    kmax, g_sweep_tune[1], kmax);
         if (dtype == SHIFTND_F32) launch_active_forward<f32_t>(p, st);
-        else launch_active_forward<f64_t>(p, st);
+        else if (dtype == SHIFTND_F64) launch_active_forward<f64_t>(p, st);
+        else if (dtype == SHIFTND_F16) launch_active_forward<f16_t>(p, st);
+        else launch_active_forward<bf16_t>(p, st);
         return SHIFTND_OK;
     }
     const int V = gather_vector_bytes(g, es, out);

@@ -96,3 +96,21 @@ def test_ragged_volume_at_size(abi):
         # (two 16-bit kernel families: 1 ulp -- the compiler may fuse the last blend and the rounding in one of them)
         assert _ulp_close(out.cpu(), out_s.cpu(), torch.bfloat16) and _ulp_close(gx.cpu(), gx_s.cpu(), torch.bfloat16), pad
         assert (gw.float() - gw_s.float()).abs().max().item() <= gw16_tol(torch.finfo(torch.bfloat16).eps) * max(1.0, gw_s.float().abs().max().item())
+
+
+@pytest.mark.parametrize("dt", ["f16", "bf16"])
+@pytest.mark.parametrize("shape", [(2, 2, 5, 16384), (1, 2, 3, 4, 12400)])
+def test_16bit_interpolating_forward_of_very_long_rows(abi, shape, dt):
+    """2-D / 3-D 16-bit tensors whose rows are beyond the LDS kernels' reach (more than 12 288 map entries): the sweep-shaped interpolating
+    forward instead of the strided fallback (route census, round 5); within 1 ulp of the oracle, every padding"""
+    tdt = TDT[dt]
+    nd = len(shape) - 2
+    rs = np.random.RandomState(sum(shape))
+    xt = torch.from_numpy(rs.uniform(-1, 1, size=shape)).to(tdt)
+    wt = torch.from_numpy(_weights(rs, shape[1], nd, shape[2:])).to(tdt)
+    x, w = xt.float().numpy(), wt.float().numpy()
+    xd, wd = xt.to(DEV), wt.to(DEV)
+    for pad in range(5):
+        out = abi.forward(xd, wd, pad, 1)
+        assert abi.last_kernel() == "sweep_active_forward", (shape, dt, abi.last_kernel())
+        assert _ulp_close(out.cpu(), torch.from_numpy(O.forward(x, w, pad, 1)).to(tdt), tdt), (shape, dt, pad)

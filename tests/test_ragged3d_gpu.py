@@ -114,3 +114,25 @@ def test_16bit_interpolating_forward_of_very_long_rows(abi, shape, dt):
         out = abi.forward(xd, wd, pad, 1)
         assert abi.last_kernel() == "sweep_active_forward", (shape, dt, abi.last_kernel())
         assert _ulp_close(out.cpu(), torch.from_numpy(O.forward(x, w, pad, 1)).to(tdt), tdt), (shape, dt, pad)
+
+
+@pytest.mark.parametrize("dt", ["f16", "bf16"])
+@pytest.mark.parametrize("shape,crop", [((2, 3, 9, 24), None), ((2, 2, 5, 6, 16), None), ((1, 2, 4, 7, 64), [[1, 0], [0, 2], [8, 8]]),
+                                        ((2, 2, 33, 40), [[2, 1], [0, 8]])])
+def test_16bit_sweep_forward_under_policy(abi, shape, crop, dt):
+    """the same kernel on everyday shapes (policy 3 = the sweep kernels or fail): windows, small planes, every padding"""
+    tdt = TDT[dt]
+    nd = len(shape) - 2
+    b, new = abi.check_borders(list(shape), crop, nd)
+    rs = np.random.RandomState(sum(shape) + 5)
+    xt = torch.from_numpy(rs.uniform(-1, 1, size=shape)).to(tdt)
+    wt = torch.from_numpy(_weights(rs, shape[1], nd, shape[2:])).to(tdt)
+    x, w = xt.float().numpy(), wt.float().numpy()
+    abi.set_path_policy(3)
+    try:
+        for pad in range(5):
+            out = abi.forward(xt.to(DEV), wt.to(DEV), pad, 1, b)
+            assert abi.last_kernel() == "sweep_active_forward", (shape, dt, abi.last_kernel())
+            assert _ulp_close(out.cpu(), torch.from_numpy(O.forward(x, w, pad, 1, b)).to(tdt), tdt), (shape, crop, dt, pad)
+    finally:
+        abi.set_path_policy(0)

@@ -234,6 +234,11 @@ def forward_quantized_pooled(xq, wq, w_zero_point, x_zero_point, pad, pool, bord
     return out
 
 
+def backward_pooled_workspace_bytes(x, pad, active, pool, borders=None):
+    p = problem(x, pad, active, borders)
+    return int(lib().shiftnd_backward_pooled_workspace_bytes(ctypes.byref(p), _pool_arg(pool, p.ndim)))
+
+
 def backward_pooled(grad_pooled, w, x, pad, active, pool, borders=None, grad_x=None, grad_w=None, workspace=None):
     assert x.is_contiguous() and grad_pooled.is_contiguous()
     p = problem(x, pad, active, borders)

@@ -22,8 +22,16 @@ The JSON line also carries
   configs       (default run only: --gpus 1, workload c2, padding 0) AFTER the headline's timed region, in the same
                 process, every other BASELINE config (C2 paddings 1-4, C3 paddings 0-4, C4, C5 per GPU) and the round's
                 other workloads are built, timed for >= 20 steps through the same dispatcher ops, measured kernel by
-                kernel with HIP events and freed again: {name: {ms_per_step, value, dtype, roofline: {kernel, frac,
-                frac_of_box, traffic}}}.  --no-configs skips it.
+                kernel with HIP events and freed again.  --no-configs skips it.
+
+OUTPUT (rank 0), in this order:
+  1. `{"bench_detail": ...}`    one line: everything measured (per-kernel medians, the box calibration, every rank's device,
+                                the whole cpu_baseline record, every config's record); also written to
+                                gpurun_out/bench_detail.json when that directory exists
+  2. the RESULT line, LAST and never longer than HEADLINE_MAX_BYTES (a consumer that keeps only a few KB of the
+     tail of stdout must still find one whole line): the contract's fields + `roofline` + `cpu_baseline` (trimmed; with
+     `own_cpu_key` = this repo's CPU dispatch key timed beside the reference) + `configs` = {name: [ms_per_step,
+     dominant kernel, its fraction of 8 TB/s, counter traffic / algorithmic bytes or null]}
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--workload NAME] [--pad 0..4]      (NAME: see WORKLOADS)
 
@@ -78,7 +86,16 @@ WORKLOADS = {
     "cl3d": (3, (8, 128, 16, 112, 112), "float32", False, "Shift3d SSL fwd+bwd N8 C128 16x112x112 fp32, channels-last (NDHWC) tensors"),
     "cl3da": (3, (8, 128, 16, 112, 112), "float32", True, "Shift3d active fwd+bwd N8 C128 16x112x112 fp32, channels-last (NDHWC) tensors"),
     "cl3dh": (3, (8, 128, 16, 112, 112), "bfloat16", True, "Shift3d active fwd+bwd N8 C128 16x112x112 bf16, channels-last (NDHWC) tensors"),
+    # round 6 -- the module's tail (modules/shifts.py:81-89,150-153): emulate_dw = {kernel_size 3, stride 2,
+    # padding 0} -> cut [[1,1],...] and avg_pool(kernel = stride = 2, ceil_mode) over the shifted window, as ONE pass
+    # through torch.ops.torchshifts._shift{N}d_pool_forward/_backward
+    "c2pool": (2, (64, 256, 224, 224), "float32", False, "Shift2d SSL + avg_pool 2 fwd+bwd N64 C256 224x224 fp32, cut [[1,1],[1,1]] (emulate_dw k3 s2 p0)"),
+    "c3pool": (3, (8, 128, 16, 112, 112), "bfloat16", True, "Shift3d active + avg_pool 2 fwd+bwd N8 C128 16x112x112 bf16, cut 1/1 per dim (emulate_dw k3 s2 p0)"),
+    "c4pool": (2, (128, 512, 56, 56), "quint8", False, "quantized Shift2d + avg_pool 2 forward N128 C512 56x56 quint8, cut [[1,1],[1,1]] (emulate_dw k3 s2 p0)"),
 }
+
+# fused shift + average pool workloads: the pool's kernel = stride
+POOLS = {"c2pool": 2, "c3pool": 2, "c4pool": 2}
 
 # workloads whose tensors are channels-last (dense NHWC / NDHWC strides behind the logical NCHW / NCDHW shape)
 CHANNELS_LAST = {"cl2d", "cl2da", "cl3d", "cl3da", "cl3dh"}
@@ -87,11 +104,15 @@ CHANNELS_LAST = {"cl2d", "cl2da", "cl3d", "cl3da", "cl3dh"}
 # -- C2 paddings 1-4, C3 paddings 0-4, C4, C5 (per GPU) -- then the round's other workloads.
 EXTRA_CONFIGS = ([("c2_pad%d" % p, "c2", p) for p in (1, 2, 3, 4)] + [("c3_pad%d" % p, "c3", p) for p in range(5)] +
                  [("c4", "c4", 0), ("c5", "c5", 0)] +
-                 [(n, n, 0) for n in ("c2a", "c2crop", "c2acrop", "t1", "t1a", "c1d", "r14", "r14a", "r62", "r222", "cl2d", "cl2da", "cl3d", "cl3da")])
+                 [(n, n, 0) for n in ("c2a", "c2crop", "c2acrop", "t1", "t1a", "c1d", "r14", "r14a", "r62", "r222", "cl2d", "cl2da", "cl3d", "cl3da",
+                                      "c2pool", "c3pool", "c4pool")])
+BASELINE_CONFIGS = [c[0] for c in EXTRA_CONFIGS[:11]]  # what BASELINE.json's `configs` list beyond the headline
+HEADLINE_MAX_BYTES = 4000  # the RESULT line is the last line of stdout and fits a small tail (round-5 verdict: a 24 KB line was lost)
 ESIZE = {"float32": 4, "bfloat16": 2, "float16": 2, "quint8": 1}
 
 # user `borders` of the cropped workloads ([nD, 2] cut-left / cut-right amounts, functional.py:22,32-35)
-CUTS = {"c2crop": [[1, 1], [1, 1]], "c2acrop": [[1, 1], [1, 1]], "t1": [[1, 1], [1, 1]], "t1a": [[1, 1], [1, 1]]}
+CUTS = {"c2crop": [[1, 1], [1, 1]], "c2acrop": [[1, 1], [1, 1]], "t1": [[1, 1], [1, 1]], "t1a": [[1, 1], [1, 1]],
+        "c2pool": [[1, 1], [1, 1]], "c3pool": [[1, 1], [1, 1], [1, 1]], "c4pool": [[1, 1], [1, 1]]}
 
 
 def shard_range(n, rank, world):
@@ -117,6 +138,131 @@ def cpu_baseline(workload_pad=0):
         return json.loads(lines[-1])
     except Exception as e:  # noqa: BLE001
         return {"value": None, "unit": "Gelem/s", "cores": 0, "kind": "unavailable", "sample": repr(e)[:300]}
+
+
+def own_cpu_key(pad=0, n=8):
+    """This repo's own CPU dispatch key (csrc/torch_cpu_backend.cpp, all host cores) on a bounded slice of the headline workload,
+    beside the reference's: `bench.py --device cpu` in a child process, before this one touches the GPU."""
+    try:
+        out = subprocess.run([sys.executable, os.path.abspath(__file__), "--device", "cpu", "--shape", "%d,256,224,224" % n, "--pad",
+                              str(pad), "--steps", "2", "--warmup", "1"], capture_output=True, text=True, timeout=600)
+        lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+        if out.returncode != 0 or not lines:
+            raise RuntimeError("exit %d: %s" % (out.returncode, (out.stderr or out.stdout)[-200:]))
+        j = json.loads(lines[-1])
+        try:
+            cores = len(os.sched_getaffinity(0))
+        except AttributeError:
+            cores = os.cpu_count() or 1
+        return {"value": j["value"], "unit": "Gelem/s", "cores": cores, "kind": "port",
+                "sample": "torch_cpu_backend.cpp, N%d C256 224x224 fp32 pad %d, mean of 2 steps (%.1f ms/step)" % (n, pad, j["ms_per_step"])}
+    except Exception as e:  # noqa: BLE001
+        return {"value": None, "kind": "unavailable", "sample": repr(e)[:200]}
+
+
+def _sig(v, digits=5):
+    """floats to `digits` significant digits (the RESULT line is size-bounded), containers recursively"""
+    if isinstance(v, float):
+        return float("%.*g" % (digits, v))
+    if isinstance(v, dict):
+        return {k: _sig(x, digits) for k, x in v.items()}
+    if isinstance(v, (list, tuple)):
+        return [_sig(x, digits) for x in v]
+    return v
+
+
+def headline_line(result, limit=None):
+    """The RESULT line from the full record: the contract's fields, `roofline`, a trimmed `cpu_baseline`, compact `configs`;
+    never longer than HEADLINE_MAX_BYTES (optional parts are dropped in a fixed order until it fits)."""
+    limit = limit or HEADLINE_MAX_BYTES
+    keep = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "ms_per_step_median", "ms_per_step_min",
+            "higher_is_better", "scaling", "vs_baseline", "dtype", "data")
+    h = {k: result[k] for k in keep if k in result}
+    cfg = result.get("config", {})
+    ranks = dict(cfg.get("ranks", {}))
+    per_rank = ranks.pop("per_rank", [])
+    ranks["per_rank"] = [[r.get("rank"), r.get("host"), r.get("device_index"), r.get("pci_bus_id")] for r in per_rank]
+    h["config"] = {"workload": cfg.get("workload"), "path": cfg.get("path"), "ranks": ranks}
+    h["per_rank_ms"] = result.get("per_rank_ms")
+    h["achieved_hbm_GBps_step"] = result.get("achieved_hbm_GBps_step")
+    h["kernels"] = {k: {f: v[f] for f in ("ms", "GB/s", "frac_of_box") if f in v} for k, v in (result.get("kernels") or {}).items()}
+    rl = result.get("roofline")
+    if rl is not None:
+        rl = dict(rl)
+        box = rl.pop("box_stream", None) or {}
+        rl.pop("traffic_source", None)
+        if box.get("2R1W_GBps"):
+            rl["box_GBps"] = {"1R1W": box.get("1R1W_GBps"), "2R1W": box.get("2R1W_GBps")}
+        src = result.get("roofline", {}).get("traffic_source")
+        if src:
+            rl["traffic_source"] = src
+    h["roofline"] = rl
+    base = result.get("cpu_baseline")
+    if base is not None:
+        b = {k: base.get(k) for k in ("value", "unit", "cores", "kind", "host_cpu", "sample")}
+        st = base.get("single_thread")
+        if st:
+            b["single_thread"] = {"value": st.get("value"), "cores": st.get("cores")}
+        full = base.get("full_size")
+        if full:
+            b["full_size"] = [{"value": f.get("value"), "cores": f.get("cores")} for f in full]
+        own = base.get("own_cpu_key")
+        if own:
+            b["own_cpu_key"] = {"value": own.get("value"), "cores": own.get("cores"), "kind": own.get("kind")}
+        h["cpu_baseline"] = b
+    cfgs = result.get("configs")
+    if cfgs is not None:
+        comp = {}
+        for name, c in cfgs.items():
+            if "roofline" not in c:
+                comp[name] = [None, "skipped" if "skipped" in c else "error", None, None]
+                continue
+            r = c["roofline"]
+            ratio = (r["traffic"] / r["algorithmic_bytes"]) if r.get("traffic") and r.get("algorithmic_bytes") else None
+            comp[name] = [float("%.4g" % c["ms_per_step"]), r["kernel"], float("%.3g" % r["frac"]),
+                          None if ratio is None else float("%.3g" % ratio)]
+        h["configs"] = comp
+        h["configs_fields"] = "ms_per_step, dominant kernel, frac of 8 TB/s, counter traffic / algorithmic bytes"
+        h["configs_wall_s"] = result.get("configs_wall_s")
+    h = _sig(h)
+
+    def dump():
+        return json.dumps(h, separators=(",", ":"))
+    # optional parts, least important first
+    drops = [lambda: h.pop("configs_fields", None),
+             lambda: h.__setitem__("configs", {k: v for k, v in h["configs"].items() if k in BASELINE_CONFIGS}) if "configs" in h else None,
+             lambda: h["config"].pop("path", None),
+             lambda: [v.pop("frac_of_box", None) for v in h["kernels"].values()],
+             lambda: h["config"]["ranks"].pop("per_rank", None),
+             lambda: (h.get("cpu_baseline") or {}).pop("full_size", None),
+             lambda: (h.get("roofline") or {}).pop("traffic_source", None),
+             lambda: h.pop("kernels", None),
+             lambda: (h.get("cpu_baseline") or {}).pop("sample", None),
+             lambda: h.pop("configs", None)]
+    line = dump()
+    for d in drops:
+        if len(line) <= limit:
+            break
+        d()
+        line = dump()
+    assert len(line) <= limit, "RESULT line is %d bytes" % len(line)
+    return line
+
+
+def emit(result, out=None):
+    """rank 0's output: the detail line first, the size-bounded RESULT line LAST."""
+    out = out or sys.stdout
+    detail = json.dumps({"bench_detail": result})
+    out.write(detail + "\n")
+    ddir = os.path.join(ROOT, "gpurun_out")
+    if os.path.isdir(ddir) and os.access(ddir, os.W_OK):
+        try:
+            with open(os.path.join(ddir, "bench_detail.json"), "w") as f:
+                f.write(detail + "\n")
+        except OSError:
+            pass
+    out.write(headline_line(result) + "\n")
+    out.flush()
 
 
 def box_stream(tensor_bytes=None):
@@ -283,6 +429,7 @@ def main(argv=None):
     if rank == 0 and world == 1 and a.workload == "c2" and a.shape is None and a.device == "cuda" \
             and not a.no_cpu_baseline:
         base = cpu_baseline(a.pad)  # child process, before any GPU initialisation in this process
+        base["own_cpu_key"] = own_cpu_key(a.pad)
     probes = {}   # same-box streams by size class: tensors within a quarter octave of each other share one calibration run
 
     def size_class(nbytes):
@@ -390,6 +537,17 @@ def main(argv=None):
             self.oelems = 1
             for s_ in self.oshape:
                 self.oelems *= s_
+            # fused shift + average pool (kernel = stride = pool, ceil_mode): the op's output / incoming gradient is the pooled window
+            self.pool = POOLS.get(name)
+            self.gshape = list(self.oshape)
+            if self.pool:
+                self.pools = [self.pool] * nd
+                self.fwd_op = getattr(ops, "_shift%dd_pool_forward" % nd)
+                self.bwd_op = getattr(ops, "_shift%dd_pool_backward" % nd)
+                self.gshape = list(self.oshape[:2]) + [-(-v // self.pool) for v in self.oshape[2:]]
+            self.pelems = 1
+            for s_ in self.gshape:
+                self.pelems *= s_
             # ---- synthetic inputs (resident before timing) ------------------------------------------------
             seed = 1000 * rank
             w32 = synth_tensor(torch, (C, nd), seed + 3, dev, torch.float32, -3.0, 3.0)
@@ -408,13 +566,19 @@ def main(argv=None):
                 if not on_gpu and dtype in (torch.float16, torch.bfloat16):
                     dtype = torch.float32  # the CPU key serves float/double like the reference's (shifts_cpu.cpp:228)
                 self.x = synth_tensor(torch, shape, seed + 1, dev, dtype).contiguous(memory_format=fmt)
-                self.go = synth_tensor(torch, tuple(self.oshape), seed + 2, dev, dtype).contiguous(memory_format=fmt)
+                self.go = synth_tensor(torch, tuple(self.gshape), seed + 2, dev, dtype).contiguous(memory_format=fmt)
                 self.w = w32.to(dtype)
                 self.esize = self.x.element_size()
             self.fmt = fmt
             sync()
 
         def step(self):
+            if self.pool:
+                if self.quant:
+                    return self.fwd_op(self.xq, self.wq, self.borders, self.oshape, self.pools, self.pad, False)
+                out = self.fwd_op(self.x, self.w, self.borders, self.oshape, self.pools, self.pad, self.active)
+                gx, gw = self.bwd_op(self.go, self.w, self.x, self.borders, self.pools, self.pad, self.active)
+                return out, gx, gw
             if self.quant:
                 return self.fwd_op(self.xq, self.wq, self.borders, self.oshape, self.pad, False)
             out = self.fwd_op(self.x, self.w, self.borders, self.oshape, self.pad, self.active)
@@ -422,6 +586,11 @@ def main(argv=None):
             return out, gx, gw
 
         def step_bytes(self):
+            """algorithmic bytes of one step.  Plain: forward x + out, backward grad_out + x + grad_x.  Pooled:
+            forward reads x and writes the pooled window, backward reads the pooled gradient and x and writes grad_x."""
+            if self.pool:
+                fwd = self.esize * (self.elems + self.pelems)
+                return fwd if self.quant else fwd + self.esize * (2 * self.elems + self.pelems)
             return 2 * self.esize * self.elems if self.quant else self.esize * (3 * self.elems + 2 * self.oelems)
 
         def kernel_times(self, kiters, probe):
@@ -436,6 +605,27 @@ def main(argv=None):
                     kernels[name]["stream"] = stream_kind
                     kernels[name]["frac_of_box"] = nbytes / t[0] / 1e6 / ref
             esize, elems, oelems, pad, active = self.esize, self.elems, self.oelems, self.pad, self.active
+            if self.pool:
+                pelems, pools = self.pelems, self.pools
+                if self.quant:
+                    xi, wi = self.xq.int_repr(), self.wq.int_repr()
+                    outb = torch.empty(self.gshape, dtype=xi.dtype, device=xi.device)
+                    t_f = event_time(lambda: abi.forward_quantized_pooled(xi, wi, 128, 0, pad, pools, borders=self.bl, out=outb), kiters)
+                    qname = abi.last_kernel()
+                    record(qname, t_f, esize * (elems + pelems), "1R1W")
+                    return kernels, (qname, t_f[0], esize * (elems + pelems), "1R1W")
+                x, go, w = self.x, self.go, self.w
+                outb, gxb, gwb = torch.empty(self.gshape, dtype=x.dtype, device=x.device), torch.empty_like(x), torch.empty_like(w)
+                t_f = event_time(lambda: abi.forward_pooled(x, w, pad, active, pools, borders=self.bl, out=outb), kiters)
+                fname = abi.last_kernel()
+                pws = torch.empty(abi.backward_pooled_workspace_bytes(x, pad, active, pools, self.bl), dtype=torch.uint8, device=x.device)
+                abi.backward_pooled(go, w, x, pad, active, pools, borders=self.bl, grad_x=gxb, grad_w=gwb, workspace=pws)
+                bname = abi.last_kernel()
+                t_b = event_time(lambda: abi.backward_pooled(go, w, x, pad, active, pools, borders=self.bl, grad_x=gxb, grad_w=gwb,
+                                                             workspace=pws), kiters)
+                record(fname + "(pool)", t_f, esize * (elems + pelems), "1R1W")
+                record(bname + "(pool)", t_b, esize * (2 * elems + pelems), "2R1W")
+                return kernels, (bname + "(pool)", t_b[0], esize * (2 * elems + pelems), "2R1W")
             if self.quant:
                 xi = self.xq.int_repr()
                 wi = self.wq.int_repr()
@@ -645,7 +835,7 @@ def main(argv=None):
                     configs[cname] = {"error": repr(e)[:300]}
             result["configs"] = configs
             result["configs_wall_s"] = time.perf_counter() - t_all
-        print(json.dumps(result), flush=True)
+        emit(result)
     if use_pg:
         dist.barrier()
         dist.destroy_process_group()

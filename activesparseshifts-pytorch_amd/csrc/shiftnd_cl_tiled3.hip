@@ -608,28 +608,38 @@ Plan3 plan3(const Geometry &g) {
 
 }  // namespace
 
+// geometry gates shared by the eligibility test and the workspace query (the query used to reserve groups * C * 24 bytes
+// for EVERY 3-D problem -- contiguous ones, volumes the kernel never takes, and flat volumes (H == 1) whose records came to 0.75 x the
+// tensor): no dtype, no strides, no knob -- both callers see the same answer
+static bool cl3_geometry_ok(const Geometry &g) {
+    if (g.nd != 3 || g.N < 1 || g.C < 1 || g.C % 4 != 0) return false;   // (pixel lines of whole 16-byte pieces: C * es % 16, es >= 2 ... 4)
+    for (int d = 0; d < 3; ++d)
+        if (g.O[d] < 1 || g.S[d] < 1 || g.L[d] < 0 || g.L[d] + g.O[d] > g.S[d]) return false;
+    if (g.S[0] >= (1 << 20) || g.S[1] >= (1 << 20) || g.S[2] >= (1 << 20) || g.N >= (1LL << 24) || g.C >= (1 << 24)) return false;
+    if ((g.S[1] != 1 && g.S[1] < 5) || (g.O[1] != 1 && g.O[1] < 5)) return false;   // the kernel folds source rows once
+    if (g.C * g.S[0] * g.S[1] * g.S[2] * 2 >= (1LL << 31)) return false;             // (never eligible: 2-byte elements are the smallest)
+    const Plan3 pl = plan3(g);
+    if (pl.groups * pl.cblocks >= (1LL << 31)) return false;
+    // partial-sum records of at most 1/8 of a 2-byte tensor (flat volumes would need 24 / (16 H es) of it)
+    return pl.groups * g.C * 24 * 8 <= g.N * g.C * g.S[0] * g.S[1] * g.S[2] * 2 || pl.groups * g.C * 24 <= (1 << 20);
+}
+
 // 3-D fp32 / fp16 / bf16; saved input and grad_x dense NDHWC, the incoming gradient NDHWC too or NCDHW-contiguous (a window
 // included: grad_out has its sizes); pixel lines of whole 16-byte pieces
 bool cl_tiled3_backward_eligible(const Geometry &g, int dtype, const void *go, const void *x, const void *gx) {
     if (g.nd != 3 || (dtype != SHIFTND_F32 && dtype != SHIFTND_F16 && dtype != SHIFTND_BF16)) return false;
     const int es = dtype_size(dtype);
-    for (int d = 0; d < 3; ++d)
-        if (g.O[d] < 1 || g.S[d] < 1 || g.L[d] < 0 || g.L[d] + g.O[d] > g.S[d]) return false;
-    if (g.N < 1 || g.C < 1 || (g.C * es) % 16 != 0) return false;
-    if (g.S[0] >= (1 << 20) || g.S[1] >= (1 << 20) || g.S[2] >= (1 << 20) || g.N >= (1LL << 24) || g.C >= (1 << 24)) return false;
-    if ((g.S[1] != 1 && g.S[1] < 5) || (g.O[1] != 1 && g.O[1] < 5)) return false;   // the kernel folds source rows once
+    if (!cl3_geometry_ok(g) || (g.C * es) % 16 != 0) return false;
     if (g.C * g.S[0] * g.S[1] * g.S[2] * es >= (1LL << 31) || g.C * g.O[0] * g.O[1] * g.O[2] * es >= (1LL << 31)) return false;
     if (!dense_ndhwc(g.xs, g, g.S) || !dense_ndhwc(g.gs, g, g.S)) return false;
     const bool go_cl = dense_ndhwc(g.os, g, g.O);
     if (!go_cl && !contiguous_ncdhw(g.os, g, g.O)) return false;
     if (reinterpret_cast<uintptr_t>(x) % es != 0 || reinterpret_cast<uintptr_t>(go) % (go_cl ? 16 : es) != 0 || reinterpret_cast<uintptr_t>(gx) % es != 0) return false;
-    const Plan3 pl = plan3(g);
-    return pl.groups * pl.cblocks < (1LL << 31);
+    return true;
 }
 
 size_t cl_tiled3_backward_workspace(const Geometry &g) {
-    if (g.nd != 3 || g.C < 1 || g.N * g.S[0] * g.S[1] * g.S[2] < 1) return 0;
-    if (g.S[0] >= (1 << 20) || g.S[1] >= (1 << 20) || g.S[2] >= (1 << 20) || g.N >= (1LL << 24)) return 0;   // (never eligible)
+    if (!cl3_geometry_ok(g)) return 0;   // (never eligible: nothing to reserve)
     return static_cast<size_t>(plan3(g).groups) * static_cast<size_t>(g.C) * 3 * sizeof(double);
 }
 

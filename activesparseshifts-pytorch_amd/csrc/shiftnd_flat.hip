@@ -776,6 +776,9 @@ FlatPlan flat_plan(const Geometry &g, int es, bool backward) {
         pl.gcov_off = static_cast<int>(cx_small);
         pl.front = static_cast<int>(slack);
         pl.lds = static_cast<size_t>(tab + (backward ? kThreads * 4 * (es == 8 ? 8 : 4) + cx_small + cg_small : cx_small)) + 2 * slack;
+        //  the slack is a whole row: planes of two very wide ragged rows pass the cover budget and still exceed the
+        // 64 KiB a launch may ask for -- decline, the router falls through to the next family
+        if (pl.lds > 64 * 1024) pl.ok = false;
         return pl;
     }
     // large: at most two planes per step, row ranges
@@ -791,6 +794,7 @@ FlatPlan flat_plan(const Geometry &g, int es, bool backward) {
     pl.gcov_off = static_cast<int>(cx_large);
     pl.front = static_cast<int>(slack);
     pl.lds = static_cast<size_t>(tab + (backward ? kThreads * 4 * (es == 8 ? 8 : 4) + cx_large + cg_large : cx_large)) + 2 * slack;
+    if (pl.lds > 64 * 1024) pl.ok = false;
     return pl;
 }
 

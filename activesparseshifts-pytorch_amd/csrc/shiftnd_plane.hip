@@ -1692,7 +1692,8 @@ size_t plane_backward_workspace(const Geometry &g, int dtype) {
     const Plan pl = backward_plan(g, dtype_size(dtype));
     const size_t own = static_cast<size_t>(pl.groups) * pl.bands * static_cast<size_t>(g.C) * 3 * sizeof(double);
     const size_t slide = g.K[0] > 0 ? 0 : slide_backward_workspace(g, dtype);  // (the fused-pool calls never slide)
-    const size_t step = std::max(step_backward_workspace(g, dtype), g.K[0] > 0 ? size_t(0) : std::max(walk16_backward_workspace(g, dtype), span_backward_workspace(g, dtype)));
+    const size_t step = std::max(step_backward_workspace(g, dtype), g.K[0] > 0 ? span_backward_pooled_workspace(g, dtype)
+                                                                                : std::max(walk16_backward_workspace(g, dtype), span_backward_workspace(g, dtype)));
     const size_t m = own > slide ? own : slide;
     return m > step ? m : step;
 }
@@ -1728,9 +1729,13 @@ bool plane_pool_backward_eligible(const Geometry &g, int dtype, const void *gx) 
     return (g.S[2] * es) % 16 == 0 && reinterpret_cast<uintptr_t>(gx) % 16 == 0;
 }
 
+extern thread_local int g_step_tune[5];   // knobs 32..35 / 38 (shiftnd_step.hip)
+
 int plane_pool_backward(const Geometry &g, int dtype, const void *go, const void *x, const void *w, void *gx, void *gw,
                         void *workspace, hipStream_t st) {
     if (step_backward_pooled_eligible(g, dtype, go, x, gx)) return step_backward(g, dtype, go, x, w, gx, gw, workspace, st);
+    // cropped windows and the interpolating shift: crop_backward<.., POOL> (round 6; knob 35 bit 6 keeps the band walk)
+    if (!(g_step_tune[3] & 64) && span_backward_pooled_eligible(g, dtype, go, x, gx)) return span_backward(g, dtype, go, x, w, gx, gw, workspace, st);
     const Plan pl = backward_plan(g, dtype_size(dtype));
     PlaneParams p{};
     p.x = x;

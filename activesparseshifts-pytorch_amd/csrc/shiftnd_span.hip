@@ -50,6 +50,7 @@ struct SpanParams {
     int cpr, seg, nseg;  // 16-byte chunks per x row, chunks per column segment (<= 256), segments per row
     int R, rsteps, spp;  // rows per step, row steps per plane, steps per plane = rsteps * nseg
     int P;               // pieces per slot
+    int P2;              // crop_backward<.., POOL>: elements per row of the pooled gradient (2 x 2 windows)
     uint32_t total_steps, steps_per_xcd;
     FastDiv d_spp, d_C, d_seg, d_nseg, d_P, d_per1x, d_per2x, d_per1g, d_per2g;
 };
@@ -150,8 +151,16 @@ __device__ __forceinline__ void span_read(const char *lds_row, const S *mem_row,
 // grad_x leaves through element-aligned 16-byte stores (gfx950 global stores take any alignment; a wave's chunks are still one
 // contiguous run of memory).  No chunk straddles rows: the lean in-row path everywhere (the flat-stream kernels of
 // shiftnd_flat.hip, which keep aligned stores, pay for that with a per-element path: N64 C256 222x222 fp32 3.0 -> 1.9 ms).
-template <typename T, bool ACTIVE, int PAD, bool XRAG = false>
+// POOL (round 6): the module's average-pool tail (modules/shifts.py:81-89: avg_pool(kernel = stride = 2, ceil_mode) behind the cropped
+// shift -- every emulate_dw with padding < kernel / 2 and stride 2; other windows keep the band-walk kernels).  `go` is the gradient of the POOLED window [P1, P2]; a row of
+// the unpooled gradient is its pooled row expanded, g(r, j) = grad_pooled[r / K1][j / K2] / (window size), rounded to the storage
+// type like the two-step sequence (ATen's avg_pool backward).  The thread that would have moved piece `pg` of a gradient row's cover
+// loads the pooled elements under columns pg E .. pg E + E - 1 instead and writes the expanded piece into the same slot at phase 0;
+// everything behind the barrier is unchanged.  (The cropped pooled backward ran the band-walk kernel before: N64 C256 224x224 cut 1/1
+// pool 2 fp32 3.94 ms.)
+template <typename T, bool ACTIVE, int PAD, bool XRAG = false, bool POOL = false>
 __global__ __launch_bounds__(kThreads) void crop_backward(const SpanParams p) {
+    static_assert(!(POOL && XRAG), "the pooled form takes x rows of whole pieces");
     using S = typename T::S;
     using CT = typename T::C;
     constexpr int ES = sizeof(S);
@@ -210,6 +219,7 @@ __global__ __launch_bounds__(kThreads) void crop_backward(const SpanParams p) {
     // own thread mapping -- thread t moves piece t mod (cpr + 2) of row t div (cpr + 2): lane-linear in LDS, hence LDS-DMA as well.
     // (The host picks R with R (cpr + 2) <= 256.)
     auto row_lo = [&](int row) { return gph + row * O2 * ES; };
+    auto gphase = [&](int row) { return POOL ? 0 : (row_lo(row) & 15); };   // (POOL: expanded rows are written at phase 0)
     const int PGi = cpr + 2;
     const int rg = static_cast<int>(fdiv(static_cast<uint32_t>(tid), p.d_P)), pg = tid - rg * PGi;   // (d_P divides by cpr + 2)
     auto dma_g = [&](int row, int piece, int lds_piece0) {   // piece `piece` of the cover of grad_out row `row`
@@ -219,6 +229,59 @@ __global__ __launch_bounds__(kThreads) void crop_backward(const SpanParams p) {
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(gp16 + static_cast<uint32_t>(p0 + piece) * 16u),
                                              (__attribute__((address_space(3))) void *)dst_wave, 16, 0, 0);
         }
+    };
+    // POOL (2 x 2 windows): the expanded piece `piece` (window columns piece E ..) of window row `row`; the loads of all of a thread's
+    // pieces are issued before the first conversion.  Branch-free (a kernel this short lives or dies by its control flow: the first
+    // version -- any window, three load paths, IEEE divisions -- had 1009 instructions and 46 branches against 454 / 9 of the plain
+    // kernel and ran 2.15 ms where the plain cropped backward takes 1.65): ONE element-aligned 8-byte load holds the E / 2 pooled
+    // elements under the piece -- its start clamped into the pooled row (host: P2 >= E / 2), the elements shifted down by the
+    // clamp's distance; what lies beyond the row's last window is never used (columns >= O2 are masked by the window test) -- and
+    // the window counts are 1, 2 or 4: the division is a multiplication by a power of two (div_count's bits).
+    struct Pooled {
+        uint64_t raw;      // the E / 2 pooled elements under the piece (fp64: the one element)
+        int lg;            // log2 of the rows of the pooled row's window (0 / 1)
+        int dst;           // tile piece (-1: none)
+        int col;
+    };
+    constexpr int HP = E >= 2 ? E / 2 : 1;      // pooled elements per piece
+    const int opieces = (O2 * ES + 15) >> 4;   // pieces of an expanded window row
+    auto pooled_load = [&](int row, int piece, int dst) {
+        Pooled q;
+        q.dst = (row >= 0 && piece < opieces) ? dst : -1;
+        q.col = piece;
+        const int pr = max(row, 0) >> 1;
+        q.lg = (O1 - 2 * pr >= 2) ? 1 : 0;
+        const S *prow = gp + static_cast<int64_t>(pr) * p.P2;
+        const int first = piece * HP, start = min(first, p.P2 - HP);   // (P2 >= HP: host)
+        if constexpr (ES == 8) {
+            q.raw = *reinterpret_cast<const uint64_t *>(prow + start);
+        } else {
+            uint64_t v;   // element-aligned 8 bytes (load_chunk: one global_load_dwordx2 at any alignment)
+            const Chunk<S, HP> h = load_chunk<S, HP>(prow + start);
+            __builtin_memcpy(&v, h.e, 8);
+            q.raw = v >> (static_cast<unsigned>(min(first - start, HP - 1)) * (8u * ES));
+        }
+        return q;
+    };
+    auto pooled_store = [&](const Pooled &q) {
+        Chunk<S, E> out;
+#pragma unroll
+        for (int h = 0; h < HP; ++h) {
+            typename raw_t<ES>::type bits = static_cast<typename raw_t<ES>::type>(ES == 8 ? q.raw : (q.raw >> (h * 8 * (ES == 8 ? 0 : ES))));
+            const CT val = widen<T>(__builtin_bit_cast(S, bits));
+            const int k = q.lg + ((O2 - 2 * (q.col * HP + h) >= 2) ? 1 : 0);   // log2 of the window's size
+            CT scale;
+            if constexpr (sizeof(CT) == 4) scale = __builtin_bit_cast(float, static_cast<uint32_t>(127 - k) << 23);
+            else scale = __builtin_bit_cast(double, static_cast<uint64_t>(1023 - k) << 52);
+            const S v = narrow<T>(val * scale);
+            if constexpr (E >= 2) {
+                out.e[2 * h] = v;
+                out.e[2 * h + 1] = v;
+            } else {
+                out.e[0] = v;
+            }
+        }
+        if (q.dst >= 0) __builtin_memcpy(__builtin_assume_aligned(tile + q.dst * 16, 16), out.e, 16);
     };
     auto gs_row = [&](int i, bool have) {   // the row grad_x reads at step row i (window coordinates through the row map)
         const int pr = b0 + i - L1;
@@ -240,10 +303,20 @@ __global__ __launch_bounds__(kThreads) void crop_backward(const SpanParams p) {
     }
     {
         const int ro = (rg < R && rg < Rn && b0 + rg - L1 >= 0 && b0 + rg - L1 < O1) ? b0 + rg - L1 : -1;   // the step's own rows
-        dma_g(ro, pg, goff / 16);
-        dma_g(gs_row(rg, rg < R && (ACTIVE ? rg <= Rn : rg < Rn)), pg, gsoff / 16);
-        if constexpr (ACTIVE) {
-            if (Rn == R && tid < PGi) dma_g(gs_row(R, true), tid, gsoff / 16 + R * PGi);   // the + 1 row of a full step
+        if constexpr (POOL) {
+            const Pooled qa = pooled_load(ro, pg, goff / 16 + tid);
+            const Pooled qb = pooled_load(gs_row(rg, rg < R && (ACTIVE ? rg <= Rn : rg < Rn)), pg, gsoff / 16 + tid);
+            Pooled qc = qa;
+            if constexpr (ACTIVE) qc = pooled_load((Rn == R && tid < PGi) ? gs_row(R, true) : -1, tid, gsoff / 16 + R * PGi + tid);
+            pooled_store(qa);
+            pooled_store(qb);
+            if constexpr (ACTIVE) pooled_store(qc);
+        } else {
+            dma_g(ro, pg, goff / 16);
+            dma_g(gs_row(rg, rg < R && (ACTIVE ? rg <= Rn : rg < Rn)), pg, gsoff / 16);
+            if constexpr (ACTIVE) {
+                if (Rn == R && tid < PGi) dma_g(gs_row(R, true), tid, gsoff / 16 + R * PGi);   // the + 1 row of a full step
+            }
         }
     }
 
@@ -300,7 +373,7 @@ __global__ __launch_bounds__(kThreads) void crop_backward(const SpanParams p) {
                 const bool dom = in_row && pr <= O1;
                 const int srow = dom ? row_map_t<PAD>(pr, d.cg1, O1, p.pad) : -1;
                 S raw[E + 1];
-                read_row(tile + gsoff + (tr + hb) * RBG + (row_lo(srow) & 15), srow >= 0, gm, raw);
+                read_row(tile + gsoff + (tr + hb) * RBG + gphase(srow), srow >= 0, gm, raw);
 #pragma unroll
                 for (int e = 0; e <= E; ++e) gv[hb][e] = widen<T>(raw[e]);
             }
@@ -312,7 +385,7 @@ __global__ __launch_bounds__(kThreads) void crop_backward(const SpanParams p) {
         } else {
             const int srow = in_row ? row_map_t<PAD>(b - L1, d.cg1, O1, p.pad) : -1;
             S raw[E + 1];
-            read_row(tile + gsoff + tr * RBG + (row_lo(srow) & 15), srow >= 0, gm, raw);
+            read_row(tile + gsoff + tr * RBG + gphase(srow), srow >= 0, gm, raw);
 #pragma unroll
             for (int e = 0; e < E; ++e) res.e[e] = inside[e] ? raw[e] : zero;
         }
@@ -328,7 +401,7 @@ __global__ __launch_bounds__(kThreads) void crop_backward(const SpanParams p) {
             for (int e = 0; e <= E; ++e) xv[hb][e] = widen<T>(raw[e]);
         }
         // (the own gradient chunk: E elements at column ji - L2 of the row's slot -- clamped to the slot, masked by the window)
-        const S *grow = reinterpret_cast<const S *>(tile + goff + tr * RBG + (in_row ? (row_lo(b - L1) & 15) : 0)) + (in_row ? ji - L2 : 0);
+        const S *grow = reinterpret_cast<const S *>(tile + goff + tr * RBG + (in_row ? gphase(b - L1) : 0)) + (in_row ? ji - L2 : 0);
 #pragma unroll
         for (int e = 0; e < E; ++e) {
             const CT v[4] = {xv[0][e], xv[1][e], xv[0][e + 1], xv[1][e + 1]};
@@ -933,9 +1006,15 @@ SpanPlan span_plan(const Geometry &g, int es) {
 }
 
 // what the kernel serves, pointers aside (the workspace is planned from this)
-bool span_geometry_ok(const Geometry &g, int dtype) {
-    if (dtype > SHIFTND_BF16 || (g.nd != 1 && g.nd != 2) || g.K[0] > 0) return false;
+static bool span_geometry_ok(const Geometry &g, int dtype, bool pooled);
+bool span_geometry_ok(const Geometry &g, int dtype) { return span_geometry_ok(g, dtype, false); }
+
+// pooled: crop_backward<.., POOL> -- 2-D, x rows of whole pieces, 2 x 2 windows, pooled rows of at least half a piece (g.K / g.P set; the
+// plan reads S, O, L only)
+static bool span_geometry_ok(const Geometry &g, int dtype, bool pooled) {
+    if (dtype > SHIFTND_BF16 || (g.nd != 1 && g.nd != 2) || (g.K[0] > 0) != pooled) return false;
     const int es = dtype_size(dtype);
+    if (pooled && (g.nd != 2 || (g.S[2] * es) % 16 != 0 || g.K[1] != 2 || g.K[2] != 2 || g.P[2] < std::max(1, 8 / es))) return false;
     if (g.S[0] != 1 || g.O[0] != 1 || g.S[1] < 1 || g.S[2] < 1 || g.O[1] < 1 || g.O[2] < 1) return false;
     // x rows: whole pieces -- or, 2-D with 4- / 8-byte elements, any length (crop_backward<.., XRAG>, round 5); int16 column tables
     // (2-byte elements: input AND gradient rows of an even number of elements -- every row at a 4-byte boundary)
@@ -1186,12 +1265,23 @@ bool span_backward_eligible(const Geometry &g, int dtype, const void *go, const 
 
 size_t span_backward_workspace(const Geometry &g, int dtype) { return span_geometry_ok(g, dtype) ? span_plan(g, dtype_size(dtype)).bytes : 0; }
 
-template <typename T, int ND, bool XRAG = false>
+// the fused shift + average-pool backward of 2-D problems (round 6): `go` = gradient of the pooled window, contiguous.  Cropped
+// windows (every emulate_dw with padding < kernel / 2) and the interpolating shift, which step_backward<.., POOL> does not take
+bool span_backward_pooled_eligible(const Geometry &g, int dtype, const void *go, const void *x, const void *gx) {
+    if (g_step_tune[0] == 1 || !span_geometry_ok(g, dtype, true)) return false;
+    if (!dense(g.xs, g.N, g.C, g.S) || !dense(g.gs, g.N, g.C, g.S)) return false;
+    if (reinterpret_cast<uintptr_t>(go) % dtype_size(dtype) || reinterpret_cast<uintptr_t>(x) % 16 || reinterpret_cast<uintptr_t>(gx) % 16) return false;
+    if (g.pad == 0 && g.O[2] == 1) return false;   // (as span_backward_eligible: the affine column state)
+    return true;
+}
+size_t span_backward_pooled_workspace(const Geometry &g, int dtype) { return span_geometry_ok(g, dtype, true) ? span_plan(g, dtype_size(dtype)).bytes : 0; }
+
+template <typename T, int ND, bool XRAG = false, bool POOL = false>
 static void launch_span_backward(const SpanParams &p, const SpanPlan &sp, bool active, void *gw, hipStream_t st) {
     const dim3 grid(p.steps_per_xcd * 8), block(kThreads);
 #define SHIFTND_SPAN_PAD(ACT, PADV) \
     case PADV: \
-        if constexpr (ND == 2) hipLaunchKernelGGL((crop_backward<T, ACT, PADV, XRAG>), grid, block, sp.lds, st, p); \
+        if constexpr (ND == 2) hipLaunchKernelGGL((crop_backward<T, ACT, PADV, XRAG, POOL>), grid, block, sp.lds, st, p); \
         else hipLaunchKernelGGL((row_backward<T, ACT, PADV>), grid, block, sp.lds, st, p); \
         break;
     // (the channel descriptors come from span_prep for every padding: computing them in crop_backward itself -- tried in round 5 to save
@@ -1232,6 +1322,11 @@ int span_backward(const Geometry &g, int dtype, const void *go, const void *x, c
     p.colg = reinterpret_cast<int16_t *>(ws + sp.off_colg);
     p.x_plane = g.S[1] * g.S[2];
     p.g_plane = g.O[1] * g.O[2];
+    const bool pooled = g.K[0] > 0;
+    if (pooled) {   // `go` is the gradient of the pooled window [P1, P2]
+        p.P2 = static_cast<int>(g.P[2]);
+        p.g_plane = g.P[1] * g.P[2];
+    }
     p.wkind = dtype;
     p.N = static_cast<int>(g.N);
     p.C = static_cast<int>(g.C);
@@ -1262,6 +1357,16 @@ int span_backward(const Geometry &g, int dtype, const void *go, const void *x, c
     p.d_per1g = make_fastdiv(static_cast<uint32_t>(map_period(p.O1, g.pad)));
     p.d_per2g = make_fastdiv(static_cast<uint32_t>(map_period(p.O2, g.pad)));
     const bool active = g.active != 0;
+    if (pooled) {
+        note_kernel("crop_backward_pool");
+        switch (dtype) {
+        case SHIFTND_F64: launch_span_backward<f64_t, 2, false, true>(p, sp, active, gw, st); break;
+        case SHIFTND_F32: launch_span_backward<f32_t, 2, false, true>(p, sp, active, gw, st); break;
+        case SHIFTND_F16: launch_span_backward<f16_t, 2, false, true>(p, sp, active, gw, st); break;
+        default: launch_span_backward<bf16_t, 2, false, true>(p, sp, active, gw, st); break;
+        }
+        return SHIFTND_OK;
+    }
     if (g.nd == 2 && (g.S[2] * es) % 16 != 0) {   // ragged x rows (4- / 8-byte elements: span_geometry_ok)
         note_kernel("crop_backward_ragged");
         switch (dtype) {

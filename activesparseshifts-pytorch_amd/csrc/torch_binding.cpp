@@ -85,6 +85,21 @@ void read_borders(const Tensor &borders, int32_t out[6]) {
     for (int i = 0; i < 6; ++i) out[i] = b.data_ptr<int32_t>()[i];
 }
 
+// The reference hands the private ops a 6-int DEVICE tensor that its kernels read (cuda/shifts_cuda.cu:61-67, ops/shifts.cpp:134).
+// When the window has the input's own spatial sizes the borders are implied -- 0 <= l < r <= size and r - l == size leave
+// l = 0, r = size -- so a reference-style caller stays free of the D2H sync and graph-capturable; a cropped window with
+// device-resident borders still costs the one read (the kernels take the window as launch arguments).
+void read_borders_for(const Tensor &borders, const Tensor &input, at::IntArrayRef window, int nd, int32_t out[6]) {
+    TORCH_CHECK(borders.numel() == 6, "borders must hold 6 integers [l_i, r_i, l_j, r_j, l_k, r_k]");
+    bool whole = !borders.is_cpu() && static_cast<int>(window.size()) == nd && input.dim() == nd + 2;
+    for (int r = 0; whole && r < nd; ++r) whole = window[r] == input.size(2 + r);
+    if (!whole) return read_borders(borders, out);
+    for (int r = 0; r < 3; ++r) {
+        out[2 * r] = 0;
+        out[2 * r + 1] = r < nd ? static_cast<int32_t>(input.size(2 + r)) : 1;
+    }
+}
+
 template <int ND> Tensor shift_public(const Tensor &input, const Tensor &weights, const Tensor &borders,
                                       int64_t padding_mode, bool active_flag) {
     auto bands = check_borders(input, borders, ND);
@@ -231,7 +246,8 @@ template <int ND> Tensor shift_forward_hip(const Tensor &input_, const Tensor &w
     c10::DeviceGuard device_guard(input_.device());
     const int dtype = to_shiftnd_dtype(input_.scalar_type(), "shiftnd_forward_cuda");
     int32_t b[6];
-    read_borders(borders, b);
+    if (static_cast<int>(new_size.size()) == ND + 2) read_borders_for(borders, input_, new_size.slice(2), ND, b);
+    else read_borders(borders, b);
     Tensor w = weights.contiguous();
     Tensor output = at::empty(new_size, input_.options(), at::MemoryFormat::Contiguous);
     shiftnd_problem p;
@@ -264,7 +280,7 @@ std::tuple<Tensor, Tensor> shift_backward_hip(const Tensor &grad_, const Tensor 
     if (padding_mode < 0 || padding_mode > 4) return std::make_tuple(Tensor(), Tensor());
     c10::DeviceGuard device_guard(grad_.device());
     int32_t b[6];
-    read_borders(borders, b);
+    read_borders_for(borders, input_, grad_.sizes().slice(2), ND, b);
     for (int r = 0; r < ND; ++r)
         TORCH_CHECK(grad_.size(2 + r) == b[2 * r + 1] - b[2 * r], "shift", ND, "d backward: grad does not match borders");
     const int dtype = to_shiftnd_dtype(grad_.scalar_type(), "shiftnd_backward_cuda");
@@ -510,7 +526,8 @@ template <int ND> Tensor qshift_forward_hip(const Tensor &input_, const Tensor &
     const int dtype = quant_dtype(input_.scalar_type(), "q_shiftnd_cuda");
     const int wdtype = quant_dtype(weights.scalar_type(), "q_shiftnd_cuda");
     int32_t b[6];
-    read_borders(borders, b);
+    if (static_cast<int>(new_size.size()) == ND + 2) read_borders_for(borders, input_, new_size.slice(2), ND, b);
+    else read_borders(borders, b);
     Tensor wrepr = weights.int_repr().to(input_.device()).contiguous();
     TORCH_CHECK(wrepr.dim() == 2 && wrepr.size(0) == input_.size(1) && wrepr.size(1) == ND,
                 "shift", ND, "d: weights must have shape [C, ", ND, "]");

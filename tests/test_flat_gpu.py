@@ -36,7 +36,10 @@ CASES = [((3, 5, 14, 14), None), ((2, 7, 7, 7), None), ((5, 3, 3, 5), None), ((2
          ((2, 3, 14, 14), [[1, 1], [1, 1]]), ((1, 2, 64, 64), [[1, 2], [3, 0]]), ((3, 2, 9, 1), None), ((2, 3, 1, 23), None),
          ((1, 1, 7, 3), None), ((2, 2, 40, 100), [[0, 0], [1, 0]]), ((1, 2, 300, 6), [[100, 150], [1, 1]]), ((1, 2, 130, 12), [[1, 1], [1, 1]]),
          ((2, 4, 45, 45), [[2, 2], [2, 2]]), ((1, 1, 500, 300), None), ((4, 3, 27, 27), None),
-         ((3, 5, 77), None), ((2, 2, 4100), None), ((2, 3, 1000), [[3, 5]]), ((1, 2, 33), [[0, 1]])]
+         ((3, 5, 77), None), ((2, 2, 4100), None), ((2, 3, 1000), [[3, 5]]), ((1, 2, 33), [[0, 1]]),
+         #  planes of two very wide ragged rows: covers within budget, covers + a whole row of slack beyond the 64 KiB
+         # a launch may ask for -- the plan declines and the older kernels serve them
+         ((2, 2, 2, 1501), None), ((1, 2, 2, 701), None)]
 
 
 def flat_serves(shape, new, es, backward):
@@ -50,13 +53,20 @@ def flat_serves(shape, new, es, backward):
     spb = xpb if backward else opb
     nplanes = (4096 + spb - 1) // spb + 1
     cover = lambda payload: ((payload + 30) // 16) * 16
+    rec = 56 if es == 8 else 48
+    slack = ((max(0 if S1 == 1 else S2, 0 if O1 == 1 else O2) + 2) * es + 15) // 16 * 16
+    partials = 256 * 4 * (8 if es == 8 else 4) if backward else 0
+
+    def lds(planes_in_table, cx, cg):   # table + per-thread partials + covers + slack on both sides: at most 64 KiB per launch
+        return 16 + (planes_in_table * rec + 15) // 16 * 16 + partials + cx + (cg if backward else 0) + 2 * slack
     if nplanes <= 72 and cover(nplanes * xpb) <= 24576 and (not backward or cover(nplanes * opb) <= 24576):
-        return True
+        return lds(72, cover(nplanes * xpb), cover(nplanes * opb)) <= 65536
     if spb < 4096:
         return False
     sr = S2 if backward else O2
     rows = (256 * E + sr - 2) // sr + 1
-    return cover((rows + 5) * S2 * es) + 32 <= 24576 and (not backward or cover((rows + 5) * O2 * es) + 32 <= 24576)
+    cx, cg = cover((rows + 5) * S2 * es) + 32, cover((rows + 5) * O2 * es) + 32
+    return cx <= 24576 and (not backward or cg <= 24576) and lds(2, cx, cg) <= 65536
 
 
 @pytest.mark.parametrize("dt", ["f32", "f64", "f16", "bf16"])

@@ -1,4 +1,4 @@
-"""A seeded, time-boxed slice of tools/fuzz_round2.py in the GPU suite: random shapes, paddings, shift kinds, launch-planning
+"""A seeded, COUNT-boxed slice of tools/fuzz_round2.py in the GPU suite: random shapes, paddings, shift kinds, launch-planning
 knobs and dtypes through the round-2 / round-3 kernel families (LDS-tiled channels-last, small planes / row bands, the
 byte kernel, the one-step kernels, the 3-D walk kernels incl. the pooled backward; round 4: crops and Shift1d through the crop / row kernels,
 channels-last windows), every case against the CPU oracle (bit-exact gathers and fp32 / fp64 interpolation,
@@ -6,7 +6,6 @@ channels-last windows), every case against the CPU oracle (bit-exact gathers and
 cases for as long as asked."""
 import os
 import sys
-import time
 
 import numpy as np
 import pytest
@@ -22,10 +21,11 @@ def test_random_cases_against_the_oracle(seed):
     assert torch.cuda.is_available()
     rs = np.random.RandomState(1000 + seed)
     F.count.clear()
-    t0, n = time.time(), 0
-    while time.time() - t0 < 25.0 or n < 96:  # ~25 s per seed, at least 8 rounds of the case list
+    # a fixed number of cases per seed (round-5 verdict: a wall-clock box made the number of cases the driver ran depend on the
+    # box): ROUNDS passes over the case list, the same cases on every box (~18 s per seed on an MI355X box: 6 s for 20 rounds measured)
+    ROUNDS = 60
+    for n in range(ROUNDS * len(F.CASES)):
         F.CASES[n % len(F.CASES)](rs)
-        n += 1
     kernels = set(F.count)
     for must in ("cl_tiled_backward", "step_backward", "step_gather_forward", "walk_forward", "walk_backward", "walk_backward16", "walk_backward_pool",
                  "crop_backward", "cl_tiled_backward/crop", "cl_tiled_forward_3d"):

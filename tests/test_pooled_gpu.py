@@ -40,6 +40,14 @@ CASES = [  # nd, shape, pool, crop
     (2, (2, 3, 10, 12), (1, 2), None),
     (3, (2, 3, 6, 7, 8), (2, 2, 2), None),
     (3, (1, 4, 5, 6, 12), (2, 3, 2), [[0, 1], [1, 0], [0, 0]]),
+    # round 6 -- the module's emulate_dw {kernel 3, stride 2, padding 0}: cut 1 / 1, pool 2 (crop_backward<.., POOL>): even and odd windows
+    # (ragged last pooled row / column), several steps per plane, a 3 x 3 pool, a one-sided cut, rows of a single piece
+    (2, (2, 4, 20, 32), (2, 2), [[1, 1], [1, 1]]),
+    (2, (2, 3, 17, 24), (2, 2), [[1, 1], [1, 1]]),
+    (2, (1, 3, 70, 64), (2, 2), [[1, 1], [1, 1]]),
+    (2, (1, 3, 16, 40), (3, 3), [[1, 1], [1, 1]]),
+    (2, (2, 2, 11, 28), (2, 2), [[0, 2], [3, 0]]),
+    (2, (2, 3, 9, 4), (2, 2), [[1, 1], [1, 1]]),
 ]
 
 
@@ -79,7 +87,13 @@ def test_pooled_vs_oracle(abi, dt):
                 gx, gw = abi.backward_pooled(_dev(gp), wd, xd, pad, active, pool, b)
                 abi.set_path_policy(0)
                 step = nd == 2 and crop is None and (shape[-1] * x.itemsize) % 16 == 0 and not active  # the one-step kernel's cases
-                want = ("walk_backward_pool",) if walk else (("step_backward_pool",) if step else ("plane_backward_pool", "plane_backward_lds_pool"))
+                # (round 6) 2-D, x rows of whole pieces: what the one-step kernel leaves -- windows, the interpolating shift -- goes to
+                # crop_backward<.., POOL> (a window one column wide under zeros padding excepted: the affine column state)
+                # 2 x 2 windows, pooled rows of at least half a 16-byte piece; other windows keep the band-walk kernels
+                span = (nd == 2 and not step and (shape[-1] * x.itemsize) % 16 == 0 and not (pad == 0 and new[-1] == 1)
+                        and tuple(pool) == (2, 2) and -(-new[-1] // 2) >= max(1, 8 // x.itemsize))
+                want = ("walk_backward_pool",) if walk else (("step_backward_pool",) if step else (("crop_backward_pool",) if span else
+                                                                                                     ("plane_backward_pool", "plane_backward_lds_pool")))
                 assert abi.last_kernel() in want, key
                 assert np.array_equal(gx.cpu().numpy(), gx_r), key
                 assert rel_err(gw.cpu().numpy(), gw_r) < (1e-5 if dt == np.float32 else 1e-12), key
@@ -90,7 +104,8 @@ def test_pooled_16bit(abi, tdt):
     rs = np.random.RandomState(5)
     eps = 2.0 ** -8 if tdt == torch.bfloat16 else 2.0 ** -11
     for nd, shape, pool, crop in [(2, (2, 4, 12, 16), (2, 2), None), (3, (1, 3, 6, 6, 8), (2, 2, 2), None),
-                                  (2, (2, 3, 13, 24), (3, 2), [[1, 0], [0, 3]])]:
+                                  (2, (2, 3, 13, 24), (3, 2), [[1, 0], [0, 3]]), (2, (2, 3, 18, 32), (2, 2), [[1, 1], [1, 1]]),
+                                  (2, (1, 2, 21, 40), (2, 2), [[1, 1], [1, 1]])]:
         xt = torch.from_numpy(rs.uniform(-1, 1, size=shape).astype(np.float32)).to(tdt)
         wt = torch.from_numpy(rs.uniform(-2.5, 2.5, size=(shape[1], nd)).astype(np.float32)).to(tdt)
         x, w = xt.float().numpy(), wt.float().numpy()

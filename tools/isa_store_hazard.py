@@ -22,7 +22,7 @@ STORE = re.compile(r"^buffer_store_dwordx[34]\s+v\[(\d+):(\d+)\],\s*(\S+),\s*s\[
 
 def dest_vgprs(ins):
     """VGPRs a VALU instruction writes (first operand), as a set; empty for instructions with a scalar destination"""
-    m = re.match(r"^v_\S+\s+(v\[(\d+):(\d+)\]|v(\d+))\b", ins)
+    m = re.match(r"^v_\S+\s+(v\[(\d+):(\d+)\]|v(\d+))(?=[,\s]|$)", ins)
     if not m:
         return set()
     if m.group(4) is not None:

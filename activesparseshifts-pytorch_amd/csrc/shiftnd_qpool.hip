@@ -700,7 +700,14 @@ bool qpool_forward_eligible(const Geometry &g, int dtype) {
 int qpool_forward(const Geometry &g, int dtype, const void *x, const void *w, int wkind, int64_t wzp, int64_t xzp, int requant, void *out,
                   hipStream_t st) {
     const QPlanePlan qp = qplane_plan(g);
-    if (qp.ok && g_qpool_tune[0] != 1) {
+    // (round 6) zeros padding, windows two columns wide, output rows of whole windows: on planes of 8 KiB and more qpool_band_fast's
+    // dword reads + v_dot4 sums beat the plane kernel's byte reads (N64 C256 112x112 uint8 pool 2: 0.084 -> 0.070 ms; cut 1/1 0.095 ->
+    // 0.089); below that a band is too little work per image and round (56x56: 0.070 vs 0.244 ms).  tools/qpool_route_bench.py;
+    // knob 36 = 2: the plane kernel first wherever it serves, 3: the band kernel first
+    const QBandPlan qb_first = qband_plan(g, x);
+    const bool band_first = qb_first.ok && qb_first.fast &&
+                            (g_qpool_tune[0] == 3 || (g_qpool_tune[0] == 0 && g.S[0] * g.S[1] * g.S[2] >= 8 * 1024));
+    if (qp.ok && g_qpool_tune[0] != 1 && !band_first) {
         QPlaneParams p{};
         p.x = static_cast<const uint8_t *>(x);
         p.out = static_cast<uint8_t *>(out);

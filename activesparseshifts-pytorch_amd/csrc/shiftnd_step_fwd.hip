@@ -113,7 +113,7 @@ __global__ __launch_bounds__(kThreads) void step_gather_forward_pool(const Gathe
     channel_shifts2<PAD>(p.w, p.wkind, p.wzp, c, p.S1, p.S2, p.d_per1, p.d_per2, cs1, cs2, p.pad);
     const int tid = static_cast<int>(threadIdx.x);
     const int tr = static_cast<int>(fdiv(static_cast<uint32_t>(tid), p.d_cpr)), tc = tid - tr * p.cpr;
-    const int P1 = (p.O1 + 1) >> 1, P2 = p.O2 >> 1;
+    const int P1 = (p.O1 + 1) >> 1, P2 = (p.O2 + 1) >> 1;   // (round 6: any window width -- a cropped 224 -> 222 is not whole pieces)
     const int pr = step * p.R + tr;   // pooled row
     if (tr >= p.R || pr >= P1) return;
     const int jo = tc * E;
@@ -147,14 +147,29 @@ __global__ __launch_bounds__(kThreads) void step_gather_forward_pool(const Gathe
         }
     }
     Chunk<S, (E / 2 > 0 ? E / 2 : 1)> outc;
+    // (sums in ATen's order: row, then column; a ragged last window -- an odd window width or height -- has one column / row)
 #pragma unroll
     for (int j = 0; j < E / 2; ++j) {
-        CT acc = (CT(0) + widen<T>(v[0].e[2 * j])) + widen<T>(v[0].e[2 * j + 1]);
-        if (n1 == 2) acc = (acc + widen<T>(v[1].e[2 * j])) + widen<T>(v[1].e[2 * j + 1]);
-        outc.e[j] = narrow<T>(div_count<CT>(acc, n1 * 2));
+        const bool two = jo + 2 * j + 1 < p.O2;
+        CT acc = CT(0) + widen<T>(v[0].e[2 * j]);
+        if (two) acc = acc + widen<T>(v[0].e[2 * j + 1]);
+        if (n1 == 2) {
+            acc = acc + widen<T>(v[1].e[2 * j]);
+            if (two) acc = acc + widen<T>(v[1].e[2 * j + 1]);
+        }
+        outc.e[j] = narrow<T>(div_count<CT>(acc, n1 * (two ? 2 : 1)));
     }
     S *dst = static_cast<S *>(p.out) + static_cast<int64_t>(plane) * p.o_plane + static_cast<int64_t>(pr) * P2 + jo / 2;
-    __builtin_memcpy(__builtin_assume_aligned(dst, 8), outc.e, 8);
+    if (jo + E <= p.O2 + 1) {   // all E / 2 pooled elements exist: one store at the element's alignment (pooled rows of any length)
+        typedef typename vec_of<8>::type v8 __attribute__((aligned(4)));
+        typename vec_of<8>::type bits;
+        __builtin_memcpy(&bits, outc.e, 8);
+        *reinterpret_cast<v8 *>(dst) = bits;
+    } else {
+#pragma unroll
+        for (int j = 0; j < E / 2; ++j)
+            if (jo + 2 * j < p.O2) dst[j] = outc.e[j];
+    }
 }
 template <int ESIZE, int PAD>
 __global__ __launch_bounds__(kThreads) void step_gather_forward_small(const GatherParams p) {
@@ -610,9 +625,10 @@ bool step_forward_pooled_eligible(const Geometry &g, int dtype, const void *x, c
     const int es = dtype_size(dtype);
     const int64_t xe = g.S[1] * g.S[2], oe = g.O[1] * g.O[2];
     if (xe < 1 || oe < 1 || xe >= (1LL << 30) || oe >= (1LL << 30)) return false;
-    if ((g.O[2] * es) % 16 != 0 || g.O[2] * es / 16 > kThreads || reinterpret_cast<uintptr_t>(out) % 8 != 0) return false;
+    // (round 6: windows of any width -- the last chunk of a row may be partial; pooled rows at the element's alignment)
+    if ((g.O[2] * es + 15) / 16 > kThreads || reinterpret_cast<uintptr_t>(out) % es != 0) return false;
     if (!dense(g.xs, g.N, g.C, g.S)) return false;
-    const int64_t cpr = g.O[2] * es / 16, R = kThreads / cpr, p1 = (g.O[1] + 1) / 2;
+    const int64_t cpr = (g.O[2] * es + 15) / 16, R = kThreads / cpr, p1 = (g.O[1] + 1) / 2;
     return g.N * g.C * ((p1 + R - 1) / R) + 8 < (1LL << 31);
 }
 
@@ -633,7 +649,7 @@ int step_forward_pooled(const Geometry &g, int dtype, const void *x, const void 
     p.L2 = static_cast<int>(g.L[2]);
     p.x_plane = g.S[1] * g.S[2];
     p.o_plane = g.P[1] * g.P[2];   // (the pooled plane)
-    p.cpr = static_cast<int>(g.O[2] * es / 16);
+    p.cpr = static_cast<int>((g.O[2] * es + 15) / 16);
     p.xppr = static_cast<int>(g.S[2] * es / 16);
     const int P1 = static_cast<int>(g.P[1]);
     p.R = kThreads / p.cpr;

@@ -283,7 +283,7 @@ def test_strided_module_uses_fused_pool():
     mg = m.to(DEV)
     xg = x.to(DEV).requires_grad_(True)
     out_g, _ = mg(xg)
-    assert abi.last_kernel() == "plane_pool_forward"
+    assert abi.last_kernel() == "step_gather_forward_pool"   # (round 6: windows of any width; 30 fp32 columns are not whole pieces)
     out_g.square().sum().backward()
     assert torch.equal(out_g.cpu(), out_c.detach())
     assert torch.allclose(xg.grad.cpu(), gx_c, rtol=1e-6, atol=1e-9)

@@ -281,6 +281,8 @@ QPlanePlan qplane_plan(const Geometry &g) {
     int ni = static_cast<int>((items + kThreads - 1) / kThreads);
     ni = ni <= 1 ? 1 : (ni == 2 ? 2 : 4);
     if (items > 4LL * kThreads || ni * q.KV > 18) return q;
+    // (round 6, measured and dropped: NI = 4 items per thread spread over five 56 x 56 planes per round -- more bytes in flight per
+    //  workgroup -- N128 C512 56x56 uint8 pool 2 0.079 -> 0.112 ms: the offsets' 64 registers cost more waves than the longer rounds return)
     q.NI = ni;
     q.items = static_cast<int>(items);
     q.ppw = ni == 1 ? static_cast<int>(std::min<int64_t>(kThreads / items, g.N)) : 1;

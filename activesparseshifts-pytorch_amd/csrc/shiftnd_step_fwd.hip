@@ -620,7 +620,8 @@ int step_forward_lds(const Geometry &g, int dtype, const void *x, const void *w,
 // the 2-D sparse shift + 2 x 2 average pool of 4- / 8-byte float elements in one sweep of one-step workgroups
 bool step_forward_pooled_eligible(const Geometry &g, int dtype, const void *x, const void *out) {
     if (g_step_tune[1] == 1) return false;
-    if (dtype != SHIFTND_F32 && dtype != SHIFTND_F64) return false;
+    // (round 6: 16-bit types too -- fp32 sums like ATen's, one rounding; knob 33 = 3 keeps them on the band-walk kernel)
+    if (dtype != SHIFTND_F32 && dtype != SHIFTND_F64 && !((dtype == SHIFTND_F16 || dtype == SHIFTND_BF16) && g_step_tune[1] != 3)) return false;
     if (g.nd != 2 || g.active || g.K[1] != 2 || g.K[2] != 2 || g.S[0] != 1 || g.O[0] != 1) return false;
     const int es = dtype_size(dtype);
     const int64_t xe = g.S[1] * g.S[2], oe = g.O[1] * g.O[2];
@@ -672,7 +673,10 @@ int step_forward_pooled(const Geometry &g, int dtype, const void *x, const void 
     case 2: hipLaunchKernelGGL((step_gather_forward_pool<TT, 2>), grid, block, 0, st, p); break; \
     default: hipLaunchKernelGGL((step_gather_forward_pool<TT, kPadMirror>), grid, block, 0, st, p); break; \
     }
-    if (dtype == SHIFTND_F32) { SHIFTND_STEP_FWD_POOL(f32_t) } else { SHIFTND_STEP_FWD_POOL(f64_t) }
+    if (dtype == SHIFTND_F32) { SHIFTND_STEP_FWD_POOL(f32_t) }
+    else if (dtype == SHIFTND_F64) { SHIFTND_STEP_FWD_POOL(f64_t) }
+    else if (dtype == SHIFTND_F16) { SHIFTND_STEP_FWD_POOL(f16_t) }
+    else { SHIFTND_STEP_FWD_POOL(bf16_t) }
 #undef SHIFTND_STEP_FWD_POOL
     return SHIFTND_OK;
 }

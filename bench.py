@@ -265,6 +265,18 @@ def emit(result, out=None):
     out.flush()
 
 
+def flush_c_stdio():
+    """RCCL announces itself with a C-level printf ("Librccl path : ...") that sits in the C library's buffer -- stdout is a pipe --
+    until the process exits, i.e. AFTER the RESULT line Python has already written: the last line of stdout was RCCL's, not the
+    result (found by tests/test_bench_ranks.py on the GPU box).  Every rank empties the C buffers right after the rendezvous and
+    again before rank 0 prints."""
+    try:
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+    except Exception:  # noqa: BLE001
+        pass
+
+
 def box_stream(tensor_bytes=None):
     """Same-box calibration: tools/stream_probe (a plain HIP binary, built by __graft_entry__.build()) streams C2-sized
     buffers with float4 accesses -- best 1-read-1-write and 2-read-1-write rates over a small fixed set of launch shapes --
@@ -490,6 +502,7 @@ def main(argv=None):
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev, timeout=limit)
         else:
             dist.init_process_group(backend, rank=rank, world_size=world, timeout=limit)
+        flush_c_stdio()
     if os.environ.get("SHIFTND_BENCH_FAIL_RANK") == str(rank):  # tests: a rank that dies after the rendezvous
         sys.stderr.write("bench.py: rank %d exits on request (SHIFTND_BENCH_FAIL_RANK)\n" % rank)
         os._exit(7)
@@ -844,10 +857,15 @@ def main(argv=None):
                     configs[cname] = {"error": repr(e)[:300]}
             result["configs"] = configs
             result["configs_wall_s"] = time.perf_counter() - t_all
-        emit(result)
+    # the RESULT line is the LAST thing any rank writes: the other ranks have left the process group (and flushed whatever the
+    # C libraries buffered) before rank 0 prints
     if use_pg:
+        flush_c_stdio()
         dist.barrier()
         dist.destroy_process_group()
+    flush_c_stdio()
+    if rank == 0:
+        emit(result)
 
 
 def distinct_device_conflicts(per_rank):

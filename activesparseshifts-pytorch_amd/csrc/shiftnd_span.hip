@@ -158,9 +158,13 @@ __device__ __forceinline__ void span_read(const char *lds_row, const S *mem_row,
 // loads the pooled elements under columns pg E .. pg E + E - 1 instead and writes the expanded piece into the same slot at phase 0;
 // everything behind the barrier is unchanged.  (The cropped pooled backward ran the band-walk kernel before: N64 C256 224x224 cut 1/1
 // pool 2 fp32 3.94 ms.)
-template <typename T, bool ACTIVE, int PAD, bool XRAG = false, bool POOL = false>
+// U (round 6): row groups per thread -- a workgroup owns U R rows, every thread stages and computes U chunks R rows apart: half the
+// per-workgroup scalar work, column-state prologue and partial-sum tail per byte for the form that is bound by instruction issue (the
+// interpolating shift; step_backward's U).
+template <typename T, bool ACTIVE, int PAD, bool XRAG = false, bool POOL = false, int U = 1>
 __global__ __launch_bounds__(kThreads) void crop_backward(const SpanParams p) {
     static_assert(!(POOL && XRAG), "the pooled form takes x rows of whole pieces");
+    static_assert(U == 1 || (!XRAG && !POOL), "two row groups per thread: plain cropped windows on rows of whole pieces");
     using S = typename T::S;
     using CT = typename T::C;
     constexpr int ES = sizeof(S);
@@ -176,7 +180,8 @@ __global__ __launch_bounds__(kThreads) void crop_backward(const SpanParams p) {
     const int step = static_cast<int>(bid - plane * static_cast<uint32_t>(p.spp));
     const int c = static_cast<int>(plane - fdiv(plane, p.d_C) * static_cast<uint32_t>(p.C));
     const ChanDesc d = p.desc[c];
-    const int R = p.R, S1 = p.S1, S2 = p.S2, O1 = p.O1, O2 = p.O2, L1 = p.L1, L2 = p.L2, cpr = p.cpr;
+    const int R0 = p.R, S1 = p.S1, S2 = p.S2, O1 = p.O1, O2 = p.O2, L1 = p.L1, L2 = p.L2, cpr = p.cpr;
+    const int R = U * R0;   // rows of this step (R0 per row group)
     const int b0 = step * R;
     const int Rn = min(R, S1 - b0);
     // tile: x corner rows [R + 1][cpr pieces] | grad_out at the step's own rows [R][cpr + 2] | the rows grad_x reads [R (+ 1)][cpr + 2]
@@ -205,9 +210,13 @@ __global__ __launch_bounds__(kThreads) void crop_backward(const SpanParams p) {
     const int xph = XRAG ? static_cast<int>((static_cast<uint64_t>(plane) * static_cast<uint64_t>(p.x_plane) * ES) & 15u) : 0;
     auto xrow_lo = [&](int row) { return xph + row * S2 * ES; };
     if constexpr (!XRAG) {
-        if (tr < R) {
-            const int sx = tr <= Rn ? row_map_t<PAD>(b0 + tr, d.cx1, S1, p.pad) : -1;
-            if (sx >= 0) dma_x(sx, tc, 0);
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (tr < R0) {
+                const int vtr = tr + u * R0;
+                const int sx = vtr <= Rn ? row_map_t<PAD>(b0 + vtr, d.cx1, S1, p.pad) : -1;
+                if (sx >= 0) dma_x(sx, tc, u * R0 * cpr);
+            }
         }
         if (Rn == R && tid < cpr) {
             const int sx = row_map_t<PAD>(b0 + R, d.cx1, S1, p.pad);
@@ -301,7 +310,18 @@ __global__ __launch_bounds__(kThreads) void crop_backward(const SpanParams p) {
         dma_xc((rg < R && rg <= Rn) ? row_map_t<PAD>(b0 + rg, d.cx1, S1, p.pad) : -1, pg, 0);
         if (Rn == R && tid < PGi) dma_xc(row_map_t<PAD>(b0 + R, d.cx1, S1, p.pad), tid, R * PGi);
     }
-    {
+    if constexpr (U > 1) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int vrg = rg + u * R0;
+            const int ro = (rg < R0 && vrg < Rn && b0 + vrg - L1 >= 0 && b0 + vrg - L1 < O1) ? b0 + vrg - L1 : -1;
+            dma_g(ro, pg, goff / 16 + u * R0 * PGi);
+            dma_g(gs_row(vrg, rg < R0 && (ACTIVE ? vrg <= Rn : vrg < Rn)), pg, gsoff / 16 + u * R0 * PGi);
+        }
+        if constexpr (ACTIVE) {
+            if (Rn == R && tid < PGi) dma_g(gs_row(R, true), tid, gsoff / 16 + R * PGi);
+        }
+    } else {
         const int ro = (rg < R && rg < Rn && b0 + rg - L1 >= 0 && b0 + rg - L1 < O1) ? b0 + rg - L1 : -1;   // the step's own rows
         if constexpr (POOL) {
             const Pooled qa = pooled_load(ro, pg, goff / 16 + tid);
@@ -339,7 +359,7 @@ __global__ __launch_bounds__(kThreads) void crop_backward(const SpanParams p) {
             // (a window one column wide ignores the shift, shifts_kernels.h:40-48 -- both corners read column 0, not an affine
             //  state: span_backward_eligible sends O2 == 1 with zeros padding to the per-channel kernels)
         } else {
-            const size_t rec = (static_cast<size_t>(c) * cpr + (tr < R ? tc : 0)) * REC;
+            const size_t rec = (static_cast<size_t>(c) * cpr + (tr < R0 ? tc : 0)) * REC;
             xm = load_colstate<E>(p.colx + rec);
             gm = load_colstate<E>(p.colg + rec);
         }
@@ -348,8 +368,11 @@ __global__ __launch_bounds__(kThreads) void crop_backward(const SpanParams p) {
     __syncthreads();
 
     CT part[NDIFF] = {CT(0), CT(0)};
-    if (tr < R && tr < Rn) {
-        const int b = b0 + tr;
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+    const int vtr = tr + u * R0;   // this row group's row of the tile
+    if (tr < R0 && vtr < Rn) {
+        const int b = b0 + vtr;
         const CT dw[3] = {static_cast<CT>(d.dw[0]), static_cast<CT>(d.dw[1]), CT(0)};
         const bool in_row = b >= L1 && b < L1 + O1;
         auto row_valid = [&](int pr, int cs, int len) { return PAD != 0 || row_map_t<PAD>(pr, cs, len, p.pad) >= 0; };
@@ -373,7 +396,7 @@ __global__ __launch_bounds__(kThreads) void crop_backward(const SpanParams p) {
                 const bool dom = in_row && pr <= O1;
                 const int srow = dom ? row_map_t<PAD>(pr, d.cg1, O1, p.pad) : -1;
                 S raw[E + 1];
-                read_row(tile + gsoff + (tr + hb) * RBG + gphase(srow), srow >= 0, gm, raw);
+                read_row(tile + gsoff + (vtr + hb) * RBG + gphase(srow), srow >= 0, gm, raw);
 #pragma unroll
                 for (int e = 0; e <= E; ++e) gv[hb][e] = widen<T>(raw[e]);
             }
@@ -385,7 +408,7 @@ __global__ __launch_bounds__(kThreads) void crop_backward(const SpanParams p) {
         } else {
             const int srow = in_row ? row_map_t<PAD>(b - L1, d.cg1, O1, p.pad) : -1;
             S raw[E + 1];
-            read_row(tile + gsoff + tr * RBG + gphase(srow), srow >= 0, gm, raw);
+            read_row(tile + gsoff + vtr * RBG + gphase(srow), srow >= 0, gm, raw);
 #pragma unroll
             for (int e = 0; e < E; ++e) res.e[e] = inside[e] ? raw[e] : zero;
         }
@@ -396,12 +419,12 @@ __global__ __launch_bounds__(kThreads) void crop_backward(const SpanParams p) {
             S raw[E + 1];
             // (XRAG: the row's first byte sits at the phase of its SOURCE row's cover)
             const int xphase = XRAG ? (xrow_lo(max(row_map_t<PAD>(b + hb, d.cx1, S1, p.pad), 0)) & 15) : 0;
-            read_row(tile + (tr + hb) * RBX + xphase, row_valid(b + hb, d.cx1, S1), xm, raw);
+            read_row(tile + (vtr + hb) * RBX + xphase, row_valid(b + hb, d.cx1, S1), xm, raw);
 #pragma unroll
             for (int e = 0; e <= E; ++e) xv[hb][e] = widen<T>(raw[e]);
         }
         // (the own gradient chunk: E elements at column ji - L2 of the row's slot -- clamped to the slot, masked by the window)
-        const S *grow = reinterpret_cast<const S *>(tile + goff + tr * RBG + (in_row ? gphase(b - L1) : 0)) + (in_row ? ji - L2 : 0);
+        const S *grow = reinterpret_cast<const S *>(tile + goff + vtr * RBG + (in_row ? gphase(b - L1) : 0)) + (in_row ? ji - L2 : 0);
 #pragma unroll
         for (int e = 0; e < E; ++e) {
             const CT v[4] = {xv[0][e], xv[1][e], xv[0][e + 1], xv[1][e + 1]};
@@ -425,6 +448,7 @@ __global__ __launch_bounds__(kThreads) void crop_backward(const SpanParams p) {
             store_chunk<S, E>(gxp + static_cast<int64_t>(b) * S2 + ji, res);
         }
     }
+    }   // (row groups)
     // ---- this step's sums: DPP tree per wave, the four waves added in fp64 by one thread ----------------------------------
     double *scratch = reinterpret_cast<double *>(tile + ((gsoff + (R + 1) * RBG + 63) & ~63) + 64);
 #pragma unroll
@@ -965,7 +989,7 @@ SpanFwdPlan span_forward_plan(const Geometry &g, int es) {
 }
 
 struct SpanPlan {
-    int cpr, seg, nseg, R, rsteps, spp, P, ndiff, rec;
+    int cpr, seg, nseg, R, U, rsteps, spp, P, ndiff, rec;
     uint64_t total;
     size_t off_desc, off_colx, off_colg, bytes, lds;
 };
@@ -986,6 +1010,16 @@ SpanPlan span_plan(const Geometry &g, int es) {
     R = std::max(1, std::min<int>(R, static_cast<int>(g.S[1])));
     if (g.nd == 1 || s.nseg > 1) R = 1;
     s.R = R;
+    // row groups per thread (crop_backward<.., U>): two for the interpolating shift on rows of whole pieces (round 6: N64 C256 224x224 cut
+    // 1/1 fp32 1.75 -> 1.615 ms, the sparse crop's 1.60; N512 C16 64x64 0.075 -> 0.069) and for the sparse shift on small tensors
+    // (N512 C16 64x64: 0.068 -> 0.064 ms; N64 C256 224x224: 1.598 -> 1.616, so not there).  4- and 2-byte elements (fp64 keeps one).
+    // Knob 35 bit 7: one everywhere, bit 8: two everywhere.  Geometry and knobs only: the workspace is planned from the same answer.
+    s.U = 1;
+    if (g.nd == 2 && !xrag && g.K[0] <= 0 && s.nseg == 1 && es <= 4 && g.S[1] >= 2 * R && !(g_step_tune[3] & 128)) {
+        const int64_t steps1 = g.N * g.C * ((g.S[1] + R - 1) / R);
+        if (g.active || steps1 <= 65536 || (g_step_tune[3] & 256)) s.U = 2;
+    }
+    R *= s.U;   // rows per step
     s.rsteps = static_cast<int>((g.S[1] + R - 1) / R);
     s.spp = s.rsteps * s.nseg;
     s.ndiff = g.nd == 1 ? 1 : 2;
@@ -1281,8 +1315,14 @@ static void launch_span_backward(const SpanParams &p, const SpanPlan &sp, bool a
     const dim3 grid(p.steps_per_xcd * 8), block(kThreads);
 #define SHIFTND_SPAN_PAD(ACT, PADV) \
     case PADV: \
-        if constexpr (ND == 2) hipLaunchKernelGGL((crop_backward<T, ACT, PADV, XRAG, POOL>), grid, block, sp.lds, st, p); \
-        else hipLaunchKernelGGL((row_backward<T, ACT, PADV>), grid, block, sp.lds, st, p); \
+        if constexpr (ND == 2 && !XRAG && !POOL && sizeof(typename T::S) <= 4) { \
+            if (sp.U == 2) hipLaunchKernelGGL((crop_backward<T, ACT, PADV, false, false, 2>), grid, block, sp.lds, st, p); \
+            else hipLaunchKernelGGL((crop_backward<T, ACT, PADV, false, false, 1>), grid, block, sp.lds, st, p); \
+        } else if constexpr (ND == 2) { \
+            hipLaunchKernelGGL((crop_backward<T, ACT, PADV, XRAG, POOL>), grid, block, sp.lds, st, p); \
+        } else { \
+            hipLaunchKernelGGL((row_backward<T, ACT, PADV>), grid, block, sp.lds, st, p); \
+        } \
         break;
     // (the channel descriptors come from span_prep for every padding: computing them in crop_backward itself -- tried in round 5 to save
     //  the 4.5 us launch -- put weight loads and 64-bit shift arithmetic in front of every one-step workgroup's first DMA: N64 C256

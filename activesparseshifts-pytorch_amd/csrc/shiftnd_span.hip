@@ -164,7 +164,7 @@ __device__ __forceinline__ void span_read(const char *lds_row, const S *mem_row,
 template <typename T, bool ACTIVE, int PAD, bool XRAG = false, bool POOL = false, int U = 1>
 __global__ __launch_bounds__(kThreads) void crop_backward(const SpanParams p) {
     static_assert(!(POOL && XRAG), "the pooled form takes x rows of whole pieces");
-    static_assert(U == 1 || (!XRAG && !POOL), "two row groups per thread: plain cropped windows on rows of whole pieces");
+    static_assert(U == 1 || U == 2, "one or two row groups per thread");
     using S = typename T::S;
     using CT = typename T::C;
     constexpr int ES = sizeof(S);
@@ -307,36 +307,40 @@ __global__ __launch_bounds__(kThreads) void crop_backward(const SpanParams p) {
                                                  (__attribute__((address_space(3))) void *)dst_wave, 16, 0, 0);
             }
         };
-        dma_xc((rg < R && rg <= Rn) ? row_map_t<PAD>(b0 + rg, d.cx1, S1, p.pad) : -1, pg, 0);
-        if (Rn == R && tid < PGi) dma_xc(row_map_t<PAD>(b0 + R, d.cx1, S1, p.pad), tid, R * PGi);
-    }
-    if constexpr (U > 1) {
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const int vrg = rg + u * R0;
-            const int ro = (rg < R0 && vrg < Rn && b0 + vrg - L1 >= 0 && b0 + vrg - L1 < O1) ? b0 + vrg - L1 : -1;
+            dma_xc((rg < R0 && vrg <= Rn) ? row_map_t<PAD>(b0 + vrg, d.cx1, S1, p.pad) : -1, pg, u * R0 * PGi);
+        }
+        if (Rn == R && tid < PGi) dma_xc(row_map_t<PAD>(b0 + R, d.cx1, S1, p.pad), tid, R * PGi);
+    }
+    if constexpr (POOL) {
+        Pooled qa[U], qb[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int vrg = rg + u * R0;
+            const int ro = (rg < R0 && vrg < Rn && b0 + vrg - L1 >= 0 && b0 + vrg - L1 < O1) ? b0 + vrg - L1 : -1;   // the step's own rows
+            qa[u] = pooled_load(ro, pg, goff / 16 + u * R0 * PGi + tid);
+            qb[u] = pooled_load(gs_row(vrg, rg < R0 && (ACTIVE ? vrg <= Rn : vrg < Rn)), pg, gsoff / 16 + u * R0 * PGi + tid);
+        }
+        Pooled qc = qa[0];
+        if constexpr (ACTIVE) qc = pooled_load((Rn == R && tid < PGi) ? gs_row(R, true) : -1, tid, gsoff / 16 + R * PGi + tid);
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            pooled_store(qa[u]);
+            pooled_store(qb[u]);
+        }
+        if constexpr (ACTIVE) pooled_store(qc);
+    } else {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int vrg = rg + u * R0;
+            const int ro = (rg < R0 && vrg < Rn && b0 + vrg - L1 >= 0 && b0 + vrg - L1 < O1) ? b0 + vrg - L1 : -1;   // the step's own rows
             dma_g(ro, pg, goff / 16 + u * R0 * PGi);
             dma_g(gs_row(vrg, rg < R0 && (ACTIVE ? vrg <= Rn : vrg < Rn)), pg, gsoff / 16 + u * R0 * PGi);
         }
         if constexpr (ACTIVE) {
-            if (Rn == R && tid < PGi) dma_g(gs_row(R, true), tid, gsoff / 16 + R * PGi);
-        }
-    } else {
-        const int ro = (rg < R && rg < Rn && b0 + rg - L1 >= 0 && b0 + rg - L1 < O1) ? b0 + rg - L1 : -1;   // the step's own rows
-        if constexpr (POOL) {
-            const Pooled qa = pooled_load(ro, pg, goff / 16 + tid);
-            const Pooled qb = pooled_load(gs_row(rg, rg < R && (ACTIVE ? rg <= Rn : rg < Rn)), pg, gsoff / 16 + tid);
-            Pooled qc = qa;
-            if constexpr (ACTIVE) qc = pooled_load((Rn == R && tid < PGi) ? gs_row(R, true) : -1, tid, gsoff / 16 + R * PGi + tid);
-            pooled_store(qa);
-            pooled_store(qb);
-            if constexpr (ACTIVE) pooled_store(qc);
-        } else {
-            dma_g(ro, pg, goff / 16);
-            dma_g(gs_row(rg, rg < R && (ACTIVE ? rg <= Rn : rg < Rn)), pg, gsoff / 16);
-            if constexpr (ACTIVE) {
-                if (Rn == R && tid < PGi) dma_g(gs_row(R, true), tid, gsoff / 16 + R * PGi);   // the + 1 row of a full step
-            }
+            if (Rn == R && tid < PGi) dma_g(gs_row(R, true), tid, gsoff / 16 + R * PGi);   // the + 1 row of a full step
         }
     }
 
@@ -1013,11 +1017,16 @@ SpanPlan span_plan(const Geometry &g, int es) {
     // row groups per thread (crop_backward<.., U>): two for the interpolating shift on rows of whole pieces (round 6: N64 C256 224x224 cut
     // 1/1 fp32 1.75 -> 1.615 ms, the sparse crop's 1.60; N512 C16 64x64 0.075 -> 0.069) and for the sparse shift on small tensors
     // (N512 C16 64x64: 0.068 -> 0.064 ms; N64 C256 224x224: 1.598 -> 1.616, so not there).  4- and 2-byte elements (fp64 keeps one).
-    // Knob 35 bit 7: one everywhere, bit 8: two everywhere.  Geometry and knobs only: the workspace is planned from the same answer.
+    // Knob 35 bit 7: one for the sparse shift everywhere, bit 8: two everywhere.  Geometry and knobs only: the workspace is planned from the
+    // same answer.
     s.U = 1;
-    if (g.nd == 2 && !xrag && g.K[0] <= 0 && s.nseg == 1 && es <= 4 && g.S[1] >= 2 * R && !(g_step_tune[3] & 128)) {
+    if (g.nd == 2 && s.nseg == 1 && es <= 4) {
+        // (ragged x rows, N512 C16 62x62 sparse: 0.072 -> 0.066 ms, N64 C256 222x222: 1.666 -> 1.668; the pooled interpolating form,
+        //  N64 C256 224x224: 1.855 -> 1.668 ms -- the same rule for every form.  The interpolating shift has NO one-group instantiation
+        //  for 4- / 2-byte elements: planes of fewer than 2 R rows leave the second group idle.)
         const int64_t steps1 = g.N * g.C * ((g.S[1] + R - 1) / R);
-        if (g.active || steps1 <= 65536 || (g_step_tune[3] & 256)) s.U = 2;
+        if (g.active) s.U = 2;
+        else if (!(g_step_tune[3] & 128) && g.S[1] >= 2 * R && (steps1 <= 65536 || (g_step_tune[3] & 256))) s.U = 2;
     }
     R *= s.U;   // rows per step
     s.rsteps = static_cast<int>((g.S[1] + R - 1) / R);
@@ -1315,9 +1324,11 @@ static void launch_span_backward(const SpanParams &p, const SpanPlan &sp, bool a
     const dim3 grid(p.steps_per_xcd * 8), block(kThreads);
 #define SHIFTND_SPAN_PAD(ACT, PADV) \
     case PADV: \
-        if constexpr (ND == 2 && !XRAG && !POOL && sizeof(typename T::S) <= 4) { \
-            if (sp.U == 2) hipLaunchKernelGGL((crop_backward<T, ACT, PADV, false, false, 2>), grid, block, sp.lds, st, p); \
-            else hipLaunchKernelGGL((crop_backward<T, ACT, PADV, false, false, 1>), grid, block, sp.lds, st, p); \
+        if constexpr (ND == 2 && sizeof(typename T::S) <= 4 && ACT) { \
+            hipLaunchKernelGGL((crop_backward<T, ACT, PADV, XRAG, POOL, 2>), grid, block, sp.lds, st, p); \
+        } else if constexpr (ND == 2 && sizeof(typename T::S) <= 4) { \
+            if (sp.U == 2) hipLaunchKernelGGL((crop_backward<T, ACT, PADV, XRAG, POOL, 2>), grid, block, sp.lds, st, p); \
+            else hipLaunchKernelGGL((crop_backward<T, ACT, PADV, XRAG, POOL, 1>), grid, block, sp.lds, st, p); \
         } else if constexpr (ND == 2) { \
             hipLaunchKernelGGL((crop_backward<T, ACT, PADV, XRAG, POOL>), grid, block, sp.lds, st, p); \
         } else { \

@@ -47,12 +47,14 @@ struct SpanParams {
     int64_t x_plane, g_plane;   // elements per (n, c)
     int wkind, N, C, pad, nd;
     int S1, S2, O1, O2, L1, L2;
+    int S0, O0, L0;      // crop_backward3: planes of the input volume / of the window, the window's first plane
     int cpr, seg, nseg;  // 16-byte chunks per x row, chunks per column segment (<= 256), segments per row
     int R, rsteps, spp;  // rows per step, row steps per plane, steps per plane = rsteps * nseg
     int P;               // pieces per slot
     int P2;              // crop_backward<.., POOL>: elements per row of the pooled gradient (2 x 2 windows)
     uint32_t total_steps, steps_per_xcd;
     FastDiv d_spp, d_C, d_seg, d_nseg, d_P, d_per1x, d_per2x, d_per1g, d_per2g;
+    FastDiv d_rsteps, d_per0x, d_per0g;   // crop_backward3
 };
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -65,19 +67,23 @@ __global__ __launch_bounds__(kThreads) void span_prep(const SpanParams p, const 
     constexpr int E = 16 / sizeof(S);
     constexpr int REC = RecSize<E>::N;
     const int c = blockIdx.x;
-    const int lead = 2 - p.nd;   // real dim r -> (row, column) index r + 2 - nd
-    int64_t sh[2] = {0, 0};
-    CT dw[2] = {CT(0), CT(0)};
+    const int lead = 3 - p.nd;   // real dim r -> (plane, row, column) index r + 3 - nd
+    int64_t sh[3] = {0, 0, 0};
+    CT dw[3] = {CT(0), CT(0), CT(0)};
     for (int r = 0; r < p.nd; ++r) {
         const CT wv = load_weight<CT>(p.w, p.wkind, static_cast<int64_t>(c) * p.nd + r);
         prep_shift_backward<CT>(wv, ACTIVE, sh[r + lead], dw[r]);
     }
-    const int cx1 = canon_shift(sh[0], p.S1, p.pad, p.d_per1x), cx2 = canon_shift(sh[1], p.S2, p.pad, p.d_per2x);
-    const int cg1 = canon_shift(ACTIVE ? sh[0] : -sh[0], p.O1, p.pad, p.d_per1g);
-    const int cg2 = canon_shift(ACTIVE ? sh[1] : -sh[1], p.O2, p.pad, p.d_per2g);
+    const int cx1 = canon_shift(sh[1], p.S1, p.pad, p.d_per1x), cx2 = canon_shift(sh[2], p.S2, p.pad, p.d_per2x);
+    const int cg1 = canon_shift(ACTIVE ? sh[1] : -sh[1], p.O1, p.pad, p.d_per1g);
+    const int cg2 = canon_shift(ACTIVE ? sh[2] : -sh[2], p.O2, p.pad, p.d_per2g);
     if (threadIdx.x == 0) {
         ChanDesc d;
         d.cx0 = d.cg0 = 0;
+        if (p.nd == 3) {   // the plane maps: over the input's planes, over the window's planes
+            d.cx0 = canon_shift(sh[0], p.S0, p.pad, p.d_per0x);
+            d.cg0 = canon_shift(ACTIVE ? sh[0] : -sh[0], p.O0, p.pad, p.d_per0g);
+        }
         d.cx1 = cx1;
         d.cg1 = cg1;
         d.cx2 = cx2;
@@ -86,7 +92,7 @@ __global__ __launch_bounds__(kThreads) void span_prep(const SpanParams p, const 
         d.pad_ = 0;
         d.dw[0] = static_cast<double>(dw[0]);
         d.dw[1] = static_cast<double>(dw[1]);
-        d.dw[2] = 0.0;
+        d.dw[2] = static_cast<double>(dw[2]);
         d.pad2_ = 0.0;
         p.desc[c] = d;
     }
@@ -455,6 +461,222 @@ __global__ __launch_bounds__(kThreads) void crop_backward(const SpanParams p) {
     }   // (row groups)
     // ---- this step's sums: DPP tree per wave, the four waves added in fp64 by one thread ----------------------------------
     double *scratch = reinterpret_cast<double *>(tile + ((gsoff + (R + 1) * RBG + 63) & ~63) + 64);
+#pragma unroll
+    for (int i = 0; i < NDIFF; ++i) {
+        const CT t = wave_total(part[i]);
+        if ((tid & 63) == 63) scratch[NDIFF * wave + i] = static_cast<double>(t);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid < NDIFF) {
+        double acc = 0.0;
+#pragma unroll
+        for (int w = 0; w < kThreads / 64; ++w) acc += scratch[NDIFF * w + tid];
+        p.partials[static_cast<size_t>(bid) * NDIFF + tid] = acc;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// crop_backward3 (round 6): the CROPPED 3-D backward -- Shift3d behind emulate_dw with padding < kernel / 2 (modules/shifts.py:41-46:
+// cut 1 / 1 per dim), which no chunk kernel took: N8 C128 16x112x112 bf16 cut 1/1/1 ran plane_backward at 1.6 ms (sparse) / 3.1 ms
+// (interpolating) where the uncropped walk takes 0.24 ms.  crop_backward's one-step shape with the depth as one more step index: a
+// step is R rows of ONE plane a of grad_x; it stages the R + 1 corner rows of the TWO input planes m0[a], m0[a + 1], the step's own
+// gradient rows (plane a - L0 of the window) and the rows grad_x reads -- of one gradient plane g0[a - L0] (sparse shift) or two
+// (interpolating) -- as covers with a phase (a row of the window starts anywhere in the tensor's stream of 16-byte pieces).  Eight sums
+// of g x corner difference per step (corner_diffs<3>: bit 0 = + 1 plane, bit 1 = + 1 row, bit 2 = + 1 column, shifts_kernels.h:58-103),
+// one record per step, step_reduce<.., 3> as for the walk kernels.  Reference: kernels/shifts_kernels.h:222-327 with the window of
+// ops/shifts.cpp:93-135.  x rows of whole 16-byte pieces, every dim of the volume and of the window at least 2 (host).
+// ---------------------------------------------------------------------------------------------------------------------
+template <typename T, bool ACTIVE, int PAD>
+__global__ __launch_bounds__(kThreads) void crop_backward3(const SpanParams p) {
+    using S = typename T::S;
+    using CT = typename T::C;
+    constexpr int ES = sizeof(S);
+    constexpr int E = 16 / ES;
+    constexpr int REC = RecSize<E>::N;
+    constexpr int NDIFF = WDiff<3>::N;
+    constexpr int NPG = ACTIVE ? 2 : 1;   // gradient planes grad_x reads
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char *tile = smem + 64;
+
+    const uint32_t bid = (blockIdx.x & 7u) * p.steps_per_xcd + (blockIdx.x >> 3);  // XCD-contiguous step ids
+    if (bid >= p.total_steps) return;
+    const uint32_t plane = fdiv(bid, p.d_spp);   // (n, c)
+    const uint32_t vstep = bid - plane * static_cast<uint32_t>(p.spp);
+    const int a = static_cast<int>(fdiv(vstep, p.d_rsteps));   // the plane of grad_x
+    const int step = static_cast<int>(vstep) - a * p.rsteps;
+    const int c = static_cast<int>(plane - fdiv(plane, p.d_C) * static_cast<uint32_t>(p.C));
+    const ChanDesc d = p.desc[c];
+    const int R = p.R, S0 = p.S0, S1 = p.S1, S2 = p.S2, O0 = p.O0, O1 = p.O1, O2 = p.O2, L0 = p.L0, L1 = p.L1, L2 = p.L2, cpr = p.cpr;
+    const int b0 = step * R;
+    const int Rn = min(R, S1 - b0);
+    // tile: x corner rows [2 planes][R + 1][cpr pieces] | grad_out at the step's own rows [R][cpr + 2] | the rows grad_x reads [NPG][R + 1][cpr + 2]
+    const int RBX = cpr * 16, PG = cpr + 2, RBG = PG * 16;
+    const int goff = 2 * (R + 1) * RBX, gsoff = goff + R * RBG;
+    const S *xp = static_cast<const S *>(p.x) + static_cast<int64_t>(plane) * p.x_plane;
+    const S *gp = static_cast<const S *>(p.go) + static_cast<int64_t>(plane) * p.g_plane;
+    S *gxp = static_cast<S *>(p.out) + static_cast<int64_t>(plane) * p.x_plane + static_cast<int64_t>(a) * S1 * S2;
+    const int gph = static_cast<int>((static_cast<uint64_t>(plane) * static_cast<uint64_t>(p.g_plane) * ES) & 15u);
+    const char *gp16 = reinterpret_cast<const char *>(gp) - gph;
+    // the planes (uniform): input corners m0[a], m0[a + 1]; the window's plane of this step; the gradient planes grad_x reads
+    int pax[2], pag[NPG];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) pax[h] = row_map_t<PAD>(a + h, d.cx0, S0, p.pad);
+    const int ao = a - L0;
+    const bool in_vol = ao >= 0 && ao < O0;   // (a plane outside the window: zero gradient, nothing counted)
+#pragma unroll
+    for (int h = 0; h < NPG; ++h) pag[h] = (in_vol && ao + h <= O0) ? row_map_t<PAD>(ao + h, d.cg0, O0, p.pad) : -1;
+
+    const int tid = static_cast<int>(threadIdx.x);
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tr = static_cast<int>(fdiv(static_cast<uint32_t>(tid), p.d_seg)), tc = tid - tr * cpr;
+    const int ji = tc * E;
+    auto dma_x = [&](int pl, int src_row, int col_piece, int lds_piece0) {
+        const uint32_t off = static_cast<uint32_t>((pl * S1 + src_row) * S2 + col_piece * E) * static_cast<uint32_t>(ES);
+        char *dst_wave = tile + (lds_piece0 + wave * 64) * 16;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(reinterpret_cast<const char *>(xp) + off),
+                                         (__attribute__((address_space(3))) void *)dst_wave, 16, 0, 0);
+    };
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        if (pax[h] < 0) continue;   // (uniform)
+        if (tr < R) {
+            const int sx = tr <= Rn ? row_map_t<PAD>(b0 + tr, d.cx1, S1, p.pad) : -1;
+            if (sx >= 0) dma_x(pax[h], sx, tc, h * (R + 1) * cpr);
+        }
+        if (Rn == R && tid < cpr) {
+            const int sx = row_map_t<PAD>(b0 + R, d.cx1, S1, p.pad);
+            if (sx >= 0) dma_x(pax[h], sx, tid, (h * (R + 1) + R) * cpr);
+        }
+    }
+    // gradient rows as covers: row `vr` of the window VOLUME (plane * O1 + row) starts vrow_lo(vr) bytes into the stream of pieces
+    auto vrow_lo = [&](int vr) { return gph + vr * O2 * ES; };
+    auto gphase = [&](int vr) { return vrow_lo(vr) & 15; };
+    const int PGi = cpr + 2;
+    const int rg = static_cast<int>(fdiv(static_cast<uint32_t>(tid), p.d_P)), pg = tid - rg * PGi;
+    auto dma_g = [&](int vr, int piece, int lds_piece0) {
+        const int lo = vrow_lo(vr), p0 = lo >> 4, cnt = ((lo + O2 * ES + 15) >> 4) - p0;
+        if (vr >= 0 && piece < cnt) {
+            char *dst_wave = tile + (lds_piece0 + wave * 64) * 16;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(gp16 + static_cast<uint32_t>(p0 + piece) * 16u),
+                                             (__attribute__((address_space(3))) void *)dst_wave, 16, 0, 0);
+        }
+    };
+    auto gs_row = [&](int i, bool have) {   // the window row grad_x reads at step row i (through the row map), or -1
+        const int pr = b0 + i - L1;
+        const bool dom = have && pr >= 0 && (ACTIVE ? pr <= O1 : pr < O1);
+        return dom ? row_map_t<PAD>(pr, d.cg1, O1, p.pad) : -1;
+    };
+    {
+        const int ro = (in_vol && rg < R && rg < Rn && b0 + rg - L1 >= 0 && b0 + rg - L1 < O1) ? ao * O1 + b0 + rg - L1 : -1;   // the step's own rows
+        dma_g(ro, pg, goff / 16);
+#pragma unroll
+        for (int h = 0; h < NPG; ++h) {
+            if (pag[h] < 0) continue;   // (uniform)
+            const int r0 = gs_row(rg, rg < R && (ACTIVE ? rg <= Rn : rg < Rn));
+            dma_g(r0 >= 0 ? pag[h] * O1 + r0 : -1, pg, gsoff / 16 + h * (R + 1) * PGi);
+            if constexpr (ACTIVE) {
+                if (Rn == R && tid < PGi) {   // the + 1 row of a full step
+                    const int r1 = gs_row(R, true);
+                    dma_g(r1 >= 0 ? pag[h] * O1 + r1 : -1, tid, gsoff / 16 + (h * (R + 1) + R) * PGi);
+                }
+            }
+        }
+    }
+    ColState<E> xm, gm;
+    {
+        auto affine_state = [&](int first, int len) {
+            ColState<E> st;
+            st.base = first;
+            if (first + E < 0 || first >= len) st.base = 0;
+            st.affine = true;
+#pragma unroll
+            for (int e = 0; e <= E; ++e) st.cm[e] = static_cast<unsigned>(first + e) < static_cast<unsigned>(len) ? first + e : -1;
+            return st;
+        };
+        if constexpr (PAD == 0) {
+            xm = affine_state(ji - d.cx2, S2);
+            gm = affine_state(ji - L2 - d.cg2, O2);
+        } else {
+            const size_t rec = (static_cast<size_t>(c) * cpr + (tr < R ? tc : 0)) * REC;
+            xm = load_colstate<E>(p.colx + rec);
+            gm = load_colstate<E>(p.colg + rec);
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    CT part[NDIFF];
+#pragma unroll
+    for (int i = 0; i < NDIFF; ++i) part[i] = CT(0);
+    if (tr < R && tr < Rn) {
+        const int b = b0 + tr;
+        const CT dw[3] = {static_cast<CT>(d.dw[0]), static_cast<CT>(d.dw[1]), static_cast<CT>(d.dw[2])};
+        const bool in_row = in_vol && b >= L1 && b < L1 + O1;
+        auto row_valid = [&](int pr, int cs, int len) { return PAD != 0 || row_map_t<PAD>(pr, cs, len, p.pad) >= 0; };
+        const S zero = static_cast<S>(0.0f);
+        auto read_row = [&](const char *row, bool valid, const ColState<E> &cst, S (&raw)[E + 1]) {
+            if constexpr (PAD == 0) lds_read_row_affine<S, E>(row, valid, cst, raw);
+            else lds_read_row<S, E>(row, valid, cst, raw);
+        };
+        bool inside[E];
+#pragma unroll
+        for (int e = 0; e < E; ++e) inside[e] = static_cast<unsigned>(ji + e - L2) < static_cast<unsigned>(in_row ? O2 : 0);
+        Chunk<S, E> res;
+        // ---- grad_x: corner k of an element: bit 0 = + 1 plane, bit 1 = + 1 row (the column corners share the E + 1 columns read) ----
+        if constexpr (ACTIVE) {
+            CT gv[4][E + 1];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int ha = k & 1, hb = k >> 1;
+                const int pr = b - L1 + hb;
+                const bool dom = in_row && pr <= O1 && pag[ha] >= 0;
+                const int srow = dom ? row_map_t<PAD>(pr, d.cg1, O1, p.pad) : -1;
+                S raw[E + 1];
+                read_row(tile + gsoff + (ha * (R + 1) + tr + hb) * RBG + (srow >= 0 ? gphase(pag[ha] * O1 + srow) : 0), srow >= 0, gm, raw);
+#pragma unroll
+                for (int e = 0; e <= E; ++e) gv[k][e] = widen<T>(raw[e]);
+            }
+#pragma unroll
+            for (int e = 0; e < E; ++e) {
+                CT v[8];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) v[q] = gv[q & 3][e + (q >> 2)];
+                res.e[e] = inside[e] ? narrow<T>(interp_t<T, 3>(v, dw)) : zero;
+            }
+        } else {
+            const int srow = (in_row && pag[0] >= 0) ? row_map_t<PAD>(b - L1, d.cg1, O1, p.pad) : -1;
+            S raw[E + 1];
+            read_row(tile + gsoff + tr * RBG + (srow >= 0 ? gphase(pag[0] * O1 + srow) : 0), srow >= 0, gm, raw);
+#pragma unroll
+            for (int e = 0; e < E; ++e) res.e[e] = inside[e] ? raw[e] : zero;
+        }
+        // ---- weight-gradient sums: the eight corners of x against grad_out at the chunk's own position (0 outside the window) -------
+        CT xv[4][E + 1];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int ha = k & 1, hb = k >> 1;
+            S raw[E + 1];
+            read_row(tile + (ha * (R + 1) + tr + hb) * RBX, pax[ha] >= 0 && row_valid(b + hb, d.cx1, S1), xm, raw);
+#pragma unroll
+            for (int e = 0; e <= E; ++e) xv[k][e] = widen<T>(raw[e]);
+        }
+        const S *grow = reinterpret_cast<const S *>(tile + goff + tr * RBG + (in_row ? gphase(ao * O1 + b - L1) : 0)) + (in_row ? ji - L2 : 0);
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+            CT v[8], df[NDIFF];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) v[q] = xv[q & 3][e + (q >> 2)];
+            corner_diffs<3, CT>(v, df);
+            const S graw = grow[e];
+            const CT gval = widen<T>(inside[e] ? graw : zero);
+#pragma unroll
+            for (int i = 0; i < NDIFF; ++i) part[i] = fma_ct(gval, df[i], part[i]);
+        }
+        store_chunk<S, E>(gxp + static_cast<int64_t>(b) * S2 + ji, res);
+    }
+    // ---- this step's sums: DPP tree per wave, the four waves added in fp64 by the first NDIFF threads -----------------------------
+    double *scratch = reinterpret_cast<double *>(tile + ((gsoff + NPG * (R + 1) * RBG + 63) & ~63) + 64);
 #pragma unroll
     for (int i = 0; i < NDIFF; ++i) {
         const CT t = wave_total(part[i]);
@@ -1010,7 +1232,7 @@ SpanPlan span_plan(const Geometry &g, int es) {
     s.nseg = (s.cpr + s.seg - 1) / s.seg;
     s.P = s.seg + 2;
     // rows per step: R * seg threads, and the tile's (3 R + 2) slots of P pieces within the staging rounds
-    int R = std::max(1, g.nd == 2 ? kThreads / (s.seg + 2) : kThreads / s.seg);   // (2-D: R covers of cpr + 2 pieces per staging pass)
+    int R = std::max(1, g.nd >= 2 ? kThreads / (s.seg + 2) : kThreads / s.seg);   // (2-D / 3-D: R covers of cpr + 2 pieces per staging pass)
     R = std::max(1, std::min<int>(R, static_cast<int>(g.S[1])));
     if (g.nd == 1 || s.nseg > 1) R = 1;
     s.R = R;
@@ -1019,7 +1241,7 @@ SpanPlan span_plan(const Geometry &g, int es) {
     // (N512 C16 64x64: 0.068 -> 0.064 ms; N64 C256 224x224: 1.598 -> 1.616, so not there).  4- and 2-byte elements (fp64 keeps one).
     // Knob 35 bit 7: one for the sparse shift everywhere, bit 8: two everywhere.  Geometry and knobs only: the workspace is planned from the
     // same answer.
-    s.U = 1;
+    s.U = 1;   // (3-D: one)
     if (g.nd == 2 && s.nseg == 1 && es <= 4) {
         // (ragged x rows, N512 C16 62x62 sparse: 0.072 -> 0.066 ms, N64 C256 222x222: 1.666 -> 1.668; the pooled interpolating form,
         //  N64 C256 224x224: 1.855 -> 1.668 ms -- the same rule for every form.  The interpolating shift has NO one-group instantiation
@@ -1030,8 +1252,8 @@ SpanPlan span_plan(const Geometry &g, int es) {
     }
     R *= s.U;   // rows per step
     s.rsteps = static_cast<int>((g.S[1] + R - 1) / R);
-    s.spp = s.rsteps * s.nseg;
-    s.ndiff = g.nd == 1 ? 1 : 2;
+    s.spp = s.rsteps * s.nseg * (g.nd == 3 ? static_cast<int>(g.S[0]) : 1);   // (3-D: the steps of a whole (n, c) volume)
+    s.ndiff = g.nd == 1 ? 1 : (g.nd == 2 ? 2 : 8);
     s.rec = (E + 3 <= 8) ? 8 : 16;
     s.total = static_cast<uint64_t>(g.N) * g.C * s.spp;
     auto up = [](size_t v) { return (v + 255) & ~static_cast<size_t>(255); };
@@ -1039,7 +1261,10 @@ SpanPlan span_plan(const Geometry &g, int es) {
     s.off_colx = s.off_desc + up(static_cast<size_t>(g.C) * sizeof(ChanDesc));
     s.off_colg = s.off_colx + up(static_cast<size_t>(g.C) * s.cpr * s.rec * sizeof(int16_t));
     s.bytes = s.off_colg + up(static_cast<size_t>(g.C) * s.cpr * s.rec * sizeof(int16_t));
-    if (g.nd == 2) {   // crop_backward: x rows [R + 1][cpr] | own rows [R][cpr + 2] | read rows [R + 1][cpr + 2]
+    if (g.nd == 3) {   // crop_backward3: x rows [2][R + 1][cpr] | own rows [R][cpr + 2] | read rows [2][R + 1][cpr + 2]
+        const size_t tile = (static_cast<size_t>(2 * (R + 1)) * s.cpr + static_cast<size_t>(R + 2 * (R + 1)) * (s.cpr + 2)) * 16;
+        s.lds = 64 + ((tile + 63) & ~static_cast<size_t>(63)) + 64 + (kThreads / 64) * 8 * sizeof(double);
+    } else if (g.nd == 2) {   // crop_backward: x rows [R + 1][cpr] | own rows [R][cpr + 2] | read rows [R + 1][cpr + 2]
         const size_t tile = (static_cast<size_t>(R + 1) * (s.cpr + (xrag ? 2 : 0)) + static_cast<size_t>(2 * R + 1) * (s.cpr + 2)) * 16;
         s.lds = 64 + ((tile + 63) & ~static_cast<size_t>(63)) + 64 + (kThreads / 64) * 2 * sizeof(double);
     } else {   // row_backward: three spans of (256 + 3) pieces
@@ -1055,10 +1280,16 @@ bool span_geometry_ok(const Geometry &g, int dtype) { return span_geometry_ok(g,
 // pooled: crop_backward<.., POOL> -- 2-D, x rows of whole pieces, 2 x 2 windows, pooled rows of at least half a piece (g.K / g.P set; the
 // plan reads S, O, L only)
 static bool span_geometry_ok(const Geometry &g, int dtype, bool pooled) {
-    if (dtype > SHIFTND_BF16 || (g.nd != 1 && g.nd != 2) || (g.K[0] > 0) != pooled) return false;
+    if (dtype > SHIFTND_BF16 || g.nd < 1 || g.nd > 3 || (g.K[0] > 0) != pooled) return false;
     const int es = dtype_size(dtype);
     if (pooled && (g.nd != 2 || (g.S[2] * es) % 16 != 0 || g.K[1] != 2 || g.K[2] != 2 || g.P[2] < std::max(1, 8 / es))) return false;
-    if (g.S[0] != 1 || g.O[0] != 1 || g.S[1] < 1 || g.S[2] < 1 || g.O[1] < 1 || g.O[2] < 1) return false;
+    if (g.nd == 3) {   // crop_backward3: x rows of whole pieces, every dim of the volume and of the window at least 2
+        if (g.S[0] < 2 || g.S[1] < 2 || g.S[2] < 2 || g.O[0] < 2 || g.O[1] < 2 || g.O[2] < 2 || (g.S[2] * es) % 16 != 0) return false;
+        if (g.S[0] * g.S[1] * g.S[2] >= (1LL << 28) || g.O[0] * g.O[1] * g.O[2] >= (1LL << 28)) return false;   // 32-bit byte offsets within a volume
+    } else if (g.S[0] != 1 || g.O[0] != 1) {
+        return false;
+    }
+    if (g.S[1] < 1 || g.S[2] < 1 || g.O[1] < 1 || g.O[2] < 1) return false;
     // x rows: whole pieces -- or, 2-D with 4- / 8-byte elements, any length (crop_backward<.., XRAG>, round 5); int16 column tables
     // (2-byte elements: input AND gradient rows of an even number of elements -- every row at a 4-byte boundary)
     const bool rag_ok = g.nd == 2 && (es >= 4 || (es == 2 && g.S[2] % 2 == 0 && g.O[2] % 2 == 0));
@@ -1066,7 +1297,7 @@ static bool span_geometry_ok(const Geometry &g, int dtype, bool pooled) {
     // (grad_out / x need not be a whole number of pieces: the last piece of a cover reaches at most 15 bytes past the tensor's
     //  end, inside the 16-byte granule -- hence the page -- of its last valid byte; those bytes are never used)
     if (g.S[1] * g.S[2] >= (1LL << 28) || g.O[1] * g.O[2] >= (1LL << 28)) return false;  // 32-bit byte offsets within a plane
-    if (g.nd == 2 && g.S[2] * es > (kThreads - 2) * 16) return false;   // crop_backward: a grad_out row's cover (cpr + 2 pieces) per staging pass
+    if (g.nd >= 2 && g.S[2] * es > (kThreads - 2) * 16) return false;   // crop_backward: a grad_out row's cover (cpr + 2 pieces) per staging pass
     const SpanPlan s = span_plan(g, es);
     return s.total + 8 < (1ull << 31) && s.lds <= 64 * 1024;
 }
@@ -1295,6 +1526,11 @@ bool span_backward_eligible(const Geometry &g, int dtype, const void *go, const 
     // (crop_backward<.., PAD = 0> reads every chunk through an affine column state; a window one column wide ignores the shift and
     //  is not one)
     if (g.nd == 2 && g.pad == 0 && g.O[2] == 1) return false;
+    if (g.nd == 3) {   // crop_backward3: cropped volumes only (the walk kernels take the others); knob 35 bit 10 keeps the plane kernels
+        bool crop3 = false;
+        for (int d = 0; d < 3; ++d) crop3 = crop3 || g.O[d] != g.S[d] || g.L[d] != 0;
+        return crop3 && !(g_step_tune[3] & 1024);
+    }
     if (g_step_tune[0] == 2) return true;
     const int es = dtype_size(dtype);
     if (g.nd == 1) return g.S[2] * es / 16 >= 128;   // (short rows: one row per workgroup would leave most lanes idle)
@@ -1331,6 +1567,8 @@ static void launch_span_backward(const SpanParams &p, const SpanPlan &sp, bool a
             else hipLaunchKernelGGL((crop_backward<T, ACT, PADV, XRAG, POOL, 1>), grid, block, sp.lds, st, p); \
         } else if constexpr (ND == 2) { \
             hipLaunchKernelGGL((crop_backward<T, ACT, PADV, XRAG, POOL>), grid, block, sp.lds, st, p); \
+        } else if constexpr (ND == 3) { \
+            hipLaunchKernelGGL((crop_backward3<T, ACT, PADV>), grid, block, sp.lds, st, p); \
         } else { \
             hipLaunchKernelGGL((row_backward<T, ACT, PADV>), grid, block, sp.lds, st, p); \
         } \
@@ -1371,8 +1609,11 @@ int span_backward(const Geometry &g, int dtype, const void *go, const void *x, c
     p.desc = reinterpret_cast<ChanDesc *>(ws + sp.off_desc);
     p.colx = reinterpret_cast<int16_t *>(ws + sp.off_colx);
     p.colg = reinterpret_cast<int16_t *>(ws + sp.off_colg);
-    p.x_plane = g.S[1] * g.S[2];
-    p.g_plane = g.O[1] * g.O[2];
+    p.x_plane = g.S[0] * g.S[1] * g.S[2];   // (2-D: S0 = O0 = 1)
+    p.g_plane = g.O[0] * g.O[1] * g.O[2];
+    p.S0 = static_cast<int>(g.S[0]);
+    p.O0 = static_cast<int>(g.O[0]);
+    p.L0 = static_cast<int>(g.L[0]);
     const bool pooled = g.K[0] > 0;
     if (pooled) {   // `go` is the gradient of the pooled window [P1, P2]
         p.P2 = static_cast<int>(g.P[2]);
@@ -1407,7 +1648,20 @@ int span_backward(const Geometry &g, int dtype, const void *go, const void *x, c
     p.d_per2x = make_fastdiv(static_cast<uint32_t>(map_period(p.S2, g.pad)));
     p.d_per1g = make_fastdiv(static_cast<uint32_t>(map_period(p.O1, g.pad)));
     p.d_per2g = make_fastdiv(static_cast<uint32_t>(map_period(p.O2, g.pad)));
+    p.d_rsteps = make_fastdiv(static_cast<uint32_t>(sp.rsteps));
+    p.d_per0x = make_fastdiv(static_cast<uint32_t>(map_period(p.S0, g.pad)));
+    p.d_per0g = make_fastdiv(static_cast<uint32_t>(map_period(p.O0, g.pad)));
     const bool active = g.active != 0;
+    if (g.nd == 3) {
+        note_kernel("crop_backward3");
+        switch (dtype) {
+        case SHIFTND_F64: launch_span_backward<f64_t, 3>(p, sp, active, gw, st); break;
+        case SHIFTND_F32: launch_span_backward<f32_t, 3>(p, sp, active, gw, st); break;
+        case SHIFTND_F16: launch_span_backward<f16_t, 3>(p, sp, active, gw, st); break;
+        default: launch_span_backward<bf16_t, 3>(p, sp, active, gw, st); break;
+        }
+        return SHIFTND_OK;
+    }
     if (pooled) {
         note_kernel("crop_backward_pool");
         switch (dtype) {

@@ -263,3 +263,52 @@ def test_ragged_rows_forward_vs_oracle(abi, shape, crop, dt):
                 assert torch.equal(out.cpu(), ref), (shape, crop, dt, pad, active)
             else:
                 assert _ulp_close(out.cpu(), ref, tdt), (shape, crop, dt, pad, active)
+
+
+# round 6 -- crop_backward3: cropped 3-D volumes (Shift3d behind emulate_dw with padding < kernel / 2: cut 1 / 1 per dim), x rows of
+# whole 16-byte pieces: symmetric and one-sided cuts, a cut in the planes only / in the rows only, several steps per plane, the
+# ragged last step, shifts beyond the volume (the weights of _weights), windows of two planes
+CASES_3D = [((2, 3, 5, 6, 8), [[1, 1], [1, 1], [1, 1]]), ((1, 4, 4, 9, 16), [[0, 1], [2, 0], [1, 2]]), ((2, 2, 6, 7, 32), [[2, 2], [0, 0], [0, 0]]),
+            ((1, 2, 3, 70, 16), [[0, 0], [1, 1], [0, 0]]), ((1, 3, 8, 5, 24), [[3, 3], [1, 2], [5, 6]]), ((2, 2, 4, 12, 64), [[1, 0], [0, 3], [7, 9]]),
+            ((1, 2, 16, 20, 112), [[1, 1], [1, 1], [1, 1]])]
+
+
+@pytest.mark.parametrize("dt", ["f32", "f64", "f16", "bf16"])
+@pytest.mark.parametrize("shape,crop", CASES_3D)
+def test_cropped_3d_backward_vs_oracle(abi, shape, crop, dt):
+    tdt = {"f32": torch.float32, "f64": torch.float64, "f16": torch.float16, "bf16": torch.bfloat16}[dt]
+    es = torch.empty(0, dtype=tdt).element_size()
+    b, new = abi.check_borders(list(shape), crop, 3)
+    rs = np.random.RandomState(sum(shape) * 17 + 1)
+    xt = torch.from_numpy(rs.uniform(-1, 1, size=shape)).to(tdt)
+    gt = torch.from_numpy(rs.uniform(-1, 1, size=new)).to(tdt)
+    wt = torch.from_numpy(_weights(rs, shape[1], 3, shape[2:])).to(tdt)
+    wide = np.float64 if tdt == torch.float64 else np.float32
+    x, go, w = (t.to(torch.float64).numpy().astype(wide) for t in (xt, gt, wt))
+    xd, god, wd = xt.to(DEV), gt.to(DEV), wt.to(DEV)
+    served = (shape[-1] * es) % 16 == 0 and min(shape[2:]) >= 2 and min(new[2:]) >= 2
+    for pad in range(5):
+        for active in (0, 1):
+            gx, gw = abi.backward(god, wd, xd, pad, active, b)
+            if served:
+                assert abi.last_kernel() == "crop_backward3", (shape, crop, pad, abi.last_kernel())
+            gx_ref = torch.from_numpy(O.backward(go, w, x, pad, active, b)[0]).to(tdt)
+            if es >= 4 or not active:
+                assert torch.equal(gx.cpu(), gx_ref), ("gx", shape, crop, dt, pad, active)
+            else:
+                assert _ulp_close(gx.cpu(), gx_ref, tdt), ("gx", shape, crop, dt, pad, active)
+            _, gw64 = O.backward(go.astype(np.float64), w.astype(np.float64), x.astype(np.float64), pad, active, b)
+            tol = {"f32": 1e-5, "f64": 1e-12}.get(dt, gw16_tol(torch.finfo(tdt).eps))
+            if dt == "f32":   # (as above: never looser than the reference's own fp32 evaluation on the same data)
+                own = 2 * rel_err(O.backward(go, w, x, pad, active, b)[1], gw64)
+                if own > tol:
+                    print("relaxed grad_w bar", shape, crop, pad, active, "%.3g" % own)
+                    tol = own
+            assert rel_err(gw.to(torch.float64).cpu().numpy(), gw64) < tol, ("gw", shape, crop, dt, pad, active)
+            gx2, gw2 = abi.backward(god, wd, xd, pad, active, b)
+            assert torch.equal(gx, gx2) and torch.equal(gw, gw2)  # deterministic
+            # the plane kernels it replaces give the same grad_x (knob 35 bit 10)
+            abi.set_tuning(35, 1024)
+            gx3, _ = abi.backward(god, wd, xd, pad, active, b)
+            abi.set_tuning(35, 0)
+            assert abi.last_kernel() != "crop_backward3" and torch.equal(gx3, gx), (shape, crop, dt, pad, active)

@@ -312,3 +312,42 @@ def test_cropped_3d_backward_vs_oracle(abi, shape, crop, dt):
             gx3, _ = abi.backward(god, wd, xd, pad, active, b)
             abi.set_tuning(35, 0)
             assert abi.last_kernel() != "crop_backward3" and torch.equal(gx3, gx), (shape, crop, dt, pad, active)
+
+
+@pytest.mark.parametrize("dt", ["f32", "f64", "f16", "bf16"])
+@pytest.mark.parametrize("shape,crop", CASES_3D)
+def test_cropped_3d_forward_vs_oracle(abi, shape, crop, dt):
+    """crop_forward3 (round 6): the forward of the same cropped volumes, both shifts, every padding, against the oracle"""
+    tdt = {"f32": torch.float32, "f64": torch.float64, "f16": torch.float16, "bf16": torch.bfloat16}[dt]
+    es = torch.empty(0, dtype=tdt).element_size()
+    b, new = abi.check_borders(list(shape), crop, 3)
+    rs = np.random.RandomState(sum(shape) * 19 + 7)
+    xt = torch.from_numpy(rs.uniform(-1, 1, size=shape)).to(tdt)
+    wt = torch.from_numpy(_weights(rs, shape[1], 3, shape[2:])).to(tdt)
+    wide = np.float64 if tdt == torch.float64 else np.float32
+    x, w = (t.to(torch.float64).numpy().astype(wide) for t in (xt, wt))
+    xd, wd = xt.to(DEV), wt.to(DEV)
+    # served: source rows of whole pieces, dims of at least 2, 16-bit windows of an even width; output rows that ARE whole pieces at
+    # the sources' own columns may go to the aligned one-step forwards instead (asked first)
+    served = (shape[-1] * es) % 16 == 0 and min(shape[2:]) >= 2 and min(new[2:]) >= 2 and (es != 2 or new[-1] % 2 == 0)
+    hit = 0
+    for pad in range(5):
+        for active in (0, 1):
+            out = abi.forward(xd, wd, pad, active, b)
+            name = abi.last_kernel()
+            if served and (new[-1] * es) % 16 != 0:
+                assert name == ("crop_active_forward3" if active else "crop_gather_forward3"), (shape, crop, pad, active, name)
+            hit += name.endswith("forward3")
+            ref = torch.from_numpy(O.forward(x, w, pad, active, b)).to(tdt)
+            if es >= 4 or not active:
+                assert torch.equal(out.cpu(), ref), (shape, crop, dt, pad, active, name)
+            else:
+                assert _ulp_close(out.cpu(), ref, tdt), (shape, crop, dt, pad, active, name)
+            abi.set_tuning(35, 1024)   # the kernels it replaces give the same bits
+            out2 = abi.forward(xd, wd, pad, active, b)
+            abi.set_tuning(35, 0)
+            assert not abi.last_kernel().endswith("forward3")
+            if es >= 4 or not active:
+                assert torch.equal(out2, out), (shape, crop, dt, pad, active)
+    if served and (new[-1] * es) % 16 != 0:
+        assert hit == 10

@@ -94,6 +94,9 @@ WORKLOADS = {
     "c4pool": (2, (128, 512, 56, 56), "quint8", False, "quantized Shift2d + avg_pool 2 forward N128 C512 56x56 quint8, cut [[1,1],[1,1]] (emulate_dw k3 s2 p0)"),
 }
 
+# (c3crop: BASELINE config 3's tensor behind emulate_dw {kernel 3, stride 1, padding 0} -- the cut without the pool; c3pool: with stride 2)
+WORKLOADS["c3crop"] = (3, (8, 128, 16, 112, 112), "bfloat16", True, "Shift3d active fwd+bwd N8 C128 16x112x112 bf16, cut 1/1 per dim (output 14x110x110)")
+
 # fused shift + average pool workloads: the pool's kernel = stride
 POOLS = {"c2pool": 2, "c3pool": 2, "c4pool": 2}
 
@@ -105,14 +108,14 @@ CHANNELS_LAST = {"cl2d", "cl2da", "cl3d", "cl3da", "cl3dh"}
 EXTRA_CONFIGS = ([("c2_pad%d" % p, "c2", p) for p in (1, 2, 3, 4)] + [("c3_pad%d" % p, "c3", p) for p in range(5)] +
                  [("c4", "c4", 0), ("c5", "c5", 0)] +
                  [(n, n, 0) for n in ("c2a", "c2crop", "c2acrop", "t1", "t1a", "c1d", "r14", "r14a", "r62", "r222", "cl2d", "cl2da", "cl3d", "cl3da",
-                                      "c2pool", "c3pool", "c4pool")])
+                                      "c2pool", "c3pool", "c4pool", "c3crop")])
 BASELINE_CONFIGS = [c[0] for c in EXTRA_CONFIGS[:11]]  # what BASELINE.json's `configs` list beyond the headline
 HEADLINE_MAX_BYTES = 4000  # the RESULT line is the last line of stdout and fits a small tail (round-5 verdict: a 24 KB line was lost)
 ESIZE = {"float32": 4, "bfloat16": 2, "float16": 2, "quint8": 1}
 
 # user `borders` of the cropped workloads ([nD, 2] cut-left / cut-right amounts, functional.py:22,32-35)
 CUTS = {"c2crop": [[1, 1], [1, 1]], "c2acrop": [[1, 1], [1, 1]], "t1": [[1, 1], [1, 1]], "t1a": [[1, 1], [1, 1]],
-        "c2pool": [[1, 1], [1, 1]], "c3pool": [[1, 1], [1, 1], [1, 1]], "c4pool": [[1, 1], [1, 1]]}
+        "c2pool": [[1, 1], [1, 1]], "c3pool": [[1, 1], [1, 1], [1, 1]], "c4pool": [[1, 1], [1, 1]], "c3crop": [[1, 1], [1, 1], [1, 1]]}
 
 
 def shard_range(n, rank, world):

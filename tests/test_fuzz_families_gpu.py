@@ -28,6 +28,6 @@ def test_random_cases_against_the_oracle(seed):
         F.CASES[n % len(F.CASES)](rs)
     kernels = set(F.count)
     for must in ("cl_tiled_backward", "step_backward", "step_gather_forward", "walk_forward", "walk_backward", "walk_backward16", "walk_backward_pool",
-                 "crop_backward", "cl_tiled_backward/crop", "cl_tiled_forward_3d"):
+                 "crop_backward", "cl_tiled_backward/crop", "cl_tiled_forward_3d", "crop_backward3", "crop_active_forward3"):
         assert must in kernels, (must, dict(F.count))
     assert any(k.startswith(("small_", "band_")) for k in kernels), dict(F.count)

@@ -461,6 +461,41 @@ def case_ragged3d(rs):
 CASES += [case_ragged3d, case_ragged3d]
 
 
+def case_crop3d(rs):
+    """round 6: cropped 3-D volumes through crop_forward3 / crop_backward3 -- x rows of whole 16-byte pieces, every float dtype, every
+    padding, both shifts, random asymmetric cuts per dim (shifts beyond the volume included)"""
+    tdt = [torch.float32, torch.float64, torch.float16, torch.bfloat16][rs.randint(4)]
+    es = torch.empty(0, dtype=tdt).element_size()
+    per16 = 16 // es
+    sp = (int(rs.choice([2, 3, 5, 8, 16])), int(rs.choice([2, 5, 9, 18, 37, 70])), per16 * int(rs.choice([1, 2, 3, 7, 14, 28, 56])))
+    N, C = int(rs.randint(1, 3)), int(rs.randint(1, 5))
+    shape = (N, C) + sp
+    crop = _random_crop(rs, sp)
+    b, new = abi.check_borders(list(shape), crop, 3)
+    pad = int(rs.randint(0, 5)); active = int(rs.randint(0, 2))
+    xt = torch.from_numpy(rs.uniform(-1, 1, size=shape)).to(tdt); gt = torch.from_numpy(rs.uniform(-1, 1, size=new)).to(tdt)
+    wt = torch.from_numpy(weights(rs, C, 3, sp, 4.5)).to(tdt)
+    wide = np.float64 if tdt == torch.float64 else np.float32
+    x, go, w = (t.to(torch.float64).numpy().astype(wide) for t in (xt, gt, wt))
+    xd, gd, wd = xt.to(DEV), gt.to(DEV), wt.to(DEV)
+    exact = tdt in (torch.float32, torch.float64) or not active
+    o = abi.forward(xd, wd, pad, active, b)
+    count[abi.last_kernel()] += 1
+    _check_float(("crop3 fwd", shape, crop, tdt, pad, active, abi.last_kernel()), tdt, o, O.forward(x, w, pad, active, b), exact, 32 * 2.0 ** -24)
+    gx, gw = abi.backward(gd, wd, xd, pad, active, b)
+    count[abi.last_kernel()] += 1
+    _check_float(("crop3 gx", shape, crop, tdt, pad, active, abi.last_kernel()), tdt, gx, O.backward(go, w, x, pad, active, b)[0], exact, 32 * 2.0 ** -24)
+    _, gw64 = O.backward(go.astype(np.float64), w.astype(np.float64), x.astype(np.float64), pad, active, b)
+    tol = {torch.float64: 1e-12, torch.float32: 1e-5}.get(tdt, 0.51 * float(torch.finfo(tdt).eps))
+    if tdt == torch.float32:
+        tol = max(tol, 2 * rel_err(O.backward(go, w, x, pad, active, b)[1], gw64))
+    e = rel_err(gw.to(torch.float64).cpu().numpy(), gw64)
+    assert e < tol, ("crop3 gw", shape, crop, tdt, pad, active, abi.last_kernel(), e)
+
+
+CASES += [case_crop3d, case_crop3d]
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--seconds", type=float, default=120)

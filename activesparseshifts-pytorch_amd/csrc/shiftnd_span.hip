@@ -1567,10 +1567,8 @@ int span_forward(const Geometry &g, int dtype, const void *x, const void *w, int
         case 2: hipLaunchKernelGGL((crop_forward3<TT, ACT, 2>), grid, block, lds, st, p); break; \
         default: hipLaunchKernelGGL((crop_forward3<TT, ACT, kPadMirror>), grid, block, lds, st, p); break; \
         }
-        // (the sparse shift is a raw copy, but the WEIGHTS are read in the tensor's dtype: one instantiation per dtype all the same)
-        if (!act) {
-            if (dtype == SHIFTND_F32) { SHIFTND_CROP3_FWD(f32_t, false) } else if (dtype == SHIFTND_F64) { SHIFTND_CROP3_FWD(f64_t, false)
-            } else if (dtype == SHIFTND_F16) { SHIFTND_CROP3_FWD(f16_t, false) } else { SHIFTND_CROP3_FWD(bf16_t, false) }
+        if (!act) {   // a raw copy (the weights are widened by their own dtype, p.wkind): one instantiation per element size
+            if (es == 2) { SHIFTND_CROP3_FWD(f16_t, false) } else if (es == 4) { SHIFTND_CROP3_FWD(f32_t, false) } else { SHIFTND_CROP3_FWD(f64_t, false) }
         } else if (dtype == SHIFTND_F32) { SHIFTND_CROP3_FWD(f32_t, true)
         } else if (dtype == SHIFTND_F64) { SHIFTND_CROP3_FWD(f64_t, true)
         } else if (dtype == SHIFTND_F16) { SHIFTND_CROP3_FWD(f16_t, true)

@@ -660,6 +660,19 @@ static int backward_pooled_planned(const shiftnd_problem *p, const int32_t *pool
     // step would be expanded from pooled rows -- measured slower than avg_pool backward + shiftnd_backward (N8 C128 16x112x112:
     // 1.42 vs 1.33 ms fp32, 1.32 vs 0.96 ms bf16), so it is not fused unless the plane-kernel policy is forced (tests)
     if (g.nd == 3 && g.active && g_policy != 2) return SHIFTND_ERR_NOT_FUSED;
+    // (round 6) a cropped 3-D volume that crop_backward3 serves: the band-walk kernels with the pool fused are SLOWER than the average
+    // pool's backward followed by crop_backward3 (N8 C128 16x56x56 cut 1/1/1 pool 2, sparse: bf16 0.32 vs 0.10 + the pool, fp32 0.33 vs
+    // 0.17 + the pool; tools/module_matrix.py) -- not fused, the op composes the two
+    if (g.nd == 3 && g_policy == 0) {
+        Geometry u = g;   // the unpooled problem: gradient of the window, dense
+        for (int d = 0; d < 3; ++d) u.K[d] = 0, u.P[d] = 0;
+        u.os[4] = 1;
+        u.os[3] = u.O[2];
+        u.os[2] = u.O[2] * u.O[1];
+        u.os[1] = u.O[2] * u.O[1] * u.O[0];
+        u.os[0] = u.os[1] * u.C;
+        if (span_backward_eligible(u, p->dtype, x, x, grad_x)) return SHIFTND_ERR_NOT_FUSED;   // (the gradient will be a fresh, aligned tensor)
+    }
     if (plane_backward_workspace(g, p->dtype) > workspace_bytes) return SHIFTND_ERR_WORKSPACE_TOO_SMALL;
     g_last_path = SHIFTND_PATH_PLANE;
     return finish(plane_pool_backward(g, p->dtype, grad_pooled, x, weights, grad_x, grad_w, workspace, st));

@@ -971,13 +971,16 @@ __global__ __launch_bounds__(kThreads) void ragged_forward(const SpanFwdParams p
 // (the window's rows start anywhere; 16-bit elements: rows of an even number of elements, every row at a 4-byte boundary).
 // Reference: kernels/shifts_kernels.h:156-220 with the window of ops/shifts.cpp:93-135; weights cuda/shifts_cuda.cu:168-183.
 // ---------------------------------------------------------------------------------------------------------------------
-template <typename T, bool ACTIVE, int PAD>
+// ND = 2: the same kernel for cropped 2-D windows whose output PLANES are not whole 16-byte pieces -- crop_forward's flat chunk stream
+// needs them to be; 110 x 110 bf16 (N32 C256 112x112 cut 1/1) ran plane_gather_forward at 2.4 TB/s, the interpolating shift the
+// flat-stream kernels at 3.4 -- one source plane, two weights, interp_t<T, 2>.
+template <typename T, bool ACTIVE, int PAD, int ND = 3>
 __global__ __launch_bounds__(kThreads) void crop_forward3(const SpanFwdParams p) {
     using S = typename T::S;
     using CT = typename T::C;
     constexpr int ES = sizeof(S);
     constexpr int E = 16 / ES;
-    constexpr int NP = ACTIVE ? 2 : 1;   // source planes of a step
+    constexpr int NP = (ACTIVE && ND == 3) ? 2 : 1;   // source planes of a step
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char *tile = smem + 64;
 
@@ -988,10 +991,12 @@ __global__ __launch_bounds__(kThreads) void crop_forward3(const SpanFwdParams p)
     const int ao = static_cast<int>(fdiv(vstep, p.d_rsteps));   // the output plane
     const int step = static_cast<int>(vstep) - ao * p.rsteps;
     const int c = static_cast<int>(plane - fdiv(plane, p.d_C) * static_cast<uint32_t>(p.C));
-    CT wv[3];
-    {
+    CT wv[3] = {CT(0), CT(0), CT(0)};   // the weights of the plane, row and column dims
+    if constexpr (ND == 3) {
         const int wcol[3] = {0, 1, 2};
         load_weights3<CT>(p.w, p.wkind, static_cast<int64_t>(c) * 3, wcol, wv);
+    } else {
+        load_weights2<CT>(p.w, p.wkind, c, wv[1], wv[2]);
     }
     CT rr[3], dw[3];
 #pragma unroll
@@ -1001,7 +1006,7 @@ __global__ __launch_bounds__(kThreads) void crop_forward3(const SpanFwdParams p)
     }
     const int S0 = p.S0, S1 = p.S1, S2 = p.S2, O1 = p.O1, O2 = p.O2, L0 = p.L0, L1 = p.L1, L2 = p.L2;
     const int cpr = p.ocp, R = p.cps, PX = p.P;   // output chunks per row, rows per step, pieces per source row
-    const int cs0 = __builtin_amdgcn_readfirstlane(canon_of<PAD, CT>(rr[0], S0, p.d_per0, p.pad));
+    const int cs0 = ND == 3 ? __builtin_amdgcn_readfirstlane(canon_of<PAD, CT>(rr[0], S0, p.d_per0, p.pad)) : 0;
     const int cs1 = __builtin_amdgcn_readfirstlane(canon_of<PAD, CT>(rr[1], S1, p.d_per1, p.pad));
     const int cs2 = __builtin_amdgcn_readfirstlane(canon_of<PAD, CT>(rr[2], S2, p.d_per2, p.pad));
     const int b0 = step * R, Rn = min(R, O1 - b0);
@@ -1009,7 +1014,7 @@ __global__ __launch_bounds__(kThreads) void crop_forward3(const SpanFwdParams p)
     S *op = static_cast<S *>(p.out) + static_cast<int64_t>(plane) * p.o_plane + static_cast<int64_t>(ao) * O1 * O2;
     int pl[NP];   // source planes (uniform; -1: padding)
 #pragma unroll
-    for (int h = 0; h < NP; ++h) pl[h] = row_map_t<PAD>(ao + L0 + h, cs0, S0, p.pad);
+    for (int h = 0; h < NP; ++h) pl[h] = ND == 3 ? row_map_t<PAD>(ao + L0 + h, cs0, S0, p.pad) : 0;
     const int tid = static_cast<int>(threadIdx.x);
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int RBX = PX * 16, TP = (R + 1) * PX;   // bytes per staged row, pieces per staged plane
@@ -1056,7 +1061,7 @@ __global__ __launch_bounds__(kThreads) void crop_forward3(const SpanFwdParams p)
         else lds_read_row<S, E>(row, valid, xm, raw);
     };
     Chunk<S, E> res;
-    if constexpr (ACTIVE) {
+    if constexpr (ACTIVE && ND == 3) {
         CT xv[4][E + 1];   // corner k: bit 0 = + 1 plane, bit 1 = + 1 row
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
@@ -1071,6 +1076,21 @@ __global__ __launch_bounds__(kThreads) void crop_forward3(const SpanFwdParams p)
 #pragma unroll
             for (int q = 0; q < 8; ++q) v[q] = xv[q & 3][e + (q >> 2)];
             res.e[e] = narrow<T>(interp_t<T, 3>(v, dw));
+        }
+    } else if constexpr (ACTIVE) {
+        CT xv[2][E + 1];
+#pragma unroll
+        for (int hb = 0; hb < 2; ++hb) {
+            S raw[E + 1];
+            read_row(0, tr + hb, raw);
+#pragma unroll
+            for (int e = 0; e <= E; ++e) xv[hb][e] = widen<T>(raw[e]);
+        }
+        const CT dw2[2] = {dw[1], dw[2]};
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+            const CT v[4] = {xv[0][e], xv[1][e], xv[0][e + 1], xv[1][e + 1]};
+            res.e[e] = narrow<T>(interp_t<T, 2>(v, dw2));
         }
     } else {
         S raw[E + 1];
@@ -1169,7 +1189,17 @@ __global__ __launch_bounds__(kThreads) void row_forward(const SpanFwdParams p) {
             res.e[e] = raw[e];
         }
     }
-    store_chunk<S, E>(op + j, res);
+    // (round 6) output rows that are not whole 16-byte pieces -- L4096 cut 1/1 fp32 ran the strided fallback, 4.1 ms against 0.7 --
+    // leave through element-aligned stores (rows at 4-byte boundaries: host), the row's last chunk element by element
+    if ((p.O2 * ES) % 16 == 0) {   // (uniform)
+        store_chunk<S, E>(op + j, res);
+    } else if (j + E <= p.O2) {
+        store_chunk_unaligned<S, E>(op + j, res);
+    } else {
+#pragma unroll
+        for (int e = 0; e < E; ++e)
+            if (j + e < p.O2) op[j + e] = res.e[e];
+    }
 }
 
 template <typename T, bool ACTIVE, int PAD>
@@ -1317,7 +1347,7 @@ SpanFwdPlan span_forward_plan(const Geometry &g, int es) {
     SpanFwdPlan s{};
     const int E = 16 / es;
     const int64_t oe = g.O[1] * g.O[2];
-    s.ocp = static_cast<int>(oe * es / 16);
+    s.ocp = static_cast<int>((oe * es + 15) / 16);   // (1-D: the last chunk of a ragged output row is partial; 2-D: whole pieces)
     // source rows a step can touch: the output rows of 256 chunks (+ the corner row)
     const int64_t rows = std::min<int64_t>(g.O[1], (static_cast<int64_t>(kThreads) * E + g.O[2] - 2) / g.O[2] + 1) + (g.active && g.nd == 2 ? 1 : 0);
     const int64_t cprx = (g.S[2] * es + 15) / 16 + 1;   // pieces that cover a (ragged) source row
@@ -1466,9 +1496,31 @@ static bool crop_forward3_ok(const Geometry &g, int dtype, const void *x, const 
     return g.N * g.C * g.O[0] * ((g.O[1] + rows - 1) / rows) + 8 < (1LL << 31);
 }
 
+// crop_forward3<.., ND = 2>: cropped 2-D windows whose output planes are not whole 16-byte pieces (crop_forward needs them to be), 2- and
+// 4-byte elements, source rows of whole pieces (at most 256), rows and columns of at least 2; 16-bit: output rows of an even number of
+// elements
+static bool crop_rows_forward_ok(const Geometry &g, int dtype, const void *x, const void *out) {
+    if (g.nd != 2 || dtype > SHIFTND_BF16 || dtype == SHIFTND_F64 || g.K[0] > 0 || (g_step_tune[3] & 1024)) return false;
+    const int es = dtype_size(dtype);
+    if (g.S[0] != 1 || g.O[0] != 1 || g.S[1] < 2 || g.S[2] < 2 || g.O[1] < 2 || g.O[2] < 2) return false;
+    bool crop = false;
+    for (int d = 1; d < 3; ++d) crop = crop || g.O[d] != g.S[d] || g.L[d] != 0;
+    if (!crop || (g.O[1] * g.O[2] * es) % 16 == 0) return false;   // (whole-piece planes: crop_forward)
+    if ((g.S[2] * es) % 16 != 0 || g.S[2] * es / 16 > kThreads || (es == 2 && g.O[2] % 2 != 0)) return false;
+    if (g.S[1] * g.S[2] >= (1LL << 28)) return false;
+    if (!dense(g.xs, g.N, g.C, g.S) || !dense(g.os, g.N, g.C, g.O)) return false;
+    if (reinterpret_cast<uintptr_t>(x) % 16 || reinterpret_cast<uintptr_t>(out) % 4) return false;
+    const int64_t xcpr = g.S[2] * es / 16, rows = std::max<int64_t>(1, std::min<int64_t>(g.O[1], kThreads / xcpr));
+    // (a step is `rows` output rows of ONE plane: planes too small to fill half a workgroup keep the flat-stream kernels, which pack
+    //  many planes into a step)
+    if (rows * ((g.O[2] * es + 15) / 16) < kThreads / 2) return false;
+    return g.N * g.C * ((g.O[1] + rows - 1) / rows) + 8 < (1LL << 31);
+}
+
 bool span_forward_eligible(const Geometry &g, int dtype, const void *x, const void *out) {
     if (g_step_tune[2] == 1) return false;   // knob 34 = 1: no forwards through LDS
     if (g.nd == 3) return crop_forward3_ok(g, dtype, x, out);
+    if (crop_rows_forward_ok(g, dtype, x, out)) return true;
     if (dtype > SHIFTND_BF16 || (g.nd != 1 && g.nd != 2) || g.K[0] > 0) return false;
     const int es = dtype_size(dtype);
     if (g.S[0] != 1 || g.O[0] != 1 || g.S[1] < 1 || g.S[2] < 1 || g.O[1] < 1 || g.O[2] < 1) return false;
@@ -1478,8 +1530,10 @@ bool span_forward_eligible(const Geometry &g, int dtype, const void *x, const vo
         const int64_t rows = std::min<int64_t>(g.O[1], kThreads / ((g.S[2] * es + 15) / 16 + 2));
         return g.N * g.C * ((g.O[1] + rows - 1) / rows) + 8 < (1LL << 31);
     }
-    if (g.nd == 1 && (g.S[2] * es) % 16 != 0) return false;   // row_forward: rows of whole pieces
-    if ((g.O[1] * g.O[2] * es) % 16 != 0 || (g.N * g.C * g.S[1] * g.S[2] * es) % 16 != 0) return false;
+    if (g.nd == 1 && (g.S[2] * es) % 16 != 0) return false;   // row_forward: SOURCE rows of whole pieces
+    // (1-D output rows of any length at a 4-byte boundary -- round 6; 2-D: output planes of whole pieces)
+    const bool ragged_row1 = g.nd == 1 && (g.O[2] * es) % 16 != 0 && (es >= 4 || g.O[2] % 2 == 0);
+    if (((g.O[1] * g.O[2] * es) % 16 != 0 && !ragged_row1) || (g.N * g.C * g.S[1] * g.S[2] * es) % 16 != 0) return false;
     if (g.S[1] * g.S[2] >= (1LL << 28) || g.O[1] * g.O[2] >= (1LL << 28)) return false;
     if (!dense(g.xs, g.N, g.C, g.S) || !dense(g.os, g.N, g.C, g.O)) return false;
     if (reinterpret_cast<uintptr_t>(x) % 16 || reinterpret_cast<uintptr_t>(out) % 16) return false;
@@ -1520,14 +1574,15 @@ static int crop_forward_groups(const Geometry &g, int es) {
 
 int span_forward(const Geometry &g, int dtype, const void *x, const void *w, int wkind, void *out, hipStream_t st) {
     const int es = dtype_size(dtype);
-    if (g.nd == 3) {   // crop_forward3
+    const bool rows2 = g.nd == 2 && crop_rows_forward_ok(g, dtype, x, out);
+    if (g.nd == 3 || rows2) {   // crop_forward3 (3-D volumes; 2-D windows whose planes are not whole pieces)
         SpanFwdParams p{};
         p.x = x;
         p.out = out;
         p.w = w;
         p.wkind = wkind;
         p.C = static_cast<int>(g.C);
-        p.nd = 3;
+        p.nd = g.nd;
         p.pad = g.pad;
         p.S0 = static_cast<int>(g.S[0]);
         p.S1 = static_cast<int>(g.S[1]);
@@ -1558,15 +1613,25 @@ int span_forward(const Geometry &g, int dtype, const void *x, const void *w, int
         p.d_per2 = make_fastdiv(static_cast<uint32_t>(map_period(p.S2, g.pad)));
         const bool act = g.active != 0;
         const size_t lds = 64 + static_cast<size_t>(act ? 2 : 1) * (p.cps + 1) * p.P * 16 + 64;
-        note_kernel(act ? "crop_active_forward3" : "crop_gather_forward3");
+        if (rows2) note_kernel(act ? "crop_active_forward_rows" : "crop_gather_forward_rows");
+        else note_kernel(act ? "crop_active_forward3" : "crop_gather_forward3");
         const dim3 grid(p.steps_per_xcd * 8), block(kThreads);
-#define SHIFTND_CROP3_FWD(TT, ACT) \
+#define SHIFTND_CROP3_FWD_ND(TT, ACT, NDV) \
         switch (pad_template(g.pad)) { \
-        case 0: hipLaunchKernelGGL((crop_forward3<TT, ACT, 0>), grid, block, lds, st, p); break; \
-        case 1: hipLaunchKernelGGL((crop_forward3<TT, ACT, 1>), grid, block, lds, st, p); break; \
-        case 2: hipLaunchKernelGGL((crop_forward3<TT, ACT, 2>), grid, block, lds, st, p); break; \
-        default: hipLaunchKernelGGL((crop_forward3<TT, ACT, kPadMirror>), grid, block, lds, st, p); break; \
+        case 0: hipLaunchKernelGGL((crop_forward3<TT, ACT, 0, NDV>), grid, block, lds, st, p); break; \
+        case 1: hipLaunchKernelGGL((crop_forward3<TT, ACT, 1, NDV>), grid, block, lds, st, p); break; \
+        case 2: hipLaunchKernelGGL((crop_forward3<TT, ACT, 2, NDV>), grid, block, lds, st, p); break; \
+        default: hipLaunchKernelGGL((crop_forward3<TT, ACT, kPadMirror, NDV>), grid, block, lds, st, p); break; \
         }
+        if (rows2) {   // 2- and 4-byte elements
+            if (!act) {
+                if (es == 2) { SHIFTND_CROP3_FWD_ND(f16_t, false, 2) } else { SHIFTND_CROP3_FWD_ND(f32_t, false, 2) }
+            } else if (dtype == SHIFTND_F32) { SHIFTND_CROP3_FWD_ND(f32_t, true, 2)
+            } else if (dtype == SHIFTND_F16) { SHIFTND_CROP3_FWD_ND(f16_t, true, 2)
+            } else { SHIFTND_CROP3_FWD_ND(bf16_t, true, 2) }
+            return SHIFTND_OK;
+        }
+#define SHIFTND_CROP3_FWD(TT, ACT) SHIFTND_CROP3_FWD_ND(TT, ACT, 3)
         if (!act) {   // a raw copy (the weights are widened by their own dtype, p.wkind): one instantiation per element size
             if (es == 2) { SHIFTND_CROP3_FWD(f16_t, false) } else if (es == 4) { SHIFTND_CROP3_FWD(f32_t, false) } else { SHIFTND_CROP3_FWD(f64_t, false) }
         } else if (dtype == SHIFTND_F32) { SHIFTND_CROP3_FWD(f32_t, true)
@@ -1574,6 +1639,7 @@ int span_forward(const Geometry &g, int dtype, const void *x, const void *w, int
         } else if (dtype == SHIFTND_F16) { SHIFTND_CROP3_FWD(f16_t, true)
         } else { SHIFTND_CROP3_FWD(bf16_t, true) }
 #undef SHIFTND_CROP3_FWD
+#undef SHIFTND_CROP3_FWD_ND
         return SHIFTND_OK;
     }
     if (ragged_forward_ok(g, es)) {

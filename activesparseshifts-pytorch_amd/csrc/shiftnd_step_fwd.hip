@@ -99,63 +99,94 @@ __global__ __launch_bounds__(kThreads) void step_gather_forward(const GatherPara
 // gathers the chunk of BOTH rows of a pooled row, sums each window in ATen's order (row, then column) in the compute type, divides
 // by the window size and stores E / 2 pooled elements -- the shift output never exists.  `out` is the pooled tensor [N, C, P1, P2];
 // p.O1 / p.O2 are the sizes of the (virtual) shift output, p.spp counts steps of R POOLED rows.
-template <typename T, int PAD>
+// ACTIVE (round 6): the interpolating shift -- three source rows (the two of the pooled row and the + 1 corner row) of E + 1 columns
+// per thread, the blends of interp_t<T, 2>, the shift's result rounded to the storage type like the two-step sequence, then the same
+// sums (the band-walk kernel ran it at 2 - 2.9 TB/s).
+template <typename T, int PAD, bool ACTIVE = false>
 __global__ __launch_bounds__(kThreads) void step_gather_forward_pool(const GatherParams p) {
     using S = typename T::S;
     using CT = typename T::C;
     constexpr int E = 16 / sizeof(S);
+    constexpr int NR = ACTIVE ? 3 : 2, NC = ACTIVE ? E + 1 : E;   // source rows / columns a thread reads
     const uint32_t bid = (blockIdx.x & 7u) * p.steps_per_xcd + (blockIdx.x >> 3);
     if (bid >= p.total_steps) return;
     const uint32_t plane = fdiv(bid, p.d_spp);
     const int step = static_cast<int>(bid - plane * static_cast<uint32_t>(p.spp));
     const int c = static_cast<int>(plane - fdiv(plane, p.d_C) * static_cast<uint32_t>(p.C));
     int cs1, cs2;
-    channel_shifts2<PAD>(p.w, p.wkind, p.wzp, c, p.S1, p.S2, p.d_per1, p.d_per2, cs1, cs2, p.pad);
+    CT dw[2] = {CT(0), CT(0)};
+    if constexpr (ACTIVE) {
+        CT wr, wc;
+        load_weights2<CT>(p.w, p.wkind, c, wr, wc);
+        const CT rr = c_floor<CT>(wr), rc = c_floor<CT>(wc);
+        dw[0] = wr - rr;
+        dw[1] = wc - rc;
+        cs1 = __builtin_amdgcn_readfirstlane(canon_of<PAD, CT>(rr, p.S1, p.d_per1, p.pad));
+        cs2 = __builtin_amdgcn_readfirstlane(canon_of<PAD, CT>(rc, p.S2, p.d_per2, p.pad));
+    } else {
+        channel_shifts2<PAD>(p.w, p.wkind, p.wzp, c, p.S1, p.S2, p.d_per1, p.d_per2, cs1, cs2, p.pad);
+    }
     const int tid = static_cast<int>(threadIdx.x);
     const int tr = static_cast<int>(fdiv(static_cast<uint32_t>(tid), p.d_cpr)), tc = tid - tr * p.cpr;
     const int P1 = (p.O1 + 1) >> 1, P2 = (p.O2 + 1) >> 1;   // (round 6: any window width -- a cropped 224 -> 222 is not whole pieces)
     const int pr = step * p.R + tr;   // pooled row
     if (tr >= p.R || pr >= P1) return;
     const int jo = tc * E;
-    int mm[E];
+    int mm[NC];
     bool contig = true;
 #pragma unroll
-    for (int e = 0; e < E; ++e) {
+    for (int e = 0; e < NC; ++e) {
         mm[e] = row_map_t<PAD>(jo + p.L2 + e, cs2, p.S2, p.pad);
-        contig = contig && (mm[e] == mm[0] + e);
+        contig = contig && (e >= E || mm[e] == mm[0] + e);   // (the first E columns: one 16-byte load; the corner column on its own)
     }
     contig = contig && mm[0] >= 0;
     const S *xp = static_cast<const S *>(p.x) + static_cast<int64_t>(plane) * p.x_plane;
     const int n1 = min(2, p.O1 - 2 * pr);   // rows of this window row (a ragged last one: 1)
     S zero;
     __builtin_memset(&zero, 0, sizeof(S));
-    Chunk<S, E> v[2];
+    S v[NR][NC];
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {
-        const int rb = h < n1 ? row_map_t<PAD>(2 * pr + h + p.L1, cs1, p.S1, p.pad) : -1;
+    for (int h = 0; h < NR; ++h) {
+        const int rb = h < n1 + (ACTIVE ? 1 : 0) ? row_map_t<PAD>(2 * pr + h + p.L1, cs1, p.S1, p.pad) : -1;
         if (rb < 0) {
 #pragma unroll
-            for (int e = 0; e < E; ++e) v[h].e[e] = zero;
+            for (int e = 0; e < NC; ++e) v[h][e] = zero;
         } else {
             const S *row = xp + rb * p.S2;
             if (contig) {
-                v[h] = load_chunk<S, E, true>(row + mm[0]);
+                const Chunk<S, E> ch = load_chunk<S, E, true>(row + mm[0]);
+#pragma unroll
+                for (int e = 0; e < E; ++e) v[h][e] = ch.e[e];
             } else {
 #pragma unroll
-                for (int e = 0; e < E; ++e) v[h].e[e] = mm[e] >= 0 ? __builtin_nontemporal_load(row + mm[e]) : zero;
+                for (int e = 0; e < E; ++e) v[h][e] = mm[e] >= 0 ? __builtin_nontemporal_load(row + mm[e]) : zero;
             }
+            if constexpr (ACTIVE) v[h][E] = mm[E] >= 0 ? row[mm[E]] : zero;
         }
     }
+    // the shift's output at the window's positions (interpolating: rounded to the storage type, as the unfused sequence stores it)
+    CT y[2][E];
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+            if constexpr (ACTIVE) {
+                const CT q[4] = {widen<T>(v[h][e]), widen<T>(v[h + 1][e]), widen<T>(v[h][e + 1]), widen<T>(v[h + 1][e + 1])};
+                y[h][e] = widen<T>(narrow<T>(interp_t<T, 2>(q, dw)));
+            } else {
+                y[h][e] = widen<T>(v[h][e]);
+            }
+        }
     Chunk<S, (E / 2 > 0 ? E / 2 : 1)> outc;
     // (sums in ATen's order: row, then column; a ragged last window -- an odd window width or height -- has one column / row)
 #pragma unroll
     for (int j = 0; j < E / 2; ++j) {
         const bool two = jo + 2 * j + 1 < p.O2;
-        CT acc = CT(0) + widen<T>(v[0].e[2 * j]);
-        if (two) acc = acc + widen<T>(v[0].e[2 * j + 1]);
+        CT acc = CT(0) + y[0][2 * j];
+        if (two) acc = acc + y[0][2 * j + 1];
         if (n1 == 2) {
-            acc = acc + widen<T>(v[1].e[2 * j]);
-            if (two) acc = acc + widen<T>(v[1].e[2 * j + 1]);
+            acc = acc + y[1][2 * j];
+            if (two) acc = acc + y[1][2 * j + 1];
         }
         outc.e[j] = narrow<T>(div_count<CT>(acc, n1 * (two ? 2 : 1)));
     }
@@ -622,7 +653,10 @@ bool step_forward_pooled_eligible(const Geometry &g, int dtype, const void *x, c
     if (g_step_tune[1] == 1) return false;
     // (round 6: 16-bit types too -- fp32 sums like ATen's, one rounding; knob 33 = 3 keeps them on the band-walk kernel)
     if (dtype != SHIFTND_F32 && dtype != SHIFTND_F64 && !((dtype == SHIFTND_F16 || dtype == SHIFTND_BF16) && g_step_tune[1] != 3)) return false;
-    if (g.nd != 2 || g.active || g.K[1] != 2 || g.K[2] != 2 || g.S[0] != 1 || g.O[0] != 1) return false;
+    if (g.nd != 2 || g.K[1] != 2 || g.K[2] != 2 || g.S[0] != 1 || g.O[0] != 1) return false;
+    // (round 6: the interpolating shift too -- 4- / 8-byte elements: N32 C256 112x112 fp32 0.183 -> 0.148 ms; bf16, whose element-aligned
+    //  16-byte loads are slow, 0.131 -> 0.163: those keep the band-walk kernel.  Knob 33 = 4: not)
+    if (g.active && (g_step_tune[1] == 4 || g.S[1] < 2 || g.S[2] < 2 || dtype_size(dtype) < 4)) return false;
     const int es = dtype_size(dtype);
     const int64_t xe = g.S[1] * g.S[2], oe = g.O[1] * g.O[2];
     if (xe < 1 || oe < 1 || xe >= (1LL << 30) || oe >= (1LL << 30)) return false;
@@ -666,17 +700,20 @@ int step_forward_pooled(const Geometry &g, int dtype, const void *x, const void 
     p.d_per2 = make_fastdiv(static_cast<uint32_t>(map_period(p.S2, g.pad)));
     const dim3 grid(p.steps_per_xcd * 8), block(kThreads);
     note_kernel("step_gather_forward_pool");
-#define SHIFTND_STEP_FWD_POOL(TT) \
+#define SHIFTND_STEP_FWD_POOL_A(TT, ACT) \
     switch (g.pad) { \
-    case 0: hipLaunchKernelGGL((step_gather_forward_pool<TT, 0>), grid, block, 0, st, p); break; \
-    case 1: hipLaunchKernelGGL((step_gather_forward_pool<TT, 1>), grid, block, 0, st, p); break; \
-    case 2: hipLaunchKernelGGL((step_gather_forward_pool<TT, 2>), grid, block, 0, st, p); break; \
-    default: hipLaunchKernelGGL((step_gather_forward_pool<TT, kPadMirror>), grid, block, 0, st, p); break; \
+    case 0: hipLaunchKernelGGL((step_gather_forward_pool<TT, 0, ACT>), grid, block, 0, st, p); break; \
+    case 1: hipLaunchKernelGGL((step_gather_forward_pool<TT, 1, ACT>), grid, block, 0, st, p); break; \
+    case 2: hipLaunchKernelGGL((step_gather_forward_pool<TT, 2, ACT>), grid, block, 0, st, p); break; \
+    default: hipLaunchKernelGGL((step_gather_forward_pool<TT, kPadMirror, ACT>), grid, block, 0, st, p); break; \
     }
+#define SHIFTND_STEP_FWD_POOL(TT) \
+    if (g.active) { SHIFTND_STEP_FWD_POOL_A(TT, true) } else { SHIFTND_STEP_FWD_POOL_A(TT, false) }
     if (dtype == SHIFTND_F32) { SHIFTND_STEP_FWD_POOL(f32_t) }
     else if (dtype == SHIFTND_F64) { SHIFTND_STEP_FWD_POOL(f64_t) }
-    else if (dtype == SHIFTND_F16) { SHIFTND_STEP_FWD_POOL(f16_t) }
-    else { SHIFTND_STEP_FWD_POOL(bf16_t) }
+    else if (dtype == SHIFTND_F16) { SHIFTND_STEP_FWD_POOL_A(f16_t, false) }   // (16-bit: the sparse shift only, step_forward_pooled_eligible)
+    else { SHIFTND_STEP_FWD_POOL_A(bf16_t, false) }
+#undef SHIFTND_STEP_FWD_POOL_A
 #undef SHIFTND_STEP_FWD_POOL
     return SHIFTND_OK;
 }

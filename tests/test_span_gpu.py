@@ -85,7 +85,10 @@ def test_cropped_backward_vs_oracle(abi, shape, crop, dt):
 
 
 CASES_1D = [((3, 5, 512), None), ((4, 3, 64), None), ((2, 2, 8), None), ((2, 3, 96), [[8, 24]]), ((2, 3, 4096), None), ((2, 2, 1024 + 256), None), ((2, 3, 2048), [[3, 5]]), ((1, 2, 4096 + 64), [[0, 16]]),
-            ((2, 2, 640), [[100, 28]]), ((1, 3, 1032), None)]
+            ((2, 2, 640), [[100, 28]]), ((1, 3, 1032), None),
+            # round 6 -- output rows that are not whole 16-byte pieces (Shift1d behind emulate_dw with padding 0: cut 1 / 1): the element-
+            # aligned stores of row_forward; an odd width (16-bit: not served, the older kernels), a one-sided cut
+            ((2, 3, 4096), [[1, 1]]), ((1, 2, 1032), [[0, 3]]), ((2, 2, 2048), [[2, 0]])]
 
 
 @pytest.mark.parametrize("dt", ["f32", "f64", "f16", "bf16"])
@@ -152,7 +155,7 @@ def test_cropped_forward_vs_oracle(abi, shape, crop, dt):
             out = abi.forward(xd, wd, pad, active, b)
             # (aligned rows / tiny planes keep their kernels, windows far smaller than their planes the strided ones; checked all the same)
             if not abi.last_kernel().startswith(("step_", "plane_", "sweep_", "small_", "band_")) and flat_serves(shape, new, es, False):
-                assert abi.last_kernel() in (("flat_active_forward", "crop_active_forward", "row_active_forward", "ragged_active_forward") if active else ("flat_gather_forward", "crop_gather_forward", "row_gather_forward", "ragged_gather_forward")), (shape, crop, abi.last_kernel())
+                assert abi.last_kernel() in (("flat_active_forward", "crop_active_forward", "row_active_forward", "ragged_active_forward", "crop_active_forward_rows") if active else ("flat_gather_forward", "crop_gather_forward", "row_gather_forward", "ragged_gather_forward", "crop_gather_forward_rows")), (shape, crop, abi.last_kernel())
             ref = torch.from_numpy(O.forward(x, w, pad, active, b)).to(tdt)
             if es >= 4 or not active:
                 assert torch.equal(out.cpu(), ref), (shape, crop, dt, pad, active)
@@ -181,7 +184,7 @@ def test_1d_forward_vs_oracle(abi, shape, crop, dt):
         for active in (0, 1):
             out = abi.forward(xd, wd, pad, active, b)
             if not abi.last_kernel().startswith(("step_", "plane_", "sweep_")):
-                assert abi.last_kernel() in (("flat_active_forward", "crop_active_forward", "row_active_forward", "ragged_active_forward") if active else ("flat_gather_forward", "crop_gather_forward", "row_gather_forward", "ragged_gather_forward")), (shape, crop, abi.last_kernel())
+                assert abi.last_kernel() in (("flat_active_forward", "crop_active_forward", "row_active_forward", "ragged_active_forward", "crop_active_forward_rows") if active else ("flat_gather_forward", "crop_gather_forward", "row_gather_forward", "ragged_gather_forward", "crop_gather_forward_rows")), (shape, crop, abi.last_kernel())
             ref = torch.from_numpy(O.forward(x, w, pad, active, b)).to(tdt)
             if es >= 4 or not active:
                 assert torch.equal(out.cpu(), ref), (shape, crop, dt, pad, active)
@@ -351,3 +354,35 @@ def test_cropped_3d_forward_vs_oracle(abi, shape, crop, dt):
                 assert torch.equal(out2, out), (shape, crop, dt, pad, active)
     if served and (new[-1] * es) % 16 != 0:
         assert hit == 10
+
+
+# round 6 -- crop_forward3<.., ND = 2>: cropped 2-D windows whose output planes are not whole 16-byte pieces (110 x 110 bf16: the
+# mixed-precision network behind emulate_dw with padding 0), row-relative; fp32 windows of an odd area take it too
+ROWS_2D = [((2, 3, 112, 112), [[1, 1], [1, 1]]), ((1, 4, 20, 32), [[1, 1], [1, 1]]), ((2, 2, 9, 24), [[0, 2], [3, 1]]), ((1, 2, 33, 64), [[1, 1], [0, 2]]),
+           ((1, 3, 12, 16), [[2, 3], [1, 0]]), ((2, 2, 7, 256), [[1, 1], [1, 1]])]
+
+
+@pytest.mark.parametrize("dt", ["f32", "f16", "bf16"])
+@pytest.mark.parametrize("shape,crop", ROWS_2D)
+def test_cropped_rows_forward_vs_oracle(abi, shape, crop, dt):
+    tdt = {"f32": torch.float32, "f16": torch.float16, "bf16": torch.bfloat16}[dt]
+    es = torch.empty(0, dtype=tdt).element_size()
+    b, new = abi.check_borders(list(shape), crop, 2)
+    rs = np.random.RandomState(sum(shape) * 23 + 3)
+    xt = torch.from_numpy(rs.uniform(-1, 1, size=shape)).to(tdt)
+    wt = torch.from_numpy(_weights(rs, shape[1], 2, shape[2:])).to(tdt)
+    x, w = (t.to(torch.float64).numpy().astype(np.float32) for t in (xt, wt))
+    xd, wd = xt.to(DEV), wt.to(DEV)
+    xcpr = shape[-1] * es // 16
+    fill = min(new[-2], 256 // xcpr) * -(-new[-1] * es // 16)   # threads of a step that have a chunk: at least half a workgroup
+    rows = ((new[-2] * new[-1] * es) % 16 != 0 and min(new[2:]) >= 2 and (es != 2 or new[-1] % 2 == 0) and fill >= 128)
+    for pad in range(5):
+        for active in (0, 1):
+            out = abi.forward(xd, wd, pad, active, b)
+            if rows:
+                assert abi.last_kernel() == ("crop_active_forward_rows" if active else "crop_gather_forward_rows"), (shape, crop, dt, abi.last_kernel())
+            ref = torch.from_numpy(O.forward(x, w, pad, active, b)).to(tdt)
+            if es >= 4 or not active:
+                assert torch.equal(out.cpu(), ref), (shape, crop, dt, pad, active, abi.last_kernel())
+            else:
+                assert _ulp_close(out.cpu(), ref, tdt), (shape, crop, dt, pad, active, abi.last_kernel())

@@ -253,7 +253,7 @@ def test_pool_op_gpu_vs_cpu():
             xg, wg = x.to(DEV).requires_grad_(True), w.to(DEV).requires_grad_(True)
             out_g = fn(xg, wg, pad, active, b, pool)
             # (3-D interpolating: the pool rides on the walk through the planes)
-            fstep = nd == 2 and not active and pool == (2, 2) and crop is None   # (2-D sparse, 2 x 2: the one-step sweep + pool)
+            fstep = nd == 2 and pool == (2, 2)   # (2-D, 2 x 2 windows: the one-step sweep + pool; round 6: both shifts, any window)
             assert abi.last_kernel() == ("walk_forward_pool" if (nd == 3 and active) else ("step_gather_forward_pool" if fstep else "plane_pool_forward"))
             out_g.backward(g.to(DEV))  # (runs on the autograd thread: its kernel name is checked in test_pooled_gpu.py)
             assert torch.equal(out_g.cpu(), out_c.detach()), (shape, pad, active)

@@ -706,6 +706,7 @@ struct SpanFwdParams {
     int wkind, C, nd, pad;   // pad: the padding mode (the PAD = kPadMirror instantiations read it: reflect or symmetric)
     int S1, S2, O1, O2, L1, L2;
     int S0, O0, L0, rsteps;   // crop_forward3: planes of the input volume / of the window, its first plane, row steps per output plane
+    int P2;                   // row_forward<.., POOL>: elements per pooled row
     int ocp, cps, spp;   // 16-byte chunks per output plane, chunks per step (256; 254 when only a column segment is staged), steps per plane
     int P, wholeP;       // pieces per slot; the same when whole rows are staged (0: only the columns the step reaches)
     uint32_t total_steps, steps_per_xcd;
@@ -1115,7 +1116,10 @@ __global__ __launch_bounds__(kThreads) void crop_forward3(const SpanFwdParams p)
 // the rest by the first threads in a second DMA).  Chunks whose columns are not all among the staged ones -- the row ends of
 // the wrapping / clamping / reflecting paddings -- read element by element from memory.
 // ---------------------------------------------------------------------------------------------------------------------
-template <typename T, bool ACTIVE, int PAD>
+// POOL (round 6): Shift1d + avg_pool1d(kernel = stride = 2, ceil_mode) in one pass -- the chunk's E shifted elements (rounded to the
+// storage type like the unfused sequence's shift output) are summed pairwise in ATen's order and E / 2 pooled elements leave; `out`
+// is the pooled row [P2], p.O2 the width of the (virtual) shift output.
+template <typename T, bool ACTIVE, int PAD, bool POOL = false>
 __global__ __launch_bounds__(kThreads) void row_forward(const SpanFwdParams p) {
     using S = typename T::S;
     using CT = typename T::C;
@@ -1189,6 +1193,30 @@ __global__ __launch_bounds__(kThreads) void row_forward(const SpanFwdParams p) {
             res.e[e] = raw[e];
         }
     }
+    if constexpr (POOL) {
+        constexpr int HP = E >= 2 ? E / 2 : 1;
+        S pooled[HP];
+#pragma unroll
+        for (int k = 0; k < HP; ++k) {
+            const bool two = E >= 2 && j + 2 * k + 1 < p.O2;
+            CT acc = CT(0) + widen<T>(res.e[E >= 2 ? 2 * k : 0]);
+            if (two) acc = acc + widen<T>(res.e[E >= 2 ? 2 * k + 1 : 0]);
+            pooled[k] = narrow<T>(div_count<CT>(acc, two ? 2 : 1));
+        }
+        S *dst = static_cast<S *>(p.out) + static_cast<int64_t>(plane) * p.o_plane + j / 2;
+        static_assert(E >= 2, "the pooled row forward: 2-, 4-byte elements");
+        if (j + E <= p.O2 + 1 && (ES >= 4 || (p.P2 & 1) == 0)) {   // all E / 2 pooled elements exist, the row at a 4-byte boundary
+            typedef typename vec_of<8>::type v8 __attribute__((aligned(4)));
+            typename vec_of<8>::type bits;
+            __builtin_memcpy(&bits, pooled, 8);
+            *reinterpret_cast<v8 *>(dst) = bits;
+        } else {
+#pragma unroll
+            for (int k = 0; k < HP; ++k)
+                if (j + 2 * k < p.O2) dst[k] = pooled[k];
+        }
+        return;
+    }
     // (round 6) output rows that are not whole 16-byte pieces -- L4096 cut 1/1 fp32 ran the strided fallback, 4.1 ms against 0.7 --
     // leave through element-aligned stores (rows at 4-byte boundaries: host), the row's last chunk element by element
     if ((p.O2 * ES) % 16 == 0) {   // (uniform)
@@ -1202,7 +1230,11 @@ __global__ __launch_bounds__(kThreads) void row_forward(const SpanFwdParams p) {
     }
 }
 
-template <typename T, bool ACTIVE, int PAD>
+// POOL (round 6): Shift1d behind a stride-2 depthwise emulation -- `go` is the gradient of the POOLED row [P2]; the two gradient spans
+// are staged EXPANDED (g(j) = grad_pooled[j / 2] / window size, rounded to the storage type), piece k of a span = columns E k .. of
+// the window at phase 0, by the thread that would have moved the piece (crop_backward<.., POOL>'s branch-free expansion).  N256 C512
+// L4096 pool 2 ran the band-walk kernel at 1.9 - 2.5 ms against 1.07 ms of the unpooled row_backward.
+template <typename T, bool ACTIVE, int PAD, bool POOL = false>
 __global__ __launch_bounds__(kThreads) void row_backward(const SpanParams p) {
     using S = typename T::S;
     using CT = typename T::C;
@@ -1232,8 +1264,10 @@ __global__ __launch_bounds__(kThreads) void row_backward(const SpanParams p) {
     const int oa0 = clampi(J0 - L2, 0, O2), oa1 = clampi(J1 - L2, 0, O2);
     const int sa0 = clampi(J0 - L2 - d.cg2, 0, O2), sa1 = clampi(J1 - L2 - d.cg2 + (ACTIVE ? 1 : 0), 0, O2);
     const int xlo = (xa0 * ES) >> 4, xn = xa1 > xa0 ? ((xa1 * ES + 15) >> 4) - xlo : 0;
-    const int olo = (gph + oa0 * ES) >> 4, on = oa1 > oa0 ? ((gph + oa1 * ES + 15) >> 4) - olo : 0;
-    const int slo = (gph + sa0 * ES) >> 4, sn = sa1 > sa0 ? ((gph + sa1 * ES + 15) >> 4) - slo : 0;
+    // (POOL: the spans are pieces of the EXPANDED window row, which starts at phase 0)
+    const int gph_s = POOL ? 0 : gph;
+    const int olo = (gph_s + oa0 * ES) >> 4, on = oa1 > oa0 ? ((gph_s + oa1 * ES + 15) >> 4) - olo : 0;
+    const int slo = (gph_s + sa0 * ES) >> 4, sn = sa1 > sa0 ? ((gph_s + sa1 * ES + 15) >> 4) - slo : 0;
     const int tid = static_cast<int>(threadIdx.x);
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     auto dma = [&](const char *base16, int piece, int lds_byte0) {
@@ -1241,13 +1275,58 @@ __global__ __launch_bounds__(kThreads) void row_backward(const SpanParams p) {
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(base16 + static_cast<uint32_t>(piece) * 16u),
                                          (__attribute__((address_space(3))) void *)dst_wave, 16, 0, 0);
     };
+    // POOL: the expanded piece `piece` (window columns E piece ..): one element-aligned 8-byte load of the pooled elements under it,
+    // its start clamped into the pooled row (host: P2 >= E / 2), the window counts 1 or 2 (a multiplication by a power of two)
+    constexpr int HP = E >= 2 ? E / 2 : 1;
+    auto pooled_scale = [&](int pc) {   // 1 / (columns of pooled column pc's window)
+        const int k = (O2 - 2 * pc >= 2) ? 1 : 0;
+        CT scale;
+        if constexpr (sizeof(CT) == 4) scale = __builtin_bit_cast(float, static_cast<uint32_t>(127 - k) << 23);
+        else scale = __builtin_bit_cast(double, static_cast<uint64_t>(1023 - k) << 52);
+        return scale;
+    };
+    auto expand_piece = [&](int piece, char *dst) {
+        const int first = piece * HP, start = max(min(first, p.P2 - HP), 0);
+        uint64_t raw;
+        if constexpr (ES == 8) {
+            raw = *reinterpret_cast<const uint64_t *>(gp + start);
+        } else {
+            const Chunk<S, HP> h = load_chunk<S, HP>(gp + start);
+            uint64_t v;
+            __builtin_memcpy(&v, h.e, 8);
+            raw = v >> (static_cast<unsigned>(min(first - start, HP - 1)) * (8u * ES));
+        }
+        Chunk<S, E> out;
+#pragma unroll
+        for (int h = 0; h < HP; ++h) {
+            typename raw_t<ES>::type bits = static_cast<typename raw_t<ES>::type>(ES == 8 ? raw : (raw >> (h * 8 * (ES == 8 ? 0 : ES))));
+            const S v = narrow<T>(widen<T>(__builtin_bit_cast(S, bits)) * pooled_scale(first + h));
+            if constexpr (E >= 2) {
+                out.e[2 * h] = v;
+                out.e[2 * h + 1] = v;
+            } else {
+                out.e[0] = v;
+            }
+        }
+        __builtin_memcpy(__builtin_assume_aligned(dst, 16), out.e, 16);
+    };
     if (tid < xn) dma(reinterpret_cast<const char *>(xp), xlo + tid, 0);
-    if (tid < on) dma(gp16, olo + tid, SLOT);
-    if (tid < sn) dma(gp16, slo + tid, 2 * SLOT);
+    if constexpr (POOL) {
+        if (tid < on) expand_piece(olo + tid, tile + SLOT + tid * 16);
+        if (tid < sn) expand_piece(slo + tid, tile + 2 * SLOT + tid * 16);
+    } else {
+        if (tid < on) dma(gp16, olo + tid, SLOT);
+        if (tid < sn) dma(gp16, slo + tid, 2 * SLOT);
+    }
     if (wave == 0) {   // the pieces beyond 256 of each span: a handful of lanes
         if (tid + kThreads < xn) dma(reinterpret_cast<const char *>(xp), xlo + kThreads + tid, kThreads * 16);
-        if (tid + kThreads < on) dma(gp16, olo + kThreads + tid, SLOT + kThreads * 16);
-        if (tid + kThreads < sn) dma(gp16, slo + kThreads + tid, 2 * SLOT + kThreads * 16);
+        if constexpr (POOL) {
+            if (tid + kThreads < on) expand_piece(olo + kThreads + tid, tile + SLOT + (kThreads + tid) * 16);
+            if (tid + kThreads < sn) expand_piece(slo + kThreads + tid, tile + 2 * SLOT + (kThreads + tid) * 16);
+        } else {
+            if (tid + kThreads < on) dma(gp16, olo + kThreads + tid, SLOT + kThreads * 16);
+            if (tid + kThreads < sn) dma(gp16, slo + kThreads + tid, 2 * SLOT + kThreads * 16);
+        }
     }
     const int jc = sg * kThreads + tid, ji = jc * E;
     const bool mine = jc < cpr;
@@ -1297,6 +1376,12 @@ __global__ __launch_bounds__(kThreads) void row_backward(const SpanParams p) {
                 lds_read_row_affine<S, E>(lds_col0, true, st, raw);
             } else if (staged) {
                 lds_read_row<S, E>(lds_col0, true, st, raw);
+            } else if (POOL && mem_col0 == gp) {   // (a gradient chunk that wraps / reflects beyond the staged span: expanded from memory)
+#pragma unroll
+                for (int e = 0; e <= E; ++e) {
+                    const int col = st.cm[e] >= 0 ? st.cm[e] : 0;
+                    raw[e] = st.cm[e] >= 0 ? narrow<T>(widen<T>(gp[col >> 1]) * pooled_scale(col >> 1)) : zero;
+                }
             } else {
 #pragma unroll
                 for (int e = 0; e <= E; ++e) raw[e] = st.cm[e] >= 0 ? mem_col0[st.cm[e]] : zero;
@@ -1304,8 +1389,8 @@ __global__ __launch_bounds__(kThreads) void row_backward(const SpanParams p) {
         };
         S xr[E + 1], gr[E + 1];
         read(tile - xlo * 16, xp, xs, xm, xr);
-        read(tile + 2 * SLOT - slo * 16 + gph, gp, gs, gm, gr);
-        const S *own = reinterpret_cast<const S *>(tile + SLOT - olo * 16 + gph);   // column 0 of the own-gradient span
+        read(tile + 2 * SLOT - slo * 16 + gph_s, gp, gs, gm, gr);
+        const S *own = reinterpret_cast<const S *>(tile + SLOT - olo * 16 + gph_s);   // column 0 of the own-gradient span
         Chunk<S, E> res;
 #pragma unroll
         for (int e = 0; e < E; ++e) {
@@ -1441,7 +1526,8 @@ bool span_geometry_ok(const Geometry &g, int dtype) { return span_geometry_ok(g,
 static bool span_geometry_ok(const Geometry &g, int dtype, bool pooled) {
     if (dtype > SHIFTND_BF16 || g.nd < 1 || g.nd > 3 || (g.K[0] > 0) != pooled) return false;
     const int es = dtype_size(dtype);
-    if (pooled && (g.nd != 2 || (g.S[2] * es) % 16 != 0 || g.K[1] != 2 || g.K[2] != 2 || g.P[2] < std::max(1, 8 / es))) return false;
+    // (pooled: 2 x 2 windows on 2-D planes; windows of 2 on 1-D rows -- row_backward<.., POOL>)
+    if (pooled && (g.nd == 3 || (g.S[2] * es) % 16 != 0 || g.K[1] != (g.nd == 2 ? 2 : 1) || g.K[2] != 2 || g.P[2] < std::max(1, 8 / es))) return false;
     if (g.nd == 3) {   // crop_backward3: x rows of whole pieces, every dim of the volume and of the window at least 2
         if (g.S[0] < 2 || g.S[1] < 2 || g.S[2] < 2 || g.O[0] < 2 || g.O[1] < 2 || g.O[2] < 2 || (g.S[2] * es) % 16 != 0) return false;
         if (g.S[0] * g.S[1] * g.S[2] >= (1LL << 28) || g.O[0] * g.O[1] * g.O[2] >= (1LL << 28)) return false;   // 32-bit byte offsets within a volume
@@ -1570,6 +1656,69 @@ static int crop_forward_groups(const Geometry &g, int es) {
     const int64_t ocp = (g.O[1] * g.O[2] * es + 15) / 16;
     if (ocp <= 2 * kThreads) return 1;
     return crop_forward_rows(g, es, 2 * kThreads) * (g.S[2] * es / 16) <= 6 * kThreads ? 2 : 1;
+}
+
+// Shift1d + avg_pool1d(2) in one pass (row_forward<.., POOL>, round 6): 2- / 4-byte float elements, source rows of whole pieces, at
+// least 128 chunks (shorter rows: the per-channel kernels, like the unpooled rule)
+bool span_forward_pooled_eligible(const Geometry &g, int dtype, const void *x, const void *out) {
+    if (g_step_tune[2] == 1 || g.nd != 1 || g.K[2] != 2 || g.K[1] > 1) return false;
+    if (dtype != SHIFTND_F32 && dtype != SHIFTND_F16 && dtype != SHIFTND_BF16) return false;
+    const int es = dtype_size(dtype);
+    if (g.S[0] != 1 || g.S[1] != 1 || g.O[0] != 1 || g.O[1] != 1 || g.S[2] < 2 || g.O[2] < 1) return false;
+    if ((g.S[2] * es) % 16 != 0 || g.S[2] >= (1LL << 28) || (g.N * g.C * g.S[2] * es) % 16 != 0) return false;
+    if (!dense(g.xs, g.N, g.C, g.S)) return false;
+    if (reinterpret_cast<uintptr_t>(x) % 16 || reinterpret_cast<uintptr_t>(out) % (es < 4 ? 4 : es)) return false;
+    const int64_t ocp = (g.O[2] * es + 15) / 16;
+    if (g.N * g.C * ((ocp + kThreads - 1) / kThreads) + 8 >= (1LL << 31)) return false;
+    return g_step_tune[2] >= 2 || ocp >= 128;
+}
+
+int span_forward_pooled(const Geometry &g, int dtype, const void *x, const void *w, int wkind, void *out, hipStream_t st) {
+    const int es = dtype_size(dtype);
+    SpanFwdParams p{};
+    p.x = x;
+    p.out = out;
+    p.w = w;
+    p.wkind = wkind;
+    p.C = static_cast<int>(g.C);
+    p.nd = 1;
+    p.S1 = p.O1 = 1;
+    p.S2 = static_cast<int>(g.S[2]);
+    p.O2 = static_cast<int>(g.O[2]);
+    p.L2 = static_cast<int>(g.L[2]);
+    p.P2 = static_cast<int>(g.P[2]);
+    p.x_plane = g.S[2];
+    p.o_plane = g.P[2];   // (the pooled row)
+    p.ocp = static_cast<int>((g.O[2] * es + 15) / 16);
+    p.cps = kThreads;
+    p.spp = (p.ocp + kThreads - 1) / kThreads;
+    p.P = kThreads + 2;
+    const uint64_t total = static_cast<uint64_t>(g.N) * g.C * p.spp;
+    p.total_steps = static_cast<uint32_t>(total);
+    p.steps_per_xcd = static_cast<uint32_t>((total + 7) / 8);
+    p.d_spp = make_fastdiv(static_cast<uint32_t>(p.spp));
+    p.d_C = make_fastdiv(static_cast<uint32_t>(p.C));
+    p.d_O2 = make_fastdiv(static_cast<uint32_t>(p.O2));
+    p.d_P = make_fastdiv(static_cast<uint32_t>(p.P));
+    p.pad = g.pad;
+    p.d_per1 = make_fastdiv(1u);
+    p.d_per2 = make_fastdiv(static_cast<uint32_t>(map_period(p.S2, g.pad)));
+    const size_t lds = 64 + (kThreads + 3) * 16 + 64;
+    note_kernel("row_forward_pool");
+    const dim3 grid(p.steps_per_xcd * 8), block(kThreads);
+#define SHIFTND_ROW_POOL(TT, ACT) \
+    switch (pad_template(g.pad)) { \
+    case 0: hipLaunchKernelGGL((row_forward<TT, ACT, 0, true>), grid, block, lds, st, p); break; \
+    case 1: hipLaunchKernelGGL((row_forward<TT, ACT, 1, true>), grid, block, lds, st, p); break; \
+    case 2: hipLaunchKernelGGL((row_forward<TT, ACT, 2, true>), grid, block, lds, st, p); break; \
+    default: hipLaunchKernelGGL((row_forward<TT, ACT, kPadMirror, true>), grid, block, lds, st, p); break; \
+    }
+#define SHIFTND_ROW_POOL_T(TT) \
+    if (g.active) { SHIFTND_ROW_POOL(TT, true) } else { SHIFTND_ROW_POOL(TT, false) }
+    if (dtype == SHIFTND_F32) { SHIFTND_ROW_POOL_T(f32_t) } else if (dtype == SHIFTND_F16) { SHIFTND_ROW_POOL_T(f16_t) } else { SHIFTND_ROW_POOL_T(bf16_t) }
+#undef SHIFTND_ROW_POOL_T
+#undef SHIFTND_ROW_POOL
+    return SHIFTND_OK;
 }
 
 int span_forward(const Geometry &g, int dtype, const void *x, const void *w, int wkind, void *out, hipStream_t st) {
@@ -1821,6 +1970,7 @@ bool span_backward_pooled_eligible(const Geometry &g, int dtype, const void *go,
     if (!dense(g.xs, g.N, g.C, g.S) || !dense(g.gs, g.N, g.C, g.S)) return false;
     if (reinterpret_cast<uintptr_t>(go) % dtype_size(dtype) || reinterpret_cast<uintptr_t>(x) % 16 || reinterpret_cast<uintptr_t>(gx) % 16) return false;
     if (g.pad == 0 && g.O[2] == 1) return false;   // (as span_backward_eligible: the affine column state)
+    if (g.nd == 1) return g.S[2] * dtype_size(dtype) / 16 >= 128 || g_step_tune[0] == 2;   // (short rows: the per-channel kernels, as unpooled)
     return true;
 }
 size_t span_backward_pooled_workspace(const Geometry &g, int dtype) { return span_geometry_ok(g, dtype, true) ? span_plan(g, dtype_size(dtype)).bytes : 0; }
@@ -1840,7 +1990,7 @@ static void launch_span_backward(const SpanParams &p, const SpanPlan &sp, bool a
         } else if constexpr (ND == 3) { \
             hipLaunchKernelGGL((crop_backward3<T, ACT, PADV>), grid, block, sp.lds, st, p); \
         } else { \
-            hipLaunchKernelGGL((row_backward<T, ACT, PADV>), grid, block, sp.lds, st, p); \
+            hipLaunchKernelGGL((row_backward<T, ACT, PADV, POOL>), grid, block, sp.lds, st, p); \
         } \
         break;
     // (the channel descriptors come from span_prep for every padding: computing them in crop_backward itself -- tried in round 5 to save
@@ -1929,6 +2079,16 @@ int span_backward(const Geometry &g, int dtype, const void *go, const void *x, c
         case SHIFTND_F32: launch_span_backward<f32_t, 3>(p, sp, active, gw, st); break;
         case SHIFTND_F16: launch_span_backward<f16_t, 3>(p, sp, active, gw, st); break;
         default: launch_span_backward<bf16_t, 3>(p, sp, active, gw, st); break;
+        }
+        return SHIFTND_OK;
+    }
+    if (pooled && g.nd == 1) {
+        note_kernel("row_backward_pool");
+        switch (dtype) {
+        case SHIFTND_F64: launch_span_backward<f64_t, 1, false, true>(p, sp, active, gw, st); break;
+        case SHIFTND_F32: launch_span_backward<f32_t, 1, false, true>(p, sp, active, gw, st); break;
+        case SHIFTND_F16: launch_span_backward<f16_t, 1, false, true>(p, sp, active, gw, st); break;
+        default: launch_span_backward<bf16_t, 1, false, true>(p, sp, active, gw, st); break;
         }
         return SHIFTND_OK;
     }

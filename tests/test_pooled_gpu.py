@@ -305,3 +305,53 @@ def test_pooled_3d_walk_backward(abi, shape, pool, dt):
                 gx_r, gw_r = O.backward(g, w, x, pad, active, b)
                 assert np.max(np.abs(gx.float().cpu().numpy() - gx_r)) <= (eps if active else 0.0) * max(1.0, np.max(np.abs(gx_r))), (shape, pool, pad, active)
                 assert rel_err(gw.float().cpu().numpy(), gw_r) < 1.02 * eps + 1e-5, (shape, pool, pad, active)
+
+
+# round 6 -- Shift1d behind a stride-2 depthwise emulation: row_forward<.., POOL> / row_backward<.., POOL> (rows of at least 128 chunks by
+# default; knobs 32 / 34 = 2 send the short rows of these cases there too): whole and ragged last windows, cuts, rows longer than one
+# workgroup pass, every padding, both shifts
+ROWS_1D = [((2, 3, 2048), None), ((2, 2, 1032), [[1, 1]]), ((1, 3, 640), [[0, 3]]), ((2, 2, 528), None), ((1, 2, 4104), [[2, 1]])]
+
+
+@pytest.mark.parametrize("dt", ["f32", "bf16", "f16"])
+@pytest.mark.parametrize("shape,crop", ROWS_1D)
+def test_pooled_1d_rows(abi, shape, crop, dt):
+    tdt = {"f32": torch.float32, "bf16": torch.bfloat16, "f16": torch.float16}[dt]
+    eps = {"f32": 0.0, "bf16": 2.0 ** -8, "f16": 2.0 ** -11}[dt]
+    rs = np.random.RandomState(sum(shape) + 3)
+    xt = torch.from_numpy(rs.uniform(-1, 1, size=shape).astype(np.float32)).to(tdt)
+    wt = torch.from_numpy(rs.uniform(-6, 6, size=(shape[1], 1)).astype(np.float32)).to(tdt)
+    wt[0, 0] = 2.5
+    x, w = xt.float().numpy(), wt.float().numpy()
+    b, new = abi.check_borders(list(shape), crop, 1)
+    abi.set_tuning(32, 2)
+    abi.set_tuning(34, 2)
+    try:
+        for pad in range(5):
+            for active in (0, 1):
+                key = (shape, crop, dt, pad, active)
+                out = abi.forward_pooled(xt.to(DEV), wt.to(DEV), pad, active, (2,), b)
+                assert abi.last_kernel() == "row_forward_pool", key + (abi.last_kernel(),)
+                # the unfused sequence on widened inputs, the shift's output rounded to the storage type
+                y = torch.from_numpy(O.forward(x, w, pad, active, b)).to(tdt).float().numpy()
+                ref = O.avg_pool(y, (2,))
+                got = out.float().cpu().numpy()
+                if dt == "f32":
+                    assert np.array_equal(got, O.forward_pooled(x, w, pad, active, (2,), b)), key
+                else:
+                    assert np.max(np.abs(got - ref)) <= eps * max(1.0, np.max(np.abs(ref))), key
+                gpt = torch.from_numpy(rs.uniform(-1, 1, size=ref.shape).astype(np.float32)).to(tdt)
+                gx, gw = abi.backward_pooled(gpt.to(DEV), wt.to(DEV), xt.to(DEV), pad, active, (2,), b)
+                assert abi.last_kernel() == "row_backward_pool", key + (abi.last_kernel(),)
+                if dt == "f32":
+                    gx_r, gw_r = O.backward_pooled(gpt.float().numpy(), w, x, pad, active, (2,), b)
+                    assert np.array_equal(gx.cpu().numpy(), gx_r), key
+                    assert rel_err(gw.cpu().numpy(), gw_r) < 1e-5, key
+                else:
+                    g = torch.from_numpy(O.avg_pool_backward(gpt.float().numpy(), (2,), y.shape[2:])).to(tdt).float().numpy()
+                    gx_r, gw_r = O.backward(g, w, x, pad, active, b)
+                    assert np.max(np.abs(gx.float().cpu().numpy() - gx_r)) <= eps * max(1.0, np.max(np.abs(gx_r))), key
+                    assert rel_err(gw.float().cpu().numpy(), gw_r) < 1.02 * eps + 1e-5, key
+    finally:
+        abi.set_tuning(32, 0)
+        abi.set_tuning(34, 0)

@@ -15,6 +15,7 @@ def short(name):
 
 def main(root):
     traffic = defaultdict(dict)  # kernel base name -> {"read_bytes", "written_bytes"} per launch (for bench.py)
+    by_inst = defaultdict(dict)  # ... and per template instantiation (round-5 verdict: a base-name average can hide one bad instantiation)
     for f in glob.glob(os.path.join(root, "trace", "**", "*kernel_trace.csv"), recursive=True):
         dur = defaultdict(list)
         res = {}
@@ -49,9 +50,11 @@ def main(root):
                     if c == "FETCH_SIZE":
                         note = "  KB/launch; x2 (gfx950 correction) = %.3f GB read" % (avg * 2 * 1024 / 1e9)
                         traffic[base]["read_bytes"] = avg * 2 * 1024
+                        by_inst[k]["read_bytes"] = avg * 2 * 1024
                     if c == "WRITE_SIZE":
                         note = "  KB/launch = %.3f GB written" % (avg * 1024 / 1e9)
                         traffic[base]["written_bytes"] = avg * 1024
+                        by_inst[k]["written_bytes"] = avg * 1024
                     print("%-70s %-28s avg %16.1f over %d launches%s" % (k[:70], c, avg, len(v), note))
 
 
@@ -60,7 +63,7 @@ def main(root):
         with open(os.path.join(root, "traffic.json"), "w") as fh:
             json.dump({"source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of bench.py (profiles/collect.sh); "
                                  "FETCH_SIZE doubled per the gfx950 correction of MI355X_MICROARCH.md",
-                       "per_launch": traffic}, fh, indent=1)
+                       "per_launch": traffic, "per_launch_by_instantiation": by_inst}, fh, indent=1)
 
 
 if __name__ == "__main__":

@@ -316,8 +316,10 @@ def newest_traffic(workload, kernel_name, pad):
         per = json.load(open(best[1]))["per_launch"]
         # (shiftnd_last_kernel names the ROUTE -- crop_backward_ragged, flat_gather_forward -- the profile the kernel function)
         t = None
-        for cand in (kernel_name, kernel_name.replace("_ragged", ""), kernel_name.replace("_gather_", "_").replace("_active_", "_"),
-                     kernel_name.replace("_ncdhw_grad", "").replace("_nchw_grad", "")):
+        plain = kernel_name.replace("(pool)", "")
+        for cand in (plain, plain.replace("_ragged", ""), plain.replace("_gather_", "_").replace("_active_", "_"),
+                     plain.replace("_ncdhw_grad", "").replace("_nchw_grad", ""), plain.replace("_pool", ""),
+                     plain.replace("_gather_", "_").replace("_active_", "_").replace("_rows", "3")):
             if cand in per:
                 t = per[cand]
                 break

@@ -113,8 +113,11 @@ SHIFTND_API void shiftnd_set_path_policy(int policy);
  * per band, 22: XCD-contiguous block ids; 23: the direct NDHWC backward 0 = automatic, 1 = never, 2 = whenever eligible), 24-26 small-plane / row-band kernels (24: on / off, 25: planes per round or rows per band, 26: rounds per
  * workgroup), 27 flat-stream kernels for ragged rows (0 = automatic, 1 = never, 2 = whenever eligible), 28-30 one-byte row kernel (28: element sizes served, 29: rows per band, 30: workgroups wanted), 32-35
  * one-step kernels (32: 2-D backward, 33: sparse-shift forward by direct loads, 34: forwards through LDS; each 0 =
- * automatic, 1 = never, 2 = whenever eligible; 35: bit set of opt-in forms, csrc/shiftnd_step.hip), 36-37 quantized
- * pool (36: 1 = the element-per-thread kernel only, 37: workgroups wanted), 38 planes per workgroup of the 3-D walk
+ * automatic, 1 = never, 2 = whenever eligible; 33 also: 3 = the 16-bit pooled gather forward off, 4 = the interpolating one off;
+ * 35: bit set of opt-in forms, csrc/shiftnd_step.hip; round 6: bit 6 = the band-walk kernel for the cropped / interpolating 2-D pooled
+ * backward, bit 7 = one row group per thread in crop_backward's sparse forms, bit 8 = two everywhere, bit 10 = the per-channel
+ * kernels for cropped 3-D volumes and 2-D windows whose planes are not whole pieces), 36-37 quantized
+ * pool (36: 1 = the element-per-thread kernel only, 2 = the plane kernel first, 3 = the band kernel first; 37: workgroups wanted), 38 planes per workgroup of the 3-D walk
  * kernels; for the sizing knobs 0 means automatic.
  * Results never depend on them.
  * shiftnd_backward_workspace_bytes (and the pooled form) returns the larger of the default knobs' plan and the calling

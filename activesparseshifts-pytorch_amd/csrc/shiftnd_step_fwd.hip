@@ -99,6 +99,18 @@ __global__ __launch_bounds__(kThreads) void step_gather_forward(const GatherPara
 // gathers the chunk of BOTH rows of a pooled row, sums each window in ATen's order (row, then column) in the compute type, divides
 // by the window size and stores E / 2 pooled elements -- the shift output never exists.  `out` is the pooled tensor [N, C, P1, P2];
 // p.O1 / p.O2 are the sizes of the (virtual) shift output, p.spp counts steps of R POOLED rows.
+// the 16 bytes at byte phase `ph` (uniform) of the 32 bytes A | B (step_gather_forward_small's funnel)
+typedef uint32_t gather_u4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ gather_u4 funnel_bytes(const gather_u4 A, const gather_u4 B, const int ph) {
+    const uint32_t sh = static_cast<uint32_t>(ph & 3) * 8u;
+    switch (ph >> 2) {  // uniform
+    case 0: return gather_u4{__builtin_amdgcn_alignbit(A.y, A.x, sh), __builtin_amdgcn_alignbit(A.z, A.y, sh), __builtin_amdgcn_alignbit(A.w, A.z, sh), __builtin_amdgcn_alignbit(B.x, A.w, sh)};
+    case 1: return gather_u4{__builtin_amdgcn_alignbit(A.z, A.y, sh), __builtin_amdgcn_alignbit(A.w, A.z, sh), __builtin_amdgcn_alignbit(B.x, A.w, sh), __builtin_amdgcn_alignbit(B.y, B.x, sh)};
+    case 2: return gather_u4{__builtin_amdgcn_alignbit(A.w, A.z, sh), __builtin_amdgcn_alignbit(B.x, A.w, sh), __builtin_amdgcn_alignbit(B.y, B.x, sh), __builtin_amdgcn_alignbit(B.z, B.y, sh)};
+    default: return gather_u4{__builtin_amdgcn_alignbit(B.x, A.w, sh), __builtin_amdgcn_alignbit(B.y, B.x, sh), __builtin_amdgcn_alignbit(B.z, B.y, sh), __builtin_amdgcn_alignbit(B.w, B.z, sh)};
+    }
+}
+
 // ACTIVE (round 6): the interpolating shift -- three source rows (the two of the pooled row and the + 1 corner row) of E + 1 columns
 // per thread, the blends of interp_t<T, 2>, the shift's result rounded to the storage type like the two-step sequence, then the same
 // sums (the band-walk kernel ran it at 2 - 2.9 TB/s).
@@ -145,8 +157,34 @@ __global__ __launch_bounds__(kThreads) void step_gather_forward_pool(const Gathe
     S zero;
     __builtin_memset(&zero, 0, sizeof(S));
     S v[NR][NC];
+    // 16-bit elements, sparse shift, zeros padding, source rows of whole aligned pieces (host: p.xppr > 0): an element-aligned 16-byte
+    // load of 2-byte elements is slow (the 2.2 - 2.5 TB/s of this kernel in bf16) -- the chunk's 16 source bytes come from the two
+    // ALIGNED pieces that hold them, displaced by a byte phase that is uniform for the workgroup (step_gather_forward_small's form);
+    // a piece is either inside the row or entirely fill
+    bool done16 = false;
+    if constexpr (sizeof(S) == 2 && !ACTIVE && PAD == 0) {
+        if (p.xppr > 0) {   // (uniform)
+            const int dcol = p.L2 - cs2, ph = (dcol * 2) & 15, q = tc + ((dcol * 2) >> 4);
+            const bool qa_in = q >= 0 && q < p.xppr, qb_in = q + 1 >= 0 && q + 1 < p.xppr;
+            const int qa = q < 0 ? 0 : (q >= p.xppr ? p.xppr - 1 : q), qb = q + 1 < 0 ? 0 : (q + 1 >= p.xppr ? p.xppr - 1 : q + 1);
+            const gather_u4 zero4 = {0u, 0u, 0u, 0u};
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int rb = h < n1 ? row_map_t<PAD>(2 * pr + h + p.L1, cs1, p.S1, p.pad) : -1;
+                const gather_u4 *xrow = reinterpret_cast<const gather_u4 *>(xp + static_cast<int64_t>(rb < 0 ? 0 : rb) * p.S2);
+                gather_u4 A = __builtin_nontemporal_load(xrow + qa), B = zero4;
+                if (ph != 0) B = __builtin_nontemporal_load(xrow + qb);   // (uniform)
+                A = (rb >= 0 && qa_in) ? A : zero4;
+                B = (rb >= 0 && qb_in) ? B : zero4;
+                const gather_u4 o = funnel_bytes(A, B, ph);
+                __builtin_memcpy(v[h], &o, 16);
+            }
+            done16 = true;
+        }
+    }
 #pragma unroll
     for (int h = 0; h < NR; ++h) {
+        if (done16) break;
         const int rb = h < n1 + (ACTIVE ? 1 : 0) ? row_map_t<PAD>(2 * pr + h + p.L1, cs1, p.S1, p.pad) : -1;
         if (rb < 0) {
 #pragma unroll
@@ -685,7 +723,8 @@ int step_forward_pooled(const Geometry &g, int dtype, const void *x, const void 
     p.x_plane = g.S[1] * g.S[2];
     p.o_plane = g.P[1] * g.P[2];   // (the pooled plane)
     p.cpr = static_cast<int>((g.O[2] * es + 15) / 16);
-    p.xppr = static_cast<int>(g.S[2] * es / 16);
+    // (16-bit: the aligned-pieces form needs source rows of whole pieces at a 16-byte boundary; 0: element-aligned loads)
+    p.xppr = ((g.S[2] * es) % 16 == 0 && reinterpret_cast<uintptr_t>(x) % 16 == 0) ? static_cast<int>(g.S[2] * es / 16) : 0;
     const int P1 = static_cast<int>(g.P[1]);
     p.R = kThreads / p.cpr;
     if (p.R > P1) p.R = P1;

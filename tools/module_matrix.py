@@ -30,14 +30,22 @@ def timeit(fn, iters=10):
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--small", action="store_true")
+ap.add_argument("--pad", type=int, default=0, help="padding mode 0..4 (zeros, border, periodic, reflect, symmetric)")
+ap.add_argument("--dtypes", default="float32,bfloat16")
+ap.add_argument("--channels-last", action="store_true", help="2-D / 3-D inputs (and gradients of the unpooled ops) as dense channels-last tensors")
 a = ap.parse_args()
+PAD = a.pad
 SHAPES = {1: (256, 512, 4096), 2: (32, 256, 112, 112), 3: (8, 128, 16, 56, 56)}
 if a.small:
     SHAPES = {1: (64, 128, 1024), 2: (8, 64, 56, 56), 3: (4, 32, 8, 28, 28)}
 rows = []
 for nd, shape in SHAPES.items():
-    for dt in (torch.float32, torch.bfloat16):
+    for dt in [getattr(torch, n) for n in a.dtypes.split(",")]:
+        if a.channels_last and nd == 1:
+            continue
         x = torch.rand(shape, device="cuda").to(dt)
+        if a.channels_last:
+            x = x.contiguous(memory_format=torch.channels_last if nd == 2 else torch.channels_last_3d)
         w = ((torch.rand(shape[1], nd, device="cuda") * 2 - 1) * 2.5).to(dt)
         es = x.element_size()
         for cut in (None, [[1, 1]] * nd):
@@ -47,19 +55,19 @@ for nd, shape in SHAPES.items():
                 for active in (False, True):
                     if pool:
                         fop, bop = getattr(ops, "_shift%dd_pool_forward" % nd), getattr(ops, "_shift%dd_pool_backward" % nd)
-                        out = fop(x, w, bt, new, [pool] * nd, 0, active)
+                        out = fop(x, w, bt, new, [pool] * nd, PAD, active)
                         g = torch.rand_like(out)
-                        tf = timeit(lambda: fop(x, w, bt, new, [pool] * nd, 0, active))
+                        tf = timeit(lambda: fop(x, w, bt, new, [pool] * nd, PAD, active))
                         kf = abi.last_kernel()
-                        tb = timeit(lambda: bop(g, w, x, bt, [pool] * nd, 0, active))
+                        tb = timeit(lambda: bop(g, w, x, bt, [pool] * nd, PAD, active))
                         kb = abi.last_kernel()
                     else:
                         fop, bop = getattr(ops, "_shift%dd_forward" % nd), getattr(ops, "_shift%dd_backward" % nd)
-                        out = fop(x, w, bt, new, 0, active)
+                        out = fop(x, w, bt, new, PAD, active)
                         g = torch.rand_like(out)
-                        tf = timeit(lambda: fop(x, w, bt, new, 0, active))
+                        tf = timeit(lambda: fop(x, w, bt, new, PAD, active))
                         kf = abi.last_kernel()
-                        tb = timeit(lambda: bop(g, w, x, bt, 0, active))
+                        tb = timeit(lambda: bop(g, w, x, bt, PAD, active))
                         kb = abi.last_kernel()
                     fb, bb = es * (x.numel() + out.numel()), es * (2 * x.numel() + out.numel())
                     rows.append((fb / tf / 1e9, "fwd", nd, str(dt)[6:], cut is not None, pool, active, kf, tf))

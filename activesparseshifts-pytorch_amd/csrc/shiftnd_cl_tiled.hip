@@ -420,14 +420,21 @@ struct ClTiledBwdParams {
 // consecutive elements per staged row, element loads with lanes along the pixels (a wave touches ~3 runs of 92 / 46
 // bytes), written to the same [pixel][channel] ring (pitch 33 words: lanes along the pixels of one channel hit
 // different banks).  Everything after the staging is the same kernel.
-template <typename T, bool ACTIVE, bool GO_NCHW>
+// TW (round 6): grad_x columns per workgroup.  16: one staged piece of each tensor per thread, 2 x 24 KB of LDS, three workgroups per CU;
+// 32 (channels-last gradient only): a halo of 39 / 32 staged pixels instead of 23 / 16 (the loads' amplification 1.22 x instead of
+// 1.44 x), twice the work between two barriers, two pieces per tensor and thread, 80 KB of LDS (two workgroups per CU).
+template <typename T, bool ACTIVE, bool GO_NCHW, int TW = kBTW>
 __global__ __launch_bounds__(kThreads) void cl_tiled_backward(const ClTiledBwdParams p) {
+    static_assert(TW == kBTW || !GO_NCHW, "the wide strip takes a channels-last gradient");
+    constexpr int BPW = TW + 2 * kR + 1;             // staged pixels per row
+    constexpr int BPIECES = BPW * (kLine / 16);      // 16-byte pieces per staged row and tensor
+    constexpr int NPX = (BPIECES + kThreads - 1) / kThreads;   // ... per thread (1 or 2)
     typedef uint32_t u4 __attribute__((ext_vector_type(4)));
     using S = typename T::S;
     using CT = typename T::C;
     static_assert(sizeof(S) == 4 || sizeof(S) == 2, "fp32, fp16, bf16");
     constexpr int ES = sizeof(S), CB = kLine / ES;   // channels per workgroup: 32 (fp32) or 64 (16-bit types)
-    constexpr int PL = kThreads / CB, NI = kBTW / PL;   // pixel lanes; pixels per thread and row (2 or 4)
+    constexpr int PL = kThreads / CB, NI = TW / PL;   // pixel lanes; pixels per thread and row (2 or 4)
     // four zero words, input ring, gradient ring, dump words.  The zero words are what a padding tap reads: row and column offsets
     // of taps that do not exist are hugely negative (kNeg), the address is max(offset sum, 0) -- no lane masks, no selects, no
     // exec-mask regions in the row loop (round 4: the loop issued 137 scalar instructions per row, and the CU's one scalar unit
@@ -437,7 +444,7 @@ __global__ __launch_bounds__(kThreads) void cl_tiled_backward(const ClTiledBwdPa
     // pixels) made half of this kernel's LDS cycles bank conflicts.  GO_NCHW stages along the pixels and keeps 33.
     // (the INPUT ring is staged by pieces and read along the channels in every form: 32; only the gradient ring of GO_NCHW is 33)
     constexpr int PITCHX = kLine / 4, PITCHG = GO_NCHW ? kPitch : kLine / 4;
-    constexpr int BROWX = kBPW * PITCHX, BROWG = kBPW * PITCHG, BRINGX = kBRing * BROWX, BRINGG = kBRing * BROWG;
+    constexpr int BROWX = BPW * PITCHX, BROWG = BPW * PITCHG, BRINGX = kBRing * BROWX, BRINGG = kBRing * BROWG;
     __shared__ __attribute__((aligned(16))) uint32_t ring_all[4 + BRINGX + BRINGG + 4];
     uint32_t *const ring = ring_all + 4;
     constexpr int kDump = BRINGX + BRINGG;
@@ -454,7 +461,7 @@ __global__ __launch_bounds__(kThreads) void cl_tiled_backward(const ClTiledBwdPa
     b = fdiv(b, p.d_wtiles);
     const int band = static_cast<int>(b - fdiv(b, p.d_bands) * p.bands);
     const int n = static_cast<int>(fdiv(b, p.d_bands));
-    const int w0 = wt * kBTW, c0 = cb * CB;
+    const int w0 = wt * TW, c0 = cb * CB;
     const int h0 = band * p.band_rows, h1 = min(p.H, h0 + p.band_rows);
     // The window (round 4; shifts_kernels.h:402-527 with the borders of shifts.cpp:93-135): grad_out has the window's sizes OH x OW
     // and sits at (LH, LW) of the input image.  The kernel stays in INPUT coordinates: the gradient ring's row y / pixel gxs hold
@@ -476,17 +483,23 @@ __global__ __launch_bounds__(kThreads) void cl_tiled_backward(const ClTiledBwdPa
 
     // ---- staging: one 16-byte piece of the input row and one of the gradient row per thread ------------------------------
     const int q = static_cast<int>(threadIdx.x);
-    const bool piece = q < kBPieces;
-    const int px = q >> 3, part = q & 7, gxs = w0 - kR + px;
-    const uint32_t poff = (piece && gxs >= 0 && gxs < W && c0 * ES + part * 16 < C * ES) ? static_cast<uint32_t>(gxs) * C * ES + c0 * ES + part * 16 : kOutOfRange;
-    const uint32_t poffg = (piece && gxs >= LW && gxs < LW + OW && c0 * ES + part * 16 < C * ES) ? static_cast<uint32_t>(gxs - LW) * C * ES + c0 * ES + part * 16 : kOutOfRange;
-    const int pdst = piece ? px * PITCHX + part * 4 : -1;   // (also the gradient's when it is channels-last: PITCHG == PITCHX then)
+    uint32_t poff[NPX], poffg[NPX];
+    int pdst[NPX];   // (also the gradient's when it is channels-last: PITCHG == PITCHX then)
+#pragma unroll
+    for (int k = 0; k < NPX; ++k) {
+        const int qk = q + k * kThreads;
+        const bool piece = qk < BPIECES;
+        const int px = qk >> 3, part = qk & 7, gxs = w0 - kR + px;
+        poff[k] = (piece && gxs >= 0 && gxs < W && c0 * ES + part * 16 < C * ES) ? static_cast<uint32_t>(gxs) * C * ES + c0 * ES + part * 16 : kOutOfRange;
+        poffg[k] = (piece && gxs >= LW && gxs < LW + OW && c0 * ES + part * 16 < C * ES) ? static_cast<uint32_t>(gxs - LW) * C * ES + c0 * ES + part * 16 : kOutOfRange;
+        pdst[k] = piece ? px * PITCHX + part * 4 : -1;
+    }
     const uint32_t row_bytes = static_cast<uint32_t>(W) * C * ES;
     constexpr int kDepth = CLT_DEPTH;
-    // GO_NCHW: element e = ch * kBPW + px of the staged gradient row, kGN per thread
-    constexpr int kGE = CB * kBPW, kGN = GO_NCHW ? (kGE + kThreads - 1) / kThreads : 1;
+    // GO_NCHW: element e = ch * BPW + px of the staged gradient row, kGN per thread
+    constexpr int kGE = CB * BPW, kGN = GO_NCHW ? (kGE + kThreads - 1) / kThreads : 1;
     struct GRow {
-        u4 v;                // the thread's 16-byte piece of a channels-last gradient row
+        u4 v[NPX];           // the thread's 16-byte pieces of a channels-last gradient row
         uint32_t e[kGN];     // GO_NCHW: its elements of the row's channel segments
     };
     uint32_t goff[kGN];      // byte offset of the element in row 0 of the (NCHW) image, or out of range
@@ -494,7 +507,7 @@ __global__ __launch_bounds__(kThreads) void cl_tiled_backward(const ClTiledBwdPa
     if constexpr (GO_NCHW) {
 #pragma unroll
         for (int k = 0; k < kGN; ++k) {
-            const int e = k * kThreads + q, ch = e / kBPW, pxe = e - ch * kBPW, gxe = w0 - kR + pxe;
+            const int e = k * kThreads + q, ch = e / BPW, pxe = e - ch * BPW, gxe = w0 - kR + pxe;
             const bool ok = e < kGE && gxe >= LW && gxe < LW + OW && c0 + ch < C;
             goff[k] = ok ? (static_cast<uint32_t>(c0 + ch) * OH * OW + (gxe - LW)) * ES : kOutOfRange;
             gdst[k] = e < kGE ? pxe * (PITCHG * 4) + ch * ES : -1;
@@ -516,25 +529,29 @@ __global__ __launch_bounds__(kThreads) void cl_tiled_backward(const ClTiledBwdPa
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int pxj = e0 + j - cstart;
-            gpdst[j] = (q < CB * kGPC && pxj >= 0 && pxj < kBPW) ? pxj * (PITCHG * 4) + ch * ES : -1;
+            gpdst[j] = (q < CB * kGPC && pxj >= 0 && pxj < BPW) ? pxj * (PITCHG * 4) + ch * ES : -1;
         }
     }
     const uint32_t grow_bytes = static_cast<uint32_t>(OW) * (GO_NCHW ? 1 : C) * ES;
-    u4 pvx[kDepth];
+    struct XRow {
+        u4 v[NPX];
+    };
+    XRow pvx[kDepth];
     GRow pvg[kDepth];
-    auto load_row = [&](int y, int ylast, u4 &vx, GRow &vg) {  // rows outside the image or beyond the band: nothing is read
+    auto load_row = [&](int y, int ylast, XRow &vx, GRow &vg) {  // rows outside the image or beyond the band: nothing is read
         // (a row that is not wanted: the out-of-range bit in the vector offset -- one scalar select per row; choosing between the
         //  image's resource and an empty one compiled to branches around duplicated loads)
         //  image's resource and an empty one compiled to branches around duplicated loads, and so did selects on "wanted": sign
         //  arithmetic instead)
         const int unwanted = (y >> 31) | ((ylast - y) >> 31);   // -1: above the image or beyond what the band needs
         const uint32_t so = static_cast<uint32_t>(y & ~unwanted) * row_bytes, dead = static_cast<uint32_t>(unwanted) & kOutOfRange;
-        vx = __builtin_amdgcn_raw_buffer_load_b128(xres, poff | dead, so, 0);
+#pragma unroll
+        for (int k = 0; k < NPX; ++k) vx.v[k] = __builtin_amdgcn_raw_buffer_load_b128(xres, poff[k] | dead, so, 0);
         const int unwanted_g = unwanted | ((y - LH) >> 31) | ((LH + OH - 1 - y) >> 31);   // grad_out's row y - LH
         const uint32_t sg = static_cast<uint32_t>((y - LH) & ~unwanted_g) * grow_bytes, dead_g = static_cast<uint32_t>(unwanted_g) & kOutOfRange;
         if constexpr (GO_NCHW) {
             if (g_pieces) {
-                vg.v = __builtin_amdgcn_raw_buffer_load_b128(gres, gpoff | dead_g, sg, 0);
+                vg.v[0] = __builtin_amdgcn_raw_buffer_load_b128(gres, gpoff | dead_g, sg, 0);
             } else {
 #pragma unroll
                 for (int k = 0; k < kGN; ++k) {
@@ -543,18 +560,22 @@ __global__ __launch_bounds__(kThreads) void cl_tiled_backward(const ClTiledBwdPa
                 }
             }
         } else {
-            vg.v = __builtin_amdgcn_raw_buffer_load_b128(gres, poffg | dead_g, sg, 0);
+#pragma unroll
+            for (int k = 0; k < NPX; ++k) vg.v[k] = __builtin_amdgcn_raw_buffer_load_b128(gres, poffg[k] | dead_g, sg, 0);
         }
     };
-    auto store_row = [&](int y, const u4 &vx, const GRow &vg) {
+    auto store_row = [&](int y, const XRow &vx, const GRow &vg) {
         const int slot = y & (kBRing - 1);
-        uint32_t *dx = ring + (pdst >= 0 ? slot * BROWX + pdst : kDump);
-        *reinterpret_cast<u4 *>(__builtin_assume_aligned(dx, 16)) = vx;   // 16-byte aligned pieces: one ds_write_b128, the 8 pieces of a pixel cover all banks
+#pragma unroll
+        for (int k = 0; k < NPX; ++k) {
+            uint32_t *dx = ring + (pdst[k] >= 0 ? slot * BROWX + pdst[k] : kDump);
+            *reinterpret_cast<u4 *>(__builtin_assume_aligned(dx, 16)) = vx.v[k];   // 16-byte aligned pieces: one ds_write_b128, the 8 pieces of a pixel cover all banks
+        }
         if constexpr (GO_NCHW) {
             char *gbase = reinterpret_cast<char *>(ring) + (BRINGX + slot * BROWG) * 4;
             char *dump = reinterpret_cast<char *>(ring) + kDump * 4;
             if (g_pieces) {
-                const uint32_t ge[4] = {vg.v.x, vg.v.y, vg.v.z, vg.v.w};
+                const uint32_t ge[4] = {vg.v[0].x, vg.v[0].y, vg.v[0].z, vg.v[0].w};
 #pragma unroll
                 for (int j = 0; j < 4; ++j) *reinterpret_cast<uint32_t *>(gpdst[j] >= 0 ? gbase + gpdst[j] : dump) = ge[j];
             } else {
@@ -566,12 +587,15 @@ __global__ __launch_bounds__(kThreads) void cl_tiled_backward(const ClTiledBwdPa
                 }
             }
         } else {
-            uint32_t *dg = ring + (pdst >= 0 ? BRINGX + slot * BROWG + pdst : kDump);
-            *reinterpret_cast<u4 *>(__builtin_assume_aligned(dg, 16)) = vg.v;
+#pragma unroll
+            for (int k = 0; k < NPX; ++k) {
+                uint32_t *dg = ring + (pdst[k] >= 0 ? BRINGX + slot * BROWG + pdst[k] : kDump);
+                *reinterpret_cast<u4 *>(__builtin_assume_aligned(dg, 16)) = vg.v[k];
+            }
         }
     };
     const int ylast = min(H - 1, h1 + kR);
-    u4 prex[2 * kR + 1];
+    XRow prex[2 * kR + 1];
     GRow preg[2 * kR + 1];
 #pragma unroll
     for (int d = 0; d < kDepth; ++d) load_row(h0 + kR + 1 + d, ylast, pvx[d], pvg[d]);
@@ -620,7 +644,7 @@ __global__ __launch_bounds__(kThreads) void cl_tiled_backward(const ClTiledBwdPa
         // (a column outside the window: zero gradient, nothing counted -- every map "padding")
         const int a0 = cpass[i] ? fold_w(wq - csxW) : -1, a1 = cpass[i] ? fold_w(wq - csxW + 1) : -1;
         const int b0 = cpass[i] ? fold_gw(wq - LW - csgW) : -1, b1 = (ACTIVE && cpass[i]) ? fold_gw(wq - LW - csgW + 1) : -1;
-        auto outside = [&](int sx) { return sx >= 0 && (sx < w0 - kR || sx > w0 + kBTW + kR); };
+        auto outside = [&](int sx) { return sx >= 0 && (sx < w0 - kR || sx > w0 + TW + kR); };
         scol[i] = near_c && w0 + col < W && (outside(a0) || outside(a1) || outside(b0) || outside(b1));
         live[i] = near_c && w0 + col < W && !scol[i];
         lcount[i] = (live[i] && cpass[i]) ? -1 : 0;
@@ -679,7 +703,7 @@ __global__ __launch_bounds__(kThreads) void cl_tiled_backward(const ClTiledBwdPa
     };
     int xrow1 = fold1(h0 - sh_s);   // the + 1 corner of step h - 1 is the first corner of step h
     int grow1 = fold1g(h0 - LH - gh_s);   // ... and so is the active shift's second gradient row
-    auto step = [&](int h, u4 &vx, GRow &vg) {
+    auto step = [&](int h, XRow &vx, GRow &vg) {
         __syncthreads();  // everybody is done with the slot that row h + R + 1 replaces (row h - R - 1)
         if (h + kR + 1 < H) store_row(h + kR + 1, vx, vg);
         __syncthreads();
@@ -830,9 +854,9 @@ __global__ __launch_bounds__(kThreads) void cl_tiled_backward(const ClTiledBwdPa
             const int fxH = canon_shift(fsh[1], H, p.pad, p.d_perH), fxW = canon_shift(fsh[2], W, p.pad, p.d_perW);
             const int fgH = canon_shift(ACTIVE ? fsh[1] : -fsh[1], OH, p.pad, p.d_perOH), fgW = canon_shift(ACTIVE ? fsh[2] : -fsh[2], OW, p.pad, p.d_perOW);
             double t0 = 0.0, t1 = 0.0;
-            const int nelem = (h1 - h0) * kBTW;
+            const int nelem = (h1 - h0) * TW;
             for (int q = static_cast<int>(threadIdx.x); q < nelem; q += kThreads) {
-                const int h = h0 + q / kBTW, wq = w0 + q % kBTW;
+                const int h = h0 + q / TW, wq = w0 + q % TW;
                 if (wq < W) far_element(cf, h, wq, fxH, fxW, fgH, fgW, ffr, t0, t1);
             }
             __syncthreads();
@@ -1362,13 +1386,15 @@ int cl_tiled_forward(const Geometry &g, int dtype, const void *x, const void *w,
 // ---- backward ------------------------------------------------------------------------------------------------------
 namespace {
 struct ClTiledBwdPlan {
-    int wtiles, cblocks, bands, band_rows;
+    int wtiles, cblocks, bands, band_rows, tw;
     int64_t groups;
 };
-ClTiledBwdPlan cl_tiled_backward_plan(const Geometry &g, int es = 4) {
+// tw: grad_x columns per workgroup (16; 32: the wide strip, round 6 -- a run's choice, the workspace is planned with 16: more groups)
+ClTiledBwdPlan cl_tiled_backward_plan(const Geometry &g, int es = 4, int tw = kBTW) {
     ClTiledBwdPlan pl;
     const int H = static_cast<int>(g.S[1]), W = static_cast<int>(g.S[2]);
-    pl.wtiles = (W + kBTW - 1) / kBTW;
+    pl.tw = tw;
+    pl.wtiles = (W + tw - 1) / tw;
     const int cbw = kLine / es;
     pl.cblocks = static_cast<int>((g.C + cbw - 1) / cbw);
     // bands along H: ~7 workgroups per workgroup slot, at least 8 R rows per band, and (when the batch allows) at most
@@ -1430,7 +1456,12 @@ void launch_cl_tiled_backward(const ClTiledBwdParams &p, const ClTiledBwdPlan &p
 
 int cl_tiled_backward(const Geometry &g, int dtype, const void *go, const void *x, const void *w, void *gx, void *gw,
                       void *workspace, hipStream_t st) {
-    const ClTiledBwdPlan pl = cl_tiled_backward_plan(g, dtype_size(dtype));
+    // (the wide strip, TW = 32 -- built and measured in round 6, same box, fp32 NHWC tensors, bit-identical grad_x over 360 shape /
+    //  padding / shift / window combinations: N16 C256 224x224 sparse 0.5115 -> 0.5216 ms, interpolating 0.5628 -> 0.5977; N32 C256
+    //  112x112 0.2875 -> 0.3043 / 0.3153 -> 0.3496; N64 C512 56x56 0.3018 -> 0.2983 / 0.3398 -> 0.3435.  The halo shrinks from 1.44 x to
+    //  1.22 x of the loads, but 80 KB of LDS and 211 - 227 VGPRs leave two workgroups per CU instead of three: no gain, not instantiated;
+    //  the kernel keeps its TW parameter)
+    const ClTiledBwdPlan pl = cl_tiled_backward_plan(g, dtype_size(dtype), kBTW);
     ClTiledBwdParams p{};
     p.x = static_cast<const char *>(x);
     p.go = static_cast<const char *>(go);

@@ -111,14 +111,31 @@ std::tuple<Tensor, std::vector<int64_t>> check_borders_op(const Tensor &input, c
 }
 
 // ---- Autograd key (ops/autograd/shifts_autograd.cpp) -------------------------------------------------
+bool is_channels_last_dense(const Tensor &t);
+Tensor channels_last_to_contiguous(const Tensor &t);
+
 template <int ND> struct ShiftFunction : public torch::autograd::Function<ShiftFunction<ND>> {
     static variable_list forward(AutogradContext *ctx, const Tensor &input, const Tensor &weight, const Tensor &borders,
                                  at::IntArrayRef new_size, int64_t padding_mode, bool active_flag) {
         at::AutoDispatchBelowADInplaceOrView guard;
-        auto output = call_forward<ND>(input, weight, borders, new_size, padding_mode, active_flag);
+        // (round 6) a dense NDHWC input on the GPU: the backward runs the contiguous kernels behind a layout change (the direct NDHWC
+        // backward is slower), and the forward through the layout change costs what the direct forward costs
+        // (N8 C128 16x112x112 fp32: 0.29 + 0.26 ms against 0.56; interpolating 0.57 against 0.71).  So the layout changes ONCE, here,
+        // and the node keeps the contiguous copy instead of the input -- the backward's 0.29 ms transpose of x is gone (1.04 -> 0.73
+        // ms with an NDHWC gradient, 0.74 -> 0.44 with the NCDHW gradient this forward's output produces); the values are the same,
+        // the original input can be freed as soon as nobody else holds it.
+        Tensor kept = input;
+        if constexpr (ND == 3) {
+            if (input.is_cuda() && !input.is_quantized() && input.dim() == 5 && at::isFloatingType(input.scalar_type()) &&
+                is_channels_last_dense(input)) {
+                c10::DeviceGuard device_guard(input.device());
+                kept = channels_last_to_contiguous(input);
+            }
+        }
+        auto output = call_forward<ND>(kept, weight, borders, new_size, padding_mode, active_flag);
         ctx->saved_data["padding_mode"] = padding_mode;
         ctx->saved_data["active_flag"] = active_flag;
-        ctx->save_for_backward({input, weight, borders});
+        ctx->save_for_backward({kept, weight, borders});
         return {output};
     }
     static variable_list backward(AutogradContext *ctx, const variable_list &grad_output) {

@@ -363,3 +363,31 @@ def test_channels_last_through_the_ops():
     w3 = (torch.rand(6, 3, device=DEV) * 4 - 2)
     assert torch.equal(TF.shift3d_func(x3.contiguous(memory_format=torch.channels_last_3d), w3, 2, True),
                        TF.shift3d_func(x3, w3, 2, True))
+
+
+def test_ndhwc_input_through_autograd_keeps_the_contiguous_copy():
+    """round 6: a dense NDHWC (channels_last_3d) input through the public op -- the autograd node changes the layout ONCE and keeps the
+    contiguous copy, so the backward runs the contiguous kernel on it (no second transpose of x).  Values: the CPU op's (= the
+    reference's) on the same tensors, forward and grad_x bit-exact in fp32, grad_w within 1e-5."""
+    from torchshifts import abi
+    torch.manual_seed(7)
+    x = torch.rand(2, 8, 5, 12, 16)
+    w = torch.rand(8, 3) * 5 - 2.5
+    for pad, active in ((0, False), (3, True), (2, True)):
+        xc, wc = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+        out_c = OPS.shift3d(xc, wc, torch.Tensor(), pad, active)
+        g = torch.rand_like(out_c)
+        out_c.backward(g)
+        xg = x.to(DEV).contiguous(memory_format=torch.channels_last_3d).requires_grad_(True)
+        wg = w.to(DEV).requires_grad_(True)
+        out_g = OPS.shift3d(xg, wg, torch.Tensor(), pad, active)
+        assert not abi.last_kernel().startswith("cl_"), abi.last_kernel()   # the contiguous forward on the copy
+        out_g.backward(g.to(DEV))
+        assert torch.equal(out_g.cpu(), out_c.detach()), (pad, active)
+        assert torch.equal(xg.grad.cpu(), xc.grad), (pad, active)
+        assert rel_err(wg.grad.cpu().numpy(), wc.grad.numpy()) < 1e-5
+        # the private op without autograd still takes the NDHWC tensor as it lies (direct kernel or its own layout change)
+        with torch.no_grad():
+            b = torch.tensor([0, 5, 0, 12, 0, 16], dtype=torch.int32)
+            o2 = OPS._shift3d_forward(xg.detach(), wg.detach(), b, [2, 8, 5, 12, 16], pad, active)
+            assert torch.equal(o2, out_g.detach())

@@ -126,8 +126,9 @@ template <int ND> struct ShiftFunction : public torch::autograd::Function<ShiftF
         // the original input can be freed as soon as nobody else holds it.
         Tensor kept = input;
         if constexpr (ND == 3) {
-            if (input.is_cuda() && !input.is_quantized() && input.dim() == 5 && at::isFloatingType(input.scalar_type()) &&
-                is_channels_last_dense(input)) {
+            // (only when a backward can follow: an inference call keeps the direct NDHWC forward)
+            if ((input.requires_grad() || weight.requires_grad()) && input.is_cuda() && !input.is_quantized() && input.dim() == 5 &&
+                at::isFloatingType(input.scalar_type()) && is_channels_last_dense(input)) {
                 c10::DeviceGuard device_guard(input.device());
                 kept = channels_last_to_contiguous(input);
             }

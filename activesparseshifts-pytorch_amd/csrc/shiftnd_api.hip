@@ -660,6 +660,12 @@ static int backward_pooled_planned(const shiftnd_problem *p, const int32_t *pool
         g_last_path = SHIFTND_PATH_PLANE;
         return finish(step_backward(g, p->dtype, grad_pooled, x, weights, grad_x, grad_w, workspace, st));
     }
+    // cropped 3-D volumes, 2 x 2 x 2 windows: crop_backward3 with the pooled gradient expanded on its way into LDS (round 6)
+    if (g_policy == 0 && g.nd == 3 && span_backward_pooled_eligible(g, p->dtype, grad_pooled, x, grad_x)) {
+        if (span_backward_pooled_workspace(g, p->dtype) > workspace_bytes) return SHIFTND_ERR_WORKSPACE_TOO_SMALL;
+        g_last_path = SHIFTND_PATH_PLANE;
+        return finish(span_backward(g, p->dtype, grad_pooled, x, weights, grad_x, grad_w, workspace, st));
+    }
     if (!plane_pool_backward_eligible(g, p->dtype, grad_x)) return SHIFTND_ERR_NOT_FUSED;
     // what the walk does not take of the 3-D interpolating backward: through the band-walk kernels 16 gradient corner rows per
     // step would be expanded from pooled rows -- measured slower than avg_pool backward + shiftnd_backward (N8 C128 16x112x112:

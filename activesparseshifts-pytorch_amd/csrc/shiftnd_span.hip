@@ -52,6 +52,7 @@ struct SpanParams {
     int R, rsteps, spp;  // rows per step, row steps per plane, steps per plane = rsteps * nseg
     int P;               // pieces per slot
     int P2;              // crop_backward<.., POOL>: elements per row of the pooled gradient (2 x 2 windows)
+    int P1;              // crop_backward3<.., POOL>: rows per plane of the pooled gradient
     uint32_t total_steps, steps_per_xcd;
     FastDiv d_spp, d_C, d_seg, d_nseg, d_P, d_per1x, d_per2x, d_per1g, d_per2g;
     FastDiv d_rsteps, d_per0x, d_per0g;   // crop_backward3
@@ -487,7 +488,10 @@ __global__ __launch_bounds__(kThreads) void crop_backward(const SpanParams p) {
 // one record per step, step_reduce<.., 3> as for the walk kernels.  Reference: kernels/shifts_kernels.h:222-327 with the window of
 // ops/shifts.cpp:93-135.  x rows of whole 16-byte pieces, every dim of the volume and of the window at least 2 (host).
 // ---------------------------------------------------------------------------------------------------------------------
-template <typename T, bool ACTIVE, int PAD>
+// POOL: the 2 x 2 x 2 average pool behind the cropped shift (emulate_dw with stride 2) -- `go` is the gradient of the POOLED window
+// [P0, P1, P2]; a staged gradient row is its pooled row expanded at phase 0 (crop_backward<.., POOL>'s branch-free expansion with the
+// plane's window count as one more power of two), which saves ATen's pool backward and its full-size gradient tensor.
+template <typename T, bool ACTIVE, int PAD, bool POOL = false>
 __global__ __launch_bounds__(kThreads) void crop_backward3(const SpanParams p) {
     using S = typename T::S;
     using CT = typename T::C;
@@ -551,7 +555,7 @@ __global__ __launch_bounds__(kThreads) void crop_backward3(const SpanParams p) {
     }
     // gradient rows as covers: row `vr` of the window VOLUME (plane * O1 + row) starts vrow_lo(vr) bytes into the stream of pieces
     auto vrow_lo = [&](int vr) { return gph + vr * O2 * ES; };
-    auto gphase = [&](int vr) { return vrow_lo(vr) & 15; };
+    auto gphase = [&](int vr) { return POOL ? 0 : (vrow_lo(vr) & 15); };
     const int PGi = cpr + 2;
     const int rg = static_cast<int>(fdiv(static_cast<uint32_t>(tid), p.d_P)), pg = tid - rg * PGi;
     auto dma_g = [&](int vr, int piece, int lds_piece0) {
@@ -562,12 +566,77 @@ __global__ __launch_bounds__(kThreads) void crop_backward3(const SpanParams p) {
                                              (__attribute__((address_space(3))) void *)dst_wave, 16, 0, 0);
         }
     };
+    // POOL: the expanded piece `piece` (window columns E piece ..) of row `row` of window plane `pl`
+    struct Pooled {
+        uint64_t raw;   // the E / 2 pooled elements under the piece
+        int lg;         // log2 of (planes x rows) of the pooled element's window
+        int dst;        // tile piece (-1: none)
+        int col;
+    };
+    constexpr int HP = E >= 2 ? E / 2 : 1;
+    const int opieces = (O2 * ES + 15) >> 4;
+    auto pooled_load = [&](int pl, int row, int piece, int dst) {
+        Pooled q;
+        q.dst = (pl >= 0 && row >= 0 && piece < opieces) ? dst : -1;
+        q.col = piece;
+        const int pp = max(pl, 0) >> 1, pr = max(row, 0) >> 1;
+        q.lg = ((O0 - 2 * pp >= 2) ? 1 : 0) + ((O1 - 2 * pr >= 2) ? 1 : 0);
+        const S *prow = gp + (static_cast<int64_t>(pp) * p.P1 + pr) * p.P2;
+        const int first = piece * HP, start = max(min(first, p.P2 - HP), 0);   // (P2 >= HP: host)
+        if constexpr (ES == 8) {
+            q.raw = *reinterpret_cast<const uint64_t *>(prow + start);
+        } else {
+            uint64_t v;
+            const Chunk<S, HP> h = load_chunk<S, HP>(prow + start);
+            __builtin_memcpy(&v, h.e, 8);
+            q.raw = v >> (static_cast<unsigned>(min(first - start, HP - 1)) * (8u * ES));
+        }
+        return q;
+    };
+    auto pooled_store = [&](const Pooled &q) {
+        Chunk<S, E> out;
+#pragma unroll
+        for (int h = 0; h < HP; ++h) {
+            typename raw_t<ES>::type bits = static_cast<typename raw_t<ES>::type>(ES == 8 ? q.raw : (q.raw >> (h * 8 * (ES == 8 ? 0 : ES))));
+            const CT val = widen<T>(__builtin_bit_cast(S, bits));
+            const int kk = q.lg + ((O2 - 2 * (q.col * HP + h) >= 2) ? 1 : 0);   // log2 of the window's size
+            CT scale;
+            if constexpr (sizeof(CT) == 4) scale = __builtin_bit_cast(float, static_cast<uint32_t>(127 - kk) << 23);
+            else scale = __builtin_bit_cast(double, static_cast<uint64_t>(1023 - kk) << 52);
+            const S v = narrow<T>(val * scale);
+            if constexpr (E >= 2) {
+                out.e[2 * h] = v;
+                out.e[2 * h + 1] = v;
+            } else {
+                out.e[0] = v;
+            }
+        }
+        if (q.dst >= 0) __builtin_memcpy(__builtin_assume_aligned(tile + q.dst * 16, 16), out.e, 16);
+    };
     auto gs_row = [&](int i, bool have) {   // the window row grad_x reads at step row i (through the row map), or -1
         const int pr = b0 + i - L1;
         const bool dom = have && pr >= 0 && (ACTIVE ? pr <= O1 : pr < O1);
         return dom ? row_map_t<PAD>(pr, d.cg1, O1, p.pad) : -1;
     };
-    {
+    if constexpr (POOL) {
+        const int ro = (in_vol && rg < R && rg < Rn && b0 + rg - L1 >= 0 && b0 + rg - L1 < O1) ? b0 + rg - L1 : -1;   // the step's own rows
+        const Pooled qa = pooled_load(ao, ro, pg, goff / 16 + tid);
+        const int r0 = gs_row(rg, rg < R && (ACTIVE ? rg <= Rn : rg < Rn));
+        const int r1 = (ACTIVE && Rn == R && tid < PGi) ? gs_row(R, true) : -1;
+        Pooled qb[NPG], qc[NPG];
+#pragma unroll
+        for (int h = 0; h < NPG; ++h) {
+            qb[h] = pooled_load(pag[h], r0, pg, gsoff / 16 + h * (R + 1) * PGi + tid);
+            qc[h] = qb[h];
+            if constexpr (ACTIVE) qc[h] = pooled_load(pag[h], r1, tid, gsoff / 16 + (h * (R + 1) + R) * PGi + tid);
+        }
+        pooled_store(qa);
+#pragma unroll
+        for (int h = 0; h < NPG; ++h) {
+            pooled_store(qb[h]);
+            if constexpr (ACTIVE) pooled_store(qc[h]);
+        }
+    } else {
         const int ro = (in_vol && rg < R && rg < Rn && b0 + rg - L1 >= 0 && b0 + rg - L1 < O1) ? ao * O1 + b0 + rg - L1 : -1;   // the step's own rows
         dma_g(ro, pg, goff / 16);
 #pragma unroll
@@ -1527,7 +1596,8 @@ static bool span_geometry_ok(const Geometry &g, int dtype, bool pooled) {
     if (dtype > SHIFTND_BF16 || g.nd < 1 || g.nd > 3 || (g.K[0] > 0) != pooled) return false;
     const int es = dtype_size(dtype);
     // (pooled: 2 x 2 windows on 2-D planes; windows of 2 on 1-D rows -- row_backward<.., POOL>)
-    if (pooled && (g.nd == 3 || (g.S[2] * es) % 16 != 0 || g.K[1] != (g.nd == 2 ? 2 : 1) || g.K[2] != 2 || g.P[2] < std::max(1, 8 / es))) return false;
+    if (pooled && ((g.S[2] * es) % 16 != 0 || g.K[0] != (g.nd == 3 ? 2 : 1) || g.K[1] != (g.nd >= 2 ? 2 : 1) || g.K[2] != 2 ||
+                   g.P[2] < std::max(1, 8 / es) || (g.nd == 3 && es == 8))) return false;   // (3-D pooled: 2- / 4-byte elements)
     if (g.nd == 3) {   // crop_backward3: x rows of whole pieces, every dim of the volume and of the window at least 2
         if (g.S[0] < 2 || g.S[1] < 2 || g.S[2] < 2 || g.O[0] < 2 || g.O[1] < 2 || g.O[2] < 2 || (g.S[2] * es) % 16 != 0) return false;
         if (g.S[0] * g.S[1] * g.S[2] >= (1LL << 28) || g.O[0] * g.O[1] * g.O[2] >= (1LL << 28)) return false;   // 32-bit byte offsets within a volume
@@ -1971,6 +2041,11 @@ bool span_backward_pooled_eligible(const Geometry &g, int dtype, const void *go,
     if (reinterpret_cast<uintptr_t>(go) % dtype_size(dtype) || reinterpret_cast<uintptr_t>(x) % 16 || reinterpret_cast<uintptr_t>(gx) % 16) return false;
     if (g.pad == 0 && g.O[2] == 1) return false;   // (as span_backward_eligible: the affine column state)
     if (g.nd == 1) return g.S[2] * dtype_size(dtype) / 16 >= 128 || g_step_tune[0] == 2;   // (short rows: the per-channel kernels, as unpooled)
+    if (g.nd == 3) {   // cropped volumes (the walk takes the others), as crop_backward3
+        bool crop3 = false;
+        for (int d = 0; d < 3; ++d) crop3 = crop3 || g.O[d] != g.S[d] || g.L[d] != 0;
+        return crop3 && !(g_step_tune[3] & 1024);
+    }
     return true;
 }
 size_t span_backward_pooled_workspace(const Geometry &g, int dtype) { return span_geometry_ok(g, dtype, true) ? span_plan(g, dtype_size(dtype)).bytes : 0; }
@@ -1988,7 +2063,7 @@ static void launch_span_backward(const SpanParams &p, const SpanPlan &sp, bool a
         } else if constexpr (ND == 2) { \
             hipLaunchKernelGGL((crop_backward<T, ACT, PADV, XRAG, POOL>), grid, block, sp.lds, st, p); \
         } else if constexpr (ND == 3) { \
-            hipLaunchKernelGGL((crop_backward3<T, ACT, PADV>), grid, block, sp.lds, st, p); \
+            hipLaunchKernelGGL((crop_backward3<T, ACT, PADV, POOL>), grid, block, sp.lds, st, p); \
         } else { \
             hipLaunchKernelGGL((row_backward<T, ACT, PADV, POOL>), grid, block, sp.lds, st, p); \
         } \
@@ -2037,7 +2112,8 @@ int span_backward(const Geometry &g, int dtype, const void *go, const void *x, c
     const bool pooled = g.K[0] > 0;
     if (pooled) {   // `go` is the gradient of the pooled window [P1, P2]
         p.P2 = static_cast<int>(g.P[2]);
-        p.g_plane = g.P[1] * g.P[2];
+        p.P1 = static_cast<int>(g.P[1]);
+        p.g_plane = g.P[0] * g.P[1] * g.P[2];   // (2-D / 1-D: P0 = 1)
     }
     p.wkind = dtype;
     p.N = static_cast<int>(g.N);
@@ -2072,6 +2148,15 @@ int span_backward(const Geometry &g, int dtype, const void *go, const void *x, c
     p.d_per0x = make_fastdiv(static_cast<uint32_t>(map_period(p.S0, g.pad)));
     p.d_per0g = make_fastdiv(static_cast<uint32_t>(map_period(p.O0, g.pad)));
     const bool active = g.active != 0;
+    if (g.nd == 3 && pooled) {
+        note_kernel("crop_backward3_pool");
+        switch (dtype) {
+        case SHIFTND_F32: launch_span_backward<f32_t, 3, false, true>(p, sp, active, gw, st); break;
+        case SHIFTND_F16: launch_span_backward<f16_t, 3, false, true>(p, sp, active, gw, st); break;
+        default: launch_span_backward<bf16_t, 3, false, true>(p, sp, active, gw, st); break;
+        }
+        return SHIFTND_OK;
+    }
     if (g.nd == 3) {
         note_kernel("crop_backward3");
         switch (dtype) {

@@ -48,6 +48,9 @@ CASES = [  # nd, shape, pool, crop
     (2, (1, 3, 16, 40), (3, 3), [[1, 1], [1, 1]]),
     (2, (2, 2, 11, 28), (2, 2), [[0, 2], [3, 0]]),
     (2, (2, 3, 9, 4), (2, 2), [[1, 1], [1, 1]]),
+    # cropped 3-D volumes with the 2 x 2 x 2 pool: crop_backward3<.., POOL> (fp32; fp64 composes the pool's backward and crop_backward3)
+    (3, (2, 3, 6, 9, 16), (2, 2, 2), [[1, 1], [1, 1], [1, 1]]),
+    (3, (1, 4, 5, 8, 12), (2, 2, 2), [[0, 1], [1, 0], [0, 2]]),
 ]
 
 
@@ -82,6 +85,14 @@ def test_pooled_vs_oracle(abi, dt):
                         and (shape[-1] * x.itemsize) % 16 == 0)   # (both shifts)
                 # (round 6) a cropped 3-D volume crop_backward3 serves is not fused either: avg_pool backward + crop_backward3 is faster
                 crop3 = (nd == 3 and crop is not None and (shape[-1] * x.itemsize) % 16 == 0 and min(shape[2:]) >= 2 and min(new[2:]) >= 2)
+                # ... unless the windows are 2 x 2 x 2 (4-byte elements here): crop_backward3<.., POOL> fuses the pool
+                fused3 = crop3 and tuple(pool) == (2, 2, 2) and x.itemsize == 4 and -(-new[-1] // 2) >= 2
+                if fused3:
+                    gx, gw = abi.backward_pooled(_dev(gp), wd, xd, pad, active, pool, b)
+                    assert abi.last_kernel() == "crop_backward3_pool", key + (abi.last_kernel(),)
+                    assert np.array_equal(gx.cpu().numpy(), gx_r), key
+                    assert rel_err(gw.cpu().numpy(), gw_r) < 1e-5, key
+                    continue
                 if nd == 3 and ((active and not walk) or crop3):
                     with pytest.raises(RuntimeError, match="not served"):
                         abi.backward_pooled(_dev(gp), wd, xd, pad, active, pool, b)

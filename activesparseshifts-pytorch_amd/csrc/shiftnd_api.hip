@@ -594,6 +594,11 @@ int shiftnd_forward_pooled(const shiftnd_problem *p, const int32_t *pool, const 
         g_last_path = SHIFTND_PATH_SWEEP;
         return finish(step_forward_pooled(g, p->dtype, x, weights, p->dtype, out, static_cast<hipStream_t>(stream)));
     }
+    // 3-D volumes, 2 x 2 x 2 windows, cropped or not (what the walk above does not take): pooled rows through LDS (round 6)
+    if (g_policy == 0 && span_forward_pooled3_eligible(g, p->dtype, x, out)) {
+        g_last_path = SHIFTND_PATH_PLANE;
+        return finish(span_forward_pooled3(g, p->dtype, x, weights, p->dtype, out, static_cast<hipStream_t>(stream)));
+    }
     // 1-D rows of at least 128 chunks, windows of 2: row_forward with the pool as its epilogue (round 6)
     if (g_policy == 0 && span_forward_pooled_eligible(g, p->dtype, x, out)) {
         g_last_path = SHIFTND_PATH_PLANE;

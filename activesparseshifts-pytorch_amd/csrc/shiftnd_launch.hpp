@@ -93,6 +93,8 @@ bool span_forward_eligible(const Geometry &g, int dtype, const void *x, const vo
 int span_forward(const Geometry &g, int dtype, const void *x, const void *w, int wkind, void *out, hipStream_t st);
 bool span_backward_eligible(const Geometry &g, int dtype, const void *go, const void *x, const void *gx);
 size_t span_backward_workspace(const Geometry &g, int dtype);
+bool span_forward_pooled3_eligible(const Geometry &g, int dtype, const void *x, const void *out);
+int span_forward_pooled3(const Geometry &g, int dtype, const void *x, const void *w, int wkind, void *out, hipStream_t st);
 bool span_forward_pooled_eligible(const Geometry &g, int dtype, const void *x, const void *out);
 int span_forward_pooled(const Geometry &g, int dtype, const void *x, const void *w, int wkind, void *out, hipStream_t st);
 bool span_backward_pooled_eligible(const Geometry &g, int dtype, const void *go, const void *x, const void *gx);

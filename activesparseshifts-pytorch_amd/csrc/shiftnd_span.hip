@@ -776,6 +776,7 @@ struct SpanFwdParams {
     int S1, S2, O1, O2, L1, L2;
     int S0, O0, L0, rsteps;   // crop_forward3: planes of the input volume / of the window, its first plane, row steps per output plane
     int P2;                   // row_forward<.., POOL>: elements per pooled row
+    int P0, P1;               // crop_forward3_pool: planes / rows of the pooled volume
     int ocp, cps, spp;   // 16-byte chunks per output plane, chunks per step (256; 254 when only a column segment is staged), steps per plane
     int P, wholeP;       // pieces per slot; the same when whole rows are staged (0: only the columns the step reaches)
     uint32_t total_steps, steps_per_xcd;
@@ -1177,6 +1178,151 @@ __global__ __launch_bounds__(kThreads) void crop_forward3(const SpanFwdParams p)
             if (ji + e < O2) dst[e] = res.e[e];
     }
     (void)RBX;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// crop_forward3_pool (round 6): Shift3d + avg_pool3d(kernel = stride = 2, ceil_mode) in one pass, cropped or not -- crop_forward3's
+// shape with POOLED rows: a step is R pooled rows of one pooled plane pa; it stages the 2 R (+ 1) source rows of the two (interpolating:
+// three) source planes under the window planes 2 pa, 2 pa + 1; thread (tr, tc) produces the up to four shift outputs (2 planes x 2 rows)
+// of E columns -- rounded to the storage type like the unfused sequence's shift output -- sums their windows in ATen's order (plane, row,
+// column) and stores E / 2 pooled elements.  p.O0 / O1 / O2: the (virtual) shift output; `out`: the pooled volume [P0, P1, P2].
+// The band-walk kernel ran N8 C128 16x112x112 bf16 cut 1/1/1 pool 2 at 0.34 ms (1.3 TB/s).
+// ---------------------------------------------------------------------------------------------------------------------
+template <typename T, bool ACTIVE, int PAD>
+__global__ __launch_bounds__(kThreads) void crop_forward3_pool(const SpanFwdParams p) {
+    using S = typename T::S;
+    using CT = typename T::C;
+    constexpr int ES = sizeof(S);
+    constexpr int E = 16 / ES;
+    static_assert(E >= 2, "2- / 4-byte elements");
+    constexpr int NPS = ACTIVE ? 3 : 2;   // source planes of a step
+    constexpr int XR = ACTIVE ? 1 : 0;    // the + 1 corner row
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char *tile = smem + 64;
+
+    const uint32_t bid = (blockIdx.x & 7u) * p.steps_per_xcd + (blockIdx.x >> 3);
+    if (bid >= p.total_steps) return;
+    const uint32_t plane = fdiv(bid, p.d_spp);   // (n, c)
+    const uint32_t vstep = bid - plane * static_cast<uint32_t>(p.spp);
+    const int pa = static_cast<int>(fdiv(vstep, p.d_rsteps));   // the pooled plane
+    const int step = static_cast<int>(vstep) - pa * p.rsteps;
+    const int c = static_cast<int>(plane - fdiv(plane, p.d_C) * static_cast<uint32_t>(p.C));
+    CT wv[3];
+    {
+        const int wcol[3] = {0, 1, 2};
+        load_weights3<CT>(p.w, p.wkind, static_cast<int64_t>(c) * 3, wcol, wv);
+    }
+    CT rr[3], dw[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        rr[k] = ACTIVE ? c_floor<CT>(wv[k]) : c_rint<CT>(wv[k]);
+        dw[k] = ACTIVE ? wv[k] - rr[k] : CT(0);
+    }
+    const int S0 = p.S0, S1 = p.S1, S2 = p.S2, O0 = p.O0, O1 = p.O1, O2 = p.O2, L0 = p.L0, L1 = p.L1, L2 = p.L2;
+    const int cpr = p.ocp, R = p.cps, PX = p.P;   // chunks per virtual output row, POOLED rows per step, pieces per source row
+    const int cs0 = __builtin_amdgcn_readfirstlane(canon_of<PAD, CT>(rr[0], S0, p.d_per0, p.pad));
+    const int cs1 = __builtin_amdgcn_readfirstlane(canon_of<PAD, CT>(rr[1], S1, p.d_per1, p.pad));
+    const int cs2 = __builtin_amdgcn_readfirstlane(canon_of<PAD, CT>(rr[2], S2, p.d_per2, p.pad));
+    const int pr0 = step * R, Rn = min(R, p.P1 - pr0);
+    const int NR = 2 * R + XR;                                   // staged rows per plane (slots)
+    const int nrows = min(2 * Rn, O1 - 2 * pr0) + XR;            // ... of which this step needs the first `nrows`
+    const S *xp = static_cast<const S *>(p.x) + static_cast<int64_t>(plane) * p.x_plane;
+    int pl[NPS];   // source planes under the window planes 2 pa (+ 1 (+ 2)); -1: padding, or beyond what the window's planes need
+    const int n0 = min(2, O0 - 2 * pa);   // planes of this pooled plane's windows
+#pragma unroll
+    for (int k = 0; k < NPS; ++k) pl[k] = k < n0 + XR ? row_map_t<PAD>(2 * pa + k + L0, cs0, S0, p.pad) : -1;
+    const int tid = static_cast<int>(threadIdx.x);
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int TP = NR * PX;   // pieces per staged plane
+    auto src_row = [&](int j) { return row_map_t<PAD>(2 * pr0 + j + L1, cs1, S1, p.pad); };   // (-1: padding)
+    {
+        const int rg = static_cast<int>(fdiv(static_cast<uint32_t>(tid), p.d_P)), pg = tid - rg * PX;
+        const int sr = rg < nrows ? src_row(rg) : -1;
+#pragma unroll
+        for (int k = 0; k < NPS; ++k) {
+            if (pl[k] < 0 || sr < 0) continue;
+            char *dst_wave = tile + (k * TP + wave * 64) * 16;
+            const uint32_t off = static_cast<uint32_t>((pl[k] * S1 + sr) * S2 * ES + pg * 16);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(reinterpret_cast<const char *>(xp) + off),
+                                             (__attribute__((address_space(3))) void *)dst_wave, 16, 0, 0);
+        }
+    }
+    const int tr = static_cast<int>(fdiv(static_cast<uint32_t>(tid), p.d_O2)), tc = tid - tr * cpr;   // (d_O2 divides by cpr here)
+    const int ji = tc * E;
+    ColState<E> xm;
+    if constexpr (PAD == 0) {
+        const int first = ji + L2 - cs2;
+        xm.base = (first + E < 0 || first >= S2) ? 0 : first;
+        xm.affine = true;
+#pragma unroll
+        for (int e = 0; e <= E; ++e) xm.cm[e] = static_cast<unsigned>(first + e) < static_cast<unsigned>(S2) ? first + e : -1;
+    } else {
+        xm = fold_colstate<E, PAD>(ji + L2, cs2, S2, p.pad);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tr >= R || tr >= Rn) return;
+    const int pr = pr0 + tr;
+    const int n1 = min(2, O1 - 2 * pr);   // rows of this pooled row's windows
+    auto read_row = [&](int k, int slot, S (&raw)[E + 1]) {
+        const bool valid = pl[k] >= 0 && slot < nrows && src_row(slot) >= 0;
+        const char *row = tile + (k * TP + slot * PX) * 16;
+        if constexpr (PAD == 0) lds_read_row_affine<S, E>(row, valid, xm, raw);
+        else lds_read_row<S, E>(row, valid, xm, raw);
+    };
+    CT acc[E / 2];
+#pragma unroll
+    for (int j = 0; j < E / 2; ++j) acc[j] = CT(0);
+#pragma unroll
+    for (int ha = 0; ha < 2; ++ha) {
+#pragma unroll
+        for (int hb = 0; hb < 2; ++hb) {
+            if (ha >= n0 || hb >= n1) continue;   // (a ragged last window: the plane / row does not exist)
+            const int slot = 2 * tr + hb;
+            CT y[E];   // the shift's output at window plane 2 pa + ha, row 2 pr + hb, columns ji ..
+            if constexpr (ACTIVE) {
+                CT xv[4][E + 1];   // corner k: bit 0 = + 1 plane, bit 1 = + 1 row
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    S raw[E + 1];
+                    read_row(ha + (k & 1), slot + (k >> 1), raw);
+#pragma unroll
+                    for (int e = 0; e <= E; ++e) xv[k][e] = widen<T>(raw[e]);
+                }
+#pragma unroll
+                for (int e = 0; e < E; ++e) {
+                    CT v[8];
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) v[q] = xv[q & 3][e + (q >> 2)];
+                    y[e] = widen<T>(narrow<T>(interp_t<T, 3>(v, dw)));
+                }
+            } else {
+                S raw[E + 1];
+                read_row(ha, slot, raw);
+#pragma unroll
+                for (int e = 0; e < E; ++e) y[e] = widen<T>(raw[e]);
+            }
+#pragma unroll
+            for (int j = 0; j < E / 2; ++j) {
+                acc[j] = acc[j] + y[2 * j];
+                if (ji + 2 * j + 1 < O2) acc[j] = acc[j] + y[2 * j + 1];
+            }
+        }
+    }
+    S pooled[E / 2];
+#pragma unroll
+    for (int j = 0; j < E / 2; ++j) pooled[j] = narrow<T>(div_count<CT>(acc[j], n0 * n1 * ((ji + 2 * j + 1 < O2) ? 2 : 1)));
+    S *dst = static_cast<S *>(p.out) + static_cast<int64_t>(plane) * p.o_plane + (static_cast<int64_t>(pa) * p.P1 + pr) * p.P2 + ji / 2;
+    if (ji + E <= O2 + 1 && (ES >= 4 || (p.P2 & 1) == 0)) {   // all E / 2 pooled elements exist, the row at a 4-byte boundary
+        typedef typename vec_of<8>::type v8 __attribute__((aligned(4)));
+        typename vec_of<8>::type bits;
+        __builtin_memcpy(&bits, pooled, 8);
+        *reinterpret_cast<v8 *>(dst) = bits;
+    } else {
+#pragma unroll
+        for (int j = 0; j < E / 2; ++j)
+            if (ji + 2 * j < O2) dst[j] = pooled[j];
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -1726,6 +1872,82 @@ static int crop_forward_groups(const Geometry &g, int es) {
     const int64_t ocp = (g.O[1] * g.O[2] * es + 15) / 16;
     if (ocp <= 2 * kThreads) return 1;
     return crop_forward_rows(g, es, 2 * kThreads) * (g.S[2] * es / 16) <= 6 * kThreads ? 2 : 1;
+}
+
+// Shift3d + avg_pool3d(2) in one pass (crop_forward3_pool, round 6): 2 x 2 x 2 windows, cropped or not, both shifts; 2- / 4-byte float
+// elements, source rows of whole pieces (at most 85: 2 R + 1 staged rows per plane with R >= 1), every dim of the volume and of the
+// window at least 2
+bool span_forward_pooled3_eligible(const Geometry &g, int dtype, const void *x, const void *out) {
+    if (g_step_tune[2] == 1 || (g_step_tune[3] & 1024) || g.nd != 3 || g.K[0] != 2 || g.K[1] != 2 || g.K[2] != 2) return false;
+    if (dtype != SHIFTND_F32 && dtype != SHIFTND_F16 && dtype != SHIFTND_BF16) return false;
+    const int es = dtype_size(dtype);
+    for (int d = 0; d < 3; ++d)
+        if (g.S[d] < 2 || g.O[d] < 2) return false;
+    if ((g.S[2] * es) % 16 != 0 || 3 * (g.S[2] * es / 16) > kThreads) return false;
+    if (g.S[0] * g.S[1] * g.S[2] >= (1LL << 28)) return false;
+    if (!dense(g.xs, g.N, g.C, g.S)) return false;
+    if (reinterpret_cast<uintptr_t>(x) % 16 || reinterpret_cast<uintptr_t>(out) % (es < 4 ? 4 : es)) return false;
+    const int64_t xcpr = g.S[2] * es / 16, R = std::max<int64_t>(1, std::min<int64_t>(g.P[1], (kThreads / xcpr - 1) / 2));
+    return g.N * g.C * g.P[0] * ((g.P[1] + R - 1) / R) + 8 < (1LL << 31);
+}
+
+int span_forward_pooled3(const Geometry &g, int dtype, const void *x, const void *w, int wkind, void *out, hipStream_t st) {
+    const int es = dtype_size(dtype);
+    SpanFwdParams p{};
+    p.x = x;
+    p.out = out;
+    p.w = w;
+    p.wkind = wkind;
+    p.C = static_cast<int>(g.C);
+    p.nd = 3;
+    p.pad = g.pad;
+    p.S0 = static_cast<int>(g.S[0]);
+    p.S1 = static_cast<int>(g.S[1]);
+    p.S2 = static_cast<int>(g.S[2]);
+    p.O0 = static_cast<int>(g.O[0]);
+    p.O1 = static_cast<int>(g.O[1]);
+    p.O2 = static_cast<int>(g.O[2]);
+    p.L0 = static_cast<int>(g.L[0]);
+    p.L1 = static_cast<int>(g.L[1]);
+    p.L2 = static_cast<int>(g.L[2]);
+    p.P0 = static_cast<int>(g.P[0]);
+    p.P1 = static_cast<int>(g.P[1]);
+    p.P2 = static_cast<int>(g.P[2]);
+    p.x_plane = g.S[0] * g.S[1] * g.S[2];
+    p.o_plane = g.P[0] * g.P[1] * g.P[2];
+    p.P = static_cast<int>(g.S[2] * es / 16);                      // pieces per staged source row
+    p.ocp = static_cast<int>((g.O[2] * es + 15) / 16);             // chunks per virtual output row
+    p.cps = static_cast<int>(std::max<int64_t>(1, std::min<int64_t>(g.P[1], (kThreads / p.P - 1) / 2)));   // pooled rows per step
+    p.rsteps = (p.P1 + p.cps - 1) / p.cps;
+    p.spp = p.rsteps * p.P0;
+    const uint64_t total = static_cast<uint64_t>(g.N) * g.C * p.spp;
+    p.total_steps = static_cast<uint32_t>(total);
+    p.steps_per_xcd = static_cast<uint32_t>((total + 7) / 8);
+    p.d_spp = make_fastdiv(static_cast<uint32_t>(p.spp));
+    p.d_C = make_fastdiv(static_cast<uint32_t>(p.C));
+    p.d_O2 = make_fastdiv(static_cast<uint32_t>(p.ocp));
+    p.d_P = make_fastdiv(static_cast<uint32_t>(p.P));
+    p.d_rsteps = make_fastdiv(static_cast<uint32_t>(p.rsteps));
+    p.d_per0 = make_fastdiv(static_cast<uint32_t>(map_period(p.S0, g.pad)));
+    p.d_per1 = make_fastdiv(static_cast<uint32_t>(map_period(p.S1, g.pad)));
+    p.d_per2 = make_fastdiv(static_cast<uint32_t>(map_period(p.S2, g.pad)));
+    const bool act = g.active != 0;
+    const size_t lds = 64 + static_cast<size_t>(act ? 3 : 2) * (2 * p.cps + 1) * p.P * 16 + 64;
+    note_kernel("crop_forward3_pool");
+    const dim3 grid(p.steps_per_xcd * 8), block(kThreads);
+#define SHIFTND_CROP3_POOL(TT, ACT) \
+    switch (pad_template(g.pad)) { \
+    case 0: hipLaunchKernelGGL((crop_forward3_pool<TT, ACT, 0>), grid, block, lds, st, p); break; \
+    case 1: hipLaunchKernelGGL((crop_forward3_pool<TT, ACT, 1>), grid, block, lds, st, p); break; \
+    case 2: hipLaunchKernelGGL((crop_forward3_pool<TT, ACT, 2>), grid, block, lds, st, p); break; \
+    default: hipLaunchKernelGGL((crop_forward3_pool<TT, ACT, kPadMirror>), grid, block, lds, st, p); break; \
+    }
+#define SHIFTND_CROP3_POOL_T(TT) \
+    if (act) { SHIFTND_CROP3_POOL(TT, true) } else { SHIFTND_CROP3_POOL(TT, false) }
+    if (dtype == SHIFTND_F32) { SHIFTND_CROP3_POOL_T(f32_t) } else if (dtype == SHIFTND_F16) { SHIFTND_CROP3_POOL_T(f16_t) } else { SHIFTND_CROP3_POOL_T(bf16_t) }
+#undef SHIFTND_CROP3_POOL_T
+#undef SHIFTND_CROP3_POOL
+    return SHIFTND_OK;
 }
 
 // Shift1d + avg_pool1d(2) in one pass (row_forward<.., POOL>, round 6): 2- / 4-byte float elements, source rows of whole pieces, at

@@ -74,7 +74,11 @@ def test_pooled_vs_oracle(abi, dt):
                          and (pool[-2] == 1 or (pool[-2] == 2 and shape[3] >= 2)))
                 # (2-D sparse shift, 2 x 2 windows -- round 6: of any width: the one-step sweep with the pool as its epilogue)
                 fstep = nd == 2 and tuple(pool) == (2, 2) and (not active or min(shape[2:]) >= 2)   # (both shifts since round 6: fp32 / fp64)
-                assert abi.last_kernel() == ("walk_forward_pool" if fwalk else ("step_gather_forward_pool" if fstep else "plane_pool_forward")), key
+                # (round 6) 3-D, 2 x 2 x 2 windows, 4-byte elements here, rows of whole pieces, dims of at least 2: pooled rows through LDS
+                f3 = (nd == 3 and not fwalk and tuple(pool) == (2, 2, 2) and x.itemsize == 4 and (shape[-1] * x.itemsize) % 16 == 0
+                      and min(shape[2:]) >= 2 and min(new[2:]) >= 2)
+                assert abi.last_kernel() == ("walk_forward_pool" if fwalk else ("step_gather_forward_pool" if fstep else
+                                                                                  ("crop_forward3_pool" if f3 else "plane_pool_forward"))), key + (abi.last_kernel(),)
                 assert list(out.shape) == list(ref.shape), key
                 assert np.array_equal(out.cpu().numpy(), ref), key
                 gp = rs.uniform(-1, 1, size=ref.shape).astype(dt)
@@ -118,7 +122,8 @@ def test_pooled_16bit(abi, tdt):
     eps = 2.0 ** -8 if tdt == torch.bfloat16 else 2.0 ** -11
     for nd, shape, pool, crop in [(2, (2, 4, 12, 16), (2, 2), None), (3, (1, 3, 6, 6, 8), (2, 2, 2), None),
                                   (2, (2, 3, 13, 24), (3, 2), [[1, 0], [0, 3]]), (2, (2, 3, 18, 32), (2, 2), [[1, 1], [1, 1]]),
-                                  (2, (1, 2, 21, 40), (2, 2), [[1, 1], [1, 1]])]:
+                                  (2, (1, 2, 21, 40), (2, 2), [[1, 1], [1, 1]]), (3, (1, 3, 6, 9, 16), (2, 2, 2), [[1, 1], [1, 1], [1, 1]]),
+                                  (3, (2, 2, 5, 7, 24), (2, 2, 2), None)]:
         xt = torch.from_numpy(rs.uniform(-1, 1, size=shape).astype(np.float32)).to(tdt)
         wt = torch.from_numpy(rs.uniform(-2.5, 2.5, size=(shape[1], nd)).astype(np.float32)).to(tdt)
         x, w = xt.float().numpy(), wt.float().numpy()
@@ -138,8 +143,11 @@ def test_pooled_16bit(abi, tdt):
                     abi.set_path_policy(policy)
                     gx, gw = abi.backward_pooled(gpt.to(DEV), wt.to(DEV), xt.to(DEV), pad, active, pool, b)
                     abi.set_path_policy(0)
-                    if nd == 3:
-                        assert (abi.last_kernel() == "walk_backward_pool") == (policy == 0), (shape, policy, abi.last_kernel())
+                    if nd == 3:   # (uncropped: the walk with the pool riding on it; cropped, round 6: crop_backward3<.., POOL>)
+                        if crop is not None:   # (the plane family hands cropped volumes to crop_backward3 under either policy)
+                            assert abi.last_kernel() == "crop_backward3_pool", (shape, policy, abi.last_kernel())
+                        else:
+                            assert (abi.last_kernel() == "walk_backward_pool") == (policy == 0), (shape, policy, abi.last_kernel())
                     assert np.max(np.abs(gx.float().cpu().numpy() - gx_r)) <= eps * max(1.0, np.max(np.abs(gx_r)))
                     assert rel_err(gw.float().cpu().numpy(), gw_r) < 1.02 * eps + 1e-5   # one rounding (eps = half a unit) + the fp32 oracle's own error
 

@@ -254,7 +254,8 @@ def test_pool_op_gpu_vs_cpu():
             out_g = fn(xg, wg, pad, active, b, pool)
             # (3-D interpolating: the pool rides on the walk through the planes)
             fstep = nd == 2 and pool == (2, 2)   # (2-D, 2 x 2 windows: the one-step sweep + pool; round 6: both shifts, any window)
-            assert abi.last_kernel() == ("walk_forward_pool" if (nd == 3 and active) else ("step_gather_forward_pool" if fstep else "plane_pool_forward"))
+            assert abi.last_kernel() == ("walk_forward_pool" if (nd == 3 and active) else
+                                         ("step_gather_forward_pool" if fstep else ("crop_forward3_pool" if nd == 3 else "plane_pool_forward")))
             out_g.backward(g.to(DEV))  # (runs on the autograd thread: its kernel name is checked in test_pooled_gpu.py)
             assert torch.equal(out_g.cpu(), out_c.detach()), (shape, pad, active)
             assert torch.equal(xg.grad.cpu(), xc.grad), (shape, pad, active)
@@ -310,7 +311,7 @@ def test_strided_3d_modules_use_the_walk_pool_kernels():
         mg = m.to(DEV)
         xg = x.to(DEV).requires_grad_(True)
         out_g, _ = mg(xg)
-        assert abi.last_kernel() == ("walk_forward_pool" if active else "plane_pool_forward"), abi.last_kernel()
+        assert abi.last_kernel() == ("walk_forward_pool" if active else "crop_forward3_pool"), abi.last_kernel()   # (sparse: pooled rows through LDS, round 6)
         out_g.square().sum().backward()
         assert torch.equal(out_g.cpu(), out_c.detach()), active
         assert torch.equal(xg.grad.cpu(), gx_c), active

@@ -491,8 +491,11 @@ __global__ __launch_bounds__(kThreads) void crop_backward(const SpanParams p) {
 // POOL: the 2 x 2 x 2 average pool behind the cropped shift (emulate_dw with stride 2) -- `go` is the gradient of the POOLED window
 // [P0, P1, P2]; a staged gradient row is its pooled row expanded at phase 0 (crop_backward<.., POOL>'s branch-free expansion with the
 // plane's window count as one more power of two), which saves ATen's pool backward and its full-size gradient tensor.
+// U row groups per thread: two for the interpolating shift of 4-byte elements (same box, N8 C128 16x112x112 cut 1/1/1: fp32 0.769 -> 0.725
+// ms; bf16 0.53 -> 0.66 -- the second group's registers cost it its waves -- so 16-bit keeps one), one elsewhere.
 template <typename T, bool ACTIVE, int PAD, bool POOL = false>
 __global__ __launch_bounds__(kThreads) void crop_backward3(const SpanParams p) {
+    constexpr int U = (ACTIVE && !POOL && sizeof(typename T::S) == 4) ? 2 : 1;
     using S = typename T::S;
     using CT = typename T::C;
     constexpr int ES = sizeof(S);
@@ -511,7 +514,7 @@ __global__ __launch_bounds__(kThreads) void crop_backward3(const SpanParams p) {
     const int step = static_cast<int>(vstep) - a * p.rsteps;
     const int c = static_cast<int>(plane - fdiv(plane, p.d_C) * static_cast<uint32_t>(p.C));
     const ChanDesc d = p.desc[c];
-    const int R = p.R, S0 = p.S0, S1 = p.S1, S2 = p.S2, O0 = p.O0, O1 = p.O1, O2 = p.O2, L0 = p.L0, L1 = p.L1, L2 = p.L2, cpr = p.cpr;
+    const int R0 = p.R, R = U * R0, S0 = p.S0, S1 = p.S1, S2 = p.S2, O0 = p.O0, O1 = p.O1, O2 = p.O2, L0 = p.L0, L1 = p.L1, L2 = p.L2, cpr = p.cpr;
     const int b0 = step * R;
     const int Rn = min(R, S1 - b0);
     // tile: x corner rows [2 planes][R + 1][cpr pieces] | grad_out at the step's own rows [R][cpr + 2] | the rows grad_x reads [NPG][R + 1][cpr + 2]
@@ -544,9 +547,13 @@ __global__ __launch_bounds__(kThreads) void crop_backward3(const SpanParams p) {
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
         if (pax[h] < 0) continue;   // (uniform)
-        if (tr < R) {
-            const int sx = tr <= Rn ? row_map_t<PAD>(b0 + tr, d.cx1, S1, p.pad) : -1;
-            if (sx >= 0) dma_x(pax[h], sx, tc, h * (R + 1) * cpr);
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int vtr = tr + u * R0;
+            if (tr < R0) {
+                const int sx = vtr <= Rn ? row_map_t<PAD>(b0 + vtr, d.cx1, S1, p.pad) : -1;
+                if (sx >= 0) dma_x(pax[h], sx, tc, (h * (R + 1) + u * R0) * cpr);
+            }
         }
         if (Rn == R && tid < cpr) {
             const int sx = row_map_t<PAD>(b0 + R, d.cx1, S1, p.pad);
@@ -637,13 +644,21 @@ __global__ __launch_bounds__(kThreads) void crop_backward3(const SpanParams p) {
             if constexpr (ACTIVE) pooled_store(qc[h]);
         }
     } else {
-        const int ro = (in_vol && rg < R && rg < Rn && b0 + rg - L1 >= 0 && b0 + rg - L1 < O1) ? ao * O1 + b0 + rg - L1 : -1;   // the step's own rows
-        dma_g(ro, pg, goff / 16);
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int vrg = rg + u * R0;
+            const int ro = (in_vol && rg < R0 && vrg < Rn && b0 + vrg - L1 >= 0 && b0 + vrg - L1 < O1) ? ao * O1 + b0 + vrg - L1 : -1;   // the step's own rows
+            dma_g(ro, pg, goff / 16 + u * R0 * PGi);
+        }
 #pragma unroll
         for (int h = 0; h < NPG; ++h) {
             if (pag[h] < 0) continue;   // (uniform)
-            const int r0 = gs_row(rg, rg < R && (ACTIVE ? rg <= Rn : rg < Rn));
-            dma_g(r0 >= 0 ? pag[h] * O1 + r0 : -1, pg, gsoff / 16 + h * (R + 1) * PGi);
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int vrg = rg + u * R0;
+                const int r0 = gs_row(vrg, rg < R0 && (ACTIVE ? vrg <= Rn : vrg < Rn));
+                dma_g(r0 >= 0 ? pag[h] * O1 + r0 : -1, pg, gsoff / 16 + (h * (R + 1) + u * R0) * PGi);
+            }
             if constexpr (ACTIVE) {
                 if (Rn == R && tid < PGi) {   // the + 1 row of a full step
                     const int r1 = gs_row(R, true);
@@ -667,7 +682,7 @@ __global__ __launch_bounds__(kThreads) void crop_backward3(const SpanParams p) {
             xm = affine_state(ji - d.cx2, S2);
             gm = affine_state(ji - L2 - d.cg2, O2);
         } else {
-            const size_t rec = (static_cast<size_t>(c) * cpr + (tr < R ? tc : 0)) * REC;
+            const size_t rec = (static_cast<size_t>(c) * cpr + (tr < R0 ? tc : 0)) * REC;
             xm = load_colstate<E>(p.colx + rec);
             gm = load_colstate<E>(p.colg + rec);
         }
@@ -678,8 +693,11 @@ __global__ __launch_bounds__(kThreads) void crop_backward3(const SpanParams p) {
     CT part[NDIFF];
 #pragma unroll
     for (int i = 0; i < NDIFF; ++i) part[i] = CT(0);
-    if (tr < R && tr < Rn) {
-        const int b = b0 + tr;
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+    const int vtr = tr + u * R0;   // this row group's row of the tile
+    if (tr < R0 && vtr < Rn) {
+        const int b = b0 + vtr;
         const CT dw[3] = {static_cast<CT>(d.dw[0]), static_cast<CT>(d.dw[1]), static_cast<CT>(d.dw[2])};
         const bool in_row = in_vol && b >= L1 && b < L1 + O1;
         auto row_valid = [&](int pr, int cs, int len) { return PAD != 0 || row_map_t<PAD>(pr, cs, len, p.pad) >= 0; };
@@ -702,7 +720,7 @@ __global__ __launch_bounds__(kThreads) void crop_backward3(const SpanParams p) {
                 const bool dom = in_row && pr <= O1 && pag[ha] >= 0;
                 const int srow = dom ? row_map_t<PAD>(pr, d.cg1, O1, p.pad) : -1;
                 S raw[E + 1];
-                read_row(tile + gsoff + (ha * (R + 1) + tr + hb) * RBG + (srow >= 0 ? gphase(pag[ha] * O1 + srow) : 0), srow >= 0, gm, raw);
+                read_row(tile + gsoff + (ha * (R + 1) + vtr + hb) * RBG + (srow >= 0 ? gphase(pag[ha] * O1 + srow) : 0), srow >= 0, gm, raw);
 #pragma unroll
                 for (int e = 0; e <= E; ++e) gv[k][e] = widen<T>(raw[e]);
             }
@@ -716,7 +734,7 @@ __global__ __launch_bounds__(kThreads) void crop_backward3(const SpanParams p) {
         } else {
             const int srow = (in_row && pag[0] >= 0) ? row_map_t<PAD>(b - L1, d.cg1, O1, p.pad) : -1;
             S raw[E + 1];
-            read_row(tile + gsoff + tr * RBG + (srow >= 0 ? gphase(pag[0] * O1 + srow) : 0), srow >= 0, gm, raw);
+            read_row(tile + gsoff + vtr * RBG + (srow >= 0 ? gphase(pag[0] * O1 + srow) : 0), srow >= 0, gm, raw);
 #pragma unroll
             for (int e = 0; e < E; ++e) res.e[e] = inside[e] ? raw[e] : zero;
         }
@@ -726,11 +744,11 @@ __global__ __launch_bounds__(kThreads) void crop_backward3(const SpanParams p) {
         for (int k = 0; k < 4; ++k) {
             const int ha = k & 1, hb = k >> 1;
             S raw[E + 1];
-            read_row(tile + (ha * (R + 1) + tr + hb) * RBX, pax[ha] >= 0 && row_valid(b + hb, d.cx1, S1), xm, raw);
+            read_row(tile + (ha * (R + 1) + vtr + hb) * RBX, pax[ha] >= 0 && row_valid(b + hb, d.cx1, S1), xm, raw);
 #pragma unroll
             for (int e = 0; e <= E; ++e) xv[k][e] = widen<T>(raw[e]);
         }
-        const S *grow = reinterpret_cast<const S *>(tile + goff + tr * RBG + (in_row ? gphase(ao * O1 + b - L1) : 0)) + (in_row ? ji - L2 : 0);
+        const S *grow = reinterpret_cast<const S *>(tile + goff + vtr * RBG + (in_row ? gphase(ao * O1 + b - L1) : 0)) + (in_row ? ji - L2 : 0);
 #pragma unroll
         for (int e = 0; e < E; ++e) {
             CT v[8], df[NDIFF];
@@ -744,6 +762,7 @@ __global__ __launch_bounds__(kThreads) void crop_backward3(const SpanParams p) {
         }
         store_chunk<S, E>(gxp + static_cast<int64_t>(b) * S2 + ji, res);
     }
+    }   // (row groups)
     // ---- this step's sums: DPP tree per wave, the four waves added in fp64 by the first NDIFF threads -----------------------------
     double *scratch = reinterpret_cast<double *>(tile + ((gsoff + NPG * (R + 1) * RBG + 63) & ~63) + 64);
 #pragma unroll
@@ -1045,8 +1064,14 @@ __global__ __launch_bounds__(kThreads) void ragged_forward(const SpanFwdParams p
 // ND = 2: the same kernel for cropped 2-D windows whose output PLANES are not whole 16-byte pieces -- crop_forward's flat chunk stream
 // needs them to be; 110 x 110 bf16 (N32 C256 112x112 cut 1/1) ran plane_gather_forward at 2.4 TB/s, the interpolating shift the
 // flat-stream kernels at 3.4 -- one source plane, two weights, interp_t<T, 2>.
+// U row groups per thread: two for the interpolating shift (4-byte elements; 2-D rows form: 16-bit too), one elsewhere (same box, U = 1 -> 2: N8 C128 16x112x112 cut 1/1/1
+// fp32 interpolating 0.310 -> 0.266 ms, bf16 0.234 -> 0.243; 2-D rows form, bf16 N32 C256 112x112 cut 1/1 interpolating 0.082 -> 0.072;
+// the sparse shift loses: bf16 3-D 0.173 -> 0.199, 2-D 0.062 -> 0.067).  The kernel issues as many scalar as vector instructions (381 /
+// 380 per wave on bf16: weights, three canonical shifts, plane / row maps, lane-mask arithmetic) and every wave of every workgroup repeats
+// the uniform part; two row groups halve the workgroups.
 template <typename T, bool ACTIVE, int PAD, int ND = 3>
 __global__ __launch_bounds__(kThreads) void crop_forward3(const SpanFwdParams p) {
+    constexpr int U = (ACTIVE && (sizeof(typename T::S) == 4 || ND == 2)) ? 2 : 1;   // (bf16 3-D interpolating: 0.234 -> 0.243-0.252 with two: one)
     using S = typename T::S;
     using CT = typename T::C;
     constexpr int ES = sizeof(S);
@@ -1076,7 +1101,8 @@ __global__ __launch_bounds__(kThreads) void crop_forward3(const SpanFwdParams p)
         dw[k] = ACTIVE ? wv[k] - rr[k] : CT(0);
     }
     const int S0 = p.S0, S1 = p.S1, S2 = p.S2, O1 = p.O1, O2 = p.O2, L0 = p.L0, L1 = p.L1, L2 = p.L2;
-    const int cpr = p.ocp, R = p.cps, PX = p.P;   // output chunks per row, rows per step, pieces per source row
+    const int cpr = p.ocp, R0 = p.cps, PX = p.P;   // output chunks per row, rows per row group, pieces per source row
+    const int R = U * R0;                           // rows per step
     const int cs0 = ND == 3 ? __builtin_amdgcn_readfirstlane(canon_of<PAD, CT>(rr[0], S0, p.d_per0, p.pad)) : 0;
     const int cs1 = __builtin_amdgcn_readfirstlane(canon_of<PAD, CT>(rr[1], S1, p.d_per1, p.pad));
     const int cs2 = __builtin_amdgcn_readfirstlane(canon_of<PAD, CT>(rr[2], S2, p.d_per2, p.pad));
@@ -1100,14 +1126,20 @@ __global__ __launch_bounds__(kThreads) void crop_forward3(const SpanFwdParams p)
     };
     {
         const int rg = static_cast<int>(fdiv(static_cast<uint32_t>(tid), p.d_P)), pg = tid - rg * PX;
-        const int sr = (rg < R && (ACTIVE ? rg <= Rn : rg < Rn)) ? src_row(rg) : -1;
 #pragma unroll
-        for (int h = 0; h < NP; ++h) {
-            if (pl[h] < 0) continue;   // (uniform)
-            dma_x(pl[h], sr, pg, h * TP);
-            if constexpr (ACTIVE) {
-                if (Rn == R && tid < PX) dma_x(pl[h], src_row(R), tid, h * TP + R * PX);   // the + 1 row of a full step
+        for (int u = 0; u < U; ++u) {
+            const int vrg = rg + u * R0;
+            const int sr = (rg < R0 && (ACTIVE ? vrg <= Rn : vrg < Rn)) ? src_row(vrg) : -1;
+#pragma unroll
+            for (int h = 0; h < NP; ++h) {
+                if (pl[h] < 0) continue;   // (uniform)
+                dma_x(pl[h], sr, pg, h * TP + u * R0 * PX);
             }
+        }
+        if constexpr (ACTIVE) {
+#pragma unroll
+            for (int h = 0; h < NP; ++h)
+                if (pl[h] >= 0 && Rn == R && tid < PX) dma_x(pl[h], src_row(R), tid, h * TP + R * PX);   // the + 1 row of a full step
         }
     }
     const int tr = static_cast<int>(fdiv(static_cast<uint32_t>(tid), p.d_O2)), tc = tid - tr * cpr;   // (d_O2 divides by cpr here)
@@ -1124,20 +1156,23 @@ __global__ __launch_bounds__(kThreads) void crop_forward3(const SpanFwdParams p)
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (tr >= R || tr >= Rn) return;
     auto read_row = [&](int h, int slot, S (&raw)[E + 1]) {
         const bool valid = pl[h] >= 0 && src_row(slot) >= 0;
         const char *row = tile + (h * TP + slot * PX) * 16;
         if constexpr (PAD == 0) lds_read_row_affine<S, E>(row, valid, xm, raw);
         else lds_read_row<S, E>(row, valid, xm, raw);
     };
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+    const int vtr = tr + u * R0;
+    if (tr >= R0 || vtr >= Rn) continue;
     Chunk<S, E> res;
     if constexpr (ACTIVE && ND == 3) {
         CT xv[4][E + 1];   // corner k: bit 0 = + 1 plane, bit 1 = + 1 row
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             S raw[E + 1];
-            read_row(k & 1, tr + (k >> 1), raw);
+            read_row(k & 1, vtr + (k >> 1), raw);
 #pragma unroll
             for (int e = 0; e <= E; ++e) xv[k][e] = widen<T>(raw[e]);
         }
@@ -1153,7 +1188,7 @@ __global__ __launch_bounds__(kThreads) void crop_forward3(const SpanFwdParams p)
 #pragma unroll
         for (int hb = 0; hb < 2; ++hb) {
             S raw[E + 1];
-            read_row(0, tr + hb, raw);
+            read_row(0, vtr + hb, raw);
 #pragma unroll
             for (int e = 0; e <= E; ++e) xv[hb][e] = widen<T>(raw[e]);
         }
@@ -1165,17 +1200,18 @@ __global__ __launch_bounds__(kThreads) void crop_forward3(const SpanFwdParams p)
         }
     } else {
         S raw[E + 1];
-        read_row(0, tr, raw);
+        read_row(0, vtr, raw);
 #pragma unroll
         for (int e = 0; e < E; ++e) res.e[e] = raw[e];
     }
-    S *dst = op + static_cast<int64_t>(b0 + tr) * O2 + ji;
+    S *dst = op + static_cast<int64_t>(b0 + vtr) * O2 + ji;
     if (ji + E <= O2) {
         store_chunk_unaligned<S, E>(dst, res);
     } else {
 #pragma unroll
         for (int e = 0; e < E; ++e)
             if (ji + e < O2) dst[e] = res.e[e];
+    }
     }
     (void)RBX;
 }
@@ -1700,7 +1736,8 @@ SpanPlan span_plan(const Geometry &g, int es) {
     // (N512 C16 64x64: 0.068 -> 0.064 ms; N64 C256 224x224: 1.598 -> 1.616, so not there).  4- and 2-byte elements (fp64 keeps one).
     // Knob 35 bit 7: one for the sparse shift everywhere, bit 8: two everywhere.  Geometry and knobs only: the workspace is planned from the
     // same answer.
-    s.U = 1;   // (3-D: one)
+    s.U = 1;
+    if (g.nd == 3 && g.active && g.K[0] <= 0 && es == 4) s.U = 2;   // (crop_backward3: the interpolating, unpooled form of 4-byte elements)
     if (g.nd == 2 && s.nseg == 1 && es <= 4) {
         // (ragged x rows, N512 C16 62x62 sparse: 0.072 -> 0.066 ms, N64 C256 222x222: 1.666 -> 1.668; the pooled interpolating form,
         //  N64 C256 224x224: 1.855 -> 1.668 ms -- the same rule for every form.  The interpolating shift has NO one-group instantiation
@@ -2038,8 +2075,9 @@ int span_forward(const Geometry &g, int dtype, const void *x, const void *w, int
         p.o_plane = g.O[0] * g.O[1] * g.O[2];
         p.P = static_cast<int>(g.S[2] * es / 16);                      // pieces per staged source row
         p.ocp = static_cast<int>((g.O[2] * es + 15) / 16);             // output chunks per row
-        p.cps = std::max(1, std::min<int>(static_cast<int>(g.O[1]), kThreads / p.P));   // rows per step
-        p.rsteps = (p.O1 + p.cps - 1) / p.cps;
+        p.cps = std::max(1, std::min<int>(static_cast<int>(g.O[1]), kThreads / p.P));   // rows per row group
+        const int kU = (g.active && (es == 4 || g.nd == 2)) ? 2 : 1;                    // row groups per thread (crop_forward3: U)
+        p.rsteps = (p.O1 + kU * p.cps - 1) / (kU * p.cps);
         p.spp = p.rsteps * p.O0;
         const uint64_t total = static_cast<uint64_t>(g.N) * g.C * p.spp;
         p.total_steps = static_cast<uint32_t>(total);
@@ -2053,7 +2091,7 @@ int span_forward(const Geometry &g, int dtype, const void *x, const void *w, int
         p.d_per1 = make_fastdiv(static_cast<uint32_t>(map_period(p.S1, g.pad)));
         p.d_per2 = make_fastdiv(static_cast<uint32_t>(map_period(p.S2, g.pad)));
         const bool act = g.active != 0;
-        const size_t lds = 64 + static_cast<size_t>(act ? 2 : 1) * (p.cps + 1) * p.P * 16 + 64;
+        const size_t lds = 64 + static_cast<size_t>(act ? 2 : 1) * (kU * p.cps + 1) * p.P * 16 + 64;
         if (rows2) note_kernel(act ? "crop_active_forward_rows" : "crop_gather_forward_rows");
         else note_kernel(act ? "crop_active_forward3" : "crop_gather_forward3");
         const dim3 grid(p.steps_per_xcd * 8), block(kThreads);

@@ -1776,26 +1776,29 @@ int plane_backward(const Geometry &g, int dtype, const void *go, const void *x, 
     }
 }
 
-// ---- 3-D volumes whose rows are not whole 16-byte pieces (round 5) -------------------------------------------------------------
+// ---- rows that are not whole 16-byte pieces, behind every chunk kernel (round 5: 3-D volumes; round 6: the rest of the tail) -----
 // 16 x 28 x 28 bf16 (56-byte rows), 8 x 56 x 62 fp32 ...: volumes beyond the small-plane kernels' 16 KiB.  The route census found
 // them on the strided fallback (one thread per element, 64-bit index arithmetic, one workgroup per (n, c)): 0.02 - 0.5 TB/s.  The
 // direct-load plane kernels serve them with chunks of 4 bytes (two 16-bit elements / one fp32) or 8 (one fp64): padding maps in LDS,
-// row bands across workgroups, coalesced element-aligned loads and stores.  Rows of an odd number of 16-bit elements stay on the
-// fallback.
-static int ragged_vector_bytes(int es, int64_t row_elems) {
-    if (es == 2) return row_elems % 2 == 0 ? 4 : 0;
+// row bands across workgroups, coalesced element-aligned loads and stores.
+// Round 6 (route census of 6 000 problems: 164 backward / 136 interpolating-forward calls still on the fallback): rows of an ODD
+// number of 16-bit elements move one element per thread (VB = 2); 1-D rows cut by a window that the flat stream declines (rows of
+// 5 - 28 elements: more than 72 planes per 4 KiB step) and -- forward -- 2-D windows on rows too long for the row-span kernels run
+// the same kernels with one element per thread.
+static int ragged_vector_bytes(int es, int64_t row_elems, int nd) {
+    if (es == 2) return (row_elems % 2 == 0 && nd == 3) ? 4 : 2;
     return es;
 }
 
 bool plane_ragged_forward_eligible(const Geometry &g, int dtype, const void *x, const void *out) {
     (void)x;
-    if (dtype > SHIFTND_BF16 || !g.active || g.nd != 3 || g.K[0] > 0 || !common_eligible(g)) return false;
+    if (dtype > SHIFTND_BF16 || !g.active || g.nd < 1 || g.nd > 3 || g.K[0] > 0 || !common_eligible(g)) return false;
     if (g.S[0] + g.S[1] + g.S[2] + 3 > kMaxMapEntries) return false;
     if (!contiguous(g.xs, g.N, g.C, g.S) || !contiguous(g.os, g.N, g.C, g.O)) return false;
     const int es = dtype_size(dtype);
     if ((g.O[2] * es) % 16 == 0) return false;   // (whole pieces: plane_forward)
-    const int vb = ragged_vector_bytes(es, g.O[2]);
-    return vb != 0 && reinterpret_cast<uintptr_t>(out) % vb == 0;
+    const int vb = ragged_vector_bytes(es, g.O[2], g.nd);
+    return reinterpret_cast<uintptr_t>(out) % vb == 0;
 }
 
 int plane_ragged_forward(const Geometry &g, int dtype, const void *x, const void *w, void *out, hipStream_t st) {
@@ -1806,47 +1809,56 @@ int plane_ragged_forward(const Geometry &g, int dtype, const void *x, const void
     p.out = out;
     p.w = w;
     p.wkind = dtype;
-    const Plan pl = make_plan(g, g.O[0] * g.O[1], g.O[2], es, ragged_vector_bytes(es, g.O[2]), entries);
+    const int vb = ragged_vector_bytes(es, g.O[2], g.nd);
+    const Plan pl = make_plan(g, g.O[0] * g.O[1], g.O[2], es, vb, entries);
     fill_params(p, g, pl, g.O[1]);
     note_kernel("plane_active_forward_ragged");
     const dim3 grid(pl.grid), block(kThreads);
+#define SHIFTND_RAGGED_FWD(TT, VB1, VB3) \
+    if (g.nd == 1) hipLaunchKernelGGL((plane_active_forward<TT, 1, VB1>), grid, block, pl.lds, st, p); \
+    else if (g.nd == 2) hipLaunchKernelGGL((plane_active_forward<TT, 2, VB1>), grid, block, pl.lds, st, p); \
+    else if (vb == VB1) hipLaunchKernelGGL((plane_active_forward<TT, 3, VB1>), grid, block, pl.lds, st, p); \
+    else hipLaunchKernelGGL((plane_active_forward<TT, 3, VB3>), grid, block, pl.lds, st, p);
     switch (dtype) {
-    case SHIFTND_F32: hipLaunchKernelGGL((plane_active_forward<f32_t, 3, 4>), grid, block, pl.lds, st, p); break;
-    case SHIFTND_F64: hipLaunchKernelGGL((plane_active_forward<f64_t, 3, 8>), grid, block, pl.lds, st, p); break;
-    case SHIFTND_F16: hipLaunchKernelGGL((plane_active_forward<f16_t, 3, 4>), grid, block, pl.lds, st, p); break;
-    default: hipLaunchKernelGGL((plane_active_forward<bf16_t, 3, 4>), grid, block, pl.lds, st, p); break;
+    case SHIFTND_F32: SHIFTND_RAGGED_FWD(f32_t, 4, 4) break;
+    case SHIFTND_F64: SHIFTND_RAGGED_FWD(f64_t, 8, 8) break;
+    case SHIFTND_F16: SHIFTND_RAGGED_FWD(f16_t, 2, 4) break;
+    default: SHIFTND_RAGGED_FWD(bf16_t, 2, 4) break;
     }
+#undef SHIFTND_RAGGED_FWD
     return SHIFTND_OK;
 }
 
 static Plan ragged_backward_plan(const Geometry &g, int es) {
     const int entries = static_cast<int>(g.S[0] + g.S[1] + g.S[2] + g.O[0] + g.O[1] + g.O[2] + 6);
-    const int vb = ragged_vector_bytes(es, g.S[2]);
-    return make_plan(g, g.S[0] * g.S[1], g.S[2], es, vb ? vb : es, entries, backward_min_wgs(g, es));
+    return make_plan(g, g.S[0] * g.S[1], g.S[2], es, ragged_vector_bytes(es, g.S[2], g.nd), entries, backward_min_wgs(g, es));
 }
 
+// (nd == 2 never reached the fallback in the census -- the flat stream and the row-span kernels take every 2-D backward -- and has no
+//  instantiation here)
 bool plane_ragged_backward_eligible(const Geometry &g, int dtype, const void *go, const void *x, const void *gx) {
     (void)go;
     (void)x;
-    if (dtype > SHIFTND_BF16 || g.nd != 3 || g.K[0] > 0 || !common_eligible(g)) return false;
+    if (dtype > SHIFTND_BF16 || (g.nd != 3 && g.nd != 1) || g.K[0] > 0 || !common_eligible(g)) return false;
     if (g.S[0] + g.S[1] + g.S[2] + g.O[0] + g.O[1] + g.O[2] + 6 > kMaxMapEntries) return false;
     if (!contiguous(g.xs, g.N, g.C, g.S) || !contiguous(g.os, g.N, g.C, g.O) || !contiguous(g.gs, g.N, g.C, g.S)) return false;
     const int es = dtype_size(dtype);
-    if ((g.S[2] * es) % 16 == 0) return false;   // (whole pieces: plane_backward)
-    const int vb = ragged_vector_bytes(es, g.S[2]);
+    if (g.nd == 3 && (g.S[2] * es) % 16 == 0) return false;   // (whole pieces: plane_backward)
+    const int vb = ragged_vector_bytes(es, g.S[2], g.nd);
     // (the incoming gradient's rows are read by element-aligned loads: a window along the row needs no alignment of its own)
-    return vb != 0 && reinterpret_cast<uintptr_t>(gx) % vb == 0;
+    return reinterpret_cast<uintptr_t>(gx) % vb == 0;
 }
 
 size_t plane_ragged_backward_workspace(const Geometry &g, int dtype) {
-    if (dtype > SHIFTND_BF16 || g.nd != 3 || g.C < 1 || g.N < 1 || g.S[0] * g.S[1] * g.S[2] < 1) return 0;
+    if (dtype > SHIFTND_BF16 || (g.nd != 3 && g.nd != 1) || g.C < 1 || g.N < 1 || g.S[0] * g.S[1] * g.S[2] < 1) return 0;
     const Plan pl = ragged_backward_plan(g, dtype_size(dtype));
     return static_cast<size_t>(pl.groups) * pl.bands * static_cast<size_t>(g.C) * 3 * sizeof(double);
 }
 
 int plane_ragged_backward(const Geometry &g, int dtype, const void *go, const void *x, const void *w, void *gx, void *gw,
                           void *workspace, hipStream_t st) {
-    const Plan pl = ragged_backward_plan(g, dtype_size(dtype));
+    const int es = dtype_size(dtype);
+    const Plan pl = ragged_backward_plan(g, es);
     PlaneParams p{};
     p.x = x;
     p.go = go;
@@ -1858,17 +1870,23 @@ int plane_ragged_backward(const Geometry &g, int dtype, const void *go, const vo
     note_kernel("plane_backward_ragged");
     const dim3 grid(pl.grid), block(kThreads);
     const bool active = g.active != 0;
-#define SHIFTND_RAGGED_BWD(TT, VBV) \
-    if (active) hipLaunchKernelGGL((plane_backward<TT, 3, true, false, VBV>), grid, block, pl.lds, st, p); \
-    else hipLaunchKernelGGL((plane_backward<TT, 3, false, false, VBV>), grid, block, pl.lds, st, p); \
+    const int vb = ragged_vector_bytes(es, g.S[2], g.nd);
+#define SHIFTND_RAGGED_BWD_K(TT, NDV, VBV) \
+    if (active) hipLaunchKernelGGL((plane_backward<TT, NDV, true, false, VBV>), grid, block, pl.lds, st, p); \
+    else hipLaunchKernelGGL((plane_backward<TT, NDV, false, false, VBV>), grid, block, pl.lds, st, p);
+#define SHIFTND_RAGGED_BWD(TT, VB1, VB3) \
+    if (g.nd == 1) { SHIFTND_RAGGED_BWD_K(TT, 1, VB1) } \
+    else if (vb == VB1) { SHIFTND_RAGGED_BWD_K(TT, 3, VB1) } \
+    else { SHIFTND_RAGGED_BWD_K(TT, 3, VB3) } \
     reduce_weight_grads_of<TT>(p.partials, pl.groups * pl.bands, p.C, p.nd, gw, st);
     switch (dtype) {
-    case SHIFTND_F32: SHIFTND_RAGGED_BWD(f32_t, 4) break;
-    case SHIFTND_F64: SHIFTND_RAGGED_BWD(f64_t, 8) break;
-    case SHIFTND_F16: SHIFTND_RAGGED_BWD(f16_t, 4) break;
-    default: SHIFTND_RAGGED_BWD(bf16_t, 4) break;
+    case SHIFTND_F32: SHIFTND_RAGGED_BWD(f32_t, 4, 4) break;
+    case SHIFTND_F64: SHIFTND_RAGGED_BWD(f64_t, 8, 8) break;
+    case SHIFTND_F16: SHIFTND_RAGGED_BWD(f16_t, 2, 4) break;
+    default: SHIFTND_RAGGED_BWD(bf16_t, 2, 4) break;
     }
 #undef SHIFTND_RAGGED_BWD
+#undef SHIFTND_RAGGED_BWD_K
     return SHIFTND_OK;
 }
 

@@ -74,6 +74,59 @@ def test_ragged_volumes_vs_oracle(abi, shape, crop, dt):
             assert torch.equal(gx, gx2) and torch.equal(gw, gw2)   # deterministic
 
 
+# round 6 -- what the route census still found on the strided fallback: (a) 3-D rows of an odd number of 16-bit elements, (b) 1-D rows
+# of 5 - 28 elements cut by a window (more planes per 4 KiB step than the flat stream's table holds), (c) -- forward only -- 2-D
+# windows on rows too long for the row-span kernels.  (shape, cut, dtypes, forward kernel or None = whatever serves, backward ditto;
+# the names are asserted for the 16-bit types -- some 4- / 8-byte rows of these shapes are whole pieces and have other kernels)
+TAIL = [((2, 2, 40, 16, 31), None, ("f16", "bf16"), "plane_active_forward_ragged", "plane_backward_ragged"),
+        ((1, 3, 300, 6, 7), None, ("f16", "bf16"), "plane_active_forward_ragged", "plane_backward_ragged"),
+        ((2, 2, 9, 18, 13), [[1, 0], [2, 1], [1, 2]], ("f16", "bf16"), "plane_active_forward_ragged", "plane_backward_ragged"),
+        ((1, 2, 300, 40, 1), None, ("bf16",), "plane_active_forward_ragged", "plane_backward_ragged"),
+        ((1, 2, 12, 14, 32), [[2, 1], [2, 2], [2, 1]], ("f16",), "plane_active_forward_ragged", None),
+        ((64, 16, 12), [[0, 2]], ("f32", "f64", "f16", "bf16"), None, "plane_backward_ragged"),
+        ((8, 3, 7), [[2, 0]], ("f32", "f64", "f16", "bf16"), None, "plane_backward_ragged"),
+        ((3, 256, 18), [[2, 2]], ("f32", "f16"), None, "plane_backward_ragged"),
+        ((2, 1, 5), [[0, 2]], ("f64", "bf16"), None, "plane_backward_ragged"),
+        ((2, 2, 6, 5000), [[1, 0], [0, 2]], ("f32", "f64", "bf16"), "plane_active_forward_ragged", None),
+        ((2, 3, 6, 5), [[2, 1], [1, 2]], ("f32", "f16"), None, None)]
+
+
+@pytest.mark.parametrize("shape,crop,dts,kf,kb", TAIL)
+def test_fallback_tail_vs_oracle(abi, shape, crop, dts, kf, kb):
+    nd = len(shape) - 2
+    b, new = abi.check_borders(list(shape), crop, nd)
+    for dt in dts:
+        tdt = TDT[dt]
+        rs = np.random.RandomState(sum(shape) * 3 + len(dt))
+        xt = torch.from_numpy(rs.uniform(-1, 1, size=shape)).to(tdt)
+        gt = torch.from_numpy(rs.uniform(-1, 1, size=new)).to(tdt)
+        wt = torch.from_numpy(_weights(rs, shape[1], nd, shape[2:])).to(tdt)
+        wide = np.float64 if tdt == torch.float64 else np.float32
+        x, go, w = (t.to(torch.float64).numpy().astype(wide) for t in (xt, gt, wt))
+        xd, god, wd = xt.to(DEV), gt.to(DEV), wt.to(DEV)
+        es = xt.element_size()
+        for pad in range(5):
+            out = abi.forward(xd, wd, pad, 1, b)
+            assert not abi.last_kernel().startswith("strided"), ("fwd", shape, crop, dt, abi.last_kernel())
+            assert kf is None or es != 2 or abi.last_kernel() == kf, ("fwd", shape, crop, dt, abi.last_kernel())
+            ref = torch.from_numpy(O.forward(x, w, pad, 1, b)).to(tdt)
+            assert (torch.equal(out.cpu(), ref) if es >= 4 else _ulp_close(out.cpu(), ref, tdt)), ("fwd", shape, crop, dt, pad)
+            for active in (0, 1):
+                gx, gw = abi.backward(god, wd, xd, pad, active, b)
+                assert not abi.last_kernel().startswith("strided"), ("bwd", shape, crop, dt, abi.last_kernel())
+                assert kb is None or es != 2 or abi.last_kernel() == kb, ("bwd", shape, crop, dt, abi.last_kernel())
+                gx_ref = torch.from_numpy(O.backward(go, w, x, pad, active, b)[0]).to(tdt)
+                if es >= 4 or not active:
+                    assert torch.equal(gx.cpu(), gx_ref), ("gx", shape, crop, dt, pad, active)
+                else:
+                    assert _ulp_close(gx.cpu(), gx_ref, tdt), ("gx", shape, crop, dt, pad, active)
+                _, gw64 = O.backward(go.astype(np.float64), w.astype(np.float64), x.astype(np.float64), pad, active, b)
+                tol = {"f32": 1e-5, "f64": 1e-12}.get(dt, gw16_tol(torch.finfo(tdt).eps))
+                assert rel_err(gw.to(torch.float64).cpu().numpy(), gw64) < tol, ("gw", shape, crop, dt, pad, active)
+                gx2, gw2 = abi.backward(god, wd, xd, pad, active, b)
+                assert torch.equal(gx, gx2) and torch.equal(gw, gw2)
+
+
 def test_ragged_volume_at_size(abi):
     """N8 C128 16 x 28 x 28 bf16 (a video network's 28 x 28 stage): linearity of the backward in the incoming gradient and the
     forward's values (1 ulp) against the strided fallback (policy 1), which the oracle-sized cases above pin"""

@@ -73,7 +73,9 @@ FAMILY_ROUTES = [
     ("backward", "slide_backward", "float16", (1, 1, 1, 2, 200), None, 0, 0, False),
     ("backward", "small_plane_backward", "float64", (2, 2, 1, 56, 7), None, 2, 1, False),
     ("backward", "step_backward", "float32", (3, 1, 1, 24), None, 1, 0, False),
-    ("backward", "strided_backward", "bfloat16", (8, 1, 12), [[2, 0]], 4, 0, False),
+    # (round 6: the census no longer reaches it -- 0 of 5 131 backward calls; what is left are index maps beyond LDS: here 13 000 planes of
+    #  odd 16-bit rows -- and tensors that are neither contiguous nor channels-last)
+    ("backward", "strided_backward", "float16", (1, 1, 13000, 2, 3), None, 1, 1, False),
     ("backward", "sweep_backward", "float16", (2, 3, 16384), None, 4, 1, False),
     ("backward", "walk_backward", "float32", (2, 2, 3, 3, 16), None, 2, 1, False),
     ("backward", "walk_backward16", "bfloat16", (1, 2, 32, 7, 200), None, 1, 1, False),
@@ -104,7 +106,7 @@ FAMILY_ROUTES = [
     ("forward", "step_gather_forward", "float32", (64, 2, 512, 28), None, 0, 0, False),
     ("forward", "step_gather_forward_lds", "bfloat16", (3, 2, 1, 16, 128), None, 3, 0, False),
     ("forward", "step_gather_forward_small", "float16", (3, 3, 100, 224), None, 0, 0, False),
-    ("forward", "strided_active_forward", "float32", (64, 1, 16), [[0, 2]], 1, 1, False),
+    ("forward", "strided_active_forward", "float16", (1, 1, 70000), [[1, 2]], 2, 1, False),   # (round 6: 11 of 5 131 -- windows on rows whose maps exceed LDS)
     ("forward", "sweep_active_forward", "float32", (8, 1, 2, 8, 40000), None, 4, 1, False),
     ("forward", "sweep_gather_forward", "float64", (8, 16, 28, 5, 32), None, 0, 0, False),
     ("forward", "walk_forward", "float32", (2, 2, 3, 3, 16), None, 2, 1, False),

@@ -152,8 +152,9 @@ def test_row_bands_vs_oracle(abi, shape, dt):
             assert np.array_equal(out.cpu().numpy(), O.forward(x, w, pad, 1)), (shape, pad, br)
             for active in (0, 1):
                 gx, gw = abi.backward(god, wd, xd, pad, active)
-                # (a 1-D fp32 row longer than the small-plane limit does not fit LDS twice with its maps: one thread per element)
-                assert abi.last_kernel() == ("strided_backward" if (nd == 1 and dt == "f32") else "band_plane_backward"), (shape, pad, active)
+                # (a 1-D fp32 row longer than the small-plane limit does not fit LDS twice with its maps: one element per thread, read
+                #  straight from memory -- round 6: the direct-load plane kernel with element-wide chunks, no longer the strided fallback)
+                assert abi.last_kernel() == ("plane_backward_ragged" if (nd == 1 and dt == "f32") else "band_plane_backward"), (shape, pad, active)
                 gx_o, _ = O.backward(go, w, x, pad, active)
                 _, gw64 = O.backward(go.astype(np.float64), w.astype(np.float64), x.astype(np.float64), pad, active)
                 assert np.array_equal(gx.cpu().numpy(), gx_o), (shape, pad, active, br)

@@ -37,17 +37,29 @@ def main():
     ap.add_argument("--cases", type=int, default=4000)
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--out", default="gpurun_out/route_census.txt")
+    ap.add_argument("--via-op", action="store_true",
+                    help="channels-last float problems through torch.ops.torchshifts._shift{N}d_forward/_backward (the op asks the "
+                         "library whether a kernel reads the layout as it lies and changes the layout once otherwise) instead of "
+                         "handing the strided tensors to the C ABI")
+    ap.add_argument("--dump", default="", help="comma-separated kernel-name prefixes: write EVERY problem they served to <out>.dump")
     a = ap.parse_args()
+    if a.via_op:
+        import torchshifts  # noqa: F401  (registers the ops)
     rs = np.random.RandomState(a.seed)
     abi.set_path_policy(0)
     seen = collections.defaultdict(list)
     count = collections.Counter()
+
+    dump_prefixes = [d for d in a.dump.split(",") if d]
+    dumped = []
 
     def note(kind, desc):
         k = (kind, abi.last_kernel())
         count[k] += 1
         if len(seen[k]) < 6:
             seen[k].append(desc)
+        if any(k[1].startswith(d) for d in dump_prefixes):
+            dumped.append("%s %s %s" % (kind, k[1], desc))
 
     for it in range(a.cases):
         nd = int(rs.randint(1, 4))
@@ -77,7 +89,19 @@ def main():
             if cl:
                 xq = abi.to_channels_last(xq)
                 outq = abi.to_channels_last(torch.empty(new, dtype=tdt, device=DEV))
-            abi.forward_quantized(xq, wq, 128, 3, pad, b, out=outq)
+            if cl and a.via_op:
+                # the QuantizedCUDA op's rule (torch_binding.cpp: qshift_forward_hip): the LDS-tiled kernel when the library serves
+                # the layout as it lies, otherwise one layout change, the contiguous kernel, one change back
+                import ctypes
+                pr = abi.problem(xq, pad, False, b)
+                direct = abi.lib().shiftnd_forward_serves_channels_last(ctypes.byref(pr), xq.data_ptr(), abi.strides5(xq),
+                                                                       outq.data_ptr(), abi.strides5(outq))
+                if direct:
+                    abi.forward_quantized(xq, wq, 128, 3, pad, b, out=outq)
+                else:
+                    abi.forward_quantized(xq.contiguous(), wq, 128, 3, pad, b)
+            else:
+                abi.forward_quantized(xq, wq, 128, 3, pad, b, out=outq)
             note("forward_quantized", "%s %s" % (str(tdt).replace("torch.", ""), desc))
             continue
         tdt = FLOATS[rs.randint(0, 4)]
@@ -89,6 +113,13 @@ def main():
             x, go = abi.to_channels_last(x), abi.to_channels_last(go)
             out, gx = torch.empty_like(go), torch.empty_like(x)
         d = "%s %s" % (str(tdt).replace("torch.", ""), desc)
+        if cl and a.via_op:
+            bt = torch.tensor(b if b else abi.default_borders(x), dtype=torch.int32)
+            getattr(torch.ops.torchshifts, "_shift%dd_forward" % nd)(x, w, bt, list(new), pad, bool(active))
+            note("forward", d)
+            getattr(torch.ops.torchshifts, "_shift%dd_backward" % nd)(go, w, x, bt, pad, bool(active))
+            note("backward", d)
+            continue
         abi.forward(x, w, pad, active, b, out=out)
         note("forward", d)
         abi.backward(go, w, x, pad, active, b, grad_x=gx)
@@ -100,6 +131,20 @@ def main():
             f.write("%-18s %-34s %5d problems\n" % (kind, k, n))
             for dsc in seen[(kind, k)]:
                 f.write("        %s\n" % dsc)
+    if dump_prefixes:
+        with open(a.out + ".dump", "w") as f:
+            f.write("\n".join(dumped) + "\n")
+    total = collections.Counter()
+    for (kind, k), n in count.items():
+        total[kind] += n
+    tail = collections.Counter()
+    for (kind, k), n in count.items():
+        if k.startswith("strided_") or k.startswith("cl_backward") or k.startswith("cl_gather") or k.startswith("cl_active"):
+            tail[kind] += n
+    with open(a.out, "a") as f:
+        for kind in sorted(total):
+            f.write("fallback tail (strided_* / cl_backward / cl_gather_forward / cl_active_forward): %-18s %4d of %5d = %.2f %%\n"
+                    % (kind, tail[kind], total[kind], 100.0 * tail[kind] / max(1, total[kind])))
     print(open(a.out).read())
 
 

@@ -174,6 +174,33 @@ def _sig(v, digits=5):
     return v
 
 
+def fallback_tail():
+    """Share of a seeded sample of 6 000 geometries (tools/route_census.py: 1-3 dims, rows of 1..70 000 elements, windows, channels-last,
+    every dtype; through the op's layout rule) that the one-thread-per-element fallback kernels served, from the newest committed
+    census (profiles/r<NN>_route_census.txt: it needs its own GPU run).  None when no census carries the summary lines."""
+    import glob
+    import re
+    best = None
+    for f in glob.glob(os.path.join(ROOT, "profiles", "r*_route_census.txt")):
+        m = re.match(r"r(\d+)_", os.path.basename(f))
+        if m and (best is None or int(m.group(1)) > best[0]):
+            best = (int(m.group(1)), f)
+    if best is None:
+        return None
+    out = {}
+    try:
+        for line in open(best[1]):
+            m = re.match(r"fallback tail .*: (\w+)\s+(\d+) of\s+(\d+) =", line)
+            if m:
+                out[m.group(1)] = [int(m.group(2)), int(m.group(3))]
+    except OSError:
+        return None
+    if not out:
+        return None
+    out["source"] = "profiles/" + os.path.basename(best[1])
+    return out
+
+
 def headline_line(result, limit=None):
     """The RESULT line from the full record: the contract's fields, `roofline`, a trimmed `cpu_baseline`, compact `configs`;
     never longer than HEADLINE_MAX_BYTES (optional parts are dropped in a fixed order until it fits)."""
@@ -200,6 +227,8 @@ def headline_line(result, limit=None):
         if src:
             rl["traffic_source"] = src
     h["roofline"] = rl
+    if result.get("fallback_tail"):
+        h["fallback_tail"] = result["fallback_tail"]   # {entry point: [problems on strided_* / cl_* fallback kernels, problems], source}
     base = result.get("cpu_baseline")
     if base is not None:
         b = {k: base.get(k) for k in ("value", "unit", "cores", "kind", "host_cpu", "sample")}
@@ -233,6 +262,7 @@ def headline_line(result, limit=None):
         return json.dumps(h, separators=(",", ":"))
     # optional parts, least important first
     drops = [lambda: h.pop("configs_fields", None),
+             lambda: h.pop("fallback_tail", None),
              lambda: h.__setitem__("configs", {k: v for k, v in h["configs"].items() if k in BASELINE_CONFIGS}) if "configs" in h else None,
              lambda: h["config"].pop("path", None),
              lambda: [v.pop("frac_of_box", None) for v in h["kernels"].values()],
@@ -819,6 +849,8 @@ def main(argv=None):
             result["data"] = "synthetic; %d ranks share %d GPU(s): functional check, not a scaling point" % (world, ndev)
         if base is not None:
             result["cpu_baseline"] = base
+        if default_run:
+            result["fallback_tail"] = fallback_tail()
 
         # ---- the other BASELINE configs and workloads, driver-timed: same process, after the headline (whose tensors are
         # freed first), each built, warmed up, timed over >= 20 steps exactly like the headline, measured kernel by kernel

@@ -198,7 +198,9 @@ def _worst_case_record(n_ranks=8):
                                  "device_name": "AMD Instinct MI355X", "per_rank": per_rank}},
             "per_rank_ms": [2.5680001999717206] * n_ranks, "achieved_hbm_GBps_step": 6402.519626042498,
             "kernels": {"step_gather_forward": kern, "step_backward": kern}, "roofline": rl, "cpu_baseline": base,
-            "configs": configs, "configs_wall_s": 6.563866232998407}
+            "configs": configs, "configs_wall_s": 6.563866232998407,
+            "fallback_tail": {"backward": [164, 5131], "forward": [136, 5131], "forward_quantized": [74, 869],
+                              "source": "profiles/r06_route_census.txt"}}
 
 
 def test_result_line_is_last_and_bounded():

@@ -1785,20 +1785,20 @@ int plane_backward(const Geometry &g, int dtype, const void *go, const void *x, 
 // number of 16-bit elements move one element per thread (VB = 2); 1-D rows cut by a window that the flat stream declines (rows of
 // 5 - 28 elements: more than 72 planes per 4 KiB step) and -- forward -- 2-D windows on rows too long for the row-span kernels run
 // the same kernels with one element per thread.
-static int ragged_vector_bytes(int es, int64_t row_elems, int nd) {
-    if (es == 2) return (row_elems % 2 == 0 && nd == 3) ? 4 : 2;
+// (tensors at an element-aligned storage offset -- a view into a larger buffer -- are declined by every 16-byte-piece family;
+//  they end here too, whatever their rows: element-wide chunks need the element's own alignment only)
+static int ragged_vector_bytes(int es, int64_t row_elems, int nd, const void *a, const void *b, const void *c) {
+    const bool dwords = (reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(b) | reinterpret_cast<uintptr_t>(c)) % 4 == 0;
+    if (es == 2) return (row_elems % 2 == 0 && nd == 3 && dwords) ? 4 : 2;
     return es;
 }
 
 bool plane_ragged_forward_eligible(const Geometry &g, int dtype, const void *x, const void *out) {
-    (void)x;
     if (dtype > SHIFTND_BF16 || !g.active || g.nd < 1 || g.nd > 3 || g.K[0] > 0 || !common_eligible(g)) return false;
     if (g.S[0] + g.S[1] + g.S[2] + 3 > kMaxMapEntries) return false;
     if (!contiguous(g.xs, g.N, g.C, g.S) || !contiguous(g.os, g.N, g.C, g.O)) return false;
-    const int es = dtype_size(dtype);
-    if ((g.O[2] * es) % 16 == 0) return false;   // (whole pieces: plane_forward)
-    const int vb = ragged_vector_bytes(es, g.O[2], g.nd);
-    return reinterpret_cast<uintptr_t>(out) % vb == 0;
+    // (rows of whole pieces are plane_forward's, earlier in the route -- unless a pointer is not 16-byte aligned)
+    return reinterpret_cast<uintptr_t>(out) % dtype_size(dtype) == 0 && reinterpret_cast<uintptr_t>(x) % dtype_size(dtype) == 0;
 }
 
 int plane_ragged_forward(const Geometry &g, int dtype, const void *x, const void *w, void *out, hipStream_t st) {
@@ -1809,7 +1809,7 @@ int plane_ragged_forward(const Geometry &g, int dtype, const void *x, const void
     p.out = out;
     p.w = w;
     p.wkind = dtype;
-    const int vb = ragged_vector_bytes(es, g.O[2], g.nd);
+    const int vb = ragged_vector_bytes(es, g.O[2], g.nd, x, out, out);
     const Plan pl = make_plan(g, g.O[0] * g.O[1], g.O[2], es, vb, entries);
     fill_params(p, g, pl, g.O[1]);
     note_kernel("plane_active_forward_ragged");
@@ -1829,36 +1829,34 @@ int plane_ragged_forward(const Geometry &g, int dtype, const void *x, const void
     return SHIFTND_OK;
 }
 
-static Plan ragged_backward_plan(const Geometry &g, int es) {
+// (vb: the chunk width; the plan's record count is largest for the narrowest chunk, so the workspace is sized for vb = es)
+static Plan ragged_backward_plan(const Geometry &g, int es, int vb) {
     const int entries = static_cast<int>(g.S[0] + g.S[1] + g.S[2] + g.O[0] + g.O[1] + g.O[2] + 6);
-    return make_plan(g, g.S[0] * g.S[1], g.S[2], es, ragged_vector_bytes(es, g.S[2], g.nd), entries, backward_min_wgs(g, es));
+    return make_plan(g, g.S[0] * g.S[1], g.S[2], es, vb, entries, backward_min_wgs(g, es));
 }
 
-// (nd == 2 never reached the fallback in the census -- the flat stream and the row-span kernels take every 2-D backward -- and has no
-//  instantiation here)
 bool plane_ragged_backward_eligible(const Geometry &g, int dtype, const void *go, const void *x, const void *gx) {
-    (void)go;
-    (void)x;
-    if (dtype > SHIFTND_BF16 || (g.nd != 3 && g.nd != 1) || g.K[0] > 0 || !common_eligible(g)) return false;
+    if (dtype > SHIFTND_BF16 || g.nd < 1 || g.nd > 3 || g.K[0] > 0 || !common_eligible(g)) return false;
     if (g.S[0] + g.S[1] + g.S[2] + g.O[0] + g.O[1] + g.O[2] + 6 > kMaxMapEntries) return false;
     if (!contiguous(g.xs, g.N, g.C, g.S) || !contiguous(g.os, g.N, g.C, g.O) || !contiguous(g.gs, g.N, g.C, g.S)) return false;
-    const int es = dtype_size(dtype);
-    if (g.nd == 3 && (g.S[2] * es) % 16 == 0) return false;   // (whole pieces: plane_backward)
-    const int vb = ragged_vector_bytes(es, g.S[2], g.nd);
-    // (the incoming gradient's rows are read by element-aligned loads: a window along the row needs no alignment of its own)
-    return reinterpret_cast<uintptr_t>(gx) % vb == 0;
+    // (rows of whole pieces are plane_backward's, earlier in the route -- unless a pointer is not 16-byte aligned)
+    const uintptr_t es = static_cast<uintptr_t>(dtype_size(dtype));
+    return reinterpret_cast<uintptr_t>(gx) % es == 0 && reinterpret_cast<uintptr_t>(x) % es == 0 && reinterpret_cast<uintptr_t>(go) % es == 0;
 }
 
 size_t plane_ragged_backward_workspace(const Geometry &g, int dtype) {
-    if (dtype > SHIFTND_BF16 || (g.nd != 3 && g.nd != 1) || g.C < 1 || g.N < 1 || g.S[0] * g.S[1] * g.S[2] < 1) return 0;
-    const Plan pl = ragged_backward_plan(g, dtype_size(dtype));
-    return static_cast<size_t>(pl.groups) * pl.bands * static_cast<size_t>(g.C) * 3 * sizeof(double);
+    if (dtype > SHIFTND_BF16 || g.nd < 1 || g.nd > 3 || g.C < 1 || g.N < 1 || g.S[0] * g.S[1] * g.S[2] < 1) return 0;
+    const int es = dtype_size(dtype);
+    const Plan a = ragged_backward_plan(g, es, es), b = ragged_backward_plan(g, es, es == 2 ? 4 : es);
+    const size_t recs = std::max(static_cast<size_t>(a.groups) * a.bands, static_cast<size_t>(b.groups) * b.bands);
+    return recs * static_cast<size_t>(g.C) * 3 * sizeof(double);
 }
 
 int plane_ragged_backward(const Geometry &g, int dtype, const void *go, const void *x, const void *w, void *gx, void *gw,
                           void *workspace, hipStream_t st) {
     const int es = dtype_size(dtype);
-    const Plan pl = ragged_backward_plan(g, es);
+    const int vb = ragged_vector_bytes(es, g.S[2], g.nd, go, x, gx);
+    const Plan pl = ragged_backward_plan(g, es, vb);
     PlaneParams p{};
     p.x = x;
     p.go = go;
@@ -1870,12 +1868,12 @@ int plane_ragged_backward(const Geometry &g, int dtype, const void *go, const vo
     note_kernel("plane_backward_ragged");
     const dim3 grid(pl.grid), block(kThreads);
     const bool active = g.active != 0;
-    const int vb = ragged_vector_bytes(es, g.S[2], g.nd);
 #define SHIFTND_RAGGED_BWD_K(TT, NDV, VBV) \
     if (active) hipLaunchKernelGGL((plane_backward<TT, NDV, true, false, VBV>), grid, block, pl.lds, st, p); \
     else hipLaunchKernelGGL((plane_backward<TT, NDV, false, false, VBV>), grid, block, pl.lds, st, p);
 #define SHIFTND_RAGGED_BWD(TT, VB1, VB3) \
     if (g.nd == 1) { SHIFTND_RAGGED_BWD_K(TT, 1, VB1) } \
+    else if (g.nd == 2) { SHIFTND_RAGGED_BWD_K(TT, 2, VB1) } \
     else if (vb == VB1) { SHIFTND_RAGGED_BWD_K(TT, 3, VB1) } \
     else { SHIFTND_RAGGED_BWD_K(TT, 3, VB3) } \
     reduce_weight_grads_of<TT>(p.partials, pl.groups * pl.bands, p.C, p.nd, gw, st);

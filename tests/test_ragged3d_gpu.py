@@ -127,6 +127,52 @@ def test_fallback_tail_vs_oracle(abi, shape, crop, dts, kf, kb):
                 assert torch.equal(gx, gx2) and torch.equal(gw, gw2)
 
 
+def _offset_copy(t, elems):
+    """the same values at a storage offset of `elems` elements (a view into a larger buffer): element-aligned, not 16-byte aligned"""
+    big = torch.empty(t.numel() + 16, dtype=t.dtype, device=t.device)
+    v = big[elems:elems + t.numel()].view(t.shape)
+    v.copy_(t)
+    assert v.data_ptr() % 16 != 0 and v.is_contiguous()
+    return v
+
+
+@pytest.mark.parametrize("shape,crop", [((8, 16, 14, 14), None), ((4, 8, 7, 7), None), ((2, 4, 6, 8, 8), None), ((4, 8, 64), None),
+                                        ((2, 3, 16, 24), [[1, 0], [2, 1]]), ((2, 2, 5, 6, 16), [[1, 1], [0, 1], [2, 2]])])
+def test_element_aligned_storage_offsets(abi, shape, crop):
+    """tensors at an element-aligned storage offset (every 16-byte-piece family declines them) ran the one-thread-per-element
+    strided kernels; they take the direct-load plane kernels with element-wide chunks now.  Against the oracle, every padding, both shifts."""
+    nd = len(shape) - 2
+    b, new = abi.check_borders(list(shape), crop, nd)
+    for dt in ("f32", "f64", "f16", "bf16"):
+        tdt = TDT[dt]
+        rs = np.random.RandomState(sum(shape) * 7 + len(dt))
+        xt = torch.from_numpy(rs.uniform(-1, 1, size=shape)).to(tdt)
+        gt = torch.from_numpy(rs.uniform(-1, 1, size=new)).to(tdt)
+        wt = torch.from_numpy(_weights(rs, shape[1], nd, shape[2:])).to(tdt)
+        wide = np.float64 if tdt == torch.float64 else np.float32
+        x, go, w = (t.to(torch.float64).numpy().astype(wide) for t in (xt, gt, wt))
+        es = xt.element_size()
+        xd, god, wd = _offset_copy(xt.to(DEV), 1), _offset_copy(gt.to(DEV), 3 if es < 8 else 1), wt.to(DEV)
+        for pad in range(5):
+            outb = _offset_copy(torch.zeros(new, dtype=tdt, device=DEV), 1)
+            out = abi.forward(xd, wd, pad, 1, b, out=outb)
+            assert not abi.last_kernel().startswith("strided"), ("fwd", shape, crop, dt, abi.last_kernel())
+            ref = torch.from_numpy(O.forward(x, w, pad, 1, b)).to(tdt)
+            assert (torch.equal(out.cpu(), ref) if es >= 4 else _ulp_close(out.cpu(), ref, tdt)), ("fwd", shape, crop, dt, pad)
+            for active in (0, 1):
+                gxb = _offset_copy(torch.zeros(shape, dtype=tdt, device=DEV), 1)
+                gx, gw = abi.backward(god, wd, xd, pad, active, b, grad_x=gxb)
+                assert not abi.last_kernel().startswith("strided"), ("bwd", shape, crop, dt, abi.last_kernel())   # (band_plane_ / plane_backward_ragged)
+                gx_ref = torch.from_numpy(O.backward(go, w, x, pad, active, b)[0]).to(tdt)
+                if es >= 4 or not active:
+                    assert torch.equal(gx.cpu(), gx_ref), ("gx", shape, crop, dt, pad, active)
+                else:
+                    assert _ulp_close(gx.cpu(), gx_ref, tdt), ("gx", shape, crop, dt, pad, active)
+                _, gw64 = O.backward(go.astype(np.float64), w.astype(np.float64), x.astype(np.float64), pad, active, b)
+                tol = {"f32": 1e-5, "f64": 1e-12}.get(dt, gw16_tol(torch.finfo(tdt).eps))
+                assert rel_err(gw.to(torch.float64).cpu().numpy(), gw64) < tol, ("gw", shape, crop, dt, pad, active)
+
+
 def test_ragged_volume_at_size(abi):
     """N8 C128 16 x 28 x 28 bf16 (a video network's 28 x 28 stage): linearity of the backward in the incoming gradient and the
     forward's values (1 ulp) against the strided fallback (policy 1), which the oracle-sized cases above pin"""

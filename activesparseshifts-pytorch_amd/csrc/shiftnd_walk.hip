@@ -190,10 +190,19 @@ __device__ __forceinline__ void walk_read(const char *tile, const WalkWindow<NA>
 
 // LEAN (paddings 1 .. 4): the workgroup's channel has small column shifts in both maps -- every window is five plain dwords between
 // filled guards, no gather path, five window addresses instead of nine.  The kernel picks the body per workgroup (its channel's shifts).
-template <typename T, bool ACTIVE, bool ZEROS, bool LEAN>
+//
+// CROP (round 6, zeros padding only): the incoming gradient is the gradient of a WINDOW [O0, O1, O2] at (L0, L1, L2) of the volume
+// (ops/shifts.cpp:93-135; Shift3d behind emulate_dw).  The gradient tile holds window rows as they lie from window column 0 -- piece tc
+// = window columns 8 tc .. 8 tc + 7, masked beyond O2 (the load runs on into the next row) -- so the crop along the row is one more
+// column shift of the gradient window (cg2 + L2), along rows and planes an offset of the staged row / plane index; the own chunk
+// (window columns ji - L2 ..) comes from the two aligned pieces around it through a funnel of L2 <= 2 elements, and grad_x is masked to
+// the window (the reference leaves it zero outside: shifts_kernels.h:291-313 with the window's sizes).  Window rows of an even number
+// of elements (every row starts on a dword), host: walk16_crop_geometry_ok.
+template <typename T, bool ACTIVE, bool ZEROS, bool LEAN, bool CROP = false>
 __device__ __forceinline__ void walk_backward16_body(const StepParams &p) {
     using S = typename T::S;
     static_assert(sizeof(S) == 2, "16-bit element types");
+    static_assert(!CROP || (ZEROS && !LEAN), "the cropped walk: zeros padding");
     constexpr int E = 8;
     constexpr bool PLAIN = ZEROS || LEAN;   // (what walk_read needs to know)
     constexpr int NA = PLAIN ? 5 : 9;
@@ -225,30 +234,53 @@ __device__ __forceinline__ void walk_backward16_body(const StepParams &p) {
         *reinterpret_cast<u4_t *>(__builtin_assume_aligned(smem + o, 16)) = u4_t{0u, 0u, 0u, 0u};
 
     // ---- the pieces this thread stages, the same for every plane: piece tc of row tr, tr <= min(R, Rn) ----------------------
+    // the gradient's geometry: the volume's own, or (CROP) the window's -- P0 / P1 / P2 = its sizes, K0 / K1 / K2 = its first plane / row / column
+    const int O0 = CROP ? p.P0 : S0, O1 = CROP ? p.P1 : S1, O2 = CROP ? p.P2 : S2;
+    const int L0 = CROP ? p.K0 : 0, L1 = CROP ? p.K1 : 0, L2 = CROP ? p.K2 : 0;
     const bool own = tr <= R && tr <= Rn;
     const int sx_own = own ? row_map(b0 + tr, d.cx1, S1, pad) : -1;
-    const int sg_own = (own && (ACTIVE || tr < R)) ? row_map(b0 + tr, d.cg1, S1, pad) : -1;
+    const int sg_own = (own && (ACTIVE || tr < R)) ? row_map(b0 + tr - L1, d.cg1, O1, pad) : -1;
     constexpr uint32_t kOOR = 0x80000000u;
     constexpr int kRsrcFlags = 0x00020000;
     const uint32_t plane_bytes = static_cast<uint32_t>(S1) * static_cast<uint32_t>(S2) * 2u;
     const uint32_t vol_bytes = static_cast<uint32_t>(S0) * plane_bytes;   // < 2^31 (host)
+    const uint32_t gplane_bytes = CROP ? static_cast<uint32_t>(O1) * static_cast<uint32_t>(O2) * 2u : plane_bytes;
+    const uint32_t gvol_bytes = CROP ? static_cast<uint32_t>(O0) * gplane_bytes : vol_bytes;
     const char *xp = reinterpret_cast<const char *>(static_cast<const S *>(p.x) + static_cast<int64_t>(plane) * p.x_plane);
-    const char *gp = reinterpret_cast<const char *>(static_cast<const S *>(p.go) + static_cast<int64_t>(plane) * p.x_plane);
+    const char *gp = reinterpret_cast<const char *>(static_cast<const S *>(p.go) + static_cast<int64_t>(plane) * (CROP ? p.g_plane : p.x_plane));
     char *gxp = reinterpret_cast<char *>(static_cast<S *>(p.out) + static_cast<int64_t>(plane) * p.x_plane);
     const __amdgpu_buffer_rsrc_t xres = __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(xp), 0, vol_bytes, kRsrcFlags);
-    const __amdgpu_buffer_rsrc_t gres = __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(gp), 0, vol_bytes, kRsrcFlags);
+    const __amdgpu_buffer_rsrc_t gres = __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(gp), 0, gvol_bytes, kRsrcFlags);
     const __amdgpu_buffer_rsrc_t ores = __builtin_amdgcn_make_buffer_rsrc(gxp, 0, vol_bytes, kRsrcFlags);
     const __amdgpu_buffer_rsrc_t none = __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(xp), 0, 0, kRsrcFlags);
     const uint32_t vx_own = sx_own >= 0 ? static_cast<uint32_t>(sx_own * S2 + ji) * 2u : kOOR;
-    const uint32_t vg_own = sg_own >= 0 ? static_cast<uint32_t>(sg_own * S2 + ji) * 2u : kOOR;
+    const uint32_t vg_own = sg_own >= 0 ? static_cast<uint32_t>(sg_own * O2 + ji) * 2u : kOOR;   // (CROP: window columns ji .., as they lie)
+    // CROP: dword masks of a piece -- the staged gradient piece keeps window columns ji + k < O2; the own chunk and grad_x keep the
+    // columns ji + k of the volume that lie in the window's row (and nothing in a row outside the window)
+    auto dword_masks = [&](int first, int len, bool row_in, uint32_t (&m)[4]) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const bool lo = row_in && static_cast<unsigned>(first + 2 * i) < static_cast<unsigned>(len);
+            const bool hi = row_in && static_cast<unsigned>(first + 2 * i + 1) < static_cast<unsigned>(len);
+            m[i] = (lo ? 0x0000ffffu : 0u) | (hi ? 0xffff0000u : 0u);
+        }
+    };
+    uint32_t mstage[4] = {~0u, ~0u, ~0u, ~0u}, mown[4] = {~0u, ~0u, ~0u, ~0u};
+    if constexpr (CROP) {
+        dword_masks(ji, O2, true, mstage);
+        dword_masks(ji - L2, O2, static_cast<unsigned>(b0 + tr - L1) < static_cast<unsigned>(O1), mown);
+    }
     // (a thread without a piece loads zeros -- out-of-range offset -- and parks them in a dump slot: every memory
     //  instruction of the loop is unconditional, the compiler's wait counts are exact)
     const uint32_t park_at = static_cast<uint32_t>(own ? kWalkMargin + tr * RP + tc : kWalkDump0 + (tid & 63)) * 4u;
     struct Staged { u4_t xo, go; };
     auto load_planes = [&](int pax, int pag, Staged &v) {   // source planes (uniform; -1: fill)
         v.xo = __builtin_amdgcn_raw_buffer_load_b128(pax >= 0 ? xres : none, vx_own, pax >= 0 ? static_cast<uint32_t>(pax) * plane_bytes : 0u, 0);
-        v.go = __builtin_amdgcn_raw_buffer_load_b128(pag >= 0 ? gres : none, vg_own, pag >= 0 ? static_cast<uint32_t>(pag) * plane_bytes : 0u, 0);
+        v.go = __builtin_amdgcn_raw_buffer_load_b128(pag >= 0 ? gres : none, vg_own, pag >= 0 ? static_cast<uint32_t>(pag) * gplane_bytes : 0u, 0);
     };
+    // the plane maps: x over the volume; the gradient over the volume or (CROP) over the window, whose plane 0 is the volume's L0
+    auto xmap0 = [&](int a) { return row_map(a, d.cx0, S0, pad); };
+    auto gmap0 = [&](int a) { return row_map(a - L0, d.cg0, O0, pad); };
     auto park_piece = [&](char *tile, const u4_t &v) {
         uint32_t *q = reinterpret_cast<uint32_t *>(tile + park_at);
         q[0] = v.x;
@@ -265,7 +297,8 @@ __device__ __forceinline__ void walk_backward16_body(const StepParams &p) {
     const WalkGuards gdg = walk_guards(small_g, own && (ACTIVE || tr < R), tc == 0, tc == cpr - 1, pad, slot0, cpr, tid & 63);
     auto park = [&](const Staged &v) {
         park_piece(tx, v.xo);
-        park_piece(tg, v.go);
+        if constexpr (CROP) park_piece(tg, u4_t{v.go.x & mstage[0], v.go.y & mstage[1], v.go.z & mstage[2], v.go.w & mstage[3]});
+        else park_piece(tg, v.go);
         if constexpr (!ZEROS) {
             if (small_x) walk_park_guards(tx, gdx, v.xo, pad);   // (uniform)
             if (small_g) walk_park_guards(tg, gdg, v.go, pad);
@@ -276,13 +309,43 @@ __device__ __forceinline__ void walk_backward16_body(const StepParams &p) {
     const bool mine = tr < R && tr < Rn;
     const int b = b0 + tr;
     const WalkWindow<NA> wx = walk_window<ZEROS, NA, LEAN>(ji, small_x ? sx2 : d.cx2, S2, pad, slot0, mine, small_x);
-    const WalkWindow<NA> wg = walk_window<ZEROS, NA, LEAN>(ji, small_g ? sg2 : d.cg2, S2, pad, slot0, mine, small_g);
+    const WalkWindow<NA> wg = walk_window<ZEROS, NA, LEAN>(ji, (small_g ? sg2 : d.cg2) + L2, S2, pad, slot0, mine, small_g);
     const uint32_t row1 = static_cast<uint32_t>(RP) * 4u;
-    const int px = (small_x ? sx2 : d.cx2) & 1, pg = (small_g ? sg2 : d.cg2) & 1;   // half-word parity of the windows (uniform: rows are whole pieces)
+    const int px = (small_x ? sx2 : d.cx2) & 1, pg = ((small_g ? sg2 : d.cg2) + L2) & 1;   // half-word parity of the windows (uniform: rows are whole pieces)
     const float dP = static_cast<float>(d.dw[0]), dR = static_cast<float>(d.dw[1]), dC = static_cast<float>(d.dw[2]);
     const uint32_t my = mine ? static_cast<uint32_t>(b * S2 + ji) * 2u : kOOR;   // own chunk, bytes within a plane
+    // CROP: the own chunk = window columns ji - L2 .. ji - L2 + 7 of window row b - L1, plane a - L0: the aligned pieces tc - 1 and tc
+    const bool mine_g = mine && static_cast<unsigned>(b - L1) < static_cast<unsigned>(O1);
+    const uint32_t myg = mine_g ? static_cast<uint32_t>((b - L1) * O2 + ji) * 2u : kOOR;
+    const uint32_t myg_prev = (mine_g && tc > 0 && L2 > 0) ? myg - 16u : kOOR;
+    struct OwnRaw { u4_t lo, hi; };
     auto load_own = [&](int a, bool have) {
-        return __builtin_amdgcn_raw_buffer_load_b128(have ? gres : none, my, static_cast<uint32_t>(a) * plane_bytes, 0);
+        OwnRaw o;
+        if constexpr (CROP) {
+            const bool in = have && static_cast<unsigned>(a - L0) < static_cast<unsigned>(O0);   // (uniform)
+            const uint32_t so = in ? static_cast<uint32_t>(a - L0) * gplane_bytes : 0u;
+            o.lo = __builtin_amdgcn_raw_buffer_load_b128(in ? gres : none, myg_prev, so, 0);
+            o.hi = __builtin_amdgcn_raw_buffer_load_b128(in ? gres : none, myg, so, 0);
+        } else {
+            o.hi = __builtin_amdgcn_raw_buffer_load_b128(have ? gres : none, my, static_cast<uint32_t>(a) * plane_bytes, 0);
+            o.lo = o.hi;
+        }
+        return o;
+    };
+    // the chunk as the wgrad sums pair it with the x dwords: CROP funnels L2 elements of the previous piece in front, and masks
+    auto own_chunk = [&](const OwnRaw &o) {
+        if constexpr (!CROP) {
+            return o.hi;
+        } else {
+            u4_t r = o.hi;
+            if (L2 == 1) {          // (uniform)
+                r = u4_t{__builtin_amdgcn_alignbit(o.hi.x, o.lo.w, 16), __builtin_amdgcn_alignbit(o.hi.y, o.hi.x, 16),
+                         __builtin_amdgcn_alignbit(o.hi.z, o.hi.y, 16), __builtin_amdgcn_alignbit(o.hi.w, o.hi.z, 16)};
+            } else if (L2 == 2) {
+                r = u4_t{o.lo.w, o.hi.x, o.hi.y, o.hi.z};
+            }
+            return u4_t{r.x & mown[0], r.y & mown[1], r.z & mown[2], r.w & mown[3]};
+        }
     };
     auto lerp = [](float v1, float v2, float x) { return lerp1_fused<float>(v1, v2, x); };
 
@@ -335,12 +398,12 @@ __device__ __forceinline__ void walk_backward16_body(const StepParams &p) {
     // travel together with the "+0" planes (one memory round trip per workgroup instead of two)
     constexpr int GA = ACTIVE ? 1 : 0;   // the gradient plane of step a: the "+1" corner plane / the plane the tap reads
     Staged stA, stB;
-    u4_t gcur;
+    OwnRaw gcur;
     {
         Staged v0;
-        load_planes(row_map(a0, d.cx0, S0, pad), ACTIVE ? row_map(a0, d.cg0, S0, pad) : -1, v0);
-        load_planes(row_map(a0 + 1, d.cx0, S0, pad), row_map(a0 + GA, d.cg0, S0, pad), stA);
-        load_planes(a0 + 1 < a1 ? row_map(a0 + 2, d.cx0, S0, pad) : -1, a0 + 1 < a1 ? row_map(a0 + 1 + GA, d.cg0, S0, pad) : -1, stB);
+        load_planes(xmap0(a0), ACTIVE ? gmap0(a0) : -1, v0);
+        load_planes(xmap0(a0 + 1), gmap0(a0 + GA), stA);
+        load_planes(a0 + 1 < a1 ? xmap0(a0 + 2) : -1, a0 + 1 < a1 ? gmap0(a0 + 1 + GA) : -1, stB);
         gcur = load_own(a0, true);
         walk_barrier();   // the tiles are zero
         park(v0);
@@ -378,9 +441,12 @@ __device__ __forceinline__ void walk_backward16_body(const StepParams &p) {
         park(pend);
         walk_barrier();
         const bool more = a + 2 < a1;
-        load_planes(more ? row_map(a + 3, d.cx0, S0, pad) : -1, more ? row_map(a + 2 + GA, d.cg0, S0, pad) : -1, pend);
-        if (px) wgrad(par1{}, gcur, x0, x1, sa, sb);
-        else wgrad(par0{}, gcur, x0, x1, sa, sb);
+        load_planes(more ? xmap0(a + 3) : -1, more ? gmap0(a + 2 + GA) : -1, pend);
+        {
+            const u4_t gown = own_chunk(gcur);
+            if (px) wgrad(par1{}, gown, x0, x1, sa, sb);
+            else wgrad(par0{}, gown, x0, x1, sa, sb);
+        }
         gcur = load_own(a + 1, a + 1 < a1);   // the next step's own chunk: in flight through the blends and the next staging
         u4_t res;
         if constexpr (ACTIVE) {
@@ -403,6 +469,10 @@ __device__ __forceinline__ void walk_backward16_body(const StepParams &p) {
                 walk_read<PLAIN, NA, 0>(tg, wg, 0u, t);
                 res = u4_t{t[0], t[1], t[2], t[3]};
             }
+        }
+        if constexpr (CROP) {   // grad_x is zero outside the window (mown: the row and the columns; the plane: uniform)
+            const uint32_t keep = static_cast<unsigned>(a - L0) < static_cast<unsigned>(O0) ? ~0u : 0u;
+            res = u4_t{res.x & mown[0] & keep, res.y & mown[1] & keep, res.z & mown[2] & keep, res.w & mown[3] & keep};
         }
         buffer_store_b128_soffset<kWalkStoreAux>(res, ores, my, static_cast<uint32_t>(a) * plane_bytes);
         if (((a - a0) & (kWalkFlush - 1)) == kWalkFlush - 1) flush();
@@ -442,10 +512,10 @@ __device__ __forceinline__ void walk_backward16_body(const StepParams &p) {
     }
 }
 
-template <typename T, bool ACTIVE, bool ZEROS>
+template <typename T, bool ACTIVE, bool ZEROS, bool CROP = false>
 __global__ __launch_bounds__(kThreads) void walk_backward16(const StepParams p) {
     if constexpr (ZEROS) {
-        walk_backward16_body<T, ACTIVE, true, false>(p);
+        walk_backward16_body<T, ACTIVE, true, false, CROP>(p);
     } else {
         const uint32_t bid = (blockIdx.x & 7u) * p.steps_per_xcd + (blockIdx.x >> 3);
         if (bid >= p.total_steps) return;
@@ -615,13 +685,29 @@ WalkPlan walk_plan(const Geometry &g) {
     return w;
 }
 
-bool walk16_geometry_ok(const Geometry &g, int dtype) {
+bool walk16_volume_ok(const Geometry &g, int dtype) {
     if ((dtype != SHIFTND_F16 && dtype != SHIFTND_BF16) || g.nd != 3 || g.K[0] > 0 || g.S[0] < 2) return false;
-    for (int d = 0; d < 3; ++d)
-        if (g.O[d] != g.S[d] || g.L[d] != 0) return false;
     if (g.S[1] < 1 || (g.S[2] * 2) % 16 != 0 || g.S[2] * 2 / 16 > kThreads / 2 || g.S[2] > 32000) return false;
     if (g.S[0] * g.S[1] * g.S[2] * 2 >= (1LL << 31)) return false;   // (one buffer resource spans an (n, c) volume)
     return walk_plan(g).total + 8 < (1ull << 31);
+}
+
+bool walk16_cropped(const Geometry &g) {
+    for (int d = 0; d < 3; ++d)
+        if (g.O[d] != g.S[d] || g.L[d] != 0) return true;
+    return false;
+}
+
+bool walk16_geometry_ok(const Geometry &g, int dtype) { return walk16_volume_ok(g, dtype) && !walk16_cropped(g); }
+
+// walk_backward16<.., CROP>: zeros padding, a window with rows of an even number of elements (every window row starts on a dword)
+// that begins at most two columns into the volume's rows (the own chunk's funnel), every window dim at least 2 (a size-1 dim ignores
+// its shift: the general kernels).  Knob 35 bit 11 keeps crop_backward3.
+bool walk16_crop_geometry_ok(const Geometry &g, int dtype) {
+    if (!walk16_volume_ok(g, dtype) || !walk16_cropped(g) || g.pad != 0 || (g_step_tune[3] & 2048)) return false;
+    for (int d = 0; d < 3; ++d)
+        if (g.O[d] < 2 || g.L[d] < 0 || g.L[d] + g.O[d] > g.S[d]) return false;
+    return g.O[2] % 2 == 0 && g.L[2] <= 2;
 }
 
 }  // namespace
@@ -676,12 +762,12 @@ int walk16_forward(const Geometry &g, int dtype, const void *x, const void *w, i
 // the 3-D backward of fp16 / bf16 tensors (both shifts, every padding): contiguous, no crop, rows of whole 16-byte pieces
 bool walk16_backward_eligible(const Geometry &g, int dtype, const void *go, const void *x, const void *gx) {
     if (g_step_tune[0] == 1 || (g_step_tune[3] & 16)) return false;   // knob 32 = 1: never; knob 35 bit 4: no walk kernels
-    if (!walk16_geometry_ok(g, dtype)) return false;
+    if (!walk16_geometry_ok(g, dtype) && !walk16_crop_geometry_ok(g, dtype)) return false;
     if (!dense(g.xs, g.N, g.C, g.S) || !dense(g.os, g.N, g.C, g.O) || !dense(g.gs, g.N, g.C, g.S)) return false;
     return reinterpret_cast<uintptr_t>(go) % 16 == 0 && reinterpret_cast<uintptr_t>(x) % 16 == 0 && reinterpret_cast<uintptr_t>(gx) % 16 == 0;
 }
 
-size_t walk16_backward_workspace(const Geometry &g, int dtype) { return walk16_geometry_ok(g, dtype) ? walk_plan(g).bytes : 0; }
+size_t walk16_backward_workspace(const Geometry &g, int dtype) { return walk16_volume_ok(g, dtype) ? walk_plan(g).bytes : 0; }
 
 int walk16_backward(const Geometry &g, int dtype, const void *go, const void *x, const void *w, void *gx, void *gw, void *workspace,
                     hipStream_t st) {
@@ -719,11 +805,24 @@ int walk16_backward(const Geometry &g, int dtype, const void *go, const void *x,
     const size_t lds = 2 * kWalkTileBytes + (kThreads / 64) * 8 * sizeof(double);
     const dim3 grid(p.steps_per_xcd * 8), block(kThreads);
     const bool active = g.active != 0, zeros = g.pad == 0;
-    note_kernel(active ? "walk_backward16" : "walk_backward16_sparse");
+    const bool crop = walk16_cropped(g);
+    if (crop) {   // the window: sizes in P0 / P1 / P2, its first plane / row / column in K0 / K1 / K2 (walk_backward16<.., CROP>)
+        p.P0 = static_cast<int>(g.O[0]);
+        p.P1 = static_cast<int>(g.O[1]);
+        p.P2 = static_cast<int>(g.O[2]);
+        p.K0 = static_cast<int>(g.L[0]);
+        p.K1 = static_cast<int>(g.L[1]);
+        p.K2 = static_cast<int>(g.L[2]);
+        p.g_plane = g.O[0] * g.O[1] * g.O[2];
+    }
+    note_kernel(crop ? (active ? "walk_backward16_crop" : "walk_backward16_crop_sparse") : (active ? "walk_backward16" : "walk_backward16_sparse"));
 #define SHIFTND_WALK16(TT) \
     { \
         launch_step_prep(TT::kDtype, active, p, st); \
-        if (active) { \
+        if (crop) { \
+            if (active) hipLaunchKernelGGL((walk_backward16<TT, true, true, true>), grid, block, lds, st, p); \
+            else hipLaunchKernelGGL((walk_backward16<TT, false, true, true>), grid, block, lds, st, p); \
+        } else if (active) { \
             if (zeros) hipLaunchKernelGGL((walk_backward16<TT, true, true>), grid, block, lds, st, p); \
             else hipLaunchKernelGGL((walk_backward16<TT, true, false>), grid, block, lds, st, p); \
         } else { \

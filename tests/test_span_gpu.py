@@ -273,7 +273,7 @@ def test_ragged_rows_forward_vs_oracle(abi, shape, crop, dt):
 # ragged last step, shifts beyond the volume (the weights of _weights), windows of two planes
 CASES_3D = [((2, 3, 5, 6, 8), [[1, 1], [1, 1], [1, 1]]), ((1, 4, 4, 9, 16), [[0, 1], [2, 0], [1, 2]]), ((2, 2, 6, 7, 32), [[2, 2], [0, 0], [0, 0]]),
             ((1, 2, 3, 70, 16), [[0, 0], [1, 1], [0, 0]]), ((1, 3, 8, 5, 24), [[3, 3], [1, 2], [5, 6]]), ((2, 2, 4, 12, 64), [[1, 0], [0, 3], [7, 9]]),
-            ((1, 2, 16, 20, 112), [[1, 1], [1, 1], [1, 1]])]
+            ((1, 2, 16, 20, 112), [[1, 1], [1, 1], [1, 1]]), ((1, 2, 4, 6, 16), [[0, 1], [1, 0], [2, 2]]), ((2, 2, 3, 40, 32), [[0, 0], [0, 0], [2, 0]])]
 
 
 @pytest.mark.parametrize("dt", ["f32", "f64", "f16", "bf16"])
@@ -290,10 +290,19 @@ def test_cropped_3d_backward_vs_oracle(abi, shape, crop, dt):
     x, go, w = (t.to(torch.float64).numpy().astype(wide) for t in (xt, gt, wt))
     xd, god, wd = xt.to(DEV), gt.to(DEV), wt.to(DEV)
     served = (shape[-1] * es) % 16 == 0 and min(shape[2:]) >= 2 and min(new[2:]) >= 2
+    # 16-bit tensors under zeros padding: the walk through the planes with the window inside (walk_backward16<.., CROP>) -- window rows of
+    # an even number of elements that begin at most two columns into the volume's rows
+    walk = served and es == 2 and new[-1] % 2 == 0 and crop[2][0] <= 2
     for pad in range(5):
         for active in (0, 1):
             gx, gw = abi.backward(god, wd, xd, pad, active, b)
-            if served:
+            if walk and pad == 0:
+                assert abi.last_kernel() == ("walk_backward16_crop" if active else "walk_backward16_crop_sparse"), (shape, crop, pad, abi.last_kernel())
+                abi.set_tuning(35, 2048)   # (knob 35 bit 11: the one-step kernel it replaces -- the sparse shift moves the same bits)
+                gx1, _ = abi.backward(god, wd, xd, pad, active, b)
+                abi.set_tuning(35, 0)
+                assert abi.last_kernel() == "crop_backward3" and (active or torch.equal(gx1, gx)), (shape, crop, dt, active)
+            elif served:
                 assert abi.last_kernel() == "crop_backward3", (shape, crop, pad, abi.last_kernel())
             gx_ref = torch.from_numpy(O.backward(go, w, x, pad, active, b)[0]).to(tdt)
             if es >= 4 or not active:
@@ -311,10 +320,11 @@ def test_cropped_3d_backward_vs_oracle(abi, shape, crop, dt):
             gx2, gw2 = abi.backward(god, wd, xd, pad, active, b)
             assert torch.equal(gx, gx2) and torch.equal(gw, gw2)  # deterministic
             # the plane kernels it replaces give the same grad_x (knob 35 bit 10)
-            abi.set_tuning(35, 1024)
+            abi.set_tuning(35, 1024 + 2048)
             gx3, _ = abi.backward(god, wd, xd, pad, active, b)
             abi.set_tuning(35, 0)
-            assert abi.last_kernel() != "crop_backward3" and torch.equal(gx3, gx), (shape, crop, dt, pad, active)
+            assert abi.last_kernel() not in ("crop_backward3", "walk_backward16_crop", "walk_backward16_crop_sparse")
+            assert torch.equal(gx3, gx) or (walk and pad == 0 and active and _ulp_close(gx3.cpu(), gx.cpu(), tdt)), (shape, crop, dt, pad, active)
 
 
 @pytest.mark.parametrize("dt", ["f32", "f64", "f16", "bf16"])

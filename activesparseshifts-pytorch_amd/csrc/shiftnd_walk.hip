@@ -704,10 +704,7 @@ bool walk16_geometry_ok(const Geometry &g, int dtype) { return walk16_volume_ok(
 // that begins at most two columns into the volume's rows (the own chunk's funnel), every window dim at least 2 (a size-1 dim ignores
 // its shift: the general kernels).  Knob 35 bit 11 keeps crop_backward3.
 bool walk16_crop_geometry_ok(const Geometry &g, int dtype) {
-    if (!walk16_volume_ok(g, dtype) || !walk16_cropped(g) || g.pad != 0 || (g_step_tune[3] & 2048)) return false;
-    for (int d = 0; d < 3; ++d)
-        if (g.O[d] < 2 || g.L[d] < 0 || g.L[d] + g.O[d] > g.S[d]) return false;
-    return g.O[2] % 2 == 0 && g.L[2] <= 2;
+    return walk16_volume_ok(g, dtype) && walk_crop_window_ok(g) && g.O[2] % 2 == 0;
 }
 
 }  // namespace
@@ -814,6 +811,7 @@ int walk16_backward(const Geometry &g, int dtype, const void *go, const void *x,
         p.K1 = static_cast<int>(g.L[1]);
         p.K2 = static_cast<int>(g.L[2]);
         p.g_plane = g.O[0] * g.O[1] * g.O[2];
+        p.crop = 1;
     }
     note_kernel(crop ? (active ? "walk_backward16_crop" : "walk_backward16_crop_sparse") : (active ? "walk_backward16" : "walk_backward16_sparse"));
 #define SHIFTND_WALK16(TT) \

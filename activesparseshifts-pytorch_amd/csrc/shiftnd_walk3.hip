@@ -216,8 +216,14 @@ __global__ __launch_bounds__(kThreads) void walk_forward(const FwdParams p) {
 // ACTIVE = false: the sparse shift.  Its weight gradient is the same eight corner sums (the x corners around i - round(w),
 // fractions frac(|w|): shifts_cpu.cpp:242-244); its grad_x is ONE tap of the gradient -- go(g0[a], g1[b], gcol[j]) -- so the
 // step stages the gradient plane g0[a] itself (no "+1" plane, nothing carried) and copies the window.
-template <typename T, int PAD, bool POOL = false, bool ACTIVE = true>
+// CROP (round 6; zeros padding, no pool): `go` is the gradient of a WINDOW [P0, P1, P2] that begins at (K0, K1, K2) of the volume
+// (ops/shifts.cpp:93-135) -- see walk_backward16<.., CROP> (shiftnd_walk.hip): the staged gradient rows are window rows as they lie
+// from window column 0, the crop along the row is one more column shift of the gradient's map (cg2 + K2, columns beyond P2 masked by
+// the map), rows and planes are offsets of the staged index, the own chunk comes from the two aligned pieces around it, and grad_x is
+// zero outside the window.
+template <typename T, int PAD, bool POOL = false, bool ACTIVE = true, bool CROP = false>
 __global__ __launch_bounds__(kThreads) void walk_backward(const StepParams p) {
+    static_assert(!CROP || (PAD == 0 && !POOL), "the cropped walk: zeros padding, no pool");
     using S = typename T::S;
     using CT = typename T::C;
     constexpr int E = 16 / sizeof(S);
@@ -240,8 +246,11 @@ __global__ __launch_bounds__(kThreads) void walk_backward(const StepParams p) {
     const int Rn = min(R, S1 - b0);
     const int RB = S2 * static_cast<int>(sizeof(S));
     const char *xp = reinterpret_cast<const char *>(static_cast<const S *>(p.x) + static_cast<int64_t>(plane) * p.x_plane);
-    const S *gp = static_cast<const S *>(p.go) + static_cast<int64_t>(plane) * (POOL ? p.g_plane : p.x_plane);
+    const S *gp = static_cast<const S *>(p.go) + static_cast<int64_t>(plane) * ((POOL || CROP) ? p.g_plane : p.x_plane);
     S *gxp = static_cast<S *>(p.out) + static_cast<int64_t>(plane) * p.x_plane;
+    // the gradient's geometry: the volume's, or (CROP) the window's
+    const int O0 = CROP ? p.P0 : S0, O1 = CROP ? p.P1 : S1, O2 = CROP ? p.P2 : S2;
+    const int L0 = CROP ? p.K0 : 0, L1 = CROP ? p.K1 : 0, L2 = CROP ? p.K2 : 0;
 
     const int tid = static_cast<int>(threadIdx.x);
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -249,17 +258,17 @@ __global__ __launch_bounds__(kThreads) void walk_backward(const StepParams p) {
     const int ji = tc * E;
     ColState<E> xm, gm;
     if constexpr (PAD == 0) {
-        auto affine_state = [&](int cs) {
+        auto affine_state = [&](int cs, int len) {
             ColState<E> st;
             st.base = ji - cs;
-            if (st.base + E < 0 || st.base >= S2) st.base = 0;
+            if (st.base + E < 0 || st.base >= len) st.base = 0;
             st.affine = true;
 #pragma unroll
-            for (int e = 0; e <= E; ++e) st.cm[e] = (ji - cs + e >= 0 && ji - cs + e < S2) ? ji - cs + e : -1;
+            for (int e = 0; e <= E; ++e) st.cm[e] = (ji - cs + e >= 0 && ji - cs + e < len) ? ji - cs + e : -1;
             return st;
         };
-        xm = affine_state(d.cx2);
-        gm = affine_state(d.cg2);
+        xm = affine_state(d.cx2, S2);
+        gm = affine_state(d.cg2 + L2, O2);
     } else {
         const size_t rec = (static_cast<size_t>(c) * cpr + tc) * REC;
         xm = load_colstate<E>(p.colx + rec);
@@ -270,10 +279,11 @@ __global__ __launch_bounds__(kThreads) void walk_backward(const StepParams p) {
     // the step's last row included -- so a plane costs one load per tensor and thread, and two planes can be in flight)
     const bool own = tr <= R && tr <= Rn;
     const int sx_own = own ? row_map_t<PAD>(b0 + tr, d.cx1, S1, p.pad) : -1;
-    const int sg_own = (own && (ACTIVE || tr < R)) ? row_map_t<PAD>(b0 + tr, d.cg1, S1, p.pad) : -1;
-    auto piece_off = [&](int row, int piece) { return static_cast<uint32_t>(max(row, 0) * S2 + piece * E) * static_cast<uint32_t>(sizeof(S)); };
-    const uint32_t ox_own = piece_off(sx_own, tc), og_own = piece_off(sg_own, tc);
+    const int sg_own = (own && (ACTIVE || tr < R)) ? row_map_t<PAD>(b0 + tr - L1, d.cg1, O1, p.pad) : -1;
+    auto piece_off = [&](int row, int piece, int rowlen) { return static_cast<uint32_t>(max(row, 0) * rowlen + piece * E) * static_cast<uint32_t>(sizeof(S)); };
+    const uint32_t ox_own = piece_off(sx_own, tc, S2), og_own = piece_off(sg_own, tc, O2);
     const uint32_t plane_bytes = static_cast<uint32_t>(S1) * static_cast<uint32_t>(S2) * static_cast<uint32_t>(sizeof(S));
+    const uint32_t gplane_bytes = CROP ? static_cast<uint32_t>(O1) * static_cast<uint32_t>(O2) * static_cast<uint32_t>(sizeof(S)) : plane_bytes;
     const int GP0 = (R + 1) * cpr;   // first LDS piece of the gradient group
     // Staging goes global -> registers -> LDS, TWO planes ahead (two register sets alternate, the loop is unrolled by two): the
     // loads of planes a + 2 and a + 3 are in flight while step a is computed -- a step lasts about as long as a memory round
@@ -288,7 +298,7 @@ __global__ __launch_bounds__(kThreads) void walk_backward(const StepParams p) {
     const uint32_t vol_bytes = static_cast<uint32_t>(S0) * plane_bytes;   // < 2^31 (host)
     const __amdgpu_buffer_rsrc_t xres = __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(xp), 0, vol_bytes, kRsrcFlags);
     const __amdgpu_buffer_rsrc_t gres = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<S *>(gp), 0, POOL ? static_cast<uint32_t>(p.g_plane) * static_cast<uint32_t>(sizeof(S)) : vol_bytes, kRsrcFlags);
+        const_cast<S *>(gp), 0, (POOL || CROP) ? static_cast<uint32_t>(p.g_plane) * static_cast<uint32_t>(sizeof(S)) : vol_bytes, kRsrcFlags);
     // POOL: the 8 bytes of pooled row `row / K1` under piece `piece` of unpooled row `row`, bytes within a pooled plane; the
     // window rows the pooled row averages
     typedef uint32_t u2 __attribute__((ext_vector_type(2)));
@@ -342,7 +352,7 @@ __global__ __launch_bounds__(kThreads) void walk_backward(const StepParams p) {
             pooled_plane(pag, sg, v.n0);
             v.po = __builtin_amdgcn_raw_buffer_load_b64(pag >= 0 ? gres : none, vg_own, sg, 0);
         } else {
-            const uint32_t sg = pag >= 0 ? static_cast<uint32_t>(pag) * plane_bytes : 0u;
+            const uint32_t sg = pag >= 0 ? static_cast<uint32_t>(pag) * gplane_bytes : 0u;
             v.go = __builtin_amdgcn_raw_buffer_load_b128(pag >= 0 ? gres : none, vg_own, sg, 0);
         }
     };
@@ -364,7 +374,7 @@ __global__ __launch_bounds__(kThreads) void walk_backward(const StepParams p) {
 #pragma unroll
         for (int e = 0; e <= E; ++e) xm.cm[e] = gm.cm[e] = -1;
     }
-    const int phx = (-d.cx2 * ES) & 15, phg = (-d.cg2 * ES) & 15;
+    const int phx = (-d.cx2 * ES) & 15, phg = (-(d.cg2 + L2) * ES) & 15;
     const bool fx = PAD == 0 || (xm.affine && ((xm.base * ES) & 15) == phx);
     const bool fg = PAD == 0 || (gm.affine && ((gm.base * ES) & 15) == phg);
     uint32_t xmask[5] = {0, 0, 0, 0, 0}, gmask[5] = {0, 0, 0, 0, 0};   // 16-bit data: per-dword column masks
@@ -440,7 +450,7 @@ __global__ __launch_bounds__(kThreads) void walk_backward(const StepParams p) {
     uint32_t cxp[2][5];
     CT cx[PACKED ? 1 : 2][PACKED ? 1 : E + 1], cg[2][E + 1];   // the "+0" planes' corner rows
     {
-        const int pax0 = row_map_t<PAD>(a0, d.cx0, S0, p.pad), pag0 = ACTIVE ? row_map_t<PAD>(a0, d.cg0, S0, p.pad) : -1;
+        const int pax0 = row_map_t<PAD>(a0, d.cx0, S0, p.pad), pag0 = ACTIVE ? row_map_t<PAD>(a0 - L0, d.cg0, O0, p.pad) : -1;
         Staged v0;
         load_planes(pax0, pag0, v0);
         park(v0);
@@ -473,6 +483,9 @@ __global__ __launch_bounds__(kThreads) void walk_backward(const StepParams p) {
         part[i] = CT(0);
     }
     const uint32_t my = mine ? static_cast<uint32_t>(b * S2 + ji) * static_cast<uint32_t>(sizeof(S)) : kOOR;   // own chunk, bytes within a plane
+    const bool mine_g = mine && static_cast<unsigned>(b - L1) < static_cast<unsigned>(O1);   // CROP: the own row lies in the window
+    const uint32_t myg = mine_g ? static_cast<uint32_t>((b - L1) * O2 + ji) * static_cast<uint32_t>(sizeof(S)) : kOOR;
+    const uint32_t myg_prev = (mine_g && tc > 0 && L2 > 0) ? myg - 16u : kOOR;
     const uint32_t myp = (POOL && mine) ? pooled_off(b, tc) : kOOR;   // POOL: its pooled bytes
     const int n1_my = POOL ? pooled_rows(b) : 1;
     auto load_own = [&](int a, bool have) {   // the incoming gradient at the thread's own chunk of plane a (raw: u4, or the pooled 8 bytes in .xy)
@@ -483,8 +496,41 @@ __global__ __launch_bounds__(kThreads) void walk_backward(const StepParams p) {
             pooled_plane(a, sg, n0);
             const u2 q = __builtin_amdgcn_raw_buffer_load_b64(have ? gres : none, myp, sg, 0);
             r = u4{q.x, q.y, static_cast<uint32_t>(n0), 0u};
+        } else if constexpr (CROP) {   // (the piece at the thread's own window columns; its predecessor: load_own_prev)
+            const bool in = have && static_cast<unsigned>(a - L0) < static_cast<unsigned>(O0);   // (uniform)
+            r = __builtin_amdgcn_raw_buffer_load_b128(in ? gres : none, myg, in ? static_cast<uint32_t>(a - L0) * gplane_bytes : 0u, 0);
         } else {
             r = __builtin_amdgcn_raw_buffer_load_b128(have ? gres : none, my, static_cast<uint32_t>(a) * plane_bytes, 0);
+        }
+        return r;
+    };
+    auto load_own_prev = [&](int a, bool have) {
+        u4 r = u4{0u, 0u, 0u, 0u};
+        if constexpr (CROP) {
+            const bool in = have && static_cast<unsigned>(a - L0) < static_cast<unsigned>(O0);
+            r = __builtin_amdgcn_raw_buffer_load_b128(in ? gres : none, myg_prev, in ? static_cast<uint32_t>(a - L0) * gplane_bytes : 0u, 0);
+        }
+        return r;
+    };
+    // CROP: the own chunk = window columns ji - L2 ..: L2 elements of the previous aligned piece in front (a funnel by whole dwords:
+    // 4- / 8-byte elements), columns beyond the window's row and rows outside the window zero
+    bool keep_col[E];
+#pragma unroll
+    for (int e = 0; e < E; ++e) keep_col[e] = !CROP || (mine_g && static_cast<unsigned>(ji + e - L2) < static_cast<unsigned>(O2));
+    auto own_chunk = [&](const u4 &lo, const u4 &hi) {
+        u4 r = hi;
+        if constexpr (CROP) {
+            const int sd = L2 * ES / 4;   // dwords (uniform): 0, 1, 2 or 4
+            if (sd == 1) r = u4{lo.w, hi.x, hi.y, hi.z};
+            else if (sd == 2) r = u4{lo.z, lo.w, hi.x, hi.y};
+            else if (sd == 4) r = lo;
+            Chunk<S, E> c;
+            __builtin_memcpy(c.e, &r, 16);
+            S zero;
+            __builtin_memset(&zero, 0, sizeof(S));
+#pragma unroll
+            for (int e = 0; e < E; ++e) c.e[e] = keep_col[e] ? c.e[e] : zero;
+            __builtin_memcpy(&r, c.e, 16);
         }
         return r;
     };
@@ -493,18 +539,21 @@ __global__ __launch_bounds__(kThreads) void walk_backward(const StepParams p) {
     // the planes of steps a0 and a0 + 1 (steps that do not exist: empty resources; a buffer's range check does not see the
     // scalar offset)
     Staged stA, stB;
-    load_planes(row_map_t<PAD>(a0 + 1, d.cx0, S0, p.pad), row_map_t<PAD>(a0 + GA, d.cg0, S0, p.pad), stA);
-    load_planes(a0 + 1 < a1 ? row_map_t<PAD>(a0 + 2, d.cx0, S0, p.pad) : -1, a0 + 1 < a1 ? row_map_t<PAD>(a0 + 1 + GA, d.cg0, S0, p.pad) : -1, stB);
-    u4 gcur = load_own(a0, true);
+    load_planes(row_map_t<PAD>(a0 + 1, d.cx0, S0, p.pad), row_map_t<PAD>(a0 + GA - L0, d.cg0, O0, p.pad), stA);
+    load_planes(a0 + 1 < a1 ? row_map_t<PAD>(a0 + 2, d.cx0, S0, p.pad) : -1, a0 + 1 < a1 ? row_map_t<PAD>(a0 + 1 + GA - L0, d.cg0, O0, p.pad) : -1, stB);
+    u4 gcur = load_own(a0, true), gprev = load_own_prev(a0, true);
     auto walk_step = [&](int a, Staged &pend) {   // `pend` holds the planes of step a; it leaves with those of step a + 2 in flight
         park(pend);
         __syncthreads();
         const bool more = a + 2 < a1;
-        load_planes(more ? row_map_t<PAD>(a + 3, d.cx0, S0, p.pad) : -1, more ? row_map_t<PAD>(a + 2 + GA, d.cg0, S0, p.pad) : -1, pend);
+        load_planes(more ? row_map_t<PAD>(a + 3, d.cx0, S0, p.pad) : -1, more ? row_map_t<PAD>(a + 2 + GA - L0, d.cg0, O0, p.pad) : -1, pend);
         Chunk<S, E> gch;
         if constexpr (POOL) {
             const u4 ex = expand(u2{gcur.x, gcur.y}, static_cast<int>(gcur.z) * n1_my * 2);
             __builtin_memcpy(gch.e, &ex, 16);
+        } else if constexpr (CROP) {
+            const u4 oc = own_chunk(gprev, gcur);
+            __builtin_memcpy(gch.e, &oc, 16);
         } else {
             __builtin_memcpy(gch.e, &gcur, 16);
         }
@@ -559,6 +608,7 @@ __global__ __launch_bounds__(kThreads) void walk_backward(const StepParams p) {
         }
         // the next step's own chunk: in flight through the blends below and the next step's staging
         gcur = load_own(a + 1, a + 1 < a1);
+        if constexpr (CROP) gprev = load_own_prev(a + 1, a + 1 < a1);
         // ---- grad_x ------------------------------------------------------------------------------------------------
         Chunk<S, E> res;
         if constexpr (ACTIVE) {
@@ -595,6 +645,13 @@ __global__ __launch_bounds__(kThreads) void walk_backward(const StepParams p) {
             window(rows_g, gm, fg, phg, gmask, rg);
 #pragma unroll
             for (int e = 0; e < E; ++e) res.e[e] = rg[e];
+        }
+        if constexpr (CROP) {   // grad_x is zero outside the window
+            const bool in_plane = static_cast<unsigned>(a - L0) < static_cast<unsigned>(O0);   // (uniform)
+            S zero;
+            __builtin_memset(&zero, 0, sizeof(S));
+#pragma unroll
+            for (int e = 0; e < E; ++e) res.e[e] = (in_plane && keep_col[e]) ? res.e[e] : zero;
         }
         {
             u4 bits;
@@ -763,8 +820,10 @@ static bool walk_backward_core(const Geometry &g, int dtype, const void *go, con
     if (g_step_tune[0] == 1 || (g_step_tune[3] & 16)) return false;   // knob 32 = 1: never; knob 35 bit 4: no walk kernels
     if (dtype > SHIFTND_BF16 || g.nd != 3 || g.S[0] < 2) return false;
     const int es = dtype_size(dtype);
-    for (int d = 0; d < 3; ++d)
-        if (g.O[d] != g.S[d] || g.L[d] != 0) return false;
+    bool cropped = false;
+    for (int d = 0; d < 3; ++d) cropped = cropped || g.O[d] != g.S[d] || g.L[d] != 0;
+    // (a window: walk_backward<.., CROP> -- 4-byte elements, zeros padding, no pool)
+    if (cropped && (pooled || es != 4 || !walk_crop_window_ok(g))) return false;
     if (g.S[1] < 1 || (g.S[2] * es) % 16 != 0 || g.S[2] * es / 16 > kThreads || g.S[2] > 32000) return false;
     if (g.S[0] * g.S[1] * g.S[2] >= (1LL << 30)) return false;
     if (!dense(g.xs, g.N, g.C, g.S) || (!pooled && !dense(g.os, g.N, g.C, g.O)) || !dense(g.gs, g.N, g.C, g.S)) return false;
@@ -789,7 +848,12 @@ template <typename T> static void launch_walk_backward(StepParams &p, size_t lds
     constexpr bool PLAIN = sizeof(S) != 2;
 #define SHIFTND_WALK_BWD(PADV) \
     case PADV: \
-        if (!active && p.K0 > 0) hipLaunchKernelGGL((walk_backward<T, PADV, true, false>), grid, block, lds, st, p); \
+        if (p.crop) { \
+            if constexpr (PADV == 0 && sizeof(S) == 4) { \
+                if (!active) hipLaunchKernelGGL((walk_backward<T, 0, false, false, true>), grid, block, lds, st, p); \
+                else hipLaunchKernelGGL((walk_backward<T, 0, false, true, true>), grid, block, lds, st, p); \
+            } \
+        } else if (!active && p.K0 > 0) hipLaunchKernelGGL((walk_backward<T, PADV, true, false>), grid, block, lds, st, p); \
         else if (p.K0 > 0) hipLaunchKernelGGL((walk_backward<T, PADV, true>), grid, block, lds, st, p); \
         else if constexpr (PLAIN) { \
             if (!active) hipLaunchKernelGGL((walk_backward<T, PADV, false, false>), grid, block, lds, st, p); \
@@ -813,6 +877,18 @@ int walk3_backward_launch(StepParams &p, const Geometry &g, int dtype, int cpr, 
             p.d_k0 = make_fastdiv(static_cast<uint32_t>(p.K0));
             p.g_plane = g.P[0] * g.P[1] * g.P[2];
         }
+        bool crop = false;
+        for (int d = 0; d < 3; ++d) crop = crop || g.O[d] != g.S[d] || g.L[d] != 0;
+        if (crop) {   // walk_backward<.., CROP>: the window's sizes in P0 / P1 / P2, its first plane / row / column in K0 / K1 / K2
+            p.crop = 1;
+            p.P0 = static_cast<int>(g.O[0]);
+            p.P1 = static_cast<int>(g.O[1]);
+            p.P2 = static_cast<int>(g.O[2]);
+            p.K0 = static_cast<int>(g.L[0]);
+            p.K1 = static_cast<int>(g.L[1]);
+            p.K2 = static_cast<int>(g.L[2]);
+            p.g_plane = g.O[0] * g.O[1] * g.O[2];
+        }
         const int rmax = std::min<int>(kThreads / L.cpr - 1, p.S1);   // (R + 1) * cpr <= 256: every staged piece has its thread
         p.spp = (p.S1 + rmax - 1) / rmax;
         p.R = (p.S1 + p.spp - 1) / p.spp;
@@ -833,7 +909,7 @@ int walk3_backward_launch(StepParams &p, const Geometry &g, int dtype, int cpr, 
         p.d_spp = make_fastdiv(static_cast<uint32_t>(p.spp));
         p.d_spv = make_fastdiv(static_cast<uint32_t>(p.spv));
         const size_t lds = 64 + static_cast<size_t>(2 * (p.R + 1)) * L.cpr * 16 + kThreads * 16 + kThreads * 8 * sizeof(double) + 64;   // tile, dump slots, sums, pad
-        note_kernel(g.K[0] > 0 ? "walk_backward_pool" : (g.active ? "walk_backward" : "walk_backward_sparse"));
+        note_kernel(g.K[0] > 0 ? "walk_backward_pool" : (crop ? (g.active ? "walk_backward_crop" : "walk_backward_crop_sparse") : (g.active ? "walk_backward" : "walk_backward_sparse")));
         switch (dtype) {
         case SHIFTND_F32: launch_walk_backward<f32_t>(p, lds, g.active != 0, gw, st); break;
         case SHIFTND_F64: launch_walk_backward<f64_t>(p, lds, g.active != 0, gw, st); break;

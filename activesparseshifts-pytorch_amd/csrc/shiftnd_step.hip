@@ -512,7 +512,7 @@ static bool step_backward_core(const Geometry &g, int dtype, const void *go, con
     if (dtype > SHIFTND_BF16 || (g.nd != 2 && g.nd != 3)) return false;
     const int es = dtype_size(dtype);
     for (int d = 0; d < 3; ++d)
-        if ((g.O[d] != g.S[d] || g.L[d] != 0) && !(es == 4 && walk_crop_window_ok(g))) return false;   // (a window: walk_backward<.., CROP>, 3-D fp32)
+        if ((g.O[d] != g.S[d] || g.L[d] != 0) && !((es == 4 || g.K[0] > 0) && walk_crop_window_ok(g, g.K[0] > 0))) return false;   // (a window: walk_backward<.., CROP>, 3-D)
     if ((g.nd == 2 && g.S[0] != 1) || g.S[0] < 1 || g.S[1] < 1 || g.S[2] < 1) return false;
     if ((g.S[2] * es) % 16 != 0 || g.S[2] * es / 16 > kThreads || g.S[2] > 32000) return false;
     if (g.S[0] * g.S[1] * g.S[2] >= (1LL << 30)) return false;
@@ -537,7 +537,7 @@ static bool step_shape_ok(const Geometry &g, int dtype) {
     if (dtype > SHIFTND_BF16 || (g.nd != 2 && g.nd != 3)) return false;
     const int es = dtype_size(dtype);
     // (a window: the cropped walk of 3-D fp32 volumes -- geometry only: the knob's state must not shrink a workspace)
-    bool window_ok = g.nd == 3 && es == 4 && g.pad == 0 && g.K[0] <= 0 && g.L[2] <= 2;
+    bool window_ok = g.nd == 3 && (es == 4 || g.K[0] > 0) && g.pad == 0 && g.L[2] <= 2;
     for (int d = 0; d < 3; ++d) window_ok = window_ok && g.O[d] >= 2 && g.L[d] >= 0 && g.L[d] + g.O[d] <= g.S[d];
     for (int d = 0; d < 3; ++d)
         if ((g.O[d] != g.S[d] || g.L[d] != 0) && !window_ok) return false;

@@ -51,14 +51,16 @@ struct StepParams {
     int K0, P0;         // 3-D pooled calls (walk_backward<..., POOL>): window and pooled size along dim0
     FastDiv d_k0;
     int walk_planes;    // walk_backward: planes a workgroup walks through (S0, or a part of the volume's depth)
-    int crop;           // walk_backward<.., CROP> / walk_backward16<.., CROP>: `go` is the gradient of the window [P0, P1, P2] at (K0, K1, K2)
+    int crop;           // walk_backward<.., CROP> / walk_backward16<.., CROP>: `go` is the gradient of a window of the volume ...
+    int wO0, wO1, wO2;  // ... of these sizes ...
+    int wL0, wL1, wL2;  // ... that begins at this plane / row / column (with POOL: `go` is the pooled gradient of that window)
 };
 
 // the cropped walks (round 6): zeros padding, no pool, a window of at least 2 x 2 x 2 that begins at most two columns into the rows;
 // 16-bit elements: window rows of an even number of elements (shiftnd_walk.hip), 4-byte elements: shiftnd_walk3.hip.  Knob 35 bit 11
 // keeps the one-step crop_backward3.
-inline bool walk_crop_window_ok(const Geometry &g) {
-    if (g.nd != 3 || g.pad != 0 || g.K[0] > 0 || (g_step_tune[3] & 2048)) return false;
+inline bool walk_crop_window_ok(const Geometry &g, bool pooled = false) {
+    if (g.nd != 3 || g.pad != 0 || (g.K[0] > 0) != pooled || (g_step_tune[3] & 2048)) return false;
     bool cropped = false;
     for (int d = 0; d < 3; ++d) {
         if (g.O[d] < 2 || g.L[d] < 0 || g.L[d] + g.O[d] > g.S[d]) return false;

@@ -234,9 +234,9 @@ __device__ __forceinline__ void walk_backward16_body(const StepParams &p) {
         *reinterpret_cast<u4_t *>(__builtin_assume_aligned(smem + o, 16)) = u4_t{0u, 0u, 0u, 0u};
 
     // ---- the pieces this thread stages, the same for every plane: piece tc of row tr, tr <= min(R, Rn) ----------------------
-    // the gradient's geometry: the volume's own, or (CROP) the window's -- P0 / P1 / P2 = its sizes, K0 / K1 / K2 = its first plane / row / column
-    const int O0 = CROP ? p.P0 : S0, O1 = CROP ? p.P1 : S1, O2 = CROP ? p.P2 : S2;
-    const int L0 = CROP ? p.K0 : 0, L1 = CROP ? p.K1 : 0, L2 = CROP ? p.K2 : 0;
+    // the gradient's geometry: the volume's own, or (CROP) the window's (StepParams wO*, wL*)
+    const int O0 = CROP ? p.wO0 : S0, O1 = CROP ? p.wO1 : S1, O2 = CROP ? p.wO2 : S2;
+    const int L0 = CROP ? p.wL0 : 0, L1 = CROP ? p.wL1 : 0, L2 = CROP ? p.wL2 : 0;
     const bool own = tr <= R && tr <= Rn;
     const int sx_own = own ? row_map(b0 + tr, d.cx1, S1, pad) : -1;
     const int sg_own = (own && (ACTIVE || tr < R)) ? row_map(b0 + tr - L1, d.cg1, O1, pad) : -1;
@@ -803,13 +803,13 @@ int walk16_backward(const Geometry &g, int dtype, const void *go, const void *x,
     const dim3 grid(p.steps_per_xcd * 8), block(kThreads);
     const bool active = g.active != 0, zeros = g.pad == 0;
     const bool crop = walk16_cropped(g);
-    if (crop) {   // the window: sizes in P0 / P1 / P2, its first plane / row / column in K0 / K1 / K2 (walk_backward16<.., CROP>)
-        p.P0 = static_cast<int>(g.O[0]);
-        p.P1 = static_cast<int>(g.O[1]);
-        p.P2 = static_cast<int>(g.O[2]);
-        p.K0 = static_cast<int>(g.L[0]);
-        p.K1 = static_cast<int>(g.L[1]);
-        p.K2 = static_cast<int>(g.L[2]);
+    if (crop) {   // the window: sizes in wO0 / wO1 / wO2, its first plane / row / column in wL0 / wL1 / wL2 (walk_backward16<.., CROP>)
+        p.wO0 = static_cast<int>(g.O[0]);
+        p.wO1 = static_cast<int>(g.O[1]);
+        p.wO2 = static_cast<int>(g.O[2]);
+        p.wL0 = static_cast<int>(g.L[0]);
+        p.wL1 = static_cast<int>(g.L[1]);
+        p.wL2 = static_cast<int>(g.L[2]);
         p.g_plane = g.O[0] * g.O[1] * g.O[2];
         p.crop = 1;
     }

@@ -216,14 +216,14 @@ __global__ __launch_bounds__(kThreads) void walk_forward(const FwdParams p) {
 // ACTIVE = false: the sparse shift.  Its weight gradient is the same eight corner sums (the x corners around i - round(w),
 // fractions frac(|w|): shifts_cpu.cpp:242-244); its grad_x is ONE tap of the gradient -- go(g0[a], g1[b], gcol[j]) -- so the
 // step stages the gradient plane g0[a] itself (no "+1" plane, nothing carried) and copies the window.
-// CROP (round 6; zeros padding, no pool): `go` is the gradient of a WINDOW [P0, P1, P2] that begins at (K0, K1, K2) of the volume
+// CROP (round 6; zeros padding, no pool): `go` is the gradient of a WINDOW [wO0, wO1, wO2] that begins at (wL0, wL1, wL2) of the volume
 // (ops/shifts.cpp:93-135) -- see walk_backward16<.., CROP> (shiftnd_walk.hip): the staged gradient rows are window rows as they lie
-// from window column 0, the crop along the row is one more column shift of the gradient's map (cg2 + K2, columns beyond P2 masked by
+// from window column 0, the crop along the row is one more column shift of the gradient's map (cg2 + wL2, columns beyond wO2 masked by
 // the map), rows and planes are offsets of the staged index, the own chunk comes from the two aligned pieces around it, and grad_x is
 // zero outside the window.
 template <typename T, int PAD, bool POOL = false, bool ACTIVE = true, bool CROP = false>
 __global__ __launch_bounds__(kThreads) void walk_backward(const StepParams p) {
-    static_assert(!CROP || (PAD == 0 && !POOL), "the cropped walk: zeros padding, no pool");
+    static_assert(!CROP || PAD == 0, "the cropped walk: zeros padding");
     using S = typename T::S;
     using CT = typename T::C;
     constexpr int E = 16 / sizeof(S);
@@ -249,8 +249,8 @@ __global__ __launch_bounds__(kThreads) void walk_backward(const StepParams p) {
     const S *gp = static_cast<const S *>(p.go) + static_cast<int64_t>(plane) * ((POOL || CROP) ? p.g_plane : p.x_plane);
     S *gxp = static_cast<S *>(p.out) + static_cast<int64_t>(plane) * p.x_plane;
     // the gradient's geometry: the volume's, or (CROP) the window's
-    const int O0 = CROP ? p.P0 : S0, O1 = CROP ? p.P1 : S1, O2 = CROP ? p.P2 : S2;
-    const int L0 = CROP ? p.K0 : 0, L1 = CROP ? p.K1 : 0, L2 = CROP ? p.K2 : 0;
+    const int O0 = CROP ? p.wO0 : S0, O1 = CROP ? p.wO1 : S1, O2 = CROP ? p.wO2 : S2;
+    const int L0 = CROP ? p.wL0 : 0, L1 = CROP ? p.wL1 : 0, L2 = CROP ? p.wL2 : 0;
 
     const int tid = static_cast<int>(threadIdx.x);
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -297,24 +297,31 @@ __global__ __launch_bounds__(kThreads) void walk_backward(const StepParams p) {
     constexpr int kRsrcFlags = 0x00020000;
     const uint32_t vol_bytes = static_cast<uint32_t>(S0) * plane_bytes;   // < 2^31 (host)
     const __amdgpu_buffer_rsrc_t xres = __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(xp), 0, vol_bytes, kRsrcFlags);
+    // POOL + CROP of 16-bit elements: the pooled rows of a window (110 columns -> 55 pooled elements) start at 2-byte boundaries, and so may the
+    // (n, c) volume of the pooled gradient; buffer loads want dwords.  The resource starts at the dword below the volume and every 8
+    // pooled bytes are taken from the three dwords around them (pooled8)
+    constexpr bool ODD16 = POOL && CROP && sizeof(S) == 2;
+    const uint32_t gmis = ODD16 ? static_cast<uint32_t>(reinterpret_cast<uintptr_t>(gp) & 3u) : 0u;
     const __amdgpu_buffer_rsrc_t gres = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<S *>(gp), 0, (POOL || CROP) ? static_cast<uint32_t>(p.g_plane) * static_cast<uint32_t>(sizeof(S)) : vol_bytes, kRsrcFlags);
+        const_cast<char *>(reinterpret_cast<const char *>(gp) - gmis), 0,
+        ((POOL || CROP) ? static_cast<uint32_t>(p.g_plane) * static_cast<uint32_t>(sizeof(S)) : vol_bytes) + gmis, kRsrcFlags);
     // POOL: the 8 bytes of pooled row `row / K1` under piece `piece` of unpooled row `row`, bytes within a pooled plane; the
     // window rows the pooled row averages
     typedef uint32_t u2 __attribute__((ext_vector_type(2)));
+    typedef uint32_t u3 __attribute__((ext_vector_type(3)));
     auto pooled_off = [&](int row, int piece) {
         const int pr = static_cast<int>(fdiv(static_cast<uint32_t>(max(row, 0)), p.d_k1));
         return static_cast<uint32_t>(pr * p.P2 + piece * (E / 2)) * static_cast<uint32_t>(sizeof(S));
     };
     auto pooled_rows = [&](int row) {
         const int pr = static_cast<int>(fdiv(static_cast<uint32_t>(max(row, 0)), p.d_k1));
-        return min(p.K1, S1 - pr * p.K1);
+        return min(p.K1, O1 - pr * p.K1);   // (O1: the rows of the tensor the pool ran over -- the volume, or (CROP) the window)
     };
     const uint32_t pooled_plane_bytes = POOL ? static_cast<uint32_t>(p.P1) * static_cast<uint32_t>(p.P2) * static_cast<uint32_t>(sizeof(S)) : 0u;
     auto pooled_plane = [&](int pa, uint32_t &soff, int &n0) {   // unpooled plane (uniform) -> byte offset of its pooled plane, window planes
         const int pp = static_cast<int>(fdiv(static_cast<uint32_t>(max(pa, 0)), p.d_k0));
         soff = static_cast<uint32_t>(pp) * pooled_plane_bytes;
-        n0 = min(p.K0, S0 - pp * p.K0);
+        n0 = min(p.K0, O0 - pp * p.K0);
     };
     // 8 pooled bytes -> the 16-byte piece of the unpooled gradient: every element twice, divided by the window size `cnt`
     auto expand = [&](u2 raw, int cnt) {
@@ -333,6 +340,17 @@ __global__ __launch_bounds__(kThreads) void walk_backward(const StepParams p) {
     };
     const __amdgpu_buffer_rsrc_t ores = __builtin_amdgcn_make_buffer_rsrc(gxp, 0, vol_bytes, kRsrcFlags);
     const __amdgpu_buffer_rsrc_t none = __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(xp), 0, 0, kRsrcFlags);
+    // 8 pooled bytes at byte `voff` (per thread; kOOR: none) + `soff` (uniform) of the (n, c) pooled volume
+    auto pooled8 = [gmis](const __amdgpu_buffer_rsrc_t res, uint32_t voff, uint32_t soff) __attribute__((always_inline)) {
+        if constexpr (ODD16) {
+            const uint32_t eff = voff + (soff + gmis);           // (an out-of-range voff stays out of range: the volume is < 2^31 bytes)
+            const u3 d = __builtin_amdgcn_raw_buffer_load_b96(res, eff & ~3u, 0u, 0);
+            const uint32_t sh = (eff & 2u) << 3;                  // 0 or 16 bits
+            return u2{__builtin_amdgcn_alignbit(d.y, d.x, sh), __builtin_amdgcn_alignbit(d.z, d.y, sh)};
+        } else {
+            return __builtin_amdgcn_raw_buffer_load_b64(res, voff, soff, 0);
+        }
+    };
     const uint32_t vx_own = sx_own >= 0 ? ox_own : kOOR;
     const uint32_t vg_own = sg_own >= 0 ? (POOL ? pooled_off(sg_own, tc) : og_own) : kOOR;
     const int n1_own = POOL ? pooled_rows(sg_own) : 1;   // window rows of the staged piece
@@ -350,7 +368,7 @@ __global__ __launch_bounds__(kThreads) void walk_backward(const StepParams p) {
         if constexpr (POOL) {
             uint32_t sg;
             pooled_plane(pag, sg, v.n0);
-            v.po = __builtin_amdgcn_raw_buffer_load_b64(pag >= 0 ? gres : none, vg_own, sg, 0);
+            v.po = pooled8(pag >= 0 ? gres : none, vg_own, sg);
         } else {
             const uint32_t sg = pag >= 0 ? static_cast<uint32_t>(pag) * gplane_bytes : 0u;
             v.go = __builtin_amdgcn_raw_buffer_load_b128(pag >= 0 ? gres : none, vg_own, sg, 0);
@@ -486,15 +504,17 @@ __global__ __launch_bounds__(kThreads) void walk_backward(const StepParams p) {
     const bool mine_g = mine && static_cast<unsigned>(b - L1) < static_cast<unsigned>(O1);   // CROP: the own row lies in the window
     const uint32_t myg = mine_g ? static_cast<uint32_t>((b - L1) * O2 + ji) * static_cast<uint32_t>(sizeof(S)) : kOOR;
     const uint32_t myg_prev = (mine_g && tc > 0 && L2 > 0) ? myg - 16u : kOOR;
-    const uint32_t myp = (POOL && mine) ? pooled_off(b, tc) : kOOR;   // POOL: its pooled bytes
-    const int n1_my = POOL ? pooled_rows(b) : 1;
+    const uint32_t myp = (POOL && mine_g) ? pooled_off(b - L1, tc) : kOOR;   // POOL: its pooled bytes (CROP: of the piece at the own window columns)
+    const uint32_t myp_prev = (POOL && CROP && mine_g && tc > 0 && L2 > 0) ? myp - 8u : kOOR;
+    const int n1_my = POOL ? pooled_rows(max(b - L1, 0)) : 1;
     auto load_own = [&](int a, bool have) {   // the incoming gradient at the thread's own chunk of plane a (raw: u4, or the pooled 8 bytes in .xy)
         u4 r;
         if constexpr (POOL) {
             uint32_t sg;
             int n0;
-            pooled_plane(a, sg, n0);
-            const u2 q = __builtin_amdgcn_raw_buffer_load_b64(have ? gres : none, myp, sg, 0);
+            const bool in = have && (!CROP || static_cast<unsigned>(a - L0) < static_cast<unsigned>(O0));   // (uniform)
+            pooled_plane(a - L0, sg, n0);
+            const u2 q = pooled8(in ? gres : none, myp, in ? sg : 0u);
             r = u4{q.x, q.y, static_cast<uint32_t>(n0), 0u};
         } else if constexpr (CROP) {   // (the piece at the thread's own window columns; its predecessor: load_own_prev)
             const bool in = have && static_cast<unsigned>(a - L0) < static_cast<unsigned>(O0);   // (uniform)
@@ -506,7 +526,14 @@ __global__ __launch_bounds__(kThreads) void walk_backward(const StepParams p) {
     };
     auto load_own_prev = [&](int a, bool have) {
         u4 r = u4{0u, 0u, 0u, 0u};
-        if constexpr (CROP) {
+        if constexpr (CROP && POOL) {
+            uint32_t sg;
+            int n0;
+            const bool in = have && static_cast<unsigned>(a - L0) < static_cast<unsigned>(O0);
+            pooled_plane(a - L0, sg, n0);
+            const u2 q = pooled8(in ? gres : none, myp_prev, in ? sg : 0u);
+            r = u4{q.x, q.y, static_cast<uint32_t>(n0), 0u};
+        } else if constexpr (CROP) {
             const bool in = have && static_cast<unsigned>(a - L0) < static_cast<unsigned>(O0);
             r = __builtin_amdgcn_raw_buffer_load_b128(in ? gres : none, myg_prev, in ? static_cast<uint32_t>(a - L0) * gplane_bytes : 0u, 0);
         }
@@ -520,10 +547,12 @@ __global__ __launch_bounds__(kThreads) void walk_backward(const StepParams p) {
     auto own_chunk = [&](const u4 &lo, const u4 &hi) {
         u4 r = hi;
         if constexpr (CROP) {
-            const int sd = L2 * ES / 4;   // dwords (uniform): 0, 1, 2 or 4
-            if (sd == 1) r = u4{lo.w, hi.x, hi.y, hi.z};
-            else if (sd == 2) r = u4{lo.z, lo.w, hi.x, hi.y};
-            else if (sd == 4) r = lo;
+            const int sb = L2 * ES;   // bytes (uniform): 0, 2, 4, 8 or 16
+            if (sb == 2) r = u4{__builtin_amdgcn_alignbit(hi.x, lo.w, 16), __builtin_amdgcn_alignbit(hi.y, hi.x, 16), __builtin_amdgcn_alignbit(hi.z, hi.y, 16),
+                                __builtin_amdgcn_alignbit(hi.w, hi.z, 16)};
+            else if (sb == 4) r = u4{lo.w, hi.x, hi.y, hi.z};
+            else if (sb == 8) r = u4{lo.z, lo.w, hi.x, hi.y};
+            else if (sb == 16) r = lo;
             Chunk<S, E> c;
             __builtin_memcpy(c.e, &r, 16);
             S zero;
@@ -548,7 +577,10 @@ __global__ __launch_bounds__(kThreads) void walk_backward(const StepParams p) {
         const bool more = a + 2 < a1;
         load_planes(more ? row_map_t<PAD>(a + 3, d.cx0, S0, p.pad) : -1, more ? row_map_t<PAD>(a + 2 + GA - L0, d.cg0, O0, p.pad) : -1, pend);
         Chunk<S, E> gch;
-        if constexpr (POOL) {
+        if constexpr (POOL && CROP) {
+            const u4 oc = own_chunk(expand(u2{gprev.x, gprev.y}, static_cast<int>(gprev.z) * n1_my * 2), expand(u2{gcur.x, gcur.y}, static_cast<int>(gcur.z) * n1_my * 2));
+            __builtin_memcpy(gch.e, &oc, 16);
+        } else if constexpr (POOL) {
             const u4 ex = expand(u2{gcur.x, gcur.y}, static_cast<int>(gcur.z) * n1_my * 2);
             __builtin_memcpy(gch.e, &ex, 16);
         } else if constexpr (CROP) {
@@ -822,8 +854,9 @@ static bool walk_backward_core(const Geometry &g, int dtype, const void *go, con
     const int es = dtype_size(dtype);
     bool cropped = false;
     for (int d = 0; d < 3; ++d) cropped = cropped || g.O[d] != g.S[d] || g.L[d] != 0;
-    // (a window: walk_backward<.., CROP> -- 4-byte elements, zeros padding, no pool)
-    if (cropped && (pooled || es != 4 || !walk_crop_window_ok(g))) return false;
+    // (a window: walk_backward<.., CROP> -- zeros padding; 4-byte elements, or -- with the pool riding on the walk -- 2-byte ones too:
+    //  the pooled gradient of a window with rows of an even number of elements)
+    if (cropped && (es == 8 || (!pooled && es != 4) || !walk_crop_window_ok(g, pooled) || (pooled && g.O[2] % 2 != 0))) return false;
     if (g.S[1] < 1 || (g.S[2] * es) % 16 != 0 || g.S[2] * es / 16 > kThreads || g.S[2] > 32000) return false;
     if (g.S[0] * g.S[1] * g.S[2] >= (1LL << 30)) return false;
     if (!dense(g.xs, g.N, g.C, g.S) || (!pooled && !dense(g.os, g.N, g.C, g.O)) || !dense(g.gs, g.N, g.C, g.S)) return false;
@@ -848,7 +881,12 @@ template <typename T> static void launch_walk_backward(StepParams &p, size_t lds
     constexpr bool PLAIN = sizeof(S) != 2;
 #define SHIFTND_WALK_BWD(PADV) \
     case PADV: \
-        if (p.crop) { \
+        if (p.crop && p.K0 > 0) { \
+            if constexpr (PADV == 0 && sizeof(S) != 8) { \
+                if (!active) hipLaunchKernelGGL((walk_backward<T, 0, true, false, true>), grid, block, lds, st, p); \
+                else hipLaunchKernelGGL((walk_backward<T, 0, true, true, true>), grid, block, lds, st, p); \
+            } \
+        } else if (p.crop) { \
             if constexpr (PADV == 0 && sizeof(S) == 4) { \
                 if (!active) hipLaunchKernelGGL((walk_backward<T, 0, false, false, true>), grid, block, lds, st, p); \
                 else hipLaunchKernelGGL((walk_backward<T, 0, false, true, true>), grid, block, lds, st, p); \
@@ -879,15 +917,15 @@ int walk3_backward_launch(StepParams &p, const Geometry &g, int dtype, int cpr, 
         }
         bool crop = false;
         for (int d = 0; d < 3; ++d) crop = crop || g.O[d] != g.S[d] || g.L[d] != 0;
-        if (crop) {   // walk_backward<.., CROP>: the window's sizes in P0 / P1 / P2, its first plane / row / column in K0 / K1 / K2
+        if (crop) {   // walk_backward<.., CROP>: the window's sizes in wO0 / wO1 / wO2, its first plane / row / column in wL0 / wL1 / wL2
             p.crop = 1;
-            p.P0 = static_cast<int>(g.O[0]);
-            p.P1 = static_cast<int>(g.O[1]);
-            p.P2 = static_cast<int>(g.O[2]);
-            p.K0 = static_cast<int>(g.L[0]);
-            p.K1 = static_cast<int>(g.L[1]);
-            p.K2 = static_cast<int>(g.L[2]);
-            p.g_plane = g.O[0] * g.O[1] * g.O[2];
+            p.wO0 = static_cast<int>(g.O[0]);
+            p.wO1 = static_cast<int>(g.O[1]);
+            p.wO2 = static_cast<int>(g.O[2]);
+            p.wL0 = static_cast<int>(g.L[0]);
+            p.wL1 = static_cast<int>(g.L[1]);
+            p.wL2 = static_cast<int>(g.L[2]);
+            if (g.K[0] <= 0) p.g_plane = g.O[0] * g.O[1] * g.O[2];   // (pooled: the pooled window's elements, set above)
         }
         const int rmax = std::min<int>(kThreads / L.cpr - 1, p.S1);   // (R + 1) * cpr <= 256: every staged piece has its thread
         p.spp = (p.S1 + rmax - 1) / rmax;
@@ -909,7 +947,7 @@ int walk3_backward_launch(StepParams &p, const Geometry &g, int dtype, int cpr, 
         p.d_spp = make_fastdiv(static_cast<uint32_t>(p.spp));
         p.d_spv = make_fastdiv(static_cast<uint32_t>(p.spv));
         const size_t lds = 64 + static_cast<size_t>(2 * (p.R + 1)) * L.cpr * 16 + kThreads * 16 + kThreads * 8 * sizeof(double) + 64;   // tile, dump slots, sums, pad
-        note_kernel(g.K[0] > 0 ? "walk_backward_pool" : (crop ? (g.active ? "walk_backward_crop" : "walk_backward_crop_sparse") : (g.active ? "walk_backward" : "walk_backward_sparse")));
+        note_kernel(g.K[0] > 0 ? (crop ? "walk_backward_crop_pool" : "walk_backward_pool") : (crop ? (g.active ? "walk_backward_crop" : "walk_backward_crop_sparse") : (g.active ? "walk_backward" : "walk_backward_sparse")));
         switch (dtype) {
         case SHIFTND_F32: launch_walk_backward<f32_t>(p, lds, g.active != 0, gw, st); break;
         case SHIFTND_F64: launch_walk_backward<f64_t>(p, lds, g.active != 0, gw, st); break;

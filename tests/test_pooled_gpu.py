@@ -91,9 +91,12 @@ def test_pooled_vs_oracle(abi, dt):
                 crop3 = (nd == 3 and crop is not None and (shape[-1] * x.itemsize) % 16 == 0 and min(shape[2:]) >= 2 and min(new[2:]) >= 2)
                 # ... unless the windows are 2 x 2 x 2 (4-byte elements here): crop_backward3<.., POOL> fuses the pool
                 fused3 = crop3 and tuple(pool) == (2, 2, 2) and x.itemsize == 4 and -(-new[-1] // 2) >= 2
-                if fused3:
+                # (zeros padding, 4-byte elements here, windows (K0, K1, 2) over a crop that begins at most two columns into the rows and
+                #  has an even width: the walk through the planes with the window inside and the pool riding on it, walk_backward<.., POOL, .., CROP>)
+                cwalk = crop3 and pad == 0 and x.itemsize == 4 and pool[-1] == 2 and crop[2][0] <= 2 and new[-1] % 2 == 0
+                if fused3 or cwalk:
                     gx, gw = abi.backward_pooled(_dev(gp), wd, xd, pad, active, pool, b)
-                    assert abi.last_kernel() == "crop_backward3_pool", key + (abi.last_kernel(),)
+                    assert abi.last_kernel() == ("walk_backward_crop_pool" if cwalk else "crop_backward3_pool"), key + (abi.last_kernel(),)
                     assert np.array_equal(gx.cpu().numpy(), gx_r), key
                     assert rel_err(gw.cpu().numpy(), gw_r) < 1e-5, key
                     continue
@@ -123,7 +126,8 @@ def test_pooled_16bit(abi, tdt):
     for nd, shape, pool, crop in [(2, (2, 4, 12, 16), (2, 2), None), (3, (1, 3, 6, 6, 8), (2, 2, 2), None),
                                   (2, (2, 3, 13, 24), (3, 2), [[1, 0], [0, 3]]), (2, (2, 3, 18, 32), (2, 2), [[1, 1], [1, 1]]),
                                   (2, (1, 2, 21, 40), (2, 2), [[1, 1], [1, 1]]), (3, (1, 3, 6, 9, 16), (2, 2, 2), [[1, 1], [1, 1], [1, 1]]),
-                                  (3, (2, 2, 5, 7, 24), (2, 2, 2), None)]:
+                                  (3, (2, 2, 5, 7, 24), (2, 2, 2), None), (3, (1, 2, 5, 8, 24), (2, 2, 2), [[1, 0], [0, 1], [2, 2]]),
+                                  (3, (2, 2, 4, 20, 32), (2, 2, 2), [[0, 0], [1, 1], [1, 1]])]:
         xt = torch.from_numpy(rs.uniform(-1, 1, size=shape).astype(np.float32)).to(tdt)
         wt = torch.from_numpy(rs.uniform(-2.5, 2.5, size=(shape[1], nd)).astype(np.float32)).to(tdt)
         x, w = xt.float().numpy(), wt.float().numpy()
@@ -144,8 +148,10 @@ def test_pooled_16bit(abi, tdt):
                     gx, gw = abi.backward_pooled(gpt.to(DEV), wt.to(DEV), xt.to(DEV), pad, active, pool, b)
                     abi.set_path_policy(0)
                     if nd == 3:   # (uncropped: the walk with the pool riding on it; cropped, round 6: crop_backward3<.., POOL>)
-                        if crop is not None:   # (the plane family hands cropped volumes to crop_backward3 under either policy)
-                            assert abi.last_kernel() == "crop_backward3_pool", (shape, policy, abi.last_kernel())
+                        if crop is not None:   # (zeros padding, policy 0: the cropped walk; else crop_backward3, which the plane family hands cropped volumes to)
+                            _, new16 = abi.check_borders(list(shape), crop, nd)
+                            cw = pad == 0 and policy == 0 and new16[-1] % 2 == 0 and crop[2][0] <= 2   # (pooled rows at 2-byte boundaries: three dwords per 8 pooled bytes)
+                            assert abi.last_kernel() == ("walk_backward_crop_pool" if cw else "crop_backward3_pool"), (shape, policy, abi.last_kernel())
                         else:
                             assert (abi.last_kernel() == "walk_backward_pool") == (policy == 0), (shape, policy, abi.last_kernel())
                     assert np.max(np.abs(gx.float().cpu().numpy() - gx_r)) <= eps * max(1.0, np.max(np.abs(gx_r)))

@@ -178,6 +178,11 @@ int forward_common(const shiftnd_problem *p, const void *x, const int64_t *xs, c
         }
         // cropped windows with ragged rows, 1-D rows of any length, ragged source rows (float tensors): one-step workgroups over
         // row spans -- what the aligned one-step forwards below do not take
+        // cropped 16-bit volumes under zeros padding, interpolating: the walk through the planes with the window inside (round 6)
+        if (g_policy == 0 && wkind == p->dtype && cropped(g) && walk16_forward_eligible(g, p->dtype, x, out)) {
+            g_last_path = SHIFTND_PATH_PLANE;
+            return finish(walk16_forward(g, p->dtype, x, w, wkind, out, st));
+        }
         if (g_policy == 0 && wkind == p->dtype && !step_forward_lds_eligible(g, p->dtype, x, out) && span_forward_eligible(g, p->dtype, x, out)) {
             g_last_path = SHIFTND_PATH_PLANE;
             return finish(span_forward(g, p->dtype, x, w, wkind, out, st));

@@ -535,10 +535,15 @@ __global__ __launch_bounds__(kThreads) void walk_backward16(const StepParams p) 
 // staged per step, its row / column blend computed once and carried to the next step as the "+0" plane (8 fp32 values).
 // Reference: kernels/shifts_kernels.h:156-220 (:187-205), interpolation.h:34-40; weights cuda/shifts_cuda.cu:168-183.
 // ---------------------------------------------------------------------------------------------------------------------
-template <typename T, bool ZEROS>
+// CROP (round 6, zeros padding): the output is a WINDOW [O0, O1, O2] that begins at (L0, L1, L2) of the shifted volume
+// (ops/shifts.cpp:93-135).  A workgroup owns R rows of the window and walks through its O0 planes; the staged source rows and planes
+// are offset by (L1, L0), the crop along the row is one more column shift of the window (cs2 - L2).  Thread (tr, tc) owns window
+// columns 8 tc ..: window rows of an even number of elements start on a dword, the row's last piece leaves as 1 - 4 dwords.
+template <typename T, bool ZEROS, bool CROP = false>
 __global__ __launch_bounds__(kThreads) void walk_forward16(const FwdParams p) {
     using S = typename T::S;
     static_assert(sizeof(S) == 2, "16-bit element types");
+    static_assert(!CROP || ZEROS, "the cropped walk: zeros padding");
     constexpr int E = 8;
     constexpr int NA = ZEROS ? 5 : 9;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -564,8 +569,10 @@ __global__ __launch_bounds__(kThreads) void walk_forward16(const FwdParams p) {
     const float dP = dn[0], dR = dn[1], dC = dn[2];
 
     const int R = p.R, S0 = p.S0, S1 = p.S1, S2 = p.S2, cpr = p.cpr;
+    const int O0 = CROP ? p.O0 : S0, O1 = CROP ? p.O1 : S1, O2 = CROP ? p.O2 : S2;
+    const int L0 = CROP ? p.L0 : 0, L1 = CROP ? p.L1 : 0, L2 = CROP ? p.L2 : 0;
     const int b0 = step * R;
-    const int Rn = min(R, S1 - b0);
+    const int Rn = min(R, O1 - b0);
     const int tid = static_cast<int>(threadIdx.x);
     const int tr = static_cast<int>(fdiv(static_cast<uint32_t>(tid), p.d_cpr)), tc = tid - tr * cpr;
     const int ji = tc * E;
@@ -574,22 +581,23 @@ __global__ __launch_bounds__(kThreads) void walk_forward16(const FwdParams p) {
         *reinterpret_cast<u4_t *>(__builtin_assume_aligned(smem + o, 16)) = u4_t{0u, 0u, 0u, 0u};
 
     const bool own = tr <= R && tr <= Rn;
-    const int sx_own = own ? row_map(b0 + tr, cs1, S1, pad) : -1;
+    const int sx_own = own ? row_map(b0 + tr + L1, cs1, S1, pad) : -1;
     constexpr uint32_t kOOR = 0x80000000u;
     constexpr int kRsrcFlags = 0x00020000;
     const uint32_t plane_bytes = static_cast<uint32_t>(S1) * static_cast<uint32_t>(S2) * 2u;
     const uint32_t vol_bytes = static_cast<uint32_t>(S0) * plane_bytes;
+    const uint32_t oplane_bytes = CROP ? static_cast<uint32_t>(O1) * static_cast<uint32_t>(O2) * 2u : plane_bytes;
     const char *xp = reinterpret_cast<const char *>(static_cast<const S *>(p.x) + static_cast<int64_t>(plane) * p.x_plane);
     char *op = reinterpret_cast<char *>(static_cast<S *>(p.out) + static_cast<int64_t>(plane) * p.o_plane);
     const __amdgpu_buffer_rsrc_t xres = __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(xp), 0, vol_bytes, kRsrcFlags);
-    const __amdgpu_buffer_rsrc_t ores = __builtin_amdgcn_make_buffer_rsrc(op, 0, vol_bytes, kRsrcFlags);
+    const __amdgpu_buffer_rsrc_t ores = __builtin_amdgcn_make_buffer_rsrc(op, 0, CROP ? static_cast<uint32_t>(O0) * oplane_bytes : vol_bytes, kRsrcFlags);
     const __amdgpu_buffer_rsrc_t none = __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(xp), 0, 0, kRsrcFlags);
     const uint32_t vx_own = sx_own >= 0 ? static_cast<uint32_t>(sx_own * S2 + ji) * 2u : kOOR;
     const uint32_t park_at = static_cast<uint32_t>(own ? kWalkMargin + tr * RP + tc : kWalkDump0 + (tid & 63)) * 4u;
     auto load_plane = [&](int pa) {   // source plane (uniform; -1: fill)
         return __builtin_amdgcn_raw_buffer_load_b128(pa >= 0 ? xres : none, vx_own, pa >= 0 ? static_cast<uint32_t>(pa) * plane_bytes : 0u, 0);
     };
-    const bool mine = tr < R && tr < Rn;
+    const bool mine = tr < R && tr < Rn && ji < O2;   // (CROP: the window's rows hold fewer pieces than the source's)
     const int slot0 = kWalkMargin + tr * RP;
     const int per2 = map_period(S2, pad);
     const int ss2 = (!ZEROS && per2 && 2 * cs2 > per2) ? cs2 - per2 : cs2;   // the signed column shift
@@ -605,10 +613,11 @@ __global__ __launch_bounds__(kThreads) void walk_forward16(const FwdParams p) {
             if (small_x) walk_park_guards(tx, gdx, v, pad);   // (uniform: the folded row ends, see WalkWindow)
         }
     };
-    const WalkWindow<NA> wx = walk_window<ZEROS, NA>(ji, small_x ? ss2 : cs2, S2, pad, slot0, mine, small_x);
+    const WalkWindow<NA> wx = walk_window<ZEROS, NA>(ji, (small_x ? ss2 : cs2) - L2, S2, pad, slot0, mine, small_x);
     const uint32_t row1 = static_cast<uint32_t>(RP) * 4u;
-    const int px = (small_x ? ss2 : cs2) & 1;
-    const uint32_t my = mine ? static_cast<uint32_t>((b0 + tr) * S2 + ji) * 2u : kOOR;
+    const int px = ((small_x ? ss2 : cs2) - L2) & 1;
+    const uint32_t my = mine ? static_cast<uint32_t>((b0 + tr) * O2 + ji) * 2u : kOOR;
+    const int ndw = CROP ? min(4, (O2 - ji) >> 1) : 4;   // dwords of the chunk inside the row (the window's last piece: 1 - 4)
     auto lerp = [](float v1, float v2, float x) { return lerp1_fused<float>(v1, v2, x); };
     auto plane_blend = [&](auto par_tag, float (&B)[E]) {
         constexpr int PAR = decltype(par_tag)::value;
@@ -630,9 +639,9 @@ __global__ __launch_bounds__(kThreads) void walk_forward16(const FwdParams p) {
     float Ba[E], Bb[E];
     u4_t stA, stB;
     {
-        const u4_t v0 = load_plane(row_map(0, cs0, S0, pad));
-        stA = load_plane(row_map(1, cs0, S0, pad));
-        stB = load_plane(1 < S0 ? row_map(2, cs0, S0, pad) : -1);
+        const u4_t v0 = load_plane(row_map(L0, cs0, S0, pad));
+        stA = load_plane(row_map(L0 + 1, cs0, S0, pad));
+        stB = load_plane(1 < O0 ? row_map(L0 + 2, cs0, S0, pad) : -1);
         walk_barrier();   // the tile is zero
         park(v0);
         walk_barrier();
@@ -643,7 +652,7 @@ __global__ __launch_bounds__(kThreads) void walk_forward16(const FwdParams p) {
     auto walk_step = [&](int a, u4_t &pend, const float (&B0)[E], float (&B1)[E]) {
         park(pend);
         walk_barrier();
-        pend = load_plane(a + 2 < S0 ? row_map(a + 3, cs0, S0, pad) : -1);
+        pend = load_plane(a + 2 < O0 ? row_map(a + 3 + L0, cs0, S0, pad) : -1);
         if (px) plane_blend(par1{}, B1);
         else plane_blend(par0{}, B1);
         Chunk<S, E> ch;
@@ -651,15 +660,26 @@ __global__ __launch_bounds__(kThreads) void walk_forward16(const FwdParams p) {
         for (int e = 0; e < E; ++e) ch.e[e] = narrow<T>(lerp(B0[e], B1[e], dP));
         u4_t res;
         __builtin_memcpy(&res, ch.e, 16);
-        buffer_store_b128_soffset<kWalkStoreAux>(res, ores, my, static_cast<uint32_t>(a) * plane_bytes);
+        if constexpr (CROP) {
+            const uint32_t so = static_cast<uint32_t>(a) * oplane_bytes;
+            if (ndw == 4) {
+                buffer_store_b128_soffset<kWalkStoreAux>(res, ores, my, so);
+            } else if (mine) {   // the row's last piece: 1 - 3 dwords (the next row begins behind them)
+                typedef uint32_t u2_t __attribute__((ext_vector_type(2)));
+                if (ndw & 2) __builtin_amdgcn_raw_buffer_store_b64(u2_t{res.x, res.y}, ores, my, so, 0);
+                if (ndw & 1) __builtin_amdgcn_raw_buffer_store_b32((ndw & 2) ? res.z : res.x, ores, my + ((ndw & 2) ? 8u : 0u), so, 0);
+            }
+        } else {
+            buffer_store_b128_soffset<kWalkStoreAux>(res, ores, my, static_cast<uint32_t>(a) * plane_bytes);
+        }
         walk_barrier();
     };
     int a = 0;
-    for (; a + 1 < S0; a += 2) {
+    for (; a + 1 < O0; a += 2) {
         walk_step(a, stA, Ba, Bb);
         walk_step(a + 1, stB, Bb, Ba);
     }
-    if (a < S0) walk_step(a, stA, Ba, Bb);
+    if (a < O0) walk_step(a, stA, Ba, Bb);
 }
 
 struct WalkPlan {
@@ -668,16 +688,18 @@ struct WalkPlan {
     size_t off_desc, bytes;
 };
 
-WalkPlan walk_plan(const Geometry &g) {
+// rows: the rows the workgroups of an (n, c) volume share -- S1, or the window's O1 for the cropped forward
+WalkPlan walk_plan(const Geometry &g, int64_t rows = 0) {
     WalkPlan w{};
+    if (rows <= 0) rows = g.S[1];
     w.cpr = static_cast<int>(g.S[2] * 2 / 16);
     if (w.cpr < 1) w.cpr = 1;
     // (R + 1) * cpr <= 256: every staged piece has its thread; the tile: margin + (R + 1) * (cpr + guard) <= 448 slots
     int rmax = kThreads / w.cpr - 1;
     rmax = std::min(rmax, (kWalkDump0 - kWalkMargin) / (w.cpr + kWalkGuard) - 1);
-    rmax = std::max(1, std::min<int>(rmax, static_cast<int>(g.S[1])));
-    w.spp = static_cast<int>((g.S[1] + rmax - 1) / rmax);
-    w.R = static_cast<int>((g.S[1] + w.spp - 1) / w.spp);   // balanced steps: 112 rows of 14 pieces -> 7 steps of 16 rows
+    rmax = std::max(1, std::min<int>(rmax, static_cast<int>(rows)));
+    w.spp = static_cast<int>((rows + rmax - 1) / rmax);
+    w.R = static_cast<int>((rows + w.spp - 1) / w.spp);   // balanced steps: 112 rows of 14 pieces -> 7 steps of 16 rows
     w.total = static_cast<uint64_t>(g.N) * g.C * w.spp;
     auto up = [](size_t v) { return (v + 255) & ~static_cast<size_t>(255); };
     w.off_desc = up(w.total * 8 * sizeof(double));
@@ -713,13 +735,17 @@ bool walk16_crop_geometry_ok(const Geometry &g, int dtype) {
 // tensor's dtype
 bool walk16_forward_eligible(const Geometry &g, int dtype, const void *x, const void *out) {
     if (g_step_tune[2] == 1 || (g_step_tune[3] & 16)) return false;   // knob 34 = 1: no forwards through LDS; knob 35 bit 4: no walk kernels
-    if (!g.active || !walk16_geometry_ok(g, dtype)) return false;
+    // (a window: walk_forward16<.., CROP> -- zeros padding, window rows of an even number of elements, every window dim at least 2)
+    bool crop_ok = walk16_volume_ok(g, dtype) && walk16_cropped(g) && g.pad == 0 && !(g_step_tune[3] & 2048) && g.O[2] % 2 == 0;
+    for (int d = 0; d < 3; ++d) crop_ok = crop_ok && g.O[d] >= 2 && g.L[d] >= 0 && g.L[d] + g.O[d] <= g.S[d];
+    if (!g.active || !(walk16_geometry_ok(g, dtype) || crop_ok)) return false;
     if (!dense(g.xs, g.N, g.C, g.S) || !dense(g.os, g.N, g.C, g.O)) return false;
     return reinterpret_cast<uintptr_t>(x) % 16 == 0 && reinterpret_cast<uintptr_t>(out) % 16 == 0;
 }
 
 int walk16_forward(const Geometry &g, int dtype, const void *x, const void *w, int wkind, void *out, hipStream_t st) {
-    const WalkPlan W = walk_plan(g);
+    const bool crop = walk16_cropped(g);
+    const WalkPlan W = walk_plan(g, crop ? g.O[1] : 0);
     FwdParams p{};
     p.x = x;
     p.out = out;
@@ -728,10 +754,17 @@ int walk16_forward(const Geometry &g, int dtype, const void *x, const void *w, i
     p.C = static_cast<int>(g.C);
     p.nd = 3;
     p.pad = g.pad;
-    p.S0 = p.O0 = static_cast<int>(g.S[0]);
-    p.S1 = p.O1 = static_cast<int>(g.S[1]);
-    p.S2 = p.O2 = static_cast<int>(g.S[2]);
-    p.x_plane = p.o_plane = g.S[0] * g.S[1] * g.S[2];
+    p.S0 = static_cast<int>(g.S[0]);
+    p.S1 = static_cast<int>(g.S[1]);
+    p.S2 = static_cast<int>(g.S[2]);
+    p.O0 = static_cast<int>(g.O[0]);
+    p.O1 = static_cast<int>(g.O[1]);
+    p.O2 = static_cast<int>(g.O[2]);
+    p.L0 = static_cast<int>(g.L[0]);
+    p.L1 = static_cast<int>(g.L[1]);
+    p.L2 = static_cast<int>(g.L[2]);
+    p.x_plane = g.S[0] * g.S[1] * g.S[2];
+    p.o_plane = g.O[0] * g.O[1] * g.O[2];
     p.cpr = p.xppr = W.cpr;
     p.R = W.R;
     p.spp = p.spv = W.spp;
@@ -744,9 +777,12 @@ int walk16_forward(const Geometry &g, int dtype, const void *x, const void *w, i
     p.d_per1 = make_fastdiv(static_cast<uint32_t>(map_period(p.S1, g.pad)));
     p.d_per2 = make_fastdiv(static_cast<uint32_t>(map_period(p.S2, g.pad)));
     const dim3 grid(p.steps_per_xcd * 8), block(kThreads);
-    note_kernel("walk_forward16");
+    note_kernel(crop ? "walk_forward16_crop" : "walk_forward16");
     const bool zeros = g.pad == 0;
-    if (dtype == SHIFTND_F16) {
+    if (crop) {
+        if (dtype == SHIFTND_F16) hipLaunchKernelGGL((walk_forward16<f16_t, true, true>), grid, block, kWalkTileBytes, st, p);
+        else hipLaunchKernelGGL((walk_forward16<bf16_t, true, true>), grid, block, kWalkTileBytes, st, p);
+    } else if (dtype == SHIFTND_F16) {
         if (zeros) hipLaunchKernelGGL((walk_forward16<f16_t, true>), grid, block, kWalkTileBytes, st, p);
         else hipLaunchKernelGGL((walk_forward16<f16_t, false>), grid, block, kWalkTileBytes, st, p);
     } else {

@@ -349,7 +349,8 @@ def newest_traffic(workload, kernel_name, pad):
         plain = kernel_name.replace("(pool)", "")
         for cand in (plain, plain.replace("_ragged", ""), plain.replace("_gather_", "_").replace("_active_", "_"),
                      plain.replace("_ncdhw_grad", "").replace("_nchw_grad", ""), plain.replace("_pool", ""),
-                     plain.replace("_gather_", "_").replace("_active_", "_").replace("_rows", "3"), plain.replace("_sparse", ""), plain.replace("_crop", "").replace("_sparse", "")):
+                     plain.replace("_gather_", "_").replace("_active_", "_").replace("_rows", "3"), plain.replace("_sparse", ""), plain.replace("_crop", "").replace("_sparse", ""),
+                     plain.replace("_crop", "").replace("_sparse", "").replace("_pool", "")):
             if cand in per:
                 t = per[cand]
                 break

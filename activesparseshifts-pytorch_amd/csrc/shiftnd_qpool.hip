@@ -282,7 +282,9 @@ QPlanePlan qplane_plan(const Geometry &g) {
     ni = ni <= 1 ? 1 : (ni == 2 ? 2 : 4);
     if (items > 4LL * kThreads || ni * q.KV > 18) return q;
     // (round 6, measured and dropped: NI = 4 items per thread spread over five 56 x 56 planes per round -- more bytes in flight per
-    //  workgroup -- N128 C512 56x56 uint8 pool 2 0.079 -> 0.112 ms: the offsets' 64 registers cost more waves than the longer rounds return)
+    //  workgroup -- N128 C512 56x56 uint8 pool 2 0.079 -> 0.112 ms: the offsets' 64 registers cost more waves than the longer rounds return;
+    //  and rounds staged global -> registers -> LDS two rounds ahead instead of one LDS-DMA round at a time: 0.0832 vs 0.0836 ms -- the
+    //  kernel is bound by its 16 byte reads and ~80 vector instructions per output dword, not by the round trip)
     q.NI = ni;
     q.items = static_cast<int>(items);
     q.ppw = ni == 1 ? static_cast<int>(std::min<int64_t>(kThreads / items, g.N)) : 1;

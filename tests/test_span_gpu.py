@@ -273,7 +273,8 @@ def test_ragged_rows_forward_vs_oracle(abi, shape, crop, dt):
 # ragged last step, shifts beyond the volume (the weights of _weights), windows of two planes
 CASES_3D = [((2, 3, 5, 6, 8), [[1, 1], [1, 1], [1, 1]]), ((1, 4, 4, 9, 16), [[0, 1], [2, 0], [1, 2]]), ((2, 2, 6, 7, 32), [[2, 2], [0, 0], [0, 0]]),
             ((1, 2, 3, 70, 16), [[0, 0], [1, 1], [0, 0]]), ((1, 3, 8, 5, 24), [[3, 3], [1, 2], [5, 6]]), ((2, 2, 4, 12, 64), [[1, 0], [0, 3], [7, 9]]),
-            ((1, 2, 16, 20, 112), [[1, 1], [1, 1], [1, 1]]), ((1, 2, 4, 6, 16), [[0, 1], [1, 0], [2, 2]]), ((2, 2, 3, 40, 32), [[0, 0], [0, 0], [2, 0]])]
+            ((1, 2, 16, 20, 112), [[1, 1], [1, 1], [1, 1]]), ((1, 2, 4, 6, 16), [[0, 1], [1, 0], [2, 2]]), ((2, 2, 3, 40, 32), [[0, 0], [0, 0], [2, 0]]),
+            ((1, 2, 4, 5, 16), [[0, 0], [1, 0], [3, 3]]), ((2, 2, 5, 33, 24), [[1, 1], [0, 0], [1, 5]])]   # (10- / 18-column windows: a last piece of one dword)
 
 
 @pytest.mark.parametrize("dt", ["f32", "f64", "f16", "bf16"])

@@ -116,7 +116,8 @@ SHIFTND_API void shiftnd_set_path_policy(int policy);
  * automatic, 1 = never, 2 = whenever eligible; 33 also: 3 = the 16-bit pooled gather forward off, 4 = the interpolating one off;
  * 35: bit set of opt-in forms, csrc/shiftnd_step.hip; round 6: bit 6 = the band-walk kernel for the cropped / interpolating 2-D pooled
  * backward, bit 7 = one row group per thread in crop_backward's sparse forms, bit 8 = two everywhere, bit 10 = the per-channel
- * kernels for cropped 3-D volumes and 2-D windows whose planes are not whole pieces), 36-37 quantized
+ * kernels for cropped 3-D volumes and 2-D windows whose planes are not whole pieces, bit 11 = crop_backward3 / crop_forward3 instead of
+ * the walk kernels with the window inside), 36-37 quantized
  * pool (36: 1 = the element-per-thread kernel only, 2 = the plane kernel first, 3 = the band kernel first; 37: workgroups wanted), 38 planes per workgroup of the 3-D walk
  * kernels; for the sizing knobs 0 means automatic.
  * Results never depend on them.

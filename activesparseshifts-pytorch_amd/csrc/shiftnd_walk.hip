@@ -539,11 +539,14 @@ __global__ __launch_bounds__(kThreads) void walk_backward16(const StepParams p) 
 // (ops/shifts.cpp:93-135).  A workgroup owns R rows of the window and walks through its O0 planes; the staged source rows and planes
 // are offset by (L1, L0), the crop along the row is one more column shift of the window (cs2 - L2).  Thread (tr, tc) owns window
 // columns 8 tc ..: window rows of an even number of elements start on a dword, the row's last piece leaves as 1 - 4 dwords.
-template <typename T, bool ZEROS, bool CROP = false>
+// ACTIVE = false (CROP only): the sparse shift of a cropped volume -- the modules' default mode -- on the same skeleton: one staged
+// plane per step, the window itself leaves (bit patterns kept), nothing is carried (weights: cuda/shifts_cuda.cu:168-183, round half even).
+template <typename T, bool ZEROS, bool CROP = false, bool ACTIVE = true>
 __global__ __launch_bounds__(kThreads) void walk_forward16(const FwdParams p) {
     using S = typename T::S;
     static_assert(sizeof(S) == 2, "16-bit element types");
     static_assert(!CROP || ZEROS, "the cropped walk: zeros padding");
+    static_assert(ACTIVE || CROP, "the sparse form: cropped volumes (the uncropped ones have their one-step kernels)");
     constexpr int E = 8;
     constexpr int NA = ZEROS ? 5 : 9;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -559,9 +562,9 @@ __global__ __launch_bounds__(kThreads) void walk_forward16(const FwdParams p) {
     load_weights_nd<float>(p.w, p.wkind, c, 3, wv);
     float rr[3], dn[3];
 #pragma unroll
-    for (int d = 0; d < 3; ++d) {   // weights_init_forward, active: floor + fraction
-        rr[d] = floorf(wv[d]);
-        dn[d] = wv[d] - rr[d];
+    for (int d = 0; d < 3; ++d) {   // weights_init_forward, active: floor + fraction; sparse: round half even
+        rr[d] = ACTIVE ? floorf(wv[d]) : rintf(wv[d]);
+        dn[d] = ACTIVE ? wv[d] - rr[d] : 0.f;
     }
     const int cs0 = __builtin_amdgcn_readfirstlane(canon_shift(static_cast<int64_t>(rr[0]), p.S0, pad, p.d_per0));
     const int cs1 = __builtin_amdgcn_readfirstlane(canon_shift(static_cast<int64_t>(rr[1]), p.S1, pad, p.d_per1));
@@ -638,7 +641,7 @@ __global__ __launch_bounds__(kThreads) void walk_forward16(const FwdParams p) {
 
     float Ba[E], Bb[E];
     u4_t stA, stB;
-    {
+    if constexpr (ACTIVE) {
         const u4_t v0 = load_plane(row_map(L0, cs0, S0, pad));
         stA = load_plane(row_map(L0 + 1, cs0, S0, pad));
         stB = load_plane(1 < O0 ? row_map(L0 + 2, cs0, S0, pad) : -1);
@@ -647,19 +650,35 @@ __global__ __launch_bounds__(kThreads) void walk_forward16(const FwdParams p) {
         walk_barrier();
         if (px) plane_blend(par1{}, Ba);
         else plane_blend(par0{}, Ba);
+    } else {   // the sparse shift: step a reads the one plane under output plane a
+        stA = load_plane(row_map(L0, cs0, S0, pad));
+        stB = load_plane(1 < O0 ? row_map(L0 + 1, cs0, S0, pad) : -1);
     }
     walk_barrier();
     auto walk_step = [&](int a, u4_t &pend, const float (&B0)[E], float (&B1)[E]) {
         park(pend);
         walk_barrier();
-        pend = load_plane(a + 2 < O0 ? row_map(a + 3 + L0, cs0, S0, pad) : -1);
-        if (px) plane_blend(par1{}, B1);
-        else plane_blend(par0{}, B1);
-        Chunk<S, E> ch;
-#pragma unroll
-        for (int e = 0; e < E; ++e) ch.e[e] = narrow<T>(lerp(B0[e], B1[e], dP));
         u4_t res;
-        __builtin_memcpy(&res, ch.e, 16);
+        if constexpr (ACTIVE) {
+            pend = load_plane(a + 2 < O0 ? row_map(a + 3 + L0, cs0, S0, pad) : -1);
+            if (px) plane_blend(par1{}, B1);
+            else plane_blend(par0{}, B1);
+            Chunk<S, E> ch;
+#pragma unroll
+            for (int e = 0; e < E; ++e) ch.e[e] = narrow<T>(lerp(B0[e], B1[e], dP));
+            __builtin_memcpy(&res, ch.e, 16);
+        } else {
+            pend = load_plane(a + 2 < O0 ? row_map(a + 2 + L0, cs0, S0, pad) : -1);
+            uint32_t t[5];
+            if (px) {
+                walk_read<ZEROS, NA, 1>(tx, wx, 0u, t);
+                res = u4_t{__builtin_amdgcn_alignbit(t[1], t[0], 16), __builtin_amdgcn_alignbit(t[2], t[1], 16),
+                           __builtin_amdgcn_alignbit(t[3], t[2], 16), __builtin_amdgcn_alignbit(t[4], t[3], 16)};
+            } else {
+                walk_read<ZEROS, NA, 0>(tx, wx, 0u, t);
+                res = u4_t{t[0], t[1], t[2], t[3]};
+            }
+        }
         if constexpr (CROP) {
             const uint32_t so = static_cast<uint32_t>(a) * oplane_bytes;
             if (ndw == 4) {
@@ -738,7 +757,7 @@ bool walk16_forward_eligible(const Geometry &g, int dtype, const void *x, const 
     // (a window: walk_forward16<.., CROP> -- zeros padding, window rows of an even number of elements, every window dim at least 2)
     bool crop_ok = walk16_volume_ok(g, dtype) && walk16_cropped(g) && g.pad == 0 && !(g_step_tune[3] & 2048) && g.O[2] % 2 == 0;
     for (int d = 0; d < 3; ++d) crop_ok = crop_ok && g.O[d] >= 2 && g.L[d] >= 0 && g.L[d] + g.O[d] <= g.S[d];
-    if (!g.active || !(walk16_geometry_ok(g, dtype) || crop_ok)) return false;
+    if (!(g.active ? (walk16_geometry_ok(g, dtype) || crop_ok) : crop_ok)) return false;   // (the sparse shift: cropped volumes only)
     if (!dense(g.xs, g.N, g.C, g.S) || !dense(g.os, g.N, g.C, g.O)) return false;
     return reinterpret_cast<uintptr_t>(x) % 16 == 0 && reinterpret_cast<uintptr_t>(out) % 16 == 0;
 }
@@ -777,9 +796,11 @@ int walk16_forward(const Geometry &g, int dtype, const void *x, const void *w, i
     p.d_per1 = make_fastdiv(static_cast<uint32_t>(map_period(p.S1, g.pad)));
     p.d_per2 = make_fastdiv(static_cast<uint32_t>(map_period(p.S2, g.pad)));
     const dim3 grid(p.steps_per_xcd * 8), block(kThreads);
-    note_kernel(crop ? "walk_forward16_crop" : "walk_forward16");
+    note_kernel(crop ? (g.active ? "walk_forward16_crop" : "walk_forward16_crop_sparse") : "walk_forward16");
     const bool zeros = g.pad == 0;
-    if (crop) {
+    if (crop && !g.active) {   // (a raw copy of the window: one instantiation for both 16-bit types)
+        hipLaunchKernelGGL((walk_forward16<f16_t, true, true, false>), grid, block, kWalkTileBytes, st, p);
+    } else if (crop) {
         if (dtype == SHIFTND_F16) hipLaunchKernelGGL((walk_forward16<f16_t, true, true>), grid, block, kWalkTileBytes, st, p);
         else hipLaunchKernelGGL((walk_forward16<bf16_t, true, true>), grid, block, kWalkTileBytes, st, p);
     } else if (dtype == SHIFTND_F16) {

@@ -53,23 +53,13 @@ def main():
     ap.add_argument("--seed", type=int, default=0)
     a = ap.parse_args()
     rs = np.random.RandomState(a.seed)
-    real_randint = rs.randint
+    zero_pad = _ZeroPad(rs)
     t0, n = time.time(), 0
     while time.time() - t0 < a.seconds:
         if n % 3 == 2:
             case_pooled(rs)
-        else:
-            if n % 2 == 0:   # zeros padding: patch the padding draw of case_crop3d (its 4th randint(0, 5) call) -- simplest: retry until pad 0
-                state = rs.get_state()
-                for _ in range(50):
-                    st2 = rs.get_state()
-                    try:
-                        F.case_crop3d(_ZeroPad(rs))
-                        break
-                    finally:
-                        pass
-            else:
-                F.case_crop3d(rs)
+        else:   # (every other case under zeros padding: the routes of the cropped walks)
+            F.case_crop3d(zero_pad if n % 2 == 0 else rs)
         n += 1
     print("OK %d cases in %.0f s" % (n, time.time() - t0))
     for k, v in sorted(F.count.items(), key=lambda kv: -kv[1]):

@@ -344,7 +344,7 @@ struct QBandParams {
     int rpw, ngroups;    // images per workgroup, image groups
     int vec, ppr;        // staging piece (16 / 4 / 1 bytes), pieces per source row
     int pitch, zrow;     // LDS bytes per staged row (>= S2 + 1: byte S2 of every row holds the zero point), the all-zero-point row
-    FastDiv d_groups, d_ppr, d_C, d_nbands, d_per1, d_per2;
+    FastDiv d_groups, d_ppr, d_C, d_nbands, d_per1, d_per2, d_S2;
 };
 
 template <typename EL, int KV, int NI>
@@ -475,7 +475,12 @@ __global__ __launch_bounds__(kThreads) void qpool_band_forward(const QBandParams
 // fills need no test either: three aligned ds_read_b32 and two v_alignbyte per row, then one v_dot4 per row and pooled element
 // (dot4 of the bytes with 0x00000101 / 0x01010000 = the sum of a byte pair) -- ~45 vector + 6 LDS instructions per item instead of
 // ~86 + 16.  A channel whose column shift is beyond +-8 (uniform per workgroup) sums byte by byte.
-template <typename EL, int K1, int NI>
+// PM (round 6): small planes whose ROWS are not whole 16-byte pieces but whose plane is (56 x 56: 196 pieces).  The band form staged
+// them as 4-byte row pieces without prefetch, four items per thread of which a 56 x 56 plane fills one: 0.244 ms on N128 C512 56 x 56
+// against the plane kernel's byte reads, 0.070.  Here the band is the whole plane, one item per thread (NI = 1): the plane travels as its
+// own 16-byte pieces through registers one image ahead and every dword is parked in its padded row (rows of a multiple of 4 bytes: a
+// dword never straddles two rows); the row shift moves from the staging to the items' row offsets.
+template <typename EL, int K1, int NI, bool PM = false>
 __global__ __launch_bounds__(kThreads) void qpool_band_fast(const QBandParams p) {
     constexpr int K2 = 2, KV = K1 * K2, kPadL = 16;
     typedef uint32_t u4 __attribute__((ext_vector_type(4)));
@@ -496,15 +501,15 @@ __global__ __launch_bounds__(kThreads) void qpool_band_fast(const QBandParams p)
     if (p.wcol2 >= 0) cs2 = canon_shift(gather_shift(p.w, p.wkind, p.wzp, static_cast<int64_t>(c) * p.nd + p.wcol2), p.S2, 0, p.d_per2);
     auto src_row = [&](int wrow) { return p.S1 == 1 ? 0 : fold_index(wrow + p.L1 - cs1, p.S1, 0); };
     const int64_t plane = static_cast<int64_t>(p.S1) * p.S2, pooled = static_cast<int64_t>(p.P1) * p.P2;
-    constexpr int NP = 16;
-    const int npieces = nb * K1 * p.ppr;
+    constexpr int NP = PM ? 4 : 16;
+    const int npieces = PM ? (p.S1 * p.S2) >> 4 : nb * K1 * p.ppr;
     int soff[NP], doff[NP];
 #pragma unroll
     for (int k = 0; k < NP; ++k) {
         const int q = t + k * kThreads;
         const int slot = static_cast<int>(fdiv(static_cast<uint32_t>(q), p.d_ppr)), pq = q - slot * p.ppr;
         const int r = q < npieces ? src_row(pb0 * K1 + slot) : -1;
-        soff[k] = r >= 0 ? r * p.S2 + pq * p.vec : -1;
+        soff[k] = PM ? (q < npieces ? q * 16 : -1) : (r >= 0 ? r * p.S2 + pq * p.vec : -1);
         doff[k] = slot * p.pitch + kPadL + pq * p.vec;
     }
     auto stage = [&](int n) {
@@ -534,6 +539,20 @@ __global__ __launch_bounds__(kThreads) void qpool_band_fast(const QBandParams p)
         for (int k = 0; k < NPRE; ++k)
             if (soff[k] >= 0) *reinterpret_cast<u4 *>(__builtin_assume_aligned(q_lds + doff[k], 16)) = pre[k];
     };
+    auto scatter_pre = [&]() {   // PM: the four dwords of every prefetched piece into their rows
+#pragma unroll
+        for (int k = 0; k < NPRE; ++k) {
+            if (k * kThreads >= npieces) break;   // (uniform)
+            if (soff[k] < 0) continue;
+            const uint32_t w4[4] = {pre[k].x, pre[k].y, pre[k].z, pre[k].w};
+#pragma unroll
+            for (int d = 0; d < 4; ++d) {
+                const uint32_t o = static_cast<uint32_t>(soff[k] + 4 * d);
+                const uint32_t row = fdiv(o, p.d_S2), col = o - row * static_cast<uint32_t>(p.S2);
+                *reinterpret_cast<uint32_t *>(q_lds + row * static_cast<uint32_t>(p.pitch) + kPadL + col) = w4[d];
+            }
+        }
+    };
     auto stage_rest = [&](int n) {
         const unsigned char *xp = p.x + (static_cast<int64_t>(min(n, p.N - 1)) * p.C + c) * plane;
 #pragma unroll
@@ -545,7 +564,12 @@ __global__ __launch_bounds__(kThreads) void qpool_band_fast(const QBandParams p)
     };
     const int n_first = ng * p.rpw;
     __syncthreads();   // the tile is all zero point
-    stage(n_first);
+    if constexpr (PM) {
+        load_pre(n_first);
+        scatter_pre();
+    } else {
+        stage(n_first);
+    }
 
     int rowoff[NI][K1], coff[NI], obyte[NI], ovalid[NI];
     float rc[NI];   // (whole windows along the columns: one count per item)
@@ -560,7 +584,10 @@ __global__ __launch_bounds__(kThreads) void qpool_band_fast(const QBandParams p)
         obyte[i] = p1 * p.P2 + cg * 4;
         ovalid[i] = live ? min(4, p.P2 - cg * 4) : 0;
 #pragma unroll
-        for (int bb = 0; bb < K1; ++bb) rowoff[i][bb] = ((bb < n1 && src_row(p1 * K1 + bb) >= 0) ? prl * K1 + bb : p.zrow) * p.pitch;
+        for (int bb = 0; bb < K1; ++bb) {
+            const int sr = bb < n1 ? src_row(p1 * K1 + bb) : -1;
+            rowoff[i][bb] = (sr >= 0 ? (PM ? sr : prl * K1 + bb) : p.zrow) * p.pitch;   // (PM: the plane lies in LDS row by row)
+        }
         coff[i] = cg * (4 * K2) + p.L2 - cs2;   // source column of the item's first window element
         const float mult = static_cast<float>(1.0 / static_cast<double>(max(n1, 1) * K2));
         rc[i] = p.zp_outside ? mult : 1.0f / (1.0f / mult);
@@ -574,7 +601,9 @@ __global__ __launch_bounds__(kThreads) void qpool_band_fast(const QBandParams p)
         const int n = n_first + r;
         if (r > 0) {
             __syncthreads();
-            if (prefetch) {
+            if constexpr (PM) {
+                scatter_pre();
+            } else if (prefetch) {
                 store_pre();
                 stage_rest(n);
             } else {
@@ -582,7 +611,7 @@ __global__ __launch_bounds__(kThreads) void qpool_band_fast(const QBandParams p)
             }
         }
         __syncthreads();
-        if (prefetch && r + 1 < p.rpw) load_pre(n + 1);
+        if ((PM || prefetch) && r + 1 < p.rpw) load_pre(n + 1);
 #pragma unroll
         for (int i = 0; i < NI; ++i) {
             int sums[4] = {0, 0, 0, 0};
@@ -638,6 +667,7 @@ __global__ __launch_bounds__(kThreads) void qpool_band_fast(const QBandParams p)
 
 struct QBandPlan {
     bool ok = false;
+    bool pm = false;     // ... with the whole plane as the band, one item per thread (qpool_band_fast<.., 1, PM>)
     bool fast = false;   // qpool_band_fast: zeros padding, windows two columns wide, output rows of whole windows
     int KV = 0, NI = 0, band = 0, nbands = 0, groups = 0, rpw = 0, ngroups = 0, vec = 0, ppr = 0, pitch = 0, lds = 0;
 };
@@ -657,6 +687,26 @@ QBandPlan qband_plan(const Geometry &g, const void *x) {
     q.fast = g.pad == 0 && k2 == 2 && g.O[2] % 2 == 0;
     q.pitch = q.fast ? static_cast<int>(((16 + g.S[2] + 32 + 15) / 16) * 16) : static_cast<int>(((g.S[2] + 1 + 15) / 16) * 16);
     int64_t band = std::min<int64_t>(g.P[1], (q.NI * kThreads) / q.groups);
+    // PM: rows that are not whole pieces on a plane that is -- all of it one band of at most 256 items and 1024 pieces
+    const int64_t plane_bytes = g.S[1] * g.S[2];
+    if (q.fast && g.S[2] % 16 != 0 && g.S[2] % 4 == 0 && plane_bytes % 16 == 0 && plane_bytes <= 16 * 1024 && reinterpret_cast<uintptr_t>(x) % 16 == 0 &&
+        g.P[1] * q.groups <= kThreads && 2 * g.P[1] * q.groups >= kThreads && (g.S[1] + 1) * q.pitch <= 60 * 1024 && g_qpool_tune[0] != 4) {
+        // (at least half the threads own an item: a 28 x 28 plane has 56 -- 0.096 ms here against the plane kernel's 0.048, which packs
+        //  several planes into a round)
+        q.pm = true;
+        q.NI = 1;
+        q.vec = 16;
+        q.ppr = 1;
+        q.band = static_cast<int>(g.P[1]);
+        q.nbands = 1;
+        q.lds = static_cast<int>((g.S[1] + 1) * q.pitch);
+        const int64_t want = 4096, ngr = std::min<int64_t>(g.N, std::max<int64_t>(1, (want + g.C - 1) / g.C));
+        q.rpw = static_cast<int>((g.N + ngr - 1) / ngr);
+        q.ngroups = static_cast<int>((g.N + q.rpw - 1) / q.rpw);
+        if (static_cast<int64_t>(q.ngroups) * g.C >= (1LL << 31)) return q;
+        q.ok = true;
+        return q;
+    }
     // the staged rows (+ the row of zero points): at most 16 pieces per thread and 60 KB of LDS
     while (band > 1 && (band * k1 * q.ppr > 16 * kThreads || (band * k1 + 1) * q.pitch > 60 * 1024)) --band;
     if (band * k1 * q.ppr > 16 * kThreads || (band * k1 + 1) * q.pitch > 60 * 1024) return q;
@@ -674,6 +724,11 @@ QBandPlan qband_plan(const Geometry &g, const void *x) {
 
 template <typename EL> void launch_qband(const QBandPlan &q, const QBandParams &p, hipStream_t st) {
     const dim3 grid(static_cast<unsigned>(q.ngroups) * static_cast<unsigned>(p.nbands) * static_cast<unsigned>(p.C)), block(kThreads);
+    if (q.fast && q.pm) {
+        if (q.KV == 4) hipLaunchKernelGGL((qpool_band_fast<EL, 2, 1, true>), grid, block, q.lds, st, p);
+        else hipLaunchKernelGGL((qpool_band_fast<EL, 1, 1, true>), grid, block, q.lds, st, p);
+        return;
+    }
     if (q.fast) {
         if (q.KV == 4) hipLaunchKernelGGL((qpool_band_fast<EL, 2, 4>), grid, block, q.lds, st, p);
         else hipLaunchKernelGGL((qpool_band_fast<EL, 1, 4>), grid, block, q.lds, st, p);
@@ -710,7 +765,7 @@ int qpool_forward(const Geometry &g, int dtype, const void *x, const void *w, in
     // knob 36 = 2: the plane kernel first wherever it serves, 3: the band kernel first
     const QBandPlan qb_first = qband_plan(g, x);
     const bool band_first = qb_first.ok && qb_first.fast &&
-                            (g_qpool_tune[0] == 3 || (g_qpool_tune[0] == 0 && g.S[0] * g.S[1] * g.S[2] >= 8 * 1024));
+                            (g_qpool_tune[0] == 3 || (g_qpool_tune[0] == 0 && (g.S[0] * g.S[1] * g.S[2] >= 8 * 1024 || qb_first.pm)));
     if (qp.ok && g_qpool_tune[0] != 1 && !band_first) {
         QPlaneParams p{};
         p.x = static_cast<const uint8_t *>(x);
@@ -786,7 +841,8 @@ int qpool_forward(const Geometry &g, int dtype, const void *x, const void *w, in
         p.vec = qb.vec;
         p.ppr = qb.ppr;
         p.pitch = qb.pitch;
-        p.zrow = qb.band * static_cast<int>(g.K[1] > 0 ? g.K[1] : 1);
+        p.zrow = qb.pm ? static_cast<int>(g.S[1]) : qb.band * static_cast<int>(g.K[1] > 0 ? g.K[1] : 1);
+        p.d_S2 = make_fastdiv(static_cast<uint32_t>(g.S[2]));
         p.d_groups = make_fastdiv(static_cast<uint32_t>(qb.groups));
         p.d_ppr = make_fastdiv(static_cast<uint32_t>(qb.ppr));
         p.d_C = make_fastdiv(static_cast<uint32_t>(g.C));

@@ -225,6 +225,10 @@ QCASES = [  # the planes the per-channel quantized kernel (qpool_plane_forward) 
     (2, (2, 2, 300, 36), (1, 2), None),               # a row window
     (1, (3, 2, 9000), (2,), None),                    # Shift1d: one long row
     (2, (2, 6, 60, 230), (2, 2), [[0, 0], [3, 2]]),   # a window whose left border is not a multiple of 4 and whose width is odd: the non-fast band kernel
+    # round 6, qpool_band_fast<.., 1, PM>: small planes of whole 16-byte pieces whose ROWS are not (56 x 56, 48 x 52), one item per thread
+    (2, (3, 6, 48, 52), (2, 2), None),                # six channels: the shifts of BAND_SHIFTS (around the pads' edges, half the plane)
+    (2, (3, 2, 56, 56), (2, 2), [[1, 1], [1, 1]]),    # the module's cut 1 / 1
+    (2, (2, 3, 24, 56), (1, 2), None),                # a row window
 ]
 
 # column shifts at and beyond the edge of qpool_band_fast's 16 / 32-byte zero-point pads (+-7, +-8, +-9), and shifts
@@ -254,7 +258,7 @@ def test_quantized_pooled_forward_vs_oracle(abi, npdt):
         xq = rs.randint(info.min, info.max + 1, size=shape).astype(npdt)
         wq = rs.randint(123, 134, size=(shape[1], nd)).astype(np.uint8)
         wq[0] = 128 + shape[-1] + 2 if shape[-1] < 120 else 130
-        if nd == 2 and shape[1] == 6 and shape[-1] >= 200:   # the band cases: shifts around the pads' edges and partially in range
+        if nd == 2 and shape[1] == 6 and (shape[-1] >= 200 or shape[-1] == 52):   # the band cases: shifts around the pads' edges and partially in range
             for ch, (sr, sc) in enumerate(BAND_SHIFTS, start=1):
                 wq[ch] = [128 + (shape[2] // 2 if sr is None else sr), 128 - (shape[3] // 2 - 14 if sc is None else -sc)]
         zp = 7 if npdt == np.uint8 else -9

@@ -403,3 +403,42 @@ def test_cropped_rows_forward_vs_oracle(abi, shape, crop, dt):
                 assert torch.equal(out.cpu(), ref), (shape, crop, dt, pad, active, abi.last_kernel())
             else:
                 assert _ulp_close(out.cpu(), ref, tdt), (shape, crop, dt, pad, active, abi.last_kernel())
+
+
+def _guarded(shape, tdt, fill=0.0):
+    """a contiguous tensor of `shape` inside a larger buffer, 16-byte aligned, with 512 sentinel bytes on either side"""
+    es = torch.empty(0, dtype=tdt).element_size()
+    n = int(np.prod(shape))
+    pad = 512 // es
+    big = torch.full((n + 2 * pad,), 7.0, dtype=tdt, device=DEV)
+    view = big[pad:pad + n].view(shape)
+    view.fill_(fill)
+    assert view.data_ptr() % 16 == 0
+    return big, view, pad
+
+
+@pytest.mark.parametrize("dt", ["f32", "f16", "bf16"])
+@pytest.mark.parametrize("shape,crop", [((2, 3, 5, 6, 16), [[1, 1], [1, 1], [1, 1]]), ((1, 2, 4, 9, 24), [[0, 1], [2, 0], [1, 5]]),
+                                        ((1, 2, 16, 20, 112), [[1, 1], [1, 1], [1, 1]]), ((2, 2, 3, 7, 8), [[0, 1], [1, 1], [0, 2]])])
+def test_cropped_3d_kernels_stay_inside_their_tensors(abi, shape, crop, dt):
+    """the cropped walks store partial pieces at the ends of window rows (forward) and mask grad_x (backward): nothing may be written
+    outside the output tensors -- sentinel bytes around `out` and `grad_x` survive every padding and both shifts"""
+    tdt = {"f32": torch.float32, "f16": torch.float16, "bf16": torch.bfloat16}[dt]
+    b, new = abi.check_borders(list(shape), crop, 3)
+    rs = np.random.RandomState(sum(shape) + 3)
+    xd = torch.from_numpy(rs.uniform(-1, 1, size=shape)).to(tdt).to(DEV)
+    gd = torch.from_numpy(rs.uniform(-1, 1, size=new)).to(tdt).to(DEV)
+    wd = torch.from_numpy(_weights(rs, shape[1], 3, shape[2:])).to(tdt).to(DEV)
+    for pad in range(5):
+        for active in (0, 1):
+            big_o, out, po = _guarded(new, tdt)
+            abi.forward(xd, wd, pad, active, b, out=out)
+            torch.cuda.synchronize()
+            assert bool((big_o[:po] == 7).all()) and bool((big_o[po + out.numel():] == 7).all()), ("fwd", shape, crop, dt, pad, active, abi.last_kernel())
+            assert torch.equal(out, abi.forward(xd, wd, pad, active, b)), ("fwd", shape, crop, dt, pad, active)
+            big_g, gx, pg = _guarded(shape, tdt)
+            gx1, gw1 = abi.backward(gd, wd, xd, pad, active, b, grad_x=gx)
+            torch.cuda.synchronize()
+            assert bool((big_g[:pg] == 7).all()) and bool((big_g[pg + gx.numel():] == 7).all()), ("bwd", shape, crop, dt, pad, active, abi.last_kernel())
+            gx2, gw2 = abi.backward(gd, wd, xd, pad, active, b)
+            assert torch.equal(gx1, gx2) and torch.equal(gw1, gw2)

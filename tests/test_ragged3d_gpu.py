@@ -235,3 +235,34 @@ def test_16bit_sweep_forward_under_policy(abi, shape, crop, dt):
             assert _ulp_close(out.cpu(), torch.from_numpy(O.forward(x, w, pad, 1, b)).to(tdt), tdt), (shape, crop, dt, pad)
     finally:
         abi.set_path_policy(0)
+
+
+@pytest.mark.parametrize("shape,crop,dt", [((2, 2, 40, 16, 31), None, "bf16"), ((2, 2, 9, 18, 13), [[1, 0], [2, 1], [1, 2]], "f16"),
+                                           ((8, 3, 7), [[2, 0]], "f32"), ((64, 16, 12), [[0, 2]], "bf16"), ((2, 2, 6, 5000), [[1, 0], [0, 2]], "f32")])
+def test_element_wide_kernels_stay_inside_their_tensors(abi, shape, crop, dt):
+    """the element-wide plane kernels behind the fallback tail: sentinel bytes around `out` and `grad_x` survive"""
+    tdt = TDT[dt]
+    nd = len(shape) - 2
+    b, new = abi.check_borders(list(shape), crop, nd)
+    rs = np.random.RandomState(sum(shape) + 9)
+    xd = torch.from_numpy(rs.uniform(-1, 1, size=shape)).to(tdt).to(DEV)
+    gd = torch.from_numpy(rs.uniform(-1, 1, size=new)).to(tdt).to(DEV)
+    wd = torch.from_numpy(_weights(rs, shape[1], nd, shape[2:])).to(tdt).to(DEV)
+    es = xd.element_size()
+
+    def guarded(shp):
+        n, padn = int(np.prod(shp)), 512 // es
+        big = torch.full((n + 2 * padn,), 7.0, dtype=tdt, device=DEV)
+        v = big[padn:padn + n].view(shp)
+        v.zero_()
+        return big, v, padn
+    for pad in (0, 2, 3):
+        for active in (0, 1):
+            big_o, out, po = guarded(new)
+            abi.forward(xd, wd, pad, active, b, out=out)
+            torch.cuda.synchronize()
+            assert bool((big_o[:po] == 7).all()) and bool((big_o[po + out.numel():] == 7).all()), ("fwd", shape, crop, dt, pad, active, abi.last_kernel())
+            big_g, gx, pg = guarded(shape)
+            abi.backward(gd, wd, xd, pad, active, b, grad_x=gx)
+            torch.cuda.synchronize()
+            assert bool((big_g[:pg] == 7).all()) and bool((big_g[pg + gx.numel():] == 7).all()), ("bwd", shape, crop, dt, pad, active, abi.last_kernel())
